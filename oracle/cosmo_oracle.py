@@ -1,0 +1,1018 @@
+"""CPU ORACLE for the COSMO ADMM hot path -- TEST INFRASTRUCTURE ONLY.
+
+This file is a NumPy/SciPy restatement of the per-iteration path of the reference
+(oxfordcontrol/COSMO.jl v0.8.11, `src/solver.jl:140-165` plus what it calls).  It is the
+checker used by `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg.
+Nothing in the product (`cosmo.jl_amd/`) may import it.
+
+Pinning status
+--------------
+* The reference is Julia; `julia` is not installed in this image, so the reference itself cannot
+  be executed.  The oracle is pinned against every literal known answer that the reference's own
+  tests hold for this path (see `tests/test_oracle_goldens.py`): simple QP x*=[0.3,0.7],
+  obj=1.88 (`test/UnitTests/simple.jl:22-47`), Box QP obj=-0.5 and the four Box infeasibility
+  statuses (`test/UnitTests/qp-box.jl:16-105`), model-update answers
+  (`test/UnitTests/model_modifications.jl:30-60`), KKT solve vs dense solve
+  (`test/UnitTests/kktsolver.jl:16-25,109,132`), closest-correlation properties
+  (`test/UnitTests/closestcorr.jl:74-76`), cone-membership properties (`test/UnitTests/sets.jl`).
+* The Krylov arithmetic (`cg!`, `minres!`) lives in IterativeSolvers.jl ("^0.9",
+  `Project.toml:30`), which is NOT vendored in /root/reference and whose tests are disabled in the
+  reference (`test/UnitTests/kktsolver.jl:7`).  The restatement below follows the published v0.9
+  algorithm; for that part parity is UNPINNED and is anchored on a dense solve, which is what the
+  disabled reference test would have done.
+* The direct (QDLDL) KKT solve of config 1 is replaced by SuperLU on the same quasi-definite KKT
+  matrix; the reference pins its direct solvers against `Matrix(K)\\b` at 1e-10
+  (`test/UnitTests/kktsolver.jl:40,109`), so any accurate direct solve is a valid stand-in.
+
+Sign conventions (`src/interface.jl:478-484`): `Constraint(A, b, K)` means `A x + b in K`; the
+internal problem is `min 1/2 x'Px + q'x  s.t.  A x + s = b, s in K` with `A := -A_c`, `b := b_c`.
+All functions below take the INTERNAL form unless stated otherwise.
+"""
+from __future__ import annotations
+
+import math
+import time
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+from scipy.linalg import lapack as _lapack
+
+# --------------------------------------------------------------------------------------------
+# cones  (src/convexset.jl)
+# --------------------------------------------------------------------------------------------
+ZERO, NONNEG, BOX, SOC, PSD_SQUARE, PSD_TRIANGLE = 0, 1, 2, 3, 4, 5
+CONE_NAMES = {ZERO: "ZeroSet", NONNEG: "Nonnegatives", BOX: "Box", SOC: "SecondOrderCone",
+              PSD_SQUARE: "PsdCone", PSD_TRIANGLE: "PsdConeTriangle"}
+
+
+@dataclass
+class Cone:
+    """One convex set of the composite set; `kind` is one of the constants above."""
+    kind: int
+    dim: int
+    l: Optional[np.ndarray] = None          # Box only (src/convexset.jl:803-813), scaled in place
+    u: Optional[np.ndarray] = None
+    constr_type: Optional[np.ndarray] = None  # Nonneg: bool loose flags (:54); Box: int {-1,0,1} (:805)
+
+    @property
+    def sqrt_dim(self) -> int:
+        if self.kind == PSD_SQUARE:
+            r = math.isqrt(self.dim)
+            assert r * r == self.dim
+            return r
+        if self.kind == PSD_TRIANGLE:           # src/convexset.jl:372
+            return (math.isqrt(1 + 8 * self.dim) - 1) // 2
+        raise ValueError("not a PSD cone")
+
+
+def ZeroSet(dim): return Cone(ZERO, int(dim))
+def Nonnegatives(dim): return Cone(NONNEG, int(dim), constr_type=np.zeros(int(dim), dtype=bool))
+def SecondOrderCone(dim): return Cone(SOC, int(dim))
+def PsdCone(dim): return Cone(PSD_SQUARE, int(dim))
+def PsdConeTriangle(dim): return Cone(PSD_TRIANGLE, int(dim))
+
+
+def Box(l, u):
+    l = np.array(l, dtype=np.float64).copy()
+    u = np.array(u, dtype=np.float64).copy()
+    if l.shape != u.shape:
+        raise ValueError("bounds must be same length")
+    if np.any(l > u):                                   # src/convexset.jl:824-828
+        raise ValueError("Box set: inconsistent lower/upper bounds")
+    return Cone(BOX, l.size, l=l, u=u, constr_type=np.zeros(l.size, dtype=np.int64))
+
+
+def copy_cones(cones: Sequence[Cone]) -> List[Cone]:
+    out = []
+    for c in cones:
+        out.append(Cone(c.kind, c.dim,
+                        None if c.l is None else c.l.copy(),
+                        None if c.u is None else c.u.copy(),
+                        None if c.constr_type is None else c.constr_type.copy()))
+    return out
+
+
+def get_set_indices(cones: Sequence[Cone]):
+    """src/convexset.jl:985-993 (0-based half-open ranges)."""
+    idx, s = [], 0
+    for c in cones:
+        idx.append((s, s + c.dim))
+        s += c.dim
+    return idx
+
+
+# ---- projections ---------------------------------------------------------------------------
+def populate_upper_triangle(x: np.ndarray, d: int) -> np.ndarray:
+    """svec -> dense matrix with only the UPPER triangle defined (src/convexset.jl:432-442).
+    Column-major upper triangle order, off-diagonals scaled by 1/sqrt(2)."""
+    X = np.zeros((d, d), order="F")
+    # k runs column by column: j = 0..d-1 outer, i = 0..j inner
+    jj, ii = np.tril_indices(d)             # (jj>=ii) enumerates j outer, i inner == column-major upper
+    vals = x * (1.0 / math.sqrt(2.0))       # scaling_factor * x[k]   (:437)
+    diag = ii == jj
+    vals = np.where(diag, x, vals)          # A[j,j] = x[k]           (:440)
+    X[ii, jj] = vals
+    return X
+
+
+def extract_upper_triangle(X: np.ndarray, x: np.ndarray) -> None:
+    """src/convexset.jl:462-472."""
+    d = X.shape[0]
+    jj, ii = np.tril_indices(d)
+    vals = math.sqrt(2.0) * X[ii, jj]
+    diag = ii == jj
+    x[:] = np.where(diag, X[ii, jj], vals)
+
+
+def _psd_project_dense(X: np.ndarray):
+    """`_project!` (src/convexset.jl:219-241): LAPACK dsyevr('V','A','U') + rank_k_update!.
+    Only the upper triangle of X is read; returns (upper-triangular-valid result, nnz_lambda)."""
+    d = X.shape[0]
+    w, Z, _m, _isuppz, info = _lapack.dsyevr(X, compute_v=1, range="A", lower=0, abstol=-1.0,
+                                             overwrite_a=0)
+    if info != 0:
+        raise RuntimeError("dsyevr failed: info=%d" % info)
+    pos = w > 0                                  # src/convexset.jl:250
+    nnz = int(pos.sum())
+    Zs = np.array(Z, order="F", copy=True)
+    Zs[:, pos] = Zs[:, pos] * np.sqrt(w[pos])    # :253
+    out = np.zeros((d, d), order="F")
+    if nnz > 0:
+        V = Zs[:, d - nnz:]                      # :259 (assumes positives are trailing columns)
+        out = np.asfortranarray(V @ V.T)         # syrk('U','N'): only the upper triangle is defined
+    return out, nnz
+
+
+def project_cone(x: np.ndarray, cone: Cone, info: Optional[dict] = None) -> None:
+    """In-place `project!` of one slice (src/convexset.jl)."""
+    k = cone.kind
+    if k == ZERO:                                 # :25-28
+        x[:] = 0.0
+    elif k == NONNEG:                             # :71-74  (Julia max: NaN propagates, -0.0 -> +0.0)
+        x[:] = np.where(np.isnan(x), x, np.maximum(x, 0.0) + 0.0)
+    elif k == BOX:                                # :844-847 with clip (src/algebra.jl:5-7)
+        x[:] = np.where(x < cone.l, cone.l, np.where(x > cone.u, cone.u, x))
+    elif k == SOC:                                # :100-114
+        if x.size == 0:
+            return
+        t = x[0]
+        nx = float(np.linalg.norm(x[1:], 2))
+        if nx <= t:
+            br = 0
+        elif nx <= -t:
+            x[:] = 0.0
+            br = 1
+        else:
+            x[0] = (nx + t) / 2.0
+            x[1:] = (nx + t) / (2.0 * nx) * x[1:]
+            br = 2
+        if info is not None:
+            info.setdefault("soc_branch", []).append(br)
+    elif k == PSD_TRIANGLE:                       # :402-412
+        if x.size == 1:
+            x[0] = max(x[0], 0.0)
+            nnz = int(x[0] > 0)
+        else:
+            d = cone.sqrt_dim
+            X = populate_upper_triangle(x, d)
+            Xp, nnz = _psd_project_dense(X)
+            extract_upper_triangle(Xp, x)
+        if info is not None:
+            info.setdefault("psd_rank", []).append(nnz)
+    elif k == PSD_SQUARE:                         # :303-321
+        if x.size == 1:
+            x[0] = max(x[0], 0.0)
+            nnz = int(x[0] > 0)
+        else:
+            d = cone.sqrt_dim
+            X = x.reshape((d, d), order="F").copy(order="F")
+            iu = np.triu_indices(d)
+            Xs = np.zeros((d, d), order="F")
+            Xs[iu] = (X[iu] + X.T[iu]) / 2.0      # symmetrize_upper! (src/algebra.jl:201-208)
+            Xp, nnz = _psd_project_dense(Xs)
+            full = np.triu(Xp) + np.triu(Xp, 1).T  # mirror upper -> lower (:316-318)
+            x[:] = full.reshape(-1, order="F")
+        if info is not None:
+            info.setdefault("psd_rank", []).append(nnz)
+    else:
+        raise ValueError("unknown cone kind %r" % k)
+
+
+def project(s: np.ndarray, cones: Sequence[Cone], info: Optional[dict] = None) -> None:
+    """`project!(::SplitVector, ::CompositeConvexSet)` (src/convexset.jl:885-891): serial loop."""
+    for (a, b), c in zip(get_set_indices(cones), cones):
+        project_cone(s[a:b], c, info)
+
+
+# ---- dual-cone / recession-cone membership (infeasibility.jl needs them) -------------------
+def _is_pos_def(X: np.ndarray, tol: float) -> bool:
+    """`is_pos_def!` (src/algebra.jl:226-233): Cholesky of Hermitian(X,'U') + tol*I."""
+    Xs = np.triu(X) + np.triu(X, 1).T + tol * np.eye(X.shape[0])
+    try:
+        np.linalg.cholesky(Xs)
+        return True
+    except np.linalg.LinAlgError:
+        return False
+
+
+def in_dual(x, cone: Cone, tol: float) -> bool:
+    k = cone.kind
+    if k == ZERO:
+        return True                                             # :30-32
+    if k == NONNEG:
+        return not np.any(x < -tol)                             # :76-78
+    if k == SOC:
+        return np.linalg.norm(x[1:]) <= (tol + x[0])            # :116-118
+    if k == PSD_TRIANGLE:
+        return _is_pos_def(populate_upper_triangle(x, cone.sqrt_dim), tol)   # :415-418
+    if k == PSD_SQUARE:
+        d = cone.sqrt_dim
+        return _is_pos_def(x.reshape((d, d), order="F"), tol)   # :324-328
+    raise ValueError("in_dual undefined for %s" % CONE_NAMES[k])
+
+
+def in_pol_recc(x, cone: Cone, tol: float) -> bool:
+    k = cone.kind
+    if k == ZERO:
+        return not np.any(np.abs(x) > tol)                      # :34-36
+    if k == NONNEG:
+        return not np.any(x > tol)                              # :80-82
+    if k == SOC:
+        return np.linalg.norm(x[1:]) <= (tol - x[0])            # :120-122
+    if k == BOX:                                                # :859-861
+        return (not np.any((cone.u == np.inf) & (x > tol))) and (not np.any((cone.l == -np.inf) & (x < -tol)))
+    if k == PSD_TRIANGLE:
+        return _is_pos_def(-populate_upper_triangle(x, cone.sqrt_dim), tol)  # :421-424 + is_neg_def!
+    if k == PSD_SQUARE:
+        d = cone.sqrt_dim
+        return _is_pos_def(-x.reshape((d, d), order="F"), tol)
+    raise ValueError
+
+
+def support_function(y, cone: Cone, tol: float) -> float:
+    """src/convexset.jl:850-856 (Box) and :928-936 (cones: 0 if -y in dual cone else Inf)."""
+    if cone.kind == BOX:
+        pos = (np.abs(y) > tol) & (y > 0)
+        with np.errstate(invalid="ignore"):
+            terms = np.where(pos, y * cone.u, y * cone.l)
+        return float(np.sum(terms))
+    return 0.0 if in_dual(-y, cone, tol) else math.inf
+
+
+# --------------------------------------------------------------------------------------------
+# settings / result (src/settings.jl:101-139, src/types.jl:65-112)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class Settings:
+    rho: float = 0.1
+    sigma: float = 1e-6
+    alpha: float = 1.6
+    eps_abs: float = 1e-5
+    eps_rel: float = 1e-5
+    eps_prim_inf: float = 1e-4
+    eps_dual_inf: float = 1e-4
+    max_iter: int = 5000
+    kkt_solver: str = "qdldl"            # "qdldl" (direct), "cg", "minres" (full KKT), "minres_reduced"
+    tol_constant: float = 1.0            # kktsolver_indirect.jl:21
+    tol_exponent: float = 1.5
+    check_termination: int = 25
+    check_infeasibility: int = 40
+    scaling: int = 10
+    MIN_SCALING: float = 1e-4
+    MAX_SCALING: float = 1e4
+    adaptive_rho: bool = True
+    adaptive_rho_interval: int = 40
+    adaptive_rho_tolerance: float = 5.0
+    adaptive_rho_max_adaptions: int = 2 ** 62
+    RHO_MIN: float = 1e-6
+    RHO_MAX: float = 1e6
+    RHO_TOL: float = 1e-4
+    RHO_EQ_OVER_RHO_INEQ: float = 1e3
+    COSMO_INFTY: float = 1e20
+    time_limit: float = 0.0
+    # the oracle only restates the EmptyAccelerator loop
+
+
+@dataclass
+class Result:
+    x: np.ndarray
+    y: np.ndarray
+    s: np.ndarray
+    obj_val: float
+    iter: int
+    status: str
+    r_prim: float
+    r_dual: float
+    max_norm_prim: float
+    max_norm_dual: float
+    rho_updates: List[float]
+    iter_time: float = 0.0
+    cg_iters: List[int] = field(default_factory=list)
+    # scaled internal iterates at exit (for parity tests against the device loop)
+    w: Optional[np.ndarray] = None
+    w_prev: Optional[np.ndarray] = None
+    s_scaled: Optional[np.ndarray] = None
+    mu_scaled: Optional[np.ndarray] = None
+
+
+# --------------------------------------------------------------------------------------------
+# Ruiz scaling (src/scaling.jl:21-116)
+# --------------------------------------------------------------------------------------------
+def _clip(s, lo, hi, lo_new=None, hi_new=None):
+    """src/algebra.jl:5-7."""
+    lo_new = lo if lo_new is None else lo_new
+    hi_new = hi if hi_new is None else hi_new
+    return np.where(s < lo, lo_new, np.where(s > hi, hi_new, s))
+
+
+def _col_norms(M: sp.csc_matrix, v: np.ndarray, reset=True):
+    """src/algebra.jl:63-77 (inf-norm of every column, running max)."""
+    if reset:
+        v[:] = 0.0
+    if M.nnz:
+        absd = np.abs(M.data)
+        nz_cols = np.repeat(np.arange(M.shape[1]), np.diff(M.indptr))
+        np.maximum.at(v, nz_cols, absd)
+    return v
+
+
+def _row_norms(M: sp.csc_matrix, v: np.ndarray):
+    """src/algebra.jl:93-107."""
+    v[:] = 0.0
+    if M.nnz:
+        np.maximum.at(v, M.indices, np.abs(M.data))
+    return v
+
+
+def _lrmul(L: Optional[np.ndarray], M: sp.csc_matrix, R: Optional[np.ndarray]):
+    """`lrmul!` (src/algebra.jl:157-173): nzval[j] *= L[row]*R[col]."""
+    if M.nnz == 0:
+        return
+    cols = np.repeat(np.arange(M.shape[1]), np.diff(M.indptr))
+    if L is not None and R is not None:
+        M.data *= L[M.indices] * R[cols]
+    elif L is not None:
+        M.data *= L[M.indices]
+    elif R is not None:
+        M.data *= R[cols]
+
+
+@dataclass
+class ScaleMatrices:
+    D: np.ndarray
+    Dinv: np.ndarray
+    E: np.ndarray
+    Einv: np.ndarray
+    c: float = 1.0
+    cinv: float = 1.0
+
+
+def scale_ruiz(P: sp.csc_matrix, q: np.ndarray, A: sp.csc_matrix, b: np.ndarray,
+               cones: List[Cone], st: Settings) -> ScaleMatrices:
+    """In-place modified Ruiz equilibration; P, q, A, b and the Box bounds are overwritten."""
+    m, n = A.shape
+    D = np.ones(n); E = np.ones(m); c = 1.0
+    Dw = np.ones(n); Ew = np.ones(m)
+    for _ in range(st.scaling):
+        _col_norms(P, Dw, reset=True)                  # kkt_col_norms! (:3-8)
+        _col_norms(A, Dw, reset=False)
+        _row_norms(A, Ew)
+        Dw[:] = _clip(Dw, st.MIN_SCALING, st.MAX_SCALING, 1.0, st.MAX_SCALING)   # limit_scaling! (:10-13)
+        Ew[:] = _clip(Ew, st.MIN_SCALING, st.MAX_SCALING, 1.0, st.MAX_SCALING)
+        Dw[:] = 1.0 / np.sqrt(Dw)                      # inv_sqrt! (:125-127)
+        Ew[:] = 1.0 / np.sqrt(Ew)
+        _lrmul(Dw, P, Dw); _lrmul(Ew, A, Dw)           # scale_data! (:157-168)
+        q *= Dw; b *= Ew
+        D *= Dw; E *= Ew
+        _col_norms(P, Dw, reset=True)                  # :68
+        mean_col_norm_P = float(np.mean(Dw)) if n else 0.0
+        inf_norm_q = float(np.max(np.abs(q))) if n else 0.0
+        if mean_col_norm_P != 0.0 and inf_norm_q != 0.0:
+            inf_norm_q = float(_clip(inf_norm_q, st.MIN_SCALING, st.MAX_SCALING, 1.0, st.MAX_SCALING))
+            scale_cost = max(inf_norm_q, mean_col_norm_P)
+            scale_cost = float(_clip(scale_cost, st.MIN_SCALING, st.MAX_SCALING, 1.0, st.MAX_SCALING))
+            ctmp = 1.0 / scale_cost
+            P.data *= ctmp; q *= ctmp; c *= ctmp
+    # rectify_set_scalings! (:129-142) with rectify_scaling! (src/convexset.jl:953-958,978-982)
+    Ew[:] = 1.0
+    changed = False
+    for (a0, a1), cone in zip(get_set_indices(cones), cones):
+        if cone.kind in (SOC, PSD_SQUARE, PSD_TRIANGLE) and cone.dim > 0:
+            tmp = float(np.mean(E[a0:a1]))
+            Ew[a0:a1] = tmp / E[a0:a1]
+            changed = True
+    if changed:
+        _lrmul(Ew, A, None); b *= Ew                   # scale_data!(P,A,q,b,I,Ework) (:95)
+        E *= Ew
+    # issymmetric(P) || symmetrize_full!(P) (:99)
+    if (abs(P - P.T)).nnz != 0:
+        Ps = ((P + P.T) / 2.0).tocsc()
+        Ps.sort_indices()
+        P.data, P.indices, P.indptr = Ps.data, Ps.indices, Ps.indptr
+    # scale_sets! (:145-154): Box bounds *= E (src/convexset.jl:863-867)
+    for (a0, a1), cone in zip(get_set_indices(cones), cones):
+        if cone.kind == BOX:
+            cone.l *= E[a0:a1]
+            cone.u *= E[a0:a1]
+    return ScaleMatrices(D=D, Dinv=1.0 / D, E=E, Einv=1.0 / E, c=c, cinv=1.0 / c)
+
+
+# --------------------------------------------------------------------------------------------
+# rho vector (src/parameters.jl, src/setup.jl:75-85)
+# --------------------------------------------------------------------------------------------
+def classify_constraints(cones: List[Cone], b: np.ndarray, st: Settings) -> None:
+    for (a0, a1), cone in zip(get_set_indices(cones), cones):
+        if cone.kind == NONNEG:                         # src/convexset.jl:62-69
+            cone.constr_type[:] = False
+            cone.constr_type[b[a0:a1] > st.COSMO_INFTY * st.MIN_SCALING] = True
+        elif cone.kind == BOX:                          # :831-842
+            loose = (cone.l < -st.COSMO_INFTY * st.MIN_SCALING) & (cone.u > st.COSMO_INFTY * st.MIN_SCALING)
+            with np.errstate(invalid="ignore"):
+                eq = (cone.u - cone.l) < st.RHO_TOL
+            cone.constr_type[:] = np.where(loose, -1, np.where(eq, 1, 0))
+
+
+def row_rho_class(cones: Sequence[Cone]) -> np.ndarray:
+    """Per-row rho class: 0 = rho, 1 = rho * RHO_EQ_OVER_RHO_INEQ, 2 = RHO_MIN (src/parameters.jl:17-49)."""
+    m = sum(c.dim for c in cones)
+    cls = np.zeros(m, dtype=np.int32)
+    for (a0, a1), cone in zip(get_set_indices(cones), cones):
+        if cone.kind == ZERO:
+            cls[a0:a1] = 1
+        elif cone.kind == NONNEG:
+            cls[a0:a1][cone.constr_type] = 2
+        elif cone.kind == BOX:
+            cls[a0:a1][cone.constr_type == -1] = 2
+            cls[a0:a1][cone.constr_type == 1] = 1
+    return cls
+
+
+def make_rho_vec(rho: float, cls: np.ndarray, st: Settings) -> np.ndarray:
+    """`ρvec .= ρ; apply_constraint_rho_scaling!` (src/parameters.jl:75-92,17-49)."""
+    v = np.full(cls.size, rho)
+    v[cls == 1] *= st.RHO_EQ_OVER_RHO_INEQ
+    v[cls == 2] = st.RHO_MIN
+    return v
+
+
+# --------------------------------------------------------------------------------------------
+# sparse mat-vec exactly as Julia's CSC kernels order the sums
+# --------------------------------------------------------------------------------------------
+class Operators:
+    """A, A', P products.  SciPy's CSR mat-vec sums each row left-to-right in column order, which
+    is the order Julia's `mul!(y, A::CSC, x)` accumulates into y[i] (column sweep) and the order
+    `mul!(y, A', x)` uses for its column dot products, so results agree bit-for-bit with a serial
+    no-FMA loop (SciPy's kernels are plain C `+= a*x`)."""
+
+    def __init__(self, P: sp.csc_matrix, A: sp.csc_matrix):
+        self.A = A.tocsr(); self.A.sort_indices()
+        self.AT = A.T.tocsr(); self.AT.sort_indices()
+        self.P = P.tocsr(); self.P.sort_indices()
+        self.counts = {"A": 0, "AT": 0, "P": 0}
+
+    def mulA(self, x):
+        self.counts["A"] += 1
+        return self.A @ x
+
+    def mulAT(self, y):
+        self.counts["AT"] += 1
+        return self.AT @ y
+
+    def mulP(self, x):
+        self.counts["P"] += 1
+        return self.P @ x
+
+
+# --------------------------------------------------------------------------------------------
+# KKT solvers (src/linear_solver/*)
+# --------------------------------------------------------------------------------------------
+def assemble_kkt_full(P: sp.spmatrix, A: sp.spmatrix, sigma: float, rho: np.ndarray) -> sp.csc_matrix:
+    """[P+sigma I  A'; A  -diag(1/rho)]  (src/linear_solver/kktsolver.jl:253-266; test kktsolver.jl:16-25)."""
+    n = P.shape[0]
+    return sp.bmat([[P + sigma * sp.eye(n), A.T], [A, -sp.diags(1.0 / rho)]], format="csc")
+
+
+class DirectKKT:
+    """Stand-in for `QdldlKKTSolver` (src/linear_solver/kktsolver.jl:285-320): sparse direct solve of
+    the same quasi-definite KKT matrix; `update_rho!` re-factors."""
+
+    def __init__(self, P, A, sigma, rho, **_):
+        self.P, self.A, self.sigma = P, A, sigma
+        self.n = P.shape[0]; self.m = A.shape[0]
+        self.update_rho(rho)
+        self.last_iters = 0
+
+    def update_rho(self, rho):
+        self.lu = spla.splu(assemble_kkt_full(self.P, self.A, self.sigma, rho))
+
+    def solve(self, rhs):
+        return self.lu.solve(rhs)
+
+
+def cg_v09(x, mul, b, abstol, maxiter):
+    """IterativeSolvers.jl v0.9 `cg!(x, L, b; abstol, reltol=0)` with `initially_zero=false`, no
+    preconditioner.  Updates x in place, returns #iterations."""
+    u = np.zeros_like(x)
+    r = b.copy()
+    c = mul(x)
+    r -= c
+    residual = float(np.linalg.norm(r))
+    tol = max(0.0 * residual, abstol)
+    prev_residual = 1.0
+    it = 0
+    while it < maxiter and not (residual <= tol):
+        beta = residual ** 2 / prev_residual ** 2
+        u = r + beta * u
+        c = mul(u)
+        alpha = residual ** 2 / float(np.dot(u, c))
+        x += alpha * u
+        r -= alpha * c
+        prev_residual = residual
+        residual = float(np.linalg.norm(r))
+        it += 1
+    return it
+
+
+def _givens(f, g):
+    """LinearAlgebra.givensAlgorithm(f, g) for reals: returns (c, s, r) with [c s; -s c][f; g] = [r; 0]."""
+    if g == 0.0:
+        return 1.0, 0.0, f
+    if f == 0.0:
+        return 0.0, 1.0, g
+    r = math.hypot(f, g)
+    c = f / r
+    s = g / r
+    if abs(f) > abs(g) and c < 0:
+        c, s, r = -c, -s, -r
+    return c, s, r
+
+
+def minres_v09(x, mul, b, abstol, maxiter):
+    """IterativeSolvers.jl v0.9 `minres!(x, L, b; abstol, reltol=0)` (Paige-Saunders via Lanczos +
+    Givens), `initially_zero=false`.  Updates x in place, returns #iterations."""
+    v_prev = np.zeros_like(x)
+    v_curr = b.copy()
+    v_next = mul(x)
+    v_curr -= v_next
+    resnorm = float(np.linalg.norm(v_curr))
+    tol = max(0.0 * resnorm, abstol)
+    H = np.zeros(4)
+    rhs = np.array([resnorm, 0.0])
+    if resnorm <= tol or resnorm == 0.0:
+        return 0
+    v_curr *= 1.0 / resnorm
+    w_prev = np.zeros_like(x); w_curr = np.zeros_like(x); w_next = np.zeros_like(x)
+    c_prev, s_prev, c_curr, s_curr = 1.0, 0.0, 1.0, 0.0
+    it = 1
+    while not (it > maxiter or resnorm <= tol):
+        v_next = mul(v_curr)
+        if it > 1:
+            v_next -= H[1] * v_prev
+        proj = float(np.dot(v_curr, v_next))
+        H[2] = proj
+        v_next -= proj * v_curr
+        H[3] = float(np.linalg.norm(v_next))
+        v_next *= 1.0 / H[3]
+        if it > 2:
+            H[0] = s_prev * H[1]
+            H[1] = c_prev * H[1]
+        if it > 1:
+            tmp = -s_curr * H[1] + c_curr * H[2]
+            H[1] = c_curr * H[1] + s_curr * H[2]
+            H[2] = tmp
+        c, s, H[2] = _givens(H[2], H[3])
+        rhs[1] = -s * rhs[0]
+        rhs[0] = c * rhs[0]
+        w_next = v_curr.copy()
+        if it > 1:
+            w_next -= H[1] * w_curr
+        if it > 2:
+            w_next -= H[0] * w_prev
+        w_next *= 1.0 / H[2]
+        x += rhs[0] * w_next
+        v_prev, v_curr = v_curr, v_next
+        w_prev, w_curr = w_curr, w_next
+        c_prev, s_prev, c_curr, s_curr = c_curr, s_curr, c, s
+        rhs[0] = rhs[1]
+        H[1] = H[3]
+        resnorm = abs(rhs[1])
+        it += 1
+    return it - 1
+
+
+class IndirectReducedKKT:
+    """`IndirectReducedKKTSolver` (src/linear_solver/kktsolver_indirect.jl:3-88): CG or MINRES on
+    (P + sigma I + A' rho A) y1 = x1 + A' rho x2, then y2 = rho (A y1 - x2)."""
+
+    def __init__(self, ops: Operators, n, m, sigma, rho, solver_type="CG",
+                 tol_constant=1.0, tol_exponent=1.5):
+        self.ops, self.n, self.m, self.sigma = ops, n, m, sigma
+        self.rho = rho.copy()
+        self.solver_type = solver_type
+        self.tol_constant, self.tol_exponent = tol_constant, tol_exponent
+        self.previous_solution = np.zeros(n)
+        self.iteration_counter = 1
+        self.multiplications: List[int] = []
+        self.last_iters = 0
+
+    def update_rho(self, rho):
+        self.rho[:] = rho                                     # :164-166
+
+    def get_tolerance(self):
+        return self.tol_constant / self.iteration_counter ** self.tol_exponent   # :168-170
+
+    def reduced_mul(self, x):
+        tmp_m = self.ops.mulA(x)                              # :59
+        tmp_m *= self.rho                                     # :60
+        tmp_n = self.ops.mulAT(tmp_m)                         # :61
+        tmp_n = self.sigma * x + tmp_n                        # axpy!(sigma, x, tmp_n) :62
+        y = self.ops.mulP(x)                                  # :63
+        y = tmp_n + y                                         # axpy!(1, tmp_n, y) :64
+        self.multiplications[-1] += 1
+        return y
+
+    def solve(self, rhs):
+        n, m = self.n, self.m
+        x1, x2 = rhs[:n], rhs[n:]
+        y2 = self.rho * x2                                    # :52
+        y1 = self.ops.mulAT(y2)                               # :53
+        y1 = y1 + x1                                          # :54
+        self.multiplications.append(0)
+        nrm = float(np.linalg.norm(y1))
+        if self.solver_type == "CG":
+            abstol = self.get_tolerance() / nrm if nrm > 0 else math.inf
+            self.last_iters = cg_v09(self.previous_solution, self.reduced_mul, y1, abstol, n)
+        else:
+            init_res = float(np.linalg.norm(self.reduced_mul(self.previous_solution) - y1))
+            abstol = self.get_tolerance() / init_res if init_res > 0 else math.inf
+            self.last_iters = minres_v09(self.previous_solution, self.reduced_mul, y1, abstol, n)
+        y1 = self.previous_solution.copy()                    # :78
+        y2 = self.ops.mulA(y1)                                # :81
+        y2 = y2 - x2                                          # axpy!(-1, x2, y2) :82
+        y2 *= self.rho                                        # :83
+        self.iteration_counter += 1                           # :85
+        return np.concatenate([y1, y2])
+
+
+class IndirectFullKKT:
+    """`IndirectKKTSolver` (src/linear_solver/kktsolver_indirect.jl:90-162): MINRES on the full
+    (n+m) quasi-definite system with warm start."""
+
+    def __init__(self, ops: Operators, n, m, sigma, rho, tol_constant=1.0, tol_exponent=1.5):
+        self.ops, self.n, self.m, self.sigma = ops, n, m, sigma
+        self.rho = rho.copy()
+        self.tol_constant, self.tol_exponent = tol_constant, tol_exponent
+        self.previous_solution = np.zeros(n + m)
+        self.iteration_counter = 1
+        self.multiplications: List[int] = []
+        self.last_iters = 0
+
+    def update_rho(self, rho):
+        self.rho[:] = rho
+
+    def get_tolerance(self):
+        return self.tol_constant / self.iteration_counter ** self.tol_exponent
+
+    def kkt_mul(self, x):
+        n = self.n
+        x1, x2 = x[:n], x[n:]
+        tmp_n = self.ops.mulAT(x2)                            # :137
+        tmp_n = self.sigma * x1 + tmp_n                       # :138
+        y1 = self.ops.mulP(x1)                                # :139
+        y1 = tmp_n + y1                                       # :140
+        y2 = -x2 / self.rho                                   # :142
+        tmp_m = self.ops.mulA(x1)                             # :143
+        y2 = tmp_m + y2                                       # :144
+        self.multiplications[-1] += 1
+        return np.concatenate([y1, y2])
+
+    def solve(self, rhs):
+        self.multiplications.append(0)
+        init_res = float(np.linalg.norm(self.kkt_mul(self.previous_solution) - rhs))   # :151
+        abstol = self.get_tolerance() / init_res if init_res > 0 else math.inf
+        self.last_iters = minres_v09(self.previous_solution, self.kkt_mul, rhs, abstol, self.n + self.m)
+        self.iteration_counter += 1
+        return self.previous_solution.copy()
+
+
+def make_kkt_solver(kind: str, P, A, ops, sigma, rho, st: Settings):
+    m, n = A.shape
+    kind = kind.lower()
+    if kind in ("qdldl", "direct", "cholmod"):
+        return DirectKKT(P, A, sigma, rho)
+    if kind == "cg":
+        return IndirectReducedKKT(ops, n, m, sigma, rho, "CG", st.tol_constant, st.tol_exponent)
+    if kind == "minres_reduced":
+        return IndirectReducedKKT(ops, n, m, sigma, rho, "MINRES", st.tol_constant, st.tol_exponent)
+    if kind == "minres":
+        return IndirectFullKKT(ops, n, m, sigma, rho, st.tol_constant, st.tol_exponent)
+    raise ValueError("unknown kkt solver %r" % kind)
+
+
+# --------------------------------------------------------------------------------------------
+# residuals (src/residuals.jl)
+# --------------------------------------------------------------------------------------------
+def _inf_norm(v):
+    return float(np.max(np.abs(v))) if v.size else 0.0
+
+
+def calculate_residuals(ops: Operators, x, s, mu, q, b, sm: Optional[ScaleMatrices], unscale: bool):
+    r_prim = ops.mulA(x)                                      # :4
+    r_prim = r_prim + s                                       # :5
+    r_prim = r_prim - b                                       # :6
+    r_dual = ops.mulP(x)                                      # :12
+    r_dual = r_dual + q                                       # :13
+    r_temp = ops.mulAT(mu)                                    # :15
+    r_dual = r_dual - r_temp                                  # :16
+    if unscale:
+        r_prim = r_prim * sm.Einv                             # :45
+        r_dual = r_dual * sm.Dinv                             # :25
+        r_dual = r_dual * sm.cinv                             # :26
+    return _inf_norm(r_prim), _inf_norm(r_dual)
+
+
+def max_res_component_norm(ops: Operators, x, s, mu, q, b, sm, unscale: bool):
+    def up(v): return v * sm.Einv if unscale else v
+    def ud(v): return (v * sm.Dinv) * sm.cinv if unscale else v
+    mp = _inf_norm(up(ops.mulA(x)))                           # :65-67
+    mp = max(mp, _inf_norm(up(s.copy())))                     # :70-72
+    mp = max(mp, _inf_norm(up(b.copy())))                     # :75-77
+    md = _inf_norm(ud(ops.mulP(x)))                           # :81-83
+    md = max(md, _inf_norm(ud(q.copy())))                     # :86-88
+    md = max(md, _inf_norm(ud(ops.mulAT(mu))))                # :91-93
+    return mp, md
+
+
+def calculate_cost(ops: Operators, x, q, cinv):
+    temp = ops.mulP(x)                                        # :145
+    return cinv * (0.5 * float(np.dot(temp, x)) + float(np.dot(q, x)))   # :146
+
+
+# --------------------------------------------------------------------------------------------
+# infeasibility (src/infeasibility.jl)
+# --------------------------------------------------------------------------------------------
+def is_primal_infeasible(dy, ops, b, cones, sm: ScaleMatrices, st: Settings) -> bool:
+    norm_dy = _inf_norm(sm.E * dy)                            # :5
+    if norm_dy > st.eps_prim_inf:
+        A_dy = ops.mulAT(dy) * sm.Dinv                        # :12-14
+        if _inf_norm(A_dy) <= st.eps_prim_inf * norm_dy:
+            dyn = dy * (-1.0 / norm_dy)                       # :19
+            dyt_b = float(np.dot(dyn, b))                     # :20
+            sF = 0.0
+            for (a0, a1), cone in zip(get_set_indices(cones), cones):
+                if cone.kind == BOX:
+                    sF += support_function(dyn[a0:a1], cone, st.eps_prim_inf)
+                else:                                         # support_function! negates y in place (:933-936)
+                    sF += support_function(dyn[a0:a1], cone, st.eps_prim_inf)
+            sF -= dyt_b                                       # :22
+            if sF <= st.eps_prim_inf:
+                return True
+    return False
+
+
+def is_dual_infeasible(dx, ops, q, cones, sm: ScaleMatrices, st: Settings) -> bool:
+    norm_dx = _inf_norm(sm.D * dx)                            # :35
+    if norm_dx > st.eps_dual_inf:
+        if float(np.dot(q, dx)) / (norm_dx * sm.c) < -st.eps_dual_inf:      # :39
+            P_dx = ops.mulP(dx) * sm.Dinv                     # :44-47
+            if _inf_norm(P_dx) / (norm_dx * sm.c) <= st.eps_dual_inf:       # :49
+                A_dx = ops.mulA(dx) * sm.Einv                 # :53-56
+                A_dx = A_dx * (1.0 / norm_dx)                 # :59
+                ok = all(in_pol_recc(A_dx[a0:a1], cone, st.eps_dual_inf)
+                         for (a0, a1), cone in zip(get_set_indices(cones), cones))
+                if ok:
+                    return True
+    return False
+
+
+# --------------------------------------------------------------------------------------------
+# the solver workspace + ADMM loop (src/solver.jl)
+# --------------------------------------------------------------------------------------------
+class Workspace:
+    """Holds what `COSMO.Workspace` holds after `setup!` (src/setup.jl:18-64): scaled data,
+    classified cones, rho vector, KKT solver."""
+
+    def __init__(self, P, q, A, b, cones: Sequence[Cone], settings: Optional[Settings] = None,
+                 x0=None, s0=None, mu0=None):
+        st = settings or Settings()
+        self.st = st
+        self.P = sp.csc_matrix(P, dtype=np.float64, copy=True); self.P.sort_indices()
+        self.A = sp.csc_matrix(A, dtype=np.float64, copy=True); self.A.sort_indices()
+        self.q = np.array(q, dtype=np.float64).copy()
+        self.b = np.array(b, dtype=np.float64).copy()
+        self.cones = copy_cones(cones)
+        self.m, self.n = self.A.shape
+        assert sum(c.dim for c in self.cones) == self.m
+        n, m = self.n, self.m
+        self.x = np.zeros(n) if x0 is None else np.array(x0, dtype=np.float64).copy()
+        self.s = np.zeros(m) if s0 is None else np.array(s0, dtype=np.float64).copy()
+        self.mu = np.zeros(m) if mu0 is None else np.array(mu0, dtype=np.float64).copy()
+        # --- setup! ---
+        if st.scaling != 0:
+            self.sm = scale_ruiz(self.P, self.q, self.A, self.b, self.cones, st)
+        else:
+            self.sm = ScaleMatrices(np.ones(n), np.ones(n), np.ones(m), np.ones(m), 1.0, 1.0)
+        # scale_variables! (src/scaling.jl:118-123)
+        self.x = self.sm.Dinv * self.x
+        self.mu = (self.sm.Einv * self.mu) * self.sm.c
+        self.s = self.sm.E * self.s
+        classify_constraints(self.cones, self.b, st)
+        self.rho_class = row_rho_class(self.cones)
+        self.rho = st.rho
+        self.rho_vec = make_rho_vec(self.rho, self.rho_class, st)
+        self.rho_updates = [self.rho]
+        self.ops = Operators(self.P, self.A)
+        self.kkt = make_kkt_solver(st.kkt_solver, self.P, self.A, self.ops, st.sigma, self.rho_vec, st)
+        self.is_optimized = False
+
+    # ---- residual helpers bound to the workspace
+    def _result_info(self, x, s, mu):
+        unscale = self.st.scaling != 0
+        rp, rd = calculate_residuals(self.ops, x, s, mu, self.q, self.b, self.sm, unscale)
+        mp, md = max_res_component_norm(self.ops, x, s, mu, self.q, self.b, self.sm, unscale)
+        return rp, rd, mp, md
+
+    def update(self, q=None, b=None):
+        """`COSMO.update!(model; q, b)` (src/interface.jl:187-211)."""
+        if q is not None:
+            self.q = (self.sm.D * np.array(q, dtype=np.float64)) * self.sm.c
+        if b is not None:
+            self.b = self.sm.E * np.array(b, dtype=np.float64)
+
+    def optimize(self, record=None, project_info: Optional[dict] = None) -> Result:
+        st = self.st
+        n, m = self.n, self.m
+        ops, q, b, cones = self.ops, self.q, self.b, self.cones
+        rho_vec = self.rho_vec
+        sigma, alpha = st.sigma, st.alpha
+        if self.is_optimized:
+            # second call: variables are rescaled again (src/setup.jl:29-33); rho, the KKT solver and
+            # its Krylov state are kept (:40-61); constraints are re-classified (:36-37)
+            self.x = self.sm.Dinv * self.x
+            self.mu = (self.sm.Einv * self.mu) * self.sm.c
+            self.s = self.sm.E * self.s
+            classify_constraints(self.cones, self.b, st)
+            self.rho_class = row_rho_class(self.cones)
+        status = "Undetermined"
+        cost = math.inf
+        info = (math.inf, math.inf, 0.0, 0.0)
+        w = np.zeros(n + m)
+        w[:n] = self.x                                          # src/solver.jl:128
+        w[n:] = (1.0 / rho_vec) * self.mu + self.s              # :129
+        w_prev = np.zeros(n + m)
+        s = self.s.copy()
+        mu = self.mu.copy()
+        dy = np.zeros(m); dx = np.zeros(n)
+        infeasibility_check_due = False
+        rho_update_due = False
+        self.is_optimized = True
+        cg_iters = []
+        t0 = time.perf_counter()
+
+        def admm_x(w, s):
+            ls = np.empty(n + m)
+            ls[:n] = sigma * w[:n] - q                          # :50
+            ls[n:] = (b - 2.0 * s) + w[n:]                      # :51
+            sol = self.kkt.solve(ls)                            # :52
+            cg_iters.append(self.kkt.last_iters)
+            nu = sol[n:]
+            s_tl = (2.0 * s - w[n:]) - nu / rho_vec             # :55
+            return sol, s_tl
+
+        def admm_w(w, sol, s_tl, s):
+            w[:n] = w[:n] + alpha * (sol[:n] - w[:n])           # :63
+            w[n:] = w[n:] + alpha * (s_tl - s)                  # :64
+
+        sol, s_tl = admm_x(w, s)                                # :137
+        admm_w(w, sol, s_tl, s)                                 # :138
+        it = 0
+        while it < st.max_iter:
+            it += 1
+            if infeasibility_check_due:                         # :145-148
+                mu = rho_vec * (w_prev[n:] - s)
+                dy[:] = mu
+            w_prev[:] = w                                       # :151
+            s[:] = w[n:]                                        # :14
+            project(s, cones, project_info)                     # :15
+            # apply_rho_adaptation_rules! (:242-282)
+            if (st.adaptive_rho and st.adaptive_rho_interval > 0 and it % st.adaptive_rho_interval == 0
+                    and (len(self.rho_updates) - 1) < st.adaptive_rho_max_adaptions):
+                rho_update_due = True
+            if rho_update_due:
+                rho_update_due = False
+                mu = rho_vec * (w_prev[n:] - s)                 # :270
+                x = w_prev[:n]
+                rp, rd = calculate_residuals(ops, x, s, mu, q, b, self.sm, False)      # parameters.jl:58
+                mp, md = max_res_component_norm(ops, x, s, mu, q, b, self.sm, False)   # :59
+                rp = rp / (mp + 1e-10)                          # :61
+                rd = rd / (md + 1e-10)                          # :62
+                new_rho = self.rho * math.sqrt(rp / (rd + 1e-10))                      # :64
+                new_rho = min(max(new_rho, st.RHO_MIN), st.RHO_MAX)                    # :65
+                if (new_rho > st.adaptive_rho_tolerance * self.rho) or \
+                        (new_rho < (1.0 / st.adaptive_rho_tolerance) * self.rho):      # :67
+                    self.rho = new_rho                          # update_rho_vec! (:75-92)
+                    rho_vec[:] = make_rho_vec(new_rho, self.rho_class, st)
+                    self.rho_updates.append(new_rho)
+                    self.kkt.update_rho(rho_vec)
+                    w[n:] = (1.0 / rho_vec) * mu + s            # solver.jl:278
+            sol, s_tl = admm_x(w, s)                            # :154
+            admm_w(w, sol, s_tl, s)                             # :155
+            if record is not None:
+                record(it, w, w_prev, s, sol)
+            # ---- check_termination! (:303-356)
+            if it % st.check_termination == 0 or it == 1:
+                mu = rho_vec * (w_prev[n:] - s)                 # :307
+                x = w_prev[:n]
+                info = self._result_info(x, s, mu)              # :308
+                cost = calculate_cost(ops, x, q, self.sm.cinv)  # :310
+                if abs(cost) > 1e20:
+                    status = "Unsolved"
+                    break
+                rp, rd, mp, md = info
+                if rp < st.eps_abs + st.eps_rel * mp and rd < st.eps_abs + st.eps_rel * md:   # residuals.jl:98-117
+                    status = "Solved"
+                    break
+            if it % st.check_infeasibility == 0:                # :326-327
+                infeasibility_check_due = True
+            elif infeasibility_check_due:                       # :329-348
+                infeasibility_check_due = False
+                mu = rho_vec * (w_prev[n:] - s)
+                dy -= mu
+                dx[:] = w[:n] - w_prev[:n]
+                if is_primal_infeasible(dy.copy(), ops, b, cones, self.sm, st):
+                    status = "Primal_infeasible"; cost = math.inf
+                    break
+                if is_dual_infeasible(dx, ops, q, cones, self.sm, st):
+                    status = "Dual_infeasible"; cost = -math.inf
+                    break
+            if st.time_limit != 0 and (time.perf_counter() - t0) > st.time_limit:
+                x = w_prev[:n]
+                mu = rho_vec * (w_prev[n:] - s)
+                info = self._result_info(x, s, mu)
+                status = "Time_limit_reached"
+                break
+        mu = rho_vec * (w_prev[n:] - s)                         # :167
+        iter_time = time.perf_counter() - t0
+        x = w_prev[:n].copy()
+        if it == st.max_iter and status == "Undetermined":      # :173-176
+            info = self._result_info(x, s, mu)
+            status = "Max_iter_reached"
+        w_out, wp_out, s_sc, mu_sc = w.copy(), w_prev.copy(), s.copy(), mu.copy()
+        # keep scaled iterates for a later warm-started optimize!
+        self.x, self.s, self.mu = x.copy(), s.copy(), mu.copy()
+        if st.scaling != 0:                                     # reverse_scaling! (scaling.jl:170-179)
+            xr = self.sm.D * x
+            sr = self.sm.Einv * s
+            mur = (self.sm.E * mu) * self.sm.cinv
+            self.x, self.s, self.mu = xr.copy(), sr.copy(), mur.copy()
+        else:
+            xr, sr, mur = x, s.copy(), mu.copy()
+        return Result(x=xr, y=-mur, s=sr, obj_val=cost, iter=it, status=status,
+                      r_prim=info[0], r_dual=info[1], max_norm_prim=info[2], max_norm_dual=info[3],
+                      rho_updates=list(self.rho_updates), iter_time=iter_time, cg_iters=cg_iters,
+                      w=w_out, w_prev=wp_out, s_scaled=s_sc, mu_scaled=mu_sc)
+
+
+def solve(P, q, A, b, cones, settings: Optional[Settings] = None, **kw) -> Result:
+    return Workspace(P, q, A, b, cones, settings, **kw).optimize()
+
+
+# --------------------------------------------------------------------------------------------
+# Constraint-level front door (mirrors `assemble!`, src/interface.jl:30-77, 411-484)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class Constraint:
+    """`A x + b in K` (src/constraint.jl:47-68)."""
+    A: sp.spmatrix
+    b: np.ndarray
+    cone: Cone
+
+    def __post_init__(self):
+        self.A = sp.csc_matrix(self.A, dtype=np.float64)
+        self.b = np.atleast_1d(np.array(self.b, dtype=np.float64))
+        if self.A.shape[0] != self.b.size:
+            raise ValueError("The dimensions of matrix A and vector b don't match.")
+        if self.A.shape[0] != self.cone.dim:
+            raise ValueError("The row dimension of A doesn't match the dimension of the constraint set.")
+
+
+_SORT_KEY = {ZERO: 1, NONNEG: 2, BOX: 3, SOC: 4, PSD_SQUARE: 5, PSD_TRIANGLE: 6}
+
+
+def assemble(constraints: Sequence[Constraint]):
+    """Returns internal (A, b, cones): merge Zero/Nonneg sets, stable-sort by set type, A := -A."""
+    cons = list(constraints)
+    for kind, ctor in ((ZERO, ZeroSet), (NONNEG, Nonnegatives)):
+        idx = [i for i, c in enumerate(cons) if c.cone.kind == kind]
+        if len(idx) > 1:                                         # merge_constraints! (:411-428)
+            Am = sp.vstack([cons[i].A for i in idx], format="csc")
+            bm = np.concatenate([cons[i].b for i in idx])
+            cons = [c for i, c in enumerate(cons) if i not in idx]
+            cons.append(Constraint(Am, bm, ctor(bm.size)))
+    cons.sort(key=lambda c: _SORT_KEY[c.cone.kind])              # stable (:55)
+    A = sp.vstack([-c.A for c in cons], format="csc")            # process_constraint! (:478-484)
+    b = np.concatenate([c.b for c in cons])
+    return A, b, [c.cone for c in cons]
