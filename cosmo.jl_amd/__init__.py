@@ -1,0 +1,15 @@
+"""cosmo.jl_amd -- MI355X-native ADMM hot path for COSMO (host-side mirror of the reference interface + ctypes
+binding of libcosmo_hip.so).  The directory name contains a dot, so import it through the `cosmo_jl_amd` shim at the
+repository root (`import cosmo_jl_amd`)."""
+from . import _ffi
+from ._ffi import CosmoHipError, Handle, load_library
+from .model import (Box, CGIndirectKKTSolver, Constraint, IndirectReducedKKTSolverMINRES, MINRESIndirectKKTSolver,
+                    Model, Nonnegatives, PsdCone, PsdConeTriangle, QdldlKKTSolver, Result, SecondOrderCone, Settings,
+                    ZeroSet, assemble, optimize, update, warm_start_dual, warm_start_primal, warm_start_slack,
+                    with_options)
+from . import problems
+
+__all__ = ["Handle", "CosmoHipError", "load_library", "Model", "Settings", "Constraint", "ZeroSet", "Nonnegatives", "Box",
+           "SecondOrderCone", "PsdCone", "PsdConeTriangle", "assemble", "optimize", "update", "warm_start_primal",
+           "warm_start_slack", "warm_start_dual", "with_options", "CGIndirectKKTSolver", "MINRESIndirectKKTSolver",
+           "IndirectReducedKKTSolverMINRES", "QdldlKKTSolver", "Result", "problems", "_ffi"]

@@ -1,0 +1,298 @@
+"""ctypes binding of libcosmo_hip.so (include/cosmo_hip.h).
+
+This is the same C ABI a Julia `ccall` layer binds (julia/CosmoHIP.jl); the Python binding
+exists because Julia is not installed in this image.  There is NO CPU fallback: if the shared library is
+missing, or no HIP device is visible, every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcosmo_hip.so")
+
+OK = 0
+ERR_NAMES = {1: "INVALID", 2: "HIP", 3: "NOT_CONVEX", 4: "NONFINITE", 5: "EIG", 6: "UNSUPPORTED", 7: "COMM"}
+
+ZERO, NONNEG, BOX, SOC, PSD_SQUARE, PSD_TRIANGLE = 0, 1, 2, 3, 4, 5
+KKT_CG, KKT_MINRES_REDUCED, KKT_MINRES = 0, 1, 2
+STATUS_NAMES = {0: "Undetermined", 1: "Solved", 2: "Max_iter_reached", 3: "Unsolved", 4: "Primal_infeasible",
+                5: "Dual_infeasible", 6: "Time_limit_reached"}
+MAT_A, MAT_AT, MAT_P, MAT_OP = 0, 1, 2, 3
+MAX_RHO_UPDATES = 64
+NUM_KERNEL_CLASSES = 16
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("sigma", C.c_double), ("alpha", C.c_double), ("rho", C.c_double),
+        ("eps_abs", C.c_double), ("eps_rel", C.c_double),
+        ("eps_prim_inf", C.c_double), ("eps_dual_inf", C.c_double),
+        ("tol_constant", C.c_double), ("tol_exponent", C.c_double),
+        ("rho_min", C.c_double), ("rho_max", C.c_double), ("rho_tol", C.c_double),
+        ("rho_eq_over_rho_ineq", C.c_double), ("adaptive_rho_tolerance", C.c_double),
+        ("cosmo_infty_min_scaling", C.c_double), ("time_limit", C.c_double),
+        ("max_iter", C.c_int64), ("adaptive_rho_max_adaptions", C.c_int64),
+        ("kkt_kind", C.c_int32), ("check_termination", C.c_int32), ("check_infeasibility", C.c_int32),
+        ("adaptive_rho", C.c_int32), ("adaptive_rho_interval", C.c_int32), ("unscale_residuals", C.c_int32),
+    ]
+
+
+class ResultStruct(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32), ("n_rho_updates", C.c_int32),
+        ("iter", C.c_int64), ("kkt_iters_total", C.c_int64), ("kkt_solves", C.c_int64),
+        ("cost", C.c_double), ("r_prim", C.c_double), ("r_dual", C.c_double),
+        ("max_norm_prim", C.c_double), ("max_norm_dual", C.c_double), ("rho", C.c_double),
+        ("iter_time", C.c_double), ("proj_time", C.c_double),
+        ("rho_updates", C.c_double * MAX_RHO_UPDATES),
+    ]
+
+
+class CosmoHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libcosmo_hip error %d (%s): %s" % (code, ERR_NAMES.get(code, "?"), msg))
+        self.code = code
+
+
+_lib = None
+
+_PD = C.POINTER(C.c_double)
+_PI64 = C.POINTER(C.c_int64)
+_PI32 = C.POINTER(C.c_int32)
+
+# name -> (restype, argtypes).  Kept in one table so tests can check it against the header.
+SIGNATURES = {
+    "cosmo_hip_version": (C.c_int32, []),
+    "cosmo_hip_default_params": (None, [C.POINTER(Params)]),
+    "cosmo_hip_create": (C.c_int32, [C.POINTER(C.c_void_p), C.c_int32]),
+    "cosmo_hip_destroy": (C.c_int32, [C.c_void_p]),
+    "cosmo_hip_last_error": (C.c_char_p, [C.c_void_p]),
+    "cosmo_hip_set_problem": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int64, _PI64, _PI64, _PD, _PI64, _PI64, _PD, _PD, _PD]),
+    "cosmo_hip_set_cones": (C.c_int32, [C.c_void_p, C.c_int64, _PI32, _PI64, _PD, _PD]),
+    "cosmo_hip_set_params": (C.c_int32, [C.c_void_p, C.POINTER(Params), _PD]),
+    "cosmo_hip_update_rho": (C.c_int32, [C.c_void_p, _PD]),
+    "cosmo_hip_set_scaling": (C.c_int32, [C.c_void_p, _PD, _PD, C.c_double]),
+    "cosmo_hip_update_qb": (C.c_int32, [C.c_void_p, _PD, _PD]),
+    "cosmo_hip_get_rho_classes": (C.c_int32, [C.c_void_p, _PI32]),
+    "cosmo_hip_get_rho_vec": (C.c_int32, [C.c_void_p, _PD]),
+    "cosmo_hip_kkt_solve": (C.c_int32, [C.c_void_p, _PD, _PD, _PI64]),
+    "cosmo_hip_project": (C.c_int32, [C.c_void_p, _PD, _PI64, _PI32]),
+    "cosmo_hip_spmv": (C.c_int32, [C.c_void_p, C.c_int32, _PD, _PD]),
+    "cosmo_hip_set_iterates": (C.c_int32, [C.c_void_p, _PD, _PD, _PD]),
+    "cosmo_hip_admm_init": (C.c_int32, [C.c_void_p]),
+    "cosmo_hip_admm_iterate": (C.c_int32, [C.c_void_p, C.c_int64]),
+    "cosmo_hip_admm_iterate_checked": (C.c_int32, [C.c_void_p, C.c_int64, _PI32]),
+    "cosmo_hip_residuals": (C.c_int32, [C.c_void_p, _PD]),
+    "cosmo_hip_optimize": (C.c_int32, [C.c_void_p, C.POINTER(ResultStruct)]),
+    "cosmo_hip_get_iterates": (C.c_int32, [C.c_void_p, _PD, _PD, _PD, _PD]),
+    "cosmo_hip_get_kkt_solution": (C.c_int32, [C.c_void_p, _PD]),
+    "cosmo_hip_get_stats": (C.c_int32, [C.c_void_p, _PI64]),
+    "cosmo_hip_time_spmv": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _PD, _PD]),
+    "cosmo_hip_set_profiling": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "cosmo_hip_get_kernel_times": (C.c_int32, [C.c_void_p, _PD, _PI64]),
+    "cosmo_hip_kernel_class_name": (C.c_char_p, [C.c_int32]),
+}
+
+
+def load_library():
+    """Loads libcosmo_hip.so (built by `__graft_entry__.build()` / `make -C cosmo.jl_amd/csrc`).  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libcosmo_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(_PD)
+
+
+def _f64(a, n=None, name="array"):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if n is not None and a.size != n:
+        raise ValueError("%s has length %d, expected %d" % (name, a.size, n))
+    return a
+
+
+def csc_julia(M):
+    """SciPy sparse -> the arrays of a Julia SparseMatrixCSC{Float64,Int64} (1-based, sorted rows)."""
+    import scipy.sparse as sp
+    M = sp.csc_matrix(M, dtype=np.float64)
+    M.sum_duplicates()
+    M.sort_indices()
+    colptr = np.ascontiguousarray(M.indptr, dtype=np.int64) + 1
+    rowval = np.ascontiguousarray(M.indices, dtype=np.int64) + 1
+    nzval = np.ascontiguousarray(M.data, dtype=np.float64)
+    return colptr, rowval, nzval
+
+
+class Handle:
+    """Thin object wrapper: one method per C entry point, NumPy arrays in and out."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self._h = C.c_void_p()
+        rc = self.lib.cosmo_hip_create(C.byref(self._h), int(device))
+        if rc != OK:
+            raise CosmoHipError(rc, "cosmo_hip_create failed (no MI355X visible? this library has no CPU path)")
+        self.n = self.m = 0
+        self.ncones = 0
+
+    def close(self):
+        if self._h:
+            self.lib.cosmo_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != OK:
+            msg = self.lib.cosmo_hip_last_error(self._h)
+            raise CosmoHipError(rc, msg.decode() if msg else "")
+
+    # ---- problem ----------------------------------------------------------------------------------------
+    def set_problem(self, P, q, A, b):
+        m, n = A.shape
+        pc, pr, pv = csc_julia(P)
+        ac, ar, av = csc_julia(A)
+        q = _f64(q, n, "q"); b = _f64(b, m, "b")
+        self._chk(self.lib.cosmo_hip_set_problem(self._h, n, m, pc.ctypes.data_as(_PI64), pr.ctypes.data_as(_PI64), _dp(pv),
+                                                 ac.ctypes.data_as(_PI64), ar.ctypes.data_as(_PI64), _dp(av), _dp(q), _dp(b)))
+        self.n, self.m = n, m
+
+    def set_cones(self, types, dims, box_l=None, box_u=None):
+        t = np.ascontiguousarray(types, dtype=np.int32)
+        d = np.ascontiguousarray(dims, dtype=np.int64)
+        bl = _f64(box_l); bu = _f64(box_u)
+        self._chk(self.lib.cosmo_hip_set_cones(self._h, t.size, t.ctypes.data_as(_PI32), d.ctypes.data_as(_PI64), _dp(bl), _dp(bu)))
+        self.ncones = t.size
+
+    def default_params(self):
+        p = Params()
+        self.lib.cosmo_hip_default_params(C.byref(p))
+        return p
+
+    def set_params(self, params, rho_vec=None):
+        rv = _f64(rho_vec, self.m, "rho_vec")
+        self._chk(self.lib.cosmo_hip_set_params(self._h, C.byref(params), _dp(rv)))
+
+    def update_rho(self, rho_vec):
+        rv = _f64(rho_vec, self.m, "rho_vec")
+        self._chk(self.lib.cosmo_hip_update_rho(self._h, _dp(rv)))
+
+    def set_scaling(self, Dinv, Einv, cinv):
+        self._chk(self.lib.cosmo_hip_set_scaling(self._h, _dp(_f64(Dinv, self.n)), _dp(_f64(Einv, self.m)), float(cinv)))
+
+    def update_qb(self, q=None, b=None):
+        self._chk(self.lib.cosmo_hip_update_qb(self._h, _dp(_f64(q, self.n)), _dp(_f64(b, self.m))))
+
+    def get_rho_classes(self):
+        out = np.empty(self.m, dtype=np.int32)
+        self._chk(self.lib.cosmo_hip_get_rho_classes(self._h, out.ctypes.data_as(_PI32)))
+        return out
+
+    def get_rho_vec(self):
+        out = np.empty(self.m)
+        self._chk(self.lib.cosmo_hip_get_rho_vec(self._h, _dp(out)))
+        return out
+
+    # ---- fine-grained ---------------------------------------------------------------------------------------
+    def kkt_solve(self, rhs):
+        rhs = _f64(rhs, self.n + self.m, "rhs")
+        lhs = np.empty(self.n + self.m)
+        it = C.c_int64(0)
+        self._chk(self.lib.cosmo_hip_kkt_solve(self._h, _dp(lhs), _dp(rhs), C.byref(it)))
+        return lhs, it.value
+
+    def project(self, s):
+        s = np.array(s, dtype=np.float64).copy()
+        ranks = np.empty(max(self.ncones, 1), dtype=np.int64)
+        br = np.empty(max(self.ncones, 1), dtype=np.int32)
+        self._chk(self.lib.cosmo_hip_project(self._h, _dp(s), ranks.ctypes.data_as(_PI64), br.ctypes.data_as(_PI32)))
+        return s, ranks[:self.ncones], br[:self.ncones]
+
+    def spmv(self, which, x):
+        nin = {MAT_A: self.n, MAT_AT: self.m, MAT_P: self.n}[which]
+        nout = {MAT_A: self.m, MAT_AT: self.n, MAT_P: self.n}[which]
+        x = _f64(x, nin, "x")
+        y = np.empty(nout)
+        self._chk(self.lib.cosmo_hip_spmv(self._h, which, _dp(y), _dp(x)))
+        return y
+
+    # ---- loop -------------------------------------------------------------------------------------------------
+    def set_iterates(self, x0=None, s0=None, mu0=None):
+        self._chk(self.lib.cosmo_hip_set_iterates(self._h, _dp(_f64(x0, self.n)), _dp(_f64(s0, self.m)), _dp(_f64(mu0, self.m))))
+
+    def admm_init(self):
+        self._chk(self.lib.cosmo_hip_admm_init(self._h))
+
+    def admm_iterate(self, n_iters):
+        self._chk(self.lib.cosmo_hip_admm_iterate(self._h, int(n_iters)))
+
+    def admm_iterate_checked(self, n_iters):
+        st = C.c_int32(0)
+        self._chk(self.lib.cosmo_hip_admm_iterate_checked(self._h, int(n_iters), C.byref(st)))
+        return st.value
+
+    def residuals(self):
+        out = np.empty(5)
+        self._chk(self.lib.cosmo_hip_residuals(self._h, _dp(out)))
+        return out
+
+    def optimize(self):
+        r = ResultStruct()
+        self._chk(self.lib.cosmo_hip_optimize(self._h, C.byref(r)))
+        return r
+
+    def get_iterates(self):
+        N = self.n + self.m
+        w = np.empty(N); wp = np.empty(N); s = np.empty(self.m); mu = np.empty(self.m)
+        self._chk(self.lib.cosmo_hip_get_iterates(self._h, _dp(w), _dp(wp), _dp(s), _dp(mu)))
+        return w, wp, s, mu
+
+    def get_kkt_solution(self):
+        sol = np.empty(self.n + self.m)
+        self._chk(self.lib.cosmo_hip_get_kkt_solution(self._h, _dp(sol)))
+        return sol
+
+    def get_stats(self):
+        out = np.zeros(8, dtype=np.int64)
+        self._chk(self.lib.cosmo_hip_get_stats(self._h, out.ctypes.data_as(_PI64)))
+        keys = ["admm_iters", "kkt_solves", "kkt_iters_total", "kkt_budget_stalls", "spmv_A", "spmv_AT", "spmv_P", "rho_updates"]
+        return dict(zip(keys, out.tolist()))
+
+    # ---- measurement -------------------------------------------------------------------------------------------
+    def time_spmv(self, which, reps=50):
+        t = C.c_double(0); by = C.c_double(0)
+        self._chk(self.lib.cosmo_hip_time_spmv(self._h, which, reps, C.byref(t), C.byref(by)))
+        return t.value, by.value
+
+    def set_profiling(self, on):
+        self._chk(self.lib.cosmo_hip_set_profiling(self._h, int(on)))
+
+    def get_kernel_times(self):
+        sec = np.zeros(NUM_KERNEL_CLASSES); cnt = np.zeros(NUM_KERNEL_CLASSES, dtype=np.int64)
+        self._chk(self.lib.cosmo_hip_get_kernel_times(self._h, _dp(sec), cnt.ctypes.data_as(_PI64)))
+        out = {}
+        for k in range(NUM_KERNEL_CLASSES):
+            if cnt[k]:
+                out[self.lib.cosmo_hip_kernel_class_name(k).decode()] = (float(sec[k]), int(cnt[k]))
+        return out

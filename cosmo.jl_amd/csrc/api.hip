@@ -1,0 +1,890 @@
+// api.hip -- C-ABI entry points of libcosmo_hip (include/cosmo_hip.h), handle lifecycle, host<->device staging of the
+// problem (Julia CSC -> device CSR), and the speculative, device-controlled enqueue of the ADMM loop.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <algorithm>
+#include <chrono>
+#include "internal.h"
+#include "device_utils.h"
+
+// launchers defined in kernels.hip
+int32_t launch_project_simple_inplace(cosmo_hip_handle* h, double* s);
+int32_t launch_z(cosmo_hip_handle* h, int guard);
+int32_t launch_soc(cosmo_hip_handle* h, double* s, int guard);
+int32_t launch_set_w(cosmo_hip_handle* h, const double* x0, const double* s0, const double* mu0);
+int32_t launch_recover_mu(cosmo_hip_handle* h);
+int32_t launch_rho_from_classes(cosmo_hip_handle* h, double rho0);
+int32_t enqueue_cg_iterations(cosmo_hip_handle* h, int guard, int k_begin, int count);
+int32_t enqueue_cg_start(cosmo_hip_handle* h, int guard, double tol_k);
+int32_t enqueue_rhs(cosmo_hip_handle* h, int guard);
+int32_t enqueue_y2_only(cosmo_hip_handle* h);
+int32_t enqueue_tail(cosmo_hip_handle* h, int loop_mode);
+int32_t enqueue_count_solve(cosmo_hip_handle* h);
+int32_t enqueue_clear_stall(cosmo_hip_handle* h);
+int32_t enqueue_check(cosmo_hip_handle* h, int guard, int mode);
+// minres.hip
+int32_t minres_enqueue_solve(cosmo_hip_handle* h, int guard, bool from_loop);
+int32_t minres_alloc(cosmo_hip_handle* h);
+
+// ---------------------------------------------------------------------------------------------------------------------
+int32_t cosmo_fail(cosmo_hip_handle* h, int32_t code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf;
+  return code;
+}
+
+template <class T>
+static int32_t dalloc(cosmo_hip_handle* h, T** p, size_t count) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (count == 0) count = 1;
+  HIPCHK(h, hipMalloc((void**)p, count * sizeof(T)));
+  HIPCHK(h, hipMemsetAsync(*p, 0, count * sizeof(T), h->stream));
+  return COSMO_HIP_OK;
+}
+template <class T>
+static void dfree(T** p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
+
+template <class T>
+static int32_t h2d(cosmo_hip_handle* h, T* dst, const T* src, size_t count) {
+  if (count == 0) return COSMO_HIP_OK;
+  HIPCHK(h, hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));  // host buffers are never retained after return
+  return COSMO_HIP_OK;
+}
+template <class T>
+static int32_t d2h(cosmo_hip_handle* h, T* dst, const T* src, size_t count) {
+  if (count == 0) return COSMO_HIP_OK;
+  HIPCHK(h, hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return COSMO_HIP_OK;
+}
+
+// ---- profiling with HIP events on the handle's stream ----------------------------------------------------------------
+void prof_begin(cosmo_hip_handle* h, int kc) {
+  if (!h->profiling) return;
+  if (h->ev_used + 2 > h->ev_pool.size()) {
+    size_t old = h->ev_pool.size();
+    h->ev_pool.resize(old + 1024);
+    for (size_t i = old; i < h->ev_pool.size(); ++i) (void)hipEventCreate(&h->ev_pool[i]);
+  }
+  (void)hipEventRecord(h->ev_pool[h->ev_used], h->stream);
+  h->ev_open.push_back(std::make_pair(kc, (int)h->ev_used));
+  h->ev_used += 2;
+}
+void prof_end(cosmo_hip_handle* h) {
+  if (!h->profiling) return;
+  const int i = h->ev_open.back().second;
+  (void)hipEventRecord(h->ev_pool[i + 1], h->stream);
+}
+int32_t prof_collect(cosmo_hip_handle* h) {
+  if (!h->profiling) return COSMO_HIP_OK;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (auto& pr : h->ev_open) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->ev_pool[pr.second], h->ev_pool[pr.second + 1]) == hipSuccess) {
+      h->kc_seconds[pr.first] += (double)ms * 1e-3;
+      h->kc_launches[pr.first] += 1;
+    }
+  }
+  h->ev_open.clear();
+  h->ev_used = 0;
+  return COSMO_HIP_OK;
+}
+
+// ---- CSR staging -----------------------------------------------------------------------------------------------------
+void free_csr(CsrDev& D) {
+  dfree(&D.rowptr); dfree(&D.col); dfree(&D.val); dfree(&D.split); dfree(&D.rb);
+  D = CsrDev();
+}
+
+// Greedy CSR-stream schedule: consecutive rows whose nonzeros fit the LDS tile; a longer row gets its own block.
+static void build_row_blocks(const std::vector<int>& rowptr, int nrows, std::vector<int>& rb) {
+  rb.clear();
+  rb.push_back(0);
+  const int ROWS_MAX = 4 * COSMO_BS;
+  int r = 0;
+  while (r < nrows) {
+    int r1 = r;
+    long long cnt = 0;
+    while (r1 < nrows) {
+      const long long rn = (long long)rowptr[r1 + 1] - rowptr[r1];
+      if (r1 > r && (cnt + rn > COSMO_NNZ_PER_BLOCK || r1 - r >= ROWS_MAX)) break;
+      cnt += rn;
+      ++r1;
+      if (cnt > COSMO_NNZ_PER_BLOCK) break;  // single long row
+    }
+    rb.push_back(r1);
+    r = r1;
+  }
+}
+
+int32_t upload_csr(cosmo_hip_handle* h, const HostCsr& M, CsrDev& D, int split_col) {
+  free_csr(D);
+  D.nrows = M.nrows; D.ncols = M.ncols; D.nnz = (long long)M.val.size();
+  D.split_col = split_col;
+  std::vector<int> rb;
+  build_row_blocks(M.rowptr, M.nrows, rb);
+  D.nb = (int)rb.size() - 1;
+  D.grid = std::max(1, std::min(D.nb, COSMO_MAX_PARTIALS));
+  CHK(dalloc(h, &D.rowptr, (size_t)M.nrows + 1));
+  CHK(dalloc(h, &D.col, M.col.size()));
+  CHK(dalloc(h, &D.val, M.val.size()));
+  CHK(dalloc(h, &D.rb, rb.size()));
+  CHK(h2d(h, D.rowptr, M.rowptr.data(), M.rowptr.size()));
+  CHK(h2d(h, D.col, M.col.data(), M.col.size()));
+  CHK(h2d(h, D.val, M.val.data(), M.val.size()));
+  CHK(h2d(h, D.rb, rb.data(), rb.size()));
+  if (!M.split.empty()) {
+    CHK(dalloc(h, &D.split, M.split.size()));
+    CHK(h2d(h, D.split, M.split.data(), M.split.size()));
+  }
+  return COSMO_HIP_OK;
+}
+
+// Julia CSC (1-based Int64) of an (nr x nc) matrix -> CSR of the TRANSPOSE (free: same arrays) and CSR of the matrix.
+static int32_t csc_to_csr_pair(cosmo_hip_handle* h, int64_t nr, int64_t nc, const int64_t* colptr, const int64_t* rowval,
+                               const double* nzval, HostCsr& Mt, HostCsr& M) {
+  const int64_t nnz = colptr[nc] - 1;
+  if (colptr[0] != 1) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "colptr must be 1-based (colptr[0] == %lld)", (long long)colptr[0]);
+  if (nnz < 0 || nnz >= (int64_t)2147483647) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "nnz out of int32 range");
+  Mt.nrows = (int)nc; Mt.ncols = (int)nr;
+  Mt.rowptr.resize(nc + 1); Mt.col.resize(nnz); Mt.val.resize(nnz);
+  for (int64_t j = 0; j <= nc; ++j) {
+    if (j > 0 && colptr[j] < colptr[j - 1]) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "colptr not monotone");
+    Mt.rowptr[j] = (int)(colptr[j] - 1);
+  }
+  std::vector<int> cnt(nr + 1, 0);
+  for (int64_t k = 0; k < nnz; ++k) {
+    const int64_t i = rowval[k] - 1;
+    if (i < 0 || i >= nr) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "row index out of range");
+    Mt.col[k] = (int)i; Mt.val[k] = nzval[k];
+    cnt[i + 1]++;
+  }
+  M.nrows = (int)nr; M.ncols = (int)nc;
+  M.rowptr.assign(nr + 1, 0);
+  for (int64_t i = 0; i < nr; ++i) M.rowptr[i + 1] = M.rowptr[i] + cnt[i + 1];
+  M.col.resize(nnz); M.val.resize(nnz);
+  std::vector<int> pos(M.rowptr.begin(), M.rowptr.end() - 1);
+  for (int64_t j = 0; j < nc; ++j)
+    for (int64_t k = colptr[j] - 1; k < colptr[j + 1] - 1; ++k) {
+      const int i = (int)(rowval[k] - 1);
+      const int p = pos[i]++;
+      M.col[p] = (int)j; M.val[p] = nzval[k];
+    }
+  return COSMO_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int32_t cosmo_hip_version(void) { return 1000; }
+
+extern "C" void cosmo_hip_default_params(cosmo_hip_params* p) {
+  if (!p) return;
+  memset(p, 0, sizeof *p);
+  p->sigma = 1e-6; p->alpha = 1.6; p->rho = 0.1; p->eps_abs = 1e-5; p->eps_rel = 1e-5;
+  p->eps_prim_inf = 1e-4; p->eps_dual_inf = 1e-4; p->tol_constant = 1.0; p->tol_exponent = 1.5;
+  p->rho_min = 1e-6; p->rho_max = 1e6; p->rho_tol = 1e-4; p->rho_eq_over_rho_ineq = 1e3;
+  p->adaptive_rho_tolerance = 5.0; p->cosmo_infty_min_scaling = 1e20 * 1e-4; p->time_limit = 0.0;
+  p->max_iter = 5000; p->adaptive_rho_max_adaptions = INT64_MAX; p->kkt_kind = COSMO_HIP_KKT_CG;
+  p->check_termination = 25; p->check_infeasibility = 40; p->adaptive_rho = 1; p->adaptive_rho_interval = 40;
+  p->unscale_residuals = 1;
+}
+
+extern "C" int32_t cosmo_hip_create(cosmo_hip_handle** out, int32_t device_id) {
+  if (!out) return COSMO_HIP_ERR_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return COSMO_HIP_ERR_HIP;  // no GPU: fail loudly, no CPU path
+  if (device_id < 0 || device_id >= ndev) return COSMO_HIP_ERR_INVALID;
+  cosmo_hip_handle* h = new cosmo_hip_handle();
+  h->device = device_id;
+  cosmo_hip_default_params(&h->prm);
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { delete h; return COSMO_HIP_ERR_HIP; }
+  if (hipMalloc((void**)&h->ctl, sizeof(Ctl)) != hipSuccess || hipHostMalloc((void**)&h->ctl_host, sizeof(Ctl)) != hipSuccess ||
+      hipMalloc((void**)&h->partials, sizeof(double) * COSMO_NSLOTS_TOTAL * COSMO_MAX_PARTIALS) != hipSuccess) {
+    delete h; return COSMO_HIP_ERR_HIP;
+  }
+  (void)hipMemset(h->ctl, 0, sizeof(Ctl));
+  (void)hipMemset(h->partials, 0, sizeof(double) * COSMO_NSLOTS_TOTAL * COSMO_MAX_PARTIALS);
+  memset(h->ctl_host, 0, sizeof(Ctl));
+  (void)hipEventCreate(&h->ev_proj0);
+  (void)hipEventCreate(&h->ev_proj1);
+  *out = h;
+  return COSMO_HIP_OK;
+}
+
+static void free_vectors(cosmo_hip_handle* h) {
+  dfree(&h->q); dfree(&h->b); dfree(&h->rho); dfree(&h->Dinv); dfree(&h->Einv);
+  dfree(&h->w); dfree(&h->w_prev); dfree(&h->s); dfree(&h->mu); dfree(&h->s_tl);
+  dfree(&h->ls_x); dfree(&h->ls_s); dfree(&h->x_tl); dfree(&h->nu);
+  dfree(&h->rhs); dfree(&h->r); dfree(&h->u); dfree(&h->c); dfree(&h->tmp_m); dfree(&h->y2); dfree(&h->mr);
+  dfree(&h->io);
+}
+static void free_cones(cosmo_hip_handle* h) {
+  dfree(&h->meta); dfree(&h->box_l); dfree(&h->box_u); dfree(&h->rho_cls);
+  dfree(&h->soc_off); dfree(&h->soc_dim); dfree(&h->soc_branch);
+  psd_plan_destroy(h);
+  h->nsoc = 0;
+}
+
+extern "C" int32_t cosmo_hip_destroy(cosmo_hip_handle* h) {
+  if (!h) return COSMO_HIP_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  free_csr(h->A); free_csr(h->AT); free_csr(h->P); free_csr(h->PT);
+  free_vectors(h);
+  free_cones(h);
+  dfree(&h->partials);
+  if (h->ctl) { (void)hipFree(h->ctl); h->ctl = nullptr; }
+  if (h->ctl_host) { (void)hipHostFree(h->ctl_host); h->ctl_host = nullptr; }
+  for (auto& e : h->ev_pool) (void)hipEventDestroy(e);
+  h->ev_pool.clear();
+  if (h->ev_proj0) (void)hipEventDestroy(h->ev_proj0);
+  if (h->ev_proj1) (void)hipEventDestroy(h->ev_proj1);
+  if (h->stream) { (void)hipStreamDestroy(h->stream); h->stream = nullptr; }
+  delete h;
+  return COSMO_HIP_OK;
+}
+
+extern "C" const char* cosmo_hip_last_error(const cosmo_hip_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+#define ENTER(h)                                                   \
+  if (!(h)) return COSMO_HIP_ERR_INVALID;                          \
+  if (hipSetDevice((h)->device) != hipSuccess) return cosmo_fail((h), COSMO_HIP_ERR_HIP, "hipSetDevice failed");
+
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int32_t cosmo_hip_set_problem(cosmo_hip_handle* h, int64_t n, int64_t m, const int64_t* P_colptr,
+                                         const int64_t* P_rowval, const double* P_nzval, const int64_t* A_colptr,
+                                         const int64_t* A_rowval, const double* A_nzval, const double* q, const double* b) {
+  ENTER(h);
+  if (n < 0 || m < 0 || n + m >= 2147483647LL) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "n, m out of int32 range");
+  if (!P_colptr || !A_colptr || (n > 0 && !q) || (m > 0 && !b)) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "null pointer");
+  h->n = n; h->m = m;
+  HostCsr Pt, Pm, At, Am;
+  CHK(csc_to_csr_pair(h, n, n, P_colptr, P_rowval, P_nzval, Pt, Pm));
+  CHK(csc_to_csr_pair(h, m, n, A_colptr, A_rowval, A_nzval, At, Am));
+  // row-merged operator [P | A'] : row j = (row j of P, columns < n) ++ (row j of A', columns shifted by n)
+  HostCsr PT;
+  PT.nrows = (int)n; PT.ncols = (int)(n + m);
+  PT.rowptr.assign(n + 1, 0);
+  PT.split.assign(n, 0);
+  const size_t tot = Pm.val.size() + At.val.size();
+  if (tot >= 2147483647ULL) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "nnz(P)+nnz(A) out of int32 range");
+  PT.col.resize(tot); PT.val.resize(tot);
+  size_t p = 0;
+  for (int64_t j = 0; j < n; ++j) {
+    PT.rowptr[j] = (int)p;
+    for (int k = Pm.rowptr[j]; k < Pm.rowptr[j + 1]; ++k) { PT.col[p] = Pm.col[k]; PT.val[p] = Pm.val[k]; ++p; }
+    PT.split[j] = (int)p;
+    for (int k = At.rowptr[j]; k < At.rowptr[j + 1]; ++k) { PT.col[p] = At.col[k] + (int)n; PT.val[p] = At.val[k]; ++p; }
+  }
+  PT.rowptr[n] = (int)p;
+  CHK(upload_csr(h, Am, h->A, (int)n));
+  CHK(upload_csr(h, At, h->AT, (int)m));
+  CHK(upload_csr(h, Pm, h->P, (int)n));
+  CHK(upload_csr(h, PT, h->PT, (int)n));
+  free_vectors(h);
+  const size_t N = (size_t)(n + m);
+  CHK(dalloc(h, &h->q, (size_t)n)); CHK(dalloc(h, &h->b, (size_t)m)); CHK(dalloc(h, &h->rho, (size_t)m));
+  CHK(dalloc(h, &h->Dinv, (size_t)n)); CHK(dalloc(h, &h->Einv, (size_t)m));
+  CHK(dalloc(h, &h->w, N)); CHK(dalloc(h, &h->w_prev, N)); CHK(dalloc(h, &h->s, (size_t)m)); CHK(dalloc(h, &h->mu, (size_t)m));
+  CHK(dalloc(h, &h->s_tl, (size_t)m)); CHK(dalloc(h, &h->ls_x, (size_t)n)); CHK(dalloc(h, &h->ls_s, (size_t)m));
+  CHK(dalloc(h, &h->x_tl, (size_t)n)); CHK(dalloc(h, &h->nu, (size_t)m)); CHK(dalloc(h, &h->rhs, (size_t)n));
+  CHK(dalloc(h, &h->r, (size_t)n)); CHK(dalloc(h, &h->u, (size_t)n)); CHK(dalloc(h, &h->c, (size_t)n));
+  CHK(dalloc(h, &h->tmp_m, (size_t)m)); CHK(dalloc(h, &h->y2, (size_t)m)); CHK(dalloc(h, &h->io, N));
+  CHK(h2d(h, h->q, q, (size_t)n));
+  CHK(h2d(h, h->b, b, (size_t)m));
+  h->has_scaling = false; h->cinv = 1.0;
+  h->have_problem = true; h->have_cones = false; h->have_iterates = false;
+  HIPCHK(h, hipMemsetAsync(h->ctl, 0, sizeof(Ctl), h->stream));
+  h->host_iter = h->host_solves = 0; h->stalls = 0; h->budget = 12;
+  return COSMO_HIP_OK;
+}
+
+// classify_constraints! (setup.jl:75-85, convexset.jl:62-69, 831-842) + apply_constraint_rho_scaling! classes
+static int32_t classify_rows(cosmo_hip_handle* h, const std::vector<double>& bhost) {
+  const ConeTable& C = h->cones;
+  h->rho_cls_host.assign((size_t)h->m, 0);
+  const double big = h->prm.cosmo_infty_min_scaling;
+  size_t boxp = 0;
+  for (size_t k = 0; k < C.type.size(); ++k) {
+    const int64_t o = C.off[k], d = C.dim[k];
+    if (C.type[k] == COSMO_HIP_ZERO) {
+      for (int64_t i = 0; i < d; ++i) h->rho_cls_host[o + i] = 1;
+    } else if (C.type[k] == COSMO_HIP_NONNEG) {
+      for (int64_t i = 0; i < d; ++i) if (bhost[o + i] > big) h->rho_cls_host[o + i] = 2;
+    } else if (C.type[k] == COSMO_HIP_BOX) {
+      for (int64_t i = 0; i < d; ++i) {
+        const double l = C.box_l[boxp + i], u = C.box_u[boxp + i];
+        int c = 0;
+        if (l < -big && u > big) c = 2;
+        else if ((u - l) < h->prm.rho_tol) c = 1;
+        h->rho_cls_host[o + i] = c;
+      }
+      boxp += (size_t)d;
+    }
+  }
+  CHK(dalloc(h, &h->rho_cls, (size_t)h->m));
+  CHK(h2d(h, h->rho_cls, h->rho_cls_host.data(), (size_t)h->m));
+  return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_set_cones(cosmo_hip_handle* h, int64_t ncones, const int32_t* type, const int64_t* dim,
+                                       const double* box_l, const double* box_u) {
+  ENTER(h);
+  if (!h->have_problem) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_problem must be called before set_cones");
+  if (ncones < 0 || (ncones > 0 && (!type || !dim))) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "bad cone table");
+  free_cones(h);
+  ConeTable& C = h->cones;
+  C = ConeTable();
+  int64_t off = 0, nbox = 0;
+  for (int64_t k = 0; k < ncones; ++k) {
+    if (dim[k] < 0) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "negative cone dimension");
+    if (type[k] < COSMO_HIP_ZERO || type[k] > COSMO_HIP_PSD_TRIANGLE)
+      return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "cone type %d is outside the hot-path scope", (int)type[k]);
+    if (type[k] == COSMO_HIP_PSD_SQUARE) {
+      const int64_t r = (int64_t)llround(sqrt((double)dim[k]));
+      if (r * r != dim[k]) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "PsdCone dimension must be a square");
+    }
+    C.type.push_back(type[k]); C.dim.push_back(dim[k]); C.off.push_back(off);
+    off += dim[k];
+    if (type[k] == COSMO_HIP_BOX) nbox += dim[k];
+  }
+  if (off != h->m) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "cone dimensions sum to %lld but m = %lld", (long long)off, (long long)h->m);
+  if (nbox > 0 && (!box_l || !box_u)) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "Box cones need bounds");
+  C.nbox_rows = nbox;
+  if (nbox > 0) { C.box_l.assign(box_l, box_l + nbox); C.box_u.assign(box_u, box_u + nbox); }
+  // per-row projection metadata + SOC table
+  std::vector<uint32_t> meta((size_t)h->m, 0u);
+  std::vector<int> soc_off, soc_dim;
+  int64_t boxp = 0;
+  for (int64_t k = 0; k < ncones; ++k) {
+    const int64_t o = C.off[k], d = C.dim[k];
+    switch (C.type[k]) {
+      case COSMO_HIP_ZERO: for (int64_t i = 0; i < d; ++i) meta[o + i] = 1u; break;
+      case COSMO_HIP_NONNEG: for (int64_t i = 0; i < d; ++i) meta[o + i] = 2u; break;
+      case COSMO_HIP_BOX:
+        if (nbox >= (1LL << 30)) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "too many Box rows");
+        for (int64_t i = 0; i < d; ++i) meta[o + i] = 3u | ((uint32_t)(boxp + i) << 2);
+        boxp += d;
+        break;
+      case COSMO_HIP_SOC:
+        soc_off.push_back((int)o); soc_dim.push_back((int)d); h->soc_cone_index.push_back((int)k);
+        break;
+      case COSMO_HIP_PSD_SQUARE:
+      case COSMO_HIP_PSD_TRIANGLE:
+        if (d == 1) for (int64_t i = 0; i < d; ++i) meta[o + i] = 2u;  // 1x1: max(x,0) (convexset.jl:307-308,404-405)
+        break;
+    }
+  }
+  CHK(dalloc(h, &h->meta, (size_t)h->m));
+  CHK(h2d(h, h->meta, meta.data(), (size_t)h->m));
+  CHK(dalloc(h, &h->box_l, (size_t)nbox)); CHK(dalloc(h, &h->box_u, (size_t)nbox));
+  if (nbox > 0) { CHK(h2d(h, h->box_l, C.box_l.data(), (size_t)nbox)); CHK(h2d(h, h->box_u, C.box_u.data(), (size_t)nbox)); }
+  h->nsoc = (int)soc_off.size();
+  if (h->nsoc == 0) h->soc_cone_index.clear();
+  CHK(dalloc(h, &h->soc_off, soc_off.size())); CHK(dalloc(h, &h->soc_dim, soc_dim.size())); CHK(dalloc(h, &h->soc_branch, soc_off.size()));
+  if (h->nsoc) { CHK(h2d(h, h->soc_off, soc_off.data(), soc_off.size())); CHK(h2d(h, h->soc_dim, soc_dim.data(), soc_dim.size())); }
+  CHK(psd_plan_create(h));
+  std::vector<double> bhost((size_t)h->m);
+  CHK(d2h(h, bhost.data(), h->b, (size_t)h->m));
+  CHK(classify_rows(h, bhost));
+  h->have_cones = true;
+  return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_params* p, const double* rho_vec) {
+  ENTER(h);
+  if (!p) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "null params");
+  if (!h->have_cones) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_cones must be called before set_params");
+  if (p->kkt_kind < COSMO_HIP_KKT_CG || p->kkt_kind > COSMO_HIP_KKT_MINRES) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "bad kkt_kind");
+  if (p->check_termination <= 0) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "check_termination must be > 0");
+  if (p->adaptive_rho && p->adaptive_rho_interval == 0)
+    return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "adaptive_rho_interval == 0 (wall-clock rule, solver.jl:244-256) is not supported");
+  const bool reclass = (p->cosmo_infty_min_scaling != h->prm.cosmo_infty_min_scaling) || (p->rho_tol != h->prm.rho_tol);
+  h->prm = *p;
+  if (reclass) {
+    std::vector<double> bhost((size_t)h->m);
+    CHK(d2h(h, bhost.data(), h->b, (size_t)h->m));
+    CHK(classify_rows(h, bhost));
+  }
+  if (rho_vec) CHK(h2d(h, h->rho, rho_vec, (size_t)h->m));
+  else CHK(launch_rho_from_classes(h, p->rho));
+  // ws.rho / ws.rho_updates (set_rho_vec!, parameters.jl:3-13)
+  CHK(d2h(h, h->ctl_host, h->ctl, 1));
+  h->ctl_host->rho = p->rho;
+  h->ctl_host->n_rho_updates = 1;
+  h->ctl_host->rho_updates[0] = p->rho;
+  h->ctl_host->solves = 0;
+  h->ctl_host->kkt_iters_total = 0;
+  CHK(h2d(h, h->ctl, h->ctl_host, 1));
+  h->host_solves = 0;
+  if (p->kkt_kind != COSMO_HIP_KKT_CG) CHK(minres_alloc(h));
+  // the Krylov warm start (previous_solution) starts at zero (kktsolver_indirect.jl:32)
+  HIPCHK(h, hipMemsetAsync(h->x_tl, 0, sizeof(double) * (size_t)std::max<long long>(h->n, 1), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->nu, 0, sizeof(double) * (size_t)std::max<long long>(h->m, 1), h->stream));
+  h->have_params = true;
+  return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_update_rho(cosmo_hip_handle* h, const double* rho_vec) {
+  ENTER(h);
+  if (!h->have_params || !rho_vec) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "update_rho: not set up");
+  return h2d(h, h->rho, rho_vec, (size_t)h->m);
+}
+
+extern "C" int32_t cosmo_hip_set_scaling(cosmo_hip_handle* h, const double* Dinv, const double* Einv, double cinv) {
+  ENTER(h);
+  if (!h->have_problem) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_problem first");
+  std::vector<double> ones;
+  if (!Dinv) { ones.assign((size_t)h->n, 1.0); CHK(h2d(h, h->Dinv, ones.data(), (size_t)h->n)); }
+  else CHK(h2d(h, h->Dinv, Dinv, (size_t)h->n));
+  if (!Einv) { ones.assign((size_t)h->m, 1.0); CHK(h2d(h, h->Einv, ones.data(), (size_t)h->m)); }
+  else CHK(h2d(h, h->Einv, Einv, (size_t)h->m));
+  h->cinv = cinv;
+  h->has_scaling = true;
+  return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_update_qb(cosmo_hip_handle* h, const double* q, const double* b) {
+  ENTER(h);
+  if (!h->have_problem) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_problem first");
+  if (q) CHK(h2d(h, h->q, q, (size_t)h->n));
+  if (b) {
+    CHK(h2d(h, h->b, b, (size_t)h->m));
+    if (h->have_cones) {  // setup! re-classifies on every optimize! (setup.jl:36-37)
+      std::vector<double> bhost(b, b + h->m);
+      CHK(classify_rows(h, bhost));
+    }
+  }
+  return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_get_rho_classes(cosmo_hip_handle* h, int32_t* cls) {
+  ENTER(h);
+  if (!h->have_cones || !cls) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "get_rho_classes: not set up");
+  return d2h(h, cls, h->rho_cls, (size_t)h->m);
+}
+extern "C" int32_t cosmo_hip_get_rho_vec(cosmo_hip_handle* h, double* rho_vec) {
+  ENTER(h);
+  if (!h->have_params || !rho_vec) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "get_rho_vec: not set up");
+  return d2h(h, rho_vec, h->rho, (size_t)h->m);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+int32_t sync_ctl(cosmo_hip_handle* h) {
+  HIPCHK(h, hipMemcpyAsync(h->ctl_host, h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  CHK(prof_collect(h));
+  if (h->ctl_host->error) return cosmo_fail(h, h->ctl_host->error, "device raised error %d", h->ctl_host->error);
+  return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_spmv(cosmo_hip_handle* h, int32_t which, double* y, const double* x) {
+  ENTER(h);
+  if (!h->have_problem || !x || !y) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "spmv: not set up");
+  const CsrDev* M = which == COSMO_HIP_MAT_A ? &h->A : which == COSMO_HIP_MAT_AT ? &h->AT : which == COSMO_HIP_MAT_P ? &h->P : nullptr;
+  if (!M) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "spmv: bad matrix id");
+  // io holds n+m doubles: input first, output after it
+  double* dx = h->io;
+  double* dy = h->io + M->ncols;
+  if ((long long)M->ncols + M->nrows > h->n + h->m) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "spmv: staging too small");
+  CHK(h2d(h, dx, x, (size_t)M->ncols));
+  CHK(launch_spmv_plain(h, *M, dx, dy));
+  CHK(d2h(h, y, dy, (size_t)M->nrows));
+  h->spmv_calls[which] += 1;
+  return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_project(cosmo_hip_handle* h, double* s, int64_t* psd_rank_out, int32_t* soc_branch_out) {
+  ENTER(h);
+  if (!h->have_cones || (!s && h->m > 0)) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "project: not set up");
+  CHK(h2d(h, h->io, s, (size_t)h->m));
+  CHK(launch_project_simple_inplace(h, h->io));
+  CHK(launch_soc(h, h->io, 0));
+  CHK(psd_enqueue_project(h, h->io, false));
+  CHK(d2h(h, s, h->io, (size_t)h->m));
+  const size_t nc = h->cones.type.size();
+  if (soc_branch_out) {
+    for (size_t k = 0; k < nc; ++k) soc_branch_out[k] = -1;
+    if (h->nsoc) {
+      std::vector<int> br((size_t)h->nsoc);
+      CHK(d2h(h, br.data(), h->soc_branch, (size_t)h->nsoc));
+      for (int i = 0; i < h->nsoc; ++i) soc_branch_out[h->soc_cone_index[i]] = br[i];
+    }
+  }
+  if (psd_rank_out) {
+    for (size_t k = 0; k < nc; ++k) psd_rank_out[k] = -1;
+    CHK(psd_get_ranks(h, psd_rank_out));
+    // 1x1 PSD cones are handled by the simple kernel
+    for (size_t k = 0; k < nc; ++k)
+      if ((h->cones.type[k] == COSMO_HIP_PSD_SQUARE || h->cones.type[k] == COSMO_HIP_PSD_TRIANGLE) && h->cones.dim[k] == 1)
+        psd_rank_out[k] = s[h->cones.off[k]] > 0.0 ? 1 : 0;
+  }
+  return COSMO_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+static double tol_for_solve(const cosmo_hip_handle* h, long long k) {
+  return h->prm.tol_constant / pow((double)k, h->prm.tol_exponent);  // get_tolerance, kktsolver_indirect.jl:168-170
+}
+
+static void adapt_budget(cosmo_hip_handle* h) {
+  const int kmax = h->ctl_host->cg_k_max;
+  int nb = kmax + 2;
+  if (nb < 3) nb = 3;
+  if (nb > 4096) nb = 4096;
+  h->budget = nb;
+}
+
+__global__ void k_ctl_reset_kmax(Ctl* ctl) { ctl->cg_k_max = 0; }
+
+extern "C" int32_t cosmo_hip_kkt_solve(cosmo_hip_handle* h, double* lhs, const double* rhs, int64_t* kkt_iters_out) {
+  ENTER(h);
+  if (!h->have_params || !lhs || !rhs) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "kkt_solve: not set up");
+  CHK(h2d(h, h->ls_x, rhs, (size_t)h->n));
+  CHK(h2d(h, h->ls_s, rhs + h->n, (size_t)h->m));
+  if (h->prm.kkt_kind == COSMO_HIP_KKT_CG) {
+    CHK(enqueue_y2_only(h));
+    CHK(enqueue_cg_start(h, 0, tol_for_solve(h, h->host_solves + 1)));
+    int k = 0, chunk = std::max(h->budget, 4);
+    for (;;) {
+      CHK(enqueue_cg_iterations(h, 0, k, chunk));
+      CHK(sync_ctl(h));
+      if (h->ctl_host->cg_done) break;
+      k += chunk;
+      chunk = std::min(chunk * 2, 1024);
+    }
+    CHK(enqueue_tail(h, 0));
+    CHK(enqueue_count_solve(h));
+  } else {
+    CHK(minres_enqueue_solve(h, 0, false));
+  }
+  h->host_solves += 1;
+  CHK(sync_ctl(h));
+  if (kkt_iters_out) *kkt_iters_out = h->ctl_host->cg_k;
+  CHK(d2h(h, lhs, h->x_tl, (size_t)h->n));
+  CHK(d2h(h, lhs + h->n, h->nu, (size_t)h->m));
+  return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_set_iterates(cosmo_hip_handle* h, const double* x0, const double* s0, const double* mu0) {
+  ENTER(h);
+  if (!h->have_params) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_iterates: set_params first");
+  const long long n = h->n, m = h->m;
+  // stage the three vectors in scratch buffers that the init step overwrites anyway
+  const double *dx = nullptr, *ds = nullptr, *dm = nullptr;
+  if (x0) { CHK(h2d(h, h->ls_x, x0, (size_t)n)); dx = h->ls_x; }
+  if (s0) { CHK(h2d(h, h->ls_s, s0, (size_t)m)); ds = h->ls_s; }
+  if (mu0) { CHK(h2d(h, h->tmp_m, mu0, (size_t)m)); dm = h->tmp_m; }
+  CHK(launch_set_w(h, dx, ds, dm));
+  HIPCHK(h, hipMemcpyAsync(h->w_prev, h->w, sizeof(double) * (size_t)(n + m), hipMemcpyDeviceToDevice, h->stream));
+  // reset the loop counters (optimize! starts at iter = 0; the KKT solver's counters persist, setup.jl:54-61)
+  CHK(d2h(h, h->ctl_host, h->ctl, 1));
+  Ctl* c = h->ctl_host;
+  c->halt = 0; c->status = 0; c->stalled = 0; c->error = 0; c->cg_done = 0; c->cg_k = 0; c->cg_k_max = 0; c->rho_changed = 0;
+  c->iter = 0;
+  c->r_prim = INFINITY; c->r_dual = INFINITY; c->max_norm_prim = 0; c->max_norm_dual = 0; c->cost = INFINITY;
+  CHK(h2d(h, h->ctl, h->ctl_host, 1));
+  h->host_iter = 0;
+  h->have_iterates = true;
+  return COSMO_HIP_OK;
+}
+
+static int32_t enqueue_solve_in_loop(cosmo_hip_handle* h) {
+  CHK(enqueue_rhs(h, 1));
+  if (h->prm.kkt_kind == COSMO_HIP_KKT_CG) {
+    CHK(enqueue_cg_start(h, 1, tol_for_solve(h, h->host_solves + 1)));
+    if (h->exact_launches) {
+      // measurement mode: one Krylov iteration per host round trip, so that every launch does full work
+      CHK(enqueue_cg_iterations(h, 1, 0, 0));
+      for (int k = 0;; ++k) {
+        CHK(sync_ctl(h));
+        if (h->ctl_host->cg_done || h->ctl_host->halt) break;
+        CHK(enqueue_cg_iterations(h, 1, k, 1));
+      }
+    } else {
+      CHK(enqueue_cg_iterations(h, 1, 0, h->budget));
+    }
+    CHK(enqueue_tail(h, 1));
+  } else {
+    CHK(minres_enqueue_solve(h, 1, true));
+  }
+  h->host_solves += 1;
+  return COSMO_HIP_OK;
+}
+
+// One loop body (solver.jl:151-155) for iteration number `it` (1-based), enqueued without synchronisation.
+static int32_t enqueue_iteration(cosmo_hip_handle* h, long long it) {
+  const bool time_proj = h->profiling;
+  (void)time_proj;
+  CHK(launch_z(h, 1));
+  CHK(launch_soc(h, h->s, 1));
+  CHK(psd_enqueue_project(h, h->s, true));
+  if (h->prm.adaptive_rho && h->prm.adaptive_rho_interval > 0 && (it % h->prm.adaptive_rho_interval) == 0)
+    CHK(enqueue_check(h, 1, 2));
+  CHK(enqueue_solve_in_loop(h));
+  h->host_iter = it;
+  return COSMO_HIP_OK;
+}
+
+// If the Krylov budget of some iteration ran out, finish that iteration synchronously and re-sync the host counters.
+static int32_t resolve_stall(cosmo_hip_handle* h) {
+  while (h->ctl_host->stalled) {
+    h->stalls += 1;
+    int extra = std::max(2 * h->budget, 8);
+    if (h->prm.kkt_kind == COSMO_HIP_KKT_CG) {
+      CHK(enqueue_clear_stall(h));
+      CHK(enqueue_cg_iterations(h, 1, h->ctl_host->cg_k, extra));
+      CHK(enqueue_tail(h, 1));
+    } else {
+      return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "internal: MINRES path does not use budgets");
+    }
+    CHK(sync_ctl(h));
+    h->budget = std::min(4096, std::max(h->budget, h->ctl_host->cg_k + 2));
+  }
+  h->host_iter = h->ctl_host->iter;
+  h->host_solves = h->ctl_host->solves;
+  return COSMO_HIP_OK;
+}
+
+// Enqueue iterations until the device has completed `target` iterations (or decided a status); optionally append
+// a check (mode as enqueue_check) after the last one.  One host synchronisation per call in the common case.
+static int32_t run_until(cosmo_hip_handle* h, long long target, int check_mode) {
+  for (;;) {
+    for (long long it = h->host_iter + 1; it <= target; ++it) CHK(enqueue_iteration(h, it));
+    if (check_mode >= 0) CHK(enqueue_check(h, 1, check_mode));
+    CHK(sync_ctl(h));
+    if (h->ctl_host->stalled) {
+      CHK(resolve_stall(h));
+      continue;  // re-enqueue what the stall skipped (later iterations and the check were no-ops)
+    }
+    adapt_budget(h);
+    hipLaunchKernelGGL(k_ctl_reset_kmax, dim3(1), dim3(1), 0, h->stream, h->ctl);
+    return COSMO_HIP_OK;
+  }
+}
+
+static int32_t admm_init_enqueue(cosmo_hip_handle* h) {
+  // admm_x! ; admm_w! (solver.jl:137-138).  The device iteration counter must not advance: compensate afterwards.
+  CHK(enqueue_solve_in_loop(h));
+  CHK(sync_ctl(h));
+  if (h->ctl_host->stalled) {
+    long long keep_iter = 0;
+    CHK(resolve_stall(h));
+    (void)keep_iter;
+  }
+  // undo the iteration count of the init step
+  CHK(d2h(h, h->ctl_host, h->ctl, 1));
+  h->ctl_host->iter = 0;
+  h->ctl_host->cg_k_max = std::max(h->ctl_host->cg_k_max, h->ctl_host->cg_k);
+  CHK(h2d(h, h->ctl, h->ctl_host, 1));
+  adapt_budget(h);
+  h->host_iter = 0;
+  h->host_solves = h->ctl_host->solves;
+  return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_admm_init(cosmo_hip_handle* h) {
+  ENTER(h);
+  if (!h->have_iterates) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "admm_init: set_iterates first");
+  return admm_init_enqueue(h);
+}
+
+extern "C" int32_t cosmo_hip_admm_iterate(cosmo_hip_handle* h, int64_t n_iters) {
+  ENTER(h);
+  if (!h->have_iterates) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "admm_iterate: set_iterates first");
+  const long long target = h->host_iter + n_iters;
+  const long long CHUNK = 50;
+  while (h->host_iter < target) {
+    const long long t = std::min(target, h->host_iter + CHUNK);
+    CHK(run_until(h, t, -1));
+    if (h->ctl_host->status != 0) break;
+  }
+  return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_admm_iterate_checked(cosmo_hip_handle* h, int64_t n_iters, int32_t* status_out) {
+  ENTER(h);
+  if (!h->have_iterates) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "admm_iterate_checked: set_iterates first");
+  const long long target = h->host_iter + n_iters;
+  const long long ct = h->prm.check_termination;
+  if (status_out) *status_out = COSMO_HIP_UNDETERMINED;
+  while (h->host_iter < target) {
+    const long long it = h->host_iter;
+    long long next = (it == 0) ? 1 : ((it / ct) + 1) * ct;
+    bool check = true;
+    if (next > target) { next = target; check = (next % ct == 0) || next == 1; }
+    CHK(run_until(h, next, check ? 1 : -1));
+    if (h->ctl_host->status != 0) { if (status_out) *status_out = h->ctl_host->status; break; }
+  }
+  return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_residuals(cosmo_hip_handle* h, double out[5]) {
+  ENTER(h);
+  if (!h->have_iterates || !out) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "residuals: set_iterates first");
+  CHK(enqueue_check(h, 0, 3));
+  CHK(sync_ctl(h));
+  const Ctl* c = h->ctl_host;
+  out[0] = c->r_prim; out[1] = c->r_dual; out[2] = c->max_norm_prim; out[3] = c->max_norm_dual; out[4] = c->cost;
+  return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_optimize(cosmo_hip_handle* h, cosmo_hip_result* res) {
+  ENTER(h);
+  if (!h->have_iterates || !res) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "optimize: set_iterates first");
+  memset(res, 0, sizeof *res);
+  const cosmo_hip_params& p = h->prm;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const auto t0 = std::chrono::steady_clock::now();
+  const long long kkt0 = h->ctl_host->kkt_iters_total;
+  (void)kkt0;
+  CHK(admm_init_enqueue(h));
+  const long long base_iters = h->ctl_host->kkt_iters_total;
+  (void)base_iters;
+  int status = COSMO_HIP_UNDETERMINED;
+  long long it = 0;
+  while (it < p.max_iter) {
+    long long next = (it == 0) ? 1 : ((it / p.check_termination) + 1) * (long long)p.check_termination;
+    bool check = true;
+    if (next > p.max_iter) { next = p.max_iter; check = (next % p.check_termination == 0) || next == 1; }
+    CHK(run_until(h, next, check ? 1 : -1));
+    it = h->ctl_host->iter;
+    if (h->ctl_host->status != 0) { status = h->ctl_host->status; break; }
+    it = next;
+    if (p.time_limit != 0.0) {
+      const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (el > p.time_limit) {  // solver.jl:351-354
+        CHK(enqueue_check(h, 0, 0));
+        CHK(sync_ctl(h));
+        status = COSMO_HIP_TIME_LIMIT_REACHED;
+        break;
+      }
+    }
+  }
+  if (status == COSMO_HIP_UNDETERMINED && it >= p.max_iter) {  // solver.jl:173-176
+    CHK(enqueue_check(h, 0, 0));
+    CHK(sync_ctl(h));
+    status = COSMO_HIP_MAX_ITER_REACHED;
+  }
+  CHK(launch_recover_mu(h));  // solver.jl:167
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const auto t1 = std::chrono::steady_clock::now();
+  const Ctl* c = h->ctl_host;
+  res->status = status;
+  res->iter = c->iter;
+  res->kkt_iters_total = c->kkt_iters_total;
+  res->kkt_solves = c->solves;
+  res->cost = c->cost;
+  res->r_prim = c->r_prim; res->r_dual = c->r_dual; res->max_norm_prim = c->max_norm_prim; res->max_norm_dual = c->max_norm_dual;
+  res->rho = c->rho;
+  res->n_rho_updates = c->n_rho_updates;
+  for (int i = 0; i < COSMO_HIP_MAX_RHO_UPDATES && i < c->n_rho_updates; ++i) res->rho_updates[i] = c->rho_updates[i];
+  res->iter_time = std::chrono::duration<double>(t1 - t0).count();
+  res->proj_time = h->kc_seconds[KC_Z] + h->kc_seconds[KC_SOC] + h->kc_seconds[KC_PSD];
+  return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_get_iterates(cosmo_hip_handle* h, double* w, double* w_prev, double* s, double* mu) {
+  ENTER(h);
+  if (!h->have_iterates) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "get_iterates: set_iterates first");
+  const size_t N = (size_t)(h->n + h->m);
+  if (mu) { CHK(launch_recover_mu(h)); CHK(d2h(h, mu, h->mu, (size_t)h->m)); }
+  if (w) CHK(d2h(h, w, h->w, N));
+  if (w_prev) CHK(d2h(h, w_prev, h->w_prev, N));
+  if (s) CHK(d2h(h, s, h->s, (size_t)h->m));
+  return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_get_kkt_solution(cosmo_hip_handle* h, double* sol) {
+  ENTER(h);
+  if (!h->have_params || !sol) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "get_kkt_solution: not set up");
+  CHK(d2h(h, sol, h->x_tl, (size_t)h->n));
+  CHK(d2h(h, sol + h->n, h->nu, (size_t)h->m));
+  return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_get_stats(cosmo_hip_handle* h, int64_t out[8]) {
+  ENTER(h);
+  if (!out) return COSMO_HIP_ERR_INVALID;
+  CHK(sync_ctl(h));
+  const Ctl* c = h->ctl_host;
+  out[0] = c->iter; out[1] = c->solves; out[2] = c->kkt_iters_total; out[3] = h->stalls;
+  out[4] = h->spmv_calls[0]; out[5] = h->spmv_calls[1]; out[6] = h->spmv_calls[2]; out[7] = c->n_rho_updates;
+  return COSMO_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// measurement hooks
+// ---------------------------------------------------------------------------------------------------------------------
+int32_t time_op_apply(cosmo_hip_handle* h, int reps, double* avg_seconds);  // kernels.hip
+
+extern "C" int32_t cosmo_hip_time_spmv(cosmo_hip_handle* h, int32_t which, int32_t reps, double* avg_seconds,
+                                       double* algorithmic_bytes) {
+  ENTER(h);
+  if (!h->have_problem || reps <= 0 || !avg_seconds) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "time_spmv: bad arguments");
+  const long long n = h->n, m = h->m;
+  hipEvent_t e0, e1;
+  HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+  double bytes = 0.0;
+  // 12 B per nonzero + 4 B per row pointer + 8 B per input and output vector element
+  if (which == COSMO_HIP_MAT_A) bytes = 12.0 * h->A.nnz + 4.0 * (m + 1) + 8.0 * n + 8.0 * m;
+  else if (which == COSMO_HIP_MAT_AT) bytes = 12.0 * h->AT.nnz + 4.0 * (n + 1) + 8.0 * m + 8.0 * n;
+  else if (which == COSMO_HIP_MAT_P) bytes = 12.0 * h->P.nnz + 4.0 * (n + 1) + 16.0 * n;
+  else if (which == 3) bytes = 12.0 * h->PT.nnz + 8.0 * (n + 1) + 8.0 * (n + m) + 8.0 * n;  // + split pointers
+  else return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "time_spmv: bad matrix id");
+  // warm up + timed back-to-back launches on the handle's stream
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1) HIPCHK(h, hipEventRecord(e0, h->stream));
+    const int R = pass == 0 ? 3 : reps;
+    for (int i = 0; i < R; ++i) {
+      if (which == COSMO_HIP_MAT_A) CHK(launch_spmv_plain(h, h->A, h->u, h->tmp_m));
+      else if (which == COSMO_HIP_MAT_AT) CHK(launch_spmv_plain(h, h->AT, h->tmp_m, h->c));
+      else if (which == COSMO_HIP_MAT_P) CHK(launch_spmv_plain(h, h->P, h->u, h->c));
+      else CHK(time_op_apply(h, 1, nullptr));
+    }
+    if (pass == 1) HIPCHK(h, hipEventRecord(e1, h->stream));
+  }
+  HIPCHK(h, hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+  *avg_seconds = (double)ms * 1e-3 / reps;
+  if (algorithmic_bytes) *algorithmic_bytes = bytes;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_set_profiling(cosmo_hip_handle* h, int32_t on) {
+  ENTER(h);
+  CHK(prof_collect(h));
+  h->profiling = on == 1;
+  h->exact_launches = on != 0;
+  if (on) { memset(h->kc_seconds, 0, sizeof h->kc_seconds); memset(h->kc_launches, 0, sizeof h->kc_launches); }
+  return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_get_kernel_times(cosmo_hip_handle* h, double seconds[COSMO_HIP_NUM_KERNEL_CLASSES],
+                                              int64_t launches[COSMO_HIP_NUM_KERNEL_CLASSES]) {
+  ENTER(h);
+  CHK(prof_collect(h));
+  for (int i = 0; i < COSMO_HIP_NUM_KERNEL_CLASSES; ++i) {
+    if (seconds) seconds[i] = h->kc_seconds[i];
+    if (launches) launches[i] = h->kc_launches[i];
+  }
+  return COSMO_HIP_OK;
+}
+
+extern "C" const char* cosmo_hip_kernel_class_name(int32_t k) {
+  static const char* names[COSMO_HIP_NUM_KERNEL_CLASSES] = {
+      "admm_z(copy+simple cones)", "proj_soc", "proj_psd", "admm_x_rhs", "spmv_AT(cg rhs)", "spmv_A(rho.*A v)",
+      "op_apply([P|A'] fused)", "cg_direction", "cg_update", "tail(A x_tl, s_tl, w)", "check_primal(A)",
+      "check_dual([P|A'])", "check_final", "rho_apply", "minres_vec", "other"};
+  if (k < 0 || k >= COSMO_HIP_NUM_KERNEL_CLASSES) return "?";
+  return names[k];
+}

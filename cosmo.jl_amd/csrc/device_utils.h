@@ -1,0 +1,130 @@
+// device_utils.h -- wave64 / workgroup reductions and the CSR-stream row-block primitive (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "internal.h"
+
+// partial-reduction slots (h->partials + slot * COSMO_MAX_PARTIALS)
+enum { SLOT_BB = 0, SLOT_RR, SLOT_UC, SLOT_RP, SLOT_MP, SLOT_RD, SLOT_MD, SLOT_XPX, SLOT_QX, SLOT_AUX0, SLOT_AUX1, SLOT_AUX2 };
+#define COSMO_NSLOTS_TOTAL 12
+
+struct CsrView {
+  const int* rowptr;
+  const int* col;
+  const double* val;
+  const int* split;  // may be null
+  const int* rb;
+  int nb;
+  int nrows;
+  int split_col;     // columns >= split_col gather from x2[col - split_col]
+};
+
+static inline CsrView view_of(const CsrDev& D) {
+  CsrView v;
+  v.rowptr = D.rowptr; v.col = D.col; v.val = D.val; v.split = D.split; v.rb = D.rb;
+  v.nb = D.nb; v.nrows = D.nrows; v.split_col = D.split_col;
+  return v;
+}
+
+// Butterfly reductions: every lane ends with the same value, combination order is fixed => deterministic.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(v, o, 64); v = (t > v) ? t : v; }
+  return v;
+}
+
+// red: COSMO_BS/64 doubles of LDS.  Result is broadcast to all threads.
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int i = 0; i < COSMO_BS / 64; ++i) t += red[i];
+  return t;
+}
+__device__ __forceinline__ double block_max(double v, double* red) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = red[0];
+#pragma unroll
+  for (int i = 1; i < COSMO_BS / 64; ++i) t = (red[i] > t) ? red[i] : t;
+  return t;
+}
+// Every workgroup re-reduces the (<= COSMO_MAX_PARTIALS) partials of the producing kernel in the same fixed
+// order, so all workgroups of all consumer kernels see bit-identical scalars without a finalize launch.
+__device__ __forceinline__ double reduce_partials_sum(const double* p, int count, double* red) {
+  double a = 0.0;
+  for (int i = threadIdx.x; i < count; i += COSMO_BS) a += p[i];
+  return block_sum(a, red);
+}
+__device__ __forceinline__ double reduce_partials_max(const double* p, int count, double* red) {
+  double a = 0.0;
+  for (int i = threadIdx.x; i < count; i += COSMO_BS) { double t = p[i]; a = (t > a || t != t) ? t : a; }
+  return block_max(a, red);
+}
+
+// abs-max that propagates NaN like Julia's norm(x, Inf)
+__device__ __forceinline__ double amax(double acc, double v) {
+  double a = fabs(v);
+  return (a > acc || a != a) ? a : acc;
+}
+
+// CSR-stream over one row block [r0, r1): phase 1 stages val*x products of the block's contiguous nonzero range
+// in LDS with fully coalesced loads of (val, col); phase 2 gives every row to one thread, which adds its LDS
+// segment left to right -- exactly the order in which Julia's CSC kernels accumulate (no FMA contraction), so the
+// row sums are bit-identical to the serial CPU loop.  Rows longer than the LDS tile take the chunked path.
+// fn(row, sum1, sum2): sum1 over [rowptr[row], split[row]) and sum2 over [split[row], rowptr[row+1]).
+template <class RowFn>
+__device__ __forceinline__ void csr_stream_block(const CsrView& M, const double* __restrict__ x1,
+                                                 const double* __restrict__ x2, int r0, int r1, double* lds,
+                                                 double* red, RowFn fn) {
+  const int nz0 = M.rowptr[r0];
+  const int nz1 = M.rowptr[r1];
+  const int cnt = nz1 - nz0;
+  if (cnt <= COSMO_NNZ_PER_BLOCK) {
+#pragma unroll
+    for (int it = 0; it < COSMO_NNZ_PER_BLOCK / COSMO_BS; ++it) {
+      const int k = it * COSMO_BS + threadIdx.x;
+      if (k < cnt) {
+        const int c = M.col[nz0 + k];
+        const double a = M.val[nz0 + k];
+        const double xv = (c < M.split_col) ? x1[c] : x2[c - M.split_col];
+        lds[k] = a * xv;
+      }
+    }
+    __syncthreads();
+    for (int r = r0 + threadIdx.x; r < r1; r += COSMO_BS) {
+      const int a = M.rowptr[r] - nz0;
+      const int b = M.rowptr[r + 1] - nz0;
+      const int sp = M.split ? (M.split[r] - nz0) : b;
+      double s1 = 0.0, s2 = 0.0;
+      for (int k = a; k < sp; ++k) s1 += lds[k];
+      for (int k = sp; k < b; ++k) s2 += lds[k];
+      fn(r, s1, s2);
+    }
+    __syncthreads();
+  } else {
+    // single long row (the schedule never mixes a long row with others)
+    const int r = r0;
+    const int sp = M.split ? M.split[r] : nz1;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = nz0 + threadIdx.x; k < nz1; k += COSMO_BS) {
+      const int c = M.col[k];
+      const double xv = (c < M.split_col) ? x1[c] : x2[c - M.split_col];
+      const double p = M.val[k] * xv;
+      if (k < sp) s1 += p; else s2 += p;
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) fn(r, s1, s2);
+    __syncthreads();
+  }
+}

@@ -1,0 +1,169 @@
+// internal.h -- shared declarations of libcosmo_hip (gfx950 only; no portability layers).
+//
+// Device data layout (all resident in HBM for the life of the handle):
+//   sparse matrices : CSR, int32 indices, fp64 values; four copies: A (m x n), A' (n x m), P (n x n) and the
+//                     row-merged operator [P | A'] (n x (n+m)) that the CG apply and the dual residual stream once
+//   vectors         : w, w_prev (n+m) ; s, mu, s_tl, rho, tmp_m, ls_s, nu (m) ; ls_x, x_tl(=CG iterate), r, u, c,
+//                     rhs (n) ; Dinv (n), Einv (m)
+//   control block   : one `Ctl` struct in device memory; every data-dependent decision of the loop (CG
+//                     convergence, rho adaptation, termination) is taken on the device and recorded there, so the
+//                     host can enqueue whole iterations without synchronising.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/cosmo_hip.h"
+
+#define COSMO_BS 256            // threads per workgroup for streaming kernels (4 waves of 64)
+#define COSMO_NNZ_PER_BLOCK 4096 // CSR-stream: nonzeros staged in LDS per row block (32 KB of products)
+#define COSMO_MAX_PARTIALS 1024 // upper bound on workgroups that emit reduction partials
+#define COSMO_NSLOTS 8          // partial-reduction slots
+
+// ---- device control block -------------------------------------------------------------------------------------
+struct Ctl {
+  int halt;          // != 0: every loop kernel returns immediately (status decided, stall, or error)
+  int status;        // COSMO_HIP_* solver status decided on the device
+  int stalled;       // the Krylov budget of the current solve ran out before convergence
+  int error;         // COSMO_HIP_ERR_* raised on the device
+  int cg_done;       // current solve has converged
+  int cg_k;          // Krylov iterations performed in the current solve
+  int cg_k_max;      // max over solves since the host last reset it (drives the launch budget)
+  int rho_changed;   // set by the adaptation kernel, consumed by the rho-apply kernel
+  int n_rho_updates; // length(ws.rho_updates)
+  int pad0;
+  long long iter;    // ADMM iterations completed
+  long long solves;  // KKT solves completed (iteration_counter - 1)
+  long long kkt_iters_total;
+  double resv[2];    // CG residual norms, indexed by iteration parity
+  double tol;        // absolute tolerance of the current solve
+  double rhs_norm;
+  double rho;        // scalar rho (ws.rho)
+  double r_prim, r_dual, max_norm_prim, max_norm_dual, cost;
+  double minres[16]; // MINRES scalar recurrences (H[4], rhs[2], c_prev, s_prev, c_curr, s_curr, resnorm, ...)
+  double rho_updates[COSMO_HIP_MAX_RHO_UPDATES];
+};
+
+// ---- CSR matrix on the device -----------------------------------------------------------------------------------
+struct CsrDev {
+  int nrows = 0, ncols = 0;
+  long long nnz = 0;
+  int* rowptr = nullptr;  // nrows+1
+  int* col = nullptr;     // nnz
+  double* val = nullptr;  // nnz
+  int* split = nullptr;   // nrows (merged operator only): index where the A' part of the row starts
+  int* rb = nullptr;      // nb+1 row-block boundaries of the CSR-stream schedule
+  int nb = 0;             // number of row blocks
+  int grid = 0;           // workgroups launched (<= COSMO_MAX_PARTIALS), each loops over row blocks
+  int split_col = 0;      // merged operator: columns >= split_col gather from the second vector
+};
+
+struct HostCsr {  // host staging of a CSR matrix (0-based)
+  int nrows = 0, ncols = 0;
+  std::vector<int> rowptr, col;
+  std::vector<double> val;
+  std::vector<int> split;
+};
+
+enum KernelClass {
+  KC_Z = 0, KC_SOC, KC_PSD, KC_RHS, KC_SPMV_AT, KC_SPMV_A, KC_OP_APPLY, KC_CG_DIR, KC_CG_UPD, KC_TAIL,
+  KC_CHK_PRIM, KC_CHK_DUAL, KC_CHK_FINAL, KC_RHO_APPLY, KC_MINRES_VEC, KC_OTHER
+};
+
+struct ConeTable {  // host copy of the composite set
+  std::vector<int32_t> type;
+  std::vector<int64_t> dim, off;
+  int64_t nbox_rows = 0;
+  std::vector<double> box_l, box_u;
+};
+
+struct PsdPlan;  // psd.hip
+
+struct cosmo_hip_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  bool destroyed = false;
+  // sizes
+  long long n = 0, m = 0;
+  bool have_problem = false, have_cones = false, have_params = false, have_iterates = false;
+  // matrices
+  CsrDev A, AT, P, PT;
+  // data vectors
+  double *q = nullptr, *b = nullptr, *rho = nullptr, *Dinv = nullptr, *Einv = nullptr;
+  double cinv = 1.0;
+  bool has_scaling = false;
+  // cones
+  ConeTable cones;
+  uint32_t* meta = nullptr;       // per row: kind (2 bits) | box index << 2
+  double *box_l = nullptr, *box_u = nullptr;
+  int* rho_cls = nullptr;         // per row rho class 0/1/2
+  std::vector<int32_t> rho_cls_host;
+  int nsoc = 0;                   // SOC table
+  int *soc_off = nullptr, *soc_dim = nullptr, *soc_branch = nullptr;
+  std::vector<int> soc_cone_index;
+  PsdPlan* psd = nullptr;
+  // loop state
+  double *w = nullptr, *w_prev = nullptr, *s = nullptr, *mu = nullptr, *s_tl = nullptr;
+  double *ls_x = nullptr, *ls_s = nullptr, *x_tl = nullptr, *nu = nullptr;
+  double *rhs = nullptr, *r = nullptr, *u = nullptr, *c = nullptr, *tmp_m = nullptr, *y2 = nullptr;
+  double *mr = nullptr;           // MINRES work vectors
+  double* partials = nullptr;     // COSMO_NSLOTS x COSMO_MAX_PARTIALS
+  Ctl* ctl = nullptr;
+  Ctl* ctl_host = nullptr;        // pinned mirror
+  double* io = nullptr;           // staging buffer, n+m
+  // parameters
+  cosmo_hip_params prm;
+  // host-side bookkeeping of the speculative enqueue
+  long long host_iter = 0;        // ADMM iterations enqueued
+  long long host_solves = 0;      // KKT solves enqueued
+  int budget = 12;                // Krylov iterations enqueued per solve
+  long long stalls = 0;
+  long long spmv_calls[3] = {0, 0, 0};
+  // profiling
+  bool profiling = false;      // HIP events around every loop kernel
+  bool exact_launches = false; // synchronise after every Krylov iteration (no guarded no-op launches)
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<std::pair<int, int>> ev_open;  // (class, event index of start)
+  size_t ev_used = 0;
+  double kc_seconds[COSMO_HIP_NUM_KERNEL_CLASSES] = {0};
+  long long kc_launches[COSMO_HIP_NUM_KERNEL_CLASSES] = {0};
+  hipEvent_t ev_proj0 = nullptr, ev_proj1 = nullptr;
+};
+
+// ---- error handling ------------------------------------------------------------------------------------------------
+int32_t cosmo_fail(cosmo_hip_handle* h, int32_t code, const char* fmt, ...);
+#define HIPCHK(h, call)                                                                                  \
+  do {                                                                                                   \
+    hipError_t e__ = (call);                                                                             \
+    if (e__ != hipSuccess)                                                                               \
+      return cosmo_fail((h), COSMO_HIP_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                        __FILE__, __LINE__);                                                             \
+  } while (0)
+#define CHK(call)                         \
+  do {                                    \
+    int32_t rc__ = (call);                \
+    if (rc__ != COSMO_HIP_OK) return rc__; \
+  } while (0)
+
+// ---- launch helpers implemented in kernels.hip ---------------------------------------------------------------------
+int32_t upload_csr(cosmo_hip_handle* h, const HostCsr& M, CsrDev& D, int split_col);
+void free_csr(CsrDev& D);
+void prof_begin(cosmo_hip_handle* h, int kc);
+void prof_end(cosmo_hip_handle* h);
+int32_t prof_collect(cosmo_hip_handle* h);
+
+// plain y = M x (fine-grained ABI + building block)
+int32_t launch_spmv_plain(cosmo_hip_handle* h, const CsrDev& M, const double* x, double* y);
+
+// loop pieces (loop.hip)
+int32_t enqueue_projection(cosmo_hip_handle* h, const double* src, double* dst, double* w_prev_dst,
+                           const double* w_src, bool in_loop);
+int32_t enqueue_admm_x_and_w(cosmo_hip_handle* h);
+int32_t sync_ctl(cosmo_hip_handle* h);
+
+// PSD projection (psd.hip)
+int32_t psd_plan_create(cosmo_hip_handle* h);
+void psd_plan_destroy(cosmo_hip_handle* h);
+int32_t psd_enqueue_project(cosmo_hip_handle* h, double* s, bool guard);
+int32_t psd_get_ranks(cosmo_hip_handle* h, int64_t* rank_per_cone);

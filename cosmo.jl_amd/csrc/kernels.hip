@@ -1,0 +1,710 @@
+// kernels.hip -- hand-written gfx950 kernels of the ADMM iteration: CSR-stream SpMV family, the fused vector
+// phases of admm_z!/admm_x!/admm_w!, simple-cone projections, the device-resident CG, residual checks and the
+// adaptive-rho rule.  Compiled with -ffp-contract=off: the elementwise phases must round exactly like Julia's
+// broadcasts (no FMA), see SURVEY.md Appendix A.  Reference citations are to /root/reference/src.
+#include "device_utils.h"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// plain SpMV  y = M x                      (mul!(y, A, x) / mul!(y, A', x) / mul!(y, P, x), residuals.jl:4,12,15)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(COSMO_BS) void k_spmv_plain(CsrView M, const double* __restrict__ x, double* __restrict__ y) {
+  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ double red[COSMO_BS / 64];
+  for (int k = blockIdx.x; k < M.nb; k += gridDim.x) {
+    csr_stream_block(M, x, x, M.rb[k], M.rb[k + 1], lds, red, [&](int r, double s1, double s2) { y[r] = s1 + s2; });
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// admm_z! simple part: w_prev = w ; s = Pi(w_s) for Zero / Nonnegatives / Box rows, copy for the others
+// (solver.jl:151, 14 ; convexset.jl:25-28, 71-74, 844-847 with clip algebra.jl:5-7)
+// meta[i] = kind | (boxindex << 2), kind: 0 copy, 1 zero, 2 nonneg, 3 box
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double project_simple(double x, uint32_t meta, const double* __restrict__ bl,
+                                                 const double* __restrict__ bu) {
+  const uint32_t kind = meta & 3u;
+  if (kind == 0u) return x;
+  if (kind == 1u) return 0.0;
+  if (kind == 2u) {
+    // Julia max(x, 0.0): NaN propagates, max(-0.0, 0.0) == +0.0
+    return (x != x) ? x : ((x > 0.0) ? x : 0.0);
+  }
+  const uint32_t j = meta >> 2;
+  const double l = bl[j], u = bu[j];
+  return (x < l) ? l : ((x > u) ? u : x);
+}
+
+__global__ __launch_bounds__(COSMO_BS) void k_z(const Ctl* __restrict__ ctl, int guard, long long n, long long m,
+                                                const double* __restrict__ w, double* __restrict__ w_prev,
+                                                double* __restrict__ s, const uint32_t* __restrict__ meta,
+                                                const double* __restrict__ bl, const double* __restrict__ bu) {
+  if (guard && ctl->halt) return;
+  const long long N = n + m;
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) {
+    const double v = w[i];
+    w_prev[i] = v;
+    if (i >= n) {
+      const long long r = i - n;
+      s[r] = project_simple(v, meta[r], bl, bu);
+    }
+  }
+}
+
+// in-place variant for the fine-grained ABI (cosmo_hip_project)
+__global__ __launch_bounds__(COSMO_BS) void k_project_simple_inplace(long long m, double* __restrict__ s,
+                                                                     const uint32_t* __restrict__ meta,
+                                                                     const double* __restrict__ bl,
+                                                                     const double* __restrict__ bu) {
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < m; i += (long long)gridDim.x * COSMO_BS)
+    s[i] = project_simple(s[i], meta[i], bl, bu);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SecondOrderCone projection, one wave per cone, in place on s (convexset.jl:100-114)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(COSMO_BS) void k_soc(const Ctl* __restrict__ ctl, int guard, int ncones,
+                                                  const int* __restrict__ off, const int* __restrict__ dim,
+                                                  double* __restrict__ s, int* __restrict__ branch) {
+  if (guard && ctl->halt) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * COSMO_BS + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * COSMO_BS) >> 6;
+  for (int c = wave; c < ncones; c += nwaves) {
+    double* x = s + off[c];
+    const int d = dim[c];
+    if (d == 0) { if (lane == 0) branch[c] = 0; continue; }
+    const double t = x[0];
+    double acc = 0.0;
+    for (int i = 1 + lane; i < d; i += 64) { const double v = x[i]; acc += v * v; }
+    const double nx = sqrt(wave_sum(acc));
+    int br;
+    if (nx <= t) {
+      br = 0;
+    } else if (nx <= -t) {
+      br = 1;
+      for (int i = lane; i < d; i += 64) x[i] = 0.0;
+    } else {
+      br = 2;
+      const double f = (nx + t) / (2.0 * nx);
+      for (int i = 1 + lane; i < d; i += 64) x[i] = f * x[i];
+      if (lane == 0) x[0] = (nx + t) / 2.0;
+    }
+    if (lane == 0) branch[c] = br;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// warm start: w[1:n] = x0 ; w[n+1:] = 1/rho * mu0 + s0 ; s = s0        (solver.jl:128-129)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(COSMO_BS) void k_set_w(long long n, long long m, const double* __restrict__ x0,
+                                                    const double* __restrict__ s0, const double* __restrict__ mu0,
+                                                    const double* __restrict__ rho, double* __restrict__ w,
+                                                    double* __restrict__ s) {
+  const long long N = n + m;
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) {
+    if (i < n) {
+      w[i] = x0 ? x0[i] : 0.0;
+    } else {
+      const long long r = i - n;
+      const double sv = s0 ? s0[r] : 0.0;
+      const double mv = mu0 ? mu0[r] : 0.0;
+      w[i] = (1.0 / rho[r]) * mv + sv;
+      s[r] = sv;
+    }
+  }
+}
+
+// mu = rho .* (w_prev[n+1:] - s)                                          (recover_mu!, solver.jl:24-26)
+__global__ __launch_bounds__(COSMO_BS) void k_recover_mu(long long n, long long m, const double* __restrict__ w_prev,
+                                                         const double* __restrict__ s, const double* __restrict__ rho,
+                                                         double* __restrict__ mu) {
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < m; i += (long long)gridDim.x * COSMO_BS)
+    mu[i] = rho[i] * (w_prev[n + i] - s[i]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// admm_x! right-hand side (solver.jl:50-51) + first line of the reduced solve (kktsolver_indirect.jl:52):
+//   ls_x = sigma*w_x - q ; ls_s = (b - 2 s) + w_s ; y2 = rho .* ls_s ; resets the per-solve flags.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(COSMO_BS) void k_rhs(Ctl* __restrict__ ctl, int guard, long long n, long long m, double sigma,
+                                                  const double* __restrict__ w, const double* __restrict__ s,
+                                                  const double* __restrict__ q, const double* __restrict__ b,
+                                                  const double* __restrict__ rho, double* __restrict__ ls_x,
+                                                  double* __restrict__ ls_s, double* __restrict__ y2) {
+  if (guard && ctl->halt) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->cg_done = 0; ctl->cg_k = 0; }
+  const long long N = n + m;
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) {
+    if (i < n) {
+      ls_x[i] = sigma * w[i] - q[i];
+    } else {
+      const long long r = i - n;
+      const double v = (b[r] - 2.0 * s[r]) + w[i];
+      ls_s[r] = v;
+      y2[r] = rho[r] * v;
+    }
+  }
+}
+
+// fine-grained solve: y2 = rho .* rhs_s (rhs already uploaded into ls_x / ls_s)
+__global__ __launch_bounds__(COSMO_BS) void k_y2_only(Ctl* __restrict__ ctl, long long m, const double* __restrict__ ls_s,
+                                                      const double* __restrict__ rho, double* __restrict__ y2) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->cg_done = 0; ctl->cg_k = 0; }
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < m; i += (long long)gridDim.x * COSMO_BS)
+    y2[i] = rho[i] * ls_s[i];
+}
+
+// rhs = A' y2 + ls_x ; partial sum of rhs^2                                (kktsolver_indirect.jl:53-54, 70)
+__global__ __launch_bounds__(COSMO_BS) void k_cg_rhs(const Ctl* __restrict__ ctl, int guard, CsrView AT,
+                                                     const double* __restrict__ y2, const double* __restrict__ ls_x,
+                                                     double* __restrict__ rhs, double* __restrict__ part_bb) {
+  if (guard && ctl->halt) return;
+  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ double red[COSMO_BS / 64];
+  double acc = 0.0;
+  for (int k = blockIdx.x; k < AT.nb; k += gridDim.x) {
+    csr_stream_block(AT, y2, y2, AT.rb[k], AT.rb[k + 1], lds, red, [&](int r, double s1, double s2) {
+      const double v = (s1 + s2) + ls_x[r];
+      rhs[r] = v;
+      acc += v * v;
+    });
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) part_bb[blockIdx.x] = acc;
+}
+
+// out = rho .* (A v)                                                       (reduced_mul!, kktsolver_indirect.jl:59-60)
+// mode 0: solve start (v = previous solution)   mode 1: Krylov iteration (skipped once the solve has converged)
+__global__ __launch_bounds__(COSMO_BS) void k_spmv_A_rho(const Ctl* __restrict__ ctl, int guard, int mode, CsrView A,
+                                                         const double* __restrict__ v, const double* __restrict__ rho,
+                                                         double* __restrict__ out) {
+  if (guard && ctl->halt) return;
+  if (mode == 1 && ctl->cg_done) return;
+  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ double red[COSMO_BS / 64];
+  for (int k = blockIdx.x; k < A.nb; k += gridDim.x) {
+    csr_stream_block(A, v, v, A.rb[k], A.rb[k + 1], lds, red,
+                     [&](int r, double s1, double s2) { out[r] = (s1 + s2) * rho[r]; });
+  }
+}
+
+// c = P v + (sigma v + A' tmp) through the row-merged operator [P | A']      (reduced_mul!, :61-64)
+// mode 0 (solve start): r = rhs - c, partial sum r^2, block 0 derives the absolute tolerance
+//                       tol = tol_k / ||rhs||  (kktsolver_indirect.jl:70 ; cg! abstol)
+// mode 1 (iteration)  : store c, partial sum u.c        mode 2: as 1 but ignores the solve flags (timing hook)
+__global__ __launch_bounds__(COSMO_BS) void k_op_apply(Ctl* __restrict__ ctl, int guard, int mode, CsrView PT, double sigma,
+                                                       const double* __restrict__ v, const double* __restrict__ tmp,
+                                                       const double* __restrict__ rhs, double* __restrict__ r,
+                                                       double* __restrict__ c, double* __restrict__ part_out,
+                                                       const double* __restrict__ part_bb, int n_bb, double tol_k) {
+  if (guard && ctl->halt) return;
+  if (mode == 1 && ctl->cg_done) return;
+  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ double red[COSMO_BS / 64];
+  if (mode == 0 && blockIdx.x == 0) {
+    const double bb = reduce_partials_sum(part_bb, n_bb, red);
+    if (threadIdx.x == 0) {
+      const double nb = sqrt(bb);
+      ctl->rhs_norm = nb;
+      ctl->tol = tol_k / nb;
+    }
+  }
+  double acc = 0.0;
+  for (int k = blockIdx.x; k < PT.nb; k += gridDim.x) {
+    csr_stream_block(PT, v, tmp, PT.rb[k], PT.rb[k + 1], lds, red, [&](int row, double s1, double s2) {
+      const double vj = v[row];
+      const double cj = s1 + (sigma * vj + s2);
+      if (mode == 0) {
+        const double rj = rhs[row] - cj;
+        r[row] = rj;
+        acc += rj * rj;
+      } else {
+        c[row] = cj;
+        acc += vj * cj;
+      }
+    });
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) part_out[blockIdx.x] = acc;
+}
+
+// Krylov step k, first half (IterativeSolvers v0.9 cg.jl `iterate`): residual_k = ||r|| from the partials;
+// stop if k >= maxiter or residual_k <= tol (checked BEFORE the iteration); else beta = res_k^2 / res_{k-1}^2,
+// u = r + beta u (u_{-1} = 0).  check_only = 1: evaluate the stopping rule after the last budgeted iteration.
+__global__ __launch_bounds__(COSMO_BS) void k_cg_dir(Ctl* __restrict__ ctl, int guard, int k, int check_only, long long n,
+                                                     long long maxiter, const double* __restrict__ part_rr, int n_rr,
+                                                     const double* __restrict__ r, double* __restrict__ u) {
+  if (guard && ctl->halt) return;
+  if (ctl->cg_done) return;
+  __shared__ double red[COSMO_BS / 64];
+  const double rr = reduce_partials_sum(part_rr, n_rr, red);
+  const double res = sqrt(rr);
+  const bool done = (k >= maxiter) || (res <= ctl->tol);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (done) ctl->cg_done = 1;
+    if (!check_only || done) ctl->resv[k & 1] = res;
+  }
+  if (done || check_only) return;
+  const double prev = (k == 0) ? 1.0 : ctl->resv[(k - 1) & 1];
+  const double beta = (res * res) / (prev * prev);
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < n; i += (long long)gridDim.x * COSMO_BS) {
+    const double ui = (k == 0) ? 0.0 : u[i];
+    u[i] = r[i] + beta * ui;
+  }
+}
+
+// Krylov step k, second half: alpha = res_k^2 / (u.c) ; x += alpha u ; r -= alpha c ; partial sum r^2
+__global__ __launch_bounds__(COSMO_BS) void k_cg_upd(Ctl* __restrict__ ctl, int guard, int k, long long n,
+                                                     const double* __restrict__ part_uc, int n_uc,
+                                                     const double* __restrict__ u, const double* __restrict__ c,
+                                                     double* __restrict__ x, double* __restrict__ r,
+                                                     double* __restrict__ part_rr) {
+  if (guard && ctl->halt) return;
+  if (ctl->cg_done) return;
+  __shared__ double red[COSMO_BS / 64];
+  const double uc = reduce_partials_sum(part_uc, n_uc, red);
+  const double res = ctl->resv[k & 1];
+  const double alpha = (res * res) / uc;
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < n; i += (long long)gridDim.x * COSMO_BS) {
+    x[i] = x[i] + alpha * u[i];
+    const double ri = r[i] - alpha * c[i];
+    r[i] = ri;
+    acc += ri * ri;
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) {
+    part_rr[blockIdx.x] = acc;
+    if (blockIdx.x == 0) ctl->cg_k = k + 1;
+  }
+}
+
+// End of solve! + rest of admm_x! + admm_w!:
+//   nu = rho .* (A x_tl - ls_s)                     (kktsolver_indirect.jl:81-83)
+//   s_tl = (2 s - w_s) - nu ./ rho                  (solver.jl:55)
+//   w_s = w_s + alpha (s_tl - s) ; w_x = w_x + alpha (x_tl - w_x)      (solver.jl:63-64)
+// loop_mode 1: also detects an exhausted Krylov budget (stall) and advances the device counters.
+// loop_mode 0: fine-grained solve (only nu is produced).
+__global__ __launch_bounds__(COSMO_BS) void k_tail(Ctl* __restrict__ ctl, int loop_mode, CsrView A, long long n, long long m,
+                                                   double alpha, const double* __restrict__ x_tl,
+                                                   const double* __restrict__ ls_s, const double* __restrict__ rho,
+                                                   const double* __restrict__ s, double* __restrict__ nu,
+                                                   double* __restrict__ s_tl, double* __restrict__ w, int nblk_rows) {
+  if (loop_mode) {
+    if (ctl->halt) return;
+    if (!ctl->cg_done) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->stalled = 1; ctl->halt = 1; }
+      return;
+    }
+  }
+  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ double red[COSMO_BS / 64];
+  if ((int)blockIdx.x < nblk_rows) {
+    for (int k = blockIdx.x; k < A.nb; k += nblk_rows) {
+      csr_stream_block(A, x_tl, x_tl, A.rb[k], A.rb[k + 1], lds, red, [&](int row, double s1, double s2) {
+        const double ax = s1 + s2;
+        const double rh = rho[row];
+        const double nv = (ax - ls_s[row]) * rh;
+        nu[row] = nv;
+        if (loop_mode) {
+          const double sv = s[row];
+          const double wv = w[n + row];
+          const double st = (2.0 * sv - wv) - nv / rh;
+          s_tl[row] = st;
+          w[n + row] = wv + alpha * (st - sv);
+        }
+      });
+    }
+  } else if (loop_mode) {
+    const long long nb2 = gridDim.x - nblk_rows;
+    for (long long i = (long long)(blockIdx.x - nblk_rows) * COSMO_BS + threadIdx.x; i < n; i += nb2 * COSMO_BS) {
+      const double wv = w[i];
+      w[i] = wv + alpha * (x_tl[i] - wv);
+    }
+    if ((int)blockIdx.x == nblk_rows && threadIdx.x == 0) {
+      const int k = ctl->cg_k;
+      ctl->iter += 1;
+      ctl->solves += 1;
+      ctl->kkt_iters_total += k;
+      if (k > ctl->cg_k_max) ctl->cg_k_max = k;
+    }
+  }
+}
+
+// counters for the fine-grained solve
+__global__ void k_count_solve(Ctl* __restrict__ ctl) {
+  const int k = ctl->cg_k;
+  ctl->solves += 1;
+  ctl->kkt_iters_total += k;
+  if (k > ctl->cg_k_max) ctl->cg_k_max = k;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// residual checks (residuals.jl:30-96, 143-147).  x = w_prev[1:n], mu = rho .* (w_prev_s - s) recovered on the fly.
+// primal pass over A:  r_prim = A x + s - b ; norms of Einv-scaled r_prim, A x, s, b
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(COSMO_BS) void k_chk_prim(const Ctl* __restrict__ ctl, int guard, CsrView A, long long n,
+                                                       const double* __restrict__ w_prev, const double* __restrict__ s,
+                                                       const double* __restrict__ b, const double* __restrict__ rho,
+                                                       const double* __restrict__ Einv, double* __restrict__ mu,
+                                                       double* __restrict__ part_rp, double* __restrict__ part_mp) {
+  if (guard && ctl->halt) return;
+  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ double red[COSMO_BS / 64];
+  double rp = 0.0, mp = 0.0;
+  for (int k = blockIdx.x; k < A.nb; k += gridDim.x) {
+    csr_stream_block(A, w_prev, w_prev, A.rb[k], A.rb[k + 1], lds, red, [&](int row, double s1, double s2) {
+      const double ax = s1 + s2;
+      const double sv = s[row];
+      const double bv = b[row];
+      mu[row] = rho[row] * (w_prev[n + row] - sv);
+      double rv = ax + sv;
+      rv = rv - bv;
+      double e = 1.0;
+      if (Einv) e = Einv[row];
+      if (Einv) rv = rv * e;
+      rp = amax(rp, rv);
+      mp = amax(mp, Einv ? ax * e : ax);
+      mp = amax(mp, Einv ? sv * e : sv);
+      mp = amax(mp, Einv ? bv * e : bv);
+    });
+  }
+  rp = block_max(rp, red);
+  mp = block_max(mp, red);
+  if (threadIdx.x == 0) { part_rp[blockIdx.x] = rp; part_mp[blockIdx.x] = mp; }
+}
+
+// dual pass over [P | A']:  r_dual = P x + q - A' mu ; norms of cinv*Dinv-scaled r_dual, P x, q, A' mu ; x'Px, q'x
+__global__ __launch_bounds__(COSMO_BS) void k_chk_dual(const Ctl* __restrict__ ctl, int guard, CsrView PT,
+                                                       const double* __restrict__ w_prev, const double* __restrict__ mu,
+                                                       const double* __restrict__ q, const double* __restrict__ Dinv,
+                                                       double cinv, int unscale, double* __restrict__ part_rd,
+                                                       double* __restrict__ part_md, double* __restrict__ part_xpx,
+                                                       double* __restrict__ part_qx) {
+  if (guard && ctl->halt) return;
+  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ double red[COSMO_BS / 64];
+  double rd = 0.0, md = 0.0, xpx = 0.0, qx = 0.0;
+  for (int k = blockIdx.x; k < PT.nb; k += gridDim.x) {
+    csr_stream_block(PT, w_prev, mu, PT.rb[k], PT.rb[k + 1], lds, red, [&](int row, double px, double atm) {
+      const double xv = w_prev[row];
+      const double qv = q[row];
+      double rv = px + qv;
+      rv = rv - atm;
+      double a = px, bq = qv, cm = atm;
+      if (unscale) {
+        const double d = Dinv ? Dinv[row] : 1.0;
+        rv = (rv * d) * cinv;
+        a = (a * d) * cinv;
+        bq = (bq * d) * cinv;
+        cm = (cm * d) * cinv;
+      }
+      rd = amax(rd, rv);
+      md = amax(md, a);
+      md = amax(md, bq);
+      md = amax(md, cm);
+      xpx += px * xv;
+      qx += qv * xv;
+    });
+  }
+  rd = block_max(rd, red);
+  md = block_max(md, red);
+  xpx = block_sum(xpx, red);
+  qx = block_sum(qx, red);
+  if (threadIdx.x == 0) {
+    part_rd[blockIdx.x] = rd; part_md[blockIdx.x] = md; part_xpx[blockIdx.x] = xpx; part_qx[blockIdx.x] = qx;
+  }
+}
+
+// One workgroup: fold the partials, then take the data-dependent decision on the device.
+// mode 0 = info only (calculate_result_info!, residuals.jl:149-153)
+// mode 1 = check_termination! (solver.jl:306-321): cost, Unsolved / Solved
+// mode 3 = info + cost without a decision (cosmo_hip_residuals)
+// mode 2 = adapt_rho_vec! (parameters.jl:53-72): scalar rule; sets rho_changed for k_rho_apply
+struct ChkArgs {
+  const double *part_rp, *part_mp, *part_rd, *part_md, *part_xpx, *part_qx;
+  int n_prim, n_dual;
+  int mode;
+  double cinv, eps_abs, eps_rel;
+  double rho_min, rho_max, adapt_tol;
+  long long max_adaptions;
+};
+__global__ __launch_bounds__(COSMO_BS) void k_chk_final(Ctl* __restrict__ ctl, int guard, ChkArgs a) {
+  if (guard && ctl->halt) return;
+  __shared__ double red[COSMO_BS / 64];
+  const double rp = reduce_partials_max(a.part_rp, a.n_prim, red);
+  const double mp = reduce_partials_max(a.part_mp, a.n_prim, red);
+  const double rd = reduce_partials_max(a.part_rd, a.n_dual, red);
+  const double md = reduce_partials_max(a.part_md, a.n_dual, red);
+  const double xpx = reduce_partials_sum(a.part_xpx, a.n_dual, red);
+  const double qx = reduce_partials_sum(a.part_qx, a.n_dual, red);
+  if (threadIdx.x != 0) return;
+  if (a.mode == 2) {
+    ctl->rho_changed = 0;
+    if ((long long)(ctl->n_rho_updates - 1) >= a.max_adaptions) return;
+    const double rpn = rp / (mp + 1e-10);
+    const double rdn = rd / (md + 1e-10);
+    const double rho = ctl->rho;
+    double nr = rho * sqrt(rpn / (rdn + 1e-10));
+    nr = fmin(fmax(nr, a.rho_min), a.rho_max);
+    if ((nr > a.adapt_tol * rho) || (nr < (1.0 / a.adapt_tol) * rho)) {
+      ctl->rho = nr;
+      ctl->rho_changed = 1;
+      const int k = ctl->n_rho_updates;
+      if (k < COSMO_HIP_MAX_RHO_UPDATES) ctl->rho_updates[k] = nr;
+      ctl->n_rho_updates = k + 1;
+    }
+    return;
+  }
+  ctl->r_prim = rp; ctl->r_dual = rd; ctl->max_norm_prim = mp; ctl->max_norm_dual = md;
+  if (a.mode == 1 || a.mode == 3) {
+    const double cost = a.cinv * (0.5 * xpx + qx);
+    ctl->cost = cost;
+    if (a.mode == 3) return;
+    if (fabs(cost) > 1e20) { ctl->status = COSMO_HIP_UNSOLVED; ctl->halt = 1; return; }
+    const bool pf = rp < a.eps_abs + a.eps_rel * mp;
+    const bool df = rd < a.eps_abs + a.eps_rel * md;
+    if (pf && df) { ctl->status = COSMO_HIP_SOLVED; ctl->halt = 1; }
+  }
+}
+
+// update_rho_vec! (parameters.jl:75-92) + w_s = 1/rho * mu + s (solver.jl:278), only if the rule fired
+__global__ __launch_bounds__(COSMO_BS) void k_rho_apply(const Ctl* __restrict__ ctl, int guard, long long n, long long m,
+                                                        const int* __restrict__ cls, double rho_min, double rho_eq,
+                                                        const double* __restrict__ mu, const double* __restrict__ s,
+                                                        double* __restrict__ rho, double* __restrict__ w) {
+  if (guard && ctl->halt) return;
+  if (!ctl->rho_changed) return;
+  const double nr = ctl->rho;
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < m; i += (long long)gridDim.x * COSMO_BS) {
+    const int c = cls[i];
+    double rv = nr;
+    if (c == 1) rv = rv * rho_eq; else if (c == 2) rv = rho_min;
+    rho[i] = rv;
+    w[n + i] = (1.0 / rv) * mu[i] + s[i];
+  }
+}
+
+// rho vector from classes (set_rho_vec!, parameters.jl:3-13)
+__global__ __launch_bounds__(COSMO_BS) void k_rho_from_classes(long long m, const int* __restrict__ cls, double rho0,
+                                                               double rho_min, double rho_eq, double* __restrict__ rho) {
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < m; i += (long long)gridDim.x * COSMO_BS) {
+    const int c = cls[i];
+    double rv = rho0;
+    if (c == 1) rv = rv * rho_eq; else if (c == 2) rv = rho_min;
+    rho[i] = rv;
+  }
+}
+
+__global__ void k_ctl_clear_stall(Ctl* ctl) { ctl->stalled = 0; ctl->halt = (ctl->status != 0 || ctl->error != 0) ? 1 : 0; }
+__global__ void k_ctl_set_done(Ctl* ctl) { ctl->cg_done = 1; }
+
+// =====================================================================================================================
+// host-side launchers
+// =====================================================================================================================
+static inline int ew_grid(long long N) {
+  long long g = (N + COSMO_BS - 1) / COSMO_BS;
+  if (g < 1) g = 1;
+  if (g > COSMO_MAX_PARTIALS) g = COSMO_MAX_PARTIALS;
+  return (int)g;
+}
+
+#define PARTS(h, slot) ((h)->partials + (size_t)(slot) * COSMO_MAX_PARTIALS)
+
+int32_t launch_spmv_plain(cosmo_hip_handle* h, const CsrDev& M, const double* x, double* y) {
+  if (M.nrows == 0) return COSMO_HIP_OK;
+  hipLaunchKernelGGL(k_spmv_plain, dim3(M.grid), dim3(COSMO_BS), 0, h->stream, view_of(M), x, y);
+  HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}
+
+int32_t launch_project_simple_inplace(cosmo_hip_handle* h, double* s) {
+  if (h->m == 0) return COSMO_HIP_OK;
+  hipLaunchKernelGGL(k_project_simple_inplace, dim3(ew_grid(h->m)), dim3(COSMO_BS), 0, h->stream, h->m, s, h->meta,
+                     h->box_l, h->box_u);
+  HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}
+
+int32_t launch_z(cosmo_hip_handle* h, int guard) {
+  prof_begin(h, KC_Z);
+  hipLaunchKernelGGL(k_z, dim3(ew_grid(h->n + h->m)), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, h->n, h->m, h->w,
+                     h->w_prev, h->s, h->meta, h->box_l, h->box_u);
+  prof_end(h);
+  HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}
+
+int32_t launch_soc(cosmo_hip_handle* h, double* s, int guard) {
+  if (h->nsoc == 0) return COSMO_HIP_OK;
+  int g = (h->nsoc + (COSMO_BS / 64) - 1) / (COSMO_BS / 64);
+  if (g > 4096) g = 4096;
+  prof_begin(h, KC_SOC);
+  hipLaunchKernelGGL(k_soc, dim3(g), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, h->nsoc, h->soc_off, h->soc_dim, s,
+                     h->soc_branch);
+  prof_end(h);
+  HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}
+
+int32_t launch_set_w(cosmo_hip_handle* h, const double* x0, const double* s0, const double* mu0) {
+  hipLaunchKernelGGL(k_set_w, dim3(ew_grid(h->n + h->m)), dim3(COSMO_BS), 0, h->stream, h->n, h->m, x0, s0, mu0, h->rho,
+                     h->w, h->s);
+  HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}
+
+int32_t launch_recover_mu(cosmo_hip_handle* h) {
+  if (h->m == 0) return COSMO_HIP_OK;
+  hipLaunchKernelGGL(k_recover_mu, dim3(ew_grid(h->m)), dim3(COSMO_BS), 0, h->stream, h->n, h->m, h->w_prev, h->s, h->rho,
+                     h->mu);
+  HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}
+
+int32_t launch_rho_from_classes(cosmo_hip_handle* h, double rho0) {
+  if (h->m == 0) return COSMO_HIP_OK;
+  hipLaunchKernelGGL(k_rho_from_classes, dim3(ew_grid(h->m)), dim3(COSMO_BS), 0, h->stream, h->m, h->rho_cls, rho0,
+                     h->prm.rho_min, h->prm.rho_eq_over_rho_ineq, h->rho);
+  HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}
+
+// ---- reduced-system CG solve, enqueued without host synchronisation --------------------------------------------------
+// from_loop: rhs comes from the loop state (k_rhs) and the tail updates w; otherwise ls_x/ls_s were uploaded.
+int32_t enqueue_cg_iterations(cosmo_hip_handle* h, int guard, int k_begin, int count) {
+  const long long n = h->n;
+  const int gE = ew_grid(n);
+  const int n_rr0 = h->PT.grid;
+  for (int k = k_begin; k < k_begin + count; ++k) {
+    prof_begin(h, KC_CG_DIR);
+    hipLaunchKernelGGL(k_cg_dir, dim3(gE), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, k, 0, n, n, PARTS(h, SLOT_RR),
+                       (k == 0) ? n_rr0 : gE, h->r, h->u);
+    prof_end(h);
+    prof_begin(h, KC_SPMV_A);
+    hipLaunchKernelGGL(k_spmv_A_rho, dim3(h->A.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, 1, view_of(h->A), h->u,
+                       h->rho, h->tmp_m);
+    prof_end(h);
+    prof_begin(h, KC_OP_APPLY);
+    hipLaunchKernelGGL(k_op_apply, dim3(h->PT.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, 1, view_of(h->PT),
+                       h->prm.sigma, h->u, h->tmp_m, h->rhs, h->r, h->c, PARTS(h, SLOT_UC), PARTS(h, SLOT_BB), 0, 0.0);
+    prof_end(h);
+    prof_begin(h, KC_CG_UPD);
+    hipLaunchKernelGGL(k_cg_upd, dim3(gE), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, k, n, PARTS(h, SLOT_UC),
+                       h->PT.grid, h->u, h->c, h->x_tl, h->r, PARTS(h, SLOT_RR));
+    prof_end(h);
+    h->spmv_calls[0] += 1; h->spmv_calls[1] += 1; h->spmv_calls[2] += 1;
+  }
+  // evaluate the stopping rule once more after the last budgeted iteration
+  const int kk = k_begin + count;
+  prof_begin(h, KC_CG_DIR);
+  hipLaunchKernelGGL(k_cg_dir, dim3(1), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, kk, 1, n, n, PARTS(h, SLOT_RR),
+                     (kk == 0) ? n_rr0 : gE, h->r, h->u);
+  prof_end(h);
+  HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}
+
+int32_t enqueue_cg_start(cosmo_hip_handle* h, int guard, double tol_k) {
+  prof_begin(h, KC_SPMV_AT);
+  hipLaunchKernelGGL(k_cg_rhs, dim3(h->AT.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, view_of(h->AT), h->y2,
+                     h->ls_x, h->rhs, PARTS(h, SLOT_BB));
+  prof_end(h);
+  prof_begin(h, KC_SPMV_A);
+  hipLaunchKernelGGL(k_spmv_A_rho, dim3(h->A.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, 0, view_of(h->A), h->x_tl,
+                     h->rho, h->tmp_m);
+  prof_end(h);
+  prof_begin(h, KC_OP_APPLY);
+  hipLaunchKernelGGL(k_op_apply, dim3(h->PT.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, 0, view_of(h->PT),
+                     h->prm.sigma, h->x_tl, h->tmp_m, h->rhs, h->r, h->c, PARTS(h, SLOT_RR), PARTS(h, SLOT_BB),
+                     h->AT.grid, tol_k);
+  prof_end(h);
+  h->spmv_calls[0] += 1; h->spmv_calls[1] += 2; h->spmv_calls[2] += 1;
+  HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}
+
+int32_t enqueue_rhs(cosmo_hip_handle* h, int guard) {
+  prof_begin(h, KC_RHS);
+  hipLaunchKernelGGL(k_rhs, dim3(ew_grid(h->n + h->m)), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, h->n, h->m,
+                     h->prm.sigma, h->w, h->s, h->q, h->b, h->rho, h->ls_x, h->ls_s, h->y2);
+  prof_end(h);
+  HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}
+
+int32_t enqueue_y2_only(cosmo_hip_handle* h) {
+  hipLaunchKernelGGL(k_y2_only, dim3(ew_grid(h->m > 0 ? h->m : 1)), dim3(COSMO_BS), 0, h->stream, h->ctl, h->m, h->ls_s,
+                     h->rho, h->y2);
+  HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}
+
+int32_t enqueue_tail(cosmo_hip_handle* h, int loop_mode) {
+  const int gr = h->A.grid > 0 ? h->A.grid : 1;
+  const int gx = loop_mode ? ew_grid(h->n) : 0;
+  prof_begin(h, KC_TAIL);
+  hipLaunchKernelGGL(k_tail, dim3(gr + gx), dim3(COSMO_BS), 0, h->stream, h->ctl, loop_mode, view_of(h->A), h->n, h->m,
+                     h->prm.alpha, h->x_tl, h->ls_s, h->rho, h->s, h->nu, h->s_tl, h->w, gr);
+  prof_end(h);
+  h->spmv_calls[0] += 1;
+  HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}
+
+int32_t enqueue_count_solve(cosmo_hip_handle* h) {
+  hipLaunchKernelGGL(k_count_solve, dim3(1), dim3(1), 0, h->stream, h->ctl);
+  HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}
+
+int32_t enqueue_clear_stall(cosmo_hip_handle* h) {
+  hipLaunchKernelGGL(k_ctl_clear_stall, dim3(1), dim3(1), 0, h->stream, h->ctl);
+  HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}
+
+// mode: 0 info, 1 termination, 2 adaptation (unscaled residuals, parameters.jl:57-59)
+int32_t enqueue_check(cosmo_hip_handle* h, int guard, int mode) {
+  const bool unscale = (mode != 2) && h->prm.unscale_residuals && h->has_scaling;
+  prof_begin(h, KC_CHK_PRIM);
+  hipLaunchKernelGGL(k_chk_prim, dim3(h->A.grid > 0 ? h->A.grid : 1), dim3(COSMO_BS), 0, h->stream, h->ctl, guard,
+                     view_of(h->A), h->n, h->w_prev, h->s, h->b, h->rho, unscale ? h->Einv : (const double*)nullptr, h->mu,
+                     PARTS(h, SLOT_RP), PARTS(h, SLOT_MP));
+  prof_end(h);
+  prof_begin(h, KC_CHK_DUAL);
+  hipLaunchKernelGGL(k_chk_dual, dim3(h->PT.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, view_of(h->PT), h->w_prev,
+                     h->mu, h->q, h->Dinv, h->cinv, unscale ? 1 : 0, PARTS(h, SLOT_RD), PARTS(h, SLOT_MD),
+                     PARTS(h, SLOT_XPX), PARTS(h, SLOT_QX));
+  prof_end(h);
+  ChkArgs a;
+  a.part_rp = PARTS(h, SLOT_RP); a.part_mp = PARTS(h, SLOT_MP); a.part_rd = PARTS(h, SLOT_RD);
+  a.part_md = PARTS(h, SLOT_MD); a.part_xpx = PARTS(h, SLOT_XPX); a.part_qx = PARTS(h, SLOT_QX);
+  a.n_prim = h->A.grid > 0 ? h->A.grid : 1; a.n_dual = h->PT.grid; a.mode = mode;
+  a.cinv = (h->prm.unscale_residuals && h->has_scaling) ? h->cinv : 1.0;
+  a.eps_abs = h->prm.eps_abs; a.eps_rel = h->prm.eps_rel;
+  a.rho_min = h->prm.rho_min; a.rho_max = h->prm.rho_max; a.adapt_tol = h->prm.adaptive_rho_tolerance;
+  a.max_adaptions = h->prm.adaptive_rho_max_adaptions;
+  prof_begin(h, KC_CHK_FINAL);
+  hipLaunchKernelGGL(k_chk_final, dim3(1), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, a);
+  prof_end(h);
+  if (mode == 2) {
+    prof_begin(h, KC_RHO_APPLY);
+    hipLaunchKernelGGL(k_rho_apply, dim3(ew_grid(h->m > 0 ? h->m : 1)), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, h->n,
+                       h->m, h->rho_cls, h->prm.rho_min, h->prm.rho_eq_over_rho_ineq, h->mu, h->s, h->rho, h->w);
+    prof_end(h);
+  }
+  h->spmv_calls[0] += 1; h->spmv_calls[1] += 1; h->spmv_calls[2] += 1;
+  HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}
+
+// timing hook: the fused operator kernel exactly as the CG iteration launches it
+int32_t time_op_apply(cosmo_hip_handle* h, int reps, double* avg_seconds) {
+  (void)avg_seconds;
+  for (int i = 0; i < reps; ++i)
+    hipLaunchKernelGGL(k_op_apply, dim3(h->PT.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, 0, 2, view_of(h->PT),
+                       h->prm.sigma, h->u, h->tmp_m, h->rhs, h->r, h->c, PARTS(h, SLOT_AUX0), PARTS(h, SLOT_BB), 0, 0.0);
+  HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}

@@ -1,0 +1,458 @@
+"""Host-side mirror of the reference's model interface for the ADMM hot path.
+
+In the real drop-in the Julia front-end stays unchanged: `COSMO.Model`, `assemble!`, `set!`, `setup!` (Ruiz
+scaling, constraint classification) run in Julia and `optimize!` hands the scaled problem to libcosmo_hip through
+`ccall` (julia/CosmoHIP.jl).  Julia is not available in this image, so this module restates that thin host layer
+in Python with the same names, argument meaning and error behaviour, so that the parity tests read like the
+reference's tests:
+
+    model = Model()
+    assemble(model, P, q, [Constraint(A, b, Nonnegatives)], settings=Settings(kkt_solver=CGIndirectKKTSolver))
+    res = optimize(model)          # -> Result(x, y, s, obj_val, iter, status, info, times)
+
+Everything numerical inside the loop runs on the GPU; the only host arithmetic here is the one-off setup
+(`scale_ruiz!`, src/scaling.jl:21-116) and the epilogue (`reverse_scaling!`, src/scaling.jl:170-179).
+References are to /root/reference/src.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Union
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _ffi
+
+# ---- AbstractKKTSolver plugin names (src/linear_solver/kktsolver_indirect.jl:173-185) ----------------------------
+CGIndirectKKTSolver = "CGIndirectKKTSolver"
+MINRESIndirectKKTSolver = "MINRESIndirectKKTSolver"
+IndirectReducedKKTSolverMINRES = "IndirectReducedKKTSolver(:MINRES)"
+QdldlKKTSolver = "QdldlKKTSolver"
+_KKT_KIND = {CGIndirectKKTSolver: _ffi.KKT_CG, MINRESIndirectKKTSolver: _ffi.KKT_MINRES,
+             IndirectReducedKKTSolverMINRES: _ffi.KKT_MINRES_REDUCED}
+
+
+@dataclass
+class OptionsFactory:
+    """`with_options(SolverType; kwargs...)` (src/settings.jl:3-17)."""
+    solver: str
+    kwargs: dict = field(default_factory=dict)
+
+
+def with_options(solver, **kwargs):
+    return OptionsFactory(solver, kwargs)
+
+
+@dataclass
+class Settings:
+    """Numeric fields of `COSMO.Settings` read by the hot path (src/settings.jl:101-139).  The accelerator is
+    always `EmptyAccelerator` (Anderson acceleration is a "next" row of SURVEY 8f)."""
+    rho: float = 0.1
+    sigma: float = 1e-6
+    alpha: float = 1.6
+    eps_abs: float = 1e-5
+    eps_rel: float = 1e-5
+    eps_prim_inf: float = 1e-4
+    eps_dual_inf: float = 1e-4
+    max_iter: int = 5000
+    verbose: bool = False
+    kkt_solver: Union[str, OptionsFactory] = CGIndirectKKTSolver   # reference default is QdldlKKTSolver (CPU)
+    check_termination: int = 25
+    check_infeasibility: int = 40
+    scaling: int = 10
+    MIN_SCALING: float = 1e-4
+    MAX_SCALING: float = 1e4
+    adaptive_rho: bool = True
+    adaptive_rho_interval: int = 40
+    adaptive_rho_tolerance: float = 5.0
+    adaptive_rho_max_adaptions: int = 2 ** 62
+    RHO_MIN: float = 1e-6
+    RHO_MAX: float = 1e6
+    RHO_TOL: float = 1e-4
+    RHO_EQ_OVER_RHO_INEQ: float = 1e3
+    COSMO_INFTY: float = 1e20
+    time_limit: float = 0.0
+    device: int = 0
+
+
+# ---- AbstractConvexSet subtypes on the hot path (src/convexset.jl) ---------------------------------------------------
+class AbstractConvexSet:
+    kind = -1
+
+    def __init__(self, dim):
+        if dim < 0:
+            raise ValueError("dimension must be nonnegative")     # DomainError in the reference
+        self.dim = int(dim)
+
+
+class ZeroSet(AbstractConvexSet):
+    kind = _ffi.ZERO
+
+
+class Nonnegatives(AbstractConvexSet):
+    kind = _ffi.NONNEG
+
+
+class SecondOrderCone(AbstractConvexSet):
+    kind = _ffi.SOC
+
+
+class PsdCone(AbstractConvexSet):
+    kind = _ffi.PSD_SQUARE
+
+    def __init__(self, dim):
+        super().__init__(dim)
+        r = math.isqrt(self.dim)
+        if r * r != self.dim:
+            raise ValueError("dimension must be a square")        # src/convexset.jl:280
+        self.sqrt_dim = r
+
+
+class PsdConeTriangle(AbstractConvexSet):
+    kind = _ffi.PSD_TRIANGLE
+
+    def __init__(self, dim):
+        super().__init__(dim)
+        self.sqrt_dim = (math.isqrt(1 + 8 * self.dim) - 1) // 2   # src/convexset.jl:372
+
+
+class Box(AbstractConvexSet):
+    kind = _ffi.BOX
+
+    def __init__(self, l, u):
+        l = np.array(l, dtype=np.float64).copy()
+        u = np.array(u, dtype=np.float64).copy()
+        if l.shape != u.shape:
+            raise ValueError("bounds must be same length")
+        bad = np.nonzero(l > u)[0]
+        if bad.size:                                              # src/convexset.jl:824-828
+            raise ValueError("Box set: inconsistent lower/upper bounds specified at index i = %d" % (bad[0] + 1))
+        super().__init__(l.size)
+        self.l, self.u = l, u
+
+
+class Constraint:
+    """`Constraint(A, b, K)`: A x + b in K (src/constraint.jl:47-108).  `K` may be a set instance or a set type."""
+
+    def __init__(self, A, b, convex_set, dim: int = 0, indices: Optional[range] = None):
+        A = sp.csc_matrix(np.atleast_2d(A) if not sp.issparse(A) else A, dtype=np.float64)
+        b = np.atleast_1d(np.array(b, dtype=np.float64)).ravel()
+        if A.shape[0] != b.size:
+            raise ValueError("The dimensions of matrix A and vector b don't match.")
+        if isinstance(convex_set, type):
+            convex_set = convex_set(A.shape[0])
+        if A.shape[0] != convex_set.dim:
+            raise ValueError("The row dimension of A doesn't match the dimension of the constraint set.")
+        if indices is not None:                                   # src/constraint.jl:63-70
+            Ac = sp.lil_matrix((A.shape[0], dim))
+            Ac[:, list(indices)] = A
+            A = Ac.tocsc()
+        self.A, self.b, self.convex_set = A, b, convex_set
+
+
+@dataclass
+class ResultInfo:
+    r_prim: float
+    r_dual: float
+    max_norm_prim: float
+    max_norm_dual: float
+    rho_updates: List[float]
+
+
+@dataclass
+class ResultTimes:
+    solver_time: float = 0.0
+    setup_time: float = 0.0
+    iter_time: float = 0.0
+    proj_time: float = 0.0
+
+
+@dataclass
+class Result:
+    """`COSMO.Result` (src/types.jl:93-112)."""
+    x: np.ndarray
+    y: np.ndarray
+    s: np.ndarray
+    obj_val: float
+    iter: int
+    status: str
+    info: ResultInfo
+    times: ResultTimes
+    kkt_iters_total: int = 0
+
+
+@dataclass
+class ScaleMatrices:
+    D: np.ndarray
+    Dinv: np.ndarray
+    E: np.ndarray
+    Einv: np.ndarray
+    c: float = 1.0
+    cinv: float = 1.0
+
+
+# ---- setup!: Ruiz equilibration (src/scaling.jl) ---------------------------------------------------------------------
+def _limit(v, lo, hi):
+    # limit_scaling! (src/scaling.jl:10-13): below MIN -> 1, above MAX -> MAX
+    return np.where(v < lo, 1.0, np.where(v > hi, hi, v))
+
+
+def _col_maxabs(M, out, reset):
+    if reset:
+        out[:] = 0.0
+    if M.nnz:
+        cols = np.repeat(np.arange(M.shape[1]), np.diff(M.indptr))
+        np.maximum.at(out, cols, np.abs(M.data))
+
+
+def _scale_csc(M, L, R):
+    if M.nnz:
+        cols = np.repeat(np.arange(M.shape[1]), np.diff(M.indptr))
+        f = np.ones(M.nnz)
+        if L is not None:
+            f = L[M.indices]
+            if R is not None:
+                f = f * R[cols]
+        elif R is not None:
+            f = R[cols]
+        M.data *= f
+
+
+def scale_ruiz(P, q, A, b, sets: Sequence[AbstractConvexSet], st: Settings) -> ScaleMatrices:
+    """`scale_ruiz!` (src/scaling.jl:21-116), in place on P, q, A, b and the Box bounds."""
+    m, n = A.shape
+    D = np.ones(n); E = np.ones(m); c = 1.0
+    Dw = np.ones(n); Ew = np.ones(m)
+    for _ in range(st.scaling):
+        _col_maxabs(P, Dw, True); _col_maxabs(A, Dw, False)
+        Ew[:] = 0.0
+        if A.nnz:
+            np.maximum.at(Ew, A.indices, np.abs(A.data))
+        Dw[:] = 1.0 / np.sqrt(_limit(Dw, st.MIN_SCALING, st.MAX_SCALING))
+        Ew[:] = 1.0 / np.sqrt(_limit(Ew, st.MIN_SCALING, st.MAX_SCALING))
+        _scale_csc(P, Dw, Dw); _scale_csc(A, Ew, Dw)
+        q *= Dw; b *= Ew; D *= Dw; E *= Ew
+        _col_maxabs(P, Dw, True)
+        mean_col = float(np.mean(Dw)) if n else 0.0
+        nq = float(np.max(np.abs(q))) if n else 0.0
+        if mean_col != 0.0 and nq != 0.0:
+            nq = float(_limit(nq, st.MIN_SCALING, st.MAX_SCALING))
+            sc = float(_limit(max(nq, mean_col), st.MIN_SCALING, st.MAX_SCALING))
+            ct = 1.0 / sc
+            P.data *= ct; q *= ct; c *= ct
+    off = 0
+    Ew[:] = 1.0
+    changed = False
+    for K in sets:                                                # rectify_set_scalings! (:129-142)
+        if K.kind in (_ffi.SOC, _ffi.PSD_SQUARE, _ffi.PSD_TRIANGLE) and K.dim > 0:
+            Ew[off:off + K.dim] = float(np.mean(E[off:off + K.dim])) / E[off:off + K.dim]
+            changed = True
+        off += K.dim
+    if changed:
+        _scale_csc(A, Ew, None); b *= Ew; E *= Ew
+    if (abs(P - P.T)).nnz != 0:                                    # symmetrize_full! (:99)
+        Ps = ((P + P.T) / 2.0).tocsc(); Ps.sort_indices()
+        P.data, P.indices, P.indptr = Ps.data, Ps.indices, Ps.indptr
+    off = 0
+    for K in sets:                                                # scale_sets! (:145-154)
+        if K.kind == _ffi.BOX:
+            K.l *= E[off:off + K.dim]; K.u *= E[off:off + K.dim]
+        off += K.dim
+    return ScaleMatrices(D, 1.0 / D, E, 1.0 / E, c, 1.0 / c)
+
+
+_SORT = {_ffi.ZERO: 1, _ffi.NONNEG: 2, _ffi.BOX: 3, _ffi.SOC: 4, _ffi.PSD_SQUARE: 5, _ffi.PSD_TRIANGLE: 6}
+
+
+def _copy_set(K):
+    if isinstance(K, Box):
+        return Box(K.l, K.u)
+    return type(K)(K.dim)
+
+
+class Model:
+    """`COSMO.Model` / `Workspace` (src/types.jl:348-403) as far as the hot path needs it."""
+
+    def __init__(self):
+        self.P = self.q = self.A = self.b = None
+        self.sets: List[AbstractConvexSet] = []
+        self.settings = Settings()
+        self.is_assembled = False
+        self.is_scaled = False
+        self.is_optimized = False
+        self.sm: Optional[ScaleMatrices] = None
+        self.handle: Optional[_ffi.Handle] = None
+        self.x = self.s = self.mu = None
+        self.n = self.m = 0
+
+    # set! (src/interface.jl:218-250): data already in internal sign convention (A x + s = b)
+    def set(self, P, q, A, b, convex_sets: Sequence[AbstractConvexSet], settings: Optional[Settings] = None):
+        P = sp.csc_matrix(P, dtype=np.float64, copy=True); A = sp.csc_matrix(A, dtype=np.float64, copy=True)
+        P.sort_indices(); A.sort_indices()
+        q = np.array(q, dtype=np.float64).ravel().copy(); b = np.array(b, dtype=np.float64).ravel().copy()
+        n = q.size; m = b.size
+        if P.shape != (n, n) or A.shape != (m, n):
+            raise ValueError("The dimensions of P, q, A, b are inconsistent.")
+        if sum(K.dim for K in convex_sets) != m:
+            raise ValueError("The dimensions of the convex sets don't match the number of rows of A.")
+        self.empty()
+        self.P, self.q, self.A, self.b = P, q, A, b
+        self.sets = [_copy_set(K) for K in convex_sets]
+        self.n, self.m = n, m
+        if settings is not None:
+            self.settings = settings
+        self.x = np.zeros(n); self.s = np.zeros(m); self.mu = np.zeros(m)
+        self.is_assembled = True
+
+    def empty(self):
+        """`empty_model!` (src/interface.jl:98-114)."""
+        if self.handle is not None:
+            self.handle.close()
+        self.handle = None
+        self.is_assembled = self.is_scaled = self.is_optimized = False
+        self.sm = None
+
+
+def assemble(model: Model, P, q, constraints: Union[Constraint, Sequence[Constraint]], settings: Optional[Settings] = None,
+             x0=None, y0=None):
+    """`assemble!` (src/interface.jl:30-77): merge Zero/Nonnegatives constraints, stable-sort the sets
+    Zero < Nonneg < Box < SOC < Psd < PsdTriangle, and store A := -A_c, b := b_c (:478-484)."""
+    cons = [constraints] if isinstance(constraints, Constraint) else list(constraints)
+    for kind, ctor in ((_ffi.ZERO, ZeroSet), (_ffi.NONNEG, Nonnegatives)):
+        idx = [i for i, c in enumerate(cons) if c.convex_set.kind == kind]
+        if len(idx) > 1:
+            Am = sp.vstack([cons[i].A for i in idx], format="csc")
+            bm = np.concatenate([cons[i].b for i in idx])
+            cons = [c for i, c in enumerate(cons) if i not in idx]
+            cons.append(Constraint(Am, bm, ctor(bm.size)))
+    cons.sort(key=lambda c: _SORT[c.convex_set.kind])
+    A = sp.vstack([-c.A for c in cons], format="csc")
+    b = np.concatenate([c.b for c in cons])
+    model.set(P, q, A, b, [c.convex_set for c in cons], settings)
+    if x0 is not None:
+        warm_start_primal(model, x0)
+    if y0 is not None:
+        warm_start_dual(model, y0)
+
+
+def warm_start_primal(model: Model, x0):
+    """`warm_start_primal!` with a full vector also warm starts s = b - A x (src/interface.jl:130-148)."""
+    x0 = np.array(x0, dtype=np.float64)
+    model.x[:] = x0
+    if model.is_scaled:
+        xs = model.sm.Dinv * x0
+        model.s[:] = model.sm.Einv * (model.b - model.A @ xs)
+    else:
+        model.s[:] = model.b - model.A @ x0
+
+
+def warm_start_slack(model: Model, s0):
+    model.s[:] = np.array(s0, dtype=np.float64)
+
+
+def warm_start_dual(model: Model, y0):
+    model.mu[:] = -np.array(y0, dtype=np.float64)                 # src/interface.jl:167
+
+
+def update(model: Model, q=None, b=None):
+    """`COSMO.update!` (src/interface.jl:187-211)."""
+    if not model.is_assembled:
+        raise RuntimeError("Model has to be assembled once before one can start updating q or b.")
+    if q is not None:
+        q = np.array(q, dtype=np.float64)
+        if q.size != model.n:
+            raise ValueError("The dimension of q, does not agree with the model dimension, n.")
+        model.q = (model.sm.D * q) * model.sm.c if model.is_scaled else q.copy()
+    if b is not None:
+        b = np.array(b, dtype=np.float64)
+        if b.size != model.m:
+            raise ValueError("The dimension of b, does not agree with the model dimension, m.")
+        model.b = model.sm.E * b if model.is_scaled else b.copy()
+    if model.handle is not None:
+        model.handle.update_qb(model.q if q is not None else None, model.b if b is not None else None)
+
+
+def _params_from_settings(h: _ffi.Handle, st: Settings):
+    p = h.default_params()
+    kkt = st.kkt_solver
+    kw = {}
+    if isinstance(kkt, OptionsFactory):
+        kw = kkt.kwargs
+        kkt = kkt.solver
+    if kkt == QdldlKKTSolver:
+        raise NotImplementedError("QdldlKKTSolver is the reference's CPU direct solver (config 1, plumbing only); "
+                                  "the MI355X path provides CGIndirectKKTSolver / MINRESIndirectKKTSolver")
+    if kkt not in _KKT_KIND:
+        raise ValueError("unknown kkt_solver %r" % (kkt,))
+    p.kkt_kind = _KKT_KIND[kkt]
+    p.tol_constant = float(kw.get("tol_constant", 1.0))
+    p.tol_exponent = float(kw.get("tol_exponent", 1.5))
+    p.sigma, p.alpha, p.rho = st.sigma, st.alpha, st.rho
+    p.eps_abs, p.eps_rel = st.eps_abs, st.eps_rel
+    p.eps_prim_inf, p.eps_dual_inf = st.eps_prim_inf, st.eps_dual_inf
+    p.rho_min, p.rho_max, p.rho_tol = st.RHO_MIN, st.RHO_MAX, st.RHO_TOL
+    p.rho_eq_over_rho_ineq = st.RHO_EQ_OVER_RHO_INEQ
+    p.adaptive_rho_tolerance = st.adaptive_rho_tolerance
+    p.cosmo_infty_min_scaling = st.COSMO_INFTY * st.MIN_SCALING
+    p.time_limit = st.time_limit
+    p.max_iter = st.max_iter
+    p.adaptive_rho_max_adaptions = min(st.adaptive_rho_max_adaptions, 2 ** 62)
+    p.check_termination = st.check_termination
+    p.check_infeasibility = st.check_infeasibility
+    p.adaptive_rho = 1 if st.adaptive_rho else 0
+    p.adaptive_rho_interval = st.adaptive_rho_interval
+    p.unscale_residuals = 1 if st.scaling != 0 else 0
+    return p
+
+
+def setup(model: Model):
+    """`setup!` (src/setup.jl:18-64): scaling once, then hand the scaled problem to the device library
+    (the `_make_kkt_solver!` step, :1-7, is where the reference constructs its AbstractKKTSolver plugin)."""
+    st = model.settings
+    if st.scaling != 0 and not model.is_scaled:
+        model.sm = scale_ruiz(model.P, model.q, model.A, model.b, model.sets, st)
+        model.is_scaled = True
+    elif model.sm is None:
+        model.sm = ScaleMatrices(np.ones(model.n), np.ones(model.n), np.ones(model.m), np.ones(model.m), 1.0, 1.0)
+    sm = model.sm
+    # scale_variables! (src/scaling.jl:118-123)
+    model.x = sm.Dinv * model.x
+    model.mu = (sm.Einv * model.mu) * sm.c
+    model.s = sm.E * model.s
+    if model.handle is None:
+        h = _ffi.Handle(st.device)
+        h.set_problem(model.P, model.q, model.A, model.b)
+        bl = np.concatenate([K.l for K in model.sets if K.kind == _ffi.BOX] or [np.zeros(0)])
+        bu = np.concatenate([K.u for K in model.sets if K.kind == _ffi.BOX] or [np.zeros(0)])
+        h.set_cones([K.kind for K in model.sets], [K.dim for K in model.sets], bl, bu)
+        h.set_params(_params_from_settings(h, st))                 # set_rho_vec! happens inside (first solve only)
+        h.set_scaling(sm.Dinv, sm.Einv, sm.cinv)
+        model.handle = h
+
+
+def optimize(model: Model) -> Result:
+    """`COSMO.optimize!` (src/solver.jl:78-203) with the `while` loop running on the MI355X."""
+    import time
+    if not model.is_assembled:
+        raise RuntimeError("The model has to be assembled! / set! before optimize!() can be called.")
+    t0 = time.perf_counter()
+    setup(model)
+    t_setup = time.perf_counter() - t0
+    h, sm, n = model.handle, model.sm, model.n
+    h.set_iterates(model.x, model.s, model.mu)                    # solver.jl:128-129
+    r = h.optimize()                                              # solver.jl:137-176
+    w, w_prev, s, mu = h.get_iterates()
+    model.is_optimized = True
+    x = w_prev[:n].copy()                                          # x is a view of w_prev (src/types.jl:274)
+    if model.settings.scaling != 0:                               # reverse_scaling! (src/scaling.jl:170-179)
+        x = sm.D * x
+        s = sm.Einv * s
+        mu = (sm.E * mu) * sm.cinv
+    model.x, model.s, model.mu = x.copy(), s.copy(), mu.copy()
+    info = ResultInfo(r.r_prim, r.r_dual, r.max_norm_prim, r.max_norm_dual,
+                      [r.rho_updates[i] for i in range(min(r.n_rho_updates, _ffi.MAX_RHO_UPDATES))])
+    times = ResultTimes(time.perf_counter() - t0, t_setup, r.iter_time, r.proj_time)
+    return Result(x=x, y=-mu, s=s, obj_val=r.cost, iter=int(r.iter), status=_ffi.STATUS_NAMES[r.status], info=info,
+                  times=times, kkt_iters_total=int(r.kkt_iters_total))

@@ -1,0 +1,219 @@
+/* cosmo_hip.h -- C ABI of libcosmo_hip.so: the MI355X (gfx950) implementation of COSMO's per-iteration
+ * ADMM hot path.  This header is the drop-in boundary.
+ *
+ * The reference (oxfordcontrol/COSMO.jl v0.8.11, pure Julia) has no FFI for this path; its plugin
+ * surfaces are Julia multiple-dispatch interfaces.  Each entry point below names the reference
+ * interface (file:line under /root/reference) that a Julia `ccall` binding replaces with it; the
+ * binding itself is shown in INTEGRATION.md and julia/CosmoHIP.jl.
+ *
+ * Conventions
+ *  - every function returns an int32 status (COSMO_HIP_OK == 0); nothing throws, nothing calls back;
+ *  - host arrays are caller-owned and never retained after return; device memory is owned by the handle;
+ *  - sparse matrices are passed exactly as Julia stores SparseMatrixCSC{Float64,Int64}: CSC, 1-based
+ *    colptr[ncols+1], rowval[nnz], nzval[nnz], row indices sorted within a column;
+ *  - the problem is in COSMO's INTERNAL, already scaled form  min 1/2 x'Px + q'x  s.t.  A x + s = b, s in K
+ *    (src/interface.jl:478-484, src/scaling.jl:21-116);
+ *  - all vectors are dense Float64; n = #variables, m = #constraint rows;
+ *  - one handle is driven by one host thread at a time; several handles may be driven concurrently.
+ */
+#ifndef COSMO_HIP_H
+#define COSMO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cosmo_hip_handle cosmo_hip_handle;
+
+/* ---- status codes -------------------------------------------------------------------------------- */
+enum {
+  COSMO_HIP_OK = 0,
+  COSMO_HIP_ERR_INVALID = 1,     /* bad argument / call order                                          */
+  COSMO_HIP_ERR_HIP = 2,         /* a HIP runtime call failed (no device, out of memory, ...)           */
+  COSMO_HIP_ERR_NOT_CONVEX = 3,  /* CG breakdown u'Lu <= 0  (reference: error("... not convex"),
+                                    src/linear_solver/kktsolver.jl:304)                                */
+  COSMO_HIP_ERR_NONFINITE = 4,   /* non-finite iterate                                                 */
+  COSMO_HIP_ERR_EIG = 5,         /* eigen-solver did not converge (reference: chklapackerror,
+                                    src/convexset.jl:186)                                              */
+  COSMO_HIP_ERR_UNSUPPORTED = 6, /* feature not built (e.g. a cone type outside SURVEY 8a)              */
+  COSMO_HIP_ERR_COMM = 7         /* RCCL failure                                                        */
+};
+
+/* ---- cone types: AbstractConvexSet subtypes on the hot path (src/convexset.jl) -------------------- */
+enum {
+  COSMO_HIP_ZERO = 0,        /* ZeroSet          src/convexset.jl:16-28   */
+  COSMO_HIP_NONNEG = 1,      /* Nonnegatives     src/convexset.jl:52-74   */
+  COSMO_HIP_BOX = 2,         /* Box              src/convexset.jl:803-847 */
+  COSMO_HIP_SOC = 3,         /* SecondOrderCone  src/convexset.jl:92-114  */
+  COSMO_HIP_PSD_SQUARE = 4,  /* PsdCone          src/convexset.jl:271-321 */
+  COSMO_HIP_PSD_TRIANGLE = 5 /* PsdConeTriangle  src/convexset.jl:362-412 */
+};
+
+/* ---- KKT solver kinds: AbstractKKTSolver subtypes (src/linear_solver/kktsolver_indirect.jl) -------- */
+enum {
+  COSMO_HIP_KKT_CG = 0,             /* CGIndirectKKTSolver      :173-178 (IndirectReducedKKTSolver, :CG)     */
+  COSMO_HIP_KKT_MINRES_REDUCED = 1, /* IndirectReducedKKTSolver :3-88 with solver_type = :MINRES            */
+  COSMO_HIP_KKT_MINRES = 2          /* MINRESIndirectKKTSolver  :180-185 (IndirectKKTSolver, full KKT)      */
+};
+
+/* ---- solver status (Result.status symbols, src/solver.jl:113,175,312,318,338,344,353) -------------- */
+enum {
+  COSMO_HIP_UNDETERMINED = 0,
+  COSMO_HIP_SOLVED = 1,
+  COSMO_HIP_MAX_ITER_REACHED = 2,
+  COSMO_HIP_UNSOLVED = 3,
+  COSMO_HIP_PRIMAL_INFEASIBLE = 4,
+  COSMO_HIP_DUAL_INFEASIBLE = 5,
+  COSMO_HIP_TIME_LIMIT_REACHED = 6
+};
+
+/* ---- which matrix for cosmo_hip_spmv --------------------------------------------------------------- */
+enum { COSMO_HIP_MAT_A = 0, COSMO_HIP_MAT_AT = 1, COSMO_HIP_MAT_P = 2 };
+
+/* Numeric fields of COSMO.Settings that the hot path reads (src/settings.jl:101-139). */
+typedef struct cosmo_hip_params {
+  double sigma;                      /* 1e-6  */
+  double alpha;                      /* 1.6   */
+  double rho;                        /* 0.1   */
+  double eps_abs, eps_rel;           /* 1e-5  */
+  double eps_prim_inf, eps_dual_inf; /* 1e-4  */
+  double tol_constant, tol_exponent; /* 1.0, 1.5  (kktsolver_indirect.jl:21) */
+  double rho_min, rho_max;           /* RHO_MIN 1e-6, RHO_MAX 1e6 */
+  double rho_tol;                    /* RHO_TOL 1e-4 */
+  double rho_eq_over_rho_ineq;       /* 1e3 */
+  double adaptive_rho_tolerance;     /* 5 */
+  double cosmo_infty_min_scaling;    /* COSMO_INFTY * MIN_SCALING = 1e20*1e-4 (src/setup.jl:79-81) */
+  double time_limit;                 /* 0 = none */
+  int64_t max_iter;                  /* 5000 */
+  int64_t adaptive_rho_max_adaptions;/* typemax(Int) */
+  int32_t kkt_kind;                  /* COSMO_HIP_KKT_* */
+  int32_t check_termination;         /* 25 */
+  int32_t check_infeasibility;       /* 40 */
+  int32_t adaptive_rho;              /* 1 */
+  int32_t adaptive_rho_interval;     /* 40 (0 = wall-clock rule, src/solver.jl:244-256: not supported) */
+  int32_t unscale_residuals;         /* 1 iff settings.scaling != 0 (src/residuals.jl:43) */
+} cosmo_hip_params;
+
+/* What `optimize!` returns to its caller besides the iterates (Result / ResultInfo, src/types.jl:65-112). */
+#define COSMO_HIP_MAX_RHO_UPDATES 64
+typedef struct cosmo_hip_result {
+  int32_t status;                    /* COSMO_HIP_SOLVED ... */
+  int32_t n_rho_updates;             /* length(ws.rho_updates) (>= 1) */
+  int64_t iter;                      /* ADMM iterations performed */
+  int64_t kkt_iters_total;           /* sum of CG/MINRES iterations over all solves */
+  int64_t kkt_solves;                /* number of solve! calls (IndirectReducedKKTSolver.iteration_counter - 1) */
+  double cost;                       /* cinv * (1/2 x'Px + q'x) at the last check (src/residuals.jl:143-147) */
+  double r_prim, r_dual, max_norm_prim, max_norm_dual; /* ResultInfo */
+  double rho;                        /* ws.rho at exit */
+  double iter_time;                  /* seconds in the while loop: ws.times.iter_time (src/solver.jl:134,169) */
+  double proj_time;                  /* seconds in admm_z! projections (ws.times.proj_time) -- measured with HIP events */
+  double rho_updates[COSMO_HIP_MAX_RHO_UPDATES];
+} cosmo_hip_result;
+
+/* ---- lifecycle -------------------------------------------------------------------------------------- */
+/* Creates a handle bound to HIP device `device_id` (one process per GPU; the handle owns one stream). */
+int32_t cosmo_hip_create(cosmo_hip_handle** h, int32_t device_id);
+/* Idempotent.  Replaces AbstractKKTSolver free_memory! (src/linear_solver/kktsolver.jl:351; called from
+ * src/solver.jl:200,206-208) and is what the Julia finalizer of the wrapper calls. */
+int32_t cosmo_hip_destroy(cosmo_hip_handle* h);
+/* Last error text of this handle (valid until the next call on it); never NULL. */
+const char* cosmo_hip_last_error(const cosmo_hip_handle* h);
+/* ABI version of the library (major*1000 + minor). */
+int32_t cosmo_hip_version(void);
+void cosmo_hip_default_params(cosmo_hip_params* p);
+
+/* ---- problem data ----------------------------------------------------------------------------------- */
+/* Replaces the AbstractKKTSolver constructor T(P, A, sigma, rho) (src/linear_solver/kktsolver.jl:5-11;
+ * called from _make_kkt_solver!, src/setup.jl:1-7) together with the (q, b) the loop reads from ws.p
+ * (src/solver.jl:137,154).  P (n x n, full symmetric storage) and A (m x n) are the SCALED matrices. */
+int32_t cosmo_hip_set_problem(cosmo_hip_handle* h, int64_t n, int64_t m,
+                              const int64_t* P_colptr, const int64_t* P_rowval, const double* P_nzval,
+                              const int64_t* A_colptr, const int64_t* A_rowval, const double* A_nzval,
+                              const double* q, const double* b);
+/* Replaces ws.p.C::CompositeConvexSet (src/projections.jl:20-31) + get_set_indices
+ * (src/convexset.jl:985-993) + classify_constraints! (src/setup.jl:75-85).  `type[k]`, `dim[k]` per cone in
+ * row order; box_l/box_u are the concatenated (already E-scaled, src/convexset.jl:863-867) bounds of all Box
+ * cones in order (may be NULL when there is no Box). */
+int32_t cosmo_hip_set_cones(cosmo_hip_handle* h, int64_t ncones, const int32_t* type, const int64_t* dim,
+                            const double* box_l, const double* box_u);
+/* Settings fields (src/settings.jl) + initial rho vector: set_rho_vec! (src/parameters.jl:3-13).
+ * rho_vec may be NULL: then it is built from p->rho and the row classes exactly as the reference does. */
+int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_params* p, const double* rho_vec);
+/* Replaces update_rho!(kkt_solver, rho_vec) (src/linear_solver/kktsolver_indirect.jl:164-166; called from
+ * update_rho_vec!, src/parameters.jl:85-89). */
+int32_t cosmo_hip_update_rho(cosmo_hip_handle* h, const double* rho_vec);
+/* ScaleMatrices Dinv (n), Einv (m), cinv used ONLY to unscale residuals (src/residuals.jl:43-49,66-92).
+ * NULL pointers mean identity. */
+int32_t cosmo_hip_set_scaling(cosmo_hip_handle* h, const double* Dinv, const double* Einv, double cinv);
+/* Replaces COSMO.update!(model; q, b) on already-scaled vectors (src/interface.jl:187-211). NULL = keep. */
+int32_t cosmo_hip_update_qb(cosmo_hip_handle* h, const double* q, const double* b);
+/* Per-row rho class computed by the library: 0 = rho, 1 = rho*RHO_EQ_OVER_RHO_INEQ, 2 = RHO_MIN
+ * (apply_constraint_rho_scaling!, src/parameters.jl:17-49) -- integer bookkeeping, compared bit-exactly. */
+int32_t cosmo_hip_get_rho_classes(cosmo_hip_handle* h, int32_t* cls /* m */);
+int32_t cosmo_hip_get_rho_vec(cosmo_hip_handle* h, double* rho_vec /* m */);
+
+/* ---- fine-grained plugin entry points (host pointers, synchronous) ----------------------------------- */
+/* Replaces solve!(kkt_solver, lhs, rhs) (src/linear_solver/kktsolver.jl:5-11, kktsolver_indirect.jl:36-88,
+ * 123-162; called from admm_x!, src/solver.jl:52).  lhs, rhs have length n+m.  kkt_iters_out may be NULL. */
+int32_t cosmo_hip_kkt_solve(cosmo_hip_handle* h, double* lhs, const double* rhs, int64_t* kkt_iters_out);
+/* Replaces project!(s::SplitVector, C::CompositeConvexSet) (src/convexset.jl:885-891) on a host vector of
+ * length m, in place.  psd_rank_out[k] (per cone, -1 for non-PSD cones) = nnz_lambda of rank_k_update!
+ * (src/convexset.jl:247-256); soc_branch_out[k] (per cone, -1 for non-SOC) = 0 keep / 1 zero / 2 scale
+ * (src/convexset.jl:104-112).  Either may be NULL. */
+int32_t cosmo_hip_project(cosmo_hip_handle* h, double* s, int64_t* psd_rank_out, int32_t* soc_branch_out);
+/* Replaces mul!(y, A, x), mul!(y, A', x), mul!(y, P, x) (src/residuals.jl:4,12,15). */
+int32_t cosmo_hip_spmv(cosmo_hip_handle* h, int32_t which, double* y, const double* x);
+
+/* ---- coarse device-resident loop (the performance path; replaces the body of optimize!) ------------- */
+/* Warm start: w[1:n] = x0 ; w[n+1:] = 1/rho .* mu0 + s0 ; s = s0 (src/solver.jl:128-129).  NULL = zeros. */
+int32_t cosmo_hip_set_iterates(cosmo_hip_handle* h, const double* x0, const double* s0, const double* mu0);
+/* admm_x! ; admm_w! once (src/solver.jl:137-138). */
+int32_t cosmo_hip_admm_init(cosmo_hip_handle* h);
+/* n_iters times the loop body admm_z! / apply_rho_adaptation_rules! / admm_x! / admm_w!
+ * (src/solver.jl:151-155) with NO termination checks; iteration numbering continues from the handle's
+ * counter (so rho adaptation fires at the same iterations as in the reference). */
+int32_t cosmo_hip_admm_iterate(cosmo_hip_handle* h, int64_t n_iters);
+/* Same, but WITH check_termination! at the reference's schedule (iter % check_termination == 0 || iter == 1,
+ * src/solver.jl:306) counted on the handle's absolute iteration counter; stops early when a status is decided.
+ * This is the timed region of the BASELINE metric (iter_time includes the checks, src/solver.jl:134,169).
+ * status_out receives COSMO_HIP_UNDETERMINED or the decided status. */
+int32_t cosmo_hip_admm_iterate_checked(cosmo_hip_handle* h, int64_t n_iters, int32_t* status_out);
+/* recover_mu! + calculate_result_info! + calculate_cost! (src/solver.jl:307-310, src/residuals.jl:30-96,
+ * 143-153) on the current iterates: out = {r_prim, r_dual, max_norm_prim, max_norm_dual, cost}. */
+int32_t cosmo_hip_residuals(cosmo_hip_handle* h, double out[5]);
+/* The whole `while` loop of optimize! (src/solver.jl:137-176): init step, iterations with
+ * check_termination!/adaptive rho at the reference's schedule, final recover_mu!.  Iterates stay on the
+ * device; fetch them with cosmo_hip_get_iterates. */
+int32_t cosmo_hip_optimize(cosmo_hip_handle* h, cosmo_hip_result* result);
+/* Copies back what the unchanged epilogue of optimize! needs (src/solver.jl:167-201): w, w_prev (n+m each),
+ * s (m), mu (m) with mu = rho .* (w_prev[n+1:] - s) recovered first.  Any pointer may be NULL. */
+int32_t cosmo_hip_get_iterates(cosmo_hip_handle* h, double* w, double* w_prev, double* s, double* mu);
+/* sol = [x_tl; nu] of the last KKT solve (ws.sol, src/solver.jl:227-228), length n+m. */
+int32_t cosmo_hip_get_kkt_solution(cosmo_hip_handle* h, double* sol);
+/* Statistics of the device loop since set_iterates: out = {admm_iters, kkt_solves, kkt_iters_total,
+ * kkt_budget_stalls, spmv_A_calls, spmv_AT_calls, spmv_P_calls, rho_updates}. */
+int32_t cosmo_hip_get_stats(cosmo_hip_handle* h, int64_t out[8]);
+
+/* ---- measurement hooks (bench.py / rocprof cross-check) ----------------------------------------------- */
+/* Times `reps` back-to-back launches of the SpMV kernel `which` (COSMO_HIP_MAT_A/AT/P, or 3 = the fused
+ * [P A'] operator kernel of the CG apply) with HIP events on the handle's stream; returns the average
+ * seconds per launch and the ALGORITHMIC bytes of one launch. */
+int32_t cosmo_hip_time_spmv(cosmo_hip_handle* h, int32_t which, int32_t reps, double* avg_seconds,
+                            double* algorithmic_bytes);
+/* Per-kernel-class durations measured with HIP events on the handle's stream.
+ * on = 0: off.  on = 1: events around every loop kernel + exact launches.  on = 2: exact launches only (for rocprofv3).
+ * "Exact launches": the host synchronises after every Krylov iteration, so no budgeted launch is a guarded no-op and
+ * every launch of a kernel does its full work -- per-kernel averages (events or rocprof) are then comparable with the
+ * algorithmic bytes of one launch.  Kernel durations are GPU-side and not affected by the host pacing. */
+int32_t cosmo_hip_set_profiling(cosmo_hip_handle* h, int32_t on);
+#define COSMO_HIP_NUM_KERNEL_CLASSES 16
+int32_t cosmo_hip_get_kernel_times(cosmo_hip_handle* h, double seconds[COSMO_HIP_NUM_KERNEL_CLASSES],
+                                   int64_t launches[COSMO_HIP_NUM_KERNEL_CLASSES]);
+const char* cosmo_hip_kernel_class_name(int32_t k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COSMO_HIP_H */

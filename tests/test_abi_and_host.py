@@ -1,0 +1,142 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every symbol include/cosmo_hip.h declares, the ctypes
+table matches the header, the library fails loudly without a GPU, and the host-side mirror of the reference interface
+(assemble!, setup!/scale_ruiz!, update!) agrees with the oracle's restatement."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import cosmo_jl_amd as cj
+from oracle import cosmo_oracle as O
+from tests import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "cosmo_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cosmo_hip_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_header_symbol():
+    names = _header_functions()
+    assert len(names) >= 25
+    lib = ctypes.CDLL(cj._ffi.LIB_PATH)
+    for nm in names:
+        assert hasattr(lib, nm), "libcosmo_hip.so does not export %s" % nm
+    assert set(cj._ffi.SIGNATURES) == set(names)              # the binding covers the whole header, nothing else
+    assert cj.load_library().cosmo_hip_version() == 1000
+
+
+def test_struct_layouts_match_header():
+    # field order/size of the two ABI structs (guards against silent drift between header and binding)
+    src = open(os.path.join(ROOT, "include", "cosmo_hip.h")).read()
+    body = re.search(r"typedef struct cosmo_hip_params \{(.*?)\} cosmo_hip_params;", src, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        typ, rest = decl.split(None, 1)
+        fields += [f.strip() for f in rest.split(",")]
+    assert fields == [f[0] for f in cj._ffi.Params._fields_]
+    assert ctypes.sizeof(cj._ffi.Params) == 16 * 8 + 2 * 8 + 6 * 4
+    assert ctypes.sizeof(cj._ffi.ResultStruct) == 2 * 4 + 3 * 8 + 8 * 8 + 64 * 8
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(cj.CosmoHipError) as e:
+        cj.Handle(0)
+    assert e.value.code == 2                                  # COSMO_HIP_ERR_HIP: fail loudly, never compute on the CPU
+    model = cj.Model()
+    model.set(np.eye(2), np.zeros(2), np.eye(2), np.zeros(2), [cj.Nonnegatives(2)])
+    with pytest.raises(cj.CosmoHipError):
+        cj.optimize(model)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "cosmo.jl_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".jl")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "oracle/" not in txt, f
+
+
+def test_default_params_match_reference_settings():
+    p = cj._ffi.Params()
+    cj.load_library().cosmo_hip_default_params(ctypes.byref(p))
+    st = O.Settings()                                         # src/settings.jl:101-139
+    assert (p.sigma, p.alpha, p.rho, p.eps_abs, p.eps_rel) == (st.sigma, st.alpha, st.rho, st.eps_abs, st.eps_rel)
+    assert (p.max_iter, p.check_termination, p.check_infeasibility, p.adaptive_rho_interval) == (5000, 25, 40, 40)
+    assert (p.rho_min, p.rho_max, p.rho_tol, p.rho_eq_over_rho_ineq, p.adaptive_rho_tolerance) == (1e-6, 1e6, 1e-4, 1e3, 5.0)
+    assert p.cosmo_infty_min_scaling == 1e20 * 1e-4 and p.tol_constant == 1.0 and p.tol_exponent == 1.5
+
+
+def test_assemble_sorts_merges_and_negates():
+    # src/interface.jl:30-77,411-484 ; test/UnitTests/interface.jl:53
+    rng = np.random.default_rng(0)
+    n = 4
+    cs = [cj.Constraint(rng.standard_normal((3, n)), rng.standard_normal(3), cj.SecondOrderCone),
+          cj.Constraint(rng.standard_normal((2, n)), rng.standard_normal(2), cj.Nonnegatives),
+          cj.Constraint(rng.standard_normal((1, n)), rng.standard_normal(1), cj.ZeroSet),
+          cj.Constraint(rng.standard_normal((2, n)), rng.standard_normal(2), cj.Box([0.0, 0], [1.0, 1])),
+          cj.Constraint(rng.standard_normal((2, n)), rng.standard_normal(2), cj.Nonnegatives),
+          cj.Constraint(rng.standard_normal((3, n)), rng.standard_normal(3), cj.PsdConeTriangle)]
+    model = cj.Model()
+    cj.assemble(model, np.eye(n), np.zeros(n), cs)
+    assert [type(K).__name__ for K in model.sets] == ["ZeroSet", "Nonnegatives", "Box", "SecondOrderCone", "PsdConeTriangle"]
+    assert [K.dim for K in model.sets] == [1, 4, 2, 3, 3]
+    Ao, bo, cones = O.assemble([O.Constraint(c.A, c.b, util.oracle_cones([c.convex_set])[0]) for c in cs])
+    assert np.array_equal(model.A.toarray(), Ao.toarray()) and np.array_equal(model.b, bo)
+    assert np.array_equal(model.A.toarray()[:1], -cs[2].A.toarray())
+    with pytest.raises(ValueError):
+        cj.Constraint(np.eye(3), np.zeros(2), cj.Nonnegatives)
+    with pytest.raises(ValueError):
+        cj.Box([1.0], [0.0])
+    with pytest.raises(ValueError):
+        cj.PsdCone(5)
+    with pytest.raises(RuntimeError):
+        cj.optimize(cj.Model())
+
+
+def test_host_scale_ruiz_equals_oracle():
+    rng = np.random.default_rng(2)
+    prob = util.random_qp(rng, 30, 3, 20, 25, soc_dims=(4, 5), psd_tri_dims=(3,))
+    st = cj.Settings()
+    P = prob["P"].copy(); A = prob["A"].copy(); q = prob["q"].copy(); b = prob["b"].copy()
+    model = cj.Model(); model.set(P, q, A, b, prob["sets"], st)
+    sm = cj.model.scale_ruiz(model.P, model.q, model.A, model.b, model.sets, st)
+    ws = O.Workspace(prob["P"], prob["q"], prob["A"], prob["b"], util.oracle_cones(prob["sets"]), O.Settings())
+    for a, b_ in ((sm.D, ws.sm.D), (sm.E, ws.sm.E), (model.q, ws.q), (model.b, ws.b), (model.P.toarray(), ws.P.toarray()),
+                  (model.A.toarray(), ws.A.toarray())):
+        assert np.array_equal(a, b_)
+    assert sm.c == ws.sm.c
+    box_m = [K for K in model.sets if K.kind == cj._ffi.BOX][0]; box_o = [c for c in ws.cones if c.kind == O.BOX][0]
+    assert np.array_equal(box_m.l, box_o.l) and np.array_equal(box_m.u, box_o.u)
+
+
+def test_generators_are_deterministic_and_shaped():
+    p1 = cj.problems.sparse_box_qp(n=2000, m=4000, nnz=40000); p2 = cj.problems.sparse_box_qp(n=2000, m=4000, nnz=40000)
+    assert (p1["A"] != p2["A"]).nnz == 0 and np.array_equal(p1["q"], p2["q"])
+    assert p1["A"].shape == (4000, 2000) and abs(p1["A"].nnz - 40000) < 400
+    K = p1["sets"][0]
+    assert 0.07 < np.mean(K.l == K.u) < 0.13 and 0.03 < np.mean(K.l < -1e29) < 0.07
+    p = cj.problems.socp()
+    assert p["A"].shape == (1000, 500) and len(p["sets"]) == 50 and all(K.dim == 20 for K in p["sets"])
+    p = cj.problems.closest_correlation(d=30)
+    assert p["A"].shape == (30 + 465, 465) and [K.dim for K in p["sets"]] == [30, 465]
+    x = cj.problems.svec(p["C"]); assert np.allclose(cj.problems.smat(x), p["C"])
+    p = cj.problems.chordal_sdp(ncliques=12, dmin=4, dmax=9, sep_min=1, sep_max=3, n_total=400, n_zero=10, n_nonneg=20)
+    assert p["A"].shape[1] == 400 and p["A"].shape[0] == sum(K.dim for K in p["sets"])
+    # feasible by construction: oracle solves it
+    res = O.solve(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), O.Settings(max_iter=3000))
+    assert res.status == "Solved"

@@ -1,0 +1,329 @@
+"""GPU parity tests (run with `-m gpu` on a MI355X): every call goes through the C ABI of libcosmo_hip.so and is
+compared with the CPU oracle on identical seeded inputs.  Tolerances are those of SURVEY.md 8c and are written at
+each assertion.  Bit-exact = `np.array_equal` on the float64 bit patterns (via view(int64) where -0.0 matters).
+"""
+import math
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import cosmo_jl_amd as cj
+from oracle import cosmo_oracle as O
+from tests import util
+from tests.util import EPS
+
+pytestmark = pytest.mark.gpu
+F = cj._ffi
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.int64)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a17: SpMV with A, A', P
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(300, 200, 0.05), (1000, 1500, 0.01), (50, 4000, 0.3), (4000, 30, 0.5), (7, 5, 1.0)])
+def test_spmv_matches_oracle(shape):
+    m, n, dens = shape
+    rng = np.random.default_rng(7 + m)
+    A = sp.random(m, n, density=dens, random_state=rng, format="csc", data_rvs=rng.standard_normal)
+    S = sp.random(n, n, density=min(1.0, 4.0 / n), random_state=rng, format="csc", data_rvs=rng.standard_normal)
+    P = (S + S.T + sp.identity(n)).tocsc()
+    h = cj.Handle(0)
+    h.set_problem(P, np.zeros(n), A, np.zeros(m))
+    ops = O.Operators(P, A)
+    x = rng.standard_normal(n); y = rng.standard_normal(m)
+    for which, M, v, ref in ((F.MAT_A, abs(A).tocsr(), x, ops.mulA(x)), (F.MAT_AT, abs(A).T.tocsr(), y, ops.mulAT(y)),
+                             (F.MAT_P, abs(P).tocsr(), x, ops.mulP(x))):
+        out = h.spmv(which, v)
+        nnz_row = np.diff(M.indptr)
+        bound = (nnz_row + 2) * EPS * (M @ np.abs(v))          # |dy_i| <= (nnz_i+2) eps sum|a_ij x_j|
+        assert np.all(np.abs(out - ref) <= bound + 1e-300)
+        # the CSR-stream kernel adds every row left-to-right without FMA, i.e. in the CPU loop's order: expect bit equality
+        assert np.array_equal(bits(out), bits(ref))
+
+
+def test_spmv_long_rows_and_empty_rows():
+    rng = np.random.default_rng(11)
+    n, m = 20000, 40
+    A = sp.lil_matrix((m, n))
+    A[3, :] = rng.standard_normal(n)                           # one row longer than the LDS tile (4096)
+    A[7, :9000] = rng.standard_normal(9000)
+    A[11, 5] = 2.0                                             # many empty rows around
+    A = A.tocsc()
+    P = sp.identity(n, format="csc")
+    h = cj.Handle(0)
+    h.set_problem(P, np.zeros(n), A, np.zeros(m))
+    ops = O.Operators(P, A)
+    x = rng.standard_normal(n); y = rng.standard_normal(m)
+    out = h.spmv(F.MAT_A, x); ref = ops.mulA(x)
+    bound = (np.diff(A.tocsr().indptr) + 2) * EPS * (abs(A).tocsr() @ np.abs(x))
+    assert np.all(np.abs(out - ref) <= 4 * bound + 1e-300)     # long rows are tree-summed: order differs
+    assert np.array_equal(bits(h.spmv(F.MAT_AT, y)), bits(ops.mulAT(y)))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a3-a6: composite projection, Zero / Nonnegatives / Box (bit-exact) and SecondOrderCone (tolerance + branch ids)
+# ---------------------------------------------------------------------------------------------------------------------
+def _handle_for_sets(sets, b=None):
+    m = sum(K.dim for K in sets)
+    n = 3
+    h = cj.Handle(0)
+    h.set_problem(sp.identity(n, format="csc"), np.zeros(n), sp.csc_matrix((m, n)), np.zeros(m) if b is None else b)
+    bl = np.concatenate([K.l for K in sets if K.kind == F.BOX] or [np.zeros(0)])
+    bu = np.concatenate([K.u for K in sets if K.kind == F.BOX] or [np.zeros(0)])
+    h.set_cones([K.kind for K in sets], [K.dim for K in sets], bl, bu)
+    return h
+
+
+def test_project_simple_cones_bit_exact():
+    rng = np.random.default_rng(5)
+    l = rng.standard_normal(1000) - 1; u = l + rng.uniform(0, 2, 1000)
+    l[:50] = -np.inf; u[50:100] = np.inf; u[100:150] = l[100:150]
+    # arbitrary (unsorted, repeated) set order is allowed by set!
+    sets = [cj.Nonnegatives(700), cj.ZeroSet(13), cj.Box(l, u), cj.Nonnegatives(1), cj.ZeroSet(300), cj.Box(l[:7], u[:7])]
+    h = _handle_for_sets(sets)
+    m = sum(K.dim for K in sets)
+    s = rng.standard_normal(m) * 2
+    s[::17] = 0.0; s[5::19] = -0.0; s[3] = np.nan; s[9] = np.inf; s[10] = -np.inf
+    s[713 + 5] = np.nan                                         # NaN in a Box row
+    ref = s.copy(); O.project(ref, util.oracle_cones(sets))
+    out, ranks, br = h.project(s)
+    assert np.array_equal(bits(out), bits(ref))                 # bit-exact incl. -0.0 -> +0.0 and NaN propagation
+    assert np.all(ranks == -1) and np.all(br == -1)
+
+
+@pytest.mark.parametrize("dims", [[20] * 50, [1, 2, 3, 64, 65, 129, 1000], [5000, 3]])
+def test_project_soc(dims):
+    rng = np.random.default_rng(len(dims))
+    sets = [cj.SecondOrderCone(d) for d in dims]
+    h = _handle_for_sets(sets)
+    s = rng.standard_normal(sum(dims))
+    off = 0
+    for i, d in enumerate(dims):                                # force all three branches
+        if i % 3 == 0: s[off] = abs(s[off]) * 10 * math.sqrt(d)
+        elif i % 3 == 1: s[off] = -abs(s[off]) * 10 * math.sqrt(d)
+        off += d
+    ref = s.copy(); info = {}
+    O.project(ref, util.oracle_cones(sets), info)
+    out, _, br = h.project(s)
+    assert br.tolist() == info["soc_branch"]                    # branch ids equal (inputs are away from ties)
+    off = 0
+    for d in dims:
+        k = max(d, 1)
+        assert np.linalg.norm(out[off:off + d] - ref[off:off + d]) <= 8 * EPS * k * max(np.linalg.norm(s[off:off + d]), 1e-300)
+        off += d
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a15 integer bookkeeping: rho classes and the initial rho vector
+# ---------------------------------------------------------------------------------------------------------------------
+def test_rho_classes_and_rho_vec_bit_exact():
+    rng = np.random.default_rng(3)
+    prob = util.random_qp(rng, 40, 5, 30, 50, soc_dims=(4, 6))
+    prob["b"][5 + 3] = 1e17                                     # a loose Nonnegatives row (convexset.jl:62-69)
+    ws = O.Workspace(prob["P"], prob["q"], prob["A"], prob["b"], util.oracle_cones(prob["sets"]), O.Settings(scaling=0))
+    h = util.make_handle_from_workspace(ws)
+    assert np.array_equal(h.get_rho_classes(), ws.rho_class)
+    assert np.array_equal(bits(h.get_rho_vec()), bits(ws.rho_vec))
+    assert set(np.unique(ws.rho_class)) == {0, 1, 2}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a10: CG reduced KKT solve
+# ---------------------------------------------------------------------------------------------------------------------
+def test_kkt_solve_cg_vs_dense_and_oracle():
+    rng = np.random.default_rng(21)
+    prob = util.random_qp(rng, 60, 4, 40, 30)
+    st = O.Settings(scaling=0, kkt_solver="cg", tol_constant=1e-10, tol_exponent=0.0)     # "tight mode" 
+    ws = O.Workspace(prob["P"], prob["q"], prob["A"], prob["b"], util.oracle_cones(prob["sets"]), st)
+    h = util.make_handle_from_workspace(ws)
+    n, m = ws.n, ws.m
+    K = O.assemble_kkt_full(ws.P, ws.A, st.sigma, ws.rho_vec).toarray()
+    for trial in range(3):                                       # second and third solves are warm started
+        rhs = rng.standard_normal(n + m)
+        ref_dense = np.linalg.solve(K, rhs)
+        ref_or = ws.kkt.solve(rhs)
+        sol, iters = h.kkt_solve(rhs)
+        assert np.linalg.norm(sol - ref_dense) <= 1e-8 * np.linalg.norm(ref_dense)      # tight mode: 1e-8 relative
+        assert np.linalg.norm(sol - ref_or) <= 1e-8 * np.linalg.norm(ref_or)
+        assert abs(iters - ws.kkt.last_iters) <= 2
+    # default tolerance schedule: both sides satisfy the same residual bound tol_k/||rhs|| (kktsolver_indirect.jl:70)
+    st2 = O.Settings(scaling=0, kkt_solver="cg")
+    ws2 = O.Workspace(prob["P"], prob["q"], prob["A"], prob["b"], util.oracle_cones(prob["sets"]), st2)
+    h2 = util.make_handle_from_workspace(ws2)
+    L = (ws2.P + st2.sigma * sp.identity(n) + ws2.A.T @ sp.diags(ws2.rho_vec) @ ws2.A).toarray()
+    for k in range(1, 6):
+        rhs = rng.standard_normal(n + m)
+        sol, iters = h2.kkt_solve(rhs)
+        ref = ws2.kkt.solve(rhs)
+        y1 = rhs[:n] + ws2.A.T @ (ws2.rho_vec * rhs[n:])
+        tol = (1.0 / k ** 1.5) / np.linalg.norm(y1)
+        assert np.linalg.norm(L @ sol[:n] - y1) <= tol * (1 + 1e-9)
+        assert np.linalg.norm(L @ ref[:n] - y1) <= tol * (1 + 1e-9)
+        assert iters == ws2.kkt.last_iters
+        # nu = rho .* (A x - rhs_s) recomputed from the returned x
+        assert np.allclose(sol[n:], ws2.rho_vec * (ws2.A @ sol[:n] - rhs[n:]), rtol=1e-12, atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a2, a9, a12, a13: one loop body, elementwise phases (bit-exact given the same KKT solution is NOT possible because the
+# inner solve is inexact; instead: tight-mode trajectory parity)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("scaling", [0, 10])
+def test_admm_trajectory_tight_mode(scaling):
+    rng = np.random.default_rng(99)
+    prob = util.random_qp(rng, 80, 6, 60, 70, soc_dims=(5, 9, 3))
+    st = O.Settings(scaling=scaling, kkt_solver="cg", tol_constant=1e-10, tol_exponent=0.0, max_iter=200,
+                    eps_abs=0.0, eps_rel=0.0, check_infeasibility=10 ** 9)
+    ws = O.Workspace(prob["P"], prob["q"], prob["A"], prob["b"], util.oracle_cones(prob["sets"]), st)
+    h = util.make_handle_from_workspace(ws)
+    h.set_iterates(None, None, None)
+    res = ws.optimize()
+    r = h.optimize()
+    w, w_prev, s, mu = h.get_iterates()
+    assert F.STATUS_NAMES[r.status] == res.status == "Max_iter_reached" and r.iter == res.iter == 200
+    scale = max(np.max(np.abs(res.w)), 1e-300)
+    assert np.max(np.abs(w - res.w)) <= 1e-7 * scale             # tight mode, 200 iterations
+    assert np.max(np.abs(w_prev - res.w_prev)) <= 1e-7 * scale
+    assert np.max(np.abs(s - res.s_scaled)) <= 1e-7 * scale
+    assert np.max(np.abs(mu - res.mu_scaled)) <= 1e-7 * max(np.max(np.abs(res.mu_scaled)), 1.0)
+    # integer bookkeeping: number of rho adaptions and the adapted values
+    assert r.n_rho_updates == len(res.rho_updates)
+    assert np.allclose([r.rho_updates[i] for i in range(r.n_rho_updates)], res.rho_updates, rtol=1e-6)
+    for a, b_ in ((r.r_prim, res.r_prim), (r.r_dual, res.r_dual), (r.max_norm_prim, res.max_norm_prim),
+                  (r.max_norm_dual, res.max_norm_dual)):
+        assert abs(a - b_) <= 1e-6 * max(abs(b_), 1e-12) + 1e-13
+
+
+def test_residuals_entry_point():
+    rng = np.random.default_rng(4)
+    prob = util.random_qp(rng, 50, 3, 30, 40)
+    st = O.Settings(scaling=10, kkt_solver="cg", tol_constant=1e-10, tol_exponent=0.0)
+    ws = O.Workspace(prob["P"], prob["q"], prob["A"], prob["b"], util.oracle_cones(prob["sets"]), st)
+    h = util.make_handle_from_workspace(ws)
+    x0 = rng.standard_normal(ws.n); s0 = rng.standard_normal(ws.m); mu0 = rng.standard_normal(ws.m)
+    O.project(s0, ws.cones)
+    h.set_iterates(x0, s0, mu0)
+    # after set_iterates: w_prev = w = [x0 ; mu0/rho + s0], s = s0  =>  mu = rho (w_prev_s - s) = mu0 (up to rounding)
+    out = h.residuals()
+    mu = ws.rho_vec * (((1.0 / ws.rho_vec) * mu0 + s0) - s0)
+    rp, rd = O.calculate_residuals(ws.ops, x0, s0, mu, ws.q, ws.b, ws.sm, True)
+    mp, md = O.max_res_component_norm(ws.ops, x0, s0, mu, ws.q, ws.b, ws.sm, True)
+    cost = O.calculate_cost(ws.ops, x0, ws.q, ws.sm.cinv)
+    ref = np.array([rp, rd, mp, md, cost])
+    assert np.allclose(out[:4], ref[:4], rtol=1e-13, atol=0)     # inf-norms of bit-identical row sums
+    assert abs(out[4] - ref[4]) <= 1e-12 * max(abs(ref[4]), 1.0)  # dot products: summation order differs
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# reference goldens through the mirrored model interface (test/UnitTests/simple.jl, qp-box.jl, model_modifications.jl)
+# ---------------------------------------------------------------------------------------------------------------------
+def _simple_constraints():
+    A = np.array([[1.0, 1], [1, 0], [0, 1]])
+    l = np.array([1.0, 0, 0]); u = np.array([1.0, 0.7, 0.7])
+    return [cj.Constraint(-A, u, cj.Nonnegatives), cj.Constraint(A, -l, cj.Nonnegatives)]
+
+
+def test_simple_qp_golden():
+    model = cj.Model()
+    cj.assemble(model, np.array([[4.0, 1], [1, 2]]), np.array([1.0, 1]), _simple_constraints(),
+                settings=cj.Settings(kkt_solver=cj.CGIndirectKKTSolver))
+    res = cj.optimize(model)
+    assert res.status == "Solved"                                             # simple.jl:45
+    assert np.linalg.norm(res.x - np.array([0.3, 0.7])) < 1e-3                # :46
+    assert abs(res.obj_val - 1.8800000298331538) < 1e-3                       # :47
+    # same answer as the oracle's CG loop, same iteration count within one check interval
+    A, b, cones = O.assemble([O.Constraint(c.A, c.b, O.Nonnegatives(3)) for c in _simple_constraints()])
+    ref = O.solve(np.array([[4.0, 1], [1, 2]]), np.array([1.0, 1]), A, b, cones, O.Settings(kkt_solver="cg"))
+    assert abs(res.iter - ref.iter) <= 25 and abs(res.obj_val - ref.obj_val) <= 1e-4 * (1 + abs(ref.obj_val))
+    assert len(res.info.rho_updates) == len(ref.rho_updates)
+
+
+def test_box_qp_golden():
+    model = cj.Model()
+    cj.assemble(model, np.eye(2), np.array([1.0, -1]), cj.Constraint(sp.identity(2, format="csc"), np.zeros(2),
+                                                                     cj.Box([0.0, 0], [1.0, 1])))
+    res = cj.optimize(model)
+    assert res.status == "Solved" and abs(res.obj_val - (-0.5)) < 1e-5        # qp-box.jl:30-31
+
+
+def test_max_iter_and_model_updates():
+    model = cj.Model()
+    cj.assemble(model, np.array([[4.0, 1], [1, 2]]), np.array([1.0, 1]), _simple_constraints(), settings=cj.Settings(max_iter=20))
+    res = cj.optimize(model)
+    assert res.status == "Max_iter_reached" and res.iter == 20                 # simple.jl:65
+    model = cj.Model()
+    cj.assemble(model, np.array([[4.0, 1], [1, 2]]), np.array([1.0, 1]), _simple_constraints())
+    r1 = cj.optimize(model)
+    cj.update(model, q=[2.0, 3.0])
+    r2 = cj.optimize(model)
+    assert abs(r2.obj_val - 3.5) < 1e-3 and np.linalg.norm(r2.x - [0.5, 0.5]) < 1e-3   # model_modifications.jl:41-42
+    model = cj.Model()
+    cj.assemble(model, np.zeros((2, 2)), np.array([1.0, 1]), cj.Constraint(np.eye(2), [-2.0, -3.0], cj.Nonnegatives),
+                settings=cj.Settings(check_termination=20))
+    r = cj.optimize(model)
+    assert np.linalg.norm(r.x - [2.0, 3.0]) < 1e-3
+    cj.update(model, b=[0.0, 1.0])
+    r2 = cj.optimize(model)
+    assert np.linalg.norm(r2.x - [0.0, -1.0]) < 1e-4                           # model_modifications.jl:60
+
+
+def test_cfg1_dense_qp_vs_direct_cpu_oracle():
+    # BASELINE config 1: the reference runs it with the QDLDL direct solver on the CPU; the GPU path runs CG.
+    prob = cj.problems.dense_qp()
+    ref = O.solve(prob["P"], prob["q"], prob["A"], prob["b"], util.oracle_cones(prob["sets"]), O.Settings(kkt_solver="qdldl"))
+    model = cj.Model(); model.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"])
+    res = cj.optimize(model)
+    assert res.status == ref.status == "Solved"
+    assert abs(res.iter - ref.iter) <= 25                        # same count within one check_termination interval
+    assert abs(res.obj_val - ref.obj_val) <= 1e-4 * (1 + abs(ref.obj_val))
+    assert np.linalg.norm(res.x - ref.x) <= 1e-3 * max(1.0, np.linalg.norm(ref.x))
+
+
+def test_determinism_bitwise():
+    rng = np.random.default_rng(8)
+    prob = util.random_qp(rng, 70, 5, 50, 60, soc_dims=(4, 4))
+    outs = []
+    for _ in range(2):
+        model = cj.Model(); model.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], cj.Settings(max_iter=150, eps_abs=0, eps_rel=0))
+        r = cj.optimize(model)
+        outs.append(np.concatenate([r.x, r.s, r.y]))
+    assert np.array_equal(bits(outs[0]), bits(outs[1]))          # all reductions use a fixed order
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# full-size property tests at BASELINE config 2 (n=1e5, m=2e5, nnz=2e6): things the oracle would take minutes for
+# ---------------------------------------------------------------------------------------------------------------------
+def test_cfg2_full_size_properties():
+    prob = cj.problems.sparse_box_qp()
+    n, m = prob["A"].shape[1], prob["A"].shape[0]
+    st = cj.Settings(max_iter=100, eps_abs=0, eps_rel=0)
+    model = cj.Model(); model.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)
+    res = cj.optimize(model)
+    assert res.status == "Max_iter_reached" and res.iter == 100
+    h = model.handle
+    # linearity + adjointness of the device SpMVs: <A x, y> == <x, A' y>
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(n); y = rng.standard_normal(m)
+    Ax = h.spmv(F.MAT_A, x); ATy = h.spmv(F.MAT_AT, y)
+    assert abs(np.dot(Ax, y) - np.dot(x, ATy)) <= 1e-10 * np.linalg.norm(Ax) * np.linalg.norm(y)
+    assert np.array_equal(bits(Ax), bits(model.A.tocsr() @ x))     # matches SciPy's serial CSR loop bit for bit
+    # projection is idempotent and lands in the (scaled) box
+    w, w_prev, s, mu = h.get_iterates()
+    s2, _, _ = h.project(s)
+    assert np.array_equal(bits(s2), bits(s))
+    K = model.sets[0]
+    assert np.all(s >= K.l) and np.all(s <= K.u)
+    # the residual scalars returned by the loop equal a recomputation from the fetched iterates with SciPy
+    sm = model.sm
+    xs = w_prev[:n]
+    r_prim = np.max(np.abs(sm.Einv * (model.A @ xs + s - model.b)))
+    r_dual = np.max(np.abs(sm.cinv * (sm.Dinv * (model.P @ xs + model.q - model.A.T @ mu))))
+    assert abs(res.info.r_prim - r_prim) <= 1e-9 * max(r_prim, 1e-12)
+    assert abs(res.info.r_dual - r_dual) <= 1e-9 * max(r_dual, 1e-12)
+    # rho classes: 10% equality rows, 5% loose rows of the generator are found exactly
+    cls = h.get_rho_classes()
+    assert np.array_equal(cls == 1, (K.u - K.l) < 1e-4) and np.array_equal(cls == 2, (K.l < -1e16) & (K.u > 1e16))
