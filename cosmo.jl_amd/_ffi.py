@@ -106,6 +106,13 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise ImportError("libcosmo_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
                           "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    try:
+        # torch bundles its own libamdhip64; if it is going to live in this process (tests, bench: torch.distributed,
+        # device selection) it must be loaded FIRST so that both share one HIP runtime.  Pure plumbing: no torch
+        # symbol is used by the library, and the binding works without torch installed.
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing

@@ -296,7 +296,7 @@ extern "C" int32_t cosmo_hip_set_problem(cosmo_hip_handle* h, int64_t n, int64_t
   CHK(dalloc(h, &h->s_tl, (size_t)m)); CHK(dalloc(h, &h->ls_x, (size_t)n)); CHK(dalloc(h, &h->ls_s, (size_t)m));
   CHK(dalloc(h, &h->x_tl, (size_t)n)); CHK(dalloc(h, &h->nu, (size_t)m)); CHK(dalloc(h, &h->rhs, (size_t)n));
   CHK(dalloc(h, &h->r, (size_t)n)); CHK(dalloc(h, &h->u, (size_t)n)); CHK(dalloc(h, &h->c, (size_t)n));
-  CHK(dalloc(h, &h->tmp_m, (size_t)m)); CHK(dalloc(h, &h->y2, (size_t)m)); CHK(dalloc(h, &h->io, N));
+  CHK(dalloc(h, &h->tmp_m, (size_t)m)); CHK(dalloc(h, &h->y2, (size_t)m)); CHK(dalloc(h, &h->io, 2 * N));
   CHK(h2d(h, h->q, q, (size_t)n));
   CHK(h2d(h, h->b, b, (size_t)m));
   h->has_scaling = false; h->cinv = 1.0;
@@ -493,7 +493,7 @@ extern "C" int32_t cosmo_hip_spmv(cosmo_hip_handle* h, int32_t which, double* y,
   // io holds n+m doubles: input first, output after it
   double* dx = h->io;
   double* dy = h->io + M->ncols;
-  if ((long long)M->ncols + M->nrows > h->n + h->m) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "spmv: staging too small");
+  if ((long long)M->ncols + M->nrows > 2 * (h->n + h->m)) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "spmv: staging too small");
   CHK(h2d(h, dx, x, (size_t)M->ncols));
   CHK(launch_spmv_plain(h, *M, dx, dy));
   CHK(d2h(h, y, dy, (size_t)M->nrows));

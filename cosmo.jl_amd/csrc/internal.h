@@ -16,8 +16,8 @@
 #include "../../include/cosmo_hip.h"
 
 #define COSMO_BS 256            // threads per workgroup for streaming kernels (4 waves of 64)
-#define COSMO_NNZ_PER_BLOCK 4096 // CSR-stream: nonzeros staged in LDS per row block (32 KB of products)
-#define COSMO_MAX_PARTIALS 1024 // upper bound on workgroups that emit reduction partials
+#define COSMO_NNZ_PER_BLOCK 2048 // CSR-stream: nonzeros staged in LDS per row block (16 KB of products; measured best of 512..4096)
+#define COSMO_MAX_PARTIALS 2048 // upper bound on workgroups that emit reduction partials
 #define COSMO_NSLOTS 8          // partial-reduction slots
 
 // ---- device control block -------------------------------------------------------------------------------------

@@ -59,7 +59,7 @@ def make_handle_from_workspace(ws: O.Workspace, kkt_kind=cj._ffi.KKT_CG, **param
     return h
 
 
-def random_qp(rng, n, m_zero, m_nonneg, m_box, soc_dims=(), density=0.1, psd_tri_dims=()):
+def random_qp(rng, n, m_zero, m_nonneg, m_box, soc_dims=(), density=0.1, psd_tri_dims=(), p_shift=0.1):
     """A feasible random conic QP in internal form with a mix of cone types."""
     m_soc = int(sum(soc_dims))
     m_psd = int(sum(d * (d + 1) // 2 for d in psd_tri_dims))
@@ -67,7 +67,7 @@ def random_qp(rng, n, m_zero, m_nonneg, m_box, soc_dims=(), density=0.1, psd_tri
     A = sp.random(m, n, density=density, random_state=rng, format="csc", data_rvs=rng.standard_normal)
     A = (A + sp.csc_matrix((np.ones(min(m, n)), (np.arange(min(m, n)), np.arange(min(m, n)))), shape=(m, n)) * 0.5).tocsc()
     S = sp.random(n, n, density=min(1.0, 3.0 / n), random_state=rng, format="csc", data_rvs=rng.standard_normal)
-    P = (S @ S.T + 0.1 * sp.identity(n)).tocsc()
+    P = (S @ S.T + p_shift * sp.identity(n)).tocsc()
     q = rng.standard_normal(n)
     x0 = rng.standard_normal(n)
     s0 = [np.zeros(m_zero), rng.uniform(0.1, 1.0, m_nonneg)]
