@@ -234,20 +234,27 @@ __global__ __launch_bounds__(COSMO_BS) void k_op_apply(Ctl* __restrict__ ctl, in
 __global__ __launch_bounds__(COSMO_BS) void k_cg_dir(Ctl* __restrict__ ctl, int guard, int k, int check_only, long long n,
                                                      long long maxiter, const double* __restrict__ part_rr, int n_rr,
                                                      const double* __restrict__ r, double* __restrict__ u) {
+  // operands of the elementwise part are requested BEFORE the scalar work so that their latency overlaps the
+  // partial reduction (the grid covers n with one element per thread; the strided loop only handles huge n)
+  const long long i0 = (long long)blockIdx.x * COSMO_BS + threadIdx.x;
+  double r0 = 0.0, u0 = 0.0;
+  if (!check_only && i0 < n) { r0 = r[i0]; if (k > 0) u0 = u[i0]; }
   if (guard && ctl->halt) return;
   if (ctl->cg_done) return;
   __shared__ double red[COSMO_BS / 64];
+  const double tol = ctl->tol;
+  const double prev = (k == 0) ? 1.0 : ctl->resv[(k - 1) & 1];
   const double rr = reduce_partials_sum(part_rr, n_rr, red);
   const double res = sqrt(rr);
-  const bool done = (k >= maxiter) || (res <= ctl->tol);
+  const bool done = (k >= maxiter) || (res <= tol);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (done) ctl->cg_done = 1;
     if (!check_only || done) ctl->resv[k & 1] = res;
   }
   if (done || check_only) return;
-  const double prev = (k == 0) ? 1.0 : ctl->resv[(k - 1) & 1];
   const double beta = (res * res) / (prev * prev);
-  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < n; i += (long long)gridDim.x * COSMO_BS) {
+  if (i0 < n) u[i0] = r0 + beta * u0;
+  for (long long i = i0 + (long long)gridDim.x * COSMO_BS; i < n; i += (long long)gridDim.x * COSMO_BS) {
     const double ui = (k == 0) ? 0.0 : u[i];
     u[i] = r[i] + beta * ui;
   }
@@ -259,14 +266,23 @@ __global__ __launch_bounds__(COSMO_BS) void k_cg_upd(Ctl* __restrict__ ctl, int 
                                                      const double* __restrict__ u, const double* __restrict__ c,
                                                      double* __restrict__ x, double* __restrict__ r,
                                                      double* __restrict__ part_rr) {
+  const long long i0 = (long long)blockIdx.x * COSMO_BS + threadIdx.x;
+  double u0 = 0.0, c0 = 0.0, x0 = 0.0, r0 = 0.0;
+  if (i0 < n) { u0 = u[i0]; c0 = c[i0]; x0 = x[i0]; r0 = r[i0]; }   // issued before the scalar work (latency overlap)
   if (guard && ctl->halt) return;
   if (ctl->cg_done) return;
   __shared__ double red[COSMO_BS / 64];
-  const double uc = reduce_partials_sum(part_uc, n_uc, red);
   const double res = ctl->resv[k & 1];
+  const double uc = reduce_partials_sum(part_uc, n_uc, red);
   const double alpha = (res * res) / uc;
   double acc = 0.0;
-  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < n; i += (long long)gridDim.x * COSMO_BS) {
+  if (i0 < n) {
+    x[i0] = x0 + alpha * u0;
+    const double ri = r0 - alpha * c0;
+    r[i0] = ri;
+    acc += ri * ri;
+  }
+  for (long long i = i0 + (long long)gridDim.x * COSMO_BS; i < n; i += (long long)gridDim.x * COSMO_BS) {
     x[i] = x[i] + alpha * u[i];
     const double ri = r[i] - alpha * c[i];
     r[i] = ri;
