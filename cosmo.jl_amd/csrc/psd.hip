@@ -1,13 +1,651 @@
-// psd.hip -- PSD cone projections (placeholder until the Jacobi eigensolver lands in this file)
-#include "internal.h"
-struct PsdPlan { int ncones = 0; };
-int32_t psd_plan_create(cosmo_hip_handle* h) {
-  int n = 0;
-  for (size_t k = 0; k < h->cones.type.size(); ++k)
-    if ((h->cones.type[k] == COSMO_HIP_PSD_SQUARE || h->cones.type[k] == COSMO_HIP_PSD_TRIANGLE) && h->cones.dim[k] > 1) ++n;
-  if (n) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "PSD cones not built yet");
+// psd.hip -- projection onto the positive semidefinite cone (PsdConeTriangle / PsdCone), gfx950.
+//
+// Reference semantics (src/convexset.jl:219-263, 303-321, 402-412): X+ = sum_{lambda_j > 0} lambda_j z_j z_j' from the
+// symmetric eigendecomposition of X (upper triangle), rank nnz_lambda = #{lambda_j > 0}; svec layout column-major upper
+// triangle with off-diagonals scaled by sqrt(2) (Appendix C of SURVEY.md).
+//
+// MI355X design.  The eigendecomposition is a Jacobi method, chosen because it is all level-3 / embarrassingly
+// parallel work for a 64-wide wave machine and needs no sequential tridiagonal QR chain:
+//   d <= 16      one WAVE per cone: cyclic two-sided Jacobi on the 16x16 (zero padded) matrix held in LDS, 8 disjoint
+//                rotations per round, all 64 lanes apply them.
+//   16 < d<=256  one WORKGROUP per cone: block one-sided (Hestenes) Jacobi on G = X + c I  (c = ||X||_F >= rho(X), so G is
+//                PSD and its SVD is its eigendecomposition: no eigenvalue-sign ambiguity).  Columns are grouped in blocks
+//                of 8; per step every wave owns one block pair (16 columns): Gram matrix W = P'P with fp64 MFMA
+//                (v_mfma_f64_16x16x4_f64), one sweep of the 16x16 Jacobi on W accumulating J, panel update P <- P J with
+//                MFMA.  Round-robin ordering, workgroup barrier between steps, sweeps until no rotation fires.
+//   d > 256      the same step as a multi-workgroup kernel (one workgroup per block pair, rows split over its waves),
+//                one launch per step, host checks the convergence flag once per sweep.
+// Then sigma_k = ||g_k||, lambda_k = sigma_k - c, and X+ = Ghat Ghat' with ghat_k = g_k sqrt(lambda_k)/sigma_k for
+// lambda_k > 0 -- a SYRK on MFMA fused with the svec write-out (the reference's rank_k_update!, :243-263).
+#include "device_utils.h"
+#include <algorithm>
+#include <math.h>
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+#define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+#define WLD 17  // leading dimension of the 16x16 LDS tiles (padded against bank conflicts)
+#define PSD_MAX_SWEEPS 40
+#define PSD_EPS 2.220446049250313e-16
+
+struct PsdConeDev {
+  int off;        // first row of the cone in s
+  int d;          // matrix side
+  int kind;       // COSMO_HIP_PSD_SQUARE / COSMO_HIP_PSD_TRIANGLE
+  int ld;         // leading dimension of G (multiple of 16 >= d)
+  int ncp;        // padded number of columns: nb * 8, nb even
+  int nb;         // number of 8-column blocks (even)
+  long long goff; // offset of G in the workspace (doubles)
+  int coff;       // offset of the per-column arrays
+  int cone_index; // index in the composite set
+};
+
+struct PsdPlan {
+  std::vector<PsdConeDev> cones;       // all PSD cones with d > 1
+  std::vector<int> tiny, wg, large;    // indices into `cones` by size class
+  std::vector<int> wg_waves;           // waves per workgroup for every wg-class launch group
+  std::vector<std::vector<int>> wg_groups;
+  PsdConeDev* d_cones = nullptr;
+  int *d_tiny = nullptr, *d_large = nullptr;
+  std::vector<int*> d_wg_groups;
+  double* G = nullptr;
+  double* colw = nullptr;              // per column: sigma then scale factor
+  double* cshift = nullptr;            // per cone shift c
+  int* rank = nullptr;                 // per cone nnz_lambda
+  int* flags = nullptr;                // [0] sweep-rotated flag (large path), [1] error flag
+  long long gsize = 0;
+  int ncolw = 0;
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 16x16 Jacobi machinery (one wave).  W and J live in LDS in row-major [16][WLD]; lane l works on column (l & 15) and
+// rows (l >> 4) + 4 r, r = 0..3 -- the C/D layout of v_mfma_f64_16x16x4_f64, so MFMA results drop in without shuffles.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// One cyclic sweep (15 rounds x 8 disjoint rotations).  mode 0: W is a Gram matrix (relative criterion
+// |w_pq| > tol sqrt(w_pp w_qq), columns with w_kk <= tiny skipped).  mode 1: W is the symmetric matrix itself (absolute
+// criterion |w_pq| > tiny).  Returns (wave-uniform) whether any rotation fired.
+__device__ __forceinline__ int jacobi16_sweep(double* W, double* J, int* part, double* ca, double* cb, double tol,
+                                              double tiny, int mode, int lane) {
+  int rotated = 0;
+  for (int rd = 0; rd < 15; ++rd) {
+    if (lane < 8) {
+      int p, q;
+      if (lane == 0) { p = rd; q = 15; }
+      else { p = (rd + lane) % 15; q = (rd - lane + 15) % 15; }
+      if (p > q) { const int t = p; p = q; q = t; }
+      const double app = W[p * WLD + p], aqq = W[q * WLD + q], apq = W[p * WLD + q];
+      double c = 1.0, s = 0.0;
+      bool rot;
+      if (mode == 0) rot = (app > tiny) && (aqq > tiny) && (fabs(apq) > tol * sqrt(app * aqq));
+      else rot = fabs(apq) > tiny;
+      if (rot) {
+        const double zeta = (aqq - app) / (2.0 * apq);
+        const double t = ((zeta >= 0.0) ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        c = 1.0 / sqrt(1.0 + t * t);
+        s = c * t;
+        rotated = 1;
+      }
+      part[p] = q; ca[p] = c; cb[p] = -s;   // col_p' = c col_p - s col_q
+      part[q] = p; ca[q] = c; cb[q] = s;    // col_q' = s col_p + c col_q
+    }
+    wave_lds_fence();
+    const int j = lane & 15;
+    const int pj = part[j];
+    const double aj = ca[j], bj = cb[j];
+    double wn[4], jn[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = (lane >> 4) + 4 * r;
+      const int pi = part[i];
+      const double ai = ca[i], bi = cb[i];
+      const double wij = W[i * WLD + j], wipj = W[i * WLD + pj], wpij = W[pi * WLD + j], wpipj = W[pi * WLD + pj];
+      wn[r] = ai * (aj * wij + bj * wipj) + bi * (aj * wpij + bj * wpipj);
+      jn[r] = aj * J[i * WLD + j] + bj * J[i * WLD + pj];
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = (lane >> 4) + 4 * r;
+      W[i * WLD + j] = wn[r];
+      J[i * WLD + j] = jn[r];
+    }
+    wave_lds_fence();
+  }
+  return __any(rotated) ? 1 : 0;
+}
+
+// svec index of (i, j), i <= j (0-based), column-major upper triangle
+__device__ __forceinline__ long long svec_idx(int i, int j) { return (long long)j * (j + 1) / 2 + i; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// d <= 16: one wave per cone, two-sided Jacobi directly on X
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(COSMO_BS) void k_psd_tiny(const Ctl* __restrict__ ctl, int guard, int ncones,
+                                                       const int* __restrict__ list, const PsdConeDev* __restrict__ cones,
+                                                       double* __restrict__ s, int* __restrict__ rank, int* __restrict__ flags) {
+  if (guard && ctl->halt) return;
+  __shared__ double Ws[COSMO_BS / 64][16 * WLD];
+  __shared__ double Js[COSMO_BS / 64][16 * WLD];
+  __shared__ double cas[COSMO_BS / 64][16], cbs[COSMO_BS / 64][16];
+  __shared__ int parts[COSMO_BS / 64][16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int widx = blockIdx.x * (COSMO_BS / 64) + wv;
+  if (widx >= ncones) return;
+  const PsdConeDev cn = cones[list[widx]];
+  double* W = Ws[wv]; double* J = Js[wv];
+  double* x = s + cn.off;
+  const int d = cn.d;
+  const double isq2 = 1.0 / sqrt(2.0), sq2 = sqrt(2.0);
+  // load X (symmetric, zero padded) and the identity
+  double fro = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = (lane >> 4) + 4 * r, j = lane & 15;
+    double v = 0.0;
+    if (i < d && j < d) {
+      const int a = i < j ? i : j, b = i < j ? j : i;
+      if (cn.kind == COSMO_HIP_PSD_TRIANGLE) {
+        const double t = x[svec_idx(a, b)];
+        v = (a == b) ? t : isq2 * t;                       // populate_upper_triangle! (convexset.jl:432-442)
+      } else {
+        v = (x[(long long)b * d + a] + x[(long long)a * d + b]) / 2.0;   // symmetrize_upper! (algebra.jl:201-208)
+      }
+    }
+    W[i * WLD + j] = v;
+    J[i * WLD + j] = (i == j) ? 1.0 : 0.0;
+    fro += v * v;
+  }
+  fro = sqrt(wave_sum(fro));
+  wave_lds_fence();
+  const double thr = PSD_EPS * fro;
+  int sweeps = 0, rot = (fro > 0.0) ? 1 : 0;
+  while (rot && sweeps < PSD_MAX_SWEEPS) {
+    rot = jacobi16_sweep(W, J, parts[wv], cas[wv], cbs[wv], 0.0, thr, 1, lane);
+    ++sweeps;
+  }
+  if (rot && lane == 0) atomicOr(&flags[1], 1);            // did not converge
+  // X+ = J max(Lambda,0) J'
+  int rk = 0;
+  for (int k = 0; k < d; ++k) rk += (W[k * WLD + k] > 0.0) ? 1 : 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = (lane >> 4) + 4 * r, j = lane & 15;
+    if (i <= j && j < d) {
+      double acc = 0.0;
+      for (int k = 0; k < d; ++k) {
+        const double lam = W[k * WLD + k];
+        if (lam > 0.0) acc += (J[i * WLD + k] * lam) * J[j * WLD + k];
+      }
+      if (cn.kind == COSMO_HIP_PSD_TRIANGLE) {
+        x[svec_idx(i, j)] = (i == j) ? acc : sq2 * acc;              // extract_upper_triangle! (:462-472)
+      } else {
+        x[(long long)j * d + i] = acc;                                // upper triangle, then mirrored (:316-318)
+        x[(long long)i * d + j] = acc;
+      }
+    }
+  }
+  if (lane == 0) rank[list[widx]] = rk;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// d > 16: build G = X + c I (full symmetric, zero padded), c = ||X||_F  (one workgroup per cone, any block size)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(COSMO_BS) void k_psd_populate(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ list,
+                                                           const PsdConeDev* __restrict__ cones, const double* __restrict__ s,
+                                                           double* __restrict__ G, double* __restrict__ cshift) {
+  if (guard && ctl->halt) return;
+  __shared__ double red[COSMO_BS / 64];
+  const int ci = list[blockIdx.y];
+  const PsdConeDev cn = cones[ci];
+  const double* x = s + cn.off;
+  const int d = cn.d;
+  double* g = G + cn.goff;
+  const double isq2 = 1.0 / sqrt(2.0);
+  // ||X||_F: for the svec layout it is ||x||_2 (the scaling makes svec an isometry)
+  double acc = 0.0;
+  if (cn.kind == COSMO_HIP_PSD_TRIANGLE) {
+    const long long len = (long long)d * (d + 1) / 2;
+    for (long long k = threadIdx.x; k < len; k += COSMO_BS) { const double v = x[k]; acc += v * v; }
+  } else {
+    for (long long k = threadIdx.x; k < (long long)d * d; k += COSMO_BS) {
+      const int i = (int)(k % d), j = (int)(k / d);
+      const double v = (x[(long long)j * d + i] + x[(long long)i * d + j]) / 2.0;
+      acc += v * v;
+    }
+  }
+  const double c = sqrt(block_sum(acc, red));
+  if (threadIdx.x == 0 && blockIdx.x == 0) cshift[ci] = c;
+  // columns are distributed over blockIdx.x
+  for (int j = blockIdx.x; j < cn.ncp; j += gridDim.x) {
+    for (int i = threadIdx.x; i < cn.ld; i += COSMO_BS) {
+      double v = 0.0;
+      if (i < d && j < d) {
+        const int a = i < j ? i : j, b = i < j ? j : i;
+        if (cn.kind == COSMO_HIP_PSD_TRIANGLE) {
+          const double t = x[svec_idx(a, b)];
+          v = (a == b) ? t : isq2 * t;
+        } else {
+          v = (x[(long long)b * d + a] + x[(long long)a * d + b]) / 2.0;
+        }
+        if (i == j) v += c;
+      }
+      g[(long long)j * cn.ld + i] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// block-pair step pieces (wave level).  cols[0..15] = global column indices of the 16 panel columns.
+// ---------------------------------------------------------------------------------------------------------------------
+// Gram matrix of a row range of the panel: W = P(r0:r1, :)' P(r0:r1, :), r0, r1 multiples of 16.
+// Lane l loads rows 16 ch + 4 (l >> 4) .. +3 of column cols(l & 15) as one 32-byte vector; the k-slot permutation this
+// implies is the same for both MFMA operands, so the sum is unchanged.
+__device__ __forceinline__ v4d panel_gram(const double* __restrict__ g, int ld, int colL, int r0, int r1, int lane) {
+  v4d acc = {0.0, 0.0, 0.0, 0.0};
+  const double* cp = g + (long long)colL * ld + 4 * (lane >> 4);
+  for (int r = r0; r < r1; r += 16) {
+    const v4d v = *reinterpret_cast<const v4d*>(cp + r);
+    acc = MFMA_F64(v.x, v.x, acc);
+    acc = MFMA_F64(v.y, v.y, acc);
+    acc = MFMA_F64(v.z, v.z, acc);
+    acc = MFMA_F64(v.w, v.w, acc);
+  }
+  return acc;
+}
+
+// Panel update P(r0:r1, :) <- P(r0:r1, :) J, computed as (J' P')' so that every lane stores 16 consecutive rows of one
+// column.  jt[t] = J[(lane >> 4) + 4 t][lane & 15] (the C layout) is exactly the A operand of step t.
+__device__ __forceinline__ void panel_update(double* __restrict__ g, int ld, const int* cols, const double jt[4], int r0, int r1,
+                                             int lane) {
+  const int rr = lane & 15, kg = lane >> 4;
+  double* src[4];
+  double* dst[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    src[t] = g + (long long)cols[4 * t + kg] * ld + rr;   // B operand of step t: P[r + rr][4 t + kg]
+    dst[t] = g + (long long)cols[kg + 4 * t] * ld + rr;   // D reg t: new column kg + 4 t, row r + rr
+  }
+  for (int r = r0; r < r1; r += 16) {
+    double b[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b[t] = src[t][r];
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = MFMA_F64(jt[t], b[t], acc);
+    dst[0][r] = acc.x; dst[1][r] = acc.y; dst[2][r] = acc.z; dst[3][r] = acc.w;
+  }
+}
+
+// round-robin tournament: block pair w (0 <= w < nb/2) of step st (0 <= st < nb-1), nb even
+__device__ __forceinline__ void rr_pair(int nb, int st, int w, int& I, int& J) {
+  const int m = nb - 1;
+  if (w == 0) { I = st % m; J = m; }
+  else { I = (st + w) % m; J = (st - w + m) % m; }
+  if (I > J) { const int t = I; I = J; J = t; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 16 < d <= 256: whole Jacobi process of one cone in one workgroup (nb/2 <= 16 waves)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_psd_jacobi_wg(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ list,
+                                                           const PsdConeDev* __restrict__ cones, double* __restrict__ G,
+                                                           const double* __restrict__ cshift, int* __restrict__ flags) {
+  if (guard && ctl->halt) return;
+  __shared__ double Ws[NW][16 * WLD];
+  __shared__ double Js[NW][16 * WLD];
+  __shared__ double cas[NW][16], cbs[NW][16];
+  __shared__ int parts[NW][16];
+  __shared__ int colss[NW][16];
+  __shared__ int any_rot;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ci = list[blockIdx.x];
+  const PsdConeDev cn = cones[ci];
+  double* g = G + cn.goff;
+  const int nb = cn.nb, npairs = nb / 2;
+  const double c = cshift[ci];
+  const double tol = (double)cn.d * PSD_EPS;
+  const double tiny = (tol * c) * (tol * c);
+  double* W = Ws[wv]; double* J = Js[wv];
+  int sweep = 0;
+  for (; sweep < PSD_MAX_SWEEPS; ++sweep) {
+    if (threadIdx.x == 0) any_rot = 0;
+    __syncthreads();
+    for (int st = 0; st < nb - 1; ++st) {
+      if (wv < npairs) {
+        int I, Jb;
+        rr_pair(nb, st, wv, I, Jb);
+        if (lane < 16) colss[wv][lane] = (lane < 8) ? (I * 8 + lane) : (Jb * 8 + lane - 8);
+        wave_lds_fence();
+        const int colL = colss[wv][lane & 15];
+        const v4d w = panel_gram(g, cn.ld, colL, 0, cn.ld, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = (lane >> 4) + 4 * r, j = lane & 15;
+          W[i * WLD + j] = w[r];
+          J[i * WLD + j] = (i == j) ? 1.0 : 0.0;
+        }
+        wave_lds_fence();
+        const int rot = jacobi16_sweep(W, J, parts[wv], cas[wv], cbs[wv], tol, tiny, 0, lane);
+        if (rot) {
+          double jt[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) jt[t] = J[((lane >> 4) + 4 * t) * WLD + (lane & 15)];
+          panel_update(g, cn.ld, colss[wv], jt, 0, cn.ld, lane);
+          if (lane == 0) any_rot = 1;
+        }
+      }
+      __syncthreads();
+    }
+    if (!any_rot) break;
+    __syncthreads();
+  }
+  if (sweep >= PSD_MAX_SWEEPS && threadIdx.x == 0) atomicOr(&flags[1], 1);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// d > 256: one step of the same process, one workgroup per block pair, panel rows split over the waves
+// grid = (npairs_max, nlarge);  flags[0] accumulates "some rotation fired in this sweep"
+// ---------------------------------------------------------------------------------------------------------------------
+#define PSD_STEP_WAVES 8
+__global__ __launch_bounds__(PSD_STEP_WAVES * 64) void k_psd_step(const int* __restrict__ list, const PsdConeDev* __restrict__ cones,
+                                                                  double* __restrict__ G, const double* __restrict__ cshift,
+                                                                  int st, int* __restrict__ flags) {
+  __shared__ double Wp[PSD_STEP_WAVES][16 * WLD];
+  __shared__ double Ws[16 * WLD];
+  __shared__ double Js[16 * WLD];
+  __shared__ double cas[16], cbs[16];
+  __shared__ int parts[16];
+  __shared__ int cols[16];
+  __shared__ int rot_s;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ci = list[blockIdx.y];
+  const PsdConeDev cn = cones[ci];
+  const int nb = cn.nb, npairs = nb / 2;
+  if ((int)blockIdx.x >= npairs || st >= nb - 1) return;
+  double* g = G + cn.goff;
+  const double c = cshift[ci];
+  const double tol = (double)cn.d * PSD_EPS;
+  const double tiny = (tol * c) * (tol * c);
+  int I, Jb;
+  rr_pair(nb, st, blockIdx.x, I, Jb);
+  if (threadIdx.x < 16) cols[threadIdx.x] = (threadIdx.x < 8) ? (I * 8 + threadIdx.x) : (Jb * 8 + threadIdx.x - 8);
+  __syncthreads();
+  // rows split in 16-row chunks over the waves
+  const int nch = cn.ld / 16;
+  const int per = (nch + PSD_STEP_WAVES - 1) / PSD_STEP_WAVES;
+  const int r0 = min(nch, wv * per) * 16, r1 = min(nch, (wv + 1) * per) * 16;
+  const v4d w = panel_gram(g, cn.ld, cols[lane & 15], r0, r1, lane);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) Wp[wv][((lane >> 4) + 4 * r) * WLD + (lane & 15)] = w[r];
+  __syncthreads();
+  if (wv == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = (lane >> 4) + 4 * r, j = lane & 15;
+      double a = 0.0;
+      for (int q = 0; q < PSD_STEP_WAVES; ++q) a += Wp[q][i * WLD + j];
+      Ws[i * WLD + j] = a;
+      Js[i * WLD + j] = (i == j) ? 1.0 : 0.0;
+    }
+    wave_lds_fence();
+    const int rot = jacobi16_sweep(Ws, Js, parts, cas, cbs, tol, tiny, 0, lane);
+    if (lane == 0) { rot_s = rot; if (rot) atomicOr(&flags[0], 1); }
+  }
+  __syncthreads();
+  if (rot_s) {
+    double jt[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) jt[t] = Js[((lane >> 4) + 4 * t) * WLD + (lane & 15)];
+    panel_update(g, cn.ld, cols, jt, r0, r1, lane);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// sigma_k = ||g_k|| ; lambda_k = sigma_k - c ; scale_k = sqrt(lambda_k) / sigma_k for lambda_k > 0 else 0 ; rank
+// grid = (1, ncones in list), one workgroup per cone; columns over waves
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(COSMO_BS) void k_psd_colscale(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ list,
+                                                           const PsdConeDev* __restrict__ cones, double* __restrict__ G,
+                                                           const double* __restrict__ cshift, double* __restrict__ colw,
+                                                           int* __restrict__ rank) {
+  if (guard && ctl->halt) return;
+  __shared__ int cnt;
+  const int ci = list[blockIdx.x];
+  const PsdConeDev cn = cones[ci];
+  double* g = G + cn.goff;
+  const double c = cshift[ci];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  int mycnt = 0;
+  for (int j = wv; j < cn.ncp; j += COSMO_BS / 64) {
+    double* col = g + (long long)j * cn.ld;
+    double a = 0.0;
+    for (int i = lane; i < cn.ld; i += 64) { const double v = col[i]; a += v * v; }
+    const double sig = sqrt(wave_sum(a));
+    const double lam = sig - c;
+    double f = 0.0;
+    if (j < cn.d + 0 && lam > 0.0 && sig > 0.0) { f = sqrt(lam) / sig; mycnt += 1; }
+    // scale the column in place: ghat_k = g_k sqrt(lambda_k) / sigma_k  (rank_k_update!, convexset.jl:248-256)
+    for (int i = lane; i < cn.ld; i += 64) col[i] = col[i] * f;
+    if (lane == 0) colw[cn.coff + j] = lam;
+  }
+  if (lane == 0 && mycnt) atomicAdd(&cnt, mycnt);
+  __syncthreads();
+  if (threadIdx.x == 0) rank[ci] = cnt;
+}
+
+// X+ = Ghat Ghat' (upper tiles) on MFMA, written straight into s.  grid = (ntiles_max, ncones); one wave per 16x16 tile.
+__global__ __launch_bounds__(COSMO_BS) void k_psd_syrk(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ list,
+                                                       const PsdConeDev* __restrict__ cones, const double* __restrict__ G,
+                                                       double* __restrict__ s) {
+  if (guard && ctl->halt) return;
+  const int ci = list[blockIdx.y];
+  const PsdConeDev cn = cones[ci];
+  const int nt = cn.ld / 16;                         // tiles per side
+  const int ntiles = nt * (nt + 1) / 2;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const double* g = G + cn.goff;
+  double* x = s + cn.off;
+  const int d = cn.d;
+  const double sq2 = sqrt(2.0);
+  for (int t = blockIdx.x * (COSMO_BS / 64) + wv; t < ntiles; t += gridDim.x * (COSMO_BS / 64)) {
+    // unrank t -> (ti <= tj), column-major over upper tiles
+    int tj = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) / 2.0);
+    while ((long long)tj * (tj + 1) / 2 > t) --tj;
+    while ((long long)(tj + 1) * (tj + 2) / 2 <= t) ++tj;
+    const int ti = t - tj * (tj + 1) / 2;
+    // D[a][b] = X[16 ti + b][16 tj + a] = sum_k Ghat[16 tj + a][k] Ghat[16 ti + b][k]
+    const double* pa = g + 16 * tj + (lane & 15) + (long long)(lane >> 4) * cn.ld;   // A[a = l&15][k = l>>4]
+    const double* pb = g + 16 * ti + (lane & 15) + (long long)(lane >> 4) * cn.ld;   // B[k = l>>4][b = l&15]
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < cn.ncp; k += 4) {
+      const double a = pa[(long long)k * cn.ld];
+      const double b = pb[(long long)k * cn.ld];
+      acc = MFMA_F64(a, b, acc);
+    }
+    const int i = 16 * ti + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = 16 * tj + (lane >> 4) + 4 * r;
+      if (i < d && j < d) {
+        if (cn.kind == COSMO_HIP_PSD_TRIANGLE) {
+          if (i <= j) x[svec_idx(i, j)] = (i == j) ? acc[r] : sq2 * acc[r];
+        } else {
+          if (i <= j) { x[(long long)j * d + i] = acc[r]; x[(long long)i * d + j] = acc[r]; }   // mirror (convexset.jl:316-318)
+        }
+      }
+    }
+  }
+}
+
+// =====================================================================================================================
+// host side
+// =====================================================================================================================
+template <class T>
+static int32_t up(cosmo_hip_handle* h, T** d, const std::vector<T>& v) {
+  if (*d) { (void)hipFree(*d); *d = nullptr; }
+  HIPCHK(h, hipMalloc((void**)d, std::max<size_t>(1, v.size()) * sizeof(T)));
+  if (!v.empty()) HIPCHK(h, hipMemcpy(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
   return COSMO_HIP_OK;
 }
-void psd_plan_destroy(cosmo_hip_handle* h) { (void)h; }
-int32_t psd_enqueue_project(cosmo_hip_handle* h, double* s, bool guard) { (void)h; (void)s; (void)guard; return COSMO_HIP_OK; }
-int32_t psd_get_ranks(cosmo_hip_handle* h, int64_t* r) { (void)h; (void)r; return COSMO_HIP_OK; }
+
+void psd_plan_destroy(cosmo_hip_handle* h) {
+  PsdPlan* p = h->psd;
+  if (!p) return;
+  if (p->d_cones) (void)hipFree(p->d_cones);
+  if (p->d_tiny) (void)hipFree(p->d_tiny);
+  if (p->d_large) (void)hipFree(p->d_large);
+  for (auto q : p->d_wg_groups) if (q) (void)hipFree(q);
+  if (p->G) (void)hipFree(p->G);
+  if (p->colw) (void)hipFree(p->colw);
+  if (p->cshift) (void)hipFree(p->cshift);
+  if (p->rank) (void)hipFree(p->rank);
+  if (p->flags) (void)hipFree(p->flags);
+  delete p;
+  h->psd = nullptr;
+}
+
+int32_t psd_plan_create(cosmo_hip_handle* h) {
+  psd_plan_destroy(h);
+  PsdPlan* p = new PsdPlan();
+  h->psd = p;
+  const ConeTable& C = h->cones;
+  long long goff = 0;
+  int coff = 0;
+  for (size_t k = 0; k < C.type.size(); ++k) {
+    if (C.type[k] != COSMO_HIP_PSD_SQUARE && C.type[k] != COSMO_HIP_PSD_TRIANGLE) continue;
+    if (C.dim[k] <= 1) continue;
+    PsdConeDev cn;
+    cn.kind = C.type[k];
+    cn.off = (int)C.off[k];
+    if (cn.kind == COSMO_HIP_PSD_SQUARE) cn.d = (int)llround(sqrt((double)C.dim[k]));
+    else cn.d = (int)((llround(floor(sqrt(1.0 + 8.0 * (double)C.dim[k]))) - 1) / 2);
+    while ((long long)cn.d * (cn.d + 1) / 2 > C.dim[k] && cn.kind == COSMO_HIP_PSD_TRIANGLE) --cn.d;
+    if (cn.kind == COSMO_HIP_PSD_TRIANGLE && (long long)cn.d * (cn.d + 1) / 2 != C.dim[k])
+      return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "PsdConeTriangle dimension %lld is not triangular", (long long)C.dim[k]);
+    cn.ld = ((cn.d + 15) / 16) * 16;
+    cn.nb = (cn.d + 7) / 8;
+    if (cn.nb & 1) cn.nb += 1;
+    cn.ncp = cn.nb * 8;
+    if (cn.ncp < cn.ld) { cn.ncp = cn.ld; cn.nb = cn.ncp / 8; }   // SYRK walks k over ncp and tiles over ld
+    cn.goff = goff;
+    cn.coff = coff;
+    cn.cone_index = (int)k;
+    const int idx = (int)p->cones.size();
+    if (cn.d <= 16) p->tiny.push_back(idx);
+    else {
+      goff += (long long)cn.ld * cn.ncp;
+      coff += cn.ncp;
+      if (cn.d <= 256) p->wg.push_back(idx); else p->large.push_back(idx);
+    }
+    p->cones.push_back(cn);
+  }
+  if (p->cones.empty()) return COSMO_HIP_OK;
+  p->gsize = goff; p->ncolw = coff;
+  CHK(up(h, &p->d_cones, p->cones));
+  CHK(up(h, &p->d_tiny, p->tiny));
+  CHK(up(h, &p->d_large, p->large));
+  // workgroup class: group by waves needed (nb/2 rounded up to 2, 4, 8, 16), largest first for load balance
+  const int classes[4] = {16, 8, 4, 2};
+  for (int c = 0; c < 4; ++c) {
+    std::vector<int> grp;
+    for (int idx : p->wg) {
+      const int need = p->cones[idx].nb / 2;
+      const int lo = (c == 3) ? 0 : classes[c + 1];
+      if (need <= classes[c] && need > lo) grp.push_back(idx);
+    }
+    if (grp.empty()) continue;
+    std::sort(grp.begin(), grp.end(), [&](int a, int b) { return p->cones[a].d > p->cones[b].d; });
+    p->wg_waves.push_back(classes[c]);
+    p->wg_groups.push_back(grp);
+    int* dptr = nullptr;
+    CHK(up(h, &dptr, grp));
+    p->d_wg_groups.push_back(dptr);
+  }
+  HIPCHK(h, hipMalloc((void**)&p->G, std::max<long long>(1, p->gsize) * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&p->colw, std::max(1, p->ncolw) * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&p->cshift, p->cones.size() * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&p->rank, p->cones.size() * sizeof(int)));
+  HIPCHK(h, hipMalloc((void**)&p->flags, 4 * sizeof(int)));
+  HIPCHK(h, hipMemset(p->rank, 0, p->cones.size() * sizeof(int)));
+  HIPCHK(h, hipMemset(p->flags, 0, 4 * sizeof(int)));
+  return COSMO_HIP_OK;
+}
+
+bool psd_needs_sync(const cosmo_hip_handle* h) { return h->psd && !h->psd->large.empty(); }
+
+int32_t psd_enqueue_project(cosmo_hip_handle* h, double* s, bool guard_b) {
+  PsdPlan* p = h->psd;
+  if (!p || p->cones.empty()) return COSMO_HIP_OK;
+  const int guard = guard_b ? 1 : 0;
+  prof_begin(h, KC_PSD);
+  if (!p->tiny.empty()) {
+    const int n = (int)p->tiny.size();
+    hipLaunchKernelGGL(k_psd_tiny, dim3((n + COSMO_BS / 64 - 1) / (COSMO_BS / 64)), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, n,
+                       p->d_tiny, p->d_cones, s, p->rank, p->flags);
+  }
+  for (size_t gi = 0; gi < p->wg_groups.size(); ++gi) {
+    const int n = (int)p->wg_groups[gi].size();
+    const int* lst = p->d_wg_groups[gi];
+    hipLaunchKernelGGL(k_psd_populate, dim3(8, n), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, lst, p->d_cones, s, p->G, p->cshift);
+    switch (p->wg_waves[gi]) {
+      case 16: hipLaunchKernelGGL((k_psd_jacobi_wg<16>), dim3(n), dim3(1024), 0, h->stream, h->ctl, guard, lst, p->d_cones, p->G, p->cshift, p->flags); break;
+      case 8: hipLaunchKernelGGL((k_psd_jacobi_wg<8>), dim3(n), dim3(512), 0, h->stream, h->ctl, guard, lst, p->d_cones, p->G, p->cshift, p->flags); break;
+      case 4: hipLaunchKernelGGL((k_psd_jacobi_wg<4>), dim3(n), dim3(256), 0, h->stream, h->ctl, guard, lst, p->d_cones, p->G, p->cshift, p->flags); break;
+      default: hipLaunchKernelGGL((k_psd_jacobi_wg<2>), dim3(n), dim3(128), 0, h->stream, h->ctl, guard, lst, p->d_cones, p->G, p->cshift, p->flags); break;
+    }
+    hipLaunchKernelGGL(k_psd_colscale, dim3(n), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, lst, p->d_cones, p->G, p->cshift, p->colw, p->rank);
+    int maxtiles = 1;
+    for (int idx : p->wg_groups[gi]) { const int nt = p->cones[idx].ld / 16; maxtiles = std::max(maxtiles, nt * (nt + 1) / 2); }
+    hipLaunchKernelGGL(k_psd_syrk, dim3((maxtiles + 3) / 4, n), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, lst, p->d_cones, p->G, s);
+  }
+  if (!p->large.empty()) {
+    // host-paced: one launch per tournament step, convergence flag read once per sweep
+    if (guard) {
+      CHK(sync_ctl(h));
+      if (h->ctl_host->halt) { prof_end(h); return COSMO_HIP_OK; }
+    }
+    const int n = (int)p->large.size();
+    int nbmax = 0;
+    for (int idx : p->large) nbmax = std::max(nbmax, p->cones[idx].nb);
+    hipLaunchKernelGGL(k_psd_populate, dim3(64, n), dim3(COSMO_BS), 0, h->stream, h->ctl, 0, p->d_large, p->d_cones, s, p->G, p->cshift);
+    int sweep = 0;
+    for (; sweep < PSD_MAX_SWEEPS; ++sweep) {
+      HIPCHK(h, hipMemsetAsync(p->flags, 0, sizeof(int), h->stream));
+      for (int st = 0; st < nbmax - 1; ++st)
+        hipLaunchKernelGGL(k_psd_step, dim3(nbmax / 2, n), dim3(PSD_STEP_WAVES * 64), 0, h->stream, p->d_large, p->d_cones, p->G,
+                           p->cshift, st, p->flags);
+      int fl = 0;
+      HIPCHK(h, hipMemcpyAsync(&fl, p->flags, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      if (!fl) break;
+    }
+    if (sweep >= PSD_MAX_SWEEPS) return cosmo_fail(h, COSMO_HIP_ERR_EIG, "Jacobi eigensolver did not converge in %d sweeps", PSD_MAX_SWEEPS);
+    hipLaunchKernelGGL(k_psd_colscale, dim3(n), dim3(COSMO_BS), 0, h->stream, h->ctl, 0, p->d_large, p->d_cones, p->G, p->cshift, p->colw, p->rank);
+    int maxtiles = 1;
+    for (int idx : p->large) { const int nt = p->cones[idx].ld / 16; maxtiles = std::max(maxtiles, nt * (nt + 1) / 2); }
+    hipLaunchKernelGGL(k_psd_syrk, dim3(std::min(8192, (maxtiles + 3) / 4), n), dim3(COSMO_BS), 0, h->stream, h->ctl, 0, p->d_large, p->d_cones, p->G, s);
+  }
+  prof_end(h);
+  HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}
+
+int32_t psd_get_ranks(cosmo_hip_handle* h, int64_t* rank_per_cone) {
+  PsdPlan* p = h->psd;
+  if (!p || p->cones.empty()) return COSMO_HIP_OK;
+  std::vector<int> r(p->cones.size());
+  int fl[4] = {0, 0, 0, 0};
+  HIPCHK(h, hipMemcpyAsync(r.data(), p->rank, r.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(fl, p->flags, sizeof fl, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (fl[1]) return cosmo_fail(h, COSMO_HIP_ERR_EIG, "Jacobi eigensolver did not converge");
+  for (size_t i = 0; i < p->cones.size(); ++i) rank_per_cone[p->cones[i].cone_index] = r[i];
+  return COSMO_HIP_OK;
+}

@@ -1,0 +1,177 @@
+"""GPU parity tests for the PSD cone projections through the C ABI, against the oracle's LAPACK
+dsyevr + syrk restatement of src/convexset.jl:219-263.  Tolerance: ||dX+||_F <= 64 d eps ||X||_F ; rank
+(nnz_lambda) equal when the spectrum has a gap at 0."""
+import math
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import cosmo_jl_amd as cj
+from oracle import cosmo_oracle as O
+from tests import util
+from tests.util import EPS
+
+pytestmark = pytest.mark.gpu
+F = cj._ffi
+
+
+def _handle_for_sets(sets):
+    m = sum(K.dim for K in sets)
+    h = cj.Handle(0)
+    h.set_problem(sp.identity(2, format="csc"), np.zeros(2), sp.csc_matrix((m, 2)), np.zeros(m))
+    h.set_cones([K.kind for K in sets], [K.dim for K in sets], None, None)
+    return h
+
+
+def sym_with_spectrum(rng, lam):
+    d = lam.size
+    Q = np.linalg.qr(rng.standard_normal((d, d)))[0]
+    X = (Q * lam) @ Q.T
+    return (X + X.T) / 2
+
+
+def gapped_spectrum(rng, d, npos=None):
+    npos = rng.integers(0, d + 1) if npos is None else npos
+    lam = np.concatenate([rng.uniform(0.1, 2.0, npos), -rng.uniform(0.1, 2.0, d - npos)])
+    rng.shuffle(lam)
+    return lam
+
+
+def check_projection(sets, mats, rtol_factor=64.0):
+    h = _handle_for_sets(sets)
+    s = []
+    for K, X in zip(sets, mats):
+        s.append(cj.problems.svec(X) if K.kind == F.PSD_TRIANGLE else X.reshape(-1, order="F"))
+    s = np.concatenate(s)
+    ref = s.copy(); info = {}
+    O.project(ref, util.oracle_cones(sets), info)
+    out, ranks, _ = h.project(s)
+    off = 0
+    for K, X, rk_ref, rk in zip(sets, mats, info["psd_rank"], ranks):
+        d = X.shape[0]
+        a = out[off:off + K.dim]; b = ref[off:off + K.dim]
+        if K.kind == F.PSD_SQUARE:
+            A = a.reshape(d, d, order="F")
+            assert np.array_equal(A, A.T)                      # lower triangle is an exact mirror (convexset.jl:316-318)
+            err = np.linalg.norm(a - b)
+        else:
+            err = np.linalg.norm(a - b)                        # svec is an isometry: this is the Frobenius norm
+        assert err <= rtol_factor * d * EPS * max(np.linalg.norm(X), 1e-300), (d, err, err / (d * EPS * np.linalg.norm(X)))
+        assert rk == rk_ref, (d, rk, rk_ref)
+        off += K.dim
+    return out
+
+
+@pytest.mark.parametrize("kind", ["tri", "square"])
+def test_psd_tiny_sizes(kind):
+    rng = np.random.default_rng(1)
+    dims = [2, 3, 4, 5, 7, 8, 9, 15, 16] * 3
+    mats = [sym_with_spectrum(rng, gapped_spectrum(rng, d)) for d in dims]
+    sets = [cj.PsdConeTriangle(d * (d + 1) // 2) if kind == "tri" else cj.PsdCone(d * d) for d in dims]
+    check_projection(sets, mats)
+
+
+@pytest.mark.parametrize("kind", ["tri", "square"])
+def test_psd_workgroup_sizes(kind):
+    rng = np.random.default_rng(2)
+    dims = [17, 20, 24, 31, 32, 33, 47, 64, 65, 100, 127, 128, 129, 200, 255, 256]
+    mats = [sym_with_spectrum(rng, gapped_spectrum(rng, d)) for d in dims]
+    sets = [cj.PsdConeTriangle(d * (d + 1) // 2) if kind == "tri" else cj.PsdCone(d * d) for d in dims]
+    check_projection(sets, mats)
+
+
+def test_psd_large_multi_workgroup():
+    rng = np.random.default_rng(3)
+    dims = [257, 300, 520]
+    mats = [sym_with_spectrum(rng, gapped_spectrum(rng, d)) for d in dims]
+    sets = [cj.PsdConeTriangle(d * (d + 1) // 2) for d in dims]
+    check_projection(sets, mats)
+
+
+def test_psd_special_spectra():
+    rng = np.random.default_rng(4)
+    mats, sets = [], []
+    for d in (6, 40, 130):
+        B = rng.standard_normal((d, d))
+        mats += [B @ B.T / d + 0.2 * np.eye(d),                 # already PSD: projection is the identity map
+                 -(B @ B.T / d + 0.2 * np.eye(d)),              # negative definite: projection is 0
+                 np.zeros((d, d)),                              # zero matrix
+                 3.0 * np.eye(d),                               # one eigenvalue of multiplicity d
+                 sym_with_spectrum(rng, np.concatenate([np.full(d // 2, 1.5), np.full(d - d // 2, -0.7)])),  # two clusters
+                 sym_with_spectrum(rng, np.concatenate([[5.0, -5.0], gapped_spectrum(rng, d - 2)])),        # +/- pair
+                 1e8 * sym_with_spectrum(rng, gapped_spectrum(rng, d)),   # badly scaled
+                 1e-9 * sym_with_spectrum(rng, gapped_spectrum(rng, d))]
+        sets += [cj.PsdConeTriangle(d * (d + 1) // 2)] * 8
+    out = check_projection(sets, mats)
+    # exact zeros for the zero matrix
+    off = 0
+    for K, X in zip(sets, mats):
+        if not X.any():
+            assert not out[off:off + K.dim].any()
+        off += K.dim
+
+
+def test_psd_one_by_one_and_mixed_composite():
+    rng = np.random.default_rng(5)
+    sets = [cj.Nonnegatives(5), cj.PsdConeTriangle(1), cj.PsdCone(1), cj.SecondOrderCone(4), cj.PsdConeTriangle(10),
+            cj.PsdCone(9), cj.PsdConeTriangle(210), cj.ZeroSet(2)]
+    m = sum(K.dim for K in sets)
+    h = _handle_for_sets(sets)
+    s = rng.standard_normal(m)
+    ref = s.copy(); info = {}
+    O.project(ref, util.oracle_cones(sets), info)
+    out, ranks, br = h.project(s)
+    assert np.linalg.norm(out - ref) <= 64 * 20 * EPS * np.linalg.norm(s)
+    assert [r for r in ranks if r >= 0] == info["psd_rank"]
+    assert [b for b in br if b >= 0] == info["soc_branch"]
+
+
+def test_psd_idempotent_and_in_cone_random_unstructured():
+    # no spectral gap here: only properties (sets.jl:73-78: min eig >= -1e-9) and idempotence
+    rng = np.random.default_rng(6)
+    dims = [12, 50, 90, 180]
+    mats = [(lambda B: (B + B.T) / 2)(rng.standard_normal((d, d))) for d in dims]
+    sets = [cj.PsdConeTriangle(d * (d + 1) // 2) for d in dims]
+    h = _handle_for_sets(sets)
+    s = np.concatenate([cj.problems.svec(X) for X in mats])
+    p1, r1, _ = h.project(s)
+    p2, r2, _ = h.project(p1)
+    off = 0
+    for K, X in zip(sets, mats):
+        d = X.shape[0]
+        Xp = cj.problems.smat(p1[off:off + K.dim])
+        assert np.linalg.eigvalsh(Xp).min() >= -1e-9
+        assert np.linalg.norm(p2[off:off + K.dim] - p1[off:off + K.dim]) <= 64 * d * EPS * np.linalg.norm(X)
+        w, V = np.linalg.eigh(X)
+        assert np.linalg.norm(Xp - (V * np.maximum(w, 0)) @ V.T) <= 64 * d * EPS * np.linalg.norm(X)
+        off += K.dim
+
+
+def test_closest_correlation_end_to_end_small():
+    # structure of test/UnitTests/closestcorr.jl:41-76 with the triangle cone, d = 30
+    prob = cj.problems.closest_correlation(d=30, seed=12345)
+    d = 30
+    st = cj.Settings(eps_abs=1e-4, eps_rel=1e-4)
+    model = cj.Model(); model.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)
+    res = cj.optimize(model)
+    X = cj.problems.smat(res.x)
+    assert res.status == "Solved"                                              # closestcorr.jl:74
+    assert np.max(np.abs(np.diag(X) - 1)) < 1e-5                               # :75
+    assert np.linalg.eigvalsh(X).min() > -1e-3                                 # :76
+    ref = O.solve(prob["P"], prob["q"], prob["A"], prob["b"], util.oracle_cones(prob["sets"]),
+                  O.Settings(kkt_solver="cg", eps_abs=1e-4, eps_rel=1e-4))
+    assert ref.status == "Solved" and abs(res.iter - ref.iter) <= 25
+    assert abs(res.obj_val - ref.obj_val) <= 1e-4 * (1 + abs(ref.obj_val))
+    assert np.max(np.abs(res.x - ref.x)) <= 1e-3
+
+
+def test_chordal_sdp_end_to_end_small():
+    prob = cj.problems.chordal_sdp(ncliques=12, dmin=4, dmax=40, sep_min=1, sep_max=3, n_total=1500, n_zero=10, n_nonneg=20)
+    model = cj.Model(); model.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], cj.Settings())
+    res = cj.optimize(model)
+    ref = O.solve(prob["P"], prob["q"], prob["A"], prob["b"], util.oracle_cones(prob["sets"]), O.Settings(kkt_solver="cg"))
+    assert res.status == ref.status == "Solved"
+    assert abs(res.iter - ref.iter) <= 25
+    assert abs(res.obj_val - ref.obj_val) <= 1e-4 * (1 + abs(ref.obj_val))
+    assert len(res.info.rho_updates) == len(ref.rho_updates)
