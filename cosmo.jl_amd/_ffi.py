@@ -95,6 +95,7 @@ SIGNATURES = {
     "cosmo_hip_set_profiling": (C.c_int32, [C.c_void_p, C.c_int32]),
     "cosmo_hip_get_kernel_times": (C.c_int32, [C.c_void_p, _PD, _PI64]),
     "cosmo_hip_kernel_class_name": (C.c_char_p, [C.c_int32]),
+    "cosmo_hip_psd_stats": (C.c_int32, [C.c_void_p, _PI64]),
 }
 
 
@@ -291,6 +292,11 @@ class Handle:
         t = C.c_double(0); by = C.c_double(0)
         self._chk(self.lib.cosmo_hip_time_spmv(self._h, which, reps, C.byref(t), C.byref(by)))
         return t.value, by.value
+
+    def psd_stats(self):
+        out = np.zeros(4, dtype=np.int64)
+        self._chk(self.lib.cosmo_hip_psd_stats(self._h, out.ctypes.data_as(_PI64)))
+        return dict(zip(["max_sweeps_wg", "sweeps_large", "not_converged", "ncones"], out.tolist()))
 
     def set_profiling(self, on):
         self._chk(self.lib.cosmo_hip_set_profiling(self._h, int(on)))

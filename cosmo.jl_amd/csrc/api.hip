@@ -27,6 +27,7 @@ int32_t enqueue_check(cosmo_hip_handle* h, int guard, int mode);
 // minres.hip
 int32_t minres_enqueue_solve(cosmo_hip_handle* h, int guard, bool from_loop);
 int32_t minres_alloc(cosmo_hip_handle* h);
+int32_t minres_resume(cosmo_hip_handle* h, int extra);
 
 // ---------------------------------------------------------------------------------------------------------------------
 int32_t cosmo_fail(cosmo_hip_handle* h, int32_t code, const char* fmt, ...) {
@@ -643,7 +644,8 @@ static int32_t resolve_stall(cosmo_hip_handle* h) {
       CHK(enqueue_cg_iterations(h, 1, h->ctl_host->cg_k, extra));
       CHK(enqueue_tail(h, 1));
     } else {
-      return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "internal: MINRES path does not use budgets");
+      CHK(enqueue_clear_stall(h));
+      CHK(minres_resume(h, extra));
     }
     CHK(sync_ctl(h));
     h->budget = std::min(4096, std::max(h->budget, h->ctl_host->cg_k + 2));

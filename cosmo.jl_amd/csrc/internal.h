@@ -40,7 +40,8 @@ struct Ctl {
   double rhs_norm;
   double rho;        // scalar rho (ws.rho)
   double r_prim, r_dual, max_norm_prim, max_norm_dual, cost;
-  double minres[16]; // MINRES scalar recurrences (H[4], rhs[2], c_prev, s_prev, c_curr, s_curr, resnorm, ...)
+  double minres[16]; // MINRES scalar recurrences, two parity slots of 8 (see minres.hip)
+  double udotc_slot; // <v_curr, v_next> of the current MINRES iteration
   double rho_updates[COSMO_HIP_MAX_RHO_UPDATES];
 };
 

@@ -724,3 +724,17 @@ int32_t time_op_apply(cosmo_hip_handle* h, int reps, double* avg_seconds) {
   HIPCHK(h, hipGetLastError());
   return COSMO_HIP_OK;
 }
+
+// launch helpers used by minres.hip (keeps every kernel launch next to its definition)
+int32_t launch_spmv_A_rho(cosmo_hip_handle* h, int guard, int mode, const double* v, double* out) {
+  hipLaunchKernelGGL(k_spmv_A_rho, dim3(h->A.grid > 0 ? h->A.grid : 1), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, mode, view_of(h->A), v,
+                     h->rho, out);
+  HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}
+int32_t launch_reduced_rhs(cosmo_hip_handle* h, int guard, double* out_rhs) {
+  hipLaunchKernelGGL(k_cg_rhs, dim3(h->AT.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, view_of(h->AT), h->y2, h->ls_x, out_rhs,
+                     PARTS(h, SLOT_BB));
+  HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}

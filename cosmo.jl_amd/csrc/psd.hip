@@ -20,6 +20,7 @@
 #include "device_utils.h"
 #include <algorithm>
 #include <math.h>
+#include <stdlib.h>
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
@@ -54,6 +55,9 @@ struct PsdPlan {
   int* flags = nullptr;                // [0] sweep-rotated flag (large path), [1] error flag
   long long gsize = 0;
   int ncolw = 0;
+  int last_large_sweeps = 0;
+  double tol_factor = 0.125;   // rotate while |w_pq| > tol_factor * d * eps * sqrt(w_pp w_qq)
+  int dbg = 0;
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -65,30 +69,43 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// One cyclic sweep (15 rounds x 8 disjoint rotations).  mode 0: W is a Gram matrix (relative criterion
-// |w_pq| > tol sqrt(w_pp w_qq), columns with w_kk <= tiny skipped).  mode 1: W is the symmetric matrix itself (absolute
-// criterion |w_pq| > tiny).  Returns (wave-uniform) whether any rotation fired.
+// Rotation that annihilates w_pq:  t = sign(delta) w_pq / (|delta| + sqrt(delta^2 + w_pq^2)), delta = (w_qq - w_pp)/2.
+// t only steers convergence, so it uses the hardware approximations (v_sqrt_f64, v_rcp_f64); c = (1+t^2)^(-1/2) is
+// refined with one Newton step because c^2 + s^2 = 1 must hold to rounding for J to stay orthogonal.
+__device__ __forceinline__ void jacobi_cs(double app, double aqq, double apq, double& c, double& s) {
+  const double delta = 0.5 * (aqq - app);
+  const double h = __builtin_amdgcn_sqrt(fma(delta, delta, apq * apq));
+  const double den = fabs(delta) + h;
+  const double t = ((delta >= 0.0) ? apq : -apq) * __builtin_amdgcn_rcp(den);
+  const double a = fma(t, t, 1.0);
+  double y = __builtin_amdgcn_rsq(a);
+  const double e = fma(-a * y, y, 1.0);          // 1 - a y^2
+  y = fma(0.5 * e, y, y);
+  c = y;
+  s = y * t;
+}
+
+// One sweep of 8-rotation rounds on the 16x16 matrix W (LDS), accumulating J.
+//  nrounds = 15: all 120 pairs (cyclic round-robin).  nrounds = 8: only the 64 cross pairs (p < 8 <= q) of a block pair.
+//  mode 0: W is a Gram matrix (relative criterion |w_pq| > tol sqrt(w_pp w_qq); columns with w_kk <= tiny are skipped).
+//  mode 1: W is the symmetric matrix itself (absolute criterion |w_pq| > tiny).
+// Returns (wave-uniform) whether any rotation fired.
 __device__ __forceinline__ int jacobi16_sweep(double* W, double* J, int* part, double* ca, double* cb, double tol,
-                                              double tiny, int mode, int lane) {
+                                              double tiny, int mode, int nrounds, int lane) {
   int rotated = 0;
-  for (int rd = 0; rd < 15; ++rd) {
+  for (int rd = 0; rd < nrounds; ++rd) {
     if (lane < 8) {
       int p, q;
-      if (lane == 0) { p = rd; q = 15; }
+      if (nrounds == 8) { p = lane; q = 8 + ((lane + rd) & 7); }
+      else if (lane == 0) { p = rd; q = 15; }
       else { p = (rd + lane) % 15; q = (rd - lane + 15) % 15; }
       if (p > q) { const int t = p; p = q; q = t; }
       const double app = W[p * WLD + p], aqq = W[q * WLD + q], apq = W[p * WLD + q];
       double c = 1.0, s = 0.0;
       bool rot;
-      if (mode == 0) rot = (app > tiny) && (aqq > tiny) && (fabs(apq) > tol * sqrt(app * aqq));
+      if (mode == 0) rot = (app > tiny) && (aqq > tiny) && (apq * apq > (tol * tol) * (app * aqq));
       else rot = fabs(apq) > tiny;
-      if (rot) {
-        const double zeta = (aqq - app) / (2.0 * apq);
-        const double t = ((zeta >= 0.0) ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        c = 1.0 / sqrt(1.0 + t * t);
-        s = c * t;
-        rotated = 1;
-      }
+      if (rot) { jacobi_cs(app, aqq, apq, c, s); rotated = 1; }
       part[p] = q; ca[p] = c; cb[p] = -s;   // col_p' = c col_p - s col_q
       part[q] = p; ca[q] = c; cb[q] = s;    // col_q' = s col_p + c col_q
     }
@@ -116,6 +133,26 @@ __device__ __forceinline__ int jacobi16_sweep(double* W, double* J, int* part, d
     wave_lds_fence();
   }
   return __any(rotated) ? 1 : 0;
+}
+
+// Does any pair of the panel need a rotation?  cross_only: test the 64 entries (p < 8 <= q), one per lane; otherwise all
+// 120 pairs (two per lane).  Wave-uniform result; lets converged block pairs skip the Jacobi sweep and the panel update.
+__device__ __forceinline__ int gram_needs_work(const double* W, double tol, double tiny, int cross_only, int lane) {
+  int need = 0;
+  if (cross_only) {
+    const int p = lane & 7, q = 8 + (lane >> 3);
+    const double app = W[p * WLD + p], aqq = W[q * WLD + q], apq = W[p * WLD + q];
+    need = (app > tiny) && (aqq > tiny) && (apq * apq > (tol * tol) * (app * aqq));
+  } else {
+    for (int e = lane; e < 120; e += 64) {
+      int p = 0, rem = e;
+      while (rem >= 15 - p) { rem -= 15 - p; ++p; }
+      const int q = p + 1 + rem;
+      const double app = W[p * WLD + p], aqq = W[q * WLD + q], apq = W[p * WLD + q];
+      need |= (app > tiny) && (aqq > tiny) && (apq * apq > (tol * tol) * (app * aqq));
+    }
+  }
+  return __any(need) ? 1 : 0;
 }
 
 // svec index of (i, j), i <= j (0-based), column-major upper triangle
@@ -164,7 +201,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_psd_tiny(const Ctl* __restrict__ c
   const double thr = PSD_EPS * fro;
   int sweeps = 0, rot = (fro > 0.0) ? 1 : 0;
   while (rot && sweeps < PSD_MAX_SWEEPS) {
-    rot = jacobi16_sweep(W, J, parts[wv], cas[wv], cbs[wv], 0.0, thr, 1, lane);
+    rot = jacobi16_sweep(W, J, parts[wv], cas[wv], cbs[wv], 0.0, thr, 1, 15, lane);
     ++sweeps;
   }
   if (rot && lane == 0) atomicOr(&flags[1], 1);            // did not converge
@@ -247,7 +284,20 @@ __global__ __launch_bounds__(COSMO_BS) void k_psd_populate(const Ctl* __restrict
 __device__ __forceinline__ v4d panel_gram(const double* __restrict__ g, int ld, int colL, int r0, int r1, int lane) {
   v4d acc = {0.0, 0.0, 0.0, 0.0};
   const double* cp = g + (long long)colL * ld + 4 * (lane >> 4);
-  for (int r = r0; r < r1; r += 16) {
+  int r = r0;
+  for (; r + 64 <= r1; r += 64) {                      // four 16-row chunks in flight
+    v4d v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const v4d*>(cp + r + 16 * u);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc = MFMA_F64(v[u].x, v[u].x, acc);
+      acc = MFMA_F64(v[u].y, v[u].y, acc);
+      acc = MFMA_F64(v[u].z, v[u].z, acc);
+      acc = MFMA_F64(v[u].w, v[u].w, acc);
+    }
+  }
+  for (; r < r1; r += 16) {
     const v4d v = *reinterpret_cast<const v4d*>(cp + r);
     acc = MFMA_F64(v.x, v.x, acc);
     acc = MFMA_F64(v.y, v.y, acc);
@@ -269,7 +319,18 @@ __device__ __forceinline__ void panel_update(double* __restrict__ g, int ld, con
     src[t] = g + (long long)cols[4 * t + kg] * ld + rr;   // B operand of step t: P[r + rr][4 t + kg]
     dst[t] = g + (long long)cols[kg + 4 * t] * ld + rr;   // D reg t: new column kg + 4 t, row r + rr
   }
-  for (int r = r0; r < r1; r += 16) {
+  int r = r0;
+  for (; r + 32 <= r1; r += 32) {                      // two chunks in flight (all loads of both chunks precede the stores)
+    double b0[4], b1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { b0[t] = src[t][r]; b1[t] = src[t][r + 16]; }
+    v4d a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { a0 = MFMA_F64(jt[t], b0[t], a0); a1 = MFMA_F64(jt[t], b1[t], a1); }
+    dst[0][r] = a0.x; dst[1][r] = a0.y; dst[2][r] = a0.z; dst[3][r] = a0.w;
+    dst[0][r + 16] = a1.x; dst[1][r + 16] = a1.y; dst[2][r + 16] = a1.z; dst[3][r + 16] = a1.w;
+  }
+  for (; r < r1; r += 16) {
     double b[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) b[t] = src[t][r];
@@ -294,7 +355,7 @@ __device__ __forceinline__ void rr_pair(int nb, int st, int w, int& I, int& J) {
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_psd_jacobi_wg(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ list,
                                                            const PsdConeDev* __restrict__ cones, double* __restrict__ G,
-                                                           const double* __restrict__ cshift, int* __restrict__ flags) {
+                                                           const double* __restrict__ cshift, int* __restrict__ flags, double tolf, int dbg) {
   if (guard && ctl->halt) return;
   __shared__ double Ws[NW][16 * WLD];
   __shared__ double Js[NW][16 * WLD];
@@ -308,43 +369,58 @@ __global__ __launch_bounds__(NW * 64) void k_psd_jacobi_wg(const Ctl* __restrict
   double* g = G + cn.goff;
   const int nb = cn.nb, npairs = nb / 2;
   const double c = cshift[ci];
-  const double tol = (double)cn.d * PSD_EPS;
+  const double tol = tolf * (double)cn.d * PSD_EPS;
   const double tiny = (tol * c) * (tol * c);
   double* W = Ws[wv]; double* J = Js[wv];
   int sweep = 0;
+  // one visit of block pair (I, Jb): Gram on MFMA, Jacobi on the 16x16 Gram matrix, panel update on MFMA
+  auto visit = [&](int I, int Jb, int full) {
+    if (lane < 16) colss[wv][lane] = (lane < 8) ? (I * 8 + lane) : (Jb * 8 + lane - 8);
+    wave_lds_fence();
+    const int colL = colss[wv][lane & 15];
+    v4d w = {1.0, 0.5, 0.25, 0.125};
+    if (!(dbg & 4)) w = panel_gram(g, cn.ld, colL, 0, cn.ld, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = (lane >> 4) + 4 * r, j = lane & 15;
+      W[i * WLD + j] = w[r];
+      J[i * WLD + j] = (i == j) ? 1.0 : 0.0;
+    }
+    wave_lds_fence();
+    if (!(dbg & 8) && !gram_needs_work(W, tol, tiny, !full, lane)) return;
+    int rot = 1;
+    if (!(dbg & 1)) rot = jacobi16_sweep(W, J, parts[wv], cas[wv], cbs[wv], tol, tiny, 0, full ? 15 : 8, lane);
+    if (dbg & 2) rot = 0;
+    if (dbg & 16) { if (lane == 0 && sweep < 10) any_rot = 1; }
+    if (rot) {
+      double jt[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) jt[t] = J[((lane >> 4) + 4 * t) * WLD + (lane & 15)];
+      panel_update(g, cn.ld, colss[wv], jt, 0, cn.ld, lane);
+      if (lane == 0) any_rot = 1;
+    }
+  };
   for (; sweep < PSD_MAX_SWEEPS; ++sweep) {
     if (threadIdx.x == 0) any_rot = 0;
+    __syncthreads();
+    // diagonal pass: all pairs inside blocks (2w, 2w+1); the tournament steps then only rotate cross pairs
+    if (wv < npairs) visit(2 * wv, 2 * wv + 1, 1);
     __syncthreads();
     for (int st = 0; st < nb - 1; ++st) {
       if (wv < npairs) {
         int I, Jb;
         rr_pair(nb, st, wv, I, Jb);
-        if (lane < 16) colss[wv][lane] = (lane < 8) ? (I * 8 + lane) : (Jb * 8 + lane - 8);
-        wave_lds_fence();
-        const int colL = colss[wv][lane & 15];
-        const v4d w = panel_gram(g, cn.ld, colL, 0, cn.ld, lane);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = (lane >> 4) + 4 * r, j = lane & 15;
-          W[i * WLD + j] = w[r];
-          J[i * WLD + j] = (i == j) ? 1.0 : 0.0;
-        }
-        wave_lds_fence();
-        const int rot = jacobi16_sweep(W, J, parts[wv], cas[wv], cbs[wv], tol, tiny, 0, lane);
-        if (rot) {
-          double jt[4];
-#pragma unroll
-          for (int t = 0; t < 4; ++t) jt[t] = J[((lane >> 4) + 4 * t) * WLD + (lane & 15)];
-          panel_update(g, cn.ld, colss[wv], jt, 0, cn.ld, lane);
-          if (lane == 0) any_rot = 1;
-        }
+        visit(I, Jb, 0);
       }
       __syncthreads();
     }
     if (!any_rot) break;
     __syncthreads();
   }
-  if (sweep >= PSD_MAX_SWEEPS && threadIdx.x == 0) atomicOr(&flags[1], 1);
+  if (threadIdx.x == 0) {
+    atomicMax(&flags[2], sweep + 1);
+    if (sweep >= PSD_MAX_SWEEPS) atomicOr(&flags[1], 1);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -354,7 +430,7 @@ __global__ __launch_bounds__(NW * 64) void k_psd_jacobi_wg(const Ctl* __restrict
 #define PSD_STEP_WAVES 8
 __global__ __launch_bounds__(PSD_STEP_WAVES * 64) void k_psd_step(const int* __restrict__ list, const PsdConeDev* __restrict__ cones,
                                                                   double* __restrict__ G, const double* __restrict__ cshift,
-                                                                  int st, int* __restrict__ flags) {
+                                                                  int st, int* __restrict__ flags, double tolf) {
   __shared__ double Wp[PSD_STEP_WAVES][16 * WLD];
   __shared__ double Ws[16 * WLD];
   __shared__ double Js[16 * WLD];
@@ -367,12 +443,14 @@ __global__ __launch_bounds__(PSD_STEP_WAVES * 64) void k_psd_step(const int* __r
   const PsdConeDev cn = cones[ci];
   const int nb = cn.nb, npairs = nb / 2;
   if ((int)blockIdx.x >= npairs || st >= nb - 1) return;
+  const int full = (st < 0) ? 1 : 0;
   double* g = G + cn.goff;
   const double c = cshift[ci];
-  const double tol = (double)cn.d * PSD_EPS;
+  const double tol = tolf * (double)cn.d * PSD_EPS;
   const double tiny = (tol * c) * (tol * c);
   int I, Jb;
-  rr_pair(nb, st, blockIdx.x, I, Jb);
+  if (full) { I = 2 * blockIdx.x; Jb = I + 1; }
+  else rr_pair(nb, st, blockIdx.x, I, Jb);
   if (threadIdx.x < 16) cols[threadIdx.x] = (threadIdx.x < 8) ? (I * 8 + threadIdx.x) : (Jb * 8 + threadIdx.x - 8);
   __syncthreads();
   // rows split in 16-row chunks over the waves
@@ -393,7 +471,8 @@ __global__ __launch_bounds__(PSD_STEP_WAVES * 64) void k_psd_step(const int* __r
       Js[i * WLD + j] = (i == j) ? 1.0 : 0.0;
     }
     wave_lds_fence();
-    const int rot = jacobi16_sweep(Ws, Js, parts, cas, cbs, tol, tiny, 0, lane);
+    int rot = 0;
+    if (gram_needs_work(Ws, tol, tiny, !full, lane)) rot = jacobi16_sweep(Ws, Js, parts, cas, cbs, tol, tiny, 0, full ? 15 : 8, lane);
     if (lane == 0) { rot_s = rot; if (rot) atomicOr(&flags[0], 1); }
   }
   __syncthreads();
@@ -414,30 +493,25 @@ __global__ __launch_bounds__(COSMO_BS) void k_psd_colscale(const Ctl* __restrict
                                                            const double* __restrict__ cshift, double* __restrict__ colw,
                                                            int* __restrict__ rank) {
   if (guard && ctl->halt) return;
-  __shared__ int cnt;
-  const int ci = list[blockIdx.x];
+  const int ci = list[blockIdx.y];
   const PsdConeDev cn = cones[ci];
   double* g = G + cn.goff;
   const double c = cshift[ci];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (threadIdx.x == 0) cnt = 0;
-  __syncthreads();
   int mycnt = 0;
-  for (int j = wv; j < cn.ncp; j += COSMO_BS / 64) {
+  for (int j = blockIdx.x * (COSMO_BS / 64) + wv; j < cn.ncp; j += gridDim.x * (COSMO_BS / 64)) {
     double* col = g + (long long)j * cn.ld;
     double a = 0.0;
     for (int i = lane; i < cn.ld; i += 64) { const double v = col[i]; a += v * v; }
     const double sig = sqrt(wave_sum(a));
     const double lam = sig - c;
     double f = 0.0;
-    if (j < cn.d + 0 && lam > 0.0 && sig > 0.0) { f = sqrt(lam) / sig; mycnt += 1; }
+    if (j < cn.d && lam > 0.0 && sig > 0.0) { f = sqrt(lam) / sig; mycnt += 1; }
     // scale the column in place: ghat_k = g_k sqrt(lambda_k) / sigma_k  (rank_k_update!, convexset.jl:248-256)
     for (int i = lane; i < cn.ld; i += 64) col[i] = col[i] * f;
     if (lane == 0) colw[cn.coff + j] = lam;
   }
-  if (lane == 0 && mycnt) atomicAdd(&cnt, mycnt);
-  __syncthreads();
-  if (threadIdx.x == 0) rank[ci] = cnt;
+  if (lane == 0 && mycnt) atomicAdd(&rank[ci], mycnt);    // integer count: order independent
 }
 
 // X+ = Ghat Ghat' (upper tiles) on MFMA, written straight into s.  grid = (ntiles_max, ncones); one wave per 16x16 tile.
@@ -546,18 +620,21 @@ int32_t psd_plan_create(cosmo_hip_handle* h) {
     }
     p->cones.push_back(cn);
   }
+  if (const char* e = getenv("COSMO_HIP_PSD_TOL_FACTOR")) p->tol_factor = atof(e);
+  if (const char* e = getenv("COSMO_HIP_PSD_DEBUG")) p->dbg = atoi(e);   // timing ablations only (results are wrong)
   if (p->cones.empty()) return COSMO_HIP_OK;
   p->gsize = goff; p->ncolw = coff;
   CHK(up(h, &p->d_cones, p->cones));
   CHK(up(h, &p->d_tiny, p->tiny));
   CHK(up(h, &p->d_large, p->large));
   // workgroup class: group by waves needed (nb/2 rounded up to 2, 4, 8, 16), largest first for load balance
-  const int classes[4] = {16, 8, 4, 2};
-  for (int c = 0; c < 4; ++c) {
+  // two launch classes (16 or 4 waves per workgroup) so that the big cones of a mixed batch run concurrently
+  const int classes[2] = {16, 4};
+  for (int c = 0; c < 2; ++c) {
     std::vector<int> grp;
     for (int idx : p->wg) {
       const int need = p->cones[idx].nb / 2;
-      const int lo = (c == 3) ? 0 : classes[c + 1];
+      const int lo = (c == 1) ? 0 : classes[c + 1];
       if (need <= classes[c] && need > lo) grp.push_back(idx);
     }
     if (grp.empty()) continue;
@@ -585,6 +662,7 @@ int32_t psd_enqueue_project(cosmo_hip_handle* h, double* s, bool guard_b) {
   if (!p || p->cones.empty()) return COSMO_HIP_OK;
   const int guard = guard_b ? 1 : 0;
   prof_begin(h, KC_PSD);
+  HIPCHK(h, hipMemsetAsync(p->rank, 0, p->cones.size() * sizeof(int), h->stream));
   if (!p->tiny.empty()) {
     const int n = (int)p->tiny.size();
     hipLaunchKernelGGL(k_psd_tiny, dim3((n + COSMO_BS / 64 - 1) / (COSMO_BS / 64)), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, n,
@@ -595,12 +673,10 @@ int32_t psd_enqueue_project(cosmo_hip_handle* h, double* s, bool guard_b) {
     const int* lst = p->d_wg_groups[gi];
     hipLaunchKernelGGL(k_psd_populate, dim3(8, n), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, lst, p->d_cones, s, p->G, p->cshift);
     switch (p->wg_waves[gi]) {
-      case 16: hipLaunchKernelGGL((k_psd_jacobi_wg<16>), dim3(n), dim3(1024), 0, h->stream, h->ctl, guard, lst, p->d_cones, p->G, p->cshift, p->flags); break;
-      case 8: hipLaunchKernelGGL((k_psd_jacobi_wg<8>), dim3(n), dim3(512), 0, h->stream, h->ctl, guard, lst, p->d_cones, p->G, p->cshift, p->flags); break;
-      case 4: hipLaunchKernelGGL((k_psd_jacobi_wg<4>), dim3(n), dim3(256), 0, h->stream, h->ctl, guard, lst, p->d_cones, p->G, p->cshift, p->flags); break;
-      default: hipLaunchKernelGGL((k_psd_jacobi_wg<2>), dim3(n), dim3(128), 0, h->stream, h->ctl, guard, lst, p->d_cones, p->G, p->cshift, p->flags); break;
+      case 16: hipLaunchKernelGGL((k_psd_jacobi_wg<16>), dim3(n), dim3(1024), 0, h->stream, h->ctl, guard, lst, p->d_cones, p->G, p->cshift, p->flags, p->tol_factor, p->dbg); break;
+      default: hipLaunchKernelGGL((k_psd_jacobi_wg<4>), dim3(n), dim3(256), 0, h->stream, h->ctl, guard, lst, p->d_cones, p->G, p->cshift, p->flags, p->tol_factor, p->dbg); break;
     }
-    hipLaunchKernelGGL(k_psd_colscale, dim3(n), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, lst, p->d_cones, p->G, p->cshift, p->colw, p->rank);
+    hipLaunchKernelGGL(k_psd_colscale, dim3(4, n), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, lst, p->d_cones, p->G, p->cshift, p->colw, p->rank);
     int maxtiles = 1;
     for (int idx : p->wg_groups[gi]) { const int nt = p->cones[idx].ld / 16; maxtiles = std::max(maxtiles, nt * (nt + 1) / 2); }
     hipLaunchKernelGGL(k_psd_syrk, dim3((maxtiles + 3) / 4, n), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, lst, p->d_cones, p->G, s);
@@ -618,16 +694,17 @@ int32_t psd_enqueue_project(cosmo_hip_handle* h, double* s, bool guard_b) {
     int sweep = 0;
     for (; sweep < PSD_MAX_SWEEPS; ++sweep) {
       HIPCHK(h, hipMemsetAsync(p->flags, 0, sizeof(int), h->stream));
-      for (int st = 0; st < nbmax - 1; ++st)
+      for (int st = -1; st < nbmax - 1; ++st)
         hipLaunchKernelGGL(k_psd_step, dim3(nbmax / 2, n), dim3(PSD_STEP_WAVES * 64), 0, h->stream, p->d_large, p->d_cones, p->G,
-                           p->cshift, st, p->flags);
+                           p->cshift, st, p->flags, p->tol_factor);
       int fl = 0;
       HIPCHK(h, hipMemcpyAsync(&fl, p->flags, sizeof(int), hipMemcpyDeviceToHost, h->stream));
       HIPCHK(h, hipStreamSynchronize(h->stream));
       if (!fl) break;
     }
+    p->last_large_sweeps = sweep + 1;
     if (sweep >= PSD_MAX_SWEEPS) return cosmo_fail(h, COSMO_HIP_ERR_EIG, "Jacobi eigensolver did not converge in %d sweeps", PSD_MAX_SWEEPS);
-    hipLaunchKernelGGL(k_psd_colscale, dim3(n), dim3(COSMO_BS), 0, h->stream, h->ctl, 0, p->d_large, p->d_cones, p->G, p->cshift, p->colw, p->rank);
+    hipLaunchKernelGGL(k_psd_colscale, dim3(128, n), dim3(COSMO_BS), 0, h->stream, h->ctl, 0, p->d_large, p->d_cones, p->G, p->cshift, p->colw, p->rank);
     int maxtiles = 1;
     for (int idx : p->large) { const int nt = p->cones[idx].ld / 16; maxtiles = std::max(maxtiles, nt * (nt + 1) / 2); }
     hipLaunchKernelGGL(k_psd_syrk, dim3(std::min(8192, (maxtiles + 3) / 4), n), dim3(COSMO_BS), 0, h->stream, h->ctl, 0, p->d_large, p->d_cones, p->G, s);
@@ -647,5 +724,18 @@ int32_t psd_get_ranks(cosmo_hip_handle* h, int64_t* rank_per_cone) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (fl[1]) return cosmo_fail(h, COSMO_HIP_ERR_EIG, "Jacobi eigensolver did not converge");
   for (size_t i = 0; i < p->cones.size(); ++i) rank_per_cone[p->cones[i].cone_index] = r[i];
+  return COSMO_HIP_OK;
+}
+
+// diagnostics: out = {max sweeps of the workgroup kernels, sweeps of the last multi-workgroup solve, error flag, #cones}
+extern "C" int32_t cosmo_hip_psd_stats(cosmo_hip_handle* h, int64_t out[4]) {
+  if (!h || !out) return COSMO_HIP_ERR_INVALID;
+  out[0] = out[1] = out[2] = out[3] = 0;
+  PsdPlan* p = h->psd;
+  if (!p || p->cones.empty()) return COSMO_HIP_OK;
+  int fl[4] = {0, 0, 0, 0};
+  HIPCHK(h, hipMemcpyAsync(fl, p->flags, sizeof fl, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  out[0] = fl[2]; out[1] = p->last_large_sweeps; out[2] = fl[1]; out[3] = (int64_t)p->cones.size();
   return COSMO_HIP_OK;
 }

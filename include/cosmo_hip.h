@@ -212,6 +212,9 @@ int32_t cosmo_hip_set_profiling(cosmo_hip_handle* h, int32_t on);
 int32_t cosmo_hip_get_kernel_times(cosmo_hip_handle* h, double seconds[COSMO_HIP_NUM_KERNEL_CLASSES],
                                    int64_t launches[COSMO_HIP_NUM_KERNEL_CLASSES]);
 const char* cosmo_hip_kernel_class_name(int32_t k);
+/* Jacobi eigensolver diagnostics of the PSD projections: out = {max sweeps used by a single-workgroup solve, sweeps of
+ * the last multi-workgroup solve, non-convergence flag, number of PSD cones}. */
+int32_t cosmo_hip_psd_stats(cosmo_hip_handle* h, int64_t out[4]);
 
 #ifdef __cplusplus
 }
