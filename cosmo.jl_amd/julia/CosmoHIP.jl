@@ -1,0 +1,233 @@
+# CosmoHIP.jl -- the `ccall` layer that drops libcosmo_hip.so under the unchanged COSMO.jl front-end.
+#
+# NOT EXECUTED in the build container (Julia is not installed there); it is kept deliberately thin and mechanical: every
+# function is a one-to-one wrapper of an entry point of include/cosmo_hip.h, whose semantics are exercised through the
+# identical C ABI by the Python ctypes binding (cosmo.jl_amd/_ffi.py) in tests/.  See INTEGRATION.md.
+#
+# Three plugin surfaces of the reference are served (SURVEY.md 8b):
+#   1. AbstractKKTSolver      : HipCGKKTSolver / HipMINRESKKTSolver      (fine-grained; one host<->device trip per solve!)
+#   2. AbstractConvexSet      : HipProjection wraps the composite projection (fine-grained)
+#   3. COSMO.optimize!(model) : optimize_hip!(model) keeps chordal_decomposition!/setup!/the epilogue in Julia and runs the
+#                               `while` loop (src/solver.jl:137-176) device-resident.  This is the performance path.
+module CosmoHIP
+
+using COSMO, SparseArrays, LinearAlgebra
+import COSMO: AbstractKKTSolver, solve!, update_rho!, free_memory!
+
+const LIB = Ref{String}(joinpath(@__DIR__, "..", "libcosmo_hip.so"))
+
+# ---- mirrors of the ABI structs (include/cosmo_hip.h) ---------------------------------------------------------------
+struct Params
+    sigma::Cdouble; alpha::Cdouble; rho::Cdouble
+    eps_abs::Cdouble; eps_rel::Cdouble
+    eps_prim_inf::Cdouble; eps_dual_inf::Cdouble
+    tol_constant::Cdouble; tol_exponent::Cdouble
+    rho_min::Cdouble; rho_max::Cdouble; rho_tol::Cdouble
+    rho_eq_over_rho_ineq::Cdouble; adaptive_rho_tolerance::Cdouble
+    cosmo_infty_min_scaling::Cdouble; time_limit::Cdouble
+    max_iter::Int64; adaptive_rho_max_adaptions::Int64
+    kkt_kind::Int32; check_termination::Int32; check_infeasibility::Int32
+    adaptive_rho::Int32; adaptive_rho_interval::Int32; unscale_residuals::Int32
+end
+
+const MAX_RHO_UPDATES = 64
+struct ResultC
+    status::Int32; n_rho_updates::Int32
+    iter::Int64; kkt_iters_total::Int64; kkt_solves::Int64
+    cost::Cdouble; r_prim::Cdouble; r_dual::Cdouble; max_norm_prim::Cdouble; max_norm_dual::Cdouble; rho::Cdouble
+    iter_time::Cdouble; proj_time::Cdouble
+    rho_updates::NTuple{MAX_RHO_UPDATES, Cdouble}
+end
+
+const KKT_CG, KKT_MINRES_REDUCED, KKT_MINRES = Int32(0), Int32(1), Int32(2)
+const STATUS = (:Undetermined, :Solved, :Max_iter_reached, :Unsolved, :Primal_infeasible, :Dual_infeasible, :Time_limit_reached)
+
+mutable struct Handle
+    ptr::Ptr{Cvoid}
+    function Handle(device::Integer = 0)
+        ref = Ref{Ptr{Cvoid}}(C_NULL)
+        rc = ccall((:cosmo_hip_create, LIB[]), Int32, (Ref{Ptr{Cvoid}}, Int32), ref, device)
+        rc == 0 || error("cosmo_hip_create failed with code $rc (no MI355X visible?)")
+        h = new(ref[])
+        finalizer(destroy!, h)      # free_memory! / GC both end here; cosmo_hip_destroy is idempotent
+        return h
+    end
+end
+
+function destroy!(h::Handle)
+    h.ptr == C_NULL && return
+    ccall((:cosmo_hip_destroy, LIB[]), Int32, (Ptr{Cvoid},), h.ptr)
+    h.ptr = C_NULL
+    nothing
+end
+
+# the reference signals errors with exceptions (e.g. src/linear_solver/kktsolver.jl:304); so does the glue
+function check(h::Handle, rc::Int32)
+    rc == 0 && return
+    msg = unsafe_string(ccall((:cosmo_hip_last_error, LIB[]), Cstring, (Ptr{Cvoid},), h.ptr))
+    error("libcosmo_hip error $rc: $msg")
+end
+
+cone_type(::COSMO.ZeroSet) = Int32(0)
+cone_type(::COSMO.Nonnegatives) = Int32(1)
+cone_type(::COSMO.Box) = Int32(2)
+cone_type(::COSMO.SecondOrderCone) = Int32(3)
+cone_type(::COSMO.PsdCone) = Int32(4)
+cone_type(::COSMO.PsdConeTriangle{T, T}) where {T} = Int32(5)
+cone_type(C) = error("cone type $(typeof(C)) is outside the MI355X hot path (SURVEY.md 8a)")
+
+# cosmo_hip_set_problem takes SparseMatrixCSC{Float64,Int64} untouched: colptr / rowval are already 1-based Int64
+function set_problem!(h::Handle, P::SparseMatrixCSC{Float64, Int64}, A::SparseMatrixCSC{Float64, Int64}, q::Vector{Float64}, b::Vector{Float64})
+    m, n = size(A)
+    GC.@preserve P A q b begin
+        check(h, ccall((:cosmo_hip_set_problem, LIB[]), Int32,
+            (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Int64}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+            h.ptr, n, m, P.colptr, P.rowval, P.nzval, A.colptr, A.rowval, A.nzval, q, b))
+    end
+end
+
+function set_cones!(h::Handle, C::COSMO.CompositeConvexSet{Float64})
+    types = Int32[cone_type(s) for s in C.sets]
+    dims = Int64[s.dim for s in C.sets]
+    bl = Float64[]; bu = Float64[]
+    for s in C.sets
+        if s isa COSMO.Box
+            append!(bl, s.l); append!(bu, s.u)          # already E-scaled by scale!(::Box) (src/convexset.jl:863-867)
+        end
+    end
+    GC.@preserve types dims bl bu begin
+        check(h, ccall((:cosmo_hip_set_cones, LIB[]), Int32, (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Cdouble}),
+            h.ptr, length(types), types, dims, isempty(bl) ? C_NULL : pointer(bl), isempty(bu) ? C_NULL : pointer(bu)))
+    end
+end
+
+function params_from(settings::COSMO.Settings{Float64}, kkt_kind::Int32; tol_constant = 1.0, tol_exponent = 1.5)
+    s = settings
+    Params(s.sigma, s.alpha, s.rho, s.eps_abs, s.eps_rel, s.eps_prim_inf, s.eps_dual_inf, tol_constant, tol_exponent,
+           s.RHO_MIN, s.RHO_MAX, s.RHO_TOL, s.RHO_EQ_OVER_RHO_INEQ, s.adaptive_rho_tolerance, s.COSMO_INFTY * s.MIN_SCALING,
+           s.time_limit, s.max_iter, min(s.adaptive_rho_max_adaptions, typemax(Int64) >> 1), kkt_kind, s.check_termination,
+           s.check_infeasibility, s.adaptive_rho ? 1 : 0, s.adaptive_rho_interval, s.scaling != 0 ? 1 : 0)
+end
+
+function set_params!(h::Handle, p::Params, rho_vec::Union{Vector{Float64}, Nothing})
+    GC.@preserve rho_vec begin
+        check(h, ccall((:cosmo_hip_set_params, LIB[]), Int32, (Ptr{Cvoid}, Ref{Params}, Ptr{Cdouble}), h.ptr, Ref(p),
+            rho_vec === nothing ? C_NULL : pointer(rho_vec)))
+    end
+end
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 1. AbstractKKTSolver plugin (src/linear_solver/kktsolver.jl:5-11).  Use as
+#       settings = COSMO.Settings(kkt_solver = with_options(CosmoHIP.HipCGKKTSolver, device = 0))
+#    The constructor receives the scaled P, A, sigma and ws.ρvec from _make_kkt_solver! (src/setup.jl:1-7).
+# ---------------------------------------------------------------------------------------------------------------------
+mutable struct HipKKTSolver <: AbstractKKTSolver
+    h::Handle
+    m::Int; n::Int
+    function HipKKTSolver(P::SparseMatrixCSC{Float64, Int64}, A::SparseMatrixCSC{Float64, Int64}, sigma::Float64, rho;
+                          kind::Int32 = KKT_CG, device::Integer = 0, tol_constant = 1.0, tol_exponent = 1.5)
+        m, n = size(A)
+        h = Handle(device)
+        set_problem!(h, P, A, zeros(n), zeros(m))          # q, b are not needed by solve!
+        types = Int32[1]; dims = Int64[m]                    # cones are irrelevant for solve!: declare one Nonnegatives(m)
+        GC.@preserve types dims check(h, ccall((:cosmo_hip_set_cones, LIB[]), Int32,
+            (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Cdouble}), h.ptr, 1, types, dims, C_NULL, C_NULL))
+        p = params_from(COSMO.Settings{Float64}(sigma = sigma), kind; tol_constant = tol_constant, tol_exponent = tol_exponent)
+        rv = isa(rho, Number) ? fill(Float64(rho), m) : Vector{Float64}(rho)
+        set_params!(h, p, rv)
+        new(h, m, n)
+    end
+end
+HipCGKKTSolver(P, A, sigma, rho; kwargs...) = HipKKTSolver(P, A, sigma, rho; kind = KKT_CG, kwargs...)
+HipMINRESKKTSolver(P, A, sigma, rho; kwargs...) = HipKKTSolver(P, A, sigma, rho; kind = KKT_MINRES, kwargs...)
+
+# called from admm_x! (src/solver.jl:52): lhs = ws.sol, rhs = ws.ls, both length n+m and caller owned
+function solve!(S::HipKKTSolver, lhs::AbstractVector{Float64}, rhs::AbstractVector{Float64})
+    GC.@preserve lhs rhs check(S.h, ccall((:cosmo_hip_kkt_solve, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Int64}),
+        S.h.ptr, pointer(lhs), pointer(rhs), C_NULL))
+    return lhs
+end
+# called from update_rho_vec! (src/parameters.jl:85-89)
+function update_rho!(S::HipKKTSolver, rho::Vector{Float64})
+    GC.@preserve rho check(S.h, ccall((:cosmo_hip_update_rho, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Cdouble}), S.h.ptr, rho))
+end
+# called from optimize! exit (src/solver.jl:200,206-208)
+free_memory!(S::HipKKTSolver) = destroy!(S.h)
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 2. projection plugin: project!(s::SplitVector, C::CompositeConvexSet) (src/convexset.jl:885-891) on the device
+# ---------------------------------------------------------------------------------------------------------------------
+function project_hip!(h::Handle, s::COSMO.SplitVector{Float64})
+    d = s.data
+    GC.@preserve d check(h, ccall((:cosmo_hip_project, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Int64}, Ptr{Int32}), h.ptr, d, C_NULL, C_NULL))
+    return nothing
+end
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 3. the coarse path: COSMO.optimize! with the while-loop on the MI355X.  Everything outside src/solver.jl:128-176 is the
+#    reference's own code, called unchanged.
+# ---------------------------------------------------------------------------------------------------------------------
+function optimize_hip!(ws::COSMO.Workspace{Float64}; device::Integer = 0, kkt_kind::Int32 = KKT_CG, tol_constant = 1.0, tol_exponent = 1.5)
+    !ws.states.IS_ASSEMBLED && throw(ErrorException("The model has to be assembled! / set! before optimize!() can be called."))
+    solver_time_start = time()
+    settings = ws.settings
+    if settings.decompose                                                     # src/solver.jl:88-94
+        if !ws.states.IS_CHORDAL_DECOMPOSED
+            ws.times.graph_time = @elapsed COSMO.chordal_decomposition!(ws)
+        elseif ws.ci.decompose
+            COSMO.pre_allocate_variables!(ws)
+        end
+    end
+    if !ws.states.IS_SCALED                                                   # :99-101
+        ws.sm = (settings.scaling > 0) ? COSMO.ScaleMatrices{Float64}(ws.p.model_size[1], ws.p.model_size[2]) : COSMO.ScaleMatrices{Float64}()
+    end
+    # setup! without the CPU KKT factorisation: scaling, row ranges, classification, rho vector (src/setup.jl:18-42)
+    settings_nokkt = settings
+    ws.times.setup_time = @elapsed begin
+        COSMO.allocate_set_memory!(ws)
+        if settings.scaling != 0 && !ws.states.IS_SCALED
+            COSMO.scale_ruiz!(ws); ws.states.IS_SCALED = true
+        else
+            COSMO.scale_variables!(ws.vars.x, ws.vars.μ, ws.vars.s, ws.sm.Dinv, ws.sm.Einv, ws.sm.E, ws.sm.c)
+        end
+        ws.row_ranges = COSMO.get_set_indices(ws.p.C.sets)
+        COSMO.classify_constraints!(ws)
+        !ws.states.IS_OPTIMIZED && COSMO.set_rho_vec!(ws)
+    end
+    m, n = ws.p.model_size
+    h = Handle(device)
+    set_problem!(h, SparseMatrixCSC(ws.p.P), SparseMatrixCSC(ws.p.A), ws.p.q, Vector(ws.p.b))
+    set_cones!(h, ws.p.C)
+    set_params!(h, params_from(settings, kkt_kind; tol_constant = tol_constant, tol_exponent = tol_exponent), ws.ρvec)
+    Dinv = settings.scaling != 0 ? ws.sm.Dinv.diag : ones(n); Einv = settings.scaling != 0 ? ws.sm.Einv.diag : ones(m)
+    GC.@preserve Dinv Einv check(h, ccall((:cosmo_hip_set_scaling, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble),
+        h.ptr, Dinv, Einv, ws.sm.cinv[]))
+    x0 = ws.vars.x; s0 = ws.vars.s.data; mu0 = ws.vars.μ
+    GC.@preserve x0 s0 mu0 check(h, ccall((:cosmo_hip_set_iterates, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+        h.ptr, x0, s0, mu0))                                                  # src/solver.jl:128-129
+    ws.states.IS_OPTIMIZED = true
+    res = Ref{ResultC}()
+    check(h, ccall((:cosmo_hip_optimize, LIB[]), Int32, (Ptr{Cvoid}, Ref{ResultC}), h.ptr, res))   # src/solver.jl:137-176
+    r = res[]
+    w = ws.vars.w; wp = ws.vars.w_prev; sd = ws.vars.s.data; mu = ws.vars.μ  # x is a view of w_prev (src/types.jl:274)
+    GC.@preserve w wp sd mu check(h, ccall((:cosmo_hip_get_iterates, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+        h.ptr, w, wp, sd, mu))
+    ws.ρ = r.rho
+    resize!(ws.rho_updates, 0); append!(ws.rho_updates, collect(r.rho_updates)[1:min(r.n_rho_updates, MAX_RHO_UPDATES)])
+    ws.times.iter_time = r.iter_time; ws.times.proj_time = r.proj_time
+    status = STATUS[r.status + 1]
+    res_info = COSMO.ResultInfo(r.r_prim, r.r_dual, r.max_norm_prim, r.max_norm_dual, ws.rho_updates)
+    settings.scaling != 0 && COSMO.reverse_scaling!(ws)                      # src/solver.jl:179-181
+    if ws.ci.decompose                                                        # :184-190
+        COSMO.reverse_decomposition!(ws, settings)
+        y = -ws.vars.μ
+    else
+        @. ws.utility_vars.vec_m = -ws.vars.μ
+        y = ws.utility_vars.vec_m
+    end
+    ws.times.solver_time = time() - solver_time_start
+    destroy!(h)
+    return COSMO.Result{Float64}(ws.vars.x, y, ws.vars.s.data, r.cost, Int(r.iter), 0, status, res_info, ws.times)
+end
+
+end # module
