@@ -5,11 +5,11 @@ from . import _ffi
 from ._ffi import CosmoHipError, Handle, load_library
 from .model import (Box, CGIndirectKKTSolver, Constraint, IndirectReducedKKTSolverMINRES, MINRESIndirectKKTSolver,
                     Model, Nonnegatives, PsdCone, PsdConeTriangle, QdldlKKTSolver, Result, SecondOrderCone, Settings,
-                    ZeroSet, assemble, optimize, update, warm_start_dual, warm_start_primal, warm_start_slack,
+                    ZeroSet, assemble, balance_cones, optimize, optimize_batch, shard_range, update, warm_start_dual, warm_start_primal, warm_start_slack,
                     with_options)
 from . import problems
 
 __all__ = ["Handle", "CosmoHipError", "load_library", "Model", "Settings", "Constraint", "ZeroSet", "Nonnegatives", "Box",
-           "SecondOrderCone", "PsdCone", "PsdConeTriangle", "assemble", "optimize", "update", "warm_start_primal",
+           "SecondOrderCone", "PsdCone", "PsdConeTriangle", "assemble", "optimize", "optimize_batch", "shard_range", "balance_cones", "update", "warm_start_primal",
            "warm_start_slack", "warm_start_dual", "with_options", "CGIndirectKKTSolver", "MINRESIndirectKKTSolver",
            "IndirectReducedKKTSolverMINRES", "QdldlKKTSolver", "Result", "problems", "_ffi"]

@@ -96,6 +96,18 @@ SIGNATURES = {
     "cosmo_hip_get_kernel_times": (C.c_int32, [C.c_void_p, _PD, _PI64]),
     "cosmo_hip_kernel_class_name": (C.c_char_p, [C.c_int32]),
     "cosmo_hip_psd_stats": (C.c_int32, [C.c_void_p, _PI64]),
+    "cosmo_hip_batch_create": (C.c_int32, [C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_int64, C.c_int64]),
+    "cosmo_hip_batch_destroy": (C.c_int32, [C.c_void_p]),
+    "cosmo_hip_batch_last_error": (C.c_char_p, [C.c_void_p]),
+    "cosmo_hip_batch_set_problem": (C.c_int32, [C.c_void_p, C.c_int64, _PI64, _PI64, _PD, _PI64, _PI64, _PD, _PD, _PD]),
+    "cosmo_hip_batch_set_cones": (C.c_int32, [C.c_void_p, C.c_int64, _PI32, _PI64, _PD, _PD]),
+    "cosmo_hip_batch_set_scaling": (C.c_int32, [C.c_void_p, C.c_int64, _PD, _PD, C.c_double]),
+    "cosmo_hip_batch_set_params": (C.c_int32, [C.c_void_p, C.POINTER(Params)]),
+    "cosmo_hip_batch_get_rho_classes": (C.c_int32, [C.c_void_p, C.c_int64, _PI32]),
+    "cosmo_hip_batch_set_iterates": (C.c_int32, [C.c_void_p, _PD, _PD, _PD]),
+    "cosmo_hip_batch_optimize": (C.c_int32, [C.c_void_p, C.POINTER(ResultStruct)]),
+    "cosmo_hip_batch_iterate": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32]),
+    "cosmo_hip_batch_get_iterates": (C.c_int32, [C.c_void_p, C.c_int64, _PD, _PD, _PD, _PD]),
 }
 
 
@@ -148,6 +160,12 @@ def csc_julia(M):
     return colptr, rowval, nzval
 
 
+def default_params():
+    p = Params()
+    load_library().cosmo_hip_default_params(C.byref(p))
+    return p
+
+
 class Handle:
     """Thin object wrapper: one method per C entry point, NumPy arrays in and out."""
 
@@ -194,9 +212,7 @@ class Handle:
         self.ncones = t.size
 
     def default_params(self):
-        p = Params()
-        self.lib.cosmo_hip_default_params(C.byref(p))
-        return p
+        return default_params()
 
     def set_params(self, params, rho_vec=None):
         rv = _f64(rho_vec, self.m, "rho_vec")
@@ -309,3 +325,72 @@ class Handle:
             if cnt[k]:
                 out[self.lib.cosmo_hip_kernel_class_name(k).decode()] = (float(sec[k]), int(cnt[k]))
         return out
+
+
+class Batch:
+    """Batch of independent problems with identical (n, m, cone structure): one persistent workgroup per problem."""
+
+    def __init__(self, nprob, n, m, device=0):
+        self.lib = load_library()
+        self._b = C.c_void_p()
+        rc = self.lib.cosmo_hip_batch_create(C.byref(self._b), int(device), int(nprob), int(n), int(m))
+        if rc != OK:
+            raise CosmoHipError(rc, "cosmo_hip_batch_create failed (no MI355X visible? this library has no CPU path)")
+        self.nprob, self.n, self.m = int(nprob), int(n), int(m)
+
+    def close(self):
+        if self._b:
+            self.lib.cosmo_hip_batch_destroy(self._b)
+            self._b = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != OK:
+            msg = self.lib.cosmo_hip_batch_last_error(self._b)
+            raise CosmoHipError(rc, msg.decode() if msg else "")
+
+    def set_problem(self, k, P, q, A, b):
+        pc, pr, pv = csc_julia(P)
+        ac, ar, av = csc_julia(A)
+        q = _f64(q, self.n, "q"); b = _f64(b, self.m, "b")
+        self._chk(self.lib.cosmo_hip_batch_set_problem(self._b, int(k), pc.ctypes.data_as(_PI64), pr.ctypes.data_as(_PI64), _dp(pv),
+                                                       ac.ctypes.data_as(_PI64), ar.ctypes.data_as(_PI64), _dp(av), _dp(q), _dp(b)))
+
+    def set_cones(self, types, dims, box_l=None, box_u=None):
+        t = np.ascontiguousarray(types, dtype=np.int32); d = np.ascontiguousarray(dims, dtype=np.int64)
+        bl = _f64(box_l); bu = _f64(box_u)
+        self._chk(self.lib.cosmo_hip_batch_set_cones(self._b, t.size, t.ctypes.data_as(_PI32), d.ctypes.data_as(_PI64), _dp(bl), _dp(bu)))
+
+    def set_scaling(self, k, Dinv, Einv, cinv):
+        self._chk(self.lib.cosmo_hip_batch_set_scaling(self._b, int(k), _dp(_f64(Dinv, self.n)), _dp(_f64(Einv, self.m)), float(cinv)))
+
+    def set_params(self, params):
+        self._chk(self.lib.cosmo_hip_batch_set_params(self._b, C.byref(params)))
+
+    def get_rho_classes(self, k):
+        out = np.empty(self.m, dtype=np.int32)
+        self._chk(self.lib.cosmo_hip_batch_get_rho_classes(self._b, int(k), out.ctypes.data_as(_PI32)))
+        return out
+
+    def set_iterates(self, x0=None, s0=None, mu0=None):
+        self._chk(self.lib.cosmo_hip_batch_set_iterates(self._b, _dp(_f64(x0, self.nprob * self.n)), _dp(_f64(s0, self.nprob * self.m)),
+                                                        _dp(_f64(mu0, self.nprob * self.m))))
+
+    def optimize(self):
+        res = (ResultStruct * self.nprob)()
+        self._chk(self.lib.cosmo_hip_batch_optimize(self._b, res))
+        return list(res)
+
+    def iterate(self, n_iters, with_init=False):
+        self._chk(self.lib.cosmo_hip_batch_iterate(self._b, int(n_iters), 1 if with_init else 0))
+
+    def get_iterates(self, k):
+        N = self.n + self.m
+        w = np.empty(N); wp = np.empty(N); s = np.empty(self.m); mu = np.empty(self.m)
+        self._chk(self.lib.cosmo_hip_batch_get_iterates(self._b, int(k), _dp(w), _dp(wp), _dp(s), _dp(mu)))
+        return w, wp, s, mu

@@ -770,7 +770,8 @@ extern "C" int32_t cosmo_hip_optimize(cosmo_hip_handle* h, cosmo_hip_result* res
       }
     }
   }
-  if (status == COSMO_HIP_UNDETERMINED && it >= p.max_iter) {  // solver.jl:173-176
+  if (h->ctl_host->iter == p.max_iter && status != COSMO_HIP_TIME_LIMIT_REACHED) {
+    // solver.jl:173-176: `if iter == max_iter` overrides ANY status decided in that very iteration (reference quirk kept)
     CHK(enqueue_check(h, 0, 0));
     CHK(sync_ctl(h));
     status = COSMO_HIP_MAX_ITER_REACHED;

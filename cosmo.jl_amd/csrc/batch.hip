@@ -1,0 +1,652 @@
+// batch.hip -- batches of INDEPENDENT small problems (BASELINE config 3: 1024 SOCPs with n = 500, m = 1000).
+//
+// The reference solves such a batch with one `optimize!` per model.  On the MI355X every problem gets ONE PERSISTENT
+// WORKGROUP that runs the complete loop of src/solver.jl:137-176 for it -- projection, rho adaptation, CG solve, w update,
+// termination check -- so that every synchronisation of the algorithm is a workgroup barrier instead of a kernel
+// boundary and nothing is launch-bound; 1024 problems are 1024 resident workgroups (4 per CU).  All per-problem scalars
+// (rho, CG residuals, counters, status) live with the problem: trajectories are those of 1024 separate solves, not of
+// one block-diagonal solve.  The phases reuse the row lambdas / CSR-stream primitive of the large-problem path, the
+// arithmetic per element is identical, reductions are single-workgroup fixed-order sums.
+// Cone support in batch mode: ZeroSet, Nonnegatives, Box, SecondOrderCone (PSD cones take the large-problem path).
+#include <stdarg.h>
+#include <string.h>
+#include <math.h>
+#include <algorithm>
+#include <chrono>
+#include "device_utils.h"
+
+struct BCtl {                 // per problem, device resident
+  int status; int n_rho_updates;
+  long long iter, solves, kkt_iters_total;
+  double rho, cost, r_prim, r_dual, max_norm_prim, max_norm_dual;
+  double rho_updates[COSMO_HIP_MAX_RHO_UPDATES];
+};
+
+struct BMat { const int* rowptr; const int* col; const double* val; const int* split; const int* rb;   // concatenated over problems
+              const long long* nz_off; const int* rb_off; const int* nb; int nrows; int split_col; };
+
+struct BatchDev {
+  int nprob; int n; int m;
+  BMat A, AT, PT;
+  const double *q, *b, *Dinv, *Einv, *cinv;
+  const uint32_t* meta; const double *box_l, *box_u; int nbox;
+  int nsoc; const int *soc_off, *soc_dim;
+  const int* rho_cls;
+  double *w, *w_prev, *s, *mu, *s_tl, *ls_s, *y2, *tmp_m, *nu, *rho;
+  double *ls_x, *x_tl, *rhs, *r, *u, *c;
+  BCtl* ctl;
+  const double* tol_table; long long tol_len;   // tol_constant / k^tol_exponent, k = 1.. (host libm, as the large path)
+};
+
+struct BParams {
+  double sigma, alpha, eps_abs, eps_rel, rho_min, rho_max, rho_eq, adapt_tol;
+  long long max_iter, max_adaptions;
+  int check_termination, adaptive_rho, adaptive_rho_interval, unscale;
+};
+
+__device__ __forceinline__ CsrView bview(const BMat& M, int k) {
+  CsrView v;
+  v.rowptr = M.rowptr + (long long)k * (M.nrows + 1);
+  v.col = M.col + M.nz_off[k];
+  v.val = M.val + M.nz_off[k];
+  v.split = M.split ? M.split + (long long)k * M.nrows : nullptr;
+  v.rb = M.rb + M.rb_off[k];
+  v.nb = M.nb[k];
+  v.nrows = M.nrows;
+  v.split_col = M.split_col;
+  return v;
+}
+
+__device__ __forceinline__ double proj_simple(double x, uint32_t meta, const double* bl, const double* bu) {
+  const uint32_t kind = meta & 3u;
+  if (kind == 0u) return x;
+  if (kind == 1u) return 0.0;
+  if (kind == 2u) return (x != x) ? x : ((x > 0.0) ? x : 0.0);
+  const uint32_t j = meta >> 2;
+  const double l = bl[j], u = bu[j];
+  return (x < l) ? l : ((x > u) ? u : x);
+}
+
+// One workgroup = one problem.  Runs iterations until a status is decided or `iter_target` iterations are done.
+__global__ __launch_bounds__(COSMO_BS) void k_batch_admm(BatchDev D, BParams P, long long iter_target, int do_init) {
+  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ double red[COSMO_BS / 64];
+  const int k = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n = D.n, m = D.m;
+  BCtl* ctl = D.ctl + k;
+  if (ctl->status != 0) return;
+  const CsrView A = bview(D.A, k), AT = bview(D.AT, k), PT = bview(D.PT, k);
+  const long long on = (long long)k * n, om = (long long)k * m, onm = (long long)k * (n + m);
+  const double *q = D.q + on, *b = D.b + om, *Dinv = D.Dinv + on, *Einv = D.Einv + om;
+  const double cinv = D.cinv[k];
+  const double *bl = D.box_l + (long long)k * D.nbox, *bu = D.box_u + (long long)k * D.nbox;
+  const int* cls = D.rho_cls + om;
+  double *w = D.w + onm, *w_prev = D.w_prev + onm, *s = D.s + om, *mu = D.mu + om, *s_tl = D.s_tl + om;
+  double *ls_s = D.ls_s + om, *y2 = D.y2 + om, *tmp_m = D.tmp_m + om, *nu = D.nu + om, *rho = D.rho + om;
+  double *ls_x = D.ls_x + on, *x_tl = D.x_tl + on, *rhs = D.rhs + on, *r = D.r + on, *u = D.u + on, *c = D.c + on;
+
+  // ---- admm_x! + admm_w! (solver.jl:32-65) with the CG reduced solve (kktsolver_indirect.jl:36-88) -------------------
+  auto solve_and_update = [&]() {
+    for (int i = tid; i < n + m; i += COSMO_BS) {                       // rhs of the KKT system + y2 = rho .* ls_s
+      if (i < n) ls_x[i] = P.sigma * w[i] - q[i];
+      else { const int rr = i - n; const double v = (b[rr] - 2.0 * s[rr]) + w[i]; ls_s[rr] = v; y2[rr] = rho[rr] * v; }
+    }
+    __syncthreads();
+    double acc = 0.0;
+    for (int t = 0; t < AT.nb; ++t)
+      csr_stream_block(AT, y2, y2, AT.rb[t], AT.rb[t + 1], lds, red, [&](int row, double s1, double s2) {
+        const double v = (s1 + s2) + ls_x[row]; rhs[row] = v; acc += v * v; });
+    const double bb = block_sum(acc, red);
+    for (int t = 0; t < A.nb; ++t)
+      csr_stream_block(A, x_tl, x_tl, A.rb[t], A.rb[t + 1], lds, red, [&](int row, double s1, double s2) { tmp_m[row] = (s1 + s2) * rho[row]; });
+    __syncthreads();
+    acc = 0.0;
+    for (int t = 0; t < PT.nb; ++t)
+      csr_stream_block(PT, x_tl, tmp_m, PT.rb[t], PT.rb[t + 1], lds, red, [&](int row, double s1, double s2) {
+        const double cj = s1 + (P.sigma * x_tl[row] + s2); const double rj = rhs[row] - cj; r[row] = rj; acc += rj * rj; });
+    double rr = block_sum(acc, red);
+    const long long ks = ctl->solves;                                    // iteration_counter - 1
+    const double tol_k = D.tol_table[ks < D.tol_len ? ks : D.tol_len - 1];
+    const double tol = tol_k / sqrt(bb);
+    double res = sqrt(rr), prev = 1.0;
+    int kk = 0;
+    while (kk < n && !(res <= tol)) {                                    // cg! (IterativeSolvers v0.9), maxiter = n
+      const double beta = (res * res) / (prev * prev);
+      for (int i = tid; i < n; i += COSMO_BS) u[i] = r[i] + beta * ((kk == 0) ? 0.0 : u[i]);
+      __syncthreads();
+      for (int t = 0; t < A.nb; ++t)
+        csr_stream_block(A, u, u, A.rb[t], A.rb[t + 1], lds, red, [&](int row, double s1, double s2) { tmp_m[row] = (s1 + s2) * rho[row]; });
+      __syncthreads();
+      acc = 0.0;
+      for (int t = 0; t < PT.nb; ++t)
+        csr_stream_block(PT, u, tmp_m, PT.rb[t], PT.rb[t + 1], lds, red, [&](int row, double s1, double s2) {
+          const double vj = u[row]; const double cj = s1 + (P.sigma * vj + s2); c[row] = cj; acc += vj * cj; });
+      const double uc = block_sum(acc, red);
+      const double a = (res * res) / uc;
+      acc = 0.0;
+      for (int i = tid; i < n; i += COSMO_BS) {
+        x_tl[i] = x_tl[i] + a * u[i];
+        const double ri = r[i] - a * c[i]; r[i] = ri; acc += ri * ri;
+      }
+      rr = block_sum(acc, red);
+      prev = res; res = sqrt(rr); ++kk;
+    }
+    __syncthreads();
+    // nu = rho (A x_tl - ls_s) ; s_tl ; w update
+    for (int t = 0; t < A.nb; ++t)
+      csr_stream_block(A, x_tl, x_tl, A.rb[t], A.rb[t + 1], lds, red, [&](int row, double s1, double s2) {
+        const double rh = rho[row]; const double nv = ((s1 + s2) - ls_s[row]) * rh; nu[row] = nv;
+        const double sv = s[row], wv = w[n + row]; const double st = (2.0 * sv - wv) - nv / rh; s_tl[row] = st;
+        w[n + row] = wv + P.alpha * (st - sv); });
+    for (int i = tid; i < n; i += COSMO_BS) { const double wv = w[i]; w[i] = wv + P.alpha * (x_tl[i] - wv); }
+    __syncthreads();
+    if (tid == 0) { ctl->solves = ks + 1; ctl->kkt_iters_total += kk; }
+    __syncthreads();
+  };
+
+  // ---- residuals (residuals.jl:30-96,143-147); x = w_prev[1:n], mu recovered on the fly ------------------------------
+  double rp, mp, rd, md, cost;
+  auto residuals = [&](bool unscale) {
+    double a_rp = 0.0, a_mp = 0.0;
+    for (int t = 0; t < A.nb; ++t)
+      csr_stream_block(A, w_prev, w_prev, A.rb[t], A.rb[t + 1], lds, red, [&](int row, double s1, double s2) {
+        const double ax = s1 + s2, sv = s[row], bv = b[row];
+        mu[row] = rho[row] * (w_prev[n + row] - sv);
+        double rv = ax + sv; rv = rv - bv;
+        const double e = unscale ? Einv[row] : 1.0;
+        if (unscale) rv = rv * e;
+        a_rp = amax(a_rp, rv);
+        a_mp = amax(a_mp, unscale ? ax * e : ax); a_mp = amax(a_mp, unscale ? sv * e : sv); a_mp = amax(a_mp, unscale ? bv * e : bv); });
+    rp = block_max(a_rp, red); mp = block_max(a_mp, red);
+    __syncthreads();
+    double a_rd = 0.0, a_md = 0.0, xpx = 0.0, qx = 0.0;
+    for (int t = 0; t < PT.nb; ++t)
+      csr_stream_block(PT, w_prev, mu, PT.rb[t], PT.rb[t + 1], lds, red, [&](int row, double px, double atm) {
+        const double xv = w_prev[row], qv = q[row];
+        double rv = px + qv; rv = rv - atm;
+        double a = px, bq = qv, cm = atm;
+        if (unscale) { const double d = Dinv[row]; rv = (rv * d) * cinv; a = (a * d) * cinv; bq = (bq * d) * cinv; cm = (cm * d) * cinv; }
+        a_rd = amax(a_rd, rv); a_md = amax(a_md, a); a_md = amax(a_md, bq); a_md = amax(a_md, cm);
+        xpx += px * xv; qx += qv * xv; });
+    rd = block_max(a_rd, red); md = block_max(a_md, red);
+    xpx = block_sum(xpx, red); qx = block_sum(qx, red);
+    cost = (unscale ? cinv : 1.0) * (0.5 * xpx + qx);
+    __syncthreads();
+  };
+
+  if (do_init) {                                                          // solver.jl:137-138
+    solve_and_update();
+  }
+  long long it = ctl->iter;
+  while (it < iter_target && it < P.max_iter) {
+    ++it;
+    // ---- admm_z!: w_prev = w ; s = Pi(w_s)  (solver.jl:151-152) ----
+    for (int i = tid; i < n + m; i += COSMO_BS) {
+      const double v = w[i]; w_prev[i] = v;
+      if (i >= n) s[i - n] = proj_simple(v, D.meta[i - n], bl, bu);
+    }
+    __syncthreads();
+    for (int cI = wv; cI < D.nsoc; cI += COSMO_BS / 64) {                 // SecondOrderCone (convexset.jl:100-114)
+      double* x = s + D.soc_off[cI]; const int d = D.soc_dim[cI];
+      if (d == 0) continue;
+      const double t = x[0];
+      double a = 0.0;
+      for (int i = 1 + lane; i < d; i += 64) { const double v = x[i]; a += v * v; }
+      const double nx = sqrt(wave_sum(a));
+      if (nx <= t) {
+      } else if (nx <= -t) { for (int i = lane; i < d; i += 64) x[i] = 0.0; }
+      else { const double f = (nx + t) / (2.0 * nx); for (int i = 1 + lane; i < d; i += 64) x[i] = f * x[i]; if (lane == 0) x[0] = (nx + t) / 2.0; }
+    }
+    __syncthreads();
+    // ---- apply_rho_adaptation_rules! (solver.jl:242-282, parameters.jl:53-92) ----
+    if (P.adaptive_rho && P.adaptive_rho_interval > 0 && (it % P.adaptive_rho_interval) == 0 &&
+        (long long)(ctl->n_rho_updates - 1) < P.max_adaptions) {
+      residuals(false);
+      const double rpn = rp / (mp + 1e-10), rdn = rd / (md + 1e-10);
+      const double rho0 = ctl->rho;
+      double nr = rho0 * sqrt(rpn / (rdn + 1e-10));
+      nr = fmin(fmax(nr, P.rho_min), P.rho_max);
+      const bool adapt = (nr > P.adapt_tol * rho0) || (nr < (1.0 / P.adapt_tol) * rho0);
+      __syncthreads();
+      if (adapt) {
+        for (int i = tid; i < m; i += COSMO_BS) {
+          const int cc = cls[i]; double rv = nr;
+          if (cc == 1) rv = rv * P.rho_eq; else if (cc == 2) rv = P.rho_min;
+          rho[i] = rv;
+          w[n + i] = (1.0 / rv) * mu[i] + s[i];
+        }
+        if (tid == 0) {
+          ctl->rho = nr;
+          const int ku = ctl->n_rho_updates;
+          if (ku < COSMO_HIP_MAX_RHO_UPDATES) ctl->rho_updates[ku] = nr;
+          ctl->n_rho_updates = ku + 1;
+        }
+      }
+      __syncthreads();
+    }
+    solve_and_update();
+    // ---- check_termination! (solver.jl:306-321) ----
+    if ((it % P.check_termination) == 0 || it == 1) {
+      residuals(P.unscale != 0);
+      int st = 0;
+      if (fabs(cost) > 1e20) st = COSMO_HIP_UNSOLVED;
+      else if (rp < P.eps_abs + P.eps_rel * mp && rd < P.eps_abs + P.eps_rel * md) st = COSMO_HIP_SOLVED;
+      if (tid == 0) { ctl->cost = cost; ctl->r_prim = rp; ctl->r_dual = rd; ctl->max_norm_prim = mp; ctl->max_norm_dual = md; ctl->status = st; }
+      __syncthreads();
+      if (st != 0) break;
+    }
+  }
+  if (tid == 0) ctl->iter = it;
+  // iter == max_iter: calculate_result_info! and Max_iter_reached, overriding a status decided in that iteration
+  // (solver.jl:173-176, reference quirk kept)
+  if (it >= P.max_iter) {
+    __syncthreads();
+    residuals(P.unscale != 0);
+    if (tid == 0) { ctl->r_prim = rp; ctl->r_dual = rd; ctl->max_norm_prim = mp; ctl->max_norm_dual = md; ctl->status = COSMO_HIP_MAX_ITER_REACHED; }
+  }
+  // recover_mu! (solver.jl:167)
+  __syncthreads();
+  for (int i = tid; i < m; i += COSMO_BS) mu[i] = rho[i] * (w_prev[n + i] - s[i]);
+}
+
+// warm start (solver.jl:128-129) for all problems
+__global__ __launch_bounds__(COSMO_BS) void k_batch_set_w(BatchDev D, const double* __restrict__ x0, const double* __restrict__ s0,
+                                                          const double* __restrict__ mu0) {
+  const long long N = (long long)D.nprob * (D.n + D.m);
+  for (long long g = (long long)blockIdx.x * COSMO_BS + threadIdx.x; g < N; g += (long long)gridDim.x * COSMO_BS) {
+    const long long k = g / (D.n + D.m); const int i = (int)(g % (D.n + D.m));
+    if (i < D.n) D.w[g] = x0 ? x0[k * D.n + i] : 0.0;
+    else {
+      const long long r = k * D.m + (i - D.n);
+      const double sv = s0 ? s0[r] : 0.0, mv = mu0 ? mu0[r] : 0.0;
+      D.w[g] = (1.0 / D.rho[r]) * mv + sv;
+      D.s[r] = sv;
+    }
+    D.w_prev[g] = D.w[g];
+  }
+}
+
+// =====================================================================================================================
+// host side: C ABI of the batch mode
+// =====================================================================================================================
+struct cosmo_hip_batch {
+  int device = 0; hipStream_t stream = nullptr; std::string err;
+  int nprob = 0; long long n = 0, m = 0;
+  std::vector<HostCsr> hA, hAT, hPT;             // staged per problem until finalize
+  std::vector<double> hq, hb;
+  std::vector<char> have;
+  ConeTable cones; std::vector<double> hbox_l, hbox_u; int nbox = 0;
+  cosmo_hip_params prm;
+  bool finalized = false, have_cones = false, have_iterates = false;
+  BatchDev D;
+  std::vector<void*> allocs;
+  std::vector<double> hDinv, hEinv, hcinv;
+  std::vector<int32_t> cls_host;
+  long long iters_done = 0;
+};
+
+static int32_t bfail(cosmo_hip_batch* b, int32_t code, const char* fmt, ...) {
+  char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  if (b) b->err = buf;
+  return code;
+}
+#define BHIP(b, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return bfail((b), COSMO_HIP_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e__)); } while (0)
+
+template <class T>
+static int32_t bup(cosmo_hip_batch* b, const T** dptr, const std::vector<T>& v) {
+  T* p = nullptr;
+  BHIP(b, hipMalloc((void**)&p, std::max<size_t>(1, v.size()) * sizeof(T)));
+  b->allocs.push_back(p);
+  if (!v.empty()) BHIP(b, hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *dptr = p;
+  return COSMO_HIP_OK;
+}
+template <class T>
+static int32_t balloc(cosmo_hip_batch* b, T** dptr, size_t count) {
+  T* p = nullptr;
+  BHIP(b, hipMalloc((void**)&p, std::max<size_t>(1, count) * sizeof(T)));
+  BHIP(b, hipMemset(p, 0, std::max<size_t>(1, count) * sizeof(T)));
+  b->allocs.push_back(p);
+  *dptr = p;
+  return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_batch_create(cosmo_hip_batch** out, int32_t device_id, int64_t nprob, int64_t n, int64_t m) {
+  if (!out || nprob <= 0 || n < 0 || m < 0) return COSMO_HIP_ERR_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return COSMO_HIP_ERR_HIP;
+  if (device_id < 0 || device_id >= ndev) return COSMO_HIP_ERR_INVALID;
+  cosmo_hip_batch* b = new cosmo_hip_batch();
+  b->device = device_id; b->nprob = (int)nprob; b->n = n; b->m = m;
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&b->stream) != hipSuccess) { delete b; return COSMO_HIP_ERR_HIP; }
+  b->hA.resize(nprob); b->hAT.resize(nprob); b->hPT.resize(nprob);
+  b->hq.assign((size_t)nprob * n, 0.0); b->hb.assign((size_t)nprob * m, 0.0);
+  b->have.assign(nprob, 0);
+  b->hDinv.assign((size_t)nprob * n, 1.0); b->hEinv.assign((size_t)nprob * m, 1.0); b->hcinv.assign(nprob, 1.0);
+  cosmo_hip_default_params(&b->prm);
+  memset(&b->D, 0, sizeof b->D);
+  *out = b;
+  return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_batch_destroy(cosmo_hip_batch* b) {
+  if (!b) return COSMO_HIP_OK;
+  (void)hipSetDevice(b->device);
+  if (b->stream) (void)hipStreamSynchronize(b->stream);
+  for (void* p : b->allocs) (void)hipFree(p);
+  if (b->stream) (void)hipStreamDestroy(b->stream);
+  delete b;
+  return COSMO_HIP_OK;
+}
+
+extern "C" const char* cosmo_hip_batch_last_error(const cosmo_hip_batch* b) { return b ? b->err.c_str() : "null batch"; }
+
+// CSC (Julia layout) -> host CSR of the matrix and of its transpose (same code path as the single-problem handle)
+static int32_t bcsc(cosmo_hip_batch* b, int64_t nr, int64_t nc, const int64_t* colptr, const int64_t* rowval, const double* nzval,
+                    HostCsr& Mt, HostCsr& M) {
+  if (colptr[0] != 1) return bfail(b, COSMO_HIP_ERR_INVALID, "colptr must be 1-based");
+  const int64_t nnz = colptr[nc] - 1;
+  Mt.nrows = (int)nc; Mt.ncols = (int)nr; Mt.rowptr.resize(nc + 1); Mt.col.resize(nnz); Mt.val.resize(nnz);
+  for (int64_t j = 0; j <= nc; ++j) Mt.rowptr[j] = (int)(colptr[j] - 1);
+  std::vector<int> cnt(nr + 1, 0);
+  for (int64_t k = 0; k < nnz; ++k) {
+    const int64_t i = rowval[k] - 1;
+    if (i < 0 || i >= nr) return bfail(b, COSMO_HIP_ERR_INVALID, "row index out of range");
+    Mt.col[k] = (int)i; Mt.val[k] = nzval[k]; cnt[i + 1]++;
+  }
+  M.nrows = (int)nr; M.ncols = (int)nc; M.rowptr.assign(nr + 1, 0);
+  for (int64_t i = 0; i < nr; ++i) M.rowptr[i + 1] = M.rowptr[i] + cnt[i + 1];
+  M.col.resize(nnz); M.val.resize(nnz);
+  std::vector<int> pos(M.rowptr.begin(), M.rowptr.end() - 1);
+  for (int64_t j = 0; j < nc; ++j)
+    for (int64_t k = colptr[j] - 1; k < colptr[j + 1] - 1; ++k) { const int i = (int)(rowval[k] - 1); const int p = pos[i]++; M.col[p] = (int)j; M.val[p] = nzval[k]; }
+  return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_batch_set_problem(cosmo_hip_batch* b, int64_t k, const int64_t* P_colptr, const int64_t* P_rowval,
+                                               const double* P_nzval, const int64_t* A_colptr, const int64_t* A_rowval,
+                                               const double* A_nzval, const double* q, const double* bvec) {
+  if (!b || k < 0 || k >= b->nprob || b->finalized) return bfail(b, COSMO_HIP_ERR_INVALID, "batch_set_problem: bad call");
+  const int64_t n = b->n, m = b->m;
+  HostCsr Pt, Pm;
+  int32_t rc = bcsc(b, n, n, P_colptr, P_rowval, P_nzval, Pt, Pm); if (rc) return rc;
+  rc = bcsc(b, m, n, A_colptr, A_rowval, A_nzval, b->hAT[k], b->hA[k]); if (rc) return rc;
+  HostCsr& PT = b->hPT[k];
+  PT.nrows = (int)n; PT.ncols = (int)(n + m); PT.rowptr.assign(n + 1, 0); PT.split.assign(n, 0);
+  PT.col.clear(); PT.val.clear();
+  for (int64_t j = 0; j < n; ++j) {
+    PT.rowptr[j] = (int)PT.col.size();
+    for (int t = Pm.rowptr[j]; t < Pm.rowptr[j + 1]; ++t) { PT.col.push_back(Pm.col[t]); PT.val.push_back(Pm.val[t]); }
+    PT.split[j] = (int)PT.col.size();
+    for (int t = b->hAT[k].rowptr[j]; t < b->hAT[k].rowptr[j + 1]; ++t) { PT.col.push_back(b->hAT[k].col[t] + (int)n); PT.val.push_back(b->hAT[k].val[t]); }
+  }
+  PT.rowptr[n] = (int)PT.col.size();
+  std::copy(q, q + n, b->hq.begin() + (size_t)k * n);
+  std::copy(bvec, bvec + m, b->hb.begin() + (size_t)k * m);
+  b->have[k] = 1;
+  return COSMO_HIP_OK;
+}
+
+// same cone structure for every problem; Box bounds are per problem: box_l/box_u have nprob * nbox entries
+extern "C" int32_t cosmo_hip_batch_set_cones(cosmo_hip_batch* b, int64_t ncones, const int32_t* type, const int64_t* dim,
+                                             const double* box_l, const double* box_u) {
+  if (!b || b->finalized) return bfail(b, COSMO_HIP_ERR_INVALID, "batch_set_cones: bad call");
+  ConeTable& C = b->cones; C = ConeTable();
+  int64_t off = 0, nbox = 0;
+  for (int64_t k = 0; k < ncones; ++k) {
+    if (type[k] == COSMO_HIP_PSD_SQUARE || type[k] == COSMO_HIP_PSD_TRIANGLE) {
+      if (dim[k] > 1) return bfail(b, COSMO_HIP_ERR_UNSUPPORTED, "PSD cones are not supported in batch mode (use one handle per problem)");
+    } else if (type[k] < COSMO_HIP_ZERO || type[k] > COSMO_HIP_SOC) return bfail(b, COSMO_HIP_ERR_UNSUPPORTED, "cone type %d", (int)type[k]);
+    C.type.push_back(type[k]); C.dim.push_back(dim[k]); C.off.push_back(off); off += dim[k];
+    if (type[k] == COSMO_HIP_BOX) nbox += dim[k];
+  }
+  if (off != b->m) return bfail(b, COSMO_HIP_ERR_INVALID, "cone dimensions do not sum to m");
+  b->nbox = (int)nbox;
+  if (nbox) { b->hbox_l.assign(box_l, box_l + (size_t)b->nprob * nbox); b->hbox_u.assign(box_u, box_u + (size_t)b->nprob * nbox); }
+  b->have_cones = true;
+  return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_batch_set_scaling(cosmo_hip_batch* b, int64_t k, const double* Dinv, const double* Einv, double cinv) {
+  if (!b || k < 0 || k >= b->nprob || b->finalized) return bfail(b, COSMO_HIP_ERR_INVALID, "batch_set_scaling: bad call");
+  if (Dinv) std::copy(Dinv, Dinv + b->n, b->hDinv.begin() + (size_t)k * b->n);
+  if (Einv) std::copy(Einv, Einv + b->m, b->hEinv.begin() + (size_t)k * b->m);
+  b->hcinv[k] = cinv;
+  return COSMO_HIP_OK;
+}
+
+static void brow_blocks(const std::vector<int>& rowptr, int nrows, std::vector<int>& rb) {
+  rb.clear(); rb.push_back(0);
+  const int ROWS_MAX = 4 * COSMO_BS;
+  int r = 0;
+  while (r < nrows) {
+    int r1 = r; long long cnt = 0;
+    while (r1 < nrows) {
+      const long long rn = (long long)rowptr[r1 + 1] - rowptr[r1];
+      if (r1 > r && (cnt + rn > COSMO_NNZ_PER_BLOCK || r1 - r >= ROWS_MAX)) break;
+      cnt += rn; ++r1;
+      if (cnt > COSMO_NNZ_PER_BLOCK) break;
+    }
+    rb.push_back(r1); r = r1;
+  }
+}
+
+static int32_t bmat_upload(cosmo_hip_batch* b, std::vector<HostCsr>& Ms, BMat& out, int nrows, int split_col, bool has_split) {
+  std::vector<int> rowptr, col, split, rb, rb_off, nb;
+  std::vector<double> val;
+  std::vector<long long> nz_off;
+  for (int k = 0; k < b->nprob; ++k) {
+    HostCsr& M = Ms[k];
+    nz_off.push_back((long long)col.size());
+    rowptr.insert(rowptr.end(), M.rowptr.begin(), M.rowptr.end());
+    col.insert(col.end(), M.col.begin(), M.col.end());
+    val.insert(val.end(), M.val.begin(), M.val.end());
+    if (has_split) split.insert(split.end(), M.split.begin(), M.split.end());
+    std::vector<int> r; brow_blocks(M.rowptr, nrows, r);
+    rb_off.push_back((int)rb.size()); nb.push_back((int)r.size() - 1);
+    rb.insert(rb.end(), r.begin(), r.end());
+    M = HostCsr();
+  }
+  out.nrows = nrows; out.split_col = split_col;
+  int32_t rc;
+  if ((rc = bup(b, &out.rowptr, rowptr))) return rc;
+  if ((rc = bup(b, &out.col, col))) return rc;
+  if ((rc = bup(b, &out.val, val))) return rc;
+  if (has_split) { if ((rc = bup(b, &out.split, split))) return rc; } else out.split = nullptr;
+  if ((rc = bup(b, &out.rb, rb))) return rc;
+  if ((rc = bup(b, &out.nz_off, nz_off))) return rc;
+  if ((rc = bup(b, &out.rb_off, rb_off))) return rc;
+  if ((rc = bup(b, &out.nb, nb))) return rc;
+  return COSMO_HIP_OK;
+}
+
+// set_params finalises the batch: uploads everything, classifies rows, builds the rho vectors (set_rho_vec!)
+extern "C" int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hip_params* p) {
+  if (!b || !p) return COSMO_HIP_ERR_INVALID;
+  if (hipSetDevice(b->device) != hipSuccess) return bfail(b, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
+  if (!b->have_cones) return bfail(b, COSMO_HIP_ERR_INVALID, "batch_set_cones first");
+  for (int k = 0; k < b->nprob; ++k) if (!b->have[k]) return bfail(b, COSMO_HIP_ERR_INVALID, "problem %d not set", k);
+  if (p->kkt_kind != COSMO_HIP_KKT_CG) return bfail(b, COSMO_HIP_ERR_UNSUPPORTED, "batch mode implements the CG KKT solver");
+  if (p->adaptive_rho && p->adaptive_rho_interval == 0) return bfail(b, COSMO_HIP_ERR_UNSUPPORTED, "adaptive_rho_interval == 0");
+  if (b->finalized) return bfail(b, COSMO_HIP_ERR_INVALID, "batch already finalised");
+  b->prm = *p;
+  const int nprob = b->nprob; const long long n = b->n, m = b->m;
+  BatchDev& D = b->D;
+  D.nprob = nprob; D.n = (int)n; D.m = (int)m;
+  int32_t rc;
+  if ((rc = bmat_upload(b, b->hA, D.A, (int)m, (int)n, false))) return rc;
+  if ((rc = bmat_upload(b, b->hAT, D.AT, (int)n, (int)m, false))) return rc;
+  if ((rc = bmat_upload(b, b->hPT, D.PT, (int)n, (int)n, true))) return rc;
+  if ((rc = bup(b, &D.q, b->hq))) return rc;
+  if ((rc = bup(b, &D.b, b->hb))) return rc;
+  if ((rc = bup(b, &D.Dinv, b->hDinv))) return rc;
+  if ((rc = bup(b, &D.Einv, b->hEinv))) return rc;
+  if ((rc = bup(b, &D.cinv, b->hcinv))) return rc;
+  // cone metadata (shared) + per-problem classification
+  const ConeTable& C = b->cones;
+  std::vector<uint32_t> meta((size_t)m, 0u);
+  std::vector<int> soc_off, soc_dim;
+  long long boxp = 0;
+  for (size_t k = 0; k < C.type.size(); ++k) {
+    const long long o = C.off[k], d = C.dim[k];
+    switch (C.type[k]) {
+      case COSMO_HIP_ZERO: for (long long i = 0; i < d; ++i) meta[o + i] = 1u; break;
+      case COSMO_HIP_NONNEG: case COSMO_HIP_PSD_SQUARE: case COSMO_HIP_PSD_TRIANGLE: for (long long i = 0; i < d; ++i) meta[o + i] = 2u; break;
+      case COSMO_HIP_BOX: for (long long i = 0; i < d; ++i) meta[o + i] = 3u | ((uint32_t)(boxp + i) << 2); boxp += d; break;
+      case COSMO_HIP_SOC: soc_off.push_back((int)o); soc_dim.push_back((int)d); break;
+    }
+  }
+  b->cls_host.assign((size_t)nprob * m, 0);
+  const double big = p->cosmo_infty_min_scaling;
+  for (int k = 0; k < nprob; ++k) {
+    long long bp = 0;
+    for (size_t c = 0; c < C.type.size(); ++c) {
+      const long long o = C.off[c], d = C.dim[c];
+      int32_t* cl = b->cls_host.data() + (size_t)k * m + o;
+      if (C.type[c] == COSMO_HIP_ZERO) for (long long i = 0; i < d; ++i) cl[i] = 1;
+      else if (C.type[c] == COSMO_HIP_NONNEG) { for (long long i = 0; i < d; ++i) if (b->hb[(size_t)k * m + o + i] > big) cl[i] = 2; }
+      else if (C.type[c] == COSMO_HIP_BOX) {
+        for (long long i = 0; i < d; ++i) {
+          const double l = b->hbox_l[(size_t)k * b->nbox + bp + i], u = b->hbox_u[(size_t)k * b->nbox + bp + i];
+          cl[i] = (l < -big && u > big) ? 2 : (((u - l) < p->rho_tol) ? 1 : 0);
+        }
+        bp += d;
+      }
+    }
+  }
+  std::vector<double> rho0((size_t)nprob * m);
+  for (size_t i = 0; i < rho0.size(); ++i) {
+    double rv = p->rho;
+    if (b->cls_host[i] == 1) rv = rv * p->rho_eq_over_rho_ineq; else if (b->cls_host[i] == 2) rv = p->rho_min;
+    rho0[i] = rv;
+  }
+  if ((rc = bup(b, &D.meta, meta))) return rc;
+  if ((rc = bup(b, &D.box_l, b->hbox_l))) return rc;
+  if ((rc = bup(b, &D.box_u, b->hbox_u))) return rc;
+  D.nbox = b->nbox;
+  D.nsoc = (int)soc_off.size();
+  if ((rc = bup(b, &D.soc_off, soc_off))) return rc;
+  if ((rc = bup(b, &D.soc_dim, soc_dim))) return rc;
+  std::vector<int> cls32(b->cls_host.begin(), b->cls_host.end());
+  if ((rc = bup(b, &D.rho_cls, cls32))) return rc;
+  const size_t NM = (size_t)nprob * (n + m), Nn = (size_t)nprob * n, Nm = (size_t)nprob * m;
+  if ((rc = balloc(b, &D.w, NM)) || (rc = balloc(b, &D.w_prev, NM)) || (rc = balloc(b, &D.s, Nm)) || (rc = balloc(b, &D.mu, Nm)) ||
+      (rc = balloc(b, &D.s_tl, Nm)) || (rc = balloc(b, &D.ls_s, Nm)) || (rc = balloc(b, &D.y2, Nm)) || (rc = balloc(b, &D.tmp_m, Nm)) ||
+      (rc = balloc(b, &D.nu, Nm)) || (rc = balloc(b, &D.rho, Nm)) || (rc = balloc(b, &D.ls_x, Nn)) || (rc = balloc(b, &D.x_tl, Nn)) ||
+      (rc = balloc(b, &D.rhs, Nn)) || (rc = balloc(b, &D.r, Nn)) || (rc = balloc(b, &D.u, Nn)) || (rc = balloc(b, &D.c, Nn))) return rc;
+  BHIP(b, hipMemcpy(D.rho, rho0.data(), Nm * sizeof(double), hipMemcpyHostToDevice));
+  std::vector<BCtl> ctl0(nprob);
+  memset(ctl0.data(), 0, sizeof(BCtl) * nprob);
+  for (auto& c : ctl0) { c.rho = p->rho; c.n_rho_updates = 1; c.rho_updates[0] = p->rho; c.cost = INFINITY; c.r_prim = INFINITY; c.r_dual = INFINITY; }
+  if ((rc = balloc(b, &D.ctl, (size_t)nprob))) return rc;
+  BHIP(b, hipMemcpy(D.ctl, ctl0.data(), sizeof(BCtl) * nprob, hipMemcpyHostToDevice));
+  // tolerance schedule tol_constant / k^tol_exponent (get_tolerance, kktsolver_indirect.jl:168-170), host libm like the large path
+  const long long tl = std::min<long long>(std::max<long long>(p->max_iter + 2, 16), 4000000);
+  std::vector<double> tt((size_t)tl);
+  for (long long k = 0; k < tl; ++k) tt[k] = p->tol_constant / pow((double)(k + 1), p->tol_exponent);
+  if ((rc = bup(b, &D.tol_table, tt))) return rc;
+  D.tol_len = tl;
+  b->finalized = true;
+  b->hq.clear(); b->hq.shrink_to_fit();
+  return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_batch_get_rho_classes(cosmo_hip_batch* b, int64_t k, int32_t* cls) {
+  if (!b || !b->finalized || k < 0 || k >= b->nprob || !cls) return bfail(b, COSMO_HIP_ERR_INVALID, "batch_get_rho_classes: bad call");
+  std::copy(b->cls_host.begin() + (size_t)k * b->m, b->cls_host.begin() + (size_t)(k + 1) * b->m, cls);
+  return COSMO_HIP_OK;
+}
+
+// x0, s0, mu0: nprob*n, nprob*m, nprob*m (NULL = zeros)
+extern "C" int32_t cosmo_hip_batch_set_iterates(cosmo_hip_batch* b, const double* x0, const double* s0, const double* mu0) {
+  if (!b || !b->finalized) return bfail(b, COSMO_HIP_ERR_INVALID, "batch_set_iterates: set_params first");
+  if (hipSetDevice(b->device) != hipSuccess) return bfail(b, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
+  const size_t Nn = (size_t)b->nprob * b->n, Nm = (size_t)b->nprob * b->m;
+  double *dx = nullptr, *ds = nullptr, *dm = nullptr;
+  if (x0) { BHIP(b, hipMalloc((void**)&dx, Nn * sizeof(double))); BHIP(b, hipMemcpy(dx, x0, Nn * sizeof(double), hipMemcpyHostToDevice)); }
+  if (s0) { BHIP(b, hipMalloc((void**)&ds, Nm * sizeof(double))); BHIP(b, hipMemcpy(ds, s0, Nm * sizeof(double), hipMemcpyHostToDevice)); }
+  if (mu0) { BHIP(b, hipMalloc((void**)&dm, Nm * sizeof(double))); BHIP(b, hipMemcpy(dm, mu0, Nm * sizeof(double), hipMemcpyHostToDevice)); }
+  hipLaunchKernelGGL(k_batch_set_w, dim3(2048), dim3(COSMO_BS), 0, b->stream, b->D, dx, ds, dm);
+  BHIP(b, hipStreamSynchronize(b->stream));
+  if (dx) (void)hipFree(dx); if (ds) (void)hipFree(ds); if (dm) (void)hipFree(dm);
+  // optimize! restarts at iter = 0 with status undetermined; KKT counters persist
+  std::vector<BCtl> c(b->nprob);
+  BHIP(b, hipMemcpy(c.data(), b->D.ctl, sizeof(BCtl) * b->nprob, hipMemcpyDeviceToHost));
+  for (auto& x : c) { x.status = 0; x.iter = 0; x.cost = INFINITY; x.r_prim = INFINITY; x.r_dual = INFINITY; x.max_norm_prim = 0; x.max_norm_dual = 0; }
+  BHIP(b, hipMemcpy(b->D.ctl, c.data(), sizeof(BCtl) * b->nprob, hipMemcpyHostToDevice));
+  b->have_iterates = true; b->iters_done = 0;
+  return COSMO_HIP_OK;
+}
+
+static BParams bparams(const cosmo_hip_params& p) {
+  BParams P;
+  P.sigma = p.sigma; P.alpha = p.alpha; P.eps_abs = p.eps_abs; P.eps_rel = p.eps_rel; P.rho_min = p.rho_min; P.rho_max = p.rho_max;
+  P.rho_eq = p.rho_eq_over_rho_ineq; P.adapt_tol = p.adaptive_rho_tolerance; P.max_iter = p.max_iter;
+  P.max_adaptions = p.adaptive_rho_max_adaptions; P.check_termination = p.check_termination; P.adaptive_rho = p.adaptive_rho;
+  P.adaptive_rho_interval = p.adaptive_rho_interval; P.unscale = p.unscale_residuals;
+  return P;
+}
+
+// Runs every problem to a status (or max_iter).  results: nprob entries.  The loop is launched in slices of
+// `check_termination`-aligned iterations so that the host can enforce time_limit.
+extern "C" int32_t cosmo_hip_batch_optimize(cosmo_hip_batch* b, cosmo_hip_result* results) {
+  if (!b || !b->have_iterates || !results) return bfail(b, COSMO_HIP_ERR_INVALID, "batch_optimize: set_iterates first");
+  if (hipSetDevice(b->device) != hipSuccess) return bfail(b, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
+  const BParams P = bparams(b->prm);
+  const auto t0 = std::chrono::steady_clock::now();
+  const long long slice = std::max<long long>(b->prm.check_termination, 1) * 8;
+  long long target = 0;
+  std::vector<BCtl> c(b->nprob);
+  int first = 1;
+  for (;;) {
+    target = std::min<long long>(target + slice, b->prm.max_iter);
+    hipLaunchKernelGGL(k_batch_admm, dim3(b->nprob), dim3(COSMO_BS), 0, b->stream, b->D, P, target, first);
+    first = 0;
+    BHIP(b, hipGetLastError());
+    BHIP(b, hipMemcpyAsync(c.data(), b->D.ctl, sizeof(BCtl) * b->nprob, hipMemcpyDeviceToHost, b->stream));
+    BHIP(b, hipStreamSynchronize(b->stream));
+    bool all = true;
+    for (auto& x : c) if (x.status == 0) { all = false; break; }
+    if (all || target >= b->prm.max_iter) break;
+    if (b->prm.time_limit != 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > b->prm.time_limit) {
+      for (auto& x : c) if (x.status == 0) x.status = COSMO_HIP_TIME_LIMIT_REACHED;
+      break;
+    }
+  }
+  const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  for (int k = 0; k < b->nprob; ++k) {
+    cosmo_hip_result& r = results[k];
+    memset(&r, 0, sizeof r);
+    r.status = c[k].status; r.n_rho_updates = c[k].n_rho_updates; r.iter = c[k].iter; r.kkt_iters_total = c[k].kkt_iters_total;
+    r.kkt_solves = c[k].solves; r.cost = c[k].cost; r.r_prim = c[k].r_prim; r.r_dual = c[k].r_dual;
+    r.max_norm_prim = c[k].max_norm_prim; r.max_norm_dual = c[k].max_norm_dual; r.rho = c[k].rho; r.iter_time = el;
+    for (int i = 0; i < COSMO_HIP_MAX_RHO_UPDATES && i < c[k].n_rho_updates; ++i) r.rho_updates[i] = c[k].rho_updates[i];
+  }
+  return COSMO_HIP_OK;
+}
+
+// Runs exactly n_iters more iterations on every undecided problem (benchmark / parity hook); no early exit on time.
+extern "C" int32_t cosmo_hip_batch_iterate(cosmo_hip_batch* b, int64_t n_iters, int32_t with_init) {
+  if (!b || !b->have_iterates) return bfail(b, COSMO_HIP_ERR_INVALID, "batch_iterate: set_iterates first");
+  if (hipSetDevice(b->device) != hipSuccess) return bfail(b, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
+  const BParams P = bparams(b->prm);
+  b->iters_done += n_iters;
+  hipLaunchKernelGGL(k_batch_admm, dim3(b->nprob), dim3(COSMO_BS), 0, b->stream, b->D, P, (long long)b->iters_done, with_init ? 1 : 0);
+  BHIP(b, hipGetLastError());
+  BHIP(b, hipStreamSynchronize(b->stream));
+  return COSMO_HIP_OK;
+}
+
+// w, w_prev: n+m ; s, mu: m  of problem k
+extern "C" int32_t cosmo_hip_batch_get_iterates(cosmo_hip_batch* b, int64_t k, double* w, double* w_prev, double* s, double* mu) {
+  if (!b || !b->have_iterates || k < 0 || k >= b->nprob) return bfail(b, COSMO_HIP_ERR_INVALID, "batch_get_iterates: bad call");
+  if (hipSetDevice(b->device) != hipSuccess) return bfail(b, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
+  const size_t N = (size_t)(b->n + b->m), m = (size_t)b->m;
+  if (w) BHIP(b, hipMemcpy(w, b->D.w + (size_t)k * N, N * sizeof(double), hipMemcpyDeviceToHost));
+  if (w_prev) BHIP(b, hipMemcpy(w_prev, b->D.w_prev + (size_t)k * N, N * sizeof(double), hipMemcpyDeviceToHost));
+  if (s) BHIP(b, hipMemcpy(s, b->D.s + (size_t)k * m, m * sizeof(double), hipMemcpyDeviceToHost));
+  if (mu) BHIP(b, hipMemcpy(mu, b->D.mu + (size_t)k * m, m * sizeof(double), hipMemcpyDeviceToHost));
+  return COSMO_HIP_OK;
+}

@@ -374,8 +374,8 @@ def update(model: Model, q=None, b=None):
         model.handle.update_qb(model.q if q is not None else None, model.b if b is not None else None)
 
 
-def _params_from_settings(h: _ffi.Handle, st: Settings):
-    p = h.default_params()
+def _params_from_settings(h, st: Settings):
+    p = _ffi.default_params()
     kkt = st.kkt_solver
     kw = {}
     if isinstance(kkt, OptionsFactory):
@@ -456,3 +456,95 @@ def optimize(model: Model) -> Result:
     times = ResultTimes(time.perf_counter() - t0, t_setup, r.iter_time, r.proj_time)
     return Result(x=x, y=-mu, s=s, obj_val=r.cost, iter=int(r.iter), status=_ffi.STATUS_NAMES[r.status], info=info,
                   times=times, kkt_iters_total=int(r.kkt_iters_total))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# batches of independent problems (BASELINE config 3) and their sharding over the GPUs of a node
+# ---------------------------------------------------------------------------------------------------------------------
+def shard_range(n_items: int, rank: int, world: int):
+    """Contiguous, balanced shard [lo, hi) of `n_items` independent problems for `rank` of `world` (no exchange step:
+    SURVEY.md 8e, batches shard naturally)."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def _solve_shard_on_device(models: Sequence[Model], device: int) -> List[Result]:
+    """All problems of the shard concurrently on one MI355X (one persistent workgroup per problem, csrc/batch.hip)."""
+    import time
+    if not models:
+        return []
+    t0 = time.perf_counter()
+    n, m = models[0].n, models[0].m
+    kinds = [K.kind for K in models[0].sets]; dims = [K.dim for K in models[0].sets]
+    for md in models:
+        if not md.is_assembled:
+            raise RuntimeError("The model has to be assembled! / set! before optimize!() can be called.")
+        if (md.n, md.m) != (n, m) or [K.kind for K in md.sets] != kinds or [K.dim for K in md.sets] != dims:
+            raise ValueError("optimize_batch: all problems of a batch must share n, m and the cone structure")
+    st = models[0].settings
+    B = _ffi.Batch(len(models), n, m, device)
+    bl, bu = [], []
+    for k, md in enumerate(models):                      # setup! per problem (scaling on the host, as in the reference)
+        if st.scaling != 0 and not md.is_scaled:
+            md.sm = scale_ruiz(md.P, md.q, md.A, md.b, md.sets, md.settings); md.is_scaled = True
+        elif md.sm is None:
+            md.sm = ScaleMatrices(np.ones(n), np.ones(n), np.ones(m), np.ones(m), 1.0, 1.0)
+        md.x = md.sm.Dinv * md.x; md.mu = (md.sm.Einv * md.mu) * md.sm.c; md.s = md.sm.E * md.s
+        B.set_problem(k, md.P, md.q, md.A, md.b)
+        B.set_scaling(k, md.sm.Dinv, md.sm.Einv, md.sm.cinv)
+        bl += [K.l for K in md.sets if K.kind == _ffi.BOX]; bu += [K.u for K in md.sets if K.kind == _ffi.BOX]
+    B.set_cones(kinds, dims, np.concatenate(bl) if bl else None, np.concatenate(bu) if bu else None)
+    p = _params_from_settings(None, st)
+    B.set_params(p)
+    B.set_iterates(np.concatenate([md.x for md in models]), np.concatenate([md.s for md in models]),
+                   np.concatenate([md.mu for md in models]))
+    t_setup = time.perf_counter() - t0
+    rs = B.optimize()
+    out = []
+    for k, (md, r) in enumerate(zip(models, rs)):
+        w, w_prev, s, mu = B.get_iterates(k)
+        x = w_prev[:n].copy()
+        if st.scaling != 0:
+            x = md.sm.D * x; s = md.sm.Einv * s; mu = (md.sm.E * mu) * md.sm.cinv
+        md.x, md.s, md.mu = x.copy(), s.copy(), mu.copy()
+        md.is_optimized = True
+        info = ResultInfo(r.r_prim, r.r_dual, r.max_norm_prim, r.max_norm_dual,
+                          [r.rho_updates[i] for i in range(min(r.n_rho_updates, _ffi.MAX_RHO_UPDATES))])
+        out.append(Result(x=x, y=-mu, s=s, obj_val=r.cost, iter=int(r.iter), status=_ffi.STATUS_NAMES[r.status], info=info,
+                          times=ResultTimes(time.perf_counter() - t0, t_setup, r.iter_time, 0.0), kkt_iters_total=int(r.kkt_iters_total)))
+    B.close()
+    return out
+
+
+def optimize_batch(models: Sequence[Model], device: Optional[int] = None, dist=None, solve_shard=None) -> List[Result]:
+    """`optimize!` for a batch of independent models.  Under torch.distributed (`dist` = the initialised module) every rank
+    solves its contiguous shard on its own GPU and the per-problem results are exchanged once at the end
+    (all_gather_object); there is no collective inside the loop.  `solve_shard(models, device)` is injectable for tests."""
+    rank = dist.get_rank() if dist is not None else 0
+    world = dist.get_world_size() if dist is not None else 1
+    lo, hi = shard_range(len(models), rank, world)
+    dev = device if device is not None else (rank if dist is not None else 0)
+    fn = solve_shard or _solve_shard_on_device
+    local = fn(list(models[lo:hi]), dev)
+    if dist is None or world == 1:
+        return local
+    gathered = [None] * world
+    dist.all_gather_object(gathered, local)
+    out: List[Result] = []
+    for part in gathered:
+        out.extend(part)
+    return out
+
+
+def balance_cones(dims: Sequence[int], world: int) -> List[List[int]]:
+    """Greedy longest-processing-time partition of PSD cliques over ranks by projection cost ~ d^3 (option 1:
+    replicated affine step, sharded projection).  Returns the cone indices owned by every rank (deterministic)."""
+    order = sorted(range(len(dims)), key=lambda i: (-int(dims[i]) ** 3, i))
+    load = [0] * world
+    owner: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda q: (load[q], q))
+        owner[r].append(i)
+        load[r] += int(dims[i]) ** 3
+    return [sorted(o) for o in owner]

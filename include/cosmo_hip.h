@@ -216,6 +216,35 @@ const char* cosmo_hip_kernel_class_name(int32_t k);
  * the last multi-workgroup solve, non-convergence flag, number of PSD cones}. */
 int32_t cosmo_hip_psd_stats(cosmo_hip_handle* h, int64_t out[4]);
 
+/* ---- batches of independent problems (BASELINE config 3) ------------------------------------------------------------
+ * The reference solves a batch with one optimize!(model) per problem (src/solver.jl:78-203).  Here all problems of a batch
+ * (identical n, m and cone structure; data, Box bounds, scalings differ) are solved concurrently, one persistent workgroup
+ * per problem running the complete loop src/solver.jl:137-176 with per-problem rho / CG / status.  CG KKT solver only;
+ * cones: ZeroSet, Nonnegatives, Box, SecondOrderCone.  Ranks of a multi-GPU job each own a contiguous shard of the batch
+ * (no collective). */
+typedef struct cosmo_hip_batch cosmo_hip_batch;
+int32_t cosmo_hip_batch_create(cosmo_hip_batch** b, int32_t device_id, int64_t nprob, int64_t n, int64_t m);
+int32_t cosmo_hip_batch_destroy(cosmo_hip_batch* b);
+const char* cosmo_hip_batch_last_error(const cosmo_hip_batch* b);
+/* problem k of the batch; arguments as cosmo_hip_set_problem */
+int32_t cosmo_hip_batch_set_problem(cosmo_hip_batch* b, int64_t k, const int64_t* P_colptr, const int64_t* P_rowval,
+                                    const double* P_nzval, const int64_t* A_colptr, const int64_t* A_rowval,
+                                    const double* A_nzval, const double* q, const double* bvec);
+/* cone structure shared by all problems; box_l / box_u hold nprob * (#Box rows) entries, problem-major */
+int32_t cosmo_hip_batch_set_cones(cosmo_hip_batch* b, int64_t ncones, const int32_t* type, const int64_t* dim,
+                                  const double* box_l, const double* box_u);
+int32_t cosmo_hip_batch_set_scaling(cosmo_hip_batch* b, int64_t k, const double* Dinv, const double* Einv, double cinv);
+/* finalises the batch (uploads, classify_constraints!, set_rho_vec! per problem) */
+int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hip_params* p);
+int32_t cosmo_hip_batch_get_rho_classes(cosmo_hip_batch* b, int64_t k, int32_t* cls /* m */);
+/* x0: nprob*n, s0 / mu0: nprob*m, problem-major; NULL = zeros (src/solver.jl:128-129 per problem) */
+int32_t cosmo_hip_batch_set_iterates(cosmo_hip_batch* b, const double* x0, const double* s0, const double* mu0);
+/* optimize! for every problem; results has nprob entries */
+int32_t cosmo_hip_batch_optimize(cosmo_hip_batch* b, cosmo_hip_result* results);
+/* n_iters more loop bodies (with checks) on every undecided problem; with_init != 0 runs the init step first */
+int32_t cosmo_hip_batch_iterate(cosmo_hip_batch* b, int64_t n_iters, int32_t with_init);
+int32_t cosmo_hip_batch_get_iterates(cosmo_hip_batch* b, int64_t k, double* w, double* w_prev, double* s, double* mu);
+
 #ifdef __cplusplus
 }
 #endif

@@ -957,7 +957,7 @@ class Workspace:
         mu = rho_vec * (w_prev[n:] - s)                         # :167
         iter_time = time.perf_counter() - t0
         x = w_prev[:n].copy()
-        if it == st.max_iter and status == "Undetermined":      # :173-176
+        if it == st.max_iter and status != "Time_limit_reached":   # :173-176 (overrides a status decided at iter == max_iter)
             info = self._result_info(x, s, mu)
             status = "Max_iter_reached"
         w_out, wp_out, s_sc, mu_sc = w.copy(), w_prev.copy(), s.copy(), mu.copy()

@@ -1,0 +1,70 @@
+"""CPU tests of the N > 1 path (gloo, world_size 2): batches of independent problems shard over ranks with no data-path
+collective; results are exchanged once at the end.  The device solver is replaced by an injected shard solver (the oracle)
+because this container has no GPU -- what is tested is the sharding / gathering logic the GPU ranks run."""
+import os
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import cosmo_jl_amd as cj
+from oracle import cosmo_oracle as O
+from tests import util
+
+
+def _oracle_shard_solver(models, device):
+    out = []
+    for md in models:
+        r = O.solve(md.P, md.q, md.A, md.b, util.oracle_cones(md.sets), O.Settings(kkt_solver="cg", max_iter=400))
+        out.append(cj.model.Result(x=r.x, y=r.y, s=r.s, obj_val=r.obj_val, iter=r.iter, status=r.status,
+                                   info=cj.model.ResultInfo(r.r_prim, r.r_dual, r.max_norm_prim, r.max_norm_dual, r.rho_updates),
+                                   times=cj.model.ResultTimes()))
+    return out
+
+
+def _models():
+    probs = [cj.problems.socp(n=20, m=30, ncones=5, nnz=120, seed=7 + k) for k in range(5)]
+    out = []
+    for p in probs:
+        md = cj.Model(); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], cj.Settings())
+        out.append(md)
+    return out
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = cj.optimize_batch(_models(), dist=dist, solve_shard=_oracle_shard_solver)
+    q.put((rank, [(r.status, r.iter, float(r.obj_val)) for r in res]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_batch_shards_over_two_ranks_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    got = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs: p.join(timeout=60)
+    serial = [(r.status, r.iter, float(r.obj_val)) for r in _oracle_shard_solver(_models(), 0)]
+    assert got[0] == got[1] == serial                       # every rank ends with all results, in problem order
+
+
+def test_shard_range_and_cone_balance():
+    for n_items in (0, 1, 7, 1024):
+        for world in (1, 2, 3, 8):
+            rs = [cj.shard_range(n_items, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == n_items
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in rs]
+            assert max(sizes) - min(sizes) <= 1
+    rng = np.random.default_rng(5)
+    dims = rng.integers(20, 201, size=400)
+    own = cj.balance_cones(dims, 8)
+    assert sorted(i for o in own for i in o) == list(range(400))
+    loads = [sum(int(dims[i]) ** 3 for i in o) for o in own]
+    assert max(loads) <= 1.05 * (sum(loads) / 8) + 200 ** 3    # LPT bound: within one largest item of the mean
