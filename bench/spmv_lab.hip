@@ -113,6 +113,35 @@ __global__ __launch_bounds__(BS) void k_stream_g(const int* __restrict__ rp, con
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// V4: panel-sorted CSR-stream.  Inside every tile the (col, val) pairs are stored sorted by column together with the slot
+// `pos` they occupy in row order; lanes of a wave then gather neighbouring lines of x (duplicates coalesce), the products
+// are scattered to lds[pos] and phase 2 is unchanged (row order => bit-exact sums).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int BS, int T>
+__global__ __launch_bounds__(BS) void k_stream_sorted(const int* __restrict__ rp, const int* __restrict__ col, const double* __restrict__ val,
+                                                      const unsigned short* __restrict__ pos, const int* __restrict__ rb, int nb,
+                                                      const double* __restrict__ x, double* __restrict__ y) {
+  __shared__ double lds[T];
+  for (int k = blockIdx.x; k < nb; k += gridDim.x) {
+    const int r0 = rb[k], r1 = rb[k + 1];
+    const int nz0 = rp[r0], cnt = rp[r1] - nz0;
+#pragma unroll
+    for (int it = 0; it < T / BS; ++it) {
+      const int i = it * BS + threadIdx.x;
+      if (i < cnt) lds[pos[nz0 + i]] = val[nz0 + i] * x[col[nz0 + i]];
+    }
+    __syncthreads();
+    for (int r = r0 + threadIdx.x; r < r1; r += BS) {
+      const int a = rp[r] - nz0, b = rp[r + 1] - nz0;
+      double s = 0.0;
+      for (int j = a; j < b; ++j) s += lds[j];
+      y[r] = s;
+    }
+    __syncthreads();
+  }
+}
+
 // ---- diagnostics: isolate streaming, gathering and launch costs ----------------------------------------------------
 __global__ void k_empty() {}
 template <int MODE>   // 0: stream val,col only   1: + coalesced x   2: + random gather restricted to 4096 entries   3: full gather
@@ -261,6 +290,33 @@ static void run_matrix(const char* label, int nr, int nc, long long nnz, unsigne
   STREAM(256, 2048, false, 512)
   STREAM(256, 1024, false, 1024)
   STREAM(256, 1024, false, 2048)
+#define SORTED(BS, T)                                                                                                  \
+  {                                                                                                                    \
+    build_rb(M, T, 8 * BS, rb); d.nb = (int)rb.size() - 1;                                                             \
+    std::vector<int> scol(z); std::vector<double> sval(z); std::vector<unsigned short> spos(z);                        \
+    for (int t = 0; t < d.nb; ++t) {                                                                                   \
+      const int a = M.rp[rb[t]], b = M.rp[rb[t + 1]];                                                                  \
+      std::vector<int> idx(b - a); for (int i = 0; i < b - a; ++i) idx[i] = i;                                         \
+      std::stable_sort(idx.begin(), idx.end(), [&](int p, int q) { return M.col[a + p] < M.col[a + q]; });             \
+      for (int i = 0; i < b - a; ++i) { scol[a + i] = M.col[a + idx[i]]; sval[a + i] = M.val[a + idx[i]]; spos[a + i] = (unsigned short)idx[i]; } \
+    }                                                                                                                  \
+    int* dcol; double* dval; unsigned short* dpos;                                                                     \
+    CK(hipMalloc(&dcol, sizeof(int) * z)); CK(hipMalloc(&dval, sizeof(double) * z)); CK(hipMalloc(&dpos, 2 * z));      \
+    CK(hipMemcpy(dcol, scol.data(), sizeof(int) * z, hipMemcpyHostToDevice));                                          \
+    CK(hipMemcpy(dval, sval.data(), sizeof(double) * z, hipMemcpyHostToDevice));                                       \
+    CK(hipMemcpy(dpos, spos.data(), 2 * z, hipMemcpyHostToDevice));                                                    \
+    CK(hipMemcpy(d.rb, rb.data(), sizeof(int) * rb.size(), hipMemcpyHostToDevice));                                    \
+    CK(hipMemset(d.y, 0, sizeof(double) * nr));                                                                        \
+    double us = time_it([&] { hipLaunchKernelGGL((k_stream_sorted<BS, T>), dim3(d.nb), dim3(BS), 0, 0, d.rp, dcol, dval, dpos, d.rb, d.nb, d.x, d.y); }, R); \
+    char nm[96]; snprintf(nm, 96, "SORTED BS=%d T=%d grid=%d", BS, T, d.nb); check(nm, M, x, d.y, us, bytes);          \
+    CK(hipFree(dcol)); CK(hipFree(dval)); CK(hipFree(dpos));                                                           \
+  }
+  SORTED(256, 2048)
+  SORTED(256, 4096)
+  SORTED(512, 4096)
+  SORTED(512, 8192)
+  SORTED(1024, 8192)
+  SORTED(1024, 16384)
 #define STREAMG(BS, T, G)                                                                                              \
   {                                                                                                                    \
     build_rb(M, T, 4 * BS, rb); d.nb = (int)rb.size() - 1;                                                             \

@@ -5,7 +5,7 @@ from . import _ffi
 from ._ffi import CosmoHipError, Handle, load_library
 from .model import (Box, CGIndirectKKTSolver, Constraint, IndirectReducedKKTSolverMINRES, MINRESIndirectKKTSolver,
                     Model, Nonnegatives, PsdCone, PsdConeTriangle, QdldlKKTSolver, Result, SecondOrderCone, Settings,
-                    ZeroSet, assemble, balance_cones, optimize, optimize_batch, shard_range, update, warm_start_dual, warm_start_primal, warm_start_slack,
+                    ZeroSet, assemble, balance_cones, cone_costs, optimize, partition_cones_contiguous, optimize_batch, shard_range, update, warm_start_dual, warm_start_primal, warm_start_slack,
                     with_options)
 from . import problems
 

@@ -96,6 +96,12 @@ SIGNATURES = {
     "cosmo_hip_get_kernel_times": (C.c_int32, [C.c_void_p, _PD, _PI64]),
     "cosmo_hip_kernel_class_name": (C.c_char_p, [C.c_int32]),
     "cosmo_hip_psd_stats": (C.c_int32, [C.c_void_p, _PI64]),
+    "cosmo_hip_comm_unique_id": (C.c_int32, [C.POINTER(C.c_uint8)]),
+    "cosmo_hip_comm_init": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]),
+    "cosmo_hip_comm_destroy": (C.c_int32, [C.c_void_p]),
+    "cosmo_hip_set_cone_shard": (C.c_int32, [C.c_void_p, _PI64]),
+    "cosmo_hip_comm_selftest": (C.c_int32, [C.c_void_p]),
+    "cosmo_hip_set_cone_ownership": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int64]),
     "cosmo_hip_batch_create": (C.c_int32, [C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_int64, C.c_int64]),
     "cosmo_hip_batch_destroy": (C.c_int32, [C.c_void_p]),
     "cosmo_hip_batch_last_error": (C.c_char_p, [C.c_void_p]),
@@ -313,6 +319,29 @@ class Handle:
         out = np.zeros(4, dtype=np.int64)
         self._chk(self.lib.cosmo_hip_psd_stats(self._h, out.ctypes.data_as(_PI64)))
         return dict(zip(["max_sweeps_wg", "sweeps_large", "not_converged", "ncones"], out.tolist()))
+
+    # ---- clique sharding -----------------------------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_uint8 * 128)()
+        rc = load_library().cosmo_hip_comm_unique_id(buf)
+        if rc != OK:
+            raise CosmoHipError(rc, "cosmo_hip_comm_unique_id failed")
+        return bytes(buf)
+
+    def comm_init(self, rank, nranks, uid: bytes):
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        self._chk(self.lib.cosmo_hip_comm_init(self._h, int(rank), int(nranks), buf))
+
+    def set_cone_shard(self, first_cone):
+        fc = np.ascontiguousarray(first_cone, dtype=np.int64)
+        self._chk(self.lib.cosmo_hip_set_cone_shard(self._h, fc.ctypes.data_as(_PI64)))
+
+    def set_cone_ownership(self, lo, hi):
+        self._chk(self.lib.cosmo_hip_set_cone_ownership(self._h, int(lo), int(hi)))
+
+    def comm_selftest(self):
+        self._chk(self.lib.cosmo_hip_comm_selftest(self._h))
 
     def set_profiling(self, on):
         self._chk(self.lib.cosmo_hip_set_profiling(self._h, int(on)))

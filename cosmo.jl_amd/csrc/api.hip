@@ -238,6 +238,7 @@ extern "C" int32_t cosmo_hip_destroy(cosmo_hip_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   free_csr(h->A); free_csr(h->AT); free_csr(h->P); free_csr(h->PT);
+  (void)cosmo_hip_comm_destroy(h);
   free_vectors(h);
   free_cones(h);
   dfree(&h->partials);
@@ -335,6 +336,22 @@ static int32_t classify_rows(cosmo_hip_handle* h, const std::vector<double>& bho
   return COSMO_HIP_OK;
 }
 
+// SOC table and PSD plan of the cones this rank owns (all cones unless cosmo_hip_set_cone_shard restricted the range)
+int32_t rebuild_cone_plans(cosmo_hip_handle* h) {
+  const ConeTable& C = h->cones;
+  std::vector<int> soc_off, soc_dim;
+  h->soc_cone_index.clear();
+  for (size_t k = 0; k < C.type.size(); ++k) {
+    if (C.type[k] != COSMO_HIP_SOC || !cone_owned(h, (long long)k)) continue;
+    soc_off.push_back((int)C.off[k]); soc_dim.push_back((int)C.dim[k]); h->soc_cone_index.push_back((int)k);
+  }
+  h->nsoc = (int)soc_off.size();
+  CHK(dalloc(h, &h->soc_off, soc_off.size())); CHK(dalloc(h, &h->soc_dim, soc_dim.size())); CHK(dalloc(h, &h->soc_branch, soc_off.size()));
+  if (h->nsoc) { CHK(h2d(h, h->soc_off, soc_off.data(), soc_off.size())); CHK(h2d(h, h->soc_dim, soc_dim.data(), soc_dim.size())); }
+  CHK(psd_plan_create(h));
+  return COSMO_HIP_OK;
+}
+
 extern "C" int32_t cosmo_hip_set_cones(cosmo_hip_handle* h, int64_t ncones, const int32_t* type, const int64_t* dim,
                                        const double* box_l, const double* box_u) {
   ENTER(h);
@@ -360,9 +377,8 @@ extern "C" int32_t cosmo_hip_set_cones(cosmo_hip_handle* h, int64_t ncones, cons
   if (nbox > 0 && (!box_l || !box_u)) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "Box cones need bounds");
   C.nbox_rows = nbox;
   if (nbox > 0) { C.box_l.assign(box_l, box_l + nbox); C.box_u.assign(box_u, box_u + nbox); }
-  // per-row projection metadata + SOC table
+  // per-row projection metadata (simple cones are projected by the elementwise copy kernel on every rank)
   std::vector<uint32_t> meta((size_t)h->m, 0u);
-  std::vector<int> soc_off, soc_dim;
   int64_t boxp = 0;
   for (int64_t k = 0; k < ncones; ++k) {
     const int64_t o = C.off[k], d = C.dim[k];
@@ -374,9 +390,7 @@ extern "C" int32_t cosmo_hip_set_cones(cosmo_hip_handle* h, int64_t ncones, cons
         for (int64_t i = 0; i < d; ++i) meta[o + i] = 3u | ((uint32_t)(boxp + i) << 2);
         boxp += d;
         break;
-      case COSMO_HIP_SOC:
-        soc_off.push_back((int)o); soc_dim.push_back((int)d); h->soc_cone_index.push_back((int)k);
-        break;
+      case COSMO_HIP_SOC: break;
       case COSMO_HIP_PSD_SQUARE:
       case COSMO_HIP_PSD_TRIANGLE:
         if (d == 1) for (int64_t i = 0; i < d; ++i) meta[o + i] = 2u;  // 1x1: max(x,0) (convexset.jl:307-308,404-405)
@@ -387,11 +401,8 @@ extern "C" int32_t cosmo_hip_set_cones(cosmo_hip_handle* h, int64_t ncones, cons
   CHK(h2d(h, h->meta, meta.data(), (size_t)h->m));
   CHK(dalloc(h, &h->box_l, (size_t)nbox)); CHK(dalloc(h, &h->box_u, (size_t)nbox));
   if (nbox > 0) { CHK(h2d(h, h->box_l, C.box_l.data(), (size_t)nbox)); CHK(h2d(h, h->box_u, C.box_u.data(), (size_t)nbox)); }
-  h->nsoc = (int)soc_off.size();
-  if (h->nsoc == 0) h->soc_cone_index.clear();
-  CHK(dalloc(h, &h->soc_off, soc_off.size())); CHK(dalloc(h, &h->soc_dim, soc_dim.size())); CHK(dalloc(h, &h->soc_branch, soc_off.size()));
-  if (h->nsoc) { CHK(h2d(h, h->soc_off, soc_off.data(), soc_off.size())); CHK(h2d(h, h->soc_dim, soc_dim.data(), soc_dim.size())); }
-  CHK(psd_plan_create(h));
+  h->cone_lo = 0; h->cone_hi = -1;
+  CHK(rebuild_cone_plans(h));
   std::vector<double> bhost((size_t)h->m);
   CHK(d2h(h, bhost.data(), h->b, (size_t)h->m));
   CHK(classify_rows(h, bhost));
@@ -509,6 +520,7 @@ extern "C" int32_t cosmo_hip_project(cosmo_hip_handle* h, double* s, int64_t* ps
   CHK(launch_project_simple_inplace(h, h->io));
   CHK(launch_soc(h, h->io, 0));
   CHK(psd_enqueue_project(h, h->io, false));
+  CHK(comm_enqueue_exchange(h, h->io));
   CHK(d2h(h, s, h->io, (size_t)h->m));
   const size_t nc = h->cones.type.size();
   if (soc_branch_out) {
@@ -627,6 +639,7 @@ static int32_t enqueue_iteration(cosmo_hip_handle* h, long long it) {
   CHK(launch_z(h, 1));
   CHK(launch_soc(h, h->s, 1));
   CHK(psd_enqueue_project(h, h->s, true));
+  CHK(comm_enqueue_exchange(h, h->s));      // clique sharding: the one exchange step of the iteration
   if (h->prm.adaptive_rho && h->prm.adaptive_rho_interval > 0 && (it % h->prm.adaptive_rho_interval) == 0)
     CHK(enqueue_check(h, 1, 2));
   CHK(enqueue_solve_in_loop(h));

@@ -1,0 +1,164 @@
+// comm.hip -- clique-sharded projections over the GPUs of one node (option 1: replicated affine step,
+// sharded projection, ONE exchange step per iteration).
+//
+// Every rank (one process per GPU) holds the whole problem and runs the identical, bit-reproducible x-/w-steps; the cone
+// projections -- which dominate SDP iterations (`proj_time`, src/solver.jl:15,152; docs/src/performance.md:35) -- are
+// partitioned: rank r projects only the SOC / PSD cones of a CONTIGUOUS range of cones, whose rows form one contiguous slice
+// of `s`.  After the local projections each rank's slice is broadcast in place from its owner (RCCL ncclBroadcast calls
+// inside one group on the handle's stream = an all-gather with unequal counts).  On a fully connected xGMI node every link
+// carries 1/N of the payload once.  No other collective exists: all scalars (CG, rho, residuals) are recomputed redundantly
+// and agree bit for bit because the gathered `s` is bit-identical everywhere.
+//
+// RCCL is loaded lazily with dlopen so that the library has no RCCL dependency for single-GPU use and shares the RCCL
+// instance of the hosting process (torch bundles its own librccl.so; loading a second copy would clash).
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <string.h>
+#include "internal.h"
+
+typedef struct { char internal[128]; } nccl_uid_t;
+typedef void* nccl_comm_t;
+enum { NCCL_FLOAT64 = 8 };   // ncclDouble / ncclFloat64 (rccl.h ncclDataType_t)
+
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(nccl_uid_t*) = nullptr;
+  int (*CommInitRank)(nccl_comm_t*, int, nccl_uid_t, int) = nullptr;
+  int (*CommDestroy)(nccl_comm_t) = nullptr;
+  int (*Broadcast)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+static RcclApi g_rccl;
+
+static const char* rccl_load() {
+  if (g_rccl.lib) return nullptr;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* lib = nullptr;
+  for (const char* nm : names) { lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
+  if (!lib) return "cannot dlopen librccl.so";
+  g_rccl.GetUniqueId = (int (*)(nccl_uid_t*))dlsym(lib, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (int (*)(nccl_comm_t*, int, nccl_uid_t, int))dlsym(lib, "ncclCommInitRank");
+  g_rccl.CommDestroy = (int (*)(nccl_comm_t))dlsym(lib, "ncclCommDestroy");
+  g_rccl.Broadcast = (int (*)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t))dlsym(lib, "ncclBroadcast");
+  g_rccl.GroupStart = (int (*)())dlsym(lib, "ncclGroupStart");
+  g_rccl.GroupEnd = (int (*)())dlsym(lib, "ncclGroupEnd");
+  g_rccl.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.Broadcast || !g_rccl.GroupStart || !g_rccl.GroupEnd)
+    return "librccl.so lacks an expected symbol";
+  g_rccl.lib = lib;
+  return nullptr;
+}
+
+#define NCHK(h, call)                                                                                                     \
+  do {                                                                                                                    \
+    int r__ = (call);                                                                                                     \
+    if (r__ != 0)                                                                                                         \
+      return cosmo_fail((h), COSMO_HIP_ERR_COMM, "%s failed: %s", #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(r__) : "?"); \
+  } while (0)
+
+struct CommState {
+  nccl_comm_t comm = nullptr;
+  int rank = 0, nranks = 1;
+  std::vector<long long> first_cone;   // nranks + 1 boundaries (cone indices)
+  std::vector<long long> row_lo, row_hi;
+};
+
+extern "C" int32_t cosmo_hip_comm_unique_id(uint8_t id[128]) {
+  if (!id) return COSMO_HIP_ERR_INVALID;
+  if (rccl_load()) return COSMO_HIP_ERR_COMM;
+  nccl_uid_t u;
+  if (g_rccl.GetUniqueId(&u) != 0) return COSMO_HIP_ERR_COMM;
+  memcpy(id, u.internal, 128);
+  return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_comm_destroy(cosmo_hip_handle* h) {
+  if (!h || !h->comm) return COSMO_HIP_OK;
+  CommState* c = (CommState*)h->comm;
+  if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+  delete c;
+  h->comm = nullptr;
+  h->cone_lo = 0; h->cone_hi = -1;
+  return COSMO_HIP_OK;
+}
+
+// One communicator per handle (one process per GPU).  `id` comes from cosmo_hip_comm_unique_id on rank 0 and is
+// distributed by the host layer (torch.distributed / MPI / a Julia Distributed broadcast).
+extern "C" int32_t cosmo_hip_comm_init(cosmo_hip_handle* h, int32_t rank, int32_t nranks, const uint8_t id[128]) {
+  if (!h || !id || nranks < 1 || rank < 0 || rank >= nranks) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "comm_init: bad arguments");
+  if (hipSetDevice(h->device) != hipSuccess) return cosmo_fail(h, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
+  if (const char* e = rccl_load()) return cosmo_fail(h, COSMO_HIP_ERR_COMM, "%s", e);
+  (void)cosmo_hip_comm_destroy(h);
+  CommState* c = new CommState();
+  c->rank = rank; c->nranks = nranks;
+  nccl_uid_t u; memcpy(u.internal, id, 128);
+  const int rc = g_rccl.CommInitRank(&c->comm, nranks, u, rank);
+  if (rc != 0) { delete c; return cosmo_fail(h, COSMO_HIP_ERR_COMM, "ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"); }
+  h->comm = c;
+  return COSMO_HIP_OK;
+}
+
+// first_cone: nranks+1 non-decreasing cone indices, first_cone[0] = 0, first_cone[nranks] = ncones.  Rank r projects the
+// SOC / PSD cones first_cone[r] <= k < first_cone[r+1]; Zero / Nonnegatives / Box rows are projected by everyone (they are
+// part of the elementwise copy kernel).  Must be called after cosmo_hip_set_cones (rebuilds the SOC table and PSD plan).
+int32_t rebuild_cone_plans(cosmo_hip_handle* h);   // api.hip
+extern "C" int32_t cosmo_hip_set_cone_shard(cosmo_hip_handle* h, const int64_t* first_cone) {
+  if (!h || !first_cone) return COSMO_HIP_ERR_INVALID;
+  if (!h->comm) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_cone_shard: comm_init first");
+  if (!h->have_cones) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_cone_shard: set_cones first");
+  CommState* c = (CommState*)h->comm;
+  const long long nc = (long long)h->cones.type.size();
+  if (first_cone[0] != 0 || first_cone[c->nranks] != nc) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_cone_shard: boundaries must span all cones");
+  c->first_cone.assign(first_cone, first_cone + c->nranks + 1);
+  c->row_lo.assign(c->nranks, 0); c->row_hi.assign(c->nranks, 0);
+  for (int r = 0; r < c->nranks; ++r) {
+    if (first_cone[r + 1] < first_cone[r]) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_cone_shard: boundaries must be non-decreasing");
+    const long long a = first_cone[r], b = first_cone[r + 1];
+    c->row_lo[r] = (a < nc) ? h->cones.off[a] : h->m;
+    c->row_hi[r] = (b < nc) ? h->cones.off[b] : h->m;
+  }
+  h->cone_lo = first_cone[c->rank];
+  h->cone_hi = first_cone[c->rank + 1];
+  return rebuild_cone_plans(h);
+}
+
+// Ownership only (no communicator): this handle projects the SOC / PSD cones cone_lo <= k < cone_hi and leaves the other
+// cones' rows untouched.  Building block of cosmo_hip_set_cone_shard; also lets the sharded projection be verified on a
+// single GPU (project with two handles owning complementary ranges, merge the slices).
+extern "C" int32_t cosmo_hip_set_cone_ownership(cosmo_hip_handle* h, int64_t cone_lo, int64_t cone_hi) {
+  if (!h) return COSMO_HIP_ERR_INVALID;
+  if (!h->have_cones) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_cone_ownership: set_cones first");
+  if (cone_lo < 0 || cone_hi < cone_lo || cone_hi > (int64_t)h->cones.type.size()) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_cone_ownership: bad range");
+  h->cone_lo = cone_lo; h->cone_hi = cone_hi;
+  return rebuild_cone_plans(h);
+}
+
+// the one exchange step: every owner broadcasts its slice of s in place (enqueued on the handle's stream)
+int32_t comm_enqueue_exchange(cosmo_hip_handle* h, double* s) {
+  if (!h->comm) return COSMO_HIP_OK;
+  CommState* c = (CommState*)h->comm;
+  if (c->nranks == 1 || c->first_cone.empty()) return COSMO_HIP_OK;
+  NCHK(h, g_rccl.GroupStart());
+  for (int r = 0; r < c->nranks; ++r) {
+    const long long cnt = c->row_hi[r] - c->row_lo[r];
+    if (cnt <= 0) continue;
+    NCHK(h, g_rccl.Broadcast(s + c->row_lo[r], s + c->row_lo[r], (size_t)cnt, NCCL_FLOAT64, r, c->comm, h->stream));
+  }
+  NCHK(h, g_rccl.GroupEnd());
+  return COSMO_HIP_OK;
+}
+
+// self-test hook: broadcast-in-place of the whole s from rank 0 through the communicator (exercises the RCCL path even
+// on a single-rank communicator, where the sharded exchange is skipped)
+extern "C" int32_t cosmo_hip_comm_selftest(cosmo_hip_handle* h) {
+  if (!h || !h->comm || !h->have_iterates) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "comm_selftest: comm_init and set_iterates first");
+  CommState* c = (CommState*)h->comm;
+  if (hipSetDevice(h->device) != hipSuccess) return cosmo_fail(h, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
+  NCHK(h, g_rccl.GroupStart());
+  NCHK(h, g_rccl.Broadcast(h->s, h->s, (size_t)h->m, NCCL_FLOAT64, 0, c->comm, h->stream));
+  NCHK(h, g_rccl.GroupEnd());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return COSMO_HIP_OK;
+}

@@ -104,6 +104,9 @@ struct cosmo_hip_handle {
   int *soc_off = nullptr, *soc_dim = nullptr, *soc_branch = nullptr;
   std::vector<int> soc_cone_index;
   PsdPlan* psd = nullptr;
+  // clique sharding (comm.hip): this rank projects the SOC / PSD cones cone_lo <= k < cone_hi (cone_hi < 0: all cones)
+  void* comm = nullptr;
+  long long cone_lo = 0, cone_hi = -1;
   // loop state
   double *w = nullptr, *w_prev = nullptr, *s = nullptr, *mu = nullptr, *s_tl = nullptr;
   double *ls_x = nullptr, *ls_s = nullptr, *x_tl = nullptr, *nu = nullptr;
@@ -168,3 +171,7 @@ int32_t psd_plan_create(cosmo_hip_handle* h);
 void psd_plan_destroy(cosmo_hip_handle* h);
 int32_t psd_enqueue_project(cosmo_hip_handle* h, double* s, bool guard);
 int32_t psd_get_ranks(cosmo_hip_handle* h, int64_t* rank_per_cone);
+static inline bool cone_owned(const cosmo_hip_handle* h, long long k) { return h->cone_hi < 0 || (k >= h->cone_lo && k < h->cone_hi); }
+// comm.hip
+int32_t comm_enqueue_exchange(cosmo_hip_handle* h, double* s);
+extern "C" int32_t cosmo_hip_comm_destroy(cosmo_hip_handle* h);

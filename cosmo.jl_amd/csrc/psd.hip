@@ -595,6 +595,7 @@ int32_t psd_plan_create(cosmo_hip_handle* h) {
   for (size_t k = 0; k < C.type.size(); ++k) {
     if (C.type[k] != COSMO_HIP_PSD_SQUARE && C.type[k] != COSMO_HIP_PSD_TRIANGLE) continue;
     if (C.dim[k] <= 1) continue;
+    if (!cone_owned(h, (long long)k)) continue;   // clique sharding: another rank projects this cone
     PsdConeDev cn;
     cn.kind = C.type[k];
     cn.off = (int)C.off[k];

@@ -432,13 +432,18 @@ def setup(model: Model):
         model.handle = h
 
 
-def optimize(model: Model) -> Result:
-    """`COSMO.optimize!` (src/solver.jl:78-203) with the `while` loop running on the MI355X."""
+def optimize(model: Model, dist=None) -> Result:
+    """`COSMO.optimize!` (src/solver.jl:78-203) with the `while` loop running on the MI355X.  With an initialised
+    torch.distributed module as `dist` (one process per GPU) the cone projections are sharded over the ranks
+    (setup_clique_sharding); every rank returns the same Result."""
     import time
     if not model.is_assembled:
         raise RuntimeError("The model has to be assembled! / set! before optimize!() can be called.")
     t0 = time.perf_counter()
+    fresh = model.handle is None
     setup(model)
+    if dist is not None and dist.get_world_size() > 1 and fresh:
+        setup_clique_sharding(model, dist)
     t_setup = time.perf_counter() - t0
     h, sm, n = model.handle, model.sm, model.n
     h.set_iterates(model.x, model.s, model.mu)                    # solver.jl:128-129
@@ -548,3 +553,54 @@ def balance_cones(dims: Sequence[int], world: int) -> List[List[int]]:
         owner[r].append(i)
         load[r] += int(dims[i]) ** 3
     return [sorted(o) for o in owner]
+
+
+def cone_costs(sets: Sequence[AbstractConvexSet]) -> List[int]:
+    """Projection cost model per cone: ~d^3 for a PSD cone of side d, ~dim for a second-order cone, 0 for the cones that the
+    elementwise kernel projects on every rank."""
+    out = []
+    for K in sets:
+        if K.kind in (_ffi.PSD_SQUARE, _ffi.PSD_TRIANGLE) and K.dim > 1:
+            out.append(int(K.sqrt_dim) ** 3)
+        elif K.kind == _ffi.SOC:
+            out.append(int(K.dim))
+        else:
+            out.append(0)
+    return out
+
+
+def partition_cones_contiguous(costs: Sequence[int], world: int) -> List[int]:
+    """Boundaries first_cone[0..world] of the contiguous partition of the cone list that minimises the maximum load
+    (binary search on the bottleneck + greedy feasibility).  Contiguous ranges keep every rank's rows one slice of `s`, so
+    the exchange step is one in-place broadcast per rank."""
+    n = len(costs)
+    if world <= 1 or n == 0:
+        return [0] + [n] * max(world, 1)
+    lo, hi = max(costs) if costs else 0, sum(costs)
+
+    def cuts(limit):
+        b, acc = [0], 0
+        for i, c in enumerate(costs):
+            if acc + c > limit and acc > 0:
+                b.append(i); acc = 0
+            acc += c
+        return b
+    while lo < hi:
+        mid = (lo + hi) // 2
+        if len(cuts(mid)) <= world:
+            hi = mid
+        else:
+            lo = mid + 1
+    b = cuts(lo)
+    b += [n] * (world + 1 - len(b))
+    return b
+
+
+def setup_clique_sharding(model: Model, dist) -> None:
+    """One communicator per handle (one process per GPU): rank 0 creates the RCCL unique id, the host layer distributes it,
+    every rank takes a contiguous cone range balanced by cone_costs()."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    uid = [_ffi.Handle.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    model.handle.comm_init(rank, world, uid[0])
+    model.handle.set_cone_shard(partition_cones_contiguous(cone_costs(model.sets), world))

@@ -1,2 +1,2 @@
 mkdir -p gpurun_out
-(timeout 900 python -m pytest tests/test_gpu_batch.py -m gpu -q -x -s 2>&1 | tail -40) > gpurun_out/t9.log; cat gpurun_out/t9.log
+(timeout 600 python -m pytest tests/test_gpu_sharding.py -m gpu -q -x 2>&1 | tail -30) > gpurun_out/t10.log; cat gpurun_out/t10.log

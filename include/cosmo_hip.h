@@ -216,6 +216,19 @@ const char* cosmo_hip_kernel_class_name(int32_t k);
  * the last multi-workgroup solve, non-convergence flag, number of PSD cones}. */
 int32_t cosmo_hip_psd_stats(cosmo_hip_handle* h, int64_t out[4]);
 
+/* ---- clique-sharded projections over the GPUs of one node (one process per GPU, RCCL over xGMI) -----------------------
+ * The reference projects the cones of a decomposed SDP serially (src/convexset.jl:885-891).  Here every rank holds the whole
+ * problem, runs the identical affine steps, projects only the SOC / PSD cones of its contiguous cone range, and the slices
+ * of s are exchanged once per iteration (ncclBroadcast group = all-gather with unequal counts).  No other collective. */
+int32_t cosmo_hip_comm_unique_id(uint8_t id[128]);                       /* ncclGetUniqueId on one rank; host layer distributes it */
+int32_t cosmo_hip_comm_init(cosmo_hip_handle* h, int32_t rank, int32_t nranks, const uint8_t id[128]);
+int32_t cosmo_hip_comm_destroy(cosmo_hip_handle* h);
+/* first_cone[nranks+1]: contiguous partition of the cone indices; call after cosmo_hip_set_cones */
+int32_t cosmo_hip_set_cone_shard(cosmo_hip_handle* h, const int64_t* first_cone);
+int32_t cosmo_hip_comm_selftest(cosmo_hip_handle* h);
+/* ownership without a communicator: project only the SOC / PSD cones cone_lo <= k < cone_hi (testing / custom exchange) */
+int32_t cosmo_hip_set_cone_ownership(cosmo_hip_handle* h, int64_t cone_lo, int64_t cone_hi);
+
 /* ---- batches of independent problems (BASELINE config 3) ------------------------------------------------------------
  * The reference solves a batch with one optimize!(model) per problem (src/solver.jl:78-203).  Here all problems of a batch
  * (identical n, m and cone structure; data, Box bounds, scalings differ) are solved concurrently, one persistent workgroup

@@ -68,3 +68,17 @@ def test_shard_range_and_cone_balance():
     assert sorted(i for o in own for i in o) == list(range(400))
     loads = [sum(int(dims[i]) ** 3 for i in o) for o in own]
     assert max(loads) <= 1.05 * (sum(loads) / 8) + 200 ** 3    # LPT bound: within one largest item of the mean
+
+
+def test_contiguous_cone_partition():
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        ncones = int(rng.integers(1, 60)); world = int(rng.integers(1, 9))
+        costs = [int(c) for c in rng.integers(0, 50, size=ncones) ** 3]
+        b = cj.partition_cones_contiguous(costs, world)
+        assert len(b) == world + 1 and b[0] == 0 and b[-1] == ncones and all(b[i] <= b[i + 1] for i in range(world))
+        loads = [sum(costs[b[i]:b[i + 1]]) for i in range(world)]
+        # optimal bottleneck: no contiguous partition into `world` parts can beat it (check against brute-force lower bounds)
+        assert max(loads) >= max(max(costs), -(-sum(costs) // world)) and max(loads) <= max(costs) + sum(costs) // world + 1
+    sets = [cj.ZeroSet(3), cj.Nonnegatives(4), cj.SecondOrderCone(5), cj.PsdConeTriangle(10), cj.PsdCone(9), cj.PsdConeTriangle(1)]
+    assert cj.cone_costs(sets) == [0, 0, 5, 64, 27, 0]
