@@ -76,6 +76,7 @@ SIGNATURES = {
     "cosmo_hip_set_params": (C.c_int32, [C.c_void_p, C.POINTER(Params), _PD]),
     "cosmo_hip_update_rho": (C.c_int32, [C.c_void_p, _PD]),
     "cosmo_hip_set_scaling": (C.c_int32, [C.c_void_p, _PD, _PD, C.c_double]),
+    "cosmo_hip_set_scaling_full": (C.c_int32, [C.c_void_p, _PD, _PD, _PD, _PD, C.c_double, C.c_double]),
     "cosmo_hip_update_qb": (C.c_int32, [C.c_void_p, _PD, _PD]),
     "cosmo_hip_get_rho_classes": (C.c_int32, [C.c_void_p, _PI32]),
     "cosmo_hip_get_rho_vec": (C.c_int32, [C.c_void_p, _PD]),
@@ -230,6 +231,10 @@ class Handle:
 
     def set_scaling(self, Dinv, Einv, cinv):
         self._chk(self.lib.cosmo_hip_set_scaling(self._h, _dp(_f64(Dinv, self.n)), _dp(_f64(Einv, self.m)), float(cinv)))
+
+    def set_scaling_full(self, D, Dinv, E, Einv, c, cinv):
+        self._chk(self.lib.cosmo_hip_set_scaling_full(self._h, _dp(_f64(D, self.n)), _dp(_f64(Dinv, self.n)), _dp(_f64(E, self.m)),
+                                                      _dp(_f64(Einv, self.m)), float(c), float(cinv)))
 
     def update_qb(self, q=None, b=None):
         self._chk(self.lib.cosmo_hip_update_qb(self._h, _dp(_f64(q, self.n)), _dp(_f64(b, self.m))))

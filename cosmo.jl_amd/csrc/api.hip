@@ -220,7 +220,8 @@ extern "C" int32_t cosmo_hip_create(cosmo_hip_handle** out, int32_t device_id) {
 }
 
 static void free_vectors(cosmo_hip_handle* h) {
-  dfree(&h->q); dfree(&h->b); dfree(&h->rho); dfree(&h->Dinv); dfree(&h->Einv);
+  dfree(&h->q); dfree(&h->b); dfree(&h->rho); dfree(&h->Dinv); dfree(&h->Einv); dfree(&h->Dscale); dfree(&h->Escale);
+  dfree(&h->inf_dy); dfree(&h->inf_dx); dfree(&h->inf_adx); dfree(&h->inf_flags);
   dfree(&h->w); dfree(&h->w_prev); dfree(&h->s); dfree(&h->mu); dfree(&h->s_tl);
   dfree(&h->ls_x); dfree(&h->ls_s); dfree(&h->x_tl); dfree(&h->nu);
   dfree(&h->rhs); dfree(&h->r); dfree(&h->u); dfree(&h->c); dfree(&h->tmp_m); dfree(&h->y2); dfree(&h->mr);
@@ -293,7 +294,10 @@ extern "C" int32_t cosmo_hip_set_problem(cosmo_hip_handle* h, int64_t n, int64_t
   free_vectors(h);
   const size_t N = (size_t)(n + m);
   CHK(dalloc(h, &h->q, (size_t)n)); CHK(dalloc(h, &h->b, (size_t)m)); CHK(dalloc(h, &h->rho, (size_t)m));
-  CHK(dalloc(h, &h->Dinv, (size_t)n)); CHK(dalloc(h, &h->Einv, (size_t)m));
+  CHK(dalloc(h, &h->Dinv, (size_t)n)); CHK(dalloc(h, &h->Einv, (size_t)m)); CHK(dalloc(h, &h->Dscale, (size_t)n)); CHK(dalloc(h, &h->Escale, (size_t)m));
+  { std::vector<double> ones((size_t)std::max<int64_t>(n, m), 1.0);
+    CHK(h2d(h, h->Dinv, ones.data(), (size_t)n)); CHK(h2d(h, h->Einv, ones.data(), (size_t)m));
+    CHK(h2d(h, h->Dscale, ones.data(), (size_t)n)); CHK(h2d(h, h->Escale, ones.data(), (size_t)m)); }
   CHK(dalloc(h, &h->w, N)); CHK(dalloc(h, &h->w_prev, N)); CHK(dalloc(h, &h->s, (size_t)m)); CHK(dalloc(h, &h->mu, (size_t)m));
   CHK(dalloc(h, &h->s_tl, (size_t)m)); CHK(dalloc(h, &h->ls_x, (size_t)n)); CHK(dalloc(h, &h->ls_s, (size_t)m));
   CHK(dalloc(h, &h->x_tl, (size_t)n)); CHK(dalloc(h, &h->nu, (size_t)m)); CHK(dalloc(h, &h->rhs, (size_t)n));
@@ -450,17 +454,32 @@ extern "C" int32_t cosmo_hip_update_rho(cosmo_hip_handle* h, const double* rho_v
   return h2d(h, h->rho, rho_vec, (size_t)h->m);
 }
 
-extern "C" int32_t cosmo_hip_set_scaling(cosmo_hip_handle* h, const double* Dinv, const double* Einv, double cinv) {
+static int32_t upload_or_ones(cosmo_hip_handle* h, double* dst, const double* src, size_t n) {
+  if (src) return h2d(h, dst, src, n);
+  std::vector<double> ones(n, 1.0);
+  return h2d(h, dst, ones.data(), n);
+}
+
+extern "C" int32_t cosmo_hip_set_scaling_full(cosmo_hip_handle* h, const double* D, const double* Dinv, const double* E, const double* Einv,
+                                              double c, double cinv) {
   ENTER(h);
   if (!h->have_problem) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_problem first");
-  std::vector<double> ones;
-  if (!Dinv) { ones.assign((size_t)h->n, 1.0); CHK(h2d(h, h->Dinv, ones.data(), (size_t)h->n)); }
-  else CHK(h2d(h, h->Dinv, Dinv, (size_t)h->n));
-  if (!Einv) { ones.assign((size_t)h->m, 1.0); CHK(h2d(h, h->Einv, ones.data(), (size_t)h->m)); }
-  else CHK(h2d(h, h->Einv, Einv, (size_t)h->m));
+  CHK(upload_or_ones(h, h->Dinv, Dinv, (size_t)h->n)); CHK(upload_or_ones(h, h->Einv, Einv, (size_t)h->m));
+  CHK(upload_or_ones(h, h->Dscale, D, (size_t)h->n)); CHK(upload_or_ones(h, h->Escale, E, (size_t)h->m));
+  (void)c;
   h->cinv = cinv;
   h->has_scaling = true;
   return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_set_scaling(cosmo_hip_handle* h, const double* Dinv, const double* Einv, double cinv) {
+  ENTER(h);
+  if (!h->have_problem) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_problem first");
+  // D and E (needed by the infeasibility tests only) are recovered as reciprocals
+  std::vector<double> D, E;
+  if (Dinv) { D.resize((size_t)h->n); for (long long i = 0; i < h->n; ++i) D[i] = 1.0 / Dinv[i]; }
+  if (Einv) { E.resize((size_t)h->m); for (long long i = 0; i < h->m; ++i) E[i] = 1.0 / Einv[i]; }
+  return cosmo_hip_set_scaling_full(h, Dinv ? D.data() : nullptr, Dinv, Einv ? E.data() : nullptr, Einv, 1.0 / cinv, cinv);
 }
 
 extern "C" int32_t cosmo_hip_update_qb(cosmo_hip_handle* h, const double* q, const double* b) {
@@ -556,6 +575,20 @@ static void adapt_budget(cosmo_hip_handle* h) {
 }
 
 __global__ void k_ctl_reset_kmax(Ctl* ctl) { ctl->cg_k_max = 0; }
+__global__ void k_ctl_set_status(Ctl* ctl, int st) { ctl->status = st; ctl->halt = 1; }
+static bool inf_due(const cosmo_hip_handle* h, long long it);
+
+// after run_until reached an iteration with a pending infeasibility test: run it, publish a decided status
+static int32_t maybe_infeas_check(cosmo_hip_handle* h, long long it) {
+  if (h->ctl_host->status != 0 || !inf_due(h, it)) return COSMO_HIP_OK;
+  int32_t st = 0;
+  CHK(infeas_check(h, &st));
+  if (st != 0) {
+    hipLaunchKernelGGL(k_ctl_set_status, dim3(1), dim3(1), 0, h->stream, h->ctl, st);
+    CHK(sync_ctl(h));
+  }
+  return COSMO_HIP_OK;
+}
 
 extern "C" int32_t cosmo_hip_kkt_solve(cosmo_hip_handle* h, double* lhs, const double* rhs, int64_t* kkt_iters_out) {
   ENTER(h);
@@ -633,9 +666,22 @@ static int32_t enqueue_solve_in_loop(cosmo_hip_handle* h) {
 }
 
 // One loop body (solver.jl:151-155) for iteration number `it` (1-based), enqueued without synchronisation.
+// infeasibility schedule (solver.jl:326-349): the flag is set when it % check_infeasibility == 0 and consumed by the NEXT
+// iteration: delta_y is captured at its top (:145-148) and the certificates are tested at its end.
+static bool inf_due(const cosmo_hip_handle* h, long long it) {
+  const long long ci = h->prm.check_infeasibility;
+  if (ci <= 0 || ci > (1LL << 40) || h->comm) return false;   // sharded runs: membership tests would need the full cone tables
+  return it > 1 && ((it - 1) % ci) == 0 && (it % ci) != 0;
+}
+static long long next_inf_iter(const cosmo_hip_handle* h, long long it) {   // smallest it' > it with inf_due(it'), or a huge value
+  const long long ci = h->prm.check_infeasibility;
+  if (ci <= 1 || ci > (1LL << 40) || h->comm) return INT64_MAX;
+  const long long k = (it <= 0) ? 1 : (it - 1) / ci + 1;   // it' = k ci + 1 with k >= 1 and it' > it
+  return k * ci + 1;
+}
+
 static int32_t enqueue_iteration(cosmo_hip_handle* h, long long it) {
-  const bool time_proj = h->profiling;
-  (void)time_proj;
+  if (inf_due(h, it)) CHK(infeas_enqueue_capture(h));
   CHK(launch_z(h, 1));
   CHK(launch_soc(h, h->s, 1));
   CHK(psd_enqueue_project(h, h->s, true));
@@ -733,9 +779,11 @@ extern "C" int32_t cosmo_hip_admm_iterate_checked(cosmo_hip_handle* h, int64_t n
   while (h->host_iter < target) {
     const long long it = h->host_iter;
     long long next = (it == 0) ? 1 : ((it / ct) + 1) * ct;
-    bool check = true;
-    if (next > target) { next = target; check = (next % ct == 0) || next == 1; }
+    next = std::min(next, next_inf_iter(h, it));
+    if (next > target) next = target;
+    const bool check = (next % ct == 0) || next == 1;
     CHK(run_until(h, next, check ? 1 : -1));
+    CHK(maybe_infeas_check(h, next));
     if (h->ctl_host->status != 0) { if (status_out) *status_out = h->ctl_host->status; break; }
   }
   return COSMO_HIP_OK;
@@ -767,9 +815,11 @@ extern "C" int32_t cosmo_hip_optimize(cosmo_hip_handle* h, cosmo_hip_result* res
   long long it = 0;
   while (it < p.max_iter) {
     long long next = (it == 0) ? 1 : ((it / p.check_termination) + 1) * (long long)p.check_termination;
-    bool check = true;
-    if (next > p.max_iter) { next = p.max_iter; check = (next % p.check_termination == 0) || next == 1; }
+    next = std::min(next, next_inf_iter(h, it));
+    if (next > p.max_iter) next = p.max_iter;
+    const bool check = (next % p.check_termination == 0) || next == 1;
     CHK(run_until(h, next, check ? 1 : -1));
+    CHK(maybe_infeas_check(h, next));
     it = h->ctl_host->iter;
     if (h->ctl_host->status != 0) { status = h->ctl_host->status; break; }
     it = next;
@@ -797,7 +847,7 @@ extern "C" int32_t cosmo_hip_optimize(cosmo_hip_handle* h, cosmo_hip_result* res
   res->iter = c->iter;
   res->kkt_iters_total = c->kkt_iters_total;
   res->kkt_solves = c->solves;
-  res->cost = c->cost;
+  res->cost = (status == COSMO_HIP_PRIMAL_INFEASIBLE) ? INFINITY : (status == COSMO_HIP_DUAL_INFEASIBLE) ? -INFINITY : c->cost;   // solver.jl:339,345
   res->r_prim = c->r_prim; res->r_dual = c->r_dual; res->max_norm_prim = c->max_norm_prim; res->max_norm_dual = c->max_norm_dual;
   res->rho = c->rho;
   res->n_rho_updates = c->n_rho_updates;

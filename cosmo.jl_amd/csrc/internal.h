@@ -91,7 +91,9 @@ struct cosmo_hip_handle {
   // matrices
   CsrDev A, AT, P, PT;
   // data vectors
-  double *q = nullptr, *b = nullptr, *rho = nullptr, *Dinv = nullptr, *Einv = nullptr;
+  double *q = nullptr, *b = nullptr, *rho = nullptr, *Dinv = nullptr, *Einv = nullptr, *Dscale = nullptr, *Escale = nullptr;
+  double *inf_dy = nullptr, *inf_dx = nullptr, *inf_adx = nullptr;   // infeasibility work vectors (infeas.hip)
+  int* inf_flags = nullptr;
   double cinv = 1.0;
   bool has_scaling = false;
   // cones
@@ -172,6 +174,9 @@ void psd_plan_destroy(cosmo_hip_handle* h);
 int32_t psd_enqueue_project(cosmo_hip_handle* h, double* s, bool guard);
 int32_t psd_get_ranks(cosmo_hip_handle* h, int64_t* rank_per_cone);
 static inline bool cone_owned(const cosmo_hip_handle* h, long long k) { return h->cone_hi < 0 || (k >= h->cone_lo && k < h->cone_hi); }
+// infeas.hip
+int32_t infeas_enqueue_capture(cosmo_hip_handle* h);
+int32_t infeas_check(cosmo_hip_handle* h, int32_t* status);
 // comm.hip
 int32_t comm_enqueue_exchange(cosmo_hip_handle* h, double* s);
 extern "C" int32_t cosmo_hip_comm_destroy(cosmo_hip_handle* h);

@@ -53,6 +53,7 @@ struct PsdPlan {
   double* cshift = nullptr;            // per cone shift c
   int* rank = nullptr;                 // per cone nnz_lambda
   int* flags = nullptr;                // [0] sweep-rotated flag (large path), [1] error flag
+  double* eigmin = nullptr;            // per cone smallest eigenvalue (definiteness tests)
   long long gsize = 0;
   int ncolw = 0;
   int last_large_sweeps = 0;
@@ -163,7 +164,9 @@ __device__ __forceinline__ long long svec_idx(int i, int j) { return (long long)
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(COSMO_BS) void k_psd_tiny(const Ctl* __restrict__ ctl, int guard, int ncones,
                                                        const int* __restrict__ list, const PsdConeDev* __restrict__ cones,
-                                                       double* __restrict__ s, int* __restrict__ rank, int* __restrict__ flags) {
+                                                       double* __restrict__ s, int* __restrict__ rank, int* __restrict__ flags,
+                                                       int mode, double sign, double* __restrict__ eigmin) {
+  // mode 0: project in place.  mode 1: only the smallest eigenvalue of sign * mat(x) (definiteness tests of infeasibility.jl)
   if (guard && ctl->halt) return;
   __shared__ double Ws[COSMO_BS / 64][16 * WLD];
   __shared__ double Js[COSMO_BS / 64][16 * WLD];
@@ -192,6 +195,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_psd_tiny(const Ctl* __restrict__ c
         v = (x[(long long)b * d + a] + x[(long long)a * d + b]) / 2.0;   // symmetrize_upper! (algebra.jl:201-208)
       }
     }
+    v = v * sign;
     W[i * WLD + j] = v;
     J[i * WLD + j] = (i == j) ? 1.0 : 0.0;
     fro += v * v;
@@ -205,6 +209,12 @@ __global__ __launch_bounds__(COSMO_BS) void k_psd_tiny(const Ctl* __restrict__ c
     ++sweeps;
   }
   if (rot && lane == 0) atomicOr(&flags[1], 1);            // did not converge
+  if (mode == 1) {
+    double lm = W[0];
+    for (int k = 1; k < d; ++k) lm = fmin(lm, W[k * WLD + k]);
+    if (lane == 0) eigmin[list[widx]] = lm;
+    return;
+  }
   // X+ = J max(Lambda,0) J'
   int rk = 0;
   for (int k = 0; k < d; ++k) rk += (W[k * WLD + k] > 0.0) ? 1 : 0;
@@ -233,7 +243,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_psd_tiny(const Ctl* __restrict__ c
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(COSMO_BS) void k_psd_populate(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ list,
                                                            const PsdConeDev* __restrict__ cones, const double* __restrict__ s,
-                                                           double* __restrict__ G, double* __restrict__ cshift) {
+                                                           double* __restrict__ G, double* __restrict__ cshift, double sign) {
   if (guard && ctl->halt) return;
   __shared__ double red[COSMO_BS / 64];
   const int ci = list[blockIdx.y];
@@ -268,6 +278,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_psd_populate(const Ctl* __restrict
         } else {
           v = (x[(long long)b * d + a] + x[(long long)a * d + b]) / 2.0;
         }
+        v = v * sign;
         if (i == j) v += c;
       }
       g[(long long)j * cn.ld + i] = v;
@@ -514,6 +525,27 @@ __global__ __launch_bounds__(COSMO_BS) void k_psd_colscale(const Ctl* __restrict
   if (lane == 0 && mycnt) atomicAdd(&rank[ci], mycnt);    // integer count: order independent
 }
 
+// smallest eigenvalue of every cone of the list: min_k (||g_k|| - c) over the real columns (one workgroup per cone)
+__global__ __launch_bounds__(COSMO_BS) void k_psd_eigmin(const int* __restrict__ list, const PsdConeDev* __restrict__ cones,
+                                                         const double* __restrict__ G, const double* __restrict__ cshift,
+                                                         double* __restrict__ eigmin) {
+  __shared__ double red[COSMO_BS / 64];
+  const int ci = list[blockIdx.x];
+  const PsdConeDev cn = cones[ci];
+  const double* g = G + cn.goff;
+  const double c = cshift[ci];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double lm = INFINITY;
+  for (int j = wv; j < cn.d; j += COSMO_BS / 64) {
+    const double* col = g + (long long)j * cn.ld;
+    double a = 0.0;
+    for (int i = lane; i < cn.ld; i += 64) { const double v = col[i]; a += v * v; }
+    lm = fmin(lm, sqrt(wave_sum(a)) - c);
+  }
+  lm = -block_max(-lm, red);
+  if (threadIdx.x == 0) eigmin[ci] = lm;
+}
+
 // X+ = Ghat Ghat' (upper tiles) on MFMA, written straight into s.  grid = (ntiles_max, ncones); one wave per 16x16 tile.
 __global__ __launch_bounds__(COSMO_BS) void k_psd_syrk(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ list,
                                                        const PsdConeDev* __restrict__ cones, const double* __restrict__ G,
@@ -581,6 +613,7 @@ void psd_plan_destroy(cosmo_hip_handle* h) {
   if (p->cshift) (void)hipFree(p->cshift);
   if (p->rank) (void)hipFree(p->rank);
   if (p->flags) (void)hipFree(p->flags);
+  if (p->eigmin) (void)hipFree(p->eigmin);
   delete p;
   h->psd = nullptr;
 }
@@ -651,8 +684,28 @@ int32_t psd_plan_create(cosmo_hip_handle* h) {
   HIPCHK(h, hipMalloc((void**)&p->cshift, p->cones.size() * sizeof(double)));
   HIPCHK(h, hipMalloc((void**)&p->rank, p->cones.size() * sizeof(int)));
   HIPCHK(h, hipMalloc((void**)&p->flags, 4 * sizeof(int)));
+  HIPCHK(h, hipMalloc((void**)&p->eigmin, p->cones.size() * sizeof(double)));
   HIPCHK(h, hipMemset(p->rank, 0, p->cones.size() * sizeof(int)));
   HIPCHK(h, hipMemset(p->flags, 0, 4 * sizeof(int)));
+  return COSMO_HIP_OK;
+}
+
+// host-paced Jacobi sweeps of the multi-workgroup path (one launch per tournament step, flag read once per sweep)
+static int32_t psd_large_sweeps(cosmo_hip_handle* h, int n, int nbmax) {
+  PsdPlan* p = h->psd;
+  int sweep = 0;
+  for (; sweep < PSD_MAX_SWEEPS; ++sweep) {
+    HIPCHK(h, hipMemsetAsync(p->flags, 0, sizeof(int), h->stream));
+    for (int st = -1; st < nbmax - 1; ++st)
+      hipLaunchKernelGGL(k_psd_step, dim3(nbmax / 2, n), dim3(PSD_STEP_WAVES * 64), 0, h->stream, p->d_large, p->d_cones, p->G,
+                         p->cshift, st, p->flags, p->tol_factor);
+    int fl = 0;
+    HIPCHK(h, hipMemcpyAsync(&fl, p->flags, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!fl) break;
+  }
+  p->last_large_sweeps = sweep + 1;
+  if (sweep >= PSD_MAX_SWEEPS) return cosmo_fail(h, COSMO_HIP_ERR_EIG, "Jacobi eigensolver did not converge in %d sweeps", PSD_MAX_SWEEPS);
   return COSMO_HIP_OK;
 }
 
@@ -667,12 +720,12 @@ int32_t psd_enqueue_project(cosmo_hip_handle* h, double* s, bool guard_b) {
   if (!p->tiny.empty()) {
     const int n = (int)p->tiny.size();
     hipLaunchKernelGGL(k_psd_tiny, dim3((n + COSMO_BS / 64 - 1) / (COSMO_BS / 64)), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, n,
-                       p->d_tiny, p->d_cones, s, p->rank, p->flags);
+                       p->d_tiny, p->d_cones, s, p->rank, p->flags, 0, 1.0, p->eigmin);
   }
   for (size_t gi = 0; gi < p->wg_groups.size(); ++gi) {
     const int n = (int)p->wg_groups[gi].size();
     const int* lst = p->d_wg_groups[gi];
-    hipLaunchKernelGGL(k_psd_populate, dim3(8, n), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, lst, p->d_cones, s, p->G, p->cshift);
+    hipLaunchKernelGGL(k_psd_populate, dim3(8, n), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, lst, p->d_cones, s, p->G, p->cshift, 1.0);
     switch (p->wg_waves[gi]) {
       case 16: hipLaunchKernelGGL((k_psd_jacobi_wg<16>), dim3(n), dim3(1024), 0, h->stream, h->ctl, guard, lst, p->d_cones, p->G, p->cshift, p->flags, p->tol_factor, p->dbg); break;
       default: hipLaunchKernelGGL((k_psd_jacobi_wg<4>), dim3(n), dim3(256), 0, h->stream, h->ctl, guard, lst, p->d_cones, p->G, p->cshift, p->flags, p->tol_factor, p->dbg); break;
@@ -691,20 +744,8 @@ int32_t psd_enqueue_project(cosmo_hip_handle* h, double* s, bool guard_b) {
     const int n = (int)p->large.size();
     int nbmax = 0;
     for (int idx : p->large) nbmax = std::max(nbmax, p->cones[idx].nb);
-    hipLaunchKernelGGL(k_psd_populate, dim3(64, n), dim3(COSMO_BS), 0, h->stream, h->ctl, 0, p->d_large, p->d_cones, s, p->G, p->cshift);
-    int sweep = 0;
-    for (; sweep < PSD_MAX_SWEEPS; ++sweep) {
-      HIPCHK(h, hipMemsetAsync(p->flags, 0, sizeof(int), h->stream));
-      for (int st = -1; st < nbmax - 1; ++st)
-        hipLaunchKernelGGL(k_psd_step, dim3(nbmax / 2, n), dim3(PSD_STEP_WAVES * 64), 0, h->stream, p->d_large, p->d_cones, p->G,
-                           p->cshift, st, p->flags, p->tol_factor);
-      int fl = 0;
-      HIPCHK(h, hipMemcpyAsync(&fl, p->flags, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-      HIPCHK(h, hipStreamSynchronize(h->stream));
-      if (!fl) break;
-    }
-    p->last_large_sweeps = sweep + 1;
-    if (sweep >= PSD_MAX_SWEEPS) return cosmo_fail(h, COSMO_HIP_ERR_EIG, "Jacobi eigensolver did not converge in %d sweeps", PSD_MAX_SWEEPS);
+    hipLaunchKernelGGL(k_psd_populate, dim3(64, n), dim3(COSMO_BS), 0, h->stream, h->ctl, 0, p->d_large, p->d_cones, s, p->G, p->cshift, 1.0);
+    CHK(psd_large_sweeps(h, n, nbmax));
     hipLaunchKernelGGL(k_psd_colscale, dim3(128, n), dim3(COSMO_BS), 0, h->stream, h->ctl, 0, p->d_large, p->d_cones, p->G, p->cshift, p->colw, p->rank);
     int maxtiles = 1;
     for (int idx : p->large) { const int nt = p->cones[idx].ld / 16; maxtiles = std::max(maxtiles, nt * (nt + 1) / 2); }
@@ -738,5 +779,42 @@ extern "C" int32_t cosmo_hip_psd_stats(cosmo_hip_handle* h, int64_t out[4]) {
   HIPCHK(h, hipMemcpyAsync(fl, p->flags, sizeof fl, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   out[0] = fl[2]; out[1] = p->last_large_sweeps; out[2] = fl[1]; out[3] = (int64_t)p->cones.size();
+  return COSMO_HIP_OK;
+}
+
+// Smallest eigenvalue of sign * mat(vec slice) for every planned PSD cone (same row layout as s).  Used by the
+// infeasibility certificates: is_pos_def!(X, tol) <=> lambda_min(X) > -tol (src/algebra.jl:226-238).  Synchronous.
+int32_t psd_extreme_eigs(cosmo_hip_handle* h, const double* vec, double sign, std::vector<double>& lam_min) {
+  PsdPlan* p = h->psd;
+  lam_min.clear();
+  if (!p || p->cones.empty()) return COSMO_HIP_OK;
+  double* v = const_cast<double*>(vec);   // mode 1 / populate only read it
+  if (!p->tiny.empty()) {
+    const int n = (int)p->tiny.size();
+    hipLaunchKernelGGL(k_psd_tiny, dim3((n + COSMO_BS / 64 - 1) / (COSMO_BS / 64)), dim3(COSMO_BS), 0, h->stream, h->ctl, 0, n, p->d_tiny,
+                       p->d_cones, v, p->rank, p->flags, 1, sign, p->eigmin);
+  }
+  for (size_t gi = 0; gi < p->wg_groups.size(); ++gi) {
+    const int n = (int)p->wg_groups[gi].size();
+    const int* lst = p->d_wg_groups[gi];
+    hipLaunchKernelGGL(k_psd_populate, dim3(8, n), dim3(COSMO_BS), 0, h->stream, h->ctl, 0, lst, p->d_cones, vec, p->G, p->cshift, sign);
+    if (p->wg_waves[gi] == 16)
+      hipLaunchKernelGGL((k_psd_jacobi_wg<16>), dim3(n), dim3(1024), 0, h->stream, h->ctl, 0, lst, p->d_cones, p->G, p->cshift, p->flags, p->tol_factor, 0);
+    else
+      hipLaunchKernelGGL((k_psd_jacobi_wg<4>), dim3(n), dim3(256), 0, h->stream, h->ctl, 0, lst, p->d_cones, p->G, p->cshift, p->flags, p->tol_factor, 0);
+    hipLaunchKernelGGL(k_psd_eigmin, dim3(n), dim3(COSMO_BS), 0, h->stream, lst, p->d_cones, p->G, p->cshift, p->eigmin);
+  }
+  if (!p->large.empty()) {
+    const int n = (int)p->large.size();
+    int nbmax = 0;
+    for (int idx : p->large) nbmax = std::max(nbmax, p->cones[idx].nb);
+    hipLaunchKernelGGL(k_psd_populate, dim3(64, n), dim3(COSMO_BS), 0, h->stream, h->ctl, 0, p->d_large, p->d_cones, vec, p->G, p->cshift, sign);
+    CHK(psd_large_sweeps(h, n, nbmax));
+    hipLaunchKernelGGL(k_psd_eigmin, dim3(n), dim3(COSMO_BS), 0, h->stream, p->d_large, p->d_cones, p->G, p->cshift, p->eigmin);
+  }
+  HIPCHK(h, hipGetLastError());
+  lam_min.resize(p->cones.size());
+  HIPCHK(h, hipMemcpyAsync(lam_min.data(), p->eigmin, sizeof(double) * lam_min.size(), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   return COSMO_HIP_OK;
 }

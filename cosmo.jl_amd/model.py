@@ -428,7 +428,7 @@ def setup(model: Model):
         bu = np.concatenate([K.u for K in model.sets if K.kind == _ffi.BOX] or [np.zeros(0)])
         h.set_cones([K.kind for K in model.sets], [K.dim for K in model.sets], bl, bu)
         h.set_params(_params_from_settings(h, st))                 # set_rho_vec! happens inside (first solve only)
-        h.set_scaling(sm.Dinv, sm.Einv, sm.cinv)
+        h.set_scaling_full(sm.D, sm.Dinv, sm.E, sm.Einv, sm.c, sm.cinv)
         model.handle = h
 
 

@@ -1,2 +1,3 @@
 mkdir -p gpurun_out
-(timeout 600 python -m pytest tests/test_gpu_sharding.py -m gpu -q -x 2>&1 | tail -30) > gpurun_out/t10.log; cat gpurun_out/t10.log
+(timeout 1000 python -m pytest tests -m gpu -q 2>&1 | tail -15) > gpurun_out/t12.log; cat gpurun_out/t12.log
+timeout 100 python __graft_entry__.py smoke 2>&1 | tail -1

@@ -147,6 +147,10 @@ int32_t cosmo_hip_update_rho(cosmo_hip_handle* h, const double* rho_vec);
 /* ScaleMatrices Dinv (n), Einv (m), cinv used ONLY to unscale residuals (src/residuals.jl:43-49,66-92).
  * NULL pointers mean identity. */
 int32_t cosmo_hip_set_scaling(cosmo_hip_handle* h, const double* Dinv, const double* Einv, double cinv);
+/* Same plus D (n), E (m), c themselves, which the infeasibility certificates scale with (src/infeasibility.jl:5,35,39);
+ * cosmo_hip_set_scaling derives them as reciprocals.  NULL = identity. */
+int32_t cosmo_hip_set_scaling_full(cosmo_hip_handle* h, const double* D, const double* Dinv, const double* E, const double* Einv,
+                                   double c, double cinv);
 /* Replaces COSMO.update!(model; q, b) on already-scaled vectors (src/interface.jl:187-211). NULL = keep. */
 int32_t cosmo_hip_update_qb(cosmo_hip_handle* h, const double* q, const double* b);
 /* Per-row rho class computed by the library: 0 = rho, 1 = rho*RHO_EQ_OVER_RHO_INEQ, 2 = RHO_MIN

@@ -55,7 +55,7 @@ def make_handle_from_workspace(ws: O.Workspace, kkt_kind=cj._ffi.KKT_CG, **param
     for k, v in param_overrides.items():
         setattr(p, k, v)
     h.set_params(p)
-    h.set_scaling(ws.sm.Dinv, ws.sm.Einv, ws.sm.cinv)
+    h.set_scaling_full(ws.sm.D, ws.sm.Dinv, ws.sm.E, ws.sm.Einv, ws.sm.c, ws.sm.cinv)
     return h
 
 
