@@ -142,6 +142,47 @@ __global__ __launch_bounds__(BS) void k_stream_sorted(const int* __restrict__ rp
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// V5: CSR-stream, NT tiles per workgroup, software pipelined: the (col,val) loads and x gathers of tile i+1 are issued
+// before tile i is reduced from LDS (register double buffering), so the memory pipe never idles during phase 2.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int BS, int T, int NT>
+__global__ __launch_bounds__(BS) void k_stream_pipe(const int* __restrict__ rp, const int* __restrict__ col, const double* __restrict__ val,
+                                                    const int* __restrict__ rb, int nb, const double* __restrict__ x, double* __restrict__ y) {
+  __shared__ double lds[T];
+  constexpr int E = T / BS;
+  const int k0 = blockIdx.x * NT;
+  double pr[E];
+  int cnt_next = 0, nz0_next = 0;
+  auto fetch = [&](int k) {   // products of tile k into registers
+    const int r0 = rb[k], r1 = rb[k + 1];
+    nz0_next = rp[r0]; cnt_next = rp[r1] - nz0_next;
+#pragma unroll
+    for (int it = 0; it < E; ++it) {
+      const int i = it * BS + threadIdx.x;
+      pr[it] = (i < cnt_next) ? val[nz0_next + i] * x[col[nz0_next + i]] : 0.0;
+    }
+  };
+  if (k0 < nb) fetch(k0);
+  for (int t = 0; t < NT; ++t) {
+    const int k = k0 + t;
+    if (k >= nb) break;
+    const int r0 = rb[k], r1 = rb[k + 1];
+    const int nz0 = nz0_next, cnt = cnt_next;
+#pragma unroll
+    for (int it = 0; it < E; ++it) { const int i = it * BS + threadIdx.x; if (i < cnt) lds[i] = pr[it]; }
+    __syncthreads();
+    if (t + 1 < NT && k + 1 < nb) fetch(k + 1);          // loads of the next tile fly while this tile is reduced
+    for (int r = r0 + threadIdx.x; r < r1; r += BS) {
+      const int a = rp[r] - nz0, b = rp[r + 1] - nz0;
+      double s = 0.0;
+      for (int j = a; j < b; ++j) s += lds[j];
+      y[r] = s;
+    }
+    __syncthreads();
+  }
+}
+
 // ---- diagnostics: isolate streaming, gathering and launch costs ----------------------------------------------------
 __global__ void k_empty() {}
 template <int MODE>   // 0: stream val,col only   1: + coalesced x   2: + random gather restricted to 4096 entries   3: full gather
@@ -317,6 +358,24 @@ static void run_matrix(const char* label, int nr, int nc, long long nnz, unsigne
   SORTED(512, 8192)
   SORTED(1024, 8192)
   SORTED(1024, 16384)
+#define PIPE(BS, T, NT)                                                                                                \
+  {                                                                                                                    \
+    build_rb(M, T, 4 * BS, rb); d.nb = (int)rb.size() - 1;                                                             \
+    CK(hipMemcpy(d.rb, rb.data(), sizeof(int) * rb.size(), hipMemcpyHostToDevice));                                    \
+    int grid = (d.nb + NT - 1) / NT;                                                                                   \
+    CK(hipMemset(d.y, 0, sizeof(double) * nr));                                                                        \
+    double us = time_it([&] { hipLaunchKernelGGL((k_stream_pipe<BS, T, NT>), dim3(grid), dim3(BS), 0, 0, d.rp, d.col, d.val, d.rb, d.nb, d.x, d.y); }, R); \
+    char nm[96]; snprintf(nm, 96, "PIPE BS=%d T=%d NT=%d grid=%d", BS, T, NT, grid); check(nm, M, x, d.y, us, bytes);  \
+  }
+  PIPE(256, 2048, 2)
+  PIPE(256, 2048, 4)
+  PIPE(256, 1024, 2)
+  PIPE(256, 1024, 4)
+  PIPE(256, 1024, 8)
+  PIPE(256, 512, 4)
+  PIPE(256, 512, 8)
+  PIPE(512, 2048, 2)
+  PIPE(512, 2048, 4)
 #define STREAMG(BS, T, G)                                                                                              \
   {                                                                                                                    \
     build_rb(M, T, 4 * BS, rb); d.nb = (int)rb.size() - 1;                                                             \

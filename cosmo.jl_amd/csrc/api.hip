@@ -129,9 +129,11 @@ int32_t upload_csr(cosmo_hip_handle* h, const HostCsr& M, CsrDev& D, int split_c
   free_csr(D);
   D.nrows = M.nrows; D.ncols = M.ncols; D.nnz = (long long)M.val.size();
   D.split_col = split_col;
-  std::vector<int> rb;
-  build_row_blocks(M.rowptr, M.nrows, rb);
-  D.nb = (int)rb.size() - 1;
+  std::vector<int> rbnd, rb;
+  build_row_blocks(M.rowptr, M.nrows, rbnd);
+  D.nb = (int)rbnd.size() - 1;
+  rb.resize((size_t)4 * std::max(D.nb, 1), 0);           // {r0, r1, nz0, nz1} per tile (16-byte aligned descriptors)
+  for (int k = 0; k < D.nb; ++k) { rb[4 * k] = rbnd[k]; rb[4 * k + 1] = rbnd[k + 1]; rb[4 * k + 2] = M.rowptr[rbnd[k]]; rb[4 * k + 3] = M.rowptr[rbnd[k + 1]]; }
   D.grid = std::max(1, std::min(D.nb, COSMO_MAX_PARTIALS));
   CHK(dalloc(h, &D.rowptr, (size_t)M.nrows + 1));
   CHK(dalloc(h, &D.col, M.col.size()));

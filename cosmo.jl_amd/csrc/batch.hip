@@ -95,15 +95,15 @@ __global__ __launch_bounds__(COSMO_BS) void k_batch_admm(BatchDev D, BParams P, 
     __syncthreads();
     double acc = 0.0;
     for (int t = 0; t < AT.nb; ++t)
-      csr_stream_block(AT, y2, y2, AT.rb[t], AT.rb[t + 1], lds, red, [&](int row, double s1, double s2) {
+      csr_stream_tile(AT, y2, y2, t, lds, red, [&](int row, double s1, double s2) {
         const double v = (s1 + s2) + ls_x[row]; rhs[row] = v; acc += v * v; });
     const double bb = block_sum(acc, red);
     for (int t = 0; t < A.nb; ++t)
-      csr_stream_block(A, x_tl, x_tl, A.rb[t], A.rb[t + 1], lds, red, [&](int row, double s1, double s2) { tmp_m[row] = (s1 + s2) * rho[row]; });
+      csr_stream_tile(A, x_tl, x_tl, t, lds, red, [&](int row, double s1, double s2) { tmp_m[row] = (s1 + s2) * rho[row]; });
     __syncthreads();
     acc = 0.0;
     for (int t = 0; t < PT.nb; ++t)
-      csr_stream_block(PT, x_tl, tmp_m, PT.rb[t], PT.rb[t + 1], lds, red, [&](int row, double s1, double s2) {
+      csr_stream_tile(PT, x_tl, tmp_m, t, lds, red, [&](int row, double s1, double s2) {
         const double cj = s1 + (P.sigma * x_tl[row] + s2); const double rj = rhs[row] - cj; r[row] = rj; acc += rj * rj; });
     double rr = block_sum(acc, red);
     const long long ks = ctl->solves;                                    // iteration_counter - 1
@@ -116,11 +116,11 @@ __global__ __launch_bounds__(COSMO_BS) void k_batch_admm(BatchDev D, BParams P, 
       for (int i = tid; i < n; i += COSMO_BS) u[i] = r[i] + beta * ((kk == 0) ? 0.0 : u[i]);
       __syncthreads();
       for (int t = 0; t < A.nb; ++t)
-        csr_stream_block(A, u, u, A.rb[t], A.rb[t + 1], lds, red, [&](int row, double s1, double s2) { tmp_m[row] = (s1 + s2) * rho[row]; });
+        csr_stream_tile(A, u, u, t, lds, red, [&](int row, double s1, double s2) { tmp_m[row] = (s1 + s2) * rho[row]; });
       __syncthreads();
       acc = 0.0;
       for (int t = 0; t < PT.nb; ++t)
-        csr_stream_block(PT, u, tmp_m, PT.rb[t], PT.rb[t + 1], lds, red, [&](int row, double s1, double s2) {
+        csr_stream_tile(PT, u, tmp_m, t, lds, red, [&](int row, double s1, double s2) {
           const double vj = u[row]; const double cj = s1 + (P.sigma * vj + s2); c[row] = cj; acc += vj * cj; });
       const double uc = block_sum(acc, red);
       const double a = (res * res) / uc;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_batch_admm(BatchDev D, BParams P, 
     __syncthreads();
     // nu = rho (A x_tl - ls_s) ; s_tl ; w update
     for (int t = 0; t < A.nb; ++t)
-      csr_stream_block(A, x_tl, x_tl, A.rb[t], A.rb[t + 1], lds, red, [&](int row, double s1, double s2) {
+      csr_stream_tile(A, x_tl, x_tl, t, lds, red, [&](int row, double s1, double s2) {
         const double rh = rho[row]; const double nv = ((s1 + s2) - ls_s[row]) * rh; nu[row] = nv;
         const double sv = s[row], wv = w[n + row]; const double st = (2.0 * sv - wv) - nv / rh; s_tl[row] = st;
         w[n + row] = wv + P.alpha * (st - sv); });
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_batch_admm(BatchDev D, BParams P, 
   auto residuals = [&](bool unscale) {
     double a_rp = 0.0, a_mp = 0.0;
     for (int t = 0; t < A.nb; ++t)
-      csr_stream_block(A, w_prev, w_prev, A.rb[t], A.rb[t + 1], lds, red, [&](int row, double s1, double s2) {
+      csr_stream_tile(A, w_prev, w_prev, t, lds, red, [&](int row, double s1, double s2) {
         const double ax = s1 + s2, sv = s[row], bv = b[row];
         mu[row] = rho[row] * (w_prev[n + row] - sv);
         double rv = ax + sv; rv = rv - bv;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_batch_admm(BatchDev D, BParams P, 
     __syncthreads();
     double a_rd = 0.0, a_md = 0.0, xpx = 0.0, qx = 0.0;
     for (int t = 0; t < PT.nb; ++t)
-      csr_stream_block(PT, w_prev, mu, PT.rb[t], PT.rb[t + 1], lds, red, [&](int row, double px, double atm) {
+      csr_stream_tile(PT, w_prev, mu, t, lds, red, [&](int row, double px, double atm) {
         const double xv = w_prev[row], qv = q[row];
         double rv = px + qv; rv = rv - atm;
         double a = px, bq = qv, cm = atm;
@@ -446,7 +446,7 @@ static int32_t bmat_upload(cosmo_hip_batch* b, std::vector<HostCsr>& Ms, BMat& o
     if (has_split) split.insert(split.end(), M.split.begin(), M.split.end());
     std::vector<int> r; brow_blocks(M.rowptr, nrows, r);
     rb_off.push_back((int)rb.size()); nb.push_back((int)r.size() - 1);
-    rb.insert(rb.end(), r.begin(), r.end());
+    for (size_t t = 0; t + 1 < r.size(); ++t) { rb.push_back(r[t]); rb.push_back(r[t + 1]); rb.push_back(M.rowptr[r[t]]); rb.push_back(M.rowptr[r[t + 1]]); }
     M = HostCsr();
   }
   out.nrows = nrows; out.split_col = split_col;

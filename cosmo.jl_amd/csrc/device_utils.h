@@ -12,7 +12,7 @@ struct CsrView {
   const int* col;
   const double* val;
   const int* split;  // may be null
-  const int* rb;
+  const int* rb;     // 4 ints per tile: {r0, r1, nz0, nz1}
   int nb;
   int nrows;
   int split_col;     // columns >= split_col gather from x2[col - split_col]
@@ -65,6 +65,12 @@ __device__ __forceinline__ double reduce_partials_sum(const double* p, int count
   for (int i = threadIdx.x; i < count; i += COSMO_BS) a += p[i];
   return block_sum(a, red);
 }
+// two-step form: issue the loads first (before any guard that waits on a scalar load), fold later
+__device__ __forceinline__ double partials_prefetch_sum(const double* p, int count) {
+  double a = 0.0;
+  for (int i = threadIdx.x; i < count; i += COSMO_BS) a += p[i];
+  return a;
+}
 __device__ __forceinline__ double reduce_partials_max(const double* p, int count, double* red) {
   double a = 0.0;
   for (int i = threadIdx.x; i < count; i += COSMO_BS) { double t = p[i]; a = (t > a || t != t) ? t : a; }
@@ -83,11 +89,9 @@ __device__ __forceinline__ double amax(double acc, double v) {
 // row sums are bit-identical to the serial CPU loop.  Rows longer than the LDS tile take the chunked path.
 // fn(row, sum1, sum2): sum1 over [rowptr[row], split[row]) and sum2 over [split[row], rowptr[row+1]).
 template <class RowFn>
-__device__ __forceinline__ void csr_stream_block(const CsrView& M, const double* __restrict__ x1,
-                                                 const double* __restrict__ x2, int r0, int r1, double* lds,
-                                                 double* red, RowFn fn) {
-  const int nz0 = M.rowptr[r0];
-  const int nz1 = M.rowptr[r1];
+__device__ __forceinline__ void csr_stream_rows(const CsrView& M, const double* __restrict__ x1,
+                                                const double* __restrict__ x2, int r0, int r1, int nz0, int nz1, double* lds,
+                                                double* red, RowFn fn) {
   const int cnt = nz1 - nz0;
   if (cnt <= COSMO_NNZ_PER_BLOCK) {
 #pragma unroll
@@ -127,4 +131,14 @@ __device__ __forceinline__ void csr_stream_block(const CsrView& M, const double*
     if (threadIdx.x == 0) fn(r, s1, s2);
     __syncthreads();
   }
+}
+
+// Tile k of the CSR-stream schedule.  M.rb holds one 16-byte descriptor {first row, end row, first nonzero, end nonzero}
+// per tile, so a workgroup needs ONE dependent load (instead of rb[k], rb[k+1], rowptr[r0], rowptr[r1]) before it can
+// start streaming -- the ramp-up of these 10-20 us kernels is a chain of dependent memory round trips.
+template <class RowFn>
+__device__ __forceinline__ void csr_stream_tile(const CsrView& M, const double* __restrict__ x1, const double* __restrict__ x2,
+                                                int k, double* lds, double* red, RowFn fn) {
+  const int4 d = reinterpret_cast<const int4*>(M.rb)[k];
+  csr_stream_rows(M, x1, x2, d.x, d.y, d.z, d.w, lds, red, fn);
 }

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_inf_op(const Ctl* __restrict__ ctl
   __shared__ double red[COSMO_BS / 64];
   double a = 0.0, b = 0.0;
   for (int k = blockIdx.x; k < PT.nb; k += gridDim.x)
-    csr_stream_block(PT, dx, dy, PT.rb[k], PT.rb[k + 1], lds, red, [&](int row, double px, double aty) {
+    csr_stream_tile(PT, dx, dy, k, lds, red, [&](int row, double px, double aty) {
       const double d = Dinv[row];
       a = amax(a, px * d);
       b = amax(b, aty * d);
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_inf_adx(CsrView A, const double* _
   __shared__ double lds[COSMO_NNZ_PER_BLOCK];
   __shared__ double red[COSMO_BS / 64];
   for (int k = blockIdx.x; k < A.nb; k += gridDim.x)
-    csr_stream_block(A, dx, dx, A.rb[k], A.rb[k + 1], lds, red, [&](int row, double s1, double s2) { adx[row] = ((s1 + s2) * Einv[row]) * inv_norm; });
+    csr_stream_tile(A, dx, dx, k, lds, red, [&](int row, double s1, double s2) { adx[row] = ((s1 + s2) * Einv[row]) * inv_norm; });
 }
 
 // primal certificate pieces on the simple rows: dyn = dy * (-1/norm) (in place) ; <dyn, b> ; Box support function ;

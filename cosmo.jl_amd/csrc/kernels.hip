@@ -11,7 +11,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_spmv_plain(CsrView M, const double
   __shared__ double lds[COSMO_NNZ_PER_BLOCK];
   __shared__ double red[COSMO_BS / 64];
   for (int k = blockIdx.x; k < M.nb; k += gridDim.x) {
-    csr_stream_block(M, x, x, M.rb[k], M.rb[k + 1], lds, red, [&](int r, double s1, double s2) { y[r] = s1 + s2; });
+    csr_stream_tile(M, x, x, k, lds, red, [&](int r, double s1, double s2) { y[r] = s1 + s2; });
   }
 }
 
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_cg_rhs(const Ctl* __restrict__ ctl
   __shared__ double red[COSMO_BS / 64];
   double acc = 0.0;
   for (int k = blockIdx.x; k < AT.nb; k += gridDim.x) {
-    csr_stream_block(AT, y2, y2, AT.rb[k], AT.rb[k + 1], lds, red, [&](int r, double s1, double s2) {
+    csr_stream_tile(AT, y2, y2, k, lds, red, [&](int r, double s1, double s2) {
       const double v = (s1 + s2) + ls_x[r];
       rhs[r] = v;
       acc += v * v;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_spmv_A_rho(const Ctl* __restrict__
   __shared__ double lds[COSMO_NNZ_PER_BLOCK];
   __shared__ double red[COSMO_BS / 64];
   for (int k = blockIdx.x; k < A.nb; k += gridDim.x) {
-    csr_stream_block(A, v, v, A.rb[k], A.rb[k + 1], lds, red,
+    csr_stream_tile(A, v, v, k, lds, red,
                      [&](int r, double s1, double s2) { out[r] = (s1 + s2) * rho[r]; });
   }
 }
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_op_apply(Ctl* __restrict__ ctl, in
   }
   double acc = 0.0;
   for (int k = blockIdx.x; k < PT.nb; k += gridDim.x) {
-    csr_stream_block(PT, v, tmp, PT.rb[k], PT.rb[k + 1], lds, red, [&](int row, double s1, double s2) {
+    csr_stream_tile(PT, v, tmp, k, lds, red, [&](int row, double s1, double s2) {
       const double vj = v[row];
       const double cj = s1 + (sigma * vj + s2);
       if (mode == 0) {
@@ -239,12 +239,13 @@ __global__ __launch_bounds__(COSMO_BS) void k_cg_dir(Ctl* __restrict__ ctl, int 
   const long long i0 = (long long)blockIdx.x * COSMO_BS + threadIdx.x;
   double r0 = 0.0, u0 = 0.0;
   if (!check_only && i0 < n) { r0 = r[i0]; if (k > 0) u0 = u[i0]; }
+  const double pa = partials_prefetch_sum(part_rr, n_rr);      // in flight while the guards wait on their scalar loads
   if (guard && ctl->halt) return;
   if (ctl->cg_done) return;
   __shared__ double red[COSMO_BS / 64];
   const double tol = ctl->tol;
   const double prev = (k == 0) ? 1.0 : ctl->resv[(k - 1) & 1];
-  const double rr = reduce_partials_sum(part_rr, n_rr, red);
+  const double rr = block_sum(pa, red);
   const double res = sqrt(rr);
   const bool done = (k >= maxiter) || (res <= tol);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -269,11 +270,12 @@ __global__ __launch_bounds__(COSMO_BS) void k_cg_upd(Ctl* __restrict__ ctl, int 
   const long long i0 = (long long)blockIdx.x * COSMO_BS + threadIdx.x;
   double u0 = 0.0, c0 = 0.0, x0 = 0.0, r0 = 0.0;
   if (i0 < n) { u0 = u[i0]; c0 = c[i0]; x0 = x[i0]; r0 = r[i0]; }   // issued before the scalar work (latency overlap)
+  const double pa = partials_prefetch_sum(part_uc, n_uc);
   if (guard && ctl->halt) return;
   if (ctl->cg_done) return;
   __shared__ double red[COSMO_BS / 64];
   const double res = ctl->resv[k & 1];
-  const double uc = reduce_partials_sum(part_uc, n_uc, red);
+  const double uc = block_sum(pa, red);
   const double alpha = (res * res) / uc;
   double acc = 0.0;
   if (i0 < n) {
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_tail(Ctl* __restrict__ ctl, int lo
   __shared__ double red[COSMO_BS / 64];
   if ((int)blockIdx.x < nblk_rows) {
     for (int k = blockIdx.x; k < A.nb; k += nblk_rows) {
-      csr_stream_block(A, x_tl, x_tl, A.rb[k], A.rb[k + 1], lds, red, [&](int row, double s1, double s2) {
+      csr_stream_tile(A, x_tl, x_tl, k, lds, red, [&](int row, double s1, double s2) {
         const double ax = s1 + s2;
         const double rh = rho[row];
         const double nv = (ax - ls_s[row]) * rh;
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_chk_prim(const Ctl* __restrict__ c
   __shared__ double red[COSMO_BS / 64];
   double rp = 0.0, mp = 0.0;
   for (int k = blockIdx.x; k < A.nb; k += gridDim.x) {
-    csr_stream_block(A, w_prev, w_prev, A.rb[k], A.rb[k + 1], lds, red, [&](int row, double s1, double s2) {
+    csr_stream_tile(A, w_prev, w_prev, k, lds, red, [&](int row, double s1, double s2) {
       const double ax = s1 + s2;
       const double sv = s[row];
       const double bv = b[row];
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_chk_dual(const Ctl* __restrict__ c
   __shared__ double red[COSMO_BS / 64];
   double rd = 0.0, md = 0.0, xpx = 0.0, qx = 0.0;
   for (int k = blockIdx.x; k < PT.nb; k += gridDim.x) {
-    csr_stream_block(PT, w_prev, mu, PT.rb[k], PT.rb[k + 1], lds, red, [&](int row, double px, double atm) {
+    csr_stream_tile(PT, w_prev, mu, k, lds, red, [&](int row, double px, double atm) {
       const double xv = w_prev[row];
       const double qv = q[row];
       double rv = px + qv;

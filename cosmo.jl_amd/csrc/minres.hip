@@ -63,7 +63,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_mr_op_top(Ctl* __restrict__ ctl, i
   }
   double acc = 0.0;
   for (int k = blockIdx.x; k < PT.nb; k += gridDim.x) {
-    csr_stream_block(PT, v1, v2, PT.rb[k], PT.rb[k + 1], lds, red, [&](int row, double s1, double s2) {
+    csr_stream_tile(PT, v1, v2, k, lds, red, [&](int row, double s1, double s2) {
       const double vc = v1[row];
       double y = s1 + (sigma * vc + s2);
       if (mode == 0) {
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_mr_op_bot(Ctl* __restrict__ ctl, i
   const double h1 = ctl->minres[((it - 1) & 1) * 8 + MS_H1];
   double acc = 0.0;
   for (int k = blockIdx.x; k < A.nb; k += gridDim.x) {
-    csr_stream_block(A, v1, v1, A.rb[k], A.rb[k + 1], lds, red, [&](int row, double s1, double s2) {
+    csr_stream_tile(A, v1, v1, k, lds, red, [&](int row, double s1, double s2) {
       const double vc = v2[row];
       double y = (s1 + s2) + (-vc / rho[row]);
       if (mode == 0) {
