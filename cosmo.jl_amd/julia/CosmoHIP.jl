@@ -199,9 +199,10 @@ function optimize_hip!(ws::COSMO.Workspace{Float64}; device::Integer = 0, kkt_ki
     set_problem!(h, SparseMatrixCSC(ws.p.P), SparseMatrixCSC(ws.p.A), ws.p.q, Vector(ws.p.b))
     set_cones!(h, ws.p.C)
     set_params!(h, params_from(settings, kkt_kind; tol_constant = tol_constant, tol_exponent = tol_exponent), ws.ρvec)
-    Dinv = settings.scaling != 0 ? ws.sm.Dinv.diag : ones(n); Einv = settings.scaling != 0 ? ws.sm.Einv.diag : ones(m)
-    GC.@preserve Dinv Einv check(h, ccall((:cosmo_hip_set_scaling, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble),
-        h.ptr, Dinv, Einv, ws.sm.cinv[]))
+    sc = settings.scaling != 0
+    D = sc ? ws.sm.D.diag : ones(n); Dinv = sc ? ws.sm.Dinv.diag : ones(n); E = sc ? ws.sm.E.diag : ones(m); Einv = sc ? ws.sm.Einv.diag : ones(m)
+    GC.@preserve D Dinv E Einv check(h, ccall((:cosmo_hip_set_scaling_full, LIB[]), Int32,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble), h.ptr, D, Dinv, E, Einv, ws.sm.c[], ws.sm.cinv[]))
     x0 = ws.vars.x; s0 = ws.vars.s.data; mu0 = ws.vars.μ
     GC.@preserve x0 s0 mu0 check(h, ccall((:cosmo_hip_set_iterates, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
         h.ptr, x0, s0, mu0))                                                  # src/solver.jl:128-129
