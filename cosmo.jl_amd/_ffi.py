@@ -18,6 +18,7 @@ OK = 0
 ERR_NAMES = {1: "INVALID", 2: "HIP", 3: "NOT_CONVEX", 4: "NONFINITE", 5: "EIG", 6: "UNSUPPORTED", 7: "COMM"}
 
 ZERO, NONNEG, BOX, SOC, PSD_SQUARE, PSD_TRIANGLE = 0, 1, 2, 3, 4, 5
+EXP, DUAL_EXP, POW, DUAL_POW = 6, 7, 8, 9
 KKT_CG, KKT_MINRES_REDUCED, KKT_MINRES = 0, 1, 2
 STATUS_NAMES = {0: "Undetermined", 1: "Solved", 2: "Max_iter_reached", 3: "Unsolved", 4: "Primal_infeasible",
                 5: "Dual_infeasible", 6: "Time_limit_reached"}
@@ -73,6 +74,7 @@ SIGNATURES = {
     "cosmo_hip_last_error": (C.c_char_p, [C.c_void_p]),
     "cosmo_hip_set_problem": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int64, _PI64, _PI64, _PD, _PI64, _PI64, _PD, _PD, _PD]),
     "cosmo_hip_set_cones": (C.c_int32, [C.c_void_p, C.c_int64, _PI32, _PI64, _PD, _PD]),
+    "cosmo_hip_set_cones_ex": (C.c_int32, [C.c_void_p, C.c_int64, _PI32, _PI64, _PD, _PD, _PD]),
     "cosmo_hip_set_params": (C.c_int32, [C.c_void_p, C.POINTER(Params), _PD]),
     "cosmo_hip_update_rho": (C.c_int32, [C.c_void_p, _PD]),
     "cosmo_hip_set_scaling": (C.c_int32, [C.c_void_p, _PD, _PD, C.c_double]),
@@ -211,11 +213,15 @@ class Handle:
                                                  ac.ctypes.data_as(_PI64), ar.ctypes.data_as(_PI64), _dp(av), _dp(q), _dp(b)))
         self.n, self.m = n, m
 
-    def set_cones(self, types, dims, box_l=None, box_u=None):
+    def set_cones(self, types, dims, box_l=None, box_u=None, cone_param=None):
         t = np.ascontiguousarray(types, dtype=np.int32)
         d = np.ascontiguousarray(dims, dtype=np.int64)
         bl = _f64(box_l); bu = _f64(box_u)
-        self._chk(self.lib.cosmo_hip_set_cones(self._h, t.size, t.ctypes.data_as(_PI32), d.ctypes.data_as(_PI64), _dp(bl), _dp(bu)))
+        if cone_param is None:
+            self._chk(self.lib.cosmo_hip_set_cones(self._h, t.size, t.ctypes.data_as(_PI32), d.ctypes.data_as(_PI64), _dp(bl), _dp(bu)))
+        else:
+            cp = _f64(cone_param, t.size, "cone_param")
+            self._chk(self.lib.cosmo_hip_set_cones_ex(self._h, t.size, t.ctypes.data_as(_PI32), d.ctypes.data_as(_PI64), _dp(bl), _dp(bu), _dp(cp)))
         self.ncones = t.size
 
     def default_params(self):

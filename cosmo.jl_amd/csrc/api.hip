@@ -233,6 +233,7 @@ static void free_cones(cosmo_hip_handle* h) {
   dfree(&h->meta); dfree(&h->box_l); dfree(&h->box_u); dfree(&h->rho_cls);
   dfree(&h->soc_off); dfree(&h->soc_dim); dfree(&h->soc_branch);
   psd_plan_destroy(h);
+  cone3_free(h);
   h->nsoc = 0;
 }
 
@@ -354,12 +355,18 @@ int32_t rebuild_cone_plans(cosmo_hip_handle* h) {
   h->nsoc = (int)soc_off.size();
   CHK(dalloc(h, &h->soc_off, soc_off.size())); CHK(dalloc(h, &h->soc_dim, soc_dim.size())); CHK(dalloc(h, &h->soc_branch, soc_off.size()));
   if (h->nsoc) { CHK(h2d(h, h->soc_off, soc_off.data(), soc_off.size())); CHK(h2d(h, h->soc_dim, soc_dim.data(), soc_dim.size())); }
+  CHK(cone3_plan_create(h));
   CHK(psd_plan_create(h));
   return COSMO_HIP_OK;
 }
 
 extern "C" int32_t cosmo_hip_set_cones(cosmo_hip_handle* h, int64_t ncones, const int32_t* type, const int64_t* dim,
                                        const double* box_l, const double* box_u) {
+  return cosmo_hip_set_cones_ex(h, ncones, type, dim, box_l, box_u, nullptr);
+}
+
+extern "C" int32_t cosmo_hip_set_cones_ex(cosmo_hip_handle* h, int64_t ncones, const int32_t* type, const int64_t* dim,
+                                          const double* box_l, const double* box_u, const double* cone_param) {
   ENTER(h);
   if (!h->have_problem) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_problem must be called before set_cones");
   if (ncones < 0 || (ncones > 0 && (!type || !dim))) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "bad cone table");
@@ -369,13 +376,19 @@ extern "C" int32_t cosmo_hip_set_cones(cosmo_hip_handle* h, int64_t ncones, cons
   int64_t off = 0, nbox = 0;
   for (int64_t k = 0; k < ncones; ++k) {
     if (dim[k] < 0) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "negative cone dimension");
-    if (type[k] < COSMO_HIP_ZERO || type[k] > COSMO_HIP_PSD_TRIANGLE)
+    if (type[k] < COSMO_HIP_ZERO || type[k] > COSMO_HIP_DUAL_POW)
       return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "cone type %d is outside the hot-path scope", (int)type[k]);
+    if (type[k] >= COSMO_HIP_EXP && dim[k] != 3) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "exponential / power cones have dimension 3");
+    if (type[k] == COSMO_HIP_POW || type[k] == COSMO_HIP_DUAL_POW) {
+      if (!cone_param || !(cone_param[k] > 0.0 && cone_param[k] < 1.0))
+        return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "The exponent alpha of the power cone has to be in (0, 1).");
+    }
     if (type[k] == COSMO_HIP_PSD_SQUARE) {
       const int64_t r = (int64_t)llround(sqrt((double)dim[k]));
       if (r * r != dim[k]) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "PsdCone dimension must be a square");
     }
     C.type.push_back(type[k]); C.dim.push_back(dim[k]); C.off.push_back(off);
+    C.param.push_back(cone_param ? cone_param[k] : 0.0);
     off += dim[k];
     if (type[k] == COSMO_HIP_BOX) nbox += dim[k];
   }
@@ -397,6 +410,7 @@ extern "C" int32_t cosmo_hip_set_cones(cosmo_hip_handle* h, int64_t ncones, cons
         boxp += d;
         break;
       case COSMO_HIP_SOC: break;
+      case COSMO_HIP_EXP: case COSMO_HIP_DUAL_EXP: case COSMO_HIP_POW: case COSMO_HIP_DUAL_POW: break;   // cone3.hip, in place
       case COSMO_HIP_PSD_SQUARE:
       case COSMO_HIP_PSD_TRIANGLE:
         if (d == 1) for (int64_t i = 0; i < d; ++i) meta[o + i] = 2u;  // 1x1: max(x,0) (convexset.jl:307-308,404-405)
@@ -540,6 +554,7 @@ extern "C" int32_t cosmo_hip_project(cosmo_hip_handle* h, double* s, int64_t* ps
   CHK(h2d(h, h->io, s, (size_t)h->m));
   CHK(launch_project_simple_inplace(h, h->io));
   CHK(launch_soc(h, h->io, 0));
+  CHK(cone3_enqueue_project(h, h->io, 0));
   CHK(psd_enqueue_project(h, h->io, false));
   CHK(comm_enqueue_exchange(h, h->io));
   CHK(d2h(h, s, h->io, (size_t)h->m));
@@ -551,6 +566,7 @@ extern "C" int32_t cosmo_hip_project(cosmo_hip_handle* h, double* s, int64_t* ps
       CHK(d2h(h, br.data(), h->soc_branch, (size_t)h->nsoc));
       for (int i = 0; i < h->nsoc; ++i) soc_branch_out[h->soc_cone_index[i]] = br[i];
     }
+    CHK(cone3_get_branches(h, soc_branch_out));
   }
   if (psd_rank_out) {
     for (size_t k = 0; k < nc; ++k) psd_rank_out[k] = -1;
@@ -686,6 +702,7 @@ static int32_t enqueue_iteration(cosmo_hip_handle* h, long long it) {
   if (inf_due(h, it)) CHK(infeas_enqueue_capture(h));
   CHK(launch_z(h, 1));
   CHK(launch_soc(h, h->s, 1));
+  CHK(cone3_enqueue_project(h, h->s, 1));
   CHK(psd_enqueue_project(h, h->s, true));
   CHK(comm_enqueue_exchange(h, h->s));      // clique sharding: the one exchange step of the iteration
   if (h->prm.adaptive_rho && h->prm.adaptive_rho_interval > 0 && (it % h->prm.adaptive_rho_interval) == 0)

@@ -211,6 +211,7 @@ int32_t infeas_check(cosmo_hip_handle* h, int32_t* status) {
                        h->b, h->inf_dy, IPARTS(h, SLOT_AUX0), IPARTS(h, SLOT_AUX1), h->inf_flags);
     if (h->nsoc) hipLaunchKernelGGL(k_inf_soc, dim3(std::min(4096, (h->nsoc + 3) / 4)), dim3(COSMO_BS), 0, h->stream, h->nsoc, h->soc_off, h->soc_dim,
                                     h->inf_dy, 0, p.eps_prim_inf, h->inf_flags);
+    CHK(cone3_enqueue_in_dual_neg(h, h->inf_dy, p.eps_prim_inf, h->inf_flags + 0));     // support_function!: in_dual(-dyn)
     HIPCHK(h, hipGetLastError());
     std::vector<double> d0, d1;
     int fl[4] = {0, 0, 0, 0};
@@ -238,6 +239,7 @@ int32_t infeas_check(cosmo_hip_handle* h, int32_t* status) {
                        h->box_l, h->box_u, h->inf_adx, h->inf_flags);
     if (h->nsoc) hipLaunchKernelGGL(k_inf_soc, dim3(std::min(4096, (h->nsoc + 3) / 4)), dim3(COSMO_BS), 0, h->stream, h->nsoc, h->soc_off, h->soc_dim,
                                     h->inf_adx, 1, p.eps_dual_inf, h->inf_flags);
+    CHK(cone3_enqueue_in_dual_neg(h, h->inf_adx, p.eps_dual_inf, h->inf_flags + 1));    // in_pol_recc(v) = in_dual(-v)
     HIPCHK(h, hipGetLastError());
     int fl[4] = {0, 0, 0, 0};
     HIPCHK(h, hipMemcpyAsync(fl, h->inf_flags, sizeof fl, hipMemcpyDeviceToHost, h->stream));

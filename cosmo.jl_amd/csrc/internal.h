@@ -76,6 +76,7 @@ struct ConeTable {  // host copy of the composite set
   std::vector<int64_t> dim, off;
   int64_t nbox_rows = 0;
   std::vector<double> box_l, box_u;
+  std::vector<double> param;       // per cone: alpha of the power cones
 };
 
 struct PsdPlan;  // psd.hip
@@ -105,6 +106,10 @@ struct cosmo_hip_handle {
   int nsoc = 0;                   // SOC table
   int *soc_off = nullptr, *soc_dim = nullptr, *soc_branch = nullptr;
   std::vector<int> soc_cone_index;
+  int ncone3 = 0;                 // exponential / power cones (cone3.hip)
+  int *c3_off = nullptr, *c3_kind = nullptr, *c3_branch = nullptr;
+  double* c3_alpha = nullptr;
+  std::vector<int> c3_cone_index;
   PsdPlan* psd = nullptr;
   // clique sharding (comm.hip): this rank projects the SOC / PSD cones cone_lo <= k < cone_hi (cone_hi < 0: all cones)
   void* comm = nullptr;
@@ -167,6 +172,13 @@ int32_t enqueue_projection(cosmo_hip_handle* h, const double* src, double* dst, 
                            const double* w_src, bool in_loop);
 int32_t enqueue_admm_x_and_w(cosmo_hip_handle* h);
 int32_t sync_ctl(cosmo_hip_handle* h);
+
+// exponential / power cones (cone3.hip)
+int32_t cone3_plan_create(cosmo_hip_handle* h);
+void cone3_free(cosmo_hip_handle* h);
+int32_t cone3_enqueue_project(cosmo_hip_handle* h, double* s, int guard);
+int32_t cone3_enqueue_in_dual_neg(cosmo_hip_handle* h, const double* v, double tol, int* flag);
+int32_t cone3_get_branches(cosmo_hip_handle* h, int32_t* out_per_cone);
 
 // PSD projection (psd.hip)
 int32_t psd_plan_create(cosmo_hip_handle* h);

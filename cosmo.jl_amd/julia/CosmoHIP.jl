@@ -74,6 +74,13 @@ cone_type(::COSMO.Box) = Int32(2)
 cone_type(::COSMO.SecondOrderCone) = Int32(3)
 cone_type(::COSMO.PsdCone) = Int32(4)
 cone_type(::COSMO.PsdConeTriangle{T, T}) where {T} = Int32(5)
+cone_type(::COSMO.ExponentialCone) = Int32(6)
+cone_type(::COSMO.DualExponentialCone) = Int32(7)
+cone_type(::COSMO.PowerCone) = Int32(8)
+cone_type(::COSMO.DualPowerCone) = Int32(9)
+cone_param(s::COSMO.PowerCone) = Float64(s.α)
+cone_param(s::COSMO.DualPowerCone) = Float64(s.primal_cone.α)
+cone_param(s) = 0.0
 cone_type(C) = error("cone type $(typeof(C)) is outside the MI355X hot path (SURVEY.md 8a)")
 
 # cosmo_hip_set_problem takes SparseMatrixCSC{Float64,Int64} untouched: colptr / rowval are already 1-based Int64
@@ -95,9 +102,10 @@ function set_cones!(h::Handle, C::COSMO.CompositeConvexSet{Float64})
             append!(bl, s.l); append!(bu, s.u)          # already E-scaled by scale!(::Box) (src/convexset.jl:863-867)
         end
     end
-    GC.@preserve types dims bl bu begin
-        check(h, ccall((:cosmo_hip_set_cones, LIB[]), Int32, (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Cdouble}),
-            h.ptr, length(types), types, dims, isempty(bl) ? C_NULL : pointer(bl), isempty(bu) ? C_NULL : pointer(bu)))
+    params = Float64[cone_param(s) for s in C.sets]      # alpha of the power cones (src/convexset.jl:607-618)
+    GC.@preserve types dims bl bu params begin
+        check(h, ccall((:cosmo_hip_set_cones_ex, LIB[]), Int32, (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+            h.ptr, length(types), types, dims, isempty(bl) ? C_NULL : pointer(bl), isempty(bu) ? C_NULL : pointer(bu), params))
     end
 end
 

