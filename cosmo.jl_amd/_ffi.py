@@ -79,6 +79,7 @@ SIGNATURES = {
     "cosmo_hip_update_rho": (C.c_int32, [C.c_void_p, _PD]),
     "cosmo_hip_set_scaling": (C.c_int32, [C.c_void_p, _PD, _PD, C.c_double]),
     "cosmo_hip_set_scaling_full": (C.c_int32, [C.c_void_p, _PD, _PD, _PD, _PD, C.c_double, C.c_double]),
+    "cosmo_hip_scale_ruiz": (C.c_int32, [C.c_void_p, C.c_int64, C.c_double, C.c_double, _PD, _PD, C.POINTER(C.c_double)]),
     "cosmo_hip_update_qb": (C.c_int32, [C.c_void_p, _PD, _PD]),
     "cosmo_hip_get_rho_classes": (C.c_int32, [C.c_void_p, _PI32]),
     "cosmo_hip_get_rho_vec": (C.c_int32, [C.c_void_p, _PD]),
@@ -234,6 +235,12 @@ class Handle:
     def update_rho(self, rho_vec):
         rv = _f64(rho_vec, self.m, "rho_vec")
         self._chk(self.lib.cosmo_hip_update_rho(self._h, _dp(rv)))
+
+    def scale_ruiz(self, iterations, min_scaling=1e-4, max_scaling=1e4):
+        """Device Ruiz equilibration of the resident (unscaled) problem; returns (D, E, c)."""
+        D = np.empty(self.n); E = np.empty(self.m); c = C.c_double(1.0)
+        self._chk(self.lib.cosmo_hip_scale_ruiz(self._h, int(iterations), float(min_scaling), float(max_scaling), _dp(D), _dp(E), C.byref(c)))
+        return D, E, float(c.value)
 
     def set_scaling(self, Dinv, Einv, cinv):
         self._chk(self.lib.cosmo_hip_set_scaling(self._h, _dp(_f64(Dinv, self.n)), _dp(_f64(Einv, self.m)), float(cinv)))

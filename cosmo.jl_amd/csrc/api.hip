@@ -274,6 +274,7 @@ extern "C" int32_t cosmo_hip_set_problem(cosmo_hip_handle* h, int64_t n, int64_t
   HostCsr Pt, Pm, At, Am;
   CHK(csc_to_csr_pair(h, n, n, P_colptr, P_rowval, P_nzval, Pt, Pm));
   CHK(csc_to_csr_pair(h, m, n, A_colptr, A_rowval, A_nzval, At, Am));
+  h->P_symmetric = (Pt.rowptr == Pm.rowptr && Pt.col == Pm.col && Pt.val == Pm.val);   // issymmetric(P) (scaling.jl:99)
   // row-merged operator [P | A'] : row j = (row j of P, columns < n) ++ (row j of A', columns shifted by n)
   HostCsr PT;
   PT.nrows = (int)n; PT.ncols = (int)(n + m);
@@ -341,6 +342,18 @@ static int32_t classify_rows(cosmo_hip_handle* h, const std::vector<double>& bho
   CHK(dalloc(h, &h->rho_cls, (size_t)h->m));
   CHK(h2d(h, h->rho_cls, h->rho_cls_host.data(), (size_t)h->m));
   return COSMO_HIP_OK;
+}
+
+// after cosmo_hip_scale_ruiz: classify_constraints! sees the scaled b and Box bounds (setup.jl:36-37, 75-85)
+int32_t reclassify_after_scaling(cosmo_hip_handle* h) {
+  ConeTable& C = h->cones;
+  if (C.nbox_rows > 0) {
+    CHK(d2h(h, C.box_l.data(), h->box_l, (size_t)C.nbox_rows));
+    CHK(d2h(h, C.box_u.data(), h->box_u, (size_t)C.nbox_rows));
+  }
+  std::vector<double> bhost((size_t)h->m);
+  CHK(d2h(h, bhost.data(), h->b, (size_t)h->m));
+  return classify_rows(h, bhost);
 }
 
 // SOC table and PSD plan of the cones this rank owns (all cones unless cosmo_hip_set_cone_shard restricted the range)

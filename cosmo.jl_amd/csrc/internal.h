@@ -97,6 +97,7 @@ struct cosmo_hip_handle {
   int* inf_flags = nullptr;
   double cinv = 1.0;
   bool has_scaling = false;
+  bool P_symmetric = true;       // set by set_problem; the device Ruiz scaling requires it
   // cones
   ConeTable cones;
   uint32_t* meta = nullptr;       // per row: kind (2 bits) | box index << 2

@@ -109,6 +109,18 @@ function set_cones!(h::Handle, C::COSMO.CompositeConvexSet{Float64})
     end
 end
 
+# scale_ruiz! (src/scaling.jl:21-116) on the device-resident UNSCALED problem; fills ws.sm so that the unchanged
+# reverse_scaling! / update! keep working.  Call between set_cones! and set_params!.
+function scale_ruiz!(h::Handle, ws::COSMO.Workspace{Float64})
+    s = ws.settings
+    D = ws.sm.D.diag; E = ws.sm.E.diag; c = Ref{Cdouble}(1.0)
+    GC.@preserve D E check(h, ccall((:cosmo_hip_scale_ruiz, LIB[]), Int32, (Ptr{Cvoid}, Int64, Cdouble, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}),
+        h.ptr, s.scaling, s.MIN_SCALING, s.MAX_SCALING, D, E, c))
+    ws.sm.Dinv.diag .= 1.0 ./ D; ws.sm.Einv.diag .= 1.0 ./ E
+    ws.sm.c[] = c[]; ws.sm.cinv[] = 1.0 / c[]
+    nothing
+end
+
 function params_from(settings::COSMO.Settings{Float64}, kkt_kind::Int32; tol_constant = 1.0, tol_exponent = 1.5)
     s = settings
     Params(s.sigma, s.alpha, s.rho, s.eps_abs, s.eps_rel, s.eps_prim_inf, s.eps_dual_inf, tol_constant, tol_exponent,

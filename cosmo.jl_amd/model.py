@@ -75,6 +75,7 @@ class Settings:
     COSMO_INFTY: float = 1e20
     time_limit: float = 0.0
     device: int = 0
+    device_scaling: bool = True      # run scale_ruiz! on the MI355X (cosmo_hip_scale_ruiz) instead of on the host
 
 
 # ---- AbstractConvexSet subtypes on the hot path (src/convexset.jl) ---------------------------------------------------
@@ -444,7 +445,36 @@ def setup(model: Model):
     """`setup!` (src/setup.jl:18-64): scaling once, then hand the scaled problem to the device library
     (the `_make_kkt_solver!` step, :1-7, is where the reference constructs its AbstractKKTSolver plugin)."""
     st = model.settings
-    if st.scaling != 0 and not model.is_scaled:
+
+    def make_handle():
+        h = _ffi.Handle(st.device)
+        h.set_problem(model.P, model.q, model.A, model.b)
+        bl = np.concatenate([K.l for K in model.sets if K.kind == _ffi.BOX] or [np.zeros(0)])
+        bu = np.concatenate([K.u for K in model.sets if K.kind == _ffi.BOX] or [np.zeros(0)])
+        h.set_cones([K.kind for K in model.sets], [K.dim for K in model.sets], bl, bu,
+                    cone_param=[getattr(K, "alpha", 0.0) for K in model.sets])
+        return h
+
+    on_device = (st.scaling != 0 and not model.is_scaled and model.handle is None and st.device_scaling
+                 and (abs(model.P - model.P.T)).nnz == 0)
+    if on_device:
+        # scale_ruiz! on the device-resident problem (csrc/scaling.hip); the host keeps only D, E, c for the O(n+m)
+        # pre/post-processing (scale_variables!, reverse_scaling!, update!) and the scaled q, b, Box bounds
+        h = make_handle()
+        D, E, c = h.scale_ruiz(st.scaling, st.MIN_SCALING, st.MAX_SCALING)
+        model.sm = ScaleMatrices(D, 1.0 / D, E, 1.0 / E, c, 1.0 / c)
+        model.q = (D * model.q) * c
+        model.b = E * model.b
+        off = 0
+        for K in model.sets:
+            if K.kind == _ffi.BOX:
+                K.l *= E[off:off + K.dim]; K.u *= E[off:off + K.dim]
+            off += K.dim
+        model.is_scaled = True
+        model.device_scaled = True            # host copies of P and A stay unscaled
+        h.set_params(_params_from_settings(h, st))
+        model.handle = h
+    elif st.scaling != 0 and not model.is_scaled:
         model.sm = scale_ruiz(model.P, model.q, model.A, model.b, model.sets, st)
         model.is_scaled = True
     elif model.sm is None:
@@ -455,12 +485,7 @@ def setup(model: Model):
     model.mu = (sm.Einv * model.mu) * sm.c
     model.s = sm.E * model.s
     if model.handle is None:
-        h = _ffi.Handle(st.device)
-        h.set_problem(model.P, model.q, model.A, model.b)
-        bl = np.concatenate([K.l for K in model.sets if K.kind == _ffi.BOX] or [np.zeros(0)])
-        bu = np.concatenate([K.u for K in model.sets if K.kind == _ffi.BOX] or [np.zeros(0)])
-        h.set_cones([K.kind for K in model.sets], [K.dim for K in model.sets], bl, bu,
-                    cone_param=[getattr(K, "alpha", 0.0) for K in model.sets])
+        h = make_handle()
         h.set_params(_params_from_settings(h, st))                 # set_rho_vec! happens inside (first solve only)
         h.set_scaling_full(sm.D, sm.Dinv, sm.E, sm.Einv, sm.c, sm.cinv)
         model.handle = h

@@ -161,6 +161,15 @@ int32_t cosmo_hip_set_scaling(cosmo_hip_handle* h, const double* Dinv, const dou
 int32_t cosmo_hip_set_scaling_full(cosmo_hip_handle* h, const double* D, const double* Dinv, const double* E, const double* Einv,
                                    double c, double cinv);
 /* Replaces COSMO.update!(model; q, b) on already-scaled vectors (src/interface.jl:187-211). NULL = keep. */
+/* Replaces scale_ruiz! (src/scaling.jl:21-116) for callers that hand over the UNSCALED problem: call after
+ * cosmo_hip_set_problem + cosmo_hip_set_cones (unscaled data and Box bounds) and before cosmo_hip_set_params.  Runs
+ * `iterations` (settings.scaling) steps of the modified Ruiz equilibration on the device-resident P, A, q, b, rectifies the
+ * scalings of the scalar-scaled cones (src/scaling.jl:129-142, src/convexset.jl:953-982), scales the Box bounds
+ * (src/convexset.jl:863-867) and re-runs classify_constraints! on the scaled data.  The scaling matrices stay on the device
+ * for the residual / infeasibility tests (as after cosmo_hip_set_scaling_full); D_out[n], E_out[m], c_out (each may be
+ * NULL) return them for the caller's reverse_scaling! (src/scaling.jl:170-179).  P must be symmetric. */
+int32_t cosmo_hip_scale_ruiz(cosmo_hip_handle* h, int64_t iterations, double min_scaling, double max_scaling, double* D_out,
+                             double* E_out, double* c_out);
 int32_t cosmo_hip_update_qb(cosmo_hip_handle* h, const double* q, const double* b);
 /* Per-row rho class computed by the library: 0 = rho, 1 = rho*RHO_EQ_OVER_RHO_INEQ, 2 = RHO_MIN
  * (apply_constraint_rho_scaling!, src/parameters.jl:17-49) -- integer bookkeeping, compared bit-exactly. */
