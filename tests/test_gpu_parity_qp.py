@@ -305,7 +305,7 @@ def test_determinism_bitwise():
 def test_cfg2_full_size_properties():
     prob = cj.problems.sparse_box_qp()
     n, m = prob["A"].shape[1], prob["A"].shape[0]
-    st = cj.Settings(max_iter=100, eps_abs=0, eps_rel=0)
+    st = cj.Settings(max_iter=100, eps_abs=0, eps_rel=0, device_scaling=False)   # host-scaled copies of P, A are compared below
     model = cj.Model(); model.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)
     res = cj.optimize(model)
     assert res.status == "Max_iter_reached" and res.iter == 100

@@ -113,3 +113,25 @@ def test_solve_with_device_scaling_matches_host_scaling(case):
     assert abs(a.iter - b_.iter) <= 25
     assert abs(a.obj_val - b_.obj_val) <= 1e-6 * max(1.0, abs(b_.obj_val))
     assert np.linalg.norm(a.x - b_.x) <= 1e-5 * max(1.0, np.linalg.norm(b_.x))
+
+
+def test_cfg2_full_size_device_scaling_equals_host_scaling():
+    """BASELINE config 2 size: the device equilibration reproduces the host restatement bit for bit (Box cone only => no
+    rectification sums), and the loop started from either gives the same iterates."""
+    prob = cj.problems.sparse_box_qp()
+    n, m = prob["A"].shape[1], prob["A"].shape[0]
+    out = []
+    for dev in (True, False):
+        model = cj.Model()
+        model.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], cj.Settings(max_iter=30, eps_abs=0, eps_rel=0, device_scaling=dev))
+        res = cj.optimize(model)
+        x = np.random.default_rng(0).standard_normal(n)
+        out.append((model.sm, res, model.handle.spmv(F.MAT_A, x), model.handle.get_rho_classes(), model.sets[0]))
+    (smd, rd, axd, cd, Kd), (smh, rh, axh, ch, Kh) = out
+    assert np.array_equal(smd.D, smh.D) and np.array_equal(smd.E, smh.E)
+    assert abs(smd.c - smh.c) <= 4e-16 * smh.c
+    assert np.array_equal(cd, ch)
+    assert np.array_equal(Kd.l, Kh.l) and np.array_equal(Kd.u, Kh.u)
+    assert np.array_equal(axd.view(np.int64), axh.view(np.int64))          # identical scaled A on the device
+    assert rd.iter == rh.iter == 30
+    assert np.linalg.norm(rd.x - rh.x) <= 1e-9 * np.linalg.norm(rh.x)
