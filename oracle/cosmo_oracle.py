@@ -464,7 +464,14 @@ class Settings:
     RHO_EQ_OVER_RHO_INEQ: float = 1e3
     COSMO_INFTY: float = 1e20
     time_limit: float = 0.0
-    # the oracle only restates the EmptyAccelerator loop
+    # accelerator (src/settings.jl:136-138, src/accelerator_interface.jl).  "empty" = EmptyAccelerator (the pinned loop);
+    # "anderson" = AndersonAccelerator{T, Type2{QRDecomp}, RestartedMemory, NoRegularizer}(mem = 15), the reference's default.
+    accelerator: str = "empty"
+    acc_mem: int = 15
+    acc_min_mem: int = 3
+    acc_start_iter: int = 2              # ImmediateActivation (accelerator_interface.jl:25-29); IterActivation(k): k
+    safeguard: bool = True
+    safeguard_tol: float = 2.0
 
 
 @dataclass
@@ -962,6 +969,98 @@ def is_dual_infeasible(dx, ops, q, cones, sm: ScaleMatrices, st: Settings) -> bo
 # --------------------------------------------------------------------------------------------
 # the solver workspace + ADMM loop (src/solver.jl)
 # --------------------------------------------------------------------------------------------
+# --------------------------------------------------------------------------------------------
+# Anderson acceleration  --  PARITY UNPINNED
+# COSMO.jl delegates to COSMOAccelerators.jl (Project.toml:8,27: "^0.1.0"), which is NOT vendored in /root/reference.
+# This class restates the published algorithm of AndersonAccelerator{T, Type2{QRDecomp}, RestartedMemory, NoRegularizer}
+# (the default of src/settings.jl:136) as used through CA.update! / CA.accelerate! / CA.was_successful / CA.restart!
+# (src/accelerator_interface.jl:58-130, src/solver.jl:268-276, src/setup.jl:44-49):
+#   update!(g, x):   f = x - g ; first call after a (re)start only stores (x, g, f);
+#                    j = iter % mem + 1; if j == 1 and iter != 0: the memory is full -> empty it (RestartedMemory), iter = 0;
+#                    G[:, j] = g - g_last ; F[:, j] = f - f_last ; modified Gram-Schmidt: Q[:, j], R[1:j, j] ; iter += 1
+#   accelerate!(g):  l = min(iter, mem) ; nothing if l < min_mem ; eta = R[1:l,1:l] \ (Q[:,1:l]' f) ;
+#                    fail if R is singular or ||eta||_2 > 1e4 ; else g <- g - G[:,1:l] eta (type II), success = true
+# The reference's tests only assert `status == :Solved` for accelerated runs (test/UnitTests/AccelerationTests), so the
+# restatement is anchored on those statuses and on the objective goldens, not on iteration counts.
+# --------------------------------------------------------------------------------------------
+class AndersonAccelerator:
+    ETA_MAX = 1e4
+
+    def __init__(self, dim: int, mem: int = 15, min_mem: int = 3):
+        self.dim = int(dim)
+        self.mem = max(1, min(int(mem), self.dim))
+        self.min_mem = int(min_mem)
+        self.G = np.zeros((self.dim, self.mem), order="F")
+        self.Q = np.zeros((self.dim, self.mem), order="F")
+        self.R = np.zeros((self.mem, self.mem), order="F")
+        self.f = np.zeros(self.dim); self.f_last = np.zeros(self.dim)
+        self.x_last = np.zeros(self.dim); self.g_last = np.zeros(self.dim)
+        self.eta = np.zeros(self.mem)
+        self.iter = 0
+        self.init_phase = True
+        self.success = False
+        self.num_accelerated_steps = 0
+        self.num_restarts = 0
+        self.fail_eta = 0
+        self.fail_singular = 0
+
+    def restart(self):                      # CA.restart! -> empty_history!
+        self.G[:] = 0.0; self.Q[:] = 0.0; self.R[:] = 0.0
+        self.f[:] = 0.0; self.f_last[:] = 0.0; self.x_last[:] = 0.0; self.g_last[:] = 0.0; self.eta[:] = 0.0
+        self.iter = 0
+        self.init_phase = True
+
+    def was_successful(self) -> bool:
+        return self.success
+
+    def update(self, g: np.ndarray, x: np.ndarray) -> None:
+        self.f[:] = x - g
+        if self.init_phase:
+            self.x_last[:] = x; self.g_last[:] = g; self.f_last[:] = self.f
+            self.init_phase = False
+            return
+        j = self.iter % self.mem               # 0-based column
+        if j == 0 and self.iter != 0:          # RestartedMemory: start over with an empty memory
+            self.G[:] = 0.0; self.Q[:] = 0.0; self.R[:] = 0.0
+            self.iter = 0
+            self.num_restarts += 1
+        self.G[:, j] = g - self.g_last
+        v = self.f - self.f_last
+        self.x_last[:] = x; self.g_last[:] = g; self.f_last[:] = self.f
+        for i in range(j):                     # qr!: modified Gram-Schmidt, column by column
+            r = float(self.Q[:, i] @ v)
+            self.R[i, j] = r
+            v = v - r * self.Q[:, i]
+        nv = float(np.linalg.norm(v))
+        self.R[j, j] = nv
+        with np.errstate(divide="ignore", invalid="ignore"):
+            self.Q[:, j] = v / nv
+        self.iter += 1
+
+    def accelerate(self, g: np.ndarray) -> None:
+        """Overwrites g with the accelerated candidate when the step succeeds."""
+        self.success = False
+        l = min(self.iter, self.mem)
+        if l < self.min_mem:
+            return
+        rhs = self.Q[:, :l].T @ self.f
+        R = self.R[:l, :l]
+        d = np.abs(np.diag(R))
+        if not np.all(np.isfinite(R)) or np.any(d == 0.0):      # LAPACK trtrs info > 0: exactly singular
+            self.fail_singular += 1
+            return
+        eta = np.zeros(l)
+        for i in range(l - 1, -1, -1):                          # back substitution
+            eta[i] = (rhs[i] - R[i, i + 1:] @ eta[i + 1:]) / R[i, i]
+        if not np.all(np.isfinite(eta)) or np.linalg.norm(eta) > self.ETA_MAX:
+            self.fail_eta += 1
+            return
+        self.eta[:l] = eta
+        g -= self.G[:, :l] @ eta
+        self.num_accelerated_steps += 1
+        self.success = True
+
+
 class Workspace:
     """Holds what `COSMO.Workspace` holds after `setup!` (src/setup.jl:18-64): scaled data,
     classified cones, rho vector, KKT solver."""
@@ -998,6 +1097,10 @@ class Workspace:
         self.ops = Operators(self.P, self.A)
         self.kkt = make_kkt_solver(st.kkt_solver, self.P, self.A, self.ops, st.sigma, self.rho_vec, st)
         self.is_optimized = False
+        # _make_accelerator! (src/setup.jl:10-16,44-49)
+        self.accelerator = AndersonAccelerator(n + m, st.acc_mem, st.acc_min_mem) if st.accelerator == "anderson" else None
+        self.accelerator_active = False
+        self.safeguarding_iter = 0
 
     # ---- residual helpers bound to the workspace
     def _result_info(self, x, s, mu):
@@ -1027,6 +1130,11 @@ class Workspace:
             self.s = self.sm.E * self.s
             classify_constraints(self.cones, self.b, st)
             self.rho_class = row_rho_class(self.cones)
+            if self.accelerator is not None:                    # src/setup.jl:47-49
+                self.accelerator.restart()
+                self.accelerator_active = False
+        acc = self.accelerator
+        self.safeguarding_iter = 0
         status = "Undetermined"
         cost = math.inf
         info = (math.inf, math.inf, 0.0, 0.0)
@@ -1060,9 +1168,19 @@ class Workspace:
         sol, s_tl = admm_x(w, s)                                # :137
         admm_w(w, sol, s_tl, s)                                 # :138
         it = 0
-        while it < st.max_iter:
+
+        def undisturbed():                                      # update_suggested (:284-292)
+            return acc is None or not acc.was_successful()
+
+        while it + self.safeguarding_iter < st.max_iter:        # :140
             it += 1
-            if infeasibility_check_due:                         # :145-148
+            if acc is not None:                                 # acceleration_pre! (accelerator_interface.jl:58-76)
+                if not self.accelerator_active and it >= st.acc_start_iter:
+                    self.accelerator_active = True
+                if self.accelerator_active:
+                    acc.update(w, w_prev)
+                    acc.accelerate(w)                           # overwrites w
+            if infeasibility_check_due and undisturbed():       # :145-148
                 mu = rho_vec * (w_prev[n:] - s)
                 dy[:] = mu
             w_prev[:] = w                                       # :151
@@ -1072,7 +1190,7 @@ class Workspace:
             if (st.adaptive_rho and st.adaptive_rho_interval > 0 and it % st.adaptive_rho_interval == 0
                     and (len(self.rho_updates) - 1) < st.adaptive_rho_max_adaptions):
                 rho_update_due = True
-            if rho_update_due:
+            if rho_update_due and undisturbed():                # :268
                 rho_update_due = False
                 mu = rho_vec * (w_prev[n:] - s)                 # :270
                 x = w_prev[:n]
@@ -1088,9 +1206,21 @@ class Workspace:
                     rho_vec[:] = make_rho_vec(new_rho, self.rho_class, st)
                     self.rho_updates.append(new_rho)
                     self.kkt.update_rho(rho_vec)
+                    if acc is not None:
+                        acc.restart()                           # :272-275: the ADMM operator changed
                     w[n:] = (1.0 / rho_vec) * mu + s            # solver.jl:278
             sol, s_tl = admm_x(w, s)                            # :154
             admm_w(w, sol, s_tl, s)                             # :155
+            # acceleration_post! (accelerator_interface.jl:85-117): safeguarding of the accelerated candidate
+            if acc is not None and self.accelerator_active and acc.was_successful() and st.safeguard:
+                nrm_tol = float(np.linalg.norm(acc.f)) * st.safeguard_tol
+                acc.f[:] = w_prev - w                           # compute_accelerated_res_norm! (:123-126)
+                if float(np.linalg.norm(acc.f)) > nrm_tol:
+                    w_prev[:] = acc.g_last; w[:] = acc.g_last   # reset_accelerated_vector! (:129-134)
+                    s[:] = w[n:]; project(s, cones, project_info)
+                    sol, s_tl = admm_x(w, s)
+                    admm_w(w, sol, s_tl, s)
+                    self.safeguarding_iter += 1
             if record is not None:
                 record(it, w, w_prev, s, sol)
             # ---- check_termination! (:303-356)
@@ -1108,7 +1238,7 @@ class Workspace:
                     break
             if it % st.check_infeasibility == 0:                # :326-327
                 infeasibility_check_due = True
-            elif infeasibility_check_due:                       # :329-348
+            elif infeasibility_check_due and undisturbed():     # :329-348
                 infeasibility_check_due = False
                 mu = rho_vec * (w_prev[n:] - s)
                 dy -= mu
@@ -1128,7 +1258,7 @@ class Workspace:
         mu = rho_vec * (w_prev[n:] - s)                         # :167
         iter_time = time.perf_counter() - t0
         x = w_prev[:n].copy()
-        if it == st.max_iter and status != "Time_limit_reached":   # :173-176 (overrides a status decided at iter == max_iter)
+        if it + self.safeguarding_iter == st.max_iter and status != "Time_limit_reached":   # :173-176 (overrides a status decided at iter == max_iter)
             info = self._result_info(x, s, mu)
             status = "Max_iter_reached"
         w_out, wp_out, s_sc, mu_sc = w.copy(), w_prev.copy(), s.copy(), mu.copy()
