@@ -42,6 +42,16 @@ class Params(C.Structure):
     ]
 
 
+class AccelParams(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("mem", C.c_int32), ("min_mem", C.c_int32), ("safeguard", C.c_int32),
+        ("start_iter", C.c_int64), ("safeguard_tol", C.c_double), ("eta_max", C.c_double),
+    ]
+
+
+ACCEL_EMPTY, ACCEL_ANDERSON = 0, 1
+
+
 class ResultStruct(C.Structure):
     _fields_ = [
         ("status", C.c_int32), ("n_rho_updates", C.c_int32),
@@ -79,6 +89,9 @@ SIGNATURES = {
     "cosmo_hip_update_rho": (C.c_int32, [C.c_void_p, _PD]),
     "cosmo_hip_set_scaling": (C.c_int32, [C.c_void_p, _PD, _PD, C.c_double]),
     "cosmo_hip_set_scaling_full": (C.c_int32, [C.c_void_p, _PD, _PD, _PD, _PD, C.c_double, C.c_double]),
+    "cosmo_hip_default_accel_params": (None, [C.POINTER(AccelParams)]),
+    "cosmo_hip_set_accelerator": (C.c_int32, [C.c_void_p, C.POINTER(AccelParams)]),
+    "cosmo_hip_get_accel_stats": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_scale_ruiz": (C.c_int32, [C.c_void_p, C.c_int64, C.c_double, C.c_double, _PD, _PD, C.POINTER(C.c_double)]),
     "cosmo_hip_update_qb": (C.c_int32, [C.c_void_p, _PD, _PD]),
     "cosmo_hip_get_rho_classes": (C.c_int32, [C.c_void_p, _PI32]),
@@ -235,6 +248,20 @@ class Handle:
     def update_rho(self, rho_vec):
         rv = _f64(rho_vec, self.m, "rho_vec")
         self._chk(self.lib.cosmo_hip_update_rho(self._h, _dp(rv)))
+
+    def set_accelerator(self, kind=ACCEL_ANDERSON, mem=15, min_mem=3, safeguard=True, safeguard_tol=2.0, start_iter=2):
+        """`_make_accelerator!` (src/setup.jl:10-16); kind ACCEL_EMPTY removes it."""
+        ap = AccelParams()
+        self.lib.cosmo_hip_default_accel_params(C.byref(ap))
+        ap.kind, ap.mem, ap.min_mem, ap.safeguard = int(kind), int(mem), int(min_mem), 1 if safeguard else 0
+        ap.safeguard_tol, ap.start_iter = float(safeguard_tol), int(start_iter)
+        self._chk(self.lib.cosmo_hip_set_accelerator(self._h, C.byref(ap)))
+
+    def accel_stats(self):
+        out = np.zeros(6, dtype=np.int64)
+        self._chk(self.lib.cosmo_hip_get_accel_stats(self._h, out.ctypes.data_as(_PI64)))
+        return dict(accelerated=int(out[0]), accepted=int(out[1]), declined=int(out[2]), restarts=int(out[3]), active=bool(out[4]),
+                    safeguarding_iter=int(out[5]))
 
     def scale_ruiz(self, iterations, min_scaling=1e-4, max_scaling=1e4):
         """Device Ruiz equilibration of the resident (unscaled) problem; returns (D, E, c)."""

@@ -1,0 +1,390 @@
+// anderson.hip -- Anderson acceleration of the ADMM fixed-point iteration on the device: the reference's default
+// AndersonAccelerator{T, Type2{QRDecomp}, RestartedMemory, NoRegularizer}(mem = 15) with safeguarding
+// (src/settings.jl:136-138, src/accelerator_interface.jl:58-130).  The accelerator itself lives in the external package
+// COSMOAccelerators.jl (Project.toml:8,27), which is not part of the reference tree: this file restates the published
+// algorithm exactly as oracle/cosmo_oracle.py::AndersonAccelerator does (PARITY UNPINNED -- see DESIGN.md section 7).
+//
+//   update!(g = w, x = w_prev):  f = x - g; G[:, j] = g - g_last; v = f - f_last; modified Gram-Schmidt of v against
+//                                Q[:, 0..j) -> R[0..j, j], Q[:, j]
+//   accelerate!(g = w):          eta = R \ (Q' f);  w -= G eta  unless R is singular or ||eta||_2 > 1e4
+//   safeguard:                   decline the candidate if ||w_prev - w|| after the step > tau * ||f||
+//
+// Layout: G and Q are (n+m) x mem column-major slabs in HBM (cfg4: 2 x 4.0M x 15 doubles = 0.96 GB of the 288 GB); every
+// pass over them is a coalesced stream.  The Gram-Schmidt sweep needs one global reduction per column; it is organised
+// so that ONE kernel per column does "v -= r_i Q_i" for the r_i reduced from the previous kernel's partials and, in the same
+// pass, the partial dots <Q_{i+1}, v>.  Reductions are fixed-order (wave butterfly -> LDS -> every consumer re-reduces
+// the producer's partials), so accelerated runs are bit-reproducible.  All data-dependent decisions (success of the least
+// squares step, safeguarding) are taken on the device and read back with the one synchronisation per iteration that the
+// accelerated loop needs anyway.
+#include "device_utils.h"
+#include <math.h>
+#include <stddef.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+
+#define AA_MAX_MEM 32
+
+struct AaFlags {
+  int success;        // CA.was_successful
+  int declined;       // safeguarding rejected the candidate
+  int fail_eta, fail_singular;
+  double nrm_f;       // ||f|| of the last update! (the non-accelerated fixed-point residual)
+  double nrm_f_acc;   // ||w_prev - w|| after the accelerated step
+  double eta_norm;
+  double R[AA_MAX_MEM * AA_MAX_MEM];   // column-major mem x mem
+  double eta[AA_MAX_MEM];
+};
+
+struct AaState {
+  cosmo_hip_accel_params prm;
+  long long N = 0;
+  int mem = 0;
+  double *G = nullptr, *Q = nullptr, *f = nullptr, *f_last = nullptr, *g_last = nullptr;
+  double* parts = nullptr;      // (AA_MAX_MEM + 1) x COSMO_MAX_PARTIALS
+  AaFlags* flags = nullptr;     // device
+  AaFlags* flags_host = nullptr;  // pinned
+  int grid = 1;
+  // host-tracked (data independent) state of the accelerator
+  int iter = 0;
+  bool init_phase = true;
+  bool active = false;
+  long long num_accelerated = 0, num_restarts = 0, num_declined = 0, num_accepted = 0;
+};
+
+namespace {
+
+#define AA_PARTS(S, k) ((S)->parts + (size_t)(k) * COSMO_MAX_PARTIALS)
+
+// f = x - g ; first call after a restart: remember (g, f) ; otherwise G_j = g - g_last, v = f - f_last (stored in Q_j) and the
+// partial dots <Q_0, v> (or ||v||^2 when j == 0)
+__global__ __launch_bounds__(COSMO_BS) void k_aa_prep(long long N, const double* __restrict__ g, const double* __restrict__ x, int init,
+                                                      double* __restrict__ f, double* __restrict__ f_last, double* __restrict__ g_last,
+                                                      double* __restrict__ Gj, double* __restrict__ v, const double* __restrict__ Q0, int j,
+                                                      double* __restrict__ p_out) {
+  __shared__ double red[COSMO_BS / 64];
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) {
+    const double gi = g[i];
+    const double fi = x[i] - gi;
+    f[i] = fi;
+    if (!init) {
+      Gj[i] = gi - g_last[i];
+      const double vi = fi - f_last[i];
+      v[i] = vi;
+      acc += (j == 0) ? vi * vi : Q0[i] * vi;
+    }
+    g_last[i] = gi;
+    f_last[i] = fi;
+  }
+  if (!init) {
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) p_out[blockIdx.x] = acc;
+  }
+}
+
+// Gram-Schmidt step i (< j): r = sum(p_in) ; R[i, j] = r ; v -= r Q_i ; partial <Q_{i+1}, v> (i + 1 < j) or ||v||^2 (i + 1 == j)
+__global__ __launch_bounds__(COSMO_BS) void k_aa_mgs(long long N, int nparts, const double* __restrict__ p_in, const double* __restrict__ Qi,
+                                                     const double* __restrict__ Qnext, double* __restrict__ v, int last, double* __restrict__ Rij,
+                                                     double* __restrict__ p_out) {
+  __shared__ double red[COSMO_BS / 64];
+  const double r = reduce_partials_sum(p_in, nparts, red);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *Rij = r;
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) {
+    const double vi = v[i] - r * Qi[i];
+    v[i] = vi;
+    acc += last ? vi * vi : Qnext[i] * vi;
+  }
+  __syncthreads();
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) p_out[blockIdx.x] = acc;
+}
+
+// R[j, j] = ||v|| ; Q_j = v / ||v||
+__global__ __launch_bounds__(COSMO_BS) void k_aa_normalize(long long N, int nparts, const double* __restrict__ p_in, double* __restrict__ v,
+                                                           double* __restrict__ Rjj) {
+  __shared__ double red[COSMO_BS / 64];
+  const double nv = sqrt(reduce_partials_sum(p_in, nparts, red));
+  if (blockIdx.x == 0 && threadIdx.x == 0) *Rjj = nv;
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) v[i] = v[i] / nv;
+}
+
+// partial Q[:, 0..l)' f and ||f||^2
+template <int L>
+__global__ __launch_bounds__(COSMO_BS) void k_aa_qtf(long long N, int l, const double* __restrict__ Q, const double* __restrict__ f,
+                                                     double* __restrict__ parts) {
+  __shared__ double red[COSMO_BS / 64];
+  double acc[L + 1];
+#pragma unroll
+  for (int k = 0; k <= L; ++k) acc[k] = 0.0;
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) {
+    const double fi = f[i];
+#pragma unroll
+    for (int k = 0; k < L; ++k) if (k < l) acc[k] += Q[(size_t)k * N + i] * fi;
+    acc[L] += fi * fi;
+  }
+#pragma unroll
+  for (int k = 0; k <= L; ++k) {
+    const int slot = (k == L) ? AA_MAX_MEM : k;
+    if (k < l || k == L) {
+      const double s = block_sum(acc[k], red);
+      if (threadIdx.x == 0) parts[(size_t)slot * COSMO_MAX_PARTIALS + blockIdx.x] = s;
+    }
+  }
+}
+
+// one workgroup: eta = R[0..l, 0..l) \ (Q' f) by back substitution ; success unless singular / non-finite / ||eta|| > eta_max
+__global__ __launch_bounds__(COSMO_BS) void k_aa_solve(int l, int nparts, const double* __restrict__ parts, double eta_max, AaFlags* __restrict__ F) {
+  __shared__ double red[COSMO_BS / 64];
+  __shared__ double rhs[AA_MAX_MEM];
+  for (int k = 0; k < l; ++k) {
+    const double s = reduce_partials_sum(parts + (size_t)k * COSMO_MAX_PARTIALS, nparts, red);
+    if (threadIdx.x == 0) rhs[k] = s;
+    __syncthreads();
+  }
+  const double ff = reduce_partials_sum(parts + (size_t)AA_MAX_MEM * COSMO_MAX_PARTIALS, nparts, red);
+  if (threadIdx.x == 0) {
+    F->nrm_f = sqrt(ff);
+    bool ok = true;
+    for (int c = 0; c < l && ok; ++c)
+      for (int r = 0; r <= c; ++r) { const double x = F->R[c * AA_MAX_MEM + r]; if (!(fabs(x) <= 1.79e308)) ok = false; }
+    for (int k = 0; k < l; ++k) if (F->R[k * AA_MAX_MEM + k] == 0.0) ok = false;
+    if (!ok) { F->success = 0; F->fail_singular += 1; return; }
+    double nrm2 = 0.0;
+    for (int i = l - 1; i >= 0; --i) {
+      double s = rhs[i];
+      for (int k = i + 1; k < l; ++k) s -= F->R[k * AA_MAX_MEM + i] * F->eta[k];
+      const double e = s / F->R[i * AA_MAX_MEM + i];
+      F->eta[i] = e;
+      nrm2 += e * e;
+    }
+    const double en = sqrt(nrm2);
+    F->eta_norm = en;
+    if (!(en <= eta_max)) { F->success = 0; F->fail_eta += 1; return; }     // also catches NaN
+    F->success = 1;
+  }
+}
+
+// w -= G[:, 0..l) eta  when the least-squares step succeeded
+template <int L>
+__global__ __launch_bounds__(COSMO_BS) void k_aa_apply(long long N, int l, const double* __restrict__ G, const AaFlags* __restrict__ F,
+                                                       double* __restrict__ w) {
+  if (!F->success) return;
+  double e[L];
+#pragma unroll
+  for (int k = 0; k < L; ++k) e[k] = (k < l) ? F->eta[k] : 0.0;
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < L; ++k) if (k < l) s += G[(size_t)k * N + i] * e[k];
+    w[i] = w[i] - s;
+  }
+}
+
+// f = w_prev - w and its partial squared norm (compute_accelerated_res_norm!, accelerator_interface.jl:123-126)
+__global__ __launch_bounds__(COSMO_BS) void k_aa_resnorm(long long N, const double* __restrict__ w, const double* __restrict__ w_prev,
+                                                         double* __restrict__ f, double* __restrict__ p_out) {
+  __shared__ double red[COSMO_BS / 64];
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) {
+    const double d = w_prev[i] - w[i];
+    f[i] = d;
+    acc += d * d;
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) p_out[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(COSMO_BS) void k_aa_guard(int nparts, const double* __restrict__ p_in, double tau, AaFlags* __restrict__ F) {
+  __shared__ double red[COSMO_BS / 64];
+  const double na = sqrt(reduce_partials_sum(p_in, nparts, red));
+  if (threadIdx.x == 0) {
+    F->nrm_f_acc = na;
+    F->declined = (na > F->nrm_f * tau) ? 1 : 0;
+  }
+}
+// reset_accelerated_vector! (accelerator_interface.jl:129-134)
+__global__ __launch_bounds__(COSMO_BS) void k_aa_reset(long long N, const double* __restrict__ g_last, double* __restrict__ w, double* __restrict__ w_prev) {
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) { const double g = g_last[i]; w[i] = g; w_prev[i] = g; }
+}
+
+inline AaState* aa_of(cosmo_hip_handle* h) { return static_cast<AaState*>(h->accel); }
+
+}  // namespace
+
+void aa_free(cosmo_hip_handle* h) {
+  AaState* S = aa_of(h);
+  if (!S) return;
+  for (double* p : {S->G, S->Q, S->f, S->f_last, S->g_last, S->parts}) if (p) (void)hipFree(p);
+  if (S->flags) (void)hipFree(S->flags);
+  if (S->flags_host) (void)hipHostFree(S->flags_host);
+  delete S;
+  h->accel = nullptr;
+}
+
+bool aa_enabled(const cosmo_hip_handle* h) { return h->accel != nullptr; }
+
+int32_t aa_restart(cosmo_hip_handle* h) {      // CA.restart! -> empty_history!
+  AaState* S = aa_of(h);
+  if (!S) return COSMO_HIP_OK;
+  const size_t slab = sizeof(double) * (size_t)S->N * (size_t)S->mem;
+  HIPCHK(h, hipMemsetAsync(S->G, 0, slab, h->stream));
+  HIPCHK(h, hipMemsetAsync(S->Q, 0, slab, h->stream));
+  HIPCHK(h, hipMemsetAsync(S->f, 0, sizeof(double) * (size_t)S->N, h->stream));
+  HIPCHK(h, hipMemsetAsync(S->f_last, 0, sizeof(double) * (size_t)S->N, h->stream));
+  HIPCHK(h, hipMemsetAsync(S->g_last, 0, sizeof(double) * (size_t)S->N, h->stream));
+  HIPCHK(h, hipMemsetAsync(S->flags, 0, sizeof(AaFlags), h->stream));
+  S->iter = 0;
+  S->init_phase = true;
+  return COSMO_HIP_OK;
+}
+
+extern "C" void cosmo_hip_default_accel_params(cosmo_hip_accel_params* p) {
+  if (!p) return;
+  p->kind = COSMO_HIP_ACCEL_ANDERSON; p->mem = 15; p->min_mem = 3; p->safeguard = 1;
+  p->start_iter = 2; p->safeguard_tol = 2.0; p->eta_max = 1e4;
+}
+
+extern "C" int32_t cosmo_hip_set_accelerator(cosmo_hip_handle* h, const cosmo_hip_accel_params* p) {
+  if (!h) return COSMO_HIP_ERR_INVALID;
+  if (hipSetDevice(h->device) != hipSuccess) return cosmo_fail(h, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
+  if (!h->have_problem) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_accelerator: set_problem first");
+  aa_free(h);
+  if (!p || p->kind == COSMO_HIP_ACCEL_EMPTY) return COSMO_HIP_OK;
+  if (p->kind != COSMO_HIP_ACCEL_ANDERSON) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "accelerator kind %d", (int)p->kind);
+  if (p->mem < 1 || p->mem > AA_MAX_MEM || p->min_mem < 1 || p->start_iter < 2 || !(p->safeguard_tol >= 0.0) || !(p->eta_max > 0.0))
+    return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_accelerator: need 1 <= mem <= %d, min_mem >= 1, start_iter >= 2", AA_MAX_MEM);
+  if (h->comm) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "acceleration with clique sharding is not built");
+  AaState* S = new AaState();
+  h->accel = S;
+  S->prm = *p;
+  S->N = h->n + h->m;
+  S->mem = (int)std::min<long long>(p->mem, std::max<long long>(S->N, 1));     // mem = min(mem, dim)
+  const size_t N = (size_t)std::max<long long>(S->N, 1);
+  HIPCHK(h, hipMalloc((void**)&S->G, sizeof(double) * N * S->mem));
+  HIPCHK(h, hipMalloc((void**)&S->Q, sizeof(double) * N * S->mem));
+  HIPCHK(h, hipMalloc((void**)&S->f, sizeof(double) * N));
+  HIPCHK(h, hipMalloc((void**)&S->f_last, sizeof(double) * N));
+  HIPCHK(h, hipMalloc((void**)&S->g_last, sizeof(double) * N));
+  HIPCHK(h, hipMalloc((void**)&S->parts, sizeof(double) * (AA_MAX_MEM + 1) * COSMO_MAX_PARTIALS));
+  HIPCHK(h, hipMalloc((void**)&S->flags, sizeof(AaFlags)));
+  HIPCHK(h, hipHostMalloc((void**)&S->flags_host, sizeof(AaFlags)));
+  memset(S->flags_host, 0, sizeof(AaFlags));
+  long long g = (S->N + (long long)COSMO_BS * 4 - 1) / ((long long)COSMO_BS * 4);
+  S->grid = (int)std::max<long long>(1, std::min<long long>(g, 1024));
+  CHK(aa_restart(h));
+  S->active = false;
+  return COSMO_HIP_OK;
+}
+
+// optimize! entry: a second optimize! restarts the accelerator and deactivates it (src/setup.jl:47-49)
+int32_t aa_begin_solve(cosmo_hip_handle* h) {
+  AaState* S = aa_of(h);
+  if (!S) return COSMO_HIP_OK;
+  CHK(aa_restart(h));
+  S->active = false;
+  S->num_accelerated = S->num_restarts = S->num_declined = S->num_accepted = 0;
+  return COSMO_HIP_OK;
+}
+
+// acceleration_pre! (accelerator_interface.jl:58-76): activation, CA.update!(w, w_prev), CA.accelerate!(w).
+// *attempted = an accelerate! kernel chain was enqueued and the success flag has to be fetched after the next sync.
+int32_t aa_enqueue_pre(cosmo_hip_handle* h, long long it, bool* attempted) {
+  AaState* S = aa_of(h);
+  *attempted = false;
+  if (!S) return COSMO_HIP_OK;
+  if (!S->active && it >= S->prm.start_iter) S->active = true;     // check_activation! (Immediate / IterActivation)
+  if (!S->active) return COSMO_HIP_OK;
+  const long long N = S->N;
+  const dim3 G(S->grid), B(COSMO_BS);
+  hipStream_t st = h->stream;
+  // ---- update! ----
+  if (S->init_phase) {
+    hipLaunchKernelGGL(k_aa_prep, G, B, 0, st, N, h->w, h->w_prev, 1, S->f, S->f_last, S->g_last, S->G, S->Q, S->Q, 0, AA_PARTS(S, 0));
+    S->init_phase = false;
+  } else {
+    int j = S->iter % S->mem;
+    if (j == 0 && S->iter != 0) {       // RestartedMemory: the memory is full -> start over
+      const size_t slab = sizeof(double) * (size_t)N * (size_t)S->mem;
+      HIPCHK(h, hipMemsetAsync(S->G, 0, slab, st));
+      HIPCHK(h, hipMemsetAsync(S->Q, 0, slab, st));
+      HIPCHK(h, hipMemsetAsync(S->flags, 0, offsetof(AaFlags, nrm_f), st));
+      HIPCHK(h, hipMemsetAsync(reinterpret_cast<char*>(S->flags) + offsetof(AaFlags, R), 0, sizeof(double) * AA_MAX_MEM * AA_MAX_MEM, st));
+      S->iter = 0;
+      S->num_restarts += 1;
+      j = 0;
+    }
+    double* Gj = S->G + (size_t)j * N;
+    double* v = S->Q + (size_t)j * N;
+    double* Rcol = reinterpret_cast<double*>(reinterpret_cast<char*>(S->flags) + offsetof(AaFlags, R)) + (size_t)j * AA_MAX_MEM;
+    hipLaunchKernelGGL(k_aa_prep, G, B, 0, st, N, h->w, h->w_prev, 0, S->f, S->f_last, S->g_last, Gj, v, S->Q, j, AA_PARTS(S, 0));
+    for (int i = 0; i < j; ++i) {
+      const int last = (i + 1 == j);
+      hipLaunchKernelGGL(k_aa_mgs, G, B, 0, st, N, S->grid, AA_PARTS(S, i & 1), S->Q + (size_t)i * N, S->Q + (size_t)(last ? i : i + 1) * N, v, last,
+                         Rcol + i, AA_PARTS(S, (i + 1) & 1));
+    }
+    hipLaunchKernelGGL(k_aa_normalize, G, B, 0, st, N, S->grid, AA_PARTS(S, j & 1), v, Rcol + j);
+    S->iter += 1;
+  }
+  // ---- accelerate! ----
+  const int l = std::min(S->iter, S->mem);
+  if (l < S->prm.min_mem) {
+    HIPCHK(h, hipMemsetAsync(&S->flags->success, 0, sizeof(int), st));
+    HIPCHK(h, hipGetLastError());
+    return COSMO_HIP_OK;
+  }
+  if (l <= 8) hipLaunchKernelGGL((k_aa_qtf<8>), G, B, 0, st, N, l, S->Q, S->f, S->parts);
+  else if (l <= 16) hipLaunchKernelGGL((k_aa_qtf<16>), G, B, 0, st, N, l, S->Q, S->f, S->parts);
+  else hipLaunchKernelGGL((k_aa_qtf<AA_MAX_MEM>), G, B, 0, st, N, l, S->Q, S->f, S->parts);
+  hipLaunchKernelGGL(k_aa_solve, dim3(1), B, 0, st, l, S->grid, S->parts, S->prm.eta_max, S->flags);
+  if (l <= 8) hipLaunchKernelGGL((k_aa_apply<8>), G, B, 0, st, N, l, S->G, S->flags, h->w);
+  else if (l <= 16) hipLaunchKernelGGL((k_aa_apply<16>), G, B, 0, st, N, l, S->G, S->flags, h->w);
+  else hipLaunchKernelGGL((k_aa_apply<AA_MAX_MEM>), G, B, 0, st, N, l, S->G, S->flags, h->w);
+  HIPCHK(h, hipGetLastError());
+  *attempted = true;
+  return COSMO_HIP_OK;
+}
+
+// after a stream synchronisation
+int32_t aa_fetch_flags(cosmo_hip_handle* h, int* success, int* declined) {
+  AaState* S = aa_of(h);
+  if (!S) { if (success) *success = 0; if (declined) *declined = 0; return COSMO_HIP_OK; }
+  HIPCHK(h, hipMemcpyAsync(S->flags_host, S->flags, offsetof(AaFlags, R), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (success) *success = S->flags_host->success;
+  if (declined) *declined = S->flags_host->declined;
+  return COSMO_HIP_OK;
+}
+
+// acceleration_post! part 1 (accelerator_interface.jl:85-100): residual of the accelerated point against tau * ||f||
+int32_t aa_enqueue_guard(cosmo_hip_handle* h) {
+  AaState* S = aa_of(h);
+  hipLaunchKernelGGL(k_aa_resnorm, dim3(S->grid), dim3(COSMO_BS), 0, h->stream, S->N, h->w, h->w_prev, S->f, AA_PARTS(S, 0));
+  hipLaunchKernelGGL(k_aa_guard, dim3(1), dim3(COSMO_BS), 0, h->stream, S->grid, AA_PARTS(S, 0), S->prm.safeguard_tol, S->flags);
+  HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}
+int32_t aa_enqueue_reset(cosmo_hip_handle* h) {
+  AaState* S = aa_of(h);
+  hipLaunchKernelGGL(k_aa_reset, dim3(S->grid), dim3(COSMO_BS), 0, h->stream, S->N, S->g_last, h->w, h->w_prev);
+  HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}
+bool aa_safeguarded(const cosmo_hip_handle* h) { const AaState* S = static_cast<const AaState*>(h->accel); return S && S->prm.safeguard != 0; }
+bool aa_active(const cosmo_hip_handle* h) { const AaState* S = static_cast<const AaState*>(h->accel); return S && S->active; }
+void aa_count(cosmo_hip_handle* h, int accelerated, int declined) {
+  AaState* S = aa_of(h);
+  if (!S) return;
+  S->num_accelerated += accelerated;
+  if (accelerated && S->prm.safeguard) { if (declined) S->num_declined += 1; else S->num_accepted += 1; }
+}
+
+extern "C" int32_t cosmo_hip_get_accel_stats(cosmo_hip_handle* h, int64_t out[6]) {
+  if (!h || !out) return COSMO_HIP_ERR_INVALID;
+  AaState* S = aa_of(h);
+  for (int i = 0; i < 6; ++i) out[i] = 0;
+  out[5] = h->safeguarding_iter;
+  if (!S) return COSMO_HIP_OK;
+  out[0] = S->num_accelerated; out[1] = S->num_accepted; out[2] = S->num_declined; out[3] = S->num_restarts; out[4] = S->active ? 1 : 0;
+  return COSMO_HIP_OK;
+}

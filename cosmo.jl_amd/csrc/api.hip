@@ -243,6 +243,7 @@ extern "C" int32_t cosmo_hip_destroy(cosmo_hip_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   free_csr(h->A); free_csr(h->AT); free_csr(h->P); free_csr(h->PT);
   (void)cosmo_hip_comm_destroy(h);
+  aa_free(h);
   free_vectors(h);
   free_cones(h);
   dfree(&h->partials);
@@ -831,6 +832,107 @@ extern "C" int32_t cosmo_hip_residuals(cosmo_hip_handle* h, double out[5]) {
   return COSMO_HIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The accelerated loop (src/solver.jl:140-165 with acceleration_pre! / acceleration_post!, src/accelerator_interface.jl).
+// One host synchronisation per iteration (two when a deferred rho update / infeasibility check is pending or the
+// safeguard has to be evaluated): the success flag of the least-squares step and the safeguarding decision are taken on
+// the device and steer what the host enqueues next, exactly where the reference branches on CA.was_successful.
+// ---------------------------------------------------------------------------------------------------------------------
+static int32_t enqueue_admm_step(cosmo_hip_handle* h, bool rho_rules) {
+  CHK(launch_z(h, 1));
+  CHK(launch_soc(h, h->s, 1));
+  CHK(cone3_enqueue_project(h, h->s, 1));
+  CHK(psd_enqueue_project(h, h->s, true));
+  if (rho_rules) CHK(enqueue_check(h, 1, 2));
+  CHK(enqueue_solve_in_loop(h));
+  return COSMO_HIP_OK;
+}
+static int32_t sync_and_resolve(cosmo_hip_handle* h) {
+  CHK(sync_ctl(h));
+  if (h->ctl_host->stalled) CHK(resolve_stall(h));
+  adapt_budget(h);
+  hipLaunchKernelGGL(k_ctl_reset_kmax, dim3(1), dim3(1), 0, h->stream, h->ctl);
+  return COSMO_HIP_OK;
+}
+
+static int32_t optimize_accelerated(cosmo_hip_handle* h, int* status_out, long long* iter_out, const std::chrono::steady_clock::time_point t0) {
+  const cosmo_hip_params& p = h->prm;
+  if (h->comm) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "acceleration with clique sharding is not built");
+  CHK(aa_begin_solve(h));
+  h->safeguarding_iter = 0;
+  CHK(admm_init_enqueue(h));
+  int status = COSMO_HIP_UNDETERMINED;
+  long long it = 0;
+  bool inf_check_due = false, rho_update_due = false;
+  const long long ct = p.check_termination, ci = p.check_infeasibility;
+  int n_rho_seen = h->ctl_host->n_rho_updates;
+  while (it + h->safeguarding_iter < p.max_iter) {
+    it += 1;
+    bool attempted = false;
+    int success = 0, declined = 0;
+    CHK(aa_enqueue_pre(h, it, &attempted));                                   // acceleration_pre!
+    if (p.adaptive_rho && p.adaptive_rho_interval > 0 && (it % p.adaptive_rho_interval) == 0 &&
+        (long long)(n_rho_seen - 1) < p.adaptive_rho_max_adaptions)
+      rho_update_due = true;                                                  // solver.jl:262-264
+    bool have_success = !attempted;
+    if (attempted && (inf_check_due || rho_update_due)) { CHK(aa_fetch_flags(h, &success, nullptr)); have_success = true; }
+    if (inf_check_due && have_success && !success) CHK(infeas_enqueue_capture(h));      // solver.jl:145-148
+    const bool do_rho = rho_update_due && have_success && !success;          // update_suggested (solver.jl:268,284-292)
+    if (do_rho) rho_update_due = false;
+    CHK(enqueue_admm_step(h, do_rho));
+    CHK(sync_and_resolve(h));
+    if (h->ctl_host->error) return cosmo_fail(h, h->ctl_host->error, "device error %d in the accelerated loop", h->ctl_host->error);
+    if (!have_success) CHK(aa_fetch_flags(h, &success, nullptr));
+    if (do_rho && h->ctl_host->n_rho_updates != n_rho_seen) {                 // solver.jl:272-275
+      n_rho_seen = h->ctl_host->n_rho_updates;
+      CHK(aa_restart(h));
+    }
+    if (aa_active(h) && success) {                                            // acceleration_post!
+      if (aa_safeguarded(h)) {
+        CHK(aa_enqueue_guard(h));
+        CHK(aa_fetch_flags(h, nullptr, &declined));
+        if (declined) {
+          CHK(aa_enqueue_reset(h));
+          CHK(enqueue_admm_step(h, false));
+          CHK(sync_and_resolve(h));
+          h->safeguarding_iter += 1;
+        }
+      }
+      aa_count(h, 1, declined);
+    }
+    if ((it % ct) == 0 || it == 1) {                                          // check_termination! (solver.jl:306-323)
+      CHK(enqueue_check(h, 1, 1));
+      CHK(sync_ctl(h));
+      if (h->ctl_host->status != 0) { status = h->ctl_host->status; break; }
+    }
+    if (ci > 0 && ci < (1LL << 40) && (it % ci) == 0) {
+      inf_check_due = true;
+    } else if (inf_check_due && !success) {                                   // solver.jl:329-348
+      inf_check_due = false;
+      int32_t st = 0;
+      CHK(infeas_check(h, &st));
+      if (st != 0) {
+        hipLaunchKernelGGL(k_ctl_set_status, dim3(1), dim3(1), 0, h->stream, h->ctl, st);
+        CHK(sync_ctl(h));
+        status = st;
+        break;
+      }
+    }
+    if (p.time_limit != 0.0) {
+      const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (el > p.time_limit) { CHK(enqueue_check(h, 0, 0)); CHK(sync_ctl(h)); status = COSMO_HIP_TIME_LIMIT_REACHED; break; }
+    }
+  }
+  if (it + h->safeguarding_iter == p.max_iter && status != COSMO_HIP_TIME_LIMIT_REACHED) {   // solver.jl:173-176
+    CHK(enqueue_check(h, 0, 0));
+    CHK(sync_ctl(h));
+    status = COSMO_HIP_MAX_ITER_REACHED;
+  }
+  *status_out = status;
+  *iter_out = it;
+  return COSMO_HIP_OK;
+}
+
 extern "C" int32_t cosmo_hip_optimize(cosmo_hip_handle* h, cosmo_hip_result* res) {
   ENTER(h);
   if (!h->have_iterates || !res) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "optimize: set_iterates first");
@@ -838,14 +940,16 @@ extern "C" int32_t cosmo_hip_optimize(cosmo_hip_handle* h, cosmo_hip_result* res
   const cosmo_hip_params& p = h->prm;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   const auto t0 = std::chrono::steady_clock::now();
-  const long long kkt0 = h->ctl_host->kkt_iters_total;
-  (void)kkt0;
-  CHK(admm_init_enqueue(h));
-  const long long base_iters = h->ctl_host->kkt_iters_total;
-  (void)base_iters;
   int status = COSMO_HIP_UNDETERMINED;
   long long it = 0;
-  while (it < p.max_iter) {
+  long long acc_iter = -1;
+  if (aa_enabled(h)) {
+    CHK(optimize_accelerated(h, &status, &acc_iter, t0));
+  } else {
+    h->safeguarding_iter = 0;
+    CHK(admm_init_enqueue(h));
+  }
+  while (!aa_enabled(h) && it < p.max_iter) {
     long long next = (it == 0) ? 1 : ((it / p.check_termination) + 1) * (long long)p.check_termination;
     next = std::min(next, next_inf_iter(h, it));
     if (next > p.max_iter) next = p.max_iter;
@@ -865,7 +969,7 @@ extern "C" int32_t cosmo_hip_optimize(cosmo_hip_handle* h, cosmo_hip_result* res
       }
     }
   }
-  if (h->ctl_host->iter == p.max_iter && status != COSMO_HIP_TIME_LIMIT_REACHED) {
+  if (!aa_enabled(h) && h->ctl_host->iter == p.max_iter && status != COSMO_HIP_TIME_LIMIT_REACHED) {
     // solver.jl:173-176: `if iter == max_iter` overrides ANY status decided in that very iteration (reference quirk kept)
     CHK(enqueue_check(h, 0, 0));
     CHK(sync_ctl(h));
@@ -876,7 +980,7 @@ extern "C" int32_t cosmo_hip_optimize(cosmo_hip_handle* h, cosmo_hip_result* res
   const auto t1 = std::chrono::steady_clock::now();
   const Ctl* c = h->ctl_host;
   res->status = status;
-  res->iter = c->iter;
+  res->iter = (acc_iter >= 0) ? acc_iter : c->iter;
   res->kkt_iters_total = c->kkt_iters_total;
   res->kkt_solves = c->solves;
   res->cost = (status == COSMO_HIP_PRIMAL_INFEASIBLE) ? INFINITY : (status == COSMO_HIP_DUAL_INFEASIBLE) ? -INFINITY : c->cost;   // solver.jl:339,345

@@ -121,6 +121,29 @@ function scale_ruiz!(h::Handle, ws::COSMO.Workspace{Float64})
     nothing
 end
 
+# mirrors cosmo_hip_accel_params
+struct AccelParams
+    kind::Int32; mem::Int32; min_mem::Int32; safeguard::Int32; start_iter::Int64; safeguard_tol::Float64; eta_max::Float64
+end
+
+# settings.accelerator is an OptionsFactory{<:AbstractAccelerator} (src/settings.jl:96,136,148-150).  The device builds the
+# reference's default AndersonAccelerator{Float64, Type2{QRDecomp}, RestartedMemory, NoRegularizer}; EmptyAccelerator maps to
+# "none"; any other variant is rejected (error) rather than silently replaced.
+function set_accelerator!(h::Handle, settings::COSMO.Settings{Float64})
+    AT = settings.accelerator.ObjectType
+    AT <: COSMO.EmptyAccelerator && return nothing
+    AT == COSMO.AndersonAccelerator{Float64, COSMO.Type2{COSMO.QRDecomp}, COSMO.RestartedMemory, COSMO.NoRegularizer} ||
+        error("accelerator $(AT) is not built on the MI355X path; use the default Type2{QRDecomp}/RestartedMemory variant or EmptyAccelerator")
+    kw = settings.accelerator.kwargs
+    act = get(kw, :activation_reason, COSMO.ImmediateActivation())
+    start = act isa COSMO.IterActivation ? act.start_iter : 2
+    act isa COSMO.AccuracyActivation && error("AccuracyActivation is not built on the MI355X path")
+    p = AccelParams(Int32(1), Int32(get(kw, :mem, 10)), Int32(get(kw, :min_mem, 3)), Int32(settings.safeguard ? 1 : 0), Int64(start),
+                    Float64(settings.safeguard_tol), 1e4)
+    check(h, ccall((:cosmo_hip_set_accelerator, LIB[]), Int32, (Ptr{Cvoid}, Ref{AccelParams}), h.ptr, Ref(p)))
+    nothing
+end
+
 function params_from(settings::COSMO.Settings{Float64}, kkt_kind::Int32; tol_constant = 1.0, tol_exponent = 1.5)
     s = settings
     Params(s.sigma, s.alpha, s.rho, s.eps_abs, s.eps_rel, s.eps_prim_inf, s.eps_dual_inf, tol_constant, tol_exponent,
@@ -223,6 +246,7 @@ function optimize_hip!(ws::COSMO.Workspace{Float64}; device::Integer = 0, kkt_ki
     D = sc ? ws.sm.D.diag : ones(n); Dinv = sc ? ws.sm.Dinv.diag : ones(n); E = sc ? ws.sm.E.diag : ones(m); Einv = sc ? ws.sm.Einv.diag : ones(m)
     GC.@preserve D Dinv E Einv check(h, ccall((:cosmo_hip_set_scaling_full, LIB[]), Int32,
         (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble), h.ptr, D, Dinv, E, Einv, ws.sm.c[], ws.sm.cinv[]))
+    set_accelerator!(h, settings)                                              # _make_accelerator! (src/setup.jl:10-16,44-49)
     x0 = ws.vars.x; s0 = ws.vars.s.data; mu0 = ws.vars.μ
     GC.@preserve x0 s0 mu0 check(h, ccall((:cosmo_hip_set_iterates, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
         h.ptr, x0, s0, mu0))                                                  # src/solver.jl:128-129

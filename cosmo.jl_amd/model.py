@@ -76,6 +76,14 @@ class Settings:
     time_limit: float = 0.0
     device: int = 0
     device_scaling: bool = True      # run scale_ruiz! on the MI355X (cosmo_hip_scale_ruiz) instead of on the host
+    # accelerator / safeguard / safeguard_tol (src/settings.jl:96-98,136-138).  NOTE: the reference's default is
+    # AndersonAccelerator{T, Type2{QRDecomp}, RestartedMemory, NoRegularizer}(mem = 15); this mirror defaults to the
+    # EmptyAccelerator because the Anderson path restates an external package (parity unpinned) -- opt in with
+    # accelerator=AndersonAccelerator or with_options(AndersonAccelerator, mem=...).
+    accelerator: object = None
+    accelerator_activation: int = 2  # ImmediateActivation; k = IterActivation(k)
+    safeguard: bool = True
+    safeguard_tol: float = 2.0
 
 
 # ---- AbstractConvexSet subtypes on the hot path (src/convexset.jl) ---------------------------------------------------
@@ -147,6 +155,14 @@ class DualPowerCone(PowerCone):
 
 
 _SCALAR_SCALED = (_ffi.SOC, _ffi.PSD_SQUARE, _ffi.PSD_TRIANGLE, _ffi.EXP, _ffi.DUAL_EXP, _ffi.POW, _ffi.DUAL_POW)   # src/convexset.jl:956-958
+
+
+class EmptyAccelerator:
+    """CA.EmptyAccelerator"""
+
+
+class AndersonAccelerator:
+    """AndersonAccelerator{T, Type2{QRDecomp}, RestartedMemory, NoRegularizer} -- the one variant built on the device."""
 
 
 class Box(AbstractConvexSet):
@@ -441,6 +457,19 @@ def _params_from_settings(h, st: Settings):
     return p
 
 
+def _install_accelerator(h, st: Settings):
+    """`_make_accelerator!` (src/setup.jl:10-16)."""
+    acc, kw = st.accelerator, {}
+    if isinstance(acc, OptionsFactory):
+        acc, kw = acc.solver, acc.kwargs
+    if acc is None or acc is EmptyAccelerator:
+        return
+    if acc is not AndersonAccelerator:
+        raise ValueError("unknown accelerator %r" % (acc,))
+    h.set_accelerator(_ffi.ACCEL_ANDERSON, mem=kw.get("mem", 15), min_mem=kw.get("min_mem", 3), safeguard=st.safeguard,
+                      safeguard_tol=st.safeguard_tol, start_iter=st.accelerator_activation)
+
+
 def setup(model: Model):
     """`setup!` (src/setup.jl:18-64): scaling once, then hand the scaled problem to the device library
     (the `_make_kkt_solver!` step, :1-7, is where the reference constructs its AbstractKKTSolver plugin)."""
@@ -473,6 +502,7 @@ def setup(model: Model):
         model.is_scaled = True
         model.device_scaled = True            # host copies of P and A stay unscaled
         h.set_params(_params_from_settings(h, st))
+        _install_accelerator(h, st)
         model.handle = h
     elif st.scaling != 0 and not model.is_scaled:
         model.sm = scale_ruiz(model.P, model.q, model.A, model.b, model.sets, st)
@@ -488,6 +518,7 @@ def setup(model: Model):
         h = make_handle()
         h.set_params(_params_from_settings(h, st))                 # set_rho_vec! happens inside (first solve only)
         h.set_scaling_full(sm.D, sm.Dinv, sm.E, sm.Einv, sm.c, sm.cinv)
+        _install_accelerator(h, st)
         model.handle = h
 
 

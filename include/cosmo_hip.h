@@ -100,6 +100,20 @@ typedef struct cosmo_hip_params {
   int32_t unscale_residuals;         /* 1 iff settings.scaling != 0 (src/residuals.jl:43) */
 } cosmo_hip_params;
 
+/* Accelerator of the fixed-point iteration (settings.accelerator, safeguard, safeguard_tol: src/settings.jl:96-98,136-138;
+ * activation: src/accelerator_interface.jl:5-47).  ANDERSON = AndersonAccelerator{T, Type2{QRDecomp}, RestartedMemory,
+ * NoRegularizer} of COSMOAccelerators.jl, the reference's default. */
+enum { COSMO_HIP_ACCEL_EMPTY = 0, COSMO_HIP_ACCEL_ANDERSON = 1 };
+typedef struct cosmo_hip_accel_params {
+  int32_t kind;          /* COSMO_HIP_ACCEL_*                                                   */
+  int32_t mem;           /* 15  (with_options(..., mem = 15), src/settings.jl:136); <= 32        */
+  int32_t min_mem;       /* 3   columns needed before a step is attempted                        */
+  int32_t safeguard;     /* 1   (settings.safeguard)                                             */
+  int64_t start_iter;    /* 2 = ImmediateActivation; k = IterActivation(k)                       */
+  double safeguard_tol;  /* 2.0 (settings.safeguard_tol)                                         */
+  double eta_max;        /* 1e4: a least-squares solution with a larger 2-norm is rejected       */
+} cosmo_hip_accel_params;
+
 /* What `optimize!` returns to its caller besides the iterates (Result / ResultInfo, src/types.jl:65-112). */
 #define COSMO_HIP_MAX_RHO_UPDATES 64
 typedef struct cosmo_hip_result {
@@ -161,6 +175,15 @@ int32_t cosmo_hip_set_scaling(cosmo_hip_handle* h, const double* Dinv, const dou
 int32_t cosmo_hip_set_scaling_full(cosmo_hip_handle* h, const double* D, const double* Dinv, const double* E, const double* Einv,
                                    double c, double cinv);
 /* Replaces COSMO.update!(model; q, b) on already-scaled vectors (src/interface.jl:187-211). NULL = keep. */
+/* Replaces _make_accelerator! (src/setup.jl:10-16): installs (or with kind EMPTY / NULL removes) the accelerator used by
+ * cosmo_hip_optimize.  With an accelerator the loop follows src/solver.jl:140-165 including acceleration_pre! /
+ * acceleration_post! (safeguarding re-does the ADMM step from the last non-accelerated point and counts it in
+ * safeguarding_iter), deferred rho updates and deferred infeasibility checks (update_suggested, src/solver.jl:284-292).
+ * Call after cosmo_hip_set_problem; every cosmo_hip_set_iterates restarts it (src/setup.jl:47-49). */
+void cosmo_hip_default_accel_params(cosmo_hip_accel_params* p);
+int32_t cosmo_hip_set_accelerator(cosmo_hip_handle* h, const cosmo_hip_accel_params* p);
+/* out = {accelerated steps, safeguard accepted, safeguard declined, memory restarts, active, safeguarding_iter} */
+int32_t cosmo_hip_get_accel_stats(cosmo_hip_handle* h, int64_t out[6]);
 /* Replaces scale_ruiz! (src/scaling.jl:21-116) for callers that hand over the UNSCALED problem: call after
  * cosmo_hip_set_problem + cosmo_hip_set_cones (unscaled data and Box bounds) and before cosmo_hip_set_params.  Runs
  * `iterations` (settings.scaling) steps of the modified Ruiz equilibration on the device-resident P, A, q, b, rectifies the
