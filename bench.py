@@ -96,7 +96,7 @@ def main():
     st.device = local_rank
     model = cj.Model()
     model.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)
-    cj.model.setup(model)                       # Ruiz scaling on the host (setup!, excluded from iter_time) + upload
+    cj.model.setup(model)                       # upload + Ruiz scaling on the device (setup!, excluded from iter_time)
     h = model.handle
     n, m = model.n, model.m
     nnzA, nnzP = model.A.nnz, model.P.nnz
@@ -177,7 +177,7 @@ def main():
                        "algorithmic_bytes_per_iteration": b_iter},
             "roofline": roof,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(prob, None, args.cpu_sample_iters if not args.small else 200)
             out["config"]["gpu_over_cpu"] = round((value / world) / out["cpu_baseline"]["value"], 2)
         print(json.dumps(out), flush=True)
