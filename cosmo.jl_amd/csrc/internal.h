@@ -125,6 +125,7 @@ void aa_count(cosmo_hip_handle* h, int accelerated, int declined);
   double* c3_alpha = nullptr;
   std::vector<int> c3_cone_index;
   PsdPlan* psd = nullptr;
+  void* psd_polar = nullptr;      // PolarPlan (psd_polar.hip): large cones
   void* accel = nullptr;          // AaState (anderson.hip)
   long long safeguarding_iter = 0;
   // clique sharding (comm.hip): this rank projects the SOC / PSD cones cone_lo <= k < cone_hi (cone_hi < 0: all cones)
@@ -208,6 +209,12 @@ void cone3_free(cosmo_hip_handle* h);
 int32_t cone3_enqueue_project(cosmo_hip_handle* h, double* s, int guard);
 int32_t cone3_enqueue_in_dual_neg(cosmo_hip_handle* h, const double* v, double tol, int* flag);
 int32_t cone3_get_branches(cosmo_hip_handle* h, int32_t* out_per_cone);
+
+// PSD projection of large cones by the matrix-sign iteration (psd_polar.hip)
+int32_t polar_plan_create(cosmo_hip_handle* h);
+void polar_plan_destroy(cosmo_hip_handle* h);
+bool polar_enabled(const cosmo_hip_handle* h);
+int32_t polar_enqueue_project(cosmo_hip_handle* h, double* s, int guard);
 
 // PSD projection (psd.hip)
 int32_t psd_plan_create(cosmo_hip_handle* h);

@@ -22,44 +22,7 @@
 #include <math.h>
 #include <stdlib.h>
 
-typedef double v4d __attribute__((ext_vector_type(4)));
-#define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
-#define WLD 17  // leading dimension of the 16x16 LDS tiles (padded against bank conflicts)
-#define PSD_MAX_SWEEPS 40
-#define PSD_EPS 2.220446049250313e-16
-
-struct PsdConeDev {
-  int off;        // first row of the cone in s
-  int d;          // matrix side
-  int kind;       // COSMO_HIP_PSD_SQUARE / COSMO_HIP_PSD_TRIANGLE
-  int ld;         // leading dimension of G (multiple of 16 >= d)
-  int ncp;        // padded number of columns: nb * 8, nb even
-  int nb;         // number of 8-column blocks (even)
-  long long goff; // offset of G in the workspace (doubles)
-  int coff;       // offset of the per-column arrays
-  int cone_index; // index in the composite set
-};
-
-struct PsdPlan {
-  std::vector<PsdConeDev> cones;       // all PSD cones with d > 1
-  std::vector<int> tiny, wg, large;    // indices into `cones` by size class
-  std::vector<int> wg_waves;           // waves per workgroup for every wg-class launch group
-  std::vector<std::vector<int>> wg_groups;
-  PsdConeDev* d_cones = nullptr;
-  int *d_tiny = nullptr, *d_large = nullptr;
-  std::vector<int*> d_wg_groups;
-  double* G = nullptr;
-  double* colw = nullptr;              // per column: sigma then scale factor
-  double* cshift = nullptr;            // per cone shift c
-  int* rank = nullptr;                 // per cone nnz_lambda
-  int* flags = nullptr;                // [0] sweep-rotated flag (large path), [1] error flag
-  double* eigmin = nullptr;            // per cone smallest eigenvalue (definiteness tests)
-  long long gsize = 0;
-  int ncolw = 0;
-  int last_large_sweeps = 0;
-  double tol_factor = 0.125;   // rotate while |w_pq| > tol_factor * d * eps * sqrt(w_pp w_qq)
-  int dbg = 0;
-};
+#include "psd_internal.h"
 
 // ---------------------------------------------------------------------------------------------------------------------
 // 16x16 Jacobi machinery (one wave).  W and J live in LDS in row-major [16][WLD]; lane l works on column (l & 15) and
@@ -616,6 +579,7 @@ void psd_plan_destroy(cosmo_hip_handle* h) {
   if (p->eigmin) (void)hipFree(p->eigmin);
   delete p;
   h->psd = nullptr;
+  polar_plan_destroy(h);
 }
 
 int32_t psd_plan_create(cosmo_hip_handle* h) {
@@ -687,7 +651,7 @@ int32_t psd_plan_create(cosmo_hip_handle* h) {
   HIPCHK(h, hipMalloc((void**)&p->eigmin, p->cones.size() * sizeof(double)));
   HIPCHK(h, hipMemset(p->rank, 0, p->cones.size() * sizeof(int)));
   HIPCHK(h, hipMemset(p->flags, 0, 4 * sizeof(int)));
-  return COSMO_HIP_OK;
+  return polar_plan_create(h);   // d > 256: matrix-sign iteration on the matrix cores (psd_polar.hip)
 }
 
 // host-paced Jacobi sweeps of the multi-workgroup path (one launch per tournament step, flag read once per sweep)
@@ -709,7 +673,7 @@ static int32_t psd_large_sweeps(cosmo_hip_handle* h, int n, int nbmax) {
   return COSMO_HIP_OK;
 }
 
-bool psd_needs_sync(const cosmo_hip_handle* h) { return h->psd && !h->psd->large.empty(); }
+bool psd_needs_sync(const cosmo_hip_handle* h) { return h->psd && !h->psd->large.empty() && !polar_enabled(h); }
 
 int32_t psd_enqueue_project(cosmo_hip_handle* h, double* s, bool guard_b) {
   PsdPlan* p = h->psd;
@@ -735,7 +699,9 @@ int32_t psd_enqueue_project(cosmo_hip_handle* h, double* s, bool guard_b) {
     for (int idx : p->wg_groups[gi]) { const int nt = p->cones[idx].ld / 16; maxtiles = std::max(maxtiles, nt * (nt + 1) / 2); }
     hipLaunchKernelGGL(k_psd_syrk, dim3((maxtiles + 3) / 4, n), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, lst, p->d_cones, p->G, s);
   }
-  if (!p->large.empty()) {
+  if (!p->large.empty() && polar_enabled(h)) {
+    CHK(polar_enqueue_project(h, s, guard));
+  } else if (!p->large.empty()) {
     // host-paced: one launch per tournament step, convergence flag read once per sweep
     if (guard) {
       CHK(sync_ctl(h));

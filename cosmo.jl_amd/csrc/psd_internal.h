@@ -1,0 +1,44 @@
+// psd_internal.h -- declarations shared by psd.hip (Jacobi eigensolvers) and psd_polar.hip (polar-iteration projection).
+#pragma once
+#include "device_utils.h"
+#include <vector>
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+#define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+#define WLD 17  // leading dimension of the 16x16 LDS tiles (padded against bank conflicts)
+#define PSD_MAX_SWEEPS 40
+#define PSD_EPS 2.220446049250313e-16
+
+struct PsdConeDev {
+  int off;        // first row of the cone in s
+  int d;          // matrix side
+  int kind;       // COSMO_HIP_PSD_SQUARE / COSMO_HIP_PSD_TRIANGLE
+  int ld;         // leading dimension of G (multiple of 16 >= d)
+  int ncp;        // padded number of columns: nb * 8, nb even
+  int nb;         // number of 8-column blocks (even)
+  long long goff; // offset of G in the workspace (doubles)
+  int coff;       // offset of the per-column arrays
+  int cone_index; // index in the composite set
+};
+
+struct PsdPlan {
+  std::vector<PsdConeDev> cones;       // all PSD cones with d > 1
+  std::vector<int> tiny, wg, large;    // indices into `cones` by size class
+  std::vector<int> wg_waves;           // waves per workgroup for every wg-class launch group
+  std::vector<std::vector<int>> wg_groups;
+  PsdConeDev* d_cones = nullptr;
+  int *d_tiny = nullptr, *d_large = nullptr;
+  std::vector<int*> d_wg_groups;
+  double* G = nullptr;
+  double* colw = nullptr;              // per column: sigma then scale factor
+  double* cshift = nullptr;            // per cone shift c
+  int* rank = nullptr;                 // per cone nnz_lambda
+  int* flags = nullptr;                // [0] sweep-rotated flag (large path), [1] error flag
+  double* eigmin = nullptr;            // per cone smallest eigenvalue (definiteness tests)
+  long long gsize = 0;
+  int ncolw = 0;
+  int last_large_sweeps = 0;
+  double tol_factor = 0.125;   // rotate while |w_pq| > tol_factor * d * eps * sqrt(w_pp w_qq)
+  int dbg = 0;
+};
+

@@ -1,0 +1,278 @@
+// psd_polar.hip -- PSD projection of LARGE cones (d > 256) as a matrix-sign (polar) iteration made only of symmetric
+// matrix products on the fp64 matrix cores.
+//
+// Reference semantics (src/convexset.jl:219-263): X+ = sum_{lambda_j > 0} lambda_j z_j z_j'.  For symmetric X this is
+//     X+ = (X + |X|) / 2 ,  |X| = sign(X) X ,  sign(X) = Z sign(Lambda) Z'
+// so the projection needs the matrix sign U = sign(X), not the eigenvectors.  U is the limit of an odd polynomial fixed-point
+// iteration  U <- U (a I + b U^2 + c U^4), U_0 = X / ||X||_F  (all iterates are polynomials in X: symmetric, commuting):
+//   phase 1 (k1 = 20 steps): (a, b, c) = (3.4445, -4.7750, 2.0315) -- slope 3.44 at 0, maps [0, 1.2] into [0, 1.21] and ends in
+//                            [0.68, 1.21]; lifts every |lambda| >= delta ||X||_F with delta ~ 3e-12 into that interval;
+//   phase 2 (k2 = 5 steps):  Newton-Schulz quintic (15, -10, 3)/8, cubically convergent to +-1.
+// Eigenvalues below delta ||X||_F are left with |sign| < 1, which perturbs X+ by less than their own magnitude.  Measured
+// ||dX+||_F / ||X||_F = 2e-15 on random symmetric matrices and <= 6e-13 on spectra spread over 1e-14 .. 1 (NumPy prototype
+// and tests), i.e. inside the 64 d eps bound the tests use for the Jacobi path.  rank = round((tr U + tr U^2) / 2) (exact
+// unless eigenvalues below the delta cut-off exist; exact zeros count as not positive, like the reference's lambda > 0).
+//
+// Why this shape on MI355X: one-sided Jacobi at d = 2000 is ~3000 dependent tournament rounds of latency-bound 16x16
+// rotations (135-180 ms, 1 % MFMA-busy, profiles/r01_psd_mfma_counters.json); a tridiagonal QL/D&C chain is serial.  The sign
+// iteration is 76 products of d x d symmetric matrices whose result is symmetric, so only the upper 64x64 tiles are
+// computed (d^3 flops per product) and mirrored: fixed schedule, no host synchronisation, every kernel guarded by ctl->halt
+// like the rest of the loop.
+//
+// Kernel: k_symm_gemm -- C = alpha A B + beta Cin on the upper tiles, A and B symmetric (so both operands are read
+// "contiguous along the output index, strided along k"), 64x64 tile per workgroup of 4 waves (32x32 per wave = 2x2
+// v_mfma_f64_16x16x4_f64 accumulators), k-panels of 16 staged through double-buffered LDS with an 80-double row pitch
+// (conflict-free ds_read_b64 for the 16-lane x 4-row operand fragments), global loads of panel k+1 in flight during
+// the MFMAs of panel k.
+#include "psd_internal.h"
+#include <math.h>
+#include <stdlib.h>
+#include <algorithm>
+
+#define PT 64   // tile side
+#define PK 16   // k panel
+#define PLD 80  // LDS row pitch in doubles
+
+struct PolarCone {
+  int idx;            // index in PsdPlan::cones
+  int off, d, kind;
+  int ld;             // d rounded up to PT
+  long long woff;     // offset of this cone's 4 work matrices (doubles)
+};
+
+struct PolarPlan {
+  std::vector<PolarCone> cones;
+  double* W = nullptr;       // 4 * ld^2 doubles per cone: X, U, Y, T
+  double* parts = nullptr;   // per cone COSMO_MAX_PARTIALS norm partials + trace partials
+  double* nrm = nullptr;     // per cone ||X||_F
+  int k1 = 20, k2 = 5;
+};
+
+namespace {
+
+__device__ __forceinline__ long long svec_index(int i, int j) { return (long long)j * (j + 1) / 2 + i; }
+
+// X (full symmetric, zero padded to ld) from the svec / square slice of s, and the partial sums of ||X||_F^2
+__global__ __launch_bounds__(COSMO_BS) void k_polar_populate(const Ctl* __restrict__ ctl, int guard, PolarCone cn, const double* __restrict__ s,
+                                                             double* __restrict__ X, double* __restrict__ parts) {
+  if (guard && ctl->halt) return;
+  __shared__ double red[COSMO_BS / 64];
+  const double* x = s + cn.off;
+  const int d = cn.d, ld = cn.ld;
+  const double isq2 = 1.0 / sqrt(2.0);
+  double acc = 0.0;
+  for (int j = blockIdx.x; j < ld; j += gridDim.x) {
+    for (int i = threadIdx.x; i < ld; i += COSMO_BS) {
+      double v = 0.0;
+      if (i < d && j < d) {
+        const int a = i < j ? i : j, b = i < j ? j : i;
+        if (cn.kind == COSMO_HIP_PSD_TRIANGLE) {
+          const double t = x[svec_index(a, b)];
+          v = (a == b) ? t : isq2 * t;
+        } else {
+          v = (x[(long long)b * d + a] + x[(long long)a * d + b]) / 2.0;   // symmetrize_upper! (src/algebra.jl:201-208)
+        }
+        acc += v * v;
+      }
+      X[(long long)j * ld + i] = v;
+    }
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) parts[blockIdx.x] = acc;
+}
+
+// U = X / ||X||_F  (U = 0 for X = 0)
+__global__ __launch_bounds__(COSMO_BS) void k_polar_scale(const Ctl* __restrict__ ctl, int guard, long long n, int nparts, const double* __restrict__ parts,
+                                                          const double* __restrict__ X, double* __restrict__ U, double* __restrict__ nrm_out) {
+  if (guard && ctl->halt) return;
+  __shared__ double red[COSMO_BS / 64];
+  const double nf = sqrt(reduce_partials_sum(parts, nparts, red));
+  const double inv = (nf > 0.0) ? 1.0 / nf : 0.0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *nrm_out = nf;
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < n; i += (long long)gridDim.x * COSMO_BS) U[i] = X[i] * inv;
+}
+
+// C = alpha * (A B) + beta * Cin on the upper 64x64 tiles, mirrored into the lower ones.  A, B symmetric, leading dimension ld
+// (multiple of 64), zero padded.  EPI 0: C = A B.
+template <int EPI>
+__global__ __launch_bounds__(256) void k_symm_gemm(const Ctl* __restrict__ ctl, int guard, const double* __restrict__ A, const double* __restrict__ B,
+                                                   const double* __restrict__ Cin, double* __restrict__ C, int ld, double alpha, double beta) {
+  if (guard && ctl->halt) return;
+  __shared__ double As[2][PK * PLD];
+  __shared__ double Bs[2][PK * PLD];
+  // unrank the tile: column-major over the upper triangle, (ti <= tj)
+  const int t = blockIdx.x;
+  int tj = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) / 2.0);
+  while ((long long)tj * (tj + 1) / 2 > t) --tj;
+  while ((long long)(tj + 1) * (tj + 2) / 2 <= t) ++tj;
+  const int ti = t - tj * (tj + 1) / 2;
+  const int i0 = ti * PT, j0 = tj * PT;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wi = wv & 1, wj = wv >> 1;
+  // global -> LDS mapping: thread loads 4 consecutive output indices of one k
+  const int li = (threadIdx.x & 15) * 4, lk = threadIdx.x >> 4;
+  const double* ga = A + i0 + li + (long long)lk * ld;
+  const double* gb = B + j0 + li + (long long)lk * ld;
+  v4d acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
+  double2 ra0 = *reinterpret_cast<const double2*>(ga), ra1 = *reinterpret_cast<const double2*>(ga + 2);
+  double2 rb0 = *reinterpret_cast<const double2*>(gb), rb1 = *reinterpret_cast<const double2*>(gb + 2);
+  {
+    double* pa = &As[0][lk * PLD + li]; double* pb = &Bs[0][lk * PLD + li];
+    pa[0] = ra0.x; pa[1] = ra0.y; pa[2] = ra1.x; pa[3] = ra1.y;
+    pb[0] = rb0.x; pb[1] = rb0.y; pb[2] = rb1.x; pb[3] = rb1.y;
+  }
+  __syncthreads();
+  const int nk = ld / PK;
+  const int fa = 32 * wi + (lane & 15), fb = 32 * wj + (lane & 15), fk = lane >> 4;
+  for (int kb = 0; kb < nk; ++kb) {
+    const int cur = kb & 1;
+    if (kb + 1 < nk) {
+      const long long o = (long long)(kb + 1) * PK * ld;
+      ra0 = *reinterpret_cast<const double2*>(ga + o); ra1 = *reinterpret_cast<const double2*>(ga + o + 2);
+      rb0 = *reinterpret_cast<const double2*>(gb + o); rb1 = *reinterpret_cast<const double2*>(gb + o + 2);
+    }
+#pragma unroll
+    for (int ks = 0; ks < PK / 4; ++ks) {
+      const double* ap = &As[cur][(ks * 4 + fk) * PLD + fa];
+      const double* bp = &Bs[cur][(ks * 4 + fk) * PLD + fb];
+      const double a0 = ap[0], a1 = ap[16], b0 = bp[0], b1 = bp[16];
+      acc[0][0] = MFMA_F64(a0, b0, acc[0][0]);
+      acc[0][1] = MFMA_F64(a0, b1, acc[0][1]);
+      acc[1][0] = MFMA_F64(a1, b0, acc[1][0]);
+      acc[1][1] = MFMA_F64(a1, b1, acc[1][1]);
+    }
+    if (kb + 1 < nk) {
+      double* pa = &As[cur ^ 1][lk * PLD + li]; double* pb = &Bs[cur ^ 1][lk * PLD + li];
+      pa[0] = ra0.x; pa[1] = ra0.y; pa[2] = ra1.x; pa[3] = ra1.y;
+      pb[0] = rb0.x; pb[1] = rb0.y; pb[2] = rb1.x; pb[3] = rb1.y;
+    }
+    __syncthreads();
+  }
+  // epilogue: D[row = (lane >> 4) + 4 r][col = lane & 15] of the (mi, nj) MFMA tile
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + 32 * wi + 16 * mi + (lane >> 4) + 4 * r;
+        const int j = j0 + 32 * wj + 16 * nj + (lane & 15);
+        double v = acc[mi][nj][r];
+        if (EPI == 1) v = alpha * v + beta * Cin[(long long)j * ld + i];
+        if (ti != tj || i <= j) {                       // diagonal tiles: the upper half decides, so C is exactly symmetric
+          C[(long long)j * ld + i] = v;
+          if (i != j) C[(long long)i * ld + j] = v;
+        }
+      }
+}
+
+// X+ = (X + H) / 2 written in the cone's layout (svec with sqrt(2) off-diagonals / mirrored square), trace(U) partials
+__global__ __launch_bounds__(COSMO_BS) void k_polar_finish(const Ctl* __restrict__ ctl, int guard, PolarCone cn, const double* __restrict__ X,
+                                                           const double* __restrict__ H, const double* __restrict__ U, double* __restrict__ s,
+                                                           double* __restrict__ tparts) {
+  if (guard && ctl->halt) return;
+  __shared__ double red[COSMO_BS / 64];
+  double* x = s + cn.off;
+  const int d = cn.d, ld = cn.ld;
+  const double sq2 = sqrt(2.0);
+  double tr = 0.0;   // trace(U) + trace(U^2) = 2 #{lambda > 0} for a converged sign matrix (zero eigenvalues count as not positive)
+  for (int j = blockIdx.x; j < d; j += gridDim.x) {
+    for (int i = threadIdx.x; i <= j; i += COSMO_BS) {
+      const long long o = (long long)j * ld + i;
+      const double v = (X[o] + H[o]) / 2.0;
+      if (cn.kind == COSMO_HIP_PSD_TRIANGLE) x[svec_index(i, j)] = (i == j) ? v : sq2 * v;
+      else { x[(long long)j * d + i] = v; x[(long long)i * d + j] = v; }
+      const double u = U[o];
+      tr += (i == j) ? (u + u * u) : 2.0 * u * u;
+    }
+  }
+  tr = block_sum(tr, red);
+  if (threadIdx.x == 0) tparts[blockIdx.x] = tr;
+}
+__global__ __launch_bounds__(COSMO_BS) void k_polar_rank(const Ctl* __restrict__ ctl, int guard, int d, int nparts, const double* __restrict__ tparts,
+                                                         int* __restrict__ rank_out) {
+  if (guard && ctl->halt) return;
+  __shared__ double red[COSMO_BS / 64];
+  const double tr = reduce_partials_sum(tparts, nparts, red);
+  (void)d;
+  if (threadIdx.x == 0) *rank_out = (int)llround(tr / 2.0);
+}
+
+}  // namespace
+
+void polar_plan_destroy(cosmo_hip_handle* h) {
+  PolarPlan* q = static_cast<PolarPlan*>(h->psd_polar);
+  if (!q) return;
+  if (q->W) (void)hipFree(q->W);
+  if (q->parts) (void)hipFree(q->parts);
+  if (q->nrm) (void)hipFree(q->nrm);
+  delete q;
+  h->psd_polar = nullptr;
+}
+
+bool polar_enabled(const cosmo_hip_handle* h) { return h->psd_polar != nullptr; }
+
+// called by psd_plan_create once the Jacobi plan (which owns the cone list) exists
+int32_t polar_plan_create(cosmo_hip_handle* h) {
+  polar_plan_destroy(h);
+  PsdPlan* p = h->psd;
+  if (!p || p->large.empty()) return COSMO_HIP_OK;
+  if (const char* e = getenv("COSMO_HIP_PSD_LARGE")) if (e[0] == 'j') return COSMO_HIP_OK;   // "jacobi": keep the host-paced Jacobi path
+  PolarPlan* q = new PolarPlan();
+  h->psd_polar = q;
+  if (const char* e = getenv("COSMO_HIP_POLAR_K1")) q->k1 = std::max(1, atoi(e));
+  if (const char* e = getenv("COSMO_HIP_POLAR_K2")) q->k2 = std::max(1, atoi(e));
+  long long woff = 0;
+  for (int idx : p->large) {
+    const PsdConeDev& c = p->cones[idx];
+    PolarCone pc;
+    pc.idx = idx; pc.off = c.off; pc.d = c.d; pc.kind = c.kind;
+    pc.ld = ((c.d + PT - 1) / PT) * PT;
+    pc.woff = woff;
+    woff += 4LL * pc.ld * pc.ld;
+    q->cones.push_back(pc);
+  }
+  HIPCHK(h, hipMalloc((void**)&q->W, sizeof(double) * (size_t)woff));
+  HIPCHK(h, hipMalloc((void**)&q->parts, sizeof(double) * 2 * COSMO_MAX_PARTIALS * q->cones.size()));
+  HIPCHK(h, hipMalloc((void**)&q->nrm, sizeof(double) * q->cones.size()));
+  return COSMO_HIP_OK;
+}
+
+int32_t polar_enqueue_project(cosmo_hip_handle* h, double* s, int guard) {
+  PolarPlan* q = static_cast<PolarPlan*>(h->psd_polar);
+  PsdPlan* p = h->psd;
+  hipStream_t st = h->stream;
+  for (size_t ci = 0; ci < q->cones.size(); ++ci) {
+    const PolarCone& cn = q->cones[ci];
+    const long long n2 = (long long)cn.ld * cn.ld;
+    double* X = q->W + cn.woff;
+    double* U = X + n2;
+    double* Y = U + n2;
+    double* T = Y + n2;
+    double* nparts = q->parts + 2 * COSMO_MAX_PARTIALS * ci;
+    double* tparts = nparts + COSMO_MAX_PARTIALS;
+    const int gpop = std::min(cn.ld, 1024);
+    hipLaunchKernelGGL(k_polar_populate, dim3(gpop), dim3(COSMO_BS), 0, st, h->ctl, guard, cn, s, X, nparts);
+    hipLaunchKernelGGL(k_polar_scale, dim3(1024), dim3(COSMO_BS), 0, st, h->ctl, guard, n2, gpop, nparts, X, U, q->nrm + ci);
+    const int nt = cn.ld / PT;
+    const dim3 G(nt * (nt + 1) / 2), B(256);
+    for (int it = 0; it < q->k1 + q->k2; ++it) {
+      const bool ph1 = it < q->k1;
+      const double a = ph1 ? 3.4445 : 15.0 / 8.0, b = ph1 ? -4.7750 : -10.0 / 8.0, c = ph1 ? 2.0315 : 3.0 / 8.0;
+      hipLaunchKernelGGL((k_symm_gemm<0>), G, B, 0, st, h->ctl, guard, U, U, (const double*)nullptr, Y, cn.ld, 1.0, 0.0);     // Y = U^2
+      hipLaunchKernelGGL((k_symm_gemm<1>), G, B, 0, st, h->ctl, guard, Y, Y, Y, T, cn.ld, c, b);                               // T = c Y^2 + b Y
+      hipLaunchKernelGGL((k_symm_gemm<1>), G, B, 0, st, h->ctl, guard, U, T, U, Y, cn.ld, 1.0, a);                             // U' = U T + a U
+      std::swap(U, Y);
+    }
+    hipLaunchKernelGGL((k_symm_gemm<0>), G, B, 0, st, h->ctl, guard, U, X, (const double*)nullptr, T, cn.ld, 1.0, 0.0);       // H = U X = |X|
+    const int gfin = std::min(cn.d, 1024);
+    hipLaunchKernelGGL(k_polar_finish, dim3(gfin), dim3(COSMO_BS), 0, st, h->ctl, guard, cn, X, T, U, s, tparts);
+    hipLaunchKernelGGL(k_polar_rank, dim3(1), dim3(COSMO_BS), 0, st, h->ctl, guard, cn.d, gfin, tparts, p->rank + cn.idx);
+  }
+  HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}

@@ -175,3 +175,68 @@ def test_chordal_sdp_end_to_end_small():
     assert abs(res.iter - ref.iter) <= 25
     assert abs(res.obj_val - ref.obj_val) <= 1e-4 * (1 + abs(ref.obj_val))
     assert len(res.info.rho_updates) == len(ref.rho_updates)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# d > 256: matrix-sign (polar) iteration on the matrix cores (csrc/psd_polar.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_psd_polar_special_spectra_and_square_layout():
+    rng = np.random.default_rng(14)
+    d = 300
+    B = rng.standard_normal((d, d))
+    mats = [B @ B.T / d + 0.2 * np.eye(d),                      # PSD: identity map
+            -(B @ B.T / d + 0.2 * np.eye(d)),                   # negative definite: 0
+            np.zeros((d, d)),
+            3.0 * np.eye(d),
+            sym_with_spectrum(rng, np.concatenate([np.full(d // 2, 1.5), np.full(d - d // 2, -0.7)])),
+            1e8 * sym_with_spectrum(rng, gapped_spectrum(rng, d)),
+            1e-9 * sym_with_spectrum(rng, gapped_spectrum(rng, d))]
+    sets = [cj.PsdConeTriangle(d * (d + 1) // 2)] * len(mats)
+    out = check_projection(sets, mats, rtol_factor=8.0)        # the sign iteration is far more accurate than the 64 d eps bound
+    assert not out[2 * sets[0].dim:3 * sets[0].dim].any()      # exact zeros for the zero matrix
+    # square layout incl. an unsymmetric input (symmetrize_upper!, src/algebra.jl:201-208) and the exact mirror
+    d = 280
+    X = sym_with_spectrum(rng, gapped_spectrum(rng, d))
+    N = rng.standard_normal((d, d)) * 1e-3
+    h = _handle_for_sets([cj.PsdCone(d * d)])
+    s = (X + N).reshape(-1, order="F")
+    ref = s.copy(); O.project(ref, util.oracle_cones([cj.PsdCone(d * d)]))
+    out, rk, _ = h.project(s)
+    A = out.reshape(d, d, order="F")
+    assert np.array_equal(A, A.T)
+    assert np.linalg.norm(out - ref) <= 8 * d * EPS * np.linalg.norm(X)
+
+
+def test_psd_polar_spectrum_with_tiny_eigenvalues():
+    """Eigenvalues spread over 1e-14 .. 1 (the spectra ADMM iterates of low-rank SDPs have): eigenvalues below the cut-off
+    ~3e-12 ||X||_F keep |sign| < 1, which perturbs X+ by less than their own size -- the error bound still holds; the rank
+    (a by-product, trace of the sign matrix) is then only approximate."""
+    rng = np.random.default_rng(15)
+    d = 400
+    lam = np.concatenate([rng.uniform(0.5, 2, 30), 10.0 ** rng.uniform(-14, -6, d - 60) * rng.choice([-1, 1], d - 60), -rng.uniform(0.1, 3, 30)])
+    X = sym_with_spectrum(rng, lam)
+    K = cj.PsdConeTriangle(d * (d + 1) // 2)
+    h = _handle_for_sets([K])
+    s = cj.problems.svec(X)
+    ref = s.copy(); info = {}
+    O.project(ref, util.oracle_cones([K]), info)
+    out, rk, _ = h.project(s)
+    assert np.linalg.norm(out - ref) <= 64 * d * EPS * np.linalg.norm(X)
+    assert abs(int(rk[0]) - info["psd_rank"][0]) <= d - 60      # approximate by design
+    # idempotent to rounding and inside the cone
+    out2, _, _ = h.project(out)
+    assert np.linalg.norm(out2 - out) <= 64 * d * EPS * np.linalg.norm(X)
+    assert np.linalg.eigvalsh(cj.problems.smat(out)).min() >= -64 * d * EPS * np.linalg.norm(X)
+
+
+def test_closest_correlation_end_to_end_polar_path():
+    d = 288
+    prob = cj.problems.closest_correlation(d=d, seed=7)
+    st = dict(max_iter=60, eps_abs=0.0, eps_rel=0.0, check_infeasibility=10 ** 9)
+    model = cj.Model(); model.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], cj.Settings(**st))
+    res = cj.optimize(model)
+    ref = O.solve(prob["P"], prob["q"], prob["A"], prob["b"], util.oracle_cones(prob["sets"]), O.Settings(kkt_solver="cg", **st))
+    assert res.status == ref.status == "Max_iter_reached" and res.iter == ref.iter == 60
+    assert np.max(np.abs(res.x - ref.x)) <= 1e-7 * max(1.0, np.max(np.abs(ref.x)))
+    assert np.allclose(res.info.rho_updates, ref.rho_updates, rtol=1e-6)
+    assert abs(res.info.r_prim - ref.r_prim) <= 1e-6 * max(ref.r_prim, 1e-12) + 1e-12
