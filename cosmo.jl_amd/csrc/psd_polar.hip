@@ -29,14 +29,14 @@
 #include <stdlib.h>
 #include <algorithm>
 
-#define PT 64   // tile side
 #define PK 16   // k panel
 #define PLD 80  // LDS row pitch in doubles
 
 struct PolarCone {
   int idx;            // index in PsdPlan::cones
   int off, d, kind;
-  int ld;             // d rounded up to PT
+  int ts;             // tile side of the products (64 or 96), chosen per cone
+  int ld;             // d rounded up to ts
   long long woff;     // offset of this cone's 4 work matrices (doubles)
 };
 
@@ -92,82 +92,157 @@ __global__ __launch_bounds__(COSMO_BS) void k_polar_scale(const Ctl* __restrict_
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < n; i += (long long)gridDim.x * COSMO_BS) U[i] = X[i] * inv;
 }
 
-// C = alpha * (A B) + beta * Cin on the upper 64x64 tiles, mirrored into the lower ones.  A, B symmetric, leading dimension ld
-// (multiple of 64), zero padded.  EPI 0: C = A B.
-template <int EPI>
+// C = alpha * (A B) + beta * Cin on the upper TS x TS tiles, mirrored into the lower ones.  A, B symmetric, leading dimension
+// ld (multiple of TS), zero padded.  EPI 0: C = A B.  TS = 64 or 96: the host picks the tile side per cone so that the number of
+// upper tiles quantises well against the 256 CUs (d = 2000: 231 tiles of 96 -> one tile per CU, instead of 528 tiles of 64
+// -> three rounds on some CUs).  4 waves per workgroup, each owns a (TS/2) x (TS/2) quadrant = (TS/32)^2 MFMA accumulators.
+// Pipeline: the global loads of k-panel kb+2 are issued before the MFMAs of panel kb, panel kb+1 (loaded one step earlier) is
+// written to the other LDS buffer after them -- two panels of MFMA work cover the load latency per workgroup.
+// Epilogue: the accumulators are transposed through LDS so that both the natural and the mirrored tile leave as full rows.
+template <int TS> struct GemmCfg {
+  static constexpr int NM = TS / 32;                 // MFMA tiles per wave and dimension
+  static constexpr int NL = TS / 32;                 // double2 loads per thread, operand and panel
+  static constexpr int PITCH = TS + 16;              // == 16 (mod 32): conflict-free ds_read_b64 of 16-lane x 4-row fragments
+  static constexpr int CPITCH = TS + 1;              // odd: conflict-free column reads in the epilogue
+  static constexpr int PANEL = PK * PITCH;           // doubles per operand panel
+  static constexpr int SMEM = (4 * PANEL > TS * CPITCH ? 4 * PANEL : TS * CPITCH) * 8;
+};
+
+template <int EPI, int TS>
 __global__ __launch_bounds__(256) void k_symm_gemm(const Ctl* __restrict__ ctl, int guard, const double* __restrict__ A, const double* __restrict__ B,
-                                                   const double* __restrict__ Cin, double* __restrict__ C, int ld, double alpha, double beta) {
+                                                   const double* __restrict__ Cin, double* __restrict__ C, int ld, int ntiles, double alpha, double beta) {
   if (guard && ctl->halt) return;
-  __shared__ double As[2][PK * PLD];
-  __shared__ double Bs[2][PK * PLD];
+  using Cfg = GemmCfg<TS>;
+  constexpr int NM = Cfg::NM, NL = Cfg::NL, PITCH = Cfg::PITCH, CPITCH = Cfg::CPITCH, PANEL = Cfg::PANEL;
+  extern __shared__ double smem[];
+  double* As = smem;               // [2][PANEL]
+  double* Bs = smem + 2 * PANEL;   // [2][PANEL]
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (round-robin dispatch), and each XCD has its own 4 MB L2.  Give every
+  // XCD a CONTIGUOUS range of the column-major upper-triangle tile list (a few adjacent tile columns: one shared B panel,
+  // consecutive A panels) so that the k-panels its concurrent tiles stream are fetched once per XCD, not once per tile.
+  const int per_xcd = gridDim.x >> 3;
+  const int t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (t >= ntiles) return;
   // unrank the tile: column-major over the upper triangle, (ti <= tj)
-  const int t = blockIdx.x;
   int tj = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) / 2.0);
   while ((long long)tj * (tj + 1) / 2 > t) --tj;
   while ((long long)(tj + 1) * (tj + 2) / 2 <= t) ++tj;
   const int ti = t - tj * (tj + 1) / 2;
-  const int i0 = ti * PT, j0 = tj * PT;
+  const int i0 = ti * TS, j0 = tj * TS;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wi = wv & 1, wj = wv >> 1;
-  // global -> LDS mapping: thread loads 4 consecutive output indices of one k
-  const int li = (threadIdx.x & 15) * 4, lk = threadIdx.x >> 4;
-  const double* ga = A + i0 + li + (long long)lk * ld;
-  const double* gb = B + j0 + li + (long long)lk * ld;
-  v4d acc[2][2];
+  const long long pstep = (long long)PK * ld;
+  v4d acc[NM][NM];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < NM; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
-  double2 ra0 = *reinterpret_cast<const double2*>(ga), ra1 = *reinterpret_cast<const double2*>(ga + 2);
-  double2 rb0 = *reinterpret_cast<const double2*>(gb), rb1 = *reinterpret_cast<const double2*>(gb + 2);
-  {
-    double* pa = &As[0][lk * PLD + li]; double* pb = &Bs[0][lk * PLD + li];
-    pa[0] = ra0.x; pa[1] = ra0.y; pa[2] = ra1.x; pa[3] = ra1.y;
-    pb[0] = rb0.x; pb[1] = rb0.y; pb[2] = rb1.x; pb[3] = rb1.y;
+    for (int b = 0; b < NM; ++b) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
+  const int nk = ld / PK;   // >= 4
+  // global -> LDS mapping: double2 number q = tid + 256 u of the PK x TS panel: k = q / (TS/2), index pair = q % (TS/2)
+  int goff[NL], soff[NL];
+#pragma unroll
+  for (int u = 0; u < NL; ++u) {
+    const int q = threadIdx.x + 256 * u;
+    const int k = q / (TS / 2), c2 = q % (TS / 2);
+    goff[u] = k * ld + 2 * c2;
+    soff[u] = k * PITCH + 2 * c2;
   }
+  const double* ga = A + i0;
+  const double* gb = B + j0;
+  double2 r[2][2 * NL];
+#define P_LOAD(R, KB)                                                                                     \
+  {                                                                                                       \
+    const long long o_ = (long long)(KB) * pstep;                                                         \
+    _Pragma("unroll") for (int u = 0; u < NL; ++u) {                                                      \
+      (R)[u] = *reinterpret_cast<const double2*>(ga + o_ + goff[u]);                                      \
+      (R)[NL + u] = *reinterpret_cast<const double2*>(gb + o_ + goff[u]);                                 \
+    }                                                                                                     \
+  }
+#define P_STORE(R, BUF)                                                                                   \
+  {                                                                                                       \
+    _Pragma("unroll") for (int u = 0; u < NL; ++u) {                                                      \
+      double* pa_ = As + (BUF) * PANEL + soff[u];                                                         \
+      double* pb_ = Bs + (BUF) * PANEL + soff[u];                                                         \
+      pa_[0] = (R)[u].x; pa_[1] = (R)[u].y;                                                               \
+      pb_[0] = (R)[NL + u].x; pb_[1] = (R)[NL + u].y;                                                     \
+    }                                                                                                     \
+  }
+  const int fa = (TS / 2) * wi + (lane & 15), fb = (TS / 2) * wj + (lane & 15), fk = lane >> 4;
+#define P_COMPUTE(BUF)                                                                                    \
+  {                                                                                                       \
+    _Pragma("unroll") for (int ks = 0; ks < PK / 4; ++ks) {                                               \
+      const double* ap = As + (BUF) * PANEL + (ks * 4 + fk) * PITCH + fa;                                 \
+      const double* bp = Bs + (BUF) * PANEL + (ks * 4 + fk) * PITCH + fb;                                 \
+      double av[NM], bv[NM];                                                                              \
+      _Pragma("unroll") for (int a = 0; a < NM; ++a) { av[a] = ap[16 * a]; bv[a] = bp[16 * a]; }          \
+      _Pragma("unroll") for (int a = 0; a < NM; ++a)                                                      \
+        _Pragma("unroll") for (int b = 0; b < NM; ++b) acc[a][b] = MFMA_F64(av[a], bv[b], acc[a][b]);     \
+    }                                                                                                     \
+  }
+  P_LOAD(r[0], 0)
+  P_LOAD(r[1], 1)
+  P_STORE(r[0], 0)
   __syncthreads();
-  const int nk = ld / PK;
-  const int fa = 32 * wi + (lane & 15), fb = 32 * wj + (lane & 15), fk = lane >> 4;
-  for (int kb = 0; kb < nk; ++kb) {
-    const int cur = kb & 1;
-    if (kb + 1 < nk) {
-      const long long o = (long long)(kb + 1) * PK * ld;
-      ra0 = *reinterpret_cast<const double2*>(ga + o); ra1 = *reinterpret_cast<const double2*>(ga + o + 2);
-      rb0 = *reinterpret_cast<const double2*>(gb + o); rb1 = *reinterpret_cast<const double2*>(gb + o + 2);
-    }
-#pragma unroll
-    for (int ks = 0; ks < PK / 4; ++ks) {
-      const double* ap = &As[cur][(ks * 4 + fk) * PLD + fa];
-      const double* bp = &Bs[cur][(ks * 4 + fk) * PLD + fb];
-      const double a0 = ap[0], a1 = ap[16], b0 = bp[0], b1 = bp[16];
-      acc[0][0] = MFMA_F64(a0, b0, acc[0][0]);
-      acc[0][1] = MFMA_F64(a0, b1, acc[0][1]);
-      acc[1][0] = MFMA_F64(a1, b0, acc[1][0]);
-      acc[1][1] = MFMA_F64(a1, b1, acc[1][1]);
-    }
-    if (kb + 1 < nk) {
-      double* pa = &As[cur ^ 1][lk * PLD + li]; double* pb = &Bs[cur ^ 1][lk * PLD + li];
-      pa[0] = ra0.x; pa[1] = ra0.y; pa[2] = ra1.x; pa[3] = ra1.y;
-      pb[0] = rb0.x; pb[1] = rb0.y; pb[2] = rb1.x; pb[3] = rb1.y;
-    }
+  // invariant at the top of step kb: LDS[kb & 1] holds panel kb, r[(kb + 1) & 1] holds panel kb + 1 (in flight)
+  for (int kb = 0; kb < nk; kb += 2) {
+    if (kb + 2 < nk) P_LOAD(r[0], kb + 2)
+    P_COMPUTE(0)
+    if (kb + 1 < nk) P_STORE(r[1], 1)
+    __syncthreads();
+    if (kb + 1 >= nk) break;
+    if (kb + 3 < nk) P_LOAD(r[1], kb + 3)
+    P_COMPUTE(1)
+    if (kb + 2 < nk) P_STORE(r[0], 0)
     __syncthreads();
   }
-  // epilogue: D[row = (lane >> 4) + 4 r][col = lane & 15] of the (mi, nj) MFMA tile
+#undef P_LOAD
+#undef P_STORE
+#undef P_COMPUTE
+  // ---- epilogue through LDS: Cs[j][i], pitch CPITCH ----
+  double* Cs = smem;
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < NM; ++mi)
 #pragma unroll
-    for (int nj = 0; nj < 2; ++nj)
+    for (int nj = 0; nj < NM; ++nj)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = i0 + 32 * wi + 16 * mi + (lane >> 4) + 4 * r;
-        const int j = j0 + 32 * wj + 16 * nj + (lane & 15);
-        double v = acc[mi][nj][r];
-        if (EPI == 1) v = alpha * v + beta * Cin[(long long)j * ld + i];
-        if (ti != tj || i <= j) {                       // diagonal tiles: the upper half decides, so C is exactly symmetric
-          C[(long long)j * ld + i] = v;
-          if (i != j) C[(long long)i * ld + j] = v;
-        }
+      for (int q = 0; q < 4; ++q) {
+        const int i = (TS / 2) * wi + 16 * mi + (lane >> 4) + 4 * q;     // D row
+        const int j = (TS / 2) * wj + 16 * nj + (lane & 15);             // D col
+        Cs[j * CPITCH + i] = acc[mi][nj][q];
       }
+  __syncthreads();
+  const bool diag = (ti == tj);
+  // natural orientation: column j0 + j, rows i0 .. i0 + TS - 1 contiguous
+  for (int e = threadIdx.x; e < TS * TS; e += 256) {
+    const int i = e % TS, j = e / TS;
+    if (diag && i > j) continue;
+    double v = Cs[j * CPITCH + i];
+    const long long o = (long long)(j0 + j) * ld + i0 + i;
+    if (EPI == 1) { v = alpha * v + beta * Cin[o]; Cs[j * CPITCH + i] = v; }
+    C[o] = v;
+  }
+  __syncthreads();
+  // mirrored orientation: column i0 + i, rows j0 .. j0 + TS - 1 contiguous
+  for (int e = threadIdx.x; e < TS * TS; e += 256) {
+    const int j = e % TS, i = e / TS;
+    if (diag && i >= j) continue;
+    C[(long long)(i0 + i) * ld + j0 + j] = Cs[j * CPITCH + i];
+  }
+}
+
+template <int EPI, int TS>
+static void launch_symm_gemm(cosmo_hip_handle* h, int guard, const double* A, const double* B, const double* Cin, double* C, int ld, double alpha,
+                             double beta) {
+  const int nt = ld / TS, ntiles = nt * (nt + 1) / 2;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_symm_gemm<EPI, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<TS>::SMEM); attr_set = true; }
+  hipLaunchKernelGGL((k_symm_gemm<EPI, TS>), dim3(((ntiles + 7) / 8) * 8), dim3(256), GemmCfg<TS>::SMEM, h->stream, h->ctl, guard, A, B, Cin, C, ld, ntiles,
+                     alpha, beta);
+}
+static void symm_gemm(cosmo_hip_handle* h, int guard, int ts, int epi, const double* A, const double* B, const double* Cin, double* C, int ld,
+                      double alpha, double beta) {
+  if (ts == 96) { if (epi) launch_symm_gemm<1, 96>(h, guard, A, B, Cin, C, ld, alpha, beta); else launch_symm_gemm<0, 96>(h, guard, A, B, Cin, C, ld, alpha, beta); }
+  else { if (epi) launch_symm_gemm<1, 64>(h, guard, A, B, Cin, C, ld, alpha, beta); else launch_symm_gemm<0, 64>(h, guard, A, B, Cin, C, ld, alpha, beta); }
 }
 
 // X+ = (X + H) / 2 written in the cone's layout (svec with sqrt(2) off-diagonals / mirrored square), trace(U) partials
@@ -231,7 +306,15 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
     const PsdConeDev& c = p->cones[idx];
     PolarCone pc;
     pc.idx = idx; pc.off = c.off; pc.d = c.d; pc.kind = c.kind;
-    pc.ld = ((c.d + PT - 1) / PT) * PT;
+    // tile side: minimise (rounds of upper tiles over the 256 CUs) x (tile work)
+    long long best = -1; pc.ts = 64;
+    for (int ts : {64, 96}) {
+      const long long nt = (c.d + ts - 1) / ts, tiles = nt * (nt + 1) / 2;
+      const long long cost = ((tiles + 255) / 256) * (long long)ts * ts;
+      if (best < 0 || cost < best) { best = cost; pc.ts = ts; }
+    }
+    if (const char* e = getenv("COSMO_HIP_POLAR_TS")) { const int v = atoi(e); if (v == 64 || v == 96) pc.ts = v; }
+    pc.ld = ((c.d + pc.ts - 1) / pc.ts) * pc.ts;
     pc.woff = woff;
     woff += 4LL * pc.ld * pc.ld;
     q->cones.push_back(pc);
@@ -258,17 +341,15 @@ int32_t polar_enqueue_project(cosmo_hip_handle* h, double* s, int guard) {
     const int gpop = std::min(cn.ld, 1024);
     hipLaunchKernelGGL(k_polar_populate, dim3(gpop), dim3(COSMO_BS), 0, st, h->ctl, guard, cn, s, X, nparts);
     hipLaunchKernelGGL(k_polar_scale, dim3(1024), dim3(COSMO_BS), 0, st, h->ctl, guard, n2, gpop, nparts, X, U, q->nrm + ci);
-    const int nt = cn.ld / PT;
-    const dim3 G(nt * (nt + 1) / 2), B(256);
     for (int it = 0; it < q->k1 + q->k2; ++it) {
       const bool ph1 = it < q->k1;
       const double a = ph1 ? 3.4445 : 15.0 / 8.0, b = ph1 ? -4.7750 : -10.0 / 8.0, c = ph1 ? 2.0315 : 3.0 / 8.0;
-      hipLaunchKernelGGL((k_symm_gemm<0>), G, B, 0, st, h->ctl, guard, U, U, (const double*)nullptr, Y, cn.ld, 1.0, 0.0);     // Y = U^2
-      hipLaunchKernelGGL((k_symm_gemm<1>), G, B, 0, st, h->ctl, guard, Y, Y, Y, T, cn.ld, c, b);                               // T = c Y^2 + b Y
-      hipLaunchKernelGGL((k_symm_gemm<1>), G, B, 0, st, h->ctl, guard, U, T, U, Y, cn.ld, 1.0, a);                             // U' = U T + a U
+      symm_gemm(h, guard, cn.ts, 0, U, U, nullptr, Y, cn.ld, 1.0, 0.0);     // Y = U^2
+      symm_gemm(h, guard, cn.ts, 1, Y, Y, Y, T, cn.ld, c, b);               // T = c Y^2 + b Y
+      symm_gemm(h, guard, cn.ts, 1, U, T, U, Y, cn.ld, 1.0, a);             // U' = U T + a U
       std::swap(U, Y);
     }
-    hipLaunchKernelGGL((k_symm_gemm<0>), G, B, 0, st, h->ctl, guard, U, X, (const double*)nullptr, T, cn.ld, 1.0, 0.0);       // H = U X = |X|
+    symm_gemm(h, guard, cn.ts, 0, U, X, nullptr, T, cn.ld, 1.0, 0.0);       // H = U X = |X|
     const int gfin = std::min(cn.d, 1024);
     hipLaunchKernelGGL(k_polar_finish, dim3(gfin), dim3(COSMO_BS), 0, st, h->ctl, guard, cn, X, T, U, s, tparts);
     hipLaunchKernelGGL(k_polar_rank, dim3(1), dim3(COSMO_BS), 0, st, h->ctl, guard, cn.d, gfin, tparts, p->rank + cn.idx);
