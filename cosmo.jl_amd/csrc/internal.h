@@ -215,6 +215,9 @@ int32_t polar_plan_create(cosmo_hip_handle* h);
 void polar_plan_destroy(cosmo_hip_handle* h);
 bool polar_enabled(const cosmo_hip_handle* h);
 int32_t polar_enqueue_project(cosmo_hip_handle* h, double* s, int guard);
+int32_t polar_enqueue_project_batch(cosmo_hip_handle* h, double* s, int guard);
+bool polar_has_batch(const cosmo_hip_handle* h);
+bool polar_has_large(const cosmo_hip_handle* h);
 
 // PSD projection (psd.hip)
 int32_t psd_plan_create(cosmo_hip_handle* h);

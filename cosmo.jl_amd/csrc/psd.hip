@@ -571,6 +571,7 @@ void psd_plan_destroy(cosmo_hip_handle* h) {
   if (p->d_tiny) (void)hipFree(p->d_tiny);
   if (p->d_large) (void)hipFree(p->d_large);
   for (auto q : p->d_wg_groups) if (q) (void)hipFree(q);
+  for (auto q : p->d_pj_groups) if (q) (void)hipFree(q);
   if (p->G) (void)hipFree(p->G);
   if (p->colw) (void)hipFree(p->colw);
   if (p->cshift) (void)hipFree(p->cshift);
@@ -643,6 +644,24 @@ int32_t psd_plan_create(cosmo_hip_handle* h) {
     CHK(up(h, &dptr, grp));
     p->d_wg_groups.push_back(dptr);
   }
+  // projection-time split of the wg class: cones with d > polar_min go to the batched matrix-sign path (psd_polar.hip), whose
+  // ~80 launches cost the same for any number of cones, while a d = 200 Jacobi workgroup needs ~300 dependent tournament steps
+  {
+    int polar_min = 64;
+    if (const char* e = getenv("COSMO_HIP_POLAR_BATCH_MIN")) polar_min = atoi(e);
+    p->polar_batch.clear();
+    for (int idx : p->wg) if (p->cones[idx].d > polar_min) p->polar_batch.push_back(idx);
+    for (size_t gi = 0; gi < p->wg_groups.size(); ++gi) {
+      std::vector<int> grp;
+      for (int idx : p->wg_groups[gi]) if (p->cones[idx].d <= polar_min) grp.push_back(idx);
+      if (grp.empty()) continue;
+      p->pj_waves.push_back(p->wg_waves[gi]);
+      p->pj_groups.push_back(grp);
+      int* dptr = nullptr;
+      CHK(up(h, &dptr, grp));
+      p->d_pj_groups.push_back(dptr);
+    }
+  }
   HIPCHK(h, hipMalloc((void**)&p->G, std::max<long long>(1, p->gsize) * sizeof(double)));
   HIPCHK(h, hipMalloc((void**)&p->colw, std::max(1, p->ncolw) * sizeof(double)));
   HIPCHK(h, hipMalloc((void**)&p->cshift, p->cones.size() * sizeof(double)));
@@ -673,7 +692,7 @@ static int32_t psd_large_sweeps(cosmo_hip_handle* h, int n, int nbmax) {
   return COSMO_HIP_OK;
 }
 
-bool psd_needs_sync(const cosmo_hip_handle* h) { return h->psd && !h->psd->large.empty() && !polar_enabled(h); }
+bool psd_needs_sync(const cosmo_hip_handle* h) { return h->psd && !h->psd->large.empty() && !polar_has_large(h); }
 
 int32_t psd_enqueue_project(cosmo_hip_handle* h, double* s, bool guard_b) {
   PsdPlan* p = h->psd;
@@ -686,20 +705,21 @@ int32_t psd_enqueue_project(cosmo_hip_handle* h, double* s, bool guard_b) {
     hipLaunchKernelGGL(k_psd_tiny, dim3((n + COSMO_BS / 64 - 1) / (COSMO_BS / 64)), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, n,
                        p->d_tiny, p->d_cones, s, p->rank, p->flags, 0, 1.0, p->eigmin);
   }
-  for (size_t gi = 0; gi < p->wg_groups.size(); ++gi) {
-    const int n = (int)p->wg_groups[gi].size();
-    const int* lst = p->d_wg_groups[gi];
+  for (size_t gi = 0; gi < p->pj_groups.size(); ++gi) {
+    const int n = (int)p->pj_groups[gi].size();
+    const int* lst = p->d_pj_groups[gi];
     hipLaunchKernelGGL(k_psd_populate, dim3(8, n), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, lst, p->d_cones, s, p->G, p->cshift, 1.0);
-    switch (p->wg_waves[gi]) {
+    switch (p->pj_waves[gi]) {
       case 16: hipLaunchKernelGGL((k_psd_jacobi_wg<16>), dim3(n), dim3(1024), 0, h->stream, h->ctl, guard, lst, p->d_cones, p->G, p->cshift, p->flags, p->tol_factor, p->dbg); break;
       default: hipLaunchKernelGGL((k_psd_jacobi_wg<4>), dim3(n), dim3(256), 0, h->stream, h->ctl, guard, lst, p->d_cones, p->G, p->cshift, p->flags, p->tol_factor, p->dbg); break;
     }
     hipLaunchKernelGGL(k_psd_colscale, dim3(4, n), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, lst, p->d_cones, p->G, p->cshift, p->colw, p->rank);
     int maxtiles = 1;
-    for (int idx : p->wg_groups[gi]) { const int nt = p->cones[idx].ld / 16; maxtiles = std::max(maxtiles, nt * (nt + 1) / 2); }
+    for (int idx : p->pj_groups[gi]) { const int nt = p->cones[idx].ld / 16; maxtiles = std::max(maxtiles, nt * (nt + 1) / 2); }
     hipLaunchKernelGGL(k_psd_syrk, dim3((maxtiles + 3) / 4, n), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, lst, p->d_cones, p->G, s);
   }
-  if (!p->large.empty() && polar_enabled(h)) {
+  if (polar_has_batch(h)) CHK(polar_enqueue_project_batch(h, s, guard));
+  if (!p->large.empty() && polar_has_large(h)) {
     CHK(polar_enqueue_project(h, s, guard));
   } else if (!p->large.empty()) {
     // host-paced: one launch per tournament step, convergence flag read once per sweep

@@ -29,6 +29,12 @@ struct PsdPlan {
   PsdConeDev* d_cones = nullptr;
   int *d_tiny = nullptr, *d_large = nullptr;
   std::vector<int*> d_wg_groups;
+  // projection-time launch groups of the workgroup Jacobi kernels: the wg-class cones that are NOT handled by the batched
+  // matrix-sign path (psd_polar.hip); the full wg_groups stay in use for the definiteness tests of the certificates
+  std::vector<int> polar_batch;        // indices of the wg-class cones projected by the batched matrix-sign path
+  std::vector<int> pj_waves;
+  std::vector<std::vector<int>> pj_groups;
+  std::vector<int*> d_pj_groups;
   double* G = nullptr;
   double* colw = nullptr;              // per column: sigma then scale factor
   double* cshift = nullptr;            // per cone shift c

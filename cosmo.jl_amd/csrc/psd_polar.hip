@@ -40,12 +40,21 @@ struct PolarCone {
   long long woff;     // offset of this cone's 4 work matrices (doubles)
 };
 
+struct BatchCone { long long woff; int off, d, kind, ld, idx, pad; };   // a mid-size cone of the batched path (device table)
+
 struct PolarPlan {
   std::vector<PolarCone> cones;
   double* W = nullptr;       // 4 * ld^2 doubles per cone: X, U, Y, T
   double* parts = nullptr;   // per cone COSMO_MAX_PARTIALS norm partials + trace partials
   double* nrm = nullptr;     // per cone ||X||_F
   int k1 = 20, k2 = 5;
+  // batch of mid-size cones (one launch per product for all of them)
+  std::vector<BatchCone> bcones;
+  BatchCone* d_bcones = nullptr;
+  int4* d_btiles = nullptr;
+  int nbtiles = 0;
+  double* BW = nullptr;
+  double* bparts = nullptr;
 };
 
 namespace {
@@ -109,25 +118,12 @@ template <int TS> struct GemmCfg {
 };
 
 template <int EPI, int TS>
-__global__ __launch_bounds__(256) void k_symm_gemm(const Ctl* __restrict__ ctl, int guard, const double* __restrict__ A, const double* __restrict__ B,
-                                                   const double* __restrict__ Cin, double* __restrict__ C, int ld, int ntiles, double alpha, double beta) {
-  if (guard && ctl->halt) return;
+__device__ __forceinline__ void symm_gemm_tile(const double* __restrict__ A, const double* __restrict__ B, const double* __restrict__ Cin,
+                                               double* __restrict__ C, int ld, int ti, int tj, double alpha, double beta, double* smem) {
   using Cfg = GemmCfg<TS>;
   constexpr int NM = Cfg::NM, NL = Cfg::NL, PITCH = Cfg::PITCH, CPITCH = Cfg::CPITCH, PANEL = Cfg::PANEL;
-  extern __shared__ double smem[];
   double* As = smem;               // [2][PANEL]
   double* Bs = smem + 2 * PANEL;   // [2][PANEL]
-  // XCD-aware tile order: workgroup b runs on XCD b % 8 (round-robin dispatch), and each XCD has its own 4 MB L2.  Give every
-  // XCD a CONTIGUOUS range of the column-major upper-triangle tile list (a few adjacent tile columns: one shared B panel,
-  // consecutive A panels) so that the k-panels its concurrent tiles stream are fetched once per XCD, not once per tile.
-  const int per_xcd = gridDim.x >> 3;
-  const int t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (t >= ntiles) return;
-  // unrank the tile: column-major over the upper triangle, (ti <= tj)
-  int tj = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) / 2.0);
-  while ((long long)tj * (tj + 1) / 2 > t) --tj;
-  while ((long long)(tj + 1) * (tj + 2) / 2 <= t) ++tj;
-  const int ti = t - tj * (tj + 1) / 2;
   const int i0 = ti * TS, j0 = tj * TS;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wi = wv & 1, wj = wv >> 1;
@@ -230,6 +226,40 @@ __global__ __launch_bounds__(256) void k_symm_gemm(const Ctl* __restrict__ ctl, 
   }
 }
 
+// one large cone: the grid walks its upper tiles
+template <int EPI, int TS>
+__global__ __launch_bounds__(256) void k_symm_gemm(const Ctl* __restrict__ ctl, int guard, const double* __restrict__ A, const double* __restrict__ B,
+                                                   const double* __restrict__ Cin, double* __restrict__ C, int ld, int ntiles, double alpha, double beta) {
+  if (guard && ctl->halt) return;
+  extern __shared__ double smem[];
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (round-robin dispatch), and each XCD has its own 4 MB L2.  Give every
+  // XCD a CONTIGUOUS range of the column-major upper-triangle tile list (a few adjacent tile columns: one shared B panel,
+  // consecutive A panels) so that the k-panels its concurrent tiles stream are fetched once per XCD, not once per tile.
+  const int per_xcd = gridDim.x >> 3;
+  const int t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (t >= ntiles) return;
+  // unrank the tile: column-major over the upper triangle, (ti <= tj)
+  int tj = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) / 2.0);
+  while ((long long)tj * (tj + 1) / 2 > t) --tj;
+  while ((long long)(tj + 1) * (tj + 2) / 2 <= t) ++tj;
+  const int ti = t - tj * (tj + 1) / 2;
+  symm_gemm_tile<EPI, TS>(A, B, Cin, C, ld, ti, tj, alpha, beta, smem);
+}
+
+// a batch of mid-size cones: one workgroup per (cone, upper tile) descriptor; buffers 0..3 of a cone are X, U/Y, Y/U, T
+template <int EPI>
+__global__ __launch_bounds__(256) void k_symm_gemm_batch(const Ctl* __restrict__ ctl, int guard, const int4* __restrict__ tiles,
+                                                         const BatchCone* __restrict__ cones, double* __restrict__ W, int ia, int ib, int icin, int ic,
+                                                         double alpha, double beta) {
+  if (guard && ctl->halt) return;
+  extern __shared__ double smem[];
+  const int4 td = tiles[blockIdx.x];
+  const BatchCone bc = cones[td.x];
+  const long long n2 = (long long)bc.ld * bc.ld;
+  double* base = W + bc.woff;
+  symm_gemm_tile<EPI, 64>(base + ia * n2, base + ib * n2, base + icin * n2, base + ic * n2, bc.ld, td.y, td.z, alpha, beta, smem);
+}
+
 template <int EPI, int TS>
 static void launch_symm_gemm(cosmo_hip_handle* h, int guard, const double* A, const double* B, const double* Cin, double* C, int ld, double alpha,
                              double beta) {
@@ -277,6 +307,86 @@ __global__ __launch_bounds__(COSMO_BS) void k_polar_rank(const Ctl* __restrict__
   if (threadIdx.x == 0) *rank_out = (int)llround(tr / 2.0);
 }
 
+// ---- batched variants of populate / scale / finish / rank: blockIdx.y = cone of the batch -------------------------------
+#define BPX 16   // workgroups per cone in the elementwise kernels (= partials per cone)
+__global__ __launch_bounds__(COSMO_BS) void k_bpolar_populate(const Ctl* __restrict__ ctl, int guard, const BatchCone* __restrict__ cones,
+                                                              const double* __restrict__ s, double* __restrict__ W, double* __restrict__ parts) {
+  if (guard && ctl->halt) return;
+  __shared__ double red[COSMO_BS / 64];
+  const BatchCone cn = cones[blockIdx.y];
+  const double* x = s + cn.off;
+  double* X = W + cn.woff;
+  const int d = cn.d, ld = cn.ld;
+  const double isq2 = 1.0 / sqrt(2.0);
+  double acc = 0.0;
+  for (int j = blockIdx.x; j < ld; j += gridDim.x) {
+    for (int i = threadIdx.x; i < ld; i += COSMO_BS) {
+      double v = 0.0;
+      if (i < d && j < d) {
+        const int a = i < j ? i : j, b = i < j ? j : i;
+        if (cn.kind == COSMO_HIP_PSD_TRIANGLE) {
+          const double t = x[svec_index(a, b)];
+          v = (a == b) ? t : isq2 * t;
+        } else {
+          v = (x[(long long)b * d + a] + x[(long long)a * d + b]) / 2.0;
+        }
+        acc += v * v;
+      }
+      X[(long long)j * ld + i] = v;
+    }
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) parts[(size_t)blockIdx.y * 2 * BPX + blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(COSMO_BS) void k_bpolar_scale(const Ctl* __restrict__ ctl, int guard, const BatchCone* __restrict__ cones,
+                                                           const double* __restrict__ parts, double* __restrict__ W) {
+  if (guard && ctl->halt) return;
+  const BatchCone cn = cones[blockIdx.y];
+  double nf2 = 0.0;
+  for (int k = 0; k < BPX; ++k) nf2 += parts[(size_t)blockIdx.y * 2 * BPX + k];     // same order in every thread: deterministic
+  const double nf = sqrt(nf2);
+  const double inv = (nf > 0.0) ? 1.0 / nf : 0.0;
+  const long long n2 = (long long)cn.ld * cn.ld;
+  const double* X = W + cn.woff;
+  double* U = W + cn.woff + n2;
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < n2; i += (long long)gridDim.x * COSMO_BS) U[i] = X[i] * inv;
+}
+__global__ __launch_bounds__(COSMO_BS) void k_bpolar_finish(const Ctl* __restrict__ ctl, int guard, const BatchCone* __restrict__ cones,
+                                                            double* __restrict__ W, int iu, double* __restrict__ s, double* __restrict__ parts) {
+  if (guard && ctl->halt) return;
+  __shared__ double red[COSMO_BS / 64];
+  const BatchCone cn = cones[blockIdx.y];
+  const long long n2 = (long long)cn.ld * cn.ld;
+  const double* X = W + cn.woff;
+  const double* U = W + cn.woff + iu * n2;
+  const double* H = W + cn.woff + 3 * n2;
+  double* x = s + cn.off;
+  const int d = cn.d, ld = cn.ld;
+  const double sq2 = sqrt(2.0);
+  double tr = 0.0;
+  for (int j = blockIdx.x; j < d; j += gridDim.x) {
+    for (int i = threadIdx.x; i <= j; i += COSMO_BS) {
+      const long long o = (long long)j * ld + i;
+      const double v = (X[o] + H[o]) / 2.0;
+      if (cn.kind == COSMO_HIP_PSD_TRIANGLE) x[svec_index(i, j)] = (i == j) ? v : sq2 * v;
+      else { x[(long long)j * d + i] = v; x[(long long)i * d + j] = v; }
+      const double u = U[o];
+      tr += (i == j) ? (u + u * u) : 2.0 * u * u;
+    }
+  }
+  tr = block_sum(tr, red);
+  if (threadIdx.x == 0) parts[(size_t)blockIdx.y * 2 * BPX + BPX + blockIdx.x] = tr;
+}
+__global__ void k_bpolar_rank(const Ctl* __restrict__ ctl, int guard, int n, const BatchCone* __restrict__ cones, const double* __restrict__ parts,
+                              int* __restrict__ rank) {
+  if (guard && ctl->halt) return;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  double tr = 0.0;
+  for (int k = 0; k < BPX; ++k) tr += parts[(size_t)c * 2 * BPX + BPX + k];
+  rank[cones[c].idx] = (int)llround(tr / 2.0);
+}
+
 }  // namespace
 
 void polar_plan_destroy(cosmo_hip_handle* h) {
@@ -285,6 +395,10 @@ void polar_plan_destroy(cosmo_hip_handle* h) {
   if (q->W) (void)hipFree(q->W);
   if (q->parts) (void)hipFree(q->parts);
   if (q->nrm) (void)hipFree(q->nrm);
+  if (q->d_bcones) (void)hipFree(q->d_bcones);
+  if (q->d_btiles) (void)hipFree(q->d_btiles);
+  if (q->BW) (void)hipFree(q->BW);
+  if (q->bparts) (void)hipFree(q->bparts);
   delete q;
   h->psd_polar = nullptr;
 }
@@ -295,33 +409,96 @@ bool polar_enabled(const cosmo_hip_handle* h) { return h->psd_polar != nullptr; 
 int32_t polar_plan_create(cosmo_hip_handle* h) {
   polar_plan_destroy(h);
   PsdPlan* p = h->psd;
-  if (!p || p->large.empty()) return COSMO_HIP_OK;
-  if (const char* e = getenv("COSMO_HIP_PSD_LARGE")) if (e[0] == 'j') return COSMO_HIP_OK;   // "jacobi": keep the host-paced Jacobi path
+  if (!p) return COSMO_HIP_OK;
+  bool use_large = !p->large.empty(), use_batch = !p->polar_batch.empty();
+  if (const char* e = getenv("COSMO_HIP_PSD_LARGE")) if (e[0] == 'j') use_large = false;   // "jacobi": keep the host-paced Jacobi path
+  if (!use_large && !use_batch) return COSMO_HIP_OK;
   PolarPlan* q = new PolarPlan();
   h->psd_polar = q;
   if (const char* e = getenv("COSMO_HIP_POLAR_K1")) q->k1 = std::max(1, atoi(e));
   if (const char* e = getenv("COSMO_HIP_POLAR_K2")) q->k2 = std::max(1, atoi(e));
-  long long woff = 0;
-  for (int idx : p->large) {
-    const PsdConeDev& c = p->cones[idx];
-    PolarCone pc;
-    pc.idx = idx; pc.off = c.off; pc.d = c.d; pc.kind = c.kind;
-    // tile side: minimise (rounds of upper tiles over the 256 CUs) x (tile work)
-    long long best = -1; pc.ts = 64;
-    for (int ts : {64, 96}) {
-      const long long nt = (c.d + ts - 1) / ts, tiles = nt * (nt + 1) / 2;
-      const long long cost = ((tiles + 255) / 256) * (long long)ts * ts;
-      if (best < 0 || cost < best) { best = cost; pc.ts = ts; }
+  if (use_large) {
+    long long woff = 0;
+    for (int idx : p->large) {
+      const PsdConeDev& c = p->cones[idx];
+      PolarCone pc;
+      pc.idx = idx; pc.off = c.off; pc.d = c.d; pc.kind = c.kind;
+      // tile side: minimise (rounds of upper tiles over the 256 CUs) x (tile work)
+      long long best = -1; pc.ts = 64;
+      for (int ts : {64, 96}) {
+        const long long nt = (c.d + ts - 1) / ts, tiles = nt * (nt + 1) / 2;
+        const long long cost = ((tiles + 255) / 256) * (long long)ts * ts;
+        if (best < 0 || cost < best) { best = cost; pc.ts = ts; }
+      }
+      if (const char* e = getenv("COSMO_HIP_POLAR_TS")) { const int v = atoi(e); if (v == 64 || v == 96) pc.ts = v; }
+      pc.ld = ((c.d + pc.ts - 1) / pc.ts) * pc.ts;
+      pc.woff = woff;
+      woff += 4LL * pc.ld * pc.ld;
+      q->cones.push_back(pc);
     }
-    if (const char* e = getenv("COSMO_HIP_POLAR_TS")) { const int v = atoi(e); if (v == 64 || v == 96) pc.ts = v; }
-    pc.ld = ((c.d + pc.ts - 1) / pc.ts) * pc.ts;
-    pc.woff = woff;
-    woff += 4LL * pc.ld * pc.ld;
-    q->cones.push_back(pc);
+    HIPCHK(h, hipMalloc((void**)&q->W, sizeof(double) * (size_t)woff));
+    HIPCHK(h, hipMalloc((void**)&q->parts, sizeof(double) * 2 * COSMO_MAX_PARTIALS * q->cones.size()));
+    HIPCHK(h, hipMalloc((void**)&q->nrm, sizeof(double) * q->cones.size()));
   }
-  HIPCHK(h, hipMalloc((void**)&q->W, sizeof(double) * (size_t)woff));
-  HIPCHK(h, hipMalloc((void**)&q->parts, sizeof(double) * 2 * COSMO_MAX_PARTIALS * q->cones.size()));
-  HIPCHK(h, hipMalloc((void**)&q->nrm, sizeof(double) * q->cones.size()));
+  if (use_batch) {
+    long long woff = 0;
+    std::vector<int4> tiles;
+    for (int idx : p->polar_batch) {
+      const PsdConeDev& c = p->cones[idx];
+      BatchCone bc;
+      bc.off = c.off; bc.d = c.d; bc.kind = c.kind; bc.idx = idx; bc.pad = 0;
+      bc.ld = ((c.d + 63) / 64) * 64;
+      bc.woff = woff;
+      woff += 4LL * bc.ld * bc.ld;
+      q->bcones.push_back(bc);
+    }
+    // longest k first: the tiles of the biggest cones start at once, the small ones fill the tail
+    std::vector<int> order(q->bcones.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return q->bcones[a].ld > q->bcones[b].ld; });
+    for (int ci : order) {
+      const int nt = q->bcones[ci].ld / 64;
+      for (int tj = 0; tj < nt; ++tj) for (int ti = 0; ti <= tj; ++ti) tiles.push_back(int4{ci, ti, tj, 0});
+    }
+    q->nbtiles = (int)tiles.size();
+    HIPCHK(h, hipMalloc((void**)&q->BW, sizeof(double) * (size_t)woff));
+    HIPCHK(h, hipMalloc((void**)&q->d_bcones, sizeof(BatchCone) * q->bcones.size()));
+    HIPCHK(h, hipMalloc((void**)&q->d_btiles, sizeof(int4) * tiles.size()));
+    HIPCHK(h, hipMalloc((void**)&q->bparts, sizeof(double) * 2 * BPX * q->bcones.size()));
+    HIPCHK(h, hipMemcpy(q->d_bcones, q->bcones.data(), sizeof(BatchCone) * q->bcones.size(), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(q->d_btiles, tiles.data(), sizeof(int4) * tiles.size(), hipMemcpyHostToDevice));
+    (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch<0>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
+    (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch<1>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
+  }
+  return COSMO_HIP_OK;
+}
+
+bool polar_has_batch(const cosmo_hip_handle* h) { const PolarPlan* q = static_cast<const PolarPlan*>(h->psd_polar); return q && !q->bcones.empty(); }
+bool polar_has_large(const cosmo_hip_handle* h) { const PolarPlan* q = static_cast<const PolarPlan*>(h->psd_polar); return q && !q->cones.empty(); }
+
+// all mid-size cones of the batch advance together: 3 launches per iteration for the whole batch
+int32_t polar_enqueue_project_batch(cosmo_hip_handle* h, double* s, int guard) {
+  PolarPlan* q = static_cast<PolarPlan*>(h->psd_polar);
+  PsdPlan* p = h->psd;
+  hipStream_t st = h->stream;
+  const int n = (int)q->bcones.size();
+  const size_t sm = GemmCfg<64>::SMEM;
+  hipLaunchKernelGGL(k_bpolar_populate, dim3(BPX, n), dim3(COSMO_BS), 0, st, h->ctl, guard, q->d_bcones, s, q->BW, q->bparts);
+  hipLaunchKernelGGL(k_bpolar_scale, dim3(BPX, n), dim3(COSMO_BS), 0, st, h->ctl, guard, q->d_bcones, q->bparts, q->BW);
+  int iu = 1, iy = 2;
+  const dim3 G(q->nbtiles), B(256);
+  for (int it = 0; it < q->k1 + q->k2; ++it) {
+    const bool ph1 = it < q->k1;
+    const double a = ph1 ? 3.4445 : 15.0 / 8.0, b = ph1 ? -4.7750 : -10.0 / 8.0, c = ph1 ? 2.0315 : 3.0 / 8.0;
+    hipLaunchKernelGGL((k_symm_gemm_batch<0>), G, B, sm, st, h->ctl, guard, q->d_btiles, q->d_bcones, q->BW, iu, iu, iu, iy, 1.0, 0.0);   // Y = U^2
+    hipLaunchKernelGGL((k_symm_gemm_batch<1>), G, B, sm, st, h->ctl, guard, q->d_btiles, q->d_bcones, q->BW, iy, iy, iy, 3, c, b);        // T = c Y^2 + b Y
+    hipLaunchKernelGGL((k_symm_gemm_batch<1>), G, B, sm, st, h->ctl, guard, q->d_btiles, q->d_bcones, q->BW, iu, 3, iu, iy, 1.0, a);      // U' = U T + a U
+    std::swap(iu, iy);
+  }
+  hipLaunchKernelGGL((k_symm_gemm_batch<0>), G, B, sm, st, h->ctl, guard, q->d_btiles, q->d_bcones, q->BW, iu, 0, 0, 3, 1.0, 0.0);       // H = U X
+  hipLaunchKernelGGL(k_bpolar_finish, dim3(BPX, n), dim3(COSMO_BS), 0, st, h->ctl, guard, q->d_bcones, q->BW, iu, s, q->bparts);
+  hipLaunchKernelGGL(k_bpolar_rank, dim3((n + 63) / 64), dim3(64), 0, st, h->ctl, guard, n, q->d_bcones, q->bparts, p->rank);
+  HIPCHK(h, hipGetLastError());
   return COSMO_HIP_OK;
 }
 
