@@ -19,6 +19,7 @@ ERR_NAMES = {1: "INVALID", 2: "HIP", 3: "NOT_CONVEX", 4: "NONFINITE", 5: "EIG", 
 
 ZERO, NONNEG, BOX, SOC, PSD_SQUARE, PSD_TRIANGLE = 0, 1, 2, 3, 4, 5
 EXP, DUAL_EXP, POW, DUAL_POW = 6, 7, 8, 9
+PSD_TRIANGLE_COMPLEX = 10
 KKT_CG, KKT_MINRES_REDUCED, KKT_MINRES = 0, 1, 2
 STATUS_NAMES = {0: "Undetermined", 1: "Solved", 2: "Max_iter_reached", 3: "Unsolved", 4: "Primal_infeasible",
                 5: "Dual_infeasible", 6: "Time_limit_reached"}

@@ -2,7 +2,7 @@
 // AndersonAccelerator{T, Type2{QRDecomp}, RestartedMemory, NoRegularizer}(mem = 15) with safeguarding
 // (src/settings.jl:136-138, src/accelerator_interface.jl:58-130).  The accelerator itself lives in the external package
 // COSMOAccelerators.jl (Project.toml:8,27), which is not part of the reference tree: this file restates the published
-// algorithm exactly as oracle/cosmo_oracle.py::AndersonAccelerator does (PARITY UNPINNED -- see DESIGN.md section 7).
+// algorithm exactly as the CPU test oracle (class AndersonAccelerator) does (PARITY UNPINNED -- see DESIGN.md section 7).
 //
 //   update!(g = w, x = w_prev):  f = x - g; G[:, j] = g - g_last; v = f - f_last; modified Gram-Schmidt of v against
 //                                Q[:, 0..j) -> R[0..j, j], Q[:, j]

@@ -390,16 +390,16 @@ extern "C" int32_t cosmo_hip_set_cones_ex(cosmo_hip_handle* h, int64_t ncones, c
   int64_t off = 0, nbox = 0;
   for (int64_t k = 0; k < ncones; ++k) {
     if (dim[k] < 0) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "negative cone dimension");
-    if (type[k] < COSMO_HIP_ZERO || type[k] > COSMO_HIP_DUAL_POW)
+    if (type[k] < COSMO_HIP_ZERO || type[k] > COSMO_HIP_PSD_TRIANGLE_COMPLEX)
       return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "cone type %d is outside the hot-path scope", (int)type[k]);
-    if (type[k] >= COSMO_HIP_EXP && dim[k] != 3) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "exponential / power cones have dimension 3");
+    if (type[k] >= COSMO_HIP_EXP && type[k] <= COSMO_HIP_DUAL_POW && dim[k] != 3) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "exponential / power cones have dimension 3");
     if (type[k] == COSMO_HIP_POW || type[k] == COSMO_HIP_DUAL_POW) {
       if (!cone_param || !(cone_param[k] > 0.0 && cone_param[k] < 1.0))
         return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "The exponent alpha of the power cone has to be in (0, 1).");
     }
-    if (type[k] == COSMO_HIP_PSD_SQUARE) {
+    if (type[k] == COSMO_HIP_PSD_SQUARE || type[k] == COSMO_HIP_PSD_TRIANGLE_COMPLEX) {
       const int64_t r = (int64_t)llround(sqrt((double)dim[k]));
-      if (r * r != dim[k]) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "PsdCone dimension must be a square");
+      if (r * r != dim[k]) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "PsdCone / complex PsdConeTriangle dimension must be a square");
     }
     C.type.push_back(type[k]); C.dim.push_back(dim[k]); C.off.push_back(off);
     C.param.push_back(cone_param ? cone_param[k] : 0.0);
@@ -427,6 +427,7 @@ extern "C" int32_t cosmo_hip_set_cones_ex(cosmo_hip_handle* h, int64_t ncones, c
       case COSMO_HIP_EXP: case COSMO_HIP_DUAL_EXP: case COSMO_HIP_POW: case COSMO_HIP_DUAL_POW: break;   // cone3.hip, in place
       case COSMO_HIP_PSD_SQUARE:
       case COSMO_HIP_PSD_TRIANGLE:
+      case COSMO_HIP_PSD_TRIANGLE_COMPLEX:
         if (d == 1) for (int64_t i = 0; i < d; ++i) meta[o + i] = 2u;  // 1x1: max(x,0) (convexset.jl:307-308,404-405)
         break;
     }

@@ -202,7 +202,7 @@ int32_t infeas_check(cosmo_hip_handle* h, int32_t* status) {
   const ConeTable& C = h->cones;
   bool has_psd = false;
   for (size_t k = 0; k < C.type.size(); ++k)
-    if ((C.type[k] == COSMO_HIP_PSD_SQUARE || C.type[k] == COSMO_HIP_PSD_TRIANGLE) && C.dim[k] > 1) has_psd = true;
+    if ((C.type[k] == COSMO_HIP_PSD_SQUARE || C.type[k] == COSMO_HIP_PSD_TRIANGLE || C.type[k] == COSMO_HIP_PSD_TRIANGLE_COMPLEX) && C.dim[k] > 1) has_psd = true;
   // ---- is_primal_infeasible! (infeasibility.jl:1-29) ----
   if (norm_dy > p.eps_prim_inf && ady_norm <= p.eps_prim_inf * norm_dy) {
     HIPCHK(h, hipMemsetAsync(h->inf_flags, 0, sizeof(int) * 4, h->stream));

@@ -591,9 +591,20 @@ int32_t psd_plan_create(cosmo_hip_handle* h) {
   long long goff = 0;
   int coff = 0;
   for (size_t k = 0; k < C.type.size(); ++k) {
-    if (C.type[k] != COSMO_HIP_PSD_SQUARE && C.type[k] != COSMO_HIP_PSD_TRIANGLE) continue;
+    if (C.type[k] != COSMO_HIP_PSD_SQUARE && C.type[k] != COSMO_HIP_PSD_TRIANGLE && C.type[k] != COSMO_HIP_PSD_TRIANGLE_COMPLEX) continue;
     if (C.dim[k] <= 1) continue;
     if (!cone_owned(h, (long long)k)) continue;   // clique sharding: another rank projects this cone
+    if (C.type[k] == COSMO_HIP_PSD_TRIANGLE_COMPLEX) {
+      // Hermitian r x r cone: projected through its real symmetric embedding [[A, -B], [B, A]] of side 2r by the matrix-sign
+      // paths (psd_polar.hip); never enters the Jacobi size classes
+      PsdConeDev cc;
+      cc.kind = C.type[k]; cc.off = (int)C.off[k];
+      cc.d = 2 * (int)llround(sqrt((double)C.dim[k]));
+      cc.ld = ((cc.d + 15) / 16) * 16; cc.nb = 0; cc.ncp = 0; cc.goff = 0; cc.coff = 0; cc.cone_index = (int)k;
+      p->cplx.push_back((int)p->cones.size());
+      p->cones.push_back(cc);
+      continue;
+    }
     PsdConeDev cn;
     cn.kind = C.type[k];
     cn.off = (int)C.off[k];
@@ -719,9 +730,8 @@ int32_t psd_enqueue_project(cosmo_hip_handle* h, double* s, bool guard_b) {
     hipLaunchKernelGGL(k_psd_syrk, dim3((maxtiles + 3) / 4, n), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, lst, p->d_cones, p->G, s);
   }
   if (polar_has_batch(h)) CHK(polar_enqueue_project_batch(h, s, guard));
-  if (!p->large.empty() && polar_has_large(h)) {
-    CHK(polar_enqueue_project(h, s, guard));
-  } else if (!p->large.empty()) {
+  if (polar_has_large(h)) CHK(polar_enqueue_project(h, s, guard));
+  if (!p->large.empty() && !(polar_has_large(h) && p->large_by_polar)) {
     // host-paced: one launch per tournament step, convergence flag read once per sweep
     if (guard) {
       CHK(sync_ctl(h));
@@ -802,5 +812,6 @@ int32_t psd_extreme_eigs(cosmo_hip_handle* h, const double* vec, double sign, st
   lam_min.resize(p->cones.size());
   HIPCHK(h, hipMemcpyAsync(lam_min.data(), p->eigmin, sizeof(double) * lam_min.size(), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (int idx : p->cplx) lam_min[idx] = -INFINITY;   // Hermitian cones: no definiteness test on the device => never certify (conservative)
   return COSMO_HIP_OK;
 }

@@ -32,6 +32,8 @@ struct PsdPlan {
   // projection-time launch groups of the workgroup Jacobi kernels: the wg-class cones that are NOT handled by the batched
   // matrix-sign path (psd_polar.hip); the full wg_groups stay in use for the definiteness tests of the certificates
   std::vector<int> polar_batch;        // indices of the wg-class cones projected by the batched matrix-sign path
+  bool large_by_polar = false;         // the real large cones are projected by psd_polar.hip
+  std::vector<int> cplx;               // complex Hermitian cones (real 2r x 2r embedding, matrix-sign paths only)
   std::vector<int> pj_waves;
   std::vector<std::vector<int>> pj_groups;
   std::vector<int*> d_pj_groups;

@@ -61,6 +61,39 @@ namespace {
 
 __device__ __forceinline__ long long svec_index(int i, int j) { return (long long)j * (j + 1) / 2 + i; }
 
+
+// value of the (real symmetric) working matrix at (i, j) read from the cone's slice x.  Real cones: svec / square layouts.
+// Complex Hermitian cone H = A + iB of side r (src/convexset.jl:444-458): the 2r x 2r embedding [[A, -B], [B, A]].
+__device__ __forceinline__ double polar_read(const double* __restrict__ x, int kind, int d, int i, int j) {
+  const double isq2 = 0.70710678118654752440;
+  if (kind == COSMO_HIP_PSD_TRIANGLE) {
+    const int a = i < j ? i : j, b = i < j ? j : i;
+    const double t = x[svec_index(a, b)];
+    return (a == b) ? t : isq2 * t;
+  }
+  if (kind == COSMO_HIP_PSD_SQUARE) {
+    const int a = i < j ? i : j, b = i < j ? j : i;
+    return (x[(long long)b * d + a] + x[(long long)a * d + b]) / 2.0;     // symmetrize_upper! (src/algebra.jl:201-208)
+  }
+  const int r = d / 2;
+  const int bi = i >= r, bj = j >= r, ii = i - bi * r, jj = j - bj * r;
+  const int a = ii < jj ? ii : jj, b = ii < jj ? jj : ii;
+  if (bi == bj) { const double t = x[svec_index(a, b)]; return (a == b) ? t : isq2 * t; }
+  if (ii == jj) return 0.0;
+  double im = isq2 * x[(long long)r * (r + 1) / 2 + (long long)b * (b - 1) / 2 + a];   // B[a, b] for a < b
+  if (ii > jj) im = -im;                                                               // B[ii, jj]
+  return (bi == 1) ? im : -im;                                                         // lower-left block B, upper-right block -B
+}
+// store the projected value v of the upper-triangle position (i <= j) into the cone's layout
+__device__ __forceinline__ void polar_write(double* __restrict__ x, int kind, int d, int i, int j, double v) {
+  const double sq2 = 1.41421356237309504880;
+  if (kind == COSMO_HIP_PSD_TRIANGLE) { x[svec_index(i, j)] = (i == j) ? v : sq2 * v; return; }
+  if (kind == COSMO_HIP_PSD_SQUARE) { x[(long long)j * d + i] = v; x[(long long)i * d + j] = v; return; }
+  const int r = d / 2;
+  if (j < r) { x[svec_index(i, j)] = (i == j) ? v : sq2 * v; return; }            // real part (extract_upper_triangle!, :474-490)
+  if (i < r) { const int jj = j - r; if (i < jj) x[(long long)r * (r + 1) / 2 + (long long)jj * (jj - 1) / 2 + i] = sq2 * (-v); }   // M[i, r + jj] = -B[i, jj]
+}
+
 // X (full symmetric, zero padded to ld) from the svec / square slice of s, and the partial sums of ||X||_F^2
 __global__ __launch_bounds__(COSMO_BS) void k_polar_populate(const Ctl* __restrict__ ctl, int guard, PolarCone cn, const double* __restrict__ s,
                                                              double* __restrict__ X, double* __restrict__ parts) {
@@ -68,21 +101,11 @@ __global__ __launch_bounds__(COSMO_BS) void k_polar_populate(const Ctl* __restri
   __shared__ double red[COSMO_BS / 64];
   const double* x = s + cn.off;
   const int d = cn.d, ld = cn.ld;
-  const double isq2 = 1.0 / sqrt(2.0);
   double acc = 0.0;
   for (int j = blockIdx.x; j < ld; j += gridDim.x) {
     for (int i = threadIdx.x; i < ld; i += COSMO_BS) {
       double v = 0.0;
-      if (i < d && j < d) {
-        const int a = i < j ? i : j, b = i < j ? j : i;
-        if (cn.kind == COSMO_HIP_PSD_TRIANGLE) {
-          const double t = x[svec_index(a, b)];
-          v = (a == b) ? t : isq2 * t;
-        } else {
-          v = (x[(long long)b * d + a] + x[(long long)a * d + b]) / 2.0;   // symmetrize_upper! (src/algebra.jl:201-208)
-        }
-        acc += v * v;
-      }
+      if (i < d && j < d) { v = polar_read(x, cn.kind, d, i, j); acc += v * v; }
       X[(long long)j * ld + i] = v;
     }
   }
@@ -283,14 +306,12 @@ __global__ __launch_bounds__(COSMO_BS) void k_polar_finish(const Ctl* __restrict
   __shared__ double red[COSMO_BS / 64];
   double* x = s + cn.off;
   const int d = cn.d, ld = cn.ld;
-  const double sq2 = sqrt(2.0);
   double tr = 0.0;   // trace(U) + trace(U^2) = 2 #{lambda > 0} for a converged sign matrix (zero eigenvalues count as not positive)
   for (int j = blockIdx.x; j < d; j += gridDim.x) {
     for (int i = threadIdx.x; i <= j; i += COSMO_BS) {
       const long long o = (long long)j * ld + i;
       const double v = (X[o] + H[o]) / 2.0;
-      if (cn.kind == COSMO_HIP_PSD_TRIANGLE) x[svec_index(i, j)] = (i == j) ? v : sq2 * v;
-      else { x[(long long)j * d + i] = v; x[(long long)i * d + j] = v; }
+      polar_write(x, cn.kind, d, i, j, v);
       const double u = U[o];
       tr += (i == j) ? (u + u * u) : 2.0 * u * u;
     }
@@ -299,12 +320,12 @@ __global__ __launch_bounds__(COSMO_BS) void k_polar_finish(const Ctl* __restrict
   if (threadIdx.x == 0) tparts[blockIdx.x] = tr;
 }
 __global__ __launch_bounds__(COSMO_BS) void k_polar_rank(const Ctl* __restrict__ ctl, int guard, int d, int nparts, const double* __restrict__ tparts,
-                                                         int* __restrict__ rank_out) {
+                                                         int* __restrict__ rank_out, int kind) {
   if (guard && ctl->halt) return;
   __shared__ double red[COSMO_BS / 64];
   const double tr = reduce_partials_sum(tparts, nparts, red);
   (void)d;
-  if (threadIdx.x == 0) *rank_out = (int)llround(tr / 2.0);
+  if (threadIdx.x == 0) *rank_out = (int)llround(tr / (kind == COSMO_HIP_PSD_TRIANGLE_COMPLEX ? 4.0 : 2.0));   // Hermitian embedding doubles every eigenvalue
 }
 
 // ---- batched variants of populate / scale / finish / rank: blockIdx.y = cone of the batch -------------------------------
@@ -317,21 +338,11 @@ __global__ __launch_bounds__(COSMO_BS) void k_bpolar_populate(const Ctl* __restr
   const double* x = s + cn.off;
   double* X = W + cn.woff;
   const int d = cn.d, ld = cn.ld;
-  const double isq2 = 1.0 / sqrt(2.0);
   double acc = 0.0;
   for (int j = blockIdx.x; j < ld; j += gridDim.x) {
     for (int i = threadIdx.x; i < ld; i += COSMO_BS) {
       double v = 0.0;
-      if (i < d && j < d) {
-        const int a = i < j ? i : j, b = i < j ? j : i;
-        if (cn.kind == COSMO_HIP_PSD_TRIANGLE) {
-          const double t = x[svec_index(a, b)];
-          v = (a == b) ? t : isq2 * t;
-        } else {
-          v = (x[(long long)b * d + a] + x[(long long)a * d + b]) / 2.0;
-        }
-        acc += v * v;
-      }
+      if (i < d && j < d) { v = polar_read(x, cn.kind, d, i, j); acc += v * v; }
       X[(long long)j * ld + i] = v;
     }
   }
@@ -362,14 +373,12 @@ __global__ __launch_bounds__(COSMO_BS) void k_bpolar_finish(const Ctl* __restric
   const double* H = W + cn.woff + 3 * n2;
   double* x = s + cn.off;
   const int d = cn.d, ld = cn.ld;
-  const double sq2 = sqrt(2.0);
   double tr = 0.0;
   for (int j = blockIdx.x; j < d; j += gridDim.x) {
     for (int i = threadIdx.x; i <= j; i += COSMO_BS) {
       const long long o = (long long)j * ld + i;
       const double v = (X[o] + H[o]) / 2.0;
-      if (cn.kind == COSMO_HIP_PSD_TRIANGLE) x[svec_index(i, j)] = (i == j) ? v : sq2 * v;
-      else { x[(long long)j * d + i] = v; x[(long long)i * d + j] = v; }
+      polar_write(x, cn.kind, d, i, j, v);
       const double u = U[o];
       tr += (i == j) ? (u + u * u) : 2.0 * u * u;
     }
@@ -384,7 +393,7 @@ __global__ void k_bpolar_rank(const Ctl* __restrict__ ctl, int guard, int n, con
   if (c >= n) return;
   double tr = 0.0;
   for (int k = 0; k < BPX; ++k) tr += parts[(size_t)c * 2 * BPX + BPX + k];
-  rank[cones[c].idx] = (int)llround(tr / 2.0);
+  rank[cones[c].idx] = (int)llround(tr / (cones[c].kind == COSMO_HIP_PSD_TRIANGLE_COMPLEX ? 4.0 : 2.0));
 }
 
 }  // namespace
@@ -410,8 +419,13 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
   polar_plan_destroy(h);
   PsdPlan* p = h->psd;
   if (!p) return COSMO_HIP_OK;
-  bool use_large = !p->large.empty(), use_batch = !p->polar_batch.empty();
-  if (const char* e = getenv("COSMO_HIP_PSD_LARGE")) if (e[0] == 'j') use_large = false;   // "jacobi": keep the host-paced Jacobi path
+  std::vector<int> large_list, batch_list = p->polar_batch;
+  bool jac = false;
+  if (const char* e = getenv("COSMO_HIP_PSD_LARGE")) if (e[0] == 'j') jac = true;   // "jacobi": keep the host-paced Jacobi path for real cones
+  if (!jac) large_list = p->large;
+  p->large_by_polar = !jac;
+  for (int idx : p->cplx) { if (p->cones[idx].d > 256) large_list.push_back(idx); else batch_list.push_back(idx); }
+  const bool use_large = !large_list.empty(), use_batch = !batch_list.empty();
   if (!use_large && !use_batch) return COSMO_HIP_OK;
   PolarPlan* q = new PolarPlan();
   h->psd_polar = q;
@@ -419,7 +433,7 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
   if (const char* e = getenv("COSMO_HIP_POLAR_K2")) q->k2 = std::max(1, atoi(e));
   if (use_large) {
     long long woff = 0;
-    for (int idx : p->large) {
+    for (int idx : large_list) {
       const PsdConeDev& c = p->cones[idx];
       PolarCone pc;
       pc.idx = idx; pc.off = c.off; pc.d = c.d; pc.kind = c.kind;
@@ -443,7 +457,7 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
   if (use_batch) {
     long long woff = 0;
     std::vector<int4> tiles;
-    for (int idx : p->polar_batch) {
+    for (int idx : batch_list) {
       const PsdConeDev& c = p->cones[idx];
       BatchCone bc;
       bc.off = c.off; bc.d = c.d; bc.kind = c.kind; bc.idx = idx; bc.pad = 0;
@@ -529,7 +543,7 @@ int32_t polar_enqueue_project(cosmo_hip_handle* h, double* s, int guard) {
     symm_gemm(h, guard, cn.ts, 0, U, X, nullptr, T, cn.ld, 1.0, 0.0);       // H = U X = |X|
     const int gfin = std::min(cn.d, 1024);
     hipLaunchKernelGGL(k_polar_finish, dim3(gfin), dim3(COSMO_BS), 0, st, h->ctl, guard, cn, X, T, U, s, tparts);
-    hipLaunchKernelGGL(k_polar_rank, dim3(1), dim3(COSMO_BS), 0, st, h->ctl, guard, cn.d, gfin, tparts, p->rank + cn.idx);
+    hipLaunchKernelGGL(k_polar_rank, dim3(1), dim3(COSMO_BS), 0, st, h->ctl, guard, cn.d, gfin, tparts, p->rank + cn.idx, cn.kind);
   }
   HIPCHK(h, hipGetLastError());
   return COSMO_HIP_OK;

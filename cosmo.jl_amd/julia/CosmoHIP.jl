@@ -74,6 +74,7 @@ cone_type(::COSMO.Box) = Int32(2)
 cone_type(::COSMO.SecondOrderCone) = Int32(3)
 cone_type(::COSMO.PsdCone) = Int32(4)
 cone_type(::COSMO.PsdConeTriangle{T, T}) where {T} = Int32(5)
+cone_type(::COSMO.PsdConeTriangle{T, Complex{T}}) where {T} = Int32(10)
 cone_type(::COSMO.ExponentialCone) = Int32(6)
 cone_type(::COSMO.DualExponentialCone) = Int32(7)
 cone_type(::COSMO.PowerCone) = Int32(8)

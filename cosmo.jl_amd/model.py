@@ -127,6 +127,19 @@ class PsdConeTriangle(AbstractConvexSet):
         self.sqrt_dim = (math.isqrt(1 + 8 * self.dim) - 1) // 2   # src/convexset.jl:372
 
 
+class ComplexPsdConeTriangle(AbstractConvexSet):
+    """`PsdConeTriangle{T, Complex{T}}(dim)`, dim = r^2 (src/convexset.jl:345-380): Hermitian r x r matrices stored as the svec of the
+    real part followed by sqrt(2) * the imaginary parts of the strict upper triangle."""
+    kind = _ffi.PSD_TRIANGLE_COMPLEX
+
+    def __init__(self, dim):
+        super().__init__(dim)
+        r = math.isqrt(self.dim)
+        if r * r != self.dim:
+            raise ValueError("dimension must be a square")
+        self.sqrt_dim = r
+
+
 class ExponentialCone(AbstractConvexSet):
     """K_exp (src/convexset.jl:497-507); MAX_ITERS = 100 and EXP_TOL = 1e-8 are the reference defaults and fixed here."""
     kind = _ffi.EXP
@@ -154,7 +167,7 @@ class DualPowerCone(PowerCone):
     kind = _ffi.DUAL_POW
 
 
-_SCALAR_SCALED = (_ffi.SOC, _ffi.PSD_SQUARE, _ffi.PSD_TRIANGLE, _ffi.EXP, _ffi.DUAL_EXP, _ffi.POW, _ffi.DUAL_POW)   # src/convexset.jl:956-958
+_SCALAR_SCALED = (_ffi.SOC, _ffi.PSD_SQUARE, _ffi.PSD_TRIANGLE, _ffi.EXP, _ffi.DUAL_EXP, _ffi.POW, _ffi.DUAL_POW, _ffi.PSD_TRIANGLE_COMPLEX)   # src/convexset.jl:956-958
 
 
 class EmptyAccelerator:
@@ -311,7 +324,7 @@ def scale_ruiz(P, q, A, b, sets: Sequence[AbstractConvexSet], st: Settings) -> S
 
 
 _SORT = {_ffi.ZERO: 1, _ffi.NONNEG: 2, _ffi.BOX: 3, _ffi.SOC: 4, _ffi.PSD_SQUARE: 5, _ffi.PSD_TRIANGLE: 6,
-         _ffi.EXP: 6, _ffi.DUAL_EXP: 6, _ffi.POW: 6, _ffi.DUAL_POW: 6}     # sort_sets fall-through (src/interface.jl:466-475)
+         _ffi.EXP: 6, _ffi.DUAL_EXP: 6, _ffi.POW: 6, _ffi.DUAL_POW: 6, _ffi.PSD_TRIANGLE_COMPLEX: 6}     # sort_sets fall-through (src/interface.jl:466-475)
 
 
 def _copy_set(K):

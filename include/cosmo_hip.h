@@ -52,7 +52,10 @@ enum {
   COSMO_HIP_EXP = 6,         /* ExponentialCone      src/convexset.jl:497-605  (dim 3, MAX_ITERS 100, EXP_TOL 1e-8) */
   COSMO_HIP_DUAL_EXP = 7,    /* DualExponentialCone  src/convexset.jl:735-779  (Moreau decomposition)               */
   COSMO_HIP_POW = 8,         /* PowerCone(alpha)     src/convexset.jl:607-726  (dim 3, MAX_ITERS 20, POW_TOL 1e-8)  */
-  COSMO_HIP_DUAL_POW = 9     /* DualPowerCone(alpha) src/convexset.jl:748-779                                       */
+  COSMO_HIP_DUAL_POW = 9,    /* DualPowerCone(alpha) src/convexset.jl:748-779                                       */
+  COSMO_HIP_PSD_TRIANGLE_COMPLEX = 10 /* PsdConeTriangle{T, Complex{T}}(r^2): Hermitian r x r matrices, vector = svec of the
+                                real part (r(r+1)/2 entries) followed by sqrt(2) * imaginary parts of the strict upper
+                                triangle, column by column (src/convexset.jl:345-380, 444-490)                          */
 };
 
 /* ---- KKT solver kinds: AbstractKKTSolver subtypes (src/linear_solver/kktsolver_indirect.jl) -------- */

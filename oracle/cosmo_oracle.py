@@ -45,10 +45,12 @@ from scipy.linalg import lapack as _lapack
 # --------------------------------------------------------------------------------------------
 ZERO, NONNEG, BOX, SOC, PSD_SQUARE, PSD_TRIANGLE = 0, 1, 2, 3, 4, 5
 EXP, DUAL_EXP, POW, DUAL_POW = 6, 7, 8, 9
+PSD_TRIANGLE_COMPLEX = 10       # PsdConeTriangle{T, Complex{T}} (src/convexset.jl:345-380)
 CONE_NAMES = {ZERO: "ZeroSet", NONNEG: "Nonnegatives", BOX: "Box", SOC: "SecondOrderCone",
               PSD_SQUARE: "PsdCone", PSD_TRIANGLE: "PsdConeTriangle", EXP: "ExponentialCone",
-              DUAL_EXP: "DualExponentialCone", POW: "PowerCone", DUAL_POW: "DualPowerCone"}
-SCALAR_SCALED = (SOC, PSD_SQUARE, PSD_TRIANGLE, EXP, DUAL_EXP, POW, DUAL_POW)   # rectify_scaling! (src/convexset.jl:956-958)
+              DUAL_EXP: "DualExponentialCone", POW: "PowerCone", DUAL_POW: "DualPowerCone",
+              PSD_TRIANGLE_COMPLEX: "PsdConeTriangle{T,Complex{T}}"}
+SCALAR_SCALED = (SOC, PSD_SQUARE, PSD_TRIANGLE, EXP, DUAL_EXP, POW, DUAL_POW, PSD_TRIANGLE_COMPLEX)   # rectify_scaling! (src/convexset.jl:956-958)
 
 
 @dataclass
@@ -71,6 +73,10 @@ class Cone:
             return r
         if self.kind == PSD_TRIANGLE:           # src/convexset.jl:372
             return (math.isqrt(1 + 8 * self.dim) - 1) // 2
+        if self.kind == PSD_TRIANGLE_COMPLEX:   # :372: R <: Complex ? isqrt(dim)
+            r = math.isqrt(self.dim)
+            assert r * r == self.dim
+            return r
         raise ValueError("not a PSD cone")
 
 
@@ -79,6 +85,7 @@ def Nonnegatives(dim): return Cone(NONNEG, int(dim), constr_type=np.zeros(int(di
 def SecondOrderCone(dim): return Cone(SOC, int(dim))
 def PsdCone(dim): return Cone(PSD_SQUARE, int(dim))
 def PsdConeTriangle(dim): return Cone(PSD_TRIANGLE, int(dim))
+def ComplexPsdConeTriangle(dim): return Cone(PSD_TRIANGLE_COMPLEX, int(dim))   # PsdConeTriangle{T, Complex{T}}(dim), dim = r^2
 def ExponentialCone(max_iter=100, tol=1e-8): return Cone(EXP, 3, max_iter=int(max_iter), tol=float(tol))          # :497-507
 def DualExponentialCone(max_iter=100, tol=1e-8): return Cone(DUAL_EXP, 3, max_iter=int(max_iter), tol=float(tol))  # :735-745
 
@@ -144,6 +151,37 @@ def extract_upper_triangle(X: np.ndarray, x: np.ndarray) -> None:
     vals = math.sqrt(2.0) * X[ii, jj]
     diag = ii == jj
     x[:] = np.where(diag, X[ii, jj], vals)
+
+
+def populate_upper_triangle_complex(x: np.ndarray, d: int) -> np.ndarray:
+    """`populate_upper_triangle!(A::Matrix{Complex}, x, 1/sqrt(2))` (src/convexset.jl:444-458): Hermitian matrix, upper part."""
+    H = np.zeros((d, d), dtype=np.complex128)
+    f = 1.0 / math.sqrt(2.0)
+    k = 0
+    for j in range(d):
+        for i in range(j):
+            H[i, j] = f * x[k]; k += 1
+        H[j, j] = x[k]; k += 1
+    for j in range(d):
+        for i in range(j):
+            H[i, j] += 1j * f * x[k]; k += 1
+    iu = np.triu_indices(d, 1)
+    H[(iu[1], iu[0])] = np.conj(H[iu])
+    return H
+
+
+def extract_upper_triangle_complex(H: np.ndarray, x: np.ndarray) -> None:
+    """`extract_upper_triangle!(A::Matrix{Complex}, x, sqrt(2))` (src/convexset.jl:474-490)."""
+    d = H.shape[0]
+    f = math.sqrt(2.0)
+    k = 0
+    for j in range(d):
+        for i in range(j):
+            x[k] = f * H[i, j].real; k += 1
+        x[k] = H[j, j].real; k += 1
+    for j in range(d):
+        for i in range(j):
+            x[k] = f * H[i, j].imag; k += 1
 
 
 def _psd_project_dense(X: np.ndarray):
@@ -214,6 +252,19 @@ def project_cone(x: np.ndarray, cone: Cone, info: Optional[dict] = None) -> None
             Xp, nnz = _psd_project_dense(Xs)
             full = np.triu(Xp) + np.triu(Xp, 1).T  # mirror upper -> lower (:316-318)
             x[:] = full.reshape(-1, order="F")
+        if info is not None:
+            info.setdefault("psd_rank", []).append(nnz)
+    elif k == PSD_TRIANGLE_COMPLEX:               # :402-412 with R = Complex{T}: zheevr + herk
+        if x.size == 1:
+            x[0] = max(x[0], 0.0)
+            nnz = int(x[0] > 0)
+        else:
+            d = cone.sqrt_dim
+            H = populate_upper_triangle_complex(x, d)
+            w, Z = np.linalg.eigh(H)
+            nnz = int(np.sum(w > 0))
+            Zp = Z[:, w > 0] * np.sqrt(w[w > 0])
+            extract_upper_triangle_complex(Zp @ Zp.conj().T, x)
         if info is not None:
             info.setdefault("psd_rank", []).append(nnz)
     elif k == EXP:
@@ -392,6 +443,9 @@ def in_dual(x, cone: Cone, tol: float) -> bool:
     if k == PSD_SQUARE:
         d = cone.sqrt_dim
         return _is_pos_def(x.reshape((d, d), order="F"), tol)   # :324-328
+    if k == PSD_TRIANGLE_COMPLEX:                               # :415-418 with is_pos_def! on the Hermitian matrix
+        H = populate_upper_triangle_complex(np.asarray(x, dtype=np.float64), cone.sqrt_dim)
+        return bool(np.linalg.eigvalsh(H + tol * np.eye(cone.sqrt_dim)).min() > 0)
     if k == EXP:
         return _exp_in_dual(x, tol)
     if k == DUAL_EXP:                                           # :770-772: dual of the dual = primal
@@ -418,7 +472,7 @@ def in_pol_recc(x, cone: Cone, tol: float) -> bool:
     if k == PSD_SQUARE:
         d = cone.sqrt_dim
         return _is_pos_def(-x.reshape((d, d), order="F"), tol)
-    if k in (EXP, DUAL_EXP, POW, DUAL_POW):                     # :603-605, 724-726, 772
+    if k in (EXP, DUAL_EXP, POW, DUAL_POW, PSD_TRIANGLE_COMPLEX):   # :603-605, 724-726, 772; :421-424 (is_neg_def!)
         return in_dual(-np.asarray(x), cone, tol)
     raise ValueError
 
@@ -1301,7 +1355,7 @@ class Constraint:
 
 
 _SORT_KEY = {ZERO: 1, NONNEG: 2, BOX: 3, SOC: 4, PSD_SQUARE: 5, PSD_TRIANGLE: 6,
-             EXP: 6, DUAL_EXP: 6, POW: 6, DUAL_POW: 6}      # sort_sets fall-through (src/interface.jl:466-475)
+             EXP: 6, DUAL_EXP: 6, POW: 6, DUAL_POW: 6, PSD_TRIANGLE_COMPLEX: 6}      # sort_sets fall-through (src/interface.jl:466-475)
 
 
 def assemble(constraints: Sequence[Constraint]):

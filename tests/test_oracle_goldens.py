@@ -420,3 +420,34 @@ def test_anderson_reaches_the_reference_goldens(name):
         q = np.zeros(n); q[2] = q[5] = -1.0
         r = O.solve(sp.csc_matrix((n, n)), q, A, b, cones, O.Settings(max_iter=5000, **st))
         assert r.status == "Solved" and abs(r.obj_val + 1.8458) < 1e-3
+
+
+# ---- complex Hermitian PSD cone (PsdConeTriangle{T, Complex{T}}): test/UnitTests/least_eigenvalue.jl -------------------------
+def _least_eig_problem(mod, X):
+    d = X.shape[0]; vec_dim = d * d
+    vec_c = np.zeros(vec_dim); O.extract_upper_triangle_complex(X, vec_c)
+    id_vec = np.zeros(vec_dim); id_vec[[k * (k + 1) // 2 - 1 for k in range(1, d + 1)]] = 1.0
+    return vec_c, id_vec, vec_dim
+
+
+def test_complex_psd_least_eigenvalue_golden():
+    # least_eigenvalue.jl:32-37: min <c, X> s.t. tr X = 1, X >= 0 (Hermitian)  ->  lambda_min = 1 - sqrt(2)
+    X = np.array([[1, 1j, 0], [-1j, 1, 1j], [0, -1j, 1]])
+    vec_c, id_vec, n = _least_eig_problem(O, X)
+    cs = [O.Constraint(id_vec[None, :], [-1.0], O.ZeroSet(1)), O.Constraint(np.eye(n), np.zeros(n), O.ComplexPsdConeTriangle(n))]
+    A, b, cones = O.assemble(cs)
+    r = O.solve(np.zeros((n, n)), vec_c, A, b, cones, O.Settings(eps_abs=1e-5, eps_rel=1e-5))
+    assert r.status == "Solved" and abs(r.obj_val - (1 - math.sqrt(2))) < 1e-4 * (1 + abs(1 - math.sqrt(2)))
+    # layout round trip (src/convexset.jl:444-490) and projection properties
+    rng = np.random.default_rng(2)
+    d = 7
+    G = rng.normal(size=(d, d)) + 1j * rng.normal(size=(d, d)); H = (G + G.conj().T) / 2
+    x = np.zeros(d * d); O.extract_upper_triangle_complex(H, x)
+    assert np.allclose(O.populate_upper_triangle_complex(x, d), H)
+    assert abs(np.linalg.norm(x) - np.linalg.norm(H)) < 1e-12          # the scaled layout is an isometry
+    p = x.copy(); info = {}
+    O.project_cone(p, O.ComplexPsdConeTriangle(d * d), info)
+    Hp = O.populate_upper_triangle_complex(p, d)
+    w = np.linalg.eigvalsh(H)
+    assert np.linalg.eigvalsh(Hp).min() > -1e-12 and info["psd_rank"][0] == int((w > 0).sum())
+    assert abs(np.vdot(Hp, Hp - H).real) < 1e-10                       # <X+, X+ - X> = 0

@@ -24,7 +24,7 @@ def oracle_cones(sets):
 
 def model_sets(cones):
     m = {O.ZERO: cj.ZeroSet, O.NONNEG: cj.Nonnegatives, O.SOC: cj.SecondOrderCone, O.PSD_SQUARE: cj.PsdCone,
-         O.PSD_TRIANGLE: cj.PsdConeTriangle}
+         O.PSD_TRIANGLE: cj.PsdConeTriangle, O.PSD_TRIANGLE_COMPLEX: cj.ComplexPsdConeTriangle}
     out = []
     for c in cones:
         if c.kind == O.BOX:

@@ -2,7 +2,6 @@ import os, sys, time
 sys.path.insert(0, "/root/repo")
 import numpy as np, scipy.sparse as sp, torch
 import cosmo_jl_amd as cj
-from oracle import cosmo_oracle as O
 rng = np.random.default_rng(5)
 for d in (2000, 1000, 500, 320):
     K = cj.PsdConeTriangle(d * (d + 1) // 2)
