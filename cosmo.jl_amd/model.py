@@ -45,6 +45,21 @@ def with_options(solver, **kwargs):
     return OptionsFactory(solver, kwargs)
 
 
+class NoMerge:
+    """COSMO.NoMerge (src/chordal_decomposition/clique_merging.jl:39)"""
+    code = 0
+
+
+class ParentChildMerge:
+    """COSMO.ParentChildMerge(t_fill = 8, t_size = 8) (clique_merging.jl:80-101)"""
+    code = 1
+
+
+class CliqueGraphMerge:
+    """COSMO.CliqueGraphMerge(edge_weight = ComplexityWeight()) (clique_merging.jl:42-75), the reference's default"""
+    code = 2
+
+
 @dataclass
 class Settings:
     """Numeric fields of `COSMO.Settings` read by the hot path (src/settings.jl:101-139).  The accelerator is
@@ -80,6 +95,10 @@ class Settings:
     # AndersonAccelerator{T, Type2{QRDecomp}, RestartedMemory, NoRegularizer}(mem = 15); this mirror defaults to the
     # EmptyAccelerator because the Anderson path restates an external package (parity unpinned) -- opt in with
     # accelerator=AndersonAccelerator or with_options(AndersonAccelerator, mem=...).
+    # chordal decomposition (src/settings.jl:129-135): host C++ front-end libcosmo_chordal.so (include/cosmo_chordal.h)
+    decompose: bool = True
+    complete_dual: bool = False
+    merge_strategy: object = CliqueGraphMerge      # or with_options(ParentChildMerge, t_fill=8, t_size=8) / NoMerge
     accelerator: object = None
     accelerator_activation: int = 2  # ImmediateActivation; k = IterActivation(k)
     safeguard: bool = True
@@ -347,6 +366,7 @@ class Model:
         self.is_optimized = False
         self.sm: Optional[ScaleMatrices] = None
         self.handle: Optional[_ffi.Handle] = None
+        self.chordal = None            # _chordal.Decomposition of a decomposed model (ws.ci)
         self.x = self.s = self.mu = None
         self.n = self.m = 0
 
@@ -376,6 +396,7 @@ class Model:
         self.handle = None
         self.is_assembled = self.is_scaled = self.is_optimized = False
         self.sm = None
+        self.chordal = None
 
 
 def assemble(model: Model, P, q, constraints: Union[Constraint, Sequence[Constraint]], settings: Optional[Settings] = None,
@@ -535,6 +556,33 @@ def setup(model: Model):
         model.handle = h
 
 
+def _chordal_decomposition(model: Model):
+    """`chordal_decomposition!` (src/chordal_decomposition/chordal_decomposition.jl:10-38) through libcosmo_chordal.so: replaces the
+    model's (P, q, A, b, sets) by the clique-tree transformed problem; `model.chordal` keeps what reverse_decomposition! needs."""
+    from . import _chordal
+    if not any(K.kind == _ffi.PSD_TRIANGLE and K.dim > 1 for K in model.sets):
+        return
+    ms, kw = model.settings.merge_strategy, {}
+    if isinstance(ms, OptionsFactory):
+        ms, kw = ms.solver, ms.kwargs
+    dec = _chordal.Decomposition(model.A, model.b, [K.kind for K in model.sets], [K.dim for K in model.sets], merge_strategy=ms.code,
+                                 t_fill=kw.get("t_fill", 8), t_size=kw.get("t_size", 8))
+    if dec.num_decomposed == 0:                                   # ws.ci.decompose = false (:33-35)
+        dec.close()
+        return
+    new_sets = []
+    for kind, dim, orig in zip(dec.kinds, dec.dims, dec.cone_map):
+        K0 = model.sets[int(orig) - 1]
+        new_sets.append(PsdConeTriangle(int(dim)) if (kind == _ffi.PSD_TRIANGLE and K0.kind == _ffi.PSD_TRIANGLE and int(dim) != K0.dim) else _copy_set(K0))
+    nov = dec.n_new - model.n
+    model.P = sp.block_diag([model.P, sp.csc_matrix((nov, nov))], format="csc")      # transformations.jl:193-194
+    model.q = np.concatenate([model.q, np.zeros(nov)])
+    model.A, model.b, model.sets = dec.A.tocsc(), dec.b.copy(), new_sets
+    model.n, model.m = dec.n_new, dec.m_new
+    model.x = np.zeros(model.n); model.s = np.zeros(model.m); model.mu = np.zeros(model.m)   # pre_allocate_variables! (:28)
+    model.chordal = dec
+
+
 def optimize(model: Model, dist=None) -> Result:
     """`COSMO.optimize!` (src/solver.jl:78-203) with the `while` loop running on the MI355X.  With an initialised
     torch.distributed module as `dist` (one process per GPU) the cone projections are sharded over the ranks
@@ -544,6 +592,8 @@ def optimize(model: Model, dist=None) -> Result:
         raise RuntimeError("The model has to be assembled! / set! before optimize!() can be called.")
     t0 = time.perf_counter()
     fresh = model.handle is None
+    if fresh and model.settings.decompose and getattr(model, "chordal", None) is None:
+        _chordal_decomposition(model)                             # chordal_decomposition!(ws) (src/solver.jl:88-94)
     setup(model)
     if dist is not None and dist.get_world_size() > 1 and fresh:
         setup_clique_sharding(model, dist)
@@ -559,6 +609,10 @@ def optimize(model: Model, dist=None) -> Result:
         s = sm.Einv * s
         mu = (sm.E * mu) * sm.cinv
     model.x, model.s, model.mu = x.copy(), s.copy(), mu.copy()
+    dec = getattr(model, "chordal", None)
+    if dec is not None:                                           # reverse_decomposition!(ws, settings) (src/solver.jl:184-190)
+        x = x[:dec.n]
+        s, mu = dec.reverse(s, mu, complete_dual=model.settings.complete_dual)
     info = ResultInfo(r.r_prim, r.r_dual, r.max_norm_prim, r.max_norm_dual,
                       [r.rho_updates[i] for i in range(min(r.n_rho_updates, _ffi.MAX_RHO_UPDATES))])
     times = ResultTimes(time.perf_counter() - t0, t_setup, r.iter_time, r.proj_time)

@@ -32,6 +32,18 @@ def test_library_exports_every_header_symbol():
     assert cj.load_library().cosmo_hip_version() == 1000
 
 
+def test_chordal_library_exports_every_header_symbol():
+    src = open(os.path.join(ROOT, "include", "cosmo_chordal.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(cosmo_chordal_[a-z0-9_]+)\s*\(", src)))
+    assert len(names) >= 10
+    lib = cj._chordal.load_library()
+    for nm in names:
+        assert hasattr(lib, nm), "libcosmo_chordal.so does not export %s" % nm
+    assert set(cj._chordal.SIGNATURES) == set(names)
+    assert ctypes.sizeof(cj._chordal.Options) == 3 * 4 + 4 + 8      # int32 x 3, padding, pointer
+
+
 def test_struct_layouts_match_header():
     # field order/size of the two ABI structs (guards against silent drift between header and binding)
     src = open(os.path.join(ROOT, "include", "cosmo_hip.h")).read()
