@@ -57,16 +57,13 @@ struct cosmo_chordal {
 namespace {
 
 // find_aggregate_sparsity (chordal_decomposition.jl:104-121): svec positions (1-based, ascending) that are nonzero in some
-// column of A or in b, plus the diagonal
-std::vector<long long> aggregate_sparsity(const cosmo_chordal& C, const int64_t* Ap, const int64_t* Ai, const double* b, long long row0, long long dimc,
-                                          int N) {
-  std::vector<char> act((size_t)dimc, 0);
-  const long long nnz = Ap[C.n] - 1;
-  for (long long k = 0; k < nnz; ++k) { const long long r = Ai[k] - 1; if (r >= row0 && r < row0 + dimc) act[(size_t)(r - row0)] = 1; }
-  for (long long i = 1; i <= N; ++i) act[(size_t)(i * (i + 1) / 2 - 1)] = 1;
-  for (long long r = 0; r < dimc; ++r) if (b[row0 + r] != 0.0) act[(size_t)r] = 1;
+// column of A or in b, plus the diagonal.  `act` = rows of the whole problem that hold a stored entry of A or a nonzero of b
+// (computed once for all cones; the reference rescans A.rowval for every cone).
+std::vector<long long> aggregate_sparsity(const std::vector<char>& act, long long row0, long long dimc, int N) {
+  std::vector<char> a(act.begin() + row0, act.begin() + row0 + dimc);
+  for (long long i = 1; i <= N; ++i) a[(size_t)(i * (i + 1) / 2 - 1)] = 1;
   std::vector<long long> out;
-  for (long long r = 0; r < dimc; ++r) if (act[(size_t)r]) out.push_back(r + 1);
+  for (long long r = 0; r < dimc; ++r) if (a[(size_t)r]) out.push_back(r + 1);
   return out;
 }
 
@@ -186,6 +183,10 @@ void run_decompose(cosmo_chordal& C, const int64_t* Ap, const int64_t* Ai, const
   const size_t nc = C.type.size();
   C.sp_of_cone.assign(nc, -1);
   const int64_t* ord_in = opt.orderings;
+  std::vector<char> act((size_t)C.m, 0);
+  { const long long nnz0 = Ap[C.n] - 1;
+    for (long long k = 0; k < nnz0; ++k) act[(size_t)(Ai[k] - 1)] = 1;
+    for (long long r = 0; r < C.m; ++r) if (b[r] != 0.0) act[(size_t)r] = 1; }
   // ---- find_sparsity_patterns! (chordal_decomposition.jl:41-77) ----
   for (size_t k = 0; k < nc; ++k) {
     if (C.type[k] != COSMO_HIP_PSD_TRIANGLE) continue;
@@ -194,7 +195,7 @@ void run_decompose(cosmo_chordal& C, const int64_t* Ap, const int64_t* Ai, const
     if ((long long)N * (N + 1) / 2 != dimc) throw std::runtime_error("PsdConeTriangle dimension is not triangular");
     const int64_t* my_ord = ord_in;
     if (ord_in) ord_in += N;
-    const std::vector<long long> csp = aggregate_sparsity(C, Ap, Ai, b, C.off[k], dimc, N);
+    const std::vector<long long> csp = aggregate_sparsity(act, C.off[k], dimc, N);
     if ((long long)csp.size() >= dimc) continue;               // dense cone: DenseEquivalent (:56-61)
     // find_graph! (trees.jl:634-645)
     std::vector<IntSet> adj(N);
