@@ -36,6 +36,7 @@ struct PolarCone {
   int idx;            // index in PsdPlan::cones
   int off, d, kind;
   int ts;             // tile side of the products (64 or 96), chosen per cone
+  int sk;             // 2: intra-workgroup split of k (8 waves), when the upper tiles give at most one tile per CU
   int ld;             // d rounded up to ts
   long long woff;     // offset of this cone's 4 work matrices (doubles)
 };
@@ -138,36 +139,43 @@ template <int TS> struct GemmCfg {
   static constexpr int CPITCH = TS + 1;              // odd: conflict-free column reads in the epilogue
   static constexpr int PANEL = PK * PITCH;           // doubles per operand panel
   static constexpr int SMEM = (4 * PANEL > TS * CPITCH ? 4 * PANEL : TS * CPITCH) * 8;
+  static constexpr int SMEM2 = (8 * PANEL > TS * CPITCH ? 8 * PANEL : TS * CPITCH) * 8;   // split-k: two groups of panels
 };
 
-template <int EPI, int TS>
+// SK = 2: intra-workgroup split of k.  8 waves; waves 0-3 (group 0) take the even k-panels, waves 4-7 (group 1) the odd ones, each
+// group with its own double-buffered LDS panels; the two partial tiles are added through LDS before the epilogue.  Used when the
+// tile count gives one tile per CU: two waves per SIMD then cover each other's LDS / barrier stalls (one wave per SIMD issues
+// MFMAs only ~59 % of the time).
+template <int EPI, int TS, int SK>
 __device__ __forceinline__ void symm_gemm_tile(const double* __restrict__ A, const double* __restrict__ B, const double* __restrict__ Cin,
                                                double* __restrict__ C, int ld, int ti, int tj, double alpha, double beta, double* smem) {
   using Cfg = GemmCfg<TS>;
   constexpr int NM = Cfg::NM, NL = Cfg::NL, PITCH = Cfg::PITCH, CPITCH = Cfg::CPITCH, PANEL = Cfg::PANEL;
-  double* As = smem;               // [2][PANEL]
-  double* Bs = smem + 2 * PANEL;   // [2][PANEL]
+  const int grp = (SK == 2) ? (threadIdx.x >> 8) : 0;          // k-split group of this wave
+  const int gtid = threadIdx.x & 255;                          // thread index within the group
+  double* As = smem + grp * 4 * PANEL;   // [2][PANEL] per group
+  double* Bs = As + 2 * PANEL;           // [2][PANEL]
   const int i0 = ti * TS, j0 = tj * TS;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) & 3;
   const int wi = wv & 1, wj = wv >> 1;
-  const long long pstep = (long long)PK * ld;
+  const long long pstep = (long long)PK * ld * SK;             // this group's next panel
   v4d acc[NM][NM];
 #pragma unroll
   for (int a = 0; a < NM; ++a)
 #pragma unroll
     for (int b = 0; b < NM; ++b) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
-  const int nk = ld / PK;   // >= 4
+  const int nk = ld / PK / SK;   // panels per group (ld / PK is a multiple of 4, so both groups run the same number of steps)
   // global -> LDS mapping: double2 number q = tid + 256 u of the PK x TS panel: k = q / (TS/2), index pair = q % (TS/2)
   int goff[NL], soff[NL];
 #pragma unroll
   for (int u = 0; u < NL; ++u) {
-    const int q = threadIdx.x + 256 * u;
+    const int q = gtid + 256 * u;
     const int k = q / (TS / 2), c2 = q % (TS / 2);
     goff[u] = k * ld + 2 * c2;
     soff[u] = k * PITCH + 2 * c2;
   }
-  const double* ga = A + i0;
-  const double* gb = B + j0;
+  const double* ga = A + i0 + (long long)grp * PK * ld;        // group 1 starts at panel 1
+  const double* gb = B + j0 + (long long)grp * PK * ld;
   double2 r[2][2 * NL];
 #define P_LOAD(R, KB)                                                                                     \
   {                                                                                                       \
@@ -219,20 +227,36 @@ __device__ __forceinline__ void symm_gemm_tile(const double* __restrict__ A, con
 #undef P_COMPUTE
   // ---- epilogue through LDS: Cs[j][i], pitch CPITCH ----
   double* Cs = smem;
+  if (SK == 2 && grp == 1) {
 #pragma unroll
-  for (int mi = 0; mi < NM; ++mi)
+    for (int mi = 0; mi < NM; ++mi)
 #pragma unroll
-    for (int nj = 0; nj < NM; ++nj)
+      for (int nj = 0; nj < NM; ++nj)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = (TS / 2) * wi + 16 * mi + (lane >> 4) + 4 * q;     // D row
-        const int j = (TS / 2) * wj + 16 * nj + (lane & 15);             // D col
-        Cs[j * CPITCH + i] = acc[mi][nj][q];
-      }
+        for (int q = 0; q < 4; ++q) {
+          const int i = (TS / 2) * wi + 16 * mi + (lane >> 4) + 4 * q;
+          const int j = (TS / 2) * wj + 16 * nj + (lane & 15);
+          Cs[j * CPITCH + i] = acc[mi][nj][q];
+        }
+  }
+  if (SK == 2) __syncthreads();
+  if (grp == 0) {
+#pragma unroll
+    for (int mi = 0; mi < NM; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < NM; ++nj)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = (TS / 2) * wi + 16 * mi + (lane >> 4) + 4 * q;     // D row
+          const int j = (TS / 2) * wj + 16 * nj + (lane & 15);             // D col
+          const double v = acc[mi][nj][q];
+          Cs[j * CPITCH + i] = (SK == 2) ? (v + Cs[j * CPITCH + i]) : v;   // even-panel partial + odd-panel partial (fixed order)
+        }
+  }
   __syncthreads();
   const bool diag = (ti == tj);
   // natural orientation: column j0 + j, rows i0 .. i0 + TS - 1 contiguous
-  for (int e = threadIdx.x; e < TS * TS; e += 256) {
+  for (int e = threadIdx.x; e < TS * TS; e += 256 * SK) {
     const int i = e % TS, j = e / TS;
     if (diag && i > j) continue;
     double v = Cs[j * CPITCH + i];
@@ -242,7 +266,7 @@ __device__ __forceinline__ void symm_gemm_tile(const double* __restrict__ A, con
   }
   __syncthreads();
   // mirrored orientation: column i0 + i, rows j0 .. j0 + TS - 1 contiguous
-  for (int e = threadIdx.x; e < TS * TS; e += 256) {
+  for (int e = threadIdx.x; e < TS * TS; e += 256 * SK) {
     const int j = e % TS, i = e / TS;
     if (diag && i >= j) continue;
     C[(long long)(i0 + i) * ld + j0 + j] = Cs[j * CPITCH + i];
@@ -250,8 +274,8 @@ __device__ __forceinline__ void symm_gemm_tile(const double* __restrict__ A, con
 }
 
 // one large cone: the grid walks its upper tiles
-template <int EPI, int TS>
-__global__ __launch_bounds__(256) void k_symm_gemm(const Ctl* __restrict__ ctl, int guard, const double* __restrict__ A, const double* __restrict__ B,
+template <int EPI, int TS, int SK>
+__global__ __launch_bounds__(256 * SK) void k_symm_gemm(const Ctl* __restrict__ ctl, int guard, const double* __restrict__ A, const double* __restrict__ B,
                                                    const double* __restrict__ Cin, double* __restrict__ C, int ld, int ntiles, double alpha, double beta) {
   if (guard && ctl->halt) return;
   extern __shared__ double smem[];
@@ -266,7 +290,7 @@ __global__ __launch_bounds__(256) void k_symm_gemm(const Ctl* __restrict__ ctl, 
   while ((long long)tj * (tj + 1) / 2 > t) --tj;
   while ((long long)(tj + 1) * (tj + 2) / 2 <= t) ++tj;
   const int ti = t - tj * (tj + 1) / 2;
-  symm_gemm_tile<EPI, TS>(A, B, Cin, C, ld, ti, tj, alpha, beta, smem);
+  symm_gemm_tile<EPI, TS, SK>(A, B, Cin, C, ld, ti, tj, alpha, beta, smem);
 }
 
 // a batch of mid-size cones: one workgroup per (cone, upper tile) descriptor; buffers 0..3 of a cone are X, U/Y, Y/U, T
@@ -280,22 +304,25 @@ __global__ __launch_bounds__(256) void k_symm_gemm_batch(const Ctl* __restrict__
   const BatchCone bc = cones[td.x];
   const long long n2 = (long long)bc.ld * bc.ld;
   double* base = W + bc.woff;
-  symm_gemm_tile<EPI, 64>(base + ia * n2, base + ib * n2, base + icin * n2, base + ic * n2, bc.ld, td.y, td.z, alpha, beta, smem);
+  symm_gemm_tile<EPI, 64, 1>(base + ia * n2, base + ib * n2, base + icin * n2, base + ic * n2, bc.ld, td.y, td.z, alpha, beta, smem);
 }
 
-template <int EPI, int TS>
+template <int EPI, int TS, int SK>
 static void launch_symm_gemm(cosmo_hip_handle* h, int guard, const double* A, const double* B, const double* Cin, double* C, int ld, double alpha,
                              double beta) {
   const int nt = ld / TS, ntiles = nt * (nt + 1) / 2;
+  constexpr int smem = (SK == 2) ? GemmCfg<TS>::SMEM2 : GemmCfg<TS>::SMEM;
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_symm_gemm<EPI, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<TS>::SMEM); attr_set = true; }
-  hipLaunchKernelGGL((k_symm_gemm<EPI, TS>), dim3(((ntiles + 7) / 8) * 8), dim3(256), GemmCfg<TS>::SMEM, h->stream, h->ctl, guard, A, B, Cin, C, ld, ntiles,
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_symm_gemm<EPI, TS, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_set = true; }
+  hipLaunchKernelGGL((k_symm_gemm<EPI, TS, SK>), dim3(((ntiles + 7) / 8) * 8), dim3(256 * SK), smem, h->stream, h->ctl, guard, A, B, Cin, C, ld, ntiles,
                      alpha, beta);
 }
-static void symm_gemm(cosmo_hip_handle* h, int guard, int ts, int epi, const double* A, const double* B, const double* Cin, double* C, int ld,
+// ts: tile side; sk: 1 or 2 (intra-workgroup split of k, only with ts = 96)
+static void symm_gemm(cosmo_hip_handle* h, int guard, int ts, int sk, int epi, const double* A, const double* B, const double* Cin, double* C, int ld,
                       double alpha, double beta) {
-  if (ts == 96) { if (epi) launch_symm_gemm<1, 96>(h, guard, A, B, Cin, C, ld, alpha, beta); else launch_symm_gemm<0, 96>(h, guard, A, B, Cin, C, ld, alpha, beta); }
-  else { if (epi) launch_symm_gemm<1, 64>(h, guard, A, B, Cin, C, ld, alpha, beta); else launch_symm_gemm<0, 64>(h, guard, A, B, Cin, C, ld, alpha, beta); }
+  if (ts == 96 && sk == 2) { if (epi) launch_symm_gemm<1, 96, 2>(h, guard, A, B, Cin, C, ld, alpha, beta); else launch_symm_gemm<0, 96, 2>(h, guard, A, B, Cin, C, ld, alpha, beta); }
+  else if (ts == 96) { if (epi) launch_symm_gemm<1, 96, 1>(h, guard, A, B, Cin, C, ld, alpha, beta); else launch_symm_gemm<0, 96, 1>(h, guard, A, B, Cin, C, ld, alpha, beta); }
+  else { if (epi) launch_symm_gemm<1, 64, 1>(h, guard, A, B, Cin, C, ld, alpha, beta); else launch_symm_gemm<0, 64, 1>(h, guard, A, B, Cin, C, ld, alpha, beta); }
 }
 
 // X+ = (X + H) / 2 written in the cone's layout (svec with sqrt(2) off-diagonals / mirrored square), trace(U) partials
@@ -446,6 +473,8 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
       }
       if (const char* e = getenv("COSMO_HIP_POLAR_TS")) { const int v = atoi(e); if (v == 64 || v == 96) pc.ts = v; }
       pc.ld = ((c.d + pc.ts - 1) / pc.ts) * pc.ts;
+      { const long long nt = pc.ld / pc.ts; pc.sk = (pc.ts == 96 && nt * (nt + 1) / 2 <= 256) ? 2 : 1; }
+      if (const char* e = getenv("COSMO_HIP_POLAR_SK")) { const int v = atoi(e); if (v == 1 || (v == 2 && pc.ts == 96)) pc.sk = v; }
       pc.woff = woff;
       woff += 4LL * pc.ld * pc.ld;
       q->cones.push_back(pc);
@@ -535,12 +564,12 @@ int32_t polar_enqueue_project(cosmo_hip_handle* h, double* s, int guard) {
     for (int it = 0; it < q->k1 + q->k2; ++it) {
       const bool ph1 = it < q->k1;
       const double a = ph1 ? 3.4445 : 15.0 / 8.0, b = ph1 ? -4.7750 : -10.0 / 8.0, c = ph1 ? 2.0315 : 3.0 / 8.0;
-      symm_gemm(h, guard, cn.ts, 0, U, U, nullptr, Y, cn.ld, 1.0, 0.0);     // Y = U^2
-      symm_gemm(h, guard, cn.ts, 1, Y, Y, Y, T, cn.ld, c, b);               // T = c Y^2 + b Y
-      symm_gemm(h, guard, cn.ts, 1, U, T, U, Y, cn.ld, 1.0, a);             // U' = U T + a U
+      symm_gemm(h, guard, cn.ts, cn.sk, 0, U, U, nullptr, Y, cn.ld, 1.0, 0.0);     // Y = U^2
+      symm_gemm(h, guard, cn.ts, cn.sk, 1, Y, Y, Y, T, cn.ld, c, b);               // T = c Y^2 + b Y
+      symm_gemm(h, guard, cn.ts, cn.sk, 1, U, T, U, Y, cn.ld, 1.0, a);             // U' = U T + a U
       std::swap(U, Y);
     }
-    symm_gemm(h, guard, cn.ts, 0, U, X, nullptr, T, cn.ld, 1.0, 0.0);       // H = U X = |X|
+    symm_gemm(h, guard, cn.ts, cn.sk, 0, U, X, nullptr, T, cn.ld, 1.0, 0.0);       // H = U X = |X|
     const int gfin = std::min(cn.d, 1024);
     hipLaunchKernelGGL(k_polar_finish, dim3(gfin), dim3(COSMO_BS), 0, st, h->ctl, guard, cn, X, T, U, s, tparts);
     hipLaunchKernelGGL(k_polar_rank, dim3(1), dim3(COSMO_BS), 0, st, h->ctl, guard, cn.d, gfin, tparts, p->rank + cn.idx, cn.kind);
