@@ -242,6 +242,7 @@ extern "C" int32_t cosmo_hip_destroy(cosmo_hip_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   free_csr(h->A); free_csr(h->AT); free_csr(h->P); free_csr(h->PT);
+  free_op_split(h);
   (void)cosmo_hip_comm_destroy(h);
   aa_free(h);
   free_vectors(h);
@@ -292,6 +293,7 @@ extern "C" int32_t cosmo_hip_set_problem(cosmo_hip_handle* h, int64_t n, int64_t
     for (int k = At.rowptr[j]; k < At.rowptr[j + 1]; ++k) { PT.col[p] = At.col[k] + (int)n; PT.val[p] = At.val[k]; ++p; }
   }
   PT.rowptr[n] = (int)p;
+  free_op_split(h);
   CHK(upload_csr(h, Am, h->A, (int)n));
   CHK(upload_csr(h, At, h->AT, (int)m));
   CHK(upload_csr(h, Pm, h->P, (int)n));
@@ -445,6 +447,87 @@ extern "C" int32_t cosmo_hip_set_cones_ex(cosmo_hip_handle* h, int64_t ncones, c
   return COSMO_HIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// CG operator split.  reduced_mul! applies  x -> P x + sigma x + A'(rho .* (A x))  (kktsolver_indirect.jl:57-64).  For a row i of
+// A with exactly ONE nonzero a_i in column j (slack / identity / overlap rows: every PSD row of BASELINE configs 4 and 5), the
+// contribution of that row to A' rho A is the scalar rho_i a_i^2 on the diagonal entry (j, j).  The CG iteration therefore only
+// needs the rows with two or more nonzeros as a matrix (Am, compact) plus a diagonal that is rebuilt whenever rho changes:
+//       x -> P x + (sigma + d) .* x + Am'(rho_m .* (Am x)),   d_j = sum_{single rows i, col j} rho_i a_i^2.
+// Same linear operator, different association (rounding differs at the 1e-16 level; CG iteration counts within +-1 in the
+// parity tests).  Enabled when the single rows hold at least half of nnz(A).  Residuals, rhs and tail keep the full matrices.
+// Built from the DEVICE copies at set_params time, i.e. after an optional cosmo_hip_scale_ruiz.
+// ---------------------------------------------------------------------------------------------------------------------
+void free_op_split(cosmo_hip_handle* h) {
+  free_csr(h->Am); free_csr(h->PTm);
+  dfree(&h->op_mrow); dfree(&h->op_sc_ptr); dfree(&h->op_sc_row); dfree(&h->op_sc_a2); dfree(&h->op_diag); dfree(&h->op_rho_m);
+  h->op_split = false; h->op_nsingle = 0;
+}
+
+int32_t build_op_split(cosmo_hip_handle* h) {
+  free_op_split(h);
+  if (const char* e = getenv("COSMO_HIP_OP_SPLIT")) if (e[0] == '0') return COSMO_HIP_OK;
+  if (h->prm.kkt_kind != COSMO_HIP_KKT_CG) return COSMO_HIP_OK;
+  const long long n = h->n, m = h->m, nnzA = h->A.nnz, nnzP = h->P.nnz;
+  if (m == 0 || nnzA == 0) return COSMO_HIP_OK;
+  std::vector<int> arp((size_t)m + 1), acol((size_t)nnzA), prp((size_t)n + 1), pcol((size_t)std::max<long long>(nnzP, 1));
+  std::vector<double> aval((size_t)nnzA), pval((size_t)std::max<long long>(nnzP, 1));
+  CHK(d2h(h, arp.data(), h->A.rowptr, (size_t)m + 1)); CHK(d2h(h, acol.data(), h->A.col, (size_t)nnzA)); CHK(d2h(h, aval.data(), h->A.val, (size_t)nnzA));
+  CHK(d2h(h, prp.data(), h->P.rowptr, (size_t)n + 1));
+  if (nnzP) { CHK(d2h(h, pcol.data(), h->P.col, (size_t)nnzP)); CHK(d2h(h, pval.data(), h->P.val, (size_t)nnzP)); }
+  long long nsingle = 0;
+  for (long long i = 0; i < m; ++i) if (arp[i + 1] - arp[i] == 1) ++nsingle;
+  if (nsingle * 2 < nnzA) return COSMO_HIP_OK;
+  // Am: rows with >= 2 nonzeros, compact
+  HostCsr Am, AmT, PTm;
+  std::vector<int> mrow;
+  Am.ncols = (int)n; Am.rowptr.push_back(0);
+  std::vector<int> sc_cnt((size_t)n + 1, 0);
+  for (long long i = 0; i < m; ++i) {
+    const int len = arp[i + 1] - arp[i];
+    if (len >= 2) {
+      mrow.push_back((int)i);
+      for (int k = arp[i]; k < arp[i + 1]; ++k) { Am.col.push_back(acol[k]); Am.val.push_back(aval[k]); }
+      Am.rowptr.push_back((int)Am.col.size());
+    } else if (len == 1) {
+      sc_cnt[(size_t)acol[arp[i]] + 1]++;
+    }
+  }
+  Am.nrows = (int)mrow.size();
+  const int mm = Am.nrows;
+  // singles grouped by column, rows ascending (fixed summation order of the diagonal)
+  std::vector<int> sc_ptr((size_t)n + 1, 0), sc_row((size_t)nsingle);
+  std::vector<double> sc_a2((size_t)nsingle);
+  for (long long j = 0; j < n; ++j) sc_ptr[j + 1] = sc_ptr[j] + sc_cnt[j + 1];
+  { std::vector<int> pos(sc_ptr.begin(), sc_ptr.end() - 1);
+    for (long long i = 0; i < m; ++i) if (arp[i + 1] - arp[i] == 1) { const int k = arp[i], j = acol[k], p = pos[j]++; sc_row[p] = (int)i; sc_a2[p] = aval[k] * aval[k]; } }
+  // Am' (CSR over the n columns)
+  AmT.nrows = (int)n; AmT.ncols = mm; AmT.rowptr.assign((size_t)n + 1, 0);
+  for (int c : Am.col) AmT.rowptr[(size_t)c + 1]++;
+  for (long long j = 0; j < n; ++j) AmT.rowptr[j + 1] += AmT.rowptr[j];
+  AmT.col.resize(Am.col.size()); AmT.val.resize(Am.col.size());
+  { std::vector<int> pos(AmT.rowptr.begin(), AmT.rowptr.end() - 1);
+    for (int r = 0; r < mm; ++r) for (int k = Am.rowptr[r]; k < Am.rowptr[r + 1]; ++k) { const int p = pos[Am.col[k]]++; AmT.col[p] = r; AmT.val[p] = Am.val[k]; } }
+  // merged [P | Am']
+  PTm.nrows = (int)n; PTm.ncols = (int)(n + mm); PTm.rowptr.assign((size_t)n + 1, 0); PTm.split.assign((size_t)n, 0);
+  PTm.col.reserve((size_t)nnzP + AmT.col.size()); PTm.val.reserve((size_t)nnzP + AmT.col.size());
+  for (long long j = 0; j < n; ++j) {
+    PTm.rowptr[j] = (int)PTm.col.size();
+    for (int k = prp[j]; k < prp[j + 1]; ++k) { PTm.col.push_back(pcol[k]); PTm.val.push_back(pval[k]); }
+    PTm.split[j] = (int)PTm.col.size();
+    for (int k = AmT.rowptr[j]; k < AmT.rowptr[j + 1]; ++k) { PTm.col.push_back(AmT.col[k] + (int)n); PTm.val.push_back(AmT.val[k]); }
+  }
+  PTm.rowptr[n] = (int)PTm.col.size();
+  CHK(upload_csr(h, Am, h->Am, (int)n));
+  CHK(upload_csr(h, PTm, h->PTm, (int)n));
+  CHK(dalloc(h, &h->op_mrow, (size_t)std::max(mm, 1))); CHK(dalloc(h, &h->op_sc_ptr, (size_t)n + 1)); CHK(dalloc(h, &h->op_sc_row, (size_t)nsingle));
+  CHK(dalloc(h, &h->op_sc_a2, (size_t)nsingle)); CHK(dalloc(h, &h->op_diag, (size_t)n)); CHK(dalloc(h, &h->op_rho_m, (size_t)std::max(mm, 1)));
+  if (mm) CHK(h2d(h, h->op_mrow, mrow.data(), (size_t)mm));
+  CHK(h2d(h, h->op_sc_ptr, sc_ptr.data(), (size_t)n + 1)); CHK(h2d(h, h->op_sc_row, sc_row.data(), (size_t)nsingle)); CHK(h2d(h, h->op_sc_a2, sc_a2.data(), (size_t)nsingle));
+  h->op_nsingle = nsingle;
+  h->op_split = true;
+  return refresh_op_split(h);
+}
+
 extern "C" int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_params* p, const double* rho_vec) {
   ENTER(h);
   if (!p) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "null params");
@@ -476,13 +559,14 @@ extern "C" int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_par
   HIPCHK(h, hipMemsetAsync(h->x_tl, 0, sizeof(double) * (size_t)std::max<long long>(h->n, 1), h->stream));
   HIPCHK(h, hipMemsetAsync(h->nu, 0, sizeof(double) * (size_t)std::max<long long>(h->m, 1), h->stream));
   h->have_params = true;
-  return COSMO_HIP_OK;
+  return build_op_split(h);   // needs the (scaled) matrices and rho: both final from here on
 }
 
 extern "C" int32_t cosmo_hip_update_rho(cosmo_hip_handle* h, const double* rho_vec) {
   ENTER(h);
   if (!h->have_params || !rho_vec) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "update_rho: not set up");
-  return h2d(h, h->rho, rho_vec, (size_t)h->m);
+  CHK(h2d(h, h->rho, rho_vec, (size_t)h->m));
+  return refresh_op_split(h);
 }
 
 static int32_t upload_or_ones(cosmo_hip_handle* h, double* dst, const double* src, size_t n) {

@@ -91,6 +91,14 @@ struct cosmo_hip_handle {
   bool have_problem = false, have_cones = false, have_params = false, have_iterates = false;
   // matrices
   CsrDev A, AT, P, PT;
+  // CG operator split (api.hip: build_op_split): rows of A with exactly one nonzero contribute a DIAGONAL to A' rho A;
+  // Am = the other rows (compact), PTm = [P | Am'], op_diag[j] = sum_{single rows i in column j} rho_i a_i^2, rho_m = rho on Am's rows
+  bool op_split = false;
+  CsrDev Am, PTm;
+  int* op_mrow = nullptr;          // Am row -> row of A
+  int *op_sc_ptr = nullptr, *op_sc_row = nullptr;
+  double *op_sc_a2 = nullptr, *op_diag = nullptr, *op_rho_m = nullptr;
+  long long op_nsingle = 0;
   // data vectors
   double *q = nullptr, *b = nullptr, *rho = nullptr, *Dinv = nullptr, *Einv = nullptr, *Dscale = nullptr, *Escale = nullptr;
   double *inf_dy = nullptr, *inf_dx = nullptr, *inf_adx = nullptr;   // infeasibility work vectors (infeas.hip)
@@ -180,6 +188,11 @@ void free_csr(CsrDev& D);
 void prof_begin(cosmo_hip_handle* h, int kc);
 void prof_end(cosmo_hip_handle* h);
 int32_t prof_collect(cosmo_hip_handle* h);
+
+// CG operator split
+int32_t build_op_split(cosmo_hip_handle* h);
+int32_t refresh_op_split(cosmo_hip_handle* h);
+void free_op_split(cosmo_hip_handle* h);
 
 // plain y = M x (fine-grained ABI + building block)
 int32_t launch_spmv_plain(cosmo_hip_handle* h, const CsrDev& M, const double* x, double* y);

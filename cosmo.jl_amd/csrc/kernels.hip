@@ -196,7 +196,8 @@ __global__ __launch_bounds__(COSMO_BS) void k_op_apply(Ctl* __restrict__ ctl, in
                                                        const double* __restrict__ v, const double* __restrict__ tmp,
                                                        const double* __restrict__ rhs, double* __restrict__ r,
                                                        double* __restrict__ c, double* __restrict__ part_out,
-                                                       const double* __restrict__ part_bb, int n_bb, double tol_k) {
+                                                       const double* __restrict__ part_bb, int n_bb, double tol_k,
+                                                       const double* __restrict__ diag) {
   if (guard && ctl->halt) return;
   if (mode == 1 && ctl->cg_done) return;
   __shared__ double lds[COSMO_NNZ_PER_BLOCK];
@@ -213,7 +214,8 @@ __global__ __launch_bounds__(COSMO_BS) void k_op_apply(Ctl* __restrict__ ctl, in
   for (int k = blockIdx.x; k < PT.nb; k += gridDim.x) {
     csr_stream_tile(PT, v, tmp, k, lds, red, [&](int row, double s1, double s2) {
       const double vj = v[row];
-      const double cj = s1 + (sigma * vj + s2);
+      double cj = s1 + (sigma * vj + s2);
+      if (diag) cj += diag[row] * vj;      // singleton rows of A: their part of A' rho A is diagonal (build_op_split)
       if (mode == 0) {
         const double rj = rhs[row] - cj;
         r[row] = rj;
@@ -593,23 +595,27 @@ int32_t launch_rho_from_classes(cosmo_hip_handle* h, double rho0) {
 int32_t enqueue_cg_iterations(cosmo_hip_handle* h, int guard, int k_begin, int count) {
   const long long n = h->n;
   const int gE = ew_grid(n);
-  const int n_rr0 = h->PT.grid;
+  const CsrDev& Ao = h->op_split ? h->Am : h->A;
+  const CsrDev& PTo = h->op_split ? h->PTm : h->PT;
+  const double* rho_o = h->op_split ? h->op_rho_m : h->rho;
+  const double* diag_o = h->op_split ? h->op_diag : nullptr;
+  const int n_rr0 = PTo.grid;
   for (int k = k_begin; k < k_begin + count; ++k) {
     prof_begin(h, KC_CG_DIR);
     hipLaunchKernelGGL(k_cg_dir, dim3(gE), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, k, 0, n, n, PARTS(h, SLOT_RR),
                        (k == 0) ? n_rr0 : gE, h->r, h->u);
     prof_end(h);
     prof_begin(h, KC_SPMV_A);
-    hipLaunchKernelGGL(k_spmv_A_rho, dim3(h->A.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, 1, view_of(h->A), h->u,
-                       h->rho, h->tmp_m);
+    hipLaunchKernelGGL(k_spmv_A_rho, dim3(Ao.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, 1, view_of(Ao), h->u,
+                       rho_o, h->tmp_m);
     prof_end(h);
     prof_begin(h, KC_OP_APPLY);
-    hipLaunchKernelGGL(k_op_apply, dim3(h->PT.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, 1, view_of(h->PT),
-                       h->prm.sigma, h->u, h->tmp_m, h->rhs, h->r, h->c, PARTS(h, SLOT_UC), PARTS(h, SLOT_BB), 0, 0.0);
+    hipLaunchKernelGGL(k_op_apply, dim3(PTo.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, 1, view_of(PTo),
+                       h->prm.sigma, h->u, h->tmp_m, h->rhs, h->r, h->c, PARTS(h, SLOT_UC), PARTS(h, SLOT_BB), 0, 0.0, diag_o);
     prof_end(h);
     prof_begin(h, KC_CG_UPD);
     hipLaunchKernelGGL(k_cg_upd, dim3(gE), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, k, n, PARTS(h, SLOT_UC),
-                       h->PT.grid, h->u, h->c, h->x_tl, h->r, PARTS(h, SLOT_RR));
+                       PTo.grid, h->u, h->c, h->x_tl, h->r, PARTS(h, SLOT_RR));
     prof_end(h);
     h->spmv_calls[0] += 1; h->spmv_calls[1] += 1; h->spmv_calls[2] += 1;
   }
@@ -628,14 +634,16 @@ int32_t enqueue_cg_start(cosmo_hip_handle* h, int guard, double tol_k) {
   hipLaunchKernelGGL(k_cg_rhs, dim3(h->AT.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, view_of(h->AT), h->y2,
                      h->ls_x, h->rhs, PARTS(h, SLOT_BB));
   prof_end(h);
+  const CsrDev& Ao = h->op_split ? h->Am : h->A;
+  const CsrDev& PTo = h->op_split ? h->PTm : h->PT;
   prof_begin(h, KC_SPMV_A);
-  hipLaunchKernelGGL(k_spmv_A_rho, dim3(h->A.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, 0, view_of(h->A), h->x_tl,
-                     h->rho, h->tmp_m);
+  hipLaunchKernelGGL(k_spmv_A_rho, dim3(Ao.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, 0, view_of(Ao), h->x_tl,
+                     h->op_split ? h->op_rho_m : h->rho, h->tmp_m);
   prof_end(h);
   prof_begin(h, KC_OP_APPLY);
-  hipLaunchKernelGGL(k_op_apply, dim3(h->PT.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, 0, view_of(h->PT),
+  hipLaunchKernelGGL(k_op_apply, dim3(PTo.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, 0, view_of(PTo),
                      h->prm.sigma, h->x_tl, h->tmp_m, h->rhs, h->r, h->c, PARTS(h, SLOT_RR), PARTS(h, SLOT_BB),
-                     h->AT.grid, tol_k);
+                     h->AT.grid, tol_k, h->op_split ? h->op_diag : nullptr);
   prof_end(h);
   h->spmv_calls[0] += 1; h->spmv_calls[1] += 2; h->spmv_calls[2] += 1;
   HIPCHK(h, hipGetLastError());
@@ -710,6 +718,7 @@ int32_t enqueue_check(cosmo_hip_handle* h, int guard, int mode) {
     prof_begin(h, KC_RHO_APPLY);
     hipLaunchKernelGGL(k_rho_apply, dim3(ew_grid(h->m > 0 ? h->m : 1)), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, h->n,
                        h->m, h->rho_cls, h->prm.rho_min, h->prm.rho_eq_over_rho_ineq, h->mu, h->s, h->rho, h->w);
+    CHK(refresh_op_split(h));      // rho may have changed on the device: the diagonal part of A' rho A follows (cheap, unconditional)
     prof_end(h);
   }
   h->spmv_calls[0] += 1; h->spmv_calls[1] += 1; h->spmv_calls[2] += 1;
@@ -721,8 +730,32 @@ int32_t enqueue_check(cosmo_hip_handle* h, int guard, int mode) {
 int32_t time_op_apply(cosmo_hip_handle* h, int reps, double* avg_seconds) {
   (void)avg_seconds;
   for (int i = 0; i < reps; ++i)
-    hipLaunchKernelGGL(k_op_apply, dim3(h->PT.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, 0, 2, view_of(h->PT),
-                       h->prm.sigma, h->u, h->tmp_m, h->rhs, h->r, h->c, PARTS(h, SLOT_AUX0), PARTS(h, SLOT_BB), 0, 0.0);
+    hipLaunchKernelGGL(k_op_apply, dim3((h->op_split ? h->PTm : h->PT).grid), dim3(COSMO_BS), 0, h->stream, h->ctl, 0, 2,
+                       view_of(h->op_split ? h->PTm : h->PT), h->prm.sigma, h->u, h->tmp_m, h->rhs, h->r, h->c, PARTS(h, SLOT_AUX0),
+                       PARTS(h, SLOT_BB), 0, 0.0, h->op_split ? h->op_diag : nullptr);
+  HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}
+
+// ---- CG operator split: refresh of the rho-dependent pieces -----------------------------------------------------------
+__global__ __launch_bounds__(COSMO_BS) void k_op_refresh(long long n, long long mm, const int* __restrict__ sc_ptr, const int* __restrict__ sc_row,
+                                                         const double* __restrict__ sc_a2, const int* __restrict__ mrow,
+                                                         const double* __restrict__ rho, double* __restrict__ diag, double* __restrict__ rho_m) {
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < n + mm; i += (long long)gridDim.x * COSMO_BS) {
+    if (i < n) {
+      double s = 0.0;
+      for (int k = sc_ptr[i]; k < sc_ptr[i + 1]; ++k) s += rho[sc_row[k]] * sc_a2[k];     // fixed order: rows ascending
+      diag[i] = s;
+    } else {
+      rho_m[i - n] = rho[mrow[i - n]];
+    }
+  }
+}
+int32_t refresh_op_split(cosmo_hip_handle* h) {
+  if (!h->op_split) return COSMO_HIP_OK;
+  const long long mm = h->Am.nrows;
+  hipLaunchKernelGGL(k_op_refresh, dim3(ew_grid(h->n + mm)), dim3(COSMO_BS), 0, h->stream, h->n, mm, h->op_sc_ptr, h->op_sc_row, h->op_sc_a2,
+                     h->op_mrow, h->rho, h->op_diag, h->op_rho_m);
   HIPCHK(h, hipGetLastError());
   return COSMO_HIP_OK;
 }
