@@ -240,3 +240,25 @@ def test_closest_correlation_end_to_end_polar_path():
     assert np.max(np.abs(res.x - ref.x)) <= 1e-7 * max(1.0, np.max(np.abs(ref.x)))
     assert np.allclose(res.info.rho_updates, ref.rho_updates, rtol=1e-6)
     assert abs(res.info.r_prim - ref.r_prim) <= 1e-6 * max(ref.r_prim, 1e-12) + 1e-12
+
+
+def test_cg_operator_split_is_the_same_operator(monkeypatch):
+    """Singleton rows of A as a diagonal of A' rho A (csrc/api.hip: build_op_split): the split and the unsplit CG operator give the
+    same KKT solutions, iteration counts and ADMM trajectories (a re-association, not a different algorithm)."""
+    prob = cj.problems.chordal_sdp(ncliques=12, dmin=4, dmax=40, sep_min=1, sep_max=3, n_total=1500, n_zero=10, n_nonneg=20)
+    out = {}
+    for split in ("1", "0"):
+        monkeypatch.setenv("COSMO_HIP_OP_SPLIT", split)
+        model = cj.Model()
+        model.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], cj.Settings(max_iter=60, eps_abs=0.0, eps_rel=0.0, check_infeasibility=10 ** 9,
+                                                                                     kkt_solver=cj.with_options(cj.CGIndirectKKTSolver, tol_constant=1e-10, tol_exponent=0.0)))
+        res = cj.optimize(model)
+        rhs = np.random.default_rng(1).standard_normal(model.n + model.m)
+        sol, its = model.handle.kkt_solve(rhs)
+        out[split] = (res, sol, its)
+    (r1, s1, k1), (r0, s0, k0) = out["1"], out["0"]
+    assert r1.iter == r0.iter == 60 and abs(k1 - k0) <= 1
+    assert abs(r1.kkt_iters_total - r0.kkt_iters_total) <= 0.02 * r0.kkt_iters_total
+    assert np.linalg.norm(s1 - s0) <= 1e-8 * np.linalg.norm(s0)
+    assert np.max(np.abs(r1.x - r0.x)) <= 1e-7 * max(1.0, np.max(np.abs(r0.x)))
+    assert np.allclose(r1.info.rho_updates, r0.info.rho_updates, rtol=1e-9)
