@@ -787,12 +787,12 @@ static int32_t enqueue_solve_in_loop(cosmo_hip_handle* h) {
 // iteration: delta_y is captured at its top (:145-148) and the certificates are tested at its end.
 static bool inf_due(const cosmo_hip_handle* h, long long it) {
   const long long ci = h->prm.check_infeasibility;
-  if (ci <= 0 || ci > (1LL << 40) || h->comm) return false;   // sharded runs: membership tests would need the full cone tables
+  if (ci <= 0 || ci > (1LL << 40)) return false;   // sharded runs: every rank tests its own cones, flags are max-reduced (comm.hip)
   return it > 1 && ((it - 1) % ci) == 0 && (it % ci) != 0;
 }
 static long long next_inf_iter(const cosmo_hip_handle* h, long long it) {   // smallest it' > it with inf_due(it'), or a huge value
   const long long ci = h->prm.check_infeasibility;
-  if (ci <= 1 || ci > (1LL << 40) || h->comm) return INT64_MAX;
+  if (ci <= 1 || ci > (1LL << 40)) return INT64_MAX;
   const long long k = (it <= 0) ? 1 : (it - 1) / ci + 1;   // it' = k ci + 1 with k >= 1 and it' > it
   return k * ci + 1;
 }

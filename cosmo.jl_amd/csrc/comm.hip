@@ -26,6 +26,7 @@ struct RcclApi {
   int (*CommInitRank)(nccl_comm_t*, int, nccl_uid_t, int) = nullptr;
   int (*CommDestroy)(nccl_comm_t) = nullptr;
   int (*Broadcast)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
@@ -42,10 +43,11 @@ static const char* rccl_load() {
   g_rccl.CommInitRank = (int (*)(nccl_comm_t*, int, nccl_uid_t, int))dlsym(lib, "ncclCommInitRank");
   g_rccl.CommDestroy = (int (*)(nccl_comm_t))dlsym(lib, "ncclCommDestroy");
   g_rccl.Broadcast = (int (*)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t))dlsym(lib, "ncclBroadcast");
+  g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t))dlsym(lib, "ncclAllReduce");
   g_rccl.GroupStart = (int (*)())dlsym(lib, "ncclGroupStart");
   g_rccl.GroupEnd = (int (*)())dlsym(lib, "ncclGroupEnd");
   g_rccl.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
-  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.Broadcast || !g_rccl.GroupStart || !g_rccl.GroupEnd)
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.Broadcast || !g_rccl.AllReduce || !g_rccl.GroupStart || !g_rccl.GroupEnd)
     return "librccl.so lacks an expected symbol";
   g_rccl.lib = lib;
   return nullptr;
@@ -63,6 +65,7 @@ struct CommState {
   int rank = 0, nranks = 1;
   std::vector<long long> first_cone;   // nranks + 1 boundaries (cone indices)
   std::vector<long long> row_lo, row_hi;
+  int* d_flag = nullptr;               // 2 ints: send / receive buffer of comm_allreduce_flag
 };
 
 extern "C" int32_t cosmo_hip_comm_unique_id(uint8_t id[128]) {
@@ -78,6 +81,7 @@ extern "C" int32_t cosmo_hip_comm_destroy(cosmo_hip_handle* h) {
   if (!h || !h->comm) return COSMO_HIP_OK;
   CommState* c = (CommState*)h->comm;
   if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+  if (c->d_flag) (void)hipFree(c->d_flag);
   delete c;
   h->comm = nullptr;
   h->cone_lo = 0; h->cone_hi = -1;
@@ -147,6 +151,21 @@ int32_t comm_enqueue_exchange(cosmo_hip_handle* h, double* s) {
     NCHK(h, g_rccl.Broadcast(s + c->row_lo[r], s + c->row_lo[r], (size_t)cnt, NCCL_FLOAT64, r, c->comm, h->stream));
   }
   NCHK(h, g_rccl.GroupEnd());
+  return COSMO_HIP_OK;
+}
+
+// Infeasibility certificates in clique-sharded runs: every rank tests the SOC / PSD cones it owns; `*flag` (0 / 1, "a cone of mine
+// violates the membership test") is combined with a max over the ranks.  All ranks take the same branches up to here (the
+// scalars of the certificates are computed redundantly and bit-identically), so the collective is matched.  ncclInt32 = 2,
+// ncclMax = 2.  Synchronous (the caller needs the decision on the host).
+int32_t comm_allreduce_flag(cosmo_hip_handle* h, int* flag) {
+  if (!h->comm) return COSMO_HIP_OK;
+  CommState* c = (CommState*)h->comm;
+  if (!c->d_flag) HIPCHK(h, hipMalloc((void**)&c->d_flag, 2 * sizeof(int)));
+  HIPCHK(h, hipMemcpyAsync(c->d_flag, flag, sizeof(int), hipMemcpyHostToDevice, h->stream));
+  NCHK(h, g_rccl.AllReduce(c->d_flag, c->d_flag + 1, 1, 2, 2, c->comm, h->stream));
+  HIPCHK(h, hipMemcpyAsync(flag, c->d_flag + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   return COSMO_HIP_OK;
 }
 

@@ -115,20 +115,7 @@ struct cosmo_hip_handle {
   int nsoc = 0;                   // SOC table
   int *soc_off = nullptr, *soc_dim = nullptr, *soc_branch = nullptr;
   std::vector<int> soc_cone_index;
-  int ncone3 = 0;                 // Anderson acceleration (anderson.hip)
-void aa_free(cosmo_hip_handle* h);
-bool aa_enabled(const cosmo_hip_handle* h);
-bool aa_safeguarded(const cosmo_hip_handle* h);
-bool aa_active(const cosmo_hip_handle* h);
-int32_t aa_restart(cosmo_hip_handle* h);
-int32_t aa_begin_solve(cosmo_hip_handle* h);
-int32_t aa_enqueue_pre(cosmo_hip_handle* h, long long it, bool* attempted);
-int32_t aa_fetch_flags(cosmo_hip_handle* h, int* success, int* declined);
-int32_t aa_enqueue_guard(cosmo_hip_handle* h);
-int32_t aa_enqueue_reset(cosmo_hip_handle* h);
-void aa_count(cosmo_hip_handle* h, int accelerated, int declined);
-
-// exponential / power cones (cone3.hip)
+  int ncone3 = 0;                 // exponential / power cones (cone3.hip)
   int *c3_off = nullptr, *c3_kind = nullptr, *c3_branch = nullptr;
   double* c3_alpha = nullptr;
   std::vector<int> c3_cone_index;
@@ -202,6 +189,8 @@ int32_t enqueue_projection(cosmo_hip_handle* h, const double* src, double* dst, 
                            const double* w_src, bool in_loop);
 int32_t enqueue_admm_x_and_w(cosmo_hip_handle* h);
 int32_t sync_ctl(cosmo_hip_handle* h);
+
+int32_t comm_allreduce_flag(cosmo_hip_handle* h, int* flag);   // comm.hip: max over the ranks of a 0/1 flag
 
 // Anderson acceleration (anderson.hip)
 void aa_free(cosmo_hip_handle* h);

@@ -64,3 +64,27 @@ def test_single_rank_communicator_rccl_path():
     res = cj.optimize(model)
     assert res.status == ref.status and res.iter == ref.iter
     assert np.array_equal(res.x, ref.x) and np.array_equal(res.s, ref.s)
+
+
+def test_infeasibility_certificates_in_sharded_runs():
+    """Clique-sharded runs keep the certificates: every rank tests the cones it owns and the violation flags are max-reduced
+    over the communicator (csrc/comm.hip: comm_allreduce_flag).  Exercised here with a single-rank communicator."""
+    cases = []
+    # primal infeasible SDP (3x3, svec variables): X psd and X11 = -1 ; plus an SOC block so that both cone kinds are owned
+    nt = 6
+    A = sp.vstack([sp.csc_matrix(([1.0], ([0], [0])), shape=(1, nt + 3)), sp.hstack([sp.identity(nt), sp.csc_matrix((nt, 3))]),
+                   sp.hstack([sp.csc_matrix((3, nt)), sp.identity(3)])], format="csc")
+    b = np.concatenate([[1.0], np.zeros(nt + 3)])
+    cases.append((sp.csc_matrix((nt + 3, nt + 3)), np.zeros(nt + 3), [cj.Constraint(A[:1], b[:1], cj.ZeroSet), cj.Constraint(A[1:1 + nt], b[1:1 + nt], cj.PsdConeTriangle),
+                                                                       cj.Constraint(A[1 + nt:], b[1 + nt:], cj.SecondOrderCone)], "Primal_infeasible"))
+    # dual infeasible SOCP: minimise -t over the cone
+    cases.append((sp.csc_matrix((3, 3)), np.array([-1.0, 0.0, 0.0]), [cj.Constraint(sp.identity(3, format="csc"), np.zeros(3), cj.SecondOrderCone)], "Dual_infeasible"))
+    for P, q, cons, want in cases:
+        ref_model = cj.Model(); cj.assemble(ref_model, P, q, cons, settings=cj.Settings())
+        ref = cj.optimize(ref_model)
+        model = cj.Model(); cj.assemble(model, P, q, cons, settings=cj.Settings())
+        cj.model.setup(model)
+        model.handle.comm_init(0, 1, cj.Handle.comm_unique_id())
+        model.handle.set_cone_shard(cj.partition_cones_contiguous(cj.cone_costs(model.sets), 1))
+        res = cj.optimize(model)
+        assert ref.status == want and res.status == want and res.iter == ref.iter
