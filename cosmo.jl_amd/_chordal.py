@@ -16,7 +16,7 @@ _PI32 = C.POINTER(C.c_int32)
 
 
 class Options(C.Structure):
-    _fields_ = [("merge_strategy", C.c_int32), ("t_fill", C.c_int32), ("t_size", C.c_int32), ("orderings", _PI64)]
+    _fields_ = [("merge_strategy", C.c_int32), ("t_fill", C.c_int32), ("t_size", C.c_int32), ("orderings", _PI64), ("compact_transformation", C.c_int32)]
 
 
 SIGNATURES = {
@@ -82,7 +82,7 @@ def _sets_csr(sets):
 class Decomposition:
     """One decomposed problem: `ws.ci` + the augmented `ws.p` of the reference."""
 
-    def __init__(self, A, b, kinds, dims, merge_strategy=CLIQUE_GRAPH_MERGE, t_fill=8, t_size=8, orderings=None):
+    def __init__(self, A, b, kinds, dims, merge_strategy=CLIQUE_GRAPH_MERGE, t_fill=8, t_size=8, orderings=None, compact=True):
         lib = load_library()
         self.lib = lib
         A = sp.csc_matrix(A, dtype=np.float64)
@@ -96,6 +96,8 @@ class Decomposition:
         opt = Options()
         lib.cosmo_chordal_default_options(C.byref(opt))
         opt.merge_strategy, opt.t_fill, opt.t_size = int(merge_strategy), int(t_fill), int(t_size)
+        opt.compact_transformation = 1 if compact else 0
+        self.compact = bool(compact)
         self._ord = None
         if orderings is not None:
             self._ord = _i64(np.concatenate([np.asarray(o, dtype=np.int64) for o in orderings]))

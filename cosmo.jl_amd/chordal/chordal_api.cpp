@@ -35,6 +35,7 @@ struct SparsityPattern {   // src/types.jl:183-215
   long long row_start = 0;     // first row (0-based) of the cone in the original problem
   int cone_ind = 0;            // index of the original cone
   int N = 0;                   // side of the matrix
+  int type = COSMO_HIP_PSD_TRIANGLE;   // PsdConeTriangle or PsdCone (square; traditional transformation only)
 };
 
 struct NewCone { int type; long long dim; int orig; int sp; int clique; };   // clique: post-order index (0-based) or -1
@@ -52,6 +53,9 @@ struct cosmo_chordal {
   std::vector<long long> colptr, rowval;   // 0-based internally
   std::vector<double> nzval, b_new;
   std::vector<NewCone> cones_new;
+  bool compact = true;
+  // traditional transformation: stacked entry e (column mO.. of the augmented A) -> original row H_I[e] (0-based)
+  std::vector<long long> H_I;
 };
 
 namespace {
@@ -189,17 +193,32 @@ void run_decompose(cosmo_chordal& C, const int64_t* Ap, const int64_t* Ai, const
     for (long long r = 0; r < C.m; ++r) if (b[r] != 0.0) act[(size_t)r] = 1; }
   // ---- find_sparsity_patterns! (chordal_decomposition.jl:41-77) ----
   for (size_t k = 0; k < nc; ++k) {
-    if (C.type[k] != COSMO_HIP_PSD_TRIANGLE) continue;
+    const bool tri = C.type[k] == COSMO_HIP_PSD_TRIANGLE, sq = C.type[k] == COSMO_HIP_PSD_SQUARE && !C.compact;
+    if (!tri && !sq) continue;
     const long long dimc = C.dim[k];
-    const int N = (int)((std::llround(std::floor(std::sqrt(1.0 + 8.0 * (double)dimc))) - 1) / 2);
-    if ((long long)N * (N + 1) / 2 != dimc) throw std::runtime_error("PsdConeTriangle dimension is not triangular");
+    const int N = tri ? (int)((std::llround(std::floor(std::sqrt(1.0 + 8.0 * (double)dimc))) - 1) / 2) : (int)std::llround(std::sqrt((double)dimc));
+    if (tri && (long long)N * (N + 1) / 2 != dimc) throw std::runtime_error("PsdConeTriangle dimension is not triangular");
+    if (sq && (long long)N * N != dimc) throw std::runtime_error("PsdCone dimension is not a square");
     const int64_t* my_ord = ord_in;
     if (ord_in) ord_in += N;
-    const std::vector<long long> csp = aggregate_sparsity(act, C.off[k], dimc, N);
+    std::vector<long long> csp;
+    if (tri) csp = aggregate_sparsity(act, C.off[k], dimc, N);
+    else {
+      // square cone: the reference flags the positions vec_dim(i, C) = i^2 instead of the diagonal (chordal_decomposition.jl:109-111
+      // with trees.jl:261) -- kept: it only adds the edges those positions stand for
+      std::vector<char> a(act.begin() + C.off[k], act.begin() + C.off[k] + dimc);
+      for (long long i = 1; i <= N; ++i) a[(size_t)(i * i - 1)] = 1;
+      for (long long r = 0; r < dimc; ++r) if (a[(size_t)r]) csp.push_back(r + 1);
+    }
     if ((long long)csp.size() >= dimc) continue;               // dense cone: DenseEquivalent (:56-61)
     // find_graph! (trees.jl:634-645)
     std::vector<IntSet> adj(N);
-    for (long long r : csp) { long long i, j; svec_to_mat(r, i, j); if (i != j) { adj[i - 1].insert((int)j - 1); adj[j - 1].insert((int)i - 1); } }
+    for (long long r : csp) {
+      long long i, j;
+      if (tri) svec_to_mat(r, i, j);
+      else { i = (r - 1) % N + 1; j = (r - 1) / N + 1; }           // row_ind_to_matrix_indices (trees.jl:659-675)
+      if (i != j) { adj[i - 1].insert((int)j - 1); adj[j - 1].insert((int)i - 1); }
+    }
     std::vector<int> perm(N);
     if (my_ord) {
       std::vector<char> seen(N, 0);
@@ -214,7 +233,7 @@ void run_decompose(cosmo_chordal& C, const int64_t* Ap, const int64_t* Ai, const
     LPattern L = symbolic_ldl(N, adj, perm);
     connect_graph(L);
     SparsityPattern sp;
-    sp.N = N; sp.row_start = C.off[k]; sp.cone_ind = (int)k; sp.ordering = perm;
+    sp.N = N; sp.row_start = C.off[k]; sp.cone_ind = (int)k; sp.ordering = perm; sp.type = C.type[k];
     build_supernode_tree(sp.sntree, L, opt.merge_strategy, opt.t_fill, opt.t_size);
     if (sp.sntree.num > 1) merge_cliques(sp.sntree);            // SparsityPattern constructor (types.jl:192-215)
     reorder_snd_consecutively(sp.sntree, sp.ordering);
@@ -222,6 +241,46 @@ void run_decompose(cosmo_chordal& C, const int64_t* Ap, const int64_t* Ai, const
     if (sp.sntree.num == 1) continue;                          // one clique left: do not decompose (:68-71)
     C.sp_of_cone[k] = (int)C.sp_arr.size();
     C.sp_arr.push_back(std::move(sp));
+  }
+  if (!C.compact) {
+    // ---- find_decomposition_matrix! + augment_system! (transformations.jl:4-138): s = H sbar, [A H; 0 -I] [x; sbar] + [s; -sbar'] ... ----
+    C.cones_new.clear(); C.H_I.clear();
+    C.cones_new.push_back({COSMO_HIP_ZERO, C.m, -1, -1, -1});
+    for (size_t k = 0; k < nc; ++k) {
+      const int spi = C.sp_of_cone[k];
+      if (spi < 0) {
+        for (long long r = 0; r < C.dim[k]; ++r) C.H_I.push_back(C.off[k] + r);
+        C.cones_new.push_back({C.type[k], C.dim[k], (int)k, -1, -1});
+        continue;
+      }
+      const SparsityPattern& sp = C.sp_arr[spi];
+      for (int iii = 0; iii < sp.sntree.num; ++iii) {             // ascending post order (transformations.jl:71-86)
+        std::vector<int> cl = get_clique(sp.sntree, iii), c;
+        for (int v : cl) c.push_back(sp.ordering[v] + 1);
+        std::sort(c.begin(), c.end());
+        long long rows = 0;
+        for (int vj : c) for (int vi : c) {
+          if (sp.type == COSMO_HIP_PSD_TRIANGLE) { if (vi <= vj) { C.H_I.push_back(sp.row_start + svec_ind(vi, vj) - 1); ++rows; } }
+          else { C.H_I.push_back(sp.row_start + (long long)(vj - 1) * sp.N + vi - 1); ++rows; }
+        }
+        C.cones_new.push_back({sp.type, rows, (int)k, spi, iii});
+      }
+    }
+    const long long nH = (long long)C.H_I.size();
+    C.n_new = C.n + nH; C.m_new = C.m + nH; C.num_overlaps = nH;
+    C.colptr.assign((size_t)C.n_new + 1, 0); C.rowval.clear(); C.nzval.clear();
+    for (long long col = 0; col < C.n; ++col) {
+      for (long long kk = Ap[col] - 1; kk < Ap[col + 1] - 1; ++kk) { C.rowval.push_back(Ai[kk] - 1); C.nzval.push_back(Ax[kk]); }
+      C.colptr[(size_t)col + 1] = (long long)C.rowval.size();
+    }
+    for (long long e = 0; e < nH; ++e) {                           // column n + e: H entry (row H_I[e], +1) then the -I entry (row m + e)
+      C.rowval.push_back(C.H_I[(size_t)e]); C.nzval.push_back(1.0);
+      C.rowval.push_back(C.m + e); C.nzval.push_back(-1.0);
+      C.colptr[(size_t)(C.n + e) + 1] = (long long)C.rowval.size();
+    }
+    C.b_new.assign((size_t)C.m_new, 0.0);
+    for (long long r = 0; r < C.m; ++r) C.b_new[(size_t)r] = b[r];
+    return;
   }
   // ---- augment_clique_based! (transformations.jl:152-200) ----
   const long long nnzA = Ap[C.n] - 1;
@@ -324,7 +383,7 @@ const char* cosmo_chordal_last_error(void) { return g_err.c_str(); }
 
 void cosmo_chordal_default_options(cosmo_chordal_options* o) {
   if (!o) return;
-  o->merge_strategy = COSMO_CHORDAL_CLIQUE_GRAPH_MERGE; o->t_fill = 8; o->t_size = 8; o->orderings = nullptr;
+  o->merge_strategy = COSMO_CHORDAL_CLIQUE_GRAPH_MERGE; o->t_fill = 8; o->t_size = 8; o->orderings = nullptr; o->compact_transformation = 1;
 }
 
 int32_t cosmo_chordal_decompose(int64_t n, int64_t m, const int64_t* A_colptr, const int64_t* A_rowval, const double* A_nzval, const double* b,
@@ -338,7 +397,7 @@ int32_t cosmo_chordal_decompose(int64_t n, int64_t m, const int64_t* A_colptr, c
     if (opt) o = *opt;
     if (o.merge_strategy < 0 || o.merge_strategy > 2) throw std::runtime_error("unknown merge strategy");
     auto* C = new cosmo_chordal();
-    C->n = n; C->m = m;
+    C->n = n; C->m = m; C->compact = o.compact_transformation != 0;
     long long off = 0;
     for (int64_t k = 0; k < ncones; ++k) { C->type.push_back(type[k]); C->dim.push_back(dim[k]); C->off.push_back(off); off += dim[k]; }
     if (off != m) { delete C; throw std::runtime_error("cone dimensions do not sum to m"); }
@@ -419,7 +478,19 @@ int32_t cosmo_chordal_reverse(const cosmo_chordal* c, const double* s_dec, const
     std::fill(s_out, s_out + c->m, 0.0);
     std::fill(mu_out, mu_out + c->m, 0.0);
     long long row_start = 0;
+    if (!c->compact) {
+      // s = H sbar ; mu = H mubar averaged over the overlapping blocks (chordal_decomposition.jl:143-146, 152-168)
+      std::vector<int> cnt((size_t)c->m, 0);
+      for (size_t e = 0; e < c->H_I.size(); ++e) {
+        const long long r = c->H_I[e];
+        s_out[r] += s_dec[c->m + (long long)e];
+        mu_out[r] += mu_dec[c->m + (long long)e];
+        cnt[(size_t)r] += 1;
+      }
+      for (long long r = 0; r < c->m; ++r) if (cnt[(size_t)r] > 1) mu_out[r] = mu_out[r] / cnt[(size_t)r];
+    }
     for (const NewCone& nc : c->cones_new) {
+      if (!c->compact) break;
       const long long o0 = c->off[(size_t)nc.orig];
       if (nc.sp < 0) {                                           // add_blocks! for non-decomposed cones (:183-188)
         for (long long r = 0; r < nc.dim; ++r) { s_out[o0 + r] = s_dec[row_start + r]; mu_out[o0 + r] = mu_dec[row_start + r]; }
@@ -447,6 +518,12 @@ int32_t cosmo_chordal_reverse(const cosmo_chordal* c, const double* s_dec, const
         const long long o0 = sp.row_start;
         Dense X = zeros(N, N);
         long long k = 0;
+        if (sp.type == COSMO_HIP_PSD_SQUARE) {                     // complete!(mu, ::PsdCone) (:231-243): reshape, upper triangle is used
+          for (int j = 0; j < N; ++j) for (int i = 0; i < N; ++i) X.at(i, j) = -mu_out[o0 + (long long)j * N + i];
+          psd_complete(X, N, sp.sntree, sp.ordering);
+          for (int j = 0; j < N; ++j) for (int i = 0; i < N; ++i) mu_out[o0 + (long long)j * N + i] = -X.at(i, j);
+          continue;
+        }
         for (int j = 0; j < N; ++j) for (int i = 0; i <= j; ++i) { const double v = -mu_out[o0 + k++]; X.at(i, j) = (i == j) ? v : isq2 * v; }
         psd_complete(X, N, sp.sntree, sp.ordering);
         k = 0;

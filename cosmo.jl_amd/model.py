@@ -98,6 +98,7 @@ class Settings:
     # chordal decomposition (src/settings.jl:129-135): host C++ front-end libcosmo_chordal.so (include/cosmo_chordal.h)
     decompose: bool = True
     complete_dual: bool = False
+    compact_transformation: bool = True
     merge_strategy: object = CliqueGraphMerge      # or with_options(ParentChildMerge, t_fill=8, t_size=8) / NoMerge
     accelerator: object = None
     accelerator_activation: int = 2  # ImmediateActivation; k = IterActivation(k)
@@ -560,20 +561,25 @@ def _chordal_decomposition(model: Model):
     """`chordal_decomposition!` (src/chordal_decomposition/chordal_decomposition.jl:10-38) through libcosmo_chordal.so: replaces the
     model's (P, q, A, b, sets) by the clique-tree transformed problem; `model.chordal` keeps what reverse_decomposition! needs."""
     from . import _chordal
-    if not any(K.kind == _ffi.PSD_TRIANGLE and K.dim > 1 for K in model.sets):
+    dk = (_ffi.PSD_TRIANGLE,) if model.settings.compact_transformation else (_ffi.PSD_TRIANGLE, _ffi.PSD_SQUARE)
+    if not any(K.kind in dk and K.dim > 1 for K in model.sets):
         return
     ms, kw = model.settings.merge_strategy, {}
     if isinstance(ms, OptionsFactory):
         ms, kw = ms.solver, ms.kwargs
     dec = _chordal.Decomposition(model.A, model.b, [K.kind for K in model.sets], [K.dim for K in model.sets], merge_strategy=ms.code,
-                                 t_fill=kw.get("t_fill", 8), t_size=kw.get("t_size", 8))
+                                 t_fill=kw.get("t_fill", 8), t_size=kw.get("t_size", 8), compact=model.settings.compact_transformation)
     if dec.num_decomposed == 0:                                   # ws.ci.decompose = false (:33-35)
         dec.close()
         return
     new_sets = []
-    for kind, dim, orig in zip(dec.kinds, dec.dims, dec.cone_map):
-        K0 = model.sets[int(orig) - 1]
-        new_sets.append(PsdConeTriangle(int(dim)) if (kind == _ffi.PSD_TRIANGLE and K0.kind == _ffi.PSD_TRIANGLE and int(dim) != K0.dim) else _copy_set(K0))
+    for kind, dim, orig, clq in zip(dec.kinds, dec.dims, dec.cone_map, dec.clique_of):
+        if int(orig) == 0:                                        # the ZeroSet(m) block of the traditional transformation
+            new_sets.append(ZeroSet(int(dim)))
+        elif int(clq) > 0:                                        # one clique of a decomposed cone
+            new_sets.append(PsdConeTriangle(int(dim)) if kind == _ffi.PSD_TRIANGLE else PsdCone(int(dim)))
+        else:
+            new_sets.append(_copy_set(model.sets[int(orig) - 1]))
     nov = dec.n_new - model.n
     model.P = sp.block_diag([model.P, sp.csc_matrix((nov, nov))], format="csc")      # transformations.jl:193-194
     model.q = np.concatenate([model.q, np.zeros(nov)])

@@ -8,9 +8,10 @@
  * cosmo_hip_set_problem / cosmo_hip_set_cones.
  *
  * Conventions: the INTERNAL problem convention of the reference (A x + s = b, s in K; see src/interface.jl:478-484), CSC with
- * 1-based Int64 indices exactly as Julia's SparseMatrixCSC stores them, cone type codes of cosmo_hip.h.  Only
- * PsdConeTriangle (type 5) cones are decomposed, like the reference's compact transformation
- * (transformations.jl:276, add_entries! is specialised on PsdConeTriangle{Float64}); every other cone is passed through.
+ * 1-based Int64 indices exactly as Julia's SparseMatrixCSC stores them, cone type codes of cosmo_hip.h.  With the compact
+ * transformation only PsdConeTriangle (type 5) cones are decomposed, like the reference's (transformations.jl:276, add_entries!
+ * is specialised on PsdConeTriangle{Float64}); the traditional transformation also decomposes PsdCone (type 4); every other
+ * cone is passed through.
  * All functions return 0 on success, non-zero on failure (cosmo_chordal_last_error gives the text).
  */
 #ifndef COSMO_CHORDAL_H
@@ -31,6 +32,11 @@ typedef struct cosmo_chordal_options {
    * eliminated k-th (what QDLDL returns as F.perm, src/chordal_decomposition/trees.jl:636-641).  NULL: an exact
    * minimum-degree ordering is computed (stand-in for the external AMD; any ordering gives a valid decomposition). */
   const int64_t* orderings;
+  /* settings.compact_transformation (src/settings.jl:135, default true).  0: the "traditional" transformation
+   * (find_decomposition_matrix! + augment_system!, src/chordal_decomposition/transformations.jl:4-138): s = H sbar with one
+   * ZeroSet(m) block in front; decomposes PsdCone (square) as well as PsdConeTriangle.  With orderings given, one ordering per
+   * decomposable cone kind that is active in the chosen mode. */
+  int32_t compact_transformation;
 } cosmo_chordal_options;
 
 void cosmo_chordal_default_options(cosmo_chordal_options* o);

@@ -41,7 +41,7 @@ def test_chordal_library_exports_every_header_symbol():
     for nm in names:
         assert hasattr(lib, nm), "libcosmo_chordal.so does not export %s" % nm
     assert set(cj._chordal.SIGNATURES) == set(names)
-    assert ctypes.sizeof(cj._chordal.Options) == 3 * 4 + 4 + 8      # int32 x 3, padding, pointer
+    assert ctypes.sizeof(cj._chordal.Options) == 3 * 4 + 4 + 8 + 8  # int32 x 3, padding, pointer, int32 + padding
 
 
 def test_struct_layouts_match_header():

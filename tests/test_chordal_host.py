@@ -209,3 +209,62 @@ def test_decomposed_problem_is_equivalent(strategy):
     # without completion the entries outside the pattern are zero
     _, mu_nc = dec.reverse(r1.s, -r1.y, complete_dual=False)
     assert _smat(mu_nc[0:10])[0, 2] == 0.0 and _smat(mu_nc[0:10])[0, 3] == 0.0
+
+
+# ---- traditional transformation (compact_transformation = false): s = H sbar, incl. square PsdCone -----------------------
+def _equivalence_problem_square(seed):
+    """CONFIG 1/2 of chordal_decomposition_triangle.jl:62-83: the same data with PsdCone (vec) instead of PsdConeTriangle (svec)."""
+    rng = np.random.default_rng(seed)
+    A1 = rng.uniform(size=(4, 4)); A1 = 0.5 * (A1 + A1.T); A1[0, 2] = A1[0, 3] = A1[2, 0] = A1[3, 0] = 0
+    S1 = A1 + (np.linalg.eigvalsh(A1)[0] + 1) * np.eye(4)
+    a2 = rng.uniform(size=2)
+    A3 = rng.uniform(size=(4, 4)); A3 = 0.5 * (A3 + A3.T)
+    for (i, j) in [(1, 3), (0, 2), (1, 2)]:
+        A3[i, j] = A3[j, i] = 0
+    S3 = A3 + (np.linalg.eigvalsh(A3)[0] + 1) * np.eye(4)
+    A4 = rng.uniform(size=(3, 3)); A4 = 0.5 * (A4 + A4.T)
+    S4 = A4 + (np.linalg.eigvalsh(A4)[0] + 1) * np.eye(3)
+    x = rng.uniform(size=1)
+    vec = lambda M: M.reshape(-1, order="F")
+    A = np.concatenate([vec(A1), a2, vec(A3), vec(A4)])[:, None]
+    s = np.concatenate([vec(S1), [0, 0], vec(S3), vec(S4)])
+    b = A @ x + s
+    y = np.concatenate([vec(_posdef(rng, 4, 0.1, 1.0)), rng.uniform(size=2), vec(_posdef(rng, 4, 0.1, 1.0)), vec(_posdef(rng, 3, 0.1, 1.0))])
+    q = -(A.T @ y)
+    return sp.csc_matrix(A), b, q, [4, ZERO, 4, 4], [16, 2, 16, 9]
+
+
+@pytest.mark.parametrize("shape", ["triangle", "square"])
+def test_traditional_transformation_is_equivalent(shape):
+    if shape == "triangle":
+        A, b, q, kinds, dims = _equivalence_problem(144545)
+    else:
+        A, b, q, kinds, dims = _equivalence_problem_square(144545)
+    P = sp.csc_matrix((1, 1))
+    cones = [O.Cone(k, d) for k, d in zip(kinds, dims)]
+    st = O.Settings(eps_abs=1e-7, eps_rel=1e-7, max_iter=20000)
+    r0 = O.solve(P, q, A, b, cones, st)
+    dec = ch.Decomposition(A, b, kinds, dims, merge_strategy=ch.NO_MERGE, compact=False)
+    # square cones: the reference flags the positions i^2 instead of the diagonal (kept, see chordal_api.cpp), which fills the
+    # (1,3)/(4,1) zeros of the first 4x4 block, so only the second block decomposes there
+    assert dec.num_decomposed == (2 if shape == "triangle" else 1)
+    m0 = A.shape[0]
+    assert dec.kinds[0] == ZERO and dec.dims[0] == m0 and dec.cone_map[0] == 0          # the ZeroSet(m) block of the augmented system
+    assert dec.m_new == m0 + dec.num_overlaps and dec.n_new == 1 + dec.num_overlaps
+    An = dec.A.toarray()
+    assert np.array_equal(An[:m0, :1], A.toarray()) and np.array_equal(An[m0:, 1:], -np.eye(dec.num_overlaps))      # [A H; 0 -I]
+    H = An[:m0, 1:]
+    assert set(np.unique(H)) <= {0.0, 1.0} and np.all(H.sum(axis=0) == 1)
+    Pn = sp.block_diag([P, sp.csc_matrix((dec.n_new - 1, dec.n_new - 1))], format="csc")
+    r1 = O.solve(Pn, np.concatenate([q, np.zeros(dec.n_new - 1)]), dec.A, dec.b, [O.Cone(int(k), int(d)) for k, d in zip(dec.kinds, dec.dims)], st)
+    assert r0.status == r1.status == "Solved" and abs(r0.obj_val - r1.obj_val) < 1e-4
+    s_rec, mu_rec = dec.reverse(r1.s, -r1.y, complete_dual=True)
+    assert np.max(np.abs(s_rec - r0.s)) < 1e-4
+    lo = 0 if shape == "triangle" else 18
+    d0 = dims[0]
+    Y = _smat(-mu_rec[:d0]) if shape == "triangle" else (-mu_rec[lo:lo + 16]).reshape(4, 4, order="F")
+    Y = (np.triu(Y) + np.triu(Y, 1).T)
+    assert np.linalg.eigvalsh(Y).min() > -1e-5
+    # compact transformation leaves square cones alone (the reference's add_entries! is specialised on PsdConeTriangle)
+    if shape == "square":
+        assert ch.Decomposition(A, b, kinds, dims, merge_strategy=ch.NO_MERGE, compact=True).num_decomposed == 0

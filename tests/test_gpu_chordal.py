@@ -67,3 +67,20 @@ def test_banded_sdp_decomposed_matches_undecomposed():
     S = _smat(r1.s)
     assert np.linalg.eigvalsh(S).min() > -1e-2 and np.allclose(S[band == 0], 0.0, atol=1e-3)   # merged cliques carry fill entries that the solve drives to 0
     print("banded SDP: iterations undecomposed %d, decomposed %d (%d cliques)" % (r0.iter, r1.iter, len(cl)))
+
+
+def test_traditional_transformation_on_device():
+    """compact_transformation = false (s = H sbar with the ZeroSet(m) block): same optimum as the undecomposed solve."""
+    A, b, q, kinds, dims = _equivalence_problem(144545)
+    P = sp.csc_matrix((1, 1))
+    tight = cj.with_options(cj.CGIndirectKKTSolver, tol_constant=1e-9, tol_exponent=0.0)
+    out = {}
+    for dec in (False, True):
+        model = cj.Model()
+        model.set(P, q, A, b, _sets(kinds, dims), cj.Settings(decompose=dec, compact_transformation=False, merge_strategy=cj.NoMerge, complete_dual=True,
+                                                                eps_abs=1e-6, eps_rel=1e-6, kkt_solver=tight))
+        out[dec] = (cj.optimize(model), model)
+    r0, _ = out[False]; r1, m1 = out[True]
+    assert m1.chordal is not None and not m1.chordal.compact and m1.sets[0].kind == F.ZERO and m1.sets[0].dim == A.shape[0]
+    assert r0.status == r1.status == "Solved" and abs(r0.obj_val - r1.obj_val) < 1e-4
+    assert r1.s.size == r0.s.size and np.max(np.abs(r1.s - r0.s)) < 1e-3
