@@ -13,8 +13,6 @@
 int32_t sync_ctl(cosmo_hip_handle* h);
 int32_t psd_extreme_eigs(cosmo_hip_handle* h, const double* vec, double sign, std::vector<double>& lam_min);   // psd.hip
 
-struct InfBufs { double *dy, *dx, *adx, *out; int* flags; };
-
 // delta_y capture at the top of the iteration: dy = rho .* (w_prev_s - s)            (solver.jl:145-148)
 __global__ __launch_bounds__(COSMO_BS) void k_inf_capture(const Ctl* __restrict__ ctl, long long n, long long m,
                                                           const double* __restrict__ w_prev, const double* __restrict__ s,
@@ -80,7 +78,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_inf_adx(CsrView A, const double* _
 }
 
 // primal certificate pieces on the simple rows: dyn = dy * (-1/norm) (in place) ; <dyn, b> ; Box support function ;
-// in_dual(-dyn) violations of Nonnegatives rows.  meta: kind | boxindex << 2 ; psd1: 1x1 PSD rows are marked kind 2 as well.
+// in_dual(-dyn) violations of Nonnegatives rows.  meta: kind | boxindex << 2 (1x1 PSD rows are marked kind 2 as well).
 __global__ __launch_bounds__(COSMO_BS) void k_inf_primal_rows(long long m, double fneg, double tol, const uint32_t* __restrict__ meta,
                                                               const double* __restrict__ bl, const double* __restrict__ bu,
                                                               const double* __restrict__ b, double* __restrict__ dy,
@@ -107,7 +105,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_inf_primal_rows(long long m, doubl
 
 // dual certificate on the simple rows: in_pol_recc(adx)                                     (convexset.jl:34-36, 80-82, 859-861)
 __global__ __launch_bounds__(COSMO_BS) void k_inf_dual_rows(long long m, double tol, const uint32_t* __restrict__ meta,
-                                                            const uint32_t* __restrict__ psd1, const double* __restrict__ bl,
+                                                            const double* __restrict__ bl,
                                                             const double* __restrict__ bu, const double* __restrict__ adx,
                                                             int* __restrict__ flags) {
   int viol = 0;
@@ -121,7 +119,6 @@ __global__ __launch_bounds__(COSMO_BS) void k_inf_dual_rows(long long m, double 
       if ((bu[j] == INFINITY && x > tol) || (bl[j] == -INFINITY && x < -tol)) viol = 1;
     }
   }
-  (void)psd1;
   if (viol) atomicOr(&flags[1], 1);
 }
 
@@ -236,7 +233,7 @@ int32_t infeas_check(cosmo_hip_handle* h, int32_t* status) {
     HIPCHK(h, hipMemsetAsync(h->inf_flags, 0, sizeof(int) * 4, h->stream));
     hipLaunchKernelGGL(k_inf_adx, dim3(h->A.grid > 0 ? h->A.grid : 1), dim3(COSMO_BS), 0, h->stream, view_of(h->A), h->inf_dx, h->Einv, 1.0 / norm_dx,
                        h->inf_adx);
-    hipLaunchKernelGGL(k_inf_dual_rows, dim3(ewg(m > 0 ? m : 1)), dim3(COSMO_BS), 0, h->stream, m, p.eps_dual_inf, h->meta, (const uint32_t*)nullptr,
+    hipLaunchKernelGGL(k_inf_dual_rows, dim3(ewg(m > 0 ? m : 1)), dim3(COSMO_BS), 0, h->stream, m, p.eps_dual_inf, h->meta,
                        h->box_l, h->box_u, h->inf_adx, h->inf_flags);
     if (h->nsoc) hipLaunchKernelGGL(k_inf_soc, dim3(std::min(4096, (h->nsoc + 3) / 4)), dim3(COSMO_BS), 0, h->stream, h->nsoc, h->soc_off, h->soc_dim,
                                     h->inf_adx, 1, p.eps_dual_inf, h->inf_flags);
