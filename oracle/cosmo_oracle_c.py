@@ -1,0 +1,92 @@
+"""ctypes loader of the compiled C restatement of the ADMM loop (oracle/cosmo_oracle_c.c).
+
+TEST / BASELINE INFRASTRUCTURE -- only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+Setup (Ruiz scaling, constraint classification, rho vector: src/setup.jl:18-64) is done by the NumPy oracle's `Workspace`;
+`run(ws)` then executes the loop of src/solver.jl:137-176 in compiled C on that workspace's scaled data.  Supported: ZeroSet,
+Nonnegatives and Box cones, CG reduced KKT solver, no accelerator -- the BASELINE configs 1 and 2.
+"""
+import ctypes as C
+import os
+import numpy as np
+from . import cosmo_oracle as O
+
+_LIB = None
+
+
+class Params(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("sigma", "alpha", "rho", "eps_abs", "eps_rel", "tol_constant", "tol_exponent", "rho_min", "rho_max",
+                                           "rho_eq_over_rho_ineq", "adaptive_rho_tolerance", "cinv")] + \
+               [("max_iter", C.c_int64), ("adaptive_rho_max_adaptions", C.c_int64), ("check_termination", C.c_int32), ("adaptive_rho", C.c_int32),
+                ("adaptive_rho_interval", C.c_int32), ("unscale", C.c_int32)]
+
+
+class CResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("n_rho_updates", C.c_int32), ("iter", C.c_int64), ("cg_iters_total", C.c_int64)] + \
+               [(k, C.c_double) for k in ("cost", "r_prim", "r_dual", "max_norm_prim", "max_norm_dual", "rho", "iter_time")]
+
+
+STATUS = {0: "Undetermined", 1: "Solved", 2: "Max_iter_reached", 3: "Unsolved"}
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libcosmo_oracle_c.so")
+        if not os.path.exists(path):
+            raise RuntimeError("compiled oracle missing: run `make -C oracle` (or __graft_entry__.build())")
+        _LIB = C.CDLL(path)
+        _LIB.cosmo_oracle_c_run.restype = C.c_int32
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def run(ws: "O.Workspace"):
+    """Run the loop on a set-up NumPy-oracle workspace (not yet optimised).  Returns a dict with scaled and unscaled iterates."""
+    st = ws.st
+    assert st.kkt_solver.lower() == "cg" and ws.accelerator is None
+    n, m = ws.n, ws.m
+    kind = np.zeros(m, np.int32); bl = np.zeros(m); bu = np.zeros(m)
+    off = 0
+    for c in ws.cones:
+        d = c.dim
+        if c.kind == O.ZERO:
+            kind[off:off + d] = 1
+        elif c.kind == O.NONNEG:
+            kind[off:off + d] = 2
+        elif c.kind == O.BOX:
+            kind[off:off + d] = 3; bl[off:off + d] = c.l; bu[off:off + d] = c.u
+        else:
+            raise ValueError("C oracle: unsupported cone kind %r" % (c.kind,))
+        off += d
+    P, A = ws.P, ws.A
+    Pp = P.indptr.astype(np.int64); Pi = P.indices.astype(np.int64); Px = np.ascontiguousarray(P.data, np.float64)
+    Ap = A.indptr.astype(np.int64); Ai = A.indices.astype(np.int64); Ax = np.ascontiguousarray(A.data, np.float64)
+    prm = Params(st.sigma, st.alpha, ws.rho, st.eps_abs, st.eps_rel, st.tol_constant, st.tol_exponent, st.RHO_MIN, st.RHO_MAX,
+                 st.RHO_EQ_OVER_RHO_INEQ, st.adaptive_rho_tolerance, ws.sm.cinv, st.max_iter, st.adaptive_rho_max_adaptions,
+                 st.check_termination, int(bool(st.adaptive_rho)), st.adaptive_rho_interval, int(st.scaling != 0))
+    x = ws.x.copy(); s = ws.s.copy(); mu = ws.mu.copy()
+    cap = 64
+    rho_updates = np.zeros(cap)
+    res = CResult()
+    cls = np.ascontiguousarray(ws.rho_class, np.int32)
+    q = np.ascontiguousarray(ws.q); b = np.ascontiguousarray(ws.b)
+    Dinv = np.ascontiguousarray(ws.sm.Dinv); Einv = np.ascontiguousarray(ws.sm.Einv)
+    rho0 = np.ascontiguousarray(ws.rho_vec, np.float64)
+    rc = lib().cosmo_oracle_c_run(C.c_int64(n), C.c_int64(m), _p(Pp, C.c_int64), _p(Pi, C.c_int64), _p(Px, C.c_double), _p(Ap, C.c_int64),
+                                  _p(Ai, C.c_int64), _p(Ax, C.c_double), _p(q, C.c_double), _p(b, C.c_double), _p(Dinv, C.c_double),
+                                  _p(Einv, C.c_double), _p(cls, C.c_int32), _p(kind, C.c_int32), _p(bl, C.c_double), _p(bu, C.c_double),
+                                  C.byref(prm), _p(rho0, C.c_double), _p(x, C.c_double), _p(s, C.c_double), _p(mu, C.c_double),
+                                  _p(rho_updates, C.c_double), C.c_int32(cap), C.byref(res))
+    if rc != 0:
+        raise MemoryError("cosmo_oracle_c_run failed (%d)" % rc)
+    out = dict(status=STATUS[res.status], iter=int(res.iter), cg_iters_total=int(res.cg_iters_total), obj_val=res.cost, r_prim=res.r_prim,
+               r_dual=res.r_dual, max_norm_prim=res.max_norm_prim, max_norm_dual=res.max_norm_dual, iter_time=res.iter_time,
+               rho_updates=list(rho_updates[:min(cap, res.n_rho_updates)]), x_scaled=x, s_scaled=s, mu_scaled=mu)
+    if st.scaling != 0:                                            # reverse_scaling! (src/scaling.jl:170-179)
+        out["x"] = ws.sm.D * x; out["s"] = ws.sm.Einv * s; out["y"] = -((ws.sm.E * mu) * ws.sm.cinv)
+    else:
+        out["x"], out["s"], out["y"] = x, s, -mu
+    return out
