@@ -20,6 +20,7 @@ ERR_NAMES = {1: "INVALID", 2: "HIP", 3: "NOT_CONVEX", 4: "NONFINITE", 5: "EIG", 
 ZERO, NONNEG, BOX, SOC, PSD_SQUARE, PSD_TRIANGLE = 0, 1, 2, 3, 4, 5
 EXP, DUAL_EXP, POW, DUAL_POW = 6, 7, 8, 9
 PSD_TRIANGLE_COMPLEX = 10
+CUSTOM = 11
 KKT_CG, KKT_MINRES_REDUCED, KKT_MINRES = 0, 1, 2
 STATUS_NAMES = {0: "Undetermined", 1: "Solved", 2: "Max_iter_reached", 3: "Unsolved", 4: "Primal_infeasible",
                 5: "Dual_infeasible", 6: "Time_limit_reached"}
@@ -77,6 +78,9 @@ _PI64 = C.POINTER(C.c_int64)
 _PI32 = C.POINTER(C.c_int32)
 
 # name -> (restype, argtypes).  Kept in one table so tests can check it against the header.
+PROJECT_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int64, C.c_void_p)                       # cosmo_hip_project_fn
+CONE_TEST_FN = C.CFUNCTYPE(C.c_int32, C.POINTER(C.c_double), C.c_int64, C.c_double, C.c_void_p)     # cosmo_hip_cone_test_fn
+
 SIGNATURES = {
     "cosmo_hip_version": (C.c_int32, []),
     "cosmo_hip_default_params": (None, [C.POINTER(Params)]),
@@ -86,6 +90,7 @@ SIGNATURES = {
     "cosmo_hip_set_problem": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int64, _PI64, _PI64, _PD, _PI64, _PI64, _PD, _PD, _PD]),
     "cosmo_hip_set_cones": (C.c_int32, [C.c_void_p, C.c_int64, _PI32, _PI64, _PD, _PD]),
     "cosmo_hip_set_cones_ex": (C.c_int32, [C.c_void_p, C.c_int64, _PI32, _PI64, _PD, _PD, _PD]),
+    "cosmo_hip_set_custom_cone": (C.c_int32, [C.c_void_p, C.c_int64, PROJECT_FN, CONE_TEST_FN, CONE_TEST_FN, C.c_void_p]),
     "cosmo_hip_set_params": (C.c_int32, [C.c_void_p, C.POINTER(Params), _PD]),
     "cosmo_hip_update_rho": (C.c_int32, [C.c_void_p, _PD]),
     "cosmo_hip_set_scaling": (C.c_int32, [C.c_void_p, _PD, _PD, C.c_double]),
@@ -201,6 +206,7 @@ class Handle:
             raise CosmoHipError(rc, "cosmo_hip_create failed (no MI355X visible? this library has no CPU path)")
         self.n = self.m = 0
         self.ncones = 0
+        self._callbacks = {}
 
     def close(self):
         if self._h:
@@ -238,6 +244,25 @@ class Handle:
             cp = _f64(cone_param, t.size, "cone_param")
             self._chk(self.lib.cosmo_hip_set_cones_ex(self._h, t.size, t.ctypes.data_as(_PI32), d.ctypes.data_as(_PI64), _dp(bl), _dp(bu), _dp(cp)))
         self.ncones = t.size
+        self._callbacks = {}
+
+    def set_custom_cone(self, cone, project, in_dual=None, in_pol_recc=None):
+        """cosmo_hip_set_custom_cone: `project(x)` projects the NumPy view x (the cone's slice) in place; `in_dual(x, tol)` /
+        `in_pol_recc(x, tol)` return truth values (optional).  The ctypes thunks are kept alive on the handle."""
+        def _view(ptr, dim):
+            return np.ctypeslib.as_array(ptr, shape=(int(dim),)) if dim > 0 else np.zeros(0)
+
+        def _proj(ptr, dim, _user):
+            project(_view(ptr, dim))
+
+        def _mk(fn):
+            if fn is None:
+                return CONE_TEST_FN(0)
+            return CONE_TEST_FN(lambda ptr, dim, tol, _user: 1 if fn(_view(ptr, dim), float(tol)) else 0)
+
+        thunks = (PROJECT_FN(_proj), _mk(in_dual), _mk(in_pol_recc))
+        self._callbacks[int(cone)] = thunks
+        self._chk(self.lib.cosmo_hip_set_custom_cone(self._h, int(cone), thunks[0], thunks[1], thunks[2], None))
 
     def default_params(self):
         return default_params()

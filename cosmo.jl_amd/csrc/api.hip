@@ -234,6 +234,7 @@ static void free_cones(cosmo_hip_handle* h) {
   dfree(&h->soc_off); dfree(&h->soc_dim); dfree(&h->soc_branch);
   psd_plan_destroy(h);
   cone3_free(h);
+  custom_free(h);
   h->nsoc = 0;
 }
 
@@ -392,7 +393,7 @@ extern "C" int32_t cosmo_hip_set_cones_ex(cosmo_hip_handle* h, int64_t ncones, c
   int64_t off = 0, nbox = 0;
   for (int64_t k = 0; k < ncones; ++k) {
     if (dim[k] < 0) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "negative cone dimension");
-    if (type[k] < COSMO_HIP_ZERO || type[k] > COSMO_HIP_PSD_TRIANGLE_COMPLEX)
+    if (type[k] < COSMO_HIP_ZERO || type[k] > COSMO_HIP_CUSTOM)
       return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "cone type %d is outside the hot-path scope", (int)type[k]);
     if (type[k] >= COSMO_HIP_EXP && type[k] <= COSMO_HIP_DUAL_POW && dim[k] != 3) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "exponential / power cones have dimension 3");
     if (type[k] == COSMO_HIP_POW || type[k] == COSMO_HIP_DUAL_POW) {
@@ -427,6 +428,7 @@ extern "C" int32_t cosmo_hip_set_cones_ex(cosmo_hip_handle* h, int64_t ncones, c
         break;
       case COSMO_HIP_SOC: break;
       case COSMO_HIP_EXP: case COSMO_HIP_DUAL_EXP: case COSMO_HIP_POW: case COSMO_HIP_DUAL_POW: break;   // cone3.hip, in place
+      case COSMO_HIP_CUSTOM: break;                                                                      // custom.hip, host callback
       case COSMO_HIP_PSD_SQUARE:
       case COSMO_HIP_PSD_TRIANGLE:
       case COSMO_HIP_PSD_TRIANGLE_COMPLEX:
@@ -440,6 +442,7 @@ extern "C" int32_t cosmo_hip_set_cones_ex(cosmo_hip_handle* h, int64_t ncones, c
   if (nbox > 0) { CHK(h2d(h, h->box_l, C.box_l.data(), (size_t)nbox)); CHK(h2d(h, h->box_u, C.box_u.data(), (size_t)nbox)); }
   h->cone_lo = 0; h->cone_hi = -1;
   CHK(rebuild_cone_plans(h));
+  CHK(custom_plan_create(h));       // callbacks are (re)installed by cosmo_hip_set_custom_cone after every set_cones
   std::vector<double> bhost((size_t)h->m);
   CHK(d2h(h, bhost.data(), h->b, (size_t)h->m));
   CHK(classify_rows(h, bhost));
@@ -655,6 +658,7 @@ extern "C" int32_t cosmo_hip_project(cosmo_hip_handle* h, double* s, int64_t* ps
   CHK(launch_soc(h, h->io, 0));
   CHK(cone3_enqueue_project(h, h->io, 0));
   CHK(psd_enqueue_project(h, h->io, false));
+  CHK(custom_enqueue_project(h, h->io, 0));
   CHK(comm_enqueue_exchange(h, h->io));
   CHK(d2h(h, s, h->io, (size_t)h->m));
   const size_t nc = h->cones.type.size();
@@ -803,6 +807,7 @@ static int32_t enqueue_iteration(cosmo_hip_handle* h, long long it) {
   CHK(launch_soc(h, h->s, 1));
   CHK(cone3_enqueue_project(h, h->s, 1));
   CHK(psd_enqueue_project(h, h->s, true));
+  CHK(custom_enqueue_project(h, h->s, 1));
   CHK(comm_enqueue_exchange(h, h->s));      // clique sharding: the one exchange step of the iteration
   if (h->prm.adaptive_rho && h->prm.adaptive_rho_interval > 0 && (it % h->prm.adaptive_rho_interval) == 0)
     CHK(enqueue_check(h, 1, 2));
@@ -928,6 +933,7 @@ static int32_t enqueue_admm_step(cosmo_hip_handle* h, bool rho_rules) {
   CHK(launch_soc(h, h->s, 1));
   CHK(cone3_enqueue_project(h, h->s, 1));
   CHK(psd_enqueue_project(h, h->s, true));
+  CHK(custom_enqueue_project(h, h->s, 1));
   if (rho_rules) CHK(enqueue_check(h, 1, 2));
   CHK(enqueue_solve_in_loop(h));
   return COSMO_HIP_OK;

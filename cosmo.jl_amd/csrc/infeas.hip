@@ -222,6 +222,7 @@ int32_t infeas_check(cosmo_hip_handle* h, int32_t* status) {
       CHK(psd_extreme_eigs(h, h->inf_dy, -1.0, lmin));
       for (double l : lmin) if (!(l > -p.eps_prim_inf)) in_dual_all = false;
     }
+    CHK(custom_test(h, h->inf_dy, 0, p.eps_prim_inf, &in_dual_all));               // user cones: in_dual(-dyn) through the callback
     if (h->comm) { int viol = in_dual_all ? 0 : 1; CHK(comm_allreduce_flag(h, &viol)); in_dual_all = (viol == 0); }   // owned cones only: combine
     const double dyt_b = host_sum(d0, gm);
     const double sF = (in_dual_all ? host_sum(d1, gm) : INFINITY) - dyt_b;
@@ -249,6 +250,7 @@ int32_t infeas_check(cosmo_hip_handle* h, int32_t* status) {
       CHK(psd_extreme_eigs(h, h->inf_adx, -1.0, lmin));
       for (double l : lmin) if (!(l > -p.eps_dual_inf)) in_recc = false;
     }
+    CHK(custom_test(h, h->inf_adx, 1, p.eps_dual_inf, &in_recc));
     if (h->comm) { int viol = in_recc ? 0 : 1; CHK(comm_allreduce_flag(h, &viol)); in_recc = (viol == 0); }
     if (in_recc) { *status = COSMO_HIP_DUAL_INFEASIBLE; return COSMO_HIP_OK; }
   }

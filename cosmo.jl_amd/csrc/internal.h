@@ -81,6 +81,13 @@ struct ConeTable {  // host copy of the composite set
 
 struct PsdPlan;  // psd.hip
 
+struct CustomCone {   // custom.hip: a user subtype of AbstractConvexCone, projected on the host by the user's callback
+  long long cone = 0, off = 0, dim = 0, host_off = 0;
+  cosmo_hip_project_fn project = nullptr;
+  cosmo_hip_cone_test_fn in_dual = nullptr, in_pol_recc = nullptr;
+  void* user = nullptr;
+};
+
 struct cosmo_hip_handle {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -119,6 +126,9 @@ struct cosmo_hip_handle {
   int *c3_off = nullptr, *c3_kind = nullptr, *c3_branch = nullptr;
   double* c3_alpha = nullptr;
   std::vector<int> c3_cone_index;
+  std::vector<CustomCone> custom;  // user-defined cones (custom.hip)
+  double* custom_host = nullptr;   // pinned staging, sum of the custom dims
+  int* custom_halt = nullptr;      // pinned copy of ctl->halt
   PsdPlan* psd = nullptr;
   void* psd_polar = nullptr;      // PolarPlan (psd_polar.hip): large cones
   void* accel = nullptr;          // AaState (anderson.hip)
@@ -211,6 +221,13 @@ void cone3_free(cosmo_hip_handle* h);
 int32_t cone3_enqueue_project(cosmo_hip_handle* h, double* s, int guard);
 int32_t cone3_enqueue_in_dual_neg(cosmo_hip_handle* h, const double* v, double tol, int* flag);
 int32_t cone3_get_branches(cosmo_hip_handle* h, int32_t* out_per_cone);
+
+// user-defined cones (custom.hip)
+int32_t custom_plan_create(cosmo_hip_handle* h);
+void custom_free(cosmo_hip_handle* h);
+int32_t custom_enqueue_project(cosmo_hip_handle* h, double* s, int guard);
+// which 0: in_dual(-v) (v = normalised -dy), 1: in_pol_recc(v); *ok is and-ed with the verdict of every custom cone
+int32_t custom_test(cosmo_hip_handle* h, const double* v_dev, int which, double tol, bool* ok);
 
 // PSD projection of large cones by the matrix-sign iteration (psd_polar.hip)
 int32_t polar_plan_create(cosmo_hip_handle* h);

@@ -82,7 +82,41 @@ cone_type(::COSMO.DualPowerCone) = Int32(9)
 cone_param(s::COSMO.PowerCone) = Float64(s.α)
 cone_param(s::COSMO.DualPowerCone) = Float64(s.primal_cone.α)
 cone_param(s) = 0.0
-cone_type(C) = error("cone type $(typeof(C)) is outside the MI355X hot path (SURVEY.md 8a)")
+# any other subtype of AbstractConvexCone is a user-defined cone (docs/src/literate/custom_cone.jl): its own project! /
+# in_dual / in_pol_recc methods run on the host, called back by the library on this task's thread (COSMO_HIP_CUSTOM)
+cone_type(::COSMO.AbstractConvexCone) = Int32(11)
+cone_type(C) = error("set type $(typeof(C)) is outside the MI355X hot path (SURVEY.md 8a)")
+
+# C-callable thunks of the three generic functions; `user` is a pointer to a Ref{Any} holding the cone object
+function _custom_project(x::Ptr{Cdouble}, dim::Int64, user::Ptr{Cvoid})::Cvoid
+    cone = unsafe_pointer_to_objref(user)[]
+    COSMO.project!(unsafe_wrap(Array, x, dim), cone)
+    return
+end
+function _custom_in_dual(x::Ptr{Cdouble}, dim::Int64, tol::Cdouble, user::Ptr{Cvoid})::Int32
+    cone = unsafe_pointer_to_objref(user)[]
+    return Int32(COSMO.in_dual(unsafe_wrap(Array, x, dim), cone, tol))
+end
+function _custom_in_pol_recc(x::Ptr{Cdouble}, dim::Int64, tol::Cdouble, user::Ptr{Cvoid})::Int32
+    cone = unsafe_pointer_to_objref(user)[]
+    return Int32(COSMO.in_pol_recc(unsafe_wrap(Array, x, dim), cone, tol))
+end
+
+# install the callbacks of every user cone; the returned Refs must stay alive as long as the handle is used (GC.@preserve)
+function set_custom_cones!(h::Handle, C::COSMO.CompositeConvexSet{Float64})
+    keep = Any[]
+    for (k, s) in enumerate(C.sets)
+        cone_type(s) == Int32(11) || continue
+        r = Ref{Any}(s); push!(keep, r)
+        T = typeof(s)
+        fproj = @cfunction(_custom_project, Cvoid, (Ptr{Cdouble}, Int64, Ptr{Cvoid}))
+        fdual = hasmethod(COSMO.in_dual, Tuple{Vector{Float64}, T, Float64}) ? @cfunction(_custom_in_dual, Int32, (Ptr{Cdouble}, Int64, Cdouble, Ptr{Cvoid})) : C_NULL
+        frecc = hasmethod(COSMO.in_pol_recc, Tuple{Vector{Float64}, T, Float64}) ? @cfunction(_custom_in_pol_recc, Int32, (Ptr{Cdouble}, Int64, Cdouble, Ptr{Cvoid})) : C_NULL
+        check(h, ccall((:cosmo_hip_set_custom_cone, LIB[]), Int32, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+            h.ptr, k - 1, fproj, fdual, frecc, pointer_from_objref(r)))
+    end
+    return keep
+end
 
 # cosmo_hip_set_problem takes SparseMatrixCSC{Float64,Int64} untouched: colptr / rowval are already 1-based Int64
 function set_problem!(h::Handle, P::SparseMatrixCSC{Float64, Int64}, A::SparseMatrixCSC{Float64, Int64}, q::Vector{Float64}, b::Vector{Float64})
@@ -242,6 +276,7 @@ function optimize_hip!(ws::COSMO.Workspace{Float64}; device::Integer = 0, kkt_ki
     h = Handle(device)
     set_problem!(h, SparseMatrixCSC(ws.p.P), SparseMatrixCSC(ws.p.A), ws.p.q, Vector(ws.p.b))
     set_cones!(h, ws.p.C)
+    custom_refs = set_custom_cones!(h, ws.p.C)                                 # user cones: callbacks into their project! methods
     set_params!(h, params_from(settings, kkt_kind; tol_constant = tol_constant, tol_exponent = tol_exponent), ws.ρvec)
     sc = settings.scaling != 0
     D = sc ? ws.sm.D.diag : ones(n); Dinv = sc ? ws.sm.Dinv.diag : ones(n); E = sc ? ws.sm.E.diag : ones(m); Einv = sc ? ws.sm.Einv.diag : ones(m)
@@ -253,7 +288,7 @@ function optimize_hip!(ws::COSMO.Workspace{Float64}; device::Integer = 0, kkt_ki
         h.ptr, x0, s0, mu0))                                                  # src/solver.jl:128-129
     ws.states.IS_OPTIMIZED = true
     res = Ref{ResultC}()
-    check(h, ccall((:cosmo_hip_optimize, LIB[]), Int32, (Ptr{Cvoid}, Ref{ResultC}), h.ptr, res))   # src/solver.jl:137-176
+    GC.@preserve custom_refs check(h, ccall((:cosmo_hip_optimize, LIB[]), Int32, (Ptr{Cvoid}, Ref{ResultC}), h.ptr, res))   # src/solver.jl:137-176
     r = res[]
     w = ws.vars.w; wp = ws.vars.w_prev; sd = ws.vars.s.data; mu = ws.vars.μ  # x is a view of w_prev (src/types.jl:274)
     GC.@preserve w wp sd mu check(h, ccall((:cosmo_hip_get_iterates, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),

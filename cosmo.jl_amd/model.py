@@ -187,7 +187,23 @@ class DualPowerCone(PowerCone):
     kind = _ffi.DUAL_POW
 
 
-_SCALAR_SCALED = (_ffi.SOC, _ffi.PSD_SQUARE, _ffi.PSD_TRIANGLE, _ffi.EXP, _ffi.DUAL_EXP, _ffi.POW, _ffi.DUAL_POW, _ffi.PSD_TRIANGLE_COMPLEX)   # src/convexset.jl:956-958
+class AbstractConvexCone(AbstractConvexSet):
+    """User extension point: `COSMO.AbstractConvexCone{T}` (src/projections.jl:5, docs/src/literate/custom_cone.jl:9-17).
+    Subclass it, keep `dim`, and define `project(self, x)` (in place on the NumPy view of the cone's slice); optionally
+    `in_dual(self, x, tol)` and `in_pol_recc(self, x, tol)` to take part in infeasibility detection (:62-68).  The methods run
+    on the host, called back by the device library once per iteration (cosmo_hip_set_custom_cone)."""
+    kind = _ffi.CUSTOM
+
+    def project(self, x):
+        raise NotImplementedError("a custom cone must define project(x)")      # MethodError in the reference
+
+    in_dual = None
+    in_pol_recc = None
+
+
+# src/convexset.jl:953-958 (the generic rectify_scaling! fall-back scalar-scales user cones as well)
+_SCALAR_SCALED = (_ffi.SOC, _ffi.PSD_SQUARE, _ffi.PSD_TRIANGLE, _ffi.EXP, _ffi.DUAL_EXP, _ffi.POW, _ffi.DUAL_POW, _ffi.PSD_TRIANGLE_COMPLEX,
+                  _ffi.CUSTOM)
 
 
 class EmptyAccelerator:
@@ -344,10 +360,12 @@ def scale_ruiz(P, q, A, b, sets: Sequence[AbstractConvexSet], st: Settings) -> S
 
 
 _SORT = {_ffi.ZERO: 1, _ffi.NONNEG: 2, _ffi.BOX: 3, _ffi.SOC: 4, _ffi.PSD_SQUARE: 5, _ffi.PSD_TRIANGLE: 6,
-         _ffi.EXP: 6, _ffi.DUAL_EXP: 6, _ffi.POW: 6, _ffi.DUAL_POW: 6, _ffi.PSD_TRIANGLE_COMPLEX: 6}     # sort_sets fall-through (src/interface.jl:466-475)
+         _ffi.EXP: 6, _ffi.DUAL_EXP: 6, _ffi.POW: 6, _ffi.DUAL_POW: 6, _ffi.PSD_TRIANGLE_COMPLEX: 6, _ffi.CUSTOM: 6}     # sort_sets fall-through (src/interface.jl:466-475)
 
 
 def _copy_set(K):
+    if K.kind == _ffi.CUSTOM:
+        return K                                     # user object: shared, as the reference shares it with the Constraint
     if isinstance(K, Box):
         return Box(K.l, K.u)
     if isinstance(K, PowerCone):
@@ -517,6 +535,10 @@ def setup(model: Model):
         bu = np.concatenate([K.u for K in model.sets if K.kind == _ffi.BOX] or [np.zeros(0)])
         h.set_cones([K.kind for K in model.sets], [K.dim for K in model.sets], bl, bu,
                     cone_param=[getattr(K, "alpha", 0.0) for K in model.sets])
+        for k, K in enumerate(model.sets):
+            if K.kind == _ffi.CUSTOM:
+                h.set_custom_cone(k, K.project, K.in_dual if callable(K.in_dual) else None,
+                                  K.in_pol_recc if callable(K.in_pol_recc) else None)
         return h
 
     on_device = (st.scaling != 0 and not model.is_scaled and model.handle is None and st.device_scaling

@@ -53,9 +53,11 @@ enum {
   COSMO_HIP_DUAL_EXP = 7,    /* DualExponentialCone  src/convexset.jl:735-779  (Moreau decomposition)               */
   COSMO_HIP_POW = 8,         /* PowerCone(alpha)     src/convexset.jl:607-726  (dim 3, MAX_ITERS 20, POW_TOL 1e-8)  */
   COSMO_HIP_DUAL_POW = 9,    /* DualPowerCone(alpha) src/convexset.jl:748-779                                       */
-  COSMO_HIP_PSD_TRIANGLE_COMPLEX = 10 /* PsdConeTriangle{T, Complex{T}}(r^2): Hermitian r x r matrices, vector = svec of the
+  COSMO_HIP_PSD_TRIANGLE_COMPLEX = 10, /* PsdConeTriangle{T, Complex{T}}(r^2): Hermitian r x r matrices, vector = svec of the
                                 real part (r(r+1)/2 entries) followed by sqrt(2) * imaginary parts of the strict upper
                                 triangle, column by column (src/convexset.jl:345-380, 444-490)                          */
+  COSMO_HIP_CUSTOM = 11      /* a user subtype of AbstractConvexCone{T} (src/projections.jl:4-5): its project! runs on the
+                                host through cosmo_hip_set_custom_cone (docs/src/literate/custom_cone.jl:9-17)          */
 };
 
 /* ---- KKT solver kinds: AbstractKKTSolver subtypes (src/linear_solver/kktsolver_indirect.jl) -------- */
@@ -164,6 +166,19 @@ int32_t cosmo_hip_set_cones(cosmo_hip_handle* h, int64_t ncones, const int32_t* 
  * composite set holds no power cone. */
 int32_t cosmo_hip_set_cones_ex(cosmo_hip_handle* h, int64_t ncones, const int32_t* type, const int64_t* dim,
                                const double* box_l, const double* box_u, const double* cone_param);
+/* ---- user-defined cones: the AbstractConvexSet plugin surface (src/projections.jl:4-5, docs/src/literate/custom_cone.jl) ----
+ * project!(x, C)            -> cosmo_hip_project_fn: x is the cone's contiguous slice (dim doubles, host memory), projected in place
+ * in_dual(x, C, tol) / in_pol_recc(x, C, tol) -> cosmo_hip_cone_test_fn: non-zero = member.  Optional (NULL): the cone then never
+ *   certifies infeasibility ("infeasibility detection is disabled", custom_cone.jl:52-54).
+ * The callbacks are invoked on the CALLING thread, from inside cosmo_hip_project / _admm_iterate / _optimize: the slice is
+ * copied device -> pinned host, projected, copied back, once per iteration (the reference calls project! at the same point,
+ * src/convexset.jl:885-891).  They must not call back into this library.  Custom cones are scaled by one scalar per cone
+ * (rectify_scaling! fall-back, src/convexset.jl:953-954) and get the inequality rho class.  cone = 0-based index into the
+ * table given to cosmo_hip_set_cones[_ex], whose type[cone] must be COSMO_HIP_CUSTOM; call after set_cones. */
+typedef void (*cosmo_hip_project_fn)(double* x, int64_t dim, void* user);
+typedef int32_t (*cosmo_hip_cone_test_fn)(const double* x, int64_t dim, double tol, void* user);
+int32_t cosmo_hip_set_custom_cone(cosmo_hip_handle* h, int64_t cone, cosmo_hip_project_fn project, cosmo_hip_cone_test_fn in_dual,
+                                  cosmo_hip_cone_test_fn in_pol_recc, void* user);
 /* Settings fields (src/settings.jl) + initial rho vector: set_rho_vec! (src/parameters.jl:3-13).
  * rho_vec may be NULL: then it is built from p->rho and the row classes exactly as the reference does. */
 int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_params* p, const double* rho_vec);

@@ -46,11 +46,13 @@ from scipy.linalg import lapack as _lapack
 ZERO, NONNEG, BOX, SOC, PSD_SQUARE, PSD_TRIANGLE = 0, 1, 2, 3, 4, 5
 EXP, DUAL_EXP, POW, DUAL_POW = 6, 7, 8, 9
 PSD_TRIANGLE_COMPLEX = 10       # PsdConeTriangle{T, Complex{T}} (src/convexset.jl:345-380)
+CUSTOM = 11                     # user subtype of AbstractConvexCone{T} with its own project! (docs/src/literate/custom_cone.jl:9-17)
 CONE_NAMES = {ZERO: "ZeroSet", NONNEG: "Nonnegatives", BOX: "Box", SOC: "SecondOrderCone",
               PSD_SQUARE: "PsdCone", PSD_TRIANGLE: "PsdConeTriangle", EXP: "ExponentialCone",
               DUAL_EXP: "DualExponentialCone", POW: "PowerCone", DUAL_POW: "DualPowerCone",
-              PSD_TRIANGLE_COMPLEX: "PsdConeTriangle{T,Complex{T}}"}
-SCALAR_SCALED = (SOC, PSD_SQUARE, PSD_TRIANGLE, EXP, DUAL_EXP, POW, DUAL_POW, PSD_TRIANGLE_COMPLEX)   # rectify_scaling! (src/convexset.jl:956-958)
+              PSD_TRIANGLE_COMPLEX: "PsdConeTriangle{T,Complex{T}}", CUSTOM: "custom AbstractConvexCone"}
+# rectify_scaling! (src/convexset.jl:953-958); the generic fall-back (:954) scalar-scales user-defined cones as well
+SCALAR_SCALED = (SOC, PSD_SQUARE, PSD_TRIANGLE, EXP, DUAL_EXP, POW, DUAL_POW, PSD_TRIANGLE_COMPLEX, CUSTOM)
 
 
 @dataclass
@@ -64,6 +66,9 @@ class Cone:
     alpha: float = 0.0                      # PowerCone / DualPowerCone exponent (:607-618)
     max_iter: int = 0                       # Exp: 100 bisection steps (:503); Pow: 20 Newton steps (:613)
     tol: float = 1e-8                       # EXP_TOL / POW_TOL
+    fn_project: Optional[object] = None     # CUSTOM: project!(x, C) as a Python callable on a NumPy view (in place)
+    fn_in_dual: Optional[object] = None     # CUSTOM: in_dual(x, C, tol) -> bool      (optional, custom_cone.jl:62-68)
+    fn_in_pol_recc: Optional[object] = None
 
     @property
     def sqrt_dim(self) -> int:
@@ -100,6 +105,10 @@ def PowerCone(alpha, max_iter=20, tol=1e-8): return Cone(POW, 3, alpha=_pow_alph
 def DualPowerCone(alpha, max_iter=20, tol=1e-8): return Cone(DUAL_POW, 3, alpha=_pow_alpha(alpha), max_iter=int(max_iter), tol=float(tol))
 
 
+def CustomCone(dim, project, in_dual=None, in_pol_recc=None):
+    return Cone(CUSTOM, int(dim), fn_project=project, fn_in_dual=in_dual, fn_in_pol_recc=in_pol_recc)
+
+
 def Box(l, u):
     l = np.array(l, dtype=np.float64).copy()
     u = np.array(u, dtype=np.float64).copy()
@@ -117,7 +126,7 @@ def copy_cones(cones: Sequence[Cone]) -> List[Cone]:
                         None if c.l is None else c.l.copy(),
                         None if c.u is None else c.u.copy(),
                         None if c.constr_type is None else c.constr_type.copy(),
-                        c.alpha, c.max_iter, c.tol))
+                        c.alpha, c.max_iter, c.tol, c.fn_project, c.fn_in_dual, c.fn_in_pol_recc))
     return out
 
 
@@ -206,7 +215,9 @@ def _psd_project_dense(X: np.ndarray):
 def project_cone(x: np.ndarray, cone: Cone, info: Optional[dict] = None) -> None:
     """In-place `project!` of one slice (src/convexset.jl)."""
     k = cone.kind
-    if k == ZERO:                                 # :25-28
+    if k == CUSTOM:                               # the user's method of project! (custom_cone.jl:15-17)
+        cone.fn_project(x)
+    elif k == ZERO:                               # :25-28
         x[:] = 0.0
     elif k == NONNEG:                             # :71-74  (Julia max: NaN propagates, -0.0 -> +0.0)
         x[:] = np.where(np.isnan(x), x, np.maximum(x, 0.0) + 0.0)
@@ -432,6 +443,8 @@ def _is_pos_def(X: np.ndarray, tol: float) -> bool:
 
 def in_dual(x, cone: Cone, tol: float) -> bool:
     k = cone.kind
+    if k == CUSTOM:                                             # user method; without one the docs call the detection "disabled"
+        return bool(cone.fn_in_dual(np.array(x), tol)) if cone.fn_in_dual is not None else False
     if k == ZERO:
         return True                                             # :30-32
     if k == NONNEG:
@@ -459,6 +472,8 @@ def in_dual(x, cone: Cone, tol: float) -> bool:
 
 def in_pol_recc(x, cone: Cone, tol: float) -> bool:
     k = cone.kind
+    if k == CUSTOM:
+        return bool(cone.fn_in_pol_recc(np.array(x), tol)) if cone.fn_in_pol_recc is not None else False
     if k == ZERO:
         return not np.any(np.abs(x) > tol)                      # :34-36
     if k == NONNEG:
@@ -1355,7 +1370,7 @@ class Constraint:
 
 
 _SORT_KEY = {ZERO: 1, NONNEG: 2, BOX: 3, SOC: 4, PSD_SQUARE: 5, PSD_TRIANGLE: 6,
-             EXP: 6, DUAL_EXP: 6, POW: 6, DUAL_POW: 6, PSD_TRIANGLE_COMPLEX: 6}      # sort_sets fall-through (src/interface.jl:466-475)
+             EXP: 6, DUAL_EXP: 6, POW: 6, DUAL_POW: 6, PSD_TRIANGLE_COMPLEX: 6, CUSTOM: 6}      # sort_sets fall-through (src/interface.jl:466-475)
 
 
 def assemble(constraints: Sequence[Constraint]):

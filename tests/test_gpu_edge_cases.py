@@ -82,7 +82,7 @@ def test_abi_error_paths():
     with pytest.raises(cj.CosmoHipError):
         h.set_cones([F.NONNEG], [4], None, None)                  # dimensions do not sum to m
     with pytest.raises(cj.CosmoHipError) as e:
-        h.set_cones([11], [3], None, None)                        # unknown cone type: outside the hot path
+        h.set_cones([12], [3], None, None)                        # unknown cone type: outside the hot path
     assert e.value.code == 6
     h.set_cones([F.NONNEG], [3], None, None)
     p = h.default_params(); p.adaptive_rho_interval = 0

@@ -451,3 +451,45 @@ def test_complex_psd_least_eigenvalue_golden():
     w = np.linalg.eigvalsh(H)
     assert np.linalg.eigvalsh(Hp).min() > -1e-12 and info["psd_rank"][0] == int((w > 0).sum())
     assert abs(np.vdot(Hp, Hp - H).real) < 1e-10                       # <X+, X+ - X> = 0
+
+
+# ---- user-defined cones: docs/src/literate/custom_cone.jl (the reference's worked example of the AbstractConvexCone surface) ----
+def _nonpositives(dim):
+    def project(x):                       # custom_cone.jl:15-17
+        np.minimum(x, 0.0, out=x)
+    return O.CustomCone(dim, project, in_dual=lambda x, tol: not np.any(x > -tol),          # :62-64
+                        in_pol_recc=lambda x, tol: not np.any(x < tol))                      # :66-68
+
+
+def test_custom_cone_lp_golden():
+    # custom_cone.jl:19-49: max x1+x2+x3  s.t. x1 <= 3, x2 <= 2, x1 + x3 == 5   ->  x = (3, 2, 2), objective 7
+    A1 = np.array([[1.0, 0, 0], [0, 1.0, 0]]); b1 = np.array([-3.0, -2.0])
+    cs = [O.Constraint(A1, b1, _nonpositives(2)), O.Constraint(np.array([[1.0, 0, 1.0]]), np.array([-5.0]), O.ZeroSet(1))]
+    A, b, cones = O.assemble(cs)
+    assert [c.kind for c in cones] == [O.ZERO, O.CUSTOM]
+    res = O.solve(sp.csc_matrix((3, 3)), -np.ones(3), A, b, cones)
+    assert res.status == "Solved"
+    np.testing.assert_allclose(res.x, [3.0, 2.0, 2.0], atol=1e-3)
+    assert abs(-res.obj_val - 7.0) < 1e-3
+
+
+def test_custom_cone_dual_infeasible_golden():
+    # custom_cone.jl:70-89: min x s.t. x <= 3  ->  :Dual_infeasible once in_dual / in_pol_recc are defined
+    A, b, cones = O.assemble([O.Constraint(np.array([[1.0]]), np.array([-3.0]), _nonpositives(1))])
+    assert O.solve(sp.csc_matrix((1, 1)), np.array([1.0]), A, b, cones).status == "Dual_infeasible"
+
+
+def test_custom_cone_equals_builtin_nonnegatives_trajectory():
+    # a user cone that happens to be R^n_+ must reproduce the built-in Nonnegatives run exactly except for the scaling rule
+    # (user cones are scalar-scaled, src/convexset.jl:953-954), so compare with scaling off
+    rng = np.random.default_rng(3)
+    n, m = 12, 20
+    Am = sp.csc_matrix(rng.standard_normal((m, n))); x0 = rng.standard_normal(n)
+    b = Am @ x0 + rng.uniform(0.1, 1.0, m)
+    Pm = sp.identity(n, format="csc"); q = rng.standard_normal(n)
+    st = O.Settings(scaling=0)
+    r1 = O.solve(Pm, q, Am, b, [O.Nonnegatives(m)], st)
+    cc = O.CustomCone(m, lambda x: np.maximum(x, 0.0, out=x))
+    r2 = O.solve(Pm, q, Am, b, [cc], st)
+    assert r1.status == r2.status == "Solved" and r1.iter == r2.iter
+    np.testing.assert_array_equal(r1.x, r2.x)
