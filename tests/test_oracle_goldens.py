@@ -493,3 +493,19 @@ def test_custom_cone_equals_builtin_nonnegatives_trajectory():
     r2 = O.solve(Pm, q, Am, b, [cc], st)
     assert r1.status == r2.status == "Solved" and r1.iter == r2.iter
     np.testing.assert_array_equal(r1.x, r2.x)
+
+
+# ---- the reference's randomised infeasible-by-construction families (InfeasibilityTests/*.jl), our RNG ------------------------
+from tests import infeasible_instances as INF   # noqa: E402
+
+
+@pytest.mark.parametrize("family,seed", INF.CASES)
+def test_infeasible_family_statuses(family, seed):
+    gen, accepted, _ = INF.FAMILIES[family]
+    P, q, cons = gen(seed)
+    A, b, cones = O.assemble([O.Constraint(Ai, bi, O.Cone(k, d, constr_type=(np.zeros(d, dtype=bool) if k == O.NONNEG else None)))
+                              for (Ai, bi, k, d) in cons])
+    res = O.solve(P, q, A, b, cones, O.Settings(max_iter=3000 if family == "primal_infeasible_3" else 10000, eps_abs=1e-5, eps_rel=1e-5))
+    assert res.status in accepted, (family, seed, res.status, res.iter)
+    if family != "primal_infeasible_3":
+        assert res.iter < 1000
