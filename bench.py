@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=25)
     ap.add_argument("--small", action="store_true", help="1/10-size instance (debugging only; not the BASELINE workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-iters", type=int, default=2)
+    ap.add_argument("--cpu-sample-iters", type=int, default=5)
     ap.add_argument("--exact-launches", action="store_true",
                     help="synchronise after every Krylov iteration (rocprofv3 runs: every launch does full work)")
     args = ap.parse_args()

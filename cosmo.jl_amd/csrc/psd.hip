@@ -155,7 +155,8 @@ __global__ __launch_bounds__(COSMO_BS) void k_psd_tiny(const Ctl* __restrict__ c
         const double t = x[svec_idx(a, b)];
         v = (a == b) ? t : isq2 * t;                       // populate_upper_triangle! (convexset.jl:432-442)
       } else {
-        v = (x[(long long)b * d + a] + x[(long long)a * d + b]) / 2.0;   // symmetrize_upper! (algebra.jl:201-208)
+        v = (mode == 1) ? x[(long long)b * d + a]                         // is_pos_def!: Hermitian(X, 'U') as is (algebra.jl:226-233)
+                        : (x[(long long)b * d + a] + x[(long long)a * d + b]) / 2.0;   // symmetrize_upper! (algebra.jl:201-208)
       }
     }
     v = v * sign;
@@ -206,7 +207,9 @@ __global__ __launch_bounds__(COSMO_BS) void k_psd_tiny(const Ctl* __restrict__ c
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(COSMO_BS) void k_psd_populate(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ list,
                                                            const PsdConeDev* __restrict__ cones, const double* __restrict__ s,
-                                                           double* __restrict__ G, double* __restrict__ cshift, double sign) {
+                                                           double* __restrict__ G, double* __restrict__ cshift, double sign, int upper_only) {
+  // upper_only: the definiteness tests read Hermitian(X, 'U') of the square layout WITHOUT symmetrising (is_pos_def!,
+  // src/algebra.jl:226-233) -- delta_y of a PsdCone is not symmetric in general -- while project! symmetrises first (:201-208)
   if (guard && ctl->halt) return;
   __shared__ double red[COSMO_BS / 64];
   const int ci = list[blockIdx.y];
@@ -223,7 +226,8 @@ __global__ __launch_bounds__(COSMO_BS) void k_psd_populate(const Ctl* __restrict
   } else {
     for (long long k = threadIdx.x; k < (long long)d * d; k += COSMO_BS) {
       const int i = (int)(k % d), j = (int)(k / d);
-      const double v = (x[(long long)j * d + i] + x[(long long)i * d + j]) / 2.0;
+      const int a = i < j ? i : j, b = i < j ? j : i;
+      const double v = upper_only ? x[(long long)b * d + a] : (x[(long long)j * d + i] + x[(long long)i * d + j]) / 2.0;
       acc += v * v;
     }
   }
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_psd_populate(const Ctl* __restrict
           const double t = x[svec_idx(a, b)];
           v = (a == b) ? t : isq2 * t;
         } else {
-          v = (x[(long long)b * d + a] + x[(long long)a * d + b]) / 2.0;
+          v = upper_only ? x[(long long)b * d + a] : (x[(long long)b * d + a] + x[(long long)a * d + b]) / 2.0;
         }
         v = v * sign;
         if (i == j) v += c;
@@ -719,7 +723,7 @@ int32_t psd_enqueue_project(cosmo_hip_handle* h, double* s, bool guard_b) {
   for (size_t gi = 0; gi < p->pj_groups.size(); ++gi) {
     const int n = (int)p->pj_groups[gi].size();
     const int* lst = p->d_pj_groups[gi];
-    hipLaunchKernelGGL(k_psd_populate, dim3(8, n), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, lst, p->d_cones, s, p->G, p->cshift, 1.0);
+    hipLaunchKernelGGL(k_psd_populate, dim3(8, n), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, lst, p->d_cones, s, p->G, p->cshift, 1.0, 0);
     switch (p->pj_waves[gi]) {
       case 16: hipLaunchKernelGGL((k_psd_jacobi_wg<16>), dim3(n), dim3(1024), 0, h->stream, h->ctl, guard, lst, p->d_cones, p->G, p->cshift, p->flags, p->tol_factor, p->dbg); break;
       default: hipLaunchKernelGGL((k_psd_jacobi_wg<4>), dim3(n), dim3(256), 0, h->stream, h->ctl, guard, lst, p->d_cones, p->G, p->cshift, p->flags, p->tol_factor, p->dbg); break;
@@ -740,7 +744,7 @@ int32_t psd_enqueue_project(cosmo_hip_handle* h, double* s, bool guard_b) {
     const int n = (int)p->large.size();
     int nbmax = 0;
     for (int idx : p->large) nbmax = std::max(nbmax, p->cones[idx].nb);
-    hipLaunchKernelGGL(k_psd_populate, dim3(64, n), dim3(COSMO_BS), 0, h->stream, h->ctl, 0, p->d_large, p->d_cones, s, p->G, p->cshift, 1.0);
+    hipLaunchKernelGGL(k_psd_populate, dim3(64, n), dim3(COSMO_BS), 0, h->stream, h->ctl, 0, p->d_large, p->d_cones, s, p->G, p->cshift, 1.0, 0);
     CHK(psd_large_sweeps(h, n, nbmax));
     hipLaunchKernelGGL(k_psd_colscale, dim3(128, n), dim3(COSMO_BS), 0, h->stream, h->ctl, 0, p->d_large, p->d_cones, p->G, p->cshift, p->colw, p->rank);
     int maxtiles = 1;
@@ -793,7 +797,7 @@ int32_t psd_extreme_eigs(cosmo_hip_handle* h, const double* vec, double sign, st
   for (size_t gi = 0; gi < p->wg_groups.size(); ++gi) {
     const int n = (int)p->wg_groups[gi].size();
     const int* lst = p->d_wg_groups[gi];
-    hipLaunchKernelGGL(k_psd_populate, dim3(8, n), dim3(COSMO_BS), 0, h->stream, h->ctl, 0, lst, p->d_cones, vec, p->G, p->cshift, sign);
+    hipLaunchKernelGGL(k_psd_populate, dim3(8, n), dim3(COSMO_BS), 0, h->stream, h->ctl, 0, lst, p->d_cones, vec, p->G, p->cshift, sign, 1);
     if (p->wg_waves[gi] == 16)
       hipLaunchKernelGGL((k_psd_jacobi_wg<16>), dim3(n), dim3(1024), 0, h->stream, h->ctl, 0, lst, p->d_cones, p->G, p->cshift, p->flags, p->tol_factor, 0);
     else
@@ -804,7 +808,7 @@ int32_t psd_extreme_eigs(cosmo_hip_handle* h, const double* vec, double sign, st
     const int n = (int)p->large.size();
     int nbmax = 0;
     for (int idx : p->large) nbmax = std::max(nbmax, p->cones[idx].nb);
-    hipLaunchKernelGGL(k_psd_populate, dim3(64, n), dim3(COSMO_BS), 0, h->stream, h->ctl, 0, p->d_large, p->d_cones, vec, p->G, p->cshift, sign);
+    hipLaunchKernelGGL(k_psd_populate, dim3(64, n), dim3(COSMO_BS), 0, h->stream, h->ctl, 0, p->d_large, p->d_cones, vec, p->G, p->cshift, sign, 1);
     CHK(psd_large_sweeps(h, n, nbmax));
     hipLaunchKernelGGL(k_psd_eigmin, dim3(n), dim3(COSMO_BS), 0, h->stream, p->d_large, p->d_cones, p->G, p->cshift, p->eigmin);
   }

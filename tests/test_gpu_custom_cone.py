@@ -32,11 +32,15 @@ def _o_nonpos(dim, full=True):
     return O.CustomCone(dim, project, in_dual=lambda x, tol: not np.any(x > -tol), in_pol_recc=lambda x, tol: not np.any(x < tol))
 
 
+TIGHT = dict(tol_constant=1e-10, tol_exponent=0.0)
+
+
 def _solve_both(P, q, cons_model, cons_oracle, **st):
-    model = cj.Model(); cj.assemble(model, P, q, cons_model, settings=cj.Settings(**st))
+    model = cj.Model()
+    cj.assemble(model, P, q, cons_model, settings=cj.Settings(kkt_solver=cj.with_options(cj.CGIndirectKKTSolver, **TIGHT), **st))
     res = cj.optimize(model)
     A, b, cones = O.assemble(cons_oracle)
-    ref = O.solve(P, q, A, b, cones, O.Settings(kkt_solver="cg", **st))
+    ref = O.solve(P, q, A, b, cones, O.Settings(kkt_solver="cg", **TIGHT, **st))
     return res, ref
 
 
@@ -46,8 +50,7 @@ def test_custom_cone_lp_golden():
     A2 = np.array([[1.0, 0, 1.0]]); b2 = np.array([-5.0])
     res, ref = _solve_both(sp.csc_matrix((3, 3)), -np.ones(3),
                            [cj.Constraint(A1, b1, Nonpositives), cj.Constraint(A2, b2, cj.ZeroSet)],
-                           [O.Constraint(A1, b1, _o_nonpos(2, False)), O.Constraint(A2, b2, O.ZeroSet(1))],
-                           tol_constant=1e-10, tol_exponent=0.0)
+                           [O.Constraint(A1, b1, _o_nonpos(2, False)), O.Constraint(A2, b2, O.ZeroSet(1))])
     assert res.status == ref.status == "Solved"
     assert res.iter == ref.iter
     np.testing.assert_allclose(res.x, [3.0, 2.0, 2.0], atol=1e-3)
@@ -89,7 +92,8 @@ def test_custom_clone_of_nonnegatives_matches_builtin_on_device():
     out = []
     for K in (cj.Nonnegatives, MyNonneg):
         model = cj.Model()
-        cj.assemble(model, Pm, q, [cj.Constraint(-Am, b, K)], settings=cj.Settings(scaling=0, tol_constant=1e-10, tol_exponent=0.0))
+        cj.assemble(model, Pm, q, [cj.Constraint(-Am, b, K)],
+                    settings=cj.Settings(scaling=0, kkt_solver=cj.with_options(cj.CGIndirectKKTSolver, **TIGHT)))
         out.append(cj.optimize(model))
     r1, r2 = out
     assert r1.status == r2.status == "Solved" and r1.iter == r2.iter
@@ -110,7 +114,7 @@ def test_custom_cone_in_a_mixed_scaled_problem_matches_oracle():
     S = rng.standard_normal((n, n)); Pm = sp.csc_matrix(S @ S.T / n + 0.1 * np.eye(n)); q = rng.standard_normal(n)
     cm = [cj.Constraint(G1, -h1, NonpositivesFull), cj.Constraint(G2, -h2, cj.SecondOrderCone), cj.Constraint(G3, -h3, cj.ZeroSet)]
     co = [O.Constraint(G1, -h1, _o_nonpos(10)), O.Constraint(G2, -h2, O.SecondOrderCone(6)), O.Constraint(G3, -h3, O.ZeroSet(8))]
-    res, ref = _solve_both(Pm, q, cm, co, tol_constant=1e-10, tol_exponent=0.0)
+    res, ref = _solve_both(Pm, q, cm, co)
     assert res.status == ref.status == "Solved"
     assert res.iter == ref.iter
     np.testing.assert_allclose(res.x, ref.x, atol=1e-7 * max(1.0, np.max(np.abs(ref.x))))

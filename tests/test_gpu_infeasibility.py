@@ -89,13 +89,15 @@ _SETS = {INF.ZERO: cj.ZeroSet, INF.NONNEG: cj.Nonnegatives, INF.SOC: cj.SecondOr
 def test_infeasible_families_match_oracle(family, seed):
     gen, accepted, _ = INF.FAMILIES[family]
     P, q, cons = gen(seed)
-    st = dict(max_iter=2000, eps_abs=1e-5, eps_rel=1e-5, tol_constant=1e-10, tol_exponent=0.0)
+    st = dict(max_iter=2000, eps_abs=1e-5, eps_rel=1e-5)
+    tight = dict(tol_constant=1e-10, tol_exponent=0.0)
     model = cj.Model()
-    cj.assemble(model, P, q, [cj.Constraint(A, b, _SETS[k]) for (A, b, k, d) in cons], settings=cj.Settings(**st))
+    cj.assemble(model, P, q, [cj.Constraint(A, b, _SETS[k]) for (A, b, k, d) in cons],
+                settings=cj.Settings(kkt_solver=cj.with_options(cj.CGIndirectKKTSolver, **tight), **st))
     res = cj.optimize(model)
     A, b, cones = O.assemble([O.Constraint(A, b, O.Cone(k, d, constr_type=(np.zeros(d, dtype=bool) if k == O.NONNEG else None)))
                               for (A, b, k, d) in cons])
-    ref = O.solve(P, q, A, b, cones, O.Settings(kkt_solver="cg", **st))
+    ref = O.solve(P, q, A, b, cones, O.Settings(kkt_solver="cg", **tight, **st))
     assert res.status == ref.status and res.status in accepted, (res.status, ref.status)
     # the iterates of an infeasible problem diverge (|w| ~ 1e10 and growing), which amplifies rounding differences: allow the
     # certificate to fire one check_infeasibility interval apart
