@@ -9,6 +9,7 @@
 // arithmetic per element is identical, reductions are single-workgroup fixed-order sums.
 // Cone support in batch mode: ZeroSet, Nonnegatives, Box, SecondOrderCone (PSD cones take the large-problem path).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 #include <math.h>
 #include <algorithm>
@@ -67,45 +68,187 @@ __device__ __forceinline__ double proj_simple(double x, uint32_t meta, const dou
   return (x < l) ? l : ((x > u) ? u : x);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Two ways of applying a problem's matrices inside its workgroup; both give every row to one thread that adds the row's
+// products left to right (the order of Julia's CSC kernels), and both visit the rows in the order of the same tile
+// descriptors, so per-thread accumulations and therefore all results are bit-identical between them.
+//   StreamOps : values / indices stream from global memory tile by tile through a 16 KB LDS product buffer (any size).
+//   LdsOps    : the whole problem is copied ONCE per launch into the workgroup's LDS -- A as (fp64 value, u16 column),
+//               A' as (u16 position into A's values, u16 row) so the values are held once, P, the tile descriptors and
+//               the two gathered vectors -- and every product of every iteration reads LDS only.  BASELINE config 3
+//               (n = 500, m = 1000, nnz = 10 000) needs 157 KB of the CU's 160 KB.  HBM then only sees the iterates.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int BS>
+__device__ __forceinline__ double bsum(double v, double* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int i = 0; i < BS / 64; ++i) t += red[i];
+  return t;
+}
+template <int BS>
+__device__ __forceinline__ double bmax(double v, double* red) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = red[0];
+#pragma unroll
+  for (int i = 1; i < BS / 64; ++i) t = (red[i] > t) ? red[i] : t;
+  return t;
+}
+
+struct StreamOps {
+  CsrView A, AT, PT;
+  double* lds; double* red;
+  static constexpr bool in_lds = false;
+  __device__ __forceinline__ double* buf_n(double* g) const { return g; }       // vector the A / P products gather from
+  __device__ __forceinline__ double* buf_m(double* g) const { return g; }       // vector the A' products gather from
+  __device__ __forceinline__ const double* stage_n(const double* g) const { return g; }
+  template <class F> __device__ __forceinline__ void rows_A(const double* x, F fn) {
+    for (int t = 0; t < A.nb; ++t) csr_stream_tile(A, x, x, t, lds, red, fn);
+  }
+  template <class F> __device__ __forceinline__ void rows_AT(const double* y, F fn) {
+    for (int t = 0; t < AT.nb; ++t) csr_stream_tile(AT, y, y, t, lds, red, fn);
+  }
+  template <class F> __device__ __forceinline__ void rows_PT(const double* x1, const double* x2, F fn) {
+    for (int t = 0; t < PT.nb; ++t) csr_stream_tile(PT, x1, x2, t, lds, red, fn);
+  }
+};
+
+// header of a problem's LDS image (built by build_lds_images): byte offsets from the start of the image
+struct LdsHdr { int nnzA, nnzP, nbA, nbAT, nbPT, oAval, oPval, oArp, oAcol, oTrp, oTpos, oTrow, oPrp, oPcol, oRbA, oRbAT, oRbPT, bytes; };
+
+template <int BS>
+struct LdsOps {
+  const double *Aval, *Pval;
+  const unsigned short *Arp, *Acol, *Trp, *Tpos, *Trow, *Prp, *Pcol;
+  const int4 *rbA, *rbAT, *rbPT;
+  int nbA, nbAT, nbPT;
+  double *xv, *tv, *red;
+  int n;
+  static constexpr bool in_lds = true;
+  __device__ __forceinline__ double* buf_n(double*) const { return xv; }
+  __device__ __forceinline__ double* buf_m(double*) const { return tv; }
+  __device__ __forceinline__ const double* stage_n(const double* g) const {     // copy a global n-vector into the LDS gather buffer
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += BS) xv[i] = g[i];
+    __syncthreads();
+    return xv;
+  }
+  template <class F> __device__ __forceinline__ void rows_A(const double* x, F fn) {
+    __syncthreads();
+    for (int t = 0; t < nbA; ++t) {
+      const int4 d = rbA[t];
+      if (d.w - d.z <= COSMO_NNZ_PER_BLOCK) {
+        for (int r = d.x + threadIdx.x; r < d.y; r += BS) {
+          double s1 = 0.0;
+          const int a = Arp[r], b = Arp[r + 1];
+          for (int k = a; k < b; ++k) s1 += Aval[k] * x[Acol[k]];
+          fn(r, s1, 0.0);
+        }
+      } else {                                                               // a single long row: strided partials, block sum
+        const int r = d.x;
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = d.z + threadIdx.x; k < d.w; k += BS) s1 += Aval[k] * x[Acol[k]];
+        s1 = bsum<BS>(s1, red); s2 = bsum<BS>(s2, red);
+        if (threadIdx.x == 0) fn(r, s1, s2);
+      }
+    }
+    __syncthreads();
+  }
+  template <class F> __device__ __forceinline__ void rows_AT(const double* y, F fn) {
+    __syncthreads();
+    for (int t = 0; t < nbAT; ++t) {
+      const int4 d = rbAT[t];
+      if (d.w - d.z <= COSMO_NNZ_PER_BLOCK) {
+        for (int r = d.x + threadIdx.x; r < d.y; r += BS) {
+          double s1 = 0.0;
+          const int a = Trp[r], b = Trp[r + 1];
+          for (int k = a; k < b; ++k) s1 += Aval[Tpos[k]] * y[Trow[k]];
+          fn(r, s1, 0.0);
+        }
+      } else {
+        const int r = d.x;
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = d.z + threadIdx.x; k < d.w; k += BS) s1 += Aval[Tpos[k]] * y[Trow[k]];
+        s1 = bsum<BS>(s1, red); s2 = bsum<BS>(s2, red);
+        if (threadIdx.x == 0) fn(r, s1, s2);
+      }
+    }
+    __syncthreads();
+  }
+  template <class F> __device__ __forceinline__ void rows_PT(const double* x1, const double* x2, F fn) {
+    __syncthreads();
+    for (int t = 0; t < nbPT; ++t) {
+      const int4 d = rbPT[t];
+      if (d.w - d.z <= COSMO_NNZ_PER_BLOCK) {
+        for (int r = d.x + threadIdx.x; r < d.y; r += BS) {
+          double s1 = 0.0, s2 = 0.0;
+          const int pa = Prp[r], pb = Prp[r + 1];
+          for (int k = pa; k < pb; ++k) s1 += Pval[k] * x1[Pcol[k]];
+          const int a = Trp[r], b = Trp[r + 1];
+          for (int k = a; k < b; ++k) s2 += Aval[Tpos[k]] * x2[Trow[k]];
+          fn(r, s1, s2);
+        }
+      } else {
+        const int r = d.x;
+        const int pa = Prp[r], lp = Prp[r + 1] - pa, a = Trp[r], lt = Trp[r + 1] - a;
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = threadIdx.x; k < lp + lt; k += BS) {
+          if (k < lp) s1 += Pval[pa + k] * x1[Pcol[pa + k]];
+          else { const int kk = a + (k - lp); s2 += Aval[Tpos[kk]] * x2[Trow[kk]]; }
+        }
+        s1 = bsum<BS>(s1, red); s2 = bsum<BS>(s2, red);
+        if (threadIdx.x == 0) fn(r, s1, s2);
+      }
+    }
+    __syncthreads();
+  }
+};
+
 // One workgroup = one problem.  Runs iterations until a status is decided or `iter_target` iterations are done.
-__global__ __launch_bounds__(COSMO_BS) void k_batch_admm(BatchDev D, BParams P, long long iter_target, int do_init) {
-  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
-  __shared__ double red[COSMO_BS / 64];
+template <int BS, class Ops>
+__device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams& P, long long iter_target, int do_init, Ops& ops, double* red) {
   const int k = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n = D.n, m = D.m;
   BCtl* ctl = D.ctl + k;
-  if (ctl->status != 0) return;
-  const CsrView A = bview(D.A, k), AT = bview(D.AT, k), PT = bview(D.PT, k);
   const long long on = (long long)k * n, om = (long long)k * m, onm = (long long)k * (n + m);
   const double *q = D.q + on, *b = D.b + om, *Dinv = D.Dinv + on, *Einv = D.Einv + om;
   const double cinv = D.cinv[k];
   const double *bl = D.box_l + (long long)k * D.nbox, *bu = D.box_u + (long long)k * D.nbox;
   const int* cls = D.rho_cls + om;
   double *w = D.w + onm, *w_prev = D.w_prev + onm, *s = D.s + om, *mu = D.mu + om, *s_tl = D.s_tl + om;
-  double *ls_s = D.ls_s + om, *y2 = D.y2 + om, *tmp_m = D.tmp_m + om, *nu = D.nu + om, *rho = D.rho + om;
-  double *ls_x = D.ls_x + on, *x_tl = D.x_tl + on, *rhs = D.rhs + on, *r = D.r + on, *u = D.u + on, *c = D.c + on;
+  double *ls_s = D.ls_s + om, *nu = D.nu + om, *rho = D.rho + om;
+  double *ls_x = D.ls_x + on, *x_tl = D.x_tl + on, *rhs = D.rhs + on, *r = D.r + on, *c = D.c + on;
+  // vectors the sparse products GATHER from: global arrays for StreamOps, the two LDS buffers for LdsOps
+  double* const u = ops.buf_n(D.u + on);                 // CG direction
+  double* const y2 = ops.buf_m(D.y2 + om);               // rho .* ls_s (dead once the rhs is formed)
+  double* const tmp_m = ops.buf_m(D.tmp_m + om);         // rho .* (A v)
+  double* const mu_g = ops.buf_m(mu);                    // mu for the dual residual
 
   // ---- admm_x! + admm_w! (solver.jl:32-65) with the CG reduced solve (kktsolver_indirect.jl:36-88) -------------------
   auto solve_and_update = [&]() {
-    for (int i = tid; i < n + m; i += COSMO_BS) {                       // rhs of the KKT system + y2 = rho .* ls_s
+    for (int i = tid; i < n + m; i += BS) {                             // rhs of the KKT system + y2 = rho .* ls_s
       if (i < n) ls_x[i] = P.sigma * w[i] - q[i];
       else { const int rr = i - n; const double v = (b[rr] - 2.0 * s[rr]) + w[i]; ls_s[rr] = v; y2[rr] = rho[rr] * v; }
     }
     __syncthreads();
     double acc = 0.0;
-    for (int t = 0; t < AT.nb; ++t)
-      csr_stream_tile(AT, y2, y2, t, lds, red, [&](int row, double s1, double s2) {
-        const double v = (s1 + s2) + ls_x[row]; rhs[row] = v; acc += v * v; });
-    const double bb = block_sum(acc, red);
-    for (int t = 0; t < A.nb; ++t)
-      csr_stream_tile(A, x_tl, x_tl, t, lds, red, [&](int row, double s1, double s2) { tmp_m[row] = (s1 + s2) * rho[row]; });
+    ops.rows_AT(y2, [&](int row, double s1, double s2) {
+      const double v = (s1 + s2) + ls_x[row]; rhs[row] = v; acc += v * v; });
+    const double bb = bsum<BS>(acc, red);
+    const double* xs = ops.stage_n(x_tl);
+    ops.rows_A(xs, [&](int row, double s1, double s2) { tmp_m[row] = (s1 + s2) * rho[row]; });
     __syncthreads();
     acc = 0.0;
-    for (int t = 0; t < PT.nb; ++t)
-      csr_stream_tile(PT, x_tl, tmp_m, t, lds, red, [&](int row, double s1, double s2) {
-        const double cj = s1 + (P.sigma * x_tl[row] + s2); const double rj = rhs[row] - cj; r[row] = rj; acc += rj * rj; });
-    double rr = block_sum(acc, red);
+    ops.rows_PT(xs, tmp_m, [&](int row, double s1, double s2) {
+      const double cj = s1 + (P.sigma * xs[row] + s2); const double rj = rhs[row] - cj; r[row] = rj; acc += rj * rj; });
+    double rr = bsum<BS>(acc, red);
     const long long ks = ctl->solves;                                    // iteration_counter - 1
     const double tol_k = D.tol_table[ks < D.tol_len ? ks : D.tol_len - 1];
     const double tol = tol_k / sqrt(bb);
@@ -113,33 +256,31 @@ __global__ __launch_bounds__(COSMO_BS) void k_batch_admm(BatchDev D, BParams P, 
     int kk = 0;
     while (kk < n && !(res <= tol)) {                                    // cg! (IterativeSolvers v0.9), maxiter = n
       const double beta = (res * res) / (prev * prev);
-      for (int i = tid; i < n; i += COSMO_BS) u[i] = r[i] + beta * ((kk == 0) ? 0.0 : u[i]);
+      for (int i = tid; i < n; i += BS) u[i] = r[i] + beta * ((kk == 0) ? 0.0 : u[i]);
       __syncthreads();
-      for (int t = 0; t < A.nb; ++t)
-        csr_stream_tile(A, u, u, t, lds, red, [&](int row, double s1, double s2) { tmp_m[row] = (s1 + s2) * rho[row]; });
+      ops.rows_A(u, [&](int row, double s1, double s2) { tmp_m[row] = (s1 + s2) * rho[row]; });
       __syncthreads();
       acc = 0.0;
-      for (int t = 0; t < PT.nb; ++t)
-        csr_stream_tile(PT, u, tmp_m, t, lds, red, [&](int row, double s1, double s2) {
-          const double vj = u[row]; const double cj = s1 + (P.sigma * vj + s2); c[row] = cj; acc += vj * cj; });
-      const double uc = block_sum(acc, red);
+      ops.rows_PT(u, tmp_m, [&](int row, double s1, double s2) {
+        const double vj = u[row]; const double cj = s1 + (P.sigma * vj + s2); c[row] = cj; acc += vj * cj; });
+      const double uc = bsum<BS>(acc, red);
       const double a = (res * res) / uc;
       acc = 0.0;
-      for (int i = tid; i < n; i += COSMO_BS) {
+      for (int i = tid; i < n; i += BS) {
         x_tl[i] = x_tl[i] + a * u[i];
         const double ri = r[i] - a * c[i]; r[i] = ri; acc += ri * ri;
       }
-      rr = block_sum(acc, red);
+      rr = bsum<BS>(acc, red);
       prev = res; res = sqrt(rr); ++kk;
     }
     __syncthreads();
     // nu = rho (A x_tl - ls_s) ; s_tl ; w update
-    for (int t = 0; t < A.nb; ++t)
-      csr_stream_tile(A, x_tl, x_tl, t, lds, red, [&](int row, double s1, double s2) {
-        const double rh = rho[row]; const double nv = ((s1 + s2) - ls_s[row]) * rh; nu[row] = nv;
-        const double sv = s[row], wv = w[n + row]; const double st = (2.0 * sv - wv) - nv / rh; s_tl[row] = st;
-        w[n + row] = wv + P.alpha * (st - sv); });
-    for (int i = tid; i < n; i += COSMO_BS) { const double wv = w[i]; w[i] = wv + P.alpha * (x_tl[i] - wv); }
+    const double* xe = ops.stage_n(x_tl);
+    ops.rows_A(xe, [&](int row, double s1, double s2) {
+      const double rh = rho[row]; const double nv = ((s1 + s2) - ls_s[row]) * rh; nu[row] = nv;
+      const double sv = s[row], wv2 = w[n + row]; const double st = (2.0 * sv - wv2) - nv / rh; s_tl[row] = st;
+      w[n + row] = wv2 + P.alpha * (st - sv); });
+    for (int i = tid; i < n; i += BS) { const double wv2 = w[i]; w[i] = wv2 + P.alpha * (x_tl[i] - wv2); }
     __syncthreads();
     if (tid == 0) { ctl->solves = ks + 1; ctl->kkt_iters_total += kk; }
     __syncthreads();
@@ -149,28 +290,29 @@ __global__ __launch_bounds__(COSMO_BS) void k_batch_admm(BatchDev D, BParams P, 
   double rp, mp, rd, md, cost;
   auto residuals = [&](bool unscale) {
     double a_rp = 0.0, a_mp = 0.0;
-    for (int t = 0; t < A.nb; ++t)
-      csr_stream_tile(A, w_prev, w_prev, t, lds, red, [&](int row, double s1, double s2) {
-        const double ax = s1 + s2, sv = s[row], bv = b[row];
-        mu[row] = rho[row] * (w_prev[n + row] - sv);
-        double rv = ax + sv; rv = rv - bv;
-        const double e = unscale ? Einv[row] : 1.0;
-        if (unscale) rv = rv * e;
-        a_rp = amax(a_rp, rv);
-        a_mp = amax(a_mp, unscale ? ax * e : ax); a_mp = amax(a_mp, unscale ? sv * e : sv); a_mp = amax(a_mp, unscale ? bv * e : bv); });
-    rp = block_max(a_rp, red); mp = block_max(a_mp, red);
+    const double* xp = ops.stage_n(w_prev);
+    ops.rows_A(xp, [&](int row, double s1, double s2) {
+      const double ax = s1 + s2, sv = s[row], bv = b[row];
+      const double muv = rho[row] * (w_prev[n + row] - sv);
+      mu[row] = muv;
+      if (Ops::in_lds) mu_g[row] = muv;
+      double rv = ax + sv; rv = rv - bv;
+      const double e = unscale ? Einv[row] : 1.0;
+      if (unscale) rv = rv * e;
+      a_rp = amax(a_rp, rv);
+      a_mp = amax(a_mp, unscale ? ax * e : ax); a_mp = amax(a_mp, unscale ? sv * e : sv); a_mp = amax(a_mp, unscale ? bv * e : bv); });
+    rp = bmax<BS>(a_rp, red); mp = bmax<BS>(a_mp, red);
     __syncthreads();
     double a_rd = 0.0, a_md = 0.0, xpx = 0.0, qx = 0.0;
-    for (int t = 0; t < PT.nb; ++t)
-      csr_stream_tile(PT, w_prev, mu, t, lds, red, [&](int row, double px, double atm) {
-        const double xv = w_prev[row], qv = q[row];
-        double rv = px + qv; rv = rv - atm;
-        double a = px, bq = qv, cm = atm;
-        if (unscale) { const double d = Dinv[row]; rv = (rv * d) * cinv; a = (a * d) * cinv; bq = (bq * d) * cinv; cm = (cm * d) * cinv; }
-        a_rd = amax(a_rd, rv); a_md = amax(a_md, a); a_md = amax(a_md, bq); a_md = amax(a_md, cm);
-        xpx += px * xv; qx += qv * xv; });
-    rd = block_max(a_rd, red); md = block_max(a_md, red);
-    xpx = block_sum(xpx, red); qx = block_sum(qx, red);
+    ops.rows_PT(xp, mu_g, [&](int row, double px, double atm) {
+      const double xv = xp[row], qv = q[row];
+      double rv = px + qv; rv = rv - atm;
+      double a = px, bq = qv, cm = atm;
+      if (unscale) { const double d = Dinv[row]; rv = (rv * d) * cinv; a = (a * d) * cinv; bq = (bq * d) * cinv; cm = (cm * d) * cinv; }
+      a_rd = amax(a_rd, rv); a_md = amax(a_md, a); a_md = amax(a_md, bq); a_md = amax(a_md, cm);
+      xpx += px * xv; qx += qv * xv; });
+    rd = bmax<BS>(a_rd, red); md = bmax<BS>(a_md, red);
+    xpx = bsum<BS>(xpx, red); qx = bsum<BS>(qx, red);
     cost = (unscale ? cinv : 1.0) * (0.5 * xpx + qx);
     __syncthreads();
   };
@@ -182,12 +324,12 @@ __global__ __launch_bounds__(COSMO_BS) void k_batch_admm(BatchDev D, BParams P, 
   while (it < iter_target && it < P.max_iter) {
     ++it;
     // ---- admm_z!: w_prev = w ; s = Pi(w_s)  (solver.jl:151-152) ----
-    for (int i = tid; i < n + m; i += COSMO_BS) {
+    for (int i = tid; i < n + m; i += BS) {
       const double v = w[i]; w_prev[i] = v;
       if (i >= n) s[i - n] = proj_simple(v, D.meta[i - n], bl, bu);
     }
     __syncthreads();
-    for (int cI = wv; cI < D.nsoc; cI += COSMO_BS / 64) {                 // SecondOrderCone (convexset.jl:100-114)
+    for (int cI = wv; cI < D.nsoc; cI += BS / 64) {                       // SecondOrderCone (convexset.jl:100-114)
       double* x = s + D.soc_off[cI]; const int d = D.soc_dim[cI];
       if (d == 0) continue;
       const double t = x[0];
@@ -210,7 +352,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_batch_admm(BatchDev D, BParams P, 
       const bool adapt = (nr > P.adapt_tol * rho0) || (nr < (1.0 / P.adapt_tol) * rho0);
       __syncthreads();
       if (adapt) {
-        for (int i = tid; i < m; i += COSMO_BS) {
+        for (int i = tid; i < m; i += BS) {
           const int cc = cls[i]; double rv = nr;
           if (cc == 1) rv = rv * P.rho_eq; else if (cc == 2) rv = P.rho_min;
           rho[i] = rv;
@@ -247,7 +389,47 @@ __global__ __launch_bounds__(COSMO_BS) void k_batch_admm(BatchDev D, BParams P, 
   }
   // recover_mu! (solver.jl:167)
   __syncthreads();
-  for (int i = tid; i < m; i += COSMO_BS) mu[i] = rho[i] * (w_prev[n + i] - s[i]);
+  for (int i = tid; i < m; i += BS) mu[i] = rho[i] * (w_prev[n + i] - s[i]);
+}
+
+__global__ __launch_bounds__(COSMO_BS) void k_batch_admm(BatchDev D, BParams P, long long iter_target, int do_init) {
+  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ double red[COSMO_BS / 64];
+  const int k = blockIdx.x;
+  if (D.ctl[k].status != 0) return;
+  StreamOps ops;
+  ops.A = bview(D.A, k); ops.AT = bview(D.AT, k); ops.PT = bview(D.PT, k); ops.lds = lds; ops.red = red;
+  batch_admm_body<COSMO_BS>(D, P, iter_target, do_init, ops, red);
+}
+
+// LDS-resident variant: `img` holds one image of `img_stride` bytes per problem (header + arrays, see build_lds_images)
+template <int BS>
+__global__ __launch_bounds__(BS) void k_batch_admm_lds(BatchDev D, BParams P, long long iter_target, int do_init,
+                                                       const unsigned char* __restrict__ img, long long img_stride) {
+  extern __shared__ double dyn_lds[];
+  const int k = blockIdx.x;
+  if (D.ctl[k].status != 0) return;
+  const unsigned char* src = img + (long long)k * img_stride;
+  const LdsHdr hd = *reinterpret_cast<const LdsHdr*>(src);
+  {
+    const double* s8 = reinterpret_cast<const double*>(src);
+    const int nd = hd.bytes / 8;
+    for (int i = threadIdx.x; i < nd; i += BS) dyn_lds[i] = s8[i];
+  }
+  unsigned char* base = reinterpret_cast<unsigned char*>(dyn_lds);
+  LdsOps<BS> ops;
+  ops.Aval = reinterpret_cast<const double*>(base + hd.oAval); ops.Pval = reinterpret_cast<const double*>(base + hd.oPval);
+  ops.Arp = reinterpret_cast<const unsigned short*>(base + hd.oArp); ops.Acol = reinterpret_cast<const unsigned short*>(base + hd.oAcol);
+  ops.Trp = reinterpret_cast<const unsigned short*>(base + hd.oTrp); ops.Tpos = reinterpret_cast<const unsigned short*>(base + hd.oTpos);
+  ops.Trow = reinterpret_cast<const unsigned short*>(base + hd.oTrow);
+  ops.Prp = reinterpret_cast<const unsigned short*>(base + hd.oPrp); ops.Pcol = reinterpret_cast<const unsigned short*>(base + hd.oPcol);
+  ops.rbA = reinterpret_cast<const int4*>(base + hd.oRbA); ops.rbAT = reinterpret_cast<const int4*>(base + hd.oRbAT);
+  ops.rbPT = reinterpret_cast<const int4*>(base + hd.oRbPT);
+  ops.nbA = hd.nbA; ops.nbAT = hd.nbAT; ops.nbPT = hd.nbPT;
+  double* wsp = reinterpret_cast<double*>(base + img_stride);            // workspace behind the image
+  ops.xv = wsp; ops.tv = wsp + D.n; ops.red = wsp + D.n + D.m; ops.n = D.n;
+  __syncthreads();
+  batch_admm_body<BS>(D, P, iter_target, do_init, ops, ops.red);
 }
 
 // warm start (solver.jl:128-129) for all problems
@@ -284,6 +466,8 @@ struct cosmo_hip_batch {
   std::vector<double> hDinv, hEinv, hcinv;
   std::vector<int32_t> cls_host;
   long long iters_done = 0;
+  // LDS-resident variant (build_lds_images): one image per problem, dynamic LDS = image + gather vectors + reduction slots
+  unsigned char* d_img = nullptr; long long img_stride = 0; int lds_bytes = 0; int lds_bs = 0;
 };
 
 static int32_t bfail(cosmo_hip_batch* b, int32_t code, const char* fmt, ...) {
@@ -462,6 +646,107 @@ static int32_t bmat_upload(cosmo_hip_batch* b, std::vector<HostCsr>& Ms, BMat& o
   return COSMO_HIP_OK;
 }
 
+static void brow_blocks(const std::vector<int>& rowptr, int nrows, std::vector<int>& rb);
+
+// Builds the per-problem LDS images of k_batch_admm_lds if every problem fits (u16 indices, image + work vectors within the
+// CU's LDS); otherwise leaves b->d_img = nullptr and the streaming kernel is used.  COSMO_HIP_BATCH_LDS=0 disables it,
+// COSMO_HIP_BATCH_BS selects the workgroup size (256, 512 or 1024; default 1024).
+static int32_t build_lds_images(cosmo_hip_batch* b) {
+  b->d_img = nullptr; b->lds_bs = 0;
+  const char* e = getenv("COSMO_HIP_BATCH_LDS");
+  if (e && atoi(e) == 0) return COSMO_HIP_OK;
+  const long long n = b->n, m = b->m;
+  if (n > 65535 || m > 65535 || n + m == 0) return COSMO_HIP_OK;
+  int bs = 1024;
+  if (const char* eb = getenv("COSMO_HIP_BATCH_BS")) { const int v = atoi(eb); if (v == 256 || v == 512 || v == 1024) bs = v; }
+  int max_lds = 0;
+  if (hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, b->device) != hipSuccess) return COSMO_HIP_OK;
+  auto up16 = [](long long x) { return (x + 15) / 16 * 16; };
+  std::vector<std::vector<unsigned char>> imgs((size_t)b->nprob);
+  long long stride = 0;
+  for (int k = 0; k < b->nprob; ++k) {
+    const HostCsr &A = b->hA[k], &AT = b->hAT[k], &PT = b->hPT[k];
+    const long long nnzA = (long long)A.val.size();
+    long long nnzP = 0;
+    for (long long j = 0; j < n; ++j) nnzP += PT.split[j] - PT.rowptr[j];
+    if (nnzA > 65535 || nnzP > 65535) return COSMO_HIP_OK;
+    std::vector<int> rA, rAT, rPT;
+    brow_blocks(A.rowptr, (int)m, rA); brow_blocks(AT.rowptr, (int)n, rAT); brow_blocks(PT.rowptr, (int)n, rPT);
+    LdsHdr h; memset(&h, 0, sizeof h);
+    h.nnzA = (int)nnzA; h.nnzP = (int)nnzP; h.nbA = (int)rA.size() - 1; h.nbAT = (int)rAT.size() - 1; h.nbPT = (int)rPT.size() - 1;
+    long long o = up16(sizeof(LdsHdr));
+    h.oAval = (int)o; o = up16(o + 8 * nnzA);
+    h.oPval = (int)o; o = up16(o + 8 * nnzP);
+    h.oRbA = (int)o; o = up16(o + 16LL * h.nbA);
+    h.oRbAT = (int)o; o = up16(o + 16LL * h.nbAT);
+    h.oRbPT = (int)o; o = up16(o + 16LL * h.nbPT);
+    h.oArp = (int)o; o = up16(o + 2 * (m + 1));
+    h.oAcol = (int)o; o = up16(o + 2 * nnzA);
+    h.oTrp = (int)o; o = up16(o + 2 * (n + 1));
+    h.oTpos = (int)o; o = up16(o + 2 * nnzA);
+    h.oTrow = (int)o; o = up16(o + 2 * nnzA);
+    h.oPrp = (int)o; o = up16(o + 2 * (n + 1));
+    h.oPcol = (int)o; o = up16(o + 2 * nnzP);
+    h.bytes = (int)o;
+    if (o + 8 * (n + m) + 8 * (bs / 64) > max_lds) return COSMO_HIP_OK;
+    std::vector<unsigned char>& im = imgs[(size_t)k];
+    im.assign((size_t)o, 0);
+    memcpy(im.data(), &h, sizeof h);
+    double* Aval = reinterpret_cast<double*>(im.data() + h.oAval);
+    double* Pval = reinterpret_cast<double*>(im.data() + h.oPval);
+    unsigned short* Arp = reinterpret_cast<unsigned short*>(im.data() + h.oArp);
+    unsigned short* Acol = reinterpret_cast<unsigned short*>(im.data() + h.oAcol);
+    unsigned short* Trp = reinterpret_cast<unsigned short*>(im.data() + h.oTrp);
+    unsigned short* Tpos = reinterpret_cast<unsigned short*>(im.data() + h.oTpos);
+    unsigned short* Trow = reinterpret_cast<unsigned short*>(im.data() + h.oTrow);
+    unsigned short* Prp = reinterpret_cast<unsigned short*>(im.data() + h.oPrp);
+    unsigned short* Pcol = reinterpret_cast<unsigned short*>(im.data() + h.oPcol);
+    for (long long t = 0; t < nnzA; ++t) { Aval[t] = A.val[t]; Acol[t] = (unsigned short)A.col[t]; }
+    for (long long i = 0; i <= m; ++i) Arp[i] = (unsigned short)A.rowptr[i];
+    std::vector<int> cur(A.rowptr.begin(), A.rowptr.end() - 1);
+    long long pp = 0;
+    for (long long j = 0; j < n; ++j) {
+      Trp[j] = (unsigned short)AT.rowptr[j]; Prp[j] = (unsigned short)pp;
+      for (int t = PT.rowptr[j]; t < PT.split[j]; ++t) { Pval[pp] = PT.val[t]; Pcol[pp] = (unsigned short)PT.col[t]; ++pp; }
+      for (int t = AT.rowptr[j]; t < AT.rowptr[j + 1]; ++t) {
+        const int i = AT.col[t]; const int p = cur[i]++;
+        if (p >= A.rowptr[i + 1] || A.col[p] != (int)j || A.val[p] != AT.val[t]) return bfail(b, COSMO_HIP_ERR_INVALID, "LDS image: A / A' mismatch");
+        Tpos[t] = (unsigned short)p; Trow[t] = (unsigned short)i;
+      }
+    }
+    Trp[n] = (unsigned short)AT.rowptr[n]; Prp[n] = (unsigned short)pp;
+    auto fill_rb = [&](int off, const std::vector<int>& r, const std::vector<int>& rowptr) {
+      int* d = reinterpret_cast<int*>(im.data() + off);
+      for (size_t t = 0; t + 1 < r.size(); ++t) { d[4 * t] = r[t]; d[4 * t + 1] = r[t + 1]; d[4 * t + 2] = rowptr[r[t]]; d[4 * t + 3] = rowptr[r[t + 1]]; }
+    };
+    fill_rb(h.oRbA, rA, A.rowptr); fill_rb(h.oRbAT, rAT, AT.rowptr); fill_rb(h.oRbPT, rPT, PT.rowptr);
+    stride = std::max(stride, o);
+  }
+  unsigned char* d = nullptr;
+  BHIP(b, hipMalloc((void**)&d, (size_t)stride * b->nprob));
+  b->allocs.push_back(d);
+  BHIP(b, hipMemset(d, 0, (size_t)stride * b->nprob));
+  for (int k = 0; k < b->nprob; ++k)
+    BHIP(b, hipMemcpy(d + (size_t)k * stride, imgs[(size_t)k].data(), imgs[(size_t)k].size(), hipMemcpyHostToDevice));
+  b->d_img = d; b->img_stride = stride; b->lds_bs = bs;
+  b->lds_bytes = (int)(stride + 8 * (n + m) + 8 * (bs / 64));
+  const void* fn = bs == 256 ? (const void*)k_batch_admm_lds<256> : (bs == 512 ? (const void*)k_batch_admm_lds<512> : (const void*)k_batch_admm_lds<1024>);
+  BHIP(b, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, b->lds_bytes));
+  return COSMO_HIP_OK;
+}
+
+static int32_t launch_batch_admm(cosmo_hip_batch* b, const BParams& P, long long target, int do_init) {
+  if (b->d_img) {
+    if (b->lds_bs == 256) hipLaunchKernelGGL((k_batch_admm_lds<256>), dim3(b->nprob), dim3(256), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
+    else if (b->lds_bs == 512) hipLaunchKernelGGL((k_batch_admm_lds<512>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
+    else hipLaunchKernelGGL((k_batch_admm_lds<1024>), dim3(b->nprob), dim3(1024), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
+  } else {
+    hipLaunchKernelGGL(k_batch_admm, dim3(b->nprob), dim3(COSMO_BS), 0, b->stream, b->D, P, target, do_init);
+  }
+  BHIP(b, hipGetLastError());
+  return COSMO_HIP_OK;
+}
+
 // set_params finalises the batch: uploads everything, classifies rows, builds the rho vectors (set_rho_vec!)
 extern "C" int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hip_params* p) {
   if (!b || !p) return COSMO_HIP_ERR_INVALID;
@@ -476,6 +761,7 @@ extern "C" int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hi
   BatchDev& D = b->D;
   D.nprob = nprob; D.n = (int)n; D.m = (int)m;
   int32_t rc;
+  if ((rc = build_lds_images(b))) return rc;               // needs the host CSR copies that bmat_upload releases
   if ((rc = bmat_upload(b, b->hA, D.A, (int)m, (int)n, false))) return rc;
   if ((rc = bmat_upload(b, b->hAT, D.AT, (int)n, (int)m, false))) return rc;
   if ((rc = bmat_upload(b, b->hPT, D.PT, (int)n, (int)n, true))) return rc;
@@ -602,9 +888,8 @@ extern "C" int32_t cosmo_hip_batch_optimize(cosmo_hip_batch* b, cosmo_hip_result
   int first = 1;
   for (;;) {
     target = std::min<long long>(target + slice, b->prm.max_iter);
-    hipLaunchKernelGGL(k_batch_admm, dim3(b->nprob), dim3(COSMO_BS), 0, b->stream, b->D, P, target, first);
+    { const int32_t lrc = launch_batch_admm(b, P, target, first); if (lrc) return lrc; }
     first = 0;
-    BHIP(b, hipGetLastError());
     BHIP(b, hipMemcpyAsync(c.data(), b->D.ctl, sizeof(BCtl) * b->nprob, hipMemcpyDeviceToHost, b->stream));
     BHIP(b, hipStreamSynchronize(b->stream));
     bool all = true;
@@ -633,8 +918,7 @@ extern "C" int32_t cosmo_hip_batch_iterate(cosmo_hip_batch* b, int64_t n_iters, 
   if (hipSetDevice(b->device) != hipSuccess) return bfail(b, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
   const BParams P = bparams(b->prm);
   b->iters_done += n_iters;
-  hipLaunchKernelGGL(k_batch_admm, dim3(b->nprob), dim3(COSMO_BS), 0, b->stream, b->D, P, (long long)b->iters_done, with_init ? 1 : 0);
-  BHIP(b, hipGetLastError());
+  { const int32_t lrc = launch_batch_admm(b, P, (long long)b->iters_done, with_init ? 1 : 0); if (lrc) return lrc; }
   BHIP(b, hipStreamSynchronize(b->stream));
   return COSMO_HIP_OK;
 }
