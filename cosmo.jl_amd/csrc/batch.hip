@@ -432,6 +432,387 @@ __global__ __launch_bounds__(BS) void k_batch_admm_lds(BatchDev D, BParams P, lo
   batch_admm_body<BS>(D, P, iter_target, do_init, ops, ops.red);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Register-resident variant of the LDS kernel for problems with n <= JN*BS and m <= JM*BS: element i of every iterate
+// vector is OWNED by thread i % BS and lives in that thread's registers (slot i / BS) for the whole launch; row r of every
+// sparse product is computed by its owner, which finds everything row-indexed (rho, ls_s, s, w, rhs, r, c ...) in its own
+// registers.  The only shared data are the two gather vectors (LDS) and the matrices (LDS).  Global memory is touched when
+// the launch starts (load state), ends (store state) and at the termination checks (scaling vectors).  The arithmetic per
+// element and the left-to-right row sums are those of batch_admm_body; block reductions add the per-thread partials of the
+// BS-strided ownership (fixed order, deterministic).
+// ---------------------------------------------------------------------------------------------------------------------
+#ifdef COSMO_BATCH_TIMING
+__device__ long long g_bt[8];     // lab instrumentation: shader-clock cycles of workgroup 0 per phase (not built by default)
+#define BT_BEGIN() long long bt__ = clock64()
+#define BT_END(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_bt[slot] += clock64() - bt__; } } while (0)
+extern "C" void cosmo_dbg_batch_timing(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bt), sizeof(long long) * 8); }
+#else
+#define BT_BEGIN()
+#define BT_END(slot)
+#endif
+
+template <int BS, int JN, int JM>
+__global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, long long iter_target, int do_init,
+                                                       const unsigned char* __restrict__ img, long long img_stride) {
+  extern __shared__ double dyn_lds[];
+  const int k = blockIdx.x;
+  BCtl* ctl = D.ctl + k;
+  if (ctl->status != 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wvid = tid >> 6;
+  const int n = D.n, m = D.m;
+  const unsigned char* src = img + (long long)k * img_stride;
+  const LdsHdr hd = *reinterpret_cast<const LdsHdr*>(src);
+  {
+    const double* s8 = reinterpret_cast<const double*>(src);
+    const int nd = hd.bytes / 8;
+    for (int i = tid; i < nd; i += BS) dyn_lds[i] = s8[i];
+  }
+  unsigned char* base = reinterpret_cast<unsigned char*>(dyn_lds);
+  const double* Aval = reinterpret_cast<const double*>(base + hd.oAval);
+  const double* Pval = reinterpret_cast<const double*>(base + hd.oPval);
+  const unsigned short* Arp = reinterpret_cast<const unsigned short*>(base + hd.oArp);
+  const unsigned short* Acol = reinterpret_cast<const unsigned short*>(base + hd.oAcol);
+  const unsigned short* Trp = reinterpret_cast<const unsigned short*>(base + hd.oTrp);
+  const unsigned short* Tpos = reinterpret_cast<const unsigned short*>(base + hd.oTpos);
+  const unsigned short* Trow = reinterpret_cast<const unsigned short*>(base + hd.oTrow);
+  const unsigned short* Prp = reinterpret_cast<const unsigned short*>(base + hd.oPrp);
+  const unsigned short* Pcol = reinterpret_cast<const unsigned short*>(base + hd.oPcol);
+  double* wsp = reinterpret_cast<double*>(base + img_stride);
+  double* xv = wsp;                 // n : vector gathered by the A / P products
+  double* tv = wsp + n;             // m : vector gathered by the A' products; staging of s for the SOC projection
+  double* red = wsp + n + m;        // BS / 64 reduction slots
+
+  const long long on = (long long)k * n, om = (long long)k * m, onm = (long long)k * (n + m);
+  // ---- load the persistent state and the per-element constants into registers -----------------------------------------
+  double wx[JN], wpx[JN], qv[JN], xtl[JN], lsx[JN], rhsv[JN], rv[JN], cv[JN];
+  double wsv[JM], wps[JM], sv[JM], rhov[JM], lss[JM], bv[JM], blv[JM], buv[JM];
+  uint32_t metav[JM];
+#pragma unroll
+  for (int j = 0; j < JN; ++j) {
+    const int i = tid + BS * j;
+    const bool ok = i < n;
+    wx[j] = ok ? D.w[onm + i] : 0.0; wpx[j] = ok ? D.w_prev[onm + i] : 0.0; qv[j] = ok ? D.q[on + i] : 0.0; xtl[j] = ok ? D.x_tl[on + i] : 0.0;
+    lsx[j] = 0.0; rhsv[j] = 0.0; rv[j] = 0.0; cv[j] = 0.0;
+  }
+#pragma unroll
+  for (int j = 0; j < JM; ++j) {
+    const int i = tid + BS * j;
+    const bool ok = i < m;
+    wsv[j] = ok ? D.w[onm + n + i] : 0.0; wps[j] = ok ? D.w_prev[onm + n + i] : 0.0; sv[j] = ok ? D.s[om + i] : 0.0;
+    rhov[j] = ok ? D.rho[om + i] : 1.0; bv[j] = ok ? D.b[om + i] : 0.0; lss[j] = 0.0;
+    metav[j] = ok ? D.meta[i] : 0u;
+    blv[j] = 0.0; buv[j] = 0.0;
+    if (ok && (metav[j] & 3u) == 3u) { const uint32_t jb = metav[j] >> 2; blv[j] = D.box_l[(long long)k * D.nbox + jb]; buv[j] = D.box_u[(long long)k * D.nbox + jb]; }
+  }
+  const int* cls = D.rho_cls + om;
+  const double cinv = D.cinv[k];
+  long long solves = ctl->solves, kkt_total = ctl->kkt_iters_total;
+  int n_rho = ctl->n_rho_updates;
+  double rho_s = ctl->rho;
+  // the cones of this wave (cone c belongs to wave c % (BS/64)): offsets / dimensions in registers when they fit
+  constexpr int JS = 8;
+  const bool soc_in_regs = D.nsoc <= JS * (BS / 64);
+  int soc_o[JS], soc_d[JS];
+#pragma unroll
+  for (int t = 0; t < JS; ++t) {
+    const int cI = wvid + (BS / 64) * t;
+    const bool ok = soc_in_regs && cI < D.nsoc;
+    soc_o[t] = ok ? D.soc_off[cI] : 0; soc_d[t] = ok ? D.soc_dim[cI] : 0;
+  }
+  double tol_next = D.tol_table[solves < D.tol_len ? solves : D.tol_len - 1];   // requested one solve ahead: its latency is hidden
+  __syncthreads();
+
+  // ---- row products on the LDS image: the owner of row r adds its products left to right -----------------------------
+  // The loops are unrolled by four with all index / value / gather loads issued before the (strictly left-to-right) adds:
+  // a workgroup is alone on its CU with two waves per SIMD, so the dependent LDS round trips col -> x[col] must overlap
+  // inside the thread or they are the whole cost of a Krylov iteration.
+  auto rowA = [&](int r) -> double {                        // (A x)_r with x = xv
+    double s1 = 0.0;
+    int t = Arp[r];
+    const int b2 = Arp[r + 1];
+    for (; t + 4 <= b2; t += 4) {
+      const int c0 = Acol[t], c1 = Acol[t + 1], c2 = Acol[t + 2], c3 = Acol[t + 3];
+      const double v0 = Aval[t], v1 = Aval[t + 1], v2 = Aval[t + 2], v3 = Aval[t + 3];
+      const double x0 = xv[c0], x1 = xv[c1], x2 = xv[c2], x3 = xv[c3];
+      s1 += v0 * x0; s1 += v1 * x1; s1 += v2 * x2; s1 += v3 * x3;
+    }
+    for (; t < b2; ++t) s1 += Aval[t] * xv[Acol[t]];
+    return s1 + 0.0;
+  };
+  auto rowAT = [&](int r) -> double {                       // (A' y)_r with y = tv
+    double s1 = 0.0;
+    int t = Trp[r];
+    const int b2 = Trp[r + 1];
+    for (; t + 4 <= b2; t += 4) {
+      const int p0 = Tpos[t], p1 = Tpos[t + 1], p2 = Tpos[t + 2], p3 = Tpos[t + 3];
+      const int r0 = Trow[t], r1 = Trow[t + 1], r2 = Trow[t + 2], r3 = Trow[t + 3];
+      const double v0 = Aval[p0], v1 = Aval[p1], v2 = Aval[p2], v3 = Aval[p3];
+      const double y0 = tv[r0], y1 = tv[r1], y2 = tv[r2], y3 = tv[r3];
+      s1 += v0 * y0; s1 += v1 * y1; s1 += v2 * y2; s1 += v3 * y3;
+    }
+    for (; t < b2; ++t) s1 += Aval[Tpos[t]] * tv[Trow[t]];
+    return s1;
+  };
+  auto rowP = [&](int r) -> double {                        // (P x)_r with x = xv
+    double s1 = 0.0;
+    const int a = Prp[r], b2 = Prp[r + 1];
+    for (int t = a; t < b2; ++t) s1 += Pval[t] * xv[Pcol[t]];
+    return s1;
+  };
+
+  // ---- admm_x! + admm_w! (solver.jl:32-65) with the CG reduced solve (kktsolver_indirect.jl:36-88) -------------------
+  auto solve_and_update = [&]() {
+#pragma unroll
+    for (int j = 0; j < JN; ++j) lsx[j] = P.sigma * wx[j] - qv[j];
+#pragma unroll
+    for (int j = 0; j < JM; ++j) {
+      const int i = tid + BS * j;
+      const double v = (bv[j] - 2.0 * sv[j]) + wsv[j];
+      lss[j] = v;
+      if (i < m) tv[i] = rhov[j] * v;                                    // y2 = rho .* ls_s
+    }
+#pragma unroll
+    for (int j = 0; j < JN; ++j) { const int i = tid + BS * j; if (i < n) xv[i] = xtl[j]; }
+    __syncthreads();
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < JN; ++j) {
+      const int i = tid + BS * j;
+      if (i < n) { const double v = (rowAT(i) + 0.0) + lsx[j]; rhsv[j] = v; acc += v * v; }
+    }
+    const double bb = bsum<BS>(acc, red);                                  // (its barriers also order tv reads before the writes below)
+    double tmpv[JM];
+#pragma unroll
+    for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; tmpv[j] = (i < m) ? rowA(i) * rhov[j] : 0.0; }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; if (i < m) tv[i] = tmpv[j]; }
+    __syncthreads();
+    acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < JN; ++j) {
+      const int i = tid + BS * j;
+      if (i < n) { const double cj = rowP(i) + (P.sigma * xtl[j] + rowAT(i)); const double rj = rhsv[j] - cj; rv[j] = rj; acc += rj * rj; }
+    }
+    double rr = bsum<BS>(acc, red);
+    const double tol_k = tol_next;
+    tol_next = D.tol_table[solves + 1 < D.tol_len ? solves + 1 : D.tol_len - 1];
+    const double tol = tol_k / sqrt(bb);
+    double res = sqrt(rr), prev = 1.0;
+    int kk = 0;
+    double uv[JN];
+#pragma unroll
+    for (int j = 0; j < JN; ++j) uv[j] = 0.0;
+    while (kk < n && !(res <= tol)) {                                    // cg! (IterativeSolvers v0.9), maxiter = n
+      const double beta = (res * res) / (prev * prev);
+#pragma unroll
+      for (int j = 0; j < JN; ++j) { const int i = tid + BS * j; uv[j] = rv[j] + beta * ((kk == 0) ? 0.0 : uv[j]); if (i < n) xv[i] = uv[j]; }
+      __syncthreads();
+      { BT_BEGIN();
+#pragma unroll
+      for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; tmpv[j] = (i < m) ? rowA(i) * rhov[j] : 0.0; }
+#pragma unroll
+      for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; if (i < m) tv[i] = tmpv[j]; }   // tv was last read before the previous barrier pair
+      __syncthreads();
+      BT_END(0); }
+      acc = 0.0;
+      { BT_BEGIN();
+#pragma unroll
+      for (int j = 0; j < JN; ++j) {
+        const int i = tid + BS * j;
+        if (i < n) { const double vj = uv[j]; const double cj = rowP(i) + (P.sigma * vj + rowAT(i)); cv[j] = cj; acc += vj * cj; }
+      }
+      __syncthreads();
+      BT_END(1); }
+      BT_BEGIN();
+      const double uc = bsum<BS>(acc, red);
+      BT_END(2);
+#ifdef COSMO_BATCH_TIMING
+      if (blockIdx.x == 0 && tid == 0) g_bt[3] += 1;
+#endif
+      const double a = (res * res) / uc;
+      acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < JN; ++j) {
+        const int i = tid + BS * j;
+        if (i < n) { xtl[j] = xtl[j] + a * uv[j]; const double ri = rv[j] - a * cv[j]; rv[j] = ri; acc += ri * ri; }
+      }
+      rr = bsum<BS>(acc, red);
+      prev = res; res = sqrt(rr); ++kk;
+    }
+    // nu = rho (A x_tl - ls_s) ; s_tl ; w update
+#pragma unroll
+    for (int j = 0; j < JN; ++j) { const int i = tid + BS * j; if (i < n) xv[i] = xtl[j]; }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < JM; ++j) {
+      const int i = tid + BS * j;
+      if (i < m) {
+        const double rh = rhov[j]; const double nv = (rowA(i) - lss[j]) * rh;
+        const double st = (2.0 * sv[j] - wsv[j]) - nv / rh;
+        wsv[j] = wsv[j] + P.alpha * (st - sv[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < JN; ++j) wx[j] = wx[j] + P.alpha * (xtl[j] - wx[j]);
+    solves += 1; kkt_total += kk;
+    __syncthreads();
+  };
+
+  // ---- residuals (residuals.jl:30-96,143-147); x = w_prev[1:n], mu recovered on the fly ------------------------------
+  double rp, mp, rd, md, cost;
+  double muv[JM];
+#pragma unroll
+  for (int j = 0; j < JM; ++j) muv[j] = 0.0;
+  auto residuals = [&](bool unscale) {
+#pragma unroll
+    for (int j = 0; j < JN; ++j) { const int i = tid + BS * j; if (i < n) xv[i] = wpx[j]; }
+    __syncthreads();
+    double a_rp = 0.0, a_mp = 0.0;
+#pragma unroll
+    for (int j = 0; j < JM; ++j) {
+      const int i = tid + BS * j;
+      if (i < m) {
+        const double ax = rowA(i), s0 = sv[j], b0 = bv[j];
+        muv[j] = rhov[j] * (wps[j] - s0);
+        tv[i] = muv[j];
+        double r0 = ax + s0; r0 = r0 - b0;
+        const double e = unscale ? D.Einv[om + i] : 1.0;
+        if (unscale) r0 = r0 * e;
+        a_rp = amax(a_rp, r0);
+        a_mp = amax(a_mp, unscale ? ax * e : ax); a_mp = amax(a_mp, unscale ? s0 * e : s0); a_mp = amax(a_mp, unscale ? b0 * e : b0);
+      }
+    }
+    rp = bmax<BS>(a_rp, red); mp = bmax<BS>(a_mp, red);
+    __syncthreads();
+    double a_rd = 0.0, a_md = 0.0, xpx = 0.0, qx = 0.0;
+#pragma unroll
+    for (int j = 0; j < JN; ++j) {
+      const int i = tid + BS * j;
+      if (i < n) {
+        const double px = rowP(i), atm = rowAT(i), x0 = wpx[j], q0 = qv[j];
+        double r0 = px + q0; r0 = r0 - atm;
+        double a = px, bq = q0, cm = atm;
+        if (unscale) { const double d = D.Dinv[on + i]; r0 = (r0 * d) * cinv; a = (a * d) * cinv; bq = (bq * d) * cinv; cm = (cm * d) * cinv; }
+        a_rd = amax(a_rd, r0); a_md = amax(a_md, a); a_md = amax(a_md, bq); a_md = amax(a_md, cm);
+        xpx += px * x0; qx += q0 * x0;
+      }
+    }
+    rd = bmax<BS>(a_rd, red); md = bmax<BS>(a_md, red);
+    xpx = bsum<BS>(xpx, red); qx = bsum<BS>(qx, red);
+    cost = (unscale ? cinv : 1.0) * (0.5 * xpx + qx);
+    __syncthreads();
+  };
+
+#ifdef COSMO_BATCH_TIMING
+  const long long kt0 = clock64();
+#endif
+  if (do_init) solve_and_update();                                        // solver.jl:137-138
+  long long it = ctl->iter;
+  int status = 0;
+  double o_cost = ctl->cost, o_rp = ctl->r_prim, o_rd = ctl->r_dual, o_mp = ctl->max_norm_prim, o_md = ctl->max_norm_dual;
+  while (it < iter_target && it < P.max_iter) {
+    ++it;
+    // ---- admm_z!: w_prev = w ; s = Pi(w_s)  (solver.jl:151-152) ----
+#pragma unroll
+    for (int j = 0; j < JN; ++j) wpx[j] = wx[j];
+#pragma unroll
+    for (int j = 0; j < JM; ++j) {
+      const int i = tid + BS * j;
+      const double v = wsv[j]; wps[j] = v;
+      const uint32_t kind = metav[j] & 3u;
+      double pv = v;
+      if (kind == 1u) pv = 0.0;
+      else if (kind == 2u) pv = (v != v) ? v : ((v > 0.0) ? v : 0.0);
+      else if (kind == 3u) pv = (v < blv[j]) ? blv[j] : ((v > buv[j]) ? buv[j] : v);
+      sv[j] = pv;
+      if (D.nsoc > 0 && i < m) tv[i] = pv;
+    }
+    if (D.nsoc > 0) {
+      __syncthreads();
+      auto soc_one = [&](double* x, int d) {                              // SecondOrderCone (convexset.jl:100-114), on the LDS copy
+        if (d == 0) return;
+        const double t = x[0];
+        double a = 0.0;
+        for (int i = 1 + lane; i < d; i += 64) { const double v = x[i]; a += v * v; }
+        const double nx = sqrt(wave_sum(a));
+        if (nx <= t) {
+        } else if (nx <= -t) { for (int i = lane; i < d; i += 64) x[i] = 0.0; }
+        else { const double f = (nx + t) / (2.0 * nx); for (int i = 1 + lane; i < d; i += 64) x[i] = f * x[i]; if (lane == 0) x[0] = (nx + t) / 2.0; }
+      };
+      if (soc_in_regs) {
+#pragma unroll
+        for (int t = 0; t < JS; ++t) soc_one(tv + soc_o[t], soc_d[t]);
+      } else {
+        for (int cI = wvid; cI < D.nsoc; cI += BS / 64) soc_one(tv + D.soc_off[cI], D.soc_dim[cI]);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; if (i < m) sv[j] = tv[i]; }
+      __syncthreads();
+    }
+    // ---- apply_rho_adaptation_rules! (solver.jl:242-282, parameters.jl:53-92) ----
+    if (P.adaptive_rho && P.adaptive_rho_interval > 0 && (it % P.adaptive_rho_interval) == 0 && (long long)(n_rho - 1) < P.max_adaptions) {
+      residuals(false);
+      const double rpn = rp / (mp + 1e-10), rdn = rd / (md + 1e-10);
+      double nr = rho_s * sqrt(rpn / (rdn + 1e-10));
+      nr = fmin(fmax(nr, P.rho_min), P.rho_max);
+      const bool adapt = (nr > P.adapt_tol * rho_s) || (nr < (1.0 / P.adapt_tol) * rho_s);
+      if (adapt) {
+#pragma unroll
+        for (int j = 0; j < JM; ++j) {
+          const int i = tid + BS * j;
+          if (i < m) {
+            const int cc = cls[i]; double r2 = nr;
+            if (cc == 1) r2 = r2 * P.rho_eq; else if (cc == 2) r2 = P.rho_min;
+            rhov[j] = r2;
+            wsv[j] = (1.0 / r2) * muv[j] + sv[j];
+          }
+        }
+        if (tid == 0 && n_rho < COSMO_HIP_MAX_RHO_UPDATES) ctl->rho_updates[n_rho] = nr;
+        rho_s = nr; n_rho += 1;
+      }
+    }
+    solve_and_update();
+    // ---- check_termination! (solver.jl:306-321) ----
+    if ((it % P.check_termination) == 0 || it == 1) {
+      residuals(P.unscale != 0);
+      int st = 0;
+      if (fabs(cost) > 1e20) st = COSMO_HIP_UNSOLVED;
+      else if (rp < P.eps_abs + P.eps_rel * mp && rd < P.eps_abs + P.eps_rel * md) st = COSMO_HIP_SOLVED;
+      o_cost = cost; o_rp = rp; o_rd = rd; o_mp = mp; o_md = md; status = st;
+      if (st != 0) break;
+    }
+  }
+  // iter == max_iter: calculate_result_info! and Max_iter_reached, overriding a status decided in that iteration
+  // (solver.jl:173-176, reference quirk kept)
+  if (it >= P.max_iter) {
+    residuals(P.unscale != 0);
+    o_rp = rp; o_rd = rd; o_mp = mp; o_md = md; status = COSMO_HIP_MAX_ITER_REACHED;
+  }
+#ifdef COSMO_BATCH_TIMING
+  if (blockIdx.x == 0 && tid == 0) { g_bt[4] += clock64() - kt0; g_bt[5] += it; }
+#endif
+  // ---- store the persistent state; recover_mu! (solver.jl:167) ----
+#pragma unroll
+  for (int j = 0; j < JN; ++j) {
+    const int i = tid + BS * j;
+    if (i < n) { D.w[onm + i] = wx[j]; D.w_prev[onm + i] = wpx[j]; D.x_tl[on + i] = xtl[j]; }
+  }
+#pragma unroll
+  for (int j = 0; j < JM; ++j) {
+    const int i = tid + BS * j;
+    if (i < m) {
+      D.w[onm + n + i] = wsv[j]; D.w_prev[onm + n + i] = wps[j]; D.s[om + i] = sv[j]; D.rho[om + i] = rhov[j];
+      D.mu[om + i] = rhov[j] * (wps[j] - sv[j]);
+    }
+  }
+  if (tid == 0) {
+    ctl->iter = it; ctl->solves = solves; ctl->kkt_iters_total = kkt_total; ctl->n_rho_updates = n_rho; ctl->rho = rho_s;
+    ctl->cost = o_cost; ctl->r_prim = o_rp; ctl->r_dual = o_rd; ctl->max_norm_prim = o_mp; ctl->max_norm_dual = o_md; ctl->status = status;
+  }
+}
+
 // warm start (solver.jl:128-129) for all problems
 __global__ __launch_bounds__(COSMO_BS) void k_batch_set_w(BatchDev D, const double* __restrict__ x0, const double* __restrict__ s0,
                                                           const double* __restrict__ mu0) {
@@ -468,6 +849,7 @@ struct cosmo_hip_batch {
   long long iters_done = 0;
   // LDS-resident variant (build_lds_images): one image per problem, dynamic LDS = image + gather vectors + reduction slots
   unsigned char* d_img = nullptr; long long img_stride = 0; int lds_bytes = 0; int lds_bs = 0;
+  int reg_mode = 0;    // 0: LdsOps kernel, 1: register-resident <512,1,2>, 2: <512,2,4>
 };
 
 static int32_t bfail(cosmo_hip_batch* b, int32_t code, const char* fmt, ...) {
@@ -650,15 +1032,24 @@ static void brow_blocks(const std::vector<int>& rowptr, int nrows, std::vector<i
 
 // Builds the per-problem LDS images of k_batch_admm_lds if every problem fits (u16 indices, image + work vectors within the
 // CU's LDS); otherwise leaves b->d_img = nullptr and the streaming kernel is used.  COSMO_HIP_BATCH_LDS=0 disables it,
-// COSMO_HIP_BATCH_BS selects the workgroup size (256, 512 or 1024; default 1024).
+// COSMO_HIP_BATCH_REG=0 keeps the iterates in global memory (LdsOps kernel), COSMO_HIP_BATCH_BS selects that kernel's
+// workgroup size (256, 512 or 1024; default 512).
 static int32_t build_lds_images(cosmo_hip_batch* b) {
   b->d_img = nullptr; b->lds_bs = 0;
   const char* e = getenv("COSMO_HIP_BATCH_LDS");
   if (e && atoi(e) == 0) return COSMO_HIP_OK;
   const long long n = b->n, m = b->m;
   if (n > 65535 || m > 65535 || n + m == 0) return COSMO_HIP_OK;
-  int bs = 1024;
+  int bs = 512;
   if (const char* eb = getenv("COSMO_HIP_BATCH_BS")) { const int v = atoi(eb); if (v == 256 || v == 512 || v == 1024) bs = v; }
+  // register-resident iterates (k_batch_admm_reg, 512 threads) when the vectors fit 1-2 (n) / 2-4 (m) elements per thread
+  b->reg_mode = 0;
+  { const char* er = getenv("COSMO_HIP_BATCH_REG");
+    if (!(er && atoi(er) == 0)) {
+      if (n <= 512 && m <= 1024) b->reg_mode = 1; else if (n <= 1024 && m <= 2048) b->reg_mode = 2;
+      if (b->reg_mode) bs = 512;
+      if (getenv("COSMO_HIP_BATCH_REG1024") && n <= 1024 && m <= 1024) { b->reg_mode = 3; bs = 1024; }   // lab: 16 waves, one row per thread
+    } }
   int max_lds = 0;
   if (hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, b->device) != hipSuccess) return COSMO_HIP_OK;
   auto up16 = [](long long x) { return (x + 15) / 16 * 16; };
@@ -731,12 +1122,21 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
   b->d_img = d; b->img_stride = stride; b->lds_bs = bs;
   b->lds_bytes = (int)(stride + 8 * (n + m) + 8 * (bs / 64));
   const void* fn = bs == 256 ? (const void*)k_batch_admm_lds<256> : (bs == 512 ? (const void*)k_batch_admm_lds<512> : (const void*)k_batch_admm_lds<1024>);
+  if (b->reg_mode == 1) fn = (const void*)k_batch_admm_reg<512, 1, 2>;
+  if (b->reg_mode == 2) fn = (const void*)k_batch_admm_reg<512, 2, 4>;
+  if (b->reg_mode == 3) fn = (const void*)k_batch_admm_reg<1024, 1, 1>;
   BHIP(b, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, b->lds_bytes));
   return COSMO_HIP_OK;
 }
 
 static int32_t launch_batch_admm(cosmo_hip_batch* b, const BParams& P, long long target, int do_init) {
-  if (b->d_img) {
+  if (b->d_img && b->reg_mode == 1) {
+    hipLaunchKernelGGL((k_batch_admm_reg<512, 1, 2>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
+  } else if (b->d_img && b->reg_mode == 3) {
+    hipLaunchKernelGGL((k_batch_admm_reg<1024, 1, 1>), dim3(b->nprob), dim3(1024), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
+  } else if (b->d_img && b->reg_mode == 2) {
+    hipLaunchKernelGGL((k_batch_admm_reg<512, 2, 4>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
+  } else if (b->d_img) {
     if (b->lds_bs == 256) hipLaunchKernelGGL((k_batch_admm_lds<256>), dim3(b->nprob), dim3(256), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
     else if (b->lds_bs == 512) hipLaunchKernelGGL((k_batch_admm_lds<512>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
     else hipLaunchKernelGGL((k_batch_admm_lds<1024>), dim3(b->nprob), dim3(1024), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
