@@ -523,34 +523,19 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   __syncthreads();
 
   // ---- row products on the LDS image: the owner of row r adds its products left to right -----------------------------
-  // The loops are unrolled by four with all index / value / gather loads issued before the (strictly left-to-right) adds:
-  // a workgroup is alone on its CU with two waves per SIMD, so the dependent LDS round trips col -> x[col] must overlap
-  // inside the thread or they are the whole cost of a Krylov iteration.
+  // (measured on config 3: a sparse pass costs ~25 cycles per wave step of three LDS reads, set by LDS issue rate and by the
+  //  spread of row lengths inside a wave, not by latency -- manual unrolling, 16 waves instead of 8 and a sliced-JDS layout
+  //  with conflict-free value / index reads were all tried and were the same speed or slower)
   auto rowA = [&](int r) -> double {                        // (A x)_r with x = xv
     double s1 = 0.0;
-    int t = Arp[r];
-    const int b2 = Arp[r + 1];
-    for (; t + 4 <= b2; t += 4) {
-      const int c0 = Acol[t], c1 = Acol[t + 1], c2 = Acol[t + 2], c3 = Acol[t + 3];
-      const double v0 = Aval[t], v1 = Aval[t + 1], v2 = Aval[t + 2], v3 = Aval[t + 3];
-      const double x0 = xv[c0], x1 = xv[c1], x2 = xv[c2], x3 = xv[c3];
-      s1 += v0 * x0; s1 += v1 * x1; s1 += v2 * x2; s1 += v3 * x3;
-    }
-    for (; t < b2; ++t) s1 += Aval[t] * xv[Acol[t]];
+    const int a = Arp[r], b2 = Arp[r + 1];
+    for (int t = a; t < b2; ++t) s1 += Aval[t] * xv[Acol[t]];
     return s1 + 0.0;
   };
   auto rowAT = [&](int r) -> double {                       // (A' y)_r with y = tv
     double s1 = 0.0;
-    int t = Trp[r];
-    const int b2 = Trp[r + 1];
-    for (; t + 4 <= b2; t += 4) {
-      const int p0 = Tpos[t], p1 = Tpos[t + 1], p2 = Tpos[t + 2], p3 = Tpos[t + 3];
-      const int r0 = Trow[t], r1 = Trow[t + 1], r2 = Trow[t + 2], r3 = Trow[t + 3];
-      const double v0 = Aval[p0], v1 = Aval[p1], v2 = Aval[p2], v3 = Aval[p3];
-      const double y0 = tv[r0], y1 = tv[r1], y2 = tv[r2], y3 = tv[r3];
-      s1 += v0 * y0; s1 += v1 * y1; s1 += v2 * y2; s1 += v3 * y3;
-    }
-    for (; t < b2; ++t) s1 += Aval[Tpos[t]] * tv[Trow[t]];
+    const int a = Trp[r], b2 = Trp[r + 1];
+    for (int t = a; t < b2; ++t) s1 += Aval[Tpos[t]] * tv[Trow[t]];
     return s1;
   };
   auto rowP = [&](int r) -> double {                        // (P x)_r with x = xv
@@ -1048,7 +1033,6 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
     if (!(er && atoi(er) == 0)) {
       if (n <= 512 && m <= 1024) b->reg_mode = 1; else if (n <= 1024 && m <= 2048) b->reg_mode = 2;
       if (b->reg_mode) bs = 512;
-      if (getenv("COSMO_HIP_BATCH_REG1024") && n <= 1024 && m <= 1024) { b->reg_mode = 3; bs = 1024; }   // lab: 16 waves, one row per thread
     } }
   int max_lds = 0;
   if (hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, b->device) != hipSuccess) return COSMO_HIP_OK;
@@ -1124,7 +1108,6 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
   const void* fn = bs == 256 ? (const void*)k_batch_admm_lds<256> : (bs == 512 ? (const void*)k_batch_admm_lds<512> : (const void*)k_batch_admm_lds<1024>);
   if (b->reg_mode == 1) fn = (const void*)k_batch_admm_reg<512, 1, 2>;
   if (b->reg_mode == 2) fn = (const void*)k_batch_admm_reg<512, 2, 4>;
-  if (b->reg_mode == 3) fn = (const void*)k_batch_admm_reg<1024, 1, 1>;
   BHIP(b, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, b->lds_bytes));
   return COSMO_HIP_OK;
 }
@@ -1132,8 +1115,6 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
 static int32_t launch_batch_admm(cosmo_hip_batch* b, const BParams& P, long long target, int do_init) {
   if (b->d_img && b->reg_mode == 1) {
     hipLaunchKernelGGL((k_batch_admm_reg<512, 1, 2>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
-  } else if (b->d_img && b->reg_mode == 3) {
-    hipLaunchKernelGGL((k_batch_admm_reg<1024, 1, 1>), dim3(b->nprob), dim3(1024), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
   } else if (b->d_img && b->reg_mode == 2) {
     hipLaunchKernelGGL((k_batch_admm_reg<512, 2, 4>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
   } else if (b->d_img) {
