@@ -95,3 +95,50 @@ def test_cfg3_full_size_batch():
         assert np.max(np.abs(p["A"] @ r.x + r.s - p["b"])) <= 1e-3
     print("cfg3 batch: iter_time %.3f s for %d problems, iterations min/median/max = %d/%d/%d" % (
         res[0].times.iter_time, len(res), min(r.iter for r in res), int(np.median([r.iter for r in res])), max(r.iter for r in res)))
+
+
+def _with_env(env, fn):
+    import os
+    keys = ("COSMO_HIP_BATCH_LDS", "COSMO_HIP_BATCH_BS", "COSMO_HIP_BATCH_REG")
+    saved = {k: os.environ.pop(k, None) for k in keys}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k in keys:
+            os.environ.pop(k, None)
+            if saved[k] is not None:
+                os.environ[k] = saved[k]
+
+
+def test_batch_kernel_variants_agree():
+    """The three batch kernels (streaming / LDS image / register-resident iterates) on the same batch: the LDS-image kernel at
+    256 threads repeats the streaming kernel bit for bit (same tile order, same row sums, same reduction tree); the
+    register-resident kernel only differs in the block-reduction tree (tight-CG trajectories agree to 1e-9)."""
+    probs = [cj.problems.socp(seed=2000 + k) for k in range(6)]           # config-3 sized: n = 500, m = 1000, 50 cones
+    tight = cj.with_options(cj.CGIndirectKKTSolver, tol_constant=1e-10, tol_exponent=0.0)
+    st = cj.Settings(kkt_solver=tight, max_iter=60, eps_abs=0.0, eps_rel=0.0)
+    run = lambda: cj.optimize_batch(_models(probs, st))
+    ref = _with_env({"COSMO_HIP_BATCH_LDS": "0"}, run)
+    lds = _with_env({"COSMO_HIP_BATCH_REG": "0", "COSMO_HIP_BATCH_BS": "256"}, run)
+    reg = _with_env({}, run)
+    for a, b, c in zip(ref, lds, reg):
+        assert np.array_equal(a.x, b.x) and np.array_equal(a.s, b.s) and np.array_equal(a.y, b.y)
+        assert a.kkt_iters_total == b.kkt_iters_total and a.info.rho_updates == b.info.rho_updates
+        sc = max(1.0, float(np.max(np.abs(a.x))))
+        assert np.max(np.abs(a.x - c.x)) <= 1e-9 * sc
+        assert np.max(np.abs(a.s - c.s)) <= 1e-9 * max(1.0, float(np.max(np.abs(a.s))))
+        assert np.max(np.abs(a.y - c.y)) <= 1e-8 * max(1.0, float(np.max(np.abs(a.y))))
+        assert len(a.info.rho_updates) == len(c.info.rho_updates)
+        assert a.iter == c.iter == 60 and a.status == c.status
+
+
+def test_batch_register_kernel_default_schedule_matches_oracle():
+    # default (inexact) CG schedule on config-3 sized problems through the register-resident kernel, against the oracle
+    probs = [cj.problems.socp(seed=3000 + k) for k in range(3)]
+    res = cj.optimize_batch(_models(probs, cj.Settings()))
+    for p, r in zip(probs, res):
+        ref = O.solve(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), O.Settings(kkt_solver="cg"))
+        assert r.status == ref.status == "Solved"
+        assert abs(r.iter - ref.iter) <= 25
+        assert abs(r.obj_val - ref.obj_val) <= 1e-4 * (1 + abs(ref.obj_val))
