@@ -11,7 +11,7 @@
 #include <vector>
 
 int32_t sync_ctl(cosmo_hip_handle* h);
-int32_t psd_extreme_eigs(cosmo_hip_handle* h, const double* vec, double sign, std::vector<double>& lam_min);   // psd.hip
+int32_t psd_extreme_eigs(cosmo_hip_handle* h, const double* vec, double sign, double tol, std::vector<double>& lam_min);   // psd.hip
 
 // delta_y capture at the top of the iteration: dy = rho .* (w_prev_s - s)            (solver.jl:145-148)
 __global__ __launch_bounds__(COSMO_BS) void k_inf_capture(const Ctl* __restrict__ ctl, long long n, long long m,
@@ -219,7 +219,7 @@ int32_t infeas_check(cosmo_hip_handle* h, int32_t* status) {
     if (in_dual_all && has_psd) {
       // in_dual!(-dyn): is_pos_def(X + tol I)  <=>  lambda_min(X) > -tol with X = mat(-dyn)   (convexset.jl:415-418, algebra.jl:226-233)
       std::vector<double> lmin;
-      CHK(psd_extreme_eigs(h, h->inf_dy, -1.0, lmin));
+      CHK(psd_extreme_eigs(h, h->inf_dy, -1.0, p.eps_prim_inf, lmin));
       for (double l : lmin) if (!(l > -p.eps_prim_inf)) in_dual_all = false;
     }
     CHK(custom_test(h, h->inf_dy, 0, p.eps_prim_inf, &in_dual_all));               // user cones: in_dual(-dyn) through the callback
@@ -247,7 +247,7 @@ int32_t infeas_check(cosmo_hip_handle* h, int32_t* status) {
     if (in_recc && has_psd) {
       // in_pol_recc!: is_neg_def(X, tol)  <=>  lambda_min(-X) > -tol                            (convexset.jl:421-424, algebra.jl:235-238)
       std::vector<double> lmin;
-      CHK(psd_extreme_eigs(h, h->inf_adx, -1.0, lmin));
+      CHK(psd_extreme_eigs(h, h->inf_adx, -1.0, p.eps_dual_inf, lmin));
       for (double l : lmin) if (!(l > -p.eps_dual_inf)) in_recc = false;
     }
     CHK(custom_test(h, h->inf_adx, 1, p.eps_dual_inf, &in_recc));

@@ -784,7 +784,9 @@ extern "C" int32_t cosmo_hip_psd_stats(cosmo_hip_handle* h, int64_t out[4]) {
 
 // Smallest eigenvalue of sign * mat(vec slice) for every planned PSD cone (same row layout as s).  Used by the
 // infeasibility certificates: is_pos_def!(X, tol) <=> lambda_min(X) > -tol (src/algebra.jl:226-238).  Synchronous.
-int32_t psd_extreme_eigs(cosmo_hip_handle* h, const double* vec, double sign, std::vector<double>& lam_min) {
+int32_t polar_complex_is_pd(cosmo_hip_handle* h, const double* vec, double sign, double tol, std::vector<int>& ok);   // psd_polar.hip
+
+int32_t psd_extreme_eigs(cosmo_hip_handle* h, const double* vec, double sign, double tol, std::vector<double>& lam_min) {
   PsdPlan* p = h->psd;
   lam_min.clear();
   if (!p || p->cones.empty()) return COSMO_HIP_OK;
@@ -816,6 +818,12 @@ int32_t psd_extreme_eigs(cosmo_hip_handle* h, const double* vec, double sign, st
   lam_min.resize(p->cones.size());
   HIPCHK(h, hipMemcpyAsync(lam_min.data(), p->eigmin, sizeof(double) * lam_min.size(), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  for (int idx : p->cplx) lam_min[idx] = -INFINITY;   // Hermitian cones: no definiteness test on the device => never certify (conservative)
+  // Hermitian cones: the reference's own test -- does the Cholesky factorisation of sign * H + tol I succeed? -- on the real embedding
+  // (psd_polar.hip); reported as lambda_min = 0 (passes the caller's "> -tol") or -inf.  Sides 2r > 1024 never certify.
+  if (!p->cplx.empty()) {
+    std::vector<int> ok;
+    CHK(polar_complex_is_pd(h, vec, sign, tol, ok));
+    for (size_t q = 0; q < p->cplx.size(); ++q) lam_min[p->cplx[q]] = ok[q] ? 0.0 : -INFINITY;
+  }
   return COSMO_HIP_OK;
 }

@@ -577,3 +577,71 @@ int32_t polar_enqueue_project(cosmo_hip_handle* h, double* s, int guard) {
   HIPCHK(h, hipGetLastError());
   return COSMO_HIP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Definiteness test of the Hermitian cones for the infeasibility certificates: is_pos_def!(X, tol) of the reference adds tol to
+// the diagonal and asks whether cholesky!(Hermitian(X)) succeeds (src/algebra.jl:226-233; in_dual! / in_pol_recc!,
+// src/convexset.jl:415-424).  Here the same question is put to the real symmetric embedding M = [[A, -B], [B, A]] of
+// sign * H (+ tol I), which is positive definite exactly when H is: one workgroup factorises M column by column (left-looking
+// Cholesky in a global scratch matrix, the current row of L cached in LDS) and reports whether every pivot was > 0.
+// The certificates are evaluated every check_infeasibility iterations and only after the cheap norm conditions passed, so the
+// O(d^3 / 3) of one workgroup is off the hot path.  Side 2r <= COSMO_CPLX_CHOL_MAX; larger Hermitian cones never certify.
+// ---------------------------------------------------------------------------------------------------------------------
+#define COSMO_CPLX_CHOL_MAX 1024
+__global__ __launch_bounds__(COSMO_BS) void k_cplx_chol_pd(int off, int d, const double* __restrict__ vec, double sign, double tol,
+                                                           double* __restrict__ G, int* __restrict__ ok_out) {
+  __shared__ double rowj[COSMO_CPLX_CHOL_MAX];
+  __shared__ double piv;
+  __shared__ int fail;
+  const double* x = vec + off;
+  for (long long e = threadIdx.x; e < (long long)d * d; e += COSMO_BS) {
+    const int i = (int)(e % d), j = (int)(e / d);
+    double v = sign * polar_read(x, COSMO_HIP_PSD_TRIANGLE_COMPLEX, d, i, j);
+    if (i == j) v += tol;
+    G[e] = v;                                                     // column major: G[j * d + i]
+  }
+  if (threadIdx.x == 0) fail = 0;
+  __syncthreads();
+  for (int j = 0; j < d; ++j) {
+    for (int k = threadIdx.x; k < j; k += COSMO_BS) rowj[k] = G[(long long)k * d + j];          // L[j, 0..j-1]
+    __syncthreads();
+    for (int i = j + threadIdx.x; i < d; i += COSMO_BS) {
+      double v = G[(long long)j * d + i];
+      for (int k = 0; k < j; ++k) v -= G[(long long)k * d + i] * rowj[k];
+      G[(long long)j * d + i] = v;
+      if (i == j) { piv = v; if (!(v > 0.0)) fail = 1; }
+    }
+    __syncthreads();
+    if (fail) break;
+    const double ljj = sqrt(piv);
+    for (int i = j + threadIdx.x; i < d; i += COSMO_BS) G[(long long)j * d + i] = (i == j) ? ljj : G[(long long)j * d + i] / ljj;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *ok_out = fail ? 0 : 1;
+}
+
+// ok[q] for the q-th entry of p->cplx: 1 = sign * H + tol I is positive definite, 0 = not (or too large to test)
+int32_t polar_complex_is_pd(cosmo_hip_handle* h, const double* vec, double sign, double tol, std::vector<int>& ok) {
+  PsdPlan* p = h->psd;
+  ok.clear();
+  if (!p || p->cplx.empty()) return COSMO_HIP_OK;
+  ok.assign(p->cplx.size(), 0);
+  int dmax = 0;
+  for (int idx : p->cplx) if (p->cones[idx].d <= COSMO_CPLX_CHOL_MAX) dmax = std::max(dmax, p->cones[idx].d);
+  if (dmax == 0) return COSMO_HIP_OK;
+  double* G = nullptr; int* d_ok = nullptr;
+  HIPCHK(h, hipMalloc((void**)&G, sizeof(double) * (size_t)dmax * dmax));
+  if (hipMalloc((void**)&d_ok, sizeof(int)) != hipSuccess) { (void)hipFree(G); return cosmo_fail(h, COSMO_HIP_ERR_HIP, "hipMalloc failed"); }
+  int32_t rc = COSMO_HIP_OK;
+  for (size_t q = 0; q < p->cplx.size() && rc == COSMO_HIP_OK; ++q) {
+    const PsdConeDev& cn = p->cones[p->cplx[q]];
+    if (cn.d > COSMO_CPLX_CHOL_MAX) continue;
+    hipLaunchKernelGGL(k_cplx_chol_pd, dim3(1), dim3(COSMO_BS), 0, h->stream, cn.off, cn.d, vec, sign, tol, G, d_ok);
+    int v = 0;
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&v, d_ok, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) rc = cosmo_fail(h, COSMO_HIP_ERR_HIP, "complex definiteness test failed");
+    ok[q] = v;
+  }
+  (void)hipFree(G); (void)hipFree(d_ok);
+  return rc;
+}

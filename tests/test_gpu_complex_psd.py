@@ -93,3 +93,34 @@ def test_least_eigenvalue_golden_on_device():
     A, b, cones = O.assemble(cs)
     ref = O.solve(np.zeros((n, n)), vec_c, A, b, cones, O.Settings(kkt_solver="cg", eps_abs=1e-5, eps_rel=1e-5))
     assert ref.status == "Solved" and abs(res.iter - ref.iter) <= 25 and abs(res.obj_val - ref.obj_val) < 1e-5
+
+
+def _vec_h(H):
+    x = np.zeros(H.shape[0] ** 2); O.extract_upper_triangle_complex(H, x); return x
+
+
+def _complex_infeasible_instances(r=3, seed=0):
+    rng = np.random.default_rng(seed)
+    G = rng.normal(size=(r, r)) + 1j * rng.normal(size=(r, r)); H1 = G @ G.conj().T        # Hermitian positive definite
+    # primal infeasible: x >= 0 and  -I - x H1  Hermitian PSD  (internal form A x + s = b)
+    A1 = sp.csc_matrix(np.concatenate([[-1.0], _vec_h(H1)]).reshape(-1, 1)); b1 = np.concatenate([[0.0], _vec_h(-np.eye(r))])
+    # dual infeasible: min -x  s.t.  x H1 Hermitian PSD  (unbounded)
+    A2 = sp.csc_matrix((-_vec_h(H1)).reshape(-1, 1)); b2 = np.zeros(r * r)
+    return [("Primal_infeasible", np.array([1.0]), A1, b1, [("nonneg", 1), ("cplx", r * r)]),
+            ("Dual_infeasible", np.array([-1.0]), A2, b2, [("cplx", r * r)])]
+
+
+@pytest.mark.parametrize("r", [3, 6])
+def test_complex_cone_infeasibility_certificates_match_oracle(r):
+    """in_dual! / in_pol_recc! of the Hermitian cone = does cholesky!(Hermitian(X) + tol I) succeed (src/convexset.jl:415-424,
+    src/algebra.jl:226-233); the device asks the same of the real embedding (one-workgroup Cholesky, csrc/psd_polar.hip)."""
+    for want, q, A, b, kinds in _complex_infeasible_instances(r, seed=r):
+        ocones = [O.Nonnegatives(d) if k == "nonneg" else O.ComplexPsdConeTriangle(d) for k, d in kinds]
+        ref = O.solve(sp.csc_matrix((1, 1)), q, A, b, ocones, O.Settings(kkt_solver="cg", tol_constant=1e-10, tol_exponent=0.0))
+        assert ref.status == want
+        sets = [cj.Nonnegatives(d) if k == "nonneg" else cj.ComplexPsdConeTriangle(d) for k, d in kinds]
+        md = cj.Model()
+        md.set(sp.csc_matrix((1, 1)), q, A, b, sets, cj.Settings(kkt_solver=cj.with_options(cj.CGIndirectKKTSolver, tol_constant=1e-10, tol_exponent=0.0)))
+        res = cj.optimize(md)
+        assert res.status == want
+        assert abs(res.iter - ref.iter) <= 40

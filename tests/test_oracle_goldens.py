@@ -509,3 +509,19 @@ def test_infeasible_family_statuses(family, seed):
     assert res.status in accepted, (family, seed, res.status, res.iter)
     if family != "primal_infeasible_3":
         assert res.iter < 1000
+
+
+def test_complex_psd_infeasibility_certificates():
+    # Hermitian cone certificates (src/convexset.jl:415-424): a primal and a dual infeasible complex SDP by construction
+    r = 3
+    rng = np.random.default_rng(0)
+    G = rng.normal(size=(r, r)) + 1j * rng.normal(size=(r, r)); H1 = G @ G.conj().T
+
+    def vec(H):
+        x = np.zeros(r * r); O.extract_upper_triangle_complex(H, x); return x
+    A = sp.csc_matrix(np.concatenate([[-1.0], vec(H1)]).reshape(-1, 1)); b = np.concatenate([[0.0], vec(-np.eye(r))])
+    res = O.solve(sp.csc_matrix((1, 1)), np.array([1.0]), A, b, [O.Nonnegatives(1), O.ComplexPsdConeTriangle(r * r)])
+    assert res.status == "Primal_infeasible"
+    A = sp.csc_matrix((-vec(H1)).reshape(-1, 1))
+    res = O.solve(sp.csc_matrix((1, 1)), np.array([-1.0]), A, np.zeros(r * r), [O.ComplexPsdConeTriangle(r * r)])
+    assert res.status == "Dual_infeasible"
