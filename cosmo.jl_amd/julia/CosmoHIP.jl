@@ -311,4 +311,85 @@ function optimize_hip!(ws::COSMO.Workspace{Float64}; device::Integer = 0, kkt_ki
     return COSMO.Result{Float64}(ws.vars.x, y, ws.vars.s.data, r.cost, Int(r.iter), 0, status, res_info, ws.times)
 end
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Batches of independent problems with identical dimensions and cone structure (BASELINE config 3): what a user loop
+# `for ws in models; COSMO.optimize!(ws); end` computes, solved concurrently -- one persistent workgroup per problem
+# (cosmo_hip_batch_*).  Supported cones: ZeroSet, Nonnegatives, Box, SecondOrderCone; CG KKT solver; EmptyAccelerator.
+# Per problem the unchanged reference code does the scaling / classification (setup!, src/setup.jl:18-42) and the epilogue
+# (src/solver.jl:167-201); the loop of src/solver.jl:137-176 runs on the device for all problems at once.
+# ---------------------------------------------------------------------------------------------------------------------
+function optimize_hip_batch!(models::Vector{COSMO.Workspace{Float64}}; device::Integer = 0, tol_constant = 1.0, tol_exponent = 1.5)
+    isempty(models) && return COSMO.Result{Float64}[]
+    ws1 = models[1]
+    m, n = ws1.p.model_size
+    settings = ws1.settings
+    t_start = time()
+    for ws in models
+        (ws.p.model_size == (m, n)) || error("optimize_hip_batch!: all problems must have the same dimensions")
+        !(ws.accelerator isa COSMO.EmptyAccelerator) && error("optimize_hip_batch!: use accelerator = EmptyAccelerator")
+        if !ws.states.IS_SCALED
+            ws.sm = (settings.scaling > 0) ? COSMO.ScaleMatrices{Float64}(m, n) : COSMO.ScaleMatrices{Float64}()
+        end
+        COSMO.allocate_set_memory!(ws)
+        if settings.scaling != 0 && !ws.states.IS_SCALED
+            COSMO.scale_ruiz!(ws); ws.states.IS_SCALED = true
+        else
+            COSMO.scale_variables!(ws.vars.x, ws.vars.μ, ws.vars.s, ws.sm.Dinv, ws.sm.Einv, ws.sm.E, ws.sm.c)
+        end
+        ws.row_ranges = COSMO.get_set_indices(ws.p.C.sets)
+    end
+    bptr = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:cosmo_hip_batch_create, LIB[]), Int32, (Ref{Ptr{Cvoid}}, Int32, Int64, Int64, Int64), bptr, device, length(models), n, m)
+    rc == 0 || error("cosmo_hip_batch_create failed (code $rc)")
+    b = bptr[]
+    bcheck(rc) = rc == 0 || error(unsafe_string(ccall((:cosmo_hip_batch_last_error, LIB[]), Cstring, (Ptr{Cvoid},), b)))
+    try
+        bl = Float64[]; bu = Float64[]
+        for (k, ws) in enumerate(models)
+            P = SparseMatrixCSC(ws.p.P); A = SparseMatrixCSC(ws.p.A); q = ws.p.q; bv = Vector(ws.p.b)
+            GC.@preserve P A q bv bcheck(ccall((:cosmo_hip_batch_set_problem, LIB[]), Int32,
+                (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Int64}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+                b, k - 1, P.colptr, P.rowval, P.nzval, A.colptr, A.rowval, A.nzval, q, bv))
+            for s in ws.p.C.sets
+                if s isa COSMO.Box
+                    append!(bl, s.l); append!(bu, s.u)
+                end
+            end
+            if settings.scaling != 0
+                Dinv = ws.sm.Dinv.diag; Einv = ws.sm.Einv.diag
+                GC.@preserve Dinv Einv bcheck(ccall((:cosmo_hip_batch_set_scaling, LIB[]), Int32, (Ptr{Cvoid}, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble),
+                    b, k - 1, Dinv, Einv, ws.sm.cinv[]))
+            end
+        end
+        types = Int32[cone_type(s) for s in ws1.p.C.sets]; dims = Int64[s.dim for s in ws1.p.C.sets]
+        GC.@preserve types dims bl bu bcheck(ccall((:cosmo_hip_batch_set_cones, LIB[]), Int32, (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Cdouble}),
+            b, length(types), types, dims, isempty(bl) ? C_NULL : pointer(bl), isempty(bu) ? C_NULL : pointer(bu)))
+        prm = Ref(params_from(settings, KKT_CG; tol_constant = tol_constant, tol_exponent = tol_exponent))
+        bcheck(ccall((:cosmo_hip_batch_set_params, LIB[]), Int32, (Ptr{Cvoid}, Ref{Params}), b, prm))   # classify_constraints! + set_rho_vec! per problem
+        x0 = reduce(vcat, [ws.vars.x for ws in models]); s0 = reduce(vcat, [ws.vars.s.data for ws in models]); mu0 = reduce(vcat, [ws.vars.μ for ws in models])
+        GC.@preserve x0 s0 mu0 bcheck(ccall((:cosmo_hip_batch_set_iterates, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}), b, x0, s0, mu0))
+        results_c = Vector{ResultC}(undef, length(models))
+        bcheck(ccall((:cosmo_hip_batch_optimize, LIB[]), Int32, (Ptr{Cvoid}, Ptr{ResultC}), b, results_c))
+        out = COSMO.Result{Float64}[]
+        for (k, ws) in enumerate(models)
+            r = results_c[k]
+            w = ws.vars.w; wp = ws.vars.w_prev; sd = ws.vars.s.data; mu = ws.vars.μ
+            GC.@preserve w wp sd mu bcheck(ccall((:cosmo_hip_batch_get_iterates, LIB[]), Int32, (Ptr{Cvoid}, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+                b, k - 1, w, wp, sd, mu))
+            ws.states.IS_OPTIMIZED = true
+            ws.ρ = r.rho
+            resize!(ws.rho_updates, 0); append!(ws.rho_updates, collect(r.rho_updates)[1:min(r.n_rho_updates, MAX_RHO_UPDATES)])
+            ws.times.iter_time = r.iter_time
+            res_info = COSMO.ResultInfo(r.r_prim, r.r_dual, r.max_norm_prim, r.max_norm_dual, ws.rho_updates)
+            settings.scaling != 0 && COSMO.reverse_scaling!(ws)
+            @. ws.utility_vars.vec_m = -ws.vars.μ
+            ws.times.solver_time = time() - t_start
+            push!(out, COSMO.Result{Float64}(copy(ws.vars.x), copy(ws.utility_vars.vec_m), copy(ws.vars.s.data), r.cost, Int(r.iter), 0, STATUS[r.status + 1], res_info, ws.times))
+        end
+        return out
+    finally
+        ccall((:cosmo_hip_batch_destroy, LIB[]), Int32, (Ptr{Cvoid},), b)
+    end
+end
+
 end # module
