@@ -1108,7 +1108,10 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
   const void* fn = bs == 256 ? (const void*)k_batch_admm_lds<256> : (bs == 512 ? (const void*)k_batch_admm_lds<512> : (const void*)k_batch_admm_lds<1024>);
   if (b->reg_mode == 1) fn = (const void*)k_batch_admm_reg<512, 1, 2>;
   if (b->reg_mode == 2) fn = (const void*)k_batch_admm_reg<512, 2, 4>;
-  BHIP(b, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, b->lds_bytes));
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, b->lds_bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    b->d_img = nullptr; b->reg_mode = 0;          // the device does not grant that much LDS: streaming kernel
+  }
   return COSMO_HIP_OK;
 }
 
