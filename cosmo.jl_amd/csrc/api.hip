@@ -139,7 +139,9 @@ int32_t upload_csr(cosmo_hip_handle* h, const HostCsr& M, CsrDev& D, int split_c
   D.nb = (int)rbnd.size() - 1;
   rb.resize((size_t)4 * std::max(D.nb, 1), 0);           // {r0, r1, nz0, nz1} per tile (16-byte aligned descriptors)
   for (int k = 0; k < D.nb; ++k) { rb[4 * k] = rbnd[k]; rb[4 * k + 1] = rbnd[k + 1]; rb[4 * k + 2] = M.rowptr[rbnd[k]]; rb[4 * k + 3] = M.rowptr[rbnd[k + 1]]; }
-  D.grid = std::max(1, std::min(D.nb, COSMO_MAX_PARTIALS));
+  int grid_cap = COSMO_MAX_PARTIALS;
+  if (const char* e = getenv("COSMO_HIP_GRID_CAP")) { const int v = atoi(e); if (v >= 64 && v <= COSMO_MAX_PARTIALS) grid_cap = v; }   // lab knob
+  D.grid = std::max(1, std::min(D.nb, grid_cap));
   CHK(dalloc(h, &D.rowptr, (size_t)M.nrows + 1));
   CHK(dalloc(h, &D.col, M.col.size()));
   CHK(dalloc(h, &D.val, M.val.size()));
