@@ -301,6 +301,7 @@ __global__ __launch_bounds__(256) void k_symm_gemm_batch(const Ctl* __restrict__
   if (guard && ctl->halt) return;
   extern __shared__ double smem[];
   const int4 td = tiles[blockIdx.x];
+  if (td.x < 0) return;                      // padding of the XCD-interleaved tile list
   const BatchCone bc = cones[td.x];
   const long long n2 = (long long)bc.ld * bc.ld;
   double* base = W + bc.woff;
@@ -499,9 +500,28 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
     std::vector<int> order(q->bcones.size());
     for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return q->bcones[a].ld > q->bcones[b].ld; });
-    for (int ci : order) {
-      const int nt = q->bcones[ci].ld / 64;
-      for (int tj = 0; tj < nt; ++tj) for (int ti = 0; ti <= tj; ++ti) tiles.push_back(int4{ci, ti, tj, 0});
+    // XCD-aware order: workgroup b runs on XCD b % 8 and each XCD has its own L2, so all tiles of a cone go to ONE XCD (they
+    // share the cone's operand panels: 1.5-2.5x fewer HBM reads than tiles scattered over eight L2s); the cones are dealt to the
+    // XCD with the least work so far, descriptor 8 * slot + x is the slot-th tile of XCD x, short lists end with null tiles.
+    if (getenv("COSMO_HIP_POLAR_BATCH_FLAT")) {
+      for (int ci : order) {
+        const int nt = q->bcones[ci].ld / 64;
+        for (int tj = 0; tj < nt; ++tj) for (int ti = 0; ti <= tj; ++ti) tiles.push_back(int4{ci, ti, tj, 0});
+      }
+    } else {
+      std::vector<std::vector<int4>> xl(8);
+      long long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int ci : order) {
+        const int nt = q->bcones[ci].ld / 64;
+        int x = 0;
+        for (int t = 1; t < 8; ++t) if (load[t] < load[x]) x = t;
+        for (int tj = 0; tj < nt; ++tj) for (int ti = 0; ti <= tj; ++ti) xl[x].push_back(int4{ci, ti, tj, 0});
+        load[x] += (long long)nt * (nt + 1) / 2 * q->bcones[ci].ld;
+      }
+      size_t maxlen = 0;
+      for (int x = 0; x < 8; ++x) maxlen = std::max(maxlen, xl[x].size());
+      tiles.assign(8 * maxlen, int4{-1, 0, 0, 0});
+      for (int x = 0; x < 8; ++x) for (size_t sl = 0; sl < xl[x].size(); ++sl) tiles[8 * sl + x] = xl[x][sl];
     }
     q->nbtiles = (int)tiles.size();
     HIPCHK(h, hipMalloc((void**)&q->BW, sizeof(double) * (size_t)woff));
