@@ -41,6 +41,7 @@ class Params(C.Structure):
         ("max_iter", C.c_int64), ("adaptive_rho_max_adaptions", C.c_int64),
         ("kkt_kind", C.c_int32), ("check_termination", C.c_int32), ("check_infeasibility", C.c_int32),
         ("adaptive_rho", C.c_int32), ("adaptive_rho_interval", C.c_int32), ("unscale_residuals", C.c_int32),
+        ("obj_true", C.c_double), ("obj_true_tol", C.c_double),
     ]
 
 

@@ -203,6 +203,7 @@ extern "C" void cosmo_hip_default_params(cosmo_hip_params* p) {
   p->max_iter = 5000; p->adaptive_rho_max_adaptions = INT64_MAX; p->kkt_kind = COSMO_HIP_KKT_CG;
   p->check_termination = 25; p->check_infeasibility = 40; p->adaptive_rho = 1; p->adaptive_rho_interval = 40;
   p->unscale_residuals = 1;
+  p->obj_true = NAN; p->obj_true_tol = 1e-3;
 }
 
 extern "C" int32_t cosmo_hip_create(cosmo_hip_handle** out, int32_t device_id) {

@@ -40,7 +40,7 @@ struct BatchDev {
 };
 
 struct BParams {
-  double sigma, alpha, eps_abs, eps_rel, rho_min, rho_max, rho_eq, adapt_tol;
+  double sigma, alpha, eps_abs, eps_rel, rho_min, rho_max, rho_eq, adapt_tol, obj_true, obj_true_tol;
   long long max_iter, max_adaptions;
   int check_termination, adaptive_rho, adaptive_rho_interval, unscale;
 };
@@ -373,7 +373,8 @@ __device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams
       residuals(P.unscale != 0);
       int st = 0;
       if (fabs(cost) > 1e20) st = COSMO_HIP_UNSOLVED;
-      else if (rp < P.eps_abs + P.eps_rel * mp && rd < P.eps_abs + P.eps_rel * md) st = COSMO_HIP_SOLVED;
+      else if (rp < P.eps_abs + P.eps_rel * mp && rd < P.eps_abs + P.eps_rel * md &&
+               ((P.obj_true != P.obj_true) || fabs(P.obj_true - cost) <= P.obj_true_tol)) st = COSMO_HIP_SOLVED;   // has_converged (residuals.jl:131-139)
       if (tid == 0) { ctl->cost = cost; ctl->r_prim = rp; ctl->r_dual = rd; ctl->max_norm_prim = mp; ctl->max_norm_dual = md; ctl->status = st; }
       __syncthreads();
       if (st != 0) break;
@@ -764,7 +765,8 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       residuals(P.unscale != 0);
       int st = 0;
       if (fabs(cost) > 1e20) st = COSMO_HIP_UNSOLVED;
-      else if (rp < P.eps_abs + P.eps_rel * mp && rd < P.eps_abs + P.eps_rel * md) st = COSMO_HIP_SOLVED;
+      else if (rp < P.eps_abs + P.eps_rel * mp && rd < P.eps_abs + P.eps_rel * md &&
+               ((P.obj_true != P.obj_true) || fabs(P.obj_true - cost) <= P.obj_true_tol)) st = COSMO_HIP_SOLVED;   // has_converged (residuals.jl:131-139)
       o_cost = cost; o_rp = rp; o_rd = rd; o_mp = mp; o_md = md; status = st;
       if (st != 0) break;
     }
@@ -1252,7 +1254,7 @@ extern "C" int32_t cosmo_hip_batch_set_iterates(cosmo_hip_batch* b, const double
 
 static BParams bparams(const cosmo_hip_params& p) {
   BParams P;
-  P.sigma = p.sigma; P.alpha = p.alpha; P.eps_abs = p.eps_abs; P.eps_rel = p.eps_rel; P.rho_min = p.rho_min; P.rho_max = p.rho_max;
+  P.sigma = p.sigma; P.alpha = p.alpha; P.eps_abs = p.eps_abs; P.eps_rel = p.eps_rel; P.obj_true = p.obj_true; P.obj_true_tol = p.obj_true_tol; P.rho_min = p.rho_min; P.rho_max = p.rho_max;
   P.rho_eq = p.rho_eq_over_rho_ineq; P.adapt_tol = p.adaptive_rho_tolerance; P.max_iter = p.max_iter;
   P.max_adaptions = p.adaptive_rho_max_adaptions; P.check_termination = p.check_termination; P.adaptive_rho = p.adaptive_rho;
   P.adaptive_rho_interval = p.adaptive_rho_interval; P.unscale = p.unscale_residuals;

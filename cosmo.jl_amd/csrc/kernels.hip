@@ -446,6 +446,7 @@ struct ChkArgs {
   int n_prim, n_dual;
   int mode;
   double cinv, eps_abs, eps_rel;
+  double obj_true, obj_true_tol;
   double rho_min, rho_max, adapt_tol;
   long long max_adaptions;
 };
@@ -484,7 +485,8 @@ __global__ __launch_bounds__(COSMO_BS) void k_chk_final(Ctl* __restrict__ ctl, i
     if (fabs(cost) > 1e20) { ctl->status = COSMO_HIP_UNSOLVED; ctl->halt = 1; return; }
     const bool pf = rp < a.eps_abs + a.eps_rel * mp;
     const bool df = rd < a.eps_abs + a.eps_rel * md;
-    if (pf && df) { ctl->status = COSMO_HIP_SOLVED; ctl->halt = 1; }
+    const bool ot = (a.obj_true != a.obj_true) || (fabs(a.obj_true - cost) <= a.obj_true_tol);   // has_converged (residuals.jl:131-139)
+    if (pf && df && ot) { ctl->status = COSMO_HIP_SOLVED; ctl->halt = 1; }
   }
 }
 
@@ -709,6 +711,7 @@ int32_t enqueue_check(cosmo_hip_handle* h, int guard, int mode) {
   a.n_prim = h->A.grid > 0 ? h->A.grid : 1; a.n_dual = h->PT.grid; a.mode = mode;
   a.cinv = (h->prm.unscale_residuals && h->has_scaling) ? h->cinv : 1.0;
   a.eps_abs = h->prm.eps_abs; a.eps_rel = h->prm.eps_rel;
+  a.obj_true = h->prm.obj_true; a.obj_true_tol = h->prm.obj_true_tol;
   a.rho_min = h->prm.rho_min; a.rho_max = h->prm.rho_max; a.adapt_tol = h->prm.adaptive_rho_tolerance;
   a.max_adaptions = h->prm.adaptive_rho_max_adaptions;
   prof_begin(h, KC_CHK_FINAL);

@@ -28,6 +28,7 @@ struct Params
     max_iter::Int64; adaptive_rho_max_adaptions::Int64
     kkt_kind::Int32; check_termination::Int32; check_infeasibility::Int32
     adaptive_rho::Int32; adaptive_rho_interval::Int32; unscale_residuals::Int32
+    obj_true::Cdouble; obj_true_tol::Cdouble
 end
 
 const MAX_RHO_UPDATES = 64
@@ -184,7 +185,7 @@ function params_from(settings::COSMO.Settings{Float64}, kkt_kind::Int32; tol_con
     Params(s.sigma, s.alpha, s.rho, s.eps_abs, s.eps_rel, s.eps_prim_inf, s.eps_dual_inf, tol_constant, tol_exponent,
            s.RHO_MIN, s.RHO_MAX, s.RHO_TOL, s.RHO_EQ_OVER_RHO_INEQ, s.adaptive_rho_tolerance, s.COSMO_INFTY * s.MIN_SCALING,
            s.time_limit, s.max_iter, min(s.adaptive_rho_max_adaptions, typemax(Int64) >> 1), kkt_kind, s.check_termination,
-           s.check_infeasibility, s.adaptive_rho ? 1 : 0, s.adaptive_rho_interval, s.scaling != 0 ? 1 : 0)
+           s.check_infeasibility, s.adaptive_rho ? 1 : 0, s.adaptive_rho_interval, s.scaling != 0 ? 1 : 0, s.obj_true, s.obj_true_tol)
 end
 
 function set_params!(h::Handle, p::Params, rho_vec::Union{Vector{Float64}, Nothing})

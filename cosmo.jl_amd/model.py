@@ -89,6 +89,8 @@ class Settings:
     RHO_EQ_OVER_RHO_INEQ: float = 1e3
     COSMO_INFTY: float = 1e20
     time_limit: float = 0.0
+    obj_true: float = float("nan")        # src/settings.jl:132-133: convergence additionally requires |obj_true - cost| <= obj_true_tol
+    obj_true_tol: float = 1e-3
     device: int = 0
     device_scaling: bool = True      # run scale_ruiz! on the MI355X (cosmo_hip_scale_ruiz) instead of on the host
     # accelerator / safeguard / safeguard_tol (src/settings.jl:96-98,136-138).  NOTE: the reference's default is
@@ -500,6 +502,7 @@ def _params_from_settings(h, st: Settings):
     p.adaptive_rho_tolerance = st.adaptive_rho_tolerance
     p.cosmo_infty_min_scaling = st.COSMO_INFTY * st.MIN_SCALING
     p.time_limit = st.time_limit
+    p.obj_true, p.obj_true_tol = st.obj_true, st.obj_true_tol
     p.max_iter = st.max_iter
     p.adaptive_rho_max_adaptions = min(st.adaptive_rho_max_adaptions, 2 ** 62)
     p.check_termination = st.check_termination

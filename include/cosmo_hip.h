@@ -103,6 +103,8 @@ typedef struct cosmo_hip_params {
   int32_t adaptive_rho;              /* 1 */
   int32_t adaptive_rho_interval;     /* 40 (0 = wall-clock rule, src/solver.jl:244-256: not supported) */
   int32_t unscale_residuals;         /* 1 iff settings.scaling != 0 (src/residuals.jl:43) */
+  double obj_true;                   /* NaN  (settings.obj_true): if set, has_converged additionally requires            */
+  double obj_true_tol;               /* 1e-3 |obj_true - cost| <= obj_true_tol (src/residuals.jl:131-139)                 */
 } cosmo_hip_params;
 
 /* Accelerator of the fixed-point iteration (settings.accelerator, safeguard, safeguard_tol: src/settings.jl:96-98,136-138;

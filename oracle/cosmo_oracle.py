@@ -533,6 +533,8 @@ class Settings:
     RHO_EQ_OVER_RHO_INEQ: float = 1e3
     COSMO_INFTY: float = 1e20
     time_limit: float = 0.0
+    obj_true: float = float("nan")          # src/settings.jl:132-133
+    obj_true_tol: float = 1e-3
     # accelerator (src/settings.jl:136-138, src/accelerator_interface.jl).  "empty" = EmptyAccelerator (the pinned loop);
     # "anderson" = AndersonAccelerator{T, Type2{QRDecomp}, RestartedMemory, NoRegularizer}(mem = 15), the reference's default.
     accelerator: str = "empty"
@@ -1302,7 +1304,8 @@ class Workspace:
                     status = "Unsolved"
                     break
                 rp, rd, mp, md = info
-                if rp < st.eps_abs + st.eps_rel * mp and rd < st.eps_abs + st.eps_rel * md:   # residuals.jl:98-117
+                obj_ok = math.isnan(st.obj_true) or abs(st.obj_true - cost) <= st.obj_true_tol   # has_converged (residuals.jl:131-139)
+                if rp < st.eps_abs + st.eps_rel * mp and rd < st.eps_abs + st.eps_rel * md and obj_ok:   # residuals.jl:98-117
                     status = "Solved"
                     break
             if it % st.check_infeasibility == 0:                # :326-327

@@ -247,6 +247,29 @@ def test_simple_qp_golden():
     assert len(res.info.rho_updates) == len(ref.rho_updates)
 
 
+def test_obj_true_gates_convergence():
+    # settings.obj_true / obj_true_tol (has_converged, src/residuals.jl:131-139) in the device-side termination decision, single
+    # problem and batch kernels
+    def solve(**kw):
+        model = cj.Model()
+        cj.assemble(model, np.array([[4.0, 1], [1, 2]]), np.array([1.0, 1]), _simple_constraints(), settings=cj.Settings(**kw))
+        return cj.optimize(model)
+    base = solve()
+    good = solve(obj_true=1.88, obj_true_tol=1e-2)
+    bad = solve(obj_true=5.0, max_iter=300)
+    assert base.status == good.status == "Solved" and good.iter == base.iter
+    assert bad.status == "Max_iter_reached" and bad.iter == 300
+    mods = []
+    for kw in (dict(obj_true=1.88, obj_true_tol=1e-2), dict(obj_true=1.88, obj_true_tol=1e-2)):
+        md = cj.Model(); cj.assemble(md, np.array([[4.0, 1], [1, 2]]), np.array([1.0, 1]), _simple_constraints(), settings=cj.Settings(**kw)); mods.append(md)
+    rb = cj.optimize_batch(mods)
+    assert all(r.status == "Solved" for r in rb)
+    mods = []
+    for _ in range(2):
+        md = cj.Model(); cj.assemble(md, np.array([[4.0, 1], [1, 2]]), np.array([1.0, 1]), _simple_constraints(), settings=cj.Settings(obj_true=5.0, max_iter=200)); mods.append(md)
+    assert all(r.status == "Max_iter_reached" for r in cj.optimize_batch(mods))
+
+
 def test_box_qp_golden():
     model = cj.Model()
     cj.assemble(model, np.eye(2), np.array([1.0, -1]), cj.Constraint(sp.identity(2, format="csc"), np.zeros(2),

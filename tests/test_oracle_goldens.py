@@ -525,3 +525,18 @@ def test_complex_psd_infeasibility_certificates():
     A = sp.csc_matrix((-vec(H1)).reshape(-1, 1))
     res = O.solve(sp.csc_matrix((1, 1)), np.array([-1.0]), A, np.zeros(r * r), [O.ComplexPsdConeTriangle(r * r)])
     assert res.status == "Dual_infeasible"
+
+
+def test_obj_true_gates_convergence():
+    # settings.obj_true (src/residuals.jl:131-139): with the right objective the run stops where it would anyway, with a wrong
+    # one the residual test alone never reports :Solved
+    P = sp.csc_matrix([[4.0, 1], [1, 2]]); q = np.array([1.0, 1])
+    A = sp.csc_matrix([[1.0, 1], [1, 0], [0, 1]]); l = np.array([1.0, 0, 0]); u = np.array([1.0, 0.7, 0.7])
+    cs = [O.Constraint(A, np.zeros(3), O.Box(l, u))]
+    Ai, bi, cones = O.assemble(cs)
+    base = O.solve(P, q, Ai, bi, cones, O.Settings())
+    assert base.status == "Solved" and abs(base.obj_val - 1.88) < 1e-3                     # simple.jl golden
+    good = O.solve(P, q, Ai, bi, O.copy_cones(cones), O.Settings(obj_true=1.88, obj_true_tol=1e-2))
+    assert good.status == "Solved" and good.iter == base.iter
+    bad = O.solve(P, q, Ai, bi, O.copy_cones(cones), O.Settings(obj_true=5.0, max_iter=300))
+    assert bad.status == "Max_iter_reached"

@@ -66,6 +66,7 @@ def make_handle_from_workspace(ws: O.Workspace, kkt_kind=cj._ffi.KKT_CG, **param
     p.adaptive_rho = 1 if st.adaptive_rho else 0
     p.adaptive_rho_interval = st.adaptive_rho_interval
     p.unscale_residuals = 1 if st.scaling != 0 else 0
+    p.obj_true, p.obj_true_tol = st.obj_true, st.obj_true_tol
     for k, v in param_overrides.items():
         setattr(p, k, v)
     h.set_params(p)
