@@ -57,7 +57,7 @@ def test_struct_layouts_match_header():
         typ, rest = decl.split(None, 1)
         fields += [f.strip() for f in rest.split(",")]
     assert fields == [f[0] for f in cj._ffi.Params._fields_]
-    assert ctypes.sizeof(cj._ffi.Params) == 16 * 8 + 2 * 8 + 6 * 4
+    assert ctypes.sizeof(cj._ffi.Params) == 16 * 8 + 2 * 8 + 6 * 4 + 2 * 8          # ... + obj_true, obj_true_tol
     assert ctypes.sizeof(cj._ffi.ResultStruct) == 2 * 4 + 3 * 8 + 8 * 8 + 64 * 8
 
 
