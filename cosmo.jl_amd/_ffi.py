@@ -48,7 +48,7 @@ class Params(C.Structure):
 class AccelParams(C.Structure):
     _fields_ = [
         ("kind", C.c_int32), ("mem", C.c_int32), ("min_mem", C.c_int32), ("safeguard", C.c_int32),
-        ("start_iter", C.c_int64), ("safeguard_tol", C.c_double), ("eta_max", C.c_double),
+        ("start_iter", C.c_int64), ("safeguard_tol", C.c_double), ("eta_max", C.c_double), ("start_accuracy", C.c_double),
     ]
 
 
@@ -276,12 +276,14 @@ class Handle:
         rv = _f64(rho_vec, self.m, "rho_vec")
         self._chk(self.lib.cosmo_hip_update_rho(self._h, _dp(rv)))
 
-    def set_accelerator(self, kind=ACCEL_ANDERSON, mem=15, min_mem=3, safeguard=True, safeguard_tol=2.0, start_iter=2):
+    def set_accelerator(self, kind=ACCEL_ANDERSON, mem=15, min_mem=3, safeguard=True, safeguard_tol=2.0, start_iter=2, start_accuracy=None):
         """`_make_accelerator!` (src/setup.jl:10-16); kind ACCEL_EMPTY removes it."""
         ap = AccelParams()
         self.lib.cosmo_hip_default_accel_params(C.byref(ap))
         ap.kind, ap.mem, ap.min_mem, ap.safeguard = int(kind), int(mem), int(min_mem), 1 if safeguard else 0
         ap.safeguard_tol, ap.start_iter = float(safeguard_tol), int(start_iter)
+        if start_accuracy is not None:
+            ap.start_accuracy = float(start_accuracy)
         self._chk(self.lib.cosmo_hip_set_accelerator(self._h, C.byref(ap)))
 
     def accel_stats(self):

@@ -242,7 +242,7 @@ int32_t aa_restart(cosmo_hip_handle* h) {      // CA.restart! -> empty_history!
 extern "C" void cosmo_hip_default_accel_params(cosmo_hip_accel_params* p) {
   if (!p) return;
   p->kind = COSMO_HIP_ACCEL_ANDERSON; p->mem = 15; p->min_mem = 3; p->safeguard = 1;
-  p->start_iter = 2; p->safeguard_tol = 2.0; p->eta_max = 1e4;
+  p->start_iter = 2; p->safeguard_tol = 2.0; p->eta_max = 1e4; p->start_accuracy = -1.0;
 }
 
 extern "C" int32_t cosmo_hip_set_accelerator(cosmo_hip_handle* h, const cosmo_hip_accel_params* p) {
@@ -293,7 +293,7 @@ int32_t aa_enqueue_pre(cosmo_hip_handle* h, long long it, bool* attempted) {
   AaState* S = aa_of(h);
   *attempted = false;
   if (!S) return COSMO_HIP_OK;
-  if (!S->active && it >= S->prm.start_iter) S->active = true;     // check_activation! (Immediate / IterActivation)
+  if (!S->active && !(S->prm.start_accuracy >= 0.0) && it >= S->prm.start_iter) S->active = true;   // check_activation! (Immediate / IterActivation)
   if (!S->active) return COSMO_HIP_OK;
   const long long N = S->N;
   const dim3 G(S->grid), B(COSMO_BS);
@@ -371,6 +371,14 @@ int32_t aa_enqueue_reset(cosmo_hip_handle* h) {
   return COSMO_HIP_OK;
 }
 bool aa_safeguarded(const cosmo_hip_handle* h) { const AaState* S = static_cast<const AaState*>(h->accel); return S && S->prm.safeguard != 0; }
+// check_activation!(ws, ::AccuracyActivation, r::ResultInfo) (accelerator_interface.jl:38-46), called from has_converged at
+// every termination check
+void aa_check_accuracy_activation(cosmo_hip_handle* h, double r_prim, double r_dual, double max_norm_prim, double max_norm_dual) {
+  AaState* S = aa_of(h);
+  if (!S || S->active || !(S->prm.start_accuracy >= 0.0)) return;
+  const double tol = S->prm.start_accuracy;
+  if (r_prim < tol + tol * max_norm_prim && r_dual < tol + tol * max_norm_dual) S->active = true;
+}
 bool aa_active(const cosmo_hip_handle* h) { const AaState* S = static_cast<const AaState*>(h->accel); return S && S->active; }
 void aa_count(cosmo_hip_handle* h, int accelerated, int declined) {
   AaState* S = aa_of(h);

@@ -1002,6 +1002,7 @@ static int32_t optimize_accelerated(cosmo_hip_handle* h, int* status_out, long l
     if ((it % ct) == 0 || it == 1) {                                          // check_termination! (solver.jl:306-323)
       CHK(enqueue_check(h, 1, 1));
       CHK(sync_ctl(h));
+      aa_check_accuracy_activation(h, h->ctl_host->r_prim, h->ctl_host->r_dual, h->ctl_host->max_norm_prim, h->ctl_host->max_norm_dual);
       if (h->ctl_host->status != 0) { status = h->ctl_host->status; break; }
     }
     if (ci > 0 && ci < (1LL << 40) && (it % ci) == 0) {

@@ -214,6 +214,7 @@ int32_t aa_fetch_flags(cosmo_hip_handle* h, int* success, int* declined);
 int32_t aa_enqueue_guard(cosmo_hip_handle* h);
 int32_t aa_enqueue_reset(cosmo_hip_handle* h);
 void aa_count(cosmo_hip_handle* h, int accelerated, int declined);
+void aa_check_accuracy_activation(cosmo_hip_handle* h, double r_prim, double r_dual, double max_norm_prim, double max_norm_dual);
 
 // exponential / power cones (cone3.hip)
 int32_t cone3_plan_create(cosmo_hip_handle* h);

@@ -160,6 +160,7 @@ end
 # mirrors cosmo_hip_accel_params
 struct AccelParams
     kind::Int32; mem::Int32; min_mem::Int32; safeguard::Int32; start_iter::Int64; safeguard_tol::Float64; eta_max::Float64
+    start_accuracy::Float64
 end
 
 # settings.accelerator is an OptionsFactory{<:AbstractAccelerator} (src/settings.jl:96,136,148-150).  The device builds the
@@ -173,9 +174,9 @@ function set_accelerator!(h::Handle, settings::COSMO.Settings{Float64})
     kw = settings.accelerator.kwargs
     act = get(kw, :activation_reason, COSMO.ImmediateActivation())
     start = act isa COSMO.IterActivation ? act.start_iter : 2
-    act isa COSMO.AccuracyActivation && error("AccuracyActivation is not built on the MI355X path")
+    acc = act isa COSMO.AccuracyActivation ? Float64(act.start_accuracy) : -1.0    # src/accelerator_interface.jl:14-21
     p = AccelParams(Int32(1), Int32(get(kw, :mem, 10)), Int32(get(kw, :min_mem, 3)), Int32(settings.safeguard ? 1 : 0), Int64(start),
-                    Float64(settings.safeguard_tol), 1e4)
+                    Float64(settings.safeguard_tol), 1e4, acc)
     check(h, ccall((:cosmo_hip_set_accelerator, LIB[]), Int32, (Ptr{Cvoid}, Ref{AccelParams}), h.ptr, Ref(p)))
     nothing
 end

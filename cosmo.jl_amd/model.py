@@ -103,7 +103,7 @@ class Settings:
     compact_transformation: bool = True
     merge_strategy: object = CliqueGraphMerge      # or with_options(ParentChildMerge, t_fill=8, t_size=8) / NoMerge
     accelerator: object = None
-    accelerator_activation: int = 2  # ImmediateActivation; k = IterActivation(k)
+    accelerator_activation: object = 2  # 2 = ImmediateActivation; int k = IterActivation(k); AccuracyActivation(eps)
     safeguard: bool = True
     safeguard_tol: float = 2.0
 
@@ -206,6 +206,18 @@ class AbstractConvexCone(AbstractConvexSet):
 # src/convexset.jl:953-958 (the generic rectify_scaling! fall-back scalar-scales user cones as well)
 _SCALAR_SCALED = (_ffi.SOC, _ffi.PSD_SQUARE, _ffi.PSD_TRIANGLE, _ffi.EXP, _ffi.DUAL_EXP, _ffi.POW, _ffi.DUAL_POW, _ffi.PSD_TRIANGLE_COMPLEX,
                   _ffi.CUSTOM)
+
+
+class AccuracyActivation:
+    """`AccuracyActivation(start_accuracy)` (src/accelerator_interface.jl:14-21): switch the accelerator on once the residuals
+    satisfy eps_abs = eps_rel = start_accuracy at a termination check."""
+
+    def __init__(self, start_accuracy):
+        self.start_accuracy = float(start_accuracy)
+
+
+class IterActivation(int):
+    """`IterActivation(start_iter)` (src/accelerator_interface.jl:5-12)."""
 
 
 class EmptyAccelerator:
@@ -522,8 +534,10 @@ def _install_accelerator(h, st: Settings):
         return
     if acc is not AndersonAccelerator:
         raise ValueError("unknown accelerator %r" % (acc,))
+    act = kw.get("activation_reason", st.accelerator_activation)
+    acc_kw = dict(start_accuracy=act.start_accuracy) if isinstance(act, AccuracyActivation) else dict(start_iter=int(act))
     h.set_accelerator(_ffi.ACCEL_ANDERSON, mem=kw.get("mem", 15), min_mem=kw.get("min_mem", 3), safeguard=st.safeguard,
-                      safeguard_tol=st.safeguard_tol, start_iter=st.accelerator_activation)
+                      safeguard_tol=st.safeguard_tol, **acc_kw)
 
 
 def setup(model: Model):

@@ -119,6 +119,9 @@ typedef struct cosmo_hip_accel_params {
   int64_t start_iter;    /* 2 = ImmediateActivation; k = IterActivation(k)                       */
   double safeguard_tol;  /* 2.0 (settings.safeguard_tol)                                         */
   double eta_max;        /* 1e4: a least-squares solution with a larger 2-norm is rejected       */
+  double start_accuracy; /* < 0 (default -1): unused.  >= 0: AccuracyActivation(start_accuracy) -- the accelerator is
+                            switched on at the first termination check whose residuals satisfy eps_abs = eps_rel =
+                            start_accuracy (src/accelerator_interface.jl:14-21,38-46); start_iter is then ignored */
 } cosmo_hip_accel_params;
 
 /* What `optimize!` returns to its caller besides the iterates (Result / ResultInfo, src/types.jl:65-112). */

@@ -541,6 +541,7 @@ class Settings:
     acc_mem: int = 15
     acc_min_mem: int = 3
     acc_start_iter: int = 2              # ImmediateActivation (accelerator_interface.jl:25-29); IterActivation(k): k
+    acc_start_accuracy: Optional[float] = None   # AccuracyActivation(eps) (:14-21,38-46); replaces the iteration rule when set
     safeguard: bool = True
     safeguard_tol: float = 2.0
 
@@ -1246,7 +1247,7 @@ class Workspace:
         while it + self.safeguarding_iter < st.max_iter:        # :140
             it += 1
             if acc is not None:                                 # acceleration_pre! (accelerator_interface.jl:58-76)
-                if not self.accelerator_active and it >= st.acc_start_iter:
+                if not self.accelerator_active and st.acc_start_accuracy is None and it >= st.acc_start_iter:
                     self.accelerator_active = True
                 if self.accelerator_active:
                     acc.update(w, w_prev)
@@ -1304,6 +1305,10 @@ class Workspace:
                     status = "Unsolved"
                     break
                 rp, rd, mp, md = info
+                if acc is not None and not self.accelerator_active and st.acc_start_accuracy is not None:   # check_activation! (:38-46)
+                    tol_a = st.acc_start_accuracy
+                    if rp < tol_a + tol_a * mp and rd < tol_a + tol_a * md:
+                        self.accelerator_active = True
                 obj_ok = math.isnan(st.obj_true) or abs(st.obj_true - cost) <= st.obj_true_tol   # has_converged (residuals.jl:131-139)
                 if rp < st.eps_abs + st.eps_rel * mp and rd < st.eps_abs + st.eps_rel * md and obj_ok:   # residuals.jl:98-117
                     status = "Solved"

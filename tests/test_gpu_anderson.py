@@ -143,3 +143,28 @@ def test_accelerated_run_is_bitwise_reproducible_and_restartable():
     assert np.array_equal(outs[0].view(np.int64), outs[1].view(np.int64))
     r2 = cj.optimize(model)                                       # warm-started second optimize!: accelerator restarted (setup.jl:47-49)
     assert r2.status in ("Max_iter_reached", "Undetermined")
+
+
+def test_accuracy_activation_matches_oracle():
+    """AccuracyActivation(eps) (src/accelerator_interface.jl:14-21,38-46): the accelerator stays off until a termination check
+    sees residuals below eps; device and oracle switch it on at the same check and then follow the same trajectory."""
+    rng = np.random.default_rng(5)
+    p = util.random_qp(rng, 40, 4, 30, 0, p_shift=1.0)
+    tight = cj.with_options(cj.CGIndirectKKTSolver, tol_constant=1e-10, tol_exponent=0.0)
+    out = {}
+    for name, act, okw in (("accuracy", cj.AccuracyActivation(1e-2), dict(acc_start_accuracy=1e-2)), ("immediate", 2, {})):
+        model = cj.Model()
+        model.set(p["P"], p["q"], p["A"], p["b"], p["sets"],
+                  cj.Settings(accelerator=cj.AndersonAccelerator, accelerator_activation=act, kkt_solver=tight, eps_abs=1e-7, eps_rel=1e-7))
+        res = cj.optimize(model)
+        stats = model.handle.accel_stats()
+        ws = O.Workspace(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]),
+                         O.Settings(kkt_solver="cg", tol_constant=1e-10, tol_exponent=0.0, accelerator="anderson", eps_abs=1e-7, eps_rel=1e-7, **okw))
+        ref = ws.optimize()
+        assert res.status == ref.status == "Solved"
+        assert abs(res.iter - ref.iter) <= 25, (name, res.iter, ref.iter)
+        assert abs(stats["accelerated"] - ws.accelerator.num_accelerated_steps) <= max(2, 0.1 * ws.accelerator.num_accelerated_steps)
+        assert np.linalg.norm(res.x - ref.x) <= 1e-5 * max(1.0, np.linalg.norm(ref.x))
+        out[name] = (res, stats)
+    # activation by accuracy starts later, so it accelerates fewer steps than immediate activation
+    assert 0 < out["accuracy"][1]["accelerated"] < out["immediate"][1]["accelerated"]

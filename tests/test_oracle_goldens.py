@@ -540,3 +540,23 @@ def test_obj_true_gates_convergence():
     assert good.status == "Solved" and good.iter == base.iter
     bad = O.solve(P, q, Ai, bi, O.copy_cones(cones), O.Settings(obj_true=5.0, max_iter=300))
     assert bad.status == "Max_iter_reached"
+
+
+def test_accuracy_activation_of_the_accelerator():
+    # AccuracyActivation(eps) (src/accelerator_interface.jl:14-21,38-46): inactive until a termination check sees residuals < eps
+    rng = np.random.default_rng(5)
+    n, m = 30, 45
+    Am = sp.csc_matrix(rng.standard_normal((m, n))); x0 = rng.standard_normal(n)
+    b = Am @ x0 + rng.uniform(0.1, 1.0, m)
+    Pm = sp.identity(n, format="csc"); q = rng.standard_normal(n)
+    ws_i = O.Workspace(Pm, q, Am, b, [O.Nonnegatives(m)], O.Settings(accelerator="anderson", eps_abs=1e-7, eps_rel=1e-7))
+    ri = ws_i.optimize()
+    ws_a = O.Workspace(Pm, q, Am, b, [O.Nonnegatives(m)], O.Settings(accelerator="anderson", acc_start_accuracy=1e-2, eps_abs=1e-7, eps_rel=1e-7))
+    ra = ws_a.optimize()
+    assert ri.status == ra.status == "Solved"
+    assert ws_a.accelerator_active and 0 < ws_a.accelerator.num_accelerated_steps < ws_i.accelerator.num_accelerated_steps + ra.iter
+    assert np.linalg.norm(ri.x - ra.x) <= 1e-4 * max(1.0, np.linalg.norm(ri.x))
+    never = O.Workspace(Pm, q, Am, b, [O.Nonnegatives(m)], O.Settings(accelerator="anderson", acc_start_accuracy=1e-30, eps_abs=1e-5, eps_rel=1e-5))
+    rn = never.optimize()
+    plain = O.solve(Pm, q, Am, b, [O.Nonnegatives(m)], O.Settings(eps_abs=1e-5, eps_rel=1e-5))
+    assert not never.accelerator_active and rn.iter == plain.iter and np.array_equal(rn.x, plain.x)
