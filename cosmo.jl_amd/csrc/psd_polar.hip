@@ -149,7 +149,10 @@ template <int TS> struct GemmCfg {
 // MFMAs only ~59 % of the time).
 template <int EPI, int TS, int SK>
 __device__ __forceinline__ void symm_gemm_tile(const double* __restrict__ A, const double* __restrict__ B, const double* __restrict__ Cin,
-                                               double* __restrict__ C, int ld, int ti, int tj, double alpha, double beta, double* smem) {
+                                               double* __restrict__ C, int ld, int ti, int tj, double alpha, double beta, double* smem,
+                                               int kext = 0) {
+  // kext: extent of the k loop (a multiple of 2 PK SK; 0 = ld).  Rows / columns beyond the cone's d are zero in every operand of
+  // the iteration, so the batched path stops the inner products at d rounded up to 32 instead of the tile-rounded ld: exact.
   using Cfg = GemmCfg<TS>;
   constexpr int NM = Cfg::NM, NL = Cfg::NL, PITCH = Cfg::PITCH, CPITCH = Cfg::CPITCH, PANEL = Cfg::PANEL;
   const int grp = (SK == 2) ? (threadIdx.x >> 8) : 0;          // k-split group of this wave
@@ -165,7 +168,7 @@ __device__ __forceinline__ void symm_gemm_tile(const double* __restrict__ A, con
   for (int a = 0; a < NM; ++a)
 #pragma unroll
     for (int b = 0; b < NM; ++b) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
-  const int nk = ld / PK / SK;   // panels per group (ld / PK is a multiple of 4, so both groups run the same number of steps)
+  const int nk = (kext > 0 ? kext : ld) / PK / SK;   // panels per group (a multiple of 2: both groups run the same number of steps)
   // global -> LDS mapping: double2 number q = tid + 256 u of the PK x TS panel: k = q / (TS/2), index pair = q % (TS/2)
   int goff[NL], soff[NL];
 #pragma unroll
@@ -306,7 +309,8 @@ __global__ __launch_bounds__(256) void k_symm_gemm_batch(const Ctl* __restrict__
   const BatchCone bc = cones[td.x];
   const long long n2 = (long long)bc.ld * bc.ld;
   double* base = W + bc.woff;
-  symm_gemm_tile<EPI, 64, 1>(base + ia * n2, base + ib * n2, base + icin * n2, base + ic * n2, bc.ld, td.y, td.z, alpha, beta, smem);
+  symm_gemm_tile<EPI, 64, 1>(base + ia * n2, base + ib * n2, base + icin * n2, base + ic * n2, bc.ld, td.y, td.z, alpha, beta, smem,
+                             ((bc.d + 31) / 32) * 32);
 }
 
 template <int EPI, int TS, int SK>
