@@ -1,5 +1,5 @@
 import sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, scipy.sparse as sp, torch
 import cosmo_jl_amd as cj
 rng = np.random.default_rng(5)
