@@ -1,4 +1,4 @@
-import sys
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, scipy.sparse as sp, torch
 import cosmo_jl_amd as cj
