@@ -247,17 +247,40 @@ class Constraint:
     """`Constraint(A, b, K)`: A x + b in K (src/constraint.jl:47-108).  `K` may be a set instance or a set type."""
 
     def __init__(self, A, b, convex_set, dim: int = 0, indices: Optional[range] = None):
-        A = sp.csc_matrix(np.atleast_2d(A) if not sp.issparse(A) else A, dtype=np.float64)
-        b = np.atleast_1d(np.array(b, dtype=np.float64)).ravel()
+        if not sp.issparse(A):
+            A = np.asarray(A, dtype=np.float64)
+            if A.ndim == 0:
+                A = A.reshape(1, 1)                               # scalar A: 1 x 1 (src/constraint.jl:110-120)
+            elif A.ndim == 1:
+                A = A.reshape(-1, 1)                              # a Julia Vector is a column: n rows, one variable
+        A = sp.csc_matrix(A, dtype=np.float64)
+        b = np.asarray(b.todense() if sp.issparse(b) else b, dtype=np.float64)
+        if b.ndim > 1 and min(b.shape) != 1:
+            raise ValueError("Input b must be a vector or a scalar.")                              # :62
+        b = np.atleast_1d(b).ravel().copy()
         if A.shape[0] != b.size:
-            raise ValueError("The dimensions of matrix A and vector b don't match.")
+            raise ValueError("The dimensions of matrix A and vector b don't match.")               # :60
         if isinstance(convex_set, type):
-            convex_set = convex_set(A.shape[0])
+            if issubclass(convex_set, PowerCone):                                                   # ArgumentCones (:97)
+                raise TypeError("You can't create a constraint by passing the convex set as a type, if your convex set is a %s. "
+                                "Please pass an object." % convex_set.__name__)
+            nrows = A.shape[0]
+            if convex_set is PsdConeTriangle and nrows != 1 and math.isqrt(nrows) ** 2 == nrows:
+                convex_set = ComplexPsdConeTriangle(nrows)       # the reference deduces real / complex from the dimension (:101-106)
+            else:
+                convex_set = convex_set(nrows)
         if A.shape[0] != convex_set.dim:
-            raise ValueError("The row dimension of A doesn't match the dimension of the constraint set.")
-        if indices is not None:                                   # src/constraint.jl:63-70
+            raise ValueError("The row dimension of A doesn't match the dimension of the constraint set.")   # :61
+        if indices is not None:                                   # src/constraint.jl:63-70 (0-based half-open `range` here)
+            idx = list(indices)
+            if not idx or idx[0] < 0 or any(b2 - a2 != 1 for a2, b2 in zip(idx, idx[1:])):
+                raise ValueError("The index range for x has to be increasing and nonnegative.")
+            if dim < idx[-1] + 1:
+                raise ValueError("The dimension of x: %d must be equal or higher than the the stop value of indices: %d." % (dim, idx[-1] + 1))
+            if len(idx) != A.shape[1]:
+                raise ValueError("The index range does not match the number of columns of A.")
             Ac = sp.lil_matrix((A.shape[0], dim))
-            Ac[:, list(indices)] = A
+            Ac[:, idx] = A
             A = Ac.tocsc()
         self.A, self.b, self.convex_set = A, b, convex_set
 

@@ -152,3 +152,40 @@ def test_generators_are_deterministic_and_shaped():
     # feasible by construction: oracle solves it
     res = O.solve(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), O.Settings(max_iter=3000))
     assert res.status == "Solved"
+
+
+def test_constraint_constructors_mirror_the_reference():
+    """test/UnitTests/constraints.jl:41-88 on the Python mirror of COSMO.Constraint (src/constraint.jl:47-108)."""
+    rng = np.random.default_rng(1872381)
+    # constructors: integers / scalars / row and column vectors / sparse inputs all end up as float64 CSC + vector
+    for A, b, shape in ((4, 2, (1, 1)), (4.0, 2.0, (1, 1)), (np.array([[1.0, 2, 3, 4]]), 1.0, (1, 4)), (np.array([1.0, 2, 3, 4]), np.array([4.0, 3, 2, 1]), (4, 1)),
+                        (sp.random(10, 2, 0.4, random_state=1), sp.csc_matrix(rng.random((10, 1))), (10, 2)), (rng.random((10, 10)), rng.random((10, 1)), (10, 10))):
+        c = cj.Constraint(A, b, cj.ZeroSet)
+        assert sp.issparse(c.A) and c.A.dtype == np.float64 and c.A.shape == shape and c.b.shape == (shape[0],) and c.convex_set.dim == shape[0]
+    # indices: the constraint acts on a slice of a longer decision vector (:47-55; 0-based half-open range here)
+    A = rng.random((3, 3)); b = rng.random(3)
+    cs = cj.Constraint(A, b, cj.ZeroSet, 10, range(2, 5))
+    assert cs.A.shape == (3, 10) and np.array_equal(cs.A[:, 2:5].toarray(), A) and cs.A[:, :2].nnz == 0 and cs.A[:, 5:].nnz == 0
+    with pytest.raises(ValueError):
+        cj.Constraint(A, b, cj.ZeroSet, 4, range(2, 5))                       # dim < stop (DomainError in the reference)
+    with pytest.raises(ValueError):
+        cj.Constraint(A, rng.random(4), cj.ZeroSet)                           # DimensionMismatch
+    with pytest.raises(ValueError):
+        cj.Constraint(A, b, cj.ZeroSet(4))                                    # DimensionMismatch with the set
+    with pytest.raises(TypeError):
+        cj.Constraint(np.eye(3), np.zeros(3), cj.PowerCone)                   # ArgumentCones need an object (:97)
+    # PsdConeTriangle given as a type: real or complex is deduced from the dimension (:101-106)
+    assert type(cj.Constraint(np.eye(6), np.zeros(6), cj.PsdConeTriangle).convex_set) is cj.PsdConeTriangle
+    assert type(cj.Constraint(np.eye(9), np.zeros(9), cj.PsdConeTriangle).convex_set) is cj.ComplexPsdConeTriangle
+    assert type(cj.Constraint(np.eye(1), np.zeros(1), cj.PsdConeTriangle).convex_set) is cj.PsdConeTriangle
+
+
+def test_merge_constraints_mirrors_the_reference():
+    # constraints.jl:57-88: ZeroSet and Nonnegatives constraints are stacked into one (merge_constraints!, src/constraint.jl:127-160)
+    rng = np.random.default_rng(3)
+    for K in (cj.ZeroSet, cj.Nonnegatives):
+        A1, b1, A2, b2 = rng.random((10, 10)), rng.random(10), rng.random((10, 10)), rng.random(10)
+        model = cj.Model()
+        cj.assemble(model, np.eye(10), np.zeros(10), [cj.Constraint(A1, b1, K), cj.Constraint(A2, b2, K)])
+        assert len(model.sets) == 1 and type(model.sets[0]) is K and model.sets[0].dim == 20
+        assert np.array_equal(model.A.toarray(), -np.vstack([A1, A2])) and np.array_equal(model.b, np.concatenate([b1, b2]))
