@@ -428,9 +428,14 @@ class Model:
 
     # set! (src/interface.jl:218-250): data already in internal sign convention (A x + s = b)
     def set(self, P, q, A, b, convex_sets: Sequence[AbstractConvexSet], settings: Optional[Settings] = None):
-        P = sp.csc_matrix(P, dtype=np.float64, copy=True); A = sp.csc_matrix(A, dtype=np.float64, copy=True)
+        def _mat(M):                                             # numbers, vectors, dense and sparse matrices (src/interface.jl:79-106)
+            return M if sp.issparse(M) else np.atleast_2d(np.asarray(M, dtype=np.float64))
+
+        def _vec(v):
+            return np.array(v.toarray() if sp.issparse(v) else v, dtype=np.float64).ravel().copy()
+        P = sp.csc_matrix(_mat(P), dtype=np.float64, copy=True); A = sp.csc_matrix(_mat(A), dtype=np.float64, copy=True)
         P.sort_indices(); A.sort_indices()
-        q = np.array(q, dtype=np.float64).ravel().copy(); b = np.array(b, dtype=np.float64).ravel().copy()
+        q = _vec(q); b = _vec(b)
         n = q.size; m = b.size
         if P.shape != (n, n) or A.shape != (m, n):
             raise ValueError("The dimensions of P, q, A, b are inconsistent.")

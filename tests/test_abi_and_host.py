@@ -189,3 +189,35 @@ def test_merge_constraints_mirrors_the_reference():
         cj.assemble(model, np.eye(10), np.zeros(10), [cj.Constraint(A1, b1, K), cj.Constraint(A2, b2, K)])
         assert len(model.sets) == 1 and type(model.sets[0]) is K and model.sets[0].dim == 20
         assert np.array_equal(model.A.toarray(), -np.vstack([A1, A2])) and np.array_equal(model.b, np.concatenate([b1, b2]))
+
+
+def test_interface_set_and_assemble_mirror_the_reference():
+    """test/UnitTests/interface.jl:16-101 and model.jl:40-62 on the Python mirror of set! / assemble! / empty_model!
+    (src/interface.jl:30-77, 218-250): dimension checks and the scalar / vector / matrix / sparse input combinations."""
+    P = np.array([[4.0, 1], [1, 2]]); q = np.array([1.0, 1]); A = np.array([[1.0, 1], [1, 0], [0, 1]])
+    l = np.array([1.0, 0, 0]); u = np.array([1.0, 0.7, 0.7])
+    Aa = np.vstack([A, -A]); b = np.concatenate([u, -l]); sets = [cj.Nonnegatives(3), cj.Nonnegatives(3)]
+    m = cj.Model(); m.set(P, q, Aa, b, sets)
+    assert (m.n, m.m) == (2, 6)
+    for bad in ((P, np.ones(3), Aa, b), (np.zeros((1, 1)), q, Aa, b), (P, q, np.array([[1.0, 2], [1, 2]]), b), (P, q, Aa, np.array([1.0, 2]))):
+        with pytest.raises(ValueError):                                       # DimensionMismatch (interface.jl:33-36)
+            cj.Model().set(*bad, sets)
+    rng = np.random.default_rng(41)
+    P = rng.random((2, 2)); q = rng.random(2); A1 = rng.random((1, 2))
+    con = cj.Constraint(A1, 1.0, cj.Nonnegatives)
+    m = cj.Model(); cj.assemble(m, P, q, con)
+    assert np.array_equal(m.P.toarray(), P) and np.array_equal(m.q, q) and np.array_equal(m.A.toarray(), -A1) and np.array_equal(m.b, [1.0])
+    m.empty(); cj.assemble(m, sp.csc_matrix(P), sp.csc_matrix(q.reshape(-1, 1)), con)   # sparse inputs (interface.jl:55-58)
+    assert np.array_equal(m.P.toarray(), P) and np.array_equal(m.q, q)
+    con5 = cj.Constraint(rng.random((5, 1)), rng.random(5), cj.Nonnegatives)
+    for Pin, qin in ((1.0, [1.0]), ([1.0], 1.0), (1.0, 1.0), ([1.0], np.array([[1.0]])), (4, 2)):   # number / vector / matrix mixes (:64-86)
+        m = cj.Model(); cj.assemble(m, Pin, qin, con5)
+        assert m.P.shape == (1, 1) and m.q.shape == (1,) and m.P[0, 0] == float(np.ravel(Pin)[0]) and m.q[0] == float(np.ravel(qin)[0])
+    with pytest.raises(ValueError):                                           # constraint with the wrong number of columns (:88-95)
+        cj.assemble(cj.Model(), sp.identity(2, format="csc"), rng.random(2), [cj.Constraint(1.0, 0.0, cj.Nonnegatives)])
+    # model.jl:40-62: scalar and 10 x 10 problems assemble
+    scalar_c = cj.Constraint(1.0, 2.0, cj.ZeroSet)
+    constr = cj.Constraint(np.eye(10), rng.random(10), cj.ZeroSet)
+    for Pin, qin, c in ((4, 2, scalar_c), (4.0, 2.0, scalar_c), (rng.random((10, 10)), rng.random((10, 1)), constr),
+                        (sp.random(10, 10, 0.4, random_state=2), rng.random((10, 1)), constr)):
+        assert cj.assemble(cj.Model(), Pin, qin, [c]) is None
