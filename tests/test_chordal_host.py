@@ -268,3 +268,40 @@ def test_traditional_transformation_is_equivalent(shape):
     # compact transformation leaves square cones alone (the reference's add_entries! is specialised on PsdConeTriangle)
     if shape == "square":
         assert ch.Decomposition(A, b, kinds, dims, merge_strategy=ch.NO_MERGE, compact=True).num_decomposed == 0
+
+
+# ---- the reference's literal LMI instance (test/UnitTests/nuclear_norm_minimization.jl:17-46) -----------------------------------
+def _sigma_max_problem():
+    """min t  s.t.  Y21 <= 4, Y22 >= 3, sum(Y) >= 12, [[t I, Y], [Y', t I]] psd  with x = [t; vec(Y)], Y 3 x 3 -- the Convex.jl
+    problem "sdp_sigma_max_atom" that once broke the compact transformation.  Returns internal (A, b) and cones (user form A x + b in K)."""
+    q = np.concatenate([[1.0], np.zeros(9)])
+    r1 = np.zeros((1, 10)); r1[0, 2] = -1.0
+    r2 = np.zeros((1, 10)); r2[0, 5] = 1.0
+    r3 = np.concatenate([[0.0], np.ones(9)])[None, :]
+    a1 = np.array([-1.0, 0, -1, 0, 0, -1, 0, 0, 0, -1, 0, 0, 0, 0, -1, 0, 0, 0, 0, 0, -1])
+    a2 = np.zeros((21, 9))
+    for row, col in ((7, 1), (8, 2), (9, 3), (11, 4), (12, 5), (13, 6), (16, 7), (17, 8), (18, 9)):   # 1-based in the reference
+        a2[row - 1, col - 1] = -np.sqrt(2.0)
+    A_lmi = np.hstack([a1[:, None], a2])
+    cons = [(r1, np.array([4.0]), O.NONNEG, 1), (r2, np.array([-3.0]), O.NONNEG, 1), (r3, np.array([-12.0]), O.NONNEG, 1), (-A_lmi, np.zeros(21), O.PSD_TRIANGLE, 21)]
+    return q, cons
+
+
+@pytest.mark.parametrize("compact", [True, False])
+def test_sigma_max_lmi_golden_through_the_decomposition(compact):
+    q, cons = _sigma_max_problem()
+    A, b, cones = O.assemble([O.Constraint(Ai, bi, O.Cone(k, d, constr_type=(np.zeros(d, dtype=bool) if k == O.NONNEG else None))) for (Ai, bi, k, d) in cons])
+    kinds = [c.kind for c in cones]; dims = [c.dim for c in cones]
+    dec = ch.Decomposition(A, b, kinds, dims, compact=compact)
+    assert dec.num_decomposed == 1                                   # the 6 x 6 block-arrow LMI is decomposed
+    n_new = dec.n_new
+    P = sp.csc_matrix((n_new, n_new)); qn = np.concatenate([q, np.zeros(n_new - 10)])
+    cones_n = [O.Cone(int(k), int(d), constr_type=(np.zeros(int(d), dtype=bool) if int(k) == O.NONNEG else None)) for k, d in zip(dec.kinds, dec.dims)]
+    r = O.solve(P, qn, dec.A, dec.b, cones_n, O.Settings(eps_abs=1e-5, eps_rel=1e-5))
+    assert r.status == "Solved"
+    Y = r.x[1:10].reshape(3, 3, order="F"); t = r.x[0]
+    assert Y[1, 0] <= 4 + 1e-3 and Y[1, 1] >= 3 - 1e-3 and Y.sum() - 12.0 >= -1e-3     # nuclear_norm_minimization.jl:39-41
+    assert abs(np.linalg.svd(Y, compute_uv=False).max() - t) <= 1e-3                   # :43-45
+    # and the undecomposed problem gives the same optimum
+    r0 = O.solve(sp.csc_matrix((10, 10)), q, A, b, cones, O.Settings(eps_abs=1e-5, eps_rel=1e-5))
+    assert r0.status == "Solved" and abs(r0.x[0] - t) <= 2e-3
