@@ -460,6 +460,38 @@ class Model:
         self.chordal = None
 
 
+def convex_sets_from_dict(cone: dict, l=None, u=None) -> List[AbstractConvexSet]:
+    """`convex_sets_from_dict` (src/interface.jl:312-367): the SCS-style cone dictionary of the cosmo-python interface --
+    "f" ZeroSet, "l" Nonnegatives, "q" SecondOrderCones, "s" PsdConeTriangles, "ep" / "ed" (dual) exponential cones, "p" power cones
+    (negative exponent = dual), "b" Box(l, u) -- in this fixed order."""
+    sets: List[AbstractConvexSet] = []
+    if "f" in cone:
+        sets.append(ZeroSet(int(cone["f"])))
+    if "l" in cone:
+        sets.append(Nonnegatives(int(cone["l"])))
+    for d in np.atleast_1d(cone.get("q", [])):
+        sets.append(SecondOrderCone(int(d)))
+    for d in np.atleast_1d(cone.get("s", [])):
+        sets.append(PsdConeTriangle(int(d)))
+    sets += [ExponentialCone() for _ in range(int(cone.get("ep", 0)))]
+    sets += [DualExponentialCone() for _ in range(int(cone.get("ed", 0)))]
+    for e in np.atleast_1d(cone.get("p", [])):
+        sets.append(PowerCone(float(e)) if e >= 0 else DualPowerCone(-1.0 * float(e)))
+    if "b" in cone:
+        sets.append(Box(l, u))
+    return sets
+
+
+def set_csc(model: Model, P_rowval, P_colptr, P_nzval, q, A_rowval, A_colptr, A_nzval, b, cone: dict, l, u, m: int, n: int,
+            settings: Optional[Settings] = None):
+    """`set!(model, Prowval, Pcolptr, Pnzval, q, Arowval, Acolptr, Anzval, b, cone, l, u, m, n[, settings])`
+    (src/interface.jl:252-301): raw CSC triplets (0-based here, as cosmo-python passes them before `juliafy_integers`) in the
+    internal convention A x + s = b plus the cone dictionary."""
+    P = sp.csc_matrix((np.asarray(P_nzval, dtype=np.float64), np.asarray(P_rowval, dtype=np.int64), np.asarray(P_colptr, dtype=np.int64)), shape=(n, n))
+    A = sp.csc_matrix((np.asarray(A_nzval, dtype=np.float64), np.asarray(A_rowval, dtype=np.int64), np.asarray(A_colptr, dtype=np.int64)), shape=(m, n))
+    model.set(P, q, A, b, convex_sets_from_dict(cone, l, u), settings)
+
+
 def assemble(model: Model, P, q, constraints: Union[Constraint, Sequence[Constraint]], settings: Optional[Settings] = None,
              x0=None, y0=None):
     """`assemble!` (src/interface.jl:30-77): merge Zero/Nonnegatives constraints, stable-sort the sets

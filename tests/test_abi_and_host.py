@@ -221,3 +221,21 @@ def test_interface_set_and_assemble_mirror_the_reference():
     for Pin, qin, c in ((4, 2, scalar_c), (4.0, 2.0, scalar_c), (rng.random((10, 10)), rng.random((10, 1)), constr),
                         (sp.random(10, 10, 0.4, random_state=2), rng.random((10, 1)), constr)):
         assert cj.assemble(cj.Model(), Pin, qin, [c]) is None
+
+
+def test_cosmo_python_interface_helpers():
+    """test/UnitTests/interface_python.jl:9-33: the SCS-style cone dictionary and the raw-CSC set! of the cosmo-python interface."""
+    cone = {"f": 2, "l": 3, "q": [3, 4], "s": [3, 6, 10], "ep": 2, "ed": 1, "p": [0.3, -0.4], "b": 2}
+    sets = cj.convex_sets_from_dict(cone, -np.array([0.3, 0.6]), np.array([0.2, 0.9]))
+    assert isinstance(sets[2], cj.SecondOrderCone) and sets[2].dim == 3            # :12-13 (1-based 3)
+    assert isinstance(sets[5], cj.PsdConeTriangle)                                  # :14
+    assert type(sets[10]) is cj.PowerCone and sets[10].alpha == 0.3                 # :15-16
+    assert type(sets[11]) is cj.DualPowerCone and sets[11].alpha == 0.4
+    assert isinstance(sets[12], cj.Box) and len(sets) == 13                         # :17
+    assert [type(K).__name__ for K in sets[:2]] == ["ZeroSet", "Nonnegatives"] and type(sets[9]) is cj.DualExponentialCone
+    P = sp.csc_matrix(np.array([[4.0, 1], [1, 2]])); A1 = np.array([[1.0, 1], [1, 0], [0, 1]]); A = sp.csc_matrix(np.vstack([A1, -A1]))
+    b = np.concatenate([[1, 0.7, 0.7], -np.array([1.0, 0, 0])])
+    model = cj.Model()
+    cj.set_csc(model, P.indices, P.indptr, P.data, np.array([1.0, 1]), A.indices, A.indptr, A.data, b, {"l": 6}, None, None, 6, 2)
+    assert (model.n, model.m) == (2, 6) and type(model.sets[0]) is cj.Nonnegatives and model.sets[0].dim == 6
+    assert np.array_equal(model.A.toarray(), A.toarray()) and np.array_equal(model.P.toarray(), P.toarray())
