@@ -239,3 +239,18 @@ def test_cosmo_python_interface_helpers():
     cj.set_csc(model, P.indices, P.indptr, P.data, np.array([1.0, 1]), A.indices, A.indptr, A.data, b, {"l": 6}, None, None, 6, 2)
     assert (model.n, model.m) == (2, 6) and type(model.sets[0]) is cj.Nonnegatives and model.sets[0].dim == 6
     assert np.array_equal(model.A.toarray(), A.toarray()) and np.array_equal(model.P.toarray(), P.toarray())
+
+
+def test_headers_are_plain_c():
+    """The drop-in boundary is a C ABI: both headers must compile as strict C99 (no C++ constructs, no torch / HIP types)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    for name in ("cosmo_hip.h", "cosmo_chordal.h"):
+        path = os.path.join(ROOT, "include", name)
+        r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", path], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        txt = open(path).read()
+        assert "torch" not in txt and "hipStream" not in txt and "#include <hip" not in txt
