@@ -254,3 +254,26 @@ def test_headers_are_plain_c():
         assert r.returncode == 0, r.stderr
         txt = open(path).read()
         assert "torch" not in txt and "hipStream" not in txt and "#include <hip" not in txt
+
+
+def test_plain_c_client_links_and_runs():
+    """tests/c_client/abi_example.c compiled with gcc against both shared libraries: defaults readable from C, and without a GPU
+    cosmo_hip_create fails loudly instead of falling back to a CPU path."""
+    import shutil
+    import subprocess
+    import tempfile
+    gcc = shutil.which("gcc")
+    if gcc is None or not os.path.exists(cj._ffi.LIB_PATH):
+        pytest.skip("gcc or the library not available")
+    libdir = os.path.dirname(cj._ffi.LIB_PATH)
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "abi_example")
+        r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_client", "abi_example.c"),
+                            "-o", exe, "-L", libdir, "-lcosmo_hip", "-lcosmo_chordal", "-Wl,-rpath," + libdir], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        assert "version=1000 alpha=1.6 max_iter=5000 check_termination=25 accel_mem=15 merge=2 obj_true_is_nan=1" in out.stdout
+        import torch
+        if not torch.cuda.is_available():
+            assert "create_rc=2" in out.stdout                                # COSMO_HIP_ERR_HIP: no device, no fallback
