@@ -77,6 +77,19 @@ def cpu_baseline(prob, st_kwargs, sample_iters):
                        % (impl, iters, secs, cg))
 
 
+def max_over_ranks(elapsed, dist, device):
+    """The bench contract's timing rule: every rank times its own K steps, the job's time is the MAX over the ranks."""
+    import torch
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def whole_job_value(world, steps, elapsed):
+    """Aggregate throughput of `world` replicas that each did `steps` iterations in `elapsed` seconds (weak scaling)."""
+    return world * steps / elapsed
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,15 +146,13 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = max_over_ranks(elapsed, dist, "cuda")
         dist.barrier()
     stats1 = h.get_stats()
     steps_done = stats1["admm_iters"] - stats0["admm_iters"]
     assert steps_done == args.steps, (steps_done, args.steps)
     kbar = (stats1["kkt_iters_total"] - stats0["kkt_iters_total"]) / max(1, stats1["kkt_solves"] - stats0["kkt_solves"])
-    value = world * args.steps / elapsed
+    value = whole_job_value(world, args.steps, elapsed)
 
     out = None
     if rank == 0:

@@ -82,3 +82,30 @@ def test_contiguous_cone_partition():
         assert max(loads) >= max(max(costs), -(-sum(costs) // world)) and max(loads) <= max(costs) + sum(costs) // world + 1
     sets = [cj.ZeroSet(3), cj.Nonnegatives(4), cj.SecondOrderCone(5), cj.PsdConeTriangle(10), cj.PsdCone(9), cj.PsdConeTriangle(1)]
     assert cj.cone_costs(sets) == [0, 0, 5, 64, 27, 0]
+
+
+def _bench_timing_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    dist.barrier()
+    mine = 0.5 + 0.25 * rank                                 # rank 1 is the slow one
+    job = bench.max_over_ranks(mine, dist, "cpu")
+    q.put((rank, job, bench.whole_job_value(world, 10, job)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_timing_rule_max_over_ranks_gloo():
+    """bench.py's contract: K steps per rank bracketed by barriers, the job time is the MAX over ranks, `value` is the whole-job
+    aggregate (replicas: world * K / time).  The two helpers are the ones bench.py itself calls (there with device = "cuda")."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_bench_timing_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    got = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs: p.join(timeout=60)
+    assert [g[1] for g in got] == [0.75, 0.75]
+    assert all(abs(g[2] - 2 * 10 / 0.75) < 1e-12 for g in got)
