@@ -162,9 +162,24 @@ static int union_dim(const IntSet& a, const IntSet& b) { return (int)a.size() + 
 void compute_reduced_clique_graph(std::vector<IntSet>& sep, const std::vector<IntSet>& snd, std::vector<int>& rows, std::vector<int>& cols) {
   std::stable_sort(sep.begin(), sep.end(), [](const IntSet& a, const IntSet& b) { return a.size() > b.size(); });
   rows.clear(); cols.clear();
+  // vertex -> cliques containing it (ascending clique index): the cliques that contain a separator are found among the cliques
+  // of its rarest vertex instead of by a scan over all cliques (same set, same ascending order as findall in the reference)
+  int maxv = -1;
+  for (const IntSet& c : snd) if (!c.empty()) maxv = std::max(maxv, *c.rbegin());
+  std::vector<std::vector<int>> occ((size_t)(maxv + 1));
+  for (int c = 0; c < (int)snd.size(); ++c) for (int v : snd[c]) occ[(size_t)v].push_back(c);
   for (const IntSet& separator : sep) {
     std::vector<int> clique_ind;
-    for (int c = 0; c < (int)snd.size(); ++c) if (is_subset(separator, snd[c])) clique_ind.push_back(c);
+    if (separator.empty()) {
+      for (int c = 0; c < (int)snd.size(); ++c) clique_ind.push_back(c);
+    } else {
+      int vbest = -1;
+      for (int v : separator) {
+        if (v < 0 || v > maxv) { vbest = -2; break; }                        // a vertex no clique holds: no clique contains the separator
+        if (vbest < 0 || occ[(size_t)v].size() < occ[(size_t)vbest].size()) vbest = v;
+      }
+      if (vbest >= 0) for (int c : occ[(size_t)vbest]) if (is_subset(separator, snd[c])) clique_ind.push_back(c);
+    }
     // separator graph H: two cliques are adjacent when their intersection is strictly larger than the separator (:59-87)
     std::map<int, std::vector<int>> H;
     for (int c : clique_ind) H[c];
