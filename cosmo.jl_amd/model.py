@@ -106,6 +106,10 @@ class Settings:
     accelerator_activation: object = 2  # 2 = ImmediateActivation; int k = IterActivation(k); AccuracyActivation(eps)
     safeguard: bool = True
     safeguard_tol: float = 2.0
+    # accepted for drop-in compatibility with COSMO.Settings (src/settings.jl:101-139); they do not touch the hot path:
+    nearly_ratio: float = 100.0            # only read by the MOI wrapper (is_primal_nearly_feasible, src/MOI_wrapper.jl:558,587)
+    adaptive_rho_fraction: float = 0.4     # only with adaptive_rho_interval = 0 (wall-clock rule, rejected by the device loop)
+    verbose_timing: bool = False           # the device loop always reports iter_time / proj_time
 
 
 # ---- AbstractConvexSet subtypes on the hot path (src/convexset.jl) ---------------------------------------------------
