@@ -277,3 +277,14 @@ def test_plain_c_client_links_and_runs():
         import torch
         if not torch.cuda.is_available():
             assert "create_rc=2" in out.stdout                                # COSMO_HIP_ERR_HIP: no device, no fallback
+
+
+def test_scripts_compile():
+    """bench.py, __graft_entry__.py and every helper under tools/ at least parse (they only run on a GPU box)."""
+    import glob
+    import py_compile
+    files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")] + sorted(glob.glob(os.path.join(ROOT, "tools", "*.py"))) + \
+        sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.py")))
+    assert len(files) >= 10
+    for f in files:
+        py_compile.compile(f, doraise=True, cfile=os.path.join(os.environ.get("TMPDIR", "/tmp"), "cosmo_pyc_" + os.path.basename(f) + "c"))
