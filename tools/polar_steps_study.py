@@ -28,7 +28,10 @@ def polar_project(X, k1, k2=4):
 
 d = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 150
-p = cj.problems.closest_correlation(d=d, seed=4)
+if len(sys.argv) > 3 and sys.argv[3] == "chordal":          # a small decomposed SDP: many cliques of side d/2 .. d
+    p = cj.problems.chordal_sdp(ncliques=12, dmin=max(4, d // 2), dmax=d, n_total=600, n_zero=20, n_nonneg=60, seed=6)
+else:
+    p = cj.problems.closest_correlation(d=d, seed=4)
 captured = []
 orig = O._psd_project_dense
 
@@ -42,7 +45,7 @@ O._psd_project_dense = spy
 ws = O.Workspace(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), O.Settings(max_iter=iters, eps_abs=0, eps_rel=0, check_infeasibility=10 ** 9))
 ws.optimize()
 O._psd_project_dense = orig
-print("captured %d projections of a %d x %d cone" % (len(captured), d, d))
+print("captured %d projections (cone sides %d .. %d)" % (len(captured), min(len(X) for X in captured), max(len(X) for X in captured)))
 sample = captured[:: max(1, len(captured) // 40)]
 lam_rel = []
 for X in sample:
