@@ -120,11 +120,16 @@ SIGNATURES = {
     "cosmo_hip_get_kernel_times": (C.c_int32, [C.c_void_p, _PD, _PI64]),
     "cosmo_hip_kernel_class_name": (C.c_char_p, [C.c_int32]),
     "cosmo_hip_psd_stats": (C.c_int32, [C.c_void_p, _PI64]),
+    "cosmo_hip_polar_stats": (C.c_int32, [C.c_void_p, _PI64]),
+    "cosmo_hip_polar_schedule": (C.c_int32, [C.c_int32, _PD, _PI32]),
+    "cosmo_hip_time_psd_product": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _PD, _PD]),
     "cosmo_hip_comm_unique_id": (C.c_int32, [C.POINTER(C.c_uint8)]),
     "cosmo_hip_comm_init": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]),
     "cosmo_hip_comm_destroy": (C.c_int32, [C.c_void_p]),
     "cosmo_hip_set_cone_shard": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_comm_selftest": (C.c_int32, [C.c_void_p]),
+    "cosmo_hip_comm_init_hostshm": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p]),
+    "cosmo_hip_comm_stats": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_set_cone_ownership": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int64]),
     "cosmo_hip_batch_create": (C.c_int32, [C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_int64, C.c_int64]),
     "cosmo_hip_batch_destroy": (C.c_int32, [C.c_void_p]),
@@ -394,6 +399,20 @@ class Handle:
         self._chk(self.lib.cosmo_hip_psd_stats(self._h, out.ctypes.data_as(_PI64)))
         return dict(zip(["max_sweeps_wg", "sweeps_large", "not_converged", "ncones"], out.tolist()))
 
+    POLAR_STAT_KEYS = ["large_cones", "batch_cones", "tile_side", "k_split", "launches_64_1", "launches_96_1", "launches_96_2", "launches_batch",
+                       "products_last_large", "fallback_rounds", "verified", "products_last_batch", "schedule_steps", "unverified", "projections",
+                       "err_max_e18"]
+
+    def polar_stats(self):
+        out = np.zeros(16, dtype=np.int64)
+        self._chk(self.lib.cosmo_hip_polar_stats(self._h, out.ctypes.data_as(_PI64)))
+        return dict(zip(self.POLAR_STAT_KEYS, out.tolist()))
+
+    def time_psd_product(self, which=0, reps=20):
+        t = C.c_double(0); fl = C.c_double(0)
+        self._chk(self.lib.cosmo_hip_time_psd_product(self._h, int(which), int(reps), C.byref(t), C.byref(fl)))
+        return t.value, fl.value
+
     # ---- clique sharding -----------------------------------------------------------------------------------------
     @staticmethod
     def comm_unique_id():
@@ -416,6 +435,14 @@ class Handle:
 
     def comm_selftest(self):
         self._chk(self.lib.cosmo_hip_comm_selftest(self._h))
+
+    def comm_init_hostshm(self, rank, nranks, name: str):
+        self._chk(self.lib.cosmo_hip_comm_init_hostshm(self._h, int(rank), int(nranks), name.encode()))
+
+    def comm_stats(self):
+        out = np.zeros(4, dtype=np.int64)
+        self._chk(self.lib.cosmo_hip_comm_stats(self._h, out.ctypes.data_as(_PI64)))
+        return dict(zip(["nranks", "rank", "exchanges", "transport"], out.tolist()))
 
     def set_profiling(self, on):
         self._chk(self.lib.cosmo_hip_set_profiling(self._h, int(on)))

@@ -858,6 +858,7 @@ static int32_t run_until(cosmo_hip_handle* h, long long target, int check_mode) 
     }
     adapt_budget(h);
     hipLaunchKernelGGL(k_ctl_reset_kmax, dim3(1), dim3(1), 0, h->stream, h->ctl);
+    if (h->psd_polar) CHK(polar_adapt(h));
     return COSMO_HIP_OK;
   }
 }

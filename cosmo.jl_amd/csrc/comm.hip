@@ -12,8 +12,15 @@
 // RCCL is loaded lazily with dlopen so that the library has no RCCL dependency for single-GPU use and shares the RCCL
 // instance of the hosting process (torch bundles its own librccl.so; loading a second copy would clash).
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sched.h>
 #include <stdarg.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+#include <atomic>
 #include "internal.h"
 
 typedef struct { char internal[128]; } nccl_uid_t;
@@ -60,13 +67,50 @@ static const char* rccl_load() {
       return cosmo_fail((h), COSMO_HIP_ERR_COMM, "%s failed: %s", #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(r__) : "?"); \
   } while (0)
 
+// Host-staged transport (cosmo_hip_comm_init_hostshm): the ranks are processes that may share ONE GPU (RCCL refuses two ranks
+// on one device), the slices travel through a POSIX shared-memory segment.  It exists so that the sharded loop -- ownership
+// ranges, row_lo / row_hi slices, the exchange point of the iteration, the flag reduction of the certificates -- executes with
+// nranks > 1 on a single-GPU box; it is synchronous and slow by construction and is not a production path.
+#define COSMO_SHM_MAX_RANKS 16
+struct ShmSeg {
+  std::atomic<int> arrive;     // sense-reversing barrier
+  std::atomic<int> gen;
+  int flag[COSMO_SHM_MAX_RANKS];
+  long long capacity;          // doubles in data[]
+  double data[1];
+};
+
 struct CommState {
   nccl_comm_t comm = nullptr;
   int rank = 0, nranks = 1;
   std::vector<long long> first_cone;   // nranks + 1 boundaries (cone indices)
   std::vector<long long> row_lo, row_hi;
   int* d_flag = nullptr;               // 2 ints: send / receive buffer of comm_allreduce_flag
+  // host-staged transport
+  ShmSeg* shm = nullptr;
+  size_t shm_bytes = 0;
+  std::string shm_name;
+  long long exchanges = 0;             // exchange steps executed with nranks > 1 (cosmo_hip_comm_stats)
 };
+
+static int32_t shm_barrier(cosmo_hip_handle* h, CommState* c) {
+  ShmSeg* g = c->shm;
+  const int gen = g->gen.load(std::memory_order_acquire);
+  if (g->arrive.fetch_add(1, std::memory_order_acq_rel) == c->nranks - 1) {
+    g->arrive.store(0, std::memory_order_relaxed);
+    g->gen.store(gen + 1, std::memory_order_release);
+    return COSMO_HIP_OK;
+  }
+  timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (long spin = 0; g->gen.load(std::memory_order_acquire) == gen; ++spin) {
+    sched_yield();
+    if ((spin & 1023) == 1023) {
+      timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+      if (t1.tv_sec - t0.tv_sec > 60) return cosmo_fail(h, COSMO_HIP_ERR_COMM, "host-staged barrier timed out (a peer rank died?)");
+    }
+  }
+  return COSMO_HIP_OK;
+}
 
 extern "C" int32_t cosmo_hip_comm_unique_id(uint8_t id[128]) {
   if (!id) return COSMO_HIP_ERR_INVALID;
@@ -81,6 +125,7 @@ extern "C" int32_t cosmo_hip_comm_destroy(cosmo_hip_handle* h) {
   if (!h || !h->comm) return COSMO_HIP_OK;
   CommState* c = (CommState*)h->comm;
   if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+  if (c->shm) { (void)munmap(c->shm, c->shm_bytes); if (c->rank == 0) (void)shm_unlink(c->shm_name.c_str()); }
   if (c->d_flag) (void)hipFree(c->d_flag);
   delete c;
   h->comm = nullptr;
@@ -101,6 +146,49 @@ extern "C" int32_t cosmo_hip_comm_init(cosmo_hip_handle* h, int32_t rank, int32_
   const int rc = g_rccl.CommInitRank(&c->comm, nranks, u, rank);
   if (rc != 0) { delete c; return cosmo_fail(h, COSMO_HIP_ERR_COMM, "ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"); }
   h->comm = c;
+  return COSMO_HIP_OK;
+}
+
+// Host-staged communicator (see ShmSeg): `name` is a POSIX shared-memory name ("/cosmo_...") unique to the job; rank 0 creates
+// the segment, the other ranks attach.  Requires set_problem (the segment holds m doubles).
+extern "C" int32_t cosmo_hip_comm_init_hostshm(cosmo_hip_handle* h, int32_t rank, int32_t nranks, const char* name) {
+  if (!h || !name || name[0] != '/' || nranks < 1 || nranks > COSMO_SHM_MAX_RANKS || rank < 0 || rank >= nranks)
+    return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "comm_init_hostshm: bad arguments");
+  if (!h->have_problem) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "comm_init_hostshm: set_problem first");
+  (void)cosmo_hip_comm_destroy(h);
+  CommState* c = new CommState();
+  c->rank = rank; c->nranks = nranks; c->shm_name = name;
+  const long long cap = h->m > 0 ? h->m : 1;
+  c->shm_bytes = sizeof(ShmSeg) + sizeof(double) * (size_t)cap;
+  int fd = -1;
+  if (rank == 0) {
+    (void)shm_unlink(name);
+    fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)c->shm_bytes) != 0) { if (fd >= 0) close(fd); delete c; return cosmo_fail(h, COSMO_HIP_ERR_COMM, "shm_open/ftruncate(%s) failed", name); }
+  } else {
+    for (int tries = 0; tries < 6000 && fd < 0; ++tries) {          // wait (<= 60 s) for rank 0 to create and size the segment
+      fd = shm_open(name, O_RDWR, 0600);
+      if (fd >= 0) { struct stat sb; if (fstat(fd, &sb) != 0 || (size_t)sb.st_size < c->shm_bytes) { close(fd); fd = -1; } }
+      if (fd < 0) usleep(10000);
+    }
+    if (fd < 0) { delete c; return cosmo_fail(h, COSMO_HIP_ERR_COMM, "cannot attach to shared segment %s", name); }
+  }
+  void* p = mmap(nullptr, c->shm_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) { delete c; return cosmo_fail(h, COSMO_HIP_ERR_COMM, "mmap of %s failed", name); }
+  c->shm = (ShmSeg*)p;
+  if (rank == 0) c->shm->capacity = cap;       // ftruncate zero-filled the barrier words
+  h->comm = c;
+  return shm_barrier(h, c);                    // everybody attached
+}
+
+// out = {nranks, rank, exchange steps executed with nranks > 1, transport (0 none, 1 RCCL, 2 host-staged)}
+extern "C" int32_t cosmo_hip_comm_stats(cosmo_hip_handle* h, int64_t out[4]) {
+  if (!h || !out) return COSMO_HIP_ERR_INVALID;
+  out[0] = 1; out[1] = 0; out[2] = 0; out[3] = 0;
+  if (!h->comm) return COSMO_HIP_OK;
+  const CommState* c = (const CommState*)h->comm;
+  out[0] = c->nranks; out[1] = c->rank; out[2] = c->exchanges; out[3] = c->shm ? 2 : 1;
   return COSMO_HIP_OK;
 }
 
@@ -144,6 +232,22 @@ int32_t comm_enqueue_exchange(cosmo_hip_handle* h, double* s) {
   if (!h->comm) return COSMO_HIP_OK;
   CommState* c = (CommState*)h->comm;
   if (c->nranks == 1 || c->first_cone.empty()) return COSMO_HIP_OK;
+  c->exchanges += 1;
+  if (c->shm) {
+    // host-staged: owner slice -> segment, barrier, the other ranks' slices <- segment, barrier (the segment is reused next time)
+    const long long lo = c->row_lo[c->rank], hi = c->row_hi[c->rank];
+    if (hi > c->shm->capacity) return cosmo_fail(h, COSMO_HIP_ERR_COMM, "shared segment too small");
+    if (hi > lo) HIPCHK(h, hipMemcpyAsync(c->shm->data + lo, s + lo, sizeof(double) * (size_t)(hi - lo), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    CHK(shm_barrier(h, c));
+    for (int r = 0; r < c->nranks; ++r) {
+      const long long cnt = c->row_hi[r] - c->row_lo[r];
+      if (r == c->rank || cnt <= 0) continue;
+      HIPCHK(h, hipMemcpyAsync(s + c->row_lo[r], c->shm->data + c->row_lo[r], sizeof(double) * (size_t)cnt, hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return shm_barrier(h, c);
+  }
   NCHK(h, g_rccl.GroupStart());
   for (int r = 0; r < c->nranks; ++r) {
     const long long cnt = c->row_hi[r] - c->row_lo[r];
@@ -161,6 +265,16 @@ int32_t comm_enqueue_exchange(cosmo_hip_handle* h, double* s) {
 int32_t comm_allreduce_flag(cosmo_hip_handle* h, int* flag) {
   if (!h->comm) return COSMO_HIP_OK;
   CommState* c = (CommState*)h->comm;
+  if (c->shm) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    c->shm->flag[c->rank] = *flag;
+    CHK(shm_barrier(h, c));
+    int v = 0;
+    for (int r = 0; r < c->nranks; ++r) v = c->shm->flag[r] > v ? c->shm->flag[r] : v;
+    CHK(shm_barrier(h, c));
+    *flag = v;
+    return COSMO_HIP_OK;
+  }
   if (!c->d_flag) HIPCHK(h, hipMalloc((void**)&c->d_flag, 2 * sizeof(int)));
   HIPCHK(h, hipMemcpyAsync(c->d_flag, flag, sizeof(int), hipMemcpyHostToDevice, h->stream));
   NCHK(h, g_rccl.AllReduce(c->d_flag, c->d_flag + 1, 1, 2, 2, c->comm, h->stream));
@@ -175,6 +289,7 @@ extern "C" int32_t cosmo_hip_comm_selftest(cosmo_hip_handle* h) {
   if (!h || !h->comm || !h->have_iterates) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "comm_selftest: comm_init and set_iterates first");
   CommState* c = (CommState*)h->comm;
   if (hipSetDevice(h->device) != hipSuccess) return cosmo_fail(h, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
+  if (c->shm) return shm_barrier(h, c);
   NCHK(h, g_rccl.GroupStart());
   NCHK(h, g_rccl.Broadcast(h->s, h->s, (size_t)h->m, NCCL_FLOAT64, 0, c->comm, h->stream));
   NCHK(h, g_rccl.GroupEnd());

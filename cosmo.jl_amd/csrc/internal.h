@@ -236,6 +236,7 @@ void polar_plan_destroy(cosmo_hip_handle* h);
 bool polar_enabled(const cosmo_hip_handle* h);
 int32_t polar_enqueue_project(cosmo_hip_handle* h, double* s, int guard);
 int32_t polar_enqueue_project_batch(cosmo_hip_handle* h, double* s, int guard);
+int32_t polar_adapt(cosmo_hip_handle* h);   // host-side schedule adaptation at a synchronisation point
 bool polar_has_batch(const cosmo_hip_handle* h);
 bool polar_has_large(const cosmo_hip_handle* h);
 

@@ -1,24 +1,34 @@
-// psd_polar.hip -- PSD projection of LARGE cones (d > 256) as a matrix-sign (polar) iteration made only of symmetric
-// matrix products on the fp64 matrix cores.
+// psd_polar.hip -- PSD projection of LARGE cones (d > 256, one cone at a time) and of MID-SIZE cones (64 < d <= 256, batched) as a
+// matrix-sign (polar) iteration made only of symmetric matrix products on the fp64 matrix cores.
 //
 // Reference semantics (src/convexset.jl:219-263): X+ = sum_{lambda_j > 0} lambda_j z_j z_j'.  For symmetric X this is
 //     X+ = (X + |X|) / 2 ,  |X| = sign(X) X ,  sign(X) = Z sign(Lambda) Z'
-// so the projection needs the matrix sign U = sign(X), not the eigenvectors.  U is the limit of an odd polynomial fixed-point
-// iteration  U <- U (a I + b U^2 + c U^4), U_0 = X / ||X||_F  (all iterates are polynomials in X: symmetric, commuting):
-//   phase 1 (k1 = 20 steps): (a, b, c) = (3.4445, -4.7750, 2.0315) -- slope 3.44 at 0, maps [0, 1.2] into [0, 1.21] and ends in
-//                            [0.68, 1.21]; lifts every |lambda| >= delta ||X||_F with delta ~ 3e-12 into that interval;
-//   phase 2 (k2 = 4 steps):  Newton-Schulz quintic (15, -10, 3)/8, cubically convergent to +-1: from the worst point of the
-//                            phase-1 interval, 0.68, the error goes 6e-2, 6e-4, 7e-10, 7e-28 (three steps leave 1e-10: measured).
-// Eigenvalues below delta ||X||_F are left with |sign| < 1, which perturbs X+ by less than their own magnitude.  Measured
-// ||dX+||_F / ||X||_F = 2e-15 on random symmetric matrices and <= 6e-13 on spectra spread over 1e-14 .. 1 (NumPy prototype
-// and tests), i.e. inside the 64 d eps bound the tests use for the Jacobi path.  rank = round((tr U + tr U^2) / 2) (exact
-// unless eigenvalues below the delta cut-off exist; exact zeros count as not positive, like the reference's lambda > 0).
+// so the projection needs the matrix sign U = sign(X), not the eigenvectors.  U is the limit of odd quintic fixed-point steps
+//     U <- U (a I + b U^2 + c U^4),  U_0 = 2 X / ||X||_F   (all iterates are polynomials in X: symmetric, commuting, spectrum in [0, 2])
+// with PER-STEP minimax-optimal coefficients (round 2; design tool tools/polar_schedule.py, which the CPU test
+// tests/test_polar_schedule.py replays against the table exported by cosmo_hip_polar_schedule):
+//   lifting   (k_lift steps, default 10): the minimax odd quintic p for [l*, 2.1], l* = 0.02212 chosen so that p maps [l*, 2.1] into
+//             [0.085, 1.915] (5 % margin at the top: rounding cannot push an eigenvalue out of the domain; the interior minimum
+//             of p equals p(l*) = 0.085, so an eigenvalue that is already lifted can never fall back below the finishing range --
+//             the l -> 0 limit polynomial, slope 4.05, has an interior ROOT and is unusable); slope 3.8438 at 0 and
+//             p(x) >= 0.9996 * 3.8438 x on [0, l*], so k steps lift every |lambda| >= 0.0425 * 3.8426^-k ||X||_F above 0.085
+//             (k = 10: 6e-8 ||X||_F; the round-1 fixed triple had slope 3.44 and needed 20 steps for its 3e-12);
+//   finishing (5 steps): the greedy minimax sequence for [0.08, 2.02] -> [0.28, 1.72] -> [0.71, 1.29] -> 1 +- 1.6e-2 -> 1 +- 1e-5
+//             -> 1 +- 2e-15 (the last two are the Newton-Schulz quintic (15, -10, 3) / 8, cubically convergent).
+// A-posteriori VERIFICATION (one extra product): with H = U X (needed anyway) the matrix G = U H - X = (U^2 - I) X has
+//     ||G||_F^2 = sum lambda_i^2 (1 - u_i^2)^2  >=  sum lambda_i^2 (1 - |u_i|)^2 = 4 ||X+ - X+_exact||_F^2,
+// so ||G||_F / 2 bounds the projection error rigorously (up to the rounding of the products, ~1e-15 ||X||_F).  If it exceeds
+// 8 d eps ||X||_F (1/8 of the parity tolerance 64 d eps), guarded FALLBACK rounds (3 more lifting steps + the finishing steps,
+// verified again) run on the device without host involvement: their launches are enqueued with the projection and return at
+// once unless the verification kernel opened the gate.  Eigenvalues so small that they never lift (|lambda| below
+// ~1e-12 ||X||_F) perturb X+ by less than their own magnitude and pass the verification by construction.
+// rank = round((tr U + tr U^2) / 2) (exact when every eigenvalue was lifted; exact zeros count as not positive, like lambda > 0).
 //
 // Why this shape on MI355X: one-sided Jacobi at d = 2000 is ~3000 dependent tournament rounds of latency-bound 16x16
 // rotations (135-180 ms, 1 % MFMA-busy, profiles/r01_psd_mfma_counters.json); a tridiagonal QL/D&C chain is serial.  The sign
-// iteration is 76 products of d x d symmetric matrices whose result is symmetric, so only the upper 64x64 tiles are
-// computed (d^3 flops per product) and mirrored: fixed schedule, no host synchronisation, every kernel guarded by ctl->halt
-// like the rest of the loop.
+// iteration is (k_lift + 5) * 3 + 2 = 47 products of d x d symmetric matrices whose result is symmetric, so only the upper
+// tiles are computed (d^3 flops per product) and mirrored: fixed schedule, no host synchronisation, every kernel guarded by
+// ctl->halt like the rest of the loop.
 //
 // Kernel: k_symm_gemm -- C = alpha A B + beta Cin on the upper tiles, A and B symmetric (so both operands are read
 // "contiguous along the output index, strided along k"), 64x64 tile per workgroup of 4 waves (32x32 per wave = 2x2
@@ -28,6 +38,7 @@
 #include "psd_internal.h"
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 #include <algorithm>
 
 #define PK 16   // k panel
@@ -44,12 +55,40 @@ struct PolarCone {
 
 struct BatchCone { long long woff; int off, d, kind, ld, idx, pad; };   // a mid-size cone of the batched path (device table)
 
+// device-side control of the verification / fallback rounds (one per plan; the large cones are projected one after the other)
+struct PolarDev {
+  int gate;          // 1: the last verification failed, the next guarded round must run
+  int rounds;        // fallback rounds executed so far
+  int verified;      // projections (large cone or whole batch) whose error bound passed
+  int unverified;    // ... that still failed after the last enqueued round
+  int projections;
+  int pad[3];
+  double err_last, err_max;   // ||G||_F / (2 ||X||_F) of the last verification, max over all
+};
+
+// schedule constants (tools/polar_schedule.py)
+static const double kPolarLift[3] = {3.8438259784376458, -2.5414431444903771, 0.42553478492344637};   // minimax on [0.02212, 2.1]: range [0.085, 1.915]
+#define POLAR_NFIN 5
+static const double kPolarFinish[POLAR_NFIN][3] = {
+    {3.4931704678738202, -2.370790022242379, 0.42240833954524776},    // [0.08, 2.02]   -> 1 +- 0.722
+    {2.7077959763108326, -2.015093165601975, 0.45683257965863566},    // [0.278, 1.722] -> 1 +- 0.289
+    {1.9693651031668091, -1.3512768962961363, 0.3852630352029357},    // [0.711, 1.289] -> 1 +- 1.56e-2
+    {1.875, -1.25, 0.375},                                            // Newton-Schulz   -> 1 +- 9.5e-6
+    {1.875, -1.25, 0.375}};                                           //                 -> 1 +- 2.1e-15
+#define POLAR_RLIFT 3        // lifting steps of a fallback round (RLIFT + NFIN is even: the buffer parity is preserved)
+
 struct PolarPlan {
   std::vector<PolarCone> cones;
   double* W = nullptr;       // 4 * ld^2 doubles per cone: X, U, Y, T
   double* parts = nullptr;   // per cone COSMO_MAX_PARTIALS norm partials + trace partials
   double* nrm = nullptr;     // per cone ||X||_F
-  int k1 = 20, k2 = 4;
+  int k_lift = 10;           // lifting steps of the main schedule (COSMO_HIP_POLAR_KLIFT; grows by 3 when fallbacks are frequent)
+  int max_rounds = 2;        // guarded fallback rounds enqueued per projection
+  double tol_factor = 8.0;   // verification threshold tol_factor * d * eps (relative to ||X||_F)
+  PolarDev* dev = nullptr;
+  PolarDev seen;             // host copy at the last polar_adapt
+  long long launches[4] = {0, 0, 0, 0};   // <64,1>, <96,1>, <96,2>, batch
+  int products_last_large = 0, products_last_batch = 0;
   // batch of mid-size cones (one launch per product for all of them)
   std::vector<BatchCone> bcones;
   BatchCone* d_bcones = nullptr;
@@ -57,7 +96,17 @@ struct PolarPlan {
   int nbtiles = 0;
   double* BW = nullptr;
   double* bparts = nullptr;
+  double* bnrm = nullptr;    // per batched cone ||X||_F
 };
+
+extern "C" int32_t cosmo_hip_polar_schedule(int32_t k_lift, double* abc, int32_t* nsteps) {
+  if (k_lift < 0 || k_lift > 64 || !nsteps) return COSMO_HIP_ERR_INVALID;
+  *nsteps = k_lift + POLAR_NFIN;
+  if (!abc) return COSMO_HIP_OK;
+  for (int t = 0; t < k_lift; ++t) for (int q = 0; q < 3; ++q) abc[3 * t + q] = kPolarLift[q];
+  for (int t = 0; t < POLAR_NFIN; ++t) for (int q = 0; q < 3; ++q) abc[3 * (k_lift + t) + q] = kPolarFinish[t][q];
+  return COSMO_HIP_OK;
+}
 
 namespace {
 
@@ -115,13 +164,13 @@ __global__ __launch_bounds__(COSMO_BS) void k_polar_populate(const Ctl* __restri
   if (threadIdx.x == 0) parts[blockIdx.x] = acc;
 }
 
-// U = X / ||X||_F  (U = 0 for X = 0)
+// U = 2 X / ||X||_F  (U = 0 for X = 0): spectrum in [0, 2], the domain of the lifting polynomial
 __global__ __launch_bounds__(COSMO_BS) void k_polar_scale(const Ctl* __restrict__ ctl, int guard, long long n, int nparts, const double* __restrict__ parts,
                                                           const double* __restrict__ X, double* __restrict__ U, double* __restrict__ nrm_out) {
   if (guard && ctl->halt) return;
   __shared__ double red[COSMO_BS / 64];
   const double nf = sqrt(reduce_partials_sum(parts, nparts, red));
-  const double inv = (nf > 0.0) ? 1.0 / nf : 0.0;
+  const double inv = (nf > 0.0) ? 2.0 / nf : 0.0;
   if (blockIdx.x == 0 && threadIdx.x == 0) *nrm_out = nf;
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < n; i += (long long)gridDim.x * COSMO_BS) U[i] = X[i] * inv;
 }
@@ -279,9 +328,11 @@ __device__ __forceinline__ void symm_gemm_tile(const double* __restrict__ A, con
 
 // one large cone: the grid walks its upper tiles
 template <int EPI, int TS, int SK>
-__global__ __launch_bounds__(256 * SK) void k_symm_gemm(const Ctl* __restrict__ ctl, int guard, const double* __restrict__ A, const double* __restrict__ B,
-                                                   const double* __restrict__ Cin, double* __restrict__ C, int ld, int ntiles, double alpha, double beta) {
+__global__ __launch_bounds__(256 * SK) void k_symm_gemm(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ gate, const double* __restrict__ A,
+                                                   const double* __restrict__ B, const double* __restrict__ Cin, double* __restrict__ C, int ld, int ntiles,
+                                                   double alpha, double beta) {
   if (guard && ctl->halt) return;
+  if (gate && !*gate) return;          // fallback round whose verification already passed
   extern __shared__ double smem[];
   // XCD-aware tile order: workgroup b runs on XCD b % 8 (round-robin dispatch), and each XCD has its own 4 MB L2.  Give every
   // XCD a CONTIGUOUS range of the column-major upper-triangle tile list (a few adjacent tile columns: one shared B panel,
@@ -299,10 +350,11 @@ __global__ __launch_bounds__(256 * SK) void k_symm_gemm(const Ctl* __restrict__ 
 
 // a batch of mid-size cones: one workgroup per (cone, upper tile) descriptor; buffers 0..3 of a cone are X, U/Y, Y/U, T
 template <int EPI>
-__global__ __launch_bounds__(256) void k_symm_gemm_batch(const Ctl* __restrict__ ctl, int guard, const int4* __restrict__ tiles,
+__global__ __launch_bounds__(256) void k_symm_gemm_batch(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ gate, const int4* __restrict__ tiles,
                                                          const BatchCone* __restrict__ cones, double* __restrict__ W, int ia, int ib, int icin, int ic,
                                                          double alpha, double beta) {
   if (guard && ctl->halt) return;
+  if (gate && !*gate) return;
   extern __shared__ double smem[];
   const int4 td = tiles[blockIdx.x];
   if (td.x < 0) return;                      // padding of the XCD-interleaved tile list
@@ -314,21 +366,53 @@ __global__ __launch_bounds__(256) void k_symm_gemm_batch(const Ctl* __restrict__
 }
 
 template <int EPI, int TS, int SK>
-static void launch_symm_gemm(cosmo_hip_handle* h, int guard, const double* A, const double* B, const double* Cin, double* C, int ld, double alpha,
-                             double beta) {
+static void launch_symm_gemm(cosmo_hip_handle* h, int guard, const int* gate, const double* A, const double* B, const double* Cin, double* C, int ld,
+                             double alpha, double beta) {
   const int nt = ld / TS, ntiles = nt * (nt + 1) / 2;
   constexpr int smem = (SK == 2) ? GemmCfg<TS>::SMEM2 : GemmCfg<TS>::SMEM;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_symm_gemm<EPI, TS, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_set = true; }
-  hipLaunchKernelGGL((k_symm_gemm<EPI, TS, SK>), dim3(((ntiles + 7) / 8) * 8), dim3(256 * SK), smem, h->stream, h->ctl, guard, A, B, Cin, C, ld, ntiles,
-                     alpha, beta);
+  hipLaunchKernelGGL((k_symm_gemm<EPI, TS, SK>), dim3(((ntiles + 7) / 8) * 8), dim3(256 * SK), smem, h->stream, h->ctl, guard, gate, A, B, Cin, C, ld,
+                     ntiles, alpha, beta);
+  static_cast<PolarPlan*>(h->psd_polar)->launches[TS == 64 ? 0 : (SK == 2 ? 2 : 1)] += 1;
 }
 // ts: tile side; sk: 1 or 2 (intra-workgroup split of k, only with ts = 96)
-static void symm_gemm(cosmo_hip_handle* h, int guard, int ts, int sk, int epi, const double* A, const double* B, const double* Cin, double* C, int ld,
-                      double alpha, double beta) {
-  if (ts == 96 && sk == 2) { if (epi) launch_symm_gemm<1, 96, 2>(h, guard, A, B, Cin, C, ld, alpha, beta); else launch_symm_gemm<0, 96, 2>(h, guard, A, B, Cin, C, ld, alpha, beta); }
-  else if (ts == 96) { if (epi) launch_symm_gemm<1, 96, 1>(h, guard, A, B, Cin, C, ld, alpha, beta); else launch_symm_gemm<0, 96, 1>(h, guard, A, B, Cin, C, ld, alpha, beta); }
-  else { if (epi) launch_symm_gemm<1, 64, 1>(h, guard, A, B, Cin, C, ld, alpha, beta); else launch_symm_gemm<0, 64, 1>(h, guard, A, B, Cin, C, ld, alpha, beta); }
+static void symm_gemm(cosmo_hip_handle* h, int guard, const int* gate, int ts, int sk, int epi, const double* A, const double* B, const double* Cin, double* C,
+                      int ld, double alpha, double beta) {
+  if (ts == 96 && sk == 2) { if (epi) launch_symm_gemm<1, 96, 2>(h, guard, gate, A, B, Cin, C, ld, alpha, beta); else launch_symm_gemm<0, 96, 2>(h, guard, gate, A, B, Cin, C, ld, alpha, beta); }
+  else if (ts == 96) { if (epi) launch_symm_gemm<1, 96, 1>(h, guard, gate, A, B, Cin, C, ld, alpha, beta); else launch_symm_gemm<0, 96, 1>(h, guard, gate, A, B, Cin, C, ld, alpha, beta); }
+  else { if (epi) launch_symm_gemm<1, 64, 1>(h, guard, gate, A, B, Cin, C, ld, alpha, beta); else launch_symm_gemm<0, 64, 1>(h, guard, gate, A, B, Cin, C, ld, alpha, beta); }
+}
+
+// ---- verification of a large cone: ||G||_F^2 partials, then the decision (one workgroup) --------------------------------
+__global__ __launch_bounds__(COSMO_BS) void k_polar_sumsq(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ gate, long long n,
+                                                          const double* __restrict__ G, double* __restrict__ parts) {
+  if (guard && ctl->halt) return;
+  if (gate && !*gate) return;
+  __shared__ double red[COSMO_BS / 64];
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < n; i += (long long)gridDim.x * COSMO_BS) { const double v = G[i]; acc += v * v; }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) parts[blockIdx.x] = acc;
+}
+// round = 0: verification of the main schedule (always runs); round >= 1: of a fallback round (runs only if the gate is open).
+// last != 0: no further round is enqueued, a failure is recorded as unverified and the gate is closed for the next projection.
+__global__ __launch_bounds__(COSMO_BS) void k_polar_decide(const Ctl* __restrict__ ctl, int guard, PolarDev* __restrict__ pd, int round, int last, int nparts,
+                                                           const double* __restrict__ parts, const double* __restrict__ nrm, double tol) {
+  if (guard && ctl->halt) return;
+  if (round > 0 && !pd->gate) return;
+  __shared__ double red[COSMO_BS / 64];
+  const double g2 = reduce_partials_sum(parts, nparts, red);
+  if (threadIdx.x != 0) return;
+  const double nf = *nrm;
+  const double err = (nf > 0.0) ? 0.5 * sqrt(g2) / nf : 0.0;
+  const bool ok = !(err > tol);                // NaN fails
+  pd->err_last = err;
+  if (err > pd->err_max || err != err) pd->err_max = err;
+  if (round == 0) pd->projections += 1; else pd->rounds += 1;
+  if (ok) { pd->verified += 1; pd->gate = 0; }
+  else if (last) { pd->unverified += 1; pd->gate = 0; }
+  else pd->gate = 1;
 }
 
 // X+ = (X + H) / 2 written in the cone's layout (svec with sqrt(2) off-diagonals / mirrored square), trace(U) partials
@@ -383,13 +467,14 @@ __global__ __launch_bounds__(COSMO_BS) void k_bpolar_populate(const Ctl* __restr
   if (threadIdx.x == 0) parts[(size_t)blockIdx.y * 2 * BPX + blockIdx.x] = acc;
 }
 __global__ __launch_bounds__(COSMO_BS) void k_bpolar_scale(const Ctl* __restrict__ ctl, int guard, const BatchCone* __restrict__ cones,
-                                                           const double* __restrict__ parts, double* __restrict__ W) {
+                                                           const double* __restrict__ parts, double* __restrict__ W, double* __restrict__ bnrm) {
   if (guard && ctl->halt) return;
   const BatchCone cn = cones[blockIdx.y];
   double nf2 = 0.0;
   for (int k = 0; k < BPX; ++k) nf2 += parts[(size_t)blockIdx.y * 2 * BPX + k];     // same order in every thread: deterministic
   const double nf = sqrt(nf2);
-  const double inv = (nf > 0.0) ? 1.0 / nf : 0.0;
+  const double inv = (nf > 0.0) ? 2.0 / nf : 0.0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) bnrm[blockIdx.y] = nf;
   const long long n2 = (long long)cn.ld * cn.ld;
   const double* X = W + cn.woff;
   double* U = W + cn.woff + n2;
@@ -429,6 +514,49 @@ __global__ void k_bpolar_rank(const Ctl* __restrict__ ctl, int guard, int n, con
   rank[cones[c].idx] = (int)llround(tr / (cones[c].kind == COSMO_HIP_PSD_TRIANGLE_COMPLEX ? 4.0 : 2.0));
 }
 
+// batched verification: per-cone ||G||_F^2 partials (G in buffer ig), then one workgroup decides for the whole batch
+__global__ __launch_bounds__(COSMO_BS) void k_bpolar_sumsq(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ gate, const BatchCone* __restrict__ cones,
+                                                           const double* __restrict__ W, int ig, double* __restrict__ vparts) {
+  if (guard && ctl->halt) return;
+  if (gate && !*gate) return;
+  __shared__ double red[COSMO_BS / 64];
+  const BatchCone cn = cones[blockIdx.y];
+  const long long n2 = (long long)cn.ld * cn.ld;
+  const double* G = W + cn.woff + ig * n2;
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < n2; i += (long long)gridDim.x * COSMO_BS) { const double v = G[i]; acc += v * v; }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) vparts[(size_t)blockIdx.y * BPX + blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(COSMO_BS) void k_bpolar_decide(const Ctl* __restrict__ ctl, int guard, PolarDev* __restrict__ pd, int round, int last, int n,
+                                                            const BatchCone* __restrict__ cones, const double* __restrict__ vparts,
+                                                            const double* __restrict__ bnrm, double tol_factor) {
+  if (guard && ctl->halt) return;
+  if (round > 0 && !pd->gate) return;
+  __shared__ double red[COSMO_BS / 64];
+  double worst = 0.0;       // max over the cones of err / tol (NaN propagates as "failed")
+  double emax = 0.0;
+  for (int c = threadIdx.x; c < n; c += COSMO_BS) {
+    double g2 = 0.0;
+    for (int k = 0; k < BPX; ++k) g2 += vparts[(size_t)c * BPX + k];
+    const double nf = bnrm[c];
+    const double err = (nf > 0.0) ? 0.5 * sqrt(g2) / nf : 0.0;
+    const double q = err / (tol_factor * cones[c].d * PSD_EPS);
+    worst = (q > worst || q != q) ? q : worst;
+    emax = (err > emax || err != err) ? err : emax;
+  }
+  worst = block_max(worst, red);
+  emax = block_max(emax, red);
+  if (threadIdx.x != 0) return;
+  const bool ok = !(worst > 1.0);
+  pd->err_last = emax;
+  if (emax > pd->err_max || emax != emax) pd->err_max = emax;
+  if (round == 0) pd->projections += 1; else pd->rounds += 1;
+  if (ok) { pd->verified += 1; pd->gate = 0; }
+  else if (last) { pd->unverified += 1; pd->gate = 0; }
+  else pd->gate = 1;
+}
+
 }  // namespace
 
 void polar_plan_destroy(cosmo_hip_handle* h) {
@@ -441,6 +569,8 @@ void polar_plan_destroy(cosmo_hip_handle* h) {
   if (q->d_btiles) (void)hipFree(q->d_btiles);
   if (q->BW) (void)hipFree(q->BW);
   if (q->bparts) (void)hipFree(q->bparts);
+  if (q->bnrm) (void)hipFree(q->bnrm);
+  if (q->dev) (void)hipFree(q->dev);
   delete q;
   h->psd_polar = nullptr;
 }
@@ -462,8 +592,11 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
   if (!use_large && !use_batch) return COSMO_HIP_OK;
   PolarPlan* q = new PolarPlan();
   h->psd_polar = q;
-  if (const char* e = getenv("COSMO_HIP_POLAR_K1")) q->k1 = std::max(1, atoi(e));
-  if (const char* e = getenv("COSMO_HIP_POLAR_K2")) q->k2 = std::max(1, atoi(e));
+  if (const char* e = getenv("COSMO_HIP_POLAR_KLIFT")) q->k_lift = std::min(40, std::max(0, atoi(e)));
+  if (const char* e = getenv("COSMO_HIP_POLAR_ROUNDS")) q->max_rounds = std::min(8, std::max(0, atoi(e)));
+  HIPCHK(h, hipMalloc((void**)&q->dev, sizeof(PolarDev)));
+  HIPCHK(h, hipMemset(q->dev, 0, sizeof(PolarDev)));
+  memset(&q->seen, 0, sizeof(PolarDev));
   if (use_large) {
     long long woff = 0;
     for (int idx : large_list) {
@@ -532,7 +665,8 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
     HIPCHK(h, hipMalloc((void**)&q->BW, sizeof(double) * (size_t)woff));
     HIPCHK(h, hipMalloc((void**)&q->d_bcones, sizeof(BatchCone) * q->bcones.size()));
     HIPCHK(h, hipMalloc((void**)&q->d_btiles, sizeof(int4) * tiles.size()));
-    HIPCHK(h, hipMalloc((void**)&q->bparts, sizeof(double) * 2 * BPX * q->bcones.size()));
+    HIPCHK(h, hipMalloc((void**)&q->bparts, sizeof(double) * 3 * BPX * q->bcones.size()));   // norm, trace and verification partials
+    HIPCHK(h, hipMalloc((void**)&q->bnrm, sizeof(double) * q->bcones.size()));
     HIPCHK(h, hipMemcpy(q->d_bcones, q->bcones.data(), sizeof(BatchCone) * q->bcones.size(), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(q->d_btiles, tiles.data(), sizeof(int4) * tiles.size(), hipMemcpyHostToDevice));
     (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch<0>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
@@ -544,26 +678,42 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
 bool polar_has_batch(const cosmo_hip_handle* h) { const PolarPlan* q = static_cast<const PolarPlan*>(h->psd_polar); return q && !q->bcones.empty(); }
 bool polar_has_large(const cosmo_hip_handle* h) { const PolarPlan* q = static_cast<const PolarPlan*>(h->psd_polar); return q && !q->cones.empty(); }
 
-// all mid-size cones of the batch advance together: 3 launches per iteration for the whole batch
+// all mid-size cones of the batch advance together: 3 launches per step for the whole batch
 int32_t polar_enqueue_project_batch(cosmo_hip_handle* h, double* s, int guard) {
   PolarPlan* q = static_cast<PolarPlan*>(h->psd_polar);
   PsdPlan* p = h->psd;
   hipStream_t st = h->stream;
   const int n = (int)q->bcones.size();
   const size_t sm = GemmCfg<64>::SMEM;
+  double* vparts = q->bparts + (size_t)2 * BPX * n;
   hipLaunchKernelGGL(k_bpolar_populate, dim3(BPX, n), dim3(COSMO_BS), 0, st, h->ctl, guard, q->d_bcones, s, q->BW, q->bparts);
-  hipLaunchKernelGGL(k_bpolar_scale, dim3(BPX, n), dim3(COSMO_BS), 0, st, h->ctl, guard, q->d_bcones, q->bparts, q->BW);
-  int iu = 1, iy = 2;
+  hipLaunchKernelGGL(k_bpolar_scale, dim3(BPX, n), dim3(COSMO_BS), 0, st, h->ctl, guard, q->d_bcones, q->bparts, q->BW, q->bnrm);
+  int iu = 1, iy = 2, products = 0;
   const dim3 G(q->nbtiles), B(256);
-  for (int it = 0; it < q->k1 + q->k2; ++it) {
-    const bool ph1 = it < q->k1;
-    const double a = ph1 ? 3.4445 : 15.0 / 8.0, b = ph1 ? -4.7750 : -10.0 / 8.0, c = ph1 ? 2.0315 : 3.0 / 8.0;
-    hipLaunchKernelGGL((k_symm_gemm_batch<0>), G, B, sm, st, h->ctl, guard, q->d_btiles, q->d_bcones, q->BW, iu, iu, iu, iy, 1.0, 0.0);   // Y = U^2
-    hipLaunchKernelGGL((k_symm_gemm_batch<1>), G, B, sm, st, h->ctl, guard, q->d_btiles, q->d_bcones, q->BW, iy, iy, iy, 3, c, b);        // T = c Y^2 + b Y
-    hipLaunchKernelGGL((k_symm_gemm_batch<1>), G, B, sm, st, h->ctl, guard, q->d_btiles, q->d_bcones, q->BW, iu, 3, iu, iy, 1.0, a);      // U' = U T + a U
+  auto step = [&](const double* co, const int* gate) {
+    hipLaunchKernelGGL((k_symm_gemm_batch<0>), G, B, sm, st, h->ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW, iu, iu, iu, iy, 1.0, 0.0);       // Y = U^2
+    hipLaunchKernelGGL((k_symm_gemm_batch<1>), G, B, sm, st, h->ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW, iy, iy, iy, 3, co[2], co[1]);    // T = c Y^2 + b Y
+    hipLaunchKernelGGL((k_symm_gemm_batch<1>), G, B, sm, st, h->ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW, iu, 3, iu, iy, 1.0, co[0]);      // U' = U T + a U
     std::swap(iu, iy);
+    products += 3; q->launches[3] += 3;
+  };
+  auto verify = [&](int round, const int* gate) {
+    hipLaunchKernelGGL((k_symm_gemm_batch<0>), G, B, sm, st, h->ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW, iu, 0, 0, 3, 1.0, 0.0);          // H = U X = |X|
+    hipLaunchKernelGGL((k_symm_gemm_batch<1>), G, B, sm, st, h->ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW, iu, 3, 0, iy, 1.0, -1.0);        // G = U H - X
+    hipLaunchKernelGGL(k_bpolar_sumsq, dim3(BPX, n), dim3(COSMO_BS), 0, st, h->ctl, guard, gate, q->d_bcones, q->BW, iy, vparts);
+    hipLaunchKernelGGL(k_bpolar_decide, dim3(1), dim3(COSMO_BS), 0, st, h->ctl, guard, q->dev, round, round == q->max_rounds ? 1 : 0, n, q->d_bcones, vparts,
+                       q->bnrm, q->tol_factor);
+    products += 2; q->launches[3] += 2;
+  };
+  for (int t = 0; t < q->k_lift; ++t) step(kPolarLift, nullptr);
+  for (int t = 0; t < POLAR_NFIN; ++t) step(kPolarFinish[t], nullptr);
+  verify(0, nullptr);
+  q->products_last_batch = products;
+  for (int r = 1; r <= q->max_rounds; ++r) {                 // guarded fallback rounds (even number of steps: iu is preserved)
+    for (int t = 0; t < POLAR_RLIFT; ++t) step(kPolarLift, &q->dev->gate);
+    for (int t = 0; t < POLAR_NFIN; ++t) step(kPolarFinish[t], &q->dev->gate);
+    verify(r, &q->dev->gate);
   }
-  hipLaunchKernelGGL((k_symm_gemm_batch<0>), G, B, sm, st, h->ctl, guard, q->d_btiles, q->d_bcones, q->BW, iu, 0, 0, 3, 1.0, 0.0);       // H = U X
   hipLaunchKernelGGL(k_bpolar_finish, dim3(BPX, n), dim3(COSMO_BS), 0, st, h->ctl, guard, q->d_bcones, q->BW, iu, s, q->bparts);
   hipLaunchKernelGGL(k_bpolar_rank, dim3((n + 63) / 64), dim3(64), 0, st, h->ctl, guard, n, q->d_bcones, q->bparts, p->rank);
   HIPCHK(h, hipGetLastError());
@@ -584,22 +734,111 @@ int32_t polar_enqueue_project(cosmo_hip_handle* h, double* s, int guard) {
     double* nparts = q->parts + 2 * COSMO_MAX_PARTIALS * ci;
     double* tparts = nparts + COSMO_MAX_PARTIALS;
     const int gpop = std::min(cn.ld, 1024);
+    int products = 0;
     hipLaunchKernelGGL(k_polar_populate, dim3(gpop), dim3(COSMO_BS), 0, st, h->ctl, guard, cn, s, X, nparts);
     hipLaunchKernelGGL(k_polar_scale, dim3(1024), dim3(COSMO_BS), 0, st, h->ctl, guard, n2, gpop, nparts, X, U, q->nrm + ci);
-    for (int it = 0; it < q->k1 + q->k2; ++it) {
-      const bool ph1 = it < q->k1;
-      const double a = ph1 ? 3.4445 : 15.0 / 8.0, b = ph1 ? -4.7750 : -10.0 / 8.0, c = ph1 ? 2.0315 : 3.0 / 8.0;
-      symm_gemm(h, guard, cn.ts, cn.sk, 0, U, U, nullptr, Y, cn.ld, 1.0, 0.0);     // Y = U^2
-      symm_gemm(h, guard, cn.ts, cn.sk, 1, Y, Y, Y, T, cn.ld, c, b);               // T = c Y^2 + b Y
-      symm_gemm(h, guard, cn.ts, cn.sk, 1, U, T, U, Y, cn.ld, 1.0, a);             // U' = U T + a U
+    auto step = [&](const double* co, const int* gate) {
+      symm_gemm(h, guard, gate, cn.ts, cn.sk, 0, U, U, nullptr, Y, cn.ld, 1.0, 0.0);         // Y = U^2
+      symm_gemm(h, guard, gate, cn.ts, cn.sk, 1, Y, Y, Y, T, cn.ld, co[2], co[1]);           // T = c Y^2 + b Y
+      symm_gemm(h, guard, gate, cn.ts, cn.sk, 1, U, T, U, Y, cn.ld, 1.0, co[0]);             // U' = U T + a U
       std::swap(U, Y);
+      products += 3;
+    };
+    auto verify = [&](int round, const int* gate) {
+      symm_gemm(h, guard, gate, cn.ts, cn.sk, 0, U, X, nullptr, T, cn.ld, 1.0, 0.0);         // H = U X = |X|
+      symm_gemm(h, guard, gate, cn.ts, cn.sk, 1, U, T, X, Y, cn.ld, 1.0, -1.0);              // G = U H - X = (U^2 - I) X
+      hipLaunchKernelGGL(k_polar_sumsq, dim3(1024), dim3(COSMO_BS), 0, st, h->ctl, guard, gate, n2, Y, nparts);
+      hipLaunchKernelGGL(k_polar_decide, dim3(1), dim3(COSMO_BS), 0, st, h->ctl, guard, q->dev, round, round == q->max_rounds ? 1 : 0, 1024, nparts,
+                         q->nrm + ci, q->tol_factor * cn.d * PSD_EPS);
+      products += 2;
+    };
+    for (int t = 0; t < q->k_lift; ++t) step(kPolarLift, nullptr);
+    for (int t = 0; t < POLAR_NFIN; ++t) step(kPolarFinish[t], nullptr);
+    verify(0, nullptr);
+    q->products_last_large = products;
+    for (int r = 1; r <= q->max_rounds; ++r) {
+      for (int t = 0; t < POLAR_RLIFT; ++t) step(kPolarLift, &q->dev->gate);
+      for (int t = 0; t < POLAR_NFIN; ++t) step(kPolarFinish[t], &q->dev->gate);
+      verify(r, &q->dev->gate);
     }
-    symm_gemm(h, guard, cn.ts, cn.sk, 0, U, X, nullptr, T, cn.ld, 1.0, 0.0);       // H = U X = |X|
     const int gfin = std::min(cn.d, 1024);
     hipLaunchKernelGGL(k_polar_finish, dim3(gfin), dim3(COSMO_BS), 0, st, h->ctl, guard, cn, X, T, U, s, tparts);
     hipLaunchKernelGGL(k_polar_rank, dim3(1), dim3(COSMO_BS), 0, st, h->ctl, guard, cn.d, gfin, tparts, p->rank + cn.idx, cn.kind);
   }
   HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}
+
+// Host-side adaptation at a synchronisation point of the loop: when fallback rounds ran on a third or more of the projections
+// since the last look, the main schedule gets three more lifting steps (sticky).  Not in sharded runs (every rank must keep
+// the schedule of the single-rank run so that the exchanged slices stay bit-identical to it).
+int32_t polar_adapt(cosmo_hip_handle* h) {
+  PolarPlan* q = static_cast<PolarPlan*>(h->psd_polar);
+  if (!q || !q->dev || h->comm || getenv("COSMO_HIP_POLAR_KLIFT")) return COSMO_HIP_OK;
+  PolarDev now;
+  HIPCHK(h, hipMemcpyAsync(&now, q->dev, sizeof now, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const int dr = now.rounds - q->seen.rounds, dp = now.projections - q->seen.projections;
+  q->seen = now;
+  if (dp > 0 && 3 * dr >= dp && q->k_lift < 18) q->k_lift = std::min(18, q->k_lift + 3);
+  return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_polar_stats(cosmo_hip_handle* h, int64_t out[16]) {
+  if (!h || !out) return COSMO_HIP_ERR_INVALID;
+  for (int i = 0; i < 16; ++i) out[i] = 0;
+  PolarPlan* q = static_cast<PolarPlan*>(h->psd_polar);
+  if (!q) return COSMO_HIP_OK;
+  if (hipSetDevice(h->device) != hipSuccess) return cosmo_fail(h, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
+  PolarDev now;
+  HIPCHK(h, hipMemcpyAsync(&now, q->dev, sizeof now, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  out[0] = (int64_t)q->cones.size(); out[1] = (int64_t)q->bcones.size();
+  if (!q->cones.empty()) { out[2] = q->cones[0].ts; out[3] = q->cones[0].sk; }
+  out[4] = q->launches[0]; out[5] = q->launches[1]; out[6] = q->launches[2]; out[7] = q->launches[3];
+  out[8] = q->products_last_large; out[9] = now.rounds; out[10] = now.verified; out[11] = q->products_last_batch;
+  out[12] = q->k_lift + POLAR_NFIN; out[13] = now.unverified; out[14] = now.projections;
+  out[15] = (int64_t)llround(now.err_max * 1e18);       // max verified error bound relative to ||X||_F, in units of 1e-18
+  return COSMO_HIP_OK;
+}
+
+// measurement hook (bench.py roofline): the product kernel exactly as the projection launches it
+extern "C" int32_t cosmo_hip_time_psd_product(cosmo_hip_handle* h, int32_t which, int32_t reps, double* avg_seconds, double* flops) {
+  if (!h || reps <= 0 || !avg_seconds) return COSMO_HIP_ERR_INVALID;
+  PolarPlan* q = static_cast<PolarPlan*>(h->psd_polar);
+  if (!q || (which == 0 && q->cones.empty()) || (which != 0 && q->bcones.empty())) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "time_psd_product: no such cones");
+  if (hipSetDevice(h->device) != hipSuccess) return cosmo_fail(h, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
+  hipEvent_t e0, e1;
+  HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+  double fl = 0.0;
+  const long long keep[4] = {q->launches[0], q->launches[1], q->launches[2], q->launches[3]};
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1) HIPCHK(h, hipEventRecord(e0, h->stream));
+    const int R = pass == 0 ? 2 : reps;
+    for (int i = 0; i < R; ++i) {
+      if (which == 0) {
+        const PolarCone& cn = q->cones[0];
+        const long long n2 = (long long)cn.ld * cn.ld;
+        double* X = q->W + cn.woff;
+        symm_gemm(h, 0, nullptr, cn.ts, cn.sk, 0, X + n2, X + n2, nullptr, X + 2 * n2, cn.ld, 1.0, 0.0);
+        const long long nt = cn.ld / cn.ts;
+        fl = 2.0 * (double)(nt * (nt + 1) / 2) * cn.ts * cn.ts * cn.ld;
+      } else {
+        hipLaunchKernelGGL((k_symm_gemm_batch<0>), dim3(q->nbtiles), dim3(256), GemmCfg<64>::SMEM, h->stream, h->ctl, 0, (const int*)nullptr, q->d_btiles,
+                           q->d_bcones, q->BW, 1, 1, 1, 2, 1.0, 0.0);
+        fl = 0.0;
+        for (const BatchCone& bc : q->bcones) { const long long nt = bc.ld / 64; fl += 2.0 * (double)(nt * (nt + 1) / 2) * 64 * 64 * (((bc.d + 31) / 32) * 32); }
+      }
+    }
+    if (pass == 1) HIPCHK(h, hipEventRecord(e1, h->stream));
+  }
+  HIPCHK(h, hipEventSynchronize(e1));
+  for (int i = 0; i < 4; ++i) q->launches[i] = keep[i];
+  float ms = 0.f;
+  HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+  *avg_seconds = (double)ms * 1e-3 / reps;
+  if (flops) *flops = fl;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return COSMO_HIP_OK;
 }
 

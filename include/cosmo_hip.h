@@ -284,6 +284,18 @@ const char* cosmo_hip_kernel_class_name(int32_t k);
 /* Jacobi eigensolver diagnostics of the PSD projections: out = {max sweeps used by a single-workgroup solve, sweeps of
  * the last multi-workgroup solve, non-convergence flag, number of PSD cones}. */
 int32_t cosmo_hip_psd_stats(cosmo_hip_handle* h, int64_t out[4]);
+/* Matrix-sign (polar) PSD path diagnostics: out = {large cones (d > 256), batched cones (64 < d <= 256), tile side of the first
+ * large cone, its k-split (1 | 2), product launches <64,1>, <96,1>, <96,2>, batched product launches, matrix products of the main
+ * schedule of the last large-cone projection, fallback rounds executed so far, verified projections, products of the last batched
+ * projection, steps of the main schedule, unverified projections, projections, max verified error bound in units of 1e-18}. */
+int32_t cosmo_hip_polar_stats(cosmo_hip_handle* h, int64_t out[16]);
+/* The coefficient table of the sign iteration for k_lift lifting steps: abc holds 3 * (*nsteps) doubles (a, b, c per step;
+ * NULL = only report *nsteps).  Host function (no device needed): lets a CPU test replay the schedule on scalars. */
+int32_t cosmo_hip_polar_schedule(int32_t k_lift, double* abc, int32_t* nsteps);
+/* Measurement hook: `reps` back-to-back launches of the symmetric-product kernel of the sign iteration exactly as the projection
+ * launches it (which = 0: first large cone, 1: the whole batch of mid-size cones), timed with HIP events on the handle's stream.
+ * Returns the average seconds per launch and the flops one launch performs (2 ts^2 k per upper tile). */
+int32_t cosmo_hip_time_psd_product(cosmo_hip_handle* h, int32_t which, int32_t reps, double* avg_seconds, double* flops);
 
 /* ---- clique-sharded projections over the GPUs of one node (one process per GPU, RCCL over xGMI) -----------------------
  * The reference projects the cones of a decomposed SDP serially (src/convexset.jl:885-891).  Here every rank holds the whole
@@ -295,6 +307,12 @@ int32_t cosmo_hip_comm_destroy(cosmo_hip_handle* h);
 /* first_cone[nranks+1]: contiguous partition of the cone indices; call after cosmo_hip_set_cones */
 int32_t cosmo_hip_set_cone_shard(cosmo_hip_handle* h, const int64_t* first_cone);
 int32_t cosmo_hip_comm_selftest(cosmo_hip_handle* h);
+/* Host-staged communicator for functional tests on a single-GPU host: ranks are processes that may share one device (RCCL
+ * refuses that), slices travel through the POSIX shared-memory segment `name` ("/..."; rank 0 creates it).  Same ownership,
+ * slices and exchange point as the RCCL path; synchronous, never a performance path.  Call after cosmo_hip_set_problem. */
+int32_t cosmo_hip_comm_init_hostshm(cosmo_hip_handle* h, int32_t rank, int32_t nranks, const char* name);
+/* out = {nranks, rank, exchange steps executed with nranks > 1, transport (0 none, 1 RCCL, 2 host-staged)} */
+int32_t cosmo_hip_comm_stats(cosmo_hip_handle* h, int64_t out[4]);
 /* ownership without a communicator: project only the SOC / PSD cones cone_lo <= k < cone_hi (testing / custom exchange) */
 int32_t cosmo_hip_set_cone_ownership(cosmo_hip_handle* h, int64_t cone_lo, int64_t cone_hi);
 
