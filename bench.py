@@ -1,17 +1,26 @@
 #!/usr/bin/env python
-"""bench.py -- ADMM iterations/sec (fp64) of the MI355X-native COSMO hot path on BASELINE.json's metric config.
+"""bench.py -- ADMM iterations/sec (fp64) of the MI355X-native COSMO hot path on BASELINE.json's configurations.
 
-Workload (BASELINE.json configs[1]): random sparse QP n=100k, m=200k, nnz(A)=2M, one Box cone,
-CG indirect KKT, fp64.  A "step" is ONE ADMM iteration of the loop body src/solver.jl:140-165 including the
-termination check every 25 iterations (the reference's own iter_time definition, src/solver.jl:134,169), with the
-fixed-work settings of SURVEY 8d: eps_abs = eps_rel = 0, adaptive_rho_interval = 40, scaling = 10, alpha = 1.6,
-sigma = 1e-6, rho = 0.1, CG tolerance 1/k^1.5, EmptyAccelerator.
+A "step" is ONE ADMM iteration of the loop body src/solver.jl:140-165 including the termination check every 25 iterations
+(the reference's own iter_time definition, src/solver.jl:134,169), with the fixed-work settings of SURVEY 8d: eps_abs = eps_rel
+= 0, adaptive_rho_interval = 40, scaling = 10, alpha = 1.6, sigma = 1e-6, rho = 0.1, CG tolerance 1/k^1.5, EmptyAccelerator.
 
-Multi-GPU (--gpus N under torch.distributed.run): a single sparse QP does not shard ("replicas only"), so
-every rank runs an independent replica of the workload on its own GPU; value = N*K / max-over-ranks time ("weak").
+Workloads (--workload):
+  cfg2  random sparse QP n=100k m=200k nnz(A)=2M, Box cone, CG indirect KKT            [BASELINE configs[1], the metric config]
+  cfg3  1024 independent SOCPs n=500 m=1000, 50 SecondOrderCones each (one step = one iteration of ALL problems)
+  cfg4  closest-correlation SDP, one PsdConeTriangle d=2000
+  cfg5  chordal-decomposed SDP n=50k, 400 PSD cliques d in [20,200] + ZeroSet / Nonnegatives
+  all   (default at N=1) headline line = cfg2; cfg3 / cfg4 / cfg5 measured in the same run and reported under "extra"
 
-Output: ONE JSON line on rank 0 (see the driver contract), with `roofline` for the dominant kernel (the fused
-[P | A'] operator SpMV of the CG iteration) and `cpu_baseline` (the CPU oracle timed on a bounded sample).
+Multi-GPU (torch.distributed.run, one process per GPU, RCCL):
+  default at N>1 = cfg5 with the cliques SHARDED over the ranks (csrc/comm.hip: every rank projects its contiguous cone range,
+  one in-place broadcast group per iteration), "scaling": "strong" -- this is the configuration BASELINE.json asks to scale;
+  rank 0 also times the unsharded problem in the same run ("single_gpu_same_workload") so the speed-up is self-contained.
+  --workload cfg3 at N>1: the batch is sharded over the ranks (no collective), strong.  cfg2 / cfg4 at N>1: a single sparse QP /
+  a single cone does not shard (replicas only), every rank runs a replica, weak.
+
+Output: ONE JSON line on rank 0 (the driver contract) with `roofline` for the dominant kernel of the headline workload and
+`cpu_baseline` (the restated CPU reference timed on a bounded sample, 1 thread and all host threads where LAPACK is involved).
 """
 import argparse
 import json
@@ -25,17 +34,25 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+F64_MFMA_PEAK_TF = 78.6    # fp64 matrix peak (the guide lists no fp64 row, the vector and matrix fp64 peaks coincide)
+METRIC = "ADMM iterations/sec (fp64) at fixed (n,m,nnz,cone)"
 
 
-def build_workload(args):
-    import cosmo_jl_amd as cj
-    if args.small:
-        prob = cj.problems.sparse_box_qp(n=10_000, m=20_000, nnz=200_000)
-    else:
-        prob = cj.problems.sparse_box_qp()
-    st = cj.Settings(eps_abs=0.0, eps_rel=0.0, max_iter=10 ** 9, check_infeasibility=10 ** 9, kkt_solver=cj.CGIndirectKKTSolver)
-    return prob, st
+# ---------------------------------------------------------------------------------------------------------------------
+# helpers shared with tests/test_distributed_cpu.py
+# ---------------------------------------------------------------------------------------------------------------------
+def max_over_ranks(elapsed, dist, device):
+    """The bench contract's timing rule: every rank times its own K steps, the job's time is the MAX over the ranks."""
+    import torch
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def whole_job_value(world, steps, elapsed):
+    """Aggregate throughput of `world` replicas that each did `steps` iterations in `elapsed` seconds (weak scaling)."""
+    return world * steps / elapsed
 
 
 def algorithmic_bytes(n, m, nnzA, nnzP):
@@ -51,23 +68,116 @@ def algorithmic_bytes(n, m, nnzA, nnzP):
     return dict(A=b_A, AT=b_AT, P=b_P, op=b_op, vec=b_vec, cgvec=b_cgvec)
 
 
-def cpu_baseline(prob, st_kwargs, sample_iters):
-    """The CPU oracle ("port") on a bounded sample of the SAME workload: `sample_iters` ADMM iterations after setup, 1 thread.
-    The loop runs in the compiled C restatement (oracle/cosmo_oracle_c.c, gcc -O2; Julia-style CSC SpMV kernels), set up by the
-    NumPy oracle; if the compiled library is absent the NumPy/SciPy loop is timed instead and the sample string says so."""
+def iteration_bytes(ab, kbar):
+    """B_iter(K) of SURVEY 8d."""
+    return ab["vec"] + (kbar + 2) * (ab["A"] + ab["AT"]) + (kbar + 1) * (ab["P"] + ab["cgvec"])
+
+
+def psd_useful_flops(d, r=None):
+    """F_psd(d, r) of SURVEY 8d: the REFERENCE algorithm's flops for one d x d block (tridiagonalise 4/3 d^3, back-transform 2 d^3,
+    SYRK d(d+1) r with r = #positive eigenvalues ~ d/2)."""
+    r = d / 2.0 if r is None else r
+    return (10.0 / 3.0) * d ** 3 + d * (d + 1.0) * r
+
+
+class Ctx:
+    def __init__(self):
+        import torch
+        self.torch = torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = None
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a MI355X (no CPU fallback)")
+        torch.cuda.set_device(self.local_rank)
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.local_rank))
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def timed(self, fn):
+        """barrier + synchronize, run fn (which must drain its stream), synchronize; MAX over the ranks."""
+        self.barrier()
+        t0 = time.perf_counter()
+        fn()
+        self.torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if self.dist is not None:
+            el = max_over_ranks(el, self.dist, "cuda")
+            self.dist.barrier()
+        return el
+
+
+def fixed_work_settings(cj, **kw):
+    base = dict(eps_abs=0.0, eps_rel=0.0, max_iter=10 ** 9, check_infeasibility=10 ** 9, kkt_solver=cj.CGIndirectKKTSolver)
+    base.update(kw)
+    return cj.Settings(**base)
+
+
+def oracle_settings(O, iters):
+    return O.Settings(kkt_solver="cg", eps_abs=0.0, eps_rel=0.0, max_iter=iters, check_infeasibility=10 ** 9)
+
+
+def host_threads():
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def oracle_rate(prob, iters, threads):
+    """ADMM iterations/s of the NumPy/SciPy oracle (LAPACK dsyevr projections through SciPy's OpenBLAS) with `threads` BLAS threads.
+    The init step (one KKT solve) is part of iter_time on both sides."""
     from oracle import cosmo_oracle as O
     from tests import util
-    st = O.Settings(kkt_solver="cg", eps_abs=0.0, eps_rel=0.0, max_iter=sample_iters, check_infeasibility=10 ** 9)
+    from threadpoolctl import threadpool_limits
+    with threadpool_limits(limits=threads):
+        ws = O.Workspace(prob["P"], prob["q"], prob["A"], prob["b"], util.oracle_cones(prob["sets"]), oracle_settings(O, iters))
+        res = ws.optimize()
+    return res.iter / res.iter_time, res.iter, res.iter_time, float(np.mean(res.cg_iters))
+
+
+def lapack_cpu_baseline(prob, iters, label):
+    """cpu_baseline for the SDP configurations: 1 BLAS thread (what the tagged reference does outside BLAS) and all host threads."""
+    nt = host_threads()
+    v1, it1, s1, cg1 = oracle_rate(prob, iters, 1)
+    out = dict(value=v1, unit="ADMM iterations/s", cores=1, kind="port",
+               sample="NumPy/SciPy oracle (dsyevr + syrk projections, restated cg!): %d ADMM iteration(s) + init step of the same %s instance, %.1f s, "
+                      "1 BLAS thread; mean CG its/solve %.1f" % (it1, label, s1, cg1))
+    if nt > 1:
+        vn, itn, sn, _ = oracle_rate(prob, iters, nt)
+        out["all_threads"] = dict(value=vn, cores=nt, sample="%d iteration(s), %.1f s, OPENBLAS threads = %d" % (itn, sn, nt))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# cfg2
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline_cfg2(prob, sample_iters):
+    """The compiled C restatement (oracle/cosmo_oracle_c.c, gcc -O3 -march=native; Julia-style CSC SpMV kernels), set up by the NumPy
+    oracle, 1 thread (the reference is single-threaded outside BLAS and this configuration has no BLAS)."""
+    from oracle import cosmo_oracle as O
+    from tests import util
+    st = oracle_settings(O, sample_iters)
     ws = O.Workspace(prob["P"], prob["q"], prob["A"], prob["b"], util.oracle_cones(prob["sets"]), st)
     try:
+        import subprocess
         from oracle import cosmo_oracle_c as OC
-        OC.lib()
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "native"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        OC.lib(native=True)                               # -march=native for the host whose core is being timed
     except Exception:
         OC = None
     if OC is not None:
-        c = OC.run(ws)
+        c = OC.run(ws, native=True)
         iters, secs, cg = c["iter"], c["iter_time"], c["cg_iters_total"] / (c["iter"] + 1.0)
-        impl = "compiled C loop (gcc -O2)"
+        impl = "compiled C loop (gcc -O3 -march=native)"
     else:
         res = ws.optimize()
         iters, secs, cg = res.iter, res.iter_time, float(np.mean(res.cg_iters))
@@ -77,98 +187,42 @@ def cpu_baseline(prob, st_kwargs, sample_iters):
                        % (impl, iters, secs, cg))
 
 
-def max_over_ranks(elapsed, dist, device):
-    """The bench contract's timing rule: every rank times its own K steps, the job's time is the MAX over the ranks."""
-    import torch
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
-
-
-def whole_job_value(world, steps, elapsed):
-    """Aggregate throughput of `world` replicas that each did `steps` iterations in `elapsed` seconds (weak scaling)."""
-    return world * steps / elapsed
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=25)
-    ap.add_argument("--small", action="store_true", help="1/10-size instance (debugging only; not the BASELINE workload)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-iters", type=int, default=5)
-    ap.add_argument("--exact-launches", action="store_true",
-                    help="synchronise after every Krylov iteration (rocprofv3 runs: every launch does full work)")
-    args = ap.parse_args()
-
-    import torch
+def bench_cfg2(ctx, args, steps, warmup):
     import cosmo_jl_amd as cj
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-
-    prob, st = build_workload(args)
-    st.device = local_rank
+    prob = cj.problems.sparse_box_qp(n=10_000, m=20_000, nnz=200_000) if args.small else cj.problems.sparse_box_qp()
+    st = fixed_work_settings(cj)
+    st.device = ctx.local_rank
     model = cj.Model()
     model.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)
     cj.model.setup(model)                       # upload + Ruiz scaling on the device (setup!, excluded from iter_time)
     h = model.handle
-    n, m = model.n, model.m
-    nnzA, nnzP = model.A.nnz, model.P.nnz
+    n, m, nnzA, nnzP = model.n, model.m, model.A.nnz, model.P.nnz
     h.set_iterates(model.x, model.s, model.mu)
     h.admm_init()
     if args.exact_launches:
         h.set_profiling(2)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # ---- warmup (untimed) ----
-    h.admm_iterate_checked(args.warmup)
+    h.admm_iterate_checked(warmup)
     stats0 = h.get_stats()
-    barrier()
-    t0 = time.perf_counter()
-    h.admm_iterate_checked(args.steps)          # returns after the stream has drained (host sync inside)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if dist is not None:
-        elapsed = max_over_ranks(elapsed, dist, "cuda")
-        dist.barrier()
+    elapsed = ctx.timed(lambda: h.admm_iterate_checked(steps))          # returns after the stream has drained (host sync inside)
     stats1 = h.get_stats()
-    steps_done = stats1["admm_iters"] - stats0["admm_iters"]
-    assert steps_done == args.steps, (steps_done, args.steps)
+    assert stats1["admm_iters"] - stats0["admm_iters"] == steps
     kbar = (stats1["kkt_iters_total"] - stats0["kkt_iters_total"]) / max(1, stats1["kkt_solves"] - stats0["kkt_solves"])
-    value = whole_job_value(world, args.steps, elapsed)
-
-    out = None
-    if rank == 0:
-        ab = algorithmic_bytes(n, m, nnzA, nnzP)
-        # ---- dominant kernel: the fused [P | A'] operator SpMV of the CG iteration (K-bar launches per ADMM iteration).
-        # Duration: HIP events on the library's stream around R back-to-back launches of exactly that kernel on the live
-        # loop state (cosmo_hip_time_spmv; one event pair per R launches, so the ~5 us cost of an event pair does not
-        # pollute a 10-20 us kernel; the ~1.6 us launch gap IS included, i.e. the number is conservative).
-        t_op, bytes_op = h.time_spmv(cj._ffi.MAT_OP, 200)
-        t_A, bytes_A = h.time_spmv(cj._ffi.MAT_A, 200)
-        t_AT, bytes_AT = h.time_spmv(cj._ffi.MAT_AT, 200)
-        t_P, bytes_P = h.time_spmv(cj._ffi.MAT_P, 200)
-        achieved = bytes_op / t_op / 1e9
-        # HBM traffic of one k_op_apply launch from the PMC counters: these need their own rocprofv3 --pmc passes (FETCH_SIZE
-        # and WRITE_SIZE separately), so bench.py reports the committed result of the latest such pass over this very command
-        traffic, traffic_src = None, None
+    world = ctx.world
+    value = whole_job_value(world, steps, elapsed)
+    out = dict(value=value, ms_per_step=1e3 * elapsed / steps, steps=steps, warmup=warmup, scaling="weak")
+    if ctx.rank != 0:
+        return out
+    ab = algorithmic_bytes(n, m, nnzA, nnzP)
+    # dominant kernel: the fused [P | A'] operator SpMV of the CG iteration (K-bar launches per ADMM iteration).  Duration: HIP events
+    # on the library's stream around R back-to-back launches of exactly that kernel on the live loop state (one event pair per R
+    # launches: the ~5 us of an event pair would swamp a 10-20 us kernel; the launch gap IS included, i.e. the number is conservative).
+    t_op, bytes_op = h.time_spmv(cj._ffi.MAT_OP, 200)
+    t_A, bytes_A = h.time_spmv(cj._ffi.MAT_A, 200)
+    t_AT, bytes_AT = h.time_spmv(cj._ffi.MAT_AT, 200)
+    t_P, bytes_P = h.time_spmv(cj._ffi.MAT_P, 200)
+    achieved = bytes_op / t_op / 1e9
+    traffic, traffic_src = None, None
+    if not args.small:
         import glob
         for fpmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cfg2_pmc_traffic.json"))):
             try:
@@ -177,37 +231,219 @@ def main():
                 traffic_src = os.path.relpath(fpmc, ROOT)
             except Exception:
                 pass
-        if args.small:
-            traffic, traffic_src = None, None
-        roof = dict(bound="hbm", kernel="k_op_apply (c = [P|A'][v; rho.*(A v)] + sigma v, CSR-stream SpMV)", achieved=round(achieved, 1),
-                    peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
-                    algorithmic_bytes_per_launch=bytes_op, avg_launch_us=round(t_op * 1e6, 3), launches_timed=200,
-                    other={"k_spmv_A_rho (A v)": dict(achieved=round(bytes_A / t_A / 1e9, 1), frac=round(bytes_A / t_A / 1e9 / HBM_PEAK_GBS, 4),
-                                                     algorithmic_bytes_per_launch=bytes_A, avg_launch_us=round(1e6 * t_A, 3)),
-                           "k_cg_rhs (A' y)": dict(achieved=round(bytes_AT / t_AT / 1e9, 1), frac=round(bytes_AT / t_AT / 1e9 / HBM_PEAK_GBS, 4),
-                                                  algorithmic_bytes_per_launch=bytes_AT, avg_launch_us=round(1e6 * t_AT, 3)),
-                           "k_spmv_plain (P x)": dict(achieved=round(bytes_P / t_P / 1e9, 1), frac=round(bytes_P / t_P / 1e9 / HBM_PEAK_GBS, 4),
-                                                     algorithmic_bytes_per_launch=bytes_P, avg_launch_us=round(1e6 * t_P, 3))})
-        b_iter = ab["vec"] + (kbar + 2) * (ab["A"] + ab["AT"]) + (kbar + 1) * (ab["P"] + ab["cgvec"])
-        out = {
-            "metric": "ADMM iterations/sec (fp64) at fixed (n,m,nnz,cone)", "value": round(value, 3), "unit": "ADMM iterations/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 6),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "cfg2: random sparse QP n=%d m=%d nnz(A)=%d nnz(P)=%d, Box cone, CG indirect KKT (tol 1/k^1.5), "
-                                   "check_termination=25, adaptive_rho_interval=40, Ruiz scaling=10, eps=0" % (n, m, nnzA, nnzP),
-                       "parallelism": "replicas x%d (a single sparse QP does not shard; SURVEY 8e)" % world,
-                       "mean_cg_iters_per_admm_iter": round(kbar, 3), "kkt_budget_stalls": stats1["kkt_budget_stalls"],
-                       "iteration_roofline_frac": round(b_iter * (value / world) / (HBM_PEAK_GBS * 1e9), 4),
-                       "algorithmic_bytes_per_iteration": b_iter},
-            "roofline": roof,
-        }
-        if not args.no_cpu_baseline and world == 1:     # reported at N=1 only
-            out["cpu_baseline"] = cpu_baseline(prob, None, args.cpu_sample_iters if not args.small else 200)
-            out["config"]["gpu_over_cpu"] = round((value / world) / out["cpu_baseline"]["value"], 2)
+
+    def other(b, t):
+        return dict(achieved=round(b / t / 1e9, 1), frac=round(b / t / 1e9 / HBM_PEAK_GBS, 4), algorithmic_bytes_per_launch=b, avg_launch_us=round(1e6 * t, 3))
+    out["roofline"] = dict(bound="hbm", kernel="k_op_apply (c = [P|A'][v; rho.*(A v)] + sigma v, CSR-stream SpMV)", achieved=round(achieved, 1),
+                           peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
+                           algorithmic_bytes_per_launch=bytes_op, avg_launch_us=round(t_op * 1e6, 3), launches_timed=200,
+                           other={"k_spmv_A_rho (A v)": other(bytes_A, t_A), "k_cg_rhs (A' y)": other(bytes_AT, t_AT), "k_spmv_plain (P x)": other(bytes_P, t_P)})
+    b_iter = iteration_bytes(ab, kbar)
+    out["config"] = {"workload": "cfg2: random sparse QP n=%d m=%d nnz(A)=%d nnz(P)=%d, Box cone, CG indirect KKT (tol 1/k^1.5), "
+                                 "check_termination=25, adaptive_rho_interval=40, Ruiz scaling=10, eps=0" % (n, m, nnzA, nnzP),
+                     "parallelism": "replicas x%d (a single sparse QP does not shard; SURVEY 8e)" % world,
+                     "mean_cg_iters_per_admm_iter": round(kbar, 3), "kkt_budget_stalls": stats1["kkt_budget_stalls"],
+                     "iteration_roofline_frac": round(b_iter * (value / world) / (HBM_PEAK_GBS * 1e9), 4),
+                     "algorithmic_bytes_per_iteration": b_iter}
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline_cfg2(prob, args.cpu_sample_iters if not args.small else 200)
+        out["config"]["gpu_over_cpu"] = round((value / world) / out["cpu_baseline"]["value"], 2)
+    h.close()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# cfg3: batch of independent SOCPs, sharded over the ranks (no collective)
+# ---------------------------------------------------------------------------------------------------------------------
+def bench_cfg3(ctx, args, steps, warmup):
+    import cosmo_jl_amd as cj
+    nprob = 64 if args.small else 1024
+    lo, hi = cj.model.shard_range(nprob, ctx.rank, ctx.world)
+    probs = [cj.problems.socp(seed=1000 + k) for k in range(lo, hi)]
+    st = fixed_work_settings(cj)
+    mods = []
+    for p in probs:
+        md = cj.Model(); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], st); mods.append(md)
+    B, _ = cj.model.prepare_batch(mods, ctx.local_rank)
+    B.iterate(warmup, with_init=True)
+    elapsed = ctx.timed(lambda: B.iterate(steps))
+    value = steps / elapsed                                  # one step = one ADMM iteration of ALL problems of the job
+    out = dict(value=value, ms_per_step=1e3 * elapsed / steps, steps=steps, warmup=warmup, scaling="strong")
+    if ctx.rank != 0:
+        B.close()
+        return out
+    n, m = mods[0].n, mods[0].m
+    nnzA, nnzP = int(np.mean([md.A.nnz for md in mods])), int(np.mean([md.P.nnz for md in mods]))
+    ab = algorithmic_bytes(n, m, nnzA, nnzP)
+    out["config"] = {"workload": "cfg3: %d independent SOCPs n=%d m=%d nnz(A)~%d, 50 SecondOrderCone(20) each; one step = one ADMM iteration of every "
+                                 "problem; one persistent workgroup per problem (csrc/batch.hip)" % (nprob, n, m, nnzA),
+                     "parallelism": "batch sharded over %d rank(s), %d problems on rank 0, no collective" % (ctx.world, hi - lo),
+                     "problem_iterations_per_s": round(value * nprob, 1)}
+    # HBM roofline of the SURVEY formula with K = 1 Krylov iteration per solve as a LOWER bound on the algorithmic traffic; the kernel
+    # keeps the problem in LDS / registers, so HBM is not what binds it (SURVEY 8d says to report both)
+    b_low = iteration_bytes(ab, 1.0) * nprob
+    out["roofline"] = dict(bound="hbm", kernel="k_batch_admm_reg (persistent, LDS-resident problem image, register-resident iterates)",
+                           achieved=round(b_low * value / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(b_low * value / 1e9 / HBM_PEAK_GBS, 4),
+                           traffic=None, note="algorithmic bytes = B_iter(K=1) x problems (a lower bound: K >= 1); the kernel touches HBM only at launch / checks")
+    if not args.no_cpu_baseline and ctx.world == 1:
+        from oracle import cosmo_oracle as O
+        from tests import util
+        t0 = time.perf_counter(); its = 0; nsamp = 4
+        for p in probs[:nsamp]:
+            ws = O.Workspace(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), oracle_settings(O, 100))
+            its += ws.optimize().iter
+        secs = time.perf_counter() - t0
+        out["cpu_baseline"] = dict(value=its / secs / nprob, unit="ADMM iterations/s (of the whole batch)", cores=1, kind="port",
+                                   sample="NumPy/SciPy oracle, %d problems x 100 iterations incl. setup, %.1f s, scaled to %d problems solved one after the other "
+                                          "(the reference's own batch mode)" % (nsamp, secs, nprob))
+    B.close()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# cfg4 / cfg5: SDPs (matrix-sign projections on the fp64 matrix cores)
+# ---------------------------------------------------------------------------------------------------------------------
+def _run_sdp(ctx, model, steps, warmup, dist=None):
+    import cosmo_jl_amd as cj
+    cj.model.setup(model)
+    if dist is not None and ctx.world > 1:
+        cj.model.setup_clique_sharding(model, dist)
+    h = model.handle
+    h.set_iterates(model.x, model.s, model.mu)
+    h.admm_init()
+    h.admm_iterate_checked(warmup)
+    s0 = h.get_stats()
+    elapsed = ctx.timed(lambda: h.admm_iterate_checked(steps))
+    s1 = h.get_stats()
+    assert s1["admm_iters"] - s0["admm_iters"] == steps
+    kbar = (s1["kkt_iters_total"] - s0["kkt_iters_total"]) / max(1, s1["kkt_solves"] - s0["kkt_solves"])
+    return h, elapsed, kbar
+
+
+def bench_cfg4(ctx, args, steps, warmup):
+    import cosmo_jl_amd as cj
+    d = 400 if args.small else 2000
+    prob = cj.problems.closest_correlation(d=d)
+    st = fixed_work_settings(cj); st.device = ctx.local_rank
+    model = cj.Model(); model.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)
+    h, elapsed, kbar = _run_sdp(ctx, model, steps, warmup)
+    value = whole_job_value(ctx.world, steps, elapsed)
+    out = dict(value=value, ms_per_step=1e3 * elapsed / steps, steps=steps, warmup=warmup, scaling="weak")
+    if ctx.rank != 0:
+        return out
+    ps = h.polar_stats()
+    t_prod, fl = h.time_psd_product(0, 20)
+    per_gpu = value / ctx.world
+    out["roofline"] = dict(bound="mfma", kernel="k_symm_gemm<EPI, %d, %d> (symmetric product of the sign iteration, v_mfma_f64_16x16x4_f64)" % (ps["tile_side"], ps["k_split"]),
+                           achieved=round(fl / t_prod / 1e12, 2), peak=F64_MFMA_PEAK_TF, unit="TFLOP/s", frac=round(fl / t_prod / 1e12 / F64_MFMA_PEAK_TF, 4), traffic=None,
+                           flops_per_launch=fl, avg_launch_us=round(1e6 * t_prod, 2), launches_timed=20,
+                           products_per_projection=ps["products_last_large"],
+                           performed_tflops_whole_iteration=round(ps["products_last_large"] * fl * per_gpu / 1e12, 2),
+                           useful_tflops_reference_algorithm=round(psd_useful_flops(d) * per_gpu / 1e12, 3),
+                           useful_frac_of_peak=round(psd_useful_flops(d) * per_gpu / 1e12 / F64_MFMA_PEAK_TF, 4))
+    out["config"] = {"workload": "cfg4: closest-correlation SDP, one PsdConeTriangle d=%d (n=%d, m=%d), CG indirect KKT" % (d, model.n, model.m),
+                     "parallelism": "replicas x%d (a single cone does not shard; SURVEY 8e)" % ctx.world,
+                     "mean_cg_iters_per_admm_iter": round(kbar, 3), "polar": {k: ps[k] for k in ("schedule_steps", "fallback_rounds", "verified", "unverified", "err_max_e18")}}
+    if not args.no_cpu_baseline and ctx.world == 1:
+        out["cpu_baseline"] = lapack_cpu_baseline(prob, 2 if not args.small else 20, "cfg4")
+    h.close()
+    return out
+
+
+def bench_cfg5(ctx, args, steps, warmup):
+    import cosmo_jl_amd as cj
+    kw = dict(ncliques=40, n_total=6000, n_zero=100, n_nonneg=500) if args.small else {}
+    prob = cj.problems.chordal_sdp(**kw)
+    st = fixed_work_settings(cj); st.device = ctx.local_rank
+    single = None
+    if ctx.world > 1:
+        # self-contained speed-up: rank 0 times the UNSHARDED problem first (the other ranks wait at the barrier inside timed())
+        if ctx.rank == 0:
+            m1 = cj.Model(); m1.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)
+            cj.model.setup(m1)
+            h1 = m1.handle
+            h1.set_iterates(m1.x, m1.s, m1.mu); h1.admm_init(); h1.admm_iterate_checked(warmup)
+            ctx.torch.cuda.synchronize()
+            t0 = time.perf_counter(); h1.admm_iterate_checked(steps); ctx.torch.cuda.synchronize()
+            single = steps / (time.perf_counter() - t0)
+            h1.close()
+        ctx.barrier()
+    model = cj.Model(); model.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)
+    h, elapsed, kbar = _run_sdp(ctx, model, steps, warmup, dist=ctx.dist)
+    value = steps / elapsed                                                # ONE problem, all ranks work on it: strong scaling
+    out = dict(value=value, ms_per_step=1e3 * elapsed / steps, steps=steps, warmup=warmup, scaling="strong")
+    if ctx.rank != 0:
+        return out
+    ps = h.polar_stats()
+    dk = np.asarray(prob["clique_dims"], dtype=np.float64)
+    useful = float(np.sum([psd_useful_flops(d) for d in dk]))
+    out["config"] = {"workload": "cfg5: chordal-decomposed SDP n=%d m=%d nnz(A)=%d, %d PsdConeTriangle cliques d in [%d, %d] + ZeroSet(%d) + Nonnegatives(%d), "
+                                 "CG indirect KKT" % (model.n, model.m, model.A.nnz, dk.size, dk.min(), dk.max(), prob["sets"][0].dim, prob["sets"][1].dim),
+                     "parallelism": ("cliques sharded over %d ranks (contiguous cone ranges balanced by sum d^3; affine step replicated; one RCCL broadcast group of the "
+                                     "projected slices of s per iteration)" % ctx.world) if ctx.world > 1 else "single GPU",
+                     "mean_cg_iters_per_admm_iter": round(kbar, 3), "comm": h.comm_stats(),
+                     "polar": {k: ps[k] for k in ("batch_cones", "schedule_steps", "products_last_batch", "fallback_rounds", "verified", "unverified", "err_max_e18")}}
+    if single is not None:
+        out["config"]["single_gpu_same_workload"] = round(single, 3)
+        out["config"]["speedup_vs_single_gpu"] = round(value / single, 3)
+    if ps["batch_cones"] > 0:
+        t_prod, fl = h.time_psd_product(1, 20)
+        out["roofline"] = dict(bound="mfma", kernel="k_symm_gemm_batch<EPI> (one workgroup per (clique, upper 64x64 tile) of rank 0's cliques)",
+                               achieved=round(fl / t_prod / 1e12, 2), peak=F64_MFMA_PEAK_TF, unit="TFLOP/s", frac=round(fl / t_prod / 1e12 / F64_MFMA_PEAK_TF, 4), traffic=None,
+                               flops_per_launch=fl, avg_launch_us=round(1e6 * t_prod, 2), launches_timed=20, products_per_projection=ps["products_last_batch"],
+                               useful_tflops_reference_algorithm=round(useful * value / 1e12, 3), useful_frac_of_peak=round(useful * value / 1e12 / F64_MFMA_PEAK_TF, 5))
+    if not args.no_cpu_baseline and ctx.world == 1:
+        out["cpu_baseline"] = lapack_cpu_baseline(prob, 1 if not args.small else 10, "cfg5")
+    h.close()
+    return out
+
+
+BENCH = {"cfg2": bench_cfg2, "cfg3": bench_cfg3, "cfg4": bench_cfg4, "cfg5": bench_cfg5}
+EXTRA_STEPS = {"cfg3": (100, 25), "cfg4": (40, 10), "cfg5": (40, 10)}      # (steps, warmup) of the extra workloads under --workload all
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=25)
+    ap.add_argument("--workload", choices=["all", "cfg2", "cfg3", "cfg4", "cfg5"], default=None,
+                    help="default: all at N=1 (headline cfg2 + extra), cfg5 clique-sharded at N>1")
+    ap.add_argument("--small", action="store_true", help="reduced-size instances (debugging only; not the BASELINE workloads)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-iters", type=int, default=5)
+    ap.add_argument("--exact-launches", action="store_true",
+                    help="cfg2: synchronise after every Krylov iteration (rocprofv3 runs: every launch does full work)")
+    args = ap.parse_args()
+
+    ctx = Ctx()
+    import cosmo_jl_amd as cj  # noqa: F401
+    workload = args.workload or ("all" if ctx.world == 1 else "cfg5")
+    head = "cfg2" if workload == "all" else workload
+    res = BENCH[head](ctx, args, args.steps, args.warmup)
+    extra = {}
+    if workload == "all":
+        for name in ("cfg3", "cfg4", "cfg5"):
+            try:
+                k, w = EXTRA_STEPS[name]
+                r = BENCH[name](ctx, args, k, w)
+                r["value"] = round(r["value"], 3); r["ms_per_step"] = round(r["ms_per_step"], 6); r["unit"] = "ADMM iterations/s"
+                extra[name] = r
+            except Exception as e:                                  # an extra workload must not take the headline line down
+                extra[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+    out = None
+    if ctx.rank == 0:
+        out = {"metric": METRIC, "value": round(res["value"], 3), "unit": "ADMM iterations/s", "n_gpus": ctx.world, "steps": res["steps"], "warmup": res["warmup"],
+               "ms_per_step": round(res["ms_per_step"], 6), "higher_is_better": True, "scaling": res["scaling"], "vs_baseline": None, "dtype": "f64",
+               "data": "synthetic", "config": res.get("config", {}), "roofline": res.get("roofline")}
+        if "cpu_baseline" in res:
+            out["cpu_baseline"] = res["cpu_baseline"]
+        if extra:
+            out["extra"] = extra
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if ctx.dist is not None:
+        ctx.dist.barrier()
+        ctx.dist.destroy_process_group()
     return out
 
 

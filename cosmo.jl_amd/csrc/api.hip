@@ -1054,6 +1054,15 @@ extern "C" int32_t cosmo_hip_optimize(cosmo_hip_handle* h, cosmo_hip_result* res
     long long next = (it == 0) ? 1 : ((it / p.check_termination) + 1) * (long long)p.check_termination;
     next = std::min(next, next_inf_iter(h, it));
     if (next > p.max_iter) next = p.max_iter;
+    if (p.time_limit != 0.0 && it > 0) {
+      // the reference tests the time limit after EVERY iteration (solver.jl:351); the enqueue runs ahead in slices, so a slice is
+      // cut to the number of iterations the measured pace fits into the remaining time (at least one)
+      const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      const double per_it = el / (double)it;
+      const double left = p.time_limit - el;
+      const long long fit = (left > 0.0 && per_it > 0.0) ? (long long)std::min(1e15, left / per_it) : 0;
+      next = std::min(next, it + std::max<long long>(1, fit));
+    }
     const bool check = (next % p.check_termination == 0) || next == 1;
     CHK(run_until(h, next, check ? 1 : -1));
     CHK(maybe_infeas_check(h, next));

@@ -1142,6 +1142,12 @@ extern "C" int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hi
   if (p->kkt_kind != COSMO_HIP_KKT_CG) return bfail(b, COSMO_HIP_ERR_UNSUPPORTED, "batch mode implements the CG KKT solver");
   if (p->adaptive_rho && p->adaptive_rho_interval == 0) return bfail(b, COSMO_HIP_ERR_UNSUPPORTED, "adaptive_rho_interval == 0");
   if (b->finalized) return bfail(b, COSMO_HIP_ERR_INVALID, "batch already finalised");
+  // The persistent per-problem kernels do not evaluate the infeasibility certificates of src/solver.jl:326-349: refuse settings
+  // under which the reference WOULD evaluate them instead of silently running to max_iter (pass check_infeasibility <= 0 or
+  // >= max_iter; infeasible instances belong to the single-problem entry points, which implement the certificates).
+  if (p->check_infeasibility > 0 && (long long)p->check_infeasibility < p->max_iter)
+    return bfail(b, COSMO_HIP_ERR_UNSUPPORTED, "batch mode does not implement the infeasibility certificates: disable them explicitly "
+                                                "(check_infeasibility <= 0 or >= max_iter) or solve with cosmo_hip_optimize");
   b->prm = *p;
   const int nprob = b->nprob; const long long n = b->n, m = b->m;
   BatchDev& D = b->D;

@@ -97,6 +97,7 @@ struct PolarPlan {
   double* BW = nullptr;
   double* bparts = nullptr;
   double* bnrm = nullptr;    // per batched cone ||X||_F
+  int* bgate = nullptr;      // per batched cone: 1 = its verification failed, the next fallback round processes it
 };
 
 extern "C" int32_t cosmo_hip_polar_schedule(int32_t k_lift, double* abc, int32_t* nsteps) {
@@ -354,10 +355,11 @@ __global__ __launch_bounds__(256) void k_symm_gemm_batch(const Ctl* __restrict__
                                                          const BatchCone* __restrict__ cones, double* __restrict__ W, int ia, int ib, int icin, int ic,
                                                          double alpha, double beta) {
   if (guard && ctl->halt) return;
-  if (gate && !*gate) return;
   extern __shared__ double smem[];
   const int4 td = tiles[blockIdx.x];
   if (td.x < 0) return;                      // padding of the XCD-interleaved tile list
+  if (gate && !gate[td.x]) return;           // fallback round: only the cones whose verification failed (per cone, so that a cone's
+                                             // arithmetic never depends on which other cones share its batch / its rank)
   const BatchCone bc = cones[td.x];
   const long long n2 = (long long)bc.ld * bc.ld;
   double* base = W + bc.woff;
@@ -518,7 +520,7 @@ __global__ void k_bpolar_rank(const Ctl* __restrict__ ctl, int guard, int n, con
 __global__ __launch_bounds__(COSMO_BS) void k_bpolar_sumsq(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ gate, const BatchCone* __restrict__ cones,
                                                            const double* __restrict__ W, int ig, double* __restrict__ vparts) {
   if (guard && ctl->halt) return;
-  if (gate && !*gate) return;
+  if (gate && !gate[blockIdx.y]) return;
   __shared__ double red[COSMO_BS / 64];
   const BatchCone cn = cones[blockIdx.y];
   const long long n2 = (long long)cn.ld * cn.ld;
@@ -528,33 +530,36 @@ __global__ __launch_bounds__(COSMO_BS) void k_bpolar_sumsq(const Ctl* __restrict
   acc = block_sum(acc, red);
   if (threadIdx.x == 0) vparts[(size_t)blockIdx.y * BPX + blockIdx.x] = acc;
 }
-__global__ __launch_bounds__(COSMO_BS) void k_bpolar_decide(const Ctl* __restrict__ ctl, int guard, PolarDev* __restrict__ pd, int round, int last, int n,
-                                                            const BatchCone* __restrict__ cones, const double* __restrict__ vparts,
+__global__ __launch_bounds__(COSMO_BS) void k_bpolar_decide(const Ctl* __restrict__ ctl, int guard, PolarDev* __restrict__ pd, int* __restrict__ bgate, int round,
+                                                            int last, int n, const BatchCone* __restrict__ cones, const double* __restrict__ vparts,
                                                             const double* __restrict__ bnrm, double tol_factor) {
   if (guard && ctl->halt) return;
   if (round > 0 && !pd->gate) return;
   __shared__ double red[COSMO_BS / 64];
-  double worst = 0.0;       // max over the cones of err / tol (NaN propagates as "failed")
-  double emax = 0.0;
+  double emax = 0.0, nfail = 0.0, nchk = 0.0;
   for (int c = threadIdx.x; c < n; c += COSMO_BS) {
+    if (round > 0 && !bgate[c]) continue;      // verified in an earlier round
     double g2 = 0.0;
     for (int k = 0; k < BPX; ++k) g2 += vparts[(size_t)c * BPX + k];
     const double nf = bnrm[c];
     const double err = (nf > 0.0) ? 0.5 * sqrt(g2) / nf : 0.0;
-    const double q = err / (tol_factor * cones[c].d * PSD_EPS);
-    worst = (q > worst || q != q) ? q : worst;
+    const bool ok = !(err > tol_factor * cones[c].d * PSD_EPS);       // NaN fails
+    bgate[c] = (!ok && !last) ? 1 : 0;
+    nchk += 1.0;
+    if (!ok) nfail += 1.0;
     emax = (err > emax || err != err) ? err : emax;
   }
-  worst = block_max(worst, red);
   emax = block_max(emax, red);
+  nfail = block_sum(nfail, red);
+  nchk = block_sum(nchk, red);
   if (threadIdx.x != 0) return;
-  const bool ok = !(worst > 1.0);
   pd->err_last = emax;
   if (emax > pd->err_max || emax != emax) pd->err_max = emax;
   if (round == 0) pd->projections += 1; else pd->rounds += 1;
-  if (ok) { pd->verified += 1; pd->gate = 0; }
+  if (nfail == 0.0) { pd->verified += 1; pd->gate = 0; }
   else if (last) { pd->unverified += 1; pd->gate = 0; }
   else pd->gate = 1;
+  (void)nchk;
 }
 
 }  // namespace
@@ -570,6 +575,7 @@ void polar_plan_destroy(cosmo_hip_handle* h) {
   if (q->BW) (void)hipFree(q->BW);
   if (q->bparts) (void)hipFree(q->bparts);
   if (q->bnrm) (void)hipFree(q->bnrm);
+  if (q->bgate) (void)hipFree(q->bgate);
   if (q->dev) (void)hipFree(q->dev);
   delete q;
   h->psd_polar = nullptr;
@@ -667,6 +673,8 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
     HIPCHK(h, hipMalloc((void**)&q->d_btiles, sizeof(int4) * tiles.size()));
     HIPCHK(h, hipMalloc((void**)&q->bparts, sizeof(double) * 3 * BPX * q->bcones.size()));   // norm, trace and verification partials
     HIPCHK(h, hipMalloc((void**)&q->bnrm, sizeof(double) * q->bcones.size()));
+    HIPCHK(h, hipMalloc((void**)&q->bgate, sizeof(int) * q->bcones.size()));
+    HIPCHK(h, hipMemset(q->bgate, 0, sizeof(int) * q->bcones.size()));
     HIPCHK(h, hipMemcpy(q->d_bcones, q->bcones.data(), sizeof(BatchCone) * q->bcones.size(), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(q->d_btiles, tiles.data(), sizeof(int4) * tiles.size(), hipMemcpyHostToDevice));
     (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch<0>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
@@ -701,8 +709,8 @@ int32_t polar_enqueue_project_batch(cosmo_hip_handle* h, double* s, int guard) {
     hipLaunchKernelGGL((k_symm_gemm_batch<0>), G, B, sm, st, h->ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW, iu, 0, 0, 3, 1.0, 0.0);          // H = U X = |X|
     hipLaunchKernelGGL((k_symm_gemm_batch<1>), G, B, sm, st, h->ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW, iu, 3, 0, iy, 1.0, -1.0);        // G = U H - X
     hipLaunchKernelGGL(k_bpolar_sumsq, dim3(BPX, n), dim3(COSMO_BS), 0, st, h->ctl, guard, gate, q->d_bcones, q->BW, iy, vparts);
-    hipLaunchKernelGGL(k_bpolar_decide, dim3(1), dim3(COSMO_BS), 0, st, h->ctl, guard, q->dev, round, round == q->max_rounds ? 1 : 0, n, q->d_bcones, vparts,
-                       q->bnrm, q->tol_factor);
+    hipLaunchKernelGGL(k_bpolar_decide, dim3(1), dim3(COSMO_BS), 0, st, h->ctl, guard, q->dev, q->bgate, round, round == q->max_rounds ? 1 : 0, n, q->d_bcones,
+                       vparts, q->bnrm, q->tol_factor);
     products += 2; q->launches[3] += 2;
   };
   for (int t = 0; t < q->k_lift; ++t) step(kPolarLift, nullptr);
@@ -710,9 +718,9 @@ int32_t polar_enqueue_project_batch(cosmo_hip_handle* h, double* s, int guard) {
   verify(0, nullptr);
   q->products_last_batch = products;
   for (int r = 1; r <= q->max_rounds; ++r) {                 // guarded fallback rounds (even number of steps: iu is preserved)
-    for (int t = 0; t < POLAR_RLIFT; ++t) step(kPolarLift, &q->dev->gate);
-    for (int t = 0; t < POLAR_NFIN; ++t) step(kPolarFinish[t], &q->dev->gate);
-    verify(r, &q->dev->gate);
+    for (int t = 0; t < POLAR_RLIFT; ++t) step(kPolarLift, q->bgate);
+    for (int t = 0; t < POLAR_NFIN; ++t) step(kPolarFinish[t], q->bgate);
+    verify(r, q->bgate);
   }
   hipLaunchKernelGGL(k_bpolar_finish, dim3(BPX, n), dim3(COSMO_BS), 0, st, h->ctl, guard, q->d_bcones, q->BW, iu, s, q->bparts);
   hipLaunchKernelGGL(k_bpolar_rank, dim3((n + 63) / 64), dim3(64), 0, st, h->ctl, guard, n, q->d_bcones, q->bparts, p->rank);

@@ -62,8 +62,8 @@ class CliqueGraphMerge:
 
 @dataclass
 class Settings:
-    """Numeric fields of `COSMO.Settings` read by the hot path (src/settings.jl:101-139).  The accelerator is
-    always `EmptyAccelerator` (Anderson acceleration is a "next" row of SURVEY 8f)."""
+    """Numeric fields of `COSMO.Settings` read by the hot path (src/settings.jl:101-139).  `accelerator` defaults to the
+    EmptyAccelerator; `AndersonAccelerator` (csrc/anderson.hip) is opt-in, see the note next to the field."""
     rho: float = 0.1
     sigma: float = 1e-6
     alpha: float = 1.6
@@ -522,7 +522,11 @@ def warm_start_primal(model: Model, x0):
     """`warm_start_primal!` with a full vector also warm starts s = b - A x (src/interface.jl:130-148)."""
     x0 = np.array(x0, dtype=np.float64)
     model.x[:] = x0
-    if model.is_scaled:
+    if model.is_scaled and getattr(model, "device_scaled", False):
+        # Ruiz scaling ran on the device (setup: device_scaling): the host keeps the UNSCALED P, A and the scaled b = E b0, so the
+        # unscaled slack b0 - A x0 is Einv .* b - A x0 (the reference holds the scaled A here, src/interface.jl:135-146)
+        model.s[:] = model.sm.Einv * model.b - model.A @ x0
+    elif model.is_scaled:
         xs = model.sm.Dinv * x0
         model.s[:] = model.sm.Einv * (model.b - model.A @ xs)
     else:
@@ -740,12 +744,11 @@ def shard_range(n_items: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def _solve_shard_on_device(models: Sequence[Model], device: int) -> List[Result]:
-    """All problems of the shard concurrently on one MI355X (one persistent workgroup per problem, csrc/batch.hip)."""
-    import time
+def prepare_batch(models: Sequence[Model], device: int):
+    """setup! of every problem of a shard (host Ruiz scaling per problem, as the reference does per optimize! call) and upload
+    into one `_ffi.Batch` (csrc/batch.hip), iterates set.  Returns (batch, settings actually used)."""
     if not models:
-        return []
-    t0 = time.perf_counter()
+        raise ValueError("prepare_batch: empty shard")
     n, m = models[0].n, models[0].m
     kinds = [K.kind for K in models[0].sets]; dims = [K.dim for K in models[0].sets]
     for md in models:
@@ -754,6 +757,18 @@ def _solve_shard_on_device(models: Sequence[Model], device: int) -> List[Result]
         if (md.n, md.m) != (n, m) or [K.kind for K in md.sets] != kinds or [K.dim for K in md.sets] != dims:
             raise ValueError("optimize_batch: all problems of a batch must share n, m and the cone structure")
     st = models[0].settings
+    for md in models[1:]:
+        if md.settings != st:
+            raise ValueError("optimize_batch: all problems of a batch share ONE Settings object (per-problem settings are not supported)")
+    if st.accelerator not in (None, EmptyAccelerator):
+        raise ValueError("optimize_batch: the batch kernels implement the plain ADMM loop (EmptyAccelerator) only")
+    if 0 < st.check_infeasibility < st.max_iter:
+        import dataclasses
+        import warnings
+        warnings.warn("optimize_batch: the batch kernels do not evaluate the infeasibility certificates (src/solver.jl:326-349); "
+                      "they are DISABLED for this batch -- an infeasible problem runs to Max_iter_reached.  Solve suspect instances with "
+                      "optimize(), which implements them.", RuntimeWarning, stacklevel=3)
+        st = dataclasses.replace(st, check_infeasibility=0)
     B = _ffi.Batch(len(models), n, m, device)
     bl, bu = [], []
     for k, md in enumerate(models):                      # setup! per problem (scaling on the host, as in the reference)
@@ -766,10 +781,20 @@ def _solve_shard_on_device(models: Sequence[Model], device: int) -> List[Result]
         B.set_scaling(k, md.sm.Dinv, md.sm.Einv, md.sm.cinv)
         bl += [K.l for K in md.sets if K.kind == _ffi.BOX]; bu += [K.u for K in md.sets if K.kind == _ffi.BOX]
     B.set_cones(kinds, dims, np.concatenate(bl) if bl else None, np.concatenate(bu) if bu else None)
-    p = _params_from_settings(None, st)
-    B.set_params(p)
+    B.set_params(_params_from_settings(None, st))
     B.set_iterates(np.concatenate([md.x for md in models]), np.concatenate([md.s for md in models]),
                    np.concatenate([md.mu for md in models]))
+    return B, st
+
+
+def _solve_shard_on_device(models: Sequence[Model], device: int) -> List[Result]:
+    """All problems of the shard concurrently on one MI355X (one persistent workgroup per problem, csrc/batch.hip)."""
+    import time
+    if not models:
+        return []
+    t0 = time.perf_counter()
+    n = models[0].n
+    B, st = prepare_batch(models, device)
     t_setup = time.perf_counter() - t0
     rs = B.optimize()
     out = []
@@ -795,7 +820,13 @@ def optimize_batch(models: Sequence[Model], device: Optional[int] = None, dist=N
     rank = dist.get_rank() if dist is not None else 0
     world = dist.get_world_size() if dist is not None else 1
     lo, hi = shard_range(len(models), rank, world)
-    dev = device if device is not None else (rank if dist is not None else 0)
+    if device is not None:
+        dev = device
+    elif dist is not None:                                        # one process per GPU of ONE node: the local rank, not the global one
+        import os
+        dev = int(os.environ.get("LOCAL_RANK", rank))
+    else:
+        dev = 0
     fn = solve_shard or _solve_shard_on_device
     local = fn(list(models[lo:hi]), dev)
     if dist is None or world == 1:
@@ -828,8 +859,12 @@ def cone_costs(sets: Sequence[AbstractConvexSet]) -> List[int]:
     for K in sets:
         if K.kind in (_ffi.PSD_SQUARE, _ffi.PSD_TRIANGLE) and K.dim > 1:
             out.append(int(K.sqrt_dim) ** 3)
+        elif K.kind == _ffi.PSD_TRIANGLE_COMPLEX and K.dim > 1:
+            out.append((2 * int(K.sqrt_dim)) ** 3)               # projected through its real 2r x 2r embedding
         elif K.kind == _ffi.SOC:
             out.append(int(K.dim))
+        elif K.kind in (_ffi.EXP, _ffi.DUAL_EXP, _ffi.POW, _ffi.DUAL_POW, _ffi.CUSTOM):
+            out.append(64)                                       # a Newton / bisection solve per 3-vector, a host call per custom cone
         else:
             out.append(0)
     return out
@@ -842,6 +877,8 @@ def partition_cones_contiguous(costs: Sequence[int], world: int) -> List[int]:
     n = len(costs)
     if world <= 1 or n == 0:
         return [0] + [n] * max(world, 1)
+    if sum(costs) == 0:                                          # nothing to balance: an even split of the cone list
+        return [(n * r) // world for r in range(world)] + [n]
     lo, hi = max(costs) if costs else 0, sum(costs)
 
     def cuts(limit):

@@ -10,7 +10,7 @@ import os
 import numpy as np
 from . import cosmo_oracle as O
 
-_LIB = None
+_LIB = {}
 
 
 class Params(C.Structure):
@@ -28,22 +28,24 @@ class CResult(C.Structure):
 STATUS = {0: "Undetermined", 1: "Solved", 2: "Max_iter_reached", 3: "Unsolved"}
 
 
-def lib():
-    global _LIB
-    if _LIB is None:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libcosmo_oracle_c.so")
+def lib(native=False):
+    """native=True: the -march=native build (`make -C oracle native`), made by bench.py on the host whose cores it times."""
+    if native not in _LIB:
+        name = "libcosmo_oracle_c_native.so" if native else "libcosmo_oracle_c.so"
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", name)
         if not os.path.exists(path):
-            raise RuntimeError("compiled oracle missing: run `make -C oracle` (or __graft_entry__.build())")
-        _LIB = C.CDLL(path)
-        _LIB.cosmo_oracle_c_run.restype = C.c_int32
-    return _LIB
+            raise RuntimeError("compiled oracle missing: run `make -C oracle%s` (or __graft_entry__.build())" % (" native" if native else ""))
+        L = C.CDLL(path)
+        L.cosmo_oracle_c_run.restype = C.c_int32
+        _LIB[native] = L
+    return _LIB[native]
 
 
 def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
 
-def run(ws: "O.Workspace"):
+def run(ws: "O.Workspace", native=False):
     """Run the loop on a set-up NumPy-oracle workspace (not yet optimised).  Returns a dict with scaled and unscaled iterates."""
     st = ws.st
     assert st.kkt_solver.lower() == "cg" and ws.accelerator is None
@@ -75,7 +77,7 @@ def run(ws: "O.Workspace"):
     q = np.ascontiguousarray(ws.q); b = np.ascontiguousarray(ws.b)
     Dinv = np.ascontiguousarray(ws.sm.Dinv); Einv = np.ascontiguousarray(ws.sm.Einv)
     rho0 = np.ascontiguousarray(ws.rho_vec, np.float64)
-    rc = lib().cosmo_oracle_c_run(C.c_int64(n), C.c_int64(m), _p(Pp, C.c_int64), _p(Pi, C.c_int64), _p(Px, C.c_double), _p(Ap, C.c_int64),
+    rc = lib(native).cosmo_oracle_c_run(C.c_int64(n), C.c_int64(m), _p(Pp, C.c_int64), _p(Pi, C.c_int64), _p(Px, C.c_double), _p(Ap, C.c_int64),
                                   _p(Ai, C.c_int64), _p(Ax, C.c_double), _p(q, C.c_double), _p(b, C.c_double), _p(Dinv, C.c_double),
                                   _p(Einv, C.c_double), _p(cls, C.c_int32), _p(kind, C.c_int32), _p(bl, C.c_double), _p(bu, C.c_double),
                                   C.byref(prm), _p(rho0, C.c_double), _p(x, C.c_double), _p(s, C.c_double), _p(mu, C.c_double),

@@ -1,0 +1,142 @@
+"""GPU parity tests at the FULL sizes of BASELINE.json configs 4 and 5: the d = 2000 PsdConeTriangle
+projection against LAPACK dsyevr (src/convexset.jl:219-263, 402-412) with an assertion on WHICH product kernel ran, the composite
+projection of all 400 cliques of the decomposed SDP and short tight-CG trajectories of both configurations against the committed
+oracle fixtures tests/golden/baseline_cfg{4,5}.npz (generator: tests/golden/make_fixtures_baseline.py; the NumPy oracle needs
+~25 s per cfg5 iteration, so it is not re-run on the GPU box), and the CG operator split on/off at full size."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+import cosmo_jl_amd as cj
+from oracle import cosmo_oracle as O
+from tests import util
+from tests.util import EPS
+
+pytestmark = pytest.mark.gpu
+F = cj._ffi
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+_spec = importlib.util.spec_from_file_location("make_fixtures_baseline", os.path.join(HERE, "make_fixtures_baseline.py"))
+MK = importlib.util.module_from_spec(_spec); _spec.loader.exec_module(MK)
+
+
+def _fixture(name):
+    return np.load(os.path.join(HERE, "baseline_%s.npz" % name))
+
+
+def _proj_handle(sets):
+    import scipy.sparse as sp
+    m = sum(K.dim for K in sets)
+    h = cj.Handle(0)
+    h.set_problem(sp.identity(2, format="csc"), np.zeros(2), sp.csc_matrix((m, 2)), np.zeros(m))
+    h.set_cones([K.kind for K in sets], [K.dim for K in sets], None, None)
+    return h
+
+
+def test_cfg4_projection_d2000_vs_lapack_and_kernel_variant():
+    """One PsdConeTriangle of side 2000 (BASELINE config 4): ||dX+||_F <= 64 d eps ||X||_F against the oracle's dsyevr + syrk,
+    exact rank on a gapped spectrum, and the 8-wave split-k <96, 2> product kernel is the one that ran (231 tiles on 256 CUs)."""
+    d = 2000
+    rng = np.random.default_rng(2000)
+    K = cj.PsdConeTriangle(d * (d + 1) // 2)
+    h = _proj_handle([K])
+    st0 = h.polar_stats()
+    assert (st0["large_cones"], st0["batch_cones"], st0["tile_side"], st0["k_split"]) == (1, 0, 96, 2)
+    # (a) the matrix the closest-correlation problem projects first: a dense symmetric matrix with no structure
+    G = rng.uniform(-1.0, 1.0, size=(d, d)); X = (G + G.T) / 2
+    # (b) a gapped spectrum (rank is then well defined)
+    Q = np.linalg.qr(rng.standard_normal((d, d)))[0]
+    lam = np.concatenate([rng.uniform(0.1, 2.0, 900), -rng.uniform(0.1, 2.0, d - 900)])
+    Xg = (Q * lam) @ Q.T; Xg = (Xg + Xg.T) / 2
+    for M, want_rank in ((X, None), (Xg, 900)):
+        s = cj.problems.svec(M)
+        ref = s.copy(); info = {}
+        O.project(ref, util.oracle_cones([K]), info)
+        before = h.polar_stats()
+        out, rk, _ = h.project(s)
+        after = h.polar_stats()
+        err = np.linalg.norm(out - ref)
+        assert err <= 64 * d * EPS * np.linalg.norm(M), err / (d * EPS * np.linalg.norm(M))
+        if want_rank is not None:
+            assert int(rk[0]) == info["psd_rank"][0] == want_rank
+        # which kernel ran: every product of this projection was a <96, 2> launch; (10 + 5) * 3 + 2 = 47 of them did the work,
+        # the rest are the gated fallback rounds (enqueued, returned at once because the verification passed)
+        assert after["launches_64_1"] == before["launches_64_1"] and after["launches_96_1"] == before["launches_96_1"]
+        assert after["launches_96_2"] - before["launches_96_2"] == 47 + 2 * (8 * 3 + 2)
+        assert after["products_last_large"] == 47 and after["schedule_steps"] == 15
+        assert after["fallback_rounds"] == before["fallback_rounds"] and after["verified"] == before["verified"] + 1
+        assert after["err_max_e18"] * 1e-18 <= 8 * d * EPS
+    h.close()
+
+
+def _run_config(name):
+    p = MK.problem(name)
+    st = cj.Settings(kkt_solver=cj.with_options(cj.CGIndirectKKTSolver, **{k: MK.SETTINGS[k] for k in ("tol_constant", "tol_exponent")}),
+                     max_iter=MK.ITERS[name], eps_abs=0.0, eps_rel=0.0, check_infeasibility=10 ** 9)
+    md = cj.Model(); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], st)
+    return p, md, cj.optimize(md)
+
+
+@pytest.mark.parametrize("name", ["cfg4", "cfg5"])
+def test_full_size_trajectory_matches_the_committed_oracle_fixture(name):
+    fx = _fixture(name)
+    p, md, r = _run_config(name)
+    sc = fx["scalars"]
+    assert r.iter == int(sc[0]) == MK.ITERS[name] and r.status == "Max_iter_reached"
+    for key, val in (("x", r.x), ("s", r.s), ("y", r.y)):
+        idx, ref, nrm = fx[key + "_idx"], fx[key + "_val"], fx[key + "_norm"]
+        assert np.max(np.abs(val[idx] - ref)) <= 1e-7 * max(1.0, float(nrm[1])), (name, key)      # SURVEY 8c trajectory tolerance
+        assert abs(np.linalg.norm(val) - nrm[0]) <= 1e-7 * max(1.0, nrm[0]) and abs(np.max(np.abs(val)) - nrm[1]) <= 1e-7 * max(1.0, nrm[1])
+    assert abs(r.obj_val - sc[3]) <= 1e-7 * (1 + abs(sc[3]))
+    assert abs(r.info.r_prim - sc[1]) <= 1e-6 * max(sc[1], 1e-12) and abs(r.info.r_dual - sc[2]) <= 1e-6 * max(sc[2], 1e-12)
+    assert abs(r.kkt_iters_total - sc[4]) <= 0.02 * sc[4] + 2
+    ps = md.handle.polar_stats()
+    if name == "cfg4":
+        assert ps["large_cones"] == 1 and ps["tile_side"] == 96 and ps["k_split"] == 2 and ps["launches_96_2"] > 0 and ps["launches_64_1"] == 0
+    else:
+        assert ps["batch_cones"] > 250 and ps["launches_batch"] > 0          # the 64 < d <= 200 cliques take the batched sign path
+        assert md.handle.psd_stats()["not_converged"] == 0                   # the d <= 64 cliques take the one-workgroup Jacobi kernels
+    assert ps["unverified"] == 0
+
+
+@pytest.mark.parametrize("name", ["cfg4", "cfg5"])
+def test_full_size_composite_projection_matches_the_committed_oracle_fixture(name):
+    """src/convexset.jl:885-891 over every cone of the configuration (cfg5: ZeroSet + Nonnegatives + 400 PsdConeTriangle of side
+    20..200, i.e. Jacobi (d <= 64) and batched matrix-sign (d > 64) kernels in one call)."""
+    fx = _fixture(name)
+    p = MK.problem(name)
+    h = _proj_handle(p["sets"])
+    m = sum(K.dim for K in p["sets"])
+    v = MK.projection_input(name, m)
+    out, ranks, _ = h.project(v)
+    offs = np.concatenate([[0], np.cumsum([K.dim for K in p["sets"]])])
+    # per-cone Frobenius norm of the projected block: a checksum over every entry; tolerance 64 d eps ||X_k||_F per cone
+    for k, K in enumerate(p["sets"]):
+        blk_in = np.linalg.norm(v[offs[k]:offs[k + 1]])
+        d = K.sqrt_dim if K.kind == F.PSD_TRIANGLE else 1
+        assert abs(np.linalg.norm(out[offs[k]:offs[k + 1]]) - fx["proj_cone_norm"][k]) <= 64 * max(d, 1) * EPS * max(blk_in, 1e-300), (name, k, d)
+    idx = fx["proj_idx"]
+    dmax = max(K.sqrt_dim for K in p["sets"] if K.kind == F.PSD_TRIANGLE)
+    assert np.max(np.abs(out[idx] - fx["proj_val"])) <= 64 * dmax * EPS * np.max([np.linalg.norm(v[offs[k]:offs[k + 1]]) for k in range(len(p["sets"]))
+                                                                                   if p["sets"][k].kind == F.PSD_TRIANGLE])
+    got = np.array([r for r in ranks if r >= 0], dtype=np.int64)
+    assert got.size == fx["proj_rank"].size
+    # a standard-normal svec has no eigenvalue cluster at 0: the ranks agree exactly on all cones
+    assert np.array_equal(got, fx["proj_rank"])
+    h.close()
+
+
+def test_cfg5_operator_split_on_off_at_full_size(monkeypatch):
+    """The singleton-row diagonal of A' rho A (csrc/api.hip: build_op_split) at BASELINE config 5's size: same iterates (1e-7)
+    and Krylov work (2 %) as the unsplit operator."""
+    out = {}
+    for split in ("1", "0"):
+        monkeypatch.setenv("COSMO_HIP_OP_SPLIT", split)
+        _, md, r = _run_config("cfg5")
+        out[split] = r
+    r1, r0 = out["1"], out["0"]
+    assert r1.iter == r0.iter
+    assert abs(r1.kkt_iters_total - r0.kkt_iters_total) <= 0.02 * r0.kkt_iters_total + 2
+    assert np.max(np.abs(r1.x - r0.x)) <= 1e-7 * max(1.0, float(np.max(np.abs(r0.x))))
+    assert np.max(np.abs(r1.s - r0.s)) <= 1e-7 * max(1.0, float(np.max(np.abs(r0.s))))

@@ -1,5 +1,13 @@
 """GPU tests of the clique-sharded projection on ONE device: ownership ranges + slice merge reproduce the full
-projection bit for bit; the RCCL path is exercised with a single-rank communicator."""
+projection bit for bit; the RCCL path is exercised with a single-rank communicator; the exchange step itself
+(comm_enqueue_exchange with nranks = 2: row_lo / row_hi slices, exchange point of the iteration) runs in TWO PROCESSES that share
+the device through the host-staged transport and must reproduce the single-rank run bit for bit."""
+import os
+import subprocess
+import sys
+import tempfile
+import uuid
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -88,3 +96,76 @@ def test_infeasibility_certificates_in_sharded_runs():
         model.handle.set_cone_shard(cj.partition_cones_contiguous(cj.cone_costs(model.sets), 1))
         res = cj.optimize(model)
         assert ref.status == want and res.status == want and res.iter == ref.iter
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# two ranks = two processes on the one GPU of the box
+# ---------------------------------------------------------------------------------------------------------------------
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "shard_worker.py")
+ITERS = 60
+
+
+def _spawn(transport, world, rdv, tmp, timeout=240):
+    env = dict(os.environ, COSMO_HIP_POLAR_KLIFT="10")            # pin the sign-iteration schedule (it is pinned in sharded runs anyway)
+    procs = [subprocess.Popen([sys.executable, WORKER, transport, str(r), str(world), rdv, os.path.join(tmp, "rank%d.npz" % r), str(ITERS)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            if transport == "rccl":
+                return [(-9, "timed out (RCCL communicator setup with two ranks on one device did not return)")]
+            raise
+        outs.append((p.returncode, o))
+    return outs
+
+
+def _single_rank_reference(monkeypatch):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("shard_worker", WORKER)
+    W = importlib.util.module_from_spec(spec); spec.loader.exec_module(W)
+    monkeypatch.setenv("COSMO_HIP_POLAR_KLIFT", "10")
+    p = W.problem()
+    md = cj.Model(); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], W.settings(ITERS))
+    return cj.optimize(md), md
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exchange_with_several_ranks_is_bit_identical_to_the_single_rank_run(world, monkeypatch):
+    ref, md = _single_rank_reference(monkeypatch)
+    bounds = cj.partition_cones_contiguous(cj.cone_costs(md.sets), world)
+    assert all(bounds[r + 1] > bounds[r] for r in range(world))                    # every rank owns cliques
+    with tempfile.TemporaryDirectory() as tmp:
+        outs = _spawn("shm", world, "/cosmo_test_" + uuid.uuid4().hex[:12], tmp)
+        for rc, o in outs:
+            assert rc == 0, o[-2000:]
+        for r in range(world):
+            z = np.load(os.path.join(tmp, "rank%d.npz" % r))
+            assert int(z["nranks"]) == world and int(z["transport"]) == 2
+            assert int(z["exchanges"]) >= ITERS                                    # one exchange step per iteration really ran with nranks > 1
+            assert np.array_equal(z["bounds"], np.array(bounds))
+            assert int(z["iter"]) == ref.iter == ITERS and int(z["kkt"]) == ref.kkt_iters_total
+            for key, val in (("x", ref.x), ("s", ref.s), ("y", ref.y)):
+                assert np.array_equal(z[key].view(np.int64), val.view(np.int64)), (r, key)       # bit for bit, on every rank
+            assert float(z["obj"]) == ref.obj_val and float(z["r_prim"]) == ref.info.r_prim
+
+
+def test_rccl_two_ranks_on_one_device_is_refused_or_identical(monkeypatch):
+    """RCCL normally rejects two ranks on one device ("Duplicate GPU detected"); when it does, this test records that as a skip
+    (the multi-rank RCCL path needs a multi-GPU node: the driver's scaling run).  Should a build accept it, the result must be
+    bit-identical to the single-rank run as well."""
+    ref, md = _single_rank_reference(monkeypatch)
+    with tempfile.TemporaryDirectory() as tmp:
+        outs = _spawn("rccl", 2, os.path.join(tmp, "uid.bin"), tmp, timeout=60)
+        if any(rc != 0 for rc, _ in outs):
+            msg = " | ".join(o.strip().splitlines()[-1] if o.strip() else "" for _, o in outs)
+            pytest.skip("RCCL refused 2 ranks on one device: " + msg[-300:])
+        for r in range(2):
+            z = np.load(os.path.join(tmp, "rank%d.npz" % r))
+            assert int(z["transport"]) == 1 and int(z["exchanges"]) >= ITERS
+            for key, val in (("x", ref.x), ("s", ref.s), ("y", ref.y)):
+                assert np.array_equal(z[key].view(np.int64), val.view(np.int64)), (r, key)
