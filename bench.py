@@ -146,14 +146,14 @@ def oracle_rate(prob, iters, threads):
 
 def lapack_cpu_baseline(prob, iters, label):
     """cpu_baseline for the SDP configurations: 1 BLAS thread (what the tagged reference does outside BLAS) and all host threads."""
-    nt = host_threads()
+    nt = min(host_threads(), 32)       # dsyevr / syrk at these sizes stop scaling long before the 256 threads of the GPU box's host
     v1, it1, s1, cg1 = oracle_rate(prob, iters, 1)
     out = dict(value=v1, unit="ADMM iterations/s", cores=1, kind="port",
                sample="NumPy/SciPy oracle (dsyevr + syrk projections, restated cg!): %d ADMM iteration(s) + init step of the same %s instance, %.1f s, "
                       "1 BLAS thread; mean CG its/solve %.1f" % (it1, label, s1, cg1))
     if nt > 1:
         vn, itn, sn, _ = oracle_rate(prob, iters, nt)
-        out["all_threads"] = dict(value=vn, cores=nt, sample="%d iteration(s), %.1f s, OPENBLAS threads = %d" % (itn, sn, nt))
+        out["all_threads"] = dict(value=vn, cores=nt, sample="%d iteration(s), %.1f s, OPENBLAS threads = %d (host has %d)" % (itn, sn, nt, host_threads()))
     return out
 
 
@@ -381,7 +381,7 @@ def bench_cfg5(ctx, args, steps, warmup):
                                  "CG indirect KKT" % (model.n, model.m, model.A.nnz, dk.size, dk.min(), dk.max(), prob["sets"][0].dim, prob["sets"][1].dim),
                      "parallelism": ("cliques sharded over %d ranks (contiguous cone ranges balanced by sum d^3; affine step replicated; one RCCL broadcast group of the "
                                      "projected slices of s per iteration)" % ctx.world) if ctx.world > 1 else "single GPU",
-                     "mean_cg_iters_per_admm_iter": round(kbar, 3), "comm": h.comm_stats(),
+                     "mean_cg_iters_per_admm_iter": round(kbar, 3), "comm": h.comm_stats(), "cg_persist": h.cg_persist_stats(),
                      "polar": {k: ps[k] for k in ("batch_cones", "schedule_steps", "products_last_batch", "fallback_rounds", "verified", "unverified", "err_max_e18")}}
     if single is not None:
         out["config"]["single_gpu_same_workload"] = round(single, 3)

@@ -113,6 +113,7 @@ SIGNATURES = {
     "cosmo_hip_residuals": (C.c_int32, [C.c_void_p, _PD]),
     "cosmo_hip_optimize": (C.c_int32, [C.c_void_p, C.POINTER(ResultStruct)]),
     "cosmo_hip_get_iterates": (C.c_int32, [C.c_void_p, _PD, _PD, _PD, _PD]),
+    "cosmo_hip_cg_persist_stats": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_get_kkt_solution": (C.c_int32, [C.c_void_p, _PD]),
     "cosmo_hip_get_stats": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_time_spmv": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _PD, _PD]),
@@ -387,6 +388,11 @@ class Handle:
         self._chk(self.lib.cosmo_hip_get_stats(self._h, out.ctypes.data_as(_PI64)))
         keys = ["admm_iters", "kkt_solves", "kkt_iters_total", "kkt_budget_stalls", "spmv_A", "spmv_AT", "spmv_P", "rho_updates"]
         return dict(zip(keys, out.tolist()))
+
+    def cg_persist_stats(self):
+        out = np.zeros(8, dtype=np.int64)
+        self._chk(self.lib.cosmo_hip_cg_persist_stats(self._h, out.ctypes.data_as(_PI64)))
+        return dict(zip(["enabled", "workgroups", "launches", "fallbacks", "tickets", "arrivals", "abort", "lds_per_quarter"], out.tolist()))
 
     # ---- measurement -------------------------------------------------------------------------------------------
     def time_spmv(self, which, reps=50):

@@ -113,6 +113,7 @@ static void build_row_blocks(const std::vector<int>& rowptr, int nrows, std::vec
   const long long nnz_total = nrows > 0 ? (long long)rowptr[nrows] : 0;
   int tile = COSMO_NNZ_PER_BLOCK;
   if (nnz_total < 512LL * COSMO_NNZ_PER_BLOCK) tile = (int)std::max<long long>(256, ((nnz_total / 512 + 63) / 64) * 64);
+  if (nnz_total <= 256LL * 768) tile = 256;     // operators of the single-launch CG (cg_persist.hip): one nonzero per thread and tile
   const int ROWS_MAX = tile < COSMO_NNZ_PER_BLOCK ? COSMO_BS : 4 * COSMO_BS;
   int r = 0;
   while (r < nrows) {
@@ -252,6 +253,7 @@ extern "C" int32_t cosmo_hip_destroy(cosmo_hip_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   free_csr(h->A); free_csr(h->AT); free_csr(h->P); free_csr(h->PT);
   free_op_split(h);
+  pcg_free(h);
   (void)cosmo_hip_comm_destroy(h);
   aa_free(h);
   free_vectors(h);
@@ -570,7 +572,8 @@ extern "C" int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_par
   HIPCHK(h, hipMemsetAsync(h->x_tl, 0, sizeof(double) * (size_t)std::max<long long>(h->n, 1), h->stream));
   HIPCHK(h, hipMemsetAsync(h->nu, 0, sizeof(double) * (size_t)std::max<long long>(h->m, 1), h->stream));
   h->have_params = true;
-  return build_op_split(h);   // needs the (scaled) matrices and rho: both final from here on
+  CHK(build_op_split(h));     // needs the (scaled) matrices and rho: both final from here on
+  return pcg_setup(h);        // single-launch CG for operators that fit one XCD's L2
 }
 
 extern "C" int32_t cosmo_hip_update_rho(cosmo_hip_handle* h, const double* rho_vec) {
@@ -728,7 +731,18 @@ extern "C" int32_t cosmo_hip_kkt_solve(cosmo_hip_handle* h, double* lhs, const d
     CHK(enqueue_y2_only(h));
     CHK(enqueue_cg_start(h, 0, tol_for_solve(h, h->host_solves + 1)));
     int k = 0, chunk = std::max(h->budget, 4);
-    for (;;) {
+    bool solved = false;
+    if (h->pcg_on) {
+      CHK(pcg_enqueue_solve(h, 0));
+      CHK(sync_ctl(h));
+      if (h->ctl_host->stalled) {           // the start-up rendezvous failed: nothing was modified, continue with the multi-kernel loop
+        h->pcg_on = false; h->pcg_fallbacks += 1;
+        CHK(enqueue_clear_stall(h));
+      } else {
+        solved = true;
+      }
+    }
+    while (!solved) {
       CHK(enqueue_cg_iterations(h, 0, k, chunk));
       CHK(sync_ctl(h));
       if (h->ctl_host->cg_done) break;
@@ -775,7 +789,9 @@ static int32_t enqueue_solve_in_loop(cosmo_hip_handle* h) {
   CHK(enqueue_rhs(h, 1));
   if (h->prm.kkt_kind == COSMO_HIP_KKT_CG) {
     CHK(enqueue_cg_start(h, 1, tol_for_solve(h, h->host_solves + 1)));
-    if (h->exact_launches) {
+    if (h->pcg_on) {
+      CHK(pcg_enqueue_solve(h, 1));        // the whole Krylov loop in one launch (cg_persist.hip)
+    } else if (h->exact_launches) {
       // measurement mode: one Krylov iteration per host round trip, so that every launch does full work
       CHK(enqueue_cg_iterations(h, 1, 0, 0));
       for (int k = 0;; ++k) {
@@ -828,6 +844,7 @@ static int32_t enqueue_iteration(cosmo_hip_handle* h, long long it) {
 static int32_t resolve_stall(cosmo_hip_handle* h) {
   while (h->ctl_host->stalled) {
     h->stalls += 1;
+    if (h->pcg_on) { h->pcg_on = false; h->pcg_fallbacks += 1; }     // only a failed start-up rendezvous stalls the persistent kernel
     int extra = std::max(2 * h->budget, 8);
     if (h->prm.kkt_kind == COSMO_HIP_KKT_CG) {
       CHK(enqueue_clear_stall(h));
@@ -1111,6 +1128,26 @@ extern "C" int32_t cosmo_hip_get_iterates(cosmo_hip_handle* h, double* w, double
   if (w) CHK(d2h(h, w, h->w, N));
   if (w_prev) CHK(d2h(h, w_prev, h->w_prev, N));
   if (s) CHK(d2h(h, s, h->s, (size_t)h->m));
+  return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_cg_persist_stats(cosmo_hip_handle* h, int64_t out[8]) {
+  if (!h || !out) return COSMO_HIP_ERR_INVALID;
+  out[0] = h->pcg_on ? 1 : 0; out[1] = h->pcg_W; out[2] = h->pcg_launches; out[3] = h->pcg_fallbacks;
+  out[4] = out[5] = out[6] = 0; out[7] = h->pcg_cap;
+  if (h->pcg_sync) {                                  // synchronisation words of the last launch: tickets, barrier arrivals, abort flag
+    unsigned w[4] = {0, 0, 0, 0};
+    if (hipSetDevice(h->device) != hipSuccess) return cosmo_fail(h, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
+    HIPCHK(h, hipMemcpyAsync(w, h->pcg_sync, sizeof w, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    out[4] = w[0]; out[5] = w[1]; out[6] = w[2];
+    if (getenv("COSMO_HIP_PCG_TIMING")) {             // lab build (-DPCG_TIMING): phase clocks of workgroup 0 (100 MHz ticks) and iterations
+      unsigned t[8];
+      HIPCHK(h, hipMemcpy(t, h->pcg_sync + 8, sizeof t, hipMemcpyDeviceToHost));
+      fprintf(stderr, "pcg timing (us per Krylov iteration over %u its): top %.2f  dirA %.2f  B2 %.2f  opapply %.2f  B3 %.2f  upd %.2f  B4 %.2f\n", t[7],
+              t[0] / 100.0 / t[7], t[1] / 100.0 / t[7], t[2] / 100.0 / t[7], t[3] / 100.0 / t[7], t[4] / 100.0 / t[7], t[5] / 100.0 / t[7], t[6] / 100.0 / t[7]);
+    }
+  }
   return COSMO_HIP_OK;
 }
 

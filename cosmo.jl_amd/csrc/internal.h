@@ -133,6 +133,13 @@ struct cosmo_hip_handle {
   void* psd_polar = nullptr;      // PolarPlan (psd_polar.hip): large cones
   void* accel = nullptr;          // AaState (anderson.hip)
   long long safeguarding_iter = 0;
+  // persistent single-launch CG (cg_persist.hip)
+  bool pcg_on = false;
+  unsigned* pcg_sync = nullptr;
+  double* pcg_u2 = nullptr;
+  int pcg_W = 0, pcg_cap = 0;
+  size_t pcg_smem = 0;
+  long long pcg_launches = 0, pcg_fallbacks = 0;
   // clique sharding (comm.hip): this rank projects the SOC / PSD cones cone_lo <= k < cone_hi (cone_hi < 0: all cones)
   void* comm = nullptr;
   long long cone_lo = 0, cone_hi = -1;
@@ -201,6 +208,11 @@ int32_t enqueue_admm_x_and_w(cosmo_hip_handle* h);
 int32_t sync_ctl(cosmo_hip_handle* h);
 
 int32_t comm_allreduce_flag(cosmo_hip_handle* h, int* flag);   // comm.hip: max over the ranks of a 0/1 flag
+
+// persistent CG (cg_persist.hip)
+int32_t pcg_setup(cosmo_hip_handle* h);
+void pcg_free(cosmo_hip_handle* h);
+int32_t pcg_enqueue_solve(cosmo_hip_handle* h, int guard);
 
 // Anderson acceleration (anderson.hip)
 void aa_free(cosmo_hip_handle* h);

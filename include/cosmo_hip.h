@@ -260,6 +260,10 @@ int32_t cosmo_hip_optimize(cosmo_hip_handle* h, cosmo_hip_result* result);
  * s (m), mu (m) with mu = rho .* (w_prev[n+1:] - s) recovered first.  Any pointer may be NULL. */
 int32_t cosmo_hip_get_iterates(cosmo_hip_handle* h, double* w, double* w_prev, double* s, double* mu);
 /* sol = [x_tl; nu] of the last KKT solve (ws.sol, src/solver.jl:227-228), length n+m. */
+/* Single-launch CG (csrc/cg_persist.hip): out = {enabled for this handle (operator fits one XCD's L2), participating workgroups,
+ * persistent launches so far, fallbacks to the multi-kernel path, tickets / barrier arrivals / abort flag of the last launch, LDS
+ * doubles per quarter}.  COSMO_HIP_CG_PERSIST=0 / 1 in the environment disables / forces it. */
+int32_t cosmo_hip_cg_persist_stats(cosmo_hip_handle* h, int64_t out[8]);
 int32_t cosmo_hip_get_kkt_solution(cosmo_hip_handle* h, double* sol);
 /* Statistics of the device loop since set_iterates: out = {admm_iters, kkt_solves, kkt_iters_total,
  * kkt_budget_stalls, spmv_A_calls, spmv_AT_calls, spmv_P_calls, rho_updates}. */

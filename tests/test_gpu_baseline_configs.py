@@ -90,7 +90,7 @@ def test_full_size_trajectory_matches_the_committed_oracle_fixture(name):
         assert abs(np.linalg.norm(val) - nrm[0]) <= 1e-7 * max(1.0, nrm[0]) and abs(np.max(np.abs(val)) - nrm[1]) <= 1e-7 * max(1.0, nrm[1])
     assert abs(r.obj_val - sc[3]) <= 1e-7 * (1 + abs(sc[3]))
     assert abs(r.info.r_prim - sc[1]) <= 1e-6 * max(sc[1], 1e-12) and abs(r.info.r_dual - sc[2]) <= 1e-6 * max(sc[2], 1e-12)
-    assert abs(r.kkt_iters_total - sc[4]) <= 0.02 * sc[4] + 2
+    assert abs(r.kkt_iters_total - sc[4]) <= 0.02 * sc[4] + (MK.ITERS[name] + 1)      # +-1 Krylov iteration per solve at the 1e-10 stopping threshold
     ps = md.handle.polar_stats()
     if name == "cfg4":
         assert ps["large_cones"] == 1 and ps["tile_side"] == 96 and ps["k_split"] == 2 and ps["launches_96_2"] > 0 and ps["launches_64_1"] == 0
