@@ -235,7 +235,7 @@ static void free_vectors(cosmo_hip_handle* h) {
   dfree(&h->inf_dy); dfree(&h->inf_dx); dfree(&h->inf_adx); dfree(&h->inf_flags);
   dfree(&h->w); dfree(&h->w_prev); dfree(&h->s); dfree(&h->mu); dfree(&h->s_tl);
   dfree(&h->ls_x); dfree(&h->ls_s); dfree(&h->x_tl); dfree(&h->nu);
-  dfree(&h->rhs); dfree(&h->r); dfree(&h->u); dfree(&h->c); dfree(&h->tmp_m); dfree(&h->y2); dfree(&h->mr);
+  dfree(&h->rhs); dfree(&h->r); dfree(&h->u); dfree(&h->c); dfree(&h->tmp_m); dfree(&h->y2); dfree(&h->mr); dfree(&h->cg_ru);
   dfree(&h->io);
 }
 static void free_cones(cosmo_hip_handle* h) {
@@ -573,7 +573,12 @@ extern "C" int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_par
   HIPCHK(h, hipMemsetAsync(h->nu, 0, sizeof(double) * (size_t)std::max<long long>(h->m, 1), h->stream));
   h->have_params = true;
   CHK(build_op_split(h));     // needs the (scaled) matrices and rho: both final from here on
-  return pcg_setup(h);        // single-launch CG for operators that fit one XCD's L2
+  // fused direction + A product (k_cg_dirA): one launch less per Krylov iteration, bit-identical; COSMO_HIP_CG_FUSE_DIR=0 disables it
+  dfree(&h->cg_ru);
+  { bool fuse = (p->kkt_kind == COSMO_HIP_KKT_CG) && h->n > 0;
+    if (const char* e = getenv("COSMO_HIP_CG_FUSE_DIR")) fuse = fuse && atoi(e) != 0;
+    if (fuse) CHK(dalloc(h, &h->cg_ru, 2 * (size_t)h->n)); }
+  return pcg_setup(h);        // single-launch CG (opt-in)
 }
 
 extern "C" int32_t cosmo_hip_update_rho(cosmo_hip_handle* h, const double* rho_vec) {

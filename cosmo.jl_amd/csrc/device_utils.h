@@ -88,27 +88,33 @@ __device__ __forceinline__ double amax(double acc, double v) {
 // segment left to right -- exactly the order in which Julia's CSC kernels accumulate (no FMA contraction), so the
 // row sums are bit-identical to the serial CPU loop.  Rows longer than the LDS tile take the chunked path.
 // fn(row, sum1, sum2): sum1 over [rowptr[row], split[row]) and sum2 over [split[row], rowptr[row+1]).
-template <class RowFn>
-__device__ __forceinline__ void csr_stream_rows(const CsrView& M, const double* __restrict__ x1,
-                                                const double* __restrict__ x2, int r0, int r1, int nz0, int nz1, double* lds,
-                                                double* red, RowFn fn) {
+// gat(c): the operand gathered for column c (the plain form below reads x1 / x2; the fused direction + product kernel of the CG
+// iteration rebuilds u = r + beta u_old at the gathered column).
+template <class GatherFn, class RowFn>
+__device__ __forceinline__ void csr_stream_rows_g(const CsrView& M, GatherFn gat, int r0, int r1, int nz0, int nz1, double* lds,
+                                                  double* red, RowFn fn) {
   const int cnt = nz1 - nz0;
   if (cnt <= COSMO_NNZ_PER_BLOCK) {
+    // row pointers of this thread's first row: requested together with (col, val) so that the dependent chain of these 3-20 us
+    // kernels is descriptor -> {col, val, rowptr} -> gather instead of descriptor -> {col, val} -> gather -> rowptr
+    const int rfirst = r0 + threadIdx.x;
+    int pa = 0, pb = 0, psp = 0;
+    if (rfirst < r1) { pa = M.rowptr[rfirst]; pb = M.rowptr[rfirst + 1]; psp = M.split ? M.split[rfirst] : pb; }
 #pragma unroll
     for (int it = 0; it < COSMO_NNZ_PER_BLOCK / COSMO_BS; ++it) {
       const int k = it * COSMO_BS + threadIdx.x;
       if (k < cnt) {
         const int c = M.col[nz0 + k];
         const double a = M.val[nz0 + k];
-        const double xv = (c < M.split_col) ? x1[c] : x2[c - M.split_col];
+        const double xv = gat(c);
         lds[k] = a * xv;
       }
     }
     __syncthreads();
-    for (int r = r0 + threadIdx.x; r < r1; r += COSMO_BS) {
-      const int a = M.rowptr[r] - nz0;
-      const int b = M.rowptr[r + 1] - nz0;
-      const int sp = M.split ? (M.split[r] - nz0) : b;
+    for (int r = rfirst; r < r1; r += COSMO_BS) {
+      const int a = ((r == rfirst) ? pa : M.rowptr[r]) - nz0;
+      const int b = ((r == rfirst) ? pb : M.rowptr[r + 1]) - nz0;
+      const int sp = (r == rfirst) ? (psp - nz0) : (M.split ? (M.split[r] - nz0) : b);
       double s1 = 0.0, s2 = 0.0;
       for (int k = a; k < sp; ++k) s1 += lds[k];
       for (int k = sp; k < b; ++k) s2 += lds[k];
@@ -122,7 +128,7 @@ __device__ __forceinline__ void csr_stream_rows(const CsrView& M, const double* 
     double s1 = 0.0, s2 = 0.0;
     for (int k = nz0 + threadIdx.x; k < nz1; k += COSMO_BS) {
       const int c = M.col[k];
-      const double xv = (c < M.split_col) ? x1[c] : x2[c - M.split_col];
+      const double xv = gat(c);
       const double p = M.val[k] * xv;
       if (k < sp) s1 += p; else s2 += p;
     }
@@ -131,6 +137,14 @@ __device__ __forceinline__ void csr_stream_rows(const CsrView& M, const double* 
     if (threadIdx.x == 0) fn(r, s1, s2);
     __syncthreads();
   }
+}
+
+template <class RowFn>
+__device__ __forceinline__ void csr_stream_rows(const CsrView& M, const double* __restrict__ x1,
+                                                const double* __restrict__ x2, int r0, int r1, int nz0, int nz1, double* lds,
+                                                double* red, RowFn fn) {
+  const int split_col = M.split_col;
+  csr_stream_rows_g(M, [&](int c) { return (c < split_col) ? x1[c] : x2[c - split_col]; }, r0, r1, nz0, nz1, lds, red, fn);
 }
 
 // Tile k of the CSR-stream schedule.  M.rb holds one 16-byte descriptor {first row, end row, first nonzero, end nonzero}

@@ -133,6 +133,7 @@ struct cosmo_hip_handle {
   void* psd_polar = nullptr;      // PolarPlan (psd_polar.hip): large cones
   void* accel = nullptr;          // AaState (anderson.hip)
   long long safeguarding_iter = 0;
+  double* cg_ru = nullptr;        // {r_i, u_i} interleaved (2n doubles): operands of the fused direction + A-product kernel (k_cg_dirA); null = unfused
   // persistent single-launch CG (cg_persist.hip)
   bool pcg_on = false;
   unsigned* pcg_sync = nullptr;

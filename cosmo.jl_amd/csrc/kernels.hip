@@ -263,12 +263,96 @@ __global__ __launch_bounds__(COSMO_BS) void k_cg_dir(Ctl* __restrict__ ctl, int 
   }
 }
 
+// Krylov step k >= 1, first half FUSED with the A product (one launch and one kernel boundary less per iteration): every workgroup
+// folds the r'r partials itself (as k_cg_dir does), applies the stopping rule, and computes tmp = rho .* (A u_k) with u_k = r + beta
+// u_{k-1} REBUILT at the gathered columns -- same expression, same bits as the owner's update.  r and u_{k-1} live interleaved in
+// `ru` ({r_i, u_i}, written by k_cg_upd), so the two operands of a column arrive with ONE 16-byte gather.  The workgroups also
+// materialise u_k (grid-stride over the elements) for the operator kernel and for k_cg_upd.
+__global__ __launch_bounds__(COSMO_BS) void k_cg_dirA(Ctl* __restrict__ ctl, int guard, int k, long long n, long long maxiter,
+                                                      const double* __restrict__ part_rr, int n_rr, CsrView A, const double2* __restrict__ ru,
+                                                      const double* __restrict__ rho, double* __restrict__ tmp, double* __restrict__ u) {
+  // Everything that does not depend on beta is requested FIRST -- the r'r partials, the tile descriptor, (col, val) and the 16-byte
+  // {r, u} gathers of the first tile, the row pointers, this workgroup's slice of {r, u} -- so that the partial reduction / stopping
+  // rule overlaps the gather latency instead of preceding it.  Absent slots read a valid address and carry a zero matrix value
+  // (a load under a per-thread `if` would make the compiler wait for it on the spot).
+  constexpr int SL = COSMO_NNZ_PER_BLOCK / COSMO_BS;
+  const double pa = partials_prefetch_sum(part_rr, n_rr);
+  const bool have_tile = (int)blockIdx.x < A.nb;
+  int4 d = make_int4(0, 0, 0, 0);
+  if (have_tile) d = reinterpret_cast<const int4*>(A.rb)[blockIdx.x];
+  const int cnt0 = d.w - d.z;
+  const bool fast = have_tile && cnt0 <= COSMO_NNZ_PER_BLOCK;      // a single long row takes the generic chunked path below
+  double av[SL]; double2 gv[SL];
+#pragma unroll
+  for (int it = 0; it < SL; ++it) {
+    const int kk = it * COSMO_BS + threadIdx.x;
+    const bool ok = fast && kk < cnt0;
+    const int e = ok ? d.z + kk : 0;
+    const int c = A.col[e];
+    const double a = A.val[e];
+    av[it] = ok ? a : 0.0;
+    gv[it] = ru[c];
+  }
+  const int rfirst = d.x + threadIdx.x;
+  const bool rowok = fast && rfirst < d.y;
+  const int rr_ = rowok ? rfirst : 0;
+  const int pa_ = A.rowptr[rr_], pb_ = A.rowptr[rr_ + 1];
+  const double rho_ = rho[rr_];
+  const long long i0 = (long long)blockIdx.x * COSMO_BS + threadIdx.x;
+  const double2 own = ru[i0 < n ? i0 : 0];
+  if (guard && ctl->halt) return;
+  if (ctl->cg_done) return;
+  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ double red[COSMO_BS / 64];
+  const double tol = ctl->tol;
+  const double prev = ctl->resv[(k - 1) & 1];
+  const double rr = block_sum(pa, red);
+  const double res = sqrt(rr);
+  const bool done = (k >= maxiter) || (res <= tol);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (done) ctl->cg_done = 1;
+    ctl->resv[k & 1] = res;
+  }
+  if (done) return;
+  const double beta = (res * res) / (prev * prev);
+  if (i0 < n) u[i0] = own.x + beta * own.y;
+  for (long long i = i0 + (long long)gridDim.x * COSMO_BS; i < n; i += (long long)gridDim.x * COSMO_BS) {
+    const double2 v = ru[i];
+    u[i] = v.x + beta * v.y;
+  }
+  if (fast) {
+#pragma unroll
+    for (int it = 0; it < SL; ++it) {
+      const int kk = it * COSMO_BS + threadIdx.x;
+      if (kk < cnt0) lds[kk] = av[it] * (gv[it].x + beta * gv[it].y);
+    }
+    __syncthreads();
+    if (rowok) {                                    // first row of this thread: pointers already here
+      double s1 = 0.0, s2 = 0.0;
+      for (int e = pa_ - d.z; e < pb_ - d.z; ++e) s1 += lds[e];
+      tmp[rfirst] = (s1 + s2) * rho_;
+    }
+    for (int r = rfirst + COSMO_BS; r < d.y; r += COSMO_BS) {
+      const int a = A.rowptr[r] - d.z, b = A.rowptr[r + 1] - d.z;
+      double s1 = 0.0, s2 = 0.0;
+      for (int e = a; e < b; ++e) s1 += lds[e];
+      tmp[r] = (s1 + s2) * rho[r];
+    }
+    __syncthreads();
+  }
+  for (int t = fast ? (int)(blockIdx.x + gridDim.x) : (int)blockIdx.x; t < A.nb; t += gridDim.x) {
+    const int4 dd = reinterpret_cast<const int4*>(A.rb)[t];
+    csr_stream_rows_g(A, [&](int c) { const double2 v = ru[c]; return v.x + beta * v.y; }, dd.x, dd.y, dd.z, dd.w, lds, red,
+                      [&](int r, double s1, double s2) { tmp[r] = (s1 + s2) * rho[r]; });
+  }
+}
+
 // Krylov step k, second half: alpha = res_k^2 / (u.c) ; x += alpha u ; r -= alpha c ; partial sum r^2
 __global__ __launch_bounds__(COSMO_BS) void k_cg_upd(Ctl* __restrict__ ctl, int guard, int k, long long n,
                                                      const double* __restrict__ part_uc, int n_uc,
                                                      const double* __restrict__ u, const double* __restrict__ c,
                                                      double* __restrict__ x, double* __restrict__ r,
-                                                     double* __restrict__ part_rr) {
+                                                     double* __restrict__ part_rr, double2* __restrict__ ru) {
   const long long i0 = (long long)blockIdx.x * COSMO_BS + threadIdx.x;
   double u0 = 0.0, c0 = 0.0, x0 = 0.0, r0 = 0.0;
   if (i0 < n) { u0 = u[i0]; c0 = c[i0]; x0 = x[i0]; r0 = r[i0]; }   // issued before the scalar work (latency overlap)
@@ -284,12 +368,15 @@ __global__ __launch_bounds__(COSMO_BS) void k_cg_upd(Ctl* __restrict__ ctl, int 
     x[i0] = x0 + alpha * u0;
     const double ri = r0 - alpha * c0;
     r[i0] = ri;
+    if (ru) ru[i0] = make_double2(ri, u0);       // {r_{k+1}, u_k}: the operands of the fused direction + product kernel
     acc += ri * ri;
   }
   for (long long i = i0 + (long long)gridDim.x * COSMO_BS; i < n; i += (long long)gridDim.x * COSMO_BS) {
-    x[i] = x[i] + alpha * u[i];
+    const double ui = u[i];
+    x[i] = x[i] + alpha * ui;
     const double ri = r[i] - alpha * c[i];
     r[i] = ri;
+    if (ru) ru[i] = make_double2(ri, ui);
     acc += ri * ri;
   }
   acc = block_sum(acc, red);
@@ -603,21 +690,28 @@ int32_t enqueue_cg_iterations(cosmo_hip_handle* h, int guard, int k_begin, int c
   const double* diag_o = h->op_split ? h->op_diag : nullptr;
   const int n_rr0 = PTo.grid;
   for (int k = k_begin; k < k_begin + count; ++k) {
-    prof_begin(h, KC_CG_DIR);
-    hipLaunchKernelGGL(k_cg_dir, dim3(gE), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, k, 0, n, n, PARTS(h, SLOT_RR),
-                       (k == 0) ? n_rr0 : gE, h->r, h->u);
-    prof_end(h);
-    prof_begin(h, KC_SPMV_A);
-    hipLaunchKernelGGL(k_spmv_A_rho, dim3(Ao.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, 1, view_of(Ao), h->u,
-                       rho_o, h->tmp_m);
-    prof_end(h);
+    if (h->cg_ru && k > 0) {
+      prof_begin(h, KC_SPMV_A);
+      hipLaunchKernelGGL(k_cg_dirA, dim3(Ao.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, k, n, n, PARTS(h, SLOT_RR), gE, view_of(Ao),
+                         (const double2*)h->cg_ru, rho_o, h->tmp_m, h->u);
+      prof_end(h);
+    } else {
+      prof_begin(h, KC_CG_DIR);
+      hipLaunchKernelGGL(k_cg_dir, dim3(gE), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, k, 0, n, n, PARTS(h, SLOT_RR),
+                         (k == 0) ? n_rr0 : gE, h->r, h->u);
+      prof_end(h);
+      prof_begin(h, KC_SPMV_A);
+      hipLaunchKernelGGL(k_spmv_A_rho, dim3(Ao.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, 1, view_of(Ao), h->u,
+                         rho_o, h->tmp_m);
+      prof_end(h);
+    }
     prof_begin(h, KC_OP_APPLY);
     hipLaunchKernelGGL(k_op_apply, dim3(PTo.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, 1, view_of(PTo),
                        h->prm.sigma, h->u, h->tmp_m, h->rhs, h->r, h->c, PARTS(h, SLOT_UC), PARTS(h, SLOT_BB), 0, 0.0, diag_o);
     prof_end(h);
     prof_begin(h, KC_CG_UPD);
     hipLaunchKernelGGL(k_cg_upd, dim3(gE), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, k, n, PARTS(h, SLOT_UC),
-                       PTo.grid, h->u, h->c, h->x_tl, h->r, PARTS(h, SLOT_RR));
+                       PTo.grid, h->u, h->c, h->x_tl, h->r, PARTS(h, SLOT_RR), (double2*)h->cg_ru);
     prof_end(h);
     h->spmv_calls[0] += 1; h->spmv_calls[1] += 1; h->spmv_calls[2] += 1;
   }

@@ -11,8 +11,9 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-def _solve(monkeypatch, persist, prob, iters, **st_kw):
+def _solve(monkeypatch, persist, prob, iters, fuse="1", **st_kw):
     monkeypatch.setenv("COSMO_HIP_CG_PERSIST", persist)
+    monkeypatch.setenv("COSMO_HIP_CG_FUSE_DIR", fuse)
     monkeypatch.setenv("COSMO_HIP_POLAR_KLIFT", "10")
     st = cj.Settings(max_iter=iters, eps_abs=0.0, eps_rel=0.0, check_infeasibility=10 ** 9, **st_kw)
     md = cj.Model(); md.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)
@@ -53,3 +54,16 @@ def test_persistent_cg_default_solve_matches_the_oracle(monkeypatch):
     assert md.handle.cg_persist_stats()["launches"] > 0
     assert r.status == ref.status == "Solved" and abs(r.iter - ref.iter) <= 25
     assert abs(r.obj_val - ref.obj_val) <= 1e-4 * (1 + abs(ref.obj_val))
+
+
+@pytest.mark.parametrize("name", sorted(PROBLEMS))
+def test_fused_direction_and_product_kernel_is_bit_identical(name, monkeypatch):
+    """k_cg_dirA (direction update rebuilt at the gathered columns of the A product, {r, u} interleaved for one 16-byte gather) against
+    the separate k_cg_dir + k_spmv_A_rho launches: same iterates, same Krylov iteration counts, bit for bit."""
+    prob = PROBLEMS[name]()
+    r1, s1, k1, _ = _solve(monkeypatch, "0", prob, 80, fuse="1")
+    r0, s0, k0, _ = _solve(monkeypatch, "0", prob, 80, fuse="0")
+    assert r1.iter == r0.iter == 80 and r1.kkt_iters_total == r0.kkt_iters_total and k1 == k0
+    for a, b in ((r1.x, r0.x), (r1.s, r0.s), (r1.y, r0.y), (s1, s0)):
+        assert np.array_equal(a.view(np.int64), b.view(np.int64))
+    assert r1.obj_val == r0.obj_val and r1.info.rho_updates == r0.info.rho_updates
