@@ -143,6 +143,8 @@ int32_t upload_csr(cosmo_hip_handle* h, const HostCsr& M, CsrDev& D, int split_c
   int grid_cap = COSMO_MAX_PARTIALS;
   if (const char* e = getenv("COSMO_HIP_GRID_CAP")) { const int v = atoi(e); if (v >= 64 && v <= COSMO_MAX_PARTIALS) grid_cap = v; }   // lab knob
   D.grid = std::max(1, std::min(D.nb, grid_cap));
+  D.xcd_affine = 1;
+  if (const char* e = getenv("COSMO_HIP_XCD_AFFINE")) D.xcd_affine = atoi(e) ? 1 : 0;
   CHK(dalloc(h, &D.rowptr, (size_t)M.nrows + 1));
   CHK(dalloc(h, &D.col, M.col.size()));
   CHK(dalloc(h, &D.val, M.val.size()));

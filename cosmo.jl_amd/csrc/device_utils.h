@@ -8,6 +8,7 @@ enum { SLOT_BB = 0, SLOT_RR, SLOT_UC, SLOT_RP, SLOT_MP, SLOT_RD, SLOT_MD, SLOT_X
 #define COSMO_NSLOTS_TOTAL 12
 
 struct CsrView {
+  int xcd_affine;    // 1: workgroup b of a one-tile-per-workgroup launch takes tile (b % 8) * (nb / 8) + b / 8 (see tile_of_block)
   const int* rowptr;
   const int* col;
   const double* val;
@@ -22,7 +23,18 @@ static inline CsrView view_of(const CsrDev& D) {
   CsrView v;
   v.rowptr = D.rowptr; v.col = D.col; v.val = D.val; v.split = D.split; v.rb = D.rb;
   v.nb = D.nb; v.nrows = D.nrows; v.split_col = D.split_col;
+  v.xcd_affine = (D.xcd_affine && D.grid == D.nb) ? 1 : 0;
   return v;
+}
+
+// XCD-affine tile order.  Workgroup b of a launch is observed on XCD b % 8 and every XCD has its own L2; with the identity order the
+// eight L2s each see every eighth tile, i.e. rows from all over the matrix.  Here XCD x works through ONE contiguous range of tiles
+// (rows), so that the lines of the row-indexed operands and -- for matrices with column locality -- of the gathered vector are
+// fetched by one L2 instead of eight.  Only a speed choice: results (including the per-tile partials, which are indexed by TILE)
+// do not depend on it.  Tiles beyond 8 * (nb / 8) keep the identity order.
+__device__ __forceinline__ int tile_of_block(int b, int nb, int affine) {
+  const int per = nb >> 3;
+  return (affine && b < (per << 3)) ? (b & 7) * per + (b >> 3) : b;
 }
 
 // Butterfly reductions: every lane ends with the same value, combination order is fixed => deterministic.
@@ -88,6 +100,20 @@ __device__ __forceinline__ double amax(double acc, double v) {
 // segment left to right -- exactly the order in which Julia's CSC kernels accumulate (no FMA contraction), so the
 // row sums are bit-identical to the serial CPU loop.  Rows longer than the LDS tile take the chunked path.
 // fn(row, sum1, sum2): sum1 over [rowptr[row], split[row]) and sum2 over [split[row], rowptr[row+1]).
+// Left-to-right sum of lds[a .. b): the additions happen strictly in index order (the order of Julia's CSC kernels: bit-identical row
+// sums), but four LDS reads are requested before the four dependent additions -- a 20-nonzero row (A', [P | A']) otherwise pays one
+// LDS round trip per nonzero with only a third of the workgroup's threads owning a row.
+__device__ __forceinline__ double lds_seq_sum(const double* lds, int a, int b) {
+  double s = 0.0;
+  int k = a;
+  for (; k + 4 <= b; k += 4) {
+    const double v0 = lds[k], v1 = lds[k + 1], v2 = lds[k + 2], v3 = lds[k + 3];
+    s += v0; s += v1; s += v2; s += v3;
+  }
+  for (; k < b; ++k) s += lds[k];
+  return s;
+}
+
 // gat(c): the operand gathered for column c (the plain form below reads x1 / x2; the fused direction + product kernel of the CG
 // iteration rebuilds u = r + beta u_old at the gathered column).
 template <class GatherFn, class RowFn>
@@ -115,9 +141,8 @@ __device__ __forceinline__ void csr_stream_rows_g(const CsrView& M, GatherFn gat
       const int a = ((r == rfirst) ? pa : M.rowptr[r]) - nz0;
       const int b = ((r == rfirst) ? pb : M.rowptr[r + 1]) - nz0;
       const int sp = (r == rfirst) ? (psp - nz0) : (M.split ? (M.split[r] - nz0) : b);
-      double s1 = 0.0, s2 = 0.0;
-      for (int k = a; k < sp; ++k) s1 += lds[k];
-      for (int k = sp; k < b; ++k) s2 += lds[k];
+      const double s1 = lds_seq_sum(lds, a, sp);
+      const double s2 = lds_seq_sum(lds, sp, b);
       fn(r, s1, s2);
     }
     __syncthreads();

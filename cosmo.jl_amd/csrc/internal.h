@@ -57,6 +57,7 @@ struct CsrDev {
   int nb = 0;             // number of row blocks
   int grid = 0;           // workgroups launched (<= COSMO_MAX_PARTIALS), each loops over row blocks
   int split_col = 0;      // merged operator: columns >= split_col gather from the second vector
+  int xcd_affine = 0;     // XCD-affine tile order in the one-tile-per-workgroup kernels (device_utils.h: tile_of_block)
 };
 
 struct HostCsr {  // host staging of a CSR matrix (0-based)

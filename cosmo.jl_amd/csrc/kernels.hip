@@ -10,8 +10,8 @@
 __global__ __launch_bounds__(COSMO_BS) void k_spmv_plain(CsrView M, const double* __restrict__ x, double* __restrict__ y) {
   __shared__ double lds[COSMO_NNZ_PER_BLOCK];
   __shared__ double red[COSMO_BS / 64];
-  for (int k = blockIdx.x; k < M.nb; k += gridDim.x) {
-    csr_stream_tile(M, x, x, k, lds, red, [&](int r, double s1, double s2) { y[r] = s1 + s2; });
+  for (int b = blockIdx.x; b < M.nb; b += gridDim.x) {
+    csr_stream_tile(M, x, x, tile_of_block(b, M.nb, M.xcd_affine), lds, red, [&](int r, double s1, double s2) { y[r] = s1 + s2; });
   }
 }
 
@@ -182,8 +182,8 @@ __global__ __launch_bounds__(COSMO_BS) void k_spmv_A_rho(const Ctl* __restrict__
   if (mode == 1 && ctl->cg_done) return;
   __shared__ double lds[COSMO_NNZ_PER_BLOCK];
   __shared__ double red[COSMO_BS / 64];
-  for (int k = blockIdx.x; k < A.nb; k += gridDim.x) {
-    csr_stream_tile(A, v, v, k, lds, red,
+  for (int b = blockIdx.x; b < A.nb; b += gridDim.x) {
+    csr_stream_tile(A, v, v, tile_of_block(b, A.nb, A.xcd_affine), lds, red,
                      [&](int r, double s1, double s2) { out[r] = (s1 + s2) * rho[r]; });
   }
 }
@@ -211,7 +211,8 @@ __global__ __launch_bounds__(COSMO_BS) void k_op_apply(Ctl* __restrict__ ctl, in
     }
   }
   double acc = 0.0;
-  for (int k = blockIdx.x; k < PT.nb; k += gridDim.x) {
+  const int first_tile = tile_of_block(blockIdx.x, PT.nb, PT.xcd_affine);     // affine => grid == nb: the loop runs once
+  for (int k = first_tile; k < PT.nb; k += gridDim.x) {
     csr_stream_tile(PT, v, tmp, k, lds, red, [&](int row, double s1, double s2) {
       const double vj = v[row];
       double cj = s1 + (sigma * vj + s2);
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_op_apply(Ctl* __restrict__ ctl, in
     });
   }
   acc = block_sum(acc, red);
-  if (threadIdx.x == 0) part_out[blockIdx.x] = acc;
+  if (threadIdx.x == 0) part_out[PT.xcd_affine ? first_tile : (int)blockIdx.x] = acc;      // indexed by TILE: independent of the tile order
 }
 
 // Krylov step k, first half (IterativeSolvers v0.9 cg.jl `iterate`): residual_k = ||r|| from the partials;
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_cg_dirA(Ctl* __restrict__ ctl, int
   const double pa = partials_prefetch_sum(part_rr, n_rr);
   const bool have_tile = (int)blockIdx.x < A.nb;
   int4 d = make_int4(0, 0, 0, 0);
-  if (have_tile) d = reinterpret_cast<const int4*>(A.rb)[blockIdx.x];
+  if (have_tile) d = reinterpret_cast<const int4*>(A.rb)[tile_of_block(blockIdx.x, A.nb, A.xcd_affine)];
   const int cnt0 = d.w - d.z;
   const bool fast = have_tile && cnt0 <= COSMO_NNZ_PER_BLOCK;      // a single long row takes the generic chunked path below
   double av[SL]; double2 gv[SL];
@@ -328,20 +329,17 @@ __global__ __launch_bounds__(COSMO_BS) void k_cg_dirA(Ctl* __restrict__ ctl, int
     }
     __syncthreads();
     if (rowok) {                                    // first row of this thread: pointers already here
-      double s1 = 0.0, s2 = 0.0;
-      for (int e = pa_ - d.z; e < pb_ - d.z; ++e) s1 += lds[e];
+      const double s1 = lds_seq_sum(lds, pa_ - d.z, pb_ - d.z), s2 = 0.0;
       tmp[rfirst] = (s1 + s2) * rho_;
     }
     for (int r = rfirst + COSMO_BS; r < d.y; r += COSMO_BS) {
-      const int a = A.rowptr[r] - d.z, b = A.rowptr[r + 1] - d.z;
-      double s1 = 0.0, s2 = 0.0;
-      for (int e = a; e < b; ++e) s1 += lds[e];
+      const double s1 = lds_seq_sum(lds, A.rowptr[r] - d.z, A.rowptr[r + 1] - d.z), s2 = 0.0;
       tmp[r] = (s1 + s2) * rho[r];
     }
     __syncthreads();
   }
-  for (int t = fast ? (int)(blockIdx.x + gridDim.x) : (int)blockIdx.x; t < A.nb; t += gridDim.x) {
-    const int4 dd = reinterpret_cast<const int4*>(A.rb)[t];
+  for (int b = fast ? (int)(blockIdx.x + gridDim.x) : (int)blockIdx.x; b < A.nb; b += gridDim.x) {
+    const int4 dd = reinterpret_cast<const int4*>(A.rb)[tile_of_block(b, A.nb, A.xcd_affine)];
     csr_stream_rows_g(A, [&](int c) { const double2 v = ru[c]; return v.x + beta * v.y; }, dd.x, dd.y, dd.z, dd.w, lds, red,
                       [&](int r, double s1, double s2) { tmp[r] = (s1 + s2) * rho[r]; });
   }
