@@ -115,8 +115,12 @@ class Ctx:
         return el
 
 
+KKT_CHOICE = {"name": "cg"}
+
+
 def fixed_work_settings(cj, **kw):
-    base = dict(eps_abs=0.0, eps_rel=0.0, max_iter=10 ** 9, check_infeasibility=10 ** 9, kkt_solver=cj.CGIndirectKKTSolver)
+    kkt = cj.CGSingleReductionKKTSolver if KKT_CHOICE["name"] == "cg-sr" else cj.CGIndirectKKTSolver
+    base = dict(eps_abs=0.0, eps_rel=0.0, max_iter=10 ** 9, check_infeasibility=10 ** 9, kkt_solver=kkt)
     base.update(kw)
     return cj.Settings(**base)
 
@@ -412,11 +416,14 @@ def main():
     ap.add_argument("--small", action="store_true", help="reduced-size instances (debugging only; not the BASELINE workloads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-iters", type=int, default=5)
+    ap.add_argument("--kkt", choices=["cg", "cg-sr"], default="cg",
+                    help="cg: the literal cg! recurrence (default, the reference's algorithm); cg-sr: opt-in single-reduction CG (csrc/cg_sr.hip)")
     ap.add_argument("--exact-launches", action="store_true",
                     help="cfg2: synchronise after every Krylov iteration (rocprofv3 runs: every launch does full work)")
     args = ap.parse_args()
 
     ctx = Ctx()
+    KKT_CHOICE["name"] = args.kkt
     import cosmo_jl_amd as cj  # noqa: F401
     workload = args.workload or ("all" if ctx.world == 1 else "cfg5")
     head = "cfg2" if workload == "all" else workload
@@ -436,6 +443,8 @@ def main():
         out = {"metric": METRIC, "value": round(res["value"], 3), "unit": "ADMM iterations/s", "n_gpus": ctx.world, "steps": res["steps"], "warmup": res["warmup"],
                "ms_per_step": round(res["ms_per_step"], 6), "higher_is_better": True, "scaling": res["scaling"], "vs_baseline": None, "dtype": "f64",
                "data": "synthetic", "config": res.get("config", {}), "roofline": res.get("roofline")}
+        out["config"]["kkt_solver"] = ("CG, literal cg! recurrence (reference algorithm)" if args.kkt == "cg" else
+                                       "CG, single-reduction (Chronopoulos-Gear) recurrence -- OPT-IN variant, same operator / stopping rule")
         if "cpu_baseline" in res:
             out["cpu_baseline"] = res["cpu_baseline"]
         if extra:

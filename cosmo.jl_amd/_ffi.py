@@ -21,7 +21,7 @@ ZERO, NONNEG, BOX, SOC, PSD_SQUARE, PSD_TRIANGLE = 0, 1, 2, 3, 4, 5
 EXP, DUAL_EXP, POW, DUAL_POW = 6, 7, 8, 9
 PSD_TRIANGLE_COMPLEX = 10
 CUSTOM = 11
-KKT_CG, KKT_MINRES_REDUCED, KKT_MINRES = 0, 1, 2
+KKT_CG, KKT_MINRES_REDUCED, KKT_MINRES, KKT_CG_SR = 0, 1, 2, 3
 STATUS_NAMES = {0: "Undetermined", 1: "Solved", 2: "Max_iter_reached", 3: "Unsolved", 4: "Primal_infeasible",
                 5: "Dual_infeasible", 6: "Time_limit_reached"}
 MAT_A, MAT_AT, MAT_P, MAT_OP = 0, 1, 2, 3

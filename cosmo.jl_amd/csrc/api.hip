@@ -256,6 +256,7 @@ extern "C" int32_t cosmo_hip_destroy(cosmo_hip_handle* h) {
   free_csr(h->A); free_csr(h->AT); free_csr(h->P); free_csr(h->PT);
   free_op_split(h);
   pcg_free(h);
+  sr_free(h);
   (void)cosmo_hip_comm_destroy(h);
   aa_free(h);
   free_vectors(h);
@@ -547,12 +548,14 @@ extern "C" int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_par
   ENTER(h);
   if (!p) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "null params");
   if (!h->have_cones) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_cones must be called before set_params");
-  if (p->kkt_kind < COSMO_HIP_KKT_CG || p->kkt_kind > COSMO_HIP_KKT_MINRES) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "bad kkt_kind");
+  if (p->kkt_kind < COSMO_HIP_KKT_CG || p->kkt_kind > COSMO_HIP_KKT_CG_SR) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "bad kkt_kind");
   if (p->check_termination <= 0) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "check_termination must be > 0");
   if (p->adaptive_rho && p->adaptive_rho_interval == 0)
     return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "adaptive_rho_interval == 0 (wall-clock rule, solver.jl:244-256) is not supported");
   const bool reclass = (p->cosmo_infty_min_scaling != h->prm.cosmo_infty_min_scaling) || (p->rho_tol != h->prm.rho_tol);
   h->prm = *p;
+  h->cg_sr = (p->kkt_kind == COSMO_HIP_KKT_CG_SR);
+  if (h->cg_sr) h->prm.kkt_kind = COSMO_HIP_KKT_CG;      // the same reduced operator, split, budget and tail; only the Krylov recurrence differs
   if (reclass) {
     std::vector<double> bhost((size_t)h->m);
     CHK(d2h(h, bhost.data(), h->b, (size_t)h->m));
@@ -569,7 +572,8 @@ extern "C" int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_par
   h->ctl_host->kkt_iters_total = 0;
   CHK(h2d(h, h->ctl, h->ctl_host, 1));
   h->host_solves = 0;
-  if (p->kkt_kind != COSMO_HIP_KKT_CG) CHK(minres_alloc(h));
+  if (h->prm.kkt_kind != COSMO_HIP_KKT_CG) CHK(minres_alloc(h));
+  CHK(sr_alloc(h));
   // the Krylov warm start (previous_solution) starts at zero (kktsolver_indirect.jl:32)
   HIPCHK(h, hipMemsetAsync(h->x_tl, 0, sizeof(double) * (size_t)std::max<long long>(h->n, 1), h->stream));
   HIPCHK(h, hipMemsetAsync(h->nu, 0, sizeof(double) * (size_t)std::max<long long>(h->m, 1), h->stream));
@@ -577,7 +581,7 @@ extern "C" int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_par
   CHK(build_op_split(h));     // needs the (scaled) matrices and rho: both final from here on
   // fused direction + A product (k_cg_dirA): one launch less per Krylov iteration, bit-identical; COSMO_HIP_CG_FUSE_DIR=0 disables it
   dfree(&h->cg_ru);
-  { bool fuse = (p->kkt_kind == COSMO_HIP_KKT_CG) && h->n > 0;
+  { bool fuse = (h->prm.kkt_kind == COSMO_HIP_KKT_CG) && !h->cg_sr && h->n > 0;
     if (const char* e = getenv("COSMO_HIP_CG_FUSE_DIR")) fuse = fuse && atoi(e) != 0;
     if (fuse) CHK(dalloc(h, &h->cg_ru, 2 * (size_t)h->n)); }
   return pcg_setup(h);        // single-launch CG (opt-in)
@@ -739,7 +743,17 @@ extern "C" int32_t cosmo_hip_kkt_solve(cosmo_hip_handle* h, double* lhs, const d
     CHK(enqueue_cg_start(h, 0, tol_for_solve(h, h->host_solves + 1)));
     int k = 0, chunk = std::max(h->budget, 4);
     bool solved = false;
-    if (h->pcg_on) {
+    if (h->cg_sr) {
+      CHK(sr_enqueue_start(h, 0));
+      for (;;) {
+        CHK(sr_enqueue_iterations(h, 0, k, chunk));
+        CHK(sync_ctl(h));
+        if (h->ctl_host->cg_done) break;
+        k += chunk;
+        chunk = std::min(chunk * 2, 1024);
+      }
+      solved = true;
+    } else if (h->pcg_on) {
       CHK(pcg_enqueue_solve(h, 0));
       CHK(sync_ctl(h));
       if (h->ctl_host->stalled) {           // the start-up rendezvous failed: nothing was modified, continue with the multi-kernel loop
@@ -796,7 +810,19 @@ static int32_t enqueue_solve_in_loop(cosmo_hip_handle* h) {
   CHK(enqueue_rhs(h, 1));
   if (h->prm.kkt_kind == COSMO_HIP_KKT_CG) {
     CHK(enqueue_cg_start(h, 1, tol_for_solve(h, h->host_solves + 1)));
-    if (h->pcg_on) {
+    if (h->cg_sr) {
+      CHK(sr_enqueue_start(h, 1));
+      if (h->exact_launches) {
+        CHK(sr_enqueue_iterations(h, 1, 0, 0));
+        for (int k = 0;; ++k) {
+          CHK(sync_ctl(h));
+          if (h->ctl_host->cg_done || h->ctl_host->halt) break;
+          CHK(sr_enqueue_iterations(h, 1, k, 1));
+        }
+      } else {
+        CHK(sr_enqueue_iterations(h, 1, 0, h->budget));
+      }
+    } else if (h->pcg_on) {
       CHK(pcg_enqueue_solve(h, 1));        // the whole Krylov loop in one launch (cg_persist.hip)
     } else if (h->exact_launches) {
       // measurement mode: one Krylov iteration per host round trip, so that every launch does full work
@@ -855,7 +881,8 @@ static int32_t resolve_stall(cosmo_hip_handle* h) {
     int extra = std::max(2 * h->budget, 8);
     if (h->prm.kkt_kind == COSMO_HIP_KKT_CG) {
       CHK(enqueue_clear_stall(h));
-      CHK(enqueue_cg_iterations(h, 1, h->ctl_host->cg_k, extra));
+      if (h->cg_sr) CHK(sr_enqueue_iterations(h, 1, h->ctl_host->cg_k, extra));
+      else CHK(enqueue_cg_iterations(h, 1, h->ctl_host->cg_k, extra));
       CHK(enqueue_tail(h, 1));
     } else {
       CHK(enqueue_clear_stall(h));

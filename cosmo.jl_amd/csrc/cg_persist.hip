@@ -364,7 +364,7 @@ int32_t pcg_setup(cosmo_hip_handle* h) {
   // iteration as an uncached (sc1) 8-byte request, and three software barriers cost about what the four kernel boundaries cost.
   int want = 0;
   if (const char* e = getenv("COSMO_HIP_CG_PERSIST")) want = atoi(e) ? 1 : 0;
-  if (want == 0 || h->prm.kkt_kind != COSMO_HIP_KKT_CG || h->n == 0) return COSMO_HIP_OK;
+  if (want == 0 || h->prm.kkt_kind != COSMO_HIP_KKT_CG || h->cg_sr || h->n == 0) return COSMO_HIP_OK;
   const CsrDev& Ao = h->op_split ? h->Am : h->A;
   const CsrDev& PTo = h->op_split ? h->PTm : h->PT;
   hipDeviceProp_t prop;

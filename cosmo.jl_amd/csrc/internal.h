@@ -42,6 +42,7 @@ struct Ctl {
   double r_prim, r_dual, max_norm_prim, max_norm_dual, cost;
   double minres[16]; // MINRES scalar recurrences, two parity slots of 8 (see minres.hip)
   double udotc_slot; // <v_curr, v_next> of the current MINRES iteration
+  double sr_gamma[2], sr_alpha[2];   // single-reduction CG (cg_sr.hip): r'r and alpha of the last two iterations, by parity
   double rho_updates[COSMO_HIP_MAX_RHO_UPDATES];
 };
 
@@ -134,6 +135,8 @@ struct cosmo_hip_handle {
   void* psd_polar = nullptr;      // PolarPlan (psd_polar.hip): large cones
   void* accel = nullptr;          // AaState (anderson.hip)
   long long safeguarding_iter = 0;
+  bool cg_sr = false;             // kkt_kind COSMO_HIP_KKT_CG_SR: single-reduction (Chronopoulos-Gear) CG, cg_sr.hip
+  void* sr_rec = nullptr;         // 2 n records {r, w, s, p}
   double* cg_ru = nullptr;        // {r_i, u_i} interleaved (2n doubles): operands of the fused direction + A-product kernel (k_cg_dirA); null = unfused
   // persistent single-launch CG (cg_persist.hip)
   bool pcg_on = false;
@@ -210,6 +213,12 @@ int32_t enqueue_admm_x_and_w(cosmo_hip_handle* h);
 int32_t sync_ctl(cosmo_hip_handle* h);
 
 int32_t comm_allreduce_flag(cosmo_hip_handle* h, int* flag);   // comm.hip: max over the ranks of a 0/1 flag
+
+// single-reduction CG (cg_sr.hip)
+int32_t sr_alloc(cosmo_hip_handle* h);
+void sr_free(cosmo_hip_handle* h);
+int32_t sr_enqueue_start(cosmo_hip_handle* h, int guard);
+int32_t sr_enqueue_iterations(cosmo_hip_handle* h, int guard, int k_begin, int count);
 
 // persistent CG (cg_persist.hip)
 int32_t pcg_setup(cosmo_hip_handle* h);

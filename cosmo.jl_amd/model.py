@@ -30,7 +30,9 @@ CGIndirectKKTSolver = "CGIndirectKKTSolver"
 MINRESIndirectKKTSolver = "MINRESIndirectKKTSolver"
 IndirectReducedKKTSolverMINRES = "IndirectReducedKKTSolver(:MINRES)"
 QdldlKKTSolver = "QdldlKKTSolver"
-_KKT_KIND = {CGIndirectKKTSolver: _ffi.KKT_CG, MINRESIndirectKKTSolver: _ffi.KKT_MINRES,
+# opt-in, no reference counterpart: the same reduced system solved by single-reduction (Chronopoulos-Gear) CG, csrc/cg_sr.hip
+CGSingleReductionKKTSolver = "CGSingleReductionKKTSolver"
+_KKT_KIND = {CGIndirectKKTSolver: _ffi.KKT_CG, MINRESIndirectKKTSolver: _ffi.KKT_MINRES, CGSingleReductionKKTSolver: _ffi.KKT_CG_SR,
              IndirectReducedKKTSolverMINRES: _ffi.KKT_MINRES_REDUCED}
 
 

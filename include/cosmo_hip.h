@@ -64,7 +64,10 @@ enum {
 enum {
   COSMO_HIP_KKT_CG = 0,             /* CGIndirectKKTSolver      :173-178 (IndirectReducedKKTSolver, :CG)     */
   COSMO_HIP_KKT_MINRES_REDUCED = 1, /* IndirectReducedKKTSolver :3-88 with solver_type = :MINRES            */
-  COSMO_HIP_KKT_MINRES = 2          /* MINRESIndirectKKTSolver  :180-185 (IndirectKKTSolver, full KKT)      */
+  COSMO_HIP_KKT_MINRES = 2,         /* MINRESIndirectKKTSolver  :180-185 (IndirectKKTSolver, full KKT)      */
+  COSMO_HIP_KKT_CG_SR = 3           /* OPT-IN, no reference counterpart: the reduced CG solve as single-reduction (Chronopoulos-Gear) CG --
+                                       same operator, stopping rule and warm start as COSMO_HIP_KKT_CG, algebraically equal iterates, two
+                                       launches per Krylov iteration; not bit-comparable with the literal recurrence (csrc/cg_sr.hip) */
 };
 
 /* ---- solver status (Result.status symbols, src/solver.jl:113,175,312,318,338,344,353) -------------- */
