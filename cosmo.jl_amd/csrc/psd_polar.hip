@@ -778,8 +778,10 @@ int32_t polar_enqueue_project(cosmo_hip_handle* h, double* s, int guard) {
 }
 
 // Host-side adaptation at a synchronisation point of the loop: when fallback rounds ran on a third or more of the projections
-// since the last look, the main schedule gets three more lifting steps (sticky).  Not in sharded runs (every rank must keep
-// the schedule of the single-rank run so that the exchanged slices stay bit-identical to it).
+// since the last look, the main schedule gets three more lifting steps (sticky).  Probing DOWNWARDS was built and measured (r02): on
+// BASELINE configs 4 and 5 the iterates need the default ten lifting steps within a few dozen iterations, every failed probe costs a
+// fallback round (26 products), and the runs ended slower (cfg4 116 -> 97 it/s) -- so the schedule only ever grows.  Not in sharded
+// runs (every rank must keep the schedule of the single-rank run so that the exchanged slices stay bit-identical to it).
 int32_t polar_adapt(cosmo_hip_handle* h) {
   PolarPlan* q = static_cast<PolarPlan*>(h->psd_polar);
   if (!q || !q->dev || h->comm || getenv("COSMO_HIP_POLAR_KLIFT")) return COSMO_HIP_OK;
