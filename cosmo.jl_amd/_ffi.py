@@ -29,41 +29,9 @@ MAX_RHO_UPDATES = 64
 NUM_KERNEL_CLASSES = 16
 
 
-class Params(C.Structure):
-    _fields_ = [
-        ("sigma", C.c_double), ("alpha", C.c_double), ("rho", C.c_double),
-        ("eps_abs", C.c_double), ("eps_rel", C.c_double),
-        ("eps_prim_inf", C.c_double), ("eps_dual_inf", C.c_double),
-        ("tol_constant", C.c_double), ("tol_exponent", C.c_double),
-        ("rho_min", C.c_double), ("rho_max", C.c_double), ("rho_tol", C.c_double),
-        ("rho_eq_over_rho_ineq", C.c_double), ("adaptive_rho_tolerance", C.c_double),
-        ("cosmo_infty_min_scaling", C.c_double), ("time_limit", C.c_double),
-        ("max_iter", C.c_int64), ("adaptive_rho_max_adaptions", C.c_int64),
-        ("kkt_kind", C.c_int32), ("check_termination", C.c_int32), ("check_infeasibility", C.c_int32),
-        ("adaptive_rho", C.c_int32), ("adaptive_rho_interval", C.c_int32), ("unscale_residuals", C.c_int32),
-        ("obj_true", C.c_double), ("obj_true_tol", C.c_double),
-    ]
-
-
-class AccelParams(C.Structure):
-    _fields_ = [
-        ("kind", C.c_int32), ("mem", C.c_int32), ("min_mem", C.c_int32), ("safeguard", C.c_int32),
-        ("start_iter", C.c_int64), ("safeguard_tol", C.c_double), ("eta_max", C.c_double), ("start_accuracy", C.c_double),
-    ]
-
+from ._abi_structs import AccelParams, Params, ResultStruct   # noqa: E402  generated from include/cosmo_hip.h (tools/gen_abi_structs.py)
 
 ACCEL_EMPTY, ACCEL_ANDERSON = 0, 1
-
-
-class ResultStruct(C.Structure):
-    _fields_ = [
-        ("status", C.c_int32), ("n_rho_updates", C.c_int32),
-        ("iter", C.c_int64), ("kkt_iters_total", C.c_int64), ("kkt_solves", C.c_int64),
-        ("cost", C.c_double), ("r_prim", C.c_double), ("r_dual", C.c_double),
-        ("max_norm_prim", C.c_double), ("max_norm_dual", C.c_double), ("rho", C.c_double),
-        ("iter_time", C.c_double), ("proj_time", C.c_double),
-        ("rho_updates", C.c_double * MAX_RHO_UPDATES),
-    ]
 
 
 class CosmoHipError(RuntimeError):

@@ -16,31 +16,10 @@ import COSMO: AbstractKKTSolver, solve!, update_rho!, free_memory!
 
 const LIB = Ref{String}(joinpath(@__DIR__, "..", "libcosmo_hip.so"))
 
-# ---- mirrors of the ABI structs (include/cosmo_hip.h) ---------------------------------------------------------------
-struct Params
-    sigma::Cdouble; alpha::Cdouble; rho::Cdouble
-    eps_abs::Cdouble; eps_rel::Cdouble
-    eps_prim_inf::Cdouble; eps_dual_inf::Cdouble
-    tol_constant::Cdouble; tol_exponent::Cdouble
-    rho_min::Cdouble; rho_max::Cdouble; rho_tol::Cdouble
-    rho_eq_over_rho_ineq::Cdouble; adaptive_rho_tolerance::Cdouble
-    cosmo_infty_min_scaling::Cdouble; time_limit::Cdouble
-    max_iter::Int64; adaptive_rho_max_adaptions::Int64
-    kkt_kind::Int32; check_termination::Int32; check_infeasibility::Int32
-    adaptive_rho::Int32; adaptive_rho_interval::Int32; unscale_residuals::Int32
-    obj_true::Cdouble; obj_true_tol::Cdouble
-end
+# ---- mirrors of the ABI structs: GENERATED from include/cosmo_hip.h by tools/gen_abi_structs.py (Params, AccelParams, ResultC, MAX_RHO_UPDATES)
+include("abi_structs.jl")
 
-const MAX_RHO_UPDATES = 64
-struct ResultC
-    status::Int32; n_rho_updates::Int32
-    iter::Int64; kkt_iters_total::Int64; kkt_solves::Int64
-    cost::Cdouble; r_prim::Cdouble; r_dual::Cdouble; max_norm_prim::Cdouble; max_norm_dual::Cdouble; rho::Cdouble
-    iter_time::Cdouble; proj_time::Cdouble
-    rho_updates::NTuple{MAX_RHO_UPDATES, Cdouble}
-end
-
-const KKT_CG, KKT_MINRES_REDUCED, KKT_MINRES = Int32(0), Int32(1), Int32(2)
+const KKT_CG, KKT_MINRES_REDUCED, KKT_MINRES, KKT_CG_SR = Int32(0), Int32(1), Int32(2), Int32(3)   # KKT_CG_SR: opt-in single-reduction CG
 const STATUS = (:Undetermined, :Solved, :Max_iter_reached, :Unsolved, :Primal_infeasible, :Dual_infeasible, :Time_limit_reached)
 
 mutable struct Handle
@@ -157,11 +136,6 @@ function scale_ruiz!(h::Handle, ws::COSMO.Workspace{Float64})
     nothing
 end
 
-# mirrors cosmo_hip_accel_params
-struct AccelParams
-    kind::Int32; mem::Int32; min_mem::Int32; safeguard::Int32; start_iter::Int64; safeguard_tol::Float64; eta_max::Float64
-    start_accuracy::Float64
-end
 
 # settings.accelerator is an OptionsFactory{<:AbstractAccelerator} (src/settings.jl:96,136,148-150).  The device builds the
 # reference's default AndersonAccelerator{Float64, Type2{QRDecomp}, RestartedMemory, NoRegularizer}; EmptyAccelerator maps to
@@ -237,6 +211,19 @@ free_memory!(S::HipKKTSolver) = destroy!(S.h)
 # ---------------------------------------------------------------------------------------------------------------------
 # 2. projection plugin: project!(s::SplitVector, C::CompositeConvexSet) (src/convexset.jl:885-891) on the device
 # ---------------------------------------------------------------------------------------------------------------------
+# diagnostics of the matrix-sign PSD path and of the opt-in single-launch CG (cosmo_hip_polar_stats / cosmo_hip_cg_persist_stats)
+function polar_stats(h::Handle)
+    out = zeros(Int64, 16)
+    check(h, ccall((:cosmo_hip_polar_stats, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Int64}), h.ptr, out))
+    return (large_cones = out[1], batch_cones = out[2], tile_side = out[3], k_split = out[4], products_last_large = out[9], fallback_rounds = out[10],
+            verified = out[11], products_last_batch = out[12], schedule_steps = out[13], unverified = out[14], projections = out[15], err_max = out[16] * 1e-18)
+end
+function cg_persist_stats(h::Handle)
+    out = zeros(Int64, 8)
+    check(h, ccall((:cosmo_hip_cg_persist_stats, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Int64}), h.ptr, out))
+    return (enabled = out[1] != 0, workgroups = out[2], launches = out[3], fallbacks = out[4])
+end
+
 function project_hip!(h::Handle, s::COSMO.SplitVector{Float64})
     d = s.data
     GC.@preserve d check(h, ccall((:cosmo_hip_project, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Int64}, Ptr{Int32}), h.ptr, d, C_NULL, C_NULL))

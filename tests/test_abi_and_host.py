@@ -61,6 +61,44 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(cj._ffi.ResultStruct) == 2 * 4 + 3 * 8 + 8 * 8 + 64 * 8
 
 
+def test_generated_struct_mirrors_agree_with_the_header_and_a_compiled_probe(tmp_path):
+    """Params / AccelParams / ResultC of the Julia glue and the ctypes binding are GENERATED from the header
+    (tools/gen_abi_structs.py); the committed files are up to date, and header layout == ctypes layout == offsetof() of a C probe."""
+    import importlib.util
+    import subprocess
+    spec = importlib.util.spec_from_file_location("gen_abi_structs", os.path.join(ROOT, "tools", "gen_abi_structs.py"))
+    G = importlib.util.module_from_spec(spec); spec.loader.exec_module(G)
+    text = open(G.HEADER).read()
+    jl, py = G.render(text)
+    assert open(G.OUT_JL).read() == jl and open(G.OUT_PY).read() == py, "stale generated mirrors: run python tools/gen_abi_structs.py"
+    lay = G.layout(text)
+    probe = ["#include <stdio.h>", "#include <stddef.h>", '#include "cosmo_hip.h"', "int main(void) {"]
+    for cname, (rows, size) in lay.items():
+        probe.append('  printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for name, _, _, _ in rows:
+            probe.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, name, cname, name))
+    probe += ["  return 0;", "}"]
+    src = tmp_path / "probe.c"; exe = tmp_path / "probe"
+    src.write_text("\n".join(probe))
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    ct = {"cosmo_hip_params": cj._ffi.Params, "cosmo_hip_accel_params": cj._ffi.AccelParams, "cosmo_hip_result": cj._ffi.ResultStruct}
+    for cname, (rows, size) in lay.items():
+        assert int(got[cname]) == size == ctypes.sizeof(ct[cname]), cname
+        assert [r[0] for r in rows] == [f[0] for f in ct[cname]._fields_]
+        for name, _, off, sz in rows:
+            assert int(got["%s.%s" % (cname, name)]) == off == getattr(ct[cname], name).offset, (cname, name)
+            assert getattr(ct[cname], name).size == sz
+    # the Julia mirror lists the same fields in the same order with the same primitive types (Julia lays isbits structs out like C)
+    for cname, jname, _ in G.STRUCTS:
+        body = re.search(r"struct %s .*?\n(.*?)\nend" % jname, jl, re.S).group(1)
+        jf = [ln.strip().split("::") for ln in body.splitlines()]
+        assert [f[0] for f in jf] == [r[0] for r in lay[cname][0]]
+        for (fname, jt), (_, ctyp, _, sz) in zip(jf, lay[cname][0]):
+            base = G.CTYPE[ctyp][0]
+            assert jt == base or jt == "NTuple{%d, %s}" % (sz // G.CTYPE[ctyp][2], base)
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     if torch.cuda.is_available():
