@@ -385,7 +385,7 @@ def bench_cfg5(ctx, args, steps, warmup):
                                  "CG indirect KKT" % (model.n, model.m, model.A.nnz, dk.size, dk.min(), dk.max(), prob["sets"][0].dim, prob["sets"][1].dim),
                      "parallelism": ("cliques sharded over %d ranks (contiguous cone ranges balanced by sum d^3; affine step replicated; one RCCL broadcast group of the "
                                      "projected slices of s per iteration)" % ctx.world) if ctx.world > 1 else "single GPU",
-                     "mean_cg_iters_per_admm_iter": round(kbar, 3), "comm": h.comm_stats(), "cg_persist": h.cg_persist_stats(),
+                     "mean_cg_iters_per_admm_iter": round(kbar, 3), "comm": h.comm_stats(), "cg_persist": h.cg_persist_stats(), "cg_assembled_operator": h.fold_stats(),
                      "polar": {k: ps[k] for k in ("batch_cones", "schedule_steps", "products_last_batch", "fallback_rounds", "verified", "unverified", "err_max_e18")}}
     if single is not None:
         out["config"]["single_gpu_same_workload"] = round(single, 3)

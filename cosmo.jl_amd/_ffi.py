@@ -82,6 +82,7 @@ SIGNATURES = {
     "cosmo_hip_optimize": (C.c_int32, [C.c_void_p, C.POINTER(ResultStruct)]),
     "cosmo_hip_get_iterates": (C.c_int32, [C.c_void_p, _PD, _PD, _PD, _PD]),
     "cosmo_hip_cg_persist_stats": (C.c_int32, [C.c_void_p, _PI64]),
+    "cosmo_hip_fold_stats": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_get_kkt_solution": (C.c_int32, [C.c_void_p, _PD]),
     "cosmo_hip_get_stats": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_time_spmv": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _PD, _PD]),
@@ -361,6 +362,11 @@ class Handle:
         out = np.zeros(8, dtype=np.int64)
         self._chk(self.lib.cosmo_hip_cg_persist_stats(self._h, out.ctypes.data_as(_PI64)))
         return dict(zip(["enabled", "workgroups", "launches", "fallbacks", "tickets", "arrivals", "abort", "lds_per_quarter"], out.tolist()))
+
+    def fold_stats(self):
+        out = np.zeros(4, dtype=np.int64)
+        self._chk(self.lib.cosmo_hip_fold_stats(self._h, out.ctypes.data_as(_PI64)))
+        return dict(zip(["enabled", "nnz", "terms", "tiles"], out.tolist()))
 
     # ---- measurement -------------------------------------------------------------------------------------------
     def time_spmv(self, which, reps=50):

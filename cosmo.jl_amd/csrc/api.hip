@@ -107,13 +107,14 @@ void free_csr(CsrDev& D) {
 // Greedy CSR-stream schedule: consecutive rows whose nonzeros fit the LDS tile; a longer row gets its own block.
 // Small matrices (the split CG operator of an SDP, small QPs) get smaller tiles so that a launch still has a few hundred
 // workgroups: with the full 2048-nonzero tile a 100 k-nonzero operator is 50 workgroups on 256 CUs and its ~9 us are all ramp.
-static void build_row_blocks(const std::vector<int>& rowptr, int nrows, std::vector<int>& rb) {
+static void build_row_blocks(const std::vector<int>& rowptr, int nrows, std::vector<int>& rb, int tile_override) {
   rb.clear();
   rb.push_back(0);
   const long long nnz_total = nrows > 0 ? (long long)rowptr[nrows] : 0;
   int tile = COSMO_NNZ_PER_BLOCK;
   if (nnz_total < 512LL * COSMO_NNZ_PER_BLOCK) tile = (int)std::max<long long>(256, ((nnz_total / 512 + 63) / 64) * 64);
   if (nnz_total <= 256LL * 768) tile = 256;     // operators of the single-launch CG (cg_persist.hip): one nonzero per thread and tile
+  if (tile_override > 0) tile = std::min(tile_override, COSMO_NNZ_PER_BLOCK);
   const int ROWS_MAX = tile < COSMO_NNZ_PER_BLOCK ? COSMO_BS : 4 * COSMO_BS;
   int r = 0;
   while (r < nrows) {
@@ -131,12 +132,12 @@ static void build_row_blocks(const std::vector<int>& rowptr, int nrows, std::vec
   }
 }
 
-int32_t upload_csr(cosmo_hip_handle* h, const HostCsr& M, CsrDev& D, int split_col) {
+int32_t upload_csr(cosmo_hip_handle* h, const HostCsr& M, CsrDev& D, int split_col, int tile_override) {
   free_csr(D);
   D.nrows = M.nrows; D.ncols = M.ncols; D.nnz = (long long)M.val.size();
   D.split_col = split_col;
   std::vector<int> rbnd, rb;
-  build_row_blocks(M.rowptr, M.nrows, rbnd);
+  build_row_blocks(M.rowptr, M.nrows, rbnd, tile_override);
   D.nb = (int)rbnd.size() - 1;
   rb.resize((size_t)4 * std::max(D.nb, 1), 0);           // {r0, r1, nz0, nz1} per tile (16-byte aligned descriptors)
   for (int k = 0; k < D.nb; ++k) { rb[4 * k] = rbnd[k]; rb[4 * k + 1] = rbnd[k + 1]; rb[4 * k + 2] = M.rowptr[rbnd[k]]; rb[4 * k + 3] = M.rowptr[rbnd[k + 1]]; }
@@ -476,6 +477,7 @@ extern "C" int32_t cosmo_hip_set_cones_ex(cosmo_hip_handle* h, int64_t ncones, c
 void free_op_split(cosmo_hip_handle* h) {
   free_csr(h->Am); free_csr(h->PTm);
   dfree(&h->op_mrow); dfree(&h->op_sc_ptr); dfree(&h->op_sc_row); dfree(&h->op_sc_a2); dfree(&h->op_diag); dfree(&h->op_rho_m);
+  fold_free(h);
   h->op_split = false; h->op_nsingle = 0;
 }
 
@@ -541,6 +543,8 @@ int32_t build_op_split(cosmo_hip_handle* h) {
   CHK(h2d(h, h->op_sc_ptr, sc_ptr.data(), (size_t)n + 1)); CHK(h2d(h, h->op_sc_row, sc_row.data(), (size_t)nsingle)); CHK(h2d(h, h->op_sc_a2, sc_a2.data(), (size_t)nsingle));
   h->op_nsingle = nsingle;
   h->op_split = true;
+  prp.resize((size_t)n + 1);
+  CHK(fold_build(h, Am, prp, pcol, pval));      // assembled operator where Am' rho Am is sparse enough (cg_fold.hip)
   return refresh_op_split(h);
 }
 
@@ -578,12 +582,13 @@ extern "C" int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_par
   HIPCHK(h, hipMemsetAsync(h->x_tl, 0, sizeof(double) * (size_t)std::max<long long>(h->n, 1), h->stream));
   HIPCHK(h, hipMemsetAsync(h->nu, 0, sizeof(double) * (size_t)std::max<long long>(h->m, 1), h->stream));
   h->have_params = true;
-  CHK(build_op_split(h));     // needs the (scaled) matrices and rho: both final from here on
   // fused direction + A product (k_cg_dirA): one launch less per Krylov iteration, bit-identical; COSMO_HIP_CG_FUSE_DIR=0 disables it
+  // (and with it the assembled operator of cg_fold.hip, which gathers the same {r, u} records)
   dfree(&h->cg_ru);
   { bool fuse = (h->prm.kkt_kind == COSMO_HIP_KKT_CG) && !h->cg_sr && h->n > 0;
     if (const char* e = getenv("COSMO_HIP_CG_FUSE_DIR")) fuse = fuse && atoi(e) != 0;
     if (fuse) CHK(dalloc(h, &h->cg_ru, 2 * (size_t)h->n)); }
+  CHK(build_op_split(h));     // needs the (scaled) matrices and rho: both final from here on
   return pcg_setup(h);        // single-launch CG (opt-in)
 }
 

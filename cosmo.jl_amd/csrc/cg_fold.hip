@@ -1,0 +1,344 @@
+// cg_fold.hip -- the reduced KKT operator of the CG solve ASSEMBLED as one sparse matrix, for problems where that is cheap.
+//
+// reduced_mul! (src/linear_solver/kktsolver_indirect.jl:57-64) applies  x -> P x + sigma x + A'(rho .* (A x))  as two dependent sparse
+// products, so a Krylov iteration of the device CG is at least three launches: [direction + A product] -> [P | A'] product + u'c ->
+// [x, r update + r'r].  On a decomposed SDP (BASELINE config 5) each of those launches is a 4-6 us chain of dependent memory round
+// trips over a ~100 k-nonzero operator, and ~170 such iterations per ADMM iteration are half of the whole run
+// (profiles/r02_cfg5_timeline_before_fold.txt).  After the operator split (api.hip: build_op_split) only the rows of A with two or
+// more nonzeros are left as a matrix Am; when Am' rho Am is sparse enough the operator is assembled here once,
+//
+//       M(rho) = P + diag(sigma + d(rho)) + Am' diag(rho_m) Am ,        d = the diagonal the single-nonzero rows contribute,
+//
+// and a Krylov iteration becomes TWO launches: k_cg_dirM (stopping rule, beta, u = r + beta u rebuilt at the gathered columns,
+// c = M u, partials of u'c) and the unchanged k_cg_upd.  The solve start is one launch instead of two.
+//
+// Parity: the same linear operator with a different association (like the operator split itself): M's entries are sums of
+// rho_k a_ki a_kj in a fixed order (Am rows ascending), row sums of M u run left to right over the columns.  The CG recurrence, the
+// stopping rule and the tolerance are the literal cg! ones; iteration counts agree with the unfolded operator to +-1 per solve and
+// trajectories to the tolerances of SURVEY 8c (tests/test_gpu_cg_fold.py).  rho may change on the device (adaptive rho): the values
+// are rebuilt by k_fold_refresh right after k_op_refresh, unconditionally, every time the adaptation rule has run.
+// COSMO_HIP_OP_FOLD=0 disables the assembly.
+#include "device_utils.h"
+#include <algorithm>
+
+#define PARTS(h, slot) ((h)->partials + (size_t)(slot) * COSMO_MAX_PARTIALS)
+
+struct FoldPlan {
+  int slots = 8;            // nonzero slots per thread of k_cg_dirM (tile <= slots * 256)
+  CsrDev M;                 // n x n; M.val is rewritten by k_fold_refresh
+  double* base = nullptr;   // nnz(M): P_ij (0 where P has no entry)
+  int* drow = nullptr;      // nnz(M): row index for diagonal entries, -1 otherwise
+  int* tptr = nullptr;      // nnz(M)+1: terms of entry p are [tptr[p], tptr[p+1])
+  int* trow = nullptr;      // term -> row of Am
+  double* tprod = nullptr;  // term -> a_ki * a_kj
+  long long nterms = 0;
+};
+
+// launch helpers of kernels.hip (every launch stays next to its kernel)
+int32_t launch_cg_upd(cosmo_hip_handle* h, int guard, int k, int n_uc);
+int32_t launch_cg_dir_check(cosmo_hip_handle* h, int guard, int kk, int n_rr);
+static inline int ew_grid(long long N) {
+  long long g = (N + COSMO_BS - 1) / COSMO_BS;
+  if (g < 1) g = 1;
+  if (g > COSMO_MAX_PARTIALS) g = COSMO_MAX_PARTIALS;
+  return (int)g;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// values of M from rho: one thread per stored entry, terms added in their stored (Am-row ascending) order
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(COSMO_BS) void k_fold_refresh(long long nnz, const double* __restrict__ base, const int* __restrict__ drow,
+                                                           const int* __restrict__ tptr, const int* __restrict__ trow,
+                                                           const double* __restrict__ tprod, const double* __restrict__ rho_m,
+                                                           const double* __restrict__ diag, double sigma, double* __restrict__ val) {
+  for (long long p = (long long)blockIdx.x * COSMO_BS + threadIdx.x; p < nnz; p += (long long)gridDim.x * COSMO_BS) {
+    double s = 0.0;
+    for (int t = tptr[p]; t < tptr[p + 1]; ++t) s += rho_m[trow[t]] * tprod[t];
+    const int i = drow[p];
+    val[p] = (i >= 0) ? base[p] + ((sigma + diag[i]) + s) : base[p] + s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// solve start: r = rhs - M x (x = warm start), {r, 0} records for the first direction, partials of r'r, abstol = tol_k / ||rhs||
+// (kktsolver_indirect.jl:70 ; cg! computes the initial residual with one operator application)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(COSMO_BS) void k_fold_start(Ctl* __restrict__ ctl, int guard, CsrView M, const double* __restrict__ x,
+                                                         const double* __restrict__ rhs, double* __restrict__ r, double2* __restrict__ ru,
+                                                         double* __restrict__ part_rr, const double* __restrict__ part_bb, int n_bb, double tol_k) {
+  if (guard && ctl->halt) return;
+  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ double red[COSMO_BS / 64];
+  if (blockIdx.x == 0) {
+    const double bb = reduce_partials_sum(part_bb, n_bb, red);
+    if (threadIdx.x == 0) {
+      const double nb = sqrt(bb);
+      ctl->rhs_norm = nb;
+      ctl->tol = tol_k / nb;
+    }
+  }
+  double acc = 0.0;
+  const int first_tile = tile_of_block(blockIdx.x, M.nb, M.xcd_affine);
+  for (int k = first_tile; k < M.nb; k += gridDim.x) {
+    csr_stream_tile(M, x, x, k, lds, red, [&](int row, double s1, double s2) {
+      const double rj = rhs[row] - (s1 + s2);
+      r[row] = rj;
+      ru[row] = make_double2(rj, 0.0);
+      acc += rj * rj;
+    });
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) part_rr[M.xcd_affine ? first_tile : (int)blockIdx.x] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Krylov step k, first half + the WHOLE operator (IterativeSolvers v0.9 cg.jl `iterate`): residual_k = ||r|| from the partials; stop if
+// k >= maxiter or residual_k <= tol (checked BEFORE the iteration); beta = res_k^2 / res_{k-1}^2 (prev = 1 at k = 0, where the
+// records carry u = 0); u_k = r + beta u_{k-1} rebuilt at the gathered columns from the 16-byte records {r_i, u_i}; c = M u_k;
+// partials of u_k'c.  Same load-first structure as k_cg_dirA (kernels.hip): everything that does not depend on beta is requested
+// before the scalar work.
+// ---------------------------------------------------------------------------------------------------------------------
+// SL = nonzero slots per thread of the register-staged first tile (tiles of the assembled matrix hold at most SL * 256 nonzeros; a
+// longer single row takes the generic path).
+template <int SL>
+__global__ __launch_bounds__(COSMO_BS) void k_cg_dirM(Ctl* __restrict__ ctl, int guard, int k, long long n, long long maxiter,
+                                                      const double* __restrict__ part_rr, int n_rr, CsrView M, const double2* __restrict__ ru,
+                                                      double* __restrict__ c, double* __restrict__ u, double* __restrict__ part_uc) {
+  const double pa = partials_prefetch_sum(part_rr, n_rr);
+  const int first_tile = tile_of_block(blockIdx.x, M.nb, M.xcd_affine);
+  const bool have_tile = first_tile < M.nb;
+  int4 d = make_int4(0, 0, 0, 0);
+  if (have_tile) d = reinterpret_cast<const int4*>(M.rb)[first_tile];
+  const int cnt0 = d.w - d.z;
+  const bool fast = have_tile && cnt0 <= SL * COSMO_BS;            // a single long row takes the generic chunked path below
+  double av[SL]; double2 gv[SL];
+#pragma unroll
+  for (int it = 0; it < SL; ++it) {
+    const int kk = it * COSMO_BS + threadIdx.x;
+    const bool ok = fast && kk < cnt0;
+    const int e = ok ? d.z + kk : 0;
+    const int cc = M.col[e];
+    const double a = M.val[e];
+    av[it] = ok ? a : 0.0;
+    gv[it] = ru[cc];
+  }
+  const int rfirst = d.x + threadIdx.x;
+  const bool rowok = fast && rfirst < d.y;
+  const int rr_ = rowok ? rfirst : 0;
+  const int pa_ = M.rowptr[rr_], pb_ = M.rowptr[rr_ + 1];
+  const double2 rw = ru[rr_];                                       // {r, u_{k-1}} of this thread's row: u_k of the row for u'c
+  const long long i0 = (long long)blockIdx.x * COSMO_BS + threadIdx.x;
+  const double2 own = ru[i0 < n ? i0 : 0];
+  if (guard && ctl->halt) return;
+  if (ctl->cg_done) return;
+  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ double red[COSMO_BS / 64];
+  const double tol = ctl->tol;
+  const double prev = (k == 0) ? 1.0 : ctl->resv[(k - 1) & 1];
+  const double rr = block_sum(pa, red);
+  const double res = sqrt(rr);
+  const bool done = (k >= maxiter) || (res <= tol);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (done) ctl->cg_done = 1;
+    ctl->resv[k & 1] = res;
+  }
+  if (done) return;
+  const double beta = (res * res) / (prev * prev);
+  if (i0 < n) u[i0] = own.x + beta * own.y;
+  for (long long i = i0 + (long long)gridDim.x * COSMO_BS; i < n; i += (long long)gridDim.x * COSMO_BS) {
+    const double2 v = ru[i];
+    u[i] = v.x + beta * v.y;
+  }
+  double acc = 0.0;
+  if (fast) {
+#pragma unroll
+    for (int it = 0; it < SL; ++it) {
+      const int kk = it * COSMO_BS + threadIdx.x;
+      if (kk < cnt0) lds[kk] = av[it] * (gv[it].x + beta * gv[it].y);
+    }
+    __syncthreads();
+    if (rowok) {                                    // first row of this thread: pointers and its own record already here
+      const double cj = lds_seq_sum(lds, pa_ - d.z, pb_ - d.z);
+      c[rfirst] = cj;
+      acc += (rw.x + beta * rw.y) * cj;
+    }
+    for (int r = rfirst + COSMO_BS; r < d.y; r += COSMO_BS) {
+      const double cj = lds_seq_sum(lds, M.rowptr[r] - d.z, M.rowptr[r + 1] - d.z);
+      const double2 v = ru[r];
+      c[r] = cj;
+      acc += (v.x + beta * v.y) * cj;
+    }
+    __syncthreads();
+  }
+  for (int t = fast ? first_tile + (int)gridDim.x : first_tile; t < M.nb; t += gridDim.x) {
+    const int4 dd = reinterpret_cast<const int4*>(M.rb)[t];
+    csr_stream_rows_g(M, [&](int cc) { const double2 v = ru[cc]; return v.x + beta * v.y; }, dd.x, dd.y, dd.z, dd.w, lds, red,
+                      [&](int r, double s1, double s2) {
+                        const double cj = s1 + s2;
+                        const double2 v = ru[r];
+                        c[r] = cj;
+                        acc += (v.x + beta * v.y) * cj;
+                      });
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) part_uc[M.xcd_affine ? first_tile : (int)blockIdx.x] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+void fold_free(cosmo_hip_handle* h) {
+  FoldPlan* f = (FoldPlan*)h->fold;
+  h->op_fold = false;
+  if (!f) return;
+  free_csr(f->M);
+  if (f->base) (void)hipFree(f->base);
+  if (f->drow) (void)hipFree(f->drow);
+  if (f->tptr) (void)hipFree(f->tptr);
+  if (f->trow) (void)hipFree(f->trow);
+  if (f->tprod) (void)hipFree(f->tprod);
+  delete f;
+  h->fold = nullptr;
+}
+
+template <class T>
+static int32_t up(cosmo_hip_handle* h, T** dst, const std::vector<T>& v) {
+  HIPCHK(h, hipMalloc((void**)dst, std::max<size_t>(v.size(), 1) * sizeof(T)));
+  if (!v.empty()) HIPCHK(h, hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return COSMO_HIP_OK;
+}
+
+// Am: the multi-nonzero rows of A (compact, columns ascending within a row); (prp, pcol, pval): CSR of P.  Called at the end of
+// build_op_split (the split is active and rho_m / diag exist on the device).
+int32_t fold_build(cosmo_hip_handle* h, const HostCsr& Am, const std::vector<int>& prp, const std::vector<int>& pcol,
+                   const std::vector<double>& pval) {
+  fold_free(h);
+  if (const char* e = getenv("COSMO_HIP_OP_FOLD")) if (e[0] == '0') return COSMO_HIP_OK;
+  if (!h->op_split || h->cg_sr || h->n <= 0 || !h->cg_ru) return COSMO_HIP_OK;
+  if (const char* e = getenv("COSMO_HIP_CG_PERSIST")) if (atoi(e)) return COSMO_HIP_OK;     // the single-launch lab path keeps the split operator
+  const long long n = h->n;
+  const int mm = Am.nrows;
+  const long long nnzP = prp.empty() ? 0 : prp[(size_t)n];
+  // cost gate: terms = sum over the rows of Am of len^2; the assembled matrix must stay within a small multiple of what the two
+  // products of the split operator stream (a 10-nonzero row becomes 100 terms: fine for a few thousand such rows, not for config 2)
+  long long nterms = 0;
+  for (int r = 0; r < mm; ++r) { const long long len = Am.rowptr[r + 1] - Am.rowptr[r]; nterms += len * len; }
+  const long long streamed = 2 * (long long)Am.col.size() + nnzP + n;
+  if (nterms > 6 * streamed || nterms > (1LL << 24)) return COSMO_HIP_OK;
+  // Am' as lists (row of Am, value) per column
+  std::vector<int> tp((size_t)n + 1, 0);
+  for (int cidx : Am.col) tp[(size_t)cidx + 1]++;
+  for (long long j = 0; j < n; ++j) tp[j + 1] += tp[j];
+  std::vector<int> trw(Am.col.size());
+  std::vector<double> tvl(Am.col.size());
+  { std::vector<int> pos(tp.begin(), tp.end() - 1);
+    for (int r = 0; r < mm; ++r) for (int k = Am.rowptr[r]; k < Am.rowptr[r + 1]; ++k) { const int p = pos[Am.col[k]]++; trw[p] = r; tvl[p] = Am.val[k]; } }
+  HostCsr M;
+  M.nrows = (int)n; M.ncols = (int)n; M.rowptr.assign((size_t)n + 1, 0);
+  std::vector<double> base;
+  std::vector<int> drow, tptr, trow;
+  std::vector<double> tprod;
+  tptr.push_back(0);
+  struct Term { int j, k; double prod; };
+  std::vector<Term> terms;
+  for (long long i = 0; i < n; ++i) {
+    terms.clear();
+    for (int q = tp[i]; q < tp[i + 1]; ++q) {
+      const int k = trw[q];
+      const double aki = tvl[q];
+      for (int p = Am.rowptr[k]; p < Am.rowptr[k + 1]; ++p) terms.push_back({Am.col[p], k, aki * Am.val[p]});
+    }
+    std::sort(terms.begin(), terms.end(), [](const Term& a, const Term& b) { return a.j != b.j ? a.j < b.j : a.k < b.k; });
+    // three-way merge over ascending columns: P row i, the term columns, the diagonal
+    size_t it = 0;
+    int ip = prp.empty() ? 0 : prp[i];
+    const int ipe = prp.empty() ? 0 : prp[i + 1];
+    bool diag_done = false;
+    for (;;) {
+      int j = INT32_MAX;
+      if (it < terms.size()) j = std::min(j, terms[it].j);
+      if (ip < ipe) j = std::min(j, pcol[ip]);
+      if (!diag_done) j = std::min(j, (int)i);
+      if (j == INT32_MAX) break;
+      double b = 0.0;
+      if (ip < ipe && pcol[ip] == j) { b = pval[ip]; ++ip; }
+      while (it < terms.size() && terms[it].j == j) { trow.push_back(terms[it].k); tprod.push_back(terms[it].prod); ++it; }
+      if (j == (int)i) diag_done = true;
+      M.col.push_back(j); M.val.push_back(0.0);
+      base.push_back(b); drow.push_back(j == (int)i ? (int)i : -1);
+      tptr.push_back((int)trow.size());
+    }
+    M.rowptr[i + 1] = (int)M.col.size();
+  }
+  if ((long long)M.col.size() >= 2147483647LL) return COSMO_HIP_OK;
+  FoldPlan* f = new FoldPlan();
+  h->fold = f;
+  f->nterms = (long long)trow.size();
+  // Tile size: measured on BASELINE config 5 (708 k nonzeros; profiles/r02_cfg5_fold_tile_sweep.txt) 256 / 384 / 512 / 768 / 1408
+  // nonzeros per tile all land within +-2 % (144-150 it/s): the kernel is a chain of dependent round trips, not a stream.  768 keeps
+  // the register-staged slots at four per thread and the tile count under the partial-slot limit for operators up to ~1.5 M nonzeros.
+  int tile = 768;
+  if ((long long)M.col.size() > 700LL * COSMO_MAX_PARTIALS) tile = 0;      // large operators: the size heuristic of build_row_blocks
+  if (const char* e = getenv("COSMO_HIP_FOLD_TILE")) { const int v = atoi(e); if (v >= 64 && v <= COSMO_NNZ_PER_BLOCK) tile = v; }
+  CHK(upload_csr(h, M, f->M, (int)n, tile));
+  f->slots = tile == 0 ? 8 : tile <= COSMO_BS ? 1 : tile <= 2 * COSMO_BS ? 2 : tile <= 4 * COSMO_BS ? 4 : 8;
+  CHK(up(h, &f->base, base)); CHK(up(h, &f->drow, drow)); CHK(up(h, &f->tptr, tptr)); CHK(up(h, &f->trow, trow)); CHK(up(h, &f->tprod, tprod));
+  h->op_fold = true;
+  return COSMO_HIP_OK;
+}
+
+int32_t fold_refresh(cosmo_hip_handle* h) {
+  FoldPlan* f = (FoldPlan*)h->fold;
+  if (!h->op_fold || !f) return COSMO_HIP_OK;
+  hipLaunchKernelGGL(k_fold_refresh, dim3(ew_grid(f->M.nnz)), dim3(COSMO_BS), 0, h->stream, f->M.nnz, f->base, f->drow, f->tptr, f->trow,
+                     f->tprod, h->op_rho_m, h->op_diag, h->prm.sigma, f->M.val);
+  HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}
+
+int32_t fold_enqueue_start(cosmo_hip_handle* h, int guard, double tol_k) {
+  FoldPlan* f = (FoldPlan*)h->fold;
+  prof_begin(h, KC_OP_APPLY);
+  hipLaunchKernelGGL(k_fold_start, dim3(f->M.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, view_of(f->M), h->x_tl, h->rhs, h->r,
+                     (double2*)h->cg_ru, PARTS(h, SLOT_RR), PARTS(h, SLOT_BB), h->AT.grid, tol_k);
+  prof_end(h);
+  h->spmv_calls[0] += 1; h->spmv_calls[1] += 1; h->spmv_calls[2] += 1;     // the reference's multiplication count (reduced_mul! = A, A', P)
+  HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}
+
+int32_t fold_enqueue_iterations(cosmo_hip_handle* h, int guard, int k_begin, int count) {
+  FoldPlan* f = (FoldPlan*)h->fold;
+  const long long n = h->n;
+  const int gE = ew_grid(n);
+  for (int k = k_begin; k < k_begin + count; ++k) {
+    prof_begin(h, KC_OP_APPLY);
+    const int n_rr = (k == 0) ? f->M.grid : gE;
+#define LAUNCH_DIRM(SLN) hipLaunchKernelGGL((k_cg_dirM<SLN>), dim3(f->M.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, k, n, n, \
+                         PARTS(h, SLOT_RR), n_rr, view_of(f->M), (const double2*)h->cg_ru, h->c, h->u, PARTS(h, SLOT_UC))
+    switch (f->slots) {
+      case 1: LAUNCH_DIRM(1); break;
+      case 2: LAUNCH_DIRM(2); break;
+      case 4: LAUNCH_DIRM(4); break;
+      default: LAUNCH_DIRM(8); break;
+    }
+#undef LAUNCH_DIRM
+    prof_end(h);
+    CHK(launch_cg_upd(h, guard, k, f->M.grid));
+    h->spmv_calls[0] += 1; h->spmv_calls[1] += 1; h->spmv_calls[2] += 1;
+  }
+  const int kk = k_begin + count;
+  CHK(launch_cg_dir_check(h, guard, kk, (kk == 0) ? f->M.grid : gE));
+  HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}
+
+// diagnostics: out = {enabled, nnz(M), terms, tiles}
+extern "C" int32_t cosmo_hip_fold_stats(cosmo_hip_handle* h, int64_t out[4]) {
+  if (!h || !out) return COSMO_HIP_ERR_INVALID;
+  out[0] = out[1] = out[2] = out[3] = 0;
+  FoldPlan* f = (FoldPlan*)h->fold;
+  if (!h->op_fold || !f) return COSMO_HIP_OK;
+  out[0] = 1; out[1] = f->M.nnz; out[2] = f->nterms; out[3] = f->M.nb;
+  return COSMO_HIP_OK;
+}

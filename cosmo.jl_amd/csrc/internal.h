@@ -108,6 +108,9 @@ struct cosmo_hip_handle {
   int *op_sc_ptr = nullptr, *op_sc_row = nullptr;
   double *op_sc_a2 = nullptr, *op_diag = nullptr, *op_rho_m = nullptr;
   long long op_nsingle = 0;
+  // assembled reduced operator M = P + diag(sigma + d) + Am' rho_m Am (cg_fold.hip): two launches per Krylov iteration
+  bool op_fold = false;
+  void* fold = nullptr;           // FoldPlan
   // data vectors
   double *q = nullptr, *b = nullptr, *rho = nullptr, *Dinv = nullptr, *Einv = nullptr, *Dscale = nullptr, *Escale = nullptr;
   double *inf_dy = nullptr, *inf_dx = nullptr, *inf_adx = nullptr;   // infeasibility work vectors (infeas.hip)
@@ -192,7 +195,8 @@ int32_t cosmo_fail(cosmo_hip_handle* h, int32_t code, const char* fmt, ...);
   } while (0)
 
 // ---- launch helpers implemented in kernels.hip ---------------------------------------------------------------------
-int32_t upload_csr(cosmo_hip_handle* h, const HostCsr& M, CsrDev& D, int split_col);
+// tile_override > 0: nonzeros per CSR-stream tile (<= COSMO_NNZ_PER_BLOCK) instead of the size heuristic of build_row_blocks
+int32_t upload_csr(cosmo_hip_handle* h, const HostCsr& M, CsrDev& D, int split_col, int tile_override = 0);
 void free_csr(CsrDev& D);
 void prof_begin(cosmo_hip_handle* h, int kc);
 void prof_end(cosmo_hip_handle* h);
@@ -202,6 +206,14 @@ int32_t prof_collect(cosmo_hip_handle* h);
 int32_t build_op_split(cosmo_hip_handle* h);
 int32_t refresh_op_split(cosmo_hip_handle* h);
 void free_op_split(cosmo_hip_handle* h);
+
+// assembled reduced operator (cg_fold.hip)
+int32_t fold_build(cosmo_hip_handle* h, const HostCsr& Am, const std::vector<int>& prp, const std::vector<int>& pcol,
+                   const std::vector<double>& pval);
+int32_t fold_refresh(cosmo_hip_handle* h);
+void fold_free(cosmo_hip_handle* h);
+int32_t fold_enqueue_start(cosmo_hip_handle* h, int guard, double tol_k);
+int32_t fold_enqueue_iterations(cosmo_hip_handle* h, int guard, int k_begin, int count);
 
 // plain y = M x (fine-grained ABI + building block)
 int32_t launch_spmv_plain(cosmo_hip_handle* h, const CsrDev& M, const double* x, double* y);

@@ -680,6 +680,7 @@ int32_t launch_rho_from_classes(cosmo_hip_handle* h, double rho0) {
 // ---- reduced-system CG solve, enqueued without host synchronisation --------------------------------------------------
 // from_loop: rhs comes from the loop state (k_rhs) and the tail updates w; otherwise ls_x/ls_s were uploaded.
 int32_t enqueue_cg_iterations(cosmo_hip_handle* h, int guard, int k_begin, int count) {
+  if (h->op_fold) return fold_enqueue_iterations(h, guard, k_begin, count);      // assembled operator: two launches per iteration
   const long long n = h->n;
   const int gE = ew_grid(n);
   const CsrDev& Ao = h->op_split ? h->Am : h->A;
@@ -728,6 +729,7 @@ int32_t enqueue_cg_start(cosmo_hip_handle* h, int guard, double tol_k) {
   hipLaunchKernelGGL(k_cg_rhs, dim3(h->AT.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, view_of(h->AT), h->y2,
                      h->ls_x, h->rhs, PARTS(h, SLOT_BB));
   prof_end(h);
+  if (h->op_fold) return fold_enqueue_start(h, guard, tol_k);
   const CsrDev& Ao = h->op_split ? h->Am : h->A;
   const CsrDev& PTo = h->op_split ? h->PTm : h->PT;
   prof_begin(h, KC_SPMV_A);
@@ -852,6 +854,21 @@ int32_t refresh_op_split(cosmo_hip_handle* h) {
   hipLaunchKernelGGL(k_op_refresh, dim3(ew_grid(h->n + mm)), dim3(COSMO_BS), 0, h->stream, h->n, mm, h->op_sc_ptr, h->op_sc_row, h->op_sc_a2,
                      h->op_mrow, h->rho, h->op_diag, h->op_rho_m);
   HIPCHK(h, hipGetLastError());
+  return fold_refresh(h);        // the assembled operator's values follow rho_m and the diagonal
+}
+
+// launch helpers used by cg_fold.hip
+int32_t launch_cg_upd(cosmo_hip_handle* h, int guard, int k, int n_uc) {
+  prof_begin(h, KC_CG_UPD);
+  hipLaunchKernelGGL(k_cg_upd, dim3(ew_grid(h->n)), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, k, h->n, PARTS(h, SLOT_UC), n_uc, h->u, h->c,
+                     h->x_tl, h->r, PARTS(h, SLOT_RR), (double2*)h->cg_ru);
+  prof_end(h);
+  return COSMO_HIP_OK;
+}
+int32_t launch_cg_dir_check(cosmo_hip_handle* h, int guard, int kk, int n_rr) {
+  prof_begin(h, KC_CG_DIR);
+  hipLaunchKernelGGL(k_cg_dir, dim3(1), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, kk, 1, h->n, h->n, PARTS(h, SLOT_RR), n_rr, h->r, h->u);
+  prof_end(h);
   return COSMO_HIP_OK;
 }
 

@@ -660,9 +660,13 @@ int32_t psd_plan_create(cosmo_hip_handle* h) {
     p->d_wg_groups.push_back(dptr);
   }
   // projection-time split of the wg class: cones with d > polar_min go to the batched matrix-sign path (psd_polar.hip), whose
-  // ~80 launches cost the same for any number of cones, while a d = 200 Jacobi workgroup needs ~300 dependent tournament steps
+  // ~80 launches cost the same for any number of cones, while a d = 200 Jacobi workgroup needs ~300 dependent tournament steps.
+  // Round 2: 64 -> 16.  A 16 < d <= 64 cone is ONE extra 64 x 64 tile in launches that already exist, whereas the one-workgroup
+  // Jacobi kernel of those cones was a 0.4-0.55 ms serial phase of BASELINE config 5 (100 of its 400 cliques): 123.9 -> 132.3 it/s
+  // (profiles/r02_cfg5_polar_batch_min_and_fold.json); and the sign path is the more accurate one (5e-15 vs 1e-11 ||X||_F).
+  // COSMO_HIP_POLAR_BATCH_MIN=256 sends every workgroup-class cone back to the Jacobi kernels (kept under test that way).
   {
-    int polar_min = 64;
+    int polar_min = 16;
     if (const char* e = getenv("COSMO_HIP_POLAR_BATCH_MIN")) polar_min = atoi(e);
     p->polar_batch.clear();
     for (int idx : p->wg) if (p->cones[idx].d > polar_min) p->polar_batch.push_back(idx);

@@ -224,6 +224,12 @@ function cg_persist_stats(h::Handle)
     return (enabled = out[1] != 0, workgroups = out[2], launches = out[3], fallbacks = out[4])
 end
 
+function fold_stats(h::Handle)      # assembled reduced CG operator (cosmo_hip_fold_stats)
+    out = zeros(Int64, 4)
+    check(h, ccall((:cosmo_hip_fold_stats, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Int64}), h.ptr, out))
+    return (enabled = out[1] != 0, nnz = out[2], terms = out[3], tiles = out[4])
+end
+
 function project_hip!(h::Handle, s::COSMO.SplitVector{Float64})
     d = s.data
     GC.@preserve d check(h, ccall((:cosmo_hip_project, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Int64}, Ptr{Int32}), h.ptr, d, C_NULL, C_NULL))

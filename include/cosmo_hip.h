@@ -268,6 +268,10 @@ int32_t cosmo_hip_get_iterates(cosmo_hip_handle* h, double* w, double* w_prev, d
  * doubles per quarter}.  COSMO_HIP_CG_PERSIST=0 / 1 in the environment disables / forces it. */
 int32_t cosmo_hip_cg_persist_stats(cosmo_hip_handle* h, int64_t out[8]);
 int32_t cosmo_hip_get_kkt_solution(cosmo_hip_handle* h, double* sol);
+/* Assembled reduced operator of the CG solve (csrc/cg_fold.hip): M = P + diag(sigma + d) + Am' rho Am as ONE sparse matrix where the
+ * operator split leaves a sparse Am' rho Am (decomposed SDPs), two launches per Krylov iteration instead of three.
+ * out = {enabled, nnz(M), rho-weighted terms behind its entries, CSR-stream tiles}.  COSMO_HIP_OP_FOLD=0 in the environment disables it. */
+int32_t cosmo_hip_fold_stats(cosmo_hip_handle* h, int64_t out[4]);
 /* Statistics of the device loop since set_iterates: out = {admm_iters, kkt_solves, kkt_iters_total,
  * kkt_budget_stalls, spmv_A_calls, spmv_AT_calls, spmv_P_calls, rho_updates}. */
 int32_t cosmo_hip_get_stats(cosmo_hip_handle* h, int64_t out[8]);

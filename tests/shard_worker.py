@@ -17,7 +17,7 @@ import numpy as np  # noqa: E402
 
 def problem():
     import cosmo_jl_amd as cj
-    # cliques on both kernels of the PSD path (Jacobi d <= 64, batched matrix-sign d > 64) + SOC-free simple rows
+    # cliques of both tile classes of the batched matrix-sign path (single 64 x 64 tile, d <= 64, and multi-tile) + SOC-free simple rows
     return cj.problems.chordal_sdp(ncliques=14, dmin=6, dmax=110, sep_min=1, sep_max=4, n_total=3000, n_zero=20, n_nonneg=40, seed=55)
 
 

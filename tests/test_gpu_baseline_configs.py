@@ -95,15 +95,16 @@ def test_full_size_trajectory_matches_the_committed_oracle_fixture(name):
     if name == "cfg4":
         assert ps["large_cones"] == 1 and ps["tile_side"] == 96 and ps["k_split"] == 2 and ps["launches_96_2"] > 0 and ps["launches_64_1"] == 0
     else:
-        assert ps["batch_cones"] > 250 and ps["launches_batch"] > 0          # the 64 < d <= 200 cliques take the batched sign path
-        assert md.handle.psd_stats()["not_converged"] == 0                   # the d <= 64 cliques take the one-workgroup Jacobi kernels
+        assert ps["batch_cones"] == 400 and ps["launches_batch"] > 0         # every clique (d in [20, 200]) takes the batched sign path
+        assert md.handle.psd_stats()["not_converged"] == 0
+        assert md.handle.fold_stats()["enabled"] == 1                        # CG on the assembled operator (csrc/cg_fold.hip)
     assert ps["unverified"] == 0
 
 
 @pytest.mark.parametrize("name", ["cfg4", "cfg5"])
 def test_full_size_composite_projection_matches_the_committed_oracle_fixture(name):
     """src/convexset.jl:885-891 over every cone of the configuration (cfg5: ZeroSet + Nonnegatives + 400 PsdConeTriangle of side
-    20..200, i.e. Jacobi (d <= 64) and batched matrix-sign (d > 64) kernels in one call)."""
+    20..200: the batched matrix-sign kernels on single-tile (d <= 64) and multi-tile cones in one call)."""
     fx = _fixture(name)
     p = MK.problem(name)
     h = _proj_handle(p["sets"])
@@ -135,6 +136,22 @@ def test_cfg5_operator_split_on_off_at_full_size(monkeypatch):
         monkeypatch.setenv("COSMO_HIP_OP_SPLIT", split)
         _, md, r = _run_config("cfg5")
         out[split] = r
+    r1, r0 = out["1"], out["0"]
+    assert r1.iter == r0.iter
+    assert abs(r1.kkt_iters_total - r0.kkt_iters_total) <= 0.02 * r0.kkt_iters_total + 2
+    assert np.max(np.abs(r1.x - r0.x)) <= 1e-7 * max(1.0, float(np.max(np.abs(r0.x))))
+    assert np.max(np.abs(r1.s - r0.s)) <= 1e-7 * max(1.0, float(np.max(np.abs(r0.s))))
+
+
+def test_cfg5_assembled_operator_on_off_at_full_size(monkeypatch):
+    """M = P + diag(sigma + d) + Am' rho Am as one sparse matrix (csrc/cg_fold.hip) at BASELINE config 5's size against the split
+    operator's two dependent products: same iterates (1e-7) and Krylov work (2 %)."""
+    out = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("COSMO_HIP_OP_FOLD", fold)
+        _, md, r = _run_config("cfg5")
+        assert md.handle.fold_stats()["enabled"] == int(fold)
+        out[fold] = r
     r1, r0 = out["1"], out["0"]
     assert r1.iter == r0.iter
     assert abs(r1.kkt_iters_total - r0.kkt_iters_total) <= 0.02 * r0.kkt_iters_total + 2

@@ -1,0 +1,118 @@
+"""The ASSEMBLED reduced operator of the CG solve (csrc/cg_fold.hip): M = P + diag(sigma + d) + Am' rho Am applied as ONE sparse
+product (two launches per Krylov iteration) against the two dependent products of reduced_mul!
+(src/linear_solver/kktsolver_indirect.jl:57-64) that the split / unsplit operators apply.  Same linear operator, different
+association: the tests hold it to the KKT tolerances of SURVEY 8c -- dense solve in tight mode, Krylov iteration counts (+-1 per
+solve), 1e-7 trajectories against the unfolded device path AND against the oracle, rho adaptation on the device included."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import cosmo_jl_amd as cj
+from oracle import cosmo_oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def bounds_qp(n=1500, nrows=40, seed=3):
+    """QP with a general sparse P, simple bounds on every variable (single-nonzero rows of A: the diagonal part of A' rho A) and a few
+    dense-ish coupling rows (the matrix part Am)."""
+    rng = np.random.default_rng(seed)
+    S = sp.random(n, n, density=3.0 / n, random_state=rng, format="csc", data_rvs=lambda k: 0.2 * rng.standard_normal(k))
+    Ps = (S + S.T).tocsc()
+    P = (Ps + sp.diags(np.asarray(abs(Ps).sum(axis=1)).ravel() + rng.uniform(0.1, 1.0, n))).tocsc()
+    P.sort_indices()
+    G = sp.random(nrows, n, density=12.0 / n, random_state=rng, format="csc", data_rvs=rng.standard_normal)
+    x0 = rng.standard_normal(n)
+    A = sp.vstack([-sp.eye(n), -G], format="csc"); A.sort_indices()
+    lo = np.concatenate([x0 - np.abs(rng.standard_normal(n)), G @ x0 - 0.1])
+    hi = np.concatenate([x0 + np.abs(rng.standard_normal(n)), G @ x0 + 0.1])
+    hi[n:n + nrows // 4] = lo[n:n + nrows // 4]                      # some equality rows: rho class x 1e3
+    return dict(P=P, q=rng.standard_normal(n), A=A, b=np.zeros(n + nrows), sets=[cj.Box(lo, hi)])
+
+
+PROBLEMS = {
+    "chordal_sdp": lambda: cj.problems.chordal_sdp(ncliques=12, dmin=4, dmax=70, sep_min=1, sep_max=3, n_total=2500, n_zero=40, n_nonneg=80),
+    "bounds_qp": bounds_qp,
+}
+
+
+def _run(monkeypatch, fold, prob, iters, **st_kw):
+    monkeypatch.setenv("COSMO_HIP_OP_FOLD", fold)
+    st = cj.Settings(max_iter=iters, eps_abs=0.0, eps_rel=0.0, check_infeasibility=10 ** 9, **st_kw)
+    md = cj.Model(); md.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)
+    r = cj.optimize(md)
+    return md, r
+
+
+TIGHT = dict(kkt_solver=cj.with_options(cj.CGIndirectKKTSolver, tol_constant=1e-10, tol_exponent=0.0))
+
+
+@pytest.mark.parametrize("name", sorted(PROBLEMS))
+def test_fold_matches_the_unfolded_operator_and_the_oracle(name, monkeypatch):
+    prob = PROBLEMS[name]()
+    iters = 60
+    md1, r1 = _run(monkeypatch, "1", prob, iters, **TIGHT)
+    fs = md1.handle.fold_stats()
+    assert fs["enabled"] == 1 and fs["nnz"] >= md1.n, fs                 # the assembled operator really ran
+    md0, r0 = _run(monkeypatch, "0", prob, iters, **TIGHT)
+    assert md0.handle.fold_stats()["enabled"] == 0
+    assert r1.iter == r0.iter == iters
+    # Krylov work: +-1 iteration per solve at the 1e-10 stopping threshold
+    assert abs(r1.kkt_iters_total - r0.kkt_iters_total) <= iters + 1, (r1.kkt_iters_total, r0.kkt_iters_total)
+    for a, b in ((r1.x, r0.x), (r1.s, r0.s), (r1.y, r0.y)):
+        assert np.max(np.abs(a - b)) <= 1e-7 * max(1.0, float(np.max(np.abs(b))))
+    assert r1.info.rho_updates == pytest.approx(r0.info.rho_updates, rel=1e-6)
+    # ... and the oracle (tight mode, ||dw|| <= 1e-7 ||w||)
+    ref = O.solve(prob["P"], prob["q"], prob["A"], prob["b"], util.oracle_cones(prob["sets"]),
+                  O.Settings(max_iter=iters, eps_abs=0.0, eps_rel=0.0, check_infeasibility=10 ** 9, kkt_solver="cg", tol_constant=1e-10, tol_exponent=0.0))
+    assert ref.iter == r1.iter
+    for a, b in ((r1.x, ref.x), (r1.s, ref.s), (r1.y, ref.y)):
+        assert np.max(np.abs(a - b)) <= 1e-7 * max(1.0, float(np.max(np.abs(b))))
+    assert len(r1.info.rho_updates) == len(ref.rho_updates)
+
+
+@pytest.mark.parametrize("name", sorted(PROBLEMS))
+def test_fold_kkt_solve_against_a_dense_solve(name, monkeypatch):
+    """AbstractKKTSolver.solve! through the assembled operator vs numpy on the full KKT matrix (test/UnitTests/kktsolver.jl:97-109)."""
+    prob = PROBLEMS[name]()
+    if name == "chordal_sdp":
+        prob = cj.problems.chordal_sdp(ncliques=6, dmin=6, dmax=20, sep_min=1, sep_max=2, n_total=600, n_zero=6, n_nonneg=12)
+    md, _ = _run(monkeypatch, "1", prob, 5, scaling=0, adaptive_rho=False, **TIGHT)
+    assert md.handle.fold_stats()["enabled"] == 1
+    n, m = md.n, md.m
+    if n + m > 4000:
+        pytest.skip("dense reference too large")
+    rho = md.handle.get_rho_vec()
+    K = O.assemble_kkt_full(sp.csc_matrix(prob["P"]), sp.csc_matrix(prob["A"]), 1e-6, rho).toarray()
+    rhs = np.random.default_rng(11).standard_normal(n + m)
+    sol, its = md.handle.kkt_solve(rhs)
+    ref = np.linalg.solve(K, rhs)
+    assert its > 0
+    assert np.linalg.norm(sol - ref) <= 1e-8 * np.linalg.norm(ref) * 10        # tight mode: ||dsol|| <= 1e-8 ||sol|| (x 10: dense-solve conditioning)
+
+
+def test_fold_follows_rho_updates_and_default_schedule(monkeypatch):
+    """Default settings (loose 1/k^1.5 Krylov tolerance, adaptive rho every 40 iterations decided on the device): the assembled
+    values are rebuilt after every adaptation; status, iteration count and objective agree with the unfolded path and the oracle."""
+    prob = PROBLEMS["chordal_sdp"]()
+    out = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("COSMO_HIP_OP_FOLD", fold)
+        md = cj.Model(); md.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], cj.Settings(kkt_solver=cj.CGIndirectKKTSolver, max_iter=3000))
+        out[fold] = (cj.optimize(md), md.handle.fold_stats()["enabled"])
+    (r1, e1), (r0, e0) = out["1"], out["0"]
+    assert e1 == 1 and e0 == 0
+    ref = O.solve(prob["P"], prob["q"], prob["A"], prob["b"], util.oracle_cones(prob["sets"]), O.Settings(kkt_solver="cg", max_iter=3000))
+    assert r1.status == r0.status == ref.status == "Solved"
+    assert len(r1.info.rho_updates) == len(r0.info.rho_updates) == len(ref.rho_updates) >= 2      # rho really changed
+    assert abs(r1.iter - r0.iter) <= 25 and abs(r1.iter - ref.iter) <= 25
+    assert abs(r1.obj_val - ref.obj_val) <= 1e-4 * (1 + abs(ref.obj_val))
+
+
+def test_fold_is_off_where_the_assembly_would_not_pay(monkeypatch):
+    """config-2-like rows (10 nonzeros per row, no single-nonzero rows): neither split nor assembled."""
+    monkeypatch.setenv("COSMO_HIP_OP_FOLD", "1")
+    prob = cj.problems.sparse_box_qp(n=2000, m=4000, nnz=40000, seed=3)
+    md, _ = _run(monkeypatch, "1", prob, 3)
+    assert md.handle.fold_stats()["enabled"] == 0

@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 def _solve(monkeypatch, persist, prob, iters, fuse="1", **st_kw):
     monkeypatch.setenv("COSMO_HIP_CG_PERSIST", persist)
     monkeypatch.setenv("COSMO_HIP_CG_FUSE_DIR", fuse)
+    monkeypatch.setenv("COSMO_HIP_OP_FOLD", "0")       # these tests compare the kernels of the split / unsplit operator (no assembled M, csrc/cg_fold.hip)
     monkeypatch.setenv("COSMO_HIP_POLAR_KLIFT", "10")
     st = cj.Settings(max_iter=iters, eps_abs=0.0, eps_rel=0.0, check_infeasibility=10 ** 9, **st_kw)
     md = cj.Model(); md.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)

@@ -72,8 +72,12 @@ def test_psd_tiny_sizes(kind):
     check_projection(sets, mats)
 
 
+@pytest.mark.parametrize("path", ["sign", "jacobi"])
 @pytest.mark.parametrize("kind", ["tri", "square"])
-def test_psd_workgroup_sizes(kind):
+def test_psd_workgroup_sizes(kind, path, monkeypatch):
+    # 16 < d <= 256: batched matrix-sign iteration by default (csrc/psd.hip: polar_min = 16); the one-workgroup block-Jacobi
+    # eigensolvers (still used by the definiteness tests of the infeasibility certificates) through COSMO_HIP_POLAR_BATCH_MIN=256
+    monkeypatch.setenv("COSMO_HIP_POLAR_BATCH_MIN", "16" if path == "sign" else "256")
     rng = np.random.default_rng(2)
     dims = [17, 20, 24, 31, 32, 33, 47, 64, 65, 100, 127, 128, 129, 200, 255, 256]
     mats = [sym_with_spectrum(rng, gapped_spectrum(rng, d)) for d in dims]
@@ -89,7 +93,9 @@ def test_psd_large_multi_workgroup():
     check_projection(sets, mats)
 
 
-def test_psd_special_spectra():
+@pytest.mark.parametrize("path", ["sign", "jacobi"])
+def test_psd_special_spectra(path, monkeypatch):
+    monkeypatch.setenv("COSMO_HIP_POLAR_BATCH_MIN", "16" if path == "sign" else "256")
     rng = np.random.default_rng(4)
     mats, sets = [], []
     for d in (6, 40, 130):
