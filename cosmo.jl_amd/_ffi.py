@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcosmo_hip.so")
+LIB_PATH = os.path.join(_HERE, "libcosmo_hip.so")            # cosmo_hip_real = double (COSMO.Model{Float64})
+LIB_PATH_F32 = os.path.join(_HERE, "libcosmo_hip_f32.so")     # the same sources, cosmo_hip_real = float (COSMO.Model{Float32})
 
 OK = 0
 ERR_NAMES = {1: "INVALID", 2: "HIP", 3: "NOT_CONVEX", 4: "NONFINITE", 5: "EIG", 6: "UNSUPPORTED", 7: "COMM"}
@@ -40,15 +41,25 @@ class CosmoHipError(RuntimeError):
         self.code = code
 
 
-_lib = None
+_libs = {}
 
 _PD = C.POINTER(C.c_double)
+_PF = C.POINTER(C.c_float)
+
+
+class _RealPtr:
+    """Placeholder in SIGNATURES for `cosmo_hip_real*` (include/cosmo_hip.h): resolved to double* or float* when a library is loaded."""
+
+
+_PR = _RealPtr
 _PI64 = C.POINTER(C.c_int64)
 _PI32 = C.POINTER(C.c_int32)
 
 # name -> (restype, argtypes).  Kept in one table so tests can check it against the header.
 PROJECT_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int64, C.c_void_p)                       # cosmo_hip_project_fn
 CONE_TEST_FN = C.CFUNCTYPE(C.c_int32, C.POINTER(C.c_double), C.c_int64, C.c_double, C.c_void_p)     # cosmo_hip_cone_test_fn
+PROJECT_FN_F32 = C.CFUNCTYPE(None, C.POINTER(C.c_float), C.c_int64, C.c_void_p)
+CONE_TEST_FN_F32 = C.CFUNCTYPE(C.c_int32, C.POINTER(C.c_float), C.c_int64, C.c_double, C.c_void_p)
 
 SIGNATURES = {
     "cosmo_hip_version": (C.c_int32, []),
@@ -56,34 +67,34 @@ SIGNATURES = {
     "cosmo_hip_create": (C.c_int32, [C.POINTER(C.c_void_p), C.c_int32]),
     "cosmo_hip_destroy": (C.c_int32, [C.c_void_p]),
     "cosmo_hip_last_error": (C.c_char_p, [C.c_void_p]),
-    "cosmo_hip_set_problem": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int64, _PI64, _PI64, _PD, _PI64, _PI64, _PD, _PD, _PD]),
-    "cosmo_hip_set_cones": (C.c_int32, [C.c_void_p, C.c_int64, _PI32, _PI64, _PD, _PD]),
-    "cosmo_hip_set_cones_ex": (C.c_int32, [C.c_void_p, C.c_int64, _PI32, _PI64, _PD, _PD, _PD]),
+    "cosmo_hip_set_problem": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int64, _PI64, _PI64, _PR, _PI64, _PI64, _PR, _PR, _PR]),
+    "cosmo_hip_set_cones": (C.c_int32, [C.c_void_p, C.c_int64, _PI32, _PI64, _PR, _PR]),
+    "cosmo_hip_set_cones_ex": (C.c_int32, [C.c_void_p, C.c_int64, _PI32, _PI64, _PR, _PR, _PR]),
     "cosmo_hip_set_custom_cone": (C.c_int32, [C.c_void_p, C.c_int64, PROJECT_FN, CONE_TEST_FN, CONE_TEST_FN, C.c_void_p]),
-    "cosmo_hip_set_params": (C.c_int32, [C.c_void_p, C.POINTER(Params), _PD]),
-    "cosmo_hip_update_rho": (C.c_int32, [C.c_void_p, _PD]),
-    "cosmo_hip_set_scaling": (C.c_int32, [C.c_void_p, _PD, _PD, C.c_double]),
-    "cosmo_hip_set_scaling_full": (C.c_int32, [C.c_void_p, _PD, _PD, _PD, _PD, C.c_double, C.c_double]),
+    "cosmo_hip_set_params": (C.c_int32, [C.c_void_p, C.POINTER(Params), _PR]),
+    "cosmo_hip_update_rho": (C.c_int32, [C.c_void_p, _PR]),
+    "cosmo_hip_set_scaling": (C.c_int32, [C.c_void_p, _PR, _PR, C.c_double]),
+    "cosmo_hip_set_scaling_full": (C.c_int32, [C.c_void_p, _PR, _PR, _PR, _PR, C.c_double, C.c_double]),
     "cosmo_hip_default_accel_params": (None, [C.POINTER(AccelParams)]),
     "cosmo_hip_set_accelerator": (C.c_int32, [C.c_void_p, C.POINTER(AccelParams)]),
     "cosmo_hip_get_accel_stats": (C.c_int32, [C.c_void_p, _PI64]),
-    "cosmo_hip_scale_ruiz": (C.c_int32, [C.c_void_p, C.c_int64, C.c_double, C.c_double, _PD, _PD, C.POINTER(C.c_double)]),
-    "cosmo_hip_update_qb": (C.c_int32, [C.c_void_p, _PD, _PD]),
+    "cosmo_hip_scale_ruiz": (C.c_int32, [C.c_void_p, C.c_int64, C.c_double, C.c_double, _PR, _PR, _PD]),
+    "cosmo_hip_update_qb": (C.c_int32, [C.c_void_p, _PR, _PR]),
     "cosmo_hip_get_rho_classes": (C.c_int32, [C.c_void_p, _PI32]),
-    "cosmo_hip_get_rho_vec": (C.c_int32, [C.c_void_p, _PD]),
-    "cosmo_hip_kkt_solve": (C.c_int32, [C.c_void_p, _PD, _PD, _PI64]),
-    "cosmo_hip_project": (C.c_int32, [C.c_void_p, _PD, _PI64, _PI32]),
-    "cosmo_hip_spmv": (C.c_int32, [C.c_void_p, C.c_int32, _PD, _PD]),
-    "cosmo_hip_set_iterates": (C.c_int32, [C.c_void_p, _PD, _PD, _PD]),
+    "cosmo_hip_get_rho_vec": (C.c_int32, [C.c_void_p, _PR]),
+    "cosmo_hip_kkt_solve": (C.c_int32, [C.c_void_p, _PR, _PR, _PI64]),
+    "cosmo_hip_project": (C.c_int32, [C.c_void_p, _PR, _PI64, _PI32]),
+    "cosmo_hip_spmv": (C.c_int32, [C.c_void_p, C.c_int32, _PR, _PR]),
+    "cosmo_hip_set_iterates": (C.c_int32, [C.c_void_p, _PR, _PR, _PR]),
     "cosmo_hip_admm_init": (C.c_int32, [C.c_void_p]),
     "cosmo_hip_admm_iterate": (C.c_int32, [C.c_void_p, C.c_int64]),
     "cosmo_hip_admm_iterate_checked": (C.c_int32, [C.c_void_p, C.c_int64, _PI32]),
     "cosmo_hip_residuals": (C.c_int32, [C.c_void_p, _PD]),
     "cosmo_hip_optimize": (C.c_int32, [C.c_void_p, C.POINTER(ResultStruct)]),
-    "cosmo_hip_get_iterates": (C.c_int32, [C.c_void_p, _PD, _PD, _PD, _PD]),
+    "cosmo_hip_get_iterates": (C.c_int32, [C.c_void_p, _PR, _PR, _PR, _PR]),
     "cosmo_hip_cg_persist_stats": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_fold_stats": (C.c_int32, [C.c_void_p, _PI64]),
-    "cosmo_hip_get_kkt_solution": (C.c_int32, [C.c_void_p, _PD]),
+    "cosmo_hip_get_kkt_solution": (C.c_int32, [C.c_void_p, _PR]),
     "cosmo_hip_get_stats": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_time_spmv": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _PD, _PD]),
     "cosmo_hip_set_profiling": (C.c_int32, [C.c_void_p, C.c_int32]),
@@ -104,26 +115,32 @@ SIGNATURES = {
     "cosmo_hip_batch_create": (C.c_int32, [C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_int64, C.c_int64]),
     "cosmo_hip_batch_destroy": (C.c_int32, [C.c_void_p]),
     "cosmo_hip_batch_last_error": (C.c_char_p, [C.c_void_p]),
-    "cosmo_hip_batch_set_problem": (C.c_int32, [C.c_void_p, C.c_int64, _PI64, _PI64, _PD, _PI64, _PI64, _PD, _PD, _PD]),
-    "cosmo_hip_batch_set_cones": (C.c_int32, [C.c_void_p, C.c_int64, _PI32, _PI64, _PD, _PD]),
-    "cosmo_hip_batch_set_scaling": (C.c_int32, [C.c_void_p, C.c_int64, _PD, _PD, C.c_double]),
+    "cosmo_hip_batch_set_problem": (C.c_int32, [C.c_void_p, C.c_int64, _PI64, _PI64, _PR, _PI64, _PI64, _PR, _PR, _PR]),
+    "cosmo_hip_batch_set_cones": (C.c_int32, [C.c_void_p, C.c_int64, _PI32, _PI64, _PR, _PR]),
+    "cosmo_hip_batch_set_scaling": (C.c_int32, [C.c_void_p, C.c_int64, _PR, _PR, C.c_double]),
     "cosmo_hip_batch_set_params": (C.c_int32, [C.c_void_p, C.POINTER(Params)]),
     "cosmo_hip_batch_get_rho_classes": (C.c_int32, [C.c_void_p, C.c_int64, _PI32]),
-    "cosmo_hip_batch_set_iterates": (C.c_int32, [C.c_void_p, _PD, _PD, _PD]),
+    "cosmo_hip_batch_set_iterates": (C.c_int32, [C.c_void_p, _PR, _PR, _PR]),
     "cosmo_hip_batch_optimize": (C.c_int32, [C.c_void_p, C.POINTER(ResultStruct)]),
     "cosmo_hip_batch_iterate": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32]),
-    "cosmo_hip_batch_get_iterates": (C.c_int32, [C.c_void_p, C.c_int64, _PD, _PD, _PD, _PD]),
+    "cosmo_hip_batch_get_iterates": (C.c_int32, [C.c_void_p, C.c_int64, _PR, _PR, _PR, _PR]),
 }
 
 
-def load_library():
-    """Loads libcosmo_hip.so (built by `__graft_entry__.build()` / `make -C cosmo.jl_amd/csrc`).  Raises if absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ImportError("libcosmo_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
-                          "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+def _is_f32(dtype):
+    return np.dtype(dtype) == np.float32
+
+
+def load_library(dtype=np.float64):
+    """Loads libcosmo_hip.so (dtype float64) or libcosmo_hip_f32.so (float32), both built by `__graft_entry__.build()` /
+    `make -C cosmo.jl_amd/csrc` from the same sources.  Raises if absent."""
+    f32 = _is_f32(dtype)
+    if f32 in _libs:
+        return _libs[f32]
+    path = LIB_PATH_F32 if f32 else LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError("%s not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback." % (os.path.basename(path), path))
     try:
         # torch bundles its own libamdhip64; if it is going to live in this process (tests, bench: torch.distributed,
         # device selection) it must be loaded FIRST so that both share one HIP runtime.  Pure plumbing: no torch
@@ -131,51 +148,57 @@ def load_library():
         import torch  # noqa: F401
     except Exception:
         pass
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
+    preal = _PF if f32 else _PD
+    fnmap = {PROJECT_FN: PROJECT_FN_F32, CONE_TEST_FN: CONE_TEST_FN_F32} if f32 else {}
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
-        fn.argtypes = args
-    _lib = lib
+        fn.argtypes = [preal if a is _PR else fnmap.get(a, a) for a in args]
+    _libs[f32] = lib
     return lib
 
 
 def _dp(a):
-    return None if a is None else a.ctypes.data_as(_PD)
+    """pointer to a data array in ITS element type (the arrays handed to a library are made with that library's dtype)"""
+    return None if a is None else a.ctypes.data_as(_PF if a.dtype == np.float32 else _PD)
 
 
-def _f64(a, n=None, name="array"):
+def _f64(a, n=None, name="array", dtype=np.float64):
     if a is None:
         return None
-    a = np.ascontiguousarray(a, dtype=np.float64)
+    a = np.ascontiguousarray(a, dtype=dtype)
     if n is not None and a.size != n:
         raise ValueError("%s has length %d, expected %d" % (name, a.size, n))
     return a
 
 
-def csc_julia(M):
-    """SciPy sparse -> the arrays of a Julia SparseMatrixCSC{Float64,Int64} (1-based, sorted rows)."""
+def csc_julia(M, dtype=np.float64):
+    """SciPy sparse -> the arrays of a Julia SparseMatrixCSC{T,Int64} (1-based, sorted rows), T = Float64 | Float32."""
     import scipy.sparse as sp
-    M = sp.csc_matrix(M, dtype=np.float64)
+    # copy: a dtype conversion copies `data` but may SHARE `indices` with the caller's matrix; sorting the indices in place would
+    # then permute the caller's index array without its values
+    M = sp.csc_matrix(M, dtype=dtype, copy=True)
     M.sum_duplicates()
     M.sort_indices()
     colptr = np.ascontiguousarray(M.indptr, dtype=np.int64) + 1
     rowval = np.ascontiguousarray(M.indices, dtype=np.int64) + 1
-    nzval = np.ascontiguousarray(M.data, dtype=np.float64)
+    nzval = np.ascontiguousarray(M.data, dtype=dtype)
     return colptr, rowval, nzval
 
 
-def default_params():
+def default_params(dtype=np.float64):
     p = Params()
-    load_library().cosmo_hip_default_params(C.byref(p))
+    load_library(dtype).cosmo_hip_default_params(C.byref(p))
     return p
 
 
 class Handle:
     """Thin object wrapper: one method per C entry point, NumPy arrays in and out."""
 
-    def __init__(self, device=0):
-        self.lib = load_library()
+    def __init__(self, device=0, dtype=np.float64):
+        self.dtype = np.dtype(np.float32 if _is_f32(dtype) else np.float64)      # element type of every data array (cosmo_hip_real)
+        self.lib = load_library(self.dtype)
         self._h = C.c_void_p()
         rc = self.lib.cosmo_hip_create(C.byref(self._h), int(device))
         if rc != OK:
@@ -183,6 +206,9 @@ class Handle:
         self.n = self.m = 0
         self.ncones = 0
         self._callbacks = {}
+
+    def _f(self, a, n=None, name="array"):
+        return _f64(a, n, name, self.dtype)
 
     def close(self):
         if self._h:
@@ -203,9 +229,9 @@ class Handle:
     # ---- problem ----------------------------------------------------------------------------------------
     def set_problem(self, P, q, A, b):
         m, n = A.shape
-        pc, pr, pv = csc_julia(P)
-        ac, ar, av = csc_julia(A)
-        q = _f64(q, n, "q"); b = _f64(b, m, "b")
+        pc, pr, pv = csc_julia(P, self.dtype)
+        ac, ar, av = csc_julia(A, self.dtype)
+        q = self._f(q, n, "q"); b = self._f(b, m, "b")
         self._chk(self.lib.cosmo_hip_set_problem(self._h, n, m, pc.ctypes.data_as(_PI64), pr.ctypes.data_as(_PI64), _dp(pv),
                                                  ac.ctypes.data_as(_PI64), ar.ctypes.data_as(_PI64), _dp(av), _dp(q), _dp(b)))
         self.n, self.m = n, m
@@ -213,11 +239,11 @@ class Handle:
     def set_cones(self, types, dims, box_l=None, box_u=None, cone_param=None):
         t = np.ascontiguousarray(types, dtype=np.int32)
         d = np.ascontiguousarray(dims, dtype=np.int64)
-        bl = _f64(box_l); bu = _f64(box_u)
+        bl = self._f(box_l); bu = self._f(box_u)
         if cone_param is None:
             self._chk(self.lib.cosmo_hip_set_cones(self._h, t.size, t.ctypes.data_as(_PI32), d.ctypes.data_as(_PI64), _dp(bl), _dp(bu)))
         else:
-            cp = _f64(cone_param, t.size, "cone_param")
+            cp = self._f(cone_param, t.size, "cone_param")
             self._chk(self.lib.cosmo_hip_set_cones_ex(self._h, t.size, t.ctypes.data_as(_PI32), d.ctypes.data_as(_PI64), _dp(bl), _dp(bu), _dp(cp)))
         self.ncones = t.size
         self._callbacks = {}
@@ -226,29 +252,31 @@ class Handle:
         """cosmo_hip_set_custom_cone: `project(x)` projects the NumPy view x (the cone's slice) in place; `in_dual(x, tol)` /
         `in_pol_recc(x, tol)` return truth values (optional).  The ctypes thunks are kept alive on the handle."""
         def _view(ptr, dim):
-            return np.ctypeslib.as_array(ptr, shape=(int(dim),)) if dim > 0 else np.zeros(0)
+            return np.ctypeslib.as_array(ptr, shape=(int(dim),)) if dim > 0 else np.zeros(0, dtype=self.dtype)
 
         def _proj(ptr, dim, _user):
             project(_view(ptr, dim))
 
         def _mk(fn):
             if fn is None:
-                return CONE_TEST_FN(0)
-            return CONE_TEST_FN(lambda ptr, dim, tol, _user: 1 if fn(_view(ptr, dim), float(tol)) else 0)
+                return test_t(0)
+            return test_t(lambda ptr, dim, tol, _user: 1 if fn(_view(ptr, dim), float(tol)) else 0)
 
-        thunks = (PROJECT_FN(_proj), _mk(in_dual), _mk(in_pol_recc))
+        f32 = self.dtype == np.float32
+        proj_t, test_t = (PROJECT_FN_F32, CONE_TEST_FN_F32) if f32 else (PROJECT_FN, CONE_TEST_FN)
+        thunks = (proj_t(_proj), _mk(in_dual), _mk(in_pol_recc))
         self._callbacks[int(cone)] = thunks
         self._chk(self.lib.cosmo_hip_set_custom_cone(self._h, int(cone), thunks[0], thunks[1], thunks[2], None))
 
     def default_params(self):
-        return default_params()
+        return default_params(self.dtype)
 
     def set_params(self, params, rho_vec=None):
-        rv = _f64(rho_vec, self.m, "rho_vec")
+        rv = self._f(rho_vec, self.m, "rho_vec")
         self._chk(self.lib.cosmo_hip_set_params(self._h, C.byref(params), _dp(rv)))
 
     def update_rho(self, rho_vec):
-        rv = _f64(rho_vec, self.m, "rho_vec")
+        rv = self._f(rho_vec, self.m, "rho_vec")
         self._chk(self.lib.cosmo_hip_update_rho(self._h, _dp(rv)))
 
     def set_accelerator(self, kind=ACCEL_ANDERSON, mem=15, min_mem=3, safeguard=True, safeguard_tol=2.0, start_iter=2, start_accuracy=None):
@@ -269,19 +297,19 @@ class Handle:
 
     def scale_ruiz(self, iterations, min_scaling=1e-4, max_scaling=1e4):
         """Device Ruiz equilibration of the resident (unscaled) problem; returns (D, E, c)."""
-        D = np.empty(self.n); E = np.empty(self.m); c = C.c_double(1.0)
+        D = np.empty(self.n, dtype=self.dtype); E = np.empty(self.m, dtype=self.dtype); c = C.c_double(1.0)
         self._chk(self.lib.cosmo_hip_scale_ruiz(self._h, int(iterations), float(min_scaling), float(max_scaling), _dp(D), _dp(E), C.byref(c)))
         return D, E, float(c.value)
 
     def set_scaling(self, Dinv, Einv, cinv):
-        self._chk(self.lib.cosmo_hip_set_scaling(self._h, _dp(_f64(Dinv, self.n)), _dp(_f64(Einv, self.m)), float(cinv)))
+        self._chk(self.lib.cosmo_hip_set_scaling(self._h, _dp(self._f(Dinv, self.n)), _dp(self._f(Einv, self.m)), float(cinv)))
 
     def set_scaling_full(self, D, Dinv, E, Einv, c, cinv):
-        self._chk(self.lib.cosmo_hip_set_scaling_full(self._h, _dp(_f64(D, self.n)), _dp(_f64(Dinv, self.n)), _dp(_f64(E, self.m)),
-                                                      _dp(_f64(Einv, self.m)), float(c), float(cinv)))
+        self._chk(self.lib.cosmo_hip_set_scaling_full(self._h, _dp(self._f(D, self.n)), _dp(self._f(Dinv, self.n)), _dp(self._f(E, self.m)),
+                                                      _dp(self._f(Einv, self.m)), float(c), float(cinv)))
 
     def update_qb(self, q=None, b=None):
-        self._chk(self.lib.cosmo_hip_update_qb(self._h, _dp(_f64(q, self.n)), _dp(_f64(b, self.m))))
+        self._chk(self.lib.cosmo_hip_update_qb(self._h, _dp(self._f(q, self.n)), _dp(self._f(b, self.m))))
 
     def get_rho_classes(self):
         out = np.empty(self.m, dtype=np.int32)
@@ -289,20 +317,20 @@ class Handle:
         return out
 
     def get_rho_vec(self):
-        out = np.empty(self.m)
+        out = np.empty(self.m, dtype=self.dtype)
         self._chk(self.lib.cosmo_hip_get_rho_vec(self._h, _dp(out)))
         return out
 
     # ---- fine-grained ---------------------------------------------------------------------------------------
     def kkt_solve(self, rhs):
-        rhs = _f64(rhs, self.n + self.m, "rhs")
-        lhs = np.empty(self.n + self.m)
+        rhs = self._f(rhs, self.n + self.m, "rhs")
+        lhs = np.empty(self.n + self.m, dtype=self.dtype)
         it = C.c_int64(0)
         self._chk(self.lib.cosmo_hip_kkt_solve(self._h, _dp(lhs), _dp(rhs), C.byref(it)))
         return lhs, it.value
 
     def project(self, s):
-        s = np.array(s, dtype=np.float64).copy()
+        s = np.array(s, dtype=self.dtype).copy()
         ranks = np.empty(max(self.ncones, 1), dtype=np.int64)
         br = np.empty(max(self.ncones, 1), dtype=np.int32)
         self._chk(self.lib.cosmo_hip_project(self._h, _dp(s), ranks.ctypes.data_as(_PI64), br.ctypes.data_as(_PI32)))
@@ -311,14 +339,14 @@ class Handle:
     def spmv(self, which, x):
         nin = {MAT_A: self.n, MAT_AT: self.m, MAT_P: self.n}[which]
         nout = {MAT_A: self.m, MAT_AT: self.n, MAT_P: self.n}[which]
-        x = _f64(x, nin, "x")
-        y = np.empty(nout)
+        x = self._f(x, nin, "x")
+        y = np.empty(nout, dtype=self.dtype)
         self._chk(self.lib.cosmo_hip_spmv(self._h, which, _dp(y), _dp(x)))
         return y
 
     # ---- loop -------------------------------------------------------------------------------------------------
     def set_iterates(self, x0=None, s0=None, mu0=None):
-        self._chk(self.lib.cosmo_hip_set_iterates(self._h, _dp(_f64(x0, self.n)), _dp(_f64(s0, self.m)), _dp(_f64(mu0, self.m))))
+        self._chk(self.lib.cosmo_hip_set_iterates(self._h, _dp(self._f(x0, self.n)), _dp(self._f(s0, self.m)), _dp(self._f(mu0, self.m))))
 
     def admm_init(self):
         self._chk(self.lib.cosmo_hip_admm_init(self._h))
@@ -343,12 +371,12 @@ class Handle:
 
     def get_iterates(self):
         N = self.n + self.m
-        w = np.empty(N); wp = np.empty(N); s = np.empty(self.m); mu = np.empty(self.m)
+        w = np.empty(N, dtype=self.dtype); wp = np.empty(N, dtype=self.dtype); s = np.empty(self.m, dtype=self.dtype); mu = np.empty(self.m, dtype=self.dtype)
         self._chk(self.lib.cosmo_hip_get_iterates(self._h, _dp(w), _dp(wp), _dp(s), _dp(mu)))
         return w, wp, s, mu
 
     def get_kkt_solution(self):
-        sol = np.empty(self.n + self.m)
+        sol = np.empty(self.n + self.m, dtype=self.dtype)
         self._chk(self.lib.cosmo_hip_get_kkt_solution(self._h, _dp(sol)))
         return sol
 
@@ -440,13 +468,17 @@ class Handle:
 class Batch:
     """Batch of independent problems with identical (n, m, cone structure): one persistent workgroup per problem."""
 
-    def __init__(self, nprob, n, m, device=0):
-        self.lib = load_library()
+    def __init__(self, nprob, n, m, device=0, dtype=np.float64):
+        self.dtype = np.dtype(np.float32 if _is_f32(dtype) else np.float64)
+        self.lib = load_library(self.dtype)
         self._b = C.c_void_p()
         rc = self.lib.cosmo_hip_batch_create(C.byref(self._b), int(device), int(nprob), int(n), int(m))
         if rc != OK:
             raise CosmoHipError(rc, "cosmo_hip_batch_create failed (no MI355X visible? this library has no CPU path)")
         self.nprob, self.n, self.m = int(nprob), int(n), int(m)
+
+    def _f(self, a, n=None, name="array"):
+        return _f64(a, n, name, self.dtype)
 
     def close(self):
         if self._b:
@@ -465,19 +497,19 @@ class Batch:
             raise CosmoHipError(rc, msg.decode() if msg else "")
 
     def set_problem(self, k, P, q, A, b):
-        pc, pr, pv = csc_julia(P)
-        ac, ar, av = csc_julia(A)
-        q = _f64(q, self.n, "q"); b = _f64(b, self.m, "b")
+        pc, pr, pv = csc_julia(P, self.dtype)
+        ac, ar, av = csc_julia(A, self.dtype)
+        q = self._f(q, self.n, "q"); b = self._f(b, self.m, "b")
         self._chk(self.lib.cosmo_hip_batch_set_problem(self._b, int(k), pc.ctypes.data_as(_PI64), pr.ctypes.data_as(_PI64), _dp(pv),
                                                        ac.ctypes.data_as(_PI64), ar.ctypes.data_as(_PI64), _dp(av), _dp(q), _dp(b)))
 
     def set_cones(self, types, dims, box_l=None, box_u=None):
         t = np.ascontiguousarray(types, dtype=np.int32); d = np.ascontiguousarray(dims, dtype=np.int64)
-        bl = _f64(box_l); bu = _f64(box_u)
+        bl = self._f(box_l); bu = self._f(box_u)
         self._chk(self.lib.cosmo_hip_batch_set_cones(self._b, t.size, t.ctypes.data_as(_PI32), d.ctypes.data_as(_PI64), _dp(bl), _dp(bu)))
 
     def set_scaling(self, k, Dinv, Einv, cinv):
-        self._chk(self.lib.cosmo_hip_batch_set_scaling(self._b, int(k), _dp(_f64(Dinv, self.n)), _dp(_f64(Einv, self.m)), float(cinv)))
+        self._chk(self.lib.cosmo_hip_batch_set_scaling(self._b, int(k), _dp(self._f(Dinv, self.n)), _dp(self._f(Einv, self.m)), float(cinv)))
 
     def set_params(self, params):
         self._chk(self.lib.cosmo_hip_batch_set_params(self._b, C.byref(params)))
@@ -488,8 +520,8 @@ class Batch:
         return out
 
     def set_iterates(self, x0=None, s0=None, mu0=None):
-        self._chk(self.lib.cosmo_hip_batch_set_iterates(self._b, _dp(_f64(x0, self.nprob * self.n)), _dp(_f64(s0, self.nprob * self.m)),
-                                                        _dp(_f64(mu0, self.nprob * self.m))))
+        self._chk(self.lib.cosmo_hip_batch_set_iterates(self._b, _dp(self._f(x0, self.nprob * self.n)), _dp(self._f(s0, self.nprob * self.m)),
+                                                        _dp(self._f(mu0, self.nprob * self.m))))
 
     def optimize(self):
         res = (ResultStruct * self.nprob)()
@@ -501,6 +533,6 @@ class Batch:
 
     def get_iterates(self, k):
         N = self.n + self.m
-        w = np.empty(N); wp = np.empty(N); s = np.empty(self.m); mu = np.empty(self.m)
+        w = np.empty(N, dtype=self.dtype); wp = np.empty(N, dtype=self.dtype); s = np.empty(self.m, dtype=self.dtype); mu = np.empty(self.m, dtype=self.dtype)
         self._chk(self.lib.cosmo_hip_batch_get_iterates(self._b, int(k), _dp(w), _dp(wp), _dp(s), _dp(mu)))
         return w, wp, s, mu

@@ -29,19 +29,19 @@ struct AaFlags {
   int success;        // CA.was_successful
   int declined;       // safeguarding rejected the candidate
   int fail_eta, fail_singular;
-  double nrm_f;       // ||f|| of the last update! (the non-accelerated fixed-point residual)
-  double nrm_f_acc;   // ||w_prev - w|| after the accelerated step
-  double eta_norm;
-  double R[AA_MAX_MEM * AA_MAX_MEM];   // column-major mem x mem
-  double eta[AA_MAX_MEM];
+  real nrm_f;       // ||f|| of the last update! (the non-accelerated fixed-point residual)
+  real nrm_f_acc;   // ||w_prev - w|| after the accelerated step
+  real eta_norm;
+  real R[AA_MAX_MEM * AA_MAX_MEM];   // column-major mem x mem
+  real eta[AA_MAX_MEM];
 };
 
 struct AaState {
   cosmo_hip_accel_params prm;
   long long N = 0;
   int mem = 0;
-  double *G = nullptr, *Q = nullptr, *f = nullptr, *f_last = nullptr, *g_last = nullptr;
-  double* parts = nullptr;      // (AA_MAX_MEM + 1) x COSMO_MAX_PARTIALS
+  real *G = nullptr, *Q = nullptr, *f = nullptr, *f_last = nullptr, *g_last = nullptr;
+  real* parts = nullptr;      // (AA_MAX_MEM + 1) x COSMO_MAX_PARTIALS
   AaFlags* flags = nullptr;     // device
   AaFlags* flags_host = nullptr;  // pinned
   int grid = 1;
@@ -58,19 +58,19 @@ namespace {
 
 // f = x - g ; first call after a restart: remember (g, f) ; otherwise G_j = g - g_last, v = f - f_last (stored in Q_j) and the
 // partial dots <Q_0, v> (or ||v||^2 when j == 0)
-__global__ __launch_bounds__(COSMO_BS) void k_aa_prep(long long N, const double* __restrict__ g, const double* __restrict__ x, int init,
-                                                      double* __restrict__ f, double* __restrict__ f_last, double* __restrict__ g_last,
-                                                      double* __restrict__ Gj, double* __restrict__ v, const double* __restrict__ Q0, int j,
-                                                      double* __restrict__ p_out) {
-  __shared__ double red[COSMO_BS / 64];
-  double acc = 0.0;
+__global__ __launch_bounds__(COSMO_BS) void k_aa_prep(long long N, const real* __restrict__ g, const real* __restrict__ x, int init,
+                                                      real* __restrict__ f, real* __restrict__ f_last, real* __restrict__ g_last,
+                                                      real* __restrict__ Gj, real* __restrict__ v, const real* __restrict__ Q0, int j,
+                                                      real* __restrict__ p_out) {
+  __shared__ real red[COSMO_BS / 64];
+  real acc = 0.0;
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) {
-    const double gi = g[i];
-    const double fi = x[i] - gi;
+    const real gi = g[i];
+    const real fi = x[i] - gi;
     f[i] = fi;
     if (!init) {
       Gj[i] = gi - g_last[i];
-      const double vi = fi - f_last[i];
+      const real vi = fi - f_last[i];
       v[i] = vi;
       acc += (j == 0) ? vi * vi : Q0[i] * vi;
     }
@@ -84,15 +84,15 @@ __global__ __launch_bounds__(COSMO_BS) void k_aa_prep(long long N, const double*
 }
 
 // Gram-Schmidt step i (< j): r = sum(p_in) ; R[i, j] = r ; v -= r Q_i ; partial <Q_{i+1}, v> (i + 1 < j) or ||v||^2 (i + 1 == j)
-__global__ __launch_bounds__(COSMO_BS) void k_aa_mgs(long long N, int nparts, const double* __restrict__ p_in, const double* __restrict__ Qi,
-                                                     const double* __restrict__ Qnext, double* __restrict__ v, int last, double* __restrict__ Rij,
-                                                     double* __restrict__ p_out) {
-  __shared__ double red[COSMO_BS / 64];
-  const double r = reduce_partials_sum(p_in, nparts, red);
+__global__ __launch_bounds__(COSMO_BS) void k_aa_mgs(long long N, int nparts, const real* __restrict__ p_in, const real* __restrict__ Qi,
+                                                     const real* __restrict__ Qnext, real* __restrict__ v, int last, real* __restrict__ Rij,
+                                                     real* __restrict__ p_out) {
+  __shared__ real red[COSMO_BS / 64];
+  const real r = reduce_partials_sum(p_in, nparts, red);
   if (blockIdx.x == 0 && threadIdx.x == 0) *Rij = r;
-  double acc = 0.0;
+  real acc = 0.0;
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) {
-    const double vi = v[i] - r * Qi[i];
+    const real vi = v[i] - r * Qi[i];
     v[i] = vi;
     acc += last ? vi * vi : Qnext[i] * vi;
   }
@@ -102,24 +102,24 @@ __global__ __launch_bounds__(COSMO_BS) void k_aa_mgs(long long N, int nparts, co
 }
 
 // R[j, j] = ||v|| ; Q_j = v / ||v||
-__global__ __launch_bounds__(COSMO_BS) void k_aa_normalize(long long N, int nparts, const double* __restrict__ p_in, double* __restrict__ v,
-                                                           double* __restrict__ Rjj) {
-  __shared__ double red[COSMO_BS / 64];
-  const double nv = sqrt(reduce_partials_sum(p_in, nparts, red));
+__global__ __launch_bounds__(COSMO_BS) void k_aa_normalize(long long N, int nparts, const real* __restrict__ p_in, real* __restrict__ v,
+                                                           real* __restrict__ Rjj) {
+  __shared__ real red[COSMO_BS / 64];
+  const real nv = sqrt(reduce_partials_sum(p_in, nparts, red));
   if (blockIdx.x == 0 && threadIdx.x == 0) *Rjj = nv;
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) v[i] = v[i] / nv;
 }
 
 // partial Q[:, 0..l)' f and ||f||^2
 template <int L>
-__global__ __launch_bounds__(COSMO_BS) void k_aa_qtf(long long N, int l, const double* __restrict__ Q, const double* __restrict__ f,
-                                                     double* __restrict__ parts) {
-  __shared__ double red[COSMO_BS / 64];
-  double acc[L + 1];
+__global__ __launch_bounds__(COSMO_BS) void k_aa_qtf(long long N, int l, const real* __restrict__ Q, const real* __restrict__ f,
+                                                     real* __restrict__ parts) {
+  __shared__ real red[COSMO_BS / 64];
+  real acc[L + 1];
 #pragma unroll
   for (int k = 0; k <= L; ++k) acc[k] = 0.0;
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) {
-    const double fi = f[i];
+    const real fi = f[i];
 #pragma unroll
     for (int k = 0; k < L; ++k) if (k < l) acc[k] += Q[(size_t)k * N + i] * fi;
     acc[L] += fi * fi;
@@ -128,38 +128,38 @@ __global__ __launch_bounds__(COSMO_BS) void k_aa_qtf(long long N, int l, const d
   for (int k = 0; k <= L; ++k) {
     const int slot = (k == L) ? AA_MAX_MEM : k;
     if (k < l || k == L) {
-      const double s = block_sum(acc[k], red);
+      const real s = block_sum(acc[k], red);
       if (threadIdx.x == 0) parts[(size_t)slot * COSMO_MAX_PARTIALS + blockIdx.x] = s;
     }
   }
 }
 
 // one workgroup: eta = R[0..l, 0..l) \ (Q' f) by back substitution ; success unless singular / non-finite / ||eta|| > eta_max
-__global__ __launch_bounds__(COSMO_BS) void k_aa_solve(int l, int nparts, const double* __restrict__ parts, double eta_max, AaFlags* __restrict__ F) {
-  __shared__ double red[COSMO_BS / 64];
-  __shared__ double rhs[AA_MAX_MEM];
+__global__ __launch_bounds__(COSMO_BS) void k_aa_solve(int l, int nparts, const real* __restrict__ parts, real eta_max, AaFlags* __restrict__ F) {
+  __shared__ real red[COSMO_BS / 64];
+  __shared__ real rhs[AA_MAX_MEM];
   for (int k = 0; k < l; ++k) {
-    const double s = reduce_partials_sum(parts + (size_t)k * COSMO_MAX_PARTIALS, nparts, red);
+    const real s = reduce_partials_sum(parts + (size_t)k * COSMO_MAX_PARTIALS, nparts, red);
     if (threadIdx.x == 0) rhs[k] = s;
     __syncthreads();
   }
-  const double ff = reduce_partials_sum(parts + (size_t)AA_MAX_MEM * COSMO_MAX_PARTIALS, nparts, red);
+  const real ff = reduce_partials_sum(parts + (size_t)AA_MAX_MEM * COSMO_MAX_PARTIALS, nparts, red);
   if (threadIdx.x == 0) {
     F->nrm_f = sqrt(ff);
     bool ok = true;
     for (int c = 0; c < l && ok; ++c)
-      for (int r = 0; r <= c; ++r) { const double x = F->R[c * AA_MAX_MEM + r]; if (!(fabs(x) <= 1.79e308)) ok = false; }
-    for (int k = 0; k < l; ++k) if (F->R[k * AA_MAX_MEM + k] == 0.0) ok = false;
+      for (int r = 0; r <= c; ++r) { const real x = F->R[c * AA_MAX_MEM + r]; if (!(fabs(x) <= REAL_MAX)) ok = false; }
+    for (int k = 0; k < l; ++k) if (F->R[k * AA_MAX_MEM + k] == R(0.0)) ok = false;
     if (!ok) { F->success = 0; F->fail_singular += 1; return; }
-    double nrm2 = 0.0;
+    real nrm2 = 0.0;
     for (int i = l - 1; i >= 0; --i) {
-      double s = rhs[i];
+      real s = rhs[i];
       for (int k = i + 1; k < l; ++k) s -= F->R[k * AA_MAX_MEM + i] * F->eta[k];
-      const double e = s / F->R[i * AA_MAX_MEM + i];
+      const real e = s / F->R[i * AA_MAX_MEM + i];
       F->eta[i] = e;
       nrm2 += e * e;
     }
-    const double en = sqrt(nrm2);
+    const real en = sqrt(nrm2);
     F->eta_norm = en;
     if (!(en <= eta_max)) { F->success = 0; F->fail_eta += 1; return; }     // also catches NaN
     F->success = 1;
@@ -168,14 +168,14 @@ __global__ __launch_bounds__(COSMO_BS) void k_aa_solve(int l, int nparts, const 
 
 // w -= G[:, 0..l) eta  when the least-squares step succeeded
 template <int L>
-__global__ __launch_bounds__(COSMO_BS) void k_aa_apply(long long N, int l, const double* __restrict__ G, const AaFlags* __restrict__ F,
-                                                       double* __restrict__ w) {
+__global__ __launch_bounds__(COSMO_BS) void k_aa_apply(long long N, int l, const real* __restrict__ G, const AaFlags* __restrict__ F,
+                                                       real* __restrict__ w) {
   if (!F->success) return;
-  double e[L];
+  real e[L];
 #pragma unroll
   for (int k = 0; k < L; ++k) e[k] = (k < l) ? F->eta[k] : 0.0;
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) {
-    double s = 0.0;
+    real s = 0.0;
 #pragma unroll
     for (int k = 0; k < L; ++k) if (k < l) s += G[(size_t)k * N + i] * e[k];
     w[i] = w[i] - s;
@@ -183,29 +183,29 @@ __global__ __launch_bounds__(COSMO_BS) void k_aa_apply(long long N, int l, const
 }
 
 // f = w_prev - w and its partial squared norm (compute_accelerated_res_norm!, accelerator_interface.jl:123-126)
-__global__ __launch_bounds__(COSMO_BS) void k_aa_resnorm(long long N, const double* __restrict__ w, const double* __restrict__ w_prev,
-                                                         double* __restrict__ f, double* __restrict__ p_out) {
-  __shared__ double red[COSMO_BS / 64];
-  double acc = 0.0;
+__global__ __launch_bounds__(COSMO_BS) void k_aa_resnorm(long long N, const real* __restrict__ w, const real* __restrict__ w_prev,
+                                                         real* __restrict__ f, real* __restrict__ p_out) {
+  __shared__ real red[COSMO_BS / 64];
+  real acc = 0.0;
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) {
-    const double d = w_prev[i] - w[i];
+    const real d = w_prev[i] - w[i];
     f[i] = d;
     acc += d * d;
   }
   acc = block_sum(acc, red);
   if (threadIdx.x == 0) p_out[blockIdx.x] = acc;
 }
-__global__ __launch_bounds__(COSMO_BS) void k_aa_guard(int nparts, const double* __restrict__ p_in, double tau, AaFlags* __restrict__ F) {
-  __shared__ double red[COSMO_BS / 64];
-  const double na = sqrt(reduce_partials_sum(p_in, nparts, red));
+__global__ __launch_bounds__(COSMO_BS) void k_aa_guard(int nparts, const real* __restrict__ p_in, real tau, AaFlags* __restrict__ F) {
+  __shared__ real red[COSMO_BS / 64];
+  const real na = sqrt(reduce_partials_sum(p_in, nparts, red));
   if (threadIdx.x == 0) {
     F->nrm_f_acc = na;
     F->declined = (na > F->nrm_f * tau) ? 1 : 0;
   }
 }
 // reset_accelerated_vector! (accelerator_interface.jl:129-134)
-__global__ __launch_bounds__(COSMO_BS) void k_aa_reset(long long N, const double* __restrict__ g_last, double* __restrict__ w, double* __restrict__ w_prev) {
-  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) { const double g = g_last[i]; w[i] = g; w_prev[i] = g; }
+__global__ __launch_bounds__(COSMO_BS) void k_aa_reset(long long N, const real* __restrict__ g_last, real* __restrict__ w, real* __restrict__ w_prev) {
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) { const real g = g_last[i]; w[i] = g; w_prev[i] = g; }
 }
 
 inline AaState* aa_of(cosmo_hip_handle* h) { return static_cast<AaState*>(h->accel); }
@@ -215,7 +215,7 @@ inline AaState* aa_of(cosmo_hip_handle* h) { return static_cast<AaState*>(h->acc
 void aa_free(cosmo_hip_handle* h) {
   AaState* S = aa_of(h);
   if (!S) return;
-  for (double* p : {S->G, S->Q, S->f, S->f_last, S->g_last, S->parts}) if (p) (void)hipFree(p);
+  for (real* p : {S->G, S->Q, S->f, S->f_last, S->g_last, S->parts}) if (p) (void)hipFree(p);
   if (S->flags) (void)hipFree(S->flags);
   if (S->flags_host) (void)hipHostFree(S->flags_host);
   delete S;
@@ -227,12 +227,12 @@ bool aa_enabled(const cosmo_hip_handle* h) { return h->accel != nullptr; }
 int32_t aa_restart(cosmo_hip_handle* h) {      // CA.restart! -> empty_history!
   AaState* S = aa_of(h);
   if (!S) return COSMO_HIP_OK;
-  const size_t slab = sizeof(double) * (size_t)S->N * (size_t)S->mem;
+  const size_t slab = sizeof(real) * (size_t)S->N * (size_t)S->mem;
   HIPCHK(h, hipMemsetAsync(S->G, 0, slab, h->stream));
   HIPCHK(h, hipMemsetAsync(S->Q, 0, slab, h->stream));
-  HIPCHK(h, hipMemsetAsync(S->f, 0, sizeof(double) * (size_t)S->N, h->stream));
-  HIPCHK(h, hipMemsetAsync(S->f_last, 0, sizeof(double) * (size_t)S->N, h->stream));
-  HIPCHK(h, hipMemsetAsync(S->g_last, 0, sizeof(double) * (size_t)S->N, h->stream));
+  HIPCHK(h, hipMemsetAsync(S->f, 0, sizeof(real) * (size_t)S->N, h->stream));
+  HIPCHK(h, hipMemsetAsync(S->f_last, 0, sizeof(real) * (size_t)S->N, h->stream));
+  HIPCHK(h, hipMemsetAsync(S->g_last, 0, sizeof(real) * (size_t)S->N, h->stream));
   HIPCHK(h, hipMemsetAsync(S->flags, 0, sizeof(AaFlags), h->stream));
   S->iter = 0;
   S->init_phase = true;
@@ -261,12 +261,12 @@ extern "C" int32_t cosmo_hip_set_accelerator(cosmo_hip_handle* h, const cosmo_hi
   S->N = h->n + h->m;
   S->mem = (int)std::min<long long>(p->mem, std::max<long long>(S->N, 1));     // mem = min(mem, dim)
   const size_t N = (size_t)std::max<long long>(S->N, 1);
-  HIPCHK(h, hipMalloc((void**)&S->G, sizeof(double) * N * S->mem));
-  HIPCHK(h, hipMalloc((void**)&S->Q, sizeof(double) * N * S->mem));
-  HIPCHK(h, hipMalloc((void**)&S->f, sizeof(double) * N));
-  HIPCHK(h, hipMalloc((void**)&S->f_last, sizeof(double) * N));
-  HIPCHK(h, hipMalloc((void**)&S->g_last, sizeof(double) * N));
-  HIPCHK(h, hipMalloc((void**)&S->parts, sizeof(double) * (AA_MAX_MEM + 1) * COSMO_MAX_PARTIALS));
+  HIPCHK(h, hipMalloc((void**)&S->G, sizeof(real) * N * S->mem));
+  HIPCHK(h, hipMalloc((void**)&S->Q, sizeof(real) * N * S->mem));
+  HIPCHK(h, hipMalloc((void**)&S->f, sizeof(real) * N));
+  HIPCHK(h, hipMalloc((void**)&S->f_last, sizeof(real) * N));
+  HIPCHK(h, hipMalloc((void**)&S->g_last, sizeof(real) * N));
+  HIPCHK(h, hipMalloc((void**)&S->parts, sizeof(real) * (AA_MAX_MEM + 1) * COSMO_MAX_PARTIALS));
   HIPCHK(h, hipMalloc((void**)&S->flags, sizeof(AaFlags)));
   HIPCHK(h, hipHostMalloc((void**)&S->flags_host, sizeof(AaFlags)));
   memset(S->flags_host, 0, sizeof(AaFlags));
@@ -305,18 +305,18 @@ int32_t aa_enqueue_pre(cosmo_hip_handle* h, long long it, bool* attempted) {
   } else {
     int j = S->iter % S->mem;
     if (j == 0 && S->iter != 0) {       // RestartedMemory: the memory is full -> start over
-      const size_t slab = sizeof(double) * (size_t)N * (size_t)S->mem;
+      const size_t slab = sizeof(real) * (size_t)N * (size_t)S->mem;
       HIPCHK(h, hipMemsetAsync(S->G, 0, slab, st));
       HIPCHK(h, hipMemsetAsync(S->Q, 0, slab, st));
       HIPCHK(h, hipMemsetAsync(S->flags, 0, offsetof(AaFlags, nrm_f), st));
-      HIPCHK(h, hipMemsetAsync(reinterpret_cast<char*>(S->flags) + offsetof(AaFlags, R), 0, sizeof(double) * AA_MAX_MEM * AA_MAX_MEM, st));
+      HIPCHK(h, hipMemsetAsync(reinterpret_cast<char*>(S->flags) + offsetof(AaFlags, R), 0, sizeof(real) * AA_MAX_MEM * AA_MAX_MEM, st));
       S->iter = 0;
       S->num_restarts += 1;
       j = 0;
     }
-    double* Gj = S->G + (size_t)j * N;
-    double* v = S->Q + (size_t)j * N;
-    double* Rcol = reinterpret_cast<double*>(reinterpret_cast<char*>(S->flags) + offsetof(AaFlags, R)) + (size_t)j * AA_MAX_MEM;
+    real* Gj = S->G + (size_t)j * N;
+    real* v = S->Q + (size_t)j * N;
+    real* Rcol = reinterpret_cast<real*>(reinterpret_cast<char*>(S->flags) + offsetof(AaFlags, R)) + (size_t)j * AA_MAX_MEM;
     hipLaunchKernelGGL(k_aa_prep, G, B, 0, st, N, h->w, h->w_prev, 0, S->f, S->f_last, S->g_last, Gj, v, S->Q, j, AA_PARTS(S, 0));
     for (int i = 0; i < j; ++i) {
       const int last = (i + 1 == j);
@@ -373,10 +373,10 @@ int32_t aa_enqueue_reset(cosmo_hip_handle* h) {
 bool aa_safeguarded(const cosmo_hip_handle* h) { const AaState* S = static_cast<const AaState*>(h->accel); return S && S->prm.safeguard != 0; }
 // check_activation!(ws, ::AccuracyActivation, r::ResultInfo) (accelerator_interface.jl:38-46), called from has_converged at
 // every termination check
-void aa_check_accuracy_activation(cosmo_hip_handle* h, double r_prim, double r_dual, double max_norm_prim, double max_norm_dual) {
+void aa_check_accuracy_activation(cosmo_hip_handle* h, real r_prim, real r_dual, real max_norm_prim, real max_norm_dual) {
   AaState* S = aa_of(h);
   if (!S || S->active || !(S->prm.start_accuracy >= 0.0)) return;
-  const double tol = S->prm.start_accuracy;
+  const real tol = S->prm.start_accuracy;
   if (r_prim < tol + tol * max_norm_prim && r_dual < tol + tol * max_norm_dual) S->active = true;
 }
 bool aa_active(const cosmo_hip_handle* h) { const AaState* S = static_cast<const AaState*>(h->accel); return S && S->active; }

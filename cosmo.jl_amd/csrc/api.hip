@@ -10,14 +10,14 @@
 #include "device_utils.h"
 
 // launchers defined in kernels.hip
-int32_t launch_project_simple_inplace(cosmo_hip_handle* h, double* s);
+int32_t launch_project_simple_inplace(cosmo_hip_handle* h, real* s);
 int32_t launch_z(cosmo_hip_handle* h, int guard);
-int32_t launch_soc(cosmo_hip_handle* h, double* s, int guard);
-int32_t launch_set_w(cosmo_hip_handle* h, const double* x0, const double* s0, const double* mu0);
+int32_t launch_soc(cosmo_hip_handle* h, real* s, int guard);
+int32_t launch_set_w(cosmo_hip_handle* h, const real* x0, const real* s0, const real* mu0);
 int32_t launch_recover_mu(cosmo_hip_handle* h);
-int32_t launch_rho_from_classes(cosmo_hip_handle* h, double rho0);
+int32_t launch_rho_from_classes(cosmo_hip_handle* h, real rho0);
 int32_t enqueue_cg_iterations(cosmo_hip_handle* h, int guard, int k_begin, int count);
-int32_t enqueue_cg_start(cosmo_hip_handle* h, int guard, double tol_k);
+int32_t enqueue_cg_start(cosmo_hip_handle* h, int guard, real tol_k);
 int32_t enqueue_rhs(cosmo_hip_handle* h, int guard);
 int32_t enqueue_y2_only(cosmo_hip_handle* h);
 int32_t enqueue_tail(cosmo_hip_handle* h, int loop_mode);
@@ -163,7 +163,7 @@ int32_t upload_csr(cosmo_hip_handle* h, const HostCsr& M, CsrDev& D, int split_c
 
 // Julia CSC (1-based Int64) of an (nr x nc) matrix -> CSR of the TRANSPOSE (free: same arrays) and CSR of the matrix.
 static int32_t csc_to_csr_pair(cosmo_hip_handle* h, int64_t nr, int64_t nc, const int64_t* colptr, const int64_t* rowval,
-                               const double* nzval, HostCsr& Mt, HostCsr& M) {
+                               const real* nzval, HostCsr& Mt, HostCsr& M) {
   const int64_t nnz = colptr[nc] - 1;
   if (colptr[0] != 1) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "colptr must be 1-based (colptr[0] == %lld)", (long long)colptr[0]);
   if (nnz < 0 || nnz >= (int64_t)2147483647) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "nnz out of int32 range");
@@ -207,7 +207,7 @@ extern "C" void cosmo_hip_default_params(cosmo_hip_params* p) {
   p->max_iter = 5000; p->adaptive_rho_max_adaptions = INT64_MAX; p->kkt_kind = COSMO_HIP_KKT_CG;
   p->check_termination = 25; p->check_infeasibility = 40; p->adaptive_rho = 1; p->adaptive_rho_interval = 40;
   p->unscale_residuals = 1;
-  p->obj_true = NAN; p->obj_true_tol = 1e-3;
+  p->obj_true = (double)NAN; p->obj_true_tol = 1e-3;
 }
 
 extern "C" int32_t cosmo_hip_create(cosmo_hip_handle** out, int32_t device_id) {
@@ -221,11 +221,11 @@ extern "C" int32_t cosmo_hip_create(cosmo_hip_handle** out, int32_t device_id) {
   cosmo_hip_default_params(&h->prm);
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { delete h; return COSMO_HIP_ERR_HIP; }
   if (hipMalloc((void**)&h->ctl, sizeof(Ctl)) != hipSuccess || hipHostMalloc((void**)&h->ctl_host, sizeof(Ctl)) != hipSuccess ||
-      hipMalloc((void**)&h->partials, sizeof(double) * COSMO_NSLOTS_TOTAL * COSMO_MAX_PARTIALS) != hipSuccess) {
+      hipMalloc((void**)&h->partials, sizeof(real) * COSMO_NSLOTS_TOTAL * COSMO_MAX_PARTIALS) != hipSuccess) {
     delete h; return COSMO_HIP_ERR_HIP;
   }
   (void)hipMemset(h->ctl, 0, sizeof(Ctl));
-  (void)hipMemset(h->partials, 0, sizeof(double) * COSMO_NSLOTS_TOTAL * COSMO_MAX_PARTIALS);
+  (void)hipMemset(h->partials, 0, sizeof(real) * COSMO_NSLOTS_TOTAL * COSMO_MAX_PARTIALS);
   memset(h->ctl_host, 0, sizeof(Ctl));
   (void)hipEventCreate(&h->ev_proj0);
   (void)hipEventCreate(&h->ev_proj1);
@@ -282,8 +282,8 @@ extern "C" const char* cosmo_hip_last_error(const cosmo_hip_handle* h) { return 
 
 // ---------------------------------------------------------------------------------------------------------------------
 extern "C" int32_t cosmo_hip_set_problem(cosmo_hip_handle* h, int64_t n, int64_t m, const int64_t* P_colptr,
-                                         const int64_t* P_rowval, const double* P_nzval, const int64_t* A_colptr,
-                                         const int64_t* A_rowval, const double* A_nzval, const double* q, const double* b) {
+                                         const int64_t* P_rowval, const real* P_nzval, const int64_t* A_colptr,
+                                         const int64_t* A_rowval, const real* A_nzval, const real* q, const real* b) {
   ENTER(h);
   if (n < 0 || m < 0 || n + m >= 2147483647LL) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "n, m out of int32 range");
   if (!P_colptr || !A_colptr || (n > 0 && !q) || (m > 0 && !b)) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "null pointer");
@@ -317,7 +317,7 @@ extern "C" int32_t cosmo_hip_set_problem(cosmo_hip_handle* h, int64_t n, int64_t
   const size_t N = (size_t)(n + m);
   CHK(dalloc(h, &h->q, (size_t)n)); CHK(dalloc(h, &h->b, (size_t)m)); CHK(dalloc(h, &h->rho, (size_t)m));
   CHK(dalloc(h, &h->Dinv, (size_t)n)); CHK(dalloc(h, &h->Einv, (size_t)m)); CHK(dalloc(h, &h->Dscale, (size_t)n)); CHK(dalloc(h, &h->Escale, (size_t)m));
-  { std::vector<double> ones((size_t)std::max<int64_t>(n, m), 1.0);
+  { std::vector<real> ones((size_t)std::max<int64_t>(n, m), 1.0);
     CHK(h2d(h, h->Dinv, ones.data(), (size_t)n)); CHK(h2d(h, h->Einv, ones.data(), (size_t)m));
     CHK(h2d(h, h->Dscale, ones.data(), (size_t)n)); CHK(h2d(h, h->Escale, ones.data(), (size_t)m)); }
   CHK(dalloc(h, &h->w, N)); CHK(dalloc(h, &h->w_prev, N)); CHK(dalloc(h, &h->s, (size_t)m)); CHK(dalloc(h, &h->mu, (size_t)m));
@@ -335,10 +335,10 @@ extern "C" int32_t cosmo_hip_set_problem(cosmo_hip_handle* h, int64_t n, int64_t
 }
 
 // classify_constraints! (setup.jl:75-85, convexset.jl:62-69, 831-842) + apply_constraint_rho_scaling! classes
-static int32_t classify_rows(cosmo_hip_handle* h, const std::vector<double>& bhost) {
+static int32_t classify_rows(cosmo_hip_handle* h, const std::vector<real>& bhost) {
   const ConeTable& C = h->cones;
   h->rho_cls_host.assign((size_t)h->m, 0);
-  const double big = h->prm.cosmo_infty_min_scaling;
+  const real big = h->prm.cosmo_infty_min_scaling;
   size_t boxp = 0;
   for (size_t k = 0; k < C.type.size(); ++k) {
     const int64_t o = C.off[k], d = C.dim[k];
@@ -348,10 +348,10 @@ static int32_t classify_rows(cosmo_hip_handle* h, const std::vector<double>& bho
       for (int64_t i = 0; i < d; ++i) if (bhost[o + i] > big) h->rho_cls_host[o + i] = 2;
     } else if (C.type[k] == COSMO_HIP_BOX) {
       for (int64_t i = 0; i < d; ++i) {
-        const double l = C.box_l[boxp + i], u = C.box_u[boxp + i];
+        const real l = C.box_l[boxp + i], u = C.box_u[boxp + i];
         int c = 0;
         if (l < -big && u > big) c = 2;
-        else if ((u - l) < h->prm.rho_tol) c = 1;
+        else if ((u - l) < (real)h->prm.rho_tol) c = 1;
         h->rho_cls_host[o + i] = c;
       }
       boxp += (size_t)d;
@@ -369,7 +369,7 @@ int32_t reclassify_after_scaling(cosmo_hip_handle* h) {
     CHK(d2h(h, C.box_l.data(), h->box_l, (size_t)C.nbox_rows));
     CHK(d2h(h, C.box_u.data(), h->box_u, (size_t)C.nbox_rows));
   }
-  std::vector<double> bhost((size_t)h->m);
+  std::vector<real> bhost((size_t)h->m);
   CHK(d2h(h, bhost.data(), h->b, (size_t)h->m));
   return classify_rows(h, bhost);
 }
@@ -392,12 +392,12 @@ int32_t rebuild_cone_plans(cosmo_hip_handle* h) {
 }
 
 extern "C" int32_t cosmo_hip_set_cones(cosmo_hip_handle* h, int64_t ncones, const int32_t* type, const int64_t* dim,
-                                       const double* box_l, const double* box_u) {
+                                       const real* box_l, const real* box_u) {
   return cosmo_hip_set_cones_ex(h, ncones, type, dim, box_l, box_u, nullptr);
 }
 
 extern "C" int32_t cosmo_hip_set_cones_ex(cosmo_hip_handle* h, int64_t ncones, const int32_t* type, const int64_t* dim,
-                                          const double* box_l, const double* box_u, const double* cone_param) {
+                                          const real* box_l, const real* box_u, const real* cone_param) {
   ENTER(h);
   if (!h->have_problem) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_problem must be called before set_cones");
   if (ncones < 0 || (ncones > 0 && (!type || !dim))) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "bad cone table");
@@ -411,11 +411,11 @@ extern "C" int32_t cosmo_hip_set_cones_ex(cosmo_hip_handle* h, int64_t ncones, c
       return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "cone type %d is outside the hot-path scope", (int)type[k]);
     if (type[k] >= COSMO_HIP_EXP && type[k] <= COSMO_HIP_DUAL_POW && dim[k] != 3) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "exponential / power cones have dimension 3");
     if (type[k] == COSMO_HIP_POW || type[k] == COSMO_HIP_DUAL_POW) {
-      if (!cone_param || !(cone_param[k] > 0.0 && cone_param[k] < 1.0))
+      if (!cone_param || !(cone_param[k] > R(0.0) && cone_param[k] < R(1.0)))
         return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "The exponent alpha of the power cone has to be in (0, 1).");
     }
     if (type[k] == COSMO_HIP_PSD_SQUARE || type[k] == COSMO_HIP_PSD_TRIANGLE_COMPLEX) {
-      const int64_t r = (int64_t)llround(sqrt((double)dim[k]));
+      const int64_t r = (int64_t)llround(sqrt((real)dim[k]));
       if (r * r != dim[k]) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "PsdCone / complex PsdConeTriangle dimension must be a square");
     }
     C.type.push_back(type[k]); C.dim.push_back(dim[k]); C.off.push_back(off);
@@ -457,7 +457,7 @@ extern "C" int32_t cosmo_hip_set_cones_ex(cosmo_hip_handle* h, int64_t ncones, c
   h->cone_lo = 0; h->cone_hi = -1;
   CHK(rebuild_cone_plans(h));
   CHK(custom_plan_create(h));       // callbacks are (re)installed by cosmo_hip_set_custom_cone after every set_cones
-  std::vector<double> bhost((size_t)h->m);
+  std::vector<real> bhost((size_t)h->m);
   CHK(d2h(h, bhost.data(), h->b, (size_t)h->m));
   CHK(classify_rows(h, bhost));
   h->have_cones = true;
@@ -488,7 +488,7 @@ int32_t build_op_split(cosmo_hip_handle* h) {
   const long long n = h->n, m = h->m, nnzA = h->A.nnz, nnzP = h->P.nnz;
   if (m == 0 || nnzA == 0) return COSMO_HIP_OK;
   std::vector<int> arp((size_t)m + 1), acol((size_t)nnzA), prp((size_t)n + 1), pcol((size_t)std::max<long long>(nnzP, 1));
-  std::vector<double> aval((size_t)nnzA), pval((size_t)std::max<long long>(nnzP, 1));
+  std::vector<real> aval((size_t)nnzA), pval((size_t)std::max<long long>(nnzP, 1));
   CHK(d2h(h, arp.data(), h->A.rowptr, (size_t)m + 1)); CHK(d2h(h, acol.data(), h->A.col, (size_t)nnzA)); CHK(d2h(h, aval.data(), h->A.val, (size_t)nnzA));
   CHK(d2h(h, prp.data(), h->P.rowptr, (size_t)n + 1));
   if (nnzP) { CHK(d2h(h, pcol.data(), h->P.col, (size_t)nnzP)); CHK(d2h(h, pval.data(), h->P.val, (size_t)nnzP)); }
@@ -514,7 +514,7 @@ int32_t build_op_split(cosmo_hip_handle* h) {
   const int mm = Am.nrows;
   // singles grouped by column, rows ascending (fixed summation order of the diagonal)
   std::vector<int> sc_ptr((size_t)n + 1, 0), sc_row((size_t)nsingle);
-  std::vector<double> sc_a2((size_t)nsingle);
+  std::vector<real> sc_a2((size_t)nsingle);
   for (long long j = 0; j < n; ++j) sc_ptr[j + 1] = sc_ptr[j] + sc_cnt[j + 1];
   { std::vector<int> pos(sc_ptr.begin(), sc_ptr.end() - 1);
     for (long long i = 0; i < m; ++i) if (arp[i + 1] - arp[i] == 1) { const int k = arp[i], j = acol[k], p = pos[j]++; sc_row[p] = (int)i; sc_a2[p] = aval[k] * aval[k]; } }
@@ -548,7 +548,7 @@ int32_t build_op_split(cosmo_hip_handle* h) {
   return refresh_op_split(h);
 }
 
-extern "C" int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_params* p, const double* rho_vec) {
+extern "C" int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_params* p, const real* rho_vec) {
   ENTER(h);
   if (!p) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "null params");
   if (!h->have_cones) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_cones must be called before set_params");
@@ -561,7 +561,7 @@ extern "C" int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_par
   h->cg_sr = (p->kkt_kind == COSMO_HIP_KKT_CG_SR);
   if (h->cg_sr) h->prm.kkt_kind = COSMO_HIP_KKT_CG;      // the same reduced operator, split, budget and tail; only the Krylov recurrence differs
   if (reclass) {
-    std::vector<double> bhost((size_t)h->m);
+    std::vector<real> bhost((size_t)h->m);
     CHK(d2h(h, bhost.data(), h->b, (size_t)h->m));
     CHK(classify_rows(h, bhost));
   }
@@ -579,8 +579,8 @@ extern "C" int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_par
   if (h->prm.kkt_kind != COSMO_HIP_KKT_CG) CHK(minres_alloc(h));
   CHK(sr_alloc(h));
   // the Krylov warm start (previous_solution) starts at zero (kktsolver_indirect.jl:32)
-  HIPCHK(h, hipMemsetAsync(h->x_tl, 0, sizeof(double) * (size_t)std::max<long long>(h->n, 1), h->stream));
-  HIPCHK(h, hipMemsetAsync(h->nu, 0, sizeof(double) * (size_t)std::max<long long>(h->m, 1), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->x_tl, 0, sizeof(real) * (size_t)std::max<long long>(h->n, 1), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->nu, 0, sizeof(real) * (size_t)std::max<long long>(h->m, 1), h->stream));
   h->have_params = true;
   // fused direction + A product (k_cg_dirA): one launch less per Krylov iteration, bit-identical; COSMO_HIP_CG_FUSE_DIR=0 disables it
   // (and with it the assembled operator of cg_fold.hip, which gathers the same {r, u} records)
@@ -592,20 +592,20 @@ extern "C" int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_par
   return pcg_setup(h);        // single-launch CG (opt-in)
 }
 
-extern "C" int32_t cosmo_hip_update_rho(cosmo_hip_handle* h, const double* rho_vec) {
+extern "C" int32_t cosmo_hip_update_rho(cosmo_hip_handle* h, const real* rho_vec) {
   ENTER(h);
   if (!h->have_params || !rho_vec) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "update_rho: not set up");
   CHK(h2d(h, h->rho, rho_vec, (size_t)h->m));
   return refresh_op_split(h);
 }
 
-static int32_t upload_or_ones(cosmo_hip_handle* h, double* dst, const double* src, size_t n) {
+static int32_t upload_or_ones(cosmo_hip_handle* h, real* dst, const real* src, size_t n) {
   if (src) return h2d(h, dst, src, n);
-  std::vector<double> ones(n, 1.0);
+  std::vector<real> ones(n, 1.0);
   return h2d(h, dst, ones.data(), n);
 }
 
-extern "C" int32_t cosmo_hip_set_scaling_full(cosmo_hip_handle* h, const double* D, const double* Dinv, const double* E, const double* Einv,
+extern "C" int32_t cosmo_hip_set_scaling_full(cosmo_hip_handle* h, const real* D, const real* Dinv, const real* E, const real* Einv,
                                               double c, double cinv) {
   ENTER(h);
   if (!h->have_problem) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_problem first");
@@ -617,24 +617,24 @@ extern "C" int32_t cosmo_hip_set_scaling_full(cosmo_hip_handle* h, const double*
   return COSMO_HIP_OK;
 }
 
-extern "C" int32_t cosmo_hip_set_scaling(cosmo_hip_handle* h, const double* Dinv, const double* Einv, double cinv) {
+extern "C" int32_t cosmo_hip_set_scaling(cosmo_hip_handle* h, const real* Dinv, const real* Einv, double cinv) {
   ENTER(h);
   if (!h->have_problem) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_problem first");
   // D and E (needed by the infeasibility tests only) are recovered as reciprocals
-  std::vector<double> D, E;
-  if (Dinv) { D.resize((size_t)h->n); for (long long i = 0; i < h->n; ++i) D[i] = 1.0 / Dinv[i]; }
-  if (Einv) { E.resize((size_t)h->m); for (long long i = 0; i < h->m; ++i) E[i] = 1.0 / Einv[i]; }
+  std::vector<real> D, E;
+  if (Dinv) { D.resize((size_t)h->n); for (long long i = 0; i < h->n; ++i) D[i] = R(1.0) / Dinv[i]; }
+  if (Einv) { E.resize((size_t)h->m); for (long long i = 0; i < h->m; ++i) E[i] = R(1.0) / Einv[i]; }
   return cosmo_hip_set_scaling_full(h, Dinv ? D.data() : nullptr, Dinv, Einv ? E.data() : nullptr, Einv, 1.0 / cinv, cinv);
 }
 
-extern "C" int32_t cosmo_hip_update_qb(cosmo_hip_handle* h, const double* q, const double* b) {
+extern "C" int32_t cosmo_hip_update_qb(cosmo_hip_handle* h, const real* q, const real* b) {
   ENTER(h);
   if (!h->have_problem) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_problem first");
   if (q) CHK(h2d(h, h->q, q, (size_t)h->n));
   if (b) {
     CHK(h2d(h, h->b, b, (size_t)h->m));
     if (h->have_cones) {  // setup! re-classifies on every optimize! (setup.jl:36-37)
-      std::vector<double> bhost(b, b + h->m);
+      std::vector<real> bhost(b, b + h->m);
       CHK(classify_rows(h, bhost));
     }
   }
@@ -646,7 +646,7 @@ extern "C" int32_t cosmo_hip_get_rho_classes(cosmo_hip_handle* h, int32_t* cls) 
   if (!h->have_cones || !cls) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "get_rho_classes: not set up");
   return d2h(h, cls, h->rho_cls, (size_t)h->m);
 }
-extern "C" int32_t cosmo_hip_get_rho_vec(cosmo_hip_handle* h, double* rho_vec) {
+extern "C" int32_t cosmo_hip_get_rho_vec(cosmo_hip_handle* h, real* rho_vec) {
   ENTER(h);
   if (!h->have_params || !rho_vec) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "get_rho_vec: not set up");
   return d2h(h, rho_vec, h->rho, (size_t)h->m);
@@ -661,14 +661,14 @@ int32_t sync_ctl(cosmo_hip_handle* h) {
   return COSMO_HIP_OK;
 }
 
-extern "C" int32_t cosmo_hip_spmv(cosmo_hip_handle* h, int32_t which, double* y, const double* x) {
+extern "C" int32_t cosmo_hip_spmv(cosmo_hip_handle* h, int32_t which, real* y, const real* x) {
   ENTER(h);
   if (!h->have_problem || !x || !y) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "spmv: not set up");
   const CsrDev* M = which == COSMO_HIP_MAT_A ? &h->A : which == COSMO_HIP_MAT_AT ? &h->AT : which == COSMO_HIP_MAT_P ? &h->P : nullptr;
   if (!M) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "spmv: bad matrix id");
   // io holds n+m doubles: input first, output after it
-  double* dx = h->io;
-  double* dy = h->io + M->ncols;
+  real* dx = h->io;
+  real* dy = h->io + M->ncols;
   if ((long long)M->ncols + M->nrows > 2 * (h->n + h->m)) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "spmv: staging too small");
   CHK(h2d(h, dx, x, (size_t)M->ncols));
   CHK(launch_spmv_plain(h, *M, dx, dy));
@@ -677,7 +677,7 @@ extern "C" int32_t cosmo_hip_spmv(cosmo_hip_handle* h, int32_t which, double* y,
   return COSMO_HIP_OK;
 }
 
-extern "C" int32_t cosmo_hip_project(cosmo_hip_handle* h, double* s, int64_t* psd_rank_out, int32_t* soc_branch_out) {
+extern "C" int32_t cosmo_hip_project(cosmo_hip_handle* h, real* s, int64_t* psd_rank_out, int32_t* soc_branch_out) {
   ENTER(h);
   if (!h->have_cones || (!s && h->m > 0)) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "project: not set up");
   CHK(h2d(h, h->io, s, (size_t)h->m));
@@ -704,14 +704,14 @@ extern "C" int32_t cosmo_hip_project(cosmo_hip_handle* h, double* s, int64_t* ps
     // 1x1 PSD cones are handled by the simple kernel
     for (size_t k = 0; k < nc; ++k)
       if ((h->cones.type[k] == COSMO_HIP_PSD_SQUARE || h->cones.type[k] == COSMO_HIP_PSD_TRIANGLE) && h->cones.dim[k] == 1)
-        psd_rank_out[k] = s[h->cones.off[k]] > 0.0 ? 1 : 0;
+        psd_rank_out[k] = s[h->cones.off[k]] > R(0.0) ? 1 : 0;
   }
   return COSMO_HIP_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-static double tol_for_solve(const cosmo_hip_handle* h, long long k) {
-  return h->prm.tol_constant / pow((double)k, h->prm.tol_exponent);  // get_tolerance, kktsolver_indirect.jl:168-170
+static real tol_for_solve(const cosmo_hip_handle* h, long long k) {
+  return h->prm.tol_constant / pow((real)k, h->prm.tol_exponent);  // get_tolerance, kktsolver_indirect.jl:168-170
 }
 
 static void adapt_budget(cosmo_hip_handle* h) {
@@ -738,7 +738,7 @@ static int32_t maybe_infeas_check(cosmo_hip_handle* h, long long it) {
   return COSMO_HIP_OK;
 }
 
-extern "C" int32_t cosmo_hip_kkt_solve(cosmo_hip_handle* h, double* lhs, const double* rhs, int64_t* kkt_iters_out) {
+extern "C" int32_t cosmo_hip_kkt_solve(cosmo_hip_handle* h, real* lhs, const real* rhs, int64_t* kkt_iters_out) {
   ENTER(h);
   if (!h->have_params || !lhs || !rhs) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "kkt_solve: not set up");
   CHK(h2d(h, h->ls_x, rhs, (size_t)h->n));
@@ -788,17 +788,17 @@ extern "C" int32_t cosmo_hip_kkt_solve(cosmo_hip_handle* h, double* lhs, const d
   return COSMO_HIP_OK;
 }
 
-extern "C" int32_t cosmo_hip_set_iterates(cosmo_hip_handle* h, const double* x0, const double* s0, const double* mu0) {
+extern "C" int32_t cosmo_hip_set_iterates(cosmo_hip_handle* h, const real* x0, const real* s0, const real* mu0) {
   ENTER(h);
   if (!h->have_params) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_iterates: set_params first");
   const long long n = h->n, m = h->m;
   // stage the three vectors in scratch buffers that the init step overwrites anyway
-  const double *dx = nullptr, *ds = nullptr, *dm = nullptr;
+  const real *dx = nullptr, *ds = nullptr, *dm = nullptr;
   if (x0) { CHK(h2d(h, h->ls_x, x0, (size_t)n)); dx = h->ls_x; }
   if (s0) { CHK(h2d(h, h->ls_s, s0, (size_t)m)); ds = h->ls_s; }
   if (mu0) { CHK(h2d(h, h->tmp_m, mu0, (size_t)m)); dm = h->tmp_m; }
   CHK(launch_set_w(h, dx, ds, dm));
-  HIPCHK(h, hipMemcpyAsync(h->w_prev, h->w, sizeof(double) * (size_t)(n + m), hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->w_prev, h->w, sizeof(real) * (size_t)(n + m), hipMemcpyDeviceToDevice, h->stream));
   // reset the loop counters (optimize! starts at iter = 0; the KKT solver's counters persist, setup.jl:54-61)
   CHK(d2h(h, h->ctl_host, h->ctl, 1));
   Ctl* c = h->ctl_host;
@@ -983,7 +983,7 @@ extern "C" int32_t cosmo_hip_residuals(cosmo_hip_handle* h, double out[5]) {
   CHK(enqueue_check(h, 0, 3));
   CHK(sync_ctl(h));
   const Ctl* c = h->ctl_host;
-  out[0] = c->r_prim; out[1] = c->r_dual; out[2] = c->max_norm_prim; out[3] = c->max_norm_dual; out[4] = c->cost;
+  out[0] = (double)c->r_prim; out[1] = (double)c->r_dual; out[2] = (double)c->max_norm_prim; out[3] = (double)c->max_norm_dual; out[4] = (double)c->cost;
   return COSMO_HIP_OK;
 }
 
@@ -1149,17 +1149,17 @@ extern "C" int32_t cosmo_hip_optimize(cosmo_hip_handle* h, cosmo_hip_result* res
   res->iter = (acc_iter >= 0) ? acc_iter : c->iter;
   res->kkt_iters_total = c->kkt_iters_total;
   res->kkt_solves = c->solves;
-  res->cost = (status == COSMO_HIP_PRIMAL_INFEASIBLE) ? INFINITY : (status == COSMO_HIP_DUAL_INFEASIBLE) ? -INFINITY : c->cost;   // solver.jl:339,345
-  res->r_prim = c->r_prim; res->r_dual = c->r_dual; res->max_norm_prim = c->max_norm_prim; res->max_norm_dual = c->max_norm_dual;
-  res->rho = c->rho;
+  res->cost = (status == COSMO_HIP_PRIMAL_INFEASIBLE) ? (double)INFINITY : (status == COSMO_HIP_DUAL_INFEASIBLE) ? -(double)INFINITY : (double)c->cost;   // solver.jl:339,345
+  res->r_prim = (double)c->r_prim; res->r_dual = (double)c->r_dual; res->max_norm_prim = (double)c->max_norm_prim; res->max_norm_dual = (double)c->max_norm_dual;
+  res->rho = (double)c->rho;
   res->n_rho_updates = c->n_rho_updates;
-  for (int i = 0; i < COSMO_HIP_MAX_RHO_UPDATES && i < c->n_rho_updates; ++i) res->rho_updates[i] = c->rho_updates[i];
+  for (int i = 0; i < COSMO_HIP_MAX_RHO_UPDATES && i < c->n_rho_updates; ++i) res->rho_updates[i] = (double)c->rho_updates[i];
   res->iter_time = std::chrono::duration<double>(t1 - t0).count();
   res->proj_time = h->kc_seconds[KC_Z] + h->kc_seconds[KC_SOC] + h->kc_seconds[KC_PSD];
   return COSMO_HIP_OK;
 }
 
-extern "C" int32_t cosmo_hip_get_iterates(cosmo_hip_handle* h, double* w, double* w_prev, double* s, double* mu) {
+extern "C" int32_t cosmo_hip_get_iterates(cosmo_hip_handle* h, real* w, real* w_prev, real* s, real* mu) {
   ENTER(h);
   if (!h->have_iterates) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "get_iterates: set_iterates first");
   const size_t N = (size_t)(h->n + h->m);
@@ -1190,7 +1190,7 @@ extern "C" int32_t cosmo_hip_cg_persist_stats(cosmo_hip_handle* h, int64_t out[8
   return COSMO_HIP_OK;
 }
 
-extern "C" int32_t cosmo_hip_get_kkt_solution(cosmo_hip_handle* h, double* sol) {
+extern "C" int32_t cosmo_hip_get_kkt_solution(cosmo_hip_handle* h, real* sol) {
   ENTER(h);
   if (!h->have_params || !sol) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "get_kkt_solution: not set up");
   CHK(d2h(h, sol, h->x_tl, (size_t)h->n));

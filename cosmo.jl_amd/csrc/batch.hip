@@ -19,28 +19,28 @@
 struct BCtl {                 // per problem, device resident
   int status; int n_rho_updates;
   long long iter, solves, kkt_iters_total;
-  double rho, cost, r_prim, r_dual, max_norm_prim, max_norm_dual;
-  double rho_updates[COSMO_HIP_MAX_RHO_UPDATES];
+  real rho, cost, r_prim, r_dual, max_norm_prim, max_norm_dual;
+  real rho_updates[COSMO_HIP_MAX_RHO_UPDATES];
 };
 
-struct BMat { const int* rowptr; const int* col; const double* val; const int* split; const int* rb;   // concatenated over problems
+struct BMat { const int* rowptr; const int* col; const real* val; const int* split; const int* rb;   // concatenated over problems
               const long long* nz_off; const int* rb_off; const int* nb; int nrows; int split_col; };
 
 struct BatchDev {
   int nprob; int n; int m;
   BMat A, AT, PT;
-  const double *q, *b, *Dinv, *Einv, *cinv;
-  const uint32_t* meta; const double *box_l, *box_u; int nbox;
+  const real *q, *b, *Dinv, *Einv, *cinv;
+  const uint32_t* meta; const real *box_l, *box_u; int nbox;
   int nsoc; const int *soc_off, *soc_dim;
   const int* rho_cls;
-  double *w, *w_prev, *s, *mu, *s_tl, *ls_s, *y2, *tmp_m, *nu, *rho;
-  double *ls_x, *x_tl, *rhs, *r, *u, *c;
+  real *w, *w_prev, *s, *mu, *s_tl, *ls_s, *y2, *tmp_m, *nu, *rho;
+  real *ls_x, *x_tl, *rhs, *r, *u, *c;
   BCtl* ctl;
-  const double* tol_table; long long tol_len;   // tol_constant / k^tol_exponent, k = 1.. (host libm, as the large path)
+  const real* tol_table; long long tol_len;   // tol_constant / k^tol_exponent, k = 1.. (host libm, as the large path)
 };
 
 struct BParams {
-  double sigma, alpha, eps_abs, eps_rel, rho_min, rho_max, rho_eq, adapt_tol, obj_true, obj_true_tol;
+  real sigma, alpha, eps_abs, eps_rel, rho_min, rho_max, rho_eq, adapt_tol, obj_true, obj_true_tol;
   long long max_iter, max_adaptions;
   int check_termination, adaptive_rho, adaptive_rho_interval, unscale;
 };
@@ -58,13 +58,13 @@ __device__ __forceinline__ CsrView bview(const BMat& M, int k) {
   return v;
 }
 
-__device__ __forceinline__ double proj_simple(double x, uint32_t meta, const double* bl, const double* bu) {
+__device__ __forceinline__ real proj_simple(real x, uint32_t meta, const real* bl, const real* bu) {
   const uint32_t kind = meta & 3u;
   if (kind == 0u) return x;
   if (kind == 1u) return 0.0;
-  if (kind == 2u) return (x != x) ? x : ((x > 0.0) ? x : 0.0);
+  if (kind == 2u) return (x != x) ? x : ((x > R(0.0)) ? x : R(0.0));
   const uint32_t j = meta >> 2;
-  const double l = bl[j], u = bu[j];
+  const real l = bl[j], u = bu[j];
   return (x < l) ? l : ((x > u) ? u : x);
 }
 
@@ -79,23 +79,23 @@ __device__ __forceinline__ double proj_simple(double x, uint32_t meta, const dou
 //               (n = 500, m = 1000, nnz = 10 000) needs 157 KB of the CU's 160 KB.  HBM then only sees the iterates.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int BS>
-__device__ __forceinline__ double bsum(double v, double* red) {
+__device__ __forceinline__ real bsum(real v, real* red) {
   v = wave_sum(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  double t = 0.0;
+  real t = 0.0;
 #pragma unroll
   for (int i = 0; i < BS / 64; ++i) t += red[i];
   return t;
 }
 template <int BS>
-__device__ __forceinline__ double bmax(double v, double* red) {
+__device__ __forceinline__ real bmax(real v, real* red) {
   v = wave_max(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  double t = red[0];
+  real t = red[0];
 #pragma unroll
   for (int i = 1; i < BS / 64; ++i) t = (red[i] > t) ? red[i] : t;
   return t;
@@ -103,18 +103,18 @@ __device__ __forceinline__ double bmax(double v, double* red) {
 
 struct StreamOps {
   CsrView A, AT, PT;
-  double* lds; double* red;
+  real* lds; real* red;
   static constexpr bool in_lds = false;
-  __device__ __forceinline__ double* buf_n(double* g) const { return g; }       // vector the A / P products gather from
-  __device__ __forceinline__ double* buf_m(double* g) const { return g; }       // vector the A' products gather from
-  __device__ __forceinline__ const double* stage_n(const double* g) const { return g; }
-  template <class F> __device__ __forceinline__ void rows_A(const double* x, F fn) {
+  __device__ __forceinline__ real* buf_n(real* g) const { return g; }       // vector the A / P products gather from
+  __device__ __forceinline__ real* buf_m(real* g) const { return g; }       // vector the A' products gather from
+  __device__ __forceinline__ const real* stage_n(const real* g) const { return g; }
+  template <class F> __device__ __forceinline__ void rows_A(const real* x, F fn) {
     for (int t = 0; t < A.nb; ++t) csr_stream_tile(A, x, x, t, lds, red, fn);
   }
-  template <class F> __device__ __forceinline__ void rows_AT(const double* y, F fn) {
+  template <class F> __device__ __forceinline__ void rows_AT(const real* y, F fn) {
     for (int t = 0; t < AT.nb; ++t) csr_stream_tile(AT, y, y, t, lds, red, fn);
   }
-  template <class F> __device__ __forceinline__ void rows_PT(const double* x1, const double* x2, F fn) {
+  template <class F> __device__ __forceinline__ void rows_PT(const real* x1, const real* x2, F fn) {
     for (int t = 0; t < PT.nb; ++t) csr_stream_tile(PT, x1, x2, t, lds, red, fn);
   }
 };
@@ -124,35 +124,35 @@ struct LdsHdr { int nnzA, nnzP, nbA, nbAT, nbPT, oAval, oPval, oArp, oAcol, oTrp
 
 template <int BS>
 struct LdsOps {
-  const double *Aval, *Pval;
+  const real *Aval, *Pval;
   const unsigned short *Arp, *Acol, *Trp, *Tpos, *Trow, *Prp, *Pcol;
   const int4 *rbA, *rbAT, *rbPT;
   int nbA, nbAT, nbPT;
-  double *xv, *tv, *red;
+  real *xv, *tv, *red;
   int n;
   static constexpr bool in_lds = true;
-  __device__ __forceinline__ double* buf_n(double*) const { return xv; }
-  __device__ __forceinline__ double* buf_m(double*) const { return tv; }
-  __device__ __forceinline__ const double* stage_n(const double* g) const {     // copy a global n-vector into the LDS gather buffer
+  __device__ __forceinline__ real* buf_n(real*) const { return xv; }
+  __device__ __forceinline__ real* buf_m(real*) const { return tv; }
+  __device__ __forceinline__ const real* stage_n(const real* g) const {     // copy a global n-vector into the LDS gather buffer
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += BS) xv[i] = g[i];
     __syncthreads();
     return xv;
   }
-  template <class F> __device__ __forceinline__ void rows_A(const double* x, F fn) {
+  template <class F> __device__ __forceinline__ void rows_A(const real* x, F fn) {
     __syncthreads();
     for (int t = 0; t < nbA; ++t) {
       const int4 d = rbA[t];
       if (d.w - d.z <= COSMO_NNZ_PER_BLOCK) {
         for (int r = d.x + threadIdx.x; r < d.y; r += BS) {
-          double s1 = 0.0;
+          real s1 = 0.0;
           const int a = Arp[r], b = Arp[r + 1];
           for (int k = a; k < b; ++k) s1 += Aval[k] * x[Acol[k]];
           fn(r, s1, 0.0);
         }
       } else {                                                               // a single long row: strided partials, block sum
         const int r = d.x;
-        double s1 = 0.0, s2 = 0.0;
+        real s1 = 0.0, s2 = 0.0;
         for (int k = d.z + threadIdx.x; k < d.w; k += BS) s1 += Aval[k] * x[Acol[k]];
         s1 = bsum<BS>(s1, red); s2 = bsum<BS>(s2, red);
         if (threadIdx.x == 0) fn(r, s1, s2);
@@ -160,20 +160,20 @@ struct LdsOps {
     }
     __syncthreads();
   }
-  template <class F> __device__ __forceinline__ void rows_AT(const double* y, F fn) {
+  template <class F> __device__ __forceinline__ void rows_AT(const real* y, F fn) {
     __syncthreads();
     for (int t = 0; t < nbAT; ++t) {
       const int4 d = rbAT[t];
       if (d.w - d.z <= COSMO_NNZ_PER_BLOCK) {
         for (int r = d.x + threadIdx.x; r < d.y; r += BS) {
-          double s1 = 0.0;
+          real s1 = 0.0;
           const int a = Trp[r], b = Trp[r + 1];
           for (int k = a; k < b; ++k) s1 += Aval[Tpos[k]] * y[Trow[k]];
           fn(r, s1, 0.0);
         }
       } else {
         const int r = d.x;
-        double s1 = 0.0, s2 = 0.0;
+        real s1 = 0.0, s2 = 0.0;
         for (int k = d.z + threadIdx.x; k < d.w; k += BS) s1 += Aval[Tpos[k]] * y[Trow[k]];
         s1 = bsum<BS>(s1, red); s2 = bsum<BS>(s2, red);
         if (threadIdx.x == 0) fn(r, s1, s2);
@@ -181,13 +181,13 @@ struct LdsOps {
     }
     __syncthreads();
   }
-  template <class F> __device__ __forceinline__ void rows_PT(const double* x1, const double* x2, F fn) {
+  template <class F> __device__ __forceinline__ void rows_PT(const real* x1, const real* x2, F fn) {
     __syncthreads();
     for (int t = 0; t < nbPT; ++t) {
       const int4 d = rbPT[t];
       if (d.w - d.z <= COSMO_NNZ_PER_BLOCK) {
         for (int r = d.x + threadIdx.x; r < d.y; r += BS) {
-          double s1 = 0.0, s2 = 0.0;
+          real s1 = 0.0, s2 = 0.0;
           const int pa = Prp[r], pb = Prp[r + 1];
           for (int k = pa; k < pb; ++k) s1 += Pval[k] * x1[Pcol[k]];
           const int a = Trp[r], b = Trp[r + 1];
@@ -197,7 +197,7 @@ struct LdsOps {
       } else {
         const int r = d.x;
         const int pa = Prp[r], lp = Prp[r + 1] - pa, a = Trp[r], lt = Trp[r + 1] - a;
-        double s1 = 0.0, s2 = 0.0;
+        real s1 = 0.0, s2 = 0.0;
         for (int k = threadIdx.x; k < lp + lt; k += BS) {
           if (k < lp) s1 += Pval[pa + k] * x1[Pcol[pa + k]];
           else { const int kk = a + (k - lp); s2 += Aval[Tpos[kk]] * x2[Trow[kk]]; }
@@ -212,108 +212,108 @@ struct LdsOps {
 
 // One workgroup = one problem.  Runs iterations until a status is decided or `iter_target` iterations are done.
 template <int BS, class Ops>
-__device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams& P, long long iter_target, int do_init, Ops& ops, double* red) {
+__device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams& P, long long iter_target, int do_init, Ops& ops, real* red) {
   const int k = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n = D.n, m = D.m;
   BCtl* ctl = D.ctl + k;
   const long long on = (long long)k * n, om = (long long)k * m, onm = (long long)k * (n + m);
-  const double *q = D.q + on, *b = D.b + om, *Dinv = D.Dinv + on, *Einv = D.Einv + om;
-  const double cinv = D.cinv[k];
-  const double *bl = D.box_l + (long long)k * D.nbox, *bu = D.box_u + (long long)k * D.nbox;
+  const real *q = D.q + on, *b = D.b + om, *Dinv = D.Dinv + on, *Einv = D.Einv + om;
+  const real cinv = D.cinv[k];
+  const real *bl = D.box_l + (long long)k * D.nbox, *bu = D.box_u + (long long)k * D.nbox;
   const int* cls = D.rho_cls + om;
-  double *w = D.w + onm, *w_prev = D.w_prev + onm, *s = D.s + om, *mu = D.mu + om, *s_tl = D.s_tl + om;
-  double *ls_s = D.ls_s + om, *nu = D.nu + om, *rho = D.rho + om;
-  double *ls_x = D.ls_x + on, *x_tl = D.x_tl + on, *rhs = D.rhs + on, *r = D.r + on, *c = D.c + on;
+  real *w = D.w + onm, *w_prev = D.w_prev + onm, *s = D.s + om, *mu = D.mu + om, *s_tl = D.s_tl + om;
+  real *ls_s = D.ls_s + om, *nu = D.nu + om, *rho = D.rho + om;
+  real *ls_x = D.ls_x + on, *x_tl = D.x_tl + on, *rhs = D.rhs + on, *r = D.r + on, *c = D.c + on;
   // vectors the sparse products GATHER from: global arrays for StreamOps, the two LDS buffers for LdsOps
-  double* const u = ops.buf_n(D.u + on);                 // CG direction
-  double* const y2 = ops.buf_m(D.y2 + om);               // rho .* ls_s (dead once the rhs is formed)
-  double* const tmp_m = ops.buf_m(D.tmp_m + om);         // rho .* (A v)
-  double* const mu_g = ops.buf_m(mu);                    // mu for the dual residual
+  real* const u = ops.buf_n(D.u + on);                 // CG direction
+  real* const y2 = ops.buf_m(D.y2 + om);               // rho .* ls_s (dead once the rhs is formed)
+  real* const tmp_m = ops.buf_m(D.tmp_m + om);         // rho .* (A v)
+  real* const mu_g = ops.buf_m(mu);                    // mu for the dual residual
 
   // ---- admm_x! + admm_w! (solver.jl:32-65) with the CG reduced solve (kktsolver_indirect.jl:36-88) -------------------
   auto solve_and_update = [&]() {
     for (int i = tid; i < n + m; i += BS) {                             // rhs of the KKT system + y2 = rho .* ls_s
       if (i < n) ls_x[i] = P.sigma * w[i] - q[i];
-      else { const int rr = i - n; const double v = (b[rr] - 2.0 * s[rr]) + w[i]; ls_s[rr] = v; y2[rr] = rho[rr] * v; }
+      else { const int rr = i - n; const real v = (b[rr] - R(2.0) * s[rr]) + w[i]; ls_s[rr] = v; y2[rr] = rho[rr] * v; }
     }
     __syncthreads();
-    double acc = 0.0;
-    ops.rows_AT(y2, [&](int row, double s1, double s2) {
-      const double v = (s1 + s2) + ls_x[row]; rhs[row] = v; acc += v * v; });
-    const double bb = bsum<BS>(acc, red);
-    const double* xs = ops.stage_n(x_tl);
-    ops.rows_A(xs, [&](int row, double s1, double s2) { tmp_m[row] = (s1 + s2) * rho[row]; });
+    real acc = 0.0;
+    ops.rows_AT(y2, [&](int row, real s1, real s2) {
+      const real v = (s1 + s2) + ls_x[row]; rhs[row] = v; acc += v * v; });
+    const real bb = bsum<BS>(acc, red);
+    const real* xs = ops.stage_n(x_tl);
+    ops.rows_A(xs, [&](int row, real s1, real s2) { tmp_m[row] = (s1 + s2) * rho[row]; });
     __syncthreads();
     acc = 0.0;
-    ops.rows_PT(xs, tmp_m, [&](int row, double s1, double s2) {
-      const double cj = s1 + (P.sigma * xs[row] + s2); const double rj = rhs[row] - cj; r[row] = rj; acc += rj * rj; });
-    double rr = bsum<BS>(acc, red);
+    ops.rows_PT(xs, tmp_m, [&](int row, real s1, real s2) {
+      const real cj = s1 + (P.sigma * xs[row] + s2); const real rj = rhs[row] - cj; r[row] = rj; acc += rj * rj; });
+    real rr = bsum<BS>(acc, red);
     const long long ks = ctl->solves;                                    // iteration_counter - 1
-    const double tol_k = D.tol_table[ks < D.tol_len ? ks : D.tol_len - 1];
-    const double tol = tol_k / sqrt(bb);
-    double res = sqrt(rr), prev = 1.0;
+    const real tol_k = D.tol_table[ks < D.tol_len ? ks : D.tol_len - 1];
+    const real tol = tol_k / sqrt(bb);
+    real res = sqrt(rr), prev = 1.0;
     int kk = 0;
     while (kk < n && !(res <= tol)) {                                    // cg! (IterativeSolvers v0.9), maxiter = n
-      const double beta = (res * res) / (prev * prev);
-      for (int i = tid; i < n; i += BS) u[i] = r[i] + beta * ((kk == 0) ? 0.0 : u[i]);
+      const real beta = (res * res) / (prev * prev);
+      for (int i = tid; i < n; i += BS) u[i] = r[i] + beta * ((kk == 0) ? R(0.0) : u[i]);
       __syncthreads();
-      ops.rows_A(u, [&](int row, double s1, double s2) { tmp_m[row] = (s1 + s2) * rho[row]; });
+      ops.rows_A(u, [&](int row, real s1, real s2) { tmp_m[row] = (s1 + s2) * rho[row]; });
       __syncthreads();
       acc = 0.0;
-      ops.rows_PT(u, tmp_m, [&](int row, double s1, double s2) {
-        const double vj = u[row]; const double cj = s1 + (P.sigma * vj + s2); c[row] = cj; acc += vj * cj; });
-      const double uc = bsum<BS>(acc, red);
-      const double a = (res * res) / uc;
+      ops.rows_PT(u, tmp_m, [&](int row, real s1, real s2) {
+        const real vj = u[row]; const real cj = s1 + (P.sigma * vj + s2); c[row] = cj; acc += vj * cj; });
+      const real uc = bsum<BS>(acc, red);
+      const real a = (res * res) / uc;
       acc = 0.0;
       for (int i = tid; i < n; i += BS) {
         x_tl[i] = x_tl[i] + a * u[i];
-        const double ri = r[i] - a * c[i]; r[i] = ri; acc += ri * ri;
+        const real ri = r[i] - a * c[i]; r[i] = ri; acc += ri * ri;
       }
       rr = bsum<BS>(acc, red);
       prev = res; res = sqrt(rr); ++kk;
     }
     __syncthreads();
     // nu = rho (A x_tl - ls_s) ; s_tl ; w update
-    const double* xe = ops.stage_n(x_tl);
-    ops.rows_A(xe, [&](int row, double s1, double s2) {
-      const double rh = rho[row]; const double nv = ((s1 + s2) - ls_s[row]) * rh; nu[row] = nv;
-      const double sv = s[row], wv2 = w[n + row]; const double st = (2.0 * sv - wv2) - nv / rh; s_tl[row] = st;
+    const real* xe = ops.stage_n(x_tl);
+    ops.rows_A(xe, [&](int row, real s1, real s2) {
+      const real rh = rho[row]; const real nv = ((s1 + s2) - ls_s[row]) * rh; nu[row] = nv;
+      const real sv = s[row], wv2 = w[n + row]; const real st = (R(2.0) * sv - wv2) - nv / rh; s_tl[row] = st;
       w[n + row] = wv2 + P.alpha * (st - sv); });
-    for (int i = tid; i < n; i += BS) { const double wv2 = w[i]; w[i] = wv2 + P.alpha * (x_tl[i] - wv2); }
+    for (int i = tid; i < n; i += BS) { const real wv2 = w[i]; w[i] = wv2 + P.alpha * (x_tl[i] - wv2); }
     __syncthreads();
     if (tid == 0) { ctl->solves = ks + 1; ctl->kkt_iters_total += kk; }
     __syncthreads();
   };
 
   // ---- residuals (residuals.jl:30-96,143-147); x = w_prev[1:n], mu recovered on the fly ------------------------------
-  double rp, mp, rd, md, cost;
+  real rp, mp, rd, md, cost;
   auto residuals = [&](bool unscale) {
-    double a_rp = 0.0, a_mp = 0.0;
-    const double* xp = ops.stage_n(w_prev);
-    ops.rows_A(xp, [&](int row, double s1, double s2) {
-      const double ax = s1 + s2, sv = s[row], bv = b[row];
-      const double muv = rho[row] * (w_prev[n + row] - sv);
+    real a_rp = 0.0, a_mp = 0.0;
+    const real* xp = ops.stage_n(w_prev);
+    ops.rows_A(xp, [&](int row, real s1, real s2) {
+      const real ax = s1 + s2, sv = s[row], bv = b[row];
+      const real muv = rho[row] * (w_prev[n + row] - sv);
       mu[row] = muv;
       if (Ops::in_lds) mu_g[row] = muv;
-      double rv = ax + sv; rv = rv - bv;
-      const double e = unscale ? Einv[row] : 1.0;
+      real rv = ax + sv; rv = rv - bv;
+      const real e = unscale ? Einv[row] : 1.0;
       if (unscale) rv = rv * e;
       a_rp = amax(a_rp, rv);
       a_mp = amax(a_mp, unscale ? ax * e : ax); a_mp = amax(a_mp, unscale ? sv * e : sv); a_mp = amax(a_mp, unscale ? bv * e : bv); });
     rp = bmax<BS>(a_rp, red); mp = bmax<BS>(a_mp, red);
     __syncthreads();
-    double a_rd = 0.0, a_md = 0.0, xpx = 0.0, qx = 0.0;
-    ops.rows_PT(xp, mu_g, [&](int row, double px, double atm) {
-      const double xv = xp[row], qv = q[row];
-      double rv = px + qv; rv = rv - atm;
-      double a = px, bq = qv, cm = atm;
-      if (unscale) { const double d = Dinv[row]; rv = (rv * d) * cinv; a = (a * d) * cinv; bq = (bq * d) * cinv; cm = (cm * d) * cinv; }
+    real a_rd = 0.0, a_md = 0.0, xpx = 0.0, qx = 0.0;
+    ops.rows_PT(xp, mu_g, [&](int row, real px, real atm) {
+      const real xv = xp[row], qv = q[row];
+      real rv = px + qv; rv = rv - atm;
+      real a = px, bq = qv, cm = atm;
+      if (unscale) { const real d = Dinv[row]; rv = (rv * d) * cinv; a = (a * d) * cinv; bq = (bq * d) * cinv; cm = (cm * d) * cinv; }
       a_rd = amax(a_rd, rv); a_md = amax(a_md, a); a_md = amax(a_md, bq); a_md = amax(a_md, cm);
       xpx += px * xv; qx += qv * xv; });
     rd = bmax<BS>(a_rd, red); md = bmax<BS>(a_md, red);
     xpx = bsum<BS>(xpx, red); qx = bsum<BS>(qx, red);
-    cost = (unscale ? cinv : 1.0) * (0.5 * xpx + qx);
+    cost = (unscale ? cinv : R(1.0)) * (R(0.5) * xpx + qx);
     __syncthreads();
   };
 
@@ -325,38 +325,38 @@ __device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams
     ++it;
     // ---- admm_z!: w_prev = w ; s = Pi(w_s)  (solver.jl:151-152) ----
     for (int i = tid; i < n + m; i += BS) {
-      const double v = w[i]; w_prev[i] = v;
+      const real v = w[i]; w_prev[i] = v;
       if (i >= n) s[i - n] = proj_simple(v, D.meta[i - n], bl, bu);
     }
     __syncthreads();
     for (int cI = wv; cI < D.nsoc; cI += BS / 64) {                       // SecondOrderCone (convexset.jl:100-114)
-      double* x = s + D.soc_off[cI]; const int d = D.soc_dim[cI];
+      real* x = s + D.soc_off[cI]; const int d = D.soc_dim[cI];
       if (d == 0) continue;
-      const double t = x[0];
-      double a = 0.0;
-      for (int i = 1 + lane; i < d; i += 64) { const double v = x[i]; a += v * v; }
-      const double nx = sqrt(wave_sum(a));
+      const real t = x[0];
+      real a = 0.0;
+      for (int i = 1 + lane; i < d; i += 64) { const real v = x[i]; a += v * v; }
+      const real nx = sqrt(wave_sum(a));
       if (nx <= t) {
       } else if (nx <= -t) { for (int i = lane; i < d; i += 64) x[i] = 0.0; }
-      else { const double f = (nx + t) / (2.0 * nx); for (int i = 1 + lane; i < d; i += 64) x[i] = f * x[i]; if (lane == 0) x[0] = (nx + t) / 2.0; }
+      else { const real f = (nx + t) / (R(2.0) * nx); for (int i = 1 + lane; i < d; i += 64) x[i] = f * x[i]; if (lane == 0) x[0] = (nx + t) / R(2.0); }
     }
     __syncthreads();
     // ---- apply_rho_adaptation_rules! (solver.jl:242-282, parameters.jl:53-92) ----
     if (P.adaptive_rho && P.adaptive_rho_interval > 0 && (it % P.adaptive_rho_interval) == 0 &&
         (long long)(ctl->n_rho_updates - 1) < P.max_adaptions) {
       residuals(false);
-      const double rpn = rp / (mp + 1e-10), rdn = rd / (md + 1e-10);
-      const double rho0 = ctl->rho;
-      double nr = rho0 * sqrt(rpn / (rdn + 1e-10));
+      const real rpn = rp / (mp + R(1e-10)), rdn = rd / (md + R(1e-10));
+      const real rho0 = ctl->rho;
+      real nr = rho0 * sqrt(rpn / (rdn + R(1e-10)));
       nr = fmin(fmax(nr, P.rho_min), P.rho_max);
-      const bool adapt = (nr > P.adapt_tol * rho0) || (nr < (1.0 / P.adapt_tol) * rho0);
+      const bool adapt = (nr > P.adapt_tol * rho0) || (nr < (R(1.0) / P.adapt_tol) * rho0);
       __syncthreads();
       if (adapt) {
         for (int i = tid; i < m; i += BS) {
-          const int cc = cls[i]; double rv = nr;
+          const int cc = cls[i]; real rv = nr;
           if (cc == 1) rv = rv * P.rho_eq; else if (cc == 2) rv = P.rho_min;
           rho[i] = rv;
-          w[n + i] = (1.0 / rv) * mu[i] + s[i];
+          w[n + i] = (R(1.0) / rv) * mu[i] + s[i];
         }
         if (tid == 0) {
           ctl->rho = nr;
@@ -372,7 +372,7 @@ __device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams
     if ((it % P.check_termination) == 0 || it == 1) {
       residuals(P.unscale != 0);
       int st = 0;
-      if (fabs(cost) > 1e20) st = COSMO_HIP_UNSOLVED;
+      if (fabs(cost) > R(1e20)) st = COSMO_HIP_UNSOLVED;
       else if (rp < P.eps_abs + P.eps_rel * mp && rd < P.eps_abs + P.eps_rel * md &&
                ((P.obj_true != P.obj_true) || fabs(P.obj_true - cost) <= P.obj_true_tol)) st = COSMO_HIP_SOLVED;   // has_converged (residuals.jl:131-139)
       if (tid == 0) { ctl->cost = cost; ctl->r_prim = rp; ctl->r_dual = rd; ctl->max_norm_prim = mp; ctl->max_norm_dual = md; ctl->status = st; }
@@ -394,8 +394,8 @@ __device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams
 }
 
 __global__ __launch_bounds__(COSMO_BS) void k_batch_admm(BatchDev D, BParams P, long long iter_target, int do_init) {
-  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
-  __shared__ double red[COSMO_BS / 64];
+  __shared__ real lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ real red[COSMO_BS / 64];
   const int k = blockIdx.x;
   if (D.ctl[k].status != 0) return;
   StreamOps ops;
@@ -407,19 +407,19 @@ __global__ __launch_bounds__(COSMO_BS) void k_batch_admm(BatchDev D, BParams P, 
 template <int BS>
 __global__ __launch_bounds__(BS) void k_batch_admm_lds(BatchDev D, BParams P, long long iter_target, int do_init,
                                                        const unsigned char* __restrict__ img, long long img_stride) {
-  extern __shared__ double dyn_lds[];
+  extern __shared__ real dyn_lds[];
   const int k = blockIdx.x;
   if (D.ctl[k].status != 0) return;
   const unsigned char* src = img + (long long)k * img_stride;
   const LdsHdr hd = *reinterpret_cast<const LdsHdr*>(src);
   {
-    const double* s8 = reinterpret_cast<const double*>(src);
-    const int nd = hd.bytes / 8;
+    const real* s8 = reinterpret_cast<const real*>(src);
+    const int nd = hd.bytes / (int)sizeof(real);
     for (int i = threadIdx.x; i < nd; i += BS) dyn_lds[i] = s8[i];
   }
   unsigned char* base = reinterpret_cast<unsigned char*>(dyn_lds);
   LdsOps<BS> ops;
-  ops.Aval = reinterpret_cast<const double*>(base + hd.oAval); ops.Pval = reinterpret_cast<const double*>(base + hd.oPval);
+  ops.Aval = reinterpret_cast<const real*>(base + hd.oAval); ops.Pval = reinterpret_cast<const real*>(base + hd.oPval);
   ops.Arp = reinterpret_cast<const unsigned short*>(base + hd.oArp); ops.Acol = reinterpret_cast<const unsigned short*>(base + hd.oAcol);
   ops.Trp = reinterpret_cast<const unsigned short*>(base + hd.oTrp); ops.Tpos = reinterpret_cast<const unsigned short*>(base + hd.oTpos);
   ops.Trow = reinterpret_cast<const unsigned short*>(base + hd.oTrow);
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_lds(BatchDev D, BParams P, lo
   ops.rbA = reinterpret_cast<const int4*>(base + hd.oRbA); ops.rbAT = reinterpret_cast<const int4*>(base + hd.oRbAT);
   ops.rbPT = reinterpret_cast<const int4*>(base + hd.oRbPT);
   ops.nbA = hd.nbA; ops.nbAT = hd.nbAT; ops.nbPT = hd.nbPT;
-  double* wsp = reinterpret_cast<double*>(base + img_stride);            // workspace behind the image
+  real* wsp = reinterpret_cast<real*>(base + img_stride);            // workspace behind the image
   ops.xv = wsp; ops.tv = wsp + D.n; ops.red = wsp + D.n + D.m; ops.n = D.n;
   __syncthreads();
   batch_admm_body<BS>(D, P, iter_target, do_init, ops, ops.red);
@@ -455,7 +455,7 @@ extern "C" void cosmo_dbg_batch_timing(long long* out) { (void)hipMemcpyFromSymb
 template <int BS, int JN, int JM>
 __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, long long iter_target, int do_init,
                                                        const unsigned char* __restrict__ img, long long img_stride) {
-  extern __shared__ double dyn_lds[];
+  extern __shared__ real dyn_lds[];
   const int k = blockIdx.x;
   BCtl* ctl = D.ctl + k;
   if (ctl->status != 0) return;
@@ -464,13 +464,13 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   const unsigned char* src = img + (long long)k * img_stride;
   const LdsHdr hd = *reinterpret_cast<const LdsHdr*>(src);
   {
-    const double* s8 = reinterpret_cast<const double*>(src);
-    const int nd = hd.bytes / 8;
+    const real* s8 = reinterpret_cast<const real*>(src);
+    const int nd = hd.bytes / (int)sizeof(real);
     for (int i = tid; i < nd; i += BS) dyn_lds[i] = s8[i];
   }
   unsigned char* base = reinterpret_cast<unsigned char*>(dyn_lds);
-  const double* Aval = reinterpret_cast<const double*>(base + hd.oAval);
-  const double* Pval = reinterpret_cast<const double*>(base + hd.oPval);
+  const real* Aval = reinterpret_cast<const real*>(base + hd.oAval);
+  const real* Pval = reinterpret_cast<const real*>(base + hd.oPval);
   const unsigned short* Arp = reinterpret_cast<const unsigned short*>(base + hd.oArp);
   const unsigned short* Acol = reinterpret_cast<const unsigned short*>(base + hd.oAcol);
   const unsigned short* Trp = reinterpret_cast<const unsigned short*>(base + hd.oTrp);
@@ -478,15 +478,15 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   const unsigned short* Trow = reinterpret_cast<const unsigned short*>(base + hd.oTrow);
   const unsigned short* Prp = reinterpret_cast<const unsigned short*>(base + hd.oPrp);
   const unsigned short* Pcol = reinterpret_cast<const unsigned short*>(base + hd.oPcol);
-  double* wsp = reinterpret_cast<double*>(base + img_stride);
-  double* xv = wsp;                 // n : vector gathered by the A / P products
-  double* tv = wsp + n;             // m : vector gathered by the A' products; staging of s for the SOC projection
-  double* red = wsp + n + m;        // BS / 64 reduction slots
+  real* wsp = reinterpret_cast<real*>(base + img_stride);
+  real* xv = wsp;                 // n : vector gathered by the A / P products
+  real* tv = wsp + n;             // m : vector gathered by the A' products; staging of s for the SOC projection
+  real* red = wsp + n + m;        // BS / 64 reduction slots
 
   const long long on = (long long)k * n, om = (long long)k * m, onm = (long long)k * (n + m);
   // ---- load the persistent state and the per-element constants into registers -----------------------------------------
-  double wx[JN], wpx[JN], qv[JN], xtl[JN], lsx[JN], rhsv[JN], rv[JN], cv[JN];
-  double wsv[JM], wps[JM], sv[JM], rhov[JM], lss[JM], bv[JM], blv[JM], buv[JM];
+  real wx[JN], wpx[JN], qv[JN], xtl[JN], lsx[JN], rhsv[JN], rv[JN], cv[JN];
+  real wsv[JM], wps[JM], sv[JM], rhov[JM], lss[JM], bv[JM], blv[JM], buv[JM];
   uint32_t metav[JM];
 #pragma unroll
   for (int j = 0; j < JN; ++j) {
@@ -506,10 +506,10 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     if (ok && (metav[j] & 3u) == 3u) { const uint32_t jb = metav[j] >> 2; blv[j] = D.box_l[(long long)k * D.nbox + jb]; buv[j] = D.box_u[(long long)k * D.nbox + jb]; }
   }
   const int* cls = D.rho_cls + om;
-  const double cinv = D.cinv[k];
+  const real cinv = D.cinv[k];
   long long solves = ctl->solves, kkt_total = ctl->kkt_iters_total;
   int n_rho = ctl->n_rho_updates;
-  double rho_s = ctl->rho;
+  real rho_s = ctl->rho;
   // the cones of this wave (cone c belongs to wave c % (BS/64)): offsets / dimensions in registers when they fit
   constexpr int JS = 8;
   const bool soc_in_regs = D.nsoc <= JS * (BS / 64);
@@ -520,27 +520,27 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     const bool ok = soc_in_regs && cI < D.nsoc;
     soc_o[t] = ok ? D.soc_off[cI] : 0; soc_d[t] = ok ? D.soc_dim[cI] : 0;
   }
-  double tol_next = D.tol_table[solves < D.tol_len ? solves : D.tol_len - 1];   // requested one solve ahead: its latency is hidden
+  real tol_next = D.tol_table[solves < D.tol_len ? solves : D.tol_len - 1];   // requested one solve ahead: its latency is hidden
   __syncthreads();
 
   // ---- row products on the LDS image: the owner of row r adds its products left to right -----------------------------
   // (measured on config 3: a sparse pass costs ~25 cycles per wave step of three LDS reads, set by LDS issue rate and by the
   //  spread of row lengths inside a wave, not by latency -- manual unrolling, 16 waves instead of 8 and a sliced-JDS layout
   //  with conflict-free value / index reads were all tried and were the same speed or slower)
-  auto rowA = [&](int r) -> double {                        // (A x)_r with x = xv
-    double s1 = 0.0;
+  auto rowA = [&](int r) -> real {                        // (A x)_r with x = xv
+    real s1 = 0.0;
     const int a = Arp[r], b2 = Arp[r + 1];
     for (int t = a; t < b2; ++t) s1 += Aval[t] * xv[Acol[t]];
-    return s1 + 0.0;
+    return s1 + R(0.0);
   };
-  auto rowAT = [&](int r) -> double {                       // (A' y)_r with y = tv
-    double s1 = 0.0;
+  auto rowAT = [&](int r) -> real {                       // (A' y)_r with y = tv
+    real s1 = 0.0;
     const int a = Trp[r], b2 = Trp[r + 1];
     for (int t = a; t < b2; ++t) s1 += Aval[Tpos[t]] * tv[Trow[t]];
     return s1;
   };
-  auto rowP = [&](int r) -> double {                        // (P x)_r with x = xv
-    double s1 = 0.0;
+  auto rowP = [&](int r) -> real {                        // (P x)_r with x = xv
+    real s1 = 0.0;
     const int a = Prp[r], b2 = Prp[r + 1];
     for (int t = a; t < b2; ++t) s1 += Pval[t] * xv[Pcol[t]];
     return s1;
@@ -553,21 +553,21 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
 #pragma unroll
     for (int j = 0; j < JM; ++j) {
       const int i = tid + BS * j;
-      const double v = (bv[j] - 2.0 * sv[j]) + wsv[j];
+      const real v = (bv[j] - R(2.0) * sv[j]) + wsv[j];
       lss[j] = v;
       if (i < m) tv[i] = rhov[j] * v;                                    // y2 = rho .* ls_s
     }
 #pragma unroll
     for (int j = 0; j < JN; ++j) { const int i = tid + BS * j; if (i < n) xv[i] = xtl[j]; }
     __syncthreads();
-    double acc = 0.0;
+    real acc = 0.0;
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
       const int i = tid + BS * j;
-      if (i < n) { const double v = (rowAT(i) + 0.0) + lsx[j]; rhsv[j] = v; acc += v * v; }
+      if (i < n) { const real v = (rowAT(i) + R(0.0)) + lsx[j]; rhsv[j] = v; acc += v * v; }
     }
-    const double bb = bsum<BS>(acc, red);                                  // (its barriers also order tv reads before the writes below)
-    double tmpv[JM];
+    const real bb = bsum<BS>(acc, red);                                  // (its barriers also order tv reads before the writes below)
+    real tmpv[JM];
 #pragma unroll
     for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; tmpv[j] = (i < m) ? rowA(i) * rhov[j] : 0.0; }
     __syncthreads();
@@ -578,21 +578,21 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
       const int i = tid + BS * j;
-      if (i < n) { const double cj = rowP(i) + (P.sigma * xtl[j] + rowAT(i)); const double rj = rhsv[j] - cj; rv[j] = rj; acc += rj * rj; }
+      if (i < n) { const real cj = rowP(i) + (P.sigma * xtl[j] + rowAT(i)); const real rj = rhsv[j] - cj; rv[j] = rj; acc += rj * rj; }
     }
-    double rr = bsum<BS>(acc, red);
-    const double tol_k = tol_next;
+    real rr = bsum<BS>(acc, red);
+    const real tol_k = tol_next;
     tol_next = D.tol_table[solves + 1 < D.tol_len ? solves + 1 : D.tol_len - 1];
-    const double tol = tol_k / sqrt(bb);
-    double res = sqrt(rr), prev = 1.0;
+    const real tol = tol_k / sqrt(bb);
+    real res = sqrt(rr), prev = 1.0;
     int kk = 0;
-    double uv[JN];
+    real uv[JN];
 #pragma unroll
     for (int j = 0; j < JN; ++j) uv[j] = 0.0;
     while (kk < n && !(res <= tol)) {                                    // cg! (IterativeSolvers v0.9), maxiter = n
-      const double beta = (res * res) / (prev * prev);
+      const real beta = (res * res) / (prev * prev);
 #pragma unroll
-      for (int j = 0; j < JN; ++j) { const int i = tid + BS * j; uv[j] = rv[j] + beta * ((kk == 0) ? 0.0 : uv[j]); if (i < n) xv[i] = uv[j]; }
+      for (int j = 0; j < JN; ++j) { const int i = tid + BS * j; uv[j] = rv[j] + beta * ((kk == 0) ? R(0.0) : uv[j]); if (i < n) xv[i] = uv[j]; }
       __syncthreads();
       { BT_BEGIN();
 #pragma unroll
@@ -606,22 +606,22 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
 #pragma unroll
       for (int j = 0; j < JN; ++j) {
         const int i = tid + BS * j;
-        if (i < n) { const double vj = uv[j]; const double cj = rowP(i) + (P.sigma * vj + rowAT(i)); cv[j] = cj; acc += vj * cj; }
+        if (i < n) { const real vj = uv[j]; const real cj = rowP(i) + (P.sigma * vj + rowAT(i)); cv[j] = cj; acc += vj * cj; }
       }
       __syncthreads();
       BT_END(1); }
       BT_BEGIN();
-      const double uc = bsum<BS>(acc, red);
+      const real uc = bsum<BS>(acc, red);
       BT_END(2);
 #ifdef COSMO_BATCH_TIMING
       if (blockIdx.x == 0 && tid == 0) g_bt[3] += 1;
 #endif
-      const double a = (res * res) / uc;
+      const real a = (res * res) / uc;
       acc = 0.0;
 #pragma unroll
       for (int j = 0; j < JN; ++j) {
         const int i = tid + BS * j;
-        if (i < n) { xtl[j] = xtl[j] + a * uv[j]; const double ri = rv[j] - a * cv[j]; rv[j] = ri; acc += ri * ri; }
+        if (i < n) { xtl[j] = xtl[j] + a * uv[j]; const real ri = rv[j] - a * cv[j]; rv[j] = ri; acc += ri * ri; }
       }
       rr = bsum<BS>(acc, red);
       prev = res; res = sqrt(rr); ++kk;
@@ -634,8 +634,8 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     for (int j = 0; j < JM; ++j) {
       const int i = tid + BS * j;
       if (i < m) {
-        const double rh = rhov[j]; const double nv = (rowA(i) - lss[j]) * rh;
-        const double st = (2.0 * sv[j] - wsv[j]) - nv / rh;
+        const real rh = rhov[j]; const real nv = (rowA(i) - lss[j]) * rh;
+        const real st = (R(2.0) * sv[j] - wsv[j]) - nv / rh;
         wsv[j] = wsv[j] + P.alpha * (st - sv[j]);
       }
     }
@@ -646,24 +646,24 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   };
 
   // ---- residuals (residuals.jl:30-96,143-147); x = w_prev[1:n], mu recovered on the fly ------------------------------
-  double rp, mp, rd, md, cost;
-  double muv[JM];
+  real rp, mp, rd, md, cost;
+  real muv[JM];
 #pragma unroll
   for (int j = 0; j < JM; ++j) muv[j] = 0.0;
   auto residuals = [&](bool unscale) {
 #pragma unroll
     for (int j = 0; j < JN; ++j) { const int i = tid + BS * j; if (i < n) xv[i] = wpx[j]; }
     __syncthreads();
-    double a_rp = 0.0, a_mp = 0.0;
+    real a_rp = 0.0, a_mp = 0.0;
 #pragma unroll
     for (int j = 0; j < JM; ++j) {
       const int i = tid + BS * j;
       if (i < m) {
-        const double ax = rowA(i), s0 = sv[j], b0 = bv[j];
+        const real ax = rowA(i), s0 = sv[j], b0 = bv[j];
         muv[j] = rhov[j] * (wps[j] - s0);
         tv[i] = muv[j];
-        double r0 = ax + s0; r0 = r0 - b0;
-        const double e = unscale ? D.Einv[om + i] : 1.0;
+        real r0 = ax + s0; r0 = r0 - b0;
+        const real e = unscale ? D.Einv[om + i] : 1.0;
         if (unscale) r0 = r0 * e;
         a_rp = amax(a_rp, r0);
         a_mp = amax(a_mp, unscale ? ax * e : ax); a_mp = amax(a_mp, unscale ? s0 * e : s0); a_mp = amax(a_mp, unscale ? b0 * e : b0);
@@ -671,22 +671,22 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     }
     rp = bmax<BS>(a_rp, red); mp = bmax<BS>(a_mp, red);
     __syncthreads();
-    double a_rd = 0.0, a_md = 0.0, xpx = 0.0, qx = 0.0;
+    real a_rd = 0.0, a_md = 0.0, xpx = 0.0, qx = 0.0;
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
       const int i = tid + BS * j;
       if (i < n) {
-        const double px = rowP(i), atm = rowAT(i), x0 = wpx[j], q0 = qv[j];
-        double r0 = px + q0; r0 = r0 - atm;
-        double a = px, bq = q0, cm = atm;
-        if (unscale) { const double d = D.Dinv[on + i]; r0 = (r0 * d) * cinv; a = (a * d) * cinv; bq = (bq * d) * cinv; cm = (cm * d) * cinv; }
+        const real px = rowP(i), atm = rowAT(i), x0 = wpx[j], q0 = qv[j];
+        real r0 = px + q0; r0 = r0 - atm;
+        real a = px, bq = q0, cm = atm;
+        if (unscale) { const real d = D.Dinv[on + i]; r0 = (r0 * d) * cinv; a = (a * d) * cinv; bq = (bq * d) * cinv; cm = (cm * d) * cinv; }
         a_rd = amax(a_rd, r0); a_md = amax(a_md, a); a_md = amax(a_md, bq); a_md = amax(a_md, cm);
         xpx += px * x0; qx += q0 * x0;
       }
     }
     rd = bmax<BS>(a_rd, red); md = bmax<BS>(a_md, red);
     xpx = bsum<BS>(xpx, red); qx = bsum<BS>(qx, red);
-    cost = (unscale ? cinv : 1.0) * (0.5 * xpx + qx);
+    cost = (unscale ? cinv : R(1.0)) * (R(0.5) * xpx + qx);
     __syncthreads();
   };
 
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   if (do_init) solve_and_update();                                        // solver.jl:137-138
   long long it = ctl->iter;
   int status = 0;
-  double o_cost = ctl->cost, o_rp = ctl->r_prim, o_rd = ctl->r_dual, o_mp = ctl->max_norm_prim, o_md = ctl->max_norm_dual;
+  real o_cost = ctl->cost, o_rp = ctl->r_prim, o_rd = ctl->r_dual, o_mp = ctl->max_norm_prim, o_md = ctl->max_norm_dual;
   while (it < iter_target && it < P.max_iter) {
     ++it;
     // ---- admm_z!: w_prev = w ; s = Pi(w_s)  (solver.jl:151-152) ----
@@ -705,26 +705,26 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
 #pragma unroll
     for (int j = 0; j < JM; ++j) {
       const int i = tid + BS * j;
-      const double v = wsv[j]; wps[j] = v;
+      const real v = wsv[j]; wps[j] = v;
       const uint32_t kind = metav[j] & 3u;
-      double pv = v;
+      real pv = v;
       if (kind == 1u) pv = 0.0;
-      else if (kind == 2u) pv = (v != v) ? v : ((v > 0.0) ? v : 0.0);
+      else if (kind == 2u) pv = (v != v) ? v : ((v > R(0.0)) ? v : R(0.0));
       else if (kind == 3u) pv = (v < blv[j]) ? blv[j] : ((v > buv[j]) ? buv[j] : v);
       sv[j] = pv;
       if (D.nsoc > 0 && i < m) tv[i] = pv;
     }
     if (D.nsoc > 0) {
       __syncthreads();
-      auto soc_one = [&](double* x, int d) {                              // SecondOrderCone (convexset.jl:100-114), on the LDS copy
+      auto soc_one = [&](real* x, int d) {                              // SecondOrderCone (convexset.jl:100-114), on the LDS copy
         if (d == 0) return;
-        const double t = x[0];
-        double a = 0.0;
-        for (int i = 1 + lane; i < d; i += 64) { const double v = x[i]; a += v * v; }
-        const double nx = sqrt(wave_sum(a));
+        const real t = x[0];
+        real a = 0.0;
+        for (int i = 1 + lane; i < d; i += 64) { const real v = x[i]; a += v * v; }
+        const real nx = sqrt(wave_sum(a));
         if (nx <= t) {
         } else if (nx <= -t) { for (int i = lane; i < d; i += 64) x[i] = 0.0; }
-        else { const double f = (nx + t) / (2.0 * nx); for (int i = 1 + lane; i < d; i += 64) x[i] = f * x[i]; if (lane == 0) x[0] = (nx + t) / 2.0; }
+        else { const real f = (nx + t) / (R(2.0) * nx); for (int i = 1 + lane; i < d; i += 64) x[i] = f * x[i]; if (lane == 0) x[0] = (nx + t) / R(2.0); }
       };
       if (soc_in_regs) {
 #pragma unroll
@@ -740,19 +740,19 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     // ---- apply_rho_adaptation_rules! (solver.jl:242-282, parameters.jl:53-92) ----
     if (P.adaptive_rho && P.adaptive_rho_interval > 0 && (it % P.adaptive_rho_interval) == 0 && (long long)(n_rho - 1) < P.max_adaptions) {
       residuals(false);
-      const double rpn = rp / (mp + 1e-10), rdn = rd / (md + 1e-10);
-      double nr = rho_s * sqrt(rpn / (rdn + 1e-10));
+      const real rpn = rp / (mp + R(1e-10)), rdn = rd / (md + R(1e-10));
+      real nr = rho_s * sqrt(rpn / (rdn + R(1e-10)));
       nr = fmin(fmax(nr, P.rho_min), P.rho_max);
-      const bool adapt = (nr > P.adapt_tol * rho_s) || (nr < (1.0 / P.adapt_tol) * rho_s);
+      const bool adapt = (nr > P.adapt_tol * rho_s) || (nr < (R(1.0) / P.adapt_tol) * rho_s);
       if (adapt) {
 #pragma unroll
         for (int j = 0; j < JM; ++j) {
           const int i = tid + BS * j;
           if (i < m) {
-            const int cc = cls[i]; double r2 = nr;
+            const int cc = cls[i]; real r2 = nr;
             if (cc == 1) r2 = r2 * P.rho_eq; else if (cc == 2) r2 = P.rho_min;
             rhov[j] = r2;
-            wsv[j] = (1.0 / r2) * muv[j] + sv[j];
+            wsv[j] = (R(1.0) / r2) * muv[j] + sv[j];
           }
         }
         if (tid == 0 && n_rho < COSMO_HIP_MAX_RHO_UPDATES) ctl->rho_updates[n_rho] = nr;
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     if ((it % P.check_termination) == 0 || it == 1) {
       residuals(P.unscale != 0);
       int st = 0;
-      if (fabs(cost) > 1e20) st = COSMO_HIP_UNSOLVED;
+      if (fabs(cost) > R(1e20)) st = COSMO_HIP_UNSOLVED;
       else if (rp < P.eps_abs + P.eps_rel * mp && rd < P.eps_abs + P.eps_rel * md &&
                ((P.obj_true != P.obj_true) || fabs(P.obj_true - cost) <= P.obj_true_tol)) st = COSMO_HIP_SOLVED;   // has_converged (residuals.jl:131-139)
       o_cost = cost; o_rp = rp; o_rd = rd; o_mp = mp; o_md = md; status = st;
@@ -801,16 +801,16 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
 }
 
 // warm start (solver.jl:128-129) for all problems
-__global__ __launch_bounds__(COSMO_BS) void k_batch_set_w(BatchDev D, const double* __restrict__ x0, const double* __restrict__ s0,
-                                                          const double* __restrict__ mu0) {
+__global__ __launch_bounds__(COSMO_BS) void k_batch_set_w(BatchDev D, const real* __restrict__ x0, const real* __restrict__ s0,
+                                                          const real* __restrict__ mu0) {
   const long long N = (long long)D.nprob * (D.n + D.m);
   for (long long g = (long long)blockIdx.x * COSMO_BS + threadIdx.x; g < N; g += (long long)gridDim.x * COSMO_BS) {
     const long long k = g / (D.n + D.m); const int i = (int)(g % (D.n + D.m));
     if (i < D.n) D.w[g] = x0 ? x0[k * D.n + i] : 0.0;
     else {
       const long long r = k * D.m + (i - D.n);
-      const double sv = s0 ? s0[r] : 0.0, mv = mu0 ? mu0[r] : 0.0;
-      D.w[g] = (1.0 / D.rho[r]) * mv + sv;
+      const real sv = s0 ? s0[r] : 0.0, mv = mu0 ? mu0[r] : 0.0;
+      D.w[g] = (R(1.0) / D.rho[r]) * mv + sv;
       D.s[r] = sv;
     }
     D.w_prev[g] = D.w[g];
@@ -824,14 +824,14 @@ struct cosmo_hip_batch {
   int device = 0; hipStream_t stream = nullptr; std::string err;
   int nprob = 0; long long n = 0, m = 0;
   std::vector<HostCsr> hA, hAT, hPT;             // staged per problem until finalize
-  std::vector<double> hq, hb;
+  std::vector<real> hq, hb;
   std::vector<char> have;
-  ConeTable cones; std::vector<double> hbox_l, hbox_u; int nbox = 0;
+  ConeTable cones; std::vector<real> hbox_l, hbox_u; int nbox = 0;
   cosmo_hip_params prm;
   bool finalized = false, have_cones = false, have_iterates = false;
   BatchDev D;
   std::vector<void*> allocs;
-  std::vector<double> hDinv, hEinv, hcinv;
+  std::vector<real> hDinv, hEinv, hcinv;
   std::vector<int32_t> cls_host;
   long long iters_done = 0;
   // LDS-resident variant (build_lds_images): one image per problem, dynamic LDS = image + gather vectors + reduction slots
@@ -897,7 +897,7 @@ extern "C" int32_t cosmo_hip_batch_destroy(cosmo_hip_batch* b) {
 extern "C" const char* cosmo_hip_batch_last_error(const cosmo_hip_batch* b) { return b ? b->err.c_str() : "null batch"; }
 
 // CSC (Julia layout) -> host CSR of the matrix and of its transpose (same code path as the single-problem handle)
-static int32_t bcsc(cosmo_hip_batch* b, int64_t nr, int64_t nc, const int64_t* colptr, const int64_t* rowval, const double* nzval,
+static int32_t bcsc(cosmo_hip_batch* b, int64_t nr, int64_t nc, const int64_t* colptr, const int64_t* rowval, const real* nzval,
                     HostCsr& Mt, HostCsr& M) {
   if (colptr[0] != 1) return bfail(b, COSMO_HIP_ERR_INVALID, "colptr must be 1-based");
   const int64_t nnz = colptr[nc] - 1;
@@ -919,8 +919,8 @@ static int32_t bcsc(cosmo_hip_batch* b, int64_t nr, int64_t nc, const int64_t* c
 }
 
 extern "C" int32_t cosmo_hip_batch_set_problem(cosmo_hip_batch* b, int64_t k, const int64_t* P_colptr, const int64_t* P_rowval,
-                                               const double* P_nzval, const int64_t* A_colptr, const int64_t* A_rowval,
-                                               const double* A_nzval, const double* q, const double* bvec) {
+                                               const real* P_nzval, const int64_t* A_colptr, const int64_t* A_rowval,
+                                               const real* A_nzval, const real* q, const real* bvec) {
   if (!b || k < 0 || k >= b->nprob || b->finalized) return bfail(b, COSMO_HIP_ERR_INVALID, "batch_set_problem: bad call");
   const int64_t n = b->n, m = b->m;
   HostCsr Pt, Pm;
@@ -944,7 +944,7 @@ extern "C" int32_t cosmo_hip_batch_set_problem(cosmo_hip_batch* b, int64_t k, co
 
 // same cone structure for every problem; Box bounds are per problem: box_l/box_u have nprob * nbox entries
 extern "C" int32_t cosmo_hip_batch_set_cones(cosmo_hip_batch* b, int64_t ncones, const int32_t* type, const int64_t* dim,
-                                             const double* box_l, const double* box_u) {
+                                             const real* box_l, const real* box_u) {
   if (!b || b->finalized) return bfail(b, COSMO_HIP_ERR_INVALID, "batch_set_cones: bad call");
   ConeTable& C = b->cones; C = ConeTable();
   int64_t off = 0, nbox = 0;
@@ -962,7 +962,7 @@ extern "C" int32_t cosmo_hip_batch_set_cones(cosmo_hip_batch* b, int64_t ncones,
   return COSMO_HIP_OK;
 }
 
-extern "C" int32_t cosmo_hip_batch_set_scaling(cosmo_hip_batch* b, int64_t k, const double* Dinv, const double* Einv, double cinv) {
+extern "C" int32_t cosmo_hip_batch_set_scaling(cosmo_hip_batch* b, int64_t k, const real* Dinv, const real* Einv, double cinv) {
   if (!b || k < 0 || k >= b->nprob || b->finalized) return bfail(b, COSMO_HIP_ERR_INVALID, "batch_set_scaling: bad call");
   if (Dinv) std::copy(Dinv, Dinv + b->n, b->hDinv.begin() + (size_t)k * b->n);
   if (Einv) std::copy(Einv, Einv + b->m, b->hEinv.begin() + (size_t)k * b->m);
@@ -988,7 +988,7 @@ static void brow_blocks(const std::vector<int>& rowptr, int nrows, std::vector<i
 
 static int32_t bmat_upload(cosmo_hip_batch* b, std::vector<HostCsr>& Ms, BMat& out, int nrows, int split_col, bool has_split) {
   std::vector<int> rowptr, col, split, rb, rb_off, nb;
-  std::vector<double> val;
+  std::vector<real> val;
   std::vector<long long> nz_off;
   for (int k = 0; k < b->nprob; ++k) {
     HostCsr& M = Ms[k];
@@ -1052,8 +1052,8 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
     LdsHdr h; memset(&h, 0, sizeof h);
     h.nnzA = (int)nnzA; h.nnzP = (int)nnzP; h.nbA = (int)rA.size() - 1; h.nbAT = (int)rAT.size() - 1; h.nbPT = (int)rPT.size() - 1;
     long long o = up16(sizeof(LdsHdr));
-    h.oAval = (int)o; o = up16(o + 8 * nnzA);
-    h.oPval = (int)o; o = up16(o + 8 * nnzP);
+    h.oAval = (int)o; o = up16(o + (long long)sizeof(real) * nnzA);
+    h.oPval = (int)o; o = up16(o + (long long)sizeof(real) * nnzP);
     h.oRbA = (int)o; o = up16(o + 16LL * h.nbA);
     h.oRbAT = (int)o; o = up16(o + 16LL * h.nbAT);
     h.oRbPT = (int)o; o = up16(o + 16LL * h.nbPT);
@@ -1065,12 +1065,12 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
     h.oPrp = (int)o; o = up16(o + 2 * (n + 1));
     h.oPcol = (int)o; o = up16(o + 2 * nnzP);
     h.bytes = (int)o;
-    if (o + 8 * (n + m) + 8 * (bs / 64) > max_lds) return COSMO_HIP_OK;
+    if (o + (long long)sizeof(real) * (n + m) + (long long)sizeof(real) * (bs / 64) > max_lds) return COSMO_HIP_OK;
     std::vector<unsigned char>& im = imgs[(size_t)k];
     im.assign((size_t)o, 0);
     memcpy(im.data(), &h, sizeof h);
-    double* Aval = reinterpret_cast<double*>(im.data() + h.oAval);
-    double* Pval = reinterpret_cast<double*>(im.data() + h.oPval);
+    real* Aval = reinterpret_cast<real*>(im.data() + h.oAval);
+    real* Pval = reinterpret_cast<real*>(im.data() + h.oPval);
     unsigned short* Arp = reinterpret_cast<unsigned short*>(im.data() + h.oArp);
     unsigned short* Acol = reinterpret_cast<unsigned short*>(im.data() + h.oAcol);
     unsigned short* Trp = reinterpret_cast<unsigned short*>(im.data() + h.oTrp);
@@ -1106,7 +1106,7 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
   for (int k = 0; k < b->nprob; ++k)
     BHIP(b, hipMemcpy(d + (size_t)k * stride, imgs[(size_t)k].data(), imgs[(size_t)k].size(), hipMemcpyHostToDevice));
   b->d_img = d; b->img_stride = stride; b->lds_bs = bs;
-  b->lds_bytes = (int)(stride + 8 * (n + m) + 8 * (bs / 64));
+  b->lds_bytes = (int)(stride + sizeof(real) * (n + m) + sizeof(real) * (bs / 64));
   const void* fn = bs == 256 ? (const void*)k_batch_admm_lds<256> : (bs == 512 ? (const void*)k_batch_admm_lds<512> : (const void*)k_batch_admm_lds<1024>);
   if (b->reg_mode == 1) fn = (const void*)k_batch_admm_reg<512, 1, 2>;
   if (b->reg_mode == 2) fn = (const void*)k_batch_admm_reg<512, 2, 4>;
@@ -1177,7 +1177,7 @@ extern "C" int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hi
     }
   }
   b->cls_host.assign((size_t)nprob * m, 0);
-  const double big = p->cosmo_infty_min_scaling;
+  const real big = p->cosmo_infty_min_scaling;
   for (int k = 0; k < nprob; ++k) {
     long long bp = 0;
     for (size_t c = 0; c < C.type.size(); ++c) {
@@ -1187,17 +1187,17 @@ extern "C" int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hi
       else if (C.type[c] == COSMO_HIP_NONNEG) { for (long long i = 0; i < d; ++i) if (b->hb[(size_t)k * m + o + i] > big) cl[i] = 2; }
       else if (C.type[c] == COSMO_HIP_BOX) {
         for (long long i = 0; i < d; ++i) {
-          const double l = b->hbox_l[(size_t)k * b->nbox + bp + i], u = b->hbox_u[(size_t)k * b->nbox + bp + i];
-          cl[i] = (l < -big && u > big) ? 2 : (((u - l) < p->rho_tol) ? 1 : 0);
+          const real l = b->hbox_l[(size_t)k * b->nbox + bp + i], u = b->hbox_u[(size_t)k * b->nbox + bp + i];
+          cl[i] = (l < -big && u > big) ? 2 : (((u - l) < (real)p->rho_tol) ? 1 : 0);
         }
         bp += d;
       }
     }
   }
-  std::vector<double> rho0((size_t)nprob * m);
+  std::vector<real> rho0((size_t)nprob * m);
   for (size_t i = 0; i < rho0.size(); ++i) {
-    double rv = p->rho;
-    if (b->cls_host[i] == 1) rv = rv * p->rho_eq_over_rho_ineq; else if (b->cls_host[i] == 2) rv = p->rho_min;
+    real rv = p->rho;
+    if (b->cls_host[i] == 1) rv = rv * (real)p->rho_eq_over_rho_ineq; else if (b->cls_host[i] == 2) rv = (real)p->rho_min;
     rho0[i] = rv;
   }
   if ((rc = bup(b, &D.meta, meta))) return rc;
@@ -1214,7 +1214,7 @@ extern "C" int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hi
       (rc = balloc(b, &D.s_tl, Nm)) || (rc = balloc(b, &D.ls_s, Nm)) || (rc = balloc(b, &D.y2, Nm)) || (rc = balloc(b, &D.tmp_m, Nm)) ||
       (rc = balloc(b, &D.nu, Nm)) || (rc = balloc(b, &D.rho, Nm)) || (rc = balloc(b, &D.ls_x, Nn)) || (rc = balloc(b, &D.x_tl, Nn)) ||
       (rc = balloc(b, &D.rhs, Nn)) || (rc = balloc(b, &D.r, Nn)) || (rc = balloc(b, &D.u, Nn)) || (rc = balloc(b, &D.c, Nn))) return rc;
-  BHIP(b, hipMemcpy(D.rho, rho0.data(), Nm * sizeof(double), hipMemcpyHostToDevice));
+  BHIP(b, hipMemcpy(D.rho, rho0.data(), Nm * sizeof(real), hipMemcpyHostToDevice));
   std::vector<BCtl> ctl0(nprob);
   memset(ctl0.data(), 0, sizeof(BCtl) * nprob);
   for (auto& c : ctl0) { c.rho = p->rho; c.n_rho_updates = 1; c.rho_updates[0] = p->rho; c.cost = INFINITY; c.r_prim = INFINITY; c.r_dual = INFINITY; }
@@ -1222,8 +1222,8 @@ extern "C" int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hi
   BHIP(b, hipMemcpy(D.ctl, ctl0.data(), sizeof(BCtl) * nprob, hipMemcpyHostToDevice));
   // tolerance schedule tol_constant / k^tol_exponent (get_tolerance, kktsolver_indirect.jl:168-170), host libm like the large path
   const long long tl = std::min<long long>(std::max<long long>(p->max_iter + 2, 16), 4000000);
-  std::vector<double> tt((size_t)tl);
-  for (long long k = 0; k < tl; ++k) tt[k] = p->tol_constant / pow((double)(k + 1), p->tol_exponent);
+  std::vector<real> tt((size_t)tl);
+  for (long long k = 0; k < tl; ++k) tt[k] = p->tol_constant / pow((real)(k + 1), p->tol_exponent);
   if ((rc = bup(b, &D.tol_table, tt))) return rc;
   D.tol_len = tl;
   b->finalized = true;
@@ -1238,14 +1238,14 @@ extern "C" int32_t cosmo_hip_batch_get_rho_classes(cosmo_hip_batch* b, int64_t k
 }
 
 // x0, s0, mu0: nprob*n, nprob*m, nprob*m (NULL = zeros)
-extern "C" int32_t cosmo_hip_batch_set_iterates(cosmo_hip_batch* b, const double* x0, const double* s0, const double* mu0) {
+extern "C" int32_t cosmo_hip_batch_set_iterates(cosmo_hip_batch* b, const real* x0, const real* s0, const real* mu0) {
   if (!b || !b->finalized) return bfail(b, COSMO_HIP_ERR_INVALID, "batch_set_iterates: set_params first");
   if (hipSetDevice(b->device) != hipSuccess) return bfail(b, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
   const size_t Nn = (size_t)b->nprob * b->n, Nm = (size_t)b->nprob * b->m;
-  double *dx = nullptr, *ds = nullptr, *dm = nullptr;
-  if (x0) { BHIP(b, hipMalloc((void**)&dx, Nn * sizeof(double))); BHIP(b, hipMemcpy(dx, x0, Nn * sizeof(double), hipMemcpyHostToDevice)); }
-  if (s0) { BHIP(b, hipMalloc((void**)&ds, Nm * sizeof(double))); BHIP(b, hipMemcpy(ds, s0, Nm * sizeof(double), hipMemcpyHostToDevice)); }
-  if (mu0) { BHIP(b, hipMalloc((void**)&dm, Nm * sizeof(double))); BHIP(b, hipMemcpy(dm, mu0, Nm * sizeof(double), hipMemcpyHostToDevice)); }
+  real *dx = nullptr, *ds = nullptr, *dm = nullptr;
+  if (x0) { BHIP(b, hipMalloc((void**)&dx, Nn * sizeof(real))); BHIP(b, hipMemcpy(dx, x0, Nn * sizeof(real), hipMemcpyHostToDevice)); }
+  if (s0) { BHIP(b, hipMalloc((void**)&ds, Nm * sizeof(real))); BHIP(b, hipMemcpy(ds, s0, Nm * sizeof(real), hipMemcpyHostToDevice)); }
+  if (mu0) { BHIP(b, hipMalloc((void**)&dm, Nm * sizeof(real))); BHIP(b, hipMemcpy(dm, mu0, Nm * sizeof(real), hipMemcpyHostToDevice)); }
   hipLaunchKernelGGL(k_batch_set_w, dim3(2048), dim3(COSMO_BS), 0, b->stream, b->D, dx, ds, dm);
   BHIP(b, hipStreamSynchronize(b->stream));
   if (dx) (void)hipFree(dx); if (ds) (void)hipFree(ds); if (dm) (void)hipFree(dm);
@@ -1297,9 +1297,9 @@ extern "C" int32_t cosmo_hip_batch_optimize(cosmo_hip_batch* b, cosmo_hip_result
     cosmo_hip_result& r = results[k];
     memset(&r, 0, sizeof r);
     r.status = c[k].status; r.n_rho_updates = c[k].n_rho_updates; r.iter = c[k].iter; r.kkt_iters_total = c[k].kkt_iters_total;
-    r.kkt_solves = c[k].solves; r.cost = c[k].cost; r.r_prim = c[k].r_prim; r.r_dual = c[k].r_dual;
-    r.max_norm_prim = c[k].max_norm_prim; r.max_norm_dual = c[k].max_norm_dual; r.rho = c[k].rho; r.iter_time = el;
-    for (int i = 0; i < COSMO_HIP_MAX_RHO_UPDATES && i < c[k].n_rho_updates; ++i) r.rho_updates[i] = c[k].rho_updates[i];
+    r.kkt_solves = c[k].solves; r.cost = (double)c[k].cost; r.r_prim = (double)c[k].r_prim; r.r_dual = (double)c[k].r_dual;
+    r.max_norm_prim = (double)c[k].max_norm_prim; r.max_norm_dual = (double)c[k].max_norm_dual; r.rho = (double)c[k].rho; r.iter_time = el;
+    for (int i = 0; i < COSMO_HIP_MAX_RHO_UPDATES && i < c[k].n_rho_updates; ++i) r.rho_updates[i] = (double)c[k].rho_updates[i];
   }
   return COSMO_HIP_OK;
 }
@@ -1316,13 +1316,13 @@ extern "C" int32_t cosmo_hip_batch_iterate(cosmo_hip_batch* b, int64_t n_iters, 
 }
 
 // w, w_prev: n+m ; s, mu: m  of problem k
-extern "C" int32_t cosmo_hip_batch_get_iterates(cosmo_hip_batch* b, int64_t k, double* w, double* w_prev, double* s, double* mu) {
+extern "C" int32_t cosmo_hip_batch_get_iterates(cosmo_hip_batch* b, int64_t k, real* w, real* w_prev, real* s, real* mu) {
   if (!b || !b->have_iterates || k < 0 || k >= b->nprob) return bfail(b, COSMO_HIP_ERR_INVALID, "batch_get_iterates: bad call");
   if (hipSetDevice(b->device) != hipSuccess) return bfail(b, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
   const size_t N = (size_t)(b->n + b->m), m = (size_t)b->m;
-  if (w) BHIP(b, hipMemcpy(w, b->D.w + (size_t)k * N, N * sizeof(double), hipMemcpyDeviceToHost));
-  if (w_prev) BHIP(b, hipMemcpy(w_prev, b->D.w_prev + (size_t)k * N, N * sizeof(double), hipMemcpyDeviceToHost));
-  if (s) BHIP(b, hipMemcpy(s, b->D.s + (size_t)k * m, m * sizeof(double), hipMemcpyDeviceToHost));
-  if (mu) BHIP(b, hipMemcpy(mu, b->D.mu + (size_t)k * m, m * sizeof(double), hipMemcpyDeviceToHost));
+  if (w) BHIP(b, hipMemcpy(w, b->D.w + (size_t)k * N, N * sizeof(real), hipMemcpyDeviceToHost));
+  if (w_prev) BHIP(b, hipMemcpy(w_prev, b->D.w_prev + (size_t)k * N, N * sizeof(real), hipMemcpyDeviceToHost));
+  if (s) BHIP(b, hipMemcpy(s, b->D.s + (size_t)k * m, m * sizeof(real), hipMemcpyDeviceToHost));
+  if (mu) BHIP(b, hipMemcpy(mu, b->D.mu + (size_t)k * m, m * sizeof(real), hipMemcpyDeviceToHost));
   return COSMO_HIP_OK;
 }

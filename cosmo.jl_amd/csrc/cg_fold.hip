@@ -26,11 +26,11 @@
 struct FoldPlan {
   int slots = 8;            // nonzero slots per thread of k_cg_dirM (tile <= slots * 256)
   CsrDev M;                 // n x n; M.val is rewritten by k_fold_refresh
-  double* base = nullptr;   // nnz(M): P_ij (0 where P has no entry)
+  real* base = nullptr;   // nnz(M): P_ij (0 where P has no entry)
   int* drow = nullptr;      // nnz(M): row index for diagonal entries, -1 otherwise
   int* tptr = nullptr;      // nnz(M)+1: terms of entry p are [tptr[p], tptr[p+1])
   int* trow = nullptr;      // term -> row of Am
-  double* tprod = nullptr;  // term -> a_ki * a_kj
+  real* tprod = nullptr;  // term -> a_ki * a_kj
   long long nterms = 0;
 };
 
@@ -47,12 +47,12 @@ static inline int ew_grid(long long N) {
 // ---------------------------------------------------------------------------------------------------------------------
 // values of M from rho: one thread per stored entry, terms added in their stored (Am-row ascending) order
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(COSMO_BS) void k_fold_refresh(long long nnz, const double* __restrict__ base, const int* __restrict__ drow,
+__global__ __launch_bounds__(COSMO_BS) void k_fold_refresh(long long nnz, const real* __restrict__ base, const int* __restrict__ drow,
                                                            const int* __restrict__ tptr, const int* __restrict__ trow,
-                                                           const double* __restrict__ tprod, const double* __restrict__ rho_m,
-                                                           const double* __restrict__ diag, double sigma, double* __restrict__ val) {
+                                                           const real* __restrict__ tprod, const real* __restrict__ rho_m,
+                                                           const real* __restrict__ diag, real sigma, real* __restrict__ val) {
   for (long long p = (long long)blockIdx.x * COSMO_BS + threadIdx.x; p < nnz; p += (long long)gridDim.x * COSMO_BS) {
-    double s = 0.0;
+    real s = 0.0;
     for (int t = tptr[p]; t < tptr[p + 1]; ++t) s += rho_m[trow[t]] * tprod[t];
     const int i = drow[p];
     val[p] = (i >= 0) ? base[p] + ((sigma + diag[i]) + s) : base[p] + s;
@@ -63,27 +63,27 @@ __global__ __launch_bounds__(COSMO_BS) void k_fold_refresh(long long nnz, const 
 // solve start: r = rhs - M x (x = warm start), {r, 0} records for the first direction, partials of r'r, abstol = tol_k / ||rhs||
 // (kktsolver_indirect.jl:70 ; cg! computes the initial residual with one operator application)
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(COSMO_BS) void k_fold_start(Ctl* __restrict__ ctl, int guard, CsrView M, const double* __restrict__ x,
-                                                         const double* __restrict__ rhs, double* __restrict__ r, double2* __restrict__ ru,
-                                                         double* __restrict__ part_rr, const double* __restrict__ part_bb, int n_bb, double tol_k) {
+__global__ __launch_bounds__(COSMO_BS) void k_fold_start(Ctl* __restrict__ ctl, int guard, CsrView M, const real* __restrict__ x,
+                                                         const real* __restrict__ rhs, real* __restrict__ r, real2* __restrict__ ru,
+                                                         real* __restrict__ part_rr, const real* __restrict__ part_bb, int n_bb, real tol_k) {
   if (guard && ctl->halt) return;
-  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
-  __shared__ double red[COSMO_BS / 64];
+  __shared__ real lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ real red[COSMO_BS / 64];
   if (blockIdx.x == 0) {
-    const double bb = reduce_partials_sum(part_bb, n_bb, red);
+    const real bb = reduce_partials_sum(part_bb, n_bb, red);
     if (threadIdx.x == 0) {
-      const double nb = sqrt(bb);
+      const real nb = sqrt(bb);
       ctl->rhs_norm = nb;
       ctl->tol = tol_k / nb;
     }
   }
-  double acc = 0.0;
+  real acc = 0.0;
   const int first_tile = tile_of_block(blockIdx.x, M.nb, M.xcd_affine);
   for (int k = first_tile; k < M.nb; k += gridDim.x) {
-    csr_stream_tile(M, x, x, k, lds, red, [&](int row, double s1, double s2) {
-      const double rj = rhs[row] - (s1 + s2);
+    csr_stream_tile(M, x, x, k, lds, red, [&](int row, real s1, real s2) {
+      const real rj = rhs[row] - (s1 + s2);
       r[row] = rj;
-      ru[row] = make_double2(rj, 0.0);
+      ru[row] = make_real2(rj, 0.0);
       acc += rj * rj;
     });
   }
@@ -102,23 +102,23 @@ __global__ __launch_bounds__(COSMO_BS) void k_fold_start(Ctl* __restrict__ ctl, 
 // longer single row takes the generic path).
 template <int SL>
 __global__ __launch_bounds__(COSMO_BS) void k_cg_dirM(Ctl* __restrict__ ctl, int guard, int k, long long n, long long maxiter,
-                                                      const double* __restrict__ part_rr, int n_rr, CsrView M, const double2* __restrict__ ru,
-                                                      double* __restrict__ c, double* __restrict__ u, double* __restrict__ part_uc) {
-  const double pa = partials_prefetch_sum(part_rr, n_rr);
+                                                      const real* __restrict__ part_rr, int n_rr, CsrView M, const real2* __restrict__ ru,
+                                                      real* __restrict__ c, real* __restrict__ u, real* __restrict__ part_uc) {
+  const real pa = partials_prefetch_sum(part_rr, n_rr);
   const int first_tile = tile_of_block(blockIdx.x, M.nb, M.xcd_affine);
   const bool have_tile = first_tile < M.nb;
   int4 d = make_int4(0, 0, 0, 0);
   if (have_tile) d = reinterpret_cast<const int4*>(M.rb)[first_tile];
   const int cnt0 = d.w - d.z;
   const bool fast = have_tile && cnt0 <= SL * COSMO_BS;            // a single long row takes the generic chunked path below
-  double av[SL]; double2 gv[SL];
+  real av[SL]; real2 gv[SL];
 #pragma unroll
   for (int it = 0; it < SL; ++it) {
     const int kk = it * COSMO_BS + threadIdx.x;
     const bool ok = fast && kk < cnt0;
     const int e = ok ? d.z + kk : 0;
     const int cc = M.col[e];
-    const double a = M.val[e];
+    const real a = M.val[e];
     av[it] = ok ? a : 0.0;
     gv[it] = ru[cc];
   }
@@ -126,30 +126,30 @@ __global__ __launch_bounds__(COSMO_BS) void k_cg_dirM(Ctl* __restrict__ ctl, int
   const bool rowok = fast && rfirst < d.y;
   const int rr_ = rowok ? rfirst : 0;
   const int pa_ = M.rowptr[rr_], pb_ = M.rowptr[rr_ + 1];
-  const double2 rw = ru[rr_];                                       // {r, u_{k-1}} of this thread's row: u_k of the row for u'c
+  const real2 rw = ru[rr_];                                       // {r, u_{k-1}} of this thread's row: u_k of the row for u'c
   const long long i0 = (long long)blockIdx.x * COSMO_BS + threadIdx.x;
-  const double2 own = ru[i0 < n ? i0 : 0];
+  const real2 own = ru[i0 < n ? i0 : 0];
   if (guard && ctl->halt) return;
   if (ctl->cg_done) return;
-  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
-  __shared__ double red[COSMO_BS / 64];
-  const double tol = ctl->tol;
-  const double prev = (k == 0) ? 1.0 : ctl->resv[(k - 1) & 1];
-  const double rr = block_sum(pa, red);
-  const double res = sqrt(rr);
+  __shared__ real lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ real red[COSMO_BS / 64];
+  const real tol = ctl->tol;
+  const real prev = (k == 0) ? 1.0 : ctl->resv[(k - 1) & 1];
+  const real rr = block_sum(pa, red);
+  const real res = sqrt(rr);
   const bool done = (k >= maxiter) || (res <= tol);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (done) ctl->cg_done = 1;
     ctl->resv[k & 1] = res;
   }
   if (done) return;
-  const double beta = (res * res) / (prev * prev);
+  const real beta = (res * res) / (prev * prev);
   if (i0 < n) u[i0] = own.x + beta * own.y;
   for (long long i = i0 + (long long)gridDim.x * COSMO_BS; i < n; i += (long long)gridDim.x * COSMO_BS) {
-    const double2 v = ru[i];
+    const real2 v = ru[i];
     u[i] = v.x + beta * v.y;
   }
-  double acc = 0.0;
+  real acc = 0.0;
   if (fast) {
 #pragma unroll
     for (int it = 0; it < SL; ++it) {
@@ -158,13 +158,13 @@ __global__ __launch_bounds__(COSMO_BS) void k_cg_dirM(Ctl* __restrict__ ctl, int
     }
     __syncthreads();
     if (rowok) {                                    // first row of this thread: pointers and its own record already here
-      const double cj = lds_seq_sum(lds, pa_ - d.z, pb_ - d.z);
+      const real cj = lds_seq_sum(lds, pa_ - d.z, pb_ - d.z);
       c[rfirst] = cj;
       acc += (rw.x + beta * rw.y) * cj;
     }
     for (int r = rfirst + COSMO_BS; r < d.y; r += COSMO_BS) {
-      const double cj = lds_seq_sum(lds, M.rowptr[r] - d.z, M.rowptr[r + 1] - d.z);
-      const double2 v = ru[r];
+      const real cj = lds_seq_sum(lds, M.rowptr[r] - d.z, M.rowptr[r + 1] - d.z);
+      const real2 v = ru[r];
       c[r] = cj;
       acc += (v.x + beta * v.y) * cj;
     }
@@ -172,10 +172,10 @@ __global__ __launch_bounds__(COSMO_BS) void k_cg_dirM(Ctl* __restrict__ ctl, int
   }
   for (int t = fast ? first_tile + (int)gridDim.x : first_tile; t < M.nb; t += gridDim.x) {
     const int4 dd = reinterpret_cast<const int4*>(M.rb)[t];
-    csr_stream_rows_g(M, [&](int cc) { const double2 v = ru[cc]; return v.x + beta * v.y; }, dd.x, dd.y, dd.z, dd.w, lds, red,
-                      [&](int r, double s1, double s2) {
-                        const double cj = s1 + s2;
-                        const double2 v = ru[r];
+    csr_stream_rows_g(M, [&](int cc) { const real2 v = ru[cc]; return v.x + beta * v.y; }, dd.x, dd.y, dd.z, dd.w, lds, red,
+                      [&](int r, real s1, real s2) {
+                        const real cj = s1 + s2;
+                        const real2 v = ru[r];
                         c[r] = cj;
                         acc += (v.x + beta * v.y) * cj;
                       });
@@ -211,7 +211,7 @@ static int32_t up(cosmo_hip_handle* h, T** dst, const std::vector<T>& v) {
 // Am: the multi-nonzero rows of A (compact, columns ascending within a row); (prp, pcol, pval): CSR of P.  Called at the end of
 // build_op_split (the split is active and rho_m / diag exist on the device).
 int32_t fold_build(cosmo_hip_handle* h, const HostCsr& Am, const std::vector<int>& prp, const std::vector<int>& pcol,
-                   const std::vector<double>& pval) {
+                   const std::vector<real>& pval) {
   fold_free(h);
   if (const char* e = getenv("COSMO_HIP_OP_FOLD")) if (e[0] == '0') return COSMO_HIP_OK;
   if (!h->op_split || h->cg_sr || h->n <= 0 || !h->cg_ru) return COSMO_HIP_OK;
@@ -230,22 +230,22 @@ int32_t fold_build(cosmo_hip_handle* h, const HostCsr& Am, const std::vector<int
   for (int cidx : Am.col) tp[(size_t)cidx + 1]++;
   for (long long j = 0; j < n; ++j) tp[j + 1] += tp[j];
   std::vector<int> trw(Am.col.size());
-  std::vector<double> tvl(Am.col.size());
+  std::vector<real> tvl(Am.col.size());
   { std::vector<int> pos(tp.begin(), tp.end() - 1);
     for (int r = 0; r < mm; ++r) for (int k = Am.rowptr[r]; k < Am.rowptr[r + 1]; ++k) { const int p = pos[Am.col[k]]++; trw[p] = r; tvl[p] = Am.val[k]; } }
   HostCsr M;
   M.nrows = (int)n; M.ncols = (int)n; M.rowptr.assign((size_t)n + 1, 0);
-  std::vector<double> base;
+  std::vector<real> base;
   std::vector<int> drow, tptr, trow;
-  std::vector<double> tprod;
+  std::vector<real> tprod;
   tptr.push_back(0);
-  struct Term { int j, k; double prod; };
+  struct Term { int j, k; real prod; };
   std::vector<Term> terms;
   for (long long i = 0; i < n; ++i) {
     terms.clear();
     for (int q = tp[i]; q < tp[i + 1]; ++q) {
       const int k = trw[q];
-      const double aki = tvl[q];
+      const real aki = tvl[q];
       for (int p = Am.rowptr[k]; p < Am.rowptr[k + 1]; ++p) terms.push_back({Am.col[p], k, aki * Am.val[p]});
     }
     std::sort(terms.begin(), terms.end(), [](const Term& a, const Term& b) { return a.j != b.j ? a.j < b.j : a.k < b.k; });
@@ -260,7 +260,7 @@ int32_t fold_build(cosmo_hip_handle* h, const HostCsr& Am, const std::vector<int
       if (ip < ipe) j = std::min(j, pcol[ip]);
       if (!diag_done) j = std::min(j, (int)i);
       if (j == INT32_MAX) break;
-      double b = 0.0;
+      real b = 0.0;
       if (ip < ipe && pcol[ip] == j) { b = pval[ip]; ++ip; }
       while (it < terms.size() && terms[it].j == j) { trow.push_back(terms[it].k); tprod.push_back(terms[it].prod); ++it; }
       if (j == (int)i) diag_done = true;
@@ -296,11 +296,11 @@ int32_t fold_refresh(cosmo_hip_handle* h) {
   return COSMO_HIP_OK;
 }
 
-int32_t fold_enqueue_start(cosmo_hip_handle* h, int guard, double tol_k) {
+int32_t fold_enqueue_start(cosmo_hip_handle* h, int guard, real tol_k) {
   FoldPlan* f = (FoldPlan*)h->fold;
   prof_begin(h, KC_OP_APPLY);
   hipLaunchKernelGGL(k_fold_start, dim3(f->M.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, view_of(f->M), h->x_tl, h->rhs, h->r,
-                     (double2*)h->cg_ru, PARTS(h, SLOT_RR), PARTS(h, SLOT_BB), h->AT.grid, tol_k);
+                     (real2*)h->cg_ru, PARTS(h, SLOT_RR), PARTS(h, SLOT_BB), h->AT.grid, tol_k);
   prof_end(h);
   h->spmv_calls[0] += 1; h->spmv_calls[1] += 1; h->spmv_calls[2] += 1;     // the reference's multiplication count (reduced_mul! = A, A', P)
   HIPCHK(h, hipGetLastError());
@@ -315,7 +315,7 @@ int32_t fold_enqueue_iterations(cosmo_hip_handle* h, int guard, int k_begin, int
     prof_begin(h, KC_OP_APPLY);
     const int n_rr = (k == 0) ? f->M.grid : gE;
 #define LAUNCH_DIRM(SLN) hipLaunchKernelGGL((k_cg_dirM<SLN>), dim3(f->M.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, k, n, n, \
-                         PARTS(h, SLOT_RR), n_rr, view_of(f->M), (const double2*)h->cg_ru, h->c, h->u, PARTS(h, SLOT_UC))
+                         PARTS(h, SLOT_RR), n_rr, view_of(f->M), (const real2*)h->cg_ru, h->c, h->u, PARTS(h, SLOT_UC))
     switch (f->slots) {
       case 1: LAUNCH_DIRM(1); break;
       case 2: LAUNCH_DIRM(2); break;

@@ -35,11 +35,11 @@
 
 struct PcgArgs {
   CsrView A, PT;                 // operator pieces (Am / [P | Am'] when the operator is split)
-  const double* rho;             // rho on A's rows
-  const double* diag;            // diagonal part of A' rho A (split operator) or null
-  double sigma;
-  double *x, *r, *c, *tmp, *u0, *u1;
-  double *part_rr, *part_uc;
+  const real* rho;             // rho on A's rows
+  const real* diag;            // diagonal part of A' rho A (split operator) or null
+  real sigma;
+  real *x, *r, *c, *tmp, *u0, *u1;
+  real *part_rr, *part_uc;
   int n_rr0;                     // number of r'r partials left by the solve-start kernel
   int nvec;                      // vector blocks of 256 elements
   long long n, maxiter;
@@ -49,10 +49,10 @@ struct PcgArgs {
   int guard;
 };
 
-__device__ __forceinline__ double ld2(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ real ld2(const real* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // indexed form with an UNSIGNED 32-bit index: lets the backend use the scalar-base + 32-bit vector-offset addressing mode instead of
 // keeping a 64-bit VGPR address per gather alive (the kernel is VGPR-bound)
-__device__ __forceinline__ double ld2i(const double* base, unsigned idx) {
+__device__ __forceinline__ real ld2i(const real* base, unsigned idx) {
   asm volatile("" : "+v"(idx));        // opaque: the 64-bit address is rebuilt at the use (2 VALU ops) instead of being hoisted out of the Krylov loop
   return __hip_atomic_load(base + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -60,19 +60,19 @@ __device__ __forceinline__ unsigned opaque(int idx) { unsigned u = (unsigned)idx
 __device__ __forceinline__ unsigned ld2u(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // block_sum of device_utils.h for the 256 threads of one quarter (tq = thread index in the quarter, red_q = 4 doubles of the quarter)
-__device__ __forceinline__ double q_sum(double v, double* red_q, int tq) {
+__device__ __forceinline__ real q_sum(real v, real* red_q, int tq) {
   v = wave_sum(v);
   __syncthreads();
   if ((tq & 63) == 0) red_q[tq >> 6] = v;
   __syncthreads();
-  double t = 0.0;
+  real t = 0.0;
 #pragma unroll
   for (int i = 0; i < COSMO_BS / 64; ++i) t += red_q[i];
   return t;
 }
 // reduce_partials_sum of device_utils.h; the partials were written by other workgroups: sc1 loads
-__device__ __forceinline__ double q_reduce_partials(const double* p, int count, double* red_q, int tq) {
-  double a = 0.0;
+__device__ __forceinline__ real q_reduce_partials(const real* p, int count, real* red_q, int tq) {
+  real a = 0.0;
   for (int i = tq; i < count; i += COSMO_BS) a += ld2(p + i);
   return q_sum(a, red_q, tq);
 }
@@ -101,7 +101,7 @@ __device__ __forceinline__ bool pcg_barrier(unsigned* sync, unsigned target, int
 
 // sum of the four wave sums in order, for NT independent reductions at once (one barrier pair): the tree of block_sum
 template <int NT>
-__device__ __forceinline__ void q_sum_multi(double (&v)[NT], double* red_q, int tq) {
+__device__ __forceinline__ void q_sum_multi(real (&v)[NT], real* red_q, int tq) {
 #pragma unroll
   for (int j = 0; j < NT; ++j) v[j] = wave_sum(v[j]);
   __syncthreads();
@@ -112,7 +112,7 @@ __device__ __forceinline__ void q_sum_multi(double (&v)[NT], double* red_q, int 
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    double t = 0.0;
+    real t = 0.0;
 #pragma unroll
     for (int i = 0; i < COSMO_BS / 64; ++i) t += red_q[4 * j + i];
     v[j] = t;
@@ -123,10 +123,10 @@ template <int PCG_TA, int PCG_TP, int PCG_TV>
 __global__ __launch_bounds__(PCG_THREADS) void k_cg_persist(Ctl* __restrict__ ctl, PcgArgs a) {
   // LDS: per quarter PCG_TP * PCG_TILE staged products and 4 * PCG_TP reduction slots; then 2 ints
   constexpr int PCG_TS = PCG_TA > PCG_TP ? PCG_TA : PCG_TP;
-  __shared__ double s_stage[PCG_Q][PCG_TS][PCG_TILE];
-  __shared__ double s_red[PCG_Q][4 * (PCG_TS > PCG_TV ? PCG_TS : PCG_TV)];
+  __shared__ real s_stage[PCG_Q][PCG_TS][PCG_TILE];
+  __shared__ real s_red[PCG_Q][4 * (PCG_TS > PCG_TV ? PCG_TS : PCG_TV)];
   // per-thread constants of the solve (matrix values, rho, diag) live in LDS, not in VGPRs: [slot][thread], conflict-free
-  __shared__ double s_aval[PCG_TA][PCG_THREADS], s_pval[PCG_TP][PCG_THREADS];     // rho / diag of the owned rows: plain (L1-cached) loads
+  __shared__ real s_aval[PCG_TA][PCG_THREADS], s_pval[PCG_TP][PCG_THREADS];     // rho / diag of the owned rows: plain (L1-cached) loads
   __shared__ int s_int[2];                 // [0] participant rank, [1] abort flag
   if (threadIdx.x == 0) {
     int rank = -1;
@@ -158,12 +158,12 @@ __global__ __launch_bounds__(PCG_THREADS) void k_cg_persist(Ctl* __restrict__ ct
     return;
   }
   const int q = threadIdx.x >> 8, tq = threadIdx.x & 255;
-  double* red_q = s_red[q];
+  real* red_q = s_red[q];
   const int vq = wg * PCG_Q + q;                 // virtual workgroup id of this quarter
   const int nq = a.W * PCG_Q;
   const long long n = a.n;
-  const double tol = ctl->tol;
-  const double sigma = a.sigma;
+  const real tol = ctl->tol;
+  const real sigma = a.sigma;
 
   // ---- the quarter's share of the operator, loaded once (rho / diag are constant during a solve) -------------------------
   // Clamped indices: EVERY load of the loop is unconditional (an absent nonzero / row / element reads entry 0 and is discarded by a
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(PCG_THREADS) void k_cg_persist(Ctl* __restrict__ ct
 #pragma unroll
   for (int j = 0; j < PCG_TA; ++j) {
     acolc[j] = 0u; arowc[j] = 0u; aoff[j] = 0;
-    double aval = 0.0;
+    real aval = 0.0;
     const int tile = vq + j * nq;
     if (tile < a.A.nb) {
       const int4 d = reinterpret_cast<const int4*>(a.A.rb)[tile];
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(PCG_THREADS) void k_cg_persist(Ctl* __restrict__ ct
 #pragma unroll
   for (int j = 0; j < PCG_TP; ++j) {
     pcolc[j] = 0u; prowc[j] = 0u; poff[j] = 0;
-    double pval = 0.0;
+    real pval = 0.0;
     const int tile = vq + j * nq;
     if (tile < a.PT.nb) {
       const int4 d = reinterpret_cast<const int4*>(a.PT.rb)[tile];
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(PCG_THREADS) void k_cg_persist(Ctl* __restrict__ ct
     s_pval[j][threadIdx.x] = pval;
   }
   // owned vector elements: x, r, u live in registers for the whole solve (r and u are also stored for the other workgroups' gathers)
-  double vx[PCG_TV], vr[PCG_TV], vu[PCG_TV];
+  real vx[PCG_TV], vr[PCG_TV], vu[PCG_TV];
 #pragma unroll
   for (int j = 0; j < PCG_TV; ++j) {
     const int vb = vq + j * nq;
@@ -212,9 +212,9 @@ __global__ __launch_bounds__(PCG_THREADS) void k_cg_persist(Ctl* __restrict__ ct
     vic[j] = 0u; vx[j] = 0.0; vr[j] = 0.0; vu[j] = 0.0;
     if (vb < a.nvec && i0 < n) { vic[j] = (unsigned)i0; valid |= 1u << (16 + j); vx[j] = a.x[i0]; vr[j] = a.r[i0]; }
   }
-  double* uold = a.u0;
-  double* unew = a.u1;
-  double prev = 1.0;
+  real* uold = a.u0;
+  real* unew = a.u1;
+  real prev = 1.0;
   int n_rr = a.n_rr0;
   unsigned bar = 0;
   int k = 0;
@@ -226,24 +226,24 @@ __global__ __launch_bounds__(PCG_THREADS) void k_cg_persist(Ctl* __restrict__ ct
 #endif
   const int split_col = a.PT.split_col;
   const bool has_diag = a.diag != nullptr;
-  const double* diagp = has_diag ? a.diag : a.rho;      // a valid address either way; the value is discarded when there is no diagonal
+  const real* diagp = has_diag ? a.diag : a.rho;      // a valid address either way; the value is discarded when there is no diagonal
   for (;; ++k) {
     // ---- loads of the first phase, all in flight together: r'r partials, gathers of r and u_{k-1}, rho of the owned rows ----------
-    double gr[PCG_TA], gu[PCG_TA], rh[PCG_TA];
+    real gr[PCG_TA], gu[PCG_TA], rh[PCG_TA];
 #pragma unroll
     for (int j = 0; j < PCG_TA; ++j) { gr[j] = ld2i(a.r, acolc[j]); gu[j] = ld2i(uold, acolc[j]); rh[j] = a.rho[arowc[j]]; }
-    double pa = 0.0;
+    real pa = 0.0;
     for (int i = tq; i < n_rr; i += COSMO_BS) pa += ld2(a.part_rr + i);
     // ---- k_cg_dir: residual norm, stopping rule (checked BEFORE the iteration), beta --------------------------------
-    const double rr = q_sum(pa, red_q, tq);
-    const double res = sqrt(rr);
+    const real rr = q_sum(pa, red_q, tq);
+    const real res = sqrt(rr);
     const bool done = ((long long)k >= a.maxiter) || (res <= tol);
     if (wg == 0 && threadIdx.x == 0) {
       ctl->resv[k & 1] = res;
       if (done) { ctl->cg_done = 1; ctl->cg_k = k; }
     }
     if (done) break;
-    const double beta = (res * res) / (prev * prev);
+    const real beta = (res * res) / (prev * prev);
     PCG_MARK(0)
     // direction update on the owned elements (stored for the gathers of the operator kernel and of the next iteration)
 #pragma unroll
@@ -254,13 +254,13 @@ __global__ __launch_bounds__(PCG_THREADS) void k_cg_persist(Ctl* __restrict__ ct
     // ---- k_spmv_A_rho: tmp = rho .* (A u), u recomputed at the gathered columns (same expression as the owner's) -------
 #pragma unroll
     for (int j = 0; j < PCG_TA; ++j) {
-      const double u0 = (k > 0) ? gu[j] : 0.0;
+      const real u0 = (k > 0) ? gu[j] : 0.0;
       s_stage[q][j][tq] = s_aval[j][threadIdx.x] * (gr[j] + beta * u0);       // absent nonzero: value 0 in a slot no row reads
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < PCG_TA; ++j) {
-      double s1 = 0.0, s2 = 0.0;
+      real s1 = 0.0, s2 = 0.0;
       for (int e = aoff[j] & 0xFFFF; e < (aoff[j] >> 16); ++e) s1 += s_stage[q][j][e];
       if (valid & (1u << j)) a.tmp[arowc[j]] = (s1 + s2) * rh[j];
     }
@@ -269,11 +269,11 @@ __global__ __launch_bounds__(PCG_THREADS) void k_cg_persist(Ctl* __restrict__ ct
     if (!pcg_barrier(a.sync, bar, s_int + 1)) break;
     PCG_MARK(2)
     // ---- k_op_apply (mode 1): c = P u + (sigma u + A' tmp) [+ diag .* u], partials of u'c -----------------------------
-    double gp[PCG_TP], gv[PCG_TP], dg[PCG_TP], acc[PCG_TP];
+    real gp[PCG_TP], gv[PCG_TP], dg[PCG_TP], acc[PCG_TP];
 #pragma unroll
     for (int j = 0; j < PCG_TP; ++j) {
       const bool left = (int)pcolc[j] < split_col;
-      const double* base = left ? unew : a.tmp;
+      const real* base = left ? unew : a.tmp;
       const unsigned idx = left ? pcolc[j] : pcolc[j] - (unsigned)split_col;
       gp[j] = ld2i(base, idx);
       gv[j] = ld2i(unew, prowc[j]);
@@ -284,16 +284,16 @@ __global__ __launch_bounds__(PCG_THREADS) void k_cg_persist(Ctl* __restrict__ ct
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < PCG_TP; ++j) {
-      double s1 = 0.0, s2 = 0.0;
+      real s1 = 0.0, s2 = 0.0;
       const int lo = poff[j] & 0x3FF, sp = (poff[j] >> 10) & 0x3FF, hi = poff[j] >> 20;
       for (int e = lo; e < sp; ++e) s1 += s_stage[q][j][e];
       for (int e = sp; e < hi; ++e) s2 += s_stage[q][j][e];
-      const double vj = gv[j];
-      double cj = s1 + (sigma * vj + s2);
-      const double cd = cj + dg[j] * vj;
+      const real vj = gv[j];
+      real cj = s1 + (sigma * vj + s2);
+      const real cd = cj + dg[j] * vj;
       cj = has_diag ? cd : cj;
       if (valid & (1u << (8 + j))) a.c[prowc[j]] = cj;
-      const double t = 0.0 + vj * cj;
+      const real t = R(0.0) + vj * cj;
       acc[j] = (valid & (1u << (8 + j))) ? t : 0.0;
     }
     q_sum_multi<PCG_TP>(acc, red_q, tq);
@@ -306,21 +306,21 @@ __global__ __launch_bounds__(PCG_THREADS) void k_cg_persist(Ctl* __restrict__ ct
     if (!pcg_barrier(a.sync, bar, s_int + 1)) break;
     PCG_MARK(4)
     // ---- k_cg_upd: alpha ; x += alpha u ; r -= alpha c ; partials of r'r ------------------------------------------------
-    double c0[PCG_TV];
+    real c0[PCG_TV];
 #pragma unroll
     for (int j = 0; j < PCG_TV; ++j) c0[j] = ld2i(a.c, vic[j]);
-    double pu = 0.0;
+    real pu = 0.0;
     for (int i = tq; i < a.PT.nb; i += COSMO_BS) pu += ld2(a.part_uc + i);
-    const double uc = q_sum(pu, red_q, tq);
-    const double alpha = (res * res) / uc;
-    double racc[PCG_TV];
+    const real uc = q_sum(pu, red_q, tq);
+    const real alpha = (res * res) / uc;
+    real racc[PCG_TV];
 #pragma unroll
     for (int j = 0; j < PCG_TV; ++j) {
       vx[j] = vx[j] + alpha * vu[j];
-      const double ri = vr[j] - alpha * c0[j];
+      const real ri = vr[j] - alpha * c0[j];
       vr[j] = (valid & (1u << (16 + j))) ? ri : 0.0;
       if (valid & (1u << (16 + j))) a.r[vic[j]] = ri;
-      const double t = 0.0 + ri * ri;
+      const real t = R(0.0) + ri * ri;
       racc[j] = (valid & (1u << (16 + j))) ? t : 0.0;
     }
     q_sum_multi<PCG_TV>(racc, red_q, tq);
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(PCG_THREADS) void k_cg_persist(Ctl* __restrict__ ct
     if (!pcg_barrier(a.sync, bar, s_int + 1)) break;
     PCG_MARK(6)
     prev = res;
-    double* t = uold; uold = unew; unew = t;
+    real* t = uold; uold = unew; unew = t;
   }
   // the iterate (register-resident during the solve) and the last direction (the multi-kernel path may resume from them)
 #pragma unroll
@@ -389,9 +389,9 @@ int32_t pcg_setup(cosmo_hip_handle* h) {
   h->pcg_cap = variant;
   h->pcg_smem = 0;
   HIPCHK(h, hipMalloc((void**)&h->pcg_sync, 16 * sizeof(unsigned)));
-  HIPCHK(h, hipMalloc((void**)&h->pcg_u2, sizeof(double) * (size_t)std::max<long long>(h->n, 1)));
+  HIPCHK(h, hipMalloc((void**)&h->pcg_u2, sizeof(real) * (size_t)std::max<long long>(h->n, 1)));
   HIPCHK(h, hipMemset(h->pcg_sync, 0, 16 * sizeof(unsigned)));
-  HIPCHK(h, hipMemset(h->pcg_u2, 0, sizeof(double) * (size_t)std::max<long long>(h->n, 1)));
+  HIPCHK(h, hipMemset(h->pcg_u2, 0, sizeof(real) * (size_t)std::max<long long>(h->n, 1)));
   h->pcg_on = true;
   return COSMO_HIP_OK;
 }

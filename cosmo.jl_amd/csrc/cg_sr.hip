@@ -21,23 +21,23 @@
 // it saves) -- hence opt-in, and the literal recurrence stays the default everywhere.
 #include "device_utils.h"
 
-struct SrRec { double r, w, s, p; };   // 32 bytes, one per variable
+struct SrRec { real r, w, s, p; };   // 32 bytes, one per variable
 
 #define PARTS(h, slot) ((h)->partials + (size_t)(slot) * COSMO_MAX_PARTIALS)
 
 // gamma / delta partials -> scalars of iteration k; returns false when the solve is (or has just been found) finished
-struct SrScalars { double res, alpha, beta; };
-__device__ __forceinline__ bool sr_scalars(Ctl* __restrict__ ctl, int k, long long maxiter, double pg, double pd, double* red, SrScalars& o) {
-  const double tol = ctl->tol;
-  const double g_old = (k > 0) ? ctl->sr_gamma[(k - 1) & 1] : 1.0;
-  const double a_old = (k > 0) ? ctl->sr_alpha[(k - 1) & 1] : 1.0;
-  const double g = block_sum(pg, red);
-  const double d = block_sum(pd, red);
-  const double res = sqrt(g);
+struct SrScalars { real res, alpha, beta; };
+__device__ __forceinline__ bool sr_scalars(Ctl* __restrict__ ctl, int k, long long maxiter, real pg, real pd, real* red, SrScalars& o) {
+  const real tol = ctl->tol;
+  const real g_old = (k > 0) ? ctl->sr_gamma[(k - 1) & 1] : 1.0;
+  const real a_old = (k > 0) ? ctl->sr_alpha[(k - 1) & 1] : 1.0;
+  const real g = block_sum(pg, red);
+  const real d = block_sum(pd, red);
+  const real res = sqrt(g);
   const bool done = (k >= maxiter) || (res <= tol);
   o.res = res;
   o.beta = (k > 0) ? g / g_old : 0.0;
-  const double den = (k > 0) ? d - o.beta * g / a_old : d;
+  const real den = (k > 0) ? d - o.beta * g / a_old : d;
   o.alpha = g / den;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (done) ctl->cg_done = 1;
@@ -49,32 +49,32 @@ __device__ __forceinline__ bool sr_scalars(Ctl* __restrict__ ctl, int k, long lo
 
 // check_only != 0: evaluate the stopping rule after the last budgeted iteration (one workgroup)
 __global__ __launch_bounds__(COSMO_BS) void k_sr_update_A(Ctl* __restrict__ ctl, int guard, int k, int check_only, long long n, long long maxiter,
-                                                          const double* __restrict__ part_g_in, int n_g, const double* __restrict__ part_d, int n_d,
-                                                          double* __restrict__ part_g_out, CsrView A, const SrRec* __restrict__ old_rec,
-                                                          SrRec* __restrict__ new_rec, double* __restrict__ x, double* __restrict__ rvec,
-                                                          const double* __restrict__ rho, double* __restrict__ tmp) {
-  const double pg = partials_prefetch_sum(part_g_in, n_g);
-  const double pd = partials_prefetch_sum(part_d, n_d);
+                                                          const real* __restrict__ part_g_in, int n_g, const real* __restrict__ part_d, int n_d,
+                                                          real* __restrict__ part_g_out, CsrView A, const SrRec* __restrict__ old_rec,
+                                                          SrRec* __restrict__ new_rec, real* __restrict__ x, real* __restrict__ rvec,
+                                                          const real* __restrict__ rho, real* __restrict__ tmp) {
+  const real pg = partials_prefetch_sum(part_g_in, n_g);
+  const real pd = partials_prefetch_sum(part_d, n_d);
   if (guard && ctl->halt) return;
   if (ctl->cg_done) return;
-  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
-  __shared__ double red[COSMO_BS / 64];
+  __shared__ real lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ real red[COSMO_BS / 64];
   SrScalars sc;
   if (check_only) {
-    const double g = block_sum(pg, red);
-    const double res = sqrt(g);
+    const real g = block_sum(pg, red);
+    const real res = sqrt(g);
     if (threadIdx.x == 0 && ((k >= maxiter) || (res <= ctl->tol))) { ctl->cg_done = 1; ctl->resv[k & 1] = res; }
     return;
   }
   if (!sr_scalars(ctl, k, maxiter, pg, pd, red, sc)) return;
-  const double alpha = sc.alpha, beta = sc.beta;
-  double acc = 0.0;
+  const real alpha = sc.alpha, beta = sc.beta;
+  real acc = 0.0;
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < n; i += (long long)gridDim.x * COSMO_BS) {
     const SrRec v = old_rec[i];
-    const double p = v.r + beta * v.p;
-    const double s = v.w + beta * v.s;
+    const real p = v.r + beta * v.p;
+    const real s = v.w + beta * v.s;
     x[i] = x[i] + alpha * p;
-    const double rn = v.r - alpha * s;
+    const real rn = v.r - alpha * s;
     SrRec o; o.r = rn; o.w = 0.0; o.s = s; o.p = p;      // w is filled by k_sr_op
     new_rec[i] = o;
     rvec[i] = rn;                                        // compact copy: the operator kernel gathers 8-byte r, not 32-byte records
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_sr_update_A(Ctl* __restrict__ ctl,
   for (int b = blockIdx.x; b < A.nb; b += gridDim.x) {
     const int4 d = reinterpret_cast<const int4*>(A.rb)[tile_of_block(b, A.nb, A.xcd_affine)];
     csr_stream_rows_g(A, [&](int c) { const SrRec v = old_rec[c]; return v.r - alpha * (v.w + beta * v.s); }, d.x, d.y, d.z, d.w, lds, red,
-                      [&](int r, double s1, double s2) { tmp[r] = (s1 + s2) * rho[r]; });
+                      [&](int r, real s1, real s2) { tmp[r] = (s1 + s2) * rho[r]; });
   }
   acc = block_sum(acc, red);
   if (threadIdx.x == 0) part_g_out[blockIdx.x] = acc;
@@ -92,22 +92,22 @@ __global__ __launch_bounds__(COSMO_BS) void k_sr_update_A(Ctl* __restrict__ ctl,
 // w = P r + (sigma r + A' tmp) [+ diag .* r] ; partials of w'r.  r is gathered from the compact vector r0 (kept next to the records:
 // a random 8-byte gather from 32-byte records would quadruple the footprint of the gathered data in the L2s).  init != 0 (solve
 // start): the record {r, w, 0, 0} is created; otherwise w is written into the record of the current iterate.
-__global__ __launch_bounds__(COSMO_BS) void k_sr_op(const Ctl* __restrict__ ctl, int guard, int init, CsrView PT, double sigma, const double* __restrict__ r0,
-                                                    SrRec* __restrict__ rec, const double* __restrict__ tmp, const double* __restrict__ diag,
-                                                    double* __restrict__ part_d) {
+__global__ __launch_bounds__(COSMO_BS) void k_sr_op(const Ctl* __restrict__ ctl, int guard, int init, CsrView PT, real sigma, const real* __restrict__ r0,
+                                                    SrRec* __restrict__ rec, const real* __restrict__ tmp, const real* __restrict__ diag,
+                                                    real* __restrict__ part_d) {
   if (guard && ctl->halt) return;
   if (!init && ctl->cg_done) return;
-  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
-  __shared__ double red[COSMO_BS / 64];
+  __shared__ real lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ real red[COSMO_BS / 64];
   const int split_col = PT.split_col;
-  double acc = 0.0;
+  real acc = 0.0;
   const int first_tile = tile_of_block(blockIdx.x, PT.nb, PT.xcd_affine);
   for (int t = first_tile; t < PT.nb; t += gridDim.x) {
     const int4 d = reinterpret_cast<const int4*>(PT.rb)[t];
     csr_stream_rows_g(PT, [&](int c) { return (c < split_col) ? r0[c] : tmp[c - split_col]; }, d.x, d.y, d.z, d.w, lds, red,
-                      [&](int row, double s1, double s2) {
-                        const double rj = r0[row];
-                        double wj = s1 + (sigma * rj + s2);
+                      [&](int row, real s1, real s2) {
+                        const real rj = r0[row];
+                        real wj = s1 + (sigma * rj + s2);
                         if (diag) wj += diag[row] * rj;
                         if (init) { SrRec o; o.r = rj; o.w = wj; o.s = 0.0; o.p = 0.0; rec[row] = o; }
                         else rec[row].w = wj;
@@ -119,13 +119,13 @@ __global__ __launch_bounds__(COSMO_BS) void k_sr_op(const Ctl* __restrict__ ctl,
 }
 
 // out = rho .* (A v) on a plain vector (solve start: A r0)
-__global__ __launch_bounds__(COSMO_BS) void k_sr_A_plain(const Ctl* __restrict__ ctl, int guard, CsrView A, const double* __restrict__ v,
-                                                         const double* __restrict__ rho, double* __restrict__ out) {
+__global__ __launch_bounds__(COSMO_BS) void k_sr_A_plain(const Ctl* __restrict__ ctl, int guard, CsrView A, const real* __restrict__ v,
+                                                         const real* __restrict__ rho, real* __restrict__ out) {
   if (guard && ctl->halt) return;
-  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
-  __shared__ double red[COSMO_BS / 64];
+  __shared__ real lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ real red[COSMO_BS / 64];
   for (int b = blockIdx.x; b < A.nb; b += gridDim.x)
-    csr_stream_tile(A, v, v, tile_of_block(b, A.nb, A.xcd_affine), lds, red, [&](int r, double s1, double s2) { out[r] = (s1 + s2) * rho[r]; });
+    csr_stream_tile(A, v, v, tile_of_block(b, A.nb, A.xcd_affine), lds, red, [&](int r, real s1, real s2) { out[r] = (s1 + s2) * rho[r]; });
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -149,8 +149,8 @@ static inline int sr_grid1(const cosmo_hip_handle* h, const CsrDev& Ao) {
 int32_t sr_enqueue_start(cosmo_hip_handle* h, int guard) {
   const CsrDev& Ao = h->op_split ? h->Am : h->A;
   const CsrDev& PTo = h->op_split ? h->PTm : h->PT;
-  const double* rho_o = h->op_split ? h->op_rho_m : h->rho;
-  const double* diag_o = h->op_split ? h->op_diag : nullptr;
+  const real* rho_o = h->op_split ? h->op_rho_m : h->rho;
+  const real* diag_o = h->op_split ? h->op_diag : nullptr;
   SrRec* rec0 = (SrRec*)h->sr_rec;
   prof_begin(h, KC_SPMV_A);
   hipLaunchKernelGGL(k_sr_A_plain, dim3(std::max(Ao.grid, 1)), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, view_of(Ao), h->r, rho_o, h->tmp_m);
@@ -168,8 +168,8 @@ int32_t sr_enqueue_iterations(cosmo_hip_handle* h, int guard, int k_begin, int c
   const long long n = h->n;
   const CsrDev& Ao = h->op_split ? h->Am : h->A;
   const CsrDev& PTo = h->op_split ? h->PTm : h->PT;
-  const double* rho_o = h->op_split ? h->op_rho_m : h->rho;
-  const double* diag_o = h->op_split ? h->op_diag : nullptr;
+  const real* rho_o = h->op_split ? h->op_rho_m : h->rho;
+  const real* diag_o = h->op_split ? h->op_diag : nullptr;
   SrRec* rec = (SrRec*)h->sr_rec;
   const int g1 = sr_grid1(h, Ao);
   auto gslot = [&](int k) { return (k & 1) ? PARTS(h, SLOT_AUX0) : PARTS(h, SLOT_RR); };
@@ -182,7 +182,7 @@ int32_t sr_enqueue_iterations(cosmo_hip_handle* h, int guard, int k_begin, int c
                        gslot(k + 1), view_of(Ao), old_rec, new_rec, h->x_tl, h->r, rho_o, h->tmp_m);
     prof_end(h);
     prof_begin(h, KC_OP_APPLY);
-    hipLaunchKernelGGL(k_sr_op, dim3(PTo.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, 0, view_of(PTo), h->prm.sigma, (const double*)h->r, new_rec,
+    hipLaunchKernelGGL(k_sr_op, dim3(PTo.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, 0, view_of(PTo), h->prm.sigma, (const real*)h->r, new_rec,
                        h->tmp_m, diag_o, PARTS(h, SLOT_UC));
     prof_end(h);
     h->spmv_calls[0] += 1; h->spmv_calls[1] += 1; h->spmv_calls[2] += 1;

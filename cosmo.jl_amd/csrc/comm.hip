@@ -77,7 +77,7 @@ struct ShmSeg {
   std::atomic<int> gen;
   int flag[COSMO_SHM_MAX_RANKS];
   long long capacity;          // doubles in data[]
-  double data[1];
+  real data[1];
 };
 
 struct CommState {
@@ -159,7 +159,7 @@ extern "C" int32_t cosmo_hip_comm_init_hostshm(cosmo_hip_handle* h, int32_t rank
   CommState* c = new CommState();
   c->rank = rank; c->nranks = nranks; c->shm_name = name;
   const long long cap = h->m > 0 ? h->m : 1;
-  c->shm_bytes = sizeof(ShmSeg) + sizeof(double) * (size_t)cap;
+  c->shm_bytes = sizeof(ShmSeg) + sizeof(real) * (size_t)cap;
   int fd = -1;
   if (rank == 0) {
     (void)shm_unlink(name);
@@ -228,7 +228,7 @@ extern "C" int32_t cosmo_hip_set_cone_ownership(cosmo_hip_handle* h, int64_t con
 }
 
 // the one exchange step: every owner broadcasts its slice of s in place (enqueued on the handle's stream)
-int32_t comm_enqueue_exchange(cosmo_hip_handle* h, double* s) {
+int32_t comm_enqueue_exchange(cosmo_hip_handle* h, real* s) {
   if (!h->comm) return COSMO_HIP_OK;
   CommState* c = (CommState*)h->comm;
   if (c->nranks == 1 || c->first_cone.empty()) return COSMO_HIP_OK;
@@ -237,13 +237,13 @@ int32_t comm_enqueue_exchange(cosmo_hip_handle* h, double* s) {
     // host-staged: owner slice -> segment, barrier, the other ranks' slices <- segment, barrier (the segment is reused next time)
     const long long lo = c->row_lo[c->rank], hi = c->row_hi[c->rank];
     if (hi > c->shm->capacity) return cosmo_fail(h, COSMO_HIP_ERR_COMM, "shared segment too small");
-    if (hi > lo) HIPCHK(h, hipMemcpyAsync(c->shm->data + lo, s + lo, sizeof(double) * (size_t)(hi - lo), hipMemcpyDeviceToHost, h->stream));
+    if (hi > lo) HIPCHK(h, hipMemcpyAsync(c->shm->data + lo, s + lo, sizeof(real) * (size_t)(hi - lo), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     CHK(shm_barrier(h, c));
     for (int r = 0; r < c->nranks; ++r) {
       const long long cnt = c->row_hi[r] - c->row_lo[r];
       if (r == c->rank || cnt <= 0) continue;
-      HIPCHK(h, hipMemcpyAsync(s + c->row_lo[r], c->shm->data + c->row_lo[r], sizeof(double) * (size_t)cnt, hipMemcpyHostToDevice, h->stream));
+      HIPCHK(h, hipMemcpyAsync(s + c->row_lo[r], c->shm->data + c->row_lo[r], sizeof(real) * (size_t)cnt, hipMemcpyHostToDevice, h->stream));
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return shm_barrier(h, c);

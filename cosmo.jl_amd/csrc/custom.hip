@@ -26,7 +26,7 @@ int32_t custom_plan_create(cosmo_hip_handle* h) {
     h->custom.push_back(cc);
   }
   if (h->custom.empty()) return COSMO_HIP_OK;
-  HIPCHK(h, hipHostMalloc((void**)&h->custom_host, sizeof(double) * (size_t)(tot > 0 ? tot : 1), hipHostMallocDefault));
+  HIPCHK(h, hipHostMalloc((void**)&h->custom_host, sizeof(real) * (size_t)(tot > 0 ? tot : 1), hipHostMallocDefault));
   HIPCHK(h, hipHostMalloc((void**)&h->custom_halt, sizeof(int), hipHostMallocDefault));
   *h->custom_halt = 0;
   return COSMO_HIP_OK;
@@ -47,12 +47,12 @@ extern "C" int32_t cosmo_hip_set_custom_cone(cosmo_hip_handle* h, int64_t cone, 
 
 // guard != 0: inside the loop; once a status has been decided on the device (ctl->halt) the iterates are frozen, so the
 // callback is skipped as every loop kernel is
-int32_t custom_enqueue_project(cosmo_hip_handle* h, double* s, int guard) {
+int32_t custom_enqueue_project(cosmo_hip_handle* h, real* s, int guard) {
   if (h->custom.empty()) return COSMO_HIP_OK;
   for (const CustomCone& cc : h->custom) {
     if (!cc.project) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "custom cone %lld has no projection callback (cosmo_hip_set_custom_cone)", cc.cone);
     if (cc.dim > 0)
-      HIPCHK(h, hipMemcpyAsync(h->custom_host + cc.host_off, s + cc.off, sizeof(double) * (size_t)cc.dim, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipMemcpyAsync(h->custom_host + cc.host_off, s + cc.off, sizeof(real) * (size_t)cc.dim, hipMemcpyDeviceToHost, h->stream));
   }
   if (guard) HIPCHK(h, hipMemcpyAsync(h->custom_halt, &h->ctl->halt, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -60,7 +60,7 @@ int32_t custom_enqueue_project(cosmo_hip_handle* h, double* s, int guard) {
   for (const CustomCone& cc : h->custom) cc.project(h->custom_host + cc.host_off, (int64_t)cc.dim, cc.user);
   for (const CustomCone& cc : h->custom)
     if (cc.dim > 0)
-      HIPCHK(h, hipMemcpyAsync(s + cc.off, h->custom_host + cc.host_off, sizeof(double) * (size_t)cc.dim, hipMemcpyHostToDevice, h->stream));
+      HIPCHK(h, hipMemcpyAsync(s + cc.off, h->custom_host + cc.host_off, sizeof(real) * (size_t)cc.dim, hipMemcpyHostToDevice, h->stream));
   return COSMO_HIP_OK;
 }
 
@@ -68,19 +68,19 @@ int32_t custom_enqueue_project(cosmo_hip_handle* h, double* s, int guard) {
 //   which 0: support_function!(dyn, cone, tol) = in_dual(-dyn) ? 0 : Inf  (src/convexset.jl:933-936)  -> the callback sees -v
 //   which 1: in_pol_recc(v, cone, tol)                                                                -> the callback sees v
 // A cone without the callback never certifies.
-int32_t custom_test(cosmo_hip_handle* h, const double* v_dev, int which, double tol, bool* ok) {
+int32_t custom_test(cosmo_hip_handle* h, const real* v_dev, int which, real tol, bool* ok) {
   if (h->custom.empty() || !*ok) return COSMO_HIP_OK;
-  std::vector<double> buf;
+  std::vector<real> buf;
   for (const CustomCone& cc : h->custom) {
     const cosmo_hip_cone_test_fn fn = which == 0 ? cc.in_dual : cc.in_pol_recc;
     if (!fn) { *ok = false; return COSMO_HIP_OK; }
     buf.resize((size_t)(cc.dim > 0 ? cc.dim : 1));
     if (cc.dim > 0) {
-      HIPCHK(h, hipMemcpyAsync(buf.data(), v_dev + cc.off, sizeof(double) * (size_t)cc.dim, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipMemcpyAsync(buf.data(), v_dev + cc.off, sizeof(real) * (size_t)cc.dim, hipMemcpyDeviceToHost, h->stream));
       HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     if (which == 0) for (long long i = 0; i < cc.dim; ++i) buf[(size_t)i] = -buf[(size_t)i];
-    if (!fn(buf.data(), (int64_t)cc.dim, tol, cc.user)) { *ok = false; return COSMO_HIP_OK; }
+    if (!fn(buf.data(), (int64_t)cc.dim, (double)tol, cc.user)) { *ok = false; return COSMO_HIP_OK; }
   }
   return COSMO_HIP_OK;
 }

@@ -11,7 +11,7 @@ struct CsrView {
   int xcd_affine;    // 1: workgroup b of a one-tile-per-workgroup launch takes tile (b % 8) * (nb / 8) + b / 8 (see tile_of_block)
   const int* rowptr;
   const int* col;
-  const double* val;
+  const real* val;
   const int* split;  // may be null
   const int* rb;     // 4 ints per tile: {r0, r1, nz0, nz1}
   int nb;
@@ -38,60 +38,60 @@ __device__ __forceinline__ int tile_of_block(int b, int nb, int affine) {
 }
 
 // Butterfly reductions: every lane ends with the same value, combination order is fixed => deterministic.
-__device__ __forceinline__ double wave_sum(double v) {
+__device__ __forceinline__ real wave_sum(real v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-__device__ __forceinline__ double wave_max(double v) {
+__device__ __forceinline__ real wave_max(real v) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(v, o, 64); v = (t > v) ? t : v; }
+  for (int o = 32; o > 0; o >>= 1) { real t = __shfl_xor(v, o, 64); v = (t > v) ? t : v; }
   return v;
 }
 
 // red: COSMO_BS/64 doubles of LDS.  Result is broadcast to all threads.
-__device__ __forceinline__ double block_sum(double v, double* red) {
+__device__ __forceinline__ real block_sum(real v, real* red) {
   v = wave_sum(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  double t = 0.0;
+  real t = 0.0;
 #pragma unroll
   for (int i = 0; i < COSMO_BS / 64; ++i) t += red[i];
   return t;
 }
-__device__ __forceinline__ double block_max(double v, double* red) {
+__device__ __forceinline__ real block_max(real v, real* red) {
   v = wave_max(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  double t = red[0];
+  real t = red[0];
 #pragma unroll
   for (int i = 1; i < COSMO_BS / 64; ++i) t = (red[i] > t) ? red[i] : t;
   return t;
 }
 // Every workgroup re-reduces the (<= COSMO_MAX_PARTIALS) partials of the producing kernel in the same fixed
 // order, so all workgroups of all consumer kernels see bit-identical scalars without a finalize launch.
-__device__ __forceinline__ double reduce_partials_sum(const double* p, int count, double* red) {
-  double a = 0.0;
+__device__ __forceinline__ real reduce_partials_sum(const real* p, int count, real* red) {
+  real a = 0.0;
   for (int i = threadIdx.x; i < count; i += COSMO_BS) a += p[i];
   return block_sum(a, red);
 }
 // two-step form: issue the loads first (before any guard that waits on a scalar load), fold later
-__device__ __forceinline__ double partials_prefetch_sum(const double* p, int count) {
-  double a = 0.0;
+__device__ __forceinline__ real partials_prefetch_sum(const real* p, int count) {
+  real a = 0.0;
   for (int i = threadIdx.x; i < count; i += COSMO_BS) a += p[i];
   return a;
 }
-__device__ __forceinline__ double reduce_partials_max(const double* p, int count, double* red) {
-  double a = 0.0;
-  for (int i = threadIdx.x; i < count; i += COSMO_BS) { double t = p[i]; a = (t > a || t != t) ? t : a; }
+__device__ __forceinline__ real reduce_partials_max(const real* p, int count, real* red) {
+  real a = 0.0;
+  for (int i = threadIdx.x; i < count; i += COSMO_BS) { real t = p[i]; a = (t > a || t != t) ? t : a; }
   return block_max(a, red);
 }
 
 // abs-max that propagates NaN like Julia's norm(x, Inf)
-__device__ __forceinline__ double amax(double acc, double v) {
-  double a = fabs(v);
+__device__ __forceinline__ real amax(real acc, real v) {
+  real a = fabs(v);
   return (a > acc || a != a) ? a : acc;
 }
 
@@ -103,11 +103,11 @@ __device__ __forceinline__ double amax(double acc, double v) {
 // Left-to-right sum of lds[a .. b): the additions happen strictly in index order (the order of Julia's CSC kernels: bit-identical row
 // sums), but four LDS reads are requested before the four dependent additions -- a 20-nonzero row (A', [P | A']) otherwise pays one
 // LDS round trip per nonzero with only a third of the workgroup's threads owning a row.
-__device__ __forceinline__ double lds_seq_sum(const double* lds, int a, int b) {
-  double s = 0.0;
+__device__ __forceinline__ real lds_seq_sum(const real* lds, int a, int b) {
+  real s = 0.0;
   int k = a;
   for (; k + 4 <= b; k += 4) {
-    const double v0 = lds[k], v1 = lds[k + 1], v2 = lds[k + 2], v3 = lds[k + 3];
+    const real v0 = lds[k], v1 = lds[k + 1], v2 = lds[k + 2], v3 = lds[k + 3];
     s += v0; s += v1; s += v2; s += v3;
   }
   for (; k < b; ++k) s += lds[k];
@@ -117,8 +117,8 @@ __device__ __forceinline__ double lds_seq_sum(const double* lds, int a, int b) {
 // gat(c): the operand gathered for column c (the plain form below reads x1 / x2; the fused direction + product kernel of the CG
 // iteration rebuilds u = r + beta u_old at the gathered column).
 template <class GatherFn, class RowFn>
-__device__ __forceinline__ void csr_stream_rows_g(const CsrView& M, GatherFn gat, int r0, int r1, int nz0, int nz1, double* lds,
-                                                  double* red, RowFn fn) {
+__device__ __forceinline__ void csr_stream_rows_g(const CsrView& M, GatherFn gat, int r0, int r1, int nz0, int nz1, real* lds,
+                                                  real* red, RowFn fn) {
   const int cnt = nz1 - nz0;
   if (cnt <= COSMO_NNZ_PER_BLOCK) {
     // row pointers of this thread's first row: requested together with (col, val) so that the dependent chain of these 3-20 us
@@ -131,8 +131,8 @@ __device__ __forceinline__ void csr_stream_rows_g(const CsrView& M, GatherFn gat
       const int k = it * COSMO_BS + threadIdx.x;
       if (k < cnt) {
         const int c = M.col[nz0 + k];
-        const double a = M.val[nz0 + k];
-        const double xv = gat(c);
+        const real a = M.val[nz0 + k];
+        const real xv = gat(c);
         lds[k] = a * xv;
       }
     }
@@ -141,8 +141,8 @@ __device__ __forceinline__ void csr_stream_rows_g(const CsrView& M, GatherFn gat
       const int a = ((r == rfirst) ? pa : M.rowptr[r]) - nz0;
       const int b = ((r == rfirst) ? pb : M.rowptr[r + 1]) - nz0;
       const int sp = (r == rfirst) ? (psp - nz0) : (M.split ? (M.split[r] - nz0) : b);
-      const double s1 = lds_seq_sum(lds, a, sp);
-      const double s2 = lds_seq_sum(lds, sp, b);
+      const real s1 = lds_seq_sum(lds, a, sp);
+      const real s2 = lds_seq_sum(lds, sp, b);
       fn(r, s1, s2);
     }
     __syncthreads();
@@ -150,11 +150,11 @@ __device__ __forceinline__ void csr_stream_rows_g(const CsrView& M, GatherFn gat
     // single long row (the schedule never mixes a long row with others)
     const int r = r0;
     const int sp = M.split ? M.split[r] : nz1;
-    double s1 = 0.0, s2 = 0.0;
+    real s1 = 0.0, s2 = 0.0;
     for (int k = nz0 + threadIdx.x; k < nz1; k += COSMO_BS) {
       const int c = M.col[k];
-      const double xv = gat(c);
-      const double p = M.val[k] * xv;
+      const real xv = gat(c);
+      const real p = M.val[k] * xv;
       if (k < sp) s1 += p; else s2 += p;
     }
     s1 = block_sum(s1, red);
@@ -165,9 +165,9 @@ __device__ __forceinline__ void csr_stream_rows_g(const CsrView& M, GatherFn gat
 }
 
 template <class RowFn>
-__device__ __forceinline__ void csr_stream_rows(const CsrView& M, const double* __restrict__ x1,
-                                                const double* __restrict__ x2, int r0, int r1, int nz0, int nz1, double* lds,
-                                                double* red, RowFn fn) {
+__device__ __forceinline__ void csr_stream_rows(const CsrView& M, const real* __restrict__ x1,
+                                                const real* __restrict__ x2, int r0, int r1, int nz0, int nz1, real* lds,
+                                                real* red, RowFn fn) {
   const int split_col = M.split_col;
   csr_stream_rows_g(M, [&](int c) { return (c < split_col) ? x1[c] : x2[c - split_col]; }, r0, r1, nz0, nz1, lds, red, fn);
 }
@@ -176,8 +176,8 @@ __device__ __forceinline__ void csr_stream_rows(const CsrView& M, const double* 
 // per tile, so a workgroup needs ONE dependent load (instead of rb[k], rb[k+1], rowptr[r0], rowptr[r1]) before it can
 // start streaming -- the ramp-up of these 10-20 us kernels is a chain of dependent memory round trips.
 template <class RowFn>
-__device__ __forceinline__ void csr_stream_tile(const CsrView& M, const double* __restrict__ x1, const double* __restrict__ x2,
-                                                int k, double* lds, double* red, RowFn fn) {
+__device__ __forceinline__ void csr_stream_tile(const CsrView& M, const real* __restrict__ x1, const real* __restrict__ x2,
+                                                int k, real* lds, real* red, RowFn fn) {
   const int4 d = reinterpret_cast<const int4*>(M.rb)[k];
   csr_stream_rows(M, x1, x2, d.x, d.y, d.z, d.w, lds, red, fn);
 }

@@ -15,6 +15,29 @@
 #include <vector>
 #include "../../include/cosmo_hip.h"
 
+// ---- the scalar type of this build ---------------------------------------------------------------------------------
+// libcosmo_hip.so: real = double (COSMO.Model{Float64}).  libcosmo_hip_f32.so: the same sources with -DCOSMO_HIP_REAL_FLOAT,
+// real = float (COSMO.Model{Float32}, src/types.jl:348).  Every data array, every device scalar and all kernel arithmetic is
+// `real`; what stays `double` on purpose: wall-clock times, the settings struct of the ABI (converted at the launch sites) and
+// host-side bookkeeping that is not part of the iteration's arithmetic.
+typedef cosmo_hip_real real;
+#ifdef COSMO_HIP_REAL_FLOAT
+typedef float2 real2;
+#define make_real2 make_float2
+#define REAL_EPS 1.1920928955078125e-07f
+#define REAL_MAX 3.402823466e+38f
+#define REAL_IS_FLOAT 1
+#else
+typedef double2 real2;
+#define make_real2 make_double2
+#define REAL_EPS 2.220446049250313e-16
+#define REAL_MAX 1.7976931348623157e308
+#define REAL_IS_FLOAT 0
+#endif
+// literal of the build's scalar type: R(2.0) * x must not promote a float expression to double (Julia's Float32 broadcasts round
+// every operation to Float32)
+#define R(x) ((real)(x))
+
 #define COSMO_BS 256            // threads per workgroup for streaming kernels (4 waves of 64)
 #define COSMO_NNZ_PER_BLOCK 2048 // CSR-stream: nonzeros staged in LDS per row block (16 KB of products; measured best of 512..4096)
 #define COSMO_MAX_PARTIALS 2048 // upper bound on workgroups that emit reduction partials
@@ -35,15 +58,15 @@ struct Ctl {
   long long iter;    // ADMM iterations completed
   long long solves;  // KKT solves completed (iteration_counter - 1)
   long long kkt_iters_total;
-  double resv[2];    // CG residual norms, indexed by iteration parity
-  double tol;        // absolute tolerance of the current solve
-  double rhs_norm;
-  double rho;        // scalar rho (ws.rho)
-  double r_prim, r_dual, max_norm_prim, max_norm_dual, cost;
-  double minres[16]; // MINRES scalar recurrences, two parity slots of 8 (see minres.hip)
-  double udotc_slot; // <v_curr, v_next> of the current MINRES iteration
-  double sr_gamma[2], sr_alpha[2];   // single-reduction CG (cg_sr.hip): r'r and alpha of the last two iterations, by parity
-  double rho_updates[COSMO_HIP_MAX_RHO_UPDATES];
+  real resv[2];    // CG residual norms, indexed by iteration parity
+  real tol;        // absolute tolerance of the current solve
+  real rhs_norm;
+  real rho;        // scalar rho (ws.rho)
+  real r_prim, r_dual, max_norm_prim, max_norm_dual, cost;
+  real minres[16]; // MINRES scalar recurrences, two parity slots of 8 (see minres.hip)
+  real udotc_slot; // <v_curr, v_next> of the current MINRES iteration
+  real sr_gamma[2], sr_alpha[2];   // single-reduction CG (cg_sr.hip): r'r and alpha of the last two iterations, by parity
+  real rho_updates[COSMO_HIP_MAX_RHO_UPDATES];
 };
 
 // ---- CSR matrix on the device -----------------------------------------------------------------------------------
@@ -52,7 +75,7 @@ struct CsrDev {
   long long nnz = 0;
   int* rowptr = nullptr;  // nrows+1
   int* col = nullptr;     // nnz
-  double* val = nullptr;  // nnz
+  real* val = nullptr;  // nnz
   int* split = nullptr;   // nrows (merged operator only): index where the A' part of the row starts
   int* rb = nullptr;      // nb+1 row-block boundaries of the CSR-stream schedule
   int nb = 0;             // number of row blocks
@@ -64,7 +87,7 @@ struct CsrDev {
 struct HostCsr {  // host staging of a CSR matrix (0-based)
   int nrows = 0, ncols = 0;
   std::vector<int> rowptr, col;
-  std::vector<double> val;
+  std::vector<real> val;
   std::vector<int> split;
 };
 
@@ -77,8 +100,8 @@ struct ConeTable {  // host copy of the composite set
   std::vector<int32_t> type;
   std::vector<int64_t> dim, off;
   int64_t nbox_rows = 0;
-  std::vector<double> box_l, box_u;
-  std::vector<double> param;       // per cone: alpha of the power cones
+  std::vector<real> box_l, box_u;
+  std::vector<real> param;       // per cone: alpha of the power cones
 };
 
 struct PsdPlan;  // psd.hip
@@ -106,22 +129,22 @@ struct cosmo_hip_handle {
   CsrDev Am, PTm;
   int* op_mrow = nullptr;          // Am row -> row of A
   int *op_sc_ptr = nullptr, *op_sc_row = nullptr;
-  double *op_sc_a2 = nullptr, *op_diag = nullptr, *op_rho_m = nullptr;
+  real *op_sc_a2 = nullptr, *op_diag = nullptr, *op_rho_m = nullptr;
   long long op_nsingle = 0;
   // assembled reduced operator M = P + diag(sigma + d) + Am' rho_m Am (cg_fold.hip): two launches per Krylov iteration
   bool op_fold = false;
   void* fold = nullptr;           // FoldPlan
   // data vectors
-  double *q = nullptr, *b = nullptr, *rho = nullptr, *Dinv = nullptr, *Einv = nullptr, *Dscale = nullptr, *Escale = nullptr;
-  double *inf_dy = nullptr, *inf_dx = nullptr, *inf_adx = nullptr;   // infeasibility work vectors (infeas.hip)
+  real *q = nullptr, *b = nullptr, *rho = nullptr, *Dinv = nullptr, *Einv = nullptr, *Dscale = nullptr, *Escale = nullptr;
+  real *inf_dy = nullptr, *inf_dx = nullptr, *inf_adx = nullptr;   // infeasibility work vectors (infeas.hip)
   int* inf_flags = nullptr;
-  double cinv = 1.0;
+  real cinv = 1.0;
   bool has_scaling = false;
   bool P_symmetric = true;       // set by set_problem; the device Ruiz scaling requires it
   // cones
   ConeTable cones;
   uint32_t* meta = nullptr;       // per row: kind (2 bits) | box index << 2
-  double *box_l = nullptr, *box_u = nullptr;
+  real *box_l = nullptr, *box_u = nullptr;
   int* rho_cls = nullptr;         // per row rho class 0/1/2
   std::vector<int32_t> rho_cls_host;
   int nsoc = 0;                   // SOC table
@@ -129,10 +152,10 @@ struct cosmo_hip_handle {
   std::vector<int> soc_cone_index;
   int ncone3 = 0;                 // exponential / power cones (cone3.hip)
   int *c3_off = nullptr, *c3_kind = nullptr, *c3_branch = nullptr;
-  double* c3_alpha = nullptr;
+  real* c3_alpha = nullptr;
   std::vector<int> c3_cone_index;
   std::vector<CustomCone> custom;  // user-defined cones (custom.hip)
-  double* custom_host = nullptr;   // pinned staging, sum of the custom dims
+  real* custom_host = nullptr;   // pinned staging, sum of the custom dims
   int* custom_halt = nullptr;      // pinned copy of ctl->halt
   PsdPlan* psd = nullptr;
   void* psd_polar = nullptr;      // PolarPlan (psd_polar.hip): large cones
@@ -140,11 +163,11 @@ struct cosmo_hip_handle {
   long long safeguarding_iter = 0;
   bool cg_sr = false;             // kkt_kind COSMO_HIP_KKT_CG_SR: single-reduction (Chronopoulos-Gear) CG, cg_sr.hip
   void* sr_rec = nullptr;         // 2 n records {r, w, s, p}
-  double* cg_ru = nullptr;        // {r_i, u_i} interleaved (2n doubles): operands of the fused direction + A-product kernel (k_cg_dirA); null = unfused
+  real* cg_ru = nullptr;        // {r_i, u_i} interleaved (2n doubles): operands of the fused direction + A-product kernel (k_cg_dirA); null = unfused
   // persistent single-launch CG (cg_persist.hip)
   bool pcg_on = false;
   unsigned* pcg_sync = nullptr;
-  double* pcg_u2 = nullptr;
+  real* pcg_u2 = nullptr;
   int pcg_W = 0, pcg_cap = 0;
   size_t pcg_smem = 0;
   long long pcg_launches = 0, pcg_fallbacks = 0;
@@ -152,14 +175,14 @@ struct cosmo_hip_handle {
   void* comm = nullptr;
   long long cone_lo = 0, cone_hi = -1;
   // loop state
-  double *w = nullptr, *w_prev = nullptr, *s = nullptr, *mu = nullptr, *s_tl = nullptr;
-  double *ls_x = nullptr, *ls_s = nullptr, *x_tl = nullptr, *nu = nullptr;
-  double *rhs = nullptr, *r = nullptr, *u = nullptr, *c = nullptr, *tmp_m = nullptr, *y2 = nullptr;
-  double *mr = nullptr;           // MINRES work vectors
-  double* partials = nullptr;     // COSMO_NSLOTS x COSMO_MAX_PARTIALS
+  real *w = nullptr, *w_prev = nullptr, *s = nullptr, *mu = nullptr, *s_tl = nullptr;
+  real *ls_x = nullptr, *ls_s = nullptr, *x_tl = nullptr, *nu = nullptr;
+  real *rhs = nullptr, *r = nullptr, *u = nullptr, *c = nullptr, *tmp_m = nullptr, *y2 = nullptr;
+  real *mr = nullptr;           // MINRES work vectors
+  real* partials = nullptr;     // COSMO_NSLOTS x COSMO_MAX_PARTIALS
   Ctl* ctl = nullptr;
   Ctl* ctl_host = nullptr;        // pinned mirror
-  double* io = nullptr;           // staging buffer, n+m
+  real* io = nullptr;           // staging buffer, n+m
   // parameters
   cosmo_hip_params prm;
   // host-side bookkeeping of the speculative enqueue
@@ -209,18 +232,18 @@ void free_op_split(cosmo_hip_handle* h);
 
 // assembled reduced operator (cg_fold.hip)
 int32_t fold_build(cosmo_hip_handle* h, const HostCsr& Am, const std::vector<int>& prp, const std::vector<int>& pcol,
-                   const std::vector<double>& pval);
+                   const std::vector<real>& pval);
 int32_t fold_refresh(cosmo_hip_handle* h);
 void fold_free(cosmo_hip_handle* h);
-int32_t fold_enqueue_start(cosmo_hip_handle* h, int guard, double tol_k);
+int32_t fold_enqueue_start(cosmo_hip_handle* h, int guard, real tol_k);
 int32_t fold_enqueue_iterations(cosmo_hip_handle* h, int guard, int k_begin, int count);
 
 // plain y = M x (fine-grained ABI + building block)
-int32_t launch_spmv_plain(cosmo_hip_handle* h, const CsrDev& M, const double* x, double* y);
+int32_t launch_spmv_plain(cosmo_hip_handle* h, const CsrDev& M, const real* x, real* y);
 
 // loop pieces (loop.hip)
-int32_t enqueue_projection(cosmo_hip_handle* h, const double* src, double* dst, double* w_prev_dst,
-                           const double* w_src, bool in_loop);
+int32_t enqueue_projection(cosmo_hip_handle* h, const real* src, real* dst, real* w_prev_dst,
+                           const real* w_src, bool in_loop);
 int32_t enqueue_admm_x_and_w(cosmo_hip_handle* h);
 int32_t sync_ctl(cosmo_hip_handle* h);
 
@@ -249,28 +272,28 @@ int32_t aa_fetch_flags(cosmo_hip_handle* h, int* success, int* declined);
 int32_t aa_enqueue_guard(cosmo_hip_handle* h);
 int32_t aa_enqueue_reset(cosmo_hip_handle* h);
 void aa_count(cosmo_hip_handle* h, int accelerated, int declined);
-void aa_check_accuracy_activation(cosmo_hip_handle* h, double r_prim, double r_dual, double max_norm_prim, double max_norm_dual);
+void aa_check_accuracy_activation(cosmo_hip_handle* h, real r_prim, real r_dual, real max_norm_prim, real max_norm_dual);
 
 // exponential / power cones (cone3.hip)
 int32_t cone3_plan_create(cosmo_hip_handle* h);
 void cone3_free(cosmo_hip_handle* h);
-int32_t cone3_enqueue_project(cosmo_hip_handle* h, double* s, int guard);
-int32_t cone3_enqueue_in_dual_neg(cosmo_hip_handle* h, const double* v, double tol, int* flag);
+int32_t cone3_enqueue_project(cosmo_hip_handle* h, real* s, int guard);
+int32_t cone3_enqueue_in_dual_neg(cosmo_hip_handle* h, const real* v, real tol, int* flag);
 int32_t cone3_get_branches(cosmo_hip_handle* h, int32_t* out_per_cone);
 
 // user-defined cones (custom.hip)
 int32_t custom_plan_create(cosmo_hip_handle* h);
 void custom_free(cosmo_hip_handle* h);
-int32_t custom_enqueue_project(cosmo_hip_handle* h, double* s, int guard);
+int32_t custom_enqueue_project(cosmo_hip_handle* h, real* s, int guard);
 // which 0: in_dual(-v) (v = normalised -dy), 1: in_pol_recc(v); *ok is and-ed with the verdict of every custom cone
-int32_t custom_test(cosmo_hip_handle* h, const double* v_dev, int which, double tol, bool* ok);
+int32_t custom_test(cosmo_hip_handle* h, const real* v_dev, int which, real tol, bool* ok);
 
 // PSD projection of large cones by the matrix-sign iteration (psd_polar.hip)
 int32_t polar_plan_create(cosmo_hip_handle* h);
 void polar_plan_destroy(cosmo_hip_handle* h);
 bool polar_enabled(const cosmo_hip_handle* h);
-int32_t polar_enqueue_project(cosmo_hip_handle* h, double* s, int guard);
-int32_t polar_enqueue_project_batch(cosmo_hip_handle* h, double* s, int guard);
+int32_t polar_enqueue_project(cosmo_hip_handle* h, real* s, int guard);
+int32_t polar_enqueue_project_batch(cosmo_hip_handle* h, real* s, int guard);
 int32_t polar_adapt(cosmo_hip_handle* h);   // host-side schedule adaptation at a synchronisation point
 bool polar_has_batch(const cosmo_hip_handle* h);
 bool polar_has_large(const cosmo_hip_handle* h);
@@ -278,12 +301,12 @@ bool polar_has_large(const cosmo_hip_handle* h);
 // PSD projection (psd.hip)
 int32_t psd_plan_create(cosmo_hip_handle* h);
 void psd_plan_destroy(cosmo_hip_handle* h);
-int32_t psd_enqueue_project(cosmo_hip_handle* h, double* s, bool guard);
+int32_t psd_enqueue_project(cosmo_hip_handle* h, real* s, bool guard);
 int32_t psd_get_ranks(cosmo_hip_handle* h, int64_t* rank_per_cone);
 static inline bool cone_owned(const cosmo_hip_handle* h, long long k) { return h->cone_hi < 0 || (k >= h->cone_lo && k < h->cone_hi); }
 // infeas.hip
 int32_t infeas_enqueue_capture(cosmo_hip_handle* h);
 int32_t infeas_check(cosmo_hip_handle* h, int32_t* status);
 // comm.hip
-int32_t comm_enqueue_exchange(cosmo_hip_handle* h, double* s);
+int32_t comm_enqueue_exchange(cosmo_hip_handle* h, real* s);
 extern "C" int32_t cosmo_hip_comm_destroy(cosmo_hip_handle* h);

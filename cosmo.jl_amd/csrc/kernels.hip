@@ -7,11 +7,11 @@
 // ---------------------------------------------------------------------------------------------------------------------
 // plain SpMV  y = M x                      (mul!(y, A, x) / mul!(y, A', x) / mul!(y, P, x), residuals.jl:4,12,15)
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(COSMO_BS) void k_spmv_plain(CsrView M, const double* __restrict__ x, double* __restrict__ y) {
-  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
-  __shared__ double red[COSMO_BS / 64];
+__global__ __launch_bounds__(COSMO_BS) void k_spmv_plain(CsrView M, const real* __restrict__ x, real* __restrict__ y) {
+  __shared__ real lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ real red[COSMO_BS / 64];
   for (int b = blockIdx.x; b < M.nb; b += gridDim.x) {
-    csr_stream_tile(M, x, x, tile_of_block(b, M.nb, M.xcd_affine), lds, red, [&](int r, double s1, double s2) { y[r] = s1 + s2; });
+    csr_stream_tile(M, x, x, tile_of_block(b, M.nb, M.xcd_affine), lds, red, [&](int r, real s1, real s2) { y[r] = s1 + s2; });
   }
 }
 
@@ -20,28 +20,28 @@ __global__ __launch_bounds__(COSMO_BS) void k_spmv_plain(CsrView M, const double
 // (solver.jl:151, 14 ; convexset.jl:25-28, 71-74, 844-847 with clip algebra.jl:5-7)
 // meta[i] = kind | (boxindex << 2), kind: 0 copy, 1 zero, 2 nonneg, 3 box
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double project_simple(double x, uint32_t meta, const double* __restrict__ bl,
-                                                 const double* __restrict__ bu) {
+__device__ __forceinline__ real project_simple(real x, uint32_t meta, const real* __restrict__ bl,
+                                                 const real* __restrict__ bu) {
   const uint32_t kind = meta & 3u;
   if (kind == 0u) return x;
   if (kind == 1u) return 0.0;
   if (kind == 2u) {
     // Julia max(x, 0.0): NaN propagates, max(-0.0, 0.0) == +0.0
-    return (x != x) ? x : ((x > 0.0) ? x : 0.0);
+    return (x != x) ? x : ((x > R(0.0)) ? x : R(0.0));
   }
   const uint32_t j = meta >> 2;
-  const double l = bl[j], u = bu[j];
+  const real l = bl[j], u = bu[j];
   return (x < l) ? l : ((x > u) ? u : x);
 }
 
 __global__ __launch_bounds__(COSMO_BS) void k_z(const Ctl* __restrict__ ctl, int guard, long long n, long long m,
-                                                const double* __restrict__ w, double* __restrict__ w_prev,
-                                                double* __restrict__ s, const uint32_t* __restrict__ meta,
-                                                const double* __restrict__ bl, const double* __restrict__ bu) {
+                                                const real* __restrict__ w, real* __restrict__ w_prev,
+                                                real* __restrict__ s, const uint32_t* __restrict__ meta,
+                                                const real* __restrict__ bl, const real* __restrict__ bu) {
   if (guard && ctl->halt) return;
   const long long N = n + m;
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) {
-    const double v = w[i];
+    const real v = w[i];
     w_prev[i] = v;
     if (i >= n) {
       const long long r = i - n;
@@ -51,10 +51,10 @@ __global__ __launch_bounds__(COSMO_BS) void k_z(const Ctl* __restrict__ ctl, int
 }
 
 // in-place variant for the fine-grained ABI (cosmo_hip_project)
-__global__ __launch_bounds__(COSMO_BS) void k_project_simple_inplace(long long m, double* __restrict__ s,
+__global__ __launch_bounds__(COSMO_BS) void k_project_simple_inplace(long long m, real* __restrict__ s,
                                                                      const uint32_t* __restrict__ meta,
-                                                                     const double* __restrict__ bl,
-                                                                     const double* __restrict__ bu) {
+                                                                     const real* __restrict__ bl,
+                                                                     const real* __restrict__ bu) {
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < m; i += (long long)gridDim.x * COSMO_BS)
     s[i] = project_simple(s[i], meta[i], bl, bu);
 }
@@ -64,19 +64,19 @@ __global__ __launch_bounds__(COSMO_BS) void k_project_simple_inplace(long long m
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(COSMO_BS) void k_soc(const Ctl* __restrict__ ctl, int guard, int ncones,
                                                   const int* __restrict__ off, const int* __restrict__ dim,
-                                                  double* __restrict__ s, int* __restrict__ branch) {
+                                                  real* __restrict__ s, int* __restrict__ branch) {
   if (guard && ctl->halt) return;
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * COSMO_BS + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * COSMO_BS) >> 6;
   for (int c = wave; c < ncones; c += nwaves) {
-    double* x = s + off[c];
+    real* x = s + off[c];
     const int d = dim[c];
     if (d == 0) { if (lane == 0) branch[c] = 0; continue; }
-    const double t = x[0];
-    double acc = 0.0;
-    for (int i = 1 + lane; i < d; i += 64) { const double v = x[i]; acc += v * v; }
-    const double nx = sqrt(wave_sum(acc));
+    const real t = x[0];
+    real acc = 0.0;
+    for (int i = 1 + lane; i < d; i += 64) { const real v = x[i]; acc += v * v; }
+    const real nx = sqrt(wave_sum(acc));
     int br;
     if (nx <= t) {
       br = 0;
@@ -85,9 +85,9 @@ __global__ __launch_bounds__(COSMO_BS) void k_soc(const Ctl* __restrict__ ctl, i
       for (int i = lane; i < d; i += 64) x[i] = 0.0;
     } else {
       br = 2;
-      const double f = (nx + t) / (2.0 * nx);
+      const real f = (nx + t) / (R(2.0) * nx);
       for (int i = 1 + lane; i < d; i += 64) x[i] = f * x[i];
-      if (lane == 0) x[0] = (nx + t) / 2.0;
+      if (lane == 0) x[0] = (nx + t) / R(2.0);
     }
     if (lane == 0) branch[c] = br;
   }
@@ -96,28 +96,28 @@ __global__ __launch_bounds__(COSMO_BS) void k_soc(const Ctl* __restrict__ ctl, i
 // ---------------------------------------------------------------------------------------------------------------------
 // warm start: w[1:n] = x0 ; w[n+1:] = 1/rho * mu0 + s0 ; s = s0        (solver.jl:128-129)
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(COSMO_BS) void k_set_w(long long n, long long m, const double* __restrict__ x0,
-                                                    const double* __restrict__ s0, const double* __restrict__ mu0,
-                                                    const double* __restrict__ rho, double* __restrict__ w,
-                                                    double* __restrict__ s) {
+__global__ __launch_bounds__(COSMO_BS) void k_set_w(long long n, long long m, const real* __restrict__ x0,
+                                                    const real* __restrict__ s0, const real* __restrict__ mu0,
+                                                    const real* __restrict__ rho, real* __restrict__ w,
+                                                    real* __restrict__ s) {
   const long long N = n + m;
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) {
     if (i < n) {
       w[i] = x0 ? x0[i] : 0.0;
     } else {
       const long long r = i - n;
-      const double sv = s0 ? s0[r] : 0.0;
-      const double mv = mu0 ? mu0[r] : 0.0;
-      w[i] = (1.0 / rho[r]) * mv + sv;
+      const real sv = s0 ? s0[r] : 0.0;
+      const real mv = mu0 ? mu0[r] : 0.0;
+      w[i] = (R(1.0) / rho[r]) * mv + sv;
       s[r] = sv;
     }
   }
 }
 
 // mu = rho .* (w_prev[n+1:] - s)                                          (recover_mu!, solver.jl:24-26)
-__global__ __launch_bounds__(COSMO_BS) void k_recover_mu(long long n, long long m, const double* __restrict__ w_prev,
-                                                         const double* __restrict__ s, const double* __restrict__ rho,
-                                                         double* __restrict__ mu) {
+__global__ __launch_bounds__(COSMO_BS) void k_recover_mu(long long n, long long m, const real* __restrict__ w_prev,
+                                                         const real* __restrict__ s, const real* __restrict__ rho,
+                                                         real* __restrict__ mu) {
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < m; i += (long long)gridDim.x * COSMO_BS)
     mu[i] = rho[i] * (w_prev[n + i] - s[i]);
 }
@@ -126,11 +126,11 @@ __global__ __launch_bounds__(COSMO_BS) void k_recover_mu(long long n, long long 
 // admm_x! right-hand side (solver.jl:50-51) + first line of the reduced solve (kktsolver_indirect.jl:52):
 //   ls_x = sigma*w_x - q ; ls_s = (b - 2 s) + w_s ; y2 = rho .* ls_s ; resets the per-solve flags.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(COSMO_BS) void k_rhs(Ctl* __restrict__ ctl, int guard, long long n, long long m, double sigma,
-                                                  const double* __restrict__ w, const double* __restrict__ s,
-                                                  const double* __restrict__ q, const double* __restrict__ b,
-                                                  const double* __restrict__ rho, double* __restrict__ ls_x,
-                                                  double* __restrict__ ls_s, double* __restrict__ y2) {
+__global__ __launch_bounds__(COSMO_BS) void k_rhs(Ctl* __restrict__ ctl, int guard, long long n, long long m, real sigma,
+                                                  const real* __restrict__ w, const real* __restrict__ s,
+                                                  const real* __restrict__ q, const real* __restrict__ b,
+                                                  const real* __restrict__ rho, real* __restrict__ ls_x,
+                                                  real* __restrict__ ls_s, real* __restrict__ y2) {
   if (guard && ctl->halt) return;
   if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->cg_done = 0; ctl->cg_k = 0; }
   const long long N = n + m;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_rhs(Ctl* __restrict__ ctl, int gua
       ls_x[i] = sigma * w[i] - q[i];
     } else {
       const long long r = i - n;
-      const double v = (b[r] - 2.0 * s[r]) + w[i];
+      const real v = (b[r] - R(2.0) * s[r]) + w[i];
       ls_s[r] = v;
       y2[r] = rho[r] * v;
     }
@@ -147,8 +147,8 @@ __global__ __launch_bounds__(COSMO_BS) void k_rhs(Ctl* __restrict__ ctl, int gua
 }
 
 // fine-grained solve: y2 = rho .* rhs_s (rhs already uploaded into ls_x / ls_s)
-__global__ __launch_bounds__(COSMO_BS) void k_y2_only(Ctl* __restrict__ ctl, long long m, const double* __restrict__ ls_s,
-                                                      const double* __restrict__ rho, double* __restrict__ y2) {
+__global__ __launch_bounds__(COSMO_BS) void k_y2_only(Ctl* __restrict__ ctl, long long m, const real* __restrict__ ls_s,
+                                                      const real* __restrict__ rho, real* __restrict__ y2) {
   if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->cg_done = 0; ctl->cg_k = 0; }
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < m; i += (long long)gridDim.x * COSMO_BS)
     y2[i] = rho[i] * ls_s[i];
@@ -156,15 +156,15 @@ __global__ __launch_bounds__(COSMO_BS) void k_y2_only(Ctl* __restrict__ ctl, lon
 
 // rhs = A' y2 + ls_x ; partial sum of rhs^2                                (kktsolver_indirect.jl:53-54, 70)
 __global__ __launch_bounds__(COSMO_BS) void k_cg_rhs(const Ctl* __restrict__ ctl, int guard, CsrView AT,
-                                                     const double* __restrict__ y2, const double* __restrict__ ls_x,
-                                                     double* __restrict__ rhs, double* __restrict__ part_bb) {
+                                                     const real* __restrict__ y2, const real* __restrict__ ls_x,
+                                                     real* __restrict__ rhs, real* __restrict__ part_bb) {
   if (guard && ctl->halt) return;
-  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
-  __shared__ double red[COSMO_BS / 64];
-  double acc = 0.0;
+  __shared__ real lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ real red[COSMO_BS / 64];
+  real acc = 0.0;
   for (int k = blockIdx.x; k < AT.nb; k += gridDim.x) {
-    csr_stream_tile(AT, y2, y2, k, lds, red, [&](int r, double s1, double s2) {
-      const double v = (s1 + s2) + ls_x[r];
+    csr_stream_tile(AT, y2, y2, k, lds, red, [&](int r, real s1, real s2) {
+      const real v = (s1 + s2) + ls_x[r];
       rhs[r] = v;
       acc += v * v;
     });
@@ -176,15 +176,15 @@ __global__ __launch_bounds__(COSMO_BS) void k_cg_rhs(const Ctl* __restrict__ ctl
 // out = rho .* (A v)                                                       (reduced_mul!, kktsolver_indirect.jl:59-60)
 // mode 0: solve start (v = previous solution)   mode 1: Krylov iteration (skipped once the solve has converged)
 __global__ __launch_bounds__(COSMO_BS) void k_spmv_A_rho(const Ctl* __restrict__ ctl, int guard, int mode, CsrView A,
-                                                         const double* __restrict__ v, const double* __restrict__ rho,
-                                                         double* __restrict__ out) {
+                                                         const real* __restrict__ v, const real* __restrict__ rho,
+                                                         real* __restrict__ out) {
   if (guard && ctl->halt) return;
   if (mode == 1 && ctl->cg_done) return;
-  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
-  __shared__ double red[COSMO_BS / 64];
+  __shared__ real lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ real red[COSMO_BS / 64];
   for (int b = blockIdx.x; b < A.nb; b += gridDim.x) {
     csr_stream_tile(A, v, v, tile_of_block(b, A.nb, A.xcd_affine), lds, red,
-                     [&](int r, double s1, double s2) { out[r] = (s1 + s2) * rho[r]; });
+                     [&](int r, real s1, real s2) { out[r] = (s1 + s2) * rho[r]; });
   }
 }
 
@@ -192,33 +192,33 @@ __global__ __launch_bounds__(COSMO_BS) void k_spmv_A_rho(const Ctl* __restrict__
 // mode 0 (solve start): r = rhs - c, partial sum r^2, block 0 derives the absolute tolerance
 //                       tol = tol_k / ||rhs||  (kktsolver_indirect.jl:70 ; cg! abstol)
 // mode 1 (iteration)  : store c, partial sum u.c        mode 2: as 1 but ignores the solve flags (timing hook)
-__global__ __launch_bounds__(COSMO_BS) void k_op_apply(Ctl* __restrict__ ctl, int guard, int mode, CsrView PT, double sigma,
-                                                       const double* __restrict__ v, const double* __restrict__ tmp,
-                                                       const double* __restrict__ rhs, double* __restrict__ r,
-                                                       double* __restrict__ c, double* __restrict__ part_out,
-                                                       const double* __restrict__ part_bb, int n_bb, double tol_k,
-                                                       const double* __restrict__ diag) {
+__global__ __launch_bounds__(COSMO_BS) void k_op_apply(Ctl* __restrict__ ctl, int guard, int mode, CsrView PT, real sigma,
+                                                       const real* __restrict__ v, const real* __restrict__ tmp,
+                                                       const real* __restrict__ rhs, real* __restrict__ r,
+                                                       real* __restrict__ c, real* __restrict__ part_out,
+                                                       const real* __restrict__ part_bb, int n_bb, real tol_k,
+                                                       const real* __restrict__ diag) {
   if (guard && ctl->halt) return;
   if (mode == 1 && ctl->cg_done) return;
-  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
-  __shared__ double red[COSMO_BS / 64];
+  __shared__ real lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ real red[COSMO_BS / 64];
   if (mode == 0 && blockIdx.x == 0) {
-    const double bb = reduce_partials_sum(part_bb, n_bb, red);
+    const real bb = reduce_partials_sum(part_bb, n_bb, red);
     if (threadIdx.x == 0) {
-      const double nb = sqrt(bb);
+      const real nb = sqrt(bb);
       ctl->rhs_norm = nb;
       ctl->tol = tol_k / nb;
     }
   }
-  double acc = 0.0;
+  real acc = 0.0;
   const int first_tile = tile_of_block(blockIdx.x, PT.nb, PT.xcd_affine);     // affine => grid == nb: the loop runs once
   for (int k = first_tile; k < PT.nb; k += gridDim.x) {
-    csr_stream_tile(PT, v, tmp, k, lds, red, [&](int row, double s1, double s2) {
-      const double vj = v[row];
-      double cj = s1 + (sigma * vj + s2);
+    csr_stream_tile(PT, v, tmp, k, lds, red, [&](int row, real s1, real s2) {
+      const real vj = v[row];
+      real cj = s1 + (sigma * vj + s2);
       if (diag) cj += diag[row] * vj;      // singleton rows of A: their part of A' rho A is diagonal (build_op_split)
       if (mode == 0) {
-        const double rj = rhs[row] - cj;
+        const real rj = rhs[row] - cj;
         r[row] = rj;
         acc += rj * rj;
       } else {
@@ -235,31 +235,31 @@ __global__ __launch_bounds__(COSMO_BS) void k_op_apply(Ctl* __restrict__ ctl, in
 // stop if k >= maxiter or residual_k <= tol (checked BEFORE the iteration); else beta = res_k^2 / res_{k-1}^2,
 // u = r + beta u (u_{-1} = 0).  check_only = 1: evaluate the stopping rule after the last budgeted iteration.
 __global__ __launch_bounds__(COSMO_BS) void k_cg_dir(Ctl* __restrict__ ctl, int guard, int k, int check_only, long long n,
-                                                     long long maxiter, const double* __restrict__ part_rr, int n_rr,
-                                                     const double* __restrict__ r, double* __restrict__ u) {
+                                                     long long maxiter, const real* __restrict__ part_rr, int n_rr,
+                                                     const real* __restrict__ r, real* __restrict__ u) {
   // operands of the elementwise part are requested BEFORE the scalar work so that their latency overlaps the
   // partial reduction (the grid covers n with one element per thread; the strided loop only handles huge n)
   const long long i0 = (long long)blockIdx.x * COSMO_BS + threadIdx.x;
-  double r0 = 0.0, u0 = 0.0;
+  real r0 = 0.0, u0 = 0.0;
   if (!check_only && i0 < n) { r0 = r[i0]; if (k > 0) u0 = u[i0]; }
-  const double pa = partials_prefetch_sum(part_rr, n_rr);      // in flight while the guards wait on their scalar loads
+  const real pa = partials_prefetch_sum(part_rr, n_rr);      // in flight while the guards wait on their scalar loads
   if (guard && ctl->halt) return;
   if (ctl->cg_done) return;
-  __shared__ double red[COSMO_BS / 64];
-  const double tol = ctl->tol;
-  const double prev = (k == 0) ? 1.0 : ctl->resv[(k - 1) & 1];
-  const double rr = block_sum(pa, red);
-  const double res = sqrt(rr);
+  __shared__ real red[COSMO_BS / 64];
+  const real tol = ctl->tol;
+  const real prev = (k == 0) ? 1.0 : ctl->resv[(k - 1) & 1];
+  const real rr = block_sum(pa, red);
+  const real res = sqrt(rr);
   const bool done = (k >= maxiter) || (res <= tol);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (done) ctl->cg_done = 1;
     if (!check_only || done) ctl->resv[k & 1] = res;
   }
   if (done || check_only) return;
-  const double beta = (res * res) / (prev * prev);
+  const real beta = (res * res) / (prev * prev);
   if (i0 < n) u[i0] = r0 + beta * u0;
   for (long long i = i0 + (long long)gridDim.x * COSMO_BS; i < n; i += (long long)gridDim.x * COSMO_BS) {
-    const double ui = (k == 0) ? 0.0 : u[i];
+    const real ui = (k == 0) ? 0.0 : u[i];
     u[i] = r[i] + beta * ui;
   }
 }
@@ -270,27 +270,27 @@ __global__ __launch_bounds__(COSMO_BS) void k_cg_dir(Ctl* __restrict__ ctl, int 
 // `ru` ({r_i, u_i}, written by k_cg_upd), so the two operands of a column arrive with ONE 16-byte gather.  The workgroups also
 // materialise u_k (grid-stride over the elements) for the operator kernel and for k_cg_upd.
 __global__ __launch_bounds__(COSMO_BS) void k_cg_dirA(Ctl* __restrict__ ctl, int guard, int k, long long n, long long maxiter,
-                                                      const double* __restrict__ part_rr, int n_rr, CsrView A, const double2* __restrict__ ru,
-                                                      const double* __restrict__ rho, double* __restrict__ tmp, double* __restrict__ u) {
+                                                      const real* __restrict__ part_rr, int n_rr, CsrView A, const real2* __restrict__ ru,
+                                                      const real* __restrict__ rho, real* __restrict__ tmp, real* __restrict__ u) {
   // Everything that does not depend on beta is requested FIRST -- the r'r partials, the tile descriptor, (col, val) and the 16-byte
   // {r, u} gathers of the first tile, the row pointers, this workgroup's slice of {r, u} -- so that the partial reduction / stopping
   // rule overlaps the gather latency instead of preceding it.  Absent slots read a valid address and carry a zero matrix value
   // (a load under a per-thread `if` would make the compiler wait for it on the spot).
   constexpr int SL = COSMO_NNZ_PER_BLOCK / COSMO_BS;
-  const double pa = partials_prefetch_sum(part_rr, n_rr);
+  const real pa = partials_prefetch_sum(part_rr, n_rr);
   const bool have_tile = (int)blockIdx.x < A.nb;
   int4 d = make_int4(0, 0, 0, 0);
   if (have_tile) d = reinterpret_cast<const int4*>(A.rb)[tile_of_block(blockIdx.x, A.nb, A.xcd_affine)];
   const int cnt0 = d.w - d.z;
   const bool fast = have_tile && cnt0 <= COSMO_NNZ_PER_BLOCK;      // a single long row takes the generic chunked path below
-  double av[SL]; double2 gv[SL];
+  real av[SL]; real2 gv[SL];
 #pragma unroll
   for (int it = 0; it < SL; ++it) {
     const int kk = it * COSMO_BS + threadIdx.x;
     const bool ok = fast && kk < cnt0;
     const int e = ok ? d.z + kk : 0;
     const int c = A.col[e];
-    const double a = A.val[e];
+    const real a = A.val[e];
     av[it] = ok ? a : 0.0;
     gv[it] = ru[c];
   }
@@ -298,27 +298,27 @@ __global__ __launch_bounds__(COSMO_BS) void k_cg_dirA(Ctl* __restrict__ ctl, int
   const bool rowok = fast && rfirst < d.y;
   const int rr_ = rowok ? rfirst : 0;
   const int pa_ = A.rowptr[rr_], pb_ = A.rowptr[rr_ + 1];
-  const double rho_ = rho[rr_];
+  const real rho_ = rho[rr_];
   const long long i0 = (long long)blockIdx.x * COSMO_BS + threadIdx.x;
-  const double2 own = ru[i0 < n ? i0 : 0];
+  const real2 own = ru[i0 < n ? i0 : 0];
   if (guard && ctl->halt) return;
   if (ctl->cg_done) return;
-  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
-  __shared__ double red[COSMO_BS / 64];
-  const double tol = ctl->tol;
-  const double prev = ctl->resv[(k - 1) & 1];
-  const double rr = block_sum(pa, red);
-  const double res = sqrt(rr);
+  __shared__ real lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ real red[COSMO_BS / 64];
+  const real tol = ctl->tol;
+  const real prev = ctl->resv[(k - 1) & 1];
+  const real rr = block_sum(pa, red);
+  const real res = sqrt(rr);
   const bool done = (k >= maxiter) || (res <= tol);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (done) ctl->cg_done = 1;
     ctl->resv[k & 1] = res;
   }
   if (done) return;
-  const double beta = (res * res) / (prev * prev);
+  const real beta = (res * res) / (prev * prev);
   if (i0 < n) u[i0] = own.x + beta * own.y;
   for (long long i = i0 + (long long)gridDim.x * COSMO_BS; i < n; i += (long long)gridDim.x * COSMO_BS) {
-    const double2 v = ru[i];
+    const real2 v = ru[i];
     u[i] = v.x + beta * v.y;
   }
   if (fast) {
@@ -329,52 +329,52 @@ __global__ __launch_bounds__(COSMO_BS) void k_cg_dirA(Ctl* __restrict__ ctl, int
     }
     __syncthreads();
     if (rowok) {                                    // first row of this thread: pointers already here
-      const double s1 = lds_seq_sum(lds, pa_ - d.z, pb_ - d.z), s2 = 0.0;
+      const real s1 = lds_seq_sum(lds, pa_ - d.z, pb_ - d.z), s2 = 0.0;
       tmp[rfirst] = (s1 + s2) * rho_;
     }
     for (int r = rfirst + COSMO_BS; r < d.y; r += COSMO_BS) {
-      const double s1 = lds_seq_sum(lds, A.rowptr[r] - d.z, A.rowptr[r + 1] - d.z), s2 = 0.0;
+      const real s1 = lds_seq_sum(lds, A.rowptr[r] - d.z, A.rowptr[r + 1] - d.z), s2 = 0.0;
       tmp[r] = (s1 + s2) * rho[r];
     }
     __syncthreads();
   }
   for (int b = fast ? (int)(blockIdx.x + gridDim.x) : (int)blockIdx.x; b < A.nb; b += gridDim.x) {
     const int4 dd = reinterpret_cast<const int4*>(A.rb)[tile_of_block(b, A.nb, A.xcd_affine)];
-    csr_stream_rows_g(A, [&](int c) { const double2 v = ru[c]; return v.x + beta * v.y; }, dd.x, dd.y, dd.z, dd.w, lds, red,
-                      [&](int r, double s1, double s2) { tmp[r] = (s1 + s2) * rho[r]; });
+    csr_stream_rows_g(A, [&](int c) { const real2 v = ru[c]; return v.x + beta * v.y; }, dd.x, dd.y, dd.z, dd.w, lds, red,
+                      [&](int r, real s1, real s2) { tmp[r] = (s1 + s2) * rho[r]; });
   }
 }
 
 // Krylov step k, second half: alpha = res_k^2 / (u.c) ; x += alpha u ; r -= alpha c ; partial sum r^2
 __global__ __launch_bounds__(COSMO_BS) void k_cg_upd(Ctl* __restrict__ ctl, int guard, int k, long long n,
-                                                     const double* __restrict__ part_uc, int n_uc,
-                                                     const double* __restrict__ u, const double* __restrict__ c,
-                                                     double* __restrict__ x, double* __restrict__ r,
-                                                     double* __restrict__ part_rr, double2* __restrict__ ru) {
+                                                     const real* __restrict__ part_uc, int n_uc,
+                                                     const real* __restrict__ u, const real* __restrict__ c,
+                                                     real* __restrict__ x, real* __restrict__ r,
+                                                     real* __restrict__ part_rr, real2* __restrict__ ru) {
   const long long i0 = (long long)blockIdx.x * COSMO_BS + threadIdx.x;
-  double u0 = 0.0, c0 = 0.0, x0 = 0.0, r0 = 0.0;
+  real u0 = 0.0, c0 = 0.0, x0 = 0.0, r0 = 0.0;
   if (i0 < n) { u0 = u[i0]; c0 = c[i0]; x0 = x[i0]; r0 = r[i0]; }   // issued before the scalar work (latency overlap)
-  const double pa = partials_prefetch_sum(part_uc, n_uc);
+  const real pa = partials_prefetch_sum(part_uc, n_uc);
   if (guard && ctl->halt) return;
   if (ctl->cg_done) return;
-  __shared__ double red[COSMO_BS / 64];
-  const double res = ctl->resv[k & 1];
-  const double uc = block_sum(pa, red);
-  const double alpha = (res * res) / uc;
-  double acc = 0.0;
+  __shared__ real red[COSMO_BS / 64];
+  const real res = ctl->resv[k & 1];
+  const real uc = block_sum(pa, red);
+  const real alpha = (res * res) / uc;
+  real acc = 0.0;
   if (i0 < n) {
     x[i0] = x0 + alpha * u0;
-    const double ri = r0 - alpha * c0;
+    const real ri = r0 - alpha * c0;
     r[i0] = ri;
-    if (ru) ru[i0] = make_double2(ri, u0);       // {r_{k+1}, u_k}: the operands of the fused direction + product kernel
+    if (ru) ru[i0] = make_real2(ri, u0);       // {r_{k+1}, u_k}: the operands of the fused direction + product kernel
     acc += ri * ri;
   }
   for (long long i = i0 + (long long)gridDim.x * COSMO_BS; i < n; i += (long long)gridDim.x * COSMO_BS) {
-    const double ui = u[i];
+    const real ui = u[i];
     x[i] = x[i] + alpha * ui;
-    const double ri = r[i] - alpha * c[i];
+    const real ri = r[i] - alpha * c[i];
     r[i] = ri;
-    if (ru) ru[i] = make_double2(ri, ui);
+    if (ru) ru[i] = make_real2(ri, ui);
     acc += ri * ri;
   }
   acc = block_sum(acc, red);
@@ -391,10 +391,10 @@ __global__ __launch_bounds__(COSMO_BS) void k_cg_upd(Ctl* __restrict__ ctl, int 
 // loop_mode 1: also detects an exhausted Krylov budget (stall) and advances the device counters.
 // loop_mode 0: fine-grained solve (only nu is produced).
 __global__ __launch_bounds__(COSMO_BS) void k_tail(Ctl* __restrict__ ctl, int loop_mode, CsrView A, long long n, long long m,
-                                                   double alpha, const double* __restrict__ x_tl,
-                                                   const double* __restrict__ ls_s, const double* __restrict__ rho,
-                                                   const double* __restrict__ s, double* __restrict__ nu,
-                                                   double* __restrict__ s_tl, double* __restrict__ w, int nblk_rows) {
+                                                   real alpha, const real* __restrict__ x_tl,
+                                                   const real* __restrict__ ls_s, const real* __restrict__ rho,
+                                                   const real* __restrict__ s, real* __restrict__ nu,
+                                                   real* __restrict__ s_tl, real* __restrict__ w, int nblk_rows) {
   if (loop_mode) {
     if (ctl->halt) return;
     if (!ctl->cg_done) {
@@ -402,19 +402,19 @@ __global__ __launch_bounds__(COSMO_BS) void k_tail(Ctl* __restrict__ ctl, int lo
       return;
     }
   }
-  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
-  __shared__ double red[COSMO_BS / 64];
+  __shared__ real lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ real red[COSMO_BS / 64];
   if ((int)blockIdx.x < nblk_rows) {
     for (int k = blockIdx.x; k < A.nb; k += nblk_rows) {
-      csr_stream_tile(A, x_tl, x_tl, k, lds, red, [&](int row, double s1, double s2) {
-        const double ax = s1 + s2;
-        const double rh = rho[row];
-        const double nv = (ax - ls_s[row]) * rh;
+      csr_stream_tile(A, x_tl, x_tl, k, lds, red, [&](int row, real s1, real s2) {
+        const real ax = s1 + s2;
+        const real rh = rho[row];
+        const real nv = (ax - ls_s[row]) * rh;
         nu[row] = nv;
         if (loop_mode) {
-          const double sv = s[row];
-          const double wv = w[n + row];
-          const double st = (2.0 * sv - wv) - nv / rh;
+          const real sv = s[row];
+          const real wv = w[n + row];
+          const real st = (R(2.0) * sv - wv) - nv / rh;
           s_tl[row] = st;
           w[n + row] = wv + alpha * (st - sv);
         }
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_tail(Ctl* __restrict__ ctl, int lo
   } else if (loop_mode) {
     const long long nb2 = gridDim.x - nblk_rows;
     for (long long i = (long long)(blockIdx.x - nblk_rows) * COSMO_BS + threadIdx.x; i < n; i += nb2 * COSMO_BS) {
-      const double wv = w[i];
+      const real wv = w[i];
       w[i] = wv + alpha * (x_tl[i] - wv);
     }
     if ((int)blockIdx.x == nblk_rows && threadIdx.x == 0) {
@@ -449,23 +449,23 @@ __global__ void k_count_solve(Ctl* __restrict__ ctl) {
 // primal pass over A:  r_prim = A x + s - b ; norms of Einv-scaled r_prim, A x, s, b
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(COSMO_BS) void k_chk_prim(const Ctl* __restrict__ ctl, int guard, CsrView A, long long n,
-                                                       const double* __restrict__ w_prev, const double* __restrict__ s,
-                                                       const double* __restrict__ b, const double* __restrict__ rho,
-                                                       const double* __restrict__ Einv, double* __restrict__ mu,
-                                                       double* __restrict__ part_rp, double* __restrict__ part_mp) {
+                                                       const real* __restrict__ w_prev, const real* __restrict__ s,
+                                                       const real* __restrict__ b, const real* __restrict__ rho,
+                                                       const real* __restrict__ Einv, real* __restrict__ mu,
+                                                       real* __restrict__ part_rp, real* __restrict__ part_mp) {
   if (guard && ctl->halt) return;
-  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
-  __shared__ double red[COSMO_BS / 64];
-  double rp = 0.0, mp = 0.0;
+  __shared__ real lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ real red[COSMO_BS / 64];
+  real rp = 0.0, mp = 0.0;
   for (int k = blockIdx.x; k < A.nb; k += gridDim.x) {
-    csr_stream_tile(A, w_prev, w_prev, k, lds, red, [&](int row, double s1, double s2) {
-      const double ax = s1 + s2;
-      const double sv = s[row];
-      const double bv = b[row];
+    csr_stream_tile(A, w_prev, w_prev, k, lds, red, [&](int row, real s1, real s2) {
+      const real ax = s1 + s2;
+      const real sv = s[row];
+      const real bv = b[row];
       mu[row] = rho[row] * (w_prev[n + row] - sv);
-      double rv = ax + sv;
+      real rv = ax + sv;
       rv = rv - bv;
-      double e = 1.0;
+      real e = 1.0;
       if (Einv) e = Einv[row];
       if (Einv) rv = rv * e;
       rp = amax(rp, rv);
@@ -481,24 +481,24 @@ __global__ __launch_bounds__(COSMO_BS) void k_chk_prim(const Ctl* __restrict__ c
 
 // dual pass over [P | A']:  r_dual = P x + q - A' mu ; norms of cinv*Dinv-scaled r_dual, P x, q, A' mu ; x'Px, q'x
 __global__ __launch_bounds__(COSMO_BS) void k_chk_dual(const Ctl* __restrict__ ctl, int guard, CsrView PT,
-                                                       const double* __restrict__ w_prev, const double* __restrict__ mu,
-                                                       const double* __restrict__ q, const double* __restrict__ Dinv,
-                                                       double cinv, int unscale, double* __restrict__ part_rd,
-                                                       double* __restrict__ part_md, double* __restrict__ part_xpx,
-                                                       double* __restrict__ part_qx) {
+                                                       const real* __restrict__ w_prev, const real* __restrict__ mu,
+                                                       const real* __restrict__ q, const real* __restrict__ Dinv,
+                                                       real cinv, int unscale, real* __restrict__ part_rd,
+                                                       real* __restrict__ part_md, real* __restrict__ part_xpx,
+                                                       real* __restrict__ part_qx) {
   if (guard && ctl->halt) return;
-  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
-  __shared__ double red[COSMO_BS / 64];
-  double rd = 0.0, md = 0.0, xpx = 0.0, qx = 0.0;
+  __shared__ real lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ real red[COSMO_BS / 64];
+  real rd = 0.0, md = 0.0, xpx = 0.0, qx = 0.0;
   for (int k = blockIdx.x; k < PT.nb; k += gridDim.x) {
-    csr_stream_tile(PT, w_prev, mu, k, lds, red, [&](int row, double px, double atm) {
-      const double xv = w_prev[row];
-      const double qv = q[row];
-      double rv = px + qv;
+    csr_stream_tile(PT, w_prev, mu, k, lds, red, [&](int row, real px, real atm) {
+      const real xv = w_prev[row];
+      const real qv = q[row];
+      real rv = px + qv;
       rv = rv - atm;
-      double a = px, bq = qv, cm = atm;
+      real a = px, bq = qv, cm = atm;
       if (unscale) {
-        const double d = Dinv ? Dinv[row] : 1.0;
+        const real d = Dinv ? Dinv[row] : 1.0;
         rv = (rv * d) * cinv;
         a = (a * d) * cinv;
         bq = (bq * d) * cinv;
@@ -527,33 +527,33 @@ __global__ __launch_bounds__(COSMO_BS) void k_chk_dual(const Ctl* __restrict__ c
 // mode 3 = info + cost without a decision (cosmo_hip_residuals)
 // mode 2 = adapt_rho_vec! (parameters.jl:53-72): scalar rule; sets rho_changed for k_rho_apply
 struct ChkArgs {
-  const double *part_rp, *part_mp, *part_rd, *part_md, *part_xpx, *part_qx;
+  const real *part_rp, *part_mp, *part_rd, *part_md, *part_xpx, *part_qx;
   int n_prim, n_dual;
   int mode;
-  double cinv, eps_abs, eps_rel;
-  double obj_true, obj_true_tol;
-  double rho_min, rho_max, adapt_tol;
+  real cinv, eps_abs, eps_rel;
+  real obj_true, obj_true_tol;
+  real rho_min, rho_max, adapt_tol;
   long long max_adaptions;
 };
 __global__ __launch_bounds__(COSMO_BS) void k_chk_final(Ctl* __restrict__ ctl, int guard, ChkArgs a) {
   if (guard && ctl->halt) return;
-  __shared__ double red[COSMO_BS / 64];
-  const double rp = reduce_partials_max(a.part_rp, a.n_prim, red);
-  const double mp = reduce_partials_max(a.part_mp, a.n_prim, red);
-  const double rd = reduce_partials_max(a.part_rd, a.n_dual, red);
-  const double md = reduce_partials_max(a.part_md, a.n_dual, red);
-  const double xpx = reduce_partials_sum(a.part_xpx, a.n_dual, red);
-  const double qx = reduce_partials_sum(a.part_qx, a.n_dual, red);
+  __shared__ real red[COSMO_BS / 64];
+  const real rp = reduce_partials_max(a.part_rp, a.n_prim, red);
+  const real mp = reduce_partials_max(a.part_mp, a.n_prim, red);
+  const real rd = reduce_partials_max(a.part_rd, a.n_dual, red);
+  const real md = reduce_partials_max(a.part_md, a.n_dual, red);
+  const real xpx = reduce_partials_sum(a.part_xpx, a.n_dual, red);
+  const real qx = reduce_partials_sum(a.part_qx, a.n_dual, red);
   if (threadIdx.x != 0) return;
   if (a.mode == 2) {
     ctl->rho_changed = 0;
     if ((long long)(ctl->n_rho_updates - 1) >= a.max_adaptions) return;
-    const double rpn = rp / (mp + 1e-10);
-    const double rdn = rd / (md + 1e-10);
-    const double rho = ctl->rho;
-    double nr = rho * sqrt(rpn / (rdn + 1e-10));
+    const real rpn = rp / (mp + R(1e-10));
+    const real rdn = rd / (md + R(1e-10));
+    const real rho = ctl->rho;
+    real nr = rho * sqrt(rpn / (rdn + R(1e-10)));
     nr = fmin(fmax(nr, a.rho_min), a.rho_max);
-    if ((nr > a.adapt_tol * rho) || (nr < (1.0 / a.adapt_tol) * rho)) {
+    if ((nr > a.adapt_tol * rho) || (nr < (R(1.0) / a.adapt_tol) * rho)) {
       ctl->rho = nr;
       ctl->rho_changed = 1;
       const int k = ctl->n_rho_updates;
@@ -564,10 +564,10 @@ __global__ __launch_bounds__(COSMO_BS) void k_chk_final(Ctl* __restrict__ ctl, i
   }
   ctl->r_prim = rp; ctl->r_dual = rd; ctl->max_norm_prim = mp; ctl->max_norm_dual = md;
   if (a.mode == 1 || a.mode == 3) {
-    const double cost = a.cinv * (0.5 * xpx + qx);
+    const real cost = a.cinv * (R(0.5) * xpx + qx);
     ctl->cost = cost;
     if (a.mode == 3) return;
-    if (fabs(cost) > 1e20) { ctl->status = COSMO_HIP_UNSOLVED; ctl->halt = 1; return; }
+    if (fabs(cost) > R(1e20)) { ctl->status = COSMO_HIP_UNSOLVED; ctl->halt = 1; return; }
     const bool pf = rp < a.eps_abs + a.eps_rel * mp;
     const bool df = rd < a.eps_abs + a.eps_rel * md;
     const bool ot = (a.obj_true != a.obj_true) || (fabs(a.obj_true - cost) <= a.obj_true_tol);   // has_converged (residuals.jl:131-139)
@@ -577,27 +577,27 @@ __global__ __launch_bounds__(COSMO_BS) void k_chk_final(Ctl* __restrict__ ctl, i
 
 // update_rho_vec! (parameters.jl:75-92) + w_s = 1/rho * mu + s (solver.jl:278), only if the rule fired
 __global__ __launch_bounds__(COSMO_BS) void k_rho_apply(const Ctl* __restrict__ ctl, int guard, long long n, long long m,
-                                                        const int* __restrict__ cls, double rho_min, double rho_eq,
-                                                        const double* __restrict__ mu, const double* __restrict__ s,
-                                                        double* __restrict__ rho, double* __restrict__ w) {
+                                                        const int* __restrict__ cls, real rho_min, real rho_eq,
+                                                        const real* __restrict__ mu, const real* __restrict__ s,
+                                                        real* __restrict__ rho, real* __restrict__ w) {
   if (guard && ctl->halt) return;
   if (!ctl->rho_changed) return;
-  const double nr = ctl->rho;
+  const real nr = ctl->rho;
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < m; i += (long long)gridDim.x * COSMO_BS) {
     const int c = cls[i];
-    double rv = nr;
+    real rv = nr;
     if (c == 1) rv = rv * rho_eq; else if (c == 2) rv = rho_min;
     rho[i] = rv;
-    w[n + i] = (1.0 / rv) * mu[i] + s[i];
+    w[n + i] = (R(1.0) / rv) * mu[i] + s[i];
   }
 }
 
 // rho vector from classes (set_rho_vec!, parameters.jl:3-13)
-__global__ __launch_bounds__(COSMO_BS) void k_rho_from_classes(long long m, const int* __restrict__ cls, double rho0,
-                                                               double rho_min, double rho_eq, double* __restrict__ rho) {
+__global__ __launch_bounds__(COSMO_BS) void k_rho_from_classes(long long m, const int* __restrict__ cls, real rho0,
+                                                               real rho_min, real rho_eq, real* __restrict__ rho) {
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < m; i += (long long)gridDim.x * COSMO_BS) {
     const int c = cls[i];
-    double rv = rho0;
+    real rv = rho0;
     if (c == 1) rv = rv * rho_eq; else if (c == 2) rv = rho_min;
     rho[i] = rv;
   }
@@ -618,14 +618,14 @@ static inline int ew_grid(long long N) {
 
 #define PARTS(h, slot) ((h)->partials + (size_t)(slot) * COSMO_MAX_PARTIALS)
 
-int32_t launch_spmv_plain(cosmo_hip_handle* h, const CsrDev& M, const double* x, double* y) {
+int32_t launch_spmv_plain(cosmo_hip_handle* h, const CsrDev& M, const real* x, real* y) {
   if (M.nrows == 0) return COSMO_HIP_OK;
   hipLaunchKernelGGL(k_spmv_plain, dim3(M.grid), dim3(COSMO_BS), 0, h->stream, view_of(M), x, y);
   HIPCHK(h, hipGetLastError());
   return COSMO_HIP_OK;
 }
 
-int32_t launch_project_simple_inplace(cosmo_hip_handle* h, double* s) {
+int32_t launch_project_simple_inplace(cosmo_hip_handle* h, real* s) {
   if (h->m == 0) return COSMO_HIP_OK;
   hipLaunchKernelGGL(k_project_simple_inplace, dim3(ew_grid(h->m)), dim3(COSMO_BS), 0, h->stream, h->m, s, h->meta,
                      h->box_l, h->box_u);
@@ -642,7 +642,7 @@ int32_t launch_z(cosmo_hip_handle* h, int guard) {
   return COSMO_HIP_OK;
 }
 
-int32_t launch_soc(cosmo_hip_handle* h, double* s, int guard) {
+int32_t launch_soc(cosmo_hip_handle* h, real* s, int guard) {
   if (h->nsoc == 0) return COSMO_HIP_OK;
   int g = (h->nsoc + (COSMO_BS / 64) - 1) / (COSMO_BS / 64);
   if (g > 4096) g = 4096;
@@ -654,7 +654,7 @@ int32_t launch_soc(cosmo_hip_handle* h, double* s, int guard) {
   return COSMO_HIP_OK;
 }
 
-int32_t launch_set_w(cosmo_hip_handle* h, const double* x0, const double* s0, const double* mu0) {
+int32_t launch_set_w(cosmo_hip_handle* h, const real* x0, const real* s0, const real* mu0) {
   hipLaunchKernelGGL(k_set_w, dim3(ew_grid(h->n + h->m)), dim3(COSMO_BS), 0, h->stream, h->n, h->m, x0, s0, mu0, h->rho,
                      h->w, h->s);
   HIPCHK(h, hipGetLastError());
@@ -669,7 +669,7 @@ int32_t launch_recover_mu(cosmo_hip_handle* h) {
   return COSMO_HIP_OK;
 }
 
-int32_t launch_rho_from_classes(cosmo_hip_handle* h, double rho0) {
+int32_t launch_rho_from_classes(cosmo_hip_handle* h, real rho0) {
   if (h->m == 0) return COSMO_HIP_OK;
   hipLaunchKernelGGL(k_rho_from_classes, dim3(ew_grid(h->m)), dim3(COSMO_BS), 0, h->stream, h->m, h->rho_cls, rho0,
                      h->prm.rho_min, h->prm.rho_eq_over_rho_ineq, h->rho);
@@ -685,14 +685,14 @@ int32_t enqueue_cg_iterations(cosmo_hip_handle* h, int guard, int k_begin, int c
   const int gE = ew_grid(n);
   const CsrDev& Ao = h->op_split ? h->Am : h->A;
   const CsrDev& PTo = h->op_split ? h->PTm : h->PT;
-  const double* rho_o = h->op_split ? h->op_rho_m : h->rho;
-  const double* diag_o = h->op_split ? h->op_diag : nullptr;
+  const real* rho_o = h->op_split ? h->op_rho_m : h->rho;
+  const real* diag_o = h->op_split ? h->op_diag : nullptr;
   const int n_rr0 = PTo.grid;
   for (int k = k_begin; k < k_begin + count; ++k) {
     if (h->cg_ru && k > 0) {
       prof_begin(h, KC_SPMV_A);
       hipLaunchKernelGGL(k_cg_dirA, dim3(Ao.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, k, n, n, PARTS(h, SLOT_RR), gE, view_of(Ao),
-                         (const double2*)h->cg_ru, rho_o, h->tmp_m, h->u);
+                         (const real2*)h->cg_ru, rho_o, h->tmp_m, h->u);
       prof_end(h);
     } else {
       prof_begin(h, KC_CG_DIR);
@@ -710,7 +710,7 @@ int32_t enqueue_cg_iterations(cosmo_hip_handle* h, int guard, int k_begin, int c
     prof_end(h);
     prof_begin(h, KC_CG_UPD);
     hipLaunchKernelGGL(k_cg_upd, dim3(gE), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, k, n, PARTS(h, SLOT_UC),
-                       PTo.grid, h->u, h->c, h->x_tl, h->r, PARTS(h, SLOT_RR), (double2*)h->cg_ru);
+                       PTo.grid, h->u, h->c, h->x_tl, h->r, PARTS(h, SLOT_RR), (real2*)h->cg_ru);
     prof_end(h);
     h->spmv_calls[0] += 1; h->spmv_calls[1] += 1; h->spmv_calls[2] += 1;
   }
@@ -724,7 +724,7 @@ int32_t enqueue_cg_iterations(cosmo_hip_handle* h, int guard, int k_begin, int c
   return COSMO_HIP_OK;
 }
 
-int32_t enqueue_cg_start(cosmo_hip_handle* h, int guard, double tol_k) {
+int32_t enqueue_cg_start(cosmo_hip_handle* h, int guard, real tol_k) {
   prof_begin(h, KC_SPMV_AT);
   hipLaunchKernelGGL(k_cg_rhs, dim3(h->AT.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, view_of(h->AT), h->y2,
                      h->ls_x, h->rhs, PARTS(h, SLOT_BB));
@@ -791,7 +791,7 @@ int32_t enqueue_check(cosmo_hip_handle* h, int guard, int mode) {
   const bool unscale = (mode != 2) && h->prm.unscale_residuals && h->has_scaling;
   prof_begin(h, KC_CHK_PRIM);
   hipLaunchKernelGGL(k_chk_prim, dim3(h->A.grid > 0 ? h->A.grid : 1), dim3(COSMO_BS), 0, h->stream, h->ctl, guard,
-                     view_of(h->A), h->n, h->w_prev, h->s, h->b, h->rho, unscale ? h->Einv : (const double*)nullptr, h->mu,
+                     view_of(h->A), h->n, h->w_prev, h->s, h->b, h->rho, unscale ? h->Einv : (const real*)nullptr, h->mu,
                      PARTS(h, SLOT_RP), PARTS(h, SLOT_MP));
   prof_end(h);
   prof_begin(h, KC_CHK_DUAL);
@@ -836,11 +836,11 @@ int32_t time_op_apply(cosmo_hip_handle* h, int reps, double* avg_seconds) {
 
 // ---- CG operator split: refresh of the rho-dependent pieces -----------------------------------------------------------
 __global__ __launch_bounds__(COSMO_BS) void k_op_refresh(long long n, long long mm, const int* __restrict__ sc_ptr, const int* __restrict__ sc_row,
-                                                         const double* __restrict__ sc_a2, const int* __restrict__ mrow,
-                                                         const double* __restrict__ rho, double* __restrict__ diag, double* __restrict__ rho_m) {
+                                                         const real* __restrict__ sc_a2, const int* __restrict__ mrow,
+                                                         const real* __restrict__ rho, real* __restrict__ diag, real* __restrict__ rho_m) {
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < n + mm; i += (long long)gridDim.x * COSMO_BS) {
     if (i < n) {
-      double s = 0.0;
+      real s = 0.0;
       for (int k = sc_ptr[i]; k < sc_ptr[i + 1]; ++k) s += rho[sc_row[k]] * sc_a2[k];     // fixed order: rows ascending
       diag[i] = s;
     } else {
@@ -861,7 +861,7 @@ int32_t refresh_op_split(cosmo_hip_handle* h) {
 int32_t launch_cg_upd(cosmo_hip_handle* h, int guard, int k, int n_uc) {
   prof_begin(h, KC_CG_UPD);
   hipLaunchKernelGGL(k_cg_upd, dim3(ew_grid(h->n)), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, k, h->n, PARTS(h, SLOT_UC), n_uc, h->u, h->c,
-                     h->x_tl, h->r, PARTS(h, SLOT_RR), (double2*)h->cg_ru);
+                     h->x_tl, h->r, PARTS(h, SLOT_RR), (real2*)h->cg_ru);
   prof_end(h);
   return COSMO_HIP_OK;
 }
@@ -873,13 +873,13 @@ int32_t launch_cg_dir_check(cosmo_hip_handle* h, int guard, int kk, int n_rr) {
 }
 
 // launch helpers used by minres.hip (keeps every kernel launch next to its definition)
-int32_t launch_spmv_A_rho(cosmo_hip_handle* h, int guard, int mode, const double* v, double* out) {
+int32_t launch_spmv_A_rho(cosmo_hip_handle* h, int guard, int mode, const real* v, real* out) {
   hipLaunchKernelGGL(k_spmv_A_rho, dim3(h->A.grid > 0 ? h->A.grid : 1), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, mode, view_of(h->A), v,
                      h->rho, out);
   HIPCHK(h, hipGetLastError());
   return COSMO_HIP_OK;
 }
-int32_t launch_reduced_rhs(cosmo_hip_handle* h, int guard, double* out_rhs) {
+int32_t launch_reduced_rhs(cosmo_hip_handle* h, int guard, real* out_rhs) {
   hipLaunchKernelGGL(k_cg_rhs, dim3(h->AT.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, view_of(h->AT), h->y2, h->ls_x, out_rhs,
                      PARTS(h, SLOT_BB));
   HIPCHK(h, hipGetLastError());

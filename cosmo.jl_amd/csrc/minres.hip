@@ -18,56 +18,56 @@
 int32_t enqueue_tail(cosmo_hip_handle* h, int loop_mode);
 int32_t enqueue_count_solve(cosmo_hip_handle* h);
 int32_t sync_ctl(cosmo_hip_handle* h);
-int32_t launch_spmv_A_rho(cosmo_hip_handle* h, int guard, int mode, const double* v, double* out);
-int32_t launch_reduced_rhs(cosmo_hip_handle* h, int guard, double* out_rhs);
+int32_t launch_spmv_A_rho(cosmo_hip_handle* h, int guard, int mode, const real* v, real* out);
+int32_t launch_reduced_rhs(cosmo_hip_handle* h, int guard, real* out_rhs);
 int32_t enqueue_y2_only(cosmo_hip_handle* h);
 
 // state slot layout inside Ctl::minres (two slots of 8 doubles, indexed by iteration parity)
 enum { MS_H1 = 0, MS_CP, MS_SP, MS_CC, MS_SC, MS_RHS0, MS_RES, MS_PAD };
 
 struct MrVecs {
-  double *v[3], *w[3];   // Krylov basis and W = V R^-1 recurrences (rotating)
-  double* x;             // solution / warm start (n or n+m)
-  double* b;             // right-hand side of the (reduced or full) system
+  real *v[3], *w[3];   // Krylov basis and W = V R^-1 recurrences (rotating)
+  real* x;             // solution / warm start (n or n+m)
+  real* b;             // right-hand side of the (reduced or full) system
   long long N;
 };
 
 // Givens rotation as LinearAlgebra.givensAlgorithm(f, g) for reals: [c s; -s c] [f; g] = [r; 0]
-__device__ __forceinline__ void givens(double f, double g, double& c, double& s, double& r) {
-  if (g == 0.0) { c = 1.0; s = 0.0; r = f; return; }
-  if (f == 0.0) { c = 0.0; s = 1.0; r = g; return; }
+__device__ __forceinline__ void givens(real f, real g, real& c, real& s, real& r) {
+  if (g == R(0.0)) { c = R(1.0); s = R(0.0); r = f; return; }
+  if (f == R(0.0)) { c = R(0.0); s = R(1.0); r = g; return; }
   r = hypot(f, g);
   c = f / r; s = g / r;
-  if (fabs(f) > fabs(g) && c < 0.0) { c = -c; s = -s; r = -r; }
+  if (fabs(f) > fabs(g) && c < R(0.0)) { c = -c; s = -s; r = -r; }
 }
 
 // top block rows (0..n): y = P v1 + (sigma v1 + A' v2) through the merged operator [P | A'].
 // mode 0 (start): vout = b - y (top part), partial ||.||^2        mode 1 (iteration): y -= h1 vprev ; vout = y ; partial <vcurr, y>
-__global__ __launch_bounds__(COSMO_BS) void k_mr_op_top(Ctl* __restrict__ ctl, int guard, int mode, int it, long long maxiter, CsrView PT, double sigma,
-                                                        const double* __restrict__ v1, const double* __restrict__ v2,
-                                                        const double* __restrict__ vprev, const double* __restrict__ b,
-                                                        double* __restrict__ vout, double* __restrict__ part) {
+__global__ __launch_bounds__(COSMO_BS) void k_mr_op_top(Ctl* __restrict__ ctl, int guard, int mode, int it, long long maxiter, CsrView PT, real sigma,
+                                                        const real* __restrict__ v1, const real* __restrict__ v2,
+                                                        const real* __restrict__ vprev, const real* __restrict__ b,
+                                                        real* __restrict__ vout, real* __restrict__ part) {
   if (guard && ctl->halt) return;
   if (ctl->cg_done) return;
-  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
-  __shared__ double red[COSMO_BS / 64];
-  const double h1 = ctl->minres[((it - 1) & 1) * 8 + MS_H1];
+  __shared__ real lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ real red[COSMO_BS / 64];
+  const real h1 = ctl->minres[((it - 1) & 1) * 8 + MS_H1];
   if (mode == 1) {
     // done(m, iteration): iteration > maxiter || resnorm <= tolerance, evaluated BEFORE the iteration.  Every workgroup
     // takes the same decision from the read-only previous state; workgroup 0 publishes it for the later kernels.
-    const double res = ctl->minres[((it - 1) & 1) * 8 + MS_RES];
+    const real res = ctl->minres[((it - 1) & 1) * 8 + MS_RES];
     if (res <= ctl->tol || (long long)it > maxiter) {
       if (blockIdx.x == 0 && threadIdx.x == 0) ctl->cg_done = 1;
       return;
     }
   }
-  double acc = 0.0;
+  real acc = 0.0;
   for (int k = blockIdx.x; k < PT.nb; k += gridDim.x) {
-    csr_stream_tile(PT, v1, v2, k, lds, red, [&](int row, double s1, double s2) {
-      const double vc = v1[row];
-      double y = s1 + (sigma * vc + s2);
+    csr_stream_tile(PT, v1, v2, k, lds, red, [&](int row, real s1, real s2) {
+      const real vc = v1[row];
+      real y = s1 + (sigma * vc + s2);
       if (mode == 0) {
-        const double r = b[row] - y;
+        const real r = b[row] - y;
         vout[row] = r;
         acc += r * r;
       } else {
@@ -83,22 +83,22 @@ __global__ __launch_bounds__(COSMO_BS) void k_mr_op_top(Ctl* __restrict__ ctl, i
 
 // bottom block rows of the full KKT operator: y2 = A v1 + (-v2 / rho)          (kktsolver_indirect.jl:142-144)
 __global__ __launch_bounds__(COSMO_BS) void k_mr_op_bot(Ctl* __restrict__ ctl, int guard, int mode, int it, CsrView A, long long n,
-                                                        const double* __restrict__ v1, const double* __restrict__ v2,
-                                                        const double* __restrict__ rho, const double* __restrict__ vprev,
-                                                        const double* __restrict__ b, double* __restrict__ vout,
-                                                        double* __restrict__ part) {
+                                                        const real* __restrict__ v1, const real* __restrict__ v2,
+                                                        const real* __restrict__ rho, const real* __restrict__ vprev,
+                                                        const real* __restrict__ b, real* __restrict__ vout,
+                                                        real* __restrict__ part) {
   if (guard && ctl->halt) return;
   if (ctl->cg_done) return;
-  __shared__ double lds[COSMO_NNZ_PER_BLOCK];
-  __shared__ double red[COSMO_BS / 64];
-  const double h1 = ctl->minres[((it - 1) & 1) * 8 + MS_H1];
-  double acc = 0.0;
+  __shared__ real lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ real red[COSMO_BS / 64];
+  const real h1 = ctl->minres[((it - 1) & 1) * 8 + MS_H1];
+  real acc = 0.0;
   for (int k = blockIdx.x; k < A.nb; k += gridDim.x) {
-    csr_stream_tile(A, v1, v1, k, lds, red, [&](int row, double s1, double s2) {
-      const double vc = v2[row];
-      double y = (s1 + s2) + (-vc / rho[row]);
+    csr_stream_tile(A, v1, v1, k, lds, red, [&](int row, real s1, real s2) {
+      const real vc = v2[row];
+      real y = (s1 + s2) + (-vc / rho[row]);
       if (mode == 0) {
-        const double r = b[n + row] - y;
+        const real r = b[n + row] - y;
         vout[n + row] = r;
         acc += r * r;
       } else {
@@ -113,41 +113,41 @@ __global__ __launch_bounds__(COSMO_BS) void k_mr_op_bot(Ctl* __restrict__ ctl, i
 }
 
 // start: resnorm = ||b - L x0|| ; tolerance = tol_k / resnorm (abstol, reltol = 0) ; v_curr /= resnorm ; state init
-__global__ __launch_bounds__(COSMO_BS) void k_mr_start(Ctl* __restrict__ ctl, int guard, long long N, const double* __restrict__ part,
-                                                       int npart, double tol_k, double* __restrict__ vcurr) {
+__global__ __launch_bounds__(COSMO_BS) void k_mr_start(Ctl* __restrict__ ctl, int guard, long long N, const real* __restrict__ part,
+                                                       int npart, real tol_k, real* __restrict__ vcurr) {
   if (guard && ctl->halt) return;
-  __shared__ double red[COSMO_BS / 64];
-  const double rr = reduce_partials_sum(part, npart, red);
-  const double res = sqrt(rr);
-  const double tol = tol_k / res;
-  const bool done = (res <= tol) || !(res > 0.0);
+  __shared__ real red[COSMO_BS / 64];
+  const real rr = reduce_partials_sum(part, npart, red);
+  const real res = sqrt(rr);
+  const real tol = tol_k / res;
+  const bool done = (res <= tol) || !(res > R(0.0));
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    double* st = ctl->minres;   // slot 0 = state "after iteration 0"
+    real* st = ctl->minres;   // slot 0 = state "after iteration 0"
     st[MS_H1] = 0.0; st[MS_CP] = 1.0; st[MS_SP] = 0.0; st[MS_CC] = 1.0; st[MS_SC] = 0.0; st[MS_RHS0] = res; st[MS_RES] = res;
     ctl->tol = tol; ctl->rhs_norm = res;
     ctl->cg_done = done ? 1 : 0;
     ctl->cg_k = 0;
   }
   if (done) return;
-  const double inv = 1.0 / res;
+  const real inv = R(1.0) / res;
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) vcurr[i] = vcurr[i] * inv;
 }
 
 // v_next -= <v_curr, v_next> v_curr ; partial ||v_next||^2                     (minres.jl: orthogonalise w.r.t. v_curr)
-__global__ __launch_bounds__(COSMO_BS) void k_mr_orth(Ctl* __restrict__ ctl, int guard, long long N, const double* __restrict__ part_in,
-                                                      int npart, const double* __restrict__ vcurr, double* __restrict__ vnext,
-                                                      double* __restrict__ part_out) {
+__global__ __launch_bounds__(COSMO_BS) void k_mr_orth(Ctl* __restrict__ ctl, int guard, long long N, const real* __restrict__ part_in,
+                                                      int npart, const real* __restrict__ vcurr, real* __restrict__ vnext,
+                                                      real* __restrict__ part_out) {
   const long long i0 = (long long)blockIdx.x * COSMO_BS + threadIdx.x;
-  double vc0 = 0.0, vn0 = 0.0;
+  real vc0 = 0.0, vn0 = 0.0;
   if (i0 < N) { vc0 = vcurr[i0]; vn0 = vnext[i0]; }
   if (guard && ctl->halt) return;
   if (ctl->cg_done) return;
-  __shared__ double red[COSMO_BS / 64];
-  const double proj = reduce_partials_sum(part_in, npart, red);
-  double acc = 0.0;
-  if (i0 < N) { const double y = vn0 - proj * vc0; vnext[i0] = y; acc += y * y; }
+  __shared__ real red[COSMO_BS / 64];
+  const real proj = reduce_partials_sum(part_in, npart, red);
+  real acc = 0.0;
+  if (i0 < N) { const real y = vn0 - proj * vc0; vnext[i0] = y; acc += y * y; }
   for (long long i = i0 + (long long)gridDim.x * COSMO_BS; i < N; i += (long long)gridDim.x * COSMO_BS) {
-    const double y = vnext[i] - proj * vcurr[i];
+    const real y = vnext[i] - proj * vcurr[i];
     vnext[i] = y;
     acc += y * y;
   }
@@ -160,34 +160,34 @@ __global__ __launch_bounds__(COSMO_BS) void k_mr_orth(Ctl* __restrict__ ctl, int
 
 // scalar recurrences + v_next normalisation + W recurrence + solution update + convergence test for the NEXT iteration
 __global__ __launch_bounds__(COSMO_BS) void k_mr_update(Ctl* __restrict__ ctl, int guard, int it, long long N, long long maxiter,
-                                                        const double* __restrict__ part_nn, int npart, const double* __restrict__ vcurr,
-                                                        double* __restrict__ vnext, const double* __restrict__ wprev,
-                                                        const double* __restrict__ wcurr, double* __restrict__ wnext,
-                                                        double* __restrict__ x) {
+                                                        const real* __restrict__ part_nn, int npart, const real* __restrict__ vcurr,
+                                                        real* __restrict__ vnext, const real* __restrict__ wprev,
+                                                        const real* __restrict__ wcurr, real* __restrict__ wnext,
+                                                        real* __restrict__ x) {
   if (guard && ctl->halt) return;
   if (ctl->cg_done) return;
-  __shared__ double red[COSMO_BS / 64];
-  const double* so = ctl->minres + ((it - 1) & 1) * 8;
-  const double nn = reduce_partials_sum(part_nn, npart, red);
-  double H0 = 0.0, H1 = so[MS_H1], H2 = ctl->udotc_slot, H3 = sqrt(nn);
-  const double c_prev = so[MS_CP], s_prev = so[MS_SP], c_curr = so[MS_CC], s_curr = so[MS_SC];
-  double rhs0 = so[MS_RHS0];
+  __shared__ real red[COSMO_BS / 64];
+  const real* so = ctl->minres + ((it - 1) & 1) * 8;
+  const real nn = reduce_partials_sum(part_nn, npart, red);
+  real H0 = 0.0, H1 = so[MS_H1], H2 = ctl->udotc_slot, H3 = sqrt(nn);
+  const real c_prev = so[MS_CP], s_prev = so[MS_SP], c_curr = so[MS_CC], s_curr = so[MS_SC];
+  real rhs0 = so[MS_RHS0];
   if (it > 2) { H0 = s_prev * H1; H1 = c_prev * H1; }
   if (it > 1) {
-    const double tmp = -s_curr * H1 + c_curr * H2;
+    const real tmp = -s_curr * H1 + c_curr * H2;
     H1 = c_curr * H1 + s_curr * H2;
     H2 = tmp;
   }
-  double c, s, r;
+  real c, s, r;
   givens(H2, H3, c, s, r);
   H2 = r;
-  const double rhs1 = -s * rhs0;
+  const real rhs1 = -s * rhs0;
   rhs0 = c * rhs0;
-  const double inv_h3 = 1.0 / H3, inv_h2 = 1.0 / H2;
+  const real inv_h3 = R(1.0) / H3, inv_h2 = R(1.0) / H2;
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) {
-    const double vc = vcurr[i];
+    const real vc = vcurr[i];
     vnext[i] = vnext[i] * inv_h3;
-    double wn = vc;
+    real wn = vc;
     if (it > 1) wn = wn - H1 * wcurr[i];
     if (it > 2) wn = wn - H0 * wprev[i];
     wn = wn * inv_h2;
@@ -195,9 +195,9 @@ __global__ __launch_bounds__(COSMO_BS) void k_mr_update(Ctl* __restrict__ ctl, i
     x[i] = x[i] + rhs0 * wn;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    double* sn = ctl->minres + (it & 1) * 8;
+    real* sn = ctl->minres + (it & 1) * 8;
     sn[MS_H1] = H3; sn[MS_CP] = c_curr; sn[MS_SP] = s_curr; sn[MS_CC] = c; sn[MS_SC] = s; sn[MS_RHS0] = rhs1;
-    const double res = fabs(rhs1);
+    const real res = fabs(rhs1);
     sn[MS_RES] = res;
     ctl->cg_k = it;   // the stop rule for iteration it+1 is evaluated by the next k_mr_op_top / k_mr_finish (never here:
                       // other workgroups of THIS kernel still read cg_done)
@@ -208,15 +208,15 @@ __global__ __launch_bounds__(COSMO_BS) void k_mr_update(Ctl* __restrict__ ctl, i
 __global__ void k_mr_finish(Ctl* ctl, long long maxiter) {
   if (ctl->cg_done) return;
   const int it = ctl->cg_k;
-  const double res = ctl->minres[(it & 1) * 8 + MS_RES];
+  const real res = ctl->minres[(it & 1) * 8 + MS_RES];
   if (res <= ctl->tol || (long long)(it + 1) > maxiter) ctl->cg_done = 1;
 }
 
 // full-KKT tail: sol = [x_tl; nu] is the MINRES iterate itself; s_tl = (2 s - w_s) - nu ./ rho ; w updates (solver.jl:55,63-64)
-__global__ __launch_bounds__(COSMO_BS) void k_mr_tail_full(Ctl* __restrict__ ctl, int loop_mode, long long n, long long m, double alpha,
-                                                           const double* __restrict__ xsol, const double* __restrict__ rho,
-                                                           const double* __restrict__ s, double* __restrict__ x_tl,
-                                                           double* __restrict__ nu, double* __restrict__ s_tl, double* __restrict__ w) {
+__global__ __launch_bounds__(COSMO_BS) void k_mr_tail_full(Ctl* __restrict__ ctl, int loop_mode, long long n, long long m, real alpha,
+                                                           const real* __restrict__ xsol, const real* __restrict__ rho,
+                                                           const real* __restrict__ s, real* __restrict__ x_tl,
+                                                           real* __restrict__ nu, real* __restrict__ s_tl, real* __restrict__ w) {
   if (loop_mode) {
     if (ctl->halt) return;
     if (!ctl->cg_done) {
@@ -226,16 +226,16 @@ __global__ __launch_bounds__(COSMO_BS) void k_mr_tail_full(Ctl* __restrict__ ctl
   }
   const long long N = n + m;
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) {
-    const double v = xsol[i];
+    const real v = xsol[i];
     if (i < n) {
       x_tl[i] = v;
-      if (loop_mode) { const double wv = w[i]; w[i] = wv + alpha * (v - wv); }
+      if (loop_mode) { const real wv = w[i]; w[i] = wv + alpha * (v - wv); }
     } else {
       const long long r = i - n;
       nu[r] = v;
       if (loop_mode) {
-        const double sv = s[r], wv = w[i];
-        const double st = (2.0 * sv - wv) - v / rho[r];
+        const real sv = s[r], wv = w[i];
+        const real st = (R(2.0) * sv - wv) - v / rho[r];
         s_tl[r] = st;
         w[i] = wv + alpha * (st - sv);
       }
@@ -249,8 +249,8 @@ __global__ __launch_bounds__(COSMO_BS) void k_mr_tail_full(Ctl* __restrict__ ctl
 }
 
 // reduced system right-hand side: b = A' (rho .* ls_s) + ls_x is produced by k_cg_rhs (kernels.hip); copy helpers below
-__global__ __launch_bounds__(COSMO_BS) void k_mr_copy2(long long n, long long m, const double* __restrict__ a, const double* __restrict__ b2,
-                                                       double* __restrict__ out) {
+__global__ __launch_bounds__(COSMO_BS) void k_mr_copy2(long long n, long long m, const real* __restrict__ a, const real* __restrict__ b2,
+                                                       real* __restrict__ out) {
   const long long N = n + m;
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS)
     out[i] = (i < n) ? a[i] : b2[i - n];
@@ -268,8 +268,8 @@ static inline int ewg(long long N) {
 int32_t minres_alloc(cosmo_hip_handle* h) {
   if (h->mr) { (void)hipFree(h->mr); h->mr = nullptr; }
   const size_t N = (size_t)(h->n + h->m);
-  HIPCHK(h, hipMalloc((void**)&h->mr, sizeof(double) * 8 * std::max<size_t>(N, 1)));
-  HIPCHK(h, hipMemsetAsync(h->mr, 0, sizeof(double) * 8 * std::max<size_t>(N, 1), h->stream));
+  HIPCHK(h, hipMalloc((void**)&h->mr, sizeof(real) * 8 * std::max<size_t>(N, 1)));
+  HIPCHK(h, hipMemsetAsync(h->mr, 0, sizeof(real) * 8 * std::max<size_t>(N, 1), h->stream));
   return COSMO_HIP_OK;
 }
 
@@ -285,8 +285,8 @@ static MrVecs vecs_of(cosmo_hip_handle* h) {
 }
 
 // operator apply y = L v for either system; partial slots: SLOT_UC (top) and SLOT_AUX1 (bottom, full system only)
-static int32_t enqueue_mr_apply(cosmo_hip_handle* h, int guard, int mode, int it, const MrVecs& V, const double* v, const double* vprev,
-                                double* vout) {
+static int32_t enqueue_mr_apply(cosmo_hip_handle* h, int guard, int mode, int it, const MrVecs& V, const real* v, const real* vprev,
+                                real* vout) {
   const bool full = h->prm.kkt_kind == COSMO_HIP_KKT_MINRES;
   const long long n = h->n;
   prof_begin(h, KC_OP_APPLY);
@@ -316,8 +316,8 @@ int32_t minres_enqueue_iterations(cosmo_hip_handle* h, int guard, int it_begin, 
   const int gE = ewg(V.N);
   for (int it = it_begin; it < it_begin + count; ++it) {
     // buffers rotate: curr = (it-1) % 3, next = it % 3, prev = (it-2) % 3  (it is 1-based)
-    double* vc = V.v[(it + 2) % 3]; double* vn = V.v[it % 3]; double* vp = V.v[(it + 1) % 3];
-    double* wc = V.w[(it + 2) % 3]; double* wn = V.w[it % 3]; double* wp = V.w[(it + 1) % 3];
+    real* vc = V.v[(it + 2) % 3]; real* vn = V.v[it % 3]; real* vp = V.v[(it + 1) % 3];
+    real* wc = V.w[(it + 2) % 3]; real* wn = V.w[it % 3]; real* wp = V.w[(it + 1) % 3];
     CHK(enqueue_mr_apply(h, guard, 1, it, V, vc, vp, vn));
     prof_begin(h, KC_MINRES_VEC);
     hipLaunchKernelGGL(k_mr_orth, dim3(gE), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, V.N, MPARTS(h, SLOT_UC), npart_apply(h), vc, vn,
@@ -342,7 +342,7 @@ static int32_t enqueue_mr_tail(cosmo_hip_handle* h, int loop_mode) {
     return COSMO_HIP_OK;
   }
   // reduced: y1 = solution ; y2 = rho (A y1 - x2) and the rest of admm_x!/admm_w! are the CG tail kernel
-  HIPCHK(h, hipMemcpyAsync(h->x_tl, V.x, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->x_tl, V.x, sizeof(real) * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
   return enqueue_tail(h, loop_mode);
 }
 
@@ -356,7 +356,7 @@ int32_t minres_resume(cosmo_hip_handle* h, int extra) {
 int32_t minres_enqueue_solve(cosmo_hip_handle* h, int guard, bool from_loop) {
   const MrVecs V = vecs_of(h);
   const bool full = h->prm.kkt_kind == COSMO_HIP_KKT_MINRES;
-  const double tol_k = h->prm.tol_constant / pow((double)(h->host_solves + 1), h->prm.tol_exponent);
+  const real tol_k = h->prm.tol_constant / pow((real)(h->host_solves + 1), h->prm.tol_exponent);
   if (!from_loop) CHK(enqueue_y2_only(h));
   if (full) {
     hipLaunchKernelGGL(k_mr_copy2, dim3(ewg(h->n + h->m)), dim3(COSMO_BS), 0, h->stream, h->n, h->m, h->ls_x, h->ls_s, V.b);

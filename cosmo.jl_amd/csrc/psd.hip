@@ -36,15 +36,15 @@ __device__ __forceinline__ void wave_lds_fence() {
 // Rotation that annihilates w_pq:  t = sign(delta) w_pq / (|delta| + sqrt(delta^2 + w_pq^2)), delta = (w_qq - w_pp)/2.
 // t only steers convergence, so it uses the hardware approximations (v_sqrt_f64, v_rcp_f64); c = (1+t^2)^(-1/2) is
 // refined with one Newton step because c^2 + s^2 = 1 must hold to rounding for J to stay orthogonal.
-__device__ __forceinline__ void jacobi_cs(double app, double aqq, double apq, double& c, double& s) {
-  const double delta = 0.5 * (aqq - app);
-  const double h = __builtin_amdgcn_sqrt(fma(delta, delta, apq * apq));
-  const double den = fabs(delta) + h;
-  const double t = ((delta >= 0.0) ? apq : -apq) * __builtin_amdgcn_rcp(den);
-  const double a = fma(t, t, 1.0);
-  double y = __builtin_amdgcn_rsq(a);
-  const double e = fma(-a * y, y, 1.0);          // 1 - a y^2
-  y = fma(0.5 * e, y, y);
+__device__ __forceinline__ void jacobi_cs(real app, real aqq, real apq, real& c, real& s) {
+  const real delta = R(0.5) * (aqq - app);
+  const real h = hw_sqrt(fma(delta, delta, apq * apq));
+  const real den = fabs(delta) + h;
+  const real t = ((delta >= R(0.0)) ? apq : -apq) * hw_rcp(den);
+  const real a = fma(t, t, 1.0);
+  real y = hw_rsq(a);
+  const real e = fma(-a * y, y, 1.0);          // 1 - a y^2
+  y = fma(R(0.5) * e, y, y);
   c = y;
   s = y * t;
 }
@@ -54,8 +54,8 @@ __device__ __forceinline__ void jacobi_cs(double app, double aqq, double apq, do
 //  mode 0: W is a Gram matrix (relative criterion |w_pq| > tol sqrt(w_pp w_qq); columns with w_kk <= tiny are skipped).
 //  mode 1: W is the symmetric matrix itself (absolute criterion |w_pq| > tiny).
 // Returns (wave-uniform) whether any rotation fired.
-__device__ __forceinline__ int jacobi16_sweep(double* W, double* J, int* part, double* ca, double* cb, double tol,
-                                              double tiny, int mode, int nrounds, int lane) {
+__device__ __forceinline__ int jacobi16_sweep(real* W, real* J, int* part, real* ca, real* cb, real tol,
+                                              real tiny, int mode, int nrounds, int lane) {
   int rotated = 0;
   for (int rd = 0; rd < nrounds; ++rd) {
     if (lane < 8) {
@@ -64,8 +64,8 @@ __device__ __forceinline__ int jacobi16_sweep(double* W, double* J, int* part, d
       else if (lane == 0) { p = rd; q = 15; }
       else { p = (rd + lane) % 15; q = (rd - lane + 15) % 15; }
       if (p > q) { const int t = p; p = q; q = t; }
-      const double app = W[p * WLD + p], aqq = W[q * WLD + q], apq = W[p * WLD + q];
-      double c = 1.0, s = 0.0;
+      const real app = W[p * WLD + p], aqq = W[q * WLD + q], apq = W[p * WLD + q];
+      real c = 1.0, s = 0.0;
       bool rot;
       if (mode == 0) rot = (app > tiny) && (aqq > tiny) && (apq * apq > (tol * tol) * (app * aqq));
       else rot = fabs(apq) > tiny;
@@ -76,21 +76,21 @@ __device__ __forceinline__ int jacobi16_sweep(double* W, double* J, int* part, d
     wave_lds_fence();
     const int j = lane & 15;
     const int pj = part[j];
-    const double aj = ca[j], bj = cb[j];
-    double wn[4], jn[4];
+    const real aj = ca[j], bj = cb[j];
+    real wn[4], jn[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int i = (lane >> 4) + 4 * r;
+      const int i = ACC_ROW(lane, r);
       const int pi = part[i];
-      const double ai = ca[i], bi = cb[i];
-      const double wij = W[i * WLD + j], wipj = W[i * WLD + pj], wpij = W[pi * WLD + j], wpipj = W[pi * WLD + pj];
+      const real ai = ca[i], bi = cb[i];
+      const real wij = W[i * WLD + j], wipj = W[i * WLD + pj], wpij = W[pi * WLD + j], wpipj = W[pi * WLD + pj];
       wn[r] = ai * (aj * wij + bj * wipj) + bi * (aj * wpij + bj * wpipj);
       jn[r] = aj * J[i * WLD + j] + bj * J[i * WLD + pj];
     }
     wave_lds_fence();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int i = (lane >> 4) + 4 * r;
+      const int i = ACC_ROW(lane, r);
       W[i * WLD + j] = wn[r];
       J[i * WLD + j] = jn[r];
     }
@@ -101,18 +101,18 @@ __device__ __forceinline__ int jacobi16_sweep(double* W, double* J, int* part, d
 
 // Does any pair of the panel need a rotation?  cross_only: test the 64 entries (p < 8 <= q), one per lane; otherwise all
 // 120 pairs (two per lane).  Wave-uniform result; lets converged block pairs skip the Jacobi sweep and the panel update.
-__device__ __forceinline__ int gram_needs_work(const double* W, double tol, double tiny, int cross_only, int lane) {
+__device__ __forceinline__ int gram_needs_work(const real* W, real tol, real tiny, int cross_only, int lane) {
   int need = 0;
   if (cross_only) {
     const int p = lane & 7, q = 8 + (lane >> 3);
-    const double app = W[p * WLD + p], aqq = W[q * WLD + q], apq = W[p * WLD + q];
+    const real app = W[p * WLD + p], aqq = W[q * WLD + q], apq = W[p * WLD + q];
     need = (app > tiny) && (aqq > tiny) && (apq * apq > (tol * tol) * (app * aqq));
   } else {
     for (int e = lane; e < 120; e += 64) {
       int p = 0, rem = e;
       while (rem >= 15 - p) { rem -= 15 - p; ++p; }
       const int q = p + 1 + rem;
-      const double app = W[p * WLD + p], aqq = W[q * WLD + q], apq = W[p * WLD + q];
+      const real app = W[p * WLD + p], aqq = W[q * WLD + q], apq = W[p * WLD + q];
       need |= (app > tiny) && (aqq > tiny) && (apq * apq > (tol * tol) * (app * aqq));
     }
   }
@@ -127,36 +127,36 @@ __device__ __forceinline__ long long svec_idx(int i, int j) { return (long long)
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(COSMO_BS) void k_psd_tiny(const Ctl* __restrict__ ctl, int guard, int ncones,
                                                        const int* __restrict__ list, const PsdConeDev* __restrict__ cones,
-                                                       double* __restrict__ s, int* __restrict__ rank, int* __restrict__ flags,
-                                                       int mode, double sign, double* __restrict__ eigmin) {
+                                                       real* __restrict__ s, int* __restrict__ rank, int* __restrict__ flags,
+                                                       int mode, real sign, real* __restrict__ eigmin) {
   // mode 0: project in place.  mode 1: only the smallest eigenvalue of sign * mat(x) (definiteness tests of infeasibility.jl)
   if (guard && ctl->halt) return;
-  __shared__ double Ws[COSMO_BS / 64][16 * WLD];
-  __shared__ double Js[COSMO_BS / 64][16 * WLD];
-  __shared__ double cas[COSMO_BS / 64][16], cbs[COSMO_BS / 64][16];
+  __shared__ real Ws[COSMO_BS / 64][16 * WLD];
+  __shared__ real Js[COSMO_BS / 64][16 * WLD];
+  __shared__ real cas[COSMO_BS / 64][16], cbs[COSMO_BS / 64][16];
   __shared__ int parts[COSMO_BS / 64][16];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int widx = blockIdx.x * (COSMO_BS / 64) + wv;
   if (widx >= ncones) return;
   const PsdConeDev cn = cones[list[widx]];
-  double* W = Ws[wv]; double* J = Js[wv];
-  double* x = s + cn.off;
+  real* W = Ws[wv]; real* J = Js[wv];
+  real* x = s + cn.off;
   const int d = cn.d;
-  const double isq2 = 1.0 / sqrt(2.0), sq2 = sqrt(2.0);
+  const real isq2 = 1.0 / sqrt(2.0), sq2 = sqrt(2.0);
   // load X (symmetric, zero padded) and the identity
-  double fro = 0.0;
+  real fro = 0.0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int i = (lane >> 4) + 4 * r, j = lane & 15;
-    double v = 0.0;
+    const int i = ACC_ROW(lane, r), j = lane & 15;
+    real v = 0.0;
     if (i < d && j < d) {
       const int a = i < j ? i : j, b = i < j ? j : i;
       if (cn.kind == COSMO_HIP_PSD_TRIANGLE) {
-        const double t = x[svec_idx(a, b)];
+        const real t = x[svec_idx(a, b)];
         v = (a == b) ? t : isq2 * t;                       // populate_upper_triangle! (convexset.jl:432-442)
       } else {
         v = (mode == 1) ? x[(long long)b * d + a]                         // is_pos_def!: Hermitian(X, 'U') as is (algebra.jl:226-233)
-                        : (x[(long long)b * d + a] + x[(long long)a * d + b]) / 2.0;   // symmetrize_upper! (algebra.jl:201-208)
+                        : (x[(long long)b * d + a] + x[(long long)a * d + b]) / R(2.0);   // symmetrize_upper! (algebra.jl:201-208)
       }
     }
     v = v * sign;
@@ -166,30 +166,30 @@ __global__ __launch_bounds__(COSMO_BS) void k_psd_tiny(const Ctl* __restrict__ c
   }
   fro = sqrt(wave_sum(fro));
   wave_lds_fence();
-  const double thr = PSD_EPS * fro;
-  int sweeps = 0, rot = (fro > 0.0) ? 1 : 0;
+  const real thr = PSD_EPS * fro;
+  int sweeps = 0, rot = (fro > R(0.0)) ? 1 : 0;
   while (rot && sweeps < PSD_MAX_SWEEPS) {
     rot = jacobi16_sweep(W, J, parts[wv], cas[wv], cbs[wv], 0.0, thr, 1, 15, lane);
     ++sweeps;
   }
   if (rot && lane == 0) atomicOr(&flags[1], 1);            // did not converge
   if (mode == 1) {
-    double lm = W[0];
+    real lm = W[0];
     for (int k = 1; k < d; ++k) lm = fmin(lm, W[k * WLD + k]);
     if (lane == 0) eigmin[list[widx]] = lm;
     return;
   }
   // X+ = J max(Lambda,0) J'
   int rk = 0;
-  for (int k = 0; k < d; ++k) rk += (W[k * WLD + k] > 0.0) ? 1 : 0;
+  for (int k = 0; k < d; ++k) rk += (W[k * WLD + k] > R(0.0)) ? 1 : 0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int i = (lane >> 4) + 4 * r, j = lane & 15;
+    const int i = ACC_ROW(lane, r), j = lane & 15;
     if (i <= j && j < d) {
-      double acc = 0.0;
+      real acc = 0.0;
       for (int k = 0; k < d; ++k) {
-        const double lam = W[k * WLD + k];
-        if (lam > 0.0) acc += (J[i * WLD + k] * lam) * J[j * WLD + k];
+        const real lam = W[k * WLD + k];
+        if (lam > R(0.0)) acc += (J[i * WLD + k] * lam) * J[j * WLD + k];
       }
       if (cn.kind == COSMO_HIP_PSD_TRIANGLE) {
         x[svec_idx(i, j)] = (i == j) ? acc : sq2 * acc;              // extract_upper_triangle! (:462-472)
@@ -206,44 +206,44 @@ __global__ __launch_bounds__(COSMO_BS) void k_psd_tiny(const Ctl* __restrict__ c
 // d > 16: build G = X + c I (full symmetric, zero padded), c = ||X||_F  (one workgroup per cone, any block size)
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(COSMO_BS) void k_psd_populate(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ list,
-                                                           const PsdConeDev* __restrict__ cones, const double* __restrict__ s,
-                                                           double* __restrict__ G, double* __restrict__ cshift, double sign, int upper_only) {
+                                                           const PsdConeDev* __restrict__ cones, const real* __restrict__ s,
+                                                           real* __restrict__ G, real* __restrict__ cshift, real sign, int upper_only) {
   // upper_only: the definiteness tests read Hermitian(X, 'U') of the square layout WITHOUT symmetrising (is_pos_def!,
   // src/algebra.jl:226-233) -- delta_y of a PsdCone is not symmetric in general -- while project! symmetrises first (:201-208)
   if (guard && ctl->halt) return;
-  __shared__ double red[COSMO_BS / 64];
+  __shared__ real red[COSMO_BS / 64];
   const int ci = list[blockIdx.y];
   const PsdConeDev cn = cones[ci];
-  const double* x = s + cn.off;
+  const real* x = s + cn.off;
   const int d = cn.d;
-  double* g = G + cn.goff;
-  const double isq2 = 1.0 / sqrt(2.0);
+  real* g = G + cn.goff;
+  const real isq2 = 1.0 / sqrt(2.0);
   // ||X||_F: for the svec layout it is ||x||_2 (the scaling makes svec an isometry)
-  double acc = 0.0;
+  real acc = 0.0;
   if (cn.kind == COSMO_HIP_PSD_TRIANGLE) {
     const long long len = (long long)d * (d + 1) / 2;
-    for (long long k = threadIdx.x; k < len; k += COSMO_BS) { const double v = x[k]; acc += v * v; }
+    for (long long k = threadIdx.x; k < len; k += COSMO_BS) { const real v = x[k]; acc += v * v; }
   } else {
     for (long long k = threadIdx.x; k < (long long)d * d; k += COSMO_BS) {
       const int i = (int)(k % d), j = (int)(k / d);
       const int a = i < j ? i : j, b = i < j ? j : i;
-      const double v = upper_only ? x[(long long)b * d + a] : (x[(long long)j * d + i] + x[(long long)i * d + j]) / 2.0;
+      const real v = upper_only ? x[(long long)b * d + a] : (x[(long long)j * d + i] + x[(long long)i * d + j]) / R(2.0);
       acc += v * v;
     }
   }
-  const double c = sqrt(block_sum(acc, red));
+  const real c = sqrt(block_sum(acc, red));
   if (threadIdx.x == 0 && blockIdx.x == 0) cshift[ci] = c;
   // columns are distributed over blockIdx.x
   for (int j = blockIdx.x; j < cn.ncp; j += gridDim.x) {
     for (int i = threadIdx.x; i < cn.ld; i += COSMO_BS) {
-      double v = 0.0;
+      real v = 0.0;
       if (i < d && j < d) {
         const int a = i < j ? i : j, b = i < j ? j : i;
         if (cn.kind == COSMO_HIP_PSD_TRIANGLE) {
-          const double t = x[svec_idx(a, b)];
+          const real t = x[svec_idx(a, b)];
           v = (a == b) ? t : isq2 * t;
         } else {
-          v = upper_only ? x[(long long)b * d + a] : (x[(long long)b * d + a] + x[(long long)a * d + b]) / 2.0;
+          v = upper_only ? x[(long long)b * d + a] : (x[(long long)b * d + a] + x[(long long)a * d + b]) / R(2.0);
         }
         v = v * sign;
         if (i == j) v += c;
@@ -259,9 +259,9 @@ __global__ __launch_bounds__(COSMO_BS) void k_psd_populate(const Ctl* __restrict
 // Gram matrix of a row range of the panel: W = P(r0:r1, :)' P(r0:r1, :), r0, r1 multiples of 16.
 // Lane l loads rows 16 ch + 4 (l >> 4) .. +3 of column cols(l & 15) as one 32-byte vector; the k-slot permutation this
 // implies is the same for both MFMA operands, so the sum is unchanged.
-__device__ __forceinline__ v4d panel_gram(const double* __restrict__ g, int ld, int colL, int r0, int r1, int lane) {
+__device__ __forceinline__ v4d panel_gram(const real* __restrict__ g, int ld, int colL, int r0, int r1, int lane) {
   v4d acc = {0.0, 0.0, 0.0, 0.0};
-  const double* cp = g + (long long)colL * ld + 4 * (lane >> 4);
+  const real* cp = g + (long long)colL * ld + 4 * (lane >> 4);
   int r = r0;
   for (; r + 64 <= r1; r += 64) {                      // four 16-row chunks in flight
     v4d v[4];
@@ -269,52 +269,52 @@ __device__ __forceinline__ v4d panel_gram(const double* __restrict__ g, int ld, 
     for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const v4d*>(cp + r + 16 * u);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      acc = MFMA_F64(v[u].x, v[u].x, acc);
-      acc = MFMA_F64(v[u].y, v[u].y, acc);
-      acc = MFMA_F64(v[u].z, v[u].z, acc);
-      acc = MFMA_F64(v[u].w, v[u].w, acc);
+      acc = MFMA_REAL(v[u].x, v[u].x, acc);
+      acc = MFMA_REAL(v[u].y, v[u].y, acc);
+      acc = MFMA_REAL(v[u].z, v[u].z, acc);
+      acc = MFMA_REAL(v[u].w, v[u].w, acc);
     }
   }
   for (; r < r1; r += 16) {
     const v4d v = *reinterpret_cast<const v4d*>(cp + r);
-    acc = MFMA_F64(v.x, v.x, acc);
-    acc = MFMA_F64(v.y, v.y, acc);
-    acc = MFMA_F64(v.z, v.z, acc);
-    acc = MFMA_F64(v.w, v.w, acc);
+    acc = MFMA_REAL(v.x, v.x, acc);
+    acc = MFMA_REAL(v.y, v.y, acc);
+    acc = MFMA_REAL(v.z, v.z, acc);
+    acc = MFMA_REAL(v.w, v.w, acc);
   }
   return acc;
 }
 
 // Panel update P(r0:r1, :) <- P(r0:r1, :) J, computed as (J' P')' so that every lane stores 16 consecutive rows of one
 // column.  jt[t] = J[(lane >> 4) + 4 t][lane & 15] (the C layout) is exactly the A operand of step t.
-__device__ __forceinline__ void panel_update(double* __restrict__ g, int ld, const int* cols, const double jt[4], int r0, int r1,
+__device__ __forceinline__ void panel_update(real* __restrict__ g, int ld, const int* cols, const real jt[4], int r0, int r1,
                                              int lane) {
   const int rr = lane & 15, kg = lane >> 4;
-  double* src[4];
-  double* dst[4];
+  real* src[4];
+  real* dst[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     src[t] = g + (long long)cols[4 * t + kg] * ld + rr;   // B operand of step t: P[r + rr][4 t + kg]
-    dst[t] = g + (long long)cols[kg + 4 * t] * ld + rr;   // D reg t: new column kg + 4 t, row r + rr
+    dst[t] = g + (long long)cols[ACC_ROW(lane, t)] * ld + rr;   // D reg t: new column ACC_ROW(lane, t) (kg + 4 t in fp64), row r + rr
   }
   int r = r0;
   for (; r + 32 <= r1; r += 32) {                      // two chunks in flight (all loads of both chunks precede the stores)
-    double b0[4], b1[4];
+    real b0[4], b1[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) { b0[t] = src[t][r]; b1[t] = src[t][r + 16]; }
     v4d a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { a0 = MFMA_F64(jt[t], b0[t], a0); a1 = MFMA_F64(jt[t], b1[t], a1); }
+    for (int t = 0; t < 4; ++t) { a0 = MFMA_REAL(jt[t], b0[t], a0); a1 = MFMA_REAL(jt[t], b1[t], a1); }
     dst[0][r] = a0.x; dst[1][r] = a0.y; dst[2][r] = a0.z; dst[3][r] = a0.w;
     dst[0][r + 16] = a1.x; dst[1][r + 16] = a1.y; dst[2][r + 16] = a1.z; dst[3][r + 16] = a1.w;
   }
   for (; r < r1; r += 16) {
-    double b[4];
+    real b[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) b[t] = src[t][r];
     v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc = MFMA_F64(jt[t], b[t], acc);
+    for (int t = 0; t < 4; ++t) acc = MFMA_REAL(jt[t], b[t], acc);
     dst[0][r] = acc.x; dst[1][r] = acc.y; dst[2][r] = acc.z; dst[3][r] = acc.w;
   }
 }
@@ -332,24 +332,24 @@ __device__ __forceinline__ void rr_pair(int nb, int st, int w, int& I, int& J) {
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_psd_jacobi_wg(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ list,
-                                                           const PsdConeDev* __restrict__ cones, double* __restrict__ G,
-                                                           const double* __restrict__ cshift, int* __restrict__ flags, double tolf, int dbg) {
+                                                           const PsdConeDev* __restrict__ cones, real* __restrict__ G,
+                                                           const real* __restrict__ cshift, int* __restrict__ flags, real tolf, int dbg) {
   if (guard && ctl->halt) return;
-  __shared__ double Ws[NW][16 * WLD];
-  __shared__ double Js[NW][16 * WLD];
-  __shared__ double cas[NW][16], cbs[NW][16];
+  __shared__ real Ws[NW][16 * WLD];
+  __shared__ real Js[NW][16 * WLD];
+  __shared__ real cas[NW][16], cbs[NW][16];
   __shared__ int parts[NW][16];
   __shared__ int colss[NW][16];
   __shared__ int any_rot;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int ci = list[blockIdx.x];
   const PsdConeDev cn = cones[ci];
-  double* g = G + cn.goff;
+  real* g = G + cn.goff;
   const int nb = cn.nb, npairs = nb / 2;
-  const double c = cshift[ci];
-  const double tol = tolf * (double)cn.d * PSD_EPS;
-  const double tiny = (tol * c) * (tol * c);
-  double* W = Ws[wv]; double* J = Js[wv];
+  const real c = cshift[ci];
+  const real tol = tolf * (real)cn.d * PSD_EPS;
+  const real tiny = (tol * c) * (tol * c);
+  real* W = Ws[wv]; real* J = Js[wv];
   int sweep = 0;
   // one visit of block pair (I, Jb): Gram on MFMA, Jacobi on the 16x16 Gram matrix, panel update on MFMA
   auto visit = [&](int I, int Jb, int full) {
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(NW * 64) void k_psd_jacobi_wg(const Ctl* __restrict
     if (!(dbg & 4)) w = panel_gram(g, cn.ld, colL, 0, cn.ld, lane);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int i = (lane >> 4) + 4 * r, j = lane & 15;
+      const int i = ACC_ROW(lane, r), j = lane & 15;
       W[i * WLD + j] = w[r];
       J[i * WLD + j] = (i == j) ? 1.0 : 0.0;
     }
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(NW * 64) void k_psd_jacobi_wg(const Ctl* __restrict
     if (dbg & 2) rot = 0;
     if (dbg & 16) { if (lane == 0 && sweep < 10) any_rot = 1; }
     if (rot) {
-      double jt[4];
+      real jt[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) jt[t] = J[((lane >> 4) + 4 * t) * WLD + (lane & 15)];
       panel_update(g, cn.ld, colss[wv], jt, 0, cn.ld, lane);
@@ -407,12 +407,12 @@ __global__ __launch_bounds__(NW * 64) void k_psd_jacobi_wg(const Ctl* __restrict
 // ---------------------------------------------------------------------------------------------------------------------
 #define PSD_STEP_WAVES 8
 __global__ __launch_bounds__(PSD_STEP_WAVES * 64) void k_psd_step(const int* __restrict__ list, const PsdConeDev* __restrict__ cones,
-                                                                  double* __restrict__ G, const double* __restrict__ cshift,
-                                                                  int st, int* __restrict__ flags, double tolf) {
-  __shared__ double Wp[PSD_STEP_WAVES][16 * WLD];
-  __shared__ double Ws[16 * WLD];
-  __shared__ double Js[16 * WLD];
-  __shared__ double cas[16], cbs[16];
+                                                                  real* __restrict__ G, const real* __restrict__ cshift,
+                                                                  int st, int* __restrict__ flags, real tolf) {
+  __shared__ real Wp[PSD_STEP_WAVES][16 * WLD];
+  __shared__ real Ws[16 * WLD];
+  __shared__ real Js[16 * WLD];
+  __shared__ real cas[16], cbs[16];
   __shared__ int parts[16];
   __shared__ int cols[16];
   __shared__ int rot_s;
@@ -422,10 +422,10 @@ __global__ __launch_bounds__(PSD_STEP_WAVES * 64) void k_psd_step(const int* __r
   const int nb = cn.nb, npairs = nb / 2;
   if ((int)blockIdx.x >= npairs || st >= nb - 1) return;
   const int full = (st < 0) ? 1 : 0;
-  double* g = G + cn.goff;
-  const double c = cshift[ci];
-  const double tol = tolf * (double)cn.d * PSD_EPS;
-  const double tiny = (tol * c) * (tol * c);
+  real* g = G + cn.goff;
+  const real c = cshift[ci];
+  const real tol = tolf * (real)cn.d * PSD_EPS;
+  const real tiny = (tol * c) * (tol * c);
   int I, Jb;
   if (full) { I = 2 * blockIdx.x; Jb = I + 1; }
   else rr_pair(nb, st, blockIdx.x, I, Jb);
@@ -437,13 +437,13 @@ __global__ __launch_bounds__(PSD_STEP_WAVES * 64) void k_psd_step(const int* __r
   const int r0 = min(nch, wv * per) * 16, r1 = min(nch, (wv + 1) * per) * 16;
   const v4d w = panel_gram(g, cn.ld, cols[lane & 15], r0, r1, lane);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) Wp[wv][((lane >> 4) + 4 * r) * WLD + (lane & 15)] = w[r];
+  for (int r = 0; r < 4; ++r) Wp[wv][ACC_ROW(lane, r) * WLD + (lane & 15)] = w[r];
   __syncthreads();
   if (wv == 0) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int i = (lane >> 4) + 4 * r, j = lane & 15;
-      double a = 0.0;
+      const int i = ACC_ROW(lane, r), j = lane & 15;
+      real a = 0.0;
       for (int q = 0; q < PSD_STEP_WAVES; ++q) a += Wp[q][i * WLD + j];
       Ws[i * WLD + j] = a;
       Js[i * WLD + j] = (i == j) ? 1.0 : 0.0;
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(PSD_STEP_WAVES * 64) void k_psd_step(const int* __r
   }
   __syncthreads();
   if (rot_s) {
-    double jt[4];
+    real jt[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) jt[t] = Js[((lane >> 4) + 4 * t) * WLD + (lane & 15)];
     panel_update(g, cn.ld, cols, jt, r0, r1, lane);
@@ -467,24 +467,24 @@ __global__ __launch_bounds__(PSD_STEP_WAVES * 64) void k_psd_step(const int* __r
 // grid = (1, ncones in list), one workgroup per cone; columns over waves
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(COSMO_BS) void k_psd_colscale(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ list,
-                                                           const PsdConeDev* __restrict__ cones, double* __restrict__ G,
-                                                           const double* __restrict__ cshift, double* __restrict__ colw,
+                                                           const PsdConeDev* __restrict__ cones, real* __restrict__ G,
+                                                           const real* __restrict__ cshift, real* __restrict__ colw,
                                                            int* __restrict__ rank) {
   if (guard && ctl->halt) return;
   const int ci = list[blockIdx.y];
   const PsdConeDev cn = cones[ci];
-  double* g = G + cn.goff;
-  const double c = cshift[ci];
+  real* g = G + cn.goff;
+  const real c = cshift[ci];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int mycnt = 0;
   for (int j = blockIdx.x * (COSMO_BS / 64) + wv; j < cn.ncp; j += gridDim.x * (COSMO_BS / 64)) {
-    double* col = g + (long long)j * cn.ld;
-    double a = 0.0;
-    for (int i = lane; i < cn.ld; i += 64) { const double v = col[i]; a += v * v; }
-    const double sig = sqrt(wave_sum(a));
-    const double lam = sig - c;
-    double f = 0.0;
-    if (j < cn.d && lam > 0.0 && sig > 0.0) { f = sqrt(lam) / sig; mycnt += 1; }
+    real* col = g + (long long)j * cn.ld;
+    real a = 0.0;
+    for (int i = lane; i < cn.ld; i += 64) { const real v = col[i]; a += v * v; }
+    const real sig = sqrt(wave_sum(a));
+    const real lam = sig - c;
+    real f = 0.0;
+    if (j < cn.d && lam > R(0.0) && sig > R(0.0)) { f = sqrt(lam) / sig; mycnt += 1; }
     // scale the column in place: ghat_k = g_k sqrt(lambda_k) / sigma_k  (rank_k_update!, convexset.jl:248-256)
     for (int i = lane; i < cn.ld; i += 64) col[i] = col[i] * f;
     if (lane == 0) colw[cn.coff + j] = lam;
@@ -494,19 +494,19 @@ __global__ __launch_bounds__(COSMO_BS) void k_psd_colscale(const Ctl* __restrict
 
 // smallest eigenvalue of every cone of the list: min_k (||g_k|| - c) over the real columns (one workgroup per cone)
 __global__ __launch_bounds__(COSMO_BS) void k_psd_eigmin(const int* __restrict__ list, const PsdConeDev* __restrict__ cones,
-                                                         const double* __restrict__ G, const double* __restrict__ cshift,
-                                                         double* __restrict__ eigmin) {
-  __shared__ double red[COSMO_BS / 64];
+                                                         const real* __restrict__ G, const real* __restrict__ cshift,
+                                                         real* __restrict__ eigmin) {
+  __shared__ real red[COSMO_BS / 64];
   const int ci = list[blockIdx.x];
   const PsdConeDev cn = cones[ci];
-  const double* g = G + cn.goff;
-  const double c = cshift[ci];
+  const real* g = G + cn.goff;
+  const real c = cshift[ci];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  double lm = INFINITY;
+  real lm = INFINITY;
   for (int j = wv; j < cn.d; j += COSMO_BS / 64) {
-    const double* col = g + (long long)j * cn.ld;
-    double a = 0.0;
-    for (int i = lane; i < cn.ld; i += 64) { const double v = col[i]; a += v * v; }
+    const real* col = g + (long long)j * cn.ld;
+    real a = 0.0;
+    for (int i = lane; i < cn.ld; i += 64) { const real v = col[i]; a += v * v; }
     lm = fmin(lm, sqrt(wave_sum(a)) - c);
   }
   lm = -block_max(-lm, red);
@@ -515,18 +515,18 @@ __global__ __launch_bounds__(COSMO_BS) void k_psd_eigmin(const int* __restrict__
 
 // X+ = Ghat Ghat' (upper tiles) on MFMA, written straight into s.  grid = (ntiles_max, ncones); one wave per 16x16 tile.
 __global__ __launch_bounds__(COSMO_BS) void k_psd_syrk(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ list,
-                                                       const PsdConeDev* __restrict__ cones, const double* __restrict__ G,
-                                                       double* __restrict__ s) {
+                                                       const PsdConeDev* __restrict__ cones, const real* __restrict__ G,
+                                                       real* __restrict__ s) {
   if (guard && ctl->halt) return;
   const int ci = list[blockIdx.y];
   const PsdConeDev cn = cones[ci];
   const int nt = cn.ld / 16;                         // tiles per side
   const int ntiles = nt * (nt + 1) / 2;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const double* g = G + cn.goff;
-  double* x = s + cn.off;
+  const real* g = G + cn.goff;
+  real* x = s + cn.off;
   const int d = cn.d;
-  const double sq2 = sqrt(2.0);
+  const real sq2 = sqrt(2.0);
   for (int t = blockIdx.x * (COSMO_BS / 64) + wv; t < ntiles; t += gridDim.x * (COSMO_BS / 64)) {
     // unrank t -> (ti <= tj), column-major over upper tiles
     int tj = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) / 2.0);
@@ -534,18 +534,18 @@ __global__ __launch_bounds__(COSMO_BS) void k_psd_syrk(const Ctl* __restrict__ c
     while ((long long)(tj + 1) * (tj + 2) / 2 <= t) ++tj;
     const int ti = t - tj * (tj + 1) / 2;
     // D[a][b] = X[16 ti + b][16 tj + a] = sum_k Ghat[16 tj + a][k] Ghat[16 ti + b][k]
-    const double* pa = g + 16 * tj + (lane & 15) + (long long)(lane >> 4) * cn.ld;   // A[a = l&15][k = l>>4]
-    const double* pb = g + 16 * ti + (lane & 15) + (long long)(lane >> 4) * cn.ld;   // B[k = l>>4][b = l&15]
+    const real* pa = g + 16 * tj + (lane & 15) + (long long)(lane >> 4) * cn.ld;   // A[a = l&15][k = l>>4]
+    const real* pb = g + 16 * ti + (lane & 15) + (long long)(lane >> 4) * cn.ld;   // B[k = l>>4][b = l&15]
     v4d acc = {0.0, 0.0, 0.0, 0.0};
     for (int k = 0; k < cn.ncp; k += 4) {
-      const double a = pa[(long long)k * cn.ld];
-      const double b = pb[(long long)k * cn.ld];
-      acc = MFMA_F64(a, b, acc);
+      const real a = pa[(long long)k * cn.ld];
+      const real b = pb[(long long)k * cn.ld];
+      acc = MFMA_REAL(a, b, acc);
     }
     const int i = 16 * ti + (lane & 15);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int j = 16 * tj + (lane >> 4) + 4 * r;
+      const int j = 16 * tj + ACC_ROW(lane, r);
       if (i < d && j < d) {
         if (cn.kind == COSMO_HIP_PSD_TRIANGLE) {
           if (i <= j) x[svec_idx(i, j)] = (i == j) ? acc[r] : sq2 * acc[r];
@@ -603,7 +603,7 @@ int32_t psd_plan_create(cosmo_hip_handle* h) {
       // paths (psd_polar.hip); never enters the Jacobi size classes
       PsdConeDev cc;
       cc.kind = C.type[k]; cc.off = (int)C.off[k];
-      cc.d = 2 * (int)llround(sqrt((double)C.dim[k]));
+      cc.d = 2 * (int)llround(sqrt((real)C.dim[k]));
       cc.ld = ((cc.d + 15) / 16) * 16; cc.nb = 0; cc.ncp = 0; cc.goff = 0; cc.coff = 0; cc.cone_index = (int)k;
       p->cplx.push_back((int)p->cones.size());
       p->cones.push_back(cc);
@@ -612,7 +612,7 @@ int32_t psd_plan_create(cosmo_hip_handle* h) {
     PsdConeDev cn;
     cn.kind = C.type[k];
     cn.off = (int)C.off[k];
-    if (cn.kind == COSMO_HIP_PSD_SQUARE) cn.d = (int)llround(sqrt((double)C.dim[k]));
+    if (cn.kind == COSMO_HIP_PSD_SQUARE) cn.d = (int)llround(sqrt((real)C.dim[k]));
     else cn.d = (int)((llround(floor(sqrt(1.0 + 8.0 * (double)C.dim[k]))) - 1) / 2);
     while ((long long)cn.d * (cn.d + 1) / 2 > C.dim[k] && cn.kind == COSMO_HIP_PSD_TRIANGLE) --cn.d;
     if (cn.kind == COSMO_HIP_PSD_TRIANGLE && (long long)cn.d * (cn.d + 1) / 2 != C.dim[k])
@@ -681,12 +681,12 @@ int32_t psd_plan_create(cosmo_hip_handle* h) {
       p->d_pj_groups.push_back(dptr);
     }
   }
-  HIPCHK(h, hipMalloc((void**)&p->G, std::max<long long>(1, p->gsize) * sizeof(double)));
-  HIPCHK(h, hipMalloc((void**)&p->colw, std::max(1, p->ncolw) * sizeof(double)));
-  HIPCHK(h, hipMalloc((void**)&p->cshift, p->cones.size() * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&p->G, std::max<long long>(1, p->gsize) * sizeof(real)));
+  HIPCHK(h, hipMalloc((void**)&p->colw, std::max(1, p->ncolw) * sizeof(real)));
+  HIPCHK(h, hipMalloc((void**)&p->cshift, p->cones.size() * sizeof(real)));
   HIPCHK(h, hipMalloc((void**)&p->rank, p->cones.size() * sizeof(int)));
   HIPCHK(h, hipMalloc((void**)&p->flags, 4 * sizeof(int)));
-  HIPCHK(h, hipMalloc((void**)&p->eigmin, p->cones.size() * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&p->eigmin, p->cones.size() * sizeof(real)));
   HIPCHK(h, hipMemset(p->rank, 0, p->cones.size() * sizeof(int)));
   HIPCHK(h, hipMemset(p->flags, 0, 4 * sizeof(int)));
   return polar_plan_create(h);   // d > 256: matrix-sign iteration on the matrix cores (psd_polar.hip)
@@ -713,7 +713,7 @@ static int32_t psd_large_sweeps(cosmo_hip_handle* h, int n, int nbmax) {
 
 bool psd_needs_sync(const cosmo_hip_handle* h) { return h->psd && !h->psd->large.empty() && !polar_has_large(h); }
 
-int32_t psd_enqueue_project(cosmo_hip_handle* h, double* s, bool guard_b) {
+int32_t psd_enqueue_project(cosmo_hip_handle* h, real* s, bool guard_b) {
   PsdPlan* p = h->psd;
   if (!p || p->cones.empty()) return COSMO_HIP_OK;
   const int guard = guard_b ? 1 : 0;
@@ -788,13 +788,13 @@ extern "C" int32_t cosmo_hip_psd_stats(cosmo_hip_handle* h, int64_t out[4]) {
 
 // Smallest eigenvalue of sign * mat(vec slice) for every planned PSD cone (same row layout as s).  Used by the
 // infeasibility certificates: is_pos_def!(X, tol) <=> lambda_min(X) > -tol (src/algebra.jl:226-238).  Synchronous.
-int32_t polar_complex_is_pd(cosmo_hip_handle* h, const double* vec, double sign, double tol, std::vector<int>& ok);   // psd_polar.hip
+int32_t polar_complex_is_pd(cosmo_hip_handle* h, const real* vec, real sign, real tol, std::vector<int>& ok);   // psd_polar.hip
 
-int32_t psd_extreme_eigs(cosmo_hip_handle* h, const double* vec, double sign, double tol, std::vector<double>& lam_min) {
+int32_t psd_extreme_eigs(cosmo_hip_handle* h, const real* vec, real sign, real tol, std::vector<real>& lam_min) {
   PsdPlan* p = h->psd;
   lam_min.clear();
   if (!p || p->cones.empty()) return COSMO_HIP_OK;
-  double* v = const_cast<double*>(vec);   // mode 1 / populate only read it
+  real* v = const_cast<real*>(vec);   // mode 1 / populate only read it
   if (!p->tiny.empty()) {
     const int n = (int)p->tiny.size();
     hipLaunchKernelGGL(k_psd_tiny, dim3((n + COSMO_BS / 64 - 1) / (COSMO_BS / 64)), dim3(COSMO_BS), 0, h->stream, h->ctl, 0, n, p->d_tiny,
@@ -820,7 +820,7 @@ int32_t psd_extreme_eigs(cosmo_hip_handle* h, const double* vec, double sign, do
   }
   HIPCHK(h, hipGetLastError());
   lam_min.resize(p->cones.size());
-  HIPCHK(h, hipMemcpyAsync(lam_min.data(), p->eigmin, sizeof(double) * lam_min.size(), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(lam_min.data(), p->eigmin, sizeof(real) * lam_min.size(), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   // Hermitian cones: the reference's own test -- does the Cholesky factorisation of sign * H + tol I succeed? -- on the real embedding
   // (psd_polar.hip); reported as lambda_min = 0 (passes the caller's "> -tol") or -inf.  Sides 2r > 1024 never certify.

@@ -32,7 +32,7 @@
 //
 // Kernel: k_symm_gemm -- C = alpha A B + beta Cin on the upper tiles, A and B symmetric (so both operands are read
 // "contiguous along the output index, strided along k"), 64x64 tile per workgroup of 4 waves (32x32 per wave = 2x2
-// v_mfma_f64_16x16x4_f64 accumulators), k-panels of 16 staged through double-buffered LDS with an 80-double row pitch
+// v_mfma_f64_16x16x4_f64 accumulators), k-panels of 16 staged through double-buffered LDS with an 80-real row pitch
 // (conflict-free ds_read_b64 for the 16-lane x 4-row operand fragments), global loads of panel k+1 in flight during
 // the MFMAs of panel k.
 #include "psd_internal.h"
@@ -63,13 +63,13 @@ struct PolarDev {
   int unverified;    // ... that still failed after the last enqueued round
   int projections;
   int pad[3];
-  double err_last, err_max;   // ||G||_F / (2 ||X||_F) of the last verification, max over all
+  real err_last, err_max;   // ||G||_F / (2 ||X||_F) of the last verification, max over all
 };
 
 // schedule constants (tools/polar_schedule.py)
-static const double kPolarLift[3] = {3.8438259784376458, -2.5414431444903771, 0.42553478492344637};   // minimax on [0.02212, 2.1]: range [0.085, 1.915]
+static const real kPolarLift[3] = {3.8438259784376458, -2.5414431444903771, 0.42553478492344637};   // minimax on [0.02212, 2.1]: range [0.085, 1.915]
 #define POLAR_NFIN 5
-static const double kPolarFinish[POLAR_NFIN][3] = {
+static const real kPolarFinish[POLAR_NFIN][3] = {
     {3.4931704678738202, -2.370790022242379, 0.42240833954524776},    // [0.08, 2.02]   -> 1 +- 0.722
     {2.7077959763108326, -2.015093165601975, 0.45683257965863566},    // [0.278, 1.722] -> 1 +- 0.289
     {1.9693651031668091, -1.3512768962961363, 0.3852630352029357},    // [0.711, 1.289] -> 1 +- 1.56e-2
@@ -79,12 +79,12 @@ static const double kPolarFinish[POLAR_NFIN][3] = {
 
 struct PolarPlan {
   std::vector<PolarCone> cones;
-  double* W = nullptr;       // 4 * ld^2 doubles per cone: X, U, Y, T
-  double* parts = nullptr;   // per cone COSMO_MAX_PARTIALS norm partials + trace partials
-  double* nrm = nullptr;     // per cone ||X||_F
+  real* W = nullptr;       // 4 * ld^2 doubles per cone: X, U, Y, T
+  real* parts = nullptr;   // per cone COSMO_MAX_PARTIALS norm partials + trace partials
+  real* nrm = nullptr;     // per cone ||X||_F
   int k_lift = 10;           // lifting steps of the main schedule (COSMO_HIP_POLAR_KLIFT; grows by 3 when fallbacks are frequent)
   int max_rounds = 2;        // guarded fallback rounds enqueued per projection
-  double tol_factor = 8.0;   // verification threshold tol_factor * d * eps (relative to ||X||_F)
+  real tol_factor = 8.0;   // verification threshold tol_factor * d * eps (relative to ||X||_F)
   PolarDev* dev = nullptr;
   PolarDev seen;             // host copy at the last polar_adapt
   long long launches[4] = {0, 0, 0, 0};   // <64,1>, <96,1>, <96,2>, batch
@@ -94,9 +94,9 @@ struct PolarPlan {
   BatchCone* d_bcones = nullptr;
   int4* d_btiles = nullptr;
   int nbtiles = 0;
-  double* BW = nullptr;
-  double* bparts = nullptr;
-  double* bnrm = nullptr;    // per batched cone ||X||_F
+  real* BW = nullptr;
+  real* bparts = nullptr;
+  real* bnrm = nullptr;    // per batched cone ||X||_F
   int* bgate = nullptr;      // per batched cone: 1 = its verification failed, the next fallback round processes it
 };
 
@@ -104,8 +104,8 @@ extern "C" int32_t cosmo_hip_polar_schedule(int32_t k_lift, double* abc, int32_t
   if (k_lift < 0 || k_lift > 64 || !nsteps) return COSMO_HIP_ERR_INVALID;
   *nsteps = k_lift + POLAR_NFIN;
   if (!abc) return COSMO_HIP_OK;
-  for (int t = 0; t < k_lift; ++t) for (int q = 0; q < 3; ++q) abc[3 * t + q] = kPolarLift[q];
-  for (int t = 0; t < POLAR_NFIN; ++t) for (int q = 0; q < 3; ++q) abc[3 * (k_lift + t) + q] = kPolarFinish[t][q];
+  for (int t = 0; t < k_lift; ++t) for (int q = 0; q < 3; ++q) abc[3 * t + q] = (double)kPolarLift[q];
+  for (int t = 0; t < POLAR_NFIN; ++t) for (int q = 0; q < 3; ++q) abc[3 * (k_lift + t) + q] = (double)kPolarFinish[t][q];
   return COSMO_HIP_OK;
 }
 
@@ -116,29 +116,29 @@ __device__ __forceinline__ long long svec_index(int i, int j) { return (long lon
 
 // value of the (real symmetric) working matrix at (i, j) read from the cone's slice x.  Real cones: svec / square layouts.
 // Complex Hermitian cone H = A + iB of side r (src/convexset.jl:444-458): the 2r x 2r embedding [[A, -B], [B, A]].
-__device__ __forceinline__ double polar_read(const double* __restrict__ x, int kind, int d, int i, int j) {
-  const double isq2 = 0.70710678118654752440;
+__device__ __forceinline__ real polar_read(const real* __restrict__ x, int kind, int d, int i, int j) {
+  const real isq2 = 0.70710678118654752440;
   if (kind == COSMO_HIP_PSD_TRIANGLE) {
     const int a = i < j ? i : j, b = i < j ? j : i;
-    const double t = x[svec_index(a, b)];
+    const real t = x[svec_index(a, b)];
     return (a == b) ? t : isq2 * t;
   }
   if (kind == COSMO_HIP_PSD_SQUARE) {
     const int a = i < j ? i : j, b = i < j ? j : i;
-    return (x[(long long)b * d + a] + x[(long long)a * d + b]) / 2.0;     // symmetrize_upper! (src/algebra.jl:201-208)
+    return (x[(long long)b * d + a] + x[(long long)a * d + b]) / R(2.0);     // symmetrize_upper! (src/algebra.jl:201-208)
   }
   const int r = d / 2;
   const int bi = i >= r, bj = j >= r, ii = i - bi * r, jj = j - bj * r;
   const int a = ii < jj ? ii : jj, b = ii < jj ? jj : ii;
-  if (bi == bj) { const double t = x[svec_index(a, b)]; return (a == b) ? t : isq2 * t; }
+  if (bi == bj) { const real t = x[svec_index(a, b)]; return (a == b) ? t : isq2 * t; }
   if (ii == jj) return 0.0;
-  double im = isq2 * x[(long long)r * (r + 1) / 2 + (long long)b * (b - 1) / 2 + a];   // B[a, b] for a < b
+  real im = isq2 * x[(long long)r * (r + 1) / 2 + (long long)b * (b - 1) / 2 + a];   // B[a, b] for a < b
   if (ii > jj) im = -im;                                                               // B[ii, jj]
   return (bi == 1) ? im : -im;                                                         // lower-left block B, upper-right block -B
 }
 // store the projected value v of the upper-triangle position (i <= j) into the cone's layout
-__device__ __forceinline__ void polar_write(double* __restrict__ x, int kind, int d, int i, int j, double v) {
-  const double sq2 = 1.41421356237309504880;
+__device__ __forceinline__ void polar_write(real* __restrict__ x, int kind, int d, int i, int j, real v) {
+  const real sq2 = 1.41421356237309504880;
   if (kind == COSMO_HIP_PSD_TRIANGLE) { x[svec_index(i, j)] = (i == j) ? v : sq2 * v; return; }
   if (kind == COSMO_HIP_PSD_SQUARE) { x[(long long)j * d + i] = v; x[(long long)i * d + j] = v; return; }
   const int r = d / 2;
@@ -147,16 +147,16 @@ __device__ __forceinline__ void polar_write(double* __restrict__ x, int kind, in
 }
 
 // X (full symmetric, zero padded to ld) from the svec / square slice of s, and the partial sums of ||X||_F^2
-__global__ __launch_bounds__(COSMO_BS) void k_polar_populate(const Ctl* __restrict__ ctl, int guard, PolarCone cn, const double* __restrict__ s,
-                                                             double* __restrict__ X, double* __restrict__ parts) {
+__global__ __launch_bounds__(COSMO_BS) void k_polar_populate(const Ctl* __restrict__ ctl, int guard, PolarCone cn, const real* __restrict__ s,
+                                                             real* __restrict__ X, real* __restrict__ parts) {
   if (guard && ctl->halt) return;
-  __shared__ double red[COSMO_BS / 64];
-  const double* x = s + cn.off;
+  __shared__ real red[COSMO_BS / 64];
+  const real* x = s + cn.off;
   const int d = cn.d, ld = cn.ld;
-  double acc = 0.0;
+  real acc = 0.0;
   for (int j = blockIdx.x; j < ld; j += gridDim.x) {
     for (int i = threadIdx.x; i < ld; i += COSMO_BS) {
-      double v = 0.0;
+      real v = 0.0;
       if (i < d && j < d) { v = polar_read(x, cn.kind, d, i, j); acc += v * v; }
       X[(long long)j * ld + i] = v;
     }
@@ -166,12 +166,12 @@ __global__ __launch_bounds__(COSMO_BS) void k_polar_populate(const Ctl* __restri
 }
 
 // U = 2 X / ||X||_F  (U = 0 for X = 0): spectrum in [0, 2], the domain of the lifting polynomial
-__global__ __launch_bounds__(COSMO_BS) void k_polar_scale(const Ctl* __restrict__ ctl, int guard, long long n, int nparts, const double* __restrict__ parts,
-                                                          const double* __restrict__ X, double* __restrict__ U, double* __restrict__ nrm_out) {
+__global__ __launch_bounds__(COSMO_BS) void k_polar_scale(const Ctl* __restrict__ ctl, int guard, long long n, int nparts, const real* __restrict__ parts,
+                                                          const real* __restrict__ X, real* __restrict__ U, real* __restrict__ nrm_out) {
   if (guard && ctl->halt) return;
-  __shared__ double red[COSMO_BS / 64];
-  const double nf = sqrt(reduce_partials_sum(parts, nparts, red));
-  const double inv = (nf > 0.0) ? 2.0 / nf : 0.0;
+  __shared__ real red[COSMO_BS / 64];
+  const real nf = sqrt(reduce_partials_sum(parts, nparts, red));
+  const real inv = (nf > R(0.0)) ? R(2.0) / nf : R(0.0);
   if (blockIdx.x == 0 && threadIdx.x == 0) *nrm_out = nf;
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < n; i += (long long)gridDim.x * COSMO_BS) U[i] = X[i] * inv;
 }
@@ -185,12 +185,12 @@ __global__ __launch_bounds__(COSMO_BS) void k_polar_scale(const Ctl* __restrict_
 // Epilogue: the accumulators are transposed through LDS so that both the natural and the mirrored tile leave as full rows.
 template <int TS> struct GemmCfg {
   static constexpr int NM = TS / 32;                 // MFMA tiles per wave and dimension
-  static constexpr int NL = TS / 32;                 // double2 loads per thread, operand and panel
+  static constexpr int NL = TS / 32;                 // real2 loads per thread, operand and panel
   static constexpr int PITCH = TS + 16;              // == 16 (mod 32): conflict-free ds_read_b64 of 16-lane x 4-row fragments
   static constexpr int CPITCH = TS + 1;              // odd: conflict-free column reads in the epilogue
   static constexpr int PANEL = PK * PITCH;           // doubles per operand panel
-  static constexpr int SMEM = (4 * PANEL > TS * CPITCH ? 4 * PANEL : TS * CPITCH) * 8;
-  static constexpr int SMEM2 = (8 * PANEL > TS * CPITCH ? 8 * PANEL : TS * CPITCH) * 8;   // split-k: two groups of panels
+  static constexpr int SMEM = (4 * PANEL > TS * CPITCH ? 4 * PANEL : TS * CPITCH) * (int)sizeof(real);
+  static constexpr int SMEM2 = (8 * PANEL > TS * CPITCH ? 8 * PANEL : TS * CPITCH) * (int)sizeof(real);   // split-k: two groups of panels
 };
 
 // SK = 2: intra-workgroup split of k.  8 waves; waves 0-3 (group 0) take the even k-panels, waves 4-7 (group 1) the odd ones, each
@@ -198,8 +198,8 @@ template <int TS> struct GemmCfg {
 // tile count gives one tile per CU: two waves per SIMD then cover each other's LDS / barrier stalls (one wave per SIMD issues
 // MFMAs only ~59 % of the time).
 template <int EPI, int TS, int SK>
-__device__ __forceinline__ void symm_gemm_tile(const double* __restrict__ A, const double* __restrict__ B, const double* __restrict__ Cin,
-                                               double* __restrict__ C, int ld, int ti, int tj, double alpha, double beta, double* smem,
+__device__ __forceinline__ void symm_gemm_tile(const real* __restrict__ A, const real* __restrict__ B, const real* __restrict__ Cin,
+                                               real* __restrict__ C, int ld, int ti, int tj, real alpha, real beta, real* smem,
                                                int kext = 0) {
   // kext: extent of the k loop (a multiple of 2 PK SK; 0 = ld).  Rows / columns beyond the cone's d are zero in every operand of
   // the iteration, so the batched path stops the inner products at d rounded up to 32 instead of the tile-rounded ld: exact.
@@ -207,8 +207,8 @@ __device__ __forceinline__ void symm_gemm_tile(const double* __restrict__ A, con
   constexpr int NM = Cfg::NM, NL = Cfg::NL, PITCH = Cfg::PITCH, CPITCH = Cfg::CPITCH, PANEL = Cfg::PANEL;
   const int grp = (SK == 2) ? (threadIdx.x >> 8) : 0;          // k-split group of this wave
   const int gtid = threadIdx.x & 255;                          // thread index within the group
-  double* As = smem + grp * 4 * PANEL;   // [2][PANEL] per group
-  double* Bs = As + 2 * PANEL;           // [2][PANEL]
+  real* As = smem + grp * 4 * PANEL;   // [2][PANEL] per group
+  real* Bs = As + 2 * PANEL;           // [2][PANEL]
   const int i0 = ti * TS, j0 = tj * TS;
   const int lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) & 3;
   const int wi = wv & 1, wj = wv >> 1;
@@ -219,7 +219,7 @@ __device__ __forceinline__ void symm_gemm_tile(const double* __restrict__ A, con
 #pragma unroll
     for (int b = 0; b < NM; ++b) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
   const int nk = (kext > 0 ? kext : ld) / PK / SK;   // panels per group (a multiple of 2: both groups run the same number of steps)
-  // global -> LDS mapping: double2 number q = tid + 256 u of the PK x TS panel: k = q / (TS/2), index pair = q % (TS/2)
+  // global -> LDS mapping: real2 number q = tid + 256 u of the PK x TS panel: k = q / (TS/2), index pair = q % (TS/2)
   int goff[NL], soff[NL];
 #pragma unroll
   for (int u = 0; u < NL; ++u) {
@@ -228,22 +228,22 @@ __device__ __forceinline__ void symm_gemm_tile(const double* __restrict__ A, con
     goff[u] = k * ld + 2 * c2;
     soff[u] = k * PITCH + 2 * c2;
   }
-  const double* ga = A + i0 + (long long)grp * PK * ld;        // group 1 starts at panel 1
-  const double* gb = B + j0 + (long long)grp * PK * ld;
-  double2 r[2][2 * NL];
+  const real* ga = A + i0 + (long long)grp * PK * ld;        // group 1 starts at panel 1
+  const real* gb = B + j0 + (long long)grp * PK * ld;
+  real2 r[2][2 * NL];
 #define P_LOAD(R, KB)                                                                                     \
   {                                                                                                       \
     const long long o_ = (long long)(KB) * pstep;                                                         \
     _Pragma("unroll") for (int u = 0; u < NL; ++u) {                                                      \
-      (R)[u] = *reinterpret_cast<const double2*>(ga + o_ + goff[u]);                                      \
-      (R)[NL + u] = *reinterpret_cast<const double2*>(gb + o_ + goff[u]);                                 \
+      (R)[u] = *reinterpret_cast<const real2*>(ga + o_ + goff[u]);                                      \
+      (R)[NL + u] = *reinterpret_cast<const real2*>(gb + o_ + goff[u]);                                 \
     }                                                                                                     \
   }
 #define P_STORE(R, BUF)                                                                                   \
   {                                                                                                       \
     _Pragma("unroll") for (int u = 0; u < NL; ++u) {                                                      \
-      double* pa_ = As + (BUF) * PANEL + soff[u];                                                         \
-      double* pb_ = Bs + (BUF) * PANEL + soff[u];                                                         \
+      real* pa_ = As + (BUF) * PANEL + soff[u];                                                         \
+      real* pb_ = Bs + (BUF) * PANEL + soff[u];                                                         \
       pa_[0] = (R)[u].x; pa_[1] = (R)[u].y;                                                               \
       pb_[0] = (R)[NL + u].x; pb_[1] = (R)[NL + u].y;                                                     \
     }                                                                                                     \
@@ -252,12 +252,12 @@ __device__ __forceinline__ void symm_gemm_tile(const double* __restrict__ A, con
 #define P_COMPUTE(BUF)                                                                                    \
   {                                                                                                       \
     _Pragma("unroll") for (int ks = 0; ks < PK / 4; ++ks) {                                               \
-      const double* ap = As + (BUF) * PANEL + (ks * 4 + fk) * PITCH + fa;                                 \
-      const double* bp = Bs + (BUF) * PANEL + (ks * 4 + fk) * PITCH + fb;                                 \
-      double av[NM], bv[NM];                                                                              \
+      const real* ap = As + (BUF) * PANEL + (ks * 4 + fk) * PITCH + fa;                                 \
+      const real* bp = Bs + (BUF) * PANEL + (ks * 4 + fk) * PITCH + fb;                                 \
+      real av[NM], bv[NM];                                                                              \
       _Pragma("unroll") for (int a = 0; a < NM; ++a) { av[a] = ap[16 * a]; bv[a] = bp[16 * a]; }          \
       _Pragma("unroll") for (int a = 0; a < NM; ++a)                                                      \
-        _Pragma("unroll") for (int b = 0; b < NM; ++b) acc[a][b] = MFMA_F64(av[a], bv[b], acc[a][b]);     \
+        _Pragma("unroll") for (int b = 0; b < NM; ++b) acc[a][b] = MFMA_REAL(av[a], bv[b], acc[a][b]);     \
     }                                                                                                     \
   }
   P_LOAD(r[0], 0)
@@ -280,7 +280,7 @@ __device__ __forceinline__ void symm_gemm_tile(const double* __restrict__ A, con
 #undef P_STORE
 #undef P_COMPUTE
   // ---- epilogue through LDS: Cs[j][i], pitch CPITCH ----
-  double* Cs = smem;
+  real* Cs = smem;
   if (SK == 2 && grp == 1) {
 #pragma unroll
     for (int mi = 0; mi < NM; ++mi)
@@ -288,7 +288,7 @@ __device__ __forceinline__ void symm_gemm_tile(const double* __restrict__ A, con
       for (int nj = 0; nj < NM; ++nj)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int i = (TS / 2) * wi + 16 * mi + (lane >> 4) + 4 * q;
+          const int i = (TS / 2) * wi + 16 * mi + ACC_ROW(lane, q);
           const int j = (TS / 2) * wj + 16 * nj + (lane & 15);
           Cs[j * CPITCH + i] = acc[mi][nj][q];
         }
@@ -301,9 +301,9 @@ __device__ __forceinline__ void symm_gemm_tile(const double* __restrict__ A, con
       for (int nj = 0; nj < NM; ++nj)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int i = (TS / 2) * wi + 16 * mi + (lane >> 4) + 4 * q;     // D row
+          const int i = (TS / 2) * wi + 16 * mi + ACC_ROW(lane, q);     // D row
           const int j = (TS / 2) * wj + 16 * nj + (lane & 15);             // D col
-          const double v = acc[mi][nj][q];
+          const real v = acc[mi][nj][q];
           Cs[j * CPITCH + i] = (SK == 2) ? (v + Cs[j * CPITCH + i]) : v;   // even-panel partial + odd-panel partial (fixed order)
         }
   }
@@ -313,7 +313,7 @@ __device__ __forceinline__ void symm_gemm_tile(const double* __restrict__ A, con
   for (int e = threadIdx.x; e < TS * TS; e += 256 * SK) {
     const int i = e % TS, j = e / TS;
     if (diag && i > j) continue;
-    double v = Cs[j * CPITCH + i];
+    real v = Cs[j * CPITCH + i];
     const long long o = (long long)(j0 + j) * ld + i0 + i;
     if (EPI == 1) { v = alpha * v + beta * Cin[o]; Cs[j * CPITCH + i] = v; }
     C[o] = v;
@@ -329,12 +329,12 @@ __device__ __forceinline__ void symm_gemm_tile(const double* __restrict__ A, con
 
 // one large cone: the grid walks its upper tiles
 template <int EPI, int TS, int SK>
-__global__ __launch_bounds__(256 * SK) void k_symm_gemm(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ gate, const double* __restrict__ A,
-                                                   const double* __restrict__ B, const double* __restrict__ Cin, double* __restrict__ C, int ld, int ntiles,
-                                                   double alpha, double beta) {
+__global__ __launch_bounds__(256 * SK) void k_symm_gemm(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ gate, const real* __restrict__ A,
+                                                   const real* __restrict__ B, const real* __restrict__ Cin, real* __restrict__ C, int ld, int ntiles,
+                                                   real alpha, real beta) {
   if (guard && ctl->halt) return;
   if (gate && !*gate) return;          // fallback round whose verification already passed
-  extern __shared__ double smem[];
+  extern __shared__ real smem[];
   // XCD-aware tile order: workgroup b runs on XCD b % 8 (round-robin dispatch), and each XCD has its own 4 MB L2.  Give every
   // XCD a CONTIGUOUS range of the column-major upper-triangle tile list (a few adjacent tile columns: one shared B panel,
   // consecutive A panels) so that the k-panels its concurrent tiles stream are fetched once per XCD, not once per tile.
@@ -352,24 +352,24 @@ __global__ __launch_bounds__(256 * SK) void k_symm_gemm(const Ctl* __restrict__ 
 // a batch of mid-size cones: one workgroup per (cone, upper tile) descriptor; buffers 0..3 of a cone are X, U/Y, Y/U, T
 template <int EPI>
 __global__ __launch_bounds__(256) void k_symm_gemm_batch(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ gate, const int4* __restrict__ tiles,
-                                                         const BatchCone* __restrict__ cones, double* __restrict__ W, int ia, int ib, int icin, int ic,
-                                                         double alpha, double beta) {
+                                                         const BatchCone* __restrict__ cones, real* __restrict__ W, int ia, int ib, int icin, int ic,
+                                                         real alpha, real beta) {
   if (guard && ctl->halt) return;
-  extern __shared__ double smem[];
+  extern __shared__ real smem[];
   const int4 td = tiles[blockIdx.x];
   if (td.x < 0) return;                      // padding of the XCD-interleaved tile list
   if (gate && !gate[td.x]) return;           // fallback round: only the cones whose verification failed (per cone, so that a cone's
                                              // arithmetic never depends on which other cones share its batch / its rank)
   const BatchCone bc = cones[td.x];
   const long long n2 = (long long)bc.ld * bc.ld;
-  double* base = W + bc.woff;
+  real* base = W + bc.woff;
   symm_gemm_tile<EPI, 64, 1>(base + ia * n2, base + ib * n2, base + icin * n2, base + ic * n2, bc.ld, td.y, td.z, alpha, beta, smem,
                              ((bc.d + 31) / 32) * 32);
 }
 
 template <int EPI, int TS, int SK>
-static void launch_symm_gemm(cosmo_hip_handle* h, int guard, const int* gate, const double* A, const double* B, const double* Cin, double* C, int ld,
-                             double alpha, double beta) {
+static void launch_symm_gemm(cosmo_hip_handle* h, int guard, const int* gate, const real* A, const real* B, const real* Cin, real* C, int ld,
+                             real alpha, real beta) {
   const int nt = ld / TS, ntiles = nt * (nt + 1) / 2;
   constexpr int smem = (SK == 2) ? GemmCfg<TS>::SMEM2 : GemmCfg<TS>::SMEM;
   static bool attr_set = false;
@@ -379,8 +379,8 @@ static void launch_symm_gemm(cosmo_hip_handle* h, int guard, const int* gate, co
   static_cast<PolarPlan*>(h->psd_polar)->launches[TS == 64 ? 0 : (SK == 2 ? 2 : 1)] += 1;
 }
 // ts: tile side; sk: 1 or 2 (intra-workgroup split of k, only with ts = 96)
-static void symm_gemm(cosmo_hip_handle* h, int guard, const int* gate, int ts, int sk, int epi, const double* A, const double* B, const double* Cin, double* C,
-                      int ld, double alpha, double beta) {
+static void symm_gemm(cosmo_hip_handle* h, int guard, const int* gate, int ts, int sk, int epi, const real* A, const real* B, const real* Cin, real* C,
+                      int ld, real alpha, real beta) {
   if (ts == 96 && sk == 2) { if (epi) launch_symm_gemm<1, 96, 2>(h, guard, gate, A, B, Cin, C, ld, alpha, beta); else launch_symm_gemm<0, 96, 2>(h, guard, gate, A, B, Cin, C, ld, alpha, beta); }
   else if (ts == 96) { if (epi) launch_symm_gemm<1, 96, 1>(h, guard, gate, A, B, Cin, C, ld, alpha, beta); else launch_symm_gemm<0, 96, 1>(h, guard, gate, A, B, Cin, C, ld, alpha, beta); }
   else { if (epi) launch_symm_gemm<1, 64, 1>(h, guard, gate, A, B, Cin, C, ld, alpha, beta); else launch_symm_gemm<0, 64, 1>(h, guard, gate, A, B, Cin, C, ld, alpha, beta); }
@@ -388,26 +388,26 @@ static void symm_gemm(cosmo_hip_handle* h, int guard, const int* gate, int ts, i
 
 // ---- verification of a large cone: ||G||_F^2 partials, then the decision (one workgroup) --------------------------------
 __global__ __launch_bounds__(COSMO_BS) void k_polar_sumsq(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ gate, long long n,
-                                                          const double* __restrict__ G, double* __restrict__ parts) {
+                                                          const real* __restrict__ G, real* __restrict__ parts) {
   if (guard && ctl->halt) return;
   if (gate && !*gate) return;
-  __shared__ double red[COSMO_BS / 64];
-  double acc = 0.0;
-  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < n; i += (long long)gridDim.x * COSMO_BS) { const double v = G[i]; acc += v * v; }
+  __shared__ real red[COSMO_BS / 64];
+  real acc = 0.0;
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < n; i += (long long)gridDim.x * COSMO_BS) { const real v = G[i]; acc += v * v; }
   acc = block_sum(acc, red);
   if (threadIdx.x == 0) parts[blockIdx.x] = acc;
 }
 // round = 0: verification of the main schedule (always runs); round >= 1: of a fallback round (runs only if the gate is open).
 // last != 0: no further round is enqueued, a failure is recorded as unverified and the gate is closed for the next projection.
 __global__ __launch_bounds__(COSMO_BS) void k_polar_decide(const Ctl* __restrict__ ctl, int guard, PolarDev* __restrict__ pd, int round, int last, int nparts,
-                                                           const double* __restrict__ parts, const double* __restrict__ nrm, double tol) {
+                                                           const real* __restrict__ parts, const real* __restrict__ nrm, real tol) {
   if (guard && ctl->halt) return;
   if (round > 0 && !pd->gate) return;
-  __shared__ double red[COSMO_BS / 64];
-  const double g2 = reduce_partials_sum(parts, nparts, red);
+  __shared__ real red[COSMO_BS / 64];
+  const real g2 = reduce_partials_sum(parts, nparts, red);
   if (threadIdx.x != 0) return;
-  const double nf = *nrm;
-  const double err = (nf > 0.0) ? 0.5 * sqrt(g2) / nf : 0.0;
+  const real nf = *nrm;
+  const real err = (nf > R(0.0)) ? R(0.5) * sqrt(g2) / nf : R(0.0);
   const bool ok = !(err > tol);                // NaN fails
   pd->err_last = err;
   if (err > pd->err_max || err != err) pd->err_max = err;
@@ -418,49 +418,49 @@ __global__ __launch_bounds__(COSMO_BS) void k_polar_decide(const Ctl* __restrict
 }
 
 // X+ = (X + H) / 2 written in the cone's layout (svec with sqrt(2) off-diagonals / mirrored square), trace(U) partials
-__global__ __launch_bounds__(COSMO_BS) void k_polar_finish(const Ctl* __restrict__ ctl, int guard, PolarCone cn, const double* __restrict__ X,
-                                                           const double* __restrict__ H, const double* __restrict__ U, double* __restrict__ s,
-                                                           double* __restrict__ tparts) {
+__global__ __launch_bounds__(COSMO_BS) void k_polar_finish(const Ctl* __restrict__ ctl, int guard, PolarCone cn, const real* __restrict__ X,
+                                                           const real* __restrict__ H, const real* __restrict__ U, real* __restrict__ s,
+                                                           real* __restrict__ tparts) {
   if (guard && ctl->halt) return;
-  __shared__ double red[COSMO_BS / 64];
-  double* x = s + cn.off;
+  __shared__ real red[COSMO_BS / 64];
+  real* x = s + cn.off;
   const int d = cn.d, ld = cn.ld;
-  double tr = 0.0;   // trace(U) + trace(U^2) = 2 #{lambda > 0} for a converged sign matrix (zero eigenvalues count as not positive)
+  real tr = 0.0;   // trace(U) + trace(U^2) = 2 #{lambda > 0} for a converged sign matrix (zero eigenvalues count as not positive)
   for (int j = blockIdx.x; j < d; j += gridDim.x) {
     for (int i = threadIdx.x; i <= j; i += COSMO_BS) {
       const long long o = (long long)j * ld + i;
-      const double v = (X[o] + H[o]) / 2.0;
+      const real v = (X[o] + H[o]) / R(2.0);
       polar_write(x, cn.kind, d, i, j, v);
-      const double u = U[o];
-      tr += (i == j) ? (u + u * u) : 2.0 * u * u;
+      const real u = U[o];
+      tr += (i == j) ? (u + u * u) : R(2.0) * u * u;
     }
   }
   tr = block_sum(tr, red);
   if (threadIdx.x == 0) tparts[blockIdx.x] = tr;
 }
-__global__ __launch_bounds__(COSMO_BS) void k_polar_rank(const Ctl* __restrict__ ctl, int guard, int d, int nparts, const double* __restrict__ tparts,
+__global__ __launch_bounds__(COSMO_BS) void k_polar_rank(const Ctl* __restrict__ ctl, int guard, int d, int nparts, const real* __restrict__ tparts,
                                                          int* __restrict__ rank_out, int kind) {
   if (guard && ctl->halt) return;
-  __shared__ double red[COSMO_BS / 64];
-  const double tr = reduce_partials_sum(tparts, nparts, red);
+  __shared__ real red[COSMO_BS / 64];
+  const real tr = reduce_partials_sum(tparts, nparts, red);
   (void)d;
-  if (threadIdx.x == 0) *rank_out = (int)llround(tr / (kind == COSMO_HIP_PSD_TRIANGLE_COMPLEX ? 4.0 : 2.0));   // Hermitian embedding doubles every eigenvalue
+  if (threadIdx.x == 0) *rank_out = (int)llround(tr / (kind == COSMO_HIP_PSD_TRIANGLE_COMPLEX ? R(4.0) : R(2.0)));   // Hermitian embedding doubles every eigenvalue
 }
 
 // ---- batched variants of populate / scale / finish / rank: blockIdx.y = cone of the batch -------------------------------
 #define BPX 16   // workgroups per cone in the elementwise kernels (= partials per cone)
 __global__ __launch_bounds__(COSMO_BS) void k_bpolar_populate(const Ctl* __restrict__ ctl, int guard, const BatchCone* __restrict__ cones,
-                                                              const double* __restrict__ s, double* __restrict__ W, double* __restrict__ parts) {
+                                                              const real* __restrict__ s, real* __restrict__ W, real* __restrict__ parts) {
   if (guard && ctl->halt) return;
-  __shared__ double red[COSMO_BS / 64];
+  __shared__ real red[COSMO_BS / 64];
   const BatchCone cn = cones[blockIdx.y];
-  const double* x = s + cn.off;
-  double* X = W + cn.woff;
+  const real* x = s + cn.off;
+  real* X = W + cn.woff;
   const int d = cn.d, ld = cn.ld;
-  double acc = 0.0;
+  real acc = 0.0;
   for (int j = blockIdx.x; j < ld; j += gridDim.x) {
     for (int i = threadIdx.x; i < ld; i += COSMO_BS) {
-      double v = 0.0;
+      real v = 0.0;
       if (i < d && j < d) { v = polar_read(x, cn.kind, d, i, j); acc += v * v; }
       X[(long long)j * ld + i] = v;
     }
@@ -469,80 +469,80 @@ __global__ __launch_bounds__(COSMO_BS) void k_bpolar_populate(const Ctl* __restr
   if (threadIdx.x == 0) parts[(size_t)blockIdx.y * 2 * BPX + blockIdx.x] = acc;
 }
 __global__ __launch_bounds__(COSMO_BS) void k_bpolar_scale(const Ctl* __restrict__ ctl, int guard, const BatchCone* __restrict__ cones,
-                                                           const double* __restrict__ parts, double* __restrict__ W, double* __restrict__ bnrm) {
+                                                           const real* __restrict__ parts, real* __restrict__ W, real* __restrict__ bnrm) {
   if (guard && ctl->halt) return;
   const BatchCone cn = cones[blockIdx.y];
-  double nf2 = 0.0;
+  real nf2 = 0.0;
   for (int k = 0; k < BPX; ++k) nf2 += parts[(size_t)blockIdx.y * 2 * BPX + k];     // same order in every thread: deterministic
-  const double nf = sqrt(nf2);
-  const double inv = (nf > 0.0) ? 2.0 / nf : 0.0;
+  const real nf = sqrt(nf2);
+  const real inv = (nf > R(0.0)) ? R(2.0) / nf : R(0.0);
   if (blockIdx.x == 0 && threadIdx.x == 0) bnrm[blockIdx.y] = nf;
   const long long n2 = (long long)cn.ld * cn.ld;
-  const double* X = W + cn.woff;
-  double* U = W + cn.woff + n2;
+  const real* X = W + cn.woff;
+  real* U = W + cn.woff + n2;
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < n2; i += (long long)gridDim.x * COSMO_BS) U[i] = X[i] * inv;
 }
 __global__ __launch_bounds__(COSMO_BS) void k_bpolar_finish(const Ctl* __restrict__ ctl, int guard, const BatchCone* __restrict__ cones,
-                                                            double* __restrict__ W, int iu, double* __restrict__ s, double* __restrict__ parts) {
+                                                            real* __restrict__ W, int iu, real* __restrict__ s, real* __restrict__ parts) {
   if (guard && ctl->halt) return;
-  __shared__ double red[COSMO_BS / 64];
+  __shared__ real red[COSMO_BS / 64];
   const BatchCone cn = cones[blockIdx.y];
   const long long n2 = (long long)cn.ld * cn.ld;
-  const double* X = W + cn.woff;
-  const double* U = W + cn.woff + iu * n2;
-  const double* H = W + cn.woff + 3 * n2;
-  double* x = s + cn.off;
+  const real* X = W + cn.woff;
+  const real* U = W + cn.woff + iu * n2;
+  const real* H = W + cn.woff + 3 * n2;
+  real* x = s + cn.off;
   const int d = cn.d, ld = cn.ld;
-  double tr = 0.0;
+  real tr = 0.0;
   for (int j = blockIdx.x; j < d; j += gridDim.x) {
     for (int i = threadIdx.x; i <= j; i += COSMO_BS) {
       const long long o = (long long)j * ld + i;
-      const double v = (X[o] + H[o]) / 2.0;
+      const real v = (X[o] + H[o]) / R(2.0);
       polar_write(x, cn.kind, d, i, j, v);
-      const double u = U[o];
-      tr += (i == j) ? (u + u * u) : 2.0 * u * u;
+      const real u = U[o];
+      tr += (i == j) ? (u + u * u) : R(2.0) * u * u;
     }
   }
   tr = block_sum(tr, red);
   if (threadIdx.x == 0) parts[(size_t)blockIdx.y * 2 * BPX + BPX + blockIdx.x] = tr;
 }
-__global__ void k_bpolar_rank(const Ctl* __restrict__ ctl, int guard, int n, const BatchCone* __restrict__ cones, const double* __restrict__ parts,
+__global__ void k_bpolar_rank(const Ctl* __restrict__ ctl, int guard, int n, const BatchCone* __restrict__ cones, const real* __restrict__ parts,
                               int* __restrict__ rank) {
   if (guard && ctl->halt) return;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n) return;
-  double tr = 0.0;
+  real tr = 0.0;
   for (int k = 0; k < BPX; ++k) tr += parts[(size_t)c * 2 * BPX + BPX + k];
-  rank[cones[c].idx] = (int)llround(tr / (cones[c].kind == COSMO_HIP_PSD_TRIANGLE_COMPLEX ? 4.0 : 2.0));
+  rank[cones[c].idx] = (int)llround(tr / (cones[c].kind == COSMO_HIP_PSD_TRIANGLE_COMPLEX ? R(4.0) : R(2.0)));
 }
 
 // batched verification: per-cone ||G||_F^2 partials (G in buffer ig), then one workgroup decides for the whole batch
 __global__ __launch_bounds__(COSMO_BS) void k_bpolar_sumsq(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ gate, const BatchCone* __restrict__ cones,
-                                                           const double* __restrict__ W, int ig, double* __restrict__ vparts) {
+                                                           const real* __restrict__ W, int ig, real* __restrict__ vparts) {
   if (guard && ctl->halt) return;
   if (gate && !gate[blockIdx.y]) return;
-  __shared__ double red[COSMO_BS / 64];
+  __shared__ real red[COSMO_BS / 64];
   const BatchCone cn = cones[blockIdx.y];
   const long long n2 = (long long)cn.ld * cn.ld;
-  const double* G = W + cn.woff + ig * n2;
-  double acc = 0.0;
-  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < n2; i += (long long)gridDim.x * COSMO_BS) { const double v = G[i]; acc += v * v; }
+  const real* G = W + cn.woff + ig * n2;
+  real acc = 0.0;
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < n2; i += (long long)gridDim.x * COSMO_BS) { const real v = G[i]; acc += v * v; }
   acc = block_sum(acc, red);
   if (threadIdx.x == 0) vparts[(size_t)blockIdx.y * BPX + blockIdx.x] = acc;
 }
 __global__ __launch_bounds__(COSMO_BS) void k_bpolar_decide(const Ctl* __restrict__ ctl, int guard, PolarDev* __restrict__ pd, int* __restrict__ bgate, int round,
-                                                            int last, int n, const BatchCone* __restrict__ cones, const double* __restrict__ vparts,
-                                                            const double* __restrict__ bnrm, double tol_factor) {
+                                                            int last, int n, const BatchCone* __restrict__ cones, const real* __restrict__ vparts,
+                                                            const real* __restrict__ bnrm, real tol_factor) {
   if (guard && ctl->halt) return;
   if (round > 0 && !pd->gate) return;
-  __shared__ double red[COSMO_BS / 64];
-  double emax = 0.0, nfail = 0.0, nchk = 0.0;
+  __shared__ real red[COSMO_BS / 64];
+  real emax = 0.0, nfail = 0.0, nchk = 0.0;
   for (int c = threadIdx.x; c < n; c += COSMO_BS) {
     if (round > 0 && !bgate[c]) continue;      // verified in an earlier round
-    double g2 = 0.0;
+    real g2 = 0.0;
     for (int k = 0; k < BPX; ++k) g2 += vparts[(size_t)c * BPX + k];
-    const double nf = bnrm[c];
-    const double err = (nf > 0.0) ? 0.5 * sqrt(g2) / nf : 0.0;
+    const real nf = bnrm[c];
+    const real err = (nf > R(0.0)) ? R(0.5) * sqrt(g2) / nf : R(0.0);
     const bool ok = !(err > tol_factor * cones[c].d * PSD_EPS);       // NaN fails
     bgate[c] = (!ok && !last) ? 1 : 0;
     nchk += 1.0;
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_bpolar_decide(const Ctl* __restric
   pd->err_last = emax;
   if (emax > pd->err_max || emax != emax) pd->err_max = emax;
   if (round == 0) pd->projections += 1; else pd->rounds += 1;
-  if (nfail == 0.0) { pd->verified += 1; pd->gate = 0; }
+  if (nfail == R(0.0)) { pd->verified += 1; pd->gate = 0; }
   else if (last) { pd->unverified += 1; pd->gate = 0; }
   else pd->gate = 1;
   (void)nchk;
@@ -624,9 +624,9 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
       woff += 4LL * pc.ld * pc.ld;
       q->cones.push_back(pc);
     }
-    HIPCHK(h, hipMalloc((void**)&q->W, sizeof(double) * (size_t)woff));
-    HIPCHK(h, hipMalloc((void**)&q->parts, sizeof(double) * 2 * COSMO_MAX_PARTIALS * q->cones.size()));
-    HIPCHK(h, hipMalloc((void**)&q->nrm, sizeof(double) * q->cones.size()));
+    HIPCHK(h, hipMalloc((void**)&q->W, sizeof(real) * (size_t)woff));
+    HIPCHK(h, hipMalloc((void**)&q->parts, sizeof(real) * 2 * COSMO_MAX_PARTIALS * q->cones.size()));
+    HIPCHK(h, hipMalloc((void**)&q->nrm, sizeof(real) * q->cones.size()));
   }
   if (use_batch) {
     long long woff = 0;
@@ -668,11 +668,11 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
       for (int x = 0; x < 8; ++x) for (size_t sl = 0; sl < xl[x].size(); ++sl) tiles[8 * sl + x] = xl[x][sl];
     }
     q->nbtiles = (int)tiles.size();
-    HIPCHK(h, hipMalloc((void**)&q->BW, sizeof(double) * (size_t)woff));
+    HIPCHK(h, hipMalloc((void**)&q->BW, sizeof(real) * (size_t)woff));
     HIPCHK(h, hipMalloc((void**)&q->d_bcones, sizeof(BatchCone) * q->bcones.size()));
     HIPCHK(h, hipMalloc((void**)&q->d_btiles, sizeof(int4) * tiles.size()));
-    HIPCHK(h, hipMalloc((void**)&q->bparts, sizeof(double) * 3 * BPX * q->bcones.size()));   // norm, trace and verification partials
-    HIPCHK(h, hipMalloc((void**)&q->bnrm, sizeof(double) * q->bcones.size()));
+    HIPCHK(h, hipMalloc((void**)&q->bparts, sizeof(real) * 3 * BPX * q->bcones.size()));   // norm, trace and verification partials
+    HIPCHK(h, hipMalloc((void**)&q->bnrm, sizeof(real) * q->bcones.size()));
     HIPCHK(h, hipMalloc((void**)&q->bgate, sizeof(int) * q->bcones.size()));
     HIPCHK(h, hipMemset(q->bgate, 0, sizeof(int) * q->bcones.size()));
     HIPCHK(h, hipMemcpy(q->d_bcones, q->bcones.data(), sizeof(BatchCone) * q->bcones.size(), hipMemcpyHostToDevice));
@@ -687,18 +687,18 @@ bool polar_has_batch(const cosmo_hip_handle* h) { const PolarPlan* q = static_ca
 bool polar_has_large(const cosmo_hip_handle* h) { const PolarPlan* q = static_cast<const PolarPlan*>(h->psd_polar); return q && !q->cones.empty(); }
 
 // all mid-size cones of the batch advance together: 3 launches per step for the whole batch
-int32_t polar_enqueue_project_batch(cosmo_hip_handle* h, double* s, int guard) {
+int32_t polar_enqueue_project_batch(cosmo_hip_handle* h, real* s, int guard) {
   PolarPlan* q = static_cast<PolarPlan*>(h->psd_polar);
   PsdPlan* p = h->psd;
   hipStream_t st = h->stream;
   const int n = (int)q->bcones.size();
   const size_t sm = GemmCfg<64>::SMEM;
-  double* vparts = q->bparts + (size_t)2 * BPX * n;
+  real* vparts = q->bparts + (size_t)2 * BPX * n;
   hipLaunchKernelGGL(k_bpolar_populate, dim3(BPX, n), dim3(COSMO_BS), 0, st, h->ctl, guard, q->d_bcones, s, q->BW, q->bparts);
   hipLaunchKernelGGL(k_bpolar_scale, dim3(BPX, n), dim3(COSMO_BS), 0, st, h->ctl, guard, q->d_bcones, q->bparts, q->BW, q->bnrm);
   int iu = 1, iy = 2, products = 0;
   const dim3 G(q->nbtiles), B(256);
-  auto step = [&](const double* co, const int* gate) {
+  auto step = [&](const real* co, const int* gate) {
     hipLaunchKernelGGL((k_symm_gemm_batch<0>), G, B, sm, st, h->ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW, iu, iu, iu, iy, 1.0, 0.0);       // Y = U^2
     hipLaunchKernelGGL((k_symm_gemm_batch<1>), G, B, sm, st, h->ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW, iy, iy, iy, 3, co[2], co[1]);    // T = c Y^2 + b Y
     hipLaunchKernelGGL((k_symm_gemm_batch<1>), G, B, sm, st, h->ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW, iu, 3, iu, iy, 1.0, co[0]);      // U' = U T + a U
@@ -728,24 +728,24 @@ int32_t polar_enqueue_project_batch(cosmo_hip_handle* h, double* s, int guard) {
   return COSMO_HIP_OK;
 }
 
-int32_t polar_enqueue_project(cosmo_hip_handle* h, double* s, int guard) {
+int32_t polar_enqueue_project(cosmo_hip_handle* h, real* s, int guard) {
   PolarPlan* q = static_cast<PolarPlan*>(h->psd_polar);
   PsdPlan* p = h->psd;
   hipStream_t st = h->stream;
   for (size_t ci = 0; ci < q->cones.size(); ++ci) {
     const PolarCone& cn = q->cones[ci];
     const long long n2 = (long long)cn.ld * cn.ld;
-    double* X = q->W + cn.woff;
-    double* U = X + n2;
-    double* Y = U + n2;
-    double* T = Y + n2;
-    double* nparts = q->parts + 2 * COSMO_MAX_PARTIALS * ci;
-    double* tparts = nparts + COSMO_MAX_PARTIALS;
+    real* X = q->W + cn.woff;
+    real* U = X + n2;
+    real* Y = U + n2;
+    real* T = Y + n2;
+    real* nparts = q->parts + 2 * COSMO_MAX_PARTIALS * ci;
+    real* tparts = nparts + COSMO_MAX_PARTIALS;
     const int gpop = std::min(cn.ld, 1024);
     int products = 0;
     hipLaunchKernelGGL(k_polar_populate, dim3(gpop), dim3(COSMO_BS), 0, st, h->ctl, guard, cn, s, X, nparts);
     hipLaunchKernelGGL(k_polar_scale, dim3(1024), dim3(COSMO_BS), 0, st, h->ctl, guard, n2, gpop, nparts, X, U, q->nrm + ci);
-    auto step = [&](const double* co, const int* gate) {
+    auto step = [&](const real* co, const int* gate) {
       symm_gemm(h, guard, gate, cn.ts, cn.sk, 0, U, U, nullptr, Y, cn.ld, 1.0, 0.0);         // Y = U^2
       symm_gemm(h, guard, gate, cn.ts, cn.sk, 1, Y, Y, Y, T, cn.ld, co[2], co[1]);           // T = c Y^2 + b Y
       symm_gemm(h, guard, gate, cn.ts, cn.sk, 1, U, T, U, Y, cn.ld, 1.0, co[0]);             // U' = U T + a U
@@ -808,7 +808,7 @@ extern "C" int32_t cosmo_hip_polar_stats(cosmo_hip_handle* h, int64_t out[16]) {
   out[4] = q->launches[0]; out[5] = q->launches[1]; out[6] = q->launches[2]; out[7] = q->launches[3];
   out[8] = q->products_last_large; out[9] = now.rounds; out[10] = now.verified; out[11] = q->products_last_batch;
   out[12] = q->k_lift + POLAR_NFIN; out[13] = now.unverified; out[14] = now.projections;
-  out[15] = (int64_t)llround(now.err_max * 1e18);       // max verified error bound relative to ||X||_F, in units of 1e-18
+  out[15] = (int64_t)llround((double)now.err_max * 1e18);       // max verified error bound relative to ||X||_F, in units of 1e-18
   return COSMO_HIP_OK;
 }
 
@@ -829,7 +829,7 @@ extern "C" int32_t cosmo_hip_time_psd_product(cosmo_hip_handle* h, int32_t which
       if (which == 0) {
         const PolarCone& cn = q->cones[0];
         const long long n2 = (long long)cn.ld * cn.ld;
-        double* X = q->W + cn.woff;
+        real* X = q->W + cn.woff;
         symm_gemm(h, 0, nullptr, cn.ts, cn.sk, 0, X + n2, X + n2, nullptr, X + 2 * n2, cn.ld, 1.0, 0.0);
         const long long nt = cn.ld / cn.ts;
         fl = 2.0 * (double)(nt * (nt + 1) / 2) * cn.ts * cn.ts * cn.ld;
@@ -862,15 +862,15 @@ extern "C" int32_t cosmo_hip_time_psd_product(cosmo_hip_handle* h, int32_t which
 // O(d^3 / 3) of one workgroup is off the hot path.  Side 2r <= COSMO_CPLX_CHOL_MAX; larger Hermitian cones never certify.
 // ---------------------------------------------------------------------------------------------------------------------
 #define COSMO_CPLX_CHOL_MAX 1024
-__global__ __launch_bounds__(COSMO_BS) void k_cplx_chol_pd(int off, int d, const double* __restrict__ vec, double sign, double tol,
-                                                           double* __restrict__ G, int* __restrict__ ok_out) {
-  __shared__ double rowj[COSMO_CPLX_CHOL_MAX];
-  __shared__ double piv;
+__global__ __launch_bounds__(COSMO_BS) void k_cplx_chol_pd(int off, int d, const real* __restrict__ vec, real sign, real tol,
+                                                           real* __restrict__ G, int* __restrict__ ok_out) {
+  __shared__ real rowj[COSMO_CPLX_CHOL_MAX];
+  __shared__ real piv;
   __shared__ int fail;
-  const double* x = vec + off;
+  const real* x = vec + off;
   for (long long e = threadIdx.x; e < (long long)d * d; e += COSMO_BS) {
     const int i = (int)(e % d), j = (int)(e / d);
-    double v = sign * polar_read(x, COSMO_HIP_PSD_TRIANGLE_COMPLEX, d, i, j);
+    real v = sign * polar_read(x, COSMO_HIP_PSD_TRIANGLE_COMPLEX, d, i, j);
     if (i == j) v += tol;
     G[e] = v;                                                     // column major: G[j * d + i]
   }
@@ -880,14 +880,14 @@ __global__ __launch_bounds__(COSMO_BS) void k_cplx_chol_pd(int off, int d, const
     for (int k = threadIdx.x; k < j; k += COSMO_BS) rowj[k] = G[(long long)k * d + j];          // L[j, 0..j-1]
     __syncthreads();
     for (int i = j + threadIdx.x; i < d; i += COSMO_BS) {
-      double v = G[(long long)j * d + i];
+      real v = G[(long long)j * d + i];
       for (int k = 0; k < j; ++k) v -= G[(long long)k * d + i] * rowj[k];
       G[(long long)j * d + i] = v;
-      if (i == j) { piv = v; if (!(v > 0.0)) fail = 1; }
+      if (i == j) { piv = v; if (!(v > R(0.0))) fail = 1; }
     }
     __syncthreads();
     if (fail) break;
-    const double ljj = sqrt(piv);
+    const real ljj = sqrt(piv);
     for (int i = j + threadIdx.x; i < d; i += COSMO_BS) G[(long long)j * d + i] = (i == j) ? ljj : G[(long long)j * d + i] / ljj;
     __syncthreads();
   }
@@ -895,7 +895,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_cplx_chol_pd(int off, int d, const
 }
 
 // ok[q] for the q-th entry of p->cplx: 1 = sign * H + tol I is positive definite, 0 = not (or too large to test)
-int32_t polar_complex_is_pd(cosmo_hip_handle* h, const double* vec, double sign, double tol, std::vector<int>& ok) {
+int32_t polar_complex_is_pd(cosmo_hip_handle* h, const real* vec, real sign, real tol, std::vector<int>& ok) {
   PsdPlan* p = h->psd;
   ok.clear();
   if (!p || p->cplx.empty()) return COSMO_HIP_OK;
@@ -903,8 +903,8 @@ int32_t polar_complex_is_pd(cosmo_hip_handle* h, const double* vec, double sign,
   int dmax = 0;
   for (int idx : p->cplx) if (p->cones[idx].d <= COSMO_CPLX_CHOL_MAX) dmax = std::max(dmax, p->cones[idx].d);
   if (dmax == 0) return COSMO_HIP_OK;
-  double* G = nullptr; int* d_ok = nullptr;
-  HIPCHK(h, hipMalloc((void**)&G, sizeof(double) * (size_t)dmax * dmax));
+  real* G = nullptr; int* d_ok = nullptr;
+  HIPCHK(h, hipMalloc((void**)&G, sizeof(real) * (size_t)dmax * dmax));
   if (hipMalloc((void**)&d_ok, sizeof(int)) != hipSuccess) { (void)hipFree(G); return cosmo_fail(h, COSMO_HIP_ERR_HIP, "hipMalloc failed"); }
   int32_t rc = COSMO_HIP_OK;
   for (size_t q = 0; q < p->cplx.size() && rc == COSMO_HIP_OK; ++q) {

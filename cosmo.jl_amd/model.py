@@ -419,7 +419,10 @@ def _copy_set(K):
 class Model:
     """`COSMO.Model` / `Workspace` (src/types.jl:348-403) as far as the hot path needs it."""
 
-    def __init__(self):
+    def __init__(self, dtype=np.float64):
+        # COSMO.Model{T}(), T = Float64 | Float32 (src/types.jl:348, :390-403): the device library of that element type runs the loop
+        # (libcosmo_hip.so / libcosmo_hip_f32.so); this host mirror keeps its own copies in float64 and hands the arrays over in T
+        self.dtype = np.dtype(np.float32 if np.dtype(dtype) == np.float32 else np.float64)
         self.P = self.q = self.A = self.b = None
         self.sets: List[AbstractConvexSet] = []
         self.settings = Settings()
@@ -616,7 +619,7 @@ def setup(model: Model):
     st = model.settings
 
     def make_handle():
-        h = _ffi.Handle(st.device)
+        h = _ffi.Handle(st.device, dtype=getattr(model, "dtype", np.float64))
         h.set_problem(model.P, model.q, model.A, model.b)
         bl = np.concatenate([K.l for K in model.sets if K.kind == _ffi.BOX] or [np.zeros(0)])
         bu = np.concatenate([K.u for K in model.sets if K.kind == _ffi.BOX] or [np.zeros(0)])

@@ -25,6 +25,16 @@
 extern "C" {
 #endif
 
+/* Element type of every DATA array that crosses this ABI (matrix values, vectors, iterates, bounds).  libcosmo_hip.so is built
+ * with double (COSMO.Model{Float64}); libcosmo_hip_f32.so is the SAME source and the SAME symbol names built with
+ * -DCOSMO_HIP_REAL_FLOAT (COSMO.Model{Float32}, src/types.jl:348; the reference's test-suite runs every test for both types,
+ * test/run_tests.jl).  Scalars (settings, residuals, times) stay double in both libraries: a Float32 setting converts exactly. */
+#ifdef COSMO_HIP_REAL_FLOAT
+typedef float cosmo_hip_real;
+#else
+typedef double cosmo_hip_real;
+#endif
+
 typedef struct cosmo_hip_handle cosmo_hip_handle;
 
 /* ---- status codes -------------------------------------------------------------------------------- */
@@ -160,20 +170,20 @@ void cosmo_hip_default_params(cosmo_hip_params* p);
  * called from _make_kkt_solver!, src/setup.jl:1-7) together with the (q, b) the loop reads from ws.p
  * (src/solver.jl:137,154).  P (n x n, full symmetric storage) and A (m x n) are the SCALED matrices. */
 int32_t cosmo_hip_set_problem(cosmo_hip_handle* h, int64_t n, int64_t m,
-                              const int64_t* P_colptr, const int64_t* P_rowval, const double* P_nzval,
-                              const int64_t* A_colptr, const int64_t* A_rowval, const double* A_nzval,
-                              const double* q, const double* b);
+                              const int64_t* P_colptr, const int64_t* P_rowval, const cosmo_hip_real* P_nzval,
+                              const int64_t* A_colptr, const int64_t* A_rowval, const cosmo_hip_real* A_nzval,
+                              const cosmo_hip_real* q, const cosmo_hip_real* b);
 /* Replaces ws.p.C::CompositeConvexSet (src/projections.jl:20-31) + get_set_indices
  * (src/convexset.jl:985-993) + classify_constraints! (src/setup.jl:75-85).  `type[k]`, `dim[k]` per cone in
  * row order; box_l/box_u are the concatenated (already E-scaled, src/convexset.jl:863-867) bounds of all Box
  * cones in order (may be NULL when there is no Box). */
 int32_t cosmo_hip_set_cones(cosmo_hip_handle* h, int64_t ncones, const int32_t* type, const int64_t* dim,
-                            const double* box_l, const double* box_u);
+                            const cosmo_hip_real* box_l, const cosmo_hip_real* box_u);
 /* Same, plus one parameter per cone: cone_param[k] = alpha for PowerCone / DualPowerCone (0 < alpha < 1, the reference
  * throws a DomainError otherwise, src/convexset.jl:614,758), ignored for every other type.  May be NULL when the
  * composite set holds no power cone. */
 int32_t cosmo_hip_set_cones_ex(cosmo_hip_handle* h, int64_t ncones, const int32_t* type, const int64_t* dim,
-                               const double* box_l, const double* box_u, const double* cone_param);
+                               const cosmo_hip_real* box_l, const cosmo_hip_real* box_u, const cosmo_hip_real* cone_param);
 /* ---- user-defined cones: the AbstractConvexSet plugin surface (src/projections.jl:4-5, docs/src/literate/custom_cone.jl) ----
  * project!(x, C)            -> cosmo_hip_project_fn: x is the cone's contiguous slice (dim doubles, host memory), projected in place
  * in_dual(x, C, tol) / in_pol_recc(x, C, tol) -> cosmo_hip_cone_test_fn: non-zero = member.  Optional (NULL): the cone then never
@@ -183,22 +193,22 @@ int32_t cosmo_hip_set_cones_ex(cosmo_hip_handle* h, int64_t ncones, const int32_
  * src/convexset.jl:885-891).  They must not call back into this library.  Custom cones are scaled by one scalar per cone
  * (rectify_scaling! fall-back, src/convexset.jl:953-954) and get the inequality rho class.  cone = 0-based index into the
  * table given to cosmo_hip_set_cones[_ex], whose type[cone] must be COSMO_HIP_CUSTOM; call after set_cones. */
-typedef void (*cosmo_hip_project_fn)(double* x, int64_t dim, void* user);
-typedef int32_t (*cosmo_hip_cone_test_fn)(const double* x, int64_t dim, double tol, void* user);
+typedef void (*cosmo_hip_project_fn)(cosmo_hip_real* x, int64_t dim, void* user);
+typedef int32_t (*cosmo_hip_cone_test_fn)(const cosmo_hip_real* x, int64_t dim, double tol, void* user);
 int32_t cosmo_hip_set_custom_cone(cosmo_hip_handle* h, int64_t cone, cosmo_hip_project_fn project, cosmo_hip_cone_test_fn in_dual,
                                   cosmo_hip_cone_test_fn in_pol_recc, void* user);
 /* Settings fields (src/settings.jl) + initial rho vector: set_rho_vec! (src/parameters.jl:3-13).
  * rho_vec may be NULL: then it is built from p->rho and the row classes exactly as the reference does. */
-int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_params* p, const double* rho_vec);
+int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_params* p, const cosmo_hip_real* rho_vec);
 /* Replaces update_rho!(kkt_solver, rho_vec) (src/linear_solver/kktsolver_indirect.jl:164-166; called from
  * update_rho_vec!, src/parameters.jl:85-89). */
-int32_t cosmo_hip_update_rho(cosmo_hip_handle* h, const double* rho_vec);
+int32_t cosmo_hip_update_rho(cosmo_hip_handle* h, const cosmo_hip_real* rho_vec);
 /* ScaleMatrices Dinv (n), Einv (m), cinv used ONLY to unscale residuals (src/residuals.jl:43-49,66-92).
  * NULL pointers mean identity. */
-int32_t cosmo_hip_set_scaling(cosmo_hip_handle* h, const double* Dinv, const double* Einv, double cinv);
+int32_t cosmo_hip_set_scaling(cosmo_hip_handle* h, const cosmo_hip_real* Dinv, const cosmo_hip_real* Einv, double cinv);
 /* Same plus D (n), E (m), c themselves, which the infeasibility certificates scale with (src/infeasibility.jl:5,35,39);
  * cosmo_hip_set_scaling derives them as reciprocals.  NULL = identity. */
-int32_t cosmo_hip_set_scaling_full(cosmo_hip_handle* h, const double* D, const double* Dinv, const double* E, const double* Einv,
+int32_t cosmo_hip_set_scaling_full(cosmo_hip_handle* h, const cosmo_hip_real* D, const cosmo_hip_real* Dinv, const cosmo_hip_real* E, const cosmo_hip_real* Einv,
                                    double c, double cinv);
 /* Replaces COSMO.update!(model; q, b) on already-scaled vectors (src/interface.jl:187-211). NULL = keep. */
 /* Replaces _make_accelerator! (src/setup.jl:10-16): installs (or with kind EMPTY / NULL removes) the accelerator used by
@@ -217,30 +227,30 @@ int32_t cosmo_hip_get_accel_stats(cosmo_hip_handle* h, int64_t out[6]);
  * (src/convexset.jl:863-867) and re-runs classify_constraints! on the scaled data.  The scaling matrices stay on the device
  * for the residual / infeasibility tests (as after cosmo_hip_set_scaling_full); D_out[n], E_out[m], c_out (each may be
  * NULL) return them for the caller's reverse_scaling! (src/scaling.jl:170-179).  P must be symmetric. */
-int32_t cosmo_hip_scale_ruiz(cosmo_hip_handle* h, int64_t iterations, double min_scaling, double max_scaling, double* D_out,
-                             double* E_out, double* c_out);
-int32_t cosmo_hip_update_qb(cosmo_hip_handle* h, const double* q, const double* b);
+int32_t cosmo_hip_scale_ruiz(cosmo_hip_handle* h, int64_t iterations, double min_scaling, double max_scaling, cosmo_hip_real* D_out,
+                             cosmo_hip_real* E_out, double* c_out);
+int32_t cosmo_hip_update_qb(cosmo_hip_handle* h, const cosmo_hip_real* q, const cosmo_hip_real* b);
 /* Per-row rho class computed by the library: 0 = rho, 1 = rho*RHO_EQ_OVER_RHO_INEQ, 2 = RHO_MIN
  * (apply_constraint_rho_scaling!, src/parameters.jl:17-49) -- integer bookkeeping, compared bit-exactly. */
 int32_t cosmo_hip_get_rho_classes(cosmo_hip_handle* h, int32_t* cls /* m */);
-int32_t cosmo_hip_get_rho_vec(cosmo_hip_handle* h, double* rho_vec /* m */);
+int32_t cosmo_hip_get_rho_vec(cosmo_hip_handle* h, cosmo_hip_real* rho_vec /* m */);
 
 /* ---- fine-grained plugin entry points (host pointers, synchronous) ----------------------------------- */
 /* Replaces solve!(kkt_solver, lhs, rhs) (src/linear_solver/kktsolver.jl:5-11, kktsolver_indirect.jl:36-88,
  * 123-162; called from admm_x!, src/solver.jl:52).  lhs, rhs have length n+m.  kkt_iters_out may be NULL. */
-int32_t cosmo_hip_kkt_solve(cosmo_hip_handle* h, double* lhs, const double* rhs, int64_t* kkt_iters_out);
+int32_t cosmo_hip_kkt_solve(cosmo_hip_handle* h, cosmo_hip_real* lhs, const cosmo_hip_real* rhs, int64_t* kkt_iters_out);
 /* Replaces project!(s::SplitVector, C::CompositeConvexSet) (src/convexset.jl:885-891) on a host vector of
  * length m, in place.  psd_rank_out[k] (per cone, -1 for non-PSD cones) = nnz_lambda of rank_k_update!
  * (src/convexset.jl:247-256); soc_branch_out[k] (per cone, -1 for non-SOC) = 0 keep / 1 zero / 2 scale
  * (src/convexset.jl:104-112); for the exponential / power cones it reports the case 1..4 of their project! (in cone /
  * polar => 0 / boundary shortcut / root finding, src/convexset.jl:510-537, 626-655).  Either may be NULL. */
-int32_t cosmo_hip_project(cosmo_hip_handle* h, double* s, int64_t* psd_rank_out, int32_t* soc_branch_out);
+int32_t cosmo_hip_project(cosmo_hip_handle* h, cosmo_hip_real* s, int64_t* psd_rank_out, int32_t* soc_branch_out);
 /* Replaces mul!(y, A, x), mul!(y, A', x), mul!(y, P, x) (src/residuals.jl:4,12,15). */
-int32_t cosmo_hip_spmv(cosmo_hip_handle* h, int32_t which, double* y, const double* x);
+int32_t cosmo_hip_spmv(cosmo_hip_handle* h, int32_t which, cosmo_hip_real* y, const cosmo_hip_real* x);
 
 /* ---- coarse device-resident loop (the performance path; replaces the body of optimize!) ------------- */
 /* Warm start: w[1:n] = x0 ; w[n+1:] = 1/rho .* mu0 + s0 ; s = s0 (src/solver.jl:128-129).  NULL = zeros. */
-int32_t cosmo_hip_set_iterates(cosmo_hip_handle* h, const double* x0, const double* s0, const double* mu0);
+int32_t cosmo_hip_set_iterates(cosmo_hip_handle* h, const cosmo_hip_real* x0, const cosmo_hip_real* s0, const cosmo_hip_real* mu0);
 /* admm_x! ; admm_w! once (src/solver.jl:137-138). */
 int32_t cosmo_hip_admm_init(cosmo_hip_handle* h);
 /* n_iters times the loop body admm_z! / apply_rho_adaptation_rules! / admm_x! / admm_w!
@@ -261,13 +271,13 @@ int32_t cosmo_hip_residuals(cosmo_hip_handle* h, double out[5]);
 int32_t cosmo_hip_optimize(cosmo_hip_handle* h, cosmo_hip_result* result);
 /* Copies back what the unchanged epilogue of optimize! needs (src/solver.jl:167-201): w, w_prev (n+m each),
  * s (m), mu (m) with mu = rho .* (w_prev[n+1:] - s) recovered first.  Any pointer may be NULL. */
-int32_t cosmo_hip_get_iterates(cosmo_hip_handle* h, double* w, double* w_prev, double* s, double* mu);
+int32_t cosmo_hip_get_iterates(cosmo_hip_handle* h, cosmo_hip_real* w, cosmo_hip_real* w_prev, cosmo_hip_real* s, cosmo_hip_real* mu);
 /* sol = [x_tl; nu] of the last KKT solve (ws.sol, src/solver.jl:227-228), length n+m. */
 /* Single-launch CG (csrc/cg_persist.hip): out = {enabled for this handle (operator fits one XCD's L2), participating workgroups,
  * persistent launches so far, fallbacks to the multi-kernel path, tickets / barrier arrivals / abort flag of the last launch, LDS
  * doubles per quarter}.  COSMO_HIP_CG_PERSIST=0 / 1 in the environment disables / forces it. */
 int32_t cosmo_hip_cg_persist_stats(cosmo_hip_handle* h, int64_t out[8]);
-int32_t cosmo_hip_get_kkt_solution(cosmo_hip_handle* h, double* sol);
+int32_t cosmo_hip_get_kkt_solution(cosmo_hip_handle* h, cosmo_hip_real* sol);
 /* Assembled reduced operator of the CG solve (csrc/cg_fold.hip): M = P + diag(sigma + d) + Am' rho Am as ONE sparse matrix where the
  * operator split leaves a sparse Am' rho Am (decomposed SDPs), two launches per Krylov iteration instead of three.
  * out = {enabled, nnz(M), rho-weighted terms behind its entries, CSR-stream tiles}.  COSMO_HIP_OP_FOLD=0 in the environment disables it. */
@@ -339,22 +349,22 @@ int32_t cosmo_hip_batch_destroy(cosmo_hip_batch* b);
 const char* cosmo_hip_batch_last_error(const cosmo_hip_batch* b);
 /* problem k of the batch; arguments as cosmo_hip_set_problem */
 int32_t cosmo_hip_batch_set_problem(cosmo_hip_batch* b, int64_t k, const int64_t* P_colptr, const int64_t* P_rowval,
-                                    const double* P_nzval, const int64_t* A_colptr, const int64_t* A_rowval,
-                                    const double* A_nzval, const double* q, const double* bvec);
+                                    const cosmo_hip_real* P_nzval, const int64_t* A_colptr, const int64_t* A_rowval,
+                                    const cosmo_hip_real* A_nzval, const cosmo_hip_real* q, const cosmo_hip_real* bvec);
 /* cone structure shared by all problems; box_l / box_u hold nprob * (#Box rows) entries, problem-major */
 int32_t cosmo_hip_batch_set_cones(cosmo_hip_batch* b, int64_t ncones, const int32_t* type, const int64_t* dim,
-                                  const double* box_l, const double* box_u);
-int32_t cosmo_hip_batch_set_scaling(cosmo_hip_batch* b, int64_t k, const double* Dinv, const double* Einv, double cinv);
+                                  const cosmo_hip_real* box_l, const cosmo_hip_real* box_u);
+int32_t cosmo_hip_batch_set_scaling(cosmo_hip_batch* b, int64_t k, const cosmo_hip_real* Dinv, const cosmo_hip_real* Einv, double cinv);
 /* finalises the batch (uploads, classify_constraints!, set_rho_vec! per problem) */
 int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hip_params* p);
 int32_t cosmo_hip_batch_get_rho_classes(cosmo_hip_batch* b, int64_t k, int32_t* cls /* m */);
 /* x0: nprob*n, s0 / mu0: nprob*m, problem-major; NULL = zeros (src/solver.jl:128-129 per problem) */
-int32_t cosmo_hip_batch_set_iterates(cosmo_hip_batch* b, const double* x0, const double* s0, const double* mu0);
+int32_t cosmo_hip_batch_set_iterates(cosmo_hip_batch* b, const cosmo_hip_real* x0, const cosmo_hip_real* s0, const cosmo_hip_real* mu0);
 /* optimize! for every problem; results has nprob entries */
 int32_t cosmo_hip_batch_optimize(cosmo_hip_batch* b, cosmo_hip_result* results);
 /* n_iters more loop bodies (with checks) on every undecided problem; with_init != 0 runs the init step first */
 int32_t cosmo_hip_batch_iterate(cosmo_hip_batch* b, int64_t n_iters, int32_t with_init);
-int32_t cosmo_hip_batch_get_iterates(cosmo_hip_batch* b, int64_t k, double* w, double* w_prev, double* s, double* mu);
+int32_t cosmo_hip_batch_get_iterates(cosmo_hip_batch* b, int64_t k, cosmo_hip_real* w, cosmo_hip_real* w_prev, cosmo_hip_real* s, cosmo_hip_real* mu);
 
 #ifdef __cplusplus
 }

@@ -32,6 +32,32 @@ def test_library_exports_every_header_symbol():
     assert cj.load_library().cosmo_hip_version() == 1000
 
 
+def test_float32_library_exports_the_same_symbols_and_real_pointers_follow_the_header():
+    """libcosmo_hip_f32.so (cosmo_hip_real = float, -DCOSMO_HIP_REAL_FLOAT) exports the same names; the binding's `_PR` placeholders
+    sit exactly where the header says `cosmo_hip_real*`, everything that stays `double*` (times, residual scalars, coefficient
+    tables) is `_PD` in both libraries."""
+    names = _header_functions()
+    lib = ctypes.CDLL(cj._ffi.LIB_PATH_F32)
+    for nm in names:
+        assert hasattr(lib, nm), "libcosmo_hip_f32.so does not export %s" % nm
+    assert cj.load_library(np.float32).cosmo_hip_version() == 1000 and cj.load_library(np.float32) is not cj.load_library()
+    src = open(os.path.join(ROOT, "include", "cosmo_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    for nm, (_, args) in cj._ffi.SIGNATURES.items():
+        m = re.search(r"\b%s\s*\((.*?)\)\s*;" % nm, src, re.S)
+        assert m, nm
+        params = [a.strip() for a in m.group(1).split(",")] if m.group(1).strip() not in ("", "void") else []
+        assert len(params) == len(args), (nm, params, args)
+        for prm, a in zip(params, args):
+            is_real_ptr = bool(re.search(r"cosmo_hip_real\s*\*", prm))
+            is_double_ptr = bool(re.search(r"\bdouble\s*\*", prm)) or bool(re.search(r"\bdouble\s+\w+\[", prm))
+            assert (a is cj._ffi._PR) == is_real_ptr, (nm, prm)
+            assert (a is cj._ffi._PD) == is_double_ptr, (nm, prm)
+    f64 = cj.load_library(); f32 = cj.load_library(np.float32)
+    assert f64.cosmo_hip_kkt_solve.argtypes[1] is cj._ffi._PD and f32.cosmo_hip_kkt_solve.argtypes[1] is cj._ffi._PF
+    assert f32.cosmo_hip_residuals.argtypes[1] is cj._ffi._PD            # scalars stay double
+
+
 def test_chordal_library_exports_every_header_symbol():
     src = open(os.path.join(ROOT, "include", "cosmo_chordal.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)

@@ -1,0 +1,246 @@
+"""`COSMO.Model{Float32}` on the device: libcosmo_hip_f32.so is the SAME source as libcosmo_hip.so compiled with
+cosmo_hip_real = float -- every kernel, the loop state and the device scalars are Float32 (src/types.jl:348; the reference runs its
+unit tests for Float32 and Float64, test/runtests.jl: UnitTestFloats).
+
+Checked here, through the same C ABI (ctypes with float pointers):
+  * bit-exactness of what is bit-exact in Float64 too -- Zero / Nonnegatives / Box projections (incl. -0.0 and NaN), the SpMV row
+    sums (left-to-right Float32 additions, no FMA), the elementwise admm phases -- against NumPy float32 expressions;
+  * SecondOrderCone and PSD projections (16x16 Jacobi wave kernels, batched matrix-sign path, large-cone matrix-sign path: the
+    v_mfma_f32_16x16x4_f32 instantiation with its own accumulator row map) against the Float64 oracle on the Float32-rounded input
+    at the SURVEY 8c tolerances with eps = eps(Float32);
+  * KKT solves (CG, MINRES, assembled operator) against a dense Float64 solve at Float32 accuracy;
+  * the reference's known answers that its own Float32 runs assert at 1e-3 (simple.jl:45-47 x = [0.3, 0.7], obj = 1.88;
+    qp-box.jl obj = -0.5 and the infeasibility statuses; closestcorr.jl properties) and random conic programs against the Float64
+    oracle at 1e-3.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import cosmo_jl_amd as cj
+from oracle import cosmo_oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+F = cj._ffi
+F32 = np.float32
+EPS32 = float(np.finfo(np.float32).eps)
+
+
+def bits32(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _handle_for_sets(sets, n=3):
+    m = sum(K.dim for K in sets)
+    h = cj.Handle(0, dtype=F32)
+    h.set_problem(sp.identity(n, format="csc"), np.zeros(n), sp.csc_matrix((m, n)), np.zeros(m))
+    bl = np.concatenate([K.l for K in sets if K.kind == F.BOX] or [np.zeros(0)])
+    bu = np.concatenate([K.u for K in sets if K.kind == F.BOX] or [np.zeros(0)])
+    h.set_cones([K.kind for K in sets], [K.dim for K in sets], bl, bu)
+    return h
+
+
+def test_the_float32_library_is_a_separate_instantiation():
+    h = cj.Handle(0, dtype=F32)
+    assert h.dtype == np.float32 and h.lib is not cj.Handle(0).lib
+    assert h.lib._name.endswith("libcosmo_hip_f32.so")
+
+
+def test_simple_cones_bit_exact_float32():
+    rng = np.random.default_rng(5)
+    l = (rng.standard_normal(1000) - 1).astype(F32); u = (l + rng.uniform(0, 2, 1000).astype(F32)).astype(F32)
+    l[:50] = -np.inf; u[50:100] = np.inf; u[100:150] = l[100:150]
+    sets = [cj.Nonnegatives(700), cj.ZeroSet(13), cj.Box(l, u), cj.Nonnegatives(1), cj.ZeroSet(300), cj.Box(l[:7], u[:7])]
+    h = _handle_for_sets(sets)
+    m = sum(K.dim for K in sets)
+    s = (rng.standard_normal(m) * 2).astype(F32)
+    s[::17] = 0.0; s[5::19] = -0.0; s[3] = np.nan; s[9] = np.inf; s[10] = -np.inf; s[713 + 5] = np.nan
+    out, ranks, br = h.project(s)
+    assert out.dtype == np.float32
+    # the same selections in NumPy float32 (convexset.jl:25-28, 71-74, 844-847; algebra.jl:5-7)
+    ref = s.copy(); off = 0
+    for K in sets:
+        v = ref[off:off + K.dim]
+        if K.kind == F.ZERO:
+            v[:] = 0.0
+        elif K.kind == F.NONNEG:
+            v[:] = np.where(np.isnan(v), v, np.where(v > 0, v, F32(0.0)))
+        else:
+            lo, hi = K.l.astype(F32), K.u.astype(F32)
+            v[:] = np.where(v < lo, lo, np.where(v > hi, hi, v))
+        off += K.dim
+    assert np.array_equal(bits32(out), bits32(ref))
+
+
+def test_spmv_row_sums_are_left_to_right_float32():
+    rng = np.random.default_rng(6)
+    m, n = 400, 300
+    A = sp.random(m, n, density=0.05, random_state=rng, format="csc", data_rvs=rng.standard_normal)
+    A = sp.csc_matrix(A, dtype=F32); A.sort_indices()
+    S = sp.random(n, n, density=0.02, random_state=rng, format="csc", data_rvs=rng.standard_normal)
+    P = sp.csc_matrix((S + S.T + 3 * sp.identity(n)), dtype=F32)
+    h = cj.Handle(0, dtype=F32)
+    h.set_problem(P, np.zeros(n), A, np.zeros(m))
+    x = rng.standard_normal(n).astype(F32); y = rng.standard_normal(m).astype(F32)
+
+    def serial(Mcsr, v):                       # Julia's CSC kernels accumulate a row's products in column order, in Float32
+        out = np.zeros(Mcsr.shape[0], dtype=F32)
+        for r in range(Mcsr.shape[0]):
+            acc = F32(0.0)
+            for k in range(Mcsr.indptr[r], Mcsr.indptr[r + 1]):
+                acc = F32(acc + F32(Mcsr.data[k] * v[Mcsr.indices[k]]))
+            out[r] = acc
+        return out
+    Acsr = A.tocsr(); Acsr.sort_indices(); ATcsr = A.T.tocsr(); ATcsr.sort_indices(); Pcsr = P.tocsr(); Pcsr.sort_indices()
+    assert np.array_equal(bits32(h.spmv(F.MAT_A, x)), bits32(serial(Acsr, x)))
+    assert np.array_equal(bits32(h.spmv(F.MAT_AT, y)), bits32(serial(ATcsr, y)))
+    assert np.array_equal(bits32(h.spmv(F.MAT_P, x)), bits32(serial(Pcsr, x)))
+
+
+@pytest.mark.parametrize("dims", [[20] * 50, [1, 2, 3, 64, 65, 129, 1000]])
+def test_soc_projection_float32(dims):
+    rng = np.random.default_rng(7)
+    sets = [cj.SecondOrderCone(d) for d in dims]
+    h = _handle_for_sets(sets)
+    s = rng.standard_normal(sum(dims)).astype(F32)
+    off = 0
+    for i, d in enumerate(dims):                                  # all three branches (convexset.jl:100-114)
+        if i % 3 == 0: s[off] = abs(s[off]) + 10 * np.sqrt(d)
+        if i % 3 == 1: s[off] = -abs(s[off]) - 10 * np.sqrt(d)
+        off += d
+    ref = s.astype(np.float64); info = {}
+    O.project(ref, util.oracle_cones(sets), info)
+    out, _, br = h.project(s)
+    off = 0
+    for d in dims:
+        assert np.linalg.norm(out[off:off + d] - ref[off:off + d]) <= 8 * EPS32 * d * max(np.linalg.norm(s[off:off + d]), 1e-30)
+        off += d
+    assert [b for b in br if b >= 0] == info["soc_branch"]
+
+
+def sym_with_spectrum(rng, lam):
+    d = lam.size
+    Q = np.linalg.qr(rng.standard_normal((d, d)))[0]
+    X = (Q * lam) @ Q.T
+    return (X + X.T) / 2
+
+
+@pytest.mark.parametrize("kind", ["tri", "square"])
+@pytest.mark.parametrize("dims", [[2, 3, 5, 8, 9, 15, 16], [17, 24, 33, 64, 65, 100, 128, 129, 200, 256], [300, 520]],
+                         ids=["tiny_jacobi", "batched_sign", "large_sign"])
+def test_psd_projection_float32(dims, kind):
+    rng = np.random.default_rng(11)
+    mats, sets, npos = [], [], []
+    for d in dims:
+        k = int(rng.integers(0, d + 1))
+        lam = np.concatenate([rng.uniform(0.1, 2.0, k), -rng.uniform(0.1, 2.0, d - k)]); rng.shuffle(lam)
+        mats.append(sym_with_spectrum(rng, lam)); npos.append(k)
+        sets.append(cj.PsdConeTriangle(d * (d + 1) // 2) if kind == "tri" else cj.PsdCone(d * d))
+    h = _handle_for_sets(sets)
+    s = np.concatenate([cj.problems.svec(X) if kind == "tri" else X.reshape(-1, order="F") for X in mats]).astype(F32)
+    ref = s.astype(np.float64); info = {}
+    O.project(ref, util.oracle_cones(sets), info)                # LAPACK dsyevr on the Float32-rounded input
+    out, ranks, _ = h.project(s)
+    assert out.dtype == np.float32
+    off = 0
+    for K, X, rk, k in zip(sets, mats, ranks, npos):
+        d = X.shape[0]
+        err = np.linalg.norm(out[off:off + K.dim] - ref[off:off + K.dim])
+        assert err <= 64 * d * EPS32 * np.linalg.norm(X), (d, err / (d * EPS32 * np.linalg.norm(X)))   # SURVEY 8c with eps(Float32)
+        assert rk == k, (d, rk, k)                               # gapped spectrum: exact rank
+        if kind == "square":
+            A = out[off:off + K.dim].reshape(d, d, order="F")
+            assert np.array_equal(A, A.T)
+        off += K.dim
+
+
+@pytest.mark.parametrize("kkt", ["cg", "minres", "minres_reduced"])
+def test_kkt_solve_float32_vs_dense(kkt):
+    rng = np.random.default_rng(13)
+    prob = util.random_qp(rng, 120, 10, 40, 50, soc_dims=(6, 9), density=0.08, p_shift=0.5)
+    kk = {"cg": F.KKT_CG, "minres": F.KKT_MINRES, "minres_reduced": F.KKT_MINRES_REDUCED}[kkt]
+    n, m = prob["A"].shape[1], prob["A"].shape[0]
+    h = cj.Handle(0, dtype=F32)
+    h.set_problem(prob["P"], prob["q"], prob["A"], prob["b"])
+    bl = np.concatenate([K.l for K in prob["sets"] if K.kind == F.BOX]); bu = np.concatenate([K.u for K in prob["sets"] if K.kind == F.BOX])
+    h.set_cones([K.kind for K in prob["sets"]], [K.dim for K in prob["sets"]], bl, bu)
+    p = h.default_params(); p.kkt_kind = kk; p.tol_constant = 1e-6; p.tol_exponent = 0.0
+    h.set_params(p)
+    rho_dev = h.get_rho_vec()
+    cones = util.oracle_cones(prob["sets"]); ost = O.Settings()
+    O.classify_constraints(cones, prob["b"], ost)
+    rho = O.make_rho_vec(0.1, O.row_rho_class(cones), ost)
+    assert np.array_equal(rho_dev, rho.astype(F32)), (np.unique(rho_dev), np.unique(rho))       # rho classes / values (parameters.jl:3-49) in Float32
+    K = O.assemble_kkt_full(sp.csc_matrix(prob["P"].astype(F32).astype(np.float64)), sp.csc_matrix(prob["A"].astype(F32).astype(np.float64)), 1e-6, rho).toarray()
+    rhs = rng.standard_normal(n + m).astype(F32)
+    sol, its = h.kkt_solve(rhs)
+    ref = np.linalg.solve(K, rhs.astype(np.float64))
+    assert sol.dtype == np.float32 and its > 0
+    # reduced operator: cond ~ 5e3 -> 2e-3 (test/UnitTests/kktsolver.jl:97-109 asserts 1e-3 in Float64 at tolerance 1e-4); the full
+    # quasi-definite KKT matrix of MINRESIndirectKKTSolver has cond ~ 2e6 (rho from 1e-6 to 1e2), i.e. cond * eps(Float32) ~ 0.2
+    bound = 2e-2 if kkt == "minres" else 2e-3
+    assert np.linalg.norm(sol - ref) <= bound * np.linalg.norm(ref), np.linalg.norm(sol - ref) / np.linalg.norm(ref)
+
+
+def _solve32(P, q, cons_or_sets, A=None, b=None, **st):
+    md = cj.Model(dtype=F32)
+    settings = cj.Settings(kkt_solver=cj.CGIndirectKKTSolver, **st)
+    if A is None:
+        cj.assemble(md, P, q, cons_or_sets, settings=settings)
+    else:
+        md.set(P, q, A, b, cons_or_sets, settings)
+    r = cj.optimize(md)
+    assert md.handle.dtype == np.float32
+    return md, r
+
+
+def test_reference_goldens_in_float32():
+    # test/UnitTests/simple.jl:16-47 run with TestFloat = Float32, tol = 1e-3
+    A = np.array([[1.0, 1], [1, 0], [0, 1]]); l = np.array([1.0, 0, 0]); u = np.array([1.0, 0.7, 0.7])
+    cons = [cj.Constraint(-A, u, cj.Nonnegatives), cj.Constraint(A, -l, cj.Nonnegatives)]
+    md, r = _solve32(np.array([[4.0, 1], [1, 2]]), np.array([1.0, 1]), cons)
+    assert r.status == "Solved" and np.linalg.norm(r.x - [0.3, 0.7]) < 1e-3 and abs(r.obj_val - 1.88) < 1e-3
+    # test/UnitTests/qp-box.jl:16-31 (obj = -0.5), :50 primal infeasible, :87 dual infeasible
+    md, r = _solve32(np.eye(2), np.array([1.0, -1.0]), [cj.Constraint(np.array([[1.0, 0], [0, 1]]), np.zeros(2), cj.Box([0.0, 0.0], [1.0, 1.0]))])
+    assert r.status == "Solved" and abs(r.obj_val + 0.5) < 1e-3
+    md, r = _solve32(np.eye(2), np.array([1.0, -1.0]), [cj.Constraint(np.array([[1.0, 0], [1, 0]]), np.array([2.0, 0]), cj.Box([0.0, 0.0], [1.0, 1.0]))])
+    assert r.status == "Primal_infeasible"
+    md, r = _solve32(np.zeros((2, 2)), np.array([1.0, 1.0]), [cj.Constraint(np.eye(2), np.array([1.0, 1.0]), cj.Box([0.0, -np.inf], [1.0, 3.0]))])
+    assert r.status == "Dual_infeasible"
+
+
+@pytest.mark.parametrize("name", ["mixed_qp", "socp", "sdp_small_cliques", "closest_correlation"])
+def test_float32_solves_match_the_float64_oracle(name):
+    rng = np.random.default_rng(17)
+    if name == "mixed_qp":
+        prob = util.random_qp(rng, 200, 15, 80, 90, soc_dims=(5, 12), density=0.05, p_shift=0.5)
+    elif name == "socp":
+        prob = cj.problems.socp(n=120, m=240, ncones=12, nnz=2000, seed=3)
+    elif name == "sdp_small_cliques":          # operator split + assembled CG operator + batched sign path, all in Float32
+        prob = cj.problems.chordal_sdp(ncliques=8, dmin=4, dmax=40, sep_min=1, sep_max=3, n_total=900, n_zero=10, n_nonneg=30)
+    else:
+        prob = cj.problems.closest_correlation(d=30, seed=4)
+    st = dict(eps_abs=1e-4, eps_rel=1e-4, max_iter=4000)
+    md, r = _solve32(prob["P"], prob["q"], prob["sets"], A=prob["A"], b=prob["b"], **st)
+    ref = O.solve(prob["P"], prob["q"], prob["A"], prob["b"], util.oracle_cones(prob["sets"]), O.Settings(kkt_solver="cg", **st))
+    assert r.x.dtype == np.float32
+    assert r.status == ref.status == "Solved", (r.status, ref.status, r.iter, ref.iter)
+    assert abs(r.obj_val - ref.obj_val) <= 1e-3 * (1 + abs(ref.obj_val)), (r.obj_val, ref.obj_val)        # the reference's Float32 tolerance
+    assert np.linalg.norm(r.x - ref.x) <= 2e-2 * max(1.0, np.linalg.norm(ref.x))
+    if name == "sdp_small_cliques":
+        assert md.handle.fold_stats()["enabled"] == 1
+    if name == "closest_correlation":          # closestcorr.jl:74-76: unit diagonal, PSD
+        d = 30
+        X = cj.problems.smat(r.x)
+        assert np.max(np.abs(np.diag(X) - 1.0)) < 1e-3 and np.linalg.eigvalsh(X.astype(np.float64)).min() > -1e-3
+
+
+def test_float32_anderson_and_batch_paths_run():
+    """The accelerated loop and the batch kernels in Float32: reference goldens / statuses only."""
+    A = np.array([[1.0, 1], [1, 0], [0, 1]]); l = np.array([1.0, 0, 0]); u = np.array([1.0, 0.7, 0.7])
+    md = cj.Model(dtype=F32)
+    cj.assemble(md, np.array([[4.0, 1], [1, 2]]), np.array([1.0, 1]), [cj.Constraint(-A, u, cj.Nonnegatives), cj.Constraint(A, -l, cj.Nonnegatives)],
+                settings=cj.Settings(kkt_solver=cj.CGIndirectKKTSolver, accelerator=cj.AndersonAccelerator))
+    r = cj.optimize(md)
+    assert r.status == "Solved" and abs(r.obj_val - 1.88) < 1e-3
