@@ -14,7 +14,14 @@ module CosmoHIP
 using COSMO, SparseArrays, LinearAlgebra
 import COSMO: AbstractKKTSolver, solve!, update_rho!, free_memory!
 
+# Two builds of the SAME sources and the SAME symbol names (include/cosmo_hip.h: cosmo_hip_real): libcosmo_hip.so for
+# COSMO.Model{Float64}, libcosmo_hip_f32.so (-DCOSMO_HIP_REAL_FLOAT) for COSMO.Model{Float32} (src/types.jl:348).  Every data array
+# crosses the ABI as Ptr{T}; scalars (settings, residuals, times) are Cdouble in both.
 const LIB = Ref{String}(joinpath(@__DIR__, "..", "libcosmo_hip.so"))
+const LIB32 = Ref{String}(joinpath(@__DIR__, "..", "libcosmo_hip_f32.so"))
+const HipFloat = Union{Float32, Float64}
+libpath(::Type{Float64}) = LIB[]
+libpath(::Type{Float32}) = LIB32[]
 
 # ---- mirrors of the ABI structs: GENERATED from include/cosmo_hip.h by tools/gen_abi_structs.py (Params, AccelParams, ResultC, MAX_RHO_UPDATES)
 include("abi_structs.jl")
@@ -22,21 +29,24 @@ include("abi_structs.jl")
 const KKT_CG, KKT_MINRES_REDUCED, KKT_MINRES, KKT_CG_SR = Int32(0), Int32(1), Int32(2), Int32(3)   # KKT_CG_SR: opt-in single-reduction CG
 const STATUS = (:Undetermined, :Solved, :Max_iter_reached, :Unsolved, :Primal_infeasible, :Dual_infeasible, :Time_limit_reached)
 
-mutable struct Handle
+mutable struct Handle{T <: HipFloat}
     ptr::Ptr{Cvoid}
-    function Handle(device::Integer = 0)
+    function Handle{T}(device::Integer = 0) where {T <: HipFloat}
         ref = Ref{Ptr{Cvoid}}(C_NULL)
-        rc = ccall((:cosmo_hip_create, LIB[]), Int32, (Ref{Ptr{Cvoid}}, Int32), ref, device)
+        rc = ccall((:cosmo_hip_create, libpath(T)), Int32, (Ref{Ptr{Cvoid}}, Int32), ref, device)
         rc == 0 || error("cosmo_hip_create failed with code $rc (no MI355X visible?)")
-        h = new(ref[])
+        h = new{T}(ref[])
         finalizer(destroy!, h)      # free_memory! / GC both end here; cosmo_hip_destroy is idempotent
         return h
     end
 end
 
+Handle(device::Integer = 0) = Handle{Float64}(device)
+lib(::Handle{T}) where {T} = libpath(T)
+
 function destroy!(h::Handle)
     h.ptr == C_NULL && return
-    ccall((:cosmo_hip_destroy, LIB[]), Int32, (Ptr{Cvoid},), h.ptr)
+    ccall((:cosmo_hip_destroy, lib(h)), Int32, (Ptr{Cvoid},), h.ptr)
     h.ptr = C_NULL
     nothing
 end
@@ -44,7 +54,7 @@ end
 # the reference signals errors with exceptions (e.g. src/linear_solver/kktsolver.jl:304); so does the glue
 function check(h::Handle, rc::Int32)
     rc == 0 && return
-    msg = unsafe_string(ccall((:cosmo_hip_last_error, LIB[]), Cstring, (Ptr{Cvoid},), h.ptr))
+    msg = unsafe_string(ccall((:cosmo_hip_last_error, lib(h)), Cstring, (Ptr{Cvoid},), h.ptr))
     error("libcosmo_hip error $rc: $msg")
 end
 
@@ -59,8 +69,8 @@ cone_type(::COSMO.ExponentialCone) = Int32(6)
 cone_type(::COSMO.DualExponentialCone) = Int32(7)
 cone_type(::COSMO.PowerCone) = Int32(8)
 cone_type(::COSMO.DualPowerCone) = Int32(9)
-cone_param(s::COSMO.PowerCone) = Float64(s.α)
-cone_param(s::COSMO.DualPowerCone) = Float64(s.primal_cone.α)
+cone_param(s::COSMO.PowerCone) = s.α
+cone_param(s::COSMO.DualPowerCone) = s.primal_cone.α
 cone_param(s) = 0.0
 # any other subtype of AbstractConvexCone is a user-defined cone (docs/src/literate/custom_cone.jl): its own project! /
 # in_dual / in_pol_recc methods run on the host, called back by the library on this task's thread (COSMO_HIP_CUSTOM)
@@ -68,71 +78,71 @@ cone_type(::COSMO.AbstractConvexCone) = Int32(11)
 cone_type(C) = error("set type $(typeof(C)) is outside the MI355X hot path (SURVEY.md 8a)")
 
 # C-callable thunks of the three generic functions; `user` is a pointer to a Ref{Any} holding the cone object
-function _custom_project(x::Ptr{Cdouble}, dim::Int64, user::Ptr{Cvoid})::Cvoid
+function _custom_project(x::Ptr{T}, dim::Int64, user::Ptr{Cvoid})::Cvoid where {T <: HipFloat}
     cone = unsafe_pointer_to_objref(user)[]
     COSMO.project!(unsafe_wrap(Array, x, dim), cone)
     return
 end
-function _custom_in_dual(x::Ptr{Cdouble}, dim::Int64, tol::Cdouble, user::Ptr{Cvoid})::Int32
+function _custom_in_dual(x::Ptr{T}, dim::Int64, tol::Cdouble, user::Ptr{Cvoid})::Int32 where {T <: HipFloat}
     cone = unsafe_pointer_to_objref(user)[]
-    return Int32(COSMO.in_dual(unsafe_wrap(Array, x, dim), cone, tol))
+    return Int32(COSMO.in_dual(unsafe_wrap(Array, x, dim), cone, T(tol)))
 end
-function _custom_in_pol_recc(x::Ptr{Cdouble}, dim::Int64, tol::Cdouble, user::Ptr{Cvoid})::Int32
+function _custom_in_pol_recc(x::Ptr{T}, dim::Int64, tol::Cdouble, user::Ptr{Cvoid})::Int32 where {T <: HipFloat}
     cone = unsafe_pointer_to_objref(user)[]
-    return Int32(COSMO.in_pol_recc(unsafe_wrap(Array, x, dim), cone, tol))
+    return Int32(COSMO.in_pol_recc(unsafe_wrap(Array, x, dim), cone, T(tol)))
 end
 
 # install the callbacks of every user cone; the returned Refs must stay alive as long as the handle is used (GC.@preserve)
-function set_custom_cones!(h::Handle, C::COSMO.CompositeConvexSet{Float64})
+function set_custom_cones!(h::Handle{T}, C::COSMO.CompositeConvexSet{T}) where {T <: HipFloat}
     keep = Any[]
     for (k, s) in enumerate(C.sets)
         cone_type(s) == Int32(11) || continue
         r = Ref{Any}(s); push!(keep, r)
-        T = typeof(s)
-        fproj = @cfunction(_custom_project, Cvoid, (Ptr{Cdouble}, Int64, Ptr{Cvoid}))
-        fdual = hasmethod(COSMO.in_dual, Tuple{Vector{Float64}, T, Float64}) ? @cfunction(_custom_in_dual, Int32, (Ptr{Cdouble}, Int64, Cdouble, Ptr{Cvoid})) : C_NULL
-        frecc = hasmethod(COSMO.in_pol_recc, Tuple{Vector{Float64}, T, Float64}) ? @cfunction(_custom_in_pol_recc, Int32, (Ptr{Cdouble}, Int64, Cdouble, Ptr{Cvoid})) : C_NULL
-        check(h, ccall((:cosmo_hip_set_custom_cone, LIB[]), Int32, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+        S = typeof(s)
+        fproj = @cfunction(_custom_project, Cvoid, (Ptr{T}, Int64, Ptr{Cvoid}))
+        fdual = hasmethod(COSMO.in_dual, Tuple{Vector{T}, S, T}) ? @cfunction(_custom_in_dual, Int32, (Ptr{T}, Int64, Cdouble, Ptr{Cvoid})) : C_NULL
+        frecc = hasmethod(COSMO.in_pol_recc, Tuple{Vector{T}, S, T}) ? @cfunction(_custom_in_pol_recc, Int32, (Ptr{T}, Int64, Cdouble, Ptr{Cvoid})) : C_NULL
+        check(h, ccall((:cosmo_hip_set_custom_cone, lib(h)), Int32, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
             h.ptr, k - 1, fproj, fdual, frecc, pointer_from_objref(r)))
     end
     return keep
 end
 
-# cosmo_hip_set_problem takes SparseMatrixCSC{Float64,Int64} untouched: colptr / rowval are already 1-based Int64
-function set_problem!(h::Handle, P::SparseMatrixCSC{Float64, Int64}, A::SparseMatrixCSC{Float64, Int64}, q::Vector{Float64}, b::Vector{Float64})
+# cosmo_hip_set_problem takes SparseMatrixCSC{T,Int64} untouched: colptr / rowval are already 1-based Int64
+function set_problem!(h::Handle{T}, P::SparseMatrixCSC{T, Int64}, A::SparseMatrixCSC{T, Int64}, q::Vector{T}, b::Vector{T}) where {T <: HipFloat}
     m, n = size(A)
     GC.@preserve P A q b begin
-        check(h, ccall((:cosmo_hip_set_problem, LIB[]), Int32,
-            (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Int64}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+        check(h, ccall((:cosmo_hip_set_problem, lib(h)), Int32,
+            (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{T}, Ptr{Int64}, Ptr{Int64}, Ptr{T}, Ptr{T}, Ptr{T}),
             h.ptr, n, m, P.colptr, P.rowval, P.nzval, A.colptr, A.rowval, A.nzval, q, b))
     end
 end
 
-function set_cones!(h::Handle, C::COSMO.CompositeConvexSet{Float64})
+function set_cones!(h::Handle{T}, C::COSMO.CompositeConvexSet{T}) where {T <: HipFloat}
     types = Int32[cone_type(s) for s in C.sets]
     dims = Int64[s.dim for s in C.sets]
-    bl = Float64[]; bu = Float64[]
+    bl = T[]; bu = T[]
     for s in C.sets
         if s isa COSMO.Box
             append!(bl, s.l); append!(bu, s.u)          # already E-scaled by scale!(::Box) (src/convexset.jl:863-867)
         end
     end
-    params = Float64[cone_param(s) for s in C.sets]      # alpha of the power cones (src/convexset.jl:607-618)
+    params = T[cone_param(s) for s in C.sets]            # alpha of the power cones (src/convexset.jl:607-618)
     GC.@preserve types dims bl bu params begin
-        check(h, ccall((:cosmo_hip_set_cones_ex, LIB[]), Int32, (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+        check(h, ccall((:cosmo_hip_set_cones_ex, lib(h)), Int32, (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int64}, Ptr{T}, Ptr{T}, Ptr{T}),
             h.ptr, length(types), types, dims, isempty(bl) ? C_NULL : pointer(bl), isempty(bu) ? C_NULL : pointer(bu), params))
     end
 end
 
 # scale_ruiz! (src/scaling.jl:21-116) on the device-resident UNSCALED problem; fills ws.sm so that the unchanged
 # reverse_scaling! / update! keep working.  Call between set_cones! and set_params!.
-function scale_ruiz!(h::Handle, ws::COSMO.Workspace{Float64})
+function scale_ruiz!(h::Handle{T}, ws::COSMO.Workspace{T}) where {T <: HipFloat}
     s = ws.settings
     D = ws.sm.D.diag; E = ws.sm.E.diag; c = Ref{Cdouble}(1.0)
-    GC.@preserve D E check(h, ccall((:cosmo_hip_scale_ruiz, LIB[]), Int32, (Ptr{Cvoid}, Int64, Cdouble, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}),
+    GC.@preserve D E check(h, ccall((:cosmo_hip_scale_ruiz, lib(h)), Int32, (Ptr{Cvoid}, Int64, Cdouble, Cdouble, Ptr{T}, Ptr{T}, Ref{Cdouble}),
         h.ptr, s.scaling, s.MIN_SCALING, s.MAX_SCALING, D, E, c))
-    ws.sm.Dinv.diag .= 1.0 ./ D; ws.sm.Einv.diag .= 1.0 ./ E
-    ws.sm.c[] = c[]; ws.sm.cinv[] = 1.0 / c[]
+    ws.sm.Dinv.diag .= one(T) ./ D; ws.sm.Einv.diag .= one(T) ./ E
+    ws.sm.c[] = T(c[]); ws.sm.cinv[] = one(T) / T(c[])
     nothing
 end
 
@@ -140,10 +150,10 @@ end
 # settings.accelerator is an OptionsFactory{<:AbstractAccelerator} (src/settings.jl:96,136,148-150).  The device builds the
 # reference's default AndersonAccelerator{Float64, Type2{QRDecomp}, RestartedMemory, NoRegularizer}; EmptyAccelerator maps to
 # "none"; any other variant is rejected (error) rather than silently replaced.
-function set_accelerator!(h::Handle, settings::COSMO.Settings{Float64})
+function set_accelerator!(h::Handle{T}, settings::COSMO.Settings{T}) where {T <: HipFloat}
     AT = settings.accelerator.ObjectType
     AT <: COSMO.EmptyAccelerator && return nothing
-    AT == COSMO.AndersonAccelerator{Float64, COSMO.Type2{COSMO.QRDecomp}, COSMO.RestartedMemory, COSMO.NoRegularizer} ||
+    AT == COSMO.AndersonAccelerator{T, COSMO.Type2{COSMO.QRDecomp}, COSMO.RestartedMemory, COSMO.NoRegularizer} ||
         error("accelerator $(AT) is not built on the MI355X path; use the default Type2{QRDecomp}/RestartedMemory variant or EmptyAccelerator")
     kw = settings.accelerator.kwargs
     act = get(kw, :activation_reason, COSMO.ImmediateActivation())
@@ -151,11 +161,12 @@ function set_accelerator!(h::Handle, settings::COSMO.Settings{Float64})
     acc = act isa COSMO.AccuracyActivation ? Float64(act.start_accuracy) : -1.0    # src/accelerator_interface.jl:14-21
     p = AccelParams(Int32(1), Int32(get(kw, :mem, 10)), Int32(get(kw, :min_mem, 3)), Int32(settings.safeguard ? 1 : 0), Int64(start),
                     Float64(settings.safeguard_tol), 1e4, acc)
-    check(h, ccall((:cosmo_hip_set_accelerator, LIB[]), Int32, (Ptr{Cvoid}, Ref{AccelParams}), h.ptr, Ref(p)))
+    check(h, ccall((:cosmo_hip_set_accelerator, lib(h)), Int32, (Ptr{Cvoid}, Ref{AccelParams}), h.ptr, Ref(p)))
     nothing
 end
 
-function params_from(settings::COSMO.Settings{Float64}, kkt_kind::Int32; tol_constant = 1.0, tol_exponent = 1.5)
+# the settings struct of the ABI is Float64 in both libraries: a Float32 setting converts exactly (Params' constructor converts)
+function params_from(settings::COSMO.Settings{T}, kkt_kind::Int32; tol_constant = 1.0, tol_exponent = 1.5) where {T <: HipFloat}
     s = settings
     Params(s.sigma, s.alpha, s.rho, s.eps_abs, s.eps_rel, s.eps_prim_inf, s.eps_dual_inf, tol_constant, tol_exponent,
            s.RHO_MIN, s.RHO_MAX, s.RHO_TOL, s.RHO_EQ_OVER_RHO_INEQ, s.adaptive_rho_tolerance, s.COSMO_INFTY * s.MIN_SCALING,
@@ -163,9 +174,9 @@ function params_from(settings::COSMO.Settings{Float64}, kkt_kind::Int32; tol_con
            s.check_infeasibility, s.adaptive_rho ? 1 : 0, s.adaptive_rho_interval, s.scaling != 0 ? 1 : 0, s.obj_true, s.obj_true_tol)
 end
 
-function set_params!(h::Handle, p::Params, rho_vec::Union{Vector{Float64}, Nothing})
+function set_params!(h::Handle{T}, p::Params, rho_vec::Union{Vector{T}, Nothing}) where {T <: HipFloat}
     GC.@preserve rho_vec begin
-        check(h, ccall((:cosmo_hip_set_params, LIB[]), Int32, (Ptr{Cvoid}, Ref{Params}, Ptr{Cdouble}), h.ptr, Ref(p),
+        check(h, ccall((:cosmo_hip_set_params, lib(h)), Int32, (Ptr{Cvoid}, Ref{Params}, Ptr{T}), h.ptr, Ref(p),
             rho_vec === nothing ? C_NULL : pointer(rho_vec)))
     end
 end
@@ -175,35 +186,35 @@ end
 #       settings = COSMO.Settings(kkt_solver = with_options(CosmoHIP.HipCGKKTSolver, device = 0))
 #    The constructor receives the scaled P, A, sigma and ws.ρvec from _make_kkt_solver! (src/setup.jl:1-7).
 # ---------------------------------------------------------------------------------------------------------------------
-mutable struct HipKKTSolver <: AbstractKKTSolver
-    h::Handle
+mutable struct HipKKTSolver{T <: HipFloat} <: AbstractKKTSolver
+    h::Handle{T}
     m::Int; n::Int
-    function HipKKTSolver(P::SparseMatrixCSC{Float64, Int64}, A::SparseMatrixCSC{Float64, Int64}, sigma::Float64, rho;
-                          kind::Int32 = KKT_CG, device::Integer = 0, tol_constant = 1.0, tol_exponent = 1.5)
+    function HipKKTSolver(P::SparseMatrixCSC{T, Int64}, A::SparseMatrixCSC{T, Int64}, sigma::T, rho;
+                          kind::Int32 = KKT_CG, device::Integer = 0, tol_constant = 1.0, tol_exponent = 1.5) where {T <: HipFloat}
         m, n = size(A)
-        h = Handle(device)
-        set_problem!(h, P, A, zeros(n), zeros(m))          # q, b are not needed by solve!
+        h = Handle{T}(device)
+        set_problem!(h, P, A, zeros(T, n), zeros(T, m))    # q, b are not needed by solve!
         types = Int32[1]; dims = Int64[m]                    # cones are irrelevant for solve!: declare one Nonnegatives(m)
-        GC.@preserve types dims check(h, ccall((:cosmo_hip_set_cones, LIB[]), Int32,
-            (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Cdouble}), h.ptr, 1, types, dims, C_NULL, C_NULL))
-        p = params_from(COSMO.Settings{Float64}(sigma = sigma), kind; tol_constant = tol_constant, tol_exponent = tol_exponent)
-        rv = isa(rho, Number) ? fill(Float64(rho), m) : Vector{Float64}(rho)
+        GC.@preserve types dims check(h, ccall((:cosmo_hip_set_cones, lib(h)), Int32,
+            (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int64}, Ptr{T}, Ptr{T}), h.ptr, 1, types, dims, C_NULL, C_NULL))
+        p = params_from(COSMO.Settings{T}(sigma = sigma), kind; tol_constant = tol_constant, tol_exponent = tol_exponent)
+        rv = isa(rho, Number) ? fill(T(rho), m) : Vector{T}(rho)
         set_params!(h, p, rv)
-        new(h, m, n)
+        new{T}(h, m, n)
     end
 end
 HipCGKKTSolver(P, A, sigma, rho; kwargs...) = HipKKTSolver(P, A, sigma, rho; kind = KKT_CG, kwargs...)
 HipMINRESKKTSolver(P, A, sigma, rho; kwargs...) = HipKKTSolver(P, A, sigma, rho; kind = KKT_MINRES, kwargs...)
 
 # called from admm_x! (src/solver.jl:52): lhs = ws.sol, rhs = ws.ls, both length n+m and caller owned
-function solve!(S::HipKKTSolver, lhs::AbstractVector{Float64}, rhs::AbstractVector{Float64})
-    GC.@preserve lhs rhs check(S.h, ccall((:cosmo_hip_kkt_solve, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Int64}),
+function solve!(S::HipKKTSolver{T}, lhs::AbstractVector{T}, rhs::AbstractVector{T}) where {T <: HipFloat}
+    GC.@preserve lhs rhs check(S.h, ccall((:cosmo_hip_kkt_solve, lib(S.h)), Int32, (Ptr{Cvoid}, Ptr{T}, Ptr{T}, Ptr{Int64}),
         S.h.ptr, pointer(lhs), pointer(rhs), C_NULL))
     return lhs
 end
 # called from update_rho_vec! (src/parameters.jl:85-89)
-function update_rho!(S::HipKKTSolver, rho::Vector{Float64})
-    GC.@preserve rho check(S.h, ccall((:cosmo_hip_update_rho, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Cdouble}), S.h.ptr, rho))
+function update_rho!(S::HipKKTSolver{T}, rho::Vector{T}) where {T <: HipFloat}
+    GC.@preserve rho check(S.h, ccall((:cosmo_hip_update_rho, lib(S.h)), Int32, (Ptr{Cvoid}, Ptr{T}), S.h.ptr, rho))
 end
 # called from optimize! exit (src/solver.jl:200,206-208)
 free_memory!(S::HipKKTSolver) = destroy!(S.h)
@@ -214,25 +225,25 @@ free_memory!(S::HipKKTSolver) = destroy!(S.h)
 # diagnostics of the matrix-sign PSD path and of the opt-in single-launch CG (cosmo_hip_polar_stats / cosmo_hip_cg_persist_stats)
 function polar_stats(h::Handle)
     out = zeros(Int64, 16)
-    check(h, ccall((:cosmo_hip_polar_stats, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Int64}), h.ptr, out))
+    check(h, ccall((:cosmo_hip_polar_stats, lib(h)), Int32, (Ptr{Cvoid}, Ptr{Int64}), h.ptr, out))
     return (large_cones = out[1], batch_cones = out[2], tile_side = out[3], k_split = out[4], products_last_large = out[9], fallback_rounds = out[10],
             verified = out[11], products_last_batch = out[12], schedule_steps = out[13], unverified = out[14], projections = out[15], err_max = out[16] * 1e-18)
 end
 function cg_persist_stats(h::Handle)
     out = zeros(Int64, 8)
-    check(h, ccall((:cosmo_hip_cg_persist_stats, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Int64}), h.ptr, out))
+    check(h, ccall((:cosmo_hip_cg_persist_stats, lib(h)), Int32, (Ptr{Cvoid}, Ptr{Int64}), h.ptr, out))
     return (enabled = out[1] != 0, workgroups = out[2], launches = out[3], fallbacks = out[4])
 end
 
 function fold_stats(h::Handle)      # assembled reduced CG operator (cosmo_hip_fold_stats)
     out = zeros(Int64, 4)
-    check(h, ccall((:cosmo_hip_fold_stats, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Int64}), h.ptr, out))
+    check(h, ccall((:cosmo_hip_fold_stats, lib(h)), Int32, (Ptr{Cvoid}, Ptr{Int64}), h.ptr, out))
     return (enabled = out[1] != 0, nnz = out[2], terms = out[3], tiles = out[4])
 end
 
-function project_hip!(h::Handle, s::COSMO.SplitVector{Float64})
+function project_hip!(h::Handle{T}, s::COSMO.SplitVector{T}) where {T <: HipFloat}
     d = s.data
-    GC.@preserve d check(h, ccall((:cosmo_hip_project, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Int64}, Ptr{Int32}), h.ptr, d, C_NULL, C_NULL))
+    GC.@preserve d check(h, ccall((:cosmo_hip_project, lib(h)), Int32, (Ptr{Cvoid}, Ptr{T}, Ptr{Int64}, Ptr{Int32}), h.ptr, d, C_NULL, C_NULL))
     return nothing
 end
 
@@ -240,7 +251,7 @@ end
 # 3. the coarse path: COSMO.optimize! with the while-loop on the MI355X.  Everything outside src/solver.jl:128-176 is the
 #    reference's own code, called unchanged.
 # ---------------------------------------------------------------------------------------------------------------------
-function optimize_hip!(ws::COSMO.Workspace{Float64}; device::Integer = 0, kkt_kind::Int32 = KKT_CG, tol_constant = 1.0, tol_exponent = 1.5)
+function optimize_hip!(ws::COSMO.Workspace{T}; device::Integer = 0, kkt_kind::Int32 = KKT_CG, tol_constant = 1.0, tol_exponent = 1.5) where {T <: HipFloat}
     !ws.states.IS_ASSEMBLED && throw(ErrorException("The model has to be assembled! / set! before optimize!() can be called."))
     solver_time_start = time()
     settings = ws.settings
@@ -252,7 +263,7 @@ function optimize_hip!(ws::COSMO.Workspace{Float64}; device::Integer = 0, kkt_ki
         end
     end
     if !ws.states.IS_SCALED                                                   # :99-101
-        ws.sm = (settings.scaling > 0) ? COSMO.ScaleMatrices{Float64}(ws.p.model_size[1], ws.p.model_size[2]) : COSMO.ScaleMatrices{Float64}()
+        ws.sm = (settings.scaling > 0) ? COSMO.ScaleMatrices{T}(ws.p.model_size[1], ws.p.model_size[2]) : COSMO.ScaleMatrices{T}()
     end
     # setup! without the CPU KKT factorisation: scaling, row ranges, classification, rho vector (src/setup.jl:18-42)
     settings_nokkt = settings
@@ -268,31 +279,31 @@ function optimize_hip!(ws::COSMO.Workspace{Float64}; device::Integer = 0, kkt_ki
         !ws.states.IS_OPTIMIZED && COSMO.set_rho_vec!(ws)
     end
     m, n = ws.p.model_size
-    h = Handle(device)
+    h = Handle{T}(device)
     set_problem!(h, SparseMatrixCSC(ws.p.P), SparseMatrixCSC(ws.p.A), ws.p.q, Vector(ws.p.b))
     set_cones!(h, ws.p.C)
     custom_refs = set_custom_cones!(h, ws.p.C)                                 # user cones: callbacks into their project! methods
     set_params!(h, params_from(settings, kkt_kind; tol_constant = tol_constant, tol_exponent = tol_exponent), ws.ρvec)
     sc = settings.scaling != 0
-    D = sc ? ws.sm.D.diag : ones(n); Dinv = sc ? ws.sm.Dinv.diag : ones(n); E = sc ? ws.sm.E.diag : ones(m); Einv = sc ? ws.sm.Einv.diag : ones(m)
-    GC.@preserve D Dinv E Einv check(h, ccall((:cosmo_hip_set_scaling_full, LIB[]), Int32,
-        (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble), h.ptr, D, Dinv, E, Einv, ws.sm.c[], ws.sm.cinv[]))
+    D = sc ? ws.sm.D.diag : ones(T, n); Dinv = sc ? ws.sm.Dinv.diag : ones(T, n); E = sc ? ws.sm.E.diag : ones(T, m); Einv = sc ? ws.sm.Einv.diag : ones(T, m)
+    GC.@preserve D Dinv E Einv check(h, ccall((:cosmo_hip_set_scaling_full, lib(h)), Int32,
+        (Ptr{Cvoid}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Cdouble, Cdouble), h.ptr, D, Dinv, E, Einv, ws.sm.c[], ws.sm.cinv[]))
     set_accelerator!(h, settings)                                              # _make_accelerator! (src/setup.jl:10-16,44-49)
     x0 = ws.vars.x; s0 = ws.vars.s.data; mu0 = ws.vars.μ
-    GC.@preserve x0 s0 mu0 check(h, ccall((:cosmo_hip_set_iterates, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+    GC.@preserve x0 s0 mu0 check(h, ccall((:cosmo_hip_set_iterates, lib(h)), Int32, (Ptr{Cvoid}, Ptr{T}, Ptr{T}, Ptr{T}),
         h.ptr, x0, s0, mu0))                                                  # src/solver.jl:128-129
     ws.states.IS_OPTIMIZED = true
     res = Ref{ResultC}()
-    GC.@preserve custom_refs check(h, ccall((:cosmo_hip_optimize, LIB[]), Int32, (Ptr{Cvoid}, Ref{ResultC}), h.ptr, res))   # src/solver.jl:137-176
+    GC.@preserve custom_refs check(h, ccall((:cosmo_hip_optimize, lib(h)), Int32, (Ptr{Cvoid}, Ref{ResultC}), h.ptr, res))   # src/solver.jl:137-176
     r = res[]
     w = ws.vars.w; wp = ws.vars.w_prev; sd = ws.vars.s.data; mu = ws.vars.μ  # x is a view of w_prev (src/types.jl:274)
-    GC.@preserve w wp sd mu check(h, ccall((:cosmo_hip_get_iterates, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+    GC.@preserve w wp sd mu check(h, ccall((:cosmo_hip_get_iterates, lib(h)), Int32, (Ptr{Cvoid}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}),
         h.ptr, w, wp, sd, mu))
-    ws.ρ = r.rho
-    resize!(ws.rho_updates, 0); append!(ws.rho_updates, collect(r.rho_updates)[1:min(r.n_rho_updates, MAX_RHO_UPDATES)])
+    ws.ρ = T(r.rho)
+    resize!(ws.rho_updates, 0); append!(ws.rho_updates, T.(collect(r.rho_updates)[1:min(r.n_rho_updates, MAX_RHO_UPDATES)]))
     ws.times.iter_time = r.iter_time; ws.times.proj_time = r.proj_time
     status = STATUS[r.status + 1]
-    res_info = COSMO.ResultInfo(r.r_prim, r.r_dual, r.max_norm_prim, r.max_norm_dual, ws.rho_updates)
+    res_info = COSMO.ResultInfo(T(r.r_prim), T(r.r_dual), T(r.max_norm_prim), T(r.max_norm_dual), ws.rho_updates)
     settings.scaling != 0 && COSMO.reverse_scaling!(ws)                      # src/solver.jl:179-181
     if ws.ci.decompose                                                        # :184-190
         COSMO.reverse_decomposition!(ws, settings)
@@ -303,7 +314,7 @@ function optimize_hip!(ws::COSMO.Workspace{Float64}; device::Integer = 0, kkt_ki
     end
     ws.times.solver_time = time() - solver_time_start
     destroy!(h)
-    return COSMO.Result{Float64}(ws.vars.x, y, ws.vars.s.data, r.cost, Int(r.iter), 0, status, res_info, ws.times)
+    return COSMO.Result{T}(ws.vars.x, y, ws.vars.s.data, T(r.cost), Int(r.iter), 0, status, res_info, ws.times)
 end
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -313,8 +324,9 @@ end
 # Per problem the unchanged reference code does the scaling / classification (setup!, src/setup.jl:18-42) and the epilogue
 # (src/solver.jl:167-201); the loop of src/solver.jl:137-176 runs on the device for all problems at once.
 # ---------------------------------------------------------------------------------------------------------------------
-function optimize_hip_batch!(models::Vector{COSMO.Workspace{Float64}}; device::Integer = 0, tol_constant = 1.0, tol_exponent = 1.5)
-    isempty(models) && return COSMO.Result{Float64}[]
+function optimize_hip_batch!(models::Vector{COSMO.Workspace{T}}; device::Integer = 0, tol_constant = 1.0, tol_exponent = 1.5) where {T <: HipFloat}
+    isempty(models) && return COSMO.Result{T}[]
+    LIBT = libpath(T)
     ws1 = models[1]
     m, n = ws1.p.model_size
     settings = ws1.settings
@@ -323,7 +335,7 @@ function optimize_hip_batch!(models::Vector{COSMO.Workspace{Float64}}; device::I
         (ws.p.model_size == (m, n)) || error("optimize_hip_batch!: all problems must have the same dimensions")
         !(ws.accelerator isa COSMO.EmptyAccelerator) && error("optimize_hip_batch!: use accelerator = EmptyAccelerator")
         if !ws.states.IS_SCALED
-            ws.sm = (settings.scaling > 0) ? COSMO.ScaleMatrices{Float64}(m, n) : COSMO.ScaleMatrices{Float64}()
+            ws.sm = (settings.scaling > 0) ? COSMO.ScaleMatrices{T}(m, n) : COSMO.ScaleMatrices{T}()
         end
         COSMO.allocate_set_memory!(ws)
         if settings.scaling != 0 && !ws.states.IS_SCALED
@@ -334,16 +346,16 @@ function optimize_hip_batch!(models::Vector{COSMO.Workspace{Float64}}; device::I
         ws.row_ranges = COSMO.get_set_indices(ws.p.C.sets)
     end
     bptr = Ref{Ptr{Cvoid}}(C_NULL)
-    rc = ccall((:cosmo_hip_batch_create, LIB[]), Int32, (Ref{Ptr{Cvoid}}, Int32, Int64, Int64, Int64), bptr, device, length(models), n, m)
+    rc = ccall((:cosmo_hip_batch_create, LIBT), Int32, (Ref{Ptr{Cvoid}}, Int32, Int64, Int64, Int64), bptr, device, length(models), n, m)
     rc == 0 || error("cosmo_hip_batch_create failed (code $rc)")
     b = bptr[]
-    bcheck(rc) = rc == 0 || error(unsafe_string(ccall((:cosmo_hip_batch_last_error, LIB[]), Cstring, (Ptr{Cvoid},), b)))
+    bcheck(rc) = rc == 0 || error(unsafe_string(ccall((:cosmo_hip_batch_last_error, LIBT), Cstring, (Ptr{Cvoid},), b)))
     try
-        bl = Float64[]; bu = Float64[]
+        bl = T[]; bu = T[]
         for (k, ws) in enumerate(models)
             P = SparseMatrixCSC(ws.p.P); A = SparseMatrixCSC(ws.p.A); q = ws.p.q; bv = Vector(ws.p.b)
-            GC.@preserve P A q bv bcheck(ccall((:cosmo_hip_batch_set_problem, LIB[]), Int32,
-                (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Int64}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+            GC.@preserve P A q bv bcheck(ccall((:cosmo_hip_batch_set_problem, LIBT), Int32,
+                (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{T}, Ptr{Int64}, Ptr{Int64}, Ptr{T}, Ptr{T}, Ptr{T}),
                 b, k - 1, P.colptr, P.rowval, P.nzval, A.colptr, A.rowval, A.nzval, q, bv))
             for s in ws.p.C.sets
                 if s isa COSMO.Box
@@ -352,38 +364,38 @@ function optimize_hip_batch!(models::Vector{COSMO.Workspace{Float64}}; device::I
             end
             if settings.scaling != 0
                 Dinv = ws.sm.Dinv.diag; Einv = ws.sm.Einv.diag
-                GC.@preserve Dinv Einv bcheck(ccall((:cosmo_hip_batch_set_scaling, LIB[]), Int32, (Ptr{Cvoid}, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble),
+                GC.@preserve Dinv Einv bcheck(ccall((:cosmo_hip_batch_set_scaling, LIBT), Int32, (Ptr{Cvoid}, Int64, Ptr{T}, Ptr{T}, Cdouble),
                     b, k - 1, Dinv, Einv, ws.sm.cinv[]))
             end
         end
         types = Int32[cone_type(s) for s in ws1.p.C.sets]; dims = Int64[s.dim for s in ws1.p.C.sets]
-        GC.@preserve types dims bl bu bcheck(ccall((:cosmo_hip_batch_set_cones, LIB[]), Int32, (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Cdouble}),
+        GC.@preserve types dims bl bu bcheck(ccall((:cosmo_hip_batch_set_cones, LIBT), Int32, (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int64}, Ptr{T}, Ptr{T}),
             b, length(types), types, dims, isempty(bl) ? C_NULL : pointer(bl), isempty(bu) ? C_NULL : pointer(bu)))
         prm = Ref(params_from(settings, KKT_CG; tol_constant = tol_constant, tol_exponent = tol_exponent))
-        bcheck(ccall((:cosmo_hip_batch_set_params, LIB[]), Int32, (Ptr{Cvoid}, Ref{Params}), b, prm))   # classify_constraints! + set_rho_vec! per problem
+        bcheck(ccall((:cosmo_hip_batch_set_params, LIBT), Int32, (Ptr{Cvoid}, Ref{Params}), b, prm))   # classify_constraints! + set_rho_vec! per problem
         x0 = reduce(vcat, [ws.vars.x for ws in models]); s0 = reduce(vcat, [ws.vars.s.data for ws in models]); mu0 = reduce(vcat, [ws.vars.μ for ws in models])
-        GC.@preserve x0 s0 mu0 bcheck(ccall((:cosmo_hip_batch_set_iterates, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}), b, x0, s0, mu0))
+        GC.@preserve x0 s0 mu0 bcheck(ccall((:cosmo_hip_batch_set_iterates, LIBT), Int32, (Ptr{Cvoid}, Ptr{T}, Ptr{T}, Ptr{T}), b, x0, s0, mu0))
         results_c = Vector{ResultC}(undef, length(models))
-        bcheck(ccall((:cosmo_hip_batch_optimize, LIB[]), Int32, (Ptr{Cvoid}, Ptr{ResultC}), b, results_c))
-        out = COSMO.Result{Float64}[]
+        bcheck(ccall((:cosmo_hip_batch_optimize, LIBT), Int32, (Ptr{Cvoid}, Ptr{ResultC}), b, results_c))
+        out = COSMO.Result{T}[]
         for (k, ws) in enumerate(models)
             r = results_c[k]
             w = ws.vars.w; wp = ws.vars.w_prev; sd = ws.vars.s.data; mu = ws.vars.μ
-            GC.@preserve w wp sd mu bcheck(ccall((:cosmo_hip_batch_get_iterates, LIB[]), Int32, (Ptr{Cvoid}, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+            GC.@preserve w wp sd mu bcheck(ccall((:cosmo_hip_batch_get_iterates, LIBT), Int32, (Ptr{Cvoid}, Int64, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}),
                 b, k - 1, w, wp, sd, mu))
             ws.states.IS_OPTIMIZED = true
-            ws.ρ = r.rho
-            resize!(ws.rho_updates, 0); append!(ws.rho_updates, collect(r.rho_updates)[1:min(r.n_rho_updates, MAX_RHO_UPDATES)])
+            ws.ρ = T(r.rho)
+            resize!(ws.rho_updates, 0); append!(ws.rho_updates, T.(collect(r.rho_updates)[1:min(r.n_rho_updates, MAX_RHO_UPDATES)]))
             ws.times.iter_time = r.iter_time
-            res_info = COSMO.ResultInfo(r.r_prim, r.r_dual, r.max_norm_prim, r.max_norm_dual, ws.rho_updates)
+            res_info = COSMO.ResultInfo(T(r.r_prim), T(r.r_dual), T(r.max_norm_prim), T(r.max_norm_dual), ws.rho_updates)
             settings.scaling != 0 && COSMO.reverse_scaling!(ws)
             @. ws.utility_vars.vec_m = -ws.vars.μ
             ws.times.solver_time = time() - t_start
-            push!(out, COSMO.Result{Float64}(copy(ws.vars.x), copy(ws.utility_vars.vec_m), copy(ws.vars.s.data), r.cost, Int(r.iter), 0, STATUS[r.status + 1], res_info, ws.times))
+            push!(out, COSMO.Result{T}(copy(ws.vars.x), copy(ws.utility_vars.vec_m), copy(ws.vars.s.data), T(r.cost), Int(r.iter), 0, STATUS[r.status + 1], res_info, ws.times))
         end
         return out
     finally
-        ccall((:cosmo_hip_batch_destroy, LIB[]), Int32, (Ptr{Cvoid},), b)
+        ccall((:cosmo_hip_batch_destroy, LIBT), Int32, (Ptr{Cvoid},), b)
     end
 end
 
