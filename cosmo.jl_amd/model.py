@@ -774,7 +774,7 @@ def prepare_batch(models: Sequence[Model], device: int):
                       "they are DISABLED for this batch -- an infeasible problem runs to Max_iter_reached.  Solve suspect instances with "
                       "optimize(), which implements them.", RuntimeWarning, stacklevel=3)
         st = dataclasses.replace(st, check_infeasibility=0)
-    B = _ffi.Batch(len(models), n, m, device)
+    B = _ffi.Batch(len(models), n, m, device, dtype=getattr(models[0], "dtype", np.float64))
     bl, bu = [], []
     for k, md in enumerate(models):                      # setup! per problem (scaling on the host, as in the reference)
         if st.scaling != 0 and not md.is_scaled:
