@@ -30,31 +30,53 @@ typedef struct {
   double cost, r_prim, r_dual, max_norm_prim, max_norm_dual, rho, iter_time;
 } oc_result;
 
-typedef struct { int64_t nr, nc; const int64_t* p; const int64_t* i; const double* x; } csc;
+/* Element type of the loop: double (COSMO.Model{Float64}) by default, float with -DOC_FLOAT (the Float32 instantiation that checks
+ * libcosmo_hip_f32.so; every operation of the loop then rounds to Float32 as Julia's Float32 broadcasts do -- the file compiles
+ * without -Wdouble-promotion warnings).  Settings and result scalars stay double in both builds. */
+#ifdef OC_FLOAT
+typedef float oc_real;
+#define RSQRT(x) sqrtf(x)
+#define RFABS(x) fabsf(x)
+#define RFMAX(a, b) fmaxf((a), (b))
+#define RFMIN(a, b) fminf((a), (b))
+#define RPOW(a, b) powf((a), (b))
+#else
+typedef double oc_real;
+#define RSQRT(x) sqrt(x)
+#define RFABS(x) fabs(x)
+#define RFMAX(a, b) fmax((a), (b))
+#define RFMIN(a, b) fmin((a), (b))
+#define RPOW(a, b) pow((a), (b))
+#endif
+#define R(x) ((oc_real)(x))
+#define RINF ((oc_real)INFINITY)
 
-static void mul(const csc* M, const double* v, double* y) {          /* y = M v : column scatter (Julia mul!(y, A, x)) */
-  for (int64_t r = 0; r < M->nr; ++r) y[r] = 0.0;
-  for (int64_t j = 0; j < M->nc; ++j) { const double vj = v[j]; for (int64_t k = M->p[j]; k < M->p[j + 1]; ++k) y[M->i[k]] += M->x[k] * vj; }
+
+typedef struct { int64_t nr, nc; const int64_t* p; const int64_t* i; const oc_real* x; } csc;
+
+static void mul(const csc* M, const oc_real* v, oc_real* y) {          /* y = M v : column scatter (Julia mul!(y, A, x)) */
+  for (int64_t r = 0; r < M->nr; ++r) y[r] = R(0.0);
+  for (int64_t j = 0; j < M->nc; ++j) { const oc_real vj = v[j]; for (int64_t k = M->p[j]; k < M->p[j + 1]; ++k) y[M->i[k]] += M->x[k] * vj; }
 }
-static void mulT(const csc* M, const double* v, double* y) {         /* y = M' v : one dot per column (mul!(y, A', x)) */
-  for (int64_t j = 0; j < M->nc; ++j) { double s = 0.0; for (int64_t k = M->p[j]; k < M->p[j + 1]; ++k) s += M->x[k] * v[M->i[k]]; y[j] = s; }
+static void mulT(const csc* M, const oc_real* v, oc_real* y) {         /* y = M' v : one dot per column (mul!(y, A', x)) */
+  for (int64_t j = 0; j < M->nc; ++j) { oc_real s = R(0.0); for (int64_t k = M->p[j]; k < M->p[j + 1]; ++k) s += M->x[k] * v[M->i[k]]; y[j] = s; }
 }
-static double nrm2(const double* v, int64_t n) { double s = 0.0; for (int64_t i = 0; i < n; ++i) s += v[i] * v[i]; return sqrt(s); }
-static double dot(const double* a, const double* b, int64_t n) { double s = 0.0; for (int64_t i = 0; i < n; ++i) s += a[i] * b[i]; return s; }
-static double amax(double acc, double v) { const double a = fabs(v); return (a > acc || a != a) ? a : acc; }
+static oc_real nrm2(const oc_real* v, int64_t n) { oc_real s = R(0.0); for (int64_t i = 0; i < n; ++i) s += v[i] * v[i]; return RSQRT(s); }
+static oc_real dot(const oc_real* a, const oc_real* b, int64_t n) { oc_real s = R(0.0); for (int64_t i = 0; i < n; ++i) s += a[i] * b[i]; return s; }
+static oc_real amax(oc_real acc, oc_real v) { const oc_real a = RFABS(v); return (a > acc || a != a) ? a : acc; }
 
 typedef struct {
   int64_t n, m;
   csc P, A;
-  const double *q, *b, *Dinv, *Einv;
+  const oc_real *q, *b, *Dinv, *Einv;
   const int32_t* cls;          /* rho class per row: 0 inequality, 1 equality, 2 loose */
   const int32_t* kind;         /* per row: 0 free (unused), 1 zero, 2 nonneg, 3 box */
-  const double *bl, *bu;       /* per row (only read on box rows) */
-  double *rho, *tn, *tm, *tm2; /* work */
+  const oc_real *bl, *bu;       /* per row (only read on box rows) */
+  oc_real *rho, *tn, *tm, *tm2; /* work */
 } prob;
 
 /* reduced_mul! (kktsolver_indirect.jl:57-64): y = P x + sigma x + A'(rho .* (A x)) */
-static void reduced_mul(const prob* W, double sigma, const double* x, double* y, double* tmp_m, double* tmp_n) {
+static void reduced_mul(const prob* W, oc_real sigma, const oc_real* x, oc_real* y, oc_real* tmp_m, oc_real* tmp_n) {
   mul(&W->A, x, tmp_m);
   for (int64_t i = 0; i < W->m; ++i) tmp_m[i] *= W->rho[i];
   mulT(&W->A, tmp_m, tmp_n);
@@ -63,60 +85,63 @@ static void reduced_mul(const prob* W, double sigma, const double* x, double* y,
   for (int64_t j = 0; j < W->n; ++j) y[j] = tmp_n[j] + y[j];
 }
 
-static void make_rho(const prob* W, const oc_params* p, double rho) {   /* set_rho_vec! / update_rho_vec! (parameters.jl:3-13,75-92) */
+static void make_rho(const prob* W, const oc_params* p, oc_real rho) {   /* set_rho_vec! / update_rho_vec! (parameters.jl:3-13,75-92) */
   for (int64_t i = 0; i < W->m; ++i)
-    W->rho[i] = (W->cls[i] == 1) ? p->rho_eq_over_rho_ineq * rho : (W->cls[i] == 2 ? p->rho_min : rho);
+    W->rho[i] = (W->cls[i] == 1) ? R(p->rho_eq_over_rho_ineq) * rho : (W->cls[i] == 2 ? R(p->rho_min) : rho);
 }
 
-int32_t cosmo_oracle_c_run(int64_t n, int64_t m, const int64_t* Pp, const int64_t* Pi, const double* Px, const int64_t* Ap, const int64_t* Ai,
-                           const double* Ax, const double* q, const double* b, const double* Dinv, const double* Einv, const int32_t* cls,
-                           const int32_t* kind, const double* bl, const double* bu, const oc_params* prm, const double* rho_vec0,
-                           double* x_io, double* s_io, double* mu_io, double* rho_updates_out, int32_t rho_updates_cap, oc_result* res) {
+int32_t cosmo_oracle_c_run(int64_t n, int64_t m, const int64_t* Pp, const int64_t* Pi, const oc_real* Px, const int64_t* Ap, const int64_t* Ai,
+                           const oc_real* Ax, const oc_real* q, const oc_real* b, const oc_real* Dinv, const oc_real* Einv, const int32_t* cls,
+                           const int32_t* kind, const oc_real* bl, const oc_real* bu, const oc_params* prm, const oc_real* rho_vec0,
+                           oc_real* x_io, oc_real* s_io, oc_real* mu_io, oc_real* rho_updates_out, int32_t rho_updates_cap, oc_result* res) {
   prob W;
   W.n = n; W.m = m;
   W.P.nr = n; W.P.nc = n; W.P.p = Pp; W.P.i = Pi; W.P.x = Px;
   W.A.nr = m; W.A.nc = n; W.A.p = Ap; W.A.i = Ai; W.A.x = Ax;
   W.q = q; W.b = b; W.Dinv = Dinv; W.Einv = Einv; W.cls = cls; W.kind = kind; W.bl = bl; W.bu = bu;
   const oc_params p = *prm;
+  /* the settings are Float64 in the ABI; the loop computes with them in its element type (COSMO.Settings{T}) */
+  const oc_real p_sigma = R(p.sigma), p_alpha = R(p.alpha), p_rho = R(p.rho), p_eps_abs = R(p.eps_abs), p_eps_rel = R(p.eps_rel), p_tol_constant = R(p.tol_constant),
+                p_tol_exponent = R(p.tol_exponent), p_rho_min = R(p.rho_min), p_rho_max = R(p.rho_max), p_adaptive_rho_tolerance = R(p.adaptive_rho_tolerance), p_cinv = R(p.cinv);
   const int64_t N = n + m;
-  double* buf = (double*)calloc((size_t)(4 * N + 6 * m + 9 * n + 16), sizeof(double));
+  oc_real* buf = (oc_real*)calloc((size_t)(4 * N + 6 * m + 9 * n + 16), sizeof(oc_real));
   if (!buf) return 1;
-  double* w = buf; double* w_prev = w + N; double* ls = w_prev + N; double* sol = ls + N;
-  double* s = sol + N; double* mu = s + m; double* s_tl = mu + m; double* tmp_m = s_tl + m; double* y2 = tmp_m + m; W.rho = y2 + m;
-  double* prev = W.rho + m; double* tmp_n = prev + n; double* y1 = tmp_n + n; double* r = y1 + n; double* u = r + n; double* c = u + n;
-  double* rd = c + n; double* rt = rd + n; double* tn2 = rt + n;
-  memcpy(W.rho, rho_vec0, sizeof(double) * (size_t)m);
-  double rho = p.rho;
+  oc_real* w = buf; oc_real* w_prev = w + N; oc_real* ls = w_prev + N; oc_real* sol = ls + N;
+  oc_real* s = sol + N; oc_real* mu = s + m; oc_real* s_tl = mu + m; oc_real* tmp_m = s_tl + m; oc_real* y2 = tmp_m + m; W.rho = y2 + m;
+  oc_real* prev = W.rho + m; oc_real* tmp_n = prev + n; oc_real* y1 = tmp_n + n; oc_real* r = y1 + n; oc_real* u = r + n; oc_real* c = u + n;
+  oc_real* rd = c + n; oc_real* rt = rd + n; oc_real* tn2 = rt + n;
+  memcpy(W.rho, rho_vec0, sizeof(oc_real) * (size_t)m);
+  oc_real rho = p_rho;
   int n_rho = 1;
   if (rho_updates_out && rho_updates_cap > 0) rho_updates_out[0] = rho;
   int64_t iteration_counter = 1, cg_total = 0;
   for (int64_t j = 0; j < n; ++j) w[j] = x_io[j];                        /* solver.jl:128-129 */
-  for (int64_t i = 0; i < m; ++i) { w[n + i] = (1.0 / W.rho[i]) * mu_io[i] + s_io[i]; s[i] = s_io[i]; mu[i] = mu_io[i]; }
+  for (int64_t i = 0; i < m; ++i) { w[n + i] = (R(1.0) / W.rho[i]) * mu_io[i] + s_io[i]; s[i] = s_io[i]; mu[i] = mu_io[i]; }
   int status = 0;
-  double cost = INFINITY, r_prim = INFINITY, r_dual = INFINITY, mnp = 0.0, mnd = 0.0;
+  oc_real cost = RINF, r_prim = RINF, r_dual = RINF, mnp = R(0.0), mnd = R(0.0);
   struct timespec t0, t1;
   clock_gettime(CLOCK_MONOTONIC, &t0);
 
 #define SOLVE_AND_W()                                                                                                         \
   {                                                                                                                           \
-    for (int64_t j = 0; j < n; ++j) ls[j] = p.sigma * w[j] - q[j];                              /* solver.jl:50 */            \
-    for (int64_t i = 0; i < m; ++i) ls[n + i] = (b[i] - 2.0 * s[i]) + w[n + i];                 /* :51 */                     \
+    for (int64_t j = 0; j < n; ++j) ls[j] = p_sigma * w[j] - q[j];                              /* solver.jl:50 */            \
+    for (int64_t i = 0; i < m; ++i) ls[n + i] = (b[i] - R(2.0) * s[i]) + w[n + i];                 /* :51 */                     \
     for (int64_t i = 0; i < m; ++i) y2[i] = W.rho[i] * ls[n + i];                               /* kktsolver_indirect.jl:52 */\
     mulT(&W.A, y2, y1);                                                                                                       \
     for (int64_t j = 0; j < n; ++j) y1[j] = y1[j] + ls[j];                                                                    \
-    const double nb = nrm2(y1, n);                                                                                            \
-    const double tolk = p.tol_constant / pow((double)iteration_counter, p.tol_exponent);                                      \
-    const double abstol = nb > 0.0 ? tolk / nb : INFINITY;                                                                    \
+    const oc_real nb = nrm2(y1, n);                                                                                            \
+    const oc_real tolk = p_tol_constant / RPOW((oc_real)iteration_counter, p_tol_exponent);                                      \
+    const oc_real abstol = nb > R(0.0) ? tolk / nb : RINF;                                                                    \
     /* cg! v0.9: warm start from `prev`, maxiter = n */                                                                       \
-    reduced_mul(&W, p.sigma, prev, c, tmp_m, tmp_n);                                                                          \
-    for (int64_t j = 0; j < n; ++j) { r[j] = y1[j] - c[j]; u[j] = 0.0; }                                                      \
-    double residual = nrm2(r, n), prev_res = 1.0;                                                                             \
+    reduced_mul(&W, p_sigma, prev, c, tmp_m, tmp_n);                                                                          \
+    for (int64_t j = 0; j < n; ++j) { r[j] = y1[j] - c[j]; u[j] = R(0.0); }                                                      \
+    oc_real residual = nrm2(r, n), prev_res = R(1.0);                                                                             \
     int64_t it_cg = 0;                                                                                                        \
     while (it_cg < n && !(residual <= abstol)) {                                                                              \
-      const double beta = (residual * residual) / (prev_res * prev_res);                                                      \
+      const oc_real beta = (residual * residual) / (prev_res * prev_res);                                                      \
       for (int64_t j = 0; j < n; ++j) u[j] = r[j] + beta * u[j];                                                              \
-      reduced_mul(&W, p.sigma, u, c, tmp_m, tmp_n);                                                                           \
-      const double al = (residual * residual) / dot(u, c, n);                                                                 \
+      reduced_mul(&W, p_sigma, u, c, tmp_m, tmp_n);                                                                           \
+      const oc_real al = (residual * residual) / dot(u, c, n);                                                                 \
       for (int64_t j = 0; j < n; ++j) { prev[j] += al * u[j]; r[j] -= al * c[j]; }                                            \
       prev_res = residual; residual = nrm2(r, n); ++it_cg;                                                                    \
     }                                                                                                                         \
@@ -125,32 +150,32 @@ int32_t cosmo_oracle_c_run(int64_t n, int64_t m, const int64_t* Pp, const int64_
     mul(&W.A, prev, tmp_m);                                                                     /* :81-83 */                  \
     for (int64_t i = 0; i < m; ++i) sol[n + i] = (tmp_m[i] - ls[n + i]) * W.rho[i];                                           \
     iteration_counter += 1;                                                                                                   \
-    for (int64_t i = 0; i < m; ++i) s_tl[i] = (2.0 * s[i] - w[n + i]) - sol[n + i] / W.rho[i];  /* solver.jl:55 */            \
-    for (int64_t j = 0; j < n; ++j) w[j] = w[j] + p.alpha * (sol[j] - w[j]);                    /* :63 */                     \
-    for (int64_t i = 0; i < m; ++i) w[n + i] = w[n + i] + p.alpha * (s_tl[i] - s[i]);           /* :64 */                     \
+    for (int64_t i = 0; i < m; ++i) s_tl[i] = (R(2.0) * s[i] - w[n + i]) - sol[n + i] / W.rho[i];  /* solver.jl:55 */            \
+    for (int64_t j = 0; j < n; ++j) w[j] = w[j] + p_alpha * (sol[j] - w[j]);                    /* :63 */                     \
+    for (int64_t i = 0; i < m; ++i) w[n + i] = w[n + i] + p_alpha * (s_tl[i] - s[i]);           /* :64 */                     \
   }
 
   /* residuals of (x = w_prev[1:n], s, mu): calculate_result_info! (residuals.jl:30-93), optionally unscaled */
 #define RESIDUALS(UNSCALE)                                                                                                    \
   {                                                                                                                           \
-    const double* xx = w_prev;                                                                                                \
+    const oc_real* xx = w_prev;                                                                                                \
     mul(&W.A, xx, tmp_m);                                                                                                     \
-    double rp = 0.0, mp = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;                                                                  \
+    oc_real rp = R(0.0), mp = R(0.0), a1 = R(0.0), a2 = R(0.0), a3 = R(0.0);                                                                  \
     for (int64_t i = 0; i < m; ++i) {                                                                                         \
-      const double e = (UNSCALE) ? Einv[i] : 1.0;                                                                             \
+      const oc_real e = (UNSCALE) ? Einv[i] : R(1.0);                                                                             \
       rp = amax(rp, ((tmp_m[i] + s[i]) - b[i]) * e);                                                                          \
       a1 = amax(a1, tmp_m[i] * e); a2 = amax(a2, s[i] * e); a3 = amax(a3, b[i] * e);                                          \
     }                                                                                                                         \
-    mp = fmax(fmax(a1, a2), a3);                                                                                              \
+    mp = RFMAX(RFMAX(a1, a2), a3);                                                                                              \
     mul(&W.P, xx, rd); mulT(&W.A, mu, rt);                                                                                    \
-    double rdn = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;                                                                           \
-    const double ci = (UNSCALE) ? p.cinv : 1.0;                                                                               \
+    oc_real rdn = R(0.0), b1 = R(0.0), b2 = R(0.0), b3 = R(0.0);                                                                           \
+    const oc_real ci = (UNSCALE) ? p_cinv : R(1.0);                                                                               \
     for (int64_t j = 0; j < n; ++j) {                                                                                         \
-      const double dj = (UNSCALE) ? Dinv[j] : 1.0;                                                                            \
+      const oc_real dj = (UNSCALE) ? Dinv[j] : R(1.0);                                                                            \
       rdn = amax(rdn, (((rd[j] + q[j]) - rt[j]) * dj) * ci);                                                                  \
       b1 = amax(b1, (rd[j] * dj) * ci); b2 = amax(b2, (q[j] * dj) * ci); b3 = amax(b3, (rt[j] * dj) * ci);                    \
     }                                                                                                                         \
-    r_prim = rp; r_dual = rdn; mnp = mp; mnd = fmax(fmax(b1, b2), b3);                                                        \
+    r_prim = rp; r_dual = rdn; mnp = mp; mnd = RFMAX(RFMAX(b1, b2), b3);                                                        \
   }
 
   SOLVE_AND_W()                                                           /* init step (solver.jl:137-138) */
@@ -158,12 +183,12 @@ int32_t cosmo_oracle_c_run(int64_t n, int64_t m, const int64_t* Pp, const int64_
   int rho_update_due = 0;
   while (it < p.max_iter) {
     it += 1;
-    memcpy(w_prev, w, sizeof(double) * (size_t)N);                       /* :151 */
+    memcpy(w_prev, w, sizeof(oc_real) * (size_t)N);                       /* :151 */
     for (int64_t i = 0; i < m; ++i) {                                    /* admm_z! (:7-21) */
-      double v = w[n + i];
+      oc_real v = w[n + i];
       switch (kind[i]) {
-        case 1: v = 0.0; break;
-        case 2: v = (v != v) ? v : ((v > 0.0) ? v : 0.0); break;
+        case 1: v = R(0.0); break;
+        case 2: v = (v != v) ? v : ((v > R(0.0)) ? v : R(0.0)); break;
         case 3: v = (v < bl[i]) ? bl[i] : ((v > bu[i]) ? bu[i] : v); break;
         default: break;
       }
@@ -174,18 +199,18 @@ int32_t cosmo_oracle_c_run(int64_t n, int64_t m, const int64_t* Pp, const int64_
     if (rho_update_due) {                                                /* apply_rho_adaptation_rules! (:242-282) */
       rho_update_due = 0;
       for (int64_t i = 0; i < m; ++i) mu[i] = W.rho[i] * (w_prev[n + i] - s[i]);
-      double sr_p = r_prim, sr_d = r_dual, smp = mnp, smd = mnd;
+      oc_real sr_p = r_prim, sr_d = r_dual, smp = mnp, smd = mnd;
       RESIDUALS(0)
-      const double rp = r_prim / (mnp + 1e-10), rdd = r_dual / (mnd + 1e-10);
+      const oc_real rp = r_prim / (mnp + R(1e-10)), rdd = r_dual / (mnd + R(1e-10));
       r_prim = sr_p; r_dual = sr_d; mnp = smp; mnd = smd;
-      double new_rho = rho * sqrt(rp / (rdd + 1e-10));
-      new_rho = fmin(fmax(new_rho, p.rho_min), p.rho_max);
-      if (new_rho > p.adaptive_rho_tolerance * rho || new_rho < (1.0 / p.adaptive_rho_tolerance) * rho) {
+      oc_real new_rho = rho * RSQRT(rp / (rdd + R(1e-10)));
+      new_rho = RFMIN(RFMAX(new_rho, p_rho_min), p_rho_max);
+      if (new_rho > p_adaptive_rho_tolerance * rho || new_rho < (R(1.0) / p_adaptive_rho_tolerance) * rho) {
         rho = new_rho;
         make_rho(&W, &p, rho);
         if (rho_updates_out && n_rho < rho_updates_cap) rho_updates_out[n_rho] = rho;
         n_rho += 1;
-        for (int64_t i = 0; i < m; ++i) w[n + i] = (1.0 / W.rho[i]) * mu[i] + s[i];
+        for (int64_t i = 0; i < m; ++i) w[n + i] = (R(1.0) / W.rho[i]) * mu[i] + s[i];
       }
     }
     SOLVE_AND_W()
@@ -193,20 +218,20 @@ int32_t cosmo_oracle_c_run(int64_t n, int64_t m, const int64_t* Pp, const int64_
       for (int64_t i = 0; i < m; ++i) mu[i] = W.rho[i] * (w_prev[n + i] - s[i]);
       RESIDUALS(p.unscale)
       mul(&W.P, w_prev, tn2);
-      cost = p.cinv * (0.5 * dot(tn2, w_prev, n) + dot(q, w_prev, n));
-      if (fabs(cost) > 1e20) { status = 3; break; }
-      if (r_prim < p.eps_abs + p.eps_rel * mnp && r_dual < p.eps_abs + p.eps_rel * mnd) { status = 1; break; }
+      cost = p_cinv * (R(0.5) * dot(tn2, w_prev, n) + dot(q, w_prev, n));
+      if (RFABS(cost) > R(1e20)) { status = 3; break; }
+      if (r_prim < p_eps_abs + p_eps_rel * mnp && r_dual < p_eps_abs + p_eps_rel * mnd) { status = 1; break; }
     }
   }
   for (int64_t i = 0; i < m; ++i) mu[i] = W.rho[i] * (w_prev[n + i] - s[i]);    /* :167 */
   clock_gettime(CLOCK_MONOTONIC, &t1);
   if (it == p.max_iter) { RESIDUALS(p.unscale) status = 2; }                    /* :173-176 */
   for (int64_t j = 0; j < n; ++j) x_io[j] = w_prev[j];
-  memcpy(s_io, s, sizeof(double) * (size_t)m);
-  memcpy(mu_io, mu, sizeof(double) * (size_t)m);
+  memcpy(s_io, s, sizeof(oc_real) * (size_t)m);
+  memcpy(mu_io, mu, sizeof(oc_real) * (size_t)m);
   res->status = status; res->n_rho_updates = n_rho; res->iter = it; res->cg_iters_total = cg_total;
   res->cost = cost; res->r_prim = r_prim; res->r_dual = r_dual; res->max_norm_prim = mnp; res->max_norm_dual = mnd; res->rho = rho;
-  res->iter_time = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+  res->iter_time = (oc_real)(t1.tv_sec - t0.tv_sec) + R(1e-9) * (oc_real)(t1.tv_nsec - t0.tv_nsec);
   free(buf);
   return 0;
 }

@@ -28,10 +28,12 @@ class CResult(C.Structure):
 STATUS = {0: "Undetermined", 1: "Solved", 2: "Max_iter_reached", 3: "Unsolved"}
 
 
-def lib(native=False):
-    """native=True: the -march=native build (`make -C oracle native`), made by bench.py on the host whose cores it times."""
+def lib(native=False, f32=False):
+    """native=True: the -march=native build (`make -C oracle native`), made by bench.py on the host whose cores it times.
+    f32=True: the Float32 instantiation of the same file (-DOC_FLOAT), the checker of libcosmo_hip_f32.so."""
+    native = "f32" if f32 else native
     if native not in _LIB:
-        name = "libcosmo_oracle_c_native.so" if native else "libcosmo_oracle_c.so"
+        name = "libcosmo_oracle_c_f32.so" if f32 else ("libcosmo_oracle_c_native.so" if native else "libcosmo_oracle_c.so")
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", name)
         if not os.path.exists(path):
             raise RuntimeError("compiled oracle missing: run `make -C oracle%s` (or __graft_entry__.build())" % (" native" if native else ""))
@@ -45,12 +47,17 @@ def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
 
-def run(ws: "O.Workspace", native=False):
-    """Run the loop on a set-up NumPy-oracle workspace (not yet optimised).  Returns a dict with scaled and unscaled iterates."""
+def run(ws: "O.Workspace", native=False, dtype=np.float64):
+    """Run the loop on a set-up NumPy-oracle workspace (not yet optimised).  Returns a dict with scaled and unscaled iterates.
+    dtype=np.float32: the workspace's (Float64-scaled) data are rounded to Float32 and the loop runs in the Float32 build -- the same
+    arrays, rounded the same way, are what libcosmo_hip_f32.so receives in the Float32 parity tests."""
+    f32 = np.dtype(dtype) == np.float32
+    T = np.float32 if f32 else np.float64
+    CT = C.c_float if f32 else C.c_double
     st = ws.st
     assert st.kkt_solver.lower() == "cg" and ws.accelerator is None
     n, m = ws.n, ws.m
-    kind = np.zeros(m, np.int32); bl = np.zeros(m); bu = np.zeros(m)
+    kind = np.zeros(m, np.int32); bl = np.zeros(m, T); bu = np.zeros(m, T)
     off = 0
     for c in ws.cones:
         d = c.dim
@@ -64,24 +71,24 @@ def run(ws: "O.Workspace", native=False):
             raise ValueError("C oracle: unsupported cone kind %r" % (c.kind,))
         off += d
     P, A = ws.P, ws.A
-    Pp = P.indptr.astype(np.int64); Pi = P.indices.astype(np.int64); Px = np.ascontiguousarray(P.data, np.float64)
-    Ap = A.indptr.astype(np.int64); Ai = A.indices.astype(np.int64); Ax = np.ascontiguousarray(A.data, np.float64)
+    Pp = P.indptr.astype(np.int64); Pi = P.indices.astype(np.int64); Px = np.ascontiguousarray(P.data, T)
+    Ap = A.indptr.astype(np.int64); Ai = A.indices.astype(np.int64); Ax = np.ascontiguousarray(A.data, T)
     prm = Params(st.sigma, st.alpha, ws.rho, st.eps_abs, st.eps_rel, st.tol_constant, st.tol_exponent, st.RHO_MIN, st.RHO_MAX,
                  st.RHO_EQ_OVER_RHO_INEQ, st.adaptive_rho_tolerance, ws.sm.cinv, st.max_iter, st.adaptive_rho_max_adaptions,
                  st.check_termination, int(bool(st.adaptive_rho)), st.adaptive_rho_interval, int(st.scaling != 0))
-    x = ws.x.copy(); s = ws.s.copy(); mu = ws.mu.copy()
+    x = ws.x.astype(T); s = ws.s.astype(T); mu = ws.mu.astype(T)
     cap = 64
-    rho_updates = np.zeros(cap)
+    rho_updates = np.zeros(cap, T)
     res = CResult()
     cls = np.ascontiguousarray(ws.rho_class, np.int32)
-    q = np.ascontiguousarray(ws.q); b = np.ascontiguousarray(ws.b)
-    Dinv = np.ascontiguousarray(ws.sm.Dinv); Einv = np.ascontiguousarray(ws.sm.Einv)
-    rho0 = np.ascontiguousarray(ws.rho_vec, np.float64)
-    rc = lib(native).cosmo_oracle_c_run(C.c_int64(n), C.c_int64(m), _p(Pp, C.c_int64), _p(Pi, C.c_int64), _p(Px, C.c_double), _p(Ap, C.c_int64),
-                                  _p(Ai, C.c_int64), _p(Ax, C.c_double), _p(q, C.c_double), _p(b, C.c_double), _p(Dinv, C.c_double),
-                                  _p(Einv, C.c_double), _p(cls, C.c_int32), _p(kind, C.c_int32), _p(bl, C.c_double), _p(bu, C.c_double),
-                                  C.byref(prm), _p(rho0, C.c_double), _p(x, C.c_double), _p(s, C.c_double), _p(mu, C.c_double),
-                                  _p(rho_updates, C.c_double), C.c_int32(cap), C.byref(res))
+    q = np.ascontiguousarray(ws.q, T); b = np.ascontiguousarray(ws.b, T)
+    Dinv = np.ascontiguousarray(ws.sm.Dinv, T); Einv = np.ascontiguousarray(ws.sm.Einv, T)
+    rho0 = np.ascontiguousarray(ws.rho_vec, T)
+    rc = lib(native, f32).cosmo_oracle_c_run(C.c_int64(n), C.c_int64(m), _p(Pp, C.c_int64), _p(Pi, C.c_int64), _p(Px, CT), _p(Ap, C.c_int64),
+                                  _p(Ai, C.c_int64), _p(Ax, CT), _p(q, CT), _p(b, CT), _p(Dinv, CT),
+                                  _p(Einv, CT), _p(cls, C.c_int32), _p(kind, C.c_int32), _p(bl, CT), _p(bu, CT),
+                                  C.byref(prm), _p(rho0, CT), _p(x, CT), _p(s, CT), _p(mu, CT),
+                                  _p(rho_updates, CT), C.c_int32(cap), C.byref(res))
     if rc != 0:
         raise MemoryError("cosmo_oracle_c_run failed (%d)" % rc)
     out = dict(status=STATUS[res.status], iter=int(res.iter), cg_iters_total=int(res.cg_iters_total), obj_val=res.cost, r_prim=res.r_prim,

@@ -19,6 +19,7 @@ import scipy.sparse as sp
 
 import cosmo_jl_amd as cj
 from oracle import cosmo_oracle as O
+from oracle import cosmo_oracle_c as OC
 from tests import util
 
 pytestmark = pytest.mark.gpu
@@ -320,3 +321,31 @@ def test_float32_batch_of_socps():
     for r, ref in zip(rs, refs):
         assert r.status == ref.status == "Solved"
         assert abs(r.obj_val - ref.obj_val) <= 1e-3 * (1 + abs(ref.obj_val))
+
+
+@pytest.mark.parametrize("iters", [1, 30])
+def test_float32_loop_against_the_float32_instantiation_of_the_c_oracle(iters):
+    """Loop-level parity IN Float32: oracle/cosmo_oracle_c.c compiled with -DOC_FLOAT (every operation rounds to float, checked with
+    -Werror=double-promotion) runs src/solver.jl:137-176 on the same Float32-rounded scaled problem as libcosmo_hip_f32.so.  The two
+    differ only where Float64 parity also allows it -- the order of the SpMV row sums (CSC scatter vs left-to-right rows) and of the
+    reductions -- so after ONE iteration with a tight CG the iterates agree to eps32 * cond (3e-5), and over 30 iterations the gap stays at
+    the 2e-4 level; Krylov iteration counts, rho updates and residual scalars follow."""
+    rng = np.random.default_rng(29)
+    prob = util.random_qp(rng, 160, 12, 70, 80, density=0.06, p_shift=0.5)
+    st = O.Settings(scaling=10, kkt_solver="cg", tol_constant=1e-5, tol_exponent=0.0, max_iter=iters, eps_abs=0.0, eps_rel=0.0, check_infeasibility=10 ** 9)
+    ws = O.Workspace(prob["P"], prob["q"], prob["A"], prob["b"], util.oracle_cones(prob["sets"]), st)
+    h = util.make_handle_from_workspace(ws, dtype=F32)
+    h.set_iterates(None, None, None)
+    ref = OC.run(ws, dtype=F32)
+    r = h.optimize()
+    w, w_prev, s, mu = h.get_iterates()
+    assert w.dtype == np.float32 and r.iter == ref["iter"] == iters
+    x_ref, s_ref = ref["x_scaled"], ref["s_scaled"]
+    n = ws.n
+    tol = 1e-4 if iters == 1 else 5e-4           # measured 3e-5 / 2e-4: eps32 * cond(reduced operator ~ 5e3) per solve, not accumulating
+    assert np.max(np.abs(w_prev[:n] - x_ref)) <= tol * max(1.0, float(np.max(np.abs(x_ref)))), np.max(np.abs(w_prev[:n] - x_ref))
+    assert np.max(np.abs(s - s_ref)) <= tol * max(1.0, float(np.max(np.abs(s_ref))))
+    assert abs(r.kkt_iters_total - ref["cg_iters_total"]) <= 0.05 * ref["cg_iters_total"] + 2 * (iters + 1)
+    assert r.n_rho_updates == len(ref["rho_updates"])
+    # residual scalars: differences of O(1..10) quantities that cancel to ~1e-3 -- in Float32 their last two digits are rounding noise
+    assert abs(r.r_prim - ref["r_prim"]) <= 0.3 * max(ref["r_prim"], 1e-6) + 1e-4 and abs(r.r_dual - ref["r_dual"]) <= 0.3 * max(ref["r_dual"], 1e-6) + 1e-4

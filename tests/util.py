@@ -42,9 +42,10 @@ def oracle_settings(**kw):
     return O.Settings(**kw)
 
 
-def make_handle_from_workspace(ws: O.Workspace, kkt_kind=cj._ffi.KKT_CG, **param_overrides):
-    """Feeds the oracle's ALREADY SCALED problem (what Julia's setup! would hand over) to the device library."""
-    h = cj.Handle(0)
+def make_handle_from_workspace(ws: O.Workspace, kkt_kind=cj._ffi.KKT_CG, dtype=np.float64, **param_overrides):
+    """Feeds the oracle's ALREADY SCALED problem (what Julia's setup! would hand over) to the device library (dtype float32: rounded
+    to Float32 at the boundary, libcosmo_hip_f32.so)."""
+    h = cj.Handle(0, dtype=dtype)
     h.set_problem(ws.P, ws.q, ws.A, ws.b)
     bl = np.concatenate([c.l for c in ws.cones if c.kind == O.BOX] or [np.zeros(0)])
     bu = np.concatenate([c.u for c in ws.cones if c.kind == O.BOX] or [np.zeros(0)])
