@@ -23,16 +23,6 @@
 
 #define PARTS(h, slot) ((h)->partials + (size_t)(slot) * COSMO_MAX_PARTIALS)
 
-struct FoldPlan {
-  int slots = 8;            // nonzero slots per thread of k_cg_dirM (tile <= slots * 256)
-  CsrDev M;                 // n x n; M.val is rewritten by k_fold_refresh
-  real* base = nullptr;   // nnz(M): P_ij (0 where P has no entry)
-  int* drow = nullptr;      // nnz(M): row index for diagonal entries, -1 otherwise
-  int* tptr = nullptr;      // nnz(M)+1: terms of entry p are [tptr[p], tptr[p+1])
-  int* trow = nullptr;      // term -> row of Am
-  real* tprod = nullptr;  // term -> a_ki * a_kj
-  long long nterms = 0;
-};
 
 // launch helpers of kernels.hip (every launch stays next to its kernel)
 int32_t launch_cg_upd(cosmo_hip_handle* h, int guard, int k, int n_uc);
@@ -83,7 +73,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_fold_start(Ctl* __restrict__ ctl, 
     csr_stream_tile(M, x, x, k, lds, red, [&](int row, real s1, real s2) {
       const real rj = rhs[row] - (s1 + s2);
       r[row] = rj;
-      ru[row] = make_real2(rj, 0.0);
+      if (ru) ru[row] = make_real2(rj, R(0.0));
       acc += rj * rj;
     });
   }
@@ -214,7 +204,7 @@ int32_t fold_build(cosmo_hip_handle* h, const HostCsr& Am, const std::vector<int
                    const std::vector<real>& pval) {
   fold_free(h);
   if (const char* e = getenv("COSMO_HIP_OP_FOLD")) if (e[0] == '0') return COSMO_HIP_OK;
-  if (!h->op_split || h->cg_sr || h->n <= 0 || !h->cg_ru) return COSMO_HIP_OK;
+  if (!h->op_split || h->n <= 0 || (!h->cg_sr && !h->cg_ru)) return COSMO_HIP_OK;     // literal CG: needs the {r, u} records; single-reduction CG: its own records
   if (const char* e = getenv("COSMO_HIP_CG_PERSIST")) if (atoi(e)) return COSMO_HIP_OK;     // the single-launch lab path keeps the split operator
   const long long n = h->n;
   const int mm = Am.nrows;

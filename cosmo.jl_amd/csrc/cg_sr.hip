@@ -18,7 +18,8 @@
 // within 3 %, ADMM trajectories within 1e-7 of the literal solver; measured 1e-13).  The bench states which solver ran.
 // Measured (profiles/r02_cg_variants.md): BASELINE config 5 (split operator, latency-bound launches) 43.5 vs 49.1 us per Krylov
 // iteration (-11 %); config 2 (gather-bound) 44.7 vs 41.6 us (+7 %: the 32-byte record gather of launch 1 costs more than the launch
-// it saves) -- hence opt-in, and the literal recurrence stays the default everywhere.
+// it saves) -- hence opt-in, and the literal recurrence stays the default everywhere.  On the ASSEMBLED operator of cg_fold.hip the
+// whole iteration is ONE launch (k_sr_M below): config 5 146.7 (literal, two launches) -> 158.2 it/s (profiles/r02_cfg5_cg_variants.json).
 #include "device_utils.h"
 
 struct SrRec { real r, w, s, p; };   // 32 bytes, one per variable
@@ -129,6 +130,78 @@ __global__ __launch_bounds__(COSMO_BS) void k_sr_A_plain(const Ctl* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The same recurrence on the ASSEMBLED operator M (cg_fold.hip): ONE launch per Krylov iteration.  The workgroup that owns the rows
+// of a tile also owns those elements of the vectors: it folds the gamma / delta partials, applies the stopping rule, and for each of
+// its rows updates {p, s, x, r} from the row's old record, computes w_new = (M r_new)_row with r_new REBUILT at the gathered columns
+// (r_j - alpha (w_j + beta s_j): 24 bytes of the column's old record), writes the new record and the partials of r'r and w'r of
+// the NEXT iteration.  Records and partial slots alternate by iteration parity (owners write new ones while others gather old ones).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(COSMO_BS) void k_sr_M(Ctl* __restrict__ ctl, int guard, int k, int check_only, long long maxiter,
+                                                   const real* __restrict__ part_g_in, const real* __restrict__ part_d_in, int n_parts,
+                                                   real* __restrict__ part_g_out, real* __restrict__ part_d_out, CsrView M,
+                                                   const SrRec* __restrict__ old_rec, SrRec* __restrict__ new_rec, real* __restrict__ x) {
+  const real pg = partials_prefetch_sum(part_g_in, n_parts);
+  const real pd = partials_prefetch_sum(part_d_in, n_parts);
+  if (guard && ctl->halt) return;
+  if (ctl->cg_done) return;
+  __shared__ real lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ real red[COSMO_BS / 64];
+  SrScalars sc;
+  if (check_only) {
+    const real g = block_sum(pg, red);
+    const real res = sqrt(g);
+    if (threadIdx.x == 0 && ((k >= maxiter) || (res <= ctl->tol))) { ctl->cg_done = 1; ctl->resv[k & 1] = res; }
+    return;
+  }
+  if (!sr_scalars(ctl, k, maxiter, pg, pd, red, sc)) return;
+  const real alpha = sc.alpha, beta = sc.beta;
+  real accg = R(0.0), accd = R(0.0);
+  const int first_tile = tile_of_block(blockIdx.x, M.nb, M.xcd_affine);
+  for (int t = first_tile; t < M.nb; t += gridDim.x) {
+    const int4 d = reinterpret_cast<const int4*>(M.rb)[t];
+    csr_stream_rows_g(M, [&](int c) { const SrRec v = old_rec[c]; return v.r - alpha * (v.w + beta * v.s); }, d.x, d.y, d.z, d.w, lds, red,
+                      [&](int row, real s1, real s2) {
+                        const SrRec v = old_rec[row];
+                        const real p = v.r + beta * v.p;
+                        const real s = v.w + beta * v.s;
+                        x[row] = x[row] + alpha * p;
+                        const real rn = v.r - alpha * s;
+                        const real wn = s1 + s2;
+                        SrRec o; o.r = rn; o.w = wn; o.s = s; o.p = p;
+                        new_rec[row] = o;
+                        accg += rn * rn;
+                        accd += wn * rn;
+                      });
+  }
+  accg = block_sum(accg, red);
+  accd = block_sum(accd, red);
+  if (threadIdx.x == 0) {
+    const int slot = M.xcd_affine ? first_tile : (int)blockIdx.x;
+    part_g_out[slot] = accg; part_d_out[slot] = accd;
+  }
+}
+
+// solve start on the assembled operator: records {r0, w0 = M r0, 0, 0}, partials of w0'r0 (r0 and its r'r partials come from k_fold_start)
+__global__ __launch_bounds__(COSMO_BS) void k_sr_M_init(const Ctl* __restrict__ ctl, int guard, CsrView M, const real* __restrict__ r0,
+                                                        SrRec* __restrict__ rec, real* __restrict__ part_d) {
+  if (guard && ctl->halt) return;
+  __shared__ real lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ real red[COSMO_BS / 64];
+  real acc = R(0.0);
+  const int first_tile = tile_of_block(blockIdx.x, M.nb, M.xcd_affine);
+  for (int t = first_tile; t < M.nb; t += gridDim.x) {
+    csr_stream_tile(M, r0, r0, t, lds, red, [&](int row, real s1, real s2) {
+      const real rj = r0[row], wj = s1 + s2;
+      SrRec o; o.r = rj; o.w = wj; o.s = R(0.0); o.p = R(0.0);
+      rec[row] = o;
+      acc += wj * rj;
+    });
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) part_d[M.xcd_affine ? first_tile : (int)blockIdx.x] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 int32_t sr_alloc(cosmo_hip_handle* h) {
   if (h->sr_rec) { (void)hipFree(h->sr_rec); h->sr_rec = nullptr; }
   if (!h->cg_sr) return COSMO_HIP_OK;
@@ -147,6 +220,16 @@ static inline int sr_grid1(const cosmo_hip_handle* h, const CsrDev& Ao) {
 
 // after enqueue_cg_start (r0 = rhs - L x0 in h->r, its r'r partials in SLOT_RR, tolerance set): w0 = L r0, records, w0'r0 partials
 int32_t sr_enqueue_start(cosmo_hip_handle* h, int guard) {
+  if (h->op_fold) {                     // assembled operator: one product (k_fold_start left r0 in h->r, its r'r partials in SLOT_RR)
+    FoldPlan* f = (FoldPlan*)h->fold;
+    prof_begin(h, KC_OP_APPLY);
+    hipLaunchKernelGGL(k_sr_M_init, dim3(f->M.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, view_of(f->M), (const real*)h->r, (SrRec*)h->sr_rec,
+                       PARTS(h, SLOT_UC));
+    prof_end(h);
+    h->spmv_calls[0] += 1; h->spmv_calls[1] += 1; h->spmv_calls[2] += 1;
+    HIPCHK(h, hipGetLastError());
+    return COSMO_HIP_OK;
+  }
   const CsrDev& Ao = h->op_split ? h->Am : h->A;
   const CsrDev& PTo = h->op_split ? h->PTm : h->PT;
   const real* rho_o = h->op_split ? h->op_rho_m : h->rho;
@@ -166,6 +249,27 @@ int32_t sr_enqueue_start(cosmo_hip_handle* h, int guard) {
 
 int32_t sr_enqueue_iterations(cosmo_hip_handle* h, int guard, int k_begin, int count) {
   const long long n = h->n;
+  if (h->op_fold) {                     // ONE launch per Krylov iteration on the assembled operator
+    FoldPlan* f = (FoldPlan*)h->fold;
+    SrRec* rec = (SrRec*)h->sr_rec;
+    const int G = f->M.grid;
+    auto gs = [&](int k) { return (k & 1) ? PARTS(h, SLOT_AUX0) : PARTS(h, SLOT_RR); };     // r'r partials by iteration parity
+    auto ds = [&](int k) { return (k & 1) ? PARTS(h, SLOT_AUX1) : PARTS(h, SLOT_UC); };     // w'r partials
+    for (int k = k_begin; k < k_begin + count; ++k) {
+      prof_begin(h, KC_OP_APPLY);
+      hipLaunchKernelGGL(k_sr_M, dim3(G), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, k, 0, n, gs(k), ds(k), G, gs(k + 1), ds(k + 1), view_of(f->M),
+                         rec + (size_t)(k & 1) * n, rec + (size_t)((k + 1) & 1) * n, h->x_tl);
+      prof_end(h);
+      h->spmv_calls[0] += 1; h->spmv_calls[1] += 1; h->spmv_calls[2] += 1;
+    }
+    const int kk = k_begin + count;
+    prof_begin(h, KC_CG_DIR);
+    hipLaunchKernelGGL(k_sr_M, dim3(1), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, kk, 1, n, gs(kk), ds(kk), G, gs(kk + 1), ds(kk + 1), view_of(f->M), rec, rec,
+                       h->x_tl);
+    prof_end(h);
+    HIPCHK(h, hipGetLastError());
+    return COSMO_HIP_OK;
+  }
   const CsrDev& Ao = h->op_split ? h->Am : h->A;
   const CsrDev& PTo = h->op_split ? h->PTm : h->PT;
   const real* rho_o = h->op_split ? h->op_rho_m : h->rho;

@@ -84,6 +84,18 @@ struct CsrDev {
   int xcd_affine = 0;     // XCD-affine tile order in the one-tile-per-workgroup kernels (device_utils.h: tile_of_block)
 };
 
+// assembled reduced operator of the CG solve (cg_fold.hip; also applied by the single-reduction CG of cg_sr.hip)
+struct FoldPlan {
+  int slots = 8;            // nonzero slots per thread of k_cg_dirM (tile <= slots * 256)
+  CsrDev M;                 // n x n; M.val is rewritten by k_fold_refresh
+  real* base = nullptr;   // nnz(M): P_ij (0 where P has no entry)
+  int* drow = nullptr;      // nnz(M): row index for diagonal entries, -1 otherwise
+  int* tptr = nullptr;      // nnz(M)+1: terms of entry p are [tptr[p], tptr[p+1])
+  int* trow = nullptr;      // term -> row of Am
+  real* tprod = nullptr;  // term -> a_ki * a_kj
+  long long nterms = 0;
+};
+
 struct HostCsr {  // host staging of a CSR matrix (0-based)
   int nrows = 0, ncols = 0;
   std::vector<int> rowptr, col;

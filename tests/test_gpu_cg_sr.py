@@ -18,6 +18,15 @@ PROBLEMS = {
 }
 
 
+@pytest.fixture(params=["assembled_operator", "split_operator"], autouse=True)
+def operator_form(request, monkeypatch):
+    """Both forms of the reduced operator under the single-reduction recurrence: M assembled as one matrix (csrc/cg_fold.hip: ONE launch
+    per Krylov iteration, k_sr_M) where the problem qualifies, and the split / plain operator (two launches).  The literal solver it is
+    compared with uses the same form."""
+    monkeypatch.setenv("COSMO_HIP_OP_FOLD", "1" if request.param == "assembled_operator" else "0")
+    return request.param
+
+
 def _run(prob, kkt, iters, tight=True):
     kw = dict(tol_constant=1e-10, tol_exponent=0.0) if tight else {}
     st = cj.Settings(kkt_solver=cj.with_options(kkt, **kw), max_iter=iters, eps_abs=0.0, eps_rel=0.0, check_infeasibility=10 ** 9)
@@ -51,12 +60,13 @@ def test_kkt_solve_matches_the_dense_solve_and_the_literal_cg(name):
 
 
 @pytest.mark.parametrize("name", sorted(PROBLEMS))
-def test_admm_trajectory_matches_the_literal_cg_in_tight_mode(name):
+def test_admm_trajectory_matches_the_literal_cg_in_tight_mode(name, operator_form):
     prob = PROBLEMS[name]()
     # 60 iterations: before these small problems converge to rounding level, where the adaptive-rho decision (a ratio of residuals
     # of size 1e-12) is noise for ANY two solvers and y = -rho .* (w - s) follows it (measured: x, s still agree to 1e-14 at 200)
-    r_sr, _ = _run(prob, cj.CGSingleReductionKKTSolver, 60)
+    r_sr, md_sr = _run(prob, cj.CGSingleReductionKKTSolver, 60)
     r_cg, _ = _run(prob, cj.CGIndirectKKTSolver, 60)
+    assert md_sr.handle.fold_stats()["enabled"] == (1 if (operator_form == "assembled_operator" and name == "chordal_sdp_split_operator") else 0)
     assert r_sr.iter == r_cg.iter == 60
     for a, b in ((r_sr.x, r_cg.x), (r_sr.s, r_cg.s), (r_sr.y, r_cg.y)):
         assert np.max(np.abs(a - b)) <= 1e-7 * max(1.0, float(np.max(np.abs(b))))                   # SURVEY 8c trajectory tolerance
