@@ -84,6 +84,7 @@ struct PolarPlan {
   real* nrm = nullptr;     // per cone ||X||_F
   int k_lift = 10;           // lifting steps of the main schedule (COSMO_HIP_POLAR_KLIFT; grows by 3 when fallbacks are frequent)
   int max_rounds = 2;        // guarded fallback rounds enqueued per projection
+  int batch_occ = 3;         // register-allocation variant of k_symm_gemm_batch: 3 or 4 waves per SIMD (COSMO_HIP_POLAR_BATCH_OCC)
   real tol_factor = 8.0;   // verification threshold tol_factor * d * eps (relative to ||X||_F)
   PolarDev* dev = nullptr;
   PolarDev seen;             // host copy at the last polar_adapt
@@ -350,8 +351,12 @@ __global__ __launch_bounds__(256 * SK) void k_symm_gemm(const Ctl* __restrict__ 
 }
 
 // a batch of mid-size cones: one workgroup per (cone, upper tile) descriptor; buffers 0..3 of a cone are X, U/Y, Y/U, T
-template <int EPI>
-__global__ __launch_bounds__(256) void k_symm_gemm_batch(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ gate, const int4* __restrict__ tiles,
+// OCC = waves per SIMD the register allocation targets: 3 (164 VGPRs, no spills; three workgroups per CU) or 4 (126 VGPRs, 8 spilled to
+// 20 bytes of scratch; four workgroups per CU -- the 40 KB of LDS per workgroup allow exactly four).  Measured on BASELINE config 5
+// (PMC: the product kernel is 31-36 % MFMA-busy and moves 3.7 TB/s, i.e. bound by neither): OCC = 4 is SLOWER, 50.9 vs 47.6 us per
+// product, 147.4 vs 151.8 it/s -- the default stays 3, COSMO_HIP_POLAR_BATCH_OCC=4 selects the other instantiation.
+template <int EPI, int OCC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_symm_gemm_batch(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ gate, const int4* __restrict__ tiles,
                                                          const BatchCone* __restrict__ cones, real* __restrict__ W, int ia, int ib, int icin, int ic,
                                                          real alpha, real beta) {
   if (guard && ctl->halt) return;
@@ -677,14 +682,24 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
     HIPCHK(h, hipMemset(q->bgate, 0, sizeof(int) * q->bcones.size()));
     HIPCHK(h, hipMemcpy(q->d_bcones, q->bcones.data(), sizeof(BatchCone) * q->bcones.size(), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(q->d_btiles, tiles.data(), sizeof(int4) * tiles.size(), hipMemcpyHostToDevice));
-    (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch<0>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
-    (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch<1>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
+    (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
+    (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
+    (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
+    (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
+    if (const char* e = getenv("COSMO_HIP_POLAR_BATCH_OCC")) { const int v = atoi(e); if (v == 3 || v == 4) q->batch_occ = v; }
   }
   return COSMO_HIP_OK;
 }
 
 bool polar_has_batch(const cosmo_hip_handle* h) { const PolarPlan* q = static_cast<const PolarPlan*>(h->psd_polar); return q && !q->bcones.empty(); }
 bool polar_has_large(const cosmo_hip_handle* h) { const PolarPlan* q = static_cast<const PolarPlan*>(h->psd_polar); return q && !q->cones.empty(); }
+
+// the batched product with the occupancy variant of the plan
+#define LAUNCH_BGEMM(EPI, occ, G, B, sm, st, ...)                                                        \
+  do {                                                                                                   \
+    if ((occ) == 4) hipLaunchKernelGGL((k_symm_gemm_batch<EPI, 4>), G, B, sm, st, __VA_ARGS__);          \
+    else hipLaunchKernelGGL((k_symm_gemm_batch<EPI, 3>), G, B, sm, st, __VA_ARGS__);                     \
+  } while (0)
 
 // all mid-size cones of the batch advance together: 3 launches per step for the whole batch
 int32_t polar_enqueue_project_batch(cosmo_hip_handle* h, real* s, int guard) {
@@ -699,15 +714,15 @@ int32_t polar_enqueue_project_batch(cosmo_hip_handle* h, real* s, int guard) {
   int iu = 1, iy = 2, products = 0;
   const dim3 G(q->nbtiles), B(256);
   auto step = [&](const real* co, const int* gate) {
-    hipLaunchKernelGGL((k_symm_gemm_batch<0>), G, B, sm, st, h->ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW, iu, iu, iu, iy, 1.0, 0.0);       // Y = U^2
-    hipLaunchKernelGGL((k_symm_gemm_batch<1>), G, B, sm, st, h->ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW, iy, iy, iy, 3, co[2], co[1]);    // T = c Y^2 + b Y
-    hipLaunchKernelGGL((k_symm_gemm_batch<1>), G, B, sm, st, h->ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW, iu, 3, iu, iy, 1.0, co[0]);      // U' = U T + a U
+    LAUNCH_BGEMM(0, q->batch_occ, G, B, sm, st, h->ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW, iu, iu, iu, iy, 1.0, 0.0);       // Y = U^2
+    LAUNCH_BGEMM(1, q->batch_occ, G, B, sm, st, h->ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW, iy, iy, iy, 3, co[2], co[1]);    // T = c Y^2 + b Y
+    LAUNCH_BGEMM(1, q->batch_occ, G, B, sm, st, h->ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW, iu, 3, iu, iy, 1.0, co[0]);      // U' = U T + a U
     std::swap(iu, iy);
     products += 3; q->launches[3] += 3;
   };
   auto verify = [&](int round, const int* gate) {
-    hipLaunchKernelGGL((k_symm_gemm_batch<0>), G, B, sm, st, h->ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW, iu, 0, 0, 3, 1.0, 0.0);          // H = U X = |X|
-    hipLaunchKernelGGL((k_symm_gemm_batch<1>), G, B, sm, st, h->ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW, iu, 3, 0, iy, 1.0, -1.0);        // G = U H - X
+    LAUNCH_BGEMM(0, q->batch_occ, G, B, sm, st, h->ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW, iu, 0, 0, 3, 1.0, 0.0);          // H = U X = |X|
+    LAUNCH_BGEMM(1, q->batch_occ, G, B, sm, st, h->ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW, iu, 3, 0, iy, 1.0, -1.0);        // G = U H - X
     hipLaunchKernelGGL(k_bpolar_sumsq, dim3(BPX, n), dim3(COSMO_BS), 0, st, h->ctl, guard, gate, q->d_bcones, q->BW, iy, vparts);
     hipLaunchKernelGGL(k_bpolar_decide, dim3(1), dim3(COSMO_BS), 0, st, h->ctl, guard, q->dev, q->bgate, round, round == q->max_rounds ? 1 : 0, n, q->d_bcones,
                        vparts, q->bnrm, q->tol_factor);
@@ -834,7 +849,7 @@ extern "C" int32_t cosmo_hip_time_psd_product(cosmo_hip_handle* h, int32_t which
         const long long nt = cn.ld / cn.ts;
         fl = 2.0 * (double)(nt * (nt + 1) / 2) * cn.ts * cn.ts * cn.ld;
       } else {
-        hipLaunchKernelGGL((k_symm_gemm_batch<0>), dim3(q->nbtiles), dim3(256), GemmCfg<64>::SMEM, h->stream, h->ctl, 0, (const int*)nullptr, q->d_btiles,
+        LAUNCH_BGEMM(0, q->batch_occ, dim3(q->nbtiles), dim3(256), GemmCfg<64>::SMEM, h->stream, h->ctl, 0, (const int*)nullptr, q->d_btiles,
                            q->d_bcones, q->BW, 1, 1, 1, 2, 1.0, 0.0);
         fl = 0.0;
         for (const BatchCone& bc : q->bcones) { const long long nt = bc.ld / 64; fl += 2.0 * (double)(nt * (nt + 1) / 2) * 64 * 64 * (((bc.d + 31) / 32) * 32); }
