@@ -213,6 +213,16 @@ __device__ __forceinline__ void symm_gemm_tile(const real* __restrict__ A, const
   const int i0 = ti * TS, j0 = tj * TS;
   const int lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) & 3;
   const int wi = wv & 1, wj = wv >> 1;
+  // Quadrant masking: a wave's (TS/2) x (TS/2) quadrant is skipped (no LDS fragment reads, no MFMAs; its accumulators stay zero, which
+  // IS the result there) when it lies entirely beyond the cone's extent -- the edge tiles of a cone whose side is not a multiple of
+  // TS -- or when it is the strictly-lower quadrant of a diagonal tile, which the epilogue never reads (it mirrors the upper one).
+  // The wave still takes part in the panel loads and barriers.  On the cone mix of BASELINE config 5 this removes 1.36x of the
+  // matrix-instruction work of a product (diagonal tiles: 4 -> 3 quadrants; d = 130: 24 -> 15 quadrants) and is bit-identical -- but
+  // buys only 0-12 % per product (d = 65: 31.4 -> 27.7 us, d = 129: 77.4 -> 74.2, d = 192: unchanged; cfg5 unchanged): the kernel is
+  // bound by its panel loads (3.7 TB/s of HBM traffic, working set of ~300 MB per launch), not by MFMA issue
+  // (profiles/r02_polar_class_time.txt).
+  const int qext = kext > 0 ? kext : ld;
+  const bool qact = (i0 + (TS / 2) * wi < qext) && (j0 + (TS / 2) * wj < qext) && !(ti == tj && wi > wj);
   const long long pstep = (long long)PK * ld * SK;             // this group's next panel
   v4d acc[NM][NM];
 #pragma unroll
@@ -251,7 +261,7 @@ __device__ __forceinline__ void symm_gemm_tile(const real* __restrict__ A, const
   }
   const int fa = (TS / 2) * wi + (lane & 15), fb = (TS / 2) * wj + (lane & 15), fk = lane >> 4;
 #define P_COMPUTE(BUF)                                                                                    \
-  {                                                                                                       \
+  if (qact) {                                                                                             \
     _Pragma("unroll") for (int ks = 0; ks < PK / 4; ++ks) {                                               \
       const real* ap = As + (BUF) * PANEL + (ks * 4 + fk) * PITCH + fa;                                 \
       const real* bp = Bs + (BUF) * PANEL + (ks * 4 + fk) * PITCH + fb;                                 \
