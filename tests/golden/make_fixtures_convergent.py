@@ -1,0 +1,41 @@
+"""Generates tests/golden/baseline_convergent.json: BASELINE.json configs 4 (closest correlation, d = 2000) and 5 (decomposed chordal
+SDP, 400 cliques, n = 50 000) at FULL size, solved by the CPU oracle with the reference's DEFAULT settings (eps_abs = eps_rel = 1e-5,
+adaptive rho, check_termination = 25, Ruiz scaling; CG indirect KKT solver with the 1 / k^1.5 tolerance schedule) until `Solved`.
+Pins what a user sees end to end -- status, iteration count, objective, the sequence of rho updates -- where baseline_cfg4/5.npz pin a
+few tight-CG iterations entry by entry.  Like those, this pins the RESTATED algorithm (the Julia reference cannot run here).
+cfg4 takes ~5 minutes, cfg5 ~2-3 hours of CPU (25 s per ADMM iteration in NumPy).  Usage: python tests/golden/make_fixtures_convergent.py [cfg4|cfg5]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import cosmo_jl_amd as cj            # noqa: E402  (problem generators only; no device code is touched)
+from oracle import cosmo_oracle as O  # noqa: E402
+from tests import util               # noqa: E402
+
+# cfg5 does not reach eps = 1e-5 within a practical CPU budget (the device run is still at r_prim = 2.6e-2 after 700 iterations): its
+# fixture is the state after 150 iterations of the default schedule (status Max_iter_reached, residuals, objective, rho updates)
+MAX_ITER = {"cfg4": 400, "cfg5": 150}
+OUT = os.path.join(ROOT, "tests", "golden", "baseline_convergent.json")
+
+
+def problem(name):
+    return cj.problems.closest_correlation() if name == "cfg4" else cj.problems.chordal_sdp()
+
+
+if __name__ == "__main__":
+    out = json.load(open(OUT)) if os.path.exists(OUT) else {}
+    for name in (sys.argv[1:] or ["cfg4", "cfg5"]):
+        t0 = time.time()
+        p = problem(name)
+        ws = O.Workspace(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), O.Settings(kkt_solver="cg", max_iter=MAX_ITER[name]))
+        r = ws.optimize()
+        out[name] = dict(max_iter=MAX_ITER[name], status=r.status, iter=int(r.iter), obj_val=float(r.obj_val), r_prim=float(r.r_prim), r_dual=float(r.r_dual),
+                         rho_updates=[float(v) for v in r.rho_updates], cg_iters_total=int(np.sum(r.cg_iters)),
+                         x_norm=float(np.linalg.norm(r.x)), x_absmax=float(np.max(np.abs(r.x))), oracle_seconds=round(time.time() - t0, 1))
+        print(name, out[name], flush=True)
+        json.dump(out, open(OUT, "w"), indent=1)

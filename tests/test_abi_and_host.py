@@ -312,9 +312,9 @@ def test_headers_are_plain_c():
     gcc = shutil.which("gcc")
     if gcc is None:
         pytest.skip("gcc not available")
-    for name in ("cosmo_hip.h", "cosmo_chordal.h"):
+    for name, defs in (("cosmo_hip.h", []), ("cosmo_hip.h", ["-DCOSMO_HIP_REAL_FLOAT"]), ("cosmo_chordal.h", [])):      # both element types of the ABI
         path = os.path.join(ROOT, "include", name)
-        r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", path], capture_output=True, text=True)
+        r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c"] + defs + [path], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         txt = open(path).read()
         assert "torch" not in txt and "hipStream" not in txt and "#include <hip" not in txt
@@ -341,6 +341,14 @@ def test_plain_c_client_links_and_runs():
         import torch
         if not torch.cuda.is_available():
             assert "create_rc=2" in out.stdout                                # COSMO_HIP_ERR_HIP: no device, no fallback
+        # the same client against the Float32 instantiation: -DCOSMO_HIP_REAL_FLOAT before the header, libcosmo_hip_f32.so at link time
+        exe32 = os.path.join(td, "abi_example_f32")
+        r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-DCOSMO_HIP_REAL_FLOAT", "-I", os.path.join(ROOT, "include"),
+                            os.path.join(ROOT, "tests", "c_client", "abi_example.c"), "-o", exe32, "-L", libdir, "-lcosmo_hip_f32", "-lcosmo_chordal",
+                            "-Wl,-rpath," + libdir], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        out32 = subprocess.run([exe32], capture_output=True, text=True, timeout=120)
+        assert out32.returncode == 0 and "version=1000 alpha=1.6 max_iter=5000" in out32.stdout, out32.stderr
 
 
 def test_scripts_compile():
