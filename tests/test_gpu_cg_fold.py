@@ -116,3 +116,22 @@ def test_fold_is_off_where_the_assembly_would_not_pay(monkeypatch):
     prob = cj.problems.sparse_box_qp(n=2000, m=4000, nnz=40000, seed=3)
     md, _ = _run(monkeypatch, "1", prob, 3)
     assert md.handle.fold_stats()["enabled"] == 0
+
+
+def test_fold_follows_update_rho_through_the_plugin_entry_point(monkeypatch):
+    """AbstractKKTSolver.update_rho! (src/linear_solver/kktsolver_indirect.jl:164-166 -> cosmo_hip_update_rho): the assembled values are
+    rebuilt for an arbitrary rho vector handed over by the host, not only after the device's own adaptation."""
+    monkeypatch.setenv("COSMO_HIP_OP_FOLD", "1")
+    prob = cj.problems.chordal_sdp(ncliques=6, dmin=6, dmax=20, sep_min=1, sep_max=2, n_total=600, n_zero=6, n_nonneg=12)
+    md, _ = _run(monkeypatch, "1", prob, 3, scaling=0, adaptive_rho=False, **TIGHT)
+    h = md.handle
+    assert h.fold_stats()["enabled"] == 1
+    n, m = md.n, md.m
+    rng = np.random.default_rng(31)
+    rho = 10.0 ** rng.uniform(-3, 2, m)
+    h.update_rho(rho)
+    K = O.assemble_kkt_full(sp.csc_matrix(prob["P"]), sp.csc_matrix(prob["A"]), 1e-6, rho).toarray()
+    rhs = rng.standard_normal(n + m)
+    sol, its = h.kkt_solve(rhs)
+    ref = np.linalg.solve(K, rhs)
+    assert its > 0 and np.linalg.norm(sol - ref) <= 1e-7 * np.linalg.norm(ref)
