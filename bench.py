@@ -324,6 +324,22 @@ def _run_sdp(ctx, model, steps, warmup, dist=None):
     return h, elapsed, kbar
 
 
+
+def float32_extra(ctx, args, prob, st, steps, warmup):
+    """The same workload on the Float32 instantiation (libcosmo_hip_f32.so, COSMO.Model{Float32}): reported NEXT to the fp64 number of
+    the contract line, never instead of it (`dtype` of this sub-object is "f32")."""
+    import cosmo_jl_amd as cj
+    m32 = cj.Model(dtype=np.float32)
+    m32.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)
+    h32, el32, k32 = _run_sdp(ctx, m32, steps, warmup)
+    ps = h32.polar_stats()
+    out = dict(value=steps / el32, ms_per_step=1e3 * el32 / steps, steps=steps, warmup=warmup, dtype="f32", unit="ADMM iterations/s",
+               mean_cg_iters_per_admm_iter=round(k32, 3), polar={k: ps[k] for k in ("fallback_rounds", "verified", "unverified")},
+               note="same instance and fixed-work settings on libcosmo_hip_f32.so (every kernel instantiated for float, v_mfma_f32_16x16x4_f32 products)")
+    h32.close()
+    return out
+
+
 def bench_cfg4(ctx, args, steps, warmup):
     import cosmo_jl_amd as cj
     d = 400 if args.small else 2000
@@ -351,6 +367,8 @@ def bench_cfg4(ctx, args, steps, warmup):
     if not args.no_cpu_baseline and ctx.world == 1:
         out["cpu_baseline"] = lapack_cpu_baseline(prob, 2 if not args.small else 20, "cfg4")
     h.close()
+    if ctx.world == 1 and not args.no_float32:
+        out["float32"] = float32_extra(ctx, args, prob, st, steps, warmup)
     return out
 
 
@@ -398,6 +416,9 @@ def bench_cfg5(ctx, args, steps, warmup):
                                useful_tflops_reference_algorithm=round(useful * value / 1e12, 3), useful_frac_of_peak=round(useful * value / 1e12 / F64_MFMA_PEAK_TF, 5))
     if not args.no_cpu_baseline and ctx.world == 1:
         out["cpu_baseline"] = lapack_cpu_baseline(prob, 1 if not args.small else 10, "cfg5")
+    if ctx.world == 1 and not args.no_float32:
+        h.close()
+        out["float32"] = float32_extra(ctx, args, prob, st, steps, warmup)
     h.close()
     return out
 
@@ -415,6 +436,7 @@ def main():
                     help="default: all at N=1 (headline cfg2 + extra), cfg5 clique-sharded at N>1")
     ap.add_argument("--small", action="store_true", help="reduced-size instances (debugging only; not the BASELINE workloads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-float32", action="store_true", help="skip the Float32 (libcosmo_hip_f32.so) side numbers of cfg4 / cfg5")
     ap.add_argument("--cpu-sample-iters", type=int, default=5)
     ap.add_argument("--kkt", choices=["cg", "cg-sr"], default="cg",
                     help="cg: the literal cg! recurrence (default, the reference's algorithm); cg-sr: opt-in single-reduction CG (csrc/cg_sr.hip)")
