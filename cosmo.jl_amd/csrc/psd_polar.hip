@@ -82,7 +82,10 @@ struct PolarPlan {
   real* W = nullptr;       // 4 * ld^2 doubles per cone: X, U, Y, T
   real* parts = nullptr;   // per cone COSMO_MAX_PARTIALS norm partials + trace partials
   real* nrm = nullptr;     // per cone ||X||_F
-  int k_lift = 10;           // lifting steps of the main schedule (COSMO_HIP_POLAR_KLIFT; grows by 3 when fallbacks are frequent)
+  // lifting steps of the main schedule (COSMO_HIP_POLAR_KLIFT; grows by 3 when fallbacks are frequent).  Float64: 10 (every
+  // |lambda| >= 6e-8 ||X||_F lifted).  Float32: 5 -- the verification threshold 8 d eps scales with eps(Float32) (2e-4 ... 2e-3 for
+  // d = 200 ... 2000), eigenvalues below it pass by construction, and 0.0425 * 3.84^-5 = 5e-5 is already beneath it
+  int k_lift = REAL_IS_FLOAT ? 5 : 10;
   int max_rounds = 2;        // guarded fallback rounds enqueued per projection
   int rescale = 1;           // spectral rescaling in the first step of a large cone's iteration (COSMO_HIP_POLAR_RESCALE=0 disables)
   int batch_occ = 3;         // register-allocation variant of k_symm_gemm_batch: 3 or 4 waves per SIMD (COSMO_HIP_POLAR_BATCH_OCC)
