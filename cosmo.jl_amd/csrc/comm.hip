@@ -25,7 +25,7 @@
 
 typedef struct { char internal[128]; } nccl_uid_t;
 typedef void* nccl_comm_t;
-enum { NCCL_FLOAT64 = 8 };   // ncclDouble / ncclFloat64 (rccl.h ncclDataType_t)
+enum { NCCL_REAL = REAL_IS_FLOAT ? 7 : 8 };   // ncclFloat32 = 7 / ncclFloat64 = 8 (rccl.h ncclDataType_t): the element type of `real`
 
 struct RcclApi {
   void* lib = nullptr;
@@ -252,7 +252,7 @@ int32_t comm_enqueue_exchange(cosmo_hip_handle* h, real* s) {
   for (int r = 0; r < c->nranks; ++r) {
     const long long cnt = c->row_hi[r] - c->row_lo[r];
     if (cnt <= 0) continue;
-    NCHK(h, g_rccl.Broadcast(s + c->row_lo[r], s + c->row_lo[r], (size_t)cnt, NCCL_FLOAT64, r, c->comm, h->stream));
+    NCHK(h, g_rccl.Broadcast(s + c->row_lo[r], s + c->row_lo[r], (size_t)cnt, NCCL_REAL, r, c->comm, h->stream));
   }
   NCHK(h, g_rccl.GroupEnd());
   return COSMO_HIP_OK;
@@ -291,7 +291,7 @@ extern "C" int32_t cosmo_hip_comm_selftest(cosmo_hip_handle* h) {
   if (hipSetDevice(h->device) != hipSuccess) return cosmo_fail(h, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
   if (c->shm) return shm_barrier(h, c);
   NCHK(h, g_rccl.GroupStart());
-  NCHK(h, g_rccl.Broadcast(h->s, h->s, (size_t)h->m, NCCL_FLOAT64, 0, c->comm, h->stream));
+  NCHK(h, g_rccl.Broadcast(h->s, h->s, (size_t)h->m, NCCL_REAL, 0, c->comm, h->stream));
   NCHK(h, g_rccl.GroupEnd());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return COSMO_HIP_OK;

@@ -246,9 +246,13 @@ __device__ __forceinline__ void symm_gemm_tile(const real* __restrict__ A, const
   const real* ga = A + i0 + (long long)grp * PK * ld;        // group 1 starts at panel 1
   const real* gb = B + j0 + (long long)grp * PK * ld;
   real2 r[2][2 * NL];
+#ifndef POLAR_LAB_KB
+#define POLAR_LAB_KB(k) (k)
+#define POLAR_LAB_SYNC() __syncthreads()
+#endif
 #define P_LOAD(R, KB)                                                                                     \
   {                                                                                                       \
-    const long long o_ = (long long)(KB) * pstep;                                                         \
+    const long long o_ = (long long)(POLAR_LAB_KB(KB)) * pstep;                                                         \
     _Pragma("unroll") for (int u = 0; u < NL; ++u) {                                                      \
       (R)[u] = *reinterpret_cast<const real2*>(ga + o_ + goff[u]);                                      \
       (R)[NL + u] = *reinterpret_cast<const real2*>(gb + o_ + goff[u]);                                 \
@@ -284,12 +288,12 @@ __device__ __forceinline__ void symm_gemm_tile(const real* __restrict__ A, const
     if (kb + 2 < nk) P_LOAD(r[0], kb + 2)
     P_COMPUTE(0)
     if (kb + 1 < nk) P_STORE(r[1], 1)
-    __syncthreads();
+    POLAR_LAB_SYNC();
     if (kb + 1 >= nk) break;
     if (kb + 3 < nk) P_LOAD(r[1], kb + 3)
     P_COMPUTE(1)
     if (kb + 2 < nk) P_STORE(r[0], 0)
-    __syncthreads();
+    POLAR_LAB_SYNC();
   }
 #undef P_LOAD
 #undef P_STORE

@@ -56,12 +56,14 @@ def test_sharded_projection_merges_to_the_full_projection():
     assert np.array_equal(merged.view(np.int64), full.view(np.int64))   # bit for bit
 
 
-def test_single_rank_communicator_rccl_path():
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_single_rank_communicator_rccl_path(dtype):
+    """Both libraries: the broadcast's element type follows `cosmo_hip_real` (ncclFloat64 / ncclFloat32)."""
     prob = cj.problems.chordal_sdp(ncliques=8, dmin=4, dmax=30, sep_min=1, sep_max=3, n_total=600, n_zero=5, n_nonneg=10)
     st = cj.Settings(max_iter=100, eps_abs=0, eps_rel=0)
-    ref_model = cj.Model(); ref_model.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)
+    ref_model = cj.Model(dtype=dtype); ref_model.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)
     ref = cj.optimize(ref_model)
-    model = cj.Model(); model.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)
+    model = cj.Model(dtype=dtype); model.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)
     cj.model.setup(model)
     uid = cj.Handle.comm_unique_id()
     assert len(uid) == 128
