@@ -102,6 +102,7 @@ SIGNATURES = {
     "cosmo_hip_kernel_class_name": (C.c_char_p, [C.c_int32]),
     "cosmo_hip_psd_stats": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_polar_stats": (C.c_int32, [C.c_void_p, _PI64]),
+    "cosmo_hip_polar_streamk_stats": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_polar_schedule": (C.c_int32, [C.c_int32, _PD, _PI32]),
     "cosmo_hip_time_psd_product": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _PD, _PD]),
     "cosmo_hip_comm_unique_id": (C.c_int32, [C.POINTER(C.c_uint8)]),
@@ -410,6 +411,11 @@ class Handle:
     POLAR_STAT_KEYS = ["large_cones", "batch_cones", "tile_side", "k_split", "launches_64_1", "launches_96_1", "launches_96_2", "launches_batch",
                        "products_last_large", "fallback_rounds", "verified", "products_last_batch", "schedule_steps", "unverified", "projections",
                        "err_max_e18"]
+
+    def polar_streamk_stats(self):
+        out = np.zeros(4, dtype=np.int64)
+        self._chk(self.lib.cosmo_hip_polar_streamk_stats(self._h, out.ctypes.data_as(_PI64)))
+        return dict(zip(["enabled", "workgroups", "classes", "timeouts"], out.tolist()))
 
     def polar_stats(self):
         out = np.zeros(16, dtype=np.int64)

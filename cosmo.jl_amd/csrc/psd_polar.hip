@@ -48,7 +48,8 @@ struct PolarCone {
   int idx;            // index in PsdPlan::cones
   int off, d, kind;
   int ts;             // tile side of the products (64 or 96), chosen per cone
-  int sk;             // 2: intra-workgroup split of k (8 waves), when the upper tiles give at most one tile per CU
+  int sk;             // 2: intra-workgroup split of k (8 waves), when the upper tiles give at most one tile per CU; 3: stream-K
+  int skg, skc;       // stream-K: workgroups of a launch, ticket classes (8 = one tile range per XCD, 1 = a single range)
   int ld;             // d rounded up to ts
   long long woff;     // offset of this cone's 4 work matrices (doubles)
 };
@@ -56,6 +57,8 @@ struct PolarCone {
 struct BatchCone { long long woff; int off, d, kind, ld, idx, pad; };   // a mid-size cone of the batched path (device table)
 
 // device-side control of the verification / fallback rounds (one per plan; the large cones are projected one after the other)
+// stream-K product (k_symm_gemm_sk): ticket counter, spin-timeout marker, flag[G] = epoch of the slot's last partial tile
+struct SkSync { unsigned ticket; unsigned timeout; unsigned pad[14]; unsigned flag[1]; };
 struct PolarDev {
   int gate;          // 1: the last verification failed, the next guarded round must run
   int rounds;        // fallback rounds executed so far
@@ -92,7 +95,14 @@ struct PolarPlan {
   real tol_factor = 8.0;   // verification threshold tol_factor * d * eps (relative to ||X||_F)
   PolarDev* dev = nullptr;
   PolarDev seen;             // host copy at the last polar_adapt
-  long long launches[4] = {0, 0, 0, 0};   // <64,1>, <96,1>, <96,2>, batch
+  long long launches[4] = {0, 0, 0, 0};   // <64,1>, <96,1>, <96,2> or stream-K, batch
+  // stream-K product of the large cones (k_symm_gemm_sk): scratch slots for the partial tiles, ticket + flags
+  int streamk = 0;           // COSMO_HIP_POLAR_STREAMK=1: stream-K product kernel (k_symm_gemm_sk) instead of one tile per workgroup; measured
+                             // slower (see the kernel's header), so opt-in
+  real* sk_scratch = nullptr;
+  SkSync* sk_sync = nullptr;
+  int sk_gmax = 0;
+  unsigned sk_base = 0, sk_epoch = 0;   // first ticket of the next launch (mod 2^32), launch counter
   int products_last_large = 0, products_last_batch = 0;
   // batch of mid-size cones (one launch per product for all of them)
   std::vector<BatchCone> bcones;
@@ -202,38 +212,20 @@ template <int TS> struct GemmCfg {
 // group with its own double-buffered LDS panels; the two partial tiles are added through LDS before the epilogue.  Used when the
 // tile count gives one tile per CU: two waves per SIMD then cover each other's LDS / barrier stalls (one wave per SIMD issues
 // MFMAs only ~59 % of the time).
-template <int EPI, int TS, int SK>
-__device__ __forceinline__ void symm_gemm_tile(const real* __restrict__ A, const real* __restrict__ B, const real* __restrict__ Cin,
-                                               real* __restrict__ C, int ld, int ti, int tj, real alpha, real beta, real* smem,
-                                               int kext = 0) {
-  // kext: extent of the k loop (a multiple of 2 PK SK; 0 = ld).  Rows / columns beyond the cone's d are zero in every operand of
-  // the iteration, so the batched path stops the inner products at d rounded up to 32 instead of the tile-rounded ld: exact.
+// Main loop of one tile: acc += A(:, i-block)' panels times B(:, j-block) panels over the k-panels [kb0, kb0 + nk) (kb0 != 0 only with
+// SK = 1: the stream-K kernel).  `qact`: this wave's quadrant is computed (quadrant masking, see symm_gemm_tile).
+template <int TS, int SK>
+__device__ __forceinline__ void symm_mainloop(const real* __restrict__ A, const real* __restrict__ B, int ld, int i0, int j0, bool qact, int kb0, int nk,
+                                              real* smem, v4d (&acc)[TS / 32][TS / 32]) {
   using Cfg = GemmCfg<TS>;
-  constexpr int NM = Cfg::NM, NL = Cfg::NL, PITCH = Cfg::PITCH, CPITCH = Cfg::CPITCH, PANEL = Cfg::PANEL;
+  constexpr int NM = Cfg::NM, NL = Cfg::NL, PITCH = Cfg::PITCH, PANEL = Cfg::PANEL;
   const int grp = (SK == 2) ? (threadIdx.x >> 8) : 0;          // k-split group of this wave
   const int gtid = threadIdx.x & 255;                          // thread index within the group
   real* As = smem + grp * 4 * PANEL;   // [2][PANEL] per group
   real* Bs = As + 2 * PANEL;           // [2][PANEL]
-  const int i0 = ti * TS, j0 = tj * TS;
   const int lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) & 3;
   const int wi = wv & 1, wj = wv >> 1;
-  // Quadrant masking: a wave's (TS/2) x (TS/2) quadrant is skipped (no LDS fragment reads, no MFMAs; its accumulators stay zero, which
-  // IS the result there) when it lies entirely beyond the cone's extent -- the edge tiles of a cone whose side is not a multiple of
-  // TS -- or when it is the strictly-lower quadrant of a diagonal tile, which the epilogue never reads (it mirrors the upper one).
-  // The wave still takes part in the panel loads and barriers.  On the cone mix of BASELINE config 5 this removes 1.36x of the
-  // matrix-instruction work of a product (diagonal tiles: 4 -> 3 quadrants; d = 130: 24 -> 15 quadrants) and is bit-identical -- but
-  // buys only 0-12 % per product (d = 65: 31.4 -> 27.7 us, d = 129: 77.4 -> 74.2, d = 192: unchanged; cfg5 unchanged): the kernel is
-  // bound by its panel loads (3.7 TB/s of HBM traffic, working set of ~300 MB per launch), not by MFMA issue
-  // (profiles/r02_polar_class_time.txt).
-  const int qext = kext > 0 ? kext : ld;
-  const bool qact = (i0 + (TS / 2) * wi < qext) && (j0 + (TS / 2) * wj < qext) && !(ti == tj && wi > wj);
   const long long pstep = (long long)PK * ld * SK;             // this group's next panel
-  v4d acc[NM][NM];
-#pragma unroll
-  for (int a = 0; a < NM; ++a)
-#pragma unroll
-    for (int b = 0; b < NM; ++b) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
-  const int nk = (kext > 0 ? kext : ld) / PK / SK;   // panels per group (a multiple of 2: both groups run the same number of steps)
   // global -> LDS mapping: real2 number q = tid + 256 u of the PK x TS panel: k = q / (TS/2), index pair = q % (TS/2)
   int goff[NL], soff[NL];
 #pragma unroll
@@ -243,8 +235,8 @@ __device__ __forceinline__ void symm_gemm_tile(const real* __restrict__ A, const
     goff[u] = k * ld + 2 * c2;
     soff[u] = k * PITCH + 2 * c2;
   }
-  const real* ga = A + i0 + (long long)grp * PK * ld;        // group 1 starts at panel 1
-  const real* gb = B + j0 + (long long)grp * PK * ld;
+  const real* ga = A + i0 + ((long long)grp + kb0) * PK * ld;        // group 1 starts at panel 1
+  const real* gb = B + j0 + ((long long)grp + kb0) * PK * ld;
   real2 r[2][2 * NL];
 #ifndef POLAR_LAB_KB
 #define POLAR_LAB_KB(k) (k)
@@ -280,7 +272,7 @@ __device__ __forceinline__ void symm_gemm_tile(const real* __restrict__ A, const
     }                                                                                                     \
   }
   P_LOAD(r[0], 0)
-  P_LOAD(r[1], 1)
+  if (1 < nk) P_LOAD(r[1], 1)
   P_STORE(r[0], 0)
   __syncthreads();
   // invariant at the top of step kb: LDS[kb & 1] holds panel kb, r[(kb + 1) & 1] holds panel kb + 1 (in flight)
@@ -298,7 +290,17 @@ __device__ __forceinline__ void symm_gemm_tile(const real* __restrict__ A, const
 #undef P_LOAD
 #undef P_STORE
 #undef P_COMPUTE
-  // ---- epilogue through LDS: Cs[j][i], pitch CPITCH ----
+}
+
+// Epilogue of one tile, first half: the accumulators go to LDS as Cs[j][i] (pitch CPITCH), transposed so that both orientations of the
+// tile can leave as full rows.  SK = 2: the two k-groups' partial tiles are added here (even panels + odd panels, fixed order).
+template <int TS, int SK>
+__device__ __forceinline__ void symm_acc_to_lds(v4d (&acc)[TS / 32][TS / 32], real* smem) {
+  using Cfg = GemmCfg<TS>;
+  constexpr int NM = Cfg::NM, CPITCH = Cfg::CPITCH;
+  const int grp = (SK == 2) ? (threadIdx.x >> 8) : 0;
+  const int lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) & 3;
+  const int wi = wv & 1, wj = wv >> 1;
   real* Cs = smem;
   if (SK == 2 && grp == 1) {
 #pragma unroll
@@ -327,15 +329,42 @@ __device__ __forceinline__ void symm_gemm_tile(const real* __restrict__ A, const
         }
   }
   __syncthreads();
+}
+// Second half: C = alpha Cs + beta Cin on the upper tile (ti <= tj), mirrored into the lower one.  Thread t owns the elements
+// e = t + 256 SK k of the tile (i = e % TS, j = e / TS) in the first loop.  The Cin values are requested a CHUNK at a time (12-18
+// independent loads in flight, then their stores): written as one loop, every Cin load was a separate round trip to memory in front
+// of its store (load, s_waitcnt vmcnt(0), store -- 18 to 36 serial round trips per tile).
+template <int EPI, int TS, int SK>
+__device__ __forceinline__ void symm_store_from_lds(const real* __restrict__ Cin, real* __restrict__ C, int ld, int ti, int tj, real alpha, real beta,
+                                                    real* smem) {
+  constexpr int CPITCH = GemmCfg<TS>::CPITCH;
+  constexpr int NE = TS * TS / (256 * SK);             // elements per thread: 36 / 18 (TS = 96), 16 (TS = 64)
+  constexpr int CH = (NE > 18) ? 12 : NE;              // chunk
+  static_assert(NE % CH == 0, "chunking");
+  const int i0 = ti * TS, j0 = tj * TS;
+  real* Cs = smem;
   const bool diag = (ti == tj);
   // natural orientation: column j0 + j, rows i0 .. i0 + TS - 1 contiguous
-  for (int e = threadIdx.x; e < TS * TS; e += 256 * SK) {
-    const int i = e % TS, j = e / TS;
-    if (diag && i > j) continue;
-    real v = Cs[j * CPITCH + i];
-    const long long o = (long long)(j0 + j) * ld + i0 + i;
-    if (EPI == 1) { v = alpha * v + beta * Cin[o]; Cs[j * CPITCH + i] = v; }
-    C[o] = v;
+#pragma unroll 1
+  for (int c = 0; c < NE / CH; ++c) {
+    real cin[CH];
+    if (EPI == 1) {
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int e = threadIdx.x + 256 * SK * (c * CH + k);
+        const int i = e % TS, j = e / TS;
+        cin[k] = (diag && i > j) ? R(0.0) : Cin[(long long)(j0 + j) * ld + i0 + i];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int e = threadIdx.x + 256 * SK * (c * CH + k);
+      const int i = e % TS, j = e / TS;
+      if (diag && i > j) continue;
+      real v = Cs[j * CPITCH + i];
+      if (EPI == 1) { v = alpha * v + beta * cin[k]; Cs[j * CPITCH + i] = v; }
+      C[(long long)(j0 + j) * ld + i0 + i] = v;
+    }
   }
   __syncthreads();
   // mirrored orientation: column i0 + i, rows j0 .. j0 + TS - 1 contiguous
@@ -344,6 +373,37 @@ __device__ __forceinline__ void symm_gemm_tile(const real* __restrict__ A, const
     if (diag && i >= j) continue;
     C[(long long)(i0 + i) * ld + j0 + j] = Cs[j * CPITCH + i];
   }
+}
+
+template <int EPI, int TS, int SK>
+__device__ __forceinline__ void symm_gemm_tile(const real* __restrict__ A, const real* __restrict__ B, const real* __restrict__ Cin,
+                                               real* __restrict__ C, int ld, int ti, int tj, real alpha, real beta, real* smem,
+                                               int kext = 0) {
+  // kext: extent of the k loop (a multiple of 2 PK SK; 0 = ld).  Rows / columns beyond the cone's d are zero in every operand of
+  // the iteration, so the batched path stops the inner products at d rounded up to 32 instead of the tile-rounded ld: exact.
+  constexpr int NM = GemmCfg<TS>::NM;
+  const int i0 = ti * TS, j0 = tj * TS;
+  const int wv = (threadIdx.x >> 6) & 3;
+  const int wi = wv & 1, wj = wv >> 1;
+  // Quadrant masking: a wave's (TS/2) x (TS/2) quadrant is skipped (no LDS fragment reads, no MFMAs; its accumulators stay zero, which
+  // IS the result there) when it lies entirely beyond the cone's extent -- the edge tiles of a cone whose side is not a multiple of
+  // TS -- or when it is the strictly-lower quadrant of a diagonal tile, which the epilogue never reads (it mirrors the upper one).
+  // The wave still takes part in the panel loads and barriers.  On the cone mix of BASELINE config 5 this removes 1.36x of the
+  // matrix-instruction work of a product (diagonal tiles: 4 -> 3 quadrants; d = 130: 24 -> 15 quadrants) and is bit-identical -- but
+  // buys only 0-12 % per product (d = 65: 31.4 -> 27.7 us, d = 129: 77.4 -> 74.2, d = 192: unchanged; cfg5 unchanged): the kernel is
+  // bound by its panel loads (3.7 TB/s of HBM traffic, working set of ~300 MB per launch), not by MFMA issue
+  // (profiles/r02_polar_class_time.txt).
+  const int qext = kext > 0 ? kext : ld;
+  const bool qact = (i0 + (TS / 2) * wi < qext) && (j0 + (TS / 2) * wj < qext) && !(ti == tj && wi > wj);
+  v4d acc[NM][NM];
+#pragma unroll
+  for (int a = 0; a < NM; ++a)
+#pragma unroll
+    for (int b = 0; b < NM; ++b) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
+  const int nk = (kext > 0 ? kext : ld) / PK / SK;   // panels per group (a multiple of 2: both groups run the same number of steps)
+  symm_mainloop<TS, SK>(A, B, ld, i0, j0, qact, 0, nk, smem, acc);
+  symm_acc_to_lds<TS, SK>(acc, smem);
+  symm_store_from_lds<EPI, TS, SK>(Cin, C, ld, ti, tj, alpha, beta, smem);
 }
 
 // one large cone: the grid walks its upper tiles
@@ -366,6 +426,118 @@ __global__ __launch_bounds__(256 * SK) void k_symm_gemm(const Ctl* __restrict__ 
   while ((long long)(tj + 1) * (tj + 2) / 2 <= t) ++tj;
   const int ti = t - tj * (tj + 1) / 2;
   symm_gemm_tile<EPI, TS, SK>(A, B, Cin, C, ld, ti, tj, alpha, beta, smem);
+}
+
+// ---- stream-K variant of the large-cone product (OPT-IN: COSMO_HIP_POLAR_STREAMK=1; a measured negative result) -----------------
+// One tile per workgroup quantises badly against the 256 CUs (d = 2000: 231 tiles of 96 -> 25 CUs idle, every other CU bound to the
+// barrier rhythm of its one workgroup; d = 1000: 66 tiles -> a quarter of the chip).  Here the WORK -- (tile, k-panel) units in
+// tile-major order -- is cut into G equal contiguous ranges, two resident workgroups of 256 threads per CU (their barriers are
+// independent, so one workgroup's LDS / barrier phases are covered by the other's matrix instructions).  A range that ends inside a tile
+// leaves a PARTIAL tile in the workgroup's scratch slot and raises the slot's flag; the workgroup
+// that owns the tile's LAST panels adds the partials to its own in increasing-k order and runs the epilogue.  Fixed ranges => the
+// summation order is fixed: results are bit-reproducible and identical on every rank of a sharded run.
+// Measured (profiles/r02_streamk_lab.txt, d = 2000, 8.58 GFLOP per product): main loops alone 156 us (the 231-workgroup kernel: 177 us
+// for everything), but the exchange -- every tile is split, so every workgroup ends with a partial-tile store, a flag wait, 74 KB of
+// partial loads and the Cin loads, all serial round trips to memory at the very moment its CU partner does the same -- brings the
+// product to 182 us; with release / acquire fences instead of write-through stores 248 us (each fence empties the XCD's L2).  Smaller
+// cones lose more (d = 500: 2.7 vs 1.8 ms per projection: 9 partials per tile).  cfg4: 120.3 vs 127.2 it/s => not the default.
+//  * No deadlock by construction: a workgroup takes a TICKET when it starts and derives its range from it; partials are only ever
+//    awaited from lower tickets (workgroups that have already started), whatever the residency.
+//  * Each workgroup walks its range from the END: the partial (head of a later tile) is produced first, so it is ready long before
+//    its consumer -- which first computes its own head partial -- asks for it.
+//  * XCD locality: ticket t works in the tile range of XCD t % 8 (contiguous tile columns: shared panels in that XCD's L2); ranges never
+//    straddle two XCD tile ranges, so a tile's partials are exchanged by workgroups of the same ticket class.
+//  * Visibility: the partial tile and the flag are written with agent-scope stores (write-through; `s_waitcnt vmcnt(0)` + workgroup barrier
+//    order them) and read with agent-scope loads -- correct wherever the workgroups were placed, and without the L2 write-back /
+//    invalidate of a release / acquire fence pair (which costs every other workgroup of the XCD its cached panels).
+#define SKG_TS 96
+
+template <int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_symm_gemm_sk(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ gate, const real* __restrict__ A,
+                                                      const real* __restrict__ B, const real* __restrict__ Cin, real* __restrict__ C, int ld, int ntiles,
+                                                      int ncls, real alpha, real beta, real* __restrict__ scratch, SkSync* __restrict__ sync, unsigned base, unsigned epoch) {
+  constexpr int TS = SKG_TS, NM = TS / 32, CPITCH = GemmCfg<TS>::CPITCH;
+  extern __shared__ real smem[];
+  __shared__ unsigned s_ticket;
+  // every workgroup of every launch takes a ticket (also when the launch is halted / gated off): the counter then advances by exactly
+  // gridDim.x per launch and the host knows each launch's first ticket (`base`, modulo 2^32)
+  if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&sync->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (guard && ctl->halt) return;
+  if (gate && !*gate) return;          // fallback round whose verification already passed
+  const unsigned G = gridDim.x, per = G / (unsigned)ncls;
+  const unsigned t = s_ticket - base;                              // 0 .. G - 1 in arrival order
+  const unsigned x = t % (unsigned)ncls, w = t / (unsigned)ncls;   // workgroup w of ticket class x (ncls = 8: class = XCD of an in-order dispatch)
+  const int nk = ld / PK;
+  const int T0 = (int)((long long)ntiles * x / ncls), T1 = (int)((long long)ntiles * (x + 1) / ncls);
+  const long long U = (long long)(T1 - T0) * nk;               // units of this class
+  const long long u0 = U * w / per, u1 = U * (w + 1) / per;
+  const int wv = (threadIdx.x >> 6) & 3, wi = wv & 1, wj = wv >> 1;
+  real* myslot = scratch + (size_t)(x * per + w) * (TS * TS);
+  long long u = u1;
+  while (u > u0) {
+    const int tl = (int)((u - 1) / nk);                        // tile (relative to T0) of the last unit not yet done
+    const long long tb = (long long)tl * nk;
+    const int ke = (int)(u - tb);                              // segment = panels [kb, ke) of that tile
+    const int kb = (int)((u0 > tb ? u0 : tb) - tb);
+    const int tt = T0 + tl;
+    int tj = (int)((sqrt(8.0 * (double)tt + 1.0) - 1.0) / 2.0);
+    while ((long long)tj * (tj + 1) / 2 > tt) --tj;
+    while ((long long)(tj + 1) * (tj + 2) / 2 <= tt) ++tj;
+    const int ti = tt - tj * (tj + 1) / 2;
+    const bool qact = !(ti == tj && wi > wj);
+    v4d acc[NM][NM];
+#pragma unroll
+    for (int a = 0; a < NM; ++a)
+#pragma unroll
+      for (int b = 0; b < NM; ++b) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
+    symm_mainloop<TS, 1>(A, B, ld, ti * TS, tj * TS, qact, kb, ke - kb, smem, acc);
+    symm_acc_to_lds<TS, 1>(acc, smem);                         // Cs[j][i]; thread t owns the elements e = t + 256 k below
+    real* Cs = smem;
+#ifdef POLAR_LAB_NOXCHG
+    if (ke < nk) {} else if (kb > 0) {} else
+#endif
+    if (ke < nk) {
+      // producer: the partial tile leaves as TS x TS contiguous values, written THROUGH to memory (agent-scope stores), then the flag
+#pragma unroll 4
+      for (int k = 0; k < TS * TS / 256; ++k) { const int e = threadIdx.x + 256 * k; __hip_atomic_store(myslot + e, Cs[(e / TS) * CPITCH + e % TS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(&sync->flag[x * per + w], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (kb > 0) {
+        // consumer: the earlier panels of this tile were computed by the workgroups w - 1, w - 2, ... of the same class
+        unsigned wf = w;
+        while (wf > 0 && U * wf / per > tb) --wf;              // wf: the workgroup whose range contains the tile's first panel
+        for (unsigned wp = wf; wp < w; ++wp) {
+          if (U * (wp + 1) / per == U * wp / per) continue;      // empty range (more workgroups than units): nothing to await
+          if (threadIdx.x == 0) {
+            long spins = 0;
+            while (__hip_atomic_load(&sync->flag[x * per + wp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+              __builtin_amdgcn_s_sleep(4);
+              if (++spins > (1L << 21)) { __hip_atomic_store(&sync->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+          }
+          __syncthreads();
+          const real* ps = scratch + (size_t)(x * per + wp) * (TS * TS);
+          // fixed order: own panels, then the partials by increasing k (agent-scope loads: served by memory, never by a stale cache line)
+          // 12 loads of a thread in flight at a time (each is a round trip to memory)
+#pragma unroll 1
+          for (int c = 0; c < TS * TS / 256 / 12; ++c) {
+            real pv[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) pv[k] = __hip_atomic_load(ps + threadIdx.x + 256 * (c * 12 + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int k = 0; k < 12; ++k) { const int e = threadIdx.x + 256 * (c * 12 + k); Cs[(e / TS) * CPITCH + e % TS] += pv[k]; }
+          }
+        }
+        __syncthreads();
+      }
+      symm_store_from_lds<EPI, TS, 1>(Cin, C, ld, ti, tj, alpha, beta, smem);
+    }
+    __syncthreads();                                           // the next segment's panels reuse this LDS image
+    u = tb + kb;
+  }
 }
 
 // a batch of mid-size cones: one workgroup per (cone, upper tile) descriptor; buffers 0..3 of a cone are X, U/Y, Y/U, T
@@ -401,9 +573,27 @@ static void launch_symm_gemm(cosmo_hip_handle* h, int guard, const int* gate, co
                      ntiles, alpha, beta);
   static_cast<PolarPlan*>(h->psd_polar)->launches[TS == 64 ? 0 : (SK == 2 ? 2 : 1)] += 1;
 }
-// ts: tile side; sk: 1 or 2 (intra-workgroup split of k, only with ts = 96)
+template <int EPI>
+static void launch_symm_gemm_sk(cosmo_hip_handle* h, int guard, const int* gate, const real* A, const real* B, const real* Cin, real* C, int ld,
+                                real alpha, real beta, int G, int ncls) {
+  PolarPlan* q = static_cast<PolarPlan*>(h->psd_polar);
+  const int nt = ld / SKG_TS, ntiles = nt * (nt + 1) / 2;
+  constexpr int smem = GemmCfg<SKG_TS>::SMEM;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_symm_gemm_sk<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_set = true; }
+  q->sk_epoch += 1u; if (q->sk_epoch == 0u) q->sk_epoch = 1u;
+  hipLaunchKernelGGL((k_symm_gemm_sk<EPI>), dim3(G), dim3(256), smem, h->stream, h->ctl, guard, gate, A, B, Cin, C, ld, ntiles, ncls, alpha, beta,
+                     q->sk_scratch, q->sk_sync, q->sk_base, q->sk_epoch);
+  q->sk_base += (unsigned)G;
+  q->launches[2] += 1;
+}
+// ts: tile side; sk: 1 or 2 (intra-workgroup split of k, only with ts = 96), 3: stream-K (ts = 96; skg workgroups in skc ticket classes)
 static void symm_gemm(cosmo_hip_handle* h, int guard, const int* gate, int ts, int sk, int epi, const real* A, const real* B, const real* Cin, real* C,
-                      int ld, real alpha, real beta) {
+                      int ld, real alpha, real beta, int skg = 0, int skc = 8) {
+  if (sk == 3) {
+    if (epi) launch_symm_gemm_sk<1>(h, guard, gate, A, B, Cin, C, ld, alpha, beta, skg, skc); else launch_symm_gemm_sk<0>(h, guard, gate, A, B, Cin, C, ld, alpha, beta, skg, skc);
+    return;
+  }
   if (ts == 96 && sk == 2) { if (epi) launch_symm_gemm<1, 96, 2>(h, guard, gate, A, B, Cin, C, ld, alpha, beta); else launch_symm_gemm<0, 96, 2>(h, guard, gate, A, B, Cin, C, ld, alpha, beta); }
   else if (ts == 96) { if (epi) launch_symm_gemm<1, 96, 1>(h, guard, gate, A, B, Cin, C, ld, alpha, beta); else launch_symm_gemm<0, 96, 1>(h, guard, gate, A, B, Cin, C, ld, alpha, beta); }
   else { if (epi) launch_symm_gemm<1, 64, 1>(h, guard, gate, A, B, Cin, C, ld, alpha, beta); else launch_symm_gemm<0, 64, 1>(h, guard, gate, A, B, Cin, C, ld, alpha, beta); }
@@ -610,6 +800,8 @@ void polar_plan_destroy(cosmo_hip_handle* h) {
   if (q->W) (void)hipFree(q->W);
   if (q->parts) (void)hipFree(q->parts);
   if (q->nrm) (void)hipFree(q->nrm);
+  if (q->sk_scratch) (void)hipFree(q->sk_scratch);
+  if (q->sk_sync) (void)hipFree(q->sk_sync);
   if (q->d_bcones) (void)hipFree(q->d_bcones);
   if (q->d_btiles) (void)hipFree(q->d_btiles);
   if (q->BW) (void)hipFree(q->BW);
@@ -640,6 +832,7 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
   h->psd_polar = q;
   if (const char* e = getenv("COSMO_HIP_POLAR_KLIFT")) q->k_lift = std::min(40, std::max(0, atoi(e)));
   if (const char* e = getenv("COSMO_HIP_POLAR_RESCALE")) q->rescale = atoi(e) ? 1 : 0;
+  if (const char* e = getenv("COSMO_HIP_POLAR_STREAMK")) q->streamk = atoi(e) ? 1 : 0;
   if (const char* e = getenv("COSMO_HIP_POLAR_ROUNDS")) q->max_rounds = std::min(8, std::max(0, atoi(e)));
   HIPCHK(h, hipMalloc((void**)&q->dev, sizeof(PolarDev)));
   HIPCHK(h, hipMemset(q->dev, 0, sizeof(PolarDev)));
@@ -661,6 +854,19 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
       pc.ld = ((c.d + pc.ts - 1) / pc.ts) * pc.ts;
       { const long long nt = pc.ld / pc.ts; pc.sk = (pc.ts == 96 && nt * (nt + 1) / 2 <= 256) ? 2 : 1; }
       if (const char* e = getenv("COSMO_HIP_POLAR_SK")) { const int v = atoi(e); if (v == 1 || (v == 2 && pc.ts == 96)) pc.sk = v; }
+      pc.skg = 0; pc.skc = 8;
+      if (q->streamk) {
+        // stream-K: tiles of 96 whatever the count (quantisation no longer matters); 2 workgroups per CU when the cone has the work
+        pc.ts = SKG_TS; pc.sk = 3;
+        pc.ld = ((c.d + pc.ts - 1) / pc.ts) * pc.ts;
+        const long long nt = pc.ld / pc.ts, tiles = nt * (nt + 1) / 2, nk = pc.ld / PK;
+        pc.skc = tiles >= 64 ? 8 : 1;
+        const long long units_min = (tiles / pc.skc) * nk;                 // units of the smallest class
+        long long per = std::min<long long>(512 / pc.skc, std::max<long long>(1, units_min / 4));   // >= 4 panels per workgroup
+        if (const char* e = getenv("COSMO_HIP_POLAR_SKG")) { const long long v = atoll(e) / pc.skc; if (v >= 1 && v <= 1024 / pc.skc) per = std::min(v, std::max<long long>(1, units_min)); }
+        pc.skg = (int)(per * pc.skc);
+        q->sk_gmax = std::max(q->sk_gmax, pc.skg);
+      }
       pc.woff = woff;
       woff += 4LL * pc.ld * pc.ld;
       q->cones.push_back(pc);
@@ -668,6 +874,13 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
     HIPCHK(h, hipMalloc((void**)&q->W, sizeof(real) * (size_t)woff));
     HIPCHK(h, hipMalloc((void**)&q->parts, sizeof(real) * 2 * COSMO_MAX_PARTIALS * q->cones.size()));
     HIPCHK(h, hipMalloc((void**)&q->nrm, sizeof(real) * q->cones.size()));
+    if (q->sk_gmax > 0) {
+      const size_t slot = (size_t)SKG_TS * SKG_TS;
+      HIPCHK(h, hipMalloc((void**)&q->sk_scratch, sizeof(real) * slot * (size_t)q->sk_gmax));
+      const size_t sb = sizeof(SkSync) + sizeof(unsigned) * (size_t)q->sk_gmax;
+      HIPCHK(h, hipMalloc((void**)&q->sk_sync, sb));
+      HIPCHK(h, hipMemset(q->sk_sync, 0, sb));
+    }
   }
   if (use_batch) {
     long long woff = 0;
@@ -797,15 +1010,15 @@ int32_t polar_enqueue_project(cosmo_hip_handle* h, real* s, int guard) {
     hipLaunchKernelGGL(k_polar_populate, dim3(gpop), dim3(COSMO_BS), 0, st, h->ctl, guard, cn, s, X, nparts);
     hipLaunchKernelGGL(k_polar_scale, dim3(1024), dim3(COSMO_BS), 0, st, h->ctl, guard, n2, gpop, nparts, X, U, q->nrm + ci);
     auto step = [&](const real* co, const int* gate) {
-      symm_gemm(h, guard, gate, cn.ts, cn.sk, 0, U, U, nullptr, Y, cn.ld, 1.0, 0.0);         // Y = U^2
-      symm_gemm(h, guard, gate, cn.ts, cn.sk, 1, Y, Y, Y, T, cn.ld, co[2], co[1]);           // T = c Y^2 + b Y
-      symm_gemm(h, guard, gate, cn.ts, cn.sk, 1, U, T, U, Y, cn.ld, 1.0, co[0]);             // U' = U T + a U
+      symm_gemm(h, guard, gate, cn.ts, cn.sk, 0, U, U, nullptr, Y, cn.ld, 1.0, 0.0, cn.skg, cn.skc);         // Y = U^2
+      symm_gemm(h, guard, gate, cn.ts, cn.sk, 1, Y, Y, Y, T, cn.ld, co[2], co[1], cn.skg, cn.skc);           // T = c Y^2 + b Y
+      symm_gemm(h, guard, gate, cn.ts, cn.sk, 1, U, T, U, Y, cn.ld, 1.0, co[0], cn.skg, cn.skc);             // U' = U T + a U
       std::swap(U, Y);
       products += 3;
     };
     auto verify = [&](int round, const int* gate) {
-      symm_gemm(h, guard, gate, cn.ts, cn.sk, 0, U, X, nullptr, T, cn.ld, 1.0, 0.0);         // H = U X = |X|
-      symm_gemm(h, guard, gate, cn.ts, cn.sk, 1, U, T, X, Y, cn.ld, 1.0, -1.0);              // G = U H - X = (U^2 - I) X
+      symm_gemm(h, guard, gate, cn.ts, cn.sk, 0, U, X, nullptr, T, cn.ld, 1.0, 0.0, cn.skg, cn.skc);         // H = U X = |X|
+      symm_gemm(h, guard, gate, cn.ts, cn.sk, 1, U, T, X, Y, cn.ld, 1.0, -1.0, cn.skg, cn.skc);              // G = U H - X = (U^2 - I) X
       hipLaunchKernelGGL(k_polar_sumsq, dim3(1024), dim3(COSMO_BS), 0, st, h->ctl, guard, gate, n2, Y, nparts);
       hipLaunchKernelGGL(k_polar_decide, dim3(1), dim3(COSMO_BS), 0, st, h->ctl, guard, q->dev, round, round == q->max_rounds ? 1 : 0, 1024, nparts,
                          q->nrm + ci, q->tol_factor * cn.d * PSD_EPS);
@@ -815,11 +1028,11 @@ int32_t polar_enqueue_project(cosmo_hip_handle* h, real* s, int guard) {
     if (q->rescale && k_main > 0) {
       // first lifting step with the spectral rescaling between its first and second product; from d = 1024 on the gain (>= 4.2)
       // exceeds the slope of a lifting step, so the main schedule is one step shorter
-      symm_gemm(h, guard, nullptr, cn.ts, cn.sk, 0, U, U, nullptr, Y, cn.ld, 1.0, 0.0);
+      symm_gemm(h, guard, nullptr, cn.ts, cn.sk, 0, U, U, nullptr, Y, cn.ld, 1.0, 0.0, cn.skg, cn.skc);
       hipLaunchKernelGGL(k_polar_sumsq, dim3(1024), dim3(COSMO_BS), 0, st, h->ctl, guard, (const int*)nullptr, n2, Y, nparts);
       hipLaunchKernelGGL(k_polar_rescale, dim3(1024), dim3(COSMO_BS), 0, st, h->ctl, guard, n2, 1024, nparts, U, Y);
-      symm_gemm(h, guard, nullptr, cn.ts, cn.sk, 1, Y, Y, Y, T, cn.ld, kPolarLift[2], kPolarLift[1]);
-      symm_gemm(h, guard, nullptr, cn.ts, cn.sk, 1, U, T, U, Y, cn.ld, 1.0, kPolarLift[0]);
+      symm_gemm(h, guard, nullptr, cn.ts, cn.sk, 1, Y, Y, Y, T, cn.ld, kPolarLift[2], kPolarLift[1], cn.skg, cn.skc);
+      symm_gemm(h, guard, nullptr, cn.ts, cn.sk, 1, U, T, U, Y, cn.ld, 1.0, kPolarLift[0], cn.skg, cn.skc);
       std::swap(U, Y);
       products += 3;
       k_main -= 1;
@@ -877,6 +1090,19 @@ extern "C" int32_t cosmo_hip_polar_stats(cosmo_hip_handle* h, int64_t out[16]) {
   return COSMO_HIP_OK;
 }
 
+extern "C" int32_t cosmo_hip_polar_streamk_stats(cosmo_hip_handle* h, int64_t out[4]) {
+  if (!h || !out) return COSMO_HIP_ERR_INVALID;
+  for (int i = 0; i < 4; ++i) out[i] = 0;
+  PolarPlan* q = static_cast<PolarPlan*>(h->psd_polar);
+  if (!q || q->cones.empty() || !q->sk_sync) return COSMO_HIP_OK;
+  if (hipSetDevice(h->device) != hipSuccess) return cosmo_fail(h, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
+  unsigned hdr[2] = {0, 0};
+  HIPCHK(h, hipMemcpyAsync(hdr, q->sk_sync, sizeof hdr, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  out[0] = 1; out[1] = q->cones[0].skg; out[2] = q->cones[0].skc; out[3] = hdr[1];
+  return COSMO_HIP_OK;
+}
+
 // measurement hook (bench.py roofline): the product kernel exactly as the projection launches it
 extern "C" int32_t cosmo_hip_time_psd_product(cosmo_hip_handle* h, int32_t which, int32_t reps, double* avg_seconds, double* flops) {
   if (!h || reps <= 0 || !avg_seconds) return COSMO_HIP_ERR_INVALID;
@@ -895,7 +1121,7 @@ extern "C" int32_t cosmo_hip_time_psd_product(cosmo_hip_handle* h, int32_t which
         const PolarCone& cn = q->cones[0];
         const long long n2 = (long long)cn.ld * cn.ld;
         real* X = q->W + cn.woff;
-        symm_gemm(h, 0, nullptr, cn.ts, cn.sk, 0, X + n2, X + n2, nullptr, X + 2 * n2, cn.ld, 1.0, 0.0);
+        symm_gemm(h, 0, nullptr, cn.ts, cn.sk, 0, X + n2, X + n2, nullptr, X + 2 * n2, cn.ld, 1.0, 0.0, cn.skg, cn.skc);
         const long long nt = cn.ld / cn.ts;
         fl = 2.0 * (double)(nt * (nt + 1) / 2) * cn.ts * cn.ts * cn.ld;
       } else {

@@ -240,6 +240,11 @@ function fold_stats(h::Handle)      # assembled reduced CG operator (cosmo_hip_f
     check(h, ccall((:cosmo_hip_fold_stats, lib(h)), Int32, (Ptr{Cvoid}, Ptr{Int64}), h.ptr, out))
     return (enabled = out[1] != 0, nnz = out[2], terms = out[3], tiles = out[4])
 end
+function polar_streamk_stats(h::Handle)      # stream-K product of the large PSD cones (cosmo_hip_polar_streamk_stats)
+    out = zeros(Int64, 4)
+    check(h, ccall((:cosmo_hip_polar_streamk_stats, lib(h)), Int32, (Ptr{Cvoid}, Ptr{Int64}), h.ptr, out))
+    return (enabled = out[1], workgroups = out[2], classes = out[3], timeouts = out[4])
+end
 
 function project_hip!(h::Handle{T}, s::COSMO.SplitVector{T}) where {T <: HipFloat}
     d = s.data

@@ -306,10 +306,14 @@ const char* cosmo_hip_kernel_class_name(int32_t k);
  * the last multi-workgroup solve, non-convergence flag, number of PSD cones}. */
 int32_t cosmo_hip_psd_stats(cosmo_hip_handle* h, int64_t out[4]);
 /* Matrix-sign (polar) PSD path diagnostics: out = {large cones (d > 256), batched cones (64 < d <= 256), tile side of the first
- * large cone, its k-split (1 | 2), product launches <64,1>, <96,1>, <96,2>, batched product launches, matrix products of the main
+ * large cone, its k-split (1 | 2 | 3 = stream-K), product launches <64,1>, <96,1>, <96,2> or stream-K, batched product launches, matrix products of the main
  * schedule of the last large-cone projection, fallback rounds executed so far, verified projections, products of the last batched
  * projection, steps of the main schedule, unverified projections, projections, max verified error bound in units of 1e-18}. */
 int32_t cosmo_hip_polar_stats(cosmo_hip_handle* h, int64_t out[16]);
+/* Opt-in stream-K product kernel of the large cones (COSMO_HIP_POLAR_STREAMK=1; d > 256; k-split reported as 3 by cosmo_hip_polar_stats,
+ * its launches under <96,2>):
+ * out = {enabled, workgroups per launch of the first large cone, its ticket classes, spin time-outs so far (must stay 0)}. */
+int32_t cosmo_hip_polar_streamk_stats(cosmo_hip_handle* h, int64_t out[4]);
 /* The coefficient table of the sign iteration for k_lift lifting steps: abc holds 3 * (*nsteps) doubles (a, b, c per step;
  * NULL = only report *nsteps).  Host function (no device needed): lets a CPU test replay the schedule on scalars. */
 int32_t cosmo_hip_polar_schedule(int32_t k_lift, double* abc, int32_t* nsteps);

@@ -34,15 +34,21 @@ def _proj_handle(sets):
     return h
 
 
-def test_cfg4_projection_d2000_vs_lapack_and_kernel_variant():
+@pytest.mark.parametrize("streamk", [1, 0])
+def test_cfg4_projection_d2000_vs_lapack_and_kernel_variant(streamk, monkeypatch):
     """One PsdConeTriangle of side 2000 (BASELINE config 4): ||dX+||_F <= 64 d eps ||X||_F against the oracle's dsyevr + syrk,
-    exact rank on a gapped spectrum, and the 8-wave split-k <96, 2> product kernel is the one that ran (231 tiles on 256 CUs)."""
+    exact rank on a gapped spectrum, and WHICH product kernel ran: the one-tile-per-workgroup 8-wave split-k <96, 2> kernel (231 tiles
+    on 256 CUs; the default), or with COSMO_HIP_POLAR_STREAMK=1 the stream-K kernel (512 workgroups in 8 ticket classes share the
+    231 tiles x 126 k-panels evenly; k-split reported as 3)."""
+    monkeypatch.setenv("COSMO_HIP_POLAR_STREAMK", str(streamk))
     d = 2000
     rng = np.random.default_rng(2000)
     K = cj.PsdConeTriangle(d * (d + 1) // 2)
     h = _proj_handle([K])
     st0 = h.polar_stats()
-    assert (st0["large_cones"], st0["batch_cones"], st0["tile_side"], st0["k_split"]) == (1, 0, 96, 2)
+    assert (st0["large_cones"], st0["batch_cones"], st0["tile_side"], st0["k_split"]) == (1, 0, 96, 3 if streamk else 2)
+    sk = h.polar_streamk_stats()
+    assert (sk["enabled"], sk["workgroups"], sk["classes"]) == ((1, 512, 8) if streamk else (0, 0, 0))
     # (a) the matrix the closest-correlation problem projects first: a dense symmetric matrix with no structure
     G = rng.uniform(-1.0, 1.0, size=(d, d)); X = (G + G.T) / 2
     # (b) a gapped spectrum (rank is then well defined)
@@ -68,6 +74,7 @@ def test_cfg4_projection_d2000_vs_lapack_and_kernel_variant():
         assert after["products_last_large"] == 44 and after["schedule_steps"] == 15
         assert after["fallback_rounds"] == before["fallback_rounds"] and after["verified"] == before["verified"] + 1
         assert after["err_max_e18"] * 1e-18 <= 8 * d * EPS
+    assert h.polar_streamk_stats()["timeouts"] == 0
     h.close()
 
 

@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, scipy.sparse as sp, torch
 import cosmo_jl_amd as cj
 rng = np.random.default_rng(5)
-for d in (2000, 1000, 500, 320):
+for d in [int(v) for v in (sys.argv[1:] or ["2000", "1000", "500", "320"])]:
     K = cj.PsdConeTriangle(d * (d + 1) // 2)
     m = K.dim
     h = cj.Handle(0)
