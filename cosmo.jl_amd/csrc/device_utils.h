@@ -72,20 +72,29 @@ __device__ __forceinline__ real block_max(real v, real* red) {
 }
 // Every workgroup re-reduces the (<= COSMO_MAX_PARTIALS) partials of the producing kernel in the same fixed
 // order, so all workgroups of all consumer kernels see bit-identical scalars without a finalize launch.
-__device__ __forceinline__ real reduce_partials_sum(const real* p, int count, real* red) {
-  real a = 0.0;
-  for (int i = threadIdx.x; i < count; i += COSMO_BS) a += p[i];
-  return block_sum(a, red);
-}
-// two-step form: issue the loads first (before any guard that waits on a scalar load), fold later
+// A thread owns the partials t, t + 256, ... (at most COSMO_MAX_PARTIALS / COSMO_BS = 8) and adds them in that order.  All of its loads
+// are REQUESTED BEFORE THE FIRST ADDITION: written as `for (i = t; i < count; i += 256) a += p[i]` the compiler emits load, s_waitcnt
+// vmcnt(0), add per iteration -- up to eight serial L2 round trips at the head of every latency-bound Krylov kernel (k_cg_upd on
+// BASELINE config 2 reduces 2048 partials: 4 of its 5.3 us).  Missing slots contribute +0.0, which cannot change the sum: the running
+// sum starts at +0.0 and therefore is never -0.0.
+#define COSMO_PARTS_PER_THREAD (COSMO_MAX_PARTIALS / COSMO_BS)
 __device__ __forceinline__ real partials_prefetch_sum(const real* p, int count) {
+  real v[COSMO_PARTS_PER_THREAD];
+#pragma unroll
+  for (int k = 0; k < COSMO_PARTS_PER_THREAD; ++k) { const int i = (int)threadIdx.x + k * COSMO_BS; v[k] = (i < count) ? p[i] : R(0.0); }
   real a = 0.0;
-  for (int i = threadIdx.x; i < count; i += COSMO_BS) a += p[i];
+#pragma unroll
+  for (int k = 0; k < COSMO_PARTS_PER_THREAD; ++k) a += v[k];
   return a;
 }
+__device__ __forceinline__ real reduce_partials_sum(const real* p, int count, real* red) { return block_sum(partials_prefetch_sum(p, count), red); }
 __device__ __forceinline__ real reduce_partials_max(const real* p, int count, real* red) {
+  real v[COSMO_PARTS_PER_THREAD];
+#pragma unroll
+  for (int k = 0; k < COSMO_PARTS_PER_THREAD; ++k) { const int i = (int)threadIdx.x + k * COSMO_BS; v[k] = (i < count) ? p[i] : R(0.0); }
   real a = 0.0;
-  for (int i = threadIdx.x; i < count; i += COSMO_BS) { real t = p[i]; a = (t > a || t != t) ? t : a; }
+#pragma unroll
+  for (int k = 0; k < COSMO_PARTS_PER_THREAD; ++k) { const real t = v[k]; a = (t > a || t != t) ? t : a; }   // a padding 0.0 never replaces a
   return block_max(a, red);
 }
 
