@@ -36,6 +36,9 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 F64_MFMA_PEAK_TF = 78.6    # fp64 matrix peak (the guide lists no fp64 row, the vector and matrix fp64 peaks coincide)
+# what a register-operand v_mfma_f64_16x16x4_f64 stream sustains on this chip with two waves per SIMD (bench/mfma_lab.hip,
+# profiles/r02_mfma_ceiling_and_gemm_lab.txt); reported beside `peak`, never instead of it
+F64_MFMA_SUSTAINED_TF = 66.9
 METRIC = "ADMM iterations/sec (fp64) at fixed (n,m,nnz,cone)"
 
 
@@ -356,6 +359,7 @@ def bench_cfg4(ctx, args, steps, warmup):
     per_gpu = value / ctx.world
     out["roofline"] = dict(bound="mfma", kernel="k_symm_gemm<EPI, %d, %d> (symmetric product of the sign iteration, v_mfma_f64_16x16x4_f64)" % (ps["tile_side"], ps["k_split"]),
                            achieved=round(fl / t_prod / 1e12, 2), peak=F64_MFMA_PEAK_TF, unit="TFLOP/s", frac=round(fl / t_prod / 1e12 / F64_MFMA_PEAK_TF, 4), traffic=None,
+                           peak_sustained_measured=F64_MFMA_SUSTAINED_TF, frac_of_sustained=round(fl / t_prod / 1e12 / F64_MFMA_SUSTAINED_TF, 4),
                            flops_per_launch=fl, avg_launch_us=round(1e6 * t_prod, 2), launches_timed=20,
                            products_per_projection=ps["products_last_large"],
                            performed_tflops_whole_iteration=round(ps["products_last_large"] * fl * per_gpu / 1e12, 2),
@@ -412,6 +416,7 @@ def bench_cfg5(ctx, args, steps, warmup):
         t_prod, fl = h.time_psd_product(1, 20)
         out["roofline"] = dict(bound="mfma", kernel="k_symm_gemm_batch<EPI> (one workgroup per (clique, upper 64x64 tile) of rank 0's cliques)",
                                achieved=round(fl / t_prod / 1e12, 2), peak=F64_MFMA_PEAK_TF, unit="TFLOP/s", frac=round(fl / t_prod / 1e12 / F64_MFMA_PEAK_TF, 4), traffic=None,
+                               peak_sustained_measured=F64_MFMA_SUSTAINED_TF, frac_of_sustained=round(fl / t_prod / 1e12 / F64_MFMA_SUSTAINED_TF, 4),
                                flops_per_launch=fl, avg_launch_us=round(1e6 * t_prod, 2), launches_timed=20, products_per_projection=ps["products_last_batch"],
                                useful_tflops_reference_algorithm=round(useful * value / 1e12, 3), useful_frac_of_peak=round(useful * value / 1e12 / F64_MFMA_PEAK_TF, 5))
     if not args.no_cpu_baseline and ctx.world == 1:
