@@ -54,7 +54,7 @@ struct PolarCone {
   long long woff;     // offset of this cone's 4 work matrices (doubles)
 };
 
-struct BatchCone { long long woff; int off, d, kind, ld, idx, pad; };   // a mid-size cone of the batched path (device table)
+struct BatchCone { long long woff; int off, d, kind, ld, idx, ts; };   // a mid-size cone of the batched path (device table); ts = tile side of its products (64 | 96)
 
 // device-side control of the verification / fallback rounds (one per plan; the large cones are projected one after the other)
 // stream-K product (k_symm_gemm_sk): ticket counter, spin-timeout marker, flag[G] = epoch of the slot's last partial tile
@@ -107,8 +107,11 @@ struct PolarPlan {
   // batch of mid-size cones (one launch per product for all of them)
   std::vector<BatchCone> bcones;
   BatchCone* d_bcones = nullptr;
-  int4* d_btiles = nullptr;
-  int nbtiles = 0;
+  int4* d_btiles = nullptr;   // tile descriptors of the cones with 64 x 64 tiles, then (from nbtiles on) of the cones with 96 x 96 tiles
+  int nbtiles = 0, nbtiles96 = 0;
+  int batch_ts96 = 0;        // COSMO_HIP_POLAR_BATCH_TS96=1: cones whose side fits 96 / 192 take 96 x 96 tiles in a second launch per product.
+                             // Measured on BASELINE config 5: SLOWER, 62.2 vs 47.0 us per product, 133.9 vs 155.2 it/s (two launch tails per
+                             // product, two workgroups per CU for the 96-class) => opt-in; profiles/r02_batch_tile_classes.txt
   real* BW = nullptr;
   real* bparts = nullptr;
   real* bnrm = nullptr;    // per batched cone ||X||_F
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // 20 bytes of scratch; four workgroups per CU -- the 40 KB of LDS per workgroup allow exactly four).  Measured on BASELINE config 5
 // (PMC: the product kernel is 31-36 % MFMA-busy and moves 3.7 TB/s, i.e. bound by neither): OCC = 4 is SLOWER, 50.9 vs 47.6 us per
 // product, 147.4 vs 151.8 it/s -- the default stays 3, COSMO_HIP_POLAR_BATCH_OCC=4 selects the other instantiation.
-template <int EPI, int OCC>
+template <int EPI, int OCC, int TS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_symm_gemm_batch(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ gate, const int4* __restrict__ tiles,
                                                          const BatchCone* __restrict__ cones, real* __restrict__ W, int ia, int ib, int icin, int ic,
                                                          real alpha, real beta) {
@@ -558,7 +561,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   const BatchCone bc = cones[td.x];
   const long long n2 = (long long)bc.ld * bc.ld;
   real* base = W + bc.woff;
-  symm_gemm_tile<EPI, 64, 1>(base + ia * n2, base + ib * n2, base + icin * n2, base + ic * n2, bc.ld, td.y, td.z, alpha, beta, smem,
+  symm_gemm_tile<EPI, TS, 1>(base + ia * n2, base + ib * n2, base + icin * n2, base + ic * n2, bc.ld, td.y, td.z, alpha, beta, smem,
                              ((bc.d + 31) / 32) * 32);
 }
 
@@ -833,6 +836,7 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
   if (const char* e = getenv("COSMO_HIP_POLAR_KLIFT")) q->k_lift = std::min(40, std::max(0, atoi(e)));
   if (const char* e = getenv("COSMO_HIP_POLAR_RESCALE")) q->rescale = atoi(e) ? 1 : 0;
   if (const char* e = getenv("COSMO_HIP_POLAR_STREAMK")) q->streamk = atoi(e) ? 1 : 0;
+  if (const char* e = getenv("COSMO_HIP_POLAR_BATCH_TS96")) q->batch_ts96 = atoi(e) ? 1 : 0;
   if (const char* e = getenv("COSMO_HIP_POLAR_ROUNDS")) q->max_rounds = std::min(8, std::max(0, atoi(e)));
   HIPCHK(h, hipMalloc((void**)&q->dev, sizeof(PolarDev)));
   HIPCHK(h, hipMemset(q->dev, 0, sizeof(PolarDev)));
@@ -888,8 +892,12 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
     for (int idx : batch_list) {
       const PsdConeDev& c = p->cones[idx];
       BatchCone bc;
-      bc.off = c.off; bc.d = c.d; bc.kind = c.kind; bc.idx = idx; bc.pad = 0;
-      bc.ld = ((c.d + 63) / 64) * 64;
+      bc.off = c.off; bc.d = c.d; bc.kind = c.kind; bc.idx = idx;
+      // tile side (opt-in, see PolarPlan::batch_ts96): 96 x 96 tiles stream 1.5x fewer operand bytes per flop than 64 x 64 tiles (12 vs 8
+      // flop per byte) and spend fewer barriers per flop; they would be used where they do not cost padding: sides in (64, 96] (one tile instead of three) and in
+      // (128, 192] (three tiles instead of six).  Everything else keeps 64 x 64 tiles.
+      bc.ts = (q->batch_ts96 && ((c.d > 64 && c.d <= 96) || (c.d > 128 && c.d <= 192))) ? 96 : 64;
+      bc.ld = ((c.d + bc.ts - 1) / bc.ts) * bc.ts;
       bc.woff = woff;
       woff += 4LL * bc.ld * bc.ld;
       q->bcones.push_back(bc);
@@ -901,27 +909,38 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
     // XCD-aware order: workgroup b runs on XCD b % 8 and each XCD has its own L2, so all tiles of a cone go to ONE XCD (they
     // share the cone's operand panels: 1.5-2.5x fewer HBM reads than tiles scattered over eight L2s); the cones are dealt to the
     // XCD with the least work so far, descriptor 8 * slot + x is the slot-th tile of XCD x, short lists end with null tiles.
-    if (getenv("COSMO_HIP_POLAR_BATCH_FLAT")) {
-      for (int ci : order) {
-        const int nt = q->bcones[ci].ld / 64;
-        for (int tj = 0; tj < nt; ++tj) for (int ti = 0; ti <= tj; ++ti) tiles.push_back(int4{ci, ti, tj, 0});
+    // One list per tile class (64, then 96): a product is one launch per class.
+    int count[2] = {0, 0};
+    for (int cls = 0; cls < 2; ++cls) {
+      const int ts = cls == 0 ? 64 : 96;
+      std::vector<int4> tl;
+      if (getenv("COSMO_HIP_POLAR_BATCH_FLAT")) {
+        for (int ci : order) {
+          if (q->bcones[ci].ts != ts) continue;
+          const int nt = q->bcones[ci].ld / ts;
+          for (int tj = 0; tj < nt; ++tj) for (int ti = 0; ti <= tj; ++ti) tl.push_back(int4{ci, ti, tj, 0});
+        }
+      } else {
+        std::vector<std::vector<int4>> xl(8);
+        long long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int ci : order) {
+          if (q->bcones[ci].ts != ts) continue;
+          const int nt = q->bcones[ci].ld / ts;
+          int x = 0;
+          for (int t = 1; t < 8; ++t) if (load[t] < load[x]) x = t;
+          for (int tj = 0; tj < nt; ++tj) for (int ti = 0; ti <= tj; ++ti) xl[x].push_back(int4{ci, ti, tj, 0});
+          load[x] += (long long)nt * (nt + 1) / 2 * q->bcones[ci].ld;
+        }
+        size_t maxlen = 0;
+        for (int x = 0; x < 8; ++x) maxlen = std::max(maxlen, xl[x].size());
+        tl.assign(8 * maxlen, int4{-1, 0, 0, 0});
+        for (int x = 0; x < 8; ++x) for (size_t sl = 0; sl < xl[x].size(); ++sl) tl[8 * sl + x] = xl[x][sl];
       }
-    } else {
-      std::vector<std::vector<int4>> xl(8);
-      long long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int ci : order) {
-        const int nt = q->bcones[ci].ld / 64;
-        int x = 0;
-        for (int t = 1; t < 8; ++t) if (load[t] < load[x]) x = t;
-        for (int tj = 0; tj < nt; ++tj) for (int ti = 0; ti <= tj; ++ti) xl[x].push_back(int4{ci, ti, tj, 0});
-        load[x] += (long long)nt * (nt + 1) / 2 * q->bcones[ci].ld;
-      }
-      size_t maxlen = 0;
-      for (int x = 0; x < 8; ++x) maxlen = std::max(maxlen, xl[x].size());
-      tiles.assign(8 * maxlen, int4{-1, 0, 0, 0});
-      for (int x = 0; x < 8; ++x) for (size_t sl = 0; sl < xl[x].size(); ++sl) tiles[8 * sl + x] = xl[x][sl];
+      count[cls] = (int)tl.size();
+      tiles.insert(tiles.end(), tl.begin(), tl.end());
     }
-    q->nbtiles = (int)tiles.size();
+    q->nbtiles = count[0]; q->nbtiles96 = count[1];
+    if (tiles.empty()) tiles.push_back(int4{-1, 0, 0, 0});
     HIPCHK(h, hipMalloc((void**)&q->BW, sizeof(real) * (size_t)woff));
     HIPCHK(h, hipMalloc((void**)&q->d_bcones, sizeof(BatchCone) * q->bcones.size()));
     HIPCHK(h, hipMalloc((void**)&q->d_btiles, sizeof(int4) * tiles.size()));
@@ -931,10 +950,12 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
     HIPCHK(h, hipMemset(q->bgate, 0, sizeof(int) * q->bcones.size()));
     HIPCHK(h, hipMemcpy(q->d_bcones, q->bcones.data(), sizeof(BatchCone) * q->bcones.size(), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(q->d_btiles, tiles.data(), sizeof(int4) * tiles.size(), hipMemcpyHostToDevice));
-    (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
-    (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
-    (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
-    (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
+    (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch<0, 3, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
+    (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch<1, 3, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
+    (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch<0, 4, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
+    (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch<1, 4, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
+    (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch<0, 2, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<96>::SMEM);
+    (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch<1, 2, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<96>::SMEM);
     if (const char* e = getenv("COSMO_HIP_POLAR_BATCH_OCC")) { const int v = atoi(e); if (v == 3 || v == 4) q->batch_occ = v; }
   }
   return COSMO_HIP_OK;
@@ -943,12 +964,22 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
 bool polar_has_batch(const cosmo_hip_handle* h) { const PolarPlan* q = static_cast<const PolarPlan*>(h->psd_polar); return q && !q->bcones.empty(); }
 bool polar_has_large(const cosmo_hip_handle* h) { const PolarPlan* q = static_cast<const PolarPlan*>(h->psd_polar); return q && !q->cones.empty(); }
 
-// the batched product with the occupancy variant of the plan
-#define LAUNCH_BGEMM(EPI, occ, G, B, sm, st, ...)                                                        \
-  do {                                                                                                   \
-    if ((occ) == 4) hipLaunchKernelGGL((k_symm_gemm_batch<EPI, 4>), G, B, sm, st, __VA_ARGS__);          \
-    else hipLaunchKernelGGL((k_symm_gemm_batch<EPI, 3>), G, B, sm, st, __VA_ARGS__);                     \
-  } while (0)
+// the batched product: one launch per tile class (64 x 64 tiles with the occupancy variant of the plan, then 96 x 96 tiles: their
+// 74.5 KB of LDS allow two workgroups per CU)
+template <int EPI>
+static void launch_bgemm(PolarPlan* q, hipStream_t st, const Ctl* ctl, int guard, const int* gate, int ia, int ib, int icin, int ic, real alpha, real beta) {
+  if (q->nbtiles96 > 0)
+    hipLaunchKernelGGL((k_symm_gemm_batch<EPI, 2, 96>), dim3(q->nbtiles96), dim3(256), GemmCfg<96>::SMEM, st, ctl, guard, gate, q->d_btiles + q->nbtiles,
+                       q->d_bcones, q->BW, ia, ib, icin, ic, alpha, beta);
+  if (q->nbtiles > 0) {
+    if (q->batch_occ == 4)
+      hipLaunchKernelGGL((k_symm_gemm_batch<EPI, 4, 64>), dim3(q->nbtiles), dim3(256), GemmCfg<64>::SMEM, st, ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW,
+                         ia, ib, icin, ic, alpha, beta);
+    else
+      hipLaunchKernelGGL((k_symm_gemm_batch<EPI, 3, 64>), dim3(q->nbtiles), dim3(256), GemmCfg<64>::SMEM, st, ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW,
+                         ia, ib, icin, ic, alpha, beta);
+  }
+}
 
 // all mid-size cones of the batch advance together: 3 launches per step for the whole batch
 int32_t polar_enqueue_project_batch(cosmo_hip_handle* h, real* s, int guard) {
@@ -956,22 +987,20 @@ int32_t polar_enqueue_project_batch(cosmo_hip_handle* h, real* s, int guard) {
   PsdPlan* p = h->psd;
   hipStream_t st = h->stream;
   const int n = (int)q->bcones.size();
-  const size_t sm = GemmCfg<64>::SMEM;
   real* vparts = q->bparts + (size_t)2 * BPX * n;
   hipLaunchKernelGGL(k_bpolar_populate, dim3(BPX, n), dim3(COSMO_BS), 0, st, h->ctl, guard, q->d_bcones, s, q->BW, q->bparts);
   hipLaunchKernelGGL(k_bpolar_scale, dim3(BPX, n), dim3(COSMO_BS), 0, st, h->ctl, guard, q->d_bcones, q->bparts, q->BW, q->bnrm);
   int iu = 1, iy = 2, products = 0;
-  const dim3 G(q->nbtiles), B(256);
   auto step = [&](const real* co, const int* gate) {
-    LAUNCH_BGEMM(0, q->batch_occ, G, B, sm, st, h->ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW, iu, iu, iu, iy, 1.0, 0.0);       // Y = U^2
-    LAUNCH_BGEMM(1, q->batch_occ, G, B, sm, st, h->ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW, iy, iy, iy, 3, co[2], co[1]);    // T = c Y^2 + b Y
-    LAUNCH_BGEMM(1, q->batch_occ, G, B, sm, st, h->ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW, iu, 3, iu, iy, 1.0, co[0]);      // U' = U T + a U
+    launch_bgemm<0>(q, st, h->ctl, guard, gate, iu, iu, iu, iy, 1.0, 0.0);       // Y = U^2
+    launch_bgemm<1>(q, st, h->ctl, guard, gate, iy, iy, iy, 3, co[2], co[1]);    // T = c Y^2 + b Y
+    launch_bgemm<1>(q, st, h->ctl, guard, gate, iu, 3, iu, iy, 1.0, co[0]);      // U' = U T + a U
     std::swap(iu, iy);
     products += 3; q->launches[3] += 3;
   };
   auto verify = [&](int round, const int* gate) {
-    LAUNCH_BGEMM(0, q->batch_occ, G, B, sm, st, h->ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW, iu, 0, 0, 3, 1.0, 0.0);          // H = U X = |X|
-    LAUNCH_BGEMM(1, q->batch_occ, G, B, sm, st, h->ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW, iu, 3, 0, iy, 1.0, -1.0);        // G = U H - X
+    launch_bgemm<0>(q, st, h->ctl, guard, gate, iu, 0, 0, 3, 1.0, 0.0);          // H = U X = |X|
+    launch_bgemm<1>(q, st, h->ctl, guard, gate, iu, 3, 0, iy, 1.0, -1.0);        // G = U H - X
     hipLaunchKernelGGL(k_bpolar_sumsq, dim3(BPX, n), dim3(COSMO_BS), 0, st, h->ctl, guard, gate, q->d_bcones, q->BW, iy, vparts);
     hipLaunchKernelGGL(k_bpolar_decide, dim3(1), dim3(COSMO_BS), 0, st, h->ctl, guard, q->dev, q->bgate, round, round == q->max_rounds ? 1 : 0, n, q->d_bcones,
                        vparts, q->bnrm, q->tol_factor);
@@ -1125,10 +1154,9 @@ extern "C" int32_t cosmo_hip_time_psd_product(cosmo_hip_handle* h, int32_t which
         const long long nt = cn.ld / cn.ts;
         fl = 2.0 * (double)(nt * (nt + 1) / 2) * cn.ts * cn.ts * cn.ld;
       } else {
-        LAUNCH_BGEMM(0, q->batch_occ, dim3(q->nbtiles), dim3(256), GemmCfg<64>::SMEM, h->stream, h->ctl, 0, (const int*)nullptr, q->d_btiles,
-                           q->d_bcones, q->BW, 1, 1, 1, 2, 1.0, 0.0);
+        launch_bgemm<0>(q, h->stream, h->ctl, 0, (const int*)nullptr, 1, 1, 1, 2, 1.0, 0.0);
         fl = 0.0;
-        for (const BatchCone& bc : q->bcones) { const long long nt = bc.ld / 64; fl += 2.0 * (double)(nt * (nt + 1) / 2) * 64 * 64 * (((bc.d + 31) / 32) * 32); }
+        for (const BatchCone& bc : q->bcones) { const long long nt = bc.ld / bc.ts; fl += 2.0 * (double)(nt * (nt + 1) / 2) * bc.ts * bc.ts * (((bc.d + 31) / 32) * 32); }
       }
     }
     if (pass == 1) HIPCHK(h, hipEventRecord(e1, h->stream));
