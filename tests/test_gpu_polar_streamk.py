@@ -113,3 +113,26 @@ def test_streamk_float32_library(monkeypatch):
     assert np.linalg.norm(out.astype(np.float64) - ref) <= 64 * d * e32 * np.linalg.norm(X)
     assert int(rk[0]) == 300 and h.polar_streamk_stats()["timeouts"] == 0
     h.close()
+
+
+def test_batched_path_second_tile_class(monkeypatch):
+    """Opt-in COSMO_HIP_POLAR_BATCH_TS96=1: cones with sides in (64, 96] and (128, 192] run their products on 96 x 96 tiles (a second
+    launch per product), the others keep 64 x 64 tiles; same projection within the 64 d eps bound, exact ranks on gapped spectra."""
+    monkeypatch.setenv("COSMO_HIP_POLAR_BATCH_TS96", "1")
+    rng = np.random.default_rng(96)
+    ds = [70, 96, 100, 130, 192, 200, 33, 64]
+    sets = [cj.PsdConeTriangle(d * (d + 1) // 2) for d in ds]
+    mats = [random_sym(rng, d, d // 2) for d in ds]
+    s = np.concatenate([cj.problems.svec(M) for M in mats])
+    ref = s.copy(); info = {}
+    O.project(ref, util.oracle_cones(sets), info)
+    h = handle_for(sets)
+    assert h.polar_stats()["batch_cones"] == len(ds)
+    out, rk, _ = h.project(s)
+    off = 0
+    for K, M, d, r_ref, r in zip(sets, mats, ds, info["psd_rank"], rk):
+        assert np.linalg.norm(out[off:off + K.dim] - ref[off:off + K.dim]) <= 64 * d * EPS * np.linalg.norm(M), d
+        assert int(r) == r_ref == d // 2
+        off += K.dim
+    assert h.polar_stats()["unverified"] == 0
+    h.close()
