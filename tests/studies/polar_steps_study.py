@@ -7,7 +7,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import cosmo_jl_amd as cj            # noqa: E402  (problem generators)
 from oracle import cosmo_oracle as O  # noqa: E402
 from tests import util               # noqa: E402

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Run one BASELINE configuration end to end on the GPU for a fixed number of ADMM iterations and (optionally) time the
-CPU oracle on a bounded sample of the same instance.  Prints one JSON line.   python tools/run_config.py cfg5 --iters 50"""
+(the CPU comparison lives in bench.py's cpu_baseline).  Prints one JSON line.   python tools/run_config.py cfg5 --iters 50"""
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,7 +11,6 @@ import cosmo_jl_amd as cj
 ap = argparse.ArgumentParser()
 ap.add_argument("config", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
 ap.add_argument("--iters", type=int, default=50)
-ap.add_argument("--cpu-iters", type=int, default=0)
 ap.add_argument("--d", type=int, default=2000)
 args = ap.parse_args()
 t0 = time.time()
@@ -40,12 +39,5 @@ else:
     out = dict(config=args.config, n=md.n, m=md.m, nnzA=int(md.A.nnz), cones=len(md.sets), iters=int(r.iter), gen_s=round(tg, 2), setup_s=round(ts, 2),
                iter_time_s=r.iter_time, iters_per_s=r.iter / r.iter_time, mean_cg_per_iter=r.kkt_iters_total / max(1, r.kkt_solves),
                r_prim=r.r_prim, r_dual=r.r_dual, psd=h.psd_stats())
-if args.cpu_iters > 0:
-    from oracle import cosmo_oracle as O
-    from tests import util
-    ws = O.Workspace(prob["P"], prob["q"], prob["A"], prob["b"], util.oracle_cones(prob["sets"]),
-                     O.Settings(kkt_solver="cg", max_iter=args.cpu_iters, eps_abs=0.0, eps_rel=0.0, check_infeasibility=10 ** 9))
-    ro = ws.optimize()
-    out["cpu_oracle_iters_per_s"] = ro.iter / ro.iter_time
-    out["cpu_sample"] = "%d iterations, %.1f s, 1 core (LAPACK may thread)" % (ro.iter, ro.iter_time)
+# (the CPU side of every configuration is bench.py's `cpu_baseline` leg: tools/ never touches oracle/)
 print(json.dumps(out))
