@@ -93,11 +93,20 @@ class Ctx:
         self.dist = None
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a MI355X (no CPU fallback)")
+        # COSMO_BENCH_TRANSPORT=shm: dry run of the multi-rank path on ONE GPU (every rank on device 0, gloo for the barriers, the
+        # host-staged exchange of csrc/comm.hip instead of RCCL, which refuses two ranks on one device).  Functional check only
+        # (tests/test_gpu_sharding.py); the line it prints says so and is not a measurement.
+        self.shm = os.environ.get("COSMO_BENCH_TRANSPORT", "") == "shm"
+        if self.shm:
+            self.local_rank = 0
         torch.cuda.set_device(self.local_rank)
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.local_rank))
+            if self.shm:
+                dist.init_process_group(backend="gloo")
+            else:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.local_rank))
             self.dist = dist
 
     def barrier(self):
@@ -113,7 +122,7 @@ class Ctx:
         self.torch.cuda.synchronize()
         el = time.perf_counter() - t0
         if self.dist is not None:
-            el = max_over_ranks(el, self.dist, "cuda")
+            el = max_over_ranks(el, self.dist, "cpu" if self.shm else "cuda")
             self.dist.barrier()
         return el
 
@@ -314,7 +323,13 @@ def _run_sdp(ctx, model, steps, warmup, dist=None):
     import cosmo_jl_amd as cj
     cj.model.setup(model)
     if dist is not None and ctx.world > 1:
-        cj.model.setup_clique_sharding(model, dist)
+        if ctx.shm:
+            name = [("/cosmo_bench_%d" % os.getpid()) if ctx.rank == 0 else None]
+            dist.broadcast_object_list(name, src=0)
+            model.handle.comm_init_hostshm(ctx.rank, ctx.world, name[0])
+            model.handle.set_cone_shard(cj.partition_cones_contiguous(cj.cone_costs(model.sets), ctx.world))
+        else:
+            cj.model.setup_clique_sharding(model, dist)
     h = model.handle
     h.set_iterates(model.x, model.s, model.mu)
     h.admm_init()
@@ -472,6 +487,8 @@ def main():
                "data": "synthetic", "config": res.get("config", {}), "roofline": res.get("roofline")}
         out["config"]["kkt_solver"] = ("CG, literal cg! recurrence (reference algorithm)" if args.kkt == "cg" else
                                        "CG, single-reduction (Chronopoulos-Gear) recurrence -- OPT-IN variant, same operator / stopping rule")
+        if ctx.shm:
+            out["data"] = "synthetic; DRY RUN of the multi-rank path: all ranks share one GPU (COSMO_BENCH_TRANSPORT=shm), not a measurement"
         if "cpu_baseline" in res:
             out["cpu_baseline"] = res["cpu_baseline"]
         if extra:

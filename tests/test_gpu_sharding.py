@@ -171,3 +171,36 @@ def test_rccl_two_ranks_on_one_device_is_refused_or_identical(monkeypatch):
             assert int(z["transport"]) == 1 and int(z["exchanges"]) >= ITERS
             for key, val in (("x", ref.x), ("s", ref.s), ("y", ref.y)):
                 assert np.array_equal(z[key].view(np.int64), val.view(np.int64)), (r, key)
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("workload", ["cfg5", "cfg3"])
+def test_bench_multi_rank_entry_point_dry_run(workload):
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one rank per process), on ONE GPU: the dry-run
+    transport (COSMO_BENCH_TRANSPORT=shm: gloo barriers, host-staged clique exchange) exercises the rank bookkeeping, the sharded cfg5 /
+    cfg3 workloads, the MAX-over-ranks timing and the one JSON line of rank 0.  With real GPUs the same code runs over RCCL."""
+    env = dict(os.environ, COSMO_BENCH_TRANSPORT="shm", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "3", "--small", "--workload", workload]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=420)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                               # exactly one JSON line, from rank 0
+    import json
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 8 and out["warmup"] == 3 and out["value"] > 0 and out["higher_is_better"] is True
+    assert "DRY RUN" in out["data"]
+    if workload == "cfg5":
+        assert out["scaling"] == "strong"
+        comm = out["config"]["comm"]
+        assert comm["nranks"] == 2 and comm["transport"] == 2 and comm["exchanges"] >= 8 + 3
+        assert out["config"]["speedup_vs_single_gpu"] > 0 and "sharded over 2 ranks" in out["config"]["parallelism"]
+    else:
+        assert out["scaling"] == "weak" or out["scaling"] == "strong"
+        assert "sharded over 2 rank" in out["config"]["parallelism"]
