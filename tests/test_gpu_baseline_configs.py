@@ -167,7 +167,7 @@ def test_cfg5_assembled_operator_on_off_at_full_size(monkeypatch):
     assert np.max(np.abs(r1.s - r0.s)) <= 1e-7 * max(1.0, float(np.max(np.abs(r0.s))))
 
 
-@pytest.mark.parametrize("name", ["cfg4", "cfg5"])
+@pytest.mark.parametrize("name", ["cfg2", "cfg4", "cfg5"])
 def test_full_size_default_settings_run_matches_the_committed_oracle_result(name):
     """End to end with the reference's DEFAULT settings (eps 1e-5, adaptive rho, Ruiz scaling, CG tolerance 1 / k^1.5) at BASELINE size
     against tests/golden/baseline_convergent.json (tests/golden/make_fixtures_convergent.py: the CPU oracle on the same instance).
@@ -179,7 +179,7 @@ def test_full_size_default_settings_run_matches_the_committed_oracle_result(name
     if name not in fx:
         pytest.skip("no committed oracle result for %s" % name)
     ref = fx[name]
-    p = MK.problem(name)
+    p = cj.problems.sparse_box_qp() if name == "cfg2" else MK.problem(name)
     md = cj.Model(); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], cj.Settings(kkt_solver=cj.CGIndirectKKTSolver, max_iter=ref["max_iter"]))
     r = cj.optimize(md)
     assert r.status == ref["status"], (r.status, ref["status"])
@@ -188,4 +188,5 @@ def test_full_size_default_settings_run_matches_the_committed_oracle_result(name
     assert len(r.info.rho_updates) == len(ref["rho_updates"])
     assert np.allclose(r.info.rho_updates, ref["rho_updates"], rtol=1e-3)
     assert abs(np.linalg.norm(r.x) - ref["x_norm"]) <= 1e-4 * ref["x_norm"]
-    assert md.handle.polar_stats()["unverified"] == 0
+    if name != "cfg2":
+        assert md.handle.polar_stats()["unverified"] == 0
