@@ -42,6 +42,10 @@
 #include <algorithm>
 
 #define PK 16   // k panel
+#ifndef POLAR_PREFETCH_DEPTH
+#define POLAR_PREFETCH_DEPTH 2   // operand panels in flight per workgroup in the tile main loop (2 | 3).  3 was measured: no gain at d = 2000
+                                 // (167.8 vs 167.4 us per product), slower in the batched kernel (51.1 vs 47.5 us): profiles/r02_prefetch_depth.txt
+#endif
 #define PLD 80  // LDS row pitch in doubles
 
 struct PolarCone {
@@ -240,7 +244,7 @@ __device__ __forceinline__ void symm_mainloop(const real* __restrict__ A, const 
   }
   const real* ga = A + i0 + ((long long)grp + kb0) * PK * ld;        // group 1 starts at panel 1
   const real* gb = B + j0 + ((long long)grp + kb0) * PK * ld;
-  real2 r[2][2 * NL];
+  real2 r[POLAR_PREFETCH_DEPTH][2 * NL];
 #ifndef POLAR_LAB_KB
 #define POLAR_LAB_KB(k) (k)
 #define POLAR_LAB_SYNC() __syncthreads()
@@ -274,6 +278,27 @@ __device__ __forceinline__ void symm_mainloop(const real* __restrict__ A, const 
         _Pragma("unroll") for (int b = 0; b < NM; ++b) acc[a][b] = MFMA_REAL(av[a], bv[b], acc[a][b]);     \
     }                                                                                                     \
   }
+#if POLAR_PREFETCH_DEPTH == 3
+  // three panels in flight: at the top of step kb, LDS[kb & 1] holds panel kb, r[(kb + 1) % 3] and r[(kb + 2) % 3] hold panels kb + 1 and
+  // kb + 2 (requested two and one steps ago), panel kb + 3 is requested now -- two panels of matrix work cover a load's latency
+  P_LOAD(r[0], 0)
+  if (1 < nk) P_LOAD(r[1], 1)
+  if (2 < nk) P_LOAD(r[2], 2)
+  P_STORE(r[0], 0)
+  __syncthreads();
+  for (int kb0 = 0; kb0 < nk; kb0 += 6) {
+#pragma unroll
+    for (int st_ = 0; st_ < 6; ++st_) {                       // (not `u`: the panel macros use that name)
+      const int kb = kb0 + st_;
+      if (kb < nk) {
+        if (kb + 3 < nk) P_LOAD(r[st_ % 3], kb + 3)            // r[kb % 3] was stored to LDS one step ago: free
+        P_COMPUTE(st_ & 1)
+        if (kb + 1 < nk) P_STORE(r[(st_ + 1) % 3], (st_ + 1) & 1)
+        POLAR_LAB_SYNC();
+      }
+    }
+  }
+#else
   P_LOAD(r[0], 0)
   if (1 < nk) P_LOAD(r[1], 1)
   P_STORE(r[0], 0)
@@ -290,6 +315,7 @@ __device__ __forceinline__ void symm_mainloop(const real* __restrict__ A, const 
     if (kb + 2 < nk) P_STORE(r[0], 0)
     POLAR_LAB_SYNC();
   }
+#endif
 #undef P_LOAD
 #undef P_STORE
 #undef P_COMPUTE
