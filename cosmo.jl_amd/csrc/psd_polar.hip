@@ -83,6 +83,11 @@ static const real kPolarFinish[POLAR_NFIN][3] = {
     {1.875, -1.25, 0.375},                                            // Newton-Schulz   -> 1 +- 9.5e-6
     {1.875, -1.25, 0.375}};                                           //                 -> 1 +- 2.1e-15
 #define POLAR_RLIFT 3        // lifting steps of a fallback round (RLIFT + NFIN is even: the buffer parity is preserved)
+// Float32, large cones (d > 256): the last Newton-Schulz step (1 +- 9.5e-6 -> 1 +- 2e-15) is below the resolution of the element type and
+// of the verification threshold 8 d eps32 >= 1.2e-4, so the schedule stops after four finishing steps; the fallback rounds lift four
+// times (4 + 4 steps: even, like 3 + 5).  The batched path (d down to 17: threshold 8e-6) keeps all five.
+#define POLAR_NFIN_LARGE (REAL_IS_FLOAT ? 4 : POLAR_NFIN)
+#define POLAR_RLIFT_LARGE (REAL_IS_FLOAT ? 4 : POLAR_RLIFT)
 
 struct PolarPlan {
   std::vector<PolarCone> cones;
@@ -1094,12 +1099,12 @@ int32_t polar_enqueue_project(cosmo_hip_handle* h, real* s, int guard) {
       if (cn.d >= 1024 && k_main > 1) k_main -= 1;
     }
     for (int t = 0; t < k_main; ++t) step(kPolarLift, nullptr);
-    for (int t = 0; t < POLAR_NFIN; ++t) step(kPolarFinish[t], nullptr);
+    for (int t = 0; t < POLAR_NFIN_LARGE; ++t) step(kPolarFinish[t], nullptr);
     verify(0, nullptr);
     q->products_last_large = products;
     for (int r = 1; r <= q->max_rounds; ++r) {
-      for (int t = 0; t < POLAR_RLIFT; ++t) step(kPolarLift, &q->dev->gate);
-      for (int t = 0; t < POLAR_NFIN; ++t) step(kPolarFinish[t], &q->dev->gate);
+      for (int t = 0; t < POLAR_RLIFT_LARGE; ++t) step(kPolarLift, &q->dev->gate);
+      for (int t = 0; t < POLAR_NFIN_LARGE; ++t) step(kPolarFinish[t], &q->dev->gate);
       verify(r, &q->dev->gate);
     }
     const int gfin = std::min(cn.d, 1024);
