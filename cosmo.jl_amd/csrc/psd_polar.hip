@@ -435,9 +435,15 @@ __device__ __forceinline__ void symm_gemm_tile(const real* __restrict__ A, const
 #pragma unroll
     for (int b = 0; b < NM; ++b) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
   const int nk = (kext > 0 ? kext : ld) / PK / SK;   // panels per group (a multiple of 2: both groups run the same number of steps)
+#ifndef POLAR_LAB_NO_MAINLOOP      // lab: epilogue only
   symm_mainloop<TS, SK>(A, B, ld, i0, j0, qact, 0, nk, smem, acc);
+#endif
   symm_acc_to_lds<TS, SK>(acc, smem);
+#ifndef POLAR_LAB_NO_EPILOGUE      // lab: main loop only (one store keeps the accumulators alive)
   symm_store_from_lds<EPI, TS, SK>(Cin, C, ld, ti, tj, alpha, beta, smem);
+#else
+  if (threadIdx.x == 0) C[(long long)j0 * ld + i0] = smem[0];
+#endif
 }
 
 // one large cone: the grid walks its upper tiles
@@ -592,7 +598,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   const BatchCone bc = cones[td.x];
   const long long n2 = (long long)bc.ld * bc.ld;
   real* base = W + bc.woff;
-  symm_gemm_tile<EPI, TS, 1>(base + ia * n2, base + ib * n2, base + icin * n2, base + ic * n2, bc.ld, td.y, td.z, alpha, beta, smem,
+#ifdef POLAR_LAB_ALIAS_READS       // lab: every cone READS the first cone's buffers (operands L2-resident), writes its own result
+  const real* rbase = W;
+#else
+  const real* rbase = base;
+#endif
+  symm_gemm_tile<EPI, TS, 1>(rbase + ia * n2, rbase + ib * n2, rbase + icin * n2, base + ic * n2, bc.ld, td.y, td.z, alpha, beta, smem,
                              ((bc.d + 31) / 32) * 32);
 }
 
