@@ -118,6 +118,8 @@ struct PolarPlan {
   BatchCone* d_bcones = nullptr;
   int4* d_btiles = nullptr;   // tile descriptors of the cones with 64 x 64 tiles, then (from nbtiles on) of the cones with 96 x 96 tiles
   int nbtiles = 0, nbtiles96 = 0;
+  int batch_wave = 0;        // COSMO_HIP_POLAR_BATCH_WAVE=1: wave-per-tile product kernel (k_symm_gemm_batch_w) for the 64 x 64 tile class.  Bit-identical
+                             // to the workgroup-per-tile kernel; measured on BASELINE config 5: 50.7 vs 47.3 us per product, 150.2 vs 154.7 it/s => opt-in
   int batch_ts96 = 0;        // COSMO_HIP_POLAR_BATCH_TS96=1: cones whose side fits 96 / 192 take 96 x 96 tiles in a second launch per product.
                              // Measured on BASELINE config 5: SLOWER, 62.2 vs 47.0 us per product, 133.9 vs 155.2 it/s (two launch tails per
                              // product, two workgroups per CU for the 96-class) => opt-in; profiles/r02_batch_tile_classes.txt
@@ -607,6 +609,124 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
                              ((bc.d + 31) / 32) * 32);
 }
 
+// ---- wave-per-tile variant of the batched product (barrier-free, LDS-free main loop) ---------------------------------------
+// The workgroup-per-tile kernel spends a workgroup barrier, a register -> LDS copy of two operand panels and LDS fragment reads on every
+// 16-deep k-panel; with the short k-loops of the mid-size cones (9-13 panels) its main loops reach 0.67 of the sustained matrix rate and do
+// not speed up when the operands are L2-resident (profiles/r02_mfma_ceiling_and_gemm_lab.txt).  Here ONE WAVE owns one 64 x 64 tile:
+//   * the matrix-instruction operands are loaded straight from global memory in fragment layout -- lane l reads X[k0 + (l >> 4)][c0 + (l & 15)],
+//     four full 128-byte rows per instruction -- three k-steps ahead of their use (ring of four register sets), so the loop has no barrier and no LDS;
+//   * operand roles are swapped (first operand from B's panel, second from A's): a lane then holds C(j, i) with i = its low lane bits, i.e.
+//     the natural-orientation stores are four full 128-byte rows per instruction without a transposition;
+//   * the mirrored tile leaves through a 16 x 64 LDS strip, one 512-byte row per store;
+//   * the strictly-lower 16 x 16 blocks of a diagonal tile are skipped (a second, straight-line copy of the loop).
+// The k-sums run in the same order with the same instruction, so the results are bit-identical to k_symm_gemm_batch.
+// Measured (profiles/r02_batch_wave_kernel.txt): NOT faster -- 50.7 vs 47.3 us per product on BASELINE config 5.  Two main loops that share
+// neither barriers nor LDS staging land on the same time, and neither speeds up with L2-resident operands: the 64 x 64 tile itself (8 flop per
+// operand byte moved from L2 to the CU, 9 TB/s of L2 -> L1 traffic per product) is what bounds the batched path, not its pipeline.
+#define WT_DEPTH 4
+#define WT_SPITCH 66
+template <int EPI>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_symm_gemm_batch_w(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ gate,
+                                                         const int4* __restrict__ tiles, const BatchCone* __restrict__ cones, real* __restrict__ W,
+                                                         int ia, int ib, int icin, int ic, real alpha, real beta) {
+  if (guard && ctl->halt) return;
+  const int4 td = tiles[blockIdx.x];
+  if (td.x < 0) return;
+  if (gate && !gate[td.x]) return;
+  __shared__ real strip[16 * WT_SPITCH];
+  const BatchCone bc = cones[td.x];
+  const int ld = bc.ld;
+  const long long n2 = (long long)ld * ld;
+  real* base = W + bc.woff;
+  const real* __restrict__ A = base + ia * n2;
+  const real* __restrict__ B = base + ib * n2;
+  const real* __restrict__ Cin = base + icin * n2;
+  real* __restrict__ C = base + ic * n2;
+  const int ti = td.y, tj = td.z, i0 = ti * 64, j0 = tj * 64;
+  const int kext = ((bc.d + 31) / 32) * 32;
+  const bool diag = (ti == tj);
+  const int lane = threadIdx.x, l15 = lane & 15, lk = lane >> 4;
+  v4d acc[4][4];            // acc[a][b][q] = C(j = 16 a + ACC_ROW(lane, q), i = 16 b + l15)
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
+  const real* pa = A + (long long)lk * ld + i0 + l15;
+  const real* pb = B + (long long)lk * ld + j0 + l15;
+  const long long kstep = 4LL * ld;
+  const int nsteps = kext / 4;
+  real fi[WT_DEPTH][4], fj[WT_DEPTH][4];
+#define WT_LOAD(SLOT, S)                                                                  \
+  {                                                                                       \
+    const long long o_ = (long long)(S) * kstep;                                          \
+    _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) { fi[SLOT][t_] = pa[o_ + 16 * t_]; fj[SLOT][t_] = pb[o_ + 16 * t_]; } \
+  }
+#define WT_MMA(SLOT, DG)                                                                  \
+  {                                                                                       \
+    _Pragma("unroll") for (int a_ = 0; a_ < 4; ++a_)                                      \
+      _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_)                                    \
+        if (!(DG) || b_ <= a_) acc[a_][b_] = MFMA_REAL(fj[SLOT][a_], fi[SLOT][b_], acc[a_][b_]); \
+  }
+  // two straight-line loop bodies (compile-time block masks): all 16 blocks, or the 10 upper blocks of a diagonal tile.  Blocks beyond the
+  // cone's extent multiply zero operands (edge tiles): a per-block run-time mask costs a branch per matrix instruction and the schedule
+#define WT_LOOP(DG)                                                                       \
+  {                                                                                       \
+    int s0 = 0;                                                                           \
+    for (; s0 + 4 < nsteps; s0 += 4) {                                                    \
+      WT_LOAD(3, s0 + 3) WT_MMA(0, DG)                                                    \
+      WT_LOAD(0, s0 + 4) WT_MMA(1, DG)                                                    \
+      WT_LOAD(1, s0 + 5) WT_MMA(2, DG)                                                    \
+      WT_LOAD(2, s0 + 6) WT_MMA(3, DG)                                                    \
+    }                                                                                     \
+    WT_LOAD(3, s0 + 3) WT_MMA(0, DG) WT_MMA(1, DG) WT_MMA(2, DG) WT_MMA(3, DG)            \
+  }
+  // nsteps = kext / 4 is a multiple of 8: groups of four k-steps, three steps of loads in flight, no branch inside a group
+  WT_LOAD(0, 0) WT_LOAD(1, 1) WT_LOAD(2, 2)
+  if (diag) WT_LOOP(1) else WT_LOOP(0)
+#undef WT_LOOP
+#undef WT_LOAD
+#undef WT_MMA
+  // natural orientation: C(i, j) at (j0 + j) * ld + i0 + i; one instruction covers four full rows of 16 consecutive i
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    real cin[4][4];
+    if (EPI == 1) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int j = 16 * a + ACC_ROW(lane, q), i = 16 * b + l15;
+          cin[b][q] = (diag && i > j) ? R(0.0) : Cin[(long long)(j0 + j) * ld + i0 + i];
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int j = 16 * a + ACC_ROW(lane, q), i = 16 * b + l15;
+        real v = acc[a][b][q];
+        if (EPI == 1) v = alpha * v + beta * cin[b][q];
+        acc[a][b][q] = v;
+        if (!(diag && i > j)) C[(long long)(j0 + j) * ld + i0 + i] = v;
+      }
+  }
+  // mirrored orientation through the LDS strip: C(j, i) at (i0 + i) * ld + j0 + j, 64 consecutive j per row
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) strip[l15 * WT_SPITCH + 16 * a + ACC_ROW(lane, q)] = acc[a][b][q];
+    __syncthreads();
+#pragma unroll 4
+    for (int rr = 0; rr < 16; ++rr) {
+      const int i = 16 * b + rr, j = lane;
+      if (!(diag && i >= j)) C[(long long)(i0 + i) * ld + j0 + j] = strip[rr * WT_SPITCH + lane];
+    }
+    __syncthreads();
+  }
+}
+
 template <int EPI, int TS, int SK>
 static void launch_symm_gemm(cosmo_hip_handle* h, int guard, const int* gate, const real* A, const real* B, const real* Cin, real* C, int ld,
                              real alpha, real beta) {
@@ -879,6 +999,7 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
   if (const char* e = getenv("COSMO_HIP_POLAR_RESCALE")) q->rescale = atoi(e) ? 1 : 0;
   if (const char* e = getenv("COSMO_HIP_POLAR_STREAMK")) q->streamk = atoi(e) ? 1 : 0;
   if (const char* e = getenv("COSMO_HIP_POLAR_BATCH_TS96")) q->batch_ts96 = atoi(e) ? 1 : 0;
+  if (const char* e = getenv("COSMO_HIP_POLAR_BATCH_WAVE")) q->batch_wave = atoi(e) ? 1 : 0;
   if (const char* e = getenv("COSMO_HIP_POLAR_ROUNDS")) q->max_rounds = std::min(8, std::max(0, atoi(e)));
   HIPCHK(h, hipMalloc((void**)&q->dev, sizeof(PolarDev)));
   HIPCHK(h, hipMemset(q->dev, 0, sizeof(PolarDev)));
@@ -1013,7 +1134,9 @@ static void launch_bgemm(PolarPlan* q, hipStream_t st, const Ctl* ctl, int guard
   if (q->nbtiles96 > 0)
     hipLaunchKernelGGL((k_symm_gemm_batch<EPI, 2, 96>), dim3(q->nbtiles96), dim3(256), GemmCfg<96>::SMEM, st, ctl, guard, gate, q->d_btiles + q->nbtiles,
                        q->d_bcones, q->BW, ia, ib, icin, ic, alpha, beta);
-  if (q->nbtiles > 0) {
+  if (q->nbtiles > 0 && q->batch_wave) {
+    hipLaunchKernelGGL((k_symm_gemm_batch_w<EPI>), dim3(q->nbtiles), dim3(64), 0, st, ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW, ia, ib, icin, ic, alpha, beta);
+  } else if (q->nbtiles > 0) {
     if (q->batch_occ == 4)
       hipLaunchKernelGGL((k_symm_gemm_batch<EPI, 4, 64>), dim3(q->nbtiles), dim3(256), GemmCfg<64>::SMEM, st, ctl, guard, gate, q->d_btiles, q->d_bcones, q->BW,
                          ia, ib, icin, ic, alpha, beta);
