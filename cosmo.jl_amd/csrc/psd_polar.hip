@@ -118,6 +118,11 @@ struct PolarPlan {
   BatchCone* d_bcones = nullptr;
   int4* d_btiles = nullptr;   // tile descriptors of the cones with 64 x 64 tiles, then (from nbtiles on) of the cones with 96 x 96 tiles
   int nbtiles = 0, nbtiles96 = 0;
+  int speculate = 0;         // 0: after the main schedule the host reads the verification flag (one small synchronisation per projection) and enqueues a
+                             // fallback round only if it is needed; COSMO_HIP_POLAR_SPECULATE=1: both rounds are always enqueued behind device-side gates
+                             // (no host synchronisation inside a projection, 52 no-op launches).  Measured: cfg4 127.9 -> 129.0, cfg5 155.1 -> 157.7 it/s
+                             // without speculation (profiles/r02_fallback_speculation.txt)
+  int* gate_host = nullptr;  // pinned copy of PolarDev::gate for the non-speculative mode
   int batch_wave = 0;        // COSMO_HIP_POLAR_BATCH_WAVE=1: wave-per-tile product kernel (k_symm_gemm_batch_w) for the 64 x 64 tile class.  Bit-identical
                              // to the workgroup-per-tile kernel; measured on BASELINE config 5: 50.7 vs 47.3 us per product, 150.2 vs 154.7 it/s => opt-in
   int batch_ts96 = 0;        // COSMO_HIP_POLAR_BATCH_TS96=1: cones whose side fits 96 / 192 take 96 x 96 tiles in a second launch per product.
@@ -965,6 +970,7 @@ void polar_plan_destroy(cosmo_hip_handle* h) {
   if (q->W) (void)hipFree(q->W);
   if (q->parts) (void)hipFree(q->parts);
   if (q->nrm) (void)hipFree(q->nrm);
+  if (q->gate_host) (void)hipHostFree(q->gate_host);
   if (q->sk_scratch) (void)hipFree(q->sk_scratch);
   if (q->sk_sync) (void)hipFree(q->sk_sync);
   if (q->d_bcones) (void)hipFree(q->d_bcones);
@@ -1000,6 +1006,9 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
   if (const char* e = getenv("COSMO_HIP_POLAR_STREAMK")) q->streamk = atoi(e) ? 1 : 0;
   if (const char* e = getenv("COSMO_HIP_POLAR_BATCH_TS96")) q->batch_ts96 = atoi(e) ? 1 : 0;
   if (const char* e = getenv("COSMO_HIP_POLAR_BATCH_WAVE")) q->batch_wave = atoi(e) ? 1 : 0;
+  if (const char* e = getenv("COSMO_HIP_POLAR_SPECULATE")) q->speculate = atoi(e) ? 1 : 0;
+  HIPCHK(h, hipHostMalloc((void**)&q->gate_host, sizeof(int), hipHostMallocDefault));
+  *q->gate_host = 0;
   if (const char* e = getenv("COSMO_HIP_POLAR_ROUNDS")) q->max_rounds = std::min(8, std::max(0, atoi(e)));
   HIPCHK(h, hipMalloc((void**)&q->dev, sizeof(PolarDev)));
   HIPCHK(h, hipMemset(q->dev, 0, sizeof(PolarDev)));
@@ -1176,6 +1185,11 @@ int32_t polar_enqueue_project_batch(cosmo_hip_handle* h, real* s, int guard) {
   verify(0, nullptr);
   q->products_last_batch = products;
   for (int r = 1; r <= q->max_rounds; ++r) {                 // guarded fallback rounds (even number of steps: iu is preserved)
+    if (!q->speculate) {                                     // ask the device whether the last verification failed
+      HIPCHK(h, hipMemcpyAsync(q->gate_host, &q->dev->gate, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipStreamSynchronize(st));
+      if (!*q->gate_host) break;
+    }
     for (int t = 0; t < POLAR_RLIFT; ++t) step(kPolarLift, q->bgate);
     for (int t = 0; t < POLAR_NFIN; ++t) step(kPolarFinish[t], q->bgate);
     verify(r, q->bgate);
@@ -1237,6 +1251,11 @@ int32_t polar_enqueue_project(cosmo_hip_handle* h, real* s, int guard) {
     verify(0, nullptr);
     q->products_last_large = products;
     for (int r = 1; r <= q->max_rounds; ++r) {
+      if (!q->speculate) {
+        HIPCHK(h, hipMemcpyAsync(q->gate_host, &q->dev->gate, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        if (!*q->gate_host) break;
+      }
       for (int t = 0; t < POLAR_RLIFT_LARGE; ++t) step(kPolarLift, &q->dev->gate);
       for (int t = 0; t < POLAR_NFIN_LARGE; ++t) step(kPolarFinish[t], &q->dev->gate);
       verify(r, &q->dev->gate);
