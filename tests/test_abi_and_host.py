@@ -360,3 +360,31 @@ def test_scripts_compile():
     assert len(files) >= 10
     for f in files:
         py_compile.compile(f, doraise=True, cfile=os.path.join(os.environ.get("TMPDIR", "/tmp"), "cosmo_pyc_" + os.path.basename(f) + "c"))
+
+
+def test_committed_bench_line_follows_the_contract():
+    """The newest bench line kept under profiles/ (written by `python bench.py` on the MI355X) carries every field of the bench contract,
+    the roofline and cpu_baseline objects, and the extra workloads -- a guard against the JSON drifting while bench.py is edited on a
+    GPU-less host."""
+    import glob
+    import json
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_all_v*.json")), key=lambda f: (f.split("_bench_all_v")[0], int(f.split("_bench_all_v")[1].split(".")[0])))
+    assert files, "no committed bench line"
+    d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                     ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert key in d and isinstance(d[key], typ), key
+    assert "vs_baseline" in d and d["vs_baseline"] is None                 # BASELINE.md publishes no number for this metric
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["dtype"] == "f64" and "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in rf, key
+    assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0 < rf["frac"] < 1
+    cb = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cb, key
+    assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-3             # value = steps / elapsed, ms_per_step = elapsed / steps
+    assert set(d.get("extra", {})) == {"cfg3", "cfg4", "cfg5"}
+    for name, e in d["extra"].items():
+        assert "error" not in e and e["value"] > 0 and "roofline" in e and "cpu_baseline" in e, name
