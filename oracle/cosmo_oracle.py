@@ -143,10 +143,10 @@ def get_set_indices(cones: Sequence[Cone]):
 def populate_upper_triangle(x: np.ndarray, d: int) -> np.ndarray:
     """svec -> dense matrix with only the UPPER triangle defined (src/convexset.jl:432-442).
     Column-major upper triangle order, off-diagonals scaled by 1/sqrt(2)."""
-    X = np.zeros((d, d), order="F")
+    X = np.zeros((d, d), order="F", dtype=x.dtype)          # element type of the slice (COSMO.Model{T}: Float32 stays Float32)
     # k runs column by column: j = 0..d-1 outer, i = 0..j inner
     jj, ii = np.tril_indices(d)             # (jj>=ii) enumerates j outer, i inner == column-major upper
-    vals = x * (1.0 / math.sqrt(2.0))       # scaling_factor * x[k]   (:437)
+    vals = x * x.dtype.type(1.0 / math.sqrt(2.0))       # scaling_factor * x[k]   (:437)
     diag = ii == jj
     vals = np.where(diag, x, vals)          # A[j,j] = x[k]           (:440)
     X[ii, jj] = vals
@@ -157,7 +157,7 @@ def extract_upper_triangle(X: np.ndarray, x: np.ndarray) -> None:
     """src/convexset.jl:462-472."""
     d = X.shape[0]
     jj, ii = np.tril_indices(d)
-    vals = math.sqrt(2.0) * X[ii, jj]
+    vals = X.dtype.type(math.sqrt(2.0)) * X[ii, jj]
     diag = ii == jj
     x[:] = np.where(diag, X[ii, jj], vals)
 
@@ -197,15 +197,15 @@ def _psd_project_dense(X: np.ndarray):
     """`_project!` (src/convexset.jl:219-241): LAPACK dsyevr('V','A','U') + rank_k_update!.
     Only the upper triangle of X is read; returns (upper-triangular-valid result, nnz_lambda)."""
     d = X.shape[0]
-    w, Z, _m, _isuppz, info = _lapack.dsyevr(X, compute_v=1, range="A", lower=0, abstol=-1.0,
-                                             overwrite_a=0)
+    syevr = _lapack.ssyevr if X.dtype == np.float32 else _lapack.dsyevr          # LAPACK.syevr! dispatches on the element type (:163-189)
+    w, Z, _m, _isuppz, info = syevr(X, compute_v=1, range="A", lower=0, abstol=-1.0, overwrite_a=0)
     if info != 0:
-        raise RuntimeError("dsyevr failed: info=%d" % info)
+        raise RuntimeError("syevr failed: info=%d" % info)
     pos = w > 0                                  # src/convexset.jl:250
     nnz = int(pos.sum())
     Zs = np.array(Z, order="F", copy=True)
     Zs[:, pos] = Zs[:, pos] * np.sqrt(w[pos])    # :253
-    out = np.zeros((d, d), order="F")
+    out = np.zeros((d, d), order="F", dtype=X.dtype)
     if nnz > 0:
         V = Zs[:, d - nnz:]                      # :259 (assumes positives are trailing columns)
         out = np.asfortranarray(V @ V.T)         # syrk('U','N'): only the upper triangle is defined
@@ -227,15 +227,15 @@ def project_cone(x: np.ndarray, cone: Cone, info: Optional[dict] = None) -> None
         if x.size == 0:
             return
         t = x[0]
-        nx = float(np.linalg.norm(x[1:], 2))
+        nx = x.dtype.type(np.linalg.norm(x[1:], 2))          # norm in the element type of the slice
         if nx <= t:
             br = 0
         elif nx <= -t:
             x[:] = 0.0
             br = 1
         else:
-            x[0] = (nx + t) / 2.0
-            x[1:] = (nx + t) / (2.0 * nx) * x[1:]
+            x[0] = (nx + t) / x.dtype.type(2.0)
+            x[1:] = (nx + t) / (x.dtype.type(2.0) * nx) * x[1:]
             br = 2
         if info is not None:
             info.setdefault("soc_branch", []).append(br)
@@ -258,8 +258,8 @@ def project_cone(x: np.ndarray, cone: Cone, info: Optional[dict] = None) -> None
             d = cone.sqrt_dim
             X = x.reshape((d, d), order="F").copy(order="F")
             iu = np.triu_indices(d)
-            Xs = np.zeros((d, d), order="F")
-            Xs[iu] = (X[iu] + X.T[iu]) / 2.0      # symmetrize_upper! (src/algebra.jl:201-208)
+            Xs = np.zeros((d, d), order="F", dtype=x.dtype)
+            Xs[iu] = (X[iu] + X.T[iu]) / x.dtype.type(2.0)      # symmetrize_upper! (src/algebra.jl:201-208)
             Xp, nnz = _psd_project_dense(Xs)
             full = np.triu(Xp) + np.triu(Xp, 1).T  # mirror upper -> lower (:316-318)
             x[:] = full.reshape(-1, order="F")
