@@ -142,6 +142,9 @@ def test_psd_projection_float32(dims, kind):
     s = np.concatenate([cj.problems.svec(X) if kind == "tri" else X.reshape(-1, order="F") for X in mats]).astype(F32)
     ref = s.astype(np.float64); info = {}
     O.project(ref, util.oracle_cones(sets), info)                # LAPACK dsyevr on the Float32-rounded input
+    ref32 = s.copy(); info32 = {}
+    O.project(ref32, util.oracle_cones(sets), info32)            # the oracle in Float32 (ssyevr, float32 arithmetic): what COSMO.Model{Float32} computes
+    assert ref32.dtype == np.float32
     out, ranks, _ = h.project(s)
     assert out.dtype == np.float32
     off = 0
@@ -149,7 +152,10 @@ def test_psd_projection_float32(dims, kind):
         d = X.shape[0]
         err = np.linalg.norm(out[off:off + K.dim] - ref[off:off + K.dim])
         assert err <= 64 * d * EPS32 * np.linalg.norm(X), (d, err / (d * EPS32 * np.linalg.norm(X)))   # SURVEY 8c with eps(Float32)
+        err32 = np.linalg.norm(out[off:off + K.dim].astype(np.float64) - ref32[off:off + K.dim].astype(np.float64))
+        assert err32 <= 64 * d * EPS32 * np.linalg.norm(X), (d, err32 / (d * EPS32 * np.linalg.norm(X)))  # ... and against the Float32 oracle
         assert rk == k, (d, rk, k)                               # gapped spectrum: exact rank
+        assert info32["psd_rank"] == info["psd_rank"]
         if kind == "square":
             A = out[off:off + K.dim].reshape(d, d, order="F")
             assert np.array_equal(A, A.T)
