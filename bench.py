@@ -12,12 +12,15 @@ Workloads (--workload):
   cfg5  chordal-decomposed SDP n=50k, 400 PSD cliques d in [20,200] + ZeroSet / Nonnegatives
   all   (default at N=1) headline line = cfg2; cfg3 / cfg4 / cfg5 measured in the same run and reported under "extra"
 
-Multi-GPU (torch.distributed.run, one process per GPU, RCCL):
-  default at N>1 = cfg5 with the cliques SHARDED over the ranks (csrc/comm.hip: every rank projects its contiguous cone range,
-  one in-place broadcast group per iteration), "scaling": "strong" -- this is the configuration BASELINE.json asks to scale;
-  rank 0 also times the unsharded problem in the same run ("single_gpu_same_workload") so the speed-up is self-contained.
-  --workload cfg3 at N>1: the batch is sharded over the ranks (no collective), strong.  cfg2 / cfg4 at N>1: a single sparse QP /
-  a single cone does not shard (replicas only), every rank runs a replica, weak.
+Multi-GPU (`python bench.py --gpus N` re-launches itself under torch.distributed.run, one process per GPU, RCCL; a launch that
+already comes from torch.distributed.run / torchrun is used as it is):
+  headline line at EVERY N = cfg2, the metric configuration: a single sparse QP does not shard (replicas only), every rank
+  runs a replica, "scaling": "weak", value = N * steps / max-over-ranks time -- the same workload string at N = 1, 2, 4, 8.
+  extra.cfg5_sharded = ONE cfg5 problem with its cones (and, --shard rows, all their rows of A / s / mu / rho) sharded over the ranks,
+  "scaling": "strong", with rank 0's unsharded time of the same problem in the same run, the exchange volume per iteration, the
+  measured shardable share f of the 1-GPU iteration and the bound 1 / ((1 - f) + f / N) it implies.
+  extra.cfg3_sharded = the batch of 1024 SOCPs sharded over the ranks (no collective), strong.
+  --workload cfgK at N>1 makes that workload the headline instead (cfg5 / cfg3: sharded, strong; cfg2 / cfg4: replicas, weak).
 
 Output: ONE JSON line on rank 0 (the driver contract) with `roofline` for the dominant kernel of the headline workload and
 `cpu_baseline` (the restated CPU reference timed on a bounded sample, 1 thread and all host threads where LAPACK is involved).
@@ -99,6 +102,9 @@ class Ctx:
         self.shm = os.environ.get("COSMO_BENCH_TRANSPORT", "") == "shm"
         if self.shm:
             self.local_rank = 0
+        elif self.world > torch.cuda.device_count():
+            raise SystemExit("bench.py: %d ranks but %d visible GPU(s) -- one process per GPU (COSMO_BENCH_TRANSPORT=shm runs a functional "
+                             "dry run of the multi-rank path on one GPU)" % (self.world, torch.cuda.device_count()))
         torch.cuda.set_device(self.local_rank)
         if self.world > 1:
             import torch.distributed as dist
@@ -319,7 +325,7 @@ def bench_cfg3(ctx, args, steps, warmup):
 # ---------------------------------------------------------------------------------------------------------------------
 # cfg4 / cfg5: SDPs (matrix-sign projections on the fp64 matrix cores)
 # ---------------------------------------------------------------------------------------------------------------------
-def _run_sdp(ctx, model, steps, warmup, dist=None):
+def _run_sdp(ctx, model, steps, warmup, dist=None, shard="rows"):
     import cosmo_jl_amd as cj
     cj.model.setup(model)
     if dist is not None and ctx.world > 1:
@@ -327,7 +333,12 @@ def _run_sdp(ctx, model, steps, warmup, dist=None):
             name = [("/cosmo_bench_%d" % os.getpid()) if ctx.rank == 0 else None]
             dist.broadcast_object_list(name, src=0)
             model.handle.comm_init_hostshm(ctx.rank, ctx.world, name[0])
-            model.handle.set_cone_shard(cj.partition_cones_contiguous(cj.cone_costs(model.sets), ctx.world))
+            if shard == "rows":
+                model.handle.set_row_shard(cj.partition_cones_contiguous(cj.model.row_shard_costs(model.sets), ctx.world))
+            else:
+                model.handle.set_cone_shard(cj.partition_cones_contiguous(cj.cone_costs(model.sets), ctx.world))
+        elif shard == "rows":
+            cj.model.setup_row_sharding(model, dist)
         else:
             cj.model.setup_clique_sharding(model, dist)
     h = model.handle
@@ -335,12 +346,31 @@ def _run_sdp(ctx, model, steps, warmup, dist=None):
     h.admm_init()
     h.admm_iterate_checked(warmup)
     s0 = h.get_stats()
+    c0 = h.comm_stats_ex()
     elapsed = ctx.timed(lambda: h.admm_iterate_checked(steps))
     s1 = h.get_stats()
+    c1 = h.comm_stats_ex()
     assert s1["admm_iters"] - s0["admm_iters"] == steps
     kbar = (s1["kkt_iters_total"] - s0["kkt_iters_total"]) / max(1, s1["kkt_solves"] - s0["kkt_solves"])
+    h.bench_comm = dict(c1, bytes_per_iteration=round((c1["bytes"] - c0["bytes"]) / steps, 1),
+                        collectives_per_iteration=round((c1["collectives"] - c0["collectives"]) / steps, 3))
     return h, elapsed, kbar
 
+
+def shardable_share(h, iters=10):
+    """Measured split of the 1-GPU iteration by kernel class (HIP events around every loop kernel, exact-launch mode): which share of the
+    iteration shards with the cones (projections), which with the rows (k_z, rhs, A' y2, A x_tl / s_tl / w_s, primal check) and which is the
+    replicated n-side (CG, dual check).  Returns (f_cones, f_rows, seconds by class)."""
+    h.set_profiling(1)
+    h.admm_iterate_checked(iters)
+    kt = h.get_kernel_times()
+    h.set_profiling(0)
+    tot = sum(v[0] for v in kt.values())
+    if tot <= 0:
+        return None, None, {}
+    proj = sum(v[0] for k, v in kt.items() if k.startswith("proj_"))
+    rows = proj + sum(v[0] for k, v in kt.items() if k.startswith(("admm_z", "admm_x_rhs", "spmv_AT", "tail", "check_primal", "rho_apply")))
+    return proj / tot, rows / tot, {k: round(1e3 * v[0] / iters, 4) for k, v in kt.items()}
 
 
 def float32_extra(ctx, args, prob, st, steps, warmup):
@@ -396,9 +426,10 @@ def bench_cfg5(ctx, args, steps, warmup):
     kw = dict(ncliques=40, n_total=6000, n_zero=100, n_nonneg=500) if args.small else {}
     prob = cj.problems.chordal_sdp(**kw)
     st = fixed_work_settings(cj); st.device = ctx.local_rank
-    single = None
+    single, share = None, None
     if ctx.world > 1:
-        # self-contained speed-up: rank 0 times the UNSHARDED problem first (the other ranks wait at the barrier inside timed())
+        # self-contained speed-up: rank 0 times the UNSHARDED problem first (the other ranks wait at the barrier inside timed()), and measures
+        # which share of that iteration shards
         if ctx.rank == 0:
             m1 = cj.Model(); m1.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)
             cj.model.setup(m1)
@@ -407,29 +438,46 @@ def bench_cfg5(ctx, args, steps, warmup):
             ctx.torch.cuda.synchronize()
             t0 = time.perf_counter(); h1.admm_iterate_checked(steps); ctx.torch.cuda.synchronize()
             single = steps / (time.perf_counter() - t0)
+            share = shardable_share(h1)
             h1.close()
         ctx.barrier()
     model = cj.Model(); model.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)
-    h, elapsed, kbar = _run_sdp(ctx, model, steps, warmup, dist=ctx.dist)
+    h, elapsed, kbar = _run_sdp(ctx, model, steps, warmup, dist=ctx.dist, shard=args.shard)
     value = steps / elapsed                                                # ONE problem, all ranks work on it: strong scaling
     out = dict(value=value, ms_per_step=1e3 * elapsed / steps, steps=steps, warmup=warmup, scaling="strong")
     if ctx.rank != 0:
+        h.close()
         return out
     ps = h.polar_stats()
     dk = np.asarray(prob["clique_dims"], dtype=np.float64)
     useful = float(np.sum([psd_useful_flops(d) for d in dk]))
+    if ctx.world == 1:
+        par = "single GPU"
+    elif args.shard == "rows":
+        par = ("cones AND their rows of A / s / mu / rho sharded over %d ranks (contiguous cone ranges balanced by sum d^3 + 8 rows; n-side CG replicated on the "
+               "assembled operator; one RCCL all-reduce of an n-vector per iteration, one more per residual check; csrc/rowshard.hip)" % ctx.world)
+    else:
+        par = ("cliques sharded over %d ranks (contiguous cone ranges balanced by sum d^3; affine step replicated; one RCCL broadcast group of the "
+               "projected slices of s per iteration)" % ctx.world)
     out["config"] = {"workload": "cfg5: chordal-decomposed SDP n=%d m=%d nnz(A)=%d, %d PsdConeTriangle cliques d in [%d, %d] + ZeroSet(%d) + Nonnegatives(%d), "
                                  "CG indirect KKT" % (model.n, model.m, model.A.nnz, dk.size, dk.min(), dk.max(), prob["sets"][0].dim, prob["sets"][1].dim),
-                     "parallelism": ("cliques sharded over %d ranks (contiguous cone ranges balanced by sum d^3; affine step replicated; one RCCL broadcast group of the "
-                                     "projected slices of s per iteration)" % ctx.world) if ctx.world > 1 else "single GPU",
-                     "mean_cg_iters_per_admm_iter": round(kbar, 3), "comm": h.comm_stats(), "cg_persist": h.cg_persist_stats(), "cg_assembled_operator": h.fold_stats(),
+                     "parallelism": par,
+                     "mean_cg_iters_per_admm_iter": round(kbar, 3), "comm": h.bench_comm, "row_shard": h.row_shard_info(), "cg_persist": h.cg_persist_stats(),
+                     "cg_assembled_operator": h.fold_stats(),
                      "polar": {k: ps[k] for k in ("batch_cones", "schedule_steps", "products_last_batch", "fallback_rounds", "verified", "unverified", "err_max_e18")}}
     if single is not None:
         out["config"]["single_gpu_same_workload"] = round(single, 3)
         out["config"]["speedup_vs_single_gpu"] = round(value / single, 3)
+        if share is not None and share[0] is not None:
+            f = share[1] if args.shard == "rows" else share[0]
+            out["config"]["shardable_share_of_single_gpu_iteration"] = dict(
+                projections=round(share[0], 4), projections_and_row_kernels=round(share[1], 4), used=round(f, 4), ms_per_iteration_by_kernel_class=share[2],
+                predicted_speedup_bound=round(1.0 / ((1.0 - f) + f / ctx.world), 3),
+                note="f = share of the 1-GPU iteration (sum of kernel durations under exact-launch profiling) that shards; bound 1 / ((1 - f) + f / N) "
+                     "ignores the exchange and load imbalance; the replicated rest is the n-side CG + dual check")
     if ps["batch_cones"] > 0:
         t_prod, fl = h.time_psd_product(1, 20)
-        out["roofline"] = dict(bound="mfma", kernel="k_symm_gemm_batch<EPI> (one workgroup per (clique, upper 64x64 tile) of rank 0's cliques)",
+        out["roofline"] = dict(bound="mfma", kernel="k_symm_gemm_batch<EPI> (one workgroup per (clique, upper tile) of rank 0's cliques)",
                                achieved=round(fl / t_prod / 1e12, 2), peak=F64_MFMA_PEAK_TF, unit="TFLOP/s", frac=round(fl / t_prod / 1e12 / F64_MFMA_PEAK_TF, 4), traffic=None,
                                peak_sustained_measured=F64_MFMA_SUSTAINED_TF, frac_of_sustained=round(fl / t_prod / 1e12 / F64_MFMA_SUSTAINED_TF, 4),
                                flops_per_launch=fl, avg_launch_us=round(1e6 * t_prod, 2), launches_timed=20, products_per_projection=ps["products_last_batch"],
@@ -444,7 +492,21 @@ def bench_cfg5(ctx, args, steps, warmup):
 
 
 BENCH = {"cfg2": bench_cfg2, "cfg3": bench_cfg3, "cfg4": bench_cfg4, "cfg5": bench_cfg5}
-EXTRA_STEPS = {"cfg3": (100, 25), "cfg4": (40, 10), "cfg5": (40, 10)}      # (steps, warmup) of the extra workloads under --workload all
+EXTRA_STEPS = {"cfg3": (100, 25), "cfg4": (40, 10), "cfg5": (40, 10)}      # (steps, warmup) of the extra workloads
+
+
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` without a launcher: replace this process by `python -m torch.distributed.run --nproc-per-node N
+    bench.py <same arguments>` (one process per GPU, rendezvous on 127.0.0.1 at a free port).  Rank 0 of that job prints the line."""
+    import socket
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    os.environ.setdefault("OMP_NUM_THREADS", "4")
+    os.environ["COSMO_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execv(sys.executable, cmd)
 
 
 def main():
@@ -453,9 +515,13 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=25)
     ap.add_argument("--workload", choices=["all", "cfg2", "cfg3", "cfg4", "cfg5"], default=None,
-                    help="default: all at N=1 (headline cfg2 + extra), cfg5 clique-sharded at N>1")
+                    help="default: headline cfg2 at every N; extras cfg3 / cfg4 / cfg5 at N=1, cfg5_sharded / cfg3_sharded at N>1")
+    ap.add_argument("--shard", choices=["rows", "cones"], default="rows",
+                    help="cfg5 at N>1: rows = every rank owns its cones AND their rows of A / s / mu / rho, one all-reduce of an n-vector per "
+                         "iteration (SURVEY 8e option 2 on a replicated CG); cones = projections only, one broadcast group of s per iteration (option 1)")
     ap.add_argument("--small", action="store_true", help="reduced-size instances (debugging only; not the BASELINE workloads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="headline workload only")
     ap.add_argument("--no-float32", action="store_true", help="skip the Float32 (libcosmo_hip_f32.so) side numbers of cfg4 / cfg5")
     ap.add_argument("--cpu-sample-iters", type=int, default=5)
     ap.add_argument("--kkt", choices=["cg", "cg-sr"], default="cg",
@@ -464,22 +530,30 @@ def main():
                     help="cfg2: synchronise after every Krylov iteration (rocprofv3 runs: every launch does full work)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args.gpus)                         # does not return
     ctx = Ctx()
+    if ctx.world != max(args.gpus, 1) and ctx.rank == 0:
+        print("bench.py: --gpus %d but the launcher started %d rank(s); reporting n_gpus = %d" % (args.gpus, ctx.world, ctx.world), file=sys.stderr)
     KKT_CHOICE["name"] = args.kkt
     import cosmo_jl_amd as cj  # noqa: F401
-    workload = args.workload or ("all" if ctx.world == 1 else "cfg5")
+    workload = args.workload or "all"
     head = "cfg2" if workload == "all" else workload
     res = BENCH[head](ctx, args, args.steps, args.warmup)
     extra = {}
-    if workload == "all":
-        for name in ("cfg3", "cfg4", "cfg5"):
+    if workload == "all" and not args.no_extra:
+        # N = 1: the other three BASELINE configurations on the one GPU.  N > 1: the two configurations that shard, strong scaling.
+        names = ("cfg3", "cfg4", "cfg5") if ctx.world == 1 else ("cfg5", "cfg3")
+        for name in names:
+            key = name if ctx.world == 1 else name + "_sharded"
             try:
                 k, w = EXTRA_STEPS[name]
                 r = BENCH[name](ctx, args, k, w)
                 r["value"] = round(r["value"], 3); r["ms_per_step"] = round(r["ms_per_step"], 6); r["unit"] = "ADMM iterations/s"
-                extra[name] = r
+                r["n_gpus"] = ctx.world
+                extra[key] = r
             except Exception as e:                                  # an extra workload must not take the headline line down
-                extra[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                extra[key] = {"error": "%s: %s" % (type(e).__name__, e)}
     out = None
     if ctx.rank == 0:
         out = {"metric": METRIC, "value": round(res["value"], 3), "unit": "ADMM iterations/s", "n_gpus": ctx.world, "steps": res["steps"], "warmup": res["warmup"],
@@ -487,6 +561,8 @@ def main():
                "data": "synthetic", "config": res.get("config", {}), "roofline": res.get("roofline")}
         out["config"]["kkt_solver"] = ("CG, literal cg! recurrence (reference algorithm)" if args.kkt == "cg" else
                                        "CG, single-reduction (Chronopoulos-Gear) recurrence -- OPT-IN variant, same operator / stopping rule")
+        out["config"]["launch"] = ("self-launched torch.distributed.run" if os.environ.get("COSMO_BENCH_SELF_LAUNCHED") else
+                                   "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "single process")
         if ctx.shm:
             out["data"] = "synthetic; DRY RUN of the multi-rank path: all ranks share one GPU (COSMO_BENCH_TRANSPORT=shm), not a measurement"
         if "cpu_baseline" in res:

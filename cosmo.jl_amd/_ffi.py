@@ -113,6 +113,9 @@ SIGNATURES = {
     "cosmo_hip_comm_init_hostshm": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p]),
     "cosmo_hip_comm_stats": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_set_cone_ownership": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int64]),
+    "cosmo_hip_set_row_shard": (C.c_int32, [C.c_void_p, _PI64]),
+    "cosmo_hip_row_shard_info": (C.c_int32, [C.c_void_p, _PI64]),
+    "cosmo_hip_comm_stats_ex": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_batch_create": (C.c_int32, [C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_int64, C.c_int64]),
     "cosmo_hip_batch_destroy": (C.c_int32, [C.c_void_p]),
     "cosmo_hip_batch_last_error": (C.c_char_p, [C.c_void_p]),
@@ -457,6 +460,23 @@ class Handle:
         out = np.zeros(4, dtype=np.int64)
         self._chk(self.lib.cosmo_hip_comm_stats(self._h, out.ctypes.data_as(_PI64)))
         return dict(zip(["nranks", "rank", "exchanges", "transport"], out.tolist()))
+
+    def set_row_shard(self, first_cone):
+        """Row sharding (csrc/rowshard.hip): this rank keeps the cones first_cone[rank] <= k < first_cone[rank+1] and their rows."""
+        fc = np.ascontiguousarray(first_cone, dtype=np.int64)
+        self._chk(self.lib.cosmo_hip_set_row_shard(self._h, fc.ctypes.data_as(_PI64)))
+
+    def row_shard_info(self):
+        out = np.zeros(6, dtype=np.int64)
+        self._chk(self.lib.cosmo_hip_row_shard_info(self._h, out.ctypes.data_as(_PI64)))
+        return dict(zip(["row_lo", "row_hi", "m_global", "nnz_A_local", "cones_local", "first_cone"], out.tolist()))
+
+    def comm_stats_ex(self):
+        out = np.zeros(8, dtype=np.int64)
+        self._chk(self.lib.cosmo_hip_comm_stats_ex(self._h, out.ctypes.data_as(_PI64)))
+        d = dict(zip(["nranks", "rank", "collectives", "transport", "mode", "bytes", "allreduces", "allreduce_elems"], out.tolist()))
+        d["mode"] = {0: "none", 1: "cones", 2: "rows"}[d["mode"]]
+        return d
 
     def set_profiling(self, on):
         self._chk(self.lib.cosmo_hip_set_profiling(self._h, int(on)))

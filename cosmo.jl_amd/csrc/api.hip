@@ -259,6 +259,7 @@ extern "C" int32_t cosmo_hip_destroy(cosmo_hip_handle* h) {
   pcg_free(h);
   sr_free(h);
   (void)cosmo_hip_comm_destroy(h);
+  rs_free(h);
   aa_free(h);
   free_vectors(h);
   free_cones(h);
@@ -285,6 +286,7 @@ extern "C" int32_t cosmo_hip_set_problem(cosmo_hip_handle* h, int64_t n, int64_t
                                          const int64_t* P_rowval, const real* P_nzval, const int64_t* A_colptr,
                                          const int64_t* A_rowval, const real* A_nzval, const real* q, const real* b) {
   ENTER(h);
+  if (h->row_shard) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "set_problem: not available on a row-sharded handle");
   if (n < 0 || m < 0 || n + m >= 2147483647LL) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "n, m out of int32 range");
   if (!P_colptr || !A_colptr || (n > 0 && !q) || (m > 0 && !b)) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "null pointer");
   h->n = n; h->m = m;
@@ -399,6 +401,7 @@ extern "C" int32_t cosmo_hip_set_cones(cosmo_hip_handle* h, int64_t ncones, cons
 extern "C" int32_t cosmo_hip_set_cones_ex(cosmo_hip_handle* h, int64_t ncones, const int32_t* type, const int64_t* dim,
                                           const real* box_l, const real* box_u, const real* cone_param) {
   ENTER(h);
+  if (h->row_shard) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "set_cones: not available on a row-sharded handle");
   if (!h->have_problem) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_problem must be called before set_cones");
   if (ncones < 0 || (ncones > 0 && (!type || !dim))) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "bad cone table");
   free_cones(h);
@@ -481,9 +484,10 @@ void free_op_split(cosmo_hip_handle* h) {
   h->op_split = false; h->op_nsingle = 0;
 }
 
-int32_t build_op_split(cosmo_hip_handle* h) {
+// force: build the split for ANY A (row-sharded runs need a reduced operator that does not depend on h->A, which becomes a row slice)
+int32_t build_op_split(cosmo_hip_handle* h, bool force) {
   free_op_split(h);
-  if (const char* e = getenv("COSMO_HIP_OP_SPLIT")) if (e[0] == '0') return COSMO_HIP_OK;
+  if (const char* e = getenv("COSMO_HIP_OP_SPLIT")) if (e[0] == '0' && !force) return COSMO_HIP_OK;
   if (h->prm.kkt_kind != COSMO_HIP_KKT_CG) return COSMO_HIP_OK;
   const long long n = h->n, m = h->m, nnzA = h->A.nnz, nnzP = h->P.nnz;
   if (m == 0 || nnzA == 0) return COSMO_HIP_OK;
@@ -494,7 +498,7 @@ int32_t build_op_split(cosmo_hip_handle* h) {
   if (nnzP) { CHK(d2h(h, pcol.data(), h->P.col, (size_t)nnzP)); CHK(d2h(h, pval.data(), h->P.val, (size_t)nnzP)); }
   long long nsingle = 0;
   for (long long i = 0; i < m; ++i) if (arp[i + 1] - arp[i] == 1) ++nsingle;
-  if (nsingle * 2 < nnzA) return COSMO_HIP_OK;
+  if (nsingle * 2 < nnzA && !force) return COSMO_HIP_OK;
   // Am: rows with >= 2 nonzeros, compact
   HostCsr Am, AmT, PTm;
   std::vector<int> mrow;
@@ -550,6 +554,7 @@ int32_t build_op_split(cosmo_hip_handle* h) {
 
 extern "C" int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_params* p, const real* rho_vec) {
   ENTER(h);
+  if (h->row_shard) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "set_params: not available on a row-sharded handle");
   if (!p) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "null params");
   if (!h->have_cones) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_cones must be called before set_params");
   if (p->kkt_kind < COSMO_HIP_KKT_CG || p->kkt_kind > COSMO_HIP_KKT_CG_SR) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "bad kkt_kind");
@@ -594,6 +599,7 @@ extern "C" int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_par
 
 extern "C" int32_t cosmo_hip_update_rho(cosmo_hip_handle* h, const real* rho_vec) {
   ENTER(h);
+  if (h->row_shard) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "update_rho: not available on a row-sharded handle");
   if (!h->have_params || !rho_vec) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "update_rho: not set up");
   CHK(h2d(h, h->rho, rho_vec, (size_t)h->m));
   return refresh_op_split(h);
@@ -608,6 +614,7 @@ static int32_t upload_or_ones(cosmo_hip_handle* h, real* dst, const real* src, s
 extern "C" int32_t cosmo_hip_set_scaling_full(cosmo_hip_handle* h, const real* D, const real* Dinv, const real* E, const real* Einv,
                                               double c, double cinv) {
   ENTER(h);
+  if (h->row_shard) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "set_scaling: not available on a row-sharded handle");
   if (!h->have_problem) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_problem first");
   CHK(upload_or_ones(h, h->Dinv, Dinv, (size_t)h->n)); CHK(upload_or_ones(h, h->Einv, Einv, (size_t)h->m));
   CHK(upload_or_ones(h, h->Dscale, D, (size_t)h->n)); CHK(upload_or_ones(h, h->Escale, E, (size_t)h->m));
@@ -630,6 +637,7 @@ extern "C" int32_t cosmo_hip_set_scaling(cosmo_hip_handle* h, const real* Dinv, 
 extern "C" int32_t cosmo_hip_update_qb(cosmo_hip_handle* h, const real* q, const real* b) {
   ENTER(h);
   if (!h->have_problem) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_problem first");
+  if (b && h->row_shard) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "update_qb(b): not available on a row-sharded handle");
   if (q) CHK(h2d(h, h->q, q, (size_t)h->n));
   if (b) {
     CHK(h2d(h, h->b, b, (size_t)h->m));
@@ -643,11 +651,13 @@ extern "C" int32_t cosmo_hip_update_qb(cosmo_hip_handle* h, const real* q, const
 
 extern "C" int32_t cosmo_hip_get_rho_classes(cosmo_hip_handle* h, int32_t* cls) {
   ENTER(h);
+  if (h->row_shard) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "get_rho_classes: not available on a row-sharded handle");
   if (!h->have_cones || !cls) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "get_rho_classes: not set up");
   return d2h(h, cls, h->rho_cls, (size_t)h->m);
 }
 extern "C" int32_t cosmo_hip_get_rho_vec(cosmo_hip_handle* h, real* rho_vec) {
   ENTER(h);
+  if (h->row_shard) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "get_rho_vec: not available on a row-sharded handle");
   if (!h->have_params || !rho_vec) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "get_rho_vec: not set up");
   return d2h(h, rho_vec, h->rho, (size_t)h->m);
 }
@@ -663,6 +673,7 @@ int32_t sync_ctl(cosmo_hip_handle* h) {
 
 extern "C" int32_t cosmo_hip_spmv(cosmo_hip_handle* h, int32_t which, real* y, const real* x) {
   ENTER(h);
+  if (h->row_shard) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "spmv: not available on a row-sharded handle");
   if (!h->have_problem || !x || !y) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "spmv: not set up");
   const CsrDev* M = which == COSMO_HIP_MAT_A ? &h->A : which == COSMO_HIP_MAT_AT ? &h->AT : which == COSMO_HIP_MAT_P ? &h->P : nullptr;
   if (!M) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "spmv: bad matrix id");
@@ -679,6 +690,7 @@ extern "C" int32_t cosmo_hip_spmv(cosmo_hip_handle* h, int32_t which, real* y, c
 
 extern "C" int32_t cosmo_hip_project(cosmo_hip_handle* h, real* s, int64_t* psd_rank_out, int32_t* soc_branch_out) {
   ENTER(h);
+  if (h->row_shard) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "project: not available on a row-sharded handle");
   if (!h->have_cones || (!s && h->m > 0)) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "project: not set up");
   CHK(h2d(h, h->io, s, (size_t)h->m));
   CHK(launch_project_simple_inplace(h, h->io));
@@ -740,6 +752,7 @@ static int32_t maybe_infeas_check(cosmo_hip_handle* h, long long it) {
 
 extern "C" int32_t cosmo_hip_kkt_solve(cosmo_hip_handle* h, real* lhs, const real* rhs, int64_t* kkt_iters_out) {
   ENTER(h);
+  if (h->row_shard) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "kkt_solve: not available on a row-sharded handle");
   if (!h->have_params || !lhs || !rhs) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "kkt_solve: not set up");
   CHK(h2d(h, h->ls_x, rhs, (size_t)h->n));
   CHK(h2d(h, h->ls_s, rhs + h->n, (size_t)h->m));
@@ -792,8 +805,10 @@ extern "C" int32_t cosmo_hip_set_iterates(cosmo_hip_handle* h, const real* x0, c
   ENTER(h);
   if (!h->have_params) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_iterates: set_params first");
   const long long n = h->n, m = h->m;
-  // stage the three vectors in scratch buffers that the init step overwrites anyway
+  // stage the three vectors in scratch buffers that the init step overwrites anyway (row-sharded: s0 / mu0 are the GLOBAL vectors, this
+  // rank takes its slice)
   const real *dx = nullptr, *ds = nullptr, *dm = nullptr;
+  if (h->row_shard) { if (s0) s0 += h->row_lo; if (mu0) mu0 += h->row_lo; }
   if (x0) { CHK(h2d(h, h->ls_x, x0, (size_t)n)); dx = h->ls_x; }
   if (s0) { CHK(h2d(h, h->ls_s, s0, (size_t)m)); ds = h->ls_s; }
   if (mu0) { CHK(h2d(h, h->tmp_m, mu0, (size_t)m)); dm = h->tmp_m; }
@@ -1162,6 +1177,7 @@ extern "C" int32_t cosmo_hip_optimize(cosmo_hip_handle* h, cosmo_hip_result* res
 extern "C" int32_t cosmo_hip_get_iterates(cosmo_hip_handle* h, real* w, real* w_prev, real* s, real* mu) {
   ENTER(h);
   if (!h->have_iterates) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "get_iterates: set_iterates first");
+  if (h->row_shard) return rs_get_iterates(h, w, w_prev, s, mu);      // every rank receives the GLOBAL vectors (all-gather of the row slices)
   const size_t N = (size_t)(h->n + h->m);
   if (mu) { CHK(launch_recover_mu(h)); CHK(d2h(h, mu, h->mu, (size_t)h->m)); }
   if (w) CHK(d2h(h, w, h->w, N));
@@ -1192,6 +1208,7 @@ extern "C" int32_t cosmo_hip_cg_persist_stats(cosmo_hip_handle* h, int64_t out[8
 
 extern "C" int32_t cosmo_hip_get_kkt_solution(cosmo_hip_handle* h, real* sol) {
   ENTER(h);
+  if (h->row_shard) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "get_kkt_solution: not available on a row-sharded handle");
   if (!h->have_params || !sol) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "get_kkt_solution: not set up");
   CHK(d2h(h, sol, h->x_tl, (size_t)h->n));
   CHK(d2h(h, sol + h->n, h->nu, (size_t)h->m));

@@ -290,9 +290,9 @@ int32_t fold_enqueue_start(cosmo_hip_handle* h, int guard, real tol_k) {
   FoldPlan* f = (FoldPlan*)h->fold;
   prof_begin(h, KC_OP_APPLY);
   hipLaunchKernelGGL(k_fold_start, dim3(f->M.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, view_of(f->M), h->x_tl, h->rhs, h->r,
-                     (real2*)h->cg_ru, PARTS(h, SLOT_RR), PARTS(h, SLOT_BB), h->AT.grid, tol_k);
+                     (real2*)h->cg_ru, PARTS(h, SLOT_RR), PARTS(h, SLOT_BB), h->n_bb, tol_k);
   prof_end(h);
-  h->spmv_calls[0] += 1; h->spmv_calls[1] += 1; h->spmv_calls[2] += 1;     // the reference's multiplication count (reduced_mul! = A, A', P)
+  h->spmv_calls[0] += 1; h->spmv_calls[1] += 2; h->spmv_calls[2] += 1;     // the reference's multiplication count (A' y2 of the rhs + reduced_mul! = A, A', P)
   HIPCHK(h, hipGetLastError());
   return COSMO_HIP_OK;
 }

@@ -20,6 +20,7 @@
 #include <sys/stat.h>
 #include <time.h>
 #include <unistd.h>
+#include <algorithm>
 #include <atomic>
 #include "internal.h"
 
@@ -76,7 +77,8 @@ struct ShmSeg {
   std::atomic<int> arrive;     // sense-reversing barrier
   std::atomic<int> gen;
   int flag[COSMO_SHM_MAX_RANKS];
-  long long capacity;          // doubles in data[]
+  double hvals[COSMO_SHM_MAX_RANKS][8];   // comm_allreduce_host
+  long long capacity;          // reals in data[]
   real data[1];
 };
 
@@ -91,7 +93,13 @@ struct CommState {
   size_t shm_bytes = 0;
   std::string shm_name;
   long long exchanges = 0;             // exchange steps executed with nranks > 1 (cosmo_hip_comm_stats)
+  long long bytes = 0;                 // payload bytes this rank contributed to / received from collectives of the loop
+  double* d_hv = nullptr;              // 16 doubles: send / receive buffer of comm_allreduce_host
+  std::vector<real> hsum;              // host-staged all-reduce: the summed vector
 };
+
+int comm_nranks(const cosmo_hip_handle* h) { return h->comm ? ((const CommState*)h->comm)->nranks : 1; }
+int comm_rank(const cosmo_hip_handle* h) { return h->comm ? ((const CommState*)h->comm)->rank : 0; }
 
 static int32_t shm_barrier(cosmo_hip_handle* h, CommState* c) {
   ShmSeg* g = c->shm;
@@ -127,6 +135,7 @@ extern "C" int32_t cosmo_hip_comm_destroy(cosmo_hip_handle* h) {
   if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
   if (c->shm) { (void)munmap(c->shm, c->shm_bytes); if (c->rank == 0) (void)shm_unlink(c->shm_name.c_str()); }
   if (c->d_flag) (void)hipFree(c->d_flag);
+  if (c->d_hv) (void)hipFree(c->d_hv);
   delete c;
   h->comm = nullptr;
   h->cone_lo = 0; h->cone_hi = -1;
@@ -158,7 +167,8 @@ extern "C" int32_t cosmo_hip_comm_init_hostshm(cosmo_hip_handle* h, int32_t rank
   (void)cosmo_hip_comm_destroy(h);
   CommState* c = new CommState();
   c->rank = rank; c->nranks = nranks; c->shm_name = name;
-  const long long cap = h->m > 0 ? h->m : 1;
+  // room for a full-length row vector (all-gather of slices) and for nranks partial n-vectors (+ 2 nranks scalars) of the all-reduce
+  const long long cap = std::max<long long>(std::max<long long>(h->m, 1), (long long)nranks * (h->n + 2LL * nranks + 8));
   c->shm_bytes = sizeof(ShmSeg) + sizeof(real) * (size_t)cap;
   int fd = -1;
   if (rank == 0) {
@@ -192,25 +202,52 @@ extern "C" int32_t cosmo_hip_comm_stats(cosmo_hip_handle* h, int64_t out[4]) {
   return COSMO_HIP_OK;
 }
 
+// out = {nranks, rank, collectives of the loop executed with nranks > 1, transport, mode (0 none, 1 cone-sharded projections, 2 row-sharded),
+//        payload bytes of those collectives (this rank's view), all-reduces of n-vectors, elements per all-reduce (last)}
+extern "C" int32_t cosmo_hip_comm_stats_ex(cosmo_hip_handle* h, int64_t out[8]) {
+  if (!h || !out) return COSMO_HIP_ERR_INVALID;
+  for (int i = 0; i < 8; ++i) out[i] = 0;
+  out[0] = 1;
+  if (!h->comm) return COSMO_HIP_OK;
+  const CommState* c = (const CommState*)h->comm;
+  out[0] = c->nranks; out[1] = c->rank; out[2] = c->exchanges; out[3] = c->shm ? 2 : 1;
+  out[4] = h->row_shard ? 2 : (c->first_cone.empty() ? 0 : 1);
+  out[5] = c->bytes; out[6] = h->rs_allreduces; out[7] = h->rs_allreduce_elems;
+  return COSMO_HIP_OK;
+}
+
 // first_cone: nranks+1 non-decreasing cone indices, first_cone[0] = 0, first_cone[nranks] = ncones.  Rank r projects the
 // SOC / PSD cones first_cone[r] <= k < first_cone[r+1]; Zero / Nonnegatives / Box rows are projected by everyone (they are
 // part of the elementwise copy kernel).  Must be called after cosmo_hip_set_cones (rebuilds the SOC table and PSD plan).
 int32_t rebuild_cone_plans(cosmo_hip_handle* h);   // api.hip
-extern "C" int32_t cosmo_hip_set_cone_shard(cosmo_hip_handle* h, const int64_t* first_cone) {
-  if (!h || !first_cone) return COSMO_HIP_ERR_INVALID;
-  if (!h->comm) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_cone_shard: comm_init first");
-  if (!h->have_cones) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_cone_shard: set_cones first");
+// boundaries -> CommState (first_cone, row_lo / row_hi of every rank), validated against the composite set currently installed
+int32_t comm_set_partition(cosmo_hip_handle* h, const int64_t* first_cone, const char* who) {
+  if (!h->comm) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "%s: comm_init first", who);
+  if (!h->have_cones) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "%s: set_cones first", who);
   CommState* c = (CommState*)h->comm;
   const long long nc = (long long)h->cones.type.size();
-  if (first_cone[0] != 0 || first_cone[c->nranks] != nc) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_cone_shard: boundaries must span all cones");
+  if (first_cone[0] != 0 || first_cone[c->nranks] != nc) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "%s: boundaries must span all cones", who);
   c->first_cone.assign(first_cone, first_cone + c->nranks + 1);
   c->row_lo.assign(c->nranks, 0); c->row_hi.assign(c->nranks, 0);
   for (int r = 0; r < c->nranks; ++r) {
-    if (first_cone[r + 1] < first_cone[r]) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_cone_shard: boundaries must be non-decreasing");
+    if (first_cone[r + 1] < first_cone[r]) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "%s: boundaries must be non-decreasing", who);
     const long long a = first_cone[r], b = first_cone[r + 1];
     c->row_lo[r] = (a < nc) ? h->cones.off[a] : h->m;
     c->row_hi[r] = (b < nc) ? h->cones.off[b] : h->m;
   }
+  return COSMO_HIP_OK;
+}
+void comm_my_range(const cosmo_hip_handle* h, long long* cone_lo, long long* cone_hi, long long* row_lo, long long* row_hi) {
+  const CommState* c = (const CommState*)h->comm;
+  *cone_lo = c->first_cone[c->rank]; *cone_hi = c->first_cone[c->rank + 1];
+  *row_lo = c->row_lo[c->rank]; *row_hi = c->row_hi[c->rank];
+}
+
+extern "C" int32_t cosmo_hip_set_cone_shard(cosmo_hip_handle* h, const int64_t* first_cone) {
+  if (!h || !first_cone) return COSMO_HIP_ERR_INVALID;
+  if (h->row_shard) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_cone_shard: the handle is row-sharded");
+  CHK(comm_set_partition(h, first_cone, "set_cone_shard"));
+  CommState* c = (CommState*)h->comm;
   h->cone_lo = first_cone[c->rank];
   h->cone_hi = first_cone[c->rank + 1];
   return rebuild_cone_plans(h);
@@ -227,12 +264,14 @@ extern "C" int32_t cosmo_hip_set_cone_ownership(cosmo_hip_handle* h, int64_t con
   return rebuild_cone_plans(h);
 }
 
-// the one exchange step: every owner broadcasts its slice of s in place (enqueued on the handle's stream)
-int32_t comm_enqueue_exchange(cosmo_hip_handle* h, real* s) {
+// in-place all-gather of a full-length (m_g) row vector: every owner broadcasts its slice (enqueued on the handle's stream)
+int32_t comm_allgather_rows(cosmo_hip_handle* h, real* s) {
   if (!h->comm) return COSMO_HIP_OK;
   CommState* c = (CommState*)h->comm;
   if (c->nranks == 1 || c->first_cone.empty()) return COSMO_HIP_OK;
-  c->exchanges += 1;
+  long long total = 0;
+  for (int r = 0; r < c->nranks; ++r) total += c->row_hi[r] - c->row_lo[r];
+  c->bytes += (long long)sizeof(real) * total;
   if (c->shm) {
     // host-staged: owner slice -> segment, barrier, the other ranks' slices <- segment, barrier (the segment is reused next time)
     const long long lo = c->row_lo[c->rank], hi = c->row_hi[c->rank];
@@ -255,6 +294,69 @@ int32_t comm_enqueue_exchange(cosmo_hip_handle* h, real* s) {
     NCHK(h, g_rccl.Broadcast(s + c->row_lo[r], s + c->row_lo[r], (size_t)cnt, NCCL_REAL, r, c->comm, h->stream));
   }
   NCHK(h, g_rccl.GroupEnd());
+  return COSMO_HIP_OK;
+}
+
+// clique sharding (option 1): the one exchange step of the iteration.  Row-sharded handles (option 2) never exchange s.
+int32_t comm_enqueue_exchange(cosmo_hip_handle* h, real* s) {
+  if (!h->comm || h->row_shard) return COSMO_HIP_OK;
+  CommState* c = (CommState*)h->comm;
+  if (c->nranks == 1 || c->first_cone.empty()) return COSMO_HIP_OK;
+  c->exchanges += 1;
+  return comm_allgather_rows(h, s);
+}
+
+// In-place sum over the ranks of `count` reals at `buf` (device), enqueued on the handle's stream.  Every rank receives the SAME bits:
+// RCCL reduces every element along one fixed path and distributes the result; the host-staged transport adds the ranks' vectors in
+// rank order on every rank.  (ncclSum = 0.)
+int32_t comm_allreduce_sum(cosmo_hip_handle* h, real* buf, size_t count) {
+  if (!h->comm || count == 0) return COSMO_HIP_OK;
+  CommState* c = (CommState*)h->comm;
+  if (c->nranks == 1) return COSMO_HIP_OK;
+  c->exchanges += 1;
+  c->bytes += (long long)(sizeof(real) * count);
+  if (c->shm) {
+    if ((long long)(count * (size_t)c->nranks) > c->shm->capacity) return cosmo_fail(h, COSMO_HIP_ERR_COMM, "shared segment too small for the all-reduce");
+    HIPCHK(h, hipMemcpyAsync(c->shm->data + (size_t)c->rank * count, buf, sizeof(real) * count, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    CHK(shm_barrier(h, c));
+    c->hsum.assign(count, R(0.0));
+    for (int r = 0; r < c->nranks; ++r) {
+      const real* src = c->shm->data + (size_t)r * count;
+      if (r == 0) for (size_t i = 0; i < count; ++i) c->hsum[i] = src[i];
+      else for (size_t i = 0; i < count; ++i) c->hsum[i] += src[i];
+    }
+    HIPCHK(h, hipMemcpyAsync(buf, c->hsum.data(), sizeof(real) * count, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return shm_barrier(h, c);
+  }
+  NCHK(h, g_rccl.AllReduce(buf, buf, count, NCCL_REAL, 0, c->comm, h->stream));
+  return COSMO_HIP_OK;
+}
+
+// Synchronous all-reduce of up to 8 host doubles (op 0: sum in rank order / RCCL sum, op 1: max).  All ranks must call it at the same
+// point; used by the certificates of row-sharded runs, whose scalar comparisons are chained on the host.  ncclFloat64 = 8, ncclMax = 2.
+int32_t comm_allreduce_host(cosmo_hip_handle* h, double* vals, int count, int op) {
+  if (!h->comm || count <= 0) return COSMO_HIP_OK;
+  CommState* c = (CommState*)h->comm;
+  if (c->nranks == 1) return COSMO_HIP_OK;
+  if (count > 8) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "comm_allreduce_host: at most 8 values");
+  if (c->shm) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < count; ++i) c->shm->hvals[c->rank][i] = vals[i];
+    CHK(shm_barrier(h, c));
+    for (int i = 0; i < count; ++i) {
+      double a = c->shm->hvals[0][i];
+      for (int r = 1; r < c->nranks; ++r) { const double v = c->shm->hvals[r][i]; a = (op == 0) ? a + v : ((v > a || v != v) ? v : a); }
+      vals[i] = a;
+    }
+    return shm_barrier(h, c);
+  }
+  if (!c->d_hv) HIPCHK(h, hipMalloc((void**)&c->d_hv, 16 * sizeof(double)));
+  HIPCHK(h, hipMemcpyAsync(c->d_hv, vals, sizeof(double) * count, hipMemcpyHostToDevice, h->stream));
+  NCHK(h, g_rccl.AllReduce(c->d_hv, c->d_hv + 8, (size_t)count, 8, op == 0 ? 0 : 2, c->comm, h->stream));
+  HIPCHK(h, hipMemcpyAsync(vals, c->d_hv + 8, sizeof(double) * count, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   return COSMO_HIP_OK;
 }
 

@@ -68,6 +68,24 @@ __global__ __launch_bounds__(COSMO_BS) void k_inf_op(const Ctl* __restrict__ ctl
   if (threadIdx.x == 0) { p_pdx[blockIdx.x] = a; p_ady[blockIdx.x] = b; }
 }
 
+// row-sharded runs: the same two norms with A' dy already summed over the ranks (aty) and P alone streamed
+__global__ __launch_bounds__(COSMO_BS) void k_inf_op_rs(const Ctl* __restrict__ ctl, CsrView P, const real* __restrict__ dx,
+                                                        const real* __restrict__ aty, const real* __restrict__ Dinv,
+                                                        real* __restrict__ p_pdx, real* __restrict__ p_ady) {
+  if (ctl->halt) return;
+  __shared__ real lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ real red[COSMO_BS / 64];
+  real a = 0.0, b = 0.0;
+  for (int k = blockIdx.x; k < P.nb; k += gridDim.x)
+    csr_stream_tile(P, dx, dx, k, lds, red, [&](int row, real s1, real s2) {
+      const real d = Dinv[row];
+      a = amax(a, (s1 + s2) * d);
+      b = amax(b, aty[row] * d);
+    });
+  a = block_max(a, red); b = block_max(b, red);
+  if (threadIdx.x == 0) { p_pdx[blockIdx.x] = a; p_ady[blockIdx.x] = b; }
+}
+
 // A dx scaled: adx = (Einv .* (A dx)) * (1/norm_dx)                                         (infeasibility.jl:53-59)
 __global__ __launch_bounds__(COSMO_BS) void k_inf_adx(CsrView A, const real* __restrict__ dx, const real* __restrict__ Einv,
                                                       real inv_norm, real* __restrict__ adx) {
@@ -186,17 +204,34 @@ int32_t infeas_check(cosmo_hip_handle* h, int32_t* status) {
   const int gE = ewg(n + m);
   hipLaunchKernelGGL(k_inf_deltas, dim3(gE), dim3(COSMO_BS), 0, h->stream, h->ctl, n, m, h->w, h->w_prev, h->s, h->rho, h->Escale, h->Dscale, h->q,
                      h->inf_dy, h->inf_dx, IPARTS(h, SLOT_AUX0), IPARTS(h, SLOT_AUX1), IPARTS(h, SLOT_AUX2));
-  hipLaunchKernelGGL(k_inf_op, dim3(h->PT.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, view_of(h->PT), h->inf_dx, h->inf_dy, h->Dinv,
-                     IPARTS(h, SLOT_RD), IPARTS(h, SLOT_MD));
+  int gop = h->PT.grid;
+  if (h->row_shard) {
+    // A' dy = sum over the ranks of A_g' dy_g (one all-reduce of an n-vector per certificate test, i.e. every check_infeasibility iterations)
+    gop = h->P.grid;
+    CHK(launch_spmv_plain(h, h->AT, h->inf_dy, h->red_n));
+    CHK(comm_allreduce_sum(h, h->red_n, (size_t)n));
+    hipLaunchKernelGGL(k_inf_op_rs, dim3(gop), dim3(COSMO_BS), 0, h->stream, h->ctl, view_of(h->P), h->inf_dx, h->red_n, h->Dinv,
+                       IPARTS(h, SLOT_RD), IPARTS(h, SLOT_MD));
+  } else {
+    hipLaunchKernelGGL(k_inf_op, dim3(h->PT.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, view_of(h->PT), h->inf_dx, h->inf_dy, h->Dinv,
+                       IPARTS(h, SLOT_RD), IPARTS(h, SLOT_MD));
+  }
   HIPCHK(h, hipGetLastError());
   std::vector<real> a0, a1, a2, b0, b1;
   CHK(fetch_parts(h, SLOT_AUX0, gE, a0)); CHK(fetch_parts(h, SLOT_AUX1, gE, a1)); CHK(fetch_parts(h, SLOT_AUX2, gE, a2));
-  CHK(fetch_parts(h, SLOT_RD, h->PT.grid, b0)); CHK(fetch_parts(h, SLOT_MD, h->PT.grid, b1));
+  CHK(fetch_parts(h, SLOT_RD, gop, b0)); CHK(fetch_parts(h, SLOT_MD, gop, b1));
   CHK(sync_ctl(h));
   if (h->ctl_host->halt) return COSMO_HIP_OK;          // a status was decided earlier in the stream: nothing was computed
   const real epi = (real)p.eps_prim_inf, edi = (real)p.eps_dual_inf;      // settings are Float64 in the ABI, tests run in the model's type
-  const real norm_dy = host_max(a0, gE), norm_dx = host_max(a1, gE), q_dx = host_sum(a2, gE);
-  const real pdx_norm = host_max(b0, h->PT.grid), ady_norm = host_max(b1, h->PT.grid);
+  real norm_dy = host_max(a0, gE), norm_dx = host_max(a1, gE), q_dx = host_sum(a2, gE);
+  real pdx_norm = host_max(b0, gop), ady_norm = host_max(b1, gop);
+  if (h->row_shard) {
+    // ||E dy||_inf is a max over all rows; the replicated scalars (their block partitions differ with m_loc, so q'dx may differ in the last
+    // bits between ranks) are made IDENTICAL on every rank by the same reduction: the branches below must not diverge
+    double v[5] = {(double)norm_dy, (double)norm_dx, (double)q_dx, (double)pdx_norm, (double)ady_norm};
+    CHK(comm_allreduce_host(h, v, 5, 1));
+    norm_dy = (real)v[0]; norm_dx = (real)v[1]; q_dx = (real)v[2]; pdx_norm = (real)v[3]; ady_norm = (real)v[4];
+  }
   const ConeTable& C = h->cones;
   bool has_psd = false;
   for (size_t k = 0; k < C.type.size(); ++k)
@@ -225,8 +260,13 @@ int32_t infeas_check(cosmo_hip_handle* h, int32_t* status) {
     }
     CHK(custom_test(h, h->inf_dy, 0, epi, &in_dual_all));               // user cones: in_dual(-dyn) through the callback
     if (h->comm) { int viol = in_dual_all ? 0 : 1; CHK(comm_allreduce_flag(h, &viol)); in_dual_all = (viol == 0); }   // owned cones only: combine
-    const real dyt_b = host_sum(d0, gm);
-    const real sF = (in_dual_all ? host_sum(d1, gm) : INFINITY) - dyt_b;
+    real dyt_b = host_sum(d0, gm), box_sf = host_sum(d1, gm);
+    if (h->row_shard) {                                   // <dyn, b> and the Box support function are sums over all rows
+      double v[2] = {(double)dyt_b, (double)box_sf};
+      CHK(comm_allreduce_host(h, v, 2, 0));
+      dyt_b = (real)v[0]; box_sf = (real)v[1];
+    }
+    const real sF = (in_dual_all ? box_sf : INFINITY) - dyt_b;
     if (sF <= epi) { *status = COSMO_HIP_PRIMAL_INFEASIBLE; return COSMO_HIP_OK; }
   }
   // ---- is_dual_infeasible! (infeasibility.jl:32-68) ----

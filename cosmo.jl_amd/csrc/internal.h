@@ -186,6 +186,18 @@ struct cosmo_hip_handle {
   // clique sharding (comm.hip): this rank projects the SOC / PSD cones cone_lo <= k < cone_hi (cone_hi < 0: all cones)
   void* comm = nullptr;
   long long cone_lo = 0, cone_hi = -1;
+  // row sharding (rowshard.hip, SURVEY 8e option 2 on a replicated CG): this rank owns the rows row_lo <= i < row_lo + m of the
+  // m_g-row problem -- its cones, its rows of A (h->A), its columns of A' (h->AT), its slices of b / rho / Einv / s / mu / w_s.
+  // Everything of length n is replicated and bit-identical on all ranks.  What stays GLOBAL: the reduced operator of the CG
+  // (Am / PTm / fold, built from the whole A before the conversion) and the vectors it is refreshed from (rho_g, rho_cls_g).
+  bool row_shard = false;
+  long long m_g = 0, row_lo = 0;
+  real* rho_g = nullptr;            // rho over all m_g rows (identical on every rank: a function of ctl->rho and the row classes)
+  int* rho_cls_g = nullptr;
+  real* red_n = nullptr;            // n + 2 nranks: partial A' products awaiting the all-reduce, then per-rank residual norms
+  ConeTable cones_g;                // the whole composite set (h->cones = this rank's cones, offsets relative to row_lo)
+  int n_bb = 0;                     // partials of ||rhs||^2 that the solve start folds (set by enqueue_cg_start)
+  long long rs_allreduces = 0, rs_allreduce_elems = 0;
   // loop state
   real *w = nullptr, *w_prev = nullptr, *s = nullptr, *mu = nullptr, *s_tl = nullptr;
   real *ls_x = nullptr, *ls_s = nullptr, *x_tl = nullptr, *nu = nullptr;
@@ -238,7 +250,7 @@ void prof_end(cosmo_hip_handle* h);
 int32_t prof_collect(cosmo_hip_handle* h);
 
 // CG operator split
-int32_t build_op_split(cosmo_hip_handle* h);
+int32_t build_op_split(cosmo_hip_handle* h, bool force = false);
 int32_t refresh_op_split(cosmo_hip_handle* h);
 void free_op_split(cosmo_hip_handle* h);
 
@@ -321,4 +333,14 @@ int32_t infeas_enqueue_capture(cosmo_hip_handle* h);
 int32_t infeas_check(cosmo_hip_handle* h, int32_t* status);
 // comm.hip
 int32_t comm_enqueue_exchange(cosmo_hip_handle* h, real* s);
+int32_t comm_allgather_rows(cosmo_hip_handle* h, real* full);                 // in-place all-gather of the ranks' row slices of a full-length vector
+int32_t comm_allreduce_sum(cosmo_hip_handle* h, real* buf, size_t count);     // in place, stream-ordered; identical bits on every rank
+int32_t comm_allreduce_host(cosmo_hip_handle* h, double* vals, int count, int op /*0 sum, 1 max*/);   // synchronous, host scalars
+int comm_nranks(const cosmo_hip_handle* h);
+int comm_rank(const cosmo_hip_handle* h);
+// rowshard.hip
+int32_t rs_enqueue_cg_rhs(cosmo_hip_handle* h, int guard);
+int32_t rs_enqueue_check(cosmo_hip_handle* h, int guard, int mode);
+int32_t rs_get_iterates(cosmo_hip_handle* h, real* w, real* w_prev, real* s, real* mu);
+void rs_free(cosmo_hip_handle* h);
 extern "C" int32_t cosmo_hip_comm_destroy(cosmo_hip_handle* h);

@@ -606,6 +606,95 @@ __global__ __launch_bounds__(COSMO_BS) void k_rho_from_classes(long long m, cons
 __global__ void k_ctl_clear_stall(Ctl* ctl) { ctl->stalled = 0; ctl->halt = (ctl->status != 0 || ctl->error != 0) ? 1 : 0; }
 __global__ void k_ctl_set_done(Ctl* ctl) { ctl->cg_done = 1; }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Row-sharded runs (rowshard.hip; SURVEY 8e option 2 on a replicated CG).  Rank g owns the rows of its cones: A_g = rows of A (h->A),
+// A_g' = columns of A' (h->AT), slices of every m-vector.  A' y = sum_g A_g' y_g is the ONE quantity of the iteration that needs the
+// other ranks: the partial products are summed by an all-reduce (comm.hip) and these kernels finish what k_cg_rhs / k_chk_dual do in
+// one pass on a single GPU.
+// ---------------------------------------------------------------------------------------------------------------------
+// rhs = (sum over ranks of A_g' y2_g) + ls_x ; partial sums of rhs^2               (kktsolver_indirect.jl:53-54, 70)
+__global__ __launch_bounds__(COSMO_BS) void k_rs_rhs_fin(const Ctl* __restrict__ ctl, int guard, long long n, const real* __restrict__ aty,
+                                                         const real* __restrict__ ls_x, real* __restrict__ rhs, real* __restrict__ part_bb) {
+  if (guard && ctl->halt) return;
+  __shared__ real red[COSMO_BS / 64];
+  real acc = 0.0;
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < n; i += (long long)gridDim.x * COSMO_BS) {
+    const real v = aty[i] + ls_x[i];
+    rhs[i] = v;
+    acc += v * v;
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) part_bb[blockIdx.x] = acc;
+}
+
+// this rank's primal norms (max over its partials) into its two slots behind the n-vector that is about to be all-reduced; the other
+// ranks' slots are zeroed, so the SUM over the ranks delivers every rank's value to everybody (NaN included) with the same collective
+__global__ __launch_bounds__(COSMO_BS) void k_rs_pack_prim(const real* __restrict__ part_rp, const real* __restrict__ part_mp, int n_parts,
+                                                           real* __restrict__ out, int rank, int nranks) {
+  __shared__ real red[COSMO_BS / 64];
+  const real rp = reduce_partials_max(part_rp, n_parts, red);
+  const real mp = reduce_partials_max(part_mp, n_parts, red);
+  if ((int)threadIdx.x < 2 * nranks) out[threadIdx.x] = R(0.0);
+  __syncthreads();
+  if (threadIdx.x == 0) { out[rank] = rp; out[nranks + rank] = mp; }
+}
+
+// dual pass with A' mu already summed over the ranks: r_dual = P x + q - atm ; norms ; x'Px, q'x       (residuals.jl:12-18, 56-96, 143-147)
+__global__ __launch_bounds__(COSMO_BS) void k_chk_dual_rs(const Ctl* __restrict__ ctl, int guard, CsrView P, const real* __restrict__ w_prev,
+                                                          const real* __restrict__ atmv, const real* __restrict__ q,
+                                                          const real* __restrict__ Dinv, real cinv, int unscale, real* __restrict__ part_rd,
+                                                          real* __restrict__ part_md, real* __restrict__ part_xpx, real* __restrict__ part_qx) {
+  if (guard && ctl->halt) return;
+  __shared__ real lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ real red[COSMO_BS / 64];
+  real rd = 0.0, md = 0.0, xpx = 0.0, qx = 0.0;
+  for (int k = blockIdx.x; k < P.nb; k += gridDim.x) {
+    csr_stream_tile(P, w_prev, w_prev, k, lds, red, [&](int row, real s1, real s2) {
+      const real px = s1 + s2;
+      const real atm = atmv[row];
+      const real xv = w_prev[row];
+      const real qv = q[row];
+      real rv = px + qv;
+      rv = rv - atm;
+      real a = px, bq = qv, cm = atm;
+      if (unscale) {
+        const real d = Dinv ? Dinv[row] : 1.0;
+        rv = (rv * d) * cinv;
+        a = (a * d) * cinv;
+        bq = (bq * d) * cinv;
+        cm = (cm * d) * cinv;
+      }
+      rd = amax(rd, rv);
+      md = amax(md, a);
+      md = amax(md, bq);
+      md = amax(md, cm);
+      xpx += px * xv;
+      qx += qv * xv;
+    });
+  }
+  rd = block_max(rd, red);
+  md = block_max(md, red);
+  xpx = block_sum(xpx, red);
+  qx = block_sum(qx, red);
+  if (threadIdx.x == 0) {
+    part_rd[blockIdx.x] = rd; part_md[blockIdx.x] = md; part_xpx[blockIdx.x] = xpx; part_qx[blockIdx.x] = qx;
+  }
+}
+
+// update_rho_vec! on the replicated full-length rho that the reduced operator is refreshed from (every rank, identical)
+__global__ __launch_bounds__(COSMO_BS) void k_rs_rho_g(const Ctl* __restrict__ ctl, int guard, long long m_g, const int* __restrict__ cls,
+                                                       real rho_min, real rho_eq, real* __restrict__ rho_g) {
+  if (guard && ctl->halt) return;
+  if (!ctl->rho_changed) return;
+  const real nr = ctl->rho;
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < m_g; i += (long long)gridDim.x * COSMO_BS) {
+    const int c = cls[i];
+    real rv = nr;
+    if (c == 1) rv = rv * rho_eq; else if (c == 2) rv = rho_min;
+    rho_g[i] = rv;
+  }
+}
+
 // =====================================================================================================================
 // host-side launchers
 // =====================================================================================================================
@@ -724,11 +813,32 @@ int32_t enqueue_cg_iterations(cosmo_hip_handle* h, int guard, int k_begin, int c
   return COSMO_HIP_OK;
 }
 
-int32_t enqueue_cg_start(cosmo_hip_handle* h, int guard, real tol_k) {
+// row-sharded: rhs = allreduce_sum(A_g' y2_g) + ls_x
+int32_t rs_enqueue_cg_rhs(cosmo_hip_handle* h, int guard) {
+  const int gE = ew_grid(h->n);
   prof_begin(h, KC_SPMV_AT);
-  hipLaunchKernelGGL(k_cg_rhs, dim3(h->AT.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, view_of(h->AT), h->y2,
-                     h->ls_x, h->rhs, PARTS(h, SLOT_BB));
+  CHK(launch_spmv_plain(h, h->AT, h->y2, h->red_n));
   prof_end(h);
+  CHK(comm_allreduce_sum(h, h->red_n, (size_t)h->n));
+  h->rs_allreduces += 1; h->rs_allreduce_elems = h->n;
+  prof_begin(h, KC_RHS);
+  hipLaunchKernelGGL(k_rs_rhs_fin, dim3(gE), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, h->n, h->red_n, h->ls_x, h->rhs, PARTS(h, SLOT_BB));
+  prof_end(h);
+  h->n_bb = gE;
+  HIPCHK(h, hipGetLastError());
+  return COSMO_HIP_OK;
+}
+
+int32_t enqueue_cg_start(cosmo_hip_handle* h, int guard, real tol_k) {
+  if (h->row_shard) {
+    CHK(rs_enqueue_cg_rhs(h, guard));
+  } else {
+    prof_begin(h, KC_SPMV_AT);
+    hipLaunchKernelGGL(k_cg_rhs, dim3(h->AT.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, view_of(h->AT), h->y2,
+                       h->ls_x, h->rhs, PARTS(h, SLOT_BB));
+    prof_end(h);
+    h->n_bb = h->AT.grid;
+  }
   if (h->op_fold) return fold_enqueue_start(h, guard, tol_k);
   const CsrDev& Ao = h->op_split ? h->Am : h->A;
   const CsrDev& PTo = h->op_split ? h->PTm : h->PT;
@@ -739,7 +849,7 @@ int32_t enqueue_cg_start(cosmo_hip_handle* h, int guard, real tol_k) {
   prof_begin(h, KC_OP_APPLY);
   hipLaunchKernelGGL(k_op_apply, dim3(PTo.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, 0, view_of(PTo),
                      h->prm.sigma, h->x_tl, h->tmp_m, h->rhs, h->r, h->c, PARTS(h, SLOT_RR), PARTS(h, SLOT_BB),
-                     h->AT.grid, tol_k, h->op_split ? h->op_diag : nullptr);
+                     h->n_bb, tol_k, h->op_split ? h->op_diag : nullptr);
   prof_end(h);
   h->spmv_calls[0] += 1; h->spmv_calls[1] += 2; h->spmv_calls[2] += 1;
   HIPCHK(h, hipGetLastError());
@@ -789,20 +899,36 @@ int32_t enqueue_clear_stall(cosmo_hip_handle* h) {
 // mode: 0 info, 1 termination, 2 adaptation (unscaled residuals, parameters.jl:57-59)
 int32_t enqueue_check(cosmo_hip_handle* h, int guard, int mode) {
   const bool unscale = (mode != 2) && h->prm.unscale_residuals && h->has_scaling;
+  const int nr = h->row_shard ? comm_nranks(h) : 1;
   prof_begin(h, KC_CHK_PRIM);
   hipLaunchKernelGGL(k_chk_prim, dim3(h->A.grid > 0 ? h->A.grid : 1), dim3(COSMO_BS), 0, h->stream, h->ctl, guard,
                      view_of(h->A), h->n, h->w_prev, h->s, h->b, h->rho, unscale ? h->Einv : (const real*)nullptr, h->mu,
                      PARTS(h, SLOT_RP), PARTS(h, SLOT_MP));
   prof_end(h);
-  prof_begin(h, KC_CHK_DUAL);
-  hipLaunchKernelGGL(k_chk_dual, dim3(h->PT.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, view_of(h->PT), h->w_prev,
-                     h->mu, h->q, h->Dinv, h->cinv, unscale ? 1 : 0, PARTS(h, SLOT_RD), PARTS(h, SLOT_MD),
-                     PARTS(h, SLOT_XPX), PARTS(h, SLOT_QX));
-  prof_end(h);
   ChkArgs a;
   a.part_rp = PARTS(h, SLOT_RP); a.part_mp = PARTS(h, SLOT_MP); a.part_rd = PARTS(h, SLOT_RD);
   a.part_md = PARTS(h, SLOT_MD); a.part_xpx = PARTS(h, SLOT_XPX); a.part_qx = PARTS(h, SLOT_QX);
   a.n_prim = h->A.grid > 0 ? h->A.grid : 1; a.n_dual = h->PT.grid; a.mode = mode;
+  if (h->row_shard) {
+    // the primal pass ran over this rank's rows; A' mu = sum_g A_g' mu_g and the per-rank primal norms travel in ONE all-reduce of n + 2 nranks
+    // reals; the dual pass (P x, q, the summed A' mu) is then replicated and bit-identical on every rank
+    real* slots = h->red_n + h->n;
+    hipLaunchKernelGGL(k_rs_pack_prim, dim3(1), dim3(COSMO_BS), 0, h->stream, PARTS(h, SLOT_RP), PARTS(h, SLOT_MP), a.n_prim, slots, comm_rank(h), nr);
+    CHK(launch_spmv_plain(h, h->AT, h->mu, h->red_n));
+    CHK(comm_allreduce_sum(h, h->red_n, (size_t)(h->n + 2 * nr)));
+    h->rs_allreduces += 1; h->rs_allreduce_elems = h->n + 2 * nr;
+    prof_begin(h, KC_CHK_DUAL);
+    hipLaunchKernelGGL(k_chk_dual_rs, dim3(h->P.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, view_of(h->P), h->w_prev, h->red_n, h->q, h->Dinv,
+                       h->cinv, unscale ? 1 : 0, PARTS(h, SLOT_RD), PARTS(h, SLOT_MD), PARTS(h, SLOT_XPX), PARTS(h, SLOT_QX));
+    prof_end(h);
+    a.part_rp = slots; a.part_mp = slots + nr; a.n_prim = nr; a.n_dual = h->P.grid;
+  } else {
+    prof_begin(h, KC_CHK_DUAL);
+    hipLaunchKernelGGL(k_chk_dual, dim3(h->PT.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, view_of(h->PT), h->w_prev,
+                       h->mu, h->q, h->Dinv, h->cinv, unscale ? 1 : 0, PARTS(h, SLOT_RD), PARTS(h, SLOT_MD),
+                       PARTS(h, SLOT_XPX), PARTS(h, SLOT_QX));
+    prof_end(h);
+  }
   a.cinv = (h->prm.unscale_residuals && h->has_scaling) ? h->cinv : 1.0;
   a.eps_abs = h->prm.eps_abs; a.eps_rel = h->prm.eps_rel;
   a.obj_true = h->prm.obj_true; a.obj_true_tol = h->prm.obj_true_tol;
@@ -815,6 +941,9 @@ int32_t enqueue_check(cosmo_hip_handle* h, int guard, int mode) {
     prof_begin(h, KC_RHO_APPLY);
     hipLaunchKernelGGL(k_rho_apply, dim3(ew_grid(h->m > 0 ? h->m : 1)), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, h->n,
                        h->m, h->rho_cls, h->prm.rho_min, h->prm.rho_eq_over_rho_ineq, h->mu, h->s, h->rho, h->w);
+    if (h->row_shard)
+      hipLaunchKernelGGL(k_rs_rho_g, dim3(ew_grid(h->m_g > 0 ? h->m_g : 1)), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, h->m_g, h->rho_cls_g,
+                         h->prm.rho_min, h->prm.rho_eq_over_rho_ineq, h->rho_g);
     CHK(refresh_op_split(h));      // rho may have changed on the device: the diagonal part of A' rho A follows (cheap, unconditional)
     prof_end(h);
   }
@@ -852,7 +981,7 @@ int32_t refresh_op_split(cosmo_hip_handle* h) {
   if (!h->op_split) return COSMO_HIP_OK;
   const long long mm = h->Am.nrows;
   hipLaunchKernelGGL(k_op_refresh, dim3(ew_grid(h->n + mm)), dim3(COSMO_BS), 0, h->stream, h->n, mm, h->op_sc_ptr, h->op_sc_row, h->op_sc_a2,
-                     h->op_mrow, h->rho, h->op_diag, h->op_rho_m);
+                     h->op_mrow, h->rho_g ? h->rho_g : h->rho, h->op_diag, h->op_rho_m);
   HIPCHK(h, hipGetLastError());
   return fold_refresh(h);        // the assembled operator's values follow rho_m and the diagonal
 }

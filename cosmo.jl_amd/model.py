@@ -701,10 +701,11 @@ def _chordal_decomposition(model: Model):
     model.chordal = dec
 
 
-def optimize(model: Model, dist=None) -> Result:
+def optimize(model: Model, dist=None, shard: str = "rows") -> Result:
     """`COSMO.optimize!` (src/solver.jl:78-203) with the `while` loop running on the MI355X.  With an initialised
-    torch.distributed module as `dist` (one process per GPU) the cone projections are sharded over the ranks
-    (setup_clique_sharding); every rank returns the same Result."""
+    torch.distributed module as `dist` (one process per GPU) the problem is sharded over the ranks: shard="rows" (default; the reduced
+    CG solvers) gives every rank its cones AND their rows (setup_row_sharding: one all-reduce of an n-vector per iteration),
+    shard="cones" only the projections (setup_clique_sharding: one all-gather of s per iteration).  Every rank returns the same Result."""
     import time
     if not model.is_assembled:
         raise RuntimeError("The model has to be assembled! / set! before optimize!() can be called.")
@@ -714,7 +715,14 @@ def optimize(model: Model, dist=None) -> Result:
         _chordal_decomposition(model)                             # chordal_decomposition!(ws) (src/solver.jl:88-94)
     setup(model)
     if dist is not None and dist.get_world_size() > 1 and fresh:
-        setup_clique_sharding(model, dist)
+        kkt = model.settings.kkt_solver.solver if isinstance(model.settings.kkt_solver, OptionsFactory) else model.settings.kkt_solver
+        acc = model.settings.accelerator.solver if isinstance(model.settings.accelerator, OptionsFactory) else model.settings.accelerator
+        rows_ok = (kkt in (CGIndirectKKTSolver, CGSingleReductionKKTSolver) and model.settings.time_limit == 0 and acc in (None, EmptyAccelerator)
+                   and not any(K.kind == _ffi.CUSTOM for K in model.sets))
+        if shard == "rows" and rows_ok:
+            setup_row_sharding(model, dist)
+        else:
+            setup_clique_sharding(model, dist)
     t_setup = time.perf_counter() - t0
     h, sm, n = model.handle, model.sm, model.n
     h.set_iterates(model.x, model.s, model.mu)                    # solver.jl:128-129
@@ -858,8 +866,8 @@ def balance_cones(dims: Sequence[int], world: int) -> List[List[int]]:
 
 
 def cone_costs(sets: Sequence[AbstractConvexSet]) -> List[int]:
-    """Projection cost model per cone: ~d^3 for a PSD cone of side d, ~dim for a second-order cone, 0 for the cones that the
-    elementwise kernel projects on every rank."""
+    """Projection cost model per cone of the CONE-sharded run: ~d^3 for a PSD cone of side d, ~dim for a second-order cone, 0 for the cones
+    that every rank projects (elementwise kernel; exponential / power / user cones, which csrc/cone3.hip / custom.hip do not shard)."""
     out = []
     for K in sets:
         if K.kind in (_ffi.PSD_SQUARE, _ffi.PSD_TRIANGLE) and K.dim > 1:
@@ -868,11 +876,16 @@ def cone_costs(sets: Sequence[AbstractConvexSet]) -> List[int]:
             out.append((2 * int(K.sqrt_dim)) ** 3)               # projected through its real 2r x 2r embedding
         elif K.kind == _ffi.SOC:
             out.append(int(K.dim))
-        elif K.kind in (_ffi.EXP, _ffi.DUAL_EXP, _ffi.POW, _ffi.DUAL_POW, _ffi.CUSTOM):
-            out.append(64)                                       # a Newton / bisection solve per 3-vector, a host call per custom cone
         else:
             out.append(0)
     return out
+
+
+def row_shard_costs(sets: Sequence[AbstractConvexSet]) -> List[int]:
+    """Cost model of the row-sharded run: the projection cost of cone_costs() plus the cone's rows (the row-local kernels -- rhs, A x_tl,
+    s_tl, w_s, primal residual -- stream ~100 B per row; a d^3 flop projection at ~1/3 of the matrix peak makes one row worth ~8 'd^3 units')."""
+    newton = (_ffi.EXP, _ffi.DUAL_EXP, _ffi.POW, _ffi.DUAL_POW)          # a Newton / bisection solve per 3-vector; row-sharded runs do shard them
+    return [c + 8 * int(K.dim) + (64 if K.kind in newton else 0) for c, K in zip(cone_costs(sets), sets)]
 
 
 def partition_cones_contiguous(costs: Sequence[int], world: int) -> List[int]:
@@ -907,8 +920,19 @@ def partition_cones_contiguous(costs: Sequence[int], world: int) -> List[int]:
 def setup_clique_sharding(model: Model, dist) -> None:
     """One communicator per handle (one process per GPU): rank 0 creates the RCCL unique id, the host layer distributes it,
     every rank takes a contiguous cone range balanced by cone_costs()."""
+    _comm_for(model, dist)
+    model.handle.set_cone_shard(partition_cones_contiguous(cone_costs(model.sets), dist.get_world_size()))
+
+
+def _comm_for(model: Model, dist) -> None:
     rank, world = dist.get_rank(), dist.get_world_size()
     uid = [_ffi.Handle.comm_unique_id() if rank == 0 else None]
     dist.broadcast_object_list(uid, src=0)
     model.handle.comm_init(rank, world, uid[0])
-    model.handle.set_cone_shard(partition_cones_contiguous(cone_costs(model.sets), world))
+
+
+def setup_row_sharding(model: Model, dist) -> None:
+    """Row sharding (csrc/rowshard.hip): a contiguous cone range per rank balanced by row_shard_costs(); the handle keeps its cones, their
+    rows of A / columns of A' and the slices of every row vector; the n-side (CG included) is replicated."""
+    _comm_for(model, dist)
+    model.handle.set_row_shard(partition_cones_contiguous(row_shard_costs(model.sets), dist.get_world_size()))

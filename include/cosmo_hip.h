@@ -341,6 +341,21 @@ int32_t cosmo_hip_comm_stats(cosmo_hip_handle* h, int64_t out[4]);
 /* ownership without a communicator: project only the SOC / PSD cones cone_lo <= k < cone_hi (testing / custom exchange) */
 int32_t cosmo_hip_set_cone_ownership(cosmo_hip_handle* h, int64_t cone_lo, int64_t cone_hi);
 
+/* ---- row-sharded runs (csrc/rowshard.hip; SURVEY 8e option 2 on a replicated n-side CG) ------------------------------------
+ * Replaces the serial cone loop of src/convexset.jl:885-891 AND the row-local parts of admm_x! / admm_w! / the primal residual
+ * (src/solver.jl:50-65, src/residuals.jl:2-9): rank r owns the cones first_cone[r] <= k < first_cone[r+1] (all kinds), their rows of A,
+ * their columns of A' and the matching slices of b / rho / s / mu / w_s.  The n-vectors and the reduced operator of the CG
+ * (src/linear_solver/kktsolver_indirect.jl:57-64) are replicated.  Exchange: ONE all-reduce(sum) of the n-vector A'(rho .* ls_s) per
+ * iteration (kktsolver_indirect.jl:52-54) and one of A' mu (+ 2 nranks norms) per residual check -- s is never exchanged.
+ * Call on a fully set-up handle: set_problem, set_cones, [scale_ruiz], set_params, comm_init / comm_init_hostshm, then this, then
+ * set_iterates (which takes the GLOBAL x0, s0, mu0; get_iterates returns the GLOBAL vectors on every rank).  CG kkt kinds only. */
+int32_t cosmo_hip_set_row_shard(cosmo_hip_handle* h, const int64_t* first_cone);
+/* out = {first row, end row, global rows m_g, nnz of this rank's rows of A, its cones, its first cone} */
+int32_t cosmo_hip_row_shard_info(cosmo_hip_handle* h, int64_t out[6]);
+/* out = {nranks, rank, collectives of the loop executed with nranks > 1, transport (0 none, 1 RCCL, 2 host-staged), mode (0 none, 1 cone-
+ * sharded projections, 2 row-sharded), payload bytes of those collectives, all-reduces of n-vectors, elements of the last all-reduce} */
+int32_t cosmo_hip_comm_stats_ex(cosmo_hip_handle* h, int64_t out[8]);
+
 /* ---- batches of independent problems (BASELINE config 3) ------------------------------------------------------------
  * The reference solves a batch with one optimize!(model) per problem (src/solver.jl:78-203).  Here all problems of a batch
  * (identical n, m and cone structure; data, Box bounds, scalings differ) are solved concurrently, one persistent workgroup

@@ -5,6 +5,9 @@
 transport = shm  : host-staged communicator (cosmo_hip_comm_init_hostshm); <rendezvous> is the POSIX shm name ("/cosmo_...")
 transport = rccl : RCCL communicator; <rendezvous> is a file through which rank 0 hands the ncclUniqueId to the other ranks
                    (two ranks on ONE device: RCCL is expected to refuse this; the test records what it says)
+Environment: COSMO_TEST_SHARD = cones (default: cosmo_hip_set_cone_shard, the projections only) | rows (cosmo_hip_set_row_shard: cones +
+their rows, csrc/rowshard.hip); COSMO_TEST_CASE = chordal (default) | pinf | dinf (the two infeasible problems of
+test_infeasibility_certificates_in_sharded_runs, default settings); COSMO_TEST_TIGHT=1: CG solved to 1e-10 (tol_exponent 0).
 Writes the final iterates, the result scalars and the communicator statistics of this rank."""
 import os
 import sys
@@ -21,16 +24,50 @@ def problem():
     return cj.problems.chordal_sdp(ncliques=14, dmin=6, dmax=110, sep_min=1, sep_max=4, n_total=3000, n_zero=20, n_nonneg=40, seed=55)
 
 
-def settings(iters):
+def settings(iters, tight=False):
     import cosmo_jl_amd as cj
-    return cj.Settings(max_iter=iters, eps_abs=0.0, eps_rel=0.0, check_infeasibility=10 ** 9)
+    kw = dict(max_iter=iters, eps_abs=0.0, eps_rel=0.0, check_infeasibility=10 ** 9)
+    if tight:
+        kw["kkt_solver"] = cj.with_options(cj.CGIndirectKKTSolver, tol_constant=1e-10, tol_exponent=0.0)
+    return cj.Settings(**kw)
+
+
+def infeasible_model(case):
+    """pinf: X psd and X11 = -1 (3 x 3, svec variables) + an SOC block; dinf: minimise -t over a second-order cone, + a free PSD block
+    so that two ranks own cones.  Default settings (certificates every 40 iterations)."""
+    import scipy.sparse as sp
+    import cosmo_jl_amd as cj
+    md = cj.Model()
+    if case == "pinf":
+        nt = 6
+        A = sp.vstack([sp.csc_matrix(([1.0], ([0], [0])), shape=(1, nt + 3)), sp.hstack([sp.identity(nt), sp.csc_matrix((nt, 3))]),
+                       sp.hstack([sp.csc_matrix((3, nt)), sp.identity(3)])], format="csc")
+        b = np.concatenate([[1.0], np.zeros(nt + 3)])
+        cons = [cj.Constraint(A[:1], b[:1], cj.ZeroSet), cj.Constraint(A[1:1 + nt], b[1:1 + nt], cj.PsdConeTriangle),
+                cj.Constraint(A[1 + nt:], b[1 + nt:], cj.SecondOrderCone)]
+        cj.assemble(md, sp.csc_matrix((nt + 3, nt + 3)), np.zeros(nt + 3), cons, settings=cj.Settings(kkt_solver=cj.CGIndirectKKTSolver))
+    else:
+        A = sp.identity(9, format="csc")
+        cons = [cj.Constraint(A[:3], np.zeros(3), cj.SecondOrderCone), cj.Constraint(A[3:], np.zeros(6), cj.PsdConeTriangle)]
+        q = np.zeros(9); q[0] = -1.0
+        cj.assemble(md, sp.identity(9, format="csc") * 0.0, q, cons, settings=cj.Settings(kkt_solver=cj.CGIndirectKKTSolver))
+    return md
+
+
+def build_model(iters):
+    import cosmo_jl_amd as cj
+    case = os.environ.get("COSMO_TEST_CASE", "chordal")
+    if case in ("pinf", "dinf"):
+        return infeasible_model(case)
+    p = problem()
+    md = cj.Model(); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], settings(iters, os.environ.get("COSMO_TEST_TIGHT", "") == "1"))
+    return md
 
 
 def main():
     transport, rank, world, rdv, out, iters = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], int(sys.argv[6])
     import cosmo_jl_amd as cj
-    p = problem()
-    md = cj.Model(); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], settings(iters))
+    md = build_model(iters)
     cj.model.setup(md)
     h = md.handle
     if transport == "shm":
@@ -49,12 +86,21 @@ def main():
                 time.sleep(0.05)
             uid = open(rdv, "rb").read()
         h.comm_init(rank, world, uid)
-    bounds = cj.partition_cones_contiguous(cj.cone_costs(md.sets), world)
-    h.set_cone_shard(bounds)
+    mode = os.environ.get("COSMO_TEST_SHARD", "cones")
+    if mode == "rows":
+        bounds = cj.partition_cones_contiguous(cj.model.row_shard_costs(md.sets), world)
+        h.set_row_shard(bounds)
+    else:
+        bounds = cj.partition_cones_contiguous(cj.cone_costs(md.sets), world)
+        h.set_cone_shard(bounds)
     r = cj.optimize(md)
     st = h.comm_stats()
+    ex = h.comm_stats_ex()
+    info = h.row_shard_info()
     np.savez(out, x=r.x, s=r.s, y=r.y, iter=r.iter, kkt=r.kkt_iters_total, obj=r.obj_val, r_prim=r.info.r_prim, r_dual=r.info.r_dual,
-             bounds=np.array(bounds), exchanges=st["exchanges"], nranks=st["nranks"], transport=st["transport"])
+             bounds=np.array(bounds), exchanges=st["exchanges"], nranks=st["nranks"], transport=st["transport"], status=r.status,
+             mode=ex["mode"], bytes=ex["bytes"], allreduces=ex["allreduces"], allreduce_elems=ex["allreduce_elems"],
+             row_lo=info["row_lo"], row_hi=info["row_hi"], rho_updates=np.array(r.info.rho_updates))
 
 
 if __name__ == "__main__":

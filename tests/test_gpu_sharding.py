@@ -108,8 +108,9 @@ WORKER = os.path.join(ROOT, "tests", "shard_worker.py")
 ITERS = 60
 
 
-def _spawn(transport, world, rdv, tmp, timeout=240):
+def _spawn(transport, world, rdv, tmp, timeout=240, extra_env=None):
     env = dict(os.environ, COSMO_HIP_POLAR_KLIFT="10")            # pin the sign-iteration schedule (it is pinned in sharded runs anyway)
+    env.update(extra_env or {})
     procs = [subprocess.Popen([sys.executable, WORKER, transport, str(r), str(world), rdv, os.path.join(tmp, "rank%d.npz" % r), str(ITERS)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
@@ -126,13 +127,18 @@ def _spawn(transport, world, rdv, tmp, timeout=240):
     return outs
 
 
-def _single_rank_reference(monkeypatch):
+def _worker_module():
     import importlib.util
     spec = importlib.util.spec_from_file_location("shard_worker", WORKER)
     W = importlib.util.module_from_spec(spec); spec.loader.exec_module(W)
+    return W
+
+
+def _single_rank_reference(monkeypatch, tight=False):
+    W = _worker_module()
     monkeypatch.setenv("COSMO_HIP_POLAR_KLIFT", "10")
     p = W.problem()
-    md = cj.Model(); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], W.settings(ITERS))
+    md = cj.Model(); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], W.settings(ITERS, tight))
     return cj.optimize(md), md
 
 
@@ -154,6 +160,60 @@ def test_exchange_with_several_ranks_is_bit_identical_to_the_single_rank_run(wor
             for key, val in (("x", ref.x), ("s", ref.s), ("y", ref.y)):
                 assert np.array_equal(z[key].view(np.int64), val.view(np.int64)), (r, key)       # bit for bit, on every rank
             assert float(z["obj"]) == ref.obj_val and float(z["r_prim"]) == ref.info.r_prim
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_sharded_run_agrees_with_the_single_rank_run(world, monkeypatch):
+    """Row sharding (csrc/rowshard.hip, SURVEY 8e option 2 on a replicated CG): every rank keeps its cones AND their rows of A / s / mu /
+    rho; the one exchange of an iteration is the all-reduce of the n-vector A'(rho .* ls_s) (kktsolver_indirect.jl:52-54).  The summation
+    order of that vector changes with the partition, so the run is compared with the single-rank run at the tight-CG trajectory tolerance
+    (1e-7) -- but the ranks must agree with EACH OTHER bit for bit (their control flow depends on it)."""
+    ref, md = _single_rank_reference(monkeypatch, tight=True)
+    bounds = cj.partition_cones_contiguous(cj.model.row_shard_costs(md.sets), world)
+    assert all(bounds[r + 1] > bounds[r] for r in range(world))
+    n, m = md.n, md.m
+    with tempfile.TemporaryDirectory() as tmp:
+        outs = _spawn("shm", world, "/cosmo_test_" + uuid.uuid4().hex[:12], tmp, extra_env={"COSMO_TEST_SHARD": "rows", "COSMO_TEST_TIGHT": "1"})
+        for rc, o in outs:
+            assert rc == 0, o[-2000:]
+        zs = [np.load(os.path.join(tmp, "rank%d.npz" % r)) for r in range(world)]
+        rows = 0
+        for r, z in enumerate(zs):
+            assert int(z["nranks"]) == world and int(z["transport"]) == 2 and str(z["mode"]) == "rows"
+            assert np.array_equal(z["bounds"], np.array(bounds))
+            rows += int(z["row_hi"]) - int(z["row_lo"])
+            # one all-reduce of n reals per KKT solve (init step + ITERS iterations) + one of n + 2 world per residual check / rho rule
+            assert int(z["allreduces"]) >= ITERS + 1 and int(z["allreduce_elems"]) in (n, n + 2 * world)
+            assert (ITERS + 1) * 8 * n <= int(z["bytes"]) <= (ITERS + 12) * 8 * (n + 2 * world) + 4 * 8 * (n + m)   # + the final all-gathers of get_iterates
+            assert int(z["iter"]) == ref.iter == ITERS and str(z["status"]) == ref.status
+            assert abs(int(z["kkt"]) - ref.kkt_iters_total) <= max(8, ref.kkt_iters_total // 50)
+            for key, val in (("x", ref.x), ("s", ref.s), ("y", ref.y)):
+                assert np.max(np.abs(z[key] - val)) <= 1e-7 * max(np.max(np.abs(val)), 1e-30), (r, key)
+            assert abs(float(z["obj"]) - ref.obj_val) <= 1e-7 * (1 + abs(ref.obj_val))
+            assert len(z["rho_updates"]) == len(ref.info.rho_updates)
+        assert rows == m                                                          # the ranks' row ranges tile [0, m)
+        for z in zs[1:]:                                                           # identical bits on every rank
+            for key in ("x", "s", "y"):
+                assert np.array_equal(z[key].view(np.int64), zs[0][key].view(np.int64)), key
+            assert float(z["obj"]) == float(zs[0]["obj"]) and float(z["r_prim"]) == float(zs[0]["r_prim"]) and float(z["r_dual"]) == float(zs[0]["r_dual"])
+            assert int(z["kkt"]) == int(zs[0]["kkt"])
+
+
+@pytest.mark.parametrize("case,want", [("pinf", "Primal_infeasible"), ("dinf", "Dual_infeasible")])
+def test_row_sharded_run_keeps_the_infeasibility_certificates(case, want, monkeypatch):
+    """Two ranks, default settings: ||E dy|| / <dy, b> / the support function are reduced over the ranks, A' dy is all-reduced, every rank
+    tests its own cones (infeas.hip) -- same status and iteration count as the single-rank run (src/infeasibility.jl:1-68)."""
+    W = _worker_module()
+    ref = cj.optimize(W.infeasible_model(case))
+    assert ref.status == want
+    with tempfile.TemporaryDirectory() as tmp:
+        outs = _spawn("shm", 2, "/cosmo_test_" + uuid.uuid4().hex[:12], tmp, extra_env={"COSMO_TEST_SHARD": "rows", "COSMO_TEST_CASE": case})
+        for rc, o in outs:
+            assert rc == 0, o[-2000:]
+        for r in range(2):
+            z = np.load(os.path.join(tmp, "rank%d.npz" % r))
+            assert str(z["mode"]) == "rows" and int(z["row_hi"]) > int(z["row_lo"])
+            assert str(z["status"]) == want and int(z["iter"]) == ref.iter
 
 
 def test_rccl_two_ranks_on_one_device_is_refused_or_identical(monkeypatch):
@@ -180,27 +240,62 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("workload", ["cfg5", "cfg3"])
-def test_bench_multi_rank_entry_point_dry_run(workload):
-    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one rank per process), on ONE GPU: the dry-run
-    transport (COSMO_BENCH_TRANSPORT=shm: gloo barriers, host-staged clique exchange) exercises the rank bookkeeping, the sharded cfg5 /
-    cfg3 workloads, the MAX-over-ranks timing and the one JSON line of rank 0.  With real GPUs the same code runs over RCCL."""
-    env = dict(os.environ, COSMO_BENCH_TRANSPORT="shm", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "3", "--small", "--workload", workload]
-    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=420)
+def _one_json_line(p):
+    import json
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1                                               # exactly one JSON line, from rank 0
-    import json
-    out = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("workload,shard", [("cfg5", "rows"), ("cfg5", "cones"), ("cfg3", "rows")])
+def test_bench_multi_rank_entry_point_dry_run(workload, shard):
+    """`bench.py --gpus 2` launched by torch.distributed.run (one rank per process), on ONE GPU: the dry-run transport
+    (COSMO_BENCH_TRANSPORT=shm: gloo barriers, host-staged collectives) exercises the rank bookkeeping, the sharded cfg5 / cfg3
+    workloads, the MAX-over-ranks timing and the one JSON line of rank 0.  With real GPUs the same code runs over RCCL."""
+    env = dict(os.environ, COSMO_BENCH_TRANSPORT="shm", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "3", "--small", "--workload", workload, "--shard", shard]
+    out = _one_json_line(subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=420))
     assert out["n_gpus"] == 2 and out["steps"] == 8 and out["warmup"] == 3 and out["value"] > 0 and out["higher_is_better"] is True
     assert "DRY RUN" in out["data"]
     if workload == "cfg5":
         assert out["scaling"] == "strong"
         comm = out["config"]["comm"]
-        assert comm["nranks"] == 2 and comm["transport"] == 2 and comm["exchanges"] >= 8 + 3
+        assert comm["nranks"] == 2 and comm["transport"] == 2 and comm["mode"] == shard and comm["collectives"] >= 8 + 3
+        n = 6000
+        if shard == "rows":                                              # one all-reduce of n doubles per iteration (+ the checks' n + 4)
+            assert 8 * n <= comm["bytes_per_iteration"] <= 8 * (n + 4) * 1.5 and 1.0 <= comm["collectives_per_iteration"] <= 1.5
+            info = out["config"]["row_shard"]
+            assert 0 <= info["row_lo"] < info["row_hi"] < info["m_global"]
+        else:                                                            # the projected PSD slices of s: far more than an n-vector
+            assert comm["bytes_per_iteration"] > 8 * 4 * n and comm["collectives_per_iteration"] == 1.0
         assert out["config"]["speedup_vs_single_gpu"] > 0 and "sharded over 2 ranks" in out["config"]["parallelism"]
+        sh = out["config"]["shardable_share_of_single_gpu_iteration"]
+        assert 0 < sh["projections"] <= sh["projections_and_row_kernels"] < 1 and 1 < sh["predicted_speedup_bound"] < 2
     else:
-        assert out["scaling"] == "weak" or out["scaling"] == "strong"
-        assert "sharded over 2 rank" in out["config"]["parallelism"]
+        assert out["scaling"] == "strong" and "sharded over 2 rank" in out["config"]["parallelism"]
+
+
+def test_bench_gpus_2_without_a_launcher_is_a_two_rank_run_of_the_same_headline_workload():
+    """The driver starts the bench as a plain `python bench.py --gpus N ...`: that command alone must produce a valid N-rank line (it
+    re-launches itself under torch.distributed.run), and the headline must be the SAME workload at every N (cfg2 replicas, weak), with
+    the configurations that shard reported under extra.*_sharded with scaling = strong."""
+    common = ["--steps", "6", "--warmup", "2", "--small", "--no-cpu-baseline", "--no-float32"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    one = _one_json_line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-extra"] + common, env=env, cwd=ROOT,
+                                        capture_output=True, text=True, timeout=420))
+    two = _one_json_line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, env=dict(env, COSMO_BENCH_TRANSPORT="shm"),
+                                        cwd=ROOT, capture_output=True, text=True, timeout=600))
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert one["config"]["workload"] == two["config"]["workload"] and one["config"]["workload"].startswith("cfg2")
+    assert one["metric"] == two["metric"] and one["scaling"] == two["scaling"] == "weak" and one["steps"] == two["steps"] == 6
+    assert two["config"]["launch"] == "self-launched torch.distributed.run" and one["config"]["launch"] == "single process"
+    assert "replicas x2" in two["config"]["parallelism"] and two["value"] > 0 and "DRY RUN" in two["data"]
+    ex = two["extra"]
+    assert set(ex) == {"cfg5_sharded", "cfg3_sharded"}
+    for key in ex:
+        assert "error" not in ex[key], ex[key]
+        assert ex[key]["scaling"] == "strong" and ex[key]["n_gpus"] == 2 and ex[key]["value"] > 0
+    c5 = ex["cfg5_sharded"]["config"]
+    assert c5["comm"]["nranks"] == 2 and c5["comm"]["mode"] == "rows" and c5["single_gpu_same_workload"] > 0
