@@ -125,6 +125,10 @@ struct PolarPlan {
   int* gate_host = nullptr;  // pinned copy of PolarDev::gate for the non-speculative mode
   int batch_wave = 0;        // COSMO_HIP_POLAR_BATCH_WAVE=1: wave-per-tile product kernel (k_symm_gemm_batch_w) for the 64 x 64 tile class.  Bit-identical
                              // to the workgroup-per-tile kernel; measured on BASELINE config 5: 50.7 vs 47.3 us per product, 150.2 vs 154.7 it/s => opt-in
+  int batch_ragged = 1;      // block-balanced ragged tiles (k_symm_gemm_batch_r); COSMO_HIP_POLAR_BATCH_RAGGED=0: the 64 x 64 quadrant kernel
+  void* d_rtiles = nullptr;  // RTile list of the ragged kernel (XCD-interleaved like d_btiles)
+  int nrtiles = 0;
+  double batch_flops_performed = 0.0, batch_flops_useful = 0.0;   // per product: 16 x 16 x 16 blocks actually issued; sum d^2 (d + 1)
   int batch_ts96 = 0;        // COSMO_HIP_POLAR_BATCH_TS96=1: cones whose side fits 96 / 192 take 96 x 96 tiles in a second launch per product.
                              // Measured on BASELINE config 5: SLOWER, 62.2 vs 47.0 us per product, 133.9 vs 155.2 it/s (two launch tails per
                              // product, two workgroups per CU for the 96-class) => opt-in; profiles/r02_batch_tile_classes.txt
@@ -614,6 +618,180 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
                              ((bc.d + 31) / 32) * 32);
 }
 
+// ---- ragged, block-balanced form of the batched product (default; COSMO_HIP_POLAR_BATCH_RAGGED=0 restores k_symm_gemm_batch) -------
+// k_symm_gemm_batch gives every wave of a workgroup a fixed 32 x 32 quadrant of a 64 x 64 tile.  The time of a tile is then the time of
+// its busiest wave: the strictly-lower quadrant of a diagonal tile and the quadrants beyond the cone's side can be skipped (quadrant
+// masking), but the three / two / one remaining waves still do four 16 x 16 blocks each, wave w of every workgroup sits on SIMD w, and
+// the product runs at the pace of the fullest SIMD -- which is why masking 1.36x of the matrix instructions away bought nothing, and why
+// the cost of a cone was a staircase in ceil(d / 64) with 2.2x more performed than useful flops on the BASELINE config 5 mix.
+// Here a cone's side is rounded to 16 (the MFMA tile), cut into ceil(d16 / 64) nearly equal parts of 1-4 blocks, and a tile is the LIST
+// of its 16 x 16 blocks -- the upper blocks only on the diagonal -- dealt round-robin to the four waves (block q -> wave q % 4, slot
+// q / 4): a 64 x 64 diagonal tile costs 3 slots instead of 4, a 48 x 48 off-diagonal tile 3, a 48 x 48 diagonal tile 2, and the
+// k-loop stops at d16.  A wave's accumulators are its slots; the operand fragments of a slot are read from the same LDS panels at the
+// block's offsets.  Same instruction, same k order per output element => bit-identical to k_symm_gemm_batch (tests/test_gpu_parity_psd.py).
+// Operand panels are still loaded 64 wide from the tile's first row / column (ld stays a multiple of 64 and i0 + 64 <= ld by the way
+// the parts are chosen), the epilogue is the same LDS transposition restricted to the tile's extents.
+struct RTile { int cone; int i0, j0; int ext; };      // ext = ei | ej << 8 | diag << 16  (ei, ej in blocks of 16)
+
+template <int NSL>
+__device__ __forceinline__ void symm_mainloop_r(const real* __restrict__ A, const real* __restrict__ B, int ld, int i0, int j0, int nk, real* smem,
+                                                v4d (&acc)[4], const int (&oa)[4], const int (&ob)[4]) {
+  using Cfg = GemmCfg<64>;
+  constexpr int NL = Cfg::NL, PITCH = Cfg::PITCH, PANEL = Cfg::PANEL;
+  real* As = smem;
+  real* Bs = As + 2 * PANEL;
+  const int lane = threadIdx.x & 63;
+  const long long pstep = (long long)PK * ld;
+  int goff[NL], soff[NL];
+#pragma unroll
+  for (int u = 0; u < NL; ++u) {
+    const int q = threadIdx.x + 256 * u;
+    const int k = q / 32, c2 = q % 32;
+    goff[u] = k * ld + 2 * c2;
+    soff[u] = k * PITCH + 2 * c2;
+  }
+  const real* ga = A + i0;
+  const real* gb = B + j0;
+  real2 r[2][2 * NL];
+#define R_LOAD(R, KB)                                                                                     \
+  {                                                                                                       \
+    const long long o_ = (long long)(KB) * pstep;                                                         \
+    _Pragma("unroll") for (int u = 0; u < NL; ++u) {                                                      \
+      (R)[u] = *reinterpret_cast<const real2*>(ga + o_ + goff[u]);                                        \
+      (R)[NL + u] = *reinterpret_cast<const real2*>(gb + o_ + goff[u]);                                   \
+    }                                                                                                     \
+  }
+#define R_STORE(R, BUF)                                                                                   \
+  {                                                                                                       \
+    _Pragma("unroll") for (int u = 0; u < NL; ++u) {                                                      \
+      real* pa_ = As + (BUF) * PANEL + soff[u];                                                           \
+      real* pb_ = Bs + (BUF) * PANEL + soff[u];                                                           \
+      pa_[0] = (R)[u].x; pa_[1] = (R)[u].y;                                                               \
+      pb_[0] = (R)[NL + u].x; pb_[1] = (R)[NL + u].y;                                                     \
+    }                                                                                                     \
+  }
+  const int fl = lane & 15, fk = lane >> 4;
+  const real* apb[4]; const real* bpb[4];
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) { apb[sl] = As + fk * PITCH + fl + oa[sl]; bpb[sl] = Bs + fk * PITCH + fl + ob[sl]; }
+#define R_COMPUTE(BUF)                                                                                    \
+  {                                                                                                       \
+    _Pragma("unroll") for (int ks = 0; ks < PK / 4; ++ks) {                                               \
+      real av[NSL > 0 ? NSL : 1], bv[NSL > 0 ? NSL : 1];                                                  \
+      _Pragma("unroll") for (int sl = 0; sl < NSL; ++sl) {                                                \
+        av[sl] = apb[sl][(BUF) * PANEL + ks * 4 * PITCH];                                                 \
+        bv[sl] = bpb[sl][(BUF) * PANEL + ks * 4 * PITCH];                                                 \
+      }                                                                                                   \
+      _Pragma("unroll") for (int sl = 0; sl < NSL; ++sl) acc[sl] = MFMA_REAL(av[sl], bv[sl], acc[sl]);    \
+    }                                                                                                     \
+  }
+  R_LOAD(r[0], 0)
+  if (1 < nk) R_LOAD(r[1], 1)
+  R_STORE(r[0], 0)
+  __syncthreads();
+  for (int kb = 0; kb < nk; kb += 2) {
+    if (kb + 2 < nk) R_LOAD(r[0], kb + 2)
+    R_COMPUTE(0)
+    if (kb + 1 < nk) R_STORE(r[1], 1)
+    __syncthreads();
+    if (kb + 1 >= nk) break;
+    if (kb + 3 < nk) R_LOAD(r[1], kb + 3)
+    R_COMPUTE(1)
+    if (kb + 2 < nk) R_STORE(r[0], 0)
+    __syncthreads();
+  }
+#undef R_LOAD
+#undef R_STORE
+#undef R_COMPUTE
+}
+
+template <int EPI, int OCC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_symm_gemm_batch_r(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ gate,
+                                                         const RTile* __restrict__ tiles, const BatchCone* __restrict__ cones, real* __restrict__ W,
+                                                         int ia, int ib, int icin, int ic, real alpha, real beta) {
+  if (guard && ctl->halt) return;
+  extern __shared__ real smem[];
+  const RTile td = tiles[blockIdx.x];
+  if (td.cone < 0) return;                   // padding of the XCD-interleaved tile list
+  if (gate && !gate[td.cone]) return;        // fallback round: only the cones whose verification failed
+  const BatchCone bc = cones[td.cone];
+  const long long n2 = (long long)bc.ld * bc.ld;
+  real* base = W + bc.woff;
+  const real* A = base + ia * n2;
+  const real* B = base + ib * n2;
+  const real* Cin = base + icin * n2;
+  real* C = base + ic * n2;
+  const int ld = bc.ld;
+  const int ei = td.ext & 255, ej = (td.ext >> 8) & 255, diag = (td.ext >> 16) & 1;
+  const int nblk = diag ? ei * (ei + 1) / 2 : ei * ej;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  // this wave's blocks: q = wv, wv + 4, ...  Off-diagonal tile: q -> (q % ei, q / ei).  Diagonal tile: upper blocks column by column.
+  int oa[4], ob[4];
+  int nsl = 0;
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) {
+    const int q = wv + 4 * sl;
+    int bi = 0, bj = 0;
+    if (q < nblk) {
+      nsl = sl + 1;
+      if (diag) { bj = (q >= 6) ? 3 : (q >= 3) ? 2 : (q >= 1) ? 1 : 0; bi = q - bj * (bj + 1) / 2; }
+      else { bj = q / ei; bi = q - bj * ei; }
+    }
+    oa[sl] = 16 * bi; ob[sl] = 16 * bj;
+  }
+  v4d acc[4];
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) acc[sl] = v4d{0.0, 0.0, 0.0, 0.0};
+  const int nk = ((bc.d + 15) / 16);         // k-panels: rows / columns beyond d are zero in every operand of the iteration
+  switch (nsl) {                             // wave-uniform; a wave without a block still takes part in the panel loads and barriers
+    case 4: symm_mainloop_r<4>(A, B, ld, td.i0, td.j0, nk, smem, acc, oa, ob); break;
+    case 3: symm_mainloop_r<3>(A, B, ld, td.i0, td.j0, nk, smem, acc, oa, ob); break;
+    case 2: symm_mainloop_r<2>(A, B, ld, td.i0, td.j0, nk, smem, acc, oa, ob); break;
+    case 1: symm_mainloop_r<1>(A, B, ld, td.i0, td.j0, nk, smem, acc, oa, ob); break;
+    default: symm_mainloop_r<0>(A, B, ld, td.i0, td.j0, nk, smem, acc, oa, ob); break;
+  }
+  // epilogue: blocks -> Cs[j][i] (transposed through LDS), then C = alpha Cs + beta Cin on the tile's extents, mirrored below the diagonal
+  constexpr int CPITCH = GemmCfg<64>::CPITCH;
+  real* Cs = smem;
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) {
+    if (sl < nsl) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Cs[(ob[sl] + (lane & 15)) * CPITCH + oa[sl] + ACC_ROW(lane, q)] = acc[sl][q];
+    }
+  }
+  __syncthreads();
+  const int xi = 16 * ei, xj = 16 * ej;      // extents in elements
+  const int i0 = td.i0, j0 = td.j0;
+  {
+    real cin[16];
+    if (EPI == 1) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int e = threadIdx.x + 256 * k;
+        const int i = e & 63, j = e >> 6;
+        const bool ok = i < xi && j < xj && !(diag && i > j);
+        cin[k] = ok ? Cin[(long long)(j0 + j) * ld + i0 + i] : R(0.0);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int e = threadIdx.x + 256 * k;
+      const int i = e & 63, j = e >> 6;
+      if (i >= xi || j >= xj || (diag && i > j)) continue;
+      real v = Cs[j * CPITCH + i];
+      if (EPI == 1) { v = alpha * v + beta * cin[k]; Cs[j * CPITCH + i] = v; }
+      C[(long long)(j0 + j) * ld + i0 + i] = v;
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int j = e & 63, i = e >> 6;
+    if (i >= xi || j >= xj || (diag && i >= j)) continue;
+    C[(long long)(i0 + i) * ld + j0 + j] = Cs[j * CPITCH + i];
+  }
+}
+
 // ---- wave-per-tile variant of the batched product (barrier-free, LDS-free main loop) ---------------------------------------
 // The workgroup-per-tile kernel spends a workgroup barrier, a register -> LDS copy of two operand panels and LDS fragment reads on every
 // 16-deep k-panel; with the short k-loops of the mid-size cones (9-13 panels) its main loops reach 0.67 of the sustained matrix rate and do
@@ -975,6 +1153,7 @@ void polar_plan_destroy(cosmo_hip_handle* h) {
   if (q->sk_sync) (void)hipFree(q->sk_sync);
   if (q->d_bcones) (void)hipFree(q->d_bcones);
   if (q->d_btiles) (void)hipFree(q->d_btiles);
+  if (q->d_rtiles) (void)hipFree(q->d_rtiles);
   if (q->BW) (void)hipFree(q->BW);
   if (q->bparts) (void)hipFree(q->bparts);
   if (q->bnrm) (void)hipFree(q->bnrm);
@@ -1112,6 +1291,44 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
       tiles.insert(tiles.end(), tl.begin(), tl.end());
     }
     q->nbtiles = count[0]; q->nbtiles96 = count[1];
+    // ragged tile list (see k_symm_gemm_batch_r): a cone's side in blocks of 16, cut into ceil(nb16 / 4) nearly equal parts
+    if (const char* e = getenv("COSMO_HIP_POLAR_BATCH_RAGGED")) q->batch_ragged = atoi(e) ? 1 : 0;
+    if (q->batch_ts96 || q->batch_wave) q->batch_ragged = 0;
+    q->batch_flops_performed = q->batch_flops_useful = 0.0;
+    for (const BatchCone& bc : q->bcones) q->batch_flops_useful += (double)bc.d * bc.d * (bc.d + 1.0);
+    if (q->batch_ragged) {
+      std::vector<std::vector<RTile>> xl(8);
+      long long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int ci : order) {
+        const BatchCone& bc = q->bcones[ci];
+        const int nb16 = (bc.d + 15) / 16, nt = (nb16 + 3) / 4;
+        std::vector<int> start(nt + 1, 0);
+        for (int t = 0; t < nt; ++t) start[t + 1] = start[t] + nb16 / nt + (t < nb16 % nt ? 1 : 0);   // larger parts first: i0 + 64 <= ld for every tile
+        int x = 0;
+        for (int t = 1; t < 8; ++t) if (load[t] < load[x]) x = t;
+        for (int tj = 0; tj < nt; ++tj)
+          for (int ti = 0; ti <= tj; ++ti) {
+            const int ei = start[ti + 1] - start[ti], ej = start[tj + 1] - start[tj], dg = (ti == tj) ? 1 : 0;
+            RTile rt; rt.cone = ci; rt.i0 = 16 * start[ti]; rt.j0 = 16 * start[tj]; rt.ext = ei | (ej << 8) | (dg << 16);
+            if (rt.i0 + 64 > bc.ld || rt.j0 + 64 > bc.ld) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "ragged tile exceeds the leading dimension");
+            xl[x].push_back(rt);
+            const int nblk = dg ? ei * (ei + 1) / 2 : ei * ej, slots = (nblk + 3) / 4;
+            load[x] += (long long)slots * nb16;
+            q->batch_flops_performed += 2.0 * 256.0 * nblk * 16.0 * nb16;
+          }
+      }
+      size_t maxlen = 0;
+      for (int x = 0; x < 8; ++x) maxlen = std::max(maxlen, xl[x].size());
+      std::vector<RTile> rl(8 * std::max<size_t>(maxlen, 1), RTile{-1, 0, 0, 0});
+      for (int x = 0; x < 8; ++x) for (size_t sl = 0; sl < xl[x].size(); ++sl) rl[8 * sl + x] = xl[x][sl];
+      q->nrtiles = (int)rl.size();
+      HIPCHK(h, hipMalloc((void**)&q->d_rtiles, sizeof(RTile) * rl.size()));
+      HIPCHK(h, hipMemcpy(q->d_rtiles, rl.data(), sizeof(RTile) * rl.size(), hipMemcpyHostToDevice));
+      (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch_r<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
+      (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch_r<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
+    } else {
+      for (const BatchCone& bc : q->bcones) { const long long nt = bc.ld / bc.ts; q->batch_flops_performed += 2.0 * (double)(nt * (nt + 1) / 2) * bc.ts * bc.ts * (((bc.d + 31) / 32) * 32); }
+    }
     if (tiles.empty()) tiles.push_back(int4{-1, 0, 0, 0});
     HIPCHK(h, hipMalloc((void**)&q->BW, sizeof(real) * (size_t)woff));
     HIPCHK(h, hipMalloc((void**)&q->d_bcones, sizeof(BatchCone) * q->bcones.size()));
@@ -1140,6 +1357,11 @@ bool polar_has_large(const cosmo_hip_handle* h) { const PolarPlan* q = static_ca
 // 74.5 KB of LDS allow two workgroups per CU)
 template <int EPI>
 static void launch_bgemm(PolarPlan* q, hipStream_t st, const Ctl* ctl, int guard, const int* gate, int ia, int ib, int icin, int ic, real alpha, real beta) {
+  if (q->batch_ragged && q->nrtiles > 0) {
+    hipLaunchKernelGGL((k_symm_gemm_batch_r<EPI, 3>), dim3(q->nrtiles), dim3(256), GemmCfg<64>::SMEM, st, ctl, guard, gate, (const RTile*)q->d_rtiles, q->d_bcones,
+                       q->BW, ia, ib, icin, ic, alpha, beta);
+    return;
+  }
   if (q->nbtiles96 > 0)
     hipLaunchKernelGGL((k_symm_gemm_batch<EPI, 2, 96>), dim3(q->nbtiles96), dim3(256), GemmCfg<96>::SMEM, st, ctl, guard, gate, q->d_btiles + q->nbtiles,
                        q->d_bcones, q->BW, ia, ib, icin, ic, alpha, beta);
@@ -1339,8 +1561,7 @@ extern "C" int32_t cosmo_hip_time_psd_product(cosmo_hip_handle* h, int32_t which
         fl = 2.0 * (double)(nt * (nt + 1) / 2) * cn.ts * cn.ts * cn.ld;
       } else {
         launch_bgemm<0>(q, h->stream, h->ctl, 0, (const int*)nullptr, 1, 1, 1, 2, 1.0, 0.0);
-        fl = 0.0;
-        for (const BatchCone& bc : q->bcones) { const long long nt = bc.ld / bc.ts; fl += 2.0 * (double)(nt * (nt + 1) / 2) * bc.ts * bc.ts * (((bc.d + 31) / 32) * 32); }
+        fl = q->batch_flops_performed;
       }
     }
     if (pass == 1) HIPCHK(h, hipEventRecord(e1, h->stream));

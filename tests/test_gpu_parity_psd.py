@@ -235,6 +235,35 @@ def test_psd_polar_spectrum_with_tiny_eigenvalues():
     assert np.linalg.eigvalsh(cj.problems.smat(out)).min() >= -64 * d * EPS * np.linalg.norm(X)
 
 
+RAGGED_SIDES = [17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 80, 81, 96, 100, 112, 127, 128, 129, 130, 144, 145, 160, 176, 177, 191, 192, 193, 200, 208,
+                209, 224, 240, 241, 255, 256]
+
+
+def test_batched_sign_path_ragged_tiles_are_bit_identical_to_the_quadrant_kernel(monkeypatch):
+    """The block-balanced ragged product kernel (k_symm_gemm_batch_r: sides rounded to 16, 1-4 blocks per part, upper blocks only on
+    the diagonal, blocks dealt to the four waves) issues the same matrix instruction in the same k order per output element as the
+    64 x 64 quadrant kernel it replaces: every projected cone is bit-identical, for every way a side can sit in the 16 / 64 grid -- and
+    both are within the 64 d eps bound of dsyevr (src/convexset.jl:219-263)."""
+    rng = np.random.default_rng(2030)
+    mats = [sym_with_spectrum(rng, gapped_spectrum(rng, d)) * rng.uniform(0.1, 10.0) for d in RAGGED_SIDES]
+    sets = [cj.PsdConeTriangle(d * (d + 1) // 2) for d in RAGGED_SIDES]
+    s = np.concatenate([cj.problems.svec(X) for X in mats])
+    outs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("COSMO_HIP_POLAR_BATCH_RAGGED", flag)
+        h = _handle_for_sets(sets)
+        out, ranks, _ = h.project(s)
+        ps = h.polar_stats()
+        assert ps["batch_cones"] == len(sets)
+        outs[flag] = (out, np.asarray(ranks), h.time_psd_product(1, 3)[1])
+        h.close()
+    assert np.array_equal(outs["0"][0], outs["1"][0]) and np.array_equal(outs["0"][1], outs["1"][1])
+    assert outs["1"][2] < 0.75 * outs["0"][2]                  # matrix-instruction flops actually issued per product: ragged < quadrant kernel
+    useful = sum(2.0 * d * d * d for d in RAGGED_SIDES)       # full (unsymmetric) product of the d x d operands
+    assert outs["1"][2] <= 0.5 * 1.4 * useful * 1.15           # upper blocks only: ~half of the full product, <= 1.4x padding (+ rounding of small sides)
+    check_projection(sets, mats)                               # and the ragged kernel (default) against LAPACK
+
+
 def test_closest_correlation_end_to_end_polar_path():
     d = 288
     prob = cj.problems.closest_correlation(d=d, seed=7)
