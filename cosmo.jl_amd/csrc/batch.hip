@@ -7,7 +7,8 @@
 // (rho, CG residuals, counters, status) live with the problem: trajectories are those of 1024 separate solves, not of
 // one block-diagonal solve.  The phases reuse the row lambdas / CSR-stream primitive of the large-problem path, the
 // arithmetic per element is identical, reductions are single-workgroup fixed-order sums.
-// Cone support in batch mode: ZeroSet, Nonnegatives, Box, SecondOrderCone (PSD cones take the large-problem path).
+// Cone support in batch mode: ZeroSet, Nonnegatives, Box, SecondOrderCone (PSD cones take the large-problem path); their infeasibility
+// certificates run between persistent launches (k_batch_inf_capture / k_batch_inf_check below).
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
@@ -36,6 +37,7 @@ struct BatchDev {
   real *w, *w_prev, *s, *mu, *s_tl, *ls_s, *y2, *tmp_m, *nu, *rho;
   real *ls_x, *x_tl, *rhs, *r, *u, *c;
   BCtl* ctl;
+  real* inf_dy;                 // nprob * m: delta_y of the infeasibility certificates (captured between two launches)
   const real* tol_table; long long tol_len;   // tol_constant / k^tol_exponent, k = 1.. (host libm, as the large path)
 };
 
@@ -800,6 +802,130 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Infeasibility certificates in batch mode (src/solver.jl:145-148, 326-349; src/infeasibility.jl:1-68).  The persistent kernels keep
+// their registers for the iteration; the certificates run every check_infeasibility iterations only, so the host cuts the persistent
+// launch at those iterations (cosmo_hip_batch_optimize):  ... iteration k ci | k_batch_inf_capture | iteration k ci + 1 |
+// k_batch_inf_check | ...   Both kernels work on the state the persistent kernels leave in global memory (w, w_prev, s, rho), one
+// workgroup per problem, all scalar tests inside the workgroup in the reference's order; a decided problem gets its status (and
+// cost = +-Inf, solver.jl:339,345) and is skipped by every later launch.  Cones: ZeroSet / Nonnegatives / Box / SecondOrderCone
+// (the cones of batch mode): in_dual, in_pol_recc, support_function of src/convexset.jl:30-36, 76-82, 116-122, 850-861, 928-936.
+// ---------------------------------------------------------------------------------------------------------------------
+// delta_y at the top of the iteration that follows a flagged one: dy = mu = rho .* (w_prev_s - s)            (solver.jl:145-148)
+__global__ __launch_bounds__(COSMO_BS) void k_batch_inf_capture(BatchDev D) {
+  const int k = blockIdx.x;
+  if (D.ctl[k].status != 0) return;
+  const int n = D.n, m = D.m;
+  const long long om = (long long)k * m, onm = (long long)k * (n + m);
+  for (int i = threadIdx.x; i < m; i += COSMO_BS) D.inf_dy[om + i] = D.rho[om + i] * (D.w_prev[onm + n + i] - D.s[om + i]);
+}
+
+__global__ __launch_bounds__(COSMO_BS) void k_batch_inf_check(BatchDev D, real epi, real edi) {
+  __shared__ real lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ real red[COSMO_BS / 64];
+  __shared__ int flag;
+  const int k = blockIdx.x;
+  BCtl* ctl = D.ctl + k;
+  if (ctl->status != 0) return;
+  constexpr int BS = COSMO_BS;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n = D.n, m = D.m;
+  const long long on = (long long)k * n, om = (long long)k * m, onm = (long long)k * (n + m);
+  const real *w = D.w + onm, *w_prev = D.w_prev + onm, *s = D.s + om, *rho = D.rho + om, *q = D.q + on, *b = D.b + om;
+  const real *Dinv = D.Dinv + on, *Einv = D.Einv + om;
+  const real *bl = D.box_l + (long long)k * D.nbox, *bu = D.box_u + (long long)k * D.nbox;
+  real *dy = D.inf_dy + om, *dx = D.ls_x + on, *adx = D.tmp_m + om;      // ls_x / tmp_m: scratch between two launches (rebuilt by every solve)
+  const real c = R(1.0) / D.cinv[k];
+  // dy -= mu_new ; dx = w_x - w_prev_x ; ||E dy||_inf, ||D dx||_inf, <q, dx>                  (solver.jl:331-335, infeasibility.jl:5, 35, 39)
+  real ndy = 0.0, ndx = 0.0, qdx = 0.0;
+  for (int i = tid; i < n + m; i += BS) {
+    if (i < n) {
+      const real d = w[i] - w_prev[i];
+      dx[i] = d;
+      ndx = amax(ndx, (R(1.0) / Dinv[i]) * d);
+      qdx += q[i] * d;
+    } else {
+      const int r = i - n;
+      const real mu = rho[r] * (w_prev[i] - s[r]);
+      const real d = dy[r] - mu;
+      dy[r] = d;
+      ndy = amax(ndy, (R(1.0) / Einv[r]) * d);
+    }
+  }
+  const real norm_dy = bmax<BS>(ndy, red), norm_dx = bmax<BS>(ndx, red), q_dx = bsum<BS>(qdx, red);
+  __syncthreads();
+  // ||Dinv P dx||_inf and ||Dinv A' dy||_inf in one pass over [P | A']                              (infeasibility.jl:12-17, 44-49)
+  real a_p = 0.0, a_a = 0.0;
+  { const CsrView PT = bview(D.PT, k);
+    for (int t = 0; t < PT.nb; ++t)
+      csr_stream_tile(PT, dx, dy, t, lds, red, [&](int row, real px, real aty) { const real d = Dinv[row]; a_p = amax(a_p, px * d); a_a = amax(a_a, aty * d); }); }
+  const real pdx_norm = bmax<BS>(a_p, red), ady_norm = bmax<BS>(a_a, red);
+  __syncthreads();
+  // ---- is_primal_infeasible! (infeasibility.jl:1-29) ----
+  if (norm_dy > epi && ady_norm <= epi * norm_dy) {
+    if (tid == 0) flag = 0;
+    __syncthreads();
+    const real fneg = -R(1.0) / norm_dy;
+    real dtb = 0.0, box = 0.0;
+    int viol = 0;
+    for (int i = tid; i < m; i += BS) {
+      const real y = dy[i] * fneg;                     // delta_y *= (-1 / norm_dy)                   (:19)
+      dy[i] = y;
+      dtb += y * b[i];
+      const uint32_t mt = D.meta[i], kind = mt & 3u;
+      if (kind == 3u) { const uint32_t j = mt >> 2; box += (fabs(y) > epi && y > R(0.0)) ? y * bu[j] : y * bl[j]; }   // Box support function (convexset.jl:850-856)
+      else if (kind == 2u) { if (-y < -epi) viol = 1; }                                                                // in_dual(-y) of Nonnegatives (:76-78)
+    }
+    __syncthreads();
+    for (int cI = wv; cI < D.nsoc; cI += BS / 64) {   // in_dual(-y) of SecondOrderCone: ||y[2:]|| <= tol + (-y[1])   (:116-118)
+      const real* x = dy + D.soc_off[cI]; const int d = D.soc_dim[cI];
+      if (d == 0) continue;
+      real a = 0.0;
+      for (int i = 1 + lane; i < d; i += 64) { const real t = x[i]; a += t * t; }
+      const real nx = sqrt(wave_sum(a));
+      if (!(nx <= epi + (-x[0]))) viol = 1;
+    }
+    if (viol) atomicOr(&flag, 1);
+    const real dyt_b = bsum<BS>(dtb, red), box_sf = bsum<BS>(box, red);          // (their barriers also publish `flag`)
+    __syncthreads();
+    const real sF = (flag ? (real)INFINITY : box_sf) - dyt_b;                     // support_function!: 0 if -y in the dual cone else Inf (:928-936)
+    if (sF <= epi) {
+      if (tid == 0) { ctl->status = COSMO_HIP_PRIMAL_INFEASIBLE; ctl->cost = (real)INFINITY; }   // solver.jl:337-340
+      return;
+    }
+    __syncthreads();
+  }
+  // ---- is_dual_infeasible! (infeasibility.jl:32-68) ----
+  if (norm_dx > edi && q_dx / (norm_dx * c) < -edi && pdx_norm / (norm_dx * c) <= edi) {
+    if (tid == 0) flag = 0;
+    __syncthreads();
+    const real inv = R(1.0) / norm_dx;
+    { const CsrView A = bview(D.A, k);
+      for (int t = 0; t < A.nb; ++t)
+        csr_stream_tile(A, dx, dx, t, lds, red, [&](int row, real s1, real s2) { adx[row] = ((s1 + s2) * Einv[row]) * inv; }); }   // (:53-59)
+    __syncthreads();
+    int viol = 0;
+    for (int i = tid; i < m; i += BS) {               // in_pol_recc (convexset.jl:34-36, 80-82, 859-861)
+      const real x = adx[i];
+      const uint32_t mt = D.meta[i], kind = mt & 3u;
+      if (kind == 1u) { if (fabs(x) > edi) viol = 1; }
+      else if (kind == 2u) { if (x > edi) viol = 1; }
+      else if (kind == 3u) { const uint32_t j = mt >> 2; if ((bu[j] == (real)INFINITY && x > edi) || (bl[j] == -(real)INFINITY && x < -edi)) viol = 1; }
+    }
+    for (int cI = wv; cI < D.nsoc; cI += BS / 64) {   // in_pol_recc of SecondOrderCone: ||x[2:]|| <= tol - x[1]   (:120-122)
+      const real* x = adx + D.soc_off[cI]; const int d = D.soc_dim[cI];
+      if (d == 0) continue;
+      real a = 0.0;
+      for (int i = 1 + lane; i < d; i += 64) { const real t = x[i]; a += t * t; }
+      const real nx = sqrt(wave_sum(a));
+      if (!(nx <= edi - x[0])) viol = 1;
+    }
+    if (viol) atomicOr(&flag, 1);
+    __syncthreads();
+    if (!flag && tid == 0) { ctl->status = COSMO_HIP_DUAL_INFEASIBLE; ctl->cost = -(real)INFINITY; }   // solver.jl:343-346
+  }
+}
+
 // warm start (solver.jl:128-129) for all problems
 __global__ __launch_bounds__(COSMO_BS) void k_batch_set_w(BatchDev D, const real* __restrict__ x0, const real* __restrict__ s0,
                                                           const real* __restrict__ mu0) {
@@ -1142,12 +1268,6 @@ extern "C" int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hi
   if (p->kkt_kind != COSMO_HIP_KKT_CG) return bfail(b, COSMO_HIP_ERR_UNSUPPORTED, "batch mode implements the CG KKT solver");
   if (p->adaptive_rho && p->adaptive_rho_interval == 0) return bfail(b, COSMO_HIP_ERR_UNSUPPORTED, "adaptive_rho_interval == 0");
   if (b->finalized) return bfail(b, COSMO_HIP_ERR_INVALID, "batch already finalised");
-  // The persistent per-problem kernels do not evaluate the infeasibility certificates of src/solver.jl:326-349: refuse settings
-  // under which the reference WOULD evaluate them instead of silently running to max_iter (pass check_infeasibility <= 0 or
-  // >= max_iter; infeasible instances belong to the single-problem entry points, which implement the certificates).
-  if (p->check_infeasibility > 0 && (long long)p->check_infeasibility < p->max_iter)
-    return bfail(b, COSMO_HIP_ERR_UNSUPPORTED, "batch mode does not implement the infeasibility certificates: disable them explicitly "
-                                                "(check_infeasibility <= 0 or >= max_iter) or solve with cosmo_hip_optimize");
   b->prm = *p;
   const int nprob = b->nprob; const long long n = b->n, m = b->m;
   BatchDev& D = b->D;
@@ -1213,7 +1333,8 @@ extern "C" int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hi
   if ((rc = balloc(b, &D.w, NM)) || (rc = balloc(b, &D.w_prev, NM)) || (rc = balloc(b, &D.s, Nm)) || (rc = balloc(b, &D.mu, Nm)) ||
       (rc = balloc(b, &D.s_tl, Nm)) || (rc = balloc(b, &D.ls_s, Nm)) || (rc = balloc(b, &D.y2, Nm)) || (rc = balloc(b, &D.tmp_m, Nm)) ||
       (rc = balloc(b, &D.nu, Nm)) || (rc = balloc(b, &D.rho, Nm)) || (rc = balloc(b, &D.ls_x, Nn)) || (rc = balloc(b, &D.x_tl, Nn)) ||
-      (rc = balloc(b, &D.rhs, Nn)) || (rc = balloc(b, &D.r, Nn)) || (rc = balloc(b, &D.u, Nn)) || (rc = balloc(b, &D.c, Nn))) return rc;
+      (rc = balloc(b, &D.rhs, Nn)) || (rc = balloc(b, &D.r, Nn)) || (rc = balloc(b, &D.u, Nn)) || (rc = balloc(b, &D.c, Nn)) ||
+      (rc = balloc(b, &D.inf_dy, Nm))) return rc;
   BHIP(b, hipMemcpy(D.rho, rho0.data(), Nm * sizeof(real), hipMemcpyHostToDevice));
   std::vector<BCtl> ctl0(nprob);
   memset(ctl0.data(), 0, sizeof(BCtl) * nprob);
@@ -1275,13 +1396,27 @@ extern "C" int32_t cosmo_hip_batch_optimize(cosmo_hip_batch* b, cosmo_hip_result
   const BParams P = bparams(b->prm);
   const auto t0 = std::chrono::steady_clock::now();
   const long long slice = std::max<long long>(b->prm.check_termination, 1) * 8;
+  // certificates (solver.jl:326-349): iteration k ci sets the flag, delta_y is captured at the top of iteration k ci + 1 and the tests run at
+  // its end -- the persistent launch is cut at those two iterations (ci = 1 never tests: every iteration re-sets the flag, as in the reference)
+  const long long ci = b->prm.check_infeasibility;
+  const bool inf_on = ci > 1 && ci < b->prm.max_iter;
+  bool captured = false;
   long long target = 0;
   std::vector<BCtl> c(b->nprob);
   int first = 1;
   for (;;) {
-    target = std::min<long long>(target + slice, b->prm.max_iter);
+    long long stop = captured ? target + 1 : target + slice;
+    if (inf_on && !captured) stop = std::min(stop, (target / ci + 1) * ci);
+    target = std::min<long long>(stop, b->prm.max_iter);
     { const int32_t lrc = launch_batch_admm(b, P, target, first); if (lrc) return lrc; }
     first = 0;
+    if (captured) {
+      hipLaunchKernelGGL(k_batch_inf_check, dim3(b->nprob), dim3(COSMO_BS), 0, b->stream, b->D, (real)b->prm.eps_prim_inf, (real)b->prm.eps_dual_inf);
+      captured = false;
+    } else if (inf_on && target % ci == 0 && target < b->prm.max_iter) {
+      hipLaunchKernelGGL(k_batch_inf_capture, dim3(b->nprob), dim3(COSMO_BS), 0, b->stream, b->D);
+      captured = true;
+    }
     BHIP(b, hipMemcpyAsync(c.data(), b->D.ctl, sizeof(BCtl) * b->nprob, hipMemcpyDeviceToHost, b->stream));
     BHIP(b, hipStreamSynchronize(b->stream));
     bool all = true;

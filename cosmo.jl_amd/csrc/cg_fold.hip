@@ -251,7 +251,7 @@ int32_t fold_build(cosmo_hip_handle* h, const HostCsr& Am, const std::vector<int
       if (!diag_done) j = std::min(j, (int)i);
       if (j == INT32_MAX) break;
       real b = 0.0;
-      if (ip < ipe && pcol[ip] == j) { b = pval[ip]; ++ip; }
+      while (ip < ipe && pcol[ip] == j) { b += pval[ip]; ++ip; }      // duplicated entries of P (the C ABI passes them through) are summed, as the SpMV kernels do
       while (it < terms.size() && terms[it].j == j) { trow.push_back(terms[it].k); tprod.push_back(terms[it].prod); ++it; }
       if (j == (int)i) diag_done = true;
       M.col.push_back(j); M.val.push_back(0.0);

@@ -18,17 +18,21 @@
 // A-posteriori VERIFICATION (one extra product): with H = U X (needed anyway) the matrix G = U H - X = (U^2 - I) X has
 //     ||G||_F^2 = sum lambda_i^2 (1 - u_i^2)^2  >=  sum lambda_i^2 (1 - |u_i|)^2 = 4 ||X+ - X+_exact||_F^2,
 // so ||G||_F / 2 bounds the projection error rigorously (up to the rounding of the products, ~1e-15 ||X||_F).  If it exceeds
-// 8 d eps ||X||_F (1/8 of the parity tolerance 64 d eps), guarded FALLBACK rounds (3 more lifting steps + the finishing steps,
-// verified again) run on the device without host involvement: their launches are enqueued with the projection and return at
-// once unless the verification kernel opened the gate.  Eigenvalues so small that they never lift (|lambda| below
+// 8 d eps ||X||_F (1/8 of the parity tolerance 64 d eps), FALLBACK rounds (3 more lifting steps + the finishing steps, verified
+// again) run.  Two ways to schedule them (PolarPlan::speculate): ON DEMAND (default for a plan with at most two large cones, and for
+// the batch) -- after the main schedule the host reads the verification flag, ONE small stream synchronisation per large cone / per
+// batch and projection, and enqueues a round only if it is needed, so the loop is NOT sync-free while such cones are present; or
+// SPECULATIVELY (default from three large cones on, COSMO_HIP_POLAR_SPECULATE=1 forces it) -- both rounds are always enqueued behind
+// a device-side gate, 26 no-op launches per cone and round, and a projection involves no host synchronisation at all (a problem with
+// many d > 256 cones would otherwise drain the pipeline once per cone in every iteration).  Eigenvalues so small that they never lift (|lambda| below
 // ~1e-12 ||X||_F) perturb X+ by less than their own magnitude and pass the verification by construction.
 // rank = round((tr U + tr U^2) / 2) (exact when every eigenvalue was lifted; exact zeros count as not positive, like lambda > 0).
 //
 // Why this shape on MI355X: one-sided Jacobi at d = 2000 is ~3000 dependent tournament rounds of latency-bound 16x16
 // rotations (135-180 ms, 1 % MFMA-busy, profiles/r01_psd_mfma_counters.json); a tridiagonal QL/D&C chain is serial.  The sign
 // iteration is (k_lift + 5) * 3 + 2 = 47 products of d x d symmetric matrices whose result is symmetric, so only the upper
-// tiles are computed (d^3 flops per product) and mirrored: fixed schedule, no host synchronisation, every kernel guarded by
-// ctl->halt like the rest of the loop.
+// tiles are computed (d^3 flops per product) and mirrored: fixed main schedule, every kernel guarded by ctl->halt like the rest of
+// the loop; host involvement only as described above for the fallback decision.
 //
 // Kernel: k_symm_gemm -- C = alpha A B + beta Cin on the upper tiles, A and B symmetric (so both operands are read
 // "contiguous along the output index, strided along k"), 64x64 tile per workgroup of 4 waves (32x32 per wave = 2x2
@@ -125,6 +129,12 @@ struct PolarPlan {
   int* gate_host = nullptr;  // pinned copy of PolarDev::gate for the non-speculative mode
   int batch_wave = 0;        // COSMO_HIP_POLAR_BATCH_WAVE=1: wave-per-tile product kernel (k_symm_gemm_batch_w) for the 64 x 64 tile class.  Bit-identical
                              // to the workgroup-per-tile kernel; measured on BASELINE config 5: 50.7 vs 47.3 us per product, 150.2 vs 154.7 it/s => opt-in
+  int bstreams = 1;          // COSMO_HIP_POLAR_BATCH_STREAMS=2: the batch's cones are dealt into two halves whose product sequences run on two HIP
+                             // streams (fork after the scaling, join before every verification), so that the ramp-up and tail of one half's
+                             // launch overlap the other half's steady state
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int rt_off[3] = {0, 0, 0}; // ragged tile list: group g owns descriptors [rt_off[g], rt_off[g + 1])
   int batch_ragged = 1;      // block-balanced ragged tiles (k_symm_gemm_batch_r); COSMO_HIP_POLAR_BATCH_RAGGED=0: the 64 x 64 quadrant kernel
   void* d_rtiles = nullptr;  // RTile list of the ragged kernel (XCD-interleaved like d_btiles)
   int nrtiles = 0;
@@ -633,9 +643,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 // the parts are chosen), the epilogue is the same LDS transposition restricted to the tile's extents.
 struct RTile { int cone; int i0, j0; int ext; };      // ext = ei | ej << 8 | diag << 16  (ei, ej in blocks of 16)
 
-template <int NSL>
+template <int NSL, class PreLast>
 __device__ __forceinline__ void symm_mainloop_r(const real* __restrict__ A, const real* __restrict__ B, int ld, int i0, int j0, int nk, real* smem,
-                                                v4d (&acc)[4], const int (&oa)[4], const int (&ob)[4]) {
+                                                v4d (&acc)[4], const int (&oa)[4], const int (&ob)[4], PreLast pre_last) {
   using Cfg = GemmCfg<64>;
   constexpr int NL = Cfg::NL, PITCH = Cfg::PITCH, PANEL = Cfg::PANEL;
   real* As = smem;
@@ -689,17 +699,23 @@ __device__ __forceinline__ void symm_mainloop_r(const real* __restrict__ A, cons
   if (1 < nk) R_LOAD(r[1], 1)
   R_STORE(r[0], 0)
   __syncthreads();
-  for (int kb = 0; kb < nk; kb += 2) {
+  // All panels but the last run in the two-phase loop; the LAST panel is peeled so that pre_last() -- a hook for work that should overlap
+  // the last panel's matrix instructions -- sits in straight-line code (inside the loop anything it loads stays live across every
+  // iteration: a Cin prefetch spilled 436 bytes per lane there).
+  for (int kb = 0; kb + 1 < nk; kb += 2) {
     if (kb + 2 < nk) R_LOAD(r[0], kb + 2)
     R_COMPUTE(0)
-    if (kb + 1 < nk) R_STORE(r[1], 1)
+    R_STORE(r[1], 1)
     __syncthreads();
-    if (kb + 1 >= nk) break;
+    if (kb + 2 >= nk) break;
     if (kb + 3 < nk) R_LOAD(r[1], kb + 3)
     R_COMPUTE(1)
-    if (kb + 2 < nk) R_STORE(r[0], 0)
+    R_STORE(r[0], 0)
     __syncthreads();
   }
+  pre_last();
+  if ((nk - 1) & 1) R_COMPUTE(1) else R_COMPUTE(0)
+  __syncthreads();
 #undef R_LOAD
 #undef R_STORE
 #undef R_COMPUTE
@@ -743,12 +759,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 #pragma unroll
   for (int sl = 0; sl < 4; ++sl) acc[sl] = v4d{0.0, 0.0, 0.0, 0.0};
   const int nk = ((bc.d + 15) / 16);         // k-panels: rows / columns beyond d are zero in every operand of the iteration
+  const int xi = 16 * ei, xj = 16 * ej;      // extents in elements
+  const int i0 = td.i0, j0 = td.j0;
+  real cin[16];
+  auto load_cin = [&]() {
+    if (EPI == 1) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int e = threadIdx.x + 256 * k;
+        const int i = e & 63, j = e >> 6;
+        const bool ok = i < xi && j < xj && !(diag && i > j);
+        cin[k] = Cin[ok ? (long long)(j0 + j) * ld + i0 + i : 0];
+        if (!ok) cin[k] = R(0.0);
+      }
+    }
+  };
+  // Requesting Cin before the last panel's matrix instructions (pre_last = load_cin) was built and measured on BASELINE config 5: 188.1 vs
+  // 188.3 it/s -- with three workgroups per CU the epilogue's round trip is already covered by the other workgroups' main loops.
+  auto pre_last = [&]() {};
   switch (nsl) {                             // wave-uniform; a wave without a block still takes part in the panel loads and barriers
-    case 4: symm_mainloop_r<4>(A, B, ld, td.i0, td.j0, nk, smem, acc, oa, ob); break;
-    case 3: symm_mainloop_r<3>(A, B, ld, td.i0, td.j0, nk, smem, acc, oa, ob); break;
-    case 2: symm_mainloop_r<2>(A, B, ld, td.i0, td.j0, nk, smem, acc, oa, ob); break;
-    case 1: symm_mainloop_r<1>(A, B, ld, td.i0, td.j0, nk, smem, acc, oa, ob); break;
-    default: symm_mainloop_r<0>(A, B, ld, td.i0, td.j0, nk, smem, acc, oa, ob); break;
+    case 4: symm_mainloop_r<4>(A, B, ld, i0, j0, nk, smem, acc, oa, ob, pre_last); break;
+    case 3: symm_mainloop_r<3>(A, B, ld, i0, j0, nk, smem, acc, oa, ob, pre_last); break;
+    case 2: symm_mainloop_r<2>(A, B, ld, i0, j0, nk, smem, acc, oa, ob, pre_last); break;
+    case 1: symm_mainloop_r<1>(A, B, ld, i0, j0, nk, smem, acc, oa, ob, pre_last); break;
+    default: symm_mainloop_r<0>(A, B, ld, i0, j0, nk, smem, acc, oa, ob, pre_last); break;
   }
   // epilogue: blocks -> Cs[j][i] (transposed through LDS), then C = alpha Cs + beta Cin on the tile's extents, mirrored below the diagonal
   constexpr int CPITCH = GemmCfg<64>::CPITCH;
@@ -761,19 +795,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     }
   }
   __syncthreads();
-  const int xi = 16 * ei, xj = 16 * ej;      // extents in elements
-  const int i0 = td.i0, j0 = td.j0;
   {
-    real cin[16];
-    if (EPI == 1) {
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int e = threadIdx.x + 256 * k;
-        const int i = e & 63, j = e >> 6;
-        const bool ok = i < xi && j < xj && !(diag && i > j);
-        cin[k] = ok ? Cin[(long long)(j0 + j) * ld + i0 + i] : R(0.0);
-      }
-    }
+    load_cin();
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int e = threadIdx.x + 256 * k;
@@ -1154,6 +1177,9 @@ void polar_plan_destroy(cosmo_hip_handle* h) {
   if (q->d_bcones) (void)hipFree(q->d_bcones);
   if (q->d_btiles) (void)hipFree(q->d_btiles);
   if (q->d_rtiles) (void)hipFree(q->d_rtiles);
+  if (q->stream2) { (void)hipStreamSynchronize(q->stream2); (void)hipStreamDestroy(q->stream2); }
+  if (q->ev_fork) (void)hipEventDestroy(q->ev_fork);
+  if (q->ev_join) (void)hipEventDestroy(q->ev_join);
   if (q->BW) (void)hipFree(q->BW);
   if (q->bparts) (void)hipFree(q->bparts);
   if (q->bnrm) (void)hipFree(q->bnrm);
@@ -1185,6 +1211,7 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
   if (const char* e = getenv("COSMO_HIP_POLAR_STREAMK")) q->streamk = atoi(e) ? 1 : 0;
   if (const char* e = getenv("COSMO_HIP_POLAR_BATCH_TS96")) q->batch_ts96 = atoi(e) ? 1 : 0;
   if (const char* e = getenv("COSMO_HIP_POLAR_BATCH_WAVE")) q->batch_wave = atoi(e) ? 1 : 0;
+  q->speculate = (large_list.size() > 2) ? 1 : 0;          // many large cones: no pipeline drain per cone (see the header)
   if (const char* e = getenv("COSMO_HIP_POLAR_SPECULATE")) q->speculate = atoi(e) ? 1 : 0;
   HIPCHK(h, hipHostMalloc((void**)&q->gate_host, sizeof(int), hipHostMallocDefault));
   *q->gate_host = 0;
@@ -1296,10 +1323,17 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
     if (q->batch_ts96 || q->batch_wave) q->batch_ragged = 0;
     q->batch_flops_performed = q->batch_flops_useful = 0.0;
     for (const BatchCone& bc : q->bcones) q->batch_flops_useful += (double)bc.d * bc.d * (bc.d + 1.0);
+    if (const char* e = getenv("COSMO_HIP_POLAR_BATCH_STREAMS")) q->bstreams = (atoi(e) == 2) ? 2 : 1;
+    if (!q->batch_ragged) q->bstreams = 1;
     if (q->batch_ragged) {
+     std::vector<RTile> rl_all;
+     for (int grp = 0; grp < q->bstreams; ++grp) {
       std::vector<std::vector<RTile>> xl(8);
       long long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      int ord_pos = -1;
       for (int ci : order) {
+        ++ord_pos;
+        if (q->bstreams == 2 && (ord_pos & 1) != grp) continue;      // cones alternate between the groups in descending-size order
         const BatchCone& bc = q->bcones[ci];
         const int nb16 = (bc.d + 15) / 16, nt = (nb16 + 3) / 4;
         std::vector<int> start(nt + 1, 0);
@@ -1321,7 +1355,17 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
       for (int x = 0; x < 8; ++x) maxlen = std::max(maxlen, xl[x].size());
       std::vector<RTile> rl(8 * std::max<size_t>(maxlen, 1), RTile{-1, 0, 0, 0});
       for (int x = 0; x < 8; ++x) for (size_t sl = 0; sl < xl[x].size(); ++sl) rl[8 * sl + x] = xl[x][sl];
+      q->rt_off[grp] = (int)rl_all.size();
+      rl_all.insert(rl_all.end(), rl.begin(), rl.end());
+      q->rt_off[grp + 1] = (int)rl_all.size();
+     }
+      const std::vector<RTile>& rl = rl_all;
       q->nrtiles = (int)rl.size();
+      if (q->bstreams == 2) {
+        HIPCHK(h, hipStreamCreateWithFlags(&q->stream2, hipStreamNonBlocking));
+        HIPCHK(h, hipEventCreateWithFlags(&q->ev_fork, hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&q->ev_join, hipEventDisableTiming));
+      }
       HIPCHK(h, hipMalloc((void**)&q->d_rtiles, sizeof(RTile) * rl.size()));
       HIPCHK(h, hipMemcpy(q->d_rtiles, rl.data(), sizeof(RTile) * rl.size(), hipMemcpyHostToDevice));
       (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch_r<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
@@ -1358,8 +1402,12 @@ bool polar_has_large(const cosmo_hip_handle* h) { const PolarPlan* q = static_ca
 template <int EPI>
 static void launch_bgemm(PolarPlan* q, hipStream_t st, const Ctl* ctl, int guard, const int* gate, int ia, int ib, int icin, int ic, real alpha, real beta) {
   if (q->batch_ragged && q->nrtiles > 0) {
-    hipLaunchKernelGGL((k_symm_gemm_batch_r<EPI, 3>), dim3(q->nrtiles), dim3(256), GemmCfg<64>::SMEM, st, ctl, guard, gate, (const RTile*)q->d_rtiles, q->d_bcones,
-                       q->BW, ia, ib, icin, ic, alpha, beta);
+    for (int grp = 0; grp < q->bstreams; ++grp) {
+      const int cnt = q->rt_off[grp + 1] - q->rt_off[grp];
+      if (cnt <= 0) continue;
+      hipLaunchKernelGGL((k_symm_gemm_batch_r<EPI, 3>), dim3(cnt), dim3(256), GemmCfg<64>::SMEM, (grp == 1) ? q->stream2 : st, ctl, guard, gate,
+                         (const RTile*)q->d_rtiles + q->rt_off[grp], q->d_bcones, q->BW, ia, ib, icin, ic, alpha, beta);
+    }
     return;
   }
   if (q->nbtiles96 > 0)
@@ -1387,6 +1435,9 @@ int32_t polar_enqueue_project_batch(cosmo_hip_handle* h, real* s, int guard) {
   hipLaunchKernelGGL(k_bpolar_populate, dim3(BPX, n), dim3(COSMO_BS), 0, st, h->ctl, guard, q->d_bcones, s, q->BW, q->bparts);
   hipLaunchKernelGGL(k_bpolar_scale, dim3(BPX, n), dim3(COSMO_BS), 0, st, h->ctl, guard, q->d_bcones, q->bparts, q->BW, q->bnrm);
   int iu = 1, iy = 2, products = 0;
+  // two-stream mode: the second half's products run on stream2 between fork (after the scaling) and join (before the verification sums)
+  auto fork = [&]() { if (q->bstreams == 2) { (void)hipEventRecord(q->ev_fork, st); (void)hipStreamWaitEvent(q->stream2, q->ev_fork, 0); } };
+  auto join = [&]() { if (q->bstreams == 2) { (void)hipEventRecord(q->ev_join, q->stream2); (void)hipStreamWaitEvent(st, q->ev_join, 0); } };
   auto step = [&](const real* co, const int* gate) {
     launch_bgemm<0>(q, st, h->ctl, guard, gate, iu, iu, iu, iy, 1.0, 0.0);       // Y = U^2
     launch_bgemm<1>(q, st, h->ctl, guard, gate, iy, iy, iy, 3, co[2], co[1]);    // T = c Y^2 + b Y
@@ -1397,11 +1448,13 @@ int32_t polar_enqueue_project_batch(cosmo_hip_handle* h, real* s, int guard) {
   auto verify = [&](int round, const int* gate) {
     launch_bgemm<0>(q, st, h->ctl, guard, gate, iu, 0, 0, 3, 1.0, 0.0);          // H = U X = |X|
     launch_bgemm<1>(q, st, h->ctl, guard, gate, iu, 3, 0, iy, 1.0, -1.0);        // G = U H - X
+    join();
     hipLaunchKernelGGL(k_bpolar_sumsq, dim3(BPX, n), dim3(COSMO_BS), 0, st, h->ctl, guard, gate, q->d_bcones, q->BW, iy, vparts);
     hipLaunchKernelGGL(k_bpolar_decide, dim3(1), dim3(COSMO_BS), 0, st, h->ctl, guard, q->dev, q->bgate, round, round == q->max_rounds ? 1 : 0, n, q->d_bcones,
                        vparts, q->bnrm, q->tol_factor);
     products += 2; q->launches[3] += 2;
   };
+  fork();
   for (int t = 0; t < q->k_lift; ++t) step(kPolarLift, nullptr);
   for (int t = 0; t < POLAR_NFIN; ++t) step(kPolarFinish[t], nullptr);
   verify(0, nullptr);
@@ -1412,6 +1465,7 @@ int32_t polar_enqueue_project_batch(cosmo_hip_handle* h, real* s, int guard) {
       HIPCHK(h, hipStreamSynchronize(st));
       if (!*q->gate_host) break;
     }
+    fork();
     for (int t = 0; t < POLAR_RLIFT; ++t) step(kPolarLift, q->bgate);
     for (int t = 0; t < POLAR_NFIN; ++t) step(kPolarFinish[t], q->bgate);
     verify(r, q->bgate);

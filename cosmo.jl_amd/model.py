@@ -775,13 +775,6 @@ def prepare_batch(models: Sequence[Model], device: int):
             raise ValueError("optimize_batch: all problems of a batch share ONE Settings object (per-problem settings are not supported)")
     if st.accelerator not in (None, EmptyAccelerator):
         raise ValueError("optimize_batch: the batch kernels implement the plain ADMM loop (EmptyAccelerator) only")
-    if 0 < st.check_infeasibility < st.max_iter:
-        import dataclasses
-        import warnings
-        warnings.warn("optimize_batch: the batch kernels do not evaluate the infeasibility certificates (src/solver.jl:326-349); "
-                      "they are DISABLED for this batch -- an infeasible problem runs to Max_iter_reached.  Solve suspect instances with "
-                      "optimize(), which implements them.", RuntimeWarning, stacklevel=3)
-        st = dataclasses.replace(st, check_infeasibility=0)
     B = _ffi.Batch(len(models), n, m, device, dtype=getattr(models[0], "dtype", np.float64))
     bl, bu = [], []
     for k, md in enumerate(models):                      # setup! per problem (scaling on the host, as in the reference)

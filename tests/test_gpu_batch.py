@@ -142,3 +142,87 @@ def test_batch_register_kernel_default_schedule_matches_oracle():
         assert r.status == ref.status == "Solved"
         assert abs(r.iter - ref.iter) <= 25
         assert abs(r.obj_val - ref.obj_val) <= 1e-4 * (1 + abs(ref.obj_val))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# infeasibility certificates in batch mode (csrc/batch.hip: k_batch_inf_capture / k_batch_inf_check between persistent launches;
+# src/solver.jl:326-349, src/infeasibility.jl:1-68, src/convexset.jl:116-122, 850-861)
+# ---------------------------------------------------------------------------------------------------------------------
+import scipy.sparse as sp          # noqa: E402
+from tests import infeasible_instances as INF   # noqa: E402
+
+
+def _box(Am, b, P, q, l, u, st):
+    md = cj.Model()
+    cj.assemble(md, np.array(P, dtype=float), np.array(q, dtype=float), cj.Constraint(sp.csc_matrix(np.array(Am, dtype=float)), np.array(b, dtype=float),
+                                                                                        cj.Box(np.array(l, dtype=float), np.array(u, dtype=float))), settings=st)
+    return md
+
+
+@pytest.mark.parametrize("stkw", [dict(), dict(check_infeasibility=20, scaling=0)])
+def test_batch_box_infeasibility_goldens(stkw):
+    """The reference's Box goldens (test/UnitTests/qp-box.jl:35-106) as ONE batch together with a feasible problem of the same structure:
+    every problem gets the status (and iteration count) of its own single-problem solve; no warning, no disabled certificates."""
+    import warnings
+    st = cj.Settings(**stkw)
+    specs = [([[1.0, 0], [1, 0]], [2.0, 0], np.eye(2), [1.0, -1], [0.0, 0], [1.0, 1], "Primal_infeasible"),          # qp-box.jl:50
+             ([[1.0, 0], [1, 0]], [0.0, 0], np.eye(2), [1.0, -1], [0.0, 2], [1.0, 3], "Primal_infeasible"),          # qp-box.jl:68
+             (np.eye(2), [1.0, 1], np.zeros((2, 2)), [1.0, 1], [0.0, -np.inf], [1.0, 3], "Dual_infeasible"),         # qp-box.jl:87,105
+             (np.eye(2), [0.0, 0], np.eye(2), [1.0, -1], [0.0, 0], [1.0, 1], "Solved")]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                                   # the round-2 RuntimeWarning ("certificates DISABLED") must be gone
+        res = cj.optimize_batch([_box(*sp_[:6], st) for sp_ in specs])
+    for sp_, r in zip(specs, res):
+        single = cj.optimize(_box(*sp_[:6], st))
+        assert r.status == single.status == sp_[6], (r.status, single.status, sp_[6])
+        assert abs(r.iter - single.iter) <= (0 if sp_[6] != "Solved" else 25), (r.iter, single.iter)
+        if sp_[6] == "Primal_infeasible":
+            assert r.obj_val == np.inf                                   # solver.jl:339
+        if sp_[6] == "Dual_infeasible":
+            assert r.obj_val == -np.inf                                  # solver.jl:345
+
+
+def test_batch_soc_infeasibility_matches_oracle():
+    n = 3
+    A1 = np.eye(3); b1 = np.zeros(3)
+    A2 = np.array([[1.0, 0, 0]])
+    # batch 1: (t, v) in SOC(3) with t fixed to -1 (primal infeasible) next to t fixed to +1 (feasible)
+    cases = [(np.zeros((n, n)), np.array([0.0, 1.0, 1.0]), np.array([1.0])), (np.zeros((n, n)), np.array([0.0, 1.0, 1.0]), np.array([-1.0]))]
+    mods, refs = [], []
+    for P, q, b2 in cases:
+        md = cj.Model(); cj.assemble(md, P, q, [cj.Constraint(A1, b1, cj.SecondOrderCone), cj.Constraint(A2, b2, cj.ZeroSet)], settings=cj.Settings())
+        mods.append(md)
+        A, b, cones = O.assemble([O.Constraint(A1, b1, O.SecondOrderCone(3)), O.Constraint(A2, b2, O.ZeroSet(1))])
+        refs.append(O.solve(P, q, A, b, cones, O.Settings(kkt_solver="cg")))
+    res = cj.optimize_batch(mods)
+    assert [r.status for r in res] == [ref.status for ref in refs] == ["Primal_infeasible", "Solved"]
+    assert res[0].iter == refs[0].iter and abs(res[1].iter - refs[1].iter) <= 25
+    # batch 2: minimise -t over the cone (unbounded: dual infeasible) next to minimise +t (solved at 0)
+    mods, refs = [], []
+    for q in (np.array([-1.0, 0.0, 0.0]), np.array([1.0, 0.0, 0.0])):
+        md = cj.Model(); cj.assemble(md, np.zeros((n, n)), q, [cj.Constraint(A1, b1, cj.SecondOrderCone)], settings=cj.Settings())
+        mods.append(md)
+        A, b, cones = O.assemble([O.Constraint(A1, b1, O.SecondOrderCone(3))])
+        refs.append(O.solve(np.zeros((n, n)), q, A, b, cones, O.Settings(kkt_solver="cg")))
+    res = cj.optimize_batch(mods)
+    assert [r.status for r in res] == [ref.status for ref in refs] == ["Dual_infeasible", "Solved"]
+    assert res[0].iter == refs[0].iter
+
+
+@pytest.mark.parametrize("family,seed", [(f, s_) for (f, s_) in INF.CASES if f in ("primal_infeasible_1", "dual_infeasible_1")])
+def test_batch_infeasible_families_match_oracle(family, seed):
+    """The reference's randomised infeasible-by-construction LP families (InfeasibilityTests/primal_infeasible_1.jl, dual_infeasible_1.jl;
+    the other three contain PsdCone blocks, which are not batch-mode cones) through optimize_batch."""
+    gen, accepted, _ = INF.FAMILIES[family]
+    P, q, cons = gen(seed)
+    st = dict(max_iter=2000, eps_abs=1e-5, eps_rel=1e-5)
+    tight = dict(tol_constant=1e-10, tol_exponent=0.0)
+    kinds = {INF.ZERO: cj.ZeroSet, INF.NONNEG: cj.Nonnegatives, INF.SOC: cj.SecondOrderCone}
+    md = cj.Model()
+    cj.assemble(md, P, q, [cj.Constraint(A, b, kinds[k]) for (A, b, k, d) in cons],
+                settings=cj.Settings(kkt_solver=cj.with_options(cj.CGIndirectKKTSolver, **tight), **st))
+    res = cj.optimize_batch([md])[0]
+    A, b, cones = O.assemble([O.Constraint(A, b, O.Cone(k, d, constr_type=(np.zeros(d, dtype=bool) if k == O.NONNEG else None))) for (A, b, k, d) in cons])
+    ref = O.solve(P, q, A, b, cones, O.Settings(kkt_solver="cg", **tight, **st))
+    assert res.status == ref.status and res.status in accepted, (res.status, ref.status)
+    assert abs(res.iter - ref.iter) <= 40, (res.iter, ref.iter)
