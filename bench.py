@@ -35,6 +35,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+if "--cpu-leg" in sys.argv:          # child process of the all-threads cpu_baseline leg: pin the cores BEFORE OpenBLAS creates its threads
+    _cpus = [int(c) for c in sys.argv[sys.argv.index("--cpu-leg-cpus") + 1].split(",")]
+    os.sched_setaffinity(0, _cpus)
+    os.environ["OPENBLAS_NUM_THREADS"] = os.environ["OMP_NUM_THREADS"] = str(len(_cpus))
+
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
@@ -154,61 +159,107 @@ def host_threads():
         return os.cpu_count() or 1
 
 
-def oracle_rate(prob, iters, threads):
-    """ADMM iterations/s of the NumPy/SciPy oracle (LAPACK dsyevr projections through SciPy's OpenBLAS) with `threads` BLAS threads.
+def _cpulist(text):
+    out = set()
+    for part in text.strip().split(","):
+        if part:
+            a, _, b = part.partition("-")
+            out.update(range(int(a), int(b or a) + 1))
+    return out
+
+
+def numa_node0_physical_cores(cap=32):
+    """One hardware thread per physical core of NUMA node 0 among the CPUs this process may use (the all-threads BLAS leg runs there: spread over
+    both sockets / all 256 hardware threads of the GPU host, OpenBLAS' syevr was SLOWER than one thread in round 2).  Returns (cpu ids, description)."""
+    allowed = set(os.sched_getaffinity(0))
+    try:
+        node0 = _cpulist(open("/sys/devices/system/node/node0/cpulist").read()) & allowed
+        where = "NUMA node 0"
+    except Exception:
+        node0, where = set(allowed), "all allowed CPUs (no NUMA information)"
+    if not node0:
+        node0, where = set(allowed), "all allowed CPUs (node 0 not in the affinity mask)"
+    cores = {}
+    for c in sorted(node0):
+        try:
+            key = min(_cpulist(open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read()))
+        except Exception:
+            key = c
+        cores.setdefault(key, c)
+    cpus = sorted(cores.values())[:cap]
+    return cpus, "%d physical cores of %s (one hardware thread each; host exposes %d hardware threads)" % (len(cpus), where, len(allowed))
+
+
+def _native_oracle():
+    """The compiled C restatement (oracle/cosmo_oracle_c.c) built -O3 -march=native ON the host whose cores are timed."""
+    import subprocess
+    from oracle import cosmo_oracle_c as OC
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "native"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    OC.lib(native=True)
+    return OC
+
+
+def compiled_cpu_rate(prob, iters, threads=1):
+    """ADMM iterations/s of the compiled C loop (Julia-style CSC SpMVs, serial cone loop, LAPACK ?syevr + BLAS ?syrk projections through SciPy's
+    OpenBLAS with `threads` BLAS threads) on a NumPy-oracle workspace (setup = scaling / classification, excluded like the reference's setup!).
     The init step (one KKT solve) is part of iter_time on both sides."""
     from oracle import cosmo_oracle as O
     from tests import util
     from threadpoolctl import threadpool_limits
+    OC = _native_oracle()
+    ws = O.Workspace(prob["P"], prob["q"], prob["A"], prob["b"], util.oracle_cones(prob["sets"]), oracle_settings(O, iters))
     with threadpool_limits(limits=threads):
-        ws = O.Workspace(prob["P"], prob["q"], prob["A"], prob["b"], util.oracle_cones(prob["sets"]), oracle_settings(O, iters))
-        res = ws.optimize()
-    return res.iter / res.iter_time, res.iter, res.iter_time, float(np.mean(res.cg_iters))
+        c = OC.run(ws, native=True)
+    return dict(rate=c["iter"] / c["iter_time"], iters=c["iter"], secs=c["iter_time"], cg=c["cg_iters_total"] / (c["iter"] + 1.0), proj_secs=c["proj_time"])
 
 
-def lapack_cpu_baseline(prob, iters, label):
-    """cpu_baseline for the SDP configurations: 1 BLAS thread (what the tagged reference does outside BLAS) and all host threads."""
-    nt = min(host_threads(), 32)       # dsyevr / syrk at these sizes stop scaling long before the 256 threads of the GPU box's host
-    v1, it1, s1, cg1 = oracle_rate(prob, iters, 1)
-    out = dict(value=v1, unit="ADMM iterations/s", cores=1, kind="port",
-               sample="NumPy/SciPy oracle (dsyevr + syrk projections, restated cg!): %d ADMM iteration(s) + init step of the same %s instance, %.1f s, "
-                      "1 BLAS thread; mean CG its/solve %.1f" % (it1, label, s1, cg1))
-    if nt > 1:
-        vn, itn, sn, _ = oracle_rate(prob, iters, nt)
-        out["all_threads"] = dict(value=vn, cores=nt, sample="%d iteration(s), %.1f s, OPENBLAS threads = %d (host has %d)" % (itn, sn, nt, host_threads()))
+def compiled_cpu_baseline(prob, iters, label, workload_key, args, with_all_threads=True):
+    """cpu_baseline of one configuration: the compiled loop with 1 thread (what the tagged reference does outside BLAS) and -- where LAPACK is
+    involved -- with the physical cores of one NUMA node as BLAS threads, run in a child process that is pinned to them before OpenBLAS starts."""
+    r1 = compiled_cpu_rate(prob, iters, 1)
+    out = dict(value=r1["rate"], unit="ADMM iterations/s", cores=1, kind="port",
+               sample="compiled C loop (gcc -O3 -march=native; oracle/cosmo_oracle_c.c): %d ADMM iteration(s) + init step of the same %s instance, %.1f s "
+                      "(%.1f s of it in the cone projections), 1 thread; mean CG its/solve %.1f" % (r1["iters"], label, r1["secs"], r1["proj_secs"], r1["cg"]))
+    if with_all_threads:
+        import subprocess
+        cpus, where = numa_node0_physical_cores()
+        if len(cpus) > 1:
+            cmd = [sys.executable, os.path.abspath(__file__), "--cpu-leg", workload_key, "--cpu-leg-cpus", ",".join(map(str, cpus)), "--cpu-leg-iters", str(iters)]
+            if args.small:
+                cmd.append("--small")
+            try:
+                p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+                rn = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+                out["all_threads"] = dict(value=rn["rate"], cores=len(cpus), sample="%d iteration(s), %.1f s (%.1f s projections), OpenBLAS threads = %s, process pinned to them"
+                                          % (rn["iters"], rn["secs"], rn["proj_secs"], where))
+            except Exception as e:
+                out["all_threads"] = dict(error="%s: %s" % (type(e).__name__, e))
     return out
+
+
+def _problem_for(key, small):
+    import cosmo_jl_amd as cj
+    if key == "cfg2":
+        return cj.problems.sparse_box_qp(n=10_000, m=20_000, nnz=200_000) if small else cj.problems.sparse_box_qp()
+    if key == "cfg4":
+        return cj.problems.closest_correlation(d=400 if small else 2000)
+    if key == "cfg5":
+        return cj.problems.chordal_sdp(**(dict(ncliques=40, n_total=6000, n_zero=100, n_nonneg=500) if small else {}))
+    raise ValueError(key)
+
+
+def cpu_leg_main():
+    """`bench.py --cpu-leg cfgK --cpu-leg-cpus a,b,c --cpu-leg-iters N`: the all-threads leg of a cpu_baseline (no GPU involved); affinity and the
+    BLAS thread count were fixed at the top of this file, before NumPy / SciPy loaded OpenBLAS."""
+    key = sys.argv[sys.argv.index("--cpu-leg") + 1]
+    iters = int(sys.argv[sys.argv.index("--cpu-leg-iters") + 1])
+    ncpu = len(sys.argv[sys.argv.index("--cpu-leg-cpus") + 1].split(","))
+    print(json.dumps(compiled_cpu_rate(_problem_for(key, "--small" in sys.argv), iters, ncpu)), flush=True)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
 # cfg2
 # ---------------------------------------------------------------------------------------------------------------------
-def cpu_baseline_cfg2(prob, sample_iters):
-    """The compiled C restatement (oracle/cosmo_oracle_c.c, gcc -O3 -march=native; Julia-style CSC SpMV kernels), set up by the NumPy
-    oracle, 1 thread (the reference is single-threaded outside BLAS and this configuration has no BLAS)."""
-    from oracle import cosmo_oracle as O
-    from tests import util
-    st = oracle_settings(O, sample_iters)
-    ws = O.Workspace(prob["P"], prob["q"], prob["A"], prob["b"], util.oracle_cones(prob["sets"]), st)
-    try:
-        import subprocess
-        from oracle import cosmo_oracle_c as OC
-        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "native"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        OC.lib(native=True)                               # -march=native for the host whose core is being timed
-    except Exception:
-        OC = None
-    if OC is not None:
-        c = OC.run(ws, native=True)
-        iters, secs, cg = c["iter"], c["iter_time"], c["cg_iters_total"] / (c["iter"] + 1.0)
-        impl = "compiled C loop (gcc -O3 -march=native)"
-    else:
-        res = ws.optimize()
-        iters, secs, cg = res.iter, res.iter_time, float(np.mean(res.cg_iters))
-        impl = "NumPy/SciPy loop"
-    return dict(value=iters / secs, unit="ADMM iterations/s", cores=1, kind="port",
-                sample="%s: %d ADMM iterations (incl. init step, checks every 25) of the same cfg2 instance, %.1f s; mean CG its/solve %.2f"
-                       % (impl, iters, secs, cg))
-
-
 def bench_cfg2(ctx, args, steps, warmup):
     import cosmo_jl_amd as cj
     prob = cj.problems.sparse_box_qp(n=10_000, m=20_000, nnz=200_000) if args.small else cj.problems.sparse_box_qp()
@@ -268,7 +319,7 @@ def bench_cfg2(ctx, args, steps, warmup):
                      "iteration_roofline_frac": round(b_iter * (value / world) / (HBM_PEAK_GBS * 1e9), 4),
                      "algorithmic_bytes_per_iteration": b_iter}
     if not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline_cfg2(prob, args.cpu_sample_iters if not args.small else 200)
+        out["cpu_baseline"] = compiled_cpu_baseline(prob, args.cpu_sample_iters if not args.small else 200, "cfg2", "cfg2", args, with_all_threads=False)   # no BLAS in this configuration
         out["config"]["gpu_over_cpu"] = round((value / world) / out["cpu_baseline"]["value"], 2)
     h.close()
     return out
@@ -288,7 +339,9 @@ def bench_cfg3(ctx, args, steps, warmup):
         md = cj.Model(); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], st); mods.append(md)
     B, _ = cj.model.prepare_batch(mods, ctx.local_rank)
     B.iterate(warmup, with_init=True)
+    _, _, kk0 = B.counters()
     elapsed = ctx.timed(lambda: B.iterate(steps))
+    _, _, kk1 = B.counters()
     value = steps / elapsed                                  # one step = one ADMM iteration of ALL problems of the job
     out = dict(value=value, ms_per_step=1e3 * elapsed / steps, steps=steps, warmup=warmup, scaling="strong")
     if ctx.rank != 0:
@@ -296,28 +349,39 @@ def bench_cfg3(ctx, args, steps, warmup):
         return out
     n, m = mods[0].n, mods[0].m
     nnzA, nnzP = int(np.mean([md.A.nnz for md in mods])), int(np.mean([md.P.nnz for md in mods]))
-    ab = algorithmic_bytes(n, m, nnzA, nnzP)
+    kry = (kk1 - kk0).astype(np.float64)                      # Krylov iterations per problem inside the timed steps (device counters)
     out["config"] = {"workload": "cfg3: %d independent SOCPs n=%d m=%d nnz(A)~%d, 50 SecondOrderCone(20) each; one step = one ADMM iteration of every "
                                  "problem; one persistent workgroup per problem (csrc/batch.hip)" % (nprob, n, m, nnzA),
                      "parallelism": "batch sharded over %d rank(s), %d problems on rank 0, no collective" % (ctx.world, hi - lo),
-                     "problem_iterations_per_s": round(value * nprob, 1)}
-    # HBM roofline of the SURVEY formula with K = 1 Krylov iteration per solve as a LOWER bound on the algorithmic traffic; the kernel
-    # keeps the problem in LDS / registers, so HBM is not what binds it (SURVEY 8d says to report both)
-    b_low = iteration_bytes(ab, 1.0) * nprob
-    out["roofline"] = dict(bound="hbm", kernel="k_batch_admm_reg (persistent, LDS-resident problem image, register-resident iterates)",
-                           achieved=round(b_low * value / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(b_low * value / 1e9 / HBM_PEAK_GBS, 4),
-                           traffic=None, note="algorithmic bytes = B_iter(K=1) x problems (a lower bound: K >= 1); the kernel touches HBM only at launch / checks")
+                     "problem_iterations_per_s": round(value * nprob, 1),
+                     "krylov_iterations_per_problem_in_timed_steps": dict(mean=round(float(kry.mean()), 1), max=int(kry.max()), min=int(kry.min())),
+                     "us_per_krylov_iteration_of_the_slowest_problem": round(1e6 * elapsed / max(float(kry.max()), 1.0), 3)}
+    # What bounds the persistent kernel is the LDS: every Krylov iteration streams the problem's LDS image once through the two sparse passes --
+    # A pass: (value 8 B + u16 column + 8 B gathered x) per nonzero; [P | A'] pass: (u16 position + u16 row + 8 B value + 8 B gathered y) per
+    # nonzero of A and (8 + 2 + 8) per nonzero of P.  achieved = MEASURED Krylov iterations of rank 0's problems x those bytes / elapsed, against
+    # the chip's LDS read peak (guide: ~150 TB/s for ds_read_b64 at 2.4 GHz).  The batch ends with its slowest problem, so the rate is set by
+    # max (not mean) Krylov iterations x the ~7 us one workgroup needs per Krylov iteration: a latency / issue bound chain, not a bandwidth one.
+    lds_bytes_per_krylov = nnzA * (8 + 2 + 8) + nnzA * (2 + 2 + 8 + 8) + nnzP * (8 + 2 + 8) + 8.0 * (4 * n + 2 * m)
+    lds_achieved = float(kry.sum()) * lds_bytes_per_krylov / elapsed / 1e9
+    LDS_PEAK_GBS = 150000.0
+    out["roofline"] = dict(bound="lds", kernel="k_batch_admm_reg (persistent, LDS-resident problem image, register-resident iterates)",
+                           achieved=round(lds_achieved, 1), peak=LDS_PEAK_GBS, unit="GB/s", frac=round(lds_achieved / LDS_PEAK_GBS, 4), traffic=None,
+                           lds_bytes_per_krylov_iteration_per_problem=lds_bytes_per_krylov, krylov_iterations_timed=int(kry.sum()),
+                           note="LDS bytes of the sparse passes x measured Krylov iterations (device counters) / elapsed; HBM is touched at launch and at the checks "
+                                "only.  The slowest problem's dependent chain of Krylov iterations, not LDS bandwidth, ends the step (see config)")
     if not args.no_cpu_baseline and ctx.world == 1:
         from oracle import cosmo_oracle as O
+        from oracle import cosmo_oracle_c  # noqa: F401
         from tests import util
-        t0 = time.perf_counter(); its = 0; nsamp = 4
+        OC = _native_oracle()
+        nsamp, its, secs = (8 if args.small else 32), 0, 0.0
         for p in probs[:nsamp]:
-            ws = O.Workspace(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), oracle_settings(O, 100))
-            its += ws.optimize().iter
-        secs = time.perf_counter() - t0
+            ws = O.Workspace(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), oracle_settings(O, warmup + steps))
+            c = OC.run(ws, native=True)
+            its += c["iter"]; secs += c["iter_time"]
         out["cpu_baseline"] = dict(value=its / secs / nprob, unit="ADMM iterations/s (of the whole batch)", cores=1, kind="port",
-                                   sample="NumPy/SciPy oracle, %d problems x 100 iterations incl. setup, %.1f s, scaled to %d problems solved one after the other "
-                                          "(the reference's own batch mode)" % (nsamp, secs, nprob))
+                                   sample="compiled C loop (gcc -O3 -march=native; oracle/cosmo_oracle_c.c), %d problems x %d iterations (+ init step), %.2f s of loop time, "
+                                          "scaled to %d problems solved one after the other (the reference's own batch mode)" % (nsamp, warmup + steps, secs, nprob))
     B.close()
     return out
 
@@ -414,7 +478,7 @@ def bench_cfg4(ctx, args, steps, warmup):
                      "parallelism": "replicas x%d (a single cone does not shard; SURVEY 8e)" % ctx.world,
                      "mean_cg_iters_per_admm_iter": round(kbar, 3), "polar": {k: ps[k] for k in ("schedule_steps", "fallback_rounds", "verified", "unverified", "err_max_e18")}}
     if not args.no_cpu_baseline and ctx.world == 1:
-        out["cpu_baseline"] = lapack_cpu_baseline(prob, 2 if not args.small else 20, "cfg4")
+        out["cpu_baseline"] = compiled_cpu_baseline(prob, 2 if not args.small else 20, "cfg4", "cfg4", args)
     h.close()
     if ctx.world == 1 and not args.no_float32:
         out["float32"] = float32_extra(ctx, args, prob, st, steps, warmup)
@@ -483,7 +547,7 @@ def bench_cfg5(ctx, args, steps, warmup):
                                flops_per_launch=fl, avg_launch_us=round(1e6 * t_prod, 2), launches_timed=20, products_per_projection=ps["products_last_batch"],
                                useful_tflops_reference_algorithm=round(useful * value / 1e12, 3), useful_frac_of_peak=round(useful * value / 1e12 / F64_MFMA_PEAK_TF, 5))
     if not args.no_cpu_baseline and ctx.world == 1:
-        out["cpu_baseline"] = lapack_cpu_baseline(prob, 1 if not args.small else 10, "cfg5")
+        out["cpu_baseline"] = compiled_cpu_baseline(prob, 1 if not args.small else 10, "cfg5", "cfg5", args)
     if ctx.world == 1 and not args.no_float32:
         h.close()
         out["float32"] = float32_extra(ctx, args, prob, st, steps, warmup)
@@ -577,4 +641,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--cpu-leg" in sys.argv:
+        cpu_leg_main()
+    else:
+        main()

@@ -128,6 +128,7 @@ SIGNATURES = {
     "cosmo_hip_batch_optimize": (C.c_int32, [C.c_void_p, C.POINTER(ResultStruct)]),
     "cosmo_hip_batch_iterate": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32]),
     "cosmo_hip_batch_get_iterates": (C.c_int32, [C.c_void_p, C.c_int64, _PR, _PR, _PR, _PR]),
+    "cosmo_hip_batch_get_counters": (C.c_int32, [C.c_void_p, _PI64]),
 }
 
 
@@ -556,6 +557,12 @@ class Batch:
 
     def iterate(self, n_iters, with_init=False):
         self._chk(self.lib.cosmo_hip_batch_iterate(self._b, int(n_iters), 1 if with_init else 0))
+
+    def counters(self):
+        """Per problem: ADMM iterations, KKT solves, Krylov iterations in total (three int64 arrays)."""
+        out = np.zeros(3 * self.nprob, dtype=np.int64)
+        self._chk(self.lib.cosmo_hip_batch_get_counters(self._b, out.ctypes.data_as(_PI64)))
+        return out[0::3].copy(), out[1::3].copy(), out[2::3].copy()
 
     def get_iterates(self, k):
         N = self.n + self.m

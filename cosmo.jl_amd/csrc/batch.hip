@@ -1450,6 +1450,18 @@ extern "C" int32_t cosmo_hip_batch_iterate(cosmo_hip_batch* b, int64_t n_iters, 
   return COSMO_HIP_OK;
 }
 
+// per problem {ADMM iterations, KKT solves, Krylov iterations in total}: out holds 3 * nprob entries (measurement: the Krylov work a batch
+// step actually did, cf. `iteration_counter` / `multiplications` of kktsolver_indirect.jl:32,56)
+extern "C" int32_t cosmo_hip_batch_get_counters(cosmo_hip_batch* b, int64_t* out) {
+  if (!b || !b->finalized || !out) return bfail(b, COSMO_HIP_ERR_INVALID, "batch_get_counters: bad call");
+  if (hipSetDevice(b->device) != hipSuccess) return bfail(b, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
+  std::vector<BCtl> c(b->nprob);
+  BHIP(b, hipMemcpyAsync(c.data(), b->D.ctl, sizeof(BCtl) * b->nprob, hipMemcpyDeviceToHost, b->stream));
+  BHIP(b, hipStreamSynchronize(b->stream));
+  for (int k = 0; k < b->nprob; ++k) { out[3 * k] = c[k].iter; out[3 * k + 1] = c[k].solves; out[3 * k + 2] = c[k].kkt_iters_total; }
+  return COSMO_HIP_OK;
+}
+
 // w, w_prev: n+m ; s, mu: m  of problem k
 extern "C" int32_t cosmo_hip_batch_get_iterates(cosmo_hip_batch* b, int64_t k, real* w, real* w_prev, real* s, real* mu) {
   if (!b || !b->have_iterates || k < 0 || k >= b->nprob) return bfail(b, COSMO_HIP_ERR_INVALID, "batch_get_iterates: bad call");

@@ -1375,6 +1375,9 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
     }
     if (tiles.empty()) tiles.push_back(int4{-1, 0, 0, 0});
     HIPCHK(h, hipMalloc((void**)&q->BW, sizeof(real) * (size_t)woff));
+    // the ragged product kernel writes a cone's d16 x d16 corner only: the padding up to ld must be zero from the start (populate / scale keep
+    // it zero in X and U; Y and T are never written there), because the verification sums run over whole ld x ld buffers
+    HIPCHK(h, hipMemset(q->BW, 0, sizeof(real) * (size_t)woff));
     HIPCHK(h, hipMalloc((void**)&q->d_bcones, sizeof(BatchCone) * q->bcones.size()));
     HIPCHK(h, hipMalloc((void**)&q->d_btiles, sizeof(int4) * tiles.size()));
     HIPCHK(h, hipMalloc((void**)&q->bparts, sizeof(real) * 3 * BPX * q->bcones.size()));   // norm, trace and verification partials

@@ -383,6 +383,9 @@ int32_t cosmo_hip_batch_set_iterates(cosmo_hip_batch* b, const cosmo_hip_real* x
 int32_t cosmo_hip_batch_optimize(cosmo_hip_batch* b, cosmo_hip_result* results);
 /* n_iters more loop bodies (with checks) on every undecided problem; with_init != 0 runs the init step first */
 int32_t cosmo_hip_batch_iterate(cosmo_hip_batch* b, int64_t n_iters, int32_t with_init);
+/* per problem {ADMM iterations, KKT solves, Krylov iterations in total}: out[3 * nprob] (measurement; the counters the reference keeps in
+ * IndirectReducedKKTSolver.iteration_counter / multiplications, src/linear_solver/kktsolver_indirect.jl:32,56) */
+int32_t cosmo_hip_batch_get_counters(cosmo_hip_batch* b, int64_t* out);
 int32_t cosmo_hip_batch_get_iterates(cosmo_hip_batch* b, int64_t k, cosmo_hip_real* w, cosmo_hip_real* w_prev, cosmo_hip_real* s, cosmo_hip_real* mu);
 
 #ifdef __cplusplus

@@ -1,12 +1,16 @@
 /* cosmo_oracle_c.c -- TEST / BASELINE INFRASTRUCTURE, not part of the product (only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg may load it).  A plain-C restatement of the reference's ADMM loop (COSMO.jl v0.8.11) for the configurations whose
- * cones are ZeroSet / Nonnegatives / Box and whose KKT solver is the CG reduced solver -- i.e. BASELINE configs 1 and 2 -- compiled
- * with gcc -O2 so that the CPU number quoted next to the GPU number comes from compiled code, as the (Julia) reference's would.
+ * cones are ZeroSet / Nonnegatives / Box / SecondOrderCone / PsdCone / PsdConeTriangle and whose KKT solver is the CG reduced solver --
+ * i.e. all five BASELINE configs -- compiled with gcc -O3 so that the CPU number quoted next to the GPU number comes from compiled
+ * code, as the (Julia) reference's would.  The PSD projections call LAPACK ?syevr and BLAS ?syrk exactly as the reference does
+ * (src/convexset.jl:163-189, 243-263) through function pointers handed in by the loader (SciPy's bundled OpenBLAS: the image has no
+ * liblapack to link against).
  * It follows oracle/cosmo_oracle.py line by line (which is pinned on the reference's goldens) and is itself pinned against it in
  * tests/test_oracle_c.py (same iteration counts, iterates to 1e-9).  Setup (scaling, classification, rho vector) stays in the
  * NumPy oracle; this file is the loop only:
  *   src/solver.jl:137-176 (loop), :7-21 admm_z!, :32-56 admm_x!, :62-65 admm_w!, :24-26 recover_mu!, :242-282 rho rules,
- *   :303-323 check_termination! (residual part); src/convexset.jl:25-28,71-74,844-847 projections; src/residuals.jl:1-153;
+ *   :303-323 check_termination! (residual part); src/convexset.jl:25-28,71-74,844-847 (Zero / Nonneg / Box), :100-114 (SecondOrderCone),
+ *   :219-263, 303-321, 402-412, 432-442, 462-472 (PSD cones), :885-891 (serial cone loop); src/residuals.jl:1-153;
  *   src/parameters.jl:3-92; src/linear_solver/kktsolver_indirect.jl:36-88 with IterativeSolvers v0.9 cg! (restated, see the
  *   header of the NumPy oracle).  SpMVs are Julia's CSC kernels: A x scatters column by column, A'y is a dot per column.
  */
@@ -75,6 +79,83 @@ typedef struct {
   oc_real *rho, *tn, *tm, *tm2; /* work */
 } prob;
 
+/* ---- cones that are projected slice by slice after the row-wise ones (src/convexset.jl:885-891: a serial loop over the cones) ---- */
+enum { CK_SOC = 1, CK_PSD_TRIANGLE = 2, CK_PSD_SQUARE = 3 };
+typedef void (*syevr_fn)(char* jobz, char* range, char* uplo, int* n, oc_real* a, int* lda, oc_real* vl, oc_real* vu, int* il, int* iu, oc_real* abstol,
+                         int* m, oc_real* w, oc_real* z, int* ldz, int* isuppz, oc_real* work, int* lwork, int* iwork, int* liwork, int* info);
+typedef void (*syrk_fn)(char* uplo, char* trans, int* n, int* k, oc_real* alpha, oc_real* a, int* lda, oc_real* beta, oc_real* c, int* ldc);
+typedef struct {
+  int64_t ncones; const int32_t* kind; const int64_t* off; const int64_t* dim;
+  syevr_fn syevr; syrk_fn syrk;
+  oc_real *X, *Z, *wv, *work; int *iwork, *isuppz; int lwork, liwork;      /* PsdBlasWorkspace (convexset.jl:129-161) */
+  int64_t* rank_out; int32_t* branch_out;                                   /* per cone, may be NULL */
+} cone_ctx;
+
+static int64_t isqrt64(int64_t v) { int64_t r = (int64_t)sqrt((double)v); while (r * r > v) --r; while ((r + 1) * (r + 1) <= v) ++r; return r; }
+static int64_t psd_side(int32_t kind, int64_t dim) { return kind == CK_PSD_SQUARE ? isqrt64(dim) : (isqrt64(1 + 8 * dim) - 1) / 2; }   /* :372 */
+
+/* _project! (convexset.jl:219-241): w, Z = syevr('V','A','U', X) ; rank_k_update! (:243-263): X = sum_{lambda > 0} lambda z z' (upper triangle) */
+static int psd_project_dense(cone_ctx* cx, int d, int64_t* nnz_out) {
+  char jobz = 'V', range = 'A', uplo = 'U', trans = 'N';
+  int n = d, m_found = 0, info = 0, il = 0, iu = 0;
+  oc_real vl = R(0.0), vu = R(0.0), abstol = R(-1.0);
+  cx->syevr(&jobz, &range, &uplo, &n, cx->X, &n, &vl, &vu, &il, &iu, &abstol, &m_found, cx->wv, cx->Z, &n, cx->isuppz, cx->work, &cx->lwork, cx->iwork,
+            &cx->liwork, &info);
+  if (info != 0) return info;
+  int nnz = 0;
+  for (int j = 0; j < d; ++j)
+    if (cx->wv[j] > R(0.0)) { nnz += 1; const oc_real sq = RSQRT(cx->wv[j]); oc_real* z = cx->Z + (size_t)j * d; for (int i = 0; i < d; ++i) z[i] = z[i] * sq; }   /* :250-254 */
+  if (nnz > 0) {
+    oc_real one = R(1.0), zero = R(0.0);
+    cx->syrk(&uplo, &trans, &n, &nnz, &one, cx->Z + (size_t)(d - nnz) * d, &n, &zero, cx->X, &n);       /* :258-261: the positive pairs are the LAST columns */
+  } else {
+    memset(cx->X, 0, sizeof(oc_real) * (size_t)d * d);
+  }
+  *nnz_out = nnz;
+  return 0;
+}
+
+static int project_cones(cone_ctx* cx, oc_real* s) {
+  const oc_real isq2 = R(1.0) / RSQRT(R(2.0)), sq2 = RSQRT(R(2.0));
+  for (int64_t c = 0; c < cx->ncones; ++c) {
+    oc_real* x = s + cx->off[c];
+    const int64_t dim = cx->dim[c];
+    if (cx->kind[c] == CK_SOC) {                                          /* convexset.jl:100-114 */
+      int br = 0;
+      if (dim > 0) {
+        const oc_real t = x[0];
+        const oc_real nx = nrm2(x + 1, dim - 1);
+        if (nx <= t) br = 0;
+        else if (nx <= -t) { br = 1; for (int64_t i = 0; i < dim; ++i) x[i] = R(0.0); }
+        else { br = 2; x[0] = (nx + t) / R(2.0); const oc_real f = (nx + t) / (R(2.0) * nx); for (int64_t i = 1; i < dim; ++i) x[i] = f * x[i]; }
+      }
+      if (cx->branch_out) cx->branch_out[c] = br;
+      continue;
+    }
+    int64_t nnz = 0;
+    if (dim == 1) {                                                       /* :307-308, 404-405 */
+      x[0] = (x[0] != x[0]) ? x[0] : ((x[0] > R(0.0)) ? x[0] : R(0.0));
+      nnz = x[0] > R(0.0);
+    } else if (cx->kind[c] == CK_PSD_TRIANGLE) {                          /* :402-412 */
+      const int d = (int)psd_side(CK_PSD_TRIANGLE, dim);
+      int64_t k = 0;
+      for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i, ++k) cx->X[(size_t)j * d + i] = (i == j) ? x[k] : isq2 * x[k];      /* populate_upper_triangle! (:432-442) */
+      const int rc = psd_project_dense(cx, d, &nnz);
+      if (rc) return rc;
+      k = 0;
+      for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i, ++k) x[k] = (i == j) ? cx->X[(size_t)j * d + i] : sq2 * cx->X[(size_t)j * d + i];   /* extract_upper_triangle! (:462-472) */
+    } else {                                                              /* PsdCone, :303-321 */
+      const int d = (int)psd_side(CK_PSD_SQUARE, dim);
+      for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) cx->X[(size_t)j * d + i] = (x[(size_t)j * d + i] + x[(size_t)i * d + j]) / R(2.0);   /* symmetrize_upper! (algebra.jl:201-208) */
+      const int rc = psd_project_dense(cx, d, &nnz);
+      if (rc) return rc;
+      for (int j = 0; j < d; ++j) for (int i = 0; i <= j; ++i) { const oc_real v = cx->X[(size_t)j * d + i]; x[(size_t)j * d + i] = v; x[(size_t)i * d + j] = v; }   /* :316-318 */
+    }
+    if (cx->rank_out) cx->rank_out[c] = nnz;
+  }
+  return 0;
+}
+
 /* reduced_mul! (kktsolver_indirect.jl:57-64): y = P x + sigma x + A'(rho .* (A x)) */
 static void reduced_mul(const prob* W, oc_real sigma, const oc_real* x, oc_real* y, oc_real* tmp_m, oc_real* tmp_n) {
   mul(&W->A, x, tmp_m);
@@ -90,10 +171,38 @@ static void make_rho(const prob* W, const oc_params* p, oc_real rho) {   /* set_
     W->rho[i] = (W->cls[i] == 1) ? R(p->rho_eq_over_rho_ineq) * rho : (W->cls[i] == 2 ? R(p->rho_min) : rho);
 }
 
-int32_t cosmo_oracle_c_run(int64_t n, int64_t m, const int64_t* Pp, const int64_t* Pi, const oc_real* Px, const int64_t* Ap, const int64_t* Ai,
-                           const oc_real* Ax, const oc_real* q, const oc_real* b, const oc_real* Dinv, const oc_real* Einv, const int32_t* cls,
-                           const int32_t* kind, const oc_real* bl, const oc_real* bu, const oc_params* prm, const oc_real* rho_vec0,
-                           oc_real* x_io, oc_real* s_io, oc_real* mu_io, oc_real* rho_updates_out, int32_t rho_updates_cap, oc_result* res) {
+/* ncones slice cones (SOC / PSD; kind per row 0 on their rows) with LAPACK / BLAS entry points `syevr`, `syrk` (NULL when there is no PSD cone);
+ * rank_out / branch_out: nnz_lambda / SOC branch id of the LAST projection per cone (NULL to skip); proj_time_out: seconds spent in the cone loop */
+int32_t cosmo_oracle_c_run_cones(int64_t n, int64_t m, const int64_t* Pp, const int64_t* Pi, const oc_real* Px, const int64_t* Ap, const int64_t* Ai,
+                                 const oc_real* Ax, const oc_real* q, const oc_real* b, const oc_real* Dinv, const oc_real* Einv, const int32_t* cls,
+                                 const int32_t* kind, const oc_real* bl, const oc_real* bu, const oc_params* prm, const oc_real* rho_vec0,
+                                 oc_real* x_io, oc_real* s_io, oc_real* mu_io, oc_real* rho_updates_out, int32_t rho_updates_cap, oc_result* res,
+                                 int64_t ncones, const int32_t* ckind, const int64_t* coff, const int64_t* cdim, void* syevr, void* syrk,
+                                 int64_t* rank_out, int32_t* branch_out, double* proj_time_out) {
+  cone_ctx cx;
+  memset(&cx, 0, sizeof cx);
+  cx.ncones = ncones; cx.kind = ckind; cx.off = coff; cx.dim = cdim; cx.syevr = (syevr_fn)syevr; cx.syrk = (syrk_fn)syrk;
+  cx.rank_out = rank_out; cx.branch_out = branch_out;
+  int dmax = 0;
+  for (int64_t c = 0; c < ncones; ++c) if (ckind[c] != CK_SOC && cdim[c] > 1) { const int d = (int)psd_side(ckind[c], cdim[c]); if (d > dmax) dmax = d; }
+  void* psd_buf = NULL;
+  if (dmax > 0) {
+    if (!cx.syevr || !cx.syrk) return 2;
+    /* workspace query (LAPACK.syevr! with lwork = -1, convexset.jl:140-156) */
+    char jobz = 'V', range = 'A', uplo = 'U';
+    int nq = dmax, mq = 0, info = 0, il = 0, iu = 0, lq = -1, liq = -1, iwq = 0, isq[2] = {0, 0};
+    oc_real vl = R(0.0), vu = R(0.0), abstol = R(-1.0), wq = R(0.0), dummy = R(0.0);
+    cx.syevr(&jobz, &range, &uplo, &nq, &dummy, &nq, &vl, &vu, &il, &iu, &abstol, &mq, &dummy, &dummy, &nq, isq, &wq, &lq, &iwq, &liq, &info);
+    cx.lwork = (int)wq; cx.liwork = iwq;
+    if (info != 0 || cx.lwork < 26 * dmax) cx.lwork = 26 * dmax;
+    if (cx.liwork < 10 * dmax) cx.liwork = 10 * dmax;
+    const size_t nd = (size_t)dmax * dmax;
+    psd_buf = malloc(sizeof(oc_real) * (2 * nd + (size_t)dmax + (size_t)cx.lwork) + sizeof(int) * ((size_t)cx.liwork + 2 * (size_t)dmax + 2));
+    if (!psd_buf) return 1;
+    cx.X = (oc_real*)psd_buf; cx.Z = cx.X + nd; cx.wv = cx.Z + nd; cx.work = cx.wv + dmax;
+    cx.iwork = (int*)(cx.work + cx.lwork); cx.isuppz = cx.iwork + cx.liwork;
+  }
+  double proj_time = 0.0;
   prob W;
   W.n = n; W.m = m;
   W.P.nr = n; W.P.nc = n; W.P.p = Pp; W.P.i = Pi; W.P.x = Px;
@@ -194,6 +303,13 @@ int32_t cosmo_oracle_c_run(int64_t n, int64_t m, const int64_t* Pp, const int64_
       }
       s[i] = v;
     }
+    if (ncones > 0) {                                                    /* project!(s, C): the slice cones (convexset.jl:885-891) */
+      struct timespec p0, p1;
+      clock_gettime(CLOCK_MONOTONIC, &p0);
+      if (project_cones(&cx, s) != 0) { free(buf); free(psd_buf); return 3; }
+      clock_gettime(CLOCK_MONOTONIC, &p1);
+      proj_time += (double)(p1.tv_sec - p0.tv_sec) + 1e-9 * (double)(p1.tv_nsec - p0.tv_nsec);
+    }
     if (p.adaptive_rho && p.adaptive_rho_interval > 0 && (it % p.adaptive_rho_interval) == 0 && (n_rho - 1) < p.adaptive_rho_max_adaptions)
       rho_update_due = 1;
     if (rho_update_due) {                                                /* apply_rho_adaptation_rules! (:242-282) */
@@ -233,5 +349,16 @@ int32_t cosmo_oracle_c_run(int64_t n, int64_t m, const int64_t* Pp, const int64_
   res->cost = cost; res->r_prim = r_prim; res->r_dual = r_dual; res->max_norm_prim = mnp; res->max_norm_dual = mnd; res->rho = rho;
   res->iter_time = (oc_real)(t1.tv_sec - t0.tv_sec) + R(1e-9) * (oc_real)(t1.tv_nsec - t0.tv_nsec);
   free(buf);
+  free(psd_buf);
+  if (proj_time_out) *proj_time_out = proj_time;
   return 0;
+}
+
+/* the row-cone-only entry point of rounds 1-2 (BASELINE configs 1 and 2) */
+int32_t cosmo_oracle_c_run(int64_t n, int64_t m, const int64_t* Pp, const int64_t* Pi, const oc_real* Px, const int64_t* Ap, const int64_t* Ai,
+                           const oc_real* Ax, const oc_real* q, const oc_real* b, const oc_real* Dinv, const oc_real* Einv, const int32_t* cls,
+                           const int32_t* kind, const oc_real* bl, const oc_real* bu, const oc_params* prm, const oc_real* rho_vec0,
+                           oc_real* x_io, oc_real* s_io, oc_real* mu_io, oc_real* rho_updates_out, int32_t rho_updates_cap, oc_result* res) {
+  return cosmo_oracle_c_run_cones(n, m, Pp, Pi, Px, Ap, Ai, Ax, q, b, Dinv, Einv, cls, kind, bl, bu, prm, rho_vec0, x_io, s_io, mu_io, rho_updates_out,
+                                  rho_updates_cap, res, 0, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL);
 }

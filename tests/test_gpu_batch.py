@@ -81,7 +81,21 @@ def test_cfg3_full_size_batch():
     mods = _models(probs, st)
     res = cj.optimize_batch(mods)
     assert all(r.status == "Solved" for r in res)
-    # spot-check a few problems against the oracle
+    # EVERY problem against the compiled C restatement of the loop (oracle/cosmo_oracle_c.c with the SecondOrderCone projection; pinned on the NumPy
+    # oracle in tests/test_oracle_c.py), a few also against the NumPy oracle itself
+    import subprocess, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "oracle")], check=True, capture_output=True)
+    from oracle import cosmo_oracle_c as OC
+    worst_it, worst_obj = 0, 0.0
+    for k, p in enumerate(probs):
+        ws = O.Workspace(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), O.Settings(kkt_solver="cg"))
+        c = OC.run(ws)
+        assert c["status"] == "Solved" and abs(res[k].iter - c["iter"]) <= 25, (k, res[k].iter, c["iter"])
+        assert abs(res[k].obj_val - c["obj_val"]) <= 1e-4 * (1 + abs(c["obj_val"])), (k, res[k].obj_val, c["obj_val"])
+        assert len(res[k].info.rho_updates) == len(c["rho_updates"]), k
+        worst_it = max(worst_it, abs(res[k].iter - c["iter"])); worst_obj = max(worst_obj, abs(res[k].obj_val - c["obj_val"]) / (1 + abs(c["obj_val"])))
+    print("cfg3 batch vs compiled oracle, all 1024 problems: max |d iter| = %d, max rel |d obj| = %.2e" % (worst_it, worst_obj))
     for k in (0, 511, 1023):
         p = probs[k]
         ref = O.solve(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), O.Settings(kkt_solver="cg"))
@@ -197,13 +211,14 @@ def test_batch_soc_infeasibility_matches_oracle():
     res = cj.optimize_batch(mods)
     assert [r.status for r in res] == [ref.status for ref in refs] == ["Primal_infeasible", "Solved"]
     assert res[0].iter == refs[0].iter and abs(res[1].iter - refs[1].iter) <= 25
-    # batch 2: minimise -t over the cone (unbounded: dual infeasible) next to minimise +t (solved at 0)
+    # batch 2: minimise -t over the cone (unbounded: dual infeasible) next to a strictly convex problem whose solution sits on the cone's
+    # boundary (minimise t + 2 v1 + |x|^2 / 2; not the apex, where the residual ratios of the rho rule are 0 / 0 noise)
     mods, refs = [], []
-    for q in (np.array([-1.0, 0.0, 0.0]), np.array([1.0, 0.0, 0.0])):
-        md = cj.Model(); cj.assemble(md, np.zeros((n, n)), q, [cj.Constraint(A1, b1, cj.SecondOrderCone)], settings=cj.Settings())
+    for P, q in ((np.zeros((n, n)), np.array([-1.0, 0.0, 0.0])), (np.eye(n), np.array([1.0, 2.0, 0.0]))):
+        md = cj.Model(); cj.assemble(md, P, q, [cj.Constraint(A1, b1, cj.SecondOrderCone)], settings=cj.Settings())
         mods.append(md)
         A, b, cones = O.assemble([O.Constraint(A1, b1, O.SecondOrderCone(3))])
-        refs.append(O.solve(np.zeros((n, n)), q, A, b, cones, O.Settings(kkt_solver="cg")))
+        refs.append(O.solve(P, q, A, b, cones, O.Settings(kkt_solver="cg")))
     res = cj.optimize_batch(mods)
     assert [r.status for r in res] == [ref.status for ref in refs] == ["Dual_infeasible", "Solved"]
     assert res[0].iter == refs[0].iter

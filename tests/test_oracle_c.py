@@ -27,7 +27,7 @@ def _pair(OC, prob, **kw):
     return ws1.optimize(), OC.run(ws2)
 
 
-def _check(r, c, tol=1e-8):
+def _check(r, c, tol=1e-8, cg_rel=0.01):
     assert c["status"] == r.status
     assert c["iter"] == r.iter
     assert len(c["rho_updates"]) == len(r.rho_updates)
@@ -38,7 +38,7 @@ def _check(r, c, tol=1e-8):
     assert np.max(np.abs(c["y"] - r.y)) <= tol * max(1.0, float(np.max(np.abs(r.y))))
     assert abs(c["obj_val"] - r.obj_val) <= tol * max(1.0, abs(r.obj_val))
     assert abs(c["r_prim"] - r.r_prim) <= 10 * tol * max(1.0, r.max_norm_prim)   # a difference of O(max_norm) terms
-    assert abs(c["cg_iters_total"] - int(np.sum(r.cg_iters))) <= max(2, 0.01 * np.sum(r.cg_iters))
+    assert abs(c["cg_iters_total"] - int(np.sum(r.cg_iters))) <= max(2, cg_rel * np.sum(r.cg_iters))
 
 
 def test_c_oracle_cfg1_dense_qp(OC):
@@ -74,3 +74,33 @@ def test_c_oracle_max_iter_status(OC):
     r, c = _pair(OC, prob, max_iter=25, eps_abs=0.0, eps_rel=0.0, tol_constant=1e-10, tol_exponent=0.0)
     assert r.status == "Max_iter_reached"
     _check(r, c)
+
+
+# ---- slice cones (round 3): SecondOrderCone, PsdConeTriangle, PsdCone through LAPACK syevr / BLAS syrk (function pointers of SciPy's OpenBLAS) ----
+def test_c_oracle_socp(OC):
+    prob = cj.problems.socp(n=60, m=120, ncones=12, nnz=900, seed=104)
+    r, c = _pair(OC, prob, tol_constant=1e-10, tol_exponent=0.0, max_iter=400)
+    assert r.status == "Solved"
+    _check(r, c, tol=1e-7)
+    assert set(c["soc_branch"].values()) <= {0, 1, 2} and len(c["soc_branch"]) == 12
+
+
+def test_c_oracle_mixed_cones_with_psd_triangle_and_square(OC):
+    rng = np.random.default_rng(21)
+    prob = util.random_qp(rng, 50, 4, 20, 10, soc_dims=(5, 9), psd_tri_dims=(6, 3), psd_sq_dims=(4,))
+    r, c = _pair(OC, prob, tol_constant=1e-10, tol_exponent=0.0, max_iter=300, eps_abs=0.0, eps_rel=0.0)
+    _check(r, c, tol=1e-6)
+    assert len(c["psd_rank"]) == 3 and all(v >= 0 for v in c["psd_rank"].values())
+
+
+def test_c_oracle_chordal_sdp_and_closest_correlation(OC):
+    """The two SDP shapes of BASELINE configs 4 and 5 at reduced size: decomposed cliques (PsdConeTriangle per clique, overlap columns) and the
+    closest-correlation problem (one cone, diagonal reduced operator)."""
+    prob = cj.problems.chordal_sdp(ncliques=8, dmin=4, dmax=24, sep_min=1, sep_max=3, n_total=500, n_zero=5, n_nonneg=10, seed=3)
+    r, c = _pair(OC, prob, max_iter=80, eps_abs=0.0, eps_rel=0.0, tol_constant=1e-10, tol_exponent=0.0)
+    _check(r, c, tol=1e-6, cg_rel=0.03)     # ~280 Krylov iterations per solve down to 1e-10: the last ones depend on the summation order of the dots
+    assert c["proj_time"] > 0.0
+    prob = cj.problems.closest_correlation(d=40, seed=9)
+    r, c = _pair(OC, prob)
+    assert r.status == "Solved"
+    _check(r, c, tol=1e-6)

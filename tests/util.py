@@ -75,10 +75,10 @@ def make_handle_from_workspace(ws: O.Workspace, kkt_kind=cj._ffi.KKT_CG, dtype=n
     return h
 
 
-def random_qp(rng, n, m_zero, m_nonneg, m_box, soc_dims=(), density=0.1, psd_tri_dims=(), p_shift=0.1):
+def random_qp(rng, n, m_zero, m_nonneg, m_box, soc_dims=(), density=0.1, psd_tri_dims=(), p_shift=0.1, psd_sq_dims=()):
     """A feasible random conic QP in internal form with a mix of cone types."""
     m_soc = int(sum(soc_dims))
-    m_psd = int(sum(d * (d + 1) // 2 for d in psd_tri_dims))
+    m_psd = int(sum(d * (d + 1) // 2 for d in psd_tri_dims)) + int(sum(d * d for d in psd_sq_dims))
     m = m_zero + m_nonneg + m_box + m_soc + m_psd
     A = sp.random(m, n, density=density, random_state=rng, format="csc", data_rvs=rng.standard_normal)
     A = (A + sp.csc_matrix((np.ones(min(m, n)), (np.arange(min(m, n)), np.arange(min(m, n)))), shape=(m, n)) * 0.5).tocsc()
@@ -109,6 +109,10 @@ def random_qp(rng, n, m_zero, m_nonneg, m_box, soc_dims=(), density=0.1, psd_tri
         B = rng.standard_normal((d, d))
         s0.append(cj.problems.svec(B @ B.T / d + 0.1 * np.eye(d)))
         sets.append(cj.PsdConeTriangle(d * (d + 1) // 2))
+    for d in psd_sq_dims:                                    # square PsdCone (vec layout), after the triangle cones
+        B = rng.standard_normal((d, d))
+        s0.append((B @ B.T / d + 0.1 * np.eye(d)).reshape(-1, order="F"))
+        sets.append(cj.PsdCone(d * d))
     s0 = np.concatenate(s0)
     b = A @ x0 + s0
     return dict(P=P, q=q, A=A, b=b, sets=sets)
