@@ -246,6 +246,28 @@ function polar_streamk_stats(h::Handle)      # stream-K product of the large PSD
     return (enabled = out[1], workgroups = out[2], classes = out[3], timeouts = out[4])
 end
 
+# ---- sharding over the GPUs of one node (one Julia process per GPU; the unique id travels through Distributed / MPI) -----------------
+# comm_unique_id() on rank 0, comm_init!(h, rank, nranks, id) on every rank, then EITHER set_cone_shard! (projections only: one all-gather
+# of the projected s per iteration) OR set_row_shard! (the rank keeps its cones AND their rows of A / s / mu / rho: one all-reduce of an
+# n-vector per iteration, src/linear_solver/kktsolver_indirect.jl:52-54).  first_cone: nranks + 1 zero-based cone boundaries.
+function comm_unique_id(::Type{T} = Float64) where {T <: HipFloat}
+    id = zeros(UInt8, 128)
+    rc = ccall((:cosmo_hip_comm_unique_id, T === Float32 ? LIB32[] : LIB[]), Int32, (Ptr{UInt8},), id)
+    rc == 0 || error("cosmo_hip_comm_unique_id failed ($rc)")
+    return id
+end
+comm_init!(h::Handle, rank::Integer, nranks::Integer, id::Vector{UInt8}) =
+    check(h, ccall((:cosmo_hip_comm_init, lib(h)), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{UInt8}), h.ptr, Int32(rank), Int32(nranks), id))
+set_cone_shard!(h::Handle, first_cone::Vector{Int64}) =
+    check(h, ccall((:cosmo_hip_set_cone_shard, lib(h)), Int32, (Ptr{Cvoid}, Ptr{Int64}), h.ptr, first_cone))
+set_row_shard!(h::Handle, first_cone::Vector{Int64}) =
+    check(h, ccall((:cosmo_hip_set_row_shard, lib(h)), Int32, (Ptr{Cvoid}, Ptr{Int64}), h.ptr, first_cone))
+function comm_stats(h::Handle)
+    out = zeros(Int64, 8)
+    check(h, ccall((:cosmo_hip_comm_stats_ex, lib(h)), Int32, (Ptr{Cvoid}, Ptr{Int64}), h.ptr, out))
+    return (nranks = out[1], rank = out[2], collectives = out[3], transport = out[4], mode = out[5], bytes = out[6], allreduces = out[7], allreduce_elems = out[8])
+end
+
 function project_hip!(h::Handle{T}, s::COSMO.SplitVector{T}) where {T <: HipFloat}
     d = s.data
     GC.@preserve d check(h, ccall((:cosmo_hip_project, lib(h)), Int32, (Ptr{Cvoid}, Ptr{T}, Ptr{Int64}, Ptr{Int32}), h.ptr, d, C_NULL, C_NULL))
