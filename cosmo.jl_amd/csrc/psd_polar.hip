@@ -129,12 +129,6 @@ struct PolarPlan {
   int* gate_host = nullptr;  // pinned copy of PolarDev::gate for the non-speculative mode
   int batch_wave = 0;        // COSMO_HIP_POLAR_BATCH_WAVE=1: wave-per-tile product kernel (k_symm_gemm_batch_w) for the 64 x 64 tile class.  Bit-identical
                              // to the workgroup-per-tile kernel; measured on BASELINE config 5: 50.7 vs 47.3 us per product, 150.2 vs 154.7 it/s => opt-in
-  int bstreams = 1;          // COSMO_HIP_POLAR_BATCH_STREAMS=2: the batch's cones are dealt into two halves whose product sequences run on two HIP
-                             // streams (fork after the scaling, join before every verification), so that the ramp-up and tail of one half's
-                             // launch overlap the other half's steady state
-  hipStream_t stream2 = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  int rt_off[3] = {0, 0, 0}; // ragged tile list: group g owns descriptors [rt_off[g], rt_off[g + 1])
   int batch_ragged = 1;      // block-balanced ragged tiles (k_symm_gemm_batch_r); COSMO_HIP_POLAR_BATCH_RAGGED=0: the 64 x 64 quadrant kernel
   void* d_rtiles = nullptr;  // RTile list of the ragged kernel (XCD-interleaved like d_btiles)
   int nrtiles = 0;
@@ -1177,9 +1171,6 @@ void polar_plan_destroy(cosmo_hip_handle* h) {
   if (q->d_bcones) (void)hipFree(q->d_bcones);
   if (q->d_btiles) (void)hipFree(q->d_btiles);
   if (q->d_rtiles) (void)hipFree(q->d_rtiles);
-  if (q->stream2) { (void)hipStreamSynchronize(q->stream2); (void)hipStreamDestroy(q->stream2); }
-  if (q->ev_fork) (void)hipEventDestroy(q->ev_fork);
-  if (q->ev_join) (void)hipEventDestroy(q->ev_join);
   if (q->BW) (void)hipFree(q->BW);
   if (q->bparts) (void)hipFree(q->bparts);
   if (q->bnrm) (void)hipFree(q->bnrm);
@@ -1323,17 +1314,10 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
     if (q->batch_ts96 || q->batch_wave) q->batch_ragged = 0;
     q->batch_flops_performed = q->batch_flops_useful = 0.0;
     for (const BatchCone& bc : q->bcones) q->batch_flops_useful += (double)bc.d * bc.d * (bc.d + 1.0);
-    if (const char* e = getenv("COSMO_HIP_POLAR_BATCH_STREAMS")) q->bstreams = (atoi(e) == 2) ? 2 : 1;
-    if (!q->batch_ragged) q->bstreams = 1;
     if (q->batch_ragged) {
-     std::vector<RTile> rl_all;
-     for (int grp = 0; grp < q->bstreams; ++grp) {
       std::vector<std::vector<RTile>> xl(8);
       long long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      int ord_pos = -1;
       for (int ci : order) {
-        ++ord_pos;
-        if (q->bstreams == 2 && (ord_pos & 1) != grp) continue;      // cones alternate between the groups in descending-size order
         const BatchCone& bc = q->bcones[ci];
         const int nb16 = (bc.d + 15) / 16, nt = (nb16 + 3) / 4;
         std::vector<int> start(nt + 1, 0);
@@ -1355,17 +1339,7 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
       for (int x = 0; x < 8; ++x) maxlen = std::max(maxlen, xl[x].size());
       std::vector<RTile> rl(8 * std::max<size_t>(maxlen, 1), RTile{-1, 0, 0, 0});
       for (int x = 0; x < 8; ++x) for (size_t sl = 0; sl < xl[x].size(); ++sl) rl[8 * sl + x] = xl[x][sl];
-      q->rt_off[grp] = (int)rl_all.size();
-      rl_all.insert(rl_all.end(), rl.begin(), rl.end());
-      q->rt_off[grp + 1] = (int)rl_all.size();
-     }
-      const std::vector<RTile>& rl = rl_all;
       q->nrtiles = (int)rl.size();
-      if (q->bstreams == 2) {
-        HIPCHK(h, hipStreamCreateWithFlags(&q->stream2, hipStreamNonBlocking));
-        HIPCHK(h, hipEventCreateWithFlags(&q->ev_fork, hipEventDisableTiming));
-        HIPCHK(h, hipEventCreateWithFlags(&q->ev_join, hipEventDisableTiming));
-      }
       HIPCHK(h, hipMalloc((void**)&q->d_rtiles, sizeof(RTile) * rl.size()));
       HIPCHK(h, hipMemcpy(q->d_rtiles, rl.data(), sizeof(RTile) * rl.size(), hipMemcpyHostToDevice));
       (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch_r<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
@@ -1405,12 +1379,10 @@ bool polar_has_large(const cosmo_hip_handle* h) { const PolarPlan* q = static_ca
 template <int EPI>
 static void launch_bgemm(PolarPlan* q, hipStream_t st, const Ctl* ctl, int guard, const int* gate, int ia, int ib, int icin, int ic, real alpha, real beta) {
   if (q->batch_ragged && q->nrtiles > 0) {
-    for (int grp = 0; grp < q->bstreams; ++grp) {
-      const int cnt = q->rt_off[grp + 1] - q->rt_off[grp];
-      if (cnt <= 0) continue;
-      hipLaunchKernelGGL((k_symm_gemm_batch_r<EPI, 3>), dim3(cnt), dim3(256), GemmCfg<64>::SMEM, (grp == 1) ? q->stream2 : st, ctl, guard, gate,
-                         (const RTile*)q->d_rtiles + q->rt_off[grp], q->d_bcones, q->BW, ia, ib, icin, ic, alpha, beta);
-    }
+    // (the two halves of the batch on two HIP streams -- so that one half's launch tail overlaps the other's steady state -- were built and
+    //  measured: 187.8-189.6 vs 187.1 it/s on BASELINE config 5, no gain, removed; profiles/r03_cfg5_ragged.txt)
+    hipLaunchKernelGGL((k_symm_gemm_batch_r<EPI, 3>), dim3(q->nrtiles), dim3(256), GemmCfg<64>::SMEM, st, ctl, guard, gate, (const RTile*)q->d_rtiles, q->d_bcones,
+                       q->BW, ia, ib, icin, ic, alpha, beta);
     return;
   }
   if (q->nbtiles96 > 0)
@@ -1438,9 +1410,6 @@ int32_t polar_enqueue_project_batch(cosmo_hip_handle* h, real* s, int guard) {
   hipLaunchKernelGGL(k_bpolar_populate, dim3(BPX, n), dim3(COSMO_BS), 0, st, h->ctl, guard, q->d_bcones, s, q->BW, q->bparts);
   hipLaunchKernelGGL(k_bpolar_scale, dim3(BPX, n), dim3(COSMO_BS), 0, st, h->ctl, guard, q->d_bcones, q->bparts, q->BW, q->bnrm);
   int iu = 1, iy = 2, products = 0;
-  // two-stream mode: the second half's products run on stream2 between fork (after the scaling) and join (before the verification sums)
-  auto fork = [&]() { if (q->bstreams == 2) { (void)hipEventRecord(q->ev_fork, st); (void)hipStreamWaitEvent(q->stream2, q->ev_fork, 0); } };
-  auto join = [&]() { if (q->bstreams == 2) { (void)hipEventRecord(q->ev_join, q->stream2); (void)hipStreamWaitEvent(st, q->ev_join, 0); } };
   auto step = [&](const real* co, const int* gate) {
     launch_bgemm<0>(q, st, h->ctl, guard, gate, iu, iu, iu, iy, 1.0, 0.0);       // Y = U^2
     launch_bgemm<1>(q, st, h->ctl, guard, gate, iy, iy, iy, 3, co[2], co[1]);    // T = c Y^2 + b Y
@@ -1451,13 +1420,11 @@ int32_t polar_enqueue_project_batch(cosmo_hip_handle* h, real* s, int guard) {
   auto verify = [&](int round, const int* gate) {
     launch_bgemm<0>(q, st, h->ctl, guard, gate, iu, 0, 0, 3, 1.0, 0.0);          // H = U X = |X|
     launch_bgemm<1>(q, st, h->ctl, guard, gate, iu, 3, 0, iy, 1.0, -1.0);        // G = U H - X
-    join();
     hipLaunchKernelGGL(k_bpolar_sumsq, dim3(BPX, n), dim3(COSMO_BS), 0, st, h->ctl, guard, gate, q->d_bcones, q->BW, iy, vparts);
     hipLaunchKernelGGL(k_bpolar_decide, dim3(1), dim3(COSMO_BS), 0, st, h->ctl, guard, q->dev, q->bgate, round, round == q->max_rounds ? 1 : 0, n, q->d_bcones,
                        vparts, q->bnrm, q->tol_factor);
     products += 2; q->launches[3] += 2;
   };
-  fork();
   for (int t = 0; t < q->k_lift; ++t) step(kPolarLift, nullptr);
   for (int t = 0; t < POLAR_NFIN; ++t) step(kPolarFinish[t], nullptr);
   verify(0, nullptr);
@@ -1468,7 +1435,6 @@ int32_t polar_enqueue_project_batch(cosmo_hip_handle* h, real* s, int guard) {
       HIPCHK(h, hipStreamSynchronize(st));
       if (!*q->gate_host) break;
     }
-    fork();
     for (int t = 0; t < POLAR_RLIFT; ++t) step(kPolarLift, q->bgate);
     for (int t = 0; t < POLAR_NFIN; ++t) step(kPolarFinish[t], q->bgate);
     verify(r, q->bgate);
