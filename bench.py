@@ -213,7 +213,7 @@ def compiled_cpu_rate(prob, iters, threads=1):
     return dict(rate=c["iter"] / c["iter_time"], iters=c["iter"], secs=c["iter_time"], cg=c["cg_iters_total"] / (c["iter"] + 1.0), proj_secs=c["proj_time"])
 
 
-def compiled_cpu_baseline(prob, iters, label, workload_key, args, with_all_threads=True):
+def compiled_cpu_baseline(prob, iters, label, workload_key, args, with_all_threads=True, iters_all=None):
     """cpu_baseline of one configuration: the compiled loop with 1 thread (what the tagged reference does outside BLAS) and -- where LAPACK is
     involved -- with the physical cores of one NUMA node as BLAS threads, run in a child process that is pinned to them before OpenBLAS starts."""
     r1 = compiled_cpu_rate(prob, iters, 1)
@@ -222,9 +222,9 @@ def compiled_cpu_baseline(prob, iters, label, workload_key, args, with_all_threa
                       "(%.1f s of it in the cone projections), 1 thread; mean CG its/solve %.1f" % (r1["iters"], label, r1["secs"], r1["proj_secs"], r1["cg"]))
     if with_all_threads:
         import subprocess
-        cpus, where = numa_node0_physical_cores()
+        cpus, where = numa_node0_physical_cores(cap=16)       # 32 threads were slower still (r03_bench_all_v3.json: cfg5 0.037 it/s against 0.153 with one)
         if len(cpus) > 1:
-            cmd = [sys.executable, os.path.abspath(__file__), "--cpu-leg", workload_key, "--cpu-leg-cpus", ",".join(map(str, cpus)), "--cpu-leg-iters", str(iters)]
+            cmd = [sys.executable, os.path.abspath(__file__), "--cpu-leg", workload_key, "--cpu-leg-cpus", ",".join(map(str, cpus)), "--cpu-leg-iters", str(iters_all or iters)]
             if args.small:
                 cmd.append("--small")
             try:
@@ -492,7 +492,7 @@ def bench_cfg4(ctx, args, steps, warmup):
                      "parallelism": "replicas x%d (a single cone does not shard; SURVEY 8e)" % ctx.world,
                      "mean_cg_iters_per_admm_iter": round(kbar, 3), "polar": {k: ps[k] for k in ("schedule_steps", "fallback_rounds", "verified", "unverified", "err_max_e18")}}
     if not args.no_cpu_baseline and ctx.world == 1:
-        out["cpu_baseline"] = compiled_cpu_baseline(prob, 2 if not args.small else 20, "cfg4", "cfg4", args)
+        out["cpu_baseline"] = compiled_cpu_baseline(prob, 8 if not args.small else 20, "cfg4", "cfg4", args, iters_all=2 if not args.small else 20)
     h.close()
     if ctx.world == 1 and not args.no_float32:
         out["float32"] = float32_extra(ctx, args, prob, st, steps, warmup)
@@ -566,7 +566,7 @@ def bench_cfg5(ctx, args, steps, warmup):
                                flops_per_launch=fl, avg_launch_us=round(1e6 * t_prod, 2), launches_timed=20, products_per_projection=ps["products_last_batch"],
                                useful_tflops_reference_algorithm=round(useful * value / 1e12, 3), useful_frac_of_peak=round(useful * value / 1e12 / F64_MFMA_PEAK_TF, 5))
     if not args.no_cpu_baseline and ctx.world == 1:
-        out["cpu_baseline"] = compiled_cpu_baseline(prob, 1 if not args.small else 10, "cfg5", "cfg5", args)
+        out["cpu_baseline"] = compiled_cpu_baseline(prob, 2 if not args.small else 10, "cfg5", "cfg5", args, iters_all=1 if not args.small else 10)
     if ctx.world == 1 and not args.no_float32:
         h.close()
         out["float32"] = float32_extra(ctx, args, prob, st, steps, warmup)

@@ -29,6 +29,15 @@ def problem(name):
     return cj.problems.closest_correlation() if name == "cfg4" else cj.problems.chordal_sdp()
 
 
+def solve_cfg5_to_convergence(p):
+    """Round 3: cfg5 DOES converge with the default settings -- the device needs 2825 iterations (9.5 s, tools/cfg5_convergent_device.py) -- and
+    the compiled restatement now projects PSD cones (LAPACK dsyevr + dsyrk), so the CPU side of that solve is affordable: ~1.5-2 hours on one core
+    (161 k Krylov iterations on a 2.9 M-nonzero A).  Stored under the key "cfg5_solved"; the 150-iteration entry "cfg5" stays."""
+    from oracle import cosmo_oracle_c as OC
+    ws = O.Workspace(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), O.Settings(kkt_solver="cg", max_iter=6000))
+    return OC.run(ws, native=os.path.exists(os.path.join(ROOT, "oracle", "_build", "libcosmo_oracle_c_native.so")))
+
+
 def solve_cfg2(p):
     """cfg2 (n = 100 000, Box cone, ~550 Krylov iterations per solve) is out of reach of the NumPy loop; the COMPILED restatement of the
     same loop (oracle/cosmo_oracle_c.c, pinned to the NumPy oracle by tests/test_oracle_c.py) runs it: setup (Ruiz scaling, rho vector) by
@@ -43,7 +52,17 @@ if __name__ == "__main__":
     out = json.load(open(OUT)) if os.path.exists(OUT) else {}
     for name in (sys.argv[1:] or ["cfg4", "cfg5"]):
         t0 = time.time()
-        p = problem(name)
+        p = problem(name) if name != "cfg5_solved" else None
+        if name == "cfg5_solved":
+            p = problem("cfg5")
+            r = solve_cfg5_to_convergence(p)
+            out[name] = dict(max_iter=6000, status=r["status"], iter=int(r["iter"]), obj_val=float(r["obj_val"]), r_prim=float(r["r_prim"]), r_dual=float(r["r_dual"]),
+                             rho_updates=[float(v) for v in r["rho_updates"]], cg_iters_total=int(r["cg_iters_total"]), x_norm=float(np.linalg.norm(r["x"])),
+                             x_absmax=float(np.max(np.abs(r["x"]))), oracle_seconds=round(time.time() - t0, 1), proj_seconds=round(r["proj_time"], 1),
+                             oracle="compiled C restatement (oracle/cosmo_oracle_c.c; dsyevr + dsyrk projections)")
+            print(name, out[name], flush=True)
+            json.dump(out, open(OUT, "w"), indent=1)
+            continue
         if name == "cfg2":
             r = solve_cfg2(p)
             out[name] = dict(max_iter=MAX_ITER[name], status=r["status"], iter=int(r["iter"]), obj_val=float(r["obj_val"]), r_prim=float(r["r_prim"]),

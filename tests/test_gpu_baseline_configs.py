@@ -168,7 +168,7 @@ def test_cfg5_assembled_operator_on_off_at_full_size(monkeypatch):
     assert np.max(np.abs(r1.s - r0.s)) <= 1e-7 * max(1.0, float(np.max(np.abs(r0.s))))
 
 
-@pytest.mark.parametrize("name", ["cfg2", "cfg4", "cfg5"])
+@pytest.mark.parametrize("name", ["cfg2", "cfg4", "cfg5", "cfg5_solved"])
 def test_full_size_default_settings_run_matches_the_committed_oracle_result(name):
     """End to end with the reference's DEFAULT settings (eps 1e-5, adaptive rho, Ruiz scaling, CG tolerance 1 / k^1.5) at BASELINE size
     against tests/golden/baseline_convergent.json (tests/golden/make_fixtures_convergent.py: the CPU oracle on the same instance).
@@ -180,11 +180,13 @@ def test_full_size_default_settings_run_matches_the_committed_oracle_result(name
     if name not in fx:
         pytest.skip("no committed oracle result for %s" % name)
     ref = fx[name]
-    p = cj.problems.sparse_box_qp() if name == "cfg2" else MK.problem(name)
+    # "cfg5_solved" (round 3): BASELINE config 5 solved to eps = 1e-5 -- 2825 iterations on the device -- against the compiled oracle's solve of the
+    # same instance (tests/golden/make_fixtures_convergent.py cfg5_solved); "cfg5" is the 150-iteration state of round 2
+    p = cj.problems.sparse_box_qp() if name == "cfg2" else MK.problem("cfg5" if name == "cfg5_solved" else name)
     md = cj.Model(); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], cj.Settings(kkt_solver=cj.CGIndirectKKTSolver, max_iter=ref["max_iter"]))
     r = cj.optimize(md)
     assert r.status == ref["status"], (r.status, ref["status"])
-    assert abs(r.iter - ref["iter"]) <= 25, (r.iter, ref["iter"])
+    assert abs(r.iter - ref["iter"]) <= (25 if ref["iter"] < 1000 else 50), (r.iter, ref["iter"])      # thousands of inexact-CG iterations: two intervals
     assert abs(r.obj_val - ref["obj_val"]) <= 1e-4 * (1 + abs(ref["obj_val"])), (r.obj_val, ref["obj_val"])
     assert len(r.info.rho_updates) == len(ref["rho_updates"])
     assert np.allclose(r.info.rho_updates, ref["rho_updates"], rtol=1e-3)
