@@ -635,11 +635,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 // block's offsets.  Same instruction, same k order per output element => bit-identical to k_symm_gemm_batch (tests/test_gpu_parity_psd.py).
 // Operand panels are still loaded 64 wide from the tile's first row / column (ld stays a multiple of 64 and i0 + 64 <= ld by the way
 // the parts are chosen), the epilogue is the same LDS transposition restricted to the tile's extents.
-struct RTile { int cone; int i0, j0; int ext; };      // ext = ei | ej << 8 | diag << 16  (ei, ej in blocks of 16)
+// ext = ei | ej << 8 | diag << 16 (ei, ej in blocks of 16).  The descriptor carries everything the kernel needs from the cone (ld, side, offset
+// of its work matrices): one 32-byte load instead of descriptor -> cone table -> operands, i.e. one dependent round trip to memory less in a
+// prologue that the in-kernel clocks (tools/ragged_timing_lab.py) put at 21 % of a tile's life.
+struct alignas(32) RTile { int cone; int i0, j0; int ext; int ld, d; long long woff; };
 
-template <int NSL, class PreLast>
+#ifdef POLAR_LAB_TIMING       // lab instrumentation (tools/build_lab_variants.sh TIMING): shader-clock cycles of wave 0 of every workgroup, summed per phase
+#define RT_MAXT 8192
+__device__ unsigned long long g_rt[RT_MAXT * 5];     // per workgroup of the LAST launch: start, first panel in LDS, end of main loop, end, k-panels (plain stores: atomics
+                                                      // on shared counters serialised 9 k tile ends and doubled the kernel time)
+#define RT_NOW() ((threadIdx.x == 0) ? (unsigned long long)clock64() : 0ull)
+#define RT_ARG , t_first
+#define RT_ADD(slot, v) do { if (threadIdx.x == 0 && blockIdx.x < RT_MAXT) g_rt[blockIdx.x * 5 + (slot)] = (unsigned long long)(v); } while (0)
+#else
+#define RT_NOW() 0ull
+#define RT_ADD(slot, v)
+#define RT_ARG
+#endif
+
+template <int NSL, int DEPTH, class PreLast>
 __device__ __forceinline__ void symm_mainloop_r(const real* __restrict__ A, const real* __restrict__ B, int ld, int i0, int j0, int nk, real* smem,
-                                                v4d (&acc)[4], const int (&oa)[4], const int (&ob)[4], PreLast pre_last) {
+                                                v4d (&acc)[4], const int (&oa)[4], const int (&ob)[4], PreLast pre_last
+#ifdef POLAR_LAB_TIMING
+                                                , unsigned long long& t_first
+#endif
+                                                ) {
   using Cfg = GemmCfg<64>;
   constexpr int NL = Cfg::NL, PITCH = Cfg::PITCH, PANEL = Cfg::PANEL;
   real* As = smem;
@@ -656,7 +676,7 @@ __device__ __forceinline__ void symm_mainloop_r(const real* __restrict__ A, cons
   }
   const real* ga = A + i0;
   const real* gb = B + j0;
-  real2 r[2][2 * NL];
+  real2 r[DEPTH][2 * NL];          // DEPTH = 2: panels kb + 1 and kb + 2 in flight; DEPTH = 1 (the four-waves-per-SIMD build): panel kb + 1 only
 #define R_LOAD(R, KB)                                                                                     \
   {                                                                                                       \
     const long long o_ = (long long)(KB) * pstep;                                                         \
@@ -690,19 +710,35 @@ __device__ __forceinline__ void symm_mainloop_r(const real* __restrict__ A, cons
     }                                                                                                     \
   }
   R_LOAD(r[0], 0)
-  if (1 < nk) R_LOAD(r[1], 1)
+  if (DEPTH == 2 && 1 < nk) R_LOAD(r[DEPTH - 1], 1)
   R_STORE(r[0], 0)
   __syncthreads();
+#ifdef POLAR_LAB_TIMING
+  t_first = RT_NOW();
+#endif
+  if (DEPTH == 1) {
+    for (int kb = 0; kb + 1 < nk; kb += 2) {
+      R_LOAD(r[0], kb + 1)
+      R_COMPUTE(0)
+      R_STORE(r[0], 1)
+      __syncthreads();
+      if (kb + 2 >= nk) break;
+      R_LOAD(r[0], kb + 2)
+      R_COMPUTE(1)
+      R_STORE(r[0], 0)
+      __syncthreads();
+    }
+  } else
   // All panels but the last run in the two-phase loop; the LAST panel is peeled so that pre_last() -- a hook for work that should overlap
   // the last panel's matrix instructions -- sits in straight-line code (inside the loop anything it loads stays live across every
   // iteration: a Cin prefetch spilled 436 bytes per lane there).
   for (int kb = 0; kb + 1 < nk; kb += 2) {
     if (kb + 2 < nk) R_LOAD(r[0], kb + 2)
     R_COMPUTE(0)
-    R_STORE(r[1], 1)
+    R_STORE(r[DEPTH - 1], 1)
     __syncthreads();
     if (kb + 2 >= nk) break;
-    if (kb + 3 < nk) R_LOAD(r[1], kb + 3)
+    if (kb + 3 < nk) R_LOAD(r[DEPTH - 1], kb + 3)
     R_COMPUTE(1)
     R_STORE(r[0], 0)
     __syncthreads();
@@ -719,19 +755,23 @@ template <int EPI, int OCC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_symm_gemm_batch_r(const Ctl* __restrict__ ctl, int guard, const int* __restrict__ gate,
                                                          const RTile* __restrict__ tiles, const BatchCone* __restrict__ cones, real* __restrict__ W,
                                                          int ia, int ib, int icin, int ic, real alpha, real beta) {
-  if (guard && ctl->halt) return;
   extern __shared__ real smem[];
-  const RTile td = tiles[blockIdx.x];
+  const unsigned long long t_start = RT_NOW();
+  unsigned long long t_first = t_start;
+  (void)t_first;
+  const RTile td = tiles[blockIdx.x];        // requested TOGETHER with the halt flag (two independent scalar loads, one wait)
+  const int halted = guard ? ctl->halt : 0;
+  if (halted) return;
   if (td.cone < 0) return;                   // padding of the XCD-interleaved tile list
   if (gate && !gate[td.cone]) return;        // fallback round: only the cones whose verification failed
-  const BatchCone bc = cones[td.cone];
-  const long long n2 = (long long)bc.ld * bc.ld;
-  real* base = W + bc.woff;
+  (void)cones;
+  const int ld = td.ld;
+  const long long n2 = (long long)ld * ld;
+  real* base = W + td.woff;
   const real* A = base + ia * n2;
   const real* B = base + ib * n2;
   const real* Cin = base + icin * n2;
   real* C = base + ic * n2;
-  const int ld = bc.ld;
   const int ei = td.ext & 255, ej = (td.ext >> 8) & 255, diag = (td.ext >> 16) & 1;
   const int nblk = diag ? ei * (ei + 1) / 2 : ei * ej;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -752,7 +792,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   v4d acc[4];
 #pragma unroll
   for (int sl = 0; sl < 4; ++sl) acc[sl] = v4d{0.0, 0.0, 0.0, 0.0};
-  const int nk = ((bc.d + 15) / 16);         // k-panels: rows / columns beyond d are zero in every operand of the iteration
+  const int nk = ((td.d + 15) / 16);         // k-panels: rows / columns beyond d are zero in every operand of the iteration
   const int xi = 16 * ei, xj = 16 * ej;      // extents in elements
   const int i0 = td.i0, j0 = td.j0;
   real cin[16];
@@ -771,13 +811,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   // Requesting Cin before the last panel's matrix instructions (pre_last = load_cin) was built and measured on BASELINE config 5: 188.1 vs
   // 188.3 it/s -- with three workgroups per CU the epilogue's round trip is already covered by the other workgroups' main loops.
   auto pre_last = [&]() {};
+#ifndef POLAR_LAB_NO_MAINLOOP               // lab builds (tools/build_lab_variants.sh): epilogue only / main loop only
   switch (nsl) {                             // wave-uniform; a wave without a block still takes part in the panel loads and barriers
-    case 4: symm_mainloop_r<4>(A, B, ld, i0, j0, nk, smem, acc, oa, ob, pre_last); break;
-    case 3: symm_mainloop_r<3>(A, B, ld, i0, j0, nk, smem, acc, oa, ob, pre_last); break;
-    case 2: symm_mainloop_r<2>(A, B, ld, i0, j0, nk, smem, acc, oa, ob, pre_last); break;
-    case 1: symm_mainloop_r<1>(A, B, ld, i0, j0, nk, smem, acc, oa, ob, pre_last); break;
-    default: symm_mainloop_r<0>(A, B, ld, i0, j0, nk, smem, acc, oa, ob, pre_last); break;
+    case 4: symm_mainloop_r<4, (OCC >= 4 ? 1 : 2)>(A, B, ld, i0, j0, nk, smem, acc, oa, ob, pre_last RT_ARG); break;
+    case 3: symm_mainloop_r<3, (OCC >= 4 ? 1 : 2)>(A, B, ld, i0, j0, nk, smem, acc, oa, ob, pre_last RT_ARG); break;
+    case 2: symm_mainloop_r<2, (OCC >= 4 ? 1 : 2)>(A, B, ld, i0, j0, nk, smem, acc, oa, ob, pre_last RT_ARG); break;
+    case 1: symm_mainloop_r<1, (OCC >= 4 ? 1 : 2)>(A, B, ld, i0, j0, nk, smem, acc, oa, ob, pre_last RT_ARG); break;
+    default: symm_mainloop_r<0, (OCC >= 4 ? 1 : 2)>(A, B, ld, i0, j0, nk, smem, acc, oa, ob, pre_last RT_ARG); break;
   }
+#else
+  (void)A; (void)B; (void)nk; (void)pre_last;
+#endif
+#ifdef POLAR_LAB_NO_EPILOGUE
+  if (lane == 0) C[(long long)j0 * ld + i0 + wv] = acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0];      // keeps the accumulators alive
+  return;
+#endif
+  const unsigned long long t_main = RT_NOW();
+  (void)t_main; (void)t_start;
   // epilogue: blocks -> Cs[j][i] (transposed through LDS), then C = alpha Cs + beta Cin on the tile's extents, mirrored below the diagonal
   constexpr int CPITCH = GemmCfg<64>::CPITCH;
   real* Cs = smem;
@@ -807,7 +857,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     if (i >= xi || j >= xj || (diag && i >= j)) continue;
     C[(long long)(i0 + i) * ld + j0 + j] = Cs[j * CPITCH + i];
   }
+#ifdef POLAR_LAB_TIMING
+  { const unsigned long long t_end = RT_NOW();
+    RT_ADD(0, t_start); RT_ADD(1, t_first); RT_ADD(2, t_main); RT_ADD(3, t_end); RT_ADD(4, nk); }
+#endif
 }
+#ifdef POLAR_LAB_TIMING
+}  // namespace
+extern "C" void cosmo_dbg_ragged_timing(unsigned long long* out /* RT_MAXT * 5 */) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rt), sizeof(unsigned long long) * RT_MAXT * 5);
+}
+namespace {
+#endif
 
 // ---- wave-per-tile variant of the batched product (barrier-free, LDS-free main loop) ---------------------------------------
 // The workgroup-per-tile kernel spends a workgroup barrier, a register -> LDS copy of two operand panels and LDS fragment reads on every
@@ -1328,6 +1390,7 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
           for (int ti = 0; ti <= tj; ++ti) {
             const int ei = start[ti + 1] - start[ti], ej = start[tj + 1] - start[tj], dg = (ti == tj) ? 1 : 0;
             RTile rt; rt.cone = ci; rt.i0 = 16 * start[ti]; rt.j0 = 16 * start[tj]; rt.ext = ei | (ej << 8) | (dg << 16);
+            rt.ld = bc.ld; rt.d = bc.d; rt.woff = bc.woff;
             if (rt.i0 + 64 > bc.ld || rt.j0 + 64 > bc.ld) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "ragged tile exceeds the leading dimension");
             xl[x].push_back(rt);
             const int nblk = dg ? ei * (ei + 1) / 2 : ei * ej, slots = (nblk + 3) / 4;
@@ -1337,13 +1400,15 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
       }
       size_t maxlen = 0;
       for (int x = 0; x < 8; ++x) maxlen = std::max(maxlen, xl[x].size());
-      std::vector<RTile> rl(8 * std::max<size_t>(maxlen, 1), RTile{-1, 0, 0, 0});
+      std::vector<RTile> rl(8 * std::max<size_t>(maxlen, 1), RTile{-1, 0, 0, 0, 0, 0, 0});
       for (int x = 0; x < 8; ++x) for (size_t sl = 0; sl < xl[x].size(); ++sl) rl[8 * sl + x] = xl[x][sl];
       q->nrtiles = (int)rl.size();
       HIPCHK(h, hipMalloc((void**)&q->d_rtiles, sizeof(RTile) * rl.size()));
       HIPCHK(h, hipMemcpy(q->d_rtiles, rl.data(), sizeof(RTile) * rl.size(), hipMemcpyHostToDevice));
       (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch_r<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
       (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch_r<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
+      (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch_r<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
+      (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch_r<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
     } else {
       for (const BatchCone& bc : q->bcones) { const long long nt = bc.ld / bc.ts; q->batch_flops_performed += 2.0 * (double)(nt * (nt + 1) / 2) * bc.ts * bc.ts * (((bc.d + 31) / 32) * 32); }
     }
@@ -1381,8 +1446,12 @@ static void launch_bgemm(PolarPlan* q, hipStream_t st, const Ctl* ctl, int guard
   if (q->batch_ragged && q->nrtiles > 0) {
     // (the two halves of the batch on two HIP streams -- so that one half's launch tail overlaps the other's steady state -- were built and
     //  measured: 187.8-189.6 vs 187.1 it/s on BASELINE config 5, no gain, removed; profiles/r03_cfg5_ragged.txt)
-    hipLaunchKernelGGL((k_symm_gemm_batch_r<EPI, 3>), dim3(q->nrtiles), dim3(256), GemmCfg<64>::SMEM, st, ctl, guard, gate, (const RTile*)q->d_rtiles, q->d_bcones,
-                       q->BW, ia, ib, icin, ic, alpha, beta);
+    if (q->batch_occ == 4)        // lab variant: four workgroups per CU (<= 128 VGPRs: one staging set, operand panels requested ONE step ahead)
+      hipLaunchKernelGGL((k_symm_gemm_batch_r<EPI, 4>), dim3(q->nrtiles), dim3(256), GemmCfg<64>::SMEM, st, ctl, guard, gate, (const RTile*)q->d_rtiles, q->d_bcones,
+                         q->BW, ia, ib, icin, ic, alpha, beta);
+    else
+      hipLaunchKernelGGL((k_symm_gemm_batch_r<EPI, 3>), dim3(q->nrtiles), dim3(256), GemmCfg<64>::SMEM, st, ctl, guard, gate, (const RTile*)q->d_rtiles, q->d_bcones,
+                         q->BW, ia, ib, icin, ic, alpha, beta);
     return;
   }
   if (q->nbtiles96 > 0)
