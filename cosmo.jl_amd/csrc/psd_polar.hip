@@ -644,6 +644,7 @@ struct alignas(32) RTile { int cone; int i0, j0; int ext; int ld, d; long long w
 #define RT_MAXT 8192
 __device__ unsigned long long g_rt[RT_MAXT * 5];     // per workgroup of the LAST launch: start, first panel in LDS, end of main loop, end, k-panels (plain stores: atomics
                                                       // on shared counters serialised 9 k tile ends and doubled the kernel time)
+__device__ unsigned long long g_rtw[RT_MAXT];
 #define RT_NOW() ((threadIdx.x == 0) ? (unsigned long long)clock64() : 0ull)
 #define RT_ARG , t_first
 #define RT_ADD(slot, v) do { if (threadIdx.x == 0 && blockIdx.x < RT_MAXT) g_rt[blockIdx.x * 5 + (slot)] = (unsigned long long)(v); } while (0)
@@ -759,6 +760,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   const unsigned long long t_start = RT_NOW();
   unsigned long long t_first = t_start;
   (void)t_first;
+#ifdef POLAR_LAB_TIMING
+  const unsigned long long w_start = (threadIdx.x == 0) ? wall_clock64() : 0ull;
+#endif
   const RTile td = tiles[blockIdx.x];        // requested TOGETHER with the halt flag (two independent scalar loads, one wait)
   const int halted = guard ? ctl->halt : 0;
   if (halted) return;
@@ -859,7 +863,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   }
 #ifdef POLAR_LAB_TIMING
   { const unsigned long long t_end = RT_NOW();
-    RT_ADD(0, t_start); RT_ADD(1, t_first); RT_ADD(2, t_main); RT_ADD(3, t_end); RT_ADD(4, nk); }
+    RT_ADD(0, t_start); RT_ADD(1, t_first); RT_ADD(2, t_main); RT_ADD(3, t_end); RT_ADD(4, nk);
+    if (threadIdx.x == 0 && blockIdx.x < RT_MAXT) g_rtw[blockIdx.x] = wall_clock64() - w_start; }   // tile life on the 100 MHz constant clock: calibrates the shader clock
 #endif
 }
 #ifdef POLAR_LAB_TIMING
@@ -867,6 +872,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 extern "C" void cosmo_dbg_ragged_timing(unsigned long long* out /* RT_MAXT * 5 */) {
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rt), sizeof(unsigned long long) * RT_MAXT * 5);
+}
+extern "C" void cosmo_dbg_ragged_wall(unsigned long long* out /* RT_MAXT */) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rtw), sizeof(unsigned long long) * RT_MAXT);
 }
 namespace {
 #endif

@@ -16,17 +16,24 @@ reps = 20
 t, fl = md.handle.time_psd_product(1, reps)
 out = (C.c_ulonglong * (8192 * 5))()
 lib.cosmo_dbg_ragged_timing(out)
+wl = (C.c_ulonglong * 8192)()
+lib.cosmo_dbg_ragged_wall(wl)
 a = np.frombuffer(out, dtype=np.uint64).reshape(8192, 5).astype(np.float64)
-a = a[a[:, 4] > 0]                                          # workgroups that ran a tile in the last launch
+w = np.frombuffer(wl, dtype=np.uint64).astype(np.float64)
+ok = a[:, 4] > 0
+a, w = a[ok], w[ok]                                         # workgroups that ran a tile in the last launch
+# shader clock against the 100 MHz wall clock: every tile's life on both clocks (the shader-clock counters of different XCDs are not synchronised,
+# so only differences inside one workgroup mean anything)
+ghz = float(np.sum(a[:, 3] - a[:, 0]) / np.sum(w)) * 0.1
+print("shader clock during the launch: %.2f GHz (tile lives in s_memtime cycles over the same lives in 100 MHz s_memrealtime ticks)" % ghz)
 t0 = a[:, 0].min()
 pro, main, epi, whole, nk = a[:, 1] - a[:, 0], a[:, 2] - a[:, 1], a[:, 3] - a[:, 2], a[:, 3] - a[:, 0], a[:, 4]
 span = a[:, 3].max() - t0
-print("product %.2f us (HIP events, %d launches); last launch: %d tiles, first start -> last end %.0f shader-clock cycles" % (1e6 * t, reps, len(a), span))
+print("product %.2f us (HIP events, %d launches) = %.0f cycles at that clock; last launch: %d tiles x mean life %.0f cycles / 768 slots = %.0f cycles if perfectly packed => slot utilisation %.0f %%"
+      % (1e6 * t, reps, 1e3 * t * 1e6 * ghz, len(a), whole.mean(), len(a) * whole.mean() / 768, 100 * len(a) * whole.mean() / 768 / (1e3 * t * 1e6 * ghz)))
 print("  per tile, mean (median) cycles: prologue %.0f (%.0f)   main loop %.0f (%.0f) = %.0f per k-panel (%.1f panels)   epilogue %.0f (%.0f)   whole %.0f"
       % (pro.mean(), np.median(pro), main.mean(), np.median(main), main.sum() / nk.sum(), nk.mean(), epi.mean(), np.median(epi), whole.mean()))
 print("  shares of a tile's life: prologue %.0f %%, main loop %.0f %%, epilogue %.0f %%" % (100 * pro.sum() / whole.sum(), 100 * main.sum() / whole.sum(), 100 * epi.sum() / whole.sum()))
-st = a[:, 0] - t0
-print("  tile start times: %.0f %% of the tiles start in the first 5 %% of the span, the last tile starts at %.0f %% of it" % (100 * np.mean(st < 0.05 * span), 100 * st.max() / span))
 for lo, hi in ((1, 3), (4, 6), (7, 9), (10, 13)):
     mk = (nk >= lo) & (nk <= hi)
     if mk.any():
