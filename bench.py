@@ -320,8 +320,10 @@ def bench_cfg2(ctx, args, steps, warmup):
                      "iteration_roofline_frac": round(b_iter * (value / world) / (HBM_PEAK_GBS * 1e9), 4),
                      "algorithmic_bytes_per_iteration": b_iter}
     if not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = compiled_cpu_baseline(prob, args.cpu_sample_iters if not args.small else 200, "cfg2", "cfg2", args, with_all_threads=False)   # no BLAS in this configuration
-        out["config"]["gpu_over_cpu"] = round((value / world) / out["cpu_baseline"]["value"], 2)
+        def cpu_leg(out=out, prob=prob, value=value):
+            out["cpu_baseline"] = compiled_cpu_baseline(prob, args.cpu_sample_iters if not args.small else 200, "cfg2", "cfg2", args, with_all_threads=False)   # no BLAS in this configuration
+            out["config"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 2)
+        args.deferred.append(cpu_leg)
     h.close()
     return out
 
@@ -371,18 +373,19 @@ def bench_cfg3(ctx, args, steps, warmup):
                            note="LDS bytes of the sparse passes x measured Krylov iterations (device counters) / elapsed; HBM is touched at launch and at the checks "
                                 "only.  The slowest problem's dependent chain of Krylov iterations, not LDS bandwidth, ends the step (see config)")
     if not args.no_cpu_baseline and ctx.world == 1:
-        from oracle import cosmo_oracle as O
-        from oracle import cosmo_oracle_c  # noqa: F401
-        from tests import util
-        OC = _native_oracle()
-        nsamp, its, secs = (8 if args.small else 128), 0, 0.0
-        for p in probs[:nsamp]:
-            ws = O.Workspace(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), oracle_settings(O, warmup + steps))
-            c = OC.run(ws, native=True)
-            its += c["iter"]; secs += c["iter_time"]
-        out["cpu_baseline"] = dict(value=its / secs / nprob, unit="ADMM iterations/s (of the whole batch)", cores=1, kind="port",
-                                   sample="compiled C loop (gcc -O3 -march=native; oracle/cosmo_oracle_c.c), %d problems x %d iterations (+ init step), %.2f s of loop time, "
-                                          "scaled to %d problems solved one after the other (the reference's own batch mode)" % (nsamp, warmup + steps, secs, nprob))
+        def cpu_leg(out=out, probs=probs):
+            from oracle import cosmo_oracle as O
+            from tests import util
+            OC = _native_oracle()
+            nsamp, its, secs = (8 if args.small else 128), 0, 0.0
+            for p in probs[:nsamp]:
+                ws = O.Workspace(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), oracle_settings(O, warmup + steps))
+                c = OC.run(ws, native=True)
+                its += c["iter"]; secs += c["iter_time"]
+            out["cpu_baseline"] = dict(value=its / secs / nprob, unit="ADMM iterations/s (of the whole batch)", cores=1, kind="port",
+                                       sample="compiled C loop (gcc -O3 -march=native; oracle/cosmo_oracle_c.c), %d problems x %d iterations (+ init step), %.2f s of loop time, "
+                                              "scaled to %d problems solved one after the other (the reference's own batch mode)" % (nsamp, warmup + steps, secs, nprob))
+        args.deferred.append(cpu_leg)
     B.close()
     return out
 
@@ -492,7 +495,8 @@ def bench_cfg4(ctx, args, steps, warmup):
                      "parallelism": "replicas x%d (a single cone does not shard; SURVEY 8e)" % ctx.world,
                      "mean_cg_iters_per_admm_iter": round(kbar, 3), "polar": {k: ps[k] for k in ("schedule_steps", "fallback_rounds", "verified", "unverified", "err_max_e18")}}
     if not args.no_cpu_baseline and ctx.world == 1:
-        out["cpu_baseline"] = compiled_cpu_baseline(prob, 8 if not args.small else 20, "cfg4", "cfg4", args, iters_all=2 if not args.small else 20)
+        args.deferred.append(lambda out=out, prob=prob: out.__setitem__("cpu_baseline", compiled_cpu_baseline(prob, 8 if not args.small else 20, "cfg4", "cfg4", args,
+                                                                                                                iters_all=2 if not args.small else 20)))
     h.close()
     if ctx.world == 1 and not args.no_float32:
         out["float32"] = float32_extra(ctx, args, prob, st, steps, warmup)
@@ -566,7 +570,8 @@ def bench_cfg5(ctx, args, steps, warmup):
                                flops_per_launch=fl, avg_launch_us=round(1e6 * t_prod, 2), launches_timed=20, products_per_projection=ps["products_last_batch"],
                                useful_tflops_reference_algorithm=round(useful * value / 1e12, 3), useful_frac_of_peak=round(useful * value / 1e12 / F64_MFMA_PEAK_TF, 5))
     if not args.no_cpu_baseline and ctx.world == 1:
-        out["cpu_baseline"] = compiled_cpu_baseline(prob, 2 if not args.small else 10, "cfg5", "cfg5", args, iters_all=1 if not args.small else 10)
+        args.deferred.append(lambda out=out, prob=prob: out.__setitem__("cpu_baseline", compiled_cpu_baseline(prob, 2 if not args.small else 10, "cfg5", "cfg5", args,
+                                                                                                                iters_all=1 if not args.small else 10)))
     if ctx.world == 1 and not args.no_float32:
         h.close()
         out["float32"] = float32_extra(ctx, args, prob, st, steps, warmup)
@@ -577,8 +582,9 @@ def bench_cfg5(ctx, args, steps, warmup):
 BENCH = {"cfg2": bench_cfg2, "cfg3": bench_cfg3, "cfg4": bench_cfg4, "cfg5": bench_cfg5}
 # (steps, warmup) of the extra workloads: the iteration WINDOW is part of the workload -- cfg5 needs 169.5 Krylov iterations per ADMM iteration in
 # iterations 11-50, 138 in 16-75 and 92 in 51-130 (after the rho update of iteration 40), i.e. 156 / 188 / 264 it/s for the same kernels -- so the
-# windows stay those of round 2.  The SDP configurations follow ~10 s of CPU-baseline work during which the GPU idles and clocks down; ten warm-up
-# iterations (60-80 ms) do not bring the clocks back, so _run_sdp first spins the product kernel for ~0.3 s (gpu_prewarm; no ADMM state is touched)
+# windows stay those of round 2.  Ten warm-up iterations (60-80 ms) do not bring the clocks of an idling GPU back up (cfg5 read 155 it/s right after
+# 10 s of CPU-baseline work against 166-170), so all cpu_baseline legs run AFTER the GPU work (args.deferred) and _run_sdp first spins the product
+# kernel for ~0.3 s (gpu_prewarm; no ADMM state is touched)
 EXTRA_STEPS = {"cfg3": (100, 25), "cfg4": (40, 10), "cfg5": (40, 10)}
 
 
@@ -619,6 +625,7 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_under_torchrun(args.gpus)                         # does not return
+    args.deferred = []          # cpu_baseline legs: run AFTER all GPU work, so that no timed window follows tens of seconds of GPU idling (clocks)
     ctx = Ctx()
     if ctx.world != max(args.gpus, 1) and ctx.rank == 0:
         print("bench.py: --gpus %d but the launcher started %d rank(s); reporting n_gpus = %d" % (args.gpus, ctx.world, ctx.world), file=sys.stderr)
@@ -641,6 +648,8 @@ def main():
                 extra[key] = r
             except Exception as e:                                  # an extra workload must not take the headline line down
                 extra[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+    for leg in args.deferred:     # the restated CPU reference on bounded samples of the same instances (rank 0 at N = 1 only)
+        leg()
     out = None
     if ctx.rank == 0:
         out = {"metric": METRIC, "value": round(res["value"], 3), "unit": "ADMM iterations/s", "n_gpus": ctx.world, "steps": res["steps"], "warmup": res["warmup"],
