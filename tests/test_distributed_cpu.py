@@ -109,3 +109,42 @@ def test_bench_timing_rule_max_over_ranks_gloo():
     for p in procs: p.join(timeout=60)
     assert [g[1] for g in got] == [0.75, 0.75]
     assert all(abs(g[2] - 2 * 10 / 0.75) < 1e-12 for g in got)
+
+
+# ---- round 3: the host-side pieces of the row-sharded run and of bench.py's launcher / CPU-baseline plumbing (no GPU involved) ----
+def test_row_shard_partition_tiles_the_cone_list_and_balances_rows_and_cubes():
+    """cj.model.row_shard_costs + partition_cones_contiguous: what every rank of a row-sharded run computes identically (csrc/rowshard.hip takes
+    the boundaries).  Contiguous, covers all cones, every rank non-empty on the BASELINE config 5 structure, bottleneck within 25 % of the mean."""
+    p = cj.problems.chordal_sdp(ncliques=60, dmin=20, dmax=120, n_total=8000, n_zero=200, n_nonneg=900, seed=9)
+    costs = cj.model.row_shard_costs(p["sets"])
+    assert len(costs) == len(p["sets"]) and costs[0] == 8 * 200 and costs[1] == 8 * 900       # simple cones cost their rows only
+    for world in (1, 2, 3, 8):
+        b = cj.partition_cones_contiguous(costs, world)
+        assert b[0] == 0 and b[-1] == len(costs) and all(b[r] <= b[r + 1] for r in range(world))
+        loads = [sum(costs[b[r]:b[r + 1]]) for r in range(world)]
+        assert all(l > 0 for l in loads)
+        assert max(loads) <= 1.25 * sum(costs) / world + max(costs)
+    # exponential / power cones shard with the rows (cost 64 + rows) but not with the cones (clique mode projects them everywhere: cost 0)
+    sets = [cj.ZeroSet(3), cj.ExponentialCone(), cj.PowerCone(0.3), cj.SecondOrderCone(5)]
+    assert cj.cone_costs(sets) == [0, 0, 0, 5] and cj.model.row_shard_costs(sets) == [24, 64 + 24, 64 + 24, 5 + 40]
+
+
+def test_bench_cpu_leg_plumbing():
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    argv = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+        B = importlib.util.module_from_spec(spec); spec.loader.exec_module(B)
+    finally:
+        sys.argv = argv
+    assert B._cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11} and B._cpulist("") == set()
+    cpus, where = B.numa_node0_physical_cores(cap=4)
+    assert 1 <= len(cpus) <= 4 and set(cpus) <= set(os.sched_getaffinity(0)) and "physical cores" in where
+    # the compiled loop as the bench times it (a small SOCP: SecondOrderCone projections in C)
+    p = cj.problems.socp(n=40, m=60, ncones=6, nnz=300, seed=3)
+    r = B.compiled_cpu_rate(p, 30, 1)
+    assert r["iters"] == 30 and r["rate"] > 0 and r["secs"] > 0 and r["cg"] > 0
+    assert B.whole_job_value(4, 10, 2.0) == 20.0
