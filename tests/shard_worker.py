@@ -7,7 +7,8 @@ transport = rccl : RCCL communicator; <rendezvous> is a file through which rank 
                    (two ranks on ONE device: RCCL is expected to refuse this; the test records what it says)
 Environment: COSMO_TEST_SHARD = cones (default: cosmo_hip_set_cone_shard, the projections only) | rows (cosmo_hip_set_row_shard: cones +
 their rows, csrc/rowshard.hip); COSMO_TEST_CASE = chordal (default) | pinf | dinf (the two infeasible problems of
-test_infeasibility_certificates_in_sharded_runs, default settings); COSMO_TEST_TIGHT=1: CG solved to 1e-10 (tol_exponent 0).
+test_infeasibility_certificates_in_sharded_runs, default settings); COSMO_TEST_TIGHT=1: CG solved to 1e-10 (tol_exponent 0);
+COSMO_TEST_DTYPE=float32: the Float32 library.
 Writes the final iterates, the result scalars and the communicator statistics of this rank."""
 import os
 import sys
@@ -60,7 +61,8 @@ def build_model(iters):
     if case in ("pinf", "dinf"):
         return infeasible_model(case)
     p = problem()
-    md = cj.Model(); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], settings(iters, os.environ.get("COSMO_TEST_TIGHT", "") == "1"))
+    dtype = np.float32 if os.environ.get("COSMO_TEST_DTYPE", "") == "float32" else np.float64       # libcosmo_hip_f32.so: the collectives carry float
+    md = cj.Model(dtype=dtype); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], settings(iters, os.environ.get("COSMO_TEST_TIGHT", "") == "1"))
     return md
 
 

@@ -199,6 +199,28 @@ def test_row_sharded_run_agrees_with_the_single_rank_run(world, monkeypatch):
             assert int(z["kkt"]) == int(zs[0]["kkt"])
 
 
+def test_row_sharded_run_in_float32(monkeypatch):
+    """The Float32 library (libcosmo_hip_f32.so): the all-reduce / all-gather element type follows cosmo_hip_real.  Two ranks against the
+    single-rank Float32 run at a Float32 tolerance (default CG schedule), the ranks bit-identical to each other."""
+    W = _worker_module()
+    monkeypatch.setenv("COSMO_HIP_POLAR_KLIFT", "5")
+    p = W.problem()
+    md = cj.Model(dtype=np.float32); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], W.settings(ITERS))
+    ref = cj.optimize(md)
+    with tempfile.TemporaryDirectory() as tmp:
+        outs = _spawn("shm", 2, "/cosmo_test_" + uuid.uuid4().hex[:12], tmp, extra_env={"COSMO_TEST_SHARD": "rows", "COSMO_TEST_DTYPE": "float32", "COSMO_HIP_POLAR_KLIFT": "5"})
+        for rc, o in outs:
+            assert rc == 0, o[-2000:]
+        zs = [np.load(os.path.join(tmp, "rank%d.npz" % r)) for r in range(2)]
+        for z in zs:
+            assert z["x"].dtype == np.float32 and str(z["mode"]) == "rows" and int(z["iter"]) == ref.iter == ITERS
+            assert int(z["allreduce_elems"]) in (md.n, md.n + 4) and int(z["bytes"]) >= (ITERS + 1) * 4 * md.n      # 4-byte elements on the wire
+            for key, val in (("x", ref.x), ("s", ref.s)):
+                assert np.max(np.abs(z[key] - val)) <= 2e-3 * max(np.max(np.abs(val)), 1e-30), key
+        for key in ("x", "s", "y"):
+            assert np.array_equal(zs[0][key].view(np.int32), zs[1][key].view(np.int32)), key
+
+
 @pytest.mark.parametrize("case,want", [("pinf", "Primal_infeasible"), ("dinf", "Dual_infeasible")])
 def test_row_sharded_run_keeps_the_infeasibility_certificates(case, want, monkeypatch):
     """Two ranks, default settings: ||E dy|| / <dy, b> / the support function are reduced over the ranks, A' dy is all-reduced, every rank
