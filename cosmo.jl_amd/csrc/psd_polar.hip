@@ -799,20 +799,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   const int nk = ((td.d + 15) / 16);         // k-panels: rows / columns beyond d are zero in every operand of the iteration
   const int xi = 16 * ei, xj = 16 * ej;      // extents in elements
   const int i0 = td.i0, j0 = td.j0;
-  real cin[16];
-  auto load_cin = [&]() {
-    if (EPI == 1) {
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int e = threadIdx.x + 256 * k;
-        const int i = e & 63, j = e >> 6;
-        const bool ok = i < xi && j < xj && !(diag && i > j);
-        cin[k] = Cin[ok ? (long long)(j0 + j) * ld + i0 + i : 0];
-        if (!ok) cin[k] = R(0.0);
-      }
-    }
-  };
-  // Requesting Cin before the last panel's matrix instructions (pre_last = load_cin) was built and measured on BASELINE config 5: 188.1 vs
+  // Requesting Cin before the last panel's matrix instructions (pre_last = a lambda loading it) was built and measured on BASELINE config 5: 188.1 vs
   // 188.3 it/s -- with three workgroups per CU the epilogue's round trip is already covered by the other workgroups' main loops.
   auto pre_last = [&]() {};
 #ifndef POLAR_LAB_NO_MAINLOOP               // lab builds (tools/build_lab_variants.sh): epilogue only / main loop only
@@ -843,23 +830,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     }
   }
   __syncthreads();
+  // (the LDS reads of a batch are issued together and the stores are predicated: one read -> wait -> store round trip per element, 32 of
+  //  them per thread, made the epilogue 8.6 k cycles of a tile's 33.7 k; now 7.1 k, product 40.0 -> 38.5 us.  A resident form of this kernel
+  //  -- workgroups walking tile lists, next tile's panels prefetched across the tile boundary, snake / LPT / ticket schedules -- was built on
+  //  top and measured: 3 % per product, nothing per ADMM iteration, not kept; profiles/r03_resident_product_kernel.txt)
   {
-    load_cin();
+    constexpr int hf = 0;
+    real cinh[16], v[16];
+    if (EPI == 1) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int e = threadIdx.x + 256 * (16 * hf + k);
+        const int i = e & 63, j = e >> 6;
+        const bool ok = i < xi && j < xj && !(diag && i > j);
+        cinh[k] = Cin[ok ? (long long)(j0 + j) * ld + i0 + i : 0];
+      }
+    }
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      const int e = threadIdx.x + 256 * k;
+      const int e = threadIdx.x + 256 * (16 * hf + k);
+      v[k] = Cs[(e >> 6) * CPITCH + (e & 63)];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int e = threadIdx.x + 256 * (16 * hf + k);
       const int i = e & 63, j = e >> 6;
-      if (i >= xi || j >= xj || (diag && i > j)) continue;
-      real v = Cs[j * CPITCH + i];
-      if (EPI == 1) { v = alpha * v + beta * cin[k]; Cs[j * CPITCH + i] = v; }
-      C[(long long)(j0 + j) * ld + i0 + i] = v;
+      const bool ok = i < xi && j < xj && !(diag && i > j);
+      if (EPI == 1) { v[k] = alpha * v[k] + beta * cinh[k]; if (ok) Cs[j * CPITCH + i] = v[k]; }
+      if (ok) C[(long long)(j0 + j) * ld + i0 + i] = v[k];
     }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
-    const int j = e & 63, i = e >> 6;
-    if (i >= xi || j >= xj || (diag && i >= j)) continue;
-    C[(long long)(i0 + i) * ld + j0 + j] = Cs[j * CPITCH + i];
+  {
+    constexpr int hf = 0;
+    real v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int e = threadIdx.x + 256 * (16 * hf + k);
+      v[k] = Cs[(e & 63) * CPITCH + (e >> 6)];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int e = threadIdx.x + 256 * (16 * hf + k);
+      const int j = e & 63, i = e >> 6;
+      if (i < xi && j < xj && !(diag && i >= j)) C[(long long)(i0 + i) * ld + j0 + j] = v[k];
+    }
   }
 #ifdef POLAR_LAB_TIMING
   { const unsigned long long t_end = RT_NOW();
