@@ -745,8 +745,7 @@ __device__ __forceinline__ void symm_mainloop_r(const real* __restrict__ A, cons
     __syncthreads();
   }
   pre_last();
-  if ((nk - 1) & 1) R_COMPUTE(1) else R_COMPUTE(0)
-  __syncthreads();
+  if ((nk - 1) & 1) R_COMPUTE(1) else R_COMPUTE(0)     // (no barrier after the last panel: the epilogue does not touch LDS)
 #undef R_LOAD
 #undef R_STORE
 #undef R_COMPUTE
@@ -819,61 +818,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 #endif
   const unsigned long long t_main = RT_NOW();
   (void)t_main; (void)t_start;
-  // epilogue: blocks -> Cs[j][i] (transposed through LDS), then C = alpha Cs + beta Cin on the tile's extents, mirrored below the diagonal
-  constexpr int CPITCH = GemmCfg<64>::CPITCH;
-  real* Cs = smem;
-#pragma unroll
-  for (int sl = 0; sl < 4; ++sl) {
-    if (sl < nsl) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) Cs[(ob[sl] + (lane & 15)) * CPITCH + oa[sl] + ACC_ROW(lane, q)] = acc[sl][q];
-    }
-  }
-  __syncthreads();
-  // (the LDS reads of a batch are issued together and the stores are predicated: one read -> wait -> store round trip per element, 32 of
-  //  them per thread, made the epilogue 8.6 k cycles of a tile's 33.7 k; now 7.1 k, product 40.0 -> 38.5 us.  A resident form of this kernel
-  //  -- workgroups walking tile lists, next tile's panels prefetched across the tile boundary, snake / LPT / ticket schedules -- was built on
-  //  top and measured: 3 % per product, nothing per ADMM iteration, not kept; profiles/r03_resident_product_kernel.txt)
+  // Epilogue, straight from the accumulators -- no LDS, no barrier: lane l of a block holds C(i, j) for column j = l & 15 and the four rows
+  // i = ACC_ROW(l, q).  Natural orientation, C(i, j) at (j0 + j) ld + i0 + i: for one q the four lanes of a column write four consecutive
+  // elements (f64) -- 32-byte pieces, four instructions complete a 128-byte line in L2.  Mirrored orientation, (i0 + i) ld + j0 + j: the 16
+  // lanes of a row group write 128 contiguous bytes.  On a diagonal block the elements below the diagonal come from the mirror of the ones
+  // above (exactly symmetric output, as the LDS-transposed epilogue of k_symm_gemm_batch produces it).
+  // Until round 3 this went through LDS (blocks -> Cs[j][i], barrier, 16 row stores, barrier, 16 mirrored stores per thread): two barriers
+  // that wait for the wave with the most blocks, and an epilogue of 8.6 k (7.1 k with batched LDS reads) of a tile's 33.7 k cycles.
+  (void)xi; (void)xj;
   {
-    constexpr int hf = 0;
-    real cinh[16], v[16];
-    if (EPI == 1) {
+    const int lj = lane & 15;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int e = threadIdx.x + 256 * (16 * hf + k);
-        const int i = e & 63, j = e >> 6;
-        const bool ok = i < xi && j < xj && !(diag && i > j);
-        cinh[k] = Cin[ok ? (long long)(j0 + j) * ld + i0 + i : 0];
+    for (int sl = 0; sl < 4; ++sl) {
+      if (sl < nsl) {
+        const int j = ob[sl] + lj;
+        const bool dblk = diag && (oa[sl] == ob[sl]);
+        real v[4];
+        if (EPI == 1) {
+          real c[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int i = oa[sl] + ACC_ROW(lane, q);
+            const bool ok = !(dblk && i > j);
+            c[q] = Cin[ok ? (long long)(j0 + j) * ld + i0 + i : 0];
+            if (!ok) c[q] = R(0.0);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = alpha * acc[sl][q] + beta * c[q];
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = acc[sl][q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = oa[sl] + ACC_ROW(lane, q);
+          if (!(dblk && i > j)) C[(long long)(j0 + j) * ld + i0 + i] = v[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = oa[sl] + ACC_ROW(lane, q);
+          if (!(dblk && i >= j)) C[(long long)(i0 + i) * ld + j0 + j] = v[q];
+        }
       }
-    }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int e = threadIdx.x + 256 * (16 * hf + k);
-      v[k] = Cs[(e >> 6) * CPITCH + (e & 63)];
-    }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int e = threadIdx.x + 256 * (16 * hf + k);
-      const int i = e & 63, j = e >> 6;
-      const bool ok = i < xi && j < xj && !(diag && i > j);
-      if (EPI == 1) { v[k] = alpha * v[k] + beta * cinh[k]; if (ok) Cs[j * CPITCH + i] = v[k]; }
-      if (ok) C[(long long)(j0 + j) * ld + i0 + i] = v[k];
-    }
-  }
-  __syncthreads();
-  {
-    constexpr int hf = 0;
-    real v[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int e = threadIdx.x + 256 * (16 * hf + k);
-      v[k] = Cs[(e & 63) * CPITCH + (e >> 6)];
-    }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int e = threadIdx.x + 256 * (16 * hf + k);
-      const int j = e & 63, i = e >> 6;
-      if (i < xi && j < xj && !(diag && i >= j)) C[(long long)(i0 + i) * ld + j0 + j] = v[k];
     }
   }
 #ifdef POLAR_LAB_TIMING
@@ -1455,6 +1441,11 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
     (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch<1, 4, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
     (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch<0, 2, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<96>::SMEM);
     (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch<1, 2, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<96>::SMEM);
+    // Ragged kernel: FOUR workgroups per CU by default (<= 128 VGPRs: one staging set, panels requested one step ahead).  Its main loops are
+    // at the pace of the matrix pipe whenever three of them share a SIMD; what the fourth wave fills is the pipe time of the others'
+    // prologues and epilogues: 36.0 vs 39.0 us per product on BASELINE config 5 (four alternating pairs of runs, 166.2 vs 162.9 it/s;
+    // profiles/r03_cfg5_ragged.txt).  The quadrant kernel stays at three (there four were slower, see k_symm_gemm_batch).
+    q->batch_occ = q->batch_ragged ? 4 : 3;
     if (const char* e = getenv("COSMO_HIP_POLAR_BATCH_OCC")) { const int v = atoi(e); if (v == 3 || v == 4) q->batch_occ = v; }
   }
   return COSMO_HIP_OK;
@@ -1470,7 +1461,7 @@ static void launch_bgemm(PolarPlan* q, hipStream_t st, const Ctl* ctl, int guard
   if (q->batch_ragged && q->nrtiles > 0) {
     // (the two halves of the batch on two HIP streams -- so that one half's launch tail overlaps the other's steady state -- were built and
     //  measured: 187.8-189.6 vs 187.1 it/s on BASELINE config 5, no gain, removed; profiles/r03_cfg5_ragged.txt)
-    if (q->batch_occ == 4)        // lab variant: four workgroups per CU (<= 128 VGPRs: one staging set, operand panels requested ONE step ahead)
+    if (q->batch_occ == 4)        // default: four workgroups per CU (<= 128 VGPRs: one staging set, operand panels requested ONE step ahead)
       hipLaunchKernelGGL((k_symm_gemm_batch_r<EPI, 4>), dim3(q->nrtiles), dim3(256), GemmCfg<64>::SMEM, st, ctl, guard, gate, (const RTile*)q->d_rtiles, q->d_bcones,
                          q->BW, ia, ib, icin, ic, alpha, beta);
     else

@@ -239,8 +239,9 @@ RAGGED_SIDES = [17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 80, 81, 96, 100, 112, 12
                 209, 224, 240, 241, 255, 256]
 
 
+@pytest.mark.parametrize("occ", ["4", "3"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_batched_sign_path_ragged_tiles_are_bit_identical_to_the_quadrant_kernel(dtype, monkeypatch):
+def test_batched_sign_path_ragged_tiles_are_bit_identical_to_the_quadrant_kernel(dtype, occ, monkeypatch):
     """The block-balanced ragged product kernel (k_symm_gemm_batch_r: sides rounded to 16, 1-4 blocks per part, upper blocks only on
     the diagonal, blocks dealt to the four waves) issues the same matrix instruction in the same k order per output element as the
     64 x 64 quadrant kernel it replaces: every projected cone is bit-identical, for every way a side can sit in the 16 / 64 grid -- and
@@ -259,6 +260,10 @@ def test_batched_sign_path_ragged_tiles_are_bit_identical_to_the_quadrant_kernel
     outs = {}
     for flag in ("0", "1"):
         monkeypatch.setenv("COSMO_HIP_POLAR_BATCH_RAGGED", flag)
+        if flag == "1":
+            monkeypatch.setenv("COSMO_HIP_POLAR_BATCH_OCC", occ)     # both register-allocation variants of the ragged kernel (4 is the default)
+        else:
+            monkeypatch.delenv("COSMO_HIP_POLAR_BATCH_OCC", raising=False)
         h = _handle_for_sets(sets, dtype)
         out, ranks, _ = h.project(s)
         ps = h.polar_stats()
