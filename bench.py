@@ -561,8 +561,8 @@ def bench_cfg5(ctx, args, steps, warmup):
         t_prod, fl = h.time_psd_product(1, 20)
         own = dk if ctx.world == 1 else None                      # rank 0's cliques only in sharded runs: useful flops not attributed there
         useful_prod = float(np.sum(dk * dk * (dk + 1.0))) if own is not None else None
-        out["roofline"] = dict(bound="mfma", kernel="k_symm_gemm_batch_r<EPI> (ragged block-balanced tiles: one workgroup per list of <= 16 blocks of 16 x 16 of one of rank 0's "
-                                                    "cliques; upper blocks only on the diagonal)",
+        out["roofline"] = dict(bound="mfma", kernel="k_symm_gemm_batch_r<EPI, 4> (ragged block-balanced tiles: one workgroup per list of <= 16 blocks of 16 x 16 of one of rank 0's "
+                                                    "cliques; upper blocks only on the diagonal; four workgroups per CU, tiles launched by decreasing cost)",
                                useful_flops_per_launch=useful_prod, performed_over_useful=(round(fl / useful_prod, 3) if useful_prod else None),
                                useful_frac_per_product=(round(useful_prod / t_prod / 1e12 / F64_MFMA_PEAK_TF, 4) if useful_prod else None),
                                achieved=round(fl / t_prod / 1e12, 2), peak=F64_MFMA_PEAK_TF, unit="TFLOP/s", frac=round(fl / t_prod / 1e12 / F64_MFMA_PEAK_TF, 4), traffic=None,

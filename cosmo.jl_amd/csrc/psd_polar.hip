@@ -405,22 +405,38 @@ __device__ __forceinline__ void symm_store_from_lds(const real* __restrict__ Cin
         cin[k] = (diag && i > j) ? R(0.0) : Cin[(long long)(j0 + j) * ld + i0 + i];
       }
     }
+    // the chunk's LDS values are read together and the stores are predicated (a read -> wait -> store round trip per element otherwise)
+    real v[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int e = threadIdx.x + 256 * SK * (c * CH + k);
+      v[k] = Cs[(e / TS) * CPITCH + (e % TS)];
+    }
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
       const int e = threadIdx.x + 256 * SK * (c * CH + k);
       const int i = e % TS, j = e / TS;
-      if (diag && i > j) continue;
-      real v = Cs[j * CPITCH + i];
-      if (EPI == 1) { v = alpha * v + beta * cin[k]; Cs[j * CPITCH + i] = v; }
-      C[(long long)(j0 + j) * ld + i0 + i] = v;
+      const bool ok = !(diag && i > j);
+      if (EPI == 1) { v[k] = alpha * v[k] + beta * cin[k]; if (ok) Cs[j * CPITCH + i] = v[k]; }
+      if (ok) C[(long long)(j0 + j) * ld + i0 + i] = v[k];
     }
   }
   __syncthreads();
   // mirrored orientation: column i0 + i, rows j0 .. j0 + TS - 1 contiguous
-  for (int e = threadIdx.x; e < TS * TS; e += 256 * SK) {
-    const int j = e % TS, i = e / TS;
-    if (diag && i >= j) continue;
-    C[(long long)(i0 + i) * ld + j0 + j] = Cs[j * CPITCH + i];
+#pragma unroll 1
+  for (int c = 0; c < NE / CH; ++c) {
+    real v[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int e = threadIdx.x + 256 * SK * (c * CH + k);
+      v[k] = Cs[(e % TS) * CPITCH + (e / TS)];
+    }
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int e = threadIdx.x + 256 * SK * (c * CH + k);
+      const int j = e % TS, i = e / TS;
+      if (!(diag && i >= j)) C[(long long)(i0 + i) * ld + j0 + j] = v[k];
+    }
   }
 }
 
@@ -1407,6 +1423,22 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
             load[x] += (long long)slots * nb16;
             q->batch_flops_performed += 2.0 * 256.0 * nblk * 16.0 * nb16;
           }
+      }
+      // Launch order inside an XCD's list = decreasing modelled cost of a tile (k-panels x slots of its fullest wave, in units of a tenth
+      // of a slot, + a fixed part for prologue and epilogue): the hardware hands the next workgroup to the first free slot, i.e. it runs
+      // longest-processing-time-first list scheduling if the list is sorted -- with ~1.5 tiles per slot the order of the cones (by leading
+      // dimension only) left expensive tiles for the tail.  35.8 -> 32.0 us per product on BASELINE config 5 (COSMO_HIP_POLAR_BATCH_SORT=0
+      // keeps the cone order; three alternating pairs of runs, profiles/r03_cfg5_ragged.txt).  A cone's tiles of one shape stay adjacent
+      // (stable sort), so they still meet in the XCD's L2.
+      int sort_tiles = 1;
+      if (const char* e = getenv("COSMO_HIP_POLAR_BATCH_SORT")) sort_tiles = atoi(e) ? 1 : 0;
+      if (sort_tiles) {
+        auto cost = [](const RTile& t) {
+          const int ei = t.ext & 255, ej = (t.ext >> 8) & 255, dg = (t.ext >> 16) & 1;
+          const int nblk = dg ? ei * (ei + 1) / 2 : ei * ej, slots = (nblk + 3) / 4;
+          return (long long)((t.d + 15) / 16) * (10 * slots + 2) + 125;
+        };
+        for (int x = 0; x < 8; ++x) std::stable_sort(xl[x].begin(), xl[x].end(), [&](const RTile& a, const RTile& b) { return cost(a) > cost(b); });
       }
       size_t maxlen = 0;
       for (int x = 0; x < 8; ++x) maxlen = std::max(maxlen, xl[x].size());
