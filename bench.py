@@ -568,6 +568,10 @@ def bench_cfg5(ctx, args, steps, warmup):
                                achieved=round(fl / t_prod / 1e12, 2), peak=F64_MFMA_PEAK_TF, unit="TFLOP/s", frac=round(fl / t_prod / 1e12 / F64_MFMA_PEAK_TF, 4), traffic=None,
                                peak_sustained_measured=F64_MFMA_SUSTAINED_TF, frac_of_sustained=round(fl / t_prod / 1e12 / F64_MFMA_SUSTAINED_TF, 4),
                                flops_per_launch=fl, avg_launch_us=round(1e6 * t_prod, 2), launches_timed=20, products_per_projection=ps["products_last_batch"],
+                               # the other roof of the same launch: Y = U^2 reads U once and writes Y once (8 B x sum d^2 each; operands that are distinct
+                               # matrices and the Cin of the alpha A B + beta Cin products add 8 B x sum d^2 apiece)
+                               hbm_algorithmic_bytes_per_launch=(16.0 * float(np.sum(dk * dk)) if own is not None else None),
+                               hbm_frac_algorithmic=(round(16.0 * float(np.sum(dk * dk)) / t_prod / 1e9 / HBM_PEAK_GBS, 4) if own is not None else None),
                                useful_tflops_reference_algorithm=round(useful * value / 1e12, 3), useful_frac_of_peak=round(useful * value / 1e12 / F64_MFMA_PEAK_TF, 5))
     if not args.no_cpu_baseline and ctx.world == 1:
         args.deferred.append(lambda out=out, prob=prob: out.__setitem__("cpu_baseline", compiled_cpu_baseline(prob, 2 if not args.small else 10, "cfg5", "cfg5", args,
