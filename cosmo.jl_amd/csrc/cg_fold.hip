@@ -123,6 +123,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_cg_dirM(Ctl* __restrict__ ctl, int
   if (ctl->cg_done) return;
   __shared__ real lds[COSMO_NNZ_PER_BLOCK];
   __shared__ real red[COSMO_BS / 64];
+  if (k < 0) k = ctl->cg_k;                      // device-side index (captured chain, k >= 1): written by the k_cg_upd in front, by nobody during this kernel
   const real tol = ctl->tol;
   const real prev = (k == 0) ? 1.0 : ctl->resv[(k - 1) & 1];
   const real rr = block_sum(pa, red);
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_cg_dirM(Ctl* __restrict__ ctl, int
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (done) ctl->cg_done = 1;
     ctl->resv[k & 1] = res;
+    ctl->cg_kd = k;
   }
   if (done) return;
   const real beta = (res * res) / (prev * prev);
@@ -187,6 +189,7 @@ void fold_free(cosmo_hip_handle* h) {
   if (f->tptr) (void)hipFree(f->tptr);
   if (f->trow) (void)hipFree(f->trow);
   if (f->tprod) (void)hipFree(f->tprod);
+  if (f->chain) (void)hipGraphExecDestroy((hipGraphExec_t)f->chain);
   delete f;
   h->fold = nullptr;
 }
@@ -297,28 +300,65 @@ int32_t fold_enqueue_start(cosmo_hip_handle* h, int guard, real tol_k) {
   return COSMO_HIP_OK;
 }
 
-int32_t fold_enqueue_iterations(cosmo_hip_handle* h, int guard, int k_begin, int count) {
-  FoldPlan* f = (FoldPlan*)h->fold;
+static void fold_launch_pair(cosmo_hip_handle* h, FoldPlan* f, int guard, int k, int n_rr) {
   const long long n = h->n;
-  const int gE = ew_grid(n);
-  for (int k = k_begin; k < k_begin + count; ++k) {
-    prof_begin(h, KC_OP_APPLY);
-    const int n_rr = (k == 0) ? f->M.grid : gE;
+  prof_begin(h, KC_OP_APPLY);
 #define LAUNCH_DIRM(SLN) hipLaunchKernelGGL((k_cg_dirM<SLN>), dim3(f->M.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, k, n, n, \
                          PARTS(h, SLOT_RR), n_rr, view_of(f->M), (const real2*)h->cg_ru, h->c, h->u, PARTS(h, SLOT_UC))
-    switch (f->slots) {
-      case 1: LAUNCH_DIRM(1); break;
-      case 2: LAUNCH_DIRM(2); break;
-      case 4: LAUNCH_DIRM(4); break;
-      default: LAUNCH_DIRM(8); break;
-    }
+  switch (f->slots) {
+    case 1: LAUNCH_DIRM(1); break;
+    case 2: LAUNCH_DIRM(2); break;
+    case 4: LAUNCH_DIRM(4); break;
+    default: LAUNCH_DIRM(8); break;
+  }
 #undef LAUNCH_DIRM
-    prof_end(h);
-    CHK(launch_cg_upd(h, guard, k, f->M.grid));
+  prof_end(h);
+  (void)launch_cg_upd(h, guard, k, f->M.grid);
+}
+
+// The speculative Krylov iterations of a solve in the loop (k = 1 .. budget - 1, all with the same arguments once the iteration index is
+// read on the device) are launched as a CAPTURED CHAIN of `chain_len` iterations: a direct launch costs the host 3.4-3.8 us, a kernel of a
+// captured chain 0.03-0.3 us (profiles/r03_launch_cost_direct_vs_graph.txt), and BASELINE config 5 issues ~ 400 such launches per ADMM
+// iteration -- the kernel timeline showed the launching thread falling behind inside the Krylov loop (12 % idle) and a loaded host cost
+// 13 % of the throughput.  Index protocol: k_cg_dirM reads ctl->cg_k (written by the k_cg_upd in front of it) and publishes it as
+// ctl->cg_kd for the k_cg_upd behind it, which writes cg_k = k + 1; the final check reads cg_k.  Arithmetic and launch order are those of
+// the direct path (COSMO_HIP_CG_GRAPH=0; tests/test_gpu_kkt.py compares the two bit for bit), and so is the number of iterations enqueued:
+// whole chains first, the remainder of the budget directly with the index as a kernel argument.
+static bool fold_chain_ready(cosmo_hip_handle* h, FoldPlan* f) {
+  if (f->chain_off || h->profiling) return false;
+  if (f->chain) return true;
+  if (const char* e = getenv("COSMO_HIP_CG_GRAPH")) { if (atoi(e) == 0) { f->chain_off = 1; return false; } }
+  int len = 16;
+  if (const char* e = getenv("COSMO_HIP_CG_GRAPH_LEN")) { const int v = atoi(e); if (v >= 1 && v <= 256) len = v; }
+  hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+  if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); f->chain_off = 1; return false; }
+  const int gE = ew_grid(h->n);
+  for (int i = 0; i < len; ++i) fold_launch_pair(h, f, 1, -1, gE);
+  if (hipStreamEndCapture(h->stream, &g) != hipSuccess || !g) { (void)hipGetLastError(); f->chain_off = 1; return false; }
+  if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipGraphDestroy(g); f->chain_off = 1; return false; }
+  (void)hipGraphDestroy(g);
+  f->chain = ge; f->chain_len = len;
+  return true;
+}
+
+int32_t fold_enqueue_iterations(cosmo_hip_handle* h, int guard, int k_begin, int count) {
+  FoldPlan* f = (FoldPlan*)h->fold;
+  const int gE = ew_grid(h->n);
+  int k = k_begin;
+  const int k_end = k_begin + count;
+  if (guard == 1 && k_begin == 0 && count > 1 && fold_chain_ready(h, f)) {
+    fold_launch_pair(h, f, guard, 0, f->M.grid);                 // k = 0 reads the partials of k_fold_start: its own launch
+    h->spmv_calls[0] += 1; h->spmv_calls[1] += 1; h->spmv_calls[2] += 1;
+    for (k = 1; k + f->chain_len <= k_end; k += f->chain_len) {  // whole chains; the remainder (< chain_len iterations) goes out directly below
+      HIPCHK(h, hipGraphLaunch((hipGraphExec_t)f->chain, h->stream));
+      h->spmv_calls[0] += f->chain_len; h->spmv_calls[1] += f->chain_len; h->spmv_calls[2] += f->chain_len;
+    }
+  }
+  for (; k < k_end; ++k) {
+    fold_launch_pair(h, f, guard, k, (k == 0) ? f->M.grid : gE);
     h->spmv_calls[0] += 1; h->spmv_calls[1] += 1; h->spmv_calls[2] += 1;
   }
-  const int kk = k_begin + count;
-  CHK(launch_cg_dir_check(h, guard, kk, (kk == 0) ? f->M.grid : gE));
+  CHK(launch_cg_dir_check(h, guard, k_end, (k_end == 0) ? f->M.grid : gE));
   HIPCHK(h, hipGetLastError());
   return COSMO_HIP_OK;
 }

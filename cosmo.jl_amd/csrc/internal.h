@@ -54,7 +54,7 @@ struct Ctl {
   int cg_k_max;      // max over solves since the host last reset it (drives the launch budget)
   int rho_changed;   // set by the adaptation kernel, consumed by the rho-apply kernel
   int n_rho_updates; // length(ws.rho_updates)
-  int pad0;
+  int cg_kd;         // iteration index of the k_cg_dirM in flight, published for the k_cg_upd behind it (device-side index of the captured chain)
   long long iter;    // ADMM iterations completed
   long long solves;  // KKT solves completed (iteration_counter - 1)
   long long kkt_iters_total;
@@ -94,6 +94,10 @@ struct FoldPlan {
   int* trow = nullptr;      // term -> row of Am
   real* tprod = nullptr;  // term -> a_ki * a_kj
   long long nterms = 0;
+  // captured chain of speculative Krylov iterations (cg_fold.hip: fold_enqueue_iterations)
+  void* chain = nullptr;    // hipGraphExec_t
+  int chain_len = 0;        // Krylov iterations per launch of the chain
+  int chain_off = 0;        // COSMO_HIP_CG_GRAPH=0
 };
 
 struct HostCsr {  // host staging of a CSR matrix (0-based)

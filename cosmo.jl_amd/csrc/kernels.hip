@@ -241,11 +241,12 @@ __global__ __launch_bounds__(COSMO_BS) void k_cg_dir(Ctl* __restrict__ ctl, int 
   // partial reduction (the grid covers n with one element per thread; the strided loop only handles huge n)
   const long long i0 = (long long)blockIdx.x * COSMO_BS + threadIdx.x;
   real r0 = 0.0, u0 = 0.0;
-  if (!check_only && i0 < n) { r0 = r[i0]; if (k > 0) u0 = u[i0]; }
+  if (!check_only && i0 < n) { r0 = r[i0]; if (k != 0) u0 = u[i0]; }
   const real pa = partials_prefetch_sum(part_rr, n_rr);      // in flight while the guards wait on their scalar loads
   if (guard && ctl->halt) return;
   if (ctl->cg_done) return;
   __shared__ real red[COSMO_BS / 64];
+  if (k < 0) k = ctl->cg_k;                      // device-side index (the check behind a captured chain, cg_fold.hip): nobody writes cg_k during this kernel
   const real tol = ctl->tol;
   const real prev = (k == 0) ? 1.0 : ctl->resv[(k - 1) & 1];
   const real rr = block_sum(pa, red);
@@ -358,6 +359,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_cg_upd(Ctl* __restrict__ ctl, int 
   if (guard && ctl->halt) return;
   if (ctl->cg_done) return;
   __shared__ real red[COSMO_BS / 64];
+  if (k < 0) k = ctl->cg_kd;                     // device-side index: published by the k_cg_dirM in front (cg_k itself is rewritten below by workgroup 0)
   const real res = ctl->resv[k & 1];
   const real uc = block_sum(pa, red);
   const real alpha = (res * res) / uc;

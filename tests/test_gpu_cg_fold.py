@@ -135,3 +135,30 @@ def test_fold_follows_update_rho_through_the_plugin_entry_point(monkeypatch):
     sol, its = h.kkt_solve(rhs)
     ref = np.linalg.solve(K, rhs)
     assert its > 0 and np.linalg.norm(sol - ref) <= 1e-7 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("chain_len", ["16", "3", "1"])
+@pytest.mark.parametrize("name", sorted(PROBLEMS))
+def test_captured_chain_of_krylov_iterations_is_bit_identical_to_direct_launches(name, chain_len, monkeypatch):
+    """The speculative Krylov iterations of a solve go out as a captured chain (hipGraph) with the iteration index read on the device
+    (csrc/cg_fold.hip: fold_enqueue_iterations); COSMO_HIP_CG_GRAPH=0 launches every kernel directly with the index as an argument.
+    Same kernels, same order, same number of enqueued iterations: iterates, Krylov counts, rho updates and stall counts are identical --
+    default schedule (loose tolerance, rho adaptation every 40 iterations) and tight mode, chains of 16 (default), 3 and 1 iterations."""
+    prob = PROBLEMS[name]()
+    monkeypatch.setenv("COSMO_HIP_OP_FOLD", "1")
+    for kw in (dict(), TIGHT):
+        res = {}
+        for graph in ("0", "1"):
+            monkeypatch.setenv("COSMO_HIP_CG_GRAPH", graph)
+            monkeypatch.setenv("COSMO_HIP_CG_GRAPH_LEN", chain_len)
+            st = cj.Settings(max_iter=90, eps_abs=0.0, eps_rel=0.0, check_infeasibility=10 ** 9, **kw)
+            md = cj.Model(); md.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)
+            r = cj.optimize(md)
+            assert md.handle.fold_stats()["enabled"] == 1
+            res[graph] = (r, md.handle.get_stats())
+        (r0, s0), (r1, s1) = res["0"], res["1"]
+        assert r0.iter == r1.iter == 90
+        assert np.array_equal(r0.x, r1.x) and np.array_equal(r0.s, r1.s) and np.array_equal(r0.y, r1.y)
+        assert s0["kkt_iters_total"] == s1["kkt_iters_total"] > 0 and s0["kkt_budget_stalls"] == s1["kkt_budget_stalls"]
+        assert s0["spmv_A"] == s1["spmv_A"]                                   # the same number of iterations was enqueued
+        assert list(r0.info.rho_updates) == list(r1.info.rho_updates)
