@@ -1,5 +1,5 @@
 // Lab: host cost and device pace of N small dependent kernel launches, direct vs one hipGraph launch of the captured chain.
-// build: hipcc --offload-arch=gfx950 -O2 tools/graph_launch_lab.hip -o bench/_lab/graph_launch_lab ; run on the GPU box.
+// build: hipcc --offload-arch=gfx950 -O2 bench/launch_cost_lab.hip -o bench/_lab/launch_cost_lab ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
