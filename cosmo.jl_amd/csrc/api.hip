@@ -267,6 +267,8 @@ extern "C" int32_t cosmo_hip_destroy(cosmo_hip_handle* h) {
   if (h->ctl) { (void)hipFree(h->ctl); h->ctl = nullptr; }
   if (h->ctl_host) { (void)hipHostFree(h->ctl_host); h->ctl_host = nullptr; }
   for (auto& e : h->ev_pool) (void)hipEventDestroy(e);
+  for (auto& e : h->fb_ev) if (e) (void)hipEventDestroy(e);
+  if (h->fb_k) (void)hipHostFree(h->fb_k);
   h->ev_pool.clear();
   if (h->ev_proj0) (void)hipEventDestroy(h->ev_proj0);
   if (h->ev_proj1) (void)hipEventDestroy(h->ev_proj1);
@@ -599,6 +601,7 @@ extern "C" int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_par
 
 extern "C" int32_t cosmo_hip_update_rho(cosmo_hip_handle* h, const real* rho_vec) {
   ENTER(h);
+  h->fb_from = h->fb_recorded;               // (Krylov budget feedback: a new rho is a new regime)
   if (h->row_shard) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "update_rho: not available on a row-sharded handle");
   if (!h->have_params || !rho_vec) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "update_rho: not set up");
   CHK(h2d(h, h->rho, rho_vec, (size_t)h->m));
@@ -823,6 +826,54 @@ extern "C" int32_t cosmo_hip_set_iterates(cosmo_hip_handle* h, const real* x0, c
   CHK(h2d(h, h->ctl, h->ctl_host, 1));
   h->host_iter = 0;
   h->have_iterates = true;
+  h->fb_from = h->fb_recorded;               // Krylov counts of an earlier run say nothing about this one
+  return COSMO_HIP_OK;
+}
+
+// ---- Krylov budget of a solve in the loop ---------------------------------------------------------------------------------------
+// The loop enqueues a solve's Krylov iterations speculatively; what is enqueued beyond the iterations the solve needs are launches that
+// return at once (4.6 + 1.1 us of device time per iteration all the same), and a budget that is too SMALL stalls the solve: everything
+// enqueued behind it turns into no-ops and is enqueued again after the next synchronisation.  Until round 3 the budget was the largest
+// count of the previous window + 2, fixed for a whole window: on BASELINE config 5 (bench window: iterations 11-50 in one call) the
+// count creeps from 188 to 196, the window stalled twice and 65 % of its Krylov launches were no-ops; behind the rho update of
+// iteration 40 the count drops to 115 -> 87 and the budget stayed at 200 (tools/cfg5_speculation_waste.py).
+// Now the count of every solve comes back through a pinned ring (4-byte copy + event behind k_tail), and solve s takes
+//     budget = max + 2 (max - min) + max / 50 + 2   of the counts K_{s-L-3} .. K_{s-L},      L = 4 solves of lag,
+// after WAITING for the event of solve s - L (already complete unless the host is more than L iterations ahead), so that the budget is a
+// function of the iteration history alone -- all ranks of a sharded run take the same decisions.  While the lagged solves predate a
+// regime change (start of the loop, an adaptive-rho check, a stall) the window rule applies with 6 % of headroom.  Three stalls on feedback budgets switch
+// the feedback off for the handle (COSMO_HIP_BUDGET_FEEDBACK=0 does so from the start).
+static const int FB_LAG = 4;
+static void feedback_reset(cosmo_hip_handle* h) { h->fb_from = h->fb_recorded; }
+static int solve_budget(cosmo_hip_handle* h) {
+  h->fb_last_used = false;
+  if (h->fb_mode == 1 && !h->fb_k) {
+    if (const char* e = getenv("COSMO_HIP_BUDGET_FEEDBACK")) { if (atoi(e) == 0) h->fb_mode = 0; }
+    if (h->fb_mode == 1 && hipHostMalloc((void**)&h->fb_k, sizeof(int) * cosmo_hip_handle::FB_RING) != hipSuccess) { (void)hipGetLastError(); h->fb_k = nullptr; h->fb_mode = 0; }
+  }
+  if (h->fb_mode != 1 || h->profiling || h->exact_launches) return h->budget;
+  const long long j = h->fb_recorded - FB_LAG;
+  const int wide = h->budget + h->budget / 16;        // regime change: the window rule with 6 % of headroom (a creeping count stalled it)
+  if (j < h->fb_from || j < 0) return wide > 4096 ? 4096 : wide;
+  const int R = cosmo_hip_handle::FB_RING;
+  if (hipEventSynchronize(h->fb_ev[j % R]) != hipSuccess) { (void)hipGetLastError(); return h->budget; }
+  int kmax = h->fb_k[j % R], kmin = kmax, nv = 1;
+  for (long long i = j - 1; i >= h->fb_from && i > j - 4; --i) { const int v = h->fb_k[i % R]; kmax = std::max(kmax, v); kmin = std::min(kmin, v); nv += 1; }
+  // newest counts of the regime: their maximum + twice their spread + 2 % + 2 (two or fewer counts: 15 % + 6 instead of the spread)
+  int b = (nv >= 3) ? kmax + 2 * (kmax - kmin) + kmax / 50 + 2 : kmax + (kmax * 15 + 99) / 100 + 6;
+  if (b < 3) b = 3;
+  if (b > 4096) b = 4096;
+  h->fb_last_used = true;
+  return b;
+}
+static int32_t feedback_record(cosmo_hip_handle* h) {
+  if (h->fb_mode != 1 || !h->fb_k) return COSMO_HIP_OK;
+  const int R = cosmo_hip_handle::FB_RING;
+  const int slot = (int)(h->fb_recorded % R);
+  if (!h->fb_ev[slot]) HIPCHK(h, hipEventCreateWithFlags(&h->fb_ev[slot], hipEventDisableTiming));
+  HIPCHK(h, hipMemcpyAsync(&h->fb_k[slot], &h->ctl->cg_k, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipEventRecord(h->fb_ev[slot], h->stream));
+  h->fb_recorded += 1;
   return COSMO_HIP_OK;
 }
 
@@ -840,7 +891,7 @@ static int32_t enqueue_solve_in_loop(cosmo_hip_handle* h) {
           CHK(sr_enqueue_iterations(h, 1, k, 1));
         }
       } else {
-        CHK(sr_enqueue_iterations(h, 1, 0, h->budget));
+        CHK(sr_enqueue_iterations(h, 1, 0, solve_budget(h)));
       }
     } else if (h->pcg_on) {
       CHK(pcg_enqueue_solve(h, 1));        // the whole Krylov loop in one launch (cg_persist.hip)
@@ -853,9 +904,10 @@ static int32_t enqueue_solve_in_loop(cosmo_hip_handle* h) {
         CHK(enqueue_cg_iterations(h, 1, k, 1));
       }
     } else {
-      CHK(enqueue_cg_iterations(h, 1, 0, h->budget));
+      CHK(enqueue_cg_iterations(h, 1, 0, solve_budget(h)));
     }
     CHK(enqueue_tail(h, 1));
+    CHK(feedback_record(h));
   } else {
     CHK(minres_enqueue_solve(h, 1, true));
   }
@@ -886,8 +938,10 @@ static int32_t enqueue_iteration(cosmo_hip_handle* h, long long it) {
   CHK(psd_enqueue_project(h, h->s, true));
   CHK(custom_enqueue_project(h, h->s, 1));
   CHK(comm_enqueue_exchange(h, h->s));      // clique sharding: the one exchange step of the iteration
-  if (h->prm.adaptive_rho && h->prm.adaptive_rho_interval > 0 && (it % h->prm.adaptive_rho_interval) == 0)
+  if (h->prm.adaptive_rho && h->prm.adaptive_rho_interval > 0 && (it % h->prm.adaptive_rho_interval) == 0) {
     CHK(enqueue_check(h, 1, 2));
+    feedback_reset(h);                       // rho may change here (decided on the device): earlier Krylov counts say nothing about this solve
+  }
   CHK(enqueue_solve_in_loop(h));
   h->host_iter = it;
   return COSMO_HIP_OK;
@@ -897,6 +951,8 @@ static int32_t enqueue_iteration(cosmo_hip_handle* h, long long it) {
 static int32_t resolve_stall(cosmo_hip_handle* h) {
   while (h->ctl_host->stalled) {
     h->stalls += 1;
+    if (h->fb_mode == 1 && h->fb_recorded - h->fb_from > FB_LAG) { h->fb_stalls += 1; if (h->fb_stalls >= 3) h->fb_mode = 0; }   // a feedback budget was in use
+    feedback_reset(h);
     if (h->pcg_on) { h->pcg_on = false; h->pcg_fallbacks += 1; }     // only a failed start-up rendezvous stalls the persistent kernel
     int extra = std::max(2 * h->budget, 8);
     if (h->prm.kkt_kind == COSMO_HIP_KKT_CG) {

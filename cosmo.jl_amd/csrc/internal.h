@@ -218,6 +218,15 @@ struct cosmo_hip_handle {
   long long host_solves = 0;      // KKT solves enqueued
   int budget = 12;                // Krylov iterations enqueued per solve
   long long stalls = 0;
+  // Krylov budget feedback (api.hip: solve_budget): Krylov count of every solve of the loop, copied back asynchronously
+  static const int FB_RING = 64;
+  int* fb_k = nullptr;                 // pinned ring, entry s % FB_RING = cg_k of loop solve s
+  hipEvent_t fb_ev[FB_RING] = {};      // recorded behind the copy of solve s
+  long long fb_recorded = 0;           // loop solves recorded so far
+  long long fb_from = 0;               // first solve whose count describes the CURRENT regime (start, rho change or stall)
+  int fb_mode = 1;                     // COSMO_HIP_BUDGET_FEEDBACK=0: window maximum + 2 only
+  long long fb_stalls = 0;             // stalls of solves that ran on a feedback budget (three of them switch it off)
+  bool fb_last_used = false;
   long long spmv_calls[3] = {0, 0, 0};
   // profiling
   bool profiling = false;      // HIP events around every loop kernel

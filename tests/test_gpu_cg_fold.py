@@ -162,3 +162,34 @@ def test_captured_chain_of_krylov_iterations_is_bit_identical_to_direct_launches
         assert s0["kkt_iters_total"] == s1["kkt_iters_total"] > 0 and s0["kkt_budget_stalls"] == s1["kkt_budget_stalls"]
         assert s0["spmv_A"] == s1["spmv_A"]                                   # the same number of iterations was enqueued
         assert list(r0.info.rho_updates) == list(r1.info.rho_updates)
+
+
+@pytest.mark.parametrize("name", sorted(PROBLEMS))
+def test_krylov_budget_feedback_changes_the_number_of_launches_not_the_results(name, monkeypatch):
+    """The loop enqueues a solve's Krylov iterations speculatively.  With the budget feedback (csrc/api.hip: solve_budget -- the count of
+    every solve comes back through a pinned ring, the budget follows the counts of four solves ago) one long call enqueues far fewer no-op
+    iterations than with the budget fixed per call (COSMO_HIP_BUDGET_FEEDBACK=0) and does not stall; iterates, Krylov counts and rho
+    updates are the same bits either way, stalled or not."""
+    prob = PROBLEMS[name]()
+    res = {}
+    for fb in ("0", "1"):
+        monkeypatch.setenv("COSMO_HIP_BUDGET_FEEDBACK", fb)
+        st = cj.Settings(max_iter=10 ** 6, eps_abs=0.0, eps_rel=0.0, check_infeasibility=10 ** 9, check_termination=10 ** 9)
+        md = cj.Model(); md.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)
+        cj.model.setup(md)
+        h = md.handle
+        h.set_iterates(md.x, md.s, md.mu); h.admm_init()
+        h.admm_iterate_checked(5)
+        s0 = h.get_stats()
+        h.admm_iterate_checked(100)                                           # ONE call: rho checks at 40 and 80 inside it
+        s1 = h.get_stats()
+        w, _, s, mu = h.get_iterates()
+        res[fb] = (w, s, mu, s1["kkt_iters_total"] - s0["kkt_iters_total"], s1["spmv_A"] - s0["spmv_A"], s1["kkt_budget_stalls"] - s0["kkt_budget_stalls"],
+                   s1["rho_updates"])
+        h.close()
+    a, b = res["0"], res["1"]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert a[3] == b[3] > 0 and a[6] == b[6]                                    # Krylov iterations performed, rho updates
+    assert b[5] == 0                                                            # no stall with the feedback
+    assert b[4] <= 1.5 * b[3] + 100 * 8                                         # enqueued <= 1.5 x performed + a few per solve
+    assert b[4] <= a[4]                                                         # and never more launches than the fixed budget
