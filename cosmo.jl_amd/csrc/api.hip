@@ -838,12 +838,12 @@ extern "C" int32_t cosmo_hip_set_iterates(cosmo_hip_handle* h, const real* x0, c
 // count creeps from 188 to 196, the window stalled twice and 65 % of its Krylov launches were no-ops; behind the rho update of
 // iteration 40 the count drops to 115 -> 87 and the budget stayed at 200 (tools/cfg5_speculation_waste.py).
 // Now the count of every solve comes back through a pinned ring (4-byte copy + event behind k_tail), and solve s takes
-//     budget = max + 2 (max - min) + max / 50 + 2   of the counts K_{s-L-3} .. K_{s-L},      L = 4 solves of lag,
+//     budget = max + 2 (max - min) + max / 50 + 2   of the counts K_{s-L-3} .. K_{s-L},      L = 2 solves of lag,
 // after WAITING for the event of solve s - L (already complete unless the host is more than L iterations ahead), so that the budget is a
 // function of the iteration history alone -- all ranks of a sharded run take the same decisions.  While the lagged solves predate a
 // regime change (start of the loop, an adaptive-rho check, a stall) the window rule applies with 6 % of headroom.  Three stalls on feedback budgets switch
 // the feedback off for the handle (COSMO_HIP_BUDGET_FEEDBACK=0 does so from the start).
-static const int FB_LAG = 4;
+static const int FB_LAG = 2;
 static void feedback_reset(cosmo_hip_handle* h) { h->fb_from = h->fb_recorded; }
 static int solve_budget(cosmo_hip_handle* h) {
   h->fb_last_used = false;

@@ -856,7 +856,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
           for (int q = 0; q < 4; ++q) {
             const int i = oa[sl] + ACC_ROW(lane, q);
             const bool ok = !(dblk && i > j);
-            c[q] = Cin[ok ? (long long)(j0 + j) * ld + i0 + i : 0];
+            // Cin is exactly symmetric (every iterate is written mirrored from one value): read element (i, j) at its MIRRORED address, where the
+            // 16 lanes of a row group are 128 contiguous bytes (the natural address gives 32-byte pieces)
+            c[q] = Cin[ok ? (long long)(i0 + i) * ld + j0 + j : 0];
             if (!ok) c[q] = R(0.0);
           }
 #pragma unroll
