@@ -836,7 +836,7 @@ extern "C" int32_t cosmo_hip_set_iterates(cosmo_hip_handle* h, const real* x0, c
 // enqueued behind it turns into no-ops and is enqueued again after the next synchronisation.  Until round 3 the budget was the largest
 // count of the previous window + 2, fixed for a whole window: on BASELINE config 5 (bench window: iterations 11-50 in one call) the
 // count creeps from 188 to 196, the window stalled twice and 65 % of its Krylov launches were no-ops; behind the rho update of
-// iteration 40 the count drops to 115 -> 87 and the budget stayed at 200 (tools/cfg5_speculation_waste.py).
+// iteration 40 the count drops to 115 -> 87 and the budget stayed at 200 (tools/speculation_waste.py).
 // Now the count of every solve comes back through a pinned ring (4-byte copy + event behind k_tail), and solve s takes
 //     budget = max + 2 (max - min) + max / 50 + 2   of the counts K_{s-L-3} .. K_{s-L},      L = 2 solves of lag,
 // after WAITING for the event of solve s - L (already complete unless the host is more than L iterations ahead), so that the budget is a

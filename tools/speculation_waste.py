@@ -1,9 +1,11 @@
-"""How many of the speculatively enqueued Krylov iterations of BASELINE config 5 are no-ops behind a converged solve: enqueued iterations
-(host counter of k_cg_dirM launches) against performed ones (device counter) over the bench window (iterations 11-50)."""
+"""How many of the speculatively enqueued Krylov iterations of a BASELINE configuration (default cfg5; argument cfg2 | cfg4) are no-ops behind
+a converged solve: enqueued iterations (host counter of the product launches) against performed ones (device counter), windows of 40 iterations
+after 10 (cfg5's bench window is iterations 11-50)."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import cosmo_jl_amd as cj
-p = cj.problems.chordal_sdp()
+which = sys.argv[1] if len(sys.argv) > 1 else "cfg5"
+p = {"cfg5": cj.problems.chordal_sdp, "cfg2": cj.problems.sparse_box_qp, "cfg4": cj.problems.closest_correlation}[which]()
 st = cj.Settings(kkt_solver=cj.CGIndirectKKTSolver, max_iter=10 ** 6, eps_abs=0.0, eps_rel=0.0, check_infeasibility=10 ** 9, check_termination=10 ** 9)
 md = cj.Model(); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], st)
 cj.model.setup(md)
