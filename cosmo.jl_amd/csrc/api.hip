@@ -838,7 +838,7 @@ extern "C" int32_t cosmo_hip_set_iterates(cosmo_hip_handle* h, const real* x0, c
 // count creeps from 188 to 196, the window stalled twice and 65 % of its Krylov launches were no-ops; behind the rho update of
 // iteration 40 the count drops to 115 -> 87 and the budget stayed at 200 (tools/speculation_waste.py).
 // Now the count of every solve comes back through a pinned ring (4-byte copy + event behind k_tail), and solve s takes
-//     budget = max + 2 (max - min) + max / 50 + 2   of the counts K_{s-L-3} .. K_{s-L},      L = 2 solves of lag,
+//     budget = max + (max - min) / 2 + max / 40 + 3   of the counts K_{s-L-3} .. K_{s-L},      L = 2 solves of lag,
 // after WAITING for the event of solve s - L (already complete unless the host is more than L iterations ahead), so that the budget is a
 // function of the iteration history alone -- all ranks of a sharded run take the same decisions.  While the lagged solves predate a
 // regime change (start of the loop, an adaptive-rho check, a stall) the window rule applies with 6 % of headroom.  Three stalls on feedback budgets switch
@@ -859,8 +859,9 @@ static int solve_budget(cosmo_hip_handle* h) {
   if (hipEventSynchronize(h->fb_ev[j % R]) != hipSuccess) { (void)hipGetLastError(); return h->budget; }
   int kmax = h->fb_k[j % R], kmin = kmax, nv = 1;
   for (long long i = j - 1; i >= h->fb_from && i > j - 4; --i) { const int v = h->fb_k[i % R]; kmax = std::max(kmax, v); kmin = std::min(kmin, v); nv += 1; }
-  // newest counts of the regime: their maximum + twice their spread + 2 % + 2 (two or fewer counts: 15 % + 6 instead of the spread)
-  int b = (nv >= 3) ? kmax + 2 * (kmax - kmin) + kmax / 50 + 2 : kmax + (kmax * 15 + 99) / 100 + 6;
+  // newest counts of the regime: their maximum + half their spread + 2.5 % + 3 (two or fewer counts: 15 % + 6 instead).  Replayed on the
+  // recorded count sequences of BASELINE configs 2 and 5 (profiles/r03_cfg5_krylov_budget.txt): no stall, 6-10 % no-op iterations
+  int b = (nv >= 3) ? kmax + (kmax - kmin) / 2 + kmax / 40 + 3 : kmax + (kmax * 15 + 99) / 100 + 6;
   if (b < 3) b = 3;
   if (b > 4096) b = 4096;
   h->fb_last_used = true;
