@@ -865,6 +865,7 @@ static int solve_budget(cosmo_hip_handle* h) {
   if (b < 3) b = 3;
   if (b > 4096) b = 4096;
   h->fb_last_used = true;
+  h->cg_k_likely = kmax + 1;                  // iterations past the largest recent count: expected no-ops (check the flags first)
   return b;
 }
 static int32_t feedback_record(cosmo_hip_handle* h) {
@@ -893,6 +894,7 @@ static int32_t enqueue_solve_in_loop(cosmo_hip_handle* h) {
         }
       } else {
         CHK(sr_enqueue_iterations(h, 1, 0, solve_budget(h)));
+        h->cg_k_likely = 0x7fffffff;
       }
     } else if (h->pcg_on) {
       CHK(pcg_enqueue_solve(h, 1));        // the whole Krylov loop in one launch (cg_persist.hip)
@@ -906,6 +908,7 @@ static int32_t enqueue_solve_in_loop(cosmo_hip_handle* h) {
       }
     } else {
       CHK(enqueue_cg_iterations(h, 1, 0, solve_budget(h)));
+      h->cg_k_likely = 0x7fffffff;
     }
     CHK(enqueue_tail(h, 1));
     CHK(feedback_record(h));

@@ -91,9 +91,10 @@ __global__ __launch_bounds__(COSMO_BS) void k_fold_start(Ctl* __restrict__ ctl, 
 // SL = nonzero slots per thread of the register-staged first tile (tiles of the assembled matrix hold at most SL * 256 nonzeros; a
 // longer single row takes the generic path).
 template <int SL>
-__global__ __launch_bounds__(COSMO_BS) void k_cg_dirM(Ctl* __restrict__ ctl, int guard, int k, long long n, long long maxiter,
+__global__ __launch_bounds__(COSMO_BS) void k_cg_dirM(Ctl* __restrict__ ctl, int guard, int check_first, int k, long long n, long long maxiter,
                                                       const real* __restrict__ part_rr, int n_rr, CsrView M, const real2* __restrict__ ru,
                                                       real* __restrict__ c, real* __restrict__ u, real* __restrict__ part_uc) {
+  if (check_first) { if (guard && ctl->halt) return; if (ctl->cg_done) return; }   // expected no-op (see k_cg_dirA): flags before any request
   const real pa = partials_prefetch_sum(part_rr, n_rr);
   const int first_tile = tile_of_block(blockIdx.x, M.nb, M.xcd_affine);
   const bool have_tile = first_tile < M.nb;
@@ -190,6 +191,7 @@ void fold_free(cosmo_hip_handle* h) {
   if (f->trow) (void)hipFree(f->trow);
   if (f->tprod) (void)hipFree(f->tprod);
   if (f->chain) (void)hipGraphExecDestroy((hipGraphExec_t)f->chain);
+  if (f->chain_cf) (void)hipGraphExecDestroy((hipGraphExec_t)f->chain_cf);
   delete f;
   h->fold = nullptr;
 }
@@ -300,10 +302,10 @@ int32_t fold_enqueue_start(cosmo_hip_handle* h, int guard, real tol_k) {
   return COSMO_HIP_OK;
 }
 
-static void fold_launch_pair(cosmo_hip_handle* h, FoldPlan* f, int guard, int k, int n_rr) {
+static void fold_launch_pair(cosmo_hip_handle* h, FoldPlan* f, int guard, int k, int n_rr, int check_first = 0) {
   const long long n = h->n;
   prof_begin(h, KC_OP_APPLY);
-#define LAUNCH_DIRM(SLN) hipLaunchKernelGGL((k_cg_dirM<SLN>), dim3(f->M.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, k, n, n, \
+#define LAUNCH_DIRM(SLN) hipLaunchKernelGGL((k_cg_dirM<SLN>), dim3(f->M.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, check_first, k, n, n, \
                          PARTS(h, SLOT_RR), n_rr, view_of(f->M), (const real2*)h->cg_ru, h->c, h->u, PARTS(h, SLOT_UC))
   switch (f->slots) {
     case 1: LAUNCH_DIRM(1); break;
@@ -330,14 +332,25 @@ static bool fold_chain_ready(cosmo_hip_handle* h, FoldPlan* f) {
   if (const char* e = getenv("COSMO_HIP_CG_GRAPH")) { if (atoi(e) == 0) { f->chain_off = 1; return false; } }
   int len = 16;
   if (const char* e = getenv("COSMO_HIP_CG_GRAPH_LEN")) { const int v = atoi(e); if (v >= 1 && v <= 256) len = v; }
-  hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
-  if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); f->chain_off = 1; return false; }
   const int gE = ew_grid(h->n);
-  for (int i = 0; i < len; ++i) fold_launch_pair(h, f, 1, -1, gE);
-  if (hipStreamEndCapture(h->stream, &g) != hipSuccess || !g) { (void)hipGetLastError(); f->chain_off = 1; return false; }
-  if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipGraphDestroy(g); f->chain_off = 1; return false; }
-  (void)hipGraphDestroy(g);
-  f->chain = ge; f->chain_len = len;
+  hipGraphExec_t ex[2] = {nullptr, nullptr};
+  for (int cf = 0; cf < 2; ++cf) {               // the chain, and the chain of iterations that are expected to be no-ops
+    hipGraph_t g = nullptr;
+    bool ok = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
+      for (int i = 0; i < len; ++i) fold_launch_pair(h, f, 1, -1, gE, cf);
+      ok = hipStreamEndCapture(h->stream, &g) == hipSuccess && g;
+    }
+    if (ok) ok = hipGraphInstantiate(&ex[cf], g, nullptr, nullptr, 0) == hipSuccess;
+    if (g) (void)hipGraphDestroy(g);
+    if (!ok) {
+      (void)hipGetLastError();
+      if (ex[0]) (void)hipGraphExecDestroy(ex[0]);
+      f->chain_off = 1;
+      return false;
+    }
+  }
+  f->chain = ex[0]; f->chain_cf = ex[1]; f->chain_len = len;
   return true;
 }
 
@@ -350,12 +363,12 @@ int32_t fold_enqueue_iterations(cosmo_hip_handle* h, int guard, int k_begin, int
     fold_launch_pair(h, f, guard, 0, f->M.grid);                 // k = 0 reads the partials of k_fold_start: its own launch
     h->spmv_calls[0] += 1; h->spmv_calls[1] += 1; h->spmv_calls[2] += 1;
     for (k = 1; k + f->chain_len <= k_end; k += f->chain_len) {  // whole chains; the remainder (< chain_len iterations) goes out directly below
-      HIPCHK(h, hipGraphLaunch((hipGraphExec_t)f->chain, h->stream));
+      HIPCHK(h, hipGraphLaunch((hipGraphExec_t)(k >= h->cg_k_likely ? f->chain_cf : f->chain), h->stream));
       h->spmv_calls[0] += f->chain_len; h->spmv_calls[1] += f->chain_len; h->spmv_calls[2] += f->chain_len;
     }
   }
   for (; k < k_end; ++k) {
-    fold_launch_pair(h, f, guard, k, (k == 0) ? f->M.grid : gE);
+    fold_launch_pair(h, f, guard, k, (k == 0) ? f->M.grid : gE, (k >= h->cg_k_likely) ? 1 : 0);
     h->spmv_calls[0] += 1; h->spmv_calls[1] += 1; h->spmv_calls[2] += 1;
   }
   CHK(launch_cg_dir_check(h, guard, k_end, (k_end == 0) ? f->M.grid : gE));

@@ -96,6 +96,7 @@ struct FoldPlan {
   long long nterms = 0;
   // captured chain of speculative Krylov iterations (cg_fold.hip: fold_enqueue_iterations)
   void* chain = nullptr;    // hipGraphExec_t
+  void* chain_cf = nullptr; // the same chain with check_first = 1 (iterations expected to be no-ops)
   int chain_len = 0;        // Krylov iterations per launch of the chain
   int chain_off = 0;        // COSMO_HIP_CG_GRAPH=0
 };
@@ -227,6 +228,7 @@ struct cosmo_hip_handle {
   int fb_mode = 1;                     // COSMO_HIP_BUDGET_FEEDBACK=0: window maximum + 2 only
   long long fb_stalls = 0;             // stalls of solves that ran on a feedback budget (three of them switch it off)
   bool fb_last_used = false;
+  int cg_k_likely = 0x7fffffff;        // Krylov iterations from this index on are expected to be no-ops (set per solve by solve_budget)
   long long spmv_calls[3] = {0, 0, 0};
   // profiling
   bool profiling = false;      // HIP events around every loop kernel
