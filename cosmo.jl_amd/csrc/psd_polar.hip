@@ -104,7 +104,7 @@ struct PolarPlan {
   int k_lift = REAL_IS_FLOAT ? 5 : 10;
   int max_rounds = 2;        // guarded fallback rounds enqueued per projection
   int rescale = 1;           // spectral rescaling in the first step of a large cone's iteration (COSMO_HIP_POLAR_RESCALE=0 disables)
-  int batch_occ = 3;         // register-allocation variant of k_symm_gemm_batch: 3 or 4 waves per SIMD (COSMO_HIP_POLAR_BATCH_OCC)
+  int batch_occ = 3;         // register-allocation variant of the batched product kernels: 3 or 4 waves per SIMD (COSMO_HIP_POLAR_BATCH_OCC; the plan sets 4 for the ragged kernel)
   real tol_factor = 8.0;   // verification threshold tol_factor * d * eps (relative to ||X||_F)
   PolarDev* dev = nullptr;
   PolarDev seen;             // host copy at the last polar_adapt
@@ -815,7 +815,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   const int xi = 16 * ei, xj = 16 * ej;      // extents in elements
   const int i0 = td.i0, j0 = td.j0;
   // Requesting Cin before the last panel's matrix instructions (pre_last = a lambda loading it) was built and measured on BASELINE config 5: 188.1 vs
-  // 188.3 it/s -- with three workgroups per CU the epilogue's round trip is already covered by the other workgroups' main loops.
+  // 188.3 it/s (three workgroups per CU, LDS epilogue), and again with the epilogue below and four workgroups per CU: 40.4 us per EPI = 1
+  // product either way, 16 spilled VGPRs -- the round trip is covered by the other workgroups' main loops.
   auto pre_last = [&]() {};
 #ifndef POLAR_LAB_NO_MAINLOOP               // lab builds (tools/build_lab_variants.sh): epilogue only / main loop only
   switch (nsl) {                             // wave-uniform; a wave without a block still takes part in the panel loads and barriers
