@@ -639,6 +639,39 @@ def main():
     head = "cfg2" if workload == "all" else workload
     res = BENCH[head](ctx, args, args.steps, args.warmup)
     extra = {}
+
+    def headline_line():
+        out = {"metric": METRIC, "value": round(res["value"], 3), "unit": "ADMM iterations/s", "n_gpus": ctx.world, "steps": res["steps"], "warmup": res["warmup"],
+               "ms_per_step": round(res["ms_per_step"], 6), "higher_is_better": True, "scaling": res["scaling"], "vs_baseline": None, "dtype": "f64",
+               "data": "synthetic", "config": res.get("config", {}), "roofline": res.get("roofline")}
+        out["config"]["kkt_solver"] = ("CG, literal cg! recurrence (reference algorithm)" if args.kkt == "cg" else
+                                       "CG, single-reduction (Chronopoulos-Gear) recurrence -- OPT-IN variant, same operator / stopping rule")
+        out["config"]["launch"] = ("self-launched torch.distributed.run" if os.environ.get("COSMO_BENCH_SELF_LAUNCHED") else
+                                   "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "single process")
+        if ctx.shm:
+            out["data"] = "synthetic; DRY RUN of the multi-rank path: all ranks share one GPU (COSMO_BENCH_TRANSPORT=shm), not a measurement"
+        if "cpu_baseline" in res:
+            out["cpu_baseline"] = res["cpu_baseline"]
+        if extra:
+            out["extra"] = dict(extra)
+        return out
+
+    # N > 1: the sharded extras are the only part of this program with data-path collectives.  If one of them hangs (a rank that failed while
+    # the others wait in a collective), the headline -- measured already -- must still be reported: a watchdog prints the line with what has
+    # been collected and ends every rank.  COSMO_BENCH_EXTRA_TIMEOUT seconds for all extras together (default 600).
+    watchdog = None
+    if ctx.world > 1 and workload == "all" and not args.no_extra:
+        import threading
+
+        def expire():
+            for name in ("cfg5", "cfg3"):
+                extra.setdefault(name + "_sharded", {"error": "not finished within COSMO_BENCH_EXTRA_TIMEOUT; the headline above was measured before"})
+            if ctx.rank == 0:
+                print(json.dumps(headline_line()), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(float(os.environ.get("COSMO_BENCH_EXTRA_TIMEOUT", "600")), expire)
+        watchdog.daemon = True
+        watchdog.start()
     if workload == "all" and not args.no_extra:
         # N = 1: the other three BASELINE configurations on the one GPU.  N > 1: the two configurations that shard, strong scaling.
         names = ("cfg3", "cfg4", "cfg5") if ctx.world == 1 else ("cfg5", "cfg3")
@@ -652,23 +685,13 @@ def main():
                 extra[key] = r
             except Exception as e:                                  # an extra workload must not take the headline line down
                 extra[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if watchdog is not None:
+        watchdog.cancel()
     for leg in args.deferred:     # the restated CPU reference on bounded samples of the same instances (rank 0 at N = 1 only)
         leg()
     out = None
     if ctx.rank == 0:
-        out = {"metric": METRIC, "value": round(res["value"], 3), "unit": "ADMM iterations/s", "n_gpus": ctx.world, "steps": res["steps"], "warmup": res["warmup"],
-               "ms_per_step": round(res["ms_per_step"], 6), "higher_is_better": True, "scaling": res["scaling"], "vs_baseline": None, "dtype": "f64",
-               "data": "synthetic", "config": res.get("config", {}), "roofline": res.get("roofline")}
-        out["config"]["kkt_solver"] = ("CG, literal cg! recurrence (reference algorithm)" if args.kkt == "cg" else
-                                       "CG, single-reduction (Chronopoulos-Gear) recurrence -- OPT-IN variant, same operator / stopping rule")
-        out["config"]["launch"] = ("self-launched torch.distributed.run" if os.environ.get("COSMO_BENCH_SELF_LAUNCHED") else
-                                   "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "single process")
-        if ctx.shm:
-            out["data"] = "synthetic; DRY RUN of the multi-rank path: all ranks share one GPU (COSMO_BENCH_TRANSPORT=shm), not a measurement"
-        if "cpu_baseline" in res:
-            out["cpu_baseline"] = res["cpu_baseline"]
-        if extra:
-            out["extra"] = extra
+        out = headline_line()
         print(json.dumps(out), flush=True)
     if ctx.dist is not None:
         ctx.dist.barrier()

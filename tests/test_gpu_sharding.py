@@ -321,3 +321,17 @@ def test_bench_gpus_2_without_a_launcher_is_a_two_rank_run_of_the_same_headline_
         assert ex[key]["scaling"] == "strong" and ex[key]["n_gpus"] == 2 and ex[key]["value"] > 0
     c5 = ex["cfg5_sharded"]["config"]
     assert c5["comm"]["nranks"] == 2 and c5["comm"]["mode"] == "rows" and c5["single_gpu_same_workload"] > 0
+
+
+def test_bench_reports_the_headline_even_if_a_sharded_extra_never_finishes():
+    """The sharded extras are the only part of bench.py with data-path collectives; if one of them hung (a rank failing while the others
+    wait in a collective) no line at all would come out of an N-GPU run.  A watchdog prints the headline -- measured before the extras
+    start -- with what has been collected and ends every rank.  Here the deadline is zero, so it fires while the first extra is being set up."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    env.update(COSMO_BENCH_TRANSPORT="shm", COSMO_BENCH_EXTRA_TIMEOUT="0.05")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--small", "--no-cpu-baseline", "--no-float32"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    two = _one_json_line(r)
+    assert two["n_gpus"] == 2 and two["value"] > 0 and two["config"]["workload"].startswith("cfg2") and two["scaling"] == "weak"
+    assert set(two["extra"]) == {"cfg5_sharded", "cfg3_sharded"}
+    assert any("error" in v for v in two["extra"].values())
