@@ -39,6 +39,10 @@ struct BatchDev {
   BCtl* ctl;
   real* inf_dy;                 // nprob * m: delta_y of the infeasibility certificates (captured between two launches)
   const real* tol_table; long long tol_len;   // tol_constant / k^tol_exponent, k = 1.. (host libm, as the large path)
+  // register kernel: COMPUTE assignment of the sparse passes inside the Krylov loop (see k_batch_admm_reg): thread t, slot j computes row
+  // permA[k][j * 512 + t] of A (-1: none) and column permT[k][j * 512 + t] of [P | A'] -- rows / columns sorted by length, so that the
+  // rows of a wave-step have similar lengths.  Null: every thread computes the rows it owns.
+  const int *permA, *permT;
 };
 
 struct BParams {
@@ -509,6 +513,23 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   }
   const int* cls = D.rho_cls + om;
   const real cinv = D.cinv[k];
+  // compute assignment of the Krylov loop's sparse passes (rows / columns sorted by length; identity without the tables) and rho of the
+  // rows this thread computes (kept in step with rhov by the same formula at every adaptation)
+  // (the <512, 2, 4> instantiation is at its 256 registers already: it keeps the owner-computes form)
+  constexpr bool SORTED = (JN == 1);
+  int ra[JM], ct[JN];
+  real rhoc[JM];
+#pragma unroll
+  for (int j = 0; j < JM; ++j) {
+    const int i = tid + BS * j;
+    ra[j] = (SORTED && D.permA) ? D.permA[(long long)k * (JM * BS) + j * BS + tid] : (i < m ? i : -1);
+    rhoc[j] = (SORTED && ra[j] >= 0) ? D.rho[om + ra[j]] : R(1.0);
+  }
+#pragma unroll
+  for (int j = 0; j < JN; ++j) {
+    const int i = tid + BS * j;
+    ct[j] = (SORTED && D.permT) ? D.permT[(long long)k * (JN * BS) + j * BS + tid] : (i < n ? i : -1);
+  }
   long long solves = ctl->solves, kkt_total = ctl->kkt_iters_total;
   int n_rho = ctl->n_rho_updates;
   real rho_s = ctl->rho;
@@ -596,22 +617,53 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
 #pragma unroll
       for (int j = 0; j < JN; ++j) { const int i = tid + BS * j; uv[j] = rv[j] + beta * ((kk == 0) ? R(0.0) : uv[j]); if (i < n) xv[i] = uv[j]; }
       __syncthreads();
+      // The two sparse passes of a Krylov iteration are bound by the CU's LDS pipe, and a wave issues as many steps as its LONGEST row.
+      // So thread t COMPUTES the rows ra[] / the column ct[] of the length-sorted assignment (rows of similar length share a wave-step:
+      // about a third fewer LDS instructions on BASELINE config 3) and hands the results to the owners through LDS -- tv is that
+      // hand-over for rho .* (A u) anyway; c = P u + sigma u + A' tmp goes through xv once every read of u is done.  The owner still
+      // does every update and reduction and each row sum is the same left-to-right sum: bit-identical to the owner-computes form.
+      if (SORTED) {
       { BT_BEGIN();
 #pragma unroll
-      for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; tmpv[j] = (i < m) ? rowA(i) * rhov[j] : 0.0; }
+      for (int j = 0; j < JM; ++j) tmpv[j] = (ra[j] >= 0) ? rowA(ra[j]) * rhoc[j] : 0.0;
 #pragma unroll
-      for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; if (i < m) tv[i] = tmpv[j]; }   // tv was last read before the previous barrier pair
+      for (int j = 0; j < JM; ++j) if (ra[j] >= 0) tv[ra[j]] = tmpv[j];   // tv was last read before the previous barrier pair
       __syncthreads();
       BT_END(0); }
       acc = 0.0;
       { BT_BEGIN();
+      real cjv[JN];
+#pragma unroll
+      for (int j = 0; j < JN; ++j) {
+        const int c = ct[j];
+        cjv[j] = 0.0;
+        if (c >= 0) { const real vj = xv[c]; cjv[j] = rowP(c) + (P.sigma * vj + rowAT(c)); }
+      }
+      __syncthreads();                                                   // every read of u (xv) is done: xv carries c to the owners
+#pragma unroll
+      for (int j = 0; j < JN; ++j) if (ct[j] >= 0) xv[ct[j]] = cjv[j];
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < JN; ++j) {
+        const int i = tid + BS * j;
+        if (i < n) { const real vj = uv[j]; const real cj = xv[i]; cv[j] = cj; acc += vj * cj; }
+      }
+      __syncthreads();
+      BT_END(1); }
+      } else {
+#pragma unroll
+      for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; tmpv[j] = (i < m) ? rowA(i) * rhov[j] : 0.0; }
+#pragma unroll
+      for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; if (i < m) tv[i] = tmpv[j]; }
+      __syncthreads();
+      acc = 0.0;
 #pragma unroll
       for (int j = 0; j < JN; ++j) {
         const int i = tid + BS * j;
         if (i < n) { const real vj = uv[j]; const real cj = rowP(i) + (P.sigma * vj + rowAT(i)); cv[j] = cj; acc += vj * cj; }
       }
       __syncthreads();
-      BT_END(1); }
+      }
       BT_BEGIN();
       const real uc = bsum<BS>(acc, red);
       BT_END(2);
@@ -755,6 +807,12 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
             if (cc == 1) r2 = r2 * P.rho_eq; else if (cc == 2) r2 = P.rho_min;
             rhov[j] = r2;
             wsv[j] = (R(1.0) / r2) * muv[j] + sv[j];
+          }
+        }
+        if (SORTED) {
+#pragma unroll
+          for (int j = 0; j < JM; ++j) {
+            if (ra[j] >= 0) { const int cc = cls[ra[j]]; real r2 = nr; if (cc == 1) r2 = r2 * P.rho_eq; else if (cc == 2) r2 = P.rho_min; rhoc[j] = r2; }
           }
         }
         if (tid == 0 && n_rho < COSMO_HIP_MAX_RHO_UPDATES) ctl->rho_updates[n_rho] = nr;
@@ -963,6 +1021,7 @@ struct cosmo_hip_batch {
   // LDS-resident variant (build_lds_images): one image per problem, dynamic LDS = image + gather vectors + reduction slots
   unsigned char* d_img = nullptr; long long img_stride = 0; int lds_bytes = 0; int lds_bs = 0;
   int reg_mode = 0;    // 0: LdsOps kernel, 1: register-resident <512,1,2>, 2: <512,2,4>
+  std::vector<int> h_permA, h_permT;          // compute assignment of the register kernel (build_lds_images), uploaded by set_params
 };
 
 static int32_t bfail(cosmo_hip_batch* b, int32_t code, const char* fmt, ...) {
@@ -1224,6 +1283,26 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
     };
     fill_rb(h.oRbA, rA, A.rowptr); fill_rb(h.oRbAT, rAT, AT.rowptr); fill_rb(h.oRbPT, rPT, PT.rowptr);
     stride = std::max(stride, o);
+    if (b->reg_mode == 1) {
+      // length-sorted compute assignment (see k_batch_admm_reg): position p of the sorted order goes to slot p / 512 of thread p % 512,
+      // i.e. a wave-step covers 64 consecutive positions
+      const int JMs = b->reg_mode == 1 ? 2 : 4, JNs = b->reg_mode == 1 ? 1 : 2;
+      if (b->h_permA.empty()) { b->h_permA.assign((size_t)b->nprob * JMs * 512, -1); b->h_permT.assign((size_t)b->nprob * JNs * 512, -1); }
+      std::vector<int> ord((size_t)m);
+      for (long long i = 0; i < m; ++i) ord[(size_t)i] = (int)i;
+      std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return A.rowptr[x + 1] - A.rowptr[x] > A.rowptr[y + 1] - A.rowptr[y]; });
+      // rows: slots alternate direction (position q of slot s goes to thread q % 512 for even s, 511 - q % 512 for odd s), so that the wave
+      // with the longest rows of one slot has the shortest of the next: the pass ends with its slowest wave
+      for (long long q = 0; q < m; ++q) {
+        const long long sl = q / 512, t = (sl & 1) ? 511 - q % 512 : q % 512;
+        b->h_permA[(size_t)k * JMs * 512 + (size_t)(sl * 512 + t)] = ord[(size_t)q];
+      }
+      ord.resize((size_t)n);
+      for (long long j = 0; j < n; ++j) ord[(size_t)j] = (int)j;
+      auto clen = [&](int j) { return (PT.split[j] - PT.rowptr[j]) + (AT.rowptr[j + 1] - AT.rowptr[j]); };
+      std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return clen(x) > clen(y); });
+      for (long long q = 0; q < n; ++q) b->h_permT[(size_t)k * JNs * 512 + (size_t)q] = ord[(size_t)q];
+    }
   }
   unsigned char* d = nullptr;
   BHIP(b, hipMalloc((void**)&d, (size_t)stride * b->nprob));
@@ -1273,7 +1352,13 @@ extern "C" int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hi
   BatchDev& D = b->D;
   D.nprob = nprob; D.n = (int)n; D.m = (int)m;
   int32_t rc;
+  D.permA = nullptr; D.permT = nullptr;
   if ((rc = build_lds_images(b))) return rc;               // needs the host CSR copies that bmat_upload releases
+  { const char* e = getenv("COSMO_HIP_BATCH_SORTED");      // =0: every thread computes the rows it owns (the form until round 3)
+    if (b->d_img && b->reg_mode == 1 && !(e && atoi(e) == 0) && !b->h_permA.empty()) {
+      if ((rc = bup(b, &D.permA, b->h_permA))) return rc;
+      if ((rc = bup(b, &D.permT, b->h_permT))) return rc;
+    } }
   if ((rc = bmat_upload(b, b->hA, D.A, (int)m, (int)n, false))) return rc;
   if ((rc = bmat_upload(b, b->hAT, D.AT, (int)n, (int)m, false))) return rc;
   if ((rc = bmat_upload(b, b->hPT, D.PT, (int)n, (int)n, true))) return rc;

@@ -160,6 +160,22 @@ def test_batch_kernel_variants_agree():
         assert a.iter == c.iter == 60 and a.status == c.status
 
 
+def test_batch_register_kernel_sorted_compute_assignment_is_bit_identical():
+    """Inside the Krylov loop the register kernel lets thread t COMPUTE the rows / the column of a length-sorted assignment and hands the
+    results to the owners through LDS (csrc/batch.hip, k_batch_admm_reg); the owners keep every update and reduction and each row sum is
+    the same left-to-right sum.  COSMO_HIP_BATCH_SORTED=0 is the owner-computes form: same bits, same Krylov counts, same rho updates --
+    default (inexact, rho-adapting) schedule and tight mode."""
+    probs = [cj.problems.socp(seed=2100 + k) for k in range(6)]
+    tight = cj.with_options(cj.CGIndirectKKTSolver, tol_constant=1e-10, tol_exponent=0.0)
+    for st in (cj.Settings(max_iter=120, eps_abs=0.0, eps_rel=0.0), cj.Settings(kkt_solver=tight, max_iter=60, eps_abs=0.0, eps_rel=0.0)):
+        run = lambda: cj.optimize_batch(_models(probs, st))
+        own = _with_env({"COSMO_HIP_BATCH_SORTED": "0"}, run)
+        srt = _with_env({}, run)
+        for a, b in zip(own, srt):
+            assert np.array_equal(a.x, b.x) and np.array_equal(a.s, b.s) and np.array_equal(a.y, b.y)
+            assert a.kkt_iters_total == b.kkt_iters_total > 0 and a.info.rho_updates == b.info.rho_updates and a.iter == b.iter
+
+
 def test_batch_register_kernel_default_schedule_matches_oracle():
     # default (inexact) CG schedule on config-3 sized problems through the register-resident kernel, against the oracle
     probs = [cj.problems.socp(seed=3000 + k) for k in range(3)]
