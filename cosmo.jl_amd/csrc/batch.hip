@@ -43,6 +43,7 @@ struct BatchDev {
   // permA[k][j * 512 + t] of A (-1: none) and column permT[k][j * 512 + t] of [P | A'] -- rows / columns sorted by length, so that the
   // rows of a wave-step have similar lengths.  Null: every thread computes the rows it owns.
   const int *permA, *permT;
+  const int *posN, *posM;       // nprob * n, nprob * m: position of an entry in the gathered LDS vectors (null: its index)
 };
 
 struct BParams {
@@ -530,6 +531,22 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     const int i = tid + BS * j;
     ct[j] = (SORTED && D.permT) ? D.permT[(long long)k * (JN * BS) + j * BS + tid] : (i < n ? i : -1);
   }
+  // POSITIONS of the gathered vectors: entry i of an n-vector sits at xv[posN[i]], entry r of an m-vector at tv[posM[r]] whenever a sparse
+  // pass gathers from them (the image's column / row indices are stored as positions).  The host chooses the positions so that the rows
+  // a wave-step works on spread over the LDS banks (build_lds_images); without the tables positions are indices.
+  int pn[JN], pm[JM], pnc[JN], pmc[JM];
+#pragma unroll
+  for (int j = 0; j < JN; ++j) {
+    const int i = tid + BS * j;
+    pn[j] = (SORTED && D.posN && i < n) ? D.posN[on + i] : i;
+    pnc[j] = (SORTED && D.posN && ct[j] >= 0) ? D.posN[on + ct[j]] : ct[j];
+  }
+#pragma unroll
+  for (int j = 0; j < JM; ++j) {
+    const int i = tid + BS * j;
+    pm[j] = (SORTED && D.posM && i < m) ? D.posM[om + i] : i;
+    pmc[j] = (SORTED && D.posM && ra[j] >= 0) ? D.posM[om + ra[j]] : ra[j];
+  }
   long long solves = ctl->solves, kkt_total = ctl->kkt_iters_total;
   int n_rho = ctl->n_rho_updates;
   real rho_s = ctl->rho;
@@ -550,6 +567,8 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   // (measured on config 3: a sparse pass costs ~25 cycles per wave step of three LDS reads, set by LDS issue rate and by the
   //  spread of row lengths inside a wave, not by latency -- manual unrolling, 16 waves instead of 8 and a sliced-JDS layout
   //  with conflict-free value / index reads were all tried and were the same speed or slower)
+  // (four nonzeros per trip with their loads issued together -- tried again in round 3 on top of the length-sorted assignment below, where
+  //  the rows of a wave have similar lengths: 3608 vs 4129 batch-it/s on config 3, slower as in round 2)
   auto rowA = [&](int r) -> real {                        // (A x)_r with x = xv
     real s1 = 0.0;
     const int a = Arp[r], b2 = Arp[r + 1];
@@ -578,10 +597,10 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       const int i = tid + BS * j;
       const real v = (bv[j] - R(2.0) * sv[j]) + wsv[j];
       lss[j] = v;
-      if (i < m) tv[i] = rhov[j] * v;                                    // y2 = rho .* ls_s
+      if (i < m) tv[pm[j]] = rhov[j] * v;                                // y2 = rho .* ls_s
     }
 #pragma unroll
-    for (int j = 0; j < JN; ++j) { const int i = tid + BS * j; if (i < n) xv[i] = xtl[j]; }
+    for (int j = 0; j < JN; ++j) { const int i = tid + BS * j; if (i < n) xv[pn[j]] = xtl[j]; }
     __syncthreads();
     real acc = 0.0;
 #pragma unroll
@@ -595,7 +614,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; tmpv[j] = (i < m) ? rowA(i) * rhov[j] : 0.0; }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; if (i < m) tv[i] = tmpv[j]; }
+    for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; if (i < m) tv[pm[j]] = tmpv[j]; }
     __syncthreads();
     acc = 0.0;
 #pragma unroll
@@ -615,7 +634,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     while (kk < n && !(res <= tol)) {                                    // cg! (IterativeSolvers v0.9), maxiter = n
       const real beta = (res * res) / (prev * prev);
 #pragma unroll
-      for (int j = 0; j < JN; ++j) { const int i = tid + BS * j; uv[j] = rv[j] + beta * ((kk == 0) ? R(0.0) : uv[j]); if (i < n) xv[i] = uv[j]; }
+      for (int j = 0; j < JN; ++j) { const int i = tid + BS * j; uv[j] = rv[j] + beta * ((kk == 0) ? R(0.0) : uv[j]); if (i < n) xv[pn[j]] = uv[j]; }
       __syncthreads();
       // The two sparse passes of a Krylov iteration are bound by the CU's LDS pipe, and a wave issues as many steps as its LONGEST row.
       // So thread t COMPUTES the rows ra[] / the column ct[] of the length-sorted assignment (rows of similar length share a wave-step:
@@ -627,7 +646,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
 #pragma unroll
       for (int j = 0; j < JM; ++j) tmpv[j] = (ra[j] >= 0) ? rowA(ra[j]) * rhoc[j] : 0.0;
 #pragma unroll
-      for (int j = 0; j < JM; ++j) if (ra[j] >= 0) tv[ra[j]] = tmpv[j];   // tv was last read before the previous barrier pair
+      for (int j = 0; j < JM; ++j) if (ra[j] >= 0) tv[pmc[j]] = tmpv[j];   // tv was last read before the previous barrier pair
       __syncthreads();
       BT_END(0); }
       acc = 0.0;
@@ -637,16 +656,16 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       for (int j = 0; j < JN; ++j) {
         const int c = ct[j];
         cjv[j] = 0.0;
-        if (c >= 0) { const real vj = xv[c]; cjv[j] = rowP(c) + (P.sigma * vj + rowAT(c)); }
+        if (c >= 0) { const real vj = xv[pnc[j]]; cjv[j] = rowP(c) + (P.sigma * vj + rowAT(c)); }
       }
       __syncthreads();                                                   // every read of u (xv) is done: xv carries c to the owners
 #pragma unroll
-      for (int j = 0; j < JN; ++j) if (ct[j] >= 0) xv[ct[j]] = cjv[j];
+      for (int j = 0; j < JN; ++j) if (ct[j] >= 0) xv[pnc[j]] = cjv[j];
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < JN; ++j) {
         const int i = tid + BS * j;
-        if (i < n) { const real vj = uv[j]; const real cj = xv[i]; cv[j] = cj; acc += vj * cj; }
+        if (i < n) { const real vj = uv[j]; const real cj = xv[pn[j]]; cv[j] = cj; acc += vj * cj; }
       }
       __syncthreads();
       BT_END(1); }
@@ -682,7 +701,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     }
     // nu = rho (A x_tl - ls_s) ; s_tl ; w update
 #pragma unroll
-    for (int j = 0; j < JN; ++j) { const int i = tid + BS * j; if (i < n) xv[i] = xtl[j]; }
+    for (int j = 0; j < JN; ++j) { const int i = tid + BS * j; if (i < n) xv[pn[j]] = xtl[j]; }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < JM; ++j) {
@@ -706,7 +725,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   for (int j = 0; j < JM; ++j) muv[j] = 0.0;
   auto residuals = [&](bool unscale) {
 #pragma unroll
-    for (int j = 0; j < JN; ++j) { const int i = tid + BS * j; if (i < n) xv[i] = wpx[j]; }
+    for (int j = 0; j < JN; ++j) { const int i = tid + BS * j; if (i < n) xv[pn[j]] = wpx[j]; }
     __syncthreads();
     real a_rp = 0.0, a_mp = 0.0;
 #pragma unroll
@@ -715,7 +734,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       if (i < m) {
         const real ax = rowA(i), s0 = sv[j], b0 = bv[j];
         muv[j] = rhov[j] * (wps[j] - s0);
-        tv[i] = muv[j];
+        tv[pm[j]] = muv[j];
         real r0 = ax + s0; r0 = r0 - b0;
         const real e = unscale ? D.Einv[om + i] : 1.0;
         if (unscale) r0 = r0 * e;
@@ -1022,6 +1041,7 @@ struct cosmo_hip_batch {
   unsigned char* d_img = nullptr; long long img_stride = 0; int lds_bytes = 0; int lds_bs = 0;
   int reg_mode = 0;    // 0: LdsOps kernel, 1: register-resident <512,1,2>, 2: <512,2,4>
   std::vector<int> h_permA, h_permT;          // compute assignment of the register kernel (build_lds_images), uploaded by set_params
+  std::vector<int> h_posN, h_posM;            // positions of the gathered LDS vectors (build_lds_images)
 };
 
 static int32_t bfail(cosmo_hip_batch* b, int32_t code, const char* fmt, ...) {
@@ -1283,7 +1303,8 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
     };
     fill_rb(h.oRbA, rA, A.rowptr); fill_rb(h.oRbAT, rAT, AT.rowptr); fill_rb(h.oRbPT, rPT, PT.rowptr);
     stride = std::max(stride, o);
-    if (b->reg_mode == 1) {
+    const char* e_sorted = getenv("COSMO_HIP_BATCH_SORTED");      // =0: every thread computes the rows it owns (the form until round 3)
+    if (b->reg_mode == 1 && !(e_sorted && atoi(e_sorted) == 0)) {
       // length-sorted compute assignment (see k_batch_admm_reg): position p of the sorted order goes to slot p / 512 of thread p % 512,
       // i.e. a wave-step covers 64 consecutive positions
       const int JMs = b->reg_mode == 1 ? 2 : 4, JNs = b->reg_mode == 1 ? 1 : 2;
@@ -1302,6 +1323,77 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
       auto clen = [&](int j) { return (PT.split[j] - PT.rowptr[j]) + (AT.rowptr[j + 1] - AT.rowptr[j]); };
       std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return clen(x) > clen(y); });
       for (long long q = 0; q < n; ++q) b->h_permT[(size_t)k * JNs * 512 + (size_t)q] = ord[(size_t)q];
+      // Positions of the gathered vectors.  A ds_read_b64 is served 32 lanes at a time and an 8-byte slot p lies in bank pair p mod 32:
+      // the 32 rows a half-wave works on in one step gather 32 entries, and every extra entry on a busy bank pair costs an LDS cycle
+      // (random indices: ~3.4 per group).  Greedy assignment: entries by decreasing number of appearances, each to the bank pair that
+      // adds the fewest conflicts over the groups it appears in (capacity = slots of that residue), slots handed out in order.
+      const char* e_color = getenv("COSMO_HIP_BATCH_COLOR");
+      if (!(e_color && atoi(e_color) == 0)) {
+        if (b->h_posN.empty()) { b->h_posN.assign((size_t)b->nprob * n, 0); b->h_posM.assign((size_t)b->nprob * m, 0); }
+        auto assign_positions = [&](int nent, const std::vector<std::vector<int>>& groups, int* pos) {
+          std::vector<std::vector<int>> where((size_t)nent);                 // entry -> groups it appears in
+          for (size_t g = 0; g < groups.size(); ++g) for (int e : groups[g]) where[(size_t)e].push_back((int)g);
+          std::vector<int> order((size_t)nent);
+          for (int e = 0; e < nent; ++e) order[(size_t)e] = e;
+          std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return where[(size_t)x].size() > where[(size_t)y].size(); });
+          std::vector<int> cap(32, 0), used(32, 0);
+          for (int q = 0; q < nent; ++q) cap[q % 32] += 1;
+          std::vector<unsigned char> cnt(groups.size() * 32, 0);
+          for (int e : order) {
+            int best = -1; long long bestc = 0;
+            for (int bk = 0; bk < 32; ++bk) {
+              if (used[bk] >= cap[bk]) continue;
+              long long c = 0;
+              for (int g : where[(size_t)e]) c += cnt[(size_t)g * 32 + bk];
+              if (best < 0 || c < bestc || (c == bestc && used[bk] < used[best])) { best = bk; bestc = c; }
+            }
+            pos[e] = best + 32 * used[best];
+            used[best] += 1;
+            for (int g : where[(size_t)e]) cnt[(size_t)g * 32 + best] += 1;
+          }
+        };
+        // groups of the x-gathers: rows computed by a half-wave in one step of the A pass; columns of P gathered by a half-wave in the column pass
+        std::vector<std::vector<int>> gN, gM;
+        for (int sl = 0; sl < JMs; ++sl)
+          for (int hw = 0; hw < 16; ++hw) {
+            int maxlen = 0;
+            for (int t = 32 * hw; t < 32 * hw + 32; ++t) { const int r = b->h_permA[(size_t)k * JMs * 512 + (size_t)sl * 512 + t]; if (r >= 0) maxlen = std::max(maxlen, A.rowptr[r + 1] - A.rowptr[r]); }
+            for (int st = 0; st < maxlen; ++st) {
+              std::vector<int> g;
+              for (int t = 32 * hw; t < 32 * hw + 32; ++t) { const int r = b->h_permA[(size_t)k * JMs * 512 + (size_t)sl * 512 + t]; if (r >= 0 && A.rowptr[r] + st < A.rowptr[r + 1]) g.push_back(A.col[A.rowptr[r] + st]); }
+              if (g.size() > 1) gN.push_back(g);
+            }
+          }
+        for (int sl = 0; sl < JNs; ++sl)
+          for (int hw = 0; hw < 16; ++hw) {
+            int maxp = 0, maxt = 0;
+            for (int t = 32 * hw; t < 32 * hw + 32; ++t) {
+              const int c = b->h_permT[(size_t)k * JNs * 512 + (size_t)sl * 512 + t];
+              if (c >= 0) { maxp = std::max(maxp, PT.split[c] - PT.rowptr[c]); maxt = std::max(maxt, AT.rowptr[c + 1] - AT.rowptr[c]); }
+            }
+            for (int st = 0; st < maxp; ++st) {
+              std::vector<int> g;
+              for (int t = 32 * hw; t < 32 * hw + 32; ++t) { const int c = b->h_permT[(size_t)k * JNs * 512 + (size_t)sl * 512 + t]; if (c >= 0 && PT.rowptr[c] + st < PT.split[c]) g.push_back(PT.col[PT.rowptr[c] + st]); }
+              if (g.size() > 1) gN.push_back(g);
+            }
+            for (int st = 0; st < maxt; ++st) {
+              std::vector<int> g;
+              for (int t = 32 * hw; t < 32 * hw + 32; ++t) { const int c = b->h_permT[(size_t)k * JNs * 512 + (size_t)sl * 512 + t]; if (c >= 0 && AT.rowptr[c] + st < AT.rowptr[c + 1]) g.push_back(AT.col[AT.rowptr[c] + st]); }
+              if (g.size() > 1) gM.push_back(g);
+            }
+          }
+        int* pN = b->h_posN.data() + (size_t)k * n;
+        int* pM = b->h_posM.data() + (size_t)k * m;
+        assign_positions((int)n, gN, pN);
+        assign_positions((int)m, gM, pM);
+        // the image's gather indices become positions
+        std::vector<unsigned char>& im2 = imgs[(size_t)k];
+        unsigned short* Acol2 = reinterpret_cast<unsigned short*>(im2.data() + h.oAcol);
+        unsigned short* Trow2 = reinterpret_cast<unsigned short*>(im2.data() + h.oTrow);
+        unsigned short* Pcol2 = reinterpret_cast<unsigned short*>(im2.data() + h.oPcol);
+        for (long long t = 0; t < nnzA; ++t) { Acol2[t] = (unsigned short)pN[Acol2[t]]; Trow2[t] = (unsigned short)pM[Trow2[t]]; }
+        for (long long t = 0; t < nnzP; ++t) Pcol2[t] = (unsigned short)pN[Pcol2[t]];
+      }
     }
   }
   unsigned char* d = nullptr;
@@ -1352,13 +1444,16 @@ extern "C" int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hi
   BatchDev& D = b->D;
   D.nprob = nprob; D.n = (int)n; D.m = (int)m;
   int32_t rc;
-  D.permA = nullptr; D.permT = nullptr;
+  D.permA = nullptr; D.permT = nullptr; D.posN = nullptr; D.posM = nullptr;
   if ((rc = build_lds_images(b))) return rc;               // needs the host CSR copies that bmat_upload releases
-  { const char* e = getenv("COSMO_HIP_BATCH_SORTED");      // =0: every thread computes the rows it owns (the form until round 3)
-    if (b->d_img && b->reg_mode == 1 && !(e && atoi(e) == 0) && !b->h_permA.empty()) {
-      if ((rc = bup(b, &D.permA, b->h_permA))) return rc;
-      if ((rc = bup(b, &D.permT, b->h_permT))) return rc;
-    } }
+  if (b->d_img && b->reg_mode == 1 && !b->h_permA.empty()) {        // (no image: the streaming kernel runs and needs none of this)
+    if ((rc = bup(b, &D.permA, b->h_permA))) return rc;
+    if ((rc = bup(b, &D.permT, b->h_permT))) return rc;
+    if (!b->h_posN.empty()) {
+      if ((rc = bup(b, &D.posN, b->h_posN))) return rc;
+      if ((rc = bup(b, &D.posM, b->h_posM))) return rc;
+    }
+  }
   if ((rc = bmat_upload(b, b->hA, D.A, (int)m, (int)n, false))) return rc;
   if ((rc = bmat_upload(b, b->hAT, D.AT, (int)n, (int)m, false))) return rc;
   if ((rc = bmat_upload(b, b->hPT, D.PT, (int)n, (int)n, true))) return rc;
