@@ -110,6 +110,7 @@ SIGNATURES = {
     "cosmo_hip_comm_destroy": (C.c_int32, [C.c_void_p]),
     "cosmo_hip_set_cone_shard": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_comm_selftest": (C.c_int32, [C.c_void_p]),
+    "cosmo_hip_comm_allreduce_check": (C.c_int32, [C.c_void_p, C.c_int64, _PI64]),
     "cosmo_hip_comm_init_hostshm": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p]),
     "cosmo_hip_comm_stats": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_set_cone_ownership": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int64]),
@@ -454,6 +455,15 @@ class Handle:
     def comm_selftest(self):
         self._chk(self.lib.cosmo_hip_comm_selftest(self._h))
 
+    def comm_allreduce_check(self, count):
+        """Known-answer all-reduce of `count` reals through the loop's own exchange path (collective: all ranks call it).  The caller compares
+        `hash` across the ranks: the replicated n-side of a row-sharded run needs the SAME bits everywhere."""
+        out = np.zeros(6, dtype=np.int64)
+        self._chk(self.lib.cosmo_hip_comm_allreduce_check(self._h, int(count), out.ctypes.data_as(_PI64)))
+        d = dict(zip(["exact_mismatches", "inexact_outside_bound", "hash", "transport", "nranks", "rccl_version_code"], out.tolist()))
+        d["count"] = int(count)
+        return d
+
     def comm_init_hostshm(self, rank, nranks, name: str):
         self._chk(self.lib.cosmo_hip_comm_init_hostshm(self._h, int(rank), int(nranks), name.encode()))
 
@@ -556,6 +566,8 @@ class Batch:
         return list(res)
 
     def iterate(self, n_iters, with_init=False):
+        """n_iters more loop bodies of every undecided problem (residual / adaptive-rho checks on schedule).  The infeasibility certificates
+        are NOT evaluated here -- only optimize() cuts the persistent launch for them -- so rates measured through iterate() exclude their cost."""
         self._chk(self.lib.cosmo_hip_batch_iterate(self._b, int(n_iters), 1 if with_init else 0))
 
     def counters(self):

@@ -845,18 +845,23 @@ extern "C" int32_t cosmo_hip_set_iterates(cosmo_hip_handle* h, const real* x0, c
 // the feedback off for the handle (COSMO_HIP_BUDGET_FEEDBACK=0 does so from the start).
 static const int FB_LAG = 2;
 static void feedback_reset(cosmo_hip_handle* h) { h->fb_from = h->fb_recorded; }
-static int solve_budget(cosmo_hip_handle* h) {
-  h->fb_last_used = false;
+static int32_t solve_budget(cosmo_hip_handle* h, int* budget_out) {
+  const int R = cosmo_hip_handle::FB_RING;
+  bool& used = h->fb_used[(h->host_solves + 1) % R];         // this solve is number host_solves + 1 (ctl->solves counts completed ones)
+  used = false;
   if (h->fb_mode == 1 && !h->fb_k) {
     if (const char* e = getenv("COSMO_HIP_BUDGET_FEEDBACK")) { if (atoi(e) == 0) h->fb_mode = 0; }
     if (h->fb_mode == 1 && hipHostMalloc((void**)&h->fb_k, sizeof(int) * cosmo_hip_handle::FB_RING) != hipSuccess) { (void)hipGetLastError(); h->fb_k = nullptr; h->fb_mode = 0; }
   }
-  if (h->fb_mode != 1 || h->profiling || h->exact_launches) return h->budget;
+  *budget_out = h->budget;
+  if (h->fb_mode != 1 || h->profiling || h->exact_launches) return COSMO_HIP_OK;
   const long long j = h->fb_recorded - FB_LAG;
   const int wide = h->budget + h->budget / 16;        // regime change: the window rule with 6 % of headroom (a creeping count stalled it)
-  if (j < h->fb_from || j < 0) return wide > 4096 ? 4096 : wide;
-  const int R = cosmo_hip_handle::FB_RING;
-  if (hipEventSynchronize(h->fb_ev[j % R]) != hipSuccess) { (void)hipGetLastError(); return h->budget; }
+  if (j < h->fb_from || j < 0) { *budget_out = wide > 4096 ? 4096 : wide; return COSMO_HIP_OK; }
+  // Bounded run-ahead: the host waits for the event of solve s - FB_LAG, i.e. it is never more than FB_LAG solves ahead of the device.  A
+  // failure here is an error of the call, not a silent rank-local fallback: in a sharded run a different budget on one rank means
+  // different stalls, a different number of re-enqueued collectives and in the end a hang inside RCCL instead of an error code.
+  HIPCHK(h, hipEventSynchronize(h->fb_ev[j % R]));
   int kmax = h->fb_k[j % R], kmin = kmax, nv = 1;
   for (long long i = j - 1; i >= h->fb_from && i > j - 4; --i) { const int v = h->fb_k[i % R]; kmax = std::max(kmax, v); kmin = std::min(kmin, v); nv += 1; }
   // newest counts of the regime: their maximum + half their spread + 2.5 % + 3 (two or fewer counts: 15 % + 6 instead).  Replayed on the
@@ -864,9 +869,10 @@ static int solve_budget(cosmo_hip_handle* h) {
   int b = (nv >= 3) ? kmax + (kmax - kmin) / 2 + kmax / 40 + 3 : kmax + (kmax * 15 + 99) / 100 + 6;
   if (b < 3) b = 3;
   if (b > 4096) b = 4096;
-  h->fb_last_used = true;
+  used = true;
   h->cg_k_likely = kmax + 1;                  // iterations past the largest recent count: expected no-ops (check the flags first)
-  return b;
+  *budget_out = b;
+  return COSMO_HIP_OK;
 }
 static int32_t feedback_record(cosmo_hip_handle* h) {
   if (h->fb_mode != 1 || !h->fb_k) return COSMO_HIP_OK;
@@ -893,7 +899,9 @@ static int32_t enqueue_solve_in_loop(cosmo_hip_handle* h) {
           CHK(sr_enqueue_iterations(h, 1, k, 1));
         }
       } else {
-        CHK(sr_enqueue_iterations(h, 1, 0, solve_budget(h)));
+        int bud = 0;
+        CHK(solve_budget(h, &bud));
+        CHK(sr_enqueue_iterations(h, 1, 0, bud));
         h->cg_k_likely = 0x7fffffff;
       }
     } else if (h->pcg_on) {
@@ -907,7 +915,9 @@ static int32_t enqueue_solve_in_loop(cosmo_hip_handle* h) {
         CHK(enqueue_cg_iterations(h, 1, k, 1));
       }
     } else {
-      CHK(enqueue_cg_iterations(h, 1, 0, solve_budget(h)));
+      int bud = 0;
+      CHK(solve_budget(h, &bud));
+      CHK(enqueue_cg_iterations(h, 1, 0, bud));
       h->cg_k_likely = 0x7fffffff;
     }
     CHK(enqueue_tail(h, 1));
@@ -955,7 +965,9 @@ static int32_t enqueue_iteration(cosmo_hip_handle* h, long long it) {
 static int32_t resolve_stall(cosmo_hip_handle* h) {
   while (h->ctl_host->stalled) {
     h->stalls += 1;
-    if (h->fb_mode == 1 && h->fb_recorded - h->fb_from > FB_LAG) { h->fb_stalls += 1; if (h->fb_stalls >= 3) h->fb_mode = 0; }   // a feedback budget was in use
+    // did the STALLED solve (number ctl->solves + 1: the counter advances when a solve completes) run on a feedback budget?  Solves
+    // enqueued behind it were no-ops and say nothing; window-rule ('wide') budgets are not the feedback's stalls
+    if (h->fb_mode == 1 && h->fb_used[(h->ctl_host->solves + 1) % cosmo_hip_handle::FB_RING]) { h->fb_stalls += 1; if (h->fb_stalls >= 3) h->fb_mode = 0; }
     feedback_reset(h);
     if (h->pcg_on) { h->pcg_on = false; h->pcg_fallbacks += 1; }     // only a failed start-up rendezvous stalls the persistent kernel
     int extra = std::max(2 * h->budget, 8);
@@ -977,7 +989,9 @@ static int32_t resolve_stall(cosmo_hip_handle* h) {
 }
 
 // Enqueue iterations until the device has completed `target` iterations (or decided a status); optionally append
-// a check (mode as enqueue_check) after the last one.  One host synchronisation per call in the common case.
+// a check (mode as enqueue_check) after the last one.  One FULL host synchronisation per call in the common case; with the budget
+// feedback on, every solve also waits for the completion event of the solve FB_LAG = 2 before it (solve_budget), which bounds the
+// host's run-ahead to two solves without draining the stream.
 static int32_t run_until(cosmo_hip_handle* h, long long target, int check_mode) {
   for (;;) {
     for (long long it = h->host_iter + 1; it <= target; ++it) CHK(enqueue_iteration(h, it));
@@ -1294,6 +1308,7 @@ extern "C" int32_t cosmo_hip_time_spmv(cosmo_hip_handle* h, int32_t which, int32
                                        double* algorithmic_bytes) {
   ENTER(h);
   if (!h->have_problem || reps <= 0 || !avg_seconds) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "time_spmv: bad arguments");
+  if (h->row_shard) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "time_spmv: not available on a row-sharded handle (A / A' are row slices, [P | A'] is dropped)");
   const long long n = h->n, m = h->m;
   hipEvent_t e0, e1;
   HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));

@@ -324,7 +324,7 @@ static void fold_launch_pair(cosmo_hip_handle* h, FoldPlan* f, int guard, int k,
 // iteration -- the kernel timeline showed the launching thread falling behind inside the Krylov loop (12 % idle) and a loaded host cost
 // 13 % of the throughput.  Index protocol: k_cg_dirM reads ctl->cg_k (written by the k_cg_upd in front of it) and publishes it as
 // ctl->cg_kd for the k_cg_upd behind it, which writes cg_k = k + 1; the final check reads cg_k.  Arithmetic and launch order are those of
-// the direct path (COSMO_HIP_CG_GRAPH=0; tests/test_gpu_kkt.py compares the two bit for bit), and so is the number of iterations enqueued:
+// the direct path (COSMO_HIP_CG_GRAPH=0; tests/test_gpu_cg_fold.py compares the two bit for bit), and so is the number of iterations enqueued:
 // whole chains first, the remainder of the budget directly with the index as a kernel argument.
 static bool fold_chain_ready(cosmo_hip_handle* h, FoldPlan* f) {
   if (f->chain_off || h->profiling) return false;

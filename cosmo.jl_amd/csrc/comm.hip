@@ -38,6 +38,7 @@ struct RcclApi {
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*GetVersion)(int*) = nullptr;
 };
 static RcclApi g_rccl;
 
@@ -55,6 +56,7 @@ static const char* rccl_load() {
   g_rccl.GroupStart = (int (*)())dlsym(lib, "ncclGroupStart");
   g_rccl.GroupEnd = (int (*)())dlsym(lib, "ncclGroupEnd");
   g_rccl.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+  g_rccl.GetVersion = (int (*)(int*))dlsym(lib, "ncclGetVersion");
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.Broadcast || !g_rccl.AllReduce || !g_rccl.GroupStart || !g_rccl.GroupEnd)
     return "librccl.so lacks an expected symbol";
   g_rccl.lib = lib;
@@ -309,12 +311,27 @@ int32_t comm_enqueue_exchange(cosmo_hip_handle* h, real* s) {
 // In-place sum over the ranks of `count` reals at `buf` (device), enqueued on the handle's stream.  Every rank receives the SAME bits:
 // RCCL reduces every element along one fixed path and distributes the result; the host-staged transport adds the ranks' vectors in
 // rank order on every rank.  (ncclSum = 0.)
+// TEST HOOK (COSMO_HIP_COMM_CORRUPT_RANK=r): rank r's contribution to every all-reduce is scaled by 1 + 1e-3 before it leaves the rank -- a
+// deliberately wrong exchange, so that the parity evidence a multi-GPU bench line carries (bench.py: comm.selftest,
+// sharded_vs_single_max_rel_dev) can be shown to turn red (tests/test_gpu_sharding.py).  Never set in production.
+__global__ void k_comm_corrupt(long long count, real* buf) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) buf[i] = buf[i] * R(1.001);
+}
+static int corrupt_rank() {
+  static int r = -2;
+  if (r == -2) { const char* e = getenv("COSMO_HIP_COMM_CORRUPT_RANK"); r = e ? atoi(e) : -1; }
+  return r;
+}
+
 int32_t comm_allreduce_sum(cosmo_hip_handle* h, real* buf, size_t count) {
   if (!h->comm || count == 0) return COSMO_HIP_OK;
   CommState* c = (CommState*)h->comm;
   if (c->nranks == 1) return COSMO_HIP_OK;
   c->exchanges += 1;
   c->bytes += (long long)(sizeof(real) * count);
+  if (corrupt_rank() == c->rank)
+    hipLaunchKernelGGL(k_comm_corrupt, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, h->stream, (long long)count, buf);
   if (c->shm) {
     if ((long long)(count * (size_t)c->nranks) > c->shm->capacity) return cosmo_fail(h, COSMO_HIP_ERR_COMM, "shared segment too small for the all-reduce");
     HIPCHK(h, hipMemcpyAsync(c->shm->data + (size_t)c->rank * count, buf, sizeof(real) * count, hipMemcpyDeviceToHost, h->stream));
@@ -391,10 +408,70 @@ extern "C" int32_t cosmo_hip_comm_selftest(cosmo_hip_handle* h) {
   if (!h || !h->comm || !h->have_iterates) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "comm_selftest: comm_init and set_iterates first");
   CommState* c = (CommState*)h->comm;
   if (hipSetDevice(h->device) != hipSuccess) return cosmo_fail(h, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
+  if (h->row_shard) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "comm_selftest: s is a row slice of rank-dependent length on a row-sharded handle (use cosmo_hip_comm_allreduce_check)");
   if (c->shm) return shm_barrier(h, c);
   NCHK(h, g_rccl.GroupStart());
   NCHK(h, g_rccl.Broadcast(h->s, h->s, (size_t)h->m, NCCL_REAL, 0, c->comm, h->stream));
   NCHK(h, g_rccl.GroupEnd());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return COSMO_HIP_OK;
+}
+
+// Known-answer test of the all-reduce the row-sharded loop relies on, through the SAME code path (comm_allreduce_sum on the handle's
+// stream, `count` reals -- pass n to exercise the loop's message size).  Two vectors:
+//   A. integer-valued contributions (rank + 1) * (i mod 997 + 1): the sum N (N + 1) / 2 * (i mod 997 + 1) is exact in any order
+//      => out[0] = number of elements that differ from it (must be 0);
+//   B. fractional contributions of mixed magnitude from a counter-based generator every rank can evaluate for every rank: the result
+//      must lie within nranks * eps * sum |contribution| of the long-double sum (out[1] = elements outside), and its BITS must be the same
+//      on every rank (the replicated n-side of the loop stays bit-identical only then): out[2] = FNV-1a hash of the result's bytes, to be
+//      compared across the ranks by the caller.
+// out[3] = transport (1 RCCL, 2 host-staged), out[4] = nranks, out[5] = RCCL version code (ncclGetVersion; 0 on the host-staged transport).
+// Collective: every rank of the communicator must call it with the same count.
+static inline double chk_contrib(int rank, long long i) {
+  unsigned long long z = (unsigned long long)i * 0x9E3779B97F4A7C15ull + (unsigned long long)(rank + 1) * 0xBF58476D1CE4E5B9ull;
+  z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
+  const double u = (double)(z >> 11) * (1.0 / 9007199254740992.0) - 0.5;          // [-0.5, 0.5)
+  static const double mag[7] = {1e-3, 1e-2, 1e-1, 1.0, 1e1, 1e2, 1e3};
+  return u * mag[i % 7];
+}
+extern "C" int32_t cosmo_hip_comm_allreduce_check(cosmo_hip_handle* h, int64_t count, int64_t out[6]) {
+  if (!h || !out || count <= 0) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "comm_allreduce_check: bad arguments");
+  for (int i = 0; i < 6; ++i) out[i] = 0;
+  if (!h->comm) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "comm_allreduce_check: comm_init first");
+  CommState* c = (CommState*)h->comm;
+  if (hipSetDevice(h->device) != hipSuccess) return cosmo_fail(h, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
+  out[3] = c->shm ? 2 : 1; out[4] = c->nranks;
+  if (!c->shm && g_rccl.GetVersion) { int v = 0; if (g_rccl.GetVersion(&v) == 0) out[5] = v; }
+  if (c->shm && (long long)count * c->nranks > c->shm->capacity) return cosmo_fail(h, COSMO_HIP_ERR_COMM, "comm_allreduce_check: shared segment too small for %lld reals", (long long)count);
+  real* d = nullptr;
+  HIPCHK(h, hipMalloc((void**)&d, sizeof(real) * (size_t)count));
+  std::vector<real> v((size_t)count);
+  const long long ex0 = c->exchanges, by0 = c->bytes;               // the check is not part of the loop's exchange statistics
+  int32_t rc = COSMO_HIP_OK;
+  for (int pass = 0; pass < 2 && rc == COSMO_HIP_OK; ++pass) {
+    for (long long i = 0; i < count; ++i) v[(size_t)i] = pass == 0 ? (real)((double)(c->rank + 1) * (double)(i % 997 + 1)) : (real)chk_contrib(c->rank, i);
+    if (hipMemcpyAsync(d, v.data(), sizeof(real) * (size_t)count, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = cosmo_fail(h, COSMO_HIP_ERR_HIP, "comm_allreduce_check: upload failed"); break; }
+    rc = comm_allreduce_sum(h, d, (size_t)count);
+    if (rc != COSMO_HIP_OK) break;
+    if (hipMemcpyAsync(v.data(), d, sizeof(real) * (size_t)count, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
+      rc = cosmo_fail(h, COSMO_HIP_ERR_HIP, "comm_allreduce_check: download failed"); break; }
+    if (pass == 0) {
+      const double tri = 0.5 * c->nranks * (c->nranks + 1.0);
+      for (long long i = 0; i < count; ++i) if ((double)v[(size_t)i] != tri * (double)(i % 997 + 1)) out[0] += 1;
+    } else {
+      unsigned long long hsh = 1469598103934665603ull;
+      const unsigned char* pb = (const unsigned char*)v.data();
+      for (size_t k = 0; k < sizeof(real) * (size_t)count; ++k) { hsh ^= pb[k]; hsh *= 1099511628211ull; }
+      out[2] = (int64_t)hsh;
+      for (long long i = 0; i < count; ++i) {
+        long double sum = 0.0L, mag = 0.0L;
+        for (int r = 0; r < c->nranks; ++r) { const long double t = (long double)(real)chk_contrib(r, i); sum += t; mag += t < 0 ? -t : t; }
+        const long double err = (long double)v[(size_t)i] - sum;
+        if ((err < 0 ? -err : err) > (long double)c->nranks * (long double)REAL_EPS * mag) out[1] += 1;
+      }
+    }
+  }
+  c->exchanges = ex0; c->bytes = by0;
+  (void)hipFree(d);
+  return rc;
 }

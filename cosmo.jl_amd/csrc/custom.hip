@@ -37,6 +37,7 @@ extern "C" int32_t cosmo_hip_set_custom_cone(cosmo_hip_handle* h, int64_t cone, 
   if (!h) return COSMO_HIP_ERR_INVALID;
   if (!h->have_cones) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_custom_cone: set_cones must be called first");
   if (!project) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_custom_cone: a projection callback is required");
+  if (h->row_shard) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "set_custom_cone: not available on a row-sharded handle (user-defined cones are projected on the host)");
   for (CustomCone& cc : h->custom) {
     if (cc.cone != cone) continue;
     cc.project = project; cc.in_dual = in_dual; cc.in_pol_recc = in_pol_recc; cc.user = user;

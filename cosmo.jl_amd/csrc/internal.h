@@ -227,7 +227,7 @@ struct cosmo_hip_handle {
   long long fb_from = 0;               // first solve whose count describes the CURRENT regime (start, rho change or stall)
   int fb_mode = 1;                     // COSMO_HIP_BUDGET_FEEDBACK=0: window maximum + 2 only
   long long fb_stalls = 0;             // stalls of solves that ran on a feedback budget (three of them switch it off)
-  bool fb_last_used = false;
+  bool fb_used[FB_RING] = {};          // entry s % FB_RING: loop solve s (1-based, as ctl->solves + 1) was enqueued with a feedback budget
   int cg_k_likely = 0x7fffffff;        // Krylov iterations from this index on are expected to be no-ops (set per solve by solve_budget)
   long long spmv_calls[3] = {0, 0, 0};
   // profiling

@@ -105,6 +105,7 @@ extern "C" int32_t cosmo_hip_scale_ruiz(cosmo_hip_handle* h, int64_t iterations,
   if (!h) return COSMO_HIP_ERR_INVALID;
   if (hipSetDevice(h->device) != hipSuccess) return cosmo_fail(h, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
   if (!h->have_problem || !h->have_cones) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "scale_ruiz: set_problem and set_cones first");
+  if (h->row_shard) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "scale_ruiz: not available on a row-sharded handle (scale before cosmo_hip_set_row_shard: [P | A'] is gone and A is a row slice)");
   if (h->has_scaling) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "scale_ruiz: the problem already carries a scaling");
   if (!h->P_symmetric)
     return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "scale_ruiz: P must be structurally and numerically symmetric (the reference's symmetrize_full! is a host step)");

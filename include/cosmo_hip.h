@@ -332,6 +332,13 @@ int32_t cosmo_hip_comm_destroy(cosmo_hip_handle* h);
 /* first_cone[nranks+1]: contiguous partition of the cone indices; call after cosmo_hip_set_cones */
 int32_t cosmo_hip_set_cone_shard(cosmo_hip_handle* h, const int64_t* first_cone);
 int32_t cosmo_hip_comm_selftest(cosmo_hip_handle* h);
+/* Known-answer test of the all-reduce of `count` reals the row-sharded loop relies on (north_star: "RCCL ... for the residual-norm
+ * all-reduce only"; the sums it replaces are src/linear_solver/kktsolver_indirect.jl:52-54 and src/residuals.jl:12-18), through the
+ * loop's own code path.  Collective: every rank calls it with the same count.  out = {elements of an exactly representable sum that
+ * came back wrong, elements of a fractional sum outside nranks * eps * sum |terms|, FNV-1a hash of the fractional result's bytes (must
+ * agree on all ranks: compare it across them), transport (1 RCCL / 2 host-staged), nranks, RCCL version code (0 when host-staged)}.
+ * COSMO_HIP_COMM_CORRUPT_RANK=r (test hook) makes rank r contribute 1.001 x its vector to every all-reduce. */
+int32_t cosmo_hip_comm_allreduce_check(cosmo_hip_handle* h, int64_t count, int64_t out[6]);
 /* Host-staged communicator for functional tests on a single-GPU host: ranks are processes that may share one device (RCCL
  * refuses that), slices travel through the POSIX shared-memory segment `name` ("/..."; rank 0 creates it).  Same ownership,
  * slices and exchange point as the RCCL path; synchronous, never a performance path.  Call after cosmo_hip_set_problem. */
@@ -381,7 +388,10 @@ int32_t cosmo_hip_batch_get_rho_classes(cosmo_hip_batch* b, int64_t k, int32_t* 
 int32_t cosmo_hip_batch_set_iterates(cosmo_hip_batch* b, const cosmo_hip_real* x0, const cosmo_hip_real* s0, const cosmo_hip_real* mu0);
 /* optimize! for every problem; results has nprob entries */
 int32_t cosmo_hip_batch_optimize(cosmo_hip_batch* b, cosmo_hip_result* results);
-/* n_iters more loop bodies (with checks) on every undecided problem; with_init != 0 runs the init step first */
+/* n_iters more loop bodies on every undecided problem, with the residual checks / adaptive-rho checks of the schedule but WITHOUT the
+ * infeasibility certificates (src/solver.jl:326-349): only cosmo_hip_batch_optimize cuts the persistent launch at the iterations the
+ * reference tests at.  A measurement / stepping entry: an infeasible problem driven through it runs on undecided.  with_init != 0 runs
+ * the init step first */
 int32_t cosmo_hip_batch_iterate(cosmo_hip_batch* b, int64_t n_iters, int32_t with_init);
 /* per problem {ADMM iterations, KKT solves, Krylov iterations in total}: out[3 * nprob] (measurement; the counters the reference keeps in
  * IndirectReducedKKTSolver.iteration_counter / multiplications, src/linear_solver/kktsolver_indirect.jl:32,56) */

@@ -71,6 +71,8 @@ def test_single_rank_communicator_rccl_path(dtype):
     model.handle.set_cone_shard(cj.partition_cones_contiguous(cj.cone_costs(model.sets), 1))
     model.handle.set_iterates(model.x, model.s, model.mu)
     model.handle.comm_selftest()                                   # ncclBroadcast on the handle's stream
+    chk = model.handle.comm_allreduce_check(model.n)               # known-answer all-reduce through the loop's exchange path (1 rank: identity)
+    assert chk["exact_mismatches"] == 0 and chk["inexact_outside_bound"] == 0 and chk["transport"] == 1 and chk["nranks"] == 1 and chk["rccl_version_code"] > 20000
     res = cj.optimize(model)
     assert res.status == ref.status and res.iter == ref.iter
     assert np.array_equal(res.x, ref.x) and np.array_equal(res.s, ref.s)
@@ -293,10 +295,40 @@ def test_bench_multi_rank_entry_point_dry_run(workload, shard):
         else:                                                            # the projected PSD slices of s: far more than an n-vector
             assert comm["bytes_per_iteration"] > 8 * 4 * n and comm["collectives_per_iteration"] == 1.0
         assert out["config"]["speedup_vs_single_gpu"] > 0 and "sharded over 2 ranks" in out["config"]["parallelism"]
+        _assert_parity_evidence(out["config"], comm, 1e-7)
         sh = out["config"]["shardable_share_of_single_gpu_iteration"]
         assert 0 < sh["projections"] <= sh["projections_and_row_kernels"] < 1 and 1 < sh["predicted_speedup_bound"] < 2
     else:
         assert out["scaling"] == "strong" and "sharded over 2 rank" in out["config"]["parallelism"]
+        par = out["config"]["parity"]
+        assert par["ok"] is True and par["sharded_vs_single_max_rel_dev"] == 0.0 and par["problems_compared"] == 32     # 16 from each rank's shard
+        rs = out["config"]["rank_seconds"]
+        assert len(rs["per_rank"]) == 2 and 0 < rs["min"] <= rs["max"]
+
+
+def _assert_parity_evidence(cfg, comm, tol):
+    """What VERDICT r03 item 1 asks of every N > 1 line: (a) the known-answer all-reduce right after comm_init, (b) the sharded iterates against
+    rank 0's unsharded run of the same problem, (d) per-rank times, (e) transport and RCCL version."""
+    assert comm["selftest"] == "ok" and comm["exact_sum_mismatches"] == 0 and comm["fractional_sum_outside_bound"] == 0
+    assert comm["result_bits_identical_on_all_ranks"] is True and comm["count"] > 0
+    assert "host-staged" in comm["transport_name"] and comm["rccl_version"] is None            # the dry-run transport (RCCL: "rccl" and a version string)
+    par = cfg["parity"]
+    assert par["ok"] is True and 0.0 <= par["sharded_vs_single_max_rel_dev"] <= tol and par["ranks_bit_identical"] is True
+    assert par["krylov_iterations"]["single"] > 0 and par["krylov_iterations"]["sharded"] > 0
+    rs = cfg["rank_seconds"]
+    assert len(rs["per_rank"]) == 2 and 0 < rs["min"] <= rs["max"]
+
+
+def test_a_corrupted_exchange_turns_the_bench_lines_parity_evidence_red():
+    """COSMO_HIP_COMM_CORRUPT_RANK=1 (test hook in csrc/comm.hip) makes rank 1 contribute 1.001 x its vector to every all-reduce: the known-answer
+    check and the sharded-vs-single deviation of the SAME bench line must both say so -- a throughput number with a wrong exchange cannot pass."""
+    env = dict(os.environ, COSMO_BENCH_TRANSPORT="shm", MASTER_ADDR="127.0.0.1", COSMO_HIP_COMM_CORRUPT_RANK="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--small", "--workload", "cfg5", "--shard", "rows"]
+    out = _one_json_line(subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=420))
+    comm, par = out["config"]["comm"], out["config"]["parity"]
+    assert comm["selftest"].startswith("FAILED") and comm["exact_sum_mismatches"] > 0
+    assert par["ok"] is False and par["sharded_vs_single_max_rel_dev"] > 1e-5
 
 
 def test_bench_gpus_2_without_a_launcher_is_a_two_rank_run_of_the_same_headline_workload():
@@ -321,6 +353,9 @@ def test_bench_gpus_2_without_a_launcher_is_a_two_rank_run_of_the_same_headline_
         assert ex[key]["scaling"] == "strong" and ex[key]["n_gpus"] == 2 and ex[key]["value"] > 0
     c5 = ex["cfg5_sharded"]["config"]
     assert c5["comm"]["nranks"] == 2 and c5["comm"]["mode"] == "rows" and c5["single_gpu_same_workload"] > 0
+    _assert_parity_evidence(c5, c5["comm"], 1e-7)
+    assert ex["cfg3_sharded"]["config"]["parity"]["ok"] is True and ex["cfg3_sharded"]["config"]["parity"]["sharded_vs_single_max_rel_dev"] == 0.0
+    assert len(two["config"]["rank_seconds"]["per_rank"]) == 2
 
 
 def test_bench_reports_the_headline_even_if_a_sharded_extra_never_finishes():
@@ -328,7 +363,7 @@ def test_bench_reports_the_headline_even_if_a_sharded_extra_never_finishes():
     wait in a collective) no line at all would come out of an N-GPU run.  A watchdog prints the headline -- measured before the extras
     start -- with what has been collected and ends every rank.  Here the deadline is zero, so it fires while the first extra is being set up."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
-    env.update(COSMO_BENCH_TRANSPORT="shm", COSMO_BENCH_EXTRA_TIMEOUT="0.05")
+    env.update(COSMO_BENCH_TRANSPORT="shm", COSMO_BENCH_EXTRA_TIMEOUT="0.05", COSMO_BENCH_EXTRA_GRACE="3")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--small", "--no-cpu-baseline", "--no-float32"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     two = _one_json_line(r)
