@@ -527,7 +527,7 @@ def cfg5_sharded_parity_leg(ctx, args, prob, iters=12):
       ranks_bit_identical: every rank's gathered (w, s) hashes to the same value (the replicated n-side and the all-gathered rows).
     The loop being sharded: src/convexset.jl:885-891 (projections), src/linear_solver/kktsolver_indirect.jl:52-54, 81-83 (the A' / A products)."""
     import cosmo_jl_amd as cj
-    st = fixed_work_settings(cj, tol_constant=1e-10, tol_exponent=0.0); st.device = ctx.local_rank
+    st = fixed_work_settings(cj, kkt_solver=cj.with_options(cj.CGIndirectKKTSolver, tol_constant=1e-10, tol_exponent=0.0)); st.device = ctx.local_rank
     ref = None
     if ctx.rank == 0:
         m1 = cj.Model(); m1.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)
@@ -701,28 +701,86 @@ def bench_cfg5(ctx, args, steps, warmup):
                 predicted_speedup_bound=round(1.0 / ((1.0 - f) + f / ctx.world), 3),
                 note="f = (event-timed ms per iteration of the kernels that shard) / (unprofiled ms per iteration of the same 1-GPU run); bound "
                      "1 / ((1 - f) + f / N) ignores the exchange and load imbalance; the replicated rest is the n-side CG + dual check")
+    # ---- roofline: the kernel class with the largest share of the step's time is named first, the other under `other` ----------------------
+    ms_step = 1e3 * elapsed / steps
+    products = None
     if ps["batch_cones"] > 0:
-        t_prod, fl = h.time_psd_product(1, 20)
+        # the product kernel timed as the IN-LOOP MIX: per repetition one Y = U^2 and the two alpha A B + beta Cin products of a step of the sign
+        # iteration with their real operands (time_psd_product mode 2), not back-to-back launches of the cheapest flavour
+        t_prod, fl = h.time_psd_product(2, 20)
+        t_sq, _ = h.time_psd_product(1, 20)
         own = dk if ctx.world == 1 else None                      # rank 0's cliques only in sharded runs: useful flops not attributed there
         useful_prod = float(np.sum(dk * dk * (dk + 1.0))) if own is not None else None
-        out["roofline"] = dict(bound="mfma", kernel="k_symm_gemm_batch_r<EPI, 4> (ragged block-balanced tiles: one workgroup per list of <= 16 blocks of 16 x 16 of one of rank 0's "
-                                                    "cliques; upper blocks only on the diagonal; four workgroups per CU, tiles launched by decreasing cost)",
-                               useful_flops_per_launch=useful_prod, performed_over_useful=(round(fl / useful_prod, 3) if useful_prod else None),
-                               useful_frac_per_product=(round(useful_prod / t_prod / 1e12 / F64_MFMA_PEAK_TF, 4) if useful_prod else None),
-                               achieved=round(fl / t_prod / 1e12, 2), peak=F64_MFMA_PEAK_TF, unit="TFLOP/s", frac=round(fl / t_prod / 1e12 / F64_MFMA_PEAK_TF, 4), traffic=None,
-                               peak_sustained_measured=F64_MFMA_SUSTAINED_TF, frac_of_sustained=round(fl / t_prod / 1e12 / F64_MFMA_SUSTAINED_TF, 4),
-                               flops_per_launch=fl, avg_launch_us=round(1e6 * t_prod, 2), launches_timed=20, products_per_projection=ps["products_last_batch"],
-                               # the other roof of the same launch: Y = U^2 reads U once and writes Y once (8 B x sum d^2 each; operands that are distinct
-                               # matrices and the Cin of the alpha A B + beta Cin products add 8 B x sum d^2 apiece)
-                               hbm_algorithmic_bytes_per_launch=(16.0 * float(np.sum(dk * dk)) if own is not None else None),
-                               hbm_frac_algorithmic=(round(16.0 * float(np.sum(dk * dk)) / t_prod / 1e9 / HBM_PEAK_GBS, 4) if own is not None else None),
-                               useful_tflops_reference_algorithm=round(useful * value / 1e12, 3), useful_frac_of_peak=round(useful * value / 1e12 / F64_MFMA_PEAK_TF, 5))
+        nprod = ps["products_last_batch"]
+        products = dict(bound="mfma", kernel="k_symm_gemm_batch_r<EPI, 4> (ragged block-balanced tiles: one workgroup per list of <= 16 blocks of 16 x 16 of one of rank 0's "
+                                            "cliques; upper blocks only on the diagonal; four workgroups per CU, tiles launched by decreasing cost)",
+                        timing="in-loop mix: 20 x (Y = U^2, T = c Y^2 + b Y, U' = U T + a U) on the batch's work matrices, HIP events on the library's stream",
+                        useful_flops_per_launch=useful_prod, performed_over_useful=(round(fl / useful_prod, 3) if useful_prod else None),
+                        useful_frac_per_product=(round(useful_prod / t_prod / 1e12 / F64_MFMA_PEAK_TF, 4) if useful_prod else None),
+                        achieved=round(fl / t_prod / 1e12, 2), peak=F64_MFMA_PEAK_TF, unit="TFLOP/s", frac=round(fl / t_prod / 1e12 / F64_MFMA_PEAK_TF, 4), traffic=None,
+                        peak_sustained_measured=F64_MFMA_SUSTAINED_TF, frac_of_sustained=round(fl / t_prod / 1e12 / F64_MFMA_SUSTAINED_TF, 4),
+                        flops_per_launch=fl, avg_launch_us=round(1e6 * t_prod, 2), avg_launch_us_square_only=round(1e6 * t_sq, 2), launches_timed=60,
+                        products_per_projection=nprod, share_of_step=round(nprod * 1e3 * t_prod / ms_step, 4),
+                        # the other roof of the same launch: Y = U^2 reads U once and writes Y once (8 B x sum d^2 each); the alpha A B + beta Cin products
+                        # read up to three distinct matrices: 2 / 3 / 4 x 8 B x sum d^2 for the three launches of a step => 3 matrices per product on average
+                        hbm_algorithmic_bytes_per_launch=(24.0 * float(np.sum(dk * dk)) if own is not None else None),
+                        hbm_frac_algorithmic=(round(24.0 * float(np.sum(dk * dk)) / t_prod / 1e9 / HBM_PEAK_GBS, 4) if own is not None else None),
+                        useful_tflops_reference_algorithm=round(useful * value / 1e12, 3), useful_frac_of_peak=round(useful * value / 1e12 / F64_MFMA_PEAK_TF, 5))
+    krylov = None
+    if ctx.world == 1:
+        try:
+            t_k, b_k, nl = min(h.time_krylov(200) for _ in range(3))
+            fs = h.fold_stats()
+            krylov = dict(bound="latency", kernel=("k_cg_dirM<%d> + k_cg_upd: ONE Krylov iteration of cg! on the assembled reduced operator M = P + sigma I + A' rho A "
+                                                   "(%d nonzeros), %d launches" % (4, fs["nnz"], nl)) if fs["enabled"] else "one Krylov iteration of cg! (%d launches)" % nl,
+                          achieved=round(b_k / t_k / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(b_k / t_k / 1e9 / HBM_PEAK_GBS, 4), traffic=None,
+                          algorithmic_bytes_per_launch=b_k, avg_launch_us=round(1e6 * t_k, 3), launches_timed=200,
+                          timing="best of 3 x 200 Krylov iterations as the loop enqueues them (captured chain), tolerance 0, HIP events on the library's stream; "
+                                 "'launch' = one Krylov iteration = %d dependent kernels incl. their boundaries" % nl,
+                          krylov_iterations_per_step=round(kbar, 2), share_of_step=round(kbar * 1e3 * t_k / ms_step, 4),
+                          note="a chain of dependent round trips on a working set that stays in L2 / Infinity Cache: the HBM fraction is reported because the "
+                               "contract asks for it; what bounds the pair is launch + load latency, not bandwidth")
+        except Exception as e:
+            krylov = dict(error="%s: %s" % (type(e).__name__, e))
+    cands = [r for r in (krylov, products) if r and "share_of_step" in r]
+    if cands:
+        cands.sort(key=lambda r: -r["share_of_step"])
+        out["roofline"] = dict(cands[0])
+        if len(cands) > 1:
+            out["roofline"]["other"] = {cands[1]["kernel"].split(" ")[0]: cands[1]}
+    elif products:
+        out["roofline"] = products
     if not args.no_cpu_baseline and ctx.world == 1:
         args.deferred.append(lambda out=out, prob=prob: out.__setitem__("cpu_baseline", compiled_cpu_baseline(prob, 2 if not args.small else 10, "cfg5", "cfg5", args,
                                                                                                                 iters_all=1 if not args.small else 10)))
-    if ctx.world == 1 and not args.no_float32:
+    if ctx.world == 1:
         h.close()
+        try:
+            out["pcg"] = jacobi_pcg_extra(ctx, args, prob, steps, warmup)
+        except Exception as e:
+            out["pcg"] = dict(error="%s: %s" % (type(e).__name__, e))
+    if ctx.world == 1 and not args.no_float32:
         out["float32"] = float32_extra(ctx, args, prob, st, steps, warmup)
+    h.close()
+    return out
+
+
+def jacobi_pcg_extra(ctx, args, prob, steps, warmup):
+    """The same workload with the OPT-IN Jacobi-preconditioned CG (kkt_kind CG_JACOBI; IterativeSolvers' PCGIterable with Pl = diag of the reduced
+    operator): a DIFFERENT Krylov method for the same systems under the same true-residual stopping rule -- the reference passes no preconditioner
+    (src/linear_solver/kktsolver_indirect.jl:70), so this number stands NEXT to the literal-cg! contract number, never in its place."""
+    import cosmo_jl_amd as cj
+    st = fixed_work_settings(cj, kkt_solver=cj.CGJacobiKKTSolver); st.device = ctx.local_rank
+    md = cj.Model(); md.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)
+    h, el, kb = _run_sdp(ctx, md, steps, warmup)
+    out = dict(value=round(steps / el, 3), ms_per_step=round(1e3 * el / steps, 6), steps=steps, warmup=warmup, unit="ADMM iterations/s", dtype="f64",
+               kkt_solver="CG, Jacobi-preconditioned (OPT-IN kkt_kind CG_JACOBI; same operator, warm start and stopping rule ||r||_2 <= tol_k / ||rhs||)",
+               mean_cg_iters_per_admm_iter=round(kb, 3))
+    try:
+        t_k, b_k, nl = min(h.time_krylov(200) for _ in range(3))
+        out["us_per_krylov_iteration"] = round(1e6 * t_k, 3)
+    except Exception as e:
+        out["us_per_krylov_iteration"] = "%s: %s" % (type(e).__name__, e)
     h.close()
     return out
 

@@ -22,7 +22,7 @@ ZERO, NONNEG, BOX, SOC, PSD_SQUARE, PSD_TRIANGLE = 0, 1, 2, 3, 4, 5
 EXP, DUAL_EXP, POW, DUAL_POW = 6, 7, 8, 9
 PSD_TRIANGLE_COMPLEX = 10
 CUSTOM = 11
-KKT_CG, KKT_MINRES_REDUCED, KKT_MINRES, KKT_CG_SR = 0, 1, 2, 3
+KKT_CG, KKT_MINRES_REDUCED, KKT_MINRES, KKT_CG_SR, KKT_CG_JACOBI = 0, 1, 2, 3, 4
 STATUS_NAMES = {0: "Undetermined", 1: "Solved", 2: "Max_iter_reached", 3: "Unsolved", 4: "Primal_infeasible",
                 5: "Dual_infeasible", 6: "Time_limit_reached"}
 MAT_A, MAT_AT, MAT_P, MAT_OP = 0, 1, 2, 3
@@ -109,6 +109,7 @@ SIGNATURES = {
     "cosmo_hip_comm_init": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]),
     "cosmo_hip_comm_destroy": (C.c_int32, [C.c_void_p]),
     "cosmo_hip_set_cone_shard": (C.c_int32, [C.c_void_p, _PI64]),
+    "cosmo_hip_time_krylov": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "cosmo_hip_comm_selftest": (C.c_int32, [C.c_void_p]),
     "cosmo_hip_comm_allreduce_check": (C.c_int32, [C.c_void_p, C.c_int64, _PI64]),
     "cosmo_hip_comm_init_hostshm": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p]),
@@ -454,6 +455,12 @@ class Handle:
 
     def comm_selftest(self):
         self._chk(self.lib.cosmo_hip_comm_selftest(self._h))
+
+    def time_krylov(self, reps):
+        """(seconds per Krylov iteration incl. the kernel boundaries between its launches, algorithmic bytes per iteration, launches per iteration)."""
+        t, b, nl = C.c_double(0.0), C.c_double(0.0), C.c_int32(0)
+        self._chk(self.lib.cosmo_hip_time_krylov(self._h, int(reps), C.byref(t), C.byref(b), C.byref(nl)))
+        return t.value, b.value, nl.value
 
     def comm_allreduce_check(self, count):
         """Known-answer all-reduce of `count` reals through the loop's own exchange path (collective: all ranks call it).  The caller compares

@@ -559,14 +559,15 @@ extern "C" int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_par
   if (h->row_shard) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "set_params: not available on a row-sharded handle");
   if (!p) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "null params");
   if (!h->have_cones) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_cones must be called before set_params");
-  if (p->kkt_kind < COSMO_HIP_KKT_CG || p->kkt_kind > COSMO_HIP_KKT_CG_SR) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "bad kkt_kind");
+  if (p->kkt_kind < COSMO_HIP_KKT_CG || p->kkt_kind > COSMO_HIP_KKT_CG_JACOBI) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "bad kkt_kind");
   if (p->check_termination <= 0) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "check_termination must be > 0");
   if (p->adaptive_rho && p->adaptive_rho_interval == 0)
     return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "adaptive_rho_interval == 0 (wall-clock rule, solver.jl:244-256) is not supported");
   const bool reclass = (p->cosmo_infty_min_scaling != h->prm.cosmo_infty_min_scaling) || (p->rho_tol != h->prm.rho_tol);
   h->prm = *p;
   h->cg_sr = (p->kkt_kind == COSMO_HIP_KKT_CG_SR);
-  if (h->cg_sr) h->prm.kkt_kind = COSMO_HIP_KKT_CG;      // the same reduced operator, split, budget and tail; only the Krylov recurrence differs
+  h->cg_jacobi = (p->kkt_kind == COSMO_HIP_KKT_CG_JACOBI);
+  if (h->cg_sr || h->cg_jacobi) h->prm.kkt_kind = COSMO_HIP_KKT_CG;      // the same reduced operator, split, budget and tail; only the Krylov recurrence differs
   if (reclass) {
     std::vector<real> bhost((size_t)h->m);
     CHK(d2h(h, bhost.data(), h->b, (size_t)h->m));
@@ -596,6 +597,12 @@ extern "C" int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_par
     if (const char* e = getenv("COSMO_HIP_CG_FUSE_DIR")) fuse = fuse && atoi(e) != 0;
     if (fuse) CHK(dalloc(h, &h->cg_ru, 2 * (size_t)h->n)); }
   CHK(build_op_split(h));     // needs the (scaled) matrices and rho: both final from here on
+  if (h->cg_jacobi) {
+    // the opt-in Jacobi-preconditioned CG lives on the ASSEMBLED reduced operator (its diagonal is the preconditioner): no silent fallback to the
+    // unpreconditioned recurrence when the operator cannot be assembled (dense A' rho A: BASELINE config 2, where Jacobi makes the count worse anyway)
+    if (!h->op_fold) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "kkt_kind CG_JACOBI needs the assembled reduced operator (csrc/cg_fold.hip: A' rho A too dense here, or COSMO_HIP_OP_FOLD=0 / COSMO_HIP_CG_FUSE_DIR=0)");
+    return COSMO_HIP_OK;
+  }
   return pcg_setup(h);        // single-launch CG (opt-in)
 }
 
@@ -1337,6 +1344,55 @@ extern "C" int32_t cosmo_hip_time_spmv(cosmo_hip_handle* h, int32_t which, int32
   *avg_seconds = (double)ms * 1e-3 / reps;
   if (algorithmic_bytes) *algorithmic_bytes = bytes;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_time_krylov(cosmo_hip_handle* h, int32_t reps, double* avg_seconds, double* algorithmic_bytes, int32_t* launches_per_iteration) {
+  ENTER(h);
+  if (!h->have_params || !h->have_iterates || reps <= 0 || !avg_seconds) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "time_krylov: set up the loop first");
+  if (h->prm.kkt_kind != COSMO_HIP_KKT_CG || h->cg_sr || h->pcg_on || h->row_shard) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "time_krylov: the literal / Jacobi CG of the loop on an unsharded handle only");
+  CHK(sync_ctl(h));
+  if (h->ctl_host->halt) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "time_krylov: the loop is halted");
+  const long long n = h->n, m = h->m;
+  real* keep = nullptr;
+  HIPCHK(h, hipMalloc((void**)&keep, sizeof(real) * (size_t)std::max<long long>(n, 1)));
+  HIPCHK(h, hipMemcpyAsync(keep, h->x_tl, sizeof(real) * (size_t)n, hipMemcpyDeviceToDevice, h->stream));
+  hipEvent_t e0, e1;
+  HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+  const long long sp[3] = {h->spmv_calls[0], h->spmv_calls[1], h->spmv_calls[2]};
+  int32_t rc = enqueue_y2_only(h);                             // resets the per-solve flags (y2 = rho .* ls_s is recomputed to the same values)
+  if (rc == COSMO_HIP_OK) rc = enqueue_cg_start(h, 1, R(0.0)); // tolerance 0: every one of the `reps` iterations does full work
+  if (rc == COSMO_HIP_OK && hipEventRecord(e0, h->stream) != hipSuccess) rc = cosmo_fail(h, COSMO_HIP_ERR_HIP, "hipEventRecord failed");
+  const int likely = h->cg_k_likely;
+  h->cg_k_likely = 0x7fffffff;
+  if (rc == COSMO_HIP_OK) rc = enqueue_cg_iterations(h, 1, 0, reps);
+  h->cg_k_likely = likely;
+  if (rc == COSMO_HIP_OK && hipEventRecord(e1, h->stream) != hipSuccess) rc = cosmo_fail(h, COSMO_HIP_ERR_HIP, "hipEventRecord failed");
+  if (rc == COSMO_HIP_OK && hipEventSynchronize(e1) != hipSuccess) rc = cosmo_fail(h, COSMO_HIP_ERR_HIP, "hipEventSynchronize failed");
+  float ms = 0.f;
+  if (rc == COSMO_HIP_OK) (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  // restore: the warm start of the next solve, the multiplication counters; r / u / c / the records are rewritten by every solve start
+  (void)hipMemcpyAsync(h->x_tl, keep, sizeof(real) * (size_t)n, hipMemcpyDeviceToDevice, h->stream);
+  (void)hipStreamSynchronize(h->stream);
+  (void)hipFree(keep);
+  h->spmv_calls[0] = sp[0]; h->spmv_calls[1] = sp[1]; h->spmv_calls[2] = sp[2];
+  if (rc != COSMO_HIP_OK) return rc;
+  *avg_seconds = (double)ms * 1e-3 / reps;
+  double bytes; int nl;
+  if (h->op_fold) {
+    const FoldPlan* f = (const FoldPlan*)h->fold;
+    bytes = 12.0 * (double)f->M.nnz + 4.0 * (n + 1) + 16.0 * n + 8.0 * 10.0 * n;       // B_spmv(M) + B_cgvec (n-side); Jacobi adds dinv: + 8 n
+    if (h->cg_jacobi) bytes += 8.0 * n;
+    nl = 2;
+  } else {
+    const CsrDev& Ao = h->op_split ? h->Am : h->A;
+    const CsrDev& PTo = h->op_split ? h->PTm : h->PT;
+    bytes = (12.0 * Ao.nnz + 4.0 * (Ao.nrows + 1) + 8.0 * n + 8.0 * Ao.nrows) + (12.0 * PTo.nnz + 8.0 * (n + 1) + 8.0 * (n + Ao.nrows) + 8.0 * n) + 8.0 * (10.0 * n + m);
+    nl = h->cg_ru ? 3 : 4;
+  }
+  if (algorithmic_bytes) *algorithmic_bytes = bytes;
+  if (launches_per_iteration) *launches_per_iteration = nl;
   return COSMO_HIP_OK;
 }
 

@@ -49,13 +49,23 @@ __global__ __launch_bounds__(COSMO_BS) void k_fold_refresh(long long nnz, const 
   }
 }
 
+// Jacobi preconditioner of the opt-in PCG: dinv_i = 1 / M_ii, read from the assembled values (dpos[i] = index of row i's diagonal entry,
+// which fold_build always stores) right after every k_fold_refresh
+__global__ __launch_bounds__(COSMO_BS) void k_fold_dinv(long long n, const int* __restrict__ dpos, const real* __restrict__ val, real* __restrict__ dinv) {
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < n; i += (long long)gridDim.x * COSMO_BS) dinv[i] = R(1.0) / val[dpos[i]];
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // solve start: r = rhs - M x (x = warm start), {r, 0} records for the first direction, partials of r'r, abstol = tol_k / ||rhs||
 // (kktsolver_indirect.jl:70 ; cg! computes the initial residual with one operator application)
 // ---------------------------------------------------------------------------------------------------------------------
+// PC (opt-in Jacobi-preconditioned CG, COSMO_HIP_KKT_CG_JACOBI; IterativeSolvers' PCGIterable with Pl = Diagonal(diag M)): the records carry
+// {z_i, u_i} with z = dinv .* r instead of {r_i, u_i}, and a second set of partials holds z'r.
+template <bool PC>
 __global__ __launch_bounds__(COSMO_BS) void k_fold_start(Ctl* __restrict__ ctl, int guard, CsrView M, const real* __restrict__ x,
                                                          const real* __restrict__ rhs, real* __restrict__ r, real2* __restrict__ ru,
-                                                         real* __restrict__ part_rr, const real* __restrict__ part_bb, int n_bb, real tol_k) {
+                                                         real* __restrict__ part_rr, const real* __restrict__ part_bb, int n_bb, real tol_k,
+                                                         const real* __restrict__ dinv, real* __restrict__ part_rz) {
   if (guard && ctl->halt) return;
   __shared__ real lds[COSMO_NNZ_PER_BLOCK];
   __shared__ real red[COSMO_BS / 64];
@@ -67,18 +77,28 @@ __global__ __launch_bounds__(COSMO_BS) void k_fold_start(Ctl* __restrict__ ctl, 
       ctl->tol = tol_k / nb;
     }
   }
-  real acc = 0.0;
+  real acc = 0.0, accz = 0.0;
   const int first_tile = tile_of_block(blockIdx.x, M.nb, M.xcd_affine);
   for (int k = first_tile; k < M.nb; k += gridDim.x) {
     csr_stream_tile(M, x, x, k, lds, red, [&](int row, real s1, real s2) {
       const real rj = rhs[row] - (s1 + s2);
       r[row] = rj;
-      if (ru) ru[row] = make_real2(rj, R(0.0));
+      if constexpr (PC) {
+        const real zj = dinv[row] * rj;                       // ldiv!(c, Pl, r)
+        ru[row] = make_real2(zj, R(0.0));
+        accz += zj * rj;
+      } else {
+        if (ru) ru[row] = make_real2(rj, R(0.0));
+      }
       acc += rj * rj;
     });
   }
   acc = block_sum(acc, red);
   if (threadIdx.x == 0) part_rr[M.xcd_affine ? first_tile : (int)blockIdx.x] = acc;
+  if constexpr (PC) {
+    accz = block_sum(accz, red);
+    if (threadIdx.x == 0) part_rz[M.xcd_affine ? first_tile : (int)blockIdx.x] = accz;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -90,12 +110,17 @@ __global__ __launch_bounds__(COSMO_BS) void k_fold_start(Ctl* __restrict__ ctl, 
 // ---------------------------------------------------------------------------------------------------------------------
 // SL = nonzero slots per thread of the register-staged first tile (tiles of the assembled matrix hold at most SL * 256 nonzeros; a
 // longer single row takes the generic path).
-template <int SL>
+// PC: beta = rho_k / rho_{k-1} with rho = z'r from the second partial set (ctl->sr_gamma, by iteration parity: the single-reduction CG that
+// otherwise owns those two scalars is a different kkt_kind), u_k = z + beta u_{k-1} from the {z, u} records; the stopping rule stays ||r||_2.
+template <int SL, bool PC>
 __global__ __launch_bounds__(COSMO_BS) void k_cg_dirM(Ctl* __restrict__ ctl, int guard, int check_first, int k, long long n, long long maxiter,
                                                       const real* __restrict__ part_rr, int n_rr, CsrView M, const real2* __restrict__ ru,
-                                                      real* __restrict__ c, real* __restrict__ u, real* __restrict__ part_uc) {
+                                                      real* __restrict__ c, real* __restrict__ u, real* __restrict__ part_uc,
+                                                      const real* __restrict__ part_rz) {
   if (check_first) { if (guard && ctl->halt) return; if (ctl->cg_done) return; }   // expected no-op (see k_cg_dirA): flags before any request
   const real pa = partials_prefetch_sum(part_rr, n_rr);
+  real pz = 0.0;
+  if constexpr (PC) pz = partials_prefetch_sum(part_rz, n_rr);
   const int first_tile = tile_of_block(blockIdx.x, M.nb, M.xcd_affine);
   const bool have_tile = first_tile < M.nb;
   int4 d = make_int4(0, 0, 0, 0);
@@ -136,7 +161,13 @@ __global__ __launch_bounds__(COSMO_BS) void k_cg_dirM(Ctl* __restrict__ ctl, int
     ctl->cg_kd = k;
   }
   if (done) return;
-  const real beta = (res * res) / (prev * prev);
+  real beta = (res * res) / (prev * prev);
+  if constexpr (PC) {
+    const real rz = block_sum(pz, red);
+    const real rz_prev = (k == 0) ? R(1.0) : ctl->sr_gamma[(k - 1) & 1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->sr_gamma[k & 1] = rz;
+    beta = rz / rz_prev;
+  }
   if (i0 < n) u[i0] = own.x + beta * own.y;
   for (long long i = i0 + (long long)gridDim.x * COSMO_BS; i < n; i += (long long)gridDim.x * COSMO_BS) {
     const real2 v = ru[i];
@@ -190,6 +221,8 @@ void fold_free(cosmo_hip_handle* h) {
   if (f->tptr) (void)hipFree(f->tptr);
   if (f->trow) (void)hipFree(f->trow);
   if (f->tprod) (void)hipFree(f->tprod);
+  if (f->dpos) (void)hipFree(f->dpos);
+  if (f->dinv) (void)hipFree(f->dinv);
   if (f->chain) (void)hipGraphExecDestroy((hipGraphExec_t)f->chain);
   if (f->chain_cf) (void)hipGraphExecDestroy((hipGraphExec_t)f->chain_cf);
   delete f;
@@ -277,6 +310,10 @@ int32_t fold_build(cosmo_hip_handle* h, const HostCsr& Am, const std::vector<int
   if (const char* e = getenv("COSMO_HIP_FOLD_TILE")) { const int v = atoi(e); if (v >= 64 && v <= COSMO_NNZ_PER_BLOCK) tile = v; }
   CHK(upload_csr(h, M, f->M, (int)n, tile));
   f->slots = tile == 0 ? 8 : tile <= COSMO_BS ? 1 : tile <= 2 * COSMO_BS ? 2 : tile <= 4 * COSMO_BS ? 4 : 8;
+  { std::vector<int> dpos((size_t)n, 0);                        // every row has its diagonal entry (the three-way merge adds it)
+    for (size_t pz = 0; pz < drow.size(); ++pz) if (drow[pz] >= 0) dpos[(size_t)drow[pz]] = (int)pz;
+    CHK(up(h, &f->dpos, dpos));
+    HIPCHK(h, hipMalloc((void**)&f->dinv, sizeof(real) * (size_t)n)); }
   CHK(up(h, &f->base, base)); CHK(up(h, &f->drow, drow)); CHK(up(h, &f->tptr, tptr)); CHK(up(h, &f->trow, trow)); CHK(up(h, &f->tprod, tprod));
   h->op_fold = true;
   return COSMO_HIP_OK;
@@ -287,6 +324,8 @@ int32_t fold_refresh(cosmo_hip_handle* h) {
   if (!h->op_fold || !f) return COSMO_HIP_OK;
   hipLaunchKernelGGL(k_fold_refresh, dim3(ew_grid(f->M.nnz)), dim3(COSMO_BS), 0, h->stream, f->M.nnz, f->base, f->drow, f->tptr, f->trow,
                      f->tprod, h->op_rho_m, h->op_diag, h->prm.sigma, f->M.val);
+  if (h->cg_jacobi)
+    hipLaunchKernelGGL(k_fold_dinv, dim3(ew_grid(h->n)), dim3(COSMO_BS), 0, h->stream, h->n, f->dpos, f->M.val, f->dinv);
   HIPCHK(h, hipGetLastError());
   return COSMO_HIP_OK;
 }
@@ -294,8 +333,12 @@ int32_t fold_refresh(cosmo_hip_handle* h) {
 int32_t fold_enqueue_start(cosmo_hip_handle* h, int guard, real tol_k) {
   FoldPlan* f = (FoldPlan*)h->fold;
   prof_begin(h, KC_OP_APPLY);
-  hipLaunchKernelGGL(k_fold_start, dim3(f->M.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, view_of(f->M), h->x_tl, h->rhs, h->r,
-                     (real2*)h->cg_ru, PARTS(h, SLOT_RR), PARTS(h, SLOT_BB), h->n_bb, tol_k);
+  if (h->cg_jacobi)
+    hipLaunchKernelGGL(k_fold_start<true>, dim3(f->M.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, view_of(f->M), h->x_tl, h->rhs, h->r,
+                       (real2*)h->cg_ru, PARTS(h, SLOT_RR), PARTS(h, SLOT_BB), h->n_bb, tol_k, (const real*)f->dinv, PARTS(h, SLOT_AUX2));
+  else
+    hipLaunchKernelGGL(k_fold_start<false>, dim3(f->M.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, view_of(f->M), h->x_tl, h->rhs, h->r,
+                       (real2*)h->cg_ru, PARTS(h, SLOT_RR), PARTS(h, SLOT_BB), h->n_bb, tol_k, (const real*)nullptr, (real*)nullptr);
   prof_end(h);
   h->spmv_calls[0] += 1; h->spmv_calls[1] += 2; h->spmv_calls[2] += 1;     // the reference's multiplication count (A' y2 of the rhs + reduced_mul! = A, A', P)
   HIPCHK(h, hipGetLastError());
@@ -305,8 +348,9 @@ int32_t fold_enqueue_start(cosmo_hip_handle* h, int guard, real tol_k) {
 static void fold_launch_pair(cosmo_hip_handle* h, FoldPlan* f, int guard, int k, int n_rr, int check_first = 0) {
   const long long n = h->n;
   prof_begin(h, KC_OP_APPLY);
-#define LAUNCH_DIRM(SLN) hipLaunchKernelGGL((k_cg_dirM<SLN>), dim3(f->M.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, check_first, k, n, n, \
-                         PARTS(h, SLOT_RR), n_rr, view_of(f->M), (const real2*)h->cg_ru, h->c, h->u, PARTS(h, SLOT_UC))
+#define LAUNCH_DIRM_(SLN, PCF) hipLaunchKernelGGL((k_cg_dirM<SLN, PCF>), dim3(f->M.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, check_first, k, n, n, \
+                         PARTS(h, SLOT_RR), n_rr, view_of(f->M), (const real2*)h->cg_ru, h->c, h->u, PARTS(h, SLOT_UC), (const real*)PARTS(h, SLOT_AUX2))
+#define LAUNCH_DIRM(SLN) do { if (h->cg_jacobi) LAUNCH_DIRM_(SLN, true); else LAUNCH_DIRM_(SLN, false); } while (0)
   switch (f->slots) {
     case 1: LAUNCH_DIRM(1); break;
     case 2: LAUNCH_DIRM(2); break;
@@ -314,6 +358,7 @@ static void fold_launch_pair(cosmo_hip_handle* h, FoldPlan* f, int guard, int k,
     default: LAUNCH_DIRM(8); break;
   }
 #undef LAUNCH_DIRM
+#undef LAUNCH_DIRM_
   prof_end(h);
   (void)launch_cg_upd(h, guard, k, f->M.grid);
 }

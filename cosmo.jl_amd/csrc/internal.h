@@ -93,6 +93,8 @@ struct FoldPlan {
   int* tptr = nullptr;      // nnz(M)+1: terms of entry p are [tptr[p], tptr[p+1])
   int* trow = nullptr;      // term -> row of Am
   real* tprod = nullptr;  // term -> a_ki * a_kj
+  int* dpos = nullptr;      // n: index of row i's diagonal entry in M.val
+  real* dinv = nullptr;   // n: 1 / M_ii, the Jacobi preconditioner of the opt-in PCG (refreshed with the values)
   long long nterms = 0;
   // captured chain of speculative Krylov iterations (cg_fold.hip: fold_enqueue_iterations)
   void* chain = nullptr;    // hipGraphExec_t
@@ -179,6 +181,7 @@ struct cosmo_hip_handle {
   void* accel = nullptr;          // AaState (anderson.hip)
   long long safeguarding_iter = 0;
   bool cg_sr = false;             // kkt_kind COSMO_HIP_KKT_CG_SR: single-reduction (Chronopoulos-Gear) CG, cg_sr.hip
+  bool cg_jacobi = false;  // kkt_kind CG_JACOBI: opt-in Jacobi-preconditioned CG on the assembled operator (cg_fold.hip)
   void* sr_rec = nullptr;         // 2 n records {r, w, s, p}
   real* cg_ru = nullptr;        // {r_i, u_i} interleaved (2n doubles): operands of the fused direction + A-product kernel (k_cg_dirA); null = unfused
   // persistent single-launch CG (cg_persist.hip)

@@ -351,14 +351,18 @@ __global__ __launch_bounds__(COSMO_BS) void k_cg_dirA(Ctl* __restrict__ ctl, int
 }
 
 // Krylov step k, second half: alpha = res_k^2 / (u.c) ; x += alpha u ; r -= alpha c ; partial sum r^2
+// PC (opt-in Jacobi PCG on the assembled operator, cg_fold.hip): alpha = rho_k / (u.c) with rho_k = z'r (ctl->sr_gamma), the records become
+// {z_{k+1}, u_k} with z = dinv .* r, and the partials of z'r go to part_rz.
+template <bool PC>
 __global__ __launch_bounds__(COSMO_BS) void k_cg_upd(Ctl* __restrict__ ctl, int guard, int k, long long n,
                                                      const real* __restrict__ part_uc, int n_uc,
                                                      const real* __restrict__ u, const real* __restrict__ c,
                                                      real* __restrict__ x, real* __restrict__ r,
-                                                     real* __restrict__ part_rr, real2* __restrict__ ru) {
+                                                     real* __restrict__ part_rr, real2* __restrict__ ru,
+                                                     const real* __restrict__ dinv, real* __restrict__ part_rz) {
   const long long i0 = (long long)blockIdx.x * COSMO_BS + threadIdx.x;
-  real u0 = 0.0, c0 = 0.0, x0 = 0.0, r0 = 0.0;
-  if (i0 < n) { u0 = u[i0]; c0 = c[i0]; x0 = x[i0]; r0 = r[i0]; }   // issued before the scalar work (latency overlap)
+  real u0 = 0.0, c0 = 0.0, x0 = 0.0, r0 = 0.0, d0 = 0.0;
+  if (i0 < n) { u0 = u[i0]; c0 = c[i0]; x0 = x[i0]; r0 = r[i0]; if constexpr (PC) d0 = dinv[i0]; }   // issued before the scalar work (latency overlap)
   const real pa = partials_prefetch_sum(part_uc, n_uc);
   if (guard && ctl->halt) return;
   if (ctl->cg_done) return;
@@ -366,13 +370,20 @@ __global__ __launch_bounds__(COSMO_BS) void k_cg_upd(Ctl* __restrict__ ctl, int 
   if (k < 0) k = ctl->cg_kd;                     // device-side index: published by the k_cg_dirM in front (cg_k itself is rewritten below by workgroup 0)
   const real res = ctl->resv[k & 1];
   const real uc = block_sum(pa, red);
-  const real alpha = (res * res) / uc;
-  real acc = 0.0;
+  real alpha = (res * res) / uc;
+  if constexpr (PC) alpha = ctl->sr_gamma[k & 1] / uc;
+  real acc = 0.0, accz = 0.0;
   if (i0 < n) {
     x[i0] = x0 + alpha * u0;
     const real ri = r0 - alpha * c0;
     r[i0] = ri;
-    if (ru) ru[i0] = make_real2(ri, u0);       // {r_{k+1}, u_k}: the operands of the fused direction + product kernel
+    if constexpr (PC) {
+      const real zi = d0 * ri;
+      ru[i0] = make_real2(zi, u0);
+      accz += zi * ri;
+    } else {
+      if (ru) ru[i0] = make_real2(ri, u0);     // {r_{k+1}, u_k}: the operands of the fused direction + product kernel
+    }
     acc += ri * ri;
   }
   for (long long i = i0 + (long long)gridDim.x * COSMO_BS; i < n; i += (long long)gridDim.x * COSMO_BS) {
@@ -380,12 +391,20 @@ __global__ __launch_bounds__(COSMO_BS) void k_cg_upd(Ctl* __restrict__ ctl, int 
     x[i] = x[i] + alpha * ui;
     const real ri = r[i] - alpha * c[i];
     r[i] = ri;
-    if (ru) ru[i] = make_real2(ri, ui);
+    if constexpr (PC) {
+      const real zi = dinv[i] * ri;
+      ru[i] = make_real2(zi, ui);
+      accz += zi * ri;
+    } else {
+      if (ru) ru[i] = make_real2(ri, ui);
+    }
     acc += ri * ri;
   }
   acc = block_sum(acc, red);
+  if constexpr (PC) accz = block_sum(accz, red);
   if (threadIdx.x == 0) {
     part_rr[blockIdx.x] = acc;
+    if constexpr (PC) part_rz[blockIdx.x] = accz;
     if (blockIdx.x == 0) ctl->cg_k = k + 1;
   }
 }
@@ -804,8 +823,8 @@ int32_t enqueue_cg_iterations(cosmo_hip_handle* h, int guard, int k_begin, int c
                        h->prm.sigma, h->u, h->tmp_m, h->rhs, h->r, h->c, PARTS(h, SLOT_UC), PARTS(h, SLOT_BB), 0, 0.0, diag_o);
     prof_end(h);
     prof_begin(h, KC_CG_UPD);
-    hipLaunchKernelGGL(k_cg_upd, dim3(gE), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, k, n, PARTS(h, SLOT_UC),
-                       PTo.grid, h->u, h->c, h->x_tl, h->r, PARTS(h, SLOT_RR), (real2*)h->cg_ru);
+    hipLaunchKernelGGL(k_cg_upd<false>, dim3(gE), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, k, n, PARTS(h, SLOT_UC),
+                       PTo.grid, h->u, h->c, h->x_tl, h->r, PARTS(h, SLOT_RR), (real2*)h->cg_ru, (const real*)nullptr, (real*)nullptr);
     prof_end(h);
     h->spmv_calls[0] += 1; h->spmv_calls[1] += 1; h->spmv_calls[2] += 1;
   }
@@ -995,8 +1014,12 @@ int32_t refresh_op_split(cosmo_hip_handle* h) {
 // launch helpers used by cg_fold.hip
 int32_t launch_cg_upd(cosmo_hip_handle* h, int guard, int k, int n_uc) {
   prof_begin(h, KC_CG_UPD);
-  hipLaunchKernelGGL(k_cg_upd, dim3(ew_grid(h->n)), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, k, h->n, PARTS(h, SLOT_UC), n_uc, h->u, h->c,
-                     h->x_tl, h->r, PARTS(h, SLOT_RR), (real2*)h->cg_ru);
+  if (h->cg_jacobi)
+    hipLaunchKernelGGL(k_cg_upd<true>, dim3(ew_grid(h->n)), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, k, h->n, PARTS(h, SLOT_UC), n_uc, h->u, h->c,
+                       h->x_tl, h->r, PARTS(h, SLOT_RR), (real2*)h->cg_ru, (const real*)((FoldPlan*)h->fold)->dinv, PARTS(h, SLOT_AUX2));
+  else
+    hipLaunchKernelGGL(k_cg_upd<false>, dim3(ew_grid(h->n)), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, k, h->n, PARTS(h, SLOT_UC), n_uc, h->u, h->c,
+                       h->x_tl, h->r, PARTS(h, SLOT_RR), (real2*)h->cg_ru, (const real*)nullptr, (real*)nullptr);
   prof_end(h);
   return COSMO_HIP_OK;
 }

@@ -1701,8 +1701,17 @@ extern "C" int32_t cosmo_hip_time_psd_product(cosmo_hip_handle* h, int32_t which
         symm_gemm(h, 0, nullptr, cn.ts, cn.sk, 0, X + n2, X + n2, nullptr, X + 2 * n2, cn.ld, 1.0, 0.0, cn.skg, cn.skc);
         const long long nt = cn.ld / cn.ts;
         fl = 2.0 * (double)(nt * (nt + 1) / 2) * cn.ts * cn.ts * cn.ld;
-      } else {
+      } else if (which == 1) {
         launch_bgemm<0>(q, h->stream, h->ctl, 0, (const int*)nullptr, 1, 1, 1, 2, 1.0, 0.0);
+        fl = q->batch_flops_performed;
+      } else {
+        // which == 2: the IN-LOOP MIX of one step of the sign iteration (polar_enqueue_project_batch): Y = U^2 (EPI 0, one operand), T = c Y^2 + b Y
+        // (EPI 1, Cin = the operand) and U' = U T + a U (EPI 1, three distinct matrices) -- two thirds of a projection's products carry the
+        // alpha A B + beta Cin epilogue and read up to three matrices.  Coefficients (a, b, c) = (1, 0, 0) keep the work matrices bounded over
+        // any number of repetitions (T = 0, U' = U); the kernels do the same work for any coefficients.
+        launch_bgemm<0>(q, h->stream, h->ctl, 0, (const int*)nullptr, 1, 1, 1, 2, 1.0, 0.0);
+        launch_bgemm<1>(q, h->stream, h->ctl, 0, (const int*)nullptr, 2, 2, 2, 3, 0.0, 0.0);
+        launch_bgemm<1>(q, h->stream, h->ctl, 0, (const int*)nullptr, 1, 3, 1, 2, 1.0, 1.0);
         fl = q->batch_flops_performed;
       }
     }
@@ -1712,7 +1721,7 @@ extern "C" int32_t cosmo_hip_time_psd_product(cosmo_hip_handle* h, int32_t which
   for (int i = 0; i < 4; ++i) q->launches[i] = keep[i];
   float ms = 0.f;
   HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
-  *avg_seconds = (double)ms * 1e-3 / reps;
+  *avg_seconds = (double)ms * 1e-3 / ((double)reps * (which == 2 ? 3.0 : 1.0));        // per PRODUCT
   if (flops) *flops = fl;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return COSMO_HIP_OK;

@@ -32,7 +32,9 @@ IndirectReducedKKTSolverMINRES = "IndirectReducedKKTSolver(:MINRES)"
 QdldlKKTSolver = "QdldlKKTSolver"
 # opt-in, no reference counterpart: the same reduced system solved by single-reduction (Chronopoulos-Gear) CG, csrc/cg_sr.hip
 CGSingleReductionKKTSolver = "CGSingleReductionKKTSolver"
-_KKT_KIND = {CGIndirectKKTSolver: _ffi.KKT_CG, MINRESIndirectKKTSolver: _ffi.KKT_MINRES, CGSingleReductionKKTSolver: _ffi.KKT_CG_SR,
+# opt-in, no reference counterpart: Jacobi-preconditioned CG (IterativeSolvers' PCGIterable, Pl = diag of the reduced operator) on the assembled operator, csrc/cg_fold.hip
+CGJacobiKKTSolver = "CGJacobiKKTSolver"
+_KKT_KIND = {CGIndirectKKTSolver: _ffi.KKT_CG, MINRESIndirectKKTSolver: _ffi.KKT_MINRES, CGSingleReductionKKTSolver: _ffi.KKT_CG_SR, CGJacobiKKTSolver: _ffi.KKT_CG_JACOBI,
              IndirectReducedKKTSolverMINRES: _ffi.KKT_MINRES_REDUCED}
 
 
@@ -717,7 +719,7 @@ def optimize(model: Model, dist=None, shard: str = "rows") -> Result:
     if dist is not None and dist.get_world_size() > 1 and fresh:
         kkt = model.settings.kkt_solver.solver if isinstance(model.settings.kkt_solver, OptionsFactory) else model.settings.kkt_solver
         acc = model.settings.accelerator.solver if isinstance(model.settings.accelerator, OptionsFactory) else model.settings.accelerator
-        rows_ok = (kkt in (CGIndirectKKTSolver, CGSingleReductionKKTSolver) and model.settings.time_limit == 0 and acc in (None, EmptyAccelerator)
+        rows_ok = (kkt in (CGIndirectKKTSolver, CGSingleReductionKKTSolver, CGJacobiKKTSolver) and model.settings.time_limit == 0 and acc in (None, EmptyAccelerator)
                    and not any(K.kind == _ffi.CUSTOM for K in model.sets))
         if shard == "rows" and rows_ok:
             setup_row_sharding(model, dist)

@@ -78,6 +78,13 @@ enum {
   COSMO_HIP_KKT_CG_SR = 3           /* OPT-IN, no reference counterpart: the reduced CG solve as single-reduction (Chronopoulos-Gear) CG --
                                        same operator, stopping rule and warm start as COSMO_HIP_KKT_CG, algebraically equal iterates, two
                                        launches per Krylov iteration; not bit-comparable with the literal recurrence (csrc/cg_sr.hip) */
+  ,
+  COSMO_HIP_KKT_CG_JACOBI = 4       /* OPT-IN, no reference counterpart (the reference calls cg! without a preconditioner,
+                                       src/linear_solver/kktsolver_indirect.jl:70): IterativeSolvers' preconditioned recurrence (PCGIterable) with
+                                       Pl = Diagonal(diag(P + sigma I + A' rho A)) on the ASSEMBLED reduced operator; same operator, warm start
+                                       and true-residual stopping rule ||r||_2 <= tol_k / ||rhs||, DIFFERENT iterates (every solve ends at another
+                                       point inside the same tolerance).  cosmo_hip_set_params fails with UNSUPPORTED where the operator cannot be
+                                       assembled (csrc/cg_fold.hip).  Never the parity path; the literal cg! stays the default. */
 };
 
 /* ---- solver status (Result.status symbols, src/solver.jl:113,175,312,318,338,344,353) -------------- */
@@ -318,9 +325,18 @@ int32_t cosmo_hip_polar_streamk_stats(cosmo_hip_handle* h, int64_t out[4]);
  * NULL = only report *nsteps).  Host function (no device needed): lets a CPU test replay the schedule on scalars. */
 int32_t cosmo_hip_polar_schedule(int32_t k_lift, double* abc, int32_t* nsteps);
 /* Measurement hook: `reps` back-to-back launches of the symmetric-product kernel of the sign iteration exactly as the projection
- * launches it (which = 0: first large cone, 1: the whole batch of mid-size cones), timed with HIP events on the handle's stream.
- * Returns the average seconds per launch and the flops one launch performs (2 ts^2 k per upper tile). */
+ * launches it (which = 0: first large cone, 1: the whole batch of mid-size cones, Y = U^2 only; 2: the batch's IN-LOOP MIX -- per
+ * repetition one Y = U^2 and two alpha A B + beta Cin products with the operands of a step of the iteration, 3 reps launches in all),
+ * timed with HIP events on the handle's stream.  Returns the average seconds per launch and the flops one launch performs
+ * (2 ts^2 k per upper tile). */
 int32_t cosmo_hip_time_psd_product(cosmo_hip_handle* h, int32_t which, int32_t reps, double* avg_seconds, double* flops);
+/* Measurement hook: `reps` Krylov iterations of the reduced CG solve (src/linear_solver/kktsolver_indirect.jl:57-70; IterativeSolvers cg!)
+ * exactly as the loop enqueues them -- solve start on the current right-hand side with tolerance 0, then the iterations (captured chain
+ * included), HIP events around the iterations only.  The warm start is restored afterwards; the ADMM state is untouched.  Returns the
+ * average seconds per Krylov iteration INCLUDING the kernel boundaries between its launches, the algorithmic bytes of one iteration
+ * (12 B per nonzero of the operator + row pointers + 8 B per vector element read or written) and the launches per iteration.
+ * kkt_kind CG / CG_JACOBI only; call after at least one loop iteration. */
+int32_t cosmo_hip_time_krylov(cosmo_hip_handle* h, int32_t reps, double* avg_seconds, double* algorithmic_bytes, int32_t* launches_per_iteration);
 
 /* ---- clique-sharded projections over the GPUs of one node (one process per GPU, RCCL over xGMI) -----------------------
  * The reference projects the cones of a decomposed SDP serially (src/convexset.jl:885-891).  Here every rank holds the whole

@@ -786,6 +786,36 @@ def cg_v09(x, mul, b, abstol, maxiter):
     return it
 
 
+def pcg_v09(x, mul, b, dinv, abstol, maxiter):
+    """IterativeSolvers.jl v0.9 `cg!(x, L, b; Pl = Diagonal(d), abstol, reltol=0)` with `initially_zero=false`: the package's `PCGIterable`
+    (cg.jl `iterate(it::PCGIterable)`; the package is not vendored, SURVEY 8c: parity unpinned, anchored like cg_v09 on the definition).
+    NOT what the reference calls -- COSMO passes no preconditioner (src/linear_solver/kktsolver_indirect.jl:70) -- this is the oracle of the
+    OPT-IN kkt_kind COSMO_HIP_KKT_CG_JACOBI: left preconditioner Pl = diag(L), ldiv! = elementwise product with dinv = 1 ./ diag(L); the stopping
+    rule is the unpreconditioned one, ||r||_2 <= abstol, checked before every iteration exactly as in cg_v09.
+        c = Pl \ r ; rho_prev = rho ; rho = c'r ; beta = rho / rho_prev ; u = c + beta u ; c = L u ; alpha = rho / u'c ; x += alpha u ; r -= alpha c"""
+    u = np.zeros_like(x)
+    r = b.copy()
+    c = mul(x)
+    r -= c
+    residual = float(np.linalg.norm(r))
+    tol = max(0.0 * residual, abstol)
+    rho = 1.0
+    it = 0
+    while it < maxiter and not (residual <= tol):
+        c = dinv * r
+        rho_prev = rho
+        rho = float(np.dot(c, r))
+        beta = rho / rho_prev
+        u = c + beta * u
+        c = mul(u)
+        alpha = rho / float(np.dot(u, c))
+        x += alpha * u
+        r -= alpha * c
+        residual = float(np.linalg.norm(r))
+        it += 1
+    return it
+
+
 def _givens(f, g):
     """LinearAlgebra.givensAlgorithm(f, g) for reals: returns (c, s, r) with [c s; -s c][f; g] = [r; 0]."""
     if g == 0.0:
@@ -874,6 +904,15 @@ class IndirectReducedKKT:
     def get_tolerance(self):
         return self.tol_constant / self.iteration_counter ** self.tol_exponent   # :168-170
 
+    def operator_diagonal(self):
+        """diag(P + sigma I + A' rho A): d_j = P_jj + sigma + sum_i rho_i a_ij^2 (recomputed when rho changed)."""
+        key = self.rho.tobytes()
+        if getattr(self, "_diag_key", None) != key:
+            A2 = self.ops.AT.copy(); A2.data = A2.data ** 2
+            self._diag = self.ops.P.diagonal() + self.sigma + A2 @ self.rho
+            self._diag_key = key
+        return self._diag
+
     def reduced_mul(self, x):
         tmp_m = self.ops.mulA(x)                              # :59
         tmp_m *= self.rho                                     # :60
@@ -895,6 +934,9 @@ class IndirectReducedKKT:
         if self.solver_type == "CG":
             abstol = self.get_tolerance() / nrm if nrm > 0 else math.inf
             self.last_iters = cg_v09(self.previous_solution, self.reduced_mul, y1, abstol, n)
+        elif self.solver_type == "CG_JACOBI":                 # opt-in, no reference counterpart: Pl = diag(P + sigma I + A' rho A)
+            abstol = self.get_tolerance() / nrm if nrm > 0 else math.inf
+            self.last_iters = pcg_v09(self.previous_solution, self.reduced_mul, y1, 1.0 / self.operator_diagonal(), abstol, n)
         else:
             init_res = float(np.linalg.norm(self.reduced_mul(self.previous_solution) - y1))
             abstol = self.get_tolerance() / init_res if init_res > 0 else math.inf
@@ -955,6 +997,8 @@ def make_kkt_solver(kind: str, P, A, ops, sigma, rho, st: Settings):
         return DirectKKT(P, A, sigma, rho)
     if kind == "cg":
         return IndirectReducedKKT(ops, n, m, sigma, rho, "CG", st.tol_constant, st.tol_exponent)
+    if kind in ("cg_jacobi", "cg-jacobi"):
+        return IndirectReducedKKT(ops, n, m, sigma, rho, "CG_JACOBI", st.tol_constant, st.tol_exponent)
     if kind == "minres_reduced":
         return IndirectReducedKKT(ops, n, m, sigma, rho, "MINRES", st.tol_constant, st.tol_exponent)
     if kind == "minres":

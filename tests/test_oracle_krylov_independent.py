@@ -202,3 +202,57 @@ def test_krylov_count_of_a_cfg2_like_admm_run_is_reproduced_by_scipy():
         tot_s += cnt[0]
         diffs.append((it, cnt[0]))
     assert abs(tot_o - tot_s) <= 0.02 * tot_o + 1, diffs
+
+
+# ---- the opt-in Jacobi-preconditioned recurrence (oracle.pcg_v09; device kkt_kind COSMO_HIP_KKT_CG_JACOBI) ----------------------------
+@pytest.mark.parametrize("k", [1, 3, 8, 20])
+def test_pcg_iterates_are_the_energy_norm_minimisers_of_the_preconditioned_krylov_space(k):
+    """Definition of left-preconditioned CG with an SPD diagonal D: x_k minimises ||x* - x||_L over x0 + K_k(D^-1 L, D^-1 r0)
+    <=> y_k = D^{1/2} x_k is the plain-CG iterate of the symmetrically scaled system (D^{-1/2} L D^{-1/2}) y = D^{-1/2} b."""
+    L, *_, rng = reduced_operator(n=120, m=240, rho_spread=True)
+    d = L.diagonal()
+    b = rng.standard_normal(120)
+    x0 = rng.standard_normal(120)
+    x = x0.copy()
+    assert O.pcg_v09(x, lambda v: L @ v, b, 1.0 / d, 0.0, k) == k
+    sq = np.sqrt(d)
+    Ls = sp.diags(1.0 / sq) @ L @ sp.diags(1.0 / sq)
+    yk = krylov_minimiser(Ls, b / sq, x0 * sq, k, "energy")
+    assert np.linalg.norm(x - yk / sq) <= 1e-8 * np.linalg.norm(yk / sq)
+
+
+def test_pcg_agrees_with_scipy_cg_with_the_same_preconditioner_and_stopping_rule():
+    """SciPy's cg with M = D^-1 and `atol` (rtol = 0) applies the same unpreconditioned-residual rule ||r|| <= atol: same iterates, same count
+    (+-1: SciPy tests the norm after the update, cg! before the next iteration -- the same thing counted from the other side)."""
+    L, *_, rng = reduced_operator(n=300, m=600, rho_spread=True)
+    d = L.diagonal()
+    b = rng.standard_normal(300)
+    x0 = rng.standard_normal(300)
+    for atol in (1e-3, 1e-8):
+        x = x0.copy()
+        its = O.pcg_v09(x, lambda v: L @ v, b, 1.0 / d, atol, 5000)
+        cnt = [0]
+        xs, info = spla.cg(L, b, x0=x0.copy(), rtol=0.0, atol=atol, maxiter=5000, M=sp.diags(1.0 / d), callback=lambda _: cnt.__setitem__(0, cnt[0] + 1))
+        assert info == 0 and abs(cnt[0] - its) <= 1, (cnt[0], its)
+        assert np.linalg.norm(b - L @ x) <= atol
+        assert np.linalg.norm(x - xs) <= 1e-6 * np.linalg.norm(xs) + 10 * atol / np.sqrt(d.min())
+    # (no claim about FEWER iterations here: on this box-QP-like operator Jacobi scaling needs more of them -- 446 against 200 to 1e-8 -- as on
+    # BASELINE config 2, profiles/r03_pcg_jacobi_study.txt; the operator it helps is the clique-coupled one of config 5)
+
+
+def test_reduced_kkt_solver_with_jacobi_pcg_solves_the_kkt_system():
+    """solve! with the CG_JACOBI recurrence against a dense solve of the full KKT matrix (test/UnitTests/kktsolver.jl:97-109 pattern), rho update included."""
+    L, P, A, rho, sigma, rng = reduced_operator(n=150, m=300, rho_spread=False)      # cg!'s default maxiter is n: a spread of 9 decades does not converge in n steps
+    n, m = 150, 300
+    ops = O.Operators(P, A)
+    kk = O.IndirectReducedKKT(ops, n, m, sigma, rho, "CG_JACOBI", 1e-10, 0.0)
+    assert np.allclose(kk.operator_diagonal(), L.diagonal(), rtol=1e-13)
+    for trial in range(2):
+        if trial == 1:
+            rho = 10.0 ** rng.uniform(-1, 1, m)
+            kk.update_rho(rho)
+        K = O.assemble_kkt_full(P, A, sigma, rho).toarray()
+        rhs = rng.standard_normal(n + m)
+        sol = kk.solve(rhs)
+        ref = np.linalg.solve(K, rhs)
+        assert np.linalg.norm(sol - ref) <= 1e-7 * np.linalg.norm(ref)
