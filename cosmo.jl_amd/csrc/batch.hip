@@ -7,8 +7,10 @@
 // (rho, CG residuals, counters, status) live with the problem: trajectories are those of 1024 separate solves, not of
 // one block-diagonal solve.  The phases reuse the row lambdas / CSR-stream primitive of the large-problem path, the
 // arithmetic per element is identical, reductions are single-workgroup fixed-order sums.
-// Cone support in batch mode: ZeroSet, Nonnegatives, Box, SecondOrderCone (PSD cones take the large-problem path); their infeasibility
-// certificates run between persistent launches (k_batch_inf_capture / k_batch_inf_check below).
+// Cone support in batch mode: ZeroSet, Nonnegatives, Box, SecondOrderCone and PsdCone / PsdConeTriangle of side <= 16 (round 4: the wave-level
+// Jacobi projection of psd16.h, the routine the single-problem path uses for such cones, called from the problem's persistent workgroup --
+// batches of small SDPs, src/convexset.jl:402-412 inside the composite projection :885-891); larger PSD cones take the single-problem path.  The
+// infeasibility certificates run between persistent launches (k_batch_inf_capture / k_batch_inf_check below).
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
@@ -16,6 +18,7 @@
 #include <algorithm>
 #include <chrono>
 #include "device_utils.h"
+#include "psd16.h"
 
 struct BCtl {                 // per problem, device resident
   int status; int n_rho_updates;
@@ -33,6 +36,8 @@ struct BatchDev {
   const real *q, *b, *Dinv, *Einv, *cinv;
   const uint32_t* meta; const real *box_l, *box_u; int nbox;
   int nsoc; const int *soc_off, *soc_dim;
+  int npsd; const int *psd_off, *psd_d, *psd_kind;   // PSD cones of side 2..16: first row, side, COSMO_HIP_PSD_SQUARE / _TRIANGLE
+  int psd_nws;                  // wave workspaces (psd16.h) available to a workgroup: waves 0 .. psd_nws-1 project the PSD cones
   const int* rho_cls;
   real *w, *w_prev, *s, *mu, *s_tl, *ls_s, *y2, *tmp_m, *nu, *rho;
   real *ls_x, *x_tl, *rhs, *r, *u, *c;
@@ -108,9 +113,22 @@ __device__ __forceinline__ real bmax(real v, real* red) {
   return t;
 }
 
+#define PSD16_WS_STRIDE ((PSD16_WS_BYTES + 15) / 16 * 16)
+// the PSD cones (side <= 16) of a problem: waves 0 .. nws-1 take the cones round-robin, each on its own LDS workspace.  x = the projected slack
+// (global memory, or its LDS staging copy in the register kernel).  Callers put a workgroup barrier in front and behind.
+__device__ __forceinline__ void batch_project_psd(const BatchDev& D, real* x, unsigned char* ws_base, int wv, int lane) {
+  if (wv >= D.psd_nws) return;
+  const Psd16Ws ws = psd16_ws_at(ws_base + (size_t)wv * PSD16_WS_STRIDE);
+  for (int cI = wv; cI < D.npsd; cI += D.psd_nws) {
+    (void)psd16_wave(x + D.psd_off[cI], D.psd_d[cI], D.psd_kind[cI], ws, lane, 0, R(1.0), nullptr, nullptr);
+    wave_lds_fence();                                   // the workspace is reused by this wave's next cone
+  }
+}
+
 struct StreamOps {
   CsrView A, AT, PT;
   real* lds; real* red;
+  unsigned char* psd_ws;
   static constexpr bool in_lds = false;
   __device__ __forceinline__ real* buf_n(real* g) const { return g; }       // vector the A / P products gather from
   __device__ __forceinline__ real* buf_m(real* g) const { return g; }       // vector the A' products gather from
@@ -136,6 +154,7 @@ struct LdsOps {
   const int4 *rbA, *rbAT, *rbPT;
   int nbA, nbAT, nbPT;
   real *xv, *tv, *red;
+  unsigned char* psd_ws;
   int n;
   static constexpr bool in_lds = true;
   __device__ __forceinline__ real* buf_n(real*) const { return xv; }
@@ -348,6 +367,10 @@ __device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams
       else { const real f = (nx + t) / (R(2.0) * nx); for (int i = 1 + lane; i < d; i += 64) x[i] = f * x[i]; if (lane == 0) x[0] = (nx + t) / R(2.0); }
     }
     __syncthreads();
+    if (D.npsd > 0) {                                                     // PsdCone / PsdConeTriangle, side <= 16 (convexset.jl:303-321, 402-412)
+      batch_project_psd(D, s, ops.psd_ws, wv, lane);
+      __syncthreads();
+    }
     // ---- apply_rho_adaptation_rules! (solver.jl:242-282, parameters.jl:53-92) ----
     if (P.adaptive_rho && P.adaptive_rho_interval > 0 && (it % P.adaptive_rho_interval) == 0 &&
         (long long)(ctl->n_rho_updates - 1) < P.max_adaptions) {
@@ -403,10 +426,11 @@ __device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams
 __global__ __launch_bounds__(COSMO_BS) void k_batch_admm(BatchDev D, BParams P, long long iter_target, int do_init) {
   __shared__ real lds[COSMO_NNZ_PER_BLOCK];
   __shared__ real red[COSMO_BS / 64];
+  __shared__ __attribute__((aligned(16))) unsigned char psd_ws[(COSMO_BS / 64) * PSD16_WS_STRIDE];
   const int k = blockIdx.x;
   if (D.ctl[k].status != 0) return;
   StreamOps ops;
-  ops.A = bview(D.A, k); ops.AT = bview(D.AT, k); ops.PT = bview(D.PT, k); ops.lds = lds; ops.red = red;
+  ops.A = bview(D.A, k); ops.AT = bview(D.AT, k); ops.PT = bview(D.PT, k); ops.lds = lds; ops.red = red; ops.psd_ws = psd_ws;
   batch_admm_body<COSMO_BS>(D, P, iter_target, do_init, ops, red);
 }
 
@@ -436,6 +460,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_lds(BatchDev D, BParams P, lo
   ops.nbA = hd.nbA; ops.nbAT = hd.nbAT; ops.nbPT = hd.nbPT;
   real* wsp = reinterpret_cast<real*>(base + img_stride);            // workspace behind the image
   ops.xv = wsp; ops.tv = wsp + D.n; ops.red = wsp + D.n + D.m; ops.n = D.n;
+  ops.psd_ws = base + ((img_stride + (long long)sizeof(real) * (D.n + D.m + BS / 64) + 15) / 16) * 16;     // behind the reduction slots (build_lds_images sizes it)
   __syncthreads();
   batch_admm_body<BS>(D, P, iter_target, do_init, ops, ops.red);
 }
@@ -489,6 +514,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   real* xv = wsp;                 // n : vector gathered by the A / P products
   real* tv = wsp + n;             // m : vector gathered by the A' products; staging of s for the SOC projection
   real* red = wsp + n + m;        // BS / 64 reduction slots
+  unsigned char* psd_ws = base + ((img_stride + (long long)sizeof(real) * (n + m + BS / 64) + 15) / 16) * 16;   // wave workspaces of the small PSD cones
 
   const long long on = (long long)k * n, om = (long long)k * m, onm = (long long)k * (n + m);
   // ---- load the persistent state and the per-element constants into registers -----------------------------------------
@@ -785,9 +811,9 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       else if (kind == 2u) pv = (v != v) ? v : ((v > R(0.0)) ? v : R(0.0));
       else if (kind == 3u) pv = (v < blv[j]) ? blv[j] : ((v > buv[j]) ? buv[j] : v);
       sv[j] = pv;
-      if (D.nsoc > 0 && i < m) tv[i] = pv;
+      if ((D.nsoc > 0 || D.npsd > 0) && i < m) tv[i] = pv;
     }
-    if (D.nsoc > 0) {
+    if (D.nsoc > 0 || D.npsd > 0) {
       __syncthreads();
       auto soc_one = [&](real* x, int d) {                              // SecondOrderCone (convexset.jl:100-114), on the LDS copy
         if (d == 0) return;
@@ -805,6 +831,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       } else {
         for (int cI = wvid; cI < D.nsoc; cI += BS / 64) soc_one(tv + D.soc_off[cI], D.soc_dim[cI]);
       }
+      if (D.npsd > 0) batch_project_psd(D, tv, psd_ws, wvid, lane);      // disjoint rows: no barrier needed between the two cone kinds
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; if (i < m) sv[j] = tv[i]; }
@@ -901,10 +928,25 @@ __global__ __launch_bounds__(COSMO_BS) void k_batch_inf_check(BatchDev D, real e
   __shared__ real lds[COSMO_NNZ_PER_BLOCK];
   __shared__ real red[COSMO_BS / 64];
   __shared__ int flag;
+  __shared__ __attribute__((aligned(16))) unsigned char psd_ws[(COSMO_BS / 64) * PSD16_WS_STRIDE];
   const int k = blockIdx.x;
   BCtl* ctl = D.ctl + k;
   if (ctl->status != 0) return;
   constexpr int BS = COSMO_BS;
+  // PSD cones (side <= 16): is_pos_def!(sign * mat(v) + tol I) <=> lambda_min(sign * mat(v)) > -tol  (convexset.jl:415-424, algebra.jl:226-238),
+  // the smallest eigenvalue from the same wave-level Jacobi as the projection (mode 1: v is only read)
+  auto psd_violates = [&](real* v, real sign, real tol) -> int {
+    int bad = 0;
+    const int wv_ = threadIdx.x >> 6, lane_ = threadIdx.x & 63;
+    const Psd16Ws ws = psd16_ws_at(psd_ws + (size_t)wv_ * PSD16_WS_STRIDE);
+    for (int cI = wv_; cI < D.npsd; cI += BS / 64) {
+      real lm = 0.0;
+      (void)psd16_wave(v + D.psd_off[cI], D.psd_d[cI], D.psd_kind[cI], ws, lane_, 1, sign, &lm, nullptr);
+      if (!(lm > -tol)) bad = 1;
+      wave_lds_fence();
+    }
+    return bad;
+  };
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n = D.n, m = D.m;
   const long long on = (long long)k * n, om = (long long)k * m, onm = (long long)k * (n + m);
@@ -962,6 +1004,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_batch_inf_check(BatchDev D, real e
       const real nx = sqrt(wave_sum(a));
       if (!(nx <= epi + (-x[0]))) viol = 1;
     }
+    if (D.npsd > 0 && psd_violates(dy, -R(1.0), epi)) viol = 1;          // in_dual!(-dyn) of the PSD cones (:415-418)
     if (viol) atomicOr(&flag, 1);
     const real dyt_b = bsum<BS>(dtb, red), box_sf = bsum<BS>(box, red);          // (their barriers also publish `flag`)
     __syncthreads();
@@ -997,6 +1040,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_batch_inf_check(BatchDev D, real e
       const real nx = sqrt(wave_sum(a));
       if (!(nx <= edi - x[0])) viol = 1;
     }
+    if (D.npsd > 0 && psd_violates(adx, -R(1.0), edi)) viol = 1;         // in_pol_recc!: is_neg_def (:421-424)
     if (viol) atomicOr(&flag, 1);
     __syncthreads();
     if (!flag && tid == 0) { ctl->status = COSMO_HIP_DUAL_INFEASIBLE; ctl->cost = -(real)INFINITY; }   // solver.jl:343-346
@@ -1155,7 +1199,11 @@ extern "C" int32_t cosmo_hip_batch_set_cones(cosmo_hip_batch* b, int64_t ncones,
   int64_t off = 0, nbox = 0;
   for (int64_t k = 0; k < ncones; ++k) {
     if (type[k] == COSMO_HIP_PSD_SQUARE || type[k] == COSMO_HIP_PSD_TRIANGLE) {
-      if (dim[k] > 1) return bfail(b, COSMO_HIP_ERR_UNSUPPORTED, "PSD cones are not supported in batch mode (use one handle per problem)");
+      // side d from the dimension (convexset.jl:372: d = (isqrt(1 + 8 dim) - 1) / 2 for the triangle, isqrt(dim) for the square)
+      long long d = 0;
+      if (type[k] == COSMO_HIP_PSD_SQUARE) { while ((d + 1) * (d + 1) <= dim[k]) ++d; if (d * d != dim[k]) return bfail(b, COSMO_HIP_ERR_INVALID, "PsdCone: dimension %lld is not a square", (long long)dim[k]); }
+      else { while ((d + 1) * (d + 2) / 2 <= dim[k]) ++d; if (d * (d + 1) / 2 != dim[k]) return bfail(b, COSMO_HIP_ERR_INVALID, "PsdConeTriangle: dimension %lld is not triangular", (long long)dim[k]); }
+      if (d > 16) return bfail(b, COSMO_HIP_ERR_UNSUPPORTED, "batch mode projects PSD cones of side <= 16 (side %lld: use one handle per problem)", d);
     } else if (type[k] < COSMO_HIP_ZERO || type[k] > COSMO_HIP_SOC) return bfail(b, COSMO_HIP_ERR_UNSUPPORTED, "cone type %d", (int)type[k]);
     C.type.push_back(type[k]); C.dim.push_back(dim[k]); C.off.push_back(off); off += dim[k];
     if (type[k] == COSMO_HIP_BOX) nbox += dim[k];
@@ -1402,8 +1450,19 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
   BHIP(b, hipMemset(d, 0, (size_t)stride * b->nprob));
   for (int k = 0; k < b->nprob; ++k)
     BHIP(b, hipMemcpy(d + (size_t)k * stride, imgs[(size_t)k].data(), imgs[(size_t)k].size(), hipMemcpyHostToDevice));
+  // wave workspaces of the small PSD cones behind the reduction slots: as many as fit, at most one per wave; none fits => streaming kernel
+  int npsd = 0;
+  for (size_t c = 0; c < b->cones.type.size(); ++c)
+    if ((b->cones.type[c] == COSMO_HIP_PSD_SQUARE || b->cones.type[c] == COSMO_HIP_PSD_TRIANGLE) && b->cones.dim[c] > 1) npsd += 1;
+  const long long ws_base = ((stride + (long long)sizeof(real) * (n + m + bs / 64) + 15) / 16) * 16;
+  int nws = 0;
+  if (npsd > 0) {
+    nws = (int)std::min<long long>(bs / 64, (max_lds - ws_base) / PSD16_WS_STRIDE);
+    if (nws < 1) { b->reg_mode = 0; return COSMO_HIP_OK; }       // (the image is released with the batch)
+  }
+  b->D.psd_nws = nws;
   b->d_img = d; b->img_stride = stride; b->lds_bs = bs;
-  b->lds_bytes = (int)(stride + sizeof(real) * (n + m) + sizeof(real) * (bs / 64));
+  b->lds_bytes = (int)(npsd > 0 ? ws_base + (long long)nws * PSD16_WS_STRIDE : stride + (long long)sizeof(real) * (n + m) + (long long)sizeof(real) * (bs / 64));
   const void* fn = bs == 256 ? (const void*)k_batch_admm_lds<256> : (bs == 512 ? (const void*)k_batch_admm_lds<512> : (const void*)k_batch_admm_lds<1024>);
   if (b->reg_mode == 1) fn = (const void*)k_batch_admm_reg<512, 1, 2>;
   if (b->reg_mode == 2) fn = (const void*)k_batch_admm_reg<512, 2, 4>;
@@ -1465,13 +1524,19 @@ extern "C" int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hi
   // cone metadata (shared) + per-problem classification
   const ConeTable& C = b->cones;
   std::vector<uint32_t> meta((size_t)m, 0u);
-  std::vector<int> soc_off, soc_dim;
+  std::vector<int> soc_off, soc_dim, psd_off, psd_d, psd_kind;
   long long boxp = 0;
   for (size_t k = 0; k < C.type.size(); ++k) {
     const long long o = C.off[k], d = C.dim[k];
     switch (C.type[k]) {
       case COSMO_HIP_ZERO: for (long long i = 0; i < d; ++i) meta[o + i] = 1u; break;
-      case COSMO_HIP_NONNEG: case COSMO_HIP_PSD_SQUARE: case COSMO_HIP_PSD_TRIANGLE: for (long long i = 0; i < d; ++i) meta[o + i] = 2u; break;
+      case COSMO_HIP_NONNEG: for (long long i = 0; i < d; ++i) meta[o + i] = 2u; break;
+      case COSMO_HIP_PSD_SQUARE: case COSMO_HIP_PSD_TRIANGLE:
+        if (d == 1) { meta[o] = 2u; break; }                        // the 1-D case is max(x, 0) (convexset.jl:303-305, 404-405)
+        { long long sd = 0;
+          if (C.type[k] == COSMO_HIP_PSD_SQUARE) { while ((sd + 1) * (sd + 1) <= d) ++sd; } else { while ((sd + 1) * (sd + 2) / 2 <= d) ++sd; }
+          psd_off.push_back((int)o); psd_d.push_back((int)sd); psd_kind.push_back((int)C.type[k]); }
+        break;
       case COSMO_HIP_BOX: for (long long i = 0; i < d; ++i) meta[o + i] = 3u | ((uint32_t)(boxp + i) << 2); boxp += d; break;
       case COSMO_HIP_SOC: soc_off.push_back((int)o); soc_dim.push_back((int)d); break;
     }
@@ -1507,6 +1572,9 @@ extern "C" int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hi
   D.nsoc = (int)soc_off.size();
   if ((rc = bup(b, &D.soc_off, soc_off))) return rc;
   if ((rc = bup(b, &D.soc_dim, soc_dim))) return rc;
+  D.npsd = (int)psd_off.size();
+  if ((rc = bup(b, &D.psd_off, psd_off)) || (rc = bup(b, &D.psd_d, psd_d)) || (rc = bup(b, &D.psd_kind, psd_kind))) return rc;
+  if (!b->d_img) D.psd_nws = COSMO_BS / 64;                    // streaming kernel: static workspaces for all of its four waves
   std::vector<int> cls32(b->cls_host.begin(), b->cls_host.end());
   if ((rc = bup(b, &D.rho_cls, cls32))) return rc;
   const size_t NM = (size_t)nprob * (n + m), Nn = (size_t)nprob * n, Nm = (size_t)nprob * m;

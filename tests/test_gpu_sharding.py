@@ -363,7 +363,7 @@ def test_bench_reports_the_headline_even_if_a_sharded_extra_never_finishes():
     wait in a collective) no line at all would come out of an N-GPU run.  A watchdog prints the headline -- measured before the extras
     start -- with what has been collected and ends every rank.  Here the deadline is zero, so it fires while the first extra is being set up."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
-    env.update(COSMO_BENCH_TRANSPORT="shm", COSMO_BENCH_EXTRA_TIMEOUT="0.05", COSMO_BENCH_EXTRA_GRACE="3")
+    env.update(COSMO_BENCH_TRANSPORT="shm", COSMO_BENCH_EXTRA_TIMEOUT="0.05", COSMO_BENCH_EXTRA_GRACE="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--small", "--no-cpu-baseline", "--no-float32"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     two = _one_json_line(r)
