@@ -400,7 +400,8 @@ def bench_cfg3(ctx, args, steps, warmup):
                                  "problem; one persistent workgroup per problem (csrc/batch.hip)" % (nprob, n, m, nnzA),
                      "parallelism": "batch sharded over %d rank(s), %d problems on rank 0, no collective" % (ctx.world, hi - lo),
                      "problem_iterations_per_s": round(value * nprob, 1), "rank_seconds": rank_seconds, "parity": parity,
-                     "krylov_iterations_per_problem_in_timed_steps": dict(mean=round(float(kry.mean()), 1), max=int(kry.max()), min=int(kry.min())),
+                     "krylov_iterations_per_problem_in_timed_steps": dict(mean=round(float(kry.mean()), 1), max=int(kry.max()), min=int(kry.min()),
+                                                                          largest_16=[int(v) for v in np.sort(kry)[::-1][:16]]),
                      "us_per_krylov_iteration_of_the_slowest_problem": round(1e6 * elapsed / max(float(kry.max()), 1.0), 3)}
     # What bounds the persistent kernel is the LDS: every Krylov iteration streams the problem's LDS image once through the two sparse passes --
     # A pass: (value 8 B + u16 column + 8 B gathered x) per nonzero; [P | A'] pass: (u16 position + u16 row + 8 B value + 8 B gathered y) per
@@ -627,7 +628,7 @@ def bench_cfg4(ctx, args, steps, warmup):
                            useful_frac_of_peak=round(psd_useful_flops(d) * per_gpu / 1e12 / F64_MFMA_PEAK_TF, 4))
     out["config"] = {"workload": "cfg4: closest-correlation SDP, one PsdConeTriangle d=%d (n=%d, m=%d), CG indirect KKT" % (d, model.n, model.m),
                      "parallelism": "replicas x%d (a single cone does not shard; SURVEY 8e)" % ctx.world,
-                     "mean_cg_iters_per_admm_iter": round(kbar, 3), "polar": {k: ps[k] for k in ("schedule_steps", "fallback_rounds", "verified", "unverified", "err_max_e18")}}
+                     "mean_cg_iters_per_admm_iter": round(kbar, 3), "polar": dict({k: ps[k] for k in ("schedule_steps", "fallback_rounds", "verified", "unverified", "err_max_e18")}, lifting_depth=h.polar_depth_stats())}
     if not args.no_cpu_baseline and ctx.world == 1:
         args.deferred.append(lambda out=out, prob=prob: out.__setitem__("cpu_baseline", compiled_cpu_baseline(prob, 8 if not args.small else 20, "cfg4", "cfg4", args,
                                                                                                                 iters_all=2 if not args.small else 20)))
@@ -687,7 +688,8 @@ def bench_cfg5(ctx, args, steps, warmup):
                      "parallelism": par,
                      "mean_cg_iters_per_admm_iter": round(kbar, 3), "comm": h.bench_comm, "row_shard": h.row_shard_info(), "cg_persist": h.cg_persist_stats(),
                      "cg_assembled_operator": h.fold_stats(),
-                     "polar": {k: ps[k] for k in ("batch_cones", "schedule_steps", "products_last_batch", "fallback_rounds", "verified", "unverified", "err_max_e18")}}
+                     "polar": dict({k: ps[k] for k in ("batch_cones", "schedule_steps", "products_last_batch", "fallback_rounds", "verified", "unverified", "err_max_e18")},
+                                   lifting_depth=h.polar_depth_stats())}
     if ctx.world > 1:
         out["config"]["rank_seconds"] = rank_seconds
         out["config"]["parity"] = parity

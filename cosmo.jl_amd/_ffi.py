@@ -109,6 +109,7 @@ SIGNATURES = {
     "cosmo_hip_comm_init": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]),
     "cosmo_hip_comm_destroy": (C.c_int32, [C.c_void_p]),
     "cosmo_hip_set_cone_shard": (C.c_int32, [C.c_void_p, _PI64]),
+    "cosmo_hip_polar_depth_stats": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_time_krylov": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "cosmo_hip_comm_selftest": (C.c_int32, [C.c_void_p]),
     "cosmo_hip_comm_allreduce_check": (C.c_int32, [C.c_void_p, C.c_int64, _PI64]),
@@ -455,6 +456,14 @@ class Handle:
 
     def comm_selftest(self):
         self._chk(self.lib.cosmo_hip_comm_selftest(self._h))
+
+    def polar_depth_stats(self):
+        out = np.zeros(8, dtype=np.int64)
+        self._chk(self.lib.cosmo_hip_polar_depth_stats(self._h, out.ctypes.data_as(_PI64)))
+        d = dict(zip(["adaptive", "depth_min", "depth_max", "depth_mean_x1000", "weighted_products_x1000", "failed_verifications", "downward_probes", "projections"], out.tolist()))
+        d["depth_mean"] = d.pop("depth_mean_x1000") / 1000.0
+        d["weighted_products_per_projection"] = d.pop("weighted_products_x1000") / 1000.0
+        return d
 
     def time_krylov(self, reps):
         """(seconds per Krylov iteration incl. the kernel boundaries between its launches, algorithmic bytes per iteration, launches per iteration)."""

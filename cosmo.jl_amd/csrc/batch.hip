@@ -237,7 +237,10 @@ struct LdsOps {
 };
 
 // One workgroup = one problem.  Runs iterations until a status is decided or `iter_target` iterations are done.
-template <int BS, class Ops>
+// PSD: the batch has PsdCone / PsdConeTriangle cones of side 2..16.  A template parameter, not a run-time test: the wave-level Jacobi of psd16.h
+// inlined into these kernels costs 55-60 VGPRs (the register kernel <512, 1, 2> went from 229 to 256 + spills), which batches without such
+// cones -- BASELINE config 3 -- must not pay.
+template <int BS, bool PSD, class Ops>
 __device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams& P, long long iter_target, int do_init, Ops& ops, real* red) {
   const int k = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -367,7 +370,7 @@ __device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams
       else { const real f = (nx + t) / (R(2.0) * nx); for (int i = 1 + lane; i < d; i += 64) x[i] = f * x[i]; if (lane == 0) x[0] = (nx + t) / R(2.0); }
     }
     __syncthreads();
-    if (D.npsd > 0) {                                                     // PsdCone / PsdConeTriangle, side <= 16 (convexset.jl:303-321, 402-412)
+    if constexpr (PSD) {                                                  // PsdCone / PsdConeTriangle, side <= 16 (convexset.jl:303-321, 402-412)
       batch_project_psd(D, s, ops.psd_ws, wv, lane);
       __syncthreads();
     }
@@ -423,19 +426,20 @@ __device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams
   for (int i = tid; i < m; i += BS) mu[i] = rho[i] * (w_prev[n + i] - s[i]);
 }
 
+template <bool PSD>
 __global__ __launch_bounds__(COSMO_BS) void k_batch_admm(BatchDev D, BParams P, long long iter_target, int do_init) {
   __shared__ real lds[COSMO_NNZ_PER_BLOCK];
   __shared__ real red[COSMO_BS / 64];
-  __shared__ __attribute__((aligned(16))) unsigned char psd_ws[(COSMO_BS / 64) * PSD16_WS_STRIDE];
+  __shared__ __attribute__((aligned(16))) unsigned char psd_ws[PSD ? (COSMO_BS / 64) * PSD16_WS_STRIDE : 16];
   const int k = blockIdx.x;
   if (D.ctl[k].status != 0) return;
   StreamOps ops;
   ops.A = bview(D.A, k); ops.AT = bview(D.AT, k); ops.PT = bview(D.PT, k); ops.lds = lds; ops.red = red; ops.psd_ws = psd_ws;
-  batch_admm_body<COSMO_BS>(D, P, iter_target, do_init, ops, red);
+  batch_admm_body<COSMO_BS, PSD>(D, P, iter_target, do_init, ops, red);
 }
 
 // LDS-resident variant: `img` holds one image of `img_stride` bytes per problem (header + arrays, see build_lds_images)
-template <int BS>
+template <int BS, bool PSD>
 __global__ __launch_bounds__(BS) void k_batch_admm_lds(BatchDev D, BParams P, long long iter_target, int do_init,
                                                        const unsigned char* __restrict__ img, long long img_stride) {
   extern __shared__ real dyn_lds[];
@@ -462,7 +466,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_lds(BatchDev D, BParams P, lo
   ops.xv = wsp; ops.tv = wsp + D.n; ops.red = wsp + D.n + D.m; ops.n = D.n;
   ops.psd_ws = base + ((img_stride + (long long)sizeof(real) * (D.n + D.m + BS / 64) + 15) / 16) * 16;     // behind the reduction slots (build_lds_images sizes it)
   __syncthreads();
-  batch_admm_body<BS>(D, P, iter_target, do_init, ops, ops.red);
+  batch_admm_body<BS, PSD>(D, P, iter_target, do_init, ops, ops.red);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -484,7 +488,7 @@ extern "C" void cosmo_dbg_batch_timing(long long* out) { (void)hipMemcpyFromSymb
 #define BT_END(slot)
 #endif
 
-template <int BS, int JN, int JM>
+template <int BS, int JN, int JM, bool PSD>
 __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, long long iter_target, int do_init,
                                                        const unsigned char* __restrict__ img, long long img_stride) {
   extern __shared__ real dyn_lds[];
@@ -515,6 +519,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   real* tv = wsp + n;             // m : vector gathered by the A' products; staging of s for the SOC projection
   real* red = wsp + n + m;        // BS / 64 reduction slots
   unsigned char* psd_ws = base + ((img_stride + (long long)sizeof(real) * (n + m + BS / 64) + 15) / 16) * 16;   // wave workspaces of the small PSD cones
+  (void)psd_ws;
 
   const long long on = (long long)k * n, om = (long long)k * m, onm = (long long)k * (n + m);
   // ---- load the persistent state and the per-element constants into registers -----------------------------------------
@@ -595,22 +600,38 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   //  with conflict-free value / index reads were all tried and were the same speed or slower)
   // (four nonzeros per trip with their loads issued together -- tried again in round 3 on top of the length-sorted assignment below, where
   //  the rows of a wave have similar lengths: 3608 vs 4129 batch-it/s on config 3, slower as in round 2)
-  auto rowA = [&](int r) -> real {                        // (A x)_r with x = xv
+  // Software-pipelined by one nonzero (round 4): the index (and value) loads of nonzero t + 1 are issued together with the gather of nonzero t, so
+  // that a trip costs ONE dependent LDS round trip instead of two (index -> gather).  Same left-to-right sums: bit-identical to the plain loops
+  // `for (t = a; t < b; ++t) s1 += Aval[t] * xv[Acol[t]]` (iterate hashes equal on all 1024 problems of config 3), 4100 -> 4367 batch-it/s
+  // (7.35 -> 6.95 us per Krylov iteration of the slowest problem; profiles/r04_batch_pipe_lab.txt).
+  auto rowA = [&](int r) -> real {
     real s1 = 0.0;
-    const int a = Arp[r], b2 = Arp[r + 1];
-    for (int t = a; t < b2; ++t) s1 += Aval[t] * xv[Acol[t]];
+    int t = Arp[r]; const int b2 = Arp[r + 1];
+    if (t < b2) {
+      real v = Aval[t]; int c = Acol[t];
+      for (++t; t < b2; ++t) { const real vn = Aval[t]; const int cn = Acol[t]; s1 += v * xv[c]; v = vn; c = cn; }
+      s1 += v * xv[c];
+    }
     return s1 + R(0.0);
   };
-  auto rowAT = [&](int r) -> real {                       // (A' y)_r with y = tv
+  auto rowAT = [&](int r) -> real {
     real s1 = 0.0;
-    const int a = Trp[r], b2 = Trp[r + 1];
-    for (int t = a; t < b2; ++t) s1 += Aval[Tpos[t]] * tv[Trow[t]];
+    int t = Trp[r]; const int b2 = Trp[r + 1];
+    if (t < b2) {
+      int p = Tpos[t], q2 = Trow[t];
+      for (++t; t < b2; ++t) { const int pn2 = Tpos[t], qn2 = Trow[t]; s1 += Aval[p] * tv[q2]; p = pn2; q2 = qn2; }
+      s1 += Aval[p] * tv[q2];
+    }
     return s1;
   };
-  auto rowP = [&](int r) -> real {                        // (P x)_r with x = xv
+  auto rowP = [&](int r) -> real {
     real s1 = 0.0;
-    const int a = Prp[r], b2 = Prp[r + 1];
-    for (int t = a; t < b2; ++t) s1 += Pval[t] * xv[Pcol[t]];
+    int t = Prp[r]; const int b2 = Prp[r + 1];
+    if (t < b2) {
+      real v = Pval[t]; int c = Pcol[t];
+      for (++t; t < b2; ++t) { const real vn = Pval[t]; const int cn = Pcol[t]; s1 += v * xv[c]; v = vn; c = cn; }
+      s1 += v * xv[c];
+    }
     return s1;
   };
 
@@ -811,9 +832,9 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       else if (kind == 2u) pv = (v != v) ? v : ((v > R(0.0)) ? v : R(0.0));
       else if (kind == 3u) pv = (v < blv[j]) ? blv[j] : ((v > buv[j]) ? buv[j] : v);
       sv[j] = pv;
-      if ((D.nsoc > 0 || D.npsd > 0) && i < m) tv[i] = pv;
+      if ((D.nsoc > 0 || PSD) && i < m) tv[i] = pv;
     }
-    if (D.nsoc > 0 || D.npsd > 0) {
+    if (D.nsoc > 0 || PSD) {
       __syncthreads();
       auto soc_one = [&](real* x, int d) {                              // SecondOrderCone (convexset.jl:100-114), on the LDS copy
         if (d == 0) return;
@@ -831,7 +852,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       } else {
         for (int cI = wvid; cI < D.nsoc; cI += BS / 64) soc_one(tv + D.soc_off[cI], D.soc_dim[cI]);
       }
-      if (D.npsd > 0) batch_project_psd(D, tv, psd_ws, wvid, lane);      // disjoint rows: no barrier needed between the two cone kinds
+      if constexpr (PSD) batch_project_psd(D, tv, psd_ws, wvid, lane);   // disjoint rows: no barrier needed between the two cone kinds
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; if (i < m) sv[j] = tv[i]; }
@@ -1280,8 +1301,12 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
   if (e && atoi(e) == 0) return COSMO_HIP_OK;
   const long long n = b->n, m = b->m;
   if (n > 65535 || m > 65535 || n + m == 0) return COSMO_HIP_OK;
+  int npsd = 0;
+  for (size_t c = 0; c < b->cones.type.size(); ++c)
+    if ((b->cones.type[c] == COSMO_HIP_PSD_SQUARE || b->cones.type[c] == COSMO_HIP_PSD_TRIANGLE) && b->cones.dim[c] > 1) npsd += 1;
   int bs = 512;
   if (const char* eb = getenv("COSMO_HIP_BATCH_BS")) { const int v = atoi(eb); if (v == 256 || v == 512 || v == 1024) bs = v; }
+  if (npsd > 0) bs = 512;                                        // the PSD instantiation of the LDS-image kernel exists for 512 threads
   // register-resident iterates (k_batch_admm_reg, 512 threads) when the vectors fit 1-2 (n) / 2-4 (m) elements per thread
   b->reg_mode = 0;
   { const char* er = getenv("COSMO_HIP_BATCH_REG");
@@ -1451,9 +1476,6 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
   for (int k = 0; k < b->nprob; ++k)
     BHIP(b, hipMemcpy(d + (size_t)k * stride, imgs[(size_t)k].data(), imgs[(size_t)k].size(), hipMemcpyHostToDevice));
   // wave workspaces of the small PSD cones behind the reduction slots: as many as fit, at most one per wave; none fits => streaming kernel
-  int npsd = 0;
-  for (size_t c = 0; c < b->cones.type.size(); ++c)
-    if ((b->cones.type[c] == COSMO_HIP_PSD_SQUARE || b->cones.type[c] == COSMO_HIP_PSD_TRIANGLE) && b->cones.dim[c] > 1) npsd += 1;
   const long long ws_base = ((stride + (long long)sizeof(real) * (n + m + bs / 64) + 15) / 16) * 16;
   int nws = 0;
   if (npsd > 0) {
@@ -1463,9 +1485,14 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
   b->D.psd_nws = nws;
   b->d_img = d; b->img_stride = stride; b->lds_bs = bs;
   b->lds_bytes = (int)(npsd > 0 ? ws_base + (long long)nws * PSD16_WS_STRIDE : stride + (long long)sizeof(real) * (n + m) + (long long)sizeof(real) * (bs / 64));
-  const void* fn = bs == 256 ? (const void*)k_batch_admm_lds<256> : (bs == 512 ? (const void*)k_batch_admm_lds<512> : (const void*)k_batch_admm_lds<1024>);
-  if (b->reg_mode == 1) fn = (const void*)k_batch_admm_reg<512, 1, 2>;
-  if (b->reg_mode == 2) fn = (const void*)k_batch_admm_reg<512, 2, 4>;
+  const void* fn = bs == 256 ? (const void*)k_batch_admm_lds<256, false> : (bs == 512 ? (const void*)k_batch_admm_lds<512, false> : (const void*)k_batch_admm_lds<1024, false>);
+  if (b->reg_mode == 1) fn = (const void*)k_batch_admm_reg<512, 1, 2, false>;
+  if (b->reg_mode == 2) fn = (const void*)k_batch_admm_reg<512, 2, 4, false>;
+  if (npsd > 0) {
+    fn = (const void*)k_batch_admm_lds<512, true>;
+    if (b->reg_mode == 1) fn = (const void*)k_batch_admm_reg<512, 1, 2, true>;
+    if (b->reg_mode == 2) fn = (const void*)k_batch_admm_reg<512, 2, 4, true>;
+  }
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, b->lds_bytes) != hipSuccess) {
     (void)hipGetLastError();
     b->d_img = nullptr; b->reg_mode = 0;          // the device does not grant that much LDS: streaming kernel
@@ -1474,17 +1501,22 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
 }
 
 static int32_t launch_batch_admm(cosmo_hip_batch* b, const BParams& P, long long target, int do_init) {
-  if (b->d_img && b->reg_mode == 1) {
-    hipLaunchKernelGGL((k_batch_admm_reg<512, 1, 2>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
-  } else if (b->d_img && b->reg_mode == 2) {
-    hipLaunchKernelGGL((k_batch_admm_reg<512, 2, 4>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
-  } else if (b->d_img) {
-    if (b->lds_bs == 256) hipLaunchKernelGGL((k_batch_admm_lds<256>), dim3(b->nprob), dim3(256), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
-    else if (b->lds_bs == 512) hipLaunchKernelGGL((k_batch_admm_lds<512>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
-    else hipLaunchKernelGGL((k_batch_admm_lds<1024>), dim3(b->nprob), dim3(1024), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
+  const bool psd = b->D.npsd > 0;
+#define LAUNCH_REG(JN_, JM_, PSD_) hipLaunchKernelGGL((k_batch_admm_reg<512, JN_, JM_, PSD_>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride)
+#define LAUNCH_LDS(BS_, PSD_) hipLaunchKernelGGL((k_batch_admm_lds<BS_, PSD_>), dim3(b->nprob), dim3(BS_), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride)
+  if (b->d_img && b->reg_mode == 1) { if (psd) LAUNCH_REG(1, 2, true); else LAUNCH_REG(1, 2, false); }
+  else if (b->d_img && b->reg_mode == 2) { if (psd) LAUNCH_REG(2, 4, true); else LAUNCH_REG(2, 4, false); }
+  else if (b->d_img) {
+    if (psd) LAUNCH_LDS(512, true);                                  // (build_lds_images fixed 512 threads for batches with PSD cones)
+    else if (b->lds_bs == 256) LAUNCH_LDS(256, false);
+    else if (b->lds_bs == 512) LAUNCH_LDS(512, false);
+    else LAUNCH_LDS(1024, false);
   } else {
-    hipLaunchKernelGGL(k_batch_admm, dim3(b->nprob), dim3(COSMO_BS), 0, b->stream, b->D, P, target, do_init);
+    if (psd) hipLaunchKernelGGL(k_batch_admm<true>, dim3(b->nprob), dim3(COSMO_BS), 0, b->stream, b->D, P, target, do_init);
+    else hipLaunchKernelGGL(k_batch_admm<false>, dim3(b->nprob), dim3(COSMO_BS), 0, b->stream, b->D, P, target, do_init);
   }
+#undef LAUNCH_REG
+#undef LAUNCH_LDS
   BHIP(b, hipGetLastError());
   return COSMO_HIP_OK;
 }

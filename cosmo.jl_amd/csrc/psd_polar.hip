@@ -140,7 +140,28 @@ struct PolarPlan {
   real* bparts = nullptr;
   real* bnrm = nullptr;    // per batched cone ||X||_F
   int* bgate = nullptr;      // per batched cone: 1 = its verification failed, the next fallback round processes it
+  // ---- per-cone lifting depth of the batch (round 4) ------------------------------------------------------------------------------------
+  // Every cone of the batch runs ITS OWN number of lifting steps bk[c] (cone c joins the batch's schedule at step kmax - bk[c]: the gate table
+  // lgate[t * n + c] = (t >= kmax - bk[c]) is handed to the product kernels as the per-cone gate they already have for the fallback rounds) and
+  // the depth follows the cone's own verification history: bk[c] - 1 after `bm[c]` consecutive verified projections, bk[c] + 1 (and the cone
+  // alone takes a fallback round, as before) on a failed verification, after which the cone waits twice as long before it probes downwards
+  // again.  The a-posteriori check is unchanged, so the error bound of every projection is the same rigorous 8 d eps ||X||_F.  Replay on the
+  // spectra of BASELINE config 5 (tests/studies/lift_depth_replay.py, profiles/r04_lift_depth_replay.txt): minimal passing depth 3-5 for
+  // 90 % of the (iteration, cone) pairs against the fixed 10.  A function of each cone's own history only => independent of how the cones are
+  // partitioned over ranks.  COSMO_HIP_POLAR_ADAPT=0: fixed depth k_lift for all cones (the schedule until round 3).
+  int adapt = 1;
+  std::vector<int> bk, bstreak, bm;     // per batched cone: lifting depth, verified projections since the last change, patience
+  int* d_lgate = nullptr;                // (LIFT_CAP x n) gate table of the lifting steps
+  int* d_ubuf = nullptr;                 // per cone: work buffer (1 | 2) that receives U_0 (the one that is `iu` when the cone joins)
+  int* bgate_host = nullptr;             // pinned: per-cone verification result of round 0
+  int lgate_kmax = -1;                   // kmax the device tables were built for (-1: dirty)
+  long long depth_fail = 0, depth_down = 0, depth_proj = 0;
+  int seen_proj_batch = 0;               // PolarDev::projections at the last depth-control step
+  std::vector<int> lk, lstreak, lm;      // the same control per LARGE cone (one cone per projection: the depth is simply its main schedule)
+  int seen_proj_large = 0;
+  double wprod_last = 0.0;               // sum_c d_c^3 * products of cone c / sum_c d_c^3 of the last projection (main schedule + verification)
 };
+#define POLAR_LIFT_CAP 18
 
 extern "C" int32_t cosmo_hip_polar_schedule(int32_t k_lift, double* abc, int32_t* nsteps) {
   if (k_lift < 0 || k_lift > 64 || !nsteps) return COSMO_HIP_ERR_INVALID;
@@ -1155,7 +1176,8 @@ __global__ __launch_bounds__(COSMO_BS) void k_bpolar_populate(const Ctl* __restr
   if (threadIdx.x == 0) parts[(size_t)blockIdx.y * 2 * BPX + blockIdx.x] = acc;
 }
 __global__ __launch_bounds__(COSMO_BS) void k_bpolar_scale(const Ctl* __restrict__ ctl, int guard, const BatchCone* __restrict__ cones,
-                                                           const real* __restrict__ parts, real* __restrict__ W, real* __restrict__ bnrm) {
+                                                           const real* __restrict__ parts, real* __restrict__ W, real* __restrict__ bnrm,
+                                                           const int* __restrict__ ubuf) {
   if (guard && ctl->halt) return;
   const BatchCone cn = cones[blockIdx.y];
   real nf2 = 0.0;
@@ -1165,7 +1187,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_bpolar_scale(const Ctl* __restrict
   if (blockIdx.x == 0 && threadIdx.x == 0) bnrm[blockIdx.y] = nf;
   const long long n2 = (long long)cn.ld * cn.ld;
   const real* X = W + cn.woff;
-  real* U = W + cn.woff + n2;
+  real* U = W + cn.woff + (ubuf ? ubuf[blockIdx.y] : 1) * n2;       // the buffer that is `iu` at the step where this cone joins the schedule
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < n2; i += (long long)gridDim.x * COSMO_BS) U[i] = X[i] * inv;
 }
 __global__ __launch_bounds__(COSMO_BS) void k_bpolar_finish(const Ctl* __restrict__ ctl, int guard, const BatchCone* __restrict__ cones,
@@ -1266,6 +1288,9 @@ void polar_plan_destroy(cosmo_hip_handle* h) {
   if (q->bparts) (void)hipFree(q->bparts);
   if (q->bnrm) (void)hipFree(q->bnrm);
   if (q->bgate) (void)hipFree(q->bgate);
+  if (q->d_lgate) (void)hipFree(q->d_lgate);
+  if (q->d_ubuf) (void)hipFree(q->d_ubuf);
+  if (q->bgate_host) (void)hipHostFree(q->bgate_host);
   if (q->dev) (void)hipFree(q->dev);
   delete q;
   h->psd_polar = nullptr;
@@ -1289,14 +1314,15 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
   PolarPlan* q = new PolarPlan();
   h->psd_polar = q;
   if (const char* e = getenv("COSMO_HIP_POLAR_KLIFT")) q->k_lift = std::min(40, std::max(0, atoi(e)));
+  if (const char* e = getenv("COSMO_HIP_POLAR_ADAPT")) q->adapt = atoi(e) ? 1 : 0;
   if (const char* e = getenv("COSMO_HIP_POLAR_RESCALE")) q->rescale = atoi(e) ? 1 : 0;
   if (const char* e = getenv("COSMO_HIP_POLAR_STREAMK")) q->streamk = atoi(e) ? 1 : 0;
   if (const char* e = getenv("COSMO_HIP_POLAR_BATCH_TS96")) q->batch_ts96 = atoi(e) ? 1 : 0;
   if (const char* e = getenv("COSMO_HIP_POLAR_BATCH_WAVE")) q->batch_wave = atoi(e) ? 1 : 0;
   q->speculate = (large_list.size() > 2) ? 1 : 0;          // many large cones: no pipeline drain per cone (see the header)
   if (const char* e = getenv("COSMO_HIP_POLAR_SPECULATE")) q->speculate = atoi(e) ? 1 : 0;
-  HIPCHK(h, hipHostMalloc((void**)&q->gate_host, sizeof(int), hipHostMallocDefault));
-  *q->gate_host = 0;
+  HIPCHK(h, hipHostMalloc((void**)&q->gate_host, 8 * sizeof(int), hipHostMallocDefault));     // {gate, rounds, verified, unverified, projections} of PolarDev
+  for (int i = 0; i < 8; ++i) q->gate_host[i] = 0;
   if (const char* e = getenv("COSMO_HIP_POLAR_ROUNDS")) q->max_rounds = std::min(8, std::max(0, atoi(e)));
   HIPCHK(h, hipMalloc((void**)&q->dev, sizeof(PolarDev)));
   HIPCHK(h, hipMemset(q->dev, 0, sizeof(PolarDev)));
@@ -1468,6 +1494,12 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
     HIPCHK(h, hipMalloc((void**)&q->bnrm, sizeof(real) * q->bcones.size()));
     HIPCHK(h, hipMalloc((void**)&q->bgate, sizeof(int) * q->bcones.size()));
     HIPCHK(h, hipMemset(q->bgate, 0, sizeof(int) * q->bcones.size()));
+    { const size_t nb = q->bcones.size();
+      q->bk.assign(nb, q->k_lift); q->bstreak.assign(nb, 0); q->bm.assign(nb, 3);
+      HIPCHK(h, hipMalloc((void**)&q->d_lgate, sizeof(int) * nb * POLAR_LIFT_CAP));
+      HIPCHK(h, hipMalloc((void**)&q->d_ubuf, sizeof(int) * nb));
+      HIPCHK(h, hipHostMalloc((void**)&q->bgate_host, sizeof(int) * nb, hipHostMallocDefault));
+      q->lgate_kmax = -1; }
     HIPCHK(h, hipMemcpy(q->d_bcones, q->bcones.data(), sizeof(BatchCone) * q->bcones.size(), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(q->d_btiles, tiles.data(), sizeof(int4) * tiles.size(), hipMemcpyHostToDevice));
     (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch<0, 3, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
@@ -1519,15 +1551,36 @@ static void launch_bgemm(PolarPlan* q, hipStream_t st, const Ctl* ctl, int guard
   }
 }
 
-// all mid-size cones of the batch advance together: 3 launches per step for the whole batch
+// all mid-size cones of the batch advance together: 3 launches per step for the whole batch; with the per-cone lifting depth (PolarPlan::adapt) a
+// cone joins at lifting step kmax - bk[c] and the product kernels skip its tiles before that
 int32_t polar_enqueue_project_batch(cosmo_hip_handle* h, real* s, int guard) {
   PolarPlan* q = static_cast<PolarPlan*>(h->psd_polar);
   PsdPlan* p = h->psd;
   hipStream_t st = h->stream;
   const int n = (int)q->bcones.size();
   real* vparts = q->bparts + (size_t)2 * BPX * n;
+  // adaptive per-cone depth needs the per-cone verification results on the host: not in speculative mode (no synchronisation inside a projection),
+  // not with a schedule forced through COSMO_HIP_POLAR_KLIFT
+  const bool adapt = q->adapt && !q->speculate && !getenv("COSMO_HIP_POLAR_KLIFT") && q->k_lift <= POLAR_LIFT_CAP;
+  int kmax = q->k_lift;
+  if (adapt) {
+    kmax = 0;
+    for (int c = 0; c < n; ++c) kmax = std::max(kmax, q->bk[c]);
+    if (q->lgate_kmax != kmax) {                     // (a change of any bk[c] resets lgate_kmax to -1)
+      std::vector<int> lg((size_t)std::max(kmax, 1) * n, 0), ub((size_t)n, 1);
+      for (int c = 0; c < n; ++c) {
+        const int t0 = kmax - q->bk[c];
+        for (int t = t0; t < kmax; ++t) lg[(size_t)t * n + c] = 1;
+        ub[(size_t)c] = (t0 & 1) ? 2 : 1;            // (iu, iy) = (1, 2) at even steps, (2, 1) at odd ones
+      }
+      HIPCHK(h, hipMemcpyAsync(q->d_lgate, lg.data(), sizeof(int) * lg.size(), hipMemcpyHostToDevice, st));
+      HIPCHK(h, hipMemcpyAsync(q->d_ubuf, ub.data(), sizeof(int) * ub.size(), hipMemcpyHostToDevice, st));
+      HIPCHK(h, hipStreamSynchronize(st));           // the host vectors go out of scope; rare (only when a depth changed)
+      q->lgate_kmax = kmax;
+    }
+  }
   hipLaunchKernelGGL(k_bpolar_populate, dim3(BPX, n), dim3(COSMO_BS), 0, st, h->ctl, guard, q->d_bcones, s, q->BW, q->bparts);
-  hipLaunchKernelGGL(k_bpolar_scale, dim3(BPX, n), dim3(COSMO_BS), 0, st, h->ctl, guard, q->d_bcones, q->bparts, q->BW, q->bnrm);
+  hipLaunchKernelGGL(k_bpolar_scale, dim3(BPX, n), dim3(COSMO_BS), 0, st, h->ctl, guard, q->d_bcones, q->bparts, q->BW, q->bnrm, adapt ? (const int*)q->d_ubuf : (const int*)nullptr);
   int iu = 1, iy = 2, products = 0;
   auto step = [&](const real* co, const int* gate) {
     launch_bgemm<0>(q, st, h->ctl, guard, gate, iu, iu, iu, iy, 1.0, 0.0);       // Y = U^2
@@ -1544,14 +1597,36 @@ int32_t polar_enqueue_project_batch(cosmo_hip_handle* h, real* s, int guard) {
                        vparts, q->bnrm, q->tol_factor);
     products += 2; q->launches[3] += 2;
   };
-  for (int t = 0; t < q->k_lift; ++t) step(kPolarLift, nullptr);
+  for (int t = 0; t < kmax; ++t) step(kPolarLift, adapt ? (const int*)(q->d_lgate + (size_t)t * n) : (const int*)nullptr);
   for (int t = 0; t < POLAR_NFIN; ++t) step(kPolarFinish[t], nullptr);
   verify(0, nullptr);
   q->products_last_batch = products;
+  { double wsum = 0.0, w3 = 0.0;                             // what the launches cost: products of a cone weighted by its d^3
+    for (int c = 0; c < n; ++c) { const double d3 = (double)q->bcones[c].d * q->bcones[c].d * q->bcones[c].d; w3 += d3; wsum += d3 * (3.0 * ((adapt ? q->bk[c] : kmax) + POLAR_NFIN) + 2.0); }
+    q->wprod_last = w3 > 0.0 ? wsum / w3 : 0.0; }
   for (int r = 1; r <= q->max_rounds; ++r) {                 // guarded fallback rounds (even number of steps: iu is preserved)
-    if (!q->speculate) {                                     // ask the device whether the last verification failed
-      HIPCHK(h, hipMemcpyAsync(q->gate_host, &q->dev->gate, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (!q->speculate) {                                     // ask the device whether the last verification failed (and, round 1 of an adaptive run, which cones)
+      HIPCHK(h, hipMemcpyAsync(q->gate_host, &q->dev->gate, (adapt && r == 1 ? 5 : 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+      if (adapt && r == 1) HIPCHK(h, hipMemcpyAsync(q->bgate_host, q->bgate, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));
       HIPCHK(h, hipStreamSynchronize(st));
+      if (adapt && r == 1 && q->gate_host[4] != q->seen_proj_batch) {
+        // depth control from this projection's per-cone results.  PolarDev::projections advances only when the verification really ran: in a
+        // halted loop (status decided, or a Krylov stall waiting for the host) every kernel above was a no-op and the flags are stale
+        q->seen_proj_batch = q->gate_host[4];
+        q->depth_proj += 1;
+        bool changed = false;
+        for (int c = 0; c < n; ++c) {
+          if (*q->gate_host && q->bgate_host[c]) {           // failed at depth bk[c]: one step deeper, probe downwards half as often
+            q->depth_fail += 1;
+            if (q->bk[c] < POLAR_LIFT_CAP) { q->bk[c] += 1; changed = true; }
+            q->bstreak[c] = 0;
+            q->bm[c] = std::min(96, 2 * q->bm[c]);
+          } else if (++q->bstreak[c] >= q->bm[c] && q->bk[c] > 0) {
+            q->bk[c] -= 1; q->bstreak[c] = 0; q->depth_down += 1; changed = true;
+          }
+        }
+        if (changed) q->lgate_kmax = -1;
+      }
       if (!*q->gate_host) break;
     }
     for (int t = 0; t < POLAR_RLIFT; ++t) step(kPolarLift, q->bgate);
@@ -1596,7 +1671,9 @@ int32_t polar_enqueue_project(cosmo_hip_handle* h, real* s, int guard) {
                          q->nrm + ci, q->tol_factor * cn.d * PSD_EPS);
       products += 2;
     };
-    int k_main = q->k_lift;
+    const bool adapt = q->adapt && !q->speculate && !getenv("COSMO_HIP_POLAR_KLIFT") && q->k_lift <= POLAR_LIFT_CAP;
+    if (adapt && q->lk.size() != q->cones.size()) { q->lk.assign(q->cones.size(), q->k_lift); q->lstreak.assign(q->cones.size(), 0); q->lm.assign(q->cones.size(), 3); }
+    int k_main = adapt ? q->lk[ci] : q->k_lift;
     if (q->rescale && k_main > 0) {
       // first lifting step with the spectral rescaling between its first and second product; from d = 1024 on the gain (>= 4.2)
       // exceeds the slope of a lifting step, so the main schedule is one step shorter
@@ -1616,8 +1693,14 @@ int32_t polar_enqueue_project(cosmo_hip_handle* h, real* s, int guard) {
     q->products_last_large = products;
     for (int r = 1; r <= q->max_rounds; ++r) {
       if (!q->speculate) {
-        HIPCHK(h, hipMemcpyAsync(q->gate_host, &q->dev->gate, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipMemcpyAsync(q->gate_host, &q->dev->gate, (adapt && r == 1 ? 5 : 1) * sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(h, hipStreamSynchronize(st));
+        if (adapt && r == 1 && q->gate_host[4] != q->seen_proj_large) {        // depth control of this cone (see PolarPlan::adapt)
+          q->seen_proj_large = q->gate_host[4];
+          q->depth_proj += 1;
+          if (*q->gate_host) { q->depth_fail += 1; q->lk[ci] = std::min(POLAR_LIFT_CAP, q->lk[ci] + 1); q->lstreak[ci] = 0; q->lm[ci] = std::min(96, 2 * q->lm[ci]); }
+          else if (++q->lstreak[ci] >= q->lm[ci] && q->lk[ci] > 2) { q->lk[ci] -= 1; q->lstreak[ci] = 0; q->depth_down += 1; }
+        }
         if (!*q->gate_host) break;
       }
       for (int t = 0; t < POLAR_RLIFT_LARGE; ++t) step(kPolarLift, &q->dev->gate);
@@ -1640,6 +1723,7 @@ int32_t polar_enqueue_project(cosmo_hip_handle* h, real* s, int guard) {
 int32_t polar_adapt(cosmo_hip_handle* h) {
   PolarPlan* q = static_cast<PolarPlan*>(h->psd_polar);
   if (!q || !q->dev || h->comm || getenv("COSMO_HIP_POLAR_KLIFT")) return COSMO_HIP_OK;
+  if (q->adapt && !q->speculate) return COSMO_HIP_OK;          // the per-cone depth control (PolarPlan::adapt) has taken over
   PolarDev now;
   HIPCHK(h, hipMemcpyAsync(&now, q->dev, sizeof now, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1664,6 +1748,26 @@ extern "C" int32_t cosmo_hip_polar_stats(cosmo_hip_handle* h, int64_t out[16]) {
   out[8] = q->products_last_large; out[9] = now.rounds; out[10] = now.verified; out[11] = q->products_last_batch;
   out[12] = q->k_lift + POLAR_NFIN; out[13] = now.unverified; out[14] = now.projections;
   out[15] = (int64_t)llround((double)now.err_max * 1e18);       // max verified error bound relative to ||X||_F, in units of 1e-18
+  return COSMO_HIP_OK;
+}
+
+// out = {adaptive depth on, min / max / mean x 1000 of the per-cone lifting depths (batch cones, else large cones), d^3-weighted products per
+//        projection x 1000 of the batch's last main schedule, failed verifications, downward probes, projections seen by the depth control}
+extern "C" int32_t cosmo_hip_polar_depth_stats(cosmo_hip_handle* h, int64_t out[8]) {
+  if (!h || !out) return COSMO_HIP_ERR_INVALID;
+  for (int i = 0; i < 8; ++i) out[i] = 0;
+  PolarPlan* q = static_cast<PolarPlan*>(h->psd_polar);
+  if (!q) return COSMO_HIP_OK;
+  const bool adapt = q->adapt && !q->speculate && !getenv("COSMO_HIP_POLAR_KLIFT") && q->k_lift <= POLAR_LIFT_CAP;
+  out[0] = adapt ? 1 : 0;
+  const std::vector<int>& ks = !q->bk.empty() ? q->bk : q->lk;
+  if (adapt && !ks.empty()) {
+    long long sum = 0; int mn = ks[0], mx = ks[0];
+    for (int v : ks) { sum += v; mn = std::min(mn, v); mx = std::max(mx, v); }
+    out[1] = mn; out[2] = mx; out[3] = (1000 * sum) / (long long)ks.size();
+  } else { out[1] = out[2] = q->k_lift; out[3] = 1000LL * q->k_lift; }
+  out[4] = (int64_t)llround(1000.0 * q->wprod_last);
+  out[5] = q->depth_fail; out[6] = q->depth_down; out[7] = q->depth_proj;
   return COSMO_HIP_OK;
 }
 

@@ -147,6 +147,8 @@ def main(which, iters):
                                             adaptive_per_cone_M5=round(cost_adaptive(5, True), 2), adaptive_per_cone_M20=round(cost_adaptive(20, True), 2),
                                             adaptive_whole_batch_M5=round(cost_adaptive(5, False), 2), adaptive_whole_batch_M20=round(cost_adaptive(20, False), 2)))
     print(json.dumps(res))
+    if os.environ.get("LIFT_REPLAY_DUMP"):
+        np.savez_compressed(os.environ["LIFT_REPLAY_DUMP"], need=need, dims=dims)
 
 
 if __name__ == "__main__":

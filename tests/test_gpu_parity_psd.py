@@ -306,8 +306,86 @@ def test_cg_operator_split_is_the_same_operator(monkeypatch):
         sol, its = model.handle.kkt_solve(rhs)
         out[split] = (res, sol, its)
     (r1, s1, k1), (r0, s0, k0) = out["1"], out["0"]
-    assert r1.iter == r0.iter == 60 and abs(k1 - k0) <= 1
+    assert r1.iter == r0.iter == 60 and abs(k1 - k0) <= 3               # a 1e-10 threshold on a ~140-iteration solve
     assert abs(r1.kkt_iters_total - r0.kkt_iters_total) <= 0.02 * r0.kkt_iters_total
     assert np.linalg.norm(s1 - s0) <= 1e-8 * np.linalg.norm(s0)
     assert np.max(np.abs(r1.x - r0.x)) <= 1e-7 * max(1.0, np.max(np.abs(r0.x)))
     assert np.allclose(r1.info.rho_updates, r0.info.rho_updates, rtol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# per-cone lifting depth of the matrix-sign projections (round 4, csrc/psd_polar.hip PolarPlan::adapt): the number of lifting steps of every
+# cone follows that cone's own verification history; the a-posteriori check -- and with it the error bound of EVERY projection -- is unchanged
+# ---------------------------------------------------------------------------------------------------------------------
+def test_adaptive_lifting_depth_keeps_every_projection_within_the_bound_and_saves_products(monkeypatch):
+    """A batch of cones with very different spectra projected 40 times: (a) cones whose smallest |lambda| is large settle at a small depth,
+    a cone with an eigenvalue of 1e-6 ||X|| stays deep; (b) EVERY one of the 40 projections of EVERY cone is within 64 d eps ||X||_F of the
+    LAPACK projection (failed verifications take their fallback round: unverified == 0); (c) the d^3-weighted product count falls well below the
+    fixed schedule's 47; (d) COSMO_HIP_POLAR_ADAPT=0 is the fixed schedule of round 3."""
+    rng = np.random.default_rng(404)
+    dims = [24, 40, 64, 90, 130, 200, 33, 57]
+    sets = [cj.PsdConeTriangle(d * (d + 1) // 2) for d in dims]
+    mats = []
+    for i, d in enumerate(dims):
+        lam = gapped_spectrum(rng, d)
+        if i == 3:
+            lam[0] = 1e-6 * np.linalg.norm(lam)                       # needs ~9 lifting steps: must not be dragged down by its neighbours
+        mats.append(sym_with_spectrum(rng, lam))
+    s0 = np.concatenate([cj.problems.svec(M) for M in mats])
+    ref = s0.copy()
+    O.project(ref, util.oracle_cones(sets), {})
+    offs = np.concatenate([[0], np.cumsum([K.dim for K in sets])])
+    h = _handle_for_sets(sets)
+    first = None
+    for it in range(40):
+        out, ranks, _ = h.project(s0 * (1.0 + 0.01 * it))              # the same spectra at a slowly changing scale, as consecutive ADMM iterates are
+        for k, d in enumerate(dims):
+            err = np.linalg.norm(out[offs[k]:offs[k + 1]] / (1.0 + 0.01 * it) - ref[offs[k]:offs[k + 1]])
+            assert err <= 64 * d * EPS * np.linalg.norm(mats[k]), (it, k, err / (d * EPS * np.linalg.norm(mats[k])))
+        st = h.polar_depth_stats()
+        if it == 0:
+            first = st
+    ps = h.polar_stats()
+    assert first["adaptive"] == 1 and first["depth_min"] == first["depth_max"] == 10 and abs(first["weighted_products_per_projection"] - 47.0) < 1e-9
+    assert ps["unverified"] == 0 and ps["batch_cones"] == len(sets)
+    assert st["depth_min"] <= 4 and st["depth_max"] >= 8, st            # well-separated spectra went down, the 1e-6 cone did not
+    assert st["weighted_products_per_projection"] <= 40.0 and st["downward_probes"] > 0, st
+    assert st["failed_verifications"] >= 1                              # the probing really found the edge (and the fallback round repaired it)
+    h.close()
+    monkeypatch.setenv("COSMO_HIP_POLAR_ADAPT", "0")
+    h = _handle_for_sets(sets)
+    for it in range(8):
+        out0, _, _ = h.project(s0)
+    st0 = h.polar_depth_stats()
+    assert st0["adaptive"] == 0 and st0["depth_min"] == st0["depth_max"] == 10 and abs(st0["weighted_products_per_projection"] - 47.0) < 1e-9
+    assert h.polar_stats()["fallback_rounds"] == 0
+    h.close()
+
+
+def test_adaptive_lifting_depth_large_cone_and_loop_level_agreement(monkeypatch):
+    """(a) A single large cone (d = 320 > 256: the per-cone path) projected repeatedly: its depth goes down, every projection within the bound.
+    (b) Loop level: a small chordal SDP solved with and without the adaptive depth -- same status, iteration count within one check interval,
+    objective to 1e-6 (the projections differ by at most their verified bound ~1e-13 ||X||_F per iteration)."""
+    rng = np.random.default_rng(77)
+    d = 320
+    K = cj.PsdConeTriangle(d * (d + 1) // 2)
+    M = sym_with_spectrum(rng, gapped_spectrum(rng, d))
+    s0 = cj.problems.svec(M)
+    ref = s0.copy(); O.project(ref, util.oracle_cones([K]), {})
+    h = _handle_for_sets([K])
+    prods = []
+    for it in range(24):
+        out, _, _ = h.project(s0)
+        assert np.linalg.norm(out - ref) <= 64 * d * EPS * np.linalg.norm(M)
+        prods.append(h.polar_stats()["products_last_large"])
+    assert h.polar_stats()["large_cones"] == 1 and h.polar_stats()["unverified"] == 0
+    assert prods[0] > prods[-1] and h.polar_depth_stats()["downward_probes"] > 0, prods
+    h.close()
+    prob = cj.problems.chordal_sdp(ncliques=12, dmin=18, dmax=70, sep_min=1, sep_max=3, n_total=2500, n_zero=40, n_nonneg=80)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("COSMO_HIP_POLAR_ADAPT", flag)
+        md = cj.Model(); md.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], cj.Settings(kkt_solver=cj.CGIndirectKKTSolver, max_iter=3000))
+        res[flag] = cj.optimize(md)
+    a, b = res["1"], res["0"]
+    assert a.status == b.status == "Solved" and abs(a.iter - b.iter) <= 25 and abs(a.obj_val - b.obj_val) <= 1e-6 * (1 + abs(b.obj_val))
