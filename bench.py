@@ -329,8 +329,10 @@ def bench_cfg2(ctx, args, steps, warmup):
                            algorithmic_bytes_per_launch=bytes_op, avg_launch_us=round(t_op * 1e6, 3), launches_timed=200, timing="best of 3 x 200 back-to-back launches",
                            other={"k_spmv_A_rho (A v)": other(bytes_A, t_A), "k_cg_rhs (A' y)": other(bytes_AT, t_AT), "k_spmv_plain (P x)": other(bytes_P, t_P)})
     b_iter = iteration_bytes(ab, kbar)
-    out["config"] = {"workload": "cfg2: random sparse QP n=%d m=%d nnz(A)=%d nnz(P)=%d, Box cone, CG indirect KKT (tol 1/k^1.5), "
-                                 "check_termination=25, adaptive_rho_interval=40, Ruiz scaling=10, eps=0" % (n, m, nnzA, nnzP),
+    # (`workload` stays under 120 characters: the driver's parsed copy of the line cut the longer string of round 3 in the middle of a word)
+    out["config"] = {"workload": "cfg2: random sparse QP n=%d m=%d nnz(A)=%d, Box cone, CG indirect KKT" % (n, m, nnzA),
+                     "workload_detail": "nnz(P)=%d; CG tolerance 1/k^1.5, check_termination=25, adaptive_rho_interval=40, Ruiz scaling=10, eps_abs=eps_rel=0 (fixed work), "
+                                        "alpha=1.6, sigma=1e-6, rho=0.1, EmptyAccelerator (SURVEY 8d)" % nnzP,
                      "parallelism": "replicas x%d (a single sparse QP does not shard; SURVEY 8e)" % world,
                      "mean_cg_iters_per_admm_iter": round(kbar, 3), "kkt_budget_stalls": stats1["kkt_budget_stalls"],
                      "iteration_roofline_frac": round(b_iter * (value / world) / (HBM_PEAK_GBS * 1e9), 4), "rank_seconds": rank_seconds,
@@ -365,6 +367,7 @@ def bench_cfg3(ctx, args, steps, warmup):
     out = dict(value=value, ms_per_step=1e3 * elapsed / steps, steps=steps, warmup=warmup, scaling="strong")
     rank_seconds = ctx.rank_seconds()
     parity = None
+    kry_every = ctx.all_gather((kk1 - kk0).astype(np.float64)) if ctx.world > 1 else None
     if ctx.world > 1:
         # parity evidence inside the N > 1 line: a sample of problems FROM EVERY RANK's shard (its first `per`), iterates after warmup + steps
         # iterations, against ONE single-rank batch of exactly those problems run by rank 0 with the same call sequence.  The problems of a batch are
@@ -396,13 +399,15 @@ def bench_cfg3(ctx, args, steps, warmup):
     n, m = mods[0].n, mods[0].m
     nnzA, nnzP = int(np.mean([md.A.nnz for md in mods])), int(np.mean([md.P.nnz for md in mods]))
     kry = (kk1 - kk0).astype(np.float64)                      # Krylov iterations per problem inside the timed steps (device counters)
-    out["config"] = {"workload": "cfg3: %d independent SOCPs n=%d m=%d nnz(A)~%d, 50 SecondOrderCone(20) each; one step = one ADMM iteration of every "
-                                 "problem; one persistent workgroup per problem (csrc/batch.hip)" % (nprob, n, m, nnzA),
+    kry_all = np.concatenate(kry_every) if kry_every is not None else kry
+    out["config"] = {"workload": "cfg3: %d independent SOCPs n=%d m=%d nnz(A)~%d, 50 SecondOrderCone(20) each" % (nprob, n, m, nnzA),
+                     "workload_detail": "one step = one ADMM iteration of every problem; one persistent workgroup per problem (csrc/batch.hip)",
                      "parallelism": "batch sharded over %d rank(s), %d problems on rank 0, no collective" % (ctx.world, hi - lo),
                      "problem_iterations_per_s": round(value * nprob, 1), "rank_seconds": rank_seconds, "parity": parity,
                      "krylov_iterations_per_problem_in_timed_steps": dict(mean=round(float(kry.mean()), 1), max=int(kry.max()), min=int(kry.min()),
                                                                           largest_16=[int(v) for v in np.sort(kry)[::-1][:16]]),
-                     "us_per_krylov_iteration_of_the_slowest_problem": round(1e6 * elapsed / max(float(kry.max()), 1.0), 3)}
+                     "us_per_krylov_iteration_of_the_slowest_problem": round(1e6 * elapsed / max(float(kry.max()), 1.0), 3),
+                     "scaling_model": cfg3_scaling_model(cj, kry_all, elapsed, ctx.world)}
     # What bounds the persistent kernel is the LDS: every Krylov iteration streams the problem's LDS image once through the two sparse passes --
     # A pass: (value 8 B + u16 column + 8 B gathered x) per nonzero; [P | A'] pass: (u16 position + u16 row + 8 B value + 8 B gathered y) per
     # nonzero of A and (8 + 2 + 8) per nonzero of P.  achieved = MEASURED Krylov iterations of rank 0's problems x those bytes / elapsed, against
@@ -431,6 +436,26 @@ def bench_cfg3(ctx, args, steps, warmup):
                                               "scaled to %d problems solved one after the other (the reference's own batch mode)" % (nsamp, warmup + steps, secs, nprob))
         args.deferred.append(cpu_leg)
     B.close()
+    return out
+
+
+def cfg3_scaling_model(cj, kry_all, elapsed, world, slots_per_gpu=256):
+    """What bounds a batch step, from the MEASURED per-problem Krylov counts of the timed window: one persistent workgroup per problem and one workgroup per
+    CU (the problem's LDS image fills the CU), so a rank's step takes  t_k * max(longest chain on the rank, work of the rank / 256 CU slots)  with t_k = the
+    measured seconds per Krylov iteration of the slowest problem.  The straggler's serial chain does not shrink with more GPUs: the bound on the sharded
+    speed-up is ~1 as long as  max K_p >> sum K_p / 256  (SURVEY 8e promised "~linear"; this is the measured reason why not)."""
+    K = np.asarray(kry_all, dtype=np.float64)
+    kmax = max(float(K.max()), 1.0)
+    t_k = elapsed / max(float(max(K[lo:hi].max() if hi > lo else 0.0 for lo, hi in (cj.model.shard_range(K.size, r, world) for r in range(world)))), 1.0)
+    out = dict(seconds_per_krylov_iteration=round(t_k, 9), longest_chain_krylov_iterations=int(kmax), total_krylov_iterations=int(K.sum()),
+               cu_slot_utilisation_this_run=round(float(K.sum()) * t_k / (slots_per_gpu * world * elapsed), 4), predicted={})
+    t1 = None
+    for N in (1, 2, 4, 8):
+        per_rank = [K[lo:hi] for lo, hi in (cj.model.shard_range(K.size, r, N) for r in range(N))]
+        tN = t_k * max(max((float(k.max()) if k.size else 0.0), float(k.sum()) / slots_per_gpu) for k in per_rank)
+        t1 = tN if N == 1 else t1
+        out["predicted"]["%d" % N] = dict(ms_per_window=round(1e3 * tN, 3), chain_limited=bool(all((k.max() if k.size else 0) >= k.sum() / slots_per_gpu for k in per_rank)),
+                                         speedup_bound=round(t1 / tN, 3))
     return out
 
 
@@ -561,9 +586,14 @@ def cfg5_sharded_parity_leg(ctx, args, prob, iters=12):
                          "infinity norm relative to the single-GPU run of rank 0")
 
 
+NO_PREWARM = [False]
+
+
 def gpu_prewarm(h, seconds=0.3):
     """Bring the GPU clocks up before a short timed window: back-to-back launches of the sign iteration's product kernel on the handle's WORK
     matrices (the measurement hook of the library; the next projection overwrites them, no ADMM state is touched)."""
+    if NO_PREWARM[0]:          # profiling runs (rocprofv3 --stats): per-kernel averages must come from the loop's own launches
+        return
     ps = h.polar_stats()
     which = 1 if ps["batch_cones"] > 0 else (0 if ps["large_cones"] > 0 else None)
     if which is None:
@@ -683,8 +713,8 @@ def bench_cfg5(ctx, args, steps, warmup):
     else:
         par = ("cliques sharded over %d ranks (contiguous cone ranges balanced by sum d^3; affine step replicated; one RCCL broadcast group of the "
                "projected slices of s per iteration)" % ctx.world)
-    out["config"] = {"workload": "cfg5: chordal-decomposed SDP n=%d m=%d nnz(A)=%d, %d PsdConeTriangle cliques d in [%d, %d] + ZeroSet(%d) + Nonnegatives(%d), "
-                                 "CG indirect KKT" % (model.n, model.m, model.A.nnz, dk.size, dk.min(), dk.max(), prob["sets"][0].dim, prob["sets"][1].dim),
+    out["config"] = {"workload": "cfg5: chordal SDP n=%d m=%d, %d PSD cliques d in [%d, %d] + Zero/Nonneg rows, CG indirect KKT" % (model.n, model.m, dk.size, dk.min(), dk.max()),
+                     "workload_detail": "nnz(A)=%d, PsdConeTriangle cliques, ZeroSet(%d) + Nonnegatives(%d)" % (model.A.nnz, prob["sets"][0].dim, prob["sets"][1].dim),
                      "parallelism": par,
                      "mean_cg_iters_per_admm_iter": round(kbar, 3), "comm": h.bench_comm, "row_shard": h.row_shard_info(), "cg_persist": h.cg_persist_stats(),
                      "cg_assembled_operator": h.fold_stats(),
@@ -827,6 +857,7 @@ def main():
     ap.add_argument("--cpu-sample-iters", type=int, default=5)
     ap.add_argument("--kkt", choices=["cg", "cg-sr"], default="cg",
                     help="cg: the literal cg! recurrence (default, the reference's algorithm); cg-sr: opt-in single-reduction CG (csrc/cg_sr.hip)")
+    ap.add_argument("--no-prewarm", action="store_true", help="skip the clock warm-up launches of the product kernel (profiling runs: kernel statistics of the loop's own launches only)")
     ap.add_argument("--exact-launches", action="store_true",
                     help="cfg2: synchronise after every Krylov iteration (rocprofv3 runs: every launch does full work)")
     args = ap.parse_args()
@@ -838,6 +869,7 @@ def main():
     if ctx.world != max(args.gpus, 1) and ctx.rank == 0:
         print("bench.py: --gpus %d but the launcher started %d rank(s); reporting n_gpus = %d" % (args.gpus, ctx.world, ctx.world), file=sys.stderr)
     KKT_CHOICE["name"] = args.kkt
+    NO_PREWARM[0] = bool(args.no_prewarm)
     import cosmo_jl_amd as cj  # noqa: F401
     workload = args.workload or "all"
     head = "cfg2" if workload == "all" else workload

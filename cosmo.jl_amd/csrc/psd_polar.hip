@@ -148,8 +148,15 @@ struct PolarPlan {
   // again.  The a-posteriori check is unchanged, so the error bound of every projection is the same rigorous 8 d eps ||X||_F.  Replay on the
   // spectra of BASELINE config 5 (tests/studies/lift_depth_replay.py, profiles/r04_lift_depth_replay.txt): minimal passing depth 3-5 for
   // 90 % of the (iteration, cone) pairs against the fixed 10.  A function of each cone's own history only => independent of how the cones are
-  // partitioned over ranks.  COSMO_HIP_POLAR_ADAPT=0: fixed depth k_lift for all cones (the schedule until round 3).
-  int adapt = 1;
+  // partitioned over ranks.
+  // MEASURED (profiles/r04_adaptive_lifting_depth.txt) and therefore OPT-IN (COSMO_HIP_POLAR_ADAPT=1; default: fixed depth k_lift for all cones,
+  // the schedule of round 3): on BASELINE config 5 the d^3-weighted products per projection fall from 47 to 36.6, yet the step gets SLOWER (223.9 vs
+  // 230.6 it/s): a cone's minimal passing depth moves by +-1 from one ADMM iterate to the next (18 % of the steps go up), so with 400 cones some
+  // cone fails its verification in nearly every projection (39 of 50), and every such projection pays the repair train -- 26 gated launches and a
+  // second host synchronisation -- whatever the size of the failing cones.  The replay with any history-based rule (running maximum of the last
+  // 10 depths + 1: 58 of 60 projections still contain a failure) says the same.  Config 4 (one cone): depth 9 instead of 10 after 50 projections,
+  // 128.8 vs 129.0 it/s.
+  int adapt = 0;
   std::vector<int> bk, bstreak, bm;     // per batched cone: lifting depth, verified projections since the last change, patience
   int* d_lgate = nullptr;                // (LIFT_CAP x n) gate table of the lifting steps
   int* d_ubuf = nullptr;                 // per cone: work buffer (1 | 2) that receives U_0 (the one that is `iu` when the cone joins)

@@ -26,7 +26,7 @@ libpath(::Type{Float32}) = LIB32[]
 # ---- mirrors of the ABI structs: GENERATED from include/cosmo_hip.h by tools/gen_abi_structs.py (Params, AccelParams, ResultC, MAX_RHO_UPDATES)
 include("abi_structs.jl")
 
-const KKT_CG, KKT_MINRES_REDUCED, KKT_MINRES, KKT_CG_SR = Int32(0), Int32(1), Int32(2), Int32(3)   # KKT_CG_SR: opt-in single-reduction CG
+const KKT_CG, KKT_MINRES_REDUCED, KKT_MINRES, KKT_CG_SR, KKT_CG_JACOBI = Int32(0), Int32(1), Int32(2), Int32(3), Int32(4)   # KKT_CG_SR: opt-in single-reduction CG; KKT_CG_JACOBI: opt-in Jacobi-preconditioned CG (assembled operator only)
 const STATUS = (:Undetermined, :Solved, :Max_iter_reached, :Unsolved, :Primal_infeasible, :Dual_infeasible, :Time_limit_reached)
 
 mutable struct Handle{T <: HipFloat}
@@ -205,6 +205,9 @@ mutable struct HipKKTSolver{T <: HipFloat} <: AbstractKKTSolver
 end
 HipCGKKTSolver(P, A, sigma, rho; kwargs...) = HipKKTSolver(P, A, sigma, rho; kind = KKT_CG, kwargs...)
 HipMINRESKKTSolver(P, A, sigma, rho; kwargs...) = HipKKTSolver(P, A, sigma, rho; kind = KKT_MINRES, kwargs...)
+# OPT-IN, no reference counterpart (COSMO calls cg! without a preconditioner, src/linear_solver/kktsolver_indirect.jl:70): IterativeSolvers' preconditioned
+# recurrence with Pl = Diagonal(diag(P + sigma I + A' rho A)); set_params! fails where the reduced operator cannot be assembled
+HipCGJacobiKKTSolver(P, A, sigma, rho; kwargs...) = HipKKTSolver(P, A, sigma, rho; kind = KKT_CG_JACOBI, kwargs...)
 
 # called from admm_x! (src/solver.jl:52): lhs = ws.sol, rhs = ws.ls, both length n+m and caller owned
 function solve!(S::HipKKTSolver{T}, lhs::AbstractVector{T}, rhs::AbstractVector{T}) where {T <: HipFloat}
@@ -235,6 +238,18 @@ function cg_persist_stats(h::Handle)
     return (enabled = out[1] != 0, workgroups = out[2], launches = out[3], fallbacks = out[4])
 end
 
+function polar_depth_stats(h::Handle)      # per-cone lifting depth of the sign iteration (opt-in COSMO_HIP_POLAR_ADAPT=1)
+    out = zeros(Int64, 8)
+    check(h, ccall((:cosmo_hip_polar_depth_stats, lib(h)), Int32, (Ptr{Cvoid}, Ptr{Int64}), h.ptr, out))
+    return (adaptive = out[1] != 0, depth_min = out[2], depth_max = out[3], depth_mean = out[4] / 1000, weighted_products = out[5] / 1000,
+            failed_verifications = out[6], downward_probes = out[7], projections = out[8])
+end
+function time_krylov(h::Handle, reps::Integer)      # measurement hook: seconds per Krylov iteration incl. kernel boundaries, algorithmic bytes, launches
+    t = Ref{Cdouble}(0.0); b = Ref{Cdouble}(0.0); nl = Ref{Int32}(0)
+    check(h, ccall((:cosmo_hip_time_krylov, lib(h)), Int32, (Ptr{Cvoid}, Int32, Ref{Cdouble}, Ref{Cdouble}, Ref{Int32}), h.ptr, Int32(reps), t, b, nl))
+    return (seconds = t[], bytes = b[], launches = nl[])
+end
+
 function fold_stats(h::Handle)      # assembled reduced CG operator (cosmo_hip_fold_stats)
     out = zeros(Int64, 4)
     check(h, ccall((:cosmo_hip_fold_stats, lib(h)), Int32, (Ptr{Cvoid}, Ptr{Int64}), h.ptr, out))
@@ -262,6 +277,12 @@ set_cone_shard!(h::Handle, first_cone::Vector{Int64}) =
     check(h, ccall((:cosmo_hip_set_cone_shard, lib(h)), Int32, (Ptr{Cvoid}, Ptr{Int64}), h.ptr, first_cone))
 set_row_shard!(h::Handle, first_cone::Vector{Int64}) =
     check(h, ccall((:cosmo_hip_set_row_shard, lib(h)), Int32, (Ptr{Cvoid}, Ptr{Int64}), h.ptr, first_cone))
+# known-answer all-reduce of `count` reals through the loop's exchange path (collective: every rank calls it); compare `hash` across the ranks
+function comm_allreduce_check(h::Handle, count::Integer)
+    out = zeros(Int64, 6)
+    check(h, ccall((:cosmo_hip_comm_allreduce_check, lib(h)), Int32, (Ptr{Cvoid}, Int64, Ptr{Int64}), h.ptr, Int64(count), out))
+    return (exact_mismatches = out[1], inexact_outside_bound = out[2], hash = out[3], transport = out[4], nranks = out[5], rccl_version_code = out[6])
+end
 function comm_stats(h::Handle)
     out = zeros(Int64, 8)
     check(h, ccall((:cosmo_hip_comm_stats_ex, lib(h)), Int32, (Ptr{Cvoid}, Ptr{Int64}), h.ptr, out))

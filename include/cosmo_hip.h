@@ -333,7 +333,8 @@ int32_t cosmo_hip_time_psd_product(cosmo_hip_handle* h, int32_t which, int32_t r
 /* Per-cone lifting depth of the matrix-sign projections (src/convexset.jl:219-263 is what they compute; the depth only steers how many products a
  * projection spends before its a-posteriori verification): out = {adaptive control on, min, max, mean x 1000 of the per-cone depths, d^3-weighted
  * products per projection x 1000 of the batch's last main schedule, failed verifications so far, downward probes so far, projections seen}.
- * COSMO_HIP_POLAR_ADAPT=0 fixes the depth at the plan's k_lift (10 lifting steps in Float64) for every cone. */
+ * OPT-IN: COSMO_HIP_POLAR_ADAPT=1 (measured slower on BASELINE config 5 although it saves 22 % of the products: csrc/psd_polar.hip, PolarPlan::adapt);
+ * by default every cone runs the plan's k_lift lifting steps (10 in Float64). */
 int32_t cosmo_hip_polar_depth_stats(cosmo_hip_handle* h, int64_t out[8]);
 /* Measurement hook: `reps` Krylov iterations of the reduced CG solve (src/linear_solver/kktsolver_indirect.jl:57-70; IterativeSolvers cg!)
  * exactly as the loop enqueues them -- solve start on the current right-hand side with tolerance 0, then the iterations (captured chain

@@ -321,7 +321,8 @@ def test_adaptive_lifting_depth_keeps_every_projection_within_the_bound_and_save
     """A batch of cones with very different spectra projected 40 times: (a) cones whose smallest |lambda| is large settle at a small depth,
     a cone with an eigenvalue of 1e-6 ||X|| stays deep; (b) EVERY one of the 40 projections of EVERY cone is within 64 d eps ||X||_F of the
     LAPACK projection (failed verifications take their fallback round: unverified == 0); (c) the d^3-weighted product count falls well below the
-    fixed schedule's 47; (d) COSMO_HIP_POLAR_ADAPT=0 is the fixed schedule of round 3."""
+    fixed schedule's 47; (d) without the opt-in (the default) the schedule is the fixed one of round 3."""
+    monkeypatch.setenv("COSMO_HIP_POLAR_ADAPT", "1")                    # opt-in (measured: fewer products, slower steps on config 5 -- see PolarPlan::adapt)
     rng = np.random.default_rng(404)
     dims = [24, 40, 64, 90, 130, 200, 33, 57]
     sets = [cj.PsdConeTriangle(d * (d + 1) // 2) for d in dims]
@@ -366,6 +367,7 @@ def test_adaptive_lifting_depth_large_cone_and_loop_level_agreement(monkeypatch)
     """(a) A single large cone (d = 320 > 256: the per-cone path) projected repeatedly: its depth goes down, every projection within the bound.
     (b) Loop level: a small chordal SDP solved with and without the adaptive depth -- same status, iteration count within one check interval,
     objective to 1e-6 (the projections differ by at most their verified bound ~1e-13 ||X||_F per iteration)."""
+    monkeypatch.setenv("COSMO_HIP_POLAR_ADAPT", "1")
     rng = np.random.default_rng(77)
     d = 320
     K = cj.PsdConeTriangle(d * (d + 1) // 2)
