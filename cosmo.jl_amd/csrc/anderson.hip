@@ -16,6 +16,12 @@
 // the producer's partials), so accelerated runs are bit-reproducible.  All data-dependent decisions (success of the least
 // squares step, safeguarding) are taken on the device and read back with the one synchronisation per iteration that the
 // accelerated loop needs anyway.
+//
+// ROW-SHARDED handles (round 4; csrc/rowshard.hip): w = [x (replicated, n) ; w_s (this rank's rows)], so every inner product of the accelerator is
+// (the x-part, counted ONCE: ranks other than 0 leave it out of their partial sums) + the sum over the ranks of the local row parts.  The
+// workgroup partials of every reduction are summed over the ranks slot by slot with ONE all-reduce of the partial array (comm_allreduce_sum, the
+// exchange path of the loop), then every consumer reduces the summed partials in the usual fixed order: all ranks obtain the SAME bits for R, eta,
+// the success flag and the safeguarding decision, so their control flow cannot diverge.  Up to mem + 3 small all-reduces per accelerated iteration.
 #include "device_utils.h"
 #include <math.h>
 #include <stddef.h>
@@ -45,6 +51,9 @@ struct AaState {
   AaFlags* flags = nullptr;     // device
   AaFlags* flags_host = nullptr;  // pinned
   int grid = 1;
+  int nparts = 1;             // partials a consumer reduces: grid, or COSMO_MAX_PARTIALS on a row-sharded handle (the all-reduced array, zero beyond grid)
+  long long dot_lo = 0;       // first element that enters this rank's inner products (n on ranks > 0 of a row-sharded run: the x-part is replicated)
+  bool sharded = false;
   // host-tracked (data independent) state of the accelerator
   int iter = 0;
   bool init_phase = true;
@@ -61,7 +70,7 @@ namespace {
 __global__ __launch_bounds__(COSMO_BS) void k_aa_prep(long long N, const real* __restrict__ g, const real* __restrict__ x, int init,
                                                       real* __restrict__ f, real* __restrict__ f_last, real* __restrict__ g_last,
                                                       real* __restrict__ Gj, real* __restrict__ v, const real* __restrict__ Q0, int j,
-                                                      real* __restrict__ p_out) {
+                                                      real* __restrict__ p_out, long long dot_lo) {
   __shared__ real red[COSMO_BS / 64];
   real acc = 0.0;
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) {
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_aa_prep(long long N, const real* _
       Gj[i] = gi - g_last[i];
       const real vi = fi - f_last[i];
       v[i] = vi;
-      acc += (j == 0) ? vi * vi : Q0[i] * vi;
+      if (i >= dot_lo) acc += (j == 0) ? vi * vi : Q0[i] * vi;
     }
     g_last[i] = gi;
     f_last[i] = fi;
@@ -86,7 +95,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_aa_prep(long long N, const real* _
 // Gram-Schmidt step i (< j): r = sum(p_in) ; R[i, j] = r ; v -= r Q_i ; partial <Q_{i+1}, v> (i + 1 < j) or ||v||^2 (i + 1 == j)
 __global__ __launch_bounds__(COSMO_BS) void k_aa_mgs(long long N, int nparts, const real* __restrict__ p_in, const real* __restrict__ Qi,
                                                      const real* __restrict__ Qnext, real* __restrict__ v, int last, real* __restrict__ Rij,
-                                                     real* __restrict__ p_out) {
+                                                     real* __restrict__ p_out, long long dot_lo) {
   __shared__ real red[COSMO_BS / 64];
   const real r = reduce_partials_sum(p_in, nparts, red);
   if (blockIdx.x == 0 && threadIdx.x == 0) *Rij = r;
@@ -94,7 +103,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_aa_mgs(long long N, int nparts, co
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) {
     const real vi = v[i] - r * Qi[i];
     v[i] = vi;
-    acc += last ? vi * vi : Qnext[i] * vi;
+    if (i >= dot_lo) acc += last ? vi * vi : Qnext[i] * vi;
   }
   __syncthreads();
   acc = block_sum(acc, red);
@@ -113,12 +122,12 @@ __global__ __launch_bounds__(COSMO_BS) void k_aa_normalize(long long N, int npar
 // partial Q[:, 0..l)' f and ||f||^2
 template <int L>
 __global__ __launch_bounds__(COSMO_BS) void k_aa_qtf(long long N, int l, const real* __restrict__ Q, const real* __restrict__ f,
-                                                     real* __restrict__ parts) {
+                                                     real* __restrict__ parts, long long dot_lo) {
   __shared__ real red[COSMO_BS / 64];
   real acc[L + 1];
 #pragma unroll
   for (int k = 0; k <= L; ++k) acc[k] = 0.0;
-  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) {
+  for (long long i = dot_lo + (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) {
     const real fi = f[i];
 #pragma unroll
     for (int k = 0; k < L; ++k) if (k < l) acc[k] += Q[(size_t)k * N + i] * fi;
@@ -184,13 +193,13 @@ __global__ __launch_bounds__(COSMO_BS) void k_aa_apply(long long N, int l, const
 
 // f = w_prev - w and its partial squared norm (compute_accelerated_res_norm!, accelerator_interface.jl:123-126)
 __global__ __launch_bounds__(COSMO_BS) void k_aa_resnorm(long long N, const real* __restrict__ w, const real* __restrict__ w_prev,
-                                                         real* __restrict__ f, real* __restrict__ p_out) {
+                                                         real* __restrict__ f, real* __restrict__ p_out, long long dot_lo) {
   __shared__ real red[COSMO_BS / 64];
   real acc = 0.0;
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) {
     const real d = w_prev[i] - w[i];
     f[i] = d;
-    acc += d * d;
+    if (i >= dot_lo) acc += d * d;
   }
   acc = block_sum(acc, red);
   if (threadIdx.x == 0) p_out[blockIdx.x] = acc;
@@ -212,6 +221,14 @@ inline AaState* aa_of(cosmo_hip_handle* h) { return static_cast<AaState*>(h->acc
 
 }  // namespace
 
+int32_t comm_allreduce_sum(cosmo_hip_handle* h, real* buf, size_t count);      // comm.hip
+// row-sharded runs: the partial array(s) starting at `p` summed over the ranks, slot by slot (same count on every rank; entries beyond a
+// rank's grid are zero from the allocation on)
+static int32_t aa_share(cosmo_hip_handle* h, AaState* S, real* p) {
+  if (!S->sharded) return COSMO_HIP_OK;
+  return comm_allreduce_sum(h, p, (size_t)S->grid);
+}
+
 void aa_free(cosmo_hip_handle* h) {
   AaState* S = aa_of(h);
   if (!S) return;
@@ -223,6 +240,7 @@ void aa_free(cosmo_hip_handle* h) {
 }
 
 bool aa_enabled(const cosmo_hip_handle* h) { return h->accel != nullptr; }
+bool aa_get_params(const cosmo_hip_handle* h, cosmo_hip_accel_params* out) { const AaState* S = static_cast<const AaState*>(h->accel); if (!S) return false; *out = S->prm; return true; }
 
 int32_t aa_restart(cosmo_hip_handle* h) {      // CA.restart! -> empty_history!
   AaState* S = aa_of(h);
@@ -254,11 +272,12 @@ extern "C" int32_t cosmo_hip_set_accelerator(cosmo_hip_handle* h, const cosmo_hi
   if (p->kind != COSMO_HIP_ACCEL_ANDERSON) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "accelerator kind %d", (int)p->kind);
   if (p->mem < 1 || p->mem > AA_MAX_MEM || p->min_mem < 1 || p->start_iter < 2 || !(p->safeguard_tol >= 0.0) || !(p->eta_max > 0.0))
     return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_accelerator: need 1 <= mem <= %d, min_mem >= 1, start_iter >= 2", AA_MAX_MEM);
-  if (h->comm) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "acceleration with clique sharding is not built");
   AaState* S = new AaState();
   h->accel = S;
   S->prm = *p;
-  S->N = h->n + h->m;
+  S->N = h->n + h->m;                           // row-sharded handle: h->m is the LOCAL row count, w = [x ; this rank's rows]
+  S->sharded = h->row_shard && comm_nranks(h) > 1;
+  S->dot_lo = (S->sharded && comm_rank(h) > 0) ? h->n : 0;
   S->mem = (int)std::min<long long>(p->mem, std::max<long long>(S->N, 1));     // mem = min(mem, dim)
   const size_t N = (size_t)std::max<long long>(S->N, 1);
   HIPCHK(h, hipMalloc((void**)&S->G, sizeof(real) * N * S->mem));
@@ -267,11 +286,16 @@ extern "C" int32_t cosmo_hip_set_accelerator(cosmo_hip_handle* h, const cosmo_hi
   HIPCHK(h, hipMalloc((void**)&S->f_last, sizeof(real) * N));
   HIPCHK(h, hipMalloc((void**)&S->g_last, sizeof(real) * N));
   HIPCHK(h, hipMalloc((void**)&S->parts, sizeof(real) * (AA_MAX_MEM + 1) * COSMO_MAX_PARTIALS));
+  HIPCHK(h, hipMemsetAsync(S->parts, 0, sizeof(real) * (AA_MAX_MEM + 1) * COSMO_MAX_PARTIALS, h->stream));   // slots beyond `grid` stay zero (all-reduced whole)
   HIPCHK(h, hipMalloc((void**)&S->flags, sizeof(AaFlags)));
   HIPCHK(h, hipHostMalloc((void**)&S->flags_host, sizeof(AaFlags)));
   memset(S->flags_host, 0, sizeof(AaFlags));
   long long g = (S->N + (long long)COSMO_BS * 4 - 1) / ((long long)COSMO_BS * 4);
   S->grid = (int)std::max<long long>(1, std::min<long long>(g, 1024));
+  // row-sharded: the SAME number of partials on every rank (the local lengths differ): a shorter rank's surplus workgroups contribute +0.0, and
+  // no slot of the all-reduced array ever keeps a stale sum of an earlier, longer reduction
+  if (S->sharded) S->grid = 1024;
+  S->nparts = S->grid;
   CHK(aa_restart(h));
   S->active = false;
   return COSMO_HIP_OK;
@@ -300,7 +324,7 @@ int32_t aa_enqueue_pre(cosmo_hip_handle* h, long long it, bool* attempted) {
   hipStream_t st = h->stream;
   // ---- update! ----
   if (S->init_phase) {
-    hipLaunchKernelGGL(k_aa_prep, G, B, 0, st, N, h->w, h->w_prev, 1, S->f, S->f_last, S->g_last, S->G, S->Q, S->Q, 0, AA_PARTS(S, 0));
+    hipLaunchKernelGGL(k_aa_prep, G, B, 0, st, N, h->w, h->w_prev, 1, S->f, S->f_last, S->g_last, S->G, S->Q, S->Q, 0, AA_PARTS(S, 0), S->dot_lo);
     S->init_phase = false;
   } else {
     int j = S->iter % S->mem;
@@ -317,13 +341,15 @@ int32_t aa_enqueue_pre(cosmo_hip_handle* h, long long it, bool* attempted) {
     real* Gj = S->G + (size_t)j * N;
     real* v = S->Q + (size_t)j * N;
     real* Rcol = reinterpret_cast<real*>(reinterpret_cast<char*>(S->flags) + offsetof(AaFlags, R)) + (size_t)j * AA_MAX_MEM;
-    hipLaunchKernelGGL(k_aa_prep, G, B, 0, st, N, h->w, h->w_prev, 0, S->f, S->f_last, S->g_last, Gj, v, S->Q, j, AA_PARTS(S, 0));
+    hipLaunchKernelGGL(k_aa_prep, G, B, 0, st, N, h->w, h->w_prev, 0, S->f, S->f_last, S->g_last, Gj, v, S->Q, j, AA_PARTS(S, 0), S->dot_lo);
+    CHK(aa_share(h, S, AA_PARTS(S, 0)));
     for (int i = 0; i < j; ++i) {
       const int last = (i + 1 == j);
-      hipLaunchKernelGGL(k_aa_mgs, G, B, 0, st, N, S->grid, AA_PARTS(S, i & 1), S->Q + (size_t)i * N, S->Q + (size_t)(last ? i : i + 1) * N, v, last,
-                         Rcol + i, AA_PARTS(S, (i + 1) & 1));
+      hipLaunchKernelGGL(k_aa_mgs, G, B, 0, st, N, S->nparts, AA_PARTS(S, i & 1), S->Q + (size_t)i * N, S->Q + (size_t)(last ? i : i + 1) * N, v, last,
+                         Rcol + i, AA_PARTS(S, (i + 1) & 1), S->dot_lo);
+      CHK(aa_share(h, S, AA_PARTS(S, (i + 1) & 1)));
     }
-    hipLaunchKernelGGL(k_aa_normalize, G, B, 0, st, N, S->grid, AA_PARTS(S, j & 1), v, Rcol + j);
+    hipLaunchKernelGGL(k_aa_normalize, G, B, 0, st, N, S->nparts, AA_PARTS(S, j & 1), v, Rcol + j);
     S->iter += 1;
   }
   // ---- accelerate! ----
@@ -333,10 +359,14 @@ int32_t aa_enqueue_pre(cosmo_hip_handle* h, long long it, bool* attempted) {
     HIPCHK(h, hipGetLastError());
     return COSMO_HIP_OK;
   }
-  if (l <= 8) hipLaunchKernelGGL((k_aa_qtf<8>), G, B, 0, st, N, l, S->Q, S->f, S->parts);
-  else if (l <= 16) hipLaunchKernelGGL((k_aa_qtf<16>), G, B, 0, st, N, l, S->Q, S->f, S->parts);
-  else hipLaunchKernelGGL((k_aa_qtf<AA_MAX_MEM>), G, B, 0, st, N, l, S->Q, S->f, S->parts);
-  hipLaunchKernelGGL(k_aa_solve, dim3(1), B, 0, st, l, S->grid, S->parts, S->prm.eta_max, S->flags);
+  if (l <= 8) hipLaunchKernelGGL((k_aa_qtf<8>), G, B, 0, st, N, l, S->Q, S->f, S->parts, S->dot_lo);
+  else if (l <= 16) hipLaunchKernelGGL((k_aa_qtf<16>), G, B, 0, st, N, l, S->Q, S->f, S->parts, S->dot_lo);
+  else hipLaunchKernelGGL((k_aa_qtf<AA_MAX_MEM>), G, B, 0, st, N, l, S->Q, S->f, S->parts, S->dot_lo);
+  if (S->sharded) {                                     // Q'f (the l written slots, contiguous) and ||f||^2 (slot AA_MAX_MEM)
+    CHK(comm_allreduce_sum(h, S->parts, (size_t)l * COSMO_MAX_PARTIALS));
+    CHK(comm_allreduce_sum(h, AA_PARTS(S, AA_MAX_MEM), (size_t)S->grid));
+  }
+  hipLaunchKernelGGL(k_aa_solve, dim3(1), B, 0, st, l, S->nparts, S->parts, S->prm.eta_max, S->flags);
   if (l <= 8) hipLaunchKernelGGL((k_aa_apply<8>), G, B, 0, st, N, l, S->G, S->flags, h->w);
   else if (l <= 16) hipLaunchKernelGGL((k_aa_apply<16>), G, B, 0, st, N, l, S->G, S->flags, h->w);
   else hipLaunchKernelGGL((k_aa_apply<AA_MAX_MEM>), G, B, 0, st, N, l, S->G, S->flags, h->w);
@@ -359,8 +389,9 @@ int32_t aa_fetch_flags(cosmo_hip_handle* h, int* success, int* declined) {
 // acceleration_post! part 1 (accelerator_interface.jl:85-100): residual of the accelerated point against tau * ||f||
 int32_t aa_enqueue_guard(cosmo_hip_handle* h) {
   AaState* S = aa_of(h);
-  hipLaunchKernelGGL(k_aa_resnorm, dim3(S->grid), dim3(COSMO_BS), 0, h->stream, S->N, h->w, h->w_prev, S->f, AA_PARTS(S, 0));
-  hipLaunchKernelGGL(k_aa_guard, dim3(1), dim3(COSMO_BS), 0, h->stream, S->grid, AA_PARTS(S, 0), S->prm.safeguard_tol, S->flags);
+  hipLaunchKernelGGL(k_aa_resnorm, dim3(S->grid), dim3(COSMO_BS), 0, h->stream, S->N, h->w, h->w_prev, S->f, AA_PARTS(S, 0), S->dot_lo);
+  CHK(aa_share(h, S, AA_PARTS(S, 0)));
+  hipLaunchKernelGGL(k_aa_guard, dim3(1), dim3(COSMO_BS), 0, h->stream, S->nparts, AA_PARTS(S, 0), S->prm.safeguard_tol, S->flags);
   HIPCHK(h, hipGetLastError());
   return COSMO_HIP_OK;
 }

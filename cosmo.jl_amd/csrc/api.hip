@@ -1095,6 +1095,7 @@ static int32_t enqueue_admm_step(cosmo_hip_handle* h, bool rho_rules) {
   CHK(cone3_enqueue_project(h, h->s, 1));
   CHK(psd_enqueue_project(h, h->s, true));
   CHK(custom_enqueue_project(h, h->s, 1));
+  CHK(comm_enqueue_exchange(h, h->s));      // clique sharding: the one exchange step of the iteration (row-sharded handles: no-op)
   if (rho_rules) CHK(enqueue_check(h, 1, 2));
   CHK(enqueue_solve_in_loop(h));
   return COSMO_HIP_OK;
@@ -1109,7 +1110,9 @@ static int32_t sync_and_resolve(cosmo_hip_handle* h) {
 
 static int32_t optimize_accelerated(cosmo_hip_handle* h, int* status_out, long long* iter_out, const std::chrono::steady_clock::time_point t0) {
   const cosmo_hip_params& p = h->prm;
-  if (h->comm) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "acceleration with clique sharding is not built");
+  // Sharded runs: with clique (cone) sharding every rank holds the whole w and all scalars are computed redundantly and bit-identically, so the
+  // accelerator needs nothing; with row sharding its inner products are all-reduced (anderson.hip).  Either way every rank takes the same
+  // branches below (success / declined flags come from identical scalars).
   CHK(aa_begin_solve(h));
   h->safeguarding_iter = 0;
   CHK(admm_init_enqueue(h));

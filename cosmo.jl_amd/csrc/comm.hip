@@ -170,7 +170,9 @@ extern "C" int32_t cosmo_hip_comm_init_hostshm(cosmo_hip_handle* h, int32_t rank
   CommState* c = new CommState();
   c->rank = rank; c->nranks = nranks; c->shm_name = name;
   // room for a full-length row vector (all-gather of slices) and for nranks partial n-vectors (+ 2 nranks scalars) of the all-reduce
-  const long long cap = std::max<long long>(std::max<long long>(h->m, 1), (long long)nranks * (h->n + 2LL * nranks + 8));
+  // ... and for the partial arrays of the accelerator's inner products in row-sharded accelerated runs (anderson.hip: (AA_MAX_MEM + 1) slots)
+  const long long cap = std::max<long long>(std::max<long long>(std::max<long long>(h->m, 1), (long long)nranks * (h->n + 2LL * nranks + 8)),
+                                             (long long)nranks * 32LL * COSMO_MAX_PARTIALS);
   c->shm_bytes = sizeof(ShmSeg) + sizeof(real) * (size_t)cap;
   int fd = -1;
   if (rank == 0) {

@@ -28,6 +28,8 @@ int32_t rebuild_cone_plans(cosmo_hip_handle* h);                                
 int32_t comm_set_partition(cosmo_hip_handle* h, const int64_t* first_cone, const char* who);         // comm.hip
 void comm_my_range(const cosmo_hip_handle* h, long long* cone_lo, long long* cone_hi, long long* row_lo, long long* row_hi);
 int32_t launch_recover_mu(cosmo_hip_handle* h);                                                      // kernels.hip
+bool aa_get_params(const cosmo_hip_handle* h, cosmo_hip_accel_params* out);                          // anderson.hip
+void aa_free(cosmo_hip_handle* h);
 
 template <class T>
 static int32_t rs_alloc(cosmo_hip_handle* h, T** p, size_t count) {
@@ -71,7 +73,9 @@ extern "C" int32_t cosmo_hip_set_row_shard(cosmo_hip_handle* h, const int64_t* f
   if (!h->have_params) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_row_shard: set_params first (the reduced operator is built from the whole A)");
   if (h->row_shard) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_row_shard: already row-sharded");
   if (h->prm.kkt_kind != COSMO_HIP_KKT_CG) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "set_row_shard: the reduced CG solvers only (kkt_kind CG / CG_SR)");
-  if (aa_enabled(h)) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "set_row_shard: acceleration with sharding is not built");
+  cosmo_hip_accel_params accel_prm;
+  const bool had_accel = aa_get_params(h, &accel_prm);      // the accelerator's history lives on w = [x ; rows]: re-created below on the local layout
+  if (had_accel) aa_free(h);
   if (h->prm.time_limit != 0.0) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "set_row_shard: a wall-clock time limit would let the ranks' control flow diverge");
   if (!h->custom.empty()) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "set_row_shard: user-defined cones are projected on the host");
   CHK(comm_set_partition(h, first_cone, "set_row_shard"));
@@ -140,6 +144,7 @@ extern "C" int32_t cosmo_hip_set_row_shard(cosmo_hip_handle* h, const int64_t* f
   h->have_iterates = false;
   CHK(rebuild_cone_plans(h));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (had_accel) CHK(cosmo_hip_set_accelerator(h, &accel_prm));      // N = n + m_loc, inner products all-reduced (anderson.hip)
   return COSMO_HIP_OK;
 }
 

@@ -8,7 +8,8 @@ transport = rccl : RCCL communicator; <rendezvous> is a file through which rank 
 Environment: COSMO_TEST_SHARD = cones (default: cosmo_hip_set_cone_shard, the projections only) | rows (cosmo_hip_set_row_shard: cones +
 their rows, csrc/rowshard.hip); COSMO_TEST_CASE = chordal (default) | pinf | dinf (the two infeasible problems of
 test_infeasibility_certificates_in_sharded_runs, default settings); COSMO_TEST_TIGHT=1: CG solved to 1e-10 (tol_exponent 0);
-COSMO_TEST_DTYPE=float32: the Float32 library.
+COSMO_TEST_DTYPE=float32: the Float32 library; COSMO_TEST_ACCEL=1: the reference's default accelerator (AndersonAccelerator, mem 15, safeguarded) with a
+tight CG and eps = 1e-6 -- a convergent accelerated run (`iters` is then max_iter).
 Writes the final iterates, the result scalars and the communicator statistics of this rank."""
 import os
 import sys
@@ -27,6 +28,9 @@ def problem():
 
 def settings(iters, tight=False):
     import cosmo_jl_amd as cj
+    if os.environ.get("COSMO_TEST_ACCEL", "") == "1":
+        return cj.Settings(max_iter=iters, eps_abs=1e-6, eps_rel=1e-6, accelerator=cj.AndersonAccelerator,
+                           kkt_solver=cj.with_options(cj.CGIndirectKKTSolver, tol_constant=1e-10, tol_exponent=0.0))
     kw = dict(max_iter=iters, eps_abs=0.0, eps_rel=0.0, check_infeasibility=10 ** 9)
     if tight:
         kw["kkt_solver"] = cj.with_options(cj.CGIndirectKKTSolver, tol_constant=1e-10, tol_exponent=0.0)
@@ -99,7 +103,8 @@ def main():
     st = h.comm_stats()
     ex = h.comm_stats_ex()
     info = h.row_shard_info()
-    np.savez(out, x=r.x, s=r.s, y=r.y, iter=r.iter, kkt=r.kkt_iters_total, obj=r.obj_val, r_prim=r.info.r_prim, r_dual=r.info.r_dual,
+    acc = h.accel_stats() if os.environ.get("COSMO_TEST_ACCEL", "") == "1" else dict(accelerated=0, accepted=0, declined=0, safeguarding_iter=0)
+    np.savez(out, accelerated=acc["accelerated"], declined=acc["declined"], safeguarding_iter=acc["safeguarding_iter"], x=r.x, s=r.s, y=r.y, iter=r.iter, kkt=r.kkt_iters_total, obj=r.obj_val, r_prim=r.info.r_prim, r_dual=r.info.r_dual,
              bounds=np.array(bounds), exchanges=st["exchanges"], nranks=st["nranks"], transport=st["transport"], status=r.status,
              mode=ex["mode"], bytes=ex["bytes"], allreduces=ex["allreduces"], allreduce_elems=ex["allreduce_elems"],
              row_lo=info["row_lo"], row_hi=info["row_hi"], rho_updates=np.array(r.info.rho_updates))

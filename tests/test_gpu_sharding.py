@@ -257,6 +257,48 @@ def test_rccl_two_ranks_on_one_device_is_refused_or_identical(monkeypatch):
                 assert np.array_equal(z[key].view(np.int64), val.view(np.int64)), (r, key)
 
 
+@pytest.mark.parametrize("mode", ["rows", "cones"])
+def test_sharded_runs_with_the_reference_default_accelerator(mode, monkeypatch):
+    """Anderson acceleration (the reference's default, src/settings.jl:136-138; src/accelerator_interface.jl:58-116) in sharded runs, two ranks.
+    rows:  w = [x ; the rank's rows]: the accelerator's inner products are all-reduced partial sums (csrc/anderson.hip) -- the ranks agree with each
+           other bit for bit (same R, eta, success and safeguarding decisions), and with the single-rank accelerated run within the f2 tolerances
+           (same status, iteration count within one check interval, objective 1e-5; acceleration is sensitive to rounding, the summation order of
+           A'y and of the inner products changes with the partition);
+    cones: every rank holds the whole w, all scalars are redundant and bit-identical => identical to the single-rank run, bit for bit."""
+    monkeypatch.setenv("COSMO_TEST_ACCEL", "1")
+    monkeypatch.setenv("COSMO_HIP_POLAR_KLIFT", "10")
+    W = _worker_module()
+    p = W.problem()
+    md = cj.Model(); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], W.settings(3000))
+    ref = cj.optimize(md)
+    racc = md.handle.accel_stats()
+    assert ref.status == "Solved" and racc["accelerated"] > 0
+    with tempfile.TemporaryDirectory() as tmp:
+        global ITERS
+        keep = ITERS
+        ITERS = 3000
+        try:
+            outs = _spawn("shm", 2, "/cosmo_test_" + uuid.uuid4().hex[:12], tmp, timeout=400, extra_env={"COSMO_TEST_SHARD": mode, "COSMO_TEST_ACCEL": "1"})
+        finally:
+            ITERS = keep
+        for rc, o in outs:
+            assert rc == 0, o[-3000:]
+        z = [np.load(os.path.join(tmp, "rank%d.npz" % r)) for r in range(2)]
+    for key in ("x", "s", "y"):
+        assert np.array_equal(z[0][key].view(np.int64), z[1][key].view(np.int64)), key                     # the ranks agree bit for bit
+    assert int(z[0]["iter"]) == int(z[1]["iter"]) and int(z[0]["accelerated"]) == int(z[1]["accelerated"]) > 0 and int(z[0]["declined"]) == int(z[1]["declined"])
+    assert str(z[0]["status"]) == ref.status
+    if mode == "cones":
+        assert int(z[0]["iter"]) == ref.iter and int(z[0]["accelerated"]) == racc["accelerated"]
+        for key, val in (("x", ref.x), ("s", ref.s), ("y", ref.y)):
+            assert np.array_equal(z[0][key].view(np.int64), val.view(np.int64)), key
+    else:
+        assert abs(int(z[0]["iter"]) - ref.iter) <= 25, (int(z[0]["iter"]), ref.iter)
+        assert abs(float(z[0]["obj"]) - ref.obj_val) <= 1e-5 * (1 + abs(ref.obj_val))
+        assert np.linalg.norm(z[0]["x"] - ref.x) <= 1e-3 * max(1.0, np.linalg.norm(ref.x))
+        assert int(z[0]["allreduces"]) >= int(z[0]["iter"])                                                  # the loop's own all-reduce ran every iteration
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
