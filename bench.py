@@ -759,6 +759,24 @@ def bench_cfg5(ctx, args, steps, warmup):
                         hbm_frac_algorithmic=(round(24.0 * float(np.sum(dk * dk)) / t_prod / 1e9 / HBM_PEAK_GBS, 4) if own is not None else None),
                         useful_tflops_reference_algorithm=round(useful * value / 1e12, 3), useful_frac_of_peak=round(useful * value / 1e12 / F64_MFMA_PEAK_TF, 5))
     krylov = None
+    pmc5 = None
+    if not args.small:
+        import glob
+        for fpmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cfg5_pmc_traffic.json"))):       # committed PMC passes (constants, like cfg2's)
+            try:
+                with open(fpmc) as fh:
+                    pmc5 = (json.load(fh), os.path.relpath(fpmc, ROOT))
+            except Exception:
+                pass
+    if products is not None and pmc5 is not None:
+        try:
+            kk = pmc5[0]["kernels"]
+            e0, e1 = kk["k_symm_gemm_batch_r<0, 4>"], kk["k_symm_gemm_batch_r<1, 4>"]
+            products["traffic"] = round((e0["hbm_bytes_per_launch"] + 2.0 * e1["hbm_bytes_per_launch"]) / 3.0, 1)      # the in-loop mix: one EPI 0 + two EPI 1 launches
+            products["traffic_source"] = pmc5[1]
+            products["mfma_busy_frac_pmc"] = round((e0["mfma_busy_frac"] + 2.0 * e1["mfma_busy_frac"]) / 3.0, 4)
+        except Exception:
+            pass
     if ctx.world == 1:
         try:
             t_k, b_k, nl = min(h.time_krylov(200) for _ in range(3))
@@ -770,8 +788,11 @@ def bench_cfg5(ctx, args, steps, warmup):
                           timing="best of 3 x 200 Krylov iterations as the loop enqueues them (captured chain), tolerance 0, HIP events on the library's stream; "
                                  "'launch' = one Krylov iteration = %d dependent kernels incl. their boundaries" % nl,
                           krylov_iterations_per_step=round(kbar, 2), share_of_step=round(kbar * 1e3 * t_k / ms_step, 4),
-                          note="a chain of dependent round trips on a working set that stays in L2 / Infinity Cache: the HBM fraction is reported because the "
-                               "contract asks for it; what bounds the pair is launch + load latency, not bandwidth")
+                          note="a chain of dependent round trips (the eight L2s are invalidated at every kernel boundary, operands come back through the fabric / "
+                               "Infinity Cache): the HBM fraction is reported because the contract asks for it; what bounds the pair is launch + load latency")
+            if pmc5 is not None and fs["enabled"]:
+                krylov["traffic"] = pmc5[0]["krylov_iteration_pair"]["hbm_bytes_per_krylov_iteration"]
+                krylov["traffic_source"] = pmc5[1]
         except Exception as e:
             krylov = dict(error="%s: %s" % (type(e).__name__, e))
     cands = [r for r in (krylov, products) if r and "share_of_step" in r]
