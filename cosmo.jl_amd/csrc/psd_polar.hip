@@ -98,10 +98,12 @@ struct PolarPlan {
   real* W = nullptr;       // 4 * ld^2 doubles per cone: X, U, Y, T
   real* parts = nullptr;   // per cone COSMO_MAX_PARTIALS norm partials + trace partials
   real* nrm = nullptr;     // per cone ||X||_F
-  // lifting steps of the main schedule (COSMO_HIP_POLAR_KLIFT; grows by 3 when fallbacks are frequent).  Float64: 10 (every
-  // |lambda| >= 6e-8 ||X||_F lifted).  Float32: 5 -- the verification threshold 8 d eps scales with eps(Float32) (2e-4 ... 2e-3 for
+  // lifting steps of the main schedule (COSMO_HIP_POLAR_KLIFT; grows by 3 when fallbacks are frequent).  Float64: 9 (every
+  // |lambda| >= 2.3e-7 ||X||_F lifted; 10 until round 3 -- the replay of real spectra, tests/studies/lift_depth_replay.py, finds the minimal passing
+  // depth <= 9 in every one of the first 100 projections of BASELINE config 4 and in 66 of 70 of config 5 (4 repair trains instead of 1); late
+  // iterates of a convergent run need 11-12, where the grow-by-3 rule of polar_adapt takes over as it did from 10).  Float32: 5 -- the verification threshold 8 d eps scales with eps(Float32) (2e-4 ... 2e-3 for
   // d = 200 ... 2000), eigenvalues below it pass by construction, and 0.0425 * 3.84^-5 = 5e-5 is already beneath it
-  int k_lift = REAL_IS_FLOAT ? 5 : 10;
+  int k_lift = REAL_IS_FLOAT ? 5 : 9;
   int max_rounds = 2;        // guarded fallback rounds enqueued per projection
   int rescale = 1;           // spectral rescaling in the first step of a large cone's iteration (COSMO_HIP_POLAR_RESCALE=0 disables)
   int batch_occ = 3;         // register-allocation variant of the batched product kernels: 3 or 4 waves per SIMD (COSMO_HIP_POLAR_BATCH_OCC; the plan sets 4 for the ragged kernel)
