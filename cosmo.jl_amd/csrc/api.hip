@@ -1108,6 +1108,14 @@ static int32_t sync_and_resolve(cosmo_hip_handle* h) {
   return COSMO_HIP_OK;
 }
 
+// The reference tests the wall clock (solver.jl:351-354).  In a sharded run the ranks' clocks differ, their decisions must not: every time-limit
+// decision is taken on the MAXIMUM of the ranks' elapsed seconds (one tiny host all-reduce through the communicator; identical on all ranks).
+static int32_t collective_elapsed(cosmo_hip_handle* h, const std::chrono::steady_clock::time_point t0, double* el) {
+  *el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (h->comm && comm_nranks(h) > 1) CHK(comm_allreduce_host(h, el, 1, 1));
+  return COSMO_HIP_OK;
+}
+
 static int32_t optimize_accelerated(cosmo_hip_handle* h, int* status_out, long long* iter_out, const std::chrono::steady_clock::time_point t0) {
   const cosmo_hip_params& p = h->prm;
   // Sharded runs: with clique (cone) sharding every rank holds the whole w and all scalars are computed redundantly and bit-identically, so the
@@ -1175,7 +1183,8 @@ static int32_t optimize_accelerated(cosmo_hip_handle* h, int* status_out, long l
       }
     }
     if (p.time_limit != 0.0) {
-      const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      double el = 0.0;
+      CHK(collective_elapsed(h, t0, &el));
       if (el > p.time_limit) { CHK(enqueue_check(h, 0, 0)); CHK(sync_ctl(h)); status = COSMO_HIP_TIME_LIMIT_REACHED; break; }
     }
   }
@@ -1212,7 +1221,8 @@ extern "C" int32_t cosmo_hip_optimize(cosmo_hip_handle* h, cosmo_hip_result* res
     if (p.time_limit != 0.0 && it > 0) {
       // the reference tests the time limit after EVERY iteration (solver.jl:351); the enqueue runs ahead in slices, so a slice is
       // cut to the number of iterations the measured pace fits into the remaining time (at least one)
-      const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      double el = 0.0;
+      CHK(collective_elapsed(h, t0, &el));                // sharded: the same slice on every rank
       const double per_it = el / (double)it;
       const double left = p.time_limit - el;
       const long long fit = (left > 0.0 && per_it > 0.0) ? (long long)std::min(1e15, left / per_it) : 0;
@@ -1225,7 +1235,8 @@ extern "C" int32_t cosmo_hip_optimize(cosmo_hip_handle* h, cosmo_hip_result* res
     if (h->ctl_host->status != 0) { status = h->ctl_host->status; break; }
     it = next;
     if (p.time_limit != 0.0) {
-      const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      double el = 0.0;
+      CHK(collective_elapsed(h, t0, &el));
       if (el > p.time_limit) {  // solver.jl:351-354
         CHK(enqueue_check(h, 0, 0));
         CHK(sync_ctl(h));

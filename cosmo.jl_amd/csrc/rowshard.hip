@@ -76,7 +76,6 @@ extern "C" int32_t cosmo_hip_set_row_shard(cosmo_hip_handle* h, const int64_t* f
   cosmo_hip_accel_params accel_prm;
   const bool had_accel = aa_get_params(h, &accel_prm);      // the accelerator's history lives on w = [x ; rows]: re-created below on the local layout
   if (had_accel) aa_free(h);
-  if (h->prm.time_limit != 0.0) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "set_row_shard: a wall-clock time limit would let the ranks' control flow diverge");
   if (!h->custom.empty()) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "set_row_shard: user-defined cones are projected on the host");
   CHK(comm_set_partition(h, first_cone, "set_row_shard"));
   long long cone_lo, cone_hi, lo, hi;

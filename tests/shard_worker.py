@@ -32,6 +32,8 @@ def settings(iters, tight=False):
         return cj.Settings(max_iter=iters, eps_abs=1e-6, eps_rel=1e-6, accelerator=cj.AndersonAccelerator,
                            kkt_solver=cj.with_options(cj.CGIndirectKKTSolver, tol_constant=1e-10, tol_exponent=0.0))
     kw = dict(max_iter=iters, eps_abs=0.0, eps_rel=0.0, check_infeasibility=10 ** 9)
+    if os.environ.get("COSMO_TEST_TIMELIMIT"):              # a wall-clock limit (solver.jl:351-354): the ranks must stop at the same iteration
+        kw["time_limit"] = float(os.environ["COSMO_TEST_TIMELIMIT"])
     if tight:
         kw["kkt_solver"] = cj.with_options(cj.CGIndirectKKTSolver, tol_constant=1e-10, tol_exponent=0.0)
     return cj.Settings(**kw)

@@ -191,5 +191,6 @@ def test_krylov_budget_feedback_changes_the_number_of_launches_not_the_results(n
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     assert a[3] == b[3] > 0 and a[6] == b[6]                                    # Krylov iterations performed, rho updates
     assert b[5] <= 1                                                            # (next to) no stall with the feedback: a stall costs a window, never a result
-    assert b[4] <= 1.5 * b[3] + 100 * 8                                         # enqueued <= 1.5 x performed + a few per solve
+    # enqueued <= 1.5 x performed + a few per solve; a stall (rare, trajectory dependent) re-enqueues the rest of the call once: twice that
+    assert b[4] <= (1 + b[5]) * (1.5 * b[3] + 100 * 8)
     assert b[4] <= a[4]                                                         # and never more launches than the fixed budget

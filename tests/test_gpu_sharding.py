@@ -299,6 +299,27 @@ def test_sharded_runs_with_the_reference_default_accelerator(mode, monkeypatch):
         assert int(z[0]["allreduces"]) >= int(z[0]["iter"])                                                  # the loop's own all-reduce ran every iteration
 
 
+def test_row_sharded_run_with_a_time_limit_stops_all_ranks_at_the_same_iteration():
+    """settings.time_limit in a sharded run (src/solver.jl:351-354): the ranks' clocks differ, so every time-limit decision (the slice a rank enqueues
+    and the test itself) is taken on the maximum of the ranks' elapsed seconds -- both ranks return Time_limit_reached at the SAME iteration with the
+    same iterates, and the collectives stay matched (no hang)."""
+    with tempfile.TemporaryDirectory() as tmp:
+        global ITERS
+        keep = ITERS
+        ITERS = 10 ** 6
+        try:
+            outs = _spawn("shm", 2, "/cosmo_test_" + uuid.uuid4().hex[:12], tmp, timeout=300, extra_env={"COSMO_TEST_SHARD": "rows", "COSMO_TEST_TIMELIMIT": "1.0"})
+        finally:
+            ITERS = keep
+        for rc, o in outs:
+            assert rc == 0, o[-3000:]
+        z = [np.load(os.path.join(tmp, "rank%d.npz" % r)) for r in range(2)]
+    assert str(z[0]["status"]) == str(z[1]["status"]) == "Time_limit_reached"
+    assert int(z[0]["iter"]) == int(z[1]["iter"]) > 0
+    for key in ("x", "s", "y"):
+        assert np.array_equal(z[0][key].view(np.int64), z[1][key].view(np.int64)), key
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
