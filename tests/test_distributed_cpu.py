@@ -148,3 +148,70 @@ def test_bench_cpu_leg_plumbing():
     r = B.compiled_cpu_rate(p, 30, 1)
     assert r["iters"] == 30 and r["rate"] > 0 and r["secs"] > 0 and r["cg"] > 0
     assert B.whole_job_value(4, 10, 2.0) == 20.0
+
+
+# ---- pure-Python parts of the N > 1 bench line (bench.py cannot run on this GPU-less host; its bookkeeping can) ----------------------------
+def _bench_module():
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    finally:
+        sys.argv = argv
+    return mod
+
+
+def test_cfg3_scaling_model_says_chain_limited_when_one_problem_dominates():
+    """The batch step is t_k * max(longest chain on a rank, the rank's work / 256 CU slots): with BASELINE config 3's measured distribution (a few
+    problems with thousands of Krylov iterations, median 50) every N is chain limited and the predicted sharded speed-up is 1.0; a flat distribution
+    with more problems than slots is work limited and scales."""
+    B = _bench_module()
+    rng = np.random.default_rng(0)
+    K = rng.integers(8, 140, 1024).astype(float)
+    K[[133, 2, 613, 606]] = [3304, 2929, 2852, 1844]
+    m = B.cfg3_scaling_model(cj, K, elapsed=3304 * 7.0e-6, world=1)
+    assert m["longest_chain_krylov_iterations"] == 3304 and abs(m["seconds_per_krylov_iteration"] - 7.0e-6) < 1e-12
+    assert all(m["predicted"][str(N)]["chain_limited"] and m["predicted"][str(N)]["speedup_bound"] == 1.0 for N in (1, 2, 4, 8))
+    assert 0.05 < m["cu_slot_utilisation_this_run"] < 0.2
+    flat = np.full(4096, 100.0)                                # 4096 equal problems on 256 slots: 16 waves of work per rank at N = 1
+    f = B.cfg3_scaling_model(cj, flat, elapsed=1600 * 7.0e-6, world=1)
+    assert not f["predicted"]["1"]["chain_limited"] and f["predicted"]["8"]["speedup_bound"] == pytest.approx(8.0)
+    # measured on several ranks: t_k comes from the slowest rank's longest chain
+    m2 = B.cfg3_scaling_model(cj, K, elapsed=3304 * 7.0e-6, world=2)
+    assert abs(m2["seconds_per_krylov_iteration"] - 7.0e-6) < 1e-12
+
+
+class _FakeCtx:
+    def __init__(self, results):
+        self.results = results
+
+    def all_gather(self, obj):
+        return self.results
+
+
+class _FakeHandle:
+    def __init__(self, out=None, err=None):
+        self.out, self.err = out, err
+
+    def comm_allreduce_check(self, count):
+        if self.err:
+            raise RuntimeError(self.err)
+        return self.out
+
+
+def test_comm_known_answer_check_combines_the_ranks_verdicts():
+    B = _bench_module()
+    good = dict(exact_mismatches=0, inexact_outside_bound=0, hash=1234, transport=1, nranks=2, rccl_version_code=22606, count=100)
+    ok = B.comm_known_answer_check(_FakeCtx([(good, None), (dict(good), None)]), _FakeHandle(good), 100)
+    assert ok["selftest"] == "ok" and ok["rccl_version"] == "2.26.6" and ok["transport_name"] == "rccl" and ok["result_bits_identical_on_all_ranks"] is True
+    other_bits = dict(good, hash=999)
+    bad = B.comm_known_answer_check(_FakeCtx([(good, None), (other_bits, None)]), _FakeHandle(good), 100)
+    assert bad["selftest"].startswith("FAILED") and bad["result_bits_identical_on_all_ranks"] is False
+    wrong_sum = dict(good, exact_mismatches=7)
+    bad = B.comm_known_answer_check(_FakeCtx([(good, None), (wrong_sum, None)]), _FakeHandle(good), 100)
+    assert bad["selftest"].startswith("FAILED") and bad["exact_sum_mismatches"] == 7
+    err = B.comm_known_answer_check(_FakeCtx([(good, None), (None, "RuntimeError: ncclAllReduce failed")]), _FakeHandle(good), 100)
+    assert err["selftest"].startswith("FAILED") and "ncclAllReduce" in err["selftest"]
