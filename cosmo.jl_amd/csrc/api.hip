@@ -107,7 +107,7 @@ void free_csr(CsrDev& D) {
 // Greedy CSR-stream schedule: consecutive rows whose nonzeros fit the LDS tile; a longer row gets its own block.
 // Small matrices (the split CG operator of an SDP, small QPs) get smaller tiles so that a launch still has a few hundred
 // workgroups: with the full 2048-nonzero tile a 100 k-nonzero operator is 50 workgroups on 256 CUs and its ~9 us are all ramp.
-static void build_row_blocks(const std::vector<int>& rowptr, int nrows, std::vector<int>& rb, int tile_override) {
+void build_row_blocks(const std::vector<int>& rowptr, int nrows, std::vector<int>& rb, int tile_override) {
   rb.clear();
   rb.push_back(0);
   const long long nnz_total = nrows > 0 ? (long long)rowptr[nrows] : 0;

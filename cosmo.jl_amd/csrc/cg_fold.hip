@@ -40,12 +40,15 @@ static inline int ew_grid(long long N) {
 __global__ __launch_bounds__(COSMO_BS) void k_fold_refresh(long long nnz, const real* __restrict__ base, const int* __restrict__ drow,
                                                            const int* __restrict__ tptr, const int* __restrict__ trow,
                                                            const real* __restrict__ tprod, const real* __restrict__ rho_m,
-                                                           const real* __restrict__ diag, real sigma, real* __restrict__ val) {
+                                                           const real* __restrict__ diag, real sigma, real* __restrict__ val,
+                                                           const int* __restrict__ ppos, real* __restrict__ pval) {
   for (long long p = (long long)blockIdx.x * COSMO_BS + threadIdx.x; p < nnz; p += (long long)gridDim.x * COSMO_BS) {
     real s = 0.0;
     for (int t = tptr[p]; t < tptr[p + 1]; ++t) s += rho_m[trow[t]] * tprod[t];
     const int i = drow[p];
-    val[p] = (i >= 0) ? base[p] + ((sigma + diag[i]) + s) : base[p] + s;
+    const real v = (i >= 0) ? base[p] + ((sigma + diag[i]) + s) : base[p] + s;
+    val[p] = v;
+    if (ppos) pval[ppos[p]] = v;                         // the tile-major padded copy k_cg_dirM streams
   }
 }
 
@@ -116,7 +119,7 @@ template <int SL, bool PC>
 __global__ __launch_bounds__(COSMO_BS) void k_cg_dirM(Ctl* __restrict__ ctl, int guard, int check_first, int k, long long n, long long maxiter,
                                                       const real* __restrict__ part_rr, int n_rr, CsrView M, const real2* __restrict__ ru,
                                                       real* __restrict__ c, real* __restrict__ u, real* __restrict__ part_uc,
-                                                      const real* __restrict__ part_rz) {
+                                                      const real* __restrict__ part_rz, const int* __restrict__ pcol, const real* __restrict__ pval) {
   if (check_first) { if (guard && ctl->halt) return; if (ctl->cg_done) return; }   // expected no-op (see k_cg_dirA): flags before any request
   const real pa = partials_prefetch_sum(part_rr, n_rr);
   real pz = 0.0;
@@ -125,18 +128,40 @@ __global__ __launch_bounds__(COSMO_BS) void k_cg_dirM(Ctl* __restrict__ ctl, int
   const bool have_tile = first_tile < M.nb;
   int4 d = make_int4(0, 0, 0, 0);
   if (have_tile) d = reinterpret_cast<const int4*>(M.rb)[first_tile];
-  const int cnt0 = d.w - d.z;
-  const bool fast = have_tile && cnt0 <= SL * COSMO_BS;            // a single long row takes the generic chunked path below
   real av[SL]; real2 gv[SL];
+  int cnt0;
+  bool fast;
+  if (pcol) {
+    // tile-major padded copy (cap = SL * 256 slots per tile): the addresses depend on the block index only, so (col, val) are requested together
+    // with the descriptor and the partials -- the dependent chain is col -> gather, one memory round trip shorter (the working set comes back
+    // through the fabric at every kernel boundary: profiles/r04_cfg5_pmc_traffic.json).  Padding slots hold column 0 / value 0 and are masked by
+    // cnt0 once the descriptor has arrived.
+    int ccs[SL];
 #pragma unroll
-  for (int it = 0; it < SL; ++it) {
-    const int kk = it * COSMO_BS + threadIdx.x;
-    const bool ok = fast && kk < cnt0;
-    const int e = ok ? d.z + kk : 0;
-    const int cc = M.col[e];
-    const real a = M.val[e];
-    av[it] = ok ? a : 0.0;
-    gv[it] = ru[cc];
+    for (int it = 0; it < SL; ++it) {
+      const long long e = have_tile ? (long long)first_tile * (SL * COSMO_BS) + it * COSMO_BS + threadIdx.x : 0;
+      ccs[it] = pcol[e];
+      av[it] = pval[e];
+    }
+#pragma unroll
+    for (int it = 0; it < SL; ++it) gv[it] = ru[ccs[it]];
+    cnt0 = d.w - d.z;
+    fast = have_tile && cnt0 <= SL * COSMO_BS;
+#pragma unroll
+    for (int it = 0; it < SL; ++it) if (!(fast && it * COSMO_BS + (int)threadIdx.x < cnt0)) av[it] = 0.0;
+  } else {
+    cnt0 = d.w - d.z;
+    fast = have_tile && cnt0 <= SL * COSMO_BS;            // a single long row takes the generic chunked path below
+#pragma unroll
+    for (int it = 0; it < SL; ++it) {
+      const int kk = it * COSMO_BS + threadIdx.x;
+      const bool ok = fast && kk < cnt0;
+      const int e = ok ? d.z + kk : 0;
+      const int cc = M.col[e];
+      const real a = M.val[e];
+      av[it] = ok ? a : 0.0;
+      gv[it] = ru[cc];
+    }
   }
   const int rfirst = d.x + threadIdx.x;
   const bool rowok = fast && rfirst < d.y;
@@ -221,6 +246,9 @@ void fold_free(cosmo_hip_handle* h) {
   if (f->tptr) (void)hipFree(f->tptr);
   if (f->trow) (void)hipFree(f->trow);
   if (f->tprod) (void)hipFree(f->tprod);
+  if (f->pcol) (void)hipFree(f->pcol);
+  if (f->pval) (void)hipFree(f->pval);
+  if (f->ppos) (void)hipFree(f->ppos);
   if (f->dpos) (void)hipFree(f->dpos);
   if (f->dinv) (void)hipFree(f->dinv);
   if (f->chain) (void)hipGraphExecDestroy((hipGraphExec_t)f->chain);
@@ -309,7 +337,32 @@ int32_t fold_build(cosmo_hip_handle* h, const HostCsr& Am, const std::vector<int
   if ((long long)M.col.size() > 700LL * COSMO_MAX_PARTIALS) tile = 0;      // large operators: the size heuristic of build_row_blocks
   if (const char* e = getenv("COSMO_HIP_FOLD_TILE")) { const int v = atoi(e); if (v >= 64 && v <= COSMO_NNZ_PER_BLOCK) tile = v; }
   CHK(upload_csr(h, M, f->M, (int)n, tile));
-  f->slots = tile == 0 ? 8 : tile <= COSMO_BS ? 1 : tile <= 2 * COSMO_BS ? 2 : tile <= 4 * COSMO_BS ? 4 : 8;
+  f->slots = tile == 0 ? 8 : tile <= COSMO_BS ? 1 : tile <= 2 * COSMO_BS ? 2 : tile <= 3 * COSMO_BS ? 3 : tile <= 4 * COSMO_BS ? 4 : 8;
+  // tile-major padded copy of (col, val) -- fixed-size tiles only.  OPT-IN (COSMO_HIP_FOLD_PAD=1): measured on BASELINE config 5, two alternating
+  // pairs of runs: 12.35 / 12.35 us per Krylov iteration with the copy against 12.27 / 12.30 us without (237.3 / 236.9 vs 237.7 / 237.9 it/s) -- the
+  // descriptor's round trip was not on the critical path (the gather behind (col, val) and the partial-sum reduction are); bit-identical either way
+  { bool pad = false;
+    if (const char* e = getenv("COSMO_HIP_FOLD_PAD")) pad = tile != 0 && f->slots <= 4 && atoi(e) != 0;
+    if (pad) {
+      const int cap = f->slots * COSMO_BS;
+      std::vector<int> rbnd, rbd;
+      build_row_blocks(M.rowptr, M.nrows, rbnd, tile);                       // the same boundaries upload_csr used
+      const size_t nbk = rbnd.size() - 1;
+      if ((long long)nbk == f->M.nb && nbk * (size_t)cap < (size_t)1 << 30) {
+        std::vector<int> pc(nbk * cap, 0), pp(M.col.size(), 0);
+        std::vector<real> pv(nbk * cap, R(0.0));
+        for (size_t k = 0; k < nbk; ++k) {
+          const int z0 = M.rowptr[rbnd[k]], z1 = M.rowptr[rbnd[k + 1]];
+          for (int e2 = z0; e2 < z1; ++e2) {
+            const size_t q = (z1 - z0 <= cap) ? k * cap + (size_t)(e2 - z0) : k * cap;     // a single long row (generic path) is not streamed from the copy
+            if (z1 - z0 <= cap) { pc[q] = M.col[e2]; pv[q] = M.val[e2]; }
+            pp[(size_t)e2] = (int)q;
+          }
+        }
+        CHK(up(h, &f->pcol, pc)); CHK(up(h, &f->pval, pv)); CHK(up(h, &f->ppos, pp));
+        f->cap = cap;
+      }
+    } }
   { std::vector<int> dpos((size_t)n, 0);                        // every row has its diagonal entry (the three-way merge adds it)
     for (size_t pz = 0; pz < drow.size(); ++pz) if (drow[pz] >= 0) dpos[(size_t)drow[pz]] = (int)pz;
     CHK(up(h, &f->dpos, dpos));
@@ -323,7 +376,7 @@ int32_t fold_refresh(cosmo_hip_handle* h) {
   FoldPlan* f = (FoldPlan*)h->fold;
   if (!h->op_fold || !f) return COSMO_HIP_OK;
   hipLaunchKernelGGL(k_fold_refresh, dim3(ew_grid(f->M.nnz)), dim3(COSMO_BS), 0, h->stream, f->M.nnz, f->base, f->drow, f->tptr, f->trow,
-                     f->tprod, h->op_rho_m, h->op_diag, h->prm.sigma, f->M.val);
+                     f->tprod, h->op_rho_m, h->op_diag, h->prm.sigma, f->M.val, (const int*)f->ppos, f->pval);
   if (h->cg_jacobi)
     hipLaunchKernelGGL(k_fold_dinv, dim3(ew_grid(h->n)), dim3(COSMO_BS), 0, h->stream, h->n, f->dpos, f->M.val, f->dinv);
   HIPCHK(h, hipGetLastError());
@@ -349,11 +402,13 @@ static void fold_launch_pair(cosmo_hip_handle* h, FoldPlan* f, int guard, int k,
   const long long n = h->n;
   prof_begin(h, KC_OP_APPLY);
 #define LAUNCH_DIRM_(SLN, PCF) hipLaunchKernelGGL((k_cg_dirM<SLN, PCF>), dim3(f->M.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, check_first, k, n, n, \
-                         PARTS(h, SLOT_RR), n_rr, view_of(f->M), (const real2*)h->cg_ru, h->c, h->u, PARTS(h, SLOT_UC), (const real*)PARTS(h, SLOT_AUX2))
+                         PARTS(h, SLOT_RR), n_rr, view_of(f->M), (const real2*)h->cg_ru, h->c, h->u, PARTS(h, SLOT_UC), (const real*)PARTS(h, SLOT_AUX2), \
+                         (const int*)(f->cap == SLN * COSMO_BS ? f->pcol : nullptr), (const real*)f->pval)
 #define LAUNCH_DIRM(SLN) do { if (h->cg_jacobi) LAUNCH_DIRM_(SLN, true); else LAUNCH_DIRM_(SLN, false); } while (0)
   switch (f->slots) {
     case 1: LAUNCH_DIRM(1); break;
     case 2: LAUNCH_DIRM(2); break;
+    case 3: LAUNCH_DIRM(3); break;
     case 4: LAUNCH_DIRM(4); break;
     default: LAUNCH_DIRM(8); break;
   }

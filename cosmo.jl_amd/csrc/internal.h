@@ -93,6 +93,12 @@ struct FoldPlan {
   int* tptr = nullptr;      // nnz(M)+1: terms of entry p are [tptr[p], tptr[p+1])
   int* trow = nullptr;      // term -> row of Am
   real* tprod = nullptr;  // term -> a_ki * a_kj
+  // tile-major PADDED copy of (col, val) for k_cg_dirM (round 4): tile k's nonzeros start at k * cap, so the workgroup requests them from its
+  // block index alone, TOGETHER with the tile descriptor and the partial sums instead of one memory round trip behind the descriptor
+  int* pcol = nullptr;      // nb * cap (padding: column 0)
+  real* pval = nullptr;   // nb * cap (padding: 0); rewritten by k_fold_refresh next to M.val
+  int* ppos = nullptr;      // nnz(M): position of entry p in pval
+  int cap = 0;              // slots per tile (= slots * 256); 0: no padded copy (size-heuristic tiles of large operators)
   int* dpos = nullptr;      // n: index of row i's diagonal entry in M.val
   real* dinv = nullptr;   // n: 1 / M_ii, the Jacobi preconditioner of the opt-in PCG (refreshed with the values)
   long long nterms = 0;
@@ -260,6 +266,7 @@ int32_t cosmo_fail(cosmo_hip_handle* h, int32_t code, const char* fmt, ...);
   } while (0)
 
 // ---- launch helpers implemented in kernels.hip ---------------------------------------------------------------------
+void build_row_blocks(const std::vector<int>& rowptr, int nrows, std::vector<int>& rb, int tile_override);   // api.hip: row boundaries of the CSR-stream tiles
 // tile_override > 0: nonzeros per CSR-stream tile (<= COSMO_NNZ_PER_BLOCK) instead of the size heuristic of build_row_blocks
 int32_t upload_csr(cosmo_hip_handle* h, const HostCsr& M, CsrDev& D, int split_col, int tile_override = 0);
 void free_csr(CsrDev& D);

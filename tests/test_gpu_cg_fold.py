@@ -194,3 +194,21 @@ def test_krylov_budget_feedback_changes_the_number_of_launches_not_the_results(n
     # enqueued <= 1.5 x performed + a few per solve; a stall (rare, trajectory dependent) re-enqueues the rest of the call once: twice that
     assert b[4] <= (1 + b[5]) * (1.5 * b[3] + 100 * 8)
     assert b[4] <= a[4]                                                         # and never more launches than the fixed budget
+
+
+@pytest.mark.parametrize("kkt", ["literal", "jacobi"])
+def test_padded_tile_major_operator_copy_is_bit_identical(kkt, monkeypatch):
+    """Opt-in COSMO_HIP_FOLD_PAD=1: k_cg_dirM streams (col, val) from a tile-major padded copy whose addresses depend on the block index only (one
+    dependent memory round trip less per workgroup; measured: no gain, hence opt-in); by default it reads the CSR arrays behind the tile descriptor.  Same arithmetic: iterates,
+    Krylov counts and rho updates are the same bits -- default (rho-adapting) schedule, so the refresh of the padded values is exercised too."""
+    prob = PROBLEMS["chordal_sdp"]()
+    solver = cj.CGJacobiKKTSolver if kkt == "jacobi" else cj.CGIndirectKKTSolver
+    out = {}
+    for pad in ("1", "0"):
+        monkeypatch.setenv("COSMO_HIP_FOLD_PAD", pad)
+        md = cj.Model(); md.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], cj.Settings(kkt_solver=solver, max_iter=130, eps_abs=0.0, eps_rel=0.0))
+        out[pad] = cj.optimize(md)
+        assert md.handle.fold_stats()["enabled"] == 1
+    a, b = out["1"], out["0"]
+    assert a.kkt_iters_total == b.kkt_iters_total > 0 and list(a.info.rho_updates) == list(b.info.rho_updates) and len(a.info.rho_updates) >= 2
+    assert np.array_equal(a.x, b.x) and np.array_equal(a.s, b.s) and np.array_equal(a.y, b.y)
