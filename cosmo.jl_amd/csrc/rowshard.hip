@@ -76,7 +76,6 @@ extern "C" int32_t cosmo_hip_set_row_shard(cosmo_hip_handle* h, const int64_t* f
   cosmo_hip_accel_params accel_prm;
   const bool had_accel = aa_get_params(h, &accel_prm);      // the accelerator's history lives on w = [x ; rows]: re-created below on the local layout
   if (had_accel) aa_free(h);
-  if (!h->custom.empty()) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "set_row_shard: user-defined cones are projected on the host");
   CHK(comm_set_partition(h, first_cone, "set_row_shard"));
   long long cone_lo, cone_hi, lo, hi;
   comm_my_range(h, &cone_lo, &cone_hi, &lo, &hi);
@@ -137,6 +136,12 @@ extern "C" int32_t cosmo_hip_set_row_shard(cosmo_hip_handle* h, const int64_t* f
   }
   L.nbox_rows = h->cones_g.nbox_rows; L.box_l = h->cones_g.box_l; L.box_u = h->cones_g.box_u;
   h->cones = L;
+  // user-defined cones (custom.hip): this rank keeps the callbacks of the cones it owns, with local cone indices / row offsets; the host staging
+  // buffer keeps its size.  Certificates: custom_test sees the local slices, the verdicts are combined by comm_allreduce_flag (infeas.hip)
+  { std::vector<CustomCone> mine;
+    for (const CustomCone& cc : h->custom)
+      if (cc.cone >= cone_lo && cc.cone < cone_hi) { CustomCone c2 = cc; c2.cone = cc.cone - cone_lo; c2.off = cc.off - lo; mine.push_back(c2); }
+    h->custom = mine; }
   h->m_g = mg; h->row_lo = lo; h->m = ml;
   h->cone_lo = 0; h->cone_hi = -1;                                  // every local cone is owned
   h->row_shard = true;

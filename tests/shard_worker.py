@@ -61,11 +61,37 @@ def infeasible_model(case):
     return md
 
 
+def custom_cone_model(iters):
+    """The reference's worked example of a user-defined cone (docs/src/literate/custom_cone.jl:19-49: Nonpositives as an AbstractConvexCone plugin,
+    LP with solution x = (3, 2, 2)) next to a decoupled 3 x 3 PSD block, so that two ranks own cones and ONE of them owns the custom cone."""
+    import scipy.sparse as sp
+    import cosmo_jl_amd as cj
+
+    class Nonpositives(cj.AbstractConvexCone):
+        def project(self, x):
+            np.minimum(x, 0.0, out=x)
+
+    nz = 6
+    Z0 = np.array([[1.0, 2.0, 0.0], [2.0, -3.0, 0.5], [0.0, 0.5, 0.2]])
+    P = sp.block_diag([sp.csc_matrix((3, 3)), sp.identity(nz)], format="csc")
+    q = np.concatenate([-np.ones(3), -cj.problems.svec(Z0)])
+    A1 = sp.hstack([sp.csc_matrix(np.array([[1.0, 0, 0], [0, 1.0, 0]])), sp.csc_matrix((2, nz))], format="csc"); b1 = np.array([-3.0, -2.0])
+    A2 = sp.hstack([sp.csc_matrix(np.array([[1.0, 0, 1.0]])), sp.csc_matrix((1, nz))], format="csc"); b2 = np.array([-5.0])
+    A3 = sp.hstack([sp.csc_matrix((nz, 3)), sp.identity(nz)], format="csc"); b3 = np.zeros(nz)
+    md = cj.Model()
+    cj.assemble(md, P, q, [cj.Constraint(A1, b1, Nonpositives), cj.Constraint(A2, b2, cj.ZeroSet), cj.Constraint(A3, b3, cj.PsdConeTriangle)],
+                settings=cj.Settings(max_iter=iters, eps_abs=0.0, eps_rel=0.0, check_infeasibility=10 ** 9,
+                                     kkt_solver=cj.with_options(cj.CGIndirectKKTSolver, tol_constant=1e-10, tol_exponent=0.0)))
+    return md
+
+
 def build_model(iters):
     import cosmo_jl_amd as cj
     case = os.environ.get("COSMO_TEST_CASE", "chordal")
     if case in ("pinf", "dinf"):
         return infeasible_model(case)
+    if case == "custom":
+        return custom_cone_model(iters)
     p = problem()
     dtype = np.float32 if os.environ.get("COSMO_TEST_DTYPE", "") == "float32" else np.float64       # libcosmo_hip_f32.so: the collectives carry float
     md = cj.Model(dtype=dtype); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], settings(iters, os.environ.get("COSMO_TEST_TIGHT", "") == "1"))

@@ -320,6 +320,31 @@ def test_row_sharded_run_with_a_time_limit_stops_all_ranks_at_the_same_iteration
         assert np.array_equal(z[0][key].view(np.int64), z[1][key].view(np.int64)), key
 
 
+def test_row_sharded_run_with_a_user_defined_cone():
+    """The AbstractConvexCone plugin surface (src/projections.jl:4-5; docs/src/literate/custom_cone.jl) on a row-sharded handle: the rank that owns the
+    user's cone keeps its host callback (local cone index / row offset), the other rank has none; 300 tight-CG iterations agree with the single-rank
+    run to 1e-7 and between the ranks bit for bit; the LP part reaches the documented solution x = (3, 2, 2)."""
+    W = _worker_module()
+    md = W.custom_cone_model(300)
+    ref = cj.optimize(md)
+    with tempfile.TemporaryDirectory() as tmp:
+        global ITERS
+        keep = ITERS
+        ITERS = 300
+        try:
+            outs = _spawn("shm", 2, "/cosmo_test_" + uuid.uuid4().hex[:12], tmp, timeout=300, extra_env={"COSMO_TEST_SHARD": "rows", "COSMO_TEST_CASE": "custom"})
+        finally:
+            ITERS = keep
+        for rc, o in outs:
+            assert rc == 0, o[-3000:]
+        z = [np.load(os.path.join(tmp, "rank%d.npz" % r)) for r in range(2)]
+    assert int(z[0]["row_hi"]) == int(z[1]["row_lo"]) and int(z[0]["row_lo"]) == 0 and int(z[0]["row_hi"]) > 0        # both ranks own rows
+    for key, val in (("x", ref.x), ("s", ref.s), ("y", ref.y)):
+        assert np.array_equal(z[0][key].view(np.int64), z[1][key].view(np.int64)), key
+        assert np.max(np.abs(z[0][key] - val)) <= 1e-7 * max(1.0, float(np.max(np.abs(val)))), key
+    np.testing.assert_allclose(z[0]["x"][:3], [3.0, 2.0, 2.0], atol=1e-3)
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
