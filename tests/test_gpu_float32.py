@@ -329,6 +329,28 @@ def test_float32_batch_of_socps():
         assert abs(r.obj_val - ref.obj_val) <= 1e-3 * (1 + abs(ref.obj_val))
 
 
+def test_float32_batch_of_small_sdps():
+    """Round 4: PsdConeTriangle / PsdCone of side <= 16 inside the batch kernels of libcosmo_hip_f32.so (csrc/psd16.h instantiated for float: the
+    v_mfma-free wave-level Jacobi with eps32 thresholds): every problem of a small batch of SDPs reaches the status and objective of its Float64
+    oracle solve."""
+    rng = np.random.default_rng(71)
+    st = dict(eps_abs=1e-4, eps_rel=1e-4, max_iter=4000, check_infeasibility=10 ** 9)
+    models, refs = [], []
+    for k in range(10):
+        p = util.random_qp(rng, 30, 2, 8, 6, soc_dims=(5,), psd_tri_dims=(5, 12, 16), psd_sq_dims=(3,), p_shift=1.0)
+        md = cj.Model(dtype=F32); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], cj.Settings(kkt_solver=cj.CGIndirectKKTSolver, **st))
+        models.append(md)
+        refs.append(O.solve(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), O.Settings(kkt_solver="cg", **st)))
+    rs = cj.optimize_batch(models)
+    solved = 0
+    for r, ref in zip(rs, refs):
+        if ref.status == "Solved":
+            solved += 1
+            assert r.status == "Solved", (r.status, r.iter, ref.iter)
+            assert abs(r.obj_val - ref.obj_val) <= 2e-3 * (1 + abs(ref.obj_val))
+    assert solved >= 8
+
+
 @pytest.mark.parametrize("iters", [1, 30])
 def test_float32_loop_against_the_float32_instantiation_of_the_c_oracle(iters):
     """Loop-level parity IN Float32: oracle/cosmo_oracle_c.c compiled with -DOC_FLOAT (every operation rounds to float, checked with
