@@ -7,9 +7,10 @@
 // (rho, CG residuals, counters, status) live with the problem: trajectories are those of 1024 separate solves, not of
 // one block-diagonal solve.  The phases reuse the row lambdas / CSR-stream primitive of the large-problem path, the
 // arithmetic per element is identical, reductions are single-workgroup fixed-order sums.
-// Cone support in batch mode: ZeroSet, Nonnegatives, Box, SecondOrderCone and PsdCone / PsdConeTriangle of side <= 16 (round 4: the wave-level
-// Jacobi projection of psd16.h, the routine the single-problem path uses for such cones, called from the problem's persistent workgroup --
-// batches of small SDPs, src/convexset.jl:402-412 inside the composite projection :885-891); larger PSD cones take the single-problem path.  The
+// Cone support in batch mode: ZeroSet, Nonnegatives, Box, SecondOrderCone and PsdCone / PsdConeTriangle of side <= 64 (round 4: side <= 16 by the
+// wave-level Jacobi projection of psd16.h, 17 .. 64 by the workgroup-level block Jacobi of psdwg.h -- the routines the single-problem path uses for
+// such cones, called from the problem's persistent workgroup: batches of small SDPs, src/convexset.jl:402-412 inside the composite projection
+// :885-891); larger PSD cones take the single-problem path.  The
 // infeasibility certificates run between persistent launches (k_batch_inf_capture / k_batch_inf_check below).
 #include <stdarg.h>
 #include <stdlib.h>
@@ -19,6 +20,7 @@
 #include <chrono>
 #include "device_utils.h"
 #include "psd16.h"
+#include "psdwg.h"
 
 struct BCtl {                 // per problem, device resident
   int status; int n_rho_updates;
@@ -38,6 +40,9 @@ struct BatchDev {
   int nsoc; const int *soc_off, *soc_dim;
   int npsd; const int *psd_off, *psd_d, *psd_kind;   // PSD cones of side 2..16: first row, side, COSMO_HIP_PSD_SQUARE / _TRIANGLE
   int psd_nws;                  // wave workspaces (psd16.h) available to a workgroup: waves 0 .. psd_nws-1 project the PSD cones
+  // PSD cones of side 17 .. 64 (psdwg.h): one cone after the other by the whole workgroup; G = X + c I lives in global memory (ld x ncp per cone)
+  int nmid; const int *mid_off, *mid_d, *mid_kind, *mid_ld, *mid_ncp; const long long* mid_goff;
+  real* psdG; long long psdG_stride;      // per problem: sum over its mid cones of ld * ncp reals
   const int* rho_cls;
   real *w, *w_prev, *s, *mu, *s_tl, *ls_s, *y2, *tmp_m, *nu, *rho;
   real *ls_x, *x_tl, *rhs, *r, *u, *c;
@@ -113,7 +118,7 @@ __device__ __forceinline__ real bmax(real v, real* red) {
   return t;
 }
 
-#define PSD16_WS_STRIDE ((PSD16_WS_BYTES + 15) / 16 * 16)
+#define PSD16_WS_STRIDE PSDWG_WS_STRIDE      // one per-wave workspace layout for both uses (psdwg.h: the psd16.h workspace + the panel's column list)
 // the PSD cones (side <= 16) of a problem: waves 0 .. nws-1 take the cones round-robin, each on its own LDS workspace.  x = the projected slack
 // (global memory, or its LDS staging copy in the register kernel).  Callers put a workgroup barrier in front and behind.
 __device__ __forceinline__ void batch_project_psd(const BatchDev& D, real* x, unsigned char* ws_base, int wv, int lane) {
@@ -122,6 +127,21 @@ __device__ __forceinline__ void batch_project_psd(const BatchDev& D, real* x, un
   for (int cI = wv; cI < D.npsd; cI += D.psd_nws) {
     (void)psd16_wave(x + D.psd_off[cI], D.psd_d[cI], D.psd_kind[cI], ws, lane, 0, R(1.0), nullptr, nullptr);
     wave_lds_fence();                                   // the workspace is reused by this wave's next cone
+  }
+}
+
+// the PSD cones of side 17 .. 64 of problem k: populate G = X + ||X||_F I, block-Jacobi sweeps (4 block pairs at most: 4 waves), column scaling +
+// SYRK back into x.  Every thread of the workgroup takes part; ws_base needs 4 workspaces of PSDWG_WS_STRIDE bytes, red BS / 64 reals.
+template <int BS>
+__device__ __forceinline__ void batch_project_psd_mid(const BatchDev& D, int k, real* x, unsigned char* ws_base, real* red, int* any_rot) {
+  for (int cI = 0; cI < D.nmid; ++cI) {
+    real* g = D.psdG + (long long)k * D.psdG_stride + D.mid_goff[cI];
+    const int d = D.mid_d[cI], kind = D.mid_kind[cI], ld = D.mid_ld[cI], ncp = D.mid_ncp[cI];
+    real* xc = x + D.mid_off[cI];
+    const real c = psdwg_populate<BS>(xc, d, kind, ld, ncp, R(1.0), 0, g, red);
+    (void)psdwg_jacobi<4>(g, ld, ncp / 8, d, c, R(0.125), 0, ws_base, any_rot);
+    __syncthreads();
+    (void)psdwg_finish<BS>(xc, d, kind, ld, ncp, c, g, 0, red);
   }
 }
 
@@ -373,6 +393,10 @@ __device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams
     if constexpr (PSD) {                                                  // PsdCone / PsdConeTriangle, side <= 16 (convexset.jl:303-321, 402-412)
       batch_project_psd(D, s, ops.psd_ws, wv, lane);
       __syncthreads();
+      if (D.nmid > 0) {                                                   // ... and side 17 .. 64: the whole workgroup, one cone after the other
+        __shared__ int any_rot_s;
+        batch_project_psd_mid<BS>(D, k, s, ops.psd_ws, red, &any_rot_s);
+      }
     }
     // ---- apply_rho_adaptation_rules! (solver.jl:242-282, parameters.jl:53-92) ----
     if (P.adaptive_rho && P.adaptive_rho_interval > 0 && (it % P.adaptive_rho_interval) == 0 &&
@@ -854,6 +878,8 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       }
       if constexpr (PSD) batch_project_psd(D, tv, psd_ws, wvid, lane);   // disjoint rows: no barrier needed between the two cone kinds
       __syncthreads();
+      // (side 17 .. 64 never reaches this kernel: build_lds_images gives such batches to the LDS-image kernel, whose registers have room for the
+      //  block-Jacobi code)
 #pragma unroll
       for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; if (i < m) sv[j] = tv[i]; }
       __syncthreads();
@@ -950,6 +976,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_batch_inf_check(BatchDev D, real e
   __shared__ real red[COSMO_BS / 64];
   __shared__ int flag;
   __shared__ __attribute__((aligned(16))) unsigned char psd_ws[(COSMO_BS / 64) * PSD16_WS_STRIDE];
+  __shared__ int flag2;
   const int k = blockIdx.x;
   BCtl* ctl = D.ctl + k;
   if (ctl->status != 0) return;
@@ -965,6 +992,16 @@ __global__ __launch_bounds__(COSMO_BS) void k_batch_inf_check(BatchDev D, real e
       (void)psd16_wave(v + D.psd_off[cI], D.psd_d[cI], D.psd_kind[cI], ws, lane_, 1, sign, &lm, nullptr);
       if (!(lm > -tol)) bad = 1;
       wave_lds_fence();
+    }
+    for (int cI = 0; cI < D.nmid; ++cI) {              // side 17 .. 64: the whole workgroup (uniform control flow: every thread is here)
+      __syncthreads();
+      real* g = D.psdG + (long long)k * D.psdG_stride + D.mid_goff[cI];
+      const int d = D.mid_d[cI], kind = D.mid_kind[cI], ld = D.mid_ld[cI], ncp = D.mid_ncp[cI];
+      const real c = psdwg_populate<BS>(v + D.mid_off[cI], d, kind, ld, ncp, sign, 1, g, red);
+      (void)psdwg_jacobi<4>(g, ld, ncp / 8, d, c, R(0.125), 0, psd_ws, &flag2);
+      __syncthreads();
+      const real lm = psdwg_finish<BS>(v + D.mid_off[cI], d, kind, ld, ncp, c, g, 1, red);
+      if (!(lm > -tol)) bad = 1;
     }
     return bad;
   };
@@ -1025,7 +1062,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_batch_inf_check(BatchDev D, real e
       const real nx = sqrt(wave_sum(a));
       if (!(nx <= epi + (-x[0]))) viol = 1;
     }
-    if (D.npsd > 0 && psd_violates(dy, -R(1.0), epi)) viol = 1;          // in_dual!(-dyn) of the PSD cones (:415-418)
+    if ((D.npsd > 0 || D.nmid > 0) && psd_violates(dy, -R(1.0), epi)) viol = 1;          // in_dual!(-dyn) of the PSD cones (:415-418)
     if (viol) atomicOr(&flag, 1);
     const real dyt_b = bsum<BS>(dtb, red), box_sf = bsum<BS>(box, red);          // (their barriers also publish `flag`)
     __syncthreads();
@@ -1061,7 +1098,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_batch_inf_check(BatchDev D, real e
       const real nx = sqrt(wave_sum(a));
       if (!(nx <= edi - x[0])) viol = 1;
     }
-    if (D.npsd > 0 && psd_violates(adx, -R(1.0), edi)) viol = 1;         // in_pol_recc!: is_neg_def (:421-424)
+    if ((D.npsd > 0 || D.nmid > 0) && psd_violates(adx, -R(1.0), edi)) viol = 1;         // in_pol_recc!: is_neg_def (:421-424)
     if (viol) atomicOr(&flag, 1);
     __syncthreads();
     if (!flag && tid == 0) { ctl->status = COSMO_HIP_DUAL_INFEASIBLE; ctl->cost = -(real)INFINITY; }   // solver.jl:343-346
@@ -1224,7 +1261,7 @@ extern "C" int32_t cosmo_hip_batch_set_cones(cosmo_hip_batch* b, int64_t ncones,
       long long d = 0;
       if (type[k] == COSMO_HIP_PSD_SQUARE) { while ((d + 1) * (d + 1) <= dim[k]) ++d; if (d * d != dim[k]) return bfail(b, COSMO_HIP_ERR_INVALID, "PsdCone: dimension %lld is not a square", (long long)dim[k]); }
       else { while ((d + 1) * (d + 2) / 2 <= dim[k]) ++d; if (d * (d + 1) / 2 != dim[k]) return bfail(b, COSMO_HIP_ERR_INVALID, "PsdConeTriangle: dimension %lld is not triangular", (long long)dim[k]); }
-      if (d > 16) return bfail(b, COSMO_HIP_ERR_UNSUPPORTED, "batch mode projects PSD cones of side <= 16 (side %lld: use one handle per problem)", d);
+      if (d > 64) return bfail(b, COSMO_HIP_ERR_UNSUPPORTED, "batch mode projects PSD cones of side <= 64 (side %lld: use one handle per problem)", d);
     } else if (type[k] < COSMO_HIP_ZERO || type[k] > COSMO_HIP_SOC) return bfail(b, COSMO_HIP_ERR_UNSUPPORTED, "cone type %d", (int)type[k]);
     C.type.push_back(type[k]); C.dim.push_back(dim[k]); C.off.push_back(off); off += dim[k];
     if (type[k] == COSMO_HIP_BOX) nbox += dim[k];
@@ -1301,9 +1338,12 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
   if (e && atoi(e) == 0) return COSMO_HIP_OK;
   const long long n = b->n, m = b->m;
   if (n > 65535 || m > 65535 || n + m == 0) return COSMO_HIP_OK;
-  int npsd = 0;
+  int npsd = 0, nmid = 0;
   for (size_t c = 0; c < b->cones.type.size(); ++c)
-    if ((b->cones.type[c] == COSMO_HIP_PSD_SQUARE || b->cones.type[c] == COSMO_HIP_PSD_TRIANGLE) && b->cones.dim[c] > 1) npsd += 1;
+    if ((b->cones.type[c] == COSMO_HIP_PSD_SQUARE || b->cones.type[c] == COSMO_HIP_PSD_TRIANGLE) && b->cones.dim[c] > 1) {
+      npsd += 1;
+      if (b->cones.dim[c] > (b->cones.type[c] == COSMO_HIP_PSD_SQUARE ? 16 * 16 : 16 * 17 / 2)) nmid += 1;        // side 17 .. 64: workgroup-level Jacobi
+    }
   int bs = 512;
   if (const char* eb = getenv("COSMO_HIP_BATCH_BS")) { const int v = atoi(eb); if (v == 256 || v == 512 || v == 1024) bs = v; }
   if (npsd > 0) bs = 512;                                        // the PSD instantiation of the LDS-image kernel exists for 512 threads
@@ -1312,6 +1352,7 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
   { const char* er = getenv("COSMO_HIP_BATCH_REG");
     if (!(er && atoi(er) == 0)) {
       if (n <= 512 && m <= 1024) b->reg_mode = 1; else if (n <= 1024 && m <= 2048) b->reg_mode = 2;
+      if (nmid > 0) b->reg_mode = 0;            // the block-Jacobi code on top of ~200 live registers would spill: the LDS-image kernel (187 VGPRs) takes such batches
       if (b->reg_mode) bs = 512;
     } }
   int max_lds = 0;
@@ -1480,7 +1521,7 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
   int nws = 0;
   if (npsd > 0) {
     nws = (int)std::min<long long>(bs / 64, (max_lds - ws_base) / PSD16_WS_STRIDE);
-    if (nws < 1) { b->reg_mode = 0; return COSMO_HIP_OK; }       // (the image is released with the batch)
+    if (nws < (nmid > 0 ? 4 : 1)) { b->reg_mode = 0; return COSMO_HIP_OK; }       // (the image is released with the batch); side 17 .. 64 needs four (one per block pair)
   }
   b->D.psd_nws = nws;
   b->d_img = d; b->img_stride = stride; b->lds_bs = bs;
@@ -1556,7 +1597,9 @@ extern "C" int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hi
   // cone metadata (shared) + per-problem classification
   const ConeTable& C = b->cones;
   std::vector<uint32_t> meta((size_t)m, 0u);
-  std::vector<int> soc_off, soc_dim, psd_off, psd_d, psd_kind;
+  std::vector<int> soc_off, soc_dim, psd_off, psd_d, psd_kind, mid_off, mid_d, mid_kind, mid_ld, mid_ncp;
+  std::vector<long long> mid_goff;
+  long long gtot = 0;
   long long boxp = 0;
   for (size_t k = 0; k < C.type.size(); ++k) {
     const long long o = C.off[k], d = C.dim[k];
@@ -1567,7 +1610,15 @@ extern "C" int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hi
         if (d == 1) { meta[o] = 2u; break; }                        // the 1-D case is max(x, 0) (convexset.jl:303-305, 404-405)
         { long long sd = 0;
           if (C.type[k] == COSMO_HIP_PSD_SQUARE) { while ((sd + 1) * (sd + 1) <= d) ++sd; } else { while ((sd + 1) * (sd + 2) / 2 <= d) ++sd; }
-          psd_off.push_back((int)o); psd_d.push_back((int)sd); psd_kind.push_back((int)C.type[k]); }
+          if (sd <= 16) { psd_off.push_back((int)o); psd_d.push_back((int)sd); psd_kind.push_back((int)C.type[k]); }
+          else {                                                    // geometry as psd.hip: psd_plan_create
+            int ld = (((int)sd + 15) / 16) * 16, nb = ((int)sd + 7) / 8;
+            if (nb & 1) nb += 1;
+            int ncp = nb * 8;
+            if (ncp < ld) ncp = ld;
+            mid_off.push_back((int)o); mid_d.push_back((int)sd); mid_kind.push_back((int)C.type[k]); mid_ld.push_back(ld); mid_ncp.push_back(ncp);
+            mid_goff.push_back(gtot); gtot += (long long)ld * ncp;
+          } }
         break;
       case COSMO_HIP_BOX: for (long long i = 0; i < d; ++i) meta[o + i] = 3u | ((uint32_t)(boxp + i) << 2); boxp += d; break;
       case COSMO_HIP_SOC: soc_off.push_back((int)o); soc_dim.push_back((int)d); break;
@@ -1607,6 +1658,11 @@ extern "C" int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hi
   D.npsd = (int)psd_off.size();
   if ((rc = bup(b, &D.psd_off, psd_off)) || (rc = bup(b, &D.psd_d, psd_d)) || (rc = bup(b, &D.psd_kind, psd_kind))) return rc;
   if (!b->d_img) D.psd_nws = COSMO_BS / 64;                    // streaming kernel: static workspaces for all of its four waves
+  D.nmid = (int)mid_off.size();
+  if ((rc = bup(b, &D.mid_off, mid_off)) || (rc = bup(b, &D.mid_d, mid_d)) || (rc = bup(b, &D.mid_kind, mid_kind)) || (rc = bup(b, &D.mid_ld, mid_ld)) ||
+      (rc = bup(b, &D.mid_ncp, mid_ncp)) || (rc = bup(b, &D.mid_goff, mid_goff))) return rc;
+  D.psdG_stride = gtot; D.psdG = nullptr;
+  if (gtot > 0 && (rc = balloc(b, &D.psdG, (size_t)gtot * nprob))) return rc;
   std::vector<int> cls32(b->cls_host.begin(), b->cls_host.end());
   if ((rc = bup(b, &D.rho_cls, cls32))) return rc;
   const size_t NM = (size_t)nprob * (n + m), Nn = (size_t)nprob * n, Nm = (size_t)nprob * m;

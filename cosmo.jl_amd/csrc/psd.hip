@@ -24,26 +24,7 @@
 
 #include "psd_internal.h"
 #include "psd16.h"
-
-// Does any pair of the panel need a rotation?  cross_only: test the 64 entries (p < 8 <= q), one per lane; otherwise all
-// 120 pairs (two per lane).  Wave-uniform result; lets converged block pairs skip the Jacobi sweep and the panel update.
-__device__ __forceinline__ int gram_needs_work(const real* W, real tol, real tiny, int cross_only, int lane) {
-  int need = 0;
-  if (cross_only) {
-    const int p = lane & 7, q = 8 + (lane >> 3);
-    const real app = W[p * WLD + p], aqq = W[q * WLD + q], apq = W[p * WLD + q];
-    need = (app > tiny) && (aqq > tiny) && (apq * apq > (tol * tol) * (app * aqq));
-  } else {
-    for (int e = lane; e < 120; e += 64) {
-      int p = 0, rem = e;
-      while (rem >= 15 - p) { rem -= 15 - p; ++p; }
-      const int q = p + 1 + rem;
-      const real app = W[p * WLD + p], aqq = W[q * WLD + q], apq = W[p * WLD + q];
-      need |= (app > tiny) && (aqq > tiny) && (apq * apq > (tol * tol) * (app * aqq));
-    }
-  }
-  return __any(need) ? 1 : 0;
-}
+#include "psdwg.h"
 
 // ---------------------------------------------------------------------------------------------------------------------
 // d <= 16: one wave per cone, two-sided Jacobi directly on X (psd16.h: the same routine the batch kernels call)
@@ -120,80 +101,6 @@ __global__ __launch_bounds__(COSMO_BS) void k_psd_populate(const Ctl* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// block-pair step pieces (wave level).  cols[0..15] = global column indices of the 16 panel columns.
-// ---------------------------------------------------------------------------------------------------------------------
-// Gram matrix of a row range of the panel: W = P(r0:r1, :)' P(r0:r1, :), r0, r1 multiples of 16.
-// Lane l loads rows 16 ch + 4 (l >> 4) .. +3 of column cols(l & 15) as one 32-byte vector; the k-slot permutation this
-// implies is the same for both MFMA operands, so the sum is unchanged.
-__device__ __forceinline__ v4d panel_gram(const real* __restrict__ g, int ld, int colL, int r0, int r1, int lane) {
-  v4d acc = {0.0, 0.0, 0.0, 0.0};
-  const real* cp = g + (long long)colL * ld + 4 * (lane >> 4);
-  int r = r0;
-  for (; r + 64 <= r1; r += 64) {                      // four 16-row chunks in flight
-    v4d v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const v4d*>(cp + r + 16 * u);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      acc = MFMA_REAL(v[u].x, v[u].x, acc);
-      acc = MFMA_REAL(v[u].y, v[u].y, acc);
-      acc = MFMA_REAL(v[u].z, v[u].z, acc);
-      acc = MFMA_REAL(v[u].w, v[u].w, acc);
-    }
-  }
-  for (; r < r1; r += 16) {
-    const v4d v = *reinterpret_cast<const v4d*>(cp + r);
-    acc = MFMA_REAL(v.x, v.x, acc);
-    acc = MFMA_REAL(v.y, v.y, acc);
-    acc = MFMA_REAL(v.z, v.z, acc);
-    acc = MFMA_REAL(v.w, v.w, acc);
-  }
-  return acc;
-}
-
-// Panel update P(r0:r1, :) <- P(r0:r1, :) J, computed as (J' P')' so that every lane stores 16 consecutive rows of one
-// column.  jt[t] = J[(lane >> 4) + 4 t][lane & 15] (the C layout) is exactly the A operand of step t.
-__device__ __forceinline__ void panel_update(real* __restrict__ g, int ld, const int* cols, const real jt[4], int r0, int r1,
-                                             int lane) {
-  const int rr = lane & 15, kg = lane >> 4;
-  real* src[4];
-  real* dst[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    src[t] = g + (long long)cols[4 * t + kg] * ld + rr;   // B operand of step t: P[r + rr][4 t + kg]
-    dst[t] = g + (long long)cols[ACC_ROW(lane, t)] * ld + rr;   // D reg t: new column ACC_ROW(lane, t) (kg + 4 t in fp64), row r + rr
-  }
-  int r = r0;
-  for (; r + 32 <= r1; r += 32) {                      // two chunks in flight (all loads of both chunks precede the stores)
-    real b0[4], b1[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) { b0[t] = src[t][r]; b1[t] = src[t][r + 16]; }
-    v4d a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int t = 0; t < 4; ++t) { a0 = MFMA_REAL(jt[t], b0[t], a0); a1 = MFMA_REAL(jt[t], b1[t], a1); }
-    dst[0][r] = a0.x; dst[1][r] = a0.y; dst[2][r] = a0.z; dst[3][r] = a0.w;
-    dst[0][r + 16] = a1.x; dst[1][r + 16] = a1.y; dst[2][r + 16] = a1.z; dst[3][r + 16] = a1.w;
-  }
-  for (; r < r1; r += 16) {
-    real b[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) b[t] = src[t][r];
-    v4d acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc = MFMA_REAL(jt[t], b[t], acc);
-    dst[0][r] = acc.x; dst[1][r] = acc.y; dst[2][r] = acc.z; dst[3][r] = acc.w;
-  }
-}
-
-// round-robin tournament: block pair w (0 <= w < nb/2) of step st (0 <= st < nb-1), nb even
-__device__ __forceinline__ void rr_pair(int nb, int st, int w, int& I, int& J) {
-  const int m = nb - 1;
-  if (w == 0) { I = st % m; J = m; }
-  else { I = (st + w) % m; J = (st - w + m) % m; }
-  if (I > J) { const int t = I; I = J; J = t; }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // 16 < d <= 256: whole Jacobi process of one cone in one workgroup (nb/2 <= 16 waves)
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NW>
@@ -201,66 +108,11 @@ __global__ __launch_bounds__(NW * 64) void k_psd_jacobi_wg(const Ctl* __restrict
                                                            const PsdConeDev* __restrict__ cones, real* __restrict__ G,
                                                            const real* __restrict__ cshift, int* __restrict__ flags, real tolf, int dbg) {
   if (guard && ctl->halt) return;
-  __shared__ real Ws[NW][16 * WLD];
-  __shared__ real Js[NW][16 * WLD];
-  __shared__ real cas[NW][16], cbs[NW][16];
-  __shared__ int parts[NW][16];
-  __shared__ int colss[NW][16];
+  __shared__ __attribute__((aligned(16))) unsigned char wsb[NW * PSDWG_WS_STRIDE];
   __shared__ int any_rot;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int ci = list[blockIdx.x];
   const PsdConeDev cn = cones[ci];
-  real* g = G + cn.goff;
-  const int nb = cn.nb, npairs = nb / 2;
-  const real c = cshift[ci];
-  const real tol = tolf * (real)cn.d * PSD_EPS;
-  const real tiny = (tol * c) * (tol * c);
-  real* W = Ws[wv]; real* J = Js[wv];
-  int sweep = 0;
-  // one visit of block pair (I, Jb): Gram on MFMA, Jacobi on the 16x16 Gram matrix, panel update on MFMA
-  auto visit = [&](int I, int Jb, int full) {
-    if (lane < 16) colss[wv][lane] = (lane < 8) ? (I * 8 + lane) : (Jb * 8 + lane - 8);
-    wave_lds_fence();
-    const int colL = colss[wv][lane & 15];
-    v4d w = {1.0, 0.5, 0.25, 0.125};
-    if (!(dbg & 4)) w = panel_gram(g, cn.ld, colL, 0, cn.ld, lane);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = ACC_ROW(lane, r), j = lane & 15;
-      W[i * WLD + j] = w[r];
-      J[i * WLD + j] = (i == j) ? 1.0 : 0.0;
-    }
-    wave_lds_fence();
-    if (!(dbg & 8) && !gram_needs_work(W, tol, tiny, !full, lane)) return;
-    int rot = 1;
-    if (!(dbg & 1)) rot = jacobi16_sweep(W, J, parts[wv], cas[wv], cbs[wv], tol, tiny, 0, full ? 15 : 8, lane);
-    if (dbg & 2) rot = 0;
-    if (dbg & 16) { if (lane == 0 && sweep < 10) any_rot = 1; }
-    if (rot) {
-      real jt[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) jt[t] = J[((lane >> 4) + 4 * t) * WLD + (lane & 15)];
-      panel_update(g, cn.ld, colss[wv], jt, 0, cn.ld, lane);
-      if (lane == 0) any_rot = 1;
-    }
-  };
-  for (; sweep < PSD_MAX_SWEEPS; ++sweep) {
-    if (threadIdx.x == 0) any_rot = 0;
-    __syncthreads();
-    // diagonal pass: all pairs inside blocks (2w, 2w+1); the tournament steps then only rotate cross pairs
-    if (wv < npairs) visit(2 * wv, 2 * wv + 1, 1);
-    __syncthreads();
-    for (int st = 0; st < nb - 1; ++st) {
-      if (wv < npairs) {
-        int I, Jb;
-        rr_pair(nb, st, wv, I, Jb);
-        visit(I, Jb, 0);
-      }
-      __syncthreads();
-    }
-    if (!any_rot) break;
-    __syncthreads();
-  }
+  const int sweep = psdwg_jacobi<NW>(G + cn.goff, cn.ld, cn.nb, cn.d, cshift[ci], tolf, dbg, wsb, &any_rot);      // psdwg.h (shared with the batch kernels)
   if (threadIdx.x == 0) {
     atomicMax(&flags[2], sweep + 1);
     if (sweep >= PSD_MAX_SWEEPS) atomicOr(&flags[1], 1);

@@ -399,7 +399,9 @@ const char* cosmo_hip_batch_last_error(const cosmo_hip_batch* b);
 int32_t cosmo_hip_batch_set_problem(cosmo_hip_batch* b, int64_t k, const int64_t* P_colptr, const int64_t* P_rowval,
                                     const cosmo_hip_real* P_nzval, const int64_t* A_colptr, const int64_t* A_rowval,
                                     const cosmo_hip_real* A_nzval, const cosmo_hip_real* q, const cosmo_hip_real* bvec);
-/* cone structure shared by all problems; box_l / box_u hold nprob * (#Box rows) entries, problem-major */
+/* cone structure shared by all problems; box_l / box_u hold nprob * (#Box rows) entries, problem-major.  Cone kinds of batch mode: ZeroSet,
+ * Nonnegatives, Box, SecondOrderCone, PsdCone / PsdConeTriangle of side <= 64 (src/convexset.jl:25-28, 71-74, 100-114, 303-321, 402-412, 844-847);
+ * anything else returns COSMO_HIP_ERR_UNSUPPORTED (one handle per problem serves it) */
 int32_t cosmo_hip_batch_set_cones(cosmo_hip_batch* b, int64_t ncones, const int32_t* type, const int64_t* dim,
                                   const cosmo_hip_real* box_l, const cosmo_hip_real* box_u);
 int32_t cosmo_hip_batch_set_scaling(cosmo_hip_batch* b, int64_t k, const cosmo_hip_real* Dinv, const cosmo_hip_real* Einv, double cinv);
