@@ -257,8 +257,8 @@ def test_rccl_two_ranks_on_one_device_is_refused_or_identical(monkeypatch):
                 assert np.array_equal(z[key].view(np.int64), val.view(np.int64)), (r, key)
 
 
-@pytest.mark.parametrize("mode", ["rows", "cones"])
-def test_sharded_runs_with_the_reference_default_accelerator(mode, monkeypatch):
+@pytest.mark.parametrize("mode,world", [("rows", 2), ("rows", 3), ("cones", 2)])
+def test_sharded_runs_with_the_reference_default_accelerator(mode, world, monkeypatch):
     """Anderson acceleration (the reference's default, src/settings.jl:136-138; src/accelerator_interface.jl:58-116) in sharded runs, two ranks.
     rows:  w = [x ; the rank's rows]: the accelerator's inner products are all-reduced partial sums (csrc/anderson.hip) -- the ranks agree with each
            other bit for bit (same R, eta, success and safeguarding decisions), and with the single-rank accelerated run within the f2 tolerances
@@ -278,15 +278,16 @@ def test_sharded_runs_with_the_reference_default_accelerator(mode, monkeypatch):
         keep = ITERS
         ITERS = 3000
         try:
-            outs = _spawn("shm", 2, "/cosmo_test_" + uuid.uuid4().hex[:12], tmp, timeout=400, extra_env={"COSMO_TEST_SHARD": mode, "COSMO_TEST_ACCEL": "1"})
+            outs = _spawn("shm", world, "/cosmo_test_" + uuid.uuid4().hex[:12], tmp, timeout=400, extra_env={"COSMO_TEST_SHARD": mode, "COSMO_TEST_ACCEL": "1"})
         finally:
             ITERS = keep
         for rc, o in outs:
             assert rc == 0, o[-3000:]
-        z = [np.load(os.path.join(tmp, "rank%d.npz" % r)) for r in range(2)]
-    for key in ("x", "s", "y"):
-        assert np.array_equal(z[0][key].view(np.int64), z[1][key].view(np.int64)), key                     # the ranks agree bit for bit
-    assert int(z[0]["iter"]) == int(z[1]["iter"]) and int(z[0]["accelerated"]) == int(z[1]["accelerated"]) > 0 and int(z[0]["declined"]) == int(z[1]["declined"])
+        z = [np.load(os.path.join(tmp, "rank%d.npz" % r)) for r in range(world)]
+    for r in range(1, world):
+        for key in ("x", "s", "y"):
+            assert np.array_equal(z[0][key].view(np.int64), z[r][key].view(np.int64)), (r, key)           # the ranks agree bit for bit
+        assert int(z[0]["iter"]) == int(z[r]["iter"]) and int(z[0]["accelerated"]) == int(z[r]["accelerated"]) > 0 and int(z[0]["declined"]) == int(z[r]["declined"])
     assert str(z[0]["status"]) == ref.status
     if mode == "cones":
         assert int(z[0]["iter"]) == ref.iter and int(z[0]["accelerated"]) == racc["accelerated"]
