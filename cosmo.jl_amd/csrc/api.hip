@@ -490,7 +490,8 @@ void free_op_split(cosmo_hip_handle* h) {
 int32_t build_op_split(cosmo_hip_handle* h, bool force) {
   free_op_split(h);
   if (const char* e = getenv("COSMO_HIP_OP_SPLIT")) if (e[0] == '0' && !force) return COSMO_HIP_OK;
-  if (h->prm.kkt_kind != COSMO_HIP_KKT_CG) return COSMO_HIP_OK;
+  // CG always; the reduced MINRES only when a row-sharded handle needs an operator that does not depend on the local slices (force)
+  if (h->prm.kkt_kind != COSMO_HIP_KKT_CG && !(force && h->prm.kkt_kind == COSMO_HIP_KKT_MINRES_REDUCED)) return COSMO_HIP_OK;
   const long long n = h->n, m = h->m, nnzA = h->A.nnz, nnzP = h->P.nnz;
   if (m == 0 || nnzA == 0) return COSMO_HIP_OK;
   std::vector<int> arp((size_t)m + 1), acol((size_t)nnzA), prp((size_t)n + 1), pcol((size_t)std::max<long long>(nnzP, 1));

@@ -1032,12 +1032,20 @@ int32_t launch_cg_dir_check(cosmo_hip_handle* h, int guard, int kk, int n_rr) {
 
 // launch helpers used by minres.hip (keeps every kernel launch next to its definition)
 int32_t launch_spmv_A_rho(cosmo_hip_handle* h, int guard, int mode, const real* v, real* out) {
-  hipLaunchKernelGGL(k_spmv_A_rho, dim3(h->A.grid > 0 ? h->A.grid : 1), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, mode, view_of(h->A), v,
-                     h->rho, out);
+  // row-sharded handle: the replicated reduced operator (Am = the multi-nonzero rows of the WHOLE A with their rho; the singleton rows are the
+  // diagonal the caller adds), not the rank's row slice
+  const CsrDev& Ao = h->row_shard ? h->Am : h->A;
+  hipLaunchKernelGGL(k_spmv_A_rho, dim3(Ao.grid > 0 ? Ao.grid : 1), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, mode, view_of(Ao), v,
+                     h->row_shard ? h->op_rho_m : h->rho, out);
   HIPCHK(h, hipGetLastError());
   return COSMO_HIP_OK;
 }
 int32_t launch_reduced_rhs(cosmo_hip_handle* h, int guard, real* out_rhs) {
+  if (h->row_shard) {                      // rhs = allreduce_sum(A_g' y2_g) + ls_x, as the CG path forms it (rs_enqueue_cg_rhs), then handed to the caller's buffer
+    CHK(rs_enqueue_cg_rhs(h, guard));
+    HIPCHK(h, hipMemcpyAsync(out_rhs, h->rhs, sizeof(real) * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
+    return COSMO_HIP_OK;
+  }
   hipLaunchKernelGGL(k_cg_rhs, dim3(h->AT.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, view_of(h->AT), h->y2, h->ls_x, out_rhs,
                      PARTS(h, SLOT_BB));
   HIPCHK(h, hipGetLastError());

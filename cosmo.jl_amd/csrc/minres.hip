@@ -46,7 +46,7 @@ __device__ __forceinline__ void givens(real f, real g, real& c, real& s, real& r
 __global__ __launch_bounds__(COSMO_BS) void k_mr_op_top(Ctl* __restrict__ ctl, int guard, int mode, int it, long long maxiter, CsrView PT, real sigma,
                                                         const real* __restrict__ v1, const real* __restrict__ v2,
                                                         const real* __restrict__ vprev, const real* __restrict__ b,
-                                                        real* __restrict__ vout, real* __restrict__ part) {
+                                                        real* __restrict__ vout, real* __restrict__ part, const real* __restrict__ diag) {
   if (guard && ctl->halt) return;
   if (ctl->cg_done) return;
   __shared__ real lds[COSMO_NNZ_PER_BLOCK];
@@ -66,6 +66,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_mr_op_top(Ctl* __restrict__ ctl, i
     csr_stream_tile(PT, v1, v2, k, lds, red, [&](int row, real s1, real s2) {
       const real vc = v1[row];
       real y = s1 + (sigma * vc + s2);
+      if (diag) y += diag[row] * vc;           // split operator (row-sharded handles): the singleton rows of A are the diagonal of A' rho A
       if (mode == 0) {
         const real r = b[row] - y;
         vout[row] = r;
@@ -293,11 +294,12 @@ static int32_t enqueue_mr_apply(cosmo_hip_handle* h, int guard, int mode, int it
   if (!full) {
     // tmp_m = rho .* (A v) ; out = [P | A'] [v; tmp_m] + sigma v
     CHK(launch_spmv_A_rho(h, guard, 1, v, h->tmp_m));
-    hipLaunchKernelGGL(k_mr_op_top, dim3(h->PT.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, mode, it, V.N, view_of(h->PT), h->prm.sigma, v,
-                       h->tmp_m, vprev, V.b, vout, MPARTS(h, SLOT_UC));
+    const CsrDev& PTo = h->row_shard ? h->PTm : h->PT;
+    hipLaunchKernelGGL(k_mr_op_top, dim3(PTo.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, mode, it, V.N, view_of(PTo), h->prm.sigma, v,
+                       h->tmp_m, vprev, V.b, vout, MPARTS(h, SLOT_UC), (const real*)(h->row_shard ? h->op_diag : nullptr));
   } else {
     hipLaunchKernelGGL(k_mr_op_top, dim3(h->PT.grid), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, mode, it, V.N, view_of(h->PT), h->prm.sigma, v,
-                       v + n, vprev, V.b, vout, MPARTS(h, SLOT_UC));
+                       v + n, vprev, V.b, vout, MPARTS(h, SLOT_UC), (const real*)nullptr);
     hipLaunchKernelGGL(k_mr_op_bot, dim3(h->A.grid > 0 ? h->A.grid : 1), dim3(COSMO_BS), 0, h->stream, h->ctl, guard, mode, it, view_of(h->A), n,
                        v, v + n, h->rho, vprev, V.b, vout, MPARTS(h, SLOT_UC) + h->PT.grid);
   }
@@ -308,6 +310,7 @@ static int32_t enqueue_mr_apply(cosmo_hip_handle* h, int guard, int mode, int it
 }
 
 static int npart_apply(const cosmo_hip_handle* h) {
+  if (h->row_shard) return h->PTm.grid;                  // reduced MINRES on the split operator
   return h->PT.grid + ((h->prm.kkt_kind == COSMO_HIP_KKT_MINRES) ? (h->A.grid > 0 ? h->A.grid : 1) : 0);
 }
 

@@ -72,7 +72,9 @@ extern "C" int32_t cosmo_hip_set_row_shard(cosmo_hip_handle* h, const int64_t* f
   if (hipSetDevice(h->device) != hipSuccess) return cosmo_fail(h, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
   if (!h->have_params) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_row_shard: set_params first (the reduced operator is built from the whole A)");
   if (h->row_shard) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_row_shard: already row-sharded");
-  if (h->prm.kkt_kind != COSMO_HIP_KKT_CG) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "set_row_shard: the reduced CG solvers only (kkt_kind CG / CG_SR)");
+  if (h->prm.kkt_kind != COSMO_HIP_KKT_CG && h->prm.kkt_kind != COSMO_HIP_KKT_MINRES_REDUCED)
+    return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "set_row_shard: the solvers of the REDUCED system only (kkt_kind CG / CG_SR / CG_JACOBI / MINRES_REDUCED); "
+                      "MINRES on the full KKT system would need an all-reduce per operator application");
   cosmo_hip_accel_params accel_prm;
   const bool had_accel = aa_get_params(h, &accel_prm);      // the accelerator's history lives on w = [x ; rows]: re-created below on the local layout
   if (had_accel) aa_free(h);

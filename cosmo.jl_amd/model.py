@@ -718,7 +718,7 @@ def optimize(model: Model, dist=None, shard: str = "rows") -> Result:
     setup(model)
     if dist is not None and dist.get_world_size() > 1 and fresh:
         kkt = model.settings.kkt_solver.solver if isinstance(model.settings.kkt_solver, OptionsFactory) else model.settings.kkt_solver
-        rows_ok = kkt in (CGIndirectKKTSolver, CGSingleReductionKKTSolver, CGJacobiKKTSolver)
+        rows_ok = kkt in (CGIndirectKKTSolver, CGSingleReductionKKTSolver, CGJacobiKKTSolver, IndirectReducedKKTSolverMINRES)
         if shard == "rows" and rows_ok:
             setup_row_sharding(model, dist)
         else:

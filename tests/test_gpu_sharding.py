@@ -346,6 +346,28 @@ def test_row_sharded_run_with_a_user_defined_cone():
     np.testing.assert_allclose(z[0]["x"][:3], [3.0, 2.0, 2.0], atol=1e-3)
 
 
+def test_row_sharded_run_with_the_reduced_minres_solver(monkeypatch):
+    """IndirectReducedKKTSolver with solver_type = :MINRES (src/linear_solver/kktsolver_indirect.jl:3-88) on a row-sharded handle: MINRES runs
+    replicated on the split reduced operator (the multi-nonzero rows of the WHOLE A + the diagonal of the singleton rows), the right-hand side comes
+    from the all-reduce the CG path uses.  60 tight iterations: ranks bit-identical, 1e-7 against the single-rank MINRES run (whose operator is the
+    unsplit one: a re-association)."""
+    monkeypatch.setenv("COSMO_TEST_KKT", "minres_reduced")
+    monkeypatch.setenv("COSMO_HIP_POLAR_KLIFT", "10")
+    W = _worker_module()
+    p = W.problem()
+    md = cj.Model(); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], W.settings(ITERS))
+    ref = cj.optimize(md)
+    with tempfile.TemporaryDirectory() as tmp:
+        outs = _spawn("shm", 2, "/cosmo_test_" + uuid.uuid4().hex[:12], tmp, extra_env={"COSMO_TEST_SHARD": "rows", "COSMO_TEST_KKT": "minres_reduced"})
+        for rc, o in outs:
+            assert rc == 0, o[-3000:]
+        z = [np.load(os.path.join(tmp, "rank%d.npz" % r)) for r in range(2)]
+    assert int(z[0]["iter"]) == int(z[1]["iter"]) == ref.iter == ITERS and str(z[0]["mode"]) == "rows"
+    for key, val in (("x", ref.x), ("s", ref.s), ("y", ref.y)):
+        assert np.array_equal(z[0][key].view(np.int64), z[1][key].view(np.int64)), key
+        assert np.max(np.abs(z[0][key] - val)) <= 1e-7 * max(1.0, float(np.max(np.abs(val)))), key
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
