@@ -368,7 +368,7 @@ def bench_cfg3(ctx, args, steps, warmup):
     rank_seconds = ctx.rank_seconds()
     parity = None
     kry_every = ctx.all_gather((kk1 - kk0).astype(np.float64)) if ctx.world > 1 else None
-    if ctx.world > 1:
+    if ctx.world > 1 and os.environ.get("COSMO_BENCH_PARITY", "1") != "0":
         # parity evidence inside the N > 1 line: a sample of problems FROM EVERY RANK's shard (its first `per`), iterates after warmup + steps
         # iterations, against ONE single-rank batch of exactly those problems run by rank 0 with the same call sequence.  The problems of a batch are
         # independent (src/solver.jl:140-165 per problem, no exchange), so the expected deviation is 0 (bit-identical).
@@ -694,7 +694,7 @@ def bench_cfg5(ctx, args, steps, warmup):
     out = dict(value=value, ms_per_step=1e3 * elapsed / steps, steps=steps, warmup=warmup, scaling="strong")
     rank_seconds = ctx.rank_seconds()
     parity = None
-    if ctx.world > 1:
+    if ctx.world > 1 and os.environ.get("COSMO_BENCH_PARITY", "1") != "0":     # (COSMO_BENCH_PARITY=0: throughput only -- for bisecting a failing multi-GPU run)
         try:                                                               # a second communicator next to the timed handle's (both stay valid)
             parity = cfg5_sharded_parity_leg(ctx, args, prob)
         except Exception as e:
