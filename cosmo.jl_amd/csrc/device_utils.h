@@ -38,14 +38,42 @@ __device__ __forceinline__ int tile_of_block(int b, int nb, int affine) {
 }
 
 // Butterfly reductions: every lane ends with the same value, combination order is fixed => deterministic.
+// The four steps inside a row of 16 lanes are DPP moves (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror: lane i is
+// paired with a lane of the OTHER half of its 2-, 4-, 8-, 16-lane group, so both partners add the same two group sums and -- addition being
+// commutative -- hold the same bits, exactly as with an xor butterfly); only the steps across rows (xor 16, xor 32) go through the LDS
+// crossbar (ds_bpermute).  A __shfl_xor butterfly pays six crossbar round trips; the reductions sit on the critical path of every
+// latency-bound Krylov kernel and of the batch kernel's CG loop.
+template <int CTRL>
+__device__ __forceinline__ real dpp_move(real v) {
+#if REAL_IS_FLOAT
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+#else
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+#endif
+}
+#define DPP_QUAD_XOR1 0xB1
+#define DPP_QUAD_XOR2 0x4E
+#define DPP_ROW_HALF_MIRROR 0x141
+#define DPP_ROW_MIRROR 0x140
 __device__ __forceinline__ real wave_sum(real v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v += dpp_move<DPP_QUAD_XOR1>(v);
+  v += dpp_move<DPP_QUAD_XOR2>(v);
+  v += dpp_move<DPP_ROW_HALF_MIRROR>(v);
+  v += dpp_move<DPP_ROW_MIRROR>(v);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
   return v;
 }
 __device__ __forceinline__ real wave_max(real v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { real t = __shfl_xor(v, o, 64); v = (t > v) ? t : v; }
+  real t;
+  t = dpp_move<DPP_QUAD_XOR1>(v); v = (t > v) ? t : v;
+  t = dpp_move<DPP_QUAD_XOR2>(v); v = (t > v) ? t : v;
+  t = dpp_move<DPP_ROW_HALF_MIRROR>(v); v = (t > v) ? t : v;
+  t = dpp_move<DPP_ROW_MIRROR>(v); v = (t > v) ? t : v;
+  t = __shfl_xor(v, 16, 64); v = (t > v) ? t : v;
+  t = __shfl_xor(v, 32, 64); v = (t > v) ? t : v;
   return v;
 }
 
