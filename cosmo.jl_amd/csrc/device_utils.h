@@ -37,12 +37,12 @@ __device__ __forceinline__ int tile_of_block(int b, int nb, int affine) {
   return (affine && b < (per << 3)) ? (b & 7) * per + (b >> 3) : b;
 }
 
-// Butterfly reductions: every lane ends with the same value, combination order is fixed => deterministic.
-// The four steps inside a row of 16 lanes are DPP moves (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror: lane i is
-// paired with a lane of the OTHER half of its 2-, 4-, 8-, 16-lane group, so both partners add the same two group sums and -- addition being
-// commutative -- hold the same bits, exactly as with an xor butterfly); only the steps across rows (xor 16, xor 32) go through the LDS
-// crossbar (ds_bpermute).  A __shfl_xor butterfly pays six crossbar round trips; the reductions sit on the critical path of every
-// latency-bound Krylov kernel and of the batch kernel's CG loop.
+// Butterfly reductions (xor 32, 16, 8, 4, 2, 1): every lane ends with the same value, combination order is fixed => deterministic.
+// The two steps across rows of 16 lanes go through the LDS crossbar (ds_bpermute); the four steps inside a row are DPP moves with the SAME
+// partners as the xor butterfly: row_ror:8 reads lane i ^ 8; row_ror:4 reads lane (i + 4) mod 16, which after the xor-8 step holds the value
+// of lane i ^ 4 (the row is 8-periodic by then); quad_perm [2,3,0,1] and [1,0,3,2] are xor 2 and xor 1.  Same additions in the same order
+// as six __shfl_xor steps (bit-identical results) at a third of the crossbar round trips -- the reductions sit on the critical path of
+// every latency-bound Krylov kernel and of the batch kernel's CG loop.
 template <int CTRL>
 __device__ __forceinline__ real dpp_move(real v) {
 #if REAL_IS_FLOAT
@@ -53,27 +53,27 @@ __device__ __forceinline__ real dpp_move(real v) {
   return __hiloint2double(hi, lo);
 #endif
 }
-#define DPP_QUAD_XOR1 0xB1
+#define DPP_ROW_ROR8 0x128
+#define DPP_ROW_ROR4 0x124
 #define DPP_QUAD_XOR2 0x4E
-#define DPP_ROW_HALF_MIRROR 0x141
-#define DPP_ROW_MIRROR 0x140
+#define DPP_QUAD_XOR1 0xB1
 __device__ __forceinline__ real wave_sum(real v) {
-  v += dpp_move<DPP_QUAD_XOR1>(v);
-  v += dpp_move<DPP_QUAD_XOR2>(v);
-  v += dpp_move<DPP_ROW_HALF_MIRROR>(v);
-  v += dpp_move<DPP_ROW_MIRROR>(v);
-  v += __shfl_xor(v, 16, 64);
   v += __shfl_xor(v, 32, 64);
+  v += __shfl_xor(v, 16, 64);
+  v += dpp_move<DPP_ROW_ROR8>(v);
+  v += dpp_move<DPP_ROW_ROR4>(v);
+  v += dpp_move<DPP_QUAD_XOR2>(v);
+  v += dpp_move<DPP_QUAD_XOR1>(v);
   return v;
 }
 __device__ __forceinline__ real wave_max(real v) {
   real t;
-  t = dpp_move<DPP_QUAD_XOR1>(v); v = (t > v) ? t : v;
-  t = dpp_move<DPP_QUAD_XOR2>(v); v = (t > v) ? t : v;
-  t = dpp_move<DPP_ROW_HALF_MIRROR>(v); v = (t > v) ? t : v;
-  t = dpp_move<DPP_ROW_MIRROR>(v); v = (t > v) ? t : v;
-  t = __shfl_xor(v, 16, 64); v = (t > v) ? t : v;
   t = __shfl_xor(v, 32, 64); v = (t > v) ? t : v;
+  t = __shfl_xor(v, 16, 64); v = (t > v) ? t : v;
+  t = dpp_move<DPP_ROW_ROR8>(v); v = (t > v) ? t : v;
+  t = dpp_move<DPP_ROW_ROR4>(v); v = (t > v) ? t : v;
+  t = dpp_move<DPP_QUAD_XOR2>(v); v = (t > v) ? t : v;
+  t = dpp_move<DPP_QUAD_XOR1>(v); v = (t > v) ? t : v;
   return v;
 }
 
