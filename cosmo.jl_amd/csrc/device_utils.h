@@ -38,11 +38,13 @@ __device__ __forceinline__ int tile_of_block(int b, int nb, int affine) {
 }
 
 // Butterfly reductions (xor 32, 16, 8, 4, 2, 1): every lane ends with the same value, combination order is fixed => deterministic.
-// The two steps across rows of 16 lanes go through the LDS crossbar (ds_bpermute); the four steps inside a row are DPP moves with the SAME
-// partners as the xor butterfly: row_ror:8 reads lane i ^ 8; row_ror:4 reads lane (i + 4) mod 16, which after the xor-8 step holds the value
-// of lane i ^ 4 (the row is 8-periodic by then); quad_perm [2,3,0,1] and [1,0,3,2] are xor 2 and xor 1.  Same additions in the same order
-// as six __shfl_xor steps (bit-identical results) at a third of the crossbar round trips -- the reductions sit on the critical path of
-// every latency-bound Krylov kernel and of the batch kernel's CG loop.
+// No step goes through the LDS crossbar (ds_bpermute, what __shfl_xor compiles to): the steps across rows of 16 lanes use gfx950's
+// v_permlane32_swap / v_permlane16_swap (with both operands = v they leave {v[i], v[i ^ 32]} resp. {v[i], v[i ^ 16]} in the two result
+// registers of every lane -- in the upper half / the odd rows in the opposite order, which an addition does not see), the four steps inside
+// a row are DPP moves with the SAME partners as the xor butterfly: row_ror:8 reads lane i ^ 8; row_ror:4 reads lane (i + 4) mod 16, which
+// after the xor-8 step holds the value of lane i ^ 4 (the row is 8-periodic by then); quad_perm [2,3,0,1] and [1,0,3,2] are xor 2 and
+// xor 1.  Same additions in the same order as six __shfl_xor steps (bit-identical results: bench/wave_reduce_lab.hip) without the six
+// crossbar round trips -- the reductions sit on the critical path of every latency-bound Krylov kernel and of the batch kernel's CG loop.
 template <int CTRL>
 __device__ __forceinline__ real dpp_move(real v) {
 #if REAL_IS_FLOAT
@@ -53,13 +55,28 @@ __device__ __forceinline__ real dpp_move(real v) {
   return __hiloint2double(hi, lo);
 #endif
 }
+// a, b = {v[i], v[i ^ (ROWS16 ? 16 : 32)]} in some order
+template <bool ROWS16>
+__device__ __forceinline__ void permlane_pair(real v, real& a, real& b) {
+#if REAL_IS_FLOAT
+  const int w = __float_as_int(v);
+  const auto r = ROWS16 ? __builtin_amdgcn_permlane16_swap(w, w, false, false) : __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  a = __int_as_float((int)r[0]); b = __int_as_float((int)r[1]);
+#else
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const auto r = ROWS16 ? __builtin_amdgcn_permlane16_swap(lo, lo, false, false) : __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto q = ROWS16 ? __builtin_amdgcn_permlane16_swap(hi, hi, false, false) : __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  a = __hiloint2double((int)q[0], (int)r[0]); b = __hiloint2double((int)q[1], (int)r[1]);
+#endif
+}
 #define DPP_ROW_ROR8 0x128
 #define DPP_ROW_ROR4 0x124
 #define DPP_QUAD_XOR2 0x4E
 #define DPP_QUAD_XOR1 0xB1
 __device__ __forceinline__ real wave_sum(real v) {
-  v += __shfl_xor(v, 32, 64);
-  v += __shfl_xor(v, 16, 64);
+  real a, b;
+  permlane_pair<false>(v, a, b); v = a + b;
+  permlane_pair<true>(v, a, b); v = a + b;
   v += dpp_move<DPP_ROW_ROR8>(v);
   v += dpp_move<DPP_ROW_ROR4>(v);
   v += dpp_move<DPP_QUAD_XOR2>(v);
@@ -67,9 +84,9 @@ __device__ __forceinline__ real wave_sum(real v) {
   return v;
 }
 __device__ __forceinline__ real wave_max(real v) {
-  real t;
-  t = __shfl_xor(v, 32, 64); v = (t > v) ? t : v;
-  t = __shfl_xor(v, 16, 64); v = (t > v) ? t : v;
+  real a, b, t;
+  permlane_pair<false>(v, a, b); v = (b > a) ? b : a;
+  permlane_pair<true>(v, a, b); v = (b > a) ? b : a;
   t = dpp_move<DPP_ROW_ROR8>(v); v = (t > v) ? t : v;
   t = dpp_move<DPP_ROW_ROR4>(v); v = (t > v) ? t : v;
   t = dpp_move<DPP_QUAD_XOR2>(v); v = (t > v) ? t : v;
