@@ -45,6 +45,7 @@ __device__ __forceinline__ int tile_of_block(int b, int nb, int affine) {
 // after the xor-8 step holds the value of lane i ^ 4 (the row is 8-periodic by then); quad_perm [2,3,0,1] and [1,0,3,2] are xor 2 and
 // xor 1.  Same additions in the same order as six __shfl_xor steps (bit-identical results: bench/wave_reduce_lab.hip) without the six
 // crossbar round trips -- the reductions sit on the critical path of every latency-bound Krylov kernel and of the batch kernel's CG loop.
+// Callers keep all 64 lanes of the wave active (every call site is wave-uniform): a swap or DPP move out of an inactive lane is not a zero.
 template <int CTRL>
 __device__ __forceinline__ real dpp_move(real v) {
 #if REAL_IS_FLOAT
