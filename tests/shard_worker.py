@@ -38,6 +38,8 @@ def settings(iters, tight=False):
         kw["kkt_solver"] = cj.with_options(cj.CGIndirectKKTSolver, tol_constant=1e-10, tol_exponent=0.0)
     if os.environ.get("COSMO_TEST_KKT", "") == "minres_reduced":      # IndirectReducedKKTSolver with solver_type = :MINRES (kktsolver_indirect.jl:3-88), solved tightly
         kw["kkt_solver"] = cj.with_options(cj.IndirectReducedKKTSolverMINRES, tol_constant=1e-10, tol_exponent=0.0)
+    if os.environ.get("COSMO_TEST_KKT", "") == "cg_jacobi":           # the opt-in Jacobi-preconditioned CG (kkt_kind CG_JACOBI) on the assembled reduced operator
+        kw["kkt_solver"] = cj.with_options(cj.CGJacobiKKTSolver, tol_constant=1e-10, tol_exponent=0.0)
     return cj.Settings(**kw)
 
 

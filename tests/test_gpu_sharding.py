@@ -368,6 +368,28 @@ def test_row_sharded_run_with_the_reduced_minres_solver(monkeypatch):
         assert np.max(np.abs(z[0][key] - val)) <= 1e-7 * max(1.0, float(np.max(np.abs(val)))), key
 
 
+def test_row_sharded_run_with_the_jacobi_preconditioned_cg(monkeypatch):
+    """The opt-in Jacobi-preconditioned CG (kkt_kind CG_JACOBI, csrc/cg_fold.hip) on a row-sharded handle: the assembled operator, its diagonal and
+    the Krylov vectors are replicated, so the ranks stay bit-identical; against the single-rank run of the same solver 1e-7 after 60 tight iterations
+    (the sharded right-hand side is a sum of per-rank partial products: a re-association)."""
+    monkeypatch.setenv("COSMO_TEST_KKT", "cg_jacobi")
+    monkeypatch.setenv("COSMO_HIP_POLAR_KLIFT", "10")
+    W = _worker_module()
+    p = W.problem()
+    md = cj.Model(); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], W.settings(ITERS))
+    ref = cj.optimize(md)
+    with tempfile.TemporaryDirectory() as tmp:
+        outs = _spawn("shm", 2, "/cosmo_test_" + uuid.uuid4().hex[:12], tmp, extra_env={"COSMO_TEST_SHARD": "rows", "COSMO_TEST_KKT": "cg_jacobi"})
+        for rc, o in outs:
+            assert rc == 0, o[-3000:]
+        z = [np.load(os.path.join(tmp, "rank%d.npz" % r)) for r in range(2)]
+    assert int(z[0]["iter"]) == int(z[1]["iter"]) == ref.iter == ITERS and str(z[0]["mode"]) == "rows"
+    assert int(z[0]["kkt"]) == int(z[1]["kkt"]) and abs(int(z[0]["kkt"]) - ref.kkt_iters_total) <= 0.05 * ref.kkt_iters_total + 10
+    for key, val in (("x", ref.x), ("s", ref.s), ("y", ref.y)):
+        assert np.array_equal(z[0][key].view(np.int64), z[1][key].view(np.int64)), key
+        assert np.max(np.abs(z[0][key] - val)) <= 1e-7 * max(1.0, float(np.max(np.abs(val)))), key
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
