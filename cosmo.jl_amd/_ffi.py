@@ -126,6 +126,8 @@ SIGNATURES = {
     "cosmo_hip_batch_set_cones": (C.c_int32, [C.c_void_p, C.c_int64, _PI32, _PI64, _PR, _PR]),
     "cosmo_hip_batch_set_scaling": (C.c_int32, [C.c_void_p, C.c_int64, _PR, _PR, C.c_double]),
     "cosmo_hip_batch_set_params": (C.c_int32, [C.c_void_p, C.POINTER(Params)]),
+    "cosmo_hip_batch_set_accelerator": (C.c_int32, [C.c_void_p, C.POINTER(AccelParams)]),
+    "cosmo_hip_batch_get_accel_stats": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_batch_get_rho_classes": (C.c_int32, [C.c_void_p, C.c_int64, _PI32]),
     "cosmo_hip_batch_set_iterates": (C.c_int32, [C.c_void_p, _PR, _PR, _PR]),
     "cosmo_hip_batch_optimize": (C.c_int32, [C.c_void_p, C.POINTER(ResultStruct)]),
@@ -566,6 +568,23 @@ class Batch:
 
     def set_params(self, params):
         self._chk(self.lib.cosmo_hip_batch_set_params(self._b, C.byref(params)))
+
+    def set_accelerator(self, kind=ACCEL_ANDERSON, mem=15, min_mem=3, safeguard=True, safeguard_tol=2.0, start_iter=2, start_accuracy=None):
+        """`_make_accelerator!` (src/setup.jl:10-16) for every problem of the batch; before set_params.  mem <= 16 in batch mode."""
+        ap = AccelParams()
+        self.lib.cosmo_hip_default_accel_params(C.byref(ap))
+        ap.kind, ap.mem, ap.min_mem, ap.safeguard = int(kind), int(mem), int(min_mem), 1 if safeguard else 0
+        ap.safeguard_tol, ap.start_iter = float(safeguard_tol), int(start_iter)
+        if start_accuracy is not None:
+            ap.start_accuracy = float(start_accuracy)
+        self._chk(self.lib.cosmo_hip_batch_set_accelerator(self._b, C.byref(ap)))
+
+    def accel_stats(self):
+        """Per problem: dict of int64 arrays (accelerated, accepted, declined, restarts, active, safeguarding_iter)."""
+        out = np.zeros(6 * self.nprob, dtype=np.int64)
+        self._chk(self.lib.cosmo_hip_batch_get_accel_stats(self._b, out.ctypes.data_as(_PI64)))
+        keys = ("accelerated", "accepted", "declined", "restarts", "active", "safeguarding_iter")
+        return {k: out[i::6].copy() for i, k in enumerate(keys)}
 
     def get_rho_classes(self, k):
         out = np.empty(self.m, dtype=np.int32)

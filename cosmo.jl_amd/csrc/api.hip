@@ -195,7 +195,7 @@ static int32_t csc_to_csr_pair(cosmo_hip_handle* h, int64_t nr, int64_t nc, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-extern "C" int32_t cosmo_hip_version(void) { return 1000; }
+extern "C" int32_t cosmo_hip_version(void) { return 1001; }
 
 extern "C" void cosmo_hip_default_params(cosmo_hip_params* p) {
   if (!p) return;
@@ -1257,7 +1257,8 @@ extern "C" int32_t cosmo_hip_optimize(cosmo_hip_handle* h, cosmo_hip_result* res
   const auto t1 = std::chrono::steady_clock::now();
   const Ctl* c = h->ctl_host;
   res->status = status;
-  res->iter = (acc_iter >= 0) ? acc_iter : c->iter;
+  res->iter = (acc_iter >= 0) ? acc_iter + h->safeguarding_iter : c->iter;      // total_iter (src/solver.jl:196)
+  res->safeguarding_iter = (acc_iter >= 0) ? h->safeguarding_iter : 0;
   res->kkt_iters_total = c->kkt_iters_total;
   res->kkt_solves = c->solves;
   res->cost = (status == COSMO_HIP_PRIMAL_INFEASIBLE) ? (double)INFINITY : (status == COSMO_HIP_DUAL_INFEASIBLE) ? -(double)INFINITY : (double)c->cost;   // solver.jl:339,345

@@ -29,6 +29,18 @@ struct BCtl {                 // per problem, device resident
   real rho_updates[COSMO_HIP_MAX_RHO_UPDATES];
 };
 
+// Per-problem state of the Anderson accelerator (k_batch_admm*<..., AA = true>; csrc/anderson.hip is the single-problem form of the same
+// algorithm).  R: the mem x mem triangular factor, column-major with leading dimension BAA_MEM.
+#define BAA_MEM 16
+struct BAa {
+  int iter, init_phase, active, success;          // columns in memory; next update! only remembers (g, f); check_activation!; CA.was_successful
+  int inf_due, need_inf, rho_due, fail_singular;  // ws.infeasibility_check_due; "run the certificates for this problem now" (host); ws.rho_update_due
+  long long accelerated, accepted, declined, restarts, sg_iter;
+  real nrm_f;
+  real eta[BAA_MEM];
+  real R[BAA_MEM * BAA_MEM];
+};
+
 struct BMat { const int* rowptr; const int* col; const real* val; const int* split; const int* rb;   // concatenated over problems
               const long long* nz_off; const int* rb_off; const int* nb; int nrows; int split_col; };
 
@@ -48,6 +60,8 @@ struct BatchDev {
   real *ls_x, *x_tl, *rhs, *r, *u, *c;
   BCtl* ctl;
   real* inf_dy;                 // nprob * m: delta_y of the infeasibility certificates (captured between two launches)
+  // Anderson accelerator (0 = none): G, Q are nprob slabs of (n + m) x aa_mem (column-major), f / f_last / g_last nprob x (n + m)
+  int aa_mem; BAa* aa; real *aa_G, *aa_Q, *aa_f, *aa_fl, *aa_gl;
   const real* tol_table; long long tol_len;   // tol_constant / k^tol_exponent, k = 1.. (host libm, as the large path)
   // register kernel: COMPUTE assignment of the sparse passes inside the Krylov loop (see k_batch_admm_reg): thread t, slot j computes row
   // permA[k][j * 512 + t] of A (-1: none) and column permT[k][j * 512 + t] of [P | A'] -- rows / columns sorted by length, so that the
@@ -60,6 +74,10 @@ struct BParams {
   real sigma, alpha, eps_abs, eps_rel, rho_min, rho_max, rho_eq, adapt_tol, obj_true, obj_true_tol;
   long long max_iter, max_adaptions;
   int check_termination, adaptive_rho, adaptive_rho_interval, unscale;
+  // accelerated loop (AA kernels only)
+  long long check_inf, aa_start_iter;     // check_infeasibility (0: no certificates in this launch); IterActivation
+  int aa_min_mem, aa_safeguard;
+  real aa_tau, aa_eta_max, aa_start_acc;  // safeguard_tol; eta_max; AccuracyActivation (< 0: unused)
 };
 
 __device__ __forceinline__ CsrView bview(const BMat& M, int k) {
@@ -260,7 +278,10 @@ struct LdsOps {
 // PSD: the batch has PsdCone / PsdConeTriangle cones of side 2..16.  A template parameter, not a run-time test: the wave-level Jacobi of psd16.h
 // inlined into these kernels costs 55-60 VGPRs (the register kernel <512, 1, 2> went from 229 to 256 + spills), which batches without such
 // cones -- BASELINE config 3 -- must not pay.
-template <int BS, bool PSD, class Ops>
+// AA: the accelerated loop (src/solver.jl:140-165 with an AndersonAccelerator; csrc/anderson.hip + optimize_accelerated of api.hip are the
+// single-problem form).  Every inner product of the accelerator is a block sum of the workgroup, every decision (success of the least-squares
+// step, safeguarding, deferred rho update / infeasibility check) is taken by the workgroup for its problem.
+template <int BS, bool PSD, bool AA, class Ops>
 __device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams& P, long long iter_target, int do_init, Ops& ops, real* red) {
   const int k = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -366,13 +387,8 @@ __device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams
     __syncthreads();
   };
 
-  if (do_init) {                                                          // solver.jl:137-138
-    solve_and_update();
-  }
-  long long it = ctl->iter;
-  while (it < iter_target && it < P.max_iter) {
-    ++it;
-    // ---- admm_z!: w_prev = w ; s = Pi(w_s)  (solver.jl:151-152) ----
+  // ---- admm_z!: w_prev = w ; s = Pi(w_s)  (solver.jl:151-152) ----
+  auto admm_z = [&]() {
     for (int i = tid; i < n + m; i += BS) {
       const real v = w[i]; w_prev[i] = v;
       if (i >= n) s[i - n] = proj_simple(v, D.meta[i - n], bl, bu);
@@ -398,9 +414,140 @@ __device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams
         batch_project_psd_mid<BS>(D, k, s, ops.psd_ws, red, &any_rot_s);
       }
     }
-    // ---- apply_rho_adaptation_rules! (solver.jl:242-282, parameters.jl:53-92) ----
-    if (P.adaptive_rho && P.adaptive_rho_interval > 0 && (it % P.adaptive_rho_interval) == 0 &&
-        (long long)(ctl->n_rho_updates - 1) < P.max_adaptions) {
+  };
+
+  // ---- the accelerator's state: block-uniform registers, kept in D.aa[k] between launches ----
+  const int N = n + m;
+  BAa* const aa = AA ? D.aa + k : nullptr;
+  int aa_iter = 0, aa_init = 1, aa_active = 0, aa_success = 0, inf_due = 0, rho_due = 0, need_inf = 0;
+  long long n_acc = 0, n_ok = 0, n_decl = 0, n_rst = 0, sg = 0;
+  real aa_nrmf = 0.0;
+  real *aG = nullptr, *aQ = nullptr, *af = nullptr, *afl = nullptr, *agl = nullptr;
+  const int amem = AA ? D.aa_mem : 0;
+  if constexpr (AA) {
+    aa_iter = aa->iter; aa_init = aa->init_phase; aa_active = aa->active; aa_success = aa->success; inf_due = aa->inf_due; rho_due = aa->rho_due;
+    n_acc = aa->accelerated; n_ok = aa->accepted; n_decl = aa->declined; n_rst = aa->restarts; sg = aa->sg_iter; aa_nrmf = aa->nrm_f;
+    aG = D.aa_G + (long long)k * N * amem; aQ = D.aa_Q + (long long)k * N * amem;
+    af = D.aa_f + onm; afl = D.aa_fl + onm; agl = D.aa_gl + onm;
+  }
+  // acceleration_pre! (accelerator_interface.jl:58-76): check_activation!, CA.update!(w, w_prev), CA.accelerate!(w).  update!: f = x - g;
+  // G_j = g - g_last; v = f - f_last, modified Gram-Schmidt of v against Q_0..Q_{j-1} -> R[0..j, j], Q_j.  accelerate!: eta = R \ (Q' f);
+  // w -= G eta unless R is singular / not finite or ||eta||_2 > eta_max.  (g = w, x = w_prev.)
+  auto aa_pre = [&](long long it) {
+    aa_success = 0;
+    if (!aa_active && !(P.aa_start_acc >= R(0.0)) && it >= P.aa_start_iter) aa_active = 1;
+    if (!aa_active) return;
+    if (aa_init) {
+      for (int e = tid; e < N; e += BS) { const real gi = w[e]; const real fi = w_prev[e] - gi; af[e] = fi; agl[e] = gi; afl[e] = fi; }
+      aa_init = 0;
+    } else {
+      int j = aa_iter % amem;
+      if (j == 0 && aa_iter != 0) { aa_iter = 0; n_rst += 1; }           // RestartedMemory: every column is rewritten before it is read again
+      real* Gj = aG + (long long)j * N; real* v = aQ + (long long)j * N;
+      real acc = 0.0;
+      for (int e = tid; e < N; e += BS) {
+        const real gi = w[e]; const real fi = w_prev[e] - gi;
+        af[e] = fi; Gj[e] = gi - agl[e];
+        const real vi = fi - afl[e];
+        v[e] = vi; agl[e] = gi; afl[e] = fi;
+        acc += (j == 0) ? vi * vi : aQ[e] * vi;
+      }
+      real rv = bsum<BS>(acc, red);
+      for (int i = 0; i < j; ++i) {
+        const bool last = (i + 1 == j);
+        const real* Qi = aQ + (long long)i * N; const real* Qn = aQ + (long long)(last ? i : i + 1) * N;
+        const real r = rv;
+        if (tid == 0) aa->R[j * BAA_MEM + i] = r;
+        acc = 0.0;
+        for (int e = tid; e < N; e += BS) { const real vi = v[e] - r * Qi[e]; v[e] = vi; acc += last ? vi * vi : Qn[e] * vi; }
+        rv = bsum<BS>(acc, red);
+      }
+      const real nv = sqrt(rv);
+      if (tid == 0) aa->R[j * BAA_MEM + j] = nv;
+      for (int e = tid; e < N; e += BS) v[e] = v[e] / nv;
+      aa_iter += 1;
+    }
+    const int l = aa_iter < amem ? aa_iter : amem;
+    if (l < P.aa_min_mem) return;
+    real myrhs = 0.0;                                                     // lane c (of every wave) keeps (Q' f)[c]
+    for (int c = 0; c < l; ++c) {
+      const real* Qc = aQ + (long long)c * N;
+      real acc = 0.0;
+      for (int e = tid; e < N; e += BS) acc += Qc[e] * af[e];
+      const real r = bsum<BS>(acc, red);
+      if (lane == c) myrhs = r;
+    }
+    { real acc = 0.0;
+      for (int e = tid; e < N; e += BS) { const real fi = af[e]; acc += fi * fi; }
+      aa_nrmf = sqrt(bsum<BS>(acc, red)); }
+    __syncthreads();                                                      // R[., j] of thread 0 is visible to wave 0
+    if (wv == 0) {                                                        // back substitution on one wave: lane i owns row i of R
+      const bool mine = lane < l;
+      real row[BAA_MEM];
+      real diag = 1.0;
+      bool bad = false;
+#pragma unroll
+      for (int c = 0; c < BAA_MEM; ++c) {
+        const bool use = mine && c >= lane && c < l;
+        row[c] = use ? aa->R[c * BAA_MEM + lane] : R(0.0);
+        if (use && !(fabs(row[c]) <= REAL_MAX)) bad = true;
+        if (use && c == lane) diag = row[c];
+      }
+      if (mine && diag == R(0.0)) bad = true;
+      int ok = __any(bad ? 1 : 0) ? 0 : 1;
+      int singular = ok ? 0 : 1;
+      if (ok) {
+        real sacc = myrhs, nrm2 = 0.0;
+#pragma unroll
+        for (int c = BAA_MEM - 1; c >= 0; --c) {
+          if (c < l) {
+            const real e_c = __shfl(sacc / diag, c, 64);
+            nrm2 += e_c * e_c;
+            if (lane < c) sacc -= row[c] * e_c;
+            if (lane == 0) aa->eta[c] = e_c;
+          }
+        }
+        if (!(sqrt(nrm2) <= P.aa_eta_max)) ok = 0;                        // also catches NaN
+      }
+      if (lane == 0) { aa->success = ok; if (singular) aa->fail_singular += 1; }
+    }
+    __syncthreads();
+    aa_success = aa->success;
+    if (aa_success) {
+      real eta[BAA_MEM];
+#pragma unroll
+      for (int c = 0; c < BAA_MEM; ++c) eta[c] = (c < l) ? aa->eta[c] : R(0.0);
+      for (int e = tid; e < N; e += BS) {
+        real sacc = 0.0;
+#pragma unroll
+        for (int c = 0; c < BAA_MEM; ++c) if (c < l) sacc += aG[(long long)c * N + e] * eta[c];
+        w[e] = w[e] - sacc;
+      }
+    }
+    __syncthreads();
+  };
+
+  if (do_init) {                                                          // solver.jl:137-138
+    solve_and_update();
+  }
+  long long it = ctl->iter;
+  while (it < iter_target && it + sg < P.max_iter) {
+    ++it;
+    if constexpr (AA) {
+      aa_pre(it);
+      // delta_y of the certificates at the first non-accelerated iteration after a flagged one (solver.jl:145-148)
+      if (inf_due && !aa_success) { for (int i = tid; i < m; i += BS) D.inf_dy[om + i] = rho[i] * (w_prev[n + i] - s[i]); }
+    }
+    admm_z();
+    // ---- apply_rho_adaptation_rules! (solver.jl:242-282, parameters.jl:53-92); with an accelerator at the next non-accelerated iteration ----
+    bool do_rho = P.adaptive_rho && P.adaptive_rho_interval > 0 && (it % P.adaptive_rho_interval) == 0 &&
+                  (long long)(ctl->n_rho_updates - 1) < P.max_adaptions;
+    if constexpr (AA) {
+      if (do_rho) rho_due = 1;
+      do_rho = rho_due && !aa_success;
+      if (do_rho) rho_due = 0;
+    }
+    if (do_rho) {
       residuals(false);
       const real rpn = rp / (mp + R(1e-10)), rdn = rd / (md + R(1e-10));
       const real rho0 = ctl->rho;
@@ -421,10 +568,29 @@ __device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams
           if (ku < COSMO_HIP_MAX_RHO_UPDATES) ctl->rho_updates[ku] = nr;
           ctl->n_rho_updates = ku + 1;
         }
+        if constexpr (AA) { aa_iter = 0; aa_init = 1; }                   // CA.restart! (solver.jl:272-275): the operator changed
       }
       __syncthreads();
     }
     solve_and_update();
+    // ---- acceleration_post! (accelerator_interface.jl:85-116): safeguarding ----
+    if constexpr (AA) {
+      if (aa_active && aa_success) {
+        if (P.aa_safeguard) {
+          real acc = 0.0;
+          for (int e = tid; e < N; e += BS) { const real d = w_prev[e] - w[e]; af[e] = d; acc += d * d; }   // compute_accelerated_res_norm!
+          const real nrm_acc = sqrt(bsum<BS>(acc, red));
+          if (nrm_acc > aa_nrmf * P.aa_tau) {                             // declined: back to the last non-accelerated point, one plain ADMM step
+            for (int e = tid; e < N; e += BS) { const real g = agl[e]; w[e] = g; w_prev[e] = g; }
+            __syncthreads();
+            admm_z();
+            solve_and_update();
+            sg += 1; n_decl += 1;
+          } else n_ok += 1;
+        }
+        n_acc += 1;
+      }
+    }
     // ---- check_termination! (solver.jl:306-321) ----
     if ((it % P.check_termination) == 0 || it == 1) {
       residuals(P.unscale != 0);
@@ -432,25 +598,39 @@ __device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams
       if (fabs(cost) > R(1e20)) st = COSMO_HIP_UNSOLVED;
       else if (rp < P.eps_abs + P.eps_rel * mp && rd < P.eps_abs + P.eps_rel * md &&
                ((P.obj_true != P.obj_true) || fabs(P.obj_true - cost) <= P.obj_true_tol)) st = COSMO_HIP_SOLVED;   // has_converged (residuals.jl:131-139)
+      if constexpr (AA) {                                                 // check_activation!(ws, ::AccuracyActivation, r) (accelerator_interface.jl:38-46)
+        if (st == 0 && !aa_active && P.aa_start_acc >= R(0.0) &&
+            rp < P.aa_start_acc + P.aa_start_acc * mp && rd < P.aa_start_acc + P.aa_start_acc * md) aa_active = 1;
+      }
       if (tid == 0) { ctl->cost = cost; ctl->r_prim = rp; ctl->r_dual = rd; ctl->max_norm_prim = mp; ctl->max_norm_dual = md; ctl->status = st; }
       __syncthreads();
       if (st != 0) break;
     }
+    if constexpr (AA) {                                                   // solver.jl:326-349: the certificates wait for a non-accelerated iteration
+      if (P.check_inf > 0 && (it % P.check_inf) == 0) inf_due = 1;
+      else if (inf_due && !aa_success) { inf_due = 0; need_inf = 1; break; }   // the host runs k_batch_inf_check on this problem, then relaunches
+    }
   }
   if (tid == 0) ctl->iter = it;
-  // iter == max_iter: calculate_result_info! and Max_iter_reached, overriding a status decided in that iteration
+  // iter (+ safeguarding_iter) == max_iter: calculate_result_info! and Max_iter_reached, overriding a status decided in that iteration
   // (solver.jl:173-176, reference quirk kept)
-  if (it >= P.max_iter) {
+  if (it + sg >= P.max_iter) {
     __syncthreads();
     residuals(P.unscale != 0);
     if (tid == 0) { ctl->r_prim = rp; ctl->r_dual = rd; ctl->max_norm_prim = mp; ctl->max_norm_dual = md; ctl->status = COSMO_HIP_MAX_ITER_REACHED; }
+  }
+  if constexpr (AA) {
+    if (tid == 0) {
+      aa->iter = aa_iter; aa->init_phase = aa_init; aa->active = aa_active; aa->success = aa_success; aa->inf_due = inf_due; aa->rho_due = rho_due;
+      aa->need_inf = need_inf; aa->accelerated = n_acc; aa->accepted = n_ok; aa->declined = n_decl; aa->restarts = n_rst; aa->sg_iter = sg; aa->nrm_f = aa_nrmf;
+    }
   }
   // recover_mu! (solver.jl:167)
   __syncthreads();
   for (int i = tid; i < m; i += BS) mu[i] = rho[i] * (w_prev[n + i] - s[i]);
 }
 
-template <bool PSD>
+template <bool PSD, bool AA>
 __global__ __launch_bounds__(COSMO_BS) void k_batch_admm(BatchDev D, BParams P, long long iter_target, int do_init) {
   __shared__ real lds[COSMO_NNZ_PER_BLOCK];
   __shared__ real red[COSMO_BS / 64];
@@ -459,11 +639,11 @@ __global__ __launch_bounds__(COSMO_BS) void k_batch_admm(BatchDev D, BParams P, 
   if (D.ctl[k].status != 0) return;
   StreamOps ops;
   ops.A = bview(D.A, k); ops.AT = bview(D.AT, k); ops.PT = bview(D.PT, k); ops.lds = lds; ops.red = red; ops.psd_ws = psd_ws;
-  batch_admm_body<COSMO_BS, PSD>(D, P, iter_target, do_init, ops, red);
+  batch_admm_body<COSMO_BS, PSD, AA>(D, P, iter_target, do_init, ops, red);
 }
 
 // LDS-resident variant: `img` holds one image of `img_stride` bytes per problem (header + arrays, see build_lds_images)
-template <int BS, bool PSD>
+template <int BS, bool PSD, bool AA>
 __global__ __launch_bounds__(BS) void k_batch_admm_lds(BatchDev D, BParams P, long long iter_target, int do_init,
                                                        const unsigned char* __restrict__ img, long long img_stride) {
   extern __shared__ real dyn_lds[];
@@ -490,7 +670,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_lds(BatchDev D, BParams P, lo
   ops.xv = wsp; ops.tv = wsp + D.n; ops.red = wsp + D.n + D.m; ops.n = D.n;
   ops.psd_ws = base + ((img_stride + (long long)sizeof(real) * (D.n + D.m + BS / 64) + 15) / 16) * 16;     // behind the reduction slots (build_lds_images sizes it)
   __syncthreads();
-  batch_admm_body<BS, PSD>(D, P, iter_target, do_init, ops, ops.red);
+  batch_admm_body<BS, PSD, AA>(D, P, iter_target, do_init, ops, ops.red);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -971,7 +1151,8 @@ __global__ __launch_bounds__(COSMO_BS) void k_batch_inf_capture(BatchDev D) {
   for (int i = threadIdx.x; i < m; i += COSMO_BS) D.inf_dy[om + i] = D.rho[om + i] * (D.w_prev[onm + n + i] - D.s[om + i]);
 }
 
-__global__ __launch_bounds__(COSMO_BS) void k_batch_inf_check(BatchDev D, real epi, real edi) {
+// flagged_only (accelerated batches): only the problems whose workgroup left its launch for this test (BAa::need_inf), see batch_admm_body
+__global__ __launch_bounds__(COSMO_BS) void k_batch_inf_check(BatchDev D, real epi, real edi, int flagged_only) {
   __shared__ real lds[COSMO_NNZ_PER_BLOCK];
   __shared__ real red[COSMO_BS / 64];
   __shared__ int flag;
@@ -980,6 +1161,12 @@ __global__ __launch_bounds__(COSMO_BS) void k_batch_inf_check(BatchDev D, real e
   const int k = blockIdx.x;
   BCtl* ctl = D.ctl + k;
   if (ctl->status != 0) return;
+  if (flagged_only) {
+    const int need = D.aa[k].need_inf;
+    __syncthreads();
+    if (!need) return;
+    if (threadIdx.x == 0) D.aa[k].need_inf = 0;
+  }
   constexpr int BS = COSMO_BS;
   // PSD cones (side <= 16): is_pos_def!(sign * mat(v) + tol I) <=> lambda_min(sign * mat(v)) > -tol  (convexset.jl:415-424, algebra.jl:226-238),
   // the smallest eigenvalue from the same wave-level Jacobi as the projection (mode 1: v is only read)
@@ -1142,6 +1329,7 @@ struct cosmo_hip_batch {
   // LDS-resident variant (build_lds_images): one image per problem, dynamic LDS = image + gather vectors + reduction slots
   unsigned char* d_img = nullptr; long long img_stride = 0; int lds_bytes = 0; int lds_bs = 0;
   int reg_mode = 0;    // 0: LdsOps kernel, 1: register-resident <512,1,2>, 2: <512,2,4>
+  bool aa_on = false; cosmo_hip_accel_params aa_prm;      // cosmo_hip_batch_set_accelerator
   std::vector<int> h_permA, h_permT;          // compute assignment of the register kernel (build_lds_images), uploaded by set_params
   std::vector<int> h_posN, h_posM;            // positions of the gathered LDS vectors (build_lds_images)
 };
@@ -1346,12 +1534,13 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
     }
   int bs = 512;
   if (const char* eb = getenv("COSMO_HIP_BATCH_BS")) { const int v = atoi(eb); if (v == 256 || v == 512 || v == 1024) bs = v; }
-  if (npsd > 0) bs = 512;                                        // the PSD instantiation of the LDS-image kernel exists for 512 threads
+  if (npsd > 0 || b->aa_on) bs = 512;                            // the PSD / accelerated instantiations of the LDS-image kernel exist for 512 threads
   // register-resident iterates (k_batch_admm_reg, 512 threads) when the vectors fit 1-2 (n) / 2-4 (m) elements per thread
   b->reg_mode = 0;
   { const char* er = getenv("COSMO_HIP_BATCH_REG");
     if (!(er && atoi(er) == 0)) {
       if (n <= 512 && m <= 1024) b->reg_mode = 1; else if (n <= 1024 && m <= 2048) b->reg_mode = 2;
+      if (b->aa_on) b->reg_mode = 0;            // the accelerated loop lives in batch_admm_body (iterates in global memory / L2), not in the register kernel
       if (nmid > 0) b->reg_mode = 0;            // the block-Jacobi code on top of ~200 live registers would spill: the LDS-image kernel (187 VGPRs) takes such batches
       if (b->reg_mode) bs = 512;
     } }
@@ -1526,14 +1715,15 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
   b->D.psd_nws = nws;
   b->d_img = d; b->img_stride = stride; b->lds_bs = bs;
   b->lds_bytes = (int)(npsd > 0 ? ws_base + (long long)nws * PSD16_WS_STRIDE : stride + (long long)sizeof(real) * (n + m) + (long long)sizeof(real) * (bs / 64));
-  const void* fn = bs == 256 ? (const void*)k_batch_admm_lds<256, false> : (bs == 512 ? (const void*)k_batch_admm_lds<512, false> : (const void*)k_batch_admm_lds<1024, false>);
+  const void* fn = bs == 256 ? (const void*)k_batch_admm_lds<256, false, false> : (bs == 512 ? (const void*)k_batch_admm_lds<512, false, false> : (const void*)k_batch_admm_lds<1024, false, false>);
   if (b->reg_mode == 1) fn = (const void*)k_batch_admm_reg<512, 1, 2, false>;
   if (b->reg_mode == 2) fn = (const void*)k_batch_admm_reg<512, 2, 4, false>;
   if (npsd > 0) {
-    fn = (const void*)k_batch_admm_lds<512, true>;
+    fn = (const void*)k_batch_admm_lds<512, true, false>;
     if (b->reg_mode == 1) fn = (const void*)k_batch_admm_reg<512, 1, 2, true>;
     if (b->reg_mode == 2) fn = (const void*)k_batch_admm_reg<512, 2, 4, true>;
   }
+  if (b->aa_on) fn = (const void*)k_batch_admm_lds<512, true, true>;
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, b->lds_bytes) != hipSuccess) {
     (void)hipGetLastError();
     b->d_img = nullptr; b->reg_mode = 0;          // the device does not grant that much LDS: streaming kernel
@@ -1544,8 +1734,12 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
 static int32_t launch_batch_admm(cosmo_hip_batch* b, const BParams& P, long long target, int do_init) {
   const bool psd = b->D.npsd > 0;
 #define LAUNCH_REG(JN_, JM_, PSD_) hipLaunchKernelGGL((k_batch_admm_reg<512, JN_, JM_, PSD_>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride)
-#define LAUNCH_LDS(BS_, PSD_) hipLaunchKernelGGL((k_batch_admm_lds<BS_, PSD_>), dim3(b->nprob), dim3(BS_), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride)
-  if (b->d_img && b->reg_mode == 1) { if (psd) LAUNCH_REG(1, 2, true); else LAUNCH_REG(1, 2, false); }
+#define LAUNCH_LDS(BS_, PSD_) hipLaunchKernelGGL((k_batch_admm_lds<BS_, PSD_, false>), dim3(b->nprob), dim3(BS_), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride)
+  if (b->aa_on) {                    // accelerated loop: the LDS-image kernel (512 threads) or the streaming kernel, both with the PSD code (a run-time no-op without such cones)
+    if (b->d_img) hipLaunchKernelGGL((k_batch_admm_lds<512, true, true>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
+    else hipLaunchKernelGGL((k_batch_admm<true, true>), dim3(b->nprob), dim3(COSMO_BS), 0, b->stream, b->D, P, target, do_init);
+  }
+  else if (b->d_img && b->reg_mode == 1) { if (psd) LAUNCH_REG(1, 2, true); else LAUNCH_REG(1, 2, false); }
   else if (b->d_img && b->reg_mode == 2) { if (psd) LAUNCH_REG(2, 4, true); else LAUNCH_REG(2, 4, false); }
   else if (b->d_img) {
     if (psd) LAUNCH_LDS(512, true);                                  // (build_lds_images fixed 512 threads for batches with PSD cones)
@@ -1553,8 +1747,8 @@ static int32_t launch_batch_admm(cosmo_hip_batch* b, const BParams& P, long long
     else if (b->lds_bs == 512) LAUNCH_LDS(512, false);
     else LAUNCH_LDS(1024, false);
   } else {
-    if (psd) hipLaunchKernelGGL(k_batch_admm<true>, dim3(b->nprob), dim3(COSMO_BS), 0, b->stream, b->D, P, target, do_init);
-    else hipLaunchKernelGGL(k_batch_admm<false>, dim3(b->nprob), dim3(COSMO_BS), 0, b->stream, b->D, P, target, do_init);
+    if (psd) hipLaunchKernelGGL((k_batch_admm<true, false>), dim3(b->nprob), dim3(COSMO_BS), 0, b->stream, b->D, P, target, do_init);
+    else hipLaunchKernelGGL((k_batch_admm<false, false>), dim3(b->nprob), dim3(COSMO_BS), 0, b->stream, b->D, P, target, do_init);
   }
 #undef LAUNCH_REG
 #undef LAUNCH_LDS
@@ -1671,6 +1865,12 @@ extern "C" int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hi
       (rc = balloc(b, &D.nu, Nm)) || (rc = balloc(b, &D.rho, Nm)) || (rc = balloc(b, &D.ls_x, Nn)) || (rc = balloc(b, &D.x_tl, Nn)) ||
       (rc = balloc(b, &D.rhs, Nn)) || (rc = balloc(b, &D.r, Nn)) || (rc = balloc(b, &D.u, Nn)) || (rc = balloc(b, &D.c, Nn)) ||
       (rc = balloc(b, &D.inf_dy, Nm))) return rc;
+  D.aa_mem = 0; D.aa = nullptr; D.aa_G = D.aa_Q = D.aa_f = D.aa_fl = D.aa_gl = nullptr;
+  if (b->aa_on) {                                           // mem = min(mem, dim), as the single-problem accelerator
+    D.aa_mem = (int)std::min<long long>(b->aa_prm.mem, std::max<long long>(n + m, 1));
+    if ((rc = balloc(b, &D.aa, (size_t)nprob)) || (rc = balloc(b, &D.aa_G, NM * D.aa_mem)) || (rc = balloc(b, &D.aa_Q, NM * D.aa_mem)) ||
+        (rc = balloc(b, &D.aa_f, NM)) || (rc = balloc(b, &D.aa_fl, NM)) || (rc = balloc(b, &D.aa_gl, NM))) return rc;
+  }
   BHIP(b, hipMemcpy(D.rho, rho0.data(), Nm * sizeof(real), hipMemcpyHostToDevice));
   std::vector<BCtl> ctl0(nprob);
   memset(ctl0.data(), 0, sizeof(BCtl) * nprob);
@@ -1711,12 +1911,57 @@ extern "C" int32_t cosmo_hip_batch_set_iterates(cosmo_hip_batch* b, const real* 
   BHIP(b, hipMemcpy(c.data(), b->D.ctl, sizeof(BCtl) * b->nprob, hipMemcpyDeviceToHost));
   for (auto& x : c) { x.status = 0; x.iter = 0; x.cost = INFINITY; x.r_prim = INFINITY; x.r_dual = INFINITY; x.max_norm_prim = 0; x.max_norm_dual = 0; }
   BHIP(b, hipMemcpy(b->D.ctl, c.data(), sizeof(BCtl) * b->nprob, hipMemcpyHostToDevice));
+  if (b->D.aa) {                                            // optimize! restarts the accelerator (src/setup.jl:47-49): empty memory, inactive, counters zero
+    std::vector<BAa> a0((size_t)b->nprob);
+    memset(a0.data(), 0, sizeof(BAa) * a0.size());
+    for (auto& a : a0) a.init_phase = 1;
+    BHIP(b, hipMemcpy(b->D.aa, a0.data(), sizeof(BAa) * a0.size(), hipMemcpyHostToDevice));
+  }
   b->have_iterates = true; b->iters_done = 0;
   return COSMO_HIP_OK;
 }
 
-static BParams bparams(const cosmo_hip_params& p) {
+extern "C" int32_t cosmo_hip_batch_set_accelerator(cosmo_hip_batch* b, const cosmo_hip_accel_params* p) {
+  if (!b) return COSMO_HIP_ERR_INVALID;
+  if (b->finalized) return bfail(b, COSMO_HIP_ERR_INVALID, "batch_set_accelerator: call before batch_set_params (the kernel variant is chosen there)");
+  b->aa_on = false;
+  if (!p || p->kind == COSMO_HIP_ACCEL_EMPTY) return COSMO_HIP_OK;
+  if (p->kind != COSMO_HIP_ACCEL_ANDERSON) return bfail(b, COSMO_HIP_ERR_UNSUPPORTED, "accelerator kind %d", (int)p->kind);
+  if (p->mem < 1 || p->mem > BAA_MEM || p->min_mem < 1 || p->start_iter < 2 || !(p->safeguard_tol >= 0.0) || !(p->eta_max > 0.0))
+    return bfail(b, p->mem > BAA_MEM ? COSMO_HIP_ERR_UNSUPPORTED : COSMO_HIP_ERR_INVALID,
+                 "batch_set_accelerator: need 1 <= mem <= %d (batch mode), min_mem >= 1, start_iter >= 2", BAA_MEM);
+  b->aa_prm = *p; b->aa_on = true;
+  return COSMO_HIP_OK;
+}
+
+// per problem {accelerated steps, safeguard accepted, safeguard declined, memory restarts, active, safeguarding_iter}
+extern "C" int32_t cosmo_hip_batch_get_accel_stats(cosmo_hip_batch* b, int64_t* out) {
+  if (!b || !b->finalized || !out) return bfail(b, COSMO_HIP_ERR_INVALID, "batch_get_accel_stats: bad call");
+  if (hipSetDevice(b->device) != hipSuccess) return bfail(b, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
+  for (long long i = 0; i < 6LL * b->nprob; ++i) out[i] = 0;
+  if (!b->D.aa) return COSMO_HIP_OK;
+  std::vector<BAa> a((size_t)b->nprob);
+  BHIP(b, hipMemcpyAsync(a.data(), b->D.aa, sizeof(BAa) * a.size(), hipMemcpyDeviceToHost, b->stream));
+  BHIP(b, hipStreamSynchronize(b->stream));
+  for (int k = 0; k < b->nprob; ++k) {
+    out[6 * k] = a[k].accelerated; out[6 * k + 1] = a[k].accepted; out[6 * k + 2] = a[k].declined; out[6 * k + 3] = a[k].restarts;
+    out[6 * k + 4] = a[k].active; out[6 * k + 5] = a[k].sg_iter;
+  }
+  return COSMO_HIP_OK;
+}
+
+static BParams bparams(const cosmo_hip_batch* b, bool certificates) {
+  const cosmo_hip_params& p = b->prm;
   BParams P;
+  memset(&P, 0, sizeof P);
+  P.aa_start_acc = -1.0;
+  if (b->aa_on) {
+    const cosmo_hip_accel_params& a = b->aa_prm;
+    P.aa_start_iter = a.start_iter; P.aa_min_mem = a.min_mem; P.aa_safeguard = a.safeguard; P.aa_tau = (real)a.safeguard_tol; P.aa_eta_max = (real)a.eta_max;
+    P.aa_start_acc = (real)a.start_accuracy;
+    const long long ci = p.check_infeasibility;
+    P.check_inf = (certificates && ci > 0 && ci < (1LL << 40)) ? ci : 0;
+  }
   P.sigma = p.sigma; P.alpha = p.alpha; P.eps_abs = p.eps_abs; P.eps_rel = p.eps_rel; P.obj_true = p.obj_true; P.obj_true_tol = p.obj_true_tol; P.rho_min = p.rho_min; P.rho_max = p.rho_max;
   P.rho_eq = p.rho_eq_over_rho_ineq; P.adapt_tol = p.adaptive_rho_tolerance; P.max_iter = p.max_iter;
   P.max_adaptions = p.adaptive_rho_max_adaptions; P.check_termination = p.check_termination; P.adaptive_rho = p.adaptive_rho;
@@ -1729,7 +1974,7 @@ static BParams bparams(const cosmo_hip_params& p) {
 extern "C" int32_t cosmo_hip_batch_optimize(cosmo_hip_batch* b, cosmo_hip_result* results) {
   if (!b || !b->have_iterates || !results) return bfail(b, COSMO_HIP_ERR_INVALID, "batch_optimize: set_iterates first");
   if (hipSetDevice(b->device) != hipSuccess) return bfail(b, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
-  const BParams P = bparams(b->prm);
+  const BParams P = bparams(b, true);
   const auto t0 = std::chrono::steady_clock::now();
   const long long slice = std::max<long long>(b->prm.check_termination, 1) * 8;
   // certificates (solver.jl:326-349): iteration k ci sets the flag, delta_y is captured at the top of iteration k ci + 1 and the tests run at
@@ -1740,6 +1985,33 @@ extern "C" int32_t cosmo_hip_batch_optimize(cosmo_hip_batch* b, cosmo_hip_result
   long long target = 0;
   std::vector<BCtl> c(b->nprob);
   int first = 1;
+  std::vector<BAa> acc;
+  if (b->aa_on) {
+    // Accelerated batches: the workgroups take every decision themselves, including WHEN their certificates are due (the first non-accelerated
+    // iteration after a flagged one -- different per problem).  A workgroup leaves its launch at that iteration (BAa::need_inf); the host runs
+    // k_batch_inf_check on the flagged problems and relaunches towards the same target until every undecided problem has reached it.
+    acc.resize((size_t)b->nprob);
+    for (;;) {
+      target = std::min<long long>(target + slice, b->prm.max_iter);
+      bool all = true, timed_out = false;
+      for (;;) {
+        { const int32_t lrc = launch_batch_admm(b, P, target, first); if (lrc) return lrc; }
+        first = 0;
+        if (P.check_inf > 0)
+          hipLaunchKernelGGL(k_batch_inf_check, dim3(b->nprob), dim3(COSMO_BS), 0, b->stream, b->D, (real)b->prm.eps_prim_inf, (real)b->prm.eps_dual_inf, 1);
+        BHIP(b, hipMemcpyAsync(c.data(), b->D.ctl, sizeof(BCtl) * b->nprob, hipMemcpyDeviceToHost, b->stream));
+        BHIP(b, hipMemcpyAsync(acc.data(), b->D.aa, sizeof(BAa) * b->nprob, hipMemcpyDeviceToHost, b->stream));
+        BHIP(b, hipStreamSynchronize(b->stream));
+        all = true;
+        bool behind = false;
+        for (int k = 0; k < b->nprob; ++k) if (c[k].status == 0) { all = false; if (c[k].iter < target) behind = true; }
+        if (b->prm.time_limit != 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > b->prm.time_limit) { timed_out = !all; break; }
+        if (!behind) break;
+      }
+      if (timed_out) { for (auto& x : c) if (x.status == 0) x.status = COSMO_HIP_TIME_LIMIT_REACHED; break; }
+      if (all || target >= b->prm.max_iter) break;
+    }
+  } else
   for (;;) {
     long long stop = captured ? target + 1 : target + slice;
     if (inf_on && !captured) stop = std::min(stop, (target / ci + 1) * ci);
@@ -1747,7 +2019,7 @@ extern "C" int32_t cosmo_hip_batch_optimize(cosmo_hip_batch* b, cosmo_hip_result
     { const int32_t lrc = launch_batch_admm(b, P, target, first); if (lrc) return lrc; }
     first = 0;
     if (captured) {
-      hipLaunchKernelGGL(k_batch_inf_check, dim3(b->nprob), dim3(COSMO_BS), 0, b->stream, b->D, (real)b->prm.eps_prim_inf, (real)b->prm.eps_dual_inf);
+      hipLaunchKernelGGL(k_batch_inf_check, dim3(b->nprob), dim3(COSMO_BS), 0, b->stream, b->D, (real)b->prm.eps_prim_inf, (real)b->prm.eps_dual_inf, 0);
       captured = false;
     } else if (inf_on && target % ci == 0 && target < b->prm.max_iter) {
       hipLaunchKernelGGL(k_batch_inf_capture, dim3(b->nprob), dim3(COSMO_BS), 0, b->stream, b->D);
@@ -1767,7 +2039,7 @@ extern "C" int32_t cosmo_hip_batch_optimize(cosmo_hip_batch* b, cosmo_hip_result
   for (int k = 0; k < b->nprob; ++k) {
     cosmo_hip_result& r = results[k];
     memset(&r, 0, sizeof r);
-    r.status = c[k].status; r.n_rho_updates = c[k].n_rho_updates; r.iter = c[k].iter; r.kkt_iters_total = c[k].kkt_iters_total;
+    r.status = c[k].status; r.n_rho_updates = c[k].n_rho_updates; r.iter = c[k].iter + (b->aa_on ? acc[(size_t)k].sg_iter : 0); r.safeguarding_iter = b->aa_on ? acc[(size_t)k].sg_iter : 0; r.kkt_iters_total = c[k].kkt_iters_total;
     r.kkt_solves = c[k].solves; r.cost = (double)c[k].cost; r.r_prim = (double)c[k].r_prim; r.r_dual = (double)c[k].r_dual;
     r.max_norm_prim = (double)c[k].max_norm_prim; r.max_norm_dual = (double)c[k].max_norm_dual; r.rho = (double)c[k].rho; r.iter_time = el;
     for (int i = 0; i < COSMO_HIP_MAX_RHO_UPDATES && i < c[k].n_rho_updates; ++i) r.rho_updates[i] = (double)c[k].rho_updates[i];
@@ -1779,7 +2051,7 @@ extern "C" int32_t cosmo_hip_batch_optimize(cosmo_hip_batch* b, cosmo_hip_result
 extern "C" int32_t cosmo_hip_batch_iterate(cosmo_hip_batch* b, int64_t n_iters, int32_t with_init) {
   if (!b || !b->have_iterates) return bfail(b, COSMO_HIP_ERR_INVALID, "batch_iterate: set_iterates first");
   if (hipSetDevice(b->device) != hipSuccess) return bfail(b, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
-  const BParams P = bparams(b->prm);
+  const BParams P = bparams(b, false);
   b->iters_done += n_iters;
   { const int32_t lrc = launch_batch_admm(b, P, (long long)b->iters_done, with_init ? 1 : 0); if (lrc) return lrc; }
   BHIP(b, hipStreamSynchronize(b->stream));

@@ -150,7 +150,7 @@ end
 # settings.accelerator is an OptionsFactory{<:AbstractAccelerator} (src/settings.jl:96,136,148-150).  The device builds the
 # reference's default AndersonAccelerator{Float64, Type2{QRDecomp}, RestartedMemory, NoRegularizer}; EmptyAccelerator maps to
 # "none"; any other variant is rejected (error) rather than silently replaced.
-function set_accelerator!(h::Handle{T}, settings::COSMO.Settings{T}) where {T <: HipFloat}
+function accel_params_from(settings::COSMO.Settings{T}) where {T <: HipFloat}
     AT = settings.accelerator.ObjectType
     AT <: COSMO.EmptyAccelerator && return nothing
     AT == COSMO.AndersonAccelerator{T, COSMO.Type2{COSMO.QRDecomp}, COSMO.RestartedMemory, COSMO.NoRegularizer} ||
@@ -159,8 +159,12 @@ function set_accelerator!(h::Handle{T}, settings::COSMO.Settings{T}) where {T <:
     act = get(kw, :activation_reason, COSMO.ImmediateActivation())
     start = act isa COSMO.IterActivation ? act.start_iter : 2
     acc = act isa COSMO.AccuracyActivation ? Float64(act.start_accuracy) : -1.0    # src/accelerator_interface.jl:14-21
-    p = AccelParams(Int32(1), Int32(get(kw, :mem, 10)), Int32(get(kw, :min_mem, 3)), Int32(settings.safeguard ? 1 : 0), Int64(start),
-                    Float64(settings.safeguard_tol), 1e4, acc)
+    return AccelParams(Int32(1), Int32(get(kw, :mem, 10)), Int32(get(kw, :min_mem, 3)), Int32(settings.safeguard ? 1 : 0), Int64(start),
+                       Float64(settings.safeguard_tol), 1e4, acc)
+end
+function set_accelerator!(h::Handle{T}, settings::COSMO.Settings{T}) where {T <: HipFloat}
+    p = accel_params_from(settings)
+    p === nothing && return nothing
     check(h, ccall((:cosmo_hip_set_accelerator, lib(h)), Int32, (Ptr{Cvoid}, Ref{AccelParams}), h.ptr, Ref(p)))
     nothing
 end
@@ -362,13 +366,14 @@ function optimize_hip!(ws::COSMO.Workspace{T}; device::Integer = 0, kkt_kind::In
     end
     ws.times.solver_time = time() - solver_time_start
     destroy!(h)
-    return COSMO.Result{T}(ws.vars.x, y, ws.vars.s.data, T(r.cost), Int(r.iter), 0, status, res_info, ws.times)
+    return COSMO.Result{T}(ws.vars.x, y, ws.vars.s.data, T(r.cost), Int(r.iter), Int(r.safeguarding_iter), status, res_info, ws.times)
 end
 
 # ---------------------------------------------------------------------------------------------------------------------
 # Batches of independent problems with identical dimensions and cone structure (BASELINE config 3): what a user loop
 # `for ws in models; COSMO.optimize!(ws); end` computes, solved concurrently -- one persistent workgroup per problem
-# (cosmo_hip_batch_*).  Supported cones: ZeroSet, Nonnegatives, Box, SecondOrderCone; CG KKT solver; EmptyAccelerator.
+# (cosmo_hip_batch_*).  Supported cones: ZeroSet, Nonnegatives, Box, SecondOrderCone, PsdCone / PsdConeTriangle of side <= 64; CG KKT solver;
+# EmptyAccelerator or the default AndersonAccelerator (mem <= 16): the accelerated loop runs inside the persistent kernels.
 # Per problem the unchanged reference code does the scaling / classification (setup!, src/setup.jl:18-42) and the epilogue
 # (src/solver.jl:167-201); the loop of src/solver.jl:137-176 runs on the device for all problems at once.
 # ---------------------------------------------------------------------------------------------------------------------
@@ -381,7 +386,6 @@ function optimize_hip_batch!(models::Vector{COSMO.Workspace{T}}; device::Integer
     t_start = time()
     for ws in models
         (ws.p.model_size == (m, n)) || error("optimize_hip_batch!: all problems must have the same dimensions")
-        !(ws.accelerator isa COSMO.EmptyAccelerator) && error("optimize_hip_batch!: use accelerator = EmptyAccelerator")
         if !ws.states.IS_SCALED
             ws.sm = (settings.scaling > 0) ? COSMO.ScaleMatrices{T}(m, n) : COSMO.ScaleMatrices{T}()
         end
@@ -419,6 +423,8 @@ function optimize_hip_batch!(models::Vector{COSMO.Workspace{T}}; device::Integer
         types = Int32[cone_type(s) for s in ws1.p.C.sets]; dims = Int64[s.dim for s in ws1.p.C.sets]
         GC.@preserve types dims bl bu bcheck(ccall((:cosmo_hip_batch_set_cones, LIBT), Int32, (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int64}, Ptr{T}, Ptr{T}),
             b, length(types), types, dims, isempty(bl) ? C_NULL : pointer(bl), isempty(bu) ? C_NULL : pointer(bu)))
+        ap = accel_params_from(settings)                     # _make_accelerator! (src/setup.jl:10-16) for every problem; before set_params
+        ap === nothing || bcheck(ccall((:cosmo_hip_batch_set_accelerator, LIBT), Int32, (Ptr{Cvoid}, Ref{AccelParams}), b, Ref(ap)))
         prm = Ref(params_from(settings, KKT_CG; tol_constant = tol_constant, tol_exponent = tol_exponent))
         bcheck(ccall((:cosmo_hip_batch_set_params, LIBT), Int32, (Ptr{Cvoid}, Ref{Params}), b, prm))   # classify_constraints! + set_rho_vec! per problem
         x0 = reduce(vcat, [ws.vars.x for ws in models]); s0 = reduce(vcat, [ws.vars.s.data for ws in models]); mu0 = reduce(vcat, [ws.vars.μ for ws in models])
@@ -439,7 +445,7 @@ function optimize_hip_batch!(models::Vector{COSMO.Workspace{T}}; device::Integer
             settings.scaling != 0 && COSMO.reverse_scaling!(ws)
             @. ws.utility_vars.vec_m = -ws.vars.μ
             ws.times.solver_time = time() - t_start
-            push!(out, COSMO.Result{T}(copy(ws.vars.x), copy(ws.utility_vars.vec_m), copy(ws.vars.s.data), T(r.cost), Int(r.iter), 0, STATUS[r.status + 1], res_info, ws.times))
+            push!(out, COSMO.Result{T}(copy(ws.vars.x), copy(ws.utility_vars.vec_m), copy(ws.vars.s.data), T(r.cost), Int(r.iter), Int(r.safeguarding_iter), STATUS[r.status + 1], res_info, ws.times))
         end
         return out
     finally

@@ -322,6 +322,7 @@ class Result:
     info: ResultInfo
     times: ResultTimes
     kkt_iters_total: int = 0
+    safeguarding_iter: int = 0          # Result.safeguarding_iter (src/types.jl:93-112); `iter` includes them (src/solver.jl:196)
 
 
 @dataclass
@@ -743,7 +744,7 @@ def optimize(model: Model, dist=None, shard: str = "rows") -> Result:
                       [r.rho_updates[i] for i in range(min(r.n_rho_updates, _ffi.MAX_RHO_UPDATES))])
     times = ResultTimes(time.perf_counter() - t0, t_setup, r.iter_time, r.proj_time)
     return Result(x=x, y=-mu, s=s, obj_val=r.cost, iter=int(r.iter), status=_ffi.STATUS_NAMES[r.status], info=info,
-                  times=times, kkt_iters_total=int(r.kkt_iters_total))
+                  times=times, kkt_iters_total=int(r.kkt_iters_total), safeguarding_iter=int(r.safeguarding_iter))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -773,9 +774,8 @@ def prepare_batch(models: Sequence[Model], device: int):
     for md in models[1:]:
         if md.settings != st:
             raise ValueError("optimize_batch: all problems of a batch share ONE Settings object (per-problem settings are not supported)")
-    if st.accelerator not in (None, EmptyAccelerator):
-        raise ValueError("optimize_batch: the batch kernels implement the plain ADMM loop (EmptyAccelerator) only")
     B = _ffi.Batch(len(models), n, m, device, dtype=getattr(models[0], "dtype", np.float64))
+    _install_accelerator(B, st)                           # before set_params: the accelerated loop runs inside the persistent kernels (csrc/batch.hip)
     bl, bu = [], []
     for k, md in enumerate(models):                      # setup! per problem (scaling on the host, as in the reference)
         if st.scaling != 0 and not md.is_scaled:
@@ -814,7 +814,8 @@ def _solve_shard_on_device(models: Sequence[Model], device: int) -> List[Result]
         info = ResultInfo(r.r_prim, r.r_dual, r.max_norm_prim, r.max_norm_dual,
                           [r.rho_updates[i] for i in range(min(r.n_rho_updates, _ffi.MAX_RHO_UPDATES))])
         out.append(Result(x=x, y=-mu, s=s, obj_val=r.cost, iter=int(r.iter), status=_ffi.STATUS_NAMES[r.status], info=info,
-                          times=ResultTimes(time.perf_counter() - t0, t_setup, r.iter_time, 0.0), kkt_iters_total=int(r.kkt_iters_total)))
+                          times=ResultTimes(time.perf_counter() - t0, t_setup, r.iter_time, 0.0), kkt_iters_total=int(r.kkt_iters_total),
+                          safeguarding_iter=int(r.safeguarding_iter)))
     B.close()
     return out
 

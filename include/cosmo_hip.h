@@ -149,7 +149,7 @@ typedef struct cosmo_hip_accel_params {
 typedef struct cosmo_hip_result {
   int32_t status;                    /* COSMO_HIP_SOLVED ... */
   int32_t n_rho_updates;             /* length(ws.rho_updates) (>= 1) */
-  int64_t iter;                      /* ADMM iterations performed */
+  int64_t iter;                      /* ADMM iterations performed: Result.iter = iter + safeguarding_iter of src/solver.jl:196 */
   int64_t kkt_iters_total;           /* sum of CG/MINRES iterations over all solves */
   int64_t kkt_solves;                /* number of solve! calls (IndirectReducedKKTSolver.iteration_counter - 1) */
   double cost;                       /* cinv * (1/2 x'Px + q'x) at the last check (src/residuals.jl:143-147) */
@@ -158,6 +158,7 @@ typedef struct cosmo_hip_result {
   double iter_time;                  /* seconds in the while loop: ws.times.iter_time (src/solver.jl:134,169) */
   double proj_time;                  /* seconds in admm_z! projections (ws.times.proj_time) -- measured with HIP events */
   double rho_updates[COSMO_HIP_MAX_RHO_UPDATES];
+  int64_t safeguarding_iter;         /* of them: extra ADMM steps after a declined accelerated candidate (Result.safeguarding_iter, src/solver.jl:201) */
 } cosmo_hip_result;
 
 /* ---- lifecycle -------------------------------------------------------------------------------------- */
@@ -405,6 +406,16 @@ int32_t cosmo_hip_batch_set_problem(cosmo_hip_batch* b, int64_t k, const int64_t
 int32_t cosmo_hip_batch_set_cones(cosmo_hip_batch* b, int64_t ncones, const int32_t* type, const int64_t* dim,
                                   const cosmo_hip_real* box_l, const cosmo_hip_real* box_u);
 int32_t cosmo_hip_batch_set_scaling(cosmo_hip_batch* b, int64_t k, const cosmo_hip_real* Dinv, const cosmo_hip_real* Einv, double cinv);
+/* The reference's accelerator for every problem of the batch (replaces _make_accelerator!, src/setup.jl:10-16, once per model): the whole
+ * accelerated loop of src/solver.jl:140-165 runs inside the problem's persistent workgroup -- acceleration_pre! (update! / accelerate! of the
+ * Type-II Anderson accelerator with QR memory, restarted when full), safeguarding with its extra ADMM step (acceleration_post!,
+ * src/accelerator_interface.jl:85-116), rho updates and infeasibility checks deferred to the next non-accelerated iteration
+ * (update_suggested, src/solver.jl:284-292), IterActivation / AccuracyActivation -- with all decisions per problem on the device.  Call BEFORE
+ * cosmo_hip_batch_set_params (the kernel variant and its LDS layout are chosen there); mem <= 16; kind EMPTY / NULL removes it.
+ * cosmo_hip_result.iter then counts the safeguarding iterations too (src/solver.jl:196). */
+int32_t cosmo_hip_batch_set_accelerator(cosmo_hip_batch* b, const cosmo_hip_accel_params* p);
+/* per problem {accelerated steps, safeguard accepted, safeguard declined, memory restarts, active, safeguarding_iter}: out[6 * nprob] */
+int32_t cosmo_hip_batch_get_accel_stats(cosmo_hip_batch* b, int64_t* out);
 /* finalises the batch (uploads, classify_constraints!, set_rho_vec! per problem) */
 int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hip_params* p);
 int32_t cosmo_hip_batch_get_rho_classes(cosmo_hip_batch* b, int64_t k, int32_t* cls /* m */);

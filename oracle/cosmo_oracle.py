@@ -566,6 +566,7 @@ class Result:
     w_prev: Optional[np.ndarray] = None
     s_scaled: Optional[np.ndarray] = None
     mu_scaled: Optional[np.ndarray] = None
+    safeguarding_iter: int = 0          # Result.safeguarding_iter (src/solver.jl:201); `iter` is total_iter = iter + safeguarding_iter (:196)
 
 
 # --------------------------------------------------------------------------------------------
@@ -1392,10 +1393,10 @@ class Workspace:
             self.x, self.s, self.mu = xr.copy(), sr.copy(), mur.copy()
         else:
             xr, sr, mur = x, s.copy(), mu.copy()
-        return Result(x=xr, y=-mur, s=sr, obj_val=cost, iter=it, status=status,
+        return Result(x=xr, y=-mur, s=sr, obj_val=cost, iter=it + self.safeguarding_iter, status=status,      # total_iter (src/solver.jl:196)
                       r_prim=info[0], r_dual=info[1], max_norm_prim=info[2], max_norm_dual=info[3],
                       rho_updates=list(self.rho_updates), iter_time=iter_time, cg_iters=cg_iters,
-                      w=w_out, w_prev=wp_out, s_scaled=s_sc, mu_scaled=mu_sc)
+                      w=w_out, w_prev=wp_out, s_scaled=s_sc, mu_scaled=mu_sc, safeguarding_iter=self.safeguarding_iter)
 
 
 def solve(P, q, A, b, cones, settings: Optional[Settings] = None, **kw) -> Result:

@@ -374,7 +374,8 @@ def test_anderson_simple_qp_and_rho_adaption_goldens():
     # simple.jl:65 with the accelerated loop: iter + safeguarding_iter == max_iter (src/solver.jl:140,173)
     ws = O.Workspace(P_SIMPLE, Q_SIMPLE, A, b, cones, O.Settings(accelerator="anderson", max_iter=20, eps_abs=1e-12, eps_rel=1e-12))
     r = ws.optimize()
-    tot = r.iter + ws.safeguarding_iter
+    tot = r.iter                                             # Result.iter is total_iter = iter + safeguarding_iter (src/solver.jl:196)
+    assert r.safeguarding_iter == ws.safeguarding_iter
     # reference quirk kept: a safeguarding step in the last iteration overshoots max_iter by one and the `==` test of
     # src/solver.jl:173 then leaves the status :Undetermined
     assert tot in (20, 21) and r.status == ("Max_iter_reached" if tot == 20 else "Undetermined")
