@@ -274,6 +274,150 @@ struct LdsOps {
   }
 };
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The accelerator inside a problem's workgroup (shared by batch_admm_body and the register kernel).  `each(fn)` visits the elements of
+// w = [x ; rows] this THREAD owns as fn(e, w_e, w_prev_e) (references: global memory in batch_admm_body, registers in k_batch_admm_reg); the
+// accelerator's own vectors (G, Q, f, f_last, g_last) live in global memory, element e of each touched only by its owner, so no barrier is needed
+// between passes beyond those of the block sums.  All scalars (AaRegs) are block-uniform.
+// ---------------------------------------------------------------------------------------------------------------------
+struct AaRegs {
+  int iter = 0, init = 1, active = 0, success = 0, inf_due = 0, rho_due = 0, need_inf = 0;
+  long long n_acc = 0, n_ok = 0, n_decl = 0, n_rst = 0, sg = 0;
+  real nrmf = 0.0;
+};
+struct AaMem { BAa* aa; real *G, *Q, *f, *fl, *gl; int N, mem; };
+
+__device__ __forceinline__ AaMem aa_mem_of(const BatchDev& D, int k) {
+  AaMem M;
+  M.N = D.n + D.m; M.mem = D.aa_mem; M.aa = D.aa + k;
+  M.G = D.aa_G + (long long)k * M.N * M.mem; M.Q = D.aa_Q + (long long)k * M.N * M.mem;
+  const long long onm = (long long)k * M.N;
+  M.f = D.aa_f + onm; M.fl = D.aa_fl + onm; M.gl = D.aa_gl + onm;
+  return M;
+}
+__device__ __forceinline__ void aa_load(AaRegs& S, const BAa* a) {
+  S.iter = a->iter; S.init = a->init_phase; S.active = a->active; S.success = a->success; S.inf_due = a->inf_due; S.rho_due = a->rho_due; S.need_inf = 0;
+  S.n_acc = a->accelerated; S.n_ok = a->accepted; S.n_decl = a->declined; S.n_rst = a->restarts; S.sg = a->sg_iter; S.nrmf = a->nrm_f;
+}
+__device__ __forceinline__ void aa_store(const AaRegs& S, BAa* a) {
+  a->iter = S.iter; a->init_phase = S.init; a->active = S.active; a->success = S.success; a->inf_due = S.inf_due; a->rho_due = S.rho_due; a->need_inf = S.need_inf;
+  a->accelerated = S.n_acc; a->accepted = S.n_ok; a->declined = S.n_decl; a->restarts = S.n_rst; a->sg_iter = S.sg; a->nrm_f = S.nrmf;
+}
+
+// acceleration_pre! (accelerator_interface.jl:58-76): check_activation!, CA.update!(w, w_prev), CA.accelerate!(w).  update!: f = x - g;
+// G_j = g - g_last; v = f - f_last, modified Gram-Schmidt of v against Q_0..Q_{j-1} -> R[0..j, j], Q_j.  accelerate!: eta = R \ (Q' f);
+// w -= G eta unless R is singular / not finite or ||eta||_2 > eta_max.  (g = w, x = w_prev.)
+template <int BS, class Each>
+__device__ __forceinline__ void aa_pre(AaRegs& S, const AaMem& M, const BParams& P, long long it, Each each, real* red) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int N = M.N;
+  S.success = 0;
+  if (!S.active && !(P.aa_start_acc >= R(0.0)) && it >= P.aa_start_iter) S.active = 1;
+  if (!S.active) return;
+  if (S.init) {
+    each([&](int e, real& we, real& wpe) { const real gi = we; const real fi = wpe - gi; M.f[e] = fi; M.gl[e] = gi; M.fl[e] = fi; });
+    S.init = 0;
+  } else {
+    int j = S.iter % M.mem;
+    if (j == 0 && S.iter != 0) { S.iter = 0; S.n_rst += 1; }             // RestartedMemory: every column is rewritten before it is read again
+    real* Gj = M.G + (long long)j * N; real* v = M.Q + (long long)j * N;
+    real acc = 0.0;
+    each([&](int e, real& we, real& wpe) {
+      const real gi = we; const real fi = wpe - gi;
+      M.f[e] = fi; Gj[e] = gi - M.gl[e];
+      const real vi = fi - M.fl[e];
+      v[e] = vi; M.gl[e] = gi; M.fl[e] = fi;
+      acc += (j == 0) ? vi * vi : M.Q[e] * vi;
+    });
+    real rv = bsum<BS>(acc, red);
+    for (int i = 0; i < j; ++i) {
+      const bool last = (i + 1 == j);
+      const real* Qi = M.Q + (long long)i * N; const real* Qn = M.Q + (long long)(last ? i : i + 1) * N;
+      const real r = rv;
+      if (tid == 0) M.aa->R[j * BAA_MEM + i] = r;
+      acc = 0.0;
+      each([&](int e, real&, real&) { const real vi = v[e] - r * Qi[e]; v[e] = vi; acc += last ? vi * vi : Qn[e] * vi; });
+      rv = bsum<BS>(acc, red);
+    }
+    const real nv = sqrt(rv);
+    if (tid == 0) M.aa->R[j * BAA_MEM + j] = nv;
+    each([&](int e, real&, real&) { v[e] = v[e] / nv; });
+    S.iter += 1;
+  }
+  const int l = S.iter < M.mem ? S.iter : M.mem;
+  if (l < P.aa_min_mem) return;
+  real myrhs = 0.0;                                                       // lane c (of every wave) keeps (Q' f)[c]
+  for (int c = 0; c < l; ++c) {
+    const real* Qc = M.Q + (long long)c * N;
+    real acc = 0.0;
+    each([&](int e, real&, real&) { acc += Qc[e] * M.f[e]; });
+    const real r = bsum<BS>(acc, red);
+    if (lane == c) myrhs = r;
+  }
+  { real acc = 0.0;
+    each([&](int e, real&, real&) { const real fi = M.f[e]; acc += fi * fi; });
+    S.nrmf = sqrt(bsum<BS>(acc, red)); }
+  __syncthreads();                                                        // R[., j] of thread 0 is visible to wave 0
+  if (wv == 0) {                                                          // back substitution on one wave: lane i owns row i of R
+    const bool mine = lane < l;
+    real row[BAA_MEM];
+    real diag = 1.0;
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < BAA_MEM; ++c) {
+      const bool use = mine && c >= lane && c < l;
+      row[c] = use ? M.aa->R[c * BAA_MEM + lane] : R(0.0);
+      if (use && !(fabs(row[c]) <= REAL_MAX)) bad = true;
+      if (use && c == lane) diag = row[c];
+    }
+    if (mine && diag == R(0.0)) bad = true;
+    int ok = __any(bad ? 1 : 0) ? 0 : 1;
+    const int singular = ok ? 0 : 1;
+    if (ok) {
+      real sacc = myrhs, nrm2 = 0.0;
+#pragma unroll
+      for (int c = BAA_MEM - 1; c >= 0; --c) {
+        if (c < l) {
+          const real e_c = __shfl(sacc / diag, c, 64);
+          nrm2 += e_c * e_c;
+          if (lane < c) sacc -= row[c] * e_c;
+          if (lane == 0) M.aa->eta[c] = e_c;
+        }
+      }
+      if (!(sqrt(nrm2) <= P.aa_eta_max)) ok = 0;                          // also catches NaN
+    }
+    if (lane == 0) { M.aa->success = ok; if (singular) M.aa->fail_singular += 1; }
+  }
+  __syncthreads();
+  S.success = M.aa->success;
+  if (S.success) {
+    real eta[BAA_MEM];
+#pragma unroll
+    for (int c = 0; c < BAA_MEM; ++c) eta[c] = (c < l) ? M.aa->eta[c] : R(0.0);
+    each([&](int e, real& we, real&) {
+      real sacc = 0.0;
+#pragma unroll
+      for (int c = 0; c < BAA_MEM; ++c) if (c < l) sacc += M.G[(long long)c * N + e] * eta[c];
+      we = we - sacc;
+    });
+  }
+  __syncthreads();
+}
+// acceleration_post! part 1 (accelerator_interface.jl:85-100, 123-126): f = w_prev - w of the accelerated point; true = declined (the caller resets
+// and re-does the ADMM step)
+template <int BS, class Each>
+__device__ __forceinline__ bool aa_declined(AaRegs& S, const AaMem& M, const BParams& P, Each each, real* red) {
+  real acc = 0.0;
+  each([&](int e, real& we, real& wpe) { const real d = wpe - we; M.f[e] = d; acc += d * d; });
+  const real nrm_acc = sqrt(bsum<BS>(acc, red));
+  return nrm_acc > S.nrmf * P.aa_tau;
+}
+// reset_accelerated_vector! (accelerator_interface.jl:129-134)
+template <class Each>
+__device__ __forceinline__ void aa_reset(const AaMem& M, Each each) {
+  each([&](int e, real& we, real& wpe) { const real g = M.gl[e]; we = g; wpe = g; });
+}
+
 // One workgroup = one problem.  Runs iterations until a status is decided or `iter_target` iterations are done.
 // PSD: the batch has PsdCone / PsdConeTriangle cones of side 2..16.  A template parameter, not a run-time test: the wave-level Jacobi of psd16.h
 // inlined into these kernels costs 55-60 VGPRs (the register kernel <512, 1, 2> went from 229 to 256 + spills), which batches without such
@@ -417,135 +561,31 @@ __device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams
   };
 
   // ---- the accelerator's state: block-uniform registers, kept in D.aa[k] between launches ----
+  AaRegs S;
+  AaMem M;
   const int N = n + m;
-  BAa* const aa = AA ? D.aa + k : nullptr;
-  int aa_iter = 0, aa_init = 1, aa_active = 0, aa_success = 0, inf_due = 0, rho_due = 0, need_inf = 0;
-  long long n_acc = 0, n_ok = 0, n_decl = 0, n_rst = 0, sg = 0;
-  real aa_nrmf = 0.0;
-  real *aG = nullptr, *aQ = nullptr, *af = nullptr, *afl = nullptr, *agl = nullptr;
-  const int amem = AA ? D.aa_mem : 0;
-  if constexpr (AA) {
-    aa_iter = aa->iter; aa_init = aa->init_phase; aa_active = aa->active; aa_success = aa->success; inf_due = aa->inf_due; rho_due = aa->rho_due;
-    n_acc = aa->accelerated; n_ok = aa->accepted; n_decl = aa->declined; n_rst = aa->restarts; sg = aa->sg_iter; aa_nrmf = aa->nrm_f;
-    aG = D.aa_G + (long long)k * N * amem; aQ = D.aa_Q + (long long)k * N * amem;
-    af = D.aa_f + onm; afl = D.aa_fl + onm; agl = D.aa_gl + onm;
-  }
-  // acceleration_pre! (accelerator_interface.jl:58-76): check_activation!, CA.update!(w, w_prev), CA.accelerate!(w).  update!: f = x - g;
-  // G_j = g - g_last; v = f - f_last, modified Gram-Schmidt of v against Q_0..Q_{j-1} -> R[0..j, j], Q_j.  accelerate!: eta = R \ (Q' f);
-  // w -= G eta unless R is singular / not finite or ||eta||_2 > eta_max.  (g = w, x = w_prev.)
-  auto aa_pre = [&](long long it) {
-    aa_success = 0;
-    if (!aa_active && !(P.aa_start_acc >= R(0.0)) && it >= P.aa_start_iter) aa_active = 1;
-    if (!aa_active) return;
-    if (aa_init) {
-      for (int e = tid; e < N; e += BS) { const real gi = w[e]; const real fi = w_prev[e] - gi; af[e] = fi; agl[e] = gi; afl[e] = fi; }
-      aa_init = 0;
-    } else {
-      int j = aa_iter % amem;
-      if (j == 0 && aa_iter != 0) { aa_iter = 0; n_rst += 1; }           // RestartedMemory: every column is rewritten before it is read again
-      real* Gj = aG + (long long)j * N; real* v = aQ + (long long)j * N;
-      real acc = 0.0;
-      for (int e = tid; e < N; e += BS) {
-        const real gi = w[e]; const real fi = w_prev[e] - gi;
-        af[e] = fi; Gj[e] = gi - agl[e];
-        const real vi = fi - afl[e];
-        v[e] = vi; agl[e] = gi; afl[e] = fi;
-        acc += (j == 0) ? vi * vi : aQ[e] * vi;
-      }
-      real rv = bsum<BS>(acc, red);
-      for (int i = 0; i < j; ++i) {
-        const bool last = (i + 1 == j);
-        const real* Qi = aQ + (long long)i * N; const real* Qn = aQ + (long long)(last ? i : i + 1) * N;
-        const real r = rv;
-        if (tid == 0) aa->R[j * BAA_MEM + i] = r;
-        acc = 0.0;
-        for (int e = tid; e < N; e += BS) { const real vi = v[e] - r * Qi[e]; v[e] = vi; acc += last ? vi * vi : Qn[e] * vi; }
-        rv = bsum<BS>(acc, red);
-      }
-      const real nv = sqrt(rv);
-      if (tid == 0) aa->R[j * BAA_MEM + j] = nv;
-      for (int e = tid; e < N; e += BS) v[e] = v[e] / nv;
-      aa_iter += 1;
-    }
-    const int l = aa_iter < amem ? aa_iter : amem;
-    if (l < P.aa_min_mem) return;
-    real myrhs = 0.0;                                                     // lane c (of every wave) keeps (Q' f)[c]
-    for (int c = 0; c < l; ++c) {
-      const real* Qc = aQ + (long long)c * N;
-      real acc = 0.0;
-      for (int e = tid; e < N; e += BS) acc += Qc[e] * af[e];
-      const real r = bsum<BS>(acc, red);
-      if (lane == c) myrhs = r;
-    }
-    { real acc = 0.0;
-      for (int e = tid; e < N; e += BS) { const real fi = af[e]; acc += fi * fi; }
-      aa_nrmf = sqrt(bsum<BS>(acc, red)); }
-    __syncthreads();                                                      // R[., j] of thread 0 is visible to wave 0
-    if (wv == 0) {                                                        // back substitution on one wave: lane i owns row i of R
-      const bool mine = lane < l;
-      real row[BAA_MEM];
-      real diag = 1.0;
-      bool bad = false;
-#pragma unroll
-      for (int c = 0; c < BAA_MEM; ++c) {
-        const bool use = mine && c >= lane && c < l;
-        row[c] = use ? aa->R[c * BAA_MEM + lane] : R(0.0);
-        if (use && !(fabs(row[c]) <= REAL_MAX)) bad = true;
-        if (use && c == lane) diag = row[c];
-      }
-      if (mine && diag == R(0.0)) bad = true;
-      int ok = __any(bad ? 1 : 0) ? 0 : 1;
-      int singular = ok ? 0 : 1;
-      if (ok) {
-        real sacc = myrhs, nrm2 = 0.0;
-#pragma unroll
-        for (int c = BAA_MEM - 1; c >= 0; --c) {
-          if (c < l) {
-            const real e_c = __shfl(sacc / diag, c, 64);
-            nrm2 += e_c * e_c;
-            if (lane < c) sacc -= row[c] * e_c;
-            if (lane == 0) aa->eta[c] = e_c;
-          }
-        }
-        if (!(sqrt(nrm2) <= P.aa_eta_max)) ok = 0;                        // also catches NaN
-      }
-      if (lane == 0) { aa->success = ok; if (singular) aa->fail_singular += 1; }
-    }
-    __syncthreads();
-    aa_success = aa->success;
-    if (aa_success) {
-      real eta[BAA_MEM];
-#pragma unroll
-      for (int c = 0; c < BAA_MEM; ++c) eta[c] = (c < l) ? aa->eta[c] : R(0.0);
-      for (int e = tid; e < N; e += BS) {
-        real sacc = 0.0;
-#pragma unroll
-        for (int c = 0; c < BAA_MEM; ++c) if (c < l) sacc += aG[(long long)c * N + e] * eta[c];
-        w[e] = w[e] - sacc;
-      }
-    }
-    __syncthreads();
-  };
+  if constexpr (AA) { M = aa_mem_of(D, k); aa_load(S, M.aa); }
+  auto each = [&](auto&& fn) { for (int e = tid; e < N; e += BS) fn(e, w[e], w_prev[e]); };
 
   if (do_init) {                                                          // solver.jl:137-138
     solve_and_update();
   }
   long long it = ctl->iter;
-  while (it < iter_target && it + sg < P.max_iter) {
+  while (it < iter_target && it + S.sg < P.max_iter) {
     ++it;
     if constexpr (AA) {
-      aa_pre(it);
+      aa_pre<BS>(S, M, P, it, each, red);
       // delta_y of the certificates at the first non-accelerated iteration after a flagged one (solver.jl:145-148)
-      if (inf_due && !aa_success) { for (int i = tid; i < m; i += BS) D.inf_dy[om + i] = rho[i] * (w_prev[n + i] - s[i]); }
+      if (S.inf_due && !S.success) { for (int i = tid; i < m; i += BS) D.inf_dy[om + i] = rho[i] * (w_prev[n + i] - s[i]); }
     }
     admm_z();
     // ---- apply_rho_adaptation_rules! (solver.jl:242-282, parameters.jl:53-92); with an accelerator at the next non-accelerated iteration ----
     bool do_rho = P.adaptive_rho && P.adaptive_rho_interval > 0 && (it % P.adaptive_rho_interval) == 0 &&
                   (long long)(ctl->n_rho_updates - 1) < P.max_adaptions;
     if constexpr (AA) {
-      if (do_rho) rho_due = 1;
-      do_rho = rho_due && !aa_success;
-      if (do_rho) rho_due = 0;
+      if (do_rho) S.rho_due = 1;
+      do_rho = S.rho_due && !S.success;
+      if (do_rho) S.rho_due = 0;
     }
     if (do_rho) {
       residuals(false);
@@ -568,27 +608,24 @@ __device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams
           if (ku < COSMO_HIP_MAX_RHO_UPDATES) ctl->rho_updates[ku] = nr;
           ctl->n_rho_updates = ku + 1;
         }
-        if constexpr (AA) { aa_iter = 0; aa_init = 1; }                   // CA.restart! (solver.jl:272-275): the operator changed
+        if constexpr (AA) { S.iter = 0; S.init = 1; }                     // CA.restart! (solver.jl:272-275): the operator changed
       }
       __syncthreads();
     }
     solve_and_update();
     // ---- acceleration_post! (accelerator_interface.jl:85-116): safeguarding ----
     if constexpr (AA) {
-      if (aa_active && aa_success) {
+      if (S.active && S.success) {
         if (P.aa_safeguard) {
-          real acc = 0.0;
-          for (int e = tid; e < N; e += BS) { const real d = w_prev[e] - w[e]; af[e] = d; acc += d * d; }   // compute_accelerated_res_norm!
-          const real nrm_acc = sqrt(bsum<BS>(acc, red));
-          if (nrm_acc > aa_nrmf * P.aa_tau) {                             // declined: back to the last non-accelerated point, one plain ADMM step
-            for (int e = tid; e < N; e += BS) { const real g = agl[e]; w[e] = g; w_prev[e] = g; }
+          if (aa_declined<BS>(S, M, P, each, red)) {                      // back to the last non-accelerated point, one plain ADMM step
+            aa_reset(M, each);
             __syncthreads();
             admm_z();
             solve_and_update();
-            sg += 1; n_decl += 1;
-          } else n_ok += 1;
+            S.sg += 1; S.n_decl += 1;
+          } else S.n_ok += 1;
         }
-        n_acc += 1;
+        S.n_acc += 1;
       }
     }
     // ---- check_termination! (solver.jl:306-321) ----
@@ -599,32 +636,27 @@ __device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams
       else if (rp < P.eps_abs + P.eps_rel * mp && rd < P.eps_abs + P.eps_rel * md &&
                ((P.obj_true != P.obj_true) || fabs(P.obj_true - cost) <= P.obj_true_tol)) st = COSMO_HIP_SOLVED;   // has_converged (residuals.jl:131-139)
       if constexpr (AA) {                                                 // check_activation!(ws, ::AccuracyActivation, r) (accelerator_interface.jl:38-46)
-        if (st == 0 && !aa_active && P.aa_start_acc >= R(0.0) &&
-            rp < P.aa_start_acc + P.aa_start_acc * mp && rd < P.aa_start_acc + P.aa_start_acc * md) aa_active = 1;
+        if (st == 0 && !S.active && P.aa_start_acc >= R(0.0) &&
+            rp < P.aa_start_acc + P.aa_start_acc * mp && rd < P.aa_start_acc + P.aa_start_acc * md) S.active = 1;
       }
       if (tid == 0) { ctl->cost = cost; ctl->r_prim = rp; ctl->r_dual = rd; ctl->max_norm_prim = mp; ctl->max_norm_dual = md; ctl->status = st; }
       __syncthreads();
       if (st != 0) break;
     }
     if constexpr (AA) {                                                   // solver.jl:326-349: the certificates wait for a non-accelerated iteration
-      if (P.check_inf > 0 && (it % P.check_inf) == 0) inf_due = 1;
-      else if (inf_due && !aa_success) { inf_due = 0; need_inf = 1; break; }   // the host runs k_batch_inf_check on this problem, then relaunches
+      if (P.check_inf > 0 && (it % P.check_inf) == 0) S.inf_due = 1;
+      else if (S.inf_due && !S.success) { S.inf_due = 0; S.need_inf = 1; break; }   // the host runs k_batch_inf_check on this problem, then relaunches
     }
   }
   if (tid == 0) ctl->iter = it;
   // iter (+ safeguarding_iter) == max_iter: calculate_result_info! and Max_iter_reached, overriding a status decided in that iteration
   // (solver.jl:173-176, reference quirk kept)
-  if (it + sg >= P.max_iter) {
+  if (it + S.sg >= P.max_iter) {
     __syncthreads();
     residuals(P.unscale != 0);
     if (tid == 0) { ctl->r_prim = rp; ctl->r_dual = rd; ctl->max_norm_prim = mp; ctl->max_norm_dual = md; ctl->status = COSMO_HIP_MAX_ITER_REACHED; }
   }
-  if constexpr (AA) {
-    if (tid == 0) {
-      aa->iter = aa_iter; aa->init_phase = aa_init; aa->active = aa_active; aa->success = aa_success; aa->inf_due = inf_due; aa->rho_due = rho_due;
-      aa->need_inf = need_inf; aa->accelerated = n_acc; aa->accepted = n_ok; aa->declined = n_decl; aa->restarts = n_rst; aa->sg_iter = sg; aa->nrm_f = aa_nrmf;
-    }
-  }
+  if constexpr (AA) { if (tid == 0) aa_store(S, M.aa); }
   // recover_mu! (solver.jl:167)
   __syncthreads();
   for (int i = tid; i < m; i += BS) mu[i] = rho[i] * (w_prev[n + i] - s[i]);
@@ -692,7 +724,7 @@ extern "C" void cosmo_dbg_batch_timing(long long* out) { (void)hipMemcpyFromSymb
 #define BT_END(slot)
 #endif
 
-template <int BS, int JN, int JM, bool PSD>
+template <int BS, int JN, int JM, bool PSD, bool AA>
 __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, long long iter_target, int do_init,
                                                        const unsigned char* __restrict__ img, long long img_stride) {
   extern __shared__ real dyn_lds[];
@@ -1017,13 +1049,8 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
 #ifdef COSMO_BATCH_TIMING
   const long long kt0 = clock64();
 #endif
-  if (do_init) solve_and_update();                                        // solver.jl:137-138
-  long long it = ctl->iter;
-  int status = 0;
-  real o_cost = ctl->cost, o_rp = ctl->r_prim, o_rd = ctl->r_dual, o_mp = ctl->max_norm_prim, o_md = ctl->max_norm_dual;
-  while (it < iter_target && it < P.max_iter) {
-    ++it;
-    // ---- admm_z!: w_prev = w ; s = Pi(w_s)  (solver.jl:151-152) ----
+  // ---- admm_z!: w_prev = w ; s = Pi(w_s)  (solver.jl:151-152) ----
+  auto admm_z = [&]() {
 #pragma unroll
     for (int j = 0; j < JN; ++j) wpx[j] = wx[j];
 #pragma unroll
@@ -1064,8 +1091,40 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; if (i < m) sv[j] = tv[i]; }
       __syncthreads();
     }
-    // ---- apply_rho_adaptation_rules! (solver.jl:242-282, parameters.jl:53-92) ----
-    if (P.adaptive_rho && P.adaptive_rho_interval > 0 && (it % P.adaptive_rho_interval) == 0 && (long long)(n_rho - 1) < P.max_adaptions) {
+  };
+  // the accelerator (shared code above batch_admm_body): this thread's elements of w = [x ; rows] are its registers
+  AaRegs S;
+  AaMem M;
+  if constexpr (AA) { M = aa_mem_of(D, k); aa_load(S, M.aa); }
+  auto each = [&](auto&& fn) {
+#pragma unroll
+    for (int j = 0; j < JN; ++j) { const int i = tid + BS * j; if (i < n) fn(i, wx[j], wpx[j]); }
+#pragma unroll
+    for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; if (i < m) fn(n + i, wsv[j], wps[j]); }
+  };
+
+  if (do_init) solve_and_update();                                        // solver.jl:137-138
+  long long it = ctl->iter;
+  int status = 0;
+  real o_cost = ctl->cost, o_rp = ctl->r_prim, o_rd = ctl->r_dual, o_mp = ctl->max_norm_prim, o_md = ctl->max_norm_dual;
+  while (it < iter_target && it + S.sg < P.max_iter) {
+    ++it;
+    if constexpr (AA) {                                                   // acceleration_pre!; delta_y of the certificates (solver.jl:145-148)
+      aa_pre<BS>(S, M, P, it, each, red);
+      if (S.inf_due && !S.success) {
+#pragma unroll
+        for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; if (i < m) D.inf_dy[om + i] = rhov[j] * (wps[j] - sv[j]); }
+      }
+    }
+    admm_z();
+    // ---- apply_rho_adaptation_rules! (solver.jl:242-282, parameters.jl:53-92); with an accelerator at the next non-accelerated iteration ----
+    bool do_rho = P.adaptive_rho && P.adaptive_rho_interval > 0 && (it % P.adaptive_rho_interval) == 0 && (long long)(n_rho - 1) < P.max_adaptions;
+    if constexpr (AA) {
+      if (do_rho) S.rho_due = 1;
+      do_rho = S.rho_due && !S.success;
+      if (do_rho) S.rho_due = 0;
+    }
+    if (do_rho) {
       residuals(false);
       const real rpn = rp / (mp + R(1e-10)), rdn = rd / (md + R(1e-10));
       real nr = rho_s * sqrt(rpn / (rdn + R(1e-10)));
@@ -1090,9 +1149,23 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
         }
         if (tid == 0 && n_rho < COSMO_HIP_MAX_RHO_UPDATES) ctl->rho_updates[n_rho] = nr;
         rho_s = nr; n_rho += 1;
+        if constexpr (AA) { S.iter = 0; S.init = 1; }                     // CA.restart! (solver.jl:272-275)
       }
     }
     solve_and_update();
+    if constexpr (AA) {                                                   // acceleration_post! (accelerator_interface.jl:85-116): safeguarding
+      if (S.active && S.success) {
+        if (P.aa_safeguard) {
+          if (aa_declined<BS>(S, M, P, each, red)) {
+            aa_reset(M, each);
+            admm_z();
+            solve_and_update();
+            S.sg += 1; S.n_decl += 1;
+          } else S.n_ok += 1;
+        }
+        S.n_acc += 1;
+      }
+    }
     // ---- check_termination! (solver.jl:306-321) ----
     if ((it % P.check_termination) == 0 || it == 1) {
       residuals(P.unscale != 0);
@@ -1100,16 +1173,25 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       if (fabs(cost) > R(1e20)) st = COSMO_HIP_UNSOLVED;
       else if (rp < P.eps_abs + P.eps_rel * mp && rd < P.eps_abs + P.eps_rel * md &&
                ((P.obj_true != P.obj_true) || fabs(P.obj_true - cost) <= P.obj_true_tol)) st = COSMO_HIP_SOLVED;   // has_converged (residuals.jl:131-139)
+      if constexpr (AA) {                                                 // check_activation!(ws, ::AccuracyActivation, r)
+        if (st == 0 && !S.active && P.aa_start_acc >= R(0.0) &&
+            rp < P.aa_start_acc + P.aa_start_acc * mp && rd < P.aa_start_acc + P.aa_start_acc * md) S.active = 1;
+      }
       o_cost = cost; o_rp = rp; o_rd = rd; o_mp = mp; o_md = md; status = st;
       if (st != 0) break;
     }
+    if constexpr (AA) {                                                   // solver.jl:326-349: the certificates wait for a non-accelerated iteration
+      if (P.check_inf > 0 && (it % P.check_inf) == 0) S.inf_due = 1;
+      else if (S.inf_due && !S.success) { S.inf_due = 0; S.need_inf = 1; break; }
+    }
   }
-  // iter == max_iter: calculate_result_info! and Max_iter_reached, overriding a status decided in that iteration
+  // iter (+ safeguarding_iter) == max_iter: calculate_result_info! and Max_iter_reached, overriding a status decided in that iteration
   // (solver.jl:173-176, reference quirk kept)
-  if (it >= P.max_iter) {
+  if (it + S.sg >= P.max_iter) {
     residuals(P.unscale != 0);
     o_rp = rp; o_rd = rd; o_mp = mp; o_md = md; status = COSMO_HIP_MAX_ITER_REACHED;
   }
+  if constexpr (AA) { if (tid == 0) aa_store(S, M.aa); }
 #ifdef COSMO_BATCH_TIMING
   if (blockIdx.x == 0 && tid == 0) { g_bt[4] += clock64() - kt0; g_bt[5] += it; }
 #endif
@@ -1540,7 +1622,7 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
   { const char* er = getenv("COSMO_HIP_BATCH_REG");
     if (!(er && atoi(er) == 0)) {
       if (n <= 512 && m <= 1024) b->reg_mode = 1; else if (n <= 1024 && m <= 2048) b->reg_mode = 2;
-      if (b->aa_on) b->reg_mode = 0;            // the accelerated loop lives in batch_admm_body (iterates in global memory / L2), not in the register kernel
+      if (b->aa_on && npsd > 0) b->reg_mode = 0;   // the accelerated register kernel is instantiated without the PSD code (registers): the LDS-image kernel takes such batches
       if (nmid > 0) b->reg_mode = 0;            // the block-Jacobi code on top of ~200 live registers would spill: the LDS-image kernel (187 VGPRs) takes such batches
       if (b->reg_mode) bs = 512;
     } }
@@ -1716,14 +1798,18 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
   b->d_img = d; b->img_stride = stride; b->lds_bs = bs;
   b->lds_bytes = (int)(npsd > 0 ? ws_base + (long long)nws * PSD16_WS_STRIDE : stride + (long long)sizeof(real) * (n + m) + (long long)sizeof(real) * (bs / 64));
   const void* fn = bs == 256 ? (const void*)k_batch_admm_lds<256, false, false> : (bs == 512 ? (const void*)k_batch_admm_lds<512, false, false> : (const void*)k_batch_admm_lds<1024, false, false>);
-  if (b->reg_mode == 1) fn = (const void*)k_batch_admm_reg<512, 1, 2, false>;
-  if (b->reg_mode == 2) fn = (const void*)k_batch_admm_reg<512, 2, 4, false>;
+  if (b->reg_mode == 1) fn = (const void*)k_batch_admm_reg<512, 1, 2, false, false>;
+  if (b->reg_mode == 2) fn = (const void*)k_batch_admm_reg<512, 2, 4, false, false>;
   if (npsd > 0) {
     fn = (const void*)k_batch_admm_lds<512, true, false>;
-    if (b->reg_mode == 1) fn = (const void*)k_batch_admm_reg<512, 1, 2, true>;
-    if (b->reg_mode == 2) fn = (const void*)k_batch_admm_reg<512, 2, 4, true>;
+    if (b->reg_mode == 1) fn = (const void*)k_batch_admm_reg<512, 1, 2, true, false>;
+    if (b->reg_mode == 2) fn = (const void*)k_batch_admm_reg<512, 2, 4, true, false>;
   }
-  if (b->aa_on) fn = (const void*)k_batch_admm_lds<512, true, true>;
+  if (b->aa_on) {
+    fn = (const void*)k_batch_admm_lds<512, true, true>;
+    if (b->reg_mode == 1) fn = (const void*)k_batch_admm_reg<512, 1, 2, false, true>;
+    if (b->reg_mode == 2) fn = (const void*)k_batch_admm_reg<512, 2, 4, false, true>;
+  }
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, b->lds_bytes) != hipSuccess) {
     (void)hipGetLastError();
     b->d_img = nullptr; b->reg_mode = 0;          // the device does not grant that much LDS: streaming kernel
@@ -1733,10 +1819,12 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
 
 static int32_t launch_batch_admm(cosmo_hip_batch* b, const BParams& P, long long target, int do_init) {
   const bool psd = b->D.npsd > 0;
-#define LAUNCH_REG(JN_, JM_, PSD_) hipLaunchKernelGGL((k_batch_admm_reg<512, JN_, JM_, PSD_>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride)
+#define LAUNCH_REG(JN_, JM_, PSD_) hipLaunchKernelGGL((k_batch_admm_reg<512, JN_, JM_, PSD_, false>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride)
 #define LAUNCH_LDS(BS_, PSD_) hipLaunchKernelGGL((k_batch_admm_lds<BS_, PSD_, false>), dim3(b->nprob), dim3(BS_), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride)
-  if (b->aa_on) {                    // accelerated loop: the LDS-image kernel (512 threads) or the streaming kernel, both with the PSD code (a run-time no-op without such cones)
-    if (b->d_img) hipLaunchKernelGGL((k_batch_admm_lds<512, true, true>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
+  if (b->aa_on) {                    // accelerated loop: register kernel (batches without PSD cones), else the LDS-image kernel (512 threads) or the streaming kernel with the PSD code (a run-time no-op without such cones)
+    if (b->d_img && b->reg_mode == 1) hipLaunchKernelGGL((k_batch_admm_reg<512, 1, 2, false, true>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
+    else if (b->d_img && b->reg_mode == 2) hipLaunchKernelGGL((k_batch_admm_reg<512, 2, 4, false, true>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
+    else if (b->d_img) hipLaunchKernelGGL((k_batch_admm_lds<512, true, true>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
     else hipLaunchKernelGGL((k_batch_admm<true, true>), dim3(b->nprob), dim3(COSMO_BS), 0, b->stream, b->D, P, target, do_init);
   }
   else if (b->d_img && b->reg_mode == 1) { if (psd) LAUNCH_REG(1, 2, true); else LAUNCH_REG(1, 2, false); }

@@ -1,0 +1,39 @@
+#!/usr/bin/env python
+"""Per-iteration cost of the accelerated batch loop: 256 problems of BASELINE config 3 (one per CU), 200 iterations through batch_iterate (no certificates,
+no exits), for the register kernel, the LDS-image kernel and the LDS-image kernel with the accelerator."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import cosmo_jl_amd as cj
+
+nprob = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+probs = [cj.problems.socp(seed=1000 + k) for k in range(nprob)]
+
+
+def run(st, label, env=None):
+    for k, v in (env or {}).items():
+        os.environ[k] = v
+    mods = []
+    for p in probs:
+        md = cj.Model(); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], st); mods.append(md)
+    B, _ = cj.model.prepare_batch(mods, 0)
+    B.iterate(10, with_init=True)
+    _, _, k0 = B.counters()
+    t0 = time.perf_counter(); B.iterate(iters); dt = time.perf_counter() - t0
+    _, _, k1 = B.counters()
+    a = B.accel_stats()
+    kk = (k1 - k0)
+    print("%-22s %d iterations: %.1f ms = %.1f us per batch iteration; Krylov iterations per problem-iteration mean %.1f / max %.1f; accelerated %d declined %d"
+          % (label, iters, 1e3 * dt, 1e6 * dt / iters, kk.mean() / iters, kk.max() / iters, a["accelerated"].sum(), a["declined"].sum()), flush=True)
+    B.close()
+    for k in (env or {}):
+        os.environ.pop(k, None)
+
+
+far = dict(eps_abs=0.0, eps_rel=0.0, max_iter=10 ** 6)
+run(cj.Settings(**far), "register kernel")
+run(cj.Settings(**far), "LDS-image kernel", {"COSMO_HIP_BATCH_REG": "0"})
+run(cj.Settings(accelerator=cj.AndersonAccelerator, **far), "register + Anderson")
+run(cj.Settings(accelerator=cj.with_options(cj.AndersonAccelerator, mem=5), **far), "register + Anderson(5)")
+run(cj.Settings(accelerator=cj.AndersonAccelerator, **far), "LDS-image + Anderson", {"COSMO_HIP_BATCH_REG": "0"})
