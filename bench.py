@@ -421,6 +421,27 @@ def bench_cfg3(ctx, args, steps, warmup):
                            lds_bytes_per_krylov_iteration_per_problem=lds_bytes_per_krylov, krylov_iterations_timed=int(kry.sum()),
                            note="LDS bytes of the sparse passes x measured Krylov iterations (device counters) / elapsed; HBM is touched at launch and at the checks "
                                 "only.  The slowest problem's dependent chain of Krylov iterations, not LDS bandwidth, ends the step (see config)")
+    if ctx.world == 1 and os.environ.get("COSMO_BENCH_TTS", "1") != "0":
+        # Time to solution of the whole batch (every problem to the default eps = 1e-5, certificates on) with a tight KKT solve, without and with the
+        # reference's default accelerator (AndersonAccelerator, mem 15, safeguarded) running inside the persistent kernels.  Reported, not the metric.
+        try:
+            tight = cj.with_options(cj.CGIndirectKKTSolver, tol_constant=1e-10, tol_exponent=0.0)
+            tts = {}
+            for label, stt in (("plain", cj.Settings(kkt_solver=tight)), ("anderson", cj.Settings(kkt_solver=tight, accelerator=cj.AndersonAccelerator))):
+                ms = []
+                for p in probs:
+                    md = cj.Model(); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], stt); ms.append(md)
+                Bt, _ = cj.model.prepare_batch(ms, ctx.local_rank)
+                t0 = time.perf_counter(); rs = Bt.optimize(); dt = time.perf_counter() - t0
+                its = np.array([r.iter for r in rs])
+                tts[label] = dict(seconds=round(dt, 4), solved=int(sum(r.status == 1 for r in rs)), admm_iterations_max=int(its.max()), admm_iterations_sum=int(its.sum()),
+                                  krylov_iterations_sum=int(sum(r.kkt_iters_total for r in rs)), safeguarding_iterations=int(sum(r.safeguarding_iter for r in rs)))
+                Bt.close()
+            tts["note"] = ("cosmo_hip_batch_optimize of all %d problems, eps = 1e-5, CG solved to 1e-10; `anderson` = the reference's default accelerator inside "
+                           "the persistent kernels (csrc/batch.hip); wall seconds of the optimize call" % nprob)
+            out["config"]["time_to_solution_tight_cg"] = tts
+        except Exception as e:                                  # a reported extra must not take the line down
+            out["config"]["time_to_solution_tight_cg"] = dict(error="%s: %s" % (type(e).__name__, e))
     if not args.no_cpu_baseline and ctx.world == 1:
         def cpu_leg(out=out, probs=probs):
             from oracle import cosmo_oracle as O

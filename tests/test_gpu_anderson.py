@@ -106,7 +106,7 @@ def test_random_qp_accelerated_matches_oracle(seed):
     ref = ws.optimize()
     assert ref.iter <= 150
     assert res.status == ref.status == "Solved"
-    assert abs(res.iter - ref.iter) <= 25
+    assert abs((res.iter - res.safeguarding_iter) - (ref.iter - ref.safeguarding_iter)) <= 25       # loop indices (Result.iter adds the safeguarding steps)
     assert abs(res.obj_val - ref.obj_val) <= 1e-5 * (1 + abs(ref.obj_val))
     assert np.linalg.norm(res.x - ref.x) <= 1e-4 * max(1.0, np.linalg.norm(ref.x))
     plain = cj.Model(); plain.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], cj.Settings(kkt_solver=tight, **st))
@@ -136,7 +136,8 @@ def test_accelerated_infeasibility_and_cones():
     res = cj.optimize(model)
     ws = O.Workspace(pr["P"], pr["q"], pr["A"], pr["b"], util.oracle_cones(pr["sets"]), O.Settings(kkt_solver="cg", accelerator="anderson", eps_abs=1e-6, eps_rel=1e-6))
     ref = ws.optimize()
-    assert res.status == ref.status == "Solved" and abs(res.iter - ref.iter) <= 25
+    # (the loop index stops on a multiple of check_termination; Result.iter adds the safeguarding steps, src/solver.jl:196)
+    assert res.status == ref.status == "Solved" and abs((res.iter - res.safeguarding_iter) - (ref.iter - ref.safeguarding_iter)) <= 25
     # both stop at eps = 1e-6 on slightly different iterations of an accelerated run: SURVEY 8c default-schedule tolerance is 1e-4 (1 + |obj|)
     assert abs(res.obj_val - ref.obj_val) < 1e-5 * (1 + abs(ref.obj_val))
 
@@ -172,7 +173,7 @@ def test_accuracy_activation_matches_oracle():
                          O.Settings(kkt_solver="cg", tol_constant=1e-10, tol_exponent=0.0, accelerator="anderson", eps_abs=1e-7, eps_rel=1e-7, **okw))
         ref = ws.optimize()
         assert res.status == ref.status == "Solved"
-        assert abs(res.iter - ref.iter) <= 25, (name, res.iter, ref.iter)
+        assert abs((res.iter - res.safeguarding_iter) - (ref.iter - ref.safeguarding_iter)) <= 25, (name, res.iter, ref.iter)
         assert abs(stats["accelerated"] - ws.accelerator.num_accelerated_steps) <= max(2, 0.1 * ws.accelerator.num_accelerated_steps)
         assert np.linalg.norm(res.x - ref.x) <= 1e-5 * max(1.0, np.linalg.norm(ref.x))
         out[name] = (res, stats)
