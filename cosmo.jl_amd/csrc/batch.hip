@@ -12,6 +12,9 @@
 // such cones, called from the problem's persistent workgroup: batches of small SDPs, src/convexset.jl:402-412 inside the composite projection
 // :885-891); larger PSD cones take the single-problem path.  The
 // infeasibility certificates run between persistent launches (k_batch_inf_capture / k_batch_inf_check below).
+// Accelerator (round 4): with cosmo_hip_batch_set_accelerator the loop is the reference's accelerated loop (src/solver.jl:140-165,
+// src/accelerator_interface.jl:58-116) per problem -- Anderson update / accelerate, safeguarding, deferred rho updates and certificates -- all inside
+// the persistent workgroup (aa_pre / aa_declined / aa_reset below, shared by batch_admm_body and k_batch_admm_reg through an element visitor).
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
