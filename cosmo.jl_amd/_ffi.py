@@ -124,6 +124,7 @@ SIGNATURES = {
     "cosmo_hip_batch_last_error": (C.c_char_p, [C.c_void_p]),
     "cosmo_hip_batch_set_problem": (C.c_int32, [C.c_void_p, C.c_int64, _PI64, _PI64, _PR, _PI64, _PI64, _PR, _PR, _PR]),
     "cosmo_hip_batch_set_cones": (C.c_int32, [C.c_void_p, C.c_int64, _PI32, _PI64, _PR, _PR]),
+    "cosmo_hip_batch_set_cones_ex": (C.c_int32, [C.c_void_p, C.c_int64, _PI32, _PI64, _PR, _PR, _PR]),
     "cosmo_hip_batch_set_scaling": (C.c_int32, [C.c_void_p, C.c_int64, _PR, _PR, C.c_double]),
     "cosmo_hip_batch_set_params": (C.c_int32, [C.c_void_p, C.POINTER(Params)]),
     "cosmo_hip_batch_set_accelerator": (C.c_int32, [C.c_void_p, C.POINTER(AccelParams)]),
@@ -558,10 +559,14 @@ class Batch:
         self._chk(self.lib.cosmo_hip_batch_set_problem(self._b, int(k), pc.ctypes.data_as(_PI64), pr.ctypes.data_as(_PI64), _dp(pv),
                                                        ac.ctypes.data_as(_PI64), ar.ctypes.data_as(_PI64), _dp(av), _dp(q), _dp(b)))
 
-    def set_cones(self, types, dims, box_l=None, box_u=None):
+    def set_cones(self, types, dims, box_l=None, box_u=None, cone_param=None):
         t = np.ascontiguousarray(types, dtype=np.int32); d = np.ascontiguousarray(dims, dtype=np.int64)
         bl = self._f(box_l); bu = self._f(box_u)
-        self._chk(self.lib.cosmo_hip_batch_set_cones(self._b, t.size, t.ctypes.data_as(_PI32), d.ctypes.data_as(_PI64), _dp(bl), _dp(bu)))
+        if cone_param is None:
+            self._chk(self.lib.cosmo_hip_batch_set_cones(self._b, t.size, t.ctypes.data_as(_PI32), d.ctypes.data_as(_PI64), _dp(bl), _dp(bu)))
+        else:                                                 # alpha of the power cones (as Handle.set_cones)
+            cp = self._f(cone_param, t.size)
+            self._chk(self.lib.cosmo_hip_batch_set_cones_ex(self._b, t.size, t.ctypes.data_as(_PI32), d.ctypes.data_as(_PI64), _dp(bl), _dp(bu), _dp(cp)))
 
     def set_scaling(self, k, Dinv, Einv, cinv):
         self._chk(self.lib.cosmo_hip_batch_set_scaling(self._b, int(k), _dp(self._f(Dinv, self.n)), _dp(self._f(Einv, self.m)), float(cinv)))

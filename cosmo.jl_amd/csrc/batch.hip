@@ -24,6 +24,7 @@
 #include "device_utils.h"
 #include "psd16.h"
 #include "psdwg.h"
+#include "cone3.h"
 
 struct BCtl {                 // per problem, device resident
   int status; int n_rho_updates;
@@ -58,6 +59,9 @@ struct BatchDev {
   // PSD cones of side 17 .. 64 (psdwg.h): one cone after the other by the whole workgroup; G = X + c I lives in global memory (ld x ncp per cone)
   int nmid; const int *mid_off, *mid_d, *mid_kind, *mid_ld, *mid_ncp; const long long* mid_goff;
   real* psdG; long long psdG_stride;      // per problem: sum over its mid cones of ld * ncp reals
+  // ExponentialCone / PowerCone and their duals (cone3.h): first row, COSMO_HIP_EXP .. COSMO_HIP_DUAL_POW, alpha.  Handled by the kernel
+  // instantiations that carry the PSD code (template flag PSD = "cones beyond Zero / Nonnegatives / Box / SecondOrderCone")
+  int n3; const int *c3_off, *c3_kind; const real* c3_alpha;
   const int* rho_cls;
   real *w, *w_prev, *s, *mu, *s_tl, *ls_s, *y2, *tmp_m, *nu, *rho;
   real *ls_x, *x_tl, *rhs, *r, *u, *c;
@@ -149,6 +153,19 @@ __device__ __forceinline__ void batch_project_psd(const BatchDev& D, real* x, un
     (void)psd16_wave(x + D.psd_off[cI], D.psd_d[cI], D.psd_kind[cI], ws, lane, 0, R(1.0), nullptr, nullptr);
     wave_lds_fence();                                   // the workspace is reused by this wave's next cone
   }
+}
+
+// ExponentialCone / PowerCone / duals of a problem: one thread per cone (src/convexset.jl:510-537, 626-684, 774-779; limits MAX_ITERS 100 / 20, tol 1e-8)
+// (a real call, not inlined: the Newton / bisection loops with exp / log / pow would otherwise raise the register count of every kernel that carries
+//  them -- the small-SDP instantiations are at the 256-VGPR limit already)
+__device__ __attribute__((noinline)) void batch_project_cone3_one(real* p, int kind, real alpha) {
+  cone3::V3 v{p[0], p[1], p[2]};
+  (void)cone3::project_kind(v, kind, alpha, 100, 20, R(1e-8), R(1e-8));
+  p[0] = v.x; p[1] = v.y; p[2] = v.z;
+}
+template <int BS>
+__device__ __forceinline__ void batch_project_cone3(const BatchDev& D, real* x) {
+  for (int c = threadIdx.x; c < D.n3; c += BS) batch_project_cone3_one(x + D.c3_off[c], D.c3_kind[c], D.c3_alpha[c]);
 }
 
 // the PSD cones of side 17 .. 64 of problem k: populate G = X + ||X||_F I, block-Jacobi sweeps (4 block pairs at most: 4 waves), column scaling +
@@ -555,6 +572,7 @@ __device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams
     __syncthreads();
     if constexpr (PSD) {                                                  // PsdCone / PsdConeTriangle, side <= 16 (convexset.jl:303-321, 402-412)
       batch_project_psd(D, s, ops.psd_ws, wv, lane);
+      batch_project_cone3<BS>(D, s);                                      // ExponentialCone / PowerCone / duals (disjoint rows)
       __syncthreads();
       if (D.nmid > 0) {                                                   // ... and side 17 .. 64: the whole workgroup, one cone after the other
         __shared__ int any_rot_s;
@@ -1086,7 +1104,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       } else {
         for (int cI = wvid; cI < D.nsoc; cI += BS / 64) soc_one(tv + D.soc_off[cI], D.soc_dim[cI]);
       }
-      if constexpr (PSD) batch_project_psd(D, tv, psd_ws, wvid, lane);   // disjoint rows: no barrier needed between the two cone kinds
+      if constexpr (PSD) { batch_project_psd(D, tv, psd_ws, wvid, lane); batch_project_cone3<BS>(D, tv); }   // disjoint rows: no barrier needed between the cone kinds
       __syncthreads();
       // (side 17 .. 64 never reaches this kernel: build_lds_images gives such batches to the LDS-image kernel, whose registers have room for the
       //  block-Jacobi code)
@@ -1335,6 +1353,10 @@ __global__ __launch_bounds__(COSMO_BS) void k_batch_inf_check(BatchDev D, real e
       if (!(nx <= epi + (-x[0]))) viol = 1;
     }
     if ((D.npsd > 0 || D.nmid > 0) && psd_violates(dy, -R(1.0), epi)) viol = 1;          // in_dual!(-dyn) of the PSD cones (:415-418)
+    for (int cI = tid; cI < D.n3; cI += BS) {                                             // in_dual(-dyn) of the 3-dimensional cones (:603-605, 724-726, 772)
+      const real* p3 = dy + D.c3_off[cI];
+      if (!cone3::in_dual_kind(cone3::V3{-p3[0], -p3[1], -p3[2]}, D.c3_kind[cI], D.c3_alpha[cI], epi)) viol = 1;
+    }
     if (viol) atomicOr(&flag, 1);
     const real dyt_b = bsum<BS>(dtb, red), box_sf = bsum<BS>(box, red);          // (their barriers also publish `flag`)
     __syncthreads();
@@ -1371,6 +1393,10 @@ __global__ __launch_bounds__(COSMO_BS) void k_batch_inf_check(BatchDev D, real e
       if (!(nx <= edi - x[0])) viol = 1;
     }
     if ((D.npsd > 0 || D.nmid > 0) && psd_violates(adx, -R(1.0), edi)) viol = 1;         // in_pol_recc!: is_neg_def (:421-424)
+    for (int cI = tid; cI < D.n3; cI += BS) {                                             // in_pol_recc(x) = in_dual(-x) of the 3-dimensional cones
+      const real* p3 = adx + D.c3_off[cI];
+      if (!cone3::in_dual_kind(cone3::V3{-p3[0], -p3[1], -p3[2]}, D.c3_kind[cI], D.c3_alpha[cI], edi)) viol = 1;
+    }
     if (viol) atomicOr(&flag, 1);
     __syncthreads();
     if (!flag && tid == 0) { ctl->status = COSMO_HIP_DUAL_INFEASIBLE; ctl->cost = -(real)INFINITY; }   // solver.jl:343-346
@@ -1523,8 +1549,15 @@ extern "C" int32_t cosmo_hip_batch_set_problem(cosmo_hip_batch* b, int64_t k, co
 }
 
 // same cone structure for every problem; Box bounds are per problem: box_l/box_u have nprob * nbox entries
+extern "C" int32_t cosmo_hip_batch_set_cones_ex(cosmo_hip_batch* b, int64_t ncones, const int32_t* type, const int64_t* dim,
+                                                const real* box_l, const real* box_u, const real* cone_param);
 extern "C" int32_t cosmo_hip_batch_set_cones(cosmo_hip_batch* b, int64_t ncones, const int32_t* type, const int64_t* dim,
                                              const real* box_l, const real* box_u) {
+  return cosmo_hip_batch_set_cones_ex(b, ncones, type, dim, box_l, box_u, nullptr);
+}
+// cone_param: alpha of PowerCone / DualPowerCone (as cosmo_hip_set_cones_ex); NULL = none
+extern "C" int32_t cosmo_hip_batch_set_cones_ex(cosmo_hip_batch* b, int64_t ncones, const int32_t* type, const int64_t* dim,
+                                                const real* box_l, const real* box_u, const real* cone_param) {
   if (!b || b->finalized) return bfail(b, COSMO_HIP_ERR_INVALID, "batch_set_cones: bad call");
   ConeTable& C = b->cones; C = ConeTable();
   int64_t off = 0, nbox = 0;
@@ -1535,8 +1568,14 @@ extern "C" int32_t cosmo_hip_batch_set_cones(cosmo_hip_batch* b, int64_t ncones,
       if (type[k] == COSMO_HIP_PSD_SQUARE) { while ((d + 1) * (d + 1) <= dim[k]) ++d; if (d * d != dim[k]) return bfail(b, COSMO_HIP_ERR_INVALID, "PsdCone: dimension %lld is not a square", (long long)dim[k]); }
       else { while ((d + 1) * (d + 2) / 2 <= dim[k]) ++d; if (d * (d + 1) / 2 != dim[k]) return bfail(b, COSMO_HIP_ERR_INVALID, "PsdConeTriangle: dimension %lld is not triangular", (long long)dim[k]); }
       if (d > 64) return bfail(b, COSMO_HIP_ERR_UNSUPPORTED, "batch mode projects PSD cones of side <= 64 (side %lld: use one handle per problem)", d);
+    } else if (type[k] >= COSMO_HIP_EXP && type[k] <= COSMO_HIP_DUAL_POW) {
+      if (dim[k] != 3) return bfail(b, COSMO_HIP_ERR_INVALID, "exponential / power cones have dimension 3");
+      if (type[k] == COSMO_HIP_POW || type[k] == COSMO_HIP_DUAL_POW) {
+        const double a = cone_param ? (double)cone_param[k] : 0.0;
+        if (!(a > 0.0 && a < 1.0)) return bfail(b, COSMO_HIP_ERR_INVALID, "PowerCone: 0 < alpha < 1 (cone_param of batch_set_cones_ex)");
+      }
     } else if (type[k] < COSMO_HIP_ZERO || type[k] > COSMO_HIP_SOC) return bfail(b, COSMO_HIP_ERR_UNSUPPORTED, "cone type %d", (int)type[k]);
-    C.type.push_back(type[k]); C.dim.push_back(dim[k]); C.off.push_back(off); off += dim[k];
+    C.type.push_back(type[k]); C.dim.push_back(dim[k]); C.off.push_back(off); C.param.push_back(cone_param ? cone_param[k] : R(0.0)); off += dim[k];
     if (type[k] == COSMO_HIP_BOX) nbox += dim[k];
   }
   if (off != b->m) return bfail(b, COSMO_HIP_ERR_INVALID, "cone dimensions do not sum to m");
@@ -1611,7 +1650,8 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
   if (e && atoi(e) == 0) return COSMO_HIP_OK;
   const long long n = b->n, m = b->m;
   if (n > 65535 || m > 65535 || n + m == 0) return COSMO_HIP_OK;
-  int npsd = 0, nmid = 0;
+  int npsd = 0, nmid = 0, n3 = 0;
+  for (size_t c = 0; c < b->cones.type.size(); ++c) if (b->cones.type[c] >= COSMO_HIP_EXP && b->cones.type[c] <= COSMO_HIP_DUAL_POW) n3 += 1;
   for (size_t c = 0; c < b->cones.type.size(); ++c)
     if ((b->cones.type[c] == COSMO_HIP_PSD_SQUARE || b->cones.type[c] == COSMO_HIP_PSD_TRIANGLE) && b->cones.dim[c] > 1) {
       npsd += 1;
@@ -1619,13 +1659,13 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
     }
   int bs = 512;
   if (const char* eb = getenv("COSMO_HIP_BATCH_BS")) { const int v = atoi(eb); if (v == 256 || v == 512 || v == 1024) bs = v; }
-  if (npsd > 0 || b->aa_on) bs = 512;                            // the PSD / accelerated instantiations of the LDS-image kernel exist for 512 threads
+  if (npsd > 0 || n3 > 0 || b->aa_on) bs = 512;                  // the extended-cone / accelerated instantiations of the LDS-image kernel exist for 512 threads
   // register-resident iterates (k_batch_admm_reg, 512 threads) when the vectors fit 1-2 (n) / 2-4 (m) elements per thread
   b->reg_mode = 0;
   { const char* er = getenv("COSMO_HIP_BATCH_REG");
     if (!(er && atoi(er) == 0)) {
       if (n <= 512 && m <= 1024) b->reg_mode = 1; else if (n <= 1024 && m <= 2048) b->reg_mode = 2;
-      if (b->aa_on && npsd > 0) b->reg_mode = 0;   // the accelerated register kernel is instantiated without the PSD code (registers): the LDS-image kernel takes such batches
+      if (b->aa_on && (npsd > 0 || n3 > 0)) b->reg_mode = 0;   // the accelerated register kernel is instantiated without the PSD / exp / pow code (registers): the LDS-image kernel takes such batches
       if (nmid > 0) b->reg_mode = 0;            // the block-Jacobi code on top of ~200 live registers would spill: the LDS-image kernel (187 VGPRs) takes such batches
       if (b->reg_mode) bs = 512;
     } }
@@ -1803,7 +1843,7 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
   const void* fn = bs == 256 ? (const void*)k_batch_admm_lds<256, false, false> : (bs == 512 ? (const void*)k_batch_admm_lds<512, false, false> : (const void*)k_batch_admm_lds<1024, false, false>);
   if (b->reg_mode == 1) fn = (const void*)k_batch_admm_reg<512, 1, 2, false, false>;
   if (b->reg_mode == 2) fn = (const void*)k_batch_admm_reg<512, 2, 4, false, false>;
-  if (npsd > 0) {
+  if (npsd > 0 || n3 > 0) {
     fn = (const void*)k_batch_admm_lds<512, true, false>;
     if (b->reg_mode == 1) fn = (const void*)k_batch_admm_reg<512, 1, 2, true, false>;
     if (b->reg_mode == 2) fn = (const void*)k_batch_admm_reg<512, 2, 4, true, false>;
@@ -1821,7 +1861,7 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
 }
 
 static int32_t launch_batch_admm(cosmo_hip_batch* b, const BParams& P, long long target, int do_init) {
-  const bool psd = b->D.npsd > 0;
+  const bool psd = b->D.npsd > 0 || b->D.n3 > 0;        // the instantiations with the cones beyond Zero / Nonnegatives / Box / SecondOrderCone
 #define LAUNCH_REG(JN_, JM_, PSD_) hipLaunchKernelGGL((k_batch_admm_reg<512, JN_, JM_, PSD_, false>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride)
 #define LAUNCH_LDS(BS_, PSD_) hipLaunchKernelGGL((k_batch_admm_lds<BS_, PSD_, false>), dim3(b->nprob), dim3(BS_), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride)
   if (b->aa_on) {                    // accelerated loop: register kernel (batches without PSD cones), else the LDS-image kernel (512 threads) or the streaming kernel with the PSD code (a run-time no-op without such cones)
@@ -1833,7 +1873,7 @@ static int32_t launch_batch_admm(cosmo_hip_batch* b, const BParams& P, long long
   else if (b->d_img && b->reg_mode == 1) { if (psd) LAUNCH_REG(1, 2, true); else LAUNCH_REG(1, 2, false); }
   else if (b->d_img && b->reg_mode == 2) { if (psd) LAUNCH_REG(2, 4, true); else LAUNCH_REG(2, 4, false); }
   else if (b->d_img) {
-    if (psd) LAUNCH_LDS(512, true);                                  // (build_lds_images fixed 512 threads for batches with PSD cones)
+    if (psd) LAUNCH_LDS(512, true);                                  // (build_lds_images fixed 512 threads for batches with PSD / exp / pow cones)
     else if (b->lds_bs == 256) LAUNCH_LDS(256, false);
     else if (b->lds_bs == 512) LAUNCH_LDS(512, false);
     else LAUNCH_LDS(1024, false);
@@ -1884,6 +1924,8 @@ extern "C" int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hi
   std::vector<uint32_t> meta((size_t)m, 0u);
   std::vector<int> soc_off, soc_dim, psd_off, psd_d, psd_kind, mid_off, mid_d, mid_kind, mid_ld, mid_ncp;
   std::vector<long long> mid_goff;
+  std::vector<int> c3_off, c3_kind;
+  std::vector<real> c3_alpha;
   long long gtot = 0;
   long long boxp = 0;
   for (size_t k = 0; k < C.type.size(); ++k) {
@@ -1907,8 +1949,12 @@ extern "C" int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hi
         break;
       case COSMO_HIP_BOX: for (long long i = 0; i < d; ++i) meta[o + i] = 3u | ((uint32_t)(boxp + i) << 2); boxp += d; break;
       case COSMO_HIP_SOC: soc_off.push_back((int)o); soc_dim.push_back((int)d); break;
+      case COSMO_HIP_EXP: case COSMO_HIP_DUAL_EXP: case COSMO_HIP_POW: case COSMO_HIP_DUAL_POW:
+        c3_off.push_back((int)o); c3_kind.push_back((int)C.type[k]); c3_alpha.push_back(k < C.param.size() ? C.param[k] : R(0.0)); break;
     }
   }
+  D.n3 = (int)c3_off.size();
+  if ((rc = bup(b, &D.c3_off, c3_off)) || (rc = bup(b, &D.c3_kind, c3_kind)) || (rc = bup(b, &D.c3_alpha, c3_alpha))) return rc;
   b->cls_host.assign((size_t)nprob * m, 0);
   const real big = p->cosmo_infty_min_scaling;
   for (int k = 0; k < nprob; ++k) {

@@ -372,7 +372,8 @@ end
 # ---------------------------------------------------------------------------------------------------------------------
 # Batches of independent problems with identical dimensions and cone structure (BASELINE config 3): what a user loop
 # `for ws in models; COSMO.optimize!(ws); end` computes, solved concurrently -- one persistent workgroup per problem
-# (cosmo_hip_batch_*).  Supported cones: ZeroSet, Nonnegatives, Box, SecondOrderCone, PsdCone / PsdConeTriangle of side <= 64; CG KKT solver;
+# (cosmo_hip_batch_*).  Supported cones: ZeroSet, Nonnegatives, Box, SecondOrderCone, PsdCone / PsdConeTriangle of side <= 64, the exponential /
+# power cones and their duals; CG KKT solver;
 # EmptyAccelerator or the default AndersonAccelerator (mem <= 16): the accelerated loop runs inside the persistent kernels.
 # Per problem the unchanged reference code does the scaling / classification (setup!, src/setup.jl:18-42) and the epilogue
 # (src/solver.jl:167-201); the loop of src/solver.jl:137-176 runs on the device for all problems at once.
@@ -421,8 +422,9 @@ function optimize_hip_batch!(models::Vector{COSMO.Workspace{T}}; device::Integer
             end
         end
         types = Int32[cone_type(s) for s in ws1.p.C.sets]; dims = Int64[s.dim for s in ws1.p.C.sets]
-        GC.@preserve types dims bl bu bcheck(ccall((:cosmo_hip_batch_set_cones, LIBT), Int32, (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int64}, Ptr{T}, Ptr{T}),
-            b, length(types), types, dims, isempty(bl) ? C_NULL : pointer(bl), isempty(bu) ? C_NULL : pointer(bu)))
+        cparams = T[cone_param(s) for s in ws1.p.C.sets]        # alpha of the power cones (shared by the problems of a batch)
+        GC.@preserve types dims bl bu cparams bcheck(ccall((:cosmo_hip_batch_set_cones_ex, LIBT), Int32, (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int64}, Ptr{T}, Ptr{T}, Ptr{T}),
+            b, length(types), types, dims, isempty(bl) ? C_NULL : pointer(bl), isempty(bu) ? C_NULL : pointer(bu), cparams))
         ap = accel_params_from(settings)                     # _make_accelerator! (src/setup.jl:10-16) for every problem; before set_params
         ap === nothing || bcheck(ccall((:cosmo_hip_batch_set_accelerator, LIBT), Int32, (Ptr{Cvoid}, Ref{AccelParams}), b, Ref(ap)))
         prm = Ref(params_from(settings, KKT_CG; tol_constant = tol_constant, tol_exponent = tol_exponent))

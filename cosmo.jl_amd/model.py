@@ -768,8 +768,9 @@ def prepare_batch(models: Sequence[Model], device: int):
     for md in models:
         if not md.is_assembled:
             raise RuntimeError("The model has to be assembled! / set! before optimize!() can be called.")
-        if (md.n, md.m) != (n, m) or [K.kind for K in md.sets] != kinds or [K.dim for K in md.sets] != dims:
-            raise ValueError("optimize_batch: all problems of a batch must share n, m and the cone structure")
+        if (md.n, md.m) != (n, m) or [K.kind for K in md.sets] != kinds or [K.dim for K in md.sets] != dims or \
+                [getattr(K, "alpha", 0.0) for K in md.sets] != [getattr(K, "alpha", 0.0) for K in models[0].sets]:
+            raise ValueError("optimize_batch: all problems of a batch must share n, m and the cone structure (kinds, dimensions, power-cone exponents)")
     st = models[0].settings
     for md in models[1:]:
         if md.settings != st:
@@ -786,7 +787,8 @@ def prepare_batch(models: Sequence[Model], device: int):
         B.set_problem(k, md.P, md.q, md.A, md.b)
         B.set_scaling(k, md.sm.Dinv, md.sm.Einv, md.sm.cinv)
         bl += [K.l for K in md.sets if K.kind == _ffi.BOX]; bu += [K.u for K in md.sets if K.kind == _ffi.BOX]
-    B.set_cones(kinds, dims, np.concatenate(bl) if bl else None, np.concatenate(bu) if bu else None)
+    B.set_cones(kinds, dims, np.concatenate(bl) if bl else None, np.concatenate(bu) if bu else None,
+                cone_param=[getattr(K, "alpha", 0.0) for K in models[0].sets])
     B.set_params(_params_from_settings(None, st))
     B.set_iterates(np.concatenate([md.x for md in models]), np.concatenate([md.s for md in models]),
                    np.concatenate([md.mu for md in models]))

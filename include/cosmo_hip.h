@@ -401,10 +401,15 @@ int32_t cosmo_hip_batch_set_problem(cosmo_hip_batch* b, int64_t k, const int64_t
                                     const cosmo_hip_real* P_nzval, const int64_t* A_colptr, const int64_t* A_rowval,
                                     const cosmo_hip_real* A_nzval, const cosmo_hip_real* q, const cosmo_hip_real* bvec);
 /* cone structure shared by all problems; box_l / box_u hold nprob * (#Box rows) entries, problem-major.  Cone kinds of batch mode: ZeroSet,
- * Nonnegatives, Box, SecondOrderCone, PsdCone / PsdConeTriangle of side <= 64 (src/convexset.jl:25-28, 71-74, 100-114, 303-321, 402-412, 844-847);
- * anything else returns COSMO_HIP_ERR_UNSUPPORTED (one handle per problem serves it) */
+ * Nonnegatives, Box, SecondOrderCone, PsdCone / PsdConeTriangle of side <= 64 (src/convexset.jl:25-28, 71-74, 100-114, 303-321, 402-412, 844-847)
+ * and, through cosmo_hip_batch_set_cones_ex, the exponential / power cones; anything else returns COSMO_HIP_ERR_UNSUPPORTED (one handle per
+ * problem serves it) */
 int32_t cosmo_hip_batch_set_cones(cosmo_hip_batch* b, int64_t ncones, const int32_t* type, const int64_t* dim,
                                   const cosmo_hip_real* box_l, const cosmo_hip_real* box_u);
+/* the same with the per-cone parameter of cosmo_hip_set_cones_ex (alpha of PowerCone / DualPowerCone; NULL = none): additionally
+ * ExponentialCone, DualExponentialCone, PowerCone, DualPowerCone (src/convexset.jl:497-779) -- one thread of the problem's workgroup per cone */
+int32_t cosmo_hip_batch_set_cones_ex(cosmo_hip_batch* b, int64_t ncones, const int32_t* type, const int64_t* dim,
+                                     const cosmo_hip_real* box_l, const cosmo_hip_real* box_u, const cosmo_hip_real* cone_param);
 int32_t cosmo_hip_batch_set_scaling(cosmo_hip_batch* b, int64_t k, const cosmo_hip_real* Dinv, const cosmo_hip_real* Einv, double cinv);
 /* The reference's accelerator for every problem of the batch (replaces _make_accelerator!, src/setup.jl:10-16, once per model): the whole
  * accelerated loop of src/solver.jl:140-165 runs inside the problem's persistent workgroup -- acceleration_pre! (update! / accelerate! of the

@@ -177,3 +177,61 @@ def test_power_cone_goldens():
                          [cj.Constraint(E3, np.zeros(3), cj.DualPowerCone(0.8)), cj.Constraint(A2, [-0.8, -0.2], cj.ZeroSet)],
                          [O.Constraint(E3, np.zeros(3), O.DualPowerCone(0.8)), O.Constraint(A2, [-0.8, -0.2], O.ZeroSet(2))])
     assert res.status == "Solved" and abs(res.obj_val + 1.0) < 1e-3                     # pow_cone.jl:136-137
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# batch mode (round 4): the 3-dimensional cones inside the persistent batch kernels (csrc/cone3.h called from csrc/batch.hip), projection AND
+# certificates -- the reference's goldens above, every one as a batch of three copies (the third with a scaled objective: its own rho / status)
+# ---------------------------------------------------------------------------------------------------------------------
+def _batch_golden(P, q, cons, want, obj=None, atol=1e-2, **st):
+    mods = []
+    for scale in (1.0, 1.0, 2.0):
+        md = cj.Model(); cj.assemble(md, P * scale, np.asarray(q, dtype=float) * scale, cons(), settings=cj.Settings(**st)); mods.append(md)
+    res = cj.optimize_batch(mods)
+    one = cj.Model(); cj.assemble(one, P, np.asarray(q, dtype=float), cons(), settings=cj.Settings(**st))
+    r1 = cj.optimize(one)
+    for k, r in enumerate(res):
+        assert r.status == want == r1.status, (k, r.status, r1.status)
+        if obj is not None:
+            assert abs(r.obj_val / (2.0 if k == 2 else 1.0) - obj) < (atol if k < 2 else 5 * atol), (k, r.obj_val)     # (the scaled copy stops on its own trajectory)
+    assert abs(res[0].iter - r1.iter) <= 25 and res[0].iter == res[1].iter
+    if obj is not None:
+        assert np.linalg.norm(res[0].x - r1.x) <= 1e-3 * max(1.0, np.linalg.norm(r1.x))
+    return res
+
+
+@pytest.mark.parametrize("env", [dict(), dict(COSMO_HIP_BATCH_REG="0"), dict(COSMO_HIP_BATCH_LDS="0")])
+def test_batch_exp_and_power_cone_goldens(env, monkeypatch):
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    A2 = sp.csc_matrix(np.array([[0, 1.0, 0], [0, 0, 1]])); b2 = np.array([-1.0, -math.exp(5)])
+    _batch_golden(P0, [-1.0, 0, 0], lambda: [cj.Constraint(E3, np.zeros(3), cj.ExponentialCone), cj.Constraint(A2, b2, cj.ZeroSet)], "Solved", -5.0,
+                  eps_abs=1e-4, eps_rel=1e-4)                                                                           # exp_cone.jl:19-42
+    _batch_golden(P0, [1.0, 0, 0], lambda: [cj.Constraint(E3, np.zeros(3), cj.ExponentialCone), cj.Constraint(np.array([[0, -1.0, 0]]), [-1.0], cj.ZeroSet),
+                                           cj.Constraint(np.array([[0, 0, -1.0]]), [1.0], cj.ZeroSet)], "Primal_infeasible")   # exp_cone.jl:47-76
+    _batch_golden(P0, [0, 0, -1.0], lambda: [cj.Constraint(E3, np.zeros(3), cj.ExponentialCone)], "Dual_infeasible")           # exp_cone.jl:106-124
+    A3 = sp.csc_matrix(np.array([[1.0, 0, 0], [0, 0, 1]])); b3 = np.array([1.0, -math.exp(5)])
+    _batch_golden(P0, [0, 1.0, 0], lambda: [cj.Constraint(E3, np.zeros(3), cj.DualExponentialCone), cj.Constraint(A3, b3, cj.ZeroSet)], "Solved", -6.0,
+                  atol=1e-3)                                                                                            # exp_cone.jl:154-155
+    n = 6
+    A1 = sp.csc_matrix((np.ones(3), (np.arange(3), np.arange(3))), shape=(3, n))
+    A4 = sp.csc_matrix((np.ones(3), (np.arange(3), np.arange(3, 6))), shape=(3, n))
+    a3 = np.array([[1.0, 2, 0, 3, 0, 0]]); a4 = np.array([[0, 0, 0, 0, 1.0, 0]])
+    q = np.zeros(n); q[2] = q[5] = -1.0
+    _batch_golden(sp.csc_matrix((n, n)), q, lambda: [cj.Constraint(A1, np.zeros(3), cj.PowerCone(0.6)), cj.Constraint(A4, np.zeros(3), cj.PowerCone(0.1)),
+                                                    cj.Constraint(a3, [-3.0], cj.ZeroSet), cj.Constraint(a4, [-1.0], cj.ZeroSet)], "Solved", -1.8458,
+                  atol=1e-3, max_iter=5000)                                                                             # pow_cone.jl:53-54
+    _batch_golden(P0, [0, 0, -1.0], lambda: [cj.Constraint(E3, np.zeros(3), cj.PowerCone(0.8)), cj.Constraint(E3, [-1.0, -1, -2], cj.ZeroSet)],
+                  "Primal_infeasible")                                                                                  # pow_cone.jl:94
+    _batch_golden(P0, [0, 0, 1.0], lambda: [cj.Constraint(E3, np.zeros(3), cj.PowerCone(0.8))], "Dual_infeasible")        # pow_cone.jl:111
+
+
+def test_batch_power_cone_api():
+    B = F.Batch(1, 3, 3, 0)
+    with pytest.raises(F.CosmoHipError) as e:
+        B.set_cones([F.POW], [3], cone_param=[1.5])
+    assert e.value.code == 1
+    with pytest.raises(F.CosmoHipError) as e:
+        B.set_cones([F.EXP], [4])
+    assert e.value.code in (1, 6)
+    B.close()
