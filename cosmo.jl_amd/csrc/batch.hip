@@ -10,7 +10,7 @@
 // Cone support in batch mode: ZeroSet, Nonnegatives, Box, SecondOrderCone and PsdCone / PsdConeTriangle of side <= 64 (round 4: side <= 16 by the
 // wave-level Jacobi projection of psd16.h, 17 .. 64 by the workgroup-level block Jacobi of psdwg.h -- the routines the single-problem path uses for
 // such cones, called from the problem's persistent workgroup: batches of small SDPs, src/convexset.jl:402-412 inside the composite projection
-// :885-891); larger PSD cones take the single-problem path.  The
+// :885-891) and ExponentialCone / PowerCone / their duals (cone3.h, one thread per cone); larger PSD cones take the single-problem path.  The
 // infeasibility certificates run between persistent launches (k_batch_inf_capture / k_batch_inf_check below).
 // Accelerator (round 4): with cosmo_hip_batch_set_accelerator the loop is the reference's accelerated loop (src/solver.jl:140-165,
 // src/accelerator_interface.jl:58-116) per problem -- Anderson update / accelerate, safeguarding, deferred rho updates and certificates -- all inside
