@@ -1242,8 +1242,10 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
 // launch at those iterations (cosmo_hip_batch_optimize):  ... iteration k ci | k_batch_inf_capture | iteration k ci + 1 |
 // k_batch_inf_check | ...   Both kernels work on the state the persistent kernels leave in global memory (w, w_prev, s, rho), one
 // workgroup per problem, all scalar tests inside the workgroup in the reference's order; a decided problem gets its status (and
-// cost = +-Inf, solver.jl:339,345) and is skipped by every later launch.  Cones: ZeroSet / Nonnegatives / Box / SecondOrderCone
-// (the cones of batch mode): in_dual, in_pol_recc, support_function of src/convexset.jl:30-36, 76-82, 116-122, 850-861, 928-936.
+// cost = +-Inf, solver.jl:339,345) and is skipped by every later launch.  Cones: ZeroSet / Nonnegatives / Box / SecondOrderCone: in_dual,
+// in_pol_recc, support_function of src/convexset.jl:30-36, 76-82, 116-122, 850-861, 928-936; PSD cones of side <= 64: the smallest-eigenvalue
+// tests of :415-424 (psd16.h / psdwg.h); exponential / power cones and duals: in_dual of the negated vector (:603-605, 724-726, 772; cone3.h).
+// Accelerated batches run the check kernel only on the problems whose workgroup asked for it (BAa::need_inf).
 // ---------------------------------------------------------------------------------------------------------------------
 // delta_y at the top of the iteration that follows a flagged one: dy = mu = rho .* (w_prev_s - s)            (solver.jl:145-148)
 __global__ __launch_bounds__(COSMO_BS) void k_batch_inf_capture(BatchDev D) {
