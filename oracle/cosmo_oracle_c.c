@@ -1,7 +1,7 @@
 /* cosmo_oracle_c.c -- TEST / BASELINE INFRASTRUCTURE, not part of the product (only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg may load it).  A plain-C restatement of the reference's ADMM loop (COSMO.jl v0.8.11) for the configurations whose
  * cones are ZeroSet / Nonnegatives / Box / SecondOrderCone / PsdCone / PsdConeTriangle and whose KKT solver is the CG reduced solver --
- * i.e. all five BASELINE configs -- compiled with gcc -O3 so that the CPU number quoted next to the GPU number comes from compiled
+ * i.e. all five BASELINE configs (since round 4 optionally with the reference's default AndersonAccelerator and its safeguarding) -- compiled with gcc -O3 so that the CPU number quoted next to the GPU number comes from compiled
  * code, as the (Julia) reference's would.  The PSD projections call LAPACK ?syevr and BLAS ?syrk exactly as the reference does
  * (src/convexset.jl:163-189, 243-263) through function pointers handed in by the loader (SciPy's bundled OpenBLAS: the image has no
  * liblapack to link against).
@@ -25,6 +25,10 @@ typedef struct {
   double rho_min, rho_max, rho_eq_over_rho_ineq, adaptive_rho_tolerance, cinv;
   int64_t max_iter, adaptive_rho_max_adaptions;
   int32_t check_termination, adaptive_rho, adaptive_rho_interval, unscale;
+  /* accelerator (src/settings.jl:136-138): accel != 0 = AndersonAccelerator{T, Type2{QRDecomp}, RestartedMemory, NoRegularizer} */
+  int32_t accel, acc_mem, acc_min_mem, safeguard;
+  int64_t acc_start_iter;            /* 2 = ImmediateActivation, k = IterActivation(k) */
+  double safeguard_tol;
 } oc_params;
 
 typedef struct {
@@ -32,6 +36,7 @@ typedef struct {
   int32_t n_rho_updates;
   int64_t iter, cg_iters_total;
   double cost, r_prim, r_dual, max_norm_prim, max_norm_dual, rho, iter_time;
+  int64_t safeguarding_iter, num_accelerated;   /* iter = loop index + safeguarding_iter (total_iter, src/solver.jl:196) */
 } oc_result;
 
 /* Element type of the loop: double (COSMO.Model{Float64}) by default, float with -DOC_FLOAT (the Float32 instantiation that checks
@@ -173,6 +178,72 @@ static void make_rho(const prob* W, const oc_params* p, oc_real rho) {   /* set_
 
 /* ncones slice cones (SOC / PSD; kind per row 0 on their rows) with LAPACK / BLAS entry points `syevr`, `syrk` (NULL when there is no PSD cone);
  * rank_out / branch_out: nnz_lambda / SOC branch id of the LAST projection per cone (NULL to skip); proj_time_out: seconds spent in the cone loop */
+/* ---- AndersonAccelerator (COSMOAccelerators.jl, external to the reference tree: restated from the published algorithm exactly as
+ * oracle/cosmo_oracle.py: class AndersonAccelerator does -- update!: f = x - g, G_j = g - g_last, v = f - f_last, modified Gram-Schmidt
+ * column by column; accelerate!: eta = R \ (Q' f), rejected if R is singular / not finite or ||eta||_2 > 1e4, else g -= G eta) ---- */
+typedef struct {
+  int64_t dim; int mem, min_mem, iter, init_phase, success;
+  int64_t num_accelerated, num_restarts;
+  oc_real *G, *Q, *Rm, *f, *f_last, *g_last, *eta, *v, *rhs;
+} aa_t;
+static void aa_restart(aa_t* a) {                                     /* CA.restart! -> empty_history! */
+  memset(a->G, 0, sizeof(oc_real) * (size_t)a->dim * a->mem); memset(a->Q, 0, sizeof(oc_real) * (size_t)a->dim * a->mem);
+  memset(a->Rm, 0, sizeof(oc_real) * (size_t)a->mem * a->mem);
+  memset(a->f, 0, sizeof(oc_real) * (size_t)a->dim); memset(a->f_last, 0, sizeof(oc_real) * (size_t)a->dim); memset(a->g_last, 0, sizeof(oc_real) * (size_t)a->dim);
+  a->iter = 0; a->init_phase = 1;
+}
+static void aa_update(aa_t* a, const oc_real* g, const oc_real* x) {
+  const int64_t N = a->dim;
+  for (int64_t i = 0; i < N; ++i) a->f[i] = x[i] - g[i];
+  if (a->init_phase) {
+    memcpy(a->g_last, g, sizeof(oc_real) * (size_t)N); memcpy(a->f_last, a->f, sizeof(oc_real) * (size_t)N);
+    a->init_phase = 0;
+    return;
+  }
+  int j = a->iter % a->mem;
+  if (j == 0 && a->iter != 0) {                                       /* RestartedMemory */
+    memset(a->G, 0, sizeof(oc_real) * (size_t)N * a->mem); memset(a->Q, 0, sizeof(oc_real) * (size_t)N * a->mem);
+    memset(a->Rm, 0, sizeof(oc_real) * (size_t)a->mem * a->mem);
+    a->iter = 0; a->num_restarts += 1;
+  }
+  oc_real* Gj = a->G + (size_t)j * N; oc_real* v = a->v;
+  for (int64_t i = 0; i < N; ++i) { Gj[i] = g[i] - a->g_last[i]; v[i] = a->f[i] - a->f_last[i]; }
+  memcpy(a->g_last, g, sizeof(oc_real) * (size_t)N); memcpy(a->f_last, a->f, sizeof(oc_real) * (size_t)N);
+  for (int i = 0; i < j; ++i) {                                       /* qr!: modified Gram-Schmidt */
+    const oc_real* Qi = a->Q + (size_t)i * N;
+    const oc_real r = dot(Qi, v, N);
+    a->Rm[(size_t)j * a->mem + i] = r;                                /* R[i, j], column-major */
+    for (int64_t e = 0; e < N; ++e) v[e] = v[e] - r * Qi[e];
+  }
+  const oc_real nv = nrm2(v, N);
+  a->Rm[(size_t)j * a->mem + j] = nv;
+  oc_real* Qj = a->Q + (size_t)j * N;
+  for (int64_t e = 0; e < N; ++e) Qj[e] = v[e] / nv;
+  a->iter += 1;
+}
+static void aa_accelerate(aa_t* a, oc_real* g) {
+  const int64_t N = a->dim;
+  a->success = 0;
+  const int l = a->iter < a->mem ? a->iter : a->mem;
+  if (l < a->min_mem) return;
+  for (int c = 0; c < l; ++c) a->rhs[c] = dot(a->Q + (size_t)c * N, a->f, N);
+  for (int c = 0; c < l; ++c)
+    for (int r = 0; r <= c; ++r) { const oc_real x = a->Rm[(size_t)c * a->mem + r]; if (!(RFABS(x) < (oc_real)INFINITY)) return; }       /* Inf or NaN */
+  for (int c = 0; c < l; ++c) if (a->Rm[(size_t)c * a->mem + c] == R(0.0)) return;      /* trtrs info > 0: exactly singular */
+  oc_real nrm = R(0.0);
+  for (int i = l - 1; i >= 0; --i) {                                  /* back substitution */
+    oc_real sacc = R(0.0);
+    for (int k = i + 1; k < l; ++k) sacc += a->Rm[(size_t)k * a->mem + i] * a->eta[k];
+    a->eta[i] = (a->rhs[i] - sacc) / a->Rm[(size_t)i * a->mem + i];
+    nrm += a->eta[i] * a->eta[i];
+  }
+  nrm = RSQRT(nrm);
+  if (!(nrm <= R(1e4))) return;                                       /* also NaN */
+  for (int64_t i = 0; i < N; ++i) { oc_real sacc = R(0.0); for (int c = 0; c < l; ++c) sacc += a->G[(size_t)c * N + i] * a->eta[c]; g[i] -= sacc; }   /* g -= G[:, 1:l] eta */
+  a->num_accelerated += 1;
+  a->success = 1;
+}
+
 int32_t cosmo_oracle_c_run_cones(int64_t n, int64_t m, const int64_t* Pp, const int64_t* Pi, const oc_real* Px, const int64_t* Ap, const int64_t* Ai,
                                  const oc_real* Ax, const oc_real* q, const oc_real* b, const oc_real* Dinv, const oc_real* Einv, const int32_t* cls,
                                  const int32_t* kind, const oc_real* bl, const oc_real* bu, const oc_params* prm, const oc_real* rho_vec0,
@@ -288,10 +359,27 @@ int32_t cosmo_oracle_c_run_cones(int64_t n, int64_t m, const int64_t* Pp, const 
   }
 
   SOLVE_AND_W()                                                           /* init step (solver.jl:137-138) */
-  int64_t it = 0;
+  int64_t it = 0, sg = 0;
   int rho_update_due = 0;
-  while (it < p.max_iter) {
+  aa_t aa;
+  memset(&aa, 0, sizeof aa);
+  oc_real* aa_buf = NULL;
+  int acc_active = 0;
+  if (p.accel) {                                                          /* _make_accelerator! (setup.jl:10-16): mem = min(mem, dim) */
+    aa.dim = N; aa.mem = (int)((int64_t)p.acc_mem < N ? p.acc_mem : N); if (aa.mem < 1) aa.mem = 1;
+    aa.min_mem = p.acc_min_mem; aa.init_phase = 1;
+    const size_t Nm = (size_t)N * aa.mem;
+    aa_buf = (oc_real*)calloc(2 * Nm + (size_t)aa.mem * aa.mem + 4 * (size_t)N + 2 * (size_t)aa.mem + 8, sizeof(oc_real));
+    if (!aa_buf) { free(buf); free(psd_buf); return 1; }
+    aa.G = aa_buf; aa.Q = aa.G + Nm; aa.Rm = aa.Q + Nm; aa.f = aa.Rm + (size_t)aa.mem * aa.mem; aa.f_last = aa.f + N; aa.g_last = aa.f_last + N;
+    aa.v = aa.g_last + N; aa.eta = aa.v + N; aa.rhs = aa.eta + aa.mem;
+  }
+  while (it + sg < p.max_iter) {                                          /* :140 */
     it += 1;
+    if (p.accel) {                                                        /* acceleration_pre! (accelerator_interface.jl:58-76) */
+      if (!acc_active && it >= p.acc_start_iter) acc_active = 1;
+      if (acc_active) { aa_update(&aa, w, w_prev); aa_accelerate(&aa, w); }
+    }
     memcpy(w_prev, w, sizeof(oc_real) * (size_t)N);                       /* :151 */
     for (int64_t i = 0; i < m; ++i) {                                    /* admm_z! (:7-21) */
       oc_real v = w[n + i];
@@ -306,13 +394,13 @@ int32_t cosmo_oracle_c_run_cones(int64_t n, int64_t m, const int64_t* Pp, const 
     if (ncones > 0) {                                                    /* project!(s, C): the slice cones (convexset.jl:885-891) */
       struct timespec p0, p1;
       clock_gettime(CLOCK_MONOTONIC, &p0);
-      if (project_cones(&cx, s) != 0) { free(buf); free(psd_buf); return 3; }
+      if (project_cones(&cx, s) != 0) { free(buf); free(psd_buf); free(aa_buf); return 3; }
       clock_gettime(CLOCK_MONOTONIC, &p1);
       proj_time += (double)(p1.tv_sec - p0.tv_sec) + 1e-9 * (double)(p1.tv_nsec - p0.tv_nsec);
     }
     if (p.adaptive_rho && p.adaptive_rho_interval > 0 && (it % p.adaptive_rho_interval) == 0 && (n_rho - 1) < p.adaptive_rho_max_adaptions)
       rho_update_due = 1;
-    if (rho_update_due) {                                                /* apply_rho_adaptation_rules! (:242-282) */
+    if (rho_update_due && !(p.accel && aa.success)) {                    /* apply_rho_adaptation_rules! (:242-282); update_suggested (:284-292) */
       rho_update_due = 0;
       for (int64_t i = 0; i < m; ++i) mu[i] = W.rho[i] * (w_prev[n + i] - s[i]);
       oc_real sr_p = r_prim, sr_d = r_dual, smp = mnp, smd = mnd;
@@ -326,10 +414,31 @@ int32_t cosmo_oracle_c_run_cones(int64_t n, int64_t m, const int64_t* Pp, const 
         make_rho(&W, &p, rho);
         if (rho_updates_out && n_rho < rho_updates_cap) rho_updates_out[n_rho] = rho;
         n_rho += 1;
+        if (p.accel) aa_restart(&aa);                                   /* :272-275: the ADMM operator changed */
         for (int64_t i = 0; i < m; ++i) w[n + i] = (R(1.0) / W.rho[i]) * mu[i] + s[i];
       }
     }
     SOLVE_AND_W()
+    if (p.accel && acc_active && aa.success && p.safeguard) {            /* acceleration_post! (accelerator_interface.jl:85-117) */
+      const oc_real nrm_tol = nrm2(aa.f, N) * R(p.safeguard_tol);
+      for (int64_t i = 0; i < N; ++i) aa.f[i] = w_prev[i] - w[i];          /* compute_accelerated_res_norm! (:123-126) */
+      if (nrm2(aa.f, N) > nrm_tol) {
+        memcpy(w_prev, aa.g_last, sizeof(oc_real) * (size_t)N); memcpy(w, aa.g_last, sizeof(oc_real) * (size_t)N);   /* reset_accelerated_vector! */
+        for (int64_t i = 0; i < m; ++i) {
+          oc_real v = w[n + i];
+          switch (kind[i]) {
+            case 1: v = R(0.0); break;
+            case 2: v = (v != v) ? v : ((v > R(0.0)) ? v : R(0.0)); break;
+            case 3: v = (v < bl[i]) ? bl[i] : ((v > bu[i]) ? bu[i] : v); break;
+            default: break;
+          }
+          s[i] = v;
+        }
+        if (ncones > 0 && project_cones(&cx, s) != 0) { free(buf); free(psd_buf); free(aa_buf); return 3; }
+        SOLVE_AND_W()
+        sg += 1;
+      }
+    }
     if ((it % p.check_termination) == 0 || it == 1) {                    /* check_termination! (:306-323) */
       for (int64_t i = 0; i < m; ++i) mu[i] = W.rho[i] * (w_prev[n + i] - s[i]);
       RESIDUALS(p.unscale)
@@ -341,11 +450,13 @@ int32_t cosmo_oracle_c_run_cones(int64_t n, int64_t m, const int64_t* Pp, const 
   }
   for (int64_t i = 0; i < m; ++i) mu[i] = W.rho[i] * (w_prev[n + i] - s[i]);    /* :167 */
   clock_gettime(CLOCK_MONOTONIC, &t1);
-  if (it == p.max_iter) { RESIDUALS(p.unscale) status = 2; }                    /* :173-176 */
+  if (it + sg == p.max_iter) { RESIDUALS(p.unscale) status = 2; }               /* :173-176 */
   for (int64_t j = 0; j < n; ++j) x_io[j] = w_prev[j];
   memcpy(s_io, s, sizeof(oc_real) * (size_t)m);
   memcpy(mu_io, mu, sizeof(oc_real) * (size_t)m);
-  res->status = status; res->n_rho_updates = n_rho; res->iter = it; res->cg_iters_total = cg_total;
+  res->status = status; res->n_rho_updates = n_rho; res->iter = it + sg; res->cg_iters_total = cg_total;    /* total_iter (:196) */
+  res->safeguarding_iter = sg; res->num_accelerated = aa.num_accelerated;
+  free(aa_buf);
   res->cost = cost; res->r_prim = r_prim; res->r_dual = r_dual; res->max_norm_prim = mnp; res->max_norm_dual = mnd; res->rho = rho;
   res->iter_time = (oc_real)(t1.tv_sec - t0.tv_sec) + R(1e-9) * (oc_real)(t1.tv_nsec - t0.tv_nsec);
   free(buf);

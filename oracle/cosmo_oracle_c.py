@@ -3,7 +3,8 @@
 TEST / BASELINE INFRASTRUCTURE -- only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 Setup (Ruiz scaling, constraint classification, rho vector: src/setup.jl:18-64) is done by the NumPy oracle's `Workspace`;
 `run(ws)` then executes the loop of src/solver.jl:137-176 in compiled C on that workspace's scaled data.  Supported: ZeroSet,
-Nonnegatives, Box, SecondOrderCone, PsdCone and PsdConeTriangle, CG reduced KKT solver, no accelerator -- all five BASELINE configs.
+Nonnegatives, Box, SecondOrderCone, PsdCone and PsdConeTriangle, CG reduced KKT solver -- all five BASELINE configs -- optionally with the
+reference's default AndersonAccelerator + safeguarding (Settings(accelerator="anderson"); no infeasibility certificates in this loop).
 The PSD projections call LAPACK ?syevr / BLAS ?syrk (src/convexset.jl:163-189, 243-263) through the function pointers SciPy exports for
 its bundled OpenBLAS (scipy.linalg.cython_lapack / cython_blas); threadpoolctl limits that library's threads as it would Julia's BLAS.
 """
@@ -19,12 +20,15 @@ class Params(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("sigma", "alpha", "rho", "eps_abs", "eps_rel", "tol_constant", "tol_exponent", "rho_min", "rho_max",
                                            "rho_eq_over_rho_ineq", "adaptive_rho_tolerance", "cinv")] + \
                [("max_iter", C.c_int64), ("adaptive_rho_max_adaptions", C.c_int64), ("check_termination", C.c_int32), ("adaptive_rho", C.c_int32),
-                ("adaptive_rho_interval", C.c_int32), ("unscale", C.c_int32)]
+                ("adaptive_rho_interval", C.c_int32), ("unscale", C.c_int32),
+                ("accel", C.c_int32), ("acc_mem", C.c_int32), ("acc_min_mem", C.c_int32), ("safeguard", C.c_int32), ("acc_start_iter", C.c_int64),
+                ("safeguard_tol", C.c_double)]
 
 
 class CResult(C.Structure):
     _fields_ = [("status", C.c_int32), ("n_rho_updates", C.c_int32), ("iter", C.c_int64), ("cg_iters_total", C.c_int64)] + \
-               [(k, C.c_double) for k in ("cost", "r_prim", "r_dual", "max_norm_prim", "max_norm_dual", "rho", "iter_time")]
+               [(k, C.c_double) for k in ("cost", "r_prim", "r_dual", "max_norm_prim", "max_norm_dual", "rho", "iter_time")] + \
+               [("safeguarding_iter", C.c_int64), ("num_accelerated", C.c_int64)]
 
 
 STATUS = {0: "Undetermined", 1: "Solved", 2: "Max_iter_reached", 3: "Unsolved"}
@@ -76,7 +80,9 @@ def run(ws: "O.Workspace", native=False, dtype=np.float64):
     T = np.float32 if f32 else np.float64
     CT = C.c_float if f32 else C.c_double
     st = ws.st
-    assert st.kkt_solver.lower() == "cg" and ws.accelerator is None
+    assert st.kkt_solver.lower() == "cg"
+    accel = ws.accelerator is not None                     # the reference's default AndersonAccelerator (Immediate / IterActivation; no certificates in this loop)
+    assert not accel or st.acc_start_accuracy is None
     n, m = ws.n, ws.m
     kind = np.zeros(m, np.int32); bl = np.zeros(m, T); bu = np.zeros(m, T)
     off = 0
@@ -105,7 +111,8 @@ def run(ws: "O.Workspace", native=False, dtype=np.float64):
     Ap = A.indptr.astype(np.int64); Ai = A.indices.astype(np.int64); Ax = np.ascontiguousarray(A.data, T)
     prm = Params(st.sigma, st.alpha, ws.rho, st.eps_abs, st.eps_rel, st.tol_constant, st.tol_exponent, st.RHO_MIN, st.RHO_MAX,
                  st.RHO_EQ_OVER_RHO_INEQ, st.adaptive_rho_tolerance, ws.sm.cinv, st.max_iter, st.adaptive_rho_max_adaptions,
-                 st.check_termination, int(bool(st.adaptive_rho)), st.adaptive_rho_interval, int(st.scaling != 0))
+                 st.check_termination, int(bool(st.adaptive_rho)), st.adaptive_rho_interval, int(st.scaling != 0),
+                 int(accel), int(getattr(st, "acc_mem", 15)), int(getattr(st, "acc_min_mem", 3)), int(bool(st.safeguard)), int(st.acc_start_iter), float(st.safeguard_tol))
     x = ws.x.astype(T); s = ws.s.astype(T); mu = ws.mu.astype(T)
     cap = 64
     rho_updates = np.zeros(cap, T)
@@ -123,7 +130,8 @@ def run(ws: "O.Workspace", native=False, dtype=np.float64):
                                   _p(rank_out, C.c_int64), _p(branch_out, C.c_int32), C.byref(proj_time))
     if rc != 0:
         raise MemoryError("cosmo_oracle_c_run_cones failed (%d)" % rc)
-    out = dict(status=STATUS[res.status], iter=int(res.iter), cg_iters_total=int(res.cg_iters_total), obj_val=res.cost, r_prim=res.r_prim,
+    out = dict(status=STATUS[res.status], iter=int(res.iter), safeguarding_iter=int(res.safeguarding_iter), num_accelerated=int(res.num_accelerated),
+               cg_iters_total=int(res.cg_iters_total), obj_val=res.cost, r_prim=res.r_prim,
                r_dual=res.r_dual, max_norm_prim=res.max_norm_prim, max_norm_dual=res.max_norm_dual, iter_time=res.iter_time, proj_time=proj_time.value,
                rho_updates=list(rho_updates[:min(cap, res.n_rho_updates)]), x_scaled=x, s_scaled=s, mu_scaled=mu,
                psd_rank={ic: int(rank_out[j]) for j, ic in enumerate(cone_index) if ck[j] != CK_SOC},

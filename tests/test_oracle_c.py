@@ -104,3 +104,57 @@ def test_c_oracle_chordal_sdp_and_closest_correlation(OC):
     r, c = _pair(OC, prob)
     assert r.status == "Solved"
     _check(r, c, tol=1e-6)
+
+
+def test_c_oracle_accelerated_loop_against_the_numpy_oracle(OC):
+    """The reference's default AndersonAccelerator + safeguarding in the compiled loop (round 4) against the NumPy oracle's accelerated loop: the
+    simple-QP golden (simple.jl:45-47 under AccelerationTests/anderson_accelerator.jl:37-43), rho adaption with restarts
+    (max_rho_adaption.jl:19-32), random QPs / SOCPs / a small SDP with a tight KKT solve.  An accelerated trajectory amplifies the rounding of the
+    inner products (sequential here, pairwise / BLAS there), so: same status, solution and objective at the solver tolerance, the loop index within
+    one check interval on short runs, accelerated-step counts within 10 %."""
+    import scipy.sparse as sp
+    # simple QP golden
+    P = sp.csc_matrix(np.array([[4.0, 1], [1, 2]])); q = np.array([1.0, 1])
+    A = np.array([[1.0, 1], [1, 0], [0, 1]]); l = np.array([1.0, 0, 0]); u = np.array([1.0, 0.7, 0.7])
+    Ao, bo, cones = O.assemble([O.Constraint(-A, u, O.Nonnegatives(3)), O.Constraint(A, -l, O.Nonnegatives(3))])
+    for kw in (dict(), dict(adaptive_rho_interval=25, adaptive_rho_max_adaptions=2, rho=1e-6, eps_abs=1e-6, eps_rel=1e-4)):
+        st = O.Settings(kkt_solver="cg", accelerator="anderson", **kw)
+        r = O.Workspace(P, q, Ao, bo, cones, st).optimize()
+        c = OC.run(O.Workspace(P, q, Ao, bo, cones, st))
+        assert c["status"] == r.status == "Solved" and abs(c["obj_val"] - 1.88) < 1e-3 and np.linalg.norm(c["x"] - [0.3, 0.7]) < 1e-3
+        assert len(c["rho_updates"]) == len(r.rho_updates) and c["num_accelerated"] > 0
+        if r.iter <= 150:                                   # (the rho = 1e-6 run takes thousands of accelerated iterations with the loose default CG: chaotic count)
+            assert abs((c["iter"] - c["safeguarding_iter"]) - (r.iter - r.safeguarding_iter)) <= 25
+    # max_iter counts the safeguarding steps (solver.jl:140,173)
+    st = O.Settings(kkt_solver="cg", accelerator="anderson", max_iter=20, eps_abs=1e-12, eps_rel=1e-12, tol_constant=1e-10, tol_exponent=0.0)
+    ws = O.Workspace(P, q, Ao, bo, cones, st); r = ws.optimize()
+    c = OC.run(O.Workspace(P, q, Ao, bo, cones, st))
+    # reference quirk kept by both: a safeguarding step in the last iteration overshoots max_iter by one and `==` (solver.jl:173) then leaves :Undetermined;
+    # whether the last candidate is declined depends on rounding
+    for it_, st_ in ((c["iter"], c["status"]), (r.iter, r.status)):
+        assert it_ in (20, 21) and st_ == ("Max_iter_reached" if it_ == 20 else "Undetermined")
+    assert abs(c["safeguarding_iter"] - r.safeguarding_iter) <= 1
+    # random problems, tight KKT solve
+    tight = dict(tol_constant=1e-10, tol_exponent=0.0, eps_abs=1e-7, eps_rel=1e-7)
+    rng = np.random.default_rng(5)
+    probs = [util.random_qp(rng, 40, 4, 30, 25, soc_dims=(5, 3), p_shift=2.0) for _ in range(6)]
+    probs.append(util.random_qp(np.random.default_rng(77), 30, 2, 8, 6, soc_dims=(4,), psd_tri_dims=(5, 9), p_shift=1.0))
+    short = 0
+    for k, p in enumerate(probs):
+        st = O.Settings(kkt_solver="cg", accelerator="anderson", **tight)
+        ws = O.Workspace(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), st); r = ws.optimize()
+        c = OC.run(O.Workspace(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), st))
+        assert c["status"] == r.status, (k, c["status"], r.status)
+        if r.status != "Solved":
+            continue
+        assert abs(c["obj_val"] - r.obj_val) <= 1e-5 * (1 + abs(r.obj_val)), k
+        assert np.linalg.norm(c["x"] - r.x) <= 1e-4 * max(1.0, np.linalg.norm(r.x)), k
+        if r.iter <= 150:
+            short += 1
+            assert abs((c["iter"] - c["safeguarding_iter"]) - (r.iter - r.safeguarding_iter)) <= 25, (k, c["iter"], r.iter)
+            assert abs(c["num_accelerated"] - ws.accelerator.num_accelerated_steps) <= max(3, 0.1 * ws.accelerator.num_accelerated_steps), k
+        # the plain compiled loop needs more iterations on the same problem
+        st0 = O.Settings(kkt_solver="cg", **tight)
+        c0 = OC.run(O.Workspace(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), st0))
+        assert c0["status"] != "Solved" or c["iter"] <= c0["iter"] + 25, (k, c["iter"], c0["iter"])
+    assert short >= 4
