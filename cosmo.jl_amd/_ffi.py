@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libcosmo_hip.so")            # cosmo_hip_real = 
 LIB_PATH_F32 = os.path.join(_HERE, "libcosmo_hip_f32.so")     # the same sources, cosmo_hip_real = float (COSMO.Model{Float32})
 
 OK = 0
-ERR_NAMES = {1: "INVALID", 2: "HIP", 3: "NOT_CONVEX", 4: "NONFINITE", 5: "EIG", 6: "UNSUPPORTED", 7: "COMM"}
+ERR_NAMES = {1: "INVALID", 2: "HIP", 5: "EIG", 6: "UNSUPPORTED", 7: "COMM"}
 
 ZERO, NONNEG, BOX, SOC, PSD_SQUARE, PSD_TRIANGLE = 0, 1, 2, 3, 4, 5
 EXP, DUAL_EXP, POW, DUAL_POW = 6, 7, 8, 9
@@ -30,7 +30,7 @@ MAX_RHO_UPDATES = 64
 NUM_KERNEL_CLASSES = 16
 
 
-from ._abi_structs import AccelParams, Params, ResultStruct   # noqa: E402  generated from include/cosmo_hip.h (tools/gen_abi_structs.py)
+from ._abi_structs import ABI_VERSION, AccelParams, Params, ResultStruct   # noqa: E402  generated from include/cosmo_hip.h (tools/gen_abi_structs.py)
 
 ACCEL_EMPTY, ACCEL_ANDERSON = 0, 1
 
@@ -166,6 +166,11 @@ def load_library(dtype=np.float64):
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = [preal if a is _PR else fnmap.get(a, a) for a in args]
+    got = int(lib.cosmo_hip_version())
+    if got != ABI_VERSION:
+        raise ImportError("%s reports ABI version %d, these bindings were generated for %d (include/cosmo_hip.h) -- rebuild the library "
+                          "(`make -C cosmo.jl_amd/csrc`) or regenerate the bindings (`python tools/gen_abi_structs.py`)"
+                          % (os.path.basename(path), got, ABI_VERSION))
     _libs[f32] = lib
     return lib
 

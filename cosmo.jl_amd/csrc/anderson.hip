@@ -278,7 +278,10 @@ extern "C" int32_t cosmo_hip_set_accelerator(cosmo_hip_handle* h, const cosmo_hi
   S->N = h->n + h->m;                           // row-sharded handle: h->m is the LOCAL row count, w = [x ; this rank's rows]
   S->sharded = h->row_shard && comm_nranks(h) > 1;
   S->dot_lo = (S->sharded && comm_rank(h) > 0) ? h->n : 0;
-  S->mem = (int)std::min<long long>(p->mem, std::max<long long>(S->N, 1));     // mem = min(mem, dim)
+  // mem = min(mem, dim) with dim = n + m of the WHOLE problem: on a row-sharded handle the local length differs per rank, and a rank with a
+  // different mem would restart on a different schedule and issue a different number of all-reduces than its peers (a hang inside RCCL)
+  const long long dim_g = S->sharded ? h->n + h->m_g : S->N;
+  S->mem = (int)std::min<long long>(p->mem, std::max<long long>(dim_g, 1));
   const size_t N = (size_t)std::max<long long>(S->N, 1);
   HIPCHK(h, hipMalloc((void**)&S->G, sizeof(real) * N * S->mem));
   HIPCHK(h, hipMalloc((void**)&S->Q, sizeof(real) * N * S->mem));

@@ -195,7 +195,7 @@ static int32_t csc_to_csr_pair(cosmo_hip_handle* h, int64_t nr, int64_t nc, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-extern "C" int32_t cosmo_hip_version(void) { return 1001; }
+extern "C" int32_t cosmo_hip_version(void) { return COSMO_HIP_ABI_VERSION; }
 
 extern "C" void cosmo_hip_default_params(cosmo_hip_params* p) {
   if (!p) return;
@@ -602,6 +602,11 @@ extern "C" int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_par
     // the opt-in Jacobi-preconditioned CG lives on the ASSEMBLED reduced operator (its diagonal is the preconditioner): no silent fallback to the
     // unpreconditioned recurrence when the operator cannot be assembled (dense A' rho A: BASELINE config 2, where Jacobi makes the count worse anyway)
     if (!h->op_fold) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "kkt_kind CG_JACOBI needs the assembled reduced operator (csrc/cg_fold.hip: A' rho A too dense here, or COSMO_HIP_OP_FOLD=0 / COSMO_HIP_CG_FUSE_DIR=0)");
+    // drop a persistent-CG state left by an earlier set_params with COSMO_HIP_CG_PERSIST=1: enqueue_solve_in_loop would otherwise run the
+    // unpreconditioned persistent recurrence against the rebuilt operator
+    h->pcg_on = false;
+    if (h->pcg_sync) { (void)hipFree(h->pcg_sync); h->pcg_sync = nullptr; }
+    if (h->pcg_u2) { (void)hipFree(h->pcg_u2); h->pcg_u2 = nullptr; }
     return COSMO_HIP_OK;
   }
   return pcg_setup(h);        // single-launch CG (opt-in)

@@ -139,7 +139,7 @@ __device__ __forceinline__ real bmax(real v, real* red) {
   __syncthreads();
   real t = red[0];
 #pragma unroll
-  for (int i = 1; i < BS / 64; ++i) t = (red[i] > t) ? red[i] : t;
+  for (int i = 1; i < BS / 64; ++i) t = (red[i] > t || red[i] != red[i]) ? red[i] : t;
   return t;
 }
 
@@ -613,7 +613,7 @@ __device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams
       const real rpn = rp / (mp + R(1e-10)), rdn = rd / (md + R(1e-10));
       const real rho0 = ctl->rho;
       real nr = rho0 * sqrt(rpn / (rdn + R(1e-10)));
-      nr = fmin(fmax(nr, P.rho_min), P.rho_max);
+      nr = clamp_keep_nan(nr, P.rho_min, P.rho_max);
       const bool adapt = (nr > P.adapt_tol * rho0) || (nr < (R(1.0) / P.adapt_tol) * rho0);
       __syncthreads();
       if (adapt) {
@@ -1149,7 +1149,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       residuals(false);
       const real rpn = rp / (mp + R(1e-10)), rdn = rd / (md + R(1e-10));
       real nr = rho_s * sqrt(rpn / (rdn + R(1e-10)));
-      nr = fmin(fmax(nr, P.rho_min), P.rho_max);
+      nr = clamp_keep_nan(nr, P.rho_min, P.rho_max);
       const bool adapt = (nr > P.adapt_tol * rho_s) || (nr < (R(1.0) / P.adapt_tol) * rho_s);
       if (adapt) {
 #pragma unroll

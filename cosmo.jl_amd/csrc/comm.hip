@@ -322,7 +322,12 @@ __global__ void k_comm_corrupt(long long count, real* buf) {
 }
 static int corrupt_rank() {
   static int r = -2;
-  if (r == -2) { const char* e = getenv("COSMO_HIP_COMM_CORRUPT_RANK"); r = e ? atoi(e) : -1; }
+  if (r == -2) {
+    const char* e = getenv("COSMO_HIP_COMM_CORRUPT_RANK"); r = e ? atoi(e) : -1;
+    // never silent: a leaked variable in a job script must not produce wrong answers that still read `Solved`
+    if (r >= 0) fprintf(stderr, "libcosmo_hip: WARNING: TEST HOOK COSMO_HIP_COMM_CORRUPT_RANK=%d is active -- rank %d's contribution to every all-reduce is "
+                                "scaled by 1.001; results of sharded runs are WRONG on purpose\n", r, r);
+  }
   return r;
 }
 

@@ -86,12 +86,14 @@ __device__ __forceinline__ real wave_sum(real v) {
 }
 __device__ __forceinline__ real wave_max(real v) {
   real a, b, t;
-  permlane_pair<false>(v, a, b); v = (b > a) ? b : a;
-  permlane_pair<true>(v, a, b); v = (b > a) ? b : a;
-  t = dpp_move<DPP_ROW_ROR8>(v); v = (t > v) ? t : v;
-  t = dpp_move<DPP_ROW_ROR4>(v); v = (t > v) ? t : v;
-  t = dpp_move<DPP_QUAD_XOR2>(v); v = (t > v) ? t : v;
-  t = dpp_move<DPP_QUAD_XOR1>(v); v = (t > v) ? t : v;
+  // every step keeps a NaN of EITHER partner (Julia's norm(x, Inf) returns NaN when x holds one, residuals.jl:30-53): `t > v` alone
+  // drops a NaN held by t; a NaN held by v survives because both comparisons are false
+  permlane_pair<false>(v, a, b); v = (b > a || b != b) ? b : a;
+  permlane_pair<true>(v, a, b); v = (b > a || b != b) ? b : a;
+  t = dpp_move<DPP_ROW_ROR8>(v); v = (t > v || t != t) ? t : v;
+  t = dpp_move<DPP_ROW_ROR4>(v); v = (t > v || t != t) ? t : v;
+  t = dpp_move<DPP_QUAD_XOR2>(v); v = (t > v || t != t) ? t : v;
+  t = dpp_move<DPP_QUAD_XOR1>(v); v = (t > v || t != t) ? t : v;
   return v;
 }
 
@@ -113,7 +115,7 @@ __device__ __forceinline__ real block_max(real v, real* red) {
   __syncthreads();
   real t = red[0];
 #pragma unroll
-  for (int i = 1; i < COSMO_BS / 64; ++i) t = (red[i] > t) ? red[i] : t;
+  for (int i = 1; i < COSMO_BS / 64; ++i) t = (red[i] > t || red[i] != red[i]) ? red[i] : t;   // a NaN of any wave survives
   return t;
 }
 // Every workgroup re-reduces the (<= COSMO_MAX_PARTIALS) partials of the producing kernel in the same fixed
@@ -143,6 +145,10 @@ __device__ __forceinline__ real reduce_partials_max(const real* p, int count, re
   for (int k = 0; k < COSMO_PARTS_PER_THREAD; ++k) { const real t = v[k]; a = (t > a || t != t) ? t : a; }   // a padding 0.0 never replaces a
   return block_max(a, red);
 }
+
+// min(max(v, lo), hi) as Julia evaluates it (parameters.jl:65): a NaN stays a NaN (C's fmax / fmin return the OTHER operand), so that a NaN
+// residual ratio fails both comparisons of the adaptive-rho rule and leaves rho alone, as in the reference
+__device__ __forceinline__ real clamp_keep_nan(real v, real lo, real hi) { return (v != v) ? v : fmin(fmax(v, lo), hi); }
 
 // abs-max that propagates NaN like Julia's norm(x, Inf)
 __device__ __forceinline__ real amax(real acc, real v) {

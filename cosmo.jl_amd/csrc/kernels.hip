@@ -577,7 +577,7 @@ __global__ __launch_bounds__(COSMO_BS) void k_chk_final(Ctl* __restrict__ ctl, i
     const real rdn = rd / (md + R(1e-10));
     const real rho = ctl->rho;
     real nr = rho * sqrt(rpn / (rdn + R(1e-10)));
-    nr = fmin(fmax(nr, a.rho_min), a.rho_max);
+    nr = clamp_keep_nan(nr, a.rho_min, a.rho_max);
     if ((nr > a.adapt_tol * rho) || (nr < (R(1.0) / a.adapt_tol) * rho)) {
       ctl->rho = nr;
       ctl->rho_changed = 1;

@@ -29,9 +29,18 @@ include("abi_structs.jl")
 const KKT_CG, KKT_MINRES_REDUCED, KKT_MINRES, KKT_CG_SR, KKT_CG_JACOBI = Int32(0), Int32(1), Int32(2), Int32(3), Int32(4)   # KKT_CG_SR: opt-in single-reduction CG; KKT_CG_JACOBI: opt-in Jacobi-preconditioned CG (assembled operator only)
 const STATUS = (:Undetermined, :Solved, :Max_iter_reached, :Unsolved, :Primal_infeasible, :Dual_infeasible, :Time_limit_reached)
 
+# the struct mirrors of abi_structs.jl were generated for ABI_VERSION: a library that reports another version would read / write them with a
+# different layout (a stale .so reads garbage into safeguarding_iter; a newer one writes past the caller's ResultC)
+function check_abi(::Type{T}) where {T <: HipFloat}
+    v = ccall((:cosmo_hip_version, libpath(T)), Int32, ())
+    v == ABI_VERSION || error("$(libpath(T)) reports ABI version $v, CosmoHIP.jl was generated for $ABI_VERSION: rebuild the library or regenerate abi_structs.jl")
+    return nothing
+end
+
 mutable struct Handle{T <: HipFloat}
     ptr::Ptr{Cvoid}
     function Handle{T}(device::Integer = 0) where {T <: HipFloat}
+        check_abi(T)
         ref = Ref{Ptr{Cvoid}}(C_NULL)
         rc = ccall((:cosmo_hip_create, libpath(T)), Int32, (Ref{Ptr{Cvoid}}, Int32), ref, device)
         rc == 0 || error("cosmo_hip_create failed with code $rc (no MI355X visible?)")
@@ -399,6 +408,7 @@ function optimize_hip_batch!(models::Vector{COSMO.Workspace{T}}; device::Integer
         ws.row_ranges = COSMO.get_set_indices(ws.p.C.sets)
     end
     bptr = Ref{Ptr{Cvoid}}(C_NULL)
+    check_abi(T)
     rc = ccall((:cosmo_hip_batch_create, LIBT), Int32, (Ref{Ptr{Cvoid}}, Int32, Int64, Int64, Int64), bptr, device, length(models), n, m)
     rc == 0 || error("cosmo_hip_batch_create failed (code $rc)")
     b = bptr[]

@@ -42,9 +42,9 @@ enum {
   COSMO_HIP_OK = 0,
   COSMO_HIP_ERR_INVALID = 1,     /* bad argument / call order                                          */
   COSMO_HIP_ERR_HIP = 2,         /* a HIP runtime call failed (no device, out of memory, ...)           */
-  COSMO_HIP_ERR_NOT_CONVEX = 3,  /* CG breakdown u'Lu <= 0  (reference: error("... not convex"),
-                                    src/linear_solver/kktsolver.jl:304)                                */
-  COSMO_HIP_ERR_NONFINITE = 4,   /* non-finite iterate                                                 */
+  /* 3 and 4 are retired (they named a CG breakdown and a non-finite iterate; the reference raises neither on this path: its cg! does
+     not test u'Lu, and a NaN iterate makes norm(., Inf) NaN => has_converged false => Max_iter_reached, src/residuals.jl:30-53,
+     98-140 -- which is what the device loop reports, tests/test_gpu_nan_residuals.py) */
   COSMO_HIP_ERR_EIG = 5,         /* eigen-solver did not converge (reference: chklapackerror,
                                     src/convexset.jl:186)                                              */
   COSMO_HIP_ERR_UNSUPPORTED = 6, /* feature not built (e.g. a cone type outside SURVEY 8a)              */
@@ -169,7 +169,10 @@ int32_t cosmo_hip_create(cosmo_hip_handle** h, int32_t device_id);
 int32_t cosmo_hip_destroy(cosmo_hip_handle* h);
 /* Last error text of this handle (valid until the next call on it); never NULL. */
 const char* cosmo_hip_last_error(const cosmo_hip_handle* h);
-/* ABI version of the library (major*1000 + minor). */
+/* ABI version of the library (major*1000 + minor).  COSMO_HIP_ABI_VERSION is the version THIS header describes; the bindings generated from
+ * it (cosmo.jl_amd/_abi_structs.py, julia/abi_structs.jl) carry the same number and refuse a library that reports another one: a stale
+ * .so paired with newer struct mirrors would read garbage, a newer .so would write past an older caller's cosmo_hip_result. */
+#define COSMO_HIP_ABI_VERSION 1002
 int32_t cosmo_hip_version(void);
 void cosmo_hip_default_params(cosmo_hip_params* p);
 

@@ -73,6 +73,7 @@ static void mulT(const csc* M, const oc_real* v, oc_real* y) {         /* y = M'
 static oc_real nrm2(const oc_real* v, int64_t n) { oc_real s = R(0.0); for (int64_t i = 0; i < n; ++i) s += v[i] * v[i]; return RSQRT(s); }
 static oc_real dot(const oc_real* a, const oc_real* b, int64_t n) { oc_real s = R(0.0); for (int64_t i = 0; i < n; ++i) s += a[i] * b[i]; return s; }
 static oc_real amax(oc_real acc, oc_real v) { const oc_real a = RFABS(v); return (a > acc || a != a) ? a : acc; }
+static oc_real maxn(oc_real a, oc_real b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }   /* max that keeps a NaN (Julia) */
 
 typedef struct {
   int64_t n, m;
@@ -346,7 +347,7 @@ int32_t cosmo_oracle_c_run_cones(int64_t n, int64_t m, const int64_t* Pp, const 
       rp = amax(rp, ((tmp_m[i] + s[i]) - b[i]) * e);                                                                          \
       a1 = amax(a1, tmp_m[i] * e); a2 = amax(a2, s[i] * e); a3 = amax(a3, b[i] * e);                                          \
     }                                                                                                                         \
-    mp = RFMAX(RFMAX(a1, a2), a3);                                                                                              \
+    mp = maxn(maxn(a1, a2), a3);   /* Julia's max keeps a NaN */                                                                                              \
     mul(&W.P, xx, rd); mulT(&W.A, mu, rt);                                                                                    \
     oc_real rdn = R(0.0), b1 = R(0.0), b2 = R(0.0), b3 = R(0.0);                                                                           \
     const oc_real ci = (UNSCALE) ? p_cinv : R(1.0);                                                                               \
@@ -355,7 +356,7 @@ int32_t cosmo_oracle_c_run_cones(int64_t n, int64_t m, const int64_t* Pp, const 
       rdn = amax(rdn, (((rd[j] + q[j]) - rt[j]) * dj) * ci);                                                                  \
       b1 = amax(b1, (rd[j] * dj) * ci); b2 = amax(b2, (q[j] * dj) * ci); b3 = amax(b3, (rt[j] * dj) * ci);                    \
     }                                                                                                                         \
-    r_prim = rp; r_dual = rdn; mnp = mp; mnd = RFMAX(RFMAX(b1, b2), b3);                                                        \
+    r_prim = rp; r_dual = rdn; mnp = mp; mnd = maxn(maxn(b1, b2), b3);                                                        \
   }
 
   SOLVE_AND_W()                                                           /* init step (solver.jl:137-138) */
@@ -408,7 +409,7 @@ int32_t cosmo_oracle_c_run_cones(int64_t n, int64_t m, const int64_t* Pp, const 
       const oc_real rp = r_prim / (mnp + R(1e-10)), rdd = r_dual / (mnd + R(1e-10));
       r_prim = sr_p; r_dual = sr_d; mnp = smp; mnd = smd;
       oc_real new_rho = rho * RSQRT(rp / (rdd + R(1e-10)));
-      new_rho = RFMIN(RFMAX(new_rho, p_rho_min), p_rho_max);
+      if (new_rho == new_rho) new_rho = RFMIN(RFMAX(new_rho, p_rho_min), p_rho_max);   /* Julia's min(max(NaN, .), .) is NaN: no update */
       if (new_rho > p_adaptive_rho_tolerance * rho || new_rho < (R(1.0) / p_adaptive_rho_tolerance) * rho) {
         rho = new_rho;
         make_rho(&W, &p, rho);

@@ -96,6 +96,12 @@ def build_model(iters):
         return infeasible_model(case)
     if case == "custom":
         return custom_cone_model(iters)
+    if case == "nanrow":          # tests/test_gpu_nan_residuals.py: an empty row of A with b = NaN, owned by rank 1 (local row 100: upper half of wave 1)
+        from tests import util
+        p = util.nan_row_qp(3, 60, 2000, 1300, split=1200)
+        md = cj.Model(); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"],
+                                cj.Settings(max_iter=iters, scaling=0, kkt_solver=cj.with_options(cj.CGIndirectKKTSolver, tol_constant=1e-10, tol_exponent=0.0)))
+        return md
     p = problem()
     dtype = np.float32 if os.environ.get("COSMO_TEST_DTYPE", "") == "float32" else np.float64       # libcosmo_hip_f32.so: the collectives carry float
     md = cj.Model(dtype=dtype); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], settings(iters, os.environ.get("COSMO_TEST_TIGHT", "") == "1"))

@@ -116,3 +116,20 @@ def random_qp(rng, n, m_zero, m_nonneg, m_box, soc_dims=(), density=0.1, psd_tri
     s0 = np.concatenate(s0)
     b = A @ x0 + s0
     return dict(P=P, q=q, A=A, b=b, sets=sets)
+
+
+def nan_row_qp(seed, n, m, nan_row, split=None):
+    """min 1/2 x'Px + q'x  s.t.  b - Ax >= 0 (Nonnegatives, strictly feasible at 0), row `nan_row` of A empty with b = NaN (None: clean)."""
+    rng = np.random.default_rng(seed)
+    A = sp.random(m, n, density=min(1.0, 6.0 / n), random_state=rng, format="lil", data_rvs=rng.standard_normal)
+    b = rng.uniform(0.5, 2.0, m)
+    if nan_row is not None:
+        A[nan_row, :] = 0.0
+    A = A.tocsc(); A.eliminate_zeros()
+    if nan_row is not None:
+        assert A.tocsr().indptr[nan_row] == A.tocsr().indptr[nan_row + 1]
+        b[nan_row] = np.nan
+    P = sp.identity(n, format="csc") * 2.0
+    q = rng.standard_normal(n)
+    dims = [m] if split is None else [split, m - split]
+    return dict(P=P, q=q, A=A, b=b, sets=[cj.Nonnegatives(d) for d in dims])
