@@ -6,24 +6,29 @@ A "step" is ONE ADMM iteration of the loop body src/solver.jl:140-165 including 
 = 0, adaptive_rho_interval = 40, scaling = 10, alpha = 1.6, sigma = 1e-6, rho = 0.1, CG tolerance 1/k^1.5, EmptyAccelerator.
 
 Workloads (--workload):
-  cfg2  random sparse QP n=100k m=200k nnz(A)=2M, Box cone, CG indirect KKT            [BASELINE configs[1], the metric config]
+  cfg5  chordal-decomposed SDP n=50k, 400 PSD cliques d in [20,200] + ZeroSet / Nonnegatives   [the workload north_star's targets are stated on;
+        the largest BASELINE configuration, fits one GPU: THE HEADLINE at every N since round 5]
+  cfg2  random sparse QP n=100k m=200k nnz(A)=2M, Box cone, CG indirect KKT            [BASELINE configs[1]]
   cfg3  1024 independent SOCPs n=500 m=1000, 50 SecondOrderCones each (one step = one iteration of ALL problems)
   cfg4  closest-correlation SDP, one PsdConeTriangle d=2000
-  cfg5  chordal-decomposed SDP n=50k, 400 PSD cliques d in [20,200] + ZeroSet / Nonnegatives
-  all   (default at N=1) headline line = cfg2; cfg3 / cfg4 / cfg5 measured in the same run and reported under "extra"
+  all   (default) headline line = cfg5; cfg2 / cfg3 / cfg4 measured in the same run and reported under "extra"
 
 Multi-GPU (`python bench.py --gpus N` re-launches itself under torch.distributed.run, one process per GPU, RCCL; a launch that
 already comes from torch.distributed.run / torchrun is used as it is):
-  headline line at EVERY N = cfg2, the metric configuration: a single sparse QP does not shard (replicas only), every rank
-  runs a replica, "scaling": "weak", value = N * steps / max-over-ranks time -- the same workload string at N = 1, 2, 4, 8.
-  extra.cfg5_sharded = ONE cfg5 problem with its cones (and, --shard rows, all their rows of A / s / mu / rho) sharded over the ranks,
-  "scaling": "strong", with rank 0's unsharded time of the same problem in the same run, the exchange volume per iteration, the
-  measured shardable share f of the 1-GPU iteration and the bound 1 / ((1 - f) + f / N) it implies.
+  headline line at EVERY N = cfg5, ONE problem: N = 1 unsharded; N > 1 its cones and all their rows of A / s / mu / rho sharded over the ranks
+  (csrc/rowshard.hip; the loop being sharded: src/convexset.jl:885-891, src/linear_solver/kktsolver_indirect.jl:52-54), "scaling": "strong",
+  value = steps / max-over-ranks time of the literal cg! path.  The line carries its own parity evidence at the TOP level (config.parity_*,
+  config.comm_selftest: flat scalars next to the nested objects), rank 0's unsharded time of the same problem in the same run, the exchange volume
+  per iteration, the measured shardable share f of the 1-GPU iteration and the bound 1 / ((1 - f) + f / N) it implies.
   extra.cfg3_sharded = the batch of 1024 SOCPs sharded over the ranks (no collective), strong.
-  --workload cfgK at N>1 makes that workload the headline instead (cfg5 / cfg3: sharded, strong; cfg2 / cfg4: replicas, weak).
+  extra.cfg2_replicas / cfg4_replicas = N independent replicas (these two do not shard): "scaling": "replicas", value = ONE replica's rate
+  (max-over-ranks time) -- never aggregated, never a headline.
+  --workload cfgK makes that workload the headline instead (cfg5 / cfg3: sharded, strong; cfg2 / cfg4: replicas, weak, value = N x rate).
 
 Output: ONE JSON line on rank 0 (the driver contract) with `roofline` for the dominant kernel of the headline workload and
-`cpu_baseline` (the restated CPU reference timed on a bounded sample, 1 thread and all host threads where LAPACK is involved).
+`cpu_baseline` (the restated CPU reference timed on a bounded sample: the CG path with 1 thread and all host threads where LAPACK is involved, and --
+`cpu_baseline.direct_kkt` -- the reference's DEFAULT direct LDL' KKT solver, the CPU path north_star names), and a compact `summary` as the LAST key
+(the driver keeps the tail of the line: all four rates must survive there).
 """
 import argparse
 import json
@@ -253,6 +258,57 @@ def compiled_cpu_baseline(prob, iters, label, workload_key, args, with_all_threa
     return out
 
 
+def direct_kkt_cpu_baseline(prob, iters, label):
+    """cpu_baseline.direct_kkt: the reference's DEFAULT CPU path (north_star: "the reference Julia/QDLDL CPU path") -- QdldlKKTSolver
+    (src/linear_solver/kktsolver.jl:285-320): quasi-definite LDL' of [P + sigma I, A'; A, -diag(1/rho)] once (+ once per rho update) and one
+    permuted triangular solve pair per ADMM iteration -- inside the same compiled loop (oracle/cosmo_oracle_c.c: the restated QDLDL algorithm, 1 thread
+    like QDLDL.jl; projections through LAPACK ?syevr + ?syrk as the reference does).  The first factorisation and the ordering are setup (outside
+    iter_time on every side) and reported separately."""
+    from oracle import cosmo_oracle as O
+    from tests import util
+    from threadpoolctl import threadpool_limits
+    OC = _native_oracle()
+    ws = O.Workspace(prob["P"], prob["q"], prob["A"], prob["b"], util.oracle_cones(prob["sets"]), oracle_settings(O, iters))
+    t0 = time.perf_counter()
+    cached = os.path.exists(os.path.join(OC.PERM_DIR, "perm_%s.npz" % OC._pattern_key(ws.P, ws.A)))
+    perm = OC.kkt_ordering(ws)
+    t_ord = time.perf_counter() - t0
+    with threadpool_limits(limits=1):
+        c = OC.run(ws, native=True, direct=dict(perm=perm, nnz_cap=int(6e8)))
+    L = c["ldl"]
+    return dict(value=c["iter"] / c["iter_time"], unit="ADMM iterations/s", cores=1, kind="port",
+                kkt="QdldlKKTSolver restated (published QDLDL algorithm: etree + up-looking LDL'; QDLDL.jl 0.4.1 / AMD.jl are not vendored in the reference tree)",
+                factor_s=round(L["factor_s"] / max(L["n_factor"], 1), 3), n_factor=L["n_factor"], solve_ms=round(1e3 * L["solve_s"] / max(L["n_solve"], 1), 3),
+                nnz_L=L["nnz_L"], kkt_dim=int(ws.n + ws.m), ordering_s=round(t_ord, 2),
+                ordering="minimum degree: rows of A with <= 1 entry first (no fill), SuperLU MMD(A'+A) on the Schur complement pattern of the rest%s"
+                         % (" (read from oracle/kkt_perm/, keyed by the sparsity pattern)" if cached else ""),
+                sample="compiled C loop with the direct solve: %d ADMM iteration(s) + init step of the same %s instance, %.1f s of loop time (%.1f s projections, %.2f s "
+                       "triangular solves), 1 thread; the first factorisation (%.1f s) is setup, refactorisations at rho updates (%d here) are inside"
+                       % (c["iter"], label, c["iter_time"], c["proj_time"], L["solve_s"], L["factor_s"] / max(L["n_factor"], 1), L["n_factor"] - 1))
+
+
+def direct_kkt_probe_cfg2(prob, cap=int(4e8)):
+    """BASELINE config 2 is DEFINED with the CG indirect solver, and for a reason that can be measured: the elimination-tree pass of the QDLDL
+    restatement counts the fill of its KKT matrix (uniformly random pattern) under two orderings and stops at `cap` nonzeros."""
+    from oracle import cosmo_oracle as O
+    from tests import util
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    OC = _native_oracle()
+    ws = O.Workspace(prob["P"], prob["q"], prob["A"], prob["b"], util.oracle_cones(prob["sets"]), oracle_settings(O, 1))
+    n, m = ws.n, ws.m
+    K = OC.kkt_full(ws)
+    t0 = time.perf_counter()
+    tried = {"rows of A first, then x (what minimum degree does with degree-10 row nodes)": np.concatenate([np.arange(n, n + m), np.arange(n)]).astype(np.int64),
+             "reverse Cuthill-McKee of K": np.asarray(reverse_cuthill_mckee(K.tocsr(), symmetric_mode=True), np.int64)}
+    res = {k: OC.ldl_nnz(ws, p, cap=cap, native=True) for k, p in tried.items()}
+    feasible = any(v >= 0 for v in res.values())
+    return dict(feasible=feasible, nnz_L={k: (v if v >= 0 else "> %d" % cap) for k, v in res.items()}, kkt_dim=int(n + m), probe_s=round(time.perf_counter() - t0, 2),
+                note=("the LDL' factor of this KKT matrix exceeds %.0e nonzeros (> %.1f GB, > ~1e12 flops per factorisation) under every ordering tried: the Schur "
+                      "complement onto x is a uniformly random graph of mean degree ~%d on %d nodes, whose Cholesky factor is essentially dense (%.1e entries); "
+                      "the direct path is not a baseline for this configuration -- BASELINE.json itself specifies the CG indirect KKT solver for it"
+                      % (cap, 12.0 * cap / 1e9, int(ws.A.nnz / n * (ws.A.nnz / m - 1.0)), n, n * (n + 1) / 2.0)) if not feasible else "fits: see nnz_L")
+
+
 def _problem_for(key, small):
     import cosmo_jl_amd as cj
     if key == "cfg2":
@@ -341,6 +397,10 @@ def bench_cfg2(ctx, args, steps, warmup):
         def cpu_leg(out=out, prob=prob, value=value):
             out["cpu_baseline"] = compiled_cpu_baseline(prob, args.cpu_sample_iters if not args.small else 200, "cfg2", "cfg2", args, with_all_threads=False)   # no BLAS in this configuration
             out["config"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 2)
+            try:
+                out["cpu_baseline"]["direct_kkt"] = direct_kkt_probe_cfg2(prob)
+            except Exception as e:
+                out["cpu_baseline"]["direct_kkt"] = dict(error="%s: %s" % (type(e).__name__, e))
         args.deferred.append(cpu_leg)
     h.close()
     return out
@@ -744,6 +804,17 @@ def bench_cfg5(ctx, args, steps, warmup):
     if ctx.world > 1:
         out["config"]["rank_seconds"] = rank_seconds
         out["config"]["parity"] = parity
+        # the same evidence as FLAT scalars: the driver's parsed copy of the line keeps the scalar entries of `config` (nested objects are dropped there)
+        comm = h.bench_comm or {}
+        out["config"]["parity_ok"] = bool(parity and parity.get("ok") and comm.get("selftest") == "ok")
+        out["config"]["parity_sharded_vs_single_max_rel_dev"] = (parity or {}).get("sharded_vs_single_max_rel_dev")
+        out["config"]["parity_expected_at_most"] = 1e-7
+        out["config"]["parity_ranks_bit_identical"] = (parity or {}).get("ranks_bit_identical")
+        out["config"]["comm_selftest"] = comm.get("selftest")
+        out["config"]["comm_transport"] = comm.get("transport_name")
+        out["config"]["comm_rccl_version"] = comm.get("rccl_version")
+        out["config"]["comm_bytes_per_iteration"] = comm.get("bytes_per_iteration")
+        out["config"]["rank_seconds_min_max"] = "%.6f / %.6f" % (rank_seconds["min"], rank_seconds["max"])
     if single is not None:
         out["config"]["single_gpu_same_workload"] = round(single, 3)
         out["config"]["speedup_vs_single_gpu"] = round(value / single, 3)
@@ -802,7 +873,7 @@ def bench_cfg5(ctx, args, steps, warmup):
         try:
             t_k, b_k, nl = min(h.time_krylov(200) for _ in range(3))
             fs = h.fold_stats()
-            krylov = dict(bound="latency", kernel=("k_cg_dirM<%d> + k_cg_upd: ONE Krylov iteration of cg! on the assembled reduced operator M = P + sigma I + A' rho A "
+            krylov = dict(bound="hbm", limited_by="latency: a chain of dependent launches and load round trips, not bandwidth", kernel=("k_cg_dirM<%d> + k_cg_upd: ONE Krylov iteration of cg! on the assembled reduced operator M = P + sigma I + A' rho A "
                                                    "(%d nonzeros), %d launches" % (4, fs["nnz"], nl)) if fs["enabled"] else "one Krylov iteration of cg! (%d launches)" % nl,
                           achieved=round(b_k / t_k / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(b_k / t_k / 1e9 / HBM_PEAK_GBS, 4), traffic=None,
                           algorithmic_bytes_per_launch=b_k, avg_launch_us=round(1e6 * t_k, 3), launches_timed=200,
@@ -825,8 +896,17 @@ def bench_cfg5(ctx, args, steps, warmup):
     elif products:
         out["roofline"] = products
     if not args.no_cpu_baseline and ctx.world == 1:
-        args.deferred.append(lambda out=out, prob=prob: out.__setitem__("cpu_baseline", compiled_cpu_baseline(prob, 2 if not args.small else 10, "cfg5", "cfg5", args,
-                                                                                                                iters_all=1 if not args.small else 10)))
+        def cpu_leg(out=out, prob=prob, value=value):
+            cb = compiled_cpu_baseline(prob, 2 if not args.small else 10, "cfg5", "cfg5", args, iters_all=1 if not args.small else 10)
+            cb["kkt"] = "CGIndirectKKTSolver (the solver of the GPU path; kktsolver_indirect.jl:36-88)"
+            try:
+                cb["direct_kkt"] = direct_kkt_cpu_baseline(prob, 10 if not args.small else 20, "cfg5")
+                out["config"]["gpu_over_cpu_direct_kkt"] = round(value / cb["direct_kkt"]["value"], 2)
+            except Exception as e:
+                cb["direct_kkt"] = dict(error="%s: %s" % (type(e).__name__, e))
+            out["config"]["gpu_over_cpu"] = round(value / cb["value"], 2)
+            out["cpu_baseline"] = cb
+        args.deferred.append(cpu_leg)
     if ctx.world == 1:
         h.close()
         try:
@@ -865,7 +945,8 @@ BENCH = {"cfg2": bench_cfg2, "cfg3": bench_cfg3, "cfg4": bench_cfg4, "cfg5": ben
 # windows stay those of round 2.  Ten warm-up iterations (60-80 ms) do not bring the clocks of an idling GPU back up (cfg5 read 155 it/s right after
 # 10 s of CPU-baseline work against 166-170), so all cpu_baseline legs run AFTER the GPU work (args.deferred) and _run_sdp first spins the product
 # kernel for ~0.3 s (gpu_prewarm; no ADMM state is touched)
-EXTRA_STEPS = {"cfg3": (100, 25), "cfg4": (40, 10), "cfg5": (40, 10)}
+EXTRA_STEPS = {"cfg2": (40, 10), "cfg3": (100, 25), "cfg4": (40, 10), "cfg5": (40, 10)}
+HEADLINE = "cfg5"       # the workload north_star's targets are stated on (">= 10x ... on a 50k-var chordal SDP at 1xMI355X", ">= 6x at 8 GPUs on clique-sharded problems")
 
 
 def relaunch_under_torchrun(n):
@@ -885,10 +966,10 @@ def relaunch_under_torchrun(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=25)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=["all", "cfg2", "cfg3", "cfg4", "cfg5"], default=None,
-                    help="default: headline cfg2 at every N; extras cfg3 / cfg4 / cfg5 at N=1, cfg5_sharded / cfg3_sharded at N>1")
+                    help="default: headline cfg5 at every N (N > 1: row-sharded, strong); extras cfg2 / cfg3 / cfg4 at N=1, cfg3_sharded + cfg2 / cfg4 replicas at N>1")
     ap.add_argument("--shard", choices=["rows", "cones"], default="rows",
                     help="cfg5 at N>1: rows = every rank owns its cones AND their rows of A / s / mu / rho, one all-reduce of an n-vector per "
                          "iteration (SURVEY 8e option 2 on a replicated CG); cones = projections only, one broadcast group of s per iteration (option 1)")
@@ -914,8 +995,28 @@ def main():
     NO_PREWARM[0] = bool(args.no_prewarm)
     import cosmo_jl_amd as cj  # noqa: F401
     workload = args.workload or "all"
-    head = "cfg2" if workload == "all" else workload
+    head = HEADLINE if workload == "all" else workload
+    # N > 1: the headline itself now runs data-path collectives (the row-sharded loop).  If it never returns -- a rank that died while the others wait
+    # inside RCCL on the first real multi-GPU execution -- a line must still come out and it must not look like a measurement: value 0, an `error`
+    # field, exit code 1 (COSMO_BENCH_HEAD_TIMEOUT seconds, default 900).
+    head_dog = None
+    if ctx.world > 1:
+        import threading as _th
+
+        def head_expired():
+            if ctx.rank == 0:
+                print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "ADMM iterations/s", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
+                                  "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                                  "config": {"workload": "%s (headline did not finish)" % head},
+                                  "error": "the %d-rank run of the headline workload did not finish within COSMO_BENCH_HEAD_TIMEOUT = %s s (a hang inside a "
+                                           "collective?): NOT a measurement" % (ctx.world, os.environ.get("COSMO_BENCH_HEAD_TIMEOUT", "900"))}), flush=True)
+            os._exit(1)
+        head_dog = _th.Timer(float(os.environ.get("COSMO_BENCH_HEAD_TIMEOUT", "900")), head_expired)
+        head_dog.daemon = True
+        head_dog.start()
     res = BENCH[head](ctx, args, args.steps, args.warmup)
+    if head_dog is not None:
+        head_dog.cancel()
     extra = {}
 
     def headline_line():
@@ -934,10 +1035,40 @@ def main():
             out["extra"] = dict(extra)
         return out
 
+    def summary_of(line):
+        """Compact digest, LAST key of the line (the driver keeps the tail of stdout): every workload's rate + roofline fraction + CPU baselines."""
+        def short(r):
+            if not isinstance(r, dict) or "error" in r or "value" not in r:
+                return {"error": (r or {}).get("error", "missing")} if isinstance(r, dict) else None
+            o = {"value": r["value"], "scaling": r.get("scaling")}
+            rf = r.get("roofline") or {}
+            if rf:
+                o["roofline_frac"] = rf.get("frac"); o["bound"] = rf.get("bound")
+            cb = r.get("cpu_baseline") or {}
+            if cb:
+                o["cpu"] = round(cb["value"], 4) if isinstance(cb.get("value"), float) else cb.get("value")
+                dk = cb.get("direct_kkt") or {}
+                if "value" in dk:
+                    o["cpu_direct_kkt"] = round(dk["value"], 4)
+                elif "feasible" in dk:
+                    o["cpu_direct_kkt"] = "infeasible (fill)" if not dk["feasible"] else "feasible"
+            return o
+        sm = {head: short(line)}
+        for k, v in (line.get("extra") or {}).items():
+            sm[k] = short(v)
+        cfgp = line.get("config", {})
+        if ctx.world > 1:
+            sm["parity_ok"] = cfgp.get("parity_ok"); sm["speedup_vs_single_gpu"] = cfgp.get("speedup_vs_single_gpu")
+        return sm
+
     # N > 1: the sharded extras are the only part of this program with data-path collectives.  If one of them hangs (a rank that failed while
     # the others wait in a collective), the headline -- measured already -- must still be reported: a watchdog prints the line with what has
     # been collected and ends every rank.  COSMO_BENCH_EXTRA_TIMEOUT seconds for all extras together (default 600).
     watchdog = None
+    others = [k for k in ("cfg2", "cfg3", "cfg4", "cfg5") if k != head]
+    extra_plan = [(k, k) for k in others] if ctx.world == 1 else \
+                 [(k, k + "_sharded") for k in others if k in ("cfg3", "cfg5")] + [(k, k + "_replicas") for k in others if k in ("cfg2", "cfg4")]
+    extra_keys = [key for _, key in extra_plan]
     import threading
     line_lock, line_state = threading.Lock(), {"printed": False}
 
@@ -950,6 +1081,7 @@ def main():
             out = headline_line()
             if extras_override is not None:
                 out["extra"] = extras_override
+            out["summary"] = summary_of(out)
             print(json.dumps(out), flush=True)
             return out
 
@@ -963,21 +1095,23 @@ def main():
             # collective, gets an exception that the per-extra try / except below records, and still prints.
             if ctx.rank == 0:
                 snap = dict(extra)
-                for name in ("cfg5", "cfg3"):
-                    snap.setdefault(name + "_sharded", {"error": "not finished within COSMO_BENCH_EXTRA_TIMEOUT; the headline above was measured before"})
+                for name in extra_keys:
+                    snap.setdefault(name, {"error": "not finished within COSMO_BENCH_EXTRA_TIMEOUT; the headline above was measured before"})
                 print_line_once(snap)
             os._exit(0)
         watchdog = threading.Timer(deadline + (float(os.environ.get("COSMO_BENCH_EXTRA_GRACE", "2")) if ctx.rank == 0 else 0.0), expire)
         watchdog.daemon = True
         watchdog.start()
     if workload == "all" and not args.no_extra:
-        # N = 1: the other three BASELINE configurations on the one GPU.  N > 1: the two configurations that shard, strong scaling.
-        names = ("cfg3", "cfg4", "cfg5") if ctx.world == 1 else ("cfg5", "cfg3")
-        for name in names:
-            key = name if ctx.world == 1 else name + "_sharded"
+        # N = 1: the other three BASELINE configurations on the one GPU.  N > 1: the batch that shards (strong scaling) and -- explicitly as REPLICAS,
+        # one replica's rate, never aggregated -- the two configurations that do not shard.
+        for name, key in extra_plan:
             try:
                 k, w = EXTRA_STEPS[name]
                 r = BENCH[name](ctx, args, k, w)
+                if key.endswith("_replicas"):
+                    r["value"] = r["value"] / ctx.world; r["scaling"] = "replicas"; r["replicas"] = ctx.world
+                    r["note"] = "%d independent replicas, value = ONE replica's rate on the max-over-ranks time (this configuration does not shard; never a headline)" % ctx.world
                 r["value"] = round(r["value"], 3); r["ms_per_step"] = round(r["ms_per_step"], 6); r["unit"] = "ADMM iterations/s"
                 r["n_gpus"] = ctx.world
                 extra[key] = r

@@ -96,6 +96,8 @@ SIGNATURES = {
     "cosmo_hip_fold_stats": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_get_kkt_solution": (C.c_int32, [C.c_void_p, _PR]),
     "cosmo_hip_get_stats": (C.c_int32, [C.c_void_p, _PI64]),
+    "cosmo_hip_set_setup_time": (C.c_int32, [C.c_void_p, C.c_double]),
+    "cosmo_hip_get_rho_interval": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_time_spmv": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _PD, _PD]),
     "cosmo_hip_set_profiling": (C.c_int32, [C.c_void_p, C.c_int32]),
     "cosmo_hip_get_kernel_times": (C.c_int32, [C.c_void_p, _PD, _PI64]),
@@ -374,6 +376,15 @@ class Handle:
         st = C.c_int32(0)
         self._chk(self.lib.cosmo_hip_admm_iterate_checked(self._h, int(n_iters), C.byref(st)))
         return st.value
+
+    def set_setup_time(self, seconds):
+        self._chk(self.lib.cosmo_hip_set_setup_time(self._h, float(seconds)))
+
+    def rho_interval(self):
+        """(adaptive_rho_interval in force, iteration at which the automatic rule fixed it or -1)"""
+        out = np.zeros(2, dtype=np.int64)
+        self._chk(self.lib.cosmo_hip_get_rho_interval(self._h, out.ctypes.data_as(_PI64)))
+        return int(out[0]), int(out[1])
 
     def residuals(self):
         out = np.empty(5)

@@ -206,6 +206,7 @@ extern "C" void cosmo_hip_default_params(cosmo_hip_params* p) {
   p->adaptive_rho_tolerance = 5.0; p->cosmo_infty_min_scaling = 1e20 * 1e-4; p->time_limit = 0.0;
   p->max_iter = 5000; p->adaptive_rho_max_adaptions = INT64_MAX; p->kkt_kind = COSMO_HIP_KKT_CG;
   p->check_termination = 25; p->check_infeasibility = 40; p->adaptive_rho = 1; p->adaptive_rho_interval = 40;
+  p->adaptive_rho_fraction = 0.4; p->setup_time = 0.0;
   p->unscale_residuals = 1;
   p->obj_true = (double)NAN; p->obj_true_tol = 1e-3;
 }
@@ -562,10 +563,11 @@ extern "C" int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_par
   if (!h->have_cones) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_cones must be called before set_params");
   if (p->kkt_kind < COSMO_HIP_KKT_CG || p->kkt_kind > COSMO_HIP_KKT_CG_JACOBI) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "bad kkt_kind");
   if (p->check_termination <= 0) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "check_termination must be > 0");
-  if (p->adaptive_rho && p->adaptive_rho_interval == 0)
-    return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "adaptive_rho_interval == 0 (wall-clock rule, solver.jl:244-256) is not supported");
+  if (p->adaptive_rho && p->adaptive_rho_interval == 0 && !(p->adaptive_rho_fraction >= 0.0 && p->setup_time >= 0.0))
+    return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "adaptive_rho_interval == 0 needs adaptive_rho_fraction >= 0 and setup_time >= 0");
   const bool reclass = (p->cosmo_infty_min_scaling != h->prm.cosmo_infty_min_scaling) || (p->rho_tol != h->prm.rho_tol);
   h->prm = *p;
+  h->auto_rho_fixed_at = -1;
   h->cg_sr = (p->kkt_kind == COSMO_HIP_KKT_CG_SR);
   h->cg_jacobi = (p->kkt_kind == COSMO_HIP_KKT_CG_JACOBI);
   if (h->cg_sr || h->cg_jacobi) h->prm.kkt_kind = COSMO_HIP_KKT_CG;      // the same reduced operator, split, budget and tail; only the Krylov recurrence differs
@@ -1122,6 +1124,26 @@ static int32_t collective_elapsed(cosmo_hip_handle* h, const std::chrono::steady
   return COSMO_HIP_OK;
 }
 
+// The reference's automatic rho interval (apply_rho_adaptation_rules!, solver.jl:244-256): `settings.adaptive_rho_interval == 0` means "fix it once the
+// loop has run for adaptive_rho_fraction * setup_time seconds" -- to round_multiple(iter, check_termination) (algebra.jl:245-247), at least
+// check_termination (25 where that is 0).  Called where the host knows that the device has finished iteration `it` (at the top of iteration it + 1 in
+// the reference's terms).  The rule fires once; the interval then lives in h->prm like a fixed one, and what the device does from there on is the
+// fixed-interval schedule.  Sharded runs decide on the maximum of the ranks' clocks, so every rank fixes the same interval at the same iteration.
+static int32_t auto_rho_interval(cosmo_hip_handle* h, long long iter, const std::chrono::steady_clock::time_point t0) {
+  cosmo_hip_params& p = h->prm;
+  if (!(p.adaptive_rho && p.adaptive_rho_interval == 0)) return COSMO_HIP_OK;
+  double el = 0.0;
+  CHK(collective_elapsed(h, t0, &el));
+  if (!(el > p.adaptive_rho_fraction * p.setup_time)) return COSMO_HIP_OK;
+  const long long N = p.check_termination > 0 ? p.check_termination : 25;
+  const double x = (double)iter + 0.5 * (double)N;
+  long long v = (long long)floor(x - fmod(x, (double)N));                 // round_multiple(iter, N)
+  v = std::max(v, N);
+  p.adaptive_rho_interval = (int32_t)std::min<long long>(v, INT32_MAX);
+  h->auto_rho_fixed_at = iter;
+  return COSMO_HIP_OK;
+}
+
 static int32_t optimize_accelerated(cosmo_hip_handle* h, int* status_out, long long* iter_out, const std::chrono::steady_clock::time_point t0) {
   const cosmo_hip_params& p = h->prm;
   // Sharded runs: with clique (cone) sharding every rank holds the whole w and all scalars are computed redundantly and bit-identically, so the
@@ -1140,6 +1162,7 @@ static int32_t optimize_accelerated(cosmo_hip_handle* h, int* status_out, long l
     bool attempted = false;
     int success = 0, declined = 0;
     CHK(aa_enqueue_pre(h, it, &attempted));                                   // acceleration_pre!
+    CHK(auto_rho_interval(h, it, t0));                                        // solver.jl:244-256 (this loop synchronises every iteration: the reference's own test point)
     if (p.adaptive_rho && p.adaptive_rho_interval > 0 && (it % p.adaptive_rho_interval) == 0 &&
         (long long)(n_rho_seen - 1) < p.adaptive_rho_max_adaptions)
       rho_update_due = true;                                                  // solver.jl:262-264
@@ -1221,6 +1244,7 @@ extern "C" int32_t cosmo_hip_optimize(cosmo_hip_handle* h, cosmo_hip_result* res
     CHK(admm_init_enqueue(h));
   }
   while (!aa_enabled(h) && it < p.max_iter) {
+    CHK(auto_rho_interval(h, it + 1, t0));                  // (the slices end at the termination checks: the rule is applied there)
     long long next = (it == 0) ? 1 : ((it / p.check_termination) + 1) * (long long)p.check_termination;
     next = std::min(next, next_inf_iter(h, it));
     if (next > p.max_iter) next = p.max_iter;
@@ -1314,6 +1338,18 @@ extern "C" int32_t cosmo_hip_get_kkt_solution(cosmo_hip_handle* h, real* sol) {
   if (!h->have_params || !sol) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "get_kkt_solution: not set up");
   CHK(d2h(h, sol, h->x_tl, (size_t)h->n));
   CHK(d2h(h, sol + h->n, h->nu, (size_t)h->m));
+  return COSMO_HIP_OK;
+}
+
+extern "C" int32_t cosmo_hip_set_setup_time(cosmo_hip_handle* h, double seconds) {
+  if (!h) return COSMO_HIP_ERR_INVALID;
+  if (!(seconds >= 0.0)) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_setup_time: need seconds >= 0");
+  h->prm.setup_time = seconds;
+  return COSMO_HIP_OK;
+}
+extern "C" int32_t cosmo_hip_get_rho_interval(cosmo_hip_handle* h, int64_t out[2]) {
+  if (!h || !out) return COSMO_HIP_ERR_INVALID;
+  out[0] = h->prm.adaptive_rho_interval; out[1] = h->auto_rho_fixed_at;
   return COSMO_HIP_OK;
 }
 

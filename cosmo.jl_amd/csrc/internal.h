@@ -187,6 +187,7 @@ struct cosmo_hip_handle {
   void* accel = nullptr;          // AaState (anderson.hip)
   long long safeguarding_iter = 0;
   bool cg_sr = false;             // kkt_kind COSMO_HIP_KKT_CG_SR: single-reduction (Chronopoulos-Gear) CG, cg_sr.hip
+  long long auto_rho_fixed_at = -1;   // iteration at which the automatic rho interval (adaptive_rho_interval == 0, solver.jl:244-256) was fixed; -1: not (yet)
   bool cg_jacobi = false;  // kkt_kind CG_JACOBI: opt-in Jacobi-preconditioned CG on the assembled operator (cg_fold.hip)
   void* sr_rec = nullptr;         // 2 n records {r, w, s, p}
   real* cg_ru = nullptr;        // {r_i, u_i} interleaved (2n doubles): operands of the fused direction + A-product kernel (k_cg_dirA); null = unfused

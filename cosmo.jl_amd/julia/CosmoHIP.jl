@@ -184,7 +184,8 @@ function params_from(settings::COSMO.Settings{T}, kkt_kind::Int32; tol_constant 
     Params(s.sigma, s.alpha, s.rho, s.eps_abs, s.eps_rel, s.eps_prim_inf, s.eps_dual_inf, tol_constant, tol_exponent,
            s.RHO_MIN, s.RHO_MAX, s.RHO_TOL, s.RHO_EQ_OVER_RHO_INEQ, s.adaptive_rho_tolerance, s.COSMO_INFTY * s.MIN_SCALING,
            s.time_limit, s.max_iter, min(s.adaptive_rho_max_adaptions, typemax(Int64) >> 1), kkt_kind, s.check_termination,
-           s.check_infeasibility, s.adaptive_rho ? 1 : 0, s.adaptive_rho_interval, s.scaling != 0 ? 1 : 0, s.obj_true, s.obj_true_tol)
+           s.check_infeasibility, s.adaptive_rho ? 1 : 0, s.adaptive_rho_interval, s.scaling != 0 ? 1 : 0, s.obj_true, s.obj_true_tol,
+           s.adaptive_rho_fraction, 0.0)      # setup_time: handed over by optimize_hip! through cosmo_hip_set_setup_time once setup! has ended
 end
 
 function set_params!(h::Handle{T}, p::Params, rho_vec::Union{Vector{T}, Nothing}) where {T <: HipFloat}
@@ -354,9 +355,16 @@ function optimize_hip!(ws::COSMO.Workspace{T}; device::Integer = 0, kkt_kind::In
     GC.@preserve x0 s0 mu0 check(h, ccall((:cosmo_hip_set_iterates, lib(h)), Int32, (Ptr{Cvoid}, Ptr{T}, Ptr{T}, Ptr{T}),
         h.ptr, x0, s0, mu0))                                                  # src/solver.jl:128-129
     ws.states.IS_OPTIMIZED = true
+    auto_rho = settings.adaptive_rho && settings.adaptive_rho_interval == 0       # the automatic interval (src/solver.jl:244-256) is measured against setup_time
+    auto_rho && check(h, ccall((:cosmo_hip_set_setup_time, lib(h)), Int32, (Ptr{Cvoid}, Cdouble), h.ptr, Float64(ws.times.setup_time)))
     res = Ref{ResultC}()
     GC.@preserve custom_refs check(h, ccall((:cosmo_hip_optimize, lib(h)), Int32, (Ptr{Cvoid}, Ref{ResultC}), h.ptr, res))   # src/solver.jl:137-176
     r = res[]
+    if auto_rho                                                                    # the reference writes the chosen interval into the settings (:249-254)
+        ri = zeros(Int64, 2)
+        check(h, ccall((:cosmo_hip_get_rho_interval, lib(h)), Int32, (Ptr{Cvoid}, Ptr{Int64}), h.ptr, ri))
+        settings.adaptive_rho_interval = Int(ri[1])
+    end
     w = ws.vars.w; wp = ws.vars.w_prev; sd = ws.vars.s.data; mu = ws.vars.μ  # x is a view of w_prev (src/types.jl:274)
     GC.@preserve w wp sd mu check(h, ccall((:cosmo_hip_get_iterates, lib(h)), Int32, (Ptr{Cvoid}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}),
         h.ptr, w, wp, sd, mu))

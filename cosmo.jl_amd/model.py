@@ -112,7 +112,7 @@ class Settings:
     safeguard_tol: float = 2.0
     # accepted for drop-in compatibility with COSMO.Settings (src/settings.jl:101-139); they do not touch the hot path:
     nearly_ratio: float = 100.0            # only read by the MOI wrapper (is_primal_nearly_feasible, src/MOI_wrapper.jl:558,587)
-    adaptive_rho_fraction: float = 0.4     # only with adaptive_rho_interval = 0 (wall-clock rule, rejected by the device loop)
+    adaptive_rho_fraction: float = 0.4     # only with adaptive_rho_interval = 0 (the automatic interval, solver.jl:244-256)
     verbose_timing: bool = False           # the device loop always reports iter_time / proj_time
 
 
@@ -597,6 +597,7 @@ def _params_from_settings(h, st: Settings):
     p.check_infeasibility = st.check_infeasibility
     p.adaptive_rho = 1 if st.adaptive_rho else 0
     p.adaptive_rho_interval = st.adaptive_rho_interval
+    p.adaptive_rho_fraction = st.adaptive_rho_fraction          # read only with adaptive_rho_interval == 0 (solver.jl:244-256)
     p.unscale_residuals = 1 if st.scaling != 0 else 0
     return p
 
@@ -727,7 +728,11 @@ def optimize(model: Model, dist=None, shard: str = "rows") -> Result:
     t_setup = time.perf_counter() - t0
     h, sm, n = model.handle, model.sm, model.n
     h.set_iterates(model.x, model.s, model.mu)                    # solver.jl:128-129
+    if model.settings.adaptive_rho and model.settings.adaptive_rho_interval == 0:
+        h.set_setup_time(t_setup)                                 # ws.times.setup_time, what the automatic rho interval is measured against (solver.jl:246)
     r = h.optimize()                                              # solver.jl:137-176
+    if model.settings.adaptive_rho and model.settings.adaptive_rho_interval == 0:
+        model.settings.adaptive_rho_interval = h.rho_interval()[0]   # the reference writes the chosen interval into the settings (solver.jl:249-254)
     w, w_prev, s, mu = h.get_iterates()
     model.is_optimized = True
     x = w_prev[:n].copy()                                          # x is a view of w_prev (src/types.jl:274)

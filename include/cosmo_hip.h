@@ -121,10 +121,16 @@ typedef struct cosmo_hip_params {
   int32_t check_termination;         /* 25 */
   int32_t check_infeasibility;       /* 40 */
   int32_t adaptive_rho;              /* 1 */
-  int32_t adaptive_rho_interval;     /* 40 (0 = wall-clock rule, src/solver.jl:244-256: not supported) */
+  int32_t adaptive_rho_interval;     /* 40.  0 = the reference's automatic interval (src/solver.jl:244-256): once the loop has run for
+                                        adaptive_rho_fraction * setup_time seconds the interval is fixed, ONCE, to the current iteration
+                                        count rounded to a multiple of check_termination (at least one); from then on the device schedule
+                                        is that of a fixed interval.  The host applies the rule where it knows the device's progress: at the
+                                        termination checks (every iteration in accelerated runs).  Not in batch mode. */
   int32_t unscale_residuals;         /* 1 iff settings.scaling != 0 (src/residuals.jl:43) */
   double obj_true;                   /* NaN  (settings.obj_true): if set, has_converged additionally requires            */
   double obj_true_tol;               /* 1e-3 |obj_true - cost| <= obj_true_tol (src/residuals.jl:131-139)                 */
+  double adaptive_rho_fraction;      /* 0.4  (settings.adaptive_rho_fraction) -- read only with adaptive_rho_interval == 0                    */
+  double setup_time;                 /* 0    ws.times.setup_time of the caller's setup! in seconds (src/solver.jl:246) -- ditto               */
 } cosmo_hip_params;
 
 /* Accelerator of the fixed-point iteration (settings.accelerator, safeguard, safeguard_tol: src/settings.jl:96-98,136-138;
@@ -296,6 +302,13 @@ int32_t cosmo_hip_fold_stats(cosmo_hip_handle* h, int64_t out[4]);
 /* Statistics of the device loop since set_iterates: out = {admm_iters, kkt_solves, kkt_iters_total,
  * kkt_budget_stalls, spmv_A_calls, spmv_AT_calls, spmv_P_calls, rho_updates}. */
 int32_t cosmo_hip_get_stats(cosmo_hip_handle* h, int64_t out[8]);
+/* The automatic rho interval (settings.adaptive_rho_interval == 0, src/solver.jl:244-256) compares the loop's elapsed time with
+ * adaptive_rho_fraction * ws.times.setup_time; setup! ends AFTER cosmo_hip_set_params, so its duration is handed over separately (any time
+ * before cosmo_hip_optimize; overrides cosmo_hip_params.setup_time). */
+int32_t cosmo_hip_set_setup_time(cosmo_hip_handle* h, double seconds);
+/* out = {adaptive_rho_interval in force (0: the automatic rule has not fired yet), iteration at which the automatic rule fixed it or -1}: what
+ * the reference writes back into settings.adaptive_rho_interval (src/solver.jl:249-254) */
+int32_t cosmo_hip_get_rho_interval(cosmo_hip_handle* h, int64_t out[2]);
 
 /* ---- measurement hooks (bench.py / rocprof cross-check) ----------------------------------------------- */
 /* Times `reps` back-to-back launches of the SpMV kernel `which` (COSMO_HIP_MAT_A/AT/P, or 3 = the fused

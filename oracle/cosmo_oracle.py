@@ -525,6 +525,7 @@ class Settings:
     MAX_SCALING: float = 1e4
     adaptive_rho: bool = True
     adaptive_rho_interval: int = 40
+    adaptive_rho_fraction: float = 0.4      # only read with adaptive_rho_interval == 0 (src/settings.jl; src/solver.jl:244-256)
     adaptive_rho_tolerance: float = 5.0
     adaptive_rho_max_adaptions: int = 2 ** 62
     RHO_MIN: float = 1e-6
@@ -763,6 +764,12 @@ class DirectKKT:
         return self.lu.solve(rhs)
 
 
+def round_multiple(x: int, N: int) -> int:
+    """src/algebra.jl:245-247: floor(x + 0.5 N - rem(x + 0.5 N, N))."""
+    v = x + 0.5 * N
+    return int(math.floor(v - math.fmod(v, N)))
+
+
 def cg_v09(x, mul, b, abstol, maxiter):
     """IterativeSolvers.jl v0.9 `cg!(x, L, b; abstol, reltol=0)` with `initially_zero=false`, no
     preconditioner.  Updates x in place, returns #iterations."""
@@ -788,7 +795,7 @@ def cg_v09(x, mul, b, abstol, maxiter):
 
 
 def pcg_v09(x, mul, b, dinv, abstol, maxiter):
-    """IterativeSolvers.jl v0.9 `cg!(x, L, b; Pl = Diagonal(d), abstol, reltol=0)` with `initially_zero=false`: the package's `PCGIterable`
+    r"""IterativeSolvers.jl v0.9 `cg!(x, L, b; Pl = Diagonal(d), abstol, reltol=0)` with `initially_zero=false`: the package's `PCGIterable`
     (cg.jl `iterate(it::PCGIterable)`; the package is not vendored, SURVEY 8c: parity unpinned, anchored like cg_v09 on the definition).
     NOT what the reference calls -- COSMO passes no preconditioner (src/linear_solver/kktsolver_indirect.jl:70) -- this is the oracle of the
     OPT-IN kkt_kind COSMO_HIP_KKT_CG_JACOBI: left preconditioner Pl = diag(L), ldiv! = elementwise product with dinv = 1 ./ diag(L); the stopping
@@ -1233,6 +1240,13 @@ class Workspace:
         if b is not None:
             self.b = self.sm.E * np.array(b, dtype=np.float64)
 
+    setup_time = 0.0                                            # ws.times.setup_time (only read by the automatic rho interval)
+
+    @staticmethod
+    def clock():
+        import time
+        return time.perf_counter()
+
     def optimize(self, record=None, project_info: Optional[dict] = None) -> Result:
         st = self.st
         n, m = self.n, self.m
@@ -1252,6 +1266,7 @@ class Workspace:
                 self.accelerator_active = False
         acc = self.accelerator
         self.safeguarding_iter = 0
+        iter_start = self.clock()                               # src/solver.jl:134
         status = "Undetermined"
         cost = math.inf
         info = (math.inf, math.inf, 0.0, 0.0)
@@ -1304,6 +1319,10 @@ class Workspace:
             s[:] = w[n:]                                        # :14
             project(s, cones, project_info)                     # :15
             # apply_rho_adaptation_rules! (:242-282)
+            if st.adaptive_rho and st.adaptive_rho_interval == 0:       # the automatic interval (:244-256); `clock` is injectable for tests
+                if (self.clock() - iter_start) > st.adaptive_rho_fraction * self.setup_time:
+                    N = st.check_termination if st.check_termination > 0 else 25
+                    st.adaptive_rho_interval = max(round_multiple(it, N), N)       # written into the settings, as the reference does
             if (st.adaptive_rho and st.adaptive_rho_interval > 0 and it % st.adaptive_rho_interval == 0
                     and (len(self.rho_updates) - 1) < st.adaptive_rho_max_adaptions):
                 rho_update_due = True

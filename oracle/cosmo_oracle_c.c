@@ -177,6 +177,139 @@ static void make_rho(const prob* W, const oc_params* p, oc_real rho) {   /* set_
     W->rho[i] = (W->cls[i] == 1) ? R(p->rho_eq_over_rho_ineq) * rho : (W->cls[i] == 2 ? R(p->rho_min) : rho);
 }
 
+
+/* ---- direct KKT path: the reference's DEFAULT solver QdldlKKTSolver (src/linear_solver/kktsolver.jl:285-320) -----------------------------
+ * K = [P + sigma I, A'; A, -diag(1 ./ rho)] (upper triangle, CSC; assemble_kkt_triangle :175-250), `qdldl(K)` = a fill-reducing symmetric permutation
+ * (AMD.jl) + QDLDL's LDL' (elimination tree, then the up-looking numeric factorisation), `solve!` = copy + permute + L \ . , D \ . , L' \ . + permute back
+ * (:310-313), `update_rho!` = rewrite the last m diagonal entries of K and refactor numerically (:316-320).  QDLDL.jl (compat "0.4.1",
+ * /root/reference/Project.toml:32) and AMD.jl ("0.4, 0.5") are NOT vendored in the reference tree: what follows restates the published QDLDL
+ * algorithm (Stellato et al., OSQP, Math. Prog. Comp. 2020, section 5.1 / the qdldl C sources it ships: QDLDL_etree, QDLDL_factor, QDLDL_Lsolve,
+ * QDLDL_Ltsolve) -- PARITY UNPINNED like the Krylov packages; anchored on a dense solve of the same system (tests/test_oracle_direct_kkt.py).  The
+ * permutation is an input (the Python side takes a minimum-degree ordering; any symmetric permutation gives the same solution).
+ * Used ONLY as bench.py's cpu_baseline.direct_kkt leg (the CPU path north_star names) and by its test. */
+typedef struct {
+  int64_t N;                       /* n + m */
+  const int64_t *Kp, *Ki;          /* upper triangle of the PERMUTED K, CSC, row indices ascending, diagonal LAST in every column */
+  oc_real* Kx;
+  const int64_t* perm;             /* permuted position k holds original index perm[k] */
+  const int64_t* rho_pos;          /* position in Kx of the diagonal entry of original row n + i (i < m) */
+  int64_t *Lp, *Li, *etree, *Lnz, *iwork; unsigned char* bwork;
+  oc_real *Lx, *D, *Dinv, *fwork, *xw;
+  int64_t nnzL, positive_D, n_factor;
+  double factor_time, solve_time; int64_t n_solve;
+} ldl_t;
+#define LDL_UNKNOWN (-1)
+/* QDLDL_etree: elimination tree + column counts of L; returns nnz(L), -1 (entry below the diagonal / empty column) or -2 (more than `cap` nonzeros) */
+static int64_t ldl_etree(int64_t n, const int64_t* Ap, const int64_t* Ai, int64_t* work, int64_t* Lnz, int64_t* etree, int64_t cap) {
+  for (int64_t i = 0; i < n; ++i) { work[i] = 0; Lnz[i] = 0; etree[i] = LDL_UNKNOWN; if (Ap[i] == Ap[i + 1]) return -1; }
+  int64_t sum = 0;
+  for (int64_t j = 0; j < n; ++j) {
+    work[j] = j;
+    for (int64_t p = Ap[j]; p < Ap[j + 1]; ++p) {
+      int64_t i = Ai[p];
+      if (i > j) return -1;
+      while (work[i] != j) {
+        if (etree[i] == LDL_UNKNOWN) etree[i] = j;
+        Lnz[i] += 1; sum += 1;
+        work[i] = j;
+        i = etree[i];
+      }
+    }
+    if (cap > 0 && sum > cap) return -2;
+  }
+  return sum;
+}
+/* QDLDL_factor: up-looking LDL'; row k of L is the solution of a sparse triangular system whose pattern is read off the elimination tree */
+static int ldl_factor(ldl_t* F) {
+  const int64_t n = F->N; const int64_t *Ap = F->Kp, *Ai = F->Ki; const oc_real* Ax = F->Kx;
+  int64_t *Lp = F->Lp, *Li = F->Li; oc_real *Lx = F->Lx, *D = F->D, *Dinv = F->Dinv;
+  unsigned char* yMarkers = F->bwork; int64_t* yIdx = F->iwork; int64_t* elimBuffer = F->iwork + n; int64_t* LNext = F->iwork + 2 * n; oc_real* yVals = F->fwork;
+  int64_t positive = 0;
+  Lp[0] = 0;
+  for (int64_t i = 0; i < n; ++i) { Lp[i + 1] = Lp[i] + F->Lnz[i]; yMarkers[i] = 0; yVals[i] = R(0.0); D[i] = R(0.0); LNext[i] = Lp[i]; }
+  D[0] = Ax[0];
+  if (D[0] == R(0.0)) return -1;
+  if (D[0] > R(0.0)) positive += 1;
+  Dinv[0] = R(1.0) / D[0];
+  for (int64_t k = 1; k < n; ++k) {
+    int64_t nnzY = 0;
+    for (int64_t i = Ap[k]; i < Ap[k + 1]; ++i) {
+      const int64_t bidx = Ai[i];
+      if (bidx == k) { D[k] = Ax[i]; continue; }
+      yVals[bidx] = Ax[i];
+      int64_t next = bidx;
+      if (!yMarkers[next]) {
+        yMarkers[next] = 1;
+        elimBuffer[0] = next;
+        int64_t nnzE = 1;
+        next = F->etree[bidx];
+        while (next != LDL_UNKNOWN && next < k) {
+          if (yMarkers[next]) break;
+          yMarkers[next] = 1;
+          elimBuffer[nnzE++] = next;
+          next = F->etree[next];
+        }
+        while (nnzE) yIdx[nnzY++] = elimBuffer[--nnzE];
+      }
+    }
+    for (int64_t i = nnzY - 1; i >= 0; --i) {
+      const int64_t cidx = yIdx[i];
+      const int64_t tmpIdx = LNext[cidx];
+      const oc_real yc = yVals[cidx];
+      for (int64_t j = Lp[cidx]; j < tmpIdx; ++j) yVals[Li[j]] -= Lx[j] * yc;
+      Li[tmpIdx] = k;
+      Lx[tmpIdx] = yc * Dinv[cidx];
+      D[k] -= yc * Lx[tmpIdx];
+      LNext[cidx] += 1;
+      yVals[cidx] = R(0.0);
+      yMarkers[cidx] = 0;
+    }
+    if (D[k] == R(0.0)) return -1;
+    if (D[k] > R(0.0)) positive += 1;
+    Dinv[k] = R(1.0) / D[k];
+  }
+  F->positive_D = positive;
+  return 0;
+}
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+static int ldl_refactor(ldl_t* F) { const double t0 = now_s(); const int rc = ldl_factor(F); F->factor_time += now_s() - t0; F->n_factor += 1; return rc; }
+/* QDLDL.solve!: x <- P' (L' \ (D \ (L \ (P x)))) */
+static void ldl_solve(ldl_t* F, const oc_real* rhs, oc_real* out) {
+  const double t0 = now_s();
+  const int64_t n = F->N; oc_real* x = F->xw;
+  for (int64_t k = 0; k < n; ++k) x[k] = rhs[F->perm[k]];
+  for (int64_t i = 0; i < n; ++i) { const oc_real v = x[i]; for (int64_t j = F->Lp[i]; j < F->Lp[i + 1]; ++j) x[F->Li[j]] -= F->Lx[j] * v; }
+  for (int64_t i = 0; i < n; ++i) x[i] *= F->Dinv[i];
+  for (int64_t i = n - 1; i >= 0; --i) { oc_real v = x[i]; for (int64_t j = F->Lp[i]; j < F->Lp[i + 1]; ++j) v -= F->Lx[j] * x[F->Li[j]]; x[i] = v; }
+  for (int64_t k = 0; k < n; ++k) out[F->perm[k]] = x[k];
+  F->solve_time += now_s() - t0; F->n_solve += 1;
+}
+static void ldl_free(ldl_t* F) { free(F->Lp); free(F->Li); free(F->etree); free(F->Lnz); free(F->iwork); free(F->bwork); free(F->Lx); free(F->D); free(F->Dinv); free(F->fwork); free(F->xw); }
+/* symbolic analysis + workspace; 0 ok, 1 out of memory, 4 K is not upper triangular with a full diagonal, 5 nnz(L) > cap */
+static int ldl_setup(ldl_t* F, int64_t cap) {
+  const int64_t n = F->N;
+  F->Lp = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n + 1)); F->etree = (int64_t*)malloc(sizeof(int64_t) * (size_t)n); F->Lnz = (int64_t*)malloc(sizeof(int64_t) * (size_t)n);
+  F->iwork = (int64_t*)malloc(sizeof(int64_t) * 3 * (size_t)n); F->bwork = (unsigned char*)malloc((size_t)n);
+  F->D = (oc_real*)malloc(sizeof(oc_real) * (size_t)n); F->Dinv = (oc_real*)malloc(sizeof(oc_real) * (size_t)n); F->fwork = (oc_real*)malloc(sizeof(oc_real) * (size_t)n);
+  F->xw = (oc_real*)malloc(sizeof(oc_real) * (size_t)n);
+  if (!F->Lp || !F->etree || !F->Lnz || !F->iwork || !F->bwork || !F->D || !F->Dinv || !F->fwork || !F->xw) return 1;
+  const int64_t nnzL = ldl_etree(n, F->Kp, F->Ki, F->iwork, F->Lnz, F->etree, cap);
+  if (nnzL == -1) return 4;
+  if (nnzL == -2) return 5;
+  F->nnzL = nnzL;
+  F->Li = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nnzL + 1)); F->Lx = (oc_real*)malloc(sizeof(oc_real) * (size_t)(nnzL + 1));
+  if (!F->Li || !F->Lx) return 1;
+  return 0;
+}
+/* nnz(L) of the permuted upper triangle alone (etree pass), -2 if it exceeds `cap` (> 0): the feasibility probe of bench.py for BASELINE config 2 */
+int64_t cosmo_oracle_c_ldl_nnz(int64_t N, const int64_t* Kp, const int64_t* Ki, int64_t cap) {
+  int64_t* w = (int64_t*)malloc(sizeof(int64_t) * 3 * (size_t)N);
+  if (!w) return -3;
+  const int64_t r = ldl_etree(N, Kp, Ki, w, w + N, w + 2 * N, cap);
+  free(w);
+  return r;
+}
+
 /* ncones slice cones (SOC / PSD; kind per row 0 on their rows) with LAPACK / BLAS entry points `syevr`, `syrk` (NULL when there is no PSD cone);
  * rank_out / branch_out: nnz_lambda / SOC branch id of the LAST projection per cone (NULL to skip); proj_time_out: seconds spent in the cone loop */
 /* ---- AndersonAccelerator (COSMOAccelerators.jl, external to the reference tree: restated from the published algorithm exactly as
@@ -245,7 +378,7 @@ static void aa_accelerate(aa_t* a, oc_real* g) {
   a->success = 1;
 }
 
-int32_t cosmo_oracle_c_run_cones(int64_t n, int64_t m, const int64_t* Pp, const int64_t* Pi, const oc_real* Px, const int64_t* Ap, const int64_t* Ai,
+static int32_t run_loop(ldl_t* dk, int64_t n, int64_t m, const int64_t* Pp, const int64_t* Pi, const oc_real* Px, const int64_t* Ap, const int64_t* Ai,
                                  const oc_real* Ax, const oc_real* q, const oc_real* b, const oc_real* Dinv, const oc_real* Einv, const int32_t* cls,
                                  const int32_t* kind, const oc_real* bl, const oc_real* bu, const oc_params* prm, const oc_real* rho_vec0,
                                  oc_real* x_io, oc_real* s_io, oc_real* mu_io, oc_real* rho_updates_out, int32_t rho_updates_cap, oc_result* res,
@@ -307,6 +440,9 @@ int32_t cosmo_oracle_c_run_cones(int64_t n, int64_t m, const int64_t* Pp, const 
   {                                                                                                                           \
     for (int64_t j = 0; j < n; ++j) ls[j] = p_sigma * w[j] - q[j];                              /* solver.jl:50 */            \
     for (int64_t i = 0; i < m; ++i) ls[n + i] = (b[i] - R(2.0) * s[i]) + w[n + i];                 /* :51 */                     \
+    if (dk) {                                                        /* solve!(::QdldlKKTSolver, sol, ls) (kktsolver.jl:310-313) */         \
+      ldl_solve(dk, ls, sol);                                                                                                 \
+    } else {                                                                                                                  \
     for (int64_t i = 0; i < m; ++i) y2[i] = W.rho[i] * ls[n + i];                               /* kktsolver_indirect.jl:52 */\
     mulT(&W.A, y2, y1);                                                                                                       \
     for (int64_t j = 0; j < n; ++j) y1[j] = y1[j] + ls[j];                                                                    \
@@ -331,6 +467,7 @@ int32_t cosmo_oracle_c_run_cones(int64_t n, int64_t m, const int64_t* Pp, const 
     mul(&W.A, prev, tmp_m);                                                                     /* :81-83 */                  \
     for (int64_t i = 0; i < m; ++i) sol[n + i] = (tmp_m[i] - ls[n + i]) * W.rho[i];                                           \
     iteration_counter += 1;                                                                                                   \
+    }                                                                                                                         \
     for (int64_t i = 0; i < m; ++i) s_tl[i] = (R(2.0) * s[i] - w[n + i]) - sol[n + i] / W.rho[i];  /* solver.jl:55 */            \
     for (int64_t j = 0; j < n; ++j) w[j] = w[j] + p_alpha * (sol[j] - w[j]);                    /* :63 */                     \
     for (int64_t i = 0; i < m; ++i) w[n + i] = w[n + i] + p_alpha * (s_tl[i] - s[i]);           /* :64 */                     \
@@ -413,6 +550,10 @@ int32_t cosmo_oracle_c_run_cones(int64_t n, int64_t m, const int64_t* Pp, const 
       if (new_rho > p_adaptive_rho_tolerance * rho || new_rho < (R(1.0) / p_adaptive_rho_tolerance) * rho) {
         rho = new_rho;
         make_rho(&W, &p, rho);
+        if (dk) {                                                          /* update_rho! (kktsolver.jl:316-320): new diagonal + numeric refactorisation */
+          for (int64_t i = 0; i < m; ++i) dk->Kx[dk->rho_pos[i]] = -R(1.0) / W.rho[i];
+          if (ldl_refactor(dk) != 0) { free(buf); free(psd_buf); free(aa_buf); return 6; }
+        }
         if (rho_updates_out && n_rho < rho_updates_cap) rho_updates_out[n_rho] = rho;
         n_rho += 1;
         if (p.accel) aa_restart(&aa);                                   /* :272-275: the ADMM operator changed */
@@ -464,6 +605,47 @@ int32_t cosmo_oracle_c_run_cones(int64_t n, int64_t m, const int64_t* Pp, const 
   free(psd_buf);
   if (proj_time_out) *proj_time_out = proj_time;
   return 0;
+}
+
+int32_t cosmo_oracle_c_run_cones(int64_t n, int64_t m, const int64_t* Pp, const int64_t* Pi, const oc_real* Px, const int64_t* Ap, const int64_t* Ai,
+                                 const oc_real* Ax, const oc_real* q, const oc_real* b, const oc_real* Dinv, const oc_real* Einv, const int32_t* cls,
+                                 const int32_t* kind, const oc_real* bl, const oc_real* bu, const oc_params* prm, const oc_real* rho_vec0,
+                                 oc_real* x_io, oc_real* s_io, oc_real* mu_io, oc_real* rho_updates_out, int32_t rho_updates_cap, oc_result* res,
+                                 int64_t ncones, const int32_t* ckind, const int64_t* coff, const int64_t* cdim, void* syevr, void* syrk,
+                                 int64_t* rank_out, int32_t* branch_out, double* proj_time_out) {
+  return run_loop(NULL, n, m, Pp, Pi, Px, Ap, Ai, Ax, q, b, Dinv, Einv, cls, kind, bl, bu, prm, rho_vec0, x_io, s_io, mu_io, rho_updates_out, rho_updates_cap, res,
+                  ncones, ckind, coff, cdim, syevr, syrk, rank_out, branch_out, proj_time_out);
+}
+
+/* The same loop with the reference's default direct KKT solver.  Kp / Ki / Kx: upper triangle of the symmetrically permuted KKT matrix (Kx is
+ * overwritten by rho updates), perm[k] = original index at permuted position k, rho_pos[i] = position in Kx of the diagonal entry of row n + i.
+ * ldl_stats_out = {nnz(L), factor seconds (all factorisations), number of factorisations, solve seconds (all solves), number of solves, positive
+ * entries of D (inertia: must equal n, kktsolver.jl:304), setup seconds (etree)}.  nnz_cap > 0: give up (return 5) if nnz(L) exceeds it. */
+int32_t cosmo_oracle_c_run_cones_direct(int64_t n, int64_t m, const int64_t* Pp, const int64_t* Pi, const oc_real* Px, const int64_t* Ap, const int64_t* Ai,
+                                        const oc_real* Ax, const oc_real* q, const oc_real* b, const oc_real* Dinv, const oc_real* Einv, const int32_t* cls,
+                                        const int32_t* kind, const oc_real* bl, const oc_real* bu, const oc_params* prm, const oc_real* rho_vec0,
+                                        oc_real* x_io, oc_real* s_io, oc_real* mu_io, oc_real* rho_updates_out, int32_t rho_updates_cap, oc_result* res,
+                                        int64_t ncones, const int32_t* ckind, const int64_t* coff, const int64_t* cdim, void* syevr, void* syrk,
+                                        int64_t* rank_out, int32_t* branch_out, double* proj_time_out,
+                                        const int64_t* Kp, const int64_t* Ki, oc_real* Kx, const int64_t* perm, const int64_t* rho_pos, int64_t nnz_cap,
+                                        double* ldl_stats_out) {
+  ldl_t F;
+  memset(&F, 0, sizeof F);
+  F.N = n + m; F.Kp = Kp; F.Ki = Ki; F.Kx = Kx; F.perm = perm; F.rho_pos = rho_pos;
+  const double t0 = now_s();
+  int rc = ldl_setup(&F, nnz_cap);
+  const double t_sym = now_s() - t0;
+  if (rc == 0 && ldl_refactor(&F) != 0) rc = 6;
+  if (rc == 0 && F.positive_D != n) rc = 7;                               /* "Objective function is not convex." (kktsolver.jl:304) */
+  if (rc == 0)
+    rc = run_loop(&F, n, m, Pp, Pi, Px, Ap, Ai, Ax, q, b, Dinv, Einv, cls, kind, bl, bu, prm, rho_vec0, x_io, s_io, mu_io, rho_updates_out, rho_updates_cap, res,
+                  ncones, ckind, coff, cdim, syevr, syrk, rank_out, branch_out, proj_time_out);
+  if (ldl_stats_out) {
+    ldl_stats_out[0] = (double)F.nnzL; ldl_stats_out[1] = F.factor_time; ldl_stats_out[2] = (double)F.n_factor; ldl_stats_out[3] = F.solve_time;
+    ldl_stats_out[4] = (double)F.n_solve; ldl_stats_out[5] = (double)F.positive_D; ldl_stats_out[6] = t_sym;
+  }
+  ldl_free(&F);
+  return rc;
 }
 
 /* the row-cone-only entry point of rounds 1-2 (BASELINE configs 1 and 2) */

@@ -83,7 +83,7 @@ def test_struct_layouts_match_header():
         typ, rest = decl.split(None, 1)
         fields += [f.strip() for f in rest.split(",")]
     assert fields == [f[0] for f in cj._ffi.Params._fields_]
-    assert ctypes.sizeof(cj._ffi.Params) == 16 * 8 + 2 * 8 + 6 * 4 + 2 * 8          # ... + obj_true, obj_true_tol
+    assert ctypes.sizeof(cj._ffi.Params) == 16 * 8 + 2 * 8 + 6 * 4 + 2 * 8 + 2 * 8  # ... + obj_true, obj_true_tol + adaptive_rho_fraction, setup_time (ABI 1002)
     assert ctypes.sizeof(cj._ffi.ResultStruct) == 2 * 4 + 3 * 8 + 8 * 8 + 64 * 8 + 8      # ... + safeguarding_iter
 
 
@@ -387,6 +387,17 @@ def test_committed_bench_line_follows_the_contract():
         assert key in cb, key
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1
     assert abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-3             # value = steps / elapsed, ms_per_step = elapsed / steps
-    assert set(d.get("extra", {})) == {"cfg3", "cfg4", "cfg5"}
+    r05 = files[-1].split(os.sep)[-1] >= "r05"
+    # round 5: the headline is config 5, the workload north_star's targets are stated on; configs 2 / 3 / 4 are the extras
+    assert d["config"]["workload"].startswith("cfg5" if r05 else "cfg2")
+    assert set(d.get("extra", {})) == ({"cfg2", "cfg3", "cfg4"} if r05 else {"cfg3", "cfg4", "cfg5"})
     for name, e in d["extra"].items():
         assert "error" not in e and e["value"] > 0 and "roofline" in e and "cpu_baseline" in e, name
+    if r05:
+        assert d["scaling"] == "strong" and list(d)[-1] == "summary" and set(d["summary"]) >= {"cfg5", "cfg2", "cfg3", "cfg4"}
+        assert all(d["summary"][k]["value"] == (d if k == "cfg5" else d["extra"][k])["value"] for k in ("cfg5", "cfg2", "cfg3", "cfg4"))
+        # the CPU path north_star names ("the reference Julia/QDLDL CPU path"): the direct-KKT leg, next to the CG leg
+        dk = cb["direct_kkt"]
+        assert dk["value"] > cb["value"] and dk["nnz_L"] > 0 and dk["factor_s"] > 0 and dk["solve_ms"] > 0 and dk["cores"] == 1
+        assert abs(d["config"]["gpu_over_cpu_direct_kkt"] - d["value"] / dk["value"]) < 0.05 * d["config"]["gpu_over_cpu_direct_kkt"]
+        assert d["extra"]["cfg2"]["cpu_baseline"]["direct_kkt"]["feasible"] is False

@@ -462,12 +462,18 @@ def test_a_corrupted_exchange_turns_the_bench_lines_parity_evidence_red():
     comm, par = out["config"]["comm"], out["config"]["parity"]
     assert comm["selftest"].startswith("FAILED") and comm["exact_sum_mismatches"] > 0
     assert par["ok"] is False and par["sharded_vs_single_max_rel_dev"] > 1e-5
+    # ... and so do the FLAT top-level copies the driver's parsed line keeps (round 5), and the digest at the end of the line
+    cfg = out["config"]
+    assert cfg["parity_ok"] is False and cfg["parity_sharded_vs_single_max_rel_dev"] > 1e-5 and cfg["comm_selftest"].startswith("FAILED")
+    assert out["summary"]["parity_ok"] is False and list(out)[-1] == "summary"
 
 
 def test_bench_gpus_2_without_a_launcher_is_a_two_rank_run_of_the_same_headline_workload():
     """The driver starts the bench as a plain `python bench.py --gpus N ...`: that command alone must produce a valid N-rank line (it
-    re-launches itself under torch.distributed.run), and the headline must be the SAME workload at every N (cfg2 replicas, weak), with
-    the configurations that shard reported under extra.*_sharded with scaling = strong."""
+    re-launches itself under torch.distributed.run), and the headline must be the SAME workload at every N -- since round 5 config 5, the workload
+    north_star's targets are stated on: ONE problem, unsharded at N = 1, row-sharded at N > 1, `scaling: strong` (the 1 -> 8 curve
+    of weak-scaled cfg2 replicas read 8x by construction).  The parity evidence sits at the TOP level of the line; the batch that shards is
+    extra.cfg3_sharded; the two configurations that do not shard are explicit replicas, one replica's rate, never aggregated."""
     common = ["--steps", "6", "--warmup", "2", "--small", "--no-cpu-baseline", "--no-float32"]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
     one = _one_json_line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-extra"] + common, env=env, cwd=ROOT,
@@ -475,20 +481,30 @@ def test_bench_gpus_2_without_a_launcher_is_a_two_rank_run_of_the_same_headline_
     two = _one_json_line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, env=dict(env, COSMO_BENCH_TRANSPORT="shm"),
                                         cwd=ROOT, capture_output=True, text=True, timeout=600))
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
-    assert one["config"]["workload"] == two["config"]["workload"] and one["config"]["workload"].startswith("cfg2")
-    assert one["metric"] == two["metric"] and one["scaling"] == two["scaling"] == "weak" and one["steps"] == two["steps"] == 6
+    assert one["config"]["workload"] == two["config"]["workload"] and one["config"]["workload"].startswith("cfg5")
+    assert one["metric"] == two["metric"] and one["scaling"] == two["scaling"] == "strong" and one["steps"] == two["steps"] == 6
     assert two["config"]["launch"] == "self-launched torch.distributed.run" and one["config"]["launch"] == "single process"
-    assert "replicas x2" in two["config"]["parallelism"] and two["value"] > 0 and "DRY RUN" in two["data"]
+    assert one["config"]["parallelism"] == "single GPU" and "sharded over 2 ranks" in two["config"]["parallelism"] and two["value"] > 0 and "DRY RUN" in two["data"]
+    assert one["roofline"]["bound"] in ("hbm", "mfma") and two["roofline"]["bound"] in ("hbm", "mfma")
+    c5 = two["config"]
+    assert c5["comm"]["nranks"] == 2 and c5["comm"]["mode"] == "rows" and c5["single_gpu_same_workload"] > 0 and c5["speedup_vs_single_gpu"] > 0
+    _assert_parity_evidence(c5, c5["comm"], 1e-7)
+    # the flat copies (what the driver's parsed line keeps) agree with the nested objects
+    assert c5["parity_ok"] is True and c5["parity_sharded_vs_single_max_rel_dev"] == c5["parity"]["sharded_vs_single_max_rel_dev"] <= 1e-7
+    assert c5["parity_ranks_bit_identical"] is True and c5["comm_selftest"] == "ok" and "host-staged" in c5["comm_transport"]
     ex = two["extra"]
-    assert set(ex) == {"cfg5_sharded", "cfg3_sharded"}
+    assert set(ex) == {"cfg3_sharded", "cfg2_replicas", "cfg4_replicas"}
     for key in ex:
         assert "error" not in ex[key], ex[key]
-        assert ex[key]["scaling"] == "strong" and ex[key]["n_gpus"] == 2 and ex[key]["value"] > 0
-    c5 = ex["cfg5_sharded"]["config"]
-    assert c5["comm"]["nranks"] == 2 and c5["comm"]["mode"] == "rows" and c5["single_gpu_same_workload"] > 0
-    _assert_parity_evidence(c5, c5["comm"], 1e-7)
+        assert ex[key]["n_gpus"] == 2 and ex[key]["value"] > 0
+    assert ex["cfg3_sharded"]["scaling"] == "strong"
     assert ex["cfg3_sharded"]["config"]["parity"]["ok"] is True and ex["cfg3_sharded"]["config"]["parity"]["sharded_vs_single_max_rel_dev"] == 0.0
-    assert len(two["config"]["rank_seconds"]["per_rank"]) == 2
+    for key in ("cfg2_replicas", "cfg4_replicas"):
+        assert ex[key]["scaling"] == "replicas" and ex[key]["replicas"] == 2
+        assert abs(ex[key]["value"] * ex[key]["ms_per_step"] / 1e3 - 1.0) < 1e-3      # ONE replica's rate = steps / max-over-ranks time: not multiplied by N
+    # the digest at the very end of the line (the driver keeps the tail): every workload's rate
+    assert list(two)[-1] == "summary" and set(two["summary"]) >= {"cfg5", "cfg3_sharded", "cfg2_replicas", "cfg4_replicas", "parity_ok", "speedup_vs_single_gpu"}
+    assert two["summary"]["cfg5"]["value"] == two["value"] and two["summary"]["parity_ok"] is True
 
 
 def test_bench_reports_the_headline_even_if_a_sharded_extra_never_finishes():
@@ -500,6 +516,6 @@ def test_bench_reports_the_headline_even_if_a_sharded_extra_never_finishes():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--small", "--no-cpu-baseline", "--no-float32"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     two = _one_json_line(r)
-    assert two["n_gpus"] == 2 and two["value"] > 0 and two["config"]["workload"].startswith("cfg2") and two["scaling"] == "weak"
-    assert set(two["extra"]) == {"cfg5_sharded", "cfg3_sharded"}
+    assert two["n_gpus"] == 2 and two["value"] > 0 and two["config"]["workload"].startswith("cfg5") and two["scaling"] == "strong"
+    assert set(two["extra"]) == {"cfg3_sharded", "cfg2_replicas", "cfg4_replicas"}
     assert any("error" in v for v in two["extra"].values())
