@@ -137,6 +137,20 @@ SIGNATURES = {
     "cosmo_hip_batch_iterate": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32]),
     "cosmo_hip_batch_get_iterates": (C.c_int32, [C.c_void_p, C.c_int64, _PR, _PR, _PR, _PR]),
     "cosmo_hip_batch_get_counters": (C.c_int32, [C.c_void_p, _PI64]),
+    "cosmo_hip_batch_group_create": (C.c_int32, [C.POINTER(C.c_void_p), C.c_int32, C.c_int64]),
+    "cosmo_hip_batch_group_destroy": (C.c_int32, [C.c_void_p]),
+    "cosmo_hip_batch_group_last_error": (C.c_char_p, [C.c_void_p]),
+    "cosmo_hip_batch_group_set_problem": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, _PI64, _PI64, _PR, _PI64, _PI64, _PR, _PR, _PR]),
+    "cosmo_hip_batch_group_set_cones": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int64, _PI32, _PI64, _PR, _PR, _PR]),
+    "cosmo_hip_batch_group_set_scaling": (C.c_int32, [C.c_void_p, C.c_int64, _PR, _PR, C.c_double]),
+    "cosmo_hip_batch_group_set_accelerator": (C.c_int32, [C.c_void_p, C.POINTER(AccelParams)]),
+    "cosmo_hip_batch_group_set_params": (C.c_int32, [C.c_void_p, C.POINTER(Params)]),
+    "cosmo_hip_batch_group_class_info": (C.c_int32, [C.c_void_p, _PI64, _PI64]),
+    "cosmo_hip_batch_group_set_iterates": (C.c_int32, [C.c_void_p, C.c_int64, _PR, _PR, _PR]),
+    "cosmo_hip_batch_group_optimize": (C.c_int32, [C.c_void_p, C.POINTER(ResultStruct)]),
+    "cosmo_hip_batch_group_get_iterates": (C.c_int32, [C.c_void_p, C.c_int64, _PR, _PR, _PR, _PR]),
+    "cosmo_hip_batch_group_get_counters": (C.c_int32, [C.c_void_p, _PI64]),
+    "cosmo_hip_batch_group_get_accel_stats": (C.c_int32, [C.c_void_p, _PI64]),
 }
 
 
@@ -637,3 +651,102 @@ class Batch:
         w = np.empty(N, dtype=self.dtype); wp = np.empty(N, dtype=self.dtype); s = np.empty(self.m, dtype=self.dtype); mu = np.empty(self.m, dtype=self.dtype)
         self._chk(self.lib.cosmo_hip_batch_get_iterates(self._b, int(k), _dp(w), _dp(wp), _dp(s), _dp(mu)))
         return w, wp, s, mu
+
+
+class BatchGroup:
+    """Batch of independent problems of DIFFERENT structure (csrc/batch_group.hip): every problem brings its own (n, m, cones); the library
+    partitions them into classes of identical structure, one `Batch` per class, and solves all classes concurrently.  The reference's batch is a
+    loop over arbitrary models (src/solver.jl:78)."""
+
+    def __init__(self, nprob, device=0, dtype=np.float64):
+        self.dtype = np.dtype(np.float32 if _is_f32(dtype) else np.float64)
+        self.lib = load_library(self.dtype)
+        self._g = C.c_void_p()
+        rc = self.lib.cosmo_hip_batch_group_create(C.byref(self._g), int(device), int(nprob))
+        if rc != OK:
+            raise CosmoHipError(rc, "cosmo_hip_batch_group_create failed (no MI355X visible? this library has no CPU path)")
+        self.nprob = int(nprob)
+        self.dims = [None] * self.nprob
+
+    def _f(self, a, n=None, name="array"):
+        return _f64(a, n, name, self.dtype)
+
+    def close(self):
+        if self._g:
+            self.lib.cosmo_hip_batch_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != OK:
+            msg = self.lib.cosmo_hip_batch_group_last_error(self._g)
+            raise CosmoHipError(rc, msg.decode() if msg else "")
+
+    def set_problem(self, k, P, q, A, b):
+        m, n = A.shape
+        pc, pr, pv = csc_julia(P, self.dtype)
+        ac, ar, av = csc_julia(A, self.dtype)
+        q = self._f(q, n, "q"); b = self._f(b, m, "b")
+        self._chk(self.lib.cosmo_hip_batch_group_set_problem(self._g, int(k), int(n), int(m), pc.ctypes.data_as(_PI64), pr.ctypes.data_as(_PI64), _dp(pv),
+                                                             ac.ctypes.data_as(_PI64), ar.ctypes.data_as(_PI64), _dp(av), _dp(q), _dp(b)))
+        self.dims[int(k)] = (int(n), int(m))
+
+    def set_cones(self, k, types, dims, box_l=None, box_u=None, cone_param=None):
+        t = np.ascontiguousarray(types, dtype=np.int32); d = np.ascontiguousarray(dims, dtype=np.int64)
+        bl = self._f(box_l); bu = self._f(box_u)
+        cp = self._f(cone_param, t.size) if cone_param is not None else None
+        self._chk(self.lib.cosmo_hip_batch_group_set_cones(self._g, int(k), t.size, t.ctypes.data_as(_PI32), d.ctypes.data_as(_PI64), _dp(bl), _dp(bu), _dp(cp)))
+
+    def set_scaling(self, k, Dinv, Einv, cinv):
+        n, m = self.dims[int(k)]
+        self._chk(self.lib.cosmo_hip_batch_group_set_scaling(self._g, int(k), _dp(self._f(Dinv, n)), _dp(self._f(Einv, m)), float(cinv)))
+
+    def set_accelerator(self, kind=ACCEL_ANDERSON, mem=15, min_mem=3, safeguard=True, safeguard_tol=2.0, start_iter=2, start_accuracy=None):
+        ap = AccelParams()
+        self.lib.cosmo_hip_default_accel_params(C.byref(ap))
+        ap.kind, ap.mem, ap.min_mem, ap.safeguard = int(kind), int(mem), int(min_mem), 1 if safeguard else 0
+        ap.safeguard_tol, ap.start_iter = float(safeguard_tol), int(start_iter)
+        if start_accuracy is not None:
+            ap.start_accuracy = float(start_accuracy)
+        self._chk(self.lib.cosmo_hip_batch_group_set_accelerator(self._g, C.byref(ap)))
+
+    def set_params(self, params):
+        self._chk(self.lib.cosmo_hip_batch_group_set_params(self._g, C.byref(params)))
+
+    def class_info(self):
+        """(number of structure classes, class index of every problem)"""
+        nc = C.c_int64(0)
+        cls = np.zeros(self.nprob, dtype=np.int64)
+        self._chk(self.lib.cosmo_hip_batch_group_class_info(self._g, C.byref(nc), cls.ctypes.data_as(_PI64)))
+        return int(nc.value), cls
+
+    def set_iterates(self, k, x0=None, s0=None, mu0=None):
+        n, m = self.dims[int(k)]
+        self._chk(self.lib.cosmo_hip_batch_group_set_iterates(self._g, int(k), _dp(self._f(x0, n)), _dp(self._f(s0, m)), _dp(self._f(mu0, m))))
+
+    def optimize(self):
+        res = (ResultStruct * self.nprob)()
+        self._chk(self.lib.cosmo_hip_batch_group_optimize(self._g, res))
+        return list(res)
+
+    def get_iterates(self, k):
+        n, m = self.dims[int(k)]
+        w = np.empty(n + m, dtype=self.dtype); wp = np.empty(n + m, dtype=self.dtype); s = np.empty(m, dtype=self.dtype); mu = np.empty(m, dtype=self.dtype)
+        self._chk(self.lib.cosmo_hip_batch_group_get_iterates(self._g, int(k), _dp(w), _dp(wp), _dp(s), _dp(mu)))
+        return w, wp, s, mu
+
+    def counters(self):
+        out = np.zeros(3 * self.nprob, dtype=np.int64)
+        self._chk(self.lib.cosmo_hip_batch_group_get_counters(self._g, out.ctypes.data_as(_PI64)))
+        return out[0::3].copy(), out[1::3].copy(), out[2::3].copy()
+
+    def accel_stats(self):
+        out = np.zeros(6 * self.nprob, dtype=np.int64)
+        self._chk(self.lib.cosmo_hip_batch_group_get_accel_stats(self._g, out.ctypes.data_as(_PI64)))
+        keys = ("accelerated", "accepted", "declined", "restarts", "active", "safeguarding_iter")
+        return {k: out[i::6].copy() for i, k in enumerate(keys)}

@@ -75,6 +75,7 @@ struct BatchDev {
   // rows of a wave-step have similar lengths.  Null: every thread computes the rows it owns.
   const int *permA, *permT;
   const int *posN, *posM;       // nprob * n, nprob * m: position of an entry in the gathered LDS vectors (null: its index)
+  int regcg;                    // LDS-image kernel with the extended cones (512 threads): Krylov vectors in registers (n <= 1024, m <= 2048; batch_admm_body)
 };
 
 struct BParams {
@@ -188,6 +189,9 @@ struct StreamOps {
   real* lds; real* red;
   unsigned char* psd_ws;
   static constexpr bool in_lds = false;
+  __device__ __forceinline__ real rowA(int, const real*) const { return R(0.0); }     // (register-CG form: LdsOps only)
+  __device__ __forceinline__ real rowAT(int, const real*) const { return R(0.0); }
+  __device__ __forceinline__ real rowP(int, const real*) const { return R(0.0); }
   __device__ __forceinline__ real* buf_n(real* g) const { return g; }       // vector the A / P products gather from
   __device__ __forceinline__ real* buf_m(real* g) const { return g; }       // vector the A' products gather from
   __device__ __forceinline__ const real* stage_n(const real* g) const { return g; }
@@ -215,6 +219,38 @@ struct LdsOps {
   unsigned char* psd_ws;
   int n;
   static constexpr bool in_lds = true;
+  // whole rows, left to right, software-pipelined by one nonzero like the register kernel's row loops (the index / value loads of nonzero t + 1 go
+  // out with the gather of nonzero t): the row functions of the register-CG form of the Krylov loop below (batch_admm_body, RCG)
+  __device__ __forceinline__ real rowA(int r, const real* x) const {
+    real s1 = 0.0;
+    int t = Arp[r]; const int b2 = Arp[r + 1];
+    if (t < b2) {
+      real v = Aval[t]; int c = Acol[t];
+      for (++t; t < b2; ++t) { const real vn = Aval[t]; const int cn = Acol[t]; s1 += v * x[c]; v = vn; c = cn; }
+      s1 += v * x[c];
+    }
+    return s1;
+  }
+  __device__ __forceinline__ real rowAT(int r, const real* y) const {
+    real s1 = 0.0;
+    int t = Trp[r]; const int b2 = Trp[r + 1];
+    if (t < b2) {
+      int p = Tpos[t], q2 = Trow[t];
+      for (++t; t < b2; ++t) { const int pn2 = Tpos[t], qn2 = Trow[t]; s1 += Aval[p] * y[q2]; p = pn2; q2 = qn2; }
+      s1 += Aval[p] * y[q2];
+    }
+    return s1;
+  }
+  __device__ __forceinline__ real rowP(int r, const real* x) const {
+    real s1 = 0.0;
+    int t = Prp[r]; const int b2 = Prp[r + 1];
+    if (t < b2) {
+      real v = Pval[t]; int c = Pcol[t];
+      for (++t; t < b2; ++t) { const real vn = Pval[t]; const int cn = Pcol[t]; s1 += v * x[c]; v = vn; c = cn; }
+      s1 += v * x[c];
+    }
+    return s1;
+  }
   __device__ __forceinline__ real* buf_n(real*) const { return xv; }
   __device__ __forceinline__ real* buf_m(real*) const { return tv; }
   __device__ __forceinline__ const real* stage_n(const real* g) const {     // copy a global n-vector into the LDS gather buffer
@@ -488,6 +524,53 @@ __device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams
     const real tol = tol_k / sqrt(bb);
     real res = sqrt(rr), prev = 1.0;
     int kk = 0;
+    // Register-CG form (round 5; the LDS-image kernel of the batches with PSD / exponential / power cones and of their accelerated runs): the four
+    // Krylov vectors r, u, x_tl, c and rho of the rows live in the registers of the threads that OWN elements tid + BS j for the whole solve --
+    // global memory is read once before and written once after the loop instead of eight times per Krylov iteration -- and the two sparse
+    // passes run whole rows on the software-pipelined row loops of the LDS image.  Same row sums (left to right); the block reductions add the
+    // partials of this BS-strided ownership instead of the tile-order ownership of the generic loop below, as the register kernel's do
+    // (trajectories agree with the streaming kernel to 1e-9 in tight-CG mode instead of bit for bit; COSMO_HIP_BATCH_LDSCG=0 restores the generic loop).
+    constexpr bool RCG = Ops::in_lds && PSD && BS == 512;
+    constexpr int RJN = 2, RJM = 4;
+    bool regcg = false;
+    if constexpr (RCG) regcg = D.regcg != 0;
+    if (regcg) {
+      if constexpr (RCG) {
+      __syncthreads();                                                   // r (written in tile order above) is visible to its strided owners
+      real rR[RJN], uR[RJN], xR[RJN], cR[RJN], rhoR[RJM];
+#pragma unroll
+      for (int j = 0; j < RJN; ++j) { const int i = tid + BS * j; const bool ok = i < n; rR[j] = ok ? r[i] : R(0.0); xR[j] = ok ? x_tl[i] : R(0.0); uR[j] = 0.0; cR[j] = 0.0; }
+#pragma unroll
+      for (int j = 0; j < RJM; ++j) { const int i = tid + BS * j; rhoR[j] = (i < m) ? rho[i] : R(1.0); }
+      while (kk < n && !(res <= tol)) {                                  // cg! (IterativeSolvers v0.9), maxiter = n
+        const real beta = (res * res) / (prev * prev);
+#pragma unroll
+        for (int j = 0; j < RJN; ++j) { const int i = tid + BS * j; uR[j] = rR[j] + beta * ((kk == 0) ? R(0.0) : uR[j]); if (i < n) u[i] = uR[j]; }
+        __syncthreads();
+        real tmpv[RJM];
+#pragma unroll
+        for (int j = 0; j < RJM; ++j) { const int i = tid + BS * j; tmpv[j] = (i < m) ? ops.rowA(i, u) * rhoR[j] : R(0.0); }
+#pragma unroll
+        for (int j = 0; j < RJM; ++j) { const int i = tid + BS * j; if (i < m) tmp_m[i] = tmpv[j]; }   // (tmp_m was last read before the block sums of the previous iteration)
+        __syncthreads();
+        acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < RJN; ++j) {
+          const int i = tid + BS * j;
+          if (i < n) { const real vj = uR[j]; const real cj = ops.rowP(i, u) + (P.sigma * vj + ops.rowAT(i, tmp_m)); cR[j] = cj; acc += vj * cj; }
+        }
+        const real uc = bsum<BS>(acc, red);
+        const real a = (res * res) / uc;
+        acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < RJN; ++j) { xR[j] = xR[j] + a * uR[j]; const real ri = rR[j] - a * cR[j]; rR[j] = ri; acc += ri * ri; }
+        rr = bsum<BS>(acc, red);
+        prev = res; res = sqrt(rr); ++kk;
+      }
+#pragma unroll
+      for (int j = 0; j < RJN; ++j) { const int i = tid + BS * j; if (i < n) x_tl[i] = xR[j]; }
+      }
+    } else
     while (kk < n && !(res <= tol)) {                                    // cg! (IterativeSolvers v0.9), maxiter = n
       const real beta = (res * res) / (prev * prev);
       for (int i = tid; i < n; i += BS) u[i] = r[i] + beta * ((kk == 0) ? R(0.0) : u[i]);
@@ -1840,6 +1923,8 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
     if (nws < (nmid > 0 ? 4 : 1)) { b->reg_mode = 0; return COSMO_HIP_OK; }       // (the image is released with the batch); side 17 .. 64 needs four (one per block pair)
   }
   b->D.psd_nws = nws;
+  { const char* ec = getenv("COSMO_HIP_BATCH_LDSCG");
+    b->D.regcg = (bs == 512 && n <= 2 * 512 && m <= 4 * 512 && !(ec && atoi(ec) == 0)) ? 1 : 0; }
   b->d_img = d; b->img_stride = stride; b->lds_bs = bs;
   b->lds_bytes = (int)(npsd > 0 ? ws_base + (long long)nws * PSD16_WS_STRIDE : stride + (long long)sizeof(real) * (n + m) + (long long)sizeof(real) * (bs / 64));
   const void* fn = bs == 256 ? (const void*)k_batch_admm_lds<256, false, false> : (bs == 512 ? (const void*)k_batch_admm_lds<512, false, false> : (const void*)k_batch_admm_lds<1024, false, false>);

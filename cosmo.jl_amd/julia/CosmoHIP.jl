@@ -387,23 +387,22 @@ function optimize_hip!(ws::COSMO.Workspace{T}; device::Integer = 0, kkt_kind::In
 end
 
 # ---------------------------------------------------------------------------------------------------------------------
-# Batches of independent problems with identical dimensions and cone structure (BASELINE config 3): what a user loop
-# `for ws in models; COSMO.optimize!(ws); end` computes, solved concurrently -- one persistent workgroup per problem
-# (cosmo_hip_batch_*).  Supported cones: ZeroSet, Nonnegatives, Box, SecondOrderCone, PsdCone / PsdConeTriangle of side <= 64, the exponential /
-# power cones and their duals; CG KKT solver;
-# EmptyAccelerator or the default AndersonAccelerator (mem <= 16): the accelerated loop runs inside the persistent kernels.
+# Batches of independent problems (BASELINE config 3 and beyond): what a user loop `for ws in models; COSMO.optimize!(ws); end` computes
+# (src/solver.jl:78), solved concurrently -- one persistent workgroup per problem.  The problems may differ in shape and cones: the library
+# partitions them into classes of identical (n, m, cone table), builds one batch per class and solves all classes at once
+# (cosmo_hip_batch_group_*, csrc/batch_group.hip).  Supported cones: ZeroSet, Nonnegatives, Box, SecondOrderCone, PsdCone / PsdConeTriangle of
+# side <= 64, the exponential / power cones and their duals; CG KKT solver; EmptyAccelerator or the default AndersonAccelerator (mem <= 16): the
+# accelerated loop runs inside the persistent kernels.  ONE Settings object for all problems (that of the first model).
 # Per problem the unchanged reference code does the scaling / classification (setup!, src/setup.jl:18-42) and the epilogue
 # (src/solver.jl:167-201); the loop of src/solver.jl:137-176 runs on the device for all problems at once.
 # ---------------------------------------------------------------------------------------------------------------------
 function optimize_hip_batch!(models::Vector{COSMO.Workspace{T}}; device::Integer = 0, tol_constant = 1.0, tol_exponent = 1.5) where {T <: HipFloat}
     isempty(models) && return COSMO.Result{T}[]
     LIBT = libpath(T)
-    ws1 = models[1]
-    m, n = ws1.p.model_size
-    settings = ws1.settings
+    settings = models[1].settings
     t_start = time()
     for ws in models
-        (ws.p.model_size == (m, n)) || error("optimize_hip_batch!: all problems must have the same dimensions")
+        m, n = ws.p.model_size
         if !ws.states.IS_SCALED
             ws.sm = (settings.scaling > 0) ? COSMO.ScaleMatrices{T}(m, n) : COSMO.ScaleMatrices{T}()
         end
@@ -415,48 +414,52 @@ function optimize_hip_batch!(models::Vector{COSMO.Workspace{T}}; device::Integer
         end
         ws.row_ranges = COSMO.get_set_indices(ws.p.C.sets)
     end
-    bptr = Ref{Ptr{Cvoid}}(C_NULL)
+    gptr = Ref{Ptr{Cvoid}}(C_NULL)
     check_abi(T)
-    rc = ccall((:cosmo_hip_batch_create, LIBT), Int32, (Ref{Ptr{Cvoid}}, Int32, Int64, Int64, Int64), bptr, device, length(models), n, m)
-    rc == 0 || error("cosmo_hip_batch_create failed (code $rc)")
-    b = bptr[]
-    bcheck(rc) = rc == 0 || error(unsafe_string(ccall((:cosmo_hip_batch_last_error, LIBT), Cstring, (Ptr{Cvoid},), b)))
+    rc = ccall((:cosmo_hip_batch_group_create, LIBT), Int32, (Ref{Ptr{Cvoid}}, Int32, Int64), gptr, device, length(models))
+    rc == 0 || error("cosmo_hip_batch_group_create failed (code $rc)")
+    g = gptr[]
+    gcheck(rc) = rc == 0 || error(unsafe_string(ccall((:cosmo_hip_batch_group_last_error, LIBT), Cstring, (Ptr{Cvoid},), g)))
     try
-        bl = T[]; bu = T[]
         for (k, ws) in enumerate(models)
+            m, n = ws.p.model_size
             P = SparseMatrixCSC(ws.p.P); A = SparseMatrixCSC(ws.p.A); q = ws.p.q; bv = Vector(ws.p.b)
-            GC.@preserve P A q bv bcheck(ccall((:cosmo_hip_batch_set_problem, LIBT), Int32,
-                (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{T}, Ptr{Int64}, Ptr{Int64}, Ptr{T}, Ptr{T}, Ptr{T}),
-                b, k - 1, P.colptr, P.rowval, P.nzval, A.colptr, A.rowval, A.nzval, q, bv))
+            GC.@preserve P A q bv gcheck(ccall((:cosmo_hip_batch_group_set_problem, LIBT), Int32,
+                (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{T}, Ptr{Int64}, Ptr{Int64}, Ptr{T}, Ptr{T}, Ptr{T}),
+                g, k - 1, n, m, P.colptr, P.rowval, P.nzval, A.colptr, A.rowval, A.nzval, q, bv))
+            bl = T[]; bu = T[]
             for s in ws.p.C.sets
                 if s isa COSMO.Box
                     append!(bl, s.l); append!(bu, s.u)
                 end
             end
+            types = Int32[cone_type(s) for s in ws.p.C.sets]; dims = Int64[s.dim for s in ws.p.C.sets]
+            cparams = T[cone_param(s) for s in ws.p.C.sets]        # alpha of the power cones
+            GC.@preserve types dims bl bu cparams gcheck(ccall((:cosmo_hip_batch_group_set_cones, LIBT), Int32,
+                (Ptr{Cvoid}, Int64, Int64, Ptr{Int32}, Ptr{Int64}, Ptr{T}, Ptr{T}, Ptr{T}),
+                g, k - 1, length(types), types, dims, isempty(bl) ? C_NULL : pointer(bl), isempty(bu) ? C_NULL : pointer(bu), cparams))
             if settings.scaling != 0
                 Dinv = ws.sm.Dinv.diag; Einv = ws.sm.Einv.diag
-                GC.@preserve Dinv Einv bcheck(ccall((:cosmo_hip_batch_set_scaling, LIBT), Int32, (Ptr{Cvoid}, Int64, Ptr{T}, Ptr{T}, Cdouble),
-                    b, k - 1, Dinv, Einv, ws.sm.cinv[]))
+                GC.@preserve Dinv Einv gcheck(ccall((:cosmo_hip_batch_group_set_scaling, LIBT), Int32, (Ptr{Cvoid}, Int64, Ptr{T}, Ptr{T}, Cdouble),
+                    g, k - 1, Dinv, Einv, ws.sm.cinv[]))
             end
         end
-        types = Int32[cone_type(s) for s in ws1.p.C.sets]; dims = Int64[s.dim for s in ws1.p.C.sets]
-        cparams = T[cone_param(s) for s in ws1.p.C.sets]        # alpha of the power cones (shared by the problems of a batch)
-        GC.@preserve types dims bl bu cparams bcheck(ccall((:cosmo_hip_batch_set_cones_ex, LIBT), Int32, (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int64}, Ptr{T}, Ptr{T}, Ptr{T}),
-            b, length(types), types, dims, isempty(bl) ? C_NULL : pointer(bl), isempty(bu) ? C_NULL : pointer(bu), cparams))
         ap = accel_params_from(settings)                     # _make_accelerator! (src/setup.jl:10-16) for every problem; before set_params
-        ap === nothing || bcheck(ccall((:cosmo_hip_batch_set_accelerator, LIBT), Int32, (Ptr{Cvoid}, Ref{AccelParams}), b, Ref(ap)))
+        ap === nothing || gcheck(ccall((:cosmo_hip_batch_group_set_accelerator, LIBT), Int32, (Ptr{Cvoid}, Ref{AccelParams}), g, Ref(ap)))
         prm = Ref(params_from(settings, KKT_CG; tol_constant = tol_constant, tol_exponent = tol_exponent))
-        bcheck(ccall((:cosmo_hip_batch_set_params, LIBT), Int32, (Ptr{Cvoid}, Ref{Params}), b, prm))   # classify_constraints! + set_rho_vec! per problem
-        x0 = reduce(vcat, [ws.vars.x for ws in models]); s0 = reduce(vcat, [ws.vars.s.data for ws in models]); mu0 = reduce(vcat, [ws.vars.μ for ws in models])
-        GC.@preserve x0 s0 mu0 bcheck(ccall((:cosmo_hip_batch_set_iterates, LIBT), Int32, (Ptr{Cvoid}, Ptr{T}, Ptr{T}, Ptr{T}), b, x0, s0, mu0))
+        gcheck(ccall((:cosmo_hip_batch_group_set_params, LIBT), Int32, (Ptr{Cvoid}, Ref{Params}), g, prm))   # classes + classify_constraints! + set_rho_vec! per problem
+        for (k, ws) in enumerate(models)
+            x0 = ws.vars.x; s0 = ws.vars.s.data; mu0 = ws.vars.μ
+            GC.@preserve x0 s0 mu0 gcheck(ccall((:cosmo_hip_batch_group_set_iterates, LIBT), Int32, (Ptr{Cvoid}, Int64, Ptr{T}, Ptr{T}, Ptr{T}), g, k - 1, x0, s0, mu0))
+        end
         results_c = Vector{ResultC}(undef, length(models))
-        bcheck(ccall((:cosmo_hip_batch_optimize, LIBT), Int32, (Ptr{Cvoid}, Ptr{ResultC}), b, results_c))
+        gcheck(ccall((:cosmo_hip_batch_group_optimize, LIBT), Int32, (Ptr{Cvoid}, Ptr{ResultC}), g, results_c))
         out = COSMO.Result{T}[]
         for (k, ws) in enumerate(models)
             r = results_c[k]
             w = ws.vars.w; wp = ws.vars.w_prev; sd = ws.vars.s.data; mu = ws.vars.μ
-            GC.@preserve w wp sd mu bcheck(ccall((:cosmo_hip_batch_get_iterates, LIBT), Int32, (Ptr{Cvoid}, Int64, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}),
-                b, k - 1, w, wp, sd, mu))
+            GC.@preserve w wp sd mu gcheck(ccall((:cosmo_hip_batch_group_get_iterates, LIBT), Int32, (Ptr{Cvoid}, Int64, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}),
+                g, k - 1, w, wp, sd, mu))
             ws.states.IS_OPTIMIZED = true
             ws.ρ = T(r.rho)
             resize!(ws.rho_updates, 0); append!(ws.rho_updates, T.(collect(r.rho_updates)[1:min(r.n_rho_updates, MAX_RHO_UPDATES)]))
@@ -469,7 +472,7 @@ function optimize_hip_batch!(models::Vector{COSMO.Workspace{T}}; device::Integer
         end
         return out
     finally
-        ccall((:cosmo_hip_batch_destroy, LIBT), Int32, (Ptr{Cvoid},), b)
+        ccall((:cosmo_hip_batch_group_destroy, LIBT), Int32, (Ptr{Cvoid},), g)
     end
 end
 

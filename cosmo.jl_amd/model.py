@@ -800,20 +800,54 @@ def prepare_batch(models: Sequence[Model], device: int):
     return B, st
 
 
+def _structure_key(md: Model):
+    return (md.n, md.m, tuple(K.kind for K in md.sets), tuple(K.dim for K in md.sets), tuple(getattr(K, "alpha", 0.0) for K in md.sets))
+
+
+def prepare_batch_group(models: Sequence[Model], device: int):
+    """setup! of every problem of a shard whose problems differ in structure, uploaded into one `_ffi.BatchGroup` (csrc/batch_group.hip: the library
+    partitions them into classes of identical (n, m, cones) and solves the classes concurrently), iterates set.  One Settings object for all."""
+    st = models[0].settings
+    for md in models:
+        if not md.is_assembled:
+            raise RuntimeError("The model has to be assembled! / set! before optimize!() can be called.")
+        if md.settings != st:
+            raise ValueError("optimize_batch: all problems of a batch share ONE Settings object (per-problem settings are not supported)")
+    G = _ffi.BatchGroup(len(models), device, dtype=getattr(models[0], "dtype", np.float64))
+    _install_accelerator(G, st)
+    for k, md in enumerate(models):
+        n, m = md.n, md.m
+        if st.scaling != 0 and not md.is_scaled:
+            md.sm = scale_ruiz(md.P, md.q, md.A, md.b, md.sets, md.settings); md.is_scaled = True
+        elif md.sm is None:
+            md.sm = ScaleMatrices(np.ones(n), np.ones(n), np.ones(m), np.ones(m), 1.0, 1.0)
+        md.x = md.sm.Dinv * md.x; md.mu = (md.sm.Einv * md.mu) * md.sm.c; md.s = md.sm.E * md.s
+        G.set_problem(k, md.P, md.q, md.A, md.b)
+        G.set_scaling(k, md.sm.Dinv, md.sm.Einv, md.sm.cinv)
+        bl = [K.l for K in md.sets if K.kind == _ffi.BOX]; bu = [K.u for K in md.sets if K.kind == _ffi.BOX]
+        G.set_cones(k, [K.kind for K in md.sets], [K.dim for K in md.sets], np.concatenate(bl) if bl else None, np.concatenate(bu) if bu else None,
+                    cone_param=[getattr(K, "alpha", 0.0) for K in md.sets])
+    G.set_params(_params_from_settings(None, st))
+    for k, md in enumerate(models):
+        G.set_iterates(k, md.x, md.s, md.mu)
+    return G, st
+
+
 def _solve_shard_on_device(models: Sequence[Model], device: int) -> List[Result]:
-    """All problems of the shard concurrently on one MI355X (one persistent workgroup per problem, csrc/batch.hip)."""
+    """All problems of the shard concurrently on one MI355X (one persistent workgroup per problem, csrc/batch.hip).  Problems of ONE structure take
+    the batch directly; a mixed list goes through the batch group (one batch per structure class, all classes concurrently)."""
     import time
     if not models:
         return []
     t0 = time.perf_counter()
-    n = models[0].n
-    B, st = prepare_batch(models, device)
+    mixed = len({_structure_key(md) for md in models}) > 1
+    B, st = prepare_batch_group(models, device) if mixed else prepare_batch(models, device)
     t_setup = time.perf_counter() - t0
     rs = B.optimize()
     out = []
     for k, (md, r) in enumerate(zip(models, rs)):
         w, w_prev, s, mu = B.get_iterates(k)
-        x = w_prev[:n].copy()
+        x = w_prev[:md.n].copy()
         if st.scaling != 0:
             x = md.sm.D * x; s = md.sm.Einv * s; mu = (md.sm.E * mu) * md.sm.cinv
         md.x, md.s, md.mu = x.copy(), s.copy(), mu.copy()

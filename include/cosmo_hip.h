@@ -454,6 +454,37 @@ int32_t cosmo_hip_batch_iterate(cosmo_hip_batch* b, int64_t n_iters, int32_t wit
 int32_t cosmo_hip_batch_get_counters(cosmo_hip_batch* b, int64_t* out);
 int32_t cosmo_hip_batch_get_iterates(cosmo_hip_batch* b, int64_t k, cosmo_hip_real* w, cosmo_hip_real* w_prev, cosmo_hip_real* s, cosmo_hip_real* mu);
 
+/* ---- batches of problems of DIFFERENT structure (csrc/batch_group.hip) ------------------------------------------------------------------
+ * The reference's batch is a loop over arbitrary models (src/solver.jl:78).  A group takes every problem with ITS OWN (n, m, cones), partitions
+ * them at set_params time into classes of identical structure (dimensions, cone types / dimensions / parameters; data, Box bounds and scalings
+ * differ freely), builds one cosmo_hip_batch per class -- so every class keeps the persistent kernel specialised for its structure -- and
+ * cosmo_hip_batch_group_optimize runs all classes concurrently (one HIP stream + host thread per class).  Call order as for a batch:
+ * create, set_problem / set_cones [/ set_scaling] for every k, [set_accelerator,] set_params, [set_iterates,] optimize, get_iterates.
+ * What a class cannot do (PSD side > 64, user-defined cones, MINRES, adaptive_rho_interval = 0) is the group's error, naming the problem. */
+typedef struct cosmo_hip_batch_group cosmo_hip_batch_group;
+int32_t cosmo_hip_batch_group_create(cosmo_hip_batch_group** g, int32_t device_id, int64_t nprob);
+int32_t cosmo_hip_batch_group_destroy(cosmo_hip_batch_group* g);
+const char* cosmo_hip_batch_group_last_error(const cosmo_hip_batch_group* g);
+/* problem k, n x n P and m x n A as cosmo_hip_set_problem */
+int32_t cosmo_hip_batch_group_set_problem(cosmo_hip_batch_group* g, int64_t k, int64_t n, int64_t m, const int64_t* P_colptr, const int64_t* P_rowval,
+                                          const cosmo_hip_real* P_nzval, const int64_t* A_colptr, const int64_t* A_rowval,
+                                          const cosmo_hip_real* A_nzval, const cosmo_hip_real* q, const cosmo_hip_real* bvec);
+/* cones of problem k as cosmo_hip_set_cones_ex; box_l / box_u = the Box rows of THIS problem */
+int32_t cosmo_hip_batch_group_set_cones(cosmo_hip_batch_group* g, int64_t k, int64_t ncones, const int32_t* type, const int64_t* dim,
+                                        const cosmo_hip_real* box_l, const cosmo_hip_real* box_u, const cosmo_hip_real* cone_param);
+int32_t cosmo_hip_batch_group_set_scaling(cosmo_hip_batch_group* g, int64_t k, const cosmo_hip_real* Dinv, const cosmo_hip_real* Einv, double cinv);
+int32_t cosmo_hip_batch_group_set_accelerator(cosmo_hip_batch_group* g, const cosmo_hip_accel_params* p);
+int32_t cosmo_hip_batch_group_set_params(cosmo_hip_batch_group* g, const cosmo_hip_params* p);
+/* number of structure classes; class_of[k] for every problem (nprob entries, may be NULL) */
+int32_t cosmo_hip_batch_group_class_info(cosmo_hip_batch_group* g, int64_t* nclasses, int64_t* class_of);
+/* warm start of problem k (n, m, m entries; NULL = zeros); problems never set start from zero (src/solver.jl:128-129) */
+int32_t cosmo_hip_batch_group_set_iterates(cosmo_hip_batch_group* g, int64_t k, const cosmo_hip_real* x0, const cosmo_hip_real* s0, const cosmo_hip_real* mu0);
+/* optimize! for every problem; results has nprob entries in the caller's order */
+int32_t cosmo_hip_batch_group_optimize(cosmo_hip_batch_group* g, cosmo_hip_result* results);
+int32_t cosmo_hip_batch_group_get_iterates(cosmo_hip_batch_group* g, int64_t k, cosmo_hip_real* w, cosmo_hip_real* w_prev, cosmo_hip_real* s, cosmo_hip_real* mu);
+int32_t cosmo_hip_batch_group_get_counters(cosmo_hip_batch_group* g, int64_t* out /* 3 * nprob */);
+int32_t cosmo_hip_batch_group_get_accel_stats(cosmo_hip_batch_group* g, int64_t* out /* 6 * nprob */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,6 +6,8 @@ import cosmo_jl_amd as cj
 from oracle import cosmo_oracle as O
 from tests import util
 
+from ctypes import byref as C_byref  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 F = cj._ffi
 
@@ -70,8 +72,94 @@ def test_batch_box_and_zero_cones_and_rho_classes():
         assert r.status == ref.status
         assert abs(r.iter - ref.iter) <= 25
         assert abs(r.obj_val - ref.obj_val) <= 1e-4 * (1 + abs(ref.obj_val))
-    with pytest.raises(ValueError):
-        cj.optimize_batch(_models([probs[0], cj.problems.socp(n=60, m=120, ncones=12, nnz=900)], st))
+    # a second structure in the same list is no longer an error (round 5: csrc/batch_group.hip; test_heterogeneous_batch_* below)
+    mixed = cj.optimize_batch(_models([probs[0], cj.problems.socp(n=60, m=120, ncones=12, nnz=900)], st))
+    assert [r.status for r in mixed] == ["Solved", "Solved"] and abs(mixed[0].obj_val - res[0].obj_val) <= 1e-9 * (1 + abs(res[0].obj_val))
+
+
+def _hetero_problems():
+    """Three shapes, different cone mixes, one of them primal infeasible: what `for model in models; optimize!(model); end` accepts (src/solver.jl:78)."""
+    rng = np.random.default_rng(77)
+    shapeA = [util.random_qp(rng, 30, 4, 20, 40) for _ in range(3)]                                    # Zero / Nonneg / Box
+    shapeB = [cj.problems.socp(n=60, m=120, ncones=12, nnz=900, seed=500 + k) for k in range(2)]      # SecondOrderCones
+    shapeC = [util.random_qp(rng, 25, 2, 10, 6, soc_dims=(4,), psd_tri_dims=(5, 9), p_shift=1.0) for _ in range(2)]   # + small PSD cones
+    # primal infeasible LP of shape D: x >= 1 and x <= 0 on one coordinate (Nonnegatives only)
+    import scipy.sparse as sp
+    n = 4
+    A = sp.vstack([-sp.identity(n), sp.identity(n)], format="csc")     # s = b - A x >= 0:  x >= 1 (rows 1..n with b = -1)  and  x <= 0
+    inf = dict(P=sp.identity(n, format="csc") * 0.0, q=np.ones(n), A=A, b=np.concatenate([-np.ones(n), np.zeros(n)]), sets=[cj.Nonnegatives(2 * n)])
+    probs = [shapeA[0], shapeB[0], shapeC[0], inf, shapeA[1], shapeC[1], shapeB[1], shapeA[2]]       # interleaved on purpose
+    return probs
+
+
+def test_heterogeneous_batch_equals_the_single_problem_solves():
+    """a mixed list through optimize_batch (one cosmo_hip_batch per structure class inside the library, the classes solved
+    concurrently) equals the per-problem single-handle solves within the default-schedule tolerances -- status, iteration within one check
+    interval, objective 1e-4 -- and the class partition is the expected one."""
+    probs = _hetero_problems()
+    st = cj.Settings()
+    res = cj.optimize_batch(_models(probs, st))
+    assert len(res) == len(probs)
+    for k, (p, r) in enumerate(zip(probs, res)):
+        md = cj.Model(); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], cj.Settings())
+        one = cj.optimize(md)
+        assert r.status == one.status, (k, r.status, one.status)
+        assert abs(r.iter - one.iter) <= 25, (k, r.iter, one.iter)
+        if r.status == "Solved":
+            assert abs(r.obj_val - one.obj_val) <= 1e-4 * (1 + abs(one.obj_val))
+            assert np.max(np.abs(r.x - one.x)) <= 1e-3 * max(1.0, np.max(np.abs(one.x)))
+        assert r.x.size == p["A"].shape[1] and r.s.size == p["A"].shape[0]
+    assert res[3].status == "Primal_infeasible" and res[3].obj_val == np.inf          # solver.jl:336-340 through the batch certificates
+    # tight CG: trajectories of the mixed batch against uniform batches of each structure alone -- the problems are independent, so bit for bit
+    tight = cj.Settings(kkt_solver=cj.with_options(cj.CGIndirectKKTSolver, tol_constant=1e-10, tol_exponent=0.0), max_iter=50, eps_abs=0.0, eps_rel=0.0,
+                        check_infeasibility=10 ** 9)
+    mixed = cj.optimize_batch(_models(probs, tight))
+    for idx in ([0, 4, 7], [1, 6], [2, 5]):
+        alone = cj.optimize_batch(_models([probs[i] for i in idx], tight))
+        for i, a in zip(idx, alone):
+            assert np.array_equal(mixed[i].x, a.x) and np.array_equal(mixed[i].s, a.s) and mixed[i].kkt_iters_total == a.kkt_iters_total
+
+
+def test_heterogeneous_batch_group_abi():
+    """The C ABI of the group directly: class partition, per-problem warm start, counters; an unsupported member is the group's error."""
+    probs = _hetero_problems()
+    G = F.BatchGroup(len(probs))
+    for k, p in enumerate(probs):
+        G.set_problem(k, p["P"], p["q"], p["A"], p["b"])
+        bl = [K.l for K in p["sets"] if K.kind == F.BOX]; bu = [K.u for K in p["sets"] if K.kind == F.BOX]
+        G.set_cones(k, [K.kind for K in p["sets"]], [K.dim for K in p["sets"]], np.concatenate(bl) if bl else None, np.concatenate(bu) if bu else None)
+    prm = F.Params(); G.lib.cosmo_hip_default_params(C_byref(prm))
+    prm.max_iter = 30; prm.eps_abs = prm.eps_rel = 0.0; prm.check_infeasibility = 10 ** 9
+    G.set_params(prm)
+    nc, cls = G.class_info()
+    assert nc == 4 and cls[0] == cls[4] == cls[7] and cls[1] == cls[6] and cls[2] == cls[5] and len(set(cls.tolist())) == 4
+    x0 = np.full(probs[1]["A"].shape[1], 0.25)
+    G.set_iterates(1, x0, None, None)                                     # only problem 1 is warm-started
+    rs = G.optimize()
+    assert all(F.STATUS_NAMES[r.status] == "Max_iter_reached" and r.iter == 30 for r in rs)
+    it, solves, kry = G.counters()
+    assert it.tolist() == [30] * len(probs) and np.all(solves == 31) and np.all(kry > 0)
+    w, _, s, _ = G.get_iterates(3)
+    assert w.size == 4 + 8 and s.size == 8
+    # the same problem 6 (cold) and problem 1 (warm) differ; two cold runs agree bit for bit
+    G2 = F.BatchGroup(2)
+    for k, i in enumerate((1, 1)):
+        p = probs[i]
+        G2.set_problem(k, p["P"], p["q"], p["A"], p["b"]); G2.set_cones(k, [K.kind for K in p["sets"]], [K.dim for K in p["sets"]])
+    G2.set_params(prm); G2.set_iterates(0, x0, None, None)
+    G2.optimize()
+    assert np.array_equal(G2.get_iterates(0)[0], G.get_iterates(1)[0]) and not np.array_equal(G2.get_iterates(1)[0], G.get_iterates(1)[0])
+    G.close(); G2.close()
+    # a member the batch kernels cannot take (PSD side 70) is refused, naming the problem
+    big = util.random_qp(np.random.default_rng(3), 20, 0, 0, 0, psd_tri_dims=(70,), p_shift=1.0)
+    G3 = F.BatchGroup(2)
+    for k, p in enumerate((probs[0], big)):
+        G3.set_problem(k, p["P"], p["q"], p["A"], p["b"])
+        bl = [K.l for K in p["sets"] if K.kind == F.BOX]; bu = [K.u for K in p["sets"] if K.kind == F.BOX]
+        G3.set_cones(k, [K.kind for K in p["sets"]], [K.dim for K in p["sets"]], np.concatenate(bl) if bl else None, np.concatenate(bu) if bu else None)
+    with pytest.raises(F.CosmoHipError, match="class of problem 1"):
+        G3.set_params(prm)
+    G3.close()
 
 
 def test_cfg3_full_size_tight_cg_all_problems():

@@ -46,7 +46,7 @@ def c_class(decl):
     if ptr == 2:
         return "ptrptr"
     b = base.split()[0] if base else ""
-    return {"cosmo_hip_handle": "handle", "cosmo_hip_batch": "handle", "cosmo_hip_real": "p_real", "int32_t": "p_i32", "int64_t": "p_i64", "double": "p_f64",
+    return {"cosmo_hip_handle": "handle", "cosmo_hip_batch": "handle", "cosmo_hip_batch_group": "handle", "cosmo_hip_real": "p_real", "int32_t": "p_i32", "int64_t": "p_i64", "double": "p_f64",
             "uint8_t": "p_u8", "char": "cstr", "void": "p_void", "cosmo_hip_params": "p_struct", "cosmo_hip_result": "p_struct",
             "cosmo_hip_accel_params": "p_struct"}.get(b, "p_other:" + b)
 
