@@ -207,12 +207,15 @@ struct StreamOps {
 };
 
 // header of a problem's LDS image (built by build_lds_images): byte offsets from the start of the image
-struct LdsHdr { int nnzA, nnzP, nbA, nbAT, nbPT, oAval, oPval, oArp, oAcol, oTrp, oTpos, oTrow, oPrp, oPcol, oRbA, oRbAT, oRbPT, bytes; };
+// oTpr: one u32 per nonzero of A' = (position into A's values) | (row, or its position in the gathered vector) << 16 -- ONE LDS read per nonzero instead
+// of two u16 reads (round 5: the A' loop of the column pass issues 3 LDS instructions per nonzero instead of 4)
+struct LdsHdr { int nnzA, nnzP, nbA, nbAT, nbPT, oAval, oPval, oArp, oAcol, oTrp, oTpr, oPrp, oPcol, oRbA, oRbAT, oRbPT, bytes; };
 
 template <int BS>
 struct LdsOps {
   const real *Aval, *Pval;
-  const unsigned short *Arp, *Acol, *Trp, *Tpos, *Trow, *Prp, *Pcol;
+  const unsigned short *Arp, *Acol, *Trp, *Prp, *Pcol;
+  const uint32_t* Tpr;
   const int4 *rbA, *rbAT, *rbPT;
   int nbA, nbAT, nbPT;
   real *xv, *tv, *red;
@@ -235,9 +238,9 @@ struct LdsOps {
     real s1 = 0.0;
     int t = Trp[r]; const int b2 = Trp[r + 1];
     if (t < b2) {
-      int p = Tpos[t], q2 = Trow[t];
-      for (++t; t < b2; ++t) { const int pn2 = Tpos[t], qn2 = Trow[t]; s1 += Aval[p] * y[q2]; p = pn2; q2 = qn2; }
-      s1 += Aval[p] * y[q2];
+      uint32_t pr = Tpr[t];
+      for (++t; t < b2; ++t) { const uint32_t prn = Tpr[t]; s1 += Aval[pr & 0xffffu] * y[pr >> 16]; pr = prn; }
+      s1 += Aval[pr & 0xffffu] * y[pr >> 16];
     }
     return s1;
   }
@@ -288,13 +291,13 @@ struct LdsOps {
         for (int r = d.x + threadIdx.x; r < d.y; r += BS) {
           real s1 = 0.0;
           const int a = Trp[r], b = Trp[r + 1];
-          for (int k = a; k < b; ++k) s1 += Aval[Tpos[k]] * y[Trow[k]];
+          for (int k = a; k < b; ++k) { const uint32_t pr = Tpr[k]; s1 += Aval[pr & 0xffffu] * y[pr >> 16]; }
           fn(r, s1, 0.0);
         }
       } else {
         const int r = d.x;
         real s1 = 0.0, s2 = 0.0;
-        for (int k = d.z + threadIdx.x; k < d.w; k += BS) s1 += Aval[Tpos[k]] * y[Trow[k]];
+        for (int k = d.z + threadIdx.x; k < d.w; k += BS) { const uint32_t pr = Tpr[k]; s1 += Aval[pr & 0xffffu] * y[pr >> 16]; }
         s1 = bsum<BS>(s1, red); s2 = bsum<BS>(s2, red);
         if (threadIdx.x == 0) fn(r, s1, s2);
       }
@@ -311,7 +314,7 @@ struct LdsOps {
           const int pa = Prp[r], pb = Prp[r + 1];
           for (int k = pa; k < pb; ++k) s1 += Pval[k] * x1[Pcol[k]];
           const int a = Trp[r], b = Trp[r + 1];
-          for (int k = a; k < b; ++k) s2 += Aval[Tpos[k]] * x2[Trow[k]];
+          for (int k = a; k < b; ++k) { const uint32_t pr = Tpr[k]; s2 += Aval[pr & 0xffffu] * x2[pr >> 16]; }
           fn(r, s1, s2);
         }
       } else {
@@ -320,7 +323,7 @@ struct LdsOps {
         real s1 = 0.0, s2 = 0.0;
         for (int k = threadIdx.x; k < lp + lt; k += BS) {
           if (k < lp) s1 += Pval[pa + k] * x1[Pcol[pa + k]];
-          else { const int kk = a + (k - lp); s2 += Aval[Tpos[kk]] * x2[Trow[kk]]; }
+          else { const uint32_t pr = Tpr[a + (k - lp)]; s2 += Aval[pr & 0xffffu] * x2[pr >> 16]; }
         }
         s1 = bsum<BS>(s1, red); s2 = bsum<BS>(s2, red);
         if (threadIdx.x == 0) fn(r, s1, s2);
@@ -796,8 +799,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_lds(BatchDev D, BParams P, lo
   LdsOps<BS> ops;
   ops.Aval = reinterpret_cast<const real*>(base + hd.oAval); ops.Pval = reinterpret_cast<const real*>(base + hd.oPval);
   ops.Arp = reinterpret_cast<const unsigned short*>(base + hd.oArp); ops.Acol = reinterpret_cast<const unsigned short*>(base + hd.oAcol);
-  ops.Trp = reinterpret_cast<const unsigned short*>(base + hd.oTrp); ops.Tpos = reinterpret_cast<const unsigned short*>(base + hd.oTpos);
-  ops.Trow = reinterpret_cast<const unsigned short*>(base + hd.oTrow);
+  ops.Trp = reinterpret_cast<const unsigned short*>(base + hd.oTrp); ops.Tpr = reinterpret_cast<const uint32_t*>(base + hd.oTpr);
   ops.Prp = reinterpret_cast<const unsigned short*>(base + hd.oPrp); ops.Pcol = reinterpret_cast<const unsigned short*>(base + hd.oPcol);
   ops.rbA = reinterpret_cast<const int4*>(base + hd.oRbA); ops.rbAT = reinterpret_cast<const int4*>(base + hd.oRbAT);
   ops.rbPT = reinterpret_cast<const int4*>(base + hd.oRbPT);
@@ -850,8 +852,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   const unsigned short* Arp = reinterpret_cast<const unsigned short*>(base + hd.oArp);
   const unsigned short* Acol = reinterpret_cast<const unsigned short*>(base + hd.oAcol);
   const unsigned short* Trp = reinterpret_cast<const unsigned short*>(base + hd.oTrp);
-  const unsigned short* Tpos = reinterpret_cast<const unsigned short*>(base + hd.oTpos);
-  const unsigned short* Trow = reinterpret_cast<const unsigned short*>(base + hd.oTrow);
+  const uint32_t* Tpr = reinterpret_cast<const uint32_t*>(base + hd.oTpr);
   const unsigned short* Prp = reinterpret_cast<const unsigned short*>(base + hd.oPrp);
   const unsigned short* Pcol = reinterpret_cast<const unsigned short*>(base + hd.oPcol);
   real* wsp = reinterpret_cast<real*>(base + img_stride);
@@ -862,14 +863,26 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   (void)psd_ws;
 
   const long long on = (long long)k * n, om = (long long)k * m, onm = (long long)k * (n + m);
+  // OWNERSHIP of the n-vectors (round 5): slot j of thread t holds element ct[j] -- the column of the length-sorted compute assignment of the
+  // Krylov loop's column pass (identity without the table: COSMO_HIP_BATCH_SORTED=0 and the <512, 2, 4> instantiation).  Until round 4 the owner of
+  // element i was thread i mod 512 and the computing thread handed c = P u + sigma u + A' tmp over through LDS (two barriers and two LDS accesses
+  // per Krylov iteration); now owner == computer, at the price of bit-identity with the owner-computes FORM: the block sums add the same per-element
+  // terms in another thread order (run-to-run deterministic; parity = the tight-CG fixture at 1e-7, tests/test_gpu_batch.py).
+  constexpr bool SORTED = (JN == 1);
+  int ct[JN];
+#pragma unroll
+  for (int j = 0; j < JN; ++j) {
+    const int i = ct[j];
+    ct[j] = (SORTED && D.permT) ? D.permT[(long long)k * (JN * BS) + j * BS + tid] : (i < n ? i : -1);
+  }
   // ---- load the persistent state and the per-element constants into registers -----------------------------------------
   real wx[JN], wpx[JN], qv[JN], xtl[JN], lsx[JN], rhsv[JN], rv[JN], cv[JN];
   real wsv[JM], wps[JM], sv[JM], rhov[JM], lss[JM], bv[JM], blv[JM], buv[JM];
   uint32_t metav[JM];
 #pragma unroll
   for (int j = 0; j < JN; ++j) {
-    const int i = tid + BS * j;
-    const bool ok = i < n;
+    const int i = ct[j];
+    const bool ok = i >= 0;
     wx[j] = ok ? D.w[onm + i] : 0.0; wpx[j] = ok ? D.w_prev[onm + i] : 0.0; qv[j] = ok ? D.q[on + i] : 0.0; xtl[j] = ok ? D.x_tl[on + i] : 0.0;
     lsx[j] = 0.0; rhsv[j] = 0.0; rv[j] = 0.0; cv[j] = 0.0;
   }
@@ -888,8 +901,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   // compute assignment of the Krylov loop's sparse passes (rows / columns sorted by length; identity without the tables) and rho of the
   // rows this thread computes (kept in step with rhov by the same formula at every adaptation)
   // (the <512, 2, 4> instantiation is at its 256 registers already: it keeps the owner-computes form)
-  constexpr bool SORTED = (JN == 1);
-  int ra[JM], ct[JN];
+  int ra[JM];
   real rhoc[JM];
 #pragma unroll
   for (int j = 0; j < JM; ++j) {
@@ -897,20 +909,14 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     ra[j] = (SORTED && D.permA) ? D.permA[(long long)k * (JM * BS) + j * BS + tid] : (i < m ? i : -1);
     rhoc[j] = (SORTED && ra[j] >= 0) ? D.rho[om + ra[j]] : R(1.0);
   }
-#pragma unroll
-  for (int j = 0; j < JN; ++j) {
-    const int i = tid + BS * j;
-    ct[j] = (SORTED && D.permT) ? D.permT[(long long)k * (JN * BS) + j * BS + tid] : (i < n ? i : -1);
-  }
   // POSITIONS of the gathered vectors: entry i of an n-vector sits at xv[posN[i]], entry r of an m-vector at tv[posM[r]] whenever a sparse
   // pass gathers from them (the image's column / row indices are stored as positions).  The host chooses the positions so that the rows
   // a wave-step works on spread over the LDS banks (build_lds_images); without the tables positions are indices.
   int pn[JN], pm[JM], pnc[JN], pmc[JM];
 #pragma unroll
   for (int j = 0; j < JN; ++j) {
-    const int i = tid + BS * j;
-    pn[j] = (SORTED && D.posN && i < n) ? D.posN[on + i] : i;
     pnc[j] = (SORTED && D.posN && ct[j] >= 0) ? D.posN[on + ct[j]] : ct[j];
+    pn[j] = pnc[j];                                    // owner == computer
   }
 #pragma unroll
   for (int j = 0; j < JM; ++j) {
@@ -958,9 +964,9 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     real s1 = 0.0;
     int t = Trp[r]; const int b2 = Trp[r + 1];
     if (t < b2) {
-      int p = Tpos[t], q2 = Trow[t];
-      for (++t; t < b2; ++t) { const int pn2 = Tpos[t], qn2 = Trow[t]; s1 += Aval[p] * tv[q2]; p = pn2; q2 = qn2; }
-      s1 += Aval[p] * tv[q2];
+      uint32_t pr = Tpr[t];
+      for (++t; t < b2; ++t) { const uint32_t prn = Tpr[t]; s1 += Aval[pr & 0xffffu] * tv[pr >> 16]; pr = prn; }
+      s1 += Aval[pr & 0xffffu] * tv[pr >> 16];
     }
     return s1;
   };
@@ -987,13 +993,13 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       if (i < m) tv[pm[j]] = rhov[j] * v;                                // y2 = rho .* ls_s
     }
 #pragma unroll
-    for (int j = 0; j < JN; ++j) { const int i = tid + BS * j; if (i < n) xv[pn[j]] = xtl[j]; }
+    for (int j = 0; j < JN; ++j) { const int i = ct[j]; if (i >= 0) xv[pn[j]] = xtl[j]; }
     __syncthreads();
     real acc = 0.0;
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
-      const int i = tid + BS * j;
-      if (i < n) { const real v = (rowAT(i) + R(0.0)) + lsx[j]; rhsv[j] = v; acc += v * v; }
+      const int i = ct[j];
+      if (i >= 0) { const real v = (rowAT(i) + R(0.0)) + lsx[j]; rhsv[j] = v; acc += v * v; }
     }
     const real bb = bsum<BS>(acc, red);                                  // (its barriers also order tv reads before the writes below)
     real tmpv[JM];
@@ -1006,8 +1012,8 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     acc = 0.0;
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
-      const int i = tid + BS * j;
-      if (i < n) { const real cj = rowP(i) + (P.sigma * xtl[j] + rowAT(i)); const real rj = rhsv[j] - cj; rv[j] = rj; acc += rj * rj; }
+      const int i = ct[j];
+      if (i >= 0) { const real cj = rowP(i) + (P.sigma * xtl[j] + rowAT(i)); const real rj = rhsv[j] - cj; rv[j] = rj; acc += rj * rj; }
     }
     real rr = bsum<BS>(acc, red);
     const real tol_k = tol_next;
@@ -1021,13 +1027,14 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     while (kk < n && !(res <= tol)) {                                    // cg! (IterativeSolvers v0.9), maxiter = n
       const real beta = (res * res) / (prev * prev);
 #pragma unroll
-      for (int j = 0; j < JN; ++j) { const int i = tid + BS * j; uv[j] = rv[j] + beta * ((kk == 0) ? R(0.0) : uv[j]); if (i < n) xv[pn[j]] = uv[j]; }
+      for (int j = 0; j < JN; ++j) { const int i = ct[j]; uv[j] = rv[j] + beta * ((kk == 0) ? R(0.0) : uv[j]); if (i >= 0) xv[pn[j]] = uv[j]; }
       __syncthreads();
       // The two sparse passes of a Krylov iteration are bound by the CU's LDS pipe, and a wave issues as many steps as its LONGEST row.
       // So thread t COMPUTES the rows ra[] / the column ct[] of the length-sorted assignment (rows of similar length share a wave-step:
-      // about a third fewer LDS instructions on BASELINE config 3) and hands the results to the owners through LDS -- tv is that
-      // hand-over for rho .* (A u) anyway; c = P u + sigma u + A' tmp goes through xv once every read of u is done.  The owner still
-      // does every update and reduction and each row sum is the same left-to-right sum: bit-identical to the owner-computes form.
+      // about a third fewer LDS instructions on BASELINE config 3).  rho .* (A u) goes to its consumers through tv anyway; the column ct[] is
+      // also the element of the n-vectors this thread OWNS (round 5), so c = P u + sigma u + A' tmp stays in its registers -- until round 4 it
+      // went back to an index-order owner through xv: two more barriers and two more LDS accesses per Krylov iteration.  Every row sum is the
+      // same left-to-right sum as in every other kernel form; the block sums add their terms in the order of this ownership.
       if (SORTED) {
       { BT_BEGIN();
 #pragma unroll
@@ -1036,40 +1043,21 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       for (int j = 0; j < JM; ++j) if (ra[j] >= 0) tv[pmc[j]] = tmpv[j];   // tv was last read before the previous barrier pair
       __syncthreads();
       BT_END(0); }
-      acc = 0.0;
-      { BT_BEGIN();
-      real cjv[JN];
-#pragma unroll
-      for (int j = 0; j < JN; ++j) {
-        const int c = ct[j];
-        cjv[j] = 0.0;
-        if (c >= 0) { const real vj = xv[pnc[j]]; cjv[j] = rowP(c) + (P.sigma * vj + rowAT(c)); }
-      }
-      __syncthreads();                                                   // every read of u (xv) is done: xv carries c to the owners
-#pragma unroll
-      for (int j = 0; j < JN; ++j) if (ct[j] >= 0) xv[pnc[j]] = cjv[j];
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < JN; ++j) {
-        const int i = tid + BS * j;
-        if (i < n) { const real vj = uv[j]; const real cj = xv[pn[j]]; cv[j] = cj; acc += vj * cj; }
-      }
-      __syncthreads();
-      BT_END(1); }
       } else {
 #pragma unroll
       for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; tmpv[j] = (i < m) ? rowA(i) * rhov[j] : 0.0; }
 #pragma unroll
       for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; if (i < m) tv[i] = tmpv[j]; }
       __syncthreads();
+      }
       acc = 0.0;
+      { BT_BEGIN();
 #pragma unroll
-      for (int j = 0; j < JN; ++j) {
-        const int i = tid + BS * j;
-        if (i < n) { const real vj = uv[j]; const real cj = rowP(i) + (P.sigma * vj + rowAT(i)); cv[j] = cj; acc += vj * cj; }
+      for (int j = 0; j < JN; ++j) {                                       // the column this thread owns AND computes
+        const int c = ct[j];
+        if (c >= 0) { const real vj = uv[j]; const real cj = rowP(c) + (P.sigma * vj + rowAT(c)); cv[j] = cj; acc += vj * cj; }
       }
-      __syncthreads();
-      }
+      BT_END(1); }
       BT_BEGIN();
       const real uc = bsum<BS>(acc, red);
       BT_END(2);
@@ -1080,15 +1068,15 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       acc = 0.0;
 #pragma unroll
       for (int j = 0; j < JN; ++j) {
-        const int i = tid + BS * j;
-        if (i < n) { xtl[j] = xtl[j] + a * uv[j]; const real ri = rv[j] - a * cv[j]; rv[j] = ri; acc += ri * ri; }
+        const int i = ct[j];
+        if (i >= 0) { xtl[j] = xtl[j] + a * uv[j]; const real ri = rv[j] - a * cv[j]; rv[j] = ri; acc += ri * ri; }
       }
       rr = bsum<BS>(acc, red);
       prev = res; res = sqrt(rr); ++kk;
     }
     // nu = rho (A x_tl - ls_s) ; s_tl ; w update
 #pragma unroll
-    for (int j = 0; j < JN; ++j) { const int i = tid + BS * j; if (i < n) xv[pn[j]] = xtl[j]; }
+    for (int j = 0; j < JN; ++j) { const int i = ct[j]; if (i >= 0) xv[pn[j]] = xtl[j]; }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < JM; ++j) {
@@ -1112,7 +1100,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   for (int j = 0; j < JM; ++j) muv[j] = 0.0;
   auto residuals = [&](bool unscale) {
 #pragma unroll
-    for (int j = 0; j < JN; ++j) { const int i = tid + BS * j; if (i < n) xv[pn[j]] = wpx[j]; }
+    for (int j = 0; j < JN; ++j) { const int i = ct[j]; if (i >= 0) xv[pn[j]] = wpx[j]; }
     __syncthreads();
     real a_rp = 0.0, a_mp = 0.0;
 #pragma unroll
@@ -1134,8 +1122,8 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     real a_rd = 0.0, a_md = 0.0, xpx = 0.0, qx = 0.0;
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
-      const int i = tid + BS * j;
-      if (i < n) {
+      const int i = ct[j];
+      if (i >= 0) {
         const real px = rowP(i), atm = rowAT(i), x0 = wpx[j], q0 = qv[j];
         real r0 = px + q0; r0 = r0 - atm;
         real a = px, bq = q0, cm = atm;
@@ -1202,7 +1190,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   if constexpr (AA) { M = aa_mem_of(D, k); aa_load(S, M.aa); }
   auto each = [&](auto&& fn) {
 #pragma unroll
-    for (int j = 0; j < JN; ++j) { const int i = tid + BS * j; if (i < n) fn(i, wx[j], wpx[j]); }
+    for (int j = 0; j < JN; ++j) { const int i = ct[j]; if (i >= 0) fn(i, wx[j], wpx[j]); }
 #pragma unroll
     for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; if (i < m) fn(n + i, wsv[j], wps[j]); }
   };
@@ -1302,8 +1290,8 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   // ---- store the persistent state; recover_mu! (solver.jl:167) ----
 #pragma unroll
   for (int j = 0; j < JN; ++j) {
-    const int i = tid + BS * j;
-    if (i < n) { D.w[onm + i] = wx[j]; D.w_prev[onm + i] = wpx[j]; D.x_tl[on + i] = xtl[j]; }
+    const int i = ct[j];
+    if (i >= 0) { D.w[onm + i] = wx[j]; D.w_prev[onm + i] = wpx[j]; D.x_tl[on + i] = xtl[j]; }
   }
 #pragma unroll
   for (int j = 0; j < JM; ++j) {
@@ -1525,6 +1513,7 @@ struct cosmo_hip_batch {
   // LDS-resident variant (build_lds_images): one image per problem, dynamic LDS = image + gather vectors + reduction slots
   unsigned char* d_img = nullptr; long long img_stride = 0; int lds_bytes = 0; int lds_bs = 0;
   int reg_mode = 0;    // 0: LdsOps kernel, 1: register-resident <512,1,2>, 2: <512,2,4>
+  bool force_ext = false;
   bool aa_on = false; cosmo_hip_accel_params aa_prm;      // cosmo_hip_batch_set_accelerator
   std::vector<int> h_permA, h_permT;          // compute assignment of the register kernel (build_lds_images), uploaded by set_params
   std::vector<int> h_posN, h_posM;            // positions of the gathered LDS vectors (build_lds_images)
@@ -1744,7 +1733,8 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
     }
   int bs = 512;
   if (const char* eb = getenv("COSMO_HIP_BATCH_BS")) { const int v = atoi(eb); if (v == 256 || v == 512 || v == 1024) bs = v; }
-  if (npsd > 0 || n3 > 0 || b->aa_on) bs = 512;                  // the extended-cone / accelerated instantiations of the LDS-image kernel exist for 512 threads
+  { const char* ex = getenv("COSMO_HIP_BATCH_EXT"); b->force_ext = ex && atoi(ex) != 0; }     // measure the extended-cone instantiations on batches without such cones
+  if (npsd > 0 || n3 > 0 || b->aa_on || b->force_ext) bs = 512;  // the extended-cone / accelerated instantiations of the LDS-image kernel exist for 512 threads
   // register-resident iterates (k_batch_admm_reg, 512 threads) when the vectors fit 1-2 (n) / 2-4 (m) elements per thread
   b->reg_mode = 0;
   { const char* er = getenv("COSMO_HIP_BATCH_REG");
@@ -1778,8 +1768,7 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
     h.oArp = (int)o; o = up16(o + 2 * (m + 1));
     h.oAcol = (int)o; o = up16(o + 2 * nnzA);
     h.oTrp = (int)o; o = up16(o + 2 * (n + 1));
-    h.oTpos = (int)o; o = up16(o + 2 * nnzA);
-    h.oTrow = (int)o; o = up16(o + 2 * nnzA);
+    h.oTpr = (int)o; o = up16(o + 4 * nnzA);
     h.oPrp = (int)o; o = up16(o + 2 * (n + 1));
     h.oPcol = (int)o; o = up16(o + 2 * nnzP);
     h.bytes = (int)o;
@@ -1792,8 +1781,7 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
     unsigned short* Arp = reinterpret_cast<unsigned short*>(im.data() + h.oArp);
     unsigned short* Acol = reinterpret_cast<unsigned short*>(im.data() + h.oAcol);
     unsigned short* Trp = reinterpret_cast<unsigned short*>(im.data() + h.oTrp);
-    unsigned short* Tpos = reinterpret_cast<unsigned short*>(im.data() + h.oTpos);
-    unsigned short* Trow = reinterpret_cast<unsigned short*>(im.data() + h.oTrow);
+    uint32_t* Tpr = reinterpret_cast<uint32_t*>(im.data() + h.oTpr);
     unsigned short* Prp = reinterpret_cast<unsigned short*>(im.data() + h.oPrp);
     unsigned short* Pcol = reinterpret_cast<unsigned short*>(im.data() + h.oPcol);
     for (long long t = 0; t < nnzA; ++t) { Aval[t] = A.val[t]; Acol[t] = (unsigned short)A.col[t]; }
@@ -1806,7 +1794,7 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
       for (int t = AT.rowptr[j]; t < AT.rowptr[j + 1]; ++t) {
         const int i = AT.col[t]; const int p = cur[i]++;
         if (p >= A.rowptr[i + 1] || A.col[p] != (int)j || A.val[p] != AT.val[t]) return bfail(b, COSMO_HIP_ERR_INVALID, "LDS image: A / A' mismatch");
-        Tpos[t] = (unsigned short)p; Trow[t] = (unsigned short)i;
+        Tpr[t] = (uint32_t)p | ((uint32_t)i << 16);
       }
     }
     Trp[n] = (unsigned short)AT.rowptr[n]; Prp[n] = (unsigned short)pp;
@@ -1902,9 +1890,9 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
         // the image's gather indices become positions
         std::vector<unsigned char>& im2 = imgs[(size_t)k];
         unsigned short* Acol2 = reinterpret_cast<unsigned short*>(im2.data() + h.oAcol);
-        unsigned short* Trow2 = reinterpret_cast<unsigned short*>(im2.data() + h.oTrow);
+        uint32_t* Tpr2 = reinterpret_cast<uint32_t*>(im2.data() + h.oTpr);
         unsigned short* Pcol2 = reinterpret_cast<unsigned short*>(im2.data() + h.oPcol);
-        for (long long t = 0; t < nnzA; ++t) { Acol2[t] = (unsigned short)pN[Acol2[t]]; Trow2[t] = (unsigned short)pM[Trow2[t]]; }
+        for (long long t = 0; t < nnzA; ++t) { Acol2[t] = (unsigned short)pN[Acol2[t]]; Tpr2[t] = (Tpr2[t] & 0xffffu) | ((uint32_t)pM[Tpr2[t] >> 16] << 16); }
         for (long long t = 0; t < nnzP; ++t) Pcol2[t] = (unsigned short)pN[Pcol2[t]];
       }
     }
@@ -1930,7 +1918,7 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
   const void* fn = bs == 256 ? (const void*)k_batch_admm_lds<256, false, false> : (bs == 512 ? (const void*)k_batch_admm_lds<512, false, false> : (const void*)k_batch_admm_lds<1024, false, false>);
   if (b->reg_mode == 1) fn = (const void*)k_batch_admm_reg<512, 1, 2, false, false>;
   if (b->reg_mode == 2) fn = (const void*)k_batch_admm_reg<512, 2, 4, false, false>;
-  if (npsd > 0 || n3 > 0) {
+  if (npsd > 0 || n3 > 0 || b->force_ext) {
     fn = (const void*)k_batch_admm_lds<512, true, false>;
     if (b->reg_mode == 1) fn = (const void*)k_batch_admm_reg<512, 1, 2, true, false>;
     if (b->reg_mode == 2) fn = (const void*)k_batch_admm_reg<512, 2, 4, true, false>;
@@ -1948,7 +1936,8 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
 }
 
 static int32_t launch_batch_admm(cosmo_hip_batch* b, const BParams& P, long long target, int do_init) {
-  const bool psd = b->D.npsd > 0 || b->D.n3 > 0;        // the instantiations with the cones beyond Zero / Nonnegatives / Box / SecondOrderCone
+  bool psd = b->D.npsd > 0 || b->D.n3 > 0;              // the instantiations with the cones beyond Zero / Nonnegatives / Box / SecondOrderCone
+  if (b->force_ext) psd = true;                           // COSMO_HIP_BATCH_EXT=1 (lab switch: that code is a run-time no-op without such cones)
 #define LAUNCH_REG(JN_, JM_, PSD_) hipLaunchKernelGGL((k_batch_admm_reg<512, JN_, JM_, PSD_, false>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride)
 #define LAUNCH_LDS(BS_, PSD_) hipLaunchKernelGGL((k_batch_admm_lds<BS_, PSD_, false>), dim3(b->nprob), dim3(BS_), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride)
   if (b->aa_on) {                    // accelerated loop: register kernel (batches without PSD cones), else the LDS-image kernel (512 threads) or the streaming kernel with the PSD code (a run-time no-op without such cones)

@@ -134,6 +134,15 @@ struct PolarPlan {
   int batch_ragged = 1;      // block-balanced ragged tiles (k_symm_gemm_batch_r); COSMO_HIP_POLAR_BATCH_RAGGED=0: the 64 x 64 quadrant kernel
   void* d_rtiles = nullptr;  // RTile list of the ragged kernel (XCD-interleaved like d_btiles)
   int nrtiles = 0;
+  // COMPACT REPAIR (round 5): a failed verification is repaired by launches over the FAILING cones' tiles only (tile list rebuilt on the host from the
+  // per-cone verification flags it has just read, uploaded from a pinned buffer), not by 26 full-grid launches in which all other tiles look at a
+  // gate and leave; the first repair round resumes with ONE lifting step (a cone that fails at its adaptive depth is one step short in the replay,
+  // tests/studies/lift_depth_replay.py), the second with the POLAR_RLIFT of before.  Used by the adaptive per-cone depth mode.
+  void* h_rtiles = nullptr;  // host copy of the RTile list (malloc)
+  void* rep_host = nullptr;  // pinned staging of the compact list
+  void* d_rtiles_rep = nullptr;
+  int nrep = 0;
+  long long repair_launch_tiles = 0, repair_trains = 0;
   double batch_flops_performed = 0.0, batch_flops_useful = 0.0;   // per product: 16 x 16 x 16 blocks actually issued; sum d^2 (d + 1)
   int batch_ts96 = 0;        // COSMO_HIP_POLAR_BATCH_TS96=1: cones whose side fits 96 / 192 take 96 x 96 tiles in a second launch per product.
                              // Measured on BASELINE config 5: SLOWER, 62.2 vs 47.0 us per product, 133.9 vs 155.2 it/s (two launch tails per
@@ -159,6 +168,7 @@ struct PolarPlan {
   // 10 depths + 1: 58 of 60 projections still contain a failure) says the same.  Config 4 (one cone): depth 9 instead of 10 after 50 projections,
   // 128.8 vs 129.0 it/s.
   int adapt = 0;
+  int compact_repair = 1;                // COSMO_HIP_POLAR_COMPACT_REPAIR=0: the full-grid gated repair train of round 4
   std::vector<int> bk, bstreak, bm;     // per batched cone: lifting depth, verified projections since the last change, patience
   int* d_lgate = nullptr;                // (LIFT_CAP x n) gate table of the lifting steps
   int* d_ubuf = nullptr;                 // per cone: work buffer (1 | 2) that receives U_0 (the one that is `iu` when the cone joins)
@@ -1293,6 +1303,9 @@ void polar_plan_destroy(cosmo_hip_handle* h) {
   if (q->d_bcones) (void)hipFree(q->d_bcones);
   if (q->d_btiles) (void)hipFree(q->d_btiles);
   if (q->d_rtiles) (void)hipFree(q->d_rtiles);
+  if (q->d_rtiles_rep) (void)hipFree(q->d_rtiles_rep);
+  if (q->rep_host) (void)hipHostFree(q->rep_host);
+  free(q->h_rtiles);
   if (q->BW) (void)hipFree(q->BW);
   if (q->bparts) (void)hipFree(q->bparts);
   if (q->bnrm) (void)hipFree(q->bnrm);
@@ -1324,6 +1337,7 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
   h->psd_polar = q;
   if (const char* e = getenv("COSMO_HIP_POLAR_KLIFT")) q->k_lift = std::min(40, std::max(0, atoi(e)));
   if (const char* e = getenv("COSMO_HIP_POLAR_ADAPT")) q->adapt = atoi(e) ? 1 : 0;
+  if (const char* e = getenv("COSMO_HIP_POLAR_COMPACT_REPAIR")) q->compact_repair = atoi(e) ? 1 : 0;
   if (const char* e = getenv("COSMO_HIP_POLAR_RESCALE")) q->rescale = atoi(e) ? 1 : 0;
   if (const char* e = getenv("COSMO_HIP_POLAR_STREAMK")) q->streamk = atoi(e) ? 1 : 0;
   if (const char* e = getenv("COSMO_HIP_POLAR_BATCH_TS96")) q->batch_ts96 = atoi(e) ? 1 : 0;
@@ -1485,6 +1499,11 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
       q->nrtiles = (int)rl.size();
       HIPCHK(h, hipMalloc((void**)&q->d_rtiles, sizeof(RTile) * rl.size()));
       HIPCHK(h, hipMemcpy(q->d_rtiles, rl.data(), sizeof(RTile) * rl.size(), hipMemcpyHostToDevice));
+      q->h_rtiles = malloc(sizeof(RTile) * rl.size());
+      if (!q->h_rtiles) return cosmo_fail(h, COSMO_HIP_ERR_HIP, "out of host memory");
+      memcpy(q->h_rtiles, rl.data(), sizeof(RTile) * rl.size());
+      HIPCHK(h, hipMalloc((void**)&q->d_rtiles_rep, sizeof(RTile) * rl.size()));
+      HIPCHK(h, hipHostMalloc((void**)&q->rep_host, sizeof(RTile) * rl.size()));
       (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch_r<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
       (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch_r<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
       (void)hipFuncSetAttribute((const void*)k_symm_gemm_batch_r<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, GemmCfg<64>::SMEM);
@@ -1504,7 +1523,8 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
     HIPCHK(h, hipMalloc((void**)&q->bgate, sizeof(int) * q->bcones.size()));
     HIPCHK(h, hipMemset(q->bgate, 0, sizeof(int) * q->bcones.size()));
     { const size_t nb = q->bcones.size();
-      q->bk.assign(nb, q->k_lift); q->bstreak.assign(nb, 0); q->bm.assign(nb, 3);
+      { int pat = 3; if (const char* e = getenv("COSMO_HIP_POLAR_PATIENCE")) pat = std::max(1, atoi(e));      // verified projections before a cone probes one step down
+        q->bk.assign(nb, q->k_lift); q->bstreak.assign(nb, 0); q->bm.assign(nb, pat); }
       HIPCHK(h, hipMalloc((void**)&q->d_lgate, sizeof(int) * nb * POLAR_LIFT_CAP));
       HIPCHK(h, hipMalloc((void**)&q->d_ubuf, sizeof(int) * nb));
       HIPCHK(h, hipHostMalloc((void**)&q->bgate_host, sizeof(int) * nb, hipHostMallocDefault));
@@ -1534,6 +1554,16 @@ bool polar_has_large(const cosmo_hip_handle* h) { const PolarPlan* q = static_ca
 // 74.5 KB of LDS allow two workgroups per CU)
 template <int EPI>
 static void launch_bgemm(PolarPlan* q, hipStream_t st, const Ctl* ctl, int guard, const int* gate, int ia, int ib, int icin, int ic, real alpha, real beta) {
+  if (q->batch_ragged && q->nrep > 0) {          // compact repair launch: the failing cones' tiles only (no gate needed: the list IS the gate)
+    if (q->batch_occ == 4)
+      hipLaunchKernelGGL((k_symm_gemm_batch_r<EPI, 4>), dim3(q->nrep), dim3(256), GemmCfg<64>::SMEM, st, ctl, guard, gate, (const RTile*)q->d_rtiles_rep, q->d_bcones,
+                         q->BW, ia, ib, icin, ic, alpha, beta);
+    else
+      hipLaunchKernelGGL((k_symm_gemm_batch_r<EPI, 3>), dim3(q->nrep), dim3(256), GemmCfg<64>::SMEM, st, ctl, guard, gate, (const RTile*)q->d_rtiles_rep, q->d_bcones,
+                         q->BW, ia, ib, icin, ic, alpha, beta);
+    q->repair_launch_tiles += q->nrep;
+    return;
+  }
   if (q->batch_ragged && q->nrtiles > 0) {
     // (the two halves of the batch on two HIP streams -- so that one half's launch tail overlaps the other's steady state -- were built and
     //  measured: 187.8-189.6 vs 187.1 it/s on BASELINE config 5, no gain, removed; profiles/r03_cfg5_ragged.txt)
@@ -1616,7 +1646,7 @@ int32_t polar_enqueue_project_batch(cosmo_hip_handle* h, real* s, int guard) {
   for (int r = 1; r <= q->max_rounds; ++r) {                 // guarded fallback rounds (even number of steps: iu is preserved)
     if (!q->speculate) {                                     // ask the device whether the last verification failed (and, round 1 of an adaptive run, which cones)
       HIPCHK(h, hipMemcpyAsync(q->gate_host, &q->dev->gate, (adapt && r == 1 ? 5 : 1) * sizeof(int), hipMemcpyDeviceToHost, st));
-      if (adapt && r == 1) HIPCHK(h, hipMemcpyAsync(q->bgate_host, q->bgate, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));
+      if (r == 1 && q->bgate_host) HIPCHK(h, hipMemcpyAsync(q->bgate_host, q->bgate, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));   // per-cone results: depth control + compact repair list
       HIPCHK(h, hipStreamSynchronize(st));
       if (adapt && r == 1 && q->gate_host[4] != q->seen_proj_batch) {
         // depth control from this projection's per-cone results.  PolarDev::projections advances only when the verification really ran: in a
@@ -1638,10 +1668,25 @@ int32_t polar_enqueue_project_batch(cosmo_hip_handle* h, real* s, int guard) {
       }
       if (!*q->gate_host) break;
     }
-    for (int t = 0; t < POLAR_RLIFT; ++t) step(kPolarLift, q->bgate);
+    int rlift = POLAR_RLIFT;
+    if (q->compact_repair && q->batch_ragged && q->h_rtiles && q->bgate_host && !q->speculate) {
+      if (r == 1) {                                          // tile list of the failing cones (bgate_host was read with the gate above)
+        const RTile* all = (const RTile*)q->h_rtiles; RTile* dst = (RTile*)q->rep_host;
+        int cnt = 0;
+        for (int t = 0; t < q->nrtiles; ++t) if (all[t].cone >= 0 && q->bgate_host[all[t].cone]) dst[cnt++] = all[t];
+        if (cnt > 0) {
+          HIPCHK(h, hipMemcpyAsync(q->d_rtiles_rep, dst, sizeof(RTile) * (size_t)cnt, hipMemcpyHostToDevice, st));
+          q->nrep = cnt; q->repair_trains += 1;
+        }
+        if (adapt) rlift = 1;                                // 1 + POLAR_NFIN steps: even, the buffer parity is preserved
+      }
+      // round 2 (r == 2): the same list behind the per-cone gate -- the cones that failed again are a subset of it
+    }
+    for (int t = 0; t < rlift; ++t) step(kPolarLift, q->bgate);
     for (int t = 0; t < POLAR_NFIN; ++t) step(kPolarFinish[t], q->bgate);
     verify(r, q->bgate);
   }
+  q->nrep = 0;
   hipLaunchKernelGGL(k_bpolar_finish, dim3(BPX, n), dim3(COSMO_BS), 0, st, h->ctl, guard, q->d_bcones, q->BW, iu, s, q->bparts);
   hipLaunchKernelGGL(k_bpolar_rank, dim3((n + 63) / 64), dim3(64), 0, st, h->ctl, guard, n, q->d_bcones, q->bparts, p->rank);
   HIPCHK(h, hipGetLastError());

@@ -64,7 +64,7 @@ def test_device_automatic_interval_equals_the_fixed_interval_runs(accel):
     (r0, w0, ri0), _ = solve(setup_time=0.0, adaptive_rho_interval=0)
     assert ri0[0] == 25 and ri0[1] in (1, 2)                        # fixed at the first test of the loop
     (r1, w1, _), _ = solve(setup_time=0.0, adaptive_rho_interval=25)
-    assert r0.iter == r1.iter and r0.status == r1.status and r0.n_rho_updates == r1.n_rho_updates >= 2
+    assert r0.iter == r1.iter and r0.status == r1.status and r0.n_rho_updates == r1.n_rho_updates >= (1 if accel else 2)   # (the accelerated run is Solved before rho moves)
     assert np.array_equal(w0, w1)                                   # the same launches in the same order
     (r2, w2, ri2), _ = solve(setup_time=1e9, adaptive_rho_interval=0)
     (r3, w3, _), _ = solve(setup_time=0.0, adaptive_rho=False)

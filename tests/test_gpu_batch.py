@@ -262,7 +262,7 @@ def test_cfg3_full_size_batch():
 
 def _with_env(env, fn):
     import os
-    keys = ("COSMO_HIP_BATCH_LDS", "COSMO_HIP_BATCH_BS", "COSMO_HIP_BATCH_REG")
+    keys = ("COSMO_HIP_BATCH_LDS", "COSMO_HIP_BATCH_BS", "COSMO_HIP_BATCH_REG", "COSMO_HIP_BATCH_LDSCG", "COSMO_HIP_BATCH_EXT", "COSMO_HIP_BATCH_SORTED")
     saved = {k: os.environ.pop(k, None) for k in keys}
     os.environ.update(env)
     try:
@@ -296,20 +296,30 @@ def test_batch_kernel_variants_agree():
         assert a.iter == c.iter == 60 and a.status == c.status
 
 
-def test_batch_register_kernel_sorted_compute_assignment_is_bit_identical():
-    """Inside the Krylov loop the register kernel lets thread t COMPUTE the rows / the column of a length-sorted assignment and hands the
-    results to the owners through LDS (csrc/batch.hip, k_batch_admm_reg); the owners keep every update and reduction and each row sum is
-    the same left-to-right sum.  COSMO_HIP_BATCH_SORTED=0 is the owner-computes form: same bits, same Krylov counts, same rho updates --
-    default (inexact, rho-adapting) schedule and tight mode."""
+def test_batch_register_kernel_sorted_ownership_agrees_with_the_index_order_form():
+    """Inside the Krylov loop the register kernel lets thread t compute the rows / the column of a length-sorted assignment (csrc/batch.hip,
+    k_batch_admm_reg).  Since round 5 that column is also the element of the n-vectors the thread OWNS (no hand-over of c through LDS: two barriers
+    fewer per Krylov iteration), so the block sums add the same per-element terms in another thread order than the index-order form
+    (COSMO_HIP_BATCH_SORTED=0): every row sum is still the same left-to-right sum, the trajectories agree to 1e-9 in tight mode (bit-identity BETWEEN
+    the two forms was given up on purpose; run-to-run determinism is not), and the default inexact schedule lands on the same
+    statuses / iteration counts / rho-update counts."""
     probs = [cj.problems.socp(seed=2100 + k) for k in range(6)]
     tight = cj.with_options(cj.CGIndirectKKTSolver, tol_constant=1e-10, tol_exponent=0.0)
-    for st in (cj.Settings(max_iter=120, eps_abs=0.0, eps_rel=0.0), cj.Settings(kkt_solver=tight, max_iter=60, eps_abs=0.0, eps_rel=0.0)):
-        run = lambda: cj.optimize_batch(_models(probs, st))
-        own = _with_env({"COSMO_HIP_BATCH_SORTED": "0"}, run)
-        srt = _with_env({}, run)
-        for a, b in zip(own, srt):
-            assert np.array_equal(a.x, b.x) and np.array_equal(a.s, b.s) and np.array_equal(a.y, b.y)
-            assert a.kkt_iters_total == b.kkt_iters_total > 0 and a.info.rho_updates == b.info.rho_updates and a.iter == b.iter
+    st = cj.Settings(kkt_solver=tight, max_iter=60, eps_abs=0.0, eps_rel=0.0)
+    run = lambda: cj.optimize_batch(_models(probs, st))
+    own = _with_env({"COSMO_HIP_BATCH_SORTED": "0"}, run)
+    srt = _with_env({}, run)
+    srt2 = _with_env({}, run)
+    for a, b, c in zip(own, srt, srt2):
+        for u, v in ((a.x, b.x), (a.s, b.s), (a.y, b.y)):
+            assert np.max(np.abs(u - v)) <= 1e-9 * max(1.0, float(np.max(np.abs(u))))
+        assert abs(a.kkt_iters_total - b.kkt_iters_total) <= 0.01 * a.kkt_iters_total + 2 and len(a.info.rho_updates) == len(b.info.rho_updates) and a.iter == b.iter
+        assert np.array_equal(b.x, c.x) and np.array_equal(b.s, c.s) and b.kkt_iters_total == c.kkt_iters_total      # run to run: bit for bit
+    st = cj.Settings(max_iter=120, eps_abs=0.0, eps_rel=0.0)
+    own = _with_env({"COSMO_HIP_BATCH_SORTED": "0"}, run)
+    srt = _with_env({}, run)
+    for a, b in zip(own, srt):
+        assert a.iter == b.iter and a.status == b.status and len(a.info.rho_updates) == len(b.info.rho_updates)
 
 
 def test_batch_register_kernel_default_schedule_matches_oracle():
@@ -480,21 +490,28 @@ def test_batch_of_small_sdps_matches_the_per_problem_oracle():
 
 
 def test_batch_small_sdp_kernel_variants_agree_and_match_the_single_problem_path():
-    """The three batch kernels project the PSD cones with the same wave routine: streaming == LDS image bit for bit, register kernel to 1e-9 (its
-    block-reduction tree differs); a problem solved alone through the single-problem handle (k_psd_tiny: the SAME routine, one wave per cone)
-    agrees to 1e-9 as well."""
+    """The batch kernels project the PSD cones with the same wave routine: streaming == LDS image with the generic Krylov loop bit for bit; the
+    LDS-image kernel's register-CG form (round 5, the default) and the register kernel to 1e-8 (their block-reduction trees differ: BS-strided
+    ownership of the Krylov vectors instead of tile order); a problem solved alone through the single-problem handle (k_psd_tiny: the SAME routine,
+    one wave per cone) agrees to 1e-8 as well."""
     probs = _small_sdps(6, 33)
     tight = cj.with_options(cj.CGIndirectKKTSolver, tol_constant=1e-10, tol_exponent=0.0)
     st = cj.Settings(kkt_solver=tight, max_iter=60, eps_abs=0.0, eps_rel=0.0)
     run = lambda: cj.optimize_batch(_models(probs, st))
     ref = _with_env({"COSMO_HIP_BATCH_LDS": "0"}, run)
-    lds = _with_env({"COSMO_HIP_BATCH_REG": "0", "COSMO_HIP_BATCH_BS": "256"}, run)
+    lds = _with_env({"COSMO_HIP_BATCH_REG": "0", "COSMO_HIP_BATCH_LDSCG": "0"}, run)
+    rcg = _with_env({"COSMO_HIP_BATCH_REG": "0"}, run)
     reg = _with_env({}, run)
-    for a, b, c in zip(ref, lds, reg):
+    for a, b, c, d in zip(ref, lds, reg, rcg):
         assert np.array_equal(a.x, b.x) and np.array_equal(a.s, b.s) and np.array_equal(a.y, b.y)
-        for u, v in ((a.x, c.x), (a.s, c.s), (a.y, c.y)):
-            assert np.max(np.abs(u - v)) <= 1e-8 * max(1.0, float(np.max(np.abs(u))))
-        assert a.iter == c.iter == 60
+        for other in (c, d):
+            for u, v in ((a.x, other.x), (a.s, other.s), (a.y, other.y)):
+                assert np.max(np.abs(u - v)) <= 1e-8 * max(1.0, float(np.max(np.abs(u))))
+            assert abs(a.kkt_iters_total - other.kkt_iters_total) <= 0.02 * a.kkt_iters_total + 2
+        assert a.iter == c.iter == d.iter == 60
+    # run-to-run determinism of the register-CG form
+    rcg2 = _with_env({"COSMO_HIP_BATCH_REG": "0"}, run)
+    assert all(np.array_equal(u.x, v.x) and u.kkt_iters_total == v.kkt_iters_total for u, v in zip(rcg, rcg2))
     single = cj.optimize(_models(probs[:1], st)[0])
     assert np.max(np.abs(single.x - ref[0].x)) <= 1e-8 * max(np.max(np.abs(ref[0].x)), 1.0)
     assert np.max(np.abs(single.s - ref[0].s)) <= 1e-8 * max(np.max(np.abs(ref[0].s)), 1.0)

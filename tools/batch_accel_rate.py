@@ -24,7 +24,7 @@ def run(st, label, env=None):
     _, _, k1 = B.counters()
     a = B.accel_stats()
     kk = (k1 - k0)
-    print("%-22s %d iterations: %.1f ms = %.1f us per batch iteration; Krylov iterations per problem-iteration mean %.1f / max %.1f; accelerated %d declined %d"
+    print("%-34s %d iterations: %.1f ms = %.1f us per batch iteration; Krylov iterations per problem-iteration mean %.1f / max %.1f; accelerated %d declined %d"
           % (label, iters, 1e3 * dt, 1e6 * dt / iters, kk.mean() / iters, kk.max() / iters, a["accelerated"].sum(), a["declined"].sum()), flush=True)
     B.close()
     for k in (env or {}):
@@ -32,8 +32,13 @@ def run(st, label, env=None):
 
 
 far = dict(eps_abs=0.0, eps_rel=0.0, max_iter=10 ** 6)
+AA = cj.Settings(accelerator=cj.AndersonAccelerator, **far)
+# "LDS-image" rows: the instantiation that serves batches with PSD / exponential / power cones (COSMO_HIP_BATCH_EXT=1 selects it on this cone-free batch;
+# the accelerated LDS-image kernel IS that instantiation), with the generic Krylov loop of round 4 (COSMO_HIP_BATCH_LDSCG=0) and the register-CG form
 run(cj.Settings(**far), "register kernel")
-run(cj.Settings(**far), "LDS-image kernel", {"COSMO_HIP_BATCH_REG": "0"})
-run(cj.Settings(accelerator=cj.AndersonAccelerator, **far), "register + Anderson")
+run(cj.Settings(**far), "LDS-image, generic CG", {"COSMO_HIP_BATCH_REG": "0", "COSMO_HIP_BATCH_EXT": "1", "COSMO_HIP_BATCH_LDSCG": "0"})
+run(cj.Settings(**far), "LDS-image, register CG", {"COSMO_HIP_BATCH_REG": "0", "COSMO_HIP_BATCH_EXT": "1"})
+run(AA, "register + Anderson")
 run(cj.Settings(accelerator=cj.with_options(cj.AndersonAccelerator, mem=5), **far), "register + Anderson(5)")
-run(cj.Settings(accelerator=cj.AndersonAccelerator, **far), "LDS-image + Anderson", {"COSMO_HIP_BATCH_REG": "0"})
+run(AA, "LDS-image + Anderson, generic CG", {"COSMO_HIP_BATCH_REG": "0", "COSMO_HIP_BATCH_LDSCG": "0"})
+run(AA, "LDS-image + Anderson, register CG", {"COSMO_HIP_BATCH_REG": "0"})
