@@ -132,6 +132,22 @@ __device__ __forceinline__ real bsum(real v, real* red) {
   for (int i = 0; i < BS / 64; ++i) t += red[i];
   return t;
 }
+// Block sum with ONE barrier: consecutive calls alternate between two sets of BS / 64 slots (ph flips).  The set written now was last read two
+// calls ago, and every thread has passed the barrier of the call in between since then, so no barrier is needed in front of the writes.  Callers
+// put a workgroup barrier between the last classic bsum / bmax on `red` and the first bsum_db (the classic ones start with their own barrier, so
+// the other direction needs nothing).  Same additions in the same order as bsum.
+template <int BS>
+__device__ __forceinline__ real bsum_db(real v, real* red, int& ph) {
+  v = wave_sum(v);
+  real* r = red + ph * (BS / 64);
+  ph ^= 1;
+  if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = v;
+  __syncthreads();
+  real t = 0.0;
+#pragma unroll
+  for (int i = 0; i < BS / 64; ++i) t += r[i];
+  return t;
+}
 template <int BS>
 __device__ __forceinline__ real bmax(real v, real* red) {
   v = wave_max(v);
@@ -806,7 +822,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_lds(BatchDev D, BParams P, lo
   ops.nbA = hd.nbA; ops.nbAT = hd.nbAT; ops.nbPT = hd.nbPT;
   real* wsp = reinterpret_cast<real*>(base + img_stride);            // workspace behind the image
   ops.xv = wsp; ops.tv = wsp + D.n; ops.red = wsp + D.n + D.m; ops.n = D.n;
-  ops.psd_ws = base + ((img_stride + (long long)sizeof(real) * (D.n + D.m + BS / 64) + 15) / 16) * 16;     // behind the reduction slots (build_lds_images sizes it)
+  ops.psd_ws = base + ((img_stride + (long long)sizeof(real) * (D.n + D.m + 2 * (BS / 64)) + 15) / 16) * 16;     // behind the reduction slots (build_lds_images sizes it)
   __syncthreads();
   batch_admm_body<BS, PSD, AA>(D, P, iter_target, do_init, ops, ops.red);
 }
@@ -858,8 +874,8 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   real* wsp = reinterpret_cast<real*>(base + img_stride);
   real* xv = wsp;                 // n : vector gathered by the A / P products
   real* tv = wsp + n;             // m : vector gathered by the A' products; staging of s for the SOC projection
-  real* red = wsp + n + m;        // BS / 64 reduction slots
-  unsigned char* psd_ws = base + ((img_stride + (long long)sizeof(real) * (n + m + BS / 64) + 15) / 16) * 16;   // wave workspaces of the small PSD cones
+  real* red = wsp + n + m;        // 2 x (BS / 64) reduction slots (the second set: double-buffered block sums of the Krylov loop, bsum_db)
+  unsigned char* psd_ws = base + ((img_stride + (long long)sizeof(real) * (n + m + 2 * (BS / 64)) + 15) / 16) * 16;   // wave workspaces of the small PSD cones
   (void)psd_ws;
 
   const long long on = (long long)k * n, om = (long long)k * m, onm = (long long)k * (n + m);
@@ -872,16 +888,18 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   int ct[JN];
 #pragma unroll
   for (int j = 0; j < JN; ++j) {
-    const int i = ct[j];
+    const int i = tid + BS * j;
     ct[j] = (SORTED && D.permT) ? D.permT[(long long)k * (JN * BS) + j * BS + tid] : (i < n ? i : -1);
   }
+  // (the index-order instantiation <512, 2, 4> recomputes its elements from the thread index instead of holding them: it has no registers to spare)
+  auto OWN = [&](int j) -> int { if constexpr (SORTED) return ct[j]; else { const int i = tid + BS * j; return i < n ? i : -1; } };
   // ---- load the persistent state and the per-element constants into registers -----------------------------------------
   real wx[JN], wpx[JN], qv[JN], xtl[JN], lsx[JN], rhsv[JN], rv[JN], cv[JN];
   real wsv[JM], wps[JM], sv[JM], rhov[JM], lss[JM], bv[JM], blv[JM], buv[JM];
   uint32_t metav[JM];
 #pragma unroll
   for (int j = 0; j < JN; ++j) {
-    const int i = ct[j];
+    const int i = OWN(j);
     const bool ok = i >= 0;
     wx[j] = ok ? D.w[onm + i] : 0.0; wpx[j] = ok ? D.w_prev[onm + i] : 0.0; qv[j] = ok ? D.q[on + i] : 0.0; xtl[j] = ok ? D.x_tl[on + i] : 0.0;
     lsx[j] = 0.0; rhsv[j] = 0.0; rv[j] = 0.0; cv[j] = 0.0;
@@ -915,7 +933,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   int pn[JN], pm[JM], pnc[JN], pmc[JM];
 #pragma unroll
   for (int j = 0; j < JN; ++j) {
-    pnc[j] = (SORTED && D.posN && ct[j] >= 0) ? D.posN[on + ct[j]] : ct[j];
+    pnc[j] = (SORTED && D.posN && OWN(j) >= 0) ? D.posN[on + OWN(j)] : OWN(j);
     pn[j] = pnc[j];                                    // owner == computer
   }
 #pragma unroll
@@ -950,6 +968,15 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   // that a trip costs ONE dependent LDS round trip instead of two (index -> gather).  Same left-to-right sums: bit-identical to the plain loops
   // `for (t = a; t < b; ++t) s1 += Aval[t] * xv[Acol[t]]` (iterate hashes equal on all 1024 problems of config 3), 4100 -> 4367 batch-it/s
   // (7.35 -> 6.95 us per Krylov iteration of the slowest problem; profiles/r04_batch_pipe_lab.txt).
+  auto rowA_b = [&](int t, const int b2) -> real {
+    real s1 = 0.0;
+    if (t < b2) {
+      real v = Aval[t]; int c = Acol[t];
+      for (++t; t < b2; ++t) { const real vn = Aval[t]; const int cn = Acol[t]; s1 += v * xv[c]; v = vn; c = cn; }
+      s1 += v * xv[c];
+    }
+    return s1 + R(0.0);
+  };
   auto rowA = [&](int r) -> real {
     real s1 = 0.0;
     int t = Arp[r]; const int b2 = Arp[r + 1];
@@ -960,6 +987,15 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     }
     return s1 + R(0.0);
   };
+  auto rowAT_b = [&](int t, const int b2) -> real {
+    real s1 = 0.0;
+    if (t < b2) {
+      uint32_t pr = Tpr[t];
+      for (++t; t < b2; ++t) { const uint32_t prn = Tpr[t]; s1 += Aval[pr & 0xffffu] * tv[pr >> 16]; pr = prn; }
+      s1 += Aval[pr & 0xffffu] * tv[pr >> 16];
+    }
+    return s1;
+  };
   auto rowAT = [&](int r) -> real {
     real s1 = 0.0;
     int t = Trp[r]; const int b2 = Trp[r + 1];
@@ -967,6 +1003,15 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       uint32_t pr = Tpr[t];
       for (++t; t < b2; ++t) { const uint32_t prn = Tpr[t]; s1 += Aval[pr & 0xffffu] * tv[pr >> 16]; pr = prn; }
       s1 += Aval[pr & 0xffffu] * tv[pr >> 16];
+    }
+    return s1;
+  };
+  auto rowP_b = [&](int t, const int b2) -> real {
+    real s1 = 0.0;
+    if (t < b2) {
+      real v = Pval[t]; int c = Pcol[t];
+      for (++t; t < b2; ++t) { const real vn = Pval[t]; const int cn = Pcol[t]; s1 += v * xv[c]; v = vn; c = cn; }
+      s1 += v * xv[c];
     }
     return s1;
   };
@@ -980,6 +1025,16 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     }
     return s1;
   };
+  // Row bounds of the rows / the column this thread computes in EVERY Krylov iteration (constant for the launch): kept in registers, so that a row
+  // starts with its first value / index loads instead of a dependent row-pointer round trip (8 LDS reads and 4 dependent round trips less per thread
+  // and Krylov iteration).  The <512, 2, 4> instantiation has no registers to spare and keeps reading them.
+  int ka0[SORTED ? JM : 1], ka1[SORTED ? JM : 1], kp0[SORTED ? JN : 1], kp1[SORTED ? JN : 1], kt0[SORTED ? JN : 1], kt1[SORTED ? JN : 1];
+  if constexpr (SORTED) {
+#pragma unroll
+    for (int j = 0; j < JM; ++j) { const int r = ra[j]; ka0[j] = r >= 0 ? Arp[r] : 0; ka1[j] = r >= 0 ? Arp[r + 1] : 0; }
+#pragma unroll
+    for (int j = 0; j < JN; ++j) { const int c = OWN(j); kp0[j] = c >= 0 ? Prp[c] : 0; kp1[j] = c >= 0 ? Prp[c + 1] : 0; kt0[j] = c >= 0 ? Trp[c] : 0; kt1[j] = c >= 0 ? Trp[c + 1] : 0; }
+  }
 
   // ---- admm_x! + admm_w! (solver.jl:32-65) with the CG reduced solve (kktsolver_indirect.jl:36-88) -------------------
   auto solve_and_update = [&]() {
@@ -993,12 +1048,12 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       if (i < m) tv[pm[j]] = rhov[j] * v;                                // y2 = rho .* ls_s
     }
 #pragma unroll
-    for (int j = 0; j < JN; ++j) { const int i = ct[j]; if (i >= 0) xv[pn[j]] = xtl[j]; }
+    for (int j = 0; j < JN; ++j) { const int i = OWN(j); if (i >= 0) xv[pn[j]] = xtl[j]; }
     __syncthreads();
     real acc = 0.0;
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
-      const int i = ct[j];
+      const int i = OWN(j);
       if (i >= 0) { const real v = (rowAT(i) + R(0.0)) + lsx[j]; rhsv[j] = v; acc += v * v; }
     }
     const real bb = bsum<BS>(acc, red);                                  // (its barriers also order tv reads before the writes below)
@@ -1012,7 +1067,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     acc = 0.0;
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
-      const int i = ct[j];
+      const int i = OWN(j);
       if (i >= 0) { const real cj = rowP(i) + (P.sigma * xtl[j] + rowAT(i)); const real rj = rhsv[j] - cj; rv[j] = rj; acc += rj * rj; }
     }
     real rr = bsum<BS>(acc, red);
@@ -1024,10 +1079,12 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     real uv[JN];
 #pragma unroll
     for (int j = 0; j < JN; ++j) uv[j] = 0.0;
+    int ph = 0;                                                          // bsum_db: which of the two slot sets the next block sum writes
+    if constexpr (SORTED) __syncthreads();                               // (the block sums above read `red`: see bsum_db)
     while (kk < n && !(res <= tol)) {                                    // cg! (IterativeSolvers v0.9), maxiter = n
       const real beta = (res * res) / (prev * prev);
 #pragma unroll
-      for (int j = 0; j < JN; ++j) { const int i = ct[j]; uv[j] = rv[j] + beta * ((kk == 0) ? R(0.0) : uv[j]); if (i >= 0) xv[pn[j]] = uv[j]; }
+      for (int j = 0; j < JN; ++j) { const int i = OWN(j); uv[j] = rv[j] + beta * ((kk == 0) ? R(0.0) : uv[j]); if (i >= 0) xv[pn[j]] = uv[j]; }
       __syncthreads();
       // The two sparse passes of a Krylov iteration are bound by the CU's LDS pipe, and a wave issues as many steps as its LONGEST row.
       // So thread t COMPUTES the rows ra[] / the column ct[] of the length-sorted assignment (rows of similar length share a wave-step:
@@ -1038,7 +1095,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       if (SORTED) {
       { BT_BEGIN();
 #pragma unroll
-      for (int j = 0; j < JM; ++j) tmpv[j] = (ra[j] >= 0) ? rowA(ra[j]) * rhoc[j] : 0.0;
+      for (int j = 0; j < JM; ++j) tmpv[j] = (ra[j] >= 0) ? rowA_b(ka0[j], ka1[j]) * rhoc[j] : 0.0;
 #pragma unroll
       for (int j = 0; j < JM; ++j) if (ra[j] >= 0) tv[pmc[j]] = tmpv[j];   // tv was last read before the previous barrier pair
       __syncthreads();
@@ -1054,12 +1111,19 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       { BT_BEGIN();
 #pragma unroll
       for (int j = 0; j < JN; ++j) {                                       // the column this thread owns AND computes
-        const int c = ct[j];
-        if (c >= 0) { const real vj = uv[j]; const real cj = rowP(c) + (P.sigma * vj + rowAT(c)); cv[j] = cj; acc += vj * cj; }
+        const int c = OWN(j);
+        if (c >= 0) {
+          const real vj = uv[j];
+          real cj;
+          if constexpr (SORTED) cj = rowP_b(kp0[j], kp1[j]) + (P.sigma * vj + rowAT_b(kt0[j], kt1[j]));
+          else cj = rowP(c) + (P.sigma * vj + rowAT(c));
+          cv[j] = cj; acc += vj * cj;
+        }
       }
       BT_END(1); }
       BT_BEGIN();
-      const real uc = bsum<BS>(acc, red);
+      real uc;
+      if constexpr (SORTED) uc = bsum_db<BS>(acc, red, ph); else uc = bsum<BS>(acc, red);
       BT_END(2);
 #ifdef COSMO_BATCH_TIMING
       if (blockIdx.x == 0 && tid == 0) g_bt[3] += 1;
@@ -1068,15 +1132,15 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       acc = 0.0;
 #pragma unroll
       for (int j = 0; j < JN; ++j) {
-        const int i = ct[j];
+        const int i = OWN(j);
         if (i >= 0) { xtl[j] = xtl[j] + a * uv[j]; const real ri = rv[j] - a * cv[j]; rv[j] = ri; acc += ri * ri; }
       }
-      rr = bsum<BS>(acc, red);
+      if constexpr (SORTED) rr = bsum_db<BS>(acc, red, ph); else rr = bsum<BS>(acc, red);
       prev = res; res = sqrt(rr); ++kk;
     }
     // nu = rho (A x_tl - ls_s) ; s_tl ; w update
 #pragma unroll
-    for (int j = 0; j < JN; ++j) { const int i = ct[j]; if (i >= 0) xv[pn[j]] = xtl[j]; }
+    for (int j = 0; j < JN; ++j) { const int i = OWN(j); if (i >= 0) xv[pn[j]] = xtl[j]; }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < JM; ++j) {
@@ -1100,7 +1164,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   for (int j = 0; j < JM; ++j) muv[j] = 0.0;
   auto residuals = [&](bool unscale) {
 #pragma unroll
-    for (int j = 0; j < JN; ++j) { const int i = ct[j]; if (i >= 0) xv[pn[j]] = wpx[j]; }
+    for (int j = 0; j < JN; ++j) { const int i = OWN(j); if (i >= 0) xv[pn[j]] = wpx[j]; }
     __syncthreads();
     real a_rp = 0.0, a_mp = 0.0;
 #pragma unroll
@@ -1122,7 +1186,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     real a_rd = 0.0, a_md = 0.0, xpx = 0.0, qx = 0.0;
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
-      const int i = ct[j];
+      const int i = OWN(j);
       if (i >= 0) {
         const real px = rowP(i), atm = rowAT(i), x0 = wpx[j], q0 = qv[j];
         real r0 = px + q0; r0 = r0 - atm;
@@ -1190,7 +1254,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   if constexpr (AA) { M = aa_mem_of(D, k); aa_load(S, M.aa); }
   auto each = [&](auto&& fn) {
 #pragma unroll
-    for (int j = 0; j < JN; ++j) { const int i = ct[j]; if (i >= 0) fn(i, wx[j], wpx[j]); }
+    for (int j = 0; j < JN; ++j) { const int i = OWN(j); if (i >= 0) fn(i, wx[j], wpx[j]); }
 #pragma unroll
     for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; if (i < m) fn(n + i, wsv[j], wps[j]); }
   };
@@ -1290,7 +1354,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   // ---- store the persistent state; recover_mu! (solver.jl:167) ----
 #pragma unroll
   for (int j = 0; j < JN; ++j) {
-    const int i = ct[j];
+    const int i = OWN(j);
     if (i >= 0) { D.w[onm + i] = wx[j]; D.w_prev[onm + i] = wpx[j]; D.x_tl[on + i] = xtl[j]; }
   }
 #pragma unroll
@@ -1772,7 +1836,7 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
     h.oPrp = (int)o; o = up16(o + 2 * (n + 1));
     h.oPcol = (int)o; o = up16(o + 2 * nnzP);
     h.bytes = (int)o;
-    if (o + (long long)sizeof(real) * (n + m) + (long long)sizeof(real) * (bs / 64) > max_lds) return COSMO_HIP_OK;
+    if (o + (long long)sizeof(real) * (n + m) + (long long)sizeof(real) * 2 * (bs / 64) > max_lds) return COSMO_HIP_OK;
     std::vector<unsigned char>& im = imgs[(size_t)k];
     im.assign((size_t)o, 0);
     memcpy(im.data(), &h, sizeof h);
@@ -1904,7 +1968,7 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
   for (int k = 0; k < b->nprob; ++k)
     BHIP(b, hipMemcpy(d + (size_t)k * stride, imgs[(size_t)k].data(), imgs[(size_t)k].size(), hipMemcpyHostToDevice));
   // wave workspaces of the small PSD cones behind the reduction slots: as many as fit, at most one per wave; none fits => streaming kernel
-  const long long ws_base = ((stride + (long long)sizeof(real) * (n + m + bs / 64) + 15) / 16) * 16;
+  const long long ws_base = ((stride + (long long)sizeof(real) * (n + m + 2 * (bs / 64)) + 15) / 16) * 16;
   int nws = 0;
   if (npsd > 0) {
     nws = (int)std::min<long long>(bs / 64, (max_lds - ws_base) / PSD16_WS_STRIDE);
@@ -1914,7 +1978,7 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
   { const char* ec = getenv("COSMO_HIP_BATCH_LDSCG");
     b->D.regcg = (bs == 512 && n <= 2 * 512 && m <= 4 * 512 && !(ec && atoi(ec) == 0)) ? 1 : 0; }
   b->d_img = d; b->img_stride = stride; b->lds_bs = bs;
-  b->lds_bytes = (int)(npsd > 0 ? ws_base + (long long)nws * PSD16_WS_STRIDE : stride + (long long)sizeof(real) * (n + m) + (long long)sizeof(real) * (bs / 64));
+  b->lds_bytes = (int)(npsd > 0 ? ws_base + (long long)nws * PSD16_WS_STRIDE : stride + (long long)sizeof(real) * (n + m) + (long long)sizeof(real) * 2 * (bs / 64));
   const void* fn = bs == 256 ? (const void*)k_batch_admm_lds<256, false, false> : (bs == 512 ? (const void*)k_batch_admm_lds<512, false, false> : (const void*)k_batch_admm_lds<1024, false, false>);
   if (b->reg_mode == 1) fn = (const void*)k_batch_admm_reg<512, 1, 2, false, false>;
   if (b->reg_mode == 2) fn = (const void*)k_batch_admm_reg<512, 2, 4, false, false>;
