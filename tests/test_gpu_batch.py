@@ -211,7 +211,12 @@ def test_cfg3_full_size_tight_cg_all_problems():
 
 
 def test_cfg3_full_size_batch():
-    # BASELINE config 3 on one GPU: 1024 independent SOCPs n=500, m=1000, 50 SecondOrderCone(20) each
+    """BASELINE config 3 on one GPU with the DEFAULT settings (inexact CG schedule 1 / k^1.5): 1024 independent SOCPs n=500, m=1000, 50 SecondOrderCone(20) each.
+    What this test can and cannot pin: with an inexact KKT solve the termination check of a problem whose residuals hover around eps
+    moves by whole check intervals under ANY change of summation order -- the NumPy and the compiled oracle themselves disagree by up to three intervals
+    on the stragglers -- so the assertion is: every status equal, >= 97 % of the iteration counts within one check interval of the compiled oracle,
+    the rest within a factor of two, objective 1e-4 on every problem.  The per-problem 1e-7 pin of the batch path at full size is the tight-CG test above
+    (all 1024 trajectories against the committed fixture); this test adds the default schedule's statuses / counts / objectives on top of it."""
     probs = [cj.problems.socp(seed=1000 + k) for k in range(1024)]
     st = cj.Settings()
     mods = _models(probs, st)
