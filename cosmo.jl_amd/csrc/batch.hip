@@ -1540,6 +1540,16 @@ __global__ __launch_bounds__(COSMO_BS) void k_batch_inf_check(BatchDev D, real e
   }
 }
 
+// what the host loop of an accelerated batch needs after every launch: 16 bytes per problem instead of the whole BCtl (600 B) + BAa (2.2 KB) arrays
+struct BState { long long iter; int status; int need_inf; };
+__global__ void k_batch_pack_state(BatchDev D, BState* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= D.nprob) return;
+  BState st;
+  st.iter = D.ctl[k].iter; st.status = D.ctl[k].status; st.need_inf = D.aa ? D.aa[k].need_inf : 0;
+  out[k] = st;
+}
+
 // warm start (solver.jl:128-129) for all problems
 __global__ __launch_bounds__(COSMO_BS) void k_batch_set_w(BatchDev D, const real* __restrict__ x0, const real* __restrict__ s0,
                                                           const real* __restrict__ mu0) {
@@ -1578,6 +1588,7 @@ struct cosmo_hip_batch {
   unsigned char* d_img = nullptr; long long img_stride = 0; int lds_bytes = 0; int lds_bs = 0;
   int reg_mode = 0;    // 0: LdsOps kernel, 1: register-resident <512,1,2>, 2: <512,2,4>
   bool force_ext = false;
+  void* d_state = nullptr; void* h_state = nullptr;     // accelerated host loop: {iter, status, need_inf} per problem (k_batch_pack_state)
   bool aa_on = false; cosmo_hip_accel_params aa_prm;      // cosmo_hip_batch_set_accelerator
   std::vector<int> h_permA, h_permT;          // compute assignment of the register kernel (build_lds_images), uploaded by set_params
   std::vector<int> h_posN, h_posM;            // positions of the gathered LDS vectors (build_lds_images)
@@ -1633,6 +1644,7 @@ extern "C" int32_t cosmo_hip_batch_destroy(cosmo_hip_batch* b) {
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   for (void* p : b->allocs) (void)hipFree(p);
+  if (b->h_state) (void)hipHostFree(b->h_state);
   if (b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
   return COSMO_HIP_OK;
@@ -2268,6 +2280,13 @@ extern "C" int32_t cosmo_hip_batch_optimize(cosmo_hip_batch* b, cosmo_hip_result
     // iteration after a flagged one -- different per problem).  A workgroup leaves its launch at that iteration (BAa::need_inf); the host runs
     // k_batch_inf_check on the flagged problems and relaunches towards the same target until every undecided problem has reached it.
     acc.resize((size_t)b->nprob);
+    // per launch the host only needs {status, iter} of every problem: a 16-byte record per problem through a pinned buffer (the full BCtl + BAa
+    // arrays, 2.8 KB per problem, were copied after EVERY relaunch); the full state is fetched once, after the loop
+    if (!b->d_state) {
+      BState* ds = nullptr; BHIP(b, hipMalloc((void**)&ds, sizeof(BState) * (size_t)b->nprob)); b->allocs.push_back(ds); b->d_state = ds;
+      BHIP(b, hipHostMalloc((void**)&b->h_state, sizeof(BState) * (size_t)b->nprob, hipHostMallocDefault));
+    }
+    const BState* hs = (const BState*)b->h_state;
     for (;;) {
       target = std::min<long long>(target + slice, b->prm.max_iter);
       bool all = true, timed_out = false;
@@ -2276,17 +2295,22 @@ extern "C" int32_t cosmo_hip_batch_optimize(cosmo_hip_batch* b, cosmo_hip_result
         first = 0;
         if (P.check_inf > 0)
           hipLaunchKernelGGL(k_batch_inf_check, dim3(b->nprob), dim3(COSMO_BS), 0, b->stream, b->D, (real)b->prm.eps_prim_inf, (real)b->prm.eps_dual_inf, 1);
-        BHIP(b, hipMemcpyAsync(c.data(), b->D.ctl, sizeof(BCtl) * b->nprob, hipMemcpyDeviceToHost, b->stream));
-        BHIP(b, hipMemcpyAsync(acc.data(), b->D.aa, sizeof(BAa) * b->nprob, hipMemcpyDeviceToHost, b->stream));
+        hipLaunchKernelGGL(k_batch_pack_state, dim3((b->nprob + 255) / 256), dim3(256), 0, b->stream, b->D, (BState*)b->d_state);
+        BHIP(b, hipMemcpyAsync(b->h_state, b->d_state, sizeof(BState) * (size_t)b->nprob, hipMemcpyDeviceToHost, b->stream));
         BHIP(b, hipStreamSynchronize(b->stream));
         all = true;
         bool behind = false;
-        for (int k = 0; k < b->nprob; ++k) if (c[k].status == 0) { all = false; if (c[k].iter < target) behind = true; }
+        for (int k = 0; k < b->nprob; ++k) if (hs[k].status == 0) { all = false; if (hs[k].iter < target) behind = true; }
         if (b->prm.time_limit != 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > b->prm.time_limit) { timed_out = !all; break; }
         if (!behind) break;
       }
-      if (timed_out) { for (auto& x : c) if (x.status == 0) x.status = COSMO_HIP_TIME_LIMIT_REACHED; break; }
-      if (all || target >= b->prm.max_iter) break;
+      if (timed_out || all || target >= b->prm.max_iter) {
+        BHIP(b, hipMemcpyAsync(c.data(), b->D.ctl, sizeof(BCtl) * b->nprob, hipMemcpyDeviceToHost, b->stream));
+        BHIP(b, hipMemcpyAsync(acc.data(), b->D.aa, sizeof(BAa) * b->nprob, hipMemcpyDeviceToHost, b->stream));
+        BHIP(b, hipStreamSynchronize(b->stream));
+        if (timed_out) for (auto& x : c) if (x.status == 0) x.status = COSMO_HIP_TIME_LIMIT_REACHED;
+        break;
+      }
     }
   } else
   for (;;) {

@@ -85,9 +85,12 @@ def test_abi_error_paths():
         h.set_cones([12], [3], None, None)                        # unknown cone type: outside the hot path
     assert e.value.code == 6
     h.set_cones([F.NONNEG], [3], None, None)
-    p = h.default_params(); p.adaptive_rho_interval = 0
+    p = h.default_params(); p.adaptive_rho_interval = 0; p.adaptive_rho_fraction = -1.0
     with pytest.raises(cj.CosmoHipError) as e:
-        h.set_params(p)                                           # wall-clock rho rule unsupported
-    assert e.value.code == 6
+        h.set_params(p)                                           # the automatic rho interval (solver.jl:244-256) is honoured since round 5 -- with sane arguments
+    assert e.value.code == 1
+    p.adaptive_rho_fraction = 0.4
+    h.set_params(p)                                               # (tests/test_gpu_auto_rho_interval.py has the behaviour)
+    h.set_params(h.default_params())
     with pytest.raises(cj.CosmoHipError):
         h.optimize()                                              # set_iterates missing
