@@ -75,6 +75,7 @@ struct BatchDev {
   // rows of a wave-step have similar lengths.  Null: every thread computes the rows it owns.
   const int *permA, *permT;
   const int *posN, *posM;       // nprob * n, nprob * m: position of an entry in the gathered LDS vectors (null: its index)
+  const int* qposA;             // nprob * m: position of row i of A in the image's storage order (non-null iff the image is stored in sorted order)
   int regcg;                    // LDS-image kernel with the extended cones (512 threads): Krylov vectors in registers (n <= 1024, m <= 2048; batch_admm_body)
 };
 
@@ -222,6 +223,72 @@ struct StreamOps {
   }
 };
 
+// ---- hand-scheduled row loops of the register kernel's Krylov passes (round 5) --------------------------------------------------------------
+// A row product needs per nonzero t:  P(t) an index load (u16 column position of A, or the packed u32 pair of A'), G(t) two b64 loads whose
+// addresses come out of that index (value + gathered operand), M(t) multiply-add.  Written in C++ the compiler's scheduler moves the loads of
+// trip t + 1 BEHIND the multiply of trip t to save registers, so every trip exposes an LDS round trip (index -> wait -> loads -> wait -> multiply: the
+// ISA of both software-pipelined forms tried before).  Here the LDS reads and their waits are inline asm, which keeps program order:
+//     trip k:   issue P(k+2)  |  s_waitcnt lgkmcnt(1): G(k) and P(k+1) have arrived (they were issued a full trip ago)  |  issue G(k+1)  |  M(k)
+// ping-pong registers, two trips per loop body (a register rotation would have to wait for the loads in flight).  Same products, added in the
+// same order by the same v_mul_f64 / v_add_f64 (the arithmetic stays C++): bit-identical to the plain loops.  Past the row's end the index
+// pointer is clamped to the last nonzero: surplus loads read valid data that is never used.
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) { return (uint32_t)(uintptr_t)p; }     // low half of a flat address into LDS = its LDS byte offset
+__device__ __forceinline__ void lds_read64(real& d, uint32_t addr) {
+#if REAL_IS_FLOAT
+  asm volatile("ds_read_b32 %0, %1" : "=v"(d) : "v"(addr));
+#else
+  asm volatile("ds_read_b64 %0, %1" : "=v"(d) : "v"(addr));
+#endif
+}
+__device__ __forceinline__ void lds_read_u32(uint32_t& d, uint32_t addr) { asm volatile("ds_read_b32 %0, %1" : "=v"(d) : "v"(addr)); }
+__device__ __forceinline__ void lds_read_u16(uint32_t& d, uint32_t addr) { asm volatile("ds_read_u16 %0, %1" : "=v"(d) : "v"(addr)); }
+// wait until at most ONE LDS operation is outstanding; the operands tie the registers whose loads have arrived to this point of the program
+__device__ __forceinline__ void lds_wait1(uint32_t& i, real& a, real& g) { asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(i), "+v"(a), "+v"(g)); }
+__device__ __forceinline__ void lds_wait1(uint32_t& i) { asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(i)); }
+__device__ __forceinline__ void lds_wait0(real& a, real& g) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(g)); }
+#define RSH (REAL_IS_FLOAT ? 2 : 3)
+// PAIR = true : A' row -- index array of packed u32 (value position | gather position << 16) at idx (byte address of the row's first entry)
+// PAIR = false: A / P row -- index array of u16 gather positions at idx, the value of nonzero t sits at val + sizeof(real) * t (val = address of the row's first value)
+template <bool PAIR>
+__device__ __forceinline__ real row_pipe3(uint32_t idx, uint32_t val, const uint32_t gat, const int len) {
+  if (len <= 0) return R(0.0);
+  constexpr uint32_t ISZ = PAIR ? 4u : 2u;
+  const uint32_t last = idx + ISZ * (uint32_t)(len - 1);
+  real s = 0.0;
+  uint32_t iA = 0, iB = 0;
+  real aA = 0.0, gA = 0.0, aB = 0.0, gB = 0.0;
+  auto load_idx = [&](uint32_t& d) { if (PAIR) lds_read_u32(d, idx); else lds_read_u16(d, idx); idx = (idx + ISZ < last) ? idx + ISZ : last; };
+  auto load_ag = [&](real& a, real& g, uint32_t i, uint32_t vaddr) {
+    if (PAIR) { lds_read64(a, val + ((i & 0xffffu) << RSH)); lds_read64(g, gat + ((i >> 16) << RSH)); }
+    else { lds_read64(a, vaddr); lds_read64(g, gat + (i << RSH)); }
+  };
+  const uint32_t vlast = val + ((uint32_t)(len - 1) << RSH);
+  uint32_t v1 = (len > 1) ? val + (1u << RSH) : vlast;           // value address of nonzero k + 1 (PAIR = false)
+  load_idx(iA);                                                   // P(0)
+  load_idx(iB);                                                   // P(1)
+  lds_wait1(iA);
+  load_ag(aA, gA, iA, val);                                       // G(0)
+  int k = 0;
+  for (;;) {
+    load_idx(iA);                                                 // P(k+2)
+    lds_wait1(iB, aA, gA);                                        // G(k), P(k+1) arrived
+    load_ag(aB, gB, iB, v1);                                      // G(k+1)
+    asm volatile("" : "+v"(aA), "+v"(gA));                       // (the product below is not scheduled in front of the loads above)
+    v1 = (v1 + (1u << RSH) < vlast) ? v1 + (1u << RSH) : vlast;
+    s += aA * gA;                                                 // M(k)
+    if (++k >= len) break;
+    load_idx(iB);                                                 // P(k+2)
+    lds_wait1(iA, aB, gB);
+    load_ag(aA, gA, iA, v1);
+    asm volatile("" : "+v"(aB), "+v"(gB));
+    v1 = (v1 + (1u << RSH) < vlast) ? v1 + (1u << RSH) : vlast;
+    s += aB * gB;
+    if (++k >= len) break;
+  }
+  lds_wait0(aA, gA);                                              // drain: nothing of this loop stays in flight behind it
+  return s;
+}
+
 // header of a problem's LDS image (built by build_lds_images): byte offsets from the start of the image
 // oTpr: one u32 per nonzero of A' = (position into A's values) | (row, or its position in the gathered vector) << 16 -- ONE LDS read per nonzero instead
 // of two u16 reads (round 5: the A' loop of the column pass issues 3 LDS instructions per nonzero instead of 4)
@@ -238,8 +305,9 @@ struct LdsOps {
   unsigned char* psd_ws;
   int n;
   static constexpr bool in_lds = true;
-  // whole rows, left to right, software-pipelined by one nonzero like the register kernel's row loops (the index / value loads of nonzero t + 1 go
-  // out with the gather of nonzero t): the row functions of the register-CG form of the Krylov loop below (batch_admm_body, RCG)
+  // whole rows, left to right, software-pipelined by one nonzero (the index / value loads of nonzero t + 1 go out with the gather of nonzero t): the
+  // row functions of the register-CG form of the Krylov loop below (batch_admm_body, RCG).  (The hand-scheduled row_pipe3 was measured here too:
+  // 262 vs 255 us per batch iteration, 443 vs 408 accelerated -- two short rows per thread do not amortise its prologue and drain; not used.)
   __device__ __forceinline__ real rowA(int r, const real* x) const {
     real s1 = 0.0;
     int t = Arp[r]; const int b2 = Arp[r + 1];
@@ -968,12 +1036,36 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   // that a trip costs ONE dependent LDS round trip instead of two (index -> gather).  Same left-to-right sums: bit-identical to the plain loops
   // `for (t = a; t < b; ++t) s1 += Aval[t] * xv[Acol[t]]` (iterate hashes equal on all 1024 problems of config 3), 4100 -> 4367 batch-it/s
   // (7.35 -> 6.95 us per Krylov iteration of the slowest problem; profiles/r04_batch_pipe_lab.txt).
+  // Two-stage software pipeline (round 5): the gathered operand of nonzero t is REQUESTED one trip before it is multiplied -- trip t issues the
+  // gather of t + 1 (its index arrived a trip ago) and the index / value loads of t + 2, then consumes the gather of t.  With the one-stage form
+  // (index -> gather in consecutive trips, gather -> product inside a trip) every trip exposed one LDS round trip: the ISA of the loop was
+  // gather, wait, multiply.  Same products added in the same order; the last trips re-load the row's last element instead of branching (clamped
+  // index, value unused).  COSMO_BATCH_PIPE2=0 at compile time restores the one-stage loops.
+#ifndef COSMO_BATCH_PIPE2
+#define COSMO_BATCH_PIPE2 1
+#endif
   auto rowA_b = [&](int t, const int b2) -> real {
     real s1 = 0.0;
     if (t < b2) {
+#if COSMO_BATCH_PIPE2
+      const int last = b2 - 1;
+      real v = Aval[t]; int c = Acol[t];
+      int t1 = (t + 1 < b2) ? t + 1 : last;
+      real vn = Aval[t1]; int cn = Acol[t1];
+      real g = xv[c];
+      for (++t; t < b2; ++t) {
+        const real gn = xv[cn];                                    // gather of nonzero t (address known since the last trip)
+        const int t2 = (t + 1 < b2) ? t + 1 : last;
+        const real v2 = Aval[t2]; const int c2 = Acol[t2];         // loads of nonzero t + 1
+        s1 += v * g;                                               // nonzero t - 1: its gather was requested a trip ago
+        v = vn; g = gn; vn = v2; cn = c2;
+      }
+      s1 += v * g;
+#else
       real v = Aval[t]; int c = Acol[t];
       for (++t; t < b2; ++t) { const real vn = Aval[t]; const int cn = Acol[t]; s1 += v * xv[c]; v = vn; c = cn; }
       s1 += v * xv[c];
+#endif
     }
     return s1 + R(0.0);
   };
@@ -990,9 +1082,23 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   auto rowAT_b = [&](int t, const int b2) -> real {
     real s1 = 0.0;
     if (t < b2) {
+#if COSMO_BATCH_PIPE2
+      const int last = b2 - 1;
+      uint32_t pr = Tpr[t];
+      uint32_t prn = Tpr[(t + 1 < b2) ? t + 1 : last];
+      real a = Aval[pr & 0xffffu], g = tv[pr >> 16];
+      for (++t; t < b2; ++t) {
+        const real an = Aval[prn & 0xffffu], gn = tv[prn >> 16];   // value and gathered operand of nonzero t
+        const uint32_t pr2 = Tpr[(t + 1 < b2) ? t + 1 : last];     // packed pair of nonzero t + 1
+        s1 += a * g;                                               // nonzero t - 1
+        a = an; g = gn; prn = pr2;
+      }
+      s1 += a * g;
+#else
       uint32_t pr = Tpr[t];
       for (++t; t < b2; ++t) { const uint32_t prn = Tpr[t]; s1 += Aval[pr & 0xffffu] * tv[pr >> 16]; pr = prn; }
       s1 += Aval[pr & 0xffffu] * tv[pr >> 16];
+#endif
     }
     return s1;
   };
@@ -1029,12 +1135,36 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   // starts with its first value / index loads instead of a dependent row-pointer round trip (8 LDS reads and 4 dependent round trips less per thread
   // and Krylov iteration).  The <512, 2, 4> instantiation has no registers to spare and keeps reading them.
   int ka0[SORTED ? JM : 1], ka1[SORTED ? JM : 1], kp0[SORTED ? JN : 1], kp1[SORTED ? JN : 1], kt0[SORTED ? JN : 1], kt1[SORTED ? JN : 1];
+  const bool stored_sorted = SORTED && D.qposA != nullptr;
+  // hand-scheduled row loops of the Krylov passes (row_pipe3 above); -DCOSMO_BATCH_HANDPIPE=0 keeps the compiled loops (lab builds)
+#ifndef COSMO_BATCH_HANDPIPE
+#define COSMO_BATCH_HANDPIPE 1
+#endif
+  constexpr bool HANDPIPE = SORTED && (COSMO_BATCH_HANDPIPE != 0);
+  const uint32_t lA_val = lds_addr_of(Aval), lA_col = lds_addr_of(Acol), lT_pr = lds_addr_of(Tpr), l_xv = lds_addr_of(xv), l_tv = lds_addr_of(tv);
   if constexpr (SORTED) {
 #pragma unroll
-    for (int j = 0; j < JM; ++j) { const int r = ra[j]; ka0[j] = r >= 0 ? Arp[r] : 0; ka1[j] = r >= 0 ? Arp[r + 1] : 0; }
+    for (int j = 0; j < JM; ++j) {
+      const int r = ra[j];
+      const int q = stored_sorted ? (BS * j + ((j & 1) ? (BS - 1 - tid) : tid)) : r;       // build_lds_images: slot j of thread t holds sorted position 512 j + (t | 511 - t)
+      ka0[j] = r >= 0 ? Arp[q] : 0; ka1[j] = r >= 0 ? Arp[q + 1] : 0;
+    }
 #pragma unroll
-    for (int j = 0; j < JN; ++j) { const int c = OWN(j); kp0[j] = c >= 0 ? Prp[c] : 0; kp1[j] = c >= 0 ? Prp[c + 1] : 0; kt0[j] = c >= 0 ? Trp[c] : 0; kt1[j] = c >= 0 ? Trp[c + 1] : 0; }
+    for (int j = 0; j < JN; ++j) {
+      const int c = OWN(j);
+      const int q = stored_sorted ? (BS * j + tid) : c;                                   // columns: sorted position q sits in slot q / 512 of thread q % 512
+      kp0[j] = c >= 0 ? Prp[q] : 0; kp1[j] = c >= 0 ? Prp[q + 1] : 0; kt0[j] = c >= 0 ? Trp[q] : 0; kt1[j] = c >= 0 ? Trp[q + 1] : 0;
+    }
   }
+  // every row / column product of this kernel goes through these three: the bounds held in registers (sorted instantiation) or the row pointers
+  // (the rows a thread OWNS are used outside the Krylov loop only -- three times per ADMM iteration: their position is read when needed, no registers held)
+  auto rowA_own = [&](int j) -> real {
+    const int i = tid + BS * j;
+    if constexpr (SORTED) { const int qo = stored_sorted ? D.qposA[om + i] : i; return rowA_b(Arp[qo], Arp[qo + 1]); }
+    else return rowA(i);
+  };
+  auto rowAT_own = [&](int j) -> real { if constexpr (SORTED) return rowAT_b(kt0[j], kt1[j]); else return rowAT(OWN(j)); };
+  auto rowP_own = [&](int j) -> real { if constexpr (SORTED) return rowP_b(kp0[j], kp1[j]); else return rowP(OWN(j)); };
 
   // ---- admm_x! + admm_w! (solver.jl:32-65) with the CG reduced solve (kktsolver_indirect.jl:36-88) -------------------
   auto solve_and_update = [&]() {
@@ -1054,12 +1184,12 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
       const int i = OWN(j);
-      if (i >= 0) { const real v = (rowAT(i) + R(0.0)) + lsx[j]; rhsv[j] = v; acc += v * v; }
+      if (i >= 0) { const real v = (rowAT_own(j) + R(0.0)) + lsx[j]; rhsv[j] = v; acc += v * v; }
     }
     const real bb = bsum<BS>(acc, red);                                  // (its barriers also order tv reads before the writes below)
     real tmpv[JM];
 #pragma unroll
-    for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; tmpv[j] = (i < m) ? rowA(i) * rhov[j] : 0.0; }
+    for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; tmpv[j] = (i < m) ? rowA_own(j) * rhov[j] : 0.0; }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; if (i < m) tv[pm[j]] = tmpv[j]; }
@@ -1068,7 +1198,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
       const int i = OWN(j);
-      if (i >= 0) { const real cj = rowP(i) + (P.sigma * xtl[j] + rowAT(i)); const real rj = rhsv[j] - cj; rv[j] = rj; acc += rj * rj; }
+      if (i >= 0) { const real cj = rowP_own(j) + (P.sigma * xtl[j] + rowAT_own(j)); const real rj = rhsv[j] - cj; rv[j] = rj; acc += rj * rj; }
     }
     real rr = bsum<BS>(acc, red);
     const real tol_k = tol_next;
@@ -1095,7 +1225,9 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       if (SORTED) {
       { BT_BEGIN();
 #pragma unroll
-      for (int j = 0; j < JM; ++j) tmpv[j] = (ra[j] >= 0) ? rowA_b(ka0[j], ka1[j]) * rhoc[j] : 0.0;
+      for (int j = 0; j < JM; ++j)
+        tmpv[j] = (ra[j] >= 0) ? (HANDPIPE ? (row_pipe3<false>(lA_col + 2u * (uint32_t)ka0[j], lA_val + ((uint32_t)ka0[j] << RSH), l_xv, ka1[j] - ka0[j]) + R(0.0))
+                                           : rowA_b(ka0[j], ka1[j])) * rhoc[j] : 0.0;
 #pragma unroll
       for (int j = 0; j < JM; ++j) if (ra[j] >= 0) tv[pmc[j]] = tmpv[j];   // tv was last read before the previous barrier pair
       __syncthreads();
@@ -1115,7 +1247,8 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
         if (c >= 0) {
           const real vj = uv[j];
           real cj;
-          if constexpr (SORTED) cj = rowP_b(kp0[j], kp1[j]) + (P.sigma * vj + rowAT_b(kt0[j], kt1[j]));
+          if constexpr (SORTED) cj = rowP_b(kp0[j], kp1[j]) + (P.sigma * vj + (HANDPIPE ? row_pipe3<true>(lT_pr + 4u * (uint32_t)kt0[j], lA_val, l_tv, kt1[j] - kt0[j])
+                                                                                                   : rowAT_b(kt0[j], kt1[j])));
           else cj = rowP(c) + (P.sigma * vj + rowAT(c));
           cv[j] = cj; acc += vj * cj;
         }
@@ -1146,7 +1279,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     for (int j = 0; j < JM; ++j) {
       const int i = tid + BS * j;
       if (i < m) {
-        const real rh = rhov[j]; const real nv = (rowA(i) - lss[j]) * rh;
+        const real rh = rhov[j]; const real nv = (rowA_own(j) - lss[j]) * rh;
         const real st = (R(2.0) * sv[j] - wsv[j]) - nv / rh;
         wsv[j] = wsv[j] + P.alpha * (st - sv[j]);
       }
@@ -1171,7 +1304,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     for (int j = 0; j < JM; ++j) {
       const int i = tid + BS * j;
       if (i < m) {
-        const real ax = rowA(i), s0 = sv[j], b0 = bv[j];
+        const real ax = rowA_own(j), s0 = sv[j], b0 = bv[j];
         muv[j] = rhov[j] * (wps[j] - s0);
         tv[pm[j]] = muv[j];
         real r0 = ax + s0; r0 = r0 - b0;
@@ -1188,7 +1321,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     for (int j = 0; j < JN; ++j) {
       const int i = OWN(j);
       if (i >= 0) {
-        const real px = rowP(i), atm = rowAT(i), x0 = wpx[j], q0 = qv[j];
+        const real px = rowP_own(j), atm = rowAT_own(j), x0 = wpx[j], q0 = qv[j];
         real r0 = px + q0; r0 = r0 - atm;
         real a = px, bq = q0, cm = atm;
         if (unscale) { const real d = D.Dinv[on + i]; r0 = (r0 * d) * cinv; a = (a * d) * cinv; bq = (bq * d) * cinv; cm = (cm * d) * cinv; }
@@ -1203,7 +1336,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   };
 
 #ifdef COSMO_BATCH_TIMING
-  const long long kt0 = clock64();
+  const long long bt_kernel_t0 = clock64();
 #endif
   // ---- admm_z!: w_prev = w ; s = Pi(w_s)  (solver.jl:151-152) ----
   auto admm_z = [&]() {
@@ -1349,7 +1482,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   }
   if constexpr (AA) { if (tid == 0) aa_store(S, M.aa); }
 #ifdef COSMO_BATCH_TIMING
-  if (blockIdx.x == 0 && tid == 0) { g_bt[4] += clock64() - kt0; g_bt[5] += it; }
+  if (blockIdx.x == 0 && tid == 0) { g_bt[4] += clock64() - bt_kernel_t0; g_bt[5] += it; }
 #endif
   // ---- store the persistent state; recover_mu! (solver.jl:167) ----
 #pragma unroll
@@ -1592,6 +1725,7 @@ struct cosmo_hip_batch {
   bool aa_on = false; cosmo_hip_accel_params aa_prm;      // cosmo_hip_batch_set_accelerator
   std::vector<int> h_permA, h_permT;          // compute assignment of the register kernel (build_lds_images), uploaded by set_params
   std::vector<int> h_posN, h_posM;            // positions of the gathered LDS vectors (build_lds_images)
+  std::vector<int> h_qposA;                   // per problem: position of row i of A in the image's (sorted) storage order
 };
 
 static int32_t bfail(cosmo_hip_batch* b, int32_t code, const char* fmt, ...) {
@@ -1895,11 +2029,47 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
         const long long sl = q / 512, t = (sl & 1) ? 511 - q % 512 : q % 512;
         b->h_permA[(size_t)k * JMs * 512 + (size_t)(sl * 512 + t)] = ord[(size_t)q];
       }
+      const std::vector<int> ordA = ord;
       ord.resize((size_t)n);
       for (long long j = 0; j < n; ++j) ord[(size_t)j] = (int)j;
       auto clen = [&](int j) { return (PT.split[j] - PT.rowptr[j]) + (AT.rowptr[j + 1] - AT.rowptr[j]); };
       std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return clen(x) > clen(y); });
       for (long long q = 0; q < n; ++q) b->h_permT[(size_t)k * JNs * 512 + (size_t)q] = ord[(size_t)q];
+      // STORAGE ORDER of the image = the sorted order (round 5): the rows of A, the columns of A' and the rows of P are laid out in the order of the
+      // compute assignment, so that the 64 rows a wave works on in one trip are NEIGHBOURS in the value / index arrays -- lane l reads at (start of
+      // its row) + t with starts about one row length apart: a constant-stride access, which the LDS serves at 4.1 (b64) / 2.2 (u16) cycles per
+      // wave-read against 7.2 for the scattered reads that CSR order gives a length-sorted assignment (bench/lds_conflict_lab.hip).  Arp / Trp / Prp
+      // are indexed by sorted POSITION from here on (the register kernel derives the positions of its rows / columns from the thread index, and
+      // reads the position of the rows it owns from D.qposA); same values, same per-row order: every row sum keeps its bits.
+      if (!(getenv("COSMO_HIP_BATCH_STORE_SORTED") && atoi(getenv("COSMO_HIP_BATCH_STORE_SORTED")) == 0)) {
+        if (b->h_qposA.empty()) b->h_qposA.assign((size_t)b->nprob * m, 0);
+        std::vector<real> nAval((size_t)nnzA); std::vector<unsigned short> nAcol((size_t)nnzA), nArp((size_t)m + 1);
+        std::vector<int> newstart((size_t)m);
+        long long w = 0;
+        for (long long q = 0; q < m; ++q) {
+          const int r = ordA[(size_t)q];
+          nArp[(size_t)q] = (unsigned short)w; newstart[(size_t)r] = (int)w;
+          b->h_qposA[(size_t)k * m + (size_t)r] = (int)q;
+          for (int t = A.rowptr[r]; t < A.rowptr[r + 1]; ++t) { nAval[(size_t)w] = Aval[t]; nAcol[(size_t)w] = Acol[t]; ++w; }
+        }
+        nArp[(size_t)m] = (unsigned short)w;
+        std::vector<uint32_t> nTpr((size_t)nnzA); std::vector<unsigned short> nTrp((size_t)n + 1), nPrp((size_t)n + 1), nPcol((size_t)nnzP);
+        std::vector<real> nPval((size_t)nnzP);
+        long long wt = 0, wp = 0;
+        for (long long q = 0; q < n; ++q) {
+          const int c = ord[(size_t)q];
+          nTrp[(size_t)q] = (unsigned short)wt; nPrp[(size_t)q] = (unsigned short)wp;
+          for (int t = Trp[c]; t < Trp[c + 1]; ++t) {
+            const uint32_t pr = Tpr[t]; const int row = (int)(pr >> 16), pold = (int)(pr & 0xffffu);
+            nTpr[(size_t)wt++] = (uint32_t)(newstart[(size_t)row] + (pold - A.rowptr[row])) | ((uint32_t)row << 16);
+          }
+          for (int t = Prp[c]; t < Prp[c + 1]; ++t) { nPval[(size_t)wp] = Pval[t]; nPcol[(size_t)wp] = Pcol[t]; ++wp; }
+        }
+        nTrp[(size_t)n] = (unsigned short)wt; nPrp[(size_t)n] = (unsigned short)wp;
+        std::copy(nAval.begin(), nAval.end(), Aval); std::copy(nAcol.begin(), nAcol.end(), Acol); std::copy(nArp.begin(), nArp.end(), Arp);
+        std::copy(nTpr.begin(), nTpr.end(), Tpr); std::copy(nTrp.begin(), nTrp.end(), Trp); std::copy(nPrp.begin(), nPrp.end(), Prp);
+        std::copy(nPval.begin(), nPval.end(), Pval); std::copy(nPcol.begin(), nPcol.end(), Pcol);
+      }
       // Positions of the gathered vectors.  A ds_read_b64 is served 32 lanes at a time and an 8-byte slot p lies in bank pair p mod 32:
       // the 32 rows a half-wave works on in one step gather 32 entries, and every extra entry on a busy bank pair costs an LDS cycle
       // (random indices: ~3.4 per group).  Greedy assignment: entries by decreasing number of appearances, each to the bank pair that
@@ -2053,11 +2223,12 @@ extern "C" int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hi
   BatchDev& D = b->D;
   D.nprob = nprob; D.n = (int)n; D.m = (int)m;
   int32_t rc;
-  D.permA = nullptr; D.permT = nullptr; D.posN = nullptr; D.posM = nullptr;
+  D.permA = nullptr; D.permT = nullptr; D.posN = nullptr; D.posM = nullptr; D.qposA = nullptr;
   if ((rc = build_lds_images(b))) return rc;               // needs the host CSR copies that bmat_upload releases
   if (b->d_img && b->reg_mode == 1 && !b->h_permA.empty()) {        // (no image: the streaming kernel runs and needs none of this)
     if ((rc = bup(b, &D.permA, b->h_permA))) return rc;
     if ((rc = bup(b, &D.permT, b->h_permT))) return rc;
+    if (!b->h_qposA.empty()) { if ((rc = bup(b, &D.qposA, b->h_qposA))) return rc; }
     if (!b->h_posN.empty()) {
       if ((rc = bup(b, &D.posN, b->h_posN))) return rc;
       if ((rc = bup(b, &D.posM, b->h_posM))) return rc;
