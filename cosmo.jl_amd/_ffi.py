@@ -145,7 +145,7 @@ SIGNATURES = {
     "cosmo_hip_batch_group_set_scaling": (C.c_int32, [C.c_void_p, C.c_int64, _PR, _PR, C.c_double]),
     "cosmo_hip_batch_group_set_accelerator": (C.c_int32, [C.c_void_p, C.POINTER(AccelParams)]),
     "cosmo_hip_batch_group_set_params": (C.c_int32, [C.c_void_p, C.POINTER(Params)]),
-    "cosmo_hip_batch_group_class_info": (C.c_int32, [C.c_void_p, _PI64, _PI64]),
+    "cosmo_hip_batch_group_class_info": (C.c_int32, [C.c_void_p, _PI64, _PI64, _PI64]),
     "cosmo_hip_batch_group_set_iterates": (C.c_int32, [C.c_void_p, C.c_int64, _PR, _PR, _PR]),
     "cosmo_hip_batch_group_optimize": (C.c_int32, [C.c_void_p, C.POINTER(ResultStruct)]),
     "cosmo_hip_batch_group_get_iterates": (C.c_int32, [C.c_void_p, C.c_int64, _PR, _PR, _PR, _PR]),
@@ -718,12 +718,12 @@ class BatchGroup:
     def set_params(self, params):
         self._chk(self.lib.cosmo_hip_batch_group_set_params(self._g, C.byref(params)))
 
-    def class_info(self):
-        """(number of structure classes, class index of every problem)"""
+    def class_info(self, with_modes=False):
+        """(number of structure classes, class index of every problem[, mode of every problem: 0 persistent batch kernel, 1 its own handle])"""
         nc = C.c_int64(0)
-        cls = np.zeros(self.nprob, dtype=np.int64)
-        self._chk(self.lib.cosmo_hip_batch_group_class_info(self._g, C.byref(nc), cls.ctypes.data_as(_PI64)))
-        return int(nc.value), cls
+        cls = np.zeros(self.nprob, dtype=np.int64); mode = np.zeros(self.nprob, dtype=np.int64)
+        self._chk(self.lib.cosmo_hip_batch_group_class_info(self._g, C.byref(nc), cls.ctypes.data_as(_PI64), mode.ctypes.data_as(_PI64)))
+        return (int(nc.value), cls, mode) if with_modes else (int(nc.value), cls)
 
     def set_iterates(self, k, x0=None, s0=None, mu0=None):
         n, m = self.dims[int(k)]

@@ -8,6 +8,10 @@
 // drives all classes CONCURRENTLY, one host thread per class (the per-class host loop of cosmo_hip_batch_optimize -- persistent launch, certificate
 // kernels, status copy -- synchronises only its own stream), so that the workgroups of all classes share the chip like those of one batch do.  A class
 // may hold a single problem (one persistent workgroup).  Results, iterates and counters are addressed by the caller's problem index.
+// A class whose structure the batch kernels REFUSE (cosmo_hip_batch_* returns COSMO_HIP_ERR_UNSUPPORTED: a PSD cone of side > 64, a KKT solver kind other
+// than the CG kinds, the automatic rho interval) is not an error of the group: its members are solved through one single-problem handle each
+// (cosmo_hip_create ... cosmo_hip_optimize: the device-resident loop of api.hip with the batched matrix-sign projections), concurrently with the batch
+// classes -- so a group accepts every problem the library can solve at all, as the reference's loop over models does.
 //
 // Host-side orchestration only: no kernel lives here.  Replaces: the reference's loop over models, src/solver.jl:78-203 per model.
 #include <string.h>
@@ -30,7 +34,9 @@ struct GProblem {
 };
 
 struct GClass {
-  cosmo_hip_batch* b = nullptr;
+  cosmo_hip_batch* b = nullptr;    // the class's persistent-kernel batch ...
+  std::vector<cosmo_hip_handle*> hs;   // ... or, for a structure the batch kernels do not take (a PSD cone of side > 64, a MINRES solver kind), one
+                                       // single-problem handle per member (the per-problem path of api.hip: the batched matrix-sign projections etc.)
   std::vector<int> members;       // problem indices, ascending
   long long n = 0, m = 0, nbox = 0;
   bool iterates_dirty = true;
@@ -68,7 +74,7 @@ extern "C" int32_t cosmo_hip_batch_group_create(cosmo_hip_batch_group** out, int
 
 extern "C" int32_t cosmo_hip_batch_group_destroy(cosmo_hip_batch_group* g) {
   if (!g) return COSMO_HIP_OK;
-  for (auto& c : g->cls) if (c.b) (void)cosmo_hip_batch_destroy(c.b);
+  for (auto& c : g->cls) { if (c.b) (void)cosmo_hip_batch_destroy(c.b); for (auto* h : c.hs) if (h) (void)cosmo_hip_destroy(h); }
   delete g;
   return COSMO_HIP_OK;
 }
@@ -176,10 +182,33 @@ extern "C" int32_t cosmo_hip_batch_group_set_params(cosmo_hip_batch_group* g, co
       if (p.have_scaling) { rc = cosmo_hip_batch_set_scaling(C.b, (int64_t)j, p.Dinv.data(), p.Einv.data(), p.cinv); if (rc) return bad(rc, "batch_set_scaling"); }
     }
     rc = cosmo_hip_batch_set_cones_ex(C.b, (int64_t)p0.ctype.size(), p0.ctype.data(), p0.cdim.data(), bl.data(), bu.data(), p0.cparam.data());
-    if (rc) return bad(rc, "batch_set_cones");
-    if (g->aa_on) { rc = cosmo_hip_batch_set_accelerator(C.b, &g->aa); if (rc) return bad(rc, "batch_set_accelerator"); }
-    rc = cosmo_hip_batch_set_params(C.b, prm);
-    if (rc) return bad(rc, "batch_set_params");
+    if (rc == COSMO_HIP_OK && g->aa_on) rc = cosmo_hip_batch_set_accelerator(C.b, &g->aa);
+    if (rc == COSMO_HIP_OK) rc = cosmo_hip_batch_set_params(C.b, prm);
+    if (rc == COSMO_HIP_ERR_UNSUPPORTED) {
+      // not a structure of the persistent kernels: one single-problem handle per member instead
+      const std::string why = cosmo_hip_batch_last_error(C.b);
+      (void)cosmo_hip_batch_destroy(C.b); C.b = nullptr;
+      auto hbad = [&](int32_t code, cosmo_hip_handle* h, const char* what, int k) {
+        const std::string detail = h ? cosmo_hip_last_error(h) : "";
+        return gfail(g, code, std::string(what) + " failed for problem " + std::to_string(k) + " (solved through its own handle because the batch kernels refuse its structure: " + why + "): " + detail);
+      };
+      for (size_t j = 0; j < C.members.size(); ++j) {
+        const int k = C.members[j];
+        const GProblem& p = g->prob[(size_t)k];
+        cosmo_hip_handle* h = nullptr;
+        int32_t hr = cosmo_hip_create(&h, g->device);
+        if (hr) return hbad(hr, nullptr, "cosmo_hip_create", k);
+        C.hs.push_back(h);
+        if ((hr = cosmo_hip_set_problem(h, p.n, p.m, p.Pp.data(), p.Pi.data(), p.Px.data(), p.Ap.data(), p.Ai.data(), p.Ax.data(), p.q.data(), p.b.data()))) return hbad(hr, h, "set_problem", k);
+        if ((hr = cosmo_hip_set_cones_ex(h, (int64_t)p.ctype.size(), p.ctype.data(), p.cdim.data(), p.box_l.empty() ? nullptr : p.box_l.data(),
+                                         p.box_u.empty() ? nullptr : p.box_u.data(), p.cparam.data()))) return hbad(hr, h, "set_cones", k);
+        if (g->aa_on && (hr = cosmo_hip_set_accelerator(h, &g->aa))) return hbad(hr, h, "set_accelerator", k);
+        if ((hr = cosmo_hip_set_params(h, prm, nullptr))) return hbad(hr, h, "set_params", k);
+        if (p.have_scaling && (hr = cosmo_hip_set_scaling(h, p.Dinv.data(), p.Einv.data(), p.cinv))) return hbad(hr, h, "set_scaling", k);
+      }
+      continue;
+    }
+    if (rc) return bad(rc, "batch set-up");
   }
   for (auto& p : g->prob) {            // the staged matrices are on the device now
     std::vector<int64_t>().swap(p.Pp); std::vector<int64_t>().swap(p.Pi); std::vector<int64_t>().swap(p.Ap); std::vector<int64_t>().swap(p.Ai);
@@ -190,10 +219,11 @@ extern "C" int32_t cosmo_hip_batch_group_set_params(cosmo_hip_batch_group* g, co
 }
 
 // out_nclasses: number of structure classes; class_of[k] (nprob entries, may be NULL): class of problem k
-extern "C" int32_t cosmo_hip_batch_group_class_info(cosmo_hip_batch_group* g, int64_t* out_nclasses, int64_t* class_of) {
+extern "C" int32_t cosmo_hip_batch_group_class_info(cosmo_hip_batch_group* g, int64_t* out_nclasses, int64_t* class_of, int64_t* mode_of) {
   if (!g || !g->finalized) return gfail(g, COSMO_HIP_ERR_INVALID, "batch_group_class_info: set_params first");
   if (out_nclasses) *out_nclasses = (int64_t)g->cls.size();
   if (class_of) for (size_t k = 0; k < g->prob.size(); ++k) class_of[k] = g->prob[k].cls;
+  if (mode_of) for (size_t k = 0; k < g->prob.size(); ++k) mode_of[k] = g->cls[(size_t)g->prob[k].cls].b ? 0 : 1;     // 0: persistent batch kernel, 1: its own handle
   return COSMO_HIP_OK;
 }
 
@@ -213,6 +243,15 @@ extern "C" int32_t cosmo_hip_batch_group_set_iterates(cosmo_hip_batch_group* g, 
 static int32_t flush_iterates(cosmo_hip_batch_group* g, GClass& C) {
   if (!C.iterates_dirty) return COSMO_HIP_OK;
   const size_t np = C.members.size();
+  if (!C.b) {
+    for (size_t j = 0; j < np; ++j) {
+      const GProblem& p = g->prob[(size_t)C.members[j]];
+      const int32_t rc = cosmo_hip_set_iterates(C.hs[j], p.have_x0 ? p.x0.data() : nullptr, p.have_s0 ? p.s0.data() : nullptr, p.have_mu0 ? p.mu0.data() : nullptr);
+      if (rc) return gfail(g, rc, std::string("set_iterates of problem ") + std::to_string(C.members[j]) + ": " + cosmo_hip_last_error(C.hs[j]));
+    }
+    C.iterates_dirty = false;
+    return COSMO_HIP_OK;
+  }
   std::vector<real> x((size_t)C.n * np, R(0.0)), s((size_t)C.m * np, R(0.0)), mu((size_t)C.m * np, R(0.0));
   for (size_t j = 0; j < np; ++j) {
     const GProblem& p = g->prob[(size_t)C.members[j]];
@@ -236,7 +275,8 @@ extern "C" int32_t cosmo_hip_batch_group_optimize(cosmo_hip_batch_group* g, cosm
   auto run = [&](size_t ci) {
     GClass& C = g->cls[ci];
     res[ci].resize(C.members.size());
-    rcs[ci] = cosmo_hip_batch_optimize(C.b, res[ci].data());       // (sets the device for its thread; synchronises its own stream only)
+    if (C.b) { rcs[ci] = cosmo_hip_batch_optimize(C.b, res[ci].data()); return; }     // (sets the device for its thread; synchronises its own stream only)
+    for (size_t j = 0; j < C.members.size() && rcs[ci] == COSMO_HIP_OK; ++j) rcs[ci] = cosmo_hip_optimize(C.hs[j], &res[ci][j]);   // its members one after the other, each on its handle's stream
   };
   if (nc == 1) run(0);
   else {
@@ -245,7 +285,11 @@ extern "C" int32_t cosmo_hip_batch_group_optimize(cosmo_hip_batch_group* g, cosm
     for (auto& t : th) t.join();
   }
   for (size_t ci = 0; ci < nc; ++ci) {
-    if (rcs[ci]) return gfail(g, rcs[ci], std::string("batch_optimize of the class of problem ") + std::to_string(g->cls[ci].members[0]) + ": " + cosmo_hip_batch_last_error(g->cls[ci].b));
+    if (rcs[ci]) {
+      std::string detail = g->cls[ci].b ? cosmo_hip_batch_last_error(g->cls[ci].b) : "";
+      if (!g->cls[ci].b) for (auto* h : g->cls[ci].hs) { const char* e = cosmo_hip_last_error(h); if (e && *e) { detail = e; break; } }
+      return gfail(g, rcs[ci], std::string("optimize of the class of problem ") + std::to_string(g->cls[ci].members[0]) + ": " + detail);
+    }
     for (size_t j = 0; j < g->cls[ci].members.size(); ++j) results[g->cls[ci].members[j]] = res[ci][j];
     g->cls[ci].iterates_dirty = false;
   }
@@ -256,8 +300,10 @@ extern "C" int32_t cosmo_hip_batch_group_get_iterates(cosmo_hip_batch_group* g, 
   GCHECK(g, k);
   if (!g->finalized) return gfail(g, COSMO_HIP_ERR_INVALID, "batch_group_get_iterates: set_params first");
   const GProblem& p = g->prob[(size_t)k];
-  const int32_t rc = cosmo_hip_batch_get_iterates(g->cls[(size_t)p.cls].b, p.pos, w, w_prev, s, mu);
-  if (rc) return gfail(g, rc, cosmo_hip_batch_last_error(g->cls[(size_t)p.cls].b));
+  GClass& C = g->cls[(size_t)p.cls];
+  if (!C.b) { const int32_t rc = cosmo_hip_get_iterates(C.hs[(size_t)p.pos], w, w_prev, s, mu); return rc ? gfail(g, rc, cosmo_hip_last_error(C.hs[(size_t)p.pos])) : COSMO_HIP_OK; }
+  const int32_t rc = cosmo_hip_batch_get_iterates(C.b, p.pos, w, w_prev, s, mu);
+  if (rc) return gfail(g, rc, cosmo_hip_batch_last_error(C.b));
   return COSMO_HIP_OK;
 }
 
@@ -266,6 +312,15 @@ extern "C" int32_t cosmo_hip_batch_group_get_counters(cosmo_hip_batch_group* g, 
   if (!g || !g->finalized || !out) return gfail(g, COSMO_HIP_ERR_INVALID, "batch_group_get_counters: set_params first");
   for (auto& C : g->cls) {
     std::vector<int64_t> c(3 * C.members.size());
+    if (!C.b) {
+      for (size_t j = 0; j < C.members.size(); ++j) {
+        int64_t st[8]; const int32_t rc = cosmo_hip_get_stats(C.hs[j], st);
+        if (rc) return gfail(g, rc, cosmo_hip_last_error(C.hs[j]));
+        c[3 * j] = st[0]; c[3 * j + 1] = st[1]; c[3 * j + 2] = st[2];
+      }
+      for (size_t j = 0; j < C.members.size(); ++j) for (int t = 0; t < 3; ++t) out[3 * (size_t)C.members[j] + t] = c[3 * j + t];
+      continue;
+    }
     const int32_t rc = cosmo_hip_batch_get_counters(C.b, c.data());
     if (rc) return gfail(g, rc, cosmo_hip_batch_last_error(C.b));
     for (size_t j = 0; j < C.members.size(); ++j) for (int t = 0; t < 3; ++t) out[3 * (size_t)C.members[j] + t] = c[3 * j + t];
@@ -278,7 +333,8 @@ extern "C" int32_t cosmo_hip_batch_group_get_accel_stats(cosmo_hip_batch_group* 
   if (!g || !g->finalized || !out) return gfail(g, COSMO_HIP_ERR_INVALID, "batch_group_get_accel_stats: set_params first");
   for (auto& C : g->cls) {
     std::vector<int64_t> c(6 * C.members.size(), 0);
-    if (g->aa_on) { const int32_t rc = cosmo_hip_batch_get_accel_stats(C.b, c.data()); if (rc) return gfail(g, rc, cosmo_hip_batch_last_error(C.b)); }
+    if (g->aa_on && !C.b) { for (size_t j = 0; j < C.members.size(); ++j) { const int32_t rc = cosmo_hip_get_accel_stats(C.hs[j], c.data() + 6 * j); if (rc) return gfail(g, rc, cosmo_hip_last_error(C.hs[j])); } }
+    else if (g->aa_on) { const int32_t rc = cosmo_hip_batch_get_accel_stats(C.b, c.data()); if (rc) return gfail(g, rc, cosmo_hip_batch_last_error(C.b)); }
     for (size_t j = 0; j < C.members.size(); ++j) for (int t = 0; t < 6; ++t) out[6 * (size_t)C.members[j] + t] = c[6 * j + t];
   }
   return COSMO_HIP_OK;

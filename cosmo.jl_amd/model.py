@@ -804,6 +804,22 @@ def _structure_key(md: Model):
     return (md.n, md.m, tuple(K.kind for K in md.sets), tuple(K.dim for K in md.sets), tuple(getattr(K, "alpha", 0.0) for K in md.sets))
 
 
+def _batch_kernels_take(md: Model) -> bool:
+    """What cosmo_hip_batch_* accepts (csrc/batch.hip): CG solver kinds, the cone types of batch mode with PSD cones of side <= 64, a fixed rho interval."""
+    st = md.settings
+    kkt = st.kkt_solver.solver if isinstance(st.kkt_solver, OptionsFactory) else st.kkt_solver
+    if kkt not in (CGIndirectKKTSolver, CGSingleReductionKKTSolver, CGJacobiKKTSolver) or (st.adaptive_rho and st.adaptive_rho_interval == 0):
+        return False
+    for K in md.sets:
+        if K.kind in (_ffi.PSD_SQUARE, _ffi.PSD_TRIANGLE):
+            d = int(round(np.sqrt(K.dim))) if K.kind == _ffi.PSD_SQUARE else int((np.sqrt(1 + 8 * K.dim) - 1) // 2)
+            if d > 64:
+                return False
+        elif K.kind not in (_ffi.ZERO, _ffi.NONNEG, _ffi.BOX, _ffi.SOC, _ffi.EXP, _ffi.DUAL_EXP, _ffi.POW, _ffi.DUAL_POW):
+            return False
+    return True
+
+
 def prepare_batch_group(models: Sequence[Model], device: int):
     """setup! of every problem of a shard whose problems differ in structure, uploaded into one `_ffi.BatchGroup` (csrc/batch_group.hip: the library
     partitions them into classes of identical (n, m, cones) and solves the classes concurrently), iterates set.  One Settings object for all."""
@@ -840,7 +856,9 @@ def _solve_shard_on_device(models: Sequence[Model], device: int) -> List[Result]
     if not models:
         return []
     t0 = time.perf_counter()
-    mixed = len({_structure_key(md) for md in models}) > 1
+    # one structure the persistent kernels take -> the batch directly; anything else (several structures, a PSD cone of side > 64, a MINRES solver kind,
+    # the automatic rho interval) -> the group, which gives every structure class its batch or, where the batch kernels refuse, one handle per problem
+    mixed = len({_structure_key(md) for md in models}) > 1 or not _batch_kernels_take(models[0])
     B, st = prepare_batch_group(models, device) if mixed else prepare_batch(models, device)
     t_setup = time.perf_counter() - t0
     rs = B.optimize()

@@ -460,7 +460,9 @@ int32_t cosmo_hip_batch_get_iterates(cosmo_hip_batch* b, int64_t k, cosmo_hip_re
  * differ freely), builds one cosmo_hip_batch per class -- so every class keeps the persistent kernel specialised for its structure -- and
  * cosmo_hip_batch_group_optimize runs all classes concurrently (one HIP stream + host thread per class).  Call order as for a batch:
  * create, set_problem / set_cones [/ set_scaling] for every k, [set_accelerator,] set_params, [set_iterates,] optimize, get_iterates.
- * What a class cannot do (PSD side > 64, user-defined cones, MINRES, adaptive_rho_interval = 0) is the group's error, naming the problem. */
+ * A class the batch kernels refuse (PSD side > 64, MINRES, adaptive_rho_interval = 0) is solved through one single-problem handle per member instead;
+ * what no path of the library takes (an unknown cone type; user-defined cones need their callbacks: one handle per problem) is the group's error,
+ * naming the problem. */
 typedef struct cosmo_hip_batch_group cosmo_hip_batch_group;
 int32_t cosmo_hip_batch_group_create(cosmo_hip_batch_group** g, int32_t device_id, int64_t nprob);
 int32_t cosmo_hip_batch_group_destroy(cosmo_hip_batch_group* g);
@@ -475,8 +477,10 @@ int32_t cosmo_hip_batch_group_set_cones(cosmo_hip_batch_group* g, int64_t k, int
 int32_t cosmo_hip_batch_group_set_scaling(cosmo_hip_batch_group* g, int64_t k, const cosmo_hip_real* Dinv, const cosmo_hip_real* Einv, double cinv);
 int32_t cosmo_hip_batch_group_set_accelerator(cosmo_hip_batch_group* g, const cosmo_hip_accel_params* p);
 int32_t cosmo_hip_batch_group_set_params(cosmo_hip_batch_group* g, const cosmo_hip_params* p);
-/* number of structure classes; class_of[k] for every problem (nprob entries, may be NULL) */
-int32_t cosmo_hip_batch_group_class_info(cosmo_hip_batch_group* g, int64_t* nclasses, int64_t* class_of);
+/* number of structure classes; class_of[k] and mode_of[k] for every problem (nprob entries each, may be NULL): mode 0 = the class runs on a
+ * persistent batch kernel, 1 = its structure is outside the batch kernels (PSD side > 64, a MINRES solver kind, ...) and every member is solved
+ * through its own single-problem handle, concurrently with the batch classes */
+int32_t cosmo_hip_batch_group_class_info(cosmo_hip_batch_group* g, int64_t* nclasses, int64_t* class_of, int64_t* mode_of);
 /* warm start of problem k (n, m, m entries; NULL = zeros); problems never set start from zero (src/solver.jl:128-129) */
 int32_t cosmo_hip_batch_group_set_iterates(cosmo_hip_batch_group* g, int64_t k, const cosmo_hip_real* x0, const cosmo_hip_real* s0, const cosmo_hip_real* mu0);
 /* optimize! for every problem; results has nprob entries in the caller's order */

@@ -150,16 +150,59 @@ def test_heterogeneous_batch_group_abi():
     G2.optimize()
     assert np.array_equal(G2.get_iterates(0)[0], G.get_iterates(1)[0]) and not np.array_equal(G2.get_iterates(1)[0], G.get_iterates(1)[0])
     G.close(); G2.close()
-    # a member the batch kernels cannot take (PSD side 70) is refused, naming the problem
-    big = util.random_qp(np.random.default_rng(3), 20, 0, 0, 0, psd_tri_dims=(70,), p_shift=1.0)
+    # a member NO path of the library takes (an unknown cone type) is the group's error, naming the problem
     G3 = F.BatchGroup(2)
-    for k, p in enumerate((probs[0], big)):
+    for k, p in enumerate((probs[0], probs[1])):
         G3.set_problem(k, p["P"], p["q"], p["A"], p["b"])
         bl = [K.l for K in p["sets"] if K.kind == F.BOX]; bu = [K.u for K in p["sets"] if K.kind == F.BOX]
-        G3.set_cones(k, [K.kind for K in p["sets"]], [K.dim for K in p["sets"]], np.concatenate(bl) if bl else None, np.concatenate(bu) if bu else None)
-    with pytest.raises(F.CosmoHipError, match="class of problem 1"):
+        kinds = [K.kind for K in p["sets"]]
+        if k == 1:
+            kinds[0] = 12                                                    # no such cone type
+        G3.set_cones(k, kinds, [K.dim for K in p["sets"]], np.concatenate(bl) if bl else None, np.concatenate(bu) if bu else None)
+    with pytest.raises(F.CosmoHipError, match="problem 1"):
         G3.set_params(prm)
     G3.close()
+
+
+def test_heterogeneous_batch_members_outside_the_batch_kernels_run_on_their_own_handles():
+    """A PSD cone of side 70 (> 64) and a MINRES solver kind are refused by cosmo_hip_batch_*; inside a group (and through optimize_batch) such
+    problems are solved through one single-problem handle each, concurrently with the batch classes: same answers as cj.optimize, mode_of = 1."""
+    rng = np.random.default_rng(12)
+    small = [util.random_qp(rng, 30, 4, 20, 40) for _ in range(2)]
+    big = util.random_qp(np.random.default_rng(3), 20, 0, 0, 0, psd_tri_dims=(70,), p_shift=1.0)
+    probs = [small[0], big, small[1]]
+    res = cj.optimize_batch(_models(probs, cj.Settings(decompose=False)))
+    for p, r in zip(probs, res):
+        md = cj.Model(); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], cj.Settings(decompose=False))
+        one = cj.optimize(md)
+        assert r.status == one.status == "Solved" and abs(r.iter - one.iter) <= 25 and abs(r.obj_val - one.obj_val) <= 1e-4 * (1 + abs(one.obj_val))
+    # the big one alone (a uniform list the batch kernels refuse) takes the same route
+    alone = cj.optimize_batch(_models([big], cj.Settings(decompose=False)))
+    assert alone[0].status == "Solved" and alone[0].iter == res[1].iter and np.allclose(alone[0].x, res[1].x, rtol=1e-9, atol=1e-12)   # its own handle either way
+    # class modes through the ABI
+    G = F.BatchGroup(3)
+    for k, p in enumerate(probs):
+        G.set_problem(k, p["P"], p["q"], p["A"], p["b"])
+        bl = [K.l for K in p["sets"] if K.kind == F.BOX]; bu = [K.u for K in p["sets"] if K.kind == F.BOX]
+        G.set_cones(k, [K.kind for K in p["sets"]], [K.dim for K in p["sets"]], np.concatenate(bl) if bl else None, np.concatenate(bu) if bu else None)
+    prm = F.Params(); G.lib.cosmo_hip_default_params(C_byref(prm))
+    prm.max_iter = 20; prm.eps_abs = prm.eps_rel = 0.0; prm.check_infeasibility = 10 ** 9
+    G.set_params(prm)
+    nc, cls, mode = G.class_info(with_modes=True)
+    assert nc == 2 and mode.tolist() == [0, 1, 0] and cls[0] == cls[2] != cls[1]
+    rs = G.optimize()
+    assert [r.iter for r in rs] == [20, 20, 20]
+    it, solves, kry = G.counters()
+    assert it.tolist() == [20, 20, 20] and np.all(kry > 0)
+    assert G.get_iterates(1)[2].size == 70 * 71 // 2
+    G.close()
+    # MINRES on the reduced system: every member on its own handle
+    st = cj.Settings(kkt_solver=cj.IndirectReducedKKTSolverMINRES)
+    res = cj.optimize_batch(_models(small, st))
+    for p, r in zip(small, res):
+        md = cj.Model(); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], cj.Settings(kkt_solver=cj.IndirectReducedKKTSolverMINRES))
+        one = cj.optimize(md)
+        assert r.status == one.status and r.iter == one.iter and np.allclose(r.x, one.x, rtol=1e-9, atol=1e-12)
 
 
 def test_cfg3_full_size_tight_cg_all_problems():
@@ -565,10 +608,13 @@ def test_batch_of_sdps_with_cones_of_side_17_to_64():
 
 
 def test_batch_psd_cone_limits_and_certificates():
-    """Side 65 is refused (four block pairs = four waves is what the workgroup routine is sized for); an infeasible small SDP in a batch returns the oracle's status: X in PSD(3) with
+    """Side 65 is refused by the batch kernels (four block pairs = four waves is what the workgroup routine is sized for; optimize_batch then solves such problems through one
+    handle each); an infeasible small SDP in a batch returns the oracle's status: X in PSD(3) with
     X_11 = -1 is primal infeasible (in_dual!(-dy) of the PSD cone is a definiteness test, src/convexset.jl:415-418), next to a feasible twin."""
     with pytest.raises(Exception, match="side <= 64"):
-        cj.optimize_batch(_models(_small_sdps(2, 5, psd_tri_dims=(65,), psd_sq_dims=()), cj.Settings()))
+        cj.model.prepare_batch(_models(_small_sdps(2, 5, psd_tri_dims=(65,), psd_sq_dims=()), cj.Settings()), 0)
+    res65 = cj.optimize_batch(_models(_small_sdps(2, 5, psd_tri_dims=(65,), psd_sq_dims=()), cj.Settings(decompose=False)))
+    assert [r.status for r in res65] == ["Solved", "Solved"]
     d = 3
     nv = d * (d + 1) // 2
     A1 = np.eye(nv); b1 = np.zeros(nv)                                # x = svec(X) in PsdConeTriangle
