@@ -401,3 +401,29 @@ def test_committed_bench_line_follows_the_contract():
         assert dk["value"] > cb["value"] and dk["nnz_L"] > 0 and dk["factor_s"] > 0 and dk["solve_ms"] > 0 and dk["cores"] == 1
         assert abs(d["config"]["gpu_over_cpu_direct_kkt"] - d["value"] / dk["value"]) < 0.05 * d["config"]["gpu_over_cpu_direct_kkt"]
         assert d["extra"]["cfg2"]["cpu_baseline"]["direct_kkt"]["feasible"] is False
+
+
+def test_optimize_batch_routing_knows_what_the_batch_kernels_take():
+    """Host logic of model._solve_shard_on_device: a list goes to cosmo_hip_batch directly only if it has ONE structure the persistent kernels take
+    (csrc/batch.hip: CG kinds, cones of batch mode with PSD side <= 64, a fixed rho interval); everything else goes through the batch group, where
+    refused classes get one handle per problem (csrc/batch_group.hip)."""
+    import scipy.sparse as sp
+    from cosmo_jl_amd import model as M
+
+    def mk(sets, m, **st):
+        md = cj.Model()
+        md.set(sp.identity(3, format="csc"), np.zeros(3), sp.random(m, 3, density=0.5, format="csc", random_state=1), np.zeros(m), sets, cj.Settings(**st))
+        return md
+    assert M._batch_kernels_take(mk([cj.ZeroSet(2), cj.Nonnegatives(3), cj.SecondOrderCone(4)], 9))
+    assert M._batch_kernels_take(mk([cj.PsdConeTriangle(64 * 65 // 2)], 64 * 65 // 2))
+    assert M._batch_kernels_take(mk([cj.PsdCone(64 * 64)], 64 * 64))
+    assert not M._batch_kernels_take(mk([cj.PsdConeTriangle(65 * 66 // 2)], 65 * 66 // 2))
+    assert not M._batch_kernels_take(mk([cj.PsdCone(65 * 65)], 65 * 65))
+    assert M._batch_kernels_take(mk([cj.ExponentialCone(), cj.PowerCone(0.3)], 6))
+    assert not M._batch_kernels_take(mk([cj.Nonnegatives(3)], 3, kkt_solver=cj.MINRESIndirectKKTSolver))
+    assert not M._batch_kernels_take(mk([cj.Nonnegatives(3)], 3, kkt_solver=cj.with_options(cj.IndirectReducedKKTSolverMINRES)))
+    assert M._batch_kernels_take(mk([cj.Nonnegatives(3)], 3, kkt_solver=cj.with_options(cj.CGIndirectKKTSolver, tol_constant=2.0)))
+    assert not M._batch_kernels_take(mk([cj.Nonnegatives(3)], 3, adaptive_rho_interval=0))
+    assert M._batch_kernels_take(mk([cj.Nonnegatives(3)], 3, adaptive_rho_interval=0, adaptive_rho=False))
+    a, b = mk([cj.Nonnegatives(3)], 3), mk([cj.Nonnegatives(4)], 4)
+    assert M._structure_key(a) != M._structure_key(b) and M._structure_key(a) == M._structure_key(mk([cj.Nonnegatives(3)], 3))
