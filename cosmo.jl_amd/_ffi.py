@@ -137,6 +137,7 @@ SIGNATURES = {
     "cosmo_hip_batch_iterate": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32]),
     "cosmo_hip_batch_get_iterates": (C.c_int32, [C.c_void_p, C.c_int64, _PR, _PR, _PR, _PR]),
     "cosmo_hip_batch_get_counters": (C.c_int32, [C.c_void_p, _PI64]),
+    "cosmo_hip_batch_kernel_info": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_batch_group_create": (C.c_int32, [C.POINTER(C.c_void_p), C.c_int32, C.c_int64]),
     "cosmo_hip_batch_group_destroy": (C.c_int32, [C.c_void_p]),
     "cosmo_hip_batch_group_last_error": (C.c_char_p, [C.c_void_p]),
@@ -639,6 +640,12 @@ class Batch:
         """n_iters more loop bodies of every undecided problem (residual / adaptive-rho checks on schedule).  The infeasibility certificates
         are NOT evaluated here -- only optimize() cuts the persistent launch for them -- so rates measured through iterate() exclude their cost."""
         self._chk(self.lib.cosmo_hip_batch_iterate(self._b, int(n_iters), 1 if with_init else 0))
+
+    def kernel_info(self):
+        """Which kernel the batch runs: dict(form = 'streaming' | 'lds_image' | 'register_1_2' | 'register_2_4', sliced, lds_bytes, p_in_registers)."""
+        out = np.zeros(4, dtype=np.int64)
+        self._chk(self.lib.cosmo_hip_batch_kernel_info(self._b, out.ctypes.data_as(_PI64)))
+        return dict(form=("streaming", "lds_image", "register_1_2", "register_2_4")[int(out[0])], sliced=bool(out[1]), lds_bytes=int(out[2]), p_in_registers=bool(out[3]))
 
     def counters(self):
         """Per problem: ADMM iterations, KKT solves, Krylov iterations in total (three int64 arrays)."""

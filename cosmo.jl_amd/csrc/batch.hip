@@ -76,6 +76,9 @@ struct BatchDev {
   const int *permA, *permT;
   const int *posN, *posM;       // nprob * n, nprob * m: position of an entry in the gathered LDS vectors (null: its index)
   const int* qposA;             // nprob * m: position of row i of A in the image's storage order (non-null iff the image is stored in sorted order)
+  // sliced image of the register kernel (row_sliced): per problem, slot and thread the first entry of its row / column in the sliced arrays | length << 16;
+  // pdiag: P is diagonal in every problem of the batch and lives in registers (nprob * n, 0 where a row of P is empty; pdiag_has: 1 where it has its entry)
+  const uint32_t *slA, *slT; const real* pdiag; const unsigned char* pdiag_has; int sliced;
   int regcg;                    // LDS-image kernel with the extended cones (512 threads): Krylov vectors in registers (n <= 1024, m <= 2048; batch_admm_body)
 };
 
@@ -288,6 +291,95 @@ __device__ __forceinline__ real row_pipe3(uint32_t idx, uint32_t val, const uint
   lds_wait0(aA, gA);                                              // drain: nothing of this loop stays in flight behind it
   return s;
 }
+
+// ---- sliced image of the register kernel (round 5, bench/lds_rowpipe_lab.hip) ------------------------------------------------------------------
+// Rows sorted by length make the row-major stride of a wave EQUAL to the row length: with lengths 8, 12, 16 four to sixteen lanes of a half-wave read
+// one bank pair, and the three address computations per nonzero were most of the instructions of a trip.  In the sliced image the 32 rows a half-wave
+// works on in one trip are NEIGHBOURS: entry (trip, lane) of a slice of 32 threads sits at trip * 32 + lane (rows padded to the slice's longest: +5 % on
+// config 3), so every value / index read of a trip is a linear wave access; the u16 entries of A / P hold the BYTE OFFSET of the gathered operand (the
+// gathered vectors sit at fixed LDS addresses in front of the image: the loaded index is the address), the u32 entries of A' hold (LDS byte address of the
+// value) | (position of the row << 21); pointers advance by immediate offsets; the trip count is the wave's longest row (scalar loop control) and a
+// product past the lane's row end is not added.  Same products in the same order: bit-identical to row_pipe3.  Lab: A pass 3826 -> 2669, A' pass
+// 5495 -> 4088 cycles (profiles/r05_lds_rowpipe_lab.txt).
+#if !REAL_IS_FLOAT
+#define SL_LANES 32
+template <int OFF> __device__ __forceinline__ void lds_r64o(real& d, uint32_t addr) { asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
+template <int OFF> __device__ __forceinline__ void lds_r32o(uint32_t& d, uint32_t addr) { asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
+template <int OFF> __device__ __forceinline__ void lds_r16o(uint32_t& d, uint32_t addr) { asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
+// A / P rows: ip = address of the lane's first u16 entry, vp = of its first value, GOFF = LDS address of the gathered vector, L = wave maximum of len
+template <int GOFF>
+__device__ __forceinline__ real row_sliced(uint32_t ip, uint32_t vp, const int len, const int L) {
+  if (L <= 0) return R(0.0);
+  real s = 0.0;
+  uint32_t iA = 0, iB = 0;
+  real aA = 0.0, gA = 0.0, aB = 0.0, gB = 0.0;
+  lds_r16o<0>(iA, ip);
+  lds_r16o<SL_LANES * 2>(iB, ip);
+  lds_wait1(iA);
+  lds_r64o<0>(aA, vp);
+  lds_r64o<GOFF>(gA, iA);
+  int k = 0;
+  for (;;) {
+    lds_r16o<SL_LANES * 4>(iA, ip);
+    lds_wait1(iB, aA, gA);
+    lds_r64o<SL_LANES * 8>(aB, vp);
+    lds_r64o<GOFF>(gB, iB);
+    asm volatile("" : "+v"(aA), "+v"(gA));
+    if (k < len) s += aA * gA;
+    if (++k >= L) break;
+    lds_r16o<SL_LANES * 6>(iB, ip);
+    lds_wait1(iA, aB, gB);
+    lds_r64o<SL_LANES * 16>(aA, vp);
+    lds_r64o<GOFF>(gA, iA);
+    asm volatile("" : "+v"(aB), "+v"(gB));
+    ip += SL_LANES * 4u; vp += SL_LANES * 16u;
+    if (k < len) s += aB * gB;
+    if (++k >= L) break;
+  }
+  lds_wait0(aA, gA);
+  asm volatile("" : "+v"(aB), "+v"(gB));
+  return s;
+}
+// A' rows: ip = address of the lane's first packed entry (value address | row position << 21)
+template <int GOFF>
+__device__ __forceinline__ real rowT_sliced(uint32_t ip, const int len, const int L) {
+  if (L <= 0) return R(0.0);
+  real s = 0.0;
+  uint32_t iA = 0, iB = 0;
+  real aA = 0.0, gA = 0.0, aB = 0.0, gB = 0.0;
+  lds_r32o<0>(iA, ip);
+  lds_r32o<SL_LANES * 4>(iB, ip);
+  lds_wait1(iA);
+  lds_r64o<0>(aA, iA & 0x3ffffu);
+  lds_r64o<GOFF>(gA, iA >> 18);
+  int k = 0;
+  for (;;) {
+    lds_r32o<SL_LANES * 8>(iA, ip);
+    lds_wait1(iB, aA, gA);
+    lds_r64o<0>(aB, iB & 0x3ffffu);
+    lds_r64o<GOFF>(gB, iB >> 18);
+    asm volatile("" : "+v"(aA), "+v"(gA));
+    if (k < len) s += aA * gA;
+    if (++k >= L) break;
+    lds_r32o<SL_LANES * 12>(iB, ip);
+    lds_wait1(iA, aB, gB);
+    lds_r64o<0>(aA, iA & 0x3ffffu);
+    lds_r64o<GOFF>(gA, iA >> 18);
+    asm volatile("" : "+v"(aB), "+v"(gB));
+    ip += SL_LANES * 8u;
+    if (k < len) s += aB * gB;
+    if (++k >= L) break;
+  }
+  lds_wait0(aA, gA);
+  asm volatile("" : "+v"(aB), "+v"(gB));
+  return s;
+}
+__device__ __forceinline__ int wave_max_int(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+  return __builtin_amdgcn_readfirstlane(v);
+}
+#endif
 
 // header of a problem's LDS image (built by build_lds_images): byte offsets from the start of the image
 // oTpr: one u32 per nonzero of A' = (position into A's values) | (row, or its position in the gathered vector) << 16 -- ONE LDS read per nonzero instead
@@ -914,10 +1006,16 @@ extern "C" void cosmo_dbg_batch_timing(long long* out) { (void)hipMemcpyFromSymb
 #define BT_END(slot)
 #endif
 
-template <int BS, int JN, int JM, bool PSD, bool AA>
+// SLICED: the image is the sliced one (row_sliced above; build_lds_images decides per batch) -- the gathered vectors and the reduction slots sit IN FRONT of
+// the image at fixed LDS addresses (xv at 0, tv at 8 JN BS, the block-sum slots behind it), the image follows
+template <int BS, int JN, int JM, bool PSD, bool AA, bool SLICED = false>
 __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, long long iter_target, int do_init,
                                                        const unsigned char* __restrict__ img, long long img_stride) {
   extern __shared__ real dyn_lds[];
+  static_assert(!SLICED || (JN == 1 && BS == 512 && !REAL_IS_FLOAT), "the sliced image exists for the <512, 1, 2> double-precision instantiations");
+  constexpr int WS0 = SLICED ? (int)sizeof(real) * (JN * BS + JM * BS + 2 * (BS / 64)) : 0;     // bytes in front of the image
+  constexpr int TVOFF = (int)sizeof(real) * JN * BS;                                              // LDS address of tv (sliced form)
+  (void)TVOFF;
   const int k = blockIdx.x;
   BCtl* ctl = D.ctl + k;
   if (ctl->status != 0) return;
@@ -928,9 +1026,9 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   {
     const real* s8 = reinterpret_cast<const real*>(src);
     const int nd = hd.bytes / (int)sizeof(real);
-    for (int i = tid; i < nd; i += BS) dyn_lds[i] = s8[i];
+    for (int i = tid; i < nd; i += BS) dyn_lds[WS0 / (int)sizeof(real) + i] = s8[i];
   }
-  unsigned char* base = reinterpret_cast<unsigned char*>(dyn_lds);
+  unsigned char* base = reinterpret_cast<unsigned char*>(dyn_lds) + WS0;
   const real* Aval = reinterpret_cast<const real*>(base + hd.oAval);
   const real* Pval = reinterpret_cast<const real*>(base + hd.oPval);
   const unsigned short* Arp = reinterpret_cast<const unsigned short*>(base + hd.oArp);
@@ -939,11 +1037,12 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   const uint32_t* Tpr = reinterpret_cast<const uint32_t*>(base + hd.oTpr);
   const unsigned short* Prp = reinterpret_cast<const unsigned short*>(base + hd.oPrp);
   const unsigned short* Pcol = reinterpret_cast<const unsigned short*>(base + hd.oPcol);
-  real* wsp = reinterpret_cast<real*>(base + img_stride);
+  real* wsp = SLICED ? dyn_lds : reinterpret_cast<real*>(base + img_stride);
   real* xv = wsp;                 // n : vector gathered by the A / P products
-  real* tv = wsp + n;             // m : vector gathered by the A' products; staging of s for the SOC projection
-  real* red = wsp + n + m;        // 2 x (BS / 64) reduction slots (the second set: double-buffered block sums of the Krylov loop, bsum_db)
-  unsigned char* psd_ws = base + ((img_stride + (long long)sizeof(real) * (n + m + 2 * (BS / 64)) + 15) / 16) * 16;   // wave workspaces of the small PSD cones
+  real* tv = SLICED ? wsp + JN * BS : wsp + n;             // m : vector gathered by the A' products; staging of s for the SOC projection
+  real* red = SLICED ? wsp + JN * BS + JM * BS : wsp + n + m;        // 2 x (BS / 64) reduction slots (the second set: double-buffered block sums of the Krylov loop, bsum_db)
+  unsigned char* psd_ws = SLICED ? reinterpret_cast<unsigned char*>(dyn_lds) + ((WS0 + img_stride + 15) / 16) * 16
+                                 : base + ((img_stride + (long long)sizeof(real) * (n + m + 2 * (BS / 64)) + 15) / 16) * 16;   // wave workspaces of the small PSD cones
   (void)psd_ws;
 
   const long long on = (long long)k * n, om = (long long)k * m, onm = (long long)k * (n + m);
@@ -1142,7 +1241,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
 #endif
   constexpr bool HANDPIPE = SORTED && (COSMO_BATCH_HANDPIPE != 0);
   const uint32_t lA_val = lds_addr_of(Aval), lA_col = lds_addr_of(Acol), lT_pr = lds_addr_of(Tpr), l_xv = lds_addr_of(xv), l_tv = lds_addr_of(tv);
-  if constexpr (SORTED) {
+  if constexpr (SORTED && !SLICED) {
 #pragma unroll
     for (int j = 0; j < JM; ++j) {
       const int r = ra[j];
@@ -1156,6 +1255,32 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       kp0[j] = c >= 0 ? Prp[q] : 0; kp1[j] = c >= 0 ? Prp[q + 1] : 0; kt0[j] = c >= 0 ? Trp[q] : 0; kt1[j] = c >= 0 ? Trp[q + 1] : 0;
     }
   }
+  // sliced image: first entries / lengths of the rows and the column this thread computes, the wave maxima of the lengths (scalar trip counts)
+  uint32_t sa_ip[SLICED ? JM : 1], sa_vp[SLICED ? JM : 1], st_ip[SLICED ? JN : 1];
+  int sa_len[SLICED ? JM : 1], sa_L[SLICED ? JM : 1], st_len[SLICED ? JN : 1], st_L[SLICED ? JN : 1];
+  real pdv[SLICED ? JN : 1];
+  bool pdh[SLICED ? JN : 1];
+  (void)sa_ip; (void)sa_vp; (void)st_ip; (void)sa_len; (void)sa_L; (void)st_len; (void)st_L; (void)pdv; (void)pdh;
+#if !REAL_IS_FLOAT
+  if constexpr (SLICED) {
+#pragma unroll
+    for (int j = 0; j < JM; ++j) {
+      const uint32_t e = D.slA[((long long)k * JM + j) * BS + tid];
+      sa_len[j] = (int)(e >> 16); sa_ip[j] = lA_col + 2u * (e & 0xffffu); sa_vp[j] = lA_val + 8u * (e & 0xffffu);
+      sa_L[j] = wave_max_int(sa_len[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < JN; ++j) {
+      const uint32_t e = D.slT[((long long)k * JN + j) * BS + tid];
+      st_len[j] = (int)(e >> 16); st_ip[j] = lT_pr + 4u * (e & 0xffffu);
+      st_L[j] = wave_max_int(st_len[j]);
+      const int c = OWN(j);
+      pdv[j] = (D.pdiag && c >= 0) ? D.pdiag[on + c] : R(0.0);
+      pdh[j] = D.pdiag && c >= 0 && D.pdiag_has[on + c] != 0;
+      if (!D.pdiag) { const int q = BS * j + tid; kp0[j] = c >= 0 ? Prp[q] : 0; kp1[j] = c >= 0 ? Prp[q + 1] : 0; }
+    }
+  }
+#endif
   // every row / column product of this kernel goes through these three: the bounds held in registers (sorted instantiation) or the row pointers
   // (the rows a thread OWNS are used outside the Krylov loop only -- three times per ADMM iteration: their position is read when needed, no registers held)
   auto rowA_own = [&](int j) -> real {
@@ -1165,6 +1290,36 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   };
   auto rowAT_own = [&](int j) -> real { if constexpr (SORTED) return rowAT_b(kt0[j], kt1[j]); else return rowAT(OWN(j)); };
   auto rowP_own = [&](int j) -> real { if constexpr (SORTED) return rowP_b(kp0[j], kp1[j]); else return rowP(OWN(j)); };
+  // sliced image: the rows ra[] of the compute assignment (A), the owned column (A', P); vj = the gathered vector's entry of the owned column (what a
+  // diagonal P held in registers multiplies: xv[position of c] is this thread's own element)
+#if !REAL_IS_FLOAT
+  auto A_sl = [&](int j) -> real { return row_sliced<0>(sa_ip[j], sa_vp[j], sa_len[j], sa_L[j]) + R(0.0); };
+  auto T_sl = [&](int j) -> real { return rowT_sliced<TVOFF>(st_ip[j], st_len[j], st_L[j]); };
+  auto P_sl = [&](int j, const real vj) -> real {
+    if (D.pdiag) return pdh[j] ? R(0.0) + pdv[j] * vj : R(0.0);
+    return rowP_b(kp0[j], kp1[j]);
+  };
+#else
+  auto A_sl = [&](int) -> real { return R(0.0); };
+  auto T_sl = [&](int) -> real { return R(0.0); };
+  auto P_sl = [&](int, const real) -> real { return R(0.0); };
+#endif
+  // (A x)_i for the rows a thread OWNS, sliced form: the computing threads hand their rows over through tv (xv holds x, published and fenced by the caller;
+  // tv is free: nobody reads it between the caller's last barrier and here).  Ends with a barrier after which tv may be overwritten.
+  auto Ax_to_owners = [&](real* ax) {
+    real t_[JM];
+#pragma unroll
+    for (int j = 0; j < JM; ++j) t_[j] = (ra[j] >= 0) ? A_sl(j) : R(0.0);
+#pragma unroll
+    for (int j = 0; j < JM; ++j) if (ra[j] >= 0) tv[pmc[j]] = t_[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; ax[j] = (i < m) ? tv[pm[j]] : R(0.0); }
+    __syncthreads();
+  };
+  (void)Ax_to_owners;
+  auto colT = [&](int j) -> real { if constexpr (SLICED) return T_sl(j); else return rowAT_own(j); };
+  auto colP = [&](int j, const real vj) -> real { if constexpr (SLICED) return P_sl(j, vj); else { (void)vj; return rowP_own(j); } };
 
   // ---- admm_x! + admm_w! (solver.jl:32-65) with the CG reduced solve (kktsolver_indirect.jl:36-88) -------------------
   auto solve_and_update = [&]() {
@@ -1184,21 +1339,31 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
       const int i = OWN(j);
-      if (i >= 0) { const real v = (rowAT_own(j) + R(0.0)) + lsx[j]; rhsv[j] = v; acc += v * v; }
+      if (i >= 0) { const real v = (colT(j) + R(0.0)) + lsx[j]; rhsv[j] = v; acc += v * v; }
     }
     const real bb = bsum<BS>(acc, red);                                  // (its barriers also order tv reads before the writes below)
     real tmpv[JM];
+    if constexpr (SLICED) {
+      // rho .* (A x_tl) by the computing threads, straight to its consumers (the same values the owners would have written)
+#pragma unroll
+      for (int j = 0; j < JM; ++j) tmpv[j] = (ra[j] >= 0) ? A_sl(j) * rhoc[j] : 0.0;
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < JM; ++j) if (ra[j] >= 0) tv[pmc[j]] = tmpv[j];
+      __syncthreads();
+    } else {
 #pragma unroll
     for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; tmpv[j] = (i < m) ? rowA_own(j) * rhov[j] : 0.0; }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; if (i < m) tv[pm[j]] = tmpv[j]; }
     __syncthreads();
+    }
     acc = 0.0;
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
       const int i = OWN(j);
-      if (i >= 0) { const real cj = rowP_own(j) + (P.sigma * xtl[j] + rowAT_own(j)); const real rj = rhsv[j] - cj; rv[j] = rj; acc += rj * rj; }
+      if (i >= 0) { const real cj = colP(j, xtl[j]) + (P.sigma * xtl[j] + colT(j)); const real rj = rhsv[j] - cj; rv[j] = rj; acc += rj * rj; }
     }
     real rr = bsum<BS>(acc, red);
     const real tol_k = tol_next;
@@ -1222,7 +1387,15 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       // also the element of the n-vectors this thread OWNS (round 5), so c = P u + sigma u + A' tmp stays in its registers -- until round 4 it
       // went back to an index-order owner through xv: two more barriers and two more LDS accesses per Krylov iteration.  Every row sum is the
       // same left-to-right sum as in every other kernel form; the block sums add their terms in the order of this ownership.
-      if (SORTED) {
+      if constexpr (SLICED) {
+      { BT_BEGIN();
+#pragma unroll
+      for (int j = 0; j < JM; ++j) tmpv[j] = (ra[j] >= 0) ? A_sl(j) * rhoc[j] : 0.0;
+#pragma unroll
+      for (int j = 0; j < JM; ++j) if (ra[j] >= 0) tv[pmc[j]] = tmpv[j];
+      __syncthreads();
+      BT_END(0); }
+      } else if (SORTED) {
       { BT_BEGIN();
 #pragma unroll
       for (int j = 0; j < JM; ++j)
@@ -1247,7 +1420,8 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
         if (c >= 0) {
           const real vj = uv[j];
           real cj;
-          if constexpr (SORTED) cj = rowP_b(kp0[j], kp1[j]) + (P.sigma * vj + (HANDPIPE ? row_pipe3<true>(lT_pr + 4u * (uint32_t)kt0[j], lA_val, l_tv, kt1[j] - kt0[j])
+          if constexpr (SLICED) cj = colP(j, vj) + (P.sigma * vj + colT(j));
+          else if constexpr (SORTED) cj = rowP_b(kp0[j], kp1[j]) + (P.sigma * vj + (HANDPIPE ? row_pipe3<true>(lT_pr + 4u * (uint32_t)kt0[j], lA_val, l_tv, kt1[j] - kt0[j])
                                                                                                    : rowAT_b(kt0[j], kt1[j])));
           else cj = rowP(c) + (P.sigma * vj + rowAT(c));
           cv[j] = cj; acc += vj * cj;
@@ -1275,11 +1449,15 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
 #pragma unroll
     for (int j = 0; j < JN; ++j) { const int i = OWN(j); if (i >= 0) xv[pn[j]] = xtl[j]; }
     __syncthreads();
+    real axo[JM];
+    if constexpr (SLICED) Ax_to_owners(axo);
 #pragma unroll
     for (int j = 0; j < JM; ++j) {
       const int i = tid + BS * j;
       if (i < m) {
-        const real rh = rhov[j]; const real nv = (rowA_own(j) - lss[j]) * rh;
+        real ax_;
+        if constexpr (SLICED) ax_ = axo[j]; else ax_ = rowA_own(j);
+        const real rh = rhov[j]; const real nv = (ax_ - lss[j]) * rh;
         const real st = (R(2.0) * sv[j] - wsv[j]) - nv / rh;
         wsv[j] = wsv[j] + P.alpha * (st - sv[j]);
       }
@@ -1300,11 +1478,15 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     for (int j = 0; j < JN; ++j) { const int i = OWN(j); if (i >= 0) xv[pn[j]] = wpx[j]; }
     __syncthreads();
     real a_rp = 0.0, a_mp = 0.0;
+    real axo[JM];
+    if constexpr (SLICED) Ax_to_owners(axo);
 #pragma unroll
     for (int j = 0; j < JM; ++j) {
       const int i = tid + BS * j;
       if (i < m) {
-        const real ax = rowA_own(j), s0 = sv[j], b0 = bv[j];
+        real ax;
+        if constexpr (SLICED) ax = axo[j]; else ax = rowA_own(j);
+        const real s0 = sv[j], b0 = bv[j];
         muv[j] = rhov[j] * (wps[j] - s0);
         tv[pm[j]] = muv[j];
         real r0 = ax + s0; r0 = r0 - b0;
@@ -1321,7 +1503,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     for (int j = 0; j < JN; ++j) {
       const int i = OWN(j);
       if (i >= 0) {
-        const real px = rowP_own(j), atm = rowAT_own(j), x0 = wpx[j], q0 = qv[j];
+        const real px = colP(j, wpx[j]), atm = colT(j), x0 = wpx[j], q0 = qv[j];
         real r0 = px + q0; r0 = r0 - atm;
         real a = px, bq = q0, cm = atm;
         if (unscale) { const real d = D.Dinv[on + i]; r0 = (r0 * d) * cinv; a = (a * d) * cinv; bq = (bq * d) * cinv; cm = (cm * d) * cinv; }
@@ -1726,6 +1908,8 @@ struct cosmo_hip_batch {
   std::vector<int> h_permA, h_permT;          // compute assignment of the register kernel (build_lds_images), uploaded by set_params
   std::vector<int> h_posN, h_posM;            // positions of the gathered LDS vectors (build_lds_images)
   std::vector<int> h_qposA;                   // per problem: position of row i of A in the image's (sorted) storage order
+  // sliced image of the register kernel (build_lds_images): first entry | length << 16 of every thread's rows / column; diagonal of P when P is diagonal in all problems
+  std::vector<uint32_t> h_slA, h_slT; std::vector<real> h_pdiag; std::vector<unsigned char> h_pdiag_has;
 };
 
 static int32_t bfail(cosmo_hip_batch* b, int32_t code, const char* fmt, ...) {
@@ -1959,6 +2143,17 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
   auto up16 = [](long long x) { return (x + 15) / 16 * 16; };
   std::vector<std::vector<unsigned char>> imgs((size_t)b->nprob);
   long long stride = 0;
+  // sliced image (register kernel <512, 1, 2>, double precision; row_sliced): built next to the row-major one, used if every problem's fits
+  std::vector<std::vector<unsigned char>> imgs2((size_t)b->nprob);
+  long long stride2 = 0;
+  const long long SL_WS0 = (long long)sizeof(real) * (512 + 2 * 512 + 2 * (512 / 64));      // xv, tv, block-sum slots in front of the image
+  bool want_sliced = !REAL_IS_FLOAT && b->reg_mode == 1 && !(getenv("COSMO_HIP_BATCH_SLICED") && atoi(getenv("COSMO_HIP_BATCH_SLICED")) == 0);
+  bool p_all_diag = true;                                                                    // P diagonal (or empty rows) in every problem: it moves into registers
+  for (int k = 0; k < b->nprob && p_all_diag; ++k) {
+    const HostCsr& PT = b->hPT[k];
+    for (long long j = 0; j < n && p_all_diag; ++j) { const int len = PT.split[j] - PT.rowptr[j]; if (len > 1 || (len == 1 && PT.col[PT.rowptr[j]] != (int)j)) p_all_diag = false; }
+  }
+  b->h_slA.clear(); b->h_slT.clear(); b->h_pdiag.clear(); b->h_pdiag_has.clear();
   for (int k = 0; k < b->nprob; ++k) {
     const HostCsr &A = b->hA[k], &AT = b->hAT[k], &PT = b->hPT[k];
     const long long nnzA = (long long)A.val.size();
@@ -2141,8 +2336,99 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
         for (long long t = 0; t < nnzA; ++t) { Acol2[t] = (unsigned short)pN[Acol2[t]]; Tpr2[t] = (Tpr2[t] & 0xffffu) | ((uint32_t)pM[Tpr2[t] >> 16] << 16); }
         for (long long t = 0; t < nnzP; ++t) Pcol2[t] = (unsigned short)pN[Pcol2[t]];
       }
+      // ---- the sliced image of this problem (see row_sliced): from the final arrays above (stored in sorted order, gather indices = positions) ----
+      if (want_sliced && b->h_qposA.empty()) want_sliced = false;                 // needs the sorted storage order (Arp / Trp / Prp indexed by position)
+      if (want_sliced) {
+        if (b->h_slA.empty()) {
+          b->h_slA.assign((size_t)b->nprob * 2 * 512, 0u); b->h_slT.assign((size_t)b->nprob * 512, 0u);
+          if (p_all_diag) { b->h_pdiag.assign((size_t)b->nprob * n, R(0.0)); b->h_pdiag_has.assign((size_t)b->nprob * n, 0); }
+        }
+        auto qA = [&](int j, int t) { return 512 * j + ((j & 1) ? 511 - t : t); };        // slot j of thread t computes the row at this sorted position
+        long long offA[32], LA[32], offT[16], LT[16], curA = 0, curT = 0, needA = 0, needT = 0;
+        for (int j = 0; j < 2; ++j) for (int sx = 0; sx < 16; ++sx) {
+          long long L = 0;
+          for (int l = 0; l < 32; ++l) { const int q = qA(j, 32 * sx + l); if (q < m) L = std::max<long long>(L, Arp[q + 1] - Arp[q]); }
+          offA[j * 16 + sx] = curA; LA[j * 16 + sx] = L; curA += 32 * L;
+        }
+        for (int sx = 0; sx < 16; ++sx) {
+          long long L = 0;
+          for (int l = 0; l < 32; ++l) { const int q = 32 * sx + l; if (q < n) L = std::max<long long>(L, Trp[q + 1] - Trp[q]); }
+          offT[sx] = curT; LT[sx] = L; curT += 32 * L;
+        }
+        // a lane runs to its WAVE's longest row and reads two trips ahead: into the slices behind its own, or into the zero tail sized here
+        for (int j = 0; j < 2; ++j) for (int sx = 0; sx < 16; ++sx) needA = std::max(needA, offA[j * 16 + sx] + 32 * (std::max(LA[j * 16 + (sx & ~1)], LA[j * 16 + (sx | 1)]) + 2));
+        for (int sx = 0; sx < 16; ++sx) needT = std::max(needT, offT[sx] + 32 * (std::max(LT[sx & ~1], LT[sx | 1]) + 2));
+        const long long nS = std::max(curA, needA), nT = std::max(curT, needT);
+        LdsHdr h2; memset(&h2, 0, sizeof h2);
+        h2.nnzA = (int)nS; h2.nnzP = p_all_diag ? 0 : (int)nnzP;
+        long long o2 = up16(sizeof(LdsHdr));
+        h2.oAval = (int)o2; o2 = up16(o2 + (long long)sizeof(real) * nS);
+        h2.oTpr = (int)o2; o2 = up16(o2 + 4 * nT);
+        h2.oAcol = (int)o2; o2 = up16(o2 + 2 * nS);
+        if (!p_all_diag) {
+          h2.oPval = (int)o2; o2 = up16(o2 + (long long)sizeof(real) * nnzP);
+          h2.oPrp = (int)o2; o2 = up16(o2 + 2 * (n + 1));
+          h2.oPcol = (int)o2; o2 = up16(o2 + 2 * nnzP);
+        }
+        h2.bytes = (int)o2;
+        if (nS > 65535 || nT > 65535 || SL_WS0 + o2 > max_lds || SL_WS0 + h2.oAval + (long long)sizeof(real) * nS >= (1LL << 18)) want_sliced = false;
+        else {
+          std::vector<unsigned char>& i2 = imgs2[(size_t)k];
+          i2.assign((size_t)o2, 0);
+          memcpy(i2.data(), &h2, sizeof h2);
+          real* Aval2 = reinterpret_cast<real*>(i2.data() + h2.oAval);
+          unsigned short* Acol2s = reinterpret_cast<unsigned short*>(i2.data() + h2.oAcol);
+          uint32_t* Tpr2s = reinterpret_cast<uint32_t*>(i2.data() + h2.oTpr);
+          std::vector<long long> newpos((size_t)std::max<long long>(nnzA, 1), 0);
+          for (int j = 0; j < 2; ++j) for (int sx = 0; sx < 16; ++sx) for (int l = 0; l < 32; ++l) {
+            const int t = 32 * sx + l, q = qA(j, t);
+            const long long off = offA[j * 16 + sx] + l;
+            const long long start = q < m ? Arp[q] : 0, len = q < m ? Arp[q + 1] - Arp[q] : 0;
+            b->h_slA[((size_t)k * 2 + (size_t)j) * 512 + (size_t)t] = (uint32_t)off | ((uint32_t)len << 16);
+            for (long long tt = 0; tt < len; ++tt) {
+              const long long e = off + 32 * tt;
+              Aval2[e] = Aval[start + tt]; Acol2s[e] = (unsigned short)(Acol[start + tt] * (unsigned)sizeof(real)); newpos[(size_t)(start + tt)] = e;
+            }
+          }
+          for (int sx = 0; sx < 16; ++sx) for (int l = 0; l < 32; ++l) {
+            const int q = 32 * sx + l;
+            const long long off = offT[sx] + l;
+            const long long start = q < n ? Trp[q] : 0, len = q < n ? Trp[q + 1] - Trp[q] : 0;
+            b->h_slT[(size_t)k * 512 + (size_t)q] = (uint32_t)off | ((uint32_t)len << 16);
+            for (long long tt = 0; tt < len; ++tt) {
+              const uint32_t pr = Tpr[start + tt];
+              Tpr2s[off + 32 * tt] = (uint32_t)(SL_WS0 + h2.oAval + (long long)sizeof(real) * newpos[(size_t)(pr & 0xffffu)]) | ((pr >> 16) << 21);
+            }
+          }
+          if (!p_all_diag) {
+            memcpy(i2.data() + h2.oPval, Pval, (size_t)nnzP * sizeof(real));
+            memcpy(i2.data() + h2.oPrp, Prp, (size_t)(n + 1) * 2);
+            memcpy(i2.data() + h2.oPcol, Pcol, (size_t)nnzP * 2);
+          } else {
+            for (long long j = 0; j < n; ++j) if (PT.split[j] > PT.rowptr[j]) { b->h_pdiag[(size_t)k * n + (size_t)j] = PT.val[PT.rowptr[j]]; b->h_pdiag_has[(size_t)k * n + (size_t)j] = 1; }
+          }
+          stride2 = std::max(stride2, o2);
+        }
+      }
     }
   }
+  // the sliced image replaces the row-major one if every problem's fits (with at least one wave workspace of the small PSD cones where the batch has such
+  // cones) and the sliced instantiation has no static LDS in front of the dynamic block (its gathered vectors must start at LDS address 0)
+  bool use_sliced = want_sliced && !b->h_slA.empty() && b->reg_mode == 1;
+#if REAL_IS_FLOAT
+  use_sliced = false;
+#else
+  if (use_sliced && npsd > 0 && (max_lds - up16(SL_WS0 + stride2)) / PSD16_WS_STRIDE < 1) use_sliced = false;
+  if (use_sliced) {
+    const void* fs = b->aa_on ? (const void*)k_batch_admm_reg<512, 1, 2, false, true, true>
+                              : ((npsd > 0 || n3 > 0 || b->force_ext) ? (const void*)k_batch_admm_reg<512, 1, 2, true, false, true> : (const void*)k_batch_admm_reg<512, 1, 2, false, false, true>);
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, fs) != hipSuccess || fa.sharedSizeBytes != 0) { (void)hipGetLastError(); use_sliced = false; }
+  }
+#endif
+  if (use_sliced) { imgs.swap(imgs2); stride = stride2; }
+  else { b->h_slA.clear(); b->h_slT.clear(); b->h_pdiag.clear(); b->h_pdiag_has.clear(); }
+  b->D.sliced = use_sliced ? 1 : 0;
   unsigned char* d = nullptr;
   BHIP(b, hipMalloc((void**)&d, (size_t)stride * b->nprob));
   b->allocs.push_back(d);
@@ -2150,7 +2436,7 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
   for (int k = 0; k < b->nprob; ++k)
     BHIP(b, hipMemcpy(d + (size_t)k * stride, imgs[(size_t)k].data(), imgs[(size_t)k].size(), hipMemcpyHostToDevice));
   // wave workspaces of the small PSD cones behind the reduction slots: as many as fit, at most one per wave; none fits => streaming kernel
-  const long long ws_base = ((stride + (long long)sizeof(real) * (n + m + 2 * (bs / 64)) + 15) / 16) * 16;
+  const long long ws_base = use_sliced ? up16(SL_WS0 + stride) : ((stride + (long long)sizeof(real) * (n + m + 2 * (bs / 64)) + 15) / 16) * 16;
   int nws = 0;
   if (npsd > 0) {
     nws = (int)std::min<long long>(bs / 64, (max_lds - ws_base) / PSD16_WS_STRIDE);
@@ -2160,7 +2446,8 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
   { const char* ec = getenv("COSMO_HIP_BATCH_LDSCG");
     b->D.regcg = (bs == 512 && n <= 2 * 512 && m <= 4 * 512 && !(ec && atoi(ec) == 0)) ? 1 : 0; }
   b->d_img = d; b->img_stride = stride; b->lds_bs = bs;
-  b->lds_bytes = (int)(npsd > 0 ? ws_base + (long long)nws * PSD16_WS_STRIDE : stride + (long long)sizeof(real) * (n + m) + (long long)sizeof(real) * 2 * (bs / 64));
+  b->lds_bytes = (int)(npsd > 0 ? ws_base + (long long)nws * PSD16_WS_STRIDE
+                                : (use_sliced ? SL_WS0 + stride : stride + (long long)sizeof(real) * (n + m) + (long long)sizeof(real) * 2 * (bs / 64)));
   const void* fn = bs == 256 ? (const void*)k_batch_admm_lds<256, false, false> : (bs == 512 ? (const void*)k_batch_admm_lds<512, false, false> : (const void*)k_batch_admm_lds<1024, false, false>);
   if (b->reg_mode == 1) fn = (const void*)k_batch_admm_reg<512, 1, 2, false, false>;
   if (b->reg_mode == 2) fn = (const void*)k_batch_admm_reg<512, 2, 4, false, false>;
@@ -2174,6 +2461,11 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
     if (b->reg_mode == 1) fn = (const void*)k_batch_admm_reg<512, 1, 2, false, true>;
     if (b->reg_mode == 2) fn = (const void*)k_batch_admm_reg<512, 2, 4, false, true>;
   }
+#if !REAL_IS_FLOAT
+  if (use_sliced)
+    fn = b->aa_on ? (const void*)k_batch_admm_reg<512, 1, 2, false, true, true>
+                  : ((npsd > 0 || n3 > 0 || b->force_ext) ? (const void*)k_batch_admm_reg<512, 1, 2, true, false, true> : (const void*)k_batch_admm_reg<512, 1, 2, false, false, true>);
+#endif
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, b->lds_bytes) != hipSuccess) {
     (void)hipGetLastError();
     b->d_img = nullptr; b->reg_mode = 0;          // the device does not grant that much LDS: streaming kernel
@@ -2185,13 +2477,20 @@ static int32_t launch_batch_admm(cosmo_hip_batch* b, const BParams& P, long long
   bool psd = b->D.npsd > 0 || b->D.n3 > 0;              // the instantiations with the cones beyond Zero / Nonnegatives / Box / SecondOrderCone
   if (b->force_ext) psd = true;                           // COSMO_HIP_BATCH_EXT=1 (lab switch: that code is a run-time no-op without such cones)
 #define LAUNCH_REG(JN_, JM_, PSD_) hipLaunchKernelGGL((k_batch_admm_reg<512, JN_, JM_, PSD_, false>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride)
+#if !REAL_IS_FLOAT
+#define LAUNCH_REG_SL(PSD_, AA_) hipLaunchKernelGGL((k_batch_admm_reg<512, 1, 2, PSD_, AA_, true>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride)
+#else
+#define LAUNCH_REG_SL(PSD_, AA_) (void)0
+#endif
 #define LAUNCH_LDS(BS_, PSD_) hipLaunchKernelGGL((k_batch_admm_lds<BS_, PSD_, false>), dim3(b->nprob), dim3(BS_), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride)
   if (b->aa_on) {                    // accelerated loop: register kernel (batches without PSD cones), else the LDS-image kernel (512 threads) or the streaming kernel with the PSD code (a run-time no-op without such cones)
-    if (b->d_img && b->reg_mode == 1) hipLaunchKernelGGL((k_batch_admm_reg<512, 1, 2, false, true>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
+    if (b->d_img && b->reg_mode == 1 && b->D.sliced) LAUNCH_REG_SL(false, true);
+    else if (b->d_img && b->reg_mode == 1) hipLaunchKernelGGL((k_batch_admm_reg<512, 1, 2, false, true>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
     else if (b->d_img && b->reg_mode == 2) hipLaunchKernelGGL((k_batch_admm_reg<512, 2, 4, false, true>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
     else if (b->d_img) hipLaunchKernelGGL((k_batch_admm_lds<512, true, true>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
     else hipLaunchKernelGGL((k_batch_admm<true, true>), dim3(b->nprob), dim3(COSMO_BS), 0, b->stream, b->D, P, target, do_init);
   }
+  else if (b->d_img && b->reg_mode == 1 && b->D.sliced) { if (psd) LAUNCH_REG_SL(true, false); else LAUNCH_REG_SL(false, false); }
   else if (b->d_img && b->reg_mode == 1) { if (psd) LAUNCH_REG(1, 2, true); else LAUNCH_REG(1, 2, false); }
   else if (b->d_img && b->reg_mode == 2) { if (psd) LAUNCH_REG(2, 4, true); else LAUNCH_REG(2, 4, false); }
   else if (b->d_img) {
@@ -2224,11 +2523,17 @@ extern "C" int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hi
   D.nprob = nprob; D.n = (int)n; D.m = (int)m;
   int32_t rc;
   D.permA = nullptr; D.permT = nullptr; D.posN = nullptr; D.posM = nullptr; D.qposA = nullptr;
+  D.slA = nullptr; D.slT = nullptr; D.pdiag = nullptr; D.pdiag_has = nullptr; D.sliced = 0;
   if ((rc = build_lds_images(b))) return rc;               // needs the host CSR copies that bmat_upload releases
   if (b->d_img && b->reg_mode == 1 && !b->h_permA.empty()) {        // (no image: the streaming kernel runs and needs none of this)
     if ((rc = bup(b, &D.permA, b->h_permA))) return rc;
     if ((rc = bup(b, &D.permT, b->h_permT))) return rc;
     if (!b->h_qposA.empty()) { if ((rc = bup(b, &D.qposA, b->h_qposA))) return rc; }
+    if (D.sliced) {
+      if ((rc = bup(b, &D.slA, b->h_slA))) return rc;
+      if ((rc = bup(b, &D.slT, b->h_slT))) return rc;
+      if (!b->h_pdiag.empty()) { if ((rc = bup(b, &D.pdiag, b->h_pdiag))) return rc; if ((rc = bup(b, &D.pdiag_has, b->h_pdiag_has))) return rc; }
+    }
     if (!b->h_posN.empty()) {
       if ((rc = bup(b, &D.posN, b->h_posN))) return rc;
       if ((rc = bup(b, &D.posM, b->h_posM))) return rc;
@@ -2527,6 +2832,17 @@ extern "C" int32_t cosmo_hip_batch_iterate(cosmo_hip_batch* b, int64_t n_iters, 
   b->iters_done += n_iters;
   { const int32_t lrc = launch_batch_admm(b, P, (long long)b->iters_done, with_init ? 1 : 0); if (lrc) return lrc; }
   BHIP(b, hipStreamSynchronize(b->stream));
+  return COSMO_HIP_OK;
+}
+
+// which kernel a batch runs (after set_params): out = {form: 0 streaming, 1 LDS image, 2 register kernel <512, 1, 2>, 3 register kernel <512, 2, 4>;
+// sliced image 0 / 1; dynamic LDS bytes per workgroup; P held in registers 0 / 1}
+extern "C" int32_t cosmo_hip_batch_kernel_info(cosmo_hip_batch* b, int64_t* out) {
+  if (!b || !out) return COSMO_HIP_ERR_INVALID;
+  out[0] = !b->d_img ? 0 : (b->reg_mode == 1 ? 2 : (b->reg_mode == 2 ? 3 : 1));
+  out[1] = (b->d_img && b->reg_mode == 1 && b->D.sliced) ? 1 : 0;
+  out[2] = b->d_img ? b->lds_bytes : 0;
+  out[3] = (out[1] && b->D.pdiag) ? 1 : 0;
   return COSMO_HIP_OK;
 }
 

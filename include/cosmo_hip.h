@@ -452,6 +452,9 @@ int32_t cosmo_hip_batch_iterate(cosmo_hip_batch* b, int64_t n_iters, int32_t wit
 /* per problem {ADMM iterations, KKT solves, Krylov iterations in total}: out[3 * nprob] (measurement; the counters the reference keeps in
  * IndirectReducedKKTSolver.iteration_counter / multiplications, src/linear_solver/kktsolver_indirect.jl:32,56) */
 int32_t cosmo_hip_batch_get_counters(cosmo_hip_batch* b, int64_t* out);
+/* which kernel the batch runs (after set_params; measurement / tests): out = {form: 0 streaming, 1 LDS image, 2 register kernel <512, 1, 2>,
+ * 3 register kernel <512, 2, 4>; sliced image 0 / 1; dynamic LDS bytes per workgroup; P held in registers 0 / 1} */
+int32_t cosmo_hip_batch_kernel_info(cosmo_hip_batch* b, int64_t out[4]);
 int32_t cosmo_hip_batch_get_iterates(cosmo_hip_batch* b, int64_t k, cosmo_hip_real* w, cosmo_hip_real* w_prev, cosmo_hip_real* s, cosmo_hip_real* mu);
 
 /* ---- batches of problems of DIFFERENT structure (csrc/batch_group.hip) ------------------------------------------------------------------

@@ -310,7 +310,7 @@ def test_cfg3_full_size_batch():
 
 def _with_env(env, fn):
     import os
-    keys = ("COSMO_HIP_BATCH_LDS", "COSMO_HIP_BATCH_BS", "COSMO_HIP_BATCH_REG", "COSMO_HIP_BATCH_LDSCG", "COSMO_HIP_BATCH_EXT", "COSMO_HIP_BATCH_SORTED")
+    keys = ("COSMO_HIP_BATCH_LDS", "COSMO_HIP_BATCH_BS", "COSMO_HIP_BATCH_REG", "COSMO_HIP_BATCH_LDSCG", "COSMO_HIP_BATCH_EXT", "COSMO_HIP_BATCH_SORTED", "COSMO_HIP_BATCH_SLICED")
     saved = {k: os.environ.pop(k, None) for k in keys}
     os.environ.update(env)
     try:
@@ -368,6 +368,40 @@ def test_batch_register_kernel_sorted_ownership_agrees_with_the_index_order_form
     srt = _with_env({}, run)
     for a, b in zip(own, srt):
         assert a.iter == b.iter and a.status == b.status and len(a.info.rho_updates) == len(b.info.rho_updates)
+
+
+def test_batch_register_kernel_sliced_image_is_bit_identical_to_the_row_major_image():
+    """The sliced image of the register kernel (csrc/batch.hip, row_sliced: the 32 rows a half-wave works on in one trip are neighbours, index entries
+    are byte offsets / value addresses, a diagonal P lives in registers, (A x) for the owners comes through tv from the computing threads) changes
+    where the operands sit and which instructions fetch them -- not one product, not one order of addition: iterates, Krylov totals, rho updates and
+    residuals equal the row-major image (COSMO_HIP_BATCH_SLICED=0) BIT FOR BIT.  Four instantiations: plain (diagonal P: config-3 SOCPs), a
+    non-diagonal P (rows of P stay in the image), the accelerated kernel, the kernel with small PSD cones."""
+    def both(probs, st, expect_pdiag):
+        def run():
+            mods = _models(probs, st)
+            B, _ = cj.model.prepare_batch(mods, 0)
+            info = B.kernel_info()
+            rs = B.optimize()
+            it = [B.get_iterates(k) for k in range(len(probs))]
+            cnt = B.counters()
+            B.close()
+            return info, rs, it, cnt
+        i0, r0, w0, c0 = _with_env({"COSMO_HIP_BATCH_SLICED": "0"}, run)
+        i1, r1, w1, c1 = _with_env({}, run)
+        assert i0["form"] == i1["form"] == "register_1_2" and not i0["sliced"] and i1["sliced"] and i1["p_in_registers"] == expect_pdiag, (i0, i1)
+        for k in range(len(probs)):
+            assert r0[k].iter == r1[k].iter and r0[k].status == r1[k].status and r0[k].n_rho_updates == r1[k].n_rho_updates
+            assert r0[k].r_prim == r1[k].r_prim and r0[k].r_dual == r1[k].r_dual and r0[k].cost == r1[k].cost
+            for a, b in zip(w0[k], w1[k]):
+                assert np.array_equal(a, b)
+        for a, b in zip(c0, c1):
+            assert np.array_equal(a, b)
+    st = cj.Settings(max_iter=150, eps_abs=0.0, eps_rel=0.0)
+    both([cj.problems.socp(seed=2300 + k) for k in range(5)], st, True)
+    rng = np.random.default_rng(5)
+    both([util.random_qp(rng, 60, 5, 30, 20, soc_dims=(6, 9)) for _ in range(4)], st, False)                           # P = S S' + shift: not diagonal
+    both([cj.problems.socp(seed=2400 + k) for k in range(3)], cj.Settings(max_iter=120, eps_abs=0.0, eps_rel=0.0, accelerator=cj.AndersonAccelerator), True)
+    both(_small_sdps(3, 11, psd_tri_dims=(6, 11), psd_sq_dims=(4,)), cj.Settings(max_iter=100, eps_abs=0.0, eps_rel=0.0), False)
 
 
 def test_batch_register_kernel_default_schedule_matches_oracle():
