@@ -467,12 +467,15 @@ def bench_cfg3(ctx, args, steps, warmup):
                      "krylov_iterations_per_problem_in_timed_steps": dict(mean=round(float(kry.mean()), 1), max=int(kry.max()), min=int(kry.min()),
                                                                           largest_16=[int(v) for v in np.sort(kry)[::-1][:16]]),
                      "us_per_krylov_iteration_of_the_slowest_problem": round(1e6 * elapsed / max(float(kry.max()), 1.0), 3),
+                     "kernel": B.kernel_info(),
                      "scaling_model": cfg3_scaling_model(cj, kry_all, elapsed, ctx.world)}
     # What bounds the persistent kernel is the LDS: every Krylov iteration streams the problem's LDS image once through the two sparse passes --
-    # A pass: (value 8 B + u16 column + 8 B gathered x) per nonzero; [P | A'] pass: (u16 position + u16 row + 8 B value + 8 B gathered y) per
-    # nonzero of A and (8 + 2 + 8) per nonzero of P.  achieved = MEASURED Krylov iterations of rank 0's problems x those bytes / elapsed, against
+    # A pass: (value 8 B + u16 column + 8 B gathered x) per nonzero; [P | A'] pass: (packed u32 position / row + 8 B value + 8 B gathered y) per
+    # nonzero of A and (8 + 2 + 8) per nonzero of P (a diagonal P sits in registers in the sliced image: those bytes are then not read, the formula keeps
+    # them).  achieved = MEASURED Krylov iterations of rank 0's problems x those bytes / elapsed, against
     # the chip's LDS read peak (guide: ~150 TB/s for ds_read_b64 at 2.4 GHz).  The batch ends with its slowest problem, so the rate is set by
-    # max (not mean) Krylov iterations x the ~7 us one workgroup needs per Krylov iteration: a latency / issue bound chain, not a bandwidth one.
+    # max (not mean) Krylov iterations x the time one workgroup needs per Krylov iteration (`us_per_krylov_iteration_of_the_slowest_problem`): the
+    # serial chain of ONE CU's LDS pipe, not the chip's LDS bandwidth.
     lds_bytes_per_krylov = nnzA * (8 + 2 + 8) + nnzA * (2 + 2 + 8 + 8) + nnzP * (8 + 2 + 8) + 8.0 * (4 * n + 2 * m)
     lds_achieved = float(kry.sum()) * lds_bytes_per_krylov / elapsed / 1e9
     LDS_PEAK_GBS = 150000.0

@@ -1377,10 +1377,12 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     int ph = 0;                                                          // bsum_db: which of the two slot sets the next block sum writes
     if constexpr (SORTED) __syncthreads();                               // (the block sums above read `red`: see bsum_db)
     while (kk < n && !(res <= tol)) {                                    // cg! (IterativeSolvers v0.9), maxiter = n
+      { BT_BEGIN();
       const real beta = (res * res) / (prev * prev);
 #pragma unroll
       for (int j = 0; j < JN; ++j) { const int i = OWN(j); uv[j] = rv[j] + beta * ((kk == 0) ? R(0.0) : uv[j]); if (i >= 0) xv[pn[j]] = uv[j]; }
       __syncthreads();
+      BT_END(6); }
       // The two sparse passes of a Krylov iteration are bound by the CU's LDS pipe, and a wave issues as many steps as its LONGEST row.
       // So thread t COMPUTES the rows ra[] / the column ct[] of the length-sorted assignment (rows of similar length share a wave-step:
       // about a third fewer LDS instructions on BASELINE config 3).  rho .* (A u) goes to its consumers through tv anyway; the column ct[] is
@@ -1435,6 +1437,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
 #ifdef COSMO_BATCH_TIMING
       if (blockIdx.x == 0 && tid == 0) g_bt[3] += 1;
 #endif
+      { BT_BEGIN();
       const real a = (res * res) / uc;
       acc = 0.0;
 #pragma unroll
@@ -1444,6 +1447,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       }
       if constexpr (SORTED) rr = bsum_db<BS>(acc, red, ph); else rr = bsum<BS>(acc, red);
       prev = res; res = sqrt(rr); ++kk;
+      BT_END(7); }
     }
     // nu = rho (A x_tl - ls_s) ; s_tl ; w update
 #pragma unroll

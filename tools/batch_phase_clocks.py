@@ -40,6 +40,6 @@ for label, idx in [("typical (problem 0)", 0)] + [("straggler (problem %d)" % i,
     Bs.iterate(25, with_init=True); Bs.iterate(100)
     c = clocks() - c0
     n = max(int(c[3]), 1)
-    print("%-28s Krylov iterations %6d: A pass %6.0f, column pass (P + A') %6.0f, u'c reduction %5.0f cycles per Krylov iteration; whole kernel %6.0f cycles per Krylov "
-          "iteration (%d ADMM iterations)" % (label, n, c[0] / n, c[1] / n, c[2] / n, c[4] / n, int(c[5])), flush=True)
+    print("%-28s Krylov iterations %6d: head (beta, u, publish, barrier) %5.0f, A pass %6.0f, column pass (P + A') %6.0f, u'c reduction %5.0f, tail (alpha, x / r update, r'r sum, sqrt) %5.0f "
+          "cycles per Krylov iteration; whole kernel %6.0f cycles per Krylov iteration (%d ADMM iterations)" % (label, n, c[6] / n, c[0] / n, c[1] / n, c[2] / n, c[7] / n, c[4] / n, int(c[5])), flush=True)
     Bs.close()
