@@ -823,6 +823,8 @@ def _batch_kernels_take(md: Model) -> bool:
 def prepare_batch_group(models: Sequence[Model], device: int):
     """setup! of every problem of a shard whose problems differ in structure, uploaded into one `_ffi.BatchGroup` (csrc/batch_group.hip: the library
     partitions them into classes of identical (n, m, cones) and solves the classes concurrently), iterates set.  One Settings object for all."""
+    import time
+    t_start = time.perf_counter()
     st = models[0].settings
     for md in models:
         if not md.is_assembled:
@@ -843,7 +845,10 @@ def prepare_batch_group(models: Sequence[Model], device: int):
         bl = [K.l for K in md.sets if K.kind == _ffi.BOX]; bu = [K.u for K in md.sets if K.kind == _ffi.BOX]
         G.set_cones(k, [K.kind for K in md.sets], [K.dim for K in md.sets], np.concatenate(bl) if bl else None, np.concatenate(bu) if bu else None,
                     cone_param=[getattr(K, "alpha", 0.0) for K in md.sets])
-    G.set_params(_params_from_settings(None, st))
+    prm = _params_from_settings(None, st)
+    if st.adaptive_rho and st.adaptive_rho_interval == 0:
+        prm.setup_time = time.perf_counter() - t_start        # ws.times.setup_time of the problems that run on their own handle (solver.jl:246)
+    G.set_params(prm)
     for k, md in enumerate(models):
         G.set_iterates(k, md.x, md.s, md.mu)
     return G, st

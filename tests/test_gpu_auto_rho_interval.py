@@ -75,11 +75,21 @@ def test_device_automatic_interval_equals_the_fixed_interval_runs(accel):
 
 
 @pytest.mark.gpu
-def test_batch_mode_still_refuses_the_automatic_interval():
+def test_batch_kernels_refuse_the_automatic_interval_and_optimize_batch_runs_it_on_handles():
+    """cosmo_hip_batch_* has no host clock inside its persistent kernels and refuses adaptive_rho_interval = 0; optimize_batch sends such a list through
+    the batch group, where every problem gets its own handle and the single-problem rule (csrc/batch_group.hip)."""
     prob = _prob()
     st = cj.Settings(adaptive_rho_interval=0)
-    ms = []
-    for _ in range(2):
-        md = cj.Model(); md.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st); ms.append(md)
+
+    def models():
+        ms = []
+        for _ in range(2):
+            md = cj.Model(); md.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st); ms.append(md)
+        return ms
     with pytest.raises(Exception, match="adaptive_rho_interval"):
-        cj.optimize_batch(ms)
+        cj.model.prepare_batch(models(), 0)
+    res = cj.optimize_batch(models())
+    md = cj.Model(); md.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], cj.Settings(adaptive_rho_interval=0))
+    one = cj.optimize(md)
+    for r in res:
+        assert r.status == one.status == "Solved" and abs(r.obj_val - one.obj_val) <= 1e-4 * (1 + abs(one.obj_val))
