@@ -140,12 +140,15 @@ extern "C" int32_t cosmo_hip_batch_group_set_accelerator(cosmo_hip_batch_group* 
   return COSMO_HIP_OK;
 }
 
-// Partitions the problems into classes of identical structure and finalises one cosmo_hip_batch per class.  An error of a class's own
-// set-up (an unsupported cone, a PSD cone of side > 64, ...) is the group's error, with the offending problem named.
+// Partitions the problems into classes of identical structure and finalises one cosmo_hip_batch per class -- or, where the batch kernels refuse the
+// structure (COSMO_HIP_ERR_UNSUPPORTED), one single-problem handle per member.  Any other error of a class's set-up, and a member that no path of the
+// library takes, is the group's error with the offending problem named; the group then holds no classes and set_params may be called again.
 extern "C" int32_t cosmo_hip_batch_group_set_params(cosmo_hip_batch_group* g, const cosmo_hip_params* prm) {
   if (!g || !prm) return COSMO_HIP_ERR_INVALID;
   if (g->finalized) return gfail(g, COSMO_HIP_ERR_INVALID, "batch_group_set_params: called twice");
   g->prm = *prm;
+  for (auto& c : g->cls) { if (c.b) (void)cosmo_hip_batch_destroy(c.b); for (auto* h : c.hs) if (h) (void)cosmo_hip_destroy(h); }     // (left over from a failed call)
+  g->cls.clear();
   std::map<std::string, int> index;
   for (size_t k = 0; k < g->prob.size(); ++k) {
     GProblem& p = g->prob[k];
@@ -202,9 +205,9 @@ extern "C" int32_t cosmo_hip_batch_group_set_params(cosmo_hip_batch_group* g, co
         if ((hr = cosmo_hip_set_problem(h, p.n, p.m, p.Pp.data(), p.Pi.data(), p.Px.data(), p.Ap.data(), p.Ai.data(), p.Ax.data(), p.q.data(), p.b.data()))) return hbad(hr, h, "set_problem", k);
         if ((hr = cosmo_hip_set_cones_ex(h, (int64_t)p.ctype.size(), p.ctype.data(), p.cdim.data(), p.box_l.empty() ? nullptr : p.box_l.data(),
                                          p.box_u.empty() ? nullptr : p.box_u.data(), p.cparam.data()))) return hbad(hr, h, "set_cones", k);
-        if (g->aa_on && (hr = cosmo_hip_set_accelerator(h, &g->aa))) return hbad(hr, h, "set_accelerator", k);
         if ((hr = cosmo_hip_set_params(h, prm, nullptr))) return hbad(hr, h, "set_params", k);
         if (p.have_scaling && (hr = cosmo_hip_set_scaling(h, p.Dinv.data(), p.Einv.data(), p.cinv))) return hbad(hr, h, "set_scaling", k);
+        if (g->aa_on && (hr = cosmo_hip_set_accelerator(h, &g->aa))) return hbad(hr, h, "set_accelerator", k);      // (the order of optimize_hip! / model.setup)
       }
       continue;
     }

@@ -196,6 +196,13 @@ def test_heterogeneous_batch_members_outside_the_batch_kernels_run_on_their_own_
     assert it.tolist() == [20, 20, 20] and np.all(kry > 0)
     assert G.get_iterates(1)[2].size == 70 * 71 // 2
     G.close()
+    # with the reference's default accelerator: the batch classes run it inside their persistent kernels, the handle member through the loop of api.hip
+    sta = cj.Settings(decompose=False, accelerator=cj.AndersonAccelerator)
+    resa = cj.optimize_batch(_models(probs, sta))
+    for p, r in zip(probs, resa):
+        md = cj.Model(); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], cj.Settings(decompose=False, accelerator=cj.AndersonAccelerator))
+        one = cj.optimize(md)
+        assert r.status == one.status == "Solved" and abs(r.obj_val - one.obj_val) <= 1e-4 * (1 + abs(one.obj_val))
     # MINRES on the reduced system: every member on its own handle
     st = cj.Settings(kkt_solver=cj.IndirectReducedKKTSolverMINRES)
     res = cj.optimize_batch(_models(small, st))
