@@ -281,6 +281,15 @@ template <int TS> struct GemmCfg {
 // MFMAs only ~59 % of the time).
 // Main loop of one tile: acc += A(:, i-block)' panels times B(:, j-block) panels over the k-panels [kb0, kb0 + nk) (kb0 != 0 only with
 // SK = 1: the stream-K kernel).  `qact`: this wave's quadrant is computed (quadrant masking, see symm_gemm_tile).
+// Fragment reads of the main loops: ONE ds_read_b64 per fragment.  Left to itself the compiler pairs the reads of two k-steps into ds_read2st64_b64, and on
+// gfx950 a ds_read2_b64 is two accesses at HALF the LDS rate of two ds_read_b64 (MI355X_MICROARCH.md, LDS table: 128 against 256 bytes per clock).  A volatile
+// access in the LDS address space is not merged (and stays a ds_read, not a flat load): the d = 2000 product 166.8 -> 162.1 us, the batched product of config 5
+// 33.1 -> 32.3-32.9 us, same values (tools/product_lab_both.py; -DPOLAR_LAB_LDS_MERGE restores the plain loads).
+#ifndef POLAR_LAB_LDS_MERGE
+#define FRAG_RD(p) (*(const volatile __attribute__((address_space(3))) real*)(p))
+#else
+#define FRAG_RD(p) (*(p))
+#endif
 template <int TS, int SK>
 __device__ __forceinline__ void symm_mainloop(const real* __restrict__ A, const real* __restrict__ B, int ld, int i0, int j0, bool qact, int kb0, int nk,
                                               real* smem, v4d (&acc)[TS / 32][TS / 32]) {
@@ -333,7 +342,7 @@ __device__ __forceinline__ void symm_mainloop(const real* __restrict__ A, const 
       const real* ap = As + (BUF) * PANEL + (ks * 4 + fk) * PITCH + fa;                                 \
       const real* bp = Bs + (BUF) * PANEL + (ks * 4 + fk) * PITCH + fb;                                 \
       real av[NM], bv[NM];                                                                              \
-      _Pragma("unroll") for (int a = 0; a < NM; ++a) { av[a] = ap[16 * a]; bv[a] = bp[16 * a]; }          \
+      _Pragma("unroll") for (int a = 0; a < NM; ++a) { av[a] = FRAG_RD(ap + 16 * a); bv[a] = FRAG_RD(bp + 16 * a); }          \
       _Pragma("unroll") for (int a = 0; a < NM; ++a)                                                      \
         _Pragma("unroll") for (int b = 0; b < NM; ++b) acc[a][b] = MFMA_REAL(av[a], bv[b], acc[a][b]);     \
     }                                                                                                     \
@@ -760,8 +769,8 @@ __device__ __forceinline__ void symm_mainloop_r(const real* __restrict__ A, cons
     _Pragma("unroll") for (int ks = 0; ks < PK / 4; ++ks) {                                               \
       real av[NSL > 0 ? NSL : 1], bv[NSL > 0 ? NSL : 1];                                                  \
       _Pragma("unroll") for (int sl = 0; sl < NSL; ++sl) {                                                \
-        av[sl] = apb[sl][(BUF) * PANEL + ks * 4 * PITCH];                                                 \
-        bv[sl] = bpb[sl][(BUF) * PANEL + ks * 4 * PITCH];                                                 \
+        av[sl] = FRAG_RD(apb[sl] + (BUF) * PANEL + ks * 4 * PITCH);                                       \
+        bv[sl] = FRAG_RD(bpb[sl] + (BUF) * PANEL + ks * 4 * PITCH);                                       \
       }                                                                                                   \
       _Pragma("unroll") for (int sl = 0; sl < NSL; ++sl) acc[sl] = MFMA_REAL(av[sl], bv[sl], acc[sl]);    \
     }                                                                                                     \
