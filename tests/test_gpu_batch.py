@@ -411,6 +411,38 @@ def test_batch_register_kernel_sliced_image_is_bit_identical_to_the_row_major_im
     both(_small_sdps(3, 11, psd_tri_dims=(6, 11), psd_sq_dims=(4,)), cj.Settings(max_iter=100, eps_abs=0.0, eps_rel=0.0), False)
 
 
+def test_batch_register_kernel_sliced_image_random_structures():
+    """The sliced image on a spread of structures -- fewer rows than one slot (m < 512), a handful of columns, empty rows and columns of A, dense-ish and
+    very sparse matrices, with and without Box / SecondOrderCone rows, diagonal and general P: every batch bit-identical to the row-major image."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(2024)
+    st = cj.Settings(max_iter=40, eps_abs=0.0, eps_rel=0.0)
+    shapes = [(12, 1, 6, 0, (), 0.5), (40, 3, 20, 10, (4,), 0.15), (200, 10, 150, 100, (8, 8, 5), 0.03), (500, 0, 400, 300, (20,) * 10, 0.02),
+              (64, 0, 1000 - 24, 0, (24,), 0.04), (300, 5, 60, 0, (), 0.004), (33, 2, 31, 33, (3,), 0.9), (510, 20, 480, 500, (), 0.01)]
+    for (n, mz, mn, mb, soc, dens) in shapes:
+        probs = [util.random_qp(rng, n, mz, mn, mb, soc_dims=soc, density=dens) for _ in range(2)]
+        if n % 2 == 0:                                                      # every other shape with a diagonal P (it then lives in registers)
+            for p in probs:
+                p["P"] = sp.diags(0.05 + rng.uniform(size=n)).tocsc()
+        if n == 300:                                                        # rows / columns of A without any entry
+            for p in probs:
+                A = p["A"].tolil(); A[5, :] = 0; A[:, 7] = 0; A[:, 8] = 0; p["A"] = A.tocsc(); p["A"].eliminate_zeros()
+        def run():
+            B, _ = cj.model.prepare_batch(_models(probs, st), 0)
+            info = B.kernel_info(); B.optimize()
+            out = [B.get_iterates(k) for k in range(len(probs))]; cnt = B.counters(); B.close()
+            return info, out, cnt
+        i0, w0, c0 = _with_env({"COSMO_HIP_BATCH_SLICED": "0"}, run)
+        i1, w1, c1 = _with_env({}, run)
+        assert i0["form"] == i1["form"] == "register_1_2" and i1["sliced"] and not i0["sliced"], (n, i0, i1)
+        assert i1["p_in_registers"] == (n % 2 == 0)
+        for k in range(2):
+            for a, b in zip(w0[k], w1[k]):
+                assert np.array_equal(a, b), (n, k)
+        for a, b in zip(c0, c1):
+            assert np.array_equal(a, b)
+
+
 def test_batch_register_kernel_default_schedule_matches_oracle():
     # default (inexact) CG schedule on config-3 sized problems through the register-resident kernel, against the oracle
     probs = [cj.problems.socp(seed=3000 + k) for k in range(3)]
