@@ -801,7 +801,7 @@ def bench_cfg5(ctx, args, steps, warmup):
                      "workload_detail": "nnz(A)=%d, PsdConeTriangle cliques, ZeroSet(%d) + Nonnegatives(%d)" % (model.A.nnz, prob["sets"][0].dim, prob["sets"][1].dim),
                      "parallelism": par,
                      "mean_cg_iters_per_admm_iter": round(kbar, 3), "comm": h.bench_comm, "row_shard": h.row_shard_info(), "cg_persist": h.cg_persist_stats(),
-                     "cg_assembled_operator": h.fold_stats(),
+                     "cg_assembled_operator": h.fold_stats(), "kkt_solver": h.kkt_recurrence(),
                      "polar": dict({k: ps[k] for k in ("batch_cones", "schedule_steps", "products_last_batch", "fallback_rounds", "verified", "unverified", "err_max_e18")},
                                    lifting_depth=h.polar_depth_stats())}
     if ctx.world > 1:
@@ -876,18 +876,22 @@ def bench_cfg5(ctx, args, steps, warmup):
         try:
             t_k, b_k, nl = min(h.time_krylov(200) for _ in range(3))
             fs = h.fold_stats()
-            krylov = dict(bound="hbm", limited_by="latency: a chain of dependent launches and load round trips, not bandwidth", kernel=("k_cg_dirM<%d> + k_cg_upd: ONE Krylov iteration of cg! on the assembled reduced operator M = P + sigma I + A' rho A "
-                                                   "(%d nonzeros), %d launches" % (4, fs["nnz"], nl)) if fs["enabled"] else "one Krylov iteration of cg! (%d launches)" % nl,
+            rec = h.kkt_recurrence()                               # the kernel names come from the handle (cosmo_hip_kkt_recurrence)
+            krylov = dict(bound="hbm", limited_by="latency: a chain of dependent launches and load round trips, not bandwidth",
+                          kernel=("%s: ONE Krylov iteration of the reduced CG solve on the assembled operator M = P + sigma I + A' rho A (%d nonzeros), %d launch(es) [%s]"
+                                  % (rec.split(", ", 1)[-1] if ", k_" in rec else rec, fs["nnz"], nl, rec.split(", k_")[0])) if fs["enabled"] else "one Krylov iteration of cg! (%d launches) [%s]" % (nl, rec),
                           achieved=round(b_k / t_k / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(b_k / t_k / 1e9 / HBM_PEAK_GBS, 4), traffic=None,
                           algorithmic_bytes_per_launch=b_k, avg_launch_us=round(1e6 * t_k, 3), launches_timed=200,
                           timing="best of 3 x 200 Krylov iterations as the loop enqueues them (captured chain), tolerance 0, HIP events on the library's stream; "
-                                 "'launch' = one Krylov iteration = %d dependent kernels incl. their boundaries" % nl,
+                                 "'launch' = one Krylov iteration = %d dependent kernel(s) incl. the boundaries" % nl,
                           krylov_iterations_per_step=round(kbar, 2), share_of_step=round(kbar * 1e3 * t_k / ms_step, 4),
                           note="a chain of dependent round trips (the eight L2s are invalidated at every kernel boundary, operands come back through the fabric / "
                                "Infinity Cache): the HBM fraction is reported because the contract asks for it; what bounds the pair is launch + load latency")
             if pmc5 is not None and fs["enabled"]:
-                krylov["traffic"] = pmc5[0]["krylov_iteration_pair"]["hbm_bytes_per_krylov_iteration"]
-                krylov["traffic_source"] = pmc5[1]
+                key = "krylov_iteration_one_launch" if nl == 1 else "krylov_iteration_pair"
+                if key in pmc5[0]:
+                    krylov["traffic"] = pmc5[0][key]["hbm_bytes_per_krylov_iteration"]
+                    krylov["traffic_source"] = pmc5[1]
         except Exception as e:
             krylov = dict(error="%s: %s" % (type(e).__name__, e))
     cands = [r for r in (krylov, products) if r and "share_of_step" in r]
@@ -916,6 +920,11 @@ def bench_cfg5(ctx, args, steps, warmup):
             out["pcg"] = jacobi_pcg_extra(ctx, args, prob, steps, warmup)
         except Exception as e:
             out["pcg"] = dict(error="%s: %s" % (type(e).__name__, e))
+        if KKT_CHOICE["name"] == "cg" and not args.no_variants:
+            try:
+                out["single_reduction_cg"] = single_reduction_extra(ctx, args, prob, steps, warmup, value, kbar)
+            except Exception as e:
+                out["single_reduction_cg"] = dict(error="%s: %s" % (type(e).__name__, e))
         if not args.no_variants:
             try:
                 out["adaptive_lifting_depth"] = adaptive_depth_extra(ctx, args, prob, steps, warmup, value)
@@ -947,6 +956,27 @@ def adaptive_depth_extra(ctx, args, prob, steps, warmup, value_fixed):
         return out
     finally:
         os.environ.pop("COSMO_HIP_POLAR_ADAPT", None)
+
+
+def single_reduction_extra(ctx, args, prob, steps, warmup, value_literal, kbar_literal):
+    """The same workload with the OPT-IN single-reduction (Chronopoulos-Gear) recurrence (kkt_kind CG_SR): ONE launch per Krylov iteration on the
+    assembled operator (csrc/cg_sr.hip: k_sr_M, captured chain, device-side iteration index).  Round 6 measured it as a candidate default for
+    assembled operators and rejected it -- slower per iteration (24-byte gathers) and more iterations at tight thresholds; the leg
+    stays so that the decision is re-measured by every run."""
+    import cosmo_jl_amd as cj
+    st = fixed_work_settings(cj, kkt_solver=cj.CGSingleReductionKKTSolver); st.device = ctx.local_rank
+    md = cj.Model(); md.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)
+    h, el, kb = _run_sdp(ctx, md, steps, warmup)
+    out = dict(value=round(steps / el, 3), ms_per_step=round(1e3 * el / steps, 6), steps=steps, warmup=warmup, unit="ADMM iterations/s", dtype="f64",
+               kkt_solver=h.kkt_recurrence(), mean_cg_iters_per_admm_iter=round(kb, 3),
+               vs_literal=round((steps / el) / value_literal, 4), krylov_iterations_per_step_minus_literal=round(kb - kbar_literal, 3))
+    try:
+        t_k, b_k, nl = min(h.time_krylov(200) for _ in range(3))
+        out["us_per_krylov_iteration"] = round(1e6 * t_k, 3)
+    except Exception as e:
+        out["us_per_krylov_iteration"] = "%s: %s" % (type(e).__name__, e)
+    h.close()
+    return out
 
 
 def jacobi_pcg_extra(ctx, args, prob, steps, warmup):
@@ -1010,7 +1040,7 @@ def main():
     ap.add_argument("--no-float32", action="store_true", help="skip the Float32 (libcosmo_hip_f32.so) side numbers of cfg4 / cfg5")
     ap.add_argument("--cpu-sample-iters", type=int, default=5)
     ap.add_argument("--kkt", choices=["cg", "cg-sr"], default="cg",
-                    help="cg: the literal cg! recurrence (default, the reference's algorithm); cg-sr: opt-in single-reduction CG (csrc/cg_sr.hip)")
+                    help="cg: the literal cg! recurrence (default, the reference's algorithm; config.kkt_solver names the kernels); cg-sr: opt-in single-reduction CG (csrc/cg_sr.hip)")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the clock warm-up launches of the product kernel (profiling runs: kernel statistics of the loop's own launches only)")
     ap.add_argument("--exact-launches", action="store_true",
                     help="cfg2: synchronise after every Krylov iteration (rocprofv3 runs: every launch does full work)")
@@ -1054,15 +1084,17 @@ def main():
         out = {"metric": METRIC, "value": round(res["value"], 3), "unit": "ADMM iterations/s", "n_gpus": ctx.world, "steps": res["steps"], "warmup": res["warmup"],
                "ms_per_step": round(res["ms_per_step"], 6), "higher_is_better": True, "scaling": res["scaling"], "vs_baseline": None, "dtype": "f64",
                "data": "synthetic", "config": res.get("config", {}), "roofline": res.get("roofline")}
-        out["config"]["kkt_solver"] = ("CG, literal cg! recurrence (reference algorithm)" if args.kkt == "cg" else
-                                       "CG, single-reduction (Chronopoulos-Gear) recurrence -- OPT-IN variant, same operator / stopping rule")
+        # which Krylov recurrence ran comes from the handle (cosmo_hip_kkt_recurrence); workloads that do not report it ran kkt_kind CG
+        out["config"].setdefault("kkt_solver", "CGIndirectKKTSolver (--kkt %s)" % args.kkt)
+        out["config"]["kkt_solver_requested"] = {"cg": "CGIndirectKKTSolver (kkt_kind CG: the literal cg! recurrence, the reference's algorithm)",
+                                                 "cg-sr": "kkt_kind CG_SR: single-reduction (Chronopoulos-Gear) recurrence -- OPT-IN variant, same operator / stopping rule"}[args.kkt]
         out["config"]["launch"] = ("self-launched torch.distributed.run" if os.environ.get("COSMO_BENCH_SELF_LAUNCHED") else
                                    "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "single process")
         if ctx.shm:
             out["data"] = "synthetic; DRY RUN of the multi-rank path: all ranks share one GPU (COSMO_BENCH_TRANSPORT=shm), not a measurement"
         if "cpu_baseline" in res:
             out["cpu_baseline"] = res["cpu_baseline"]
-        var = {k: res[k] for k in ("pcg", "adaptive_lifting_depth", "float32") if k in res}      # opt-in variants of the headline workload: next to, never instead of, `value`
+        var = {k: res[k] for k in ("single_reduction_cg", "pcg", "adaptive_lifting_depth", "float32") if k in res}      # opt-in variants of the headline workload: next to, never instead of, `value`
         if var:
             out["variants"] = var
         if extra:

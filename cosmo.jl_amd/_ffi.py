@@ -94,6 +94,7 @@ SIGNATURES = {
     "cosmo_hip_get_iterates": (C.c_int32, [C.c_void_p, _PR, _PR, _PR, _PR]),
     "cosmo_hip_cg_persist_stats": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_fold_stats": (C.c_int32, [C.c_void_p, _PI64]),
+    "cosmo_hip_kkt_recurrence": (C.c_char_p, [C.c_void_p]),
     "cosmo_hip_get_kkt_solution": (C.c_int32, [C.c_void_p, _PR]),
     "cosmo_hip_get_stats": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_set_setup_time": (C.c_int32, [C.c_void_p, C.c_double]),
@@ -432,6 +433,10 @@ class Handle:
         out = np.zeros(8, dtype=np.int64)
         self._chk(self.lib.cosmo_hip_cg_persist_stats(self._h, out.ctypes.data_as(_PI64)))
         return dict(zip(["enabled", "workgroups", "launches", "fallbacks", "tickets", "arrivals", "abort", "lds_per_quarter"], out.tolist()))
+
+    def kkt_recurrence(self):
+        """Which Krylov recurrence / kernels the KKT solves of this handle run (cosmo_hip_kkt_recurrence)."""
+        return self.lib.cosmo_hip_kkt_recurrence(self._h).decode()
 
     def fold_stats(self):
         out = np.zeros(4, dtype=np.int64)

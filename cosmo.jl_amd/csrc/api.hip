@@ -556,6 +556,20 @@ int32_t build_op_split(cosmo_hip_handle* h, bool force) {
   return refresh_op_split(h);
 }
 
+// LAB SWITCH (COSMO_HIP_CG_SR_DEFAULT=1; round 6): kkt_kind CG on an ASSEMBLED reduced operator runs the one-launch
+// single-reduction recurrence (cg_sr.hip: k_sr_M) instead of the literal pair.  Measured as a candidate default and REJECTED (BASELINE config 5:
+// 12.42 vs 11.50 us per Krylov iteration -- the 24-byte gathers of {r, w, s} from 32-byte records cost more than the launch they save, every
+// XCD re-fetches the whole table through the fabric at each kernel boundary --, 236.6 vs 244.9 it/s; and at a 1e-10 stopping threshold the
+// recurrence needs +1.2 % Krylov iterations, outside the +-1 per solve the parity tests allow; profiles/r06_cg_one_launch_default.txt).
+int32_t choose_cg_recurrence(cosmo_hip_handle* h) {
+  if (h->prm.kkt_kind != COSMO_HIP_KKT_CG || h->cg_jacobi || h->cg_sr || !h->op_fold) return COSMO_HIP_OK;
+  const char* e = getenv("COSMO_HIP_CG_SR_DEFAULT");
+  if (!e || atoi(e) == 0) return COSMO_HIP_OK;
+  h->cg_sr = true; h->cg_sr_auto = true;
+  dfree(&h->cg_ru);                      // the {r, u} records of the literal pair
+  return sr_alloc(h);
+}
+
 extern "C" int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_params* p, const real* rho_vec) {
   ENTER(h);
   if (h->row_shard) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "set_params: not available on a row-sharded handle");
@@ -569,6 +583,7 @@ extern "C" int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_par
   h->prm = *p;
   h->auto_rho_fixed_at = -1;
   h->cg_sr = (p->kkt_kind == COSMO_HIP_KKT_CG_SR);
+  h->cg_sr_auto = false;
   h->cg_jacobi = (p->kkt_kind == COSMO_HIP_KKT_CG_JACOBI);
   if (h->cg_sr || h->cg_jacobi) h->prm.kkt_kind = COSMO_HIP_KKT_CG;      // the same reduced operator, split, budget and tail; only the Krylov recurrence differs
   if (reclass) {
@@ -600,6 +615,7 @@ extern "C" int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_par
     if (const char* e = getenv("COSMO_HIP_CG_FUSE_DIR")) fuse = fuse && atoi(e) != 0;
     if (fuse) CHK(dalloc(h, &h->cg_ru, 2 * (size_t)h->n)); }
   CHK(build_op_split(h));     // needs the (scaled) matrices and rho: both final from here on
+  CHK(choose_cg_recurrence(h));
   if (h->cg_jacobi) {
     // the opt-in Jacobi-preconditioned CG lives on the ASSEMBLED reduced operator (its diagonal is the preconditioner): no silent fallback to the
     // unpreconditioned recurrence when the operator cannot be assembled (dense A' rho A: BASELINE config 2, where Jacobi makes the count worse anyway)
@@ -1407,7 +1423,7 @@ extern "C" int32_t cosmo_hip_time_spmv(cosmo_hip_handle* h, int32_t which, int32
 extern "C" int32_t cosmo_hip_time_krylov(cosmo_hip_handle* h, int32_t reps, double* avg_seconds, double* algorithmic_bytes, int32_t* launches_per_iteration) {
   ENTER(h);
   if (!h->have_params || !h->have_iterates || reps <= 0 || !avg_seconds) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "time_krylov: set up the loop first");
-  if (h->prm.kkt_kind != COSMO_HIP_KKT_CG || h->cg_sr || h->pcg_on || h->row_shard) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "time_krylov: the literal / Jacobi CG of the loop on an unsharded handle only");
+  if (h->prm.kkt_kind != COSMO_HIP_KKT_CG || (h->cg_sr && !h->op_fold) || h->pcg_on || h->row_shard) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "time_krylov: the CG recurrences of the loop (literal, Jacobi, one-launch single-reduction on the assembled operator) on an unsharded handle only");
   CHK(sync_ctl(h));
   if (h->ctl_host->halt) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "time_krylov: the loop is halted");
   const long long n = h->n, m = h->m;
@@ -1419,10 +1435,11 @@ extern "C" int32_t cosmo_hip_time_krylov(cosmo_hip_handle* h, int32_t reps, doub
   const long long sp[3] = {h->spmv_calls[0], h->spmv_calls[1], h->spmv_calls[2]};
   int32_t rc = enqueue_y2_only(h);                             // resets the per-solve flags (y2 = rho .* ls_s is recomputed to the same values)
   if (rc == COSMO_HIP_OK) rc = enqueue_cg_start(h, 1, R(0.0)); // tolerance 0: every one of the `reps` iterations does full work
+  if (rc == COSMO_HIP_OK && h->cg_sr) rc = sr_enqueue_start(h, 1);
   if (rc == COSMO_HIP_OK && hipEventRecord(e0, h->stream) != hipSuccess) rc = cosmo_fail(h, COSMO_HIP_ERR_HIP, "hipEventRecord failed");
   const int likely = h->cg_k_likely;
   h->cg_k_likely = 0x7fffffff;
-  if (rc == COSMO_HIP_OK) rc = enqueue_cg_iterations(h, 1, 0, reps);
+  if (rc == COSMO_HIP_OK) rc = h->cg_sr ? sr_enqueue_iterations(h, 1, 0, reps) : enqueue_cg_iterations(h, 1, 0, reps);
   h->cg_k_likely = likely;
   if (rc == COSMO_HIP_OK && hipEventRecord(e1, h->stream) != hipSuccess) rc = cosmo_fail(h, COSMO_HIP_ERR_HIP, "hipEventRecord failed");
   if (rc == COSMO_HIP_OK && hipEventSynchronize(e1) != hipSuccess) rc = cosmo_fail(h, COSMO_HIP_ERR_HIP, "hipEventSynchronize failed");
@@ -1442,6 +1459,8 @@ extern "C" int32_t cosmo_hip_time_krylov(cosmo_hip_handle* h, int32_t reps, doub
     bytes = 12.0 * (double)f->M.nnz + 4.0 * (n + 1) + 16.0 * n + 8.0 * 10.0 * n;       // B_spmv(M) + B_cgvec (n-side); Jacobi adds dinv: + 8 n
     if (h->cg_jacobi) bytes += 8.0 * n;
     nl = 2;
+    if (h->cg_sr) nl = 1;      // one-launch recurrence: the SAME algorithmic bytes (SURVEY 8d prices a Krylov iteration of the reference: operator + 10 n-vectors; the
+                               // records {r, w, s, p} read and written once by their owners + x read and written are 10 n words too)
   } else {
     const CsrDev& Ao = h->op_split ? h->Am : h->A;
     const CsrDev& PTo = h->op_split ? h->PTm : h->PT;
@@ -1451,6 +1470,30 @@ extern "C" int32_t cosmo_hip_time_krylov(cosmo_hip_handle* h, int32_t reps, doub
   if (algorithmic_bytes) *algorithmic_bytes = bytes;
   if (launches_per_iteration) *launches_per_iteration = nl;
   return COSMO_HIP_OK;
+}
+
+extern "C" const char* cosmo_hip_kkt_recurrence(cosmo_hip_handle* h) {
+  if (!h || !h->have_params) return "not set up";
+  static const char* sr_names[] = {"", "k_sr_M<1>", "k_sr_M<2>", "k_sr_M<3>", "k_sr_M<4>", "", "", "", "k_sr_M<8>"};
+  static const char* pair_names[] = {"", "k_cg_dirM<1, false> + k_cg_upd<false>", "k_cg_dirM<2, false> + k_cg_upd<false>", "k_cg_dirM<3, false> + k_cg_upd<false>",
+                                     "k_cg_dirM<4, false> + k_cg_upd<false>", "", "", "", "k_cg_dirM<8, false> + k_cg_upd<false>"};
+  static const char* pc_names[] = {"", "k_cg_dirM<1, true> + k_cg_upd<true>", "k_cg_dirM<2, true> + k_cg_upd<true>", "k_cg_dirM<3, true> + k_cg_upd<true>",
+                                   "k_cg_dirM<4, true> + k_cg_upd<true>", "", "", "", "k_cg_dirM<8, true> + k_cg_upd<true>"};
+  static thread_local char buf[256];
+  if (h->prm.kkt_kind == COSMO_HIP_KKT_MINRES) return "minres on the full KKT system (csrc/minres.hip)";
+  if (h->prm.kkt_kind == COSMO_HIP_KKT_MINRES_REDUCED) return "minres on the reduced system (csrc/minres.hip)";
+  const FoldPlan* f = (const FoldPlan*)h->fold;
+  const int sl = (h->op_fold && f) ? ((f->slots >= 1 && f->slots <= 4) ? f->slots : 8) : 0;
+  if (h->pcg_on) return "cg: literal recurrence in one persistent launch (csrc/cg_persist.hip, opt-in)";
+  if (h->cg_jacobi) { snprintf(buf, sizeof buf, "cg: Jacobi-preconditioned recurrence on the assembled operator (opt-in), %s", pc_names[sl]); return buf; }
+  if (h->cg_sr && h->op_fold) {
+    snprintf(buf, sizeof buf, "cg: one-launch single-reduction recurrence on the assembled operator%s, %s", h->cg_sr_auto ? " (lab switch COSMO_HIP_CG_SR_DEFAULT=1)" : " (opt-in kkt_kind CG_SR)", sr_names[sl]);
+    return buf;
+  }
+  if (h->cg_sr) return "cg: single-reduction recurrence, two launches per iteration (kkt_kind CG_SR), k_sr_update_A + k_sr_op";
+  if (h->op_fold) { snprintf(buf, sizeof buf, "cg: literal recurrence on the assembled operator, two launches per iteration, %s", pair_names[sl]); return buf; }
+  return h->cg_ru ? "cg: literal recurrence, three launches per iteration, k_cg_dirA + k_op_apply + k_cg_upd<false>"
+                  : "cg: literal recurrence, four launches per iteration, k_cg_dir + k_spmv_A_rho + k_op_apply + k_cg_upd<false>";
 }
 
 extern "C" int32_t cosmo_hip_set_profiling(cosmo_hip_handle* h, int32_t on) {

@@ -253,6 +253,8 @@ void fold_free(cosmo_hip_handle* h) {
   if (f->dinv) (void)hipFree(f->dinv);
   if (f->chain) (void)hipGraphExecDestroy((hipGraphExec_t)f->chain);
   if (f->chain_cf) (void)hipGraphExecDestroy((hipGraphExec_t)f->chain_cf);
+  if (f->sr_chain) (void)hipGraphExecDestroy((hipGraphExec_t)f->sr_chain);
+  if (f->sr_chain_cf) (void)hipGraphExecDestroy((hipGraphExec_t)f->sr_chain_cf);
   delete f;
   h->fold = nullptr;
 }

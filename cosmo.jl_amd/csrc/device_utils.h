@@ -108,6 +108,17 @@ __device__ __forceinline__ real block_sum(real v, real* red) {
   for (int i = 0; i < COSMO_BS / 64; ++i) t += red[i];
   return t;
 }
+// two sums behind ONE pair of barriers (red2: 2 * COSMO_BS/64 reals); each is added exactly as block_sum adds it (same bits)
+__device__ __forceinline__ void block_sum2(real& a, real& b, real* red2) {
+  a = wave_sum(a); b = wave_sum(b);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { red2[threadIdx.x >> 6] = a; red2[COSMO_BS / 64 + (threadIdx.x >> 6)] = b; }
+  __syncthreads();
+  real t = 0.0, u = 0.0;
+#pragma unroll
+  for (int i = 0; i < COSMO_BS / 64; ++i) { t += red2[i]; u += red2[COSMO_BS / 64 + i]; }
+  a = t; b = u;
+}
 __device__ __forceinline__ real block_max(real v, real* red) {
   v = wave_max(v);
   __syncthreads();

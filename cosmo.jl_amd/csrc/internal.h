@@ -66,6 +66,8 @@ struct Ctl {
   real minres[16]; // MINRES scalar recurrences, two parity slots of 8 (see minres.hip)
   real udotc_slot; // <v_curr, v_next> of the current MINRES iteration
   real sr_gamma[2], sr_alpha[2];   // single-reduction CG (cg_sr.hip): r'r and alpha of the last two iterations, by parity
+  int sr_k[2];       // single-reduction CG, captured chain: the launch of parity p reads its iteration index from sr_k[p] and publishes k + 1 in
+                     // sr_k[p ^ 1] (cg_k is rewritten by workgroup 0 WHILE the other workgroups of the same launch would read it)
   real rho_updates[COSMO_HIP_MAX_RHO_UPDATES];
 };
 
@@ -107,6 +109,10 @@ struct FoldPlan {
   void* chain_cf = nullptr; // the same chain with check_first = 1 (iterations expected to be no-ops)
   int chain_len = 0;        // Krylov iterations per launch of the chain
   int chain_off = 0;        // COSMO_HIP_CG_GRAPH=0
+  // the same for the one-launch single-reduction recurrence (cg_sr.hip: k_sr_M); chain_len is even there (records / partials alternate by parity)
+  void* sr_chain = nullptr;
+  void* sr_chain_cf = nullptr;
+  int sr_chain_len = 0;
 };
 
 struct HostCsr {  // host staging of a CSR matrix (0-based)
@@ -186,7 +192,8 @@ struct cosmo_hip_handle {
   void* psd_polar = nullptr;      // PolarPlan (psd_polar.hip): large cones
   void* accel = nullptr;          // AaState (anderson.hip)
   long long safeguarding_iter = 0;
-  bool cg_sr = false;             // kkt_kind COSMO_HIP_KKT_CG_SR: single-reduction (Chronopoulos-Gear) CG, cg_sr.hip
+  bool cg_sr = false;             // single-reduction (Chronopoulos-Gear) CG, cg_sr.hip: kkt_kind COSMO_HIP_KKT_CG_SR (or the lab switch behind cg_sr_auto)
+  bool cg_sr_auto = false;        // lab switch COSMO_HIP_CG_SR_DEFAULT=1: kkt_kind CG took the one-launch recurrence on an assembled operator (measured and rejected as the default, api.hip: choose_cg_recurrence)
   long long auto_rho_fixed_at = -1;   // iteration at which the automatic rho interval (adaptive_rho_interval == 0, solver.jl:244-256) was fixed; -1: not (yet)
   bool cg_jacobi = false;  // kkt_kind CG_JACOBI: opt-in Jacobi-preconditioned CG on the assembled operator (cg_fold.hip)
   void* sr_rec = nullptr;         // 2 n records {r, w, s, p}
@@ -277,6 +284,7 @@ int32_t prof_collect(cosmo_hip_handle* h);
 
 // CG operator split
 int32_t build_op_split(cosmo_hip_handle* h, bool force = false);
+int32_t choose_cg_recurrence(cosmo_hip_handle* h);      // api.hip: kkt_kind CG on an assembled operator -> the one-launch recurrence of cg_sr.hip
 int32_t refresh_op_split(cosmo_hip_handle* h);
 void free_op_split(cosmo_hip_handle* h);
 

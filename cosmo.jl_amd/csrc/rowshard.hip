@@ -86,7 +86,7 @@ extern "C" int32_t cosmo_hip_set_row_shard(cosmo_hip_handle* h, const int64_t* f
 
   // 1. the reduced operator must not depend on h->A / h->rho: force the split form (Am = rows with >= 2 nonzeros, diagonal from the
   //    singleton rows; assembled where sparse enough) and stop the single-launch CG, whose operands are sized at set_params time
-  if (!h->op_split) CHK(build_op_split(h, true));
+  if (!h->op_split) { CHK(build_op_split(h, true)); CHK(choose_cg_recurrence(h)); }
   if (!h->op_split) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "set_row_shard: no split form of the reduced operator (empty A?)");
   if (h->pcg_on) { pcg_free(h); h->pcg_on = false; }
 

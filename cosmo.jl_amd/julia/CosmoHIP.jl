@@ -264,6 +264,7 @@ function time_krylov(h::Handle, reps::Integer)      # measurement hook: seconds 
     return (seconds = t[], bytes = b[], launches = nl[])
 end
 
+kkt_recurrence(h::Handle) = unsafe_string(ccall((:cosmo_hip_kkt_recurrence, lib(h)), Cstring, (Ptr{Cvoid},), h.ptr))   # which Krylov recurrence / kernels the handle's KKT solves run
 function fold_stats(h::Handle)      # assembled reduced CG operator (cosmo_hip_fold_stats)
     out = zeros(Int64, 4)
     check(h, ccall((:cosmo_hip_fold_stats, lib(h)), Int32, (Ptr{Cvoid}, Ptr{Int64}), h.ptr, out))

@@ -72,19 +72,23 @@ enum {
 
 /* ---- KKT solver kinds: AbstractKKTSolver subtypes (src/linear_solver/kktsolver_indirect.jl) -------- */
 enum {
-  COSMO_HIP_KKT_CG = 0,             /* CGIndirectKKTSolver      :173-178 (IndirectReducedKKTSolver, :CG)     */
+  COSMO_HIP_KKT_CG = 0,             /* CGIndirectKKTSolver      :173-178 (IndirectReducedKKTSolver, :CG): the literal recurrence of
+                                       IterativeSolvers v0.9's cg! everywhere (cosmo_hip_kkt_recurrence names the kernels that run it)  */
   COSMO_HIP_KKT_MINRES_REDUCED = 1, /* IndirectReducedKKTSolver :3-88 with solver_type = :MINRES            */
   COSMO_HIP_KKT_MINRES = 2,         /* MINRESIndirectKKTSolver  :180-185 (IndirectKKTSolver, full KKT)      */
   COSMO_HIP_KKT_CG_SR = 3           /* OPT-IN, no reference counterpart: the reduced CG solve as single-reduction (Chronopoulos-Gear) CG --
                                        same operator, stopping rule and warm start as COSMO_HIP_KKT_CG, algebraically equal iterates, two
-                                       launches per Krylov iteration; not bit-comparable with the literal recurrence (csrc/cg_sr.hip) */
+                                       launches per Krylov iteration (ONE on an assembled operator); not bit-comparable with the literal
+                                       recurrence (csrc/cg_sr.hip).  Measured in round 6 as a candidate DEFAULT for assembled operators and
+                                       rejected: 12.4 vs 11.5 us per Krylov iteration on BASELINE config 5 (24-byte gathers), +1.2 % Krylov
+                                       iterations at a 1e-10 stopping threshold */
   ,
   COSMO_HIP_KKT_CG_JACOBI = 4       /* OPT-IN, no reference counterpart (the reference calls cg! without a preconditioner,
                                        src/linear_solver/kktsolver_indirect.jl:70): IterativeSolvers' preconditioned recurrence (PCGIterable) with
                                        Pl = Diagonal(diag(P + sigma I + A' rho A)) on the ASSEMBLED reduced operator; same operator, warm start
                                        and true-residual stopping rule ||r||_2 <= tol_k / ||rhs||, DIFFERENT iterates (every solve ends at another
                                        point inside the same tolerance).  cosmo_hip_set_params fails with UNSUPPORTED where the operator cannot be
-                                       assembled (csrc/cg_fold.hip).  Never the parity path; the literal cg! stays the default. */
+                                       assembled (csrc/cg_fold.hip).  Never the parity path. */
 };
 
 /* ---- solver status (Result.status symbols, src/solver.jl:113,175,312,318,338,344,353) -------------- */
@@ -178,7 +182,7 @@ const char* cosmo_hip_last_error(const cosmo_hip_handle* h);
 /* ABI version of the library (major*1000 + minor).  COSMO_HIP_ABI_VERSION is the version THIS header describes; the bindings generated from
  * it (cosmo.jl_amd/_abi_structs.py, julia/abi_structs.jl) carry the same number and refuse a library that reports another one: a stale
  * .so paired with newer struct mirrors would read garbage, a newer .so would write past an older caller's cosmo_hip_result. */
-#define COSMO_HIP_ABI_VERSION 1002
+#define COSMO_HIP_ABI_VERSION 1003
 int32_t cosmo_hip_version(void);
 void cosmo_hip_default_params(cosmo_hip_params* p);
 
@@ -299,6 +303,10 @@ int32_t cosmo_hip_get_kkt_solution(cosmo_hip_handle* h, cosmo_hip_real* sol);
  * operator split leaves a sparse Am' rho Am (decomposed SDPs), two launches per Krylov iteration instead of three.
  * out = {enabled, nnz(M), rho-weighted terms behind its entries, CSR-stream tiles}.  COSMO_HIP_OP_FOLD=0 in the environment disables it. */
 int32_t cosmo_hip_fold_stats(cosmo_hip_handle* h, int64_t out[4]);
+/* Which Krylov recurrence / kernels the KKT solves of this handle run (valid after cosmo_hip_set_params; a string owned by the library, e.g.
+ * "cg: literal recurrence on the assembled operator, two launches per iteration, k_cg_dirM<3, false> + k_cg_upd<false>"): bench.py's
+ * config.kkt_solver and roofline.kernel. */
+const char* cosmo_hip_kkt_recurrence(cosmo_hip_handle* h);
 /* Statistics of the device loop since set_iterates: out = {admm_iters, kkt_solves, kkt_iters_total,
  * kkt_budget_stalls, spmv_A_calls, spmv_AT_calls, spmv_P_calls, rho_updates}. */
 int32_t cosmo_hip_get_stats(cosmo_hip_handle* h, int64_t out[8]);

@@ -81,3 +81,41 @@ def test_default_tolerance_solve_matches_the_oracle():
     ref = O.solve(prob["P"], prob["q"], prob["A"], prob["b"], util.oracle_cones(prob["sets"]), O.Settings(kkt_solver="cg"))
     assert r.status == ref.status == "Solved" and abs(r.iter - ref.iter) <= 25
     assert abs(r.obj_val - ref.obj_val) <= 1e-4 * (1 + abs(ref.obj_val))
+
+
+@pytest.mark.parametrize("chain_len", ["16", "3", "1"])
+def test_one_launch_recurrence_captured_chain_is_bit_identical_to_direct_launches(chain_len, monkeypatch):
+    """Round 6: on the assembled operator the single-reduction recurrence is ONE kernel per Krylov iteration (k_sr_M) and its speculative iterations go
+    out as a captured chain with the iteration index read on the device (ctl->sr_k[parity]; records and partial slots alternate by parity, so an odd
+    COSMO_HIP_CG_GRAPH_LEN is rounded up).  COSMO_HIP_CG_GRAPH=0 launches every kernel directly with the index as an argument: same bits, same
+    Krylov counts, same number of enqueued iterations -- default schedule (rho adaptation) and tight mode."""
+    monkeypatch.setenv("COSMO_HIP_OP_FOLD", "1")
+    prob = PROBLEMS["chordal_sdp_split_operator"]()
+    for kw in (dict(), dict(tol_constant=1e-10, tol_exponent=0.0)):
+        res = {}
+        for graph in ("0", "1"):
+            monkeypatch.setenv("COSMO_HIP_CG_GRAPH", graph)
+            monkeypatch.setenv("COSMO_HIP_CG_GRAPH_LEN", chain_len)
+            st = cj.Settings(kkt_solver=cj.with_options(cj.CGSingleReductionKKTSolver, **kw), max_iter=90, eps_abs=0.0, eps_rel=0.0, check_infeasibility=10 ** 9)
+            md = cj.Model(); md.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)
+            r = cj.optimize(md)
+            assert md.handle.fold_stats()["enabled"] == 1 and "one-launch single-reduction" in md.handle.kkt_recurrence() and "k_sr_M<" in md.handle.kkt_recurrence()
+            res[graph] = (r, md.handle.get_stats())
+        (r0, s0), (r1, s1) = res["0"], res["1"]
+        assert r0.iter == r1.iter == 90
+        assert np.array_equal(r0.x, r1.x) and np.array_equal(r0.s, r1.s) and np.array_equal(r0.y, r1.y)
+        assert s0["kkt_iters_total"] == s1["kkt_iters_total"] > 0 and s0["kkt_budget_stalls"] == s1["kkt_budget_stalls"]
+        assert list(r0.info.rho_updates) == list(r1.info.rho_updates)
+
+
+def test_kkt_recurrence_names_the_kernels_that_run(monkeypatch):
+    """cosmo_hip_kkt_recurrence: kkt_kind CG is the literal recurrence everywhere (two launches on an assembled operator, three on the split one); the
+    one-launch form is opt-in (kkt_kind CG_SR) -- round 6 measured it as a default for assembled operators and rejected it."""
+    monkeypatch.setenv("COSMO_HIP_OP_FOLD", "1")
+    prob = PROBLEMS["chordal_sdp_split_operator"]()
+    _, md = _run(prob, cj.CGIndirectKKTSolver, 2)
+    assert md.handle.kkt_recurrence().startswith("cg: literal recurrence on the assembled operator, two launches per iteration, k_cg_dirM<")
+    _, md = _run(PROBLEMS["box_qp"](), cj.CGIndirectKKTSolver, 2)
+    assert md.handle.kkt_recurrence().startswith("cg: literal recurrence, three launches per iteration, k_cg_dirA + k_op_apply + k_cg_upd<false>")
+    _, md = _run(prob, cj.CGJacobiKKTSolver, 2)
+    assert "Jacobi" in md.handle.kkt_recurrence() and "k_cg_dirM<" in md.handle.kkt_recurrence()
