@@ -617,6 +617,7 @@ def _run_sdp(ctx, model, steps, warmup, dist=None, shard="rows"):
     h.admm_iterate_checked(warmup)
     s0 = h.get_stats()
     c0 = h.comm_stats_ex()
+    h.polar_dataflow_stats(reset=True)                             # event timing of the persistent sign-iteration launch: the timed window only
     elapsed = ctx.timed(lambda: h.admm_iterate_checked(steps))
     s1 = h.get_stats()
     c1 = h.comm_stats_ex()
@@ -839,20 +840,43 @@ def bench_cfg5(ctx, args, steps, warmup):
         own = dk if ctx.world == 1 else None                      # rank 0's cliques only in sharded runs: useful flops not attributed there
         useful_prod = float(np.sum(dk * dk * (dk + 1.0))) if own is not None else None
         nprod = ps["products_last_batch"]
-        products = dict(bound="mfma", kernel="k_symm_gemm_batch_r<EPI, 4> (ragged block-balanced tiles: one workgroup per list of <= 16 blocks of 16 x 16 of one of rank 0's "
-                                            "cliques; upper blocks only on the diagonal; four workgroups per CU, tiles launched by decreasing cost)",
-                        timing="in-loop mix: 20 x (Y = U^2, T = c Y^2 + b Y, U' = U T + a U) on the batch's work matrices, HIP events on the library's stream",
-                        useful_flops_per_launch=useful_prod, performed_over_useful=(round(fl / useful_prod, 3) if useful_prod else None),
-                        useful_frac_per_product=(round(useful_prod / t_prod / 1e12 / F64_MFMA_PEAK_TF, 4) if useful_prod else None),
-                        achieved=round(fl / t_prod / 1e12, 2), peak=F64_MFMA_PEAK_TF, unit="TFLOP/s", frac=round(fl / t_prod / 1e12 / F64_MFMA_PEAK_TF, 4), traffic=None,
-                        peak_sustained_measured=F64_MFMA_SUSTAINED_TF, frac_of_sustained=round(fl / t_prod / 1e12 / F64_MFMA_SUSTAINED_TF, 4),
-                        flops_per_launch=fl, avg_launch_us=round(1e6 * t_prod, 2), avg_launch_us_square_only=round(1e6 * t_sq, 2), launches_timed=60,
-                        products_per_projection=nprod, share_of_step=round(nprod * 1e3 * t_prod / ms_step, 4),
-                        # the other roof of the same launch: Y = U^2 reads U once and writes Y once (8 B x sum d^2 each); the alpha A B + beta Cin products
-                        # read up to three distinct matrices: 2 / 3 / 4 x 8 B x sum d^2 for the three launches of a step => 3 matrices per product on average
-                        hbm_algorithmic_bytes_per_launch=(24.0 * float(np.sum(dk * dk)) if own is not None else None),
-                        hbm_frac_algorithmic=(round(24.0 * float(np.sum(dk * dk)) / t_prod / 1e9 / HBM_PEAK_GBS, 4) if own is not None else None),
-                        useful_tflops_reference_algorithm=round(useful * value / 1e12, 3), useful_frac_of_peak=round(useful * value / 1e12 / F64_MFMA_PEAK_TF, 5))
+        df = h.polar_dataflow_stats()
+        if df["enabled"] and df["timed_launches"] > 0:
+            # round 6: the main schedule is ONE persistent dependency-driven launch (k_polar_dataflow); its duration comes from the HIP events the library records
+            # around every such launch of the timed window; a "product" below = the launch divided by its number of products
+            t_launch, npl = df["avg_launch_seconds"], df["products_per_launch"]
+            t_eq = t_launch / npl
+            products = dict(bound="mfma", kernel="k_polar_dataflow<4> (the %d products of the sign iteration's main schedule in ONE persistent launch of %d workgroups: per-XCD in-order "
+                                                "tile queue, per-cone completion counters, operands read with sc1 loads; tile arithmetic = k_symm_gemm_batch_r<EPI, 4>, same bits)"
+                                                % (npl, df["workgroups"]),
+                            timing="HIP events recorded by the library around every persistent launch of the timed window (%d launches)" % df["timed_launches"],
+                            useful_flops_per_launch=(useful_prod * npl if useful_prod else None), performed_over_useful=(round(fl / useful_prod, 3) if useful_prod else None),
+                            useful_frac_per_product=(round(useful_prod / t_eq / 1e12 / F64_MFMA_PEAK_TF, 4) if useful_prod else None),
+                            achieved=round(fl / t_eq / 1e12, 2), peak=F64_MFMA_PEAK_TF, unit="TFLOP/s", frac=round(fl / t_eq / 1e12 / F64_MFMA_PEAK_TF, 4), traffic=None,
+                            peak_sustained_measured=F64_MFMA_SUSTAINED_TF, frac_of_sustained=round(fl / t_eq / 1e12 / F64_MFMA_SUSTAINED_TF, 4),
+                            flops_per_launch=fl * npl, avg_launch_us=round(1e6 * t_launch, 2), us_per_product_equivalent=round(1e6 * t_eq, 2),
+                            launches_timed=df["timed_launches"], products_per_projection=nprod, share_of_step=round(1e3 * t_launch / ms_step, 4),
+                            launch_per_product_form=dict(avg_launch_us=round(1e6 * t_prod, 2), avg_launch_us_square_only=round(1e6 * t_sq, 2), frac=round(fl / t_prod / 1e12 / F64_MFMA_PEAK_TF, 4),
+                                                         note="k_symm_gemm_batch_r<EPI, 4>, one launch per product (COSMO_HIP_POLAR_DATAFLOW=0; still used by the repair rounds): in-loop mix "
+                                                              "20 x (Y = U^2, T = c Y^2 + b Y, U' = U T + a U), HIP events"),
+                            hbm_algorithmic_bytes_per_launch=(24.0 * float(np.sum(dk * dk)) * npl if own is not None else None),
+                            hbm_frac_algorithmic=(round(24.0 * float(np.sum(dk * dk)) / t_eq / 1e9 / HBM_PEAK_GBS, 4) if own is not None else None),
+                            useful_tflops_reference_algorithm=round(useful * value / 1e12, 3), useful_frac_of_peak=round(useful * value / 1e12 / F64_MFMA_PEAK_TF, 5))
+        else:
+            products = dict(bound="mfma", kernel="k_symm_gemm_batch_r<EPI, 4> (ragged block-balanced tiles: one workgroup per list of <= 16 blocks of 16 x 16 of one of rank 0's "
+                                                "cliques; upper blocks only on the diagonal; four workgroups per CU, tiles launched by decreasing cost)",
+                            timing="in-loop mix: 20 x (Y = U^2, T = c Y^2 + b Y, U' = U T + a U) on the batch's work matrices, HIP events on the library's stream",
+                            useful_flops_per_launch=useful_prod, performed_over_useful=(round(fl / useful_prod, 3) if useful_prod else None),
+                            useful_frac_per_product=(round(useful_prod / t_prod / 1e12 / F64_MFMA_PEAK_TF, 4) if useful_prod else None),
+                            achieved=round(fl / t_prod / 1e12, 2), peak=F64_MFMA_PEAK_TF, unit="TFLOP/s", frac=round(fl / t_prod / 1e12 / F64_MFMA_PEAK_TF, 4), traffic=None,
+                            peak_sustained_measured=F64_MFMA_SUSTAINED_TF, frac_of_sustained=round(fl / t_prod / 1e12 / F64_MFMA_SUSTAINED_TF, 4),
+                            flops_per_launch=fl, avg_launch_us=round(1e6 * t_prod, 2), avg_launch_us_square_only=round(1e6 * t_sq, 2), launches_timed=60,
+                            products_per_projection=nprod, share_of_step=round(nprod * 1e3 * t_prod / ms_step, 4),
+                            # the other roof of the same launch: Y = U^2 reads U once and writes Y once (8 B x sum d^2 each); the alpha A B + beta Cin products
+                            # read up to three distinct matrices: 2 / 3 / 4 x 8 B x sum d^2 for the three launches of a step => 3 matrices per product on average
+                            hbm_algorithmic_bytes_per_launch=(24.0 * float(np.sum(dk * dk)) if own is not None else None),
+                            hbm_frac_algorithmic=(round(24.0 * float(np.sum(dk * dk)) / t_prod / 1e9 / HBM_PEAK_GBS, 4) if own is not None else None),
+                            useful_tflops_reference_algorithm=round(useful * value / 1e12, 3), useful_frac_of_peak=round(useful * value / 1e12 / F64_MFMA_PEAK_TF, 5))
     krylov = None
     pmc5 = None
     if not args.small:
@@ -866,10 +890,15 @@ def bench_cfg5(ctx, args, steps, warmup):
     if products is not None and pmc5 is not None:
         try:
             kk = pmc5[0]["kernels"]
-            e0, e1 = kk["k_symm_gemm_batch_r<0, 4>"], kk["k_symm_gemm_batch_r<1, 4>"]
-            products["traffic"] = round((e0["hbm_bytes_per_launch"] + 2.0 * e1["hbm_bytes_per_launch"]) / 3.0, 1)      # the in-loop mix: one EPI 0 + two EPI 1 launches
+            if products["kernel"].startswith("k_polar_dataflow"):
+                e = kk["k_polar_dataflow<4>"]
+                products["traffic"] = round(e["hbm_bytes_per_launch"], 1)
+                products["mfma_busy_frac_pmc"] = round(e["mfma_busy_frac"], 4)
+            else:
+                e0, e1 = kk["k_symm_gemm_batch_r<0, 4>"], kk["k_symm_gemm_batch_r<1, 4>"]
+                products["traffic"] = round((e0["hbm_bytes_per_launch"] + 2.0 * e1["hbm_bytes_per_launch"]) / 3.0, 1)      # the in-loop mix: one EPI 0 + two EPI 1 launches
+                products["mfma_busy_frac_pmc"] = round((e0["mfma_busy_frac"] + 2.0 * e1["mfma_busy_frac"]) / 3.0, 4)
             products["traffic_source"] = pmc5[1]
-            products["mfma_busy_frac_pmc"] = round((e0["mfma_busy_frac"] + 2.0 * e1["mfma_busy_frac"]) / 3.0, 4)
         except Exception:
             pass
     if ctx.world == 1:

@@ -95,6 +95,8 @@ SIGNATURES = {
     "cosmo_hip_cg_persist_stats": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_fold_stats": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_kkt_recurrence": (C.c_char_p, [C.c_void_p]),
+    "cosmo_hip_polar_dataflow_stats": (C.c_int32, [C.c_void_p, _PD]),
+    "cosmo_hip_polar_dataflow_reset_timing": (C.c_int32, [C.c_void_p]),
     "cosmo_hip_get_kkt_solution": (C.c_int32, [C.c_void_p, _PR]),
     "cosmo_hip_get_stats": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_set_setup_time": (C.c_int32, [C.c_void_p, C.c_double]),
@@ -467,6 +469,15 @@ class Handle:
         out = np.zeros(16, dtype=np.int64)
         self._chk(self.lib.cosmo_hip_polar_stats(self._h, out.ctypes.data_as(_PI64)))
         return dict(zip(self.POLAR_STAT_KEYS, out.tolist()))
+
+    def polar_dataflow_stats(self, reset=False):
+        """The batch's main schedule as one persistent dependency-driven launch (cosmo_hip_polar_dataflow_stats)."""
+        out = np.zeros(8, dtype=np.float64)
+        self._chk(self.lib.cosmo_hip_polar_dataflow_stats(self._h, out.ctypes.data_as(_PD)))
+        if reset:
+            self._chk(self.lib.cosmo_hip_polar_dataflow_reset_timing(self._h))
+        return dict(enabled=int(out[0]), launches=int(out[1]), products_per_launch=int(out[2]), timed_launches=int(out[3]), avg_launch_seconds=float(out[4]),
+                    flops_per_launch=float(out[5]), workgroups=int(out[6]), tiles_per_product=int(out[7]))
 
     def time_psd_product(self, which=0, reps=20):
         t = C.c_double(0); fl = C.c_double(0)

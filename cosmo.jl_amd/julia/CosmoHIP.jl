@@ -252,6 +252,13 @@ function cg_persist_stats(h::Handle)
     return (enabled = out[1] != 0, workgroups = out[2], launches = out[3], fallbacks = out[4])
 end
 
+function polar_dataflow_stats(h::Handle)   # the batch's main schedule as one persistent dependency-driven launch (cosmo_hip_polar_dataflow_stats)
+    out = zeros(Float64, 8)
+    check(h, ccall((:cosmo_hip_polar_dataflow_stats, lib(h)), Int32, (Ptr{Cvoid}, Ptr{Cdouble}), h.ptr, out))
+    return (enabled = Int(out[1]), launches = Int(out[2]), products_per_launch = Int(out[3]), timed_launches = Int(out[4]), avg_launch_seconds = out[5],
+            flops_per_launch = out[6], workgroups = Int(out[7]), tiles_per_product = Int(out[8]))
+end
+polar_dataflow_reset_timing(h::Handle) = check(h, ccall((:cosmo_hip_polar_dataflow_reset_timing, lib(h)), Int32, (Ptr{Cvoid},), h.ptr))
 function polar_depth_stats(h::Handle)      # per-cone lifting depth of the sign iteration (opt-in COSMO_HIP_POLAR_ADAPT=1)
     out = zeros(Int64, 8)
     check(h, ccall((:cosmo_hip_polar_depth_stats, lib(h)), Int32, (Ptr{Cvoid}, Ptr{Int64}), h.ptr, out))

@@ -36,6 +36,13 @@ typedef double cosmo_hip_real;
 #endif
 
 typedef struct cosmo_hip_handle cosmo_hip_handle;
+/* The libraries are built with -fvisibility=hidden: the functions tagged COSMO_HIP_API below are their ONLY exported symbols
+ * (tests/test_abi_and_host.py compares `nm -D` with this header). */
+#if defined(__GNUC__) || defined(__clang__)
+#define COSMO_HIP_API __attribute__((visibility("default")))
+#else
+#define COSMO_HIP_API
+#endif
 
 /* ---- status codes -------------------------------------------------------------------------------- */
 enum {
@@ -173,24 +180,24 @@ typedef struct cosmo_hip_result {
 
 /* ---- lifecycle -------------------------------------------------------------------------------------- */
 /* Creates a handle bound to HIP device `device_id` (one process per GPU; the handle owns one stream). */
-int32_t cosmo_hip_create(cosmo_hip_handle** h, int32_t device_id);
+COSMO_HIP_API int32_t cosmo_hip_create(cosmo_hip_handle** h, int32_t device_id);
 /* Idempotent.  Replaces AbstractKKTSolver free_memory! (src/linear_solver/kktsolver.jl:351; called from
  * src/solver.jl:200,206-208) and is what the Julia finalizer of the wrapper calls. */
-int32_t cosmo_hip_destroy(cosmo_hip_handle* h);
+COSMO_HIP_API int32_t cosmo_hip_destroy(cosmo_hip_handle* h);
 /* Last error text of this handle (valid until the next call on it); never NULL. */
-const char* cosmo_hip_last_error(const cosmo_hip_handle* h);
+COSMO_HIP_API const char* cosmo_hip_last_error(const cosmo_hip_handle* h);
 /* ABI version of the library (major*1000 + minor).  COSMO_HIP_ABI_VERSION is the version THIS header describes; the bindings generated from
  * it (cosmo.jl_amd/_abi_structs.py, julia/abi_structs.jl) carry the same number and refuse a library that reports another one: a stale
  * .so paired with newer struct mirrors would read garbage, a newer .so would write past an older caller's cosmo_hip_result. */
 #define COSMO_HIP_ABI_VERSION 1003
-int32_t cosmo_hip_version(void);
-void cosmo_hip_default_params(cosmo_hip_params* p);
+COSMO_HIP_API int32_t cosmo_hip_version(void);
+COSMO_HIP_API void cosmo_hip_default_params(cosmo_hip_params* p);
 
 /* ---- problem data ----------------------------------------------------------------------------------- */
 /* Replaces the AbstractKKTSolver constructor T(P, A, sigma, rho) (src/linear_solver/kktsolver.jl:5-11;
  * called from _make_kkt_solver!, src/setup.jl:1-7) together with the (q, b) the loop reads from ws.p
  * (src/solver.jl:137,154).  P (n x n, full symmetric storage) and A (m x n) are the SCALED matrices. */
-int32_t cosmo_hip_set_problem(cosmo_hip_handle* h, int64_t n, int64_t m,
+COSMO_HIP_API int32_t cosmo_hip_set_problem(cosmo_hip_handle* h, int64_t n, int64_t m,
                               const int64_t* P_colptr, const int64_t* P_rowval, const cosmo_hip_real* P_nzval,
                               const int64_t* A_colptr, const int64_t* A_rowval, const cosmo_hip_real* A_nzval,
                               const cosmo_hip_real* q, const cosmo_hip_real* b);
@@ -198,12 +205,12 @@ int32_t cosmo_hip_set_problem(cosmo_hip_handle* h, int64_t n, int64_t m,
  * (src/convexset.jl:985-993) + classify_constraints! (src/setup.jl:75-85).  `type[k]`, `dim[k]` per cone in
  * row order; box_l/box_u are the concatenated (already E-scaled, src/convexset.jl:863-867) bounds of all Box
  * cones in order (may be NULL when there is no Box). */
-int32_t cosmo_hip_set_cones(cosmo_hip_handle* h, int64_t ncones, const int32_t* type, const int64_t* dim,
+COSMO_HIP_API int32_t cosmo_hip_set_cones(cosmo_hip_handle* h, int64_t ncones, const int32_t* type, const int64_t* dim,
                             const cosmo_hip_real* box_l, const cosmo_hip_real* box_u);
 /* Same, plus one parameter per cone: cone_param[k] = alpha for PowerCone / DualPowerCone (0 < alpha < 1, the reference
  * throws a DomainError otherwise, src/convexset.jl:614,758), ignored for every other type.  May be NULL when the
  * composite set holds no power cone. */
-int32_t cosmo_hip_set_cones_ex(cosmo_hip_handle* h, int64_t ncones, const int32_t* type, const int64_t* dim,
+COSMO_HIP_API int32_t cosmo_hip_set_cones_ex(cosmo_hip_handle* h, int64_t ncones, const int32_t* type, const int64_t* dim,
                                const cosmo_hip_real* box_l, const cosmo_hip_real* box_u, const cosmo_hip_real* cone_param);
 /* ---- user-defined cones: the AbstractConvexSet plugin surface (src/projections.jl:4-5, docs/src/literate/custom_cone.jl) ----
  * project!(x, C)            -> cosmo_hip_project_fn: x is the cone's contiguous slice (dim doubles, host memory), projected in place
@@ -216,20 +223,20 @@ int32_t cosmo_hip_set_cones_ex(cosmo_hip_handle* h, int64_t ncones, const int32_
  * table given to cosmo_hip_set_cones[_ex], whose type[cone] must be COSMO_HIP_CUSTOM; call after set_cones. */
 typedef void (*cosmo_hip_project_fn)(cosmo_hip_real* x, int64_t dim, void* user);
 typedef int32_t (*cosmo_hip_cone_test_fn)(const cosmo_hip_real* x, int64_t dim, double tol, void* user);
-int32_t cosmo_hip_set_custom_cone(cosmo_hip_handle* h, int64_t cone, cosmo_hip_project_fn project, cosmo_hip_cone_test_fn in_dual,
+COSMO_HIP_API int32_t cosmo_hip_set_custom_cone(cosmo_hip_handle* h, int64_t cone, cosmo_hip_project_fn project, cosmo_hip_cone_test_fn in_dual,
                                   cosmo_hip_cone_test_fn in_pol_recc, void* user);
 /* Settings fields (src/settings.jl) + initial rho vector: set_rho_vec! (src/parameters.jl:3-13).
  * rho_vec may be NULL: then it is built from p->rho and the row classes exactly as the reference does. */
-int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_params* p, const cosmo_hip_real* rho_vec);
+COSMO_HIP_API int32_t cosmo_hip_set_params(cosmo_hip_handle* h, const cosmo_hip_params* p, const cosmo_hip_real* rho_vec);
 /* Replaces update_rho!(kkt_solver, rho_vec) (src/linear_solver/kktsolver_indirect.jl:164-166; called from
  * update_rho_vec!, src/parameters.jl:85-89). */
-int32_t cosmo_hip_update_rho(cosmo_hip_handle* h, const cosmo_hip_real* rho_vec);
+COSMO_HIP_API int32_t cosmo_hip_update_rho(cosmo_hip_handle* h, const cosmo_hip_real* rho_vec);
 /* ScaleMatrices Dinv (n), Einv (m), cinv used ONLY to unscale residuals (src/residuals.jl:43-49,66-92).
  * NULL pointers mean identity. */
-int32_t cosmo_hip_set_scaling(cosmo_hip_handle* h, const cosmo_hip_real* Dinv, const cosmo_hip_real* Einv, double cinv);
+COSMO_HIP_API int32_t cosmo_hip_set_scaling(cosmo_hip_handle* h, const cosmo_hip_real* Dinv, const cosmo_hip_real* Einv, double cinv);
 /* Same plus D (n), E (m), c themselves, which the infeasibility certificates scale with (src/infeasibility.jl:5,35,39);
  * cosmo_hip_set_scaling derives them as reciprocals.  NULL = identity. */
-int32_t cosmo_hip_set_scaling_full(cosmo_hip_handle* h, const cosmo_hip_real* D, const cosmo_hip_real* Dinv, const cosmo_hip_real* E, const cosmo_hip_real* Einv,
+COSMO_HIP_API int32_t cosmo_hip_set_scaling_full(cosmo_hip_handle* h, const cosmo_hip_real* D, const cosmo_hip_real* Dinv, const cosmo_hip_real* E, const cosmo_hip_real* Einv,
                                    double c, double cinv);
 /* Replaces COSMO.update!(model; q, b) on already-scaled vectors (src/interface.jl:187-211). NULL = keep. */
 /* Replaces _make_accelerator! (src/setup.jl:10-16): installs (or with kind EMPTY / NULL removes) the accelerator used by
@@ -237,10 +244,10 @@ int32_t cosmo_hip_set_scaling_full(cosmo_hip_handle* h, const cosmo_hip_real* D,
  * acceleration_post! (safeguarding re-does the ADMM step from the last non-accelerated point and counts it in
  * safeguarding_iter), deferred rho updates and deferred infeasibility checks (update_suggested, src/solver.jl:284-292).
  * Call after cosmo_hip_set_problem; every cosmo_hip_set_iterates restarts it (src/setup.jl:47-49). */
-void cosmo_hip_default_accel_params(cosmo_hip_accel_params* p);
-int32_t cosmo_hip_set_accelerator(cosmo_hip_handle* h, const cosmo_hip_accel_params* p);
+COSMO_HIP_API void cosmo_hip_default_accel_params(cosmo_hip_accel_params* p);
+COSMO_HIP_API int32_t cosmo_hip_set_accelerator(cosmo_hip_handle* h, const cosmo_hip_accel_params* p);
 /* out = {accelerated steps, safeguard accepted, safeguard declined, memory restarts, active, safeguarding_iter} */
-int32_t cosmo_hip_get_accel_stats(cosmo_hip_handle* h, int64_t out[6]);
+COSMO_HIP_API int32_t cosmo_hip_get_accel_stats(cosmo_hip_handle* h, int64_t out[6]);
 /* Replaces scale_ruiz! (src/scaling.jl:21-116) for callers that hand over the UNSCALED problem: call after
  * cosmo_hip_set_problem + cosmo_hip_set_cones (unscaled data and Box bounds) and before cosmo_hip_set_params.  Runs
  * `iterations` (settings.scaling) steps of the modified Ruiz equilibration on the device-resident P, A, q, b, rectifies the
@@ -248,152 +255,157 @@ int32_t cosmo_hip_get_accel_stats(cosmo_hip_handle* h, int64_t out[6]);
  * (src/convexset.jl:863-867) and re-runs classify_constraints! on the scaled data.  The scaling matrices stay on the device
  * for the residual / infeasibility tests (as after cosmo_hip_set_scaling_full); D_out[n], E_out[m], c_out (each may be
  * NULL) return them for the caller's reverse_scaling! (src/scaling.jl:170-179).  P must be symmetric. */
-int32_t cosmo_hip_scale_ruiz(cosmo_hip_handle* h, int64_t iterations, double min_scaling, double max_scaling, cosmo_hip_real* D_out,
+COSMO_HIP_API int32_t cosmo_hip_scale_ruiz(cosmo_hip_handle* h, int64_t iterations, double min_scaling, double max_scaling, cosmo_hip_real* D_out,
                              cosmo_hip_real* E_out, double* c_out);
-int32_t cosmo_hip_update_qb(cosmo_hip_handle* h, const cosmo_hip_real* q, const cosmo_hip_real* b);
+COSMO_HIP_API int32_t cosmo_hip_update_qb(cosmo_hip_handle* h, const cosmo_hip_real* q, const cosmo_hip_real* b);
 /* Per-row rho class computed by the library: 0 = rho, 1 = rho*RHO_EQ_OVER_RHO_INEQ, 2 = RHO_MIN
  * (apply_constraint_rho_scaling!, src/parameters.jl:17-49) -- integer bookkeeping, compared bit-exactly. */
-int32_t cosmo_hip_get_rho_classes(cosmo_hip_handle* h, int32_t* cls /* m */);
-int32_t cosmo_hip_get_rho_vec(cosmo_hip_handle* h, cosmo_hip_real* rho_vec /* m */);
+COSMO_HIP_API int32_t cosmo_hip_get_rho_classes(cosmo_hip_handle* h, int32_t* cls /* m */);
+COSMO_HIP_API int32_t cosmo_hip_get_rho_vec(cosmo_hip_handle* h, cosmo_hip_real* rho_vec /* m */);
 
 /* ---- fine-grained plugin entry points (host pointers, synchronous) ----------------------------------- */
 /* Replaces solve!(kkt_solver, lhs, rhs) (src/linear_solver/kktsolver.jl:5-11, kktsolver_indirect.jl:36-88,
  * 123-162; called from admm_x!, src/solver.jl:52).  lhs, rhs have length n+m.  kkt_iters_out may be NULL. */
-int32_t cosmo_hip_kkt_solve(cosmo_hip_handle* h, cosmo_hip_real* lhs, const cosmo_hip_real* rhs, int64_t* kkt_iters_out);
+COSMO_HIP_API int32_t cosmo_hip_kkt_solve(cosmo_hip_handle* h, cosmo_hip_real* lhs, const cosmo_hip_real* rhs, int64_t* kkt_iters_out);
 /* Replaces project!(s::SplitVector, C::CompositeConvexSet) (src/convexset.jl:885-891) on a host vector of
  * length m, in place.  psd_rank_out[k] (per cone, -1 for non-PSD cones) = nnz_lambda of rank_k_update!
  * (src/convexset.jl:247-256); soc_branch_out[k] (per cone, -1 for non-SOC) = 0 keep / 1 zero / 2 scale
  * (src/convexset.jl:104-112); for the exponential / power cones it reports the case 1..4 of their project! (in cone /
  * polar => 0 / boundary shortcut / root finding, src/convexset.jl:510-537, 626-655).  Either may be NULL. */
-int32_t cosmo_hip_project(cosmo_hip_handle* h, cosmo_hip_real* s, int64_t* psd_rank_out, int32_t* soc_branch_out);
+COSMO_HIP_API int32_t cosmo_hip_project(cosmo_hip_handle* h, cosmo_hip_real* s, int64_t* psd_rank_out, int32_t* soc_branch_out);
 /* Replaces mul!(y, A, x), mul!(y, A', x), mul!(y, P, x) (src/residuals.jl:4,12,15). */
-int32_t cosmo_hip_spmv(cosmo_hip_handle* h, int32_t which, cosmo_hip_real* y, const cosmo_hip_real* x);
+COSMO_HIP_API int32_t cosmo_hip_spmv(cosmo_hip_handle* h, int32_t which, cosmo_hip_real* y, const cosmo_hip_real* x);
 
 /* ---- coarse device-resident loop (the performance path; replaces the body of optimize!) ------------- */
 /* Warm start: w[1:n] = x0 ; w[n+1:] = 1/rho .* mu0 + s0 ; s = s0 (src/solver.jl:128-129).  NULL = zeros. */
-int32_t cosmo_hip_set_iterates(cosmo_hip_handle* h, const cosmo_hip_real* x0, const cosmo_hip_real* s0, const cosmo_hip_real* mu0);
+COSMO_HIP_API int32_t cosmo_hip_set_iterates(cosmo_hip_handle* h, const cosmo_hip_real* x0, const cosmo_hip_real* s0, const cosmo_hip_real* mu0);
 /* admm_x! ; admm_w! once (src/solver.jl:137-138). */
-int32_t cosmo_hip_admm_init(cosmo_hip_handle* h);
+COSMO_HIP_API int32_t cosmo_hip_admm_init(cosmo_hip_handle* h);
 /* n_iters times the loop body admm_z! / apply_rho_adaptation_rules! / admm_x! / admm_w!
  * (src/solver.jl:151-155) with NO termination checks; iteration numbering continues from the handle's
  * counter (so rho adaptation fires at the same iterations as in the reference). */
-int32_t cosmo_hip_admm_iterate(cosmo_hip_handle* h, int64_t n_iters);
+COSMO_HIP_API int32_t cosmo_hip_admm_iterate(cosmo_hip_handle* h, int64_t n_iters);
 /* Same, but WITH check_termination! at the reference's schedule (iter % check_termination == 0 || iter == 1,
  * src/solver.jl:306) counted on the handle's absolute iteration counter; stops early when a status is decided.
  * This is the timed region of the BASELINE metric (iter_time includes the checks, src/solver.jl:134,169).
  * status_out receives COSMO_HIP_UNDETERMINED or the decided status. */
-int32_t cosmo_hip_admm_iterate_checked(cosmo_hip_handle* h, int64_t n_iters, int32_t* status_out);
+COSMO_HIP_API int32_t cosmo_hip_admm_iterate_checked(cosmo_hip_handle* h, int64_t n_iters, int32_t* status_out);
 /* recover_mu! + calculate_result_info! + calculate_cost! (src/solver.jl:307-310, src/residuals.jl:30-96,
  * 143-153) on the current iterates: out = {r_prim, r_dual, max_norm_prim, max_norm_dual, cost}. */
-int32_t cosmo_hip_residuals(cosmo_hip_handle* h, double out[5]);
+COSMO_HIP_API int32_t cosmo_hip_residuals(cosmo_hip_handle* h, double out[5]);
 /* The whole `while` loop of optimize! (src/solver.jl:137-176): init step, iterations with
  * check_termination!/adaptive rho at the reference's schedule, final recover_mu!.  Iterates stay on the
  * device; fetch them with cosmo_hip_get_iterates. */
-int32_t cosmo_hip_optimize(cosmo_hip_handle* h, cosmo_hip_result* result);
+COSMO_HIP_API int32_t cosmo_hip_optimize(cosmo_hip_handle* h, cosmo_hip_result* result);
 /* Copies back what the unchanged epilogue of optimize! needs (src/solver.jl:167-201): w, w_prev (n+m each),
  * s (m), mu (m) with mu = rho .* (w_prev[n+1:] - s) recovered first.  Any pointer may be NULL. */
-int32_t cosmo_hip_get_iterates(cosmo_hip_handle* h, cosmo_hip_real* w, cosmo_hip_real* w_prev, cosmo_hip_real* s, cosmo_hip_real* mu);
+COSMO_HIP_API int32_t cosmo_hip_get_iterates(cosmo_hip_handle* h, cosmo_hip_real* w, cosmo_hip_real* w_prev, cosmo_hip_real* s, cosmo_hip_real* mu);
 /* sol = [x_tl; nu] of the last KKT solve (ws.sol, src/solver.jl:227-228), length n+m. */
 /* Single-launch CG (csrc/cg_persist.hip): out = {enabled for this handle (operator fits one XCD's L2), participating workgroups,
  * persistent launches so far, fallbacks to the multi-kernel path, tickets / barrier arrivals / abort flag of the last launch, LDS
  * doubles per quarter}.  COSMO_HIP_CG_PERSIST=0 / 1 in the environment disables / forces it. */
-int32_t cosmo_hip_cg_persist_stats(cosmo_hip_handle* h, int64_t out[8]);
-int32_t cosmo_hip_get_kkt_solution(cosmo_hip_handle* h, cosmo_hip_real* sol);
+COSMO_HIP_API int32_t cosmo_hip_cg_persist_stats(cosmo_hip_handle* h, int64_t out[8]);
+COSMO_HIP_API int32_t cosmo_hip_get_kkt_solution(cosmo_hip_handle* h, cosmo_hip_real* sol);
 /* Assembled reduced operator of the CG solve (csrc/cg_fold.hip): M = P + diag(sigma + d) + Am' rho Am as ONE sparse matrix where the
  * operator split leaves a sparse Am' rho Am (decomposed SDPs), two launches per Krylov iteration instead of three.
  * out = {enabled, nnz(M), rho-weighted terms behind its entries, CSR-stream tiles}.  COSMO_HIP_OP_FOLD=0 in the environment disables it. */
-int32_t cosmo_hip_fold_stats(cosmo_hip_handle* h, int64_t out[4]);
+COSMO_HIP_API int32_t cosmo_hip_fold_stats(cosmo_hip_handle* h, int64_t out[4]);
 /* Which Krylov recurrence / kernels the KKT solves of this handle run (valid after cosmo_hip_set_params; a string owned by the library, e.g.
  * "cg: literal recurrence on the assembled operator, two launches per iteration, k_cg_dirM<3, false> + k_cg_upd<false>"): bench.py's
  * config.kkt_solver and roofline.kernel. */
-const char* cosmo_hip_kkt_recurrence(cosmo_hip_handle* h);
+COSMO_HIP_API const char* cosmo_hip_kkt_recurrence(cosmo_hip_handle* h);
 /* Statistics of the device loop since set_iterates: out = {admm_iters, kkt_solves, kkt_iters_total,
  * kkt_budget_stalls, spmv_A_calls, spmv_AT_calls, spmv_P_calls, rho_updates}. */
-int32_t cosmo_hip_get_stats(cosmo_hip_handle* h, int64_t out[8]);
+COSMO_HIP_API int32_t cosmo_hip_get_stats(cosmo_hip_handle* h, int64_t out[8]);
 /* The automatic rho interval (settings.adaptive_rho_interval == 0, src/solver.jl:244-256) compares the loop's elapsed time with
  * adaptive_rho_fraction * ws.times.setup_time; setup! ends AFTER cosmo_hip_set_params, so its duration is handed over separately (any time
  * before cosmo_hip_optimize; overrides cosmo_hip_params.setup_time). */
-int32_t cosmo_hip_set_setup_time(cosmo_hip_handle* h, double seconds);
+COSMO_HIP_API int32_t cosmo_hip_set_setup_time(cosmo_hip_handle* h, double seconds);
 /* out = {adaptive_rho_interval in force (0: the automatic rule has not fired yet), iteration at which the automatic rule fixed it or -1}: what
  * the reference writes back into settings.adaptive_rho_interval (src/solver.jl:249-254) */
-int32_t cosmo_hip_get_rho_interval(cosmo_hip_handle* h, int64_t out[2]);
+COSMO_HIP_API int32_t cosmo_hip_get_rho_interval(cosmo_hip_handle* h, int64_t out[2]);
 
 /* ---- measurement hooks (bench.py / rocprof cross-check) ----------------------------------------------- */
 /* Times `reps` back-to-back launches of the SpMV kernel `which` (COSMO_HIP_MAT_A/AT/P, or 3 = the fused
  * [P A'] operator kernel of the CG apply) with HIP events on the handle's stream; returns the average
  * seconds per launch and the ALGORITHMIC bytes of one launch. */
-int32_t cosmo_hip_time_spmv(cosmo_hip_handle* h, int32_t which, int32_t reps, double* avg_seconds,
+COSMO_HIP_API int32_t cosmo_hip_time_spmv(cosmo_hip_handle* h, int32_t which, int32_t reps, double* avg_seconds,
                             double* algorithmic_bytes);
 /* Per-kernel-class durations measured with HIP events on the handle's stream.
  * on = 0: off.  on = 1: events around every loop kernel + exact launches.  on = 2: exact launches only (for rocprofv3).
  * "Exact launches": the host synchronises after every Krylov iteration, so no budgeted launch is a guarded no-op and
  * every launch of a kernel does its full work -- per-kernel averages (events or rocprof) are then comparable with the
  * algorithmic bytes of one launch.  Kernel durations are GPU-side and not affected by the host pacing. */
-int32_t cosmo_hip_set_profiling(cosmo_hip_handle* h, int32_t on);
+COSMO_HIP_API int32_t cosmo_hip_set_profiling(cosmo_hip_handle* h, int32_t on);
 #define COSMO_HIP_NUM_KERNEL_CLASSES 16
-int32_t cosmo_hip_get_kernel_times(cosmo_hip_handle* h, double seconds[COSMO_HIP_NUM_KERNEL_CLASSES],
+COSMO_HIP_API int32_t cosmo_hip_get_kernel_times(cosmo_hip_handle* h, double seconds[COSMO_HIP_NUM_KERNEL_CLASSES],
                                    int64_t launches[COSMO_HIP_NUM_KERNEL_CLASSES]);
-const char* cosmo_hip_kernel_class_name(int32_t k);
+COSMO_HIP_API const char* cosmo_hip_kernel_class_name(int32_t k);
 /* Jacobi eigensolver diagnostics of the PSD projections: out = {max sweeps used by a single-workgroup solve, sweeps of
  * the last multi-workgroup solve, non-convergence flag, number of PSD cones}. */
-int32_t cosmo_hip_psd_stats(cosmo_hip_handle* h, int64_t out[4]);
+COSMO_HIP_API int32_t cosmo_hip_psd_stats(cosmo_hip_handle* h, int64_t out[4]);
 /* Matrix-sign (polar) PSD path diagnostics: out = {large cones (d > 256), batched cones (64 < d <= 256), tile side of the first
  * large cone, its k-split (1 | 2 | 3 = stream-K), product launches <64,1>, <96,1>, <96,2> or stream-K, batched product launches, matrix products of the main
  * schedule of the last large-cone projection, fallback rounds executed so far, verified projections, products of the last batched
  * projection, steps of the main schedule, unverified projections, projections, max verified error bound in units of 1e-18}. */
-int32_t cosmo_hip_polar_stats(cosmo_hip_handle* h, int64_t out[16]);
+COSMO_HIP_API int32_t cosmo_hip_polar_stats(cosmo_hip_handle* h, int64_t out[16]);
 /* Opt-in stream-K product kernel of the large cones (COSMO_HIP_POLAR_STREAMK=1; d > 256; k-split reported as 3 by cosmo_hip_polar_stats,
  * its launches under <96,2>):
  * out = {enabled, workgroups per launch of the first large cone, its ticket classes, spin time-outs so far (must stay 0)}. */
-int32_t cosmo_hip_polar_streamk_stats(cosmo_hip_handle* h, int64_t out[4]);
+COSMO_HIP_API int32_t cosmo_hip_polar_streamk_stats(cosmo_hip_handle* h, int64_t out[4]);
 /* The coefficient table of the sign iteration for k_lift lifting steps: abc holds 3 * (*nsteps) doubles (a, b, c per step;
  * NULL = only report *nsteps).  Host function (no device needed): lets a CPU test replay the schedule on scalars. */
-int32_t cosmo_hip_polar_schedule(int32_t k_lift, double* abc, int32_t* nsteps);
+COSMO_HIP_API int32_t cosmo_hip_polar_schedule(int32_t k_lift, double* abc, int32_t* nsteps);
 /* Measurement hook: `reps` back-to-back launches of the symmetric-product kernel of the sign iteration exactly as the projection
  * launches it (which = 0: first large cone, 1: the whole batch of mid-size cones, Y = U^2 only; 2: the batch's IN-LOOP MIX -- per
  * repetition one Y = U^2 and two alpha A B + beta Cin products with the operands of a step of the iteration, 3 reps launches in all),
  * timed with HIP events on the handle's stream.  Returns the average seconds per launch and the flops one launch performs
  * (2 ts^2 k per upper tile). */
-int32_t cosmo_hip_time_psd_product(cosmo_hip_handle* h, int32_t which, int32_t reps, double* avg_seconds, double* flops);
+COSMO_HIP_API int32_t cosmo_hip_time_psd_product(cosmo_hip_handle* h, int32_t which, int32_t reps, double* avg_seconds, double* flops);
 /* Per-cone lifting depth of the matrix-sign projections (src/convexset.jl:219-263 is what they compute; the depth only steers how many products a
  * projection spends before its a-posteriori verification): out = {adaptive control on, min, max, mean x 1000 of the per-cone depths, d^3-weighted
  * products per projection x 1000 of the batch's last main schedule, failed verifications so far, downward probes so far, projections seen}.
  * OPT-IN: COSMO_HIP_POLAR_ADAPT=1 (measured slower on BASELINE config 5 although it saves 22 % of the products: csrc/psd_polar.hip, PolarPlan::adapt);
  * by default every cone runs the plan's k_lift lifting steps (10 in Float64). */
-int32_t cosmo_hip_polar_depth_stats(cosmo_hip_handle* h, int64_t out[8]);
+/* The main schedule of the batched sign iteration as ONE persistent, dependency-driven launch (csrc/psd_polar.hip: k_polar_dataflow; default where every
+ * XCD's tile list is at least as long as its workgroup slots, COSMO_HIP_POLAR_DATAFLOW=0|1 forces it): out = {enabled, launches, products per launch,
+ * event-timed launches, average seconds per timed launch (HIP events on the handle's stream), matrix flops performed per launch, workgroups, tiles per product}. */
+COSMO_HIP_API int32_t cosmo_hip_polar_dataflow_stats(cosmo_hip_handle* h, double out[8]);
+COSMO_HIP_API int32_t cosmo_hip_polar_dataflow_reset_timing(cosmo_hip_handle* h);
+COSMO_HIP_API int32_t cosmo_hip_polar_depth_stats(cosmo_hip_handle* h, int64_t out[8]);
 /* Measurement hook: `reps` Krylov iterations of the reduced CG solve (src/linear_solver/kktsolver_indirect.jl:57-70; IterativeSolvers cg!)
  * exactly as the loop enqueues them -- solve start on the current right-hand side with tolerance 0, then the iterations (captured chain
  * included), HIP events around the iterations only.  The warm start is restored afterwards; the ADMM state is untouched.  Returns the
  * average seconds per Krylov iteration INCLUDING the kernel boundaries between its launches, the algorithmic bytes of one iteration
  * (12 B per nonzero of the operator + row pointers + 8 B per vector element read or written) and the launches per iteration.
  * kkt_kind CG / CG_JACOBI only; call after at least one loop iteration. */
-int32_t cosmo_hip_time_krylov(cosmo_hip_handle* h, int32_t reps, double* avg_seconds, double* algorithmic_bytes, int32_t* launches_per_iteration);
+COSMO_HIP_API int32_t cosmo_hip_time_krylov(cosmo_hip_handle* h, int32_t reps, double* avg_seconds, double* algorithmic_bytes, int32_t* launches_per_iteration);
 
 /* ---- clique-sharded projections over the GPUs of one node (one process per GPU, RCCL over xGMI) -----------------------
  * The reference projects the cones of a decomposed SDP serially (src/convexset.jl:885-891).  Here every rank holds the whole
  * problem, runs the identical affine steps, projects only the SOC / PSD cones of its contiguous cone range, and the slices
  * of s are exchanged once per iteration (ncclBroadcast group = all-gather with unequal counts).  No other collective. */
-int32_t cosmo_hip_comm_unique_id(uint8_t id[128]);                       /* ncclGetUniqueId on one rank; host layer distributes it */
-int32_t cosmo_hip_comm_init(cosmo_hip_handle* h, int32_t rank, int32_t nranks, const uint8_t id[128]);
-int32_t cosmo_hip_comm_destroy(cosmo_hip_handle* h);
+COSMO_HIP_API int32_t cosmo_hip_comm_unique_id(uint8_t id[128]);                       /* ncclGetUniqueId on one rank; host layer distributes it */
+COSMO_HIP_API int32_t cosmo_hip_comm_init(cosmo_hip_handle* h, int32_t rank, int32_t nranks, const uint8_t id[128]);
+COSMO_HIP_API int32_t cosmo_hip_comm_destroy(cosmo_hip_handle* h);
 /* first_cone[nranks+1]: contiguous partition of the cone indices; call after cosmo_hip_set_cones */
-int32_t cosmo_hip_set_cone_shard(cosmo_hip_handle* h, const int64_t* first_cone);
-int32_t cosmo_hip_comm_selftest(cosmo_hip_handle* h);
+COSMO_HIP_API int32_t cosmo_hip_set_cone_shard(cosmo_hip_handle* h, const int64_t* first_cone);
+COSMO_HIP_API int32_t cosmo_hip_comm_selftest(cosmo_hip_handle* h);
 /* Known-answer test of the all-reduce of `count` reals the row-sharded loop relies on (north_star: "RCCL ... for the residual-norm
  * all-reduce only"; the sums it replaces are src/linear_solver/kktsolver_indirect.jl:52-54 and src/residuals.jl:12-18), through the
  * loop's own code path.  Collective: every rank calls it with the same count.  out = {elements of an exactly representable sum that
  * came back wrong, elements of a fractional sum outside nranks * eps * sum |terms|, FNV-1a hash of the fractional result's bytes (must
  * agree on all ranks: compare it across them), transport (1 RCCL / 2 host-staged), nranks, RCCL version code (0 when host-staged)}.
  * COSMO_HIP_COMM_CORRUPT_RANK=r (test hook) makes rank r contribute 1.001 x its vector to every all-reduce. */
-int32_t cosmo_hip_comm_allreduce_check(cosmo_hip_handle* h, int64_t count, int64_t out[6]);
+COSMO_HIP_API int32_t cosmo_hip_comm_allreduce_check(cosmo_hip_handle* h, int64_t count, int64_t out[6]);
 /* Host-staged communicator for functional tests on a single-GPU host: ranks are processes that may share one device (RCCL
  * refuses that), slices travel through the POSIX shared-memory segment `name` ("/..."; rank 0 creates it).  Same ownership,
  * slices and exchange point as the RCCL path; synchronous, never a performance path.  Call after cosmo_hip_set_problem. */
-int32_t cosmo_hip_comm_init_hostshm(cosmo_hip_handle* h, int32_t rank, int32_t nranks, const char* name);
+COSMO_HIP_API int32_t cosmo_hip_comm_init_hostshm(cosmo_hip_handle* h, int32_t rank, int32_t nranks, const char* name);
 /* out = {nranks, rank, exchange steps executed with nranks > 1, transport (0 none, 1 RCCL, 2 host-staged)} */
-int32_t cosmo_hip_comm_stats(cosmo_hip_handle* h, int64_t out[4]);
+COSMO_HIP_API int32_t cosmo_hip_comm_stats(cosmo_hip_handle* h, int64_t out[4]);
 /* ownership without a communicator: project only the SOC / PSD cones cone_lo <= k < cone_hi (testing / custom exchange) */
-int32_t cosmo_hip_set_cone_ownership(cosmo_hip_handle* h, int64_t cone_lo, int64_t cone_hi);
+COSMO_HIP_API int32_t cosmo_hip_set_cone_ownership(cosmo_hip_handle* h, int64_t cone_lo, int64_t cone_hi);
 
 /* ---- row-sharded runs (csrc/rowshard.hip; SURVEY 8e option 2 on a replicated n-side CG) ------------------------------------
  * Replaces the serial cone loop of src/convexset.jl:885-891 AND the row-local parts of admm_x! / admm_w! / the primal residual
@@ -403,12 +415,12 @@ int32_t cosmo_hip_set_cone_ownership(cosmo_hip_handle* h, int64_t cone_lo, int64
  * iteration (kktsolver_indirect.jl:52-54) and one of A' mu (+ 2 nranks norms) per residual check -- s is never exchanged.
  * Call on a fully set-up handle: set_problem, set_cones, [scale_ruiz], set_params, comm_init / comm_init_hostshm, then this, then
  * set_iterates (which takes the GLOBAL x0, s0, mu0; get_iterates returns the GLOBAL vectors on every rank).  CG kkt kinds only. */
-int32_t cosmo_hip_set_row_shard(cosmo_hip_handle* h, const int64_t* first_cone);
+COSMO_HIP_API int32_t cosmo_hip_set_row_shard(cosmo_hip_handle* h, const int64_t* first_cone);
 /* out = {first row, end row, global rows m_g, nnz of this rank's rows of A, its cones, its first cone} */
-int32_t cosmo_hip_row_shard_info(cosmo_hip_handle* h, int64_t out[6]);
+COSMO_HIP_API int32_t cosmo_hip_row_shard_info(cosmo_hip_handle* h, int64_t out[6]);
 /* out = {nranks, rank, collectives of the loop executed with nranks > 1, transport (0 none, 1 RCCL, 2 host-staged), mode (0 none, 1 cone-
  * sharded projections, 2 row-sharded), payload bytes of those collectives, all-reduces of n-vectors, elements of the last all-reduce} */
-int32_t cosmo_hip_comm_stats_ex(cosmo_hip_handle* h, int64_t out[8]);
+COSMO_HIP_API int32_t cosmo_hip_comm_stats_ex(cosmo_hip_handle* h, int64_t out[8]);
 
 /* ---- batches of independent problems (BASELINE config 3) ------------------------------------------------------------
  * The reference solves a batch with one optimize!(model) per problem (src/solver.jl:78-203).  Here all problems of a batch
@@ -417,24 +429,24 @@ int32_t cosmo_hip_comm_stats_ex(cosmo_hip_handle* h, int64_t out[8]);
  * cones: ZeroSet, Nonnegatives, Box, SecondOrderCone.  Ranks of a multi-GPU job each own a contiguous shard of the batch
  * (no collective). */
 typedef struct cosmo_hip_batch cosmo_hip_batch;
-int32_t cosmo_hip_batch_create(cosmo_hip_batch** b, int32_t device_id, int64_t nprob, int64_t n, int64_t m);
-int32_t cosmo_hip_batch_destroy(cosmo_hip_batch* b);
-const char* cosmo_hip_batch_last_error(const cosmo_hip_batch* b);
+COSMO_HIP_API int32_t cosmo_hip_batch_create(cosmo_hip_batch** b, int32_t device_id, int64_t nprob, int64_t n, int64_t m);
+COSMO_HIP_API int32_t cosmo_hip_batch_destroy(cosmo_hip_batch* b);
+COSMO_HIP_API const char* cosmo_hip_batch_last_error(const cosmo_hip_batch* b);
 /* problem k of the batch; arguments as cosmo_hip_set_problem */
-int32_t cosmo_hip_batch_set_problem(cosmo_hip_batch* b, int64_t k, const int64_t* P_colptr, const int64_t* P_rowval,
+COSMO_HIP_API int32_t cosmo_hip_batch_set_problem(cosmo_hip_batch* b, int64_t k, const int64_t* P_colptr, const int64_t* P_rowval,
                                     const cosmo_hip_real* P_nzval, const int64_t* A_colptr, const int64_t* A_rowval,
                                     const cosmo_hip_real* A_nzval, const cosmo_hip_real* q, const cosmo_hip_real* bvec);
 /* cone structure shared by all problems; box_l / box_u hold nprob * (#Box rows) entries, problem-major.  Cone kinds of batch mode: ZeroSet,
  * Nonnegatives, Box, SecondOrderCone, PsdCone / PsdConeTriangle of side <= 64 (src/convexset.jl:25-28, 71-74, 100-114, 303-321, 402-412, 844-847)
  * and, through cosmo_hip_batch_set_cones_ex, the exponential / power cones; anything else returns COSMO_HIP_ERR_UNSUPPORTED (one handle per
  * problem serves it) */
-int32_t cosmo_hip_batch_set_cones(cosmo_hip_batch* b, int64_t ncones, const int32_t* type, const int64_t* dim,
+COSMO_HIP_API int32_t cosmo_hip_batch_set_cones(cosmo_hip_batch* b, int64_t ncones, const int32_t* type, const int64_t* dim,
                                   const cosmo_hip_real* box_l, const cosmo_hip_real* box_u);
 /* the same with the per-cone parameter of cosmo_hip_set_cones_ex (alpha of PowerCone / DualPowerCone; NULL = none): additionally
  * ExponentialCone, DualExponentialCone, PowerCone, DualPowerCone (src/convexset.jl:497-779) -- one thread of the problem's workgroup per cone */
-int32_t cosmo_hip_batch_set_cones_ex(cosmo_hip_batch* b, int64_t ncones, const int32_t* type, const int64_t* dim,
+COSMO_HIP_API int32_t cosmo_hip_batch_set_cones_ex(cosmo_hip_batch* b, int64_t ncones, const int32_t* type, const int64_t* dim,
                                      const cosmo_hip_real* box_l, const cosmo_hip_real* box_u, const cosmo_hip_real* cone_param);
-int32_t cosmo_hip_batch_set_scaling(cosmo_hip_batch* b, int64_t k, const cosmo_hip_real* Dinv, const cosmo_hip_real* Einv, double cinv);
+COSMO_HIP_API int32_t cosmo_hip_batch_set_scaling(cosmo_hip_batch* b, int64_t k, const cosmo_hip_real* Dinv, const cosmo_hip_real* Einv, double cinv);
 /* The reference's accelerator for every problem of the batch (replaces _make_accelerator!, src/setup.jl:10-16, once per model): the whole
  * accelerated loop of src/solver.jl:140-165 runs inside the problem's persistent workgroup -- acceleration_pre! (update! / accelerate! of the
  * Type-II Anderson accelerator with QR memory, restarted when full), safeguarding with its extra ADMM step (acceleration_post!,
@@ -442,28 +454,28 @@ int32_t cosmo_hip_batch_set_scaling(cosmo_hip_batch* b, int64_t k, const cosmo_h
  * (update_suggested, src/solver.jl:284-292), IterActivation / AccuracyActivation -- with all decisions per problem on the device.  Call BEFORE
  * cosmo_hip_batch_set_params (the kernel variant and its LDS layout are chosen there); mem <= 16; kind EMPTY / NULL removes it.
  * cosmo_hip_result.iter then counts the safeguarding iterations too (src/solver.jl:196). */
-int32_t cosmo_hip_batch_set_accelerator(cosmo_hip_batch* b, const cosmo_hip_accel_params* p);
+COSMO_HIP_API int32_t cosmo_hip_batch_set_accelerator(cosmo_hip_batch* b, const cosmo_hip_accel_params* p);
 /* per problem {accelerated steps, safeguard accepted, safeguard declined, memory restarts, active, safeguarding_iter}: out[6 * nprob] */
-int32_t cosmo_hip_batch_get_accel_stats(cosmo_hip_batch* b, int64_t* out);
+COSMO_HIP_API int32_t cosmo_hip_batch_get_accel_stats(cosmo_hip_batch* b, int64_t* out);
 /* finalises the batch (uploads, classify_constraints!, set_rho_vec! per problem) */
-int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hip_params* p);
-int32_t cosmo_hip_batch_get_rho_classes(cosmo_hip_batch* b, int64_t k, int32_t* cls /* m */);
+COSMO_HIP_API int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hip_params* p);
+COSMO_HIP_API int32_t cosmo_hip_batch_get_rho_classes(cosmo_hip_batch* b, int64_t k, int32_t* cls /* m */);
 /* x0: nprob*n, s0 / mu0: nprob*m, problem-major; NULL = zeros (src/solver.jl:128-129 per problem) */
-int32_t cosmo_hip_batch_set_iterates(cosmo_hip_batch* b, const cosmo_hip_real* x0, const cosmo_hip_real* s0, const cosmo_hip_real* mu0);
+COSMO_HIP_API int32_t cosmo_hip_batch_set_iterates(cosmo_hip_batch* b, const cosmo_hip_real* x0, const cosmo_hip_real* s0, const cosmo_hip_real* mu0);
 /* optimize! for every problem; results has nprob entries */
-int32_t cosmo_hip_batch_optimize(cosmo_hip_batch* b, cosmo_hip_result* results);
+COSMO_HIP_API int32_t cosmo_hip_batch_optimize(cosmo_hip_batch* b, cosmo_hip_result* results);
 /* n_iters more loop bodies on every undecided problem, with the residual checks / adaptive-rho checks of the schedule but WITHOUT the
  * infeasibility certificates (src/solver.jl:326-349): only cosmo_hip_batch_optimize cuts the persistent launch at the iterations the
  * reference tests at.  A measurement / stepping entry: an infeasible problem driven through it runs on undecided.  with_init != 0 runs
  * the init step first */
-int32_t cosmo_hip_batch_iterate(cosmo_hip_batch* b, int64_t n_iters, int32_t with_init);
+COSMO_HIP_API int32_t cosmo_hip_batch_iterate(cosmo_hip_batch* b, int64_t n_iters, int32_t with_init);
 /* per problem {ADMM iterations, KKT solves, Krylov iterations in total}: out[3 * nprob] (measurement; the counters the reference keeps in
  * IndirectReducedKKTSolver.iteration_counter / multiplications, src/linear_solver/kktsolver_indirect.jl:32,56) */
-int32_t cosmo_hip_batch_get_counters(cosmo_hip_batch* b, int64_t* out);
+COSMO_HIP_API int32_t cosmo_hip_batch_get_counters(cosmo_hip_batch* b, int64_t* out);
 /* which kernel the batch runs (after set_params; measurement / tests): out = {form: 0 streaming, 1 LDS image, 2 register kernel <512, 1, 2>,
  * 3 register kernel <512, 2, 4>; sliced image 0 / 1; dynamic LDS bytes per workgroup; P held in registers 0 / 1} */
-int32_t cosmo_hip_batch_kernel_info(cosmo_hip_batch* b, int64_t out[4]);
-int32_t cosmo_hip_batch_get_iterates(cosmo_hip_batch* b, int64_t k, cosmo_hip_real* w, cosmo_hip_real* w_prev, cosmo_hip_real* s, cosmo_hip_real* mu);
+COSMO_HIP_API int32_t cosmo_hip_batch_kernel_info(cosmo_hip_batch* b, int64_t out[4]);
+COSMO_HIP_API int32_t cosmo_hip_batch_get_iterates(cosmo_hip_batch* b, int64_t k, cosmo_hip_real* w, cosmo_hip_real* w_prev, cosmo_hip_real* s, cosmo_hip_real* mu);
 
 /* ---- batches of problems of DIFFERENT structure (csrc/batch_group.hip) ------------------------------------------------------------------
  * The reference's batch is a loop over arbitrary models (src/solver.jl:78).  A group takes every problem with ITS OWN (n, m, cones), partitions
@@ -475,30 +487,30 @@ int32_t cosmo_hip_batch_get_iterates(cosmo_hip_batch* b, int64_t k, cosmo_hip_re
  * what no path of the library takes (an unknown cone type; user-defined cones need their callbacks: one handle per problem) is the group's error,
  * naming the problem. */
 typedef struct cosmo_hip_batch_group cosmo_hip_batch_group;
-int32_t cosmo_hip_batch_group_create(cosmo_hip_batch_group** g, int32_t device_id, int64_t nprob);
-int32_t cosmo_hip_batch_group_destroy(cosmo_hip_batch_group* g);
-const char* cosmo_hip_batch_group_last_error(const cosmo_hip_batch_group* g);
+COSMO_HIP_API int32_t cosmo_hip_batch_group_create(cosmo_hip_batch_group** g, int32_t device_id, int64_t nprob);
+COSMO_HIP_API int32_t cosmo_hip_batch_group_destroy(cosmo_hip_batch_group* g);
+COSMO_HIP_API const char* cosmo_hip_batch_group_last_error(const cosmo_hip_batch_group* g);
 /* problem k, n x n P and m x n A as cosmo_hip_set_problem */
-int32_t cosmo_hip_batch_group_set_problem(cosmo_hip_batch_group* g, int64_t k, int64_t n, int64_t m, const int64_t* P_colptr, const int64_t* P_rowval,
+COSMO_HIP_API int32_t cosmo_hip_batch_group_set_problem(cosmo_hip_batch_group* g, int64_t k, int64_t n, int64_t m, const int64_t* P_colptr, const int64_t* P_rowval,
                                           const cosmo_hip_real* P_nzval, const int64_t* A_colptr, const int64_t* A_rowval,
                                           const cosmo_hip_real* A_nzval, const cosmo_hip_real* q, const cosmo_hip_real* bvec);
 /* cones of problem k as cosmo_hip_set_cones_ex; box_l / box_u = the Box rows of THIS problem */
-int32_t cosmo_hip_batch_group_set_cones(cosmo_hip_batch_group* g, int64_t k, int64_t ncones, const int32_t* type, const int64_t* dim,
+COSMO_HIP_API int32_t cosmo_hip_batch_group_set_cones(cosmo_hip_batch_group* g, int64_t k, int64_t ncones, const int32_t* type, const int64_t* dim,
                                         const cosmo_hip_real* box_l, const cosmo_hip_real* box_u, const cosmo_hip_real* cone_param);
-int32_t cosmo_hip_batch_group_set_scaling(cosmo_hip_batch_group* g, int64_t k, const cosmo_hip_real* Dinv, const cosmo_hip_real* Einv, double cinv);
-int32_t cosmo_hip_batch_group_set_accelerator(cosmo_hip_batch_group* g, const cosmo_hip_accel_params* p);
-int32_t cosmo_hip_batch_group_set_params(cosmo_hip_batch_group* g, const cosmo_hip_params* p);
+COSMO_HIP_API int32_t cosmo_hip_batch_group_set_scaling(cosmo_hip_batch_group* g, int64_t k, const cosmo_hip_real* Dinv, const cosmo_hip_real* Einv, double cinv);
+COSMO_HIP_API int32_t cosmo_hip_batch_group_set_accelerator(cosmo_hip_batch_group* g, const cosmo_hip_accel_params* p);
+COSMO_HIP_API int32_t cosmo_hip_batch_group_set_params(cosmo_hip_batch_group* g, const cosmo_hip_params* p);
 /* number of structure classes; class_of[k] and mode_of[k] for every problem (nprob entries each, may be NULL): mode 0 = the class runs on a
  * persistent batch kernel, 1 = its structure is outside the batch kernels (PSD side > 64, a MINRES solver kind, ...) and every member is solved
  * through its own single-problem handle, concurrently with the batch classes */
-int32_t cosmo_hip_batch_group_class_info(cosmo_hip_batch_group* g, int64_t* nclasses, int64_t* class_of, int64_t* mode_of);
+COSMO_HIP_API int32_t cosmo_hip_batch_group_class_info(cosmo_hip_batch_group* g, int64_t* nclasses, int64_t* class_of, int64_t* mode_of);
 /* warm start of problem k (n, m, m entries; NULL = zeros); problems never set start from zero (src/solver.jl:128-129) */
-int32_t cosmo_hip_batch_group_set_iterates(cosmo_hip_batch_group* g, int64_t k, const cosmo_hip_real* x0, const cosmo_hip_real* s0, const cosmo_hip_real* mu0);
+COSMO_HIP_API int32_t cosmo_hip_batch_group_set_iterates(cosmo_hip_batch_group* g, int64_t k, const cosmo_hip_real* x0, const cosmo_hip_real* s0, const cosmo_hip_real* mu0);
 /* optimize! for every problem; results has nprob entries in the caller's order */
-int32_t cosmo_hip_batch_group_optimize(cosmo_hip_batch_group* g, cosmo_hip_result* results);
-int32_t cosmo_hip_batch_group_get_iterates(cosmo_hip_batch_group* g, int64_t k, cosmo_hip_real* w, cosmo_hip_real* w_prev, cosmo_hip_real* s, cosmo_hip_real* mu);
-int32_t cosmo_hip_batch_group_get_counters(cosmo_hip_batch_group* g, int64_t* out /* 3 * nprob */);
-int32_t cosmo_hip_batch_group_get_accel_stats(cosmo_hip_batch_group* g, int64_t* out /* 6 * nprob */);
+COSMO_HIP_API int32_t cosmo_hip_batch_group_optimize(cosmo_hip_batch_group* g, cosmo_hip_result* results);
+COSMO_HIP_API int32_t cosmo_hip_batch_group_get_iterates(cosmo_hip_batch_group* g, int64_t k, cosmo_hip_real* w, cosmo_hip_real* w_prev, cosmo_hip_real* s, cosmo_hip_real* mu);
+COSMO_HIP_API int32_t cosmo_hip_batch_group_get_counters(cosmo_hip_batch_group* g, int64_t* out /* 3 * nprob */);
+COSMO_HIP_API int32_t cosmo_hip_batch_group_get_accel_stats(cosmo_hip_batch_group* g, int64_t* out /* 6 * nprob */);
 
 #ifdef __cplusplus
 }

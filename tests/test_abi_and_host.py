@@ -32,6 +32,25 @@ def test_library_exports_every_header_symbol():
     assert cj.load_library().cosmo_hip_version() == cj._ffi.ABI_VERSION == 1003
 
 
+def test_the_dynamic_symbol_table_is_the_c_abi_and_nothing_else():
+    """Both libraries are built with -fvisibility=hidden + a linker version script (csrc/exports.map): `nm -D --defined-only` lists exactly the
+    COSMO_HIP_API functions of include/cosmo_hip.h -- no mangled internals (`_Z10cosmo_failP16cosmo_hip_handle...`), no kernel stubs or handle
+    variables, no weak template instantiations that the two libraries (same names, one process) would otherwise have to keep apart with -Bsymbolic."""
+    import shutil
+    import subprocess
+    nm = shutil.which("nm")
+    if nm is None:
+        pytest.skip("nm not available")
+    names = set(_header_functions())
+    hdr = open(os.path.join(ROOT, "include", "cosmo_hip.h")).read()
+    assert len(re.findall(r"(?m)^COSMO_HIP_API ", hdr)) == len(names)            # every prototype of the header carries the export attribute
+    for path in (cj._ffi.LIB_PATH, cj._ffi.LIB_PATH_F32):
+        out = subprocess.run([nm, "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        syms = [ln.split() for ln in out.splitlines() if ln.strip()]
+        assert {t[-1] for t in syms} == names, (path, sorted({t[-1] for t in syms} ^ names)[:10])
+        assert {t[-2] for t in syms} == {"T"}, path                                # functions only
+
+
 def test_float32_library_exports_the_same_symbols_and_real_pointers_follow_the_header():
     """libcosmo_hip_f32.so (cosmo_hip_real = float, -DCOSMO_HIP_REAL_FLOAT) exports the same names; the binding's `_PR` placeholders
     sit exactly where the header says `cosmo_hip_real*`, everything that stays `double*` (times, residual scalars, coefficient
@@ -349,6 +368,28 @@ def test_plain_c_client_links_and_runs():
         assert r.returncode == 0, r.stderr
         out32 = subprocess.run([exe32], capture_output=True, text=True, timeout=120)
         assert out32.returncode == 0 and "version=1003 alpha=1.6 max_iter=5000" in out32.stdout, out32.stderr
+
+
+def test_c_client_that_solves_compiles_warning_free_against_both_libraries():
+    """tests/c_client/solve_simple_qp.c (the reference's simple QP through the header; run on the GPU by tests/test_gpu_c_client.py) builds with
+    gcc -std=c99 -Wall -Werror against both libraries, and without a GPU it fails at cosmo_hip_create with COSMO_HIP_ERR_HIP (exit code 10 + 2)."""
+    import shutil
+    import subprocess
+    import tempfile
+    gcc = shutil.which("gcc")
+    if gcc is None or not os.path.exists(cj._ffi.LIB_PATH):
+        pytest.skip("gcc or the library not available")
+    libdir = os.path.dirname(cj._ffi.LIB_PATH)
+    import torch
+    with tempfile.TemporaryDirectory() as td:
+        for flags, lib in (([], "-lcosmo_hip"), (["-DCOSMO_HIP_REAL_FLOAT"], "-lcosmo_hip_f32")):
+            exe = os.path.join(td, "solve" + lib[2:])
+            r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror"] + flags + ["-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_client", "solve_simple_qp.c"),
+                                "-o", exe, "-L", libdir, lib, "-lm", "-Wl,-rpath," + libdir], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            if not torch.cuda.is_available():
+                out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+                assert out.returncode == 12 and "cosmo_hip_create" in out.stderr, (out.returncode, out.stderr)
 
 
 def test_scripts_compile():

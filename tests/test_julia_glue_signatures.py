@@ -55,7 +55,7 @@ def header_prototypes():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"(?:^|\n)\s*(int32_t|const char\s*\*|void)\s*(cosmo_hip_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"(?:^|\n)\s*(?:COSMO_HIP_API\s+)?(int32_t|const char\s*\*|void)\s*(cosmo_hip_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         ret, name, args = m.group(1), m.group(2), " ".join(m.group(3).split())
         params = [] if args in ("", "void") else [c_class(a) for a in split_top(args)]
         protos[name] = ("cstr" if "char" in ret else ("i32" if ret == "int32_t" else "void"), params)
