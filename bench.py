@@ -908,7 +908,7 @@ def bench_cfg5(ctx, args, steps, warmup):
             rec = h.kkt_recurrence()                               # the kernel names come from the handle (cosmo_hip_kkt_recurrence)
             krylov = dict(bound="hbm", limited_by="latency: a chain of dependent launches and load round trips, not bandwidth",
                           kernel=("%s: ONE Krylov iteration of the reduced CG solve on the assembled operator M = P + sigma I + A' rho A (%d nonzeros), %d launch(es) [%s]"
-                                  % (rec.split(", ", 1)[-1] if ", k_" in rec else rec, fs["nnz"], nl, rec.split(", k_")[0])) if fs["enabled"] else "one Krylov iteration of cg! (%d launches) [%s]" % (nl, rec),
+                                  % (("k_" + rec.split(", k_", 1)[1]) if ", k_" in rec else rec, fs["nnz"], nl, rec.split(", k_")[0])) if fs["enabled"] else "one Krylov iteration of cg! (%d launches) [%s]" % (nl, rec),
                           achieved=round(b_k / t_k / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(b_k / t_k / 1e9 / HBM_PEAK_GBS, 4), traffic=None,
                           algorithmic_bytes_per_launch=b_k, avg_launch_us=round(1e6 * t_k, 3), launches_timed=200,
                           timing="best of 3 x 200 Krylov iterations as the loop enqueues them (captured chain), tolerance 0, HIP events on the library's stream; "

@@ -150,6 +150,7 @@ SIGNATURES = {
     "cosmo_hip_batch_group_set_accelerator": (C.c_int32, [C.c_void_p, C.POINTER(AccelParams)]),
     "cosmo_hip_batch_group_set_params": (C.c_int32, [C.c_void_p, C.POINTER(Params)]),
     "cosmo_hip_batch_group_class_info": (C.c_int32, [C.c_void_p, _PI64, _PI64, _PI64]),
+    "cosmo_hip_batch_group_run_info": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_batch_group_set_iterates": (C.c_int32, [C.c_void_p, C.c_int64, _PR, _PR, _PR]),
     "cosmo_hip_batch_group_optimize": (C.c_int32, [C.c_void_p, C.POINTER(ResultStruct)]),
     "cosmo_hip_batch_group_get_iterates": (C.c_int32, [C.c_void_p, C.c_int64, _PR, _PR, _PR, _PR]),
@@ -747,6 +748,12 @@ class BatchGroup:
         cls = np.zeros(self.nprob, dtype=np.int64); mode = np.zeros(self.nprob, dtype=np.int64)
         self._chk(self.lib.cosmo_hip_batch_group_class_info(self._g, C.byref(nc), cls.ctypes.data_as(_PI64), mode.ctypes.data_as(_PI64)))
         return (int(nc.value), cls, mode) if with_modes else (int(nc.value), cls)
+
+    def run_info(self):
+        """worker threads and jobs of the last optimize (a bounded pool), classes, problems"""
+        out = np.zeros(4, dtype=np.int64)
+        self._chk(self.lib.cosmo_hip_batch_group_run_info(self._g, out.ctypes.data_as(_PI64)))
+        return dict(zip(["workers", "jobs", "classes", "problems"], out.tolist()))
 
     def set_iterates(self, k, x0=None, s0=None, mu0=None):
         n, m = self.dims[int(k)]

@@ -1144,13 +1144,16 @@ static int32_t collective_elapsed(cosmo_hip_handle* h, const std::chrono::steady
 // loop has run for adaptive_rho_fraction * setup_time seconds" -- to round_multiple(iter, check_termination) (algebra.jl:245-247), at least
 // check_termination (25 where that is 0).  Called where the host knows that the device has finished iteration `it` (at the top of iteration it + 1 in
 // the reference's terms).  The rule fires once; the interval then lives in h->prm like a fixed one, and what the device does from there on is the
-// fixed-interval schedule.  Sharded runs decide on the maximum of the ranks' clocks, so every rank fixes the same interval at the same iteration.
+// fixed-interval schedule.  Sharded runs: BOTH sides of the comparison are rank-local (every process measures its own loop time and its own
+// setup_time -- model.optimize() times its own setup_row_sharding), so the DECISION is made collective: the ranks all-reduce (max) the margin
+// elapsed - fraction * setup_time and fire together as soon as any of them would.  A rank that fired alone would stop calling this all-reduce while its
+// peers go on, and schedule its rho checks (and their all-reduces) at other iterations: mismatched collectives, i.e. a hang inside RCCL.
 static int32_t auto_rho_interval(cosmo_hip_handle* h, long long iter, const std::chrono::steady_clock::time_point t0) {
   cosmo_hip_params& p = h->prm;
   if (!(p.adaptive_rho && p.adaptive_rho_interval == 0)) return COSMO_HIP_OK;
-  double el = 0.0;
-  CHK(collective_elapsed(h, t0, &el));
-  if (!(el > p.adaptive_rho_fraction * p.setup_time)) return COSMO_HIP_OK;
+  double margin = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() - p.adaptive_rho_fraction * p.setup_time;
+  if (h->comm && comm_nranks(h) > 1) CHK(comm_allreduce_host(h, &margin, 1, 1));
+  if (!(margin > 0.0)) return COSMO_HIP_OK;
   const long long N = p.check_termination > 0 ? p.check_termination : 25;
   const double x = (double)iter + 0.5 * (double)N;
   long long v = (long long)floor(x - fmod(x, (double)N));                 // round_multiple(iter, N)

@@ -14,7 +14,10 @@
 // classes -- so a group accepts every problem the library can solve at all, as the reference's loop over models does.
 //
 // Host-side orchestration only: no kernel lives here.  Replaces: the reference's loop over models, src/solver.jl:78-203 per model.
+#include <stdlib.h>
 #include <string.h>
+#include <algorithm>
+#include <atomic>
 #include <map>
 #include <string>
 #include <thread>
@@ -31,6 +34,7 @@ struct GProblem {
   double cinv = 1.0;
   bool have = false, have_cones = false, have_scaling = false, have_x0 = false, have_s0 = false, have_mu0 = false;
   int cls = -1, pos = -1;         // class and position inside the class
+  bool dirty = true;              // set_iterates was called for THIS problem since the class last ran (or it never ran)
 };
 
 struct GClass {
@@ -40,6 +44,7 @@ struct GClass {
   std::vector<int> members;       // problem indices, ascending
   long long n = 0, m = 0, nbox = 0;
   bool iterates_dirty = true;
+  bool ran = false;               // the class has been optimized at least once (its device state is a solved / warm state)
 };
 
 }  // namespace
@@ -50,6 +55,7 @@ struct cosmo_hip_batch_group {
   std::vector<GProblem> prob;
   std::vector<GClass> cls;
   bool finalized = false, aa_on = false;
+  int last_workers = 0; long long last_jobs = 0;     // of the last optimize: worker threads, jobs (batch classes + members on their own handles)
   cosmo_hip_accel_params aa;
   cosmo_hip_params prm;
 };
@@ -230,6 +236,13 @@ extern "C" int32_t cosmo_hip_batch_group_class_info(cosmo_hip_batch_group* g, in
   return COSMO_HIP_OK;
 }
 
+// out = {worker threads of the last optimize, its jobs (batch classes + members solved on their own handles), classes, problems}
+extern "C" int32_t cosmo_hip_batch_group_run_info(cosmo_hip_batch_group* g, int64_t out[4]) {
+  if (!g || !out) return COSMO_HIP_ERR_INVALID;
+  out[0] = g->last_workers; out[1] = g->last_jobs; out[2] = (int64_t)g->cls.size(); out[3] = (int64_t)g->prob.size();
+  return COSMO_HIP_OK;
+}
+
 // warm start of problem k (NULL = zeros; src/solver.jl:128-129); problems never set start from zero
 extern "C" int32_t cosmo_hip_batch_group_set_iterates(cosmo_hip_batch_group* g, int64_t k, const real* x0, const real* s0, const real* mu0) {
   GCHECK(g, k);
@@ -239,6 +252,7 @@ extern "C" int32_t cosmo_hip_batch_group_set_iterates(cosmo_hip_batch_group* g, 
   if (x0) p.x0.assign(x0, x0 + p.n);
   if (s0) p.s0.assign(s0, s0 + p.m);
   if (mu0) p.mu0.assign(mu0, mu0 + p.m);
+  p.dirty = true;
   g->cls[(size_t)p.cls].iterates_dirty = true;
   return COSMO_HIP_OK;
 }
@@ -246,21 +260,34 @@ extern "C" int32_t cosmo_hip_batch_group_set_iterates(cosmo_hip_batch_group* g, 
 static int32_t flush_iterates(cosmo_hip_batch_group* g, GClass& C) {
   if (!C.iterates_dirty) return COSMO_HIP_OK;
   const size_t np = C.members.size();
+  // Dirtiness is tracked PER PROBLEM: a set_iterates on one member after the class has run must not throw the others back to their old
+  // staged start.  Single-handle members: only the touched handles are reset.  Batch classes: cosmo_hip_batch_set_iterates restarts the whole class, so
+  // the untouched members are handed their CURRENT device state (x, s, mu) as their start -- the warm start they already had.
   if (!C.b) {
     for (size_t j = 0; j < np; ++j) {
-      const GProblem& p = g->prob[(size_t)C.members[j]];
+      GProblem& p = g->prob[(size_t)C.members[j]];
+      if (C.ran && !p.dirty) continue;
       const int32_t rc = cosmo_hip_set_iterates(C.hs[j], p.have_x0 ? p.x0.data() : nullptr, p.have_s0 ? p.s0.data() : nullptr, p.have_mu0 ? p.mu0.data() : nullptr);
       if (rc) return gfail(g, rc, std::string("set_iterates of problem ") + std::to_string(C.members[j]) + ": " + cosmo_hip_last_error(C.hs[j]));
+      p.dirty = false;
     }
     C.iterates_dirty = false;
     return COSMO_HIP_OK;
   }
   std::vector<real> x((size_t)C.n * np, R(0.0)), s((size_t)C.m * np, R(0.0)), mu((size_t)C.m * np, R(0.0));
+  std::vector<real> wk((size_t)(C.n + C.m)), wp((size_t)(C.n + C.m));
   for (size_t j = 0; j < np; ++j) {
-    const GProblem& p = g->prob[(size_t)C.members[j]];
+    GProblem& p = g->prob[(size_t)C.members[j]];
+    if (C.ran && !p.dirty) {
+      const int32_t rc = cosmo_hip_batch_get_iterates(C.b, (int64_t)j, wk.data(), wp.data(), s.data() + (size_t)C.m * j, mu.data() + (size_t)C.m * j);
+      if (rc) return gfail(g, rc, std::string("batch_get_iterates: ") + cosmo_hip_batch_last_error(C.b));
+      std::copy(wp.begin(), wp.begin() + C.n, x.begin() + (size_t)C.n * j);       // x is the head of w_prev (src/types.jl:274)
+      continue;
+    }
     if (p.have_x0) std::copy(p.x0.begin(), p.x0.end(), x.begin() + (size_t)C.n * j);
     if (p.have_s0) std::copy(p.s0.begin(), p.s0.end(), s.begin() + (size_t)C.m * j);
     if (p.have_mu0) std::copy(p.mu0.begin(), p.mu0.end(), mu.begin() + (size_t)C.m * j);
+    p.dirty = false;
   }
   const int32_t rc = cosmo_hip_batch_set_iterates(C.b, x.data(), s.data(), mu.data());
   if (rc) return gfail(g, rc, std::string("batch_set_iterates: ") + cosmo_hip_batch_last_error(C.b));
@@ -275,18 +302,42 @@ extern "C" int32_t cosmo_hip_batch_group_optimize(cosmo_hip_batch_group* g, cosm
   const size_t nc = g->cls.size();
   std::vector<std::vector<cosmo_hip_result>> res(nc);
   std::vector<int32_t> rcs(nc, COSMO_HIP_OK);
-  auto run = [&](size_t ci) {
+  // JOBS: one per batch class (the class's own host loop on its own stream: persistent launch, certificate kernels, status copy) and one per MEMBER of a
+  // class that runs on single-problem handles (each handle has its own stream, so refused members overlap like classes do -- until round 6 they ran one
+  // after the other inside their class's thread).  A BOUNDED pool of worker threads takes the jobs off a shared counter, largest first: a list of 1024
+  // models of 1024 shapes (the reference's `for model in models; optimize!(model)`, src/solver.jl:78) is 1024 jobs on at most COSMO_HIP_GROUP_WORKERS
+  // (default 32) threads and streams in flight, not 1024 threads -- the chip has 256 CUs, and the runtime serialises the submissions anyway.
+  struct Job { size_t ci; long long j; double weight; };      // j < 0: the whole batch class
+  std::vector<Job> jobs;
+  for (size_t ci = 0; ci < nc; ++ci) {
     GClass& C = g->cls[ci];
     res[ci].resize(C.members.size());
-    if (C.b) { rcs[ci] = cosmo_hip_batch_optimize(C.b, res[ci].data()); return; }     // (sets the device for its thread; synchronises its own stream only)
-    for (size_t j = 0; j < C.members.size() && rcs[ci] == COSMO_HIP_OK; ++j) rcs[ci] = cosmo_hip_optimize(C.hs[j], &res[ci][j]);   // its members one after the other, each on its handle's stream
+    const double wt = (double)(C.n + C.m);
+    if (C.b) jobs.push_back({ci, -1, wt * (double)C.members.size()});
+    else for (size_t j = 0; j < C.members.size(); ++j) jobs.push_back({ci, (long long)j, 64.0 * wt});      // (the launch-per-kernel loop of a single handle is the slow path)
+  }
+  std::stable_sort(jobs.begin(), jobs.end(), [](const Job& a, const Job& b) { return a.weight > b.weight; });
+  std::vector<std::atomic<int32_t>> jrc(nc);
+  for (auto& v : jrc) v.store(COSMO_HIP_OK);
+  auto run = [&](const Job& jb) {
+    GClass& C = g->cls[jb.ci];
+    int32_t rc;
+    if (jb.j < 0) rc = cosmo_hip_batch_optimize(C.b, res[jb.ci].data());     // (sets the device for its thread; synchronises its own stream only)
+    else rc = cosmo_hip_optimize(C.hs[(size_t)jb.j], &res[jb.ci][(size_t)jb.j]);
+    if (rc) { int32_t expect = COSMO_HIP_OK; jrc[jb.ci].compare_exchange_strong(expect, rc); }
   };
-  if (nc == 1) run(0);
+  int nworkers = 32;
+  if (const char* e = getenv("COSMO_HIP_GROUP_WORKERS")) { const int v = atoi(e); if (v >= 1 && v <= 1024) nworkers = v; }
+  nworkers = (int)std::min<size_t>((size_t)nworkers, jobs.size());
+  g->last_workers = nworkers; g->last_jobs = (long long)jobs.size();
+  if (nworkers <= 1) { for (const Job& jb : jobs) run(jb); }
   else {
+    std::atomic<size_t> next(0);
     std::vector<std::thread> th;
-    for (size_t ci = 0; ci < nc; ++ci) th.emplace_back(run, ci);
+    for (int t = 0; t < nworkers; ++t) th.emplace_back([&]() { for (;;) { const size_t i = next.fetch_add(1); if (i >= jobs.size()) return; run(jobs[i]); } });
     for (auto& t : th) t.join();
   }
+  for (size_t ci = 0; ci < nc; ++ci) rcs[ci] = jrc[ci].load();
   for (size_t ci = 0; ci < nc; ++ci) {
     if (rcs[ci]) {
       std::string detail = g->cls[ci].b ? cosmo_hip_batch_last_error(g->cls[ci].b) : "";
@@ -294,7 +345,7 @@ extern "C" int32_t cosmo_hip_batch_group_optimize(cosmo_hip_batch_group* g, cosm
       return gfail(g, rcs[ci], std::string("optimize of the class of problem ") + std::to_string(g->cls[ci].members[0]) + ": " + detail);
     }
     for (size_t j = 0; j < g->cls[ci].members.size(); ++j) results[g->cls[ci].members[j]] = res[ci][j];
-    g->cls[ci].iterates_dirty = false;
+    g->cls[ci].iterates_dirty = false; g->cls[ci].ran = true;
   }
   return COSMO_HIP_OK;
 }

@@ -854,6 +854,9 @@ def prepare_batch_group(models: Sequence[Model], device: int):
     return G, st
 
 
+LAST_BATCH_INFO: dict = {}     # diagnostics of the last _solve_shard_on_device call (tests / timing labs)
+
+
 def _solve_shard_on_device(models: Sequence[Model], device: int) -> List[Result]:
     """All problems of the shard concurrently on one MI355X (one persistent workgroup per problem, csrc/batch.hip).  Problems of ONE structure take
     the batch directly; a mixed list goes through the batch group (one batch per structure class, all classes concurrently)."""
@@ -866,7 +869,12 @@ def _solve_shard_on_device(models: Sequence[Model], device: int) -> List[Result]
     mixed = len({_structure_key(md) for md in models}) > 1 or not _batch_kernels_take(models[0])
     B, st = prepare_batch_group(models, device) if mixed else prepare_batch(models, device)
     t_setup = time.perf_counter() - t0
+    t1 = time.perf_counter()
     rs = B.optimize()
+    LAST_BATCH_INFO.clear()
+    LAST_BATCH_INFO.update(dict(problems=len(models), mixed=bool(mixed), setup_seconds=t_setup, optimize_seconds=time.perf_counter() - t1))
+    if mixed:
+        LAST_BATCH_INFO.update(B.run_info())                       # worker threads / jobs of the group's bounded pool, structure classes
     out = []
     for k, (md, r) in enumerate(zip(models, rs)):
         w, w_prev, s, mu = B.get_iterates(k)

@@ -32,6 +32,8 @@ def settings(iters, tight=False):
         return cj.Settings(max_iter=iters, eps_abs=1e-6, eps_rel=1e-6, accelerator=cj.AndersonAccelerator,
                            kkt_solver=cj.with_options(cj.CGIndirectKKTSolver, tol_constant=1e-10, tol_exponent=0.0))
     kw = dict(max_iter=iters, eps_abs=0.0, eps_rel=0.0, check_infeasibility=10 ** 9)
+    if os.environ.get("COSMO_TEST_AUTO_RHO"):               # the automatic rho interval (adaptive_rho_interval = 0, solver.jl:244-256); setup times per rank: see main()
+        kw["adaptive_rho_interval"] = 0
     if os.environ.get("COSMO_TEST_TIMELIMIT"):              # a wall-clock limit (solver.jl:351-354): the ranks must stop at the same iteration
         kw["time_limit"] = float(os.environ["COSMO_TEST_TIMELIMIT"])
     if tight:
@@ -103,6 +105,12 @@ def build_model(iters):
                                 cj.Settings(max_iter=iters, scaling=0, kkt_solver=cj.with_options(cj.CGIndirectKKTSolver, tol_constant=1e-10, tol_exponent=0.0)))
         return md
     p = problem()
+    if case == "chordal_split":
+        # the same problem with its ZeroSet(20) written as ZeroSet(1) + ZeroSet(19): a cone of ONE row, so that an explicit partition (COSMO_TEST_BOUNDS)
+        # can give a rank a single row and no PSD cone; rows, matrices and therefore the single-rank iterates are unchanged
+        z = p["sets"][0]
+        assert z.kind == cj._ffi.ZERO and z.dim == 20
+        p["sets"] = [cj.ZeroSet(1), cj.ZeroSet(19)] + list(p["sets"][1:])
     dtype = np.float32 if os.environ.get("COSMO_TEST_DTYPE", "") == "float32" else np.float64       # libcosmo_hip_f32.so: the collectives carry float
     md = cj.Model(dtype=dtype); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], settings(iters, os.environ.get("COSMO_TEST_TIGHT", "") == "1"))
     return md
@@ -131,12 +139,18 @@ def main():
             uid = open(rdv, "rb").read()
         h.comm_init(rank, world, uid)
     mode = os.environ.get("COSMO_TEST_SHARD", "cones")
+    explicit = os.environ.get("COSMO_TEST_BOUNDS")              # "0,1,3,...": first cone of every rank + the number of cones (an explicit partition)
     if mode == "rows":
-        bounds = cj.partition_cones_contiguous(cj.model.row_shard_costs(md.sets), world)
+        bounds = [int(v) for v in explicit.split(",")] if explicit else cj.partition_cones_contiguous(cj.model.row_shard_costs(md.sets), world)
         h.set_row_shard(bounds)
     else:
-        bounds = cj.partition_cones_contiguous(cj.cone_costs(md.sets), world)
+        bounds = [int(v) for v in explicit.split(",")] if explicit else cj.partition_cones_contiguous(cj.cone_costs(md.sets), world)
         h.set_cone_shard(bounds)
+    if os.environ.get("COSMO_TEST_AUTO_RHO"):
+        # every rank is GIVEN its own ws.times.setup_time ("a,b,..." seconds by rank; model.optimize() would hand over this process's own measurement)
+        forced = float(os.environ["COSMO_TEST_AUTO_RHO"].split(",")[rank])
+        orig = h.set_setup_time
+        h.set_setup_time = lambda t: orig(forced)
     r = cj.optimize(md)
     st = h.comm_stats()
     ex = h.comm_stats_ex()
@@ -145,7 +159,7 @@ def main():
     np.savez(out, accelerated=acc["accelerated"], declined=acc["declined"], safeguarding_iter=acc["safeguarding_iter"], x=r.x, s=r.s, y=r.y, iter=r.iter, kkt=r.kkt_iters_total, obj=r.obj_val, r_prim=r.info.r_prim, r_dual=r.info.r_dual,
              bounds=np.array(bounds), exchanges=st["exchanges"], nranks=st["nranks"], transport=st["transport"], status=r.status,
              mode=ex["mode"], bytes=ex["bytes"], allreduces=ex["allreduces"], allreduce_elems=ex["allreduce_elems"],
-             row_lo=info["row_lo"], row_hi=info["row_hi"], rho_updates=np.array(r.info.rho_updates))
+             row_lo=info["row_lo"], row_hi=info["row_hi"], rho_updates=np.array(r.info.rho_updates), rho_interval=np.array(h.rho_interval()))
 
 
 if __name__ == "__main__":

@@ -120,6 +120,85 @@ def test_heterogeneous_batch_equals_the_single_problem_solves():
             assert np.array_equal(mixed[i].x, a.x) and np.array_equal(mixed[i].s, a.s) and mixed[i].kkt_iters_total == a.kkt_iters_total
 
 
+def _many_shapes(count, seed=2024):
+    """`count` problems of `count` DISTINCT structures (dimensions and cone tables): Zero / Nonnegatives / Box rows throughout, every fourth with second-order
+    cones, every eighth with small PSD cones."""
+    rng = np.random.default_rng(seed)
+    probs, keys = [], set()
+    for k in range(count):
+        n = 16 + (k % 37)
+        mz, mn, mb = 1 + (k % 5), 8 + (k // 5) % 23, 6 + (k // 3) % 17
+        soc = (3 + k % 4, 4 + (k // 7) % 5) if k % 4 == 1 else ()
+        psd = (3 + (k // 8) % 6,) if k % 8 == 2 else ()
+        p = util.random_qp(rng, n, mz, mn, mb, soc_dims=soc, psd_tri_dims=psd, p_shift=1.0)
+        key = (n, tuple((K.kind, K.dim) for K in p["sets"]))
+        while key in keys:                                                       # bump the Nonnegatives block until the structure is new
+            mn += 29
+            p = util.random_qp(rng, n, mz, mn, mb, soc_dims=soc, psd_tri_dims=psd, p_shift=1.0)
+            key = (n, tuple((K.kind, K.dim) for K in p["sets"]))
+        keys.add(key)
+        probs.append(p)
+    return probs
+
+
+def test_256_problems_of_256_shapes_against_the_oracle_and_against_sequential_solves():
+    """the reference's batch mode is `for model in models; optimize!(model); end` over ARBITRARY models (src/solver.jl:78).  256 models
+    of 256 distinct structures through optimize_batch -- 256 structure classes of one problem each inside the group, solved by a BOUNDED pool of worker
+    threads (at most 32 streams in flight, not 256 threads) -- (i) every result equals oracle.solve of that problem (status, iteration within one check
+    interval, objective 1e-4): the direct device-vs-oracle check of the group path; (ii) in less wall time than 256 sequential optimize calls."""
+    import time
+    probs = _many_shapes(256)
+    st = cj.Settings()
+    t0 = time.perf_counter()
+    res = cj.optimize_batch(_models(probs, st))
+    t_group = time.perf_counter() - t0
+    info = dict(cj.model.LAST_BATCH_INFO)
+    assert info["problems"] == 256 and info["mixed"] and info["classes"] == 256 and info["jobs"] == 256 and 1 <= info["workers"] <= 32
+    t0 = time.perf_counter()
+    seq = []
+    for p in probs:
+        md = cj.Model(); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], cj.Settings())
+        seq.append(cj.optimize(md)); md.handle.close()
+    t_seq = time.perf_counter() - t0
+    print("256 shapes: group %.2f s (setup %.2f s, optimize %.2f s, %d workers) vs sequential single-problem solves %.2f s" %
+          (t_group, info["setup_seconds"], info["optimize_seconds"], info["workers"], t_seq))
+    bad = []
+    for k, (p, r, one) in enumerate(zip(probs, res, seq)):
+        ref = O.solve(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), O.Settings(kkt_solver="cg"))
+        ok = (r.status == ref.status and abs(r.iter - ref.iter) <= 25 and abs(r.obj_val - ref.obj_val) <= 1e-4 * (1 + abs(ref.obj_val)))
+        ok1 = (one.status == ref.status and abs(one.iter - ref.iter) <= 25 and abs(one.obj_val - ref.obj_val) <= 1e-4 * (1 + abs(ref.obj_val)))
+        if not (ok and ok1):
+            bad.append((k, r.status, r.iter, r.obj_val, one.status, one.iter, ref.status, ref.iter, ref.obj_val))
+    assert not bad, bad[:5]
+    assert all(r.status == "Solved" for r in res)
+    assert t_group < t_seq, (t_group, t_seq)
+
+
+def test_set_iterates_on_one_member_keeps_the_other_members_state():
+    """dirtiness of the staged warm starts is tracked per problem.  After an optimize, set_iterates on ONE member of a batch class restarts the class
+    with that member's new start and every other member's CURRENT state as its start: the untouched member, already solved, is done at the first check
+    instead of repeating its whole run from the old staged start."""
+    rng = np.random.default_rng(5)
+    probs = [util.random_qp(rng, 30, 4, 20, 40) for _ in range(3)]
+    G = F.BatchGroup(len(probs))
+    for k, p in enumerate(probs):
+        G.set_problem(k, p["P"], p["q"], p["A"], p["b"])
+        bl = [K.l for K in p["sets"] if K.kind == F.BOX]; bu = [K.u for K in p["sets"] if K.kind == F.BOX]
+        G.set_cones(k, [K.kind for K in p["sets"]], [K.dim for K in p["sets"]], np.concatenate(bl) if bl else None, np.concatenate(bu) if bu else None)
+    prm = F.Params(); G.lib.cosmo_hip_default_params(C_byref(prm))
+    G.set_params(prm)
+    r1 = G.optimize()
+    assert all(F.STATUS_NAMES[r.status] == "Solved" for r in r1) and all(r.iter > 25 for r in r1)
+    x_before = [G.get_iterates(k)[1][:30].copy() for k in range(3)]
+    G.set_iterates(1, np.zeros(30), None, None)                                # only problem 1 starts again (from zero)
+    r2 = G.optimize()
+    assert F.STATUS_NAMES[r2[1].status] == "Solved" and r2[1].iter == r1[1].iter          # the same cold run as before
+    for k in (0, 2):
+        assert F.STATUS_NAMES[r2[k].status] == "Solved" and r2[k].iter <= 25 < r1[k].iter          # warm at its solution: done at the first check
+        assert np.max(np.abs(G.get_iterates(k)[1][:30] - x_before[k])) <= 1e-3 * max(1.0, np.max(np.abs(x_before[k])))
+    G.close()
+
+
 def test_heterogeneous_batch_group_abi():
     """The C ABI of the group directly: class partition, per-problem warm start, counters; an unsupported member is the group's error."""
     probs = _hetero_problems()

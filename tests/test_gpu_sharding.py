@@ -321,6 +321,108 @@ def test_row_sharded_run_with_a_time_limit_stops_all_ranks_at_the_same_iteration
         assert np.array_equal(z[0][key].view(np.int64), z[1][key].view(np.int64)), key
 
 
+def test_row_sharded_auto_rho_interval_fires_on_all_ranks_together_when_their_setup_times_differ():
+    """adaptive_rho_interval = 0 (the automatic interval, src/solver.jl:244-256) in a row-sharded run where the ranks were GIVEN different
+    ws.times.setup_time (rank 0: 0 s -- its rule would fire at the first test; rank 1: 1e9 s -- alone it would never fire).  The decision is collective
+    (max over the ranks of elapsed - fraction * setup_time, csrc/api.hip: auto_rho_interval): both ranks fix the SAME interval at the SAME iteration,
+    schedule the same rho checks, and finish with the same bits.  Before the fix rank 0 stopped calling the decision's all-reduce while
+    rank 1 kept calling it: mismatched collectives -- this test then ends in the spawn timeout."""
+    with tempfile.TemporaryDirectory() as tmp:
+        global ITERS
+        keep = ITERS
+        ITERS = 130
+        try:
+            outs = _spawn("shm", 2, "/cosmo_test_" + uuid.uuid4().hex[:12], tmp, timeout=300,
+                          extra_env={"COSMO_TEST_SHARD": "rows", "COSMO_TEST_AUTO_RHO": "0.0,1000000000.0"})
+        finally:
+            ITERS = keep
+        for rc, o in outs:
+            assert rc == 0, o[-3000:]
+        z = [np.load(os.path.join(tmp, "rank%d.npz" % r)) for r in range(2)]
+    assert list(z[0]["rho_interval"]) == list(z[1]["rho_interval"])
+    interval, fixed_at = int(z[0]["rho_interval"][0]), int(z[0]["rho_interval"][1])
+    assert interval == 25 and 0 < fixed_at <= 25                       # fired at the first test point of the plain loop: round_multiple(iter, 25) = 25
+    assert int(z[0]["iter"]) == int(z[1]["iter"]) == 130 and int(z[0]["kkt"]) == int(z[1]["kkt"])
+    assert len(z[0]["rho_updates"]) == len(z[1]["rho_updates"]) and np.array_equal(z[0]["rho_updates"], z[1]["rho_updates"])
+    for key in ("x", "s", "y"):
+        assert np.array_equal(z[0][key].view(np.int64), z[1][key].view(np.int64)), key
+
+
+def _split_reference(monkeypatch, tight):
+    """single-rank run of the worker's problem with the ZeroSet written as ZeroSet(1) + ZeroSet(19) (COSMO_TEST_CASE=chordal_split)"""
+    W = _worker_module()
+    monkeypatch.setenv("COSMO_HIP_POLAR_KLIFT", "10")
+    p = W.problem()
+    sets = [cj.ZeroSet(1), cj.ZeroSet(19)] + list(p["sets"][1:])
+    md = cj.Model(); md.set(p["P"], p["q"], p["A"], p["b"], sets, W.settings(ITERS, tight))
+    return cj.optimize(md), md
+
+
+@pytest.mark.parametrize("world", [4, 8])
+@pytest.mark.parametrize("mode", ["rows", "cones"])
+def test_first_contact_readiness_four_and_eight_ranks_incl_a_rank_without_psd_cones_and_a_single_row_rank(mode, world, monkeypatch):
+    """What the first real multi-GPU run (driver-side, unattended: `bench.py --gpus 8`) can meet, found on ONE GPU: 4 and 8 ranks over the
+    host-staged transport, with an explicit partition in which rank 0 owns a SINGLE ROW (a ZeroSet(1)) and rank 1 owns the other simple rows -- neither owns a
+    PSD cone, so their handles have no sign-iteration plan and their projections / residual partials are trivial -- while the cliques are dealt to the other
+    ranks (8 ranks: one or two cliques each).  Row-sharded (csrc/rowshard.hip; the loop being sharded: src/convexset.jl:885-891 and
+    src/linear_solver/kktsolver_indirect.jl:52-54): 1e-7 against the single-rank run in tight-CG mode and bit-identical ranks; clique-sharded
+    (csrc/comm.hip): bit-identical to the single-rank run."""
+    tight = mode == "rows"
+    ref, md = _split_reference(monkeypatch, tight)
+    ncones = len(md.sets)                                           # ZeroSet(1), ZeroSet(19), Nonnegatives(40), 14 cliques
+    assert ncones == 17
+    # ranks 0 and 1: no PSD cone; the 14 cliques over the remaining world - 2 ranks, contiguous
+    rest = world - 2
+    cuts = [3 + (14 * k) // rest for k in range(rest + 1)]
+    bounds = [0, 1] + cuts
+    assert len(bounds) == world + 1 and bounds[-1] == ncones and all(b > a for a, b in zip(bounds, bounds[1:]))
+    env = {"COSMO_TEST_SHARD": mode, "COSMO_TEST_CASE": "chordal_split", "COSMO_TEST_BOUNDS": ",".join(str(b) for b in bounds)}
+    if tight:
+        env["COSMO_TEST_TIGHT"] = "1"
+    with tempfile.TemporaryDirectory() as tmp:
+        outs = _spawn("shm", world, "/cosmo_test_" + uuid.uuid4().hex[:12], tmp, timeout=420, extra_env=env)
+        for rc, o in outs:
+            assert rc == 0, o[-3000:]
+        zs = [np.load(os.path.join(tmp, "rank%d.npz" % r)) for r in range(world)]
+    rows = 0
+    for r, z in enumerate(zs):
+        assert int(z["nranks"]) == world and int(z["transport"]) == 2 and list(z["bounds"]) == bounds
+        assert int(z["iter"]) == ref.iter == ITERS and str(z["status"]) == ref.status
+        if mode == "rows":
+            rows += int(z["row_hi"]) - int(z["row_lo"])
+            if r == 0:
+                assert int(z["row_hi"]) - int(z["row_lo"]) == 1                   # the single-row rank
+            for key, val in (("x", ref.x), ("s", ref.s), ("y", ref.y)):
+                assert np.max(np.abs(z[key] - val)) <= 1e-7 * max(np.max(np.abs(val)), 1e-30), (r, key)
+            assert int(z["allreduces"]) >= ITERS + 1 and int(z["allreduce_elems"]) in (md.n, md.n + 2 * world)
+        else:
+            assert int(z["kkt"]) == ref.kkt_iters_total
+            for key, val in (("x", ref.x), ("s", ref.s), ("y", ref.y)):
+                assert np.array_equal(z[key].view(np.int64), val.view(np.int64)), (r, key)
+    if mode == "rows":
+        assert rows == md.m
+    for z in zs[1:]:                                                               # identical bits on every rank
+        for key in ("x", "s", "y"):
+            assert np.array_equal(z[key].view(np.int64), zs[0][key].view(np.int64)), key
+        assert int(z["kkt"]) == int(zs[0]["kkt"]) and float(z["obj"]) == float(zs[0]["obj"])
+
+
+def test_bench_gpus_8_dry_run_prints_a_well_formed_line_with_parity_evidence():
+    """`bench.py --gpus 8` as the driver launches it (torch.distributed.run, 8 ranks), all ranks on ONE GPU over the host-staged transport
+    (COSMO_BENCH_TRANSPORT=shm): the row-sharded headline with `parity_ok`, eight per-rank times, the flat parity scalars the driver's parsed copy keeps
+    and the summary tail.  The committed line of this command is profiles/r06_cfg5_row_sharded_8ranks_one_gpu_dryrun.json."""
+    env = dict(os.environ, COSMO_BENCH_TRANSPORT="shm", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "6", "--warmup", "2", "--small", "--no-extra", "--no-cpu-baseline"]
+    out = _one_json_line(subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900))
+    assert out["n_gpus"] == 8 and out["steps"] == 6 and out["value"] > 0 and out["scaling"] == "strong" and "DRY RUN" in out["data"]
+    cfg = out["config"]
+    assert cfg["parity_ok"] is True and cfg["parity_ranks_bit_identical"] is True and 0.0 <= cfg["parity_sharded_vs_single_max_rel_dev"] <= 1e-7
+    assert cfg["comm_selftest"] == "ok" and cfg["comm"]["nranks"] == 8 and len(cfg["rank_seconds"]["per_rank"]) == 8
+    assert "sharded over 8 ranks" in cfg["parallelism"] and cfg["speedup_vs_single_gpu"] > 0
+    assert list(out)[-1] == "summary" and out["summary"]["parity_ok"] is True
+
+
 def test_row_sharded_run_with_a_user_defined_cone():
     """The AbstractConvexCone plugin surface (src/projections.jl:4-5; docs/src/literate/custom_cone.jl) on a row-sharded handle: the rank that owns the
     user's cone keeps its host callback (local cone index / row offset), the other rank has none; 300 tight-CG iterations agree with the single-rank
