@@ -751,9 +751,9 @@ class BatchGroup:
 
     def run_info(self):
         """worker threads and jobs of the last optimize (a bounded pool), classes, problems"""
-        out = np.zeros(4, dtype=np.int64)
+        out = np.zeros(5, dtype=np.int64)
         self._chk(self.lib.cosmo_hip_batch_group_run_info(self._g, out.ctypes.data_as(_PI64)))
-        return dict(zip(["workers", "jobs", "classes", "problems"], out.tolist()))
+        return dict(zip(["workers", "jobs", "classes", "problems", "merged_classes"], out.tolist()))
 
     def set_iterates(self, k, x0=None, s0=None, mu0=None):
         n, m = self.dims[int(k)]

@@ -661,8 +661,7 @@ __device__ __forceinline__ void aa_reset(const AaMem& M, Each each) {
 // single-problem form).  Every inner product of the accelerator is a block sum of the workgroup, every decision (success of the least-squares
 // step, safeguarding, deferred rho update / infeasibility check) is taken by the workgroup for its problem.
 template <int BS, bool PSD, bool AA, class Ops>
-__device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams& P, long long iter_target, int do_init, Ops& ops, real* red) {
-  const int k = blockIdx.x;
+__device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams& P, long long iter_target, int do_init, Ops& ops, real* red, const int k) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n = D.n, m = D.m;
   BCtl* ctl = D.ctl + k;
@@ -954,7 +953,21 @@ __global__ __launch_bounds__(COSMO_BS) void k_batch_admm(BatchDev D, BParams P, 
   if (D.ctl[k].status != 0) return;
   StreamOps ops;
   ops.A = bview(D.A, k); ops.AT = bview(D.AT, k); ops.PT = bview(D.PT, k); ops.lds = lds; ops.red = red; ops.psd_ws = psd_ws;
-  batch_admm_body<COSMO_BS, PSD, AA>(D, P, iter_target, do_init, ops, red);
+  batch_admm_body<COSMO_BS, PSD, AA>(D, P, iter_target, do_init, ops, red, k);
+}
+
+// MERGED launch over one-problem batches of DIFFERENT structure (batch_multi_optimize): the streaming form takes any size and reads everything it needs
+// about its problem from the descriptor -- one workgroup per batch, one launch for all of them
+template <bool PSD>
+__global__ __launch_bounds__(COSMO_BS) void k_batch_admm_multi(const BatchDev* __restrict__ Ds, BParams P, long long iter_target, int do_init) {
+  __shared__ real lds[COSMO_NNZ_PER_BLOCK];
+  __shared__ real red[COSMO_BS / 64];
+  __shared__ __attribute__((aligned(16))) unsigned char psd_ws[PSD ? (COSMO_BS / 64) * PSD16_WS_STRIDE : 16];
+  const BatchDev& D = Ds[blockIdx.x];
+  if (D.ctl[0].status != 0) return;
+  StreamOps ops;
+  ops.A = bview(D.A, 0); ops.AT = bview(D.AT, 0); ops.PT = bview(D.PT, 0); ops.lds = lds; ops.red = red; ops.psd_ws = psd_ws;
+  batch_admm_body<COSMO_BS, PSD, false>(D, P, iter_target, do_init, ops, red, 0);
 }
 
 // LDS-resident variant: `img` holds one image of `img_stride` bytes per problem (header + arrays, see build_lds_images)
@@ -984,7 +997,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_lds(BatchDev D, BParams P, lo
   ops.xv = wsp; ops.tv = wsp + D.n; ops.red = wsp + D.n + D.m; ops.n = D.n;
   ops.psd_ws = base + ((img_stride + (long long)sizeof(real) * (D.n + D.m + 2 * (BS / 64)) + 15) / 16) * 16;     // behind the reduction slots (build_lds_images sizes it)
   __syncthreads();
-  batch_admm_body<BS, PSD, AA>(D, P, iter_target, do_init, ops, ops.red);
+  batch_admm_body<BS, PSD, AA>(D, P, iter_target, do_init, ops, ops.red, k);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1702,22 +1715,24 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
 // Accelerated batches run the check kernel only on the problems whose workgroup asked for it (BAa::need_inf).
 // ---------------------------------------------------------------------------------------------------------------------
 // delta_y at the top of the iteration that follows a flagged one: dy = mu = rho .* (w_prev_s - s)            (solver.jl:145-148)
-__global__ __launch_bounds__(COSMO_BS) void k_batch_inf_capture(BatchDev D) {
-  const int k = blockIdx.x;
+__device__ __forceinline__ void batch_inf_capture_body(const BatchDev& D, const int k) {
   if (D.ctl[k].status != 0) return;
   const int n = D.n, m = D.m;
   const long long om = (long long)k * m, onm = (long long)k * (n + m);
   for (int i = threadIdx.x; i < m; i += COSMO_BS) D.inf_dy[om + i] = D.rho[om + i] * (D.w_prev[onm + n + i] - D.s[om + i]);
 }
+__global__ __launch_bounds__(COSMO_BS) void k_batch_inf_capture(BatchDev D) { batch_inf_capture_body(D, (int)blockIdx.x); }
+// MERGED launches over several one-problem batches of different structure (batch_multi_optimize below): workgroup c takes the descriptor Ds[c] of ITS
+// batch -- dimensions, cone tables, matrix and iterate pointers -- from global memory instead of the kernel arguments, and runs problem 0 of it
+__global__ __launch_bounds__(COSMO_BS) void k_batch_inf_capture_multi(const BatchDev* __restrict__ Ds) { batch_inf_capture_body(Ds[blockIdx.x], 0); }
 
 // flagged_only (accelerated batches): only the problems whose workgroup left its launch for this test (BAa::need_inf), see batch_admm_body
-__global__ __launch_bounds__(COSMO_BS) void k_batch_inf_check(BatchDev D, real epi, real edi, int flagged_only) {
+__device__ __forceinline__ void batch_inf_check_body(const BatchDev& D, const int k, real epi, real edi, int flagged_only) {
   __shared__ real lds[COSMO_NNZ_PER_BLOCK];
   __shared__ real red[COSMO_BS / 64];
   __shared__ int flag;
   __shared__ __attribute__((aligned(16))) unsigned char psd_ws[(COSMO_BS / 64) * PSD16_WS_STRIDE];
   __shared__ int flag2;
-  const int k = blockIdx.x;
   BCtl* ctl = D.ctl + k;
   if (ctl->status != 0) return;
   if (flagged_only) {
@@ -1857,6 +1872,14 @@ __global__ __launch_bounds__(COSMO_BS) void k_batch_inf_check(BatchDev D, real e
     __syncthreads();
     if (!flag && tid == 0) { ctl->status = COSMO_HIP_DUAL_INFEASIBLE; ctl->cost = -(real)INFINITY; }   // solver.jl:343-346
   }
+}
+
+__global__ __launch_bounds__(COSMO_BS) void k_batch_inf_check(BatchDev D, real epi, real edi, int flagged_only) { batch_inf_check_body(D, (int)blockIdx.x, epi, edi, flagged_only); }
+__global__ __launch_bounds__(COSMO_BS) void k_batch_inf_check_multi(const BatchDev* __restrict__ Ds, real epi, real edi) { batch_inf_check_body(Ds[blockIdx.x], 0, epi, edi, 0); }
+// the control blocks of the merged batches, gathered into one array for ONE copy to the host per slice
+__global__ void k_batch_pack_ctl_multi(const BatchDev* __restrict__ Ds, int count, BCtl* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < count) out[c] = Ds[c].ctl[0];
 }
 
 // what the host loop of an accelerated batch needs after every launch: 16 bytes per problem instead of the whole BCtl (600 B) + BAa (2.2 KB) arrays
@@ -2826,6 +2849,76 @@ extern "C" int32_t cosmo_hip_batch_optimize(cosmo_hip_batch* b, cosmo_hip_result
     for (int i = 0; i < COSMO_HIP_MAX_RHO_UPDATES && i < c[k].n_rho_updates; ++i) r.rho_updates[i] = (double)c[k].rho_updates[i];
   }
   return COSMO_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// MERGED optimize over `count` one-problem batches of different structure (csrc/batch_group.hip: the singleton classes of a heterogeneous list).  The
+// reference's batch mode is `for model in models; optimize!(model); end` (src/solver.jl:78): a list of 256 models of 256 shapes used to be 256 host loops
+// of single-workgroup launches; here it is ONE host loop (the non-accelerated branch of cosmo_hip_batch_optimize) whose every launch covers all of them --
+// workgroup c runs the streaming kernel on the descriptor of batch c.  Same per-problem arithmetic as k_batch_admm (batch_admm_body), hence the same
+// iterates as a one-problem streaming batch; certificates and time limit as there.  Requirements (batch_multi_supported): one problem, no accelerator,
+// no PSD cone of side 17..64 (their Jacobi workspace is sized per launch).  All batches carry the group's parameters.
+// ---------------------------------------------------------------------------------------------------------------------
+bool batch_multi_supported(const cosmo_hip_batch* b) { return b && b->finalized && b->nprob == 1 && !b->aa_on && b->D.nmid == 0 && b->D.A.rowptr != nullptr; }
+bool batch_multi_needs_ext(const cosmo_hip_batch* b) { return b->D.npsd > 0 || b->D.n3 > 0; }
+
+int32_t batch_multi_optimize(cosmo_hip_batch** bs, int count, bool ext, cosmo_hip_result* results) {
+  if (count <= 0) return COSMO_HIP_OK;
+  cosmo_hip_batch* b = bs[0];                                     // errors are reported on the first batch; its stream carries the merged launches
+  for (int c = 0; c < count; ++c) if (!bs[c]->have_iterates) return bfail(b, COSMO_HIP_ERR_INVALID, "batch_multi_optimize: set_iterates first");
+  if (hipSetDevice(b->device) != hipSuccess) return bfail(b, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
+  for (int c = 0; c < count; ++c) BHIP(b, hipStreamSynchronize(bs[c]->stream));          // every batch's set_iterates ran on its own stream
+  std::vector<BatchDev> hd((size_t)count);
+  for (int c = 0; c < count; ++c) hd[(size_t)c] = bs[c]->D;
+  BatchDev* dD = nullptr; BCtl* dC = nullptr;
+  BHIP(b, hipMalloc((void**)&dD, sizeof(BatchDev) * (size_t)count));
+  if (hipMalloc((void**)&dC, sizeof(BCtl) * (size_t)count) != hipSuccess) { (void)hipFree(dD); return bfail(b, COSMO_HIP_ERR_HIP, "hipMalloc failed"); }
+  auto done = [&](int32_t rc) { (void)hipFree(dD); (void)hipFree(dC); return rc; };
+  if (hipMemcpy(dD, hd.data(), sizeof(BatchDev) * (size_t)count, hipMemcpyHostToDevice) != hipSuccess) return done(bfail(b, COSMO_HIP_ERR_HIP, "hipMemcpy failed"));
+  const BParams P = bparams(b, true);
+  const auto t0 = std::chrono::steady_clock::now();
+  const long long slice = std::max<long long>(b->prm.check_termination, 1) * 8;
+  const long long ci = b->prm.check_infeasibility;
+  const bool inf_on = ci > 1 && ci < b->prm.max_iter;
+  bool captured = false;
+  long long target = 0;
+  std::vector<BCtl> c((size_t)count);
+  int first = 1;
+  for (;;) {
+    long long stop = captured ? target + 1 : target + slice;
+    if (inf_on && !captured) stop = std::min(stop, (target / ci + 1) * ci);
+    target = std::min<long long>(stop, b->prm.max_iter);
+    if (ext) hipLaunchKernelGGL((k_batch_admm_multi<true>), dim3(count), dim3(COSMO_BS), 0, b->stream, (const BatchDev*)dD, P, target, first);
+    else hipLaunchKernelGGL((k_batch_admm_multi<false>), dim3(count), dim3(COSMO_BS), 0, b->stream, (const BatchDev*)dD, P, target, first);
+    first = 0;
+    if (captured) {
+      hipLaunchKernelGGL(k_batch_inf_check_multi, dim3(count), dim3(COSMO_BS), 0, b->stream, (const BatchDev*)dD, (real)b->prm.eps_prim_inf, (real)b->prm.eps_dual_inf);
+      captured = false;
+    } else if (inf_on && target % ci == 0 && target < b->prm.max_iter) {
+      hipLaunchKernelGGL(k_batch_inf_capture_multi, dim3(count), dim3(COSMO_BS), 0, b->stream, (const BatchDev*)dD);
+      captured = true;
+    }
+    hipLaunchKernelGGL(k_batch_pack_ctl_multi, dim3((count + 255) / 256), dim3(256), 0, b->stream, (const BatchDev*)dD, count, dC);
+    if (hipMemcpyAsync(c.data(), dC, sizeof(BCtl) * (size_t)count, hipMemcpyDeviceToHost, b->stream) != hipSuccess || hipStreamSynchronize(b->stream) != hipSuccess)
+      return done(bfail(b, COSMO_HIP_ERR_HIP, "merged batch launch failed: %s", hipGetErrorString(hipGetLastError())));
+    bool all = true;
+    for (auto& x : c) if (x.status == 0) { all = false; break; }
+    if (all || target >= b->prm.max_iter) break;
+    if (b->prm.time_limit != 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > b->prm.time_limit) {
+      for (auto& x : c) if (x.status == 0) x.status = COSMO_HIP_TIME_LIMIT_REACHED;
+      break;
+    }
+  }
+  const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  for (int k = 0; k < count; ++k) {
+    cosmo_hip_result& r = results[k];
+    memset(&r, 0, sizeof r);
+    r.status = c[(size_t)k].status; r.n_rho_updates = c[(size_t)k].n_rho_updates; r.iter = c[(size_t)k].iter; r.kkt_iters_total = c[(size_t)k].kkt_iters_total;
+    r.kkt_solves = c[(size_t)k].solves; r.cost = (double)c[(size_t)k].cost; r.r_prim = (double)c[(size_t)k].r_prim; r.r_dual = (double)c[(size_t)k].r_dual;
+    r.max_norm_prim = (double)c[(size_t)k].max_norm_prim; r.max_norm_dual = (double)c[(size_t)k].max_norm_dual; r.rho = (double)c[(size_t)k].rho; r.iter_time = el;
+    for (int i = 0; i < COSMO_HIP_MAX_RHO_UPDATES && i < c[(size_t)k].n_rho_updates; ++i) r.rho_updates[i] = (double)c[(size_t)k].rho_updates[i];
+  }
+  return done(COSMO_HIP_OK);
 }
 
 // Runs exactly n_iters more iterations on every undecided problem (benchmark / parity hook); no early exit on time.

@@ -55,7 +55,7 @@ struct cosmo_hip_batch_group {
   std::vector<GProblem> prob;
   std::vector<GClass> cls;
   bool finalized = false, aa_on = false;
-  int last_workers = 0; long long last_jobs = 0;     // of the last optimize: worker threads, jobs (batch classes + members on their own handles)
+  int last_workers = 0; long long last_jobs = 0, last_merged = 0;     // of the last optimize: worker threads, jobs (merged sets + batch classes + members on their own handles), classes in merged sets
   cosmo_hip_accel_params aa;
   cosmo_hip_params prm;
 };
@@ -236,10 +236,11 @@ extern "C" int32_t cosmo_hip_batch_group_class_info(cosmo_hip_batch_group* g, in
   return COSMO_HIP_OK;
 }
 
-// out = {worker threads of the last optimize, its jobs (batch classes + members solved on their own handles), classes, problems}
-extern "C" int32_t cosmo_hip_batch_group_run_info(cosmo_hip_batch_group* g, int64_t out[4]) {
+// out = {worker threads of the last optimize, its jobs (merged sets + batch classes + members solved on their own handles), classes, problems, classes that
+// ran inside a merged set}
+extern "C" int32_t cosmo_hip_batch_group_run_info(cosmo_hip_batch_group* g, int64_t out[5]) {
   if (!g || !out) return COSMO_HIP_ERR_INVALID;
-  out[0] = g->last_workers; out[1] = g->last_jobs; out[2] = (int64_t)g->cls.size(); out[3] = (int64_t)g->prob.size();
+  out[0] = g->last_workers; out[1] = g->last_jobs; out[2] = (int64_t)g->cls.size(); out[3] = (int64_t)g->prob.size(); out[4] = g->last_merged;
   return COSMO_HIP_OK;
 }
 
@@ -307,19 +308,47 @@ extern "C" int32_t cosmo_hip_batch_group_optimize(cosmo_hip_batch_group* g, cosm
   // after the other inside their class's thread).  A BOUNDED pool of worker threads takes the jobs off a shared counter, largest first: a list of 1024
   // models of 1024 shapes (the reference's `for model in models; optimize!(model)`, src/solver.jl:78) is 1024 jobs on at most COSMO_HIP_GROUP_WORKERS
   // (default 32) threads and streams in flight, not 1024 threads -- the chip has 256 CUs, and the runtime serialises the submissions anyway.
-  struct Job { size_t ci; long long j; double weight; };      // j < 0: the whole batch class
+  // MERGED SETS (round 6): the singleton classes whose batch the streaming kernel takes (batch_multi_supported) do not get a host loop each -- all of them run
+  // in ONE host loop whose launches cover every member (batch.hip: batch_multi_optimize, k_batch_admm_multi: workgroup c reads the descriptor of batch c) --
+  // one set for the classes that need the extended-cone code, one for the others.  COSMO_HIP_GROUP_MERGE=0 keeps one job per class.
+  struct Job { size_t ci; long long j; double weight; int set; };      // j < 0: the whole batch class; set >= 0: merged set `set` (ci unused)
   std::vector<Job> jobs;
+  std::vector<size_t> msets[2];
+  bool merge = !g->aa_on;
+  if (const char* e = getenv("COSMO_HIP_GROUP_MERGE")) merge = merge && atoi(e) != 0;
   for (size_t ci = 0; ci < nc; ++ci) {
     GClass& C = g->cls[ci];
     res[ci].resize(C.members.size());
+    if (merge && C.b && C.members.size() == 1 && batch_multi_supported(C.b)) msets[batch_multi_needs_ext(C.b) ? 1 : 0].push_back(ci);
+  }
+  // a set pays from about a dozen classes on (the streaming form is the slowest kernel per problem; what it saves is host loops and single-workgroup
+  // launches): smaller lists keep one job per class and with it the kernel form -- and the bits -- of a uniform batch of each structure
+  size_t min_set = 16;
+  if (const char* e = getenv("COSMO_HIP_GROUP_MERGE_MIN")) { const int v = atoi(e); if (v >= 2) min_set = (size_t)v; }
+  for (int t = 0; t < 2; ++t) if (msets[t].size() < min_set) msets[t].clear();
+  std::vector<char> in_set(nc, 0);
+  for (int t = 0; t < 2; ++t) { double wsum = 0.0; for (size_t ci : msets[t]) { in_set[ci] = 1; wsum += (double)(g->cls[ci].n + g->cls[ci].m); } if (!msets[t].empty()) jobs.push_back({0, -1, 4.0 * wsum, t}); }
+  g->last_merged = (long long)(msets[0].size() + msets[1].size());
+  for (size_t ci = 0; ci < nc; ++ci) {
+    GClass& C = g->cls[ci];
+    if (in_set[ci]) continue;
     const double wt = (double)(C.n + C.m);
-    if (C.b) jobs.push_back({ci, -1, wt * (double)C.members.size()});
-    else for (size_t j = 0; j < C.members.size(); ++j) jobs.push_back({ci, (long long)j, 64.0 * wt});      // (the launch-per-kernel loop of a single handle is the slow path)
+    if (C.b) jobs.push_back({ci, -1, wt * (double)C.members.size(), -1});
+    else for (size_t j = 0; j < C.members.size(); ++j) jobs.push_back({ci, (long long)j, 64.0 * wt, -1});      // (the launch-per-kernel loop of a single handle is the slow path)
   }
   std::stable_sort(jobs.begin(), jobs.end(), [](const Job& a, const Job& b) { return a.weight > b.weight; });
   std::vector<std::atomic<int32_t>> jrc(nc);
   for (auto& v : jrc) v.store(COSMO_HIP_OK);
   auto run = [&](const Job& jb) {
+    if (jb.set >= 0) {
+      const std::vector<size_t>& ms = msets[jb.set];
+      std::vector<cosmo_hip_batch*> bs; std::vector<cosmo_hip_result> rr(ms.size());
+      for (size_t ci : ms) bs.push_back(g->cls[ci].b);
+      const int32_t rc = batch_multi_optimize(bs.data(), (int)bs.size(), jb.set == 1, rr.data());
+      for (size_t i = 0; i < ms.size(); ++i) { res[ms[i]][0] = rr[i]; if (rc) { int32_t expect = COSMO_HIP_OK; jrc[ms[i]].compare_exchange_strong(expect, rc); } }
+      if (rc && !ms.empty() && ms[0] != 0) { /* the error text lives on the first batch of the set */ }
+      return;
+    }
     GClass& C = g->cls[jb.ci];
     int32_t rc;
     if (jb.j < 0) rc = cosmo_hip_batch_optimize(C.b, res[jb.ci].data());     // (sets the device for its thread; synchronises its own stream only)

@@ -313,6 +313,11 @@ void sr_free(cosmo_hip_handle* h);
 int32_t sr_enqueue_start(cosmo_hip_handle* h, int guard);
 int32_t sr_enqueue_iterations(cosmo_hip_handle* h, int guard, int k_begin, int count);
 
+// merged launches over one-problem batches of different structure (batch.hip; used by batch_group.hip)
+bool batch_multi_supported(const cosmo_hip_batch* b);
+bool batch_multi_needs_ext(const cosmo_hip_batch* b);
+int32_t batch_multi_optimize(cosmo_hip_batch** bs, int count, bool ext, cosmo_hip_result* results);
+
 // persistent CG (cg_persist.hip)
 int32_t pcg_setup(cosmo_hip_handle* h);
 void pcg_free(cosmo_hip_handle* h);

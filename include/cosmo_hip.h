@@ -504,9 +504,10 @@ COSMO_HIP_API int32_t cosmo_hip_batch_group_set_params(cosmo_hip_batch_group* g,
  * persistent batch kernel, 1 = its structure is outside the batch kernels (PSD side > 64, a MINRES solver kind, ...) and every member is solved
  * through its own single-problem handle, concurrently with the batch classes */
 COSMO_HIP_API int32_t cosmo_hip_batch_group_class_info(cosmo_hip_batch_group* g, int64_t* nclasses, int64_t* class_of, int64_t* mode_of);
-/* out = {worker threads of the last cosmo_hip_batch_group_optimize (a bounded pool: COSMO_HIP_GROUP_WORKERS, default 32), its jobs (one per batch class + one
- * per member that runs on its own handle), classes, problems} */
-COSMO_HIP_API int32_t cosmo_hip_batch_group_run_info(cosmo_hip_batch_group* g, int64_t out[4]);
+/* out = {worker threads of the last cosmo_hip_batch_group_optimize (a bounded pool: COSMO_HIP_GROUP_WORKERS, default 32), its jobs (one per MERGED SET of
+ * one-problem classes -- all of them run in one host loop whose every launch covers them, workgroup c reading the descriptor of class c --, one per other batch
+ * class, one per member that runs on its own handle), classes, problems, classes that ran inside a merged set} */
+COSMO_HIP_API int32_t cosmo_hip_batch_group_run_info(cosmo_hip_batch_group* g, int64_t out[5]);
 /* warm start of problem k (n, m, m entries; NULL = zeros); problems never set start from zero (src/solver.jl:128-129) */
 COSMO_HIP_API int32_t cosmo_hip_batch_group_set_iterates(cosmo_hip_batch_group* g, int64_t k, const cosmo_hip_real* x0, const cosmo_hip_real* s0, const cosmo_hip_real* mu0);
 /* optimize! for every problem; results has nprob entries in the caller's order */
