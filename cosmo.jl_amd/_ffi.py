@@ -442,9 +442,9 @@ class Handle:
         return self.lib.cosmo_hip_kkt_recurrence(self._h).decode()
 
     def fold_stats(self):
-        out = np.zeros(4, dtype=np.int64)
+        out = np.zeros(6, dtype=np.int64)
         self._chk(self.lib.cosmo_hip_fold_stats(self._h, out.ctypes.data_as(_PI64)))
-        return dict(zip(["enabled", "nnz", "terms", "tiles"], out.tolist()))
+        return dict(zip(["enabled", "nnz", "terms", "tiles", "factored_rows", "stored_entries"], out.tolist()))
 
     # ---- measurement -------------------------------------------------------------------------------------------
     def time_spmv(self, which, reps=50):

@@ -563,6 +563,7 @@ int32_t build_op_split(cosmo_hip_handle* h, bool force) {
 // recurrence needs +1.2 % Krylov iterations, outside the +-1 per solve the parity tests allow; profiles/r06_cg_one_launch_default.txt).
 int32_t choose_cg_recurrence(cosmo_hip_handle* h) {
   if (h->prm.kkt_kind != COSMO_HIP_KKT_CG || h->cg_jacobi || h->cg_sr || !h->op_fold) return COSMO_HIP_OK;
+  if (((FoldPlan*)h->fold)->nd > 0) return COSMO_HIP_OK;          // a partially assembled operator belongs to the literal pair
   const char* e = getenv("COSMO_HIP_CG_SR_DEFAULT");
   if (!e || atoi(e) == 0) return COSMO_HIP_OK;
   h->cg_sr = true; h->cg_sr_auto = true;
@@ -1459,7 +1460,8 @@ extern "C" int32_t cosmo_hip_time_krylov(cosmo_hip_handle* h, int32_t reps, doub
   double bytes; int nl;
   if (h->op_fold) {
     const FoldPlan* f = (const FoldPlan*)h->fold;
-    bytes = 12.0 * (double)f->M.nnz + 4.0 * (n + 1) + 16.0 * n + 8.0 * 10.0 * n;       // B_spmv(M) + B_cgvec (n-side); Jacobi adds dinv: + 8 n
+    bytes = 12.0 * (double)f->nnz_full + 4.0 * (n + 1) + 16.0 * n + 8.0 * 10.0 * n;    // B_spmv(M) of the FULLY assembled operator (the unit since round 2; a partially
+                                                                                        // assembled operator streams fewer entries for the same product) + B_cgvec (n-side); Jacobi adds dinv: + 8 n
     if (h->cg_jacobi) bytes += 8.0 * n;
     nl = 2;
     if (h->cg_sr) nl = 1;      // one-launch recurrence: the SAME algorithmic bytes (SURVEY 8d prices a Krylov iteration of the reference: operator + 10 n-vectors; the
@@ -1480,6 +1482,8 @@ extern "C" const char* cosmo_hip_kkt_recurrence(cosmo_hip_handle* h) {
   static const char* sr_names[] = {"", "k_sr_M<1>", "k_sr_M<2>", "k_sr_M<3>", "k_sr_M<4>", "", "", "", "k_sr_M<8>"};
   static const char* pair_names[] = {"", "k_cg_dirM<1, false> + k_cg_upd<false>", "k_cg_dirM<2, false> + k_cg_upd<false>", "k_cg_dirM<3, false> + k_cg_upd<false>",
                                      "k_cg_dirM<4, false> + k_cg_upd<false>", "", "", "", "k_cg_dirM<8, false> + k_cg_upd<false>"};
+  static const char* updf_names[] = {"", "k_cg_dirM<1, false> + k_cg_updF", "k_cg_dirM<2, false> + k_cg_updF", "k_cg_dirM<3, false> + k_cg_updF", "k_cg_dirM<4, false> + k_cg_updF", "", "", "",
+                                     "k_cg_dirM<8, false> + k_cg_updF"};
   static const char* pc_names[] = {"", "k_cg_dirM<1, true> + k_cg_upd<true>", "k_cg_dirM<2, true> + k_cg_upd<true>", "k_cg_dirM<3, true> + k_cg_upd<true>",
                                    "k_cg_dirM<4, true> + k_cg_upd<true>", "", "", "", "k_cg_dirM<8, true> + k_cg_upd<true>"};
   static thread_local char buf[256];
@@ -1494,6 +1498,7 @@ extern "C" const char* cosmo_hip_kkt_recurrence(cosmo_hip_handle* h) {
     return buf;
   }
   if (h->cg_sr) return "cg: single-reduction recurrence, two launches per iteration (kkt_kind CG_SR), k_sr_update_A + k_sr_op";
+  if (h->op_fold && f->nd > 0) { snprintf(buf, sizeof buf, "cg: literal recurrence on the partially assembled operator (%d rows of A kept factored), two launches per iteration, %s", f->nd, updf_names[sl]); return buf; }
   if (h->op_fold) { snprintf(buf, sizeof buf, "cg: literal recurrence on the assembled operator, two launches per iteration, %s", pair_names[sl]); return buf; }
   return h->cg_ru ? "cg: literal recurrence, three launches per iteration, k_cg_dirA + k_op_apply + k_cg_upd<false>"
                   : "cg: literal recurrence, four launches per iteration, k_cg_dir + k_spmv_A_rho + k_op_apply + k_cg_upd<false>";

@@ -245,6 +245,13 @@ __device__ __forceinline__ void lds_read64(real& d, uint32_t addr) {
 }
 __device__ __forceinline__ void lds_read_u32(uint32_t& d, uint32_t addr) { asm volatile("ds_read_b32 %0, %1" : "=v"(d) : "v"(addr)); }
 __device__ __forceinline__ void lds_read_u16(uint32_t& d, uint32_t addr) { asm volatile("ds_read_u16 %0, %1" : "=v"(d) : "v"(addr)); }
+// CONSTRAINT of the counted waits below: `s_waitcnt lgkmcnt(1)` means "the older LDS reads have arrived" only while NO scalar memory load is in
+// flight -- s_load / s_buffer_load share the lgkm counter and return out of order, and the compiler's wait-count insertion does not see the counters of
+// inline asm.  Two guards: (1) every hand-scheduled loop starts with lds_drain() (`s_waitcnt lgkmcnt(0)`: whatever the compiler issued in front of the loop --
+// kernel-argument loads hoisted to that point, as found in the Float32 build of k_batch_admm_reg<512, 1, 2, true, false, false> -- has returned before the
+// first asm read); (2) tests/test_isa_lgkm_waits.py disassembles both libraries at build time and fails if any counted lgkm wait can be reached with a
+// scalar load outstanding, i.e. if a future compiler schedules one INTO a loop.
+__device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)"); }
 // wait until at most ONE LDS operation is outstanding; the operands tie the registers whose loads have arrived to this point of the program
 __device__ __forceinline__ void lds_wait1(uint32_t& i, real& a, real& g) { asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(i), "+v"(a), "+v"(g)); }
 __device__ __forceinline__ void lds_wait1(uint32_t& i) { asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(i)); }
@@ -267,6 +274,7 @@ __device__ __forceinline__ real row_pipe3(uint32_t idx, uint32_t val, const uint
   };
   const uint32_t vlast = val + ((uint32_t)(len - 1) << RSH);
   uint32_t v1 = (len > 1) ? val + (1u << RSH) : vlast;           // value address of nonzero k + 1 (PAIR = false)
+  lds_drain();
   load_idx(iA);                                                   // P(0)
   load_idx(iB);                                                   // P(1)
   lds_wait1(iA);
@@ -313,6 +321,7 @@ __device__ __forceinline__ real row_sliced(uint32_t ip, uint32_t vp, const int l
   real s = 0.0;
   uint32_t iA = 0, iB = 0;
   real aA = 0.0, gA = 0.0, aB = 0.0, gB = 0.0;
+  lds_drain();
   lds_r16o<0>(iA, ip);
   lds_r16o<SL_LANES * 2>(iB, ip);
   lds_wait1(iA);
@@ -347,6 +356,7 @@ __device__ __forceinline__ real rowT_sliced(uint32_t ip, const int len, const in
   real s = 0.0;
   uint32_t iA = 0, iB = 0;
   real aA = 0.0, gA = 0.0, aB = 0.0, gB = 0.0;
+  lds_drain();
   lds_r32o<0>(iA, ip);
   lds_r32o<SL_LANES * 4>(iB, ip);
   lds_wait1(iA);

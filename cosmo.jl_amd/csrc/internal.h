@@ -109,6 +109,18 @@ struct FoldPlan {
   void* chain_cf = nullptr; // the same chain with check_first = 1 (iterations expected to be no-ops)
   int chain_len = 0;        // Krylov iterations per launch of the chain
   int chain_off = 0;        // COSMO_HIP_CG_GRAPH=0
+  // PARTIAL ASSEMBLY (round 6): rows of Am with >= 4 nonzeros (`dense` rows: a row of len nonzeros costs len^2 assembled entries but 2 len factored ones) stay
+  // FACTORED: M = Ms + Ad' diag(rho_d) Ad.  The stored matrix is the row-merged [Ms | Ad' rho_d] (n x (n + nd), split_col = n); the columns >= n gather from
+  // the records tt[kd] = {(Ad r)_kd, (Ad u_prev)_kd} exactly as the columns < n gather from {r, u}.  k_cg_updF forms (Ad r_new) as a FRESH product from the
+  // complete vectors of the iteration -- sum a_kj (r_j - alpha c_j), the owners' own expression -- for which the {r, u} records are double-buffered by
+  // iteration parity (the owners write the new records while the dense rows gather the old ones).  (A first version advanced (Ad r) by linearity,
+  // tr -= alpha (Ad c): a recurrence whose absolute error stays at eps |Ad r_0| while r shrinks -- 5e-7 trajectory deviations at a 1e-10 stopping threshold.)
+  int nd = 0;               // dense rows kept factored (0: fully assembled)
+  long long nnz_full = 0;   // nonzeros the FULLY assembled operator has (the unit of the bench's algorithmic bytes)
+  CsrDev Ad;                // the dense rows (nd x n, values without rho) with their own CSR-stream tiles
+  real2* tt = nullptr;    // nd records {Ad r, Ad u_prev}
+  real* tcur = nullptr;   // nd: Ad u of the iteration in flight (written by k_cg_dirM, stored into the record by k_cg_updF)
+  real* tx = nullptr;     // nd: Ad x (solve start)
   // the same for the one-launch single-reduction recurrence (cg_sr.hip: k_sr_M); chain_len is even there (records / partials alternate by parity)
   void* sr_chain = nullptr;
   void* sr_chain_cf = nullptr;

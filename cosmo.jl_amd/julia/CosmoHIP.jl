@@ -273,9 +273,9 @@ end
 
 kkt_recurrence(h::Handle) = unsafe_string(ccall((:cosmo_hip_kkt_recurrence, lib(h)), Cstring, (Ptr{Cvoid},), h.ptr))   # which Krylov recurrence / kernels the handle's KKT solves run
 function fold_stats(h::Handle)      # assembled reduced CG operator (cosmo_hip_fold_stats)
-    out = zeros(Int64, 4)
+    out = zeros(Int64, 6)
     check(h, ccall((:cosmo_hip_fold_stats, lib(h)), Int32, (Ptr{Cvoid}, Ptr{Int64}), h.ptr, out))
-    return (enabled = out[1] != 0, nnz = out[2], terms = out[3], tiles = out[4])
+    return (enabled = out[1] != 0, nnz = out[2], terms = out[3], tiles = out[4], factored_rows = out[5], stored_entries = out[6])
 end
 function polar_streamk_stats(h::Handle)      # stream-K product of the large PSD cones (cosmo_hip_polar_streamk_stats)
     out = zeros(Int64, 4)

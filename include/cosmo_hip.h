@@ -308,8 +308,10 @@ COSMO_HIP_API int32_t cosmo_hip_cg_persist_stats(cosmo_hip_handle* h, int64_t ou
 COSMO_HIP_API int32_t cosmo_hip_get_kkt_solution(cosmo_hip_handle* h, cosmo_hip_real* sol);
 /* Assembled reduced operator of the CG solve (csrc/cg_fold.hip): M = P + diag(sigma + d) + Am' rho Am as ONE sparse matrix where the
  * operator split leaves a sparse Am' rho Am (decomposed SDPs), two launches per Krylov iteration instead of three.
- * out = {enabled, nnz(M), rho-weighted terms behind its entries, CSR-stream tiles}.  COSMO_HIP_OP_FOLD=0 in the environment disables it. */
-COSMO_HIP_API int32_t cosmo_hip_fold_stats(cosmo_hip_handle* h, int64_t out[4]);
+ * out = {enabled, nnz of the fully assembled M, rho-weighted terms behind the stored entries, CSR-stream tiles, rows of Am kept FACTORED (partial assembly,
+ * round 6: a row of len >= 4 nonzeros costs len^2 assembled entries but 2 len factored ones; 0 = fully assembled), stored entries of [Ms | Ad' rho]}.
+ * COSMO_HIP_OP_FOLD=0 in the environment disables the assembly, COSMO_HIP_FOLD_FACTOR=0 the factored rows. */
+COSMO_HIP_API int32_t cosmo_hip_fold_stats(cosmo_hip_handle* h, int64_t out[6]);
 /* Which Krylov recurrence / kernels the KKT solves of this handle run (valid after cosmo_hip_set_params; a string owned by the library, e.g.
  * "cg: literal recurrence on the assembled operator, two launches per iteration, k_cg_dirM<3, false> + k_cg_upd<false>"): bench.py's
  * config.kkt_solver and roofline.kernel. */
