@@ -212,3 +212,42 @@ def test_padded_tile_major_operator_copy_is_bit_identical(kkt, monkeypatch):
     a, b = out["1"], out["0"]
     assert a.kkt_iters_total == b.kkt_iters_total > 0 and list(a.info.rho_updates) == list(b.info.rho_updates) and len(a.info.rho_updates) >= 2
     assert np.array_equal(a.x, b.x) and np.array_equal(a.s, b.s) and np.array_equal(a.y, b.y)
+
+
+@pytest.mark.parametrize("name", sorted(PROBLEMS))
+def test_partially_assembled_operator_opt_in(name, monkeypatch):
+    """Opt-in COSMO_HIP_FOLD_FACTOR=1 (round 6): rows of Am with >= 4 nonzeros stay FACTORED, M = Ms + Ad' rho Ad; their columns of the stored matrix gather
+    {(Ad r), (Ad u_prev)} records, k_cg_updF forms (Ad r_new) as a fresh product from parity-buffered {r, u} records.  Same operator in another association:
+    held to the fold tests' own tolerances against the fully assembled form, the unfolded operator and the oracle (tight mode: 1e-7 trajectories, Krylov totals
+    +-1 per solve), and the captured chain (even length: records alternate by parity) against direct launches bit for bit."""
+    prob = PROBLEMS[name]()
+    iters = 60
+    monkeypatch.setenv("COSMO_HIP_FOLD_FACTOR", "1")
+    md1, r1 = _run(monkeypatch, "1", prob, iters, **TIGHT)
+    fs = md1.handle.fold_stats()
+    assert fs["enabled"] == 1 and fs["factored_rows"] > 0 and 2 * fs["stored_entries"] <= fs["nnz"] and "partially assembled" in md1.handle.kkt_recurrence()
+    monkeypatch.setenv("COSMO_HIP_FOLD_FACTOR", "0")
+    md2, r2 = _run(monkeypatch, "1", prob, iters, **TIGHT)
+    assert md2.handle.fold_stats()["factored_rows"] == 0 and md2.handle.fold_stats()["nnz"] == fs["nnz"]
+    md0, r0 = _run(monkeypatch, "0", prob, iters, **TIGHT)
+    for other in (r2, r0):
+        assert abs(r1.kkt_iters_total - other.kkt_iters_total) <= iters + 1, (r1.kkt_iters_total, other.kkt_iters_total)
+        for a, b in ((r1.x, other.x), (r1.s, other.s), (r1.y, other.y)):
+            assert np.max(np.abs(a - b)) <= 1e-7 * max(1.0, float(np.max(np.abs(b))))
+    ref = O.solve(prob["P"], prob["q"], prob["A"], prob["b"], util.oracle_cones(prob["sets"]),
+                  O.Settings(max_iter=iters, eps_abs=0.0, eps_rel=0.0, check_infeasibility=10 ** 9, kkt_solver="cg", tol_constant=1e-10, tol_exponent=0.0))
+    for a, b in ((r1.x, ref.x), (r1.s, ref.s), (r1.y, ref.y)):
+        assert np.max(np.abs(a - b)) <= 1e-7 * max(1.0, float(np.max(np.abs(b))))
+    # captured chain (odd requested length: rounded up) vs direct launches, default schedule with rho adaptation
+    monkeypatch.setenv("COSMO_HIP_FOLD_FACTOR", "1")
+    res = {}
+    for graph in ("0", "1"):
+        monkeypatch.setenv("COSMO_HIP_CG_GRAPH", graph)
+        monkeypatch.setenv("COSMO_HIP_CG_GRAPH_LEN", "3")
+        st = cj.Settings(max_iter=90, eps_abs=0.0, eps_rel=0.0, check_infeasibility=10 ** 9)
+        md = cj.Model(); md.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)
+        res[graph] = cj.optimize(md)
+        assert md.handle.fold_stats()["factored_rows"] > 0
+    a, b = res["0"], res["1"]
+    assert np.array_equal(a.x, b.x) and np.array_equal(a.s, b.s) and np.array_equal(a.y, b.y) and a.kkt_iters_total == b.kkt_iters_total
+    assert list(a.info.rho_updates) == list(b.info.rho_updates)
