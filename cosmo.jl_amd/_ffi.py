@@ -147,10 +147,12 @@ SIGNATURES = {
     "cosmo_hip_batch_group_set_problem": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, _PI64, _PI64, _PR, _PI64, _PI64, _PR, _PR, _PR]),
     "cosmo_hip_batch_group_set_cones": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int64, _PI32, _PI64, _PR, _PR, _PR]),
     "cosmo_hip_batch_group_set_scaling": (C.c_int32, [C.c_void_p, C.c_int64, _PR, _PR, C.c_double]),
+    "cosmo_hip_batch_group_set_scaling_full": (C.c_int32, [C.c_void_p, C.c_int64, _PR, _PR, _PR, _PR, C.c_double, C.c_double]),
     "cosmo_hip_batch_group_set_accelerator": (C.c_int32, [C.c_void_p, C.POINTER(AccelParams)]),
     "cosmo_hip_batch_group_set_params": (C.c_int32, [C.c_void_p, C.POINTER(Params)]),
     "cosmo_hip_batch_group_class_info": (C.c_int32, [C.c_void_p, _PI64, _PI64, _PI64]),
     "cosmo_hip_batch_group_run_info": (C.c_int32, [C.c_void_p, _PI64]),
+    "cosmo_hip_batch_group_get_rho_interval": (C.c_int32, [C.c_void_p, C.c_int64, _PI64]),
     "cosmo_hip_batch_group_set_iterates": (C.c_int32, [C.c_void_p, C.c_int64, _PR, _PR, _PR]),
     "cosmo_hip_batch_group_optimize": (C.c_int32, [C.c_void_p, C.POINTER(ResultStruct)]),
     "cosmo_hip_batch_group_get_iterates": (C.c_int32, [C.c_void_p, C.c_int64, _PR, _PR, _PR, _PR]),
@@ -730,6 +732,11 @@ class BatchGroup:
         n, m = self.dims[int(k)]
         self._chk(self.lib.cosmo_hip_batch_group_set_scaling(self._g, int(k), _dp(self._f(Dinv, n)), _dp(self._f(Einv, m)), float(cinv)))
 
+    def set_scaling_full(self, k, D, Dinv, E, Einv, c, cinv):
+        n, m = self.dims[int(k)]
+        self._chk(self.lib.cosmo_hip_batch_group_set_scaling_full(self._g, int(k), _dp(self._f(D, n)), _dp(self._f(Dinv, n)), _dp(self._f(E, m)), _dp(self._f(Einv, m)),
+                                                                  float(c), float(cinv)))
+
     def set_accelerator(self, kind=ACCEL_ANDERSON, mem=15, min_mem=3, safeguard=True, safeguard_tol=2.0, start_iter=2, start_accuracy=None):
         ap = AccelParams()
         self.lib.cosmo_hip_default_accel_params(C.byref(ap))
@@ -748,6 +755,12 @@ class BatchGroup:
         cls = np.zeros(self.nprob, dtype=np.int64); mode = np.zeros(self.nprob, dtype=np.int64)
         self._chk(self.lib.cosmo_hip_batch_group_class_info(self._g, C.byref(nc), cls.ctypes.data_as(_PI64), mode.ctypes.data_as(_PI64)))
         return (int(nc.value), cls, mode) if with_modes else (int(nc.value), cls)
+
+    def rho_interval(self, k):
+        """(adaptive_rho_interval in force for problem k, iteration at which the automatic rule fixed it or -1)"""
+        out = np.zeros(2, dtype=np.int64)
+        self._chk(self.lib.cosmo_hip_batch_group_get_rho_interval(self._g, int(k), out.ctypes.data_as(_PI64)))
+        return int(out[0]), int(out[1])
 
     def run_info(self):
         """worker threads and jobs of the last optimize (a bounded pool), classes, problems"""

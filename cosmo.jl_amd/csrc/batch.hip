@@ -2503,7 +2503,10 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
     fn = b->aa_on ? (const void*)k_batch_admm_reg<512, 1, 2, false, true, true>
                   : ((npsd > 0 || n3 > 0 || b->force_ext) ? (const void*)k_batch_admm_reg<512, 1, 2, true, false, true> : (const void*)k_batch_admm_reg<512, 1, 2, false, false, true>);
 #endif
-  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, b->lds_bytes) != hipSuccess) {
+  // The attribute belongs to the kernel INSTANTIATION, which is process-global, not to this batch: a batch group builds several classes that share an
+  // instantiation with different lds_bytes, from several threads.  It is therefore set to the device maximum (every lds_bytes is <= max_lds by construction),
+  // so that a later, smaller class cannot lower it under an earlier one's launch on a runtime that enforces the value.
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds) != hipSuccess) {
     (void)hipGetLastError();
     b->d_img = nullptr; b->reg_mode = 0;          // the device does not grant that much LDS: streaming kernel
   }

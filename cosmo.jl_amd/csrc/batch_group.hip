@@ -29,7 +29,7 @@ namespace {
 struct GProblem {
   long long n = 0, m = 0;
   std::vector<int64_t> Pp, Pi, Ap, Ai;
-  std::vector<real> Px, Ax, q, b, box_l, box_u, Dinv, Einv, x0, s0, mu0;
+  std::vector<real> Px, Ax, q, b, box_l, box_u, Dinv, Einv, Dsc, Esc, x0, s0, mu0;     // Dsc / Esc: D, E themselves where the caller handed them over (set_scaling_full)
   std::vector<int32_t> ctype; std::vector<int64_t> cdim; std::vector<real> cparam;
   double cinv = 1.0;
   bool have = false, have_cones = false, have_scaling = false, have_x0 = false, have_s0 = false, have_mu0 = false;
@@ -137,6 +137,19 @@ extern "C" int32_t cosmo_hip_batch_group_set_scaling(cosmo_hip_batch_group* g, i
   return COSMO_HIP_OK;
 }
 
+// The same with D, E and c themselves (cosmo_hip_set_scaling_full): a member that runs on its own handle then carries EXACTLY the scaling matrices of a
+// single-handle solve into its infeasibility tests (src/infeasibility.jl:5,35,39) instead of reciprocals of reciprocals.
+extern "C" int32_t cosmo_hip_batch_group_set_scaling_full(cosmo_hip_batch_group* g, int64_t k, const real* D, const real* Dinv, const real* E, const real* Einv, double c,
+                                                          double cinv) {
+  const int32_t rc = cosmo_hip_batch_group_set_scaling(g, k, Dinv, Einv, cinv);
+  if (rc) return rc;
+  (void)c;
+  GProblem& p = g->prob[(size_t)k];
+  if (D) p.Dsc.assign(D, D + p.n); else p.Dsc.clear();
+  if (E) p.Esc.assign(E, E + p.m); else p.Esc.clear();
+  return COSMO_HIP_OK;
+}
+
 // the reference's accelerator for every problem (as cosmo_hip_batch_set_accelerator); before set_params
 extern "C" int32_t cosmo_hip_batch_group_set_accelerator(cosmo_hip_batch_group* g, const cosmo_hip_accel_params* p) {
   if (!g) return COSMO_HIP_ERR_INVALID;
@@ -212,7 +225,11 @@ extern "C" int32_t cosmo_hip_batch_group_set_params(cosmo_hip_batch_group* g, co
         if ((hr = cosmo_hip_set_cones_ex(h, (int64_t)p.ctype.size(), p.ctype.data(), p.cdim.data(), p.box_l.empty() ? nullptr : p.box_l.data(),
                                          p.box_u.empty() ? nullptr : p.box_u.data(), p.cparam.data()))) return hbad(hr, h, "set_cones", k);
         if ((hr = cosmo_hip_set_params(h, prm, nullptr))) return hbad(hr, h, "set_params", k);
-        if (p.have_scaling && (hr = cosmo_hip_set_scaling(h, p.Dinv.data(), p.Einv.data(), p.cinv))) return hbad(hr, h, "set_scaling", k);
+        if (p.have_scaling) {
+          if (!p.Dsc.empty() && !p.Esc.empty()) hr = cosmo_hip_set_scaling_full(h, p.Dsc.data(), p.Dinv.data(), p.Esc.data(), p.Einv.data(), 1.0 / p.cinv, p.cinv);
+          else hr = cosmo_hip_set_scaling(h, p.Dinv.data(), p.Einv.data(), p.cinv);
+          if (hr) return hbad(hr, h, "set_scaling", k);
+        }
         if (g->aa_on && (hr = cosmo_hip_set_accelerator(h, &g->aa))) return hbad(hr, h, "set_accelerator", k);      // (the order of optimize_hip! / model.setup)
       }
       continue;
@@ -233,6 +250,19 @@ extern "C" int32_t cosmo_hip_batch_group_class_info(cosmo_hip_batch_group* g, in
   if (out_nclasses) *out_nclasses = (int64_t)g->cls.size();
   if (class_of) for (size_t k = 0; k < g->prob.size(); ++k) class_of[k] = g->prob[k].cls;
   if (mode_of) for (size_t k = 0; k < g->prob.size(); ++k) mode_of[k] = g->cls[(size_t)g->prob[k].cls].b ? 0 : 1;     // 0: persistent batch kernel, 1: its own handle
+  return COSMO_HIP_OK;
+}
+
+// the adaptive-rho interval in force for problem k: out = {interval (0: the automatic rule of solver.jl:244-256 has not fired), iteration at which the
+// automatic rule fixed it or -1} -- what the reference writes back into settings.adaptive_rho_interval (solver.jl:249-254).  Problems inside a batch class
+// run on the fixed interval of the group's parameters (the automatic interval is one of the structures the batch kernels refuse).
+extern "C" int32_t cosmo_hip_batch_group_get_rho_interval(cosmo_hip_batch_group* g, int64_t k, int64_t out[2]) {
+  GCHECK(g, k);
+  if (!g->finalized || !out) return gfail(g, COSMO_HIP_ERR_INVALID, "batch_group_get_rho_interval: set_params first");
+  const GProblem& p = g->prob[(size_t)k];
+  GClass& C = g->cls[(size_t)p.cls];
+  if (!C.b) { const int32_t rc = cosmo_hip_get_rho_interval(C.hs[(size_t)p.pos], out); return rc ? gfail(g, rc, cosmo_hip_last_error(C.hs[(size_t)p.pos])) : COSMO_HIP_OK; }
+  out[0] = g->prm.adaptive_rho_interval; out[1] = -1;
   return COSMO_HIP_OK;
 }
 

@@ -44,6 +44,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <mutex>
 
 #define PK 16   // k panel
 #ifndef POLAR_PREFETCH_DEPTH
@@ -1204,8 +1205,8 @@ static void launch_symm_gemm(cosmo_hip_handle* h, int guard, const int* gate, co
                              real alpha, real beta) {
   const int nt = ld / TS, ntiles = nt * (nt + 1) / 2;
   constexpr int smem = (SK == 2) ? GemmCfg<TS>::SMEM2 : GemmCfg<TS>::SMEM;
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_symm_gemm<EPI, TS, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_set = true; }
+  static std::once_flag attr_once;         // (handles of a batch group set up their plans from several threads)
+  std::call_once(attr_once, [&]() { (void)hipFuncSetAttribute((const void*)k_symm_gemm<EPI, TS, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); });
   hipLaunchKernelGGL((k_symm_gemm<EPI, TS, SK>), dim3(((ntiles + 7) / 8) * 8), dim3(256 * SK), smem, h->stream, h->ctl, guard, gate, A, B, Cin, C, ld,
                      ntiles, alpha, beta);
   static_cast<PolarPlan*>(h->psd_polar)->launches[TS == 64 ? 0 : (SK == 2 ? 2 : 1)] += 1;
@@ -1216,8 +1217,8 @@ static void launch_symm_gemm_sk(cosmo_hip_handle* h, int guard, const int* gate,
   PolarPlan* q = static_cast<PolarPlan*>(h->psd_polar);
   const int nt = ld / SKG_TS, ntiles = nt * (nt + 1) / 2;
   constexpr int smem = GemmCfg<SKG_TS>::SMEM;
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_symm_gemm_sk<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_set = true; }
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [&]() { (void)hipFuncSetAttribute((const void*)k_symm_gemm_sk<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); });
   q->sk_epoch += 1u; if (q->sk_epoch == 0u) q->sk_epoch = 1u;
   hipLaunchKernelGGL((k_symm_gemm_sk<EPI>), dim3(G), dim3(256), smem, h->stream, h->ctl, guard, gate, A, B, Cin, C, ld, ntiles, ncls, alpha, beta,
                      q->sk_scratch, q->sk_sync, q->sk_base, q->sk_epoch);

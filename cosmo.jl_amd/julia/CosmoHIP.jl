@@ -179,13 +179,13 @@ function set_accelerator!(h::Handle{T}, settings::COSMO.Settings{T}) where {T <:
 end
 
 # the settings struct of the ABI is Float64 in both libraries: a Float32 setting converts exactly (Params' constructor converts)
-function params_from(settings::COSMO.Settings{T}, kkt_kind::Int32; tol_constant = 1.0, tol_exponent = 1.5) where {T <: HipFloat}
+function params_from(settings::COSMO.Settings{T}, kkt_kind::Int32; tol_constant = 1.0, tol_exponent = 1.5, setup_time = 0.0) where {T <: HipFloat}
     s = settings
     Params(s.sigma, s.alpha, s.rho, s.eps_abs, s.eps_rel, s.eps_prim_inf, s.eps_dual_inf, tol_constant, tol_exponent,
            s.RHO_MIN, s.RHO_MAX, s.RHO_TOL, s.RHO_EQ_OVER_RHO_INEQ, s.adaptive_rho_tolerance, s.COSMO_INFTY * s.MIN_SCALING,
            s.time_limit, s.max_iter, min(s.adaptive_rho_max_adaptions, typemax(Int64) >> 1), kkt_kind, s.check_termination,
            s.check_infeasibility, s.adaptive_rho ? 1 : 0, s.adaptive_rho_interval, s.scaling != 0 ? 1 : 0, s.obj_true, s.obj_true_tol,
-           s.adaptive_rho_fraction, 0.0)      # setup_time: handed over by optimize_hip! through cosmo_hip_set_setup_time once setup! has ended
+           s.adaptive_rho_fraction, Float64(setup_time))      # setup_time: optimize_hip! hands it over through cosmo_hip_set_setup_time once setup! has ended; optimize_hip_batch! puts its measured set-up phase here
 end
 
 function set_params!(h::Handle{T}, p::Params, rho_vec::Union{Vector{T}, Nothing}) where {T <: HipFloat}
@@ -404,7 +404,7 @@ end
 # Per problem the unchanged reference code does the scaling / classification (setup!, src/setup.jl:18-42) and the epilogue
 # (src/solver.jl:167-201); the loop of src/solver.jl:137-176 runs on the device for all problems at once.
 # ---------------------------------------------------------------------------------------------------------------------
-function optimize_hip_batch!(models::Vector{COSMO.Workspace{T}}; device::Integer = 0, tol_constant = 1.0, tol_exponent = 1.5) where {T <: HipFloat}
+function optimize_hip_batch!(models::Vector{COSMO.Workspace{T}}; device::Integer = 0, kkt_kind::Int32 = KKT_CG, tol_constant = 1.0, tol_exponent = 1.5) where {T <: HipFloat}
     isempty(models) && return COSMO.Result{T}[]
     LIBT = libpath(T)
     settings = models[1].settings
@@ -447,14 +447,15 @@ function optimize_hip_batch!(models::Vector{COSMO.Workspace{T}}; device::Integer
                 (Ptr{Cvoid}, Int64, Int64, Ptr{Int32}, Ptr{Int64}, Ptr{T}, Ptr{T}, Ptr{T}),
                 g, k - 1, length(types), types, dims, isempty(bl) ? C_NULL : pointer(bl), isempty(bu) ? C_NULL : pointer(bu), cparams))
             if settings.scaling != 0
-                Dinv = ws.sm.Dinv.diag; Einv = ws.sm.Einv.diag
-                GC.@preserve Dinv Einv gcheck(ccall((:cosmo_hip_batch_group_set_scaling, LIBT), Int32, (Ptr{Cvoid}, Int64, Ptr{T}, Ptr{T}, Cdouble),
-                    g, k - 1, Dinv, Einv, ws.sm.cinv[]))
+                Dm = ws.sm.D.diag; Dinv = ws.sm.Dinv.diag; Em = ws.sm.E.diag; Einv = ws.sm.Einv.diag
+                GC.@preserve Dm Dinv Em Einv gcheck(ccall((:cosmo_hip_batch_group_set_scaling_full, LIBT), Int32, (Ptr{Cvoid}, Int64, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Cdouble, Cdouble),
+                    g, k - 1, Dm, Dinv, Em, Einv, ws.sm.c[], ws.sm.cinv[]))
             end
         end
         ap = accel_params_from(settings)                     # _make_accelerator! (src/setup.jl:10-16) for every problem; before set_params
         ap === nothing || gcheck(ccall((:cosmo_hip_batch_group_set_accelerator, LIBT), Int32, (Ptr{Cvoid}, Ref{AccelParams}), g, Ref(ap)))
-        prm = Ref(params_from(settings, KKT_CG; tol_constant = tol_constant, tol_exponent = tol_exponent))
+        # ws.times.setup_time of this call's set-up phase (solver.jl:246: what the automatic rho interval of the members that run on their own handles is measured against)
+        prm = Ref(params_from(settings, kkt_kind; tol_constant = tol_constant, tol_exponent = tol_exponent, setup_time = time() - t_start))
         gcheck(ccall((:cosmo_hip_batch_group_set_params, LIBT), Int32, (Ptr{Cvoid}, Ref{Params}), g, prm))   # classes + classify_constraints! + set_rho_vec! per problem
         for (k, ws) in enumerate(models)
             x0 = ws.vars.x; s0 = ws.vars.s.data; mu0 = ws.vars.μ
@@ -470,6 +471,11 @@ function optimize_hip_batch!(models::Vector{COSMO.Workspace{T}}; device::Integer
                 g, k - 1, w, wp, sd, mu))
             ws.states.IS_OPTIMIZED = true
             ws.ρ = T(r.rho)
+            if ws.settings.adaptive_rho && ws.settings.adaptive_rho_interval == 0      # the reference writes the chosen interval into the settings (src/solver.jl:249-254)
+                ri = zeros(Int64, 2)
+                gcheck(ccall((:cosmo_hip_batch_group_get_rho_interval, LIBT), Int32, (Ptr{Cvoid}, Int64, Ptr{Int64}), g, k - 1, ri))
+                ri[1] > 0 && (ws.settings.adaptive_rho_interval = Int(ri[1]))
+            end
             resize!(ws.rho_updates, 0); append!(ws.rho_updates, T.(collect(r.rho_updates)[1:min(r.n_rho_updates, MAX_RHO_UPDATES)]))
             ws.times.iter_time = r.iter_time
             res_info = COSMO.ResultInfo(T(r.r_prim), T(r.r_dual), T(r.max_norm_prim), T(r.max_norm_dual), ws.rho_updates)

@@ -841,7 +841,7 @@ def prepare_batch_group(models: Sequence[Model], device: int):
             md.sm = ScaleMatrices(np.ones(n), np.ones(n), np.ones(m), np.ones(m), 1.0, 1.0)
         md.x = md.sm.Dinv * md.x; md.mu = (md.sm.Einv * md.mu) * md.sm.c; md.s = md.sm.E * md.s
         G.set_problem(k, md.P, md.q, md.A, md.b)
-        G.set_scaling(k, md.sm.Dinv, md.sm.Einv, md.sm.cinv)
+        G.set_scaling_full(k, md.sm.D, md.sm.Dinv, md.sm.E, md.sm.Einv, md.sm.c, md.sm.cinv)      # (D, E themselves: a member on its own handle tests its certificates with them)
         bl = [K.l for K in md.sets if K.kind == _ffi.BOX]; bu = [K.u for K in md.sets if K.kind == _ffi.BOX]
         G.set_cones(k, [K.kind for K in md.sets], [K.dim for K in md.sets], np.concatenate(bl) if bl else None, np.concatenate(bu) if bu else None,
                     cone_param=[getattr(K, "alpha", 0.0) for K in md.sets])
@@ -883,6 +883,10 @@ def _solve_shard_on_device(models: Sequence[Model], device: int) -> List[Result]
             x = md.sm.D * x; s = md.sm.Einv * s; mu = (md.sm.E * mu) * md.sm.cinv
         md.x, md.s, md.mu = x.copy(), s.copy(), mu.copy()
         md.is_optimized = True
+        if mixed and md.settings.adaptive_rho and md.settings.adaptive_rho_interval == 0:
+            chosen = B.rho_interval(k)[0]                          # the reference writes the chosen interval into the settings (src/solver.jl:249-254)
+            if chosen > 0:
+                md.settings.adaptive_rho_interval = chosen
         info = ResultInfo(r.r_prim, r.r_dual, r.max_norm_prim, r.max_norm_dual,
                           [r.rho_updates[i] for i in range(min(r.n_rho_updates, _ffi.MAX_RHO_UPDATES))])
         out.append(Result(x=x, y=-mu, s=s, obj_val=r.cost, iter=int(r.iter), status=_ffi.STATUS_NAMES[r.status], info=info,

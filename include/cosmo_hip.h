@@ -500,12 +500,17 @@ COSMO_HIP_API int32_t cosmo_hip_batch_group_set_problem(cosmo_hip_batch_group* g
 COSMO_HIP_API int32_t cosmo_hip_batch_group_set_cones(cosmo_hip_batch_group* g, int64_t k, int64_t ncones, const int32_t* type, const int64_t* dim,
                                         const cosmo_hip_real* box_l, const cosmo_hip_real* box_u, const cosmo_hip_real* cone_param);
 COSMO_HIP_API int32_t cosmo_hip_batch_group_set_scaling(cosmo_hip_batch_group* g, int64_t k, const cosmo_hip_real* Dinv, const cosmo_hip_real* Einv, double cinv);
+/* ... with D, E, c themselves (as cosmo_hip_set_scaling_full): members that run on their own handles test their certificates with exactly these */
+COSMO_HIP_API int32_t cosmo_hip_batch_group_set_scaling_full(cosmo_hip_batch_group* g, int64_t k, const cosmo_hip_real* D, const cosmo_hip_real* Dinv, const cosmo_hip_real* E,
+                                               const cosmo_hip_real* Einv, double c, double cinv);
 COSMO_HIP_API int32_t cosmo_hip_batch_group_set_accelerator(cosmo_hip_batch_group* g, const cosmo_hip_accel_params* p);
 COSMO_HIP_API int32_t cosmo_hip_batch_group_set_params(cosmo_hip_batch_group* g, const cosmo_hip_params* p);
 /* number of structure classes; class_of[k] and mode_of[k] for every problem (nprob entries each, may be NULL): mode 0 = the class runs on a
  * persistent batch kernel, 1 = its structure is outside the batch kernels (PSD side > 64, a MINRES solver kind, ...) and every member is solved
  * through its own single-problem handle, concurrently with the batch classes */
 COSMO_HIP_API int32_t cosmo_hip_batch_group_class_info(cosmo_hip_batch_group* g, int64_t* nclasses, int64_t* class_of, int64_t* mode_of);
+/* cosmo_hip_get_rho_interval for problem k of a group (members with the automatic interval run on their own handles): out as there */
+COSMO_HIP_API int32_t cosmo_hip_batch_group_get_rho_interval(cosmo_hip_batch_group* g, int64_t k, int64_t out[2]);
 /* out = {worker threads of the last cosmo_hip_batch_group_optimize (a bounded pool: COSMO_HIP_GROUP_WORKERS, default 32), its jobs (one per MERGED SET of
  * one-problem classes -- all of them run in one host loop whose every launch covers them, workgroup c reading the descriptor of class c --, one per other batch
  * class, one per member that runs on its own handle), classes, problems, classes that ran inside a merged set} */
