@@ -191,6 +191,31 @@ def test_256_problems_of_256_shapes_against_the_oracle_and_against_sequential_so
     assert t_group < t_seq, (t_group, t_seq)
 
 
+def test_merged_sets_in_the_float32_library(monkeypatch):
+    """The merged launch of singleton classes (k_batch_admm_multi) in libcosmo_hip_f32.so: 24 problems of 24 shapes as COSMO.Model{Float32}, eps 1e-4 -- every
+    result against the Float64 oracle of that problem (status, objective 1e-2) and against the one-job-per-class form of the same library (status, objective 1e-3)."""
+    probs = _many_shapes(24, seed=7)
+    st = cj.Settings(eps_abs=1e-4, eps_rel=1e-4)
+
+    def models():
+        out = []
+        for p in probs:
+            md = cj.Model(dtype=np.float32); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], st)
+            out.append(md)
+        return out
+    res = cj.optimize_batch(models())
+    info = dict(cj.model.LAST_BATCH_INFO)
+    assert info["classes"] == 24 and info["merged_classes"] >= 20
+    monkeypatch.setenv("COSMO_HIP_GROUP_MERGE", "0")
+    res_nm = cj.optimize_batch(models())
+    assert cj.model.LAST_BATCH_INFO["merged_classes"] == 0
+    for p, a, b in zip(probs, res, res_nm):
+        ref = O.solve(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), O.Settings(kkt_solver="cg", eps_abs=1e-4, eps_rel=1e-4))
+        assert a.status == b.status == ref.status
+        assert abs(a.obj_val - b.obj_val) <= 1e-3 * (1 + abs(b.obj_val))      # iteration counts differ: the rho interval is set from measured times
+        assert abs(a.obj_val - ref.obj_val) <= 1e-2 * (1 + abs(ref.obj_val))
+
+
 def test_set_iterates_on_one_member_keeps_the_other_members_state():
     """dirtiness of the staged warm starts is tracked per problem.  After an optimize, set_iterates on ONE member of a batch class restarts the class
     with that member's new start and every other member's CURRENT state as its start: the untouched member, already solved, is done at the first check

@@ -10,13 +10,13 @@ import cosmo_jl_amd as cj
 pytestmark = pytest.mark.gpu
 
 
-def _run(prob, iters, monkeypatch, dataflow):
+def _run(prob, iters, monkeypatch, dataflow, dtype=np.float64):
     if dataflow is None:
         monkeypatch.delenv("COSMO_HIP_POLAR_DATAFLOW", raising=False)
     else:
         monkeypatch.setenv("COSMO_HIP_POLAR_DATAFLOW", dataflow)
     st = cj.Settings(max_iter=iters, eps_abs=0.0, eps_rel=0.0, check_infeasibility=10 ** 9)
-    md = cj.Model(); md.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)
+    md = cj.Model(dtype=dtype); md.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)
     r = cj.optimize(md)
     h = md.handle
     out = (r, h.polar_stats(), h.polar_dataflow_stats())
@@ -53,3 +53,14 @@ def test_default_on_baseline_config_5_is_bit_identical_including_repair_rounds(m
     assert np.array_equal(r0.x, r1.x) and np.array_equal(r0.s, r1.s) and np.array_equal(r0.y, r1.y)
     assert p0["fallback_rounds"] == p1["fallback_rounds"] and p0["verified"] == p1["verified"] and p1["unverified"] == 0
     assert r0.kkt_iters_total == r1.kkt_iters_total
+
+
+def test_float32_library_persistent_form_is_bit_identical(monkeypatch):
+    """libcosmo_hip_f32.so (COSMO.Model{Float32}): the same kernel instantiated for float -- `v_mfma_f32_16x16x4_f32` tiles, 8-byte sc1 buffer loads of the
+    operand pairs -- forced on for a 40-clique batch: the same bits as the launch-per-product form of that library."""
+    prob = cj.problems.chordal_sdp(ncliques=40, n_total=6000, n_zero=100, n_nonneg=500)
+    r0, p0, d0 = _run(prob, 30, monkeypatch, "0", dtype=np.float32)
+    r1, p1, d1 = _run(prob, 30, monkeypatch, "1", dtype=np.float32)
+    assert d0["enabled"] == 0 and d1["enabled"] == 1 and d1["launches"] >= 30
+    assert np.array_equal(r0.x, r1.x) and np.array_equal(r0.s, r1.s) and np.array_equal(r0.y, r1.y)
+    assert p1["unverified"] == 0 and p1["verified"] == p0["verified"] and p1["fallback_rounds"] == p0["fallback_rounds"]
