@@ -661,10 +661,12 @@ class Batch:
         self._chk(self.lib.cosmo_hip_batch_iterate(self._b, int(n_iters), 1 if with_init else 0))
 
     def kernel_info(self):
-        """Which kernel the batch runs: dict(form = 'streaming' | 'lds_image' | 'register_1_2' | 'register_2_4', sliced, lds_bytes, p_in_registers)."""
-        out = np.zeros(4, dtype=np.int64)
+        """Which kernel the batch runs: dict(form = 'streaming' | 'lds_image' | 'register_1_2' | 'register_2_4', sliced, lds_bytes, p_in_registers,
+        registers / scratch_bytes per thread and static_lds_bytes of that instantiation (from the loaded code object), sorted_assignment)."""
+        out = np.zeros(8, dtype=np.int64)
         self._chk(self.lib.cosmo_hip_batch_kernel_info(self._b, out.ctypes.data_as(_PI64)))
-        return dict(form=("streaming", "lds_image", "register_1_2", "register_2_4")[int(out[0])], sliced=bool(out[1]), lds_bytes=int(out[2]), p_in_registers=bool(out[3]))
+        return dict(form=("streaming", "lds_image", "register_1_2", "register_2_4")[int(out[0])], sliced=bool(out[1]), lds_bytes=int(out[2]), p_in_registers=bool(out[3]),
+                    registers=int(out[4]), scratch_bytes=int(out[5]), static_lds_bytes=int(out[6]), sorted_assignment=bool(out[7]))
 
     def counters(self):
         """Per problem: ADMM iterations, KKT solves, Krylov iterations in total (three int64 arrays)."""

@@ -394,7 +394,9 @@ __device__ __forceinline__ int wave_max_int(int v) {
 // header of a problem's LDS image (built by build_lds_images): byte offsets from the start of the image
 // oTpr: one u32 per nonzero of A' = (position into A's values) | (row, or its position in the gathered vector) << 16 -- ONE LDS read per nonzero instead
 // of two u16 reads (round 5: the A' loop of the column pass issues 3 LDS instructions per nonzero instead of 4)
-struct LdsHdr { int nnzA, nnzP, nbA, nbAT, nbPT, oAval, oPval, oArp, oAcol, oTrp, oTpr, oPrp, oPcol, oRbA, oRbAT, oRbPT, bytes; };
+// oAord / oTord (round 6, 0 = none): the image is stored in the SORTED order of the register-CG compute assignment -- Arp is indexed by sorted position q and
+// Aord[q] (u16) is the row stored there; Trp / Prp by the sorted position of the column, Tord[q] the column
+struct LdsHdr { int nnzA, nnzP, nbA, nbAT, nbPT, oAval, oPval, oArp, oAcol, oTrp, oTpr, oPrp, oPcol, oRbA, oRbAT, oRbPT, bytes, oAord, oTord; };
 
 template <int BS>
 struct LdsOps {
@@ -402,11 +404,14 @@ struct LdsOps {
   const unsigned short *Arp, *Acol, *Trp, *Prp, *Pcol;
   const uint32_t* Tpr;
   const int4 *rbA, *rbAT, *rbPT;
+  const unsigned short *Aord, *Tord;          // stored-sorted image: row / column at a storage position (null: positions are indices)
   int nbA, nbAT, nbPT;
   real *xv, *tv, *red;
   unsigned char* psd_ws;
   int n;
   static constexpr bool in_lds = true;
+  __device__ __forceinline__ int rowA_at(int q) const { return Aord ? (int)Aord[q] : q; }
+  __device__ __forceinline__ int col_at(int q) const { return Tord ? (int)Tord[q] : q; }
   // whole rows, left to right, software-pipelined by one nonzero (the index / value loads of nonzero t + 1 go out with the gather of nonzero t): the
   // row functions of the register-CG form of the Krylov loop below (batch_admm_body, RCG).  (The hand-scheduled row_pipe3 was measured here too:
   // 262 vs 255 us per batch iteration, 443 vs 408 accelerated -- two short rows per thread do not amortise its prologue and drain; not used.)
@@ -440,6 +445,33 @@ struct LdsOps {
     }
     return s1;
   }
+  __device__ __forceinline__ real rowA_b(int t, const int b2, const real* x) const {      // rows between two entry positions (bounds held by the caller)
+    real s1 = 0.0;
+    if (t < b2) {
+      real v = Aval[t]; int c = Acol[t];
+      for (++t; t < b2; ++t) { const real vn = Aval[t]; const int cn = Acol[t]; s1 += v * x[c]; v = vn; c = cn; }
+      s1 += v * x[c];
+    }
+    return s1;
+  }
+  __device__ __forceinline__ real rowAT_b(int t, const int b2, const real* y) const {
+    real s1 = 0.0;
+    if (t < b2) {
+      uint32_t pr = Tpr[t];
+      for (++t; t < b2; ++t) { const uint32_t prn = Tpr[t]; s1 += Aval[pr & 0xffffu] * y[pr >> 16]; pr = prn; }
+      s1 += Aval[pr & 0xffffu] * y[pr >> 16];
+    }
+    return s1;
+  }
+  __device__ __forceinline__ real rowP_b(int t, const int b2, const real* x) const {
+    real s1 = 0.0;
+    if (t < b2) {
+      real v = Pval[t]; int c = Pcol[t];
+      for (++t; t < b2; ++t) { const real vn = Pval[t]; const int cn = Pcol[t]; s1 += v * x[c]; v = vn; c = cn; }
+      s1 += v * x[c];
+    }
+    return s1;
+  }
   __device__ __forceinline__ real* buf_n(real*) const { return xv; }
   __device__ __forceinline__ real* buf_m(real*) const { return tv; }
   __device__ __forceinline__ const real* stage_n(const real* g) const {     // copy a global n-vector into the LDS gather buffer
@@ -457,14 +489,14 @@ struct LdsOps {
           real s1 = 0.0;
           const int a = Arp[r], b = Arp[r + 1];
           for (int k = a; k < b; ++k) s1 += Aval[k] * x[Acol[k]];
-          fn(r, s1, 0.0);
+          fn(rowA_at(r), s1, 0.0);
         }
       } else {                                                               // a single long row: strided partials, block sum
         const int r = d.x;
         real s1 = 0.0, s2 = 0.0;
         for (int k = d.z + threadIdx.x; k < d.w; k += BS) s1 += Aval[k] * x[Acol[k]];
         s1 = bsum<BS>(s1, red); s2 = bsum<BS>(s2, red);
-        if (threadIdx.x == 0) fn(r, s1, s2);
+        if (threadIdx.x == 0) fn(rowA_at(r), s1, s2);
       }
     }
     __syncthreads();
@@ -478,14 +510,14 @@ struct LdsOps {
           real s1 = 0.0;
           const int a = Trp[r], b = Trp[r + 1];
           for (int k = a; k < b; ++k) { const uint32_t pr = Tpr[k]; s1 += Aval[pr & 0xffffu] * y[pr >> 16]; }
-          fn(r, s1, 0.0);
+          fn(col_at(r), s1, 0.0);
         }
       } else {
         const int r = d.x;
         real s1 = 0.0, s2 = 0.0;
         for (int k = d.z + threadIdx.x; k < d.w; k += BS) { const uint32_t pr = Tpr[k]; s1 += Aval[pr & 0xffffu] * y[pr >> 16]; }
         s1 = bsum<BS>(s1, red); s2 = bsum<BS>(s2, red);
-        if (threadIdx.x == 0) fn(r, s1, s2);
+        if (threadIdx.x == 0) fn(col_at(r), s1, s2);
       }
     }
     __syncthreads();
@@ -501,7 +533,7 @@ struct LdsOps {
           for (int k = pa; k < pb; ++k) s1 += Pval[k] * x1[Pcol[k]];
           const int a = Trp[r], b = Trp[r + 1];
           for (int k = a; k < b; ++k) { const uint32_t pr = Tpr[k]; s2 += Aval[pr & 0xffffu] * x2[pr >> 16]; }
-          fn(r, s1, s2);
+          fn(col_at(r), s1, s2);
         }
       } else {
         const int r = d.x;
@@ -512,7 +544,7 @@ struct LdsOps {
           else { const uint32_t pr = Tpr[a + (k - lp)]; s2 += Aval[pr & 0xffffu] * x2[pr >> 16]; }
         }
         s1 = bsum<BS>(s1, red); s2 = bsum<BS>(s2, red);
-        if (threadIdx.x == 0) fn(r, s1, s2);
+        if (threadIdx.x == 0) fn(col_at(r), s1, s2);
       }
     }
     __syncthreads();
@@ -670,6 +702,9 @@ __device__ __forceinline__ void aa_reset(const AaMem& M, Each each) {
 // AA: the accelerated loop (src/solver.jl:140-165 with an AndersonAccelerator; csrc/anderson.hip + optimize_accelerated of api.hip are the
 // single-problem form).  Every inner product of the accelerator is a block sum of the workgroup, every decision (success of the least-squares
 // step, safeguarding, deferred rho update / infeasibility check) is taken by the workgroup for its problem.
+#ifndef COSMO_LDSCG_HANDPIPE
+#define COSMO_LDSCG_HANDPIPE 1          // lab builds: 0 = the compiled one-stage pipelined row loops in the register-CG form of the LDS-image kernel
+#endif
 template <int BS, bool PSD, bool AA, class Ops>
 __device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams& P, long long iter_target, int do_init, Ops& ops, real* red, const int k) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -690,7 +725,137 @@ __device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams
   real* const mu_g = ops.buf_m(mu);                    // mu for the dual residual
 
   // ---- admm_x! + admm_w! (solver.jl:32-65) with the CG reduced solve (kktsolver_indirect.jl:36-88) -------------------
+  // Register-CG form of the whole reduced solve (LDS-image kernel of the batches with PSD / exponential / power cones and of their accelerated runs;
+  // round 5: the Krylov loop, round 6: every sparse pass of the solve).  Thread t COMPUTES the rows ra[] of A and the column ct[] of [P | A'] of the
+  // length-sorted assignment (D.permA / D.permT in the <2, 4>-slot layout of this kernel, build_lds_images; index order without the tables:
+  // COSMO_HIP_BATCH_LDSCG_SORTED=0) -- the rows of a wave-step have similar lengths -- and HOLDS elements ct[] of rhs, r, u, x_tl, c in registers for
+  // the solve: the ownership is local to the solve, so c never travels and global memory sees x_tl once at the start and once at the end.  The bounds
+  // of those rows / columns are read once per solve; the A and A' rows run on the hand-scheduled two-stage pipeline row_pipe3; the block sums take one
+  // barrier each (bsum_db).  Round 6 also moved the three passes in front of the loop (rhs = A' y2 + ls_x, tmp = rho .* A x_tl, r = rhs - M x_tl)
+  // and the pass behind it (A x_tl for nu / s_tl / w) from the tile loops of LdsOps (~10 us each on config 3) onto the same rows: ~1.5 us each.  Same
+  // left-to-right row sums everywhere; the block sums add the per-element terms in the order of this assignment (trajectories agree with the
+  // streaming kernel to 1e-9 in tight-CG mode; COSMO_HIP_BATCH_LDSCG=0 restores the generic form below).
+  constexpr bool RCG = Ops::in_lds && PSD && BS == 512;
+  auto solve_and_update_rcg = [&]() {
+    if constexpr (RCG) {
+    constexpr int RJN = 2, RJM = 4;
+    int ra[RJM], ct[RJN];
+    uint32_t kA[RJM], kT[RJN], kP[RJN];                                  // first entry | entries << 16 of the row of A, the columns of A' and P (u16 each: the image's limits)
+    real rR[RJN], uR[RJN], xR[RJN], cR[RJN], rhoR[RJM];
+    for (int i = tid; i < n + m; i += BS) {                             // rhs of the KKT system + y2 = rho .* ls_s  (index owners)
+      if (i < n) ls_x[i] = P.sigma * w[i] - q[i];
+      else { const int rr = i - n; const real v = (b[rr] - R(2.0) * s[rr]) + w[i]; ls_s[rr] = v; y2[rr] = rho[rr] * v; }
+    }
+#pragma unroll
+    for (int j = 0; j < RJM; ++j) {
+      const int i = tid + BS * j;
+      const int rr_ = D.permA ? D.permA[((long long)k * RJM + j) * BS + tid] : (i < m ? i : -1);
+      ra[j] = rr_;
+      rhoR[j] = rr_ >= 0 ? rho[rr_] : R(1.0);
+      const int qa = ops.Aord ? BS * j + ((j & 1) ? BS - 1 - tid : tid) : rr_;       // stored-sorted image: Arp is indexed by the position of the compute assignment
+      const int a0 = rr_ >= 0 ? (int)ops.Arp[qa] : 0, a1 = rr_ >= 0 ? (int)ops.Arp[qa + 1] : 0;
+      kA[j] = (uint32_t)a0 | ((uint32_t)(a1 - a0) << 16);
+    }
+#pragma unroll
+    for (int j = 0; j < RJN; ++j) {
+      const int i = tid + BS * j;
+      const int cc_ = D.permT ? D.permT[((long long)k * RJN + j) * BS + tid] : (i < n ? i : -1);
+      ct[j] = cc_;
+      const bool ok = cc_ >= 0;
+      xR[j] = ok ? x_tl[cc_] : R(0.0); uR[j] = 0.0; cR[j] = 0.0; rR[j] = 0.0;
+      if (ok) u[cc_] = xR[j];                                            // the n-vector buffer gathers x_tl first
+      const int qc = ops.Tord ? BS * j + tid : cc_;
+      const int t0 = ok ? (int)ops.Trp[qc] : 0, t1 = ok ? (int)ops.Trp[qc + 1] : 0;
+      kT[j] = (uint32_t)t0 | ((uint32_t)(t1 - t0) << 16);
+      const int p0 = ok ? (int)ops.Prp[qc] : 0, p1 = ok ? (int)ops.Prp[qc + 1] : 0;
+      kP[j] = (uint32_t)p0 | ((uint32_t)(p1 - p0) << 16);
+    }
+    const uint32_t lA_val = lds_addr_of(ops.Aval), lA_col = lds_addr_of(ops.Acol), lT_pr = lds_addr_of(ops.Tpr), l_xv = lds_addr_of(u), l_tv = lds_addr_of(tmp_m);
+    (void)lA_val; (void)lA_col; (void)lT_pr; (void)l_xv; (void)l_tv;
+    auto rowA_c = [&](int j) -> real {                                   // row ra[j] of A times the n-vector buffer
+      return COSMO_LDSCG_HANDPIPE ? row_pipe3<false>(lA_col + 2u * (kA[j] & 0xffffu), lA_val + ((kA[j] & 0xffffu) << RSH), l_xv, (int)(kA[j] >> 16))
+                                  : ops.rowA_b((int)(kA[j] & 0xffffu), (int)((kA[j] & 0xffffu) + (kA[j] >> 16)), u);
+    };
+    auto colT_c = [&](int j) -> real {                                   // column ct[j] of A (row of A') times the m-vector buffer
+      const int t0 = (int)(kT[j] & 0xffffu);
+      return COSMO_LDSCG_HANDPIPE ? row_pipe3<true>(lT_pr + 4u * (uint32_t)t0, lA_val, l_tv, (int)(kT[j] >> 16)) : ops.rowAT_b(t0, t0 + (int)(kT[j] >> 16), tmp_m);
+    };
+    auto colP_c = [&](int j) -> real { const int p0 = (int)(kP[j] & 0xffffu); return ops.rowP_b(p0, p0 + (int)(kP[j] >> 16), u); };
+    int ph = 0;
+    __syncthreads();                                                     // y2, the gathered x_tl and ls_x are visible; the classic block sums on `red` are behind us (bsum_db)
+    real acc = 0.0;
+    real rhsR[RJN];
+#pragma unroll
+    for (int j = 0; j < RJN; ++j) {
+      rhsR[j] = 0.0;
+      if (ct[j] >= 0) { const real v = (colT_c(j) + R(0.0)) + ls_x[ct[j]]; rhsR[j] = v; acc += v * v; }
+    }
+    const real bb = bsum_db<BS>(acc, red, ph);                           // (its barrier also orders the reads of y2 before the writes of tmp_m below: one buffer)
+    real tmpv[RJM];
+#pragma unroll
+    for (int j = 0; j < RJM; ++j) tmpv[j] = (ra[j] >= 0) ? (rowA_c(j) + R(0.0)) * rhoR[j] : R(0.0);
+#pragma unroll
+    for (int j = 0; j < RJM; ++j) if (ra[j] >= 0) tmp_m[ra[j]] = tmpv[j];
+    __syncthreads();
+    acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < RJN; ++j) {
+      if (ct[j] >= 0) { const real cj = colP_c(j) + (P.sigma * xR[j] + (colT_c(j) + R(0.0))); const real rj = rhsR[j] - cj; rR[j] = rj; acc += rj * rj; }
+    }
+    real rr = bsum_db<BS>(acc, red, ph);
+    const long long ks = ctl->solves;                                    // iteration_counter - 1
+    const real tol_k = D.tol_table[ks < D.tol_len ? ks : D.tol_len - 1];
+    const real tol = tol_k / sqrt(bb);
+    real res = sqrt(rr), prev = 1.0;
+    int kk = 0;
+    while (kk < n && !(res <= tol)) {                                    // cg! (IterativeSolvers v0.9), maxiter = n
+      const real beta = (res * res) / (prev * prev);
+#pragma unroll
+      for (int j = 0; j < RJN; ++j) { uR[j] = rR[j] + beta * ((kk == 0) ? R(0.0) : uR[j]); if (ct[j] >= 0) u[ct[j]] = uR[j]; }   // (u was last read before the block sums above)
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < RJM; ++j) tmpv[j] = (ra[j] >= 0) ? rowA_c(j) * rhoR[j] : R(0.0);
+#pragma unroll
+      for (int j = 0; j < RJM; ++j) if (ra[j] >= 0) tmp_m[ra[j]] = tmpv[j];     // (tmp_m was last read before the block sums of the previous iteration)
+      __syncthreads();
+      acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < RJN; ++j) {
+        if (ct[j] >= 0) { const real vj = uR[j]; const real cj = colP_c(j) + (P.sigma * vj + colT_c(j)); cR[j] = cj; acc += vj * cj; }
+      }
+      const real uc = bsum_db<BS>(acc, red, ph);
+      const real a = (res * res) / uc;
+      acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < RJN; ++j) { xR[j] = xR[j] + a * uR[j]; const real ri = rR[j] - a * cR[j]; rR[j] = ri; acc += ri * ri; }
+      rr = bsum_db<BS>(acc, red, ph);
+      prev = res; res = sqrt(rr); ++kk;
+    }
+    // nu = rho (A x_tl - ls_s) ; s_tl ; w update: A x_tl by the computing threads, handed to the index owners through the m-vector buffer
+#pragma unroll
+    for (int j = 0; j < RJN; ++j) if (ct[j] >= 0) { x_tl[ct[j]] = xR[j]; u[ct[j]] = xR[j]; }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RJM; ++j) tmpv[j] = (ra[j] >= 0) ? (rowA_c(j) + R(0.0)) : R(0.0);
+#pragma unroll
+    for (int j = 0; j < RJM; ++j) if (ra[j] >= 0) tmp_m[ra[j]] = tmpv[j];
+    __syncthreads();
+    for (int i = tid; i < n + m; i += BS) {
+      if (i < n) { const real wv2 = w[i]; w[i] = wv2 + P.alpha * (u[i] - wv2); }
+      else {
+        const int row = i - n;
+        const real rh = rho[row]; const real nv = (tmp_m[row] - ls_s[row]) * rh; nu[row] = nv;
+        const real sv = s[row], wv2 = w[i]; const real st = (R(2.0) * sv - wv2) - nv / rh; s_tl[row] = st;
+        w[i] = wv2 + P.alpha * (st - sv);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) { ctl->solves = ks + 1; ctl->kkt_iters_total += kk; }
+    __syncthreads();
+    }
+  };
   auto solve_and_update = [&]() {
+    if constexpr (RCG) { if (D.regcg != 0) { solve_and_update_rcg(); return; } }
     for (int i = tid; i < n + m; i += BS) {                             // rhs of the KKT system + y2 = rho .* ls_s
       if (i < n) ls_x[i] = P.sigma * w[i] - q[i];
       else { const int rr = i - n; const real v = (b[rr] - R(2.0) * s[rr]) + w[i]; ls_s[rr] = v; y2[rr] = rho[rr] * v; }
@@ -712,53 +877,6 @@ __device__ __forceinline__ void batch_admm_body(const BatchDev& D, const BParams
     const real tol = tol_k / sqrt(bb);
     real res = sqrt(rr), prev = 1.0;
     int kk = 0;
-    // Register-CG form (round 5; the LDS-image kernel of the batches with PSD / exponential / power cones and of their accelerated runs): the four
-    // Krylov vectors r, u, x_tl, c and rho of the rows live in the registers of the threads that OWN elements tid + BS j for the whole solve --
-    // global memory is read once before and written once after the loop instead of eight times per Krylov iteration -- and the two sparse
-    // passes run whole rows on the software-pipelined row loops of the LDS image.  Same row sums (left to right); the block reductions add the
-    // partials of this BS-strided ownership instead of the tile-order ownership of the generic loop below, as the register kernel's do
-    // (trajectories agree with the streaming kernel to 1e-9 in tight-CG mode instead of bit for bit; COSMO_HIP_BATCH_LDSCG=0 restores the generic loop).
-    constexpr bool RCG = Ops::in_lds && PSD && BS == 512;
-    constexpr int RJN = 2, RJM = 4;
-    bool regcg = false;
-    if constexpr (RCG) regcg = D.regcg != 0;
-    if (regcg) {
-      if constexpr (RCG) {
-      __syncthreads();                                                   // r (written in tile order above) is visible to its strided owners
-      real rR[RJN], uR[RJN], xR[RJN], cR[RJN], rhoR[RJM];
-#pragma unroll
-      for (int j = 0; j < RJN; ++j) { const int i = tid + BS * j; const bool ok = i < n; rR[j] = ok ? r[i] : R(0.0); xR[j] = ok ? x_tl[i] : R(0.0); uR[j] = 0.0; cR[j] = 0.0; }
-#pragma unroll
-      for (int j = 0; j < RJM; ++j) { const int i = tid + BS * j; rhoR[j] = (i < m) ? rho[i] : R(1.0); }
-      while (kk < n && !(res <= tol)) {                                  // cg! (IterativeSolvers v0.9), maxiter = n
-        const real beta = (res * res) / (prev * prev);
-#pragma unroll
-        for (int j = 0; j < RJN; ++j) { const int i = tid + BS * j; uR[j] = rR[j] + beta * ((kk == 0) ? R(0.0) : uR[j]); if (i < n) u[i] = uR[j]; }
-        __syncthreads();
-        real tmpv[RJM];
-#pragma unroll
-        for (int j = 0; j < RJM; ++j) { const int i = tid + BS * j; tmpv[j] = (i < m) ? ops.rowA(i, u) * rhoR[j] : R(0.0); }
-#pragma unroll
-        for (int j = 0; j < RJM; ++j) { const int i = tid + BS * j; if (i < m) tmp_m[i] = tmpv[j]; }   // (tmp_m was last read before the block sums of the previous iteration)
-        __syncthreads();
-        acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < RJN; ++j) {
-          const int i = tid + BS * j;
-          if (i < n) { const real vj = uR[j]; const real cj = ops.rowP(i, u) + (P.sigma * vj + ops.rowAT(i, tmp_m)); cR[j] = cj; acc += vj * cj; }
-        }
-        const real uc = bsum<BS>(acc, red);
-        const real a = (res * res) / uc;
-        acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < RJN; ++j) { xR[j] = xR[j] + a * uR[j]; const real ri = rR[j] - a * cR[j]; rR[j] = ri; acc += ri * ri; }
-        rr = bsum<BS>(acc, red);
-        prev = res; res = sqrt(rr); ++kk;
-      }
-#pragma unroll
-      for (int j = 0; j < RJN; ++j) { const int i = tid + BS * j; if (i < n) x_tl[i] = xR[j]; }
-      }
-    } else
     while (kk < n && !(res <= tol)) {                                    // cg! (IterativeSolvers v0.9), maxiter = n
       const real beta = (res * res) / (prev * prev);
       for (int i = tid; i < n; i += BS) u[i] = r[i] + beta * ((kk == 0) ? R(0.0) : u[i]);
@@ -1003,6 +1121,8 @@ __global__ __launch_bounds__(BS) void k_batch_admm_lds(BatchDev D, BParams P, lo
   ops.rbA = reinterpret_cast<const int4*>(base + hd.oRbA); ops.rbAT = reinterpret_cast<const int4*>(base + hd.oRbAT);
   ops.rbPT = reinterpret_cast<const int4*>(base + hd.oRbPT);
   ops.nbA = hd.nbA; ops.nbAT = hd.nbAT; ops.nbPT = hd.nbPT;
+  ops.Aord = hd.oAord ? reinterpret_cast<const unsigned short*>(base + hd.oAord) : nullptr;
+  ops.Tord = hd.oTord ? reinterpret_cast<const unsigned short*>(base + hd.oTord) : nullptr;
   real* wsp = reinterpret_cast<real*>(base + img_stride);            // workspace behind the image
   ops.xv = wsp; ops.tv = wsp + D.n; ops.red = wsp + D.n + D.m; ops.n = D.n;
   ops.psd_ws = base + ((img_stride + (long long)sizeof(real) * (D.n + D.m + 2 * (BS / 64)) + 15) / 16) * 16;     // behind the reduction slots (build_lds_images sizes it)
@@ -1931,6 +2051,7 @@ struct cosmo_hip_batch {
   ConeTable cones; std::vector<real> hbox_l, hbox_u; int nbox = 0;
   cosmo_hip_params prm;
   bool finalized = false, have_cones = false, have_iterates = false;
+  bool ext_cones = false;                     // the batch has cones beyond Zero / Nonnegatives / Box / SecondOrderCone (set_params): PSD of side >= 2, exponential, power
   BatchDev D;
   std::vector<void*> allocs;
   std::vector<real> hDinv, hEinv, hcinv;
@@ -2145,6 +2266,35 @@ static int32_t bmat_upload(cosmo_hip_batch* b, std::vector<HostCsr>& Ms, BMat& o
 
 static void brow_blocks(const std::vector<int>& rowptr, int nrows, std::vector<int>& rb);
 
+// the kernel instantiation a batch runs (one place: launch_batch_admm launches it, cosmo_hip_batch_kernel_info reports its registers / scratch)
+struct BKernel { const void* fn; int bs; bool image; };
+static BKernel batch_kernel_of(const cosmo_hip_batch* b) {
+  bool psd = b->ext_cones;                               // the instantiations with the cones beyond Zero / Nonnegatives / Box / SecondOrderCone
+  if (b->force_ext) psd = true;                           // COSMO_HIP_BATCH_EXT=1 (lab switch: that code is a run-time no-op without such cones)
+  const bool img = b->d_img != nullptr;
+#if !REAL_IS_FLOAT
+  if (img && b->reg_mode == 1 && b->D.sliced) {
+    if (b->aa_on) return {(const void*)k_batch_admm_reg<512, 1, 2, false, true, true>, 512, true};
+    return {psd ? (const void*)k_batch_admm_reg<512, 1, 2, true, false, true> : (const void*)k_batch_admm_reg<512, 1, 2, false, false, true>, 512, true};
+  }
+#endif
+  if (b->aa_on) {                    // accelerated loop: register kernel (batches without PSD cones), else the LDS-image kernel (512 threads) or the streaming kernel with the PSD code (a run-time no-op without such cones)
+    if (img && b->reg_mode == 1) return {(const void*)k_batch_admm_reg<512, 1, 2, false, true>, 512, true};
+    if (img && b->reg_mode == 2) return {(const void*)k_batch_admm_reg<512, 2, 4, false, true>, 512, true};
+    if (img) return {(const void*)k_batch_admm_lds<512, true, true>, 512, true};
+    return {(const void*)k_batch_admm<true, true>, COSMO_BS, false};
+  }
+  if (img && b->reg_mode == 1) return {psd ? (const void*)k_batch_admm_reg<512, 1, 2, true, false> : (const void*)k_batch_admm_reg<512, 1, 2, false, false>, 512, true};
+  if (img && b->reg_mode == 2) return {psd ? (const void*)k_batch_admm_reg<512, 2, 4, true, false> : (const void*)k_batch_admm_reg<512, 2, 4, false, false>, 512, true};
+  if (img) {
+    if (psd) return {(const void*)k_batch_admm_lds<512, true, false>, 512, true};      // (build_lds_images fixed 512 threads for batches with PSD / exp / pow cones)
+    if (b->lds_bs == 256) return {(const void*)k_batch_admm_lds<256, false, false>, 256, true};
+    if (b->lds_bs == 512) return {(const void*)k_batch_admm_lds<512, false, false>, 512, true};
+    return {(const void*)k_batch_admm_lds<1024, false, false>, 1024, true};
+  }
+  return {psd ? (const void*)k_batch_admm<true, false> : (const void*)k_batch_admm<false, false>, COSMO_BS, false};
+}
+
 // Builds the per-problem LDS images of k_batch_admm_lds if every problem fits (u16 indices, image + work vectors within the
 // CU's LDS); otherwise leaves b->d_img = nullptr and the streaming kernel is used.  COSMO_HIP_BATCH_LDS=0 disables it,
 // COSMO_HIP_BATCH_REG=0 keeps the iterates in global memory (LdsOps kernel), COSMO_HIP_BATCH_BS selects that kernel's
@@ -2191,6 +2341,12 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
     for (long long j = 0; j < n && p_all_diag; ++j) { const int len = PT.split[j] - PT.rowptr[j]; if (len > 1 || (len == 1 && PT.col[PT.rowptr[j]] != (int)j)) p_all_diag = false; }
   }
   b->h_slA.clear(); b->h_slT.clear(); b->h_pdiag.clear(); b->h_pdiag_has.clear();
+  // LDS-image kernel, register-CG form of its reduced solve (batch_admm_body, RCG: the 512-thread instantiations with the extended cones): the compute
+  // assignment sorted by length (D.permA / D.permT in that form's <2, 4>-slot layout) and, with it, the image STORED in that order (round 6)
+  const bool rcg_form = b->reg_mode == 0 && bs == 512 && n <= 2 * 512 && m <= 4 * 512 && (npsd > 0 || n3 > 0 || b->aa_on || b->force_ext) &&
+                        !(getenv("COSMO_HIP_BATCH_LDSCG") && atoi(getenv("COSMO_HIP_BATCH_LDSCG")) == 0);
+  const bool rcg_sorted = rcg_form && !(getenv("COSMO_HIP_BATCH_LDSCG_SORTED") && atoi(getenv("COSMO_HIP_BATCH_LDSCG_SORTED")) == 0);
+  const bool rcg_stored = rcg_sorted && !(getenv("COSMO_HIP_BATCH_STORE_SORTED") && atoi(getenv("COSMO_HIP_BATCH_STORE_SORTED")) == 0);
   for (int k = 0; k < b->nprob; ++k) {
     const HostCsr &A = b->hA[k], &AT = b->hAT[k], &PT = b->hPT[k];
     const long long nnzA = (long long)A.val.size();
@@ -2198,7 +2354,34 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
     for (long long j = 0; j < n; ++j) nnzP += PT.split[j] - PT.rowptr[j];
     if (nnzA > 65535 || nnzP > 65535) return COSMO_HIP_OK;
     std::vector<int> rA, rAT, rPT;
+    // register-CG form: rows of A by decreasing length, columns by decreasing length of [P | A'] (stable: equal lengths stay in index order)
+    std::vector<int> gordA, gordT, prA, prT, prPT;
+    if (rcg_sorted) {
+      gordA.resize((size_t)m); gordT.resize((size_t)n);
+      for (long long i = 0; i < m; ++i) gordA[(size_t)i] = (int)i;
+      for (long long j = 0; j < n; ++j) gordT[(size_t)j] = (int)j;
+      std::stable_sort(gordA.begin(), gordA.end(), [&](int x, int y) { return A.rowptr[x + 1] - A.rowptr[x] > A.rowptr[y + 1] - A.rowptr[y]; });
+      auto clen = [&](int j) { return (PT.split[j] - PT.rowptr[j]) + (AT.rowptr[j + 1] - AT.rowptr[j]); };
+      std::stable_sort(gordT.begin(), gordT.end(), [&](int x, int y) { return clen(x) > clen(y); });
+      if (b->h_permA.empty()) { b->h_permA.assign((size_t)b->nprob * 4 * 512, -1); b->h_permT.assign((size_t)b->nprob * 2 * 512, -1); }
+      for (long long q = 0; q < m; ++q) {                      // position q: slot q / 512 of thread q % 512, odd slots backwards (as in the register kernel)
+        const long long sl = q / 512, t = (sl & 1) ? 511 - q % 512 : q % 512;
+        b->h_permA[(size_t)k * 4 * 512 + (size_t)(sl * 512 + t)] = gordA[(size_t)q];
+      }
+      for (long long q = 0; q < n; ++q) b->h_permT[(size_t)k * 2 * 512 + (size_t)q] = gordT[(size_t)q];
+    }
+    if (rcg_stored) {                                         // row pointers of the stored order: the tile lists of the generic loops are cut on them
+      prA.assign((size_t)m + 1, 0); prT.assign((size_t)n + 1, 0); prPT.assign((size_t)n + 1, 0);
+      for (long long q = 0; q < m; ++q) prA[(size_t)q + 1] = prA[(size_t)q] + (A.rowptr[gordA[(size_t)q] + 1] - A.rowptr[gordA[(size_t)q]]);
+      for (long long q = 0; q < n; ++q) {
+        const int c = gordT[(size_t)q];
+        prT[(size_t)q + 1] = prT[(size_t)q] + (AT.rowptr[c + 1] - AT.rowptr[c]);
+        prPT[(size_t)q + 1] = prPT[(size_t)q] + (PT.rowptr[c + 1] - PT.rowptr[c]);
+      }
+      brow_blocks(prA, (int)m, rA); brow_blocks(prT, (int)n, rAT); brow_blocks(prPT, (int)n, rPT);
+    } else {
     brow_blocks(A.rowptr, (int)m, rA); brow_blocks(AT.rowptr, (int)n, rAT); brow_blocks(PT.rowptr, (int)n, rPT);
+    }
     LdsHdr h; memset(&h, 0, sizeof h);
     h.nnzA = (int)nnzA; h.nnzP = (int)nnzP; h.nbA = (int)rA.size() - 1; h.nbAT = (int)rAT.size() - 1; h.nbPT = (int)rPT.size() - 1;
     long long o = up16(sizeof(LdsHdr));
@@ -2213,6 +2396,7 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
     h.oTpr = (int)o; o = up16(o + 4 * nnzA);
     h.oPrp = (int)o; o = up16(o + 2 * (n + 1));
     h.oPcol = (int)o; o = up16(o + 2 * nnzP);
+    if (rcg_stored) { h.oAord = (int)o; o = up16(o + 2 * m); h.oTord = (int)o; o = up16(o + 2 * n); }
     h.bytes = (int)o;
     if (o + (long long)sizeof(real) * (n + m) + (long long)sizeof(real) * 2 * (bs / 64) > max_lds) return COSMO_HIP_OK;
     std::vector<unsigned char>& im = imgs[(size_t)k];
@@ -2244,7 +2428,41 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
       int* d = reinterpret_cast<int*>(im.data() + off);
       for (size_t t = 0; t + 1 < r.size(); ++t) { d[4 * t] = r[t]; d[4 * t + 1] = r[t + 1]; d[4 * t + 2] = rowptr[r[t]]; d[4 * t + 3] = rowptr[r[t + 1]]; }
     };
+    if (rcg_stored) {
+      // the arrays filled above in index order move to the stored order: same values, same order inside every row -- every row sum keeps its bits
+      std::vector<real> nAval((size_t)nnzA), nPval((size_t)nnzP);
+      std::vector<unsigned short> nAcol((size_t)nnzA), nPcol((size_t)nnzP);
+      std::vector<uint32_t> nTpr((size_t)nnzA);
+      std::vector<int> newstart((size_t)m);
+      long long wq = 0;
+      for (long long q = 0; q < m; ++q) {
+        const int r = gordA[(size_t)q];
+        newstart[(size_t)r] = (int)wq;
+        for (int t = A.rowptr[r]; t < A.rowptr[r + 1]; ++t) { nAval[(size_t)wq] = Aval[t]; nAcol[(size_t)wq] = Acol[t]; ++wq; }
+      }
+      long long wt = 0, wp = 0;
+      for (long long q = 0; q < n; ++q) {
+        const int c = gordT[(size_t)q];
+        for (int t = Trp[c]; t < Trp[c + 1]; ++t) {
+          const uint32_t pr = Tpr[t]; const int row = (int)(pr >> 16), pold = (int)(pr & 0xffffu);
+          nTpr[(size_t)wt++] = (uint32_t)(newstart[(size_t)row] + (pold - A.rowptr[row])) | ((uint32_t)row << 16);
+        }
+        for (int t = Prp[c]; t < Prp[c + 1]; ++t) { nPval[(size_t)wp] = Pval[t]; nPcol[(size_t)wp] = Pcol[t]; ++wp; }
+      }
+      std::copy(nAval.begin(), nAval.end(), Aval); std::copy(nAcol.begin(), nAcol.end(), Acol);
+      std::copy(nTpr.begin(), nTpr.end(), Tpr); std::copy(nPval.begin(), nPval.end(), Pval); std::copy(nPcol.begin(), nPcol.end(), Pcol);
+      for (long long q = 0; q <= m; ++q) Arp[q] = (unsigned short)prA[(size_t)q];
+      long long pq = 0;
+      for (long long q = 0; q < n; ++q) { Trp[q] = (unsigned short)prT[(size_t)q]; Prp[q] = (unsigned short)pq; pq += PT.split[gordT[(size_t)q]] - PT.rowptr[gordT[(size_t)q]]; }
+      Trp[n] = (unsigned short)prT[(size_t)n]; Prp[n] = (unsigned short)pq;
+      unsigned short* Aord = reinterpret_cast<unsigned short*>(im.data() + h.oAord);
+      unsigned short* Tord = reinterpret_cast<unsigned short*>(im.data() + h.oTord);
+      for (long long q = 0; q < m; ++q) Aord[q] = (unsigned short)gordA[(size_t)q];
+      for (long long q = 0; q < n; ++q) Tord[q] = (unsigned short)gordT[(size_t)q];
+      fill_rb(h.oRbA, rA, prA); fill_rb(h.oRbAT, rAT, prT); fill_rb(h.oRbPT, rPT, prPT);
+    } else {
     fill_rb(h.oRbA, rA, A.rowptr); fill_rb(h.oRbAT, rAT, AT.rowptr); fill_rb(h.oRbPT, rPT, PT.rowptr);
+    }
     stride = std::max(stride, o);
     const char* e_sorted = getenv("COSMO_HIP_BATCH_SORTED");      // =0: every thread computes the rows it owns (the form until round 3)
     if (b->reg_mode == 1 && !(e_sorted && atoi(e_sorted) == 0)) {
@@ -2482,68 +2700,33 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
   b->D.psd_nws = nws;
   { const char* ec = getenv("COSMO_HIP_BATCH_LDSCG");
     b->D.regcg = (bs == 512 && n <= 2 * 512 && m <= 4 * 512 && !(ec && atoi(ec) == 0)) ? 1 : 0; }
+  if (!b->D.regcg || b->reg_mode != 0) { if (rcg_sorted) { b->h_permA.clear(); b->h_permT.clear(); } }
   b->d_img = d; b->img_stride = stride; b->lds_bs = bs;
   b->lds_bytes = (int)(npsd > 0 ? ws_base + (long long)nws * PSD16_WS_STRIDE
                                 : (use_sliced ? SL_WS0 + stride : stride + (long long)sizeof(real) * (n + m) + (long long)sizeof(real) * 2 * (bs / 64)));
-  const void* fn = bs == 256 ? (const void*)k_batch_admm_lds<256, false, false> : (bs == 512 ? (const void*)k_batch_admm_lds<512, false, false> : (const void*)k_batch_admm_lds<1024, false, false>);
-  if (b->reg_mode == 1) fn = (const void*)k_batch_admm_reg<512, 1, 2, false, false>;
-  if (b->reg_mode == 2) fn = (const void*)k_batch_admm_reg<512, 2, 4, false, false>;
-  if (npsd > 0 || n3 > 0 || b->force_ext) {
-    fn = (const void*)k_batch_admm_lds<512, true, false>;
-    if (b->reg_mode == 1) fn = (const void*)k_batch_admm_reg<512, 1, 2, true, false>;
-    if (b->reg_mode == 2) fn = (const void*)k_batch_admm_reg<512, 2, 4, true, false>;
-  }
-  if (b->aa_on) {
-    fn = (const void*)k_batch_admm_lds<512, true, true>;
-    if (b->reg_mode == 1) fn = (const void*)k_batch_admm_reg<512, 1, 2, false, true>;
-    if (b->reg_mode == 2) fn = (const void*)k_batch_admm_reg<512, 2, 4, false, true>;
-  }
-#if !REAL_IS_FLOAT
-  if (use_sliced)
-    fn = b->aa_on ? (const void*)k_batch_admm_reg<512, 1, 2, false, true, true>
-                  : ((npsd > 0 || n3 > 0 || b->force_ext) ? (const void*)k_batch_admm_reg<512, 1, 2, true, false, true> : (const void*)k_batch_admm_reg<512, 1, 2, false, false, true>);
-#endif
+  const void* fn = batch_kernel_of(b).fn;                  // (d_img, reg_mode, sliced, lds_bs are set: the instantiation launch_batch_admm will launch)
   // The attribute belongs to the kernel INSTANTIATION, which is process-global, not to this batch: a batch group builds several classes that share an
-  // instantiation with different lds_bytes, from several threads.  It is therefore set to the device maximum (every lds_bytes is <= max_lds by construction),
-  // so that a later, smaller class cannot lower it under an earlier one's launch on a runtime that enforces the value.
-  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds) != hipSuccess) {
-    (void)hipGetLastError();
-    b->d_img = nullptr; b->reg_mode = 0;          // the device does not grant that much LDS: streaming kernel
-  }
+  // instantiation with different lds_bytes, from several threads.  It is therefore set to the most the instantiation can be granted -- the device maximum
+  // minus the instantiation's own static LDS (every lds_bytes is <= max_lds by construction) -- so that a later, smaller class cannot lower it under an
+  // earlier one's launch on a runtime that enforces the value.  (Round 6, first form: the plain device maximum -- refused for the
+  // instantiations with a few bytes of static LDS, and every batch with PSD / exponential / power cones fell back to the streaming kernel; found with
+  // cosmo_hip_batch_kernel_info, pinned by tests/test_gpu_batch.py::test_extended_cone_batches_run_the_lds_image_kernel.)
+  { hipFuncAttributes fa;
+    int grant = 0;
+    if (hipFuncGetAttributes(&fa, fn) == hipSuccess) grant = max_lds - (int)fa.sharedSizeBytes;
+    if (grant < b->lds_bytes || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, grant) != hipSuccess) {
+      (void)hipGetLastError();
+      b->d_img = nullptr; b->reg_mode = 0;          // the device does not grant that much LDS: streaming kernel
+    } }
   return COSMO_HIP_OK;
 }
 
 static int32_t launch_batch_admm(cosmo_hip_batch* b, const BParams& P, long long target, int do_init) {
-  bool psd = b->D.npsd > 0 || b->D.n3 > 0;              // the instantiations with the cones beyond Zero / Nonnegatives / Box / SecondOrderCone
-  if (b->force_ext) psd = true;                           // COSMO_HIP_BATCH_EXT=1 (lab switch: that code is a run-time no-op without such cones)
-#define LAUNCH_REG(JN_, JM_, PSD_) hipLaunchKernelGGL((k_batch_admm_reg<512, JN_, JM_, PSD_, false>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride)
-#if !REAL_IS_FLOAT
-#define LAUNCH_REG_SL(PSD_, AA_) hipLaunchKernelGGL((k_batch_admm_reg<512, 1, 2, PSD_, AA_, true>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride)
-#else
-#define LAUNCH_REG_SL(PSD_, AA_) (void)0
-#endif
-#define LAUNCH_LDS(BS_, PSD_) hipLaunchKernelGGL((k_batch_admm_lds<BS_, PSD_, false>), dim3(b->nprob), dim3(BS_), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride)
-  if (b->aa_on) {                    // accelerated loop: register kernel (batches without PSD cones), else the LDS-image kernel (512 threads) or the streaming kernel with the PSD code (a run-time no-op without such cones)
-    if (b->d_img && b->reg_mode == 1 && b->D.sliced) LAUNCH_REG_SL(false, true);
-    else if (b->d_img && b->reg_mode == 1) hipLaunchKernelGGL((k_batch_admm_reg<512, 1, 2, false, true>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
-    else if (b->d_img && b->reg_mode == 2) hipLaunchKernelGGL((k_batch_admm_reg<512, 2, 4, false, true>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
-    else if (b->d_img) hipLaunchKernelGGL((k_batch_admm_lds<512, true, true>), dim3(b->nprob), dim3(512), b->lds_bytes, b->stream, b->D, P, target, do_init, b->d_img, b->img_stride);
-    else hipLaunchKernelGGL((k_batch_admm<true, true>), dim3(b->nprob), dim3(COSMO_BS), 0, b->stream, b->D, P, target, do_init);
-  }
-  else if (b->d_img && b->reg_mode == 1 && b->D.sliced) { if (psd) LAUNCH_REG_SL(true, false); else LAUNCH_REG_SL(false, false); }
-  else if (b->d_img && b->reg_mode == 1) { if (psd) LAUNCH_REG(1, 2, true); else LAUNCH_REG(1, 2, false); }
-  else if (b->d_img && b->reg_mode == 2) { if (psd) LAUNCH_REG(2, 4, true); else LAUNCH_REG(2, 4, false); }
-  else if (b->d_img) {
-    if (psd) LAUNCH_LDS(512, true);                                  // (build_lds_images fixed 512 threads for batches with PSD / exp / pow cones)
-    else if (b->lds_bs == 256) LAUNCH_LDS(256, false);
-    else if (b->lds_bs == 512) LAUNCH_LDS(512, false);
-    else LAUNCH_LDS(1024, false);
-  } else {
-    if (psd) hipLaunchKernelGGL((k_batch_admm<true, false>), dim3(b->nprob), dim3(COSMO_BS), 0, b->stream, b->D, P, target, do_init);
-    else hipLaunchKernelGGL((k_batch_admm<false, false>), dim3(b->nprob), dim3(COSMO_BS), 0, b->stream, b->D, P, target, do_init);
-  }
-#undef LAUNCH_REG
-#undef LAUNCH_LDS
+  const BKernel K = batch_kernel_of(b);
+  BatchDev D = b->D; BParams Pc = P; long long tg = target; int di = do_init;
+  const unsigned char* img = b->d_img; long long stride = b->img_stride;
+  void* args[6] = {&D, &Pc, &tg, &di, &img, &stride};         // (the streaming kernels take the first four)
+  BHIP(b, hipLaunchKernel(K.fn, dim3(b->nprob), dim3(K.bs), args, K.image ? (size_t)b->lds_bytes : 0, b->stream));
   BHIP(b, hipGetLastError());
   return COSMO_HIP_OK;
 }
@@ -2564,8 +2747,16 @@ extern "C" int32_t cosmo_hip_batch_set_params(cosmo_hip_batch* b, const cosmo_hi
   int32_t rc;
   D.permA = nullptr; D.permT = nullptr; D.posN = nullptr; D.posM = nullptr; D.qposA = nullptr;
   D.slA = nullptr; D.slT = nullptr; D.pdiag = nullptr; D.pdiag_has = nullptr; D.sliced = 0;
+  // (until round 6 the launch looked at the cones of side <= 16 and the three-dimensional cones only: a batch whose ONLY such cones were PSD cones of side
+  //  17 .. 64 would have run an instantiation without the PSD code)
+  b->ext_cones = false;
+  for (size_t c = 0; c < b->cones.type.size(); ++c) {
+    const int ty = b->cones.type[c];
+    if (ty >= COSMO_HIP_EXP && ty <= COSMO_HIP_DUAL_POW) b->ext_cones = true;
+    if ((ty == COSMO_HIP_PSD_SQUARE || ty == COSMO_HIP_PSD_TRIANGLE) && b->cones.dim[c] > 1) b->ext_cones = true;
+  }
   if ((rc = build_lds_images(b))) return rc;               // needs the host CSR copies that bmat_upload releases
-  if (b->d_img && b->reg_mode == 1 && !b->h_permA.empty()) {        // (no image: the streaming kernel runs and needs none of this)
+  if (b->d_img && (b->reg_mode == 1 || (b->reg_mode == 0 && D.regcg)) && !b->h_permA.empty()) {        // (no image: the streaming kernel runs and needs none of this)
     if ((rc = bup(b, &D.permA, b->h_permA))) return rc;
     if ((rc = bup(b, &D.permT, b->h_permT))) return rc;
     if (!b->h_qposA.empty()) { if ((rc = bup(b, &D.qposA, b->h_qposA))) return rc; }
@@ -2946,9 +3137,17 @@ extern "C" int32_t cosmo_hip_batch_iterate(cosmo_hip_batch* b, int64_t n_iters, 
 }
 
 // which kernel a batch runs (after set_params): out = {form: 0 streaming, 1 LDS image, 2 register kernel <512, 1, 2>, 3 register kernel <512, 2, 4>;
-// sliced image 0 / 1; dynamic LDS bytes per workgroup; P held in registers 0 / 1}
+// sliced image 0 / 1; dynamic LDS bytes per workgroup; P held in registers 0 / 1; registers per thread and scratch bytes per thread of that
+// instantiation as the loaded code object reports them (hipFuncGetAttributes: VGPRs + AGPRs of the unified file; scratch > 0 = it spills);
+// its static LDS bytes; length-sorted compute assignment in the Krylov loop 0 / 1}
 extern "C" int32_t cosmo_hip_batch_kernel_info(cosmo_hip_batch* b, int64_t* out) {
   if (!b || !out) return COSMO_HIP_ERR_INVALID;
+  if (!b->finalized) return bfail(b, COSMO_HIP_ERR_INVALID, "batch_kernel_info: set_params first");
+  if (hipSetDevice(b->device) != hipSuccess) return bfail(b, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
+  { hipFuncAttributes fa;
+    BHIP(b, hipFuncGetAttributes(&fa, batch_kernel_of(b).fn));
+    out[4] = fa.numRegs; out[5] = (int64_t)fa.localSizeBytes; out[6] = (int64_t)fa.sharedSizeBytes; }
+  out[7] = b->D.permA ? 1 : 0;
   out[0] = !b->d_img ? 0 : (b->reg_mode == 1 ? 2 : (b->reg_mode == 2 ? 3 : 1));
   out[1] = (b->d_img && b->reg_mode == 1 && b->D.sliced) ? 1 : 0;
   out[2] = b->d_img ? b->lds_bytes : 0;

@@ -189,7 +189,7 @@ COSMO_HIP_API const char* cosmo_hip_last_error(const cosmo_hip_handle* h);
 /* ABI version of the library (major*1000 + minor).  COSMO_HIP_ABI_VERSION is the version THIS header describes; the bindings generated from
  * it (cosmo.jl_amd/_abi_structs.py, julia/abi_structs.jl) carry the same number and refuse a library that reports another one: a stale
  * .so paired with newer struct mirrors would read garbage, a newer .so would write past an older caller's cosmo_hip_result. */
-#define COSMO_HIP_ABI_VERSION 1003
+#define COSMO_HIP_ABI_VERSION 1004
 COSMO_HIP_API int32_t cosmo_hip_version(void);
 COSMO_HIP_API void cosmo_hip_default_params(cosmo_hip_params* p);
 
@@ -475,8 +475,10 @@ COSMO_HIP_API int32_t cosmo_hip_batch_iterate(cosmo_hip_batch* b, int64_t n_iter
  * IndirectReducedKKTSolver.iteration_counter / multiplications, src/linear_solver/kktsolver_indirect.jl:32,56) */
 COSMO_HIP_API int32_t cosmo_hip_batch_get_counters(cosmo_hip_batch* b, int64_t* out);
 /* which kernel the batch runs (after set_params; measurement / tests): out = {form: 0 streaming, 1 LDS image, 2 register kernel <512, 1, 2>,
- * 3 register kernel <512, 2, 4>; sliced image 0 / 1; dynamic LDS bytes per workgroup; P held in registers 0 / 1} */
-COSMO_HIP_API int32_t cosmo_hip_batch_kernel_info(cosmo_hip_batch* b, int64_t out[4]);
+ * 3 register kernel <512, 2, 4>; sliced image 0 / 1; dynamic LDS bytes per workgroup; P held in registers 0 / 1; registers per thread and
+ * scratch bytes per thread of that kernel instantiation as the loaded code object reports them (> 0 scratch: it spills); its static LDS bytes;
+ * length-sorted compute assignment in the Krylov loop 0 / 1}  (ABI 1004: out grew from 4 to 8 entries) */
+COSMO_HIP_API int32_t cosmo_hip_batch_kernel_info(cosmo_hip_batch* b, int64_t out[8]);
 COSMO_HIP_API int32_t cosmo_hip_batch_get_iterates(cosmo_hip_batch* b, int64_t k, cosmo_hip_real* w, cosmo_hip_real* w_prev, cosmo_hip_real* s, cosmo_hip_real* mu);
 
 /* ---- batches of problems of DIFFERENT structure (csrc/batch_group.hip) ------------------------------------------------------------------

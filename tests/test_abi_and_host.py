@@ -29,7 +29,7 @@ def test_library_exports_every_header_symbol():
     for nm in names:
         assert hasattr(lib, nm), "libcosmo_hip.so does not export %s" % nm
     assert set(cj._ffi.SIGNATURES) == set(names)              # the binding covers the whole header, nothing else
-    assert cj.load_library().cosmo_hip_version() == cj._ffi.ABI_VERSION == 1003
+    assert cj.load_library().cosmo_hip_version() == cj._ffi.ABI_VERSION == 1004
 
 
 def test_the_dynamic_symbol_table_is_the_c_abi_and_nothing_else():
@@ -59,7 +59,7 @@ def test_float32_library_exports_the_same_symbols_and_real_pointers_follow_the_h
     lib = ctypes.CDLL(cj._ffi.LIB_PATH_F32)
     for nm in names:
         assert hasattr(lib, nm), "libcosmo_hip_f32.so does not export %s" % nm
-    assert cj.load_library(np.float32).cosmo_hip_version() == cj._ffi.ABI_VERSION == 1003 and cj.load_library(np.float32) is not cj.load_library()
+    assert cj.load_library(np.float32).cosmo_hip_version() == cj._ffi.ABI_VERSION == 1004 and cj.load_library(np.float32) is not cj.load_library()
     src = open(os.path.join(ROOT, "include", "cosmo_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     for nm, (_, args) in cj._ffi.SIGNATURES.items():
@@ -356,7 +356,7 @@ def test_plain_c_client_links_and_runs():
         assert r.returncode == 0, r.stderr
         out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, out.stderr
-        assert "version=1003 alpha=1.6 max_iter=5000 check_termination=25 accel_mem=15 merge=2 obj_true_is_nan=1" in out.stdout
+        assert "version=1004 alpha=1.6 max_iter=5000 check_termination=25 accel_mem=15 merge=2 obj_true_is_nan=1" in out.stdout
         import torch
         if not torch.cuda.is_available():
             assert "create_rc=2" in out.stdout                                # COSMO_HIP_ERR_HIP: no device, no fallback
@@ -367,7 +367,7 @@ def test_plain_c_client_links_and_runs():
                             "-Wl,-rpath," + libdir], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         out32 = subprocess.run([exe32], capture_output=True, text=True, timeout=120)
-        assert out32.returncode == 0 and "version=1003 alpha=1.6 max_iter=5000" in out32.stdout, out32.stderr
+        assert out32.returncode == 0 and "version=1004 alpha=1.6 max_iter=5000" in out32.stdout, out32.stderr
 
 
 def test_c_client_that_solves_compiles_warning_free_against_both_libraries():

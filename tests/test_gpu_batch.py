@@ -438,7 +438,8 @@ def test_cfg3_full_size_batch():
 
 def _with_env(env, fn):
     import os
-    keys = ("COSMO_HIP_BATCH_LDS", "COSMO_HIP_BATCH_BS", "COSMO_HIP_BATCH_REG", "COSMO_HIP_BATCH_LDSCG", "COSMO_HIP_BATCH_EXT", "COSMO_HIP_BATCH_SORTED", "COSMO_HIP_BATCH_SLICED")
+    keys = ("COSMO_HIP_BATCH_LDS", "COSMO_HIP_BATCH_BS", "COSMO_HIP_BATCH_REG", "COSMO_HIP_BATCH_LDSCG", "COSMO_HIP_BATCH_EXT", "COSMO_HIP_BATCH_SORTED", "COSMO_HIP_BATCH_SLICED",
+            "COSMO_HIP_BATCH_LDSCG_SORTED", "COSMO_HIP_BATCH_STORE_SORTED")
     saved = {k: os.environ.pop(k, None) for k in keys}
     os.environ.update(env)
     try:
@@ -757,6 +758,56 @@ def test_batch_small_sdp_kernel_variants_agree_and_match_the_single_problem_path
     single = cj.optimize(_models(probs[:1], st)[0])
     assert np.max(np.abs(single.x - ref[0].x)) <= 1e-8 * max(np.max(np.abs(ref[0].x)), 1.0)
     assert np.max(np.abs(single.s - ref[0].s)) <= 1e-8 * max(np.max(np.abs(ref[0].s)), 1.0)
+
+
+def test_extended_cone_batches_run_the_lds_image_kernel():
+    """Which kernel a batch with PSD / exponential / power cones actually runs (cosmo_hip_batch_kernel_info), and the forms of the LDS-image kernel's
+    register-CG solve (round 6) against each other.  (Round 6, first half: every such batch had silently fallen back to the streaming kernel -- the
+    dynamic-LDS attribute of the instantiations with a few bytes of static LDS was refused -- and no test looked at the form.)
+    - small SDPs: default = the register kernel; COSMO_HIP_BATCH_REG=0 = the LDS-image kernel, sorted assignment on a stored-sorted image; with the
+      accelerator = the LDS-image kernel; the code object's registers / scratch are reported;
+    - sorted + stored-sorted (default), sorted on the index-order image, index-order assignment, generic loops, streaming: tight-CG trajectories agree
+      to 1e-8, the generic loops repeat the streaming kernel bit for bit;
+    - a batch whose ONLY extended cones are PSD cones of side 24 (no cone of side <= 16: until round 6 the launch would have picked an instantiation
+      without the PSD code) against the oracle."""
+    probs = _small_sdps(6, 33)
+    tight = cj.with_options(cj.CGIndirectKKTSolver, tol_constant=1e-10, tol_exponent=0.0)
+    st = cj.Settings(kkt_solver=tight, max_iter=60, eps_abs=0.0, eps_rel=0.0)
+
+    def run(stt=st, pp=probs):
+        B, _ = cj.model.prepare_batch(_models(pp, stt), 0)
+        info = B.kernel_info()
+        B.close()
+        return info, cj.optimize_batch(_models(pp, stt))
+    i_reg, r_reg = _with_env({}, run)
+    assert i_reg["form"] == "register_1_2" and i_reg["registers"] > 0, i_reg
+    i_def, r_def = _with_env({"COSMO_HIP_BATCH_REG": "0"}, run)
+    assert i_def["form"] == "lds_image" and i_def["sorted_assignment"] and i_def["registers"] > 0 and i_def["lds_bytes"] > 0, i_def
+    i_aa, _ = _with_env({}, lambda: run(cj.Settings(accelerator=cj.AndersonAccelerator, max_iter=60, eps_abs=0.0, eps_rel=0.0)))
+    assert i_aa["form"] == "lds_image" and i_aa["sorted_assignment"], i_aa
+    i_ns, r_ns = _with_env({"COSMO_HIP_BATCH_REG": "0", "COSMO_HIP_BATCH_STORE_SORTED": "0"}, run)
+    i_io, r_io = _with_env({"COSMO_HIP_BATCH_REG": "0", "COSMO_HIP_BATCH_LDSCG_SORTED": "0"}, run)
+    i_g, r_g = _with_env({"COSMO_HIP_BATCH_REG": "0", "COSMO_HIP_BATCH_LDSCG": "0"}, run)
+    i_s, r_s = _with_env({"COSMO_HIP_BATCH_LDS": "0"}, run)
+    assert i_ns["form"] == i_io["form"] == i_g["form"] == "lds_image" and i_ns["sorted_assignment"] and not i_io["sorted_assignment"] and i_s["form"] == "streaming"
+    assert i_ns["lds_bytes"] < i_def["lds_bytes"]                     # the stored-sorted image carries its two position -> row / column maps
+    for k in range(len(probs)):
+        a = r_s[k]
+        assert np.array_equal(a.x, r_g[k].x) and np.array_equal(a.s, r_g[k].s) and a.kkt_iters_total == r_g[k].kkt_iters_total
+        for other in (r_def[k], r_ns[k], r_io[k]):
+            for u, v in ((a.x, other.x), (a.s, other.s), (a.y, other.y)):
+                assert np.max(np.abs(u - v)) <= 1e-8 * max(1.0, float(np.max(np.abs(u)))), k
+            assert abs(a.kkt_iters_total - other.kkt_iters_total) <= 0.02 * a.kkt_iters_total + 2 and other.iter == 60
+    # same compute assignment, same row sums, same block-sum tree as the register kernel: the same bits
+    assert all(np.array_equal(u.x, v.x) and np.array_equal(u.s, v.s) and u.kkt_iters_total == v.kkt_iters_total for u, v in zip(r_def, r_reg))
+    # PSD cones of side 24 only
+    rng = np.random.default_rng(424)
+    mid = [util.random_qp(rng, 30, 0, 6, 0, soc_dims=(), psd_tri_dims=(24,), psd_sq_dims=(), p_shift=1.0, density=0.05) for _ in range(4)]
+    i_mid, r_mid = _with_env({}, lambda: run(cj.Settings(), mid))
+    assert i_mid["form"] == "lds_image", i_mid
+    for p, r in zip(mid, r_mid):
+        ref = O.solve(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), O.Settings(kkt_solver="cg"))
+        assert r.status == ref.status == "Solved" and abs(r.iter - ref.iter) <= 25 and abs(r.obj_val - ref.obj_val) <= 1e-4 * (1 + abs(ref.obj_val)), (r.status, ref.status, r.iter, ref.iter)
 
 
 def test_batch_of_sdps_with_cones_of_side_17_to_64():
