@@ -33,6 +33,8 @@ NUM_KERNEL_CLASSES = 16
 from ._abi_structs import ABI_VERSION, AccelParams, Params, ResultStruct   # noqa: E402  generated from include/cosmo_hip.h (tools/gen_abi_structs.py)
 
 ACCEL_EMPTY, ACCEL_ANDERSON = 0, 1
+# the non-default variants of docs/src/acceleration.md:23 (include/cosmo_hip.h: COSMO_HIP_ACCEL_ANDERSON_*)
+ACCEL_ANDERSON_TYPE1_RESTARTED, ACCEL_ANDERSON_TYPE1_ROLLING, ACCEL_ANDERSON_TYPE2NE_RESTARTED, ACCEL_ANDERSON_TYPE2NE_ROLLING = 2, 3, 4, 5
 
 
 class CosmoHipError(RuntimeError):

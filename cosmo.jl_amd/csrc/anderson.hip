@@ -17,6 +17,11 @@
 // squares step, safeguarding) are taken on the device and read back with the one synchronisation per iteration that the
 // accelerated loop needs anyway.
 //
+// Round 6: the non-default variants the reference documents (docs/src/acceleration.md:23-26) -- Type1 and Type2{NormalEquations} with RestartedMemory or
+// RollingMemory: histories X (Type1), F, G; the mem x mem matrix M = L' F (L = X resp. F) is kept current with 2 l inner products per update
+// (column j and row j), eta = M \ (L' f) by LU with partial pivoting in one workgroup (k_aa_prep_ne, k_aa_gram, k_aa_gram_store, k_aa_solve_ne).
+// Restated from the published algorithm like the default variant (PARITY UNPINNED); checked against oracle.AndersonAcceleratorNE.
+//
 // ROW-SHARDED handles (round 4; csrc/rowshard.hip): w = [x (replicated, n) ; w_s (this rank's rows)], so every inner product of the accelerator is
 // (the x-part, counted ONCE: ranks other than 0 leave it out of their partial sums) + the sum over the ranks of the local row parts.  The
 // workgroup partials of every reduction are summed over the ranks slot by slot with ONE all-reduce of the partial array (comm_allreduce_sum, the
@@ -47,7 +52,11 @@ struct AaState {
   long long N = 0;
   int mem = 0;
   real *G = nullptr, *Q = nullptr, *f = nullptr, *f_last = nullptr, *g_last = nullptr;
-  real* parts = nullptr;      // (AA_MAX_MEM + 1) x COSMO_MAX_PARTIALS
+  // normal-equations variants (Type1 / Type2{NormalEquations}; kind >= 2): Q holds F (the f-differences), X the x-differences (Type1 only);
+  // the mem x mem matrix M = L' F (L = X or F) lives in flags->R and is kept current column by column / row by row
+  real *X = nullptr, *x_last = nullptr;
+  bool ne = false, type1 = false, rolling = false;
+  real* parts = nullptr;      // (2 AA_MAX_MEM + 2) x COSMO_MAX_PARTIALS (the second half: the row partials of the normal-equations variants)
   AaFlags* flags = nullptr;     // device
   AaFlags* flags_host = nullptr;  // pinned
   int grid = 1;
@@ -217,6 +226,107 @@ __global__ __launch_bounds__(COSMO_BS) void k_aa_reset(long long N, const real* 
   for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) { const real g = g_last[i]; w[i] = g; w_prev[i] = g; }
 }
 
+// ---- normal-equations variants (Type1, Type2{NormalEquations}; RestartedMemory / RollingMemory) ------------------------------------------------
+// update!: f = x - g ; first call after a restart: remember (x, g, f) ; otherwise X_j = x - x_last (Type1), G_j = g - g_last, F_j = f - f_last
+__global__ __launch_bounds__(COSMO_BS) void k_aa_prep_ne(long long N, const real* __restrict__ g, const real* __restrict__ x, int init,
+                                                         real* __restrict__ f, real* __restrict__ f_last, real* __restrict__ g_last, real* __restrict__ x_last,
+                                                         real* __restrict__ Gj, real* __restrict__ Fj, real* __restrict__ Xj) {
+  for (long long i = (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) {
+    const real gi = g[i], xi = x[i];
+    const real fi = xi - gi;
+    f[i] = fi;
+    if (!init) {
+      Gj[i] = gi - g_last[i];
+      Fj[i] = fi - f_last[i];
+      if (Xj) Xj[i] = xi - x_last[i];
+    }
+    g_last[i] = gi; f_last[i] = fi;
+    if (x_last) x_last[i] = xi;
+  }
+}
+// column j and row j of M = L' F over the first l columns: col[k] = <L_k, F_j>, row[k] = <L_j, F_k> (partials: slots k and AA_MAX_MEM + 1 + k)
+template <int L>
+__global__ __launch_bounds__(COSMO_BS) void k_aa_gram(long long N, int l, int j, const real* __restrict__ Lm, const real* __restrict__ Fm,
+                                                      real* __restrict__ parts, long long dot_lo) {
+  __shared__ real red[COSMO_BS / 64];
+  real col[L], row[L];
+#pragma unroll
+  for (int k = 0; k < L; ++k) { col[k] = 0.0; row[k] = 0.0; }
+  const real* Fj = Fm + (size_t)j * N;
+  const real* Lj = Lm + (size_t)j * N;
+  for (long long i = dot_lo + (long long)blockIdx.x * COSMO_BS + threadIdx.x; i < N; i += (long long)gridDim.x * COSMO_BS) {
+    const real fj = Fj[i], lj = Lj[i];
+#pragma unroll
+    for (int k = 0; k < L; ++k) if (k < l) { col[k] += Lm[(size_t)k * N + i] * fj; row[k] += lj * Fm[(size_t)k * N + i]; }
+  }
+#pragma unroll
+  for (int k = 0; k < L; ++k) {
+    if (k < l) {
+      const real a = block_sum(col[k], red);
+      const real b = block_sum(row[k], red);
+      if (threadIdx.x == 0) { parts[(size_t)k * COSMO_MAX_PARTIALS + blockIdx.x] = a; parts[(size_t)(AA_MAX_MEM + 1 + k) * COSMO_MAX_PARTIALS + blockIdx.x] = b; }
+    }
+  }
+}
+// one workgroup: M[:, j] and M[j, :] from the partials (column-major, leading dimension AA_MAX_MEM)
+__global__ __launch_bounds__(COSMO_BS) void k_aa_gram_store(int l, int j, int nparts, const real* __restrict__ parts, AaFlags* __restrict__ F) {
+  __shared__ real red[COSMO_BS / 64];
+  for (int k = 0; k < l; ++k) {
+    const real a = reduce_partials_sum(parts + (size_t)k * COSMO_MAX_PARTIALS, nparts, red);
+    __syncthreads();
+    const real b = reduce_partials_sum(parts + (size_t)(AA_MAX_MEM + 1 + k) * COSMO_MAX_PARTIALS, nparts, red);
+    if (threadIdx.x == 0) { F->R[j * AA_MAX_MEM + k] = a; if (k != j) F->R[k * AA_MAX_MEM + j] = b; }
+    __syncthreads();
+  }
+}
+// one workgroup: eta = M[0..l, 0..l) \ (L' f) by LU with partial pivoting (LAPACK gesv on a copy); success unless a pivot is exactly zero / not finite
+// (gesv's info > 0) or ||eta|| > eta_max or eta is not finite
+__global__ __launch_bounds__(COSMO_BS) void k_aa_solve_ne(int l, int nparts, const real* __restrict__ parts, real eta_max, AaFlags* __restrict__ F) {
+  __shared__ real red[COSMO_BS / 64];
+  __shared__ real rhs[AA_MAX_MEM];
+  __shared__ real Mw[AA_MAX_MEM * AA_MAX_MEM];
+  for (int k = 0; k < l; ++k) {
+    const real s = reduce_partials_sum(parts + (size_t)k * COSMO_MAX_PARTIALS, nparts, red);
+    if (threadIdx.x == 0) rhs[k] = s;
+    __syncthreads();
+  }
+  const real ff = reduce_partials_sum(parts + (size_t)AA_MAX_MEM * COSMO_MAX_PARTIALS, nparts, red);
+  if (threadIdx.x == 0) {
+    F->nrm_f = sqrt(ff);
+    for (int c = 0; c < l; ++c) for (int r = 0; r < l; ++r) Mw[c * AA_MAX_MEM + r] = F->R[c * AA_MAX_MEM + r];
+    bool ok = true;
+    for (int c = 0; c < l && ok; ++c) {
+      int pv = c; real best = fabs(Mw[c * AA_MAX_MEM + c]);
+      for (int r = c + 1; r < l; ++r) { const real a = fabs(Mw[c * AA_MAX_MEM + r]); if (a > best) { best = a; pv = r; } }     // first maximum, as idamax
+      const real piv = Mw[c * AA_MAX_MEM + pv];
+      if (!(fabs(piv) <= REAL_MAX) || piv == R(0.0)) { ok = false; break; }
+      if (pv != c) {
+        for (int cc = 0; cc < l; ++cc) { const real t = Mw[cc * AA_MAX_MEM + c]; Mw[cc * AA_MAX_MEM + c] = Mw[cc * AA_MAX_MEM + pv]; Mw[cc * AA_MAX_MEM + pv] = t; }
+        const real t = rhs[c]; rhs[c] = rhs[pv]; rhs[pv] = t;
+      }
+      for (int r = c + 1; r < l; ++r) {
+        const real mlt = Mw[c * AA_MAX_MEM + r] / piv;
+        Mw[c * AA_MAX_MEM + r] = mlt;
+        for (int cc = c + 1; cc < l; ++cc) Mw[cc * AA_MAX_MEM + r] -= mlt * Mw[cc * AA_MAX_MEM + c];
+        rhs[r] -= mlt * rhs[c];
+      }
+    }
+    if (!ok) { F->success = 0; F->fail_singular += 1; return; }
+    real nrm2 = 0.0;
+    for (int i = l - 1; i >= 0; --i) {
+      real s = rhs[i];
+      for (int k = i + 1; k < l; ++k) s -= Mw[k * AA_MAX_MEM + i] * F->eta[k];
+      const real e = s / Mw[i * AA_MAX_MEM + i];
+      F->eta[i] = e;
+      nrm2 += e * e;
+    }
+    const real en = sqrt(nrm2);
+    F->eta_norm = en;
+    if (!(en <= eta_max)) { F->success = 0; F->fail_eta += 1; return; }     // also catches NaN
+    F->success = 1;
+  }
+}
+
 inline AaState* aa_of(cosmo_hip_handle* h) { return static_cast<AaState*>(h->accel); }
 
 }  // namespace
@@ -232,7 +342,7 @@ static int32_t aa_share(cosmo_hip_handle* h, AaState* S, real* p) {
 void aa_free(cosmo_hip_handle* h) {
   AaState* S = aa_of(h);
   if (!S) return;
-  for (real* p : {S->G, S->Q, S->f, S->f_last, S->g_last, S->parts}) if (p) (void)hipFree(p);
+  for (real* p : {S->G, S->Q, S->f, S->f_last, S->g_last, S->parts, S->X, S->x_last}) if (p) (void)hipFree(p);
   if (S->flags) (void)hipFree(S->flags);
   if (S->flags_host) (void)hipHostFree(S->flags_host);
   delete S;
@@ -251,6 +361,8 @@ int32_t aa_restart(cosmo_hip_handle* h) {      // CA.restart! -> empty_history!
   HIPCHK(h, hipMemsetAsync(S->f, 0, sizeof(real) * (size_t)S->N, h->stream));
   HIPCHK(h, hipMemsetAsync(S->f_last, 0, sizeof(real) * (size_t)S->N, h->stream));
   HIPCHK(h, hipMemsetAsync(S->g_last, 0, sizeof(real) * (size_t)S->N, h->stream));
+  if (S->X) HIPCHK(h, hipMemsetAsync(S->X, 0, slab, h->stream));
+  if (S->x_last) HIPCHK(h, hipMemsetAsync(S->x_last, 0, sizeof(real) * (size_t)S->N, h->stream));
   HIPCHK(h, hipMemsetAsync(S->flags, 0, sizeof(AaFlags), h->stream));
   S->iter = 0;
   S->init_phase = true;
@@ -269,12 +381,15 @@ extern "C" int32_t cosmo_hip_set_accelerator(cosmo_hip_handle* h, const cosmo_hi
   if (!h->have_problem) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_accelerator: set_problem first");
   aa_free(h);
   if (!p || p->kind == COSMO_HIP_ACCEL_EMPTY) return COSMO_HIP_OK;
-  if (p->kind != COSMO_HIP_ACCEL_ANDERSON) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "accelerator kind %d", (int)p->kind);
+  if (p->kind < COSMO_HIP_ACCEL_ANDERSON || p->kind > COSMO_HIP_ACCEL_ANDERSON_TYPE2NE_ROLLING) return cosmo_fail(h, COSMO_HIP_ERR_UNSUPPORTED, "accelerator kind %d", (int)p->kind);
   if (p->mem < 1 || p->mem > AA_MAX_MEM || p->min_mem < 1 || p->start_iter < 2 || !(p->safeguard_tol >= 0.0) || !(p->eta_max > 0.0))
     return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_accelerator: need 1 <= mem <= %d, min_mem >= 1, start_iter >= 2", AA_MAX_MEM);
   AaState* S = new AaState();
   h->accel = S;
   S->prm = *p;
+  S->ne = p->kind != COSMO_HIP_ACCEL_ANDERSON;
+  S->type1 = p->kind == COSMO_HIP_ACCEL_ANDERSON_TYPE1_RESTARTED || p->kind == COSMO_HIP_ACCEL_ANDERSON_TYPE1_ROLLING;
+  S->rolling = p->kind == COSMO_HIP_ACCEL_ANDERSON_TYPE1_ROLLING || p->kind == COSMO_HIP_ACCEL_ANDERSON_TYPE2NE_ROLLING;
   S->N = h->n + h->m;                           // row-sharded handle: h->m is the LOCAL row count, w = [x ; this rank's rows]
   S->sharded = h->row_shard && comm_nranks(h) > 1;
   S->dot_lo = (S->sharded && comm_rank(h) > 0) ? h->n : 0;
@@ -288,8 +403,12 @@ extern "C" int32_t cosmo_hip_set_accelerator(cosmo_hip_handle* h, const cosmo_hi
   HIPCHK(h, hipMalloc((void**)&S->f, sizeof(real) * N));
   HIPCHK(h, hipMalloc((void**)&S->f_last, sizeof(real) * N));
   HIPCHK(h, hipMalloc((void**)&S->g_last, sizeof(real) * N));
-  HIPCHK(h, hipMalloc((void**)&S->parts, sizeof(real) * (AA_MAX_MEM + 1) * COSMO_MAX_PARTIALS));
-  HIPCHK(h, hipMemsetAsync(S->parts, 0, sizeof(real) * (AA_MAX_MEM + 1) * COSMO_MAX_PARTIALS, h->stream));   // slots beyond `grid` stay zero (all-reduced whole)
+  if (S->type1) {
+    HIPCHK(h, hipMalloc((void**)&S->X, sizeof(real) * N * S->mem));
+    HIPCHK(h, hipMalloc((void**)&S->x_last, sizeof(real) * N));
+  }
+  HIPCHK(h, hipMalloc((void**)&S->parts, sizeof(real) * (2 * AA_MAX_MEM + 2) * COSMO_MAX_PARTIALS));
+  HIPCHK(h, hipMemsetAsync(S->parts, 0, sizeof(real) * (2 * AA_MAX_MEM + 2) * COSMO_MAX_PARTIALS, h->stream));   // slots beyond `grid` stay zero (all-reduced whole)
   HIPCHK(h, hipMalloc((void**)&S->flags, sizeof(AaFlags)));
   HIPCHK(h, hipHostMalloc((void**)&S->flags_host, sizeof(AaFlags)));
   memset(S->flags_host, 0, sizeof(AaFlags));
@@ -326,6 +445,38 @@ int32_t aa_enqueue_pre(cosmo_hip_handle* h, long long it, bool* attempted) {
   const dim3 G(S->grid), B(COSMO_BS);
   hipStream_t st = h->stream;
   // ---- update! ----
+  if (S->ne) {
+    // Type1 / Type2{NormalEquations}: the histories X (Type1), F (in the Q slab), G; M = L' F kept current (L = X or F)
+    const real* Lm = S->type1 ? S->X : S->Q;
+    if (S->init_phase) {
+      hipLaunchKernelGGL(k_aa_prep_ne, G, B, 0, st, N, h->w, h->w_prev, 1, S->f, S->f_last, S->g_last, S->x_last, S->G, S->Q, S->X);
+      S->init_phase = false;
+    } else {
+      int j = S->iter % S->mem;
+      if (j == 0 && S->iter != 0 && !S->rolling) {       // RestartedMemory: the memory is full -> start over (RollingMemory: column j, the oldest, is overwritten)
+        const size_t slab = sizeof(real) * (size_t)N * (size_t)S->mem;
+        HIPCHK(h, hipMemsetAsync(S->G, 0, slab, st));
+        HIPCHK(h, hipMemsetAsync(S->Q, 0, slab, st));
+        if (S->X) HIPCHK(h, hipMemsetAsync(S->X, 0, slab, st));
+        HIPCHK(h, hipMemsetAsync(S->flags, 0, offsetof(AaFlags, nrm_f), st));
+        HIPCHK(h, hipMemsetAsync(reinterpret_cast<char*>(S->flags) + offsetof(AaFlags, R), 0, sizeof(real) * AA_MAX_MEM * AA_MAX_MEM, st));
+        S->iter = 0;
+        S->num_restarts += 1;
+      }
+      hipLaunchKernelGGL(k_aa_prep_ne, G, B, 0, st, N, h->w, h->w_prev, 0, S->f, S->f_last, S->g_last, S->x_last, S->G + (size_t)j * N, S->Q + (size_t)j * N,
+                         S->X ? S->X + (size_t)j * N : (real*)nullptr);
+      S->iter += 1;
+      const int ln = std::min(S->iter, S->mem);           // columns in the history, the new one included
+      if (ln <= 8) hipLaunchKernelGGL((k_aa_gram<8>), G, B, 0, st, N, ln, j, Lm, S->Q, S->parts, S->dot_lo);
+      else if (ln <= 16) hipLaunchKernelGGL((k_aa_gram<16>), G, B, 0, st, N, ln, j, Lm, S->Q, S->parts, S->dot_lo);
+      else hipLaunchKernelGGL((k_aa_gram<AA_MAX_MEM>), G, B, 0, st, N, ln, j, Lm, S->Q, S->parts, S->dot_lo);
+      if (S->sharded) {
+        CHK(comm_allreduce_sum(h, S->parts, (size_t)ln * COSMO_MAX_PARTIALS));
+        CHK(comm_allreduce_sum(h, AA_PARTS(S, AA_MAX_MEM + 1), (size_t)ln * COSMO_MAX_PARTIALS));
+      }
+      hipLaunchKernelGGL(k_aa_gram_store, dim3(1), B, 0, st, ln, j, S->nparts, S->parts, S->flags);
+    }
+  } else
   if (S->init_phase) {
     hipLaunchKernelGGL(k_aa_prep, G, B, 0, st, N, h->w, h->w_prev, 1, S->f, S->f_last, S->g_last, S->G, S->Q, S->Q, 0, AA_PARTS(S, 0), S->dot_lo);
     S->init_phase = false;
@@ -362,14 +513,16 @@ int32_t aa_enqueue_pre(cosmo_hip_handle* h, long long it, bool* attempted) {
     HIPCHK(h, hipGetLastError());
     return COSMO_HIP_OK;
   }
-  if (l <= 8) hipLaunchKernelGGL((k_aa_qtf<8>), G, B, 0, st, N, l, S->Q, S->f, S->parts, S->dot_lo);
-  else if (l <= 16) hipLaunchKernelGGL((k_aa_qtf<16>), G, B, 0, st, N, l, S->Q, S->f, S->parts, S->dot_lo);
-  else hipLaunchKernelGGL((k_aa_qtf<AA_MAX_MEM>), G, B, 0, st, N, l, S->Q, S->f, S->parts, S->dot_lo);
+  const real* Lq = (S->ne && S->type1) ? S->X : S->Q;     // Q' f (default), X' f (Type1), F' f (Type2{NormalEquations}: F lives in the Q slab)
+  if (l <= 8) hipLaunchKernelGGL((k_aa_qtf<8>), G, B, 0, st, N, l, Lq, S->f, S->parts, S->dot_lo);
+  else if (l <= 16) hipLaunchKernelGGL((k_aa_qtf<16>), G, B, 0, st, N, l, Lq, S->f, S->parts, S->dot_lo);
+  else hipLaunchKernelGGL((k_aa_qtf<AA_MAX_MEM>), G, B, 0, st, N, l, Lq, S->f, S->parts, S->dot_lo);
   if (S->sharded) {                                     // Q'f (the l written slots, contiguous) and ||f||^2 (slot AA_MAX_MEM)
     CHK(comm_allreduce_sum(h, S->parts, (size_t)l * COSMO_MAX_PARTIALS));
     CHK(comm_allreduce_sum(h, AA_PARTS(S, AA_MAX_MEM), (size_t)S->grid));
   }
-  hipLaunchKernelGGL(k_aa_solve, dim3(1), B, 0, st, l, S->nparts, S->parts, S->prm.eta_max, S->flags);
+  if (S->ne) hipLaunchKernelGGL(k_aa_solve_ne, dim3(1), B, 0, st, l, S->nparts, S->parts, S->prm.eta_max, S->flags);
+  else hipLaunchKernelGGL(k_aa_solve, dim3(1), B, 0, st, l, S->nparts, S->parts, S->prm.eta_max, S->flags);
   if (l <= 8) hipLaunchKernelGGL((k_aa_apply<8>), G, B, 0, st, N, l, S->G, S->flags, h->w);
   else if (l <= 16) hipLaunchKernelGGL((k_aa_apply<16>), G, B, 0, st, N, l, S->G, S->flags, h->w);
   else hipLaunchKernelGGL((k_aa_apply<AA_MAX_MEM>), G, B, 0, st, N, l, S->G, S->flags, h->w);

@@ -157,18 +157,28 @@ end
 
 
 # settings.accelerator is an OptionsFactory{<:AbstractAccelerator} (src/settings.jl:96,136,148-150).  The device builds the
-# reference's default AndersonAccelerator{Float64, Type2{QRDecomp}, RestartedMemory, NoRegularizer}; EmptyAccelerator maps to
-# "none"; any other variant is rejected (error) rather than silently replaced.
+# reference's default AndersonAccelerator{T, Type2{QRDecomp}, RestartedMemory, NoRegularizer} (kind 1) and, since round 6, the variants of
+# docs/src/acceleration.md:23-26 with broyden type Type1 / Type2{NormalEquations} and RestartedMemory / RollingMemory (kinds 2 .. 5 of
+# include/cosmo_hip.h); EmptyAccelerator maps to "none"; anything else (a regulariser, Type2{QRDecomp} with a rolling memory) is rejected
+# (error) rather than silently replaced.
+function accel_kind(::Type{AT}, ::Type{T}) where {AT, T}
+    CA = COSMO.CA                                   # const CA = COSMOAccelerators (src/accelerator_interface.jl:3)
+    AT == CA.AndersonAccelerator{T, CA.Type2{CA.QRDecomp}, CA.RestartedMemory, CA.NoRegularizer} && return Int32(1)
+    AT == CA.AndersonAccelerator{T, CA.Type1, CA.RestartedMemory, CA.NoRegularizer} && return Int32(2)
+    AT == CA.AndersonAccelerator{T, CA.Type1, CA.RollingMemory, CA.NoRegularizer} && return Int32(3)
+    AT == CA.AndersonAccelerator{T, CA.Type2{CA.NormalEquations}, CA.RestartedMemory, CA.NoRegularizer} && return Int32(4)
+    AT == CA.AndersonAccelerator{T, CA.Type2{CA.NormalEquations}, CA.RollingMemory, CA.NoRegularizer} && return Int32(5)
+    error("accelerator $(AT) is not built on the MI355X path; use AndersonAccelerator{T, BT, MT, NoRegularizer} with BT in (Type2{QRDecomp} [RestartedMemory only], Type1, Type2{NormalEquations}) or EmptyAccelerator")
+end
 function accel_params_from(settings::COSMO.Settings{T}) where {T <: HipFloat}
     AT = settings.accelerator.ObjectType
     AT <: COSMO.EmptyAccelerator && return nothing
-    AT == COSMO.AndersonAccelerator{T, COSMO.Type2{COSMO.QRDecomp}, COSMO.RestartedMemory, COSMO.NoRegularizer} ||
-        error("accelerator $(AT) is not built on the MI355X path; use the default Type2{QRDecomp}/RestartedMemory variant or EmptyAccelerator")
+    kind = accel_kind(AT, T)
     kw = settings.accelerator.kwargs
     act = get(kw, :activation_reason, COSMO.ImmediateActivation())
     start = act isa COSMO.IterActivation ? act.start_iter : 2
     acc = act isa COSMO.AccuracyActivation ? Float64(act.start_accuracy) : -1.0    # src/accelerator_interface.jl:14-21
-    return AccelParams(Int32(1), Int32(get(kw, :mem, 10)), Int32(get(kw, :min_mem, 3)), Int32(settings.safeguard ? 1 : 0), Int64(start),
+    return AccelParams(kind, Int32(get(kw, :mem, 10)), Int32(get(kw, :min_mem, 3)), Int32(settings.safeguard ? 1 : 0), Int64(start),
                        Float64(settings.safeguard_tol), 1e4, acc)
 end
 function set_accelerator!(h::Handle{T}, settings::COSMO.Settings{T}) where {T <: HipFloat}

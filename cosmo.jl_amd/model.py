@@ -232,8 +232,80 @@ class EmptyAccelerator:
     """CA.EmptyAccelerator"""
 
 
+# type parameters of CA.AndersonAccelerator{T, BT, MT, RE} (src/printing.jl:83-97, docs/src/acceleration.md:5,23)
+class QRDecomp:
+    """CA.QRDecomp"""
+
+
+class NormalEquations:
+    """CA.NormalEquations"""
+
+
+class Type1:
+    """CA.Type1: eta solves (X' F) eta = X' f"""
+
+
+class Type2:
+    """CA.Type2{QRDecomp} (bare `Type2`) / CA.Type2{NormalEquations} (`Type2[NormalEquations]`): eta = argmin ||f - F eta||"""
+    method = QRDecomp
+
+    def __class_getitem__(cls, method):
+        if method is QRDecomp:
+            return cls
+        if method is NormalEquations:
+            return _Type2NormalEquations
+        raise TypeError("Type2{...}: QRDecomp or NormalEquations")
+
+
+class _Type2NormalEquations(Type2):
+    method = NormalEquations
+
+
+class RestartedMemory:
+    """CA.RestartedMemory: the history is emptied when it is full"""
+
+
+class RollingMemory:
+    """CA.RollingMemory: the oldest column is replaced by the newest"""
+
+
+class NoRegularizer:
+    """CA.NoRegularizer (the only regulariser on the device)"""
+
+
 class AndersonAccelerator:
-    """AndersonAccelerator{T, Type2{QRDecomp}, RestartedMemory, NoRegularizer} -- the one variant built on the device."""
+    """AndersonAccelerator{T, Type2{QRDecomp}, RestartedMemory, NoRegularizer}, the reference's default (csrc/anderson.hip, and inside the persistent
+    batch kernels).  `AndersonAccelerator[Type1, RollingMemory]` etc. -- Julia's `AndersonAccelerator{Float64, Type1, RollingMemory, NoRegularizer}`
+    (docs/src/acceleration.md:23-26; a leading dtype and a trailing NoRegularizer are accepted and ignored) -- select the other broyden types
+    (Type1, Type2[NormalEquations]) and memory types on single-problem handles; Type2{QRDecomp} with RollingMemory does not exist in the package either."""
+    broyden, memory = Type2, RestartedMemory
+    accel_kind = _ffi.ACCEL_ANDERSON
+    _variants: dict = {}
+
+    def __class_getitem__(cls, params):
+        params = params if isinstance(params, tuple) else (params,)
+        bt, mt = Type2, RestartedMemory
+        for prm in params:
+            if isinstance(prm, type) and issubclass(prm, (Type1, Type2)):
+                bt = prm
+            elif prm in (RestartedMemory, RollingMemory):
+                mt = prm
+            elif prm is NoRegularizer or prm in (float, np.float64, np.float32):
+                pass
+            else:
+                raise TypeError("AndersonAccelerator{...}: unknown type parameter %r" % (prm,))
+        if bt is Type2 and mt is RestartedMemory:
+            return AndersonAccelerator
+        if bt is Type2 and mt is RollingMemory:
+            raise TypeError("AndersonAccelerator{Type2{QRDecomp}, RollingMemory}: a rolling memory needs Type1 or Type2{NormalEquations}")
+        key = (bt, mt)
+        if key not in cls._variants:
+            kind = {(Type1, RestartedMemory): _ffi.ACCEL_ANDERSON_TYPE1_RESTARTED, (Type1, RollingMemory): _ffi.ACCEL_ANDERSON_TYPE1_ROLLING,
+                    (_Type2NormalEquations, RestartedMemory): _ffi.ACCEL_ANDERSON_TYPE2NE_RESTARTED,
+                    (_Type2NormalEquations, RollingMemory): _ffi.ACCEL_ANDERSON_TYPE2NE_ROLLING}[key]
+            cls._variants[key] = type("AndersonAccelerator_%s_%s" % (bt.__name__.strip("_"), mt.__name__), (AndersonAccelerator,),
+                                      dict(broyden=bt, memory=mt, accel_kind=kind))
+        return cls._variants[key]
 
 
 class Box(AbstractConvexSet):
@@ -609,11 +681,11 @@ def _install_accelerator(h, st: Settings):
         acc, kw = acc.solver, acc.kwargs
     if acc is None or acc is EmptyAccelerator:
         return
-    if acc is not AndersonAccelerator:
+    if not (isinstance(acc, type) and issubclass(acc, AndersonAccelerator)):
         raise ValueError("unknown accelerator %r" % (acc,))
     act = kw.get("activation_reason", st.accelerator_activation)
     acc_kw = dict(start_accuracy=act.start_accuracy) if isinstance(act, AccuracyActivation) else dict(start_iter=int(act))
-    h.set_accelerator(_ffi.ACCEL_ANDERSON, mem=kw.get("mem", 15), min_mem=kw.get("min_mem", 3), safeguard=st.safeguard,
+    h.set_accelerator(acc.accel_kind, mem=kw.get("mem", 15), min_mem=kw.get("min_mem", 3), safeguard=st.safeguard,
                       safeguard_tol=st.safeguard_tol, **acc_kw)
 
 
@@ -810,6 +882,9 @@ def _batch_kernels_take(md: Model) -> bool:
     kkt = st.kkt_solver.solver if isinstance(st.kkt_solver, OptionsFactory) else st.kkt_solver
     if kkt not in (CGIndirectKKTSolver, CGSingleReductionKKTSolver, CGJacobiKKTSolver) or (st.adaptive_rho and st.adaptive_rho_interval == 0):
         return False
+    acc = st.accelerator.solver if isinstance(st.accelerator, OptionsFactory) else st.accelerator
+    if isinstance(acc, type) and issubclass(acc, AndersonAccelerator) and acc.accel_kind != _ffi.ACCEL_ANDERSON:
+        return False                      # the persistent kernels carry the default Type2{QRDecomp} / RestartedMemory variant only
     for K in md.sets:
         if K.kind in (_ffi.PSD_SQUARE, _ffi.PSD_TRIANGLE):
             d = int(round(np.sqrt(K.dim))) if K.kind == _ffi.PSD_SQUARE else int((np.sqrt(1 + 8 * K.dim) - 1) // 2)
@@ -875,6 +950,7 @@ def _solve_shard_on_device(models: Sequence[Model], device: int) -> List[Result]
     LAST_BATCH_INFO.update(dict(problems=len(models), mixed=bool(mixed), setup_seconds=t_setup, optimize_seconds=time.perf_counter() - t1))
     if mixed:
         LAST_BATCH_INFO.update(B.run_info())                       # worker threads / jobs of the group's bounded pool, structure classes
+        LAST_BATCH_INFO["own_handle_members"] = int(np.sum(B.class_info(with_modes=True)[2] == 1))     # members the batch kernels refused
     out = []
     for k, (md, r) in enumerate(zip(models, rs)):
         w, w_prev, s, mu = B.get_iterates(k)

@@ -147,7 +147,13 @@ typedef struct cosmo_hip_params {
 /* Accelerator of the fixed-point iteration (settings.accelerator, safeguard, safeguard_tol: src/settings.jl:96-98,136-138;
  * activation: src/accelerator_interface.jl:5-47).  ANDERSON = AndersonAccelerator{T, Type2{QRDecomp}, RestartedMemory,
  * NoRegularizer} of COSMOAccelerators.jl, the reference's default. */
-enum { COSMO_HIP_ACCEL_EMPTY = 0, COSMO_HIP_ACCEL_ANDERSON = 1 };
+/* Round 6: the non-default variants the reference documents (docs/src/acceleration.md:23-26, src/printing.jl:83-97) -- broyden type Type1 or
+ * Type2{NormalEquations} (the mem x mem system M eta = L' f with M = L' F, L = X resp. F, solved by LU with partial pivoting) with RestartedMemory
+ * or RollingMemory (the oldest column is overwritten).  Single-problem handles, also row-sharded; the persistent batch kernels carry the default
+ * variant only (cosmo_hip_batch_set_accelerator returns UNSUPPORTED for the others: a group runs such members on their own handles). */
+enum { COSMO_HIP_ACCEL_EMPTY = 0, COSMO_HIP_ACCEL_ANDERSON = 1,
+       COSMO_HIP_ACCEL_ANDERSON_TYPE1_RESTARTED = 2, COSMO_HIP_ACCEL_ANDERSON_TYPE1_ROLLING = 3,
+       COSMO_HIP_ACCEL_ANDERSON_TYPE2NE_RESTARTED = 4, COSMO_HIP_ACCEL_ANDERSON_TYPE2NE_ROLLING = 5 };
 typedef struct cosmo_hip_accel_params {
   int32_t kind;          /* COSMO_HIP_ACCEL_*                                                   */
   int32_t mem;           /* 15  (with_options(..., mem = 15), src/settings.jl:136); <= 32        */

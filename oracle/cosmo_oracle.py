@@ -537,6 +537,7 @@ class Settings:
     obj_true: float = float("nan")          # src/settings.jl:132-133
     obj_true_tol: float = 1e-3
     # accelerator (src/settings.jl:136-138, src/accelerator_interface.jl).  "empty" = EmptyAccelerator (the pinned loop);
+    # "anderson_type1_rolling" / "_type1_restarted" / "_type2ne_rolling" / "_type2ne_restarted" = the non-default variants of docs/src/acceleration.md:23;
     # "anderson" = AndersonAccelerator{T, Type2{QRDecomp}, RestartedMemory, NoRegularizer}(mem = 15), the reference's default.
     accelerator: str = "empty"
     acc_mem: int = 15
@@ -1185,6 +1186,121 @@ class AndersonAccelerator:
         self.success = True
 
 
+# --------------------------------------------------------------------------------------------
+# The non-default variants the reference documents (docs/src/acceleration.md:23-26, src/printing.jl:83-97):
+#   AndersonAccelerator{T, Type1, RollingMemory, NoRegularizer} and the other combinations of
+#   broyden type in {Type1, Type2{NormalEquations}} and memory in {RestartedMemory, RollingMemory}  --  PARITY UNPINNED, as above.
+# Published algorithm (Anderson 1965; Fang & Saad 2009 for the two types; Walker & Ni 2011) as the package's interface exposes it:
+#   update!(g, x):   f = x - g ; the first call after a (re)start only stores (x, g, f);
+#                    j = iter % mem + 1; if j == 1 and iter != 0: RestartedMemory empties the history (iter = 0), RollingMemory keeps it
+#                    and column j -- the OLDEST -- is overwritten; X[:, j] = x - x_last, G[:, j] = g - g_last, F[:, j] = f - f_last; iter += 1
+#   accelerate!(g):  l = min(iter, mem); nothing if l < min_mem;
+#                    Type1:  M = X' F, eta = X' f        Type2{NormalEquations}:  M = F' F, eta = F' f      (first l columns)
+#                    eta <- M \ eta by LU with partial pivoting (LAPACK gesv); fail if M is exactly singular or ||eta||_2 > 1e4;
+#                    else g <- g - G eta, success = true
+# Type2{NormalEquations} solves the SAME least-squares problem as the default Type2{QRDecomp} (through its normal equations); Type1 is the
+# "good Broyden" variant: eta makes the residual f - F eta orthogonal to the x-differences instead of the f-differences.
+# Definition-level anchors: tests/test_oracle_anderson_definition.py.
+# --------------------------------------------------------------------------------------------
+class AndersonAcceleratorNE:
+    ETA_MAX = 1e4
+
+    def __init__(self, dim: int, mem: int = 15, min_mem: int = 3, type1: bool = True, rolling: bool = True):
+        self.dim = int(dim)
+        self.mem = max(1, min(int(mem), self.dim))
+        self.min_mem = int(min_mem)
+        self.type1, self.rolling = bool(type1), bool(rolling)
+        self.X = np.zeros((self.dim, self.mem), order="F")
+        self.F = np.zeros((self.dim, self.mem), order="F")
+        self.G = np.zeros((self.dim, self.mem), order="F")
+        self.f = np.zeros(self.dim); self.f_last = np.zeros(self.dim)
+        self.x_last = np.zeros(self.dim); self.g_last = np.zeros(self.dim)
+        self.eta = np.zeros(self.mem)
+        self.iter = 0
+        self.init_phase = True
+        self.success = False
+        self.num_accelerated_steps = 0
+        self.num_restarts = 0
+        self.fail_eta = 0
+        self.fail_singular = 0
+
+    def restart(self):                      # CA.restart! -> empty_history!
+        self.X[:] = 0.0; self.F[:] = 0.0; self.G[:] = 0.0
+        self.f[:] = 0.0; self.f_last[:] = 0.0; self.x_last[:] = 0.0; self.g_last[:] = 0.0; self.eta[:] = 0.0
+        self.iter = 0
+        self.init_phase = True
+
+    def was_successful(self) -> bool:
+        return self.success
+
+    def update(self, g: np.ndarray, x: np.ndarray) -> None:
+        self.f[:] = x - g
+        if self.init_phase:
+            self.x_last[:] = x; self.g_last[:] = g; self.f_last[:] = self.f
+            self.init_phase = False
+            return
+        j = self.iter % self.mem
+        if j == 0 and self.iter != 0 and not self.rolling:      # RestartedMemory: start over with an empty memory
+            self.X[:] = 0.0; self.F[:] = 0.0; self.G[:] = 0.0
+            self.iter = 0
+            self.num_restarts += 1
+        self.X[:, j] = x - self.x_last
+        self.G[:, j] = g - self.g_last
+        self.F[:, j] = self.f - self.f_last
+        self.x_last[:] = x; self.g_last[:] = g; self.f_last[:] = self.f
+        self.iter += 1
+
+    def accelerate(self, g: np.ndarray) -> None:
+        self.success = False
+        l = min(self.iter, self.mem)
+        if l < self.min_mem:
+            return
+        L = self.X[:, :l] if self.type1 else self.F[:, :l]
+        M = L.T @ self.F[:, :l]
+        eta = L.T @ self.f
+        # gesv: LU with partial pivoting, in place; an exactly zero pivot is LAPACK's info > 0
+        M = M.copy(); eta = eta.copy()
+        for c in range(l):
+            pv = c + int(np.argmax(np.abs(M[c:, c])))
+            if not np.isfinite(M[pv, c]) or M[pv, c] == 0.0:
+                self.fail_singular += 1
+                return
+            if pv != c:
+                M[[c, pv], :] = M[[pv, c], :]; eta[[c, pv]] = eta[[pv, c]]
+            for r in range(c + 1, l):
+                m_ = M[r, c] / M[c, c]
+                M[r, c] = m_
+                M[r, c + 1:] -= m_ * M[c, c + 1:]
+                eta[r] -= m_ * eta[c]
+        for i in range(l - 1, -1, -1):
+            eta[i] = (eta[i] - M[i, i + 1:] @ eta[i + 1:]) / M[i, i]
+        if not np.all(np.isfinite(eta)) or np.linalg.norm(eta) > self.ETA_MAX:
+            self.fail_eta += 1
+            return
+        self.eta[:l] = eta
+        g -= self.G[:, :l] @ eta
+        self.num_accelerated_steps += 1
+        self.success = True
+
+
+ACCELERATOR_VARIANTS = {            # Settings.accelerator -> (type1, rolling) of AndersonAcceleratorNE
+    "anderson_type1_rolling": (True, True), "anderson_type1_restarted": (True, False),
+    "anderson_type2ne_rolling": (False, True), "anderson_type2ne_restarted": (False, False),
+}
+
+
+def make_accelerator(name: str, dim: int, mem: int, min_mem: int):
+    """`_make_accelerator!` (src/setup.jl:10-16)."""
+    if name == "anderson":
+        return AndersonAccelerator(dim, mem, min_mem)
+    if name in ACCELERATOR_VARIANTS:
+        t1, roll = ACCELERATOR_VARIANTS[name]
+        return AndersonAcceleratorNE(dim, mem, min_mem, type1=t1, rolling=roll)
+    if name in ("empty", None):
+        return None
+    raise ValueError("unknown accelerator %r" % (name,))
+
+
 class Workspace:
     """Holds what `COSMO.Workspace` holds after `setup!` (src/setup.jl:18-64): scaled data,
     classified cones, rho vector, KKT solver."""
@@ -1222,7 +1338,7 @@ class Workspace:
         self.kkt = make_kkt_solver(st.kkt_solver, self.P, self.A, self.ops, st.sigma, self.rho_vec, st)
         self.is_optimized = False
         # _make_accelerator! (src/setup.jl:10-16,44-49)
-        self.accelerator = AndersonAccelerator(n + m, st.acc_mem, st.acc_min_mem) if st.accelerator == "anderson" else None
+        self.accelerator = make_accelerator(st.accelerator, n + m, st.acc_mem, st.acc_min_mem)
         self.accelerator_active = False
         self.safeguarding_iter = 0
 

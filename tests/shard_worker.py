@@ -8,7 +8,7 @@ transport = rccl : RCCL communicator; <rendezvous> is a file through which rank 
 Environment: COSMO_TEST_SHARD = cones (default: cosmo_hip_set_cone_shard, the projections only) | rows (cosmo_hip_set_row_shard: cones +
 their rows, csrc/rowshard.hip); COSMO_TEST_CASE = chordal (default) | pinf | dinf (the two infeasible problems of
 test_infeasibility_certificates_in_sharded_runs, default settings); COSMO_TEST_TIGHT=1: CG solved to 1e-10 (tol_exponent 0);
-COSMO_TEST_DTYPE=float32: the Float32 library; COSMO_TEST_ACCEL=1: the reference's default accelerator (AndersonAccelerator, mem 15, safeguarded) with a
+COSMO_TEST_DTYPE=float32: the Float32 library; COSMO_TEST_ACCEL=1: the reference's default accelerator (COSMO_TEST_ACCEL_VARIANT=type1_rolling: the Type1 / RollingMemory variant) (AndersonAccelerator, mem 15, safeguarded) with a
 tight CG and eps = 1e-6 -- a convergent accelerated run (`iters` is then max_iter).
 Writes the final iterates, the result scalars and the communicator statistics of this rank."""
 import os
@@ -29,7 +29,10 @@ def problem():
 def settings(iters, tight=False):
     import cosmo_jl_amd as cj
     if os.environ.get("COSMO_TEST_ACCEL", "") == "1":
-        return cj.Settings(max_iter=iters, eps_abs=1e-6, eps_rel=1e-6, accelerator=cj.AndersonAccelerator,
+        acc = cj.AndersonAccelerator
+        if os.environ.get("COSMO_TEST_ACCEL_VARIANT", "") == "type1_rolling":        # docs/src/acceleration.md:23
+            acc = cj.AndersonAccelerator[cj.Type1, cj.RollingMemory]
+        return cj.Settings(max_iter=iters, eps_abs=1e-6, eps_rel=1e-6, accelerator=acc,
                            kkt_solver=cj.with_options(cj.CGIndirectKKTSolver, tol_constant=1e-10, tol_exponent=0.0))
     kw = dict(max_iter=iters, eps_abs=0.0, eps_rel=0.0, check_infeasibility=10 ** 9)
     if os.environ.get("COSMO_TEST_AUTO_RHO"):               # the automatic rho interval (adaptive_rho_interval = 0, solver.jl:244-256); setup times per rank: see main()

@@ -299,6 +299,40 @@ def test_sharded_runs_with_the_reference_default_accelerator(mode, world, monkey
         assert np.linalg.norm(z[0]["x"] - ref.x) <= 1e-3 * max(1.0, np.linalg.norm(ref.x))
         assert int(z[0]["allreduces"]) >= int(z[0]["iter"])                                                  # the loop's own all-reduce ran every iteration
 
+def test_row_sharded_run_with_the_type1_rolling_accelerator(monkeypatch):
+    """The Type1 / RollingMemory variant (docs/src/acceleration.md:23) on a row-sharded handle: the 2 l inner products per update that keep M = X' F
+    current and the l products of X' f are all-reduced partial sums like the default variant's -- two ranks agree with each other bit for bit and
+    with the single-rank run within the f2 tolerances."""
+    monkeypatch.setenv("COSMO_TEST_ACCEL", "1")
+    monkeypatch.setenv("COSMO_TEST_ACCEL_VARIANT", "type1_rolling")
+    monkeypatch.setenv("COSMO_HIP_POLAR_KLIFT", "10")
+    W = _worker_module()
+    p = W.problem()
+    md = cj.Model(); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], W.settings(3000))
+    assert md.settings.accelerator.accel_kind == cj._ffi.ACCEL_ANDERSON_TYPE1_ROLLING
+    ref = cj.optimize(md)
+    racc = md.handle.accel_stats()
+    assert ref.status == "Solved" and racc["accelerated"] > 0 and racc["restarts"] == 0
+    with tempfile.TemporaryDirectory() as tmp:
+        global ITERS
+        keep = ITERS
+        ITERS = 3000
+        try:
+            outs = _spawn("shm", 2, "/cosmo_test_" + uuid.uuid4().hex[:12], tmp, timeout=400,
+                          extra_env={"COSMO_TEST_SHARD": "rows", "COSMO_TEST_ACCEL": "1", "COSMO_TEST_ACCEL_VARIANT": "type1_rolling"})
+        finally:
+            ITERS = keep
+        for rc, o in outs:
+            assert rc == 0, o[-3000:]
+        z = [np.load(os.path.join(tmp, "rank%d.npz" % r)) for r in range(2)]
+    for key in ("x", "s", "y"):
+        assert np.array_equal(z[0][key].view(np.int64), z[1][key].view(np.int64)), key
+    assert int(z[0]["iter"]) == int(z[1]["iter"]) and int(z[0]["accelerated"]) == int(z[1]["accelerated"]) > 0 and int(z[0]["declined"]) == int(z[1]["declined"])
+    assert str(z[0]["status"]) == ref.status
+    assert abs(float(z[0]["obj"]) - ref.obj_val) <= 1e-5 * (1 + abs(ref.obj_val))
+    assert np.linalg.norm(z[0]["x"] - ref.x) <= 1e-3 * max(1.0, np.linalg.norm(ref.x))
+
+
 
 def test_row_sharded_run_with_a_time_limit_stops_all_ranks_at_the_same_iteration():
     """settings.time_limit in a sharded run (src/solver.jl:351-354): the ranks' clocks differ, so every time-limit decision (the slice a rank enqueues
