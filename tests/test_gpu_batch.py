@@ -810,6 +810,56 @@ def test_extended_cone_batches_run_the_lds_image_kernel():
         assert r.status == ref.status == "Solved" and abs(r.iter - ref.iter) <= 25 and abs(r.obj_val - ref.obj_val) <= 1e-4 * (1 + abs(ref.obj_val)), (r.status, ref.status, r.iter, ref.iter)
 
 
+def test_lds_image_register_cg_all_slots_and_a_long_column():
+    """The register-CG form of the LDS-image kernel with every slot of its compute assignment in use: n = 700 (column slots 0 and 1), m = 1 628 (row slots
+    0 .. 3, the odd ones assigned backwards), one DENSE column of A (2 049 > COSMO_NNZ_PER_BLOCK combined entries with its P row would take the long-row
+    branch of the tile loops; here 1 628 + 1: a single thread walks it in the Krylov passes) and a small PSD cone, so that the extended-cone instantiation
+    is the natural choice once the register kernel is switched off.  Sorted + stored-sorted (default), sorted on the index-order image, index order,
+    generic loops: tight-CG trajectories against the streaming kernel at 1e-8; default settings against the oracle (status, objective)."""
+    rng = np.random.default_rng(99)
+    probs = []
+    for _ in range(3):
+        p = util.random_qp(rng, 700, 20, 900, 400, soc_dims=(12, 9), psd_tri_dims=(7, 10), p_shift=1.0, density=0.003)
+        A = p["A"].tolil()
+        col = rng.integers(0, 700)
+        A[:, col] = rng.standard_normal((A.shape[0], 1)) * 0.05           # a dense column
+        p["A"] = A.tocsc()
+        # a P the image has room for: diagonal plus a few symmetric off-diagonal pairs (rows of P with 1 .. 3 entries)
+        Pd = sp.diags(rng.uniform(0.5, 2.0, 700)).tolil()
+        for _ in range(40):
+            i, j = rng.integers(0, 700, 2)
+            if i != j:
+                Pd[i, j] = Pd[j, i] = 0.05
+        p["P"] = Pd.tocsc()
+        probs.append(p)
+    assert probs[0]["A"].shape == (20 + 900 + 400 + 21 + 28 + 55, 700) and probs[0]["A"].nnz < 12000
+    tight = cj.with_options(cj.CGIndirectKKTSolver, tol_constant=1e-10, tol_exponent=0.0)
+    st = cj.Settings(kkt_solver=tight, max_iter=40, eps_abs=0.0, eps_rel=0.0)
+
+    def run(stt=st):
+        B, _ = cj.model.prepare_batch(_models(probs, stt), 0)
+        info = B.kernel_info()
+        B.close()
+        return info, cj.optimize_batch(_models(probs, stt))
+    i_s, r_s = _with_env({"COSMO_HIP_BATCH_LDS": "0"}, run)
+    i_d, r_d = _with_env({"COSMO_HIP_BATCH_REG": "0"}, run)
+    i_n, r_n = _with_env({"COSMO_HIP_BATCH_REG": "0", "COSMO_HIP_BATCH_STORE_SORTED": "0"}, run)
+    i_i, r_i = _with_env({"COSMO_HIP_BATCH_REG": "0", "COSMO_HIP_BATCH_LDSCG_SORTED": "0"}, run)
+    i_g, r_g = _with_env({"COSMO_HIP_BATCH_REG": "0", "COSMO_HIP_BATCH_LDSCG": "0"}, run)
+    assert i_s["form"] == "streaming" and i_d["form"] == i_n["form"] == i_i["form"] == i_g["form"] == "lds_image", (i_s, i_d)
+    assert i_d["sorted_assignment"] and i_n["sorted_assignment"] and not i_i["sorted_assignment"]
+    for k in range(len(probs)):
+        a = r_s[k]
+        for other in (r_d[k], r_n[k], r_i[k], r_g[k]):
+            for u, v in ((a.x, other.x), (a.s, other.s), (a.y, other.y)):
+                assert np.max(np.abs(u - v)) <= 1e-8 * max(1.0, float(np.max(np.abs(u)))), k
+            assert abs(a.kkt_iters_total - other.kkt_iters_total) <= 0.02 * a.kkt_iters_total + 2 and other.iter == 40
+    _, r_def = _with_env({"COSMO_HIP_BATCH_REG": "0"}, lambda: run(cj.Settings()))
+    for p, r in list(zip(probs, r_def))[:1]:                 # (one oracle solve of this size is ~20 s of Python)
+        ref = O.solve(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), O.Settings(kkt_solver="cg"))
+        assert r.status == ref.status and abs(r.obj_val - ref.obj_val) <= 1e-4 * (1 + abs(ref.obj_val)), (r.status, ref.status, r.obj_val, ref.obj_val)
+
+
 def test_batch_of_sdps_with_cones_of_side_17_to_64():
     """PSD cones of side 17 .. 64 in batch mode: the persistent workgroup runs the block one-sided Jacobi of csrc/psdwg.h (the routine of the
     single-problem path's k_psd_jacobi_wg) cone after cone.  64 problems with triangle cones of side 9, 24, 40 and 64 and a square cone of side 20:
