@@ -959,6 +959,10 @@ def bench_cfg5(ctx, args, steps, warmup):
                 out["adaptive_lifting_depth"] = adaptive_depth_extra(ctx, args, prob, steps, warmup, value)
             except Exception as e:
                 out["adaptive_lifting_depth"] = dict(error="%s: %s" % (type(e).__name__, e))
+            try:
+                out["eigen_projection"] = eigen_projection_extra(ctx, args, prob, value)
+            except Exception as e:
+                out["eigen_projection"] = dict(error="%s: %s" % (type(e).__name__, e))
             if not args.small:
                 try:
                     out["time_to_solution"] = time_to_solution_extra(ctx, args, prob)
@@ -966,6 +970,24 @@ def bench_cfg5(ctx, args, steps, warmup):
                     out["time_to_solution"] = dict(error="%s: %s" % (type(e).__name__, e))
     if ctx.world == 1 and not args.no_float32:
         out["float32"] = float32_extra(ctx, args, prob, st, steps, warmup)
+    h.close()
+    return out
+
+
+def eigen_projection_extra(ctx, args, prob, value_sign):
+    """The same workload with the eigendecomposition-based PSD projection the reference performs (src/convexset.jl:163-189, 243-263; north_star's wording of
+    a7 / a8) instead of the verified matrix-sign iteration: Settings.psd_projection = 'eigen' = cosmo_hip_set_psd_projection(EIGEN) -- one workgroup per
+    clique runs a block one-sided Jacobi eigensolver (csrc/psd.hip), nnz_lambda is counted from the eigenvalues.  A short window (the projections take
+    several times longer): the PRICE of that shape on this chip, re-measured by every run."""
+    import cosmo_jl_amd as cj
+    steps, warmup = (4, 2) if not args.small else (3, 1)
+    st = fixed_work_settings(cj, psd_projection="eigen"); st.device = ctx.local_rank
+    md = cj.Model(); md.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], st)
+    h, el, kb = _run_sdp(ctx, md, steps, warmup)
+    ps = h.psd_stats() if hasattr(h, "psd_stats") else None
+    out = dict(value=round(steps / el, 3), ms_per_step=round(1e3 * el / steps, 6), steps=steps, warmup=warmup, unit="ADMM iterations/s", dtype="f64",
+               vs_sign_iteration=round(steps / el / value_sign, 4), mean_cg_iters_per_admm_iter=round(kb, 3), jacobi=ps,
+               note="OPT-IN psd_projection='eigen': Jacobi eigendecomposition of every clique (exact nnz_lambda) instead of the verified matrix-sign iteration")
     h.close()
     return out
 
@@ -1149,7 +1171,7 @@ def main():
             out["data"] = "synthetic; DRY RUN of the multi-rank path: all ranks share one GPU (COSMO_BENCH_TRANSPORT=shm), not a measurement"
         if "cpu_baseline" in res:
             out["cpu_baseline"] = res["cpu_baseline"]
-        var = {k: res[k] for k in ("time_to_solution", "single_reduction_cg", "pcg", "adaptive_lifting_depth", "float32") if k in res}      # opt-in variants of the headline workload: next to, never instead of, `value`
+        var = {k: res[k] for k in ("time_to_solution", "single_reduction_cg", "pcg", "adaptive_lifting_depth", "eigen_projection", "float32") if k in res}      # opt-in variants of the headline workload: next to, never instead of, `value`
         if var:
             out["variants"] = var
         if extra:

@@ -33,6 +33,7 @@ NUM_KERNEL_CLASSES = 16
 from ._abi_structs import ABI_VERSION, AccelParams, Params, ResultStruct   # noqa: E402  generated from include/cosmo_hip.h (tools/gen_abi_structs.py)
 
 ACCEL_EMPTY, ACCEL_ANDERSON = 0, 1
+PSD_PROJECTION_SIGN, PSD_PROJECTION_EIGEN = 0, 1
 # the non-default variants of docs/src/acceleration.md:23 (include/cosmo_hip.h: COSMO_HIP_ACCEL_ANDERSON_*)
 ACCEL_ANDERSON_TYPE1_RESTARTED, ACCEL_ANDERSON_TYPE1_ROLLING, ACCEL_ANDERSON_TYPE2NE_RESTARTED, ACCEL_ANDERSON_TYPE2NE_ROLLING = 2, 3, 4, 5
 
@@ -108,6 +109,7 @@ SIGNATURES = {
     "cosmo_hip_get_kernel_times": (C.c_int32, [C.c_void_p, _PD, _PI64]),
     "cosmo_hip_kernel_class_name": (C.c_char_p, [C.c_int32]),
     "cosmo_hip_psd_stats": (C.c_int32, [C.c_void_p, _PI64]),
+    "cosmo_hip_set_psd_projection": (C.c_int32, [C.c_void_p, C.c_int32]),
     "cosmo_hip_polar_stats": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_polar_streamk_stats": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_polar_schedule": (C.c_int32, [C.c_int32, _PD, _PI32]),
@@ -329,6 +331,10 @@ class Handle:
         if start_accuracy is not None:
             ap.start_accuracy = float(start_accuracy)
         self._chk(self.lib.cosmo_hip_set_accelerator(self._h, C.byref(ap)))
+
+    def set_psd_projection(self, mode):
+        """0 = verified matrix-sign iteration above side 16 (default), 1 = eigendecomposition (Jacobi) at every side; after set_cones."""
+        self._chk(self.lib.cosmo_hip_set_psd_projection(self._h, int(mode)))
 
     def accel_stats(self):
         out = np.zeros(6, dtype=np.int64)

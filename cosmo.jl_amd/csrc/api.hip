@@ -396,6 +396,22 @@ int32_t rebuild_cone_plans(cosmo_hip_handle* h) {
   return COSMO_HIP_OK;
 }
 
+// How the PSD cones are projected (after set_cones; rebuilds the cone plans).  SIGN (default): side <= 16 by the wave-level Jacobi eigensolver, above it
+// the verified matrix-sign iteration on the matrix cores (psd_polar.hip) -- the projection within its a-posteriori bound, nnz_lambda exact on gapped
+// spectra.  EIGEN: the eigendecomposition-based projection the reference performs (src/convexset.jl:163-189, 243-263: syevr! + rank-k update) at EVERY
+// side -- block one-sided Jacobi on G = X + ||X||_F I (psd.hip: one workgroup per cone up to side 256, multi-workgroup host-paced sweeps above), X+ =
+// sum over lambda > 0 of lambda v v' and nnz_lambda counted from the eigenvalues themselves; several times slower on this chip (bench variants).
+extern "C" int32_t cosmo_hip_set_psd_projection(cosmo_hip_handle* h, int32_t mode) {
+  if (!h) return COSMO_HIP_ERR_INVALID;
+  if (mode != COSMO_HIP_PSD_PROJECTION_SIGN && mode != COSMO_HIP_PSD_PROJECTION_EIGEN) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_psd_projection: mode %d", (int)mode);
+  if (hipSetDevice(h->device) != hipSuccess) return cosmo_fail(h, COSMO_HIP_ERR_HIP, "hipSetDevice failed");
+  if (!h->have_cones) return cosmo_fail(h, COSMO_HIP_ERR_INVALID, "set_psd_projection: set_cones first");
+  if (h->psd_mode == mode) return COSMO_HIP_OK;
+  h->psd_mode = mode;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return rebuild_cone_plans(h);
+}
+
 extern "C" int32_t cosmo_hip_set_cones(cosmo_hip_handle* h, int64_t ncones, const int32_t* type, const int64_t* dim,
                                        const real* box_l, const real* box_u) {
   return cosmo_hip_set_cones_ex(h, ncones, type, dim, box_l, box_u, nullptr);

@@ -164,6 +164,7 @@ struct cosmo_hip_handle {
   // sizes
   long long n = 0, m = 0;
   bool have_problem = false, have_cones = false, have_params = false, have_iterates = false;
+  int psd_mode = 0;                // cosmo_hip_set_psd_projection: 0 = verified matrix-sign iteration above side 16 (default), 1 = eigendecomposition (Jacobi) at every side
   // matrices
   CsrDev A, AT, P, PT;
   // CG operator split (api.hip: build_op_split): rows of A with exactly one nonzero contribute a DIAGONAL to A' rho A;

@@ -384,7 +384,7 @@ int32_t psd_plan_create(cosmo_hip_handle* h) {
   // (profiles/r02_cfg5_polar_batch_min_and_fold.json); and the sign path is the more accurate one (5e-15 vs 1e-11 ||X||_F).
   // COSMO_HIP_POLAR_BATCH_MIN=256 sends every workgroup-class cone back to the Jacobi kernels (kept under test that way).
   {
-    int polar_min = 16;
+    int polar_min = (h->psd_mode == 1) ? 256 : 16;        // cosmo_hip_set_psd_projection(EIGEN): every workgroup-class cone on the Jacobi kernels
     if (const char* e = getenv("COSMO_HIP_POLAR_BATCH_MIN")) polar_min = atoi(e);
     p->polar_batch.clear();
     for (int idx : p->wg) if (p->cones[idx].d > polar_min) p->polar_batch.push_back(idx);

@@ -1472,8 +1472,8 @@ int32_t polar_plan_create(cosmo_hip_handle* h) {
   PsdPlan* p = h->psd;
   if (!p) return COSMO_HIP_OK;
   std::vector<int> large_list, batch_list = p->polar_batch;
-  bool jac = false;
-  if (const char* e = getenv("COSMO_HIP_PSD_LARGE")) if (e[0] == 'j') jac = true;   // "jacobi": keep the host-paced Jacobi path for real cones
+  bool jac = h->psd_mode == 1;                                                        // cosmo_hip_set_psd_projection(EIGEN)
+  if (const char* e = getenv("COSMO_HIP_PSD_LARGE")) jac = (e[0] == 'j');            // "jacobi": keep the host-paced Jacobi path for real cones
   if (!jac) large_list = p->large;
   p->large_by_polar = !jac;
   for (int idx : p->cplx) { if (p->cones[idx].d > 256) large_list.push_back(idx); else batch_list.push_back(idx); }

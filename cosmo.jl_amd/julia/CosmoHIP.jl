@@ -331,7 +331,9 @@ end
 # 3. the coarse path: COSMO.optimize! with the while-loop on the MI355X.  Everything outside src/solver.jl:128-176 is the
 #    reference's own code, called unchanged.
 # ---------------------------------------------------------------------------------------------------------------------
-function optimize_hip!(ws::COSMO.Workspace{T}; device::Integer = 0, kkt_kind::Int32 = KKT_CG, tol_constant = 1.0, tol_exponent = 1.5) where {T <: HipFloat}
+# psd_projection = :sign (default: verified matrix-sign iteration above side 16) or :eigen (the eigendecomposition-based projection of
+# src/convexset.jl:163-189, 243-263 by Jacobi eigensolvers at every side: exact nnz_lambda, several times slower) -- cosmo_hip_set_psd_projection
+function optimize_hip!(ws::COSMO.Workspace{T}; device::Integer = 0, kkt_kind::Int32 = KKT_CG, tol_constant = 1.0, tol_exponent = 1.5, psd_projection::Symbol = :sign) where {T <: HipFloat}
     !ws.states.IS_ASSEMBLED && throw(ErrorException("The model has to be assembled! / set! before optimize!() can be called."))
     solver_time_start = time()
     settings = ws.settings
@@ -363,6 +365,8 @@ function optimize_hip!(ws::COSMO.Workspace{T}; device::Integer = 0, kkt_kind::In
     set_problem!(h, SparseMatrixCSC(ws.p.P), SparseMatrixCSC(ws.p.A), ws.p.q, Vector(ws.p.b))
     set_cones!(h, ws.p.C)
     custom_refs = set_custom_cones!(h, ws.p.C)                                 # user cones: callbacks into their project! methods
+    psd_projection in (:sign, :eigen) || error("psd_projection: :sign or :eigen")
+    psd_projection == :eigen && check(h, ccall((:cosmo_hip_set_psd_projection, lib(h)), Int32, (Ptr{Cvoid}, Int32), h.ptr, Int32(1)))
     set_params!(h, params_from(settings, kkt_kind; tol_constant = tol_constant, tol_exponent = tol_exponent), ws.ρvec)
     sc = settings.scaling != 0
     D = sc ? ws.sm.D.diag : ones(T, n); Dinv = sc ? ws.sm.Dinv.diag : ones(T, n); E = sc ? ws.sm.E.diag : ones(T, m); Einv = sc ? ws.sm.Einv.diag : ones(T, m)

@@ -110,6 +110,10 @@ class Settings:
     accelerator_activation: object = 2  # 2 = ImmediateActivation; int k = IterActivation(k); AccuracyActivation(eps)
     safeguard: bool = True
     safeguard_tol: float = 2.0
+    # how PsdCone / PsdConeTriangle are projected on the device (not a field of COSMO.Settings): "sign" = the verified matrix-sign iteration above side 16
+    # (default), "eigen" = the eigendecomposition-based projection of the reference (syevr! + rank-k update, src/convexset.jl:163-189, 243-263) at every
+    # side by Jacobi eigensolvers -- exact nnz_lambda, several times slower (cosmo_hip_set_psd_projection)
+    psd_projection: str = "sign"
     # accepted for drop-in compatibility with COSMO.Settings (src/settings.jl:101-139); they do not touch the hot path:
     nearly_ratio: float = 100.0            # only read by the MOI wrapper (is_primal_nearly_feasible, src/MOI_wrapper.jl:558,587)
     adaptive_rho_fraction: float = 0.4     # only with adaptive_rho_interval = 0 (the automatic interval, solver.jl:244-256)
@@ -705,6 +709,10 @@ def setup(model: Model):
             if K.kind == _ffi.CUSTOM:
                 h.set_custom_cone(k, K.project, K.in_dual if callable(K.in_dual) else None,
                                   K.in_pol_recc if callable(K.in_pol_recc) else None)
+        if st.psd_projection not in ("sign", "eigen"):
+            raise ValueError("Settings.psd_projection: 'sign' or 'eigen'")
+        if st.psd_projection == "eigen":
+            h.set_psd_projection(_ffi.PSD_PROJECTION_EIGEN)
         return h
 
     on_device = (st.scaling != 0 and not model.is_scaled and model.handle is None and st.device_scaling
@@ -876,6 +884,18 @@ def _structure_key(md: Model):
     return (md.n, md.m, tuple(K.kind for K in md.sets), tuple(K.dim for K in md.sets), tuple(getattr(K, "alpha", 0.0) for K in md.sets))
 
 
+def _check_batch_psd_projection(models) -> None:
+    """psd_projection = "eigen" in batch mode: the persistent kernels project cones of side <= 64 by Jacobi eigensolvers anyway; a member with a larger
+    cone would run on a group-internal handle, which has no such switch."""
+    for md in models:
+        if md.settings.psd_projection == "eigen":
+            for K in md.sets:
+                if K.kind in (_ffi.PSD_SQUARE, _ffi.PSD_TRIANGLE):
+                    d = int(round(np.sqrt(K.dim))) if K.kind == _ffi.PSD_SQUARE else int((np.sqrt(1 + 8 * K.dim) - 1) // 2)
+                    if d > 64:
+                        raise NotImplementedError("optimize_batch with psd_projection='eigen' and a PSD cone of side %d > 64: solve such models with optimize()" % d)
+
+
 def _batch_kernels_take(md: Model) -> bool:
     """What cosmo_hip_batch_* accepts (csrc/batch.hip): CG solver kinds, the cone types of batch mode with PSD cones of side <= 64, a fixed rho interval."""
     st = md.settings
@@ -938,6 +958,7 @@ def _solve_shard_on_device(models: Sequence[Model], device: int) -> List[Result]
     import time
     if not models:
         return []
+    _check_batch_psd_projection(models)
     t0 = time.perf_counter()
     # one structure the persistent kernels take -> the batch directly; anything else (several structures, a PSD cone of side > 64, a MINRES solver kind,
     # the automatic rho interval) -> the group, which gives every structure class its batch or, where the batch kernels refuse, one handle per problem

@@ -352,6 +352,13 @@ COSMO_HIP_API const char* cosmo_hip_kernel_class_name(int32_t k);
 /* Jacobi eigensolver diagnostics of the PSD projections: out = {max sweeps used by a single-workgroup solve, sweeps of
  * the last multi-workgroup solve, non-convergence flag, number of PSD cones}. */
 COSMO_HIP_API int32_t cosmo_hip_psd_stats(cosmo_hip_handle* h, int64_t out[4]);
+/* How PsdCone / PsdConeTriangle are projected (call after set_cones; rebuilds the cone plans; before optimize).  SIGN (default): side <= 16 by a
+ * wave-level Jacobi eigensolver, above it the verified matrix-sign iteration on the fp64 matrix cores.  EIGEN: the eigendecomposition-based projection
+ * of the reference (src/convexset.jl:163-189, 243-263: syevr! + rank_k_update!) at every side -- Jacobi eigensolvers, X+ = sum_{lambda > 0} lambda v v',
+ * nnz_lambda (cosmo_hip_project's psd_rank_out) counted from the eigenvalues themselves.  Complex Hermitian cones keep the sign path. */
+enum { COSMO_HIP_PSD_PROJECTION_SIGN = 0, COSMO_HIP_PSD_PROJECTION_EIGEN = 1 };
+COSMO_HIP_API int32_t cosmo_hip_set_psd_projection(cosmo_hip_handle* h, int32_t mode);
+
 /* Matrix-sign (polar) PSD path diagnostics: out = {large cones (d > 256), batched cones (64 < d <= 256), tile side of the first
  * large cone, its k-split (1 | 2 | 3 = stream-K), product launches <64,1>, <96,1>, <96,2> or stream-K, batched product launches, matrix products of the main
  * schedule of the last large-cone projection, fallback rounds executed so far, verified projections, products of the last batched

