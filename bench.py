@@ -510,7 +510,7 @@ def bench_cfg3(ctx, args, steps, warmup):
             from oracle import cosmo_oracle as O
             from tests import util
             OC = _native_oracle()
-            nsamp, its, secs = (8 if args.small else 128), 0, 0.0
+            nsamp, its, secs = (8 if args.small else 512), 0, 0.0
             for p in probs[:nsamp]:
                 ws = O.Workspace(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), oracle_settings(O, warmup + steps))
                 c = OC.run(ws, native=True)
@@ -745,7 +745,7 @@ def bench_cfg4(ctx, args, steps, warmup):
                      "parallelism": "replicas x%d (a single cone does not shard; SURVEY 8e)" % ctx.world,
                      "mean_cg_iters_per_admm_iter": round(kbar, 3), "polar": dict({k: ps[k] for k in ("schedule_steps", "fallback_rounds", "verified", "unverified", "err_max_e18")}, lifting_depth=h.polar_depth_stats())}
     if not args.no_cpu_baseline and ctx.world == 1:
-        args.deferred.append(lambda out=out, prob=prob: out.__setitem__("cpu_baseline", compiled_cpu_baseline(prob, 8 if not args.small else 20, "cfg4", "cfg4", args,
+        args.deferred.append(lambda out=out, prob=prob: out.__setitem__("cpu_baseline", compiled_cpu_baseline(prob, 16 if not args.small else 20, "cfg4", "cfg4", args,
                                                                                                                 iters_all=2 if not args.small else 20)))
     h.close()
     if ctx.world == 1 and not args.no_float32:
@@ -933,7 +933,7 @@ def bench_cfg5(ctx, args, steps, warmup):
         out["roofline"] = products
     if not args.no_cpu_baseline and ctx.world == 1:
         def cpu_leg(out=out, prob=prob, value=value):
-            cb = compiled_cpu_baseline(prob, 2 if not args.small else 10, "cfg5", "cfg5", args, iters_all=1 if not args.small else 10)
+            cb = compiled_cpu_baseline(prob, 3 if not args.small else 10, "cfg5", "cfg5", args, iters_all=1 if not args.small else 10)
             cb["kkt"] = "CGIndirectKKTSolver (the solver of the GPU path; kktsolver_indirect.jl:36-88)"
             try:
                 cb["direct_kkt"] = direct_kkt_cpu_baseline(prob, 10 if not args.small else 20, "cfg5")
