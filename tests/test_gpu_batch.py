@@ -815,10 +815,10 @@ def test_lds_image_register_cg_all_slots_and_a_long_column():
     0 .. 3, the odd ones assigned backwards), one DENSE column of A (2 049 > COSMO_NNZ_PER_BLOCK combined entries with its P row would take the long-row
     branch of the tile loops; here 1 628 + 1: a single thread walks it in the Krylov passes) and a small PSD cone, so that the extended-cone instantiation
     is the natural choice once the register kernel is switched off.  Sorted + stored-sorted (default), sorted on the index-order image, index order,
-    generic loops: tight-CG trajectories against the streaming kernel at 1e-8; default settings against the oracle (status, objective)."""
+    generic loops: tight-CG trajectories against the streaming kernel at 1e-8 and against the compiled oracle at 1e-6."""
     rng = np.random.default_rng(99)
     probs = []
-    for _ in range(3):
+    for _ in range(2):
         p = util.random_qp(rng, 700, 20, 900, 400, soc_dims=(12, 9), psd_tri_dims=(7, 10), p_shift=1.0, density=0.003)
         A = p["A"].tolil()
         col = rng.integers(0, 700)
@@ -854,10 +854,16 @@ def test_lds_image_register_cg_all_slots_and_a_long_column():
             for u, v in ((a.x, other.x), (a.s, other.s), (a.y, other.y)):
                 assert np.max(np.abs(u - v)) <= 1e-8 * max(1.0, float(np.max(np.abs(u)))), k
             assert abs(a.kkt_iters_total - other.kkt_iters_total) <= 0.02 * a.kkt_iters_total + 2 and other.iter == 40
-    _, r_def = _with_env({"COSMO_HIP_BATCH_REG": "0"}, lambda: run(cj.Settings()))
-    for p, r in list(zip(probs, r_def))[:1]:                 # (one oracle solve of this size is ~20 s of Python)
-        ref = O.solve(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), O.Settings(kkt_solver="cg"))
-        assert r.status == ref.status and abs(r.obj_val - ref.obj_val) <= 1e-4 * (1 + abs(ref.obj_val)), (r.status, ref.status, r.obj_val, ref.obj_val)
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "oracle")], check=True, capture_output=True)
+    from oracle import cosmo_oracle_c as OC
+    st_o = O.Settings(kkt_solver="cg", tol_constant=1e-10, tol_exponent=0.0, max_iter=40, eps_abs=0.0, eps_rel=0.0, check_infeasibility=10 ** 9)
+    for p, r in zip(probs, r_d):                                    # the same 40 iterations in the compiled restatement of the loop
+        c = OC.run(O.Workspace(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), st_o))
+        for key, v in (("x", r.x), ("s", r.s), ("y", r.y)):
+            assert float(np.max(np.abs(v - c[key])) / max(np.max(np.abs(c[key])), 1.0)) <= 1e-6, key
 
 
 def test_batch_of_sdps_with_cones_of_side_17_to_64():
