@@ -674,7 +674,7 @@ class Batch:
         out = np.zeros(8, dtype=np.int64)
         self._chk(self.lib.cosmo_hip_batch_kernel_info(self._b, out.ctypes.data_as(_PI64)))
         return dict(form=("streaming", "lds_image", "register_1_2", "register_2_4")[int(out[0])], sliced=bool(out[1]), lds_bytes=int(out[2]), p_in_registers=bool(out[3]),
-                    registers=int(out[4]), scratch_bytes=int(out[5]), static_lds_bytes=int(out[6]), sorted_assignment=bool(out[7]))
+                    registers=int(out[4]), scratch_bytes=int(out[5]), static_lds_bytes=int(out[6]), sorted_assignment=bool(out[7] & 1), long_rows=bool(out[7] & 2))
 
     def counters(self):
         """Per problem: ADMM iterations, KKT solves, Krylov iterations in total (three int64 arrays)."""

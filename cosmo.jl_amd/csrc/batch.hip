@@ -300,6 +300,44 @@ __device__ __forceinline__ real row_pipe3(uint32_t idx, uint32_t val, const uint
   return s;
 }
 
+// ---- rows of many entries (round 6; the LONG instantiations of the register kernel) ---------------------------------------------------------------
+// Every sparse pass gives a row to ONE thread, so a dense row of A -- the budget constraint sum(x) = 1 of a portfolio problem -- is walked serially in
+// every Krylov iteration while 511 threads wait (profiles/r06_batch_dense_row_probe.txt: 3.9 -> 20 us per Krylov iteration at n = 300).  Here the lanes
+// of the wave that holds such a row (>= LONG_ROW entries; the sorted assignment puts them in the first wave) walk it TOGETHER: lane l takes entries
+// l, l + 64, ..., the partial sums are added by the wave butterfly, the owner keeps the result; the other rows of the wave then run on row_pipe3 as
+// usual.  Called by all lanes of a wave at the same point (no per-lane condition around the call: a lane without a row passes len = 0).  The sum of a
+// long row is added in lane-strided instead of left-to-right order: a batch with such rows agrees with the other kernel forms to rounding, not bit for bit.
+#define LONG_ROW 64
+template <bool PAIR>
+__device__ __forceinline__ real row_long_or_pipe3(uint32_t idx, uint32_t val, const uint32_t gat, const int len) {
+  constexpr uint32_t ISZ = PAIR ? 4u : 2u;
+  const bool is_long = len >= LONG_ROW;
+  unsigned long long todo = __ballot(is_long);
+  const int lane = threadIdx.x & 63;
+  real mine = 0.0;
+  while (todo) {                                                      // wave-uniform
+    const int src = __ffsll((long long)todo) - 1;
+    todo &= todo - 1ull;
+    const uint32_t idx_s = (uint32_t)__shfl((int)idx, src, 64), val_s = (uint32_t)__shfl((int)val, src, 64);
+    const int len_s = __shfl(len, src, 64);
+    real part = 0.0;
+    for (int t = lane; t < len_s; t += 64) {
+      uint32_t e = 0; real a = 0.0, g = 0.0;
+      lds_drain();
+      if (PAIR) lds_read_u32(e, idx_s + ISZ * (uint32_t)t); else lds_read_u16(e, idx_s + ISZ * (uint32_t)t);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e));
+      if (PAIR) { lds_read64(a, val_s + ((e & 0xffffu) << RSH)); lds_read64(g, gat + ((e >> 16) << RSH)); }
+      else { lds_read64(a, val_s + ((uint32_t)t << RSH)); lds_read64(g, gat + (e << RSH)); }
+      lds_wait0(a, g);
+      part += a * g;
+    }
+    part = wave_sum(part);
+    if (lane == src) mine = part;
+  }
+  const real s = row_pipe3<PAIR>(idx, val, gat, is_long ? 0 : len);
+  return is_long ? mine : s;
+}
+
 // ---- sliced image of the register kernel (round 5, bench/lds_rowpipe_lab.hip) ------------------------------------------------------------------
 // Rows sorted by length make the row-major stride of a wave EQUAL to the row length: with lengths 8, 12, 16 four to sixteen lanes of a half-wave read
 // one bank pair, and the three address computations per nonzero were most of the instructions of a trip.  In the sliced image the 32 rows a half-wave
@@ -1151,11 +1189,14 @@ extern "C" void cosmo_dbg_batch_timing(long long* out) { (void)hipMemcpyFromSymb
 
 // SLICED: the image is the sliced one (row_sliced above; build_lds_images decides per batch) -- the gathered vectors and the reduction slots sit IN FRONT of
 // the image at fixed LDS addresses (xv at 0, tv at 8 JN BS, the block-sum slots behind it), the image follows
-template <int BS, int JN, int JM, bool PSD, bool AA, bool SLICED = false>
+// LONG (round 6): the batch has rows / columns of A with >= LONG_ROW entries; the Krylov passes of the row-major sorted form hand them to the whole wave
+// (row_long_or_pipe3).  A separate instantiation: the kernels of the batches without such rows are the same code as before.
+template <int BS, int JN, int JM, bool PSD, bool AA, bool SLICED = false, bool LONG = false>
 __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, long long iter_target, int do_init,
                                                        const unsigned char* __restrict__ img, long long img_stride) {
   extern __shared__ real dyn_lds[];
   static_assert(!SLICED || (JN == 1 && BS == 512 && !REAL_IS_FLOAT), "the sliced image exists for the <512, 1, 2> double-precision instantiations");
+  static_assert(!LONG || (JN == 1 && !SLICED), "the cooperative long-row passes exist for the sorted row-major form <512, 1, 2>");
   constexpr int WS0 = SLICED ? (int)sizeof(real) * (JN * BS + JM * BS + 2 * (BS / 64)) : 0;     // bytes in front of the image
   constexpr int TVOFF = (int)sizeof(real) * JN * BS;                                              // LDS address of tv (sliced form)
   (void)TVOFF;
@@ -1544,6 +1585,8 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       { BT_BEGIN();
 #pragma unroll
       for (int j = 0; j < JM; ++j)
+        if constexpr (LONG) tmpv[j] = (row_long_or_pipe3<false>(lA_col + 2u * (uint32_t)ka0[j], lA_val + ((uint32_t)ka0[j] << RSH), l_xv, ka1[j] - ka0[j]) + R(0.0)) * rhoc[j];   // (no row: ka0 = ka1 = 0, rhoc = 1)
+        else
         tmpv[j] = (ra[j] >= 0) ? (HANDPIPE ? (row_pipe3<false>(lA_col + 2u * (uint32_t)ka0[j], lA_val + ((uint32_t)ka0[j] << RSH), l_xv, ka1[j] - ka0[j]) + R(0.0))
                                            : rowA_b(ka0[j], ka1[j])) * rhoc[j] : 0.0;
 #pragma unroll
@@ -1559,6 +1602,12 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       }
       acc = 0.0;
       { BT_BEGIN();
+      real tlong[JN];
+      (void)tlong;
+      if constexpr (LONG) {                                                // (all lanes: a lane without a column has kt0 = kt1 = 0)
+#pragma unroll
+        for (int j = 0; j < JN; ++j) tlong[j] = row_long_or_pipe3<true>(lT_pr + 4u * (uint32_t)kt0[j], lA_val, l_tv, kt1[j] - kt0[j]);
+      }
 #pragma unroll
       for (int j = 0; j < JN; ++j) {                                       // the column this thread owns AND computes
         const int c = OWN(j);
@@ -1566,6 +1615,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
           const real vj = uv[j];
           real cj;
           if constexpr (SLICED) cj = colP(j, vj) + (P.sigma * vj + colT(j));
+          else if constexpr (LONG) cj = rowP_b(kp0[j], kp1[j]) + (P.sigma * vj + tlong[j]);
           else if constexpr (SORTED) cj = rowP_b(kp0[j], kp1[j]) + (P.sigma * vj + (HANDPIPE ? row_pipe3<true>(lT_pr + 4u * (uint32_t)kt0[j], lA_val, l_tv, kt1[j] - kt0[j])
                                                                                                    : rowAT_b(kt0[j], kt1[j])));
           else cj = rowP(c) + (P.sigma * vj + rowAT(c));
@@ -2051,6 +2101,7 @@ struct cosmo_hip_batch {
   ConeTable cones; std::vector<real> hbox_l, hbox_u; int nbox = 0;
   cosmo_hip_params prm;
   bool finalized = false, have_cones = false, have_iterates = false;
+  bool long_rows = false;                     // a row or a column of A with >= LONG_ROW entries in some problem: the LONG instantiations of the register kernel (build_lds_images)
   bool ext_cones = false;                     // the batch has cones beyond Zero / Nonnegatives / Box / SecondOrderCone (set_params): PSD of side >= 2, exponential, power
   BatchDev D;
   std::vector<void*> allocs;
@@ -2278,6 +2329,10 @@ static BKernel batch_kernel_of(const cosmo_hip_batch* b) {
     return {psd ? (const void*)k_batch_admm_reg<512, 1, 2, true, false, true> : (const void*)k_batch_admm_reg<512, 1, 2, false, false, true>, 512, true};
   }
 #endif
+  if (img && b->reg_mode == 1 && b->long_rows) {          // rows / columns of >= LONG_ROW entries: the cooperative passes (never with the sliced image)
+    if (b->aa_on) return {(const void*)k_batch_admm_reg<512, 1, 2, false, true, false, true>, 512, true};
+    return {psd ? (const void*)k_batch_admm_reg<512, 1, 2, true, false, false, true> : (const void*)k_batch_admm_reg<512, 1, 2, false, false, false, true>, 512, true};
+  }
   if (b->aa_on) {                    // accelerated loop: register kernel (batches without PSD cones), else the LDS-image kernel (512 threads) or the streaming kernel with the PSD code (a run-time no-op without such cones)
     if (img && b->reg_mode == 1) return {(const void*)k_batch_admm_reg<512, 1, 2, false, true>, 512, true};
     if (img && b->reg_mode == 2) return {(const void*)k_batch_admm_reg<512, 2, 4, false, true>, 512, true};
@@ -2339,6 +2394,17 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
   for (int k = 0; k < b->nprob && p_all_diag; ++k) {
     const HostCsr& PT = b->hPT[k];
     for (long long j = 0; j < n && p_all_diag; ++j) { const int len = PT.split[j] - PT.rowptr[j]; if (len > 1 || (len == 1 && PT.col[PT.rowptr[j]] != (int)j)) p_all_diag = false; }
+  }
+  // rows / columns of A with >= LONG_ROW entries (a dense budget row, an epigraph variable): the register kernel <512, 1, 2> hands them to a whole wave in
+  // its Krylov passes (LONG instantiations, row_long_or_pipe3); the sliced image would pad the 32 rows of such a row's slice to its length: not built then
+  b->long_rows = false;
+  if (b->reg_mode == 1 && !(getenv("COSMO_HIP_BATCH_LONG") && atoi(getenv("COSMO_HIP_BATCH_LONG")) == 0)) {
+    for (int k = 0; k < b->nprob && !b->long_rows; ++k) {
+      const HostCsr &A = b->hA[k], &AT = b->hAT[k];
+      for (long long i = 0; i < m && !b->long_rows; ++i) if (A.rowptr[i + 1] - A.rowptr[i] >= LONG_ROW) b->long_rows = true;
+      for (long long j = 0; j < n && !b->long_rows; ++j) if (AT.rowptr[j + 1] - AT.rowptr[j] >= LONG_ROW) b->long_rows = true;
+    }
+    if (b->long_rows) want_sliced = false;
   }
   b->h_slA.clear(); b->h_slT.clear(); b->h_pdiag.clear(); b->h_pdiag_has.clear();
   // LDS-image kernel, register-CG form of its reduced solve (batch_admm_body, RCG: the 512-thread instantiations with the extended cones): the compute
@@ -3139,7 +3205,7 @@ extern "C" int32_t cosmo_hip_batch_iterate(cosmo_hip_batch* b, int64_t n_iters, 
 // which kernel a batch runs (after set_params): out = {form: 0 streaming, 1 LDS image, 2 register kernel <512, 1, 2>, 3 register kernel <512, 2, 4>;
 // sliced image 0 / 1; dynamic LDS bytes per workgroup; P held in registers 0 / 1; registers per thread and scratch bytes per thread of that
 // instantiation as the loaded code object reports them (hipFuncGetAttributes: VGPRs + AGPRs of the unified file; scratch > 0 = it spills);
-// its static LDS bytes; length-sorted compute assignment in the Krylov loop 0 / 1}
+// its static LDS bytes; bit 0: length-sorted compute assignment in the Krylov loop, bit 1: cooperative long-row passes (the LONG instantiations)}
 extern "C" int32_t cosmo_hip_batch_kernel_info(cosmo_hip_batch* b, int64_t* out) {
   if (!b || !out) return COSMO_HIP_ERR_INVALID;
   if (!b->finalized) return bfail(b, COSMO_HIP_ERR_INVALID, "batch_kernel_info: set_params first");
@@ -3147,7 +3213,7 @@ extern "C" int32_t cosmo_hip_batch_kernel_info(cosmo_hip_batch* b, int64_t* out)
   { hipFuncAttributes fa;
     BHIP(b, hipFuncGetAttributes(&fa, batch_kernel_of(b).fn));
     out[4] = fa.numRegs; out[5] = (int64_t)fa.localSizeBytes; out[6] = (int64_t)fa.sharedSizeBytes; }
-  out[7] = b->D.permA ? 1 : 0;
+  out[7] = (b->D.permA ? 1 : 0) | ((b->d_img && b->reg_mode == 1 && b->long_rows && !b->D.sliced) ? 2 : 0);
   out[0] = !b->d_img ? 0 : (b->reg_mode == 1 ? 2 : (b->reg_mode == 2 ? 3 : 1));
   out[1] = (b->d_img && b->reg_mode == 1 && b->D.sliced) ? 1 : 0;
   out[2] = b->d_img ? b->lds_bytes : 0;

@@ -490,7 +490,8 @@ COSMO_HIP_API int32_t cosmo_hip_batch_get_counters(cosmo_hip_batch* b, int64_t* 
 /* which kernel the batch runs (after set_params; measurement / tests): out = {form: 0 streaming, 1 LDS image, 2 register kernel <512, 1, 2>,
  * 3 register kernel <512, 2, 4>; sliced image 0 / 1; dynamic LDS bytes per workgroup; P held in registers 0 / 1; registers per thread and
  * scratch bytes per thread of that kernel instantiation as the loaded code object reports them (> 0 scratch: it spills); its static LDS bytes;
- * length-sorted compute assignment in the Krylov loop 0 / 1}  (ABI 1004: out grew from 4 to 8 entries) */
+ * bit 0: length-sorted compute assignment in the Krylov loop, bit 1: rows of >= 64 entries handed to a whole wave (cooperative long-row passes)}
+ * (ABI 1004: out grew from 4 to 8 entries) */
 COSMO_HIP_API int32_t cosmo_hip_batch_kernel_info(cosmo_hip_batch* b, int64_t out[8]);
 COSMO_HIP_API int32_t cosmo_hip_batch_get_iterates(cosmo_hip_batch* b, int64_t k, cosmo_hip_real* w, cosmo_hip_real* w_prev, cosmo_hip_real* s, cosmo_hip_real* mu);
 

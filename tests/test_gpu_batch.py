@@ -439,7 +439,7 @@ def test_cfg3_full_size_batch():
 def _with_env(env, fn):
     import os
     keys = ("COSMO_HIP_BATCH_LDS", "COSMO_HIP_BATCH_BS", "COSMO_HIP_BATCH_REG", "COSMO_HIP_BATCH_LDSCG", "COSMO_HIP_BATCH_EXT", "COSMO_HIP_BATCH_SORTED", "COSMO_HIP_BATCH_SLICED",
-            "COSMO_HIP_BATCH_LDSCG_SORTED", "COSMO_HIP_BATCH_STORE_SORTED")
+            "COSMO_HIP_BATCH_LDSCG_SORTED", "COSMO_HIP_BATCH_STORE_SORTED")          # (COSMO_HIP_BATCH_LONG is left to monkeypatch)
     saved = {k: os.environ.pop(k, None) for k in keys}
     os.environ.update(env)
     try:
@@ -864,6 +864,61 @@ def test_lds_image_register_cg_all_slots_and_a_long_column():
         c = OC.run(O.Workspace(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), st_o))
         for key, v in (("x", r.x), ("s", r.s), ("y", r.y)):
             assert float(np.max(np.abs(v - c[key])) / max(np.max(np.abs(c[key])), 1.0)) <= 1e-6, key
+
+
+def test_batches_with_a_dense_row_run_the_cooperative_long_row_passes(monkeypatch):
+    """A dense row of A (the budget constraint sum(x) = 1 of the reference's portfolio examples) and a dense column (an epigraph-like variable) in a batch
+    the register kernel takes: rows / columns of >= 64 entries are walked by a whole wave in the Krylov passes (LONG instantiations, row_long_or_pipe3)
+    instead of by one thread.  Kernel form reported; tight-CG trajectories against the streaming kernel (1e-8), against the compiled oracle (1e-6), and
+    against the same kernel family with the cooperative passes off (COSMO_HIP_BATCH_LONG=0: one thread per row, 1e-9); plain, accelerated and Float32."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "oracle")], check=True, capture_output=True)
+    from oracle import cosmo_oracle_c as OC
+    probs = []
+    for k in range(4):
+        p = cj.problems.socp(n=200, m=400, ncones=20, nnz=3000, seed=4000 + k)
+        n = p["A"].shape[1]
+        A = sp.vstack([p["A"], sp.csr_matrix(np.ones((1, n)))]).tolil()
+        A[:, 7] = np.random.default_rng(k).standard_normal((A.shape[0], 1)) * 0.05          # ... and a dense column
+        probs.append(dict(P=p["P"], q=p["q"], A=A.tocsc(), b=np.concatenate([p["b"], [1.0]]), sets=list(p["sets"]) + [cj.ZeroSet(1)]))
+    tight = cj.with_options(cj.CGIndirectKKTSolver, tol_constant=1e-10, tol_exponent=0.0)
+    st = cj.Settings(kkt_solver=tight, max_iter=50, eps_abs=0.0, eps_rel=0.0)
+
+    def run(stt=st, dtype=np.float64):
+        def models():
+            out = []
+            for p in probs:
+                md = cj.Model(dtype=dtype); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], stt); out.append(md)
+            return out
+        B, _ = cj.model.prepare_batch(models(), 0)
+        info = B.kernel_info()
+        B.close()
+        return info, cj.optimize_batch(models())
+    i_l, r_l = _with_env({}, run)
+    monkeypatch.setenv("COSMO_HIP_BATCH_LONG", "0")
+    i_n, r_n = _with_env({}, run)
+    monkeypatch.delenv("COSMO_HIP_BATCH_LONG")
+    i_s, r_s = _with_env({"COSMO_HIP_BATCH_LDS": "0"}, run)
+    assert i_l["form"] == "register_1_2" and i_l["long_rows"] and not i_l["sliced"], i_l
+    assert i_n["form"] == "register_1_2" and not i_n["long_rows"] and i_s["form"] == "streaming"
+    st_o = O.Settings(kkt_solver="cg", tol_constant=1e-10, tol_exponent=0.0, max_iter=50, eps_abs=0.0, eps_rel=0.0, check_infeasibility=10 ** 9)
+    for p, a, b, c in zip(probs, r_l, r_n, r_s):
+        ref = OC.run(O.Workspace(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), st_o))
+        for key, v, w, z in (("x", a.x, b.x, c.x), ("s", a.s, b.s, c.s), ("y", a.y, b.y, c.y)):
+            sc = max(1.0, float(np.max(np.abs(ref[key]))))
+            assert np.max(np.abs(v - w)) <= 1e-9 * sc and np.max(np.abs(v - z)) <= 1e-8 * sc and np.max(np.abs(v - ref[key])) <= 1e-6 * sc, key
+        assert a.iter == b.iter == c.iter == 50 and abs(a.kkt_iters_total - c.kkt_iters_total) <= 0.02 * c.kkt_iters_total + 2
+    # the accelerated and the Float32 instantiations: default settings against the oracle
+    i_a, r_a = _with_env({}, lambda: run(cj.Settings(accelerator=cj.AndersonAccelerator)))
+    assert i_a["long_rows"] and i_a["form"] == "register_1_2"
+    i_f, r_f = _with_env({}, lambda: run(cj.Settings(eps_abs=1e-4, eps_rel=1e-4), np.float32))
+    assert i_f["long_rows"]
+    for p, a, f in zip(probs, r_a, r_f):
+        ref = OC.run(O.Workspace(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), O.Settings(kkt_solver="cg")))
+        assert a.status == f.status == ref["status"] == "Solved"
+        assert abs(a.obj_val - ref["obj_val"]) <= 1e-4 * (1 + abs(ref["obj_val"])) and abs(f.obj_val - ref["obj_val"]) <= 1e-2 * (1 + abs(ref["obj_val"]))
 
 
 def test_batch_of_sdps_with_cones_of_side_17_to_64():
