@@ -1196,7 +1196,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
                                                        const unsigned char* __restrict__ img, long long img_stride) {
   extern __shared__ real dyn_lds[];
   static_assert(!SLICED || (JN == 1 && BS == 512 && !REAL_IS_FLOAT), "the sliced image exists for the <512, 1, 2> double-precision instantiations");
-  static_assert(!LONG || (JN == 1 && !SLICED), "the cooperative long-row passes exist for the sorted row-major form <512, 1, 2>");
+  static_assert(!LONG || !SLICED, "the cooperative long-row passes exist for the row-major forms (<512, 1, 2> sorted, <512, 2, 4> index order)");
   constexpr int WS0 = SLICED ? (int)sizeof(real) * (JN * BS + JM * BS + 2 * (BS / 64)) : 0;     // bytes in front of the image
   constexpr int TVOFF = (int)sizeof(real) * JN * BS;                                              // LDS address of tv (sliced form)
   (void)TVOFF;
@@ -1594,8 +1594,17 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       __syncthreads();
       BT_END(0); }
       } else {
+      if constexpr (LONG) {                                                // index-order form <512, 2, 4>: the bounds are read per iteration (no registers to hold them)
+#pragma unroll
+        for (int j = 0; j < JM; ++j) {
+          const int i = tid + BS * j;
+          const int a0 = (i < m) ? (int)Arp[i] : 0, a1 = (i < m) ? (int)Arp[i + 1] : 0;
+          tmpv[j] = row_long_or_pipe3<false>(lA_col + 2u * (uint32_t)a0, lA_val + ((uint32_t)a0 << RSH), l_xv, a1 - a0) * rhov[j];
+        }
+      } else {
 #pragma unroll
       for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; tmpv[j] = (i < m) ? rowA(i) * rhov[j] : 0.0; }
+      }
 #pragma unroll
       for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; if (i < m) tv[i] = tmpv[j]; }
       __syncthreads();
@@ -1604,9 +1613,14 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       { BT_BEGIN();
       real tlong[JN];
       (void)tlong;
-      if constexpr (LONG) {                                                // (all lanes: a lane without a column has kt0 = kt1 = 0)
+      if constexpr (LONG) {                                                // (all lanes: a lane without a column passes an empty range)
 #pragma unroll
-        for (int j = 0; j < JN; ++j) tlong[j] = row_long_or_pipe3<true>(lT_pr + 4u * (uint32_t)kt0[j], lA_val, l_tv, kt1[j] - kt0[j]);
+        for (int j = 0; j < JN; ++j) {
+          int t0, t1;
+          if constexpr (SORTED) { t0 = kt0[j]; t1 = kt1[j]; }
+          else { const int c = OWN(j); t0 = c >= 0 ? (int)Trp[c] : 0; t1 = c >= 0 ? (int)Trp[c + 1] : 0; }
+          tlong[j] = row_long_or_pipe3<true>(lT_pr + 4u * (uint32_t)t0, lA_val, l_tv, t1 - t0);
+        }
       }
 #pragma unroll
       for (int j = 0; j < JN; ++j) {                                       // the column this thread owns AND computes
@@ -1615,7 +1629,8 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
           const real vj = uv[j];
           real cj;
           if constexpr (SLICED) cj = colP(j, vj) + (P.sigma * vj + colT(j));
-          else if constexpr (LONG) cj = rowP_b(kp0[j], kp1[j]) + (P.sigma * vj + tlong[j]);
+          else if constexpr (LONG && SORTED) cj = rowP_b(kp0[j], kp1[j]) + (P.sigma * vj + tlong[j]);
+          else if constexpr (LONG) cj = rowP(c) + (P.sigma * vj + tlong[j]);
           else if constexpr (SORTED) cj = rowP_b(kp0[j], kp1[j]) + (P.sigma * vj + (HANDPIPE ? row_pipe3<true>(lT_pr + 4u * (uint32_t)kt0[j], lA_val, l_tv, kt1[j] - kt0[j])
                                                                                                    : rowAT_b(kt0[j], kt1[j])));
           else cj = rowP(c) + (P.sigma * vj + rowAT(c));
@@ -2333,6 +2348,10 @@ static BKernel batch_kernel_of(const cosmo_hip_batch* b) {
     if (b->aa_on) return {(const void*)k_batch_admm_reg<512, 1, 2, false, true, false, true>, 512, true};
     return {psd ? (const void*)k_batch_admm_reg<512, 1, 2, true, false, false, true> : (const void*)k_batch_admm_reg<512, 1, 2, false, false, false, true>, 512, true};
   }
+  if (img && b->reg_mode == 2 && b->long_rows) {
+    if (b->aa_on) return {(const void*)k_batch_admm_reg<512, 2, 4, false, true, false, true>, 512, true};
+    return {psd ? (const void*)k_batch_admm_reg<512, 2, 4, true, false, false, true> : (const void*)k_batch_admm_reg<512, 2, 4, false, false, false, true>, 512, true};
+  }
   if (b->aa_on) {                    // accelerated loop: register kernel (batches without PSD cones), else the LDS-image kernel (512 threads) or the streaming kernel with the PSD code (a run-time no-op without such cones)
     if (img && b->reg_mode == 1) return {(const void*)k_batch_admm_reg<512, 1, 2, false, true>, 512, true};
     if (img && b->reg_mode == 2) return {(const void*)k_batch_admm_reg<512, 2, 4, false, true>, 512, true};
@@ -2398,7 +2417,7 @@ static int32_t build_lds_images(cosmo_hip_batch* b) {
   // rows / columns of A with >= LONG_ROW entries (a dense budget row, an epigraph variable): the register kernel <512, 1, 2> hands them to a whole wave in
   // its Krylov passes (LONG instantiations, row_long_or_pipe3); the sliced image would pad the 32 rows of such a row's slice to its length: not built then
   b->long_rows = false;
-  if (b->reg_mode == 1 && !(getenv("COSMO_HIP_BATCH_LONG") && atoi(getenv("COSMO_HIP_BATCH_LONG")) == 0)) {
+  if (b->reg_mode != 0 && !(getenv("COSMO_HIP_BATCH_LONG") && atoi(getenv("COSMO_HIP_BATCH_LONG")) == 0)) {
     for (int k = 0; k < b->nprob && !b->long_rows; ++k) {
       const HostCsr &A = b->hA[k], &AT = b->hAT[k];
       for (long long i = 0; i < m && !b->long_rows; ++i) if (A.rowptr[i + 1] - A.rowptr[i] >= LONG_ROW) b->long_rows = true;
@@ -3213,7 +3232,7 @@ extern "C" int32_t cosmo_hip_batch_kernel_info(cosmo_hip_batch* b, int64_t* out)
   { hipFuncAttributes fa;
     BHIP(b, hipFuncGetAttributes(&fa, batch_kernel_of(b).fn));
     out[4] = fa.numRegs; out[5] = (int64_t)fa.localSizeBytes; out[6] = (int64_t)fa.sharedSizeBytes; }
-  out[7] = (b->D.permA ? 1 : 0) | ((b->d_img && b->reg_mode == 1 && b->long_rows && !b->D.sliced) ? 2 : 0);
+  out[7] = (b->D.permA ? 1 : 0) | ((b->d_img && b->reg_mode != 0 && b->long_rows && !b->D.sliced) ? 2 : 0);
   out[0] = !b->d_img ? 0 : (b->reg_mode == 1 ? 2 : (b->reg_mode == 2 ? 3 : 1));
   out[1] = (b->d_img && b->reg_mode == 1 && b->D.sliced) ? 1 : 0;
   out[2] = b->d_img ? b->lds_bytes : 0;

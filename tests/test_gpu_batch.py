@@ -913,6 +913,22 @@ def test_batches_with_a_dense_row_run_the_cooperative_long_row_passes(monkeypatc
             sc = max(1.0, float(np.max(np.abs(ref[key]))))
             assert np.max(np.abs(v - w)) <= 1e-9 * sc and np.max(np.abs(v - z)) <= 1e-8 * sc and np.max(np.abs(v - ref[key])) <= 1e-6 * sc, key
         assert a.iter == b.iter == c.iter == 50 and abs(a.kkt_iters_total - c.kkt_iters_total) <= 0.02 * c.kkt_iters_total + 2
+    # the index-order register kernel <512, 2, 4> (n > 512): the same passes, bounds read per iteration
+    keep = probs
+    probs = []
+    for k in range(2):
+        p = cj.problems.socp(n=600, m=1200, ncones=30, nnz=7000, seed=4100 + k)
+        A = sp.vstack([p["A"], sp.csr_matrix(np.ones((1, 600)))]).tocsc()
+        probs.append(dict(P=p["P"], q=p["q"], A=A, b=np.concatenate([p["b"], [1.0]]), sets=list(p["sets"]) + [cj.ZeroSet(1)]))
+    st2 = cj.Settings(kkt_solver=tight, max_iter=15, eps_abs=0.0, eps_rel=0.0)
+    i_b, r_b = _with_env({}, lambda: run(st2))
+    i_c, r_c = _with_env({"COSMO_HIP_BATCH_LDS": "0"}, lambda: run(st2))
+    assert i_b["form"] == "register_2_4" and i_b["long_rows"] and i_c["form"] == "streaming", (i_b, i_c)
+    for a, c in zip(r_b, r_c):
+        for v, z in ((a.x, c.x), (a.s, c.s), (a.y, c.y)):
+            assert np.max(np.abs(v - z)) <= 1e-8 * max(1.0, float(np.max(np.abs(z))))
+        assert a.iter == c.iter == 15
+    probs = keep
     # the accelerated and the Float32 instantiations: default settings against the oracle
     i_a, r_a = _with_env({}, lambda: run(cj.Settings(accelerator=cj.AndersonAccelerator)))
     assert i_a["long_rows"] and i_a["form"] == "register_1_2"

@@ -8,7 +8,11 @@ import scipy.sparse as sp
 import cosmo_jl_amd as cj
 
 nprob = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-base = [cj.problems.socp(n=300, m=600, ncones=30, nnz=6000, seed=1000 + k) for k in range(nprob)]      # config-3 structure at 60 % size: the image has room for the extra row
+large = len(sys.argv) > 2 and sys.argv[2] == "large"        # n = 800, m = 1600: the <512, 2, 4> register kernel (index-order assignment)
+if large:
+    base = [cj.problems.socp(n=800, m=1600, ncones=40, nnz=8000, seed=1000 + k) for k in range(nprob)]
+else:
+    base = [cj.problems.socp(n=300, m=600, ncones=30, nnz=6000, seed=1000 + k) for k in range(nprob)]      # config-3 structure at 60 % size: the image has room for the extra row
 
 
 def with_dense_row(p):
@@ -38,7 +42,10 @@ def run(probs, label, env):
 
 
 dense = [with_dense_row(p) for p in base]
-for probs, tag in ((base, "socp 300 x 600"), (dense, "socp 300 x 600 + one dense row")):
+name = "socp 800 x 1600" if large else "socp 300 x 600"
+for probs, tag in ((base, name), (dense, name + " + one dense row")):
     run(probs, tag + ", default kernel", {})
+    if probs is dense:
+        run(probs, tag + ", one thread per row (COSMO_HIP_BATCH_LONG=0)", {"COSMO_HIP_BATCH_LONG": "0"})
     run(probs, tag + ", LDS-image (generic loops)", {"COSMO_HIP_BATCH_REG": "0"})
     run(probs, tag + ", streaming", {"COSMO_HIP_BATCH_LDS": "0"})
