@@ -940,6 +940,43 @@ def test_batches_with_a_dense_row_run_the_cooperative_long_row_passes(monkeypatc
         assert abs(a.obj_val - ref["obj_val"]) <= 1e-4 * (1 + abs(ref["obj_val"])) and abs(f.obj_val - ref["obj_val"]) <= 1e-2 * (1 + abs(ref["obj_val"]))
 
 
+def test_batch_of_factor_model_portfolios_like_the_reference_example():
+    """examples/portfolio_optimisation.jl of the reference as a BATCH: the factor-model QP  min x'Dx + y'y - mu'x / gamma  s.t.  y = F'x, 1'x = 1, x >= 0
+    (:25-46), n = 200 assets, k = 10 factors, solved for 24 values of the risk-aversion parameter gamma -- the Pareto front of the example (:85-110) -- in
+    one optimize_batch call.  The k + 1 equality rows are DENSE (up to 200 entries): the register kernel runs its cooperative long-row passes.  Every
+    problem against the oracle (status, objective 1e-4, x 1e-3) and the properties the example asserts: the budget holds, no short selling, the risk
+    falls as gamma grows."""
+    n_assets, k = 200, 10
+    rng = np.random.default_rng(1)
+    Dd = rng.uniform(size=n_assets) * np.sqrt(k)
+    F = sp.random(n_assets, k, density=0.5, random_state=rng, data_rvs=rng.standard_normal).tocsc()
+    mu = (3.0 + 9.0 * rng.uniform(size=n_assets)) / 100.0
+    gammas = np.logspace(-2, 1, 24)
+    nvar = n_assets + k
+    P = sp.block_diag([2.0 * sp.diags(Dd), 2.0 * sp.identity(k)]).tocsc()                  # x'Dx + y'y = 1/2 z' P z
+    # internal form A z + s = b, s in K: rows 0..k: (F'x - y) + s = 0; 1'x + s = 1; -x + s = 0 with s >= 0  <=>  x = s >= 0
+    A = sp.vstack([sp.hstack([F.T, -sp.identity(k)]), sp.hstack([sp.csr_matrix(np.ones((1, n_assets))), sp.csr_matrix((1, k))]),
+                   sp.hstack([-sp.identity(n_assets), sp.csr_matrix((n_assets, k))])]).tocsc()
+    b = np.concatenate([np.zeros(k), [1.0], np.zeros(n_assets)])
+    sets = [cj.ZeroSet(k + 1), cj.Nonnegatives(n_assets)]
+    probs = [dict(P=P, q=np.concatenate([-mu / g, np.zeros(k)]), A=A, b=b, sets=sets) for g in gammas]
+    st = cj.Settings(eps_abs=1e-6, eps_rel=1e-6)
+    B, _ = cj.model.prepare_batch(_models(probs, st), 0)
+    info = B.kernel_info()
+    B.close()
+    assert info["form"] == "register_1_2" and info["long_rows"], info
+    res = cj.optimize_batch(_models(probs, st))
+    risks = []
+    for p, r in zip(probs, res):
+        ref = O.solve(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), O.Settings(kkt_solver="cg", eps_abs=1e-6, eps_rel=1e-6))
+        assert r.status == ref.status == "Solved", (r.status, ref.status)
+        assert abs(r.obj_val - ref.obj_val) <= 1e-4 * (1 + abs(ref.obj_val)) and np.max(np.abs(r.x - ref.x)) <= 1e-3
+        x, y = r.x[:n_assets], r.x[n_assets:]
+        assert abs(np.sum(x) - 1.0) <= 1e-4 and np.min(x) >= -1e-5 and np.max(np.abs(F.T @ x - y)) <= 1e-4
+        risks.append(float(x @ (Dd * x) + y @ y))
+    assert all(risks[i + 1] <= risks[i] + 1e-6 for i in range(len(risks) - 1))             # more risk aversion, less variance
+
+
 def test_batch_of_sdps_with_cones_of_side_17_to_64():
     """PSD cones of side 17 .. 64 in batch mode: the persistent workgroup runs the block one-sided Jacobi of csrc/psdwg.h (the routine of the
     single-problem path's k_psd_jacobi_wg) cone after cone.  64 problems with triangle cones of side 9, 24, 40 and 64 and a square cone of side 20:
