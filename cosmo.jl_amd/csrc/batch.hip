@@ -1504,6 +1504,27 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   (void)Ax_to_owners;
   auto colT = [&](int j) -> real { if constexpr (SLICED) return T_sl(j); else return rowAT_own(j); };
   auto colP = [&](int j, const real vj) -> real { if constexpr (SLICED) return P_sl(j, vj); else { (void)vj; return rowP_own(j); } };
+  // LONG instantiations: the passes OUTSIDE the Krylov loop -- (A x)_i for the rows a thread owns, (A' y)_c for its columns -- with the rows of >= LONG_ROW
+  // entries walked by the whole wave (called by every lane: no per-lane condition around them)
+  auto ownA_all = [&](real* out) {
+#pragma unroll
+    for (int j = 0; j < JM; ++j) {
+      const int i = tid + BS * j;
+      int a0 = 0, len = 0;
+      if (i < m) { int qo = i; if constexpr (SORTED) { if (stored_sorted) qo = D.qposA[om + i]; } a0 = (int)Arp[qo]; len = (int)Arp[qo + 1] - a0; }
+      out[j] = row_long_or_pipe3<false>(lA_col + 2u * (uint32_t)a0, lA_val + ((uint32_t)a0 << RSH), l_xv, len) + R(0.0);
+    }
+  };
+  auto colT_all = [&](real* out) {
+#pragma unroll
+    for (int j = 0; j < JN; ++j) {
+      int t0, t1;
+      if constexpr (SORTED) { t0 = kt0[j]; t1 = kt1[j]; }
+      else { const int c = OWN(j); t0 = c >= 0 ? (int)Trp[c] : 0; t1 = c >= 0 ? (int)Trp[c + 1] : 0; }
+      out[j] = row_long_or_pipe3<true>(lT_pr + 4u * (uint32_t)t0, lA_val, l_tv, t1 - t0);
+    }
+  };
+  (void)ownA_all; (void)colT_all;
 
   // ---- admm_x! + admm_w! (solver.jl:32-65) with the CG reduced solve (kktsolver_indirect.jl:36-88) -------------------
   auto solve_and_update = [&]() {
@@ -1520,10 +1541,13 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     for (int j = 0; j < JN; ++j) { const int i = OWN(j); if (i >= 0) xv[pn[j]] = xtl[j]; }
     __syncthreads();
     real acc = 0.0;
+    real tall[JN];
+    (void)tall;
+    if constexpr (LONG) colT_all(tall);
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
       const int i = OWN(j);
-      if (i >= 0) { const real v = (colT(j) + R(0.0)) + lsx[j]; rhsv[j] = v; acc += v * v; }
+      if (i >= 0) { real ct_; if constexpr (LONG) ct_ = tall[j]; else ct_ = colT(j); const real v = (ct_ + R(0.0)) + lsx[j]; rhsv[j] = v; acc += v * v; }
     }
     const real bb = bsum<BS>(acc, red);                                  // (its barriers also order tv reads before the writes below)
     real tmpv[JM];
@@ -1536,18 +1560,25 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       for (int j = 0; j < JM; ++j) if (ra[j] >= 0) tv[pmc[j]] = tmpv[j];
       __syncthreads();
     } else {
+    if constexpr (LONG) {
+      ownA_all(tmpv);
+#pragma unroll
+      for (int j = 0; j < JM; ++j) tmpv[j] = tmpv[j] * rhov[j];           // (rows beyond m: 0 x 1)
+    } else {
 #pragma unroll
     for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; tmpv[j] = (i < m) ? rowA_own(j) * rhov[j] : 0.0; }
+    }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < JM; ++j) { const int i = tid + BS * j; if (i < m) tv[pm[j]] = tmpv[j]; }
     __syncthreads();
     }
     acc = 0.0;
+    if constexpr (LONG) colT_all(tall);
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
       const int i = OWN(j);
-      if (i >= 0) { const real cj = colP(j, xtl[j]) + (P.sigma * xtl[j] + colT(j)); const real rj = rhsv[j] - cj; rv[j] = rj; acc += rj * rj; }
+      if (i >= 0) { real ct_; if constexpr (LONG) ct_ = tall[j]; else ct_ = colT(j); const real cj = colP(j, xtl[j]) + (P.sigma * xtl[j] + ct_); const real rj = rhsv[j] - cj; rv[j] = rj; acc += rj * rj; }
     }
     real rr = bsum<BS>(acc, red);
     const real tol_k = tol_next;
@@ -1663,12 +1694,13 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     __syncthreads();
     real axo[JM];
     if constexpr (SLICED) Ax_to_owners(axo);
+    else if constexpr (LONG) ownA_all(axo);
 #pragma unroll
     for (int j = 0; j < JM; ++j) {
       const int i = tid + BS * j;
       if (i < m) {
         real ax_;
-        if constexpr (SLICED) ax_ = axo[j]; else ax_ = rowA_own(j);
+        if constexpr (SLICED || LONG) ax_ = axo[j]; else ax_ = rowA_own(j);
         const real rh = rhov[j]; const real nv = (ax_ - lss[j]) * rh;
         const real st = (R(2.0) * sv[j] - wsv[j]) - nv / rh;
         wsv[j] = wsv[j] + P.alpha * (st - sv[j]);
@@ -1692,12 +1724,13 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     real a_rp = 0.0, a_mp = 0.0;
     real axo[JM];
     if constexpr (SLICED) Ax_to_owners(axo);
+    else if constexpr (LONG) ownA_all(axo);
 #pragma unroll
     for (int j = 0; j < JM; ++j) {
       const int i = tid + BS * j;
       if (i < m) {
         real ax;
-        if constexpr (SLICED) ax = axo[j]; else ax = rowA_own(j);
+        if constexpr (SLICED || LONG) ax = axo[j]; else ax = rowA_own(j);
         const real s0 = sv[j], b0 = bv[j];
         muv[j] = rhov[j] * (wps[j] - s0);
         tv[pm[j]] = muv[j];
@@ -1711,11 +1744,15 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
     rp = bmax<BS>(a_rp, red); mp = bmax<BS>(a_mp, red);
     __syncthreads();
     real a_rd = 0.0, a_md = 0.0, xpx = 0.0, qx = 0.0;
+    real tall[JN];
+    (void)tall;
+    if constexpr (LONG) colT_all(tall);
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
       const int i = OWN(j);
       if (i >= 0) {
-        const real px = colP(j, wpx[j]), atm = colT(j), x0 = wpx[j], q0 = qv[j];
+        real atm; if constexpr (LONG) atm = tall[j]; else atm = colT(j);
+        const real px = colP(j, wpx[j]), x0 = wpx[j], q0 = qv[j];
         real r0 = px + q0; r0 = r0 - atm;
         real a = px, bq = q0, cm = atm;
         if (unscale) { const real d = D.Dinv[on + i]; r0 = (r0 * d) * cinv; a = (a * d) * cinv; bq = (bq * d) * cinv; cm = (cm * d) * cinv; }
