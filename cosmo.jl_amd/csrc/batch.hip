@@ -305,15 +305,26 @@ __device__ __forceinline__ real row_pipe3(uint32_t idx, uint32_t val, const uint
 // every Krylov iteration while 511 threads wait (profiles/r06_batch_dense_row_probe.txt: 3.9 -> 20 us per Krylov iteration at n = 300).  Here the lanes
 // of the wave that holds such a row (>= LONG_ROW entries; the sorted assignment puts them in the first wave) walk it TOGETHER: lane l takes entries
 // l, l + 64, ..., the partial sums are added by the wave butterfly, the owner keeps the result; the other rows of the wave then run on row_pipe3 as
-// usual.  Called by all lanes of a wave at the same point (no per-lane condition around the call: a lane without a row passes len = 0).  The sum of a
+// usual -- unless the wave holds so many long rows that walking them one after the other would cost more than its longest row.  Called by all lanes of a wave at the same point (no per-lane condition around the call: a lane without a row passes len = 0).  The sum of a
 // long row is added in lane-strided instead of left-to-right order: a batch with such rows agrees with the other kernel forms to rounding, not bit for bit.
 #define LONG_ROW 64
-template <bool PAIR>
-__device__ __forceinline__ real row_long_or_pipe3(uint32_t idx, uint32_t val, const uint32_t gat, const int len) {
-  constexpr uint32_t ISZ = PAIR ? 4u : 2u;
+// which lanes of this wave hand their row to the whole wave (wave-uniform; computed ONCE per launch and slot: the rows of a slot do not change).  One thread
+// per row costs the wave its LONGEST row (the lanes run side by side); together it costs the sum over the long rows of (entries / 64 + the butterfly,
+// ~6 trips): a wave full of equally long rows -- a dense P-like block -- keeps one thread per row (mask 0).
+__device__ __forceinline__ unsigned long long long_row_mask(const int len) {
   const bool is_long = len >= LONG_ROW;
-  unsigned long long todo = __ballot(is_long);
+  const unsigned long long todo = __ballot(is_long);
+  if (!todo) return 0ull;
+  int mx = is_long ? len : 0, sm = is_long ? (len + 63) / 64 + 6 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(mx, o, 64); mx = t > mx ? t : mx; sm += __shfl_xor(sm, o, 64); }
+  return (sm < mx) ? todo : 0ull;
+}
+template <bool PAIR>
+__device__ __forceinline__ real row_long_or_pipe3(uint32_t idx, uint32_t val, const uint32_t gat, const int len, unsigned long long todo) {
+  constexpr uint32_t ISZ = PAIR ? 4u : 2u;
   const int lane = threadIdx.x & 63;
+  const bool is_long = (todo >> lane) & 1ull;
   real mine = 0.0;
   while (todo) {                                                      // wave-uniform
     const int src = __ffsll((long long)todo) - 1;
@@ -1504,6 +1515,27 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
   (void)Ax_to_owners;
   auto colT = [&](int j) -> real { if constexpr (SLICED) return T_sl(j); else return rowAT_own(j); };
   auto colP = [&](int j, const real vj) -> real { if constexpr (SLICED) return P_sl(j, vj); else { (void)vj; return rowP_own(j); } };
+  // LONG instantiations: which lanes hand their row to the wave -- per slot, for the rows of the Krylov A pass (mkA: the sorted assignment), the rows a
+  // thread owns (mkO: index order; the same rows in the index-order form) and the columns (mkT)
+  unsigned long long mkA[LONG ? JM : 1], mkO[LONG ? JM : 1], mkT[LONG ? JN : 1];
+  (void)mkA; (void)mkO; (void)mkT;
+  if constexpr (LONG) {
+#pragma unroll
+    for (int j = 0; j < JM; ++j) {
+      const int i = tid + BS * j;
+      int lo = 0;
+      if (i < m) { int qo = i; if constexpr (SORTED) { if (stored_sorted) qo = D.qposA[om + i]; } lo = (int)Arp[qo + 1] - (int)Arp[qo]; }
+      mkO[j] = long_row_mask(lo);
+      if constexpr (SORTED) mkA[j] = long_row_mask(ka1[j] - ka0[j]); else mkA[j] = mkO[j];
+    }
+#pragma unroll
+    for (int j = 0; j < JN; ++j) {
+      int lt;
+      if constexpr (SORTED) lt = kt1[j] - kt0[j];
+      else { const int c = OWN(j); lt = c >= 0 ? (int)Trp[c + 1] - (int)Trp[c] : 0; }
+      mkT[j] = long_row_mask(lt);
+    }
+  }
   // LONG instantiations: the passes OUTSIDE the Krylov loop -- (A x)_i for the rows a thread owns, (A' y)_c for its columns -- with the rows of >= LONG_ROW
   // entries walked by the whole wave (called by every lane: no per-lane condition around them)
   auto ownA_all = [&](real* out) {
@@ -1512,7 +1544,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       const int i = tid + BS * j;
       int a0 = 0, len = 0;
       if (i < m) { int qo = i; if constexpr (SORTED) { if (stored_sorted) qo = D.qposA[om + i]; } a0 = (int)Arp[qo]; len = (int)Arp[qo + 1] - a0; }
-      out[j] = row_long_or_pipe3<false>(lA_col + 2u * (uint32_t)a0, lA_val + ((uint32_t)a0 << RSH), l_xv, len) + R(0.0);
+      out[j] = row_long_or_pipe3<false>(lA_col + 2u * (uint32_t)a0, lA_val + ((uint32_t)a0 << RSH), l_xv, len, mkO[j]) + R(0.0);
     }
   };
   auto colT_all = [&](real* out) {
@@ -1521,7 +1553,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       int t0, t1;
       if constexpr (SORTED) { t0 = kt0[j]; t1 = kt1[j]; }
       else { const int c = OWN(j); t0 = c >= 0 ? (int)Trp[c] : 0; t1 = c >= 0 ? (int)Trp[c + 1] : 0; }
-      out[j] = row_long_or_pipe3<true>(lT_pr + 4u * (uint32_t)t0, lA_val, l_tv, t1 - t0);
+      out[j] = row_long_or_pipe3<true>(lT_pr + 4u * (uint32_t)t0, lA_val, l_tv, t1 - t0, mkT[j]);
     }
   };
   (void)ownA_all; (void)colT_all;
@@ -1616,7 +1648,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
       { BT_BEGIN();
 #pragma unroll
       for (int j = 0; j < JM; ++j)
-        if constexpr (LONG) tmpv[j] = (row_long_or_pipe3<false>(lA_col + 2u * (uint32_t)ka0[j], lA_val + ((uint32_t)ka0[j] << RSH), l_xv, ka1[j] - ka0[j]) + R(0.0)) * rhoc[j];   // (no row: ka0 = ka1 = 0, rhoc = 1)
+        if constexpr (LONG) tmpv[j] = (row_long_or_pipe3<false>(lA_col + 2u * (uint32_t)ka0[j], lA_val + ((uint32_t)ka0[j] << RSH), l_xv, ka1[j] - ka0[j], mkA[j]) + R(0.0)) * rhoc[j];   // (no row: ka0 = ka1 = 0, rhoc = 1)
         else
         tmpv[j] = (ra[j] >= 0) ? (HANDPIPE ? (row_pipe3<false>(lA_col + 2u * (uint32_t)ka0[j], lA_val + ((uint32_t)ka0[j] << RSH), l_xv, ka1[j] - ka0[j]) + R(0.0))
                                            : rowA_b(ka0[j], ka1[j])) * rhoc[j] : 0.0;
@@ -1630,7 +1662,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
         for (int j = 0; j < JM; ++j) {
           const int i = tid + BS * j;
           const int a0 = (i < m) ? (int)Arp[i] : 0, a1 = (i < m) ? (int)Arp[i + 1] : 0;
-          tmpv[j] = row_long_or_pipe3<false>(lA_col + 2u * (uint32_t)a0, lA_val + ((uint32_t)a0 << RSH), l_xv, a1 - a0) * rhov[j];
+          tmpv[j] = row_long_or_pipe3<false>(lA_col + 2u * (uint32_t)a0, lA_val + ((uint32_t)a0 << RSH), l_xv, a1 - a0, mkO[j]) * rhov[j];
         }
       } else {
 #pragma unroll
@@ -1650,7 +1682,7 @@ __global__ __launch_bounds__(BS) void k_batch_admm_reg(BatchDev D, BParams P, lo
           int t0, t1;
           if constexpr (SORTED) { t0 = kt0[j]; t1 = kt1[j]; }
           else { const int c = OWN(j); t0 = c >= 0 ? (int)Trp[c] : 0; t1 = c >= 0 ? (int)Trp[c + 1] : 0; }
-          tlong[j] = row_long_or_pipe3<true>(lT_pr + 4u * (uint32_t)t0, lA_val, l_tv, t1 - t0);
+          tlong[j] = row_long_or_pipe3<true>(lT_pr + 4u * (uint32_t)t0, lA_val, l_tv, t1 - t0, mkT[j]);
         }
       }
 #pragma unroll
