@@ -952,7 +952,6 @@ def test_batch_of_factor_model_portfolios_like_the_reference_example():
     F = sp.random(n_assets, k, density=0.5, random_state=rng, data_rvs=rng.standard_normal).tocsc()
     mu = (3.0 + 9.0 * rng.uniform(size=n_assets)) / 100.0
     gammas = np.logspace(-2, 1, 24)
-    nvar = n_assets + k
     P = sp.block_diag([2.0 * sp.diags(Dd), 2.0 * sp.identity(k)]).tocsc()                  # x'Dx + y'y = 1/2 z' P z
     # internal form A z + s = b, s in K: rows 0..k: (F'x - y) + s = 0; 1'x + s = 1; -x + s = 0 with s >= 0  <=>  x = s >= 0
     A = sp.vstack([sp.hstack([F.T, -sp.identity(k)]), sp.hstack([sp.csr_matrix(np.ones((1, n_assets))), sp.csr_matrix((1, k))]),
