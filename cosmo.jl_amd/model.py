@@ -114,6 +114,12 @@ class Settings:
     # (default), "eigen" = the eigendecomposition-based projection of the reference (syevr! + rank-k update, src/convexset.jl:163-189, 243-263) at every
     # side by Jacobi eigensolvers -- exact nnz_lambda, several times slower (cosmo_hip_set_psd_projection)
     psd_projection: str = "sign"
+    # optimize() of ONE small model through the batch path (not a field of COSMO.Settings): a single-problem handle runs an ADMM iteration as a chain of
+    # dependent launches (~150 us per iteration whatever the size); the batch kernels keep a whole problem in one persistent workgroup (INTEGRATION.md,
+    # "Small problems": 20 against 65 ms per solve on the reference's portfolio example).  True: optimize() takes that path when the model fits it (no
+    # distributed run, no chordal decomposition to apply, a structure the batch kernels take, an image small enough for the CU's LDS) -- same statuses and
+    # solutions to solver accuracy, not the same bits; the model then has no single-problem handle (model.handle stays None).
+    persistent_kernel: bool = False
     # accepted for drop-in compatibility with COSMO.Settings (src/settings.jl:101-139); they do not touch the hot path:
     nearly_ratio: float = 100.0            # only read by the MOI wrapper (is_primal_nearly_feasible, src/MOI_wrapper.jl:558,587)
     adaptive_rho_fraction: float = 0.4     # only with adaptive_rho_interval = 0 (the automatic interval, solver.jl:244-256)
@@ -793,6 +799,8 @@ def optimize(model: Model, dist=None, shard: str = "rows") -> Result:
     import time
     if not model.is_assembled:
         raise RuntimeError("The model has to be assembled! / set! before optimize!() can be called.")
+    if model.settings.persistent_kernel and dist is None and model.handle is None and _fits_persistent_kernel(model):
+        return _solve_shard_on_device([model], model.settings.device)[0]
     t0 = time.perf_counter()
     fresh = model.handle is None
     if fresh and model.settings.decompose and getattr(model, "chordal", None) is None:
@@ -882,6 +890,20 @@ def prepare_batch(models: Sequence[Model], device: int):
 
 def _structure_key(md: Model):
     return (md.n, md.m, tuple(K.kind for K in md.sets), tuple(K.dim for K in md.sets), tuple(getattr(K, "alpha", 0.0) for K in md.sets))
+
+
+def _fits_persistent_kernel(md: Model) -> bool:
+    """Settings.persistent_kernel: would the LDS-resident batch kernels take this ONE model?  (A model they only take through their streaming form, or
+    one whose PSD cones the front end could decompose, stays on the single-problem handle.)"""
+    if not _batch_kernels_take(md) or getattr(md, "chordal", None) is not None:
+        return False
+    if md.settings.decompose and any(K.kind in (_ffi.PSD_SQUARE, _ffi.PSD_TRIANGLE) for K in md.sets):
+        return False
+    if md.n > 1024 or md.m > 2048:
+        return False
+    isz = 4 if getattr(md, "dtype", np.float64) == np.float32 else 8
+    image = (isz + 6) * md.A.nnz + (isz + 2) * md.P.nnz + isz * (md.n + md.m) + 4 * (md.n + md.m)     # values + index entries of A, A', P; work vectors; row pointers
+    return image <= 150 * 1024 and md.A.nnz <= 65535 and md.P.nnz <= 65535
 
 
 def _check_batch_psd_projection(models) -> None:

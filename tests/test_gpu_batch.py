@@ -1044,3 +1044,32 @@ def test_batch_psd_cone_limits_and_certificates():
     res = cj.optimize_batch(mods)
     assert [r.status for r in res] == [ref.status for ref in refs] == ["Primal_infeasible", "Solved"]
     assert res[0].iter == refs[0].iter and abs(res[1].iter - refs[1].iter) <= 25
+
+
+def test_settings_persistent_kernel_routes_one_small_model_through_the_batch_kernels():
+    """Settings(persistent_kernel=True): optimize() of ONE small model runs on the LDS-resident batch kernels (one persistent workgroup) instead of the
+    launch chain of a single-problem handle -- same status, objective 1e-6, x 1e-4, iterations within one check interval of the handle path and of the
+    oracle; a model the batch kernels would only stream (image > LDS), one with a decomposable PSD cone and a distributed run keep the handle path."""
+    p = cj.problems.socp(n=120, m=240, ncones=12, nnz=1800, seed=77)
+    res = {}
+    for flag in (False, True):
+        md = cj.Model(); md.set(p["P"], p["q"], p["A"], p["b"], p["sets"], cj.Settings(persistent_kernel=flag, eps_abs=1e-6, eps_rel=1e-6))
+        res[flag] = (cj.optimize(md), md.handle is None, md.is_optimized, md.x.copy())
+    (a, a_nohandle, _, _), (b, b_nohandle, b_opt, bx) = res[False], res[True]
+    assert not a_nohandle and b_nohandle and b_opt and np.array_equal(bx, b.x)
+    ref = O.solve(p["P"], p["q"], p["A"], p["b"], util.oracle_cones(p["sets"]), O.Settings(kkt_solver="cg", eps_abs=1e-6, eps_rel=1e-6))
+    assert a.status == b.status == ref.status == "Solved" and abs(a.iter - b.iter) <= 25 and abs(b.iter - ref.iter) <= 25
+    assert abs(a.obj_val - b.obj_val) <= 1e-6 * (1 + abs(a.obj_val)) and np.max(np.abs(a.x - b.x)) <= 1e-4 * max(1.0, float(np.max(np.abs(a.x))))
+    assert cj.model.LAST_BATCH_INFO["problems"] == 1
+    # not routed: config-2-like size (streams), a PSD cone with decompose = True
+    big = cj.problems.socp(n=1500, m=3000, ncones=50, nnz=30000, seed=5)
+    mdb = cj.Model(); mdb.set(big["P"], big["q"], big["A"], big["b"], big["sets"], cj.Settings(persistent_kernel=True, max_iter=50))
+    cj.optimize(mdb)
+    assert mdb.handle is not None
+    sdp = _small_sdps(1, 3)[0]
+    mds = cj.Model(); mds.set(sdp["P"], sdp["q"], sdp["A"], sdp["b"], sdp["sets"], cj.Settings(persistent_kernel=True, max_iter=50))
+    cj.optimize(mds)
+    assert mds.handle is not None
+    mds2 = cj.Model(); mds2.set(sdp["P"], sdp["q"], sdp["A"], sdp["b"], sdp["sets"], cj.Settings(persistent_kernel=True, decompose=False, max_iter=50))
+    cj.optimize(mds2)
+    assert mds2.handle is None
