@@ -81,6 +81,7 @@ SIGNATURES = {
     "cosmo_hip_default_accel_params": (None, [C.POINTER(AccelParams)]),
     "cosmo_hip_set_accelerator": (C.c_int32, [C.c_void_p, C.POINTER(AccelParams)]),
     "cosmo_hip_get_accel_stats": (C.c_int32, [C.c_void_p, _PI64]),
+    "cosmo_hip_get_accel_restarts": (C.c_int32, [C.c_void_p, _PI64]),
     "cosmo_hip_scale_ruiz": (C.c_int32, [C.c_void_p, C.c_int64, C.c_double, C.c_double, _PR, _PR, _PD]),
     "cosmo_hip_update_qb": (C.c_int32, [C.c_void_p, _PR, _PR]),
     "cosmo_hip_get_rho_classes": (C.c_int32, [C.c_void_p, _PI32]),
@@ -331,6 +332,12 @@ class Handle:
         if start_accuracy is not None:
             ap.start_accuracy = float(start_accuracy)
         self._chk(self.lib.cosmo_hip_set_accelerator(self._h, C.byref(ap)))
+
+    def accel_restarts(self):
+        """(restarts because the memory was full, restarts because rho was adapted) of the last optimize"""
+        out = np.zeros(2, dtype=np.int64)
+        self._chk(self.lib.cosmo_hip_get_accel_restarts(self._h, out.ctypes.data_as(_PI64)))
+        return int(out[0]), int(out[1])
 
     def set_psd_projection(self, mode):
         """0 = verified matrix-sign iteration above side 16 (default), 1 = eigendecomposition (Jacobi) at every side; after set_cones."""

@@ -68,6 +68,7 @@ struct AaState {
   bool init_phase = true;
   bool active = false;
   long long num_accelerated = 0, num_restarts = 0, num_declined = 0, num_accepted = 0;
+  long long num_rho_restarts = 0;     // CA.restart! calls because rho was adapted (src/solver.jl:272-275)
 };
 
 namespace {
@@ -430,6 +431,7 @@ int32_t aa_begin_solve(cosmo_hip_handle* h) {
   CHK(aa_restart(h));
   S->active = false;
   S->num_accelerated = S->num_restarts = S->num_declined = S->num_accepted = 0;
+  S->num_rho_restarts = 0;
   return COSMO_HIP_OK;
 }
 
@@ -572,6 +574,16 @@ void aa_count(cosmo_hip_handle* h, int accelerated, int declined) {
   if (!S) return;
   S->num_accelerated += accelerated;
   if (accelerated && S->prm.safeguard) { if (declined) S->num_declined += 1; else S->num_accepted += 1; }
+}
+
+void aa_note_rho_restart(cosmo_hip_handle* h) { AaState* S = aa_of(h); if (S) S->num_rho_restarts += 1; }
+// out = {restarts because the memory was full (RestartedMemory), restarts because rho was adapted} of the last optimize -- the second is what the reference's
+// test/UnitTests/AccelerationTests/adaptive_rho_acc_restarts.jl counts in the accelerator's log (`:rho_adapted` entries == num_rho_adaptions)
+extern "C" int32_t cosmo_hip_get_accel_restarts(cosmo_hip_handle* h, int64_t out[2]) {
+  if (!h || !out) return COSMO_HIP_ERR_INVALID;
+  AaState* S = aa_of(h);
+  out[0] = S ? S->num_restarts : 0; out[1] = S ? S->num_rho_restarts : 0;
+  return COSMO_HIP_OK;
 }
 
 extern "C" int32_t cosmo_hip_get_accel_stats(cosmo_hip_handle* h, int64_t out[6]) {

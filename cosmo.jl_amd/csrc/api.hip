@@ -1214,6 +1214,7 @@ static int32_t optimize_accelerated(cosmo_hip_handle* h, int* status_out, long l
     if (do_rho && h->ctl_host->n_rho_updates != n_rho_seen) {                 // solver.jl:272-275
       n_rho_seen = h->ctl_host->n_rho_updates;
       CHK(aa_restart(h));
+      aa_note_rho_restart(h);
     }
     if (aa_active(h) && success) {                                            // acceleration_post!
       if (aa_safeguarded(h)) {

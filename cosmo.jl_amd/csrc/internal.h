@@ -342,6 +342,7 @@ bool aa_enabled(const cosmo_hip_handle* h);
 bool aa_safeguarded(const cosmo_hip_handle* h);
 bool aa_active(const cosmo_hip_handle* h);
 int32_t aa_restart(cosmo_hip_handle* h);
+void aa_note_rho_restart(cosmo_hip_handle* h);
 int32_t aa_begin_solve(cosmo_hip_handle* h);
 int32_t aa_enqueue_pre(cosmo_hip_handle* h, long long it, bool* attempted);
 int32_t aa_fetch_flags(cosmo_hip_handle* h, int* success, int* declined);

@@ -254,6 +254,9 @@ COSMO_HIP_API void cosmo_hip_default_accel_params(cosmo_hip_accel_params* p);
 COSMO_HIP_API int32_t cosmo_hip_set_accelerator(cosmo_hip_handle* h, const cosmo_hip_accel_params* p);
 /* out = {accelerated steps, safeguard accepted, safeguard declined, memory restarts, active, safeguarding_iter} */
 COSMO_HIP_API int32_t cosmo_hip_get_accel_stats(cosmo_hip_handle* h, int64_t out[6]);
+/* out = {restarts of the accelerator because its memory was full (RestartedMemory), restarts because rho was adapted (CA.restart!, src/solver.jl:272-275)}
+ * of the last optimize; the second equals num_rho_adaptions in test/UnitTests/AccelerationTests/adaptive_rho_acc_restarts.jl:24 */
+COSMO_HIP_API int32_t cosmo_hip_get_accel_restarts(cosmo_hip_handle* h, int64_t out[2]);
 /* Replaces scale_ruiz! (src/scaling.jl:21-116) for callers that hand over the UNSCALED problem: call after
  * cosmo_hip_set_problem + cosmo_hip_set_cones (unscaled data and Box bounds) and before cosmo_hip_set_params.  Runs
  * `iterations` (settings.scaling) steps of the modified Ruiz equilibration on the device-resident P, A, q, b, rectifies the
